@@ -1,0 +1,14 @@
+"""agile3d_amd -- MI355X-native implementation of the AGILE3D model hot path
+(forward_backbone + forward_mask) behind the reference's own model API.
+
+Public surface (mirrors the reference):
+    build_model(args)            models/__init__.py:5-6
+    Agile3d.forward_backbone     models/agile3d.py:163-181
+    Agile3d.forward_mask         models/agile3d.py:183-339
+    SparseTensor, utils          the subset of MinkowskiEngine the callers touch
+"""
+from .model import build_model, build_agile3d, Agile3d, default_args, randomize_bn_stats  # noqa: F401
+from .sparse import SparseTensor, sparse_quantize, batched_coordinates  # noqa: F401
+
+__all__ = ["build_model", "build_agile3d", "Agile3d", "default_args", "randomize_bn_stats",
+           "SparseTensor", "sparse_quantize", "batched_coordinates"]

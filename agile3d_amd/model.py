@@ -1,0 +1,142 @@
+"""``build_model(args)`` -> ``Agile3d`` with ``forward_backbone`` / ``forward_mask``.
+
+Drop-in for the reference's model boundary:
+  * ``models/__init__.py:5-6``      build_model(args)
+  * ``models/agile3d.py:163-181``   forward_backbone(x, raw_coordinates)
+  * ``models/agile3d.py:183-339``   forward_mask(pcd_features, aux, coordinates,
+                                    pos_encodings_pcd, click_idx, click_time_idx)
+Same argument meaning, same return structures, same ``state_dict`` keys.  All arithmetic
+runs in ``libagile3d_hip.so`` (hand-written gfx950 kernels); there is NO CPU fallback --
+calling a forward without the HIP library or on a non-GPU tensor raises.
+"""
+from __future__ import annotations
+
+import argparse
+
+import torch
+import torch.nn as nn
+
+from . import modules as M
+
+
+def default_args(**overrides):
+    """The model-relevant flag defaults of the reference's entry points
+    (``main.py:24-84``, ``eval_multi_obj.py:28-72``)."""
+    a = argparse.Namespace(
+        conv1_kernel_size=5, bn_momentum=0.02, voxel_size=0.05, hidden_dim=128,
+        dim_feedforward=1024, num_heads=8, num_decoders=3, num_bg_queries=10, dropout=0.0,
+        pre_norm=False, normalize_pos_enc=True, positional_encoding_type="fourier",
+        gauss_scale=1.0, hlevels=[4], shared_decoder=False, aux=True)
+    for k, v in overrides.items():
+        setattr(a, k, v)
+    return a
+
+
+class Agile3d(nn.Module):
+    """Parameter layout of ``models/agile3d.py:19-138``; compute in HIP."""
+
+    def __init__(self, args):
+        super().__init__()
+        if args.pre_norm:
+            raise NotImplementedError("pre_norm=True is outside the hot path (reference default False)")
+        if args.positional_encoding_type != "fourier":
+            raise NotImplementedError("only the default 'fourier' position encoding is on the hot path")
+        if list(args.hlevels) != [4]:
+            raise NotImplementedError("only hlevels=[4] (reference default) is on the hot path")
+        if args.dropout != 0.0:
+            raise NotImplementedError("dropout != 0 is outside the hot path (reference default 0.0)")
+        if args.hidden_dim != 128 or args.num_heads != 8:
+            raise NotImplementedError("kernels are specialised for hidden_dim=128, num_heads=8")
+        self.args = args
+        d, h, ff = args.hidden_dim, args.num_heads, args.dim_feedforward
+        self.mask_dim = d
+        self.num_heads = h
+        self.num_decoders = args.num_decoders
+        self.num_bg_queries = args.num_bg_queries
+        self.shared_decoder = args.shared_decoder
+        self.hlevels = list(args.hlevels)
+        self.aux = args.aux
+        self.voxel_size = args.voxel_size
+
+        self.backbone = M.Res16UNet34CParams(3, args.conv1_kernel_size, args.bn_momentum)
+        self.lin_squeeze_head = M.SparseConvParams(self.backbone.PLANES[7], d, 1, bias=True)
+        self.bg_query_feat = nn.Embedding(args.num_bg_queries, d)
+        self.bg_query_pos = nn.Embedding(args.num_bg_queries, d)
+        self.mask_embed_head = nn.Sequential(nn.Linear(d, d), nn.ReLU(), nn.Linear(d, d))
+        self.pos_enc = M.FourierPosEncParams(d, 3, args.gauss_scale)
+
+        n_shared = 1 if args.shared_decoder else args.num_decoders
+        self.c2s_attention = nn.ModuleList()
+        self.c2c_attention = nn.ModuleList()
+        self.ffn_attention = nn.ModuleList()
+        self.s2c_attention = nn.ModuleList()
+        for _ in range(n_shared):
+            self.c2s_attention.append(nn.ModuleList([M.cross_attention_params(d, h)]))
+            self.s2c_attention.append(nn.ModuleList([M.cross_attention_params(d, h)]))
+            self.c2c_attention.append(nn.ModuleList([M.self_attention_params(d, h)]))
+            self.ffn_attention.append(nn.ModuleList([M.FFNLayerParams(d, ff)]))
+        self.decoder_norm = nn.LayerNorm(d)
+        self._engine = None          # lazily created agile3d_amd.engine.Engine
+        self._packed_version = None
+
+    # ------------------------------------------------------------------ engine plumbing
+    def _get_engine(self):
+        from .engine import Engine
+        dev = next(self.parameters()).device
+        if dev.type != "cuda":
+            raise RuntimeError("agile3d_amd: the model must live on a ROCm GPU (model.to('cuda')); "
+                               "there is no CPU path")
+        if self._engine is None or self._engine.device != dev:
+            self._engine = Engine(self, dev)
+        if self.training:
+            raise RuntimeError("agile3d_amd: round-1 kernels implement eval-mode forward only "
+                               "(BatchNorm uses running statistics); call model.eval()")
+        self._engine.refresh_weights_if_stale()
+        return self._engine
+
+    def load_state_dict(self, state_dict, strict=True, **kw):
+        sd = dict(state_dict)
+        own = self.state_dict()   # accept ME<0.5 checkpoints holding 1x1 kernels as [1,Cin,Cout]
+        for k, v in list(sd.items()):
+            if k in own and own[k].dim() == 2 and v.dim() == 3 and v.shape[0] == 1 and k.endswith(".kernel"):
+                sd[k] = v[0]
+        res = super().load_state_dict(sd, strict=strict, **kw)
+        if self._engine is not None:
+            self._engine.mark_stale()
+        return res
+
+    # ------------------------------------------------------------------ the hot path
+    def forward_backbone(self, x, raw_coordinates=None):
+        """Reference ``agile3d.py:163-181``.  ``x``: SparseTensor of int32 [N,4] coords +
+        fp32 [N,3] colours; ``raw_coordinates`` fp32 [N,3].  Returns
+        (pcd_features, aux, coordinates, pos_encodings_pcd), opaque to callers."""
+        return self._get_engine().forward_backbone(x, raw_coordinates)
+
+    def forward_mask(self, pcd_features, aux, coordinates, pos_encodings_pcd,
+                     click_idx=None, click_time_idx=None):
+        """Reference ``agile3d.py:183-339``."""
+        return self._get_engine().forward_mask(pcd_features, aux, coordinates, pos_encodings_pcd,
+                                               click_idx, click_time_idx)
+
+
+def build_agile3d(args):
+    return Agile3d(args)
+
+
+def build_model(args):
+    """Reference ``models/__init__.py:5-6``."""
+    return build_agile3d(args)
+
+
+def randomize_bn_stats(model: nn.Module, seed: int = 0):
+    """Give every BatchNorm non-trivial running statistics / affine so that eval-mode folding is
+    exercised (mean N(0,0.1), var U(0.5,1.5))."""
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for m in model.modules():
+            if isinstance(m, nn.BatchNorm1d):
+                m.running_mean.copy_(torch.randn(m.running_mean.shape, generator=g) * 0.1)
+                m.running_var.copy_(torch.rand(m.running_var.shape, generator=g) + 0.5)
+                m.weight.copy_(1.0 + 0.1 * torch.randn(m.weight.shape, generator=g))
+                m.bias.copy_(0.1 * torch.randn(m.bias.shape, generator=g))
+    return model
