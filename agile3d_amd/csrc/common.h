@@ -1,0 +1,119 @@
+// Shared host/device helpers for libagile3d_hip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include "../../include/agile3d_hip.h"
+
+namespace a3d {
+
+// ---- error plumbing (thread-local text, negative codes across the C ABI) -----------------
+void set_error(const char* fmt, ...);
+const char* get_error();
+
+#define A3D_HIP_CHECK(expr)                                                              \
+  do {                                                                                   \
+    hipError_t _e = (expr);                                                              \
+    if (_e != hipSuccess) {                                                              \
+      a3d::set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #expr, hipGetErrorString(_e)); \
+      return A3D_ERR_HIP;                                                                \
+    }                                                                                    \
+  } while (0)
+
+#define A3D_LAUNCH_CHECK() A3D_HIP_CHECK(hipGetLastError())
+
+static inline int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
+static inline size_t align256(size_t x) { return (x + 255) & ~size_t(255); }
+
+// ---- geometry constants -------------------------------------------------------------------
+constexpr int kTileRows = 128;   // output rows per conv workgroup
+constexpr int kGroupRows = 16;   // MFMA row granularity (v_mfma_f32_16x16x4_f32)
+constexpr int kSuperTile = 1024; // rows re-ordered by neighbour pattern inside one super tile
+constexpr int kCoordOff = 1 << 17;
+constexpr uint64_t kEmptyKey = ~0ull;
+
+// ---- Morton keys / voxel hash (shared by scene.hip and spconv.hip)
+__host__ __device__ inline uint64_t spread3(uint64_t x) {
+  x &= 0x1fffffULL;
+  x = (x | x << 32) & 0x1f00000000ffffULL;
+  x = (x | x << 16) & 0x1f0000ff0000ffULL;
+  x = (x | x << 8) & 0x100f00f00f00f00fULL;
+  x = (x | x << 4) & 0x10c30c30c30c30c3ULL;
+  x = (x | x << 2) & 0x1249249249249249ULL;
+  return x;
+}
+__host__ __device__ inline uint32_t compact3(uint64_t x) {
+  x &= 0x1249249249249249ULL;
+  x = (x ^ (x >> 2)) & 0x10c30c30c30c30c3ULL;
+  x = (x ^ (x >> 4)) & 0x100f00f00f00f00fULL;
+  x = (x ^ (x >> 8)) & 0x1f0000ff0000ffULL;
+  x = (x ^ (x >> 16)) & 0x1f00000000ffffULL;
+  x = (x ^ (x >> 32)) & 0x1fffffULL;
+  return (uint32_t)x;
+}
+// key of voxel (b, X, Y, Z) given in units of level L.  key_{L+1}(parent) == key_L(child) >> 3.
+__host__ __device__ inline uint64_t make_key(int b, int X, int Y, int Z, int L) {
+  const int off = kCoordOff >> L;
+  return spread3((uint64_t)(X + off)) | (spread3((uint64_t)(Y + off)) << 1) |
+         (spread3((uint64_t)(Z + off)) << 2) | ((uint64_t)b << (54 - 3 * L));
+}
+__host__ __device__ inline void decode_key(uint64_t key, int L, int& b, int& X, int& Y, int& Z) {
+  const int bits = 54 - 3 * L;
+  const int off = kCoordOff >> L;
+  b = (int)(key >> bits);
+  const uint64_t low = key & ((1ULL << bits) - 1);
+  X = (int)compact3(low) - off;
+  Y = (int)compact3(low >> 1) - off;
+  Z = (int)compact3(low >> 2) - off;
+}
+__device__ inline uint32_t hash64(uint64_t k) {
+  k ^= k >> 33;
+  k *= 0xff51afd7ed558ccdULL;
+  k ^= k >> 33;
+  k *= 0xc4ceb9fe1a85ec53ULL;
+  k ^= k >> 33;
+  return (uint32_t)k;
+}
+__device__ inline int hash_lookup(const uint64_t* __restrict__ hk, const int* __restrict__ hv,
+                                  uint32_t hmask, uint64_t key) {
+  uint32_t h = hash64(key) & hmask;
+  for (uint32_t probe = 0; probe <= hmask; ++probe) {
+    const uint64_t k = hk[h];
+    if (k == key) return hv[h];
+    if (k == kEmptyKey) return -1;
+    h = (h + 1) & hmask;
+  }
+  return -1;
+}
+
+
+// ---- the scene ----------------------------------------------------------------------------
+struct Level {
+  int n = 0, npad = 0;
+  uint64_t* keys = nullptr;     // [n]   Morton keys, Morton order
+  int* perm = nullptr;          // [n]   Morton row -> internal row
+  int* inv = nullptr;           // [n]   internal row -> Morton row
+  int* parentM = nullptr;       // [n]   Morton row -> Morton row at level+1 (levels 0..3)
+  int32_t* xyzb = nullptr;      // [n][4] internal order
+  uint64_t* hkeys = nullptr;    // hash table (key -> internal row)
+  int* hvals = nullptr;
+  uint32_t hmask = 0;
+  int* nbr27 = nullptr;         // [27][npad]
+  uint32_t* gmask27 = nullptr;  // [npad/16]
+  int* child8 = nullptr;        // [8][npad(level+1)]     (levels 0..3)
+  uint32_t* gmask_down = nullptr;
+  int* up8 = nullptr;           // [8][npad]              (levels 0..3)
+  uint32_t* gmask_up = nullptr;
+  int* up_rows = nullptr;       // [npad]
+};
+
+}  // namespace a3d
+
+struct a3d_scene {
+  int64_t n0 = 0;
+  a3d::Level lv[A3D_NUM_LEVELS];
+  int* orig_row = nullptr;      // [n0] internal level-0 row -> caller row
+  void* workspace = nullptr;
+  size_t workspace_bytes = 0;
+};

@@ -1,0 +1,827 @@
+// Click-query transformer decoder on gfx950.
+//
+// Replaces Agile3d.forward_mask / mask_module (reference models/agile3d.py:183-384), the
+// post-norm CrossAttentionLayer / SelfAttentionLayer / FFNLayer built on nn.MultiheadAttention
+// (models/modules/attention_block.py:28-38,86-98,151-155) and the Fourier / click-time position
+// encodings (models/position_embedding.py:13-41,123-152,210-225; agile3d.py:141-161).
+//
+// Decomposition per decoder iteration (DESIGN.md "decoder"):
+//   N-point GEMMs (K/V/Q/out projections)       -> the fp32-MFMA GEMM of spconv.hip (a3d_linear)
+//   click-to-scene attention over N keys        -> k_c2s_attn: flash-decoding with 16x16x4 MFMA,
+//                                                  never materialises [heads,Q,N]; the label-derived
+//                                                  mask (agile3d.py:367-380) is evaluated from one
+//                                                  byte per point + per-label counts
+//   everything of size [Q,128] (Q <= 64)        -> k_query_layer: one workgroup
+//   scene-to-click attention (Q keys per point) -> k_s2c_attn: MFMA, softmax in registers
+//   LayerNorm + mask head + argmax + histogram  -> k_ln_mask
+// The (pos @ W) halves of the c2s key and s2c query projections are click independent and are
+// cached per scene (a3d_decoder_build_cache).
+#include "common.h"
+
+namespace a3d {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+constexpr int D = 128;        // hidden_dim
+constexpr int H = 8;          // heads
+constexpr int DH = 16;        // head dim
+constexpr float kLnEps = 1e-5f;
+constexpr float kNegBig = -1e30f;
+constexpr int kC2SChunk = 256;   // points per c2s workgroup
+constexpr int kPartStride = 18;  // m, l, acc[16]
+
+// ------------------------------------------------------------------------------ posenc
+__global__ void __launch_bounds__(256) k_minmax_partial(const float* __restrict__ xyz, int n, float* part) {
+  __shared__ float s[6][256];
+  float mn[3] = {3.4e38f, 3.4e38f, 3.4e38f}, mx[3] = {-3.4e38f, -3.4e38f, -3.4e38f};
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      const float v = xyz[3 * (size_t)i + a];
+      mn[a] = fminf(mn[a], v);
+      mx[a] = fmaxf(mx[a], v);
+    }
+  }
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    s[a][threadIdx.x] = mn[a];
+    s[3 + a][threadIdx.x] = mx[a];
+  }
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) {
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        s[a][threadIdx.x] = fminf(s[a][threadIdx.x], s[a][threadIdx.x + o]);
+        s[3 + a][threadIdx.x] = fmaxf(s[3 + a][threadIdx.x], s[3 + a][threadIdx.x + o]);
+      }
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x < 6) part[blockIdx.x * 6 + threadIdx.x] = s[threadIdx.x][0];
+}
+__global__ void k_minmax_final(const float* __restrict__ part, int nb, float* minmax) {
+  const int a = threadIdx.x;
+  if (a >= 6) return;
+  float v = part[a];
+  for (int b = 1; b < nb; ++b) v = a < 3 ? fminf(v, part[b * 6 + a]) : fmaxf(v, part[b * 6 + a]);
+  minmax[a] = v;
+}
+// get_fourier_embeddings with normalize=True: u = (x-min)/(max-min); p = (2 pi u) @ B; [sin p, cos p]
+__global__ void k_fourier(const float* __restrict__ xyz, int n, const float* __restrict__ gaussB,
+                          const float* __restrict__ minmax, float* out) {
+  const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= (size_t)n * 64) return;
+  const int i = (int)(e >> 6), jj = (int)(e & 63);
+  const float two_pi = 6.283185307179586f;
+  float p = 0.f;
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    const float mn = minmax[a], mx = minmax[3 + a];
+    float u = (xyz[3 * (size_t)i + a] - mn) / (mx - mn);
+    u *= two_pi;
+    p += u * gaussB[a * 64 + jj];
+  }
+  out[(size_t)i * D + jj] = sinf(p);
+  out[(size_t)i * D + 64 + jj] = cosf(p);
+}
+
+// ------------------------------------------------------------------------------ click-to-scene
+// One wave = one head over a chunk of points.  S = K_h q_h^T (A = key rows, B = q^T), online
+// softmax per query column (lane-local: column = lane & 15), O^T += V_h^T P.
+template <int QT>
+__global__ void __launch_bounds__(512) k_c2s_attn(const float* __restrict__ Kc, const float* __restrict__ V,
+                                                  int n, const float* qproj, const int* qobj,
+                                                  const unsigned char* labels, const int* counts,
+                                                  float* part) {
+  const int lane = threadIdx.x & 63;
+  const int h = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int g = lane >> 4, j = lane & 15;
+  const int pbeg = blockIdx.x * kC2SChunk;
+  const int pend = min(n, pbeg + kC2SChunk);
+
+  f32x4 qf[QT];
+  int obj[QT];
+  bool qmask[QT];
+#pragma unroll
+  for (int qt = 0; qt < QT; ++qt) {
+    qf[qt] = *(const f32x4*)(qproj + (size_t)(qt * 16 + j) * D + h * DH + 4 * g);
+    obj[qt] = qobj[qt * 16 + j];
+    // a query is masked only if its object currently owns at least one point (agile3d.py:369,375)
+    qmask[qt] = labels != nullptr && obj[qt] >= 0 && counts[obj[qt]] > 0;
+  }
+  float m[QT], l[QT];
+  f32x4 acc[QT];
+#pragma unroll
+  for (int qt = 0; qt < QT; ++qt) {
+    m[qt] = kNegBig;
+    l[qt] = 0.f;
+    acc[qt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
+  for (int p0 = pbeg; p0 < pend; p0 += 16) {
+    const int prow = p0 + j;
+    f32x4 kf = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (prow < n) kf = *(const f32x4*)(Kc + (size_t)prow * D + h * DH + 4 * g);
+    float vf[4];
+    unsigned lab4 = 0;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int pr = p0 + 4 * g + t;
+      vf[t] = pr < n ? V[(size_t)pr * D + h * DH + j] : 0.f;
+    }
+    if (labels) lab4 = *(const unsigned*)(labels + p0 + 4 * g);
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) {
+      f32x4 s = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int t = 0; t < 4; ++t) s = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[t], qf[qt][t], s, 0, 0, 0);
+      float mx = kNegBig;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int pr = p0 + 4 * g + t;
+        const int lab = (int)((lab4 >> (8 * t)) & 0xffu);
+        const bool blocked = pr >= n || (qmask[qt] && lab != obj[qt]);
+        s[t] = blocked ? kNegBig : s[t];
+        mx = fmaxf(mx, s[t]);
+      }
+      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      const float mnew = fmaxf(m[qt], mx);
+      const float sc = expf(m[qt] - mnew);
+      m[qt] = mnew;
+      f32x4 p;
+      float ps = 0.f;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        p[t] = expf(s[t] - mnew);
+        ps += p[t];
+      }
+      l[qt] = l[qt] * sc + ps;
+      acc[qt] *= sc;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) acc[qt] = __builtin_amdgcn_mfma_f32_16x16x4f32(vf[t], p[t], acc[qt], 0, 0, 0);
+    }
+  }
+  const int QP = QT * 16;
+  float* P = part + ((size_t)blockIdx.x * H + h) * QP * kPartStride;
+#pragma unroll
+  for (int qt = 0; qt < QT; ++qt) {
+    float lt = l[qt];
+    lt += __shfl_xor(lt, 16, 64);
+    lt += __shfl_xor(lt, 32, 64);
+    float* pq = P + (size_t)(qt * 16 + j) * kPartStride;
+    if (g == 0) {
+      pq[0] = m[qt];
+      pq[1] = lt;
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) pq[2 + 4 * g + t] = acc[qt][t];
+  }
+}
+
+// ------------------------------------------------------------------------------ scene-to-click
+// 8 waves x 16 points per workgroup; keys/values of the <= 64 queries staged in LDS (row stride
+// 132 floats: conflict-free b128 fragment reads).  S^T = ks_h Qs_h^T, softmax over keys in
+// registers (key = 4 g + t within a tile -> 2 shuffles), O^T = vs_h^T P.
+template <int QT>
+__global__ void __launch_bounds__(512) k_s2c_attn(const float* __restrict__ Qs, int n, const float* ks,
+                                                  const float* vs, int nq, float* O) {
+  constexpr int QP = QT * 16, LD = 132;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* ks_l = (float*)smem;
+  float* vs_l = ks_l + QP * LD;
+  for (int e = threadIdx.x; e < QP * 32; e += 512) {
+    const int r = e >> 5, c4 = (e & 31) * 4;
+    *(f32x4*)(ks_l + r * LD + c4) = *(const f32x4*)(ks + (size_t)r * D + c4);
+    *(f32x4*)(vs_l + r * LD + c4) = *(const f32x4*)(vs + (size_t)r * D + c4);
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int g = lane >> 4, j = lane & 15;
+  const int p0 = (blockIdx.x * 8 + wave) * 16;
+  if (p0 >= n) return;
+  const int prow = min(p0 + j, n - 1);
+  const float* qrow = Qs + (size_t)prow * D;
+  float* orow = O + (size_t)prow * D;
+#pragma unroll 1
+  for (int h = 0; h < H; ++h) {
+    const f32x4 qf = *(const f32x4*)(qrow + h * DH + 4 * g);
+    f32x4 s[QT];
+    float mx = kNegBig;
+#pragma unroll
+    for (int kt = 0; kt < QT; ++kt) {
+      const f32x4 kf = *(const f32x4*)(ks_l + (kt * 16 + j) * LD + h * DH + 4 * g);
+      s[kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int t = 0; t < 4; ++t) s[kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[t], qf[t], s[kt], 0, 0, 0);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        if (kt * 16 + 4 * g + t >= nq) s[kt][t] = kNegBig;
+        mx = fmaxf(mx, s[kt][t]);
+      }
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    float sum = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < QT; ++kt)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        s[kt][t] = expf(s[kt][t] - mx);
+        sum += s[kt][t];
+      }
+    sum += __shfl_xor(sum, 16, 64);
+    sum += __shfl_xor(sum, 32, 64);
+    const float inv = 1.f / sum;
+    f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kt = 0; kt < QT; ++kt)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const float vf = vs_l[(kt * 16 + 4 * g + t) * LD + h * DH + j];
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(vf, s[kt][t] * inv, acc, 0, 0, 0);
+      }
+    if (p0 + j < n) *(f32x4*)(orow + h * DH + 4 * g) = acc;
+  }
+}
+
+// ------------------------------------------------------------------------------ LN + mask head
+// src_new = LayerNorm(Y) (in place); logits[p, q] = src_new[p] . E[q]; per-object max -> [1+K];
+// argmax (first max) -> label byte; per-label histogram.  4 waves x 16 points per workgroup.
+template <int QT>
+__global__ void __launch_bounds__(256) k_ln_mask(float* Y, int n, const float* __restrict__ gamma,
+                                                 const float* __restrict__ beta, const float* E, int nq,
+                                                 const int* qrange /*[K+2]*/, int n_fg, int K, float* logits,
+                                                 unsigned char* labels, int* counts) {
+  constexpr int QP = QT * 16, LD = 132, LL = QP + 1;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* E_l = (float*)smem;                    // [QP][132]
+  float* L_l = E_l + QP * LD;                   // [4 waves][16][LL]
+  float* O_l = L_l + 4 * 16 * LL;               // [4 waves][16][K+1]
+  int* hist = (int*)(O_l + 4 * 16 * (K + 1));   // [K+1]
+  for (int e = threadIdx.x; e < QP * 32; e += 256) {
+    const int r = e >> 5, c4 = (e & 31) * 4;
+    *(f32x4*)(E_l + r * LD + c4) = *(const f32x4*)(E + (size_t)r * D + c4);
+  }
+  for (int e = threadIdx.x; e <= K; e += 256) hist[e] = 0;
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int g = lane >> 4, j = lane & 15;
+  const int p0 = (blockIdx.x * 4 + wave) * 16;
+  const bool wave_active = p0 < n;
+  const int prow = min(p0 + j, n - 1);
+  float* Lw = L_l + wave * 16 * LL;
+  float* Ow = O_l + wave * 16 * (K + 1);
+  if (wave_active) {
+    float* yrow = Y + (size_t)prow * D;
+    f32x4 y[8];
+    float sum = 0.f;
+#pragma unroll
+    for (int S = 0; S < 8; ++S) {
+      y[S] = *(const f32x4*)(yrow + 16 * S + 4 * g);
+      sum += y[S][0] + y[S][1] + y[S][2] + y[S][3];
+    }
+    sum += __shfl_xor(sum, 16, 64);
+    sum += __shfl_xor(sum, 32, 64);
+    const float mean = sum * (1.f / D);
+    float var = 0.f;
+#pragma unroll
+    for (int S = 0; S < 8; ++S)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const float d = y[S][t] - mean;
+        var += d * d;
+      }
+    var += __shfl_xor(var, 16, 64);
+    var += __shfl_xor(var, 32, 64);
+    const float rstd = rsqrtf(var * (1.f / D) + kLnEps);
+#pragma unroll
+    for (int S = 0; S < 8; ++S) {
+      const f32x4 ga = *(const f32x4*)(gamma + 16 * S + 4 * g);
+      const f32x4 be = *(const f32x4*)(beta + 16 * S + 4 * g);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) y[S][t] = (y[S][t] - mean) * rstd * ga[t] + be[t];
+      if (p0 + j < n) *(f32x4*)(yrow + 16 * S + 4 * g) = y[S];
+    }
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) {
+      f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int S = 0; S < 8; ++S) {
+        const f32x4 ef = *(const f32x4*)(E_l + (qt * 16 + j) * LD + 16 * S + 4 * g);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(y[S][t], ef[t], acc, 0, 0, 0);
+      }
+#pragma unroll
+      for (int t = 0; t < 4; ++t) Lw[(4 * g + t) * LL + qt * 16 + j] = acc[t];
+    }
+  }
+  __syncthreads();
+  if (wave_active) {
+    // per-object max over that object's queries: object o>=1 -> fg queries [qrange[o], qrange[o+1]);
+    // object 0 -> all background queries [n_fg, nq)   (agile3d.py:348-365)
+    for (int o = g; o <= K; o += 4) {
+      const int qb = o == 0 ? n_fg : qrange[o], qe = o == 0 ? nq : qrange[o + 1];
+      float mxv = -3.4e38f;
+      for (int q = qb; q < qe; ++q) mxv = fmaxf(mxv, Lw[j * LL + q]);
+      Ow[j * (K + 1) + o] = mxv;
+    }
+  }
+  __syncthreads();
+  if (wave_active) {
+    if (lane < 16 && p0 + lane < n) {
+      float best = Ow[lane * (K + 1)];
+      int bi = 0;
+      for (int o = 1; o <= K; ++o) {
+        const float v = Ow[lane * (K + 1) + o];
+        if (v > best) {
+          best = v;
+          bi = o;
+        }
+      }
+      labels[p0 + lane] = (unsigned char)bi;
+      atomicAdd(&hist[bi], 1);
+    }
+    const int rows = min(16, n - p0);
+    for (int e = lane; e < rows * (K + 1); e += 64) logits[(size_t)p0 * (K + 1) + e] = Ow[e];
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e <= K; e += 256)
+    if (hist[e]) atomicAdd(&counts[e], hist[e]);
+}
+
+// ------------------------------------------------------------------------------ query side
+struct QueryMeta {   // device-resident, uploaded once per forward_mask
+  int n_fg, n_bg_click, n_bgl, nq, K;
+  int row[A3D_MAX_QUERIES];     // click row per query (-1 for learned bg)
+  int time[A3D_MAX_QUERIES];    // click time per query
+  int obj[A3D_MAX_QUERIES];     // object id per query (0 = background, -1 = padding)
+  int qrange[A3D_MAX_QUERIES + 2];
+};
+
+struct QueryLayerW {
+  const float *c2s_in_wt, *c2s_in_b, *c2s_out_wt, *c2s_out_b, *c2s_norm_w, *c2s_norm_b;
+  const float *c2c_in_wt, *c2c_in_b, *c2c_out_wt, *c2c_out_b, *c2c_norm_w, *c2c_norm_b;
+  const float *ffn_w1t, *ffn_b1, *ffn_w2t, *ffn_b2, *ffn_norm_w, *ffn_norm_b;
+  const float *s2c_in_wt, *s2c_in_b;
+  const float *dn_w, *dn_b, *m_w0t, *m_b0, *m_w2t, *m_b2;
+  const float *next_c2s_in_wt, *next_c2s_in_b;   // nullptr on the last layer
+  int dim_ff;
+};
+
+struct QueryBufs {   // all [QP][...] fp32 in global scratch
+  float *queries, *qpos, *qproj, *ks, *vs, *E;
+  float *attn, *tmp, *tgt, *qk, *vc, *hidden;
+};
+
+// Y[q][n] = ((X[q][:] (+ Xadd[q][:])) @ Wt[:, n] + bias[n]) * scale, optional relu.
+// Wt is [K][ldw] (transposed torch weight), X staged through LDS in 128-wide slices.
+template <int QP>
+__device__ __noinline__ void lin(const float* X, int ldx, const float* Xadd, int Q, int K, const float* __restrict__ Wt,
+                    int ldw, const float* __restrict__ bias, int N, float* Y, int ldy, bool relu, float scale,
+                    float* lds /*[QP][128]*/) {
+  const int tid = threadIdx.x, nt = blockDim.x;
+  for (int n0 = 0; n0 < N; n0 += nt) {
+    const int nn = n0 + tid;
+    float acc[QP];
+#pragma unroll
+    for (int q = 0; q < QP; ++q) acc[q] = 0.f;
+    for (int kc = 0; kc < K; kc += 128) {
+      __syncthreads();
+      for (int e = tid; e < QP * 128; e += nt) {
+        const int q = e >> 7, kk = e & 127;
+        float v = 0.f;
+        if (q < Q) {
+          v = X[(size_t)q * ldx + kc + kk];
+          if (Xadd) v += Xadd[(size_t)q * D + kc + kk];
+        }
+        lds[e] = v;
+      }
+      __syncthreads();
+      if (nn < N) {
+        for (int kk = 0; kk < 128; ++kk) {
+          const float w = Wt[(size_t)(kc + kk) * ldw + nn];
+#pragma unroll
+          for (int q = 0; q < QP; ++q) acc[q] += lds[q * 128 + kk] * w;
+        }
+      }
+    }
+    if (nn < N) {
+      const float b = bias ? bias[nn] : 0.f;
+#pragma unroll
+      for (int q = 0; q < QP; ++q) {
+        if (q < Q) {
+          float y = (acc[q] + b) * scale;
+          if (relu) y = fmaxf(y, 0.f);
+          Y[(size_t)q * ldy + nn] = y;
+        }
+      }
+    }
+  }
+  __syncthreads();
+}
+
+// out[q] = LayerNorm(a[q] + b[q]) * w + bias ; one wave per row
+__device__ __noinline__ void add_ln(const float* a, const float* b, int Q, const float* __restrict__ w,
+                       const float* __restrict__ bias, float* out) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  for (int q = wave; q < Q; q += nw) {
+    float x0 = a[(size_t)q * D + lane], x1 = a[(size_t)q * D + 64 + lane];
+    if (b) {
+      x0 += b[(size_t)q * D + lane];
+      x1 += b[(size_t)q * D + 64 + lane];
+    }
+    float s = x0 + x1;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    const float mean = s * (1.f / D);
+    const float d0 = x0 - mean, d1 = x1 - mean;
+    float v = d0 * d0 + d1 * d1;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    const float rstd = rsqrtf(v * (1.f / D) + kLnEps);
+    out[(size_t)q * D + lane] = d0 * rstd * w[lane] + bias[lane];
+    out[(size_t)q * D + 64 + lane] = d1 * rstd * w[64 + lane] + bias[64 + lane];
+  }
+  __syncthreads();
+}
+
+template <int QP>
+__global__ void __launch_bounds__(512) k_query_init(const QueryMeta* meta, const float* feats128,
+                                                     const float* posenc, const float* bg_feat,
+                                                     const float* bg_pos, const float* time_table,
+                                                     const float* c2s_in_wt, const float* c2s_in_b,
+                                                     QueryBufs B, int* counts, int n_counts) {
+  __shared__ float lds[QP * 128];
+  const int Q = meta->nq, n_fg = meta->n_fg, n_bgl = meta->n_bgl;
+  for (int e = threadIdx.x; e < n_counts; e += blockDim.x) counts[e] = 0;
+  for (int e = threadIdx.x; e < QP * D; e += blockDim.x) {
+    const int q = e >> 7, c = e & 127;
+    float f = 0.f, p = 0.f;
+    if (q < Q) {
+      const int r = meta->row[q];
+      if (r >= 0) {   // clicked query: feature + Fourier(click xyz) + time encoding (agile3d.py:213-264)
+        f = feats128[(size_t)r * D + c];
+        p = posenc[(size_t)r * D + c] + time_table[(size_t)meta->time[q] * D + c];
+      } else {        // learned background query
+        const int b = q - n_fg;
+        f = bg_feat[(size_t)b * D + c];
+        p = bg_pos[(size_t)b * D + c];
+      }
+    }
+    B.queries[e] = f;
+    B.qpos[e] = p;
+    B.qproj[e] = 0.f;
+    B.ks[e] = 0.f;
+    B.vs[e] = 0.f;
+    B.E[e] = 0.f;
+  }
+  (void)n_bgl;
+  __syncthreads();
+  // c2s query projection of the first layer, pre-scaled by 1/sqrt(head_dim)
+  lin<QP>(B.queries, D, B.qpos, Q, D, c2s_in_wt, 3 * D, c2s_in_b, D, B.qproj, D, false, 0.25f, lds);
+}
+
+template <int QP>
+__global__ void __launch_bounds__(512) k_query_layer(const QueryMeta* meta, QueryLayerW W, QueryBufs B,
+                                                      const float* part, int nchunk) {
+  __shared__ float lds[QP * 128];
+  const int Q = meta->nq;
+  const int tid = threadIdx.x, nt = blockDim.x;
+  // 1. combine the flash partials of the click-to-scene attention
+  for (int e = tid; e < Q * D; e += nt) {
+    const int q = e >> 7, c = e & 127, h = c >> 4, d = c & 15;
+    float M = kNegBig;
+    for (int ch = 0; ch < nchunk; ++ch)
+      M = fmaxf(M, part[(((size_t)ch * H + h) * QP + q) * kPartStride]);
+    float Lsum = 0.f, o = 0.f;
+    for (int ch = 0; ch < nchunk; ++ch) {
+      const float* p = part + (((size_t)ch * H + h) * QP + q) * kPartStride;
+      const float w = expf(p[0] - M);
+      Lsum += p[1] * w;
+      o += p[2 + d] * w;
+    }
+    B.attn[e] = o / Lsum;
+  }
+  __syncthreads();
+  // 2. c2s output projection + residual + LayerNorm (attention_block.py:95-96)
+  lin<QP>(B.attn, D, nullptr, Q, D, W.c2s_out_wt, D, W.c2s_out_b, D, B.tmp, D, false, 1.f, lds);
+  add_ln(B.queries, B.tmp, Q, W.c2s_norm_w, W.c2s_norm_b, B.tgt);
+  // 3. click-to-click self attention (attention_block.py:32-36)
+  lin<QP>(B.tgt, D, B.qpos, Q, D, W.c2c_in_wt, 3 * D, W.c2c_in_b, 2 * D, B.qk, 2 * D, false, 1.f, lds);
+  lin<QP>(B.tgt, D, nullptr, Q, D, W.c2c_in_wt + 2 * D, 3 * D, W.c2c_in_b + 2 * D, D, B.vc, D, false, 1.f, lds);
+  for (int e = tid; e < Q * H; e += nt) {
+    const int q = e / H, h = e % H;
+    float qv[DH];
+#pragma unroll
+    for (int d = 0; d < DH; ++d) qv[d] = B.qk[(size_t)q * 2 * D + h * DH + d] * 0.25f;
+    float mx = kNegBig;
+    for (int k = 0; k < Q; ++k) {
+      float s = 0.f;
+#pragma unroll
+      for (int d = 0; d < DH; ++d) s += qv[d] * B.qk[(size_t)k * 2 * D + D + h * DH + d];
+      mx = fmaxf(mx, s);
+    }
+    float sum = 0.f, o[DH];
+#pragma unroll
+    for (int d = 0; d < DH; ++d) o[d] = 0.f;
+    for (int k = 0; k < Q; ++k) {
+      float s = 0.f;
+#pragma unroll
+      for (int d = 0; d < DH; ++d) s += qv[d] * B.qk[(size_t)k * 2 * D + D + h * DH + d];
+      const float p = expf(s - mx);
+      sum += p;
+#pragma unroll
+      for (int d = 0; d < DH; ++d) o[d] += p * B.vc[(size_t)k * D + h * DH + d];
+    }
+    const float inv = 1.f / sum;
+#pragma unroll
+    for (int d = 0; d < DH; ++d) B.attn[(size_t)q * D + h * DH + d] = o[d] * inv;
+  }
+  __syncthreads();
+  lin<QP>(B.attn, D, nullptr, Q, D, W.c2c_out_wt, D, W.c2c_out_b, D, B.tmp, D, false, 1.f, lds);
+  add_ln(B.tgt, B.tmp, Q, W.c2c_norm_w, W.c2c_norm_b, B.tgt);
+  // 4. FFN (attention_block.py:151-155)
+  lin<QP>(B.tgt, D, nullptr, Q, D, W.ffn_w1t, W.dim_ff, W.ffn_b1, W.dim_ff, B.hidden, W.dim_ff, true, 1.f, lds);
+  lin<QP>(B.hidden, W.dim_ff, nullptr, Q, W.dim_ff, W.ffn_w2t, D, W.ffn_b2, D, B.tmp, D, false, 1.f, lds);
+  add_ln(B.tgt, B.tmp, Q, W.ffn_norm_w, W.ffn_norm_b, B.queries);
+  // 5. keys / values of the scene-to-click attention (keys pre-scaled by 1/sqrt(head_dim))
+  lin<QP>(B.queries, D, B.qpos, Q, D, W.s2c_in_wt + D, 3 * D, W.s2c_in_b + D, D, B.ks, D, false, 0.25f, lds);
+  lin<QP>(B.queries, D, nullptr, Q, D, W.s2c_in_wt + 2 * D, 3 * D, W.s2c_in_b + 2 * D, D, B.vs, D, false, 1.f, lds);
+  // 6. mask embeddings E = MLP(decoder_norm(q))  (agile3d.py:345-346)
+  add_ln(B.queries, nullptr, Q, W.dn_w, W.dn_b, B.tmp);
+  lin<QP>(B.tmp, D, nullptr, Q, D, W.m_w0t, D, W.m_b0, D, B.attn, D, true, 1.f, lds);
+  lin<QP>(B.attn, D, nullptr, Q, D, W.m_w2t, D, W.m_b2, D, B.E, D, false, 1.f, lds);
+  // 7. query projection for the next iteration's click-to-scene attention
+  if (W.next_c2s_in_wt)
+    lin<QP>(B.queries, D, B.qpos, Q, D, W.next_c2s_in_wt, 3 * D, W.next_c2s_in_b, D, B.qproj, D, false, 0.25f, lds);
+}
+
+}  // namespace a3d
+
+using namespace a3d;
+
+// ------------------------------------------------------------------------------ C ABI
+extern "C" int a3d_posenc_fourier(const float* xyz_dev, int64_t n, const float* gauss_B_dev, float* minmax_dev,
+                                  float* out_dev, void* workspace_dev, size_t workspace_bytes, void* stream) {
+  if (!xyz_dev || !gauss_B_dev || !minmax_dev || !out_dev || n <= 0 || n > (int64_t)1 << 30) {
+    set_error("a3d_posenc_fourier: bad arguments");
+    return A3D_ERR_INVALID;
+  }
+  const int nb = (int)((n + 255) / 256 < 256 ? (n + 255) / 256 : 256);
+  if (!workspace_dev || workspace_bytes < (size_t)nb * 6 * 4) {
+    set_error("a3d_posenc_fourier: workspace needs >= %zu bytes", (size_t)256 * 6 * 4);
+    return A3D_ERR_WORKSPACE;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  float* part = (float*)workspace_dev;
+  k_minmax_partial<<<nb, 256, 0, st>>>(xyz_dev, (int)n, part);
+  k_minmax_final<<<1, 64, 0, st>>>(part, nb, minmax_dev);
+  const size_t total = (size_t)n * 64;
+  k_fourier<<<(unsigned)((total + 255) / 256), 256, 0, st>>>(xyz_dev, (int)n, gauss_B_dev, minmax_dev, out_dev);
+  A3D_LAUNCH_CHECK();
+  return A3D_OK;
+}
+
+extern "C" size_t a3d_decoder_cache_bytes(int64_t n, int n_layers) {
+  return (size_t)n_layers * 2 * align256((size_t)n * D * 4);
+}
+
+static int check_weights(const a3d_decoder_weights* w) {
+  if (!w || w->n_layers < 1 || w->n_layers > A3D_MAX_DEC_LAYERS || w->n_bg_queries < 0 ||
+      w->n_bg_queries > A3D_MAX_QUERIES || w->dim_ff % 128 != 0) {
+    set_error("decoder: bad weight struct");
+    return A3D_ERR_INVALID;
+  }
+  return A3D_OK;
+}
+
+extern "C" int a3d_decoder_build_cache(const a3d_decoder_weights* w, const float* posenc_dev, int64_t n,
+                                       void* cache_dev, size_t cache_bytes, void* workspace_dev,
+                                       size_t workspace_bytes, void* stream) {
+  int rc = check_weights(w);
+  if (rc) return rc;
+  if (!posenc_dev || !cache_dev || cache_bytes < a3d_decoder_cache_bytes(n, w->n_layers)) {
+    set_error("a3d_decoder_build_cache: bad arguments / cache too small");
+    return A3D_ERR_INVALID;
+  }
+  const size_t one = align256((size_t)n * D * 4);
+  for (int l = 0; l < w->n_layers; ++l) {
+    const a3d_decoder_layer& L = w->layers[l];
+    float* posk = (float*)((char*)cache_dev + (size_t)(2 * l) * one);
+    float* posq = (float*)((char*)cache_dev + (size_t)(2 * l + 1) * one);
+    // pos @ Wk^T + bk   (bias rows D..2D of in_proj_bias) ; pos @ Wq^T + bq (rows 0..D)
+    rc = a3d_linear(posenc_dev, D, n, D, D, L.c2s_wk_packed, nullptr, L.c2s_in_b + D, nullptr, 0, 0, posk, D,
+                    workspace_dev, workspace_bytes, stream);
+    if (rc) return rc;
+    rc = a3d_linear(posenc_dev, D, n, D, D, L.s2c_wq_packed, nullptr, L.s2c_in_b, nullptr, 0, 0, posq, D,
+                    workspace_dev, workspace_bytes, stream);
+    if (rc) return rc;
+  }
+  return A3D_OK;
+}
+
+namespace {
+struct DecLayout {
+  size_t buf[4], labels, counts, part, meta, q[12], total;
+  int qp, nchunk;
+};
+int round_qp(int nq) { return nq <= 16 ? 16 : nq <= 32 ? 32 : nq <= 48 ? 48 : 64; }
+void dec_layout(int64_t n, int nq, DecLayout& L) {
+  size_t off = 0;
+  auto take = [&](size_t bytes) {
+    size_t o = off;
+    off += align256(bytes);
+    return o;
+  };
+  L.qp = round_qp(nq);
+  L.nchunk = (int)((n + kC2SChunk - 1) / kC2SChunk);
+  for (int i = 0; i < 4; ++i) L.buf[i] = take((size_t)n * D * 4);
+  L.labels = take((size_t)n + 64);
+  L.counts = take((size_t)A3D_MAX_DEC_LAYERS * (A3D_MAX_QUERIES + 1) * 4);
+  L.part = take((size_t)L.nchunk * H * L.qp * kPartStride * 4);
+  L.meta = take(sizeof(QueryMeta));
+  const size_t qb = (size_t)L.qp * D * 4;
+  for (int i = 0; i < 9; ++i) L.q[i] = take(qb);        // queries qpos qproj ks vs E attn tmp tgt
+  L.q[9] = take(2 * qb);                                // qk
+  L.q[10] = take(qb);                                   // vc
+  L.q[11] = take((size_t)L.qp * 4096 * 4);              // hidden (dim_ff <= 4096)
+  L.total = off;
+}
+}  // namespace
+
+extern "C" size_t a3d_decoder_workspace_bytes(int64_t n, int n_queries) {
+  if (n <= 0 || n_queries < 1 || n_queries > A3D_MAX_QUERIES) return 0;
+  DecLayout L;
+  dec_layout(n, n_queries, L);
+  return L.total + 256;
+}
+
+template <int QT>
+static int run_decoder(const a3d_decoder_weights* w, const float* feats128, const float* posenc,
+                       const void* cache, int64_t n64, const QueryMeta& hm, float* logits, char* ws,
+                       const DecLayout& L, hipStream_t st) {
+  constexpr int QP = QT * 16;
+  const int n = (int)n64, K = hm.K, nq = hm.nq;
+  float* bufA = (float*)(ws + L.buf[0]);
+  float* bufB = (float*)(ws + L.buf[1]);
+  float* bufC = (float*)(ws + L.buf[2]);
+  float* bufD = (float*)(ws + L.buf[3]);
+  unsigned char* labels = (unsigned char*)(ws + L.labels);
+  int* counts = (int*)(ws + L.counts);
+  float* part = (float*)(ws + L.part);
+  QueryMeta* meta = (QueryMeta*)(ws + L.meta);
+  QueryBufs B;
+  B.queries = (float*)(ws + L.q[0]);
+  B.qpos = (float*)(ws + L.q[1]);
+  B.qproj = (float*)(ws + L.q[2]);
+  B.ks = (float*)(ws + L.q[3]);
+  B.vs = (float*)(ws + L.q[4]);
+  B.E = (float*)(ws + L.q[5]);
+  B.attn = (float*)(ws + L.q[6]);
+  B.tmp = (float*)(ws + L.q[7]);
+  B.tgt = (float*)(ws + L.q[8]);
+  B.qk = (float*)(ws + L.q[9]);
+  B.vc = (float*)(ws + L.q[10]);
+  B.hidden = (float*)(ws + L.q[11]);
+  A3D_HIP_CHECK(hipMemcpyAsync(meta, &hm, sizeof(QueryMeta), hipMemcpyHostToDevice, st));
+  const int n_counts = A3D_MAX_DEC_LAYERS * (A3D_MAX_QUERIES + 1);
+  k_query_init<QP><<<1, 512, 0, st>>>(meta, feats128, posenc, w->bg_query_feat, w->bg_query_pos, w->time_table,
+                                       w->layers[0].c2s_in_w, w->layers[0].c2s_in_b, B, counts, n_counts);
+  A3D_LAUNCH_CHECK();
+  const size_t one = align256((size_t)n * D * 4);
+  const float* src = feats128;
+  const size_t s2c_lds = (size_t)2 * QP * 132 * 4;
+  const size_t lnm_lds = ((size_t)QP * 132 + 4 * 16 * (QP + 1) + 4 * 16 * (K + 1)) * 4 + (size_t)(K + 1) * 4;
+  for (int l = 0; l < w->n_layers; ++l) {
+    const a3d_decoder_layer& LW = w->layers[l];
+    const float* posk = (const float*)((const char*)cache + (size_t)(2 * l) * one);
+    const float* posq = (const float*)((const char*)cache + (size_t)(2 * l + 1) * one);
+    int rc;
+    // ---- click-to-scene: K = src Wk^T + (pos Wk^T + bk), V = src Wv^T + bv
+    rc = a3d_linear(src, D, n, D, D, LW.c2s_wk_packed, nullptr, nullptr, posk, D, 0, bufA, D, nullptr, 0, st);
+    if (rc) return rc;
+    rc = a3d_linear(src, D, n, D, D, LW.c2s_wv_packed, nullptr, LW.c2s_in_b + 2 * D, nullptr, 0, 0, bufB, D, nullptr, 0, st);
+    if (rc) return rc;
+    const int* prev_counts = l > 0 ? counts + (size_t)(l - 1) * (A3D_MAX_QUERIES + 1) : nullptr;
+    k_c2s_attn<QT><<<L.nchunk, 512, 0, st>>>(bufA, bufB, n, B.qproj, meta->obj, l > 0 ? labels : nullptr,
+                                            prev_counts, part);
+    A3D_LAUNCH_CHECK();
+    QueryLayerW QW;
+    QW.c2s_in_wt = LW.c2s_in_w; QW.c2s_in_b = LW.c2s_in_b; QW.c2s_out_wt = LW.c2s_out_w; QW.c2s_out_b = LW.c2s_out_b;
+    QW.c2s_norm_w = LW.c2s_norm_w; QW.c2s_norm_b = LW.c2s_norm_b;
+    QW.c2c_in_wt = LW.c2c_in_w; QW.c2c_in_b = LW.c2c_in_b; QW.c2c_out_wt = LW.c2c_out_w; QW.c2c_out_b = LW.c2c_out_b;
+    QW.c2c_norm_w = LW.c2c_norm_w; QW.c2c_norm_b = LW.c2c_norm_b;
+    QW.ffn_w1t = LW.ffn_w1; QW.ffn_b1 = LW.ffn_b1; QW.ffn_w2t = LW.ffn_w2; QW.ffn_b2 = LW.ffn_b2;
+    QW.ffn_norm_w = LW.ffn_norm_w; QW.ffn_norm_b = LW.ffn_norm_b;
+    QW.s2c_in_wt = LW.s2c_in_w; QW.s2c_in_b = LW.s2c_in_b;
+    QW.dn_w = w->decoder_norm_w; QW.dn_b = w->decoder_norm_b;
+    QW.m_w0t = w->mask_w0; QW.m_b0 = w->mask_b0; QW.m_w2t = w->mask_w2; QW.m_b2 = w->mask_b2;
+    QW.next_c2s_in_wt = l + 1 < w->n_layers ? w->layers[l + 1].c2s_in_w : nullptr;
+    QW.next_c2s_in_b = l + 1 < w->n_layers ? w->layers[l + 1].c2s_in_b : nullptr;
+    QW.dim_ff = w->dim_ff;
+    k_query_layer<QP><<<1, 512, 0, st>>>(meta, QW, B, part, L.nchunk);
+    A3D_LAUNCH_CHECK();
+    // ---- scene-to-click: Q = src Wq^T + (pos Wq^T + bq); attention; Y = O Wo^T + bo + src; LN
+    rc = a3d_linear(src, D, n, D, D, LW.s2c_wq_packed, nullptr, nullptr, posq, D, 0, bufA, D, nullptr, 0, st);
+    if (rc) return rc;
+    k_s2c_attn<QT><<<(n + 127) / 128, 512, s2c_lds, st>>>(bufA, n, B.ks, B.vs, nq, bufB);
+    A3D_LAUNCH_CHECK();
+    float* Y = (l & 1) ? bufD : bufC;
+    rc = a3d_linear(bufB, D, n, D, D, LW.s2c_wo_packed, nullptr, LW.s2c_out_b, src, D, 0, Y, D, nullptr, 0, st);
+    if (rc) return rc;
+    k_ln_mask<QT><<<(n + 63) / 64, 256, lnm_lds, st>>>(Y, n, LW.s2c_norm_w, LW.s2c_norm_b, B.E, nq, meta->qrange,
+                                                      hm.n_fg, K, logits + (size_t)l * n * (K + 1), labels,
+                                                      counts + (size_t)l * (A3D_MAX_QUERIES + 1));
+    A3D_LAUNCH_CHECK();
+    src = Y;
+  }
+  return A3D_OK;
+}
+
+extern "C" int a3d_decoder_forward(const a3d_decoder_weights* w, const float* feats128_dev, const float* xyz_dev,
+                                   const float* posenc_dev, const float* minmax_dev, const void* cache_dev,
+                                   int64_t n, const int32_t* click_row, const int32_t* click_obj,
+                                   const int32_t* click_time, int n_clicks, int n_objects, float* logits_dev,
+                                   void* workspace_dev, size_t workspace_bytes, void* stream) {
+  (void)xyz_dev;
+  (void)minmax_dev;   // click encodings equal the scene encoding rows
+  int rc = check_weights(w);
+  if (rc) return rc;
+  if (!feats128_dev || !posenc_dev || !cache_dev || !logits_dev || n <= 0 || n_objects < 1 ||
+      n_clicks < n_objects || (n_clicks && (!click_row || !click_obj || !click_time))) {
+    set_error("a3d_decoder_forward: bad arguments (every object needs >= 1 click, agile3d.py:353)");
+    return A3D_ERR_INVALID;
+  }
+  const int nq = n_clicks + w->n_bg_queries;
+  if (nq > A3D_MAX_QUERIES || n_objects > 254) {
+    set_error("a3d_decoder_forward: %d queries > %d", nq, A3D_MAX_QUERIES);
+    return A3D_ERR_UNSUPPORTED;
+  }
+  QueryMeta hm;
+  memset(&hm, 0, sizeof(hm));
+  hm.K = n_objects;
+  hm.n_bgl = w->n_bg_queries;
+  // order: foreground clicks object-major, learned background queries, background clicks
+  int q = 0;
+  for (int o = 1; o <= n_objects; ++o) {
+    hm.qrange[o] = q;
+    for (int i = 0; i < n_clicks; ++i)
+      if (click_obj[i] == o) {
+        hm.row[q] = click_row[i];
+        hm.time[q] = click_time[i];
+        hm.obj[q] = o;
+        ++q;
+      }
+    if (q == hm.qrange[o]) {
+      set_error("a3d_decoder_forward: object %d has no click", o);
+      return A3D_ERR_INVALID;
+    }
+  }
+  hm.qrange[n_objects + 1] = q;
+  hm.n_fg = q;
+  for (int b = 0; b < w->n_bg_queries; ++b) {
+    hm.row[q] = -1;
+    hm.obj[q] = 0;
+    ++q;
+  }
+  for (int i = 0; i < n_clicks; ++i)
+    if (click_obj[i] == 0) {
+      hm.row[q] = click_row[i];
+      hm.time[q] = click_time[i];
+      hm.obj[q] = 0;
+      ++q;
+      ++hm.n_bg_click;
+    }
+  if (q != nq) {
+    set_error("a3d_decoder_forward: click_obj outside 0..%d", n_objects);
+    return A3D_ERR_INVALID;
+  }
+  hm.nq = nq;
+  for (int i = 0; i < nq; ++i)
+    if (hm.row[i] >= n || hm.time[i] < 0 || hm.time[i] >= 200) {
+      set_error("a3d_decoder_forward: click row/time out of range");
+      return A3D_ERR_INVALID;
+    }
+  for (int i = nq; i < A3D_MAX_QUERIES; ++i) {
+    hm.obj[i] = -1;
+    hm.row[i] = -1;
+  }
+  DecLayout L;
+  dec_layout(n, nq, L);
+  if (!workspace_dev || workspace_bytes < L.total || ((uintptr_t)workspace_dev & 255)) {
+    set_error("a3d_decoder_forward: workspace too small or misaligned (%zu < %zu)", workspace_bytes, L.total);
+    return A3D_ERR_WORKSPACE;
+  }
+  if (w->dim_ff > 4096) {
+    set_error("a3d_decoder_forward: dim_feedforward > 4096");
+    return A3D_ERR_UNSUPPORTED;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  char* ws = (char*)workspace_dev;
+  switch (L.qp) {
+    case 16: return run_decoder<1>(w, feats128_dev, posenc_dev, cache_dev, n, hm, logits_dev, ws, L, st);
+    case 32: return run_decoder<2>(w, feats128_dev, posenc_dev, cache_dev, n, hm, logits_dev, ws, L, st);
+    case 48: return run_decoder<3>(w, feats128_dev, posenc_dev, cache_dev, n, hm, logits_dev, ws, L, st);
+    default: return run_decoder<4>(w, feats128_dev, posenc_dev, cache_dev, n, hm, logits_dev, ws, L, st);
+  }
+}

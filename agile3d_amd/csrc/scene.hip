@@ -1,0 +1,538 @@
+// Coordinate manager for the sparse-voxel backbone, built on the GPU.
+//
+// Replaces what MinkowskiEngine's coordinate manager does implicitly behind
+// ME.SparseTensor(...) (reference engine.py:47-51) and every ME layer: voxel hash,
+// stride-2 coordinate sets (res16unet.py:229,234,239,245), kernel maps for the 3^3
+// (resnet_block.py:24-43) and 2^3-stride-2 kernels (and their transposes).
+//
+// MI355X-first design (DESIGN.md "scene"):
+//   * voxels are sorted by a 64-bit Morton key (batch | z y x interleaved); siblings of a
+//     coarse voxel are then contiguous, so each coarser level is a run-length compaction of
+//     the finer one (one scan per level, no hash insert races, deterministic row ids);
+//   * inside super tiles of 1024 Morton-consecutive rows, rows are re-ordered by their 27-bit
+//     neighbour-presence pattern, so that a 16-row MFMA group mostly shares one pattern and the
+//     implicit-GEMM kernel can skip absent kernel offsets per group (42 % -> ~85 % useful MFMAs);
+//   * kernel maps are output-major neighbour tables int32[K][npad] (k-major: the 128 rows of a
+//     workgroup tile are contiguous for every offset) with "missing" = the all-zero row n.
+#include "common.h"
+#include <rocprim/rocprim.hpp>
+#include <stdarg.h>
+#include <stdlib.h>
+
+namespace a3d {
+
+static thread_local char g_err[512] = "";
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+const char* get_error() { return g_err; }
+
+// ------------------------------------------------------------------------------ block scan
+__device__ inline int wave_incl_scan(int v) {
+  const int lane = threadIdx.x & 63;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int t = __shfl_up(v, o, 64);
+    if (lane >= o) v += t;
+  }
+  return v;
+}
+// inclusive scan over a 1024-thread block; lds must hold 17 ints; returns scan, *total = block sum
+__device__ inline int block_incl_scan(int v, int* lds, int* total) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  const int s = wave_incl_scan(v);
+  if (lane == 63) lds[w] = s;
+  __syncthreads();
+  if (w == 0) {
+    const int x = lane < nw ? lds[lane] : 0;
+    const int xs = wave_incl_scan(x);
+    if (lane < nw) lds[lane] = xs - x;
+    if (lane == nw - 1) lds[16] = xs;
+  }
+  __syncthreads();
+  const int r = s + lds[w];
+  *total = lds[16];
+  __syncthreads();
+  return r;
+}
+
+// ------------------------------------------------------------------------------ kernels
+// sizes_dev: [0..4] level sizes, [5] error code
+__global__ void k_make_keys(const int32_t* __restrict__ coords4, int n, uint64_t* keys, int* vals,
+                            int* sizes_dev) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int b = coords4[4 * i + 0], x = coords4[4 * i + 1], y = coords4[4 * i + 2], z = coords4[4 * i + 3];
+  const int lim = kCoordOff;
+  if (b < 0 || b > 1022 || x < -lim || x >= lim || y < -lim || y >= lim || z < -lim || z >= lim) {
+    atomicMin(&sizes_dev[5], A3D_ERR_COORD_RANGE);
+    keys[i] = 0;
+    vals[i] = i;
+    return;
+  }
+  keys[i] = make_key(b, x, y, z, 0);
+  vals[i] = i;
+}
+
+__global__ void k_check_dups(const uint64_t* __restrict__ keys, int n, int* sizes_dev) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= 1 && i < n && keys[i] == keys[i - 1]) atomicMin(&sizes_dev[5], A3D_ERR_DUPLICATE);
+}
+
+// level L -> L+1, pass 1: count run heads per block of 1024 rows
+__global__ void __launch_bounds__(1024) k_head_count(const uint64_t* __restrict__ keys,
+                                                     const int* __restrict__ n_dev, int* blocksums) {
+  __shared__ int lds[17];
+  const int n = *n_dev;
+  const int i = blockIdx.x * 1024 + threadIdx.x;
+  int f = 0;
+  if (i < n) f = (i == 0) || ((keys[i] >> 3) != (keys[i - 1] >> 3));
+  int total;
+  block_incl_scan(f, lds, &total);
+  if (threadIdx.x == 0) blocksums[blockIdx.x] = total;
+}
+// exclusive scan of up to nb block sums by one block; writes the grand total
+__global__ void __launch_bounds__(1024) k_scan_blocksums(int* blocksums, int nb, int* total_out) {
+  __shared__ int lds[17];
+  int running = 0;
+  for (int base = 0; base < nb; base += 1024) {
+    const int i = base + threadIdx.x;
+    const int v = i < nb ? blocksums[i] : 0;
+    int total;
+    const int s = block_incl_scan(v, lds, &total);
+    if (i < nb) blocksums[i] = running + s - v;
+    running += total;
+  }
+  if (threadIdx.x == 0) *total_out = running;
+}
+__global__ void __launch_bounds__(1024) k_head_write(const uint64_t* __restrict__ keys,
+                                                     const int* __restrict__ n_dev,
+                                                     const int* __restrict__ blockoffs, int* parentM,
+                                                     uint64_t* keys_next) {
+  __shared__ int lds[17];
+  const int n = *n_dev;
+  const int i = blockIdx.x * 1024 + threadIdx.x;
+  int f = 0;
+  uint64_t k3 = 0;
+  if (i < n) {
+    k3 = keys[i] >> 3;
+    f = (i == 0) || (k3 != (keys[i - 1] >> 3));
+  }
+  int total;
+  const int s = block_incl_scan(f, lds, &total);
+  if (i < n) {
+    const int pid = blockoffs[blockIdx.x] + s - 1;
+    parentM[i] = pid;
+    if (f) keys_next[pid] = k3;
+  }
+}
+
+__global__ void k_fill_u64(uint64_t* p, size_t n, uint64_t v) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = v;
+}
+__global__ void k_fill_i32(int* p, size_t n, int v) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = v;
+}
+
+__global__ void k_hash_insert(const uint64_t* __restrict__ keys, int n, uint64_t* hk, int* hv,
+                              uint32_t hmask) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint64_t key = keys[i];
+  uint32_t h = hash64(key) & hmask;
+  for (uint32_t probe = 0; probe <= hmask; ++probe) {
+    const unsigned long long prev =
+        atomicCAS((unsigned long long*)&hk[h], (unsigned long long)kEmptyKey, (unsigned long long)key);
+    if (prev == kEmptyKey || prev == key) {
+      hv[h] = i;
+      return;
+    }
+    h = (h + 1) & hmask;
+  }
+}
+
+// 3^3 neighbours in Morton row ids: nbrM[k][npad] (-1 = missing) and the 27-bit presence mask
+__global__ void k_nbr_morton(const uint64_t* __restrict__ keys, int n, int npad, int L,
+                             const uint64_t* __restrict__ hk, const int* __restrict__ hv,
+                             uint32_t hmask, int* nbrM, uint32_t* mask27) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  int b, X, Y, Z;
+  decode_key(keys[i], L, b, X, Y, Z);
+  const int lim = kCoordOff >> L;
+  uint32_t m = 0;
+#pragma unroll 1
+  for (int k = 0; k < 27; ++k) {
+    const int dx = k % 3 - 1, dy = (k / 3) % 3 - 1, dz = k / 9 - 1;  // x fastest
+    const int x = X + dx, y = Y + dy, z = Z + dz;
+    int r = -1;
+    if (k == 13) {
+      r = i;
+    } else if (x >= -lim && x < lim && y >= -lim && y < lim && z >= -lim && z < lim) {
+      r = hash_lookup(hk, hv, hmask, make_key(b, x, y, z, L));
+    }
+    nbrM[(size_t)k * npad + i] = r;
+    if (r >= 0) m |= 1u << k;
+  }
+  mask27[i] = m;
+}
+
+// sort the rows of each 1024-row super tile by `sortkey` (stable: ties keep Morton order)
+__global__ void __launch_bounds__(1024) k_tile_sort(const uint32_t* __restrict__ sortkey, int n,
+                                                    int* perm, int* inv) {
+  __shared__ uint64_t s[kSuperTile];
+  const int tid = threadIdx.x;
+  const int base = blockIdx.x * kSuperTile;
+  const int i = base + tid;
+  s[tid] = i < n ? (((uint64_t)sortkey[i] << 10) | (uint64_t)tid) : ~0ULL;
+  __syncthreads();
+  for (int k = 2; k <= kSuperTile; k <<= 1) {
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      const int ixj = tid ^ j;
+      if (ixj > tid) {
+        const bool asc = (tid & k) == 0;
+        const uint64_t a = s[tid], b = s[ixj];
+        if ((a > b) == asc) {
+          s[tid] = b;
+          s[ixj] = a;
+        }
+      }
+      __syncthreads();
+    }
+  }
+  const uint64_t v = s[tid];
+  if (v != ~0ULL) {
+    const int e = (int)(v & 1023);
+    perm[base + e] = base + tid;
+    inv[base + tid] = base + e;
+  }
+}
+
+// nbr27[k][f] in internal row ids (missing / padding -> n) + per-16-row-group presence masks
+__global__ void k_remap_nbr(const int* __restrict__ nbrM, const int* __restrict__ perm,
+                            const int* __restrict__ inv, int n, int npad, int* nbr27,
+                            uint32_t* gmask27) {
+  const int f = blockIdx.x * blockDim.x + threadIdx.x;
+  const int k = blockIdx.y;
+  if (f >= npad) return;
+  int o = n;
+  bool present = false;
+  if (f < n) {
+    const int v = nbrM[(size_t)k * npad + inv[f]];
+    if (v >= 0) {
+      o = perm[v];
+      present = true;
+    }
+  }
+  nbr27[(size_t)k * npad + f] = o;
+  const unsigned long long bal = __ballot(present);
+  const int lane = threadIdx.x & 63;
+  if ((lane & 15) == 0) {
+    if ((bal >> lane) & 0xffffULL) atomicOr(&gmask27[f >> 4], 1u << k);
+  }
+}
+
+__global__ void k_xyzb(const uint64_t* __restrict__ keys, const int* __restrict__ inv, int n, int L,
+                       int32_t* xyzb) {
+  const int f = blockIdx.x * blockDim.x + threadIdx.x;
+  if (f >= n) return;
+  int b, X, Y, Z;
+  decode_key(keys[inv[f]], L, b, X, Y, Z);
+  xyzb[4 * f + 0] = X;
+  xyzb[4 * f + 1] = Y;
+  xyzb[4 * f + 2] = Z;
+  xyzb[4 * f + 3] = b;
+}
+
+__global__ void k_hash_fix(const uint64_t* __restrict__ hk, int* hv, uint32_t cap,
+                           const int* __restrict__ perm) {
+  const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s < cap && hk[s] != kEmptyKey) hv[s] = perm[hv[s]];
+}
+
+// child8[slot][coarse row] = fine row  (fine level L, coarse L+1)
+__global__ void k_child(const uint64_t* __restrict__ keysF, const int* __restrict__ parentM,
+                        const int* __restrict__ permF, const int* __restrict__ permC, int nF,
+                        int npadC, int* child8, uint32_t* gmask_down) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nF) return;
+  const int slot = (int)(keysF[i] & 7);
+  const int pf = permC[parentM[i]];
+  child8[(size_t)slot * npadC + pf] = permF[i];
+  atomicOr(&gmask_down[pf >> 4], 1u << slot);
+}
+
+__global__ void k_slot_key(const uint64_t* __restrict__ keysF, const int* __restrict__ invF, int nF,
+                           uint32_t* sortkey) {
+  const int f = blockIdx.x * blockDim.x + threadIdx.x;
+  if (f < nF) sortkey[f] = (uint32_t)(keysF[invF[f]] & 7);
+}
+
+// transposed-conv tables over virtual rows v (fine rows sorted by child slot inside super tiles)
+__global__ void k_up(const uint64_t* __restrict__ keysF, const int* __restrict__ invF,
+                     const int* __restrict__ parentM, const int* __restrict__ permC,
+                     const int* __restrict__ up_rows, int nF, int npadF, int nC, int* up8,
+                     uint32_t* gmask_up) {
+  const int v = blockIdx.x * blockDim.x + threadIdx.x;
+  if (v >= npadF) return;
+  int slot = -1, pf = nC;
+  if (v < nF) {
+    const int m = invF[up_rows[v]];
+    slot = (int)(keysF[m] & 7);
+    pf = permC[parentM[m]];
+    atomicOr(&gmask_up[v >> 4], 1u << slot);
+  }
+#pragma unroll
+  for (int s = 0; s < 8; ++s) up8[(size_t)s * npadF + v] = (s == slot) ? pf : nC;
+}
+
+__global__ void k_orig_row(const int* __restrict__ vals_sorted, const int* __restrict__ inv0, int n,
+                           int* orig_row) {
+  const int f = blockIdx.x * blockDim.x + threadIdx.x;
+  if (f < n) orig_row[f] = vals_sorted[inv0[f]];
+}
+
+// ------------------------------------------------------------------------------ host side
+struct Bump {
+  char* base;
+  size_t off = 0;
+  explicit Bump(void* b) : base((char*)b) {}
+  template <typename T>
+  T* take(size_t count) {
+    off = align256(off);
+    T* p = base ? (T*)(base + off) : nullptr;
+    off += count * sizeof(T);
+    return p;
+  }
+};
+
+static uint32_t hash_capacity(int n) {
+  uint32_t c = 1024;
+  while (c < 2u * (uint32_t)n) c <<= 1;
+  return c;
+}
+
+static size_t sort_temp_bytes(int n) {
+  size_t bytes = 0;
+  (void)rocprim::radix_sort_pairs(nullptr, bytes, (uint64_t*)nullptr, (uint64_t*)nullptr, (int*)nullptr,
+                                  (int*)nullptr, (size_t)n, 0, 64, (hipStream_t)0, false);
+  return bytes;
+}
+
+// phase-1 arrays (sized by the n0 upper bound) and phase-2 tables (sized by the real level sizes)
+struct Phase1 {
+  uint64_t *keys_in, *keys[A3D_NUM_LEVELS];
+  int *vals_in, *vals_sorted, *parentM[A3D_NUM_LEVELS - 1], *blocksums, *sizes_dev;
+  void* sort_temp;
+  size_t sort_temp_bytes;
+};
+static void carve_phase1(Bump& b, int n0, Phase1& p) {
+  p.keys_in = b.take<uint64_t>(n0);
+  p.vals_in = b.take<int>(n0);
+  p.vals_sorted = b.take<int>(n0);
+  for (int L = 0; L < A3D_NUM_LEVELS; ++L) p.keys[L] = b.take<uint64_t>(n0);
+  for (int L = 0; L < A3D_NUM_LEVELS - 1; ++L) p.parentM[L] = b.take<int>(n0);
+  p.blocksums = b.take<int>(n0 / 1024 + 2);
+  p.sizes_dev = b.take<int>(8);
+  p.sort_temp_bytes = sort_temp_bytes(n0);
+  p.sort_temp = b.take<char>(p.sort_temp_bytes);
+}
+struct Phase2Tmp {
+  int* nbrM;
+  uint32_t* sortkey;
+  int* permU;
+};
+static void carve_phase2(Bump& b, const int* sizes, a3d_scene* sc, Phase2Tmp& t) {
+  int maxn = 0;
+  for (int L = 0; L < A3D_NUM_LEVELS; ++L) {
+    Level& lv = sc->lv[L];
+    lv.n = sizes[L];
+    lv.npad = (int)round_up(lv.n > 0 ? lv.n : 1, kTileRows);
+    if (lv.npad > maxn) maxn = lv.npad;
+  }
+  for (int L = 0; L < A3D_NUM_LEVELS; ++L) {
+    Level& lv = sc->lv[L];
+    lv.perm = b.take<int>(lv.npad);
+    lv.inv = b.take<int>(lv.npad);
+    lv.xyzb = b.take<int32_t>((size_t)lv.npad * 4);
+    lv.hmask = hash_capacity(lv.n) - 1;
+    lv.hkeys = b.take<uint64_t>((size_t)lv.hmask + 1);
+    lv.hvals = b.take<int>((size_t)lv.hmask + 1);
+    lv.nbr27 = b.take<int>((size_t)27 * lv.npad);
+    lv.gmask27 = b.take<uint32_t>(lv.npad / 16);
+    if (L < A3D_NUM_LEVELS - 1) {
+      const int npadC = (int)round_up(sizes[L + 1] > 0 ? sizes[L + 1] : 1, kTileRows);
+      lv.child8 = b.take<int>((size_t)8 * npadC);
+      lv.gmask_down = b.take<uint32_t>(npadC / 16);
+      lv.up8 = b.take<int>((size_t)8 * lv.npad);
+      lv.gmask_up = b.take<uint32_t>(lv.npad / 16);
+      lv.up_rows = b.take<int>(lv.npad);
+    }
+  }
+  sc->orig_row = b.take<int>(sc->lv[0].npad);
+  t.nbrM = b.take<int>((size_t)27 * maxn);
+  t.sortkey = b.take<uint32_t>(maxn);
+  t.permU = b.take<int>(maxn);
+}
+
+}  // namespace a3d
+
+using namespace a3d;
+
+extern "C" int a3d_version(void) { return 1; }
+extern "C" const char* a3d_last_error(void) { return a3d::get_error(); }
+
+extern "C" int a3d_memcpy_d2h(void* dst_host, const void* src_dev, size_t bytes, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  A3D_HIP_CHECK(hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, st));
+  A3D_HIP_CHECK(hipStreamSynchronize(st));
+  return A3D_OK;
+}
+
+extern "C" size_t a3d_scene_workspace_bytes(int64_t n_voxels) {
+  if (n_voxels <= 0 || n_voxels > (int64_t)1 << 28) return 0;
+  const int n0 = (int)n_voxels;
+  Bump b(nullptr);
+  Phase1 p1;
+  carve_phase1(b, n0, p1);
+  a3d_scene tmp;
+  int sizes[A3D_NUM_LEVELS];
+  for (int L = 0; L < A3D_NUM_LEVELS; ++L) sizes[L] = n0;  // upper bound: n_L <= n_0
+  Phase2Tmp t;
+  carve_phase2(b, sizes, &tmp, t);
+  return align256(b.off) + 4096;
+}
+
+extern "C" int a3d_scene_create(const int32_t* coords4_dev, int64_t n_voxels, void* workspace_dev,
+                                size_t workspace_bytes, void* stream, a3d_scene** out) {
+  if (!coords4_dev || !workspace_dev || !out || n_voxels <= 0 || n_voxels > (int64_t)1 << 28) {
+    set_error("a3d_scene_create: bad arguments (n=%lld)", (long long)n_voxels);
+    return A3D_ERR_INVALID;
+  }
+  if (((uintptr_t)workspace_dev & 255) != 0) {
+    set_error("a3d_scene_create: workspace must be 256-byte aligned");
+    return A3D_ERR_INVALID;
+  }
+  if (workspace_bytes < a3d_scene_workspace_bytes(n_voxels)) {
+    set_error("a3d_scene_create: workspace too small (%zu < %zu)", workspace_bytes,
+              a3d_scene_workspace_bytes(n_voxels));
+    return A3D_ERR_WORKSPACE;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  const int n0 = (int)n_voxels;
+  Bump b(workspace_dev);
+  Phase1 p;
+  carve_phase1(b, n0, p);
+  const int T = 256;
+  auto nblk = [](int64_t n, int t) { return (unsigned)((n + t - 1) / t); };
+
+  // ---- phase 1: keys, sort, levels (all sized by the n0 bound; real sizes stay on the device)
+  int init_sizes[8] = {n0, 0, 0, 0, 0, 0, 0, 0};
+  A3D_HIP_CHECK(hipMemcpyAsync(p.sizes_dev, init_sizes, sizeof(init_sizes), hipMemcpyHostToDevice, st));
+  k_make_keys<<<nblk(n0, T), T, 0, st>>>(coords4_dev, n0, p.keys_in, p.vals_in, p.sizes_dev);
+  A3D_LAUNCH_CHECK();
+  size_t tb = p.sort_temp_bytes;
+  A3D_HIP_CHECK(rocprim::radix_sort_pairs(p.sort_temp, tb, p.keys_in, p.keys[0], p.vals_in, p.vals_sorted,
+                                          (size_t)n0, 0, 64, st, false));
+  k_check_dups<<<nblk(n0, T), T, 0, st>>>(p.keys[0], n0, p.sizes_dev);
+  A3D_LAUNCH_CHECK();
+  const int nb = (n0 + 1023) / 1024;
+  for (int L = 0; L < A3D_NUM_LEVELS - 1; ++L) {
+    k_head_count<<<nb, 1024, 0, st>>>(p.keys[L], p.sizes_dev + L, p.blocksums);
+    k_scan_blocksums<<<1, 1024, 0, st>>>(p.blocksums, nb, p.sizes_dev + L + 1);
+    k_head_write<<<nb, 1024, 0, st>>>(p.keys[L], p.sizes_dev + L, p.blocksums, p.parentM[L], p.keys[L + 1]);
+    A3D_LAUNCH_CHECK();
+  }
+  int sizes[8];
+  A3D_HIP_CHECK(hipMemcpyAsync(sizes, p.sizes_dev, sizeof(sizes), hipMemcpyDeviceToHost, st));
+  A3D_HIP_CHECK(hipStreamSynchronize(st));
+  if (sizes[5] != 0) {
+    set_error(sizes[5] == A3D_ERR_DUPLICATE ? "a3d_scene_create: duplicate voxel coordinates"
+                                            : "a3d_scene_create: coordinate out of range");
+    return sizes[5];
+  }
+
+  // ---- phase 2: per-level tables with exact sizes
+  a3d_scene* sc = new a3d_scene();
+  sc->n0 = n0;
+  sc->workspace = workspace_dev;
+  sc->workspace_bytes = workspace_bytes;
+  Phase2Tmp t;
+  carve_phase2(b, sizes, sc, t);
+  if (b.off > workspace_bytes) {
+    delete sc;
+    set_error("a3d_scene_create: internal workspace overflow");
+    return A3D_ERR_WORKSPACE;
+  }
+  for (int L = 0; L < A3D_NUM_LEVELS; ++L) {
+    Level& lv = sc->lv[L];
+    lv.keys = p.keys[L];
+    lv.parentM = L < A3D_NUM_LEVELS - 1 ? p.parentM[L] : nullptr;
+    const int n = lv.n, npad = lv.npad;
+    const uint32_t cap = lv.hmask + 1;
+    k_fill_u64<<<nblk(cap, T), T, 0, st>>>(lv.hkeys, cap, kEmptyKey);
+    k_hash_insert<<<nblk(n, T), T, 0, st>>>(lv.keys, n, lv.hkeys, lv.hvals, lv.hmask);
+    k_nbr_morton<<<nblk(n, T), T, 0, st>>>(lv.keys, n, npad, L, lv.hkeys, lv.hvals, lv.hmask, t.nbrM, t.sortkey);
+    k_tile_sort<<<nblk(n, kSuperTile), kSuperTile, 0, st>>>(t.sortkey, n, lv.perm, lv.inv);
+    A3D_HIP_CHECK(hipMemsetAsync(lv.gmask27, 0, sizeof(uint32_t) * (npad / 16), st));
+    k_remap_nbr<<<dim3(nblk(npad, T), 27), T, 0, st>>>(t.nbrM, lv.perm, lv.inv, n, npad, lv.nbr27, lv.gmask27);
+    k_xyzb<<<nblk(n, T), T, 0, st>>>(lv.keys, lv.inv, n, L, lv.xyzb);
+    k_hash_fix<<<nblk(cap, T), T, 0, st>>>(lv.hkeys, lv.hvals, cap, lv.perm);
+    A3D_LAUNCH_CHECK();
+  }
+  for (int L = 0; L < A3D_NUM_LEVELS - 1; ++L) {
+    Level& f = sc->lv[L];
+    Level& c = sc->lv[L + 1];
+    k_fill_i32<<<nblk((size_t)8 * c.npad, T), T, 0, st>>>(f.child8, (size_t)8 * c.npad, f.n);
+    A3D_HIP_CHECK(hipMemsetAsync(f.gmask_down, 0, sizeof(uint32_t) * (c.npad / 16), st));
+    k_child<<<nblk(f.n, T), T, 0, st>>>(f.keys, f.parentM, f.perm, c.perm, f.n, c.npad, f.child8, f.gmask_down);
+    k_slot_key<<<nblk(f.n, T), T, 0, st>>>(f.keys, f.inv, f.n, t.sortkey);
+    A3D_HIP_CHECK(hipMemsetAsync(f.up_rows, 0, sizeof(int) * f.npad, st));
+    k_tile_sort<<<nblk(f.n, kSuperTile), kSuperTile, 0, st>>>(t.sortkey, f.n, t.permU, f.up_rows);
+    A3D_HIP_CHECK(hipMemsetAsync(f.gmask_up, 0, sizeof(uint32_t) * (f.npad / 16), st));
+    k_up<<<nblk(f.npad, T), T, 0, st>>>(f.keys, f.inv, f.parentM, c.perm, f.up_rows, f.n, f.npad, c.n, f.up8, f.gmask_up);
+    A3D_LAUNCH_CHECK();
+  }
+  k_orig_row<<<nblk(n0, T), T, 0, st>>>(p.vals_sorted, sc->lv[0].inv, n0, sc->orig_row);
+  A3D_LAUNCH_CHECK();
+  *out = sc;
+  return A3D_OK;
+}
+
+extern "C" void a3d_scene_destroy(a3d_scene* s) { delete s; }
+
+extern "C" int64_t a3d_scene_level_size(const a3d_scene* s, int level) {
+  if (!s || level < 0 || level >= A3D_NUM_LEVELS) return -1;
+  return s->lv[level].n;
+}
+
+extern "C" int a3d_scene_table(const a3d_scene* s, int level, int which, const void** ptr_dev, int64_t* count) {
+  if (!s || !ptr_dev || !count || level < 0 || level >= A3D_NUM_LEVELS) {
+    set_error("a3d_scene_table: bad arguments");
+    return A3D_ERR_INVALID;
+  }
+  const Level& lv = s->lv[level];
+  const bool has_coarse = level < A3D_NUM_LEVELS - 1;
+  const int npadC = has_coarse ? s->lv[level + 1].npad : 0;
+  switch (which) {
+    case A3D_TAB_XYZB: *ptr_dev = lv.xyzb; *count = (int64_t)lv.n * 4; break;
+    case A3D_TAB_NBR27: *ptr_dev = lv.nbr27; *count = (int64_t)27 * lv.npad; break;
+    case A3D_TAB_GMASK27: *ptr_dev = lv.gmask27; *count = lv.npad / 16; break;
+    case A3D_TAB_CHILD8: if (!has_coarse) goto bad; *ptr_dev = lv.child8; *count = (int64_t)8 * npadC; break;
+    case A3D_TAB_GMASKDOWN: if (!has_coarse) goto bad; *ptr_dev = lv.gmask_down; *count = npadC / 16; break;
+    case A3D_TAB_UP8: if (!has_coarse) goto bad; *ptr_dev = lv.up8; *count = (int64_t)8 * lv.npad; break;
+    case A3D_TAB_GMASKUP: if (!has_coarse) goto bad; *ptr_dev = lv.gmask_up; *count = lv.npad / 16; break;
+    case A3D_TAB_UPROWS: if (!has_coarse) goto bad; *ptr_dev = lv.up_rows; *count = lv.npad; break;
+    case A3D_TAB_ORIGROW: if (level != 0) goto bad; *ptr_dev = s->orig_row; *count = lv.n; break;
+    default: goto bad;
+  }
+  return A3D_OK;
+bad:
+  set_error("a3d_scene_table: table %d does not exist at level %d", which, level);
+  return A3D_ERR_INVALID;
+}

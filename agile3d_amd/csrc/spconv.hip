@@ -1,0 +1,615 @@
+// Sparse convolution as an output-stationary implicit GEMM on the fp32 matrix cores.
+//
+// Replaces ME.MinkowskiConvolution / MinkowskiConvolutionTranspose (+ the MinkowskiBatchNorm,
+// MinkowskiReLU, residual add and me.cat that follow them) at the reference's call sites:
+// models/modules/common.py:137-155,170-188; models/modules/resnet_block.py:48-64;
+// models/res16unet.py:222-295; models/agile3d.py:43-45,179.
+//
+//   out[u, :] = act( (sum_k in[nbr[k][u], :] @ W[k]) * scale + shift + res[u, :] )
+//
+// One kernel covers the 3^3, 2^3-stride-2, transposed 2^3 and 1x1 layers (and the dense
+// [N,128]x[128,128] projections of the decoder): they only differ in the neighbour table.
+//
+// gfx950 mapping (DESIGN.md "spconv"):
+//   * workgroup = 4 waves = 128 output rows x BN output channels; a wave owns two 16-row MFMA
+//     groups; v_mfma_f32_16x16x4_f32 (exact fp32) accumulates 16x16 tiles in registers;
+//   * per (kernel offset k, 32-channel slice): the 128 gathered input rows and the packed weight
+//     slice are DMA'd global->LDS with global_load_lds_dwordx4 (per-lane source = gathered row,
+//     LDS image linear; the 16-byte XOR swizzle is applied on the SOURCE address and again on
+//     the ds_read_b128, so fragment reads are bank-conflict free);
+//   * offsets k absent from a whole 16-row group are skipped (no gather, no MFMA): rows were
+//     clustered by neighbour pattern when the scene was built (scene.hip);
+//   * the K dimension inside a 16-channel step is permuted (channel = 16S + 4g + t for lane
+//     group g, MFMA t) identically for A and B, so one ds_read_b128 feeds four MFMAs;
+//   * BatchNorm(eval) scale/shift, residual, ReLU and the channel-slice concat are the epilogue.
+#include "common.h"
+
+namespace a3d {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct ConvArgs {
+  const float* in;
+  int ldi, n_in;
+  const int* nbr;
+  int nbr_stride;
+  const uint32_t* gmask;
+  const float* w;
+  int K, cin, cout;
+  float* out;
+  int ldo, n_out;
+  const int* out_map;
+  const float* scale;
+  const float* shift;
+  const float* res;
+  int ldr;
+  int relu;
+  float* partial;
+  int kper;
+  int zero_row;
+};
+
+__device__ __forceinline__ void glds16(const float* src, float* lds_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                   (__attribute__((address_space(3))) void*)lds_base, 16, 0, 0);
+}
+
+template <int BN>
+__global__ void __launch_bounds__(256) k_spconv(const ConvArgs a) {
+  constexpr int NCT = BN / 16;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* A_lds = (float*)smem;               // [128 rows][32 ch], 16-byte pieces XOR-swizzled by row&7
+  float* W_lds = A_lds + 128 * 32;           // [2 steps][NCT][64 lanes][4]
+  int* idx_lds = (int*)(W_lds + 2 * NCT * 256);  // [kper][128]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = lane >> 4, j = lane & 15;
+  const int r0 = blockIdx.x * 128;
+  const int ct0 = blockIdx.y * NCT;
+  const int kbeg = blockIdx.z * a.kper;
+  const int kend = min(a.K, kbeg + a.kper);
+
+  // ---- which offsets does this tile / this wave's two groups need
+  uint32_t un = 0, gm0, gm1;
+  if (a.gmask) {
+    const uint32_t* gp = a.gmask + (r0 >> 4);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) un |= gp[i];
+    gm0 = gp[2 * wave];
+    gm1 = gp[2 * wave + 1];
+  } else {
+    un = gm0 = gm1 = 0xffffffffu;
+  }
+  un = __builtin_amdgcn_readfirstlane(un);
+  gm0 = __builtin_amdgcn_readfirstlane(gm0);
+  gm1 = __builtin_amdgcn_readfirstlane(gm1);
+
+  // ---- neighbour rows of the tile for every offset of this split
+  for (int e = tid; e < (kend - kbeg) * 128; e += 256) {
+    const int kk = e >> 7, r = e & 127;
+    int v;
+    if (a.nbr) {
+      v = a.nbr[(size_t)(kbeg + kk) * a.nbr_stride + r0 + r];
+    } else {
+      v = r0 + r;
+      if (v >= a.n_in) v = a.n_in - 1;
+    }
+    idx_lds[e] = v;
+  }
+  __syncthreads();
+
+  f32x4 acc[2][NCT];
+#pragma unroll
+  for (int G = 0; G < 2; ++G)
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct) acc[G][ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int nchunk = a.cin >> 5;
+  const int cin16 = a.cin >> 4, cout16 = a.cout >> 4;
+  const int swz = lane >> 3;  // == (row & 7) for the staging lanes
+
+  for (int k = kbeg; k < kend; ++k) {
+    if (!((un >> k) & 1u)) continue;
+    const bool act0 = (gm0 >> k) & 1u, act1 = (gm1 >> k) & 1u;
+    const int* idxk = idx_lds + (k - kbeg) * 128;
+    for (int c = 0; c < nchunk; ++c) {
+      // -- stage the wave's own 32 gathered rows (4 x 1 KiB DMA instructions)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const bool act = (i < 2) ? act0 : act1;
+        if (act) {
+          const int row = 32 * wave + 8 * i + swz;
+          const int src_row = idxk[row];
+          const float* src = a.in + (size_t)src_row * a.ldi + c * 32 + 4 * ((lane & 7) ^ swz);
+          glds16(src, A_lds + (32 * wave + 8 * i) * 32);
+        }
+      }
+      // -- stage the weight slice W[k][32 ch of this chunk][BN cols], already in fragment order
+      for (int q = wave; q < 2 * NCT; q += 4) {
+        const int s = q / NCT, ctl = q - s * NCT;
+        const float* src =
+            a.w + (((size_t)k * cin16 + (2 * c + s)) * cout16 + ct0 + ctl) * 256 + lane * 4;
+        glds16(src, W_lds + q * 256);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (act0 || act1) {
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+          const int p = ((4 * s + g) ^ (j & 7)) * 4;
+          const f32x4 a0 = *(const f32x4*)(A_lds + (32 * wave + j) * 32 + p);
+          const f32x4 a1 = *(const f32x4*)(A_lds + (32 * wave + 16 + j) * 32 + p);
+#pragma unroll
+          for (int ct = 0; ct < NCT; ++ct) {
+            const f32x4 b = *(const f32x4*)(W_lds + (s * NCT + ct) * 256 + lane * 4);
+            if (act0) {
+#pragma unroll
+              for (int t = 0; t < 4; ++t)
+                acc[0][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[t], b[t], acc[0][ct], 0, 0, 0);
+            }
+            if (act1) {
+#pragma unroll
+              for (int t = 0; t < 4; ++t)
+                acc[1][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[t], b[t], acc[1][ct], 0, 0, 0);
+            }
+          }
+        }
+      }
+      __syncthreads();
+    }
+  }
+
+  // ---- epilogue.  C/D layout of 16x16x4: column = lane & 15, row = 4 * (lane >> 4) + reg
+  if (a.partial) {
+    float* P = a.partial + (size_t)blockIdx.z * ((size_t)gridDim.x * 128) * a.cout;
+#pragma unroll
+    for (int G = 0; G < 2; ++G)
+#pragma unroll
+      for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const int vrow = r0 + 32 * wave + 16 * G + 4 * g + t;
+          P[(size_t)vrow * a.cout + (ct0 + ct) * 16 + j] = acc[G][ct][t];
+        }
+    return;
+  }
+#pragma unroll
+  for (int ct = 0; ct < NCT; ++ct) {
+    const int col = (ct0 + ct) * 16 + j;
+    const float sc = a.scale ? a.scale[col] : 1.f;
+    const float sh = a.shift ? a.shift[col] : 0.f;
+#pragma unroll
+    for (int G = 0; G < 2; ++G)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int vrow = r0 + 32 * wave + 16 * G + 4 * g + t;
+        if (vrow < a.n_out) {
+          const int orow = a.out_map ? a.out_map[vrow] : vrow;
+          float v = acc[G][ct][t] * sc + sh;
+          if (a.res) v += a.res[(size_t)orow * a.ldr + col];
+          if (a.relu) v = fmaxf(v, 0.f);
+          a.out[(size_t)orow * a.ldo + col] = v;
+        }
+      }
+  }
+  if (a.zero_row >= 0 && blockIdx.x == 0 && tid < BN)
+    a.out[(size_t)a.zero_row * a.ldo + ct0 * 16 + tid] = 0.f;
+}
+
+// sum the split-K partials and apply the epilogue
+__global__ void k_splitk_epilogue(const float* __restrict__ partial, int ksplit, size_t split_stride,
+                                  int n_out, int cout, const int* __restrict__ out_map,
+                                  const float* __restrict__ scale, const float* __restrict__ shift,
+                                  const float* __restrict__ res, int ldr, int relu, float* out, int ldo,
+                                  int zero_row) {
+  const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int c4 = cout >> 2;
+  const size_t total = (size_t)n_out * c4;
+  if (e < total) {
+    const int vrow = (int)(e / c4), col = (int)(e % c4) * 4;
+    f32x4 s = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int z = 0; z < ksplit; ++z) s += *(const f32x4*)(partial + z * split_stride + (size_t)vrow * cout + col);
+    const int orow = out_map ? out_map[vrow] : vrow;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      float v = s[t] * (scale ? scale[col + t] : 1.f) + (shift ? shift[col + t] : 0.f);
+      if (res) v += res[(size_t)orow * ldr + col + t];
+      if (relu) v = fmaxf(v, 0.f);
+      out[(size_t)orow * ldo + col + t] = v;
+    }
+  }
+  if (zero_row >= 0 && e < (size_t)cout) out[(size_t)zero_row * ldo + e] = 0.f;
+}
+
+// ------------------------------------------------------------------------------ stem
+// 5^3 (or 3^3) conv with Cin = 3 (res16unet.py:39-47,225-227; conv1_kernel_size main.py:37).
+// FLOPs are negligible (0.6 GF at 80 k voxels); the cost is 125 hash probes per voxel, so the
+// kernel map is never materialised: probe -> LDS table -> 3x32 FMAs per existing neighbour.
+__global__ void __launch_bounds__(256) k_stem(const int32_t* __restrict__ xyzb, int n,
+                                              const uint64_t* __restrict__ hk, const int* __restrict__ hv,
+                                              uint32_t hmask, const f32x4* __restrict__ feats4,
+                                              const float* __restrict__ w, int ks,
+                                              const float* __restrict__ scale, const float* __restrict__ shift,
+                                              int relu, float* out, int ldo, int zero_row) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int K = ks * ks * ks;
+  float* W = (float*)smem;              // [K][3][32]
+  int* nb = (int*)(W + K * 96);         // [64][K]
+  const int tid = threadIdx.x;
+  for (int e = tid; e < K * 96; e += 256) W[e] = w[e];
+  const int v0 = blockIdx.x * 64;
+  const int h = ks / 2;
+  for (int e = tid; e < 64 * K; e += 256) {
+    const int v = e / K, k = e - v * K;
+    const int row = v0 + v;
+    int r = -1;
+    if (row < n) {
+      const int X = xyzb[4 * row + 0] + (k % ks) - h;
+      const int Y = xyzb[4 * row + 1] + ((k / ks) % ks) - h;
+      const int Z = xyzb[4 * row + 2] + (k / (ks * ks)) - h;
+      const int b = xyzb[4 * row + 3];
+      const int lim = kCoordOff;
+      if (X >= -lim && X < lim && Y >= -lim && Y < lim && Z >= -lim && Z < lim)
+        r = hash_lookup(hk, hv, hmask, make_key(b, X, Y, Z, 0));
+    }
+    nb[e] = r;
+  }
+  __syncthreads();
+  const int v = tid >> 2, cg = tid & 3;
+  const int row = v0 + v;
+  float acc[8];
+#pragma unroll
+  for (int c = 0; c < 8; ++c) acc[c] = 0.f;
+  for (int k = 0; k < K; ++k) {
+    const int r = nb[v * K + k];
+    if (r >= 0) {
+      const f32x4 f = feats4[r];
+      const float* wk = W + k * 96 + cg * 8;
+#pragma unroll
+      for (int c = 0; c < 8; ++c) acc[c] += f[0] * wk[c] + f[1] * wk[32 + c] + f[2] * wk[64 + c];
+    }
+  }
+  if (row < n) {
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      const int col = cg * 8 + c;
+      float y = acc[c] * (scale ? scale[col] : 1.f) + (shift ? shift[col] : 0.f);
+      if (relu) y = fmaxf(y, 0.f);
+      out[(size_t)row * ldo + col] = y;
+    }
+  }
+  if (zero_row >= 0 && blockIdx.x == 0 && tid < 32) out[(size_t)zero_row * ldo + tid] = 0.f;
+}
+
+__global__ void k_gather_feats(const float* __restrict__ feats3, const int* __restrict__ orig_row, int n,
+                               f32x4* feats4) {
+  const int f = blockIdx.x * blockDim.x + threadIdx.x;
+  if (f >= n) return;
+  const float* p = feats3 + (size_t)orig_row[f] * 3;
+  feats4[f] = (f32x4){p[0], p[1], p[2], 0.f};
+}
+
+// W[K][cin][cout] -> Wp[K][cin/16][cout/16][lane = 16 g + j][t] = W[k][16 S + 4 g + t][16 ct + j]
+__global__ void k_pack_weight(const float* __restrict__ w, int K, int cin, int cout, float* out) {
+  const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t total = (size_t)K * cin * cout;
+  if (e >= total) return;
+  const int t = (int)(e & 3), lane = (int)((e >> 2) & 63);
+  size_t rest = e >> 8;
+  const int cout16 = cout >> 4, cin16 = cin >> 4;
+  const int ct = (int)(rest % cout16);
+  rest /= cout16;
+  const int S = (int)(rest % cin16);
+  const int k = (int)(rest / cin16);
+  const int g = lane >> 4, j = lane & 15;
+  out[e] = w[((size_t)k * cin + 16 * S + 4 * g + t) * cout + 16 * ct + j];
+}
+
+// ------------------------------------------------------------------------------ host: launch
+struct ConvPlan {
+  int bn, ksplit, kper, ntile;
+  size_t lds, partial_floats;
+};
+
+static ConvPlan plan_conv(int n_rows, int K, int cin, int cout) {
+  ConvPlan p;
+  p.ntile = (int)((n_rows + 127) / 128);
+  if (p.ntile < 1) p.ntile = 1;
+  int bn = (cout % 128 == 0) ? 128 : cout;
+  if (cout % 64 == 0 && (int64_t)p.ntile * (cout / bn) < 128 && bn > 64) bn = 64;
+  p.bn = bn;
+  const int blocks = p.ntile * (cout / bn);
+  int ksplit = 1;
+  if (K > 1 && blocks < 256) {
+    ksplit = (512 + blocks - 1) / blocks;
+    if (ksplit > K) ksplit = K;
+  }
+  p.kper = (K + ksplit - 1) / ksplit;
+  p.ksplit = (K + p.kper - 1) / p.kper;
+  p.lds = (size_t)(128 * 32 + 2 * (bn / 16) * 256) * 4 + (size_t)p.kper * 128 * 4;
+  p.partial_floats = p.ksplit > 1 ? (size_t)p.ksplit * p.ntile * 128 * cout : 0;
+  return p;
+}
+
+static int launch_conv(ConvArgs a, float* partial_ws, size_t partial_ws_floats, hipStream_t st) {
+  if (a.cin % 32 != 0 || a.cout % 16 != 0 || !(a.cout % 128 == 0 || a.cout == 32 || a.cout == 64 || a.cout == 96)) {
+    set_error("spconv: unsupported channels cin=%d cout=%d", a.cin, a.cout);
+    return A3D_ERR_UNSUPPORTED;
+  }
+  if (a.K > 32) {
+    set_error("spconv: kernel volume %d > 32", a.K);
+    return A3D_ERR_UNSUPPORTED;
+  }
+  ConvPlan p = plan_conv(a.n_out, a.K, a.cin, a.cout);
+  a.kper = p.kper;
+  a.partial = nullptr;
+  if (p.ksplit > 1) {
+    if (p.partial_floats > partial_ws_floats) {
+      set_error("spconv: split-K workspace too small");
+      return A3D_ERR_WORKSPACE;
+    }
+    a.partial = partial_ws;
+  }
+  dim3 grid(p.ntile, a.cout / p.bn, p.ksplit);
+  switch (p.bn) {
+    case 32: k_spconv<32><<<grid, 256, p.lds, st>>>(a); break;
+    case 64: k_spconv<64><<<grid, 256, p.lds, st>>>(a); break;
+    case 96: k_spconv<96><<<grid, 256, p.lds, st>>>(a); break;
+    case 128: k_spconv<128><<<grid, 256, p.lds, st>>>(a); break;
+    default: set_error("spconv: bad BN %d", p.bn); return A3D_ERR_UNSUPPORTED;
+  }
+  A3D_LAUNCH_CHECK();
+  if (p.ksplit > 1) {
+    const size_t total = (size_t)a.n_out * (a.cout / 4);
+    const size_t thr = total > (size_t)a.cout ? total : (size_t)a.cout;
+    k_splitk_epilogue<<<(unsigned)((thr + 255) / 256), 256, 0, st>>>(
+        partial_ws, p.ksplit, (size_t)p.ntile * 128 * a.cout, a.n_out, a.cout, a.out_map, a.scale, a.shift,
+        a.res, a.ldr, a.relu, a.out, a.ldo, a.zero_row);
+    A3D_LAUNCH_CHECK();
+  }
+  return A3D_OK;
+}
+
+// ------------------------------------------------------------------------------ program
+struct ProgLayout {
+  size_t buf_off[64];
+  size_t feats4_off, partial_off, partial_floats, total;
+};
+
+static int layout_program(const a3d_scene* s, const a3d_buf_desc* bufs, int n_bufs, const a3d_op* ops,
+                          int n_ops, ProgLayout& L) {
+  if (!s || n_bufs < 0 || n_bufs > 64 || (n_bufs && !bufs)) {
+    set_error("program: bad buffer list");
+    return A3D_ERR_INVALID;
+  }
+  size_t off = 0;
+  for (int i = 0; i < n_bufs; ++i) {
+    if (bufs[i].level < 0 || bufs[i].level >= A3D_NUM_LEVELS || bufs[i].channels <= 0 || bufs[i].channels % 4) {
+      set_error("program: bad buffer %d", i);
+      return A3D_ERR_INVALID;
+    }
+    L.buf_off[i] = off;
+    off += align256((size_t)(s->lv[bufs[i].level].n + 1) * bufs[i].channels * 4);
+  }
+  L.feats4_off = off;
+  off += align256((size_t)s->lv[0].npad * 16);
+  size_t pf = 0;
+  for (int i = 0; i < n_ops; ++i) {
+    const a3d_op& o = ops[i];
+    if (o.kind == A3D_OP_STEM) continue;
+    int lvl_out = o.level_in;
+    if (o.kind == A3D_OP_DOWN) lvl_out = o.level_in + 1;
+    if (o.kind == A3D_OP_UP) lvl_out = o.level_in - 1;
+    if (lvl_out < 0 || lvl_out >= A3D_NUM_LEVELS) {
+      set_error("program: op %d leaves the level range", i);
+      return A3D_ERR_INVALID;
+    }
+    ConvPlan p = plan_conv(s->lv[lvl_out].n, o.kernel_volume, o.cin, o.cout);
+    if (p.partial_floats > pf) pf = p.partial_floats;
+  }
+  L.partial_off = off;
+  L.partial_floats = pf;
+  off += align256(pf * 4);
+  L.total = off;
+  return A3D_OK;
+}
+
+}  // namespace a3d
+
+using namespace a3d;
+
+extern "C" int a3d_pack_conv_weight(const float* w_dev, int kernel_volume, int cin, int cout,
+                                    float* packed_dev, void* stream) {
+  if (!w_dev || !packed_dev || kernel_volume < 1 || cin % 16 || cout % 16) {
+    set_error("a3d_pack_conv_weight: bad arguments (K=%d cin=%d cout=%d)", kernel_volume, cin, cout);
+    return A3D_ERR_INVALID;
+  }
+  const size_t total = (size_t)kernel_volume * cin * cout;
+  k_pack_weight<<<(unsigned)((total + 255) / 256), 256, 0, (hipStream_t)stream>>>(w_dev, kernel_volume, cin, cout, packed_dev);
+  A3D_LAUNCH_CHECK();
+  return A3D_OK;
+}
+
+extern "C" size_t a3d_program_workspace_bytes(const a3d_scene* s, const a3d_buf_desc* bufs, int n_bufs,
+                                              const a3d_op* ops, int n_ops) {
+  ProgLayout L;
+  if (layout_program(s, bufs, n_bufs, ops, n_ops, L) != A3D_OK) return 0;
+  return L.total + 256;
+}
+
+extern "C" size_t a3d_program_buffer_offset(const a3d_scene* s, const a3d_buf_desc* bufs, int n_bufs, int i) {
+  ProgLayout L;
+  if (i < 0 || i >= n_bufs || layout_program(s, bufs, n_bufs, nullptr, 0, L) != A3D_OK) return (size_t)-1;
+  return L.buf_off[i];
+}
+
+extern "C" int a3d_program_run(const a3d_scene* s, const a3d_buf_desc* bufs, int n_bufs, const a3d_op* ops,
+                               int n_ops, const float* feats3_dev, float* ext_out_dev, int ext_out_ld,
+                               void* workspace_dev, size_t workspace_bytes, void* stream) {
+  ProgLayout L;
+  int rc = layout_program(s, bufs, n_bufs, ops, n_ops, L);
+  if (rc != A3D_OK) return rc;
+  if (!workspace_dev || workspace_bytes < L.total || ((uintptr_t)workspace_dev & 255)) {
+    set_error("a3d_program_run: workspace too small or misaligned (%zu < %zu)", workspace_bytes, L.total);
+    return A3D_ERR_WORKSPACE;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  char* ws = (char*)workspace_dev;
+  f32x4* feats4 = (f32x4*)(ws + L.feats4_off);
+  float* partial = (float*)(ws + L.partial_off);
+  bool feats_ready = false;
+  auto buf_ptr = [&](int id) -> float* { return (float*)(ws + L.buf_off[id]); };
+
+  for (int i = 0; i < n_ops; ++i) {
+    const a3d_op& o = ops[i];
+    const int Lin = o.level_in;
+    if (Lin < 0 || Lin >= A3D_NUM_LEVELS) {
+      set_error("op %d: bad level", i);
+      return A3D_ERR_INVALID;
+    }
+    // ---- output placement
+    float* out = nullptr;
+    int ldo = 0;
+    const int* out_map = nullptr;
+    int zero_row = -1;
+    int lvl_out = Lin;
+    if (o.kind == A3D_OP_DOWN) lvl_out = Lin + 1;
+    if (o.kind == A3D_OP_UP) lvl_out = Lin - 1;
+    if (o.out_buf == A3D_BUF_EXT_OUT) {
+      if (!ext_out_dev || lvl_out != 0 || o.kind == A3D_OP_UP) {
+        set_error("op %d: external output needs a level-0, non-transposed op", i);
+        return A3D_ERR_INVALID;
+      }
+      out = ext_out_dev + o.out_coff;
+      ldo = ext_out_ld;
+      out_map = s->orig_row;
+    } else {
+      if (o.out_buf < 0 || o.out_buf >= n_bufs || bufs[o.out_buf].level != lvl_out ||
+          o.out_coff + o.cout > bufs[o.out_buf].channels) {
+        set_error("op %d: bad output buffer", i);
+        return A3D_ERR_INVALID;
+      }
+      out = buf_ptr(o.out_buf) + o.out_coff;
+      ldo = bufs[o.out_buf].channels;
+      zero_row = s->lv[lvl_out].n;
+    }
+    const float* res = nullptr;
+    int ldr = 0;
+    if (o.res_buf != A3D_BUF_NONE) {
+      if (o.res_buf < 0 || o.res_buf >= n_bufs || bufs[o.res_buf].level != lvl_out ||
+          o.res_coff + o.cout > bufs[o.res_buf].channels || o.out_buf == A3D_BUF_EXT_OUT) {
+        set_error("op %d: bad residual buffer", i);
+        return A3D_ERR_INVALID;
+      }
+      res = buf_ptr(o.res_buf) + o.res_coff;
+      ldr = bufs[o.res_buf].channels;
+    }
+
+    if (o.kind == A3D_OP_STEM) {
+      if (Lin != 0 || o.cin != 3 || o.cout != 32 || !feats3_dev ||
+          !(o.kernel_volume == 125 || o.kernel_volume == 27)) {
+        set_error("op %d: stem expects level 0, 3->32 channels, 5^3 or 3^3 kernel", i);
+        return A3D_ERR_UNSUPPORTED;
+      }
+      const Level& lv = s->lv[0];
+      if (!feats_ready) {
+        k_gather_feats<<<(lv.n + 255) / 256, 256, 0, st>>>(feats3_dev, s->orig_row, lv.n, feats4);
+        feats_ready = true;
+      }
+      const int ks = o.kernel_volume == 125 ? 5 : 3;
+      const size_t lds = (size_t)o.kernel_volume * 96 * 4 + (size_t)64 * o.kernel_volume * 4;
+      k_stem<<<(lv.n + 63) / 64, 256, lds, st>>>(lv.xyzb, lv.n, lv.hkeys, lv.hvals, lv.hmask, feats4, o.w_dev, ks,
+                                                o.scale_dev, o.shift_dev, o.relu, out, ldo, zero_row);
+      A3D_LAUNCH_CHECK();
+      continue;
+    }
+
+    // ---- input placement
+    if (o.in_buf < 0 || o.in_buf >= n_bufs || bufs[o.in_buf].level != Lin ||
+        o.in_coff + o.cin > bufs[o.in_buf].channels) {
+      set_error("op %d: bad input buffer", i);
+      return A3D_ERR_INVALID;
+    }
+    ConvArgs a;
+    memset(&a, 0, sizeof(a));
+    a.in = buf_ptr(o.in_buf) + o.in_coff;
+    a.ldi = bufs[o.in_buf].channels;
+    a.n_in = s->lv[Lin].n;
+    a.w = o.w_dev;
+    a.K = o.kernel_volume;
+    a.cin = o.cin;
+    a.cout = o.cout;
+    a.out = out;
+    a.ldo = ldo;
+    a.out_map = out_map;
+    a.scale = o.scale_dev;
+    a.shift = o.shift_dev;
+    a.res = res;
+    a.ldr = ldr;
+    a.relu = o.relu;
+    a.zero_row = zero_row;
+    a.n_out = s->lv[lvl_out].n;
+    switch (o.kind) {
+      case A3D_OP_CONV3:
+        if (o.kernel_volume != 27) { set_error("op %d: CONV3 needs kernel volume 27", i); return A3D_ERR_INVALID; }
+        a.nbr = s->lv[Lin].nbr27;
+        a.nbr_stride = s->lv[Lin].npad;
+        a.gmask = s->lv[Lin].gmask27;
+        break;
+      case A3D_OP_DOWN:
+        if (o.kernel_volume != 8 || Lin >= A3D_NUM_LEVELS - 1) { set_error("op %d: bad DOWN", i); return A3D_ERR_INVALID; }
+        a.nbr = s->lv[Lin].child8;
+        a.nbr_stride = s->lv[Lin + 1].npad;
+        a.gmask = s->lv[Lin].gmask_down;
+        break;
+      case A3D_OP_UP:
+        if (o.kernel_volume != 8 || Lin < 1) { set_error("op %d: bad UP", i); return A3D_ERR_INVALID; }
+        a.nbr = s->lv[Lin - 1].up8;
+        a.nbr_stride = s->lv[Lin - 1].npad;
+        a.gmask = s->lv[Lin - 1].gmask_up;
+        a.out_map = s->lv[Lin - 1].up_rows;
+        break;
+      case A3D_OP_LINEAR:
+        if (o.kernel_volume != 1) { set_error("op %d: LINEAR needs kernel volume 1", i); return A3D_ERR_INVALID; }
+        break;
+      default:
+        set_error("op %d: unknown kind %d", i, o.kind);
+        return A3D_ERR_INVALID;
+    }
+    rc = launch_conv(a, partial, L.partial_floats, st);
+    if (rc != A3D_OK) return rc;
+  }
+  return A3D_OK;
+}
+
+extern "C" int a3d_linear(const float* in_dev, int ldi, int64_t n, int cin, int cout, const float* w_packed_dev,
+                          const float* scale_dev, const float* shift_dev, const float* res_dev, int ldr, int relu,
+                          float* out_dev, int ldo, void* workspace_dev, size_t workspace_bytes, void* stream) {
+  (void)workspace_dev;
+  (void)workspace_bytes;
+  if (!in_dev || !out_dev || !w_packed_dev || n <= 0 || n > (int64_t)1 << 30) {
+    set_error("a3d_linear: bad arguments");
+    return A3D_ERR_INVALID;
+  }
+  ConvArgs a;
+  memset(&a, 0, sizeof(a));
+  a.in = in_dev;
+  a.ldi = ldi;
+  a.n_in = (int)n;
+  a.w = w_packed_dev;
+  a.K = 1;
+  a.cin = cin;
+  a.cout = cout;
+  a.out = out_dev;
+  a.ldo = ldo;
+  a.n_out = (int)n;
+  a.scale = scale_dev;
+  a.shift = shift_dev;
+  a.res = res_dev;
+  a.ldr = ldr;
+  a.relu = relu;
+  a.zero_row = -1;
+  return launch_conv(a, nullptr, 0, (hipStream_t)stream);
+}

@@ -1,0 +1,503 @@
+"""Host side of the hot path: packs the model's weights for the HIP library, describes the
+Res16UNet34C topology as an op program, and implements ``forward_backbone`` /
+``forward_mask`` on top of the C ABI (include/agile3d_hip.h).
+
+Mirrors the reference's host code for this path:
+  * ``models/res16unet.py:222-295``  (layer sequence, skip concatenations)
+  * ``models/resnet.py:96-149`` / ``models/modules/resnet_block.py:48-64`` (BasicBlock)
+  * ``models/agile3d.py:141-181``   (forward_backbone, get_pos_encs)
+  * ``models/agile3d.py:183-339``   (forward_mask: per-sample loop, output dict)
+PyTorch is used for device memory, streams and parameter storage only.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+
+import numpy as np
+import torch
+
+from . import lib as L
+from .sparse import SparseTensor
+
+BN_EPS = 1e-5
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class Scene:
+    """Owner of one ``a3d_scene`` handle and its device workspace."""
+
+    def __init__(self, coords: torch.Tensor):
+        lib = L.load()
+        assert coords.is_cuda and coords.dtype == torch.int32 and coords.dim() == 2 and coords.shape[1] == 4
+        self.coords = coords.contiguous()
+        n = self.coords.shape[0]
+        nbytes = lib.a3d_scene_workspace_bytes(n)
+        if nbytes == 0:
+            raise L.A3DError(f"cannot build a scene of {n} voxels")
+        self.workspace = torch.empty(nbytes, dtype=torch.uint8, device=coords.device)
+        h = C.c_void_p()
+        L.check(lib.a3d_scene_create(_ptr(self.coords), n, _ptr(self.workspace), nbytes, _stream(), C.byref(h)),
+                "a3d_scene_create")
+        self.handle = h
+        self.n = [int(lib.a3d_scene_level_size(h, i)) for i in range(L.A3D_NUM_LEVELS)]
+
+    def table(self, level: int, which: int) -> np.ndarray:
+        """Copy one scene table to the host (tests / debugging)."""
+        lib = L.load()
+        p, cnt = C.c_void_p(), C.c_int64()
+        L.check(lib.a3d_scene_table(self.handle, level, which, C.byref(p), C.byref(cnt)), "a3d_scene_table")
+        dt = np.uint32 if which in (L.TAB_GMASK27, L.TAB_GMASKDOWN, L.TAB_GMASKUP) else np.int32
+        out = np.empty(cnt.value, dtype=dt)
+        L.check(lib.a3d_memcpy_d2h(out.ctypes.data_as(C.c_void_p), p, out.nbytes, _stream()), "a3d_memcpy_d2h")
+        return out
+
+    def __del__(self):
+        try:
+            if getattr(self, "handle", None):
+                L.load().a3d_scene_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+
+class _Pool:
+    """Activation buffers of the op program; buffers are recycled once their last reader ran."""
+
+    def __init__(self):
+        self.descs = []
+        self.free = {}
+
+    def get(self, level, ch):
+        lst = self.free.get((level, ch))
+        if lst:
+            return lst.pop()
+        self.descs.append((level, ch))
+        return len(self.descs) - 1
+
+    def put(self, i):
+        self.free.setdefault(self.descs[i], []).append(i)
+
+
+class BackboneProgram:
+    """Res16UNet34C + lin_squeeze_head as a list of ``a3d_op`` (built once per weight version)."""
+
+    def __init__(self, model, device):
+        lib = L.load()
+        self.keep = []          # tensors referenced by raw pointers
+        self.ops = []
+        self.pool = _Pool()
+        self.fm_bufs = []       # buffer ids of the 5 feature maps (res16unet.py:250-290)
+        bb = model.backbone
+        dev = device
+
+        def pack(conv):
+            w = conv.kernel3().detach().to(dev, torch.float32).contiguous()
+            K, cin, cout = w.shape
+            out = torch.empty_like(w)
+            L.check(lib.a3d_pack_conv_weight(_ptr(w), K, cin, cout, _ptr(out), _stream()), "a3d_pack_conv_weight")
+            self.keep.append(out)
+            return out
+
+        def fold(bn):
+            b = bn.bn
+            scale = (b.weight.detach() / torch.sqrt(b.running_var.detach() + b.eps)).to(dev, torch.float32)
+            shift = (b.bias.detach() - b.running_mean.detach() * scale.to(b.bias.device)).to(dev, torch.float32)
+            scale, shift = scale.contiguous(), shift.contiguous()
+            self.keep += [scale, shift]
+            return scale, shift
+
+        def op(kind, level_in, cin, cout, src, dst, res, relu, kvol, w, scale, shift):
+            o = L.Op()
+            o.kind, o.level_in, o.cin, o.cout = kind, level_in, cin, cout
+            o.in_buf, o.in_coff = src
+            o.out_buf, o.out_coff = dst
+            o.res_buf, o.res_coff = res if res is not None else (L.BUF_NONE, 0)
+            o.relu, o.kernel_volume = int(relu), kvol
+            o.w_dev = w.data_ptr()
+            o.scale_dev = scale.data_ptr() if scale is not None else None
+            o.shift_dev = shift.data_ptr() if shift is not None else None
+            self.ops.append(o)
+
+        def basic_block(blk, level, src, cin, cout, dst):
+            """BasicBlock.forward (resnet_block.py:48-64); src/dst = (buffer, column offset)."""
+            tmp = self.pool.get(level, cout)
+            s1, h1 = fold(blk.norm1)
+            op(L.OP_CONV3, level, cin, cout, src, (tmp, 0), None, True, 27, pack(blk.conv1), s1, h1)
+            res, proj = src, None
+            if blk.downsample is not None:
+                proj = self.pool.get(level, cout)
+                sp, hp = fold(blk.downsample[1])
+                op(L.OP_LINEAR, level, cin, cout, src, (proj, 0), None, False, 1, pack(blk.downsample[0]), sp, hp)
+                res = (proj, 0)
+            s2, h2 = fold(blk.norm2)
+            op(L.OP_CONV3, level, cout, cout, (tmp, 0), dst, res, True, 27, pack(blk.conv2), s2, h2)
+            self.pool.put(tmp)
+            if proj is not None:
+                self.pool.put(proj)
+
+        def layer(blocks, level, src, cin, cout, dst, free_src):
+            """_make_layer's Sequential of BasicBlocks; the last block writes to dst."""
+            cur, cur_c, owned = src, cin, free_src
+            n = len(blocks)
+            for i, blk in enumerate(blocks):
+                if i == n - 1:
+                    out = dst
+                else:
+                    out = (self.pool.get(level, cout), 0)
+                basic_block(blk, level, cur, cur_c, cout, out)
+                if owned:
+                    self.pool.put(cur[0])
+                cur, cur_c, owned = out, cout, (i != n - 1)
+
+        P = bb.PLANES
+        # concat buffers: [upsampled | skip] -- me.cat(out, skip) puts the skip LAST (res16unet.py:257)
+        cat8 = self.pool.get(0, P[7] + 32)
+        cat7 = self.pool.get(1, P[6] + P[0])
+        cat6 = self.pool.get(2, P[5] + P[1])
+        cat5 = self.pool.get(3, P[4] + P[2])
+        s, h = fold(bb.bn0)
+        w0 = bb.conv0p1s1.kernel3().detach().to(dev, torch.float32).contiguous()
+        self.keep.append(w0)
+        op(L.OP_STEM, 0, 3, 32, (L.BUF_NONE, 0), (cat8, P[7]), None, True, w0.shape[0], w0, s, h)
+
+        def down(conv, bn, level, src, c):
+            dst = self.pool.get(level + 1, c)
+            sc, sh = fold(bn)
+            op(L.OP_DOWN, level, c, c, src, (dst, 0), None, True, 8, pack(conv), sc, sh)
+            return dst
+
+        x = down(bb.conv1p1s2, bb.bn1, 0, (cat8, P[7]), 32)
+        layer(bb.block1, 1, (x, 0), 32, P[0], (cat7, P[6]), True)
+        x = down(bb.conv2p2s2, bb.bn2, 1, (cat7, P[6]), P[0])
+        layer(bb.block2, 2, (x, 0), P[0], P[1], (cat6, P[5]), True)
+        x = down(bb.conv3p4s2, bb.bn3, 2, (cat6, P[5]), P[1])
+        layer(bb.block3, 3, (x, 0), P[1], P[2], (cat5, P[4]), True)
+        x = down(bb.conv4p8s2, bb.bn4, 3, (cat5, P[4]), P[2])
+        f0 = self.pool.get(4, P[3])
+        layer(bb.block4, 4, (x, 0), P[2], P[3], (f0, 0), True)
+
+        def up(conv, bn, level_in, src, cin, dst, cout):
+            sc, sh = fold(bn)
+            op(L.OP_UP, level_in, cin, cout, src, dst, None, True, 8, pack(conv), sc, sh)
+
+        up(bb.convtr4p16s2, bb.bntr4, 4, (f0, 0), P[3], (cat5, 0), P[4])
+        f1 = self.pool.get(3, P[4])
+        layer(bb.block5, 3, (cat5, 0), P[4] + P[2], P[4], (f1, 0), False)
+        up(bb.convtr5p8s2, bb.bntr5, 3, (f1, 0), P[4], (cat6, 0), P[5])
+        f2 = self.pool.get(2, P[5])
+        layer(bb.block6, 2, (cat6, 0), P[5] + P[1], P[5], (f2, 0), False)
+        up(bb.convtr6p4s2, bb.bntr6, 2, (f2, 0), P[5], (cat7, 0), P[6])
+        f3 = self.pool.get(1, P[6])
+        layer(bb.block7, 1, (cat7, 0), P[6] + P[0], P[6], (f3, 0), False)
+        up(bb.convtr7p2s2, bb.bntr7, 1, (f3, 0), P[6], (cat8, 0), P[7])
+        f4 = self.pool.get(0, P[7])
+        layer(bb.block8, 0, (cat8, 0), P[7] + 32, P[7], (f4, 0), False)
+        self.fm_bufs = [f0, f1, f2, f3, f4]
+        # lin_squeeze_head: 1x1 conv + bias into the caller-ordered output (agile3d.py:179)
+        head = model.lin_squeeze_head
+        hb = head.bias.detach().reshape(-1).to(dev, torch.float32).contiguous()
+        self.keep.append(hb)
+        op(L.OP_LINEAR, 0, P[7], model.mask_dim, (f4, 0), (L.BUF_EXT_OUT, 0), None, False, 1, pack(head), None, hb)
+
+        self.n_ops = len(self.ops)
+        self.ops_arr = (L.Op * self.n_ops)(*self.ops)
+        self.n_bufs = len(self.pool.descs)
+        self.bufs_arr = (L.BufDesc * self.n_bufs)(*[L.BufDesc(lv, ch) for lv, ch in self.pool.descs])
+
+    def run(self, scene: Scene, feats: torch.Tensor, out: torch.Tensor):
+        lib = L.load()
+        nbytes = lib.a3d_program_workspace_bytes(scene.handle, self.bufs_arr, self.n_bufs, self.ops_arr, self.n_ops)
+        if nbytes == 0:
+            raise L.A3DError("a3d_program_workspace_bytes: " + lib.a3d_last_error().decode())
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=feats.device)
+        L.check(lib.a3d_program_run(scene.handle, self.bufs_arr, self.n_bufs, self.ops_arr, self.n_ops,
+                                    _ptr(feats), _ptr(out), out.shape[1], _ptr(ws), nbytes, _stream()),
+                "a3d_program_run")
+        return ws
+
+    def feature_map(self, scene: Scene, ws: torch.Tensor, i: int) -> torch.Tensor:
+        lib = L.load()
+        b = self.fm_bufs[i]
+        off = lib.a3d_program_buffer_offset(scene.handle, self.bufs_arr, self.n_bufs, b)
+        level, ch = self.pool.descs[b]
+        n = scene.n[level]
+        return ws[off:off + n * ch * 4].view(torch.float32).view(n, ch)
+
+
+def time_table(d_model=128, length=200):
+    """PositionalEncoding1D (position_embedding.py:210-225)."""
+    pe = torch.zeros(length, d_model)
+    position = torch.arange(0, length).unsqueeze(1)
+    div_term = torch.exp(torch.arange(0, d_model, 2, dtype=torch.float) * -(math.log(10000.0) / d_model))
+    pe[:, 0::2] = torch.sin(position.float() * div_term)
+    pe[:, 1::2] = torch.cos(position.float() * div_term)
+    return pe
+
+
+class DecoderPack:
+    """``a3d_decoder_weights`` for the model's current parameters."""
+
+    def __init__(self, model, device):
+        lib = L.load()
+        self.keep = []
+        dev = device
+        W = L.DecoderWeights()
+        n_layers = model.num_decoders
+        if n_layers > L.A3D_MAX_DEC_LAYERS:
+            raise L.A3DError("too many decoder layers")
+        W.n_layers = n_layers
+        W.n_bg_queries = model.num_bg_queries
+        W.dim_ff = model.args.dim_feedforward
+
+        def dv(t):
+            t = t.detach().to(dev, torch.float32).contiguous()
+            self.keep.append(t)
+            return t.data_ptr()
+
+        def tr(t):
+            return dv(t.detach().t())
+
+        def packed(wt_in_out):  # [in][out] -> MFMA fragment order
+            w = wt_in_out.detach().to(dev, torch.float32).contiguous().unsqueeze(0)
+            out = torch.empty_like(w)
+            L.check(lib.a3d_pack_conv_weight(_ptr(w), 1, w.shape[1], w.shape[2], _ptr(out), _stream()),
+                    "a3d_pack_conv_weight")
+            self.keep.append(out)
+            return out.data_ptr()
+
+        d = model.mask_dim
+        for l in range(n_layers):
+            li = 0 if model.shared_decoder else l
+            c2s = model.c2s_attention[li][0]
+            c2c = model.c2c_attention[li][0]
+            ffn = model.ffn_attention[li][0]
+            s2c = model.s2c_attention[li][0]
+            lw = W.layers[l]
+            a = c2s.multihead_attn
+            lw.c2s_in_w, lw.c2s_in_b = tr(a.in_proj_weight), dv(a.in_proj_bias)
+            lw.c2s_out_w, lw.c2s_out_b = tr(a.out_proj.weight), dv(a.out_proj.bias)
+            lw.c2s_norm_w, lw.c2s_norm_b = dv(c2s.norm.weight), dv(c2s.norm.bias)
+            lw.c2s_wk_packed = packed(a.in_proj_weight[d:2 * d].t())
+            lw.c2s_wv_packed = packed(a.in_proj_weight[2 * d:].t())
+            a = c2c.self_attn
+            lw.c2c_in_w, lw.c2c_in_b = tr(a.in_proj_weight), dv(a.in_proj_bias)
+            lw.c2c_out_w, lw.c2c_out_b = tr(a.out_proj.weight), dv(a.out_proj.bias)
+            lw.c2c_norm_w, lw.c2c_norm_b = dv(c2c.norm.weight), dv(c2c.norm.bias)
+            lw.ffn_w1, lw.ffn_b1 = tr(ffn.linear1.weight), dv(ffn.linear1.bias)
+            lw.ffn_w2, lw.ffn_b2 = tr(ffn.linear2.weight), dv(ffn.linear2.bias)
+            lw.ffn_norm_w, lw.ffn_norm_b = dv(ffn.norm.weight), dv(ffn.norm.bias)
+            a = s2c.multihead_attn
+            lw.s2c_in_w, lw.s2c_in_b = tr(a.in_proj_weight), dv(a.in_proj_bias)
+            lw.s2c_out_w, lw.s2c_out_b = tr(a.out_proj.weight), dv(a.out_proj.bias)
+            lw.s2c_norm_w, lw.s2c_norm_b = dv(s2c.norm.weight), dv(s2c.norm.bias)
+            lw.s2c_wq_packed = packed(a.in_proj_weight[:d].t())
+            lw.s2c_wo_packed = packed(a.out_proj.weight.t())
+        W.decoder_norm_w, W.decoder_norm_b = dv(model.decoder_norm.weight), dv(model.decoder_norm.bias)
+        m0, m2 = model.mask_embed_head[0], model.mask_embed_head[2]
+        W.mask_w0, W.mask_b0 = tr(m0.weight), dv(m0.bias)
+        W.mask_w2, W.mask_b2 = tr(m2.weight), dv(m2.bias)
+        W.bg_query_feat, W.bg_query_pos = dv(model.bg_query_feat.weight), dv(model.bg_query_pos.weight)
+        W.gauss_B = dv(model.pos_enc.gauss_B)
+        W.time_table = dv(time_table(d, 200))
+        self.W = W
+        self.n_layers = n_layers
+        self.gauss_B_ptr = W.gauss_B
+
+
+class _SceneState:
+    """Everything forward_mask needs from forward_backbone; rides on the returned pcd_features."""
+
+    def __init__(self):
+        self.scene = None
+        self.ws = None
+        self.ranges = None
+        self.posenc = None      # list[Tensor [n_b,128]]
+        self.minmax = None      # list[Tensor [6]]
+        self.cache = None       # list[uint8 Tensor]
+        self.engine_id = None
+
+
+class Engine:
+    def __init__(self, model, device):
+        L.load()
+        self.model = model
+        self.device = device
+        self._stale = True
+        self._version = None
+        self.program = None
+        self.decoder = None
+
+    def mark_stale(self):
+        self._stale = True
+
+    def _weights_version(self):
+        return sum(int(t._version) for t in self.model.state_dict(keep_vars=True).values())
+
+    def refresh_weights_if_stale(self, check_versions=False):
+        if not self._stale and check_versions:
+            if self._weights_version() != self._version:
+                self._stale = True
+        if self._stale:
+            with torch.no_grad():
+                self.program = BackboneProgram(self.model, self.device)
+                self.decoder = DecoderPack(self.model, self.device)
+            self._version = self._weights_version()
+            self._stale = False
+
+    # ---------------------------------------------------------------- forward_backbone
+    def forward_backbone(self, x, raw_coordinates=None):
+        lib = L.load()
+        self.refresh_weights_if_stale(check_versions=True)
+        if not isinstance(x, SparseTensor):
+            x = SparseTensor(features=x.F, coordinates=x.C, device=self.device)
+        if x.device != self.device:
+            x = SparseTensor(features=x.F, coordinates=x.C, device=self.device)
+        if raw_coordinates is None:
+            raise ValueError("forward_backbone needs raw_coordinates (agile3d.py:163)")
+        raw = raw_coordinates.to(self.device, torch.float32).contiguous()
+        n = len(x)
+        if raw.shape != (n, 3):
+            raise ValueError("raw_coordinates must be [N,3]")
+        with torch.no_grad():
+            st = _SceneState()
+            st.engine_id = id(self)
+            st.scene = Scene(x.C)
+            out = torch.empty((n, self.model.mask_dim), dtype=torch.float32, device=self.device)
+            st.ws = self.program.run(st.scene, x.F, out)
+            st.ranges = x.batch_ranges()
+            st.posenc, st.minmax, st.cache = [], [], []
+            tmp = torch.empty(256 * 6 * 4, dtype=torch.uint8, device=self.device)
+            W = self.decoder.W
+            for (s, e) in st.ranges:
+                nb = e - s
+                pe = torch.empty((nb, 128), dtype=torch.float32, device=self.device)
+                mm = torch.empty(6, dtype=torch.float32, device=self.device)
+                L.check(lib.a3d_posenc_fourier(_ptr(raw[s:e]), nb, self.decoder.gauss_B_ptr, _ptr(mm), _ptr(pe),
+                                               _ptr(tmp), tmp.numel(), _stream()), "a3d_posenc_fourier")
+                cb = lib.a3d_decoder_cache_bytes(nb, self.decoder.n_layers)
+                cache = torch.empty(cb, dtype=torch.uint8, device=self.device)
+                L.check(lib.a3d_decoder_build_cache(C.byref(W), _ptr(pe), nb, _ptr(cache), cb, None, 0, _stream()),
+                        "a3d_decoder_build_cache")
+                st.posenc.append(pe)
+                st.minmax.append(mm)
+                st.cache.append(cache)
+        pcd_features = SparseTensor(features=out, coordinates=x.C)
+        pcd_features._a3d = st
+        coordinates = SparseTensor(features=raw, coordinates=x.C)
+        aux = _AuxList(self.program, st)
+        pos_encodings_pcd = [[[None] * len(st.ranges)] for _ in range(4)] + [[list(st.posenc)]]
+        return pcd_features, aux, coordinates, pos_encodings_pcd
+
+    def decoder_inputs(self, feats128: torch.Tensor, raw_xyz: torch.Tensor):
+        """Single-sample decoder inputs from an explicit [N,128] feature matrix (what
+        forward_backbone would have produced) -- used by the golden-vector parity tests, which
+        hold the reference's decoder inputs directly."""
+        lib = L.load()
+        self.refresh_weights_if_stale(check_versions=True)
+        feats = feats128.to(self.device, torch.float32).contiguous()
+        raw = raw_xyz.to(self.device, torch.float32).contiguous()
+        n = feats.shape[0]
+        C4 = torch.zeros((n, 4), dtype=torch.int32, device=self.device)
+        st = _SceneState()
+        st.engine_id = id(self)
+        st.ranges = [(0, n)]
+        with torch.no_grad():
+            tmp = torch.empty(256 * 6 * 4, dtype=torch.uint8, device=self.device)
+            pe = torch.empty((n, 128), dtype=torch.float32, device=self.device)
+            mm = torch.empty(6, dtype=torch.float32, device=self.device)
+            L.check(lib.a3d_posenc_fourier(_ptr(raw), n, self.decoder.gauss_B_ptr, _ptr(mm), _ptr(pe), _ptr(tmp),
+                                           tmp.numel(), _stream()), "a3d_posenc_fourier")
+            cb = lib.a3d_decoder_cache_bytes(n, self.decoder.n_layers)
+            cache = torch.empty(cb, dtype=torch.uint8, device=self.device)
+            L.check(lib.a3d_decoder_build_cache(C.byref(self.decoder.W), _ptr(pe), n, _ptr(cache), cb, None, 0,
+                                                _stream()), "a3d_decoder_build_cache")
+        st.posenc, st.minmax, st.cache = [pe], [mm], [cache]
+        pcd = SparseTensor(features=feats, coordinates=C4)
+        pcd._a3d = st
+        coordinates = SparseTensor(features=raw, coordinates=C4)
+        return pcd, None, coordinates, [[[None]] for _ in range(4)] + [[[pe]]]
+
+    # ---------------------------------------------------------------- forward_mask
+    def forward_mask(self, pcd_features, aux, coordinates, pos_encodings_pcd, click_idx=None, click_time_idx=None):
+        lib = L.load()
+        st = getattr(pcd_features, "_a3d", None)
+        if st is None or st.engine_id != id(self):
+            raise RuntimeError("forward_mask needs the objects returned by this model's forward_backbone")
+        if click_idx is None or click_time_idx is None:
+            raise ValueError("click_idx and click_time_idx are required")
+        W = self.decoder.W
+        n_layers = self.decoder.n_layers
+        preds = [[] for _ in range(n_layers)]
+        with torch.no_grad():
+            for b, (s, e) in enumerate(st.ranges):
+                nb = e - s
+                ci, ct = click_idx[b], click_time_idx[b]
+                K = len(ci) - 1
+                rows, objs, times = [], [], []
+                for o in list(range(1, K + 1)) + [0]:
+                    r = list(ci[str(o)])
+                    t = list(ct[str(o)])
+                    if len(r) != len(t):
+                        raise ValueError("click_idx / click_time_idx length mismatch")
+                    if o > 0 and len(r) == 0:
+                        raise ValueError(f"object {o} has no click (the reference fails on an empty max, "
+                                         "agile3d.py:353)")
+                    rows += [int(v) for v in r]
+                    times += [int(v) for v in t]
+                    objs += [o] * len(r)
+                nc = len(rows)
+                nq = nc + W.n_bg_queries
+                wsb = lib.a3d_decoder_workspace_bytes(nb, nq)
+                if wsb == 0:
+                    raise L.A3DError(f"too many queries ({nq} > {L.A3D_MAX_QUERIES})")
+                ws = torch.empty(wsb, dtype=torch.uint8, device=self.device)
+                logits = torch.empty((n_layers, nb, K + 1), dtype=torch.float32, device=self.device)
+                arr = lambda v: (C.c_int32 * max(1, len(v)))(*v)
+                feats = pcd_features.F[s:e]
+                L.check(lib.a3d_decoder_forward(C.byref(W), _ptr(feats), _ptr(coordinates.F[s:e]),
+                                                _ptr(st.posenc[b]), _ptr(st.minmax[b]), _ptr(st.cache[b]), nb,
+                                                arr(rows), arr(objs), arr(times), nc, K, _ptr(logits),
+                                                _ptr(ws), wsb, _stream()), "a3d_decoder_forward")
+                for l in range(n_layers):
+                    preds[l].append(logits[l])
+        out = {"pred_masks": preds[-1], "backbone_features": pcd_features}
+        if self.model.aux:
+            out["aux_outputs"] = [{"pred_masks": p} for p in preds[:-1]]
+        return out
+
+
+class _AuxFeature:
+    """One of the 5 backbone feature maps (res16unet.py:250-290), rows in the library's internal
+    order with matching coordinates.  The reference's forward_mask never reads ``aux``."""
+
+    def __init__(self, program, st, i):
+        self._p, self._st, self._i = program, st, i
+
+    @property
+    def F(self):
+        return self._p.feature_map(self._st.scene, self._st.ws, self._i)
+
+    @property
+    def C(self):
+        level = 4 - self._i
+        t = torch.from_numpy(self._st.scene.table(level, L.TAB_XYZB).reshape(-1, 4).astype(np.int32))
+        scale = 1 << level
+        c = torch.stack([t[:, 3], t[:, 0] * scale, t[:, 1] * scale, t[:, 2] * scale], 1)
+        return c.to(self._st.ws.device)
+
+    @property
+    def device(self):
+        return self._st.ws.device
+
+
+class _AuxList(list):
+    def __init__(self, program, st):
+        super().__init__(_AuxFeature(program, st, i) for i in range(5))

@@ -1,0 +1,114 @@
+"""ctypes binding of libagile3d_hip.so (the C ABI declared in include/agile3d_hip.h).
+
+The product path has no fallback: if the shared object is missing or a symbol cannot be
+resolved, importing this module's ``load()`` raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libagile3d_hip.so")
+
+A3D_NUM_LEVELS = 5
+A3D_MAX_QUERIES = 64
+A3D_MAX_DEC_LAYERS = 8
+OP_STEM, OP_CONV3, OP_DOWN, OP_UP, OP_LINEAR = 0, 1, 2, 3, 4
+BUF_NONE, BUF_EXT_OUT = -1, -2
+(TAB_XYZB, TAB_NBR27, TAB_GMASK27, TAB_CHILD8, TAB_GMASKDOWN, TAB_UP8, TAB_GMASKUP, TAB_UPROWS,
+ TAB_ORIGROW) = range(9)
+
+c_float_p = C.c_void_p  # device pointers travel as integers
+
+
+class BufDesc(C.Structure):
+    _fields_ = [("level", C.c_int32), ("channels", C.c_int32)]
+
+
+class Op(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("level_in", C.c_int32), ("cin", C.c_int32), ("cout", C.c_int32),
+                ("in_buf", C.c_int32), ("in_coff", C.c_int32), ("out_buf", C.c_int32), ("out_coff", C.c_int32),
+                ("res_buf", C.c_int32), ("res_coff", C.c_int32), ("relu", C.c_int32),
+                ("kernel_volume", C.c_int32),
+                ("w_dev", C.c_void_p), ("scale_dev", C.c_void_p), ("shift_dev", C.c_void_p)]
+
+
+_LAYER_FIELDS = ["c2s_in_w", "c2s_in_b", "c2s_out_w", "c2s_out_b", "c2s_norm_w", "c2s_norm_b",
+                 "c2c_in_w", "c2c_in_b", "c2c_out_w", "c2c_out_b", "c2c_norm_w", "c2c_norm_b",
+                 "ffn_w1", "ffn_b1", "ffn_w2", "ffn_b2", "ffn_norm_w", "ffn_norm_b",
+                 "s2c_in_w", "s2c_in_b", "s2c_out_w", "s2c_out_b", "s2c_norm_w", "s2c_norm_b",
+                 "c2s_wk_packed", "c2s_wv_packed", "s2c_wq_packed", "s2c_wo_packed"]
+
+
+class DecoderLayer(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in _LAYER_FIELDS]
+
+
+class DecoderWeights(C.Structure):
+    _fields_ = [("n_layers", C.c_int32), ("n_bg_queries", C.c_int32), ("dim_ff", C.c_int32),
+                ("layers", DecoderLayer * A3D_MAX_DEC_LAYERS),
+                ("decoder_norm_w", C.c_void_p), ("decoder_norm_b", C.c_void_p),
+                ("mask_w0", C.c_void_p), ("mask_b0", C.c_void_p), ("mask_w2", C.c_void_p), ("mask_b2", C.c_void_p),
+                ("bg_query_feat", C.c_void_p), ("bg_query_pos", C.c_void_p),
+                ("gauss_B", C.c_void_p), ("time_table", C.c_void_p)]
+
+
+# name -> (restype, argtypes): every symbol include/agile3d_hip.h declares
+SYMBOLS = {
+    "a3d_version": (C.c_int, []),
+    "a3d_last_error": (C.c_char_p, []),
+    "a3d_memcpy_d2h": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "a3d_scene_workspace_bytes": (C.c_size_t, [C.c_int64]),
+    "a3d_scene_create": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_size_t, C.c_void_p,
+                                   C.POINTER(C.c_void_p)]),
+    "a3d_scene_destroy": (None, [C.c_void_p]),
+    "a3d_scene_level_size": (C.c_int64, [C.c_void_p, C.c_int]),
+    "a3d_scene_table": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]),
+    "a3d_pack_conv_weight": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "a3d_program_workspace_bytes": (C.c_size_t, [C.c_void_p, C.POINTER(BufDesc), C.c_int, C.POINTER(Op), C.c_int]),
+    "a3d_program_buffer_offset": (C.c_size_t, [C.c_void_p, C.POINTER(BufDesc), C.c_int, C.c_int]),
+    "a3d_program_run": (C.c_int, [C.c_void_p, C.POINTER(BufDesc), C.c_int, C.POINTER(Op), C.c_int, C.c_void_p,
+                                  C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "a3d_linear": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                             C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "a3d_posenc_fourier": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                     C.c_size_t, C.c_void_p]),
+    "a3d_decoder_cache_bytes": (C.c_size_t, [C.c_int64, C.c_int]),
+    "a3d_decoder_build_cache": (C.c_int, [C.POINTER(DecoderWeights), C.c_void_p, C.c_int64, C.c_void_p, C.c_size_t,
+                                          C.c_void_p, C.c_size_t, C.c_void_p]),
+    "a3d_decoder_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int]),
+    "a3d_decoder_forward": (C.c_int, [C.POINTER(DecoderWeights), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                      C.c_void_p, C.c_int64, C.POINTER(C.c_int32), C.POINTER(C.c_int32),
+                                      C.POINTER(C.c_int32), C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t,
+                                      C.c_void_p]),
+}
+
+_lib = None
+
+
+class A3DError(RuntimeError):
+    pass
+
+
+def load():
+    """dlopen the in-tree library and bind every symbol.  Raises if anything is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise A3DError(f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                       "(there is no CPU fallback)")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str = ""):
+    if rc != 0:
+        msg = load().a3d_last_error()
+        raise A3DError(f"{what} failed ({rc}): {msg.decode() if msg else ''}")

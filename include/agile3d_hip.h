@@ -1,0 +1,204 @@
+/*
+ * agile3d_hip.h -- C ABI of libagile3d_hip.so (MI355X / gfx950).
+ *
+ * The reference (ywyue/AGILE3D) is pure Python and has no FFI of its own: its hot path
+ * calls MinkowskiEngine (third-party C++/CUDA) and torch.nn.  This header is the boundary a
+ * maintainer would bind instead (ctypes stub in INTEGRATION.md).  Every entry point cites the
+ * reference interface it replaces (paths relative to the reference repository).
+ *
+ * Conventions
+ *   - every pointer named *_dev is a DEVICE pointer owned by the caller; the library never
+ *     allocates device memory: callers pass workspaces sized by the *_workspace_bytes queries.
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream).
+ *   - all feature matrices are row-major fp32; coordinates are int32 (batch, x, y, z).
+ *   - return value: 0 = ok, negative = error (a3d_last_error() gives the text; thread-local).
+ *   - no exceptions cross the ABI; a scene/program handle is not thread-safe, distinct
+ *     handles are independent.
+ */
+#ifndef AGILE3D_HIP_H
+#define AGILE3D_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define A3D_OK                 0
+#define A3D_ERR_INVALID       -1   /* bad argument */
+#define A3D_ERR_HIP           -2   /* HIP runtime error */
+#define A3D_ERR_COORD_RANGE   -3   /* |xyz| >= 2^17 or batch index > 1022 */
+#define A3D_ERR_DUPLICATE     -4   /* duplicate voxel coordinates */
+#define A3D_ERR_WORKSPACE     -5   /* workspace too small */
+#define A3D_ERR_UNSUPPORTED   -6   /* shape outside what the kernels are built for */
+
+#define A3D_NUM_LEVELS 5           /* tensor strides 1,2,4,8,16 (res16unet.py:222-295) */
+
+int         a3d_version(void);
+const char* a3d_last_error(void);
+/* plain hipMemcpy device->host (+ stream sync); lets non-torch hosts and tests read tables */
+int         a3d_memcpy_d2h(void* dst_host, const void* src_dev, size_t bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Scene = the coordinate manager.
+ * Replaces: ME.SparseTensor(coordinates=, features=, device=) (engine.py:47-51,
+ * eval_multi_obj.py:94-98) and the coordinate manager every ME layer consults implicitly
+ * (voxel hash, stride-2 coordinate sets, kernel maps for 3^3 / 5^3 / 2^3-stride-2 kernels).
+ * Rows of level 0 keep the caller's order at the API surface; internally every level is
+ * re-ordered (Morton super-tiles, rows clustered by neighbour pattern) -- see DESIGN.md.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct a3d_scene a3d_scene;
+
+size_t  a3d_scene_workspace_bytes(int64_t n_voxels);
+int     a3d_scene_create(const int32_t* coords4_dev, int64_t n_voxels,
+                         void* workspace_dev, size_t workspace_bytes,
+                         void* stream, a3d_scene** out);
+void    a3d_scene_destroy(a3d_scene* s);
+int64_t a3d_scene_level_size(const a3d_scene* s, int level);
+
+/* read-only views of the scene tables (device pointers valid while the workspace lives) */
+enum {
+  A3D_TAB_XYZB      = 0,  /* int32 [n][4]  (x,y,z,batch) in level units, internal row order       */
+  A3D_TAB_NBR27     = 1,  /* int32 [27][npad]  3^3 neighbour rows, missing -> n (the zero row)    */
+  A3D_TAB_GMASK27   = 2,  /* uint32 [npad/16]  offsets present in each 16-row group               */
+  A3D_TAB_CHILD8    = 3,  /* int32 [8][npad(level+1)] rows of `level` under each coarse row       */
+  A3D_TAB_GMASKDOWN = 4,  /* uint32 [npad(level+1)/16]                                            */
+  A3D_TAB_UP8       = 5,  /* int32 [8][npad] parent row (level+1) of virtual row v at its slot    */
+  A3D_TAB_GMASKUP   = 6,  /* uint32 [npad/16]                                                     */
+  A3D_TAB_UPROWS    = 7,  /* int32 [npad] virtual row -> row of `level`                           */
+  A3D_TAB_ORIGROW   = 8   /* int32 [n0]   internal level-0 row -> caller's row                    */
+};
+int a3d_scene_table(const a3d_scene* s, int level, int which, const void** ptr_dev, int64_t* count);
+
+/* ------------------------------------------------------------------------------------------
+ * Backbone program.
+ * Replaces: Res16UNetBase.forward (models/res16unet.py:222-295), BasicBlock.forward
+ * (models/modules/resnet_block.py:48-64), ME.MinkowskiConvolution / ConvolutionTranspose /
+ * BatchNorm / ReLU / cat, and lin_squeeze_head (models/agile3d.py:43-45,179).
+ * The host describes the network as a list of ops over numbered activation buffers (the
+ * topology stays where the reference keeps it: in the host language); the library runs it.
+ * ------------------------------------------------------------------------------------------ */
+enum {
+  A3D_OP_STEM   = 0,  /* 5^3 (or 3^3) conv, Cin=3, input = caller features          (res16unet.py:225) */
+  A3D_OP_CONV3  = 1,  /* 3^3 stride-1 conv on `level_in`                           (resnet_block.py:24-43) */
+  A3D_OP_DOWN   = 2,  /* 2^3 stride-2 conv level_in -> level_in+1                  (res16unet.py:229,...) */
+  A3D_OP_UP     = 3,  /* 2^3 stride-2 transposed conv level_in -> level_in-1       (res16unet.py:253,...) */
+  A3D_OP_LINEAR = 4   /* 1x1 conv                                                  (resnet.py:108-123)   */
+};
+#define A3D_BUF_NONE       -1
+#define A3D_BUF_EXT_OUT    -2   /* out: caller's [n0][cout] matrix, rows in the CALLER's order */
+
+typedef struct {
+  int32_t level;       /* rows = a3d_scene_level_size(level) + 1 (last row = zeros) */
+  int32_t channels;    /* row stride in floats */
+} a3d_buf_desc;
+
+typedef struct {
+  int32_t kind;
+  int32_t level_in;
+  int32_t cin, cout;
+  int32_t in_buf,  in_coff;    /* input  = columns [in_coff, in_coff+cin)   of buffer in_buf  */
+  int32_t out_buf, out_coff;   /* output = columns [out_coff, out_coff+cout) of buffer out_buf */
+  int32_t res_buf, res_coff;   /* residual added before the ReLU, or A3D_BUF_NONE             */
+  int32_t relu;
+  int32_t kernel_volume;       /* 125 / 27 / 8 / 1 */
+  const float* w_dev;          /* weights packed by a3d_pack_conv_weight (STEM: raw [K][3][32]) */
+  const float* scale_dev;      /* [cout] folded BatchNorm scale, or NULL (=1)                   */
+  const float* shift_dev;      /* [cout] folded BatchNorm shift / bias, or NULL (=0)            */
+} a3d_op;
+
+/* W[K][cin][cout] (ME layout, models/modules/common.py:137-155) -> MFMA B-fragment order */
+int a3d_pack_conv_weight(const float* w_dev, int kernel_volume, int cin, int cout,
+                         float* packed_dev, void* stream);
+
+size_t a3d_program_workspace_bytes(const a3d_scene* s, const a3d_buf_desc* bufs, int n_bufs,
+                                   const a3d_op* ops, int n_ops);
+/* byte offset of activation buffer i inside the program workspace (for aux feature maps) */
+size_t a3d_program_buffer_offset(const a3d_scene* s, const a3d_buf_desc* bufs, int n_bufs, int i);
+int    a3d_program_run(const a3d_scene* s, const a3d_buf_desc* bufs, int n_bufs,
+                       const a3d_op* ops, int n_ops,
+                       const float* feats3_dev,     /* [n0][3] caller order (STEM input)   */
+                       float* ext_out_dev, int ext_out_ld,
+                       void* workspace_dev, size_t workspace_bytes, void* stream);
+
+/* Dense row-major GEMM on the same MFMA kernel: out[n][cout] = act(in[n][cin] @ W + shift + res).
+ * Replaces the nn.Linear / in_proj pieces of nn.MultiheadAttention that run over all N points
+ * (models/modules/attention_block.py:91-94). */
+int a3d_linear(const float* in_dev, int ldi, int64_t n, int cin, int cout,
+               const float* w_packed_dev, const float* scale_dev, const float* shift_dev,
+               const float* res_dev, int ldr, int relu, float* out_dev, int ldo,
+               void* workspace_dev, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Position encoding.
+ * Replaces: Agile3d.get_pos_encs (models/agile3d.py:141-161) ->
+ * PositionEmbeddingCoordsSine.get_fourier_embeddings (models/position_embedding.py:123-152).
+ * minmax_dev receives [min_x,min_y,min_z,max_x,max_y,max_z] of the sample.
+ * ------------------------------------------------------------------------------------------ */
+int a3d_posenc_fourier(const float* xyz_dev, int64_t n, const float* gauss_B_dev /*[3][64]*/,
+                       float* minmax_dev /*[6]*/, float* out_dev /*[n][128]*/,
+                       void* workspace_dev, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Click-query decoder.
+ * Replaces: Agile3d.forward_mask + mask_module (models/agile3d.py:183-384) and the post-norm
+ * CrossAttentionLayer / SelfAttentionLayer / FFNLayer (models/modules/attention_block.py).
+ * One call = one batch sample, all `n_layers` decoder iterations.
+ * ------------------------------------------------------------------------------------------ */
+#define A3D_MAX_QUERIES 64
+#define A3D_MAX_DEC_LAYERS 8
+
+typedef struct {
+  /* nn.MultiheadAttention / LayerNorm / Linear parameters.  Every matrix used on the query side
+   * ([Q<=64,128] operands) is passed TRANSPOSED, i.e. row-major [in][out]:
+   *   *_in_w  = in_proj_weight^T  [128][384]  (columns 0..127 q, 128..255 k, 256..383 v)
+   *   *_out_w = out_proj.weight^T [128][128]
+   *   ffn_w1  = linear1.weight^T  [128][dim_ff],  ffn_w2 = linear2.weight^T [dim_ff][128]
+   * biases / LayerNorm vectors are unchanged. */
+  const float *c2s_in_w, *c2s_in_b, *c2s_out_w, *c2s_out_b, *c2s_norm_w, *c2s_norm_b;
+  const float *c2c_in_w, *c2c_in_b, *c2c_out_w, *c2c_out_b, *c2c_norm_w, *c2c_norm_b;
+  const float *ffn_w1, *ffn_b1, *ffn_w2, *ffn_b2, *ffn_norm_w, *ffn_norm_b;
+  const float *s2c_in_w, *s2c_in_b, *s2c_out_w, *s2c_out_b, *s2c_norm_w, *s2c_norm_b;
+  /* the [128][128] blocks that multiply all N points (c2s Wk, Wv; s2c Wq, Wo), as W^T packed by
+   * a3d_pack_conv_weight(kernel_volume=1) */
+  const float *c2s_wk_packed, *c2s_wv_packed, *s2c_wq_packed, *s2c_wo_packed;
+} a3d_decoder_layer;
+
+typedef struct {
+  int32_t n_layers;
+  int32_t n_bg_queries;                 /* learned background queries (agile3d.py:47-48) */
+  int32_t dim_ff;
+  a3d_decoder_layer layers[A3D_MAX_DEC_LAYERS];
+  const float *decoder_norm_w, *decoder_norm_b;
+  const float *mask_w0, *mask_b0, *mask_w2, *mask_b2;     /* mask_embed_head.{0,2}, weights transposed */
+  const float *bg_query_feat, *bg_query_pos;              /* [n_bg][128] */
+  const float *gauss_B;                                   /* [3][64] */
+  const float *time_table;                                /* [200][128] PositionalEncoding1D */
+} a3d_decoder_weights;
+
+/* per-scene, click-independent cache: pos @ Wk^T + bk (c2s) and pos @ Wq^T + bq (s2c) for every
+ * layer; computed once after forward_backbone and reused by every forward_mask of the scene. */
+size_t a3d_decoder_cache_bytes(int64_t n, int n_layers);
+int    a3d_decoder_build_cache(const a3d_decoder_weights* w, const float* posenc_dev, int64_t n,
+                               void* cache_dev, size_t cache_bytes,
+                               void* workspace_dev, size_t workspace_bytes, void* stream);
+
+size_t a3d_decoder_workspace_bytes(int64_t n, int n_queries);
+/* click arrays are HOST arrays, object-major as the reference builds its queries
+ * (agile3d.py:249-264): all clicks of object 1, ..., object K, then background clicks.
+ * click_obj[i] in 0..K (0 = background), click_row = row of the sample, click_time < 200.
+ * logits_dev: n_layers matrices [n][1+K]; the LAST is 'pred_masks', the others 'aux_outputs'. */
+int    a3d_decoder_forward(const a3d_decoder_weights* w,
+                           const float* feats128_dev, const float* xyz_dev,
+                           const float* posenc_dev, const float* minmax_dev,
+                           const void* cache_dev, int64_t n,
+                           const int32_t* click_row, const int32_t* click_obj,
+                           const int32_t* click_time, int n_clicks, int n_objects,
+                           float* logits_dev,
+                           void* workspace_dev, size_t workspace_bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AGILE3D_HIP_H */

@@ -1,0 +1,143 @@
+"""-m gpu: every op kind of the backbone program, one at a time, through the C ABI against the
+oracle's gather-GEMM-scatter (same seeded inputs, rows matched by coordinates)."""
+import numpy as np
+import pytest
+import torch
+
+from agile3d_amd import lib as L
+from agile3d_amd.engine import Scene
+from agile3d_amd.synthetic import make_scene
+from gpu_util import OneOp, internal_to_oracle_rows, pack_weight
+from oracle import backbone as ob
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def world():
+    coords = make_scene(6000, seed=5)["coords"]
+    sc = Scene(torch.from_numpy(coords).cuda())
+    lv = ob.SparseLevels(coords)
+    maps = [torch.from_numpy(internal_to_oracle_rows(sc, lv, i)) for i in range(5)]
+    return coords, sc, lv, maps
+
+
+def _check(got, ref, what, tol=2e-4):
+    err = (got - ref).abs().max().item()
+    scale = max(1.0, ref.abs().max().item())
+    print(f"{what}: max|diff|={err:.3e} (ref scale {scale:.2f})")
+    assert err <= tol * scale, (what, err)
+
+
+CONV3 = [(0, 32, 32), (0, 128, 96), (1, 96, 96), (1, 32, 64), (2, 192, 128), (3, 384, 256), (4, 256, 256), (2, 64, 64)]
+
+
+@pytest.mark.parametrize("level,cin,cout", CONV3)
+@pytest.mark.parametrize("epi", ["plain", "bn_res_relu"])
+def test_conv3(world, level, cin, cout, epi):
+    coords, sc, lv, maps = world
+    g = torch.Generator().manual_seed(level * 1000 + cin + cout)
+    n = sc.n[level]
+    X = torch.randn(n, cin, generator=g)
+    W = torch.randn(27, cin, cout, generator=g) / (cin * 14) ** 0.5
+    full = epi == "bn_res_relu"
+    scale = (torch.rand(cout, generator=g) + 0.5).cuda() if full else None
+    shift = torch.randn(cout, generator=g).cuda() if full else None
+    R = torch.randn(n, cout, generator=g) if full else None
+    op = OneOp(sc, L.OP_CONV3, level, cin, cout, 27, pack_weight(W.cuda()), scale, shift, relu=full, use_res=full,
+               in_pad=32 if full else 0, out_pad=32 if full else 0)
+    m = maps[level]
+    op.buffer(0)[:n, op.in_pad:] = X[m].cuda()
+    if full:
+        op.buffer(2)[:n] = R[m].cuda()
+    op.buffer(1).fill_(float("nan"))
+    op.run()
+    ref = ob.sparse_conv(X, W, lv.kernel_map(level, 3), n)
+    if full:
+        ref = torch.relu(ref * scale.cpu() + shift.cpu() + R)
+    out = op.buffer(1).cpu()
+    _check(out[:n, op.out_pad:], ref[m], f"conv3 L{level} {cin}->{cout} {epi}")
+    assert (out[n, op.out_pad:] == 0).all(), "zero row not written"
+    if full:
+        assert torch.isnan(out[:n, :op.out_pad]).all(), "wrote outside its column slice"
+
+
+@pytest.mark.parametrize("level,c", [(0, 32), (1, 32), (2, 64), (3, 128)])
+def test_down(world, level, c):
+    coords, sc, lv, maps = world
+    g = torch.Generator().manual_seed(7 + level)
+    n, nC = sc.n[level], sc.n[level + 1]
+    X = torch.randn(n, c, generator=g)
+    W = torch.randn(8, c, c, generator=g) / (c * 4) ** 0.5
+    scale = (torch.rand(c, generator=g) + 0.5).cuda()
+    shift = torch.randn(c, generator=g).cuda()
+    op = OneOp(sc, L.OP_DOWN, level, c, c, 8, pack_weight(W.cuda()), scale, shift, relu=True)
+    op.buffer(0)[:n] = X[maps[level]].cuda()
+    op.run()
+    ref = torch.relu(ob.sparse_conv(X, W, lv.stride_map(level), nC) * scale.cpu() + shift.cpu())
+    _check(op.buffer(1).cpu()[:nC], ref[maps[level + 1]], f"down L{level}->{level + 1} {c}")
+
+
+@pytest.mark.parametrize("level_in,cin,cout", [(4, 256, 256), (3, 256, 128), (2, 128, 96), (1, 96, 96)])
+def test_up(world, level_in, cin, cout):
+    coords, sc, lv, maps = world
+    g = torch.Generator().manual_seed(11 + level_in)
+    nC, nF = sc.n[level_in], sc.n[level_in - 1]
+    X = torch.randn(nC, cin, generator=g)
+    W = torch.randn(8, cin, cout, generator=g) / cin ** 0.5
+    shift = torch.randn(cout, generator=g).cuda()
+    op = OneOp(sc, L.OP_UP, level_in, cin, cout, 8, pack_weight(W.cuda()), None, shift, relu=True, out_pad=32)
+    op.buffer(0)[:nC] = X[maps[level_in]].cuda()
+    op.run()
+    kmap = [(rc, rf) for (rf, rc) in lv.stride_map(level_in - 1)]
+    ref = torch.relu(ob.sparse_conv(X, W, kmap, nF) + shift.cpu())
+    _check(op.buffer(1).cpu()[:nF, 32:], ref[maps[level_in - 1]], f"up L{level_in}->{level_in - 1} {cin}->{cout}")
+
+
+@pytest.mark.parametrize("level,cin,cout", [(0, 128, 96), (2, 32, 64), (3, 384, 256), (4, 128, 256)])
+def test_linear(world, level, cin, cout):
+    coords, sc, lv, maps = world
+    g = torch.Generator().manual_seed(13 + level)
+    n = sc.n[level]
+    X = torch.randn(n, cin, generator=g)
+    W = torch.randn(1, cin, cout, generator=g) / cin ** 0.5
+    scale = (torch.rand(cout, generator=g) + 0.5).cuda()
+    shift = torch.randn(cout, generator=g).cuda()
+    op = OneOp(sc, L.OP_LINEAR, level, cin, cout, 1, pack_weight(W.cuda()), scale, shift)
+    op.buffer(0)[:n] = X[maps[level]].cuda()
+    op.run()
+    ref = (X @ W[0]) * scale.cpu() + shift.cpu()
+    _check(op.buffer(1).cpu()[:n], ref[maps[level]], f"linear L{level} {cin}->{cout}")
+
+
+@pytest.mark.parametrize("ks", [5, 3])
+def test_stem(world, ks):
+    coords, sc, lv, maps = world
+    g = torch.Generator().manual_seed(17 + ks)
+    n = sc.n[0]
+    F3 = torch.rand(n, 3, generator=g)
+    W = torch.randn(ks ** 3, 3, 32, generator=g) / 6.0
+    scale = (torch.rand(32, generator=g) + 0.5).cuda()
+    shift = torch.randn(32, generator=g).cuda()
+    op = OneOp(sc, L.OP_STEM, 0, 3, 32, ks ** 3, W.cuda().contiguous(), scale, shift, relu=True, out_pad=96)
+    op.run(F3.cuda())
+    ref = torch.relu(ob.sparse_conv(F3, W, lv.kernel_map(0, ks), n) * scale.cpu() + shift.cpu())
+    _check(op.buffer(1).cpu()[:n, 96:], ref[maps[0]], f"stem k{ks}")
+
+
+def test_standalone_linear_matches_matmul():
+    from agile3d_amd.engine import _ptr, _stream
+    lib = L.load()
+    g = torch.Generator().manual_seed(3)
+    for n in (1, 100, 128, 5000):
+        X = torch.randn(n, 128, generator=g).cuda()
+        W = torch.randn(128, 128, generator=g).cuda() / 11.3
+        b = torch.randn(128, generator=g).cuda()
+        R = torch.randn(n, 128, generator=g).cuda()
+        out = torch.empty(n, 128, device="cuda")
+        L.check(lib.a3d_linear(_ptr(X), 128, n, 128, 128, _ptr(pack_weight(W.unsqueeze(0))), None, _ptr(b), _ptr(R),
+                               128, 0, _ptr(out), 128, None, 0, _stream()), "a3d_linear")
+        ref = X.double() @ W.double() + b.double() + R.double()
+        err = (out.double() - ref).abs().max().item()
+        print(f"a3d_linear n={n}: max|diff| vs fp64 = {err:.3e}")
+        assert err < 1e-4
