@@ -11,8 +11,8 @@ from agile3d_amd.engine import Scene, _ptr, _stream
 
 def key4(c):
     c = np.asarray(c).astype(np.int64)
-    off = 1 << 20
-    return (c[:, 0] << 60) | ((c[:, 1] + off) << 40) | ((c[:, 2] + off) << 20) | (c[:, 3] + off)
+    off = 1 << 18   # |xyz| < 2^17 -> every field fits its 20 bits
+    return (c[:, 0] << 60) + ((c[:, 1] + off) << 40) + ((c[:, 2] + off) << 20) + (c[:, 3] + off)
 
 
 def internal_to_oracle_rows(scene: Scene, lv, level):
@@ -46,7 +46,7 @@ class OneOp:
         lvl_out = level_in + (1 if kind == L.OP_DOWN else -1 if kind == L.OP_UP else 0)
         self.lvl_in, self.lvl_out = level_in, lvl_out
         self.cin, self.cout, self.in_pad, self.out_pad = cin, cout, in_pad, out_pad
-        descs = [(level_in, cin + in_pad), (lvl_out, cout + out_pad)]
+        descs = [(level_in, 4 if kind == L.OP_STEM else cin + in_pad), (lvl_out, cout + out_pad)]
         if use_res:
             descs.append((lvl_out, cout))
         self.descs = descs
