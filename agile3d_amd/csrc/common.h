@@ -23,6 +23,22 @@ const char* get_error();
 
 #define A3D_LAUNCH_CHECK() A3D_HIP_CHECK(hipGetLastError())
 
+// ---- optional event timing ----------------------------------------------------------------
+bool prof_enabled();
+int prof_begin(hipStream_t st, int id, int bn = 0, int K = 0, int cin = 0, int cout = 0, int n_out = 0,
+               int table = 0, int level = 0, int ksplit = 0);
+void prof_end(hipStream_t st, int idx);
+struct ProfScope {
+  hipStream_t st;
+  int idx;
+  ProfScope(hipStream_t s, int id, int bn = 0, int K = 0, int cin = 0, int cout = 0, int n_out = 0, int table = 0,
+            int level = 0, int ksplit = 0)
+      : st(s), idx(prof_enabled() ? prof_begin(s, id, bn, K, cin, cout, n_out, table, level, ksplit) : -1) {}
+  ~ProfScope() {
+    if (idx >= 0) prof_end(st, idx);
+  }
+};
+
 static inline int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
 static inline size_t align256(size_t x) { return (x + 255) & ~size_t(255); }
 

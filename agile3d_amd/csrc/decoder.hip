@@ -574,6 +574,7 @@ extern "C" int a3d_posenc_fourier(const float* xyz_dev, int64_t n, const float* 
   }
   hipStream_t st = (hipStream_t)stream;
   float* part = (float*)workspace_dev;
+  ProfScope ps(st, A3D_PROF_POSENC, 0, 0, 3, 128, (int)n);
   k_minmax_partial<<<nb, 256, 0, st>>>(xyz_dev, (int)n, part);
   k_minmax_final<<<1, 64, 0, st>>>(part, nb, minmax_dev);
   const size_t total = (size_t)n * 64;
@@ -685,8 +686,11 @@ static int run_decoder(const a3d_decoder_weights* w, const float* feats128, cons
   B.hidden = (float*)(ws + L.q[11]);
   A3D_HIP_CHECK(hipMemcpyAsync(meta, &hm, sizeof(QueryMeta), hipMemcpyHostToDevice, st));
   const int n_counts = A3D_MAX_DEC_LAYERS * (A3D_MAX_QUERIES + 1);
+  {
+  ProfScope ps(st, A3D_PROF_QUERY, 0, 0, 0, 0, nq);
   k_query_init<QP><<<1, 512, 0, st>>>(meta, feats128, posenc, w->bg_query_feat, w->bg_query_pos, w->time_table,
                                        w->layers[0].c2s_in_w, w->layers[0].c2s_in_b, B, counts, n_counts);
+  }
   A3D_LAUNCH_CHECK();
   const size_t one = align256((size_t)n * D * 4);
   const float* src = feats128;
@@ -703,8 +707,11 @@ static int run_decoder(const a3d_decoder_weights* w, const float* feats128, cons
     rc = a3d_linear(src, D, n, D, D, LW.c2s_wv_packed, nullptr, LW.c2s_in_b + 2 * D, nullptr, 0, 0, bufB, D, nullptr, 0, st);
     if (rc) return rc;
     const int* prev_counts = l > 0 ? counts + (size_t)(l - 1) * (A3D_MAX_QUERIES + 1) : nullptr;
+    {
+    ProfScope ps(st, A3D_PROF_C2S, 0, 0, 0, 0, n);
     k_c2s_attn<QT><<<L.nchunk, 512, 0, st>>>(bufA, bufB, n, B.qproj, meta->obj, l > 0 ? labels : nullptr,
                                             prev_counts, part);
+    }
     A3D_LAUNCH_CHECK();
     QueryLayerW QW;
     QW.c2s_in_wt = LW.c2s_in_w; QW.c2s_in_b = LW.c2s_in_b; QW.c2s_out_wt = LW.c2s_out_w; QW.c2s_out_b = LW.c2s_out_b;
@@ -719,19 +726,28 @@ static int run_decoder(const a3d_decoder_weights* w, const float* feats128, cons
     QW.next_c2s_in_wt = l + 1 < w->n_layers ? w->layers[l + 1].c2s_in_w : nullptr;
     QW.next_c2s_in_b = l + 1 < w->n_layers ? w->layers[l + 1].c2s_in_b : nullptr;
     QW.dim_ff = w->dim_ff;
+    {
+    ProfScope ps(st, A3D_PROF_QUERY, 0, 0, 0, 0, nq);
     k_query_layer<QP><<<1, 512, 0, st>>>(meta, QW, B, part, L.nchunk);
+    }
     A3D_LAUNCH_CHECK();
     // ---- scene-to-click: Q = src Wq^T + (pos Wq^T + bq); attention; Y = O Wo^T + bo + src; LN
     rc = a3d_linear(src, D, n, D, D, LW.s2c_wq_packed, nullptr, nullptr, posq, D, 0, bufA, D, nullptr, 0, st);
     if (rc) return rc;
+    {
+    ProfScope ps(st, A3D_PROF_S2C, 0, 0, 0, 0, n);
     k_s2c_attn<QT><<<(n + 127) / 128, 512, s2c_lds, st>>>(bufA, n, B.ks, B.vs, nq, bufB);
+    }
     A3D_LAUNCH_CHECK();
     float* Y = (l & 1) ? bufD : bufC;
     rc = a3d_linear(bufB, D, n, D, D, LW.s2c_wo_packed, nullptr, LW.s2c_out_b, src, D, 0, Y, D, nullptr, 0, st);
     if (rc) return rc;
+    {
+    ProfScope ps(st, A3D_PROF_LNMASK, 0, 0, 0, 0, n);
     k_ln_mask<QT><<<(n + 63) / 64, 256, lnm_lds, st>>>(Y, n, LW.s2c_norm_w, LW.s2c_norm_b, B.E, nq, meta->qrange,
                                                       hm.n_fg, K, logits + (size_t)l * n * (K + 1), labels,
                                                       counts + (size_t)l * (A3D_MAX_QUERIES + 1));
+    }
     A3D_LAUNCH_CHECK();
     src = Y;
   }

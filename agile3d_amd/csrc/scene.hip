@@ -30,6 +30,39 @@ void set_error(const char* fmt, ...) {
 }
 const char* get_error() { return g_err; }
 
+// ------------------------------------------------------------------------------ profiler
+}  // namespace a3d
+#include <vector>
+namespace a3d {
+struct ProfRec {
+  a3d_prof_entry e;
+  hipEvent_t e0, e1;
+};
+static bool g_prof_on = false;
+static std::vector<ProfRec> g_prof;
+static std::vector<hipEvent_t> g_event_pool;
+static hipEvent_t get_event() {
+  if (!g_event_pool.empty()) {
+    hipEvent_t e = g_event_pool.back();
+    g_event_pool.pop_back();
+    return e;
+  }
+  hipEvent_t e;
+  (void)hipEventCreate(&e);
+  return e;
+}
+bool prof_enabled() { return g_prof_on; }
+int prof_begin(hipStream_t st, int id, int bn, int K, int cin, int cout, int n_out, int table, int level, int ksplit) {
+  ProfRec r;
+  r.e = a3d_prof_entry{id, bn, K, cin, cout, n_out, table, level, ksplit, 0.f};
+  r.e0 = get_event();
+  r.e1 = get_event();
+  (void)hipEventRecord(r.e0, st);
+  g_prof.push_back(r);
+  return (int)g_prof.size() - 1;
+}
+void prof_end(hipStream_t st, int idx) { (void)hipEventRecord(g_prof[idx].e1, st); }
+
 // ------------------------------------------------------------------------------ block scan
 __device__ inline int wave_incl_scan(int v) {
   const int lane = threadIdx.x & 63;
@@ -385,6 +418,25 @@ static void carve_phase2(Bump& b, const int* sizes, a3d_scene* sc, Phase2Tmp& t)
 using namespace a3d;
 
 extern "C" int a3d_version(void) { return 1; }
+
+extern "C" int a3d_profile_enable(int on) {
+  g_prof_on = on != 0;
+  return A3D_OK;
+}
+extern "C" int a3d_profile_read(a3d_prof_entry* out, int max_entries) {
+  int n = 0;
+  for (auto& r : g_prof) {
+    (void)hipEventSynchronize(r.e1);
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, r.e0, r.e1);
+    r.e.ms = ms;
+    if (out && n < max_entries) out[n++] = r.e;
+    g_event_pool.push_back(r.e0);
+    g_event_pool.push_back(r.e1);
+  }
+  g_prof.clear();
+  return n;
+}
 extern "C" const char* a3d_last_error(void) { return a3d::get_error(); }
 
 extern "C" int a3d_memcpy_d2h(void* dst_host, const void* src_dev, size_t bytes, void* stream) {
@@ -432,6 +484,7 @@ extern "C" int a3d_scene_create(const int32_t* coords4_dev, int64_t n_voxels, vo
   auto nblk = [](int64_t n, int t) { return (unsigned)((n + t - 1) / t); };
 
   // ---- phase 1: keys, sort, levels (all sized by the n0 bound; real sizes stay on the device)
+  int prof1 = prof_enabled() ? prof_begin(st, A3D_PROF_SCENE_SORT, 0, 0, 0, 0, n0) : -1;
   int init_sizes[8] = {n0, 0, 0, 0, 0, 0, 0, 0};
   A3D_HIP_CHECK(hipMemcpyAsync(p.sizes_dev, init_sizes, sizeof(init_sizes), hipMemcpyHostToDevice, st));
   k_make_keys<<<nblk(n0, T), T, 0, st>>>(coords4_dev, n0, p.keys_in, p.vals_in, p.sizes_dev);
@@ -448,6 +501,7 @@ extern "C" int a3d_scene_create(const int32_t* coords4_dev, int64_t n_voxels, vo
     k_head_write<<<nb, 1024, 0, st>>>(p.keys[L], p.sizes_dev + L, p.blocksums, p.parentM[L], p.keys[L + 1]);
     A3D_LAUNCH_CHECK();
   }
+  if (prof1 >= 0) prof_end(st, prof1);
   int sizes[8];
   A3D_HIP_CHECK(hipMemcpyAsync(sizes, p.sizes_dev, sizeof(sizes), hipMemcpyDeviceToHost, st));
   A3D_HIP_CHECK(hipStreamSynchronize(st));
@@ -469,6 +523,7 @@ extern "C" int a3d_scene_create(const int32_t* coords4_dev, int64_t n_voxels, vo
     set_error("a3d_scene_create: internal workspace overflow");
     return A3D_ERR_WORKSPACE;
   }
+  ProfScope prof2(st, A3D_PROF_SCENE_TABLES, 0, 0, 0, 0, n0);
   for (int L = 0; L < A3D_NUM_LEVELS; ++L) {
     Level& lv = sc->lv[L];
     lv.keys = p.keys[L];

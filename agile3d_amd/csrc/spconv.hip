@@ -47,6 +47,7 @@ struct ConvArgs {
   float* partial;
   int kper;
   int zero_row;
+  int tag_table, tag_level;   // profiling only
 };
 
 __device__ __forceinline__ void glds16(const float* src, float* lds_base) {
@@ -353,6 +354,8 @@ static int launch_conv(ConvArgs a, float* partial_ws, size_t partial_ws_floats, 
     a.partial = partial_ws;
   }
   dim3 grid(p.ntile, a.cout / p.bn, p.ksplit);
+  {
+  ProfScope ps(st, A3D_PROF_SPCONV, p.bn, a.K, a.cin, a.cout, a.n_out, a.tag_table, a.tag_level, p.ksplit);
   switch (p.bn) {
     case 32: k_spconv<32><<<grid, 256, p.lds, st>>>(a); break;
     case 64: k_spconv<64><<<grid, 256, p.lds, st>>>(a); break;
@@ -360,8 +363,10 @@ static int launch_conv(ConvArgs a, float* partial_ws, size_t partial_ws_floats, 
     case 128: k_spconv<128><<<grid, 256, p.lds, st>>>(a); break;
     default: set_error("spconv: bad BN %d", p.bn); return A3D_ERR_UNSUPPORTED;
   }
+  }
   A3D_LAUNCH_CHECK();
   if (p.ksplit > 1) {
+    ProfScope ps(st, A3D_PROF_SPLITK, p.bn, a.K, a.cin, a.cout, a.n_out, a.tag_table, a.tag_level, p.ksplit);
     const size_t total = (size_t)a.n_out * (a.cout / 4);
     const size_t thr = total > (size_t)a.cout ? total : (size_t)a.cout;
     k_splitk_epilogue<<<(unsigned)((thr + 255) / 256), 256, 0, st>>>(
@@ -520,6 +525,7 @@ extern "C" int a3d_program_run(const a3d_scene* s, const a3d_buf_desc* bufs, int
       }
       const int ks = o.kernel_volume == 125 ? 5 : 3;
       const size_t lds = (size_t)o.kernel_volume * 96 * 4 + (size_t)64 * o.kernel_volume * 4;
+      ProfScope ps(st, A3D_PROF_STEM, 0, o.kernel_volume, 3, 32, lv.n);
       k_stem<<<(lv.n + 63) / 64, 256, lds, st>>>(lv.xyzb, lv.n, lv.hkeys, lv.hvals, lv.hmask, feats4, o.w_dev, ks,
                                                 o.scale_dev, o.shift_dev, o.relu, out, ldo, zero_row);
       A3D_LAUNCH_CHECK();
@@ -551,6 +557,8 @@ extern "C" int a3d_program_run(const a3d_scene* s, const a3d_buf_desc* bufs, int
     a.relu = o.relu;
     a.zero_row = zero_row;
     a.n_out = s->lv[lvl_out].n;
+    a.tag_table = o.kind;
+    a.tag_level = Lin;
     switch (o.kind) {
       case A3D_OP_CONV3:
         if (o.kernel_volume != 27) { set_error("op %d: CONV3 needs kernel volume 27", i); return A3D_ERR_INVALID; }
@@ -611,5 +619,7 @@ extern "C" int a3d_linear(const float* in_dev, int ldi, int64_t n, int cin, int 
   a.ldr = ldr;
   a.relu = relu;
   a.zero_row = -1;
+  a.tag_table = A3D_OP_LINEAR;
+  a.tag_level = -1;
   return launch_conv(a, nullptr, 0, (hipStream_t)stream);
 }

@@ -54,11 +54,21 @@ class DecoderWeights(C.Structure):
                 ("gauss_B", C.c_void_p), ("time_table", C.c_void_p)]
 
 
+class ProfEntry(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("id", "bn", "kernel_volume", "cin", "cout", "n_out", "table", "level",
+                                         "ksplit")] + [("ms", C.c_float)]
+
+
+PROF_NAMES = ["spconv", "splitk_epilogue", "stem", "c2s_attn", "query_chain", "s2c_attn", "ln_mask", "posenc",
+              "scene_sort_levels", "scene_tables"]
+
 # name -> (restype, argtypes): every symbol include/agile3d_hip.h declares
 SYMBOLS = {
     "a3d_version": (C.c_int, []),
     "a3d_last_error": (C.c_char_p, []),
     "a3d_memcpy_d2h": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "a3d_profile_enable": (C.c_int, [C.c_int]),
+    "a3d_profile_read": (C.c_int, [C.POINTER(ProfEntry), C.c_int]),
     "a3d_scene_workspace_bytes": (C.c_size_t, [C.c_int64]),
     "a3d_scene_create": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_size_t, C.c_void_p,
                                    C.POINTER(C.c_void_p)]),

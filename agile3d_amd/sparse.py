@@ -58,13 +58,14 @@ class SparseTensor:
             if b.numel() == 0:
                 self._extra["ranges"] = []
             else:
-                bs = int(b.max().item()) + 1
-                counts = torch.bincount(b.to(torch.int64), minlength=bs).cpu().tolist()
-                # contiguity check (cheap, host side on the counts only when batch>1)
-                if bs > 1:
-                    chg = int((b[1:] != b[:-1]).sum().item())
-                    if chg != bs - 1:
-                        raise ValueError("rows of each batch sample must be contiguous")
+                # one device->host copy: per-sample counts followed by the number of batch-index
+                # changes (rows of one sample must be contiguous, as batched_coordinates produces)
+                counts = torch.bincount(b.to(torch.int64))
+                chg = (b[1:] != b[:-1]).sum().reshape(1)
+                host = torch.cat([counts, chg]).cpu().tolist()
+                counts, chg = host[:-1], host[-1]
+                if chg != len(counts) - 1 or min(counts) == 0:
+                    raise ValueError("rows of each batch sample must be contiguous and batch indices dense")
                 r, s = [], 0
                 for c in counts:
                     r.append((s, s + c))

@@ -72,19 +72,23 @@ def make_scene(n_target: int = 80_000, seed: int = 0, voxel_size: float = 0.02,
     raw_xyz fp32  [N,3]  metres, min-shifted like the reference dataset does
     labels  int32 [N]    0 = room shell, 1..n_boxes = furniture id (for click simulation)
     """
-    lo, hi = 1.0, 400.0
-    best = None
-    for _ in range(40):
-        mid = 0.5 * (lo + hi)
-        c, own = _scene_at_scale(seed, mid, n_boxes)
+    # voxel count grows ~ scale^2 (surfaces): secant steps on that law, then bisection if needed
+    best, scale, lo, hi = None, 40.0, None, None
+    for it in range(40):
+        c, own = _scene_at_scale(seed, scale, n_boxes)
         if best is None or abs(len(c) - n_target) < abs(len(best[0]) - n_target):
             best = (c, own)
         if abs(len(c) - n_target) <= 0.01 * n_target:
             break
         if len(c) < n_target:
-            lo = mid
+            lo = scale if lo is None else max(lo, scale)
         else:
-            hi = mid
+            hi = scale if hi is None else min(hi, scale)
+        guess = scale * (n_target / max(len(c), 1)) ** 0.5
+        if lo is not None and hi is not None:
+            if not (lo < guess < hi) or it > 6:
+                guess = 0.5 * (lo + hi)
+        scale = min(max(guess, 0.5), 2000.0)
     c, own = best
     rng = np.random.default_rng(seed + 1_000_003)
     if shuffle:  # dataset order is not spatially sorted; do not let tests rely on it

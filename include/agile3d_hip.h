@@ -41,6 +41,29 @@ const char* a3d_last_error(void);
 int         a3d_memcpy_d2h(void* dst_host, const void* src_dev, size_t bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Optional kernel timing (bench.py's live roofline numbers).  While enabled, every launch of the
+ * kernels listed below is bracketed by a hipEvent pair on the launch stream.
+ * ------------------------------------------------------------------------------------------ */
+enum {
+  A3D_PROF_SPCONV = 0,      /* k_spconv<bn>   (3^3 / 2^3 / transposed / 1x1 / dense GEMM)  */
+  A3D_PROF_SPLITK = 1,      /* split-K reduction + epilogue                              */
+  A3D_PROF_STEM = 2,        /* 5^3 stem                                                  */
+  A3D_PROF_C2S = 3,         /* click-to-scene attention                                  */
+  A3D_PROF_QUERY = 4,       /* query-side chain (one workgroup)                          */
+  A3D_PROF_S2C = 5,         /* scene-to-click attention                                  */
+  A3D_PROF_LNMASK = 6,      /* LayerNorm + mask head                                     */
+  A3D_PROF_POSENC = 7,      /* Fourier position encoding                                 */
+  A3D_PROF_SCENE_SORT = 8,  /* keys + radix sort + level compaction                      */
+  A3D_PROF_SCENE_TABLES = 9 /* hash, neighbour tables, row clustering                    */
+};
+typedef struct {
+  int32_t id, bn, kernel_volume, cin, cout, n_out, table, level, ksplit;
+  float   ms;
+} a3d_prof_entry;
+int a3d_profile_enable(int on);
+int a3d_profile_read(a3d_prof_entry* out, int max_entries);   /* returns #entries, clears */
+
+/* ------------------------------------------------------------------------------------------
  * Scene = the coordinate manager.
  * Replaces: ME.SparseTensor(coordinates=, features=, device=) (engine.py:47-51,
  * eval_multi_obj.py:94-98) and the coordinate manager every ME layer consults implicitly
