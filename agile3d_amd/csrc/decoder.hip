@@ -178,6 +178,40 @@ __global__ void __launch_bounds__(512) k_c2s_attn(const float* __restrict__ Kc, 
   }
 }
 
+// merge the per-chunk flash partials (m, l, acc[16]) of one (query, head): one wave per pair
+template <int QT>
+__global__ void __launch_bounds__(64) k_c2s_combine(const float* __restrict__ part, int nchunk, float* attn) {
+  constexpr int QP = QT * 16;
+  const int q = blockIdx.x / H, h = blockIdx.x % H, lane = threadIdx.x;
+  float m = kNegBig, l = 0.f, o[DH];
+#pragma unroll
+  for (int d = 0; d < DH; ++d) o[d] = 0.f;
+  for (int ch = lane; ch < nchunk; ch += 64) {
+    const float* p = part + (((size_t)ch * H + h) * QP + q) * kPartStride;
+    const float pm = p[0];
+    const float mn = fmaxf(m, pm);
+    const float a = expf(m - mn), b = expf(pm - mn);
+    l = l * a + p[1] * b;
+#pragma unroll
+    for (int d = 0; d < DH; ++d) o[d] = o[d] * a + p[2 + d] * b;
+    m = mn;
+  }
+  float M = m;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) M = fmaxf(M, __shfl_xor(M, off, 64));
+  const float sc = expf(m - M);
+  l *= sc;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) l += __shfl_xor(l, off, 64);
+#pragma unroll
+  for (int d = 0; d < DH; ++d) {
+    float v = o[d] * sc;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    if (lane == d) attn[(size_t)q * D + h * DH + d] = v / l;
+  }
+}
+
 // ------------------------------------------------------------------------------ scene-to-click
 // 8 waves x 16 points per workgroup; keys/values of the <= 64 queries staged in LDS (row stride
 // 132 floats: conflict-free b128 fragment reads).  S^T = ks_h Qs_h^T, softmax over keys in
@@ -374,14 +408,17 @@ struct QueryBufs {   // all [QP][...] fp32 in global scratch
 };
 
 // Y[q][n] = ((X[q][:] (+ Xadd[q][:])) @ Wt[:, n] + bias[n]) * scale, optional relu.
-// Wt is [K][ldw] (transposed torch weight), X staged through LDS in 128-wide slices.
+// Wt is [K][ldw] (transposed torch weight).  512 threads = 128 output columns x 4 interleaved
+// K slices (adjacent lanes -> two shuffles reduce them); X is staged through LDS 128 columns at a
+// time (vector loads: the operands were written earlier in this kernel, never use the scalar cache).
 template <int QP>
 __device__ __noinline__ void lin(const float* X, int ldx, const float* Xadd, int Q, int K, const float* __restrict__ Wt,
-                    int ldw, const float* __restrict__ bias, int N, float* Y, int ldy, bool relu, float scale,
-                    float* lds /*[QP][128]*/) {
+                                 int ldw, const float* __restrict__ bias, int N, float* Y, int ldy, bool relu,
+                                 float scale, float* lds /*[QP][128]*/) {
   const int tid = threadIdx.x, nt = blockDim.x;
-  for (int n0 = 0; n0 < N; n0 += nt) {
-    const int nn = n0 + tid;
+  const int ks = tid & 3, nl = tid >> 2;
+  for (int n0 = 0; n0 < N; n0 += 128) {
+    const int nn = n0 + nl;
     float acc[QP];
 #pragma unroll
     for (int q = 0; q < QP; ++q) acc[q] = 0.f;
@@ -398,14 +435,20 @@ __device__ __noinline__ void lin(const float* X, int ldx, const float* Xadd, int
       }
       __syncthreads();
       if (nn < N) {
-        for (int kk = 0; kk < 128; ++kk) {
+#pragma unroll 4
+        for (int kk = ks; kk < 128; kk += 4) {
           const float w = Wt[(size_t)(kc + kk) * ldw + nn];
 #pragma unroll
           for (int q = 0; q < QP; ++q) acc[q] += lds[q * 128 + kk] * w;
         }
       }
     }
-    if (nn < N) {
+#pragma unroll
+    for (int q = 0; q < QP; ++q) {
+      acc[q] += __shfl_xor(acc[q], 1, 64);
+      acc[q] += __shfl_xor(acc[q], 2, 64);
+    }
+    if (nn < N && ks == 0) {
       const float b = bias ? bias[nn] : 0.f;
 #pragma unroll
       for (int q = 0; q < QP; ++q) {
@@ -482,27 +525,10 @@ __global__ void __launch_bounds__(512) k_query_init(const QueryMeta* meta, const
 }
 
 template <int QP>
-__global__ void __launch_bounds__(512) k_query_layer(const QueryMeta* meta, QueryLayerW W, QueryBufs B,
-                                                      const float* part, int nchunk) {
+__global__ void __launch_bounds__(512) k_query_layer(const QueryMeta* meta, QueryLayerW W, QueryBufs B) {
   __shared__ float lds[QP * 128];
   const int Q = meta->nq;
   const int tid = threadIdx.x, nt = blockDim.x;
-  // 1. combine the flash partials of the click-to-scene attention
-  for (int e = tid; e < Q * D; e += nt) {
-    const int q = e >> 7, c = e & 127, h = c >> 4, d = c & 15;
-    float M = kNegBig;
-    for (int ch = 0; ch < nchunk; ++ch)
-      M = fmaxf(M, part[(((size_t)ch * H + h) * QP + q) * kPartStride]);
-    float Lsum = 0.f, o = 0.f;
-    for (int ch = 0; ch < nchunk; ++ch) {
-      const float* p = part + (((size_t)ch * H + h) * QP + q) * kPartStride;
-      const float w = expf(p[0] - M);
-      Lsum += p[1] * w;
-      o += p[2 + d] * w;
-    }
-    B.attn[e] = o / Lsum;
-  }
-  __syncthreads();
   // 2. c2s output projection + residual + LayerNorm (attention_block.py:95-96)
   lin<QP>(B.attn, D, nullptr, Q, D, W.c2s_out_wt, D, W.c2s_out_b, D, B.tmp, D, false, 1.f, lds);
   add_ln(B.queries, B.tmp, Q, W.c2s_norm_w, W.c2s_norm_b, B.tgt);
@@ -728,7 +754,8 @@ static int run_decoder(const a3d_decoder_weights* w, const float* feats128, cons
     QW.dim_ff = w->dim_ff;
     {
     ProfScope ps(st, A3D_PROF_QUERY, 0, 0, 0, 0, nq);
-    k_query_layer<QP><<<1, 512, 0, st>>>(meta, QW, B, part, L.nchunk);
+    k_c2s_combine<QT><<<nq * H, 64, 0, st>>>(part, L.nchunk, B.attn);
+    k_query_layer<QP><<<1, 512, 0, st>>>(meta, QW, B);
     }
     A3D_LAUNCH_CHECK();
     // ---- scene-to-click: Q = src Wq^T + (pos Wq^T + bq); attention; Y = O Wo^T + bo + src; LN

@@ -189,29 +189,32 @@ __global__ void k_hash_insert(const uint64_t* __restrict__ keys, int n, uint64_t
   }
 }
 
-// 3^3 neighbours in Morton row ids: nbrM[k][npad] (-1 = missing) and the 27-bit presence mask
+// 3^3 neighbours in Morton row ids: nbrM[k][npad] (-1 = missing); one thread per (row, offset)
 __global__ void k_nbr_morton(const uint64_t* __restrict__ keys, int n, int npad, int L,
                              const uint64_t* __restrict__ hk, const int* __restrict__ hv,
-                             uint32_t hmask, int* nbrM, uint32_t* mask27) {
+                             uint32_t hmask, int* nbrM) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int k = blockIdx.y;
+  if (i >= n) return;
+  int r = i;
+  if (k != 13) {
+    int b, X, Y, Z;
+    decode_key(keys[i], L, b, X, Y, Z);
+    const int lim = kCoordOff >> L;
+    const int x = X + k % 3 - 1, y = Y + (k / 3) % 3 - 1, z = Z + k / 9 - 1;  // x fastest
+    r = -1;
+    if (x >= -lim && x < lim && y >= -lim && y < lim && z >= -lim && z < lim)
+      r = hash_lookup(hk, hv, hmask, make_key(b, x, y, z, L));
+  }
+  nbrM[(size_t)k * npad + i] = r;
+}
+// 27-bit presence mask per row (the sort key of the row clustering)
+__global__ void k_mask27(const int* __restrict__ nbrM, int n, int npad, uint32_t* mask27) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  int b, X, Y, Z;
-  decode_key(keys[i], L, b, X, Y, Z);
-  const int lim = kCoordOff >> L;
   uint32_t m = 0;
-#pragma unroll 1
-  for (int k = 0; k < 27; ++k) {
-    const int dx = k % 3 - 1, dy = (k / 3) % 3 - 1, dz = k / 9 - 1;  // x fastest
-    const int x = X + dx, y = Y + dy, z = Z + dz;
-    int r = -1;
-    if (k == 13) {
-      r = i;
-    } else if (x >= -lim && x < lim && y >= -lim && y < lim && z >= -lim && z < lim) {
-      r = hash_lookup(hk, hv, hmask, make_key(b, x, y, z, L));
-    }
-    nbrM[(size_t)k * npad + i] = r;
-    if (r >= 0) m |= 1u << k;
-  }
+#pragma unroll
+  for (int k = 0; k < 27; ++k) m |= (nbrM[(size_t)k * npad + i] >= 0 ? 1u : 0u) << k;
   mask27[i] = m;
 }
 
@@ -532,7 +535,8 @@ extern "C" int a3d_scene_create(const int32_t* coords4_dev, int64_t n_voxels, vo
     const uint32_t cap = lv.hmask + 1;
     k_fill_u64<<<nblk(cap, T), T, 0, st>>>(lv.hkeys, cap, kEmptyKey);
     k_hash_insert<<<nblk(n, T), T, 0, st>>>(lv.keys, n, lv.hkeys, lv.hvals, lv.hmask);
-    k_nbr_morton<<<nblk(n, T), T, 0, st>>>(lv.keys, n, npad, L, lv.hkeys, lv.hvals, lv.hmask, t.nbrM, t.sortkey);
+    k_nbr_morton<<<dim3(nblk(n, T), 27), T, 0, st>>>(lv.keys, n, npad, L, lv.hkeys, lv.hvals, lv.hmask, t.nbrM);
+    k_mask27<<<nblk(n, T), T, 0, st>>>(t.nbrM, n, npad, t.sortkey);
     k_tile_sort<<<nblk(n, kSuperTile), kSuperTile, 0, st>>>(t.sortkey, n, lv.perm, lv.inv);
     A3D_HIP_CHECK(hipMemsetAsync(lv.gmask27, 0, sizeof(uint32_t) * (npad / 16), st));
     k_remap_nbr<<<dim3(nblk(npad, T), 27), T, 0, st>>>(t.nbrM, lv.perm, lv.inv, n, npad, lv.nbr27, lv.gmask27);
