@@ -407,57 +407,68 @@ struct QueryBufs {   // all [QP][...] fp32 in global scratch
   float *attn, *tmp, *tgt, *qk, *vc, *hidden;
 };
 
-// Y[q][n] = ((X[q][:] (+ Xadd[q][:])) @ Wt[:, n] + bias[n]) * scale, optional relu.
-// Wt is [K][ldw] (transposed torch weight).  512 threads = 128 output columns x 4 interleaved
-// K slices (adjacent lanes -> two shuffles reduce them); X is staged through LDS 128 columns at a
-// time (vector loads: the operands were written earlier in this kernel, never use the scalar cache).
-template <int QP>
-__device__ __noinline__ void lin(const float* X, int ldx, const float* Xadd, int Q, int K, const float* __restrict__ Wt,
+// Y[q][n] = ((X[q][:] (+ Xadd[q][:])) . W[n][:] + bias[n]) * scale, optional relu -- a skinny GEMM
+// on the matrix cores.  W is the torch weight [N][ldw] (K contiguous): lane (g, j) loads
+// W[n0 + j][16 S + 4 g .. +3] as one float4 = the B fragments of four MFMAs (same K permutation as
+// spconv.hip).  X (<= 64 rows) is staged through LDS in 256-column slices (row stride 260 floats:
+// conflict-free b128 A-fragment reads; vector loads only -- X was written earlier in this kernel).
+// 8 waves; wave w owns output column tiles w, w+8, ...
+constexpr int kLinKC = 256, kLinLD = kLinKC + 4;
+template <int QT>
+__device__ __noinline__ void lin(const float* X, int ldx, const float* Xadd, int Q, int K, const float* __restrict__ W,
                                  int ldw, const float* __restrict__ bias, int N, float* Y, int ldy, bool relu,
-                                 float scale, float* lds /*[QP][128]*/) {
+                                 float scale, float* lds /*[QT*16][260]*/) {
   const int tid = threadIdx.x, nt = blockDim.x;
-  const int ks = tid & 3, nl = tid >> 2;
-  for (int n0 = 0; n0 < N; n0 += 128) {
-    const int nn = n0 + nl;
-    float acc[QP];
+  const int lane = tid & 63, wave = tid >> 6, nw = nt >> 6;
+  const int g = lane >> 4, j = lane & 15;
+  const int ntiles = N >> 4;
+  for (int t0 = 0; t0 < ntiles; t0 += nw) {
+    const int ntile = t0 + wave;
+    const bool active = ntile < ntiles;
+    f32x4 acc[QT];
 #pragma unroll
-    for (int q = 0; q < QP; ++q) acc[q] = 0.f;
-    for (int kc = 0; kc < K; kc += 128) {
+    for (int qt = 0; qt < QT; ++qt) acc[qt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int kc = 0; kc < K; kc += kLinKC) {
+      const int kcur = min(kLinKC, K - kc);
       __syncthreads();
-      for (int e = tid; e < QP * 128; e += nt) {
-        const int q = e >> 7, kk = e & 127;
-        float v = 0.f;
+      for (int e = tid; e < QT * 16 * (kcur >> 2); e += nt) {
+        const int q = e / (kcur >> 2), k4 = (e - q * (kcur >> 2)) * 4;
+        f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
         if (q < Q) {
-          v = X[(size_t)q * ldx + kc + kk];
-          if (Xadd) v += Xadd[(size_t)q * D + kc + kk];
+          v = *(const f32x4*)(X + (size_t)q * ldx + kc + k4);
+          if (Xadd) v += *(const f32x4*)(Xadd + (size_t)q * D + kc + k4);
         }
-        lds[e] = v;
+        *(f32x4*)(lds + q * kLinLD + k4) = v;
       }
       __syncthreads();
-      if (nn < N) {
+      if (active) {
+        const float* wrow = W + (size_t)(ntile * 16 + j) * ldw + kc + 4 * g;
 #pragma unroll 4
-        for (int kk = ks; kk < 128; kk += 4) {
-          const float w = Wt[(size_t)(kc + kk) * ldw + nn];
+        for (int S = 0; S < (kcur >> 4); ++S) {
+          const f32x4 b = *(const f32x4*)(wrow + 16 * S);
 #pragma unroll
-          for (int q = 0; q < QP; ++q) acc[q] += lds[q * 128 + kk] * w;
+          for (int qt = 0; qt < QT; ++qt) {
+            const f32x4 a = *(const f32x4*)(lds + (qt * 16 + j) * kLinLD + 16 * S + 4 * g);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) acc[qt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t], b[t], acc[qt], 0, 0, 0);
+          }
         }
       }
     }
+    if (active) {
+      const int col = ntile * 16 + j;
+      const float b = bias ? bias[col] : 0.f;
 #pragma unroll
-    for (int q = 0; q < QP; ++q) {
-      acc[q] += __shfl_xor(acc[q], 1, 64);
-      acc[q] += __shfl_xor(acc[q], 2, 64);
-    }
-    if (nn < N && ks == 0) {
-      const float b = bias ? bias[nn] : 0.f;
+      for (int qt = 0; qt < QT; ++qt)
 #pragma unroll
-      for (int q = 0; q < QP; ++q) {
-        if (q < Q) {
-          float y = (acc[q] + b) * scale;
-          if (relu) y = fmaxf(y, 0.f);
-          Y[(size_t)q * ldy + nn] = y;
+        for (int t = 0; t < 4; ++t) {
+          const int q = qt * 16 + 4 * g + t;
+          if (q < Q) {
+            float y = (acc[qt][t] + b) * scale;
+            if (relu) y = fmaxf(y, 0.f);
+            Y[(size_t)q * ldy + col] = y;
+          }
         }
-      }
     }
   }
   __syncthreads();
@@ -488,13 +499,14 @@ __device__ __noinline__ void add_ln(const float* a, const float* b, int Q, const
   __syncthreads();
 }
 
-template <int QP>
+template <int QT>
 __global__ void __launch_bounds__(512) k_query_init(const QueryMeta* meta, const float* feats128,
                                                      const float* posenc, const float* bg_feat,
                                                      const float* bg_pos, const float* time_table,
                                                      const float* c2s_in_wt, const float* c2s_in_b,
                                                      QueryBufs B, int* counts, int n_counts) {
-  __shared__ float lds[QP * 128];
+  constexpr int QP = QT * 16;
+  __shared__ __attribute__((aligned(16))) float lds[QP * kLinLD];
   const int Q = meta->nq, n_fg = meta->n_fg, n_bgl = meta->n_bgl;
   for (int e = threadIdx.x; e < n_counts; e += blockDim.x) counts[e] = 0;
   for (int e = threadIdx.x; e < QP * D; e += blockDim.x) {
@@ -521,20 +533,21 @@ __global__ void __launch_bounds__(512) k_query_init(const QueryMeta* meta, const
   (void)n_bgl;
   __syncthreads();
   // c2s query projection of the first layer, pre-scaled by 1/sqrt(head_dim)
-  lin<QP>(B.queries, D, B.qpos, Q, D, c2s_in_wt, 3 * D, c2s_in_b, D, B.qproj, D, false, 0.25f, lds);
+  lin<QT>(B.queries, D, B.qpos, Q, D, c2s_in_wt, D, c2s_in_b, D, B.qproj, D, false, 0.25f, lds);
 }
 
-template <int QP>
+template <int QT>
 __global__ void __launch_bounds__(512) k_query_layer(const QueryMeta* meta, QueryLayerW W, QueryBufs B) {
-  __shared__ float lds[QP * 128];
+  constexpr int QP = QT * 16;
+  __shared__ __attribute__((aligned(16))) float lds[QP * kLinLD];
   const int Q = meta->nq;
   const int tid = threadIdx.x, nt = blockDim.x;
   // 2. c2s output projection + residual + LayerNorm (attention_block.py:95-96)
-  lin<QP>(B.attn, D, nullptr, Q, D, W.c2s_out_wt, D, W.c2s_out_b, D, B.tmp, D, false, 1.f, lds);
+  lin<QT>(B.attn, D, nullptr, Q, D, W.c2s_out_wt, D, W.c2s_out_b, D, B.tmp, D, false, 1.f, lds);
   add_ln(B.queries, B.tmp, Q, W.c2s_norm_w, W.c2s_norm_b, B.tgt);
   // 3. click-to-click self attention (attention_block.py:32-36)
-  lin<QP>(B.tgt, D, B.qpos, Q, D, W.c2c_in_wt, 3 * D, W.c2c_in_b, 2 * D, B.qk, 2 * D, false, 1.f, lds);
-  lin<QP>(B.tgt, D, nullptr, Q, D, W.c2c_in_wt + 2 * D, 3 * D, W.c2c_in_b + 2 * D, D, B.vc, D, false, 1.f, lds);
+  lin<QT>(B.tgt, D, B.qpos, Q, D, W.c2c_in_wt, D, W.c2c_in_b, 2 * D, B.qk, 2 * D, false, 1.f, lds);
+  lin<QT>(B.tgt, D, nullptr, Q, D, W.c2c_in_wt + 2 * D * D, D, W.c2c_in_b + 2 * D, D, B.vc, D, false, 1.f, lds);
   for (int e = tid; e < Q * H; e += nt) {
     const int q = e / H, h = e % H;
     float qv[DH];
@@ -564,22 +577,22 @@ __global__ void __launch_bounds__(512) k_query_layer(const QueryMeta* meta, Quer
     for (int d = 0; d < DH; ++d) B.attn[(size_t)q * D + h * DH + d] = o[d] * inv;
   }
   __syncthreads();
-  lin<QP>(B.attn, D, nullptr, Q, D, W.c2c_out_wt, D, W.c2c_out_b, D, B.tmp, D, false, 1.f, lds);
+  lin<QT>(B.attn, D, nullptr, Q, D, W.c2c_out_wt, D, W.c2c_out_b, D, B.tmp, D, false, 1.f, lds);
   add_ln(B.tgt, B.tmp, Q, W.c2c_norm_w, W.c2c_norm_b, B.tgt);
   // 4. FFN (attention_block.py:151-155)
-  lin<QP>(B.tgt, D, nullptr, Q, D, W.ffn_w1t, W.dim_ff, W.ffn_b1, W.dim_ff, B.hidden, W.dim_ff, true, 1.f, lds);
-  lin<QP>(B.hidden, W.dim_ff, nullptr, Q, W.dim_ff, W.ffn_w2t, D, W.ffn_b2, D, B.tmp, D, false, 1.f, lds);
+  lin<QT>(B.tgt, D, nullptr, Q, D, W.ffn_w1t, D, W.ffn_b1, W.dim_ff, B.hidden, W.dim_ff, true, 1.f, lds);
+  lin<QT>(B.hidden, W.dim_ff, nullptr, Q, W.dim_ff, W.ffn_w2t, W.dim_ff, W.ffn_b2, D, B.tmp, D, false, 1.f, lds);
   add_ln(B.tgt, B.tmp, Q, W.ffn_norm_w, W.ffn_norm_b, B.queries);
   // 5. keys / values of the scene-to-click attention (keys pre-scaled by 1/sqrt(head_dim))
-  lin<QP>(B.queries, D, B.qpos, Q, D, W.s2c_in_wt + D, 3 * D, W.s2c_in_b + D, D, B.ks, D, false, 0.25f, lds);
-  lin<QP>(B.queries, D, nullptr, Q, D, W.s2c_in_wt + 2 * D, 3 * D, W.s2c_in_b + 2 * D, D, B.vs, D, false, 1.f, lds);
+  lin<QT>(B.queries, D, B.qpos, Q, D, W.s2c_in_wt + D * D, D, W.s2c_in_b + D, D, B.ks, D, false, 0.25f, lds);
+  lin<QT>(B.queries, D, nullptr, Q, D, W.s2c_in_wt + 2 * D * D, D, W.s2c_in_b + 2 * D, D, B.vs, D, false, 1.f, lds);
   // 6. mask embeddings E = MLP(decoder_norm(q))  (agile3d.py:345-346)
   add_ln(B.queries, nullptr, Q, W.dn_w, W.dn_b, B.tmp);
-  lin<QP>(B.tmp, D, nullptr, Q, D, W.m_w0t, D, W.m_b0, D, B.attn, D, true, 1.f, lds);
-  lin<QP>(B.attn, D, nullptr, Q, D, W.m_w2t, D, W.m_b2, D, B.E, D, false, 1.f, lds);
+  lin<QT>(B.tmp, D, nullptr, Q, D, W.m_w0t, D, W.m_b0, D, B.attn, D, true, 1.f, lds);
+  lin<QT>(B.attn, D, nullptr, Q, D, W.m_w2t, D, W.m_b2, D, B.E, D, false, 1.f, lds);
   // 7. query projection for the next iteration's click-to-scene attention
   if (W.next_c2s_in_wt)
-    lin<QP>(B.queries, D, B.qpos, Q, D, W.next_c2s_in_wt, 3 * D, W.next_c2s_in_b, D, B.qproj, D, false, 0.25f, lds);
+    lin<QT>(B.queries, D, B.qpos, Q, D, W.next_c2s_in_wt, D, W.next_c2s_in_b, D, B.qproj, D, false, 0.25f, lds);
 }
 
 }  // namespace a3d
@@ -714,7 +727,7 @@ static int run_decoder(const a3d_decoder_weights* w, const float* feats128, cons
   const int n_counts = A3D_MAX_DEC_LAYERS * (A3D_MAX_QUERIES + 1);
   {
   ProfScope ps(st, A3D_PROF_QUERY, 0, 0, 0, 0, nq);
-  k_query_init<QP><<<1, 512, 0, st>>>(meta, feats128, posenc, w->bg_query_feat, w->bg_query_pos, w->time_table,
+  k_query_init<QT><<<1, 512, 0, st>>>(meta, feats128, posenc, w->bg_query_feat, w->bg_query_pos, w->time_table,
                                        w->layers[0].c2s_in_w, w->layers[0].c2s_in_b, B, counts, n_counts);
   }
   A3D_LAUNCH_CHECK();
@@ -755,7 +768,7 @@ static int run_decoder(const a3d_decoder_weights* w, const float* feats128, cons
     {
     ProfScope ps(st, A3D_PROF_QUERY, 0, 0, 0, 0, nq);
     k_c2s_combine<QT><<<nq * H, 64, 0, st>>>(part, L.nchunk, B.attn);
-    k_query_layer<QP><<<1, 512, 0, st>>>(meta, QW, B);
+    k_query_layer<QT><<<1, 512, 0, st>>>(meta, QW, B);
     }
     A3D_LAUNCH_CHECK();
     // ---- scene-to-click: Q = src Wq^T + (pos Wq^T + bq); attention; Y = O Wo^T + bo + src; LN

@@ -262,8 +262,8 @@ class DecoderPack:
             self.keep.append(t)
             return t.data_ptr()
 
-        def tr(t):
-            return dv(t.detach().t())
+        def tr(t):   # query-side matrices stay in torch layout [out][in]
+            return dv(t)
 
         def packed(wt_in_out):  # [in][out] -> MFMA fragment order
             w = wt_in_out.detach().to(dev, torch.float32).contiguous().unsqueeze(0)

@@ -173,12 +173,10 @@ int a3d_posenc_fourier(const float* xyz_dev, int64_t n, const float* gauss_B_dev
 #define A3D_MAX_DEC_LAYERS 8
 
 typedef struct {
-  /* nn.MultiheadAttention / LayerNorm / Linear parameters.  Every matrix used on the query side
-   * ([Q<=64,128] operands) is passed TRANSPOSED, i.e. row-major [in][out]:
-   *   *_in_w  = in_proj_weight^T  [128][384]  (columns 0..127 q, 128..255 k, 256..383 v)
-   *   *_out_w = out_proj.weight^T [128][128]
-   *   ffn_w1  = linear1.weight^T  [128][dim_ff],  ffn_w2 = linear2.weight^T [dim_ff][128]
-   * biases / LayerNorm vectors are unchanged. */
+  /* nn.MultiheadAttention / LayerNorm / Linear parameters in torch layout (row-major [out][in]):
+   *   *_in_w = in_proj_weight [384][128] (rows 0..127 q, 128..255 k, 256..383 v),
+   *   *_out_w = out_proj.weight [128][128], ffn_w1 = linear1.weight [dim_ff][128],
+   *   ffn_w2 = linear2.weight [128][dim_ff]. */
   const float *c2s_in_w, *c2s_in_b, *c2s_out_w, *c2s_out_b, *c2s_norm_w, *c2s_norm_b;
   const float *c2c_in_w, *c2c_in_b, *c2c_out_w, *c2c_out_b, *c2c_norm_w, *c2c_norm_b;
   const float *ffn_w1, *ffn_b1, *ffn_w2, *ffn_b2, *ffn_norm_w, *ffn_norm_b;
@@ -194,7 +192,7 @@ typedef struct {
   int32_t dim_ff;
   a3d_decoder_layer layers[A3D_MAX_DEC_LAYERS];
   const float *decoder_norm_w, *decoder_norm_b;
-  const float *mask_w0, *mask_b0, *mask_w2, *mask_b2;     /* mask_embed_head.{0,2}, weights transposed */
+  const float *mask_w0, *mask_b0, *mask_w2, *mask_b2;     /* mask_embed_head.{0,2} */
   const float *bg_query_feat, *bg_query_pos;              /* [n_bg][128] */
   const float *gauss_B;                                   /* [3][64] */
   const float *time_table;                                /* [200][128] PositionalEncoding1D */
