@@ -58,10 +58,12 @@ __device__ __forceinline__ void glds16(const float* src, float* lds_base) {
 template <int BN>
 __global__ void __launch_bounds__(256) k_spconv(const ConvArgs a) {
   constexpr int NCT = BN / 16;
+  constexpr int A_FLOATS = 128 * 32;        // [128 rows][32 ch], 16-byte pieces XOR-swizzled by row&7
+  constexpr int W_FLOATS = 2 * NCT * 256;   // [2 steps][NCT][64 lanes][4]
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  float* A_lds = (float*)smem;               // [128 rows][32 ch], 16-byte pieces XOR-swizzled by row&7
-  float* W_lds = A_lds + 128 * 32;           // [2 steps][NCT][64 lanes][4]
-  int* idx_lds = (int*)(W_lds + 2 * NCT * 256);  // [kper][128]
+  float* A_lds = (float*)smem;                       // 2 stage buffers
+  float* W_lds = A_lds + 2 * A_FLOATS;               // 2 stage buffers
+  int* idx_lds = (int*)(W_lds + 2 * W_FLOATS);       // [kper][128]
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -111,55 +113,94 @@ __global__ void __launch_bounds__(256) k_spconv(const ConvArgs a) {
   const int cin16 = a.cin >> 4, cout16 = a.cout >> 4;
   const int swz = lane >> 3;  // == (row & 7) for the staging lanes
 
-  for (int k = kbeg; k < kend; ++k) {
-    if (!((un >> k) & 1u)) continue;
+  // DMA one stage = (offset k, 32-channel slice c) into stage buffer `buf`
+  auto issue = [&](int k, int c, int buf) {
     const bool act0 = (gm0 >> k) & 1u, act1 = (gm1 >> k) & 1u;
     const int* idxk = idx_lds + (k - kbeg) * 128;
-    for (int c = 0; c < nchunk; ++c) {
-      // -- stage the wave's own 32 gathered rows (4 x 1 KiB DMA instructions)
+    float* Ab = A_lds + buf * A_FLOATS;
+    float* Wb = W_lds + buf * W_FLOATS;
+    int src_row[4];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const bool act = (i < 2) ? act0 : act1;
-        if (act) {
-          const int row = 32 * wave + 8 * i + swz;
-          const int src_row = idxk[row];
-          const float* src = a.in + (size_t)src_row * a.ldi + c * 32 + 4 * ((lane & 7) ^ swz);
-          glds16(src, A_lds + (32 * wave + 8 * i) * 32);
-        }
+    for (int i = 0; i < 4; ++i) src_row[i] = idxk[32 * wave + 8 * i + swz];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {   // the wave's own 32 gathered rows: 4 x 1 KiB
+      const bool act = (i < 2) ? act0 : act1;
+      if (act) {
+        const float* src = a.in + (size_t)src_row[i] * a.ldi + c * 32 + 4 * ((lane & 7) ^ swz);
+        glds16(src, Ab + (32 * wave + 8 * i) * 32);
       }
-      // -- stage the weight slice W[k][32 ch of this chunk][BN cols], already in fragment order
-      for (int q = wave; q < 2 * NCT; q += 4) {
-        const int s = q / NCT, ctl = q - s * NCT;
-        const float* src =
-            a.w + (((size_t)k * cin16 + (2 * c + s)) * cout16 + ct0 + ctl) * 256 + lane * 4;
-        glds16(src, W_lds + q * 256);
-      }
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
-      if (act0 || act1) {
+    }
+    for (int q = wave; q < 2 * NCT; q += 4) {   // weight slice, already in fragment order
+      const int s = q / NCT, ctl = q - s * NCT;
+      const float* src = a.w + (((size_t)k * cin16 + (2 * c + s)) * cout16 + ct0 + ctl) * 256 + lane * 4;
+      glds16(src, Wb + q * 256);
+    }
+  };
+  auto next_k = [&](int k) {
+    ++k;
+    while (k < kend && !((un >> k) & 1u)) ++k;
+    return k;
+  };
+
+  int k_cur = next_k(kbeg - 1), c_cur = 0, buf = 0;
+  if (k_cur < kend) issue(k_cur, 0, 0);
+  while (k_cur < kend) {
+    int k_nxt = k_cur, c_nxt = c_cur + 1;
+    if (c_nxt == nchunk) {
+      c_nxt = 0;
+      k_nxt = next_k(k_cur);
+    }
+    // stage (k_cur, c_cur) has landed for every wave; every wave is done reading the other buffer
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (k_nxt < kend) issue(k_nxt, c_nxt, buf ^ 1);
+    const bool act0 = (gm0 >> k_cur) & 1u, act1 = (gm1 >> k_cur) & 1u;
+    const float* Ab = A_lds + buf * A_FLOATS + (32 * wave + j) * 32;
+    const float* Wb = W_lds + buf * W_FLOATS + lane * 4;
+    const int p0 = ((0 + g) ^ (j & 7)) * 4, p1 = ((4 + g) ^ (j & 7)) * 4;
+    if (act0 && act1) {
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
-          const int p = ((4 * s + g) ^ (j & 7)) * 4;
-          const f32x4 a0 = *(const f32x4*)(A_lds + (32 * wave + j) * 32 + p);
-          const f32x4 a1 = *(const f32x4*)(A_lds + (32 * wave + 16 + j) * 32 + p);
+      for (int s = 0; s < 2; ++s) {
+        const f32x4 a0 = *(const f32x4*)(Ab + (s ? p1 : p0));
+        const f32x4 a1 = *(const f32x4*)(Ab + 16 * 32 + (s ? p1 : p0));
 #pragma unroll
-          for (int ct = 0; ct < NCT; ++ct) {
-            const f32x4 b = *(const f32x4*)(W_lds + (s * NCT + ct) * 256 + lane * 4);
-            if (act0) {
+        for (int ct = 0; ct < NCT; ++ct) {
+          const f32x4 b = *(const f32x4*)(Wb + (s * NCT + ct) * 256);
 #pragma unroll
-              for (int t = 0; t < 4; ++t)
-                acc[0][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[t], b[t], acc[0][ct], 0, 0, 0);
-            }
-            if (act1) {
-#pragma unroll
-              for (int t = 0; t < 4; ++t)
-                acc[1][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[t], b[t], acc[1][ct], 0, 0, 0);
-            }
+          for (int t = 0; t < 4; ++t) {
+            acc[0][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[t], b[t], acc[0][ct], 0, 0, 0);
+            acc[1][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[t], b[t], acc[1][ct], 0, 0, 0);
           }
         }
       }
-      __syncthreads();
+    } else if (act0) {
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        const f32x4 a0 = *(const f32x4*)(Ab + (s ? p1 : p0));
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct) {
+          const f32x4 b = *(const f32x4*)(Wb + (s * NCT + ct) * 256);
+#pragma unroll
+          for (int t = 0; t < 4; ++t)
+            acc[0][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[t], b[t], acc[0][ct], 0, 0, 0);
+        }
+      }
+    } else if (act1) {
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        const f32x4 a1 = *(const f32x4*)(Ab + 16 * 32 + (s ? p1 : p0));
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct) {
+          const f32x4 b = *(const f32x4*)(Wb + (s * NCT + ct) * 256);
+#pragma unroll
+          for (int t = 0; t < 4; ++t)
+            acc[1][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[t], b[t], acc[1][ct], 0, 0, 0);
+        }
+      }
     }
+    k_cur = k_nxt;
+    c_cur = c_nxt;
+    buf ^= 1;
   }
 
   // ---- epilogue.  C/D layout of 16x16x4: column = lane & 15, row = 4 * (lane >> 4) + reg
@@ -329,12 +370,23 @@ static ConvPlan plan_conv(int n_rows, int K, int cin, int cout) {
   }
   p.kper = (K + ksplit - 1) / ksplit;
   p.ksplit = (K + p.kper - 1) / p.kper;
-  p.lds = (size_t)(128 * 32 + 2 * (bn / 16) * 256) * 4 + (size_t)p.kper * 128 * 4;
+  p.lds = (size_t)2 * (128 * 32 + 2 * (bn / 16) * 256) * 4 + (size_t)p.kper * 128 * 4;
   p.partial_floats = p.ksplit > 1 ? (size_t)p.ksplit * p.ntile * 128 * cout : 0;
   return p;
 }
 
+static void allow_big_lds() {
+  static bool done = false;
+  if (done) return;
+  done = true;
+  (void)hipFuncSetAttribute((const void*)k_spconv<32>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  (void)hipFuncSetAttribute((const void*)k_spconv<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  (void)hipFuncSetAttribute((const void*)k_spconv<96>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  (void)hipFuncSetAttribute((const void*)k_spconv<128>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+}
+
 static int launch_conv(ConvArgs a, float* partial_ws, size_t partial_ws_floats, hipStream_t st) {
+  allow_big_lds();
   if (a.cin % 32 != 0 || a.cout % 16 != 0 || !(a.cout % 128 == 0 || a.cout == 32 || a.cout == 64 || a.cout == 96)) {
     set_error("spconv: unsupported channels cin=%d cout=%d", a.cin, a.cout);
     return A3D_ERR_UNSUPPORTED;
