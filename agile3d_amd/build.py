@@ -32,7 +32,10 @@ def build(force: bool = False, verbose: bool = True):
     procs = []
     for src in SOURCES:
         obj = os.path.join(CSRC, src.replace(".hip", ".o"))
-        cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-c",
+        # -amdgpu-mfma-vgpr-form: keep MFMA accumulators in VGPRs.  Without it hipcc runs the MFMAs in
+        # AGPR form but keeps the loop-carried accumulators in VGPRs, copying all of them in and out
+        # (v_accvgpr_write/read + hazard nops + an MFMA pipeline drain) every stage: 2x slower.
+        cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-mllvm", "-amdgpu-mfma-vgpr-form", "-c",
                os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)

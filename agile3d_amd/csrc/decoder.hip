@@ -645,16 +645,20 @@ extern "C" int a3d_decoder_build_cache(const a3d_decoder_weights* w, const float
     return A3D_ERR_INVALID;
   }
   const size_t one = align256((size_t)n * D * 4);
+  const bool have_q = workspace_dev && workspace_bytes >= (size_t)2 * A3D_MAX_DEC_LAYERS * 512;
+  if (have_q) A3D_HIP_CHECK(hipMemsetAsync(workspace_dev, 0, (size_t)2 * A3D_MAX_DEC_LAYERS * 512, (hipStream_t)stream));
   for (int l = 0; l < w->n_layers; ++l) {
     const a3d_decoder_layer& L = w->layers[l];
+    char* q0 = have_q ? (char*)workspace_dev + (size_t)(2 * l) * 512 : nullptr;
+    char* q1 = have_q ? (char*)workspace_dev + (size_t)(2 * l + 1) * 512 : nullptr;
     float* posk = (float*)((char*)cache_dev + (size_t)(2 * l) * one);
     float* posq = (float*)((char*)cache_dev + (size_t)(2 * l + 1) * one);
     // pos @ Wk^T + bk   (bias rows D..2D of in_proj_bias) ; pos @ Wq^T + bq (rows 0..D)
     rc = a3d_linear(posenc_dev, D, n, D, D, L.c2s_wk_packed, nullptr, L.c2s_in_b + D, nullptr, 0, 0, posk, D,
-                    workspace_dev, workspace_bytes, stream);
+                    q0, q0 ? 512 : 0, stream);
     if (rc) return rc;
     rc = a3d_linear(posenc_dev, D, n, D, D, L.s2c_wq_packed, nullptr, L.s2c_in_b, nullptr, 0, 0, posq, D,
-                    workspace_dev, workspace_bytes, stream);
+                    q1, q1 ? 512 : 0, stream);
     if (rc) return rc;
   }
   return A3D_OK;
@@ -662,7 +666,7 @@ extern "C" int a3d_decoder_build_cache(const a3d_decoder_weights* w, const float
 
 namespace {
 struct DecLayout {
-  size_t buf[4], labels, counts, part, meta, q[12], total;
+  size_t buf[4], labels, counts, part, meta, q[12], queues, total;
   int qp, nchunk;
 };
 int round_qp(int nq) { return nq <= 16 ? 16 : nq <= 32 ? 32 : nq <= 48 ? 48 : 64; }
@@ -685,6 +689,7 @@ void dec_layout(int64_t n, int nq, DecLayout& L) {
   L.q[9] = take(2 * qb);                                // qk
   L.q[10] = take(qb);                                   // vc
   L.q[11] = take((size_t)L.qp * 4096 * 4);              // hidden (dim_ff <= 4096)
+  L.queues = take((size_t)A3D_MAX_DEC_LAYERS * 4 * 512); // zeroed tile-queue heads, one slot per GEMM
   L.total = off;
 }
 }  // namespace
@@ -724,6 +729,8 @@ static int run_decoder(const a3d_decoder_weights* w, const float* feats128, cons
   B.vc = (float*)(ws + L.q[10]);
   B.hidden = (float*)(ws + L.q[11]);
   A3D_HIP_CHECK(hipMemcpyAsync(meta, &hm, sizeof(QueryMeta), hipMemcpyHostToDevice, st));
+  char* queues = ws + L.queues;
+  A3D_HIP_CHECK(hipMemsetAsync(queues, 0, (size_t)A3D_MAX_DEC_LAYERS * 4 * 512, st));
   const int n_counts = A3D_MAX_DEC_LAYERS * (A3D_MAX_QUERIES + 1);
   {
   ProfScope ps(st, A3D_PROF_QUERY, 0, 0, 0, 0, nq);
@@ -741,9 +748,9 @@ static int run_decoder(const a3d_decoder_weights* w, const float* feats128, cons
     const float* posq = (const float*)((const char*)cache + (size_t)(2 * l + 1) * one);
     int rc;
     // ---- click-to-scene: K = src Wk^T + (pos Wk^T + bk), V = src Wv^T + bv
-    rc = a3d_linear(src, D, n, D, D, LW.c2s_wk_packed, nullptr, nullptr, posk, D, 0, bufA, D, nullptr, 0, st);
+    rc = a3d_linear(src, D, n, D, D, LW.c2s_wk_packed, nullptr, nullptr, posk, D, 0, bufA, D, queues + (4 * l + 0) * 512, 512, st);
     if (rc) return rc;
-    rc = a3d_linear(src, D, n, D, D, LW.c2s_wv_packed, nullptr, LW.c2s_in_b + 2 * D, nullptr, 0, 0, bufB, D, nullptr, 0, st);
+    rc = a3d_linear(src, D, n, D, D, LW.c2s_wv_packed, nullptr, LW.c2s_in_b + 2 * D, nullptr, 0, 0, bufB, D, queues + (4 * l + 1) * 512, 512, st);
     if (rc) return rc;
     const int* prev_counts = l > 0 ? counts + (size_t)(l - 1) * (A3D_MAX_QUERIES + 1) : nullptr;
     {
@@ -772,7 +779,7 @@ static int run_decoder(const a3d_decoder_weights* w, const float* feats128, cons
     }
     A3D_LAUNCH_CHECK();
     // ---- scene-to-click: Q = src Wq^T + (pos Wq^T + bq); attention; Y = O Wo^T + bo + src; LN
-    rc = a3d_linear(src, D, n, D, D, LW.s2c_wq_packed, nullptr, nullptr, posq, D, 0, bufA, D, nullptr, 0, st);
+    rc = a3d_linear(src, D, n, D, D, LW.s2c_wq_packed, nullptr, nullptr, posq, D, 0, bufA, D, queues + (4 * l + 2) * 512, 512, st);
     if (rc) return rc;
     {
     ProfScope ps(st, A3D_PROF_S2C, 0, 0, 0, 0, n);
@@ -780,7 +787,7 @@ static int run_decoder(const a3d_decoder_weights* w, const float* feats128, cons
     }
     A3D_LAUNCH_CHECK();
     float* Y = (l & 1) ? bufD : bufC;
-    rc = a3d_linear(bufB, D, n, D, D, LW.s2c_wo_packed, nullptr, LW.s2c_out_b, src, D, 0, Y, D, nullptr, 0, st);
+    rc = a3d_linear(bufB, D, n, D, D, LW.s2c_wo_packed, nullptr, LW.s2c_out_b, src, D, 0, Y, D, queues + (4 * l + 3) * 512, 512, st);
     if (rc) return rc;
     {
     ProfScope ps(st, A3D_PROF_LNMASK, 0, 0, 0, 0, n);

@@ -23,6 +23,7 @@
 //     group g, MFMA t) identically for A and B, so one ds_read_b128 feeds four MFMAs;
 //   * BatchNorm(eval) scale/shift, residual, ReLU and the channel-slice concat are the epilogue.
 #include "common.h"
+#include <stdlib.h>
 
 namespace a3d {
 
@@ -48,6 +49,9 @@ struct ConvArgs {
   int kper;
   int zero_row;
   int tag_table, tag_level;   // profiling only
+  int* tile_counter;          // per (cout tile, k split) queue heads, zeroed by the caller; nullptr = static
+  int n_tiles;
+  int dbg;                    // ablation switches (A3D_DBG env): 1 = no A gather, 2 = no W load, 4 = no MFMA
 };
 
 __device__ __forceinline__ void glds16(const float* src, float* lds_base) {
@@ -55,189 +59,164 @@ __device__ __forceinline__ void glds16(const float* src, float* lds_base) {
                                    (__attribute__((address_space(3))) void*)lds_base, 16, 0, 0);
 }
 
+constexpr int kConvTile = 64;   // output rows per tile: 4 waves x one 16-row MFMA group
+
 template <int BN>
 __global__ void __launch_bounds__(256) k_spconv(const ConvArgs a) {
   constexpr int NCT = BN / 16;
-  constexpr int A_FLOATS = 128 * 32;        // [128 rows][32 ch], 16-byte pieces XOR-swizzled by row&7
+  constexpr int A_FLOATS = kConvTile * 32;  // [64 rows][32 ch], 16-byte pieces XOR-swizzled by row&7
   constexpr int W_FLOATS = 2 * NCT * 256;   // [2 steps][NCT][64 lanes][4]
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* A_lds = (float*)smem;                       // 2 stage buffers
   float* W_lds = A_lds + 2 * A_FLOATS;               // 2 stage buffers
-  int* idx_lds = (int*)(W_lds + 2 * W_FLOATS);       // [kper][128]
+  int* idx_lds = (int*)(W_lds + 2 * W_FLOATS);       // [kper][64]
+  int* tile_slot = idx_lds + a.kper * kConvTile;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int g = lane >> 4, j = lane & 15;
-  const int r0 = blockIdx.x * 128;
   const int ct0 = blockIdx.y * NCT;
   const int kbeg = blockIdx.z * a.kper;
   const int kend = min(a.K, kbeg + a.kper);
-
-  // ---- which offsets does this tile / this wave's two groups need
-  uint32_t un = 0, gm0, gm1;
-  if (a.gmask) {
-    const uint32_t* gp = a.gmask + (r0 >> 4);
-#pragma unroll
-    for (int i = 0; i < 8; ++i) un |= gp[i];
-    gm0 = gp[2 * wave];
-    gm1 = gp[2 * wave + 1];
-  } else {
-    un = gm0 = gm1 = 0xffffffffu;
-  }
-  un = __builtin_amdgcn_readfirstlane(un);
-  gm0 = __builtin_amdgcn_readfirstlane(gm0);
-  gm1 = __builtin_amdgcn_readfirstlane(gm1);
-
-  // ---- neighbour rows of the tile for every offset of this split
-  for (int e = tid; e < (kend - kbeg) * 128; e += 256) {
-    const int kk = e >> 7, r = e & 127;
-    int v;
-    if (a.nbr) {
-      v = a.nbr[(size_t)(kbeg + kk) * a.nbr_stride + r0 + r];
-    } else {
-      v = r0 + r;
-      if (v >= a.n_in) v = a.n_in - 1;
-    }
-    idx_lds[e] = v;
-  }
-  __syncthreads();
-
-  f32x4 acc[2][NCT];
-#pragma unroll
-  for (int G = 0; G < 2; ++G)
-#pragma unroll
-    for (int ct = 0; ct < NCT; ++ct) acc[G][ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
   const int nchunk = a.cin >> 5;
   const int cin16 = a.cin >> 4, cout16 = a.cout >> 4;
   const int swz = lane >> 3;  // == (row & 7) for the staging lanes
+  int* counter = a.tile_counter ? a.tile_counter + (blockIdx.y * gridDim.z + blockIdx.z) : nullptr;
 
-  // DMA one stage = (offset k, 32-channel slice c) into stage buffer `buf`
-  auto issue = [&](int k, int c, int buf) {
-    const bool act0 = (gm0 >> k) & 1u, act1 = (gm1 >> k) & 1u;
-    const int* idxk = idx_lds + (k - kbeg) * 128;
-    float* Ab = A_lds + buf * A_FLOATS;
-    float* Wb = W_lds + buf * W_FLOATS;
-    int src_row[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) src_row[i] = idxk[32 * wave + 8 * i + swz];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {   // the wave's own 32 gathered rows: 4 x 1 KiB
-      const bool act = (i < 2) ? act0 : act1;
-      if (act) {
-        const float* src = a.in + (size_t)src_row[i] * a.ldi + c * 32 + 4 * ((lane & 7) ^ swz);
-        glds16(src, Ab + (32 * wave + 8 * i) * 32);
+  for (int tile = blockIdx.x;; tile += gridDim.x) {
+    // ---- persistent blocks pull 64-row tiles from a queue (static stride when no counter given)
+    if (counter) {
+      if (tid == 0) *tile_slot = atomicAdd(counter, 1);
+      __syncthreads();
+      tile = *tile_slot;
+    }
+    if (tile >= a.n_tiles) break;
+    const int r0 = tile * kConvTile;
+
+    // ---- which offsets does this tile / this wave's group need
+    uint32_t un, gm;
+    if (a.gmask) {
+      const uint32_t* gp = a.gmask + (r0 >> 4);
+      un = gp[0] | gp[1] | gp[2] | gp[3];
+      gm = gp[wave];
+    } else {
+      un = gm = 0xffffffffu;
+    }
+    un = __builtin_amdgcn_readfirstlane(un);
+    gm = __builtin_amdgcn_readfirstlane(gm);
+
+    // ---- neighbour rows of the tile for every offset of this split
+#pragma unroll 4
+    for (int e = tid; e < (kend - kbeg) * kConvTile; e += 256) {
+      const int kk = e >> 6, r = e & 63;
+      int v;
+      if (a.nbr) {
+        v = a.nbr[(size_t)(kbeg + kk) * a.nbr_stride + r0 + r];
+      } else {
+        v = r0 + r;
+        if (v >= a.n_in) v = a.n_in - 1;
       }
+      idx_lds[e] = v;
     }
-    for (int q = wave; q < 2 * NCT; q += 4) {   // weight slice, already in fragment order
-      const int s = q / NCT, ctl = q - s * NCT;
-      const float* src = a.w + (((size_t)k * cin16 + (2 * c + s)) * cout16 + ct0 + ctl) * 256 + lane * 4;
-      glds16(src, Wb + q * 256);
-    }
-  };
-  auto next_k = [&](int k) {
-    ++k;
-    while (k < kend && !((un >> k) & 1u)) ++k;
-    return k;
-  };
-
-  int k_cur = next_k(kbeg - 1), c_cur = 0, buf = 0;
-  if (k_cur < kend) issue(k_cur, 0, 0);
-  while (k_cur < kend) {
-    int k_nxt = k_cur, c_nxt = c_cur + 1;
-    if (c_nxt == nchunk) {
-      c_nxt = 0;
-      k_nxt = next_k(k_cur);
-    }
-    // stage (k_cur, c_cur) has landed for every wave; every wave is done reading the other buffer
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (k_nxt < kend) issue(k_nxt, c_nxt, buf ^ 1);
-    const bool act0 = (gm0 >> k_cur) & 1u, act1 = (gm1 >> k_cur) & 1u;
-    const float* Ab = A_lds + buf * A_FLOATS + (32 * wave + j) * 32;
-    const float* Wb = W_lds + buf * W_FLOATS + lane * 4;
-    const int p0 = ((0 + g) ^ (j & 7)) * 4, p1 = ((4 + g) ^ (j & 7)) * 4;
-    if (act0 && act1) {
-#pragma unroll
-      for (int s = 0; s < 2; ++s) {
-        const f32x4 a0 = *(const f32x4*)(Ab + (s ? p1 : p0));
-        const f32x4 a1 = *(const f32x4*)(Ab + 16 * 32 + (s ? p1 : p0));
-#pragma unroll
-        for (int ct = 0; ct < NCT; ++ct) {
-          const f32x4 b = *(const f32x4*)(Wb + (s * NCT + ct) * 256);
-#pragma unroll
-          for (int t = 0; t < 4; ++t) {
-            acc[0][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[t], b[t], acc[0][ct], 0, 0, 0);
-            acc[1][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[t], b[t], acc[1][ct], 0, 0, 0);
-          }
-        }
-      }
-    } else if (act0) {
-#pragma unroll
-      for (int s = 0; s < 2; ++s) {
-        const f32x4 a0 = *(const f32x4*)(Ab + (s ? p1 : p0));
-#pragma unroll
-        for (int ct = 0; ct < NCT; ++ct) {
-          const f32x4 b = *(const f32x4*)(Wb + (s * NCT + ct) * 256);
-#pragma unroll
-          for (int t = 0; t < 4; ++t)
-            acc[0][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[t], b[t], acc[0][ct], 0, 0, 0);
-        }
-      }
-    } else if (act1) {
-#pragma unroll
-      for (int s = 0; s < 2; ++s) {
-        const f32x4 a1 = *(const f32x4*)(Ab + 16 * 32 + (s ? p1 : p0));
-#pragma unroll
-        for (int ct = 0; ct < NCT; ++ct) {
-          const f32x4 b = *(const f32x4*)(Wb + (s * NCT + ct) * 256);
-#pragma unroll
-          for (int t = 0; t < 4; ++t)
-            acc[1][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[t], b[t], acc[1][ct], 0, 0, 0);
-        }
-      }
-    }
-    k_cur = k_nxt;
-    c_cur = c_nxt;
-    buf ^= 1;
-  }
 
-  // ---- epilogue.  C/D layout of 16x16x4: column = lane & 15, row = 4 * (lane >> 4) + reg
-  if (a.partial) {
-    float* P = a.partial + (size_t)blockIdx.z * ((size_t)gridDim.x * 128) * a.cout;
+    f32x4 acc[NCT];
 #pragma unroll
-    for (int G = 0; G < 2; ++G)
+    for (int ct = 0; ct < NCT; ++ct) acc[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // DMA one stage = (offset k, 32-channel slice c) into stage buffer `buf`
+    auto issue = [&](int k, int c, int buf) {
+      const bool act = (gm >> k) & 1u;
+      const int* idxk = idx_lds + (k - kbeg) * kConvTile;
+      float* Ab = A_lds + buf * A_FLOATS;
+      float* Wb = W_lds + buf * W_FLOATS;
+      if (act && !(a.dbg & 1)) {   // the wave's own 16 gathered rows: 2 x 1 KiB
+        const int r_a = idxk[16 * wave + swz], r_b = idxk[16 * wave + 8 + swz];
+        const int coff = c * 32 + 4 * ((lane & 7) ^ swz);
+        glds16(a.in + (size_t)r_a * a.ldi + coff, Ab + (16 * wave) * 32);
+        glds16(a.in + (size_t)r_b * a.ldi + coff, Ab + (16 * wave + 8) * 32);
+      }
+      if (!(a.dbg & 2))
+        for (int q = wave; q < 2 * NCT; q += 4) {   // weight slice, already in fragment order
+          const int s = q / NCT, ctl = q - s * NCT;
+          const float* src = a.w + (((size_t)k * cin16 + (2 * c + s)) * cout16 + ct0 + ctl) * 256 + lane * 4;
+          glds16(src, Wb + q * 256);
+        }
+    };
+    auto next_k = [&](int k) {
+      ++k;
+      while (k < kend && !((un >> k) & 1u)) ++k;
+      return k;
+    };
+
+    int k_cur = next_k(kbeg - 1), c_cur = 0, buf = 0;
+    if (k_cur < kend) issue(k_cur, 0, 0);
+    while (k_cur < kend) {
+      int k_nxt = k_cur, c_nxt = c_cur + 1;
+      if (c_nxt == nchunk) {
+        c_nxt = 0;
+        k_nxt = next_k(k_cur);
+      }
+      // stage (k_cur, c_cur) has landed for every wave; every wave is done reading the other buffer
+      if (!(a.dbg & 8)) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+      }
+      if (k_nxt < kend) issue(k_nxt, c_nxt, buf ^ 1);
+      if (((gm >> k_cur) & 1u) && !(a.dbg & 4)) {
+        const float* Ab = A_lds + buf * A_FLOATS + (16 * wave + j) * 32;
+        const float* Wb = W_lds + buf * W_FLOATS + lane * 4;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+          const f32x4 av = *(const f32x4*)(Ab + ((4 * s + g) ^ (j & 7)) * 4);
+          f32x4 bv[NCT];
+#pragma unroll
+          for (int ct = 0; ct < NCT; ++ct) bv[ct] = *(const f32x4*)(Wb + (s * NCT + ct) * 256);
+#pragma unroll
+          for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct)
+              acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t], bv[ct][t], acc[ct], 0, 0, 0);
+        }
+      }
+      k_cur = k_nxt;
+      c_cur = c_nxt;
+      buf ^= 1;
+    }
+
+    // ---- epilogue.  C/D layout of 16x16x4: column = lane & 15, row = 4 * (lane >> 4) + reg
+    if (a.partial) {
+      float* P = a.partial + (size_t)blockIdx.z * ((size_t)a.n_tiles * kConvTile) * a.cout;
 #pragma unroll
       for (int ct = 0; ct < NCT; ++ct)
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-          const int vrow = r0 + 32 * wave + 16 * G + 4 * g + t;
-          P[(size_t)vrow * a.cout + (ct0 + ct) * 16 + j] = acc[G][ct][t];
+          const int vrow = r0 + 16 * wave + 4 * g + t;
+          P[(size_t)vrow * a.cout + (ct0 + ct) * 16 + j] = acc[ct][t];
         }
-    return;
-  }
+    } else {
 #pragma unroll
-  for (int ct = 0; ct < NCT; ++ct) {
-    const int col = (ct0 + ct) * 16 + j;
-    const float sc = a.scale ? a.scale[col] : 1.f;
-    const float sh = a.shift ? a.shift[col] : 0.f;
+      for (int ct = 0; ct < NCT; ++ct) {
+        const int col = (ct0 + ct) * 16 + j;
+        const float sc = a.scale ? a.scale[col] : 1.f;
+        const float sh = a.shift ? a.shift[col] : 0.f;
 #pragma unroll
-    for (int G = 0; G < 2; ++G)
-#pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        const int vrow = r0 + 32 * wave + 16 * G + 4 * g + t;
-        if (vrow < a.n_out) {
-          const int orow = a.out_map ? a.out_map[vrow] : vrow;
-          float v = acc[G][ct][t] * sc + sh;
-          if (a.res) v += a.res[(size_t)orow * a.ldr + col];
-          if (a.relu) v = fmaxf(v, 0.f);
-          a.out[(size_t)orow * a.ldo + col] = v;
+        for (int t = 0; t < 4; ++t) {
+          const int vrow = r0 + 16 * wave + 4 * g + t;
+          if (vrow < a.n_out) {
+            const int orow = a.out_map ? a.out_map[vrow] : vrow;
+            float v = acc[ct][t] * sc + sh;
+            if (a.res) v += a.res[(size_t)orow * a.ldr + col];
+            if (a.relu) v = fmaxf(v, 0.f);
+            a.out[(size_t)orow * a.ldo + col] = v;
+          }
         }
       }
+      if (a.zero_row >= 0 && tile == 0 && tid < BN) a.out[(size_t)a.zero_row * a.ldo + ct0 * 16 + tid] = 0.f;
+    }
+    __syncthreads();   // all waves are done with the LDS stage buffers / idx table of this tile
   }
-  if (a.zero_row >= 0 && blockIdx.x == 0 && tid < BN)
-    a.out[(size_t)a.zero_row * a.ldo + ct0 * 16 + tid] = 0.f;
 }
 
 // sum the split-K partials and apply the epilogue
@@ -351,27 +330,33 @@ __global__ void k_pack_weight(const float* __restrict__ w, int K, int cin, int c
 
 // ------------------------------------------------------------------------------ host: launch
 struct ConvPlan {
-  int bn, ksplit, kper, ntile;
+  int bn, ksplit, kper, ntile, grid_x;
   size_t lds, partial_floats;
 };
 
+constexpr int kMaxQueuesPerOp = 128;   // cout tiles x k splits
+
 static ConvPlan plan_conv(int n_rows, int K, int cin, int cout) {
   ConvPlan p;
-  p.ntile = (int)((n_rows + 127) / 128);
+  p.ntile = (int)((n_rows + kConvTile - 1) / kConvTile);
   if (p.ntile < 1) p.ntile = 1;
   int bn = (cout % 128 == 0) ? 128 : cout;
-  if (cout % 64 == 0 && (int64_t)p.ntile * (cout / bn) < 128 && bn > 64) bn = 64;
+  if (cout % 64 == 0 && (int64_t)p.ntile * (cout / bn) < 256 && bn > 64) bn = 64;
   p.bn = bn;
   const int blocks = p.ntile * (cout / bn);
   int ksplit = 1;
-  if (K > 1 && blocks < 256) {
-    ksplit = (512 + blocks - 1) / blocks;
+  if (K > 1 && blocks < 512) {
+    ksplit = (768 + blocks - 1) / blocks;
     if (ksplit > K) ksplit = K;
   }
   p.kper = (K + ksplit - 1) / ksplit;
   p.ksplit = (K + p.kper - 1) / p.kper;
-  p.lds = (size_t)2 * (128 * 32 + 2 * (bn / 16) * 256) * 4 + (size_t)p.kper * 128 * 4;
-  p.partial_floats = p.ksplit > 1 ? (size_t)p.ksplit * p.ntile * 128 * cout : 0;
+  p.lds = (size_t)2 * (kConvTile * 32 + 2 * (bn / 16) * 256) * 4 + (size_t)p.kper * kConvTile * 4 + 16;
+  p.partial_floats = p.ksplit > 1 ? (size_t)p.ksplit * p.ntile * kConvTile * cout : 0;
+  const int max_resident = 256 * 3;   // CUs x workgroups per CU
+  int gx = max_resident / ((cout / bn) * p.ksplit);
+  if (gx < 1) gx = 1;
+  p.grid_x = p.ntile < gx ? p.ntile : gx;
   return p;
 }
 
@@ -385,8 +370,16 @@ static void allow_big_lds() {
   (void)hipFuncSetAttribute((const void*)k_spconv<128>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 }
 
-static int launch_conv(ConvArgs a, float* partial_ws, size_t partial_ws_floats, hipStream_t st) {
+static int launch_conv(ConvArgs a, float* partial_ws, size_t partial_ws_floats, int* queue_heads, hipStream_t st) {
   allow_big_lds();
+  {
+    static int dbg = -1;
+    if (dbg < 0) {
+      const char* e = getenv("A3D_DBG");
+      dbg = e ? atoi(e) : 0;
+    }
+    a.dbg = dbg;
+  }
   if (a.cin % 32 != 0 || a.cout % 16 != 0 || !(a.cout % 128 == 0 || a.cout == 32 || a.cout == 64 || a.cout == 96)) {
     set_error("spconv: unsupported channels cin=%d cout=%d", a.cin, a.cout);
     return A3D_ERR_UNSUPPORTED;
@@ -397,7 +390,14 @@ static int launch_conv(ConvArgs a, float* partial_ws, size_t partial_ws_floats, 
   }
   ConvPlan p = plan_conv(a.n_out, a.K, a.cin, a.cout);
   a.kper = p.kper;
+  a.n_tiles = p.ntile;
+  a.tile_counter = nullptr;
   a.partial = nullptr;
+  int grid_x = p.ntile;
+  if (queue_heads && (a.cout / p.bn) * p.ksplit <= kMaxQueuesPerOp && p.grid_x < p.ntile) {
+    a.tile_counter = queue_heads;   // persistent workgroups + dynamic tile queue
+    grid_x = p.grid_x;
+  }
   if (p.ksplit > 1) {
     if (p.partial_floats > partial_ws_floats) {
       set_error("spconv: split-K workspace too small");
@@ -405,7 +405,7 @@ static int launch_conv(ConvArgs a, float* partial_ws, size_t partial_ws_floats, 
     }
     a.partial = partial_ws;
   }
-  dim3 grid(p.ntile, a.cout / p.bn, p.ksplit);
+  dim3 grid(grid_x, a.cout / p.bn, p.ksplit);
   {
   ProfScope ps(st, A3D_PROF_SPCONV, p.bn, a.K, a.cin, a.cout, a.n_out, a.tag_table, a.tag_level, p.ksplit);
   switch (p.bn) {
@@ -422,7 +422,7 @@ static int launch_conv(ConvArgs a, float* partial_ws, size_t partial_ws_floats, 
     const size_t total = (size_t)a.n_out * (a.cout / 4);
     const size_t thr = total > (size_t)a.cout ? total : (size_t)a.cout;
     k_splitk_epilogue<<<(unsigned)((thr + 255) / 256), 256, 0, st>>>(
-        partial_ws, p.ksplit, (size_t)p.ntile * 128 * a.cout, a.n_out, a.cout, a.out_map, a.scale, a.shift,
+        partial_ws, p.ksplit, (size_t)p.ntile * kConvTile * a.cout, a.n_out, a.cout, a.out_map, a.scale, a.shift,
         a.res, a.ldr, a.relu, a.out, a.ldo, a.zero_row);
     A3D_LAUNCH_CHECK();
   }
@@ -432,7 +432,7 @@ static int launch_conv(ConvArgs a, float* partial_ws, size_t partial_ws_floats, 
 // ------------------------------------------------------------------------------ program
 struct ProgLayout {
   size_t buf_off[64];
-  size_t feats4_off, partial_off, partial_floats, total;
+  size_t feats4_off, partial_off, partial_floats, queue_off, total;
 };
 
 static int layout_program(const a3d_scene* s, const a3d_buf_desc* bufs, int n_bufs, const a3d_op* ops,
@@ -469,6 +469,8 @@ static int layout_program(const a3d_scene* s, const a3d_buf_desc* bufs, int n_bu
   L.partial_off = off;
   L.partial_floats = pf;
   off += align256(pf * 4);
+  L.queue_off = off;
+  off += align256((size_t)(n_ops > 0 ? n_ops : 1) * kMaxQueuesPerOp * 4);
   L.total = off;
   return A3D_OK;
 }
@@ -516,6 +518,8 @@ extern "C" int a3d_program_run(const a3d_scene* s, const a3d_buf_desc* bufs, int
   char* ws = (char*)workspace_dev;
   f32x4* feats4 = (f32x4*)(ws + L.feats4_off);
   float* partial = (float*)(ws + L.partial_off);
+  int* queues = (int*)(ws + L.queue_off);
+  A3D_HIP_CHECK(hipMemsetAsync(queues, 0, (size_t)n_ops * kMaxQueuesPerOp * 4, st));
   bool feats_ready = false;
   auto buf_ptr = [&](int id) -> float* { return (float*)(ws + L.buf_off[id]); };
 
@@ -638,7 +642,7 @@ extern "C" int a3d_program_run(const a3d_scene* s, const a3d_buf_desc* bufs, int
         set_error("op %d: unknown kind %d", i, o.kind);
         return A3D_ERR_INVALID;
     }
-    rc = launch_conv(a, partial, L.partial_floats, st);
+    rc = launch_conv(a, partial, L.partial_floats, queues + (size_t)i * kMaxQueuesPerOp, st);
     if (rc != A3D_OK) return rc;
   }
   return A3D_OK;
@@ -647,8 +651,6 @@ extern "C" int a3d_program_run(const a3d_scene* s, const a3d_buf_desc* bufs, int
 extern "C" int a3d_linear(const float* in_dev, int ldi, int64_t n, int cin, int cout, const float* w_packed_dev,
                           const float* scale_dev, const float* shift_dev, const float* res_dev, int ldr, int relu,
                           float* out_dev, int ldo, void* workspace_dev, size_t workspace_bytes, void* stream) {
-  (void)workspace_dev;
-  (void)workspace_bytes;
   if (!in_dev || !out_dev || !w_packed_dev || n <= 0 || n > (int64_t)1 << 30) {
     set_error("a3d_linear: bad arguments");
     return A3D_ERR_INVALID;
@@ -673,5 +675,7 @@ extern "C" int a3d_linear(const float* in_dev, int ldi, int64_t n, int cin, int 
   a.zero_row = -1;
   a.tag_table = A3D_OP_LINEAR;
   a.tag_level = -1;
-  return launch_conv(a, nullptr, 0, (hipStream_t)stream);
+  // workspace (optional): >= 512 bytes of ZEROED memory = the tile queue heads of this call
+  int* queues = (workspace_dev && workspace_bytes >= (size_t)kMaxQueuesPerOp * 4) ? (int*)workspace_dev : nullptr;
+  return launch_conv(a, nullptr, 0, queues, (hipStream_t)stream);
 }

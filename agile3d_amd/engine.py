@@ -375,6 +375,7 @@ class Engine:
             st.ranges = x.batch_ranges()
             st.posenc, st.minmax, st.cache = [], [], []
             tmp = torch.empty(256 * 6 * 4, dtype=torch.uint8, device=self.device)
+            qws = torch.empty(2 * L.A3D_MAX_DEC_LAYERS * 512, dtype=torch.uint8, device=self.device)
             W = self.decoder.W
             for (s, e) in st.ranges:
                 nb = e - s
@@ -384,7 +385,7 @@ class Engine:
                                                _ptr(tmp), tmp.numel(), _stream()), "a3d_posenc_fourier")
                 cb = lib.a3d_decoder_cache_bytes(nb, self.decoder.n_layers)
                 cache = torch.empty(cb, dtype=torch.uint8, device=self.device)
-                L.check(lib.a3d_decoder_build_cache(C.byref(W), _ptr(pe), nb, _ptr(cache), cb, None, 0, _stream()),
+                L.check(lib.a3d_decoder_build_cache(C.byref(W), _ptr(pe), nb, _ptr(cache), cb, _ptr(qws), qws.numel(), _stream()),
                         "a3d_decoder_build_cache")
                 st.posenc.append(pe)
                 st.minmax.append(mm)

@@ -147,7 +147,8 @@ int    a3d_program_run(const a3d_scene* s, const a3d_buf_desc* bufs, int n_bufs,
 
 /* Dense row-major GEMM on the same MFMA kernel: out[n][cout] = act(in[n][cin] @ W + shift + res).
  * Replaces the nn.Linear / in_proj pieces of nn.MultiheadAttention that run over all N points
- * (models/modules/attention_block.py:91-94). */
+ * (models/modules/attention_block.py:91-94).  workspace (optional): >= 512 bytes of ZEROED device
+ * memory used as the dynamic tile queue of this call; NULL = static tile assignment. */
 int a3d_linear(const float* in_dev, int ldi, int64_t n, int cin, int cout,
                const float* w_packed_dev, const float* scale_dev, const float* shift_dev,
                const float* res_dev, int ldr, int relu, float* out_dev, int ldo,
