@@ -51,26 +51,61 @@ struct ConvArgs {
   int tag_table, tag_level;   // profiling only
   int* tile_counter;          // per (cout tile, k split) queue heads, zeroed by the caller; nullptr = static
   int n_tiles;
+  unsigned long long* dbg_cycles;   // [8] phase cycle sums (A3D_DBG & 64)
   int dbg;                    // ablation switches (A3D_DBG env): 1 = no A gather, 2 = no W load, 4 = no MFMA
 };
 
-__device__ __forceinline__ void glds16(const float* src, float* lds_base) {
-  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                   (__attribute__((address_space(3))) void*)lds_base, 16, 0, 0);
+// global -> LDS DMA of 64 x 16 bytes: per-lane SOURCE address, LDS image = uniform base + 16 * lane.
+// Issued through inline asm so that hipcc neither tracks it in its s_waitcnt bookkeeping nor drains
+// it with a vmcnt(0) of its own (cdna_hip_programming.md 5.7): completion is waited for explicitly
+// with counted s_waitcnt vmcnt(N) in the stage loop.  M0 (the LDS base) is saved and restored.
+__device__ __forceinline__ void glds16(const float* src, unsigned lds_byte_addr) {
+  const unsigned lds_addr = __builtin_amdgcn_readfirstlane(lds_byte_addr);
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\t"
+      "s_mov_b32 m0, %2\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %1, off\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(src), "s"(lds_addr)
+      : "memory");
 }
 
-constexpr int kConvTile = 64;   // output rows per tile: 4 waves x one 16-row MFMA group
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
 
-template <int BN>
-__global__ void __launch_bounds__(256) k_spconv(const ConvArgs a) {
+// Geometry is a template parameter: NW waves, GPW 16-row MFMA groups per wave (tile = 16 NW GPW rows;
+// wave w owns groups w, w + NW, ... -- interleaved, so that every wave samples the whole range of
+// neighbour patterns of the pattern-sorted tile) and a ring of DEPTH LDS stage slots.
+//
+// Stage = (kernel offset k, 32-channel slice).  Per stage a wave DMAs the gathered rows of those of
+// its groups that have offset k (2 x 1 KiB each) and its share of the packed weight slice into ring
+// slot (stage % DEPTH); the weight fragments it then reads from LDS are shared by all its groups.
+// Memory latency under load is several times the MFMA time of a stage, so DEPTH-1 stages stay in
+// flight behind a COUNTED s_waitcnt: every wave issues at least WPW_MIN weight pieces per stage,
+// hence "all DMA of stage s has landed" == vmcnt(<= WPW_MIN * stages issued after s).
+template <int BN, int NW, int GPW, int DEPTH>
+__global__ void __launch_bounds__(NW * 64) k_spconv(const ConvArgs a) {
   constexpr int NCT = BN / 16;
-  constexpr int A_FLOATS = kConvTile * 32;  // [64 rows][32 ch], 16-byte pieces XOR-swizzled by row&7
-  constexpr int W_FLOATS = 2 * NCT * 256;   // [2 steps][NCT][64 lanes][4]
+  constexpr int NG = NW * GPW;                   // row groups per tile
+  constexpr int kConvTile = 16 * NG;
+  constexpr int NT = NW * 64;
+  constexpr int WPW = (2 * NCT + NW - 1) / NW;   // weight pieces (1 KiB) per wave per stage, upper bound
+  constexpr int WPW_MIN = 2 * NCT / NW;          // ... lower bound (what a counted wait may rely on)
+  constexpr int A_FLOATS = kConvTile * 32;       // [rows][32 ch], 16-byte pieces XOR-swizzled by row&7
+  constexpr int W_FLOATS = 2 * NCT * 256;        // [2 steps][NCT][64 lanes][4]
+  constexpr int S_FLOATS = A_FLOATS + W_FLOATS;
+  constexpr int NP = WPW + 2 * GPW;              // DMA pieces per wave per stage (fixed slots)
+  static_assert(NP <= 8 * GPW, "more DMA pieces than MFMA groups to hide them behind");
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  float* A_lds = (float*)smem;                       // 2 stage buffers
-  float* W_lds = A_lds + 2 * A_FLOATS;               // 2 stage buffers
-  int* idx_lds = (int*)(W_lds + 2 * W_FLOATS);       // [kper][64]
+  float* ring = (float*)smem;                              // DEPTH slots of [A | W]
+  int* idx_lds = (int*)(ring + DEPTH * S_FLOATS);          // [kper][kConvTile]
   int* tile_slot = idx_lds + a.kper * kConvTile;
+  const unsigned ring_addr = (unsigned)(size_t)ring;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -83,9 +118,36 @@ __global__ void __launch_bounds__(256) k_spconv(const ConvArgs a) {
   const int cin16 = a.cin >> 4, cout16 = a.cout >> 4;
   const int swz = lane >> 3;  // == (row & 7) for the staging lanes
   int* counter = a.tile_counter ? a.tile_counter + (blockIdx.y * gridDim.z + blockIdx.z) : nullptr;
+  // weight slice of a stage = pieces q = 0..2*NCT-1; piece q sits at float offset
+  // (q < NCT ? q : q - NCT + cout16) * 256 from the stage base.  Wave w copies pieces w, w+NW, ...
+  int woff[WPW];
+#pragma unroll
+  for (int i = 0; i < WPW; ++i) {
+    const int q = wave + NW * i;
+    woff[i] = (q < NCT ? q : q - NCT + cout16) * 256;
+  }
+  const float* wlane = a.w + (size_t)ct0 * 256 + lane * 4;
+  const size_t wstride_k = (size_t)cin16 * cout16 * 256, wstride_c = (size_t)2 * cout16 * 256;
+  const int a_lane_off = 4 * ((lane & 7) ^ swz);   // source-side swizzle of the 16-byte piece
 
+  const bool timing = (a.dbg & 64) && a.dbg_cycles;
+  unsigned long long tc[6] = {0, 0, 0, 0, 0, 0};
+  unsigned long long t_prev = timing ? __builtin_amdgcn_s_memtime() : 0;
+  const bool tracing = (a.dbg & 128) && a.dbg_cycles && blockIdx.x == 7 && blockIdx.y == 0 && blockIdx.z == 0;
+  int trace_n = 0;
+  auto lap = [&](int slot) {
+    if (timing) {
+      const unsigned long long t = __builtin_amdgcn_s_memtime();
+      tc[slot] += t - t_prev;
+      t_prev = t;
+    }
+    if (tracing && lane == 0 && trace_n < 64 * 6) {
+      a.dbg_cycles[16 + (wave * 64 * 6) + trace_n] = __builtin_amdgcn_s_memtime();
+      ++trace_n;
+    }
+  };
   for (int tile = blockIdx.x;; tile += gridDim.x) {
-    // ---- persistent blocks pull 64-row tiles from a queue (static stride when no counter given)
+    // ---- persistent workgroups pull tiles from a queue (static stride without a counter)
     if (counter) {
       if (tid == 0) *tile_slot = atomicAdd(counter, 1);
       __syncthreads();
@@ -94,22 +156,24 @@ __global__ void __launch_bounds__(256) k_spconv(const ConvArgs a) {
     if (tile >= a.n_tiles) break;
     const int r0 = tile * kConvTile;
 
-    // ---- which offsets does this tile / this wave's group need
-    uint32_t un, gm;
+    // ---- which offsets does the tile / each of this wave's groups need
+    uint32_t un = 0xffffffffu, gm[GPW];
+#pragma unroll
+    for (int G = 0; G < GPW; ++G) gm[G] = 0xffffffffu;
     if (a.gmask) {
       const uint32_t* gp = a.gmask + (r0 >> 4);
-      un = gp[0] | gp[1] | gp[2] | gp[3];
-      gm = gp[wave];
-    } else {
-      un = gm = 0xffffffffu;
+      un = 0;
+#pragma unroll
+      for (int i = 0; i < NG; ++i) un |= gp[i];
+#pragma unroll
+      for (int G = 0; G < GPW; ++G) gm[G] = __builtin_amdgcn_readfirstlane(gp[wave + NW * G]);
     }
     un = __builtin_amdgcn_readfirstlane(un);
-    gm = __builtin_amdgcn_readfirstlane(gm);
 
     // ---- neighbour rows of the tile for every offset of this split
 #pragma unroll 4
-    for (int e = tid; e < (kend - kbeg) * kConvTile; e += 256) {
-      const int kk = e >> 6, r = e & 63;
+    for (int e = tid; e < (kend - kbeg) * kConvTile; e += NT) {
+      const int kk = e / kConvTile, r = e % kConvTile;
       int v;
       if (a.nbr) {
         v = a.nbr[(size_t)(kbeg + kk) * a.nbr_stride + r0 + r];
@@ -120,102 +184,240 @@ __global__ void __launch_bounds__(256) k_spconv(const ConvArgs a) {
       idx_lds[e] = v;
     }
     __syncthreads();
+    lap(0);   // queue + masks + idx table
 
-    f32x4 acc[NCT];
+    f32x4 acc[GPW][NCT];
 #pragma unroll
-    for (int ct = 0; ct < NCT; ++ct) acc[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int G = 0; G < GPW; ++G)
+#pragma unroll
+      for (int ct = 0; ct < NCT; ++ct) acc[G][ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    // DMA one stage = (offset k, 32-channel slice c) into stage buffer `buf`
-    auto issue = [&](int k, int c, int buf) {
-      const bool act = (gm >> k) & 1u;
-      const int* idxk = idx_lds + (k - kbeg) * kConvTile;
-      float* Ab = A_lds + buf * A_FLOATS;
-      float* Wb = W_lds + buf * W_FLOATS;
-      if (act && !(a.dbg & 1)) {   // the wave's own 16 gathered rows: 2 x 1 KiB
-        const int r_a = idxk[16 * wave + swz], r_b = idxk[16 * wave + 8 + swz];
-        const int coff = c * 32 + 4 * ((lane & 7) ^ swz);
-        glds16(a.in + (size_t)r_a * a.ldi + coff, Ab + (16 * wave) * 32);
-        glds16(a.in + (size_t)r_b * a.ldi + coff, Ab + (16 * wave + 8) * 32);
-      }
-      if (!(a.dbg & 2))
-        for (int q = wave; q < 2 * NCT; q += 4) {   // weight slice, already in fragment order
-          const int s = q / NCT, ctl = q - s * NCT;
-          const float* src = a.w + (((size_t)k * cin16 + (2 * c + s)) * cout16 + ct0 + ctl) * 256 + lane * 4;
-          glds16(src, Wb + q * 256);
-        }
-    };
     auto next_k = [&](int k) {
       ++k;
       while (k < kend && !((un >> k) & 1u)) ++k;
       return k;
     };
-
-    int k_cur = next_k(kbeg - 1), c_cur = 0, buf = 0;
-    if (k_cur < kend) issue(k_cur, 0, 0);
-    while (k_cur < kend) {
-      int k_nxt = k_cur, c_nxt = c_cur + 1;
-      if (c_nxt == nchunk) {
-        c_nxt = 0;
-        k_nxt = next_k(k_cur);
-      }
-      // stage (k_cur, c_cur) has landed for every wave; every wave is done reading the other buffer
-      if (!(a.dbg & 8)) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-      }
-      if (k_nxt < kend) issue(k_nxt, c_nxt, buf ^ 1);
-      if (((gm >> k_cur) & 1u) && !(a.dbg & 4)) {
-        const float* Ab = A_lds + buf * A_FLOATS + (16 * wave + j) * 32;
-        const float* Wb = W_lds + buf * W_FLOATS + lane * 4;
+    // ---- issue iterator (runs DEPTH-1 stages ahead of the compute iterator)
+    int ki = next_k(kbeg - 1), ci = 0, slot_i = 0;
+    const float *pa[GPW], *pb[GPW];   // this lane's gathered-row sources for offset ki, per group
+    bool acti[GPW];
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
-          const f32x4 av = *(const f32x4*)(Ab + ((4 * s + g) ^ (j & 7)) * 4);
-          f32x4 bv[NCT];
-#pragma unroll
-          for (int ct = 0; ct < NCT; ++ct) bv[ct] = *(const f32x4*)(Wb + (s * NCT + ct) * 256);
-#pragma unroll
-          for (int t = 0; t < 4; ++t)
-#pragma unroll
-            for (int ct = 0; ct < NCT; ++ct)
-              acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t], bv[ct][t], acc[ct], 0, 0, 0);
-        }
-      }
-      k_cur = k_nxt;
-      c_cur = c_nxt;
-      buf ^= 1;
+    for (int G = 0; G < GPW; ++G) {
+      pa[G] = pb[G] = a.in;
+      acti[G] = false;
     }
-
-    // ---- epilogue.  C/D layout of 16x16x4: column = lane & 15, row = 4 * (lane >> 4) + reg
-    if (a.partial) {
-      float* P = a.partial + (size_t)blockIdx.z * ((size_t)a.n_tiles * kConvTile) * a.cout;
+    auto enter_k = [&]() {
+      if (ki < kend) {
 #pragma unroll
-      for (int ct = 0; ct < NCT; ++ct)
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-          const int vrow = r0 + 16 * wave + 4 * g + t;
-          P[(size_t)vrow * a.cout + (ct0 + ct) * 16 + j] = acc[ct][t];
-        }
-    } else {
-#pragma unroll
-      for (int ct = 0; ct < NCT; ++ct) {
-        const int col = (ct0 + ct) * 16 + j;
-        const float sc = a.scale ? a.scale[col] : 1.f;
-        const float sh = a.shift ? a.shift[col] : 0.f;
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-          const int vrow = r0 + 16 * wave + 4 * g + t;
-          if (vrow < a.n_out) {
-            const int orow = a.out_map ? a.out_map[vrow] : vrow;
-            float v = acc[ct][t] * sc + sh;
-            if (a.res) v += a.res[(size_t)orow * a.ldr + col];
-            if (a.relu) v = fmaxf(v, 0.f);
-            a.out[(size_t)orow * a.ldo + col] = v;
+        for (int G = 0; G < GPW; ++G) {
+          acti[G] = ((gm[G] >> ki) & 1u) && !(a.dbg & 1);
+          if (acti[G]) {
+            const int* idxk = idx_lds + (ki - kbeg) * kConvTile + 16 * (wave + NW * G) + swz;
+            pa[G] = a.in + (size_t)idxk[0] * a.ldi + a_lane_off;
+            pb[G] = a.in + (size_t)idxk[8] * a.ldi + a_lane_off;
           }
         }
       }
-      if (a.zero_row >= 0 && tile == 0 && tid < BN) a.out[(size_t)a.zero_row * a.ldo + ct0 * 16 + tid] = 0.f;
+    };
+    // The DMA of one stage is prepared (addresses) and fired piece by piece so that, on a wave that
+    // has MFMAs to do, the pieces are issued in the shadow of the MFMAs instead of in front of them.
+    const float* psrc[NP];
+    unsigned pdst[NP];               // LDS byte addresses
+    unsigned pmask = 0;              // which of the NP fixed slots hold a piece for the prepared stage
+    auto prepare = [&]() {           // stage (ki, ci) -> ring slot slot_i; advances the issue iterator
+      const unsigned Ab = ring_addr + (unsigned)(slot_i * S_FLOATS) * 4u;
+      const unsigned Wb = Ab + A_FLOATS * 4u;
+      const float* wst = wlane + (size_t)ki * wstride_k + (size_t)ci * wstride_c;
+      pmask = 0;
+#pragma unroll
+      for (int i = 0; i < WPW; ++i) {
+        psrc[i] = wst + woff[i];
+        pdst[i] = Wb + (unsigned)(wave + NW * i) * 1024u;
+        if (wave + NW * i < 2 * NCT) pmask |= 1u << i;
+      }
+#pragma unroll
+      for (int G = 0; G < GPW; ++G) {
+        psrc[WPW + 2 * G] = pa[G] + ci * 32;
+        pdst[WPW + 2 * G] = Ab + (unsigned)(16 * (wave + NW * G)) * 128u;
+        psrc[WPW + 2 * G + 1] = pb[G] + ci * 32;
+        pdst[WPW + 2 * G + 1] = Ab + (unsigned)(16 * (wave + NW * G) + 8) * 128u;
+        if (acti[G]) pmask |= 3u << (WPW + 2 * G);
+      }
+      slot_i = slot_i + 1 == DEPTH ? 0 : slot_i + 1;
+      if (++ci == nchunk) {
+        ci = 0;
+        ki = next_k(ki);
+        enter_k();
+      }
+    };
+    auto fire = [&](int i) {
+      if ((pmask >> i) & 1u) glds16(psrc[i], pdst[i]);
+    };
+    auto issue_one = [&]() {
+      prepare();
+#pragma unroll
+      for (int i = 0; i < NP; ++i) fire(i);
+    };
+    enter_k();
+    int ahead = 0;   // stages issued but not yet computed
+    while (ahead < DEPTH - 1 && ki < kend) {
+      issue_one();
+      ++ahead;
     }
-    __syncthreads();   // all waves are done with the LDS stage buffers / idx table of this tile
+
+    // ---- compute iterator
+    int kc = next_k(kbeg - 1), cc = 0, slot_c = 0;
+    while (kc < kend) {
+      lap(1);   // loop control
+      // stage (kc, cc) must have landed: leave only the younger stages' weight pieces in flight
+      if (DEPTH >= 3 && WPW_MIN >= 1 && ahead >= 2) wait_vmcnt<(DEPTH >= 3 ? WPW_MIN : 0)>(); else wait_vmcnt<0>();
+      __builtin_amdgcn_s_barrier();
+      lap(2);   // wait + barrier
+      // every wave has left the slot computed one iteration ago: it is refilled while this stage runs
+      bool actc[GPW], any = false;
+#pragma unroll
+      for (int G = 0; G < GPW; ++G) {
+        actc[G] = ((gm[G] >> kc) & 1u) && !(a.dbg & 4);
+        any |= actc[G];
+      }
+      const bool have_next = ki < kend;
+      if (any) {
+        // fragments first (their LDS latency hides under the address work of prepare()) ...
+        const float* Abase = ring + slot_c * S_FLOATS;
+        const float* Wb = Abase + A_FLOATS + lane * 4;
+        f32x4 av[GPW][2], bv[2][NCT];
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+#pragma unroll
+          for (int G = 0; G < GPW; ++G)
+            if (actc[G]) av[G][s] = *(const f32x4*)(Abase + (16 * (wave + NW * G) + j) * 32 + ((4 * s + g) ^ (j & 7)) * 4);
+#pragma unroll
+          for (int ct = 0; ct < NCT; ++ct) bv[s][ct] = *(const f32x4*)(Wb + (s * NCT + ct) * 256);
+        }
+        if (have_next) {
+          prepare();
+          ++ahead;
+          if (a.dbg & 16) {   // A/B switch: fire the whole stage up front instead of between MFMAs
+#pragma unroll
+            for (int i = 0; i < NP; ++i) fire(i);
+            pmask = 0;
+          }
+        } else {
+          pmask = 0;
+        }
+        lap(3);   // fragment reads issued + next stage prepared
+        // ... then the MFMAs, one DMA piece fired after each block of NCT MFMAs
+        int fired = 0;
+#pragma unroll
+        for (int G = 0; G < GPW; ++G) {
+          if (actc[G]) {
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+              for (int t = 0; t < 4; ++t) {
+#pragma unroll
+                for (int ct = 0; ct < NCT; ++ct)
+                  acc[G][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[G][s][t], bv[s][ct][t], acc[G][ct], 0, 0, 0);
+                if (G * 8 + s * 4 + t < NP) {
+                  __builtin_amdgcn_sched_barrier(0);
+                  fire(G * 8 + s * 4 + t);
+                  __builtin_amdgcn_sched_barrier(0);
+                }
+              }
+            fired = (G + 1) * 8;
+          } else {
+#pragma unroll
+            for (int i = G * 8; i < (G + 1) * 8; ++i)
+              if (i < NP) fire(i);
+          }
+        }
+        (void)fired;
+      } else {
+        if (have_next) {
+          issue_one();
+          ++ahead;
+        }
+        lap(3);
+      }
+      lap(4);   // fragment reads + MFMA
+      --ahead;
+      slot_c = slot_c + 1 == DEPTH ? 0 : slot_c + 1;
+      if (++cc == nchunk) {
+        cc = 0;
+        kc = next_k(kc);
+      }
+    }
+
+    // ---- epilogue.  C/D layout of 16x16x4: column = lane & 15, row = 4 * (lane >> 4) + reg.
+    // All loads (row map, scale/shift, residual) are issued as batches before anything is stored.
+#pragma unroll
+    for (int G = 0; G < GPW; ++G) {
+      const int rg = r0 + 16 * (wave + NW * G) + 4 * g;
+      if (a.partial) {
+        float* P = a.partial + (size_t)blockIdx.z * ((size_t)a.n_tiles * kConvTile) * a.cout;
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+          for (int t = 0; t < 4; ++t) P[(size_t)(rg + t) * a.cout + (ct0 + ct) * 16 + j] = acc[G][ct][t];
+      } else {
+        // rows past the end are clamped for the LOADS (always a valid address -> no per-element
+        // predication, the loads issue back to back) and predicated only for the stores
+        int orow[4];
+        bool ok[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          ok[t] = rg + t < a.n_out;
+          orow[t] = ok[t] ? rg + t : a.n_out - 1;
+        }
+        if (a.out_map) {
+#pragma unroll
+          for (int t = 0; t < 4; ++t) orow[t] = a.out_map[orow[t]];
+        }
+        float sc[NCT], sh[NCT];
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct) {
+          const int col = (ct0 + ct) * 16 + j;
+          sc[ct] = a.scale ? a.scale[col] : 1.f;
+          sh[ct] = a.shift ? a.shift[col] : 0.f;
+        }
+        if (a.res) {
+          float rv[NCT][4];
+#pragma unroll
+          for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) rv[ct][t] = a.res[(size_t)orow[t] * a.ldr + (ct0 + ct) * 16 + j];
+#pragma unroll
+          for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) acc[G][ct][t] = acc[G][ct][t] * sc[ct] + sh[ct] + rv[ct][t];
+        } else {
+#pragma unroll
+          for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) acc[G][ct][t] = acc[G][ct][t] * sc[ct] + sh[ct];
+        }
+        if (a.relu) {
+#pragma unroll
+          for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) acc[G][ct][t] = fmaxf(acc[G][ct][t], 0.f);
+        }
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+          for (int t = 0; t < 4; ++t)
+            if (ok[t]) a.out[(size_t)orow[t] * a.ldo + (ct0 + ct) * 16 + j] = acc[G][ct][t];
+      }
+    }
+    if (!a.partial && a.zero_row >= 0 && tile == 0 && tid < BN)
+      a.out[(size_t)a.zero_row * a.ldo + ct0 * 16 + tid] = 0.f;
+    __syncthreads();   // all waves are done with the ring / idx table of this tile
+    lap(5);   // epilogue + end-of-tile barrier
+  }
+  if (timing && lane == 0) {
+#pragma unroll
+    for (int i = 0; i < 6; ++i) atomicAdd(&a.dbg_cycles[i], tc[i]);
+    atomicAdd(&a.dbg_cycles[6], 1ULL);
   }
 }
 
@@ -330,14 +532,29 @@ __global__ void k_pack_weight(const float* __restrict__ w, int K, int cin, int c
 
 // ------------------------------------------------------------------------------ host: launch
 struct ConvPlan {
-  int bn, ksplit, kper, ntile, grid_x;
+  int bn, nw, gpw, depth, tile, ksplit, kper, ntile, grid_x;
   size_t lds, partial_floats;
 };
+
+static int conv_variant() {   // A3D_CONV_VARIANT=<waves><groups per wave><depth>
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("A3D_CONV_VARIANT");
+    v = e ? atoi(e) : 413;
+    if (v != 413 && v != 412 && v != 422 && v != 423 && v != 812) v = 413;
+  }
+  return v;
+}
 
 constexpr int kMaxQueuesPerOp = 128;   // cout tiles x k splits
 
 static ConvPlan plan_conv(int n_rows, int K, int cin, int cout) {
   ConvPlan p;
+  p.nw = conv_variant() / 100;
+  p.gpw = (conv_variant() / 10) % 10;
+  p.depth = conv_variant() % 10;
+  p.tile = 16 * p.nw * p.gpw;
+  const int kConvTile = p.tile, kConvDepth = p.depth;
   p.ntile = (int)((n_rows + kConvTile - 1) / kConvTile);
   if (p.ntile < 1) p.ntile = 1;
   int bn = (cout % 128 == 0) ? 128 : cout;
@@ -351,9 +568,9 @@ static ConvPlan plan_conv(int n_rows, int K, int cin, int cout) {
   }
   p.kper = (K + ksplit - 1) / ksplit;
   p.ksplit = (K + p.kper - 1) / p.kper;
-  p.lds = (size_t)2 * (kConvTile * 32 + 2 * (bn / 16) * 256) * 4 + (size_t)p.kper * kConvTile * 4 + 16;
+  p.lds = (size_t)kConvDepth * (kConvTile * 32 + 2 * (bn / 16) * 256) * 4 + (size_t)p.kper * kConvTile * 4 + 16;
   p.partial_floats = p.ksplit > 1 ? (size_t)p.ksplit * p.ntile * kConvTile * cout : 0;
-  const int max_resident = 256 * 3;   // CUs x workgroups per CU
+  const int max_resident = 256 * (int)(160 * 1024 / p.lds > 4 ? 4 : 160 * 1024 / p.lds);   // CUs x resident workgroups
   int gx = max_resident / ((cout / bn) * p.ksplit);
   if (gx < 1) gx = 1;
   p.grid_x = p.ntile < gx ? p.ntile : gx;
@@ -364,10 +581,12 @@ static void allow_big_lds() {
   static bool done = false;
   if (done) return;
   done = true;
-  (void)hipFuncSetAttribute((const void*)k_spconv<32>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  (void)hipFuncSetAttribute((const void*)k_spconv<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  (void)hipFuncSetAttribute((const void*)k_spconv<96>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  (void)hipFuncSetAttribute((const void*)k_spconv<128>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+#define A3D_BIG1(BN_, NW_, G_, D_) \
+  (void)hipFuncSetAttribute((const void*)k_spconv<BN_, NW_, G_, D_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+#define A3D_BIG(BN_) A3D_BIG1(BN_, 4, 1, 2) A3D_BIG1(BN_, 4, 1, 3) A3D_BIG1(BN_, 4, 2, 2) A3D_BIG1(BN_, 4, 2, 3) A3D_BIG1(BN_, 8, 1, 2)
+  A3D_BIG(32) A3D_BIG(64) A3D_BIG(96) A3D_BIG(128)
+#undef A3D_BIG
+#undef A3D_BIG1
 }
 
 static int launch_conv(ConvArgs a, float* partial_ws, size_t partial_ws_floats, int* queue_heads, hipStream_t st) {
@@ -379,6 +598,13 @@ static int launch_conv(ConvArgs a, float* partial_ws, size_t partial_ws_floats, 
       dbg = e ? atoi(e) : 0;
     }
     a.dbg = dbg;
+    a.dbg_cycles = nullptr;
+    if (dbg & (64 | 128)) {
+      static unsigned long long* buf = nullptr;
+      if (!buf) (void)hipMalloc(&buf, 64 + 8 * 64 * 6 * 8 + 128);
+      (void)hipMemsetAsync(buf, 0, 64 + 8 * 64 * 6 * 8 + 128, st);
+      a.dbg_cycles = buf;
+    }
   }
   if (a.cin % 32 != 0 || a.cout % 16 != 0 || !(a.cout % 128 == 0 || a.cout == 32 || a.cout == 64 || a.cout == 96)) {
     set_error("spconv: unsupported channels cin=%d cout=%d", a.cin, a.cout);
@@ -408,21 +634,49 @@ static int launch_conv(ConvArgs a, float* partial_ws, size_t partial_ws_floats, 
   dim3 grid(grid_x, a.cout / p.bn, p.ksplit);
   {
   ProfScope ps(st, A3D_PROF_SPCONV, p.bn, a.K, a.cin, a.cout, a.n_out, a.tag_table, a.tag_level, p.ksplit);
+#define A3D_LAUNCH_BN(BN_)                                                                  \
+  switch (p.nw * 100 + p.gpw * 10 + p.depth) {                                               \
+    case 412: k_spconv<BN_, 4, 1, 2><<<grid, 256, p.lds, st>>>(a); break;                     \
+    case 422: k_spconv<BN_, 4, 2, 2><<<grid, 256, p.lds, st>>>(a); break;                     \
+    case 423: k_spconv<BN_, 4, 2, 3><<<grid, 256, p.lds, st>>>(a); break;                     \
+    case 812: k_spconv<BN_, 8, 1, 2><<<grid, 512, p.lds, st>>>(a); break;                     \
+    default: k_spconv<BN_, 4, 1, 3><<<grid, 256, p.lds, st>>>(a); break;                      \
+  }
   switch (p.bn) {
-    case 32: k_spconv<32><<<grid, 256, p.lds, st>>>(a); break;
-    case 64: k_spconv<64><<<grid, 256, p.lds, st>>>(a); break;
-    case 96: k_spconv<96><<<grid, 256, p.lds, st>>>(a); break;
-    case 128: k_spconv<128><<<grid, 256, p.lds, st>>>(a); break;
+    case 32: A3D_LAUNCH_BN(32); break;
+    case 64: A3D_LAUNCH_BN(64); break;
+    case 96: A3D_LAUNCH_BN(96); break;
+    case 128: A3D_LAUNCH_BN(128); break;
     default: set_error("spconv: bad BN %d", p.bn); return A3D_ERR_UNSUPPORTED;
   }
+#undef A3D_LAUNCH_BN
   }
   A3D_LAUNCH_CHECK();
+  if (a.dbg_cycles && (a.dbg & 128)) {
+    static unsigned long long tr[16 + 8 * 64 * 6];
+    (void)hipMemcpyAsync(tr, a.dbg_cycles, sizeof(tr), hipMemcpyDeviceToHost, st);
+    (void)hipStreamSynchronize(st);
+    for (int w = 0; w < p.nw; ++w) {
+      const unsigned long long* t = tr + 16 + w * 64 * 6;
+      fprintf(stderr, "[trace wave %d] deltas:", w);
+      for (int i = 1; i < 64 * 6 && t[i]; ++i) fprintf(stderr, " %llu", t[i] - t[i - 1]);
+      fprintf(stderr, "\n");
+    }
+  }
+  if (a.dbg_cycles && (a.dbg & 64)) {
+    unsigned long long h[8];
+    (void)hipMemcpyAsync(h, a.dbg_cycles, 64, hipMemcpyDeviceToHost, st);
+    (void)hipStreamSynchronize(st);
+    const double w = (double)(h[6] ? h[6] : 1);
+    fprintf(stderr, "[spconv<%d> K=%d %d->%d n=%d] per-wave cycles: setup %.0f ctrl %.0f wait+barrier %.0f issue %.0f mfma %.0f epilogue %.0f (waves %llu)\n",
+            p.bn, a.K, a.cin, a.cout, a.n_out, h[0] / w, h[1] / w, h[2] / w, h[3] / w, h[4] / w, h[5] / w, h[6]);
+  }
   if (p.ksplit > 1) {
     ProfScope ps(st, A3D_PROF_SPLITK, p.bn, a.K, a.cin, a.cout, a.n_out, a.tag_table, a.tag_level, p.ksplit);
     const size_t total = (size_t)a.n_out * (a.cout / 4);
     const size_t thr = total > (size_t)a.cout ? total : (size_t)a.cout;
     k_splitk_epilogue<<<(unsigned)((thr + 255) / 256), 256, 0, st>>>(
-        partial_ws, p.ksplit, (size_t)p.ntile * kConvTile * a.cout, a.n_out, a.cout, a.out_map, a.scale, a.shift,
+        partial_ws, p.ksplit, (size_t)p.ntile * p.tile * a.cout, a.n_out, a.cout, a.out_map, a.scale, a.shift,
         a.res, a.ldr, a.relu, a.out, a.ldo, a.zero_row);
     A3D_LAUNCH_CHECK();
   }
