@@ -66,7 +66,7 @@ def profile_pass(step, scene_pairs, n_steps):
         e = buf[i]
         name = L.PROF_NAMES[e.id]
         if e.id == 0:
-            name = f"k_spconv<{e.bn}>"
+            name = f"k_spconv<{e.bn},4,1,3>"   # BN, waves, groups/wave, ring depth (plan_conv default)
         a = agg.setdefault(name, {"ms": 0.0, "launches": 0, "flops": 0.0})
         a["ms"] += e.ms
         a["launches"] += 1
