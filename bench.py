@@ -50,6 +50,22 @@ def algorithmic_flops(entry, pairs):
     return 2.0 * p * entry.cin * entry.cout
 
 
+def algorithmic_bytes(entry, pairs):
+    """Compulsory HBM bytes of one conv launch: read input + weights once, write output once, read
+    the kernel map once: 4 (N_in Cin + N_out Cout + K Cin Cout) + 8 pairs."""
+    from agile3d_amd import lib as L
+    n_out = entry.n_out
+    if entry.table == L.OP_CONV3:
+        n_in, p = pairs["n"][entry.level], pairs["conv3"][entry.level]
+    elif entry.table == L.OP_DOWN:
+        n_in = p = pairs["n"][entry.level]
+    elif entry.table == L.OP_UP:
+        n_in, p = pairs["n"][entry.level], pairs["n"][entry.level - 1]
+    else:
+        n_in, p = n_out, 0
+    return 4.0 * (n_in * entry.cin + n_out * entry.cout + entry.kernel_volume * entry.cin * entry.cout) + 8.0 * p
+
+
 def profile_pass(step, scene_pairs, n_steps):
     from agile3d_amd import lib as L
     lib = L.load()
@@ -67,11 +83,12 @@ def profile_pass(step, scene_pairs, n_steps):
         name = L.PROF_NAMES[e.id]
         if e.id == 0:
             name = f"k_spconv<{e.bn},4,1,3>"   # BN, waves, groups/wave, ring depth (plan_conv default)
-        a = agg.setdefault(name, {"ms": 0.0, "launches": 0, "flops": 0.0})
+        a = agg.setdefault(name, {"ms": 0.0, "launches": 0, "flops": 0.0, "bytes": 0.0})
         a["ms"] += e.ms
         a["launches"] += 1
         if e.id == 0:
             a["flops"] += algorithmic_flops(e, scene_pairs)
+            a["bytes"] += algorithmic_bytes(e, scene_pairs)
     for a in agg.values():
         a["ms_per_step"] = a["ms"] / n_steps
         a["launches_per_step"] = a["launches"] / n_steps
@@ -145,24 +162,10 @@ def main():
         r = model.forward_backbone(x, raw_coordinates=raw)
         return model.forward_mask(*r, click_idx=[ci], click_time_idx=[ct])
 
+    from agile3d_amd.sharding import timed_steps
     for _ in range(args.warmup):
         step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    dt, out = timed_steps(step, args.steps, world, dev)
     assert torch.isfinite(out["pred_masks"][0]).all()
 
     res = {
@@ -199,7 +202,8 @@ def main():
             res["roofline"] = {"bound": "mfma", "kernel": dom, "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS,
                                "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic,
                                "avg_launch_ms": d["ms"] / d["launches"], "launches_per_step": d["launches_per_step"],
-                               "algorithmic_gflop_per_launch": d["flops"] / d["launches"] / 1e9}
+                               "algorithmic_gflop_per_launch": d["flops"] / d["launches"] / 1e9,
+                               "algorithmic_bytes_per_launch": d["bytes"] / d["launches"]}
             tot_flops = sum(v["flops"] for v in conv.values()) / max(3, min(10, args.steps))
             res["kernels_ms_per_step"] = {k: round(v["ms_per_step"], 4) for k, v in sorted(agg.items())}
             res["conv_tflops"] = {k: round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2) for k, v in conv.items()}

@@ -1,0 +1,73 @@
+"""world_size-2 coverage of the multi-GPU path on CPU (gloo): scene sharding, barrier-bracketed
+timing with MAX over ranks, host-side gather.  The data path itself has no collective."""
+import os
+import socket
+import sys
+import time
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from conftest import ROOT
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from agile3d_amd.sharding import gather_rows, scenes_of_rank, timed_steps
+    from agile3d_amd.synthetic import make_scene
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    mine = scenes_of_rank(5, rank, world)
+    scenes = [make_scene(1500, seed=i) for i in mine]
+    delay = 0.02 * (rank + 1)   # rank 1 is slower: the reported time must be ITS time
+
+    def step():
+        time.sleep(delay)
+        return sum(len(s["coords"]) for s in scenes)
+
+    dt, out = timed_steps(step, 5, world, torch.device("cpu"))
+    rows = gather_rows([(i, int(len(s["coords"]))) for i, s in zip(mine, scenes)], world)
+    q.put((rank, mine, dt, out, sorted(rows)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_scene_sharding_and_max_timing_world2():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (r0, s0, dt0, _, rows0), (r1, s1, dt1, _, rows1) = res
+    assert s0 == [0, 2, 4] and s1 == [1, 3]                 # disjoint, complete
+    assert abs(dt0 - dt1) < 1e-9                            # every rank holds the MAX
+    assert dt0 >= 5 * 0.04 * 0.95                           # ... which is the slow rank's time
+    assert rows0 == rows1 and [r[0] for r in rows0] == [0, 1, 2, 3, 4]
+
+
+def test_sharding_is_a_partition():
+    from agile3d_amd.sharding import scenes_of_rank
+    for n in (0, 1, 7, 64):
+        for w in (1, 2, 3, 8):
+            parts = [scenes_of_rank(n, r, w) for r in range(w)]
+            flat = sorted(i for p in parts for i in p)
+            assert flat == list(range(n))
+            assert max(len(p) for p in parts) - min(len(p) for p in parts) <= 1
