@@ -536,63 +536,226 @@ __global__ void __launch_bounds__(512) k_query_init(const QueryMeta* meta, const
   lin<QT>(B.queries, D, B.qpos, Q, D, c2s_in_wt, D, c2s_in_b, D, B.qproj, D, false, 0.25f, lds);
 }
 
+// ---- query-side layer with all [Q,128] activations resident in LDS ---------------------------
+// 8 waves; in every GEMM round wave w owns output column tile(s) w (+8, ...).  Weight fragments are
+// loaded straight from the torch-layout rows (lane (g,j): W[n0+j][16S+4g..+3]) into registers, where
+// possible one round ahead of their use; activations never leave LDS between rounds (row stride 132
+// floats: conflict-free b128 A-fragment reads).
+constexpr int kQLD = 132;
+
+__device__ __forceinline__ void qload_w(const float* __restrict__ W, int ldw, int row0, int col0, f32x4 (&wf)[8]) {
+  const int lane = threadIdx.x & 63, g = lane >> 4, j = lane & 15;
+  const float* p = W + (size_t)(row0 + j) * ldw + col0 + 4 * g;
+#pragma unroll
+  for (int S = 0; S < 8; ++S) wf[S] = *(const f32x4*)(p + 16 * S);
+}
+template <int QT>
+__device__ __forceinline__ void qmm(const float* Xl, const f32x4 (&wf)[8], f32x4 (&acc)[QT]) {
+  const int lane = threadIdx.x & 63, g = lane >> 4, j = lane & 15;
+#pragma unroll
+  for (int S = 0; S < 8; ++S)
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) {
+      const f32x4 x = *(const f32x4*)(Xl + (qt * 16 + j) * kQLD + 16 * S + 4 * g);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) acc[qt] = __builtin_amdgcn_mfma_f32_16x16x4f32(x[t], wf[S][t], acc[qt], 0, 0, 0);
+    }
+}
+// y[q][col0 + j] = act((acc + bias) * scale) for q < Q; dst row stride ld (LDS or global)
+template <int QT>
+__device__ __forceinline__ void qstore(const f32x4 (&acc)[QT], const float* __restrict__ bias, int bcol, float scale,
+                                       bool relu, float* dst, int ld, int col0, int Q) {
+  const int lane = threadIdx.x & 63, g = lane >> 4, j = lane & 15;
+  const float b = bias ? bias[bcol + j] : 0.f;
+#pragma unroll
+  for (int qt = 0; qt < QT; ++qt)
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int q = qt * 16 + 4 * g + t;
+      if (q < Q) {
+        float y = (acc[qt][t] + b) * scale;
+        if (relu) y = fmaxf(y, 0.f);
+        dst[(size_t)q * ld + col0 + j] = y;
+      }
+    }
+}
+template <int QT>
+__device__ __forceinline__ void qzero(f32x4 (&acc)[QT]) {
+#pragma unroll
+  for (int qt = 0; qt < QT; ++qt) acc[qt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+}
+// dst[q] = LayerNorm(a[q] + b[q]) (b optional), all LDS, rows q < Q; one wave per row
+__device__ __forceinline__ void qadd_ln(const float* a, const float* b, int Q, const float* __restrict__ w,
+                                        const float* __restrict__ bias, float* dst, float* gdst) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  for (int q = wave; q < Q; q += nw) {
+    float x0 = a[q * kQLD + lane], x1 = a[q * kQLD + 64 + lane];
+    if (b) {
+      x0 += b[q * kQLD + lane];
+      x1 += b[q * kQLD + 64 + lane];
+    }
+    float s = x0 + x1;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    const float mean = s * (1.f / D);
+    const float d0 = x0 - mean, d1 = x1 - mean;
+    float v = d0 * d0 + d1 * d1;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    const float rstd = rsqrtf(v * (1.f / D) + kLnEps);
+    const float y0 = d0 * rstd * w[lane] + bias[lane], y1 = d1 * rstd * w[64 + lane] + bias[64 + lane];
+    dst[q * kQLD + lane] = y0;
+    dst[q * kQLD + 64 + lane] = y1;
+    if (gdst) {
+      gdst[(size_t)q * D + lane] = y0;
+      gdst[(size_t)q * D + 64 + lane] = y1;
+    }
+  }
+}
+
 template <int QT>
 __global__ void __launch_bounds__(512) k_query_layer(const QueryMeta* meta, QueryLayerW W, QueryBufs B) {
   constexpr int QP = QT * 16;
-  __shared__ __attribute__((aligned(16))) float lds[QP * kLinLD];
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* qpos = (float*)smem;            // [QP][132]  query position encodings (later: mask MLP hidden)
+  float* cur = qpos + QP * kQLD;         // queries -> tgt -> queries
+  float* xa = cur + QP * kQLD;           // GEMM input staging
+  float* xb = xa + QP * kQLD;            // GEMM output staging / FFN hidden chunk
   const int Q = meta->nq;
   const int tid = threadIdx.x, nt = blockDim.x;
-  // 2. c2s output projection + residual + LayerNorm (attention_block.py:95-96)
-  lin<QT>(B.attn, D, nullptr, Q, D, W.c2s_out_wt, D, W.c2s_out_b, D, B.tmp, D, false, 1.f, lds);
-  add_ln(B.queries, B.tmp, Q, W.c2s_norm_w, W.c2s_norm_b, B.tgt);
-  // 3. click-to-click self attention (attention_block.py:32-36)
-  lin<QT>(B.tgt, D, B.qpos, Q, D, W.c2c_in_wt, D, W.c2c_in_b, 2 * D, B.qk, 2 * D, false, 1.f, lds);
-  lin<QT>(B.tgt, D, nullptr, Q, D, W.c2c_in_wt + 2 * D * D, D, W.c2c_in_b + 2 * D, D, B.vc, D, false, 1.f, lds);
+  const int wave = tid >> 6;
+  f32x4 wfa[8], wfb[8], acc[QT];
+
+  // ---- load the layer inputs (queries, qpos, click-to-scene attention result) into LDS
+  qload_w(W.c2s_out_wt, D, 16 * wave, 0, wfa);                      // first round's weights meanwhile
+  for (int e = tid; e < QP * 32; e += nt) {
+    const int q = e >> 5, c4 = (e & 31) * 4;
+    f32x4 vq = (f32x4){0.f, 0.f, 0.f, 0.f}, vp = vq, va = vq;
+    if (q < Q) {
+      vq = *(const f32x4*)(B.queries + (size_t)q * D + c4);
+      vp = *(const f32x4*)(B.qpos + (size_t)q * D + c4);
+      va = *(const f32x4*)(B.attn + (size_t)q * D + c4);
+    }
+    *(f32x4*)(cur + q * kQLD + c4) = vq;
+    *(f32x4*)(qpos + q * kQLD + c4) = vp;
+    *(f32x4*)(xa + q * kQLD + c4) = va;
+  }
+  __syncthreads();
+  // ---- 1. click-to-scene output projection + residual + LayerNorm (attention_block.py:95-96)
+  qzero<QT>(acc);
+  qmm<QT>(xa, wfa, acc);
+  qstore<QT>(acc, W.c2s_out_b, 16 * wave, 1.f, false, xb, kQLD, 16 * wave, QP);
+  qload_w(W.c2c_in_wt, D, 16 * wave, 0, wfa);                       // q rows of the c2c in_proj
+  qload_w(W.c2c_in_wt, D, D + 16 * wave, 0, wfb);                   // k rows
+  __syncthreads();
+  qadd_ln(cur, xb, Q, W.c2s_norm_w, W.c2s_norm_b, cur, nullptr);     // cur = tgt
+  __syncthreads();
+  // ---- 2. click-to-click self attention (attention_block.py:32-36): q|k from tgt+qpos, v from tgt
+  for (int e = tid; e < QP * 128; e += nt) {
+    const int q = e >> 7, c = e & 127;
+    xa[q * kQLD + c] = cur[q * kQLD + c] + qpos[q * kQLD + c];
+  }
+  __syncthreads();
+  qzero<QT>(acc);
+  qmm<QT>(xa, wfa, acc);
+  qstore<QT>(acc, W.c2c_in_b, 16 * wave, 0.25f, false, B.qk, 2 * D, 16 * wave, Q);            // q (pre-scaled)
+  qzero<QT>(acc);
+  qmm<QT>(xa, wfb, acc);
+  qstore<QT>(acc, W.c2c_in_b, D + 16 * wave, 1.f, false, B.qk, 2 * D, D + 16 * wave, Q);      // k
+  qload_w(W.c2c_in_wt, D, 2 * D + 16 * wave, 0, wfa);                                         // v rows
+  qzero<QT>(acc);
+  qmm<QT>(cur, wfa, acc);
+  qstore<QT>(acc, W.c2c_in_b, 2 * D + 16 * wave, 1.f, false, B.vc, D, 16 * wave, Q);          // v
+  qload_w(W.c2c_out_wt, D, 16 * wave, 0, wfa);                      // next round's weights
+  __syncthreads();
   for (int e = tid; e < Q * H; e += nt) {
     const int q = e / H, h = e % H;
     float qv[DH];
 #pragma unroll
-    for (int d = 0; d < DH; ++d) qv[d] = B.qk[(size_t)q * 2 * D + h * DH + d] * 0.25f;
+    for (int d = 0; d < DH; ++d) qv[d] = B.qk[(size_t)q * 2 * D + h * DH + d];
     float mx = kNegBig;
     for (int k = 0; k < Q; ++k) {
-      float s = 0.f;
+      float sdot = 0.f;
 #pragma unroll
-      for (int d = 0; d < DH; ++d) s += qv[d] * B.qk[(size_t)k * 2 * D + D + h * DH + d];
-      mx = fmaxf(mx, s);
+      for (int d = 0; d < DH; ++d) sdot += qv[d] * B.qk[(size_t)k * 2 * D + D + h * DH + d];
+      mx = fmaxf(mx, sdot);
     }
     float sum = 0.f, o[DH];
 #pragma unroll
     for (int d = 0; d < DH; ++d) o[d] = 0.f;
     for (int k = 0; k < Q; ++k) {
-      float s = 0.f;
+      float sdot = 0.f;
 #pragma unroll
-      for (int d = 0; d < DH; ++d) s += qv[d] * B.qk[(size_t)k * 2 * D + D + h * DH + d];
-      const float p = expf(s - mx);
-      sum += p;
+      for (int d = 0; d < DH; ++d) sdot += qv[d] * B.qk[(size_t)k * 2 * D + D + h * DH + d];
+      const float pw = expf(sdot - mx);
+      sum += pw;
 #pragma unroll
-      for (int d = 0; d < DH; ++d) o[d] += p * B.vc[(size_t)k * D + h * DH + d];
+      for (int d = 0; d < DH; ++d) o[d] += pw * B.vc[(size_t)k * D + h * DH + d];
     }
     const float inv = 1.f / sum;
 #pragma unroll
-    for (int d = 0; d < DH; ++d) B.attn[(size_t)q * D + h * DH + d] = o[d] * inv;
+    for (int d = 0; d < DH; ++d) xa[q * kQLD + h * DH + d] = o[d] * inv;
+  }
+  for (int e = tid; e < (QP - Q) * 128; e += nt) xa[(Q + (e >> 7)) * kQLD + (e & 127)] = 0.f;   // padded rows
+  __syncthreads();
+  qzero<QT>(acc);
+  qmm<QT>(xa, wfa, acc);
+  qstore<QT>(acc, W.c2c_out_b, 16 * wave, 1.f, false, xb, kQLD, 16 * wave, QP);
+  qload_w(W.ffn_w1t, D, 16 * wave, 0, wfa);                         // FFN chunk 0, hidden tile `wave`
+  __syncthreads();
+  qadd_ln(cur, xb, Q, W.c2c_norm_w, W.c2c_norm_b, cur, nullptr);
+  __syncthreads();
+  // ---- 3. FFN (attention_block.py:151-155) in hidden chunks of 128: wave w computes hidden tile w of
+  //         the chunk into xb, then accumulates output tile w over the chunk
+  f32x4 facc[QT];
+  qzero<QT>(facc);
+  const int nchunk = W.dim_ff >> 7;
+  for (int c = 0; c < nchunk; ++c) {
+    qload_w(W.ffn_w2t, W.dim_ff, 16 * wave, c * 128, wfb);          // linear2 rows (output cols), chunk cols
+    qzero<QT>(acc);
+    qmm<QT>(cur, wfa, acc);
+    qstore<QT>(acc, W.ffn_b1, c * 128 + 16 * wave, 1.f, true, xb, kQLD, 16 * wave, QP);
+    if (c + 1 < nchunk) qload_w(W.ffn_w1t, D, (c + 1) * 128 + 16 * wave, 0, wfa);
+    __syncthreads();
+    qmm<QT>(xb, wfb, facc);
+    __syncthreads();
+  }
+  qstore<QT>(facc, W.ffn_b2, 16 * wave, 1.f, false, xa, kQLD, 16 * wave, QP);
+  qload_w(W.s2c_in_wt, D, D + 16 * wave, 0, wfa);                   // s2c k rows
+  qload_w(W.s2c_in_wt, D, 2 * D + 16 * wave, 0, wfb);               // s2c v rows
+  __syncthreads();
+  qadd_ln(cur, xa, Q, W.ffn_norm_w, W.ffn_norm_b, cur, B.queries);   // cur = queries (also to global)
+  __syncthreads();
+  // ---- 4. everything that depends only on the new queries: s2c keys/values, mask MLP layer 0, next
+  //         iteration's c2s query projection
+  qadd_ln(cur, nullptr, Q, W.dn_w, W.dn_b, xb, nullptr);             // decoder_norm(queries)
+  for (int e = tid; e < QP * 128; e += nt) {
+    const int q = e >> 7, c = e & 127;
+    xa[q * kQLD + c] = cur[q * kQLD + c] + qpos[q * kQLD + c];
   }
   __syncthreads();
-  lin<QT>(B.attn, D, nullptr, Q, D, W.c2c_out_wt, D, W.c2c_out_b, D, B.tmp, D, false, 1.f, lds);
-  add_ln(B.tgt, B.tmp, Q, W.c2c_norm_w, W.c2c_norm_b, B.tgt);
-  // 4. FFN (attention_block.py:151-155)
-  lin<QT>(B.tgt, D, nullptr, Q, D, W.ffn_w1t, D, W.ffn_b1, W.dim_ff, B.hidden, W.dim_ff, true, 1.f, lds);
-  lin<QT>(B.hidden, W.dim_ff, nullptr, Q, W.dim_ff, W.ffn_w2t, W.dim_ff, W.ffn_b2, D, B.tmp, D, false, 1.f, lds);
-  add_ln(B.tgt, B.tmp, Q, W.ffn_norm_w, W.ffn_norm_b, B.queries);
-  // 5. keys / values of the scene-to-click attention (keys pre-scaled by 1/sqrt(head_dim))
-  lin<QT>(B.queries, D, B.qpos, Q, D, W.s2c_in_wt + D * D, D, W.s2c_in_b + D, D, B.ks, D, false, 0.25f, lds);
-  lin<QT>(B.queries, D, nullptr, Q, D, W.s2c_in_wt + 2 * D * D, D, W.s2c_in_b + 2 * D, D, B.vs, D, false, 1.f, lds);
-  // 6. mask embeddings E = MLP(decoder_norm(q))  (agile3d.py:345-346)
-  add_ln(B.queries, nullptr, Q, W.dn_w, W.dn_b, B.tmp);
-  lin<QT>(B.tmp, D, nullptr, Q, D, W.m_w0t, D, W.m_b0, D, B.attn, D, true, 1.f, lds);
-  lin<QT>(B.attn, D, nullptr, Q, D, W.m_w2t, D, W.m_b2, D, B.E, D, false, 1.f, lds);
-  // 7. query projection for the next iteration's click-to-scene attention
-  if (W.next_c2s_in_wt)
-    lin<QT>(B.queries, D, B.qpos, Q, D, W.next_c2s_in_wt, D, W.next_c2s_in_b, D, B.qproj, D, false, 0.25f, lds);
+  qzero<QT>(acc);
+  qmm<QT>(xa, wfa, acc);
+  qstore<QT>(acc, W.s2c_in_b, D + 16 * wave, 0.25f, false, B.ks, D, 16 * wave, Q);   // keys pre-scaled
+  qload_w(W.m_w0t, D, 16 * wave, 0, wfa);
+  qzero<QT>(acc);
+  qmm<QT>(cur, wfb, acc);
+  qstore<QT>(acc, W.s2c_in_b, 2 * D + 16 * wave, 1.f, false, B.vs, D, 16 * wave, Q);
+  if (W.next_c2s_in_wt) {
+    qload_w(W.next_c2s_in_wt, D, 16 * wave, 0, wfb);
+    qzero<QT>(acc);
+    qmm<QT>(xa, wfb, acc);
+    qstore<QT>(acc, W.next_c2s_in_b, 16 * wave, 0.25f, false, B.qproj, D, 16 * wave, Q);
+  }
+  __syncthreads();                                                   // everyone is done reading xa / qpos
+  qzero<QT>(acc);
+  qmm<QT>(xb, wfa, acc);
+  qstore<QT>(acc, W.m_b0, 16 * wave, 1.f, true, qpos, kQLD, 16 * wave, QP);          // mask MLP hidden
+  qload_w(W.m_w2t, D, 16 * wave, 0, wfa);
+  __syncthreads();
+  qzero<QT>(acc);
+  qmm<QT>(qpos, wfa, acc);
+  qstore<QT>(acc, W.m_b2, 16 * wave, 1.f, false, B.E, D, 16 * wave, Q);
 }
 
 }  // namespace a3d
@@ -728,6 +891,16 @@ static int run_decoder(const a3d_decoder_weights* w, const float* feats128, cons
   B.qk = (float*)(ws + L.q[9]);
   B.vc = (float*)(ws + L.q[10]);
   B.hidden = (float*)(ws + L.q[11]);
+  {
+    static bool big = false;
+    if (!big) {
+      big = true;
+      (void)hipFuncSetAttribute((const void*)k_query_layer<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      (void)hipFuncSetAttribute((const void*)k_query_layer<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      (void)hipFuncSetAttribute((const void*)k_query_layer<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      (void)hipFuncSetAttribute((const void*)k_query_layer<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    }
+  }
   A3D_HIP_CHECK(hipMemcpyAsync(meta, &hm, sizeof(QueryMeta), hipMemcpyHostToDevice, st));
   char* queues = ws + L.queues;
   A3D_HIP_CHECK(hipMemsetAsync(queues, 0, (size_t)A3D_MAX_DEC_LAYERS * 4 * 512, st));
@@ -775,7 +948,7 @@ static int run_decoder(const a3d_decoder_weights* w, const float* feats128, cons
     {
     ProfScope ps(st, A3D_PROF_QUERY, 0, 0, 0, 0, nq);
     k_c2s_combine<QT><<<nq * H, 64, 0, st>>>(part, L.nchunk, B.attn);
-    k_query_layer<QT><<<1, 512, 0, st>>>(meta, QW, B);
+    k_query_layer<QT><<<1, 512, (size_t)4 * QP * kQLD * 4, st>>>(meta, QW, B);
     }
     A3D_LAUNCH_CHECK();
     // ---- scene-to-click: Q = src Wq^T + (pos Wq^T + bq); attention; Y = O Wo^T + bo + src; LN
