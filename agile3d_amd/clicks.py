@@ -1,0 +1,188 @@
+"""Host mirror of the reference's ``utils/seg.py`` for the interactive loop, on the HIP library.
+
+Same function names, argument meaning and return values as the reference (file:line cited per
+function); the arithmetic runs in ``libagile3d_hip.so`` (``csrc/clicks.hip``): one exact
+nearest-outside-point pass for all error clusters instead of one ``torch.cdist`` matrix per cluster.
+There is no CPU path: tensors must live on the GPU.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import random
+
+import numpy as np
+import torch
+
+from . import lib as L
+
+MAX_CLUSTERS = 1024
+
+
+def _i32(t: torch.Tensor) -> torch.Tensor:
+    """labels / predictions arrive as float, long or int tensors in the reference; ids are small ints."""
+    if not t.is_cuda:
+        raise RuntimeError("agile3d_amd.clicks runs on the GPU only (no CPU fallback); got a CPU tensor")
+    return t.to(torch.int32).contiguous()
+
+
+def _stream(t):
+    return C.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+def _host_i32(values):
+    a = np.ascontiguousarray(values, dtype=np.int32)
+    return a, a.ctypes.data_as(C.POINTER(C.c_int32))
+
+
+def argmax_labels(logits: torch.Tensor, click_idx: dict | None = None) -> torch.Tensor:
+    """``p.argmax(-1)`` followed by "update prediction with sparse gt" (eval_multi_obj.py:119-134):
+    int32 labels [N]; rows listed in ``click_idx`` are overwritten with their object id, dict order."""
+    lib = L.load()
+    logits = logits.contiguous()
+    if logits.dtype != torch.float32 or not logits.is_cuda or logits.dim() != 2:
+        raise RuntimeError("argmax_labels: logits must be a CUDA float32 [N, 1+K] tensor")
+    rows, objs = [], []
+    for obj_id, cids in (click_idx or {}).items():
+        rows += [int(c) for c in cids]
+        objs += [int(obj_id)] * len(cids)
+    r, rp = _host_i32(rows)
+    o, op = _host_i32(objs)
+    pred = torch.empty(logits.shape[0], dtype=torch.int32, device=logits.device)
+    L.check(lib.a3d_argmax_labels(logits.data_ptr(), logits.shape[0], logits.shape[1], rp, op, len(rows),
+                                  pred.data_ptr(), _stream(logits)), "a3d_argmax_labels")
+    return pred
+
+
+def iou_counts(pred, labels, inverse_map=None, n_ids: int | None = None) -> np.ndarray:
+    """int64 [3][n_ids]: |pred==id & label==id|, |pred==id|, |label==id| with pred read through
+    ``inverse_map`` (voxel -> full-resolution points, eval_multi_obj.py:138) when given."""
+    lib = L.load()
+    p, l = _i32(pred), _i32(labels)
+    inv = None
+    if inverse_map is not None:
+        inv = inverse_map.to(device=p.device, dtype=torch.int64).contiguous()
+        if inv.numel() != l.numel():
+            raise RuntimeError("iou_counts: inverse_map and labels differ in length")
+    elif p.numel() != l.numel():
+        raise RuntimeError("iou_counts: pred and labels differ in length")
+    n_ids = 256 if n_ids is None else n_ids
+    counts = torch.empty(3 * n_ids + 1, dtype=torch.int64, device=p.device)
+    L.check(lib.a3d_iou_counts(p.data_ptr(), p.numel(), inv.data_ptr() if inv is not None else None, l.data_ptr(),
+                               l.numel(), n_ids, counts.data_ptr(), _stream(p)), "a3d_iou_counts")
+    host = counts.cpu().numpy()
+    if host[-1]:
+        raise RuntimeError("iou_counts: inverse_map holds rows outside the prediction")
+    return host[:-1].reshape(3, n_ids)
+
+
+def mean_iou_scene(pred, labels, inverse_map=None):
+    """utils/seg.py:44-58.  Returns (mean IoU as a 0-d float32 tensor, {object id: IoU}); the fp32
+    arithmetic (int counts -> fp32 divide -> sequential fp32 sum) is the reference's."""
+    c = iou_counts(pred, labels, inverse_map)
+    ids = [i for i in range(1, c.shape[1]) if c[2, i] > 0]
+    total = np.float32(0.0)
+    per_obj = {}
+    with np.errstate(divide="ignore", invalid="ignore"):
+        for i in ids:
+            v = np.float32(c[0, i]) / np.float32(c[1, i] + c[2, i] - c[0, i])
+            per_obj[i] = float(v)
+            total = np.float32(total + v)
+        total = np.float32(total / np.float32(len(ids))) if ids else np.float32(np.nan)
+    return torch.tensor(total, dtype=torch.float32), per_obj
+
+
+_ws_cache: dict = {}
+
+
+def error_clusters(pred, labels, coords):
+    """Per error cluster (ascending cluster id = 96*label + 11*pred, utils/seg.py:206): the point
+    farthest from everything outside the cluster and that distance.  List of dicts
+    {cluster_id, row, label, pred, error_size}."""
+    lib = L.load()
+    p, l = _i32(pred), _i32(labels)
+    xyz = coords.to(torch.float32).contiguous()
+    n = p.numel()
+    if xyz.shape != (n, 3) or l.numel() != n:
+        raise RuntimeError("error_clusters: pred [N], labels [N], coords [N,3] expected")
+    if n == 0:
+        return []
+    key = (p.device.index, n)
+    ws = _ws_cache.get(key)
+    if ws is None:
+        _ws_cache.clear()
+        ws = _ws_cache[key] = (torch.empty(lib.a3d_click_workspace_bytes(n), dtype=torch.uint8, device=p.device),
+                               torch.empty(MAX_CLUSTERS * C.sizeof(L.ClickCluster) + 16, dtype=torch.uint8,
+                                           device=p.device))
+    work, out = ws
+    n_out_ptr = out.data_ptr() + MAX_CLUSTERS * C.sizeof(L.ClickCluster)
+    L.check(lib.a3d_click_clusters(xyz.data_ptr(), p.data_ptr(), l.data_ptr(), n, out.data_ptr(), MAX_CLUSTERS,
+                                   n_out_ptr, work.data_ptr(), work.numel(), _stream(p)), "a3d_click_clusters")
+    host = out.cpu().numpy()
+    count = int(host[MAX_CLUSTERS * C.sizeof(L.ClickCluster):][:4].view(np.int32)[0])
+    if count < 0:
+        raise RuntimeError("error_clusters: labels / predictions must be object ids in 0..255")
+    if count > MAX_CLUSTERS:
+        raise RuntimeError(f"error_clusters: {count} error clusters > {MAX_CLUSTERS}")
+    recs = np.frombuffer(host[:count * C.sizeof(L.ClickCluster)].tobytes(),
+                         dtype=np.dtype([("cluster_id", "<i4"), ("row", "<i4"), ("label", "<i4"), ("pred", "<i4"),
+                                         ("error_size", "<f4")]))
+    res = []
+    for r in recs:
+        if not np.isfinite(r["error_size"]):
+            raise RuntimeError("error cluster covers the whole sample (the reference fails here too)")
+        res.append({k: (float(r[k]) if k == "error_size" else int(r[k])) for k in recs.dtype.names})
+    return res
+
+
+def get_simulated_clicks(pred_qv, labels_qv, coords_qv, current_num_clicks=None, training=True):
+    """utils/seg.py:177-228.  Same returns: (new_clicks {str(label): [rows]}, click_num,
+    new_click_pos {str(label): [xyz tensors]}, new_click_time {str(label): [order]}), or four Nones when
+    the prediction is already right.  Consumes the global ``random`` stream like the reference
+    (one ``random.shuffle`` of the selected cluster ids)."""
+    clusters = error_clusters(pred_qv, labels_qv, coords_qv)
+    if not clusters:
+        return None, None, None, None
+    by_id = {c["cluster_id"]: c for c in clusters}
+    # ranked by error size, largest first; equal sizes keep ascending-id order (stable sort)
+    ranked = sorted(by_id, key=lambda cid: by_id[cid]["error_size"], reverse=True)
+    if training:
+        num_obj = int((torch.unique(labels_qv) != 0).sum())
+        chosen = ranked[:num_obj] if len(ranked) >= num_obj else ranked
+    else:
+        chosen = ranked if current_num_clicks == 0 else ranked[:1]
+    random.shuffle(chosen)
+    new_clicks, new_pos, new_time = {}, {}, {}
+    for order, cid in enumerate(chosen):
+        c = by_id[cid]
+        key = str(c["label"])
+        new_clicks.setdefault(key, []).append(c["row"])
+        new_pos.setdefault(key, []).append(coords_qv[c["row"]])
+        new_time.setdefault(key, []).append(order)
+    return new_clicks, len(chosen), new_pos, new_time
+
+
+def extend_clicks(current_clicks, current_clicks_time, new_clicks, new_click_time):
+    """utils/seg.py:231-242."""
+    offset = sum(len(v) for v in current_clicks_time.values())
+    for obj_id, rows in new_clicks.items():
+        current_clicks[obj_id].extend(rows)
+        current_clicks_time[obj_id].extend(t + offset for t in new_click_time[obj_id])
+    return current_clicks, current_clicks_time
+
+
+def cal_click_loss_weights(batch_idx, raw_coords, labels, click_idx, alpha=0.8, beta=2.0, tita=0.3):
+    """utils/seg.py:71-89: per sample, weights[i] = alpha + (beta-alpha)(1 - min(d_i, tita)/tita) with
+    d_i the distance of point i to the nearest click of any object."""
+    lib = L.load()
+    if not raw_coords.is_cuda:
+        raise RuntimeError("cal_click_loss_weights runs on the GPU only")
+    weights = []
+    for i in range(int(batch_idx.max()) + 1):
+        xyz = raw_coords[batch_idx == i].to(torch.float32).contiguous()
+        rows = [int(r) for v in click_idx[i].values() for r in v]
+        r, rp = _host_i32(rows)
+        w = torch.empty(xyz.shape[0], dtype=torch.float32, device=xyz.device)
+        L.check(lib.a3d_click_loss_weights(xyz.data_ptr(), xyz.shape[0], rp, len(rows), tita, alpha, beta,
+                                           w.data_ptr(), _stream(xyz)), "a3d_click_loss_weights")
+        weights.append(w)
+    return weights

@@ -1,0 +1,352 @@
+// clicks.hip -- the interactive loop around forward_mask: label argmax, IoU counting and the click
+// simulator (gfx950).
+//
+// Replaces (reference file:line):
+//   p.argmax(-1) + "update prediction with sparse gt"      eval_multi_obj.py:119-134
+//   mean_iou_scene / mean_iou_single                        utils/seg.py:10-18,44-58
+//   get_simulated_clicks / measure_error_size / get_next_click_coo_torch   utils/seg.py:93-239
+//   loss_weights                                            utils/seg.py:60-69
+//
+// The simulator's cost is measure_error_size: for every wrongly labelled point the distance to the
+// nearest point that is NOT in its error cluster (the reference builds the full [other x cluster]
+// torch.cdist matrix per cluster).  Here it is ONE exact brute-force pass for all clusters at once:
+// candidates are wave-uniform, so they stream through the scalar cache as SGPR operands and the inner
+// loop is 9 VALU ops per (query, candidate) with no LDS or vector-memory traffic.
+#include "common.h"
+
+namespace a3d {
+
+constexpr int kClusterTable = 1 << 15;      // cluster id = 96*label + 11*pred, label/pred <= 255
+constexpr unsigned kInfBits = 0x7f800000u;
+constexpr int kQueriesPerThread = 2;
+constexpr int kNearestBlock = 256;
+constexpr int kNearestSplit = 16;           // candidate chunks (grid.y)
+
+// ---- argmax over the 1+K mask logits of every point (first maximum wins, like torch.argmax) ------
+__global__ void k_argmax_labels(const float* __restrict__ logits, int64_t n, int C, int32_t* __restrict__ pred) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float* r = logits + i * C;
+  float best = r[0];
+  int arg = 0;
+  for (int c = 1; c < C; ++c) {
+    const float v = r[c];
+    if (v > best) { best = v; arg = c; }
+  }
+  pred[i] = arg;
+}
+
+struct ClickList {
+  int n;
+  int row[A3D_MAX_CLICKS];
+  unsigned char obj[A3D_MAX_CLICKS];
+};
+// sequential on purpose: a row clicked for two objects keeps the LAST one, as the reference's dict loop does
+__global__ void k_click_overwrite(ClickList cl, int64_t n, int32_t* __restrict__ pred) {
+  for (int i = 0; i < cl.n; ++i)
+    if (cl.row[i] >= 0 && cl.row[i] < n) pred[cl.row[i]] = cl.obj[i];
+}
+
+// ---- IoU counts: counts[0][id] = |pred==id & label==id|, [1][id] = |pred==id|, [2][id] = |label==id| ----
+__global__ void k_iou_counts(const int32_t* __restrict__ pred, const int64_t* __restrict__ inverse_map,
+                             const int32_t* __restrict__ labels, int64_t n_full, int64_t n_pred, int n_ids,
+                             unsigned long long* __restrict__ counts, int* __restrict__ err) {
+  __shared__ unsigned h[3 * 256];
+  for (int i = threadIdx.x; i < 3 * 256; i += blockDim.x) h[i] = 0;
+  __syncthreads();
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_full; i += stride) {
+    const int64_t src = inverse_map ? inverse_map[i] : i;
+    if (src < 0 || src >= n_pred) { atomicOr(err, 1); continue; }
+    const int p = pred[src], l = labels[i];
+    if (p >= 0 && p < n_ids) atomicAdd(&h[256 + p], 1u);
+    if (l >= 0 && l < n_ids) {
+      atomicAdd(&h[512 + l], 1u);
+      if (p == l) atomicAdd(&h[l], 1u);
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 3 * 256; i += blockDim.x) {
+    const int id = i & 255;
+    if (id < n_ids && h[i]) atomicAdd(&counts[(size_t)(i >> 8) * n_ids + id], (unsigned long long)h[i]);
+  }
+}
+
+// ---- click simulator --------------------------------------------------------------------------
+// cand[i] = (x, y, z, cluster id bits) for EVERY point (cluster -1 = correctly labelled);
+// err_rows = rows of wrongly labelled points in arbitrary order (the result does not depend on it).
+__global__ void k_err_compact(const float* __restrict__ xyz, const int32_t* __restrict__ pred,
+                              const int32_t* __restrict__ labels, int64_t n, float4* __restrict__ cand,
+                              int32_t* __restrict__ err_rows, unsigned* __restrict__ d2bits,
+                              int* __restrict__ n_err, int* __restrict__ err) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  bool wrong = false;
+  if (i < n) {
+    const int p = pred[i], l = labels[i];
+    if (p < 0 || p > 255 || l < 0 || l > 255) atomicOr(err, 2);
+    wrong = p != l;
+    const int cid = wrong ? 96 * l + 11 * p : -1;
+    cand[i] = make_float4(xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2], __int_as_float(cid));
+  }
+  const unsigned long long m = __ballot(wrong);
+  const int lane = threadIdx.x & 63;
+  int base = 0;
+  if (lane == 0 && m) base = atomicAdd(n_err, __popcll(m));
+  base = __shfl(base, 0);
+  if (wrong) {
+    const int slot = base + __popcll(m & ((1ull << lane) - 1));
+    err_rows[slot] = (int)i;
+    d2bits[slot] = kInfBits;
+  }
+}
+
+__global__ __launch_bounds__(kNearestBlock) void k_nearest_other(const float4* __restrict__ cand, int64_t n,
+                                                                 const int32_t* __restrict__ err_rows,
+                                                                 const int* __restrict__ n_err_p,
+                                                                 unsigned* __restrict__ d2bits, int chunk) {
+  const int n_err = *n_err_p;
+  const int q0 = blockIdx.x * (kNearestBlock * kQueriesPerThread);
+  if (q0 >= n_err) return;
+  float qx[kQueriesPerThread], qy[kQueriesPerThread], qz[kQueriesPerThread], best[kQueriesPerThread];
+  int qc[kQueriesPerThread];
+#pragma unroll
+  for (int u = 0; u < kQueriesPerThread; ++u) {
+    const int e = q0 + u * kNearestBlock + threadIdx.x;
+    float4 c = make_float4(0.f, 0.f, 0.f, __int_as_float(-2));
+    if (e < n_err) c = cand[err_rows[e]];
+    qx[u] = c.x; qy[u] = c.y; qz[u] = c.z; qc[u] = __float_as_int(c.w);
+    best[u] = __uint_as_float(kInfBits);
+  }
+  const int j0 = blockIdx.y * chunk;
+  const int j1 = (int)min((int64_t)j0 + chunk, n);
+  auto visit = [&](const float4 c) {
+    const int cc = __float_as_int(c.w);
+#pragma unroll
+    for (int u = 0; u < kQueriesPerThread; ++u) {
+      const float dx = qx[u] - c.x, dy = qy[u] - c.y, dz = qz[u] - c.z;
+      const float d2 = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
+      best[u] = fminf(best[u], cc != qc[u] ? d2 : __uint_as_float(kInfBits));
+    }
+  };
+  int j = j0;                              // j is wave-uniform: cand[j..j+3] arrive as one s_load_dwordx16
+  for (; j + 4 <= j1; j += 4) {
+    const float4 c0 = cand[j], c1 = cand[j + 1], c2 = cand[j + 2], c3 = cand[j + 3];
+    visit(c0); visit(c1); visit(c2); visit(c3);
+  }
+  for (; j < j1; ++j) visit(cand[j]);
+#pragma unroll
+  for (int u = 0; u < kQueriesPerThread; ++u) {
+    const int e = q0 + u * kNearestBlock + threadIdx.x;
+    if (e < n_err) atomicMin(&d2bits[e], __float_as_uint(best[u]));   // d2 >= 0: bit order == value order
+  }
+}
+
+// largest "distance to the nearest outside point" per cluster; ties -> lowest row (torch.where(...)[0][0])
+__global__ void k_cluster_best(const float4* __restrict__ cand, const int32_t* __restrict__ err_rows,
+                               const int* __restrict__ n_err_p, const unsigned* __restrict__ d2bits,
+                               unsigned long long* __restrict__ table) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= *n_err_p) return;
+  const int row = err_rows[e];
+  const int cid = __float_as_int(cand[row].w);
+  atomicMax(&table[cid], ((unsigned long long)d2bits[e] << 32) | (0xffffffffu - (unsigned)row));
+}
+
+// ordered compaction of the table (ascending cluster id, like torch.unique)
+__global__ void k_cluster_list(const unsigned long long* __restrict__ table, const int32_t* __restrict__ pred,
+                               const int32_t* __restrict__ labels, a3d_click_cluster* __restrict__ out,
+                               int max_out, int32_t* __restrict__ n_out, const int* __restrict__ err) {
+  constexpr int PER = kClusterTable / 1024;
+  __shared__ int sums[1024];
+  const int t = threadIdx.x;
+  int cnt = 0;
+  for (int k = 0; k < PER; ++k) cnt += table[t * PER + k] != 0;
+  sums[t] = cnt;
+  __syncthreads();
+  for (int off = 1; off < 1024; off <<= 1) {
+    const int v = t >= off ? sums[t - off] : 0;
+    __syncthreads();
+    sums[t] += v;
+    __syncthreads();
+  }
+  int pos = sums[t] - cnt;
+  if (*err) {
+    if (t == 1023) *n_out = -1;   // a label or prediction outside 0..255
+    return;
+  }
+  for (int k = 0; k < PER; ++k) {
+    const unsigned long long e = table[t * PER + k];
+    if (!e) continue;
+    if (pos < max_out) {
+      const int row = (int)(0xffffffffu - (unsigned)(e & 0xffffffffu));
+      a3d_click_cluster c;
+      c.cluster_id = t * PER + k;
+      c.row = row;
+      c.label = labels[row];
+      c.pred = pred[row];
+      c.error_size = sqrtf(__uint_as_float((unsigned)(e >> 32)));
+      out[pos] = c;
+    }
+    ++pos;
+  }
+  if (t == 1023) *n_out = sums[1023];
+}
+
+// ---- loss weights: alpha + (beta-alpha) * (1 - min(d, tita)/tita), d = distance to the nearest click ----
+struct ClickRows {
+  int n;
+  int row[A3D_MAX_CLICKS];
+};
+__global__ void k_click_weights(const float* __restrict__ xyz, int64_t n, ClickRows cl, float tita, float alpha,
+                                float beta, float* __restrict__ w) {
+  __shared__ float cx[A3D_MAX_CLICKS], cy[A3D_MAX_CLICKS], cz[A3D_MAX_CLICKS];
+  for (int i = threadIdx.x; i < cl.n; i += blockDim.x) {
+    const int r = cl.row[i];
+    cx[i] = xyz[3 * (int64_t)r]; cy[i] = xyz[3 * (int64_t)r + 1]; cz[i] = xyz[3 * (int64_t)r + 2];
+  }
+  __syncthreads();
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float x = xyz[3 * i], y = xyz[3 * i + 1], z = xyz[3 * i + 2];
+  float best = __uint_as_float(kInfBits);
+  for (int c = 0; c < cl.n; ++c) {
+    const float dx = x - cx[c], dy = y - cy[c], dz = z - cz[c];
+    best = fminf(best, fmaf(dz, dz, fmaf(dy, dy, dx * dx)));
+  }
+  const float d = fminf(sqrtf(best), tita);
+  w[i] = alpha + (beta - alpha) * (1.f - d / tita);
+}
+
+struct ClickWs {
+  float4* cand;
+  int32_t* err_rows;
+  unsigned* d2bits;
+  unsigned long long* table;
+  int* n_err;
+  int* err;
+  size_t bytes;
+};
+static ClickWs carve_click(void* base, int64_t n) {
+  ClickWs w;
+  size_t off = 0;
+  auto take = [&](size_t b) {
+    void* p = base ? (char*)base + off : nullptr;
+    off += align256(b);
+    return p;
+  };
+  w.table = (unsigned long long*)take((size_t)kClusterTable * 8);
+  w.n_err = (int*)take(256);
+  w.err = w.n_err ? w.n_err + 1 : nullptr;
+  w.cand = (float4*)take((size_t)n * 16);
+  w.err_rows = (int32_t*)take((size_t)n * 4);
+  w.d2bits = (unsigned*)take((size_t)n * 4);
+  w.bytes = off;
+  return w;
+}
+
+}  // namespace a3d
+
+using namespace a3d;
+
+extern "C" int a3d_argmax_labels(const float* logits_dev, int64_t n, int n_classes, const int32_t* click_row,
+                                 const int32_t* click_obj, int n_clicks, int32_t* pred_dev, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  if (n < 0 || n_classes < 1 || n_clicks < 0 || n_clicks > A3D_MAX_CLICKS || !pred_dev || (n && !logits_dev)) {
+    set_error("a3d_argmax_labels: bad arguments (n=%lld classes=%d clicks=%d)", (long long)n, n_classes, n_clicks);
+    return A3D_ERR_INVALID;
+  }
+  if (n == 0) return A3D_OK;
+  k_argmax_labels<<<(unsigned)((n + 255) / 256), 256, 0, st>>>(logits_dev, n, n_classes, pred_dev);
+  A3D_LAUNCH_CHECK();
+  if (n_clicks) {
+    ClickList cl;
+    cl.n = n_clicks;
+    for (int i = 0; i < n_clicks; ++i) {
+      if (click_obj[i] < 0 || click_obj[i] > 255) {
+        set_error("a3d_argmax_labels: click object %d out of range", click_obj[i]);
+        return A3D_ERR_INVALID;
+      }
+      cl.row[i] = click_row[i];
+      cl.obj[i] = (unsigned char)click_obj[i];
+    }
+    k_click_overwrite<<<1, 1, 0, st>>>(cl, n, pred_dev);
+    A3D_LAUNCH_CHECK();
+  }
+  return A3D_OK;
+}
+
+extern "C" int a3d_iou_counts(const int32_t* pred_dev, int64_t n_pred, const int64_t* inverse_map_dev,
+                              const int32_t* labels_dev, int64_t n_full, int n_ids, int64_t* counts_dev,
+                              void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  if (n_full < 0 || n_pred < 0 || n_ids < 1 || n_ids > 256 || !counts_dev) {
+    set_error("a3d_iou_counts: bad arguments (n_full=%lld n_ids=%d)", (long long)n_full, n_ids);
+    return A3D_ERR_INVALID;
+  }
+  // counts_dev: [3][n_ids] int64 followed by one int32 error flag slot (caller passes 3*n_ids+1 int64)
+  A3D_HIP_CHECK(hipMemsetAsync(counts_dev, 0, ((size_t)3 * n_ids + 1) * 8, st));
+  if (n_full == 0) return A3D_OK;
+  const int64_t want = (n_full + 1023) / 1024;
+  const unsigned grid = (unsigned)(want < 2048 ? want : 2048);
+  k_iou_counts<<<grid, 256, 0, st>>>(pred_dev, inverse_map_dev, labels_dev, n_full, n_pred, n_ids,
+                                     (unsigned long long*)counts_dev, (int*)(counts_dev + (size_t)3 * n_ids));
+  A3D_LAUNCH_CHECK();
+  return A3D_OK;
+}
+
+extern "C" size_t a3d_click_workspace_bytes(int64_t n) {
+  if (n <= 0 || n > (int64_t)1 << 30) return 0;
+  return carve_click(nullptr, n).bytes;
+}
+
+extern "C" int a3d_click_clusters(const float* xyz_dev, const int32_t* pred_dev, const int32_t* labels_dev,
+                                  int64_t n, a3d_click_cluster* out_dev, int max_out, int32_t* n_out_dev,
+                                  void* workspace_dev, size_t workspace_bytes, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  if (n <= 0 || !xyz_dev || !pred_dev || !labels_dev || !out_dev || !n_out_dev || max_out < 1) {
+    set_error("a3d_click_clusters: bad arguments");
+    return A3D_ERR_INVALID;
+  }
+  ClickWs w = carve_click(workspace_dev, n);
+  if (!workspace_dev || workspace_bytes < w.bytes) {
+    set_error("a3d_click_clusters: workspace %zu < %zu", workspace_bytes, w.bytes);
+    return A3D_ERR_WORKSPACE;
+  }
+  ProfScope prof(st, A3D_PROF_CLICKS);
+  A3D_HIP_CHECK(hipMemsetAsync(w.table, 0, (size_t)kClusterTable * 8 + 256, st));   // table + counters
+  const unsigned nb = (unsigned)((n + 255) / 256);
+  k_err_compact<<<nb, 256, 0, st>>>(xyz_dev, pred_dev, labels_dev, n, w.cand, w.err_rows, w.d2bits, w.n_err, w.err);
+  A3D_LAUNCH_CHECK();
+  const int per_block = kNearestBlock * kQueriesPerThread;
+  int chunk = (int)((n + kNearestSplit - 1) / kNearestSplit);
+  chunk = (chunk + 3) & ~3;
+  dim3 grid((unsigned)((n + per_block - 1) / per_block), (unsigned)((n + chunk - 1) / chunk));
+  k_nearest_other<<<grid, kNearestBlock, 0, st>>>(w.cand, n, w.err_rows, w.n_err, w.d2bits, chunk);
+  A3D_LAUNCH_CHECK();
+  k_cluster_best<<<nb, 256, 0, st>>>(w.cand, w.err_rows, w.n_err, w.d2bits, w.table);
+  A3D_LAUNCH_CHECK();
+  k_cluster_list<<<1, 1024, 0, st>>>(w.table, pred_dev, labels_dev, out_dev, max_out, n_out_dev, w.err);
+  A3D_LAUNCH_CHECK();
+  return A3D_OK;
+}
+
+extern "C" int a3d_click_loss_weights(const float* xyz_dev, int64_t n, const int32_t* click_row, int n_clicks,
+                                      float tita, float alpha, float beta, float* weights_dev, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  if (n <= 0 || n_clicks < 1 || n_clicks > A3D_MAX_CLICKS || !xyz_dev || !weights_dev || !(tita > 0.f)) {
+    set_error("a3d_click_loss_weights: bad arguments (n=%lld clicks=%d)", (long long)n, n_clicks);
+    return A3D_ERR_INVALID;
+  }
+  ClickRows cl;
+  cl.n = n_clicks;
+  for (int i = 0; i < n_clicks; ++i) {
+    if (click_row[i] < 0 || click_row[i] >= n) {
+      set_error("a3d_click_loss_weights: click row %d out of range", click_row[i]);
+      return A3D_ERR_INVALID;
+    }
+    cl.row[i] = click_row[i];
+  }
+  k_click_weights<<<(unsigned)((n + 255) / 256), 256, 0, st>>>(xyz_dev, n, cl, tita, alpha, beta, weights_dev);
+  A3D_LAUNCH_CHECK();
+  return A3D_OK;
+}

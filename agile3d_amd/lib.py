@@ -59,8 +59,14 @@ class ProfEntry(C.Structure):
                                          "ksplit")] + [("ms", C.c_float)]
 
 
+class ClickCluster(C.Structure):
+    _fields_ = [("cluster_id", C.c_int32), ("row", C.c_int32), ("label", C.c_int32), ("pred", C.c_int32),
+                ("error_size", C.c_float)]
+
+
+A3D_MAX_CLICKS = 256
 PROF_NAMES = ["spconv", "splitk_epilogue", "stem", "c2s_attn", "query_chain", "s2c_attn", "ln_mask", "posenc",
-              "scene_sort_levels", "scene_tables"]
+              "scene_sort_levels", "scene_tables", "click_simulator"]
 
 # name -> (restype, argtypes): every symbol include/agile3d_hip.h declares
 SYMBOLS = {
@@ -92,6 +98,15 @@ SYMBOLS = {
                                       C.c_void_p, C.c_int64, C.POINTER(C.c_int32), C.POINTER(C.c_int32),
                                       C.POINTER(C.c_int32), C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t,
                                       C.c_void_p]),
+    "a3d_argmax_labels": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_int32),
+                                    C.c_int, C.c_void_p, C.c_void_p]),
+    "a3d_iou_counts": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p,
+                                 C.c_void_p]),
+    "a3d_click_workspace_bytes": (C.c_size_t, [C.c_int64]),
+    "a3d_click_clusters": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int,
+                                     C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "a3d_click_loss_weights": (C.c_int, [C.c_void_p, C.c_int64, C.POINTER(C.c_int32), C.c_int, C.c_float,
+                                         C.c_float, C.c_float, C.c_void_p, C.c_void_p]),
 }
 
 _lib = None

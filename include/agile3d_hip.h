@@ -54,7 +54,8 @@ enum {
   A3D_PROF_LNMASK = 6,      /* LayerNorm + mask head                                     */
   A3D_PROF_POSENC = 7,      /* Fourier position encoding                                 */
   A3D_PROF_SCENE_SORT = 8,  /* keys + radix sort + level compaction                      */
-  A3D_PROF_SCENE_TABLES = 9 /* hash, neighbour tables, row clustering                    */
+  A3D_PROF_SCENE_TABLES = 9,/* hash, neighbour tables, row clustering                    */
+  A3D_PROF_CLICKS = 10      /* click simulator (error clusters + nearest outside point)  */
 };
 typedef struct {
   int32_t id, bn, kernel_volume, cin, cout, n_out, table, level, ksplit;
@@ -219,6 +220,49 @@ int    a3d_decoder_forward(const a3d_decoder_weights* w,
                            const int32_t* click_time, int n_clicks, int n_objects,
                            float* logits_dev,
                            void* workspace_dev, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * The interactive loop around forward_mask.
+ * Replaces: `p.argmax(-1)` + "update prediction with sparse gt" (eval_multi_obj.py:119-134),
+ * mean_iou_scene (utils/seg.py:44-58), get_simulated_clicks + measure_error_size +
+ * get_next_click_coo_torch (utils/seg.py:93-239) and loss_weights (utils/seg.py:60-69).
+ * Labels and predictions are int32 object ids in 0..255 (0 = background).
+ * ------------------------------------------------------------------------------------------ */
+#define A3D_MAX_CLICKS 256
+
+/* pred[i] = argmax_c logits[i][c] (first maximum), then pred[click_row[k]] = click_obj[k] in the
+ * given order; click arrays are HOST arrays. */
+int    a3d_argmax_labels(const float* logits_dev, int64_t n, int n_classes,
+                         const int32_t* click_row, const int32_t* click_obj, int n_clicks,
+                         int32_t* pred_dev, void* stream);
+
+/* counts_dev: int64 [3][n_ids] + 1 trailing int64 (non-zero = an inverse_map entry was out of
+ * range): [0][id] = |pred==id & label==id|, [1][id] = |pred==id|, [2][id] = |label==id| over the
+ * n_full points i, with pred taken at inverse_map_dev[i] (NULL = identity).  IoU(id) =
+ * [0]/([1]+[2]-[0]). */
+int    a3d_iou_counts(const int32_t* pred_dev, int64_t n_pred, const int64_t* inverse_map_dev,
+                      const int32_t* labels_dev, int64_t n_full, int n_ids,
+                      int64_t* counts_dev, void* stream);
+
+/* One entry per error cluster (cluster id = 96*label + 11*pred over the wrongly labelled points,
+ * utils/seg.py:206): `row` is the cluster point farthest from every point outside the cluster
+ * (lowest row on ties), `error_size` that distance -- the next simulated click and the key the
+ * reference sorts clusters by.  Entries come out in ascending cluster id (torch.unique order). */
+typedef struct {
+  int32_t cluster_id, row, label, pred;
+  float   error_size;
+} a3d_click_cluster;
+size_t a3d_click_workspace_bytes(int64_t n);
+/* *n_out_dev = number of clusters (may exceed max_out: only max_out are written), -1 if a label or
+ * prediction was outside 0..255. */
+int    a3d_click_clusters(const float* xyz_dev, const int32_t* pred_dev, const int32_t* labels_dev,
+                          int64_t n, a3d_click_cluster* out_dev, int max_out, int32_t* n_out_dev,
+                          void* workspace_dev, size_t workspace_bytes, void* stream);
+
+/* weights[i] = alpha + (beta-alpha) * (1 - min(d_i, tita)/tita), d_i = distance of point i to the
+ * nearest clicked point; click_row is a HOST array. */
+int    a3d_click_loss_weights(const float* xyz_dev, int64_t n, const int32_t* click_row, int n_clicks,
+                              float tita, float alpha, float beta, float* weights_dev, void* stream);
 
 #ifdef __cplusplus
 }

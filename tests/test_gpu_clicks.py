@@ -1,0 +1,228 @@
+"""-m gpu: the interactive loop around forward_mask through the C ABI:
+label argmax, IoU counts, the click simulator and the Evaluate loop.
+  * against vectors captured from the reference's utils/seg.py (tests/golden/clicks_cases.npz);
+  * against the CPU oracle on fresh seeded inputs;
+  * at the benchmark size (80 k voxels) against an exact float64 k-d tree.
+Integer results (labels, counts, click rows, click order) are compared bit-exactly; a click row may
+differ from the reference only where two candidates tie within the fp32 error of torch.cdist's
+matmul formula (checked explicitly), distances within 2e-4 m."""
+import os
+import random
+import types
+
+import numpy as np
+import pytest
+import torch
+from scipy.spatial import cKDTree
+
+from agile3d_amd import SparseTensor, build_model, clicks as pc, default_args, randomize_bn_stats
+from agile3d_amd.evaluate import Evaluate
+from agile3d_amd.synthetic import make_scene
+from oracle import backbone as ob, clicks as oc, decoder as od
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+G = np.load(os.path.join(HERE, "golden", "clicks_cases.npz"))
+NAMES = [str(n) for n in G["names"]]
+DIST_TOL = 2e-4
+
+
+def unflat(keys, lens, vals):
+    out, p = {}, 0
+    for k, n in zip(keys, lens):
+        out[str(int(k))] = [int(v) for v in vals[p:p + n]]
+        p += n
+    return out
+
+
+def exact_outside(xyz, cid):
+    """float64 reference: per error point the distance to the nearest point of another cluster."""
+    d = np.full(len(xyz), -1.0)
+    x64 = xyz.astype(np.float64)
+    for c in np.unique(cid[cid >= 0]):
+        m = cid == c
+        d[m] = cKDTree(x64[~m]).query(x64[m])[0]
+    return d
+
+
+def check_clusters(got, xyz, pred, labels, want_rows=None):
+    cid = np.where(pred != labels, 96 * labels.astype(np.int64) + 11 * pred.astype(np.int64), -1)
+    d = exact_outside(xyz, cid)
+    ids = sorted(np.unique(cid[cid >= 0]).tolist())
+    assert [c["cluster_id"] for c in got] == ids
+    for k, c in enumerate(got):
+        m = cid == c["cluster_id"]
+        assert cid[c["row"]] == c["cluster_id"] and c["label"] == labels[c["row"]] and c["pred"] == pred[c["row"]]
+        assert abs(c["error_size"] - d[m].max()) <= 1e-5, (c, d[m].max())
+        assert d[c["row"]] >= d[m].max() - 1e-6          # it IS a farthest point
+        first = int(np.flatnonzero(m & (d >= d[c["row"]] - 1e-7))[0])
+        assert c["row"] <= first or d[c["row"]] > d[first]          # lowest row among exact ties
+        if want_rows is not None and want_rows[k] != c["row"]:
+            assert abs(d[want_rows[k]] - d[c["row"]]) <= DIST_TOL, "differs from the reference beyond a cdist tie"
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_cluster_table_vs_reference(name):
+    xyz, pred, lab = G[f"{name}/xyz"], G[f"{name}/pred"], G[f"{name}/labels"]
+    got = pc.error_clusters(torch.from_numpy(pred).cuda(), torch.from_numpy(lab).cuda(), torch.from_numpy(xyz).cuda())
+    want = G[f"{name}/clusters"]
+    assert [c["cluster_id"] for c in got] == [int(v) for v in want[:, 0]]
+    check_clusters(got, xyz, pred, lab, [int(v) for v in want[:, 1]])
+    assert np.abs(np.array([c["error_size"] for c in got]) - want[:, 2]).max() <= DIST_TOL
+    same = sum(c["row"] == int(w) for c, w in zip(got, want[:, 1]))
+    print(f"{name}: {len(got)} clusters, {same} identical click rows")
+
+
+@pytest.mark.parametrize("name", NAMES)
+@pytest.mark.parametrize("mode", ["eval0", "evalk", "train"])
+def test_simulated_clicks_vs_reference(name, mode):
+    xyz, pred, lab = (torch.from_numpy(G[f"{name}/{k}"]).cuda() for k in ("xyz", "pred", "labels"))
+    seed = int(G[f"{name}/seed"])
+    cur, training, p = {"eval0": (0, False, torch.zeros(len(lab), device="cuda")), "evalk": (7, False, pred.long()),
+                        "train": (None, True, pred.long())}[mode]
+    random.seed(seed)
+    clicks, num, pos, times = pc.get_simulated_clicks(p, lab.long(), xyz, cur, training=training)
+    want_c = unflat(G[f"{name}/{mode}/keys"], G[f"{name}/{mode}/lens"], G[f"{name}/{mode}/rows"])
+    want_t = unflat(G[f"{name}/{mode}/keys"], G[f"{name}/{mode}/lens"], G[f"{name}/{mode}/times"])
+    assert num == int(G[f"{name}/{mode}/num"])
+    assert clicks == want_c and list(clicks) == list(want_c) and times == want_t
+    got_pos = np.stack([x.cpu().numpy() for k in clicks for x in pos[k]])
+    assert np.array_equal(got_pos, G[f"{name}/{mode}/pos"])
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_iou_and_weights_vs_reference(name):
+    xyz, pred, lab = (torch.from_numpy(G[f"{name}/{k}"]).cuda() for k in ("xyz", "pred", "labels"))
+    iou, per = pc.mean_iou_scene(pred, lab)
+    assert np.float32(iou.numpy()) == G[f"{name}/iou"]                       # same fp32 bits
+    assert list(per) == [int(v) for v in G[f"{name}/iou_ids"]]
+    assert np.array_equal(np.array(list(per.values())), G[f"{name}/iou_vals"])
+    c2 = unflat(G[f"{name}/extend/keys"], G[f"{name}/extend/lens"], G[f"{name}/extend/rows"])
+    w = pc.cal_click_loss_weights(torch.zeros(len(lab), dtype=torch.long, device="cuda"), xyz, [lab], [c2])[0]
+    # exact float64 statement of utils/seg.py:60-69 ...
+    x64 = G[f"{name}/xyz"].astype(np.float64)
+    rows = [r for v in c2.values() for r in v]
+    d = cKDTree(x64[rows]).query(x64)[0]
+    assert np.abs(w.cpu().numpy() - (0.8 + 1.2 * (1 - np.minimum(d, 0.3) / 0.3))).max() <= 2e-6
+    # ... and the reference's own output, whose torch.cdist (matmul formula) is off by up to
+    # sqrt(eps * |x|^2) ~ 1e-3 m next to a click: 1.2 / 0.3 * 1e-3 = 4e-3 on the weight
+    assert np.abs(w.cpu().numpy() - G[f"{name}/weights"]).max() <= 4e-3
+
+
+def test_iou_counts_through_inverse_map():
+    rng = np.random.default_rng(3)
+    n, nf = 5000, 23000
+    pred = rng.integers(0, 7, n).astype(np.int32)
+    inv = rng.integers(0, n, nf)
+    lab_full = rng.integers(0, 9, nf).astype(np.int32)
+    c = pc.iou_counts(torch.from_numpy(pred).cuda(), torch.from_numpy(lab_full).cuda(), torch.from_numpy(inv).cuda(), 16)
+    pf = pred[inv]
+    for i in range(16):
+        assert c[0, i] == ((pf == i) & (lab_full == i)).sum() and c[1, i] == (pf == i).sum() and c[2, i] == (lab_full == i).sum()
+    iou, per = pc.mean_iou_scene(torch.from_numpy(pred).cuda(), torch.from_numpy(lab_full).cuda(), torch.from_numpy(inv).cuda())
+    want, wper = oc.mean_iou_scene(torch.from_numpy(pf).long(), torch.from_numpy(lab_full).long())
+    assert np.float32(iou.numpy()) == np.float32(want.numpy()) and per == wper
+    with pytest.raises(RuntimeError):
+        pc.iou_counts(torch.from_numpy(pred).cuda(), torch.from_numpy(lab_full).cuda(), torch.from_numpy(inv + n).cuda())
+
+
+def test_argmax_labels_and_click_overwrite():
+    torch.manual_seed(1)
+    logits = torch.randn(7001, 6, device="cuda")
+    logits[5] = 0.25                       # all equal -> first index
+    logits[6, 2] = logits[6, 4] = 9.0      # tie -> first of the two
+    clicks = {"0": [11], "1": [3, 4], "2": [], "3": [7000, 3]}          # row 3 clicked twice: last wins
+    got = pc.argmax_labels(logits, clicks).cpu()
+    want = logits.cpu().argmax(-1)
+    assert got[5] == 0 and got[6] == 2
+    for k, rows in clicks.items():
+        want[rows] = int(k)
+    assert torch.equal(got.long(), want)
+    assert torch.equal(pc.argmax_labels(logits).cpu().long(), logits.cpu().argmax(-1))
+
+
+def test_full_size_scene_vs_kdtree():
+    """BASELINE size: 80 k voxels, 10 objects, a prediction with large wrong regions."""
+    sc = make_scene(80_000, seed=0)
+    rng = np.random.default_rng(0)
+    labels = np.where(sc["labels"] <= 10, sc["labels"], 0).astype(np.int32)
+    xyz = sc["raw_xyz"]
+    pred = labels.copy()
+    for _ in range(12):
+        i = rng.integers(len(xyz))
+        pred[np.linalg.norm(xyz - xyz[i], axis=1) < rng.uniform(0.2, 1.2)] = rng.integers(0, 11)
+    t = lambda a: torch.from_numpy(a).cuda()
+    got = pc.error_clusters(t(pred), t(labels), t(xyz))
+    assert len(got) > 5
+    check_clusters(got, xyz, pred, labels)
+    zero = pc.error_clusters(torch.zeros(len(labels), device="cuda"), t(labels), t(xyz))     # round 0 of the loop
+    check_clusters(zero, xyz, np.zeros_like(labels), labels)
+    assert pc.error_clusters(t(labels), t(labels), t(xyz)) == []
+    assert pc.get_simulated_clicks(t(labels), t(labels), t(xyz), 3, training=False) == (None, None, None, None)
+
+
+def test_bad_inputs_fail_loudly():
+    with pytest.raises(RuntimeError):
+        pc.error_clusters(torch.zeros(10), torch.zeros(10), torch.zeros(10, 3))          # CPU tensors
+    x = torch.rand(100, 3, device="cuda")
+    with pytest.raises(RuntimeError):
+        pc.error_clusters(torch.full((100,), 300, device="cuda"), torch.zeros(100, device="cuda"), x)
+    with pytest.raises(RuntimeError):                                                   # one cluster = everything
+        pc.error_clusters(torch.ones(100, device="cuda"), torch.zeros(100, device="cuda"), x)
+
+
+def test_evaluate_loop_teacher_forced(tmp_path):
+    """Run the product's Evaluate on one synthetic scene and re-derive every round with the oracle from the
+    product's own state (prediction, clicks, RNG state): CSV rows, IoU bits, next clicks, and the final
+    round's logits (<= 1e-3)."""
+    torch.manual_seed(0)
+    model = randomize_bn_stats(build_model(default_args())).eval()
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    model = model.cuda()
+    sc = make_scene(4000, seed=5)
+    n = len(sc["coords"])
+    ids = [i for i in np.unique(sc["labels"]) if i > 0][:3]
+    labels = np.zeros(n, np.int64)
+    for k, i in enumerate(ids, start=1):
+        labels[sc["labels"] == i] = k
+    rng = np.random.default_rng(1)
+    inv = np.concatenate([np.arange(n), rng.integers(0, n, n)])             # full-res cloud = 2n points
+    labels_full = labels[inv]
+    batch = (torch.from_numpy(sc["coords"]), torch.from_numpy(sc["raw_xyz"]), torch.from_numpy(sc["feats"]),
+             [torch.from_numpy(labels)], [torch.from_numpy(labels_full)], [torch.from_numpy(inv)],
+             [{str(k): [1, 2] for k in range(4)}], ["scene0042_00"], [3])
+    args = types.SimpleNamespace(output_dir=str(tmp_path), max_num_clicks=2, val_list=None)
+    log = []
+
+    def on_round(idx, current, pred, iou, ci, ct):
+        log.append({"current": current, "pred": pred.cpu().clone(), "iou": np.float32(iou.numpy()),
+                    "ci": {k: list(v) for k, v in ci.items()}, "ct": {k: list(v) for k, v in ct.items()},
+                    "rng": random.getstate()})
+
+    random.seed(9)
+    csv = Evaluate(model, [batch], args, torch.device("cuda"), on_round)
+    lines = open(csv).read().strip().split("\n")
+    assert [r["current"] for r in log] == [0, 3, 4, 5, 6] and len(lines) == 5
+    xyz = torch.from_numpy(sc["raw_xyz"])
+    for r, line in zip(log, lines):
+        want_iou, _ = oc.mean_iou_scene(r["pred"].long()[torch.from_numpy(inv)], torch.from_numpy(labels_full))
+        assert r["iou"] == np.float32(want_iou.numpy())
+        assert line == f"0 0042_00 3 {r['current'] / 3} {r['iou']}"
+    assert log[0]["ci"] == {str(k): [] for k in range(4)}                    # click ids set null
+    for a, b in zip(log[:-1], log[1:]):                                      # the clicks added after round a
+        random.setstate(a["rng"])
+        new, _, _, new_t = oc.get_simulated_clicks(a["pred"].long(), torch.from_numpy(labels), xyz, a["current"], False)
+        ci, ct = oc.extend_clicks({k: list(v) for k, v in a["ci"].items()}, {k: list(v) for k, v in a["ct"].items()},
+                                  new, new_t)
+        assert (ci, ct) == (b["ci"], b["ct"])
+    last = log[-1]
+    ref_b = ob.forward_backbone(sd, sc["coords"], torch.from_numpy(sc["feats"]), xyz)
+    ref = od.forward_mask(sd, ref_b["pcd_features"], xyz, ref_b["pos_enc"], last["ci"], last["ct"])[-1]
+    want = ref.argmax(-1)
+    for k, rows in last["ci"].items():
+        want[rows] = int(k)
+    agree = (want == last["pred"].long()).float().mean().item()
+    top2 = ref.topk(2, dim=-1).values
+    unsure = (top2[:, 0] - top2[:, 1]) < 2e-3                                # labels may differ only at near-ties
+    assert bool(((want == last["pred"].long()) | unsure).all()), agree
+    print(f"Evaluate: {len(lines)} rounds, final IoU {last['iou']:.4f}, label agreement with the oracle {agree:.5f}")

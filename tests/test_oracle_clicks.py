@@ -1,0 +1,103 @@
+"""oracle/clicks.py against vectors produced by the reference's own utils/seg.py
+(tests/golden/make_click_goldens.py) -- this is what pins the click-simulator oracle."""
+import json
+import os
+import random
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import clicks as oc
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+G = np.load(os.path.join(HERE, "golden", "clicks_cases.npz"))
+NAMES = [str(n) for n in G["names"]]
+
+
+def unflat(keys, lens, vals):
+    out, p = {}, 0
+    for k, n in zip(keys, lens):
+        out[str(int(k))] = [int(v) for v in vals[p:p + n]]
+        p += n
+    return out
+
+
+def case(name):
+    return (torch.from_numpy(G[f"{name}/xyz"]), torch.from_numpy(G[f"{name}/pred"]).long(),
+            torch.from_numpy(G[f"{name}/labels"]).long(), int(G[f"{name}/seed"]))
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_cluster_table(name):
+    xyz, pred, lab, _ = case(name)
+    got = oc.error_clusters(pred, lab, xyz)
+    want = G[f"{name}/clusters"]
+    assert [c["cluster_id"] for c in got] == [int(v) for v in want[:, 0]]
+    assert [c["row"] for c in got] == [int(v) for v in want[:, 1]]
+    assert np.array_equal(np.array([c["error_size"] for c in got]), want[:, 2])   # same torch.cdist: bit equal
+
+
+@pytest.mark.parametrize("name", NAMES)
+@pytest.mark.parametrize("mode", ["eval0", "evalk", "train"])
+def test_simulated_clicks(name, mode):
+    xyz, pred, lab, seed = case(name)
+    cur, training, p = {"eval0": (0, False, torch.zeros(len(lab))), "evalk": (7, False, pred),
+                        "train": (None, True, pred)}[mode]
+    random.seed(seed)
+    clicks, num, pos, times = oc.get_simulated_clicks(p, lab, xyz, cur, training=training)
+    want_c = unflat(G[f"{name}/{mode}/keys"], G[f"{name}/{mode}/lens"], G[f"{name}/{mode}/rows"])
+    want_t = unflat(G[f"{name}/{mode}/keys"], G[f"{name}/{mode}/lens"], G[f"{name}/{mode}/times"])
+    assert clicks == want_c and list(clicks) == list(want_c)          # same dict order too
+    assert times == want_t
+    assert num == int(G[f"{name}/{mode}/num"])
+    got_pos = np.stack([x.numpy() for k in clicks for x in pos[k]])
+    assert np.array_equal(got_pos, G[f"{name}/{mode}/pos"])
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_iou_extend_weights(name):
+    xyz, pred, lab, seed = case(name)
+    iou, per = oc.mean_iou_scene(pred, lab)
+    assert np.float32(iou.numpy()) == G[f"{name}/iou"]
+    assert list(per) == [int(v) for v in G[f"{name}/iou_ids"]]
+    assert np.array_equal(np.array(list(per.values())), G[f"{name}/iou_vals"])
+    cur = unflat(G[f"{name}/extend/before_keys"], G[f"{name}/extend/before_lens"], G[f"{name}/extend/before_rows"])
+    cur_t = {k: ([int(k)] if v else []) for k, v in cur.items()}
+    random.seed(seed)
+    clicks, _, _, times = oc.get_simulated_clicks(pred, lab, xyz, 3, training=False)
+    c2, t2 = oc.extend_clicks(cur, cur_t, clicks, times)
+    want_c = unflat(G[f"{name}/extend/keys"], G[f"{name}/extend/lens"], G[f"{name}/extend/rows"])
+    want_t = unflat(G[f"{name}/extend/keys"], G[f"{name}/extend/lens"], G[f"{name}/extend/times"])
+    assert c2 == want_c and t2 == want_t
+    w = oc.click_loss_weights(xyz, c2)
+    assert np.array_equal(w.numpy(), G[f"{name}/weights"])
+
+
+def test_no_error_returns_none():
+    xyz = torch.rand(50, 3)
+    lab = torch.randint(0, 3, (50,))
+    assert oc.get_simulated_clicks(lab.clone(), lab, xyz, 3, training=False) == (None, None, None, None)
+
+
+def test_evaluator_mo_golden(tmp_path):
+    """The product's EvaluatorMO is host code; it is pinned directly on the reference's output."""
+    from agile3d_amd.evaluate import EvaluatorMO
+    g = json.load(open(os.path.join(HERE, "golden", "evaluator_case.json")))
+    (tmp_path / "list.json").write_text(json.dumps(g["scene_list"]))
+    (tmp_path / "res.csv").write_text("\n".join(g["lines"]) + "\n")
+    res = EvaluatorMO(str(tmp_path / "list.json"), str(tmp_path / "res.csv"), [0.5, 0.65, 0.8, 0.85, 0.9]).eval_results()
+    assert res == g["expected"]
+    (tmp_path / "none.json").write_text("{}")
+    assert EvaluatorMO(str(tmp_path / "none.json"), str(tmp_path / "res.csv"), [0.5]).eval_per_class(0.5) == 0
+
+
+def test_extend_clicks_host_matches_oracle():
+    from agile3d_amd.clicks import extend_clicks
+    a = {"0": [5], "1": [7, 9], "2": []}
+    t = {"0": [2], "1": [0, 1], "2": []}
+    new, new_t = {"2": [11], "1": [4]}, {"2": [0], "1": [1]}
+    import copy
+    got = extend_clicks(copy.deepcopy(a), copy.deepcopy(t), new, new_t)
+    want = oc.extend_clicks(copy.deepcopy(a), copy.deepcopy(t), new, new_t)
+    assert got == want == ({"0": [5], "1": [7, 9, 4], "2": [11]}, {"0": [2], "1": [0, 1, 4], "2": [3]})
