@@ -11,7 +11,10 @@
 //                                                  never materialises [heads,Q,N]; the label-derived
 //                                                  mask (agile3d.py:367-380) is evaluated from one
 //                                                  byte per point + per-label counts
-//   everything of size [Q,128] (Q <= 64)        -> k_query_layer: one workgroup
+//   everything of size [Q,128]                  -> k_query_layer: one workgroup, activations resident
+//                                                  in LDS (Q <= 64); for 64 < Q <= 256 the queries are
+//                                                  processed in blocks of 64 (one workgroup per block,
+//                                                  split in two launches around the self attention)
 //   scene-to-click attention (Q keys per point) -> k_s2c_attn: MFMA, softmax in registers
 //   LayerNorm + mask head + argmax + histogram  -> k_ln_mask
 // The (pos @ W) halves of the c2s key and s2c query projections are click independent and are
@@ -92,8 +95,11 @@ template <int QT>
 __global__ void __launch_bounds__(512) k_c2s_attn(const float* __restrict__ Kc, const float* __restrict__ V,
                                                   int n, const float* qproj, const int* qobj,
                                                   const unsigned char* labels, const int* counts,
-                                                  float* part) {
+                                                  float* part, int qp_total) {
   const int lane = threadIdx.x & 63;
+  const int qb0 = blockIdx.y * (QT * 16);   // first query of this launch's query block
+  qproj += (size_t)qb0 * D;
+  qobj += qb0;
   const int h = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int g = lane >> 4, j = lane & 15;
   const int pbeg = blockIdx.x * kC2SChunk;
@@ -161,8 +167,7 @@ __global__ void __launch_bounds__(512) k_c2s_attn(const float* __restrict__ Kc, 
       for (int t = 0; t < 4; ++t) acc[qt] = __builtin_amdgcn_mfma_f32_16x16x4f32(vf[t], p[t], acc[qt], 0, 0, 0);
     }
   }
-  const int QP = QT * 16;
-  float* P = part + ((size_t)blockIdx.x * H + h) * QP * kPartStride;
+  float* P = part + (((size_t)blockIdx.x * H + h) * qp_total + qb0) * kPartStride;
 #pragma unroll
   for (int qt = 0; qt < QT; ++qt) {
     float lt = l[qt];
@@ -179,9 +184,7 @@ __global__ void __launch_bounds__(512) k_c2s_attn(const float* __restrict__ Kc, 
 }
 
 // merge the per-chunk flash partials (m, l, acc[16]) of one (query, head): one wave per pair
-template <int QT>
-__global__ void __launch_bounds__(64) k_c2s_combine(const float* __restrict__ part, int nchunk, float* attn) {
-  constexpr int QP = QT * 16;
+__global__ void __launch_bounds__(64) k_c2s_combine(const float* __restrict__ part, int nchunk, float* attn, int QP) {
   const int q = blockIdx.x / H, h = blockIdx.x % H, lane = threadIdx.x;
   float m = kNegBig, l = 0.f, o[DH];
 #pragma unroll
@@ -278,6 +281,91 @@ __global__ void __launch_bounds__(512) k_s2c_attn(const float* __restrict__ Qs, 
   }
 }
 
+
+// The same attention for more than 64 queries: keys/values staged in blocks of 64, online softmax
+// across blocks (per head: running max, partial sum, O^T accumulator in registers).
+template <int QT>
+__global__ void __launch_bounds__(512) k_s2c_attn_wide(const float* __restrict__ Qs, int n, const float* ks,
+                                                       const float* vs, int nq, int nblk, float* O) {
+  constexpr int QP = QT * 16, LD = 132;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* ks_l = (float*)smem;
+  float* vs_l = ks_l + QP * LD;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int g = lane >> 4, j = lane & 15;
+  const int p0 = (blockIdx.x * 8 + wave) * 16;
+  const bool active = p0 < n;
+  const int prow = min(p0 + j, n - 1);
+  const float* qrow = Qs + (size_t)prow * D;
+  float m[H], l[H];
+  f32x4 acc[H];
+#pragma unroll
+  for (int h = 0; h < H; ++h) {
+    m[h] = kNegBig;
+    l[h] = 0.f;
+    acc[h] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
+  for (int kb = 0; kb < nblk; ++kb) {
+    __syncthreads();
+    for (int e = threadIdx.x; e < QP * 32; e += 512) {
+      const int r = e >> 5, c4 = (e & 31) * 4;
+      *(f32x4*)(ks_l + r * LD + c4) = *(const f32x4*)(ks + (size_t)(kb * QP + r) * D + c4);
+      *(f32x4*)(vs_l + r * LD + c4) = *(const f32x4*)(vs + (size_t)(kb * QP + r) * D + c4);
+    }
+    __syncthreads();
+    if (!active) continue;
+#pragma unroll
+    for (int h = 0; h < H; ++h) {
+      const f32x4 qf = *(const f32x4*)(qrow + h * DH + 4 * g);
+      f32x4 s[QT];
+      float mx = kNegBig;
+#pragma unroll
+      for (int kt = 0; kt < QT; ++kt) {
+        const f32x4 kf = *(const f32x4*)(ks_l + (kt * 16 + j) * LD + h * DH + 4 * g);
+        s[kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < 4; ++t) s[kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[t], qf[t], s[kt], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          if (kb * QP + kt * 16 + 4 * g + t >= nq) s[kt][t] = kNegBig;
+          mx = fmaxf(mx, s[kt][t]);
+        }
+      }
+      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      const float mnew = fmaxf(m[h], mx);
+      const float sc = expf(m[h] - mnew);
+      m[h] = mnew;
+      float ps = 0.f;
+#pragma unroll
+      for (int kt = 0; kt < QT; ++kt)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          s[kt][t] = expf(s[kt][t] - mnew);
+          ps += s[kt][t];
+        }
+      l[h] = l[h] * sc + ps;
+      acc[h] *= sc;
+#pragma unroll
+      for (int kt = 0; kt < QT; ++kt)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const float vf = vs_l[(kt * 16 + 4 * g + t) * LD + h * DH + j];
+          acc[h] = __builtin_amdgcn_mfma_f32_16x16x4f32(vf, s[kt][t], acc[h], 0, 0, 0);
+        }
+    }
+  }
+  if (!active) return;
+  float* orow = O + (size_t)prow * D;
+#pragma unroll
+  for (int h = 0; h < H; ++h) {
+    float lt = l[h];
+    lt += __shfl_xor(lt, 16, 64);
+    lt += __shfl_xor(lt, 32, 64);
+    if (p0 + j < n) *(f32x4*)(orow + h * DH + 4 * g) = acc[h] * (1.f / lt);
+  }
+}
+
 // ------------------------------------------------------------------------------ LN + mask head
 // src_new = LayerNorm(Y) (in place); logits[p, q] = src_new[p] . E[q]; per-object max -> [1+K];
 // argmax (first max) -> label byte; per-label histogram.  4 waves x 16 points per workgroup.
@@ -285,19 +373,15 @@ template <int QT>
 __global__ void __launch_bounds__(256) k_ln_mask(float* Y, int n, const float* __restrict__ gamma,
                                                  const float* __restrict__ beta, const float* E, int nq,
                                                  const int* qrange /*[K+2]*/, int n_fg, int K, float* logits,
-                                                 unsigned char* labels, int* counts) {
-  constexpr int QP = QT * 16, LD = 132, LL = QP + 1;
+                                                 unsigned char* labels, int* counts, int nblk) {
+  constexpr int QP = QT * 16, LD = 132;
+  const int LL = nblk * QP + 1;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* E_l = (float*)smem;                    // [QP][132]
   float* L_l = E_l + QP * LD;                   // [4 waves][16][LL]
   float* O_l = L_l + 4 * 16 * LL;               // [4 waves][16][K+1]
   int* hist = (int*)(O_l + 4 * 16 * (K + 1));   // [K+1]
-  for (int e = threadIdx.x; e < QP * 32; e += 256) {
-    const int r = e >> 5, c4 = (e & 31) * 4;
-    *(f32x4*)(E_l + r * LD + c4) = *(const f32x4*)(E + (size_t)r * D + c4);
-  }
   for (int e = threadIdx.x; e <= K; e += 256) hist[e] = 0;
-  __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int g = lane >> 4, j = lane & 15;
   const int p0 = (blockIdx.x * 4 + wave) * 16;
@@ -305,9 +389,9 @@ __global__ void __launch_bounds__(256) k_ln_mask(float* Y, int n, const float* _
   const int prow = min(p0 + j, n - 1);
   float* Lw = L_l + wave * 16 * LL;
   float* Ow = O_l + wave * 16 * (K + 1);
+  f32x4 y[8];
   if (wave_active) {
     float* yrow = Y + (size_t)prow * D;
-    f32x4 y[8];
     float sum = 0.f;
 #pragma unroll
     for (int S = 0; S < 8; ++S) {
@@ -336,6 +420,15 @@ __global__ void __launch_bounds__(256) k_ln_mask(float* Y, int n, const float* _
       for (int t = 0; t < 4; ++t) y[S][t] = (y[S][t] - mean) * rstd * ga[t] + be[t];
       if (p0 + j < n) *(f32x4*)(yrow + 16 * S + 4 * g) = y[S];
     }
+  }
+  for (int qb = 0; qb < nblk; ++qb) {   // mask-embedding rows of 64 queries at a time through LDS
+    if (qb) __syncthreads();
+    for (int e = threadIdx.x; e < QP * 32; e += 256) {
+      const int r = e >> 5, c4 = (e & 31) * 4;
+      *(f32x4*)(E_l + r * LD + c4) = *(const f32x4*)(E + (size_t)(qb * QP + r) * D + c4);
+    }
+    __syncthreads();
+    if (!wave_active) continue;
 #pragma unroll
     for (int qt = 0; qt < QT; ++qt) {
       f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -346,7 +439,7 @@ __global__ void __launch_bounds__(256) k_ln_mask(float* Y, int n, const float* _
         for (int t = 0; t < 4; ++t) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(y[S][t], ef[t], acc, 0, 0, 0);
       }
 #pragma unroll
-      for (int t = 0; t < 4; ++t) Lw[(4 * g + t) * LL + qt * 16 + j] = acc[t];
+      for (int t = 0; t < 4; ++t) Lw[(4 * g + t) * LL + qb * QP + qt * 16 + j] = acc[t];
     }
   }
   __syncthreads();
@@ -507,12 +600,17 @@ __global__ void __launch_bounds__(512) k_query_init(const QueryMeta* meta, const
                                                      QueryBufs B, int* counts, int n_counts) {
   constexpr int QP = QT * 16;
   __shared__ __attribute__((aligned(16))) float lds[QP * kLinLD];
-  const int Q = meta->nq, n_fg = meta->n_fg, n_bgl = meta->n_bgl;
-  for (int e = threadIdx.x; e < n_counts; e += blockDim.x) counts[e] = 0;
+  const int q0 = blockIdx.x * QP;                 // this workgroup's block of queries
+  const int Q = max(0, min(QP, meta->nq - q0)), n_fg = meta->n_fg, n_bgl = meta->n_bgl;
+  B.queries += (size_t)q0 * D; B.qpos += (size_t)q0 * D; B.qproj += (size_t)q0 * D;
+  B.ks += (size_t)q0 * D; B.vs += (size_t)q0 * D; B.E += (size_t)q0 * D;
+  if (blockIdx.x == 0)
+    for (int e = threadIdx.x; e < n_counts; e += blockDim.x) counts[e] = 0;
   for (int e = threadIdx.x; e < QP * D; e += blockDim.x) {
-    const int q = e >> 7, c = e & 127;
+    const int c = e & 127;
+    const int q = q0 + (e >> 7);
     float f = 0.f, p = 0.f;
-    if (q < Q) {
+    if (q < meta->nq) {
       const int r = meta->row[q];
       if (r >= 0) {   // clicked query: feature + Fourier(click xyz) + time encoding (agile3d.py:213-264)
         f = feats128[(size_t)r * D + c];
@@ -613,19 +711,30 @@ __device__ __forceinline__ void qadd_ln(const float* a, const float* b, int Q, c
   }
 }
 
-template <int QT>
+// PART 0: the whole layer in one workgroup (nq <= 64).  More queries run as blocks of QP rows, one
+// workgroup each, in two launches around the click-to-click attention (which needs every block's
+// keys/values): PART 1 = steps 1-2 up to the q/k/v projections (tgt kept in B.tgt), PART 2 = the rest.
+template <int QT, int PART>
 __global__ void __launch_bounds__(512) k_query_layer(const QueryMeta* meta, QueryLayerW W, QueryBufs B) {
   constexpr int QP = QT * 16;
+  const int q0 = blockIdx.x * QP;
+  const int Qall = meta->nq;
+  const float* all_qk = B.qk;
+  const float* all_vc = B.vc;
+  B.queries += (size_t)q0 * D; B.qpos += (size_t)q0 * D; B.qproj += (size_t)q0 * D; B.attn += (size_t)q0 * D;
+  B.ks += (size_t)q0 * D; B.vs += (size_t)q0 * D; B.E += (size_t)q0 * D; B.tgt += (size_t)q0 * D;
+  B.qk += (size_t)q0 * 2 * D; B.vc += (size_t)q0 * D;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* qpos = (float*)smem;            // [QP][132]  query position encodings (later: mask MLP hidden)
   float* cur = qpos + QP * kQLD;         // queries -> tgt -> queries
   float* xa = cur + QP * kQLD;           // GEMM input staging
   float* xb = xa + QP * kQLD;            // GEMM output staging / FFN hidden chunk
-  const int Q = meta->nq;
+  const int Q = max(0, min(QP, Qall - q0));
   const int tid = threadIdx.x, nt = blockDim.x;
   const int wave = tid >> 6;
   f32x4 wfa[8], wfb[8], acc[QT];
 
+  if constexpr (PART != 2) {
   // ---- load the layer inputs (queries, qpos, click-to-scene attention result) into LDS
   qload_w(W.c2s_out_wt, D, 16 * wave, 0, wfa);                      // first round's weights meanwhile
   for (int e = tid; e < QP * 32; e += nt) {
@@ -666,6 +775,22 @@ __global__ void __launch_bounds__(512) k_query_layer(const QueryMeta* meta, Quer
   qzero<QT>(acc);
   qmm<QT>(cur, wfa, acc);
   qstore<QT>(acc, W.c2c_in_b, 2 * D + 16 * wave, 1.f, false, B.vc, D, 16 * wave, Q);          // v
+  if constexpr (PART == 1) {
+    for (int e = tid; e < QP * 32; e += nt) {
+      const int q = e >> 5, c4 = (e & 31) * 4;
+      *(f32x4*)(B.tgt + (size_t)q * D + c4) = *(const f32x4*)(cur + q * kQLD + c4);
+    }
+    return;
+  }
+  } else {
+    for (int e = tid; e < QP * 32; e += nt) {
+      const int q = e >> 5, c4 = (e & 31) * 4;
+      *(f32x4*)(cur + q * kQLD + c4) = *(const f32x4*)(B.tgt + (size_t)q * D + c4);
+      f32x4 vp = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (q < Q) vp = *(const f32x4*)(B.qpos + (size_t)q * D + c4);
+      *(f32x4*)(qpos + q * kQLD + c4) = vp;
+    }
+  }
   qload_w(W.c2c_out_wt, D, 16 * wave, 0, wfa);                      // next round's weights
   __syncthreads();
   for (int e = tid; e < Q * H; e += nt) {
@@ -674,23 +799,23 @@ __global__ void __launch_bounds__(512) k_query_layer(const QueryMeta* meta, Quer
 #pragma unroll
     for (int d = 0; d < DH; ++d) qv[d] = B.qk[(size_t)q * 2 * D + h * DH + d];
     float mx = kNegBig;
-    for (int k = 0; k < Q; ++k) {
+    for (int k = 0; k < Qall; ++k) {
       float sdot = 0.f;
 #pragma unroll
-      for (int d = 0; d < DH; ++d) sdot += qv[d] * B.qk[(size_t)k * 2 * D + D + h * DH + d];
+      for (int d = 0; d < DH; ++d) sdot += qv[d] * all_qk[(size_t)k * 2 * D + D + h * DH + d];
       mx = fmaxf(mx, sdot);
     }
     float sum = 0.f, o[DH];
 #pragma unroll
     for (int d = 0; d < DH; ++d) o[d] = 0.f;
-    for (int k = 0; k < Q; ++k) {
+    for (int k = 0; k < Qall; ++k) {
       float sdot = 0.f;
 #pragma unroll
-      for (int d = 0; d < DH; ++d) sdot += qv[d] * B.qk[(size_t)k * 2 * D + D + h * DH + d];
+      for (int d = 0; d < DH; ++d) sdot += qv[d] * all_qk[(size_t)k * 2 * D + D + h * DH + d];
       const float pw = expf(sdot - mx);
       sum += pw;
 #pragma unroll
-      for (int d = 0; d < DH; ++d) o[d] += pw * B.vc[(size_t)k * D + h * DH + d];
+      for (int d = 0; d < DH; ++d) o[d] += pw * all_vc[(size_t)k * D + h * DH + d];
     }
     const float inv = 1.f / sum;
 #pragma unroll
@@ -832,7 +957,7 @@ struct DecLayout {
   size_t buf[4], labels, counts, part, meta, q[12], queues, total;
   int qp, nchunk;
 };
-int round_qp(int nq) { return nq <= 16 ? 16 : nq <= 32 ? 32 : nq <= 48 ? 48 : 64; }
+int round_qp(int nq) { return nq <= 16 ? 16 : nq <= 32 ? 32 : nq <= 48 ? 48 : (nq + 63) / 64 * 64; }
 void dec_layout(int64_t n, int nq, DecLayout& L) {
   size_t off = 0;
   auto take = [&](size_t bytes) {
@@ -870,6 +995,7 @@ static int run_decoder(const a3d_decoder_weights* w, const float* feats128, cons
                        const DecLayout& L, hipStream_t st) {
   constexpr int QP = QT * 16;
   const int n = (int)n64, K = hm.K, nq = hm.nq;
+  const int nblk = L.qp / QP;          // query blocks (1 unless nq > 64)
   float* bufA = (float*)(ws + L.buf[0]);
   float* bufB = (float*)(ws + L.buf[1]);
   float* bufC = (float*)(ws + L.buf[2]);
@@ -895,10 +1021,16 @@ static int run_decoder(const a3d_decoder_weights* w, const float* feats128, cons
     static bool big = false;
     if (!big) {
       big = true;
-      (void)hipFuncSetAttribute((const void*)k_query_layer<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      (void)hipFuncSetAttribute((const void*)k_query_layer<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      (void)hipFuncSetAttribute((const void*)k_query_layer<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      (void)hipFuncSetAttribute((const void*)k_query_layer<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      const int big_lds = 160 * 1024;
+      (void)hipFuncSetAttribute((const void*)k_query_layer<1, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, big_lds);
+      (void)hipFuncSetAttribute((const void*)k_query_layer<2, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, big_lds);
+      (void)hipFuncSetAttribute((const void*)k_query_layer<3, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, big_lds);
+      (void)hipFuncSetAttribute((const void*)k_query_layer<4, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, big_lds);
+      (void)hipFuncSetAttribute((const void*)k_query_layer<4, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, big_lds);
+      (void)hipFuncSetAttribute((const void*)k_query_layer<4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, big_lds);
+      (void)hipFuncSetAttribute((const void*)k_s2c_attn_wide<4>, hipFuncAttributeMaxDynamicSharedMemorySize, big_lds);
+      (void)hipFuncSetAttribute((const void*)k_s2c_attn<4>, hipFuncAttributeMaxDynamicSharedMemorySize, big_lds);
+      (void)hipFuncSetAttribute((const void*)k_ln_mask<4>, hipFuncAttributeMaxDynamicSharedMemorySize, big_lds);
     }
   }
   A3D_HIP_CHECK(hipMemcpyAsync(meta, &hm, sizeof(QueryMeta), hipMemcpyHostToDevice, st));
@@ -907,14 +1039,18 @@ static int run_decoder(const a3d_decoder_weights* w, const float* feats128, cons
   const int n_counts = A3D_MAX_DEC_LAYERS * (A3D_MAX_QUERIES + 1);
   {
   ProfScope ps(st, A3D_PROF_QUERY, 0, 0, 0, 0, nq);
-  k_query_init<QT><<<1, 512, 0, st>>>(meta, feats128, posenc, w->bg_query_feat, w->bg_query_pos, w->time_table,
+  k_query_init<QT><<<nblk, 512, 0, st>>>(meta, feats128, posenc, w->bg_query_feat, w->bg_query_pos, w->time_table,
                                        w->layers[0].c2s_in_w, w->layers[0].c2s_in_b, B, counts, n_counts);
   }
   A3D_LAUNCH_CHECK();
   const size_t one = align256((size_t)n * D * 4);
   const float* src = feats128;
   const size_t s2c_lds = (size_t)2 * QP * 132 * 4;
-  const size_t lnm_lds = ((size_t)QP * 132 + 4 * 16 * (QP + 1) + 4 * 16 * (K + 1)) * 4 + (size_t)(K + 1) * 4;
+  const size_t lnm_lds = ((size_t)QP * 132 + 4 * 16 * (L.qp + 1) + 4 * 16 * (K + 1)) * 4 + (size_t)(K + 1) * 4;
+  if (lnm_lds > 160 * 1024) {
+    set_error("a3d_decoder_forward: %d queries x %d objects need %zu bytes of LDS in the mask head", nq, K, lnm_lds);
+    return A3D_ERR_UNSUPPORTED;
+  }
   for (int l = 0; l < w->n_layers; ++l) {
     const a3d_decoder_layer& LW = w->layers[l];
     const float* posk = (const float*)((const char*)cache + (size_t)(2 * l) * one);
@@ -928,8 +1064,8 @@ static int run_decoder(const a3d_decoder_weights* w, const float* feats128, cons
     const int* prev_counts = l > 0 ? counts + (size_t)(l - 1) * (A3D_MAX_QUERIES + 1) : nullptr;
     {
     ProfScope ps(st, A3D_PROF_C2S, 0, 0, 0, 0, n);
-    k_c2s_attn<QT><<<L.nchunk, 512, 0, st>>>(bufA, bufB, n, B.qproj, meta->obj, l > 0 ? labels : nullptr,
-                                            prev_counts, part);
+    k_c2s_attn<QT><<<dim3(L.nchunk, nblk), 512, 0, st>>>(bufA, bufB, n, B.qproj, meta->obj,
+                                                          l > 0 ? labels : nullptr, prev_counts, part, L.qp);
     }
     A3D_LAUNCH_CHECK();
     QueryLayerW QW;
@@ -947,8 +1083,14 @@ static int run_decoder(const a3d_decoder_weights* w, const float* feats128, cons
     QW.dim_ff = w->dim_ff;
     {
     ProfScope ps(st, A3D_PROF_QUERY, 0, 0, 0, 0, nq);
-    k_c2s_combine<QT><<<nq * H, 64, 0, st>>>(part, L.nchunk, B.attn);
-    k_query_layer<QT><<<1, 512, (size_t)4 * QP * kQLD * 4, st>>>(meta, QW, B);
+    k_c2s_combine<<<nq * H, 64, 0, st>>>(part, L.nchunk, B.attn, L.qp);
+    const size_t ql_lds = (size_t)4 * QP * kQLD * 4;
+    if (nblk == 1) {
+      k_query_layer<QT, 0><<<1, 512, ql_lds, st>>>(meta, QW, B);
+    } else {
+      k_query_layer<QT, 1><<<nblk, 512, ql_lds, st>>>(meta, QW, B);
+      k_query_layer<QT, 2><<<nblk, 512, ql_lds, st>>>(meta, QW, B);
+    }
     }
     A3D_LAUNCH_CHECK();
     // ---- scene-to-click: Q = src Wq^T + (pos Wq^T + bq); attention; Y = O Wo^T + bo + src; LN
@@ -956,7 +1098,10 @@ static int run_decoder(const a3d_decoder_weights* w, const float* feats128, cons
     if (rc) return rc;
     {
     ProfScope ps(st, A3D_PROF_S2C, 0, 0, 0, 0, n);
-    k_s2c_attn<QT><<<(n + 127) / 128, 512, s2c_lds, st>>>(bufA, n, B.ks, B.vs, nq, bufB);
+    if (nblk == 1)
+      k_s2c_attn<QT><<<(n + 127) / 128, 512, s2c_lds, st>>>(bufA, n, B.ks, B.vs, nq, bufB);
+    else
+      k_s2c_attn_wide<QT><<<(n + 127) / 128, 512, s2c_lds, st>>>(bufA, n, B.ks, B.vs, nq, nblk, bufB);
     }
     A3D_LAUNCH_CHECK();
     float* Y = (l & 1) ? bufD : bufC;
@@ -966,7 +1111,7 @@ static int run_decoder(const a3d_decoder_weights* w, const float* feats128, cons
     ProfScope ps(st, A3D_PROF_LNMASK, 0, 0, 0, 0, n);
     k_ln_mask<QT><<<(n + 63) / 64, 256, lnm_lds, st>>>(Y, n, LW.s2c_norm_w, LW.s2c_norm_b, B.E, nq, meta->qrange,
                                                       hm.n_fg, K, logits + (size_t)l * n * (K + 1), labels,
-                                                      counts + (size_t)l * (A3D_MAX_QUERIES + 1));
+                                                      counts + (size_t)l * (A3D_MAX_QUERIES + 1), nblk);
     }
     A3D_LAUNCH_CHECK();
     src = Y;
@@ -989,7 +1134,7 @@ extern "C" int a3d_decoder_forward(const a3d_decoder_weights* w, const float* fe
     return A3D_ERR_INVALID;
   }
   const int nq = n_clicks + w->n_bg_queries;
-  if (nq > A3D_MAX_QUERIES || n_objects > 254) {
+  if (nq > A3D_MAX_QUERIES || n_objects > 254 || n_clicks > 200) {
     set_error("a3d_decoder_forward: %d queries > %d", nq, A3D_MAX_QUERIES);
     return A3D_ERR_UNSUPPORTED;
   }

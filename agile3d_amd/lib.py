@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libagile3d_hip.so")
 
 A3D_NUM_LEVELS = 5
-A3D_MAX_QUERIES = 64
+A3D_MAX_QUERIES = 256
 A3D_MAX_DEC_LAYERS = 8
 OP_STEM, OP_CONV3, OP_DOWN, OP_UP, OP_LINEAR = 0, 1, 2, 3, 4
 BUF_NONE, BUF_EXT_OUT = -1, -2

@@ -171,7 +171,7 @@ int a3d_posenc_fourier(const float* xyz_dev, int64_t n, const float* gauss_B_dev
  * CrossAttentionLayer / SelfAttentionLayer / FFNLayer (models/modules/attention_block.py).
  * One call = one batch sample, all `n_layers` decoder iterations.
  * ------------------------------------------------------------------------------------------ */
-#define A3D_MAX_QUERIES 64
+#define A3D_MAX_QUERIES 256       /* clicks + learned background queries of one sample */
 #define A3D_MAX_DEC_LAYERS 8
 
 typedef struct {

@@ -226,3 +226,33 @@ def test_evaluate_loop_teacher_forced(tmp_path):
     unsure = (top2[:, 0] - top2[:, 1]) < 2e-3                                # labels may differ only at near-ties
     assert bool(((want == last["pred"].long()) | unsure).all()), agree
     print(f"Evaluate: {len(lines)} rounds, final IoU {last['iou']:.4f}, label agreement with the oracle {agree:.5f}")
+
+
+def test_evaluate_full_protocol(tmp_path):
+    """The reference's protocol end to end: up to 20 clicks per object (eval_multi_obj.py:70,114) on a batch
+    of one 5-object scene -> 100 clicks + 10 learned background queries (two 64-query blocks in the
+    decoder), results CSV -> EvaluatorMO tables."""
+    import json
+    torch.manual_seed(0)
+    model = randomize_bn_stats(build_model(default_args())).eval().cuda()
+    sc = make_scene(5000, seed=8)
+    n = len(sc["coords"])
+    sizes = sorted(((int((sc["labels"] == i).sum()), i) for i in np.unique(sc["labels"]) if i > 0), reverse=True)
+    labels = np.zeros(n, np.int64)
+    for k, (_, i) in enumerate(sizes[:5], start=1):
+        labels[sc["labels"] == i] = k
+    batch = (torch.from_numpy(sc["coords"]), torch.from_numpy(sc["raw_xyz"]), torch.from_numpy(sc["feats"]),
+             [torch.from_numpy(labels)], [torch.from_numpy(labels)], [torch.arange(n)],
+             [{str(k): [] for k in range(6)}], ["scene0007_01"], [5])
+    (tmp_path / "val.json").write_text(json.dumps({"scene0007_01_obj_5": {}}))
+    args = types.SimpleNamespace(output_dir=str(tmp_path), max_num_clicks=20, val_list=str(tmp_path / "val.json"))
+    seen = []
+    random.seed(3)
+    res = Evaluate(model, [batch], args, torch.device("cuda"),
+                   lambda idx, cur, pred, iou, ci, ct: seen.append((cur, sum(len(v) for v in ci.values()))))
+    lines = open(tmp_path / "val_results_multi.csv").read().strip().split("\n")
+    assert [c for c, _ in seen] == [0] + list(range(5, 101)) and len(lines) == 97
+    assert all(have <= cur for cur, have in seen) and seen[1][1] == 5      # one click per object after round 0
+    assert seen[-1][1] > 64                                                # the wide (>64 query) path ran
+    assert set(res) == {"NoC@50", "NoC@65", "NoC@80", "NoC@85", "NoC@90", "IoU@1", "IoU@3", "IoU@5", "IoU@10", "IoU@15"}
+    assert all(0.0 <= res[k] <= 1.0 for k in res if k.startswith("IoU")) and all(1.0 <= res[k] <= 20.0 for k in res if k.startswith("NoC"))

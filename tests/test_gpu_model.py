@@ -99,6 +99,41 @@ def test_forward_mask_matches_reference_goldens(model_and_sd, name, decoder_weig
     assert perr <= 1e-4 and worst <= TOL
 
 
+@pytest.mark.parametrize("n_obj,per_obj,n_bg", [(5, 7, 3), (6, 8, 5), (6, 9, 1), (8, 15, 10), (8, 24, 8)])
+def test_forward_mask_many_clicks(model_and_sd, decoder_weights, n_obj, per_obj, n_bg):
+    """48 / 63 queries (three / four 16-query tiles in one workgroup) and 65 / 140 / 210 queries (two to four
+    64-query blocks: the full evaluation protocol reaches 20 clicks per object, eval_multi_obj.py:114)
+    against the oracle's forward_mask on the same decoder inputs."""
+    model, sd = model_and_sd
+    g = torch.Generator().manual_seed(n_obj * 100 + per_obj)
+    n = 6000
+    feats = torch.randn(n, 128, generator=g) * 0.5
+    xyz = torch.rand(n, 3, generator=g) * torch.tensor([8.0, 6.0, 2.6])
+    rows = torch.randperm(n, generator=g)[:n_obj * per_obj + n_bg].tolist()
+    order = torch.randperm(len(rows), generator=g).tolist()           # click times are a global order
+    ci = {str(o): rows[(o - 1) * per_obj:o * per_obj] for o in range(1, n_obj + 1)}
+    ct = {str(o): order[(o - 1) * per_obj:o * per_obj] for o in range(1, n_obj + 1)}
+    ci["0"], ct["0"] = rows[n_obj * per_obj:], order[n_obj * per_obj:]
+    eng = model._get_engine()
+    pcd, aux, coords, pos = eng.decoder_inputs(feats, xyz)
+    out = model.forward_mask(pcd, aux, coords, pos, click_idx=[ci], click_time_idx=[ct])
+    got = [a["pred_masks"][0] for a in out["aux_outputs"]] + [out["pred_masks"][0]]
+    ref = od.forward_mask(sd, feats, xyz, pos[4][0][0].cpu(), ci, ct)
+    for i in range(3):
+        err = (got[i].cpu() - ref[i]).abs().max().item()
+        print(f"{len(rows) + 10} queries, iteration {i}: logits max|diff|={err:.3e} (scale {ref[i].abs().max():.2f})")
+        assert err <= TOL * max(1.0, ref[i].abs().max().item())
+
+
+def test_too_many_clicks_is_an_error(model_and_sd):
+    model, _ = model_and_sd
+    eng = model._get_engine()
+    pcd, aux, coords, pos = eng.decoder_inputs(torch.randn(3000, 128), torch.rand(3000, 3))
+    ci = {"0": [], "1": list(range(201))}                              # the time table has 200 entries
+    with pytest.raises(Exception):
+        model.forward_mask(pcd, aux, coords, pos, click_idx=[ci], click_time_idx=[{"0": [], "1": list(range(201))}])
+
+
 def test_batch_of_two_equals_two_single_scenes(model_and_sd):
     """Inference has no cross-scene coupling (BatchNorm uses running stats; agile3d.py:192 loops over
     samples): a 2-scene batch must reproduce the two single-scene results."""
