@@ -17,8 +17,8 @@
 //                                                  split in two launches around the self attention)
 //   scene-to-click attention (Q keys per point) -> k_s2c_attn: MFMA, softmax in registers
 //   LayerNorm + mask head + argmax + histogram  -> k_ln_mask
-// The (pos @ W) halves of the c2s key and s2c query projections are click independent and are
-// cached per scene (a3d_decoder_build_cache).
+// The position encoding is added to the GEMM input on the fly (K = (src + pos) Wk^T, Q likewise):
+// k_dense reads both operands once, nothing click-independent is cached.
 #include "common.h"
 
 namespace a3d {
@@ -910,10 +910,6 @@ extern "C" int a3d_posenc_fourier(const float* xyz_dev, int64_t n, const float* 
   return A3D_OK;
 }
 
-extern "C" size_t a3d_decoder_cache_bytes(int64_t n, int n_layers) {
-  return (size_t)n_layers * 2 * align256((size_t)n * D * 4);
-}
-
 static int check_weights(const a3d_decoder_weights* w) {
   if (!w || w->n_layers < 1 || w->n_layers > A3D_MAX_DEC_LAYERS || w->n_bg_queries < 0 ||
       w->n_bg_queries > A3D_MAX_QUERIES || w->dim_ff % 128 != 0) {
@@ -923,38 +919,9 @@ static int check_weights(const a3d_decoder_weights* w) {
   return A3D_OK;
 }
 
-extern "C" int a3d_decoder_build_cache(const a3d_decoder_weights* w, const float* posenc_dev, int64_t n,
-                                       void* cache_dev, size_t cache_bytes, void* workspace_dev,
-                                       size_t workspace_bytes, void* stream) {
-  int rc = check_weights(w);
-  if (rc) return rc;
-  if (!posenc_dev || !cache_dev || cache_bytes < a3d_decoder_cache_bytes(n, w->n_layers)) {
-    set_error("a3d_decoder_build_cache: bad arguments / cache too small");
-    return A3D_ERR_INVALID;
-  }
-  const size_t one = align256((size_t)n * D * 4);
-  const bool have_q = workspace_dev && workspace_bytes >= (size_t)2 * A3D_MAX_DEC_LAYERS * 512;
-  if (have_q) A3D_HIP_CHECK(hipMemsetAsync(workspace_dev, 0, (size_t)2 * A3D_MAX_DEC_LAYERS * 512, (hipStream_t)stream));
-  for (int l = 0; l < w->n_layers; ++l) {
-    const a3d_decoder_layer& L = w->layers[l];
-    char* q0 = have_q ? (char*)workspace_dev + (size_t)(2 * l) * 512 : nullptr;
-    char* q1 = have_q ? (char*)workspace_dev + (size_t)(2 * l + 1) * 512 : nullptr;
-    float* posk = (float*)((char*)cache_dev + (size_t)(2 * l) * one);
-    float* posq = (float*)((char*)cache_dev + (size_t)(2 * l + 1) * one);
-    // pos @ Wk^T + bk   (bias rows D..2D of in_proj_bias) ; pos @ Wq^T + bq (rows 0..D)
-    rc = a3d_linear(posenc_dev, D, n, D, D, L.c2s_wk_packed, nullptr, L.c2s_in_b + D, nullptr, 0, 0, posk, D,
-                    q0, q0 ? 512 : 0, stream);
-    if (rc) return rc;
-    rc = a3d_linear(posenc_dev, D, n, D, D, L.s2c_wq_packed, nullptr, L.s2c_in_b, nullptr, 0, 0, posq, D,
-                    q1, q1 ? 512 : 0, stream);
-    if (rc) return rc;
-  }
-  return A3D_OK;
-}
-
 namespace {
 struct DecLayout {
-  size_t buf[4], labels, counts, part, meta, q[12], queues, total;
+  size_t buf[4], labels, counts, part, meta, q[12], total;
   int qp, nchunk;
 };
 int round_qp(int nq) { return nq <= 16 ? 16 : nq <= 32 ? 32 : nq <= 48 ? 48 : (nq + 63) / 64 * 64; }
@@ -977,7 +944,6 @@ void dec_layout(int64_t n, int nq, DecLayout& L) {
   L.q[9] = take(2 * qb);                                // qk
   L.q[10] = take(qb);                                   // vc
   L.q[11] = take((size_t)L.qp * 4096 * 4);              // hidden (dim_ff <= 4096)
-  L.queues = take((size_t)A3D_MAX_DEC_LAYERS * 4 * 512); // zeroed tile-queue heads, one slot per GEMM
   L.total = off;
 }
 }  // namespace
@@ -990,8 +956,7 @@ extern "C" size_t a3d_decoder_workspace_bytes(int64_t n, int n_queries) {
 }
 
 template <int QT>
-static int run_decoder(const a3d_decoder_weights* w, const float* feats128, const float* posenc,
-                       const void* cache, int64_t n64, const QueryMeta& hm, float* logits, char* ws,
+static int run_decoder(const a3d_decoder_weights* w, const float* feats128, const float* posenc, int64_t n64, const QueryMeta& hm, float* logits, char* ws,
                        const DecLayout& L, hipStream_t st) {
   constexpr int QP = QT * 16;
   const int n = (int)n64, K = hm.K, nq = hm.nq;
@@ -1034,8 +999,6 @@ static int run_decoder(const a3d_decoder_weights* w, const float* feats128, cons
     }
   }
   A3D_HIP_CHECK(hipMemcpyAsync(meta, &hm, sizeof(QueryMeta), hipMemcpyHostToDevice, st));
-  char* queues = ws + L.queues;
-  A3D_HIP_CHECK(hipMemsetAsync(queues, 0, (size_t)A3D_MAX_DEC_LAYERS * 4 * 512, st));
   const int n_counts = A3D_MAX_DEC_LAYERS * (A3D_MAX_QUERIES + 1);
   {
   ProfScope ps(st, A3D_PROF_QUERY, 0, 0, 0, 0, nq);
@@ -1043,7 +1006,6 @@ static int run_decoder(const a3d_decoder_weights* w, const float* feats128, cons
                                        w->layers[0].c2s_in_w, w->layers[0].c2s_in_b, B, counts, n_counts);
   }
   A3D_LAUNCH_CHECK();
-  const size_t one = align256((size_t)n * D * 4);
   const float* src = feats128;
   const size_t s2c_lds = (size_t)2 * QP * 132 * 4;
   const size_t lnm_lds = ((size_t)QP * 132 + 4 * 16 * (L.qp + 1) + 4 * 16 * (K + 1)) * 4 + (size_t)(K + 1) * 4;
@@ -1053,13 +1015,11 @@ static int run_decoder(const a3d_decoder_weights* w, const float* feats128, cons
   }
   for (int l = 0; l < w->n_layers; ++l) {
     const a3d_decoder_layer& LW = w->layers[l];
-    const float* posk = (const float*)((const char*)cache + (size_t)(2 * l) * one);
-    const float* posq = (const float*)((const char*)cache + (size_t)(2 * l + 1) * one);
     int rc;
-    // ---- click-to-scene: K = src Wk^T + (pos Wk^T + bk), V = src Wv^T + bv
-    rc = a3d_linear(src, D, n, D, D, LW.c2s_wk_packed, nullptr, nullptr, posk, D, 0, bufA, D, queues + (4 * l + 0) * 512, 512, st);
+    // ---- click-to-scene: K = (src + pos) Wk^T + bk, V = src Wv^T + bv   (attention_block.py:88-94)
+    rc = a3d_linear(src, D, posenc, D, n, D, D, LW.c2s_wk_packed, nullptr, LW.c2s_in_b + D, nullptr, 0, 0, bufA, D, nullptr, 0, st);
     if (rc) return rc;
-    rc = a3d_linear(src, D, n, D, D, LW.c2s_wv_packed, nullptr, LW.c2s_in_b + 2 * D, nullptr, 0, 0, bufB, D, queues + (4 * l + 1) * 512, 512, st);
+    rc = a3d_linear(src, D, nullptr, 0, n, D, D, LW.c2s_wv_packed, nullptr, LW.c2s_in_b + 2 * D, nullptr, 0, 0, bufB, D, nullptr, 0, st);
     if (rc) return rc;
     const int* prev_counts = l > 0 ? counts + (size_t)(l - 1) * (A3D_MAX_QUERIES + 1) : nullptr;
     {
@@ -1093,8 +1053,8 @@ static int run_decoder(const a3d_decoder_weights* w, const float* feats128, cons
     }
     }
     A3D_LAUNCH_CHECK();
-    // ---- scene-to-click: Q = src Wq^T + (pos Wq^T + bq); attention; Y = O Wo^T + bo + src; LN
-    rc = a3d_linear(src, D, n, D, D, LW.s2c_wq_packed, nullptr, nullptr, posq, D, 0, bufA, D, queues + (4 * l + 2) * 512, 512, st);
+    // ---- scene-to-click: Q = (src + pos) Wq^T + bq; attention; Y = O Wo^T + bo + src; LN
+    rc = a3d_linear(src, D, posenc, D, n, D, D, LW.s2c_wq_packed, nullptr, LW.s2c_in_b, nullptr, 0, 0, bufA, D, nullptr, 0, st);
     if (rc) return rc;
     {
     ProfScope ps(st, A3D_PROF_S2C, 0, 0, 0, 0, n);
@@ -1105,7 +1065,7 @@ static int run_decoder(const a3d_decoder_weights* w, const float* feats128, cons
     }
     A3D_LAUNCH_CHECK();
     float* Y = (l & 1) ? bufD : bufC;
-    rc = a3d_linear(bufB, D, n, D, D, LW.s2c_wo_packed, nullptr, LW.s2c_out_b, src, D, 0, Y, D, queues + (4 * l + 3) * 512, 512, st);
+    rc = a3d_linear(bufB, D, nullptr, 0, n, D, D, LW.s2c_wo_packed, nullptr, LW.s2c_out_b, src, D, 0, Y, D, nullptr, 0, st);
     if (rc) return rc;
     {
     ProfScope ps(st, A3D_PROF_LNMASK, 0, 0, 0, 0, n);
@@ -1120,15 +1080,14 @@ static int run_decoder(const a3d_decoder_weights* w, const float* feats128, cons
 }
 
 extern "C" int a3d_decoder_forward(const a3d_decoder_weights* w, const float* feats128_dev, const float* xyz_dev,
-                                   const float* posenc_dev, const float* minmax_dev, const void* cache_dev,
-                                   int64_t n, const int32_t* click_row, const int32_t* click_obj,
+                                   const float* posenc_dev, const float* minmax_dev, int64_t n, const int32_t* click_row, const int32_t* click_obj,
                                    const int32_t* click_time, int n_clicks, int n_objects, float* logits_dev,
                                    void* workspace_dev, size_t workspace_bytes, void* stream) {
   (void)xyz_dev;
   (void)minmax_dev;   // click encodings equal the scene encoding rows
   int rc = check_weights(w);
   if (rc) return rc;
-  if (!feats128_dev || !posenc_dev || !cache_dev || !logits_dev || n <= 0 || n_objects < 1 ||
+  if (!feats128_dev || !posenc_dev || !logits_dev || n <= 0 || n_objects < 1 ||
       n_clicks < n_objects || (n_clicks && (!click_row || !click_obj || !click_time))) {
     set_error("a3d_decoder_forward: bad arguments (every object needs >= 1 click, agile3d.py:353)");
     return A3D_ERR_INVALID;
@@ -1200,9 +1159,9 @@ extern "C" int a3d_decoder_forward(const a3d_decoder_weights* w, const float* fe
   hipStream_t st = (hipStream_t)stream;
   char* ws = (char*)workspace_dev;
   switch (L.qp) {
-    case 16: return run_decoder<1>(w, feats128_dev, posenc_dev, cache_dev, n, hm, logits_dev, ws, L, st);
-    case 32: return run_decoder<2>(w, feats128_dev, posenc_dev, cache_dev, n, hm, logits_dev, ws, L, st);
-    case 48: return run_decoder<3>(w, feats128_dev, posenc_dev, cache_dev, n, hm, logits_dev, ws, L, st);
-    default: return run_decoder<4>(w, feats128_dev, posenc_dev, cache_dev, n, hm, logits_dev, ws, L, st);
+    case 16: return run_decoder<1>(w, feats128_dev, posenc_dev, n, hm, logits_dev, ws, L, st);
+    case 32: return run_decoder<2>(w, feats128_dev, posenc_dev, n, hm, logits_dev, ws, L, st);
+    case 48: return run_decoder<3>(w, feats128_dev, posenc_dev, n, hm, logits_dev, ws, L, st);
+    default: return run_decoder<4>(w, feats128_dev, posenc_dev, n, hm, logits_dev, ws, L, st);
   }
 }

@@ -433,7 +433,17 @@ __global__ void k_splitk_epilogue(const float* __restrict__ partial, int ksplit,
   if (e < total) {
     const int vrow = (int)(e / c4), col = (int)(e % c4) * 4;
     f32x4 s = (f32x4){0.f, 0.f, 0.f, 0.f};
-    for (int z = 0; z < ksplit; ++z) s += *(const f32x4*)(partial + z * split_stride + (size_t)vrow * cout + col);
+    // loads in batches of 9 so their latencies overlap; the additions keep the z order (bit-stable)
+    const float* pp = partial + (size_t)vrow * cout + col;
+    int z = 0;
+    for (; z + 9 <= ksplit; z += 9) {
+      f32x4 v[9];
+#pragma unroll
+      for (int u = 0; u < 9; ++u) v[u] = *(const f32x4*)(pp + (size_t)(z + u) * split_stride);
+#pragma unroll
+      for (int u = 0; u < 9; ++u) s += v[u];
+    }
+    for (; z < ksplit; ++z) s += *(const f32x4*)(pp + (size_t)z * split_stride);
     const int orow = out_map ? out_map[vrow] : vrow;
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
@@ -444,6 +454,139 @@ __global__ void k_splitk_epilogue(const float* __restrict__ partial, int ksplit,
     }
   }
   if (zero_row >= 0 && e < (size_t)cout) out[(size_t)zero_row * ldo + e] = 0.f;
+}
+
+// ------------------------------------------------------------------------------ dense GEMM
+// Y[n][16*NCT] = act(((X (+ X2))[n][16*NS] @ W) * scale + shift + res): the N-point nn.Linear pieces of the
+// decoder and the 1x1 convolutions (no gather, no masks).  HBM-bound (reads X (+X2), writes Y once), so the
+// kernel is built around that: the packed weight matrix (<= 64 KB) sits in LDS for the life of a persistent
+// workgroup, every lane pulls its MFMA fragments of X straight from global memory (row j, channels
+// 16S+4g..+3: the same K permutation as k_spconv, so the fragment is one 16-byte load), the loads of the
+// wave's NEXT 16-row group are in flight behind the MFMAs of the current one, and the product is computed
+// TRANSPOSED (weights as the A operand), which leaves
+// four consecutive output channels of one row in each lane: 16-byte stores, 16-byte scale/shift/res loads.
+template <int NS, int NCT>
+__global__ void __launch_bounds__(768) k_dense(const float* __restrict__ X, int ldx, const float* __restrict__ X2,
+                                                   int ldx2, int n, const float* __restrict__ Wp,
+                                                   const float* __restrict__ scale, const float* __restrict__ shift,
+                                                   const float* __restrict__ res, int ldr, int relu,
+                                                   float* __restrict__ Y, int ldy, int ngroups, int zero_row,
+                                                   const int* __restrict__ out_map, int dbg) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  f32x4* Wl = (f32x4*)smem;                         // [NS][NCT][64 lanes]
+  if (zero_row >= 0 && blockIdx.x == 0 && threadIdx.x < 16 * NCT) Y[(size_t)zero_row * ldy + threadIdx.x] = 0.f;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int g = lane >> 4, j = lane & 15;
+  // every wave walks its own sequence of 16-row groups (no workgroup-level coupling after the weight load)
+  const int nw = blockDim.x >> 6;
+  const int stride = gridDim.x * nw;
+  int grp = blockIdx.x * nw + wave;
+  f32x4 nx[NS], nx2[NS];
+  auto fetch = [&](int gq) {
+    const int row = (dbg & 1) ? j : min(gq * 16 + j, n - 1);
+    const float* xr = X + (size_t)row * ldx + 4 * g;
+#pragma unroll
+    for (int S = 0; S < NS; ++S) nx[S] = *(const f32x4*)(xr + 16 * S);
+    if (X2) {
+      const float* x2r = X2 + (size_t)row * ldx2 + 4 * g;
+#pragma unroll
+      for (int S = 0; S < NS; ++S) nx2[S] = *(const f32x4*)(x2r + 16 * S);
+    }
+  };
+  if (grp < ngroups) fetch(grp);
+  {  // stage the packed weights: 8 independent 16-byte loads in flight per thread, then the LDS stores
+    constexpr int TOT = NS * NCT * 64;
+    const int bd = blockDim.x;
+    for (int base = threadIdx.x; base < TOT; base += 8 * bd) {
+      f32x4 t8[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (base + u * bd < TOT) t8[u] = ((const f32x4*)Wp)[base + u * bd];
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (base + u * bd < TOT) Wl[base + u * bd] = t8[u];
+    }
+  }
+  __syncthreads();
+  while (grp < ngroups) {
+    f32x4 a[NS];
+#pragma unroll
+    for (int S = 0; S < NS; ++S) a[S] = X2 ? nx[S] + nx2[S] : nx[S];
+    const int next = grp + stride;
+    if (next < ngroups) fetch(next);                // in flight behind this group's 32 NS NCT/8 k-cycles of MFMA
+    f32x4 acc[NCT];
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct) acc[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int S = 0; S < NS; ++S) {
+#pragma unroll
+      for (int ct = 0; ct < NCT; ++ct) {
+        const f32x4 w = Wl[(S * NCT + ct) * 64 + lane];
+        if (!(dbg & 4)) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[t], a[S][t], acc[ct], 0, 0, 0);
+        } else acc[ct] += w * a[S];
+      }
+      asm volatile("" ::: "memory");   // keep the weight reads of later k-steps from being hoisted (256 VGPRs + spills)
+    }
+    // acc[ct][t] = Y[16 grp + j][16 ct + 4 g + t]
+    if (grp * 16 + j < n && (!(dbg & 2) || acc[0][0] == 123.456f)) {
+      const int row = out_map ? out_map[grp * 16 + j] : grp * 16 + j;
+#pragma unroll
+      for (int ct = 0; ct < NCT; ++ct) {
+        const int col = 16 * ct + 4 * g;
+        f32x4 v = acc[ct];
+        if (scale) v *= *(const f32x4*)(scale + col);
+        if (shift) v += *(const f32x4*)(shift + col);
+        if (res) v += *(const f32x4*)(res + (size_t)row * ldr + col);
+        if (relu) {
+#pragma unroll
+          for (int t = 0; t < 4; ++t) v[t] = fmaxf(v[t], 0.f);
+        }
+        *(f32x4*)(Y + (size_t)row * ldy + col) = v;
+      }
+    }
+    grp = next;
+  }
+}
+
+static void allow_big_lds();
+static bool dense_supported(int cin, int cout) {
+  return (cin == 96 || cin == 128) && (cout == 96 || cout == 128);
+}
+static int launch_dense(const float* X, int ldx, const float* X2, int ldx2, int n, int cin, int cout, const float* Wp,
+                        const float* scale, const float* shift, const float* res, int ldr, int relu, float* Y,
+                        int ldy, int zero_row, int tag_level, const int* out_map, hipStream_t st) {
+  if ((ldx | ldx2 | ldr | ldy) & 3) {
+    set_error("a3d_linear: leading dimensions must be multiples of 4");
+    return A3D_ERR_INVALID;
+  }
+  allow_big_lds();
+  const int ngroups = (n + 15) / 16;
+  static int nw = 0, wg_per_cu = 0;
+  if (!nw) {   // measured (80 k rows, 128 -> 128): 4x2 41 us, 8x2 48, 8x1 47, 12x1 46, 6x2 60
+    const char* e = getenv("A3D_DENSE_SHAPE");   // "<waves per workgroup><workgroups per CU>", e.g. 42
+    const int v = e ? atoi(e) : 42;
+    nw = v / 10;
+    wg_per_cu = v % 10;
+    if (nw < 1 || nw > 12 || wg_per_cu < 1 || wg_per_cu > 2) nw = 4, wg_per_cu = 2;
+  }
+  static int dbg = -1;
+  if (dbg < 0) { const char* e = getenv("A3D_DENSE_DBG"); dbg = e ? atoi(e) : 0; }
+  const int max_grid = 256 * wg_per_cu;
+  const int grid = (ngroups + nw - 1) / nw < max_grid ? (ngroups + nw - 1) / nw : max_grid;
+  const size_t lds = (size_t)(cin / 16) * (cout / 16) * 1024;
+  ProfScope ps(st, A3D_PROF_DENSE, 0, 1, cin, cout, n, A3D_OP_LINEAR, tag_level, 1);
+#define A3D_DENSE(NS_, NCT_) \
+  k_dense<NS_, NCT_><<<grid, 64 * nw, lds, st>>>(X, ldx, X2, ldx2, n, Wp, scale, shift, res, ldr, relu, Y, ldy, ngroups, \
+                                             zero_row, out_map, dbg)
+  if (cin == 128 && cout == 128) A3D_DENSE(8, 8);
+  else if (cin == 128 && cout == 96) A3D_DENSE(8, 6);
+  else if (cin == 96 && cout == 128) A3D_DENSE(6, 8);
+  else A3D_DENSE(6, 6);
+#undef A3D_DENSE
+  A3D_LAUNCH_CHECK();
+  return A3D_OK;
 }
 
 // ------------------------------------------------------------------------------ stem
@@ -585,6 +728,10 @@ static void allow_big_lds() {
   (void)hipFuncSetAttribute((const void*)k_spconv<BN_, NW_, G_, D_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 #define A3D_BIG(BN_) A3D_BIG1(BN_, 4, 1, 2) A3D_BIG1(BN_, 4, 1, 3) A3D_BIG1(BN_, 4, 2, 2) A3D_BIG1(BN_, 4, 2, 3) A3D_BIG1(BN_, 8, 1, 2)
   A3D_BIG(32) A3D_BIG(64) A3D_BIG(96) A3D_BIG(128)
+  (void)hipFuncSetAttribute((const void*)k_dense<8, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  (void)hipFuncSetAttribute((const void*)k_dense<8, 6>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  (void)hipFuncSetAttribute((const void*)k_dense<6, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  (void)hipFuncSetAttribute((const void*)k_dense<6, 6>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 #undef A3D_BIG
 #undef A3D_BIG1
 }
@@ -896,18 +1043,30 @@ extern "C" int a3d_program_run(const a3d_scene* s, const a3d_buf_desc* bufs, int
         set_error("op %d: unknown kind %d", i, o.kind);
         return A3D_ERR_INVALID;
     }
-    rc = launch_conv(a, partial, L.partial_floats, queues + (size_t)i * kMaxQueuesPerOp, st);
+    if (o.kind == A3D_OP_LINEAR && dense_supported(a.cin, a.cout) && a.n_out >= 4096)
+      rc = launch_dense(a.in, a.ldi, nullptr, 0, a.n_out, a.cin, a.cout, a.w, a.scale, a.shift, a.res, a.ldr, a.relu,
+                        a.out, a.ldo, a.zero_row, Lin, a.out_map, st);
+    else
+      rc = launch_conv(a, partial, L.partial_floats, queues + (size_t)i * kMaxQueuesPerOp, st);
     if (rc != A3D_OK) return rc;
   }
   return A3D_OK;
 }
 
-extern "C" int a3d_linear(const float* in_dev, int ldi, int64_t n, int cin, int cout, const float* w_packed_dev,
-                          const float* scale_dev, const float* shift_dev, const float* res_dev, int ldr, int relu,
-                          float* out_dev, int ldo, void* workspace_dev, size_t workspace_bytes, void* stream) {
+extern "C" int a3d_linear(const float* in_dev, int ldi, const float* in_add_dev, int ldi_add, int64_t n, int cin,
+                          int cout, const float* w_packed_dev, const float* scale_dev, const float* shift_dev,
+                          const float* res_dev, int ldr, int relu, float* out_dev, int ldo, void* workspace_dev,
+                          size_t workspace_bytes, void* stream) {
   if (!in_dev || !out_dev || !w_packed_dev || n <= 0 || n > (int64_t)1 << 30) {
     set_error("a3d_linear: bad arguments");
     return A3D_ERR_INVALID;
+  }
+  if (dense_supported(cin, cout))
+    return launch_dense(in_dev, ldi, in_add_dev, ldi_add, (int)n, cin, cout, w_packed_dev, scale_dev, shift_dev, res_dev,
+                        ldr, relu, out_dev, ldo, -1, -1, nullptr, (hipStream_t)stream);
+  if (in_add_dev) {
+    set_error("a3d_linear: a second input is only supported for 96/128 -> 96/128 channels (got %d -> %d)", cin, cout);
+    return A3D_ERR_UNSUPPORTED;
   }
   ConvArgs a;
   memset(&a, 0, sizeof(a));

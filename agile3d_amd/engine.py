@@ -321,7 +321,6 @@ class _SceneState:
         self.ranges = None
         self.posenc = None      # list[Tensor [n_b,128]]
         self.minmax = None      # list[Tensor [6]]
-        self.cache = None       # list[uint8 Tensor]
         self.engine_id = None
 
 
@@ -373,23 +372,16 @@ class Engine:
             out = torch.empty((n, self.model.mask_dim), dtype=torch.float32, device=self.device)
             st.ws = self.program.run(st.scene, x.F, out)
             st.ranges = x.batch_ranges()
-            st.posenc, st.minmax, st.cache = [], [], []
+            st.posenc, st.minmax = [], []
             tmp = torch.empty(256 * 6 * 4, dtype=torch.uint8, device=self.device)
-            qws = torch.empty(2 * L.A3D_MAX_DEC_LAYERS * 512, dtype=torch.uint8, device=self.device)
-            W = self.decoder.W
             for (s, e) in st.ranges:
                 nb = e - s
                 pe = torch.empty((nb, 128), dtype=torch.float32, device=self.device)
                 mm = torch.empty(6, dtype=torch.float32, device=self.device)
                 L.check(lib.a3d_posenc_fourier(_ptr(raw[s:e]), nb, self.decoder.gauss_B_ptr, _ptr(mm), _ptr(pe),
                                                _ptr(tmp), tmp.numel(), _stream()), "a3d_posenc_fourier")
-                cb = lib.a3d_decoder_cache_bytes(nb, self.decoder.n_layers)
-                cache = torch.empty(cb, dtype=torch.uint8, device=self.device)
-                L.check(lib.a3d_decoder_build_cache(C.byref(W), _ptr(pe), nb, _ptr(cache), cb, _ptr(qws), qws.numel(), _stream()),
-                        "a3d_decoder_build_cache")
                 st.posenc.append(pe)
                 st.minmax.append(mm)
-                st.cache.append(cache)
         pcd_features = SparseTensor(features=out, coordinates=x.C)
         pcd_features._a3d = st
         coordinates = SparseTensor(features=raw, coordinates=x.C)
@@ -416,11 +408,7 @@ class Engine:
             mm = torch.empty(6, dtype=torch.float32, device=self.device)
             L.check(lib.a3d_posenc_fourier(_ptr(raw), n, self.decoder.gauss_B_ptr, _ptr(mm), _ptr(pe), _ptr(tmp),
                                            tmp.numel(), _stream()), "a3d_posenc_fourier")
-            cb = lib.a3d_decoder_cache_bytes(n, self.decoder.n_layers)
-            cache = torch.empty(cb, dtype=torch.uint8, device=self.device)
-            L.check(lib.a3d_decoder_build_cache(C.byref(self.decoder.W), _ptr(pe), n, _ptr(cache), cb, None, 0,
-                                                _stream()), "a3d_decoder_build_cache")
-        st.posenc, st.minmax, st.cache = [pe], [mm], [cache]
+        st.posenc, st.minmax = [pe], [mm]
         pcd = SparseTensor(features=feats, coordinates=C4)
         pcd._a3d = st
         coordinates = SparseTensor(features=raw, coordinates=C4)
@@ -464,7 +452,7 @@ class Engine:
                 arr = lambda v: (C.c_int32 * max(1, len(v)))(*v)
                 feats = pcd_features.F[s:e]
                 L.check(lib.a3d_decoder_forward(C.byref(W), _ptr(feats), _ptr(coordinates.F[s:e]),
-                                                _ptr(st.posenc[b]), _ptr(st.minmax[b]), _ptr(st.cache[b]), nb,
+                                                _ptr(st.posenc[b]), _ptr(st.minmax[b]), nb,
                                                 arr(rows), arr(objs), arr(times), nc, K, _ptr(logits),
                                                 _ptr(ws), wsb, _stream()), "a3d_decoder_forward")
                 for l in range(n_layers):

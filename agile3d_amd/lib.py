@@ -65,8 +65,9 @@ class ClickCluster(C.Structure):
 
 
 A3D_MAX_CLICKS = 256
+PROF_DENSE = 11
 PROF_NAMES = ["spconv", "splitk_epilogue", "stem", "c2s_attn", "query_chain", "s2c_attn", "ln_mask", "posenc",
-              "scene_sort_levels", "scene_tables", "click_simulator"]
+              "scene_sort_levels", "scene_tables", "click_simulator", "dense_gemm"]
 
 # name -> (restype, argtypes): every symbol include/agile3d_hip.h declares
 SYMBOLS = {
@@ -86,16 +87,13 @@ SYMBOLS = {
     "a3d_program_buffer_offset": (C.c_size_t, [C.c_void_p, C.POINTER(BufDesc), C.c_int, C.c_int]),
     "a3d_program_run": (C.c_int, [C.c_void_p, C.POINTER(BufDesc), C.c_int, C.POINTER(Op), C.c_int, C.c_void_p,
                                   C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
-    "a3d_linear": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+    "a3d_linear": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                              C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
     "a3d_posenc_fourier": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                      C.c_size_t, C.c_void_p]),
-    "a3d_decoder_cache_bytes": (C.c_size_t, [C.c_int64, C.c_int]),
-    "a3d_decoder_build_cache": (C.c_int, [C.POINTER(DecoderWeights), C.c_void_p, C.c_int64, C.c_void_p, C.c_size_t,
-                                          C.c_void_p, C.c_size_t, C.c_void_p]),
     "a3d_decoder_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int]),
     "a3d_decoder_forward": (C.c_int, [C.POINTER(DecoderWeights), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
-                                      C.c_void_p, C.c_int64, C.POINTER(C.c_int32), C.POINTER(C.c_int32),
+                                      C.c_int64, C.POINTER(C.c_int32), C.POINTER(C.c_int32),
                                       C.POINTER(C.c_int32), C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t,
                                       C.c_void_p]),
     "a3d_argmax_labels": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_int32),

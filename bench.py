@@ -83,12 +83,17 @@ def profile_pass(step, scene_pairs, n_steps):
         name = L.PROF_NAMES[e.id]
         if e.id == 0:
             name = f"k_spconv<{e.bn},4,1,3>"   # BN, waves, groups/wave, ring depth (plan_conv default)
+        elif e.id == L.PROF_DENSE:
+            name = f"k_dense<{e.cin // 16},{e.cout // 16}>"
         a = agg.setdefault(name, {"ms": 0.0, "launches": 0, "flops": 0.0, "bytes": 0.0})
         a["ms"] += e.ms
         a["launches"] += 1
         if e.id == 0:
             a["flops"] += algorithmic_flops(e, scene_pairs)
             a["bytes"] += algorithmic_bytes(e, scene_pairs)
+        elif e.id == L.PROF_DENSE:                 # [n,cin] x [cin,cout]: read X (+X2/res: not counted), write Y
+            a["flops"] += 2.0 * e.n_out * e.cin * e.cout
+            a["bytes"] += 4.0 * e.n_out * (e.cin + e.cout) + 4.0 * e.cin * e.cout
     for a in agg.values():
         a["ms_per_step"] = a["ms"] / n_steps
         a["launches_per_step"] = a["launches"] / n_steps
@@ -188,8 +193,8 @@ def main():
                 nb = scn.table(lvl, L.TAB_NBR27).reshape(27, npad)
                 pairs["conv3"].append(int((nb[:, :scn.n[lvl]] < scn.n[lvl]).sum()))
             agg = profile_pass(step, pairs, max(3, min(10, args.steps)))
-            conv = {k: v for k, v in agg.items() if k.startswith("k_spconv")}
-            dom = max(conv, key=lambda k: conv[k]["ms"])
+            conv = {k: v for k, v in agg.items() if k.startswith("k_spconv") or k.startswith("k_dense")}
+            dom = max((k for k in conv if k.startswith("k_spconv")), key=lambda k: conv[k]["ms"])
             d = conv[dom]
             achieved = d["flops"] / (d["ms"] * 1e-3) / 1e12
             traffic = None

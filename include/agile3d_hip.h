@@ -55,7 +55,8 @@ enum {
   A3D_PROF_POSENC = 7,      /* Fourier position encoding                                 */
   A3D_PROF_SCENE_SORT = 8,  /* keys + radix sort + level compaction                      */
   A3D_PROF_SCENE_TABLES = 9,/* hash, neighbour tables, row clustering                    */
-  A3D_PROF_CLICKS = 10      /* click simulator (error clusters + nearest outside point)  */
+  A3D_PROF_CLICKS = 10,     /* click simulator (error clusters + nearest outside point)  */
+  A3D_PROF_DENSE = 11       /* k_dense: N-point nn.Linear / 1x1 conv (no gather)          */
 };
 typedef struct {
   int32_t id, bn, kernel_volume, cin, cout, n_out, table, level, ksplit;
@@ -146,11 +147,15 @@ int    a3d_program_run(const a3d_scene* s, const a3d_buf_desc* bufs, int n_bufs,
                        float* ext_out_dev, int ext_out_ld,
                        void* workspace_dev, size_t workspace_bytes, void* stream);
 
-/* Dense row-major GEMM on the same MFMA kernel: out[n][cout] = act(in[n][cin] @ W + shift + res).
+/* Dense row-major GEMM: out[n][cout] = act(((in (+ in_add))[n][cin] @ W) * scale + shift + res).
  * Replaces the nn.Linear / in_proj pieces of nn.MultiheadAttention that run over all N points
- * (models/modules/attention_block.py:91-94).  workspace (optional): >= 512 bytes of ZEROED device
- * memory used as the dynamic tile queue of this call; NULL = static tile assignment. */
-int a3d_linear(const float* in_dev, int ldi, int64_t n, int cin, int cout,
+ * (models/modules/attention_block.py:91-94; `in_add` is the position encoding the reference adds to
+ * its queries / keys before projecting them, attention_block.py:25-26,88-90).  96/128 -> 96/128
+ * channels run on a dedicated HBM-bound kernel (k_dense); other shapes fall back to the sparse-conv
+ * kernel with kernel volume 1 (no in_add there; workspace (optional): >= 512 bytes of ZEROED device
+ * memory used as its dynamic tile queue, NULL = static tile assignment). */
+int a3d_linear(const float* in_dev, int ldi, const float* in_add_dev, int ldi_add,
+               int64_t n, int cin, int cout,
                const float* w_packed_dev, const float* scale_dev, const float* shift_dev,
                const float* res_dev, int ldr, int relu, float* out_dev, int ldo,
                void* workspace_dev, size_t workspace_bytes, void* stream);
@@ -200,13 +205,6 @@ typedef struct {
   const float *time_table;                                /* [200][128] PositionalEncoding1D */
 } a3d_decoder_weights;
 
-/* per-scene, click-independent cache: pos @ Wk^T + bk (c2s) and pos @ Wq^T + bq (s2c) for every
- * layer; computed once after forward_backbone and reused by every forward_mask of the scene. */
-size_t a3d_decoder_cache_bytes(int64_t n, int n_layers);
-int    a3d_decoder_build_cache(const a3d_decoder_weights* w, const float* posenc_dev, int64_t n,
-                               void* cache_dev, size_t cache_bytes,
-                               void* workspace_dev, size_t workspace_bytes, void* stream);
-
 size_t a3d_decoder_workspace_bytes(int64_t n, int n_queries);
 /* click arrays are HOST arrays, object-major as the reference builds its queries
  * (agile3d.py:249-264): all clicks of object 1, ..., object K, then background clicks.
@@ -215,7 +213,7 @@ size_t a3d_decoder_workspace_bytes(int64_t n, int n_queries);
 int    a3d_decoder_forward(const a3d_decoder_weights* w,
                            const float* feats128_dev, const float* xyz_dev,
                            const float* posenc_dev, const float* minmax_dev,
-                           const void* cache_dev, int64_t n,
+                           int64_t n,
                            const int32_t* click_row, const int32_t* click_obj,
                            const int32_t* click_time, int n_clicks, int n_objects,
                            float* logits_dev,

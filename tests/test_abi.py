@@ -24,8 +24,7 @@ def test_library_exports_every_declared_symbol():
     # pure host-side queries work without a GPU
     assert L.a3d_scene_workspace_bytes(80000) > 80000 * 27 * 4
     assert L.a3d_decoder_workspace_bytes(80000, 20) > 4 * 80000 * 128 * 4
-    assert L.a3d_decoder_workspace_bytes(80000, 65) == 0
-    assert L.a3d_decoder_cache_bytes(1000, 3) >= 3 * 2 * 1000 * 128 * 4
+    assert L.a3d_decoder_workspace_bytes(80000, 257) == 0
 
 
 def test_struct_layouts_match_header():

@@ -135,9 +135,51 @@ def test_standalone_linear_matches_matmul():
         b = torch.randn(128, generator=g).cuda()
         R = torch.randn(n, 128, generator=g).cuda()
         out = torch.empty(n, 128, device="cuda")
-        L.check(lib.a3d_linear(_ptr(X), 128, n, 128, 128, _ptr(pack_weight(W.unsqueeze(0))), None, _ptr(b), _ptr(R),
+        L.check(lib.a3d_linear(_ptr(X), 128, None, 0, n, 128, 128, _ptr(pack_weight(W.unsqueeze(0))), None, _ptr(b), _ptr(R),
                                128, 0, _ptr(out), 128, None, 0, _stream()), "a3d_linear")
         ref = X.double() @ W.double() + b.double() + R.double()
         err = (out.double() - ref).abs().max().item()
         print(f"a3d_linear n={n}: max|diff| vs fp64 = {err:.3e}")
         assert err < 1e-4
+
+
+@pytest.mark.parametrize("cin,cout", [(128, 128), (128, 96), (96, 128), (96, 96)])
+def test_dense_linear_all_options(cin, cout):
+    """k_dense: second input added on the fly, BN-style scale/shift, residual, relu, strided operands,
+    ragged row counts (tile = 128 rows, wave = 32 rows, group = 16 rows)."""
+    from agile3d_amd.engine import _ptr, _stream
+    lib = L.load()
+    g = torch.Generator().manual_seed(cin + cout)
+    W = torch.randn(cin, cout, generator=g).cuda() / 9.0
+    Wp = pack_weight(W.unsqueeze(0))
+    scale = (torch.rand(cout, generator=g) + 0.5).cuda()
+    shift = torch.randn(cout, generator=g).cuda()
+    for n in (1, 15, 16, 17, 127, 128, 129, 4999, 80_001):
+        ldx, ldx2, ldr, ldo = cin + 32, cin, cout + 4, cout + 64
+        X = torch.randn(n, ldx, generator=g).cuda()
+        X2 = torch.randn(n, ldx2, generator=g).cuda()
+        R = torch.randn(n, ldr, generator=g).cuda()
+        out = torch.full((n, ldo), 7.0, device="cuda")
+        L.check(lib.a3d_linear(_ptr(X), ldx, _ptr(X2), ldx2, n, cin, cout, _ptr(Wp), _ptr(scale), _ptr(shift), _ptr(R),
+                               ldr, 1, _ptr(out), ldo, None, 0, _stream()), "a3d_linear")
+        ref = torch.relu(((X[:, :cin].double() + X2.double()) @ W.double()) * scale.double() + shift.double()
+                         + R[:, :cout].double())
+        err = (out[:, :cout].double() - ref).abs().max().item()
+        assert err < 1e-4, (n, err)
+        assert bool((out[:, cout:] == 7.0).all()), "wrote outside its columns"
+
+
+def test_linear_other_shapes_use_the_conv_kernel_and_reject_in_add():
+    from agile3d_amd.engine import _ptr, _stream
+    lib = L.load()
+    g = torch.Generator().manual_seed(5)
+    n = 3000
+    X = torch.randn(n, 64, generator=g).cuda()
+    W = torch.randn(64, 32, generator=g).cuda() / 8.0
+    out = torch.empty(n, 32, device="cuda")
+    L.check(lib.a3d_linear(_ptr(X), 64, None, 0, n, 64, 32, _ptr(pack_weight(W.unsqueeze(0))), None, None, None, 0, 0,
+                           _ptr(out), 32, None, 0, _stream()), "a3d_linear")
+    assert (out.double() - X.double() @ W.double()).abs().max().item() < 1e-4
+    rc = lib.a3d_linear(_ptr(X), 64, _ptr(X), 64, n, 64, 32, _ptr(pack_weight(W.unsqueeze(0))), None, None, None, 0, 0,
+                        _ptr(out), 32, None, 0, _stream())
+    assert rc == -6      # A3D_ERR_UNSUPPORTED
