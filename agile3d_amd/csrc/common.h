@@ -126,8 +126,14 @@ struct Level {
 
 }  // namespace a3d
 
+namespace a3d {
+constexpr int kSizesInts = 8 + 1024;   // device-side size/error/batch-start block read back by a3d_scene_create
+}
+
 struct a3d_scene {
   int64_t n0 = 0;
+  int n_batch = 0;
+  int batch_start[1024];        // first row of every batch sample (rows of a sample are contiguous)
   a3d::Level lv[A3D_NUM_LEVELS];
   int* orig_row = nullptr;      // [n0] internal level-0 row -> caller row
   void* workspace = nullptr;

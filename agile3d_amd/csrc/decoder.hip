@@ -63,11 +63,16 @@ __global__ void __launch_bounds__(256) k_minmax_partial(const float* __restrict_
   if (threadIdx.x < 6) part[blockIdx.x * 6 + threadIdx.x] = s[threadIdx.x][0];
 }
 __global__ void k_minmax_final(const float* __restrict__ part, int nb, float* minmax) {
-  const int a = threadIdx.x;
-  if (a >= 6) return;
-  float v = part[a];
-  for (int b = 1; b < nb; ++b) v = a < 3 ? fminf(v, part[b * 6 + a]) : fmaxf(v, part[b * 6 + a]);
-  minmax[a] = v;
+  // 6 waves, one per statistic (min x,y,z, max x,y,z) over the nb block partials
+  const int a = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  float v = a < 3 ? 3.4e38f : -3.4e38f;
+  for (int b = lane; b < nb; b += 64) v = a < 3 ? fminf(v, part[b * 6 + a]) : fmaxf(v, part[b * 6 + a]);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float w = __shfl_xor(v, o, 64);
+    v = a < 3 ? fminf(v, w) : fmaxf(v, w);
+  }
+  if (lane == 0) minmax[a] = v;
 }
 // get_fourier_embeddings with normalize=True: u = (x-min)/(max-min); p = (2 pi u) @ B; [sin p, cos p]
 __global__ void k_fourier(const float* __restrict__ xyz, int n, const float* __restrict__ gaussB,
@@ -903,7 +908,7 @@ extern "C" int a3d_posenc_fourier(const float* xyz_dev, int64_t n, const float* 
   float* part = (float*)workspace_dev;
   ProfScope ps(st, A3D_PROF_POSENC, 0, 0, 3, 128, (int)n);
   k_minmax_partial<<<nb, 256, 0, st>>>(xyz_dev, (int)n, part);
-  k_minmax_final<<<1, 64, 0, st>>>(part, nb, minmax_dev);
+  k_minmax_final<<<1, 384, 0, st>>>(part, nb, minmax_dev);
   const size_t total = (size_t)n * 64;
   k_fourier<<<(unsigned)((total + 255) / 256), 256, 0, st>>>(xyz_dev, (int)n, gauss_B_dev, minmax_dev, out_dev);
   A3D_LAUNCH_CHECK();

@@ -93,7 +93,8 @@ __device__ inline int block_incl_scan(int v, int* lds, int* total) {
 }
 
 // ------------------------------------------------------------------------------ kernels
-// sizes_dev: [0..4] level sizes, [5] error code
+// sizes_dev: [0..4] level sizes, [5] error code, [6] number of batch segments, [7] largest batch index,
+// [8 + b] first row of batch sample b (-1 = absent)
 __global__ void k_make_keys(const int32_t* __restrict__ coords4, int n, uint64_t* keys, int* vals,
                             int* sizes_dev) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -108,6 +109,13 @@ __global__ void k_make_keys(const int32_t* __restrict__ coords4, int n, uint64_t
   }
   keys[i] = make_key(b, x, y, z, 0);
   vals[i] = i;
+  // batch samples must be contiguous row ranges (ME.utils.batched_coordinates): record where each starts
+  const int prev = i > 0 ? coords4[4 * (i - 1)] : -1;
+  if (b != prev) {
+    atomicAdd(&sizes_dev[6], 1);
+    atomicMax(&sizes_dev[7], b);
+    if (atomicCAS(&sizes_dev[8 + b], -1, i) != -1) atomicMin(&sizes_dev[5], A3D_ERR_INVALID);
+  }
 }
 
 __global__ void k_check_dups(const uint64_t* __restrict__ keys, int n, int* sizes_dev) {
@@ -374,7 +382,7 @@ static void carve_phase1(Bump& b, int n0, Phase1& p) {
   for (int L = 0; L < A3D_NUM_LEVELS; ++L) p.keys[L] = b.take<uint64_t>(n0);
   for (int L = 0; L < A3D_NUM_LEVELS - 1; ++L) p.parentM[L] = b.take<int>(n0);
   p.blocksums = b.take<int>(n0 / 1024 + 2);
-  p.sizes_dev = b.take<int>(8);
+  p.sizes_dev = b.take<int>(kSizesInts);
   p.sort_temp_bytes = sort_temp_bytes(n0);
   p.sort_temp = b.take<char>(p.sort_temp_bytes);
 }
@@ -488,8 +496,10 @@ extern "C" int a3d_scene_create(const int32_t* coords4_dev, int64_t n_voxels, vo
 
   // ---- phase 1: keys, sort, levels (all sized by the n0 bound; real sizes stay on the device)
   int prof1 = prof_enabled() ? prof_begin(st, A3D_PROF_SCENE_SORT, 0, 0, 0, 0, n0) : -1;
-  int init_sizes[8] = {n0, 0, 0, 0, 0, 0, 0, 0};
-  A3D_HIP_CHECK(hipMemcpyAsync(p.sizes_dev, init_sizes, sizeof(init_sizes), hipMemcpyHostToDevice, st));
+  int sizes[kSizesInts];
+  for (int i = 0; i < kSizesInts; ++i) sizes[i] = i < 8 ? 0 : -1;
+  sizes[0] = n0;
+  A3D_HIP_CHECK(hipMemcpyAsync(p.sizes_dev, sizes, sizeof(sizes), hipMemcpyHostToDevice, st));
   k_make_keys<<<nblk(n0, T), T, 0, st>>>(coords4_dev, n0, p.keys_in, p.vals_in, p.sizes_dev);
   A3D_LAUNCH_CHECK();
   size_t tb = p.sort_temp_bytes;
@@ -505,18 +515,28 @@ extern "C" int a3d_scene_create(const int32_t* coords4_dev, int64_t n_voxels, vo
     A3D_LAUNCH_CHECK();
   }
   if (prof1 >= 0) prof_end(st, prof1);
-  int sizes[8];
   A3D_HIP_CHECK(hipMemcpyAsync(sizes, p.sizes_dev, sizeof(sizes), hipMemcpyDeviceToHost, st));
   A3D_HIP_CHECK(hipStreamSynchronize(st));
   if (sizes[5] != 0) {
-    set_error(sizes[5] == A3D_ERR_DUPLICATE ? "a3d_scene_create: duplicate voxel coordinates"
-                                            : "a3d_scene_create: coordinate out of range");
+    set_error(sizes[5] == A3D_ERR_DUPLICATE     ? "a3d_scene_create: duplicate voxel coordinates"
+              : sizes[5] == A3D_ERR_COORD_RANGE ? "a3d_scene_create: coordinate out of range"
+                                                : "a3d_scene_create: rows of a batch sample are not contiguous");
     return sizes[5];
+  }
+  const int n_batch = sizes[7] + 1;
+  bool dense = sizes[6] == n_batch;
+  for (int bi = 0; dense && bi < n_batch; ++bi)
+    dense = sizes[8 + bi] >= 0 && (bi == 0 ? sizes[8] == 0 : sizes[8 + bi] > sizes[8 + bi - 1]);
+  if (!dense) {
+    set_error("a3d_scene_create: batch indices must be 0..B-1, each a contiguous row range in ascending order");
+    return A3D_ERR_INVALID;
   }
 
   // ---- phase 2: per-level tables with exact sizes
   a3d_scene* sc = new a3d_scene();
   sc->n0 = n0;
+  sc->n_batch = n_batch;
+  for (int bi = 0; bi < n_batch; ++bi) sc->batch_start[bi] = sizes[8 + bi];
   sc->workspace = workspace_dev;
   sc->workspace_bytes = workspace_bytes;
   Phase2Tmp t;
@@ -564,6 +584,12 @@ extern "C" int a3d_scene_create(const int32_t* coords4_dev, int64_t n_voxels, vo
 }
 
 extern "C" void a3d_scene_destroy(a3d_scene* s) { delete s; }
+
+extern "C" int a3d_scene_batch_ranges(const a3d_scene* s, int64_t* starts_out, int max_out) {
+  if (!s) return A3D_ERR_INVALID;
+  for (int i = 0; i < s->n_batch && i < max_out; ++i) starts_out[i] = s->batch_start[i];
+  return s->n_batch;
+}
 
 extern "C" int64_t a3d_scene_level_size(const a3d_scene* s, int level) {
   if (!s || level < 0 || level >= A3D_NUM_LEVELS) return -1;

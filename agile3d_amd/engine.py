@@ -48,6 +48,10 @@ class Scene:
                 "a3d_scene_create")
         self.handle = h
         self.n = [int(lib.a3d_scene_level_size(h, i)) for i in range(L.A3D_NUM_LEVELS)]
+        starts = (C.c_int64 * 1024)()
+        nb = lib.a3d_scene_batch_ranges(h, starts, 1024)
+        ends = [int(starts[i + 1]) for i in range(nb - 1)] + [n]
+        self.batch_ranges = [(int(starts[i]), ends[i]) for i in range(nb)]
 
     def table(self, level: int, which: int) -> np.ndarray:
         """Copy one scene table to the host (tests / debugging)."""
@@ -371,7 +375,7 @@ class Engine:
             st.scene = Scene(x.C)
             out = torch.empty((n, self.model.mask_dim), dtype=torch.float32, device=self.device)
             st.ws = self.program.run(st.scene, x.F, out)
-            st.ranges = x.batch_ranges()
+            st.ranges = st.scene.batch_ranges      # from the scene build's single read-back, no torch kernels
             st.posenc, st.minmax = [], []
             tmp = torch.empty(256 * 6 * 4, dtype=torch.uint8, device=self.device)
             for (s, e) in st.ranges:

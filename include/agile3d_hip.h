@@ -81,6 +81,10 @@ int     a3d_scene_create(const int32_t* coords4_dev, int64_t n_voxels,
                          void* stream, a3d_scene** out);
 void    a3d_scene_destroy(a3d_scene* s);
 int64_t a3d_scene_level_size(const a3d_scene* s, int level);
+/* batch samples are contiguous row ranges in ascending batch order (ME.utils.batched_coordinates,
+ * datasets/InterMultiObj3DSegDataset.py:129); returns their number B and writes the first row of
+ * sample i to starts_out[i] (i < max_out); sample i ends where sample i+1 starts (the last at n). */
+int     a3d_scene_batch_ranges(const a3d_scene* s, int64_t* starts_out, int max_out);
 
 /* read-only views of the scene tables (device pointers valid while the workspace lives) */
 enum {

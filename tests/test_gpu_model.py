@@ -188,3 +188,32 @@ def test_full_size_properties(model_and_sd):
     st["coords"][:, 1:] += np.array([32, -48, 16], np.int32)
     r4 = _run_backbone(model, st)
     assert (r4[0].F - r1[0].F).abs().max().item() <= 1e-5
+
+
+def test_two_scenes_in_flight_on_two_streams(model_and_sd):
+    """bench.py issues consecutive scenes round-robin on two HIP streams.  The library keeps no state
+    between calls that two in-flight scenes could share: results must be bit-identical to serial runs."""
+    model, _ = model_and_sd
+    jobs = []
+    for seed, n in ((11, 3000), (12, 7000), (13, 4500), (14, 6000)):
+        sc = make_scene(n, seed=seed)
+        ci, ct = make_clicks(sc["labels"], 3, 2, 1, seed=seed)
+        jobs.append((SparseTensor(features=torch.from_numpy(sc["feats"]), coordinates=torch.from_numpy(sc["coords"]),
+                                  device="cuda"), torch.from_numpy(sc["raw_xyz"]).cuda(), ci, ct))
+
+    def run(job):
+        x, raw, ci, ct = job
+        r = model.forward_backbone(x, raw_coordinates=raw)
+        return r[0].F, model.forward_mask(*r, click_idx=[ci], click_time_idx=[ct])["pred_masks"][0]
+
+    serial = [run(j) for j in jobs]
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    for rep in range(3):
+        outs = []
+        for i, j in enumerate(jobs * 2):
+            with torch.cuda.stream(streams[i % 2]):
+                outs.append(run(j))
+        torch.cuda.synchronize()
+        for i, (f, m) in enumerate(outs):
+            assert torch.equal(f, serial[i % len(jobs)][0]) and torch.equal(m, serial[i % len(jobs)][1]), (rep, i)

@@ -136,3 +136,23 @@ def test_group_skip_efficiency_reported():
     print(f"pairs={pairs} group-active slots={active} dense slots={dense} "
           f"useful={pairs / active:.3f} (dense would be {pairs / dense:.3f})")
     assert pairs / active > 1.3 * pairs / dense
+
+
+def test_batch_ranges_and_malformed_batches():
+    """Batch samples are contiguous ascending row ranges (ME.utils.batched_coordinates); the scene build
+    reports them from its single read-back and rejects anything else."""
+    from agile3d_amd.engine import Scene
+    from agile3d_amd.lib import A3DError
+    parts = [make_scene(n, seed=s, batch_index=b)["coords"] for b, (n, s) in enumerate([(700, 1), (1500, 2), (300, 3)])]
+    c = np.concatenate(parts)
+    sc = Scene(torch.from_numpy(c).cuda())
+    lens = [len(p) for p in parts]
+    assert sc.batch_ranges == [(0, lens[0]), (lens[0], lens[0] + lens[1]), (lens[0] + lens[1], sum(lens))]
+    assert Scene(torch.from_numpy(parts[0]).cuda()).batch_ranges == [(0, lens[0])]
+    swapped = np.concatenate([parts[1], parts[0], parts[2]])                  # not ascending
+    interleaved = c.copy()
+    interleaved[[5, lens[0] + 5]] = interleaved[[lens[0] + 5, 5]]             # sample 0 no longer contiguous
+    gap = np.concatenate([parts[0], parts[2]])                                # batch index 1 missing
+    for bad in (swapped, interleaved, gap):
+        with pytest.raises(A3DError):
+            Scene(torch.from_numpy(np.ascontiguousarray(bad)).cuda())
