@@ -421,6 +421,208 @@ __global__ void __launch_bounds__(NW * 64) k_spconv(const ConvArgs a) {
   }
 }
 
+
+// ------------------------------------------------------------------------------ k_spconv2
+// Second-generation kernel: stage = (offset k, CH input channels) with CH up to 96, so a 96-channel layer
+// has ONE barrier per offset (k_spconv: three), and the gathered rows never touch LDS:
+//   * each lane loads its own MFMA A-fragments straight from global memory (row nbr[k][16w+j], channels
+//     16S+4g..+3 -- the K permutation makes that one 16-byte load), for the NEXT stage while the current
+//     one is multiplied: a whole stage of MFMA time (144 MFMAs at 96x96) hides the gather latency;
+//   * the packed weight slice of the next stage is loaded to registers at the same time and written to the
+//     other half of a two-slot LDS ring after the MFMAs; all loads are plain compiler-tracked loads, so
+//     every wait is exact (no counted-vmcnt protocol, no LDS-DMA);
+//   * a wave whose 16-row group lacks offset k issues neither loads nor MFMAs for it.
+// Workgroup = 4 waves = 64 output rows x BN columns; persistent, tiles from an atomic queue; split-K and the
+// epilogue are those of k_spconv.
+template <int BN, int CH>
+__global__ void __launch_bounds__(256, 2) k_spconv2(const ConvArgs a) {
+  constexpr int NCT = BN / 16, NS = CH / 16, NW = 4, NT = 256, kTile = 64;
+  constexpr int NPIECE = NS * NCT;             // 1 KiB weight pieces per stage
+  constexpr int WV = (NPIECE + NW - 1) / NW;   // pieces per wave
+  constexpr int WF = NPIECE * 256;             // floats per ring slot
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* wring = (float*)smem;                         // [2][WF]
+  int* idx_lds = (int*)(wring + 2 * WF);               // [kper][64]
+  int* tile_slot = idx_lds + a.kper * kTile;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = lane >> 4, j = lane & 15;
+  const int ct0 = blockIdx.y * NCT;
+  const int kbeg = blockIdx.z * a.kper;
+  const int kend = min(a.K, kbeg + a.kper);
+  const int nchunk = a.cin / CH;
+  const int cin16 = a.cin >> 4, cout16 = a.cout >> 4;
+  int* counter = a.tile_counter ? a.tile_counter + (blockIdx.y * gridDim.z + blockIdx.z) : nullptr;
+  const float* wlane = a.w + (size_t)ct0 * 256 + lane * 4;
+
+  for (int tile = blockIdx.x;; tile += gridDim.x) {
+    if (counter) {
+      if (tid == 0) *tile_slot = atomicAdd(counter, 1);
+      __syncthreads();
+      tile = *tile_slot;
+    }
+    if (tile >= a.n_tiles) break;
+    const int r0 = tile * kTile;
+    uint32_t un = 0xffffffffu, gm = 0xffffffffu;
+    if (a.gmask) {
+      const uint32_t* gp = a.gmask + (r0 >> 4);
+      un = gp[0] | gp[1] | gp[2] | gp[3];
+      gm = __builtin_amdgcn_readfirstlane(gp[wave]);
+    }
+    un = __builtin_amdgcn_readfirstlane(un);
+    for (int e = tid; e < (kend - kbeg) * kTile; e += NT) {
+      const int kk = e >> 6, r = e & 63;
+      int v;
+      if (a.nbr) {
+        v = a.nbr[(size_t)(kbeg + kk) * a.nbr_stride + r0 + r];
+      } else {
+        v = r0 + r;
+        if (v >= a.n_in) v = a.n_in - 1;
+      }
+      idx_lds[e] = v;
+    }
+    __syncthreads();
+
+    f32x4 acc[NCT];
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct) acc[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    auto next_k = [&](int k) {
+      ++k;
+      while (k < kend && !((un >> k) & 1u)) ++k;
+      return k;
+    };
+    f32x4 an[NS], wn[WV];
+    // loads of stage (k, c): this lane's A fragments (if its group has k) and its weight pieces
+    auto load_stage = [&](int k, int c) {
+      if ((gm >> k) & 1u) {
+        const int row = idx_lds[(k - kbeg) * kTile + 16 * wave + j];
+        const float* ar = a.in + (size_t)row * a.ldi + c * CH + 4 * g;
+#pragma unroll
+        for (int S = 0; S < NS; ++S) an[S] = *(const f32x4*)(ar + 16 * S);
+      }
+      const float* wst = wlane + ((size_t)k * cin16 + (size_t)c * NS) * cout16 * 256;
+#pragma unroll
+      for (int i = 0; i < WV; ++i) {
+        const int q = wave + NW * i;               // piece -> (S, ct)
+        if (q < NPIECE) wn[i] = *(const f32x4*)(wst + ((size_t)(q / NCT) * cout16 + (q % NCT)) * 256);
+      }
+    };
+    auto store_w = [&](int slot) {
+      f32x4* dst = (f32x4*)(wring + slot * WF) + lane;
+#pragma unroll
+      for (int i = 0; i < WV; ++i) {
+        const int q = wave + NW * i;
+        if (q < NPIECE) dst[q * 64] = wn[i];
+      }
+    };
+    int k = next_k(kbeg - 1), c = 0, slot = 0;
+    if (k < kend) {
+      load_stage(k, c);
+      store_w(0);
+    }
+    __syncthreads();
+    while (k < kend) {
+      f32x4 ac[NS];
+      const bool present = (gm >> k) & 1u;
+#pragma unroll
+      for (int S = 0; S < NS; ++S) ac[S] = an[S];
+      int k2 = k, c2 = c + 1;
+      if (c2 == nchunk) {
+        c2 = 0;
+        k2 = next_k(k);
+      }
+      const bool has_next = k2 < kend;
+      if (has_next) load_stage(k2, c2);          // in flight behind this stage's MFMAs
+      if (present) {
+        const f32x4* Ws = (const f32x4*)(wring + slot * WF) + lane;
+#pragma unroll
+        for (int S = 0; S < NS; ++S) {
+          f32x4 b[NCT];
+#pragma unroll
+          for (int ct = 0; ct < NCT; ++ct) b[ct] = Ws[(S * NCT + ct) * 64];
+#pragma unroll
+          for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct)
+              acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(ac[S][t], b[ct][t], acc[ct], 0, 0, 0);
+          asm volatile("" ::: "memory");   // keep later k-steps' weight reads from being hoisted
+        }
+      }
+      if (has_next) store_w(slot ^ 1);
+      __syncthreads();   // next slot visible; everyone is done with the current one
+      slot ^= 1;
+      k = k2;
+      c = c2;
+    }
+
+    // ---- epilogue (C/D layout of 16x16x4: column = lane & 15, row = 4 * (lane >> 4) + reg)
+    const int rg = r0 + 16 * wave + 4 * g;
+    if (a.partial) {
+      float* P = a.partial + (size_t)blockIdx.z * ((size_t)a.n_tiles * kTile) * a.cout;
+#pragma unroll
+      for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) P[(size_t)(rg + t) * a.cout + (ct0 + ct) * 16 + j] = acc[ct][t];
+    } else {
+      int orow[4];
+      bool ok[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        ok[t] = rg + t < a.n_out;
+        orow[t] = ok[t] ? rg + t : a.n_out - 1;
+      }
+      if (a.out_map) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) orow[t] = a.out_map[orow[t]];
+      }
+      float sc[NCT], sh[NCT];
+#pragma unroll
+      for (int ct = 0; ct < NCT; ++ct) {
+        const int col = (ct0 + ct) * 16 + j;
+        sc[ct] = a.scale ? a.scale[col] : 1.f;
+        sh[ct] = a.shift ? a.shift[col] : 0.f;
+      }
+      if (a.res) {
+        float rv[NCT][4];
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+          for (int t = 0; t < 4; ++t) rv[ct][t] = a.res[(size_t)orow[t] * a.ldr + (ct0 + ct) * 16 + j];
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+          for (int t = 0; t < 4; ++t) acc[ct][t] = acc[ct][t] * sc[ct] + sh[ct] + rv[ct][t];
+      } else {
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+          for (int t = 0; t < 4; ++t) acc[ct][t] = acc[ct][t] * sc[ct] + sh[ct];
+      }
+      if (a.relu) {
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+          for (int t = 0; t < 4; ++t) acc[ct][t] = fmaxf(acc[ct][t], 0.f);
+      }
+#pragma unroll
+      for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+          if (ok[t]) a.out[(size_t)orow[t] * a.ldo + (ct0 + ct) * 16 + j] = acc[ct][t];
+      if (a.zero_row >= 0 && tile == 0 && tid < BN) a.out[(size_t)a.zero_row * a.ldo + ct0 * 16 + tid] = 0.f;
+    }
+    __syncthreads();   // the idx table / tile slot are reused by the next tile
+  }
+}
+
+static int conv2_ch(int cin, int bn) {   // input channels per stage: largest of 96/64/32 dividing cin with a ring <= 74 KB
+  const int cand[3] = {96, 64, 32};
+  for (int i = 0; i < 3; ++i)
+    if (cin % cand[i] == 0 && 2 * cand[i] * bn * 4 <= 74 * 1024) return cand[i];
+  return 0;
+}
+
 // sum the split-K partials and apply the epilogue
 __global__ void k_splitk_epilogue(const float* __restrict__ partial, int ksplit, size_t split_stride,
                                   int n_out, int cout, const int* __restrict__ out_map,
@@ -675,16 +877,16 @@ __global__ void k_pack_weight(const float* __restrict__ w, int K, int cin, int c
 
 // ------------------------------------------------------------------------------ host: launch
 struct ConvPlan {
-  int bn, nw, gpw, depth, tile, ksplit, kper, ntile, grid_x;
+  int bn, nw, gpw, depth, tile, ksplit, kper, ntile, grid_x, ch;
   size_t lds, partial_floats;
 };
 
-static int conv_variant() {   // A3D_CONV_VARIANT=<waves><groups per wave><depth>
+static int conv_variant() {   // A3D_CONV_VARIANT=2 (k_spconv2, default) or <waves><groups per wave><depth> of k_spconv
   static int v = -1;
   if (v < 0) {
     const char* e = getenv("A3D_CONV_VARIANT");
-    v = e ? atoi(e) : 413;
-    if (v != 413 && v != 412 && v != 422 && v != 423 && v != 812) v = 413;
+    v = e ? atoi(e) : 2;
+    if (v != 2 && v != 413 && v != 412 && v != 422 && v != 423 && v != 812) v = 413;
   }
   return v;
 }
@@ -693,9 +895,11 @@ constexpr int kMaxQueuesPerOp = 128;   // cout tiles x k splits
 
 static ConvPlan plan_conv(int n_rows, int K, int cin, int cout) {
   ConvPlan p;
-  p.nw = conv_variant() / 100;
-  p.gpw = (conv_variant() / 10) % 10;
-  p.depth = conv_variant() % 10;
+  const bool gen2 = conv_variant() == 2;
+  p.nw = gen2 ? 4 : conv_variant() / 100;
+  p.gpw = gen2 ? 1 : (conv_variant() / 10) % 10;
+  p.depth = gen2 ? 2 : conv_variant() % 10;
+  p.ch = 0;
   p.tile = 16 * p.nw * p.gpw;
   const int kConvTile = p.tile, kConvDepth = p.depth;
   p.ntile = (int)((n_rows + kConvTile - 1) / kConvTile);
@@ -712,6 +916,10 @@ static ConvPlan plan_conv(int n_rows, int K, int cin, int cout) {
   p.kper = (K + ksplit - 1) / ksplit;
   p.ksplit = (K + p.kper - 1) / p.kper;
   p.lds = (size_t)kConvDepth * (kConvTile * 32 + 2 * (bn / 16) * 256) * 4 + (size_t)p.kper * kConvTile * 4 + 16;
+  if (gen2) {
+    p.ch = conv2_ch(cin, bn);
+    p.lds = (size_t)2 * p.ch * bn * 4 + (size_t)p.kper * kConvTile * 4 + 16;
+  }
   p.partial_floats = p.ksplit > 1 ? (size_t)p.ksplit * p.ntile * kConvTile * cout : 0;
   const int max_resident = 256 * (int)(160 * 1024 / p.lds > 4 ? 4 : 160 * 1024 / p.lds);   // CUs x resident workgroups
   int gx = max_resident / ((cout / bn) * p.ksplit);
@@ -728,6 +936,11 @@ static void allow_big_lds() {
   (void)hipFuncSetAttribute((const void*)k_spconv<BN_, NW_, G_, D_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 #define A3D_BIG(BN_) A3D_BIG1(BN_, 4, 1, 2) A3D_BIG1(BN_, 4, 1, 3) A3D_BIG1(BN_, 4, 2, 2) A3D_BIG1(BN_, 4, 2, 3) A3D_BIG1(BN_, 8, 1, 2)
   A3D_BIG(32) A3D_BIG(64) A3D_BIG(96) A3D_BIG(128)
+#define A3D_BIG2(BN_, CH_) \
+  (void)hipFuncSetAttribute((const void*)k_spconv2<BN_, CH_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  A3D_BIG2(32, 32) A3D_BIG2(32, 64) A3D_BIG2(32, 96) A3D_BIG2(64, 32) A3D_BIG2(64, 64) A3D_BIG2(64, 96)
+  A3D_BIG2(96, 32) A3D_BIG2(96, 64) A3D_BIG2(96, 96) A3D_BIG2(128, 32) A3D_BIG2(128, 64)
+#undef A3D_BIG2
   (void)hipFuncSetAttribute((const void*)k_dense<8, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   (void)hipFuncSetAttribute((const void*)k_dense<8, 6>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   (void)hipFuncSetAttribute((const void*)k_dense<6, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -789,6 +1002,14 @@ static int launch_conv(ConvArgs a, float* partial_ws, size_t partial_ws_floats, 
     case 812: k_spconv<BN_, 8, 1, 2><<<grid, 512, p.lds, st>>>(a); break;                     \
     default: k_spconv<BN_, 4, 1, 3><<<grid, 256, p.lds, st>>>(a); break;                      \
   }
+  if (p.ch) {
+#define A3D_L2(BN_, CH_) \
+  if (p.bn == BN_ && p.ch == CH_) k_spconv2<BN_, CH_><<<grid, 256, p.lds, st>>>(a); else
+    A3D_L2(32, 32) A3D_L2(32, 64) A3D_L2(32, 96) A3D_L2(64, 32) A3D_L2(64, 64) A3D_L2(64, 96)
+    A3D_L2(96, 32) A3D_L2(96, 64) A3D_L2(96, 96) A3D_L2(128, 32) A3D_L2(128, 64)
+    { set_error("spconv2: no kernel for BN %d CH %d", p.bn, p.ch); return A3D_ERR_UNSUPPORTED; }
+#undef A3D_L2
+  } else
   switch (p.bn) {
     case 32: A3D_LAUNCH_BN(32); break;
     case 64: A3D_LAUNCH_BN(64); break;

@@ -2,7 +2,7 @@
 """bench.py -- scenes/s of the AGILE3D hot path on MI355X (BASELINE.json metric).
 
 One *step* = one scene through the whole hot path with inputs already resident in HBM
-(consecutive steps are issued round-robin on --streams HIP streams, default 2 scenes in flight, so one
+(consecutive steps are issued round-robin on --streams HIP streams, default 3 scenes in flight, so one
 scene's latency-bound coarse levels overlap the other's fine-level convolutions; --streams 1 = strictly
 one scene at a time):
     coordinate manager build (a3d_scene_create) + forward_backbone + ONE forward_mask
@@ -85,7 +85,7 @@ def profile_pass(step, scene_pairs, n_steps):
         e = buf[i]
         name = L.PROF_NAMES[e.id]
         if e.id == 0:
-            name = f"k_spconv<{e.bn},4,1,3>"   # BN, waves, groups/wave, ring depth (plan_conv default)
+            name = f"k_spconv2<{e.bn}>"        # BN (columns per workgroup); CH follows from Cin (plan_conv)
         elif e.id == L.PROF_DENSE:
             name = f"k_dense<{e.cin // 16},{e.cout // 16}>"
         a = agg.setdefault(name, {"ms": 0.0, "launches": 0, "flops": 0.0, "bytes": 0.0})
@@ -128,7 +128,7 @@ def main():
     ap.add_argument("--clicks-per-object", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
-    ap.add_argument("--streams", type=int, default=int(os.environ.get("A3D_BENCH_STREAMS", "2")),
+    ap.add_argument("--streams", type=int, default=int(os.environ.get("A3D_BENCH_STREAMS", "3")),
                     help="scenes in flight per GPU: consecutive steps are issued round-robin on this many HIP streams")
     args = ap.parse_args()
 
