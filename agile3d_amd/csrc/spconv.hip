@@ -438,12 +438,14 @@ template <int BN, int CH>
 __global__ void __launch_bounds__(256, 2) k_spconv2(const ConvArgs a) {
   constexpr int NCT = BN / 16, NS = CH / 16, NW = 4, NT = 256, kTile = 64;
   constexpr int NPIECE = NS * NCT;             // 1 KiB weight pieces per stage
-  constexpr int WV = (NPIECE + NW - 1) / NW;   // pieces per wave
+  static_assert(NPIECE % NW == 0, "pieces must split evenly over the waves");
+  constexpr int WV = NPIECE / NW;              // pieces per wave
   constexpr int WF = NPIECE * 256;             // floats per ring slot
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* wring = (float*)smem;                         // [2][WF]
   int* idx_lds = (int*)(wring + 2 * WF);               // [kper][64]
   int* tile_slot = idx_lds + a.kper * kTile;
+  const unsigned ring_addr = (unsigned)(size_t)wring;
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -455,7 +457,26 @@ __global__ void __launch_bounds__(256, 2) k_spconv2(const ConvArgs a) {
   const int cin16 = a.cin >> 4, cout16 = a.cout >> 4;
   int* counter = a.tile_counter ? a.tile_counter + (blockIdx.y * gridDim.z + blockIdx.z) : nullptr;
   const float* wlane = a.w + (size_t)ct0 * 256 + lane * 4;
+  // this wave's weight pieces q = wave + NW*i of a stage: source offset (floats) and LDS byte offset
+  int wsrc[WV];
+  unsigned wdst[WV];
+#pragma unroll
+  for (int i = 0; i < WV; ++i) {
+    const int q = wave + NW * i;
+    wsrc[i] = ((q / NCT) * cout16 + (q % NCT)) * 256;
+    wdst[i] = (unsigned)q * 1024u;
+  }
 
+  const bool timing = (a.dbg & 64) && a.dbg_cycles;   // phase cycle sums (A3D_DBG=64), see launch_conv
+  unsigned long long tc[6] = {0, 0, 0, 0, 0, 0};
+  unsigned long long t_prev = timing ? __builtin_amdgcn_s_memtime() : 0;
+  auto lap = [&](int slot) {
+    if (timing) {
+      const unsigned long long t = __builtin_amdgcn_s_memtime();
+      tc[slot] += t - t_prev;
+      t_prev = t;
+    }
+  };
   for (int tile = blockIdx.x;; tile += gridDim.x) {
     if (counter) {
       if (tid == 0) *tile_slot = atomicAdd(counter, 1);
@@ -484,6 +505,7 @@ __global__ void __launch_bounds__(256, 2) k_spconv2(const ConvArgs a) {
     }
     __syncthreads();
 
+    lap(0);   // queue + masks + idx table
     f32x4 acc[NCT];
 #pragma unroll
     for (int ct = 0; ct < NCT; ++ct) acc[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -492,36 +514,27 @@ __global__ void __launch_bounds__(256, 2) k_spconv2(const ConvArgs a) {
       while (k < kend && !((un >> k) & 1u)) ++k;
       return k;
     };
-    f32x4 an[NS], wn[WV];
-    // loads of stage (k, c): this lane's A fragments (if its group has k) and its weight pieces
-    auto load_stage = [&](int k, int c) {
+    f32x4 an[NS];
+    // stage (k, c): this lane's A fragments (if its group has k) into registers, this wave's weight pieces by
+    // LDS-DMA into ring slot `slot`.  The DMA is inline asm the compiler does not track: every stage ends with
+    // an explicit vmcnt(0) before the barrier, by which time both have had a whole stage of MFMAs to land.
+    auto load_stage = [&](int k, int c, int slot) {
       if ((gm >> k) & 1u) {
-        const int row = idx_lds[(k - kbeg) * kTile + 16 * wave + j];
+        const int row = (a.dbg & 1) ? j : idx_lds[(k - kbeg) * kTile + 16 * wave + j];
         const float* ar = a.in + (size_t)row * a.ldi + c * CH + 4 * g;
 #pragma unroll
         for (int S = 0; S < NS; ++S) an[S] = *(const f32x4*)(ar + 16 * S);
       }
       const float* wst = wlane + ((size_t)k * cin16 + (size_t)c * NS) * cout16 * 256;
+      const unsigned dst = ring_addr + (unsigned)slot * (WF * 4u);
 #pragma unroll
-      for (int i = 0; i < WV; ++i) {
-        const int q = wave + NW * i;               // piece -> (S, ct)
-        if (q < NPIECE) wn[i] = *(const f32x4*)(wst + ((size_t)(q / NCT) * cout16 + (q % NCT)) * 256);
-      }
-    };
-    auto store_w = [&](int slot) {
-      f32x4* dst = (f32x4*)(wring + slot * WF) + lane;
-#pragma unroll
-      for (int i = 0; i < WV; ++i) {
-        const int q = wave + NW * i;
-        if (q < NPIECE) dst[q * 64] = wn[i];
-      }
+      for (int i = 0; i < WV; ++i)
+        if (!(a.dbg & 2)) glds16(wst + wsrc[i], dst + wdst[i]);
     };
     int k = next_k(kbeg - 1), c = 0, slot = 0;
-    if (k < kend) {
-      load_stage(k, c);
-      store_w(0);
-    }
-    __syncthreads();
+    if (k < kend) load_stage(k, c, 0);
+    wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
     while (k < kend) {
       f32x4 ac[NS];
       const bool present = (gm >> k) & 1u;
@@ -532,25 +545,31 @@ __global__ void __launch_bounds__(256, 2) k_spconv2(const ConvArgs a) {
         c2 = 0;
         k2 = next_k(k);
       }
-      const bool has_next = k2 < kend;
-      if (has_next) load_stage(k2, c2);          // in flight behind this stage's MFMAs
-      if (present) {
+      if (k2 < kend) load_stage(k2, c2, slot ^ 1);   // in flight behind this stage's MFMAs
+      lap(1);   // stage control + load issue
+      if (present && !(a.dbg & 4)) {
         const f32x4* Ws = (const f32x4*)(wring + slot * WF) + lane;
+        f32x4 b[2][NCT];
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct) b[0][ct] = Ws[ct * 64];
 #pragma unroll
         for (int S = 0; S < NS; ++S) {
-          f32x4 b[NCT];
+          if (S + 1 < NS) {                           // next k-step's weight fragments before this one's MFMAs
 #pragma unroll
-          for (int ct = 0; ct < NCT; ++ct) b[ct] = Ws[(S * NCT + ct) * 64];
+            for (int ct = 0; ct < NCT; ++ct) b[(S + 1) & 1][ct] = Ws[((S + 1) * NCT + ct) * 64];
+          }
+          asm volatile("" ::: "memory");              // ... and no further ahead than that (VGPRs)
 #pragma unroll
           for (int t = 0; t < 4; ++t)
 #pragma unroll
             for (int ct = 0; ct < NCT; ++ct)
-              acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(ac[S][t], b[ct][t], acc[ct], 0, 0, 0);
-          asm volatile("" ::: "memory");   // keep later k-steps' weight reads from being hoisted
+              acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(ac[S][t], b[S & 1][ct][t], acc[ct], 0, 0, 0);
         }
       }
-      if (has_next) store_w(slot ^ 1);
-      __syncthreads();   // next slot visible; everyone is done with the current one
+      lap(4);   // fragment reads + MFMA
+      wait_vmcnt<0>();
+      __builtin_amdgcn_s_barrier();   // next slot landed for every wave; everyone is done with the current one
+      lap(2);   // wait + barrier
       slot ^= 1;
       k = k2;
       c = c2;
@@ -613,6 +632,12 @@ __global__ void __launch_bounds__(256, 2) k_spconv2(const ConvArgs a) {
       if (a.zero_row >= 0 && tile == 0 && tid < BN) a.out[(size_t)a.zero_row * a.ldo + ct0 * 16 + tid] = 0.f;
     }
     __syncthreads();   // the idx table / tile slot are reused by the next tile
+    lap(5);   // epilogue + end-of-tile barrier
+  }
+  if (timing && lane == 0) {
+#pragma unroll
+    for (int i = 0; i < 6; ++i) atomicAdd(&a.dbg_cycles[i], tc[i]);
+    atomicAdd(&a.dbg_cycles[6], 1ULL);
   }
 }
 
