@@ -117,6 +117,7 @@ struct Level {
   uint32_t hmask = 0;
   int* nbr27 = nullptr;         // [27][npad]
   uint32_t* gmask27 = nullptr;  // [npad/16]
+  int* order27 = nullptr;       // [npad/64] 64-row tiles, most offsets first (conv workgroups pull them in this order)
   int* child8 = nullptr;        // [8][npad(level+1)]     (levels 0..3)
   uint32_t* gmask_down = nullptr;
   int* up8 = nullptr;           // [8][npad]              (levels 0..3)

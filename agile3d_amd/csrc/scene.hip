@@ -93,6 +93,33 @@ __device__ inline int block_incl_scan(int v, int* lds, int* total) {
 }
 
 // ------------------------------------------------------------------------------ kernels
+// 64-row conv tiles ordered by cost (number of kernel offsets any of their 4 groups has), most expensive
+// first: a counting sort in one workgroup.  Longest-processing-time-first order for the persistent conv
+// workgroups' tile queue -- the cheap tiles fill the tail.  Ties land in arbitrary order (no result depends
+// on the order tiles are processed in).
+__global__ void __launch_bounds__(1024) k_tile_order(const uint32_t* __restrict__ gmask, int ntile, int* order) {
+  __shared__ int hist[32], base[32];
+  if (threadIdx.x < 32) hist[threadIdx.x] = 0;
+  __syncthreads();
+  for (int t = threadIdx.x; t < ntile; t += 1024) {
+    const uint32_t un = gmask[4 * t] | gmask[4 * t + 1] | gmask[4 * t + 2] | gmask[4 * t + 3];
+    atomicAdd(&hist[__popc(un)], 1);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int acc = 0;
+    for (int c = 31; c >= 0; --c) {
+      base[c] = acc;
+      acc += hist[c];
+    }
+  }
+  __syncthreads();
+  for (int t = threadIdx.x; t < ntile; t += 1024) {
+    const uint32_t un = gmask[4 * t] | gmask[4 * t + 1] | gmask[4 * t + 2] | gmask[4 * t + 3];
+    order[atomicAdd(&base[__popc(un)], 1)] = t;
+  }
+}
+
 // sizes_dev: [0..4] level sizes, [5] error code, [6] number of batch segments, [7] largest batch index,
 // [8 + b] first row of batch sample b (-1 = absent)
 __global__ void k_make_keys(const int32_t* __restrict__ coords4, int n, uint64_t* keys, int* vals,
@@ -409,6 +436,7 @@ static void carve_phase2(Bump& b, const int* sizes, a3d_scene* sc, Phase2Tmp& t)
     lv.hvals = b.take<int>((size_t)lv.hmask + 1);
     lv.nbr27 = b.take<int>((size_t)27 * lv.npad);
     lv.gmask27 = b.take<uint32_t>(lv.npad / 16);
+    lv.order27 = b.take<int>(lv.npad / 64);
     if (L < A3D_NUM_LEVELS - 1) {
       const int npadC = (int)round_up(sizes[L + 1] > 0 ? sizes[L + 1] : 1, kTileRows);
       lv.child8 = b.take<int>((size_t)8 * npadC);
@@ -560,6 +588,7 @@ extern "C" int a3d_scene_create(const int32_t* coords4_dev, int64_t n_voxels, vo
     k_tile_sort<<<nblk(n, kSuperTile), kSuperTile, 0, st>>>(t.sortkey, n, lv.perm, lv.inv);
     A3D_HIP_CHECK(hipMemsetAsync(lv.gmask27, 0, sizeof(uint32_t) * (npad / 16), st));
     k_remap_nbr<<<dim3(nblk(npad, T), 27), T, 0, st>>>(t.nbrM, lv.perm, lv.inv, n, npad, lv.nbr27, lv.gmask27);
+    k_tile_order<<<1, 1024, 0, st>>>(lv.gmask27, npad / 64, lv.order27);
     k_xyzb<<<nblk(n, T), T, 0, st>>>(lv.keys, lv.inv, n, L, lv.xyzb);
     k_hash_fix<<<nblk(cap, T), T, 0, st>>>(lv.hkeys, lv.hvals, cap, lv.perm);
     A3D_LAUNCH_CHECK();
@@ -608,6 +637,7 @@ extern "C" int a3d_scene_table(const a3d_scene* s, int level, int which, const v
     case A3D_TAB_XYZB: *ptr_dev = lv.xyzb; *count = (int64_t)lv.n * 4; break;
     case A3D_TAB_NBR27: *ptr_dev = lv.nbr27; *count = (int64_t)27 * lv.npad; break;
     case A3D_TAB_GMASK27: *ptr_dev = lv.gmask27; *count = lv.npad / 16; break;
+    case A3D_TAB_ORDER27: *ptr_dev = lv.order27; *count = lv.npad / 64; break;
     case A3D_TAB_CHILD8: if (!has_coarse) goto bad; *ptr_dev = lv.child8; *count = (int64_t)8 * npadC; break;
     case A3D_TAB_GMASKDOWN: if (!has_coarse) goto bad; *ptr_dev = lv.gmask_down; *count = npadC / 16; break;
     case A3D_TAB_UP8: if (!has_coarse) goto bad; *ptr_dev = lv.up8; *count = (int64_t)8 * lv.npad; break;

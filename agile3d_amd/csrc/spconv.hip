@@ -50,6 +50,7 @@ struct ConvArgs {
   int zero_row;
   int tag_table, tag_level;   // profiling only
   int* tile_counter;          // per (cout tile, k split) queue heads, zeroed by the caller; nullptr = static
+  const int* tile_order;      // [n_tiles] order in which 64-row tiles are handed out (most offsets first) or nullptr
   int n_tiles;
   unsigned long long* dbg_cycles;   // [8] phase cycle sums (A3D_DBG & 64)
   int dbg;                    // ablation switches (A3D_DBG env): 1 = no A gather, 2 = no W load, 4 = no MFMA
@@ -434,16 +435,15 @@ __global__ void __launch_bounds__(NW * 64) k_spconv(const ConvArgs a) {
 //   * a wave whose 16-row group lacks offset k issues neither loads nor MFMAs for it.
 // Workgroup = 4 waves = 64 output rows x BN columns; persistent, tiles from an atomic queue; split-K and the
 // epilogue are those of k_spconv.
-template <int BN, int CH>
-__global__ void __launch_bounds__(256, 2) k_spconv2(const ConvArgs a) {
-  constexpr int NCT = BN / 16, NS = CH / 16, NW = 4, NT = 256, kTile = 64;
+template <int BN, int CH, bool TR>
+__global__ void __launch_bounds__(256, CH >= 64 ? 2 : 3) k_spconv2(const ConvArgs a) {
+  constexpr int NCT = BN / 16, NS = CH / 16, NW = 4, kTile = 64;
   constexpr int NPIECE = NS * NCT;             // 1 KiB weight pieces per stage
-  static_assert(NPIECE % NW == 0, "pieces must split evenly over the waves");
-  constexpr int WV = NPIECE / NW;              // pieces per wave
+  constexpr int WV = (NPIECE + NW - 1) / NW;   // pieces per wave (the last ones guarded when NPIECE % NW != 0)
   constexpr int WF = NPIECE * 256;             // floats per ring slot
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* wring = (float*)smem;                         // [2][WF]
-  int* idx_lds = (int*)(wring + 2 * WF);               // [kper][64]
+  int* idx_lds = (int*)(wring + 2 * WF);               // [kper][64] gather rows of the tile
   int* tile_slot = idx_lds + a.kper * kTile;
   const unsigned ring_addr = (unsigned)(size_t)wring;
 
@@ -466,7 +466,6 @@ __global__ void __launch_bounds__(256, 2) k_spconv2(const ConvArgs a) {
     wsrc[i] = ((q / NCT) * cout16 + (q % NCT)) * 256;
     wdst[i] = (unsigned)q * 1024u;
   }
-
   const bool timing = (a.dbg & 64) && a.dbg_cycles;   // phase cycle sums (A3D_DBG=64), see launch_conv
   unsigned long long tc[6] = {0, 0, 0, 0, 0, 0};
   unsigned long long t_prev = timing ? __builtin_amdgcn_s_memtime() : 0;
@@ -477,6 +476,7 @@ __global__ void __launch_bounds__(256, 2) k_spconv2(const ConvArgs a) {
       t_prev = t;
     }
   };
+
   for (int tile = blockIdx.x;; tile += gridDim.x) {
     if (counter) {
       if (tid == 0) *tile_slot = atomicAdd(counter, 1);
@@ -484,7 +484,8 @@ __global__ void __launch_bounds__(256, 2) k_spconv2(const ConvArgs a) {
       tile = *tile_slot;
     }
     if (tile >= a.n_tiles) break;
-    const int r0 = tile * kTile;
+    const int r0 = (a.tile_order ? a.tile_order[tile] : tile) * kTile;
+    const int myrow = r0 + 16 * wave + j;          // this lane's output row (and gather row of its group)
     uint32_t un = 0xffffffffu, gm = 0xffffffffu;
     if (a.gmask) {
       const uint32_t* gp = a.gmask + (r0 >> 4);
@@ -492,35 +493,47 @@ __global__ void __launch_bounds__(256, 2) k_spconv2(const ConvArgs a) {
       gm = __builtin_amdgcn_readfirstlane(gp[wave]);
     }
     un = __builtin_amdgcn_readfirstlane(un);
-    for (int e = tid; e < (kend - kbeg) * kTile; e += NT) {
-      const int kk = e >> 6, r = e & 63;
-      int v;
-      if (a.nbr) {
-        v = a.nbr[(size_t)(kbeg + kk) * a.nbr_stride + r0 + r];
-      } else {
-        v = r0 + r;
-        if (v >= a.n_in) v = a.n_in - 1;
+    if (a.dbg & 32) un = gm = 0xffffffffu;   // experiment: every offset present in every group
+    if (kend < 32) un &= (1u << kend) - 1u;
+    un &= ~((1u << kbeg) - 1u);
+    // gather rows of the tile for every offset of this split: all loads in flight, then the LDS stores
+    {
+      const int total = (kend - kbeg) * kTile;
+      for (int base = tid; base < total; base += 8 * 256) {
+        int v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int e = base + u * 256;
+          const int kk = e >> 6, r = e & 63;
+          v[u] = 0;
+          if (e < total) v[u] = a.nbr ? a.nbr[(size_t)(kbeg + kk) * a.nbr_stride + r0 + r] : min(r0 + r, a.n_in - 1);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+          if (base + u * 256 < total) idx_lds[base + u * 256] = v[u];
       }
-      idx_lds[e] = v;
     }
     __syncthreads();
-
     lap(0);   // queue + masks + idx table
+
     f32x4 acc[NCT];
 #pragma unroll
     for (int ct = 0; ct < NCT; ++ct) acc[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    auto next_k = [&](int k) {
-      ++k;
-      while (k < kend && !((un >> k) & 1u)) ++k;
-      return k;
+    auto next_k = [&](int k) {               // next offset of the tile after k (32 = none)
+      const uint32_t rest = k >= 31 ? 0u : un & ~((2u << k) - 1u);
+      return rest ? __builtin_ctz(rest) : 32;
+    };
+    // neighbour row of this lane for offset k (the zero row when the group does not have k: never read then)
+    auto nbr_row = [&](int k) -> int {
+      if (a.dbg & 1) return j;
+      return idx_lds[(k - kbeg) * kTile + 16 * wave + j];
     };
     f32x4 an[NS];
     // stage (k, c): this lane's A fragments (if its group has k) into registers, this wave's weight pieces by
     // LDS-DMA into ring slot `slot`.  The DMA is inline asm the compiler does not track: every stage ends with
     // an explicit vmcnt(0) before the barrier, by which time both have had a whole stage of MFMAs to land.
-    auto load_stage = [&](int k, int c, int slot) {
+    auto load_stage = [&](int k, int c, int slot, int row) {
       if ((gm >> k) & 1u) {
-        const int row = (a.dbg & 1) ? j : idx_lds[(k - kbeg) * kTile + 16 * wave + j];
         const float* ar = a.in + (size_t)row * a.ldi + c * CH + 4 * g;
 #pragma unroll
         for (int S = 0; S < NS; ++S) an[S] = *(const f32x4*)(ar + 16 * S);
@@ -529,23 +542,36 @@ __global__ void __launch_bounds__(256, 2) k_spconv2(const ConvArgs a) {
       const unsigned dst = ring_addr + (unsigned)slot * (WF * 4u);
 #pragma unroll
       for (int i = 0; i < WV; ++i)
-        if (!(a.dbg & 2)) glds16(wst + wsrc[i], dst + wdst[i]);
+        if ((NPIECE % NW == 0 || wave + NW * i < NPIECE) && !(a.dbg & 2)) glds16(wst + wsrc[i], dst + wdst[i]);
     };
-    int k = next_k(kbeg - 1), c = 0, slot = 0;
-    if (k < kend) load_stage(k, c, 0);
+    // gather rows are requested one offset ahead of the A loads that need them:
+    //   row_cur = row for offset k (being computed / chunk-loaded), row_nxt = row for the offset after k
+    int k = un ? __builtin_ctz(un) : 32, c = 0, slot = 0;
+    int k1 = k < 32 ? next_k(k) : 32;
+    int row_cur = 0, row_nxt = 0;
+    if (k < 32) {
+      if ((gm >> k) & 1u) row_cur = nbr_row(k);
+      if (k1 < 32 && ((gm >> k1) & 1u)) row_nxt = nbr_row(k1);
+      load_stage(k, 0, 0, row_cur);
+    }
     wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();
-    while (k < kend) {
+    while (k < 32) {
       f32x4 ac[NS];
       const bool present = (gm >> k) & 1u;
 #pragma unroll
       for (int S = 0; S < NS; ++S) ac[S] = an[S];
-      int k2 = k, c2 = c + 1;
-      if (c2 == nchunk) {
-        c2 = 0;
-        k2 = next_k(k);
+      // next stage: another chunk of k, or the first chunk of k1
+      const bool same_k = c + 1 < nchunk;
+      const int k2 = same_k ? k : k1, c2 = same_k ? c + 1 : 0;
+      if (k2 < 32) {
+        load_stage(k2, c2, slot ^ 1, same_k ? row_cur : row_nxt);   // in flight behind this stage's MFMAs
+        if (!same_k) {
+          row_cur = row_nxt;
+          k1 = next_k(k2);
+          if (k1 < 32 && ((gm >> k1) & 1u)) row_nxt = nbr_row(k1);   // lands during the next stage
+        }
       }
-      if (k2 < kend) load_stage(k2, c2, slot ^ 1);   // in flight behind this stage's MFMAs
       lap(1);   // stage control + load issue
       if (present && !(a.dbg & 4)) {
         const f32x4* Ws = (const f32x4*)(wring + slot * WF) + lane;
@@ -554,84 +580,95 @@ __global__ void __launch_bounds__(256, 2) k_spconv2(const ConvArgs a) {
         for (int ct = 0; ct < NCT; ++ct) b[0][ct] = Ws[ct * 64];
 #pragma unroll
         for (int S = 0; S < NS; ++S) {
-          if (S + 1 < NS) {                           // next k-step's weight fragments before this one's MFMAs
+          if (S + 1 < NS && !(a.dbg & 8)) {           // next k-step's weight fragments before this one's MFMAs
 #pragma unroll
             for (int ct = 0; ct < NCT; ++ct) b[(S + 1) & 1][ct] = Ws[((S + 1) * NCT + ct) * 64];
           }
           asm volatile("" ::: "memory");              // ... and no further ahead than that (VGPRs)
+          // weights as the A operand: D[i][j] = sum_k W[k][16ct+i] X[row j][k], i.e. lane (g, j) ends up with
+          // output channels 16ct+4g..+3 of row j -> 16-byte epilogue accesses
 #pragma unroll
           for (int t = 0; t < 4; ++t)
 #pragma unroll
             for (int ct = 0; ct < NCT; ++ct)
-              acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(ac[S][t], b[S & 1][ct][t], acc[ct], 0, 0, 0);
+              acc[ct] = TR ? __builtin_amdgcn_mfma_f32_16x16x4f32(b[S & 1][ct][t], ac[S][t], acc[ct], 0, 0, 0)
+                           : __builtin_amdgcn_mfma_f32_16x16x4f32(ac[S][t], b[S & 1][ct][t], acc[ct], 0, 0, 0);
         }
       }
       lap(4);   // fragment reads + MFMA
       wait_vmcnt<0>();
-      __builtin_amdgcn_s_barrier();   // next slot landed for every wave; everyone is done with the current one
+      if (!(a.dbg & 16)) __builtin_amdgcn_s_barrier();   // next slot landed for every wave; current one is free
       lap(2);   // wait + barrier
       slot ^= 1;
       k = k2;
       c = c2;
     }
 
-    // ---- epilogue (C/D layout of 16x16x4: column = lane & 15, row = 4 * (lane >> 4) + reg)
-    const int rg = r0 + 16 * wave + 4 * g;
+    if constexpr (TR) {
+    // ---- epilogue: acc[ct] = output channels (ct0+ct)*16 + 4g .. +3 of row `myrow`
     if (a.partial) {
-      float* P = a.partial + (size_t)blockIdx.z * ((size_t)a.n_tiles * kTile) * a.cout;
+      float* P = a.partial + (size_t)blockIdx.z * ((size_t)a.n_tiles * kTile) * a.cout + (size_t)myrow * a.cout;
 #pragma unroll
-      for (int ct = 0; ct < NCT; ++ct)
+      for (int ct = 0; ct < NCT; ++ct) *(f32x4*)(P + (ct0 + ct) * 16 + 4 * g) = acc[ct];
+    } else if (myrow < a.n_out) {
+      const int orow = a.out_map ? a.out_map[myrow] : myrow;
+      float* po = a.out + (size_t)orow * a.ldo + ct0 * 16 + 4 * g;
+      const float* pr = a.res ? a.res + (size_t)orow * a.ldr + ct0 * 16 + 4 * g : nullptr;
+      f32x4 rv[NCT];
+      if (pr) {
 #pragma unroll
-        for (int t = 0; t < 4; ++t) P[(size_t)(rg + t) * a.cout + (ct0 + ct) * 16 + j] = acc[ct][t];
-    } else {
-      int orow[4];
-      bool ok[4];
-#pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        ok[t] = rg + t < a.n_out;
-        orow[t] = ok[t] ? rg + t : a.n_out - 1;
+        for (int ct = 0; ct < NCT; ++ct) rv[ct] = *(const f32x4*)(pr + ct * 16);
       }
-      if (a.out_map) {
-#pragma unroll
-        for (int t = 0; t < 4; ++t) orow[t] = a.out_map[orow[t]];
-      }
-      float sc[NCT], sh[NCT];
 #pragma unroll
       for (int ct = 0; ct < NCT; ++ct) {
-        const int col = (ct0 + ct) * 16 + j;
-        sc[ct] = a.scale ? a.scale[col] : 1.f;
-        sh[ct] = a.shift ? a.shift[col] : 0.f;
+        f32x4 v = acc[ct];
+        if (a.scale) v *= *(const f32x4*)(a.scale + (ct0 + ct) * 16 + 4 * g);
+        if (a.shift) v += *(const f32x4*)(a.shift + (ct0 + ct) * 16 + 4 * g);
+        if (pr) v += rv[ct];
+        if (a.relu) {
+#pragma unroll
+          for (int t = 0; t < 4; ++t) v[t] = fmaxf(v[t], 0.f);
+        }
+        *(f32x4*)(po + ct * 16) = v;
       }
-      if (a.res) {
-        float rv[NCT][4];
-#pragma unroll
-        for (int ct = 0; ct < NCT; ++ct)
-#pragma unroll
-          for (int t = 0; t < 4; ++t) rv[ct][t] = a.res[(size_t)orow[t] * a.ldr + (ct0 + ct) * 16 + j];
-#pragma unroll
-        for (int ct = 0; ct < NCT; ++ct)
-#pragma unroll
-          for (int t = 0; t < 4; ++t) acc[ct][t] = acc[ct][t] * sc[ct] + sh[ct] + rv[ct][t];
-      } else {
-#pragma unroll
-        for (int ct = 0; ct < NCT; ++ct)
-#pragma unroll
-          for (int t = 0; t < 4; ++t) acc[ct][t] = acc[ct][t] * sc[ct] + sh[ct];
-      }
-      if (a.relu) {
-#pragma unroll
-        for (int ct = 0; ct < NCT; ++ct)
-#pragma unroll
-          for (int t = 0; t < 4; ++t) acc[ct][t] = fmaxf(acc[ct][t], 0.f);
-      }
-#pragma unroll
-      for (int ct = 0; ct < NCT; ++ct)
-#pragma unroll
-        for (int t = 0; t < 4; ++t)
-          if (ok[t]) a.out[(size_t)orow[t] * a.ldo + (ct0 + ct) * 16 + j] = acc[ct][t];
-      if (a.zero_row >= 0 && tile == 0 && tid < BN) a.out[(size_t)a.zero_row * a.ldo + ct0 * 16 + tid] = 0.f;
     }
-    __syncthreads();   // the idx table / tile slot are reused by the next tile
+    } else {
+      // untransposed accumulators: column = lane & 15, row = 4 * (lane >> 4) + reg
+      const int rg = r0 + 16 * wave + 4 * g;
+      if (a.partial) {
+        float* P = a.partial + (size_t)blockIdx.z * ((size_t)a.n_tiles * kTile) * a.cout;
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+          for (int t = 0; t < 4; ++t) P[(size_t)(rg + t) * a.cout + (ct0 + ct) * 16 + j] = acc[ct][t];
+      } else {
+        int orow[4];
+        bool ok[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          ok[t] = rg + t < a.n_out;
+          orow[t] = ok[t] ? rg + t : a.n_out - 1;
+        }
+        if (a.out_map) {
+#pragma unroll
+          for (int t = 0; t < 4; ++t) orow[t] = a.out_map[orow[t]];
+        }
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct) {
+          const int col = (ct0 + ct) * 16 + j;
+          const float sc = a.scale ? a.scale[col] : 1.f, sh = a.shift ? a.shift[col] : 0.f;
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            float v = acc[ct][t] * sc + sh;
+            if (a.res) v += a.res[(size_t)orow[t] * a.ldr + col];
+            if (a.relu) v = fmaxf(v, 0.f);
+            if (ok[t]) a.out[(size_t)orow[t] * a.ldo + col] = v;
+          }
+        }
+      }
+    }
+    if (!a.partial && a.zero_row >= 0 && tile == 0 && tid < BN) a.out[(size_t)a.zero_row * a.ldo + ct0 * 16 + tid] = 0.f;
+    __syncthreads();   // tile_slot / the idx table are rewritten for the next tile
     lap(5);   // epilogue + end-of-tile barrier
   }
   if (timing && lane == 0) {
@@ -642,6 +679,12 @@ __global__ void __launch_bounds__(256, 2) k_spconv2(const ConvArgs a) {
 }
 
 static int conv2_ch(int cin, int bn) {   // input channels per stage: largest of 96/64/32 dividing cin with a ring <= 74 KB
+  static int forced = -1;
+  if (forced < 0) {
+    const char* e = getenv("A3D_CONV2_CH");   // experiment: force CH for 96-column workgroups
+    forced = e ? atoi(e) : 0;
+  }
+  if (forced && bn == 96 && cin % forced == 0) return forced;
   const int cand[3] = {96, 64, 32};
   for (int i = 0; i < 3; ++i)
     if (cin % cand[i] == 0 && 2 * cand[i] * bn * 4 <= 74 * 1024) return cand[i];
@@ -962,9 +1005,10 @@ static void allow_big_lds() {
 #define A3D_BIG(BN_) A3D_BIG1(BN_, 4, 1, 2) A3D_BIG1(BN_, 4, 1, 3) A3D_BIG1(BN_, 4, 2, 2) A3D_BIG1(BN_, 4, 2, 3) A3D_BIG1(BN_, 8, 1, 2)
   A3D_BIG(32) A3D_BIG(64) A3D_BIG(96) A3D_BIG(128)
 #define A3D_BIG2(BN_, CH_) \
-  (void)hipFuncSetAttribute((const void*)k_spconv2<BN_, CH_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  (void)hipFuncSetAttribute((const void*)k_spconv2<BN_, CH_, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+  (void)hipFuncSetAttribute((const void*)k_spconv2<BN_, CH_, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   A3D_BIG2(32, 32) A3D_BIG2(32, 64) A3D_BIG2(32, 96) A3D_BIG2(64, 32) A3D_BIG2(64, 64) A3D_BIG2(64, 96)
-  A3D_BIG2(96, 32) A3D_BIG2(96, 64) A3D_BIG2(96, 96) A3D_BIG2(128, 32) A3D_BIG2(128, 64)
+  A3D_BIG2(96, 32) A3D_BIG2(96, 48) A3D_BIG2(96, 64) A3D_BIG2(96, 96) A3D_BIG2(128, 32) A3D_BIG2(128, 64)
 #undef A3D_BIG2
   (void)hipFuncSetAttribute((const void*)k_dense<8, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   (void)hipFuncSetAttribute((const void*)k_dense<8, 6>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -1028,10 +1072,12 @@ static int launch_conv(ConvArgs a, float* partial_ws, size_t partial_ws_floats, 
     default: k_spconv<BN_, 4, 1, 3><<<grid, 256, p.lds, st>>>(a); break;                      \
   }
   if (p.ch) {
+    static int tr = -1;
+    if (tr < 0) { const char* e = getenv("A3D_CONV2_TR"); tr = e ? atoi(e) : 1; }
 #define A3D_L2(BN_, CH_) \
-  if (p.bn == BN_ && p.ch == CH_) k_spconv2<BN_, CH_><<<grid, 256, p.lds, st>>>(a); else
+  if (p.bn == BN_ && p.ch == CH_) { if (tr) k_spconv2<BN_, CH_, true><<<grid, 256, p.lds, st>>>(a); else k_spconv2<BN_, CH_, false><<<grid, 256, p.lds, st>>>(a); } else
     A3D_L2(32, 32) A3D_L2(32, 64) A3D_L2(32, 96) A3D_L2(64, 32) A3D_L2(64, 64) A3D_L2(64, 96)
-    A3D_L2(96, 32) A3D_L2(96, 64) A3D_L2(96, 96) A3D_L2(128, 32) A3D_L2(128, 64)
+    A3D_L2(96, 32) A3D_L2(96, 48) A3D_L2(96, 64) A3D_L2(96, 96) A3D_L2(128, 32) A3D_L2(128, 64)
     { set_error("spconv2: no kernel for BN %d CH %d", p.bn, p.ch); return A3D_ERR_UNSUPPORTED; }
 #undef A3D_L2
   } else
@@ -1268,6 +1314,11 @@ extern "C" int a3d_program_run(const a3d_scene* s, const a3d_buf_desc* bufs, int
         a.nbr = s->lv[Lin].nbr27;
         a.nbr_stride = s->lv[Lin].npad;
         a.gmask = s->lv[Lin].gmask27;
+        {
+          static int use_order = -1;
+          if (use_order < 0) { const char* e = getenv("A3D_TILE_ORDER"); use_order = e ? atoi(e) : 1; }
+          a.tile_order = conv_variant() == 2 && use_order ? s->lv[Lin].order27 : nullptr;   // 64-row tiles (k_spconv2)
+        }
         break;
       case A3D_OP_DOWN:
         if (o.kernel_volume != 8 || Lin >= A3D_NUM_LEVELS - 1) { set_error("op %d: bad DOWN", i); return A3D_ERR_INVALID; }

@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libagile3d_hip.so")
+LIB_PATH = os.environ.get("A3D_LIB_PATH") or os.path.join(HERE, "libagile3d_hip.so")   # override: A/B of two builds
 
 A3D_NUM_LEVELS = 5
 A3D_MAX_QUERIES = 256
@@ -17,7 +17,7 @@ A3D_MAX_DEC_LAYERS = 8
 OP_STEM, OP_CONV3, OP_DOWN, OP_UP, OP_LINEAR = 0, 1, 2, 3, 4
 BUF_NONE, BUF_EXT_OUT = -1, -2
 (TAB_XYZB, TAB_NBR27, TAB_GMASK27, TAB_CHILD8, TAB_GMASKDOWN, TAB_UP8, TAB_GMASKUP, TAB_UPROWS,
- TAB_ORIGROW) = range(9)
+ TAB_ORIGROW, TAB_ORDER27) = range(10)
 
 c_float_p = C.c_void_p  # device pointers travel as integers
 

@@ -96,7 +96,8 @@ enum {
   A3D_TAB_UP8       = 5,  /* int32 [8][npad] parent row (level+1) of virtual row v at its slot    */
   A3D_TAB_GMASKUP   = 6,  /* uint32 [npad/16]                                                     */
   A3D_TAB_UPROWS    = 7,  /* int32 [npad] virtual row -> row of `level`                           */
-  A3D_TAB_ORIGROW   = 8   /* int32 [n0]   internal level-0 row -> caller's row                    */
+  A3D_TAB_ORIGROW   = 8,  /* int32 [n0]   internal level-0 row -> caller's row                    */
+  A3D_TAB_ORDER27   = 9   /* int32 [npad/64] 64-row tiles sorted by number of 3^3 offsets, most first */
 };
 int a3d_scene_table(const a3d_scene* s, int level, int which, const void** ptr_dev, int64_t* count);
 
