@@ -85,7 +85,8 @@ def profile_pass(step, scene_pairs, n_steps):
         e = buf[i]
         name = L.PROF_NAMES[e.id]
         if e.id == 0:
-            name = f"k_spconv2<{e.bn}>"        # BN (columns per workgroup); CH follows from Cin (plan_conv)
+            ch = next(c for c in (96, 64, 32) if e.cin % c == 0 and 2 * c * e.bn * 4 <= 74 * 1024)
+            name = f"k_spconv2<{e.bn},{ch}>"   # BN columns per workgroup, CH input channels per stage (plan_conv)
         elif e.id == L.PROF_DENSE:
             name = f"k_dense<{e.cin // 16},{e.cout // 16}>"
         a = agg.setdefault(name, {"ms": 0.0, "launches": 0, "flops": 0.0, "bytes": 0.0})

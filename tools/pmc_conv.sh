@@ -1,9 +1,7 @@
-set -x
+# SQ counters of the dominant conv kernel (L0 3^3 96->96) -- separate --pmc passes, kernel trace only.
 R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
-run() { n=$1; shift; rocprofv3 --pmc "$@" --kernel-trace -d /tmp/pmc_$n -o p -- python $R/tools/conv_bench.py --only L0_conv3_96_96 --reps 5 > /tmp/pmc_$n.log 2>&1; python $R/tools/pmc_summary.py /tmp/pmc_$n 2>&1 | grep -E "spconv2" ; }
+run() { n=$1; shift; rocprofv3 --pmc "$@" --kernel-trace -d /tmp/pmc_$n -o p -- python $R/tools/conv_bench.py --only ${CASE:-L0_conv3_96_96} --reps 5 > /tmp/pmc_$n.log 2>&1; python $R/tools/pmc_summary.py /tmp/pmc_$n 2>&1 | grep -E "spconv2" ; }
 run a SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY
 run b SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_ACTIVE_INST_VALU SQ_WAIT_ANY
-run c SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_VMEM
-run d SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_MISC SQ_ACTIVE_INST_SCA
 run e GRBM_GUI_ACTIVE SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU

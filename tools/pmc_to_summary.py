@@ -1,0 +1,39 @@
+#!/usr/bin/env python3
+"""pmc_raw.json (per-kernel mean counters from tools/rocprof_summary.py) -> profiles/pmc_summary.json with the
+names bench.py uses and the gfx950 corrections of MI355X_MICROARCH.md (HBM section)."""
+import json
+import re
+import sys
+
+raw = json.load(open(sys.argv[1]))
+out = {"_note": "rocprofv3 --pmc passes of `python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-profile "
+                "--streams 1` on MI355X (tools/profile_round.sh). Separate passes for FETCH_SIZE, WRITE_SIZE and the SQ "
+                "group (never combined with tracing). hbm_bytes_per_launch = (2*FETCH_SIZE + WRITE_SIZE) KiB: on gfx950 "
+                "FETCH_SIZE reports half the bytes of a wide coalesced read (MI355X_MICROARCH.md, HBM section); WRITE_SIZE "
+                "is taken as is (uncalibrated). mfma_util = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs * GRBM_GUI_ACTIVE / 8 "
+                "XCDs); wave_residency = 4*SQ_WAVE_CYCLES / waves / (GRBM_GUI_ACTIVE / 8) is reported for the conv kernels."}
+for name, c in raw.items():
+    short = name.replace("void ", "").replace("a3d::", "")
+    m = re.match(r"k_spconv2<(\d+), (\d+), (true|false)>", short)
+    key = short
+    if m:
+        key = f"k_spconv2<{m.group(1)},{m.group(2)}>"
+    m = re.match(r"k_dense<(\d+), (\d+)>", short)
+    if m:
+        key = f"k_dense<{m.group(1)},{m.group(2)}>"
+    e = out.setdefault(key, {"fetch_kib_raw": 0.0, "write_kib_raw": 0.0, "_n": 0})
+    # several template instances can fold into one key: keep the heaviest (largest FETCH_SIZE) as representative
+    if c.get("FETCH_SIZE", 0.0) >= e["fetch_kib_raw"]:
+        e["fetch_kib_raw"] = c.get("FETCH_SIZE", 0.0)
+        e["write_kib_raw"] = c.get("WRITE_SIZE", 0.0)
+        e["hbm_bytes_per_launch"] = (2.0 * e["fetch_kib_raw"] + e["write_kib_raw"]) * 1024.0
+        gui = c.get("GRBM_GUI_ACTIVE", 0.0) / 8.0
+        e["mfma_util"] = c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (1024.0 * gui) if gui else 0.0
+        e["lds_bank_conflict_cycles"] = c.get("SQ_LDS_BANK_CONFLICT", 0.0)
+        e["instance"] = short
+    e["_n"] += 1
+for e in out.values():
+    if isinstance(e, dict):
+        e.pop("_n", None)
+json.dump(out, open(sys.argv[2], "w"), indent=1)
+print("wrote", sys.argv[2], len(out) - 1, "kernels")

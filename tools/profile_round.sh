@@ -1,0 +1,21 @@
+#!/bin/bash
+# Regenerate the profiles/ artefacts of a round on the GPU box:  bash tools/profile_round.sh r01
+# (run through gpurun; raw rocprofv3 databases stay in /tmp, text/JSON summaries go to gpurun_out/<tag>/).
+# Passes: kernel trace + stats, then SEPARATE --pmc passes (FETCH_SIZE, WRITE_SIZE, SQ group) -- counters are
+# never combined with the hip/hsa/memory trace domains.
+TAG=${1:-r01}
+R=$GRAFT_REPO_ROOT
+OUT=$R/gpurun_out/$TAG
+mkdir -p $OUT
+CMD="python $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --streams 1"
+python $R/bench.py > $OUT/bench.json 2> $OUT/bench.err
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats -d /tmp/$TAG/trace -o t -- $CMD > $OUT/bench_under_rocprof.json 2> $OUT/trace.err
+python $R/tools/rocprof_summary.py /tmp/$TAG/trace > $OUT/kernel_trace_stats.txt 2>&1
+PMC="python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-profile --streams 1"
+rocprofv3 --pmc FETCH_SIZE --kernel-trace -d /tmp/$TAG/pmc_fetch -o p -- $PMC > /dev/null 2> $OUT/pmc_fetch.err
+rocprofv3 --pmc WRITE_SIZE --kernel-trace -d /tmp/$TAG/pmc_write -o p -- $PMC > /dev/null 2> $OUT/pmc_write.err
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_LDS_BANK_CONFLICT SQ_WAVE_CYCLES --kernel-trace -d /tmp/$TAG/pmc_sq -o p -- $PMC > /dev/null 2> $OUT/pmc_sq.err
+PMC_JSON=$OUT/pmc_raw.json python $R/tools/rocprof_summary.py /tmp/$TAG/pmc_fetch /tmp/$TAG/pmc_write /tmp/$TAG/pmc_sq > $OUT/pmc_counters.txt 2>&1
+python $R/tools/pmc_to_summary.py $OUT/pmc_raw.json $OUT/pmc_summary.json
+ls -la $OUT
