@@ -877,20 +877,57 @@ __global__ void __launch_bounds__(256) k_stem(const int32_t* __restrict__ xyzb, 
   for (int e = tid; e < K * 96; e += 256) W[e] = w[e];
   const int v0 = blockIdx.x * 64;
   const int h = ks / 2;
-  for (int e = tid; e < 64 * K; e += 256) {
-    const int v = e / K, k = e - v * K;
-    const int row = v0 + v;
-    int r = -1;
-    if (row < n) {
-      const int X = xyzb[4 * row + 0] + (k % ks) - h;
-      const int Y = xyzb[4 * row + 1] + ((k / ks) % ks) - h;
-      const int Z = xyzb[4 * row + 2] + (k / (ks * ks)) - h;
-      const int b = xyzb[4 * row + 3];
-      const int lim = kCoordOff;
-      if (X >= -lim && X < lim && Y >= -lim && Y < lim && Z >= -lim && Z < lim)
-        r = hash_lookup(hk, hv, hmask, make_key(b, X, Y, Z, 0));
+  // hash probes, four independent lookups in flight per thread (the probes are L2-latency bound)
+  for (int e0 = tid; e0 < 64 * K; e0 += 4 * 256) {
+    uint64_t key[4];
+    uint32_t hh[4];
+    int res[4];
+    bool open[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int e = e0 + u * 256;
+      const int v = e / K, k = e - v * K;
+      const int row = v0 + v;
+      res[u] = -1;
+      open[u] = false;
+      key[u] = 0;
+      hh[u] = 0;
+      if (e < 64 * K && row < n) {
+        const int X = xyzb[4 * row + 0] + (k % ks) - h;
+        const int Y = xyzb[4 * row + 1] + ((k / ks) % ks) - h;
+        const int Z = xyzb[4 * row + 2] + (k / (ks * ks)) - h;
+        const int b = xyzb[4 * row + 3];
+        const int lim = kCoordOff;
+        if (X >= -lim && X < lim && Y >= -lim && Y < lim && Z >= -lim && Z < lim) {
+          key[u] = make_key(b, X, Y, Z, 0);
+          hh[u] = hash64(key[u]) & hmask;
+          open[u] = true;
+        }
+      }
     }
-    nb[e] = r;
+    for (uint32_t probe = 0; probe <= hmask; ++probe) {
+      uint64_t got[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) got[u] = open[u] ? hk[hh[u]] : kEmptyKey;
+      bool any = false;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (!open[u]) continue;
+        if (got[u] == key[u]) {
+          res[u] = hv[hh[u]];
+          open[u] = false;
+        } else if (got[u] == kEmptyKey) {
+          open[u] = false;
+        } else {
+          hh[u] = (hh[u] + 1) & hmask;
+          any = true;
+        }
+      }
+      if (!any) break;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (e0 + u * 256 < 64 * K) nb[e0 + u * 256] = res[u];
   }
   __syncthreads();
   const int v = tid >> 2, cg = tid & 3;
@@ -898,13 +935,20 @@ __global__ void __launch_bounds__(256) k_stem(const int32_t* __restrict__ xyzb, 
   float acc[8];
 #pragma unroll
   for (int c = 0; c < 8; ++c) acc[c] = 0.f;
-  for (int k = 0; k < K; ++k) {
-    const int r = nb[v * K + k];
-    if (r >= 0) {
-      const f32x4 f = feats4[r];
-      const float* wk = W + k * 96 + cg * 8;
+  // neighbour features: five gathers in flight per thread (missing neighbours read row 0 and are masked)
+  for (int k0 = 0; k0 < K; k0 += 5) {
+    int r[5];
+    f32x4 f[5];
 #pragma unroll
-      for (int c = 0; c < 8; ++c) acc[c] += f[0] * wk[c] + f[1] * wk[32 + c] + f[2] * wk[64 + c];
+    for (int u = 0; u < 5; ++u) r[u] = k0 + u < K ? nb[v * K + k0 + u] : -1;
+#pragma unroll
+    for (int u = 0; u < 5; ++u) f[u] = feats4[r[u] >= 0 ? r[u] : 0];
+#pragma unroll
+    for (int u = 0; u < 5; ++u) {
+      if (r[u] < 0) continue;
+      const float* wk = W + (k0 + u) * 96 + cg * 8;
+#pragma unroll
+      for (int c = 0; c < 8; ++c) acc[c] += f[u][0] * wk[c] + f[u][1] * wk[32 + c] + f[u][2] * wk[64 + c];
     }
   }
   if (row < n) {
