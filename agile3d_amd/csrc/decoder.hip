@@ -29,7 +29,7 @@ constexpr int H = 8;          // heads
 constexpr int DH = 16;        // head dim
 constexpr float kLnEps = 1e-5f;
 constexpr float kNegBig = -1e30f;
-constexpr int kC2SChunk = 256;   // points per c2s workgroup
+constexpr int kC2SChunk = 128;   // points per c2s workgroup
 constexpr int kPartStride = 18;  // m, l, acc[16]
 
 // ------------------------------------------------------------------------------ posenc
@@ -128,18 +128,29 @@ __global__ void __launch_bounds__(512) k_c2s_attn(const float* __restrict__ Kc, 
     l[qt] = 0.f;
     acc[qt] = (f32x4){0.f, 0.f, 0.f, 0.f};
   }
-  for (int p0 = pbeg; p0 < pend; p0 += 16) {
+  // the 16 points of the NEXT iteration are loaded while the current ones are multiplied
+  f32x4 kf_n = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float vf_n[4] = {0.f, 0.f, 0.f, 0.f};
+  unsigned lab_n = 0;
+  auto fetch = [&](int p0) {
     const int prow = p0 + j;
-    f32x4 kf = (f32x4){0.f, 0.f, 0.f, 0.f};
-    if (prow < n) kf = *(const f32x4*)(Kc + (size_t)prow * D + h * DH + 4 * g);
-    float vf[4];
-    unsigned lab4 = 0;
+    kf_n = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (prow < n) kf_n = *(const f32x4*)(Kc + (size_t)prow * D + h * DH + 4 * g);
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
       const int pr = p0 + 4 * g + t;
-      vf[t] = pr < n ? V[(size_t)pr * D + h * DH + j] : 0.f;
+      vf_n[t] = pr < n ? V[(size_t)pr * D + h * DH + j] : 0.f;
     }
-    if (labels) lab4 = *(const unsigned*)(labels + p0 + 4 * g);
+    lab_n = labels ? *(const unsigned*)(labels + p0 + 4 * g) : 0u;
+  };
+  if (pbeg < pend) fetch(pbeg);
+  for (int p0 = pbeg; p0 < pend; p0 += 16) {
+    const f32x4 kf = kf_n;
+    float vf[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) vf[t] = vf_n[t];
+    const unsigned lab4 = lab_n;
+    if (p0 + 16 < pend) fetch(p0 + 16);
 #pragma unroll
     for (int qt = 0; qt < QT; ++qt) {
       f32x4 s = (f32x4){0.f, 0.f, 0.f, 0.f};
