@@ -85,7 +85,13 @@ def sparse_quantize(coordinates, features=None, labels=None, quantization_size=N
                     return_index=False, return_inverse=False, **_ignored):
     """``ME.utils.sparse_quantize``: ``floor(coords / quantization_size)`` in the
     input's own float dtype, int32 cast, unique voxels; ``unique_map`` = index of the first point
-    of each voxel (in input order), ``inverse_map`` = voxel row of every point."""
+    of each voxel (in input order), ``inverse_map`` = voxel row of every point.
+
+    A CUDA tensor is voxelised on the GPU (``a3d_sparse_quantize``, csrc/quantize.hip; results stay on
+    the device); numpy arrays / CPU tensors take the host path the reference's dataset code runs in its
+    loader workers.  Both produce identical integers."""
+    if torch.is_tensor(coordinates) and coordinates.is_cuda:
+        return _sparse_quantize_device(coordinates, features, labels, quantization_size, return_index, return_inverse)
     c = np.asarray(coordinates.cpu() if torch.is_tensor(coordinates) else coordinates)
     if quantization_size is not None:
         c = np.floor(c / quantization_size)
@@ -107,6 +113,42 @@ def sparse_quantize(coordinates, features=None, labels=None, quantization_size=N
         out.append(torch.from_numpy(unique_map) if torch.is_tensor(coordinates) else unique_map)
     if return_inverse:
         out.append(torch.from_numpy(inverse_map) if torch.is_tensor(coordinates) else inverse_map)
+    return out[0] if len(out) == 1 else tuple(out)
+
+
+def _sparse_quantize_device(coordinates, features, labels, quantization_size, return_index, return_inverse):
+    import ctypes as C
+
+    from . import lib as L
+    lib = L.load()
+    xyz = coordinates
+    if xyz.dim() != 2 or xyz.shape[1] != 3 or xyz.dtype not in (torch.float32, torch.float64):
+        raise ValueError("sparse_quantize on the GPU takes float32/float64 [N,3] coordinates")
+    xyz = xyz.contiguous()
+    n = xyz.shape[0]
+    dev = xyz.device
+    if n == 0:
+        raise ValueError("sparse_quantize: empty point cloud")
+    ws = torch.empty(lib.a3d_quantize_workspace_bytes(n), dtype=torch.uint8, device=dev)
+    q = torch.empty((n, 3), dtype=torch.int32, device=dev)
+    umap = torch.empty(n, dtype=torch.int64, device=dev)
+    inv = torch.empty(n, dtype=torch.int64, device=dev)
+    nv = C.c_int64()
+    size = 1.0 if quantization_size is None else float(quantization_size)
+    L.check(lib.a3d_sparse_quantize(xyz.data_ptr(), int(xyz.dtype == torch.float64), n, size, q.data_ptr(),
+                                    umap.data_ptr(), inv.data_ptr(), C.byref(nv), ws.data_ptr(), ws.numel(),
+                                    C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)), "a3d_sparse_quantize")
+    m = nv.value
+    unique_map = umap[:m]
+    out = [q[:m]]
+    if features is not None:
+        out.append(features[unique_map])
+    if labels is not None:
+        out.append(labels[unique_map])
+    if return_index:
+        out.append(unique_map)
+    if return_inverse:
+        out.append(inv)
     return out[0] if len(out) == 1 else tuple(out)
 
 

@@ -267,6 +267,19 @@ int    a3d_click_clusters(const float* xyz_dev, const int32_t* pred_dev, const i
 int    a3d_click_loss_weights(const float* xyz_dev, int64_t n, const int32_t* click_row, int n_clicks,
                               float tita, float alpha, float beta, float* weights_dev, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * On-device voxelisation.
+ * Replaces: ME.utils.sparse_quantize(coordinates, quantization_size, return_index=True,
+ * return_inverse=True) (datasets/InterMultiObj3DSegDataset.py:67-75): q = int32(floor(xyz / size)) in
+ * the input's own dtype (is_f64: 0 = float32 [n][3], 1 = float64), voxels in first-occurrence order,
+ * unique_map[v] = first point of voxel v, inverse_map[i] = voxel of point i.  Output arrays must hold
+ * n_points entries; *n_voxels (HOST) receives the voxel count (one stream synchronisation).
+ * ------------------------------------------------------------------------------------------ */
+size_t a3d_quantize_workspace_bytes(int64_t n_points);
+int    a3d_sparse_quantize(const void* xyz_dev, int is_f64, int64_t n_points, double quantization_size,
+                           int32_t* coords_out_dev, int64_t* unique_map_dev, int64_t* inverse_map_dev,
+                           int64_t* n_voxels, void* workspace_dev, size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
