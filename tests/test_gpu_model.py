@@ -217,3 +217,25 @@ def test_two_scenes_in_flight_on_two_streams(model_and_sd):
         torch.cuda.synchronize()
         for i, (f, m) in enumerate(outs):
             assert torch.equal(f, serial[i % len(jobs)][0]) and torch.equal(m, serial[i % len(jobs)][1]), (rep, i)
+
+
+def test_outdoor_scan_size_stress(model_and_sd):
+    """BASELINE.json configs[4]: ~300 k voxels, 20 clicks.  Size-independent properties only (the oracle needs
+    minutes at this size): bit-determinism, finite logits, and agreement with a run on a row-permuted copy."""
+    model, _ = model_and_sd
+    sc = make_scene(300_000, seed=2)
+    n = len(sc["coords"])
+    ci, ct = make_clicks(sc["labels"], 10, 2, 0, seed=2)
+    r = _run_backbone(model, sc)
+    o1 = model.forward_mask(*r, click_idx=[ci], click_time_idx=[ct])["pred_masks"][0]
+    o2 = model.forward_mask(*_run_backbone(model, sc), click_idx=[ci], click_time_idx=[ct])["pred_masks"][0]
+    assert o1.shape == (n, 11) and torch.isfinite(o1).all() and torch.equal(o1, o2)
+    perm = np.random.default_rng(0).permutation(n)
+    inv = np.empty(n, np.int64)
+    inv[perm] = np.arange(n)
+    sp = {k: (v[perm] if k != "labels" else v[perm]) for k, v in sc.items()}
+    cip = {k: [int(inv[i]) for i in v] for k, v in ci.items()}
+    op = model.forward_mask(*_run_backbone(model, sp), click_idx=[cip], click_time_idx=[ct])["pred_masks"][0]
+    err = (op[torch.from_numpy(inv).cuda()] - o1).abs().max().item()
+    print(f"300k voxels: permuted-input max|diff| = {err:.2e}")
+    assert err <= 1e-4
