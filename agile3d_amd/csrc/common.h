@@ -45,7 +45,7 @@ static inline size_t align256(size_t x) { return (x + 255) & ~size_t(255); }
 // ---- geometry constants -------------------------------------------------------------------
 constexpr int kTileRows = 128;   // output rows per conv workgroup
 constexpr int kGroupRows = 16;   // MFMA row granularity (v_mfma_f32_16x16x4_f32)
-constexpr int kSuperTile = 1024; // rows re-ordered by neighbour pattern inside one super tile
+constexpr int kSuperTile = 1 << 18;  // rows re-ordered by neighbour pattern inside one super tile (= whole level up to 262 k rows)
 constexpr int kCoordOff = 1 << 17;
 constexpr uint64_t kEmptyKey = ~0ull;
 

@@ -244,44 +244,39 @@ __global__ void k_nbr_morton(const uint64_t* __restrict__ keys, int n, int npad,
   nbrM[(size_t)k * npad + i] = r;
 }
 // 27-bit presence mask per row (the sort key of the row clustering)
-__global__ void k_mask27(const int* __restrict__ nbrM, int n, int npad, uint32_t* mask27) {
+// Rows are re-ordered inside super tiles of 2^st_shift consecutive rows by a small key (the 27-bit neighbour
+// presence mask / the child slot): ALL levels go through one stable device-wide radix sort of
+//   key = level << 45 | super tile << 27 | small key,   value = position in the concatenated row list.
+__global__ void k_mask27(const int* __restrict__ nbrM, int n, int npad, int level, int off, int st_shift,
+                         uint64_t* cat_keys, int* cat_vals) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   uint32_t m = 0;
 #pragma unroll
   for (int k = 0; k < 27; ++k) m |= (nbrM[(size_t)k * npad + i] >= 0 ? 1u : 0u) << k;
-  mask27[i] = m;
+  cat_keys[off + i] = ((uint64_t)level << 45) | ((uint64_t)(i >> st_shift) << 27) | m;
+  cat_vals[off + i] = off + i;
+}
+// sorted segment of one level -> perm (old row -> new row) and inv (new row -> old row)
+__global__ void k_perm_from_sorted(const int* __restrict__ sorted_vals, int n, int off, int* perm, int* inv) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n) return;
+  const int src = sorted_vals[off + p] - off;
+  perm[src] = p;
+  inv[p] = src;
 }
 
-// sort the rows of each 1024-row super tile by `sortkey` (stable: ties keep Morton order)
-__global__ void __launch_bounds__(1024) k_tile_sort(const uint32_t* __restrict__ sortkey, int n,
-                                                    int* perm, int* inv) {
-  __shared__ uint64_t s[kSuperTile];
-  const int tid = threadIdx.x;
-  const int base = blockIdx.x * kSuperTile;
-  const int i = base + tid;
-  s[tid] = i < n ? (((uint64_t)sortkey[i] << 10) | (uint64_t)tid) : ~0ULL;
-  __syncthreads();
-  for (int k = 2; k <= kSuperTile; k <<= 1) {
-    for (int j = k >> 1; j > 0; j >>= 1) {
-      const int ixj = tid ^ j;
-      if (ixj > tid) {
-        const bool asc = (tid & k) == 0;
-        const uint64_t a = s[tid], b = s[ixj];
-        if ((a > b) == asc) {
-          s[tid] = b;
-          s[ixj] = a;
-        }
-      }
-      __syncthreads();
-    }
+static int super_tile_shift() {   // log2 of the super-tile size, A3D_SUPERTILE = rows (power of two), default kSuperTile
+  static int sh = -1;
+  if (sh < 0) {
+    const char* e = getenv("A3D_SUPERTILE");
+    int st = e ? atoi(e) : kSuperTile;
+    if (st < 64 || (st & (st - 1))) st = kSuperTile;
+    sh = 0;
+    while ((1 << sh) < st) ++sh;
+    if (sh > 18) sh = 18;
   }
-  const uint64_t v = s[tid];
-  if (v != ~0ULL) {
-    const int e = (int)(v & 1023);
-    perm[base + e] = base + tid;
-    inv[base + tid] = base + e;
-  }
+  return sh;
 }
 
 // nbr27[k][f] in internal row ids (missing / padding -> n) + per-16-row-group presence masks
@@ -338,10 +333,12 @@ __global__ void k_child(const uint64_t* __restrict__ keysF, const int* __restric
   atomicOr(&gmask_down[pf >> 4], 1u << slot);
 }
 
-__global__ void k_slot_key(const uint64_t* __restrict__ keysF, const int* __restrict__ invF, int nF,
-                           uint32_t* sortkey) {
+__global__ void k_slot_key(const uint64_t* __restrict__ keysF, const int* __restrict__ invF, int nF, int level,
+                           int off, int st_shift, uint64_t* cat_keys, int* cat_vals) {
   const int f = blockIdx.x * blockDim.x + threadIdx.x;
-  if (f < nF) sortkey[f] = (uint32_t)(keysF[invF[f]] & 7);
+  if (f >= nF) return;
+  cat_keys[off + f] = ((uint64_t)level << 45) | ((uint64_t)(f >> st_shift) << 27) | (keysF[invF[f]] & 7);
+  cat_vals[off + f] = off + f;
 }
 
 // transposed-conv tables over virtual rows v (fine rows sorted by child slot inside super tiles)
@@ -410,12 +407,14 @@ static void carve_phase1(Bump& b, int n0, Phase1& p) {
   for (int L = 0; L < A3D_NUM_LEVELS - 1; ++L) p.parentM[L] = b.take<int>(n0);
   p.blocksums = b.take<int>(n0 / 1024 + 2);
   p.sizes_dev = b.take<int>(kSizesInts);
-  p.sort_temp_bytes = sort_temp_bytes(n0);
+  p.sort_temp_bytes = sort_temp_bytes(A3D_NUM_LEVELS * n0 + 1024);   // also used for the concatenated per-level row sorts (sum of n_L <= 5 n0)
   p.sort_temp = b.take<char>(p.sort_temp_bytes);
 }
 struct Phase2Tmp {
-  int* nbrM;
-  uint32_t* sortkey;
+  int* nbrM[A3D_NUM_LEVELS];     // [27][npad] neighbour rows in Morton order, kept until the rows are re-ordered
+  int off[A3D_NUM_LEVELS + 1];   // start of every level in the concatenated row list
+  uint64_t *cat_keys, *cat_keys_sorted;
+  int *cat_vals, *cat_vals_sorted;
   int* permU;
 };
 static void carve_phase2(Bump& b, const int* sizes, a3d_scene* sc, Phase2Tmp& t) {
@@ -447,8 +446,17 @@ static void carve_phase2(Bump& b, const int* sizes, a3d_scene* sc, Phase2Tmp& t)
     }
   }
   sc->orig_row = b.take<int>(sc->lv[0].npad);
-  t.nbrM = b.take<int>((size_t)27 * maxn);
-  t.sortkey = b.take<uint32_t>(maxn);
+  int tot = 0;
+  for (int L = 0; L < A3D_NUM_LEVELS; ++L) {
+    t.nbrM[L] = b.take<int>((size_t)27 * sc->lv[L].npad);
+    t.off[L] = tot;
+    tot += sc->lv[L].npad;
+  }
+  t.off[A3D_NUM_LEVELS] = tot;
+  t.cat_keys = b.take<uint64_t>(tot);
+  t.cat_keys_sorted = b.take<uint64_t>(tot);
+  t.cat_vals = b.take<int>(tot);
+  t.cat_vals_sorted = b.take<int>(tot);
   t.permU = b.take<int>(maxn);
 }
 
@@ -575,6 +583,21 @@ extern "C" int a3d_scene_create(const int32_t* coords4_dev, int64_t n_voxels, vo
     return A3D_ERR_WORKSPACE;
   }
   ProfScope prof2(st, A3D_PROF_SCENE_TABLES, 0, 0, 0, 0, n0);
+  const int st_shift = super_tile_shift();
+  // the concatenated list is sized by npad per level; only the first n rows of a level carry keys
+  auto sort_cat = [&](int n_levels) -> int {
+    // compact the per-level segments [off[L], off[L]+n_L) into one dense run for the sort
+    int tot = 0;
+    for (int L = 0; L < n_levels; ++L) tot += sc->lv[L].n;
+    size_t tb = p.sort_temp_bytes;
+    A3D_HIP_CHECK(rocprim::radix_sort_pairs(p.sort_temp, tb, t.cat_keys, t.cat_keys_sorted, t.cat_vals, t.cat_vals_sorted,
+                                            (size_t)tot, 0, 48, st, false));
+    return A3D_OK;
+  };
+  int off[A3D_NUM_LEVELS + 1];   // dense offsets (sum of n, not npad)
+  off[0] = 0;
+  for (int L = 0; L < A3D_NUM_LEVELS; ++L) off[L + 1] = off[L] + sc->lv[L].n;
+  // ---- stage A: hash + neighbours in Morton order + sort keys, every level
   for (int L = 0; L < A3D_NUM_LEVELS; ++L) {
     Level& lv = sc->lv[L];
     lv.keys = p.keys[L];
@@ -583,25 +606,47 @@ extern "C" int a3d_scene_create(const int32_t* coords4_dev, int64_t n_voxels, vo
     const uint32_t cap = lv.hmask + 1;
     k_fill_u64<<<nblk(cap, T), T, 0, st>>>(lv.hkeys, cap, kEmptyKey);
     k_hash_insert<<<nblk(n, T), T, 0, st>>>(lv.keys, n, lv.hkeys, lv.hvals, lv.hmask);
-    k_nbr_morton<<<dim3(nblk(n, T), 27), T, 0, st>>>(lv.keys, n, npad, L, lv.hkeys, lv.hvals, lv.hmask, t.nbrM);
-    k_mask27<<<nblk(n, T), T, 0, st>>>(t.nbrM, n, npad, t.sortkey);
-    k_tile_sort<<<nblk(n, kSuperTile), kSuperTile, 0, st>>>(t.sortkey, n, lv.perm, lv.inv);
+    k_nbr_morton<<<dim3(nblk(n, T), 27), T, 0, st>>>(lv.keys, n, npad, L, lv.hkeys, lv.hvals, lv.hmask, t.nbrM[L]);
+    k_mask27<<<nblk(n, T), T, 0, st>>>(t.nbrM[L], n, npad, L, off[L], st_shift, t.cat_keys, t.cat_vals);
+    A3D_LAUNCH_CHECK();
+  }
+  // ---- stage B: ONE stable radix sort re-orders the rows of all levels inside their super tiles
+  {
+    int rc = sort_cat(A3D_NUM_LEVELS);
+    if (rc) { delete sc; return rc; }
+  }
+  // ---- stage C: tables in the new row order
+  for (int L = 0; L < A3D_NUM_LEVELS; ++L) {
+    Level& lv = sc->lv[L];
+    const int n = lv.n, npad = lv.npad;
+    const uint32_t cap = lv.hmask + 1;
+    k_perm_from_sorted<<<nblk(n, T), T, 0, st>>>(t.cat_vals_sorted, n, off[L], lv.perm, lv.inv);
     A3D_HIP_CHECK(hipMemsetAsync(lv.gmask27, 0, sizeof(uint32_t) * (npad / 16), st));
-    k_remap_nbr<<<dim3(nblk(npad, T), 27), T, 0, st>>>(t.nbrM, lv.perm, lv.inv, n, npad, lv.nbr27, lv.gmask27);
+    k_remap_nbr<<<dim3(nblk(npad, T), 27), T, 0, st>>>(t.nbrM[L], lv.perm, lv.inv, n, npad, lv.nbr27, lv.gmask27);
     k_tile_order<<<1, 1024, 0, st>>>(lv.gmask27, npad / 64, lv.order27);
     k_xyzb<<<nblk(n, T), T, 0, st>>>(lv.keys, lv.inv, n, L, lv.xyzb);
     k_hash_fix<<<nblk(cap, T), T, 0, st>>>(lv.hkeys, lv.hvals, cap, lv.perm);
     A3D_LAUNCH_CHECK();
   }
+  // ---- stage D: stride-2 tables + child-slot sort keys of the fine rows, levels 0..3
   for (int L = 0; L < A3D_NUM_LEVELS - 1; ++L) {
     Level& f = sc->lv[L];
     Level& c = sc->lv[L + 1];
     k_fill_i32<<<nblk((size_t)8 * c.npad, T), T, 0, st>>>(f.child8, (size_t)8 * c.npad, f.n);
     A3D_HIP_CHECK(hipMemsetAsync(f.gmask_down, 0, sizeof(uint32_t) * (c.npad / 16), st));
     k_child<<<nblk(f.n, T), T, 0, st>>>(f.keys, f.parentM, f.perm, c.perm, f.n, c.npad, f.child8, f.gmask_down);
-    k_slot_key<<<nblk(f.n, T), T, 0, st>>>(f.keys, f.inv, f.n, t.sortkey);
+    k_slot_key<<<nblk(f.n, T), T, 0, st>>>(f.keys, f.inv, f.n, L, off[L], st_shift, t.cat_keys, t.cat_vals);
+    A3D_LAUNCH_CHECK();
+  }
+  {
+    int rc = sort_cat(A3D_NUM_LEVELS - 1);
+    if (rc) { delete sc; return rc; }
+  }
+  for (int L = 0; L < A3D_NUM_LEVELS - 1; ++L) {
+    Level& f = sc->lv[L];
+    Level& c = sc->lv[L + 1];
     A3D_HIP_CHECK(hipMemsetAsync(f.up_rows, 0, sizeof(int) * f.npad, st));
-    k_tile_sort<<<nblk(f.n, kSuperTile), kSuperTile, 0, st>>>(t.sortkey, f.n, t.permU, f.up_rows);
+    k_perm_from_sorted<<<nblk(f.n, T), T, 0, st>>>(t.cat_vals_sorted, f.n, off[L], t.permU, f.up_rows);
     A3D_HIP_CHECK(hipMemsetAsync(f.gmask_up, 0, sizeof(uint32_t) * (f.npad / 16), st));
     k_up<<<nblk(f.npad, T), T, 0, st>>>(f.keys, f.inv, f.parentM, c.perm, f.up_rows, f.n, f.npad, c.n, f.up8, f.gmask_up);
     A3D_LAUNCH_CHECK();
