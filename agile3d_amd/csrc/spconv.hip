@@ -486,6 +486,14 @@ __global__ void __launch_bounds__(256, CH >= 64 ? 2 : 3) k_spconv2(const ConvArg
     if (tile >= a.n_tiles) break;
     const int r0 = (a.tile_order ? a.tile_order[tile] : tile) * kTile;
     const int myrow = r0 + 16 * wave + j;          // this lane's output row (and gather row of its group)
+    const bool tl = (a.dbg & 4096) && a.dbg_cycles && tid == 0 && tile < 8000;   // per-tile timeline (A3D_DBG=4096)
+    unsigned long long* rec = a.dbg_cycles + 16 + (size_t)tile * 8;
+    if (tl) {
+      rec[0] = __builtin_amdgcn_s_memtime();
+      rec[4] = __builtin_amdgcn_s_getreg(((32 - 1) << 11) | 4);      // HW_ID
+      rec[5] = __builtin_amdgcn_s_getreg(((4 - 1) << 11) | 20);      // XCC_ID
+      rec[6] = blockIdx.x;
+    }
     uint32_t un = 0xffffffffu, gm = 0xffffffffu;
     if (a.gmask) {
       const uint32_t* gp = a.gmask + (r0 >> 4);
@@ -556,6 +564,7 @@ __global__ void __launch_bounds__(256, CH >= 64 ? 2 : 3) k_spconv2(const ConvArg
     }
     wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();
+    if (tl) rec[1] = __builtin_amdgcn_s_memtime();
     while (k < 32) {
       f32x4 ac[NS];
       const bool present = (gm >> k) & 1u;
@@ -605,6 +614,7 @@ __global__ void __launch_bounds__(256, CH >= 64 ? 2 : 3) k_spconv2(const ConvArg
     }
 
     if constexpr (TR) {
+    if (tl) rec[2] = __builtin_amdgcn_s_memtime();
     // ---- epilogue: acc[ct] = output channels (ct0+ct)*16 + 4g .. +3 of row `myrow`
     if (a.partial) {
       float* P = a.partial + (size_t)blockIdx.z * ((size_t)a.n_tiles * kTile) * a.cout + (size_t)myrow * a.cout;
@@ -669,6 +679,10 @@ __global__ void __launch_bounds__(256, CH >= 64 ? 2 : 3) k_spconv2(const ConvArg
     }
     if (!a.partial && a.zero_row >= 0 && tile == 0 && tid < BN) a.out[(size_t)a.zero_row * a.ldo + ct0 * 16 + tid] = 0.f;
     __syncthreads();   // tile_slot / the idx table are rewritten for the next tile
+    if (tl) {
+      rec[3] = __builtin_amdgcn_s_memtime();
+      rec[7] = __builtin_popcount(un);
+    }
     lap(5);   // epilogue + end-of-tile barrier
   }
   if (timing && lane == 0) {
@@ -1033,7 +1047,13 @@ static ConvPlan plan_conv(int n_rows, int K, int cin, int cout) {
     p.lds = (size_t)2 * p.ch * bn * 4 + (size_t)p.kper * kConvTile * 4 + 16;
   }
   p.partial_floats = p.ksplit > 1 ? (size_t)p.ksplit * p.ntile * kConvTile * cout : 0;
-  const int max_resident = 256 * (int)(160 * 1024 / p.lds > 4 ? 4 : 160 * 1024 / p.lds);   // CUs x resident workgroups
+  int per_cu = (int)(160 * 1024 / p.lds > 4 ? 4 : 160 * 1024 / p.lds);
+  {
+    static int cap = -1;
+    if (cap < 0) { const char* e = getenv("A3D_CONV_WGS_PER_CU"); cap = e ? atoi(e) : 0; }   // experiment
+    if (cap > 0 && per_cu > cap) per_cu = cap;
+  }
+  const int max_resident = 256 * per_cu;   // CUs x resident workgroups
   int gx = max_resident / ((cout / bn) * p.ksplit);
   if (gx < 1) gx = 1;
   p.grid_x = p.ntile < gx ? p.ntile : gx;
@@ -1072,10 +1092,10 @@ static int launch_conv(ConvArgs a, float* partial_ws, size_t partial_ws_floats, 
     }
     a.dbg = dbg;
     a.dbg_cycles = nullptr;
-    if (dbg & (64 | 128)) {
+    if (dbg & (64 | 128 | 4096)) {
       static unsigned long long* buf = nullptr;
-      if (!buf) (void)hipMalloc(&buf, 64 + 8 * 64 * 6 * 8 + 128);
-      (void)hipMemsetAsync(buf, 0, 64 + 8 * 64 * 6 * 8 + 128, st);
+      if (!buf) (void)hipMalloc(&buf, (size_t)1 << 20);
+      (void)hipMemsetAsync(buf, 0, (size_t)1 << 20, st);
       a.dbg_cycles = buf;
     }
   }
@@ -1144,6 +1164,16 @@ static int launch_conv(ConvArgs a, float* partial_ws, size_t partial_ws_floats, 
       fprintf(stderr, "[trace wave %d] deltas:", w);
       for (int i = 1; i < 64 * 6 && t[i]; ++i) fprintf(stderr, " %llu", t[i] - t[i - 1]);
       fprintf(stderr, "\n");
+    }
+  }
+  if (a.dbg_cycles && (a.dbg & 4096)) {
+    static unsigned long long tl[8000 * 8 + 16];
+    (void)hipMemcpyAsync(tl, a.dbg_cycles, sizeof(tl), hipMemcpyDeviceToHost, st);
+    (void)hipStreamSynchronize(st);
+    for (int t = 0; t < p.ntile && t < 8000; ++t) {
+      const unsigned long long* r = tl + 16 + (size_t)t * 8;
+      fprintf(stderr, "TT %d wg %llu hwid %llu xcc %llu stages %llu t %llu %llu %llu %llu\n", t, r[6], r[4], r[5], r[7], r[0],
+              r[1], r[2], r[3]);
     }
   }
   if (a.dbg_cycles && (a.dbg & 64)) {

@@ -1,6 +1,7 @@
 // Calibration microbenchmark: fp32 MFMA issue rate on gfx950 (not part of the library).
 #include <hip/hip_runtime.h>
 #include <stdio.h>
+#include <stdlib.h>
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 template <int NACC, bool LDS>
@@ -63,7 +64,7 @@ template <int NCT>
 void run_stage(int blocks_per_cu) {
   float* out;
   hipMalloc(&out, 256 * 8 * 256 * 4);
-  const int iters = 4000, grid = 256 * blocks_per_cu;
+  const int iters = getenv("UB_ITERS") ? atoi(getenv("UB_ITERS")) : 4000, grid = 256 * blocks_per_cu;
   hipEvent_t e0, e1;
   hipEventCreate(&e0);
   hipEventCreate(&e1);
@@ -85,7 +86,7 @@ template <int NACC, bool LDS>
 void run(const char* name, int blocks_per_cu) {
   float* out;
   hipMalloc(&out, 256 * 8 * 256 * 4);
-  const int iters = 4000, grid = 256 * blocks_per_cu;
+  const int iters = getenv("UB_ITERS") ? atoi(getenv("UB_ITERS")) : 4000, grid = 256 * blocks_per_cu;
   hipEvent_t e0, e1;
   hipEventCreate(&e0);
   hipEventCreate(&e1);
