@@ -1,0 +1,100 @@
+"""Host mirror of the reference's ``models/criterion.py`` on the HIP library (first
+piece): same class name, constructor, ``forward(outputs, targets, weights)`` and loss-dict keys
+(``loss_bce``, ``loss_dice`` and their ``_<i>`` copies for ``aux_outputs``).  The backward pass of the network is
+not built yet; what is here is the loss values and ``grad_logits`` -- the gradient of the weighted total
+(engine.py:126-128) with respect to every prediction level's logits, i.e. what a backward pass would start from.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import lib as L
+
+
+def _losses_one(logits, target, weight, coef_bce, coef_dice, want_grad):
+    lib = L.load()
+    if not logits.is_cuda:
+        raise RuntimeError("agile3d_amd.criterion runs on the GPU only (no CPU fallback)")
+    z = logits.to(torch.float32).contiguous()
+    t = target.to(device=z.device, dtype=torch.int32).contiguous()
+    w = None if weight is None else weight.to(device=z.device, dtype=torch.float32).contiguous()
+    n, c = z.shape
+    out = torch.empty(2, dtype=torch.float32, device=z.device)
+    grad = torch.empty_like(z) if want_grad else None
+    ws = torch.empty(64, dtype=torch.uint8, device=z.device)
+    L.check(lib.a3d_mask_losses(z.data_ptr(), t.data_ptr(), w.data_ptr() if w is not None else None, n, c,
+                                float(coef_bce), float(coef_dice), out.data_ptr(),
+                                grad.data_ptr() if grad is not None else None, ws.data_ptr(), ws.numel(),
+                                C.c_void_p(torch.cuda.current_stream(z.device).cuda_stream)), "a3d_mask_losses")
+    return out, grad
+
+
+class SetCriterion:
+    """models/criterion.py:7-140.  ``losses`` is a subset of ('bce', 'dice')."""
+
+    def __init__(self, weight_dict, losses):
+        for l in losses:
+            if l not in ("bce", "dice"):
+                raise AssertionError(f"do you really want to compute {l} loss?")
+        self.weight_dict = weight_dict
+        self.losses = list(losses)
+        self.training = True
+
+    def train(self, mode=True):
+        self.training = mode
+        return self
+
+    def eval(self):
+        return self.train(False)
+
+    def _level(self, pred_masks, targets, weights, suffix, want_grad):
+        wb = self.weight_dict.get("loss_bce" + suffix, 0.0) if "bce" in self.losses else 0.0
+        wd = self.weight_dict.get("loss_dice" + suffix, 0.0) if "dice" in self.losses else 0.0
+        nb = len(pred_masks)
+        tot = torch.zeros(2, dtype=torch.float32, device=pred_masks[0].device)
+        grads = []
+        for i in range(nb):
+            out, g = _losses_one(pred_masks[i], targets[i], None if weights is None else weights[i], wb / nb, wd / nb,
+                                 want_grad)
+            tot = tot + out
+            grads.append(g)
+        tot = tot / nb
+        d = {}
+        if "bce" in self.losses:
+            d["loss_bce" + suffix] = tot[0]
+        if "dice" in self.losses:
+            d["loss_dice" + suffix] = tot[1]
+        return d, grads
+
+    def __call__(self, outputs, targets, weights=None):
+        return self.forward(outputs, targets, weights)
+
+    def forward(self, outputs, targets, weights=None):
+        losses, _ = self._level(outputs["pred_masks"], targets, weights, "", False)
+        for i, aux in enumerate(outputs.get("aux_outputs", [])):
+            d, _ = self._level(aux["pred_masks"], targets, weights, f"_{i}", False)
+            losses.update(d)
+        return losses
+
+    def grad_logits(self, outputs, targets, weights=None):
+        """{'pred_masks': [grad per sample], 'aux_outputs': [[grad per sample] per level]}: gradient of
+        sum_k weight_dict[k] * loss_dict[k] (engine.py:128) w.r.t. the logits of every level."""
+        _, g = self._level(outputs["pred_masks"], targets, weights, "", True)
+        res = {"pred_masks": g, "aux_outputs": []}
+        for i, aux in enumerate(outputs.get("aux_outputs", [])):
+            _, ga = self._level(aux["pred_masks"], targets, weights, f"_{i}", True)
+            res["aux_outputs"].append(ga)
+        return res
+
+
+def build_mask_criterion(args):
+    """models/criterion.py:142-155."""
+    weight_dict = {"loss_bce": args.bce_loss_coef, "loss_dice": args.dice_loss_coef}
+    if args.aux:
+        aux = {}
+        for i in range(args.num_decoders * len(args.hlevels)):
+            aux.update({k + f"_{i}": v for k, v in weight_dict.items()})
+        weight_dict.update(aux)
+    return SetCriterion(weight_dict, args.losses)

@@ -104,6 +104,8 @@ SYMBOLS = {
     "a3d_click_workspace_bytes": (C.c_size_t, [C.c_int64]),
     "a3d_click_clusters": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int,
                                      C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "a3d_mask_losses": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_float, C.c_float,
+                                  C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "a3d_quantize_workspace_bytes": (C.c_size_t, [C.c_int64]),
     "a3d_sparse_quantize": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p,
                                       C.POINTER(C.c_int64), C.c_void_p, C.c_size_t, C.c_void_p]),

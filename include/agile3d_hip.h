@@ -268,6 +268,20 @@ int    a3d_click_loss_weights(const float* xyz_dev, int64_t n, const int32_t* cl
                               float tita, float alpha, float beta, float* weights_dev, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Mask losses (first piece of SURVEY.md section 8 row f-2).
+ * Replaces: SetCriterion.loss_bce / loss_dice (models/criterion.py:14-110) for ONE sample and ONE
+ * prediction level: losses_dev[0] = mean_i w_i * CE(logits_i, target_i), losses_dev[1] = mean_i w_i *
+ * dice_i (per-point soft IoU of softmax(logits_i) against the one-hot target, eps = 1e-6; NaN in both if
+ * a target is outside 0..n_classes-1).  grad_logits_dev (optional, [n][n_classes]) receives
+ * d(coef_bce * losses[0] + coef_dice * losses[1]) / d logits.  weights_dev NULL = all ones;
+ * workspace: 64 bytes.
+ * ------------------------------------------------------------------------------------------ */
+int    a3d_mask_losses(const float* logits_dev, const int32_t* target_dev, const float* weights_dev,
+                       int64_t n, int n_classes, float coef_bce, float coef_dice,
+                       float* losses_dev, float* grad_logits_dev,
+                       void* workspace_dev, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * On-device voxelisation.
  * Replaces: ME.utils.sparse_quantize(coordinates, quantization_size, return_index=True,
  * return_inverse=True) (datasets/InterMultiObj3DSegDataset.py:67-75): q = int32(floor(xyz / size)) in
