@@ -199,6 +199,148 @@ __global__ void __launch_bounds__(512) k_c2s_attn(const float* __restrict__ Kc, 
   }
 }
 
+
+// ---- K/V projections fused into the click-to-scene attention (<= 32 queries) ------------------------------
+// K = (src + pos) Wk^T + bk and V = src Wv^T + bv are produced per 16-point group straight into the MFMA
+// operand layouts the attention consumes and never reach HBM: the transposed product (weights as the A
+// operand) leaves K[point j][16h+4g..+3] in lane (g, j) = the A fragment of S = K_h q_h^T; the plain product
+// leaves V[point 4g+t][16h+j] = the A fragment of O^T += V_h^T P.  Both packed weight matrices (2 x 64 KB)
+// sit in LDS for the life of a persistent 8-wave workgroup; a wave walks its own sequence of 16-point groups,
+// head by head (one 16-column slice of each GEMM at a time), and keeps the flash state of all 8 heads in
+// registers.  Saves writing and re-reading K and V (4 x 41 MB per decoder iteration at 80 k points).
+template <int QT>
+__global__ void __launch_bounds__(512) k_kv_c2s(const float* __restrict__ X, const float* __restrict__ Pe, int n,
+                                                const float* __restrict__ Wk, const float* __restrict__ Wv,
+                                                const float* __restrict__ bk, const float* __restrict__ bv,
+                                                const float* qproj, const int* qobj, const unsigned char* labels,
+                                                const int* counts, float* part, int qp_total, int ngroups) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  f32x4* Wkl = (f32x4*)smem;              // [8 S][8 ct][64 lanes]
+  f32x4* Wvl = Wkl + 8 * 8 * 64;
+  {
+    constexpr int TOT = 2 * 8 * 8 * 64;
+    for (int base = threadIdx.x; base < TOT; base += 8 * 512) {
+      f32x4 t8[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int e = base + u * 512;
+        if (e < TOT) t8[u] = e < TOT / 2 ? ((const f32x4*)Wk)[e] : ((const f32x4*)Wv)[e - TOT / 2];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (base + u * 512 < TOT) Wkl[base + u * 512] = t8[u];
+    }
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int g = lane >> 4, j = lane & 15;
+  int obj[QT];
+  bool qmask[QT];
+#pragma unroll
+  for (int qt = 0; qt < QT; ++qt) {
+    obj[qt] = qobj[qt * 16 + j];
+    qmask[qt] = labels != nullptr && obj[qt] >= 0 && counts[obj[qt]] > 0;
+  }
+  // two waves share a sequence of point groups: wave 2s takes heads 0..3 of it, wave 2s+1 heads 4..7 (the flash
+  // state of 8 heads does not fit the register file next to the activation fragments)
+  constexpr int HW = H / 2;
+  const int h0 = (wave & 1) * HW;
+  float m[HW][QT], l[HW][QT];
+  f32x4 acc[HW][QT];
+#pragma unroll
+  for (int hl = 0; hl < HW; ++hl)
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) {
+      m[hl][qt] = kNegBig;
+      l[hl][qt] = 0.f;
+      acc[hl][qt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+  const int slot = blockIdx.x * 4 + (wave >> 1), nslots = gridDim.x * 4;
+  for (int grp = slot; grp < ngroups; grp += nslots) {
+    const int p0 = grp * 16;
+    const int row = min(p0 + j, n - 1);
+    f32x4 xs[8], xp[8];
+    {
+      const float* xr = X + (size_t)row * D + 4 * g;
+      const float* pr = Pe + (size_t)row * D + 4 * g;
+#pragma unroll
+      for (int S = 0; S < 8; ++S) xs[S] = *(const f32x4*)(xr + 16 * S);
+#pragma unroll
+      for (int S = 0; S < 8; ++S) xp[S] = xs[S] + *(const f32x4*)(pr + 16 * S);
+    }
+    const unsigned lab4 = labels ? *(const unsigned*)(labels + p0 + 4 * g) : 0u;
+#pragma unroll
+    for (int hl = 0; hl < HW; ++hl) {
+      const int h = h0 + hl;
+      f32x4 kf = *(const f32x4*)(bk + 16 * h + 4 * g);      // K^T slice: channels 16h+4g..+3 of point j
+      const float bvj = bv[16 * h + j];
+      f32x4 vv = (f32x4){bvj, bvj, bvj, bvj};               // V slice: channel 16h+j of points 4g..4g+3
+#pragma unroll
+      for (int S = 0; S < 8; ++S) {
+        const f32x4 wk = Wkl[(S * 8 + h) * 64 + lane], wv = Wvl[(S * 8 + h) * 64 + lane];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          kf = __builtin_amdgcn_mfma_f32_16x16x4f32(wk[t], xp[S][t], kf, 0, 0, 0);
+          vv = __builtin_amdgcn_mfma_f32_16x16x4f32(xs[S][t], wv[t], vv, 0, 0, 0);
+        }
+        if (S & 1) asm volatile("" ::: "memory");   // at most two k-steps of weight fragments in registers
+      }
+#pragma unroll
+      for (int qt = 0; qt < QT; ++qt) {
+        const f32x4 qf = *(const f32x4*)(qproj + (size_t)(qt * 16 + j) * D + h * DH + 4 * g);
+        f32x4 sc4 = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < 4; ++t) sc4 = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[t], qf[t], sc4, 0, 0, 0);
+        float mx = kNegBig;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const int pr = p0 + 4 * g + t;
+          const int lab = (int)((lab4 >> (8 * t)) & 0xffu);
+          const bool blocked = pr >= n || (qmask[qt] && lab != obj[qt]);
+          sc4[t] = blocked ? kNegBig : sc4[t];
+          mx = fmaxf(mx, sc4[t]);
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float mnew = fmaxf(m[hl][qt], mx);
+        const float scl = expf(m[hl][qt] - mnew);
+        m[hl][qt] = mnew;
+        f32x4 pw;
+        float ps = 0.f;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          pw[t] = expf(sc4[t] - mnew);
+          ps += pw[t];
+        }
+        l[hl][qt] = l[hl][qt] * scl + ps;
+        acc[hl][qt] *= scl;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[hl][qt] = __builtin_amdgcn_mfma_f32_16x16x4f32(vv[t], pw[t], acc[hl][qt], 0, 0, 0);
+      }
+    }
+  }
+  // one flash partial (m, l, acc[16]) per wave slot, head and query -- merged by k_c2s_combine
+#pragma unroll
+  for (int hl = 0; hl < HW; ++hl) {
+    const int h = h0 + hl;
+    float* P = part + ((size_t)slot * H + h) * qp_total * kPartStride;
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) {
+      float lt = l[hl][qt];
+      lt += __shfl_xor(lt, 16, 64);
+      lt += __shfl_xor(lt, 32, 64);
+      float* pq = P + (size_t)(qt * 16 + j) * kPartStride;
+      if (g == 0) {
+        pq[0] = m[hl][qt];
+        pq[1] = lt;
+      }
+#pragma unroll
+      for (int t = 0; t < 4; ++t) pq[2 + 4 * g + t] = acc[hl][qt][t];
+    }
+  }
+}
+constexpr int kFusedC2SGrid = 256;   // one persistent 8-wave workgroup per CU (128 KB of weights in LDS)
+
 // merge the per-chunk flash partials (m, l, acc[16]) of one (query, head): one wave per pair
 __global__ void __launch_bounds__(64) k_c2s_combine(const float* __restrict__ part, int nchunk, float* attn, int QP) {
   const int q = blockIdx.x / H, h = blockIdx.x % H, lane = threadIdx.x;
@@ -953,7 +1095,7 @@ void dec_layout(int64_t n, int nq, DecLayout& L) {
   for (int i = 0; i < 4; ++i) L.buf[i] = take((size_t)n * D * 4);
   L.labels = take((size_t)n + 64);
   L.counts = take((size_t)A3D_MAX_DEC_LAYERS * (A3D_MAX_QUERIES + 1) * 4);
-  L.part = take((size_t)L.nchunk * H * L.qp * kPartStride * 4);
+  L.part = take((size_t)(L.nchunk > kFusedC2SGrid * 8 ? L.nchunk : kFusedC2SGrid * 8) * H * L.qp * kPartStride * 4);
   L.meta = take(sizeof(QueryMeta));
   const size_t qb = (size_t)L.qp * D * 4;
   for (int i = 0; i < 9; ++i) L.q[i] = take(qb);        // queries qpos qproj ks vs E attn tmp tgt
@@ -969,6 +1111,15 @@ extern "C" size_t a3d_decoder_workspace_bytes(int64_t n, int n_queries) {
   DecLayout L;
   dec_layout(n, n_queries, L);
   return L.total + 256;
+}
+
+static bool fused_c2s() {   // A3D_FUSED_C2S=0 keeps the separate K / V GEMMs + k_c2s_attn (A/B switch)
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("A3D_FUSED_C2S");
+    v = e ? atoi(e) : 1;
+  }
+  return v != 0;
 }
 
 template <int QT>
@@ -1011,6 +1162,8 @@ static int run_decoder(const a3d_decoder_weights* w, const float* feats128, cons
       (void)hipFuncSetAttribute((const void*)k_query_layer<4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, big_lds);
       (void)hipFuncSetAttribute((const void*)k_s2c_attn_wide<4>, hipFuncAttributeMaxDynamicSharedMemorySize, big_lds);
       (void)hipFuncSetAttribute((const void*)k_s2c_attn<4>, hipFuncAttributeMaxDynamicSharedMemorySize, big_lds);
+      (void)hipFuncSetAttribute((const void*)k_kv_c2s<1>, hipFuncAttributeMaxDynamicSharedMemorySize, big_lds);
+      (void)hipFuncSetAttribute((const void*)k_kv_c2s<2>, hipFuncAttributeMaxDynamicSharedMemorySize, big_lds);
       (void)hipFuncSetAttribute((const void*)k_ln_mask<4>, hipFuncAttributeMaxDynamicSharedMemorySize, big_lds);
     }
   }
@@ -1032,18 +1185,29 @@ static int run_decoder(const a3d_decoder_weights* w, const float* feats128, cons
   for (int l = 0; l < w->n_layers; ++l) {
     const a3d_decoder_layer& LW = w->layers[l];
     int rc;
-    // ---- click-to-scene: K = (src + pos) Wk^T + bk, V = src Wv^T + bv   (attention_block.py:88-94)
-    rc = a3d_linear(src, D, posenc, D, n, D, D, LW.c2s_wk_packed, nullptr, LW.c2s_in_b + D, nullptr, 0, 0, bufA, D, nullptr, 0, st);
-    if (rc) return rc;
-    rc = a3d_linear(src, D, nullptr, 0, n, D, D, LW.c2s_wv_packed, nullptr, LW.c2s_in_b + 2 * D, nullptr, 0, 0, bufB, D, nullptr, 0, st);
-    if (rc) return rc;
     const int* prev_counts = l > 0 ? counts + (size_t)(l - 1) * (A3D_MAX_QUERIES + 1) : nullptr;
-    {
-    ProfScope ps(st, A3D_PROF_C2S, 0, 0, 0, 0, n);
-    k_c2s_attn<QT><<<dim3(L.nchunk, nblk), 512, 0, st>>>(bufA, bufB, n, B.qproj, meta->obj,
-                                                          l > 0 ? labels : nullptr, prev_counts, part, L.qp);
+    int n_part = L.nchunk;
+    if (QT <= 2 && fused_c2s()) {
+      // ---- click-to-scene with the K / V projections fused in (K, V never reach HBM)
+      const int ngroups = (n + 15) / 16;
+      const int grid = (ngroups + 3) / 4 < kFusedC2SGrid ? (ngroups + 3) / 4 : kFusedC2SGrid;
+      n_part = grid * 4;
+      ProfScope ps(st, A3D_PROF_C2S, 0, 0, 0, 0, n);
+      k_kv_c2s<(QT <= 2 ? QT : 1)><<<grid, 512, 128 * 1024, st>>>(src, posenc, n, LW.c2s_wk_packed, LW.c2s_wv_packed,
+                                                             LW.c2s_in_b + D, LW.c2s_in_b + 2 * D, B.qproj, meta->obj,
+                                                             l > 0 ? labels : nullptr, prev_counts, part, L.qp, ngroups);
+      A3D_LAUNCH_CHECK();
+    } else {
+      // ---- click-to-scene: K = (src + pos) Wk^T + bk, V = src Wv^T + bv   (attention_block.py:88-94)
+      rc = a3d_linear(src, D, posenc, D, n, D, D, LW.c2s_wk_packed, nullptr, LW.c2s_in_b + D, nullptr, 0, 0, bufA, D, nullptr, 0, st);
+      if (rc) return rc;
+      rc = a3d_linear(src, D, nullptr, 0, n, D, D, LW.c2s_wv_packed, nullptr, LW.c2s_in_b + 2 * D, nullptr, 0, 0, bufB, D, nullptr, 0, st);
+      if (rc) return rc;
+      ProfScope ps(st, A3D_PROF_C2S, 0, 0, 0, 0, n);
+      k_c2s_attn<QT><<<dim3(L.nchunk, nblk), 512, 0, st>>>(bufA, bufB, n, B.qproj, meta->obj,
+                                                            l > 0 ? labels : nullptr, prev_counts, part, L.qp);
+      A3D_LAUNCH_CHECK();
     }
-    A3D_LAUNCH_CHECK();
     QueryLayerW QW;
     QW.c2s_in_wt = LW.c2s_in_w; QW.c2s_in_b = LW.c2s_in_b; QW.c2s_out_wt = LW.c2s_out_w; QW.c2s_out_b = LW.c2s_out_b;
     QW.c2s_norm_w = LW.c2s_norm_w; QW.c2s_norm_b = LW.c2s_norm_b;
@@ -1059,7 +1223,7 @@ static int run_decoder(const a3d_decoder_weights* w, const float* feats128, cons
     QW.dim_ff = w->dim_ff;
     {
     ProfScope ps(st, A3D_PROF_QUERY, 0, 0, 0, 0, nq);
-    k_c2s_combine<<<nq * H, 64, 0, st>>>(part, L.nchunk, B.attn, L.qp);
+    k_c2s_combine<<<nq * H, 64, 0, st>>>(part, n_part, B.attn, L.qp);
     const size_t ql_lds = (size_t)4 * QP * kQLD * 4;
     if (nblk == 1) {
       k_query_layer<QT, 0><<<1, 512, ql_lds, st>>>(meta, QW, B);
