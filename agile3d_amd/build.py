@@ -12,16 +12,32 @@ LIB = os.path.join(HERE, "libagile3d_hip.so")
 SOURCES = ["scene.hip", "spconv.hip", "decoder.hip", "clicks.hip", "quantize.hip", "criterion.hip"]
 
 
-def _newest(paths):
-    return max(os.path.getmtime(p) for p in paths)
+STAMP = LIB + ".stamp"
+
+
+def _sources_digest():
+    """sha256 over the kernel sources, the ABI header and the compiler flags -- NOT modification times: the
+    snapshot that carries the prebuilt library to the GPU box does not preserve them, and an unnecessary rebuild
+    there would land inside the driver's timing of the first command that imports the package."""
+    import hashlib
+    h = hashlib.sha256()
+    paths = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h")))
+    paths.append(os.path.join(os.path.dirname(HERE), "include", "agile3d_hip.h"))
+    paths.append(os.path.abspath(__file__))
+    for p in paths:
+        h.update(os.path.basename(p).encode())
+        with open(p, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
 
 
 def needs_build():
-    if not os.path.exists(LIB):
+    if not os.path.exists(LIB) or not os.path.exists(STAMP):
         return True
-    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)]
-    deps.append(os.path.join(os.path.dirname(HERE), "include", "agile3d_hip.h"))
-    return _newest(deps) > os.path.getmtime(LIB)
+    try:
+        return open(STAMP).read().strip() != _sources_digest()
+    except OSError:
+        return True
 
 
 def build(force: bool = False, verbose: bool = True):
@@ -55,6 +71,8 @@ def build(force: bool = False, verbose: bool = True):
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
+    with open(STAMP, "w") as f:
+        f.write(_sources_digest() + "\n")
     return LIB
 
 
