@@ -634,6 +634,150 @@ __global__ void __launch_bounds__(256) k_ln_mask(float* Y, int n, const float* _
     if (hist[e]) atomicAdd(&counts[e], hist[e]);
 }
 
+
+// ---- scene-to-click output projection fused with the residual, LayerNorm and the mask head (<= 64 queries) -----
+// Y = LayerNorm(O Wo^T + bo + src) and everything k_ln_mask does with it, per 16-point group, straight from the
+// transposed MFMA accumulators (lane (g, j) holds channels 16ct+4g..+3 of point j = the layout the LayerNorm and
+// the logits MFMA want): the pre-norm activation never reaches HBM.  Persistent 8-wave workgroups keep the packed
+// Wo (64 KB) and the mask embeddings E in LDS; waves walk their own sequences of groups (wave-private LDS scratch,
+// no workgroup barrier inside the loop) with the next group's fragments in flight behind the current MFMAs.
+template <int QT>
+__global__ void __launch_bounds__(512) k_out_ln_mask(const float* __restrict__ O, const float* __restrict__ Xres, int n,
+                                                     const float* __restrict__ Wo, const float* __restrict__ bo,
+                                                     const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                     const float* E, int nq, const int* qrange, int n_fg, int K,
+                                                     float* __restrict__ Y, float* logits, unsigned char* labels,
+                                                     int* counts, int ngroups) {
+  constexpr int QP = QT * 16, LD = 132, LL = QP + 1, NW = 8;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  f32x4* Wl = (f32x4*)smem;                       // [8 S][8 ct][64]
+  float* E_l = (float*)(Wl + 8 * 8 * 64);         // [QP][132]
+  float* L_l = E_l + QP * LD;                     // [NW][16][LL]
+  float* O_l = L_l + NW * 16 * LL;                // [NW][16][K+1]
+  int* hist = (int*)(O_l + NW * 16 * (K + 1));    // [K+1]
+  {
+    constexpr int TOT = 8 * 8 * 64;
+    for (int base = threadIdx.x; base < TOT; base += 8 * 512) {
+      f32x4 t8[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (base + u * 512 < TOT) t8[u] = ((const f32x4*)Wo)[base + u * 512];
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (base + u * 512 < TOT) Wl[base + u * 512] = t8[u];
+    }
+  }
+  for (int e = threadIdx.x; e < QP * 32; e += 512) {
+    const int r = e >> 5, c4 = (e & 31) * 4;
+    *(f32x4*)(E_l + r * LD + c4) = *(const f32x4*)(E + (size_t)r * D + c4);
+  }
+  for (int e = threadIdx.x; e <= K; e += 512) hist[e] = 0;
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int g = lane >> 4, j = lane & 15;
+  float* Lw = L_l + wave * 16 * LL;
+  float* Ow = O_l + wave * 16 * (K + 1);
+  const int stride = gridDim.x * NW;
+  int grp = blockIdx.x * NW + wave;
+  f32x4 nx[8];
+  auto fetch = [&](int gq) {
+    const float* orow = O + (size_t)min(gq * 16 + j, n - 1) * D + 4 * g;
+#pragma unroll
+    for (int S = 0; S < 8; ++S) nx[S] = *(const f32x4*)(orow + 16 * S);
+  };
+  if (grp < ngroups) fetch(grp);
+  while (grp < ngroups) {
+    const int p0 = grp * 16;
+    const int prow = min(p0 + j, n - 1);
+    f32x4 a[8];
+#pragma unroll
+    for (int S = 0; S < 8; ++S) a[S] = nx[S];
+    const int next = grp + stride;
+    if (next < ngroups) fetch(next);
+    f32x4 y[8];   // y[ct] = channels 16ct+4g..+3 of point j
+#pragma unroll
+    for (int ct = 0; ct < 8; ++ct) y[ct] = *(const f32x4*)(bo + 16 * ct + 4 * g) + *(const f32x4*)(Xres + (size_t)prow * D + 16 * ct + 4 * g);
+#pragma unroll
+    for (int S = 0; S < 8; ++S) {
+#pragma unroll
+      for (int ct = 0; ct < 8; ++ct) {
+        const f32x4 w = Wl[(S * 8 + ct) * 64 + lane];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) y[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[t], a[S][t], y[ct], 0, 0, 0);
+      }
+      asm volatile("" ::: "memory");
+    }
+    // LayerNorm over the 128 channels of point j (4 g-lanes x 8 ct x 4)
+    float sum = 0.f;
+#pragma unroll
+    for (int ct = 0; ct < 8; ++ct) sum += y[ct][0] + y[ct][1] + y[ct][2] + y[ct][3];
+    sum += __shfl_xor(sum, 16, 64);
+    sum += __shfl_xor(sum, 32, 64);
+    const float mean = sum * (1.f / D);
+    float var = 0.f;
+#pragma unroll
+    for (int ct = 0; ct < 8; ++ct)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const float d = y[ct][t] - mean;
+        var += d * d;
+      }
+    var += __shfl_xor(var, 16, 64);
+    var += __shfl_xor(var, 32, 64);
+    const float rstd = rsqrtf(var * (1.f / D) + kLnEps);
+    float* yrow = Y + (size_t)prow * D;
+#pragma unroll
+    for (int ct = 0; ct < 8; ++ct) {
+      const f32x4 ga = *(const f32x4*)(gamma + 16 * ct + 4 * g);
+      const f32x4 be = *(const f32x4*)(beta + 16 * ct + 4 * g);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) y[ct][t] = (y[ct][t] - mean) * rstd * ga[t] + be[t];
+      if (p0 + j < n) *(f32x4*)(yrow + 16 * ct + 4 * g) = y[ct];
+    }
+    // logits of the 16 points against every query (C layout: row = point 4g+t, column = query j)
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) {
+      f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int S = 0; S < 8; ++S) {
+        const f32x4 ef = *(const f32x4*)(E_l + (qt * 16 + j) * LD + 16 * S + 4 * g);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(y[S][t], ef[t], acc, 0, 0, 0);
+      }
+#pragma unroll
+      for (int t = 0; t < 4; ++t) Lw[(4 * g + t) * LL + qt * 16 + j] = acc[t];
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // wave-private scratch: written above, read below by other lanes
+    for (int o = g; o <= K; o += 4) {
+      const int qb = o == 0 ? n_fg : qrange[o], qe = o == 0 ? nq : qrange[o + 1];
+      float mxv = -3.4e38f;
+      for (int q = qb; q < qe; ++q) mxv = fmaxf(mxv, Lw[j * LL + q]);
+      Ow[j * (K + 1) + o] = mxv;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (lane < 16 && p0 + lane < n) {
+      float best = Ow[lane * (K + 1)];
+      int bi = 0;
+      for (int o = 1; o <= K; ++o) {
+        const float v = Ow[lane * (K + 1) + o];
+        if (v > best) {
+          best = v;
+          bi = o;
+        }
+      }
+      labels[p0 + lane] = (unsigned char)bi;
+      atomicAdd(&hist[bi], 1);
+    }
+    const int rows = min(16, n - p0);
+    for (int e = lane; e < rows * (K + 1); e += 64) logits[(size_t)p0 * (K + 1) + e] = Ow[e];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // scratch is rewritten by the next group
+    grp = next;
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e <= K; e += 512)
+    if (hist[e]) atomicAdd(&counts[e], hist[e]);
+}
+
 // ------------------------------------------------------------------------------ query side
 struct QueryMeta {   // device-resident, uploaded once per forward_mask
   int n_fg, n_bg_click, n_bgl, nq, K;
@@ -1162,6 +1306,10 @@ static int run_decoder(const a3d_decoder_weights* w, const float* feats128, cons
       (void)hipFuncSetAttribute((const void*)k_query_layer<4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, big_lds);
       (void)hipFuncSetAttribute((const void*)k_s2c_attn_wide<4>, hipFuncAttributeMaxDynamicSharedMemorySize, big_lds);
       (void)hipFuncSetAttribute((const void*)k_s2c_attn<4>, hipFuncAttributeMaxDynamicSharedMemorySize, big_lds);
+      (void)hipFuncSetAttribute((const void*)k_out_ln_mask<1>, hipFuncAttributeMaxDynamicSharedMemorySize, big_lds);
+      (void)hipFuncSetAttribute((const void*)k_out_ln_mask<2>, hipFuncAttributeMaxDynamicSharedMemorySize, big_lds);
+      (void)hipFuncSetAttribute((const void*)k_out_ln_mask<3>, hipFuncAttributeMaxDynamicSharedMemorySize, big_lds);
+      (void)hipFuncSetAttribute((const void*)k_out_ln_mask<4>, hipFuncAttributeMaxDynamicSharedMemorySize, big_lds);
       (void)hipFuncSetAttribute((const void*)k_kv_c2s<1>, hipFuncAttributeMaxDynamicSharedMemorySize, big_lds);
       (void)hipFuncSetAttribute((const void*)k_kv_c2s<2>, hipFuncAttributeMaxDynamicSharedMemorySize, big_lds);
       (void)hipFuncSetAttribute((const void*)k_ln_mask<4>, hipFuncAttributeMaxDynamicSharedMemorySize, big_lds);
@@ -1245,15 +1393,26 @@ static int run_decoder(const a3d_decoder_weights* w, const float* feats128, cons
     }
     A3D_LAUNCH_CHECK();
     float* Y = (l & 1) ? bufD : bufC;
-    rc = a3d_linear(bufB, D, nullptr, 0, n, D, D, LW.s2c_wo_packed, nullptr, LW.s2c_out_b, src, D, 0, Y, D, nullptr, 0, st);
-    if (rc) return rc;
-    {
-    ProfScope ps(st, A3D_PROF_LNMASK, 0, 0, 0, 0, n);
-    k_ln_mask<QT><<<(n + 63) / 64, 256, lnm_lds, st>>>(Y, n, LW.s2c_norm_w, LW.s2c_norm_b, B.E, nq, meta->qrange,
-                                                      hm.n_fg, K, logits + (size_t)l * n * (K + 1), labels,
-                                                      counts + (size_t)l * (A3D_MAX_QUERIES + 1), nblk);
+    const size_t fused_lds = (size_t)64 * 1024 + ((size_t)QP * 132 + 8 * 16 * (QP + 1) + 8 * 16 * (K + 1)) * 4 + (size_t)(K + 1) * 4;
+    if (nblk == 1 && fused_c2s() && fused_lds <= 160 * 1024) {
+      // ---- output projection + residual + LayerNorm + mask head in one pass (the pre-norm activation stays on chip)
+      const int ngroups = (n + 15) / 16;
+      const int grid = (ngroups + 7) / 8 < 256 ? (ngroups + 7) / 8 : 256;
+      ProfScope ps(st, A3D_PROF_LNMASK, 0, 0, 0, 0, n);
+      k_out_ln_mask<QT><<<grid, 512, fused_lds, st>>>(bufB, src, n, LW.s2c_wo_packed, LW.s2c_out_b, LW.s2c_norm_w,
+                                                      LW.s2c_norm_b, B.E, nq, meta->qrange, hm.n_fg, K, Y,
+                                                      logits + (size_t)l * n * (K + 1), labels,
+                                                      counts + (size_t)l * (A3D_MAX_QUERIES + 1), ngroups);
+      A3D_LAUNCH_CHECK();
+    } else {
+      rc = a3d_linear(bufB, D, nullptr, 0, n, D, D, LW.s2c_wo_packed, nullptr, LW.s2c_out_b, src, D, 0, Y, D, nullptr, 0, st);
+      if (rc) return rc;
+      ProfScope ps(st, A3D_PROF_LNMASK, 0, 0, 0, 0, n);
+      k_ln_mask<QT><<<(n + 63) / 64, 256, lnm_lds, st>>>(Y, n, LW.s2c_norm_w, LW.s2c_norm_b, B.E, nq, meta->qrange,
+                                                        hm.n_fg, K, logits + (size_t)l * n * (K + 1), labels,
+                                                        counts + (size_t)l * (A3D_MAX_QUERIES + 1), nblk);
+      A3D_LAUNCH_CHECK();
     }
-    A3D_LAUNCH_CHECK();
     src = Y;
   }
   return A3D_OK;
