@@ -635,6 +635,113 @@ __global__ void __launch_bounds__(256) k_ln_mask(float* Y, int n, const float* _
 }
 
 
+
+// ---- scene-to-click query projection fused into the attention (<= 64 queries) ---------------------------------
+// Q = (src + pos) Wq^T + bq per 16-point group, head by head, in the transposed accumulator layout = the B fragment
+// of S^T = ks_h Q_h^T; softmax over the (few) queries in registers; O^T = vs_h^T P.  Q never reaches HBM.
+// Persistent 8-wave workgroups: packed Wq (64 KB) + the queries' keys / values in LDS.
+template <int QT>
+__global__ void __launch_bounds__(512) k_q_s2c(const float* __restrict__ X, const float* __restrict__ Pe, int n,
+                                               const float* __restrict__ Wq, const float* __restrict__ bq,
+                                               const float* ks, const float* vs, int nq, float* __restrict__ O,
+                                               int ngroups) {
+  constexpr int QP = QT * 16, LD = 132, NW = 8;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  f32x4* Wl = (f32x4*)smem;                       // [8 S][8 ct][64]
+  float* ks_l = (float*)(Wl + 8 * 8 * 64);        // [QP][132]
+  float* vs_l = ks_l + QP * LD;
+  {
+    constexpr int TOT = 8 * 8 * 64;
+    for (int base = threadIdx.x; base < TOT; base += 8 * 512) {
+      f32x4 t8[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (base + u * 512 < TOT) t8[u] = ((const f32x4*)Wq)[base + u * 512];
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (base + u * 512 < TOT) Wl[base + u * 512] = t8[u];
+    }
+  }
+  for (int e = threadIdx.x; e < QP * 32; e += 512) {
+    const int r = e >> 5, c4 = (e & 31) * 4;
+    *(f32x4*)(ks_l + r * LD + c4) = *(const f32x4*)(ks + (size_t)r * D + c4);
+    *(f32x4*)(vs_l + r * LD + c4) = *(const f32x4*)(vs + (size_t)r * D + c4);
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int g = lane >> 4, j = lane & 15;
+  const int stride = gridDim.x * NW;
+  int grp = blockIdx.x * NW + wave;
+  f32x4 nx[8], np[8];
+  auto fetch = [&](int gq) {
+    const size_t row = (size_t)min(gq * 16 + j, n - 1);
+    const float* xr = X + row * D + 4 * g;
+    const float* pr = Pe + row * D + 4 * g;
+#pragma unroll
+    for (int S = 0; S < 8; ++S) nx[S] = *(const f32x4*)(xr + 16 * S);
+#pragma unroll
+    for (int S = 0; S < 8; ++S) np[S] = *(const f32x4*)(pr + 16 * S);
+  };
+  if (grp < ngroups) fetch(grp);
+  while (grp < ngroups) {
+    const int p0 = grp * 16;
+    const int prow = min(p0 + j, n - 1);
+    f32x4 xp[8];
+#pragma unroll
+    for (int S = 0; S < 8; ++S) xp[S] = nx[S] + np[S];
+    const int next = grp + stride;
+    if (next < ngroups) fetch(next);
+    float* orow = O + (size_t)prow * D;
+#pragma unroll 2
+    for (int h = 0; h < H; ++h) {
+      f32x4 qf = *(const f32x4*)(bq + 16 * h + 4 * g);     // Q[point j][16h+4g..+3]
+#pragma unroll
+      for (int S = 0; S < 8; ++S) {
+        const f32x4 w = Wl[(S * 8 + h) * 64 + lane];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) qf = __builtin_amdgcn_mfma_f32_16x16x4f32(w[t], xp[S][t], qf, 0, 0, 0);
+      }
+      f32x4 sc[QT];
+      float mx = kNegBig;
+#pragma unroll
+      for (int kt = 0; kt < QT; ++kt) {
+        const f32x4 kf = *(const f32x4*)(ks_l + (kt * 16 + j) * LD + h * DH + 4 * g);
+        sc[kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < 4; ++t) sc[kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[t], qf[t], sc[kt], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          if (kt * 16 + 4 * g + t >= nq) sc[kt][t] = kNegBig;
+          mx = fmaxf(mx, sc[kt][t]);
+        }
+      }
+      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      float sum = 0.f;
+#pragma unroll
+      for (int kt = 0; kt < QT; ++kt)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          sc[kt][t] = expf(sc[kt][t] - mx);
+          sum += sc[kt][t];
+        }
+      sum += __shfl_xor(sum, 16, 64);
+      sum += __shfl_xor(sum, 32, 64);
+      const float inv = 1.f / sum;
+      f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int kt = 0; kt < QT; ++kt)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const float vf = vs_l[(kt * 16 + 4 * g + t) * LD + h * DH + j];
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(vf, sc[kt][t] * inv, acc, 0, 0, 0);
+        }
+      if (p0 + j < n) *(f32x4*)(orow + h * DH + 4 * g) = acc;
+    }
+    grp = next;
+  }
+}
+
 // ---- scene-to-click output projection fused with the residual, LayerNorm and the mask head (<= 64 queries) -----
 // Y = LayerNorm(O Wo^T + bo + src) and everything k_ln_mask does with it, per 16-point group, straight from the
 // transposed MFMA accumulators (lane (g, j) holds channels 16ct+4g..+3 of point j = the layout the LayerNorm and
@@ -1306,6 +1413,10 @@ static int run_decoder(const a3d_decoder_weights* w, const float* feats128, cons
       (void)hipFuncSetAttribute((const void*)k_query_layer<4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, big_lds);
       (void)hipFuncSetAttribute((const void*)k_s2c_attn_wide<4>, hipFuncAttributeMaxDynamicSharedMemorySize, big_lds);
       (void)hipFuncSetAttribute((const void*)k_s2c_attn<4>, hipFuncAttributeMaxDynamicSharedMemorySize, big_lds);
+      (void)hipFuncSetAttribute((const void*)k_q_s2c<1>, hipFuncAttributeMaxDynamicSharedMemorySize, big_lds);
+      (void)hipFuncSetAttribute((const void*)k_q_s2c<2>, hipFuncAttributeMaxDynamicSharedMemorySize, big_lds);
+      (void)hipFuncSetAttribute((const void*)k_q_s2c<3>, hipFuncAttributeMaxDynamicSharedMemorySize, big_lds);
+      (void)hipFuncSetAttribute((const void*)k_q_s2c<4>, hipFuncAttributeMaxDynamicSharedMemorySize, big_lds);
       (void)hipFuncSetAttribute((const void*)k_out_ln_mask<1>, hipFuncAttributeMaxDynamicSharedMemorySize, big_lds);
       (void)hipFuncSetAttribute((const void*)k_out_ln_mask<2>, hipFuncAttributeMaxDynamicSharedMemorySize, big_lds);
       (void)hipFuncSetAttribute((const void*)k_out_ln_mask<3>, hipFuncAttributeMaxDynamicSharedMemorySize, big_lds);
@@ -1382,16 +1493,23 @@ static int run_decoder(const a3d_decoder_weights* w, const float* feats128, cons
     }
     A3D_LAUNCH_CHECK();
     // ---- scene-to-click: Q = (src + pos) Wq^T + bq; attention; Y = O Wo^T + bo + src; LN
-    rc = a3d_linear(src, D, posenc, D, n, D, D, LW.s2c_wq_packed, nullptr, LW.s2c_in_b, nullptr, 0, 0, bufA, D, nullptr, 0, st);
-    if (rc) return rc;
-    {
-    ProfScope ps(st, A3D_PROF_S2C, 0, 0, 0, 0, n);
-    if (nblk == 1)
-      k_s2c_attn<QT><<<(n + 127) / 128, 512, s2c_lds, st>>>(bufA, n, B.ks, B.vs, nq, bufB);
-    else
-      k_s2c_attn_wide<QT><<<(n + 127) / 128, 512, s2c_lds, st>>>(bufA, n, B.ks, B.vs, nq, nblk, bufB);
+    if (nblk == 1 && fused_c2s()) {
+      const int ngroups = (n + 15) / 16;
+      const int grid = (ngroups + 7) / 8 < 256 ? (ngroups + 7) / 8 : 256;
+      ProfScope ps(st, A3D_PROF_S2C, 0, 0, 0, 0, n);
+      k_q_s2c<QT><<<grid, 512, (size_t)64 * 1024 + s2c_lds, st>>>(src, posenc, n, LW.s2c_wq_packed, LW.s2c_in_b, B.ks, B.vs, nq,
+                                                                bufB, ngroups);
+      A3D_LAUNCH_CHECK();
+    } else {
+      rc = a3d_linear(src, D, posenc, D, n, D, D, LW.s2c_wq_packed, nullptr, LW.s2c_in_b, nullptr, 0, 0, bufA, D, nullptr, 0, st);
+      if (rc) return rc;
+      ProfScope ps(st, A3D_PROF_S2C, 0, 0, 0, 0, n);
+      if (nblk == 1)
+        k_s2c_attn<QT><<<(n + 127) / 128, 512, s2c_lds, st>>>(bufA, n, B.ks, B.vs, nq, bufB);
+      else
+        k_s2c_attn_wide<QT><<<(n + 127) / 128, 512, s2c_lds, st>>>(bufA, n, B.ks, B.vs, nq, nblk, bufB);
+      A3D_LAUNCH_CHECK();
     }
-    A3D_LAUNCH_CHECK();
     float* Y = (l & 1) ? bufD : bufC;
     const size_t fused_lds = (size_t)64 * 1024 + ((size_t)QP * 132 + 8 * 16 * (QP + 1) + 8 * 16 * (K + 1)) * 4 + (size_t)(K + 1) * 4;
     if (nblk == 1 && fused_c2s() && fused_lds <= 160 * 1024) {
