@@ -239,3 +239,35 @@ def test_outdoor_scan_size_stress(model_and_sd):
     err = (op[torch.from_numpy(inv).cuda()] - o1).abs().max().item()
     print(f"300k voxels: permuted-input max|diff| = {err:.2e}")
     assert err <= 1e-4
+
+
+def test_unfused_decoder_path_still_matches_goldens():
+    """A3D_FUSED_C2S=0 keeps the separate projection GEMMs + attention kernels (the A/B switch of DESIGN.md 4.2; the
+    library reads the variable once per process, hence the subprocess)."""
+    import os
+    import subprocess
+    import sys
+    code = r'''
+import numpy as np, torch, sys
+sys.path.insert(0, "tests")
+from agile3d_amd import build_model, default_args, randomize_bn_stats
+from conftest import arrays_to_clicks, load_case
+torch.manual_seed(0)
+model = randomize_bn_stats(build_model(default_args())).eval().cuda()
+worst = 0.0
+for name in ("n4096_k5x2", "n3000_k10_bg", "n2048_k1"):
+    c = load_case(name)
+    ci, ct = arrays_to_clicks(c["click_rows"], c["click_objs"], c["click_times"], int(c["K"]))
+    r = model._get_engine().decoder_inputs(torch.from_numpy(c["feats128"]), torch.from_numpy(c["xyz"]))
+    out = model.forward_mask(*r, click_idx=[ci], click_time_idx=[ct])
+    got = [a["pred_masks"][0] for a in out["aux_outputs"]] + [out["pred_masks"][0]]
+    for i in range(3):
+        worst = max(worst, float(np.abs(got[i].cpu().numpy() - c[f"logits{i}"]).max()))
+print("WORST", worst)
+assert worst <= 1e-3
+'''
+    env = dict(os.environ, A3D_FUSED_C2S="0")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
+    assert "WORST" in res.stdout
