@@ -7,21 +7,22 @@
 //
 //   out[u, :] = act( (sum_k in[nbr[k][u], :] @ W[k]) * scale + shift + res[u, :] )
 //
-// One kernel covers the 3^3, 2^3-stride-2, transposed 2^3 and 1x1 layers (and the dense
-// [N,128]x[128,128] projections of the decoder): they only differ in the neighbour table.
+// k_spconv2 covers the 3^3, 2^3-stride-2, transposed 2^3 and small 1x1 layers: they only differ in the
+// neighbour table.  k_dense is the gather-free GEMM for the N-point linears of the decoder and the large 1x1
+// convolutions.  k_stem is the 5^3 input convolution (Cin = 3).
 //
-// gfx950 mapping (DESIGN.md "spconv"):
-//   * workgroup = 4 waves = 128 output rows x BN output channels; a wave owns two 16-row MFMA
-//     groups; v_mfma_f32_16x16x4_f32 (exact fp32) accumulates 16x16 tiles in registers;
-//   * per (kernel offset k, 32-channel slice): the 128 gathered input rows and the packed weight
-//     slice are DMA'd global->LDS with global_load_lds_dwordx4 (per-lane source = gathered row,
-//     LDS image linear; the 16-byte XOR swizzle is applied on the SOURCE address and again on
-//     the ds_read_b128, so fragment reads are bank-conflict free);
-//   * offsets k absent from a whole 16-row group are skipped (no gather, no MFMA): rows were
-//     clustered by neighbour pattern when the scene was built (scene.hip);
-//   * the K dimension inside a 16-channel step is permuted (channel = 16S + 4g + t for lane
-//     group g, MFMA t) identically for A and B, so one ds_read_b128 feeds four MFMAs;
-//   * BatchNorm(eval) scale/shift, residual, ReLU and the channel-slice concat are the epilogue.
+// gfx950 mapping:
+//   * workgroup = 4 waves = 64 output rows x BN output channels; a wave owns one 16-row MFMA group;
+//     v_mfma_f32_16x16x4_f32 (exact fp32) accumulates 16x16 tiles in registers;
+//   * stage = (kernel offset k, up to 96 input channels): every lane loads its own A fragments of the NEXT stage
+//     straight from global memory (gathered row, 16 bytes per 16-channel step) while the current stage is
+//     multiplied; the packed weight slice goes global->LDS by global_load_lds_dwordx4 into a two-slot ring;
+//   * offsets k absent from a whole 16-row group are skipped (no gather, no MFMA): rows were sorted by
+//     neighbour pattern when the scene was built (scene.hip), tiles are handed out longest first;
+//   * the K dimension inside a 16-channel step is permuted (channel = 16S + 4g + t for lane group g, MFMA t)
+//     identically for both operands, so one 16-byte load / ds_read_b128 feeds four MFMAs;
+//   * weights are the MFMA A operand: a lane ends up with 4 consecutive output channels of one row, so
+//     BatchNorm(eval) scale/shift, residual, ReLU and the channel-slice concat are 16-byte epilogue accesses.
 #include "common.h"
 #include <stdlib.h>
 
@@ -53,13 +54,14 @@ struct ConvArgs {
   const int* tile_order;      // [n_tiles] order in which 64-row tiles are handed out (most offsets first) or nullptr
   int n_tiles;
   unsigned long long* dbg_cycles;   // [8] phase cycle sums (A3D_DBG & 64)
-  int dbg;                    // ablation switches (A3D_DBG env): 1 = no A gather, 2 = no W load, 4 = no MFMA
+  int dbg;                    // A3D_DBG env: 1 no A gather, 2 no W load, 4 no MFMA, 8 no B reads, 16 no stage barrier,
+                              // 32 all offsets present, 64 phase cycle sums, 4096 per-tile timeline
 };
 
 // global -> LDS DMA of 64 x 16 bytes: per-lane SOURCE address, LDS image = uniform base + 16 * lane.
 // Issued through inline asm so that hipcc neither tracks it in its s_waitcnt bookkeeping nor drains
 // it with a vmcnt(0) of its own (cdna_hip_programming.md 5.7): completion is waited for explicitly
-// with counted s_waitcnt vmcnt(N) in the stage loop.  M0 (the LDS base) is saved and restored.
+// (s_waitcnt vmcnt(0) at the end of every stage).  M0 (the LDS base) is saved and restored.
 __device__ __forceinline__ void glds16(const float* src, unsigned lds_byte_addr) {
   const unsigned lds_addr = __builtin_amdgcn_readfirstlane(lds_byte_addr);
   unsigned keep;
@@ -78,350 +80,6 @@ template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
-
-// Geometry is a template parameter: NW waves, GPW 16-row MFMA groups per wave (tile = 16 NW GPW rows;
-// wave w owns groups w, w + NW, ... -- interleaved, so that every wave samples the whole range of
-// neighbour patterns of the pattern-sorted tile) and a ring of DEPTH LDS stage slots.
-//
-// Stage = (kernel offset k, 32-channel slice).  Per stage a wave DMAs the gathered rows of those of
-// its groups that have offset k (2 x 1 KiB each) and its share of the packed weight slice into ring
-// slot (stage % DEPTH); the weight fragments it then reads from LDS are shared by all its groups.
-// Memory latency under load is several times the MFMA time of a stage, so DEPTH-1 stages stay in
-// flight behind a COUNTED s_waitcnt: every wave issues at least WPW_MIN weight pieces per stage,
-// hence "all DMA of stage s has landed" == vmcnt(<= WPW_MIN * stages issued after s).
-template <int BN, int NW, int GPW, int DEPTH>
-__global__ void __launch_bounds__(NW * 64) k_spconv(const ConvArgs a) {
-  constexpr int NCT = BN / 16;
-  constexpr int NG = NW * GPW;                   // row groups per tile
-  constexpr int kConvTile = 16 * NG;
-  constexpr int NT = NW * 64;
-  constexpr int WPW = (2 * NCT + NW - 1) / NW;   // weight pieces (1 KiB) per wave per stage, upper bound
-  constexpr int WPW_MIN = 2 * NCT / NW;          // ... lower bound (what a counted wait may rely on)
-  constexpr int A_FLOATS = kConvTile * 32;       // [rows][32 ch], 16-byte pieces XOR-swizzled by row&7
-  constexpr int W_FLOATS = 2 * NCT * 256;        // [2 steps][NCT][64 lanes][4]
-  constexpr int S_FLOATS = A_FLOATS + W_FLOATS;
-  constexpr int NP = WPW + 2 * GPW;              // DMA pieces per wave per stage (fixed slots)
-  static_assert(NP <= 8 * GPW, "more DMA pieces than MFMA groups to hide them behind");
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  float* ring = (float*)smem;                              // DEPTH slots of [A | W]
-  int* idx_lds = (int*)(ring + DEPTH * S_FLOATS);          // [kper][kConvTile]
-  int* tile_slot = idx_lds + a.kper * kConvTile;
-  const unsigned ring_addr = (unsigned)(size_t)ring;
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int g = lane >> 4, j = lane & 15;
-  const int ct0 = blockIdx.y * NCT;
-  const int kbeg = blockIdx.z * a.kper;
-  const int kend = min(a.K, kbeg + a.kper);
-  const int nchunk = a.cin >> 5;
-  const int cin16 = a.cin >> 4, cout16 = a.cout >> 4;
-  const int swz = lane >> 3;  // == (row & 7) for the staging lanes
-  int* counter = a.tile_counter ? a.tile_counter + (blockIdx.y * gridDim.z + blockIdx.z) : nullptr;
-  // weight slice of a stage = pieces q = 0..2*NCT-1; piece q sits at float offset
-  // (q < NCT ? q : q - NCT + cout16) * 256 from the stage base.  Wave w copies pieces w, w+NW, ...
-  int woff[WPW];
-#pragma unroll
-  for (int i = 0; i < WPW; ++i) {
-    const int q = wave + NW * i;
-    woff[i] = (q < NCT ? q : q - NCT + cout16) * 256;
-  }
-  const float* wlane = a.w + (size_t)ct0 * 256 + lane * 4;
-  const size_t wstride_k = (size_t)cin16 * cout16 * 256, wstride_c = (size_t)2 * cout16 * 256;
-  const int a_lane_off = 4 * ((lane & 7) ^ swz);   // source-side swizzle of the 16-byte piece
-
-  const bool timing = (a.dbg & 64) && a.dbg_cycles;
-  unsigned long long tc[6] = {0, 0, 0, 0, 0, 0};
-  unsigned long long t_prev = timing ? __builtin_amdgcn_s_memtime() : 0;
-  const bool tracing = (a.dbg & 128) && a.dbg_cycles && blockIdx.x == 7 && blockIdx.y == 0 && blockIdx.z == 0;
-  int trace_n = 0;
-  auto lap = [&](int slot) {
-    if (timing) {
-      const unsigned long long t = __builtin_amdgcn_s_memtime();
-      tc[slot] += t - t_prev;
-      t_prev = t;
-    }
-    if (tracing && lane == 0 && trace_n < 64 * 6) {
-      a.dbg_cycles[16 + (wave * 64 * 6) + trace_n] = __builtin_amdgcn_s_memtime();
-      ++trace_n;
-    }
-  };
-  for (int tile = blockIdx.x;; tile += gridDim.x) {
-    // ---- persistent workgroups pull tiles from a queue (static stride without a counter)
-    if (counter) {
-      if (tid == 0) *tile_slot = atomicAdd(counter, 1);
-      __syncthreads();
-      tile = *tile_slot;
-    }
-    if (tile >= a.n_tiles) break;
-    const int r0 = tile * kConvTile;
-
-    // ---- which offsets does the tile / each of this wave's groups need
-    uint32_t un = 0xffffffffu, gm[GPW];
-#pragma unroll
-    for (int G = 0; G < GPW; ++G) gm[G] = 0xffffffffu;
-    if (a.gmask) {
-      const uint32_t* gp = a.gmask + (r0 >> 4);
-      un = 0;
-#pragma unroll
-      for (int i = 0; i < NG; ++i) un |= gp[i];
-#pragma unroll
-      for (int G = 0; G < GPW; ++G) gm[G] = __builtin_amdgcn_readfirstlane(gp[wave + NW * G]);
-    }
-    un = __builtin_amdgcn_readfirstlane(un);
-
-    // ---- neighbour rows of the tile for every offset of this split
-#pragma unroll 4
-    for (int e = tid; e < (kend - kbeg) * kConvTile; e += NT) {
-      const int kk = e / kConvTile, r = e % kConvTile;
-      int v;
-      if (a.nbr) {
-        v = a.nbr[(size_t)(kbeg + kk) * a.nbr_stride + r0 + r];
-      } else {
-        v = r0 + r;
-        if (v >= a.n_in) v = a.n_in - 1;
-      }
-      idx_lds[e] = v;
-    }
-    __syncthreads();
-    lap(0);   // queue + masks + idx table
-
-    f32x4 acc[GPW][NCT];
-#pragma unroll
-    for (int G = 0; G < GPW; ++G)
-#pragma unroll
-      for (int ct = 0; ct < NCT; ++ct) acc[G][ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-    auto next_k = [&](int k) {
-      ++k;
-      while (k < kend && !((un >> k) & 1u)) ++k;
-      return k;
-    };
-    // ---- issue iterator (runs DEPTH-1 stages ahead of the compute iterator)
-    int ki = next_k(kbeg - 1), ci = 0, slot_i = 0;
-    const float *pa[GPW], *pb[GPW];   // this lane's gathered-row sources for offset ki, per group
-    bool acti[GPW];
-#pragma unroll
-    for (int G = 0; G < GPW; ++G) {
-      pa[G] = pb[G] = a.in;
-      acti[G] = false;
-    }
-    auto enter_k = [&]() {
-      if (ki < kend) {
-#pragma unroll
-        for (int G = 0; G < GPW; ++G) {
-          acti[G] = ((gm[G] >> ki) & 1u) && !(a.dbg & 1);
-          if (acti[G]) {
-            const int* idxk = idx_lds + (ki - kbeg) * kConvTile + 16 * (wave + NW * G) + swz;
-            pa[G] = a.in + (size_t)idxk[0] * a.ldi + a_lane_off;
-            pb[G] = a.in + (size_t)idxk[8] * a.ldi + a_lane_off;
-          }
-        }
-      }
-    };
-    // The DMA of one stage is prepared (addresses) and fired piece by piece so that, on a wave that
-    // has MFMAs to do, the pieces are issued in the shadow of the MFMAs instead of in front of them.
-    const float* psrc[NP];
-    unsigned pdst[NP];               // LDS byte addresses
-    unsigned pmask = 0;              // which of the NP fixed slots hold a piece for the prepared stage
-    auto prepare = [&]() {           // stage (ki, ci) -> ring slot slot_i; advances the issue iterator
-      const unsigned Ab = ring_addr + (unsigned)(slot_i * S_FLOATS) * 4u;
-      const unsigned Wb = Ab + A_FLOATS * 4u;
-      const float* wst = wlane + (size_t)ki * wstride_k + (size_t)ci * wstride_c;
-      pmask = 0;
-#pragma unroll
-      for (int i = 0; i < WPW; ++i) {
-        psrc[i] = wst + woff[i];
-        pdst[i] = Wb + (unsigned)(wave + NW * i) * 1024u;
-        if (wave + NW * i < 2 * NCT) pmask |= 1u << i;
-      }
-#pragma unroll
-      for (int G = 0; G < GPW; ++G) {
-        psrc[WPW + 2 * G] = pa[G] + ci * 32;
-        pdst[WPW + 2 * G] = Ab + (unsigned)(16 * (wave + NW * G)) * 128u;
-        psrc[WPW + 2 * G + 1] = pb[G] + ci * 32;
-        pdst[WPW + 2 * G + 1] = Ab + (unsigned)(16 * (wave + NW * G) + 8) * 128u;
-        if (acti[G]) pmask |= 3u << (WPW + 2 * G);
-      }
-      slot_i = slot_i + 1 == DEPTH ? 0 : slot_i + 1;
-      if (++ci == nchunk) {
-        ci = 0;
-        ki = next_k(ki);
-        enter_k();
-      }
-    };
-    auto fire = [&](int i) {
-      if ((pmask >> i) & 1u) glds16(psrc[i], pdst[i]);
-    };
-    auto issue_one = [&]() {
-      prepare();
-#pragma unroll
-      for (int i = 0; i < NP; ++i) fire(i);
-    };
-    enter_k();
-    int ahead = 0;   // stages issued but not yet computed
-    while (ahead < DEPTH - 1 && ki < kend) {
-      issue_one();
-      ++ahead;
-    }
-
-    // ---- compute iterator
-    int kc = next_k(kbeg - 1), cc = 0, slot_c = 0;
-    while (kc < kend) {
-      lap(1);   // loop control
-      // stage (kc, cc) must have landed: leave only the younger stages' weight pieces in flight
-      if (DEPTH >= 3 && WPW_MIN >= 1 && ahead >= 2) wait_vmcnt<(DEPTH >= 3 ? WPW_MIN : 0)>(); else wait_vmcnt<0>();
-      __builtin_amdgcn_s_barrier();
-      lap(2);   // wait + barrier
-      // every wave has left the slot computed one iteration ago: it is refilled while this stage runs
-      bool actc[GPW], any = false;
-#pragma unroll
-      for (int G = 0; G < GPW; ++G) {
-        actc[G] = ((gm[G] >> kc) & 1u) && !(a.dbg & 4);
-        any |= actc[G];
-      }
-      const bool have_next = ki < kend;
-      if (any) {
-        // fragments first (their LDS latency hides under the address work of prepare()) ...
-        const float* Abase = ring + slot_c * S_FLOATS;
-        const float* Wb = Abase + A_FLOATS + lane * 4;
-        f32x4 av[GPW][2], bv[2][NCT];
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-#pragma unroll
-          for (int G = 0; G < GPW; ++G)
-            if (actc[G]) av[G][s] = *(const f32x4*)(Abase + (16 * (wave + NW * G) + j) * 32 + ((4 * s + g) ^ (j & 7)) * 4);
-#pragma unroll
-          for (int ct = 0; ct < NCT; ++ct) bv[s][ct] = *(const f32x4*)(Wb + (s * NCT + ct) * 256);
-        }
-        if (have_next) {
-          prepare();
-          ++ahead;
-          if (a.dbg & 16) {   // A/B switch: fire the whole stage up front instead of between MFMAs
-#pragma unroll
-            for (int i = 0; i < NP; ++i) fire(i);
-            pmask = 0;
-          }
-        } else {
-          pmask = 0;
-        }
-        lap(3);   // fragment reads issued + next stage prepared
-        // ... then the MFMAs, one DMA piece fired after each block of NCT MFMAs
-        int fired = 0;
-#pragma unroll
-        for (int G = 0; G < GPW; ++G) {
-          if (actc[G]) {
-#pragma unroll
-            for (int s = 0; s < 2; ++s)
-#pragma unroll
-              for (int t = 0; t < 4; ++t) {
-#pragma unroll
-                for (int ct = 0; ct < NCT; ++ct)
-                  acc[G][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[G][s][t], bv[s][ct][t], acc[G][ct], 0, 0, 0);
-                if (G * 8 + s * 4 + t < NP) {
-                  __builtin_amdgcn_sched_barrier(0);
-                  fire(G * 8 + s * 4 + t);
-                  __builtin_amdgcn_sched_barrier(0);
-                }
-              }
-            fired = (G + 1) * 8;
-          } else {
-#pragma unroll
-            for (int i = G * 8; i < (G + 1) * 8; ++i)
-              if (i < NP) fire(i);
-          }
-        }
-        (void)fired;
-      } else {
-        if (have_next) {
-          issue_one();
-          ++ahead;
-        }
-        lap(3);
-      }
-      lap(4);   // fragment reads + MFMA
-      --ahead;
-      slot_c = slot_c + 1 == DEPTH ? 0 : slot_c + 1;
-      if (++cc == nchunk) {
-        cc = 0;
-        kc = next_k(kc);
-      }
-    }
-
-    // ---- epilogue.  C/D layout of 16x16x4: column = lane & 15, row = 4 * (lane >> 4) + reg.
-    // All loads (row map, scale/shift, residual) are issued as batches before anything is stored.
-#pragma unroll
-    for (int G = 0; G < GPW; ++G) {
-      const int rg = r0 + 16 * (wave + NW * G) + 4 * g;
-      if (a.partial) {
-        float* P = a.partial + (size_t)blockIdx.z * ((size_t)a.n_tiles * kConvTile) * a.cout;
-#pragma unroll
-        for (int ct = 0; ct < NCT; ++ct)
-#pragma unroll
-          for (int t = 0; t < 4; ++t) P[(size_t)(rg + t) * a.cout + (ct0 + ct) * 16 + j] = acc[G][ct][t];
-      } else {
-        // rows past the end are clamped for the LOADS (always a valid address -> no per-element
-        // predication, the loads issue back to back) and predicated only for the stores
-        int orow[4];
-        bool ok[4];
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-          ok[t] = rg + t < a.n_out;
-          orow[t] = ok[t] ? rg + t : a.n_out - 1;
-        }
-        if (a.out_map) {
-#pragma unroll
-          for (int t = 0; t < 4; ++t) orow[t] = a.out_map[orow[t]];
-        }
-        float sc[NCT], sh[NCT];
-#pragma unroll
-        for (int ct = 0; ct < NCT; ++ct) {
-          const int col = (ct0 + ct) * 16 + j;
-          sc[ct] = a.scale ? a.scale[col] : 1.f;
-          sh[ct] = a.shift ? a.shift[col] : 0.f;
-        }
-        if (a.res) {
-          float rv[NCT][4];
-#pragma unroll
-          for (int ct = 0; ct < NCT; ++ct)
-#pragma unroll
-            for (int t = 0; t < 4; ++t) rv[ct][t] = a.res[(size_t)orow[t] * a.ldr + (ct0 + ct) * 16 + j];
-#pragma unroll
-          for (int ct = 0; ct < NCT; ++ct)
-#pragma unroll
-            for (int t = 0; t < 4; ++t) acc[G][ct][t] = acc[G][ct][t] * sc[ct] + sh[ct] + rv[ct][t];
-        } else {
-#pragma unroll
-          for (int ct = 0; ct < NCT; ++ct)
-#pragma unroll
-            for (int t = 0; t < 4; ++t) acc[G][ct][t] = acc[G][ct][t] * sc[ct] + sh[ct];
-        }
-        if (a.relu) {
-#pragma unroll
-          for (int ct = 0; ct < NCT; ++ct)
-#pragma unroll
-            for (int t = 0; t < 4; ++t) acc[G][ct][t] = fmaxf(acc[G][ct][t], 0.f);
-        }
-#pragma unroll
-        for (int ct = 0; ct < NCT; ++ct)
-#pragma unroll
-          for (int t = 0; t < 4; ++t)
-            if (ok[t]) a.out[(size_t)orow[t] * a.ldo + (ct0 + ct) * 16 + j] = acc[G][ct][t];
-      }
-    }
-    if (!a.partial && a.zero_row >= 0 && tile == 0 && tid < BN)
-      a.out[(size_t)a.zero_row * a.ldo + ct0 * 16 + tid] = 0.f;
-    __syncthreads();   // all waves are done with the ring / idx table of this tile
-    lap(5);   // epilogue + end-of-tile barrier
-  }
-  if (timing && lane == 0) {
-#pragma unroll
-    for (int i = 0; i < 6; ++i) atomicAdd(&a.dbg_cycles[i], tc[i]);
-    atomicAdd(&a.dbg_cycles[6], 1ULL);
-  }
-}
-
 
 // ------------------------------------------------------------------------------ k_spconv2
 // Second-generation kernel: stage = (offset k, CH input channels) with CH up to 96, so a 96-channel layer
@@ -1003,31 +661,16 @@ __global__ void k_pack_weight(const float* __restrict__ w, int K, int cin, int c
 
 // ------------------------------------------------------------------------------ host: launch
 struct ConvPlan {
-  int bn, nw, gpw, depth, tile, ksplit, kper, ntile, grid_x, ch;
+  int bn, tile, ksplit, kper, ntile, grid_x, ch;
   size_t lds, partial_floats;
 };
-
-static int conv_variant() {   // A3D_CONV_VARIANT=2 (k_spconv2, default) or <waves><groups per wave><depth> of k_spconv
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("A3D_CONV_VARIANT");
-    v = e ? atoi(e) : 2;
-    if (v != 2 && v != 413 && v != 412 && v != 422 && v != 423 && v != 812) v = 413;
-  }
-  return v;
-}
 
 constexpr int kMaxQueuesPerOp = 128;   // cout tiles x k splits
 
 static ConvPlan plan_conv(int n_rows, int K, int cin, int cout) {
   ConvPlan p;
-  const bool gen2 = conv_variant() == 2;
-  p.nw = gen2 ? 4 : conv_variant() / 100;
-  p.gpw = gen2 ? 1 : (conv_variant() / 10) % 10;
-  p.depth = gen2 ? 2 : conv_variant() % 10;
-  p.ch = 0;
-  p.tile = 16 * p.nw * p.gpw;
-  const int kConvTile = p.tile, kConvDepth = p.depth;
+  p.tile = 64;   // k_spconv2: 4 waves x one 16-row group
+  const int kConvTile = p.tile;
   p.ntile = (int)((n_rows + kConvTile - 1) / kConvTile);
   if (p.ntile < 1) p.ntile = 1;
   int bn = (cout % 128 == 0) ? 128 : cout;
@@ -1041,18 +684,10 @@ static ConvPlan plan_conv(int n_rows, int K, int cin, int cout) {
   }
   p.kper = (K + ksplit - 1) / ksplit;
   p.ksplit = (K + p.kper - 1) / p.kper;
-  p.lds = (size_t)kConvDepth * (kConvTile * 32 + 2 * (bn / 16) * 256) * 4 + (size_t)p.kper * kConvTile * 4 + 16;
-  if (gen2) {
-    p.ch = conv2_ch(cin, bn);
-    p.lds = (size_t)2 * p.ch * bn * 4 + (size_t)p.kper * kConvTile * 4 + 16;
-  }
+  p.ch = conv2_ch(cin, bn);
+  p.lds = (size_t)2 * p.ch * bn * 4 + (size_t)p.kper * kConvTile * 4 + 16;   // two-slot weight ring + gather-row table
   p.partial_floats = p.ksplit > 1 ? (size_t)p.ksplit * p.ntile * kConvTile * cout : 0;
-  int per_cu = (int)(160 * 1024 / p.lds > 4 ? 4 : 160 * 1024 / p.lds);
-  {
-    static int cap = -1;
-    if (cap < 0) { const char* e = getenv("A3D_CONV_WGS_PER_CU"); cap = e ? atoi(e) : 0; }   // experiment
-    if (cap > 0 && per_cu > cap) per_cu = cap;
-  }
+  const int per_cu = (int)(160 * 1024 / p.lds > 4 ? 4 : 160 * 1024 / p.lds);
   const int max_resident = 256 * per_cu;   // CUs x resident workgroups
   int gx = max_resident / ((cout / bn) * p.ksplit);
   if (gx < 1) gx = 1;
@@ -1064,10 +699,6 @@ static void allow_big_lds() {
   static bool done = false;
   if (done) return;
   done = true;
-#define A3D_BIG1(BN_, NW_, G_, D_) \
-  (void)hipFuncSetAttribute((const void*)k_spconv<BN_, NW_, G_, D_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-#define A3D_BIG(BN_) A3D_BIG1(BN_, 4, 1, 2) A3D_BIG1(BN_, 4, 1, 3) A3D_BIG1(BN_, 4, 2, 2) A3D_BIG1(BN_, 4, 2, 3) A3D_BIG1(BN_, 8, 1, 2)
-  A3D_BIG(32) A3D_BIG(64) A3D_BIG(96) A3D_BIG(128)
 #define A3D_BIG2(BN_, CH_) \
   (void)hipFuncSetAttribute((const void*)k_spconv2<BN_, CH_, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
   (void)hipFuncSetAttribute((const void*)k_spconv2<BN_, CH_, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -1078,8 +709,6 @@ static void allow_big_lds() {
   (void)hipFuncSetAttribute((const void*)k_dense<8, 6>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   (void)hipFuncSetAttribute((const void*)k_dense<6, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   (void)hipFuncSetAttribute((const void*)k_dense<6, 6>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-#undef A3D_BIG
-#undef A3D_BIG1
 }
 
 static int launch_conv(ConvArgs a, float* partial_ws, size_t partial_ws_floats, int* queue_heads, hipStream_t st) {
@@ -1092,7 +721,7 @@ static int launch_conv(ConvArgs a, float* partial_ws, size_t partial_ws_floats, 
     }
     a.dbg = dbg;
     a.dbg_cycles = nullptr;
-    if (dbg & (64 | 128 | 4096)) {
+    if (dbg & (64 | 4096)) {
       static unsigned long long* buf = nullptr;
       if (!buf) (void)hipMalloc(&buf, (size_t)1 << 20);
       (void)hipMemsetAsync(buf, 0, (size_t)1 << 20, st);
@@ -1127,15 +756,11 @@ static int launch_conv(ConvArgs a, float* partial_ws, size_t partial_ws_floats, 
   dim3 grid(grid_x, a.cout / p.bn, p.ksplit);
   {
   ProfScope ps(st, A3D_PROF_SPCONV, p.bn, a.K, a.cin, a.cout, a.n_out, a.tag_table, a.tag_level, p.ksplit);
-#define A3D_LAUNCH_BN(BN_)                                                                  \
-  switch (p.nw * 100 + p.gpw * 10 + p.depth) {                                               \
-    case 412: k_spconv<BN_, 4, 1, 2><<<grid, 256, p.lds, st>>>(a); break;                     \
-    case 422: k_spconv<BN_, 4, 2, 2><<<grid, 256, p.lds, st>>>(a); break;                     \
-    case 423: k_spconv<BN_, 4, 2, 3><<<grid, 256, p.lds, st>>>(a); break;                     \
-    case 812: k_spconv<BN_, 8, 1, 2><<<grid, 512, p.lds, st>>>(a); break;                     \
-    default: k_spconv<BN_, 4, 1, 3><<<grid, 256, p.lds, st>>>(a); break;                      \
+  if (!p.ch) {
+    set_error("spconv: no stage size for cin=%d with %d-column workgroups", a.cin, p.bn);
+    return A3D_ERR_UNSUPPORTED;
   }
-  if (p.ch) {
+  {
     static int tr = -1;
     if (tr < 0) { const char* e = getenv("A3D_CONV2_TR"); tr = e ? atoi(e) : 1; }
 #define A3D_L2(BN_, CH_) \
@@ -1144,28 +769,9 @@ static int launch_conv(ConvArgs a, float* partial_ws, size_t partial_ws_floats, 
     A3D_L2(96, 32) A3D_L2(96, 48) A3D_L2(96, 64) A3D_L2(96, 96) A3D_L2(128, 32) A3D_L2(128, 64)
     { set_error("spconv2: no kernel for BN %d CH %d", p.bn, p.ch); return A3D_ERR_UNSUPPORTED; }
 #undef A3D_L2
-  } else
-  switch (p.bn) {
-    case 32: A3D_LAUNCH_BN(32); break;
-    case 64: A3D_LAUNCH_BN(64); break;
-    case 96: A3D_LAUNCH_BN(96); break;
-    case 128: A3D_LAUNCH_BN(128); break;
-    default: set_error("spconv: bad BN %d", p.bn); return A3D_ERR_UNSUPPORTED;
   }
-#undef A3D_LAUNCH_BN
   }
   A3D_LAUNCH_CHECK();
-  if (a.dbg_cycles && (a.dbg & 128)) {
-    static unsigned long long tr[16 + 8 * 64 * 6];
-    (void)hipMemcpyAsync(tr, a.dbg_cycles, sizeof(tr), hipMemcpyDeviceToHost, st);
-    (void)hipStreamSynchronize(st);
-    for (int w = 0; w < p.nw; ++w) {
-      const unsigned long long* t = tr + 16 + w * 64 * 6;
-      fprintf(stderr, "[trace wave %d] deltas:", w);
-      for (int i = 1; i < 64 * 6 && t[i]; ++i) fprintf(stderr, " %llu", t[i] - t[i - 1]);
-      fprintf(stderr, "\n");
-    }
-  }
   if (a.dbg_cycles && (a.dbg & 4096)) {
     static unsigned long long tl[8000 * 8 + 16];
     (void)hipMemcpyAsync(tl, a.dbg_cycles, sizeof(tl), hipMemcpyDeviceToHost, st);
@@ -1391,7 +997,7 @@ extern "C" int a3d_program_run(const a3d_scene* s, const a3d_buf_desc* bufs, int
         {
           static int use_order = -1;
           if (use_order < 0) { const char* e = getenv("A3D_TILE_ORDER"); use_order = e ? atoi(e) : 1; }
-          a.tile_order = conv_variant() == 2 && use_order ? s->lv[Lin].order27 : nullptr;   // 64-row tiles (k_spconv2)
+          a.tile_order = use_order ? s->lv[Lin].order27 : nullptr;   // 64-row tiles
         }
         break;
       case A3D_OP_DOWN:

@@ -45,7 +45,7 @@ int         a3d_memcpy_d2h(void* dst_host, const void* src_dev, size_t bytes, vo
  * kernels listed below is bracketed by a hipEvent pair on the launch stream.
  * ------------------------------------------------------------------------------------------ */
 enum {
-  A3D_PROF_SPCONV = 0,      /* k_spconv<bn>   (3^3 / 2^3 / transposed / 1x1 / dense GEMM)  */
+  A3D_PROF_SPCONV = 0,      /* k_spconv2<bn,ch> (3^3 / 2^3 s2 / transposed / small 1x1)      */
   A3D_PROF_SPLITK = 1,      /* split-K reduction + epilogue                              */
   A3D_PROF_STEM = 2,        /* 5^3 stem                                                  */
   A3D_PROF_C2S = 3,         /* click-to-scene attention                                  */
