@@ -374,74 +374,10 @@ __global__ void __launch_bounds__(64) k_c2s_combine(const float* __restrict__ pa
 }
 
 // ------------------------------------------------------------------------------ scene-to-click
-// 8 waves x 16 points per workgroup; keys/values of the <= 64 queries staged in LDS (row stride
-// 132 floats: conflict-free b128 fragment reads).  S^T = ks_h Qs_h^T, softmax over keys in
-// registers (key = 4 g + t within a tile -> 2 shuffles), O^T = vs_h^T P.
-template <int QT>
-__global__ void __launch_bounds__(512) k_s2c_attn(const float* __restrict__ Qs, int n, const float* ks,
-                                                  const float* vs, int nq, float* O) {
-  constexpr int QP = QT * 16, LD = 132;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  float* ks_l = (float*)smem;
-  float* vs_l = ks_l + QP * LD;
-  for (int e = threadIdx.x; e < QP * 32; e += 512) {
-    const int r = e >> 5, c4 = (e & 31) * 4;
-    *(f32x4*)(ks_l + r * LD + c4) = *(const f32x4*)(ks + (size_t)r * D + c4);
-    *(f32x4*)(vs_l + r * LD + c4) = *(const f32x4*)(vs + (size_t)r * D + c4);
-  }
-  __syncthreads();
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int g = lane >> 4, j = lane & 15;
-  const int p0 = (blockIdx.x * 8 + wave) * 16;
-  if (p0 >= n) return;
-  const int prow = min(p0 + j, n - 1);
-  const float* qrow = Qs + (size_t)prow * D;
-  float* orow = O + (size_t)prow * D;
-#pragma unroll 1
-  for (int h = 0; h < H; ++h) {
-    const f32x4 qf = *(const f32x4*)(qrow + h * DH + 4 * g);
-    f32x4 s[QT];
-    float mx = kNegBig;
-#pragma unroll
-    for (int kt = 0; kt < QT; ++kt) {
-      const f32x4 kf = *(const f32x4*)(ks_l + (kt * 16 + j) * LD + h * DH + 4 * g);
-      s[kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int t = 0; t < 4; ++t) s[kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[t], qf[t], s[kt], 0, 0, 0);
-#pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        if (kt * 16 + 4 * g + t >= nq) s[kt][t] = kNegBig;
-        mx = fmaxf(mx, s[kt][t]);
-      }
-    }
-    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    float sum = 0.f;
-#pragma unroll
-    for (int kt = 0; kt < QT; ++kt)
-#pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        s[kt][t] = expf(s[kt][t] - mx);
-        sum += s[kt][t];
-      }
-    sum += __shfl_xor(sum, 16, 64);
-    sum += __shfl_xor(sum, 32, 64);
-    const float inv = 1.f / sum;
-    f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int kt = 0; kt < QT; ++kt)
-#pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        const float vf = vs_l[(kt * 16 + 4 * g + t) * LD + h * DH + j];
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(vf, s[kt][t] * inv, acc, 0, 0, 0);
-      }
-    if (p0 + j < n) *(f32x4*)(orow + h * DH + 4 * g) = acc;
-  }
-}
-
-
-// The same attention for more than 64 queries: keys/values staged in blocks of 64, online softmax
-// across blocks (per head: running max, partial sum, O^T accumulator in registers).
+// Unfused scene-to-click attention (more than 64 queries, or A3D_FUSED_C2S=0): 8 waves x 16 points per workgroup,
+// S^T = ks_h Qs_h^T with the queries' keys/values staged in LDS in blocks of 64 (row stride 132 floats:
+// conflict-free b128 fragment reads), online softmax across blocks (per head: running max, partial sum, O^T
+// accumulator in registers).
 template <int QT>
 __global__ void __launch_bounds__(512) k_s2c_attn_wide(const float* __restrict__ Qs, int n, const float* ks,
                                                        const float* vs, int nq, int nblk, float* O) {
@@ -1412,7 +1348,6 @@ static int run_decoder(const a3d_decoder_weights* w, const float* feats128, cons
       (void)hipFuncSetAttribute((const void*)k_query_layer<4, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, big_lds);
       (void)hipFuncSetAttribute((const void*)k_query_layer<4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, big_lds);
       (void)hipFuncSetAttribute((const void*)k_s2c_attn_wide<4>, hipFuncAttributeMaxDynamicSharedMemorySize, big_lds);
-      (void)hipFuncSetAttribute((const void*)k_s2c_attn<4>, hipFuncAttributeMaxDynamicSharedMemorySize, big_lds);
       (void)hipFuncSetAttribute((const void*)k_q_s2c<1>, hipFuncAttributeMaxDynamicSharedMemorySize, big_lds);
       (void)hipFuncSetAttribute((const void*)k_q_s2c<2>, hipFuncAttributeMaxDynamicSharedMemorySize, big_lds);
       (void)hipFuncSetAttribute((const void*)k_q_s2c<3>, hipFuncAttributeMaxDynamicSharedMemorySize, big_lds);
@@ -1504,10 +1439,7 @@ static int run_decoder(const a3d_decoder_weights* w, const float* feats128, cons
       rc = a3d_linear(src, D, posenc, D, n, D, D, LW.s2c_wq_packed, nullptr, LW.s2c_in_b, nullptr, 0, 0, bufA, D, nullptr, 0, st);
       if (rc) return rc;
       ProfScope ps(st, A3D_PROF_S2C, 0, 0, 0, 0, n);
-      if (nblk == 1)
-        k_s2c_attn<QT><<<(n + 127) / 128, 512, s2c_lds, st>>>(bufA, n, B.ks, B.vs, nq, bufB);
-      else
-        k_s2c_attn_wide<QT><<<(n + 127) / 128, 512, s2c_lds, st>>>(bufA, n, B.ks, B.vs, nq, nblk, bufB);
+      k_s2c_attn_wide<QT><<<(n + 127) / 128, 512, s2c_lds, st>>>(bufA, n, B.ks, B.vs, nq, nblk, bufB);
       A3D_LAUNCH_CHECK();
     }
     float* Y = (l & 1) ? bufD : bufC;
