@@ -535,7 +535,8 @@ static int launch_dense(const float* X, int ldx, const float* X2, int ldx2, int 
 // 5^3 (or 3^3) conv with Cin = 3 (res16unet.py:39-47,225-227; conv1_kernel_size main.py:37).
 // FLOPs are negligible (0.6 GF at 80 k voxels); the cost is 125 hash probes per voxel, so the
 // kernel map is never materialised: probe -> LDS table -> 3x32 FMAs per existing neighbour.
-__global__ void __launch_bounds__(256) k_stem(const int32_t* __restrict__ xyzb, int n,
+template <int NT>   // threads per 64-voxel workgroup: NT / 64 threads share a voxel, 32 * 64 / NT output channels each
+__global__ void __launch_bounds__(NT) k_stem(const int32_t* __restrict__ xyzb, int n,
                                               const uint64_t* __restrict__ hk, const int* __restrict__ hv,
                                               uint32_t hmask, const f32x4* __restrict__ feats4,
                                               const float* __restrict__ w, int ks,
@@ -546,18 +547,18 @@ __global__ void __launch_bounds__(256) k_stem(const int32_t* __restrict__ xyzb, 
   float* W = (float*)smem;              // [K][3][32]
   int* nb = (int*)(W + K * 96);         // [64][K]
   const int tid = threadIdx.x;
-  for (int e = tid; e < K * 96; e += 256) W[e] = w[e];
+  for (int e = tid; e < K * 96; e += NT) W[e] = w[e];
   const int v0 = blockIdx.x * 64;
   const int h = ks / 2;
   // hash probes, four independent lookups in flight per thread (the probes are L2-latency bound)
-  for (int e0 = tid; e0 < 64 * K; e0 += 4 * 256) {
+  for (int e0 = tid; e0 < 64 * K; e0 += 4 * NT) {
     uint64_t key[4];
     uint32_t hh[4];
     int res[4];
     bool open[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      const int e = e0 + u * 256;
+      const int e = e0 + u * NT;
       const int v = e / K, k = e - v * K;
       const int row = v0 + v;
       res[u] = -1;
@@ -599,14 +600,15 @@ __global__ void __launch_bounds__(256) k_stem(const int32_t* __restrict__ xyzb, 
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u)
-      if (e0 + u * 256 < 64 * K) nb[e0 + u * 256] = res[u];
+      if (e0 + u * NT < 64 * K) nb[e0 + u * NT] = res[u];
   }
   __syncthreads();
-  const int v = tid >> 2, cg = tid & 3;
+  constexpr int TPV = NT / 64, CPT = 32 / TPV;
+  const int v = tid / TPV, cg = tid % TPV;
   const int row = v0 + v;
-  float acc[8];
+  float acc[CPT];
 #pragma unroll
-  for (int c = 0; c < 8; ++c) acc[c] = 0.f;
+  for (int c = 0; c < CPT; ++c) acc[c] = 0.f;
   // neighbour features: five gathers in flight per thread (missing neighbours read row 0 and are masked)
   for (int k0 = 0; k0 < K; k0 += 5) {
     int r[5];
@@ -618,15 +620,15 @@ __global__ void __launch_bounds__(256) k_stem(const int32_t* __restrict__ xyzb, 
 #pragma unroll
     for (int u = 0; u < 5; ++u) {
       if (r[u] < 0) continue;
-      const float* wk = W + (k0 + u) * 96 + cg * 8;
+      const float* wk = W + (k0 + u) * 96 + cg * CPT;
 #pragma unroll
-      for (int c = 0; c < 8; ++c) acc[c] += f[u][0] * wk[c] + f[u][1] * wk[32 + c] + f[u][2] * wk[64 + c];
+      for (int c = 0; c < CPT; ++c) acc[c] += f[u][0] * wk[c] + f[u][1] * wk[32 + c] + f[u][2] * wk[64 + c];
     }
   }
   if (row < n) {
 #pragma unroll
-    for (int c = 0; c < 8; ++c) {
-      const int col = cg * 8 + c;
+    for (int c = 0; c < CPT; ++c) {
+      const int col = cg * CPT + c;
       float y = acc[c] * (scale ? scale[col] : 1.f) + (shift ? shift[col] : 0.f);
       if (relu) y = fmaxf(y, 0.f);
       out[(size_t)row * ldo + col] = y;
@@ -955,7 +957,8 @@ extern "C" int a3d_program_run(const a3d_scene* s, const a3d_buf_desc* bufs, int
       const int ks = o.kernel_volume == 125 ? 5 : 3;
       const size_t lds = (size_t)o.kernel_volume * 96 * 4 + (size_t)64 * o.kernel_volume * 4;
       ProfScope ps(st, A3D_PROF_STEM, 0, o.kernel_volume, 3, 32, lv.n);
-      k_stem<<<(lv.n + 63) / 64, 256, lds, st>>>(lv.xyzb, lv.n, lv.hkeys, lv.hvals, lv.hmask, feats4, o.w_dev, ks,
+      // 8 waves per 64-voxel workgroup (measured: 4 waves 229 us, 8 waves 164 us, 16 waves 159 us)
+      k_stem<512><<<(lv.n + 63) / 64, 512, lds, st>>>(lv.xyzb, lv.n, lv.hkeys, lv.hvals, lv.hmask, feats4, o.w_dev, ks,
                                                 o.scale_dev, o.shift_dev, o.relu, out, ldo, zero_row);
       A3D_LAUNCH_CHECK();
       continue;
