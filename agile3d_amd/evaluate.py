@@ -79,6 +79,121 @@ def Evaluate(model, data_loader, args, device, on_round=None):
     return results_file
 
 
+def EvaluateSingle(model, data_loader, args, device, on_round=None):
+    """eval_single_obj.py:76-173: the single-object protocol -- one target object per sample (labels are 0/1), click
+    dicts {'0': [], '1': []}, one new click per round up to ``args.max_num_clicks``; rows of
+    ``val_results_single.csv`` are ``<instance idx> <scene> <object id> <num clicks> <IoU>``.  Returns the results
+    dict of EvaluatorSO when ``args.val_list`` and ``args.val_list_classes`` are set, else the CSV path."""
+    model.eval()
+    os.makedirs(args.output_dir, exist_ok=True)
+    results_file = os.path.join(args.output_dir, "val_results_single.csv")
+    instance_counter = 0
+    with open(results_file, "w") as f:
+        for batch in data_loader:
+            coords, raw_coords, feats, labels, labels_full, inverse_map, _click_idx, scene_name, object_id = batch
+            coords = coords.to(device)
+            raw_coords = raw_coords.to(device)
+            labels = [l.to(device) for l in labels]
+            labels_full = [l.to(device) for l in labels_full]
+            inverse_map = [(m if torch.is_tensor(m) else torch.as_tensor(np.asarray(m))).to(device)
+                           for m in inverse_map]
+            data = SparseTensor(coordinates=coords, features=feats, device=device)
+            batch_idx = coords[:, 0]
+            n_samples = int(batch_idx.max()) + 1
+            masks = [batch_idx == i for i in range(n_samples)]
+            click_idx = [{"0": [], "1": []} for _ in range(n_samples)]
+            click_time_idx = copy.deepcopy(click_idx)
+            backbone_out = model.forward_backbone(data, raw_coordinates=raw_coords)
+            for current in range(args.max_num_clicks + 1):
+                if current:
+                    logits = model.forward_mask(*backbone_out, click_idx=click_idx,
+                                                click_time_idx=click_time_idx)["pred_masks"]
+                for idx in range(n_samples):
+                    if current == 0:
+                        pred = torch.zeros(labels[idx].shape[0], dtype=torch.int32, device=device)
+                    else:
+                        pred = argmax_labels(logits[idx], click_idx[idx])
+                    iou, _ = mean_iou_scene(pred, labels_full[idx], inverse_map[idx])
+                    f.write(f"{instance_counter + idx} {scene_name[idx].replace('scene', '')} {object_id[idx]} "
+                            f"{current} {iou.cpu().numpy()}\n")
+                    if on_round is not None:
+                        on_round(idx, current, pred, iou, click_idx[idx], click_time_idx[idx])
+                    new_clicks, _, _, new_time = get_simulated_clicks(pred, labels[idx], raw_coords[masks[idx]],
+                                                                      current, training=False)
+                    if new_clicks is not None:
+                        extend_clicks(click_idx[idx], click_time_idx[idx], new_clicks, new_time)
+            instance_counter += len(object_id)
+    if getattr(args, "val_list", None) and getattr(args, "val_list_classes", None):
+        return EvaluatorSO(getattr(args, "dataset", None), args.val_list, args.val_list_classes, results_file,
+                           [0.5, 0.65, 0.8, 0.85, 0.9], label_all=getattr(args, "label_all", None)).eval_results()
+    return results_file
+
+
+class EvaluatorSO:
+    """evaluation/evaluator_SO.py:10-155: NoC@q / IoU@k of the single-object protocol, accumulated class by class
+    over ``label_all`` (the reference takes it from ``evaluation/labels.py[dataset]``, a table of class names that is
+    data of the benchmark, not code: pass it in; default = the classes present in the class list file).  Objects are
+    rows ``(scene, object id)`` of ``object_list_file`` (.npy) with their class in ``object_classes_list_file``."""
+
+    def __init__(self, dataset, object_list_file, object_classes_list_file, result_file, MAX_IOU, label_all=None):
+        self.dataset = dataset
+        self.MAX_IOU = MAX_IOU
+        self.dataset_list = np.load(object_list_file)
+        self.dataset_classes = np.loadtxt(object_classes_list_file, dtype=str)
+        self.label_all = list(label_all) if label_all is not None else sorted(set(self.dataset_classes.tolist()))
+        self.result_file = result_file
+
+    def eval_per_class(self, label=None, MAX_IOU=0.8, dataset_=None, dataset_classes=None,
+                       exclude_classes=("wall", "ceiling", "floor", "unlabelled", "unlabeled")):
+        dataset_ = self.dataset_list if dataset_ is None else dataset_
+        dataset_classes = self.dataset_classes if dataset_classes is None else dataset_classes
+        if exclude_classes:
+            keep = np.isin(dataset_classes, list(exclude_classes), invert=True)
+            dataset_, dataset_classes = dataset_[keep], dataset_classes[keep]
+        if label:
+            dataset_ = dataset_[dataset_classes == label]
+        wanted = {row[0].replace("scene", "") + "_" + row[1] for row in dataset_}
+        first_hit, iou_sum, rows_at = {}, {}, {}
+        with open(self.result_file) as fh:
+            for line in fh:
+                parts = line.rstrip().split(" ")
+                if len(parts) < 5:
+                    continue
+                key = parts[1].replace("scene", "") + "_" + parts[2]
+                if key not in wanted:
+                    continue
+                clicks_s, iou = parts[3], float(parts[4])
+                if key not in first_hit and (iou >= MAX_IOU or (int(clicks_s) >= 20 and iou >= 0)):
+                    first_hit[key] = float(clicks_s)
+                rows_at[clicks_s] = rows_at.get(clicks_s, 0) + 1
+                iou_sum[clicks_s] = iou_sum.get(clicks_s, 0) + iou
+        if not first_hit:
+            print("no objects to eval")
+            return 0
+        ordered = list(first_hit.values())
+        return ordered, sum(ordered), len(ordered), iou_sum, rows_at
+
+    def eval_results(self):
+        noc = {}
+        iou_sum = rows_at = None
+        for q in self.MAX_IOU:
+            clicks = objects = 0
+            iou_sum, rows_at = {}, {}
+            for label in set(self.label_all):
+                _, c, o, isum, rows = self.eval_per_class(label, q, self.dataset_list, self.dataset_classes,
+                                                          exclude_classes=None)
+                clicks, objects = clicks + c, objects + o
+                for k in isum:
+                    iou_sum[k] = iou_sum.get(k, 0) + isum[k]
+                    rows_at[k] = rows_at.get(k, 0) + rows[k]
+            noc[q] = clicks / objects
+        results = {f"NoC@{int(round(100 * q))}": noc[q] for q in (0.5, 0.65, 0.8, 0.85, 0.9)}
+        for k in (1, 2, 3, 5, 10, 15):
+            results[f"IoU@{k}"] = iou_sum[str(k)] / rows_at[str(k)]
+        print(results)
+        return results
+
+
 class EvaluatorMO:
     """evaluation/evaluator_MO.py:10-139: NoC@q (clicks per object until the scene's mean IoU reaches q,
     capped at the first row with >= 20 clicks) and IoU@k (mean IoU after exactly k clicks per object)."""

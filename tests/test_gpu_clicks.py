@@ -256,3 +256,30 @@ def test_evaluate_full_protocol(tmp_path):
     assert seen[-1][1] > 64                                                # the wide (>64 query) path ran
     assert set(res) == {"NoC@50", "NoC@65", "NoC@80", "NoC@85", "NoC@90", "IoU@1", "IoU@3", "IoU@5", "IoU@10", "IoU@15"}
     assert all(0.0 <= res[k] <= 1.0 for k in res if k.startswith("IoU")) and all(1.0 <= res[k] <= 20.0 for k in res if k.startswith("NoC"))
+
+
+def test_evaluate_single_object_protocol(tmp_path):
+    """eval_single_obj.py's loop: binary labels, one click per round, rows '<idx> <scene> <object id> <clicks> <IoU>';
+    every row's IoU is re-derived with the oracle from the prediction the product used."""
+    from agile3d_amd.evaluate import EvaluateSingle
+    torch.manual_seed(0)
+    model = randomize_bn_stats(build_model(default_args())).eval().cuda()
+    sc = make_scene(4000, seed=6)
+    n = len(sc["coords"])
+    big = max((i for i in np.unique(sc["labels"]) if i > 0), key=lambda i: (sc["labels"] == i).sum())
+    labels = (sc["labels"] == big).astype(np.int64)
+    batch = (torch.from_numpy(sc["coords"]), torch.from_numpy(sc["raw_xyz"]), torch.from_numpy(sc["feats"]),
+             [torch.from_numpy(labels)], [torch.from_numpy(labels)], [torch.arange(n)], None, ["scene0011_00"], ["7"])
+    args = types.SimpleNamespace(output_dir=str(tmp_path), max_num_clicks=6, val_list=None)
+    log = []
+    random.seed(4)
+    csv = EvaluateSingle(model, [batch], args, torch.device("cuda"),
+                         lambda idx, cur, pred, iou, ci, ct: log.append((cur, pred.cpu().clone(), np.float32(iou.numpy()),
+                                                                        {k: list(v) for k, v in ci.items()})))
+    lines = open(csv).read().strip().split("\n")
+    assert [r[0] for r in log] == list(range(7)) and len(lines) == 7
+    for (cur, pred, iou, ci), line in zip(log, lines):
+        want, _ = oc.mean_iou_scene(pred.long(), torch.from_numpy(labels))
+        assert iou == np.float32(want.numpy()) and line == f"0 0011_00 7 {cur} {iou}"
+        assert sum(len(v) for v in ci.values()) == cur and set(ci) == {"0", "1"}
+    assert log[1][3]["1"] and not log[1][3]["0"]            # the first click lands on the object

@@ -101,3 +101,22 @@ def test_extend_clicks_host_matches_oracle():
     got = extend_clicks(copy.deepcopy(a), copy.deepcopy(t), new, new_t)
     want = oc.extend_clicks(copy.deepcopy(a), copy.deepcopy(t), new, new_t)
     assert got == want == ({"0": [5], "1": [7, 9, 4], "2": [11]}, {"0": [2], "1": [0, 1, 4], "2": [3]})
+
+
+def test_evaluator_so_golden(tmp_path):
+    """Single-object tables (evaluation/evaluator_SO.py) against the reference's output on a synthetic object list."""
+    from agile3d_amd.evaluate import EvaluatorSO
+    g = json.load(open(os.path.join(HERE, "golden", "evaluator_so_case.json")))
+    np.save(tmp_path / "objs.npy", np.array(g["objects"]))
+    np.savetxt(tmp_path / "classes.txt", np.array(g["classes"]), fmt="%s")
+    (tmp_path / "res.csv").write_text("\n".join(g["lines"]) + "\n")
+    ev = EvaluatorSO("scannet40", str(tmp_path / "objs.npy"), str(tmp_path / "classes.txt"), str(tmp_path / "res.csv"),
+                     [0.5, 0.65, 0.8, 0.85, 0.9], label_all=set(g["classes"]))
+    res = ev.eval_results()
+    assert set(res) == set(g["expected"])
+    for k, v in g["expected"].items():
+        assert abs(res[k] - v) <= 1e-12 * max(1.0, abs(v)), (k, res[k], v)     # the per-class sums add up in set order
+    # default label_all = the classes of the list file -> same numbers
+    res2 = EvaluatorSO(None, str(tmp_path / "objs.npy"), str(tmp_path / "classes.txt"), str(tmp_path / "res.csv"),
+                       [0.5, 0.65, 0.8, 0.85, 0.9]).eval_results()
+    assert all(abs(res2[k] - res[k]) <= 1e-12 for k in res)
