@@ -9,13 +9,14 @@
 //   * voxels are sorted by a 64-bit Morton key (batch | z y x interleaved); siblings of a
 //     coarse voxel are then contiguous, so each coarser level is a run-length compaction of
 //     the finer one (one scan per level, no hash insert races, deterministic row ids);
-//   * inside super tiles of 1024 Morton-consecutive rows, rows are re-ordered by their 27-bit
-//     neighbour-presence pattern, so that a 16-row MFMA group mostly shares one pattern and the
-//     implicit-GEMM kernel can skip absent kernel offsets per group (42 % -> ~85 % useful MFMAs);
+//   * the rows of every level are then re-ordered by their 27-bit neighbour-presence pattern (one stable
+//     radix sort over all levels, ties keep Morton order), so that a 16-row MFMA group shares one pattern and
+//     the implicit-GEMM kernel can skip absent kernel offsets per group (27 -> 11.7 offsets per group);
 //   * kernel maps are output-major neighbour tables int32[K][npad] (k-major: the 128 rows of a
 //     workgroup tile are contiguous for every offset) with "missing" = the all-zero row n.
 #include "common.h"
 #include <rocprim/rocprim.hpp>
+#include <algorithm>
 #include <stdarg.h>
 #include <stdlib.h>
 
@@ -93,33 +94,6 @@ __device__ inline int block_incl_scan(int v, int* lds, int* total) {
 }
 
 // ------------------------------------------------------------------------------ kernels
-// 64-row conv tiles ordered by cost (number of kernel offsets any of their 4 groups has), most expensive
-// first: a counting sort in one workgroup.  Longest-processing-time-first order for the persistent conv
-// workgroups' tile queue -- the cheap tiles fill the tail.  Ties land in arbitrary order (no result depends
-// on the order tiles are processed in).
-__global__ void __launch_bounds__(1024) k_tile_order(const uint32_t* __restrict__ gmask, int ntile, int* order) {
-  __shared__ int hist[32], base[32];
-  if (threadIdx.x < 32) hist[threadIdx.x] = 0;
-  __syncthreads();
-  for (int t = threadIdx.x; t < ntile; t += 1024) {
-    const uint32_t un = gmask[4 * t] | gmask[4 * t + 1] | gmask[4 * t + 2] | gmask[4 * t + 3];
-    atomicAdd(&hist[__popc(un)], 1);
-  }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    int acc = 0;
-    for (int c = 31; c >= 0; --c) {
-      base[c] = acc;
-      acc += hist[c];
-    }
-  }
-  __syncthreads();
-  for (int t = threadIdx.x; t < ntile; t += 1024) {
-    const uint32_t un = gmask[4 * t] | gmask[4 * t + 1] | gmask[4 * t + 2] | gmask[4 * t + 3];
-    order[atomicAdd(&base[__popc(un)], 1)] = t;
-  }
-}
-
 // sizes_dev: [0..4] level sizes, [5] error code, [6] number of batch segments, [7] largest batch index,
 // [8 + b] first row of batch sample b (-1 = absent)
 __global__ void k_make_keys(const int32_t* __restrict__ coords4, int n, uint64_t* keys, int* vals,
@@ -198,74 +172,229 @@ __global__ void __launch_bounds__(1024) k_head_write(const uint64_t* __restrict_
   }
 }
 
-__global__ void k_fill_u64(uint64_t* p, size_t n, uint64_t v) {
-  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) p[i] = v;
-}
-__global__ void k_fill_i32(int* p, size_t n, int v) {
-  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) p[i] = v;
+// ---- per-level table kernels, batched over levels -------------------------------------------------------
+// The phase-2 kernels are tiny (a level has 140 .. 80 k rows) and launch-bound, so each of them is launched ONCE for
+// all levels: the block index selects the level (S.blk = block prefix per level), the rest is the per-level kernel.
+struct LevelSet {
+  Level lv[A3D_NUM_LEVELS];
+  int* nbrM[A3D_NUM_LEVELS];   // [27][npad] neighbour rows in Morton order
+  int off[A3D_NUM_LEVELS + 1]; // start of every level in the concatenated row list of the sorts
+  int blk[A3D_NUM_LEVELS + 1]; // first block of every level in THIS launch
+  int nlev;                    // levels taking part in this launch
+  int st_shift, level_shift;
+  uint64_t* cat_keys;
+  int *cat_vals, *cat_sorted;
+};
+__device__ __forceinline__ int ls_level(const LevelSet& S, int& local_block) {
+  int L = 0;
+  while (L + 1 < S.nlev && (int)blockIdx.x >= S.blk[L + 1]) ++L;
+  local_block = blockIdx.x - S.blk[L];
+  return L;
 }
 
-__global__ void k_hash_insert(const uint64_t* __restrict__ keys, int n, uint64_t* hk, int* hv,
-                              uint32_t hmask) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const uint64_t key = keys[i];
-  uint32_t h = hash64(key) & hmask;
-  for (uint32_t probe = 0; probe <= hmask; ++probe) {
+// hash table of a level: fill with the empty key, then insert (two launches: the fill must be complete first)
+__global__ void k_hash_clear(const LevelSet S) {
+  int lb;
+  const Level& lv = S.lv[ls_level(S, lb)];
+  const uint32_t i = lb * blockDim.x + threadIdx.x;
+  if (i <= lv.hmask) lv.hkeys[i] = kEmptyKey;
+}
+__global__ void k_hash_insert(const LevelSet S) {
+  int lb;
+  const Level& lv = S.lv[ls_level(S, lb)];
+  const int i = lb * blockDim.x + threadIdx.x;
+  if (i >= lv.n) return;
+  const uint64_t key = lv.keys[i];
+  uint32_t h = hash64(key) & lv.hmask;
+  for (uint32_t probe = 0; probe <= lv.hmask; ++probe) {
     const unsigned long long prev =
-        atomicCAS((unsigned long long*)&hk[h], (unsigned long long)kEmptyKey, (unsigned long long)key);
+        atomicCAS((unsigned long long*)&lv.hkeys[h], (unsigned long long)kEmptyKey, (unsigned long long)key);
     if (prev == kEmptyKey || prev == key) {
-      hv[h] = i;
+      lv.hvals[h] = i;
       return;
     }
-    h = (h + 1) & hmask;
+    h = (h + 1) & lv.hmask;
   }
 }
 
-// 3^3 neighbours in Morton row ids: nbrM[k][npad] (-1 = missing); one thread per (row, offset)
-__global__ void k_nbr_morton(const uint64_t* __restrict__ keys, int n, int npad, int L,
-                             const uint64_t* __restrict__ hk, const int* __restrict__ hv,
-                             uint32_t hmask, int* nbrM) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+// 3^3 neighbours in Morton row ids: nbrM[k][npad] (-1 = missing); one thread per (row, offset = blockIdx.y)
+__global__ void k_nbr_morton(const LevelSet S) {
+  int lb;
+  const int L = ls_level(S, lb);
+  const Level& lv = S.lv[L];
+  const int i = lb * blockDim.x + threadIdx.x;
   const int k = blockIdx.y;
-  if (i >= n) return;
+  if (i >= lv.n) return;
   int r = i;
   if (k != 13) {
     int b, X, Y, Z;
-    decode_key(keys[i], L, b, X, Y, Z);
+    decode_key(lv.keys[i], L, b, X, Y, Z);
     const int lim = kCoordOff >> L;
     const int x = X + k % 3 - 1, y = Y + (k / 3) % 3 - 1, z = Z + k / 9 - 1;  // x fastest
     r = -1;
     if (x >= -lim && x < lim && y >= -lim && y < lim && z >= -lim && z < lim)
-      r = hash_lookup(hk, hv, hmask, make_key(b, x, y, z, L));
+      r = hash_lookup(lv.hkeys, lv.hvals, lv.hmask, make_key(b, x, y, z, L));
   }
-  nbrM[(size_t)k * npad + i] = r;
+  S.nbrM[L][(size_t)k * lv.npad + i] = r;
 }
-// 27-bit presence mask per row (the sort key of the row clustering)
 // Rows are re-ordered inside super tiles of 2^st_shift consecutive rows by a small key (the 27-bit neighbour
 // presence mask / the child slot): ALL levels go through one stable device-wide radix sort of
-//   key = level << 45 | super tile << 27 | small key,   value = position in the concatenated row list.
-__global__ void k_mask27(const int* __restrict__ nbrM, int n, int npad, int level, int off, int st_shift,
-                         uint64_t* cat_keys, int* cat_vals) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
+//   key = level << (27 + super-tile bits) | super tile << 27 | small key,   value = position in the concatenated row list.
+__global__ void k_mask27(const LevelSet S) {
+  int lb;
+  const int L = ls_level(S, lb);
+  const Level& lv = S.lv[L];
+  const int i = lb * blockDim.x + threadIdx.x;
+  if (i >= lv.n) return;
   uint32_t m = 0;
 #pragma unroll
-  for (int k = 0; k < 27; ++k) m |= (nbrM[(size_t)k * npad + i] >= 0 ? 1u : 0u) << k;
-  cat_keys[off + i] = ((uint64_t)level << 45) | ((uint64_t)(i >> st_shift) << 27) | m;
-  cat_vals[off + i] = off + i;
+  for (int k = 0; k < 27; ++k) m |= (S.nbrM[L][(size_t)k * lv.npad + i] >= 0 ? 1u : 0u) << k;
+  S.cat_keys[S.off[L] + i] = ((uint64_t)L << S.level_shift) | ((uint64_t)(i >> S.st_shift) << 27) | m;
+  S.cat_vals[S.off[L] + i] = S.off[L] + i;
 }
-// sorted segment of one level -> perm (old row -> new row) and inv (new row -> old row)
-__global__ void k_perm_from_sorted(const int* __restrict__ sorted_vals, int n, int off, int* perm, int* inv) {
-  const int p = blockIdx.x * blockDim.x + threadIdx.x;
-  if (p >= n) return;
-  const int src = sorted_vals[off + p] - off;
-  perm[src] = p;
-  inv[p] = src;
+// sorted segment of a level -> perm (old row -> new row) and inv (new row -> old row); `up` selects the second
+// sort (virtual rows of the transposed convs: only the new -> old map, up_rows, is kept)
+__global__ void k_perm_from_sorted(const LevelSet S, int up) {
+  int lb;
+  const int L = ls_level(S, lb);
+  const Level& lv = S.lv[L];
+  const int p = lb * blockDim.x + threadIdx.x;
+  if (p >= lv.n) return;
+  const int src = S.cat_sorted[S.off[L] + p] - S.off[L];
+  if (up) {
+    lv.up_rows[p] = src;
+  } else {
+    lv.perm[src] = p;
+    lv.inv[p] = src;
+  }
 }
 
+// nbr27[k][f] in internal row ids (missing / padding -> n) + per-16-row-group presence masks
+__global__ void k_remap_nbr(const LevelSet S) {
+  int lb;
+  const int L = ls_level(S, lb);
+  const Level& lv = S.lv[L];
+  const int f = lb * blockDim.x + threadIdx.x;
+  const int k = blockIdx.y;
+  if (f >= lv.npad) return;
+  int o = lv.n;
+  bool present = false;
+  if (f < lv.n) {
+    const int v = S.nbrM[L][(size_t)k * lv.npad + lv.inv[f]];
+    if (v >= 0) {
+      o = lv.perm[v];
+      present = true;
+    }
+  }
+  lv.nbr27[(size_t)k * lv.npad + f] = o;
+  const unsigned long long bal = __ballot(present);
+  const int lane = threadIdx.x & 63;
+  if ((lane & 15) == 0) {
+    if ((bal >> lane) & 0xffffULL) atomicOr(&lv.gmask27[f >> 4], 1u << k);
+  }
+}
+
+// 64-row conv tiles ordered by cost (number of kernel offsets any of their 4 groups has), most expensive
+// first: a counting sort, one workgroup per level.  Longest-processing-time-first order for the persistent conv
+// workgroups' tile queue -- the cheap tiles fill the tail.  Ties land in arbitrary order (no result depends
+// on the order tiles are processed in).
+__global__ void __launch_bounds__(1024) k_tile_order(const LevelSet S) {
+  __shared__ int hist[32], base[32];
+  const Level& lv = S.lv[blockIdx.x];
+  const uint32_t* gmask = lv.gmask27;
+  const int ntile = lv.npad / 64;
+  if (threadIdx.x < 32) hist[threadIdx.x] = 0;
+  __syncthreads();
+  for (int t = threadIdx.x; t < ntile; t += 1024) {
+    const uint32_t un = gmask[4 * t] | gmask[4 * t + 1] | gmask[4 * t + 2] | gmask[4 * t + 3];
+    atomicAdd(&hist[__popc(un)], 1);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int acc = 0;
+    for (int c = 31; c >= 0; --c) {
+      base[c] = acc;
+      acc += hist[c];
+    }
+  }
+  __syncthreads();
+  for (int t = threadIdx.x; t < ntile; t += 1024) {
+    const uint32_t un = gmask[4 * t] | gmask[4 * t + 1] | gmask[4 * t + 2] | gmask[4 * t + 3];
+    lv.order27[atomicAdd(&base[__popc(un)], 1)] = t;
+  }
+}
+
+// coordinates in the new row order + hash values -> new rows (one launch over max(n, capacity) per level)
+__global__ void k_xyzb_hashfix(const LevelSet S) {
+  int lb;
+  const int L = ls_level(S, lb);
+  const Level& lv = S.lv[L];
+  const uint32_t f = lb * blockDim.x + threadIdx.x;
+  if ((int)f < lv.n) {
+    int b, X, Y, Z;
+    decode_key(lv.keys[lv.inv[f]], L, b, X, Y, Z);
+    lv.xyzb[4 * f + 0] = X;
+    lv.xyzb[4 * f + 1] = Y;
+    lv.xyzb[4 * f + 2] = Z;
+    lv.xyzb[4 * f + 3] = b;
+  }
+  if (f <= lv.hmask && lv.hkeys[f] != kEmptyKey) lv.hvals[f] = lv.perm[lv.hvals[f]];
+}
+
+// child8[slot][coarse row] = fine row (fine level L, coarse L+1), initialised to "missing" = n_fine by k_child_clear
+__global__ void k_child_clear(const LevelSet S) {
+  int lb;
+  const int L = ls_level(S, lb);
+  const size_t i = (size_t)lb * blockDim.x + threadIdx.x;
+  if (i < (size_t)8 * S.lv[L + 1].npad) S.lv[L].child8[i] = S.lv[L].n;
+}
+// ... and the child-slot sort key of every fine row (second radix sort)
+__global__ void k_child(const LevelSet S) {
+  int lb;
+  const int L = ls_level(S, lb);
+  const Level& f = S.lv[L];
+  const Level& c = S.lv[L + 1];
+  const int i = lb * blockDim.x + threadIdx.x;
+  if (i >= f.n) return;
+  {   // i as a Morton row of the fine level
+    const int slot = (int)(f.keys[i] & 7);
+    const int pf = c.perm[f.parentM[i]];
+    f.child8[(size_t)slot * c.npad + pf] = f.perm[i];
+    // up to 128 children set the same 8 bits of a group word: skip the atomic when the bit is already visible
+    if (!(__builtin_nontemporal_load(&f.gmask_down[pf >> 4]) & (1u << slot))) atomicOr(&f.gmask_down[pf >> 4], 1u << slot);
+  }
+  {   // i as an internal row of the fine level
+    S.cat_keys[S.off[L] + i] = ((uint64_t)L << S.level_shift) | ((uint64_t)(i >> S.st_shift) << 27) | (f.keys[f.inv[i]] & 7);
+    S.cat_vals[S.off[L] + i] = S.off[L] + i;
+  }
+}
+
+// transposed-conv tables over virtual rows v (fine rows sorted by child slot inside super tiles)
+__global__ void k_up(const LevelSet S) {
+  int lb;
+  const int L = ls_level(S, lb);
+  const Level& f = S.lv[L];
+  const Level& c = S.lv[L + 1];
+  const int v = lb * blockDim.x + threadIdx.x;
+  if (v >= f.npad) return;
+  int slot = -1, pf = c.n;
+  if (v < f.n) {
+    const int m = f.inv[f.up_rows[v]];
+    slot = (int)(f.keys[m] & 7);
+    pf = c.perm[f.parentM[m]];
+    atomicOr(&f.gmask_up[v >> 4], 1u << slot);
+  }
+#pragma unroll
+  for (int s = 0; s < 8; ++s) f.up8[(size_t)s * f.npad + v] = (s == slot) ? pf : c.n;
+}
+
+__global__ void k_orig_row(const int* __restrict__ vals_sorted, const int* __restrict__ inv0, int n,
+                           int* orig_row) {
+  const int f = blockIdx.x * blockDim.x + threadIdx.x;
+  if (f < n) orig_row[f] = vals_sorted[inv0[f]];
+}
+
+// ------------------------------------------------------------------------------ host side
 static int super_tile_shift() {   // log2 of the super-tile size, A3D_SUPERTILE = rows (power of two), default kSuperTile
   static int sh = -1;
   if (sh < 0) {
@@ -279,93 +408,6 @@ static int super_tile_shift() {   // log2 of the super-tile size, A3D_SUPERTILE 
   return sh;
 }
 
-// nbr27[k][f] in internal row ids (missing / padding -> n) + per-16-row-group presence masks
-__global__ void k_remap_nbr(const int* __restrict__ nbrM, const int* __restrict__ perm,
-                            const int* __restrict__ inv, int n, int npad, int* nbr27,
-                            uint32_t* gmask27) {
-  const int f = blockIdx.x * blockDim.x + threadIdx.x;
-  const int k = blockIdx.y;
-  if (f >= npad) return;
-  int o = n;
-  bool present = false;
-  if (f < n) {
-    const int v = nbrM[(size_t)k * npad + inv[f]];
-    if (v >= 0) {
-      o = perm[v];
-      present = true;
-    }
-  }
-  nbr27[(size_t)k * npad + f] = o;
-  const unsigned long long bal = __ballot(present);
-  const int lane = threadIdx.x & 63;
-  if ((lane & 15) == 0) {
-    if ((bal >> lane) & 0xffffULL) atomicOr(&gmask27[f >> 4], 1u << k);
-  }
-}
-
-__global__ void k_xyzb(const uint64_t* __restrict__ keys, const int* __restrict__ inv, int n, int L,
-                       int32_t* xyzb) {
-  const int f = blockIdx.x * blockDim.x + threadIdx.x;
-  if (f >= n) return;
-  int b, X, Y, Z;
-  decode_key(keys[inv[f]], L, b, X, Y, Z);
-  xyzb[4 * f + 0] = X;
-  xyzb[4 * f + 1] = Y;
-  xyzb[4 * f + 2] = Z;
-  xyzb[4 * f + 3] = b;
-}
-
-__global__ void k_hash_fix(const uint64_t* __restrict__ hk, int* hv, uint32_t cap,
-                           const int* __restrict__ perm) {
-  const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
-  if (s < cap && hk[s] != kEmptyKey) hv[s] = perm[hv[s]];
-}
-
-// child8[slot][coarse row] = fine row  (fine level L, coarse L+1)
-__global__ void k_child(const uint64_t* __restrict__ keysF, const int* __restrict__ parentM,
-                        const int* __restrict__ permF, const int* __restrict__ permC, int nF,
-                        int npadC, int* child8, uint32_t* gmask_down) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= nF) return;
-  const int slot = (int)(keysF[i] & 7);
-  const int pf = permC[parentM[i]];
-  child8[(size_t)slot * npadC + pf] = permF[i];
-  atomicOr(&gmask_down[pf >> 4], 1u << slot);
-}
-
-__global__ void k_slot_key(const uint64_t* __restrict__ keysF, const int* __restrict__ invF, int nF, int level,
-                           int off, int st_shift, uint64_t* cat_keys, int* cat_vals) {
-  const int f = blockIdx.x * blockDim.x + threadIdx.x;
-  if (f >= nF) return;
-  cat_keys[off + f] = ((uint64_t)level << 45) | ((uint64_t)(f >> st_shift) << 27) | (keysF[invF[f]] & 7);
-  cat_vals[off + f] = off + f;
-}
-
-// transposed-conv tables over virtual rows v (fine rows sorted by child slot inside super tiles)
-__global__ void k_up(const uint64_t* __restrict__ keysF, const int* __restrict__ invF,
-                     const int* __restrict__ parentM, const int* __restrict__ permC,
-                     const int* __restrict__ up_rows, int nF, int npadF, int nC, int* up8,
-                     uint32_t* gmask_up) {
-  const int v = blockIdx.x * blockDim.x + threadIdx.x;
-  if (v >= npadF) return;
-  int slot = -1, pf = nC;
-  if (v < nF) {
-    const int m = invF[up_rows[v]];
-    slot = (int)(keysF[m] & 7);
-    pf = permC[parentM[m]];
-    atomicOr(&gmask_up[v >> 4], 1u << slot);
-  }
-#pragma unroll
-  for (int s = 0; s < 8; ++s) up8[(size_t)s * npadF + v] = (s == slot) ? pf : nC;
-}
-
-__global__ void k_orig_row(const int* __restrict__ vals_sorted, const int* __restrict__ inv0, int n,
-                           int* orig_row) {
-  const int f = blockIdx.x * blockDim.x + threadIdx.x;
-  if (f < n) orig_row[f] = vals_sorted[inv0[f]];
-}
-
-// ------------------------------------------------------------------------------ host side
 struct Bump {
   char* base;
   size_t off = 0;
@@ -412,19 +454,32 @@ static void carve_phase1(Bump& b, int n0, Phase1& p) {
 }
 struct Phase2Tmp {
   int* nbrM[A3D_NUM_LEVELS];     // [27][npad] neighbour rows in Morton order, kept until the rows are re-ordered
-  int off[A3D_NUM_LEVELS + 1];   // start of every level in the concatenated row list
   uint64_t *cat_keys, *cat_keys_sorted;
   int *cat_vals, *cat_vals_sorted;
-  int* permU;
+  size_t zero_begin, zero_end;   // workspace byte range of the zero-initialised tables
 };
 static void carve_phase2(Bump& b, const int* sizes, a3d_scene* sc, Phase2Tmp& t) {
-  int maxn = 0;
   for (int L = 0; L < A3D_NUM_LEVELS; ++L) {
     Level& lv = sc->lv[L];
     lv.n = sizes[L];
     lv.npad = (int)round_up(lv.n > 0 ? lv.n : 1, kTileRows);
-    if (lv.npad > maxn) maxn = lv.npad;
   }
+  // tables that start out as zeros sit in one contiguous region (one memset per scene)
+  b.off = align256(b.off);
+  t.zero_begin = b.off;
+  for (int L = 0; L < A3D_NUM_LEVELS; ++L) {
+    Level& lv = sc->lv[L];
+    lv.gmask27 = b.take<uint32_t>(lv.npad / 16);
+    if (L < A3D_NUM_LEVELS - 1) {
+      const int npadC = sc->lv[L + 1].npad;
+      lv.gmask_down = b.take<uint32_t>(npadC / 16);
+      lv.gmask_up = b.take<uint32_t>(lv.npad / 16);
+      lv.up_rows = b.take<int>(lv.npad);
+    }
+  }
+  b.off = align256(b.off);
+  t.zero_end = b.off;
+  int tot = 0;
   for (int L = 0; L < A3D_NUM_LEVELS; ++L) {
     Level& lv = sc->lv[L];
     lv.perm = b.take<int>(lv.npad);
@@ -434,30 +489,20 @@ static void carve_phase2(Bump& b, const int* sizes, a3d_scene* sc, Phase2Tmp& t)
     lv.hkeys = b.take<uint64_t>((size_t)lv.hmask + 1);
     lv.hvals = b.take<int>((size_t)lv.hmask + 1);
     lv.nbr27 = b.take<int>((size_t)27 * lv.npad);
-    lv.gmask27 = b.take<uint32_t>(lv.npad / 16);
     lv.order27 = b.take<int>(lv.npad / 64);
     if (L < A3D_NUM_LEVELS - 1) {
-      const int npadC = (int)round_up(sizes[L + 1] > 0 ? sizes[L + 1] : 1, kTileRows);
+      const int npadC = sc->lv[L + 1].npad;
       lv.child8 = b.take<int>((size_t)8 * npadC);
-      lv.gmask_down = b.take<uint32_t>(npadC / 16);
       lv.up8 = b.take<int>((size_t)8 * lv.npad);
-      lv.gmask_up = b.take<uint32_t>(lv.npad / 16);
-      lv.up_rows = b.take<int>(lv.npad);
     }
+    t.nbrM[L] = b.take<int>((size_t)27 * lv.npad);
+    tot += lv.npad;
   }
   sc->orig_row = b.take<int>(sc->lv[0].npad);
-  int tot = 0;
-  for (int L = 0; L < A3D_NUM_LEVELS; ++L) {
-    t.nbrM[L] = b.take<int>((size_t)27 * sc->lv[L].npad);
-    t.off[L] = tot;
-    tot += sc->lv[L].npad;
-  }
-  t.off[A3D_NUM_LEVELS] = tot;
   t.cat_keys = b.take<uint64_t>(tot);
   t.cat_keys_sorted = b.take<uint64_t>(tot);
   t.cat_vals = b.take<int>(tot);
   t.cat_vals_sorted = b.take<int>(tot);
-  t.permU = b.take<int>(maxn);
 }
 
 }  // namespace a3d
@@ -583,74 +628,76 @@ extern "C" int a3d_scene_create(const int32_t* coords4_dev, int64_t n_voxels, vo
     return A3D_ERR_WORKSPACE;
   }
   ProfScope prof2(st, A3D_PROF_SCENE_TABLES, 0, 0, 0, 0, n0);
-  const int st_shift = super_tile_shift();
-  // the concatenated list is sized by npad per level; only the first n rows of a level carry keys
-  auto sort_cat = [&](int n_levels) -> int {
-    // compact the per-level segments [off[L], off[L]+n_L) into one dense run for the sort
-    int tot = 0;
-    for (int L = 0; L < n_levels; ++L) tot += sc->lv[L].n;
-    size_t tb = p.sort_temp_bytes;
-    A3D_HIP_CHECK(rocprim::radix_sort_pairs(p.sort_temp, tb, t.cat_keys, t.cat_keys_sorted, t.cat_vals, t.cat_vals_sorted,
-                                            (size_t)tot, 0, 48, st, false));
-    return A3D_OK;
-  };
-  int off[A3D_NUM_LEVELS + 1];   // dense offsets (sum of n, not npad)
-  off[0] = 0;
-  for (int L = 0; L < A3D_NUM_LEVELS; ++L) off[L + 1] = off[L] + sc->lv[L].n;
-  // ---- stage A: hash + neighbours in Morton order + sort keys, every level
+  A3D_HIP_CHECK(hipMemsetAsync((char*)workspace_dev + t.zero_begin, 0, t.zero_end - t.zero_begin, st));
+  LevelSet S;
+  memset(&S, 0, sizeof(S));
+  S.st_shift = super_tile_shift();
+  // key = level << (27 + super-tile bits) | super tile << 27 | small key: the sorts only look at the bits in use
+  int tile_bits = 0;
+  while (((sc->lv[0].npad - 1) >> S.st_shift) >> tile_bits) ++tile_bits;
+  S.level_shift = 27 + tile_bits;
+  S.cat_keys = t.cat_keys;
+  S.cat_vals = t.cat_vals;
+  S.cat_sorted = t.cat_vals_sorted;
+  S.off[0] = 0;
   for (int L = 0; L < A3D_NUM_LEVELS; ++L) {
     Level& lv = sc->lv[L];
     lv.keys = p.keys[L];
     lv.parentM = L < A3D_NUM_LEVELS - 1 ? p.parentM[L] : nullptr;
-    const int n = lv.n, npad = lv.npad;
-    const uint32_t cap = lv.hmask + 1;
-    k_fill_u64<<<nblk(cap, T), T, 0, st>>>(lv.hkeys, cap, kEmptyKey);
-    k_hash_insert<<<nblk(n, T), T, 0, st>>>(lv.keys, n, lv.hkeys, lv.hvals, lv.hmask);
-    k_nbr_morton<<<dim3(nblk(n, T), 27), T, 0, st>>>(lv.keys, n, npad, L, lv.hkeys, lv.hvals, lv.hmask, t.nbrM[L]);
-    k_mask27<<<nblk(n, T), T, 0, st>>>(t.nbrM[L], n, npad, L, off[L], st_shift, t.cat_keys, t.cat_vals);
-    A3D_LAUNCH_CHECK();
+    S.lv[L] = lv;
+    S.nbrM[L] = t.nbrM[L];
+    S.off[L + 1] = S.off[L] + lv.n;
   }
+  // one launch per kernel for all levels: blocks [blk[L], blk[L+1]) belong to level L
+  auto blocks = [&](int nlev, auto count) -> unsigned {
+    S.nlev = nlev;
+    S.blk[0] = 0;
+    for (int L = 0; L < nlev; ++L) S.blk[L + 1] = S.blk[L] + (int)nblk((int64_t)count(L), T);
+    return (unsigned)S.blk[nlev];
+  };
+  auto sort_cat = [&](int nlev) -> int {
+    size_t tb = p.sort_temp_bytes;
+    A3D_HIP_CHECK(rocprim::radix_sort_pairs(p.sort_temp, tb, t.cat_keys, t.cat_keys_sorted, t.cat_vals, t.cat_vals_sorted,
+                                            (size_t)S.off[nlev], 0, S.level_shift + 3, st, false));
+    return A3D_OK;
+  };
+  const int NL = A3D_NUM_LEVELS;
+  unsigned g;
+  // ---- stage A: hash, neighbours in Morton order, sort keys
+  g = blocks(NL, [&](int L) { return (int64_t)sc->lv[L].hmask + 1; });
+  k_hash_clear<<<g, T, 0, st>>>(S);
+  g = blocks(NL, [&](int L) { return (int64_t)sc->lv[L].n; });
+  k_hash_insert<<<g, T, 0, st>>>(S);
+  k_nbr_morton<<<dim3(g, 27), T, 0, st>>>(S);
+  k_mask27<<<g, T, 0, st>>>(S);
+  A3D_LAUNCH_CHECK();
   // ---- stage B: ONE stable radix sort re-orders the rows of all levels inside their super tiles
   {
-    int rc = sort_cat(A3D_NUM_LEVELS);
+    int rc = sort_cat(NL);
     if (rc) { delete sc; return rc; }
   }
   // ---- stage C: tables in the new row order
-  for (int L = 0; L < A3D_NUM_LEVELS; ++L) {
-    Level& lv = sc->lv[L];
-    const int n = lv.n, npad = lv.npad;
-    const uint32_t cap = lv.hmask + 1;
-    k_perm_from_sorted<<<nblk(n, T), T, 0, st>>>(t.cat_vals_sorted, n, off[L], lv.perm, lv.inv);
-    A3D_HIP_CHECK(hipMemsetAsync(lv.gmask27, 0, sizeof(uint32_t) * (npad / 16), st));
-    k_remap_nbr<<<dim3(nblk(npad, T), 27), T, 0, st>>>(t.nbrM[L], lv.perm, lv.inv, n, npad, lv.nbr27, lv.gmask27);
-    k_tile_order<<<1, 1024, 0, st>>>(lv.gmask27, npad / 64, lv.order27);
-    k_xyzb<<<nblk(n, T), T, 0, st>>>(lv.keys, lv.inv, n, L, lv.xyzb);
-    k_hash_fix<<<nblk(cap, T), T, 0, st>>>(lv.hkeys, lv.hvals, cap, lv.perm);
-    A3D_LAUNCH_CHECK();
-  }
-  // ---- stage D: stride-2 tables + child-slot sort keys of the fine rows, levels 0..3
-  for (int L = 0; L < A3D_NUM_LEVELS - 1; ++L) {
-    Level& f = sc->lv[L];
-    Level& c = sc->lv[L + 1];
-    k_fill_i32<<<nblk((size_t)8 * c.npad, T), T, 0, st>>>(f.child8, (size_t)8 * c.npad, f.n);
-    A3D_HIP_CHECK(hipMemsetAsync(f.gmask_down, 0, sizeof(uint32_t) * (c.npad / 16), st));
-    k_child<<<nblk(f.n, T), T, 0, st>>>(f.keys, f.parentM, f.perm, c.perm, f.n, c.npad, f.child8, f.gmask_down);
-    k_slot_key<<<nblk(f.n, T), T, 0, st>>>(f.keys, f.inv, f.n, L, off[L], st_shift, t.cat_keys, t.cat_vals);
-    A3D_LAUNCH_CHECK();
-  }
+  k_perm_from_sorted<<<g, T, 0, st>>>(S, 0);
+  g = blocks(NL, [&](int L) { return (int64_t)sc->lv[L].npad; });
+  k_remap_nbr<<<dim3(g, 27), T, 0, st>>>(S);
+  k_tile_order<<<NL, 1024, 0, st>>>(S);
+  g = blocks(NL, [&](int L) { return std::max<int64_t>(sc->lv[L].n, (int64_t)sc->lv[L].hmask + 1); });
+  k_xyzb_hashfix<<<g, T, 0, st>>>(S);
+  A3D_LAUNCH_CHECK();
+  // ---- stage D: stride-2 tables + child-slot sort keys of the fine rows (levels 0..3), second sort, up tables
+  g = blocks(NL - 1, [&](int L) { return (int64_t)8 * sc->lv[L + 1].npad; });
+  k_child_clear<<<g, T, 0, st>>>(S);
+  g = blocks(NL - 1, [&](int L) { return (int64_t)sc->lv[L].n; });
+  k_child<<<g, T, 0, st>>>(S);
+  A3D_LAUNCH_CHECK();
   {
-    int rc = sort_cat(A3D_NUM_LEVELS - 1);
+    int rc = sort_cat(NL - 1);
     if (rc) { delete sc; return rc; }
   }
-  for (int L = 0; L < A3D_NUM_LEVELS - 1; ++L) {
-    Level& f = sc->lv[L];
-    Level& c = sc->lv[L + 1];
-    A3D_HIP_CHECK(hipMemsetAsync(f.up_rows, 0, sizeof(int) * f.npad, st));
-    k_perm_from_sorted<<<nblk(f.n, T), T, 0, st>>>(t.cat_vals_sorted, f.n, off[L], t.permU, f.up_rows);
-    A3D_HIP_CHECK(hipMemsetAsync(f.gmask_up, 0, sizeof(uint32_t) * (f.npad / 16), st));
-    k_up<<<nblk(f.npad, T), T, 0, st>>>(f.keys, f.inv, f.parentM, c.perm, f.up_rows, f.n, f.npad, c.n, f.up8, f.gmask_up);
-    A3D_LAUNCH_CHECK();
-  }
+  k_perm_from_sorted<<<g, T, 0, st>>>(S, 1);
+  g = blocks(NL - 1, [&](int L) { return (int64_t)sc->lv[L].npad; });
+  k_up<<<g, T, 0, st>>>(S);
+  A3D_LAUNCH_CHECK();
   k_orig_row<<<nblk(n0, T), T, 0, st>>>(p.vals_sorted, sc->lv[0].inv, n0, sc->orig_row);
   A3D_LAUNCH_CHECK();
   *out = sc;
