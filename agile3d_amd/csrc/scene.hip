@@ -124,51 +124,70 @@ __global__ void k_check_dups(const uint64_t* __restrict__ keys, int n, int* size
   if (i >= 1 && i < n && keys[i] == keys[i - 1]) atomicMin(&sizes_dev[5], A3D_ERR_DUPLICATE);
 }
 
-// level L -> L+1, pass 1: count run heads per block of 1024 rows
-__global__ void __launch_bounds__(1024) k_head_count(const uint64_t* __restrict__ keys,
-                                                     const int* __restrict__ n_dev, int* blocksums) {
-  __shared__ int lds[17];
-  const int n = *n_dev;
-  const int i = blockIdx.x * 1024 + threadIdx.x;
-  int f = 0;
-  if (i < n) f = (i == 0) || ((keys[i] >> 3) != (keys[i - 1] >> 3));
-  int total;
-  block_incl_scan(f, lds, &total);
-  if (threadIdx.x == 0) blocksums[blockIdx.x] = total;
+// ---- coarser levels: key_{L}(voxel) = key_0 >> 3L, so a row of level L is a run of equal (key_0 >> 3L) in the
+// sorted level-0 keys and ALL four coarser levels come out of one pass over them (3 launches instead of 12):
+// head_L[i] = first element of its level-L run; rank_L(i) = #heads_L in [0, i] - 1 = the level-L row of voxel i.
+struct CoarseOut {
+  uint64_t* keys[A3D_NUM_LEVELS - 1];   // keys[L-1] = level-L keys
+  int* parentM[A3D_NUM_LEVELS - 1];     // parentM[L] : level-L row -> level-(L+1) row
+};
+__device__ __forceinline__ void head_flags(const uint64_t* __restrict__ keys, int n, int i, int (&f)[A3D_NUM_LEVELS - 1]) {
+#pragma unroll
+  for (int L = 1; L < A3D_NUM_LEVELS; ++L) f[L - 1] = 0;
+  if (i < n) {
+    const uint64_t k = keys[i], kp = i > 0 ? keys[i - 1] : 0;
+#pragma unroll
+    for (int L = 1; L < A3D_NUM_LEVELS; ++L) f[L - 1] = (i == 0) || ((k >> (3 * L)) != (kp >> (3 * L)));
+  }
 }
-// exclusive scan of up to nb block sums by one block; writes the grand total
-__global__ void __launch_bounds__(1024) k_scan_blocksums(int* blocksums, int nb, int* total_out) {
+// pass 1: heads per block of 1024 voxels, blocksums[L-1][block]
+__global__ void __launch_bounds__(1024) k_heads_count(const uint64_t* __restrict__ keys, int n, int nb, int* blocksums) {
   __shared__ int lds[17];
+  int f[A3D_NUM_LEVELS - 1];
+  head_flags(keys, n, blockIdx.x * 1024 + threadIdx.x, f);
+#pragma unroll
+  for (int L = 0; L < A3D_NUM_LEVELS - 1; ++L) {
+    int total;
+    block_incl_scan(f[L], lds, &total);
+    if (threadIdx.x == 0) blocksums[L * nb + blockIdx.x] = total;
+  }
+}
+// pass 2: exclusive scan of the block sums of every level (one workgroup per level); level sizes -> sizes_dev[1..4]
+__global__ void __launch_bounds__(1024) k_heads_scan(int* blocksums, int nb, int* sizes_dev) {
+  __shared__ int lds[17];
+  int* bs = blocksums + blockIdx.x * nb;
   int running = 0;
   for (int base = 0; base < nb; base += 1024) {
     const int i = base + threadIdx.x;
-    const int v = i < nb ? blocksums[i] : 0;
+    const int v = i < nb ? bs[i] : 0;
     int total;
     const int s = block_incl_scan(v, lds, &total);
-    if (i < nb) blocksums[i] = running + s - v;
+    if (i < nb) bs[i] = running + s - v;
     running += total;
   }
-  if (threadIdx.x == 0) *total_out = running;
+  if (threadIdx.x == 0) sizes_dev[1 + blockIdx.x] = running;
 }
-__global__ void __launch_bounds__(1024) k_head_write(const uint64_t* __restrict__ keys,
-                                                     const int* __restrict__ n_dev,
-                                                     const int* __restrict__ blockoffs, int* parentM,
-                                                     uint64_t* keys_next) {
+// pass 3: keys of the coarser levels and the row -> parent-row maps
+__global__ void __launch_bounds__(1024) k_heads_write(const uint64_t* __restrict__ keys, int n, int nb,
+                                                      const int* __restrict__ blockoffs, CoarseOut out) {
   __shared__ int lds[17];
-  const int n = *n_dev;
   const int i = blockIdx.x * 1024 + threadIdx.x;
-  int f = 0;
-  uint64_t k3 = 0;
-  if (i < n) {
-    k3 = keys[i] >> 3;
-    f = (i == 0) || (k3 != (keys[i - 1] >> 3));
+  int f[A3D_NUM_LEVELS - 1], rank[A3D_NUM_LEVELS];
+  head_flags(keys, n, i, f);
+  rank[0] = i;
+#pragma unroll
+  for (int L = 0; L < A3D_NUM_LEVELS - 1; ++L) {
+    int total;
+    const int s = block_incl_scan(f[L], lds, &total);
+    rank[L + 1] = blockoffs[L * nb + blockIdx.x] + s - 1;
   }
-  int total;
-  const int s = block_incl_scan(f, lds, &total);
-  if (i < n) {
-    const int pid = blockoffs[blockIdx.x] + s - 1;
-    parentM[i] = pid;
-    if (f) keys_next[pid] = k3;
+  if (i >= n) return;
+  const uint64_t k = keys[i];
+#pragma unroll
+  for (int L = 1; L < A3D_NUM_LEVELS; ++L) {
+    if (f[L - 1]) out.keys[L - 1][rank[L]] = k >> (3 * L);
+    // voxel i is a row of level L-1 iff it heads its level-(L-1) run (every voxel is a row of level 0)
+    if (L == 1 || f[L - 2]) out.parentM[L - 1][rank[L - 1]] = rank[L];
   }
 }
 
@@ -447,7 +466,7 @@ static void carve_phase1(Bump& b, int n0, Phase1& p) {
   p.vals_sorted = b.take<int>(n0);
   for (int L = 0; L < A3D_NUM_LEVELS; ++L) p.keys[L] = b.take<uint64_t>(n0);
   for (int L = 0; L < A3D_NUM_LEVELS - 1; ++L) p.parentM[L] = b.take<int>(n0);
-  p.blocksums = b.take<int>(n0 / 1024 + 2);
+  p.blocksums = b.take<int>((size_t)(A3D_NUM_LEVELS - 1) * (n0 / 1024 + 2));
   p.sizes_dev = b.take<int>(kSizesInts);
   p.sort_temp_bytes = sort_temp_bytes(A3D_NUM_LEVELS * n0 + 1024);   // also used for the concatenated per-level row sorts (sum of n_L <= 5 n0)
   p.sort_temp = b.take<char>(p.sort_temp_bytes);
@@ -589,10 +608,15 @@ extern "C" int a3d_scene_create(const int32_t* coords4_dev, int64_t n_voxels, vo
   k_check_dups<<<nblk(n0, T), T, 0, st>>>(p.keys[0], n0, p.sizes_dev);
   A3D_LAUNCH_CHECK();
   const int nb = (n0 + 1023) / 1024;
-  for (int L = 0; L < A3D_NUM_LEVELS - 1; ++L) {
-    k_head_count<<<nb, 1024, 0, st>>>(p.keys[L], p.sizes_dev + L, p.blocksums);
-    k_scan_blocksums<<<1, 1024, 0, st>>>(p.blocksums, nb, p.sizes_dev + L + 1);
-    k_head_write<<<nb, 1024, 0, st>>>(p.keys[L], p.sizes_dev + L, p.blocksums, p.parentM[L], p.keys[L + 1]);
+  {
+    CoarseOut co;
+    for (int L = 0; L < A3D_NUM_LEVELS - 1; ++L) {
+      co.keys[L] = p.keys[L + 1];
+      co.parentM[L] = p.parentM[L];
+    }
+    k_heads_count<<<nb, 1024, 0, st>>>(p.keys[0], n0, nb, p.blocksums);
+    k_heads_scan<<<A3D_NUM_LEVELS - 1, 1024, 0, st>>>(p.blocksums, nb, p.sizes_dev);
+    k_heads_write<<<nb, 1024, 0, st>>>(p.keys[0], n0, nb, p.blocksums, co);
     A3D_LAUNCH_CHECK();
   }
   if (prof1 >= 0) prof_end(st, prof1);
