@@ -1110,16 +1110,29 @@ __global__ void __launch_bounds__(512) k_query_layer(const QueryMeta* meta, Quer
     xa[q * kQLD + c] = cur[q * kQLD + c] + qpos[q * kQLD + c];
   }
   __syncthreads();
-  qzero<QT>(acc);
-  qmm<QT>(xa, wfa, acc);
-  qstore<QT>(acc, W.c2c_in_b, 16 * wave, 0.25f, false, B.qk, 2 * D, 16 * wave, Q);            // q (pre-scaled)
+  f32x4 accq[QT];
+  qzero<QT>(accq);
+  qmm<QT>(xa, wfa, accq);
   qzero<QT>(acc);
   qmm<QT>(xa, wfb, acc);
-  qstore<QT>(acc, W.c2c_in_b, D + 16 * wave, 1.f, false, B.qk, 2 * D, D + 16 * wave, Q);      // k
-  qload_w(W.c2c_in_wt, D, 2 * D + 16 * wave, 0, wfa);                                         // v rows
-  qzero<QT>(acc);
-  qmm<QT>(cur, wfa, acc);
-  qstore<QT>(acc, W.c2c_in_b, 2 * D + 16 * wave, 1.f, false, B.vc, D, 16 * wave, Q);          // v
+  if constexpr (PART == 0) {
+    // single block: q, k, v stay in LDS (k -> xb, v -> the qpos buffer, which is re-read from global after the
+    // attention; q -> xa once every wave is done reading xa): the attention loop below never touches global memory
+    qstore<QT>(acc, W.c2c_in_b, D + 16 * wave, 1.f, false, xb, kQLD, 16 * wave, Q);             // k
+    qload_w(W.c2c_in_wt, D, 2 * D + 16 * wave, 0, wfa);                                         // v rows
+    qzero<QT>(acc);
+    qmm<QT>(cur, wfa, acc);
+    qstore<QT>(acc, W.c2c_in_b, 2 * D + 16 * wave, 1.f, false, qpos, kQLD, 16 * wave, Q);       // v
+    __syncthreads();                                                                            // xa fully consumed
+    qstore<QT>(accq, W.c2c_in_b, 16 * wave, 0.25f, false, xa, kQLD, 16 * wave, Q);              // q (pre-scaled)
+  } else {
+    qstore<QT>(accq, W.c2c_in_b, 16 * wave, 0.25f, false, B.qk, 2 * D, 16 * wave, Q);           // q (pre-scaled)
+    qstore<QT>(acc, W.c2c_in_b, D + 16 * wave, 1.f, false, B.qk, 2 * D, D + 16 * wave, Q);      // k
+    qload_w(W.c2c_in_wt, D, 2 * D + 16 * wave, 0, wfa);                                         // v rows
+    qzero<QT>(acc);
+    qmm<QT>(cur, wfa, acc);
+    qstore<QT>(acc, W.c2c_in_b, 2 * D + 16 * wave, 1.f, false, B.vc, D, 16 * wave, Q);          // v
+  }
   if constexpr (PART == 1) {
     for (int e = tid; e < QP * 32; e += nt) {
       const int q = e >> 5, c4 = (e & 31) * 4;
@@ -1138,16 +1151,20 @@ __global__ void __launch_bounds__(512) k_query_layer(const QueryMeta* meta, Quer
   }
   qload_w(W.c2c_out_wt, D, 16 * wave, 0, wfa);                      // next round's weights
   __syncthreads();
+  // keys / values of the attention: LDS (PART 0) or the global buffers every block wrote (PART 2)
+  const float* kbase = PART == 0 ? xb : all_qk + D;
+  const float* vbase = PART == 0 ? qpos : all_vc;
+  const int kld = PART == 0 ? kQLD : 2 * D, vld = PART == 0 ? kQLD : D;
   for (int e = tid; e < Q * H; e += nt) {
     const int q = e / H, h = e % H;
     float qv[DH];
 #pragma unroll
-    for (int d = 0; d < DH; ++d) qv[d] = B.qk[(size_t)q * 2 * D + h * DH + d];
+    for (int d = 0; d < DH; ++d) qv[d] = PART == 0 ? xa[q * kQLD + h * DH + d] : B.qk[(size_t)q * 2 * D + h * DH + d];
     float mx = kNegBig;
     for (int k = 0; k < Qall; ++k) {
       float sdot = 0.f;
 #pragma unroll
-      for (int d = 0; d < DH; ++d) sdot += qv[d] * all_qk[(size_t)k * 2 * D + D + h * DH + d];
+      for (int d = 0; d < DH; ++d) sdot += qv[d] * kbase[(size_t)k * kld + h * DH + d];
       mx = fmaxf(mx, sdot);
     }
     float sum = 0.f, o[DH];
@@ -1156,11 +1173,11 @@ __global__ void __launch_bounds__(512) k_query_layer(const QueryMeta* meta, Quer
     for (int k = 0; k < Qall; ++k) {
       float sdot = 0.f;
 #pragma unroll
-      for (int d = 0; d < DH; ++d) sdot += qv[d] * all_qk[(size_t)k * 2 * D + D + h * DH + d];
+      for (int d = 0; d < DH; ++d) sdot += qv[d] * kbase[(size_t)k * kld + h * DH + d];
       const float pw = expf(sdot - mx);
       sum += pw;
 #pragma unroll
-      for (int d = 0; d < DH; ++d) o[d] += pw * all_vc[(size_t)k * D + h * DH + d];
+      for (int d = 0; d < DH; ++d) o[d] += pw * vbase[(size_t)k * vld + h * DH + d];
     }
     const float inv = 1.f / sum;
 #pragma unroll
@@ -1168,6 +1185,14 @@ __global__ void __launch_bounds__(512) k_query_layer(const QueryMeta* meta, Quer
   }
   for (int e = tid; e < (QP - Q) * 128; e += nt) xa[(Q + (e >> 7)) * kQLD + (e & 127)] = 0.f;   // padded rows
   __syncthreads();
+  if constexpr (PART == 0) {   // the qpos buffer held v: restore the position encodings for step 4
+    for (int e = tid; e < QP * 32; e += nt) {
+      const int q = e >> 5, c4 = (e & 31) * 4;
+      f32x4 vp = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (q < Q) vp = *(const f32x4*)(B.qpos + (size_t)q * D + c4);
+      *(f32x4*)(qpos + q * kQLD + c4) = vp;
+    }
+  }
   qzero<QT>(acc);
   qmm<QT>(xa, wfa, acc);
   qstore<QT>(acc, W.c2c_out_b, 16 * wave, 1.f, false, xb, kQLD, 16 * wave, QP);
