@@ -20,7 +20,7 @@ constexpr int kClusterTable = 1 << 15;      // cluster id = 96*label + 11*pred, 
 constexpr unsigned kInfBits = 0x7f800000u;
 constexpr int kQueriesPerThread = 2;
 constexpr int kNearestBlock = 256;
-constexpr int kNearestSplit = 16;           // candidate chunks (grid.y)
+constexpr int kNearestSplit = 128;           // candidate chunks (grid.y): enough waves when only a few thousand points are wrong
 
 // ---- argmax over the 1+K mask logits of every point (first maximum wins, like torch.argmax) ------
 __global__ void k_argmax_labels(const float* __restrict__ logits, int64_t n, int C, int32_t* __restrict__ pred) {

@@ -47,3 +47,17 @@ for r in range(a.rounds):
         pc.extend_clicks(ci, ct, new, nt)
 nq = sum(len(v) for v in ci.values())
 print({k: round(1e3 * v / a.rounds, 3) for k, v in T.items()}, "ms/round;", nq, "clicks at the end; IoU", float(iou))
+
+# GPU time of the click-simulator kernels alone (HIP events around a3d_click_clusters)
+from agile3d_amd import lib as L
+lib = L.load()
+lib.a3d_profile_read(None, 0); lib.a3d_profile_enable(1)
+pred0 = torch.zeros(n, dtype=torch.int32, device="cuda")
+for p_ in (pred0, pred):
+    for _ in range(5):
+        pc.error_clusters(p_, lab, raw)
+torch.cuda.synchronize(); lib.a3d_profile_enable(0)
+buf = (L.ProfEntry * 64)(); k = lib.a3d_profile_read(buf, 64)
+ms = [buf[i].ms for i in range(k) if buf[i].id == 10]
+print("click kernels: round-0 prediction %.3f ms, last prediction %.3f ms (n_err %d / %d)" % (
+    sum(ms[:5]) / 5, sum(ms[5:]) / 5, int((pred != lab).sum()), n))
