@@ -1,15 +1,16 @@
 #!/usr/bin/env python3
 """bench.py -- scenes/s of the AGILE3D hot path on MI355X (BASELINE.json metric).
 
-One *step* = one scene through the whole hot path with inputs already resident in HBM
-(consecutive steps are issued round-robin on --streams HIP streams, default 4 scenes in flight, so one
-scene's latency-bound coarse levels overlap the other's fine-level convolutions; --streams 1 = strictly
-one scene at a time):
-    coordinate manager build (a3d_scene_create) + forward_backbone + ONE forward_mask
-on BASELINE.json configs[1]: a seeded synthetic 80k-voxel scene, 10 clicks (5 objects x 2,
-no background clicks -> 20 queries), fp32, random-init weights with randomised BatchNorm
-statistics.  N GPUs = N independent scenes (one per rank, scene-sharded,
-no data-path collective): weak scaling.
+One *step* = one batch of --batch (default 4) independent scenes through the whole hot path, inputs already
+resident in HBM: ONE batched SparseTensor as the reference's collate builds it (batch index in column 0),
+coordinate manager build (a3d_scene_create) + forward_backbone over the batch + ONE forward_mask (one decoder
+pass per sample).  Every scene is BASELINE.json configs[1]: a seeded synthetic 80k-voxel scene, 10 clicks
+(5 objects x 2, no background clicks -> 20 queries), fp32, random-init weights with randomised BatchNorm
+statistics.  `value` counts SCENES per second.
+Consecutive steps are issued round-robin on --streams HIP streams (default 4 steps in flight), so one step's
+latency-bound coarse levels and scene build overlap another's fine-level convolutions; `--batch 1 --streams 1`
+is strictly one scene at a time.  N GPUs = N ranks with their own scenes (scene-sharded, no data-path
+collective): weak scaling.
 
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
@@ -133,6 +134,8 @@ def main():
     ap.add_argument("--clicks-per-object", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--batch", type=int, default=int(os.environ.get("A3D_BENCH_BATCH", "4")),
+                    help="scenes per step and rank (one batched SparseTensor, as the reference's collate builds)")
     ap.add_argument("--streams", type=int, default=int(os.environ.get("A3D_BENCH_STREAMS", "4")),
                     help="scenes in flight per GPU: consecutive steps are issued round-robin on this many HIP streams")
     args = ap.parse_args()
@@ -166,16 +169,22 @@ def main():
     model = randomize_bn_stats(build_model(default_args())).eval()
     sd = {k: v.clone() for k, v in model.state_dict().items()}
     model = model.to(dev)
-    sc = make_scene(args.voxels, seed=rank)                 # one scene per rank (scene-sharded DP)
-    ci, ct = make_clicks(sc["labels"], args.objects, args.clicks_per_object, 0, seed=rank)
-    coords = torch.from_numpy(sc["coords"]).to(dev)
-    feats = torch.from_numpy(sc["feats"]).to(dev)
-    raw = torch.from_numpy(sc["raw_xyz"]).to(dev)
+    # one step = one batch of --batch scenes (different seeds) per rank, as ME.utils.batched_coordinates would
+    # collate them (datasets/InterMultiObj3DSegDataset.py:129): batch index in column 0, samples contiguous
+    scenes = [make_scene(args.voxels, seed=rank * args.batch + b, batch_index=b) for b in range(args.batch)]
+    clicks = [make_clicks(s_["labels"], args.objects, args.clicks_per_object, 0, seed=rank * args.batch + b)
+              for b, s_ in enumerate(scenes)]
+    sc = scenes[0]
+    ci, ct = clicks[0]
+    cis, cts = [c[0] for c in clicks], [c[1] for c in clicks]
+    coords = torch.from_numpy(np.concatenate([s_["coords"] for s_ in scenes])).to(dev)
+    feats = torch.from_numpy(np.concatenate([s_["feats"] for s_ in scenes])).to(dev)
+    raw = torch.from_numpy(np.concatenate([s_["raw_xyz"] for s_ in scenes])).to(dev)
 
-    def one_scene():
+    def one_scene():       # one STEP: the whole batch through scene build + backbone + one decoder pass per sample
         x = SparseTensor(features=feats, coordinates=coords)
         r = model.forward_backbone(x, raw_coordinates=raw)
-        return model.forward_mask(*r, click_idx=[ci], click_time_idx=[ct])
+        return model.forward_mask(*r, click_idx=cis, click_time_idx=cts)
 
     out0 = one_scene()                      # packs the weights once, on the default stream
     torch.cuda.synchronize()
@@ -197,15 +206,16 @@ def main():
     assert torch.isfinite(out["pred_masks"][0]).all()
 
     res = {
-        "metric": "scenes/s (80k-voxel, 10 clicks)", "value": world * args.steps / dt, "unit": "scenes/s",
+        "metric": "scenes/s (80k-voxel, 10 clicks)", "value": world * args.batch * args.steps / dt, "unit": "scenes/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"synthetic {len(sc['coords'])}-voxel scene, {args.objects * args.clicks_per_object} "
-                               f"clicks ({args.objects} objects x {args.clicks_per_object}), scene build + "
-                               "forward_backbone + 1 forward_mask, fp32, eval",
+        "config": {"workload": f"batch of {args.batch} synthetic {len(sc['coords'])}-voxel scenes, "
+                               f"{args.objects * args.clicks_per_object} clicks each ({args.objects} objects x "
+                               f"{args.clicks_per_object}), scene build + forward_backbone + 1 forward_mask per scene, fp32, eval",
                    "voxels": int(len(sc["coords"])), "queries": args.objects * args.clicks_per_object + 10,
                    "parallelism": f"scene-sharded x{world} (no data-path collective)",
-                   "scenes_in_flight_per_gpu": args.streams},
+                   "scenes_per_step_per_gpu": args.batch, "global_batch": world * args.batch,
+                   "steps_in_flight_per_gpu": args.streams},
     }
 
     if rank == 0 and world == 1:
