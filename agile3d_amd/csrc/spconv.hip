@@ -54,7 +54,7 @@ struct ConvArgs {
   const int* tile_order;      // [n_tiles] order in which 64-row tiles are handed out (most offsets first) or nullptr
   int n_tiles;
   unsigned long long* dbg_cycles;   // [8] phase cycle sums (A3D_DBG & 64)
-  int dbg;                    // A3D_DBG env: 1 no A gather, 2 no W load, 4 no MFMA, 8 no B reads, 16 no stage barrier,
+  int dbg;                    // A3D_DBG env: 1 no A gather, 2 no W load, 4 no MFMA, (8 unused), 16 no stage barrier,
                               // 32 all offsets present, 64 phase cycle sums, 4096 per-tile timeline
 };
 
@@ -247,11 +247,11 @@ __global__ void __launch_bounds__(256, CH >= 64 ? 2 : 3) k_spconv2(const ConvArg
         for (int ct = 0; ct < NCT; ++ct) b[0][ct] = Ws[ct * 64];
 #pragma unroll
         for (int S = 0; S < NS; ++S) {
-          if (S + 1 < NS && !(a.dbg & 8)) {           // next k-step's weight fragments before this one's MFMAs
+          if (S + 1 < NS) {           // next k-step's weight fragments before this one's MFMAs
 #pragma unroll
             for (int ct = 0; ct < NCT; ++ct) b[(S + 1) & 1][ct] = Ws[((S + 1) * NCT + ct) * 64];
           }
-          asm volatile("" ::: "memory");              // ... and no further ahead than that (VGPRs)
+          __builtin_amdgcn_sched_barrier(0);          // ... and no further ahead than that (VGPRs)
           // weights as the A operand: D[i][j] = sum_k W[k][16ct+i] X[row j][k], i.e. lane (g, j) ends up with
           // output channels 16ct+4g..+3 of row j -> 16-byte epilogue accesses
 #pragma unroll

@@ -10,12 +10,15 @@ from agile3d_amd.synthetic import make_clicks, make_scene
 
 torch.manual_seed(0)
 model = randomize_bn_stats(build_model(default_args())).eval().cuda()
-sc = make_scene(80_000, seed=0)
-ci, ct = make_clicks(sc["labels"], 5, 2, 0, seed=0)
-coords, feats, raw = (torch.from_numpy(sc[k]).cuda() for k in ("coords", "feats", "raw_xyz"))
+import numpy as np
+B = int(os.environ.get("LT_BATCH", "1"))
+scs = [make_scene(80_000, seed=b, batch_index=b) for b in range(B)]
+cl = [make_clicks(s["labels"], 5, 2, 0, seed=b) for b, s in enumerate(scs)]
+cis, cts = [c[0] for c in cl], [c[1] for c in cl]
+coords, feats, raw = (torch.from_numpy(np.concatenate([s[k] for s in scs])).cuda() for k in ("coords", "feats", "raw_xyz"))
 def step():
     r = model.forward_backbone(SparseTensor(features=feats, coordinates=coords), raw_coordinates=raw)
-    return model.forward_mask(*r, click_idx=[ci], click_time_idx=[ct])
+    return model.forward_mask(*r, click_idx=cis, click_time_idx=cts)
 for _ in range(3): step()
 scn = Scene(coords)
 pairs = {"n": scn.n, "conv3": []}
