@@ -123,12 +123,25 @@ struct Level {
   int* up8 = nullptr;           // [8][npad]              (levels 0..3)
   uint32_t* gmask_up = nullptr;
   int* up_rows = nullptr;       // [npad]
+  // level 0 only, when the bounding box of the batch is small enough (<= kGridCellsPerVoxel cells per voxel):
+  // dense voxel -> row grid, x fastest, kGridPad empty cells on every side so that a 5^3 neighbourhood of an existing
+  // voxel never leaves it (no bounds checks).  nullptr -> the hash table is used instead.
+  int* grid = nullptr;
+  int gorg[3] = {0, 0, 0};      // coordinate of cell (0, 0, 0)
+  int gdim[3] = {0, 0, 0};
 };
+constexpr int kGridPad = 2;
+constexpr int64_t kGridCellsPerVoxel = 64;
+__device__ __forceinline__ size_t grid_cell(const Level& lv, int b, int x, int y, int z) {
+  return (((size_t)b * lv.gdim[2] + (z - lv.gorg[2])) * lv.gdim[1] + (y - lv.gorg[1])) * lv.gdim[0] + (x - lv.gorg[0]);
+}
 
 }  // namespace a3d
 
 namespace a3d {
-constexpr int kSizesInts = 8 + 1024;   // device-side size/error/batch-start block read back by a3d_scene_create
+constexpr int kBBox = 8 + 1024;        // kBBoxSlots x {min x,y,z, max x,y,z, -, -} of the level-0 coordinates (slot = block % slots:
+constexpr int kBBoxSlots = 64;         // thousands of atomics on six addresses would serialise; the host folds the slots)
+constexpr int kSizesInts = kBBox + 8 * kBBoxSlots;  // device-side size/error/batch-start/bounding-box block read back by a3d_scene_create
 }
 
 struct a3d_scene {

@@ -17,6 +17,7 @@
 #include "common.h"
 #include <rocprim/rocprim.hpp>
 #include <algorithm>
+#include <limits.h>
 #include <stdarg.h>
 #include <stdlib.h>
 
@@ -99,23 +100,48 @@ __device__ inline int block_incl_scan(int v, int* lds, int* total) {
 __global__ void k_make_keys(const int32_t* __restrict__ coords4, int n, uint64_t* keys, int* vals,
                             int* sizes_dev) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const int b = coords4[4 * i + 0], x = coords4[4 * i + 1], y = coords4[4 * i + 2], z = coords4[4 * i + 3];
-  const int lim = kCoordOff;
-  if (b < 0 || b > 1022 || x < -lim || x >= lim || y < -lim || y >= lim || z < -lim || z >= lim) {
-    atomicMin(&sizes_dev[5], A3D_ERR_COORD_RANGE);
-    keys[i] = 0;
+  int lo[3] = {INT_MAX, INT_MAX, INT_MAX}, hi[3] = {INT_MIN, INT_MIN, INT_MIN};
+  if (i < n) {
+    const int b = coords4[4 * i + 0], x = coords4[4 * i + 1], y = coords4[4 * i + 2], z = coords4[4 * i + 3];
+    const int lim = kCoordOff;
     vals[i] = i;
-    return;
+    if (b < 0 || b > 1022 || x < -lim || x >= lim || y < -lim || y >= lim || z < -lim || z >= lim) {
+      atomicMin(&sizes_dev[5], A3D_ERR_COORD_RANGE);
+      keys[i] = 0;
+    } else {
+      keys[i] = make_key(b, x, y, z, 0);
+      lo[0] = hi[0] = x, lo[1] = hi[1] = y, lo[2] = hi[2] = z;
+      // batch samples must be contiguous row ranges (ME.utils.batched_coordinates): record where each starts
+      const int prev = i > 0 ? coords4[4 * (i - 1)] : -1;
+      if (b != prev) {
+        atomicAdd(&sizes_dev[6], 1);
+        atomicMax(&sizes_dev[7], b);
+        if (atomicCAS(&sizes_dev[8 + b], -1, i) != -1) atomicMin(&sizes_dev[5], A3D_ERR_INVALID);
+      }
+    }
   }
-  keys[i] = make_key(b, x, y, z, 0);
-  vals[i] = i;
-  // batch samples must be contiguous row ranges (ME.utils.batched_coordinates): record where each starts
-  const int prev = i > 0 ? coords4[4 * (i - 1)] : -1;
-  if (b != prev) {
-    atomicAdd(&sizes_dev[6], 1);
-    atomicMax(&sizes_dev[7], b);
-    if (atomicCAS(&sizes_dev[8 + b], -1, i) != -1) atomicMin(&sizes_dev[5], A3D_ERR_INVALID);
+  // bounding box of the batch (decides whether level 0 gets a dense voxel grid): wave shuffle -> LDS -> one atomic
+  // pair per workgroup and axis, spread over kBBoxSlots slots
+  __shared__ int blo[3], bhi[3];
+  if (threadIdx.x < 3) blo[threadIdx.x] = INT_MAX, bhi[threadIdx.x] = INT_MIN;
+  __syncthreads();
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+      lo[a] = min(lo[a], __shfl_xor(lo[a], d));
+      hi[a] = max(hi[a], __shfl_xor(hi[a], d));
+    }
+    if ((threadIdx.x & 63) == 0 && lo[a] <= hi[a]) {
+      atomicMin(&blo[a], lo[a]);
+      atomicMax(&bhi[a], hi[a]);
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < 3 && blo[threadIdx.x] <= bhi[threadIdx.x]) {
+    int* slot = sizes_dev + kBBox + 8 * (blockIdx.x % kBBoxSlots);
+    atomicMin(&slot[threadIdx.x], blo[threadIdx.x]);
+    atomicMax(&slot[3 + threadIdx.x], bhi[threadIdx.x]);
   }
 }
 
@@ -216,7 +242,7 @@ __global__ void k_hash_clear(const LevelSet S) {
   int lb;
   const Level& lv = S.lv[ls_level(S, lb)];
   const uint32_t i = lb * blockDim.x + threadIdx.x;
-  if (i <= lv.hmask) lv.hkeys[i] = kEmptyKey;
+  if (i <= lv.hmask && !lv.grid) lv.hkeys[i] = kEmptyKey;
 }
 __global__ void k_hash_insert(const LevelSet S) {
   int lb;
@@ -224,6 +250,12 @@ __global__ void k_hash_insert(const LevelSet S) {
   const int i = lb * blockDim.x + threadIdx.x;
   if (i >= lv.n) return;
   const uint64_t key = lv.keys[i];
+  if (lv.grid) {   // level 0 with a dense grid (cleared to -1 by the host): no hash table
+    int b, X, Y, Z;
+    decode_key(key, 0, b, X, Y, Z);
+    lv.grid[grid_cell(lv, b, X, Y, Z)] = i;
+    return;
+  }
   uint32_t h = hash64(key) & lv.hmask;
   for (uint32_t probe = 0; probe <= lv.hmask; ++probe) {
     const unsigned long long prev =
@@ -251,7 +283,9 @@ __global__ void k_nbr_morton(const LevelSet S) {
     const int lim = kCoordOff >> L;
     const int x = X + k % 3 - 1, y = Y + (k / 3) % 3 - 1, z = Z + k / 9 - 1;  // x fastest
     r = -1;
-    if (x >= -lim && x < lim && y >= -lim && y < lim && z >= -lim && z < lim)
+    if (lv.grid)
+      r = lv.grid[grid_cell(lv, b, x, y, z)];
+    else if (x >= -lim && x < lim && y >= -lim && y < lim && z >= -lim && z < lim)
       r = hash_lookup(lv.hkeys, lv.hvals, lv.hmask, make_key(b, x, y, z, L));
   }
   S.nbrM[L][(size_t)k * lv.npad + i] = r;
@@ -356,8 +390,9 @@ __global__ void k_xyzb_hashfix(const LevelSet S) {
     lv.xyzb[4 * f + 1] = Y;
     lv.xyzb[4 * f + 2] = Z;
     lv.xyzb[4 * f + 3] = b;
+    if (lv.grid) lv.grid[grid_cell(lv, b, X, Y, Z)] = f;
   }
-  if (f <= lv.hmask && lv.hkeys[f] != kEmptyKey) lv.hvals[f] = lv.perm[lv.hvals[f]];
+  if (!lv.grid && f <= lv.hmask && lv.hkeys[f] != kEmptyKey) lv.hvals[f] = lv.perm[lv.hvals[f]];
 }
 
 // child8[slot][coarse row] = fine row (fine level L, coarse L+1), initialised to "missing" = n_fine by k_child_clear
@@ -477,7 +512,7 @@ struct Phase2Tmp {
   int *cat_vals, *cat_vals_sorted;
   size_t zero_begin, zero_end;   // workspace byte range of the zero-initialised tables
 };
-static void carve_phase2(Bump& b, const int* sizes, a3d_scene* sc, Phase2Tmp& t) {
+static void carve_phase2(Bump& b, const int* sizes, a3d_scene* sc, Phase2Tmp& t, int64_t grid_cells) {
   for (int L = 0; L < A3D_NUM_LEVELS; ++L) {
     Level& lv = sc->lv[L];
     lv.n = sizes[L];
@@ -518,6 +553,7 @@ static void carve_phase2(Bump& b, const int* sizes, a3d_scene* sc, Phase2Tmp& t)
     tot += lv.npad;
   }
   sc->orig_row = b.take<int>(sc->lv[0].npad);
+  sc->lv[0].grid = grid_cells > 0 ? b.take<int>((size_t)grid_cells) : nullptr;
   t.cat_keys = b.take<uint64_t>(tot);
   t.cat_keys_sorted = b.take<uint64_t>(tot);
   t.cat_vals = b.take<int>(tot);
@@ -567,7 +603,7 @@ extern "C" size_t a3d_scene_workspace_bytes(int64_t n_voxels) {
   int sizes[A3D_NUM_LEVELS];
   for (int L = 0; L < A3D_NUM_LEVELS; ++L) sizes[L] = n0;  // upper bound: n_L <= n_0
   Phase2Tmp t;
-  carve_phase2(b, sizes, &tmp, t);
+  carve_phase2(b, sizes, &tmp, t, kGridCellsPerVoxel * n0);
   return align256(b.off) + 4096;
 }
 
@@ -598,6 +634,8 @@ extern "C" int a3d_scene_create(const int32_t* coords4_dev, int64_t n_voxels, vo
   int prof1 = prof_enabled() ? prof_begin(st, A3D_PROF_SCENE_SORT, 0, 0, 0, 0, n0) : -1;
   int sizes[kSizesInts];
   for (int i = 0; i < kSizesInts; ++i) sizes[i] = i < 8 ? 0 : -1;
+  for (int sl = 0; sl < kBBoxSlots; ++sl)
+    for (int a = 0; a < 3; ++a) sizes[kBBox + 8 * sl + a] = INT_MAX, sizes[kBBox + 8 * sl + 3 + a] = INT_MIN;
   sizes[0] = n0;
   A3D_HIP_CHECK(hipMemcpyAsync(p.sizes_dev, sizes, sizeof(sizes), hipMemcpyHostToDevice, st));
   k_make_keys<<<nblk(n0, T), T, 0, st>>>(coords4_dev, n0, p.keys_in, p.vals_in, p.sizes_dev);
@@ -644,8 +682,32 @@ extern "C" int a3d_scene_create(const int32_t* coords4_dev, int64_t n_voxels, vo
   for (int bi = 0; bi < n_batch; ++bi) sc->batch_start[bi] = sizes[8 + bi];
   sc->workspace = workspace_dev;
   sc->workspace_bytes = workspace_bytes;
+  // level 0 gets a dense voxel -> row grid when the padded bounding box of the batch has at most
+  // kGridCellsPerVoxel cells per voxel (indoor scans: 15-30); sparser inputs keep the hash table
+  int64_t grid_cells = 0;
+  int gdim[3], gorg[3];
+  {
+    static int use_grid = -1;
+    if (use_grid < 0) {
+      const char* e = getenv("A3D_GRID");
+      use_grid = e ? atoi(e) : 1;
+    }
+    grid_cells = n_batch;
+    for (int a = 0; a < 3; ++a) {
+      int lo = INT_MAX, hi = INT_MIN;
+      for (int sl = 0; sl < kBBoxSlots; ++sl) {
+        lo = std::min(lo, sizes[kBBox + 8 * sl + a]);
+        hi = std::max(hi, sizes[kBBox + 8 * sl + 3 + a]);
+      }
+      gorg[a] = lo - kGridPad;
+      gdim[a] = hi - lo + 1 + 2 * kGridPad;
+      grid_cells = grid_cells <= kGridCellsPerVoxel * n0 ? grid_cells * gdim[a] : grid_cells;
+    }
+    if (!use_grid || grid_cells > kGridCellsPerVoxel * n0) grid_cells = 0;
+  }
   Phase2Tmp t;
-  carve_phase2(b, sizes, sc, t);
+  carve_phase2(b, sizes, sc, t, grid_cells);
+  for (int a = 0; a < 3; ++a) sc->lv[0].gorg[a] = gorg[a], sc->lv[0].gdim[a] = gdim[a];
   if (b.off > workspace_bytes) {
     delete sc;
     set_error("a3d_scene_create: internal workspace overflow");
@@ -653,6 +715,7 @@ extern "C" int a3d_scene_create(const int32_t* coords4_dev, int64_t n_voxels, vo
   }
   ProfScope prof2(st, A3D_PROF_SCENE_TABLES, 0, 0, 0, 0, n0);
   A3D_HIP_CHECK(hipMemsetAsync((char*)workspace_dev + t.zero_begin, 0, t.zero_end - t.zero_begin, st));
+  if (sc->lv[0].grid) A3D_HIP_CHECK(hipMemsetAsync(sc->lv[0].grid, 0xff, (size_t)grid_cells * sizeof(int), st));   // -1 = empty
   LevelSet S;
   memset(&S, 0, sizeof(S));
   S.st_shift = super_tile_shift();
@@ -734,6 +797,14 @@ extern "C" int a3d_scene_batch_ranges(const a3d_scene* s, int64_t* starts_out, i
   if (!s) return A3D_ERR_INVALID;
   for (int i = 0; i < s->n_batch && i < max_out; ++i) starts_out[i] = s->batch_start[i];
   return s->n_batch;
+}
+
+extern "C" int a3d_scene_grid_dims(const a3d_scene* s, int dims_out[3]) {
+  if (!s) return A3D_ERR_INVALID;
+  if (!s->lv[0].grid) return 0;
+  if (dims_out)
+    for (int a = 0; a < 3; ++a) dims_out[a] = s->lv[0].gdim[a];
+  return 1;
 }
 
 extern "C" int64_t a3d_scene_level_size(const a3d_scene* s, int level) {

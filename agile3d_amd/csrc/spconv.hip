@@ -541,7 +541,7 @@ __global__ void __launch_bounds__(NT) k_stem(const int32_t* __restrict__ xyzb, i
                                               uint32_t hmask, const f32x4* __restrict__ feats4,
                                               const float* __restrict__ w, int ks,
                                               const float* __restrict__ scale, const float* __restrict__ shift,
-                                              int relu, float* out, int ldo, int zero_row) {
+                                              int relu, float* out, int ldo, int zero_row, const Level glv) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int K = ks * ks * ks;
   float* W = (float*)smem;              // [K][3][32]
@@ -550,6 +550,27 @@ __global__ void __launch_bounds__(NT) k_stem(const int32_t* __restrict__ xyzb, i
   for (int e = tid; e < K * 96; e += NT) W[e] = w[e];
   const int v0 = blockIdx.x * 64;
   const int h = ks / 2;
+  if (glv.grid) {
+    // dense level-0 grid (scene.hip): one 4-byte load per neighbour, x fastest -> the ks lanes of one (y, z) offset
+    // read consecutive cells; eight lookups in flight per thread
+    for (int e0 = tid; e0 < 64 * K; e0 += 8 * NT) {
+      int res[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int e = e0 + u * NT;
+        const int v = e / K, k = e - v * K;
+        const int row = v0 + v;
+        res[u] = -1;
+        if (e < 64 * K && row < n) {
+          const int4 c = *(const int4*)(xyzb + 4 * row);
+          res[u] = glv.grid[grid_cell(glv, c.w, c.x + (k % ks) - h, c.y + ((k / ks) % ks) - h, c.z + (k / (ks * ks)) - h)];
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (e0 + u * NT < 64 * K) nb[e0 + u * NT] = res[u];
+    }
+  } else
   // hash probes, four independent lookups in flight per thread (the probes are L2-latency bound)
   for (int e0 = tid; e0 < 64 * K; e0 += 4 * NT) {
     uint64_t key[4];
@@ -958,8 +979,10 @@ extern "C" int a3d_program_run(const a3d_scene* s, const a3d_buf_desc* bufs, int
       const size_t lds = (size_t)o.kernel_volume * 96 * 4 + (size_t)64 * o.kernel_volume * 4;
       ProfScope ps(st, A3D_PROF_STEM, 0, o.kernel_volume, 3, 32, lv.n);
       // 8 waves per 64-voxel workgroup (measured: 4 waves 229 us, 8 waves 164 us, 16 waves 159 us)
+      Level glv = lv;
+      if (ks / 2 > kGridPad) glv.grid = nullptr;   // the grid's empty border covers 5^3 neighbourhoods
       k_stem<512><<<(lv.n + 63) / 64, 512, lds, st>>>(lv.xyzb, lv.n, lv.hkeys, lv.hvals, lv.hmask, feats4, o.w_dev, ks,
-                                                o.scale_dev, o.shift_dev, o.relu, out, ldo, zero_row);
+                                                o.scale_dev, o.shift_dev, o.relu, out, ldo, zero_row, glv);
       A3D_LAUNCH_CHECK();
       continue;
     }

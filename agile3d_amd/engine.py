@@ -52,6 +52,9 @@ class Scene:
         nb = lib.a3d_scene_batch_ranges(h, starts, 1024)
         ends = [int(starts[i + 1]) for i in range(nb - 1)] + [n]
         self.batch_ranges = [(int(starts[i]), ends[i]) for i in range(nb)]
+        dims = (C.c_int * 3)()
+        # level-0 lookups go through a dense voxel grid when the batch's bounding box is small, else a hash table
+        self.grid_dims = tuple(dims) if lib.a3d_scene_grid_dims(h, dims) == 1 else None
 
     def table(self, level: int, which: int) -> np.ndarray:
         """Copy one scene table to the host (tests / debugging)."""

@@ -248,6 +248,23 @@ def main():
             res["conv_tflops"] = {k: round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2) for k, v in conv.items()}
             res["scene_algorithmic_gflop_convs"] = round(tot_flops / 1e9, 2)
             res["gpu_ms_per_step_sum_of_kernels"] = round(sum(v["ms_per_step"] for v in agg.values()), 3)
+            # the three phases on their own (one step at a time, one stream, wall clock with a device
+            # sync around each) and the eval loop's number, decoder passes/s (backbone results reused per round)
+            def wall(fn, reps=10):
+                fn()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(reps):
+                    out = fn()
+                torch.cuda.synchronize()
+                return (time.perf_counter() - t0) / reps * 1e3, out
+            t_scene, _ = wall(lambda: Scene(coords))
+            t_bb, r = wall(lambda: model.forward_backbone(SparseTensor(features=feats, coordinates=coords),
+                                                          raw_coordinates=raw))
+            t_dec, _ = wall(lambda: model.forward_mask(*r, click_idx=cis, click_time_idx=cts))
+            res["phases_ms_per_step"] = {"scene_build": round(t_scene, 3), "backbone": round(t_bb - t_scene, 3),
+                                         "decoder_pass": round(t_dec, 3), "note": "single stream, host wall clock"}
+            res["decoder_passes_per_s"] = round(args.batch / (t_dec * 1e-3), 1)
         if not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(sd, sc, ci, ct)
     if rank == 0:

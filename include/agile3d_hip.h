@@ -85,6 +85,10 @@ int64_t a3d_scene_level_size(const a3d_scene* s, int level);
  * datasets/InterMultiObj3DSegDataset.py:129); returns their number B and writes the first row of
  * sample i to starts_out[i] (i < max_out); sample i ends where sample i+1 starts (the last at n). */
 int     a3d_scene_batch_ranges(const a3d_scene* s, int64_t* starts_out, int max_out);
+/* Level-0 voxel lookup structure chosen by a3d_scene_create: returns 1 and the (x, y, z) cell counts when the batch's
+ * bounding box was small enough for a dense voxel -> row grid (at most 64 cells per voxel), 0 when the hash table is
+ * used (results are identical; A3D_GRID=0 in the environment forces the hash table). */
+int     a3d_scene_grid_dims(const a3d_scene* s, int dims_out[3]);
 
 /* read-only views of the scene tables (device pointers valid while the workspace lives) */
 enum {

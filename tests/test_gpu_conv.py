@@ -125,6 +125,24 @@ def test_stem(world, ks):
     _check(op.buffer(1).cpu()[:n, 96:], ref[maps[0]], f"stem k{ks}")
 
 
+@pytest.mark.parametrize("ks", [5, 3])
+def test_stem_hash_path(ks):
+    """One far-away voxel blows the bounding box up: level 0 falls back from the dense grid to the hash table."""
+    coords = np.concatenate([make_scene(3000, seed=9)["coords"], np.array([[0, 80000, -3, 7]], np.int32)])
+    sc = Scene(torch.from_numpy(coords).cuda())
+    assert sc.grid_dims is None
+    lv = ob.SparseLevels(coords)
+    m = torch.from_numpy(internal_to_oracle_rows(sc, lv, 0))
+    g = torch.Generator().manual_seed(23 + ks)
+    n = sc.n[0]
+    F3 = torch.rand(n, 3, generator=g)
+    W = torch.randn(ks ** 3, 3, 32, generator=g) / 6.0
+    op = OneOp(sc, L.OP_STEM, 0, 3, 32, ks ** 3, W.cuda().contiguous(), None, None, relu=False, out_pad=0)
+    op.run(F3.cuda())
+    ref = ob.sparse_conv(F3, W, lv.kernel_map(0, ks), n)
+    _check(op.buffer(1).cpu()[:n], ref[m], f"stem k{ks} (hash)")
+
+
 def test_standalone_linear_matches_matmul():
     from agile3d_amd.engine import _ptr, _stream
     lib = L.load()

@@ -31,7 +31,12 @@ CASES = {
     "synthetic5k": lambda: make_scene(5000, seed=2)["coords"],
     "single_voxel": lambda: np.array([[0, 3, 4, 5]], np.int32),
     "tiny_line": lambda: np.array([[0, i, 0, 0] for i in range(37)], np.int32),
+    "sparse_far": lambda: _random_coords(800, 60000, 3, negative=True),
+    "compact_plus_outlier": lambda: np.concatenate([_random_coords(700, 24, 4), np.array([[0, 90000, -70000, 5]], np.int32)]),
 }
+# level 0 uses a dense voxel grid when the padded bounding box has <= 64 cells per voxel, the hash table otherwise
+GRID = {"dense24": True, "neg_batch2": False, "synthetic5k": True, "single_voxel": False, "tiny_line": True,
+        "sparse_far": False, "compact_plus_outlier": False}
 
 
 @pytest.mark.parametrize("name", list(CASES))
@@ -40,6 +45,10 @@ def test_scene_tables(name):
     sc = Scene(torch.from_numpy(coords).cuda())
     lv = ob.SparseLevels(coords)
     assert sc.n == [lv.n(i) for i in range(5)]
+    assert (sc.grid_dims is not None) == GRID[name], (name, sc.grid_dims)
+    if sc.grid_dims:
+        ext = coords[:, 1:].max(0) - coords[:, 1:].min(0) + 1
+        assert sc.grid_dims == tuple(int(e) + 4 for e in ext)
     maps = [internal_to_oracle_rows(sc, lv, i) for i in range(5)]   # also checks coordinate sets
     for level in range(5):
         n = sc.n[level]
