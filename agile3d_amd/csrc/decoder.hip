@@ -32,6 +32,27 @@ constexpr float kNegBig = -1e30f;
 constexpr int kC2SChunk = 128;   // points per c2s workgroup
 constexpr int kPartStride = 18;  // m, l, acc[16]
 
+// All-reduce over the four 16-lane rows of a wave (lanes l, l^16, l^32, l^48): the transposed MFMA layouts put the
+// softmax / LayerNorm reductions there.  gfx950's v_permlane16_swap / v_permlane32_swap do each step as one VALU
+// op (swap of the odd rows of one operand with the even rows of the other: with both operands = x the two results
+// hold the two partners in every lane) instead of a ds_bpermute round trip through the LDS pipeline; same
+// association order as the __shfl_xor(16) / __shfl_xor(32) pair (tools/permlane_check.hip).
+__device__ __forceinline__ float rows_max(float x) {
+  auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  x = fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));
+  auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  return fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));
+}
+__device__ __forceinline__ float rows_sum(float x) {
+  auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  x = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+  auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  return __uint_as_float(b[0]) + __uint_as_float(b[1]);
+}
+// exp for the softmax weights (argument <= 0 after the max is subtracted): v_exp_f32 on x log2(e), ~2 ulp, against
+// the ~15-instruction expf; the decoder's 1e-3 logits bar leaves four orders of magnitude of room
+__device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.4426950408889634f); }
+
 // ------------------------------------------------------------------------------ posenc
 __global__ void __launch_bounds__(256) k_minmax_partial(const float* __restrict__ xyz, int n, float* part) {
   __shared__ float s[6][256];
@@ -165,16 +186,15 @@ __global__ void __launch_bounds__(512) k_c2s_attn(const float* __restrict__ Kc, 
         s[t] = blocked ? kNegBig : s[t];
         mx = fmaxf(mx, s[t]);
       }
-      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      mx = rows_max(mx);
       const float mnew = fmaxf(m[qt], mx);
-      const float sc = expf(m[qt] - mnew);
+      const float sc = fast_exp(m[qt] - mnew);
       m[qt] = mnew;
       f32x4 p;
       float ps = 0.f;
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
-        p[t] = expf(s[t] - mnew);
+        p[t] = fast_exp(s[t] - mnew);
         ps += p[t];
       }
       l[qt] = l[qt] * sc + ps;
@@ -187,8 +207,7 @@ __global__ void __launch_bounds__(512) k_c2s_attn(const float* __restrict__ Kc, 
 #pragma unroll
   for (int qt = 0; qt < QT; ++qt) {
     float lt = l[qt];
-    lt += __shfl_xor(lt, 16, 64);
-    lt += __shfl_xor(lt, 32, 64);
+    lt = rows_sum(lt);
     float* pq = P + (size_t)(qt * 16 + j) * kPartStride;
     if (g == 0) {
       pq[0] = m[qt];
@@ -300,16 +319,15 @@ __global__ void __launch_bounds__(512) k_kv_c2s(const float* __restrict__ X, con
           sc4[t] = blocked ? kNegBig : sc4[t];
           mx = fmaxf(mx, sc4[t]);
         }
-        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        mx = rows_max(mx);
         const float mnew = fmaxf(m[hl][qt], mx);
-        const float scl = expf(m[hl][qt] - mnew);
+        const float scl = fast_exp(m[hl][qt] - mnew);
         m[hl][qt] = mnew;
         f32x4 pw;
         float ps = 0.f;
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-          pw[t] = expf(sc4[t] - mnew);
+          pw[t] = fast_exp(sc4[t] - mnew);
           ps += pw[t];
         }
         l[hl][qt] = l[hl][qt] * scl + ps;
@@ -327,8 +345,7 @@ __global__ void __launch_bounds__(512) k_kv_c2s(const float* __restrict__ X, con
 #pragma unroll
     for (int qt = 0; qt < QT; ++qt) {
       float lt = l[hl][qt];
-      lt += __shfl_xor(lt, 16, 64);
-      lt += __shfl_xor(lt, 32, 64);
+      lt = rows_sum(lt);
       float* pq = P + (size_t)(qt * 16 + j) * kPartStride;
       if (g == 0) {
         pq[0] = m[hl][qt];
@@ -425,17 +442,16 @@ __global__ void __launch_bounds__(512) k_s2c_attn_wide(const float* __restrict__
           mx = fmaxf(mx, s[kt][t]);
         }
       }
-      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      mx = rows_max(mx);
       const float mnew = fmaxf(m[h], mx);
-      const float sc = expf(m[h] - mnew);
+      const float sc = fast_exp(m[h] - mnew);
       m[h] = mnew;
       float ps = 0.f;
 #pragma unroll
       for (int kt = 0; kt < QT; ++kt)
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-          s[kt][t] = expf(s[kt][t] - mnew);
+          s[kt][t] = fast_exp(s[kt][t] - mnew);
           ps += s[kt][t];
         }
       l[h] = l[h] * sc + ps;
@@ -454,8 +470,7 @@ __global__ void __launch_bounds__(512) k_s2c_attn_wide(const float* __restrict__
 #pragma unroll
   for (int h = 0; h < H; ++h) {
     float lt = l[h];
-    lt += __shfl_xor(lt, 16, 64);
-    lt += __shfl_xor(lt, 32, 64);
+    lt = rows_sum(lt);
     if (p0 + j < n) *(f32x4*)(orow + h * DH + 4 * g) = acc[h] * (1.f / lt);
   }
 }
@@ -492,8 +507,7 @@ __global__ void __launch_bounds__(256) k_ln_mask(float* Y, int n, const float* _
       y[S] = *(const f32x4*)(yrow + 16 * S + 4 * g);
       sum += y[S][0] + y[S][1] + y[S][2] + y[S][3];
     }
-    sum += __shfl_xor(sum, 16, 64);
-    sum += __shfl_xor(sum, 32, 64);
+    sum = rows_sum(sum);
     const float mean = sum * (1.f / D);
     float var = 0.f;
 #pragma unroll
@@ -503,8 +517,7 @@ __global__ void __launch_bounds__(256) k_ln_mask(float* Y, int n, const float* _
         const float d = y[S][t] - mean;
         var += d * d;
       }
-    var += __shfl_xor(var, 16, 64);
-    var += __shfl_xor(var, 32, 64);
+    var = rows_sum(var);
     const float rstd = rsqrtf(var * (1.f / D) + kLnEps);
 #pragma unroll
     for (int S = 0; S < 8; ++S) {
@@ -580,12 +593,16 @@ template <int QT>
 __global__ void __launch_bounds__(512) k_q_s2c(const float* __restrict__ X, const float* __restrict__ Pe, int n,
                                                const float* __restrict__ Wq, const float* __restrict__ bq,
                                                const float* ks, const float* vs, int nq, float* __restrict__ O,
-                                               int ngroups) {
+                                               int ngroups, unsigned long long* dbg) {
   constexpr int QP = QT * 16, LD = 132, NW = 8;
+  const unsigned long long t_start = dbg ? __builtin_amdgcn_s_memtime() : 0;   // A3D_DEC_DBG=1: per-wave phase cycles
   extern __shared__ __attribute__((aligned(16))) char smem[];
   f32x4* Wl = (f32x4*)smem;                       // [8 S][8 ct][64]
+  constexpr int LT = QP + 4;                      // row stride of the transposed values (16-byte rows, bank spread)
   float* ks_l = (float*)(Wl + 8 * 8 * 64);        // [QP][132]
-  float* vs_l = ks_l + QP * LD;
+  float* vt_l = ks_l + QP * LD;                   // [128][LT]  V^T: the PV fragment (4 keys of one channel) is one b128
+  float* bq_l = vt_l + D * LT;                    // [128]
+  if (threadIdx.x < D) bq_l[threadIdx.x] = bq[threadIdx.x];
   {
     constexpr int TOT = 8 * 8 * 64;
     for (int base = threadIdx.x; base < TOT; base += 8 * 512) {
@@ -601,7 +618,9 @@ __global__ void __launch_bounds__(512) k_q_s2c(const float* __restrict__ X, cons
   for (int e = threadIdx.x; e < QP * 32; e += 512) {
     const int r = e >> 5, c4 = (e & 31) * 4;
     *(f32x4*)(ks_l + r * LD + c4) = *(const f32x4*)(ks + (size_t)r * D + c4);
-    *(f32x4*)(vs_l + r * LD + c4) = *(const f32x4*)(vs + (size_t)r * D + c4);
+    const f32x4 v4 = *(const f32x4*)(vs + (size_t)r * D + c4);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) vt_l[(c4 + t) * LT + r] = v4[t];
   }
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -619,6 +638,16 @@ __global__ void __launch_bounds__(512) k_q_s2c(const float* __restrict__ X, cons
     for (int S = 0; S < 8; ++S) np[S] = *(const f32x4*)(pr + 16 * S);
   };
   if (grp < ngroups) fetch(grp);
+  const unsigned long long t_loop = dbg ? __builtin_amdgcn_s_memtime() : 0;
+  unsigned long long tc[4] = {0, 0, 0, 0}, t_prev = t_loop;
+  int ngrp_done = 0;
+  auto lap = [&](int i) {
+    if (dbg) {
+      const unsigned long long t = __builtin_amdgcn_s_memtime();
+      tc[i] += t - t_prev;
+      t_prev = t;
+    }
+  };
   while (grp < ngroups) {
     const int p0 = grp * 16;
     const int prow = min(p0 + j, n - 1);
@@ -628,14 +657,25 @@ __global__ void __launch_bounds__(512) k_q_s2c(const float* __restrict__ X, cons
     const int next = grp + stride;
     if (next < ngroups) fetch(next);
     float* orow = O + (size_t)prow * D;
+    ++ngrp_done;
+    if (dbg) {
+      asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+      lap(0);   // waiting for this group's rows
+    }
 #pragma unroll 2
     for (int h = 0; h < H; ++h) {
-      f32x4 qf = *(const f32x4*)(bq + 16 * h + 4 * g);     // Q[point j][16h+4g..+3]
+      // bias from LDS: the only vector-memory traffic inside the loop is the prefetch and the stores (vmcnt is
+      // in order -- a global load here would wait for the whole prefetch and the previous head's store)
+      f32x4 qf = *(const f32x4*)(bq_l + 16 * h + 4 * g);   // Q[point j][16h+4g..+3]
 #pragma unroll
       for (int S = 0; S < 8; ++S) {
         const f32x4 w = Wl[(S * 8 + h) * 64 + lane];
 #pragma unroll
         for (int t = 0; t < 4; ++t) qf = __builtin_amdgcn_mfma_f32_16x16x4f32(w[t], xp[S][t], qf, 0, 0, 0);
+      }
+      if (dbg) {
+        asm volatile("v_mov_b32 %0, %0" : "+v"(qf[0]));   // the clock is read after the MFMA chain
+        lap(1);
       }
       f32x4 sc[QT];
       float mx = kNegBig;
@@ -651,30 +691,40 @@ __global__ void __launch_bounds__(512) k_q_s2c(const float* __restrict__ X, cons
           mx = fmaxf(mx, sc[kt][t]);
         }
       }
-      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      mx = rows_max(mx);
       float sum = 0.f;
 #pragma unroll
       for (int kt = 0; kt < QT; ++kt)
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-          sc[kt][t] = expf(sc[kt][t] - mx);
+          sc[kt][t] = fast_exp(sc[kt][t] - mx);
           sum += sc[kt][t];
         }
-      sum += __shfl_xor(sum, 16, 64);
-      sum += __shfl_xor(sum, 32, 64);
-      const float inv = 1.f / sum;
+      sum = rows_sum(sum);
+      const float inv = __builtin_amdgcn_rcpf(sum);
       f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int kt = 0; kt < QT; ++kt)
+      for (int kt = 0; kt < QT; ++kt) {
+        const f32x4 vf = *(const f32x4*)(vt_l + (h * DH + j) * LT + kt * 16 + 4 * g);   // V^T: keys 4g..4g+3 of channel 16h+j
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-          const float vf = vs_l[(kt * 16 + 4 * g + t) * LD + h * DH + j];
-          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(vf, sc[kt][t] * inv, acc, 0, 0, 0);
-        }
+        for (int t = 0; t < 4; ++t) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(vf[t], sc[kt][t] * inv, acc, 0, 0, 0);
+      }
       if (p0 + j < n) *(f32x4*)(orow + h * DH + 4 * g) = acc;
+      if (dbg) {
+        asm volatile("v_mov_b32 %0, %0" : "+v"(acc[0]));
+        lap(2);
+      }
     }
     grp = next;
+  }
+  if (dbg && lane == 0) {
+    unsigned long long* r = dbg + (size_t)(blockIdx.x * NW + wave) * 8;
+    r[0] = t_loop - t_start;                                // prologue
+    r[1] = __builtin_amdgcn_s_memtime() - t_loop;           // loop
+    r[2] = tc[0], r[3] = tc[1], r[4] = tc[2];
+    r[5] = ngrp_done;
+    r[6] = t_start;
+    r[7] = __builtin_amdgcn_s_memtime();
   }
 }
 
@@ -694,10 +744,15 @@ __global__ void __launch_bounds__(512) k_out_ln_mask(const float* __restrict__ O
   constexpr int QP = QT * 16, LD = 132, LL = QP + 1, NW = 8;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   f32x4* Wl = (f32x4*)smem;                       // [8 S][8 ct][64]
-  float* E_l = (float*)(Wl + 8 * 8 * 64);         // [QP][132]
+  float* bo_l = (float*)(Wl + 8 * 8 * 64);        // [128] x 3: bias, LayerNorm weight and bias (no vector-memory
+  float* ga_l = bo_l + D;                         // loads inside the loop except the prefetch: vmcnt is in order)
+  float* be_l = ga_l + D;
+  float* E_l = be_l + D;                          // [QP][132]
   float* L_l = E_l + QP * LD;                     // [NW][16][LL]
   float* O_l = L_l + NW * 16 * LL;                // [NW][16][K+1]
   int* hist = (int*)(O_l + NW * 16 * (K + 1));    // [K+1]
+  int* qr_l = hist + K + 1;                       // [K+2] query range of every object
+  for (int e = threadIdx.x; e <= K + 1; e += 512) qr_l[e] = qrange[e];
   {
     constexpr int TOT = 8 * 8 * 64;
     for (int base = threadIdx.x; base < TOT; base += 8 * 512) {
@@ -715,6 +770,11 @@ __global__ void __launch_bounds__(512) k_out_ln_mask(const float* __restrict__ O
     *(f32x4*)(E_l + r * LD + c4) = *(const f32x4*)(E + (size_t)r * D + c4);
   }
   for (int e = threadIdx.x; e <= K; e += 512) hist[e] = 0;
+  if (threadIdx.x < D) {
+    bo_l[threadIdx.x] = bo[threadIdx.x];
+    ga_l[threadIdx.x] = gamma[threadIdx.x];
+    be_l[threadIdx.x] = beta[threadIdx.x];
+  }
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int g = lane >> 4, j = lane & 15;
@@ -722,24 +782,28 @@ __global__ void __launch_bounds__(512) k_out_ln_mask(const float* __restrict__ O
   float* Ow = O_l + wave * 16 * (K + 1);
   const int stride = gridDim.x * NW;
   int grp = blockIdx.x * NW + wave;
-  f32x4 nx[8];
+  f32x4 nx[8], nr[8];
   auto fetch = [&](int gq) {
-    const float* orow = O + (size_t)min(gq * 16 + j, n - 1) * D + 4 * g;
+    const size_t row = (size_t)min(gq * 16 + j, n - 1);
+    const float* orow = O + row * D + 4 * g;
+    const float* rrow = Xres + row * D + 4 * g;
 #pragma unroll
     for (int S = 0; S < 8; ++S) nx[S] = *(const f32x4*)(orow + 16 * S);
+#pragma unroll
+    for (int S = 0; S < 8; ++S) nr[S] = *(const f32x4*)(rrow + 16 * S);   // residual rows: channels 16ct+4g..+3
   };
   if (grp < ngroups) fetch(grp);
   while (grp < ngroups) {
     const int p0 = grp * 16;
     const int prow = min(p0 + j, n - 1);
     f32x4 a[8];
-#pragma unroll
-    for (int S = 0; S < 8; ++S) a[S] = nx[S];
-    const int next = grp + stride;
-    if (next < ngroups) fetch(next);
     f32x4 y[8];   // y[ct] = channels 16ct+4g..+3 of point j
 #pragma unroll
-    for (int ct = 0; ct < 8; ++ct) y[ct] = *(const f32x4*)(bo + 16 * ct + 4 * g) + *(const f32x4*)(Xres + (size_t)prow * D + 16 * ct + 4 * g);
+    for (int S = 0; S < 8; ++S) a[S] = nx[S];
+#pragma unroll
+    for (int ct = 0; ct < 8; ++ct) y[ct] = *(const f32x4*)(bo_l + 16 * ct + 4 * g) + nr[ct];
+    const int next = grp + stride;
+    if (next < ngroups) fetch(next);
 #pragma unroll
     for (int S = 0; S < 8; ++S) {
 #pragma unroll
@@ -754,8 +818,7 @@ __global__ void __launch_bounds__(512) k_out_ln_mask(const float* __restrict__ O
     float sum = 0.f;
 #pragma unroll
     for (int ct = 0; ct < 8; ++ct) sum += y[ct][0] + y[ct][1] + y[ct][2] + y[ct][3];
-    sum += __shfl_xor(sum, 16, 64);
-    sum += __shfl_xor(sum, 32, 64);
+    sum = rows_sum(sum);
     const float mean = sum * (1.f / D);
     float var = 0.f;
 #pragma unroll
@@ -765,14 +828,13 @@ __global__ void __launch_bounds__(512) k_out_ln_mask(const float* __restrict__ O
         const float d = y[ct][t] - mean;
         var += d * d;
       }
-    var += __shfl_xor(var, 16, 64);
-    var += __shfl_xor(var, 32, 64);
+    var = rows_sum(var);
     const float rstd = rsqrtf(var * (1.f / D) + kLnEps);
     float* yrow = Y + (size_t)prow * D;
 #pragma unroll
     for (int ct = 0; ct < 8; ++ct) {
-      const f32x4 ga = *(const f32x4*)(gamma + 16 * ct + 4 * g);
-      const f32x4 be = *(const f32x4*)(beta + 16 * ct + 4 * g);
+      const f32x4 ga = *(const f32x4*)(ga_l + 16 * ct + 4 * g);
+      const f32x4 be = *(const f32x4*)(be_l + 16 * ct + 4 * g);
 #pragma unroll
       for (int t = 0; t < 4; ++t) y[ct][t] = (y[ct][t] - mean) * rstd * ga[t] + be[t];
       if (p0 + j < n) *(f32x4*)(yrow + 16 * ct + 4 * g) = y[ct];
@@ -792,7 +854,7 @@ __global__ void __launch_bounds__(512) k_out_ln_mask(const float* __restrict__ O
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // wave-private scratch: written above, read below by other lanes
     for (int o = g; o <= K; o += 4) {
-      const int qb = o == 0 ? n_fg : qrange[o], qe = o == 0 ? nq : qrange[o + 1];
+      const int qb = o == 0 ? n_fg : qr_l[o], qe = o == 0 ? nq : qr_l[o + 1];
       float mxv = -3.4e38f;
       for (int q = qb; q < qe; ++q) mxv = fmaxf(mxv, Lw[j * LL + q]);
       Ow[j * (K + 1) + o] = mxv;
@@ -1395,7 +1457,8 @@ static int run_decoder(const a3d_decoder_weights* w, const float* feats128, cons
   }
   A3D_LAUNCH_CHECK();
   const float* src = feats128;
-  const size_t s2c_lds = (size_t)2 * QP * 132 * 4;
+  const size_t s2c_lds = (size_t)2 * QP * 132 * 4;             // keys + values of the queries (k_s2c_attn_wide)
+  const size_t qs2c_lds = ((size_t)QP * 132 + (size_t)D * (QP + 4) + D) * 4;   // k_q_s2c: keys, transposed values, bias
   const size_t lnm_lds = ((size_t)QP * 132 + 4 * 16 * (L.qp + 1) + 4 * 16 * (K + 1)) * 4 + (size_t)(K + 1) * 4;
   if (lnm_lds > 160 * 1024) {
     set_error("a3d_decoder_forward: %d queries x %d objects need %zu bytes of LDS in the mask head", nq, K, lnm_lds);
@@ -1457,9 +1520,34 @@ static int run_decoder(const a3d_decoder_weights* w, const float* feats128, cons
       const int ngroups = (n + 15) / 16;
       const int grid = (ngroups + 7) / 8 < 256 ? (ngroups + 7) / 8 : 256;
       ProfScope ps(st, A3D_PROF_S2C, 0, 0, 0, 0, n);
-      k_q_s2c<QT><<<grid, 512, (size_t)64 * 1024 + s2c_lds, st>>>(src, posenc, n, LW.s2c_wq_packed, LW.s2c_in_b, B.ks, B.vs, nq,
-                                                                bufB, ngroups);
+      static int dec_dbg = -1;
+      static unsigned long long* dbg_buf = nullptr;
+      if (dec_dbg < 0) {
+        const char* e = getenv("A3D_DEC_DBG");
+        dec_dbg = e ? atoi(e) : 0;
+        if (dec_dbg) (void)hipMalloc(&dbg_buf, (size_t)256 * 8 * 8 * sizeof(unsigned long long));
+      }
+      k_q_s2c<QT><<<grid, 512, (size_t)64 * 1024 + qs2c_lds, st>>>(src, posenc, n, LW.s2c_wq_packed, LW.s2c_in_b, B.ks, B.vs, nq,
+                                                                bufB, ngroups, dbg_buf);
       A3D_LAUNCH_CHECK();
+      if (dbg_buf && l == 0) {   // per-wave phase cycles of the first layer's launch (debugging aid, synchronous)
+        static unsigned long long hb[256 * 8 * 8];
+        (void)hipMemcpyAsync(hb, dbg_buf, (size_t)grid * 8 * 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st);
+        (void)hipStreamSynchronize(st);
+        double sum[6] = {0, 0, 0, 0, 0, 0};
+        unsigned long long t0 = ~0ull, t1 = 0, mx_loop = 0;
+        for (int wv = 0; wv < grid * 8; ++wv) {
+          const unsigned long long* r = hb + (size_t)wv * 8;
+          for (int i = 0; i < 6; ++i) sum[i] += (double)r[i];
+          t0 = r[6] < t0 ? r[6] : t0;
+          t1 = r[7] > t1 ? r[7] : t1;
+          mx_loop = r[1] > mx_loop ? r[1] : mx_loop;
+        }
+        const double nw = grid * 8.0;
+        fprintf(stderr, "k_q_s2c dbg (memtime ticks, mean per wave): prologue %.0f loop %.0f (max %llu) = wait %.0f + qproj %.0f + attn %.0f; "
+                        "groups/wave %.2f; kernel span %llu ticks\n", sum[0] / nw, sum[1] / nw, mx_loop, sum[2] / nw, sum[3] / nw,
+                sum[4] / nw, sum[5] / nw, t1 - t0);
+      }
     } else {
       rc = a3d_linear(src, D, posenc, D, n, D, D, LW.s2c_wq_packed, nullptr, LW.s2c_in_b, nullptr, 0, 0, bufA, D, nullptr, 0, st);
       if (rc) return rc;
@@ -1468,7 +1556,7 @@ static int run_decoder(const a3d_decoder_weights* w, const float* feats128, cons
       A3D_LAUNCH_CHECK();
     }
     float* Y = (l & 1) ? bufD : bufC;
-    const size_t fused_lds = (size_t)64 * 1024 + ((size_t)QP * 132 + 8 * 16 * (QP + 1) + 8 * 16 * (K + 1)) * 4 + (size_t)(K + 1) * 4;
+    const size_t fused_lds = (size_t)64 * 1024 + ((size_t)3 * D + QP * 132 + 8 * 16 * (QP + 1) + 8 * 16 * (K + 1)) * 4 + (size_t)(2 * K + 3) * 4;
     if (nblk == 1 && fused_c2s() && fused_lds <= 160 * 1024) {
       // ---- output projection + residual + LayerNorm + mask head in one pass (the pre-norm activation stays on chip)
       const int ngroups = (n + 15) / 16;
