@@ -234,8 +234,26 @@ __global__ void __launch_bounds__(512) k_kv_c2s(const float* __restrict__ X, con
                                                 const float* qproj, const int* qobj, const unsigned char* labels,
                                                 const int* counts, float* part, int qp_total, int ngroups) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int QP = QT * 16, LDQ = 132;
   f32x4* Wkl = (f32x4*)smem;              // [8 S][8 ct][64 lanes]
   f32x4* Wvl = Wkl + 8 * 8 * 64;
+  float* qp_l = (float*)(Wvl + 8 * 8 * 64);   // [QP][132] projected queries
+  float* bk_l = qp_l + QP * LDQ;              // [128] + [128] biases: the loop below touches global memory only for
+  float* bv_l = bk_l + D;                     // the point rows (vmcnt is in order: any other load would wait for them)
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int g = lane >> 4, j = lane & 15;
+  const int slot = blockIdx.x * 4 + (wave >> 1), nslots = gridDim.x * 4;
+  // rows of the first group: in flight behind the weight staging
+  f32x4 xs[8], pe[8];
+  unsigned lab_nx = 0u;
+  if (slot < ngroups) {
+    const size_t row = (size_t)min(slot * 16 + j, n - 1);
+    if (labels) lab_nx = *(const unsigned*)(labels + slot * 16 + 4 * g);
+#pragma unroll
+    for (int S = 0; S < 8; ++S) xs[S] = *(const f32x4*)(X + row * D + 16 * S + 4 * g);
+#pragma unroll
+    for (int S = 0; S < 8; ++S) pe[S] = *(const f32x4*)(Pe + row * D + 16 * S + 4 * g);
+  }
   {
     constexpr int TOT = 2 * 8 * 8 * 64;
     for (int base = threadIdx.x; base < TOT; base += 8 * 512) {
@@ -250,9 +268,14 @@ __global__ void __launch_bounds__(512) k_kv_c2s(const float* __restrict__ X, con
         if (base + u * 512 < TOT) Wkl[base + u * 512] = t8[u];
     }
   }
-  __syncthreads();
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int g = lane >> 4, j = lane & 15;
+  for (int e = threadIdx.x; e < QP * 32; e += 512) {
+    const int r = e >> 5, c4 = (e & 31) * 4;
+    *(f32x4*)(qp_l + r * LDQ + c4) = *(const f32x4*)(qproj + (size_t)r * D + c4);
+  }
+  if (threadIdx.x < D) {
+    bk_l[threadIdx.x] = bk[threadIdx.x];
+    bv_l[threadIdx.x] = bv[threadIdx.x];
+  }
   int obj[QT];
   bool qmask[QT];
 #pragma unroll
@@ -260,6 +283,7 @@ __global__ void __launch_bounds__(512) k_kv_c2s(const float* __restrict__ X, con
     obj[qt] = qobj[qt * 16 + j];
     qmask[qt] = labels != nullptr && obj[qt] >= 0 && counts[obj[qt]] > 0;
   }
+  __syncthreads();
   // two waves share a sequence of point groups: wave 2s takes heads 0..3 of it, wave 2s+1 heads 4..7 (the flash
   // state of 8 heads does not fit the register file next to the activation fragments)
   constexpr int HW = H / 2;
@@ -274,42 +298,51 @@ __global__ void __launch_bounds__(512) k_kv_c2s(const float* __restrict__ X, con
       l[hl][qt] = 0.f;
       acc[hl][qt] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
-  const int slot = blockIdx.x * 4 + (wave >> 1), nslots = gridDim.x * 4;
   for (int grp = slot; grp < ngroups; grp += nslots) {
     const int p0 = grp * 16;
-    const int row = min(p0 + j, n - 1);
-    f32x4 xs[8], xp[8];
-    {
-      const float* xr = X + (size_t)row * D + 4 * g;
-      const float* pr = Pe + (size_t)row * D + 4 * g;
+    const unsigned lab4 = lab_nx;
+    // the next group of this wave pair (the last iteration re-reads its own rows: unconditional loads keep the
+    // compiler from sinking the prefetch into one conditional block behind the attention phase)
+    const int next = grp + nslots < ngroups ? grp + nslots : grp;
+    const size_t nrow = (size_t)min(next * 16 + j, n - 1);
+    if (labels) lab_nx = *(const unsigned*)(labels + next * 16 + 4 * g);
+    // ---- projections of this wave's four heads, k-step by k-step: K^T slice kf[hl] = channels 16h+4g..+3 of point j,
+    // V slice vv[hl] = channel 16h+j of points 4g..4g+3.  A k-step's row fragments are dead once its MFMAs are
+    // issued, so the SAME registers take the next group's rows right away: the loads have the rest of this phase
+    // and the whole attention phase to land (rolling prefetch, no extra registers).
+    f32x4 kf[HW], vv[HW];
 #pragma unroll
-      for (int S = 0; S < 8; ++S) xs[S] = *(const f32x4*)(xr + 16 * S);
-#pragma unroll
-      for (int S = 0; S < 8; ++S) xp[S] = xs[S] + *(const f32x4*)(pr + 16 * S);
+    for (int hl = 0; hl < HW; ++hl) {
+      kf[hl] = *(const f32x4*)(bk_l + 16 * (h0 + hl) + 4 * g);
+      const float bvj = bv_l[16 * (h0 + hl) + j];
+      vv[hl] = (f32x4){bvj, bvj, bvj, bvj};
     }
-    const unsigned lab4 = labels ? *(const unsigned*)(labels + p0 + 4 * g) : 0u;
+#pragma unroll
+    for (int S = 0; S < 8; ++S) {
+      const f32x4 xp = xs[S] + pe[S];
+#pragma unroll
+      for (int hl = 0; hl < HW; ++hl) {
+        const f32x4 wk = Wkl[(S * 8 + h0 + hl) * 64 + lane], wv = Wvl[(S * 8 + h0 + hl) * 64 + lane];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          kf[hl] = __builtin_amdgcn_mfma_f32_16x16x4f32(wk[t], xp[t], kf[hl], 0, 0, 0);
+          vv[hl] = __builtin_amdgcn_mfma_f32_16x16x4f32(xs[S][t], wv[t], vv[hl], 0, 0, 0);
+        }
+      }
+      xs[S] = *(const f32x4*)(X + nrow * D + 16 * S + 4 * g);
+      pe[S] = *(const f32x4*)(Pe + nrow * D + 16 * S + 4 * g);
+      __builtin_amdgcn_sched_barrier(0);   // one k-step of weight fragments in registers at a time
+    }
+    // ---- attention of the 16 points against every query, flash-style running state per (head, query tile)
 #pragma unroll
     for (int hl = 0; hl < HW; ++hl) {
       const int h = h0 + hl;
-      f32x4 kf = *(const f32x4*)(bk + 16 * h + 4 * g);      // K^T slice: channels 16h+4g..+3 of point j
-      const float bvj = bv[16 * h + j];
-      f32x4 vv = (f32x4){bvj, bvj, bvj, bvj};               // V slice: channel 16h+j of points 4g..4g+3
-#pragma unroll
-      for (int S = 0; S < 8; ++S) {
-        const f32x4 wk = Wkl[(S * 8 + h) * 64 + lane], wv = Wvl[(S * 8 + h) * 64 + lane];
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-          kf = __builtin_amdgcn_mfma_f32_16x16x4f32(wk[t], xp[S][t], kf, 0, 0, 0);
-          vv = __builtin_amdgcn_mfma_f32_16x16x4f32(xs[S][t], wv[t], vv, 0, 0, 0);
-        }
-        if (S & 1) asm volatile("" ::: "memory");   // at most two k-steps of weight fragments in registers
-      }
 #pragma unroll
       for (int qt = 0; qt < QT; ++qt) {
-        const f32x4 qf = *(const f32x4*)(qproj + (size_t)(qt * 16 + j) * D + h * DH + 4 * g);
+        const f32x4 qf = *(const f32x4*)(qp_l + (qt * 16 + j) * LDQ + h * DH + 4 * g);
         f32x4 sc4 = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int t = 0; t < 4; ++t) sc4 = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[t], qf[t], sc4, 0, 0, 0);
+        for (int t = 0; t < 4; ++t) sc4 = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[hl][t], qf[t], sc4, 0, 0, 0);
         float mx = kNegBig;
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
@@ -333,7 +366,7 @@ __global__ void __launch_bounds__(512) k_kv_c2s(const float* __restrict__ X, con
         l[hl][qt] = l[hl][qt] * scl + ps;
         acc[hl][qt] *= scl;
 #pragma unroll
-        for (int t = 0; t < 4; ++t) acc[hl][qt] = __builtin_amdgcn_mfma_f32_16x16x4f32(vv[t], pw[t], acc[hl][qt], 0, 0, 0);
+        for (int t = 0; t < 4; ++t) acc[hl][qt] = __builtin_amdgcn_mfma_f32_16x16x4f32(vv[hl][t], pw[t], acc[hl][qt], 0, 0, 0);
       }
     }
   }
@@ -1475,7 +1508,7 @@ static int run_decoder(const a3d_decoder_weights* w, const float* feats128, cons
       const int grid = (ngroups + 3) / 4 < kFusedC2SGrid ? (ngroups + 3) / 4 : kFusedC2SGrid;
       n_part = grid * 4;
       ProfScope ps(st, A3D_PROF_C2S, 0, 0, 0, 0, n);
-      k_kv_c2s<(QT <= 2 ? QT : 1)><<<grid, 512, 128 * 1024, st>>>(src, posenc, n, LW.c2s_wk_packed, LW.c2s_wv_packed,
+      k_kv_c2s<(QT <= 2 ? QT : 1)><<<grid, 512, 128 * 1024 + ((size_t)(QT <= 2 ? QT : 1) * 16 * 132 + 2 * D) * 4, st>>>(src, posenc, n, LW.c2s_wk_packed, LW.c2s_wv_packed,
                                                              LW.c2s_in_b + D, LW.c2s_in_b + 2 * D, B.qproj, meta->obj,
                                                              l > 0 ? labels : nullptr, prev_counts, part, L.qp, ngroups);
       A3D_LAUNCH_CHECK();
