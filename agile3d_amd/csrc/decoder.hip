@@ -20,6 +20,7 @@
 // The position encoding is added to the GEMM input on the fly (K = (src + pos) Wk^T, Q likewise):
 // k_dense reads both operands once, nothing click-independent is cached.
 #include "common.h"
+#include <vector>
 
 namespace a3d {
 
@@ -112,6 +113,33 @@ __global__ void k_fourier(const float* __restrict__ xyz, int n, const float* __r
   }
   out[(size_t)i * D + jj] = sinf(p);
   out[(size_t)i * D + 64 + jj] = cosf(p);
+}
+
+// ---- one batch sample as the fused wide kernels see it (a3d_decoder_forward_batch) ------------------------------
+// The three persistent wide kernels of a decoder layer (k_kv_c2s, k_q_s2c, k_out_ln_mask) are launched ONCE for all
+// samples of a batch: workgroups [wg_begin, wg_end) work on this sample (its queries' data in their LDS), the waves
+// of those workgroups stride over its 16-point groups.  One launch per layer instead of one per sample: the weight
+// staging prologue and the last, partly filled round of groups are paid once per batch.
+struct DecSampleDev {
+  int wg_begin, wg_end;
+  int n, nq, K, n_fg;
+  const float *feats, *posenc;     // layer-0 input [n,128], position encoding [n,128]
+  float *bufB, *bufC, *bufD;       // attention output; layer outputs (even layers -> bufC, odd -> bufD)
+  float* logits;                   // [layers][n][K+1]
+  unsigned char* labels;           // [n] arg-max object of the previous layer's mask
+  int* counts;                     // [layers][A3D_MAX_QUERIES+1] points per object
+  float* part;                     // click-to-scene flash partials [slots][H][QP][kPartStride]
+  const int *qobj, *qrange;        // QueryMeta::obj / qrange (device)
+  const float *qproj, *ks, *vs, *E;
+};
+constexpr int kMaxBatchSamples = 64;
+__device__ __forceinline__ const DecSampleDev& sample_of_wg(const DecSampleDev* samples, int ns) {
+  int si = 0;
+  while (si + 1 < ns && (int)blockIdx.x >= samples[si + 1].wg_begin) ++si;
+  return samples[si];
+}
+__device__ __forceinline__ const float* layer_input(const DecSampleDev& sm, int l) {
+  return l == 0 ? sm.feats : (((l - 1) & 1) ? sm.bufD : sm.bufC);
 }
 
 // ------------------------------------------------------------------------------ click-to-scene
@@ -228,13 +256,21 @@ __global__ void __launch_bounds__(512) k_c2s_attn(const float* __restrict__ Kc, 
 // head by head (one 16-column slice of each GEMM at a time), and keeps the flash state of all 8 heads in
 // registers.  Saves writing and re-reading K and V (4 x 41 MB per decoder iteration at 80 k points).
 template <int QT>
-__global__ void __launch_bounds__(512) k_kv_c2s(const float* __restrict__ X, const float* __restrict__ Pe, int n,
+__global__ void __launch_bounds__(512) k_kv_c2s(const DecSampleDev* __restrict__ samples, int ns, int layer,
                                                 const float* __restrict__ Wk, const float* __restrict__ Wv,
-                                                const float* __restrict__ bk, const float* __restrict__ bv,
-                                                const float* qproj, const int* qobj, const unsigned char* labels,
-                                                const int* counts, float* part, int qp_total, int ngroups) {
+                                                const float* __restrict__ bk, const float* __restrict__ bv) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int QP = QT * 16, LDQ = 132;
+  const DecSampleDev& sm = sample_of_wg(samples, ns);
+  const int lb = blockIdx.x - sm.wg_begin, nwg = sm.wg_end - sm.wg_begin;
+  const int n = sm.n, ngroups = (n + 15) / 16, qp_total = QP;
+  const float* __restrict__ X = layer_input(sm, layer);
+  const float* __restrict__ Pe = sm.posenc;
+  const float* qproj = sm.qproj;
+  const int* qobj = sm.qobj;
+  const unsigned char* labels = layer > 0 ? sm.labels : nullptr;                       // previous layer's mask labels
+  const int* counts = layer > 0 ? sm.counts + (size_t)(layer - 1) * (A3D_MAX_QUERIES + 1) : nullptr;
+  float* part = sm.part;
   f32x4* Wkl = (f32x4*)smem;              // [8 S][8 ct][64 lanes]
   f32x4* Wvl = Wkl + 8 * 8 * 64;
   float* qp_l = (float*)(Wvl + 8 * 8 * 64);   // [QP][132] projected queries
@@ -242,7 +278,7 @@ __global__ void __launch_bounds__(512) k_kv_c2s(const float* __restrict__ X, con
   float* bv_l = bk_l + D;                     // the point rows (vmcnt is in order: any other load would wait for them)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int g = lane >> 4, j = lane & 15;
-  const int slot = blockIdx.x * 4 + (wave >> 1), nslots = gridDim.x * 4;
+  const int slot = lb * 4 + (wave >> 1), nslots = nwg * 4;
   // rows of the first group: in flight behind the weight staging
   f32x4 xs[8], pe[8];
   unsigned lab_nx = 0u;
@@ -623,11 +659,18 @@ __global__ void __launch_bounds__(256) k_ln_mask(float* Y, int n, const float* _
 // of S^T = ks_h Q_h^T; softmax over the (few) queries in registers; O^T = vs_h^T P.  Q never reaches HBM.
 // Persistent 8-wave workgroups: packed Wq (64 KB) + the queries' keys / values in LDS.
 template <int QT>
-__global__ void __launch_bounds__(512) k_q_s2c(const float* __restrict__ X, const float* __restrict__ Pe, int n,
+__global__ void __launch_bounds__(512) k_q_s2c(const DecSampleDev* __restrict__ samples, int ns, int layer,
                                                const float* __restrict__ Wq, const float* __restrict__ bq,
-                                               const float* ks, const float* vs, int nq, float* __restrict__ O,
-                                               int ngroups, unsigned long long* dbg) {
+                                               unsigned long long* dbg) {
   constexpr int QP = QT * 16, LD = 132, NW = 8;
+  const DecSampleDev& sm = sample_of_wg(samples, ns);
+  const int lb = blockIdx.x - sm.wg_begin, nwg = sm.wg_end - sm.wg_begin;
+  const int n = sm.n, ngroups = (n + 15) / 16, nq = sm.nq;
+  const float* __restrict__ X = layer_input(sm, layer);
+  const float* __restrict__ Pe = sm.posenc;
+  const float* ks = sm.ks;
+  const float* vs = sm.vs;
+  float* __restrict__ O = sm.bufB;
   const unsigned long long t_start = dbg ? __builtin_amdgcn_s_memtime() : 0;   // A3D_DEC_DBG=1: per-wave phase cycles
   extern __shared__ __attribute__((aligned(16))) char smem[];
   f32x4* Wl = (f32x4*)smem;                       // [8 S][8 ct][64]
@@ -658,8 +701,8 @@ __global__ void __launch_bounds__(512) k_q_s2c(const float* __restrict__ X, cons
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int g = lane >> 4, j = lane & 15;
-  const int stride = gridDim.x * NW;
-  int grp = blockIdx.x * NW + wave;
+  const int stride = nwg * NW;
+  int grp = lb * NW + wave;
   f32x4 nx[8], np[8];
   auto fetch = [&](int gq) {
     const size_t row = (size_t)min(gq * 16 + j, n - 1);
@@ -768,13 +811,21 @@ __global__ void __launch_bounds__(512) k_q_s2c(const float* __restrict__ X, cons
 // Wo (64 KB) and the mask embeddings E in LDS; waves walk their own sequences of groups (wave-private LDS scratch,
 // no workgroup barrier inside the loop) with the next group's fragments in flight behind the current MFMAs.
 template <int QT>
-__global__ void __launch_bounds__(512) k_out_ln_mask(const float* __restrict__ O, const float* __restrict__ Xres, int n,
+__global__ void __launch_bounds__(512) k_out_ln_mask(const DecSampleDev* __restrict__ samples, int ns, int layer,
                                                      const float* __restrict__ Wo, const float* __restrict__ bo,
-                                                     const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                     const float* E, int nq, const int* qrange, int n_fg, int K,
-                                                     float* __restrict__ Y, float* logits, unsigned char* labels,
-                                                     int* counts, int ngroups) {
+                                                     const float* __restrict__ gamma, const float* __restrict__ beta) {
   constexpr int QP = QT * 16, LD = 132, LL = QP + 1, NW = 8;
+  const DecSampleDev& sm = sample_of_wg(samples, ns);
+  const int lb = blockIdx.x - sm.wg_begin, nwg = sm.wg_end - sm.wg_begin;
+  const int n = sm.n, ngroups = (n + 15) / 16, nq = sm.nq, n_fg = sm.n_fg, K = sm.K;
+  const float* __restrict__ O = sm.bufB;
+  const float* __restrict__ Xres = layer_input(sm, layer);
+  const float* E = sm.E;
+  const int* qrange = sm.qrange;
+  float* __restrict__ Y = (layer & 1) ? sm.bufD : sm.bufC;
+  float* logits = sm.logits + (size_t)layer * n * (K + 1);
+  unsigned char* labels = sm.labels;
+  int* counts = sm.counts + (size_t)layer * (A3D_MAX_QUERIES + 1);
   extern __shared__ __attribute__((aligned(16))) char smem[];
   f32x4* Wl = (f32x4*)smem;                       // [8 S][8 ct][64]
   float* bo_l = (float*)(Wl + 8 * 8 * 64);        // [128] x 3: bias, LayerNorm weight and bias (no vector-memory
@@ -813,8 +864,8 @@ __global__ void __launch_bounds__(512) k_out_ln_mask(const float* __restrict__ O
   const int g = lane >> 4, j = lane & 15;
   float* Lw = L_l + wave * 16 * LL;
   float* Ow = O_l + wave * 16 * (K + 1);
-  const int stride = gridDim.x * NW;
-  int grp = blockIdx.x * NW + wave;
+  const int stride = nwg * NW;
+  int grp = lb * NW + wave;
   f32x4 nx[8], nr[8];
   auto fetch = [&](int gq) {
     const size_t row = (size_t)min(gq * 16 + j, n - 1);
@@ -1386,7 +1437,7 @@ static int check_weights(const a3d_decoder_weights* w) {
 
 namespace {
 struct DecLayout {
-  size_t buf[4], labels, counts, part, meta, q[12], total;
+  size_t buf[4], labels, counts, part, meta, desc, q[12], total;
   int qp, nchunk;
 };
 int round_qp(int nq) { return nq <= 16 ? 16 : nq <= 32 ? 32 : nq <= 48 ? 48 : (nq + 63) / 64 * 64; }
@@ -1404,6 +1455,7 @@ void dec_layout(int64_t n, int nq, DecLayout& L) {
   L.counts = take((size_t)A3D_MAX_DEC_LAYERS * (A3D_MAX_QUERIES + 1) * 4);
   L.part = take((size_t)(L.nchunk > kFusedC2SGrid * 8 ? L.nchunk : kFusedC2SGrid * 8) * H * L.qp * kPartStride * 4);
   L.meta = take(sizeof(QueryMeta));
+  L.desc = take(sizeof(DecSampleDev) * kMaxBatchSamples);   // sample table of a batched call (kept in the first sample's workspace)
   const size_t qb = (size_t)L.qp * D * 4;
   for (int i = 0; i < 9; ++i) L.q[i] = take(qb);        // queries qpos qproj ks vs E attn tmp tgt
   L.q[9] = take(2 * qb);                                // qk
@@ -1429,33 +1481,51 @@ static bool fused_c2s() {   // A3D_FUSED_C2S=0 keeps the separate K / V GEMMs + 
   return v != 0;
 }
 
-template <int QT>
-static int run_decoder(const a3d_decoder_weights* w, const float* feats128, const float* posenc, int64_t n64, const QueryMeta& hm, float* logits, char* ws,
-                       const DecLayout& L, hipStream_t st) {
-  constexpr int QP = QT * 16;
-  const int n = (int)n64, K = hm.K, nq = hm.nq;
-  const int nblk = L.qp / QP;          // query blocks (1 unless nq > 64)
-  float* bufA = (float*)(ws + L.buf[0]);
-  float* bufB = (float*)(ws + L.buf[1]);
-  float* bufC = (float*)(ws + L.buf[2]);
-  float* bufD = (float*)(ws + L.buf[3]);
-  unsigned char* labels = (unsigned char*)(ws + L.labels);
-  int* counts = (int*)(ws + L.counts);
-  float* part = (float*)(ws + L.part);
-  QueryMeta* meta = (QueryMeta*)(ws + L.meta);
+// one batch sample on the host: validated query list, workspace layout and the views into its workspace
+struct Prepared {
+  QueryMeta hm;
+  DecLayout L;
+  char* ws;
+  const float *feats, *posenc;
+  int n;
+  float* logits;
+  // views
+  float *bufA, *bufB, *bufC, *bufD, *part;
+  unsigned char* labels;
+  int* counts;
+  QueryMeta* meta;
   QueryBufs B;
-  B.queries = (float*)(ws + L.q[0]);
-  B.qpos = (float*)(ws + L.q[1]);
-  B.qproj = (float*)(ws + L.q[2]);
-  B.ks = (float*)(ws + L.q[3]);
-  B.vs = (float*)(ws + L.q[4]);
-  B.E = (float*)(ws + L.q[5]);
-  B.attn = (float*)(ws + L.q[6]);
-  B.tmp = (float*)(ws + L.q[7]);
-  B.tgt = (float*)(ws + L.q[8]);
-  B.qk = (float*)(ws + L.q[9]);
-  B.vc = (float*)(ws + L.q[10]);
-  B.hidden = (float*)(ws + L.q[11]);
+  int wg_begin, wg_end;
+  void bind() {
+    bufA = (float*)(ws + L.buf[0]);
+    bufB = (float*)(ws + L.buf[1]);
+    bufC = (float*)(ws + L.buf[2]);
+    bufD = (float*)(ws + L.buf[3]);
+    labels = (unsigned char*)(ws + L.labels);
+    counts = (int*)(ws + L.counts);
+    part = (float*)(ws + L.part);
+    meta = (QueryMeta*)(ws + L.meta);
+    B.queries = (float*)(ws + L.q[0]);
+    B.qpos = (float*)(ws + L.q[1]);
+    B.qproj = (float*)(ws + L.q[2]);
+    B.ks = (float*)(ws + L.q[3]);
+    B.vs = (float*)(ws + L.q[4]);
+    B.E = (float*)(ws + L.q[5]);
+    B.attn = (float*)(ws + L.q[6]);
+    B.tmp = (float*)(ws + L.q[7]);
+    B.tgt = (float*)(ws + L.q[8]);
+    B.qk = (float*)(ws + L.q[9]);
+    B.vc = (float*)(ws + L.q[10]);
+    B.hidden = (float*)(ws + L.q[11]);
+  }
+};
+
+// All samples of one call share QT (= padded query count / 16).  Per decoder layer: ONE launch of each fused wide
+// kernel for the whole batch (DecSampleDev table), the small query-side kernels once per sample in between.
+template <int QT>
+static int run_decoder(const a3d_decoder_weights* w, Prepared* P, int ns, hipStream_t st) {
+  constexpr int QP = QT * 16;
+  const int nblk = P[0].L.qp / QP;          // query blocks (1 unless nq > 64)
   {
     static bool big = false;
     if (!big) {
@@ -1481,48 +1551,106 @@ static int run_decoder(const a3d_decoder_weights* w, const float* feats128, cons
       (void)hipFuncSetAttribute((const void*)k_ln_mask<4>, hipFuncAttributeMaxDynamicSharedMemorySize, big_lds);
     }
   }
-  A3D_HIP_CHECK(hipMemcpyAsync(meta, &hm, sizeof(QueryMeta), hipMemcpyHostToDevice, st));
   const int n_counts = A3D_MAX_DEC_LAYERS * (A3D_MAX_QUERIES + 1);
-  {
-  ProfScope ps(st, A3D_PROF_QUERY, 0, 0, 0, 0, nq);
-  k_query_init<QT><<<nblk, 512, 0, st>>>(meta, feats128, posenc, w->bg_query_feat, w->bg_query_pos, w->time_table,
-                                       w->layers[0].c2s_in_w, w->layers[0].c2s_in_b, B, counts, n_counts);
+  int64_t n_total = 0;
+  int Kmax = 0, nq_max = 0;
+  for (int si = 0; si < ns; ++si) {
+    Prepared& p = P[si];
+    n_total += p.n;
+    Kmax = p.hm.K > Kmax ? p.hm.K : Kmax;
+    nq_max = p.hm.nq > nq_max ? p.hm.nq : nq_max;
+    A3D_HIP_CHECK(hipMemcpyAsync(p.meta, &p.hm, sizeof(QueryMeta), hipMemcpyHostToDevice, st));
+    ProfScope ps(st, A3D_PROF_QUERY, 0, 0, 0, 0, p.hm.nq);
+    k_query_init<QT><<<nblk, 512, 0, st>>>(p.meta, p.feats, p.posenc, w->bg_query_feat, w->bg_query_pos, w->time_table,
+                                         w->layers[0].c2s_in_w, w->layers[0].c2s_in_b, p.B, p.counts, n_counts);
   }
   A3D_LAUNCH_CHECK();
-  const float* src = feats128;
   const size_t s2c_lds = (size_t)2 * QP * 132 * 4;             // keys + values of the queries (k_s2c_attn_wide)
   const size_t qs2c_lds = ((size_t)QP * 132 + (size_t)D * (QP + 4) + D) * 4;   // k_q_s2c: keys, transposed values, bias
-  const size_t lnm_lds = ((size_t)QP * 132 + 4 * 16 * (L.qp + 1) + 4 * 16 * (K + 1)) * 4 + (size_t)(K + 1) * 4;
-  if (lnm_lds > 160 * 1024) {
-    set_error("a3d_decoder_forward: %d queries x %d objects need %zu bytes of LDS in the mask head", nq, K, lnm_lds);
-    return A3D_ERR_UNSUPPORTED;
+  const size_t fused_lds = (size_t)64 * 1024 + ((size_t)3 * D + QP * 132 + 8 * 16 * (QP + 1) + 8 * 16 * (Kmax + 1)) * 4 +
+                           (size_t)(2 * Kmax + 3) * 4;
+  for (int si = 0; si < ns; ++si) {
+    const size_t lnm_lds = ((size_t)QP * 132 + 4 * 16 * (P[si].L.qp + 1) + 4 * 16 * (P[si].hm.K + 1)) * 4 + (size_t)(P[si].hm.K + 1) * 4;
+    if (lnm_lds > 160 * 1024) {
+      set_error("a3d_decoder_forward: %d queries x %d objects need %zu bytes of LDS in the mask head", P[si].hm.nq,
+                P[si].hm.K, lnm_lds);
+      return A3D_ERR_UNSUPPORTED;
+    }
+  }
+  // which of the wide phases run as one fused launch for the batch
+  const bool fuse_c2s = fused_c2s() && QT <= 2;
+  const bool fuse_s2c = fused_c2s() && nblk == 1;
+  const bool fuse_out = fuse_s2c && fused_lds <= 160 * 1024;
+  // ---- sample table: workgroups of the persistent kernels in proportion to the samples' point groups
+  int grid = 0;
+  DecSampleDev* samples_dev = (DecSampleDev*)(P[0].ws + P[0].L.desc);
+  {
+    DecSampleDev hd[kMaxBatchSamples];
+    int64_t tot_groups = 0;
+    for (int si = 0; si < ns; ++si) tot_groups += (P[si].n + 15) / 16;
+    const int max_grid = 256;
+    for (int si = 0; si < ns; ++si) {
+      Prepared& p = P[si];
+      const int ngroups = (p.n + 15) / 16;
+      int share = (int)((int64_t)max_grid * ngroups / tot_groups);
+      const int useful = (ngroups + 7) / 8;
+      share = share < 1 ? 1 : share;
+      share = share > useful ? useful : share;
+      p.wg_begin = grid;
+      p.wg_end = grid += share;
+      DecSampleDev& d = hd[si];
+      d.wg_begin = p.wg_begin;
+      d.wg_end = p.wg_end;
+      d.n = p.n;
+      d.nq = p.hm.nq;
+      d.K = p.hm.K;
+      d.n_fg = p.hm.n_fg;
+      d.feats = p.feats;
+      d.posenc = p.posenc;
+      d.bufB = p.bufB;
+      d.bufC = p.bufC;
+      d.bufD = p.bufD;
+      d.logits = p.logits;
+      d.labels = p.labels;
+      d.counts = p.counts;
+      d.part = p.part;
+      d.qobj = p.meta->obj;          // addresses inside the device copy of QueryMeta
+      d.qrange = p.meta->qrange;
+      d.qproj = p.B.qproj;
+      d.ks = p.B.ks;
+      d.vs = p.B.vs;
+      d.E = p.B.E;
+    }
+    // pageable source: the runtime stages it before returning (like the QueryMeta copies above)
+    A3D_HIP_CHECK(hipMemcpyAsync(samples_dev, hd, sizeof(DecSampleDev) * ns, hipMemcpyHostToDevice, st));
   }
   for (int l = 0; l < w->n_layers; ++l) {
     const a3d_decoder_layer& LW = w->layers[l];
     int rc;
-    const int* prev_counts = l > 0 ? counts + (size_t)(l - 1) * (A3D_MAX_QUERIES + 1) : nullptr;
-    int n_part = L.nchunk;
-    if (QT <= 2 && fused_c2s()) {
-      // ---- click-to-scene with the K / V projections fused in (K, V never reach HBM)
-      const int ngroups = (n + 15) / 16;
-      const int grid = (ngroups + 3) / 4 < kFusedC2SGrid ? (ngroups + 3) / 4 : kFusedC2SGrid;
-      n_part = grid * 4;
-      ProfScope ps(st, A3D_PROF_C2S, 0, 0, 0, 0, n);
-      k_kv_c2s<(QT <= 2 ? QT : 1)><<<grid, 512, 128 * 1024 + ((size_t)(QT <= 2 ? QT : 1) * 16 * 132 + 2 * D) * 4, st>>>(src, posenc, n, LW.c2s_wk_packed, LW.c2s_wv_packed,
-                                                             LW.c2s_in_b + D, LW.c2s_in_b + 2 * D, B.qproj, meta->obj,
-                                                             l > 0 ? labels : nullptr, prev_counts, part, L.qp, ngroups);
+    // ---- click-to-scene
+    if (fuse_c2s) {
+      // K / V projections fused in (K, V never reach HBM), all samples in one launch
+      ProfScope ps(st, A3D_PROF_C2S, 0, 0, 0, 0, (int)n_total);
+      k_kv_c2s<(QT <= 2 ? QT : 1)><<<grid, 512, 128 * 1024 + ((size_t)(QT <= 2 ? QT : 1) * 16 * 132 + 2 * D) * 4, st>>>(
+          samples_dev, ns, l, LW.c2s_wk_packed, LW.c2s_wv_packed, LW.c2s_in_b + D, LW.c2s_in_b + 2 * D);
       A3D_LAUNCH_CHECK();
     } else {
-      // ---- click-to-scene: K = (src + pos) Wk^T + bk, V = src Wv^T + bv   (attention_block.py:88-94)
-      rc = a3d_linear(src, D, posenc, D, n, D, D, LW.c2s_wk_packed, nullptr, LW.c2s_in_b + D, nullptr, 0, 0, bufA, D, nullptr, 0, st);
-      if (rc) return rc;
-      rc = a3d_linear(src, D, nullptr, 0, n, D, D, LW.c2s_wv_packed, nullptr, LW.c2s_in_b + 2 * D, nullptr, 0, 0, bufB, D, nullptr, 0, st);
-      if (rc) return rc;
-      ProfScope ps(st, A3D_PROF_C2S, 0, 0, 0, 0, n);
-      k_c2s_attn<QT><<<dim3(L.nchunk, nblk), 512, 0, st>>>(bufA, bufB, n, B.qproj, meta->obj,
-                                                            l > 0 ? labels : nullptr, prev_counts, part, L.qp);
-      A3D_LAUNCH_CHECK();
+      for (int si = 0; si < ns; ++si) {
+        Prepared& p = P[si];
+        const float* src = l == 0 ? p.feats : (((l - 1) & 1) ? p.bufD : p.bufC);
+        const int* prev_counts = l > 0 ? p.counts + (size_t)(l - 1) * (A3D_MAX_QUERIES + 1) : nullptr;
+        // K = (src + pos) Wk^T + bk, V = src Wv^T + bv   (attention_block.py:88-94)
+        rc = a3d_linear(src, D, p.posenc, D, p.n, D, D, LW.c2s_wk_packed, nullptr, LW.c2s_in_b + D, nullptr, 0, 0, p.bufA, D, nullptr, 0, st);
+        if (rc) return rc;
+        rc = a3d_linear(src, D, nullptr, 0, p.n, D, D, LW.c2s_wv_packed, nullptr, LW.c2s_in_b + 2 * D, nullptr, 0, 0, p.bufB, D, nullptr, 0, st);
+        if (rc) return rc;
+        ProfScope ps(st, A3D_PROF_C2S, 0, 0, 0, 0, p.n);
+        k_c2s_attn<QT><<<dim3(p.L.nchunk, nblk), 512, 0, st>>>(p.bufA, p.bufB, p.n, p.B.qproj, p.meta->obj,
+                                                              l > 0 ? p.labels : nullptr, prev_counts, p.part, p.L.qp);
+        A3D_LAUNCH_CHECK();
+      }
     }
+    // ---- query side, per sample
     QueryLayerW QW;
     QW.c2s_in_wt = LW.c2s_in_w; QW.c2s_in_b = LW.c2s_in_b; QW.c2s_out_wt = LW.c2s_out_w; QW.c2s_out_b = LW.c2s_out_b;
     QW.c2s_norm_w = LW.c2s_norm_w; QW.c2s_norm_b = LW.c2s_norm_b;
@@ -1536,23 +1664,23 @@ static int run_decoder(const a3d_decoder_weights* w, const float* feats128, cons
     QW.next_c2s_in_wt = l + 1 < w->n_layers ? w->layers[l + 1].c2s_in_w : nullptr;
     QW.next_c2s_in_b = l + 1 < w->n_layers ? w->layers[l + 1].c2s_in_b : nullptr;
     QW.dim_ff = w->dim_ff;
-    {
-    ProfScope ps(st, A3D_PROF_QUERY, 0, 0, 0, 0, nq);
-    k_c2s_combine<<<nq * H, 64, 0, st>>>(part, n_part, B.attn, L.qp);
-    const size_t ql_lds = (size_t)4 * QP * kQLD * 4;
-    if (nblk == 1) {
-      k_query_layer<QT, 0><<<1, 512, ql_lds, st>>>(meta, QW, B);
-    } else {
-      k_query_layer<QT, 1><<<nblk, 512, ql_lds, st>>>(meta, QW, B);
-      k_query_layer<QT, 2><<<nblk, 512, ql_lds, st>>>(meta, QW, B);
-    }
+    for (int si = 0; si < ns; ++si) {
+      Prepared& p = P[si];
+      const int n_part = fuse_c2s ? (p.wg_end - p.wg_begin) * 4 : p.L.nchunk;
+      ProfScope ps(st, A3D_PROF_QUERY, 0, 0, 0, 0, p.hm.nq);
+      k_c2s_combine<<<p.hm.nq * H, 64, 0, st>>>(p.part, n_part, p.B.attn, p.L.qp);
+      const size_t ql_lds = (size_t)4 * QP * kQLD * 4;
+      if (nblk == 1) {
+        k_query_layer<QT, 0><<<1, 512, ql_lds, st>>>(p.meta, QW, p.B);
+      } else {
+        k_query_layer<QT, 1><<<nblk, 512, ql_lds, st>>>(p.meta, QW, p.B);
+        k_query_layer<QT, 2><<<nblk, 512, ql_lds, st>>>(p.meta, QW, p.B);
+      }
     }
     A3D_LAUNCH_CHECK();
     // ---- scene-to-click: Q = (src + pos) Wq^T + bq; attention; Y = O Wo^T + bo + src; LN
-    if (nblk == 1 && fused_c2s()) {
-      const int ngroups = (n + 15) / 16;
-      const int grid = (ngroups + 7) / 8 < 256 ? (ngroups + 7) / 8 : 256;
-      ProfScope ps(st, A3D_PROF_S2C, 0, 0, 0, 0, n);
+    if (fuse_s2c) {
+      ProfScope ps(st, A3D_PROF_S2C, 0, 0, 0, 0, (int)n_total);
       static int dec_dbg = -1;
       static unsigned long long* dbg_buf = nullptr;
       if (dec_dbg < 0) {
@@ -1560,8 +1688,7 @@ static int run_decoder(const a3d_decoder_weights* w, const float* feats128, cons
         dec_dbg = e ? atoi(e) : 0;
         if (dec_dbg) (void)hipMalloc(&dbg_buf, (size_t)256 * 8 * 8 * sizeof(unsigned long long));
       }
-      k_q_s2c<QT><<<grid, 512, (size_t)64 * 1024 + qs2c_lds, st>>>(src, posenc, n, LW.s2c_wq_packed, LW.s2c_in_b, B.ks, B.vs, nq,
-                                                                bufB, ngroups, dbg_buf);
+      k_q_s2c<QT><<<grid, 512, (size_t)64 * 1024 + qs2c_lds, st>>>(samples_dev, ns, l, LW.s2c_wq_packed, LW.s2c_in_b, dbg_buf);
       A3D_LAUNCH_CHECK();
       if (dbg_buf && l == 0) {   // per-wave phase cycles of the first layer's launch (debugging aid, synchronous)
         static unsigned long long hb[256 * 8 * 8];
@@ -1582,47 +1709,50 @@ static int run_decoder(const a3d_decoder_weights* w, const float* feats128, cons
                 sum[4] / nw, sum[5] / nw, t1 - t0);
       }
     } else {
-      rc = a3d_linear(src, D, posenc, D, n, D, D, LW.s2c_wq_packed, nullptr, LW.s2c_in_b, nullptr, 0, 0, bufA, D, nullptr, 0, st);
-      if (rc) return rc;
-      ProfScope ps(st, A3D_PROF_S2C, 0, 0, 0, 0, n);
-      k_s2c_attn_wide<QT><<<(n + 127) / 128, 512, s2c_lds, st>>>(bufA, n, B.ks, B.vs, nq, nblk, bufB);
-      A3D_LAUNCH_CHECK();
+      for (int si = 0; si < ns; ++si) {
+        Prepared& p = P[si];
+        const float* src = l == 0 ? p.feats : (((l - 1) & 1) ? p.bufD : p.bufC);
+        rc = a3d_linear(src, D, p.posenc, D, p.n, D, D, LW.s2c_wq_packed, nullptr, LW.s2c_in_b, nullptr, 0, 0, p.bufA, D, nullptr, 0, st);
+        if (rc) return rc;
+        ProfScope ps(st, A3D_PROF_S2C, 0, 0, 0, 0, p.n);
+        k_s2c_attn_wide<QT><<<(p.n + 127) / 128, 512, s2c_lds, st>>>(p.bufA, p.n, p.B.ks, p.B.vs, p.hm.nq, nblk, p.bufB);
+        A3D_LAUNCH_CHECK();
+      }
     }
-    float* Y = (l & 1) ? bufD : bufC;
-    const size_t fused_lds = (size_t)64 * 1024 + ((size_t)3 * D + QP * 132 + 8 * 16 * (QP + 1) + 8 * 16 * (K + 1)) * 4 + (size_t)(2 * K + 3) * 4;
-    if (nblk == 1 && fused_c2s() && fused_lds <= 160 * 1024) {
+    if (fuse_out) {
       // ---- output projection + residual + LayerNorm + mask head in one pass (the pre-norm activation stays on chip)
-      const int ngroups = (n + 15) / 16;
-      const int grid = (ngroups + 7) / 8 < 256 ? (ngroups + 7) / 8 : 256;
-      ProfScope ps(st, A3D_PROF_LNMASK, 0, 0, 0, 0, n);
-      k_out_ln_mask<QT><<<grid, 512, fused_lds, st>>>(bufB, src, n, LW.s2c_wo_packed, LW.s2c_out_b, LW.s2c_norm_w,
-                                                      LW.s2c_norm_b, B.E, nq, meta->qrange, hm.n_fg, K, Y,
-                                                      logits + (size_t)l * n * (K + 1), labels,
-                                                      counts + (size_t)l * (A3D_MAX_QUERIES + 1), ngroups);
+      ProfScope ps(st, A3D_PROF_LNMASK, 0, 0, 0, 0, (int)n_total);
+      k_out_ln_mask<QT><<<grid, 512, fused_lds, st>>>(samples_dev, ns, l, LW.s2c_wo_packed, LW.s2c_out_b, LW.s2c_norm_w,
+                                                      LW.s2c_norm_b);
       A3D_LAUNCH_CHECK();
     } else {
-      rc = a3d_linear(bufB, D, nullptr, 0, n, D, D, LW.s2c_wo_packed, nullptr, LW.s2c_out_b, src, D, 0, Y, D, nullptr, 0, st);
-      if (rc) return rc;
-      ProfScope ps(st, A3D_PROF_LNMASK, 0, 0, 0, 0, n);
-      k_ln_mask<QT><<<(n + 63) / 64, 256, lnm_lds, st>>>(Y, n, LW.s2c_norm_w, LW.s2c_norm_b, B.E, nq, meta->qrange,
-                                                        hm.n_fg, K, logits + (size_t)l * n * (K + 1), labels,
-                                                        counts + (size_t)l * (A3D_MAX_QUERIES + 1), nblk);
-      A3D_LAUNCH_CHECK();
+      for (int si = 0; si < ns; ++si) {
+        Prepared& p = P[si];
+        const float* src = l == 0 ? p.feats : (((l - 1) & 1) ? p.bufD : p.bufC);
+        float* Y = (l & 1) ? p.bufD : p.bufC;
+        const int K = p.hm.K;
+        const size_t lnm_lds = ((size_t)QP * 132 + 4 * 16 * (p.L.qp + 1) + 4 * 16 * (K + 1)) * 4 + (size_t)(K + 1) * 4;
+        rc = a3d_linear(p.bufB, D, nullptr, 0, p.n, D, D, LW.s2c_wo_packed, nullptr, LW.s2c_out_b, src, D, 0, Y, D, nullptr, 0, st);
+        if (rc) return rc;
+        ProfScope ps(st, A3D_PROF_LNMASK, 0, 0, 0, 0, p.n);
+        k_ln_mask<QT><<<(p.n + 63) / 64, 256, lnm_lds, st>>>(Y, p.n, LW.s2c_norm_w, LW.s2c_norm_b, p.B.E, p.hm.nq, p.meta->qrange,
+                                                          p.hm.n_fg, K, p.logits + (size_t)l * p.n * (K + 1), p.labels,
+                                                          p.counts + (size_t)l * (A3D_MAX_QUERIES + 1), nblk);
+        A3D_LAUNCH_CHECK();
+      }
     }
-    src = Y;
   }
   return A3D_OK;
 }
 
-extern "C" int a3d_decoder_forward(const a3d_decoder_weights* w, const float* feats128_dev, const float* xyz_dev,
-                                   const float* posenc_dev, const float* minmax_dev, int64_t n, const int32_t* click_row, const int32_t* click_obj,
-                                   const int32_t* click_time, int n_clicks, int n_objects, float* logits_dev,
-                                   void* workspace_dev, size_t workspace_bytes, void* stream) {
-  (void)xyz_dev;
-  (void)minmax_dev;   // click encodings equal the scene encoding rows (SURVEY App. C.1)
-  int rc = check_weights(w);
-  if (rc) return rc;
-  if (!feats128_dev || !posenc_dev || !logits_dev || n <= 0 || n_objects < 1 ||
+// validate one sample and lay out its workspace (a3d_decoder_forward / a3d_decoder_forward_batch)
+static int prepare_sample(const a3d_decoder_weights* w, const a3d_decoder_sample& sp, Prepared& P) {
+  const float* feats128_dev = sp.feats128_dev;
+  const float* posenc_dev = sp.posenc_dev;
+  const int64_t n = sp.n;
+  const int32_t *click_row = sp.click_row, *click_obj = sp.click_obj, *click_time = sp.click_time;
+  const int n_clicks = sp.n_clicks, n_objects = sp.n_objects;
+  if (!feats128_dev || !posenc_dev || !sp.logits_dev || n <= 0 || n > (int64_t)1 << 30 || n_objects < 1 ||
       n_clicks < n_objects || (n_clicks && (!click_row || !click_obj || !click_time))) {
     set_error("a3d_decoder_forward: bad arguments (every object needs >= 1 click, agile3d.py:353)");
     return A3D_ERR_INVALID;
@@ -1632,7 +1762,7 @@ extern "C" int a3d_decoder_forward(const a3d_decoder_weights* w, const float* fe
     set_error("a3d_decoder_forward: %d queries > %d", nq, A3D_MAX_QUERIES);
     return A3D_ERR_UNSUPPORTED;
   }
-  QueryMeta hm;
+  QueryMeta& hm = P.hm;
   memset(&hm, 0, sizeof(hm));
   hm.K = n_objects;
   hm.n_bgl = w->n_bg_queries;
@@ -1681,22 +1811,75 @@ extern "C" int a3d_decoder_forward(const a3d_decoder_weights* w, const float* fe
     hm.obj[i] = -1;
     hm.row[i] = -1;
   }
-  DecLayout L;
-  dec_layout(n, nq, L);
-  if (!workspace_dev || workspace_bytes < L.total || ((uintptr_t)workspace_dev & 255)) {
-    set_error("a3d_decoder_forward: workspace too small or misaligned (%zu < %zu)", workspace_bytes, L.total);
+  dec_layout(n, nq, P.L);
+  if (!sp.workspace_dev || sp.workspace_bytes < P.L.total || ((uintptr_t)sp.workspace_dev & 255)) {
+    set_error("a3d_decoder_forward: workspace too small or misaligned (%zu < %zu)", sp.workspace_bytes, P.L.total);
     return A3D_ERR_WORKSPACE;
+  }
+  P.ws = (char*)sp.workspace_dev;
+  P.feats = feats128_dev;
+  P.posenc = posenc_dev;
+  P.n = (int)n;
+  P.logits = sp.logits_dev;
+  P.bind();
+  return A3D_OK;
+}
+
+static int dispatch_decoder(const a3d_decoder_weights* w, Prepared* P, int ns, hipStream_t st) {
+  switch (P[0].L.qp) {
+    case 16: return run_decoder<1>(w, P, ns, st);
+    case 32: return run_decoder<2>(w, P, ns, st);
+    case 48: return run_decoder<3>(w, P, ns, st);
+    default: return run_decoder<4>(w, P, ns, st);
+  }
+}
+
+extern "C" int a3d_decoder_forward_batch(const a3d_decoder_weights* w, const a3d_decoder_sample* samples, int n_samples,
+                                         void* stream) {
+  int rc = check_weights(w);
+  if (rc) return rc;
+  if (!samples || n_samples < 1 || n_samples > 1024) {
+    set_error("a3d_decoder_forward_batch: bad arguments");
+    return A3D_ERR_INVALID;
   }
   if (w->dim_ff > 4096) {
     set_error("a3d_decoder_forward: dim_feedforward > 4096");
     return A3D_ERR_UNSUPPORTED;
   }
-  hipStream_t st = (hipStream_t)stream;
-  char* ws = (char*)workspace_dev;
-  switch (L.qp) {
-    case 16: return run_decoder<1>(w, feats128_dev, posenc_dev, n, hm, logits_dev, ws, L, st);
-    case 32: return run_decoder<2>(w, feats128_dev, posenc_dev, n, hm, logits_dev, ws, L, st);
-    case 48: return run_decoder<3>(w, feats128_dev, posenc_dev, n, hm, logits_dev, ws, L, st);
-    default: return run_decoder<4>(w, feats128_dev, posenc_dev, n, hm, logits_dev, ws, L, st);
+  std::vector<Prepared> P((size_t)n_samples);
+  for (int i = 0; i < n_samples; ++i) {
+    rc = prepare_sample(w, samples[i], P[(size_t)i]);
+    if (rc) return rc;
   }
+  hipStream_t st = (hipStream_t)stream;
+  // consecutive samples with the same padded query count go through the kernels together
+  for (int i = 0; i < n_samples;) {
+    int e = i + 1;
+    while (e < n_samples && e - i < kMaxBatchSamples && P[(size_t)e].L.qp == P[(size_t)i].L.qp) ++e;
+    rc = dispatch_decoder(w, &P[(size_t)i], e - i, st);
+    if (rc) return rc;
+    i = e;
+  }
+  return A3D_OK;
+}
+
+extern "C" int a3d_decoder_forward(const a3d_decoder_weights* w, const float* feats128_dev, const float* xyz_dev,
+                                   const float* posenc_dev, const float* minmax_dev, int64_t n, const int32_t* click_row, const int32_t* click_obj,
+                                   const int32_t* click_time, int n_clicks, int n_objects, float* logits_dev,
+                                   void* workspace_dev, size_t workspace_bytes, void* stream) {
+  (void)xyz_dev;
+  (void)minmax_dev;   // click encodings equal the scene encoding rows (SURVEY App. C.1)
+  a3d_decoder_sample sp;
+  sp.feats128_dev = feats128_dev;
+  sp.posenc_dev = posenc_dev;
+  sp.n = n;
+  sp.click_row = click_row;
+  sp.click_obj = click_obj;
+  sp.click_time = click_time;
+  sp.n_clicks = n_clicks;
+  sp.n_objects = n_objects;
+  sp.logits_dev = logits_dev;
+  sp.workspace_dev = workspace_dev;
+  sp.workspace_bytes = workspace_bytes;
+  return a3d_decoder_forward_batch(w, &sp, 1, stream);
 }

@@ -433,6 +433,10 @@ class Engine:
         n_layers = self.decoder.n_layers
         preds = [[] for _ in range(n_layers)]
         with torch.no_grad():
+            # the reference loops over the batch samples (agile3d.py:192); here every sample is described once and
+            # the whole batch goes through a3d_decoder_forward_batch (one launch of each wide kernel per layer)
+            samples = (L.DecoderSample * len(st.ranges))()
+            keep = []                                   # host arrays / tensors the library reads during the call
             for b, (s, e) in enumerate(st.ranges):
                 nb = e - s
                 ci, ct = click_idx[b], click_time_idx[b]
@@ -458,12 +462,19 @@ class Engine:
                 logits = torch.empty((n_layers, nb, K + 1), dtype=torch.float32, device=self.device)
                 arr = lambda v: (C.c_int32 * max(1, len(v)))(*v)
                 feats = pcd_features.F[s:e]
-                L.check(lib.a3d_decoder_forward(C.byref(W), _ptr(feats), _ptr(coordinates.F[s:e]),
-                                                _ptr(st.posenc[b]), _ptr(st.minmax[b]), nb,
-                                                arr(rows), arr(objs), arr(times), nc, K, _ptr(logits),
-                                                _ptr(ws), wsb, _stream()), "a3d_decoder_forward")
+                a_rows, a_objs, a_times = arr(rows), arr(objs), arr(times)
+                keep += [ws, feats, a_rows, a_objs, a_times]
+                sp = samples[b]
+                sp.feats128_dev, sp.posenc_dev, sp.n = _ptr(feats), _ptr(st.posenc[b]), nb
+                sp.click_row = C.cast(a_rows, C.POINTER(C.c_int32))
+                sp.click_obj = C.cast(a_objs, C.POINTER(C.c_int32))
+                sp.click_time = C.cast(a_times, C.POINTER(C.c_int32))
+                sp.n_clicks, sp.n_objects = nc, K
+                sp.logits_dev, sp.workspace_dev, sp.workspace_bytes = _ptr(logits), _ptr(ws), wsb
                 for l in range(n_layers):
                     preds[l].append(logits[l])
+            L.check(lib.a3d_decoder_forward_batch(C.byref(W), samples, len(st.ranges), _stream()),
+                    "a3d_decoder_forward_batch")
         out = {"pred_masks": preds[-1], "backbone_features": pcd_features}
         if self.model.aux:
             out["aux_outputs"] = [{"pred_masks": p} for p in preds[:-1]]

@@ -59,6 +59,14 @@ class ProfEntry(C.Structure):
                                          "ksplit")] + [("ms", C.c_float)]
 
 
+class DecoderSample(C.Structure):
+    """a3d_decoder_sample: one batch sample of a3d_decoder_forward_batch."""
+    _fields_ = [("feats128_dev", C.c_void_p), ("posenc_dev", C.c_void_p), ("n", C.c_int64),
+                ("click_row", C.POINTER(C.c_int32)), ("click_obj", C.POINTER(C.c_int32)),
+                ("click_time", C.POINTER(C.c_int32)), ("n_clicks", C.c_int32), ("n_objects", C.c_int32),
+                ("logits_dev", C.c_void_p), ("workspace_dev", C.c_void_p), ("workspace_bytes", C.c_size_t)]
+
+
 class ClickCluster(C.Structure):
     _fields_ = [("cluster_id", C.c_int32), ("row", C.c_int32), ("label", C.c_int32), ("pred", C.c_int32),
                 ("error_size", C.c_float)]
@@ -94,6 +102,7 @@ SYMBOLS = {
     "a3d_posenc_fourier": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                      C.c_size_t, C.c_void_p]),
     "a3d_decoder_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int]),
+    "a3d_decoder_forward_batch": (C.c_int, [C.POINTER(DecoderWeights), C.POINTER(DecoderSample), C.c_int, C.c_void_p]),
     "a3d_decoder_forward": (C.c_int, [C.POINTER(DecoderWeights), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                       C.c_int64, C.POINTER(C.c_int32), C.POINTER(C.c_int32),
                                       C.POINTER(C.c_int32), C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t,

@@ -215,6 +215,24 @@ typedef struct {
 } a3d_decoder_weights;
 
 size_t a3d_decoder_workspace_bytes(int64_t n, int n_queries);
+
+/* One batch sample of forward_mask (agile3d.py:192: the reference loops `for b in range(batch_size)`).  Fields as in
+ * a3d_decoder_forward; every sample brings its own workspace (a3d_decoder_workspace_bytes(n, n_clicks + n_bg)). */
+typedef struct a3d_decoder_sample {
+  const float* feats128_dev;            /* [n][128] rows of this sample */
+  const float* posenc_dev;              /* [n][128] */
+  int64_t n;
+  const int32_t *click_row, *click_obj, *click_time;   /* HOST arrays, see below */
+  int32_t n_clicks, n_objects;
+  float* logits_dev;                    /* n_layers x [n][1 + n_objects] */
+  void* workspace_dev;
+  size_t workspace_bytes;
+} a3d_decoder_sample;
+/* All samples of a batch in one call: per decoder layer the three wide kernels are launched once for the whole batch
+ * (samples with the same padded query count share the launches); results per sample equal a3d_decoder_forward's up to
+ * the summation order of the click-to-scene partials. */
+int    a3d_decoder_forward_batch(const a3d_decoder_weights* w, const a3d_decoder_sample* samples, int n_samples,
+                                 void* stream);
 /* click arrays are HOST arrays, object-major as the reference builds its queries
  * (agile3d.py:249-264): all clicks of object 1, ..., object K, then background clicks.
  * click_obj[i] in 0..K (0 = background), click_row = row of the sample, click_time < 200.
