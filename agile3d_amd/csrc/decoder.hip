@@ -115,6 +115,29 @@ __global__ void k_fourier(const float* __restrict__ xyz, int n, const float* __r
   out[(size_t)i * D + 64 + jj] = cosf(p);
 }
 
+struct QueryMeta {   // device-resident, uploaded once per forward_mask
+  int n_fg, n_bg_click, n_bgl, nq, K;
+  int row[A3D_MAX_QUERIES];     // click row per query (-1 for learned bg)
+  int time[A3D_MAX_QUERIES];    // click time per query
+  int obj[A3D_MAX_QUERIES];     // object id per query (0 = background, -1 = padding)
+  int qrange[A3D_MAX_QUERIES + 2];
+};
+
+struct QueryBufs {   // all [QP][...] fp32 in global scratch
+  float *queries, *qpos, *qproj, *ks, *vs, *E;
+  float *attn, *tmp, *tgt, *qk, *vc, *hidden;
+};
+
+// ---- one batch sample as the query-side kernels see it (k_query_init, k_c2s_combine, k_query_layer: blockIdx.y)
+struct QuerySample {
+  const QueryMeta* meta;
+  QueryBufs B;
+  const float *feats, *posenc;   // the sample's rows: click features / encodings are gathered from them
+  int* counts;
+  const float* part;             // click-to-scene flash partials of this sample and how many there are
+  int n_part;
+};
+
 // ---- one batch sample as the fused wide kernels see it (a3d_decoder_forward_batch) ------------------------------
 // The three persistent wide kernels of a decoder layer (k_kv_c2s, k_q_s2c, k_out_ln_mask) are launched ONCE for all
 // samples of a batch: workgroups [wg_begin, wg_end) work on this sample (its queries' data in their LDS), the waves
@@ -428,8 +451,13 @@ __global__ void __launch_bounds__(512) k_kv_c2s(const DecSampleDev* __restrict__
 constexpr int kFusedC2SGrid = 256;   // one persistent 8-wave workgroup per CU (128 KB of weights in LDS)
 
 // merge the per-chunk flash partials (m, l, acc[16]) of one (query, head): one wave per pair
-__global__ void __launch_bounds__(64) k_c2s_combine(const float* __restrict__ part, int nchunk, float* attn, int QP) {
+__global__ void __launch_bounds__(64) k_c2s_combine(const QuerySample* __restrict__ qs, int QP) {
+  const QuerySample& smp = qs[blockIdx.y];
   const int q = blockIdx.x / H, h = blockIdx.x % H, lane = threadIdx.x;
+  if (q >= smp.meta->nq) return;
+  const float* __restrict__ part = smp.part;
+  const int nchunk = smp.n_part;
+  float* attn = smp.B.attn;
   float m = kNegBig, l = 0.f, o[DH];
 #pragma unroll
   for (int d = 0; d < DH; ++d) o[d] = 0.f;
@@ -968,14 +996,6 @@ __global__ void __launch_bounds__(512) k_out_ln_mask(const DecSampleDev* __restr
 }
 
 // ------------------------------------------------------------------------------ query side
-struct QueryMeta {   // device-resident, uploaded once per forward_mask
-  int n_fg, n_bg_click, n_bgl, nq, K;
-  int row[A3D_MAX_QUERIES];     // click row per query (-1 for learned bg)
-  int time[A3D_MAX_QUERIES];    // click time per query
-  int obj[A3D_MAX_QUERIES];     // object id per query (0 = background, -1 = padding)
-  int qrange[A3D_MAX_QUERIES + 2];
-};
-
 struct QueryLayerW {
   const float *c2s_in_wt, *c2s_in_b, *c2s_out_wt, *c2s_out_b, *c2s_norm_w, *c2s_norm_b;
   const float *c2c_in_wt, *c2c_in_b, *c2c_out_wt, *c2c_out_b, *c2c_norm_w, *c2c_norm_b;
@@ -986,10 +1006,6 @@ struct QueryLayerW {
   int dim_ff;
 };
 
-struct QueryBufs {   // all [QP][...] fp32 in global scratch
-  float *queries, *qpos, *qproj, *ks, *vs, *E;
-  float *attn, *tmp, *tgt, *qk, *vc, *hidden;
-};
 
 // Y[q][n] = ((X[q][:] (+ Xadd[q][:])) . W[n][:] + bias[n]) * scale, optional relu -- a skinny GEMM
 // on the matrix cores.  W is the torch weight [N][ldw] (K contiguous): lane (g, j) loads
@@ -1084,12 +1100,15 @@ __device__ __noinline__ void add_ln(const float* a, const float* b, int Q, const
 }
 
 template <int QT>
-__global__ void __launch_bounds__(512) k_query_init(const QueryMeta* meta, const float* feats128,
-                                                     const float* posenc, const float* bg_feat,
+__global__ void __launch_bounds__(512) k_query_init(const QuerySample* __restrict__ qs, const float* bg_feat,
                                                      const float* bg_pos, const float* time_table,
-                                                     const float* c2s_in_wt, const float* c2s_in_b,
-                                                     QueryBufs B, int* counts, int n_counts) {
+                                                     const float* c2s_in_wt, const float* c2s_in_b, int n_counts) {
   constexpr int QP = QT * 16;
+  const QueryMeta* meta = qs[blockIdx.y].meta;
+  const float* feats128 = qs[blockIdx.y].feats;
+  const float* posenc = qs[blockIdx.y].posenc;
+  QueryBufs B = qs[blockIdx.y].B;
+  int* counts = qs[blockIdx.y].counts;
   __shared__ __attribute__((aligned(16))) float lds[QP * kLinLD];
   const int q0 = blockIdx.x * QP;                 // this workgroup's block of queries
   const int Q = max(0, min(QP, meta->nq - q0)), n_fg = meta->n_fg, n_bgl = meta->n_bgl;
@@ -1206,8 +1225,10 @@ __device__ __forceinline__ void qadd_ln(const float* a, const float* b, int Q, c
 // workgroup each, in two launches around the click-to-click attention (which needs every block's
 // keys/values): PART 1 = steps 1-2 up to the q/k/v projections (tgt kept in B.tgt), PART 2 = the rest.
 template <int QT, int PART>
-__global__ void __launch_bounds__(512) k_query_layer(const QueryMeta* meta, QueryLayerW W, QueryBufs B) {
+__global__ void __launch_bounds__(512) k_query_layer(const QuerySample* __restrict__ qs, QueryLayerW W) {
   constexpr int QP = QT * 16;
+  const QueryMeta* meta = qs[blockIdx.y].meta;
+  QueryBufs B = qs[blockIdx.y].B;
   const int q0 = blockIdx.x * QP;
   const int Qall = meta->nq;
   const float* all_qk = B.qk;
@@ -1455,7 +1476,7 @@ void dec_layout(int64_t n, int nq, DecLayout& L) {
   L.counts = take((size_t)A3D_MAX_DEC_LAYERS * (A3D_MAX_QUERIES + 1) * 4);
   L.part = take((size_t)(L.nchunk > kFusedC2SGrid * 8 ? L.nchunk : kFusedC2SGrid * 8) * H * L.qp * kPartStride * 4);
   L.meta = take(sizeof(QueryMeta));
-  L.desc = take(sizeof(DecSampleDev) * kMaxBatchSamples);   // sample table of a batched call (kept in the first sample's workspace)
+  L.desc = take((sizeof(DecSampleDev) + sizeof(QuerySample)) * kMaxBatchSamples);   // sample tables of a batched call (kept in the first sample's workspace)
   const size_t qb = (size_t)L.qp * D * 4;
   for (int i = 0; i < 9; ++i) L.q[i] = take(qb);        // queries qpos qproj ks vs E attn tmp tgt
   L.q[9] = take(2 * qb);                                // qk
@@ -1560,11 +1581,7 @@ static int run_decoder(const a3d_decoder_weights* w, Prepared* P, int ns, hipStr
     Kmax = p.hm.K > Kmax ? p.hm.K : Kmax;
     nq_max = p.hm.nq > nq_max ? p.hm.nq : nq_max;
     A3D_HIP_CHECK(hipMemcpyAsync(p.meta, &p.hm, sizeof(QueryMeta), hipMemcpyHostToDevice, st));
-    ProfScope ps(st, A3D_PROF_QUERY, 0, 0, 0, 0, p.hm.nq);
-    k_query_init<QT><<<nblk, 512, 0, st>>>(p.meta, p.feats, p.posenc, w->bg_query_feat, w->bg_query_pos, w->time_table,
-                                         w->layers[0].c2s_in_w, w->layers[0].c2s_in_b, p.B, p.counts, n_counts);
   }
-  A3D_LAUNCH_CHECK();
   const size_t s2c_lds = (size_t)2 * QP * 132 * 4;             // keys + values of the queries (k_s2c_attn_wide)
   const size_t qs2c_lds = ((size_t)QP * 132 + (size_t)D * (QP + 4) + D) * 4;   // k_q_s2c: keys, transposed values, bias
   const size_t fused_lds = (size_t)64 * 1024 + ((size_t)3 * D + QP * 132 + 8 * 16 * (QP + 1) + 8 * 16 * (Kmax + 1)) * 4 +
@@ -1584,6 +1601,7 @@ static int run_decoder(const a3d_decoder_weights* w, Prepared* P, int ns, hipStr
   // ---- sample table: workgroups of the persistent kernels in proportion to the samples' point groups
   int grid = 0;
   DecSampleDev* samples_dev = (DecSampleDev*)(P[0].ws + P[0].L.desc);
+  QuerySample* qs_dev = (QuerySample*)(samples_dev + kMaxBatchSamples);
   {
     DecSampleDev hd[kMaxBatchSamples];
     int64_t tot_groups = 0;
@@ -1623,6 +1641,24 @@ static int run_decoder(const a3d_decoder_weights* w, Prepared* P, int ns, hipStr
     }
     // pageable source: the runtime stages it before returning (like the QueryMeta copies above)
     A3D_HIP_CHECK(hipMemcpyAsync(samples_dev, hd, sizeof(DecSampleDev) * ns, hipMemcpyHostToDevice, st));
+    QuerySample hq[kMaxBatchSamples];
+    for (int si = 0; si < ns; ++si) {
+      Prepared& p = P[si];
+      hq[si].meta = p.meta;
+      hq[si].B = p.B;
+      hq[si].feats = p.feats;
+      hq[si].posenc = p.posenc;
+      hq[si].counts = p.counts;
+      hq[si].part = p.part;
+      hq[si].n_part = fuse_c2s ? (p.wg_end - p.wg_begin) * 4 : p.L.nchunk;
+    }
+    A3D_HIP_CHECK(hipMemcpyAsync(qs_dev, hq, sizeof(QuerySample) * ns, hipMemcpyHostToDevice, st));
+  }
+  {
+    ProfScope ps(st, A3D_PROF_QUERY, 0, 0, 0, 0, nq_max);
+    k_query_init<QT><<<dim3(nblk, ns), 512, 0, st>>>(qs_dev, w->bg_query_feat, w->bg_query_pos, w->time_table,
+                                                    w->layers[0].c2s_in_w, w->layers[0].c2s_in_b, n_counts);
+    A3D_LAUNCH_CHECK();
   }
   for (int l = 0; l < w->n_layers; ++l) {
     const a3d_decoder_layer& LW = w->layers[l];
@@ -1664,17 +1700,15 @@ static int run_decoder(const a3d_decoder_weights* w, Prepared* P, int ns, hipStr
     QW.next_c2s_in_wt = l + 1 < w->n_layers ? w->layers[l + 1].c2s_in_w : nullptr;
     QW.next_c2s_in_b = l + 1 < w->n_layers ? w->layers[l + 1].c2s_in_b : nullptr;
     QW.dim_ff = w->dim_ff;
-    for (int si = 0; si < ns; ++si) {
-      Prepared& p = P[si];
-      const int n_part = fuse_c2s ? (p.wg_end - p.wg_begin) * 4 : p.L.nchunk;
-      ProfScope ps(st, A3D_PROF_QUERY, 0, 0, 0, 0, p.hm.nq);
-      k_c2s_combine<<<p.hm.nq * H, 64, 0, st>>>(p.part, n_part, p.B.attn, p.L.qp);
+    {   // one workgroup (or chain of query blocks) per sample: blockIdx.y
+      ProfScope ps(st, A3D_PROF_QUERY, 0, 0, 0, 0, nq_max);
+      k_c2s_combine<<<dim3(nq_max * H, ns), 64, 0, st>>>(qs_dev, P[0].L.qp);
       const size_t ql_lds = (size_t)4 * QP * kQLD * 4;
       if (nblk == 1) {
-        k_query_layer<QT, 0><<<1, 512, ql_lds, st>>>(p.meta, QW, p.B);
+        k_query_layer<QT, 0><<<dim3(1, ns), 512, ql_lds, st>>>(qs_dev, QW);
       } else {
-        k_query_layer<QT, 1><<<nblk, 512, ql_lds, st>>>(p.meta, QW, p.B);
-        k_query_layer<QT, 2><<<nblk, 512, ql_lds, st>>>(p.meta, QW, p.B);
+        k_query_layer<QT, 1><<<dim3(nblk, ns), 512, ql_lds, st>>>(qs_dev, QW);
+        k_query_layer<QT, 2><<<dim3(nblk, ns), 512, ql_lds, st>>>(qs_dev, QW);
       }
     }
     A3D_LAUNCH_CHECK();
