@@ -159,6 +159,36 @@ def test_batch_of_two_equals_two_single_scenes(model_and_sd):
     assert (out["pred_masks"][1] - singles[1][1]).abs().max().item() <= 1e-4
 
 
+def test_batched_decoder_equals_per_sample_runs(model_and_sd):
+    """a3d_decoder_forward_batch: samples with the same padded query count share one launch of each wide kernel per
+    layer (sample table), others go separately.  Four samples -- 14, 22 and 26 queries (the last two share launches),
+    one with 44 -- different object counts: every layer's logits must equal the single-sample results."""
+    model, sd = model_and_sd
+    specs = [(2600, 11, 2, 2, 0), (3100, 12, 3, 4, 0), (2800, 13, 4, 3, 4), (3000, 14, 2, 15, 4)]
+    scenes = [make_scene(n, seed=sd_) for n, sd_, *_ in specs]
+    clicks = [make_clicks(sc["labels"], sp[2], sp[3], sp[4], seed=sp[1]) for sc, sp in zip(scenes, specs)]
+    singles = []
+    for sc, (ci, ct) in zip(scenes, clicks):
+        r = _run_backbone(model, sc)
+        o = model.forward_mask(*r, click_idx=[ci], click_time_idx=[ct])
+        singles.append([o["pred_masks"][0]] + [a["pred_masks"][0] for a in o["aux_outputs"]])
+    coords = []
+    for b, sc in enumerate(scenes):
+        c = sc["coords"].copy()
+        c[:, 0] = b
+        coords.append(c)
+    x = SparseTensor(features=torch.from_numpy(np.concatenate([sc["feats"] for sc in scenes])),
+                     coordinates=torch.from_numpy(np.concatenate(coords)), device="cuda")
+    raw = torch.from_numpy(np.concatenate([sc["raw_xyz"] for sc in scenes])).cuda()
+    r = model.forward_backbone(x, raw_coordinates=raw)
+    out = model.forward_mask(*r, click_idx=[c[0] for c in clicks], click_time_idx=[c[1] for c in clicks])
+    for b in range(len(scenes)):
+        got = [out["pred_masks"][b]] + [a["pred_masks"][b] for a in out["aux_outputs"]]
+        for g, ref in zip(got, singles[b]):
+            assert g.shape == ref.shape
+            assert (g - ref).abs().max().item() <= 1e-4, (b, (g - ref).abs().max().item())
+
+
 def test_full_size_properties(model_and_sd):
     """BASELINE.json config 2 (80 k voxels, 10 clicks): size-independent properties.
     (a) row-permutation equivariance: shuffling the caller's row order permutes the outputs;
