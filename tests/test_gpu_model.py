@@ -189,6 +189,31 @@ def test_batched_decoder_equals_per_sample_runs(model_and_sd):
             assert (g - ref).abs().max().item() <= 1e-4, (b, (g - ref).abs().max().item())
 
 
+def test_many_small_samples_in_one_batch(model_and_sd):
+    """70 samples: more than one sample table (64 entries) -> the batch is cut into two groups of launches; the
+    workgroup shares of tiny samples are clamped to what their few 16-point groups can use."""
+    model, sd = model_and_sd
+    scenes, clicks, coords = [], [], []
+    for b in range(70):
+        sc = make_scene(400 + 13 * b, seed=100 + b, n_boxes=4)
+        scenes.append(sc)
+        clicks.append(make_clicks(sc["labels"], 2, 1 + b % 2, 0, seed=b))
+        c = sc["coords"].copy()
+        c[:, 0] = b
+        coords.append(c)
+    x = SparseTensor(features=torch.from_numpy(np.concatenate([sc["feats"] for sc in scenes])),
+                     coordinates=torch.from_numpy(np.concatenate(coords)), device="cuda")
+    raw = torch.from_numpy(np.concatenate([sc["raw_xyz"] for sc in scenes])).cuda()
+    r = model.forward_backbone(x, raw_coordinates=raw)
+    out = model.forward_mask(*r, click_idx=[c[0] for c in clicks], click_time_idx=[c[1] for c in clicks])
+    for b in (0, 1, 37, 63, 64, 69):
+        rb = _run_backbone(model, scenes[b])
+        ref = model.forward_mask(*rb, click_idx=[clicks[b][0]], click_time_idx=[clicks[b][1]])["pred_masks"][0]
+        got = out["pred_masks"][b]
+        assert got.shape == ref.shape == (len(scenes[b]["coords"]), 3)
+        assert (got - ref).abs().max().item() <= 1e-4, b
+
+
 def test_full_size_properties(model_and_sd):
     """BASELINE.json config 2 (80 k voxels, 10 clicks): size-independent properties.
     (a) row-permutation equivariance: shuffling the caller's row order permutes the outputs;
