@@ -6,6 +6,8 @@ Public surface (mirrors the reference):
     Agile3d.forward_backbone     models/agile3d.py:163-181
     Agile3d.forward_mask         models/agile3d.py:183-339
     SparseTensor, utils          the subset of MinkowskiEngine the callers touch
+Around the path (same names as the reference): ``datasets`` (scan datasets + collate), ``ply`` (binary PLY),
+``evaluate`` (Evaluate loops, NoC / IoU@k tables), ``clicks`` (click simulator, IoU), ``criterion`` (mask losses).
 """
 from .model import build_model, build_agile3d, Agile3d, default_args, randomize_bn_stats  # noqa: F401
 from .sparse import SparseTensor, sparse_quantize, batched_coordinates  # noqa: F401
