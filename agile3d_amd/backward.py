@@ -1,0 +1,119 @@
+"""Backward of the sparse convolutions (first part of SURVEY.md section 8 row f-2, the training path):
+
+    conv_input_grad(scene, kind, level_in, w, dy)        dL/dx of conv / conv_tr (models/modules/common.py:125-188)
+    conv_weight_grad(scene, kind, level_in, x, dy, K)    dL/dW [K, Cin, Cout]
+
+for the four kernel-map kinds of the backbone (3^3 stride 1, 2^3 stride 2, 2^3 transposed, 1x1).  What autograd does
+inside MinkowskiEngine for ``engine.py:137-150`` (``losses.backward()``); the rest of the training step (BatchNorm in
+training mode, the decoder's backward, the optimiser) is not built yet -- DESIGN.md section 7.
+
+The input gradient needs no new kernel: it is the FORWARD kernel on the transposed kernel map with transposed
+weights -- for the 3^3 stride-1 map offset k of row i is row j exactly when offset 26-k of j is i, so
+dx = conv3(dy, W'[k] = W[26-k]^T) on the same neighbour tables; the stride-2 conv's input gradient is the transposed
+conv with W_s^T and vice versa; 1x1 is a GEMM with W^T.  The weight gradient is its own kernel (csrc/wgrad.hip).
+All tensors are in the scene's internal row order (the order of the op program's activation buffers), on the GPU.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import lib as L
+
+_KVOL = {L.OP_CONV3: 27, L.OP_DOWN: 8, L.OP_UP: 8, L.OP_LINEAR: 1}
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def level_out(kind, level_in):
+    return level_in + (1 if kind == L.OP_DOWN else -1 if kind == L.OP_UP else 0)
+
+
+def pack_weight(w: torch.Tensor) -> torch.Tensor:
+    """[K, Cin, Cout] (ME layout) -> the MFMA fragment order the conv kernels read (a3d_pack_conv_weight)."""
+    lib = L.load()
+    w = w.contiguous()
+    out = torch.empty_like(w)
+    L.check(lib.a3d_pack_conv_weight(_ptr(w), w.shape[0], w.shape[1], w.shape[2], _ptr(out), _stream()),
+            "a3d_pack_conv_weight")
+    return out
+
+
+def run_conv(scene, kind, level_in, w_packed, x, cin, cout):
+    """One conv of the op program on its own: x [n_in, cin] -> [n_out, cout] (no BatchNorm / ReLU / residual)."""
+    lib = L.load()
+    if not x.is_cuda or x.dtype != torch.float32:
+        raise RuntimeError("agile3d_amd.backward runs on the GPU only (fp32 CUDA tensors)")
+    lo = level_out(kind, level_in)
+    n_in, n_out = scene.n[level_in], scene.n[lo]
+    if x.shape != (n_in, cin):
+        raise ValueError(f"input must be [{n_in}, {cin}], got {tuple(x.shape)}")
+    bufs = (L.BufDesc * 2)(L.BufDesc(level_in, cin), L.BufDesc(lo, cout))
+    o = L.Op()
+    o.kind, o.level_in, o.cin, o.cout = kind, level_in, cin, cout
+    o.in_buf, o.in_coff, o.out_buf, o.out_coff = 0, 0, 1, 0
+    o.res_buf, o.res_coff, o.relu, o.kernel_volume = L.BUF_NONE, 0, 0, _KVOL[kind]
+    o.w_dev, o.scale_dev, o.shift_dev = w_packed.data_ptr(), None, None
+    ops = (L.Op * 1)(o)
+    nbytes = lib.a3d_program_workspace_bytes(scene.handle, bufs, 2, ops, 1)
+    if nbytes == 0:
+        raise L.A3DError(lib.a3d_last_error().decode())
+    ws = torch.zeros(nbytes, dtype=torch.uint8, device=x.device)
+
+    def view(i, rows, ch):
+        off = lib.a3d_program_buffer_offset(scene.handle, bufs, 2, i)
+        return ws[off:off + (rows + 1) * ch * 4].view(torch.float32).view(rows + 1, ch)
+    view(0, n_in, cin)[:n_in].copy_(x)
+    L.check(lib.a3d_program_run(scene.handle, bufs, 2, ops, 1, None, None, 0, _ptr(ws), nbytes, _stream()),
+            "a3d_program_run")
+    return view(1, n_out, cout)[:n_out].clone()
+
+
+def conv_input_grad(scene, kind, level_in, w: torch.Tensor, dy: torch.Tensor) -> torch.Tensor:
+    """dL/dx [n_in, Cin] of y = conv(x; W) from dL/dy [n_out, Cout]; ``w`` is the forward weight [K, Cin, Cout]."""
+    K, cin, cout = w.shape
+    if K != _KVOL[kind]:
+        raise ValueError(f"kind {kind} needs kernel volume {_KVOL[kind]}, got {K}")
+    wt = w.transpose(1, 2)                               # [K, Cout, Cin]
+    if kind == L.OP_CONV3:
+        wt = wt.flip(0)                                  # offset k of the backward map is offset 26-k of the forward map
+    back_kind = {L.OP_CONV3: L.OP_CONV3, L.OP_DOWN: L.OP_UP, L.OP_UP: L.OP_DOWN, L.OP_LINEAR: L.OP_LINEAR}[kind]
+    dy = dy.contiguous()
+    # the conv kernels write 32 / 64 / 96 or multiples of 128 output columns: the concatenated inputs of the decoder
+    # blocks (192 = 128 + 64 channels) get their gradient in column slices
+    parts, c0 = [], 0
+    while c0 < cin:
+        rest = cin - c0
+        width = rest if (rest % 128 == 0 or rest in (32, 64, 96)) else max(w_ for w_ in (128, 96, 64, 32) if w_ <= rest)
+        parts.append(run_conv(scene, back_kind, level_out(kind, level_in), pack_weight(wt[:, :, c0:c0 + width].contiguous()),
+                              dy, cout, width))
+        c0 += width
+    return parts[0] if len(parts) == 1 else torch.cat(parts, 1)
+
+
+def conv_weight_grad(scene, kind, level_in, x: torch.Tensor, dy: torch.Tensor) -> torch.Tensor:
+    """dL/dW [K, Cin, Cout] = sum over the kernel map's (input row, output row) pairs of offset k of x_in^T dy_out."""
+    lib = L.load()
+    if not (x.is_cuda and dy.is_cuda and x.dtype == dy.dtype == torch.float32):
+        raise RuntimeError("agile3d_amd.backward runs on the GPU only (fp32 CUDA tensors)")
+    lo = level_out(kind, level_in)
+    cin, cout = x.shape[1], dy.shape[1]
+    if x.shape[0] != scene.n[level_in] or dy.shape[0] != scene.n[lo]:
+        raise ValueError("x / dy row counts do not match the scene levels")
+    x, dy = x.contiguous(), dy.contiguous()
+    K = _KVOL[kind]
+    dw = torch.empty((K, cin, cout), dtype=torch.float32, device=x.device)
+    nbytes = lib.a3d_conv_wgrad_workspace_bytes(scene.handle, kind, level_in, cin, cout)
+    if nbytes == 0:
+        raise L.A3DError(lib.a3d_last_error().decode())
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+    L.check(lib.a3d_conv_wgrad(scene.handle, kind, level_in, _ptr(x), x.shape[1], _ptr(dy), dy.shape[1], cin, cout,
+                               _ptr(dw), _ptr(ws), nbytes, _stream()), "a3d_conv_wgrad")
+    return dw

@@ -102,6 +102,9 @@ SYMBOLS = {
     "a3d_posenc_fourier": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                      C.c_size_t, C.c_void_p]),
     "a3d_decoder_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int]),
+    "a3d_conv_wgrad_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "a3d_conv_wgrad": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int,
+                                 C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "a3d_decoder_forward_batch": (C.c_int, [C.POINTER(DecoderWeights), C.POINTER(DecoderSample), C.c_int, C.c_void_p]),
     "a3d_decoder_forward": (C.c_int, [C.POINTER(DecoderWeights), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                       C.c_int64, C.POINTER(C.c_int32), C.POINTER(C.c_int32),

@@ -156,6 +156,21 @@ int    a3d_program_run(const a3d_scene* s, const a3d_buf_desc* bufs, int n_bufs,
                        float* ext_out_dev, int ext_out_ld,
                        void* workspace_dev, size_t workspace_bytes, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Backward of the sparse convolutions (first part): what MinkowskiEngine's autograd
+ * computes for `losses.backward()` (engine.py:137-150) through conv / conv_tr (models/modules/common.py:125-188).
+ * dL/dx needs no entry point of its own: it is a3d_program_run on the transposed kernel map with transposed weights
+ * (3^3: W'[k] = W[26-k]^T, same op; stride 2 <-> transposed with W_s^T; 1x1: W^T) -- agile3d_amd/backward.py.
+ * a3d_conv_wgrad: dW[k][ci][co] = sum over the pairs (r_in, r_out) of offset k of x[r_in][ci] * dy[r_out][co];
+ * kind / level_in as in the op struct: A3D_OP_CONV3 / DOWN / UP / LINEAR, x [n_in][ldx], dy [n_out][ldy] in the scene's
+ * internal row order, channels multiples of 32, dw_dev [K][cin][cout] (ME layout).  Deterministic (fixed summation
+ * order).
+ * ------------------------------------------------------------------------------------------ */
+size_t a3d_conv_wgrad_workspace_bytes(const a3d_scene* s, int kind, int level_in, int cin, int cout);
+int    a3d_conv_wgrad(const a3d_scene* s, int kind, int level_in, const float* x_dev, int ldx,
+                      const float* dy_dev, int ldy, int cin, int cout, float* dw_dev,
+                      void* workspace_dev, size_t workspace_bytes, void* stream);
+
 /* Dense row-major GEMM: out[n][cout] = act(((in (+ in_add))[n][cin] @ W) * scale + shift + res).
  * Replaces the nn.Linear / in_proj pieces of nn.MultiheadAttention that run over all N points
  * (models/modules/attention_block.py:91-94; `in_add` is the position encoding the reference adds to

@@ -1,0 +1,67 @@
+#!/usr/bin/env python3
+"""Timing of the sparse-conv backward kernels (row f-2, first part) on the bench scene: input gradient (the forward
+kernel on the transposed map) and weight gradient (k_wgrad) per layer shape, algorithmic TFLOP/s = 2*pairs*Cin*Cout/t.
+Usage: python tools/backward_bench.py [--voxels N] [--batch B]"""
+import argparse
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from agile3d_amd import backward as B  # noqa: E402
+from agile3d_amd import lib as L  # noqa: E402
+from agile3d_amd.engine import Scene  # noqa: E402
+from agile3d_amd.synthetic import make_scene  # noqa: E402
+
+CASES = [("L0 3^3  96-> 96", L.OP_CONV3, 0, 96, 96), ("L0 3^3 128-> 96", L.OP_CONV3, 0, 128, 96),
+         ("L1 3^3  96-> 96", L.OP_CONV3, 1, 96, 96), ("L1 3^3  32-> 32", L.OP_CONV3, 1, 32, 32),
+         ("L2 3^3 128->128", L.OP_CONV3, 2, 128, 128), ("L3 3^3 256->256", L.OP_CONV3, 3, 256, 256),
+         ("L4 3^3 256->256", L.OP_CONV3, 4, 256, 256), ("L0 2^3s2 32->32", L.OP_DOWN, 0, 32, 32),
+         ("L1 2^3tr 96->96", L.OP_UP, 1, 96, 96), ("L0 1x1  96->128", L.OP_LINEAR, 0, 96, 128)]
+
+
+def timed(fn, reps):
+    fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--voxels", type=int, default=80_000)
+    ap.add_argument("--batch", type=int, default=1)
+    ap.add_argument("--reps", type=int, default=10)
+    a = ap.parse_args()
+    coords = np.concatenate([make_scene(a.voxels, seed=b, batch_index=b)["coords"] for b in range(a.batch)])
+    sc = Scene(torch.from_numpy(coords).cuda())
+    print("levels", sc.n)
+    pairs3 = []
+    for lvl in range(5):
+        npad = (max(sc.n[lvl], 1) + 127) // 128 * 128
+        nb = sc.table(lvl, L.TAB_NBR27).reshape(27, npad)
+        pairs3.append(int((nb[:, :sc.n[lvl]] < sc.n[lvl]).sum()))
+    for name, kind, lvl, cin, cout in CASES:
+        lo = B.level_out(kind, lvl)
+        K = {L.OP_CONV3: 27, L.OP_DOWN: 8, L.OP_UP: 8, L.OP_LINEAR: 1}[kind]
+        pairs = pairs3[lvl] if kind == L.OP_CONV3 else sc.n[min(lvl, lo)]
+        x = torch.randn(sc.n[lvl], cin, device="cuda")
+        dy = torch.randn(sc.n[lo], cout, device="cuda")
+        w = torch.randn(K, cin, cout, device="cuda") / (cin * 4) ** 0.5
+        t_w = timed(lambda: B.conv_weight_grad(sc, kind, lvl, x, dy), a.reps)
+        t_x = timed(lambda: B.conv_input_grad(sc, kind, lvl, w, dy), a.reps)
+        fl = 2.0 * pairs * cin * cout
+        print(f"{name}: pairs {pairs:8d}  dW {1e3 * t_w:8.1f} us {fl / t_w / 1e9:6.1f} TF/s   "
+              f"dx (incl. weight repack + buffer copies) {1e3 * t_x:8.1f} us {fl / t_x / 1e9:6.1f} TF/s")
+
+
+if __name__ == "__main__":
+    main()
