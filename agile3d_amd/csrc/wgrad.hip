@@ -31,6 +31,7 @@ struct WgradArgs {
   int n_pos;             // positions (output rows of the kernel map)
   int K, cin, cout;
   int chunk_groups;      // 16-position groups per chunk
+  int n_chunks;
   float* part;           // [chunks][K][cin][cout]
 };
 
@@ -62,11 +63,17 @@ __global__ void __launch_bounds__(256) k_wgrad(const WgradArgs a) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int g = lane >> 4, j = lane & 15;
   const int nbx = a.cin / (16 * CX);
-  const int k = blockIdx.y;
+  // workgroup id -> (chunk, offset): consecutive ids go to different XCDs (id % 8), so the K offsets of one row chunk
+  // are given to ONE XCD, back to back -- they read the same dy rows and neighbouring x rows, which then come out of
+  // that XCD's L2 instead of being fetched once per offset
+  const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
+  const int k = q % a.K;
+  const int chunk = (q / a.K) * 8 + xcd;
+  if (chunk >= a.n_chunks) return;
   const int bx = blockIdx.z % nbx, by = blockIdx.z / nbx;       // channel blocks
   const int ci0 = bx * 16 * CX + CX * j, co0 = by * 16 * CY + CY * j;
   const int ngroups = (a.n_pos + 15) >> 4;
-  const int g_begin = blockIdx.x * a.chunk_groups;
+  const int g_begin = chunk * a.chunk_groups;
   const int g_end = min(ngroups, g_begin + a.chunk_groups);
   f32x4 acc[CX][CY];
 #pragma unroll
@@ -126,7 +133,7 @@ __global__ void __launch_bounds__(256) k_wgrad(const WgradArgs a) {
     }
     __syncthreads();
   }
-  float* P = a.part + (((size_t)blockIdx.x * a.K + k) * a.cin + (size_t)bx * 16 * CX) * a.cout + (size_t)by * BW;
+  float* P = a.part + (((size_t)chunk * a.K + k) * a.cin + (size_t)bx * 16 * CX) * a.cout + (size_t)by * BW;
   for (int e = threadIdx.x; e < 16 * CX * BW; e += 256) P[(size_t)(e / BW) * a.cout + e % BW] = fold[e];
 }
 
@@ -233,8 +240,9 @@ extern "C" int a3d_conv_wgrad(const a3d_scene* s, int kind, int level_in, const 
   hipStream_t st = (hipStream_t)stream;
   a.x = x_dev, a.dy = dy_dev, a.ldx = ldx, a.ldy = ldy, a.cin = cin, a.cout = cout;
   a.chunk_groups = p.chunk_groups;
+  a.n_chunks = p.chunks;
   a.part = (float*)workspace_dev;
-  const dim3 grid(p.chunks, a.K, p.nblocks);
+  const dim3 grid((unsigned)((p.chunks + 7) / 8 * 8 * a.K), 1, p.nblocks);
   const size_t lds = (size_t)16 * p.cx * 16 * p.cy * sizeof(float);
 #define A3D_WG(CX_, CY_)                                                                                          \
   if (p.cx == CX_ && p.cy == CY_) {                                                                               \
