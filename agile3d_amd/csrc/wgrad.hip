@@ -14,11 +14,13 @@
 // offset k, channel block); its four waves' accumulators are folded through LDS in wave order and the chunk partials
 // are summed by a second kernel in chunk order: the result does not depend on scheduling.
 #include "common.h"
+#include <stdlib.h>
 
 namespace a3d {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4u __attribute__((ext_vector_type(4), aligned(8)));
 
 struct WgradArgs {
   const float* x;        // [n_in][ldx]
@@ -47,9 +49,10 @@ __device__ __forceinline__ void load_c(const float* p, bool ok, float (&v)[C]) {
     const f32x4 a = *(const f32x4*)p;
 #pragma unroll
     for (int i = 0; i < 4; ++i) v[i] = a[i];
-  } else if constexpr (C == 6) {
-    const f32x2 a = *(const f32x2*)p, b = *(const f32x2*)(p + 2), c = *(const f32x2*)(p + 4);
-    v[0] = a[0], v[1] = a[1], v[2] = b[0], v[3] = b[1], v[4] = c[0], v[5] = c[1];
+  } else if constexpr (C == 6) {   // 24 bytes per lane at 8-byte alignment: one dwordx4 + one dwordx2
+    const f32x4u a = *(const f32x4u*)p;
+    const f32x2 b = *(const f32x2*)(p + 4);
+    v[0] = a[0], v[1] = a[1], v[2] = a[2], v[3] = a[3], v[4] = b[0], v[5] = b[1];
   } else {
     const f32x4 a = *(const f32x4*)p, b = *(const f32x4*)(p + 4);
 #pragma unroll
@@ -82,68 +85,96 @@ __global__ void __launch_bounds__(256) k_wgrad(const WgradArgs a) {
     for (int ty = 0; ty < CY; ++ty) acc[tx][ty] = (f32x4){0.f, 0.f, 0.f, 0.f};
   const int* tab = a.tab ? a.tab + (size_t)k * a.tab_stride : nullptr;
 
-  for (int grp = g_begin + wave; grp < g_end; grp += 4) {
-    if (a.gmask && !((a.gmask[grp] >> k) & 1u)) continue;        // no position of this group has offset k
-    // the group's 16 (input row, output row) pairs: lanes 0..15 of every 16-lane row hold them
-    const int p16 = grp * 16 + j;
-    int xi = a.n_in, yi = a.n_out;
-    if (p16 < a.n_pos) {
+  // this wave's groups: g_begin + wave, +4, ... that have offset k.  Software pipeline across groups: the next
+  // group's 16 row pairs are requested while the current group is multiplied, and its first four rows during the
+  // current group's last step, so neither the table nor the row latency is exposed between groups.
+  auto next_group = [&](int from) {
+    int n = from;
+    while (n < g_end && a.gmask && !((a.gmask[n] >> k) & 1u)) n += 4;
+    return n;
+  };
+  auto load_pairs = [&](int grp, int& xi, int& yi) {
+    const int p16 = grp * 16 + j;                                // lanes 0..15 of every 16-lane row hold the 16 pairs
+    xi = a.n_in, yi = a.n_out;
+    if (grp < g_end && p16 < a.n_pos) {
       xi = tab ? tab[p16] : p16;
       yi = a.out_map ? a.out_map[p16] : p16;
     }
-    float xv[CX], yv[CY], xn[CX], yn[CY];
-    {
-      const int xr = __shfl(xi, g, 16), yr = __shfl(yi, g, 16);
-      const bool ok = xr < a.n_in && yr < a.n_out;
-      load_c<CX>(a.x + (size_t)(ok ? xr : 0) * a.ldx + ci0, ok, xn);
-      load_c<CY>(a.dy + (size_t)(ok ? yr : 0) * a.ldy + co0, ok, yn);
-    }
-#pragma unroll
+  };
+  float xv[CX], yv[CY], x1[CX], y1[CY], x2[CX], y2[CY];
+  auto load_rows = [&](int xi, int yi, int s, float (&xd)[CX], float (&yd)[CY]) {   // rows of positions 4s .. 4s+3
+    const int xr = __shfl(xi, 4 * s + g, 16), yr = __shfl(yi, 4 * s + g, 16);
+    const bool ok = xr < a.n_in && yr < a.n_out;
+    load_c<CX>(a.x + (size_t)(ok ? xr : 0) * a.ldx + ci0, ok, xd);
+    load_c<CY>(a.dy + (size_t)(ok ? yr : 0) * a.ldy + co0, ok, yd);
+  };
+  int grp = next_group(g_begin + wave);
+  int xi, yi;
+  load_pairs(grp, xi, yi);
+  if (grp < g_end) {
+    load_rows(xi, yi, 0, x1, y1);
+    load_rows(xi, yi, 1, x2, y2);
+  }
+  while (grp < g_end) {
+    const int ngrp = next_group(grp + 4);
+    int xi_n, yi_n;
+    load_pairs(ngrp, xi_n, yi_n);
+#pragma unroll 1
     for (int s = 0; s < 4; ++s) {
 #pragma unroll
-      for (int i = 0; i < CX; ++i) xv[i] = xn[i];
+      for (int i = 0; i < CX; ++i) xv[i] = x1[i], x1[i] = x2[i];
 #pragma unroll
-      for (int i = 0; i < CY; ++i) yv[i] = yn[i];
-      if (s < 3) {   // next four positions in flight behind this step's MFMAs
-        const int xr = __shfl(xi, 4 * (s + 1) + g, 16), yr = __shfl(yi, 4 * (s + 1) + g, 16);
-        const bool ok = xr < a.n_in && yr < a.n_out;
-        load_c<CX>(a.x + (size_t)(ok ? xr : 0) * a.ldx + ci0, ok, xn);
-        load_c<CY>(a.dy + (size_t)(ok ? yr : 0) * a.ldy + co0, ok, yn);
-      }
+      for (int i = 0; i < CY; ++i) yv[i] = y1[i], y1[i] = y2[i];
+      // two steps ahead (2 waves per SIMD do not cover a row fetch with one step of MFMAs): rows of step s+2 of this
+      // group, or of the next group's first steps; past the end it re-reads rows that are never multiplied
+      load_rows(s < 2 ? xi : xi_n, s < 2 ? yi : yi_n, (s + 2) & 3, x2, y2);
 #pragma unroll
       for (int tx = 0; tx < CX; ++tx)
 #pragma unroll
         for (int ty = 0; ty < CY; ++ty)
           acc[tx][ty] = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[tx], yv[ty], acc[tx][ty], 0, 0, 0);
     }
+    grp = ngrp, xi = xi_n, yi = yi_n;
   }
-  // fold the four waves in wave order; lane (g, j) holds dW[ci = CX (4g + r) + tx][co = CY j + ty] in acc[tx][ty][r]
-  constexpr int BW = 16 * CY;
+  // fold the four waves in wave order, in the accumulators' own layout (one conflict-free 16-byte LDS access per
+  // tile and lane), and write the partial in that layout too: [chunk][k][block][tile][lane] x 4 floats -- the reduce
+  // kernel does the (tile, lane, r) -> (ci, co) mapping once per weight instead of once per workgroup
+  f32x4* fold4 = (f32x4*)fold;
   for (int w = 0; w < 4; ++w) {
     if (wave == w) {
 #pragma unroll
       for (int tx = 0; tx < CX; ++tx)
 #pragma unroll
-        for (int ty = 0; ty < CY; ++ty)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            float* f = fold + (CX * (4 * g + r) + tx) * BW + CY * j + ty;
-            *f = w == 0 ? acc[tx][ty][r] : *f + acc[tx][ty][r];
-          }
+        for (int ty = 0; ty < CY; ++ty) {
+          f32x4* f = fold4 + (tx * CY + ty) * 64 + lane;
+          *f = w == 0 ? acc[tx][ty] : *f + acc[tx][ty];
+        }
     }
     __syncthreads();
   }
-  float* P = a.part + (((size_t)chunk * a.K + k) * a.cin + (size_t)bx * 16 * CX) * a.cout + (size_t)by * BW;
-  for (int e = threadIdx.x; e < 16 * CX * BW; e += 256) P[(size_t)(e / BW) * a.cout + e % BW] = fold[e];
+  constexpr int TILE4 = CX * CY * 64;   // f32x4 per block
+  f32x4* P = (f32x4*)a.part + (((size_t)chunk * a.K + k) * gridDim.z + blockIdx.z) * TILE4;
+  for (int e = threadIdx.x; e < TILE4; e += 256) P[e] = fold4[e];
 }
 
-// dw[e] = sum over chunks of part[chunk][e], chunk order
-__global__ void k_wgrad_reduce(const float* __restrict__ part, int nchunk, size_t total, float* __restrict__ dw) {
+// dw[k][ci][co] = sum over chunks (chunk order) of the fragment-layout partials: element e of a block is
+// (tile = tx * CY + ty, lane = 16 g + j, r) -> ci = block_x * 16 CX + CX (4g + r) + tx, co = block_y * 16 CY + CY j + ty
+__global__ void k_wgrad_reduce(const float* __restrict__ part, int nchunk, int K, int cin, int cout, int cx, int cy,
+                               float* __restrict__ dw) {
+  const size_t total = (size_t)K * cin * cout;
   const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= total) return;
   float s = 0.f;
   for (int c = 0; c < nchunk; ++c) s += part[(size_t)c * total + e];
-  dw[e] = s;
+  const int block_elems = 16 * cx * 16 * cy, nbx = cin / (16 * cx);
+  const int per_k = cin * cout;
+  const int k = (int)(e / per_k), rem = (int)(e % per_k);
+  const int blk = rem / block_elems, in_blk = rem % block_elems;
+  const int tile = in_blk / 256, lane = (in_blk % 256) / 4, r = in_blk & 3;
+  const int tx = tile / cy, ty = tile % cy, g = lane >> 4, j = lane & 15;
+  const int ci = (blk % nbx) * 16 * cx + cx * (4 * g + r) + tx;
+  const int co = (blk / nbx) * 16 * cy + cy * j + ty;
+  dw[((size_t)k * cin + ci) * cout + co] = s;
 }
 
 struct WgradPlan {
@@ -164,7 +195,17 @@ static bool wgrad_plan(int n_pos, int K, int cin, int cout, WgradPlan& p) {
   if (!best) return false;
   p.nblocks = (cin / (16 * p.cx)) * (cout / (16 * p.cy));
   const int ngroups = (n_pos + 15) / 16;
-  int chunks = (1536 + K * p.nblocks - 1) / (K * p.nblocks);      // ~6 workgroups per CU over the whole launch
+  static int target = -1;
+  if (target < 0) {
+    const char* e = getenv("A3D_WGRAD_WGS");
+    target = e ? atoi(e) : 0;
+  }
+  // workgroups over the whole launch: (chunk, offset) items differ a lot in work (rows are sorted by neighbour mask,
+  // so an offset's pairs cluster in some chunks) -- many small items balance the big levels (measured: 3072 at 320 k
+  // rows, 1536 below); every chunk costs a fold and a pass of the reduce kernel, so 1x1 maps stay at <= 256 chunks
+  const int tgt = target > 0 ? target : (n_pos > 200000 ? 3072 : 1536);
+  int chunks = (tgt + K * p.nblocks - 1) / (K * p.nblocks);
+  if (chunks > 256) chunks = 256;
   if (chunks > (ngroups + 3) / 4) chunks = (ngroups + 3) / 4;      // at least one group per wave
   if (chunks < 1) chunks = 1;
   p.chunk_groups = (ngroups + chunks - 1) / chunks;
@@ -257,7 +298,7 @@ extern "C" int a3d_conv_wgrad(const a3d_scene* s, int kind, int level_in, const 
 #undef A3D_WG
   A3D_LAUNCH_CHECK();
   const size_t total = (size_t)a.K * cin * cout;
-  k_wgrad_reduce<<<(unsigned)((total + 255) / 256), 256, 0, st>>>(a.part, p.chunks, total, dw_dev);
+  k_wgrad_reduce<<<(unsigned)((total + 255) / 256), 256, 0, st>>>(a.part, p.chunks, a.K, cin, cout, p.cx, p.cy, dw_dev);
   A3D_LAUNCH_CHECK();
   return A3D_OK;
 }
