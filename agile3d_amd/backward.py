@@ -117,3 +117,54 @@ def conv_weight_grad(scene, kind, level_in, x: torch.Tensor, dy: torch.Tensor) -
     L.check(lib.a3d_conv_wgrad(scene.handle, kind, level_in, _ptr(x), x.shape[1], _ptr(dy), dy.shape[1], cin, cout,
                                _ptr(dw), _ptr(ws), nbytes, _stream()), "a3d_conv_wgrad")
     return dw
+
+
+def _ws(n, C, device):
+    lib = L.load()
+    return torch.empty(lib.a3d_bn_workspace_bytes(n, C), dtype=torch.uint8, device=device)
+
+
+def bn_train_forward(x, gamma, beta, eps=1e-5, res=None, relu=False, running_mean=None, running_var=None, momentum=0.1):
+    """ME.MinkowskiBatchNorm in training mode (+ residual, + ReLU): returns (y, save_mean, save_rstd); running
+    statistics, when given, are updated in place like torch's."""
+    lib = L.load()
+    if not x.is_cuda or x.dtype != torch.float32:
+        raise RuntimeError("agile3d_amd.backward runs on the GPU only (fp32 CUDA tensors)")
+    x = x.contiguous()
+    n, C_ = x.shape
+    y = torch.empty_like(x)
+    mean = torch.empty(C_, dtype=torch.float32, device=x.device)
+    rstd = torch.empty_like(mean)
+    res = res.contiguous() if res is not None else None
+    ws = _ws(n, C_, x.device)
+    L.check(lib.a3d_bn_train_forward(_ptr(x), C_, n, C_, _ptr(gamma), _ptr(beta), eps, _ptr(res), C_, int(relu), _ptr(y),
+                                     C_, _ptr(mean), _ptr(rstd), _ptr(running_mean), _ptr(running_var), momentum,
+                                     _ptr(ws), ws.numel(), _stream()), "a3d_bn_train_forward")
+    return y, mean, rstd
+
+
+def bn_train_backward(x, y, dy, gamma, mean, rstd, relu=False, want_dres=False):
+    """-> (dx, dgamma, dbeta, dres or None); ``y`` (the forward output) gives the ReLU mask."""
+    lib = L.load()
+    x, dy = x.contiguous(), dy.contiguous()
+    n, C_ = x.shape
+    dx = torch.empty_like(x)
+    dres = torch.empty_like(x) if want_dres else None
+    dgamma = torch.empty(C_, dtype=torch.float32, device=x.device)
+    dbeta = torch.empty_like(dgamma)
+    ws = _ws(n, C_, x.device)
+    L.check(lib.a3d_bn_train_backward(_ptr(x), C_, _ptr(y.contiguous()) if relu else None, C_, _ptr(dy), C_, n, C_,
+                                      _ptr(gamma), _ptr(mean), _ptr(rstd), int(relu), _ptr(dx), C_, _ptr(dres), C_,
+                                      _ptr(dgamma), _ptr(dbeta), _ptr(ws), ws.numel(), _stream()),
+            "a3d_bn_train_backward")
+    return dx, dgamma, dbeta, dres
+
+
+def column_sums(x):
+    lib = L.load()
+    x = x.contiguous()
+    n, C_ = x.shape
+    out = torch.empty(C_, dtype=torch.float32, device=x.device)
+    ws = _ws(n, C_, x.device)
+    L.check(lib.a3d_column_sums(_ptr(x), C_, n, C_, _ptr(out), _ptr(ws), ws.numel(), _stream()), "a3d_column_sums")
+    return out

@@ -1,0 +1,275 @@
+// libagile3d_hip -- BatchNorm in TRAINING mode over the [N, C] rows of a sparse tensor (ME.MinkowskiBatchNorm =
+// nn.BatchNorm1d over the concatenated rows of the batch, models/modules/common.py:22), forward and backward, with the
+// residual add and the ReLU of BasicBlock.forward (resnet_block.py:48-64) fused in.  Second kernel family of the
+// training path.  All of it is HBM-bound column statistics + element-wise work:
+//   forward : mean_c, var_c (two passes, like torch: the variance is taken around the mean), y = (x-mean) rstd g + b
+//             (+ res) (ReLU); running statistics updated with the unbiased variance
+//   backward: g = dy (y > 0);  dbeta = sum g, dgamma = sum g xhat;  dx = gamma rstd (g - dbeta/N - xhat dgamma/N);
+//             the residual branch receives g
+// Column sums are two-stage and deterministic: row blocks -> partial[block][C] (fp32) -> one thread per column sums
+// the partials in block order in fp64.
+#include "common.h"
+
+namespace a3d {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kBnThreads = 192;     // divisible by C/4 for every channel count of the net (8..96 float4 columns)
+constexpr int kBnMaxBlocks = 1024;
+
+// mode 0: sum x            mode 1: sum (x - m)^2
+// mode 2: two sums for the backward: g = dy * (y > 0 or 1), sum g and sum g * (x - m) * rstd   (out: [2][C])
+struct ColArgs {
+  const float *x, *y, *dy, *mean, *rstd;
+  int ldx, ldy, lddy, n, C, relu, mode, rows_per_block;
+  float* partial;   // [blocks][nsum][C]
+};
+
+__global__ void __launch_bounds__(kBnThreads) k_col_partial(const ColArgs a) {
+  __shared__ f32x4 red[2][kBnThreads];
+  const int c4n = a.C >> 2;
+  const int col = threadIdx.x % c4n, rsub = threadIdx.x / c4n, rstep = kBnThreads / c4n;
+  const int r0 = blockIdx.x * a.rows_per_block, r1 = min(a.n, r0 + a.rows_per_block);
+  f32x4 s0 = (f32x4){0.f, 0.f, 0.f, 0.f}, s1 = s0;
+  f32x4 m = s0, rs = s0;
+  if (a.mode != 0) m = *(const f32x4*)(a.mean + 4 * col);
+  if (a.mode == 2) rs = *(const f32x4*)(a.rstd + 4 * col);
+  for (int r = r0 + rsub; r < r1; r += rstep) {
+    const f32x4 xv = *(const f32x4*)(a.x + (size_t)r * a.ldx + 4 * col);
+    if (a.mode == 0) {
+      s0 += xv;
+    } else if (a.mode == 1) {
+      const f32x4 d = xv - m;
+      s0 += d * d;
+    } else {
+      f32x4 g = *(const f32x4*)(a.dy + (size_t)r * a.lddy + 4 * col);
+      if (a.relu) {
+        const f32x4 yv = *(const f32x4*)(a.y + (size_t)r * a.ldy + 4 * col);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) g[t] = yv[t] > 0.f ? g[t] : 0.f;
+      }
+      s0 += g;
+      s1 += g * ((xv - m) * rs);
+    }
+  }
+  red[0][threadIdx.x] = s0;
+  red[1][threadIdx.x] = s1;
+  __syncthreads();
+  if (rsub == 0) {   // fold the row sub-lanes of this column in a fixed order
+    for (int k = 1; k < rstep; ++k) {
+      s0 += red[0][k * c4n + col];
+      s1 += red[1][k * c4n + col];
+    }
+    const int nsum = a.mode == 2 ? 2 : 1;
+    float* p = a.partial + (size_t)blockIdx.x * nsum * a.C + 4 * col;
+    *(f32x4*)p = s0;
+    if (nsum == 2) *(f32x4*)(p + a.C) = s1;
+  }
+}
+
+// one thread per column: partials in block order, fp64
+__global__ void k_col_final(const float* __restrict__ partial, int nblocks, int nsum, int C, double* out) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= nsum * C) return;
+  double s = 0.0;
+  for (int b = 0; b < nblocks; ++b) s += (double)partial[(size_t)b * nsum * C + c];
+  out[c] = s;
+}
+
+__global__ void k_bn_mean(const double* sums, int C, double n, float* mean) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c < C) mean[c] = (float)(sums[c] / n);
+}
+__global__ void k_bn_rstd(const double* sq, int C, double n, float eps, float* rstd, const float* mean,
+                          float* running_mean, float* running_var, float momentum) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const float var = (float)(sq[c] / n);
+  rstd[c] = 1.0f / sqrtf(var + eps);
+  if (running_mean) {
+    const float unbiased = n > 1.0 ? (float)(sq[c] / (n - 1.0)) : var;
+    running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean[c];
+    running_var[c] = (1.f - momentum) * running_var[c] + momentum * unbiased;
+  }
+}
+
+struct ApplyArgs {
+  const float *x, *mean, *rstd, *gamma, *beta, *res;
+  int ldx, ldr, ldy, n, C, relu;
+  float* y;
+};
+__global__ void k_bn_apply(const ApplyArgs a) {
+  const int c4n = a.C >> 2;
+  const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= (size_t)a.n * c4n) return;
+  const int r = (int)(e / c4n), col = (int)(e % c4n);
+  const f32x4 xv = *(const f32x4*)(a.x + (size_t)r * a.ldx + 4 * col);
+  const f32x4 m = *(const f32x4*)(a.mean + 4 * col), rs = *(const f32x4*)(a.rstd + 4 * col);
+  const f32x4 ga = *(const f32x4*)(a.gamma + 4 * col), be = *(const f32x4*)(a.beta + 4 * col);
+  f32x4 y = (xv - m) * rs * ga + be;
+  if (a.res) y += *(const f32x4*)(a.res + (size_t)r * a.ldr + 4 * col);
+  if (a.relu) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) y[t] = fmaxf(y[t], 0.f);
+  }
+  *(f32x4*)(a.y + (size_t)r * a.ldy + 4 * col) = y;
+}
+
+struct BwdArgs {
+  const float *x, *y, *dy, *mean, *rstd, *gamma;
+  const double* sums;   // [2][C]: sum g, sum g xhat
+  int ldx, ldy, lddy, lddx, lddres, n, C, relu;
+  float *dx, *dres, *dgamma, *dbeta;
+};
+__global__ void k_bn_bwd_apply(const BwdArgs a) {
+  const int c4n = a.C >> 2;
+  const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= (size_t)a.n * c4n) return;
+  const int r = (int)(e / c4n), col = (int)(e % c4n);
+  const f32x4 xv = *(const f32x4*)(a.x + (size_t)r * a.ldx + 4 * col);
+  f32x4 g = *(const f32x4*)(a.dy + (size_t)r * a.lddy + 4 * col);
+  if (a.relu) {
+    const f32x4 yv = *(const f32x4*)(a.y + (size_t)r * a.ldy + 4 * col);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) g[t] = yv[t] > 0.f ? g[t] : 0.f;
+  }
+  if (a.dres) *(f32x4*)(a.dres + (size_t)r * a.lddres + 4 * col) = g;
+  const f32x4 m = *(const f32x4*)(a.mean + 4 * col), rs = *(const f32x4*)(a.rstd + 4 * col);
+  const f32x4 ga = *(const f32x4*)(a.gamma + 4 * col);
+  const float inv_n = 1.f / (float)a.n;
+  f32x4 dx;
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const float xh = (xv[t] - m[t]) * rs[t];
+    const float db = (float)a.sums[4 * col + t], dg = (float)a.sums[a.C + 4 * col + t];
+    dx[t] = ga[t] * rs[t] * (g[t] - db * inv_n - xh * dg * inv_n);
+  }
+  *(f32x4*)(a.dx + (size_t)r * a.lddx + 4 * col) = dx;
+  if (r == 0) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      a.dbeta[4 * col + t] = (float)a.sums[4 * col + t];
+      a.dgamma[4 * col + t] = (float)a.sums[a.C + 4 * col + t];
+    }
+  }
+}
+
+static bool bn_shape_ok(int64_t n, int C, int ld0, int ld1, int ld2) {
+  return n > 0 && n <= (int64_t)1 << 30 && C >= 32 && C % 32 == 0 && kBnThreads % (C / 4) == 0 && ld0 % 4 == 0 &&
+         ld1 % 4 == 0 && ld2 % 4 == 0;
+}
+static int bn_blocks(int64_t n, int& rows_per_block) {
+  int blocks = (int)((n + 511) / 512);
+  if (blocks > kBnMaxBlocks) blocks = kBnMaxBlocks;
+  rows_per_block = (int)((n + blocks - 1) / blocks);
+  return (int)((n + rows_per_block - 1) / rows_per_block);
+}
+
+}  // namespace a3d
+
+using namespace a3d;
+
+extern "C" size_t a3d_bn_workspace_bytes(int64_t n, int C) {
+  if (n <= 0 || C <= 0) return 0;
+  return align256((size_t)kBnMaxBlocks * 2 * C * sizeof(float)) + align256((size_t)2 * C * sizeof(double)) + 256;
+}
+
+extern "C" int a3d_bn_train_forward(const float* x_dev, int ldx, int64_t n, int C, const float* gamma_dev,
+                                    const float* beta_dev, float eps, const float* res_dev, int ldr, int relu,
+                                    float* y_dev, int ldy, float* save_mean_dev, float* save_rstd_dev,
+                                    float* running_mean_dev, float* running_var_dev, float momentum,
+                                    void* workspace_dev, size_t workspace_bytes, void* stream) {
+  if (!x_dev || !gamma_dev || !beta_dev || !y_dev || !save_mean_dev || !save_rstd_dev || !workspace_dev ||
+      !bn_shape_ok(n, C, ldx, ldy, res_dev ? ldr : 4) || (running_mean_dev == nullptr) != (running_var_dev == nullptr)) {
+    set_error("a3d_bn_train_forward: bad arguments (C a multiple of 32 dividing 768, leading dimensions multiples of 4)");
+    return A3D_ERR_INVALID;
+  }
+  if (workspace_bytes < a3d_bn_workspace_bytes(n, C) || ((uintptr_t)workspace_dev & 15)) {
+    set_error("a3d_bn_train_forward: workspace too small or misaligned");
+    return A3D_ERR_WORKSPACE;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  float* partial = (float*)workspace_dev;
+  double* sums = (double*)((char*)workspace_dev + align256((size_t)kBnMaxBlocks * 2 * C * sizeof(float)));
+  ColArgs c;
+  memset(&c, 0, sizeof(c));
+  c.x = x_dev, c.ldx = ldx, c.n = (int)n, c.C = C, c.partial = partial;
+  const int blocks = bn_blocks(n, c.rows_per_block);
+  const unsigned cb = (unsigned)((2 * C + 255) / 256);
+  c.mode = 0;
+  k_col_partial<<<blocks, kBnThreads, 0, st>>>(c);
+  k_col_final<<<cb, 256, 0, st>>>(partial, blocks, 1, C, sums);
+  k_bn_mean<<<cb, 256, 0, st>>>(sums, C, (double)n, save_mean_dev);
+  c.mode = 1, c.mean = save_mean_dev;
+  k_col_partial<<<blocks, kBnThreads, 0, st>>>(c);
+  k_col_final<<<cb, 256, 0, st>>>(partial, blocks, 1, C, sums);
+  k_bn_rstd<<<cb, 256, 0, st>>>(sums, C, (double)n, eps, save_rstd_dev, save_mean_dev, running_mean_dev, running_var_dev,
+                               momentum);
+  ApplyArgs a;
+  a.x = x_dev, a.mean = save_mean_dev, a.rstd = save_rstd_dev, a.gamma = gamma_dev, a.beta = beta_dev, a.res = res_dev;
+  a.ldx = ldx, a.ldr = ldr, a.ldy = ldy, a.n = (int)n, a.C = C, a.relu = relu, a.y = y_dev;
+  const size_t total = (size_t)n * (C / 4);
+  k_bn_apply<<<(unsigned)((total + 255) / 256), 256, 0, st>>>(a);
+  A3D_LAUNCH_CHECK();
+  return A3D_OK;
+}
+
+extern "C" int a3d_bn_train_backward(const float* x_dev, int ldx, const float* y_dev, int ldy, const float* dy_dev,
+                                     int lddy, int64_t n, int C, const float* gamma_dev, const float* save_mean_dev,
+                                     const float* save_rstd_dev, int relu, float* dx_dev, int lddx, float* dres_dev,
+                                     int lddres, float* dgamma_dev, float* dbeta_dev, void* workspace_dev,
+                                     size_t workspace_bytes, void* stream) {
+  if (!x_dev || !dy_dev || !gamma_dev || !save_mean_dev || !save_rstd_dev || !dx_dev || !dgamma_dev || !dbeta_dev ||
+      !workspace_dev || (relu && !y_dev) || !bn_shape_ok(n, C, ldx, lddy, lddx) || (relu && ldy % 4) ||
+      (dres_dev && lddres % 4)) {
+    set_error("a3d_bn_train_backward: bad arguments");
+    return A3D_ERR_INVALID;
+  }
+  if (workspace_bytes < a3d_bn_workspace_bytes(n, C) || ((uintptr_t)workspace_dev & 15)) {
+    set_error("a3d_bn_train_backward: workspace too small or misaligned");
+    return A3D_ERR_WORKSPACE;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  float* partial = (float*)workspace_dev;
+  double* sums = (double*)((char*)workspace_dev + align256((size_t)kBnMaxBlocks * 2 * C * sizeof(float)));
+  ColArgs c;
+  memset(&c, 0, sizeof(c));
+  c.x = x_dev, c.y = y_dev, c.dy = dy_dev, c.mean = save_mean_dev, c.rstd = save_rstd_dev;
+  c.ldx = ldx, c.ldy = ldy, c.lddy = lddy, c.n = (int)n, c.C = C, c.relu = relu, c.mode = 2, c.partial = partial;
+  const int blocks = bn_blocks(n, c.rows_per_block);
+  k_col_partial<<<blocks, kBnThreads, 0, st>>>(c);
+  k_col_final<<<(unsigned)((2 * C + 255) / 256), 256, 0, st>>>(partial, blocks, 2, C, sums);
+  BwdArgs b;
+  b.x = x_dev, b.y = y_dev, b.dy = dy_dev, b.mean = save_mean_dev, b.rstd = save_rstd_dev, b.gamma = gamma_dev;
+  b.sums = sums, b.ldx = ldx, b.ldy = ldy, b.lddy = lddy, b.lddx = lddx, b.lddres = lddres, b.n = (int)n, b.C = C;
+  b.relu = relu, b.dx = dx_dev, b.dres = dres_dev, b.dgamma = dgamma_dev, b.dbeta = dbeta_dev;
+  const size_t total = (size_t)n * (C / 4);
+  k_bn_bwd_apply<<<(unsigned)((total + 255) / 256), 256, 0, st>>>(b);
+  A3D_LAUNCH_CHECK();
+  return A3D_OK;
+}
+
+// column sums of a [n][C] matrix (bias gradient of lin_squeeze_head: sum over rows of dy)
+extern "C" int a3d_column_sums(const float* x_dev, int ldx, int64_t n, int C, float* out_dev, void* workspace_dev,
+                               size_t workspace_bytes, void* stream) {
+  if (!x_dev || !out_dev || !workspace_dev || !bn_shape_ok(n, C, ldx, 4, 4)) {
+    set_error("a3d_column_sums: bad arguments");
+    return A3D_ERR_INVALID;
+  }
+  if (workspace_bytes < a3d_bn_workspace_bytes(n, C) || ((uintptr_t)workspace_dev & 15)) {
+    set_error("a3d_column_sums: workspace too small or misaligned");
+    return A3D_ERR_WORKSPACE;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  float* partial = (float*)workspace_dev;
+  double* sums = (double*)((char*)workspace_dev + align256((size_t)kBnMaxBlocks * 2 * C * sizeof(float)));
+  ColArgs c;
+  memset(&c, 0, sizeof(c));
+  c.x = x_dev, c.ldx = ldx, c.n = (int)n, c.C = C, c.partial = partial, c.mode = 0;
+  const int blocks = bn_blocks(n, c.rows_per_block);
+  k_col_partial<<<blocks, kBnThreads, 0, st>>>(c);
+  k_col_final<<<(unsigned)((C + 255) / 256), 256, 0, st>>>(partial, blocks, 1, C, sums);
+  k_bn_mean<<<(unsigned)((C + 255) / 256), 256, 0, st>>>(sums, C, 1.0, out_dev);
+  A3D_LAUNCH_CHECK();
+  return A3D_OK;
+}

@@ -171,6 +171,28 @@ int    a3d_conv_wgrad(const a3d_scene* s, int kind, int level_in, const float* x
                       const float* dy_dev, int ldy, int cin, int cout, float* dw_dev,
                       void* workspace_dev, size_t workspace_bytes, void* stream);
 
+/* BatchNorm in training mode over the [n][C] rows (ME.MinkowskiBatchNorm = nn.BatchNorm1d over the rows of the whole
+ * batch, models/modules/common.py:22), with the residual add and ReLU of BasicBlock.forward (resnet_block.py:48-64):
+ *   forward : y = relu?((x - mean) * rstd * gamma + beta (+ res)); mean / rstd of THIS batch are saved for the
+ *             backward; running statistics (optional) are updated like torch (momentum, unbiased variance)
+ *   backward: g = dy masked by (y > 0) when relu; dres (optional) = g; dbeta = sum g; dgamma = sum g * xhat;
+ *             dx = gamma * rstd * (g - dbeta / n - xhat * dgamma / n)
+ * C a multiple of 32 that divides 768 (32 .. 384), leading dimensions multiples of 4.  Deterministic. */
+size_t a3d_bn_workspace_bytes(int64_t n, int C);
+int    a3d_bn_train_forward(const float* x_dev, int ldx, int64_t n, int C, const float* gamma_dev,
+                            const float* beta_dev, float eps, const float* res_dev, int ldr, int relu,
+                            float* y_dev, int ldy, float* save_mean_dev, float* save_rstd_dev,
+                            float* running_mean_dev, float* running_var_dev, float momentum,
+                            void* workspace_dev, size_t workspace_bytes, void* stream);
+int    a3d_bn_train_backward(const float* x_dev, int ldx, const float* y_dev, int ldy, const float* dy_dev, int lddy,
+                             int64_t n, int C, const float* gamma_dev, const float* save_mean_dev,
+                             const float* save_rstd_dev, int relu, float* dx_dev, int lddx, float* dres_dev,
+                             int lddres, float* dgamma_dev, float* dbeta_dev,
+                             void* workspace_dev, size_t workspace_bytes, void* stream);
+/* out[c] = sum over rows of x[i][c] (bias gradient of lin_squeeze_head, agile3d.py:43-45); workspace as above */
+int    a3d_column_sums(const float* x_dev, int ldx, int64_t n, int C, float* out_dev,
+                       void* workspace_dev, size_t workspace_bytes, void* stream);
+
 /* Dense row-major GEMM: out[n][cout] = act(((in (+ in_add))[n][cin] @ W) * scale + shift + res).
  * Replaces the nn.Linear / in_proj pieces of nn.MultiheadAttention that run over all N points
  * (models/modules/attention_block.py:91-94; `in_add` is the position encoding the reference adds to

@@ -103,3 +103,39 @@ def test_finite_difference_of_a_small_loss(world):
     fd = ((lp - lm) / (2 * eps)).item()
     an = (dW.double() * V.double()).sum().item()
     assert abs(fd - an) <= 1e-3 * max(1.0, abs(an)), (fd, an)
+
+
+@pytest.mark.parametrize("n,C,relu,with_res", [(5000, 96, True, True), (777, 32, True, False), (1300, 256, False, False),
+                                                (16, 128, True, True), (40000, 64, True, True)])
+def test_batchnorm_training_forward_backward_vs_torch(n, C, relu, with_res):
+    """nn.BatchNorm1d(training) (+ residual, + ReLU) and its autograd on the CPU in float64 as the reference."""
+    g = torch.Generator().manual_seed(n + C)
+    x = (torch.randn(n, C, generator=g) * 2 + 0.5)
+    res = torch.randn(n, C, generator=g) if with_res else None
+    gamma, beta = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g)
+    rm, rv = torch.randn(C, generator=g) * 0.1, torch.rand(C, generator=g) + 0.5
+    dy = torch.randn(n, C, generator=g)
+    xd, gd, bd = x.double().requires_grad_(), gamma.double().requires_grad_(), beta.double().requires_grad_()
+    rd = res.double().requires_grad_() if with_res else None
+    rm_ref, rv_ref = rm.double().clone(), rv.double().clone()
+    y_ref = torch.nn.functional.batch_norm(xd, rm_ref, rv_ref, gd, bd, training=True, momentum=0.02, eps=1e-5)
+    if with_res:
+        y_ref = y_ref + rd
+    if relu:
+        y_ref = torch.relu(y_ref)
+    y_ref.backward(dy.double())
+    rm_d, rv_d = rm.cuda(), rv.cuda()
+    y, mean, rstd = B.bn_train_forward(x.cuda(), gamma.cuda(), beta.cuda(), 1e-5, res.cuda() if with_res else None, relu,
+                                       rm_d, rv_d, 0.02)
+    assert (y.cpu().double() - y_ref.detach()).abs().max().item() <= 2e-5
+    assert (rm_d.cpu().double() - rm_ref).abs().max().item() <= 1e-6 and (rv_d.cpu().double() - rv_ref).abs().max().item() <= 1e-5
+    dx, dgamma, dbeta, dres = B.bn_train_backward(x.cuda(), y, dy.cuda(), gamma.cuda(), mean, rstd, relu, with_res)
+    sx = max(1.0, xd.grad.abs().max().item())
+    assert (dx.cpu().double() - xd.grad).abs().max().item() <= 5e-5 * sx
+    assert (dgamma.cpu().double() - gd.grad).abs().max().item() <= 2e-4 * max(1.0, gd.grad.abs().max().item())
+    assert (dbeta.cpu().double() - bd.grad).abs().max().item() <= 2e-4 * max(1.0, bd.grad.abs().max().item())
+    if with_res:
+        assert (dres.cpu().double() - rd.grad).abs().max().item() <= 1e-6
+    s = B.column_sums(dy.cuda())
+    assert (s.cpu().double() - dy.double().sum(0)).abs().max().item() <= 1e-3
+    assert torch.equal(B.column_sums(dy.cuda()), s)      # deterministic
