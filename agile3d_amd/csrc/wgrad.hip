@@ -247,9 +247,100 @@ static int wgrad_tables(const a3d_scene* s, int kind, int level_in, WgradArgs& a
   return A3D_OK;
 }
 
+// ---- weight gradient of the input convolution (5^3 or 3^3, 3 -> 32 channels; res16unet.py:225): the neighbours are
+// looked up on the fly like in the forward kernel (dense level-0 grid or hash), one workgroup = (offset k, row split);
+// a thread owns whole rows and keeps the 3 x 32 outer-product sums in registers, the workgroup folds them in a
+// fixed-order LDS tree, the splits are summed in order by k_stem_wgrad_reduce.
+constexpr int kStemSplits = 8;
+__global__ void __launch_bounds__(256) k_stem_wgrad(const Level lv, const float* __restrict__ feats3,
+                                                    const int* __restrict__ orig_row, const float* __restrict__ dy,
+                                                    int lddy, int ks, float* __restrict__ part) {
+  __shared__ float red[256][33];
+  const int k = blockIdx.x, split = blockIdx.y, h = ks / 2;
+  const int dx = k % ks - h, dyo = (k / ks) % ks - h, dz = k / (ks * ks) - h;
+  const int per = (lv.n + kStemSplits - 1) / kStemSplits;
+  const int r0 = split * per, r1 = min(lv.n, r0 + per);
+  float acc[3][32];
+#pragma unroll
+  for (int c = 0; c < 3; ++c)
+#pragma unroll
+    for (int o = 0; o < 32; ++o) acc[c][o] = 0.f;
+  for (int i = r0 + threadIdx.x; i < r1; i += 256) {
+    const int4 c = *(const int4*)(lv.xyzb + 4 * i);
+    const int X = c.x + dx, Y = c.y + dyo, Z = c.z + dz;
+    int nb = -1;
+    if (lv.grid && h <= kGridPad) {
+      nb = lv.grid[grid_cell(lv, c.w, X, Y, Z)];
+    } else {
+      const int lim = kCoordOff;
+      if (X >= -lim && X < lim && Y >= -lim && Y < lim && Z >= -lim && Z < lim)
+        nb = hash_lookup(lv.hkeys, lv.hvals, lv.hmask, make_key(c.w, X, Y, Z, 0));
+    }
+    if (nb < 0) continue;
+    const float* fr = feats3 + (size_t)orig_row[nb] * 3;
+    const float f0 = fr[0], f1 = fr[1], f2 = fr[2];
+    const f32x4* dr = (const f32x4*)(dy + (size_t)i * lddy);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const f32x4 d = dr[q];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        acc[0][4 * q + t] += f0 * d[t];
+        acc[1][4 * q + t] += f1 * d[t];
+        acc[2][4 * q + t] += f2 * d[t];
+      }
+    }
+  }
+  for (int c = 0; c < 3; ++c) {
+#pragma unroll
+    for (int o = 0; o < 32; ++o) red[threadIdx.x][o] = acc[c][o];
+    __syncthreads();
+    for (int stride = 128; stride >= 1; stride >>= 1) {
+      for (int e = threadIdx.x; e < stride * 32; e += 256) red[e >> 5][e & 31] += red[(e >> 5) + stride][e & 31];
+      __syncthreads();
+    }
+    if (threadIdx.x < 32) part[((size_t)split * gridDim.x + k) * 96 + c * 32 + threadIdx.x] = red[0][threadIdx.x];
+    __syncthreads();
+  }
+}
+__global__ void k_stem_wgrad_reduce(const float* __restrict__ part, int total, float* __restrict__ dw) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= total) return;
+  float s = 0.f;
+  for (int sp = 0; sp < kStemSplits; ++sp) s += part[(size_t)sp * total + e];
+  dw[e] = s;
+}
+
 }  // namespace a3d
 
 using namespace a3d;
+
+extern "C" size_t a3d_stem_wgrad_workspace_bytes(int kernel_volume) {
+  if (kernel_volume != 125 && kernel_volume != 27) return 0;
+  return (size_t)kStemSplits * kernel_volume * 96 * sizeof(float) + 256;
+}
+
+extern "C" int a3d_stem_wgrad(const a3d_scene* s, const float* feats3_dev, const float* dy_dev, int lddy,
+                              int kernel_volume, float* dw_dev, void* workspace_dev, size_t workspace_bytes,
+                              void* stream) {
+  if (!s || !feats3_dev || !dy_dev || !dw_dev || !workspace_dev || lddy < 32 || (lddy & 3) ||
+      (kernel_volume != 125 && kernel_volume != 27)) {
+    set_error("a3d_stem_wgrad: bad arguments (5^3 or 3^3 kernel, dy with 32 columns, leading dimension a multiple of 4)");
+    return A3D_ERR_INVALID;
+  }
+  if (workspace_bytes < a3d_stem_wgrad_workspace_bytes(kernel_volume) || ((uintptr_t)workspace_dev & 15)) {
+    set_error("a3d_stem_wgrad: workspace too small or misaligned");
+    return A3D_ERR_WORKSPACE;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  const int ks = kernel_volume == 125 ? 5 : 3;
+  k_stem_wgrad<<<dim3(kernel_volume, kStemSplits), 256, 0, st>>>(s->lv[0], feats3_dev, s->orig_row, dy_dev, lddy, ks,
+                                                               (float*)workspace_dev);
+  const int total = kernel_volume * 96;
+  k_stem_wgrad_reduce<<<(total + 255) / 256, 256, 0, st>>>((const float*)workspace_dev, total, dw_dev);
+  A3D_LAUNCH_CHECK();
+  return A3D_OK;
+}
 
 extern "C" size_t a3d_conv_wgrad_workspace_bytes(const a3d_scene* s, int kind, int level_in, int cin, int cout) {
   WgradArgs a;

@@ -171,6 +171,12 @@ int    a3d_conv_wgrad(const a3d_scene* s, int kind, int level_in, const float* x
                       const float* dy_dev, int ldy, int cin, int cout, float* dw_dev,
                       void* workspace_dev, size_t workspace_bytes, void* stream);
 
+/* weight gradient of the input convolution conv0p1s1 (5^3 or 3^3, 3 -> 32; res16unet.py:225): feats3_dev in the
+ * caller's row order as for a3d_program_run, dy_dev [n0][lddy >= 32] in internal row order, dw_dev [K][3][32] */
+size_t a3d_stem_wgrad_workspace_bytes(int kernel_volume);
+int    a3d_stem_wgrad(const a3d_scene* s, const float* feats3_dev, const float* dy_dev, int lddy, int kernel_volume,
+                      float* dw_dev, void* workspace_dev, size_t workspace_bytes, void* stream);
+
 /* BatchNorm in training mode over the [n][C] rows (ME.MinkowskiBatchNorm = nn.BatchNorm1d over the rows of the whole
  * batch, models/modules/common.py:22), with the residual add and ReLU of BasicBlock.forward (resnet_block.py:48-64):
  *   forward : y = relu?((x - mean) * rstd * gamma + beta (+ res)); mean / rstd of THIS batch are saved for the

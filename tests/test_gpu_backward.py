@@ -139,3 +139,18 @@ def test_batchnorm_training_forward_backward_vs_torch(n, C, relu, with_res):
     s = B.column_sums(dy.cuda())
     assert (s.cpu().double() - dy.double().sum(0)).abs().max().item() <= 1e-3
     assert torch.equal(B.column_sums(dy.cuda()), s)      # deterministic
+
+
+@pytest.mark.parametrize("ks", [5, 3])
+def test_stem_weight_grad_matches_autograd(world, ks):
+    sc, lv, maps = world
+    n = sc.n[0]
+    g = torch.Generator().manual_seed(31 + ks)
+    F3 = torch.rand(n, 3, generator=g)                                   # caller row order = the oracle's
+    W = (torch.randn(ks ** 3, 3, 32, generator=g) / 6.0).requires_grad_()
+    dY = torch.randn(n, 32, generator=g)
+    ob.sparse_conv(F3, W, lv.kernel_map(0, ks), n).backward(dY)
+    dw = B.stem_weight_grad(sc, F3.cuda(), dY[maps[0]].cuda(), ks ** 3).cpu()
+    err = (dw - W.grad).abs().max().item()
+    assert err <= 2e-4 * max(1.0, W.grad.abs().max().item()), err
+    assert torch.equal(B.stem_weight_grad(sc, F3.cuda(), dY[maps[0]].cuda(), ks ** 3).cpu(), dw)
