@@ -1,0 +1,171 @@
+"""Training-mode forward and backward of the backbone (Res16UNet34C + lin_squeeze_head) on the HIP kernels -- the
+backbone half of SURVEY.md section 8 row f-2 (``engine.py:26-179``: ``model.train()``, ``losses.backward()``).
+
+    tape = BackboneTape(model, scene, feats3)        forward: res16unet.py:222-295 with BatchNorm on batch statistics
+    pcd = tape.output                                [N, 128] in the caller's row order (agile3d.py:179)
+    grads = tape.backward(d_pcd)                     {state-dict key: gradient} for every backbone parameter
+
+Every FLOP runs in libagile3d_hip (conv forward = the inference kernels, conv input gradient = the same kernels on the
+transposed maps, k_wgrad, the BatchNorm training kernels, k_stem_wgrad); this module is the reverse-mode bookkeeping:
+which activation feeds which layer, the two-way fan-outs of the residual / skip connections (a tensor add), the channel
+split of the concatenations.  A layer-at-a-time executor meant for parity, not yet for speed: every conv call goes
+through a one-op program with its own workspace.  The decoder's backward and the optimiser are not built yet.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import backward as B
+from . import lib as L
+
+
+class _T:
+    """Activation node: value, level, accumulated gradient."""
+    __slots__ = ("v", "level", "g")
+
+    def __init__(self, v, level):
+        self.v, self.level, self.g = v, level, None
+
+    def add_grad(self, g):
+        self.g = g if self.g is None else self.g + g
+
+
+def _run_stem(scene, w, feats3, kvol):
+    """conv0p1s1 on its own (OP_STEM reads the caller-ordered features) -> [n0, 32] internal order."""
+    lib = L.load()
+    n0 = scene.n[0]
+    bufs = (L.BufDesc * 1)(L.BufDesc(0, 32))
+    o = L.Op()
+    o.kind, o.level_in, o.cin, o.cout = L.OP_STEM, 0, 3, 32
+    o.in_buf, o.in_coff, o.out_buf, o.out_coff = L.BUF_NONE, 0, 0, 0
+    o.res_buf, o.res_coff, o.relu, o.kernel_volume = L.BUF_NONE, 0, 0, kvol
+    o.w_dev, o.scale_dev, o.shift_dev = w.data_ptr(), None, None
+    ops = (L.Op * 1)(o)
+    nbytes = lib.a3d_program_workspace_bytes(scene.handle, bufs, 1, ops, 1)
+    ws = torch.zeros(nbytes, dtype=torch.uint8, device=feats3.device)
+    L.check(lib.a3d_program_run(scene.handle, bufs, 1, ops, 1, B._ptr(feats3), None, 0, B._ptr(ws), nbytes, B._stream()),
+            "a3d_program_run")
+    off = lib.a3d_program_buffer_offset(scene.handle, bufs, 1, 0)
+    return ws[off:off + n0 * 32 * 4].view(torch.float32).view(n0, 32).clone()
+
+
+class BackboneTape:
+    def __init__(self, model, scene, feats3: torch.Tensor):
+        if not feats3.is_cuda:
+            raise RuntimeError("BackboneTape runs on the GPU only")
+        self.model, self.scene = model, scene
+        self.feats3 = feats3.to(torch.float32).contiguous()
+        self.steps = []          # backward closures, in forward order
+        self.relu_levels = []
+        self.grads = {}
+        self._names = {id(p): n for n, p in model.named_parameters()}
+        self._forward()
+
+    # ------------------------------------------------------------------ layers
+    def _pgrad(self, param, g):
+        name = self._names[id(param)]
+        g = g.reshape(param.shape)
+        self.grads[name] = g if name not in self.grads else self.grads[name] + g
+
+    def _conv(self, kind, x: _T, conv) -> _T:
+        w = conv.kernel3().detach()
+        K, cin, cout = w.shape
+        y = _T(B.run_conv(self.scene, kind, x.level, B.pack_weight(w), x.v, cin, cout), B.level_out(kind, x.level))
+
+        def back():
+            self._pgrad(conv.kernel, B.conv_weight_grad(self.scene, kind, x.level, x.v, y.g))
+            x.add_grad(B.conv_input_grad(self.scene, kind, x.level, w, y.g))
+        self.steps.append(back)
+        return y
+
+    def _bn(self, x: _T, norm, res: _T | None = None, relu=True) -> _T:
+        b = norm.bn
+        v, mean, rstd = B.bn_train_forward(x.v, b.weight.detach(), b.bias.detach(), b.eps, res.v if res is not None else None,
+                                           relu, b.running_mean, b.running_var, b.momentum)
+        y = _T(v, x.level)
+        if relu:
+            self.relu_levels.append((x.level, y))       # forward order of the ReLUs (tests read the 0/1 masks off y.v)
+
+        def back():
+            dx, dg, db, dres = B.bn_train_backward(x.v, y.v, y.g, b.weight.detach(), mean, rstd, relu, res is not None)
+            self._pgrad(b.weight, dg)
+            self._pgrad(b.bias, db)
+            x.add_grad(dx)
+            if res is not None:
+                res.add_grad(dres)
+        self.steps.append(back)
+        return y
+
+    def _cat(self, a: _T, b: _T) -> _T:
+        y = _T(torch.cat([a.v, b.v], 1), a.level)
+        ca = a.v.shape[1]
+
+        def back():
+            a.add_grad(y.g[:, :ca].contiguous())
+            b.add_grad(y.g[:, ca:].contiguous())
+        self.steps.append(back)
+        return y
+
+    def _block(self, blk, x: _T) -> _T:
+        """BasicBlock.forward (resnet_block.py:48-64)."""
+        out = self._bn(self._conv(L.OP_CONV3, x, blk.conv1), blk.norm1)
+        out = self._conv(L.OP_CONV3, out, blk.conv2)
+        res = x
+        if blk.downsample is not None:
+            res = self._bn(self._conv(L.OP_LINEAR, x, blk.downsample[0]), blk.downsample[1], relu=False)
+        return self._bn(out, blk.norm2, res=res, relu=True)
+
+    def _layer(self, blocks, x: _T) -> _T:
+        for blk in blocks:
+            x = self._block(blk, x)
+        return x
+
+    # ------------------------------------------------------------------ forward (res16unet.py:222-295)
+    def _forward(self):
+        bb, sc = self.model.backbone, self.scene
+        w0 = bb.conv0p1s1.kernel3().detach().contiguous()
+        stem = _T(_run_stem(sc, w0, self.feats3, w0.shape[0]), 0)
+
+        def stem_back():
+            self._pgrad(bb.conv0p1s1.kernel, B.stem_weight_grad(sc, self.feats3, stem.g, w0.shape[0]))
+        self.steps.append(stem_back)
+        out_p1 = self._bn(stem, bb.bn0)
+        out = self._bn(self._conv(L.OP_DOWN, out_p1, bb.conv1p1s2), bb.bn1)
+        out_b1p2 = self._layer(bb.block1, out)
+        out = self._bn(self._conv(L.OP_DOWN, out_b1p2, bb.conv2p2s2), bb.bn2)
+        out_b2p4 = self._layer(bb.block2, out)
+        out = self._bn(self._conv(L.OP_DOWN, out_b2p4, bb.conv3p4s2), bb.bn3)
+        out_b3p8 = self._layer(bb.block3, out)
+        out = self._bn(self._conv(L.OP_DOWN, out_b3p8, bb.conv4p8s2), bb.bn4)
+        out = self._layer(bb.block4, out)
+        out = self._bn(self._conv(L.OP_UP, out, bb.convtr4p16s2), bb.bntr4)
+        out = self._layer(bb.block5, self._cat(out, out_b3p8))
+        out = self._bn(self._conv(L.OP_UP, out, bb.convtr5p8s2), bb.bntr5)
+        out = self._layer(bb.block6, self._cat(out, out_b2p4))
+        out = self._bn(self._conv(L.OP_UP, out, bb.convtr6p4s2), bb.bntr6)
+        out = self._layer(bb.block7, self._cat(out, out_b1p2))
+        out = self._bn(self._conv(L.OP_UP, out, bb.convtr7p2s2), bb.bntr7)
+        out = self._layer(bb.block8, self._cat(out, out_p1))
+        # lin_squeeze_head: 1x1 conv + bias (agile3d.py:43-45,179), back to the caller's row order
+        head = self.model.lin_squeeze_head
+        y = self._conv(L.OP_LINEAR, out, head)
+        self.head_out = y
+        self.orig_row = torch.from_numpy(sc.table(0, L.TAB_ORIGROW)).to(self.feats3.device).long()
+        bias = head.bias.detach().reshape(1, -1)
+        pcd = torch.empty_like(y.v)
+        pcd[self.orig_row] = y.v + bias
+        self.output = pcd
+
+    # ------------------------------------------------------------------ backward
+    def backward(self, d_output: torch.Tensor) -> dict:
+        """``d_output`` = dL/d(pcd_features) [N, 128] in the caller's row order -> gradients keyed like state_dict()."""
+        head = self.model.lin_squeeze_head
+        g = d_output.to(torch.float32)[self.orig_row].contiguous()          # internal row order
+        self.grads = {}
+        self._pgrad(head.bias, B.column_sums(g))
+        self.head_out.g = g
+        for back in reversed(self.steps):
+            back()
+        return self.grads

@@ -126,6 +126,12 @@ def sparse_conv(x: torch.Tensor, W: torch.Tensor, kmap, n_out: int) -> torch.Ten
     return out
 
 
+# the activation of the backbone: a module attribute so that a test can substitute "multiply by a given 0/1 mask" for
+# the gradient comparison of the training path (ReLU's derivative jumps at 0: with the masks of the implementation under
+# test, two forward passes that differ in the last bits still define the SAME piecewise-linear function)
+RELU = torch.relu
+
+
 def batch_norm_eval(x, sd, prefix):
     """nn.BatchNorm1d in eval mode over the [N,C] rows (ME.MinkowskiBatchNorm, common.py:22)."""
     w, b = sd[prefix + "bn.weight"], sd[prefix + "bn.bias"]
@@ -137,72 +143,87 @@ def _k3(W):
     return W if W.dim() == 3 else W.unsqueeze(0)
 
 
-def basic_block(x, sd, prefix, lv: SparseLevels, level: int):
+def batch_norm_train(x, sd, prefix, momentum=None):
+    """nn.BatchNorm1d in TRAINING mode (batch statistics over all rows of the batch; the running statistics in ``sd``
+    are updated in place like the module's buffers) -- the training path, engine.py:26-179.  Momentum as the reference
+    builds its layers: the two norms inside a BasicBlock keep the class default 0.1 (``_make_layer`` does not pass
+    ``bn_momentum`` to the blocks, resnet.py:123-147, resnet_block.py:19), every other norm gets config.bn_momentum =
+    0.02 (res16unet.py:29,49; the projection's norm: resnet.py:116-121)."""
+    if momentum is None:
+        momentum = 0.1 if prefix.endswith(("norm1.", "norm2.")) else 0.02
+    return torch.nn.functional.batch_norm(x, sd[prefix + "bn.running_mean"], sd[prefix + "bn.running_var"],
+                                          sd[prefix + "bn.weight"], sd[prefix + "bn.bias"], training=True,
+                                          momentum=momentum, eps=BN_EPS)
+
+
+def basic_block(x, sd, prefix, lv: SparseLevels, level: int, bn=batch_norm_eval):
     """BasicBlock.forward, resnet_block.py:48-64."""
     km = lv.kernel_map(level, 3)
     n = lv.n(level)
     out = sparse_conv(x, sd[prefix + "conv1.kernel"], km, n)
-    out = torch.relu(batch_norm_eval(out, sd, prefix + "norm1."))
+    out = RELU(bn(out, sd, prefix + "norm1."))
     out = sparse_conv(out, sd[prefix + "conv2.kernel"], km, n)
-    out = batch_norm_eval(out, sd, prefix + "norm2.")
+    out = bn(out, sd, prefix + "norm2.")
     if (prefix + "downsample.0.kernel") in sd:
         Wp = sd[prefix + "downsample.0.kernel"]
         Wp = Wp if Wp.dim() == 2 else Wp[0]
-        residual = batch_norm_eval(x @ Wp, sd, prefix + "downsample.1.")
+        residual = bn(x @ Wp, sd, prefix + "downsample.1.")
     else:
         residual = x
-    return torch.relu(out + residual)
+    return RELU(out + residual)
 
 
-def _layer(x, sd, prefix, n_blocks, lv, level):
+def _layer(x, sd, prefix, n_blocks, lv, level, bn=batch_norm_eval):
     for i in range(n_blocks):
-        x = basic_block(x, sd, f"{prefix}{i}.", lv, level)
+        x = basic_block(x, sd, f"{prefix}{i}.", lv, level, bn)
     return x
 
 
-def res16unet34c_forward(sd, lv: SparseLevels, feats: torch.Tensor, prefix: str = "backbone."):
-    """Res16UNetBase.forward, res16unet.py:222-295.  Returns (out [N0,96], feature_maps[5])."""
+def res16unet34c_forward(sd, lv: SparseLevels, feats: torch.Tensor, prefix: str = "backbone.", bn=batch_norm_eval):
+    """Res16UNetBase.forward, res16unet.py:222-295.  Returns (out [N0,96], feature_maps[5]).  ``bn`` selects eval-mode
+    (inference path) or ``batch_norm_train`` (training path; differentiable through torch autograd)."""
+    norm = bn              # (down / up below take the NAME of their norm layer in a parameter called bn)
     p = prefix
     ksz = round(sd[p + "conv0p1s1.kernel"].shape[0] ** (1 / 3))
     fm = []
     out = sparse_conv(feats, sd[p + "conv0p1s1.kernel"], lv.kernel_map(0, ksz), lv.n(0))
-    out_p1 = torch.relu(batch_norm_eval(out, sd, p + "bn0."))
+    out_p1 = RELU(norm(out, sd, p + "bn0."))
 
     def down(x, conv, bn, level):
         y = sparse_conv(x, sd[p + conv + ".kernel"], lv.stride_map(level), lv.n(level + 1))
-        return torch.relu(batch_norm_eval(y, sd, p + bn + "."))
+        return RELU(norm(y, sd, p + bn + "."))
 
     def up(x, conv, bn, level_out):
         # transposed conv = the stride map of level_out with in/out swapped (App. B.5)
         kmap = [(rc, rf) for (rf, rc) in lv.stride_map(level_out)]
         y = sparse_conv(x, sd[p + conv + ".kernel"], kmap, lv.n(level_out))
-        return torch.relu(batch_norm_eval(y, sd, p + bn + "."))
+        return RELU(norm(y, sd, p + bn + "."))
 
     out = down(out_p1, "conv1p1s2", "bn1", 0)
-    out_b1p2 = _layer(out, sd, p + "block1.", LAYERS[0], lv, 1)
+    out_b1p2 = _layer(out, sd, p + "block1.", LAYERS[0], lv, 1, bn)
     out = down(out_b1p2, "conv2p2s2", "bn2", 1)
-    out_b2p4 = _layer(out, sd, p + "block2.", LAYERS[1], lv, 2)
+    out_b2p4 = _layer(out, sd, p + "block2.", LAYERS[1], lv, 2, bn)
     out = down(out_b2p4, "conv3p4s2", "bn3", 2)
-    out_b3p8 = _layer(out, sd, p + "block3.", LAYERS[2], lv, 3)
+    out_b3p8 = _layer(out, sd, p + "block3.", LAYERS[2], lv, 3, bn)
     out = down(out_b3p8, "conv4p8s2", "bn4", 3)
-    out = _layer(out, sd, p + "block4.", LAYERS[3], lv, 4)
+    out = _layer(out, sd, p + "block4.", LAYERS[3], lv, 4, bn)
     fm.append(out)
 
     out = up(out, "convtr4p16s2", "bntr4", 3)
     out = torch.cat([out, out_b3p8], 1)            # me.cat(out, skip): skip = LAST columns
-    out = _layer(out, sd, p + "block5.", LAYERS[4], lv, 3)
+    out = _layer(out, sd, p + "block5.", LAYERS[4], lv, 3, bn)
     fm.append(out)
     out = up(out, "convtr5p8s2", "bntr5", 2)
     out = torch.cat([out, out_b2p4], 1)
-    out = _layer(out, sd, p + "block6.", LAYERS[5], lv, 2)
+    out = _layer(out, sd, p + "block6.", LAYERS[5], lv, 2, bn)
     fm.append(out)
     out = up(out, "convtr6p4s2", "bntr6", 1)
     out = torch.cat([out, out_b1p2], 1)
-    out = _layer(out, sd, p + "block7.", LAYERS[6], lv, 1)
+    out = _layer(out, sd, p + "block7.", LAYERS[6], lv, 1, bn)
     fm.append(out)
     out = up(out, "convtr7p2s2", "bntr7", 0)
     out = torch.cat([out, out_p1], 1)
-    out = _layer(out, sd, p + "block8.", LAYERS[7], lv, 0)
+    out = _layer(out, sd, p + "block8.", LAYERS[7], lv, 0, bn)
     fm.append(out)
     return out, fm
 

@@ -1,6 +1,8 @@
 """-m gpu: backward of the sparse convolutions (first part) against torch autograd through
 the oracle's gather-GEMM-scatter convolution (oracle/backbone.py: sparse_conv, ME's CPU algorithm) on the same seeded
 inputs, rows matched by coordinates.  Tolerance 2e-4 of the gradient's scale (fp32 sums over up to 27 x N pairs)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -154,3 +156,73 @@ def test_stem_weight_grad_matches_autograd(world, ks):
     err = (dw - W.grad).abs().max().item()
     assert err <= 2e-4 * max(1.0, W.grad.abs().max().item()), err
     assert torch.equal(B.stem_weight_grad(sc, F3.cuda(), dY[maps[0]].cuda(), ks ** 3).cpu(), dw)
+
+
+def test_backbone_training_step_matches_autograd():
+    """Training-mode forward (BatchNorm on batch statistics) and backward of the whole Res16UNet34C + lin_squeeze_head
+    on the HIP kernels against torch autograd (float64) through the oracle backbone: the output, the updated running
+    statistics and the gradient of EVERY backbone parameter (63 conv kernels, 62 x 2 BatchNorm parameters, the bias)."""
+    from agile3d_amd import build_model, default_args
+    from agile3d_amd.train_backbone import BackboneTape
+    torch.manual_seed(3)
+    model = build_model(default_args()).cuda().train()
+    with torch.no_grad():                                   # non-trivial BatchNorm parameters
+        for n_, p in model.named_parameters():
+            if n_.endswith("bn.weight"):
+                p.uniform_(0.5, 1.5)
+            elif n_.endswith("bn.bias"):
+                p.normal_(0, 0.2)
+    DT = torch.float32 if os.environ.get('A3D_ORACLE_F32') else torch.float64   # ground truth in float64
+    sd0 = {k: v.detach().cpu().to(DT).clone() if v.is_floating_point() else v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    scn = make_scene(int(os.environ.get("A3D_TRAIN_VOX", "2500")), seed=12)
+    coords, n = scn["coords"], len(scn["coords"])
+    g = torch.Generator().manual_seed(4)
+    feats = torch.rand(n, 3, generator=g)
+    R = torch.randn(n, 128, generator=g) / 16
+    # ---- HIP kernels: forward
+    sc = Scene(torch.from_numpy(coords).cuda())
+    tape = BackboneTape(model, sc, feats.cuda())
+    # ---- oracle: autograd through the training-mode forward.  ReLU's derivative jumps at 0 and the sums behind the
+    # gradients cancel heavily (a single flipped element moves a BatchNorm bias gradient by a percent), so the oracle
+    # applies the 0/1 masks of the forward pass under test, in the same order: both sides then differentiate the SAME
+    # piecewise-linear function, and the forward outputs are still compared on their own.
+    lv = ob.SparseLevels(coords)
+    maps = [torch.from_numpy(internal_to_oracle_rows(sc, lv, i)) for i in range(5)]
+    masks = []
+    for level, node in tape.relu_levels:
+        m = torch.empty(node.v.shape, dtype=DT)
+        m[maps[level]] = (node.v > 0).cpu().to(DT)          # internal row order -> oracle row order
+        masks.append(m)
+    assert len(masks) == 1 + 8 + 2 * sum(ob.LAYERS)             # stem, 4 down + 4 up, two per BasicBlock
+    it = iter(masks)
+    sd = {k: (v.clone().requires_grad_() if v.is_floating_point() and "running" not in k else v.clone()) for k, v in sd0.items()}
+    ob.RELU = lambda z: z * next(it)
+    try:
+        out, _ = ob.res16unet34c_forward(sd, lv, feats.to(DT), bn=ob.batch_norm_train)
+    finally:
+        ob.RELU = torch.relu
+    Wh = sd["lin_squeeze_head.kernel"]
+    pcd_ref = out @ (Wh if Wh.dim() == 2 else Wh[0]) + sd["lin_squeeze_head.bias"].reshape(1, -1)
+    (pcd_ref * R.to(DT)).sum().backward()
+    err_out = (tape.output.cpu().double() - pcd_ref.detach()).abs().max().item()
+    assert err_out <= 2e-4 * max(1.0, pcd_ref.abs().max().item()), err_out
+    grads = tape.backward(R.cuda())
+    names = [k for k in sd if k.startswith(("backbone.", "lin_squeeze_head.")) and sd[k].requires_grad and
+             sd[k].grad is not None]                        # (the backbone's unused `final` layer has no gradient)
+    assert len(names) == 63 + 62 * 2 + 1                   # 63 conv kernels (62 + the head), BatchNorm pairs, the head bias
+    assert set(grads) == set(names), set(names) ^ set(grads)
+    worst = ("", 0.0)
+    for k in names:
+        ref = sd[k].grad
+        got = grads[k].cpu().double()
+        assert got.shape == ref.shape, k
+        rel = (got - ref).abs().max().item() / max(1e-3, ref.abs().max().item())
+        worst = max(worst, (k, rel), key=lambda t: t[1])
+        if os.environ.get("A3D_SHOW_GRADS"):
+            print(f"   {k:48s} rel {rel:.2e}  scale {ref.abs().max().item():.3e}")
+    print(f"backbone training step: output err {err_out:.2e}, {len(names)} parameter gradients, worst relative error "
+          f"{worst[1]:.2e} ({worst[0]})")
+    assert worst[1] <= 2e-3, worst
+    for k, v in model.state_dict().items():                 # running statistics moved like torch's (momentum 0.02)
+        if "running_" in k and k.startswith("backbone."):
+            assert (v.cpu().double() - sd[k]).abs().max().item() <= 1e-4 * max(1.0, sd[k].abs().max().item()), k
