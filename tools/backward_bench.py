@@ -40,6 +40,7 @@ def main():
     ap.add_argument("--voxels", type=int, default=80_000)
     ap.add_argument("--batch", type=int, default=1)
     ap.add_argument("--reps", type=int, default=10)
+    ap.add_argument("--tape", action="store_true", help="also time a training-mode forward + backward of the backbone")
     a = ap.parse_args()
     coords = np.concatenate([make_scene(a.voxels, seed=b, batch_index=b)["coords"] for b in range(a.batch)])
     sc = Scene(torch.from_numpy(coords).cuda())
@@ -63,5 +64,32 @@ def main():
               f"dx (incl. weight repack + buffer copies) {1e3 * t_x:8.1f} us {fl / t_x / 1e9:6.1f} TF/s")
 
 
+def tape_time(voxels, batch):
+    """Training-mode forward + backward of the whole backbone through BackboneTape (layer-at-a-time executor)."""
+    import time
+    from agile3d_amd import build_model, default_args
+    from agile3d_amd.train_backbone import BackboneTape
+    torch.manual_seed(0)
+    model = build_model(default_args()).cuda().train()
+    scenes = [make_scene(voxels, seed=b, batch_index=b) for b in range(batch)]
+    coords = torch.from_numpy(np.concatenate([s["coords"] for s in scenes])).cuda()
+    feats = torch.from_numpy(np.concatenate([s["feats"] for s in scenes])).cuda()
+    sc = Scene(coords)
+    d_out = torch.randn(sc.n[0], 128, device="cuda") / 16
+    for it in range(3):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        tape = BackboneTape(model, sc, feats)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        grads = tape.backward(d_out)
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+    print(f"BackboneTape, {batch} x {voxels} voxels: forward {1e3 * (t1 - t0):.1f} ms, backward {1e3 * (t2 - t1):.1f} ms "
+          f"({len(grads)} gradients)")
+
+
 if __name__ == "__main__":
     main()
+    if "--tape" in sys.argv:
+        tape_time(80_000, 4)
