@@ -1,0 +1,101 @@
+"""Optimiser of the reference's training loop on the HIP library:
+
+    clip_grad_norm_(grads, max_norm)      torch.nn.utils.clip_grad_norm_ (engine.py:145-148, max_norm = 0.1)
+    AdamW(params, lr, weight_decay)       torch.optim.AdamW (main.py:125-127), .step(grads)
+    allreduce_mean_(grads, group)         what DistributedDataParallel does to the gradients (one bucketed all-reduce,
+                                          RCCL on the GPUs; SURVEY section 8e: 39.3 M fp32 = 157 MB per step)
+
+Gradients are a dict {parameter name: tensor} as ``train_backbone.BackboneTape.backward`` returns them.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+
+import torch
+
+from . import lib as L
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr())
+
+
+def _stream(t):
+    return C.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+def total_grad_norm(grads: dict) -> float:
+    """sqrt(sum over all tensors of sum g^2): the 2-norm clip_grad_norm_ computes (fp64 accumulation on the device)."""
+    lib = L.load()
+    total, ws = 0.0, None
+    for g in grads.values():
+        if not g.is_cuda or g.dtype != torch.float32:
+            raise RuntimeError("agile3d_amd.optim runs on the GPU only (fp32 CUDA tensors)")
+        g = g.contiguous()
+        if ws is None:
+            ws = torch.empty(lib.a3d_sum_squares_workspace_bytes(), dtype=torch.uint8, device=g.device)
+        out = C.c_double()
+        L.check(lib.a3d_sum_squares(_ptr(g), g.numel(), C.byref(out), _ptr(ws), ws.numel(), _stream(g)), "a3d_sum_squares")
+        total += out.value
+    return math.sqrt(total)
+
+
+def clip_grad_norm_(grads: dict, max_norm: float):
+    """-> (total norm before clipping, coefficient to scale the gradients with); torch clamps max_norm / (norm + 1e-6)
+    to 1.  The coefficient is applied inside ``AdamW.step`` (no extra pass over the gradients)."""
+    norm = total_grad_norm(grads)
+    coef = min(1.0, max_norm / (norm + 1e-6)) if max_norm > 0 else 1.0
+    return norm, coef
+
+
+class AdamW:
+    """torch.optim.AdamW's update rule, one kernel launch per parameter tensor; state lives next to the parameters."""
+
+    def __init__(self, named_params, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2):
+        self.params = dict(named_params)
+        self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
+        self.state = {}
+        self.step_count = 0
+
+    def step(self, grads: dict, grad_scale: float = 1.0):
+        lib = L.load()
+        self.step_count += 1
+        for name, g in grads.items():
+            p = self.params[name]
+            if not p.is_cuda or p.dtype != torch.float32 or not p.is_contiguous():
+                raise RuntimeError("AdamW: parameters must be contiguous fp32 CUDA tensors")
+            st = self.state.get(name)
+            if st is None:
+                st = self.state[name] = (torch.zeros_like(p), torch.zeros_like(p))
+            g = g.reshape(p.shape).contiguous()
+            L.check(lib.a3d_adamw_step(_ptr(p.data), _ptr(g), _ptr(st[0]), _ptr(st[1]), p.numel(), self.step_count,
+                                       self.lr, self.betas[0], self.betas[1], self.eps, self.weight_decay, grad_scale,
+                                       _stream(p)), "a3d_adamw_step")
+
+
+def allreduce_mean_(grads: dict, group=None, bucket_bytes: int = 64 << 20):
+    """Average the gradients over the data-parallel ranks in place: tensors are packed into ~64 MB buckets (few, large
+    collectives: the xGMI links are bound per ring step) and all-reduced with torch.distributed
+    (nccl = RCCL on the GPUs; gloo in the CPU tests)."""
+    import torch.distributed as dist
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return grads
+    world = dist.get_world_size(group)
+    names = sorted(grads)
+    i = 0
+    while i < len(names):
+        bucket, size = [], 0
+        while i < len(names) and (not bucket or size + grads[names[i]].numel() * 4 <= bucket_bytes):
+            bucket.append(names[i])
+            size += grads[names[i]].numel() * 4
+            i += 1
+        flat = torch.cat([grads[n].reshape(-1) for n in bucket])
+        dist.all_reduce(flat, group=group)
+        flat /= world
+        off = 0
+        for n in bucket:
+            k = grads[n].numel()
+            grads[n].copy_(flat[off:off + k].view_as(grads[n]))
+            off += k
+    return grads

@@ -199,6 +199,18 @@ int    a3d_bn_train_backward(const float* x_dev, int ldx, const float* y_dev, in
 int    a3d_column_sums(const float* x_dev, int ldx, int64_t n, int C, float* out_dev,
                        void* workspace_dev, size_t workspace_bytes, void* stream);
 
+/* Optimiser step of the reference's training loop: torch.optim.AdamW(lr, weight_decay) (main.py:125-127) after
+ * clip_grad_norm_(parameters, max_norm) (engine.py:145-150).  a3d_sum_squares returns sum g^2 of one tensor to the
+ * host (the caller adds the tensors, clip coefficient = min(1, max_norm / (sqrt(total) + 1e-6))); a3d_adamw_step is
+ * torch's single-tensor AdamW update with the gradient read multiplied by grad_scale (the clip coefficient);
+ * step counts from 1. */
+size_t a3d_sum_squares_workspace_bytes(void);
+int    a3d_sum_squares(const float* g_dev, int64_t n, double* out_host, void* workspace_dev, size_t workspace_bytes,
+                       void* stream);
+int    a3d_adamw_step(float* param_dev, const float* grad_dev, float* exp_avg_dev, float* exp_avg_sq_dev, int64_t n,
+                      int step, float lr, float beta1, float beta2, float eps, float weight_decay, float grad_scale,
+                      void* stream);
+
 /* Dense row-major GEMM: out[n][cout] = act(((in (+ in_add))[n][cin] @ W) * scale + shift + res).
  * Replaces the nn.Linear / in_proj pieces of nn.MultiheadAttention that run over all N points
  * (models/modules/attention_block.py:91-94; `in_add` is the position encoding the reference adds to

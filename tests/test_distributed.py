@@ -71,3 +71,38 @@ def test_sharding_is_a_partition():
             flat = sorted(i for p in parts for i in p)
             assert flat == list(range(n))
             assert max(len(p) for p in parts) - min(len(p) for p in parts) <= 1
+
+
+def _grad_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from agile3d_amd.optim import allreduce_mean_
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    g = torch.Generator().manual_seed(100 + rank)
+    grads = {f"p{i}": torch.randn(shape, generator=g) for i, shape in enumerate([(27, 32, 32), (96,), (5, 7), (1, 128)])}
+    before = {k: v.clone() for k, v in grads.items()}
+    allreduce_mean_(grads, bucket_bytes=27 * 32 * 32 * 4 + 96 * 4)       # small buckets: several collectives
+    q.put((rank, {k: v.numpy() for k, v in before.items()}, {k: v.numpy() for k, v in grads.items()}))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gradient_allreduce_mean_world2():
+    """Training DP: every rank ends up with the mean of the ranks' gradients, tensor shapes untouched."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_grad_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=120) for _ in range(world)), key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (_, b0, a0), (_, b1, a1) = res
+    for k in b0:
+        want = (b0[k] + b1[k]) / 2
+        assert a0[k].shape == b0[k].shape and np.allclose(a0[k], want, atol=1e-7) and np.array_equal(a0[k], a1[k])

@@ -226,3 +226,30 @@ def test_backbone_training_step_matches_autograd():
     for k, v in model.state_dict().items():                 # running statistics moved like torch's (momentum 0.02)
         if "running_" in k and k.startswith("backbone."):
             assert (v.cpu().double() - sd[k]).abs().max().item() <= 1e-4 * max(1.0, sd[k].abs().max().item()), k
+
+
+def test_adamw_and_grad_clip_match_torch():
+    """Three steps of clip_grad_norm_(0.1) + AdamW(lr 1e-4, weight_decay 1e-4) (main.py:125-127, engine.py:145-150)
+    against torch.optim.AdamW / torch.nn.utils.clip_grad_norm_ on the CPU."""
+    from agile3d_amd.optim import AdamW, clip_grad_norm_
+    g = torch.Generator().manual_seed(8)
+    shapes = {"a.kernel": (27, 96, 96), "b.bn.weight": (96,), "c.kernel": (128, 96), "d.bias": (1, 128)}
+    ref_p = {k: torch.nn.Parameter(torch.randn(s, generator=g)) for k, s in shapes.items()}
+    dev_p = {k: v.detach().clone().cuda() for k, v in ref_p.items()}
+    ref_opt = torch.optim.AdamW(ref_p.values(), lr=1e-4, weight_decay=1e-4)
+    opt = AdamW(dev_p.items(), lr=1e-4, weight_decay=1e-4)
+    for step in range(3):
+        grads = {k: torch.randn(s, generator=g) * (0.02 if step == 1 else 1.0) for k, s in shapes.items()}
+        for k, p in ref_p.items():
+            p.grad = grads[k].clone()
+        ref_norm = torch.nn.utils.clip_grad_norm_(ref_p.values(), 0.1)
+        ref_opt.step()
+        dgr = {k: v.cuda() for k, v in grads.items()}
+        norm, coef = clip_grad_norm_(dgr, 0.1)
+        assert abs(norm - ref_norm.item()) <= 1e-5 * ref_norm.item()
+        opt.step(dgr, coef)
+        for k in shapes:
+            assert (dev_p[k].cpu() - ref_p[k].detach()).abs().max().item() <= 1e-6, (step, k)   # a couple of ulps at |p| ~ 4
+    st = ref_opt.state[ref_p["a.kernel"]]
+    assert (opt.state["a.kernel"][0].cpu() - st["exp_avg"]).abs().max().item() <= 1e-9
+    assert (opt.state["a.kernel"][1].cpu() - st["exp_avg_sq"]).abs().max().item() <= 1e-12
