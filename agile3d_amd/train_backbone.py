@@ -13,8 +13,6 @@ through a one-op program with its own workspace.  The decoder's backward and the
 """
 from __future__ import annotations
 
-import ctypes as C
-
 import torch
 
 from . import backward as B
