@@ -1004,6 +1004,7 @@ struct QueryLayerW {
   const float *dn_w, *dn_b, *m_w0t, *m_b0, *m_w2t, *m_b2;
   const float *next_c2s_in_wt, *next_c2s_in_b;   // nullptr on the last layer
   int dim_ff;
+  unsigned long long* dbg;                       // A3D_DEC_DBG=2: s_memtime marks of workgroup (0, 0), else nullptr
 };
 
 
@@ -1245,6 +1246,10 @@ __global__ void __launch_bounds__(512) k_query_layer(const QuerySample* __restri
   const int tid = threadIdx.x, nt = blockDim.x;
   const int wave = tid >> 6;
   f32x4 wfa[8], wfb[8], acc[QT];
+  auto mark = [&](int i) {
+    if (W.dbg && tid == 0 && blockIdx.x == 0 && blockIdx.y == 0) W.dbg[i] = __builtin_amdgcn_s_memtime();
+  };
+  mark(0);
 
   if constexpr (PART != 2) {
   // ---- load the layer inputs (queries, qpos, click-to-scene attention result) into LDS
@@ -1262,6 +1267,7 @@ __global__ void __launch_bounds__(512) k_query_layer(const QuerySample* __restri
     *(f32x4*)(xa + q * kQLD + c4) = va;
   }
   __syncthreads();
+  mark(1);
   // ---- 1. click-to-scene output projection + residual + LayerNorm (attention_block.py:95-96)
   qzero<QT>(acc);
   qmm<QT>(xa, wfa, acc);
@@ -1271,6 +1277,7 @@ __global__ void __launch_bounds__(512) k_query_layer(const QuerySample* __restri
   __syncthreads();
   qadd_ln(cur, xb, Q, W.c2s_norm_w, W.c2s_norm_b, cur, nullptr);     // cur = tgt
   __syncthreads();
+  mark(2);
   // ---- 2. click-to-click self attention (attention_block.py:32-36): q|k from tgt+qpos, v from tgt
   for (int e = tid; e < QP * 128; e += nt) {
     const int q = e >> 7, c = e & 127;
@@ -1316,6 +1323,7 @@ __global__ void __launch_bounds__(512) k_query_layer(const QuerySample* __restri
       *(f32x4*)(qpos + q * kQLD + c4) = vp;
     }
   }
+  mark(3);
   qload_w(W.c2c_out_wt, D, 16 * wave, 0, wfa);                      // next round's weights
   __syncthreads();
   // keys / values of the attention: LDS (PART 0) or the global buffers every block wrote (PART 2)
@@ -1350,6 +1358,7 @@ __global__ void __launch_bounds__(512) k_query_layer(const QuerySample* __restri
 #pragma unroll
     for (int d = 0; d < DH; ++d) xa[q * kQLD + h * DH + d] = o[d] * inv;
   }
+  mark(4);
   for (int e = tid; e < (QP - Q) * 128; e += nt) xa[(Q + (e >> 7)) * kQLD + (e & 127)] = 0.f;   // padded rows
   __syncthreads();
   if constexpr (PART == 0) {   // the qpos buffer held v: restore the position encodings for step 4
@@ -1367,6 +1376,7 @@ __global__ void __launch_bounds__(512) k_query_layer(const QuerySample* __restri
   __syncthreads();
   qadd_ln(cur, xb, Q, W.c2c_norm_w, W.c2c_norm_b, cur, nullptr);
   __syncthreads();
+  mark(5);
   // ---- 3. FFN (attention_block.py:151-155) in hidden chunks of 128: wave w computes hidden tile w of
   //         the chunk into xb, then accumulates output tile w over the chunk
   f32x4 facc[QT];
@@ -1382,12 +1392,14 @@ __global__ void __launch_bounds__(512) k_query_layer(const QuerySample* __restri
     qmm<QT>(xb, wfb, facc);
     __syncthreads();
   }
+  mark(6);
   qstore<QT>(facc, W.ffn_b2, 16 * wave, 1.f, false, xa, kQLD, 16 * wave, QP);
   qload_w(W.s2c_in_wt, D, D + 16 * wave, 0, wfa);                   // s2c k rows
   qload_w(W.s2c_in_wt, D, 2 * D + 16 * wave, 0, wfb);               // s2c v rows
   __syncthreads();
   qadd_ln(cur, xa, Q, W.ffn_norm_w, W.ffn_norm_b, cur, B.queries);   // cur = queries (also to global)
   __syncthreads();
+  mark(7);
   // ---- 4. everything that depends only on the new queries: s2c keys/values, mask MLP layer 0, next
   //         iteration's c2s query projection
   qadd_ln(cur, nullptr, Q, W.dn_w, W.dn_b, xb, nullptr);             // decoder_norm(queries)
@@ -1418,6 +1430,7 @@ __global__ void __launch_bounds__(512) k_query_layer(const QuerySample* __restri
   qzero<QT>(acc);
   qmm<QT>(qpos, wfa, acc);
   qstore<QT>(acc, W.m_b2, 16 * wave, 1.f, false, B.E, D, 16 * wave, Q);
+  mark(8);
 }
 
 }  // namespace a3d
@@ -1700,6 +1713,17 @@ static int run_decoder(const a3d_decoder_weights* w, Prepared* P, int ns, hipStr
     QW.next_c2s_in_wt = l + 1 < w->n_layers ? w->layers[l + 1].c2s_in_w : nullptr;
     QW.next_c2s_in_b = l + 1 < w->n_layers ? w->layers[l + 1].c2s_in_b : nullptr;
     QW.dim_ff = w->dim_ff;
+    QW.dbg = nullptr;
+    {
+      static int dbg_on = -1;
+      static unsigned long long* qdbg = nullptr;
+      if (dbg_on < 0) {
+        const char* e = getenv("A3D_DEC_DBG");
+        dbg_on = e && atoi(e) == 2;
+        if (dbg_on) (void)hipMalloc(&qdbg, 16 * sizeof(unsigned long long));
+      }
+      if (dbg_on && l == 0) QW.dbg = qdbg;
+    }
     {   // one workgroup (or chain of query blocks) per sample: blockIdx.y
       ProfScope ps(st, A3D_PROF_QUERY, 0, 0, 0, 0, nq_max);
       k_c2s_combine<<<dim3(nq_max * H, ns), 64, 0, st>>>(qs_dev, P[0].L.qp);
@@ -1712,6 +1736,15 @@ static int run_decoder(const a3d_decoder_weights* w, Prepared* P, int ns, hipStr
       }
     }
     A3D_LAUNCH_CHECK();
+    if (QW.dbg) {   // phase marks of the query-side workgroup of sample 0 (debugging aid, synchronous)
+      unsigned long long h[16];
+      (void)hipMemcpyAsync(h, QW.dbg, sizeof(h), hipMemcpyDeviceToHost, st);
+      (void)hipStreamSynchronize(st);
+      fprintf(stderr, "k_query_layer dbg (ticks): load %llu | c2s out+LN %llu | qkv proj %llu | c2c attn %llu | "
+                      "c2c out+LN %llu | FFN %llu | LN %llu | s2c kv, qproj, mask MLP %llu | total %llu\n",
+              h[1] - h[0], h[2] - h[1], h[3] - h[2], h[4] - h[3], h[5] - h[4], h[6] - h[5], h[7] - h[6], h[8] - h[7],
+              h[8] - h[0]);
+    }
     // ---- scene-to-click: Q = (src + pos) Wq^T + bq; attention; Y = O Wo^T + bo + src; LN
     if (fuse_s2c) {
       ProfScope ps(st, A3D_PROF_S2C, 0, 0, 0, 0, (int)n_total);
