@@ -184,3 +184,43 @@ def stem_weight_grad(scene, feats3, dy, kernel_volume=125):
     L.check(lib.a3d_stem_wgrad(scene.handle, _ptr(feats3), _ptr(dy), dy.shape[1], kernel_volume, _ptr(dw), _ptr(ws),
                                nbytes, _stream()), "a3d_stem_wgrad")
     return dw
+
+
+def layernorm_forward(x, gamma, beta, eps=1e-5):
+    lib = L.load()
+    x = x.contiguous()
+    n, C_ = x.shape
+    y = torch.empty_like(x)
+    L.check(lib.a3d_layernorm_forward(_ptr(x), C_, n, C_, _ptr(gamma), _ptr(beta), eps, _ptr(y), C_, _stream()),
+            "a3d_layernorm_forward")
+    return y
+
+
+def layernorm_backward(x, dy, gamma, eps=1e-5):
+    """-> (dx, dgamma, dbeta) of y = LayerNorm(x) over the channels of every row."""
+    lib = L.load()
+    x, dy = x.contiguous(), dy.contiguous()
+    n, C_ = x.shape
+    dx = torch.empty_like(x)
+    dgamma = torch.empty(C_, dtype=torch.float32, device=x.device)
+    dbeta = torch.empty_like(dgamma)
+    ws = _ws(n, C_, x.device)
+    L.check(lib.a3d_layernorm_backward(_ptr(x), C_, _ptr(dy), C_, n, C_, _ptr(gamma), eps, _ptr(dx), _ptr(dgamma),
+                                       _ptr(dbeta), _ptr(ws), ws.numel(), _stream()), "a3d_layernorm_backward")
+    return dx, dgamma, dbeta
+
+
+def linear_weight_grad(x, dy):
+    """dW [Cin, Cout] = x^T dy for [n, Cin], [n, Cout] (weights in the [in, out] layout the kernels use)."""
+    lib = L.load()
+    x, dy = x.contiguous(), dy.contiguous()
+    n, cin = x.shape
+    cout = dy.shape[1]
+    nbytes = lib.a3d_linear_wgrad_workspace_bytes(n, cin, cout)
+    if nbytes == 0:
+        raise L.A3DError(lib.a3d_last_error().decode())
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+    dw = torch.empty((cin, cout), dtype=torch.float32, device=x.device)
+    L.check(lib.a3d_linear_wgrad(_ptr(x), cin, _ptr(dy), cout, n, cin, cout, _ptr(dw), _ptr(ws), nbytes, _stream()),
+            "a3d_linear_wgrad")
+    return dw

@@ -154,6 +154,91 @@ __global__ void k_bn_bwd_apply(const BwdArgs a) {
   }
 }
 
+// ---- LayerNorm over the channels of every row (nn.LayerNorm(128) of the decoder: attention_block.py:38,98,155,
+// agile3d.py:137), forward and backward: one wave per row, lane = two channels at C = 128 (C <= 512: C / 64 per lane).
+//   backward: gh = dy * gamma;  dx = rstd * (gh - mean(gh) - xhat * mean(gh * xhat));  dgamma = sum_rows dy * xhat,
+//             dbeta = sum_rows dy  (row-block partials -> k_col_final, deterministic)
+constexpr int kLnMaxPerLane = 8;
+struct LnArgs {
+  const float *x, *dy, *gamma, *beta;
+  float *y, *dx, *partial;   // partial [blocks][2][C]
+  int ldx, ldy, n, C, rows_per_block;
+  float eps;
+};
+__global__ void __launch_bounds__(256) k_ln_forward(const LnArgs a) {
+  const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= a.n) return;
+  const int per = a.C >> 6;
+  float v[kLnMaxPerLane];
+  float s = 0.f;
+  for (int i = 0; i < per; ++i) {
+    v[i] = a.x[(size_t)row * a.ldx + lane + 64 * i];
+    s += v[i];
+  }
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  const float mean = s / (float)a.C;
+  float q = 0.f;
+  for (int i = 0; i < per; ++i) q += (v[i] - mean) * (v[i] - mean);
+  for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
+  const float rstd = 1.0f / sqrtf(q / (float)a.C + a.eps);
+  for (int i = 0; i < per; ++i) {
+    const int c = lane + 64 * i;
+    a.y[(size_t)row * a.ldy + c] = (v[i] - mean) * rstd * a.gamma[c] + a.beta[c];
+  }
+}
+__global__ void __launch_bounds__(256) k_ln_backward(const LnArgs a) {
+  __shared__ float red[2][4][64 * kLnMaxPerLane];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int per = a.C >> 6;
+  const int r0 = blockIdx.x * a.rows_per_block, r1 = min(a.n, r0 + a.rows_per_block);
+  float dg[kLnMaxPerLane], db[kLnMaxPerLane], ga[kLnMaxPerLane];
+  for (int i = 0; i < per; ++i) dg[i] = db[i] = 0.f, ga[i] = a.gamma[lane + 64 * i];
+  for (int row = r0 + wave; row < r1; row += 4) {
+    float v[kLnMaxPerLane], g[kLnMaxPerLane];
+    float s = 0.f;
+    for (int i = 0; i < per; ++i) {
+      v[i] = a.x[(size_t)row * a.ldx + lane + 64 * i];
+      g[i] = a.dy[(size_t)row * a.ldy + lane + 64 * i];
+      s += v[i];
+    }
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    const float mean = s / (float)a.C;
+    float q = 0.f;
+    for (int i = 0; i < per; ++i) q += (v[i] - mean) * (v[i] - mean);
+    for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
+    const float rstd = 1.0f / sqrtf(q / (float)a.C + a.eps);
+    float m1 = 0.f, m2 = 0.f;
+    for (int i = 0; i < per; ++i) {
+      v[i] = (v[i] - mean) * rstd;                  // xhat
+      dg[i] += g[i] * v[i];
+      db[i] += g[i];
+      g[i] *= ga[i];                                // gh
+      m1 += g[i];
+      m2 += g[i] * v[i];
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+      m1 += __shfl_xor(m1, o, 64);
+      m2 += __shfl_xor(m2, o, 64);
+    }
+    m1 /= (float)a.C, m2 /= (float)a.C;
+    for (int i = 0; i < per; ++i) a.dx[(size_t)row * a.ldx + lane + 64 * i] = rstd * (g[i] - m1 - v[i] * m2);
+  }
+  for (int i = 0; i < per; ++i) {
+    red[0][wave][lane + 64 * i] = dg[i];
+    red[1][wave][lane + 64 * i] = db[i];
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < a.C; c += 256) {
+    // [2][C]: dbeta sums first, dgamma second (k_col_final sums column-wise over the blocks)
+    a.partial[(size_t)blockIdx.x * 2 * a.C + c] = red[1][0][c] + red[1][1][c] + red[1][2][c] + red[1][3][c];
+    a.partial[(size_t)blockIdx.x * 2 * a.C + a.C + c] = red[0][0][c] + red[0][1][c] + red[0][2][c] + red[0][3][c];
+  }
+}
+__global__ void k_ln_params(const double* sums, int C, float* dgamma, float* dbeta) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c < C) dbeta[c] = (float)sums[c], dgamma[c] = (float)sums[C + c];
+}
+
 static bool bn_shape_ok(int64_t n, int C, int ld0, int ld1, int ld2) {
   return n > 0 && n <= (int64_t)1 << 30 && C >= 32 && C % 32 == 0 && kBnThreads % (C / 4) == 0 && ld0 % 4 == 0 &&
          ld1 % 4 == 0 && ld2 % 4 == 0;
@@ -270,6 +355,48 @@ extern "C" int a3d_column_sums(const float* x_dev, int ldx, int64_t n, int C, fl
   k_col_partial<<<blocks, kBnThreads, 0, st>>>(c);
   k_col_final<<<(unsigned)((C + 255) / 256), 256, 0, st>>>(partial, blocks, 1, C, sums);
   k_bn_mean<<<(unsigned)((C + 255) / 256), 256, 0, st>>>(sums, C, 1.0, out_dev);
+  A3D_LAUNCH_CHECK();
+  return A3D_OK;
+}
+
+extern "C" int a3d_layernorm_forward(const float* x_dev, int ldx, int64_t n, int C, const float* gamma_dev,
+                                     const float* beta_dev, float eps, float* y_dev, int ldy, void* stream) {
+  if (!x_dev || !gamma_dev || !beta_dev || !y_dev || n <= 0 || n > (int64_t)1 << 30 || C < 64 || C % 64 ||
+      C > 64 * kLnMaxPerLane || ldx < C || ldy < C) {
+    set_error("a3d_layernorm_forward: bad arguments (C a multiple of 64, <= 512)");
+    return A3D_ERR_INVALID;
+  }
+  LnArgs a;
+  memset(&a, 0, sizeof(a));
+  a.x = x_dev, a.gamma = gamma_dev, a.beta = beta_dev, a.y = y_dev, a.ldx = ldx, a.ldy = ldy, a.n = (int)n, a.C = C, a.eps = eps;
+  k_ln_forward<<<(unsigned)((n + 3) / 4), 256, 0, (hipStream_t)stream>>>(a);
+  A3D_LAUNCH_CHECK();
+  return A3D_OK;
+}
+
+extern "C" int a3d_layernorm_backward(const float* x_dev, int ldx, const float* dy_dev, int lddy, int64_t n, int C,
+                                      const float* gamma_dev, float eps, float* dx_dev, float* dgamma_dev,
+                                      float* dbeta_dev, void* workspace_dev, size_t workspace_bytes, void* stream) {
+  if (!x_dev || !dy_dev || !gamma_dev || !dx_dev || !dgamma_dev || !dbeta_dev || !workspace_dev || n <= 0 ||
+      n > (int64_t)1 << 30 || C < 64 || C % 64 || C > 64 * kLnMaxPerLane || ldx < C || lddy < C) {
+    set_error("a3d_layernorm_backward: bad arguments (C a multiple of 64, <= 512; dx has the layout of x)");
+    return A3D_ERR_INVALID;
+  }
+  if (workspace_bytes < a3d_bn_workspace_bytes(n, C) || ((uintptr_t)workspace_dev & 15)) {
+    set_error("a3d_layernorm_backward: workspace too small or misaligned (a3d_bn_workspace_bytes)");
+    return A3D_ERR_WORKSPACE;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  float* partial = (float*)workspace_dev;
+  double* sums = (double*)((char*)workspace_dev + align256((size_t)kBnMaxBlocks * 2 * C * sizeof(float)));
+  LnArgs a;
+  memset(&a, 0, sizeof(a));
+  a.x = x_dev, a.dy = dy_dev, a.gamma = gamma_dev, a.dx = dx_dev, a.partial = partial;
+  a.ldx = ldx, a.ldy = lddy, a.n = (int)n, a.C = C, a.eps = eps;
+  const int blocks = bn_blocks(n, a.rows_per_block);
+  k_ln_backward<<<blocks, 256, 0, st>>>(a);
+  k_col_final<<<(unsigned)((2 * C + 255) / 256), 256, 0, st>>>(partial, blocks, 2, C, sums);
+  k_ln_params<<<(unsigned)((C + 255) / 256), 256, 0, st>>>(sums, C, dgamma_dev, dbeta_dev);
   A3D_LAUNCH_CHECK();
   return A3D_OK;
 }

@@ -315,6 +315,56 @@ __global__ void k_stem_wgrad_reduce(const float* __restrict__ part, int total, f
 
 using namespace a3d;
 
+// dW [cin][cout] = x^T dy for plain row-major matrices of n rows (the nn.Linear layers of the decoder that run over all
+// points or over the queries: attention_block.py, agile3d.py:51-55): the 1x1 case of a3d_conv_wgrad without a scene
+extern "C" size_t a3d_linear_wgrad_workspace_bytes(int64_t n, int cin, int cout) {
+  WgradPlan p;
+  if (n <= 0 || n > (int64_t)1 << 30 || !wgrad_plan((int)n, 1, cin, cout, p)) {
+    set_error("a3d_linear_wgrad: channels must be multiples of 32 (got %d -> %d)", cin, cout);
+    return 0;
+  }
+  return p.part_bytes + 256;
+}
+extern "C" int a3d_linear_wgrad(const float* x_dev, int ldx, const float* dy_dev, int ldy, int64_t n, int cin, int cout,
+                                float* dw_dev, void* workspace_dev, size_t workspace_bytes, void* stream) {
+  WgradPlan p;
+  if (!x_dev || !dy_dev || !dw_dev || !workspace_dev || n <= 0 || n > (int64_t)1 << 30 || ldx < cin || ldy < cout ||
+      (ldx & 1) || (ldy & 1) || !wgrad_plan((int)n, 1, cin, cout, p)) {
+    set_error("a3d_linear_wgrad: bad arguments (channels multiples of 32, even leading dimensions)");
+    return A3D_ERR_INVALID;
+  }
+  if (workspace_bytes < p.part_bytes || ((uintptr_t)workspace_dev & 15)) {
+    set_error("a3d_linear_wgrad: workspace too small or misaligned");
+    return A3D_ERR_WORKSPACE;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  WgradArgs a;
+  memset(&a, 0, sizeof(a));
+  a.x = x_dev, a.dy = dy_dev, a.ldx = ldx, a.ldy = ldy, a.cin = cin, a.cout = cout;
+  a.K = 1, a.n_in = a.n_out = a.n_pos = (int)n;
+  a.chunk_groups = p.chunk_groups;
+  a.n_chunks = p.chunks;
+  a.part = (float*)workspace_dev;
+  const dim3 grid((unsigned)((p.chunks + 7) / 8 * 8), 1, p.nblocks);
+  const size_t lds = (size_t)16 * p.cx * 16 * p.cy * sizeof(float);
+#define A3D_WG(CX_, CY_)                                                                                          \
+  if (p.cx == CX_ && p.cy == CY_) {                                                                               \
+    (void)hipFuncSetAttribute((const void*)k_wgrad<CX_, CY_>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024); \
+    k_wgrad<CX_, CY_><<<grid, 256, lds, st>>>(a);                                                                  \
+  } else
+  A3D_WG(2, 2) A3D_WG(2, 4) A3D_WG(2, 6) A3D_WG(2, 8) A3D_WG(4, 2) A3D_WG(4, 4) A3D_WG(4, 6) A3D_WG(4, 8)
+  A3D_WG(6, 2) A3D_WG(6, 4) A3D_WG(6, 6) A3D_WG(8, 2) A3D_WG(8, 4) {
+    set_error("a3d_linear_wgrad: no kernel for %d x %d channels per lane", p.cx, p.cy);
+    return A3D_ERR_UNSUPPORTED;
+  }
+#undef A3D_WG
+  A3D_LAUNCH_CHECK();
+  k_wgrad_reduce<<<(unsigned)(((size_t)cin * cout + 255) / 256), 256, 0, st>>>(a.part, p.chunks, 1, cin, cout, p.cx, p.cy,
+                                                                              dw_dev);
+  A3D_LAUNCH_CHECK();
+  return A3D_OK;
+}
+
 extern "C" size_t a3d_stem_wgrad_workspace_bytes(int kernel_volume) {
   if (kernel_volume != 125 && kernel_volume != 27) return 0;
   return (size_t)kStemSplits * kernel_volume * 96 * sizeof(float) + 256;

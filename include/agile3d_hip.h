@@ -199,6 +199,19 @@ int    a3d_bn_train_backward(const float* x_dev, int ldx, const float* y_dev, in
 int    a3d_column_sums(const float* x_dev, int ldx, int64_t n, int C, float* out_dev,
                        void* workspace_dev, size_t workspace_bytes, void* stream);
 
+/* nn.LayerNorm over the channels of every row (the decoder's norms: attention_block.py:38,98,155; agile3d.py:137),
+ * forward and backward (C a multiple of 64, <= 512; dx has the layout of x; workspace: a3d_bn_workspace_bytes(n, C)) */
+int    a3d_layernorm_forward(const float* x_dev, int ldx, int64_t n, int C, const float* gamma_dev,
+                             const float* beta_dev, float eps, float* y_dev, int ldy, void* stream);
+int    a3d_layernorm_backward(const float* x_dev, int ldx, const float* dy_dev, int lddy, int64_t n, int C,
+                              const float* gamma_dev, float eps, float* dx_dev, float* dgamma_dev, float* dbeta_dev,
+                              void* workspace_dev, size_t workspace_bytes, void* stream);
+/* dW [cin][cout] = x^T dy for row-major [n][ld] matrices: weight gradient of the decoder's nn.Linear layers (the input
+ * gradient dy W^T is a3d_linear with the transposed weight) */
+size_t a3d_linear_wgrad_workspace_bytes(int64_t n, int cin, int cout);
+int    a3d_linear_wgrad(const float* x_dev, int ldx, const float* dy_dev, int ldy, int64_t n, int cin, int cout,
+                        float* dw_dev, void* workspace_dev, size_t workspace_bytes, void* stream);
+
 /* Optimiser step of the reference's training loop: torch.optim.AdamW(lr, weight_decay) (main.py:125-127) after
  * clip_grad_norm_(parameters, max_norm) (engine.py:145-150).  a3d_sum_squares returns sum g^2 of one tensor to the
  * host (the caller adds the tensors, clip coefficient = min(1, max_norm / (sqrt(total) + 1e-6))); a3d_adamw_step is

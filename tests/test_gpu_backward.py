@@ -253,3 +253,27 @@ def test_adamw_and_grad_clip_match_torch():
     st = ref_opt.state[ref_p["a.kernel"]]
     assert (opt.state["a.kernel"][0].cpu() - st["exp_avg"]).abs().max().item() <= 1e-9
     assert (opt.state["a.kernel"][1].cpu() - st["exp_avg_sq"]).abs().max().item() <= 1e-12
+
+
+@pytest.mark.parametrize("n", [20, 1000, 40001])
+def test_layernorm_and_linear_weight_grad_vs_torch(n):
+    """The decoder's row-wise pieces: nn.LayerNorm(128) forward / backward and dW = x^T dy of its nn.Linear layers."""
+    g = torch.Generator().manual_seed(n)
+    x = torch.randn(n, 128, generator=g) * 1.7 + 0.3
+    gamma, beta = torch.rand(128, generator=g) + 0.5, torch.randn(128, generator=g)
+    dy = torch.randn(n, 128, generator=g)
+    xd, gd, bd = x.double().requires_grad_(), gamma.double().requires_grad_(), beta.double().requires_grad_()
+    y_ref = torch.nn.functional.layer_norm(xd, (128,), gd, bd, 1e-5)
+    y_ref.backward(dy.double())
+    y = B.layernorm_forward(x.cuda(), gamma.cuda(), beta.cuda())
+    assert (y.cpu().double() - y_ref.detach()).abs().max().item() <= 1e-5
+    dx, dg, db = B.layernorm_backward(x.cuda(), dy.cuda(), gamma.cuda())
+    assert (dx.cpu().double() - xd.grad).abs().max().item() <= 2e-5 * max(1.0, xd.grad.abs().max().item())
+    assert (dg.cpu().double() - gd.grad).abs().max().item() <= 1e-4 * max(1.0, gd.grad.abs().max().item())
+    assert (db.cpu().double() - bd.grad).abs().max().item() <= 1e-4 * max(1.0, bd.grad.abs().max().item())
+    x2 = torch.randn(n, 128, generator=g)
+    for cout in (128, 1024) if n >= 32 else (128,):
+        d2 = torch.randn(n, cout, generator=g)
+        dw = B.linear_weight_grad(x2.cuda(), d2.cuda()).cpu().double()
+        ref = x2.double().t() @ d2.double()
+        assert (dw - ref).abs().max().item() <= 2e-4 * max(1.0, ref.abs().max().item())
