@@ -277,3 +277,30 @@ def test_layernorm_and_linear_weight_grad_vs_torch(n):
         dw = B.linear_weight_grad(x2.cuda(), d2.cuda()).cpu().double()
         ref = x2.double().t() @ d2.double()
         assert (dw - ref).abs().max().item() <= 2e-4 * max(1.0, ref.abs().max().item())
+
+
+def test_backbone_trains_with_clip_and_adamw():
+    """The training pieces together: BackboneTape gradients -> clip_grad_norm_(0.1) -> AdamW, eight steps on one scene
+    with a least-squares target on pcd_features.  The loss must fall; nothing here touches torch autograd."""
+    from agile3d_amd import build_model, default_args
+    from agile3d_amd.optim import AdamW, clip_grad_norm_
+    from agile3d_amd.train_backbone import BackboneTape
+    torch.manual_seed(5)
+    model = build_model(default_args()).cuda().train()
+    scn = make_scene(4000, seed=20)
+    sc = Scene(torch.from_numpy(scn["coords"]).cuda())
+    feats = torch.from_numpy(scn["feats"]).cuda()
+    target = torch.randn(len(scn["coords"]), 128, generator=torch.Generator().manual_seed(6)).cuda() * 0.5
+    params = {k: p for k, p in model.named_parameters() if k.startswith(("backbone.", "lin_squeeze_head."))}
+    opt = AdamW(params.items(), lr=2e-3, weight_decay=1e-4)
+    losses = []
+    for step in range(8):
+        tape = BackboneTape(model, sc, feats)
+        diff = tape.output - target
+        losses.append(float((diff * diff).mean()))
+        grads = tape.backward(diff * (2.0 / diff.numel()))
+        norm, coef = clip_grad_norm_(grads, 0.1)
+        assert np.isfinite(norm) and 0.0 < coef <= 1.0
+        opt.step(grads, coef)
+    print("losses", [round(v, 4) for v in losses])
+    assert all(np.isfinite(losses)) and losses[-1] < 0.9 * losses[0], losses
