@@ -1,0 +1,209 @@
+// libagile3d_hip -- attention and mask-head primitives WITH their backward, for the training path of the decoder
+// (nn.MultiheadAttention as attention_block.py composes it, Agile3d.mask_module
+// agile3d.py:342-384).  The inference path uses fused flash-style kernels (decoder.hip) that keep nothing; training
+// needs the probabilities again, so here the score matrix [heads, Lq, Lk] is materialised (51 MB for 20 queries x 80 k
+// points) and every step is one simple, deterministic kernel:
+//   scores   S[h,i,j] = sum_d q[i,h,d] k[j,h,d] (mask -> -inf)        also used for dP = dO v^T and for src E^T
+//   softmax  rows of S in place;   backward dS = P (dP - sum_j P dP) in place of dP
+//   apply    O[i,h,:]  = sum_j P[h,i,j] V[j,h,:]                     (o = P v, dq = dS k, dsrc = dlogits E)
+//   apply_T  O2[j,h,:] = sum_i P[h,i,j] X[i,h,:]                     (dv = P^T dO, dk = dS^T q, dE = dlogits^T src)
+//   group max / its routing backward for the per-object max over an object's queries
+// Written for parity first (thread per output element, fp32 sums in a fixed order); the fused kernels stay the fast path.
+#include "common.h"
+
+namespace a3d {
+
+__global__ void k_tr_scores(const float* __restrict__ q, const float* __restrict__ k, int Lq, int Lk, int H, int dh,
+                            float scale, const unsigned char* __restrict__ mask, float* __restrict__ S) {
+  const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t total = (size_t)H * Lq * Lk;
+  if (e >= total) return;
+  const int j = (int)(e % Lk);
+  const int i = (int)((e / Lk) % Lq);
+  const int h = (int)(e / ((size_t)Lk * Lq));
+  const float* qr = q + (size_t)i * H * dh + h * dh;
+  const float* kr = k + (size_t)j * H * dh + h * dh;
+  float s = 0.f;
+  for (int d = 0; d < dh; ++d) s += qr[d] * kr[d];
+  s *= scale;
+  if (mask && mask[(size_t)i * Lk + j]) s = -INFINITY;
+  S[e] = s;
+}
+
+// one workgroup per row (long rows) or one thread per row (short rows); mode 0: softmax in place,
+// mode 1: a = P, b = dP -> b = P * (dP - sum P dP)
+__global__ void __launch_bounds__(256) k_tr_rows_block(float* __restrict__ a, float* __restrict__ b, int L, int mode) {
+  __shared__ float red[256];
+  float* row = a + (size_t)blockIdx.x * L;
+  float* rb = b ? b + (size_t)blockIdx.x * L : nullptr;
+  auto reduce = [&](float v, bool is_max) {
+    red[threadIdx.x] = v;
+    __syncthreads();
+    for (int s = 128; s >= 1; s >>= 1) {
+      if (threadIdx.x < s) red[threadIdx.x] = is_max ? fmaxf(red[threadIdx.x], red[threadIdx.x + s]) : red[threadIdx.x] + red[threadIdx.x + s];
+      __syncthreads();
+    }
+    const float r = red[0];
+    __syncthreads();
+    return r;
+  };
+  if (mode == 0) {
+    float m = -INFINITY;
+    for (int j = threadIdx.x; j < L; j += 256) m = fmaxf(m, row[j]);
+    m = reduce(m, true);
+    float s = 0.f;
+    for (int j = threadIdx.x; j < L; j += 256) {
+      const float p = expf(row[j] - m);
+      row[j] = p;
+      s += p;
+    }
+    s = reduce(s, false);
+    const float inv = 1.f / s;
+    for (int j = threadIdx.x; j < L; j += 256) row[j] *= inv;
+  } else {
+    float s = 0.f;
+    for (int j = threadIdx.x; j < L; j += 256) s += row[j] * rb[j];
+    s = reduce(s, false);
+    for (int j = threadIdx.x; j < L; j += 256) rb[j] = row[j] * (rb[j] - s);
+  }
+}
+__global__ void k_tr_rows_thread(float* __restrict__ a, float* __restrict__ b, size_t R, int L, int mode) {
+  const size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= R) return;
+  float* row = a + r * L;
+  if (mode == 0) {
+    float m = -INFINITY;
+    for (int j = 0; j < L; ++j) m = fmaxf(m, row[j]);
+    float s = 0.f;
+    for (int j = 0; j < L; ++j) {
+      const float p = expf(row[j] - m);
+      row[j] = p;
+      s += p;
+    }
+    const float inv = 1.f / s;
+    for (int j = 0; j < L; ++j) row[j] *= inv;
+  } else {
+    float* rb = b + r * L;
+    float s = 0.f;
+    for (int j = 0; j < L; ++j) s += row[j] * rb[j];
+    for (int j = 0; j < L; ++j) rb[j] = row[j] * (rb[j] - s);
+  }
+}
+
+__global__ void k_tr_apply(const float* __restrict__ P, const float* __restrict__ V, int Lq, int Lk, int H, int dh,
+                           float scale, float* __restrict__ O) {
+  const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int C = H * dh;
+  if (e >= (size_t)Lq * C) return;
+  const int c = (int)(e % C), i = (int)(e / C), h = c / dh;
+  const float* p = P + ((size_t)h * Lq + i) * Lk;
+  float s = 0.f;
+  for (int j = 0; j < Lk; ++j) s += p[j] * V[(size_t)j * C + c];
+  O[e] = s * scale;
+}
+__global__ void k_tr_apply_t(const float* __restrict__ P, const float* __restrict__ X, int Lq, int Lk, int H, int dh,
+                             float scale, float* __restrict__ O) {
+  const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int C = H * dh;
+  if (e >= (size_t)Lk * C) return;
+  const int c = (int)(e % C), j = (int)(e / C), h = c / dh;
+  const float* p = P + (size_t)h * Lq * Lk + j;
+  float s = 0.f;
+  for (int i = 0; i < Lq; ++i) s += p[(size_t)i * Lk] * X[(size_t)i * C + c];
+  O[e] = s * scale;
+}
+
+// group g covers queries [qbeg[g], qend[g]); out[n][g] = max, arg[n][g] = first arg max (torch.max picks the first)
+__global__ void k_tr_group_max(const float* __restrict__ lq, int N, int Q, const int* __restrict__ qbeg,
+                               const int* __restrict__ qend, int G, float* __restrict__ out, int* __restrict__ arg) {
+  const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= (size_t)N * G) return;
+  const int g = (int)(e % G), n = (int)(e / G);
+  float best = -INFINITY;
+  int bi = qbeg[g];
+  for (int q = qbeg[g]; q < qend[g]; ++q) {
+    const float v = lq[(size_t)n * Q + q];
+    if (v > best) best = v, bi = q;
+  }
+  out[e] = best;
+  arg[e] = bi;
+}
+__global__ void k_tr_group_max_bwd(const float* __restrict__ dout, const int* __restrict__ arg, int N, int Q, int G,
+                                   float* __restrict__ dlq) {
+  const size_t n = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= (size_t)N) return;
+  for (int q = 0; q < Q; ++q) dlq[n * Q + q] = 0.f;
+  for (int g = 0; g < G; ++g) dlq[n * Q + arg[n * G + g]] += dout[n * G + g];   // groups are disjoint
+}
+
+static unsigned blocks_of(size_t total, int t) { return (unsigned)((total + t - 1) / t); }
+
+}  // namespace a3d
+
+using namespace a3d;
+
+extern "C" int a3d_attn_scores(const float* q_dev, const float* k_dev, int64_t Lq, int64_t Lk, int H, int dh, float scale,
+                               const unsigned char* mask_dev, float* S_dev, void* stream) {
+  if (!q_dev || !k_dev || !S_dev || Lq <= 0 || Lk <= 0 || H < 1 || dh < 1 || (int64_t)H * Lq * Lk > (int64_t)1 << 33) {
+    set_error("a3d_attn_scores: bad arguments");
+    return A3D_ERR_INVALID;
+  }
+  k_tr_scores<<<blocks_of((size_t)H * Lq * Lk, 256), 256, 0, (hipStream_t)stream>>>(q_dev, k_dev, (int)Lq, (int)Lk, H, dh,
+                                                                                 scale, mask_dev, S_dev);
+  A3D_LAUNCH_CHECK();
+  return A3D_OK;
+}
+extern "C" int a3d_softmax_rows(float* S_dev, int64_t rows, int64_t L, void* stream) {
+  if (!S_dev || rows <= 0 || L <= 0 || L > (int64_t)1 << 30 || rows > (int64_t)1 << 31) {
+    set_error("a3d_softmax_rows: bad arguments");
+    return A3D_ERR_INVALID;
+  }
+  if (L >= 512) k_tr_rows_block<<<(unsigned)rows, 256, 0, (hipStream_t)stream>>>(S_dev, nullptr, (int)L, 0);
+  else k_tr_rows_thread<<<blocks_of((size_t)rows, 256), 256, 0, (hipStream_t)stream>>>(S_dev, nullptr, (size_t)rows, (int)L, 0);
+  A3D_LAUNCH_CHECK();
+  return A3D_OK;
+}
+extern "C" int a3d_softmax_rows_backward(const float* P_dev, float* dP_dev, int64_t rows, int64_t L, void* stream) {
+  if (!P_dev || !dP_dev || rows <= 0 || L <= 0 || L > (int64_t)1 << 30 || rows > (int64_t)1 << 31) {
+    set_error("a3d_softmax_rows_backward: bad arguments");
+    return A3D_ERR_INVALID;
+  }
+  if (L >= 512) k_tr_rows_block<<<(unsigned)rows, 256, 0, (hipStream_t)stream>>>((float*)P_dev, dP_dev, (int)L, 1);
+  else k_tr_rows_thread<<<blocks_of((size_t)rows, 256), 256, 0, (hipStream_t)stream>>>((float*)P_dev, dP_dev, (size_t)rows, (int)L, 1);
+  A3D_LAUNCH_CHECK();
+  return A3D_OK;
+}
+extern "C" int a3d_attn_apply(const float* P_dev, const float* V_dev, int64_t Lq, int64_t Lk, int H, int dh, int transposed,
+                              float scale, float* O_dev, void* stream) {
+  if (!P_dev || !V_dev || !O_dev || Lq <= 0 || Lk <= 0 || H < 1 || dh < 1) {
+    set_error("a3d_attn_apply: bad arguments");
+    return A3D_ERR_INVALID;
+  }
+  if (transposed)
+    k_tr_apply_t<<<blocks_of((size_t)Lk * H * dh, 256), 256, 0, (hipStream_t)stream>>>(P_dev, V_dev, (int)Lq, (int)Lk, H, dh, scale, O_dev);
+  else
+    k_tr_apply<<<blocks_of((size_t)Lq * H * dh, 256), 256, 0, (hipStream_t)stream>>>(P_dev, V_dev, (int)Lq, (int)Lk, H, dh, scale, O_dev);
+  A3D_LAUNCH_CHECK();
+  return A3D_OK;
+}
+extern "C" int a3d_group_max(const float* lq_dev, int64_t N, int Q, const int32_t* qbeg_dev, const int32_t* qend_dev, int G,
+                             float* out_dev, int32_t* arg_dev, void* stream) {
+  if (!lq_dev || !qbeg_dev || !qend_dev || !out_dev || !arg_dev || N <= 0 || Q <= 0 || G <= 0) {
+    set_error("a3d_group_max: bad arguments");
+    return A3D_ERR_INVALID;
+  }
+  k_tr_group_max<<<blocks_of((size_t)N * G, 256), 256, 0, (hipStream_t)stream>>>(lq_dev, (int)N, Q, qbeg_dev, qend_dev, G,
+                                                                               out_dev, arg_dev);
+  A3D_LAUNCH_CHECK();
+  return A3D_OK;
+}
+extern "C" int a3d_group_max_backward(const float* dout_dev, const int32_t* arg_dev, int64_t N, int Q, int G, float* dlq_dev,
+                                      void* stream) {
+  if (!dout_dev || !arg_dev || !dlq_dev || N <= 0 || Q <= 0 || G <= 0) {
+    set_error("a3d_group_max_backward: bad arguments");
+    return A3D_ERR_INVALID;
+  }
+  k_tr_group_max_bwd<<<blocks_of((size_t)N, 256), 256, 0, (hipStream_t)stream>>>(dout_dev, arg_dev, (int)N, Q, G, dlq_dev);
+  A3D_LAUNCH_CHECK();
+  return A3D_OK;
+}

@@ -212,6 +212,25 @@ size_t a3d_linear_wgrad_workspace_bytes(int64_t n, int cin, int cout);
 int    a3d_linear_wgrad(const float* x_dev, int ldx, const float* dy_dev, int ldy, int64_t n, int cin, int cout,
                         float* dw_dev, void* workspace_dev, size_t workspace_bytes, void* stream);
 
+/* Attention and mask-head primitives with their backward (training path of the decoder; the inference path uses the
+ * fused kernels behind a3d_decoder_forward).  nn.MultiheadAttention (attention_block.py) = scores -> softmax -> apply
+ * on [heads, Lq, Lk]; q / k / v are row-major [L][H*dh].  mask_dev: uint8 [Lq][Lk], non-zero = blocked (-inf).
+ *   a3d_attn_scores        S[h][i][j] = scale * sum_d q[i][h*dh+d] k[j][h*dh+d]
+ *   a3d_softmax_rows       in place over the last dimension of [rows][L]
+ *   a3d_softmax_rows_backward   dP <- P * (dP - sum_j P dP)
+ *   a3d_attn_apply         transposed = 0: O[i][c] = scale * sum_j P[h(c)][i][j] V[j][c];  1: O[j][c] = scale * sum_i P[h(c)][i][j] V[i][c]
+ *   a3d_group_max(_backward)    per-object max over an object's queries (agile3d.py:353-360) and its gradient routing */
+int a3d_attn_scores(const float* q_dev, const float* k_dev, int64_t Lq, int64_t Lk, int H, int dh, float scale,
+                    const unsigned char* mask_dev, float* S_dev, void* stream);
+int a3d_softmax_rows(float* S_dev, int64_t rows, int64_t L, void* stream);
+int a3d_softmax_rows_backward(const float* P_dev, float* dP_dev, int64_t rows, int64_t L, void* stream);
+int a3d_attn_apply(const float* P_dev, const float* V_dev, int64_t Lq, int64_t Lk, int H, int dh, int transposed,
+                   float scale, float* O_dev, void* stream);
+int a3d_group_max(const float* lq_dev, int64_t N, int Q, const int32_t* qbeg_dev, const int32_t* qend_dev, int G,
+                  float* out_dev, int32_t* arg_dev, void* stream);
+int a3d_group_max_backward(const float* dout_dev, const int32_t* arg_dev, int64_t N, int Q, int G, float* dlq_dev,
+                           void* stream);
+
 /* Optimiser step of the reference's training loop: torch.optim.AdamW(lr, weight_decay) (main.py:125-127) after
  * clip_grad_norm_(parameters, max_norm) (engine.py:145-150).  a3d_sum_squares returns sum g^2 of one tensor to the
  * host (the caller adds the tensors, clip coefficient = min(1, max_norm / (sqrt(total) + 1e-6))); a3d_adamw_step is

@@ -42,6 +42,11 @@ def time_table(d_model: int = 128, length: int = 200):
 
 
 # ----------------------------------------------------------------------------- layers
+# the activation of the FFN and of the mask MLP: a module attribute so that the gradient comparison of the training path
+# can substitute the 0/1 masks of the implementation under test (see oracle/backbone.py: RELU)
+RELU = torch.relu
+
+
 def layer_norm(x, sd, prefix):
     return F.layer_norm(x, (x.shape[-1],), sd[prefix + "weight"], sd[prefix + "bias"], LN_EPS)
 
@@ -82,7 +87,7 @@ def self_attention_layer(sd, prefix, tgt, query_pos):
 
 def ffn_layer(sd, prefix, tgt):
     """FFNLayer.forward_post, attention_block.py:151-155."""
-    h = torch.relu(tgt @ sd[prefix + "linear1.weight"].T + sd[prefix + "linear1.bias"])
+    h = RELU(tgt @ sd[prefix + "linear1.weight"].T + sd[prefix + "linear1.bias"])
     tgt2 = h @ sd[prefix + "linear2.weight"].T + sd[prefix + "linear2.bias"]
     return layer_norm(tgt + tgt2, sd, prefix + "norm.")
 
@@ -91,7 +96,7 @@ def mask_module(sd, fg_q, bg_q, mask_features, fg_split):
     """Agile3d.mask_module, agile3d.py:342-384.  Returns (logits [N,1+K], attn_mask [Q,N] bool)."""
     def embed(q):
         q = layer_norm(q, sd, "decoder_norm.")
-        h = torch.relu(q @ sd["mask_embed_head.0.weight"].T + sd["mask_embed_head.0.bias"])
+        h = RELU(q @ sd["mask_embed_head.0.weight"].T + sd["mask_embed_head.0.bias"])
         return h @ sd["mask_embed_head.2.weight"].T + sd["mask_embed_head.2.bias"]
 
     fg_prods = (mask_features @ embed(fg_q).T).split(fg_split, dim=1)
@@ -114,15 +119,17 @@ def mask_module(sd, fg_q, bg_q, mask_features, fg_split):
 
 # ----------------------------------------------------------------------------- forward_mask
 def forward_mask(sd, pcd_features, raw_xyz, pos_enc, click_idx, click_time_idx,
-                 num_decoders: int = 3, return_masks: bool = False):
+                 num_decoders: int = 3, return_masks: bool = False, grad: bool = False, force_masks=None):
     """Agile3d.forward_mask for ONE batch sample (agile3d.py:192-323).
 
     pcd_features [N,128], raw_xyz [N,3], pos_enc [N,128] (level-4 Fourier encoding),
     click_idx / click_time_idx: dict str -> list[int] ('0' = background).
     Returns list of ``num_decoders`` logits tensors [N,1+K] (last = 'pred_masks', earlier =
-    'aux_outputs').
+    'aux_outputs').  ``grad=True`` keeps the autograd graph (training-path tests); ``force_masks`` replaces the
+    label-derived attention masks of the layers by given ones (they are not differentiated; a test passes the masks of
+    the implementation under test so that both follow the same branch).
     """
-    with torch.no_grad():
+    with torch.set_grad_enabled(grad):
         mins, maxs = raw_xyz.min(0)[0], raw_xyz.max(0)[0]
         K = len(click_idx) - 1
         fg_split = [len(click_idx[str(i)]) for i in range(1, K + 1)]
@@ -152,6 +159,8 @@ def forward_mask(sd, pcd_features, raw_xyz, pos_enc, click_idx, click_time_idx,
             src = cross_attention_layer(sd, f"s2c_attention.{d}.0.", src, queries, None, qpos, pos_enc)
             fg_q, bg_q = queries.split([n_fg, n_bg], 0)
             logits, attn_mask = mask_module(sd, fg_q, bg_q, src, fg_split)
+            if force_masks is not None:
+                attn_mask = force_masks[d]
             outs.append(logits)
             masks.append(attn_mask)
     return (outs, masks) if return_masks else outs

@@ -304,3 +304,61 @@ def test_backbone_trains_with_clip_and_adamw():
         opt.step(grads, coef)
     print("losses", [round(v, 4) for v in losses])
     assert all(np.isfinite(losses)) and losses[-1] < 0.9 * losses[0], losses
+
+
+def test_decoder_training_step_matches_autograd():
+    """Forward and backward of the click decoder (three layers of click-to-scene / click-to-click / FFN / scene-to-click
+    + mask head, aux outputs included) on the HIP library against float64 autograd through oracle/decoder.py: the three
+    logits tensors, the gradient of every decoder parameter and dL/d(pcd_features).  Like in the backbone test the
+    oracle follows the branch of the forward pass under test (ReLU masks, label-derived attention masks)."""
+    from agile3d_amd import build_model, default_args
+    from agile3d_amd.train_decoder import DecoderTape
+    from oracle import decoder as od
+    torch.manual_seed(11)
+    model = build_model(default_args()).cuda().train()
+    g = torch.Generator().manual_seed(12)
+    N = 1500
+    pcd = torch.randn(N, 128, generator=g) * 0.7
+    xyz = torch.rand(N, 3, generator=g) * 4.0
+    sd = {k: v.detach().cpu().double().clone() for k, v in model.state_dict().items() if v.is_floating_point()}
+    pos = od.fourier_pos_enc(xyz.double(), sd["pos_enc.gauss_B"], xyz.double().min(0)[0], xyz.double().max(0)[0])
+    ci = {"0": [7], "1": [10, 400], "2": [33], "3": [900, 1200, 77]}
+    ct = {"0": [6], "1": [0, 3], "2": [1], "3": [2, 4, 5]}
+    R = [torch.randn(N, 4, generator=g) / 8 for _ in range(3)]
+    tape = DecoderTape(model, pcd.cuda(), pos.float().cuda(), ci, ct)
+    # ---- oracle with the tape's branch decisions
+    n_fg = 6
+    relu_seq = []
+    for l in range(3):
+        ffn, mlp = tape.relu_masks[2 * l].cpu().double(), tape.relu_masks[2 * l + 1].cpu().double()
+        relu_seq += [ffn, mlp[:n_fg], mlp[n_fg:]]
+    it = iter(relu_seq)
+    for k in sd:
+        if not k.startswith(("backbone.", "pos_enc.")):
+            sd[k].requires_grad_()
+    pcd_o = pcd.double().requires_grad_()
+    od.RELU = lambda z: z * next(it)
+    try:
+        outs = od.forward_mask(sd, pcd_o, xyz.double(), pos, ci, ct, grad=True,
+                               force_masks=[m.cpu().bool() for m in tape.attn_masks])
+    finally:
+        od.RELU = torch.relu
+    for l in range(3):
+        err = (tape.logits[l].cpu().double() - outs[l].detach()).abs().max().item()
+        assert err <= 2e-4 * max(1.0, outs[l].abs().max().item()), (l, err)
+    sum((o * r.double()).sum() for o, r in zip(outs, R)).backward()
+    grads, d_pcd = tape.backward([r.cuda() for r in R])
+    names = [k for k in sd if sd[k].requires_grad and sd[k].grad is not None]
+    assert set(grads) == set(names), set(names) ^ set(grads)
+    worst = ("", 0.0)
+    for k in names:
+        ref, got = sd[k].grad, grads[k].cpu().double()
+        assert got.shape == ref.shape, k
+        rel = (got - ref).abs().max().item() / max(1e-3, ref.abs().max().item())
+        worst = max(worst, (k, rel), key=lambda t: t[1])
+        if os.environ.get("A3D_SHOW_GRADS"):
+            print(f"   {k:56s} rel {rel:.2e}  scale {ref.abs().max().item():.3e}")
+    rel_pcd = (d_pcd.cpu().double() - pcd_o.grad).abs().max().item() / pcd_o.grad.abs().max().item()
+    print(f"decoder training step: {len(names)} parameter gradients, worst relative error {worst[1]:.2e} ({worst[0]}), "
+          f"d_pcd {rel_pcd:.2e}")
+    assert worst[1] <= 2e-3 and rel_pcd <= 2e-3, (worst, rel_pcd)
