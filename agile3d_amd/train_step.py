@@ -1,0 +1,115 @@
+"""One iteration of the reference's training loop on the HIP library (``engine.py:38-150``, SURVEY.md section 8 row
+f-2): backbone forward in training mode, random object selection and click simulation with no-grad decoder passes,
+decoder forward in training mode, the mask losses with click weights, backward through decoder and backbone,
+gradient-norm clip, AdamW.
+
+    stats = train_one_step(model, criterion, optimizer, batch, device, max_norm=0.1)
+
+``batch`` is what ``datasets.collation_fn`` produces.  Random numbers are drawn from ``np.random``, ``torch`` and
+``random`` in the reference's order (object count, object permutation, number of click rounds, click order).  With
+``torch.distributed`` initialised the gradients are averaged over the ranks before the clip (what DDP does).
+"""
+from __future__ import annotations
+
+import copy
+import random
+
+import numpy as np
+import torch
+
+from .clicks import cal_click_loss_weights, extend_clicks, get_simulated_clicks
+from .engine import Scene
+from .optim import allreduce_mean_, clip_grad_norm_
+from .train_backbone import BackboneTape
+from .train_decoder import DecoderTape
+
+
+def train_one_step(model, criterion, optimizer, batch, device, max_norm: float = 0.1):
+    coords, raw_coords, feats, labels, _, _, click_idx, _scene_name, _num_obj = batch
+    coords = coords.to(device)
+    raw_coords = raw_coords.to(device)
+    feats = feats.to(device)
+    labels = [l.to(device) for l in labels]
+    batch_idx = coords[:, 0]
+    n_samples = int(batch_idx.max()) + 1
+    click_idx = [dict(c) for c in click_idx]
+
+    # ---- backbone, training mode (BatchNorm on the statistics of this batch), engine.py:53
+    model.train()
+    scene = Scene(coords.to(torch.int32).contiguous())
+    bb = BackboneTape(model, scene, feats)
+    pcd = bb.output
+    ranges = scene.batch_ranges
+
+    # ---- objects of this iteration, engine.py:55-77
+    labels_new = []
+    for idx in range(n_samples):
+        sample_labels = labels[idx]
+        valid = torch.unique(sample_labels)
+        valid = valid[valid != -1]
+        max_num_obj = len(valid)
+        num_obj = np.random.randint(1, min(10, max_num_obj) + 1)
+        obj_idxs = valid[torch.randperm(max_num_obj)[:num_obj].to(valid.device)]
+        new = torch.zeros(sample_labels.shape[0], device=device)
+        for i, obj_id in enumerate(obj_idxs):
+            new[sample_labels == obj_id] = i + 1
+            click_idx[idx][str(i + 1)] = []
+        click_idx[idx]["0"] = []
+        labels_new.append(new)
+    click_time_idx = copy.deepcopy(click_idx)
+
+    # ---- click simulation with the current weights, no gradient (engine.py:82-116)
+    num_forward_iters = random.randint(0, 19)
+    model.eval()
+    eng = model._get_engine()
+    eng.mark_stale()                         # the optimiser writes the parameters in place, behind torch's back
+    eng.refresh_weights_if_stale()
+    dec_in = [eng.decoder_inputs(pcd[s:e], raw_coords[s:e]) for s, e in ranges]
+    pos_enc = [d[3][4][0][0] for d in dec_in]
+    for it in range(num_forward_iters + 1):
+        for idx, (s, e) in enumerate(ranges):
+            if it == 0:
+                pred = torch.zeros(e - s, device=device)
+            else:
+                out = eng.forward_mask(*dec_in[idx], click_idx=[click_idx[idx]], click_time_idx=[click_time_idx[idx]])
+                pred = out["pred_masks"][0].argmax(-1)
+                for obj_id, cids in click_idx[idx].items():
+                    pred[cids] = int(obj_id)
+            new_clicks, _, _, new_time = get_simulated_clicks(pred, labels_new[idx], raw_coords[s:e], it, training=True)
+            if new_clicks is not None:
+                click_idx[idx], click_time_idx[idx] = extend_clicks(click_idx[idx], click_time_idx[idx], new_clicks,
+                                                                    new_time)
+    model.train()
+
+    # ---- decoder, training mode, one tape per sample (agile3d.py:192 loops over the samples)
+    tapes = [DecoderTape(model, pcd[s:e], pos_enc[i], click_idx[i], click_time_idx[i]) for i, (s, e) in enumerate(ranges)]
+    n_layers = len(tapes[0].logits)
+    outputs = {"pred_masks": [t.logits[-1] for t in tapes],
+               "aux_outputs": [{"pred_masks": [t.logits[l] for t in tapes]} for l in range(n_layers - 1)]}
+
+    # ---- losses (engine.py:124-128) and their gradient with respect to every level's logits
+    click_weights = cal_click_loss_weights(batch_idx, raw_coords, torch.cat(labels_new), click_idx)
+    loss_dict = criterion(outputs, labels_new, click_weights)
+    total = sum(float(loss_dict[k]) * criterion.weight_dict[k] for k in loss_dict if k in criterion.weight_dict)
+    if not np.isfinite(total):
+        raise FloatingPointError(f"Loss is {total}, stopping training")
+    gl = criterion.grad_logits(outputs, labels_new, click_weights)
+
+    # ---- backward: decoders, then the backbone through d(pcd_features)
+    grads = {}
+    d_pcd = torch.empty_like(pcd)
+    for i, ((s, e), t) in enumerate(zip(ranges, tapes)):
+        dl = [gl["aux_outputs"][l][i] for l in range(n_layers - 1)] + [gl["pred_masks"][i]]
+        g, dp = t.backward(dl)
+        d_pcd[s:e] = dp
+        for k, v in g.items():
+            grads[k] = v if k not in grads else grads[k] + v
+    grads.update(bb.backward(d_pcd))
+
+    # ---- data-parallel average, clip, AdamW (engine.py:143-150)
+    allreduce_mean_(grads)
+    norm, coef = clip_grad_norm_(grads, max_norm)
+    optimizer.step(grads, coef)
+    eng.mark_stale()
+    return {"loss": total, "grad_norm": norm, "loss_dict": {k: float(v) for k, v in loss_dict.items()},
+            "clicks": [sum(len(v) for v in c.values()) for c in click_idx]}
