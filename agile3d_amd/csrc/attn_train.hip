@@ -13,6 +13,8 @@
 
 namespace a3d {
 
+static unsigned blocks_of(size_t total, int t) { return (unsigned)((total + t - 1) / t); }
+
 __global__ void k_tr_scores(const float* __restrict__ q, const float* __restrict__ k, int Lq, int Lk, int H, int dh,
                             float scale, const unsigned char* __restrict__ mask, float* __restrict__ S) {
   const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -113,6 +115,39 @@ __global__ void k_tr_apply_t(const float* __restrict__ P, const float* __restric
   O[e] = s * scale;
 }
 
+// long reductions (20 queries x 80 k points: 2 560 outputs, each a sum over 80 k terms): the reduced dimension is cut
+// into `splits` ranges, one grid.y slice each, partial sums to part[split][out] and a second kernel adds them in order
+__global__ void k_tr_apply_split(const float* __restrict__ P, const float* __restrict__ V, int Lq, int Lk, int H, int dh,
+                                 int transposed, int chunk, float* __restrict__ part) {
+  const int C = H * dh;
+  const int rows = transposed ? Lk : Lq, Lred = transposed ? Lq : Lk;
+  const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= (size_t)rows * C) return;
+  const int c = (int)(e % C), r = (int)(e / C), h = c / dh;
+  const int b = blockIdx.y * chunk, end = min(Lred, b + chunk);
+  float s = 0.f;
+  if (!transposed) {
+    const float* p = P + ((size_t)h * Lq + r) * Lk;
+    for (int j = b; j < end; ++j) s += p[j] * V[(size_t)j * C + c];
+  } else {
+    const float* p = P + (size_t)h * Lq * Lk + r;
+    for (int i = b; i < end; ++i) s += p[(size_t)i * Lk] * V[(size_t)i * C + c];
+  }
+  part[(size_t)blockIdx.y * rows * C + e] = s;
+}
+__global__ void k_tr_apply_reduce(const float* __restrict__ part, int splits, size_t total, float scale, float* __restrict__ O) {
+  const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= total) return;
+  float s = 0.f;
+  for (int k = 0; k < splits; ++k) s += part[(size_t)k * total + e];
+  O[e] = s * scale;
+}
+static int apply_splits(int64_t rows, int64_t Lred, int C) {
+  if (Lred < 4096 || rows * C > (1 << 20)) return 1;
+  int64_t s = (Lred + 511) / 512;
+  return (int)(s > 256 ? 256 : s);
+}
+
 // group g covers queries [qbeg[g], qend[g]); out[n][g] = max, arg[n][g] = first arg max (torch.max picks the first)
 __global__ void k_tr_group_max(const float* __restrict__ lq, int N, int Q, const int* __restrict__ qbeg,
                                const int* __restrict__ qend, int G, float* __restrict__ out, int* __restrict__ arg) {
@@ -135,8 +170,6 @@ __global__ void k_tr_group_max_bwd(const float* __restrict__ dout, const int* __
   for (int q = 0; q < Q; ++q) dlq[n * Q + q] = 0.f;
   for (int g = 0; g < G; ++g) dlq[n * Q + arg[n * G + g]] += dout[n * G + g];   // groups are disjoint
 }
-
-static unsigned blocks_of(size_t total, int t) { return (unsigned)((total + t - 1) / t); }
 
 }  // namespace a3d
 
@@ -173,16 +206,35 @@ extern "C" int a3d_softmax_rows_backward(const float* P_dev, float* dP_dev, int6
   A3D_LAUNCH_CHECK();
   return A3D_OK;
 }
+extern "C" size_t a3d_attn_apply_workspace_bytes(int64_t Lq, int64_t Lk, int H, int dh, int transposed) {
+  const int64_t rows = transposed ? Lk : Lq, Lred = transposed ? Lq : Lk;
+  const int sp = apply_splits(rows, Lred, H * dh);
+  return sp > 1 ? (size_t)sp * rows * H * dh * sizeof(float) + 256 : 256;
+}
 extern "C" int a3d_attn_apply(const float* P_dev, const float* V_dev, int64_t Lq, int64_t Lk, int H, int dh, int transposed,
-                              float scale, float* O_dev, void* stream) {
+                              float scale, float* O_dev, void* workspace_dev, size_t workspace_bytes, void* stream) {
   if (!P_dev || !V_dev || !O_dev || Lq <= 0 || Lk <= 0 || H < 1 || dh < 1) {
     set_error("a3d_attn_apply: bad arguments");
     return A3D_ERR_INVALID;
   }
-  if (transposed)
-    k_tr_apply_t<<<blocks_of((size_t)Lk * H * dh, 256), 256, 0, (hipStream_t)stream>>>(P_dev, V_dev, (int)Lq, (int)Lk, H, dh, scale, O_dev);
-  else
-    k_tr_apply<<<blocks_of((size_t)Lq * H * dh, 256), 256, 0, (hipStream_t)stream>>>(P_dev, V_dev, (int)Lq, (int)Lk, H, dh, scale, O_dev);
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t rows = transposed ? Lk : Lq, Lred = transposed ? Lq : Lk;
+  const int sp = apply_splits(rows, Lred, H * dh);
+  if (sp > 1) {
+    if (!workspace_dev || workspace_bytes < a3d_attn_apply_workspace_bytes(Lq, Lk, H, dh, transposed)) {
+      set_error("a3d_attn_apply: workspace too small (a3d_attn_apply_workspace_bytes)");
+      return A3D_ERR_WORKSPACE;
+    }
+    const size_t total = (size_t)rows * H * dh;
+    const int chunk = (int)((Lred + sp - 1) / sp);
+    k_tr_apply_split<<<dim3(blocks_of(total, 256), sp), 256, 0, st>>>(P_dev, V_dev, (int)Lq, (int)Lk, H, dh, transposed, chunk,
+                                                                      (float*)workspace_dev);
+    k_tr_apply_reduce<<<blocks_of(total, 256), 256, 0, st>>>((const float*)workspace_dev, sp, total, scale, O_dev);
+  } else if (transposed) {
+    k_tr_apply_t<<<blocks_of((size_t)Lk * H * dh, 256), 256, 0, st>>>(P_dev, V_dev, (int)Lq, (int)Lk, H, dh, scale, O_dev);
+  } else {
+    k_tr_apply<<<blocks_of((size_t)Lq * H * dh, 256), 256, 0, st>>>(P_dev, V_dev, (int)Lq, (int)Lk, H, dh, scale, O_dev);
+  }
   A3D_LAUNCH_CHECK();
   return A3D_OK;
 }

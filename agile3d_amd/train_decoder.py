@@ -58,6 +58,14 @@ def _linear(x, w_in_out, bias=None):
     return y
 
 
+def _apply(P, V, Lq, Lk, Hh, dh, transposed, scale, out):
+    lib = L.load()
+    nbytes = lib.a3d_attn_apply_workspace_bytes(Lq, Lk, Hh, dh, transposed)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=out.device)
+    L.check(lib.a3d_attn_apply(_ptr(P), _ptr(V), Lq, Lk, Hh, dh, transposed, scale, _ptr(out), _ptr(ws), nbytes, _stream()),
+            "a3d_attn_apply")
+
+
 def _col_sums(dy):
     """bias gradient: column sums for any channel count (the kernel takes 128-column slices)."""
     n, c = dy.shape
@@ -158,7 +166,7 @@ class DecoderTape:
         L.check(lib.a3d_attn_scores(_ptr(q.v), _ptr(k.v), Lq, Lk, H, DH, scale, _ptr(mask), _ptr(Pm), _stream()), "scores")
         L.check(lib.a3d_softmax_rows(_ptr(Pm), H * Lq, Lk, _stream()), "softmax")
         o = torch.empty((Lq, H * DH), dtype=torch.float32, device=dev)
-        L.check(lib.a3d_attn_apply(_ptr(Pm), _ptr(v.v), Lq, Lk, H, DH, 0, 1.0, _ptr(o), _stream()), "apply")
+        _apply(Pm, v.v, Lq, Lk, H, DH, 0, 1.0, o)
         y = _T(o)
 
         def back():
@@ -168,12 +176,12 @@ class DecoderTape:
             dP = torch.empty_like(Pm)
             L.check(lib.a3d_attn_scores(_ptr(do), _ptr(v.v), Lq, Lk, H, DH, 1.0, None, _ptr(dP), _stream()), "scores")
             dv = torch.empty_like(v.v)
-            L.check(lib.a3d_attn_apply(_ptr(Pm), _ptr(do), Lq, Lk, H, DH, 1, 1.0, _ptr(dv), _stream()), "apply_t")
+            _apply(Pm, do, Lq, Lk, H, DH, 1, 1.0, dv)
             L.check(lib.a3d_softmax_rows_backward(_ptr(Pm), _ptr(dP), H * Lq, Lk, _stream()), "softmax_bwd")   # dP <- dS
             dq = torch.empty_like(q.v)
-            L.check(lib.a3d_attn_apply(_ptr(dP), _ptr(k.v), Lq, Lk, H, DH, 0, scale, _ptr(dq), _stream()), "apply")
+            _apply(dP, k.v, Lq, Lk, H, DH, 0, scale, dq)
             dk = torch.empty_like(k.v)
-            L.check(lib.a3d_attn_apply(_ptr(dP), _ptr(q.v), Lq, Lk, H, DH, 1, scale, _ptr(dk), _stream()), "apply_t")
+            _apply(dP, q.v, Lq, Lk, H, DH, 1, scale, dk)
             q.add_grad(dq)
             k.add_grad(dk)
             v.add_grad(dv)
@@ -210,9 +218,9 @@ class DecoderTape:
             dlq = torch.empty_like(lq)
             L.check(lib.a3d_group_max_backward(_ptr(y.g.contiguous()), _ptr(arg), N, Q, G, _ptr(dlq), _stream()), "gm_bwd")
             dsrc = torch.empty_like(src.v)
-            L.check(lib.a3d_attn_apply(_ptr(dlq), _ptr(E.v), N, Q, 1, 128, 0, 1.0, _ptr(dsrc), _stream()), "apply")
+            _apply(dlq, E.v, N, Q, 1, 128, 0, 1.0, dsrc)
             dE = torch.empty_like(E.v)
-            L.check(lib.a3d_attn_apply(_ptr(dlq), _ptr(src.v), N, Q, 1, 128, 1, 1.0, _ptr(dE), _stream()), "apply_t")
+            _apply(dlq, src.v, N, Q, 1, 128, 1, 1.0, dE)
             src.add_grad(dsrc)
             E.add_grad(dE)
         self.steps.append(back)

@@ -224,8 +224,9 @@ int a3d_attn_scores(const float* q_dev, const float* k_dev, int64_t Lq, int64_t 
                     const unsigned char* mask_dev, float* S_dev, void* stream);
 int a3d_softmax_rows(float* S_dev, int64_t rows, int64_t L, void* stream);
 int a3d_softmax_rows_backward(const float* P_dev, float* dP_dev, int64_t rows, int64_t L, void* stream);
+size_t a3d_attn_apply_workspace_bytes(int64_t Lq, int64_t Lk, int H, int dh, int transposed);
 int a3d_attn_apply(const float* P_dev, const float* V_dev, int64_t Lq, int64_t Lk, int H, int dh, int transposed,
-                   float scale, float* O_dev, void* stream);
+                   float scale, float* O_dev, void* workspace_dev, size_t workspace_bytes, void* stream);
 int a3d_group_max(const float* lq_dev, int64_t N, int Q, const int32_t* qbeg_dev, const int32_t* qend_dev, int G,
                   float* out_dev, int32_t* arg_dev, void* stream);
 int a3d_group_max_backward(const float* dout_dev, const int32_t* arg_dev, int64_t N, int Q, int G, float* dlq_dev,

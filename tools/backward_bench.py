@@ -41,6 +41,7 @@ def main():
     ap.add_argument("--batch", type=int, default=1)
     ap.add_argument("--reps", type=int, default=10)
     ap.add_argument("--tape", action="store_true", help="also time a training-mode forward + backward of the backbone")
+    ap.add_argument("--step", action="store_true", help="also time complete training iterations")
     a = ap.parse_args()
     coords = np.concatenate([make_scene(a.voxels, seed=b, batch_index=b)["coords"] for b in range(a.batch)])
     sc = Scene(torch.from_numpy(coords).cuda())
@@ -89,7 +90,37 @@ def tape_time(voxels, batch):
           f"({len(grads)} gradients)")
 
 
+def step_time(voxels, batch):
+    """Complete training iterations (engine.py:38-150) on a synthetic labelled batch."""
+    import random
+    import time
+    from agile3d_amd import batched_coordinates, build_model, default_args
+    from agile3d_amd.criterion import build_mask_criterion
+    from agile3d_amd.optim import AdamW
+    from agile3d_amd.train_step import train_one_step
+    torch.manual_seed(0)
+    args = default_args(bce_loss_coef=1.0, dice_loss_coef=2.0, losses=["bce", "dice"])
+    model = build_model(args).cuda()
+    crit = build_mask_criterion(args)
+    scenes = [make_scene(voxels, seed=b) for b in range(batch)]
+    b = (batched_coordinates([s["coords"][:, 1:] for s in scenes]),
+         torch.from_numpy(np.concatenate([s["raw_xyz"] for s in scenes])),
+         torch.from_numpy(np.concatenate([s["feats"] for s in scenes])),
+         [torch.from_numpy(s["labels"].astype(np.int64)) for s in scenes], None, None, [{} for _ in scenes],
+         tuple(f"scene{i:04d}_00" for i in range(batch)), tuple(0 for _ in scenes))
+    opt = AdamW(model.named_parameters(), lr=1e-4, weight_decay=1e-4)
+    np.random.seed(1), random.seed(1)
+    for it in range(4):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        st = train_one_step(model, crit, opt, b, torch.device("cuda"), 0.1)
+        torch.cuda.synchronize()
+        print(f"training iteration {it}: {1e3 * (time.perf_counter() - t0):.0f} ms, loss {st['loss']:.3f}, clicks {st['clicks']}")
+
+
 if __name__ == "__main__":
     main()
     if "--tape" in sys.argv:
         tape_time(80_000, 4)
+    if "--step" in sys.argv:
+        step_time(80_000, 4)
