@@ -113,3 +113,40 @@ def train_one_step(model, criterion, optimizer, batch, device, max_norm: float =
     eng.mark_stale()
     return {"loss": total, "grad_norm": norm, "loss_dict": {k: float(v) for k, v in loss_dict.items()},
             "clicks": [sum(len(v) for v in c.values()) for c in click_idx]}
+
+
+def train_one_epoch(model, criterion, data_loader, optimizer, device, epoch: int, train_total_iter: int = 0,
+                    max_norm: float = 0.0, print_freq: int = 10, log=print):
+    """engine.py:26-179 around ``train_one_step``: one pass over ``data_loader``; returns (averaged statistics,
+    train_total_iter) like the reference (its wandb / MetricLogger bookkeeping reduced to running means)."""
+    sums, n = {}, 0
+    for i, batch in enumerate(data_loader):
+        st = train_one_step(model, criterion, optimizer, batch, device, max_norm)
+        train_total_iter += 1
+        n += 1
+        for k, v in {"loss": st["loss"], "grad_norm": st["grad_norm"], **st["loss_dict"]}.items():
+            sums[k] = sums.get(k, 0.0) + float(v)
+        if log is not None and i % print_freq == 0:
+            log(f"Epoch: [{epoch}] [{i}/{len(data_loader)}] loss {st['loss']:.4f} grad_norm {st['grad_norm']:.3f} "
+                f"lr {optimizer.lr:.6f}")
+    return {k: v / max(n, 1) for k, v in sums.items()}, train_total_iter
+
+
+class MultiStepLR:
+    """torch.optim.lr_scheduler.MultiStepLR(optimizer, milestones) as main.py:127 uses it (gamma 0.1), for
+    ``agile3d_amd.optim.AdamW``: call ``step()`` once per epoch."""
+
+    def __init__(self, optimizer, milestones, gamma=0.1):
+        self.optimizer, self.milestones, self.gamma = optimizer, sorted(milestones), gamma
+        self.base_lr, self.last_epoch = optimizer.lr, 0
+
+    def step(self):
+        self.last_epoch += 1
+        self.optimizer.lr = self.base_lr * self.gamma ** sum(1 for m in self.milestones if m <= self.last_epoch)
+
+    def state_dict(self):
+        return {"last_epoch": self.last_epoch, "base_lr": self.base_lr, "milestones": self.milestones, "gamma": self.gamma}
+
+    def load_state_dict(self, sd):
+        self.last_epoch, self.base_lr, self.milestones, self.gamma = sd["last_epoch"], sd["base_lr"], sd["milestones"], sd["gamma"]
+        self.optimizer.lr = self.base_lr * self.gamma ** sum(1 for m in self.milestones if m <= self.last_epoch)

@@ -187,3 +187,33 @@ def test_ply_to_evaluate_end_to_end(tmp_path):
     assert seen[0][1] == 0.0 and all(0.0 <= iou <= 1.0 for _, iou, _ in seen) and seen[1][2] == 3
     assert set(k for k in res if k.startswith("IoU")) == {"IoU@1", "IoU@3", "IoU@5", "IoU@10", "IoU@15"}
     assert all(1.0 <= res[k] <= 20.0 for k in res if k.startswith("NoC"))
+
+
+@pytest.mark.gpu
+def test_ply_to_training_epoch(tmp_path):
+    """File on disk -> training dataset (augmentation on) -> DataLoader(collate) -> train_one_epoch: two iterations of
+    the reference's loop (engine.py:26-179) on the fixture scan, then the LR schedule steps."""
+    import random
+    import types
+
+    from agile3d_amd import build_model, default_args
+    from agile3d_amd.criterion import build_mask_criterion
+    from agile3d_amd.optim import AdamW
+    from agile3d_amd.train_step import MultiStepLR, train_one_epoch
+    tl = tmp_path / "train.json"                # training lists carry no pre-recorded clicks (the augmentation re-voxelises)
+    tl.write_text(json.dumps({"scene0001_00_obj_3": {}, "scene0001_00_obj_2": {}}))
+    ds, fn = D.build_dataset("train", types.SimpleNamespace(dataset_mode="multi_obj", scan_folder=os.path.join(DATA, "scans"),
+                                                           train_list=str(tl), val_list="", voxel_size=0.05, crop=False))
+    assert ds.transforms is True
+    loader = torch.utils.data.DataLoader(ds, batch_size=1, collate_fn=fn, shuffle=False)
+    np.random.seed(2), torch.manual_seed(2), random.seed(2)
+    args = default_args(bce_loss_coef=1.0, dice_loss_coef=2.0, losses=["bce", "dice"])
+    model = build_model(args).cuda()
+    opt = AdamW(model.named_parameters(), lr=1e-4, weight_decay=1e-4)
+    sched = MultiStepLR(opt, [1])
+    lines = []
+    stats, it = train_one_epoch(model, build_mask_criterion(args), loader, opt, torch.device("cuda"), 0, 0, 0.1, 1, lines.append)
+    assert it == 2 and len(lines) == 2 and np.isfinite(stats["loss"]) and stats["grad_norm"] > 0
+    assert {"loss_bce", "loss_dice", "loss_bce_1", "loss_dice_1"} <= set(stats)
+    sched.step()
+    assert abs(opt.lr - 1e-5) < 1e-12
