@@ -27,9 +27,9 @@ __global__ void __launch_bounds__(256) k_sumsq_partial(const float* __restrict__
   }
   if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
 }
-__global__ void k_sumsq_final(const double* partial, int nb, double* out) {
+__global__ void k_sumsq_final(const double* partial, int nb, double* out, int accumulate) {
   if (blockIdx.x == 0 && threadIdx.x == 0) {
-    double s = 0.0;
+    double s = accumulate ? *out : 0.0;
     for (int b = 0; b < nb; ++b) s += partial[b];
     *out = s;
   }
@@ -69,10 +69,29 @@ extern "C" int a3d_sum_squares(const float* g_dev, int64_t n, double* out_host, 
   int nb = (int)((n + 256 * 8 - 1) / (256 * 8));
   nb = nb < 1 ? 1 : nb > kSqBlocks ? kSqBlocks : nb;
   k_sumsq_partial<<<nb, 256, 0, st>>>(g_dev, (size_t)n, partial);
-  k_sumsq_final<<<1, 64, 0, st>>>(partial, nb, partial + kSqBlocks);
+  k_sumsq_final<<<1, 64, 0, st>>>(partial, nb, partial + kSqBlocks, 0);
   A3D_LAUNCH_CHECK();
   A3D_HIP_CHECK(hipMemcpyAsync(out_host, partial + kSqBlocks, sizeof(double), hipMemcpyDeviceToHost, st));
   A3D_HIP_CHECK(hipStreamSynchronize(st));
+  return A3D_OK;
+}
+
+// the same sum added to *acc_dev (a device double the caller zeroes first): no host synchronisation, so the norm over
+// hundreds of parameter tensors costs one read-back instead of one per tensor
+extern "C" int a3d_sum_squares_accumulate(const float* g_dev, int64_t n, double* acc_dev, void* workspace_dev,
+                                          size_t workspace_bytes, void* stream) {
+  if (!g_dev || n <= 0 || !acc_dev || !workspace_dev || workspace_bytes < a3d_sum_squares_workspace_bytes() ||
+      ((uintptr_t)workspace_dev & 7)) {
+    set_error("a3d_sum_squares_accumulate: bad arguments");
+    return A3D_ERR_INVALID;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  double* partial = (double*)workspace_dev;
+  int nb = (int)((n + 256 * 8 - 1) / (256 * 8));
+  nb = nb < 1 ? 1 : nb > kSqBlocks ? kSqBlocks : nb;
+  k_sumsq_partial<<<nb, 256, 0, st>>>(g_dev, (size_t)n, partial);
+  k_sumsq_final<<<1, 64, 0, st>>>(partial, nb, acc_dev, 1);
+  A3D_LAUNCH_CHECK();
   return A3D_OK;
 }
 

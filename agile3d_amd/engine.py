@@ -421,6 +421,35 @@ class Engine:
         coordinates = SparseTensor(features=raw, coordinates=C4)
         return pcd, None, coordinates, [[[None]] for _ in range(4)] + [[[pe]]]
 
+    def decoder_inputs_batch(self, feats128: torch.Tensor, raw_xyz: torch.Tensor, ranges):
+        """Decoder inputs of a whole batch from an explicit feature matrix (rows of sample i = ``ranges[i]``): what
+        forward_backbone returns for it -- the training iteration runs its no-grad click rounds on the training-mode
+        backbone's features this way (engine.py:82-116 of the reference)."""
+        lib = L.load()
+        self.refresh_weights_if_stale(check_versions=True)
+        feats = feats128.to(self.device, torch.float32).contiguous()
+        raw = raw_xyz.to(self.device, torch.float32).contiguous()
+        n = feats.shape[0]
+        C4 = torch.zeros((n, 4), dtype=torch.int32, device=self.device)
+        st = _SceneState()
+        st.engine_id = id(self)
+        st.ranges = [(int(s), int(e)) for s, e in ranges]
+        st.posenc, st.minmax = [], []
+        with torch.no_grad():
+            tmp = torch.empty(256 * 6 * 4, dtype=torch.uint8, device=self.device)
+            for b, (s, e) in enumerate(st.ranges):
+                C4[s:e, 0] = b
+                pe = torch.empty((e - s, 128), dtype=torch.float32, device=self.device)
+                mm = torch.empty(6, dtype=torch.float32, device=self.device)
+                L.check(lib.a3d_posenc_fourier(_ptr(raw[s:e]), e - s, self.decoder.gauss_B_ptr, _ptr(mm), _ptr(pe), _ptr(tmp),
+                                               tmp.numel(), _stream()), "a3d_posenc_fourier")
+                st.posenc.append(pe)
+                st.minmax.append(mm)
+        pcd = SparseTensor(features=feats, coordinates=C4)
+        pcd._a3d = st
+        coordinates = SparseTensor(features=raw, coordinates=C4)
+        return pcd, None, coordinates, [[[None] * len(st.ranges)] for _ in range(4)] + [[list(st.posenc)]]
+
     # ---------------------------------------------------------------- forward_mask
     def forward_mask(self, pcd_features, aux, coordinates, pos_encodings_pcd, click_idx=None, click_time_idx=None):
         lib = L.load()

@@ -28,16 +28,17 @@ def _stream(t):
 def total_grad_norm(grads: dict) -> float:
     """sqrt(sum over all tensors of sum g^2): the 2-norm clip_grad_norm_ computes (fp64 accumulation on the device)."""
     lib = L.load()
-    total, ws = 0.0, None
+    ws = acc = None
     for g in grads.values():
         if not g.is_cuda or g.dtype != torch.float32:
             raise RuntimeError("agile3d_amd.optim runs on the GPU only (fp32 CUDA tensors)")
         g = g.contiguous()
         if ws is None:
             ws = torch.empty(lib.a3d_sum_squares_workspace_bytes(), dtype=torch.uint8, device=g.device)
-        out = C.c_double()
-        L.check(lib.a3d_sum_squares(_ptr(g), g.numel(), C.byref(out), _ptr(ws), ws.numel(), _stream(g)), "a3d_sum_squares")
-        total += out.value
+            acc = torch.zeros(1, dtype=torch.float64, device=g.device)
+        L.check(lib.a3d_sum_squares_accumulate(_ptr(g), g.numel(), _ptr(acc), _ptr(ws), ws.numel(), _stream(g)),
+                "a3d_sum_squares_accumulate")
+    total = float(acc.item()) if acc is not None else 0.0      # the one host synchronisation of the clip
     return math.sqrt(total)
 
 

@@ -12,7 +12,9 @@ gradient-norm clip, AdamW.
 from __future__ import annotations
 
 import copy
+import os
 import random
+import time
 
 import numpy as np
 import torch
@@ -26,6 +28,14 @@ from .train_decoder import DecoderTape
 
 def train_one_step(model, criterion, optimizer, batch, device, max_norm: float = 0.1):
     coords, raw_coords, feats, labels, _, _, click_idx, _scene_name, _num_obj = batch
+    timing = os.environ.get("A3D_TRAIN_TIMING")           # phase wall times (device-synchronised) on stderr
+    marks = []
+
+    def mark(name):
+        if timing:
+            torch.cuda.synchronize()
+            marks.append((name, time.perf_counter()))
+    mark("start")
     coords = coords.to(device)
     raw_coords = raw_coords.to(device)
     feats = feats.to(device)
@@ -40,6 +50,7 @@ def train_one_step(model, criterion, optimizer, batch, device, max_norm: float =
     bb = BackboneTape(model, scene, feats)
     pcd = bb.output
     ranges = scene.batch_ranges
+    mark("backbone forward")
 
     # ---- objects of this iteration, engine.py:55-77
     labels_new = []
@@ -64,15 +75,16 @@ def train_one_step(model, criterion, optimizer, batch, device, max_norm: float =
     eng = model._get_engine()
     eng.mark_stale()                         # the optimiser writes the parameters in place, behind torch's back
     eng.refresh_weights_if_stale()
-    dec_in = [eng.decoder_inputs(pcd[s:e], raw_coords[s:e]) for s, e in ranges]
-    pos_enc = [d[3][4][0][0] for d in dec_in]
+    dec_in = eng.decoder_inputs_batch(pcd, raw_coords, ranges)
+    pos_enc = dec_in[3][4][0]
     for it in range(num_forward_iters + 1):
+        if it:                                 # one batched decoder pass for all samples (5 launches per layer)
+            out = eng.forward_mask(*dec_in, click_idx=click_idx, click_time_idx=click_time_idx)
         for idx, (s, e) in enumerate(ranges):
             if it == 0:
                 pred = torch.zeros(e - s, device=device)
             else:
-                out = eng.forward_mask(*dec_in[idx], click_idx=[click_idx[idx]], click_time_idx=[click_time_idx[idx]])
-                pred = out["pred_masks"][0].argmax(-1)
+                pred = out["pred_masks"][idx].argmax(-1)
                 for obj_id, cids in click_idx[idx].items():
                     pred[cids] = int(obj_id)
             new_clicks, _, _, new_time = get_simulated_clicks(pred, labels_new[idx], raw_coords[s:e], it, training=True)
@@ -80,6 +92,7 @@ def train_one_step(model, criterion, optimizer, batch, device, max_norm: float =
                 click_idx[idx], click_time_idx[idx] = extend_clicks(click_idx[idx], click_time_idx[idx], new_clicks,
                                                                     new_time)
     model.train()
+    mark(f"click simulation ({num_forward_iters} decoder rounds)")
 
     # ---- decoder, training mode, one tape per sample (agile3d.py:192 loops over the samples)
     tapes = [DecoderTape(model, pcd[s:e], pos_enc[i], click_idx[i], click_time_idx[i]) for i, (s, e) in enumerate(ranges)]
@@ -87,6 +100,7 @@ def train_one_step(model, criterion, optimizer, batch, device, max_norm: float =
     outputs = {"pred_masks": [t.logits[-1] for t in tapes],
                "aux_outputs": [{"pred_masks": [t.logits[l] for t in tapes]} for l in range(n_layers - 1)]}
 
+    mark("decoder forward")
     # ---- losses (engine.py:124-128) and their gradient with respect to every level's logits
     click_weights = cal_click_loss_weights(batch_idx, raw_coords, torch.cat(labels_new), click_idx)
     loss_dict = criterion(outputs, labels_new, click_weights)
@@ -95,6 +109,7 @@ def train_one_step(model, criterion, optimizer, batch, device, max_norm: float =
         raise FloatingPointError(f"Loss is {total}, stopping training")
     gl = criterion.grad_logits(outputs, labels_new, click_weights)
 
+    mark("losses")
     # ---- backward: decoders, then the backbone through d(pcd_features)
     grads = {}
     d_pcd = torch.empty_like(pcd)
@@ -104,13 +119,20 @@ def train_one_step(model, criterion, optimizer, batch, device, max_norm: float =
         d_pcd[s:e] = dp
         for k, v in g.items():
             grads[k] = v if k not in grads else grads[k] + v
+    mark("decoder backward")
     grads.update(bb.backward(d_pcd))
+    mark("backbone backward")
 
     # ---- data-parallel average, clip, AdamW (engine.py:143-150)
     allreduce_mean_(grads)
     norm, coef = clip_grad_norm_(grads, max_norm)
     optimizer.step(grads, coef)
     eng.mark_stale()
+    mark("clip + AdamW")
+    if timing:
+        import sys
+        print("train_one_step: " + ", ".join(f"{n} {1e3 * (t - marks[i][1]):.1f} ms" for i, (n, t) in enumerate(marks[1:])),
+              file=sys.stderr)
     return {"loss": total, "grad_norm": norm, "loss_dict": {k: float(v) for k, v in loss_dict.items()},
             "clicks": [sum(len(v) for v in c.values()) for c in click_idx]}
 

@@ -240,6 +240,9 @@ int a3d_group_max_backward(const float* dout_dev, const int32_t* arg_dev, int64_
 size_t a3d_sum_squares_workspace_bytes(void);
 int    a3d_sum_squares(const float* g_dev, int64_t n, double* out_host, void* workspace_dev, size_t workspace_bytes,
                        void* stream);
+/* the same, added to *acc_dev (device double, zeroed by the caller) without a host synchronisation */
+int    a3d_sum_squares_accumulate(const float* g_dev, int64_t n, double* acc_dev, void* workspace_dev,
+                                  size_t workspace_bytes, void* stream);
 int    a3d_adamw_step(float* param_dev, const float* grad_dev, float* exp_avg_dev, float* exp_avg_sq_dev, int64_t n,
                       int step, float lr, float beta1, float beta2, float eps, float weight_decay, float grad_scale,
                       void* stream);
