@@ -32,6 +32,33 @@ __global__ void k_tr_scores(const float* __restrict__ q, const float* __restrict
   S[e] = s;
 }
 
+// the same scores with one thread per (head, row of the LONG side): its dh-vector stays in registers, the short side's
+// vectors are wave-uniform (scalar loads); by_k = 1: thread = key j (writes coalesced over j), 0: thread = query i
+template <int DHT>
+__global__ void __launch_bounds__(256) k_tr_scores_long(const float* __restrict__ q, const float* __restrict__ k, int Lq,
+                                                        int Lk, int H, float scale, const unsigned char* __restrict__ mask,
+                                                        float* __restrict__ S, int by_k) {
+  const int h = blockIdx.y, C = H * DHT;
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  const int nlong = by_k ? Lk : Lq, nshort = by_k ? Lq : Lk;
+  if (t >= nlong) return;
+  const float* mine = (by_k ? k : q) + (size_t)t * C + h * DHT;
+  const float* other = (by_k ? q : k) + h * DHT;
+  float r[DHT];
+#pragma unroll
+  for (int d = 0; d < DHT; ++d) r[d] = mine[d];
+  for (int o = 0; o < nshort; ++o) {
+    const float* orow = other + (size_t)o * C;
+    float s = 0.f;
+#pragma unroll
+    for (int d = 0; d < DHT; ++d) s += r[d] * orow[d];
+    s *= scale;
+    const int i = by_k ? o : t, j = by_k ? t : o;
+    if (mask && mask[(size_t)i * Lk + j]) s = -INFINITY;
+    S[((size_t)h * Lq + i) * Lk + j] = s;
+  }
+}
+
 // one workgroup per row (long rows) or one thread per row (short rows); mode 0: softmax in place,
 // mode 1: a = P, b = dP -> b = P * (dP - sum P dP)
 __global__ void __launch_bounds__(256) k_tr_rows_block(float* __restrict__ a, float* __restrict__ b, int L, int mode) {
@@ -181,8 +208,17 @@ extern "C" int a3d_attn_scores(const float* q_dev, const float* k_dev, int64_t L
     set_error("a3d_attn_scores: bad arguments");
     return A3D_ERR_INVALID;
   }
-  k_tr_scores<<<blocks_of((size_t)H * Lq * Lk, 256), 256, 0, (hipStream_t)stream>>>(q_dev, k_dev, (int)Lq, (int)Lk, H, dh,
-                                                                                 scale, mask_dev, S_dev);
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t nlong = Lq > Lk ? Lq : Lk;
+  const int by_k = Lk >= Lq;
+  if ((dh == 16 || dh == 128) && nlong >= 1024) {
+    const dim3 grid(blocks_of((size_t)nlong, 256), H);
+    if (dh == 16) k_tr_scores_long<16><<<grid, 256, 0, st>>>(q_dev, k_dev, (int)Lq, (int)Lk, H, scale, mask_dev, S_dev, by_k);
+    else k_tr_scores_long<128><<<grid, 256, 0, st>>>(q_dev, k_dev, (int)Lq, (int)Lk, H, scale, mask_dev, S_dev, by_k);
+  } else {
+    k_tr_scores<<<blocks_of((size_t)H * Lq * Lk, 256), 256, 0, st>>>(q_dev, k_dev, (int)Lq, (int)Lk, H, dh, scale, mask_dev,
+                                                                    S_dev);
+  }
   A3D_LAUNCH_CHECK();
   return A3D_OK;
 }
