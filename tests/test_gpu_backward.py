@@ -403,3 +403,73 @@ def test_full_training_step_reduces_the_loss():
     model.eval()                                   # and the inference path sees the new weights
     x = SparseTensor(features=batch[2], coordinates=batch[0], device="cuda")
     assert torch.isfinite(model.forward_backbone(x, raw_coordinates=batch[1].cuda())[0].F).all()
+
+
+def test_whole_network_gradients_match_autograd():
+    """Backbone and decoder chained (the hand-off is dL/d(pcd_features)): all 268 trained tensors of the model against
+    float64 autograd through oracle backbone (training-mode BatchNorm) + oracle decoder, same branch on both sides."""
+    from agile3d_amd import build_model, default_args
+    from agile3d_amd.train_backbone import BackboneTape
+    from agile3d_amd.train_decoder import DecoderTape
+    from oracle import decoder as od
+    torch.manual_seed(13)
+    model = build_model(default_args()).cuda().train()
+    with torch.no_grad():
+        for n_, p in model.named_parameters():
+            if n_.endswith("bn.weight"):
+                p.uniform_(0.5, 1.5)
+            elif n_.endswith("bn.bias"):
+                p.normal_(0, 0.2)
+    DT = torch.float64
+    sd0 = {k: v.detach().cpu().to(DT).clone() if v.is_floating_point() else v.detach().cpu().clone()
+           for k, v in model.state_dict().items()}
+    scn = make_scene(3000, seed=14)
+    coords, n = scn["coords"], len(scn["coords"])
+    g = torch.Generator().manual_seed(15)
+    feats = torch.rand(n, 3, generator=g)
+    xyz = torch.from_numpy(scn["raw_xyz"])
+    lab = scn["labels"]
+    ids = [i for i in np.unique(lab) if i > 0 and (lab == i).sum() >= 3][:2]
+    ci = {"0": [int(np.flatnonzero(lab == 0)[5])], "1": [int(r) for r in np.flatnonzero(lab == ids[0])[:2]],
+          "2": [int(np.flatnonzero(lab == ids[1])[0])]}
+    ct = {"0": [3], "1": [0, 2], "2": [1]}
+    R = [torch.randn(n, 3, generator=g) / 8 for _ in range(3)]
+    # ---- HIP: backbone tape -> decoder tape -> backward through both
+    sc = Scene(torch.from_numpy(coords).cuda())
+    bt = BackboneTape(model, sc, feats.cuda())
+    pos = od.fourier_pos_enc(xyz.to(DT), sd0["pos_enc.gauss_B"], xyz.to(DT).min(0)[0], xyz.to(DT).max(0)[0])
+    dtp = DecoderTape(model, bt.output, pos.float().cuda(), ci, ct)
+    gd, d_pcd = dtp.backward([r.cuda() for r in R])
+    grads = dict(gd)
+    grads.update(bt.backward(d_pcd))
+    # ---- oracle on the same branch
+    lv = ob.SparseLevels(coords)
+    maps = [torch.from_numpy(internal_to_oracle_rows(sc, lv, i)) for i in range(5)]
+    bmasks = []
+    for level, node in bt.relu_levels:
+        m = torch.empty(node.v.shape, dtype=DT)
+        m[maps[level]] = (node.v > 0).cpu().to(DT)
+        bmasks.append(m)
+    n_fg = 3
+    dmasks = []
+    for l in range(3):
+        ffn, mlp = dtp.relu_masks[2 * l].cpu().to(DT), dtp.relu_masks[2 * l + 1].cpu().to(DT)
+        dmasks += [ffn, mlp[:n_fg], mlp[n_fg:]]
+    sd = {k: (v.clone().requires_grad_() if v.is_floating_point() and "running" not in k and k != "pos_enc.gauss_B" else v.clone())
+          for k, v in sd0.items()}
+    itb, itd = iter(bmasks), iter(dmasks)
+    ob.RELU, od.RELU = (lambda z: z * next(itb)), (lambda z: z * next(itd))
+    try:
+        out, _ = ob.res16unet34c_forward(sd, lv, feats.to(DT), bn=ob.batch_norm_train)
+        Wh = sd["lin_squeeze_head.kernel"]
+        pcd_o = out @ (Wh if Wh.dim() == 2 else Wh[0]) + sd["lin_squeeze_head.bias"].reshape(1, -1)
+        outs = od.forward_mask(sd, pcd_o, xyz.to(DT), pos, ci, ct, grad=True, force_masks=[m.cpu().bool() for m in dtp.attn_masks])
+    finally:
+        ob.RELU = od.RELU = torch.relu
+    sum((o * r.to(DT)).sum() for o, r in zip(outs, R)).backward()
+    names = [k for k in sd if sd[k].requires_grad and sd[k].grad is not None]
+    assert len(names) == 268 and set(grads) == set(names), set(names) ^ set(grads)
+    worst = max(((grads[k].cpu().to(DT) - sd[k].grad).abs().max().item() / max(1e-3, sd[k].grad.abs().max().item()), k)
+                for k in names)
+    print(f"whole network: 268 gradients, worst relative error {worst[0]:.2e} ({worst[1]})")
+    assert worst[0] <= 3e-3, worst
