@@ -100,3 +100,33 @@ def allreduce_mean_(grads: dict, group=None, bucket_bytes: int = 64 << 20):
             grads[n].copy_(flat[off:off + k].view_as(grads[n]))
             off += k
     return grads
+
+
+# ---- optimiser state in torch.optim.AdamW's state_dict() layout (so checkpoints interchange with the reference's)
+def _adamw_state_dict(self):
+    names = list(self.params)
+    state = {}
+    for i, n in enumerate(names):
+        if n in self.state:
+            state[i] = {"step": torch.tensor(float(self.step_count)), "exp_avg": self.state[n][0].detach().cpu().clone(),
+                        "exp_avg_sq": self.state[n][1].detach().cpu().clone()}
+    group = {"lr": self.lr, "betas": tuple(self.betas), "eps": self.eps, "weight_decay": self.weight_decay,
+             "amsgrad": False, "params": list(range(len(names)))}
+    return {"state": state, "param_groups": [group]}
+
+
+def _adamw_load_state_dict(self, sd):
+    names = list(self.params)
+    g = sd["param_groups"][0]
+    self.lr, self.betas, self.eps, self.weight_decay = g["lr"], tuple(g["betas"]), g["eps"], g["weight_decay"]
+    self.state, steps = {}, []
+    for i, st in sd["state"].items():
+        p = self.params[names[int(i)]]
+        self.state[names[int(i)]] = (st["exp_avg"].to(p.device, torch.float32).contiguous().clone(),
+                                     st["exp_avg_sq"].to(p.device, torch.float32).contiguous().clone())
+        steps.append(int(float(st["step"])))
+    self.step_count = max(steps) if steps else 0
+
+
+AdamW.state_dict = _adamw_state_dict
+AdamW.load_state_dict = _adamw_load_state_dict

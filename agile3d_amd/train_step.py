@@ -172,3 +172,32 @@ class MultiStepLR:
     def load_state_dict(self, sd):
         self.last_epoch, self.base_lr, self.milestones, self.gamma = sd["last_epoch"], sd["base_lr"], sd["milestones"], sd["gamma"]
         self.optimizer.lr = self.base_lr * self.gamma ** sum(1 for m in self.milestones if m <= self.last_epoch)
+
+
+def save_checkpoint(path, model, optimizer, lr_scheduler, epoch, args=None):
+    """The reference's checkpoint file (main.py:190-201): {'model', 'optimizer', 'lr_scheduler', 'epoch', 'args'}; the
+    optimiser state is in torch.optim.AdamW's own layout."""
+    torch.save({"model": {k: v.detach().cpu() for k, v in model.state_dict().items()}, "optimizer": optimizer.state_dict(),
+                "lr_scheduler": lr_scheduler.state_dict() if lr_scheduler is not None else None, "epoch": epoch,
+                "args": args}, path)
+
+
+def load_checkpoint(path, model, optimizer=None, lr_scheduler=None):
+    """Resume like main.py:131-152: weights with strict=False, then optimiser state and epoch when the file has them
+    (the learning rate of the running configuration is kept, as the reference does).  Returns the epoch to start from."""
+    ck = torch.load(path, map_location="cpu", weights_only=False)
+    missing, unexpected = model.load_state_dict(ck["model"], strict=False)
+    unexpected = [k for k in unexpected if not (k.endswith("total_params") or k.endswith("total_ops"))]
+    if missing:
+        print("Missing Keys: {}".format(missing))
+    if unexpected:
+        print("Unexpected Keys: {}".format(unexpected))
+    start = 0
+    if optimizer is not None and "optimizer" in ck and "epoch" in ck and ck["optimizer"] is not None:
+        lr = optimizer.lr
+        optimizer.load_state_dict(ck["optimizer"])
+        optimizer.lr = lr
+        if lr_scheduler is not None and ck.get("lr_scheduler") is not None:
+            lr_scheduler.load_state_dict(ck["lr_scheduler"])
+        start = ck["epoch"] + 1
+    return start

@@ -473,3 +473,49 @@ def test_whole_network_gradients_match_autograd():
                 for k in names)
     print(f"whole network: 268 gradients, worst relative error {worst[0]:.2e} ({worst[1]})")
     assert worst[0] <= 3e-3, worst
+
+
+def test_checkpoint_resume_continues_bit_identically(tmp_path):
+    """main.py:131-152,190-201: train two iterations, save, load into a fresh model + optimiser, and the third iteration
+    equals the third iteration of the uninterrupted run bit for bit (weights, Adam moments, step count, BatchNorm
+    running statistics all travel); the optimiser entry is readable by torch.optim.AdamW."""
+    import random
+
+    from agile3d_amd import batched_coordinates, build_model, default_args
+    from agile3d_amd.criterion import build_mask_criterion
+    from agile3d_amd.optim import AdamW
+    from agile3d_amd.train_step import MultiStepLR, load_checkpoint, save_checkpoint, train_one_step
+    args = default_args(bce_loss_coef=1.0, dice_loss_coef=2.0, losses=["bce", "dice"])
+    sc_ = make_scene(2500, seed=40)
+    batch = (batched_coordinates([sc_["coords"][:, 1:]]), torch.from_numpy(sc_["raw_xyz"]), torch.from_numpy(sc_["feats"]),
+             [torch.from_numpy(sc_["labels"].astype(np.int64))], None, None, [{}], ("scene0040_00",), (0,))
+    crit = build_mask_criterion(args)
+    dev = torch.device("cuda")
+
+    def seeds(i):
+        np.random.seed(i), torch.manual_seed(i), random.seed(i)
+    torch.manual_seed(1)
+    model = build_model(args).cuda()
+    opt = AdamW(model.named_parameters(), lr=5e-4, weight_decay=1e-4)
+    sched = MultiStepLR(opt, [1000])
+    for i in range(2):
+        seeds(10 + i)
+        train_one_step(model, crit, opt, batch, dev, 0.1)
+    save_checkpoint(str(tmp_path / "checkpoint.pth"), model, opt, sched, 0, args)
+    seeds(12)
+    ref = train_one_step(model, crit, opt, batch, dev, 0.1)
+    ref_sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    torch.manual_seed(99)
+    model2 = build_model(args).cuda()                                   # different initial weights, overwritten by the file
+    opt2 = AdamW(model2.named_parameters(), lr=5e-4, weight_decay=1e-4)
+    assert load_checkpoint(str(tmp_path / "checkpoint.pth"), model2, opt2, MultiStepLR(opt2, [1000])) == 1
+    assert opt2.step_count == 2
+    seeds(12)
+    got = train_one_step(model2, crit, opt2, batch, dev, 0.1)
+    assert got["loss"] == ref["loss"] and got["grad_norm"] == ref["grad_norm"]
+    for k, v in model2.state_dict().items():
+        assert torch.equal(v, ref_sd[k]), k
+    ck = torch.load(str(tmp_path / "checkpoint.pth"), map_location="cpu", weights_only=False)
+    topt = torch.optim.AdamW([torch.nn.Parameter(p.detach().cpu().clone()) for p in model.parameters()], lr=5e-4)
+    topt.load_state_dict(ck["optimizer"])                               # same layout as the reference's files
+    assert set(ck) == {"model", "optimizer", "lr_scheduler", "epoch", "args"}
