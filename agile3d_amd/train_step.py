@@ -201,3 +201,66 @@ def load_checkpoint(path, model, optimizer=None, lr_scheduler=None):
             lr_scheduler.load_state_dict(ck["lr_scheduler"])
         start = ck["epoch"] + 1
     return start
+
+
+def evaluate(model, criterion, data_loader, args, epoch, device):
+    """engine.py:182-300: the validation pass of the training script -- the interactive protocol of ``Evaluate`` with
+    the losses of every click round on top; writes ``val_results_epoch_<epoch>.csv`` into ``args.valResults_dir`` and
+    returns the averaged statistics + the NoC / IoU@k table.  No gradients; inference kernels only."""
+    import os as _os
+
+    from .clicks import argmax_labels, mean_iou_scene
+    from .evaluate import EvaluatorMO
+    from .sparse import SparseTensor
+    model.eval()
+    criterion.eval()
+    _os.makedirs(args.valResults_dir, exist_ok=True)
+    results_file = _os.path.join(args.valResults_dir, "val_results_epoch_" + str(epoch) + ".csv")
+    sums, rounds, instance_counter = {}, 0, 0
+    with open(results_file, "w") as f:
+        for batch in data_loader:
+            coords, raw_coords, feats, labels, labels_full, inverse_map, click_idx, scene_name, num_obj = batch
+            coords, raw_coords = coords.to(device), raw_coords.to(device)
+            labels = [l.to(device) for l in labels]
+            labels_full = [l.to(device) for l in labels_full]
+            inverse_map = [(m if torch.is_tensor(m) else torch.as_tensor(np.asarray(m))).to(device) for m in inverse_map]
+            batch_idx = coords[:, 0]
+            n_samples = int(batch_idx.max()) + 1
+            masks = [batch_idx == i for i in range(n_samples)]
+            for c in click_idx:
+                for obj_id in c:
+                    c[obj_id] = []
+            click_time_idx = copy.deepcopy(click_idx)
+            backbone_out = model.forward_backbone(SparseTensor(coordinates=coords, features=feats, device=device),
+                                                  raw_coordinates=raw_coords)
+            current, max_clicks = 0, num_obj[0] * args.max_num_clicks
+            while current <= max_clicks:
+                if current:
+                    outputs = model.forward_mask(*backbone_out, click_idx=click_idx, click_time_idx=click_time_idx)
+                    cw = cal_click_loss_weights(batch_idx, raw_coords, torch.cat(labels), click_idx)
+                    loss_dict = criterion(outputs, labels, cw)
+                    scaled = {k: float(v) * criterion.weight_dict[k] for k, v in loss_dict.items() if k in criterion.weight_dict}
+                    for k, v in {"loss": sum(scaled.values()), **scaled, **{k + "_unscaled": float(v) for k, v in loss_dict.items()}}.items():
+                        sums[k] = sums.get(k, 0.0) + v
+                miou = 0.0
+                for idx in range(n_samples):
+                    if current == 0:
+                        pred = torch.zeros(labels[idx].shape[0], dtype=torch.int32, device=device)
+                    else:
+                        pred = argmax_labels(outputs["pred_masks"][idx], click_idx[idx])        # + sparse-gt update
+                        miou += float(mean_iou_scene(pred, labels[idx])[0])
+                    iou, _ = mean_iou_scene(pred, labels_full[idx], inverse_map[idx])
+                    f.write(f"{instance_counter + idx} {scene_name[idx].replace('scene', '')} {num_obj[idx]} "
+                            f"{current / num_obj[idx]} {iou.cpu().numpy()}\n")
+                    new_clicks, _, _, new_time = get_simulated_clicks(pred, labels[idx], raw_coords[masks[idx]], current,
+                                                                      training=False)
+                    if new_clicks is not None:
+                        extend_clicks(click_idx[idx], click_time_idx[idx], new_clicks, new_time)
+                if current:
+                    sums["mIoU"] = sums.get("mIoU", 0.0) + miou / n_samples
+                    rounds += 1
+                current += num_obj[n_samples - 1] if current == 0 else 1
+            instance_counter += len(num_obj)
+    stats = {k: v / max(rounds, 1) for k, v in sums.items()}
+    stats.update(EvaluatorMO(args.val_list, results_file, [0.5, 0.65, 0.8, 0.85, 0.9]).eval_results())
+    return stats

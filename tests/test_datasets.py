@@ -217,3 +217,31 @@ def test_ply_to_training_epoch(tmp_path):
     assert {"loss_bce", "loss_dice", "loss_bce_1", "loss_dice_1"} <= set(stats)
     sched.step()
     assert abs(opt.lr - 1e-5) < 1e-12
+
+
+@pytest.mark.gpu
+def test_training_script_validation_pass(tmp_path):
+    """engine.evaluate (engine.py:182-300): interactive protocol + per-round losses + the results table, from the PLY
+    fixture through the DataLoader."""
+    import random
+    import types
+
+    from agile3d_amd import build_model, default_args
+    from agile3d_amd.criterion import build_mask_criterion
+    from agile3d_amd.train_step import evaluate
+    lst = json.load(open(os.path.join(DATA, "val_list.json")))
+    vl = tmp_path / "val.json"
+    vl.write_text(json.dumps({"scene0001_00_obj_3": lst["scene0001_00_obj_3"]}))
+    ds, fn = D.build_dataset("val", types.SimpleNamespace(dataset_mode="multi_obj", scan_folder=os.path.join(DATA, "scans"),
+                                                         train_list="", val_list=str(vl), voxel_size=0.05, crop=False))
+    loader = torch.utils.data.DataLoader(ds, batch_size=1, collate_fn=fn)
+    args = default_args(bce_loss_coef=1.0, dice_loss_coef=2.0, losses=["bce", "dice"], max_num_clicks=20,
+                        valResults_dir=str(tmp_path / "val"), val_list=str(vl))
+    torch.manual_seed(0)
+    random.seed(1)
+    model = build_model(args).cuda()
+    stats = evaluate(model, build_mask_criterion(args), loader, args, 7, torch.device("cuda"))
+    rows = open(tmp_path / "val" / "val_results_epoch_7.csv").read().strip().split("\n")
+    assert len(rows) == 59 and rows[0].split()[3] == "0.0"
+    assert {"loss", "mIoU", "loss_bce", "loss_dice_1", "loss_bce_unscaled", "NoC@80", "IoU@5"} <= set(stats)
+    assert np.isfinite(stats["loss"]) and 0.0 <= stats["mIoU"] <= 1.0
