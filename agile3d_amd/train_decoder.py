@@ -44,17 +44,20 @@ def _stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
-def _linear(x, w_in_out, bias=None):
-    """x [n, cin] @ w [cin, cout] (+ bias) through a3d_linear."""
+def _pack(w_in_out):
+    cin, cout = w_in_out.shape
+    return B.pack_weight(w_in_out.reshape(1, cin, cout)), cin, cout
+
+
+def _linear(x, packed, bias=None):
+    """x [n, cin] @ w [cin, cout] (+ bias) through a3d_linear; ``packed`` = _pack(w)."""
     lib = L.load()
+    wp, cin, cout = packed
     x = x.contiguous()
-    n, cin = x.shape
-    cout = w_in_out.shape[1]
-    wp = B.pack_weight(w_in_out.reshape(1, cin, cout))
+    n = x.shape[0]
     y = torch.empty((n, cout), dtype=torch.float32, device=x.device)
-    ws = torch.zeros(1024, dtype=torch.uint8, device=x.device)
     L.check(lib.a3d_linear(_ptr(x), cin, None, 0, n, cin, cout, _ptr(wp), None, _ptr(bias), None, 0, 0, _ptr(y), cout,
-                           _ptr(ws), ws.numel(), _stream()), "a3d_linear")
+                           None, 0, _stream()), "a3d_linear")
     return y
 
 
@@ -80,7 +83,7 @@ class DecoderTape:
             raise RuntimeError("DecoderTape runs on the GPU only")
         self.model = model
         self.P = dict(model.named_parameters())
-        self.steps, self.grads = [], {}
+        self.steps, self.grads, self._packed = [], {}, {}
         self.relu_masks, self.attn_masks, self.args = [], [], []      # what a reference needs to follow the same branch
         self._forward(pcd_features.to(torch.float32).contiguous(), pos_enc.to(torch.float32).contiguous(), click_idx,
                       click_time_idx)
@@ -108,13 +111,17 @@ class DecoderTape:
         if rows is not None:
             W, b = W[rows[0]:rows[1]], (b[rows[0]:rows[1]] if b is not None else None)
         W = W.contiguous()
-        y = _T(_linear(x.v, W.t().contiguous(), b.contiguous() if b is not None else None))
+        key = (wname, rows)
+        if key not in self._packed:          # both orientations packed once per tape (the weights do not change in it)
+            self._packed[key] = (_pack(W.t().contiguous()), _pack(W))
+        fwd_w, bwd_w = self._packed[key]
+        y = _T(_linear(x.v, fwd_w, b.contiguous() if b is not None else None))
 
         def back():
             if y.g is None:
                 return
             dy = y.g.contiguous()
-            x.add_grad(_linear(dy, W))                                   # dy @ W
+            x.add_grad(_linear(dy, bwd_w))                               # dy @ W
             dW = B.linear_weight_grad(x.v, dy).t()                        # [out, in]
             if rows is None:
                 self._pg(wname, dW)
