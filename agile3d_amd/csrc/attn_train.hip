@@ -119,6 +119,33 @@ __global__ void k_tr_rows_thread(float* __restrict__ a, float* __restrict__ b, s
   }
 }
 
+// softmax over the MIDDLE dimension of [H][Lq][Lk] (one thread per (h, j), walking i with stride Lk: coalesced over j).
+// Scene-to-click attention keeps its scores transposed -- [head][query][point], the point index fastest -- so that every
+// kernel touching the 80 k-long dimension reads and writes consecutive addresses.  mode 0 / 1 as above.
+__global__ void k_tr_cols(float* __restrict__ a, float* __restrict__ b, int H, int Lq, int Lk, int mode) {
+  const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= (size_t)H * Lk) return;
+  const int j = (int)(e % Lk), h = (int)(e / Lk);
+  float* col = a + (size_t)h * Lq * Lk + j;
+  if (mode == 0) {
+    float m = -INFINITY;
+    for (int i = 0; i < Lq; ++i) m = fmaxf(m, col[(size_t)i * Lk]);
+    float s = 0.f;
+    for (int i = 0; i < Lq; ++i) {
+      const float p = expf(col[(size_t)i * Lk] - m);
+      col[(size_t)i * Lk] = p;
+      s += p;
+    }
+    const float inv = 1.f / s;
+    for (int i = 0; i < Lq; ++i) col[(size_t)i * Lk] *= inv;
+  } else {
+    float* cb = b + (size_t)h * Lq * Lk + j;
+    float s = 0.f;
+    for (int i = 0; i < Lq; ++i) s += col[(size_t)i * Lk] * cb[(size_t)i * Lk];
+    for (int i = 0; i < Lq; ++i) cb[(size_t)i * Lk] = col[(size_t)i * Lk] * (cb[(size_t)i * Lk] - s);
+  }
+}
+
 __global__ void k_tr_apply(const float* __restrict__ P, const float* __restrict__ V, int Lq, int Lk, int H, int dh,
                            float scale, float* __restrict__ O) {
   const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -239,6 +266,24 @@ extern "C" int a3d_softmax_rows_backward(const float* P_dev, float* dP_dev, int6
   }
   if (L >= 512) k_tr_rows_block<<<(unsigned)rows, 256, 0, (hipStream_t)stream>>>((float*)P_dev, dP_dev, (int)L, 1);
   else k_tr_rows_thread<<<blocks_of((size_t)rows, 256), 256, 0, (hipStream_t)stream>>>((float*)P_dev, dP_dev, (size_t)rows, (int)L, 1);
+  A3D_LAUNCH_CHECK();
+  return A3D_OK;
+}
+extern "C" int a3d_softmax_cols(float* S_dev, int H, int64_t Lq, int64_t Lk, void* stream) {
+  if (!S_dev || H < 1 || Lq <= 0 || Lk <= 0) {
+    set_error("a3d_softmax_cols: bad arguments");
+    return A3D_ERR_INVALID;
+  }
+  k_tr_cols<<<blocks_of((size_t)H * Lk, 256), 256, 0, (hipStream_t)stream>>>(S_dev, nullptr, H, (int)Lq, (int)Lk, 0);
+  A3D_LAUNCH_CHECK();
+  return A3D_OK;
+}
+extern "C" int a3d_softmax_cols_backward(const float* P_dev, float* dP_dev, int H, int64_t Lq, int64_t Lk, void* stream) {
+  if (!P_dev || !dP_dev || H < 1 || Lq <= 0 || Lk <= 0) {
+    set_error("a3d_softmax_cols_backward: bad arguments");
+    return A3D_ERR_INVALID;
+  }
+  k_tr_cols<<<blocks_of((size_t)H * Lk, 256), 256, 0, (hipStream_t)stream>>>((float*)P_dev, dP_dev, H, (int)Lq, (int)Lk, 1);
   A3D_LAUNCH_CHECK();
   return A3D_OK;
 }

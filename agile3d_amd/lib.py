@@ -120,6 +120,8 @@ SYMBOLS = {
                                   C.c_void_p, C.c_void_p]),
     "a3d_softmax_rows": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]),
     "a3d_softmax_rows_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]),
+    "a3d_softmax_cols": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_int64, C.c_void_p]),
+    "a3d_softmax_cols_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_int64, C.c_void_p]),
     "a3d_attn_apply_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int]),
     "a3d_attn_apply": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_float,
                                  C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),

@@ -195,13 +195,48 @@ class DecoderTape:
         self.steps.append(back)
         return y
 
+    def attention_t(self, q: _T, k: _T, v: _T) -> _T:
+        """The same attention for MANY queries over FEW keys (scene-to-click: 80 k points x ~20 click queries), with the
+        score matrix kept transposed, [head][key][query]: the long index is the fastest one in every kernel."""
+        lib = L.load()
+        Lq, Lk = q.v.shape[0], k.v.shape[0]
+        scale = 1.0 / (DH ** 0.5)
+        dev = q.v.device
+        Pt = torch.empty((H, Lk, Lq), dtype=torch.float32, device=dev)                      # P^T[h][key][query]
+        L.check(lib.a3d_attn_scores(_ptr(k.v), _ptr(q.v), Lk, Lq, H, DH, scale, None, _ptr(Pt), _stream()), "scores")
+        L.check(lib.a3d_softmax_cols(_ptr(Pt), H, Lk, Lq, _stream()), "softmax_cols")         # over the keys
+        o = torch.empty((Lq, H * DH), dtype=torch.float32, device=dev)
+        _apply(Pt, v.v, Lk, Lq, H, DH, 1, 1.0, o)                                            # o[query] = sum_key P^T v[key]
+        y = _T(o)
+
+        def back():
+            if y.g is None:
+                return
+            do = y.g.contiguous()
+            dPt = torch.empty_like(Pt)
+            L.check(lib.a3d_attn_scores(_ptr(v.v), _ptr(do), Lk, Lq, H, DH, 1.0, None, _ptr(dPt), _stream()), "scores")
+            dv = torch.empty_like(v.v)
+            _apply(Pt, do, Lk, Lq, H, DH, 0, 1.0, dv)                                        # dv[key] = sum_query P^T dO
+            L.check(lib.a3d_softmax_cols_backward(_ptr(Pt), _ptr(dPt), H, Lk, Lq, _stream()), "softmax_cols_bwd")
+            dq = torch.empty_like(q.v)
+            _apply(dPt, k.v, Lk, Lq, H, DH, 1, scale, dq)                                    # dq[query] = sum_key dS^T k
+            dk = torch.empty_like(k.v)
+            _apply(dPt, q.v, Lk, Lq, H, DH, 0, scale, dk)                                    # dk[key] = sum_query dS^T q
+            q.add_grad(dq)
+            k.add_grad(dk)
+            v.add_grad(dv)
+        self.steps.append(back)
+        return y
+
     def mha(self, prefix, query: _T, key: _T, value: _T, mask=None) -> _T:
         """nn.MultiheadAttention (attention_block.py:25-26,88-94): in_proj slices, attention, out_proj."""
         w, b = prefix + "in_proj_weight", prefix + "in_proj_bias"
         q = self.lin(query, w, b, rows=(0, 128))
         k = self.lin(key, w, b, rows=(128, 256))
         v = self.lin(value, w, b, rows=(256, 384))
-        return self.lin(self.attention(q, k, v, mask), prefix + "out_proj.weight", prefix + "out_proj.bias")
+        long_queries = mask is None and q.v.shape[0] >= 1024 and q.v.shape[0] > 8 * k.v.shape[0]
+        a = self.attention_t(q, k, v) if long_queries else self.attention(q, k, v, mask)
+        return self.lin(a, prefix + "out_proj.weight", prefix + "out_proj.bias")
 
     def mask_head(self, queries: _T, src: _T, groups):
         """Agile3d.mask_module (agile3d.py:342-384): per-object max over its queries of src . MLP(LN(q))."""

@@ -224,6 +224,10 @@ int a3d_attn_scores(const float* q_dev, const float* k_dev, int64_t Lq, int64_t 
                     const unsigned char* mask_dev, float* S_dev, void* stream);
 int a3d_softmax_rows(float* S_dev, int64_t rows, int64_t L, void* stream);
 int a3d_softmax_rows_backward(const float* P_dev, float* dP_dev, int64_t rows, int64_t L, void* stream);
+/* the same over the MIDDLE dimension of [H][Lq][Lk] (scores kept transposed: scene-to-click attention stores
+ * [head][query][point] so that the 80 k-long point index is the fastest one everywhere) */
+int a3d_softmax_cols(float* S_dev, int H, int64_t Lq, int64_t Lk, void* stream);
+int a3d_softmax_cols_backward(const float* P_dev, float* dP_dev, int H, int64_t Lq, int64_t Lk, void* stream);
 size_t a3d_attn_apply_workspace_bytes(int64_t Lq, int64_t Lk, int H, int dh, int transposed);
 int a3d_attn_apply(const float* P_dev, const float* V_dev, int64_t Lq, int64_t Lk, int H, int dh, int transposed,
                    float scale, float* O_dev, void* workspace_dev, size_t workspace_bytes, void* stream);
