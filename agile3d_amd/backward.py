@@ -3,9 +3,10 @@
     conv_input_grad(scene, kind, level_in, w, dy)        dL/dx of conv / conv_tr (models/modules/common.py:125-188)
     conv_weight_grad(scene, kind, level_in, x, dy, K)    dL/dW [K, Cin, Cout]
 
-for the four kernel-map kinds of the backbone (3^3 stride 1, 2^3 stride 2, 2^3 transposed, 1x1).  What autograd does
-inside MinkowskiEngine for ``engine.py:137-150`` (``losses.backward()``); the rest of the training step (BatchNorm in
-training mode, the decoder's backward, the optimiser) is not built yet -- DESIGN.md section 7.
+for the four kernel-map kinds of the backbone (3^3 stride 1, 2^3 stride 2, 2^3 transposed, 1x1) -- what autograd does
+inside MinkowskiEngine for ``engine.py:137-150`` (``losses.backward()``) -- plus the wrappers of the other training
+kernels (BatchNorm in training mode, LayerNorm, column sums, the input conv's weight gradient).  The tapes that string
+them together are ``train_backbone.py`` / ``train_decoder.py``; the iteration is ``train_step.py``.
 
 The input gradient needs no new kernel: it is the FORWARD kernel on the transposed kernel map with transposed
 weights -- for the 3^3 stride-1 map offset k of row i is row j exactly when offset 26-k of j is i, so

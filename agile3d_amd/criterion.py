@@ -1,8 +1,8 @@
-"""Host mirror of the reference's ``models/criterion.py`` on the HIP library (first
-piece): same class name, constructor, ``forward(outputs, targets, weights)`` and loss-dict keys
-(``loss_bce``, ``loss_dice`` and their ``_<i>`` copies for ``aux_outputs``).  The backward pass of the network is
-not built yet; what is here is the loss values and ``grad_logits`` -- the gradient of the weighted total
-(engine.py:126-128) with respect to every prediction level's logits, i.e. what a backward pass would start from.
+"""Host mirror of the reference's ``models/criterion.py`` on the HIP library:
+same class name, constructor, ``forward(outputs, targets, weights)`` and loss-dict keys (``loss_bce``, ``loss_dice``
+and their ``_<i>`` copies for ``aux_outputs``).  Besides the loss values there is ``grad_logits`` -- the gradient of
+the weighted total (engine.py:126-128) with respect to every prediction level's logits, which is where
+``train_step.train_one_step`` starts the backward pass.
 """
 from __future__ import annotations
 

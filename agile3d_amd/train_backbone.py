@@ -9,7 +9,8 @@ Every FLOP runs in libagile3d_hip (conv forward = the inference kernels, conv in
 transposed maps, k_wgrad, the BatchNorm training kernels, k_stem_wgrad); this module is the reverse-mode bookkeeping:
 which activation feeds which layer, the two-way fan-outs of the residual / skip connections (a tensor add), the channel
 split of the concatenations.  A layer-at-a-time executor meant for parity, not yet for speed: every conv call goes
-through a one-op program with its own workspace.  The decoder's backward and the optimiser are not built yet.
+through a one-op program with its own workspace.  The decoder's half is ``train_decoder.DecoderTape``, the whole
+iteration ``train_step.train_one_step``.
 """
 from __future__ import annotations
 
