@@ -218,31 +218,6 @@ __global__ void __launch_bounds__(256) k_tr_apply_t_head(const float* __restrict
 #pragma unroll
   for (int d = 0; d < DHT; ++d) o[d] = acc[d] * scale;
 }
-// plain apply over a LONG reduced dimension with few output rows (<= 32 queries): one thread per (channel, range of
-// the long dimension) keeps every row's partial sum in registers, so V is read once instead of once per row
-constexpr int kApplyRowsMax = 32;
-__global__ void __launch_bounds__(128) k_tr_apply_rows(const float* __restrict__ P, const float* __restrict__ V, int Lq,
-                                                       int Lk, int H, int dh, int chunk, float* __restrict__ part) {
-  const int C = H * dh;
-  const int c = blockIdx.x * 128 + threadIdx.x;
-  if (c >= C) return;
-  const int h = c / dh;
-  const int b = blockIdx.y * chunk, end = min(Lk, b + chunk);
-  float acc[kApplyRowsMax];
-#pragma unroll
-  for (int r = 0; r < kApplyRowsMax; ++r) acc[r] = 0.f;
-  const float* p = P + (size_t)h * Lq * Lk;
-  for (int j = b; j < end; ++j) {
-    const float v = V[(size_t)j * C + c];
-#pragma unroll
-    for (int r = 0; r < kApplyRowsMax; ++r)
-      if (r < Lq) acc[r] += p[(size_t)r * Lk + j] * v;
-  }
-#pragma unroll
-  for (int r = 0; r < kApplyRowsMax; ++r)
-    if (r < Lq) part[((size_t)blockIdx.y * Lq + r) * C + c] = acc[r];
-}
-
 static int apply_splits(int64_t rows, int64_t Lred, int C) {
   if (Lred < 4096 || rows * C > (1 << 20)) return 1;
   int64_t s = (Lred + 511) / 512;
@@ -355,12 +330,8 @@ extern "C" int a3d_attn_apply(const float* P_dev, const float* V_dev, int64_t Lq
     }
     const size_t total = (size_t)rows * H * dh;
     const int chunk = (int)((Lred + sp - 1) / sp);
-    if (!transposed && Lq <= kApplyRowsMax)
-      k_tr_apply_rows<<<dim3(blocks_of((size_t)H * dh, 128), sp), 128, 0, st>>>(P_dev, V_dev, (int)Lq, (int)Lk, H, dh, chunk,
-                                                                                (float*)workspace_dev);
-    else
-      k_tr_apply_split<<<dim3(blocks_of(total, 256), sp), 256, 0, st>>>(P_dev, V_dev, (int)Lq, (int)Lk, H, dh, transposed, chunk,
-                                                                        (float*)workspace_dev);
+    k_tr_apply_split<<<dim3(blocks_of(total, 256), sp), 256, 0, st>>>(P_dev, V_dev, (int)Lq, (int)Lk, H, dh, transposed, chunk,
+                                                                      (float*)workspace_dev);
     k_tr_apply_reduce<<<blocks_of(total, 256), 256, 0, st>>>((const float*)workspace_dev, sp, total, scale, O_dev);
   } else if (transposed && Lk >= 1024 && (dh == 16 || dh == 128)) {
     const dim3 grid(blocks_of((size_t)Lk, 256), H);
