@@ -11,6 +11,7 @@ Around the path (same names as the reference): ``datasets`` (scan datasets + col
 """
 from .model import build_model, build_agile3d, Agile3d, default_args, randomize_bn_stats  # noqa: F401
 from .sparse import SparseTensor, sparse_quantize, batched_coordinates  # noqa: F401
+from . import utils  # noqa: F401  (ME.utils.sparse_quantize / ME.utils.batched_coordinates)
 
 __all__ = ["build_model", "build_agile3d", "Agile3d", "default_args", "randomize_bn_stats",
-           "SparseTensor", "sparse_quantize", "batched_coordinates"]
+           "SparseTensor", "sparse_quantize", "batched_coordinates", "utils"]

@@ -64,3 +64,15 @@ def test_device_path_full_resolution_scan_and_errors():
         sparse_quantize(bad, quantization_size=0.05, return_index=True)
     with pytest.raises(A3DError):
         sparse_quantize(t * 1e6, quantization_size=0.05)
+
+
+def test_me_style_utils_namespace():
+    """`import agile3d_amd as ME`: the dataset code's ME.utils.sparse_quantize / ME.utils.batched_coordinates calls
+    (datasets/InterMultiObj3DSegDataset.py:67-71,129) resolve to the same functions."""
+    import agile3d_amd as ME
+    pts = np.array([[0.01, 0.02, 0.03], [0.04, 0.01, 0.02], [0.26, 0.0, 0.0]], np.float32)
+    q, idx, inv = ME.utils.sparse_quantize(coordinates=pts, quantization_size=0.05, return_index=True, return_inverse=True)
+    assert q.tolist() == [[0, 0, 0], [5, 0, 0]] and idx.tolist() == [0, 2] and inv.tolist() == [0, 0, 1]
+    bc = ME.utils.batched_coordinates([q, q[:1]])
+    assert bc.tolist() == [[0, 0, 0, 0], [0, 5, 0, 0], [1, 0, 0, 0]]
+    assert ME.SparseTensor is not None and ME.utils.sparse_quantize is ME.sparse_quantize
