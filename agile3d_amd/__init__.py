@@ -13,5 +13,11 @@ from .model import build_model, build_agile3d, Agile3d, default_args, randomize_
 from .sparse import SparseTensor, sparse_quantize, batched_coordinates  # noqa: F401
 from . import utils  # noqa: F401  (ME.utils.sparse_quantize / ME.utils.batched_coordinates)
 
+
+def build_criterion(args):
+    """models/__init__.py:10-11."""
+    from .criterion import build_mask_criterion
+    return build_mask_criterion(args)
+
 __all__ = ["build_model", "build_agile3d", "Agile3d", "default_args", "randomize_bn_stats",
-           "SparseTensor", "sparse_quantize", "batched_coordinates", "utils"]
+           "SparseTensor", "sparse_quantize", "batched_coordinates", "utils", "build_criterion"]
