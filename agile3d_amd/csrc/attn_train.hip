@@ -218,6 +218,45 @@ __global__ void __launch_bounds__(256) k_tr_apply_t_head(const float* __restrict
 #pragma unroll
   for (int d = 0; d < DHT; ++d) o[d] = acc[d] * scale;
 }
+// the same partial sums on the matrix cores for 16-wide heads: one wave = (16 output rows, head, range of the long
+// dimension); D[16 rows][16 channels] += P[h][rows][j..j+15] V[j..j+15][h*16 ..].  K is permuted inside a 16-step (lane
+// (g, m) loads P[row m][j0 + 4g .. +3] as one 16-byte access and the matching value rows V[j0 + 4g + t] one MFMA at a
+// time), so the 80 k value rows are read once per 16 output rows instead of once per output row.
+typedef float f32x4t __attribute__((ext_vector_type(4)));
+__global__ void __launch_bounds__(64) k_tr_apply_mfma(const float* __restrict__ P, const float* __restrict__ V, int Lq, int Lk,
+                                                      int H, int chunk, float* __restrict__ part) {
+  const int lane = threadIdx.x, g = lane >> 4, m = lane & 15;
+  const int i0 = blockIdx.x * 16, h = blockIdx.y, C = H * 16;
+  const int b = blockIdx.z * chunk, end = min(Lk, b + chunk);
+  const int row = i0 + m;
+  const float* prow = P + ((size_t)h * Lq + min(row, Lq - 1)) * Lk;
+  const bool row_ok = row < Lq;
+  f32x4t acc = (f32x4t){0.f, 0.f, 0.f, 0.f};
+  for (int j0 = b; j0 < end; j0 += 16) {
+    const int jj = j0 + 4 * g;
+    f32x4t a = (f32x4t){0.f, 0.f, 0.f, 0.f};
+    if (row_ok) {
+      if (jj + 3 < end && ((size_t)(prow + jj) & 15) == 0) a = *(const f32x4t*)(prow + jj);
+      else {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) a[t] = jj + t < end ? prow[jj + t] : 0.f;
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int j = jj + t;
+      const float v = j < end ? V[(size_t)j * C + h * 16 + m] : 0.f;
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t], v, acc, 0, 0, 0);
+    }
+  }
+  // lane (g, n = m) holds D[4g + r][n]
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int i = i0 + 4 * g + r;
+    if (i < Lq) part[((size_t)blockIdx.z * Lq + i) * C + h * 16 + m] = acc[r];
+  }
+}
+
 static int apply_splits(int64_t rows, int64_t Lred, int C) {
   if (Lred < 4096 || rows * C > (1 << 20)) return 1;
   int64_t s = (Lred + 511) / 512;
@@ -329,9 +368,14 @@ extern "C" int a3d_attn_apply(const float* P_dev, const float* V_dev, int64_t Lq
       return A3D_ERR_WORKSPACE;
     }
     const size_t total = (size_t)rows * H * dh;
-    const int chunk = (int)((Lred + sp - 1) / sp);
-    k_tr_apply_split<<<dim3(blocks_of(total, 256), sp), 256, 0, st>>>(P_dev, V_dev, (int)Lq, (int)Lk, H, dh, transposed, chunk,
-                                                                      (float*)workspace_dev);
+    int chunk = (int)((Lred + sp - 1) / sp);
+    chunk = (chunk + 15) / 16 * 16;        // 16-step aligned ranges (trailing ranges may be empty: they write zeros)
+    if (!transposed && dh == 16)
+      k_tr_apply_mfma<<<dim3((unsigned)((Lq + 15) / 16), H, sp), 64, 0, st>>>(P_dev, V_dev, (int)Lq, (int)Lk, H, chunk,
+                                                                           (float*)workspace_dev);
+    else
+      k_tr_apply_split<<<dim3(blocks_of(total, 256), sp), 256, 0, st>>>(P_dev, V_dev, (int)Lq, (int)Lk, H, dh, transposed, chunk,
+                                                                        (float*)workspace_dev);
     k_tr_apply_reduce<<<blocks_of(total, 256), 256, 0, st>>>((const float*)workspace_dev, sp, total, scale, O_dev);
   } else if (transposed && Lk >= 1024 && (dh == 16 || dh == 128)) {
     const dim3 grid(blocks_of((size_t)Lk, 256), H);

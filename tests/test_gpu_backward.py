@@ -519,3 +519,31 @@ def test_checkpoint_resume_continues_bit_identically(tmp_path):
     topt = torch.optim.AdamW([torch.nn.Parameter(p.detach().cpu().clone()) for p in model.parameters()], lr=5e-4)
     topt.load_state_dict(ck["optimizer"])                               # same layout as the reference's files
     assert set(ck) == {"model", "optimizer", "lr_scheduler", "epoch", "args"}
+
+
+@pytest.mark.parametrize("Lq,Lk,Hh,dh,tr", [(20, 50000, 8, 16, 0), (37, 70001, 8, 16, 0), (20, 50000, 8, 16, 1),
+                                             (50000, 20, 8, 16, 1), (40000, 30, 1, 128, 1), (40000, 30, 1, 128, 0)])
+def test_attention_primitives_long_dimensions(Lq, Lk, Hh, dh, tr):
+    """a3d_attn_scores / a3d_attn_apply at the sizes of the training path (tens of thousands of points on one side): the
+    split / per-head / matrix-core variants against float64 einsum."""
+    from agile3d_amd.train_decoder import _apply
+    lib = L.load()
+    g = torch.Generator().manual_seed(Lq + Lk + dh)
+    C_ = Hh * dh
+    q = torch.randn(Lq, C_, generator=g).cuda()
+    k = torch.randn(Lk, C_, generator=g).cuda()
+    S = torch.empty((Hh, Lq, Lk), dtype=torch.float32, device="cuda")
+    L.check(lib.a3d_attn_scores(q.data_ptr(), k.data_ptr(), Lq, Lk, Hh, dh, 0.25, None, S.data_ptr(), None), "scores")
+    ref_S = 0.25 * torch.einsum("ihd,jhd->hij", q.cpu().double().view(Lq, Hh, dh), k.cpu().double().view(Lk, Hh, dh))
+    assert (S.cpu().double() - ref_S).abs().max().item() <= 1e-4
+    P = torch.softmax(S, -1).contiguous()
+    if tr:      # O[j, h, :] = sum_i P[h, i, j] X[i, h, :]
+        out = torch.empty((Lk, C_), dtype=torch.float32, device="cuda")
+        _apply(P, q, Lq, Lk, Hh, dh, 1, 0.5, out)
+        ref = 0.5 * torch.einsum("hij,ihd->jhd", P.cpu().double(), q.cpu().double().view(Lq, Hh, dh)).reshape(Lk, C_)
+    else:       # O[i, h, :] = sum_j P[h, i, j] V[j, h, :]
+        out = torch.empty((Lq, C_), dtype=torch.float32, device="cuda")
+        _apply(P, k, Lq, Lk, Hh, dh, 0, 0.5, out)
+        ref = 0.5 * torch.einsum("hij,jhd->ihd", P.cpu().double(), k.cpu().double().view(Lk, Hh, dh)).reshape(Lq, C_)
+    err = (out.cpu().double() - ref).abs().max().item()
+    assert err <= 2e-5 * max(1.0, ref.abs().max().item()), err
