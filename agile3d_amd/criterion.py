@@ -72,10 +72,28 @@ class SetCriterion:
         return self.forward(outputs, targets, weights)
 
     def forward(self, outputs, targets, weights=None):
-        losses, _ = self._level(outputs["pred_masks"], targets, weights, "", False)
-        for i, aux in enumerate(outputs.get("aux_outputs", [])):
-            d, _ = self._level(aux["pred_masks"], targets, weights, f"_{i}", False)
+        levels = [("", outputs["pred_masks"])] + [(f"_{i}", aux["pred_masks"]) for i, aux in enumerate(outputs.get("aux_outputs", []))]
+        tracked = torch.is_grad_enabled() and any(p.requires_grad for _, preds in levels for p in preds)
+        losses, vals = {}, []
+        for suffix, preds in levels:
+            d, _ = self._level([p.detach() for p in preds], targets, weights, suffix, False)
             losses.update(d)
+            vals += [d.get("loss_bce" + suffix), d.get("loss_dice" + suffix)]
+        if not tracked:
+            return losses
+        # training through torch.autograd (engine.py:128-147: losses.backward()): the loss values become the outputs of
+        # ONE autograd node over every level's logits; its backward is a3d_mask_losses again (autograd.CriterionFn)
+        from .autograd import CriterionFn, _Holder
+        zero = torch.zeros((), dtype=torch.float32, device=levels[0][1][0].device)
+        h = _Holder(values=torch.stack([zero if v is None else v for v in vals]), targets=list(targets),
+                    weights=None if weights is None else list(weights), n_levels=len(levels), n_samples=len(levels[0][1]))
+        flat = [p for _, preds in levels for p in preds]
+        out = CriterionFn.apply(h, *flat)
+        for l, (suffix, _) in enumerate(levels):
+            if "loss_bce" + suffix in losses:
+                losses["loss_bce" + suffix] = out[2 * l]
+            if "loss_dice" + suffix in losses:
+                losses["loss_dice" + suffix] = out[2 * l + 1]
         return losses
 
     def grad_logits(self, outputs, targets, weights=None):

@@ -117,7 +117,15 @@ struct Level {
   uint32_t hmask = 0;
   int* nbr27 = nullptr;         // [27][npad]
   uint32_t* gmask27 = nullptr;  // [npad/16]
-  int* order27 = nullptr;       // [npad/64] 64-row tiles, most offsets first (conv workgroups pull them in this order)
+  int* order27 = nullptr;       // [npad/64] 64-row tiles, most offsets first
+  // exclusive prefix sums over 64-row tiles of the number of offsets a tile has (popcount of the OR of its four group
+  // masks): the conv kernel cuts the (tile, offset) work of a layer into equal shares with them (spconv.hip)
+  int* pre27 = nullptr;         // [npad/64 + 1]
+  int* pre_down = nullptr;      // [npad(level+1)/64 + 1]   (levels 0..3)
+  int* pre_up = nullptr;        // [npad/64 + 1]            (levels 0..3)
+  int* pre27b = nullptr;        // the same three over 128-row tiles: [npad/128 + 1], [npad(level+1)/128 + 1], [npad/128 + 1]
+  int* pre_downb = nullptr;
+  int* pre_upb = nullptr;
   int* child8 = nullptr;        // [8][npad(level+1)]     (levels 0..3)
   uint32_t* gmask_down = nullptr;
   int* up8 = nullptr;           // [8][npad]              (levels 0..3)

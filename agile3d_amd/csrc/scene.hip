@@ -377,6 +377,46 @@ __global__ void __launch_bounds__(1024) k_tile_order(const LevelSet S) {
   }
 }
 
+// pre[t] = number of (tile, offset) pairs of the tiles before tile t, for the three mask tables of a level
+// (blockIdx.y: 0 = 3^3, 1 = stride-2 down, 2 = transposed up) and two tile heights (blockIdx.z: 64 / 128 rows); one
+// workgroup per (level, table, height), serial over 1024-tile chunks (a 1 M-voxel level has 16 k tiles)
+__global__ void __launch_bounds__(1024) k_tile_prefix(const LevelSet S) {
+  __shared__ int lds[17];
+  __shared__ int carry;
+  const Level& lv = S.lv[blockIdx.x];
+  const int gpt = blockIdx.z ? 8 : 4;   // 16-row groups per tile
+  const uint32_t* gmask;
+  int* pre;
+  int npad;
+  if (blockIdx.y == 0) {
+    gmask = lv.gmask27, pre = blockIdx.z ? lv.pre27b : lv.pre27, npad = lv.npad;
+  } else {
+    if ((int)blockIdx.x >= A3D_NUM_LEVELS - 1) return;
+    if (blockIdx.y == 1) gmask = lv.gmask_down, pre = blockIdx.z ? lv.pre_downb : lv.pre_down, npad = S.lv[blockIdx.x + 1].npad;
+    else gmask = lv.gmask_up, pre = blockIdx.z ? lv.pre_upb : lv.pre_up, npad = lv.npad;
+  }
+  const int ntile = npad / (16 * gpt);
+  if (threadIdx.x == 0) carry = 0;
+  __syncthreads();
+  for (int t0 = 0; t0 < ntile; t0 += 1024) {
+    const int t = t0 + threadIdx.x;
+    int c = 0;
+    if (t < ntile) {
+      uint32_t un = 0;
+      for (int q = 0; q < gpt; ++q) un |= gmask[gpt * t + q];
+      c = __popc(un);
+    }
+    int total;
+    const int incl = block_incl_scan(c, lds, &total);
+    const int base = carry;
+    if (t < ntile) pre[t] = base + incl - c;
+    __syncthreads();
+    if (threadIdx.x == 0) carry = base + total;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) pre[ntile] = carry;
+}
+
 // coordinates in the new row order + hash values -> new rows (one launch over max(n, capacity) per level)
 __global__ void k_xyzb_hashfix(const LevelSet S) {
   int lb;
@@ -546,8 +586,14 @@ static void carve_phase2(Bump& b, const int* sizes, a3d_scene* sc, Phase2Tmp& t,
     lv.hvals = b.take<int>((size_t)lv.hmask + 1);
     lv.nbr27 = b.take<int>((size_t)27 * lv.npad);
     lv.order27 = b.take<int>(lv.npad / 64);
+    lv.pre27 = b.take<int>(lv.npad / 64 + 1);
+    lv.pre27b = b.take<int>(lv.npad / 128 + 1);
     if (L < A3D_NUM_LEVELS - 1) {
       const int npadC = sc->lv[L + 1].npad;
+      lv.pre_down = b.take<int>(npadC / 64 + 1);
+      lv.pre_up = b.take<int>(lv.npad / 64 + 1);
+      lv.pre_downb = b.take<int>(npadC / 128 + 1);
+      lv.pre_upb = b.take<int>(lv.npad / 128 + 1);
       lv.child8 = b.take<int>((size_t)8 * npadC);
       lv.up8 = b.take<int>((size_t)8 * lv.npad);
     }
@@ -788,6 +834,7 @@ extern "C" int a3d_scene_create(const int32_t* coords4_dev, int64_t n_voxels, vo
   k_up<<<g, T, 0, st>>>(S);
   A3D_LAUNCH_CHECK();
   k_orig_row<<<nblk(n0, T), T, 0, st>>>(p.vals_sorted, sc->lv[0].inv, n0, sc->orig_row);
+  k_tile_prefix<<<dim3(NL, 3, 2), 1024, 0, st>>>(S);   // all three mask tables are final here
   A3D_LAUNCH_CHECK();
   *out = sc;
   return A3D_OK;
@@ -827,6 +874,9 @@ extern "C" int a3d_scene_table(const a3d_scene* s, int level, int which, const v
     case A3D_TAB_NBR27: *ptr_dev = lv.nbr27; *count = (int64_t)27 * lv.npad; break;
     case A3D_TAB_GMASK27: *ptr_dev = lv.gmask27; *count = lv.npad / 16; break;
     case A3D_TAB_ORDER27: *ptr_dev = lv.order27; *count = lv.npad / 64; break;
+    case A3D_TAB_PRE27: *ptr_dev = lv.pre27; *count = lv.npad / 64 + 1; break;
+    case A3D_TAB_PREDOWN: if (!has_coarse) goto bad; *ptr_dev = lv.pre_down; *count = npadC / 64 + 1; break;
+    case A3D_TAB_PREUP: if (!has_coarse) goto bad; *ptr_dev = lv.pre_up; *count = lv.npad / 64 + 1; break;
     case A3D_TAB_CHILD8: if (!has_coarse) goto bad; *ptr_dev = lv.child8; *count = (int64_t)8 * npadC; break;
     case A3D_TAB_GMASKDOWN: if (!has_coarse) goto bad; *ptr_dev = lv.gmask_down; *count = npadC / 16; break;
     case A3D_TAB_UP8: if (!has_coarse) goto bad; *ptr_dev = lv.up8; *count = (int64_t)8 * lv.npad; break;

@@ -350,6 +350,396 @@ __global__ void __launch_bounds__(256, CH >= 64 ? 2 : 3) k_spconv2(const ConvArg
   }
 }
 
+// ------------------------------------------------------------------------------ k_conv_sk
+// Third-generation kernel: the stage loop of k_spconv2 with
+//   * a STATIC equal-share partition of the layer's work ("stream-K"): the (cout block, 64-row tile, offset, channel
+//     chunk) stages of a layer form one line; workgroup w of G owns the stretch [w Tot / G, (w+1) Tot / G) of it
+//     (cost of a tile = its number of stages + `ov` units for its prologue/epilogue, prefix sums from the scene's
+//     pre27 / pre_down / pre_up tables).  No tile queue, no last partly-filled round, no split-K launch geometry
+//     and no separate reduction kernel: a tile cut by a share boundary is finished by the workgroup that holds its
+//     LAST stages (the owner); the others hand it their partial accumulators through a slab in global memory
+//     (write-through stores + one flag per workgroup, agent-scope acquire on the reader: cdna_hip_programming.md
+//     Guideline 16).  Summation order is fixed (ascending stage ranges), so results are bit-identical run to run.
+//     Deadlock freedom does not depend on dispatch order or residency: the logical index w is a ticket drawn at
+//     start-up, a workgroup computes the part it must PUBLISH first and the part it must WAIT for last, and it
+//     only ever waits for lower tickets -- whose holders have started and publish without waiting for anybody.
+//   * a lean stage: gather rows are byte offsets (32-bit VGPR offset + scalar base: no 64-bit vector address
+//     arithmetic), the A fragments alternate between two register sets (stage loop unrolled by two: no copies),
+//     the weight DMA addresses are scalar base + constant per-lane offsets.  The VALU instructions of a stage that
+//     are not MFMAs compete with the co-resident workgroup's MFMA stream for the SIMD's issue port.
+struct SkArgs {
+  ConvArgs c;
+  const int* pre;        // [n_tiles + 1] (tile, offset) pairs before each tile; nullptr: K per tile
+  int nchunk, ov;
+  int n_cblk;            // cout / BN
+  int G;                 // workgroups launched (shares; the kernel uses min(G, total cost))
+  int* ticket;           // zeroed by the caller; nullptr: whole tiles only (no hand-offs), w = blockIdx.x
+  unsigned* flags;       // [G] zeroed by the caller
+  float* slab;           // [G][64 * BN] partial accumulators
+  unsigned in_row_bytes; // ldi * 4
+  int* fail;             // set when a bounded wait ran out (never in a healthy run)
+  int dbg;               // A3D_DBG ablations: 1 no A gather, 2 no weight DMA, 4 no MFMA, 8 no stage-end vmcnt wait
+};
+
+__device__ __forceinline__ void store_sc1(float* p, f32x4 v) {   // write-through (agent scope) 16-byte store
+  asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+}
+// global -> LDS DMA with a scalar base and a 32-bit per-lane byte offset; M0 = LDS destination (saved and restored:
+// scalar instructions only)
+__device__ __forceinline__ void glds16_s(const float* sbase, unsigned voff, unsigned lds_byte_addr) {
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\t"
+      "s_mov_b32 m0, %3\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %1, %2\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(voff), "s"(sbase), "s"(lds_byte_addr)
+      : "memory");
+}
+
+// s_waitcnt vmcnt(0) through the builtin: unlike an asm statement the compiler's wait-count pass models it, so it
+// knows every load it tracks (the A fragments) has landed and inserts no conservative vmcnt of its own in front of
+// the MFMAs -- which would also wait for the LDS-DMA pieces it cannot see.  simm16: vmcnt 0, expcnt 7, lgkmcnt 15.
+__device__ __forceinline__ void wait_all_vmem() { __builtin_amdgcn_s_waitcnt(0x0F70); }
+
+template <int BN, int CH, int RG>   // BN output columns, CH input channels per stage, RG 16-row groups per wave
+__global__ void __launch_bounds__(256, 2) k_conv_sk(const SkArgs a) {
+  constexpr int NCT = BN / 16, NS = CH / 16, NW = 4, kTile = 64 * RG;
+  constexpr int NPIECE = NS * NCT;
+  constexpr int WV = (NPIECE + NW - 1) / NW;
+  constexpr int WF = NPIECE * 256;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* wring = (float*)smem;                            // [2][WF]
+  int* misc = (int*)(wring + 2 * WF);
+  const unsigned ring_addr = (unsigned)(size_t)wring;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = lane >> 4, j = lane & 15;
+  const int K = a.c.K, nchunk = a.nchunk, ov = a.ov;
+  const int T = a.c.n_tiles;
+  const int cin16 = a.c.cin >> 4, cout16 = a.c.cout >> 4;
+
+  int w = blockIdx.x;
+  if (a.ticket) {
+    if (tid == 0) misc[0] = atomicAdd(a.ticket, 1);
+    __syncthreads();
+    w = __builtin_amdgcn_readfirstlane(misc[0]);
+  }
+  if (w == 0 && a.c.zero_row >= 0)
+    for (int cidx = tid; cidx < a.c.cout; cidx += 256) a.c.out[(size_t)a.c.zero_row * a.c.ldo + cidx] = 0.f;
+
+  auto prefix = [&](int t) -> long long {   // cost units of one cout block before tile t
+    const long long n = a.pre ? (long long)a.pre[t] : (long long)K * t;
+    return n * nchunk + (long long)ov * t;
+  };
+  const long long tile_tot = prefix(T);                       // one pass over all tiles
+  const long long tot = (long long)a.n_cblk * tile_tot;
+  const int G = (int)min((long long)a.G, tot);
+  if (w >= G) return;
+  auto share_begin = [&](int ww) -> long long { return tot * ww / G; };
+  // 64-ary search, every wave on its own (no LDS): lane i probes the i-th of 64 evenly spaced tiles of the current
+  // range, a ballot finds the last one at or below r; three rounds cover 2^18 tiles (a binary search is 13+ dependent
+  // loads per workgroup before its first MFMA)
+  auto locate = [&](long long x) -> int {
+    const int cb = (int)(x / tile_tot);
+    const long long r = x - (long long)cb * tile_tot;
+    int lo_t = 0, hi_t = T;   // prefix(lo_t) <= r < prefix(hi_t)
+    while (hi_t - lo_t > 1) {
+      const int span = hi_t - lo_t;
+      const int step = (span + 63) >> 6;
+      const int tp = lo_t + lane * step;                       // lane 0 probes lo_t itself (always <= r)
+      const bool le = tp < hi_t && prefix(tp) <= r;
+      const unsigned long long m = __ballot(le);
+      const int last = 63 - __builtin_clzll(m);                // m has bit 0 set
+      const int nlo = lo_t + last * step;
+      hi_t = min(hi_t, nlo + step);
+      lo_t = nlo;
+    }
+    return cb * T + __builtin_amdgcn_readfirstlane(lo_t);
+  };
+
+  long long lo, hi;
+  int u_lo, u_hi;
+  if (a.ticket) {
+    lo = share_begin(w);
+    hi = share_begin(w + 1);
+    if (hi <= lo) return;
+    u_lo = locate(lo);
+    u_hi = locate(hi - 1);
+  } else {   // whole tiles: no tile is shared (w < a.G <= number of tiles: the launch guarantees it)
+    const long long NU = (long long)a.n_cblk * T;
+    u_lo = (int)(NU * w / a.G);
+    u_hi = (int)(NU * (w + 1) / a.G) - 1;
+    if (u_hi < u_lo) return;
+    lo = 0;
+    hi = tot;
+  }
+
+  // this wave's weight pieces q = wave + NW*i of a stage: constant per-lane source byte offset, LDS byte offset
+  unsigned wsrc[WV], wdst[WV];
+#pragma unroll
+  for (int i = 0; i < WV; ++i) {
+    const int q = wave + NW * i;
+    wsrc[i] = (unsigned)(((q / NCT) * cout16 + (q % NCT)) * 1024 + lane * 16);
+    wdst[i] = (unsigned)q * 1024u;
+  }
+  const unsigned lane_a_off = 16u * g;   // channels 4g..4g+3 of a 16-channel step
+  const int wrow = 16 * RG * wave + j;   // this lane's row inside the tile for its group 0 (group r: + 16 r)
+
+  const int n_u = u_hi - u_lo + 1;
+  for (int it = 0; it < n_u; ++it) {
+    // order: the tile at the END of the share first (its part is published), the tile at the START last (it may wait)
+    const int u = n_u == 1 ? u_lo : (it == 0 ? u_hi : (it == n_u - 1 ? u_lo : u_lo + it));
+    const int cb = u / T, t = u - cb * T;
+    const int ct0 = cb * NCT;
+    const int r0 = t * kTile;
+    // gm: offsets this wave works on = those any of its RG groups has (with two groups per wave a group that lacks
+    // one of them gathers the zero row for it: rows are sorted by neighbour pattern, adjacent groups rarely differ)
+    uint32_t un = K >= 32 ? 0xffffffffu : (1u << K) - 1u, gm = un;
+    if (a.c.gmask) {
+      const uint32_t* gp = a.c.gmask + (r0 >> 4);
+      uint32_t o = 0;
+#pragma unroll
+      for (int q = 0; q < 4 * RG; ++q) o |= gp[q];
+      un &= o;
+      gm = 0;
+#pragma unroll
+      for (int r = 0; r < RG; ++r) gm |= gp[RG * wave + r];
+    }
+    un = __builtin_amdgcn_readfirstlane(un);
+    gm = __builtin_amdgcn_readfirstlane(gm);
+    const int S = __builtin_popcount(un) * nchunk;
+    int s0 = 0, s1 = S;
+    bool owner = true;
+    long long Cu = 0;
+    if (a.ticket) {
+      Cu = (long long)cb * tile_tot + prefix(t);
+      const long long Cu1 = (long long)cb * tile_tot + prefix(t + 1);
+      if (lo > Cu) s0 = (int)min((long long)S, max(0LL, lo - Cu - ov));
+      if (hi < Cu1) {
+        s1 = (int)min((long long)S, max(0LL, hi - Cu - ov));
+        owner = false;
+      }
+      if (!owner && s1 <= s0) continue;   // only overhead units of this tile fall into the share
+    }
+
+    f32x4 acc[RG][NCT];
+#pragma unroll
+    for (int r = 0; r < RG; ++r)
+#pragma unroll
+      for (int ct = 0; ct < NCT; ++ct) acc[r][ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    if (s1 > s0) {
+      auto next_k = [&](int k) -> int {   // next offset of the tile after k (32 = none)
+        const uint32_t rest = k >= 31 ? 0u : un & ~((2u << k) - 1u);
+        return rest ? __builtin_ctz(rest) : 32;
+      };
+      // first stage of the part: skip s0 / nchunk offsets
+      int k = __builtin_ctz(un), c = s0 % nchunk;
+      for (int i = s0 / nchunk; i > 0; --i) k = next_k(k);
+      int rem = s1 - s0;
+      const float* wbase = a.c.w + (size_t)ct0 * 256;
+      const char* inb = (const char*)a.c.in;
+      // gather rows of offset kk for this lane's groups, straight from the neighbour table (requested one offset
+      // before the A loads that need them); a missing neighbour is the zero row
+      auto fetch_rows = [&](int kk, int (&rows)[RG]) {
+        const int kc = kk < 32 ? kk : 0;   // unconditional loads (no select behind them: the loop-carried register is
+                                           // the load's destination, nothing waits for it before its use a stage later)
+#pragma unroll
+        for (int r = 0; r < RG; ++r)
+          rows[r] = a.c.nbr ? a.c.nbr[(size_t)kc * a.c.nbr_stride + r0 + wrow + 16 * r] : min(r0 + wrow + 16 * r, a.c.n_in - 1);
+      };
+      // stage (k, c): this lane's A fragments (for its groups that have k), this wave's weight pieces by LDS-DMA
+      auto load_stage = [&](f32x4 (&A)[RG][NS], int kk, int cc, int slot, const int (&rows)[RG]) {
+        const char* ar = inb + (size_t)cc * (CH * 4);
+        if (((gm >> kk) & 1u) && !(a.dbg & 1)) {
+#pragma unroll
+          for (int r = 0; r < RG; ++r) {
+            const unsigned roff = (unsigned)rows[r] * a.in_row_bytes + lane_a_off;
+#pragma unroll
+            for (int Sx = 0; Sx < NS; ++Sx) A[r][Sx] = *(const f32x4*)(ar + roff + 64 * Sx);
+          }
+        }
+        const float* wst = wbase + ((size_t)kk * cin16 + (size_t)cc * NS) * cout16 * 256;
+        const unsigned dst = ring_addr + (unsigned)slot * (WF * 4u);
+#pragma unroll
+        for (int i = 0; i < WV; ++i)
+          if ((NPIECE % NW == 0 || wave + NW * i < NPIECE) && !(a.dbg & 2)) glds16_s(wst, wsrc[i], dst + wdst[i]);
+      };
+      auto compute = [&](const f32x4 (&A)[RG][NS], int kk, int slot) {
+        if (!((gm >> kk) & 1u) || (a.dbg & 4)) return;
+        const f32x4* Ws = (const f32x4*)(wring + slot * WF) + lane;
+        if constexpr (RG == 1) {
+          // one group per wave: the weight fragments of a whole 16-channel step in registers, the next step's read
+          // behind this step's MFMAs; consecutive MFMAs go to different accumulators
+          f32x4 b[2][NCT];
+#pragma unroll
+          for (int ct = 0; ct < NCT; ++ct) b[0][ct] = Ws[ct * 64];
+#pragma unroll
+          for (int Sx = 0; Sx < NS; ++Sx) {
+            if (Sx + 1 < NS) {
+#pragma unroll
+              for (int ct = 0; ct < NCT; ++ct) b[(Sx + 1) & 1][ct] = Ws[((Sx + 1) * NCT + ct) * 64];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+              for (int ct = 0; ct < NCT; ++ct)
+                acc[0][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[Sx & 1][ct][tt], A[0][Sx][tt], acc[0][ct], 0, 0, 0);
+          }
+        } else {
+          // two groups per wave share every weight fragment: ONE fragment (4 registers) feeds 8 MFMAs (two
+          // accumulators alternating), the next fragment's ds_read_b128 is in flight behind them -- the weight
+          // operand costs 8 registers instead of 2 * 4 * NCT
+          f32x4 bc = Ws[0];
+#pragma unroll
+          for (int Sx = 0; Sx < NS; ++Sx) {
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct) {
+              f32x4 bn = bc;
+              if (Sx * NCT + ct + 1 < NS * NCT) bn = Ws[(Sx * NCT + ct + 1) * 64];
+              __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+              for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+                for (int r = 0; r < RG; ++r)
+                  acc[r][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(bc[tt], A[r][Sx][tt], acc[r][ct], 0, 0, 0);
+              __builtin_amdgcn_sched_barrier(0);
+              bc = bn;
+            }
+          }
+        }
+      };
+      f32x4 A0[RG][NS], A1[RG][NS];
+      if (a.dbg & 1) {
+#pragma unroll
+        for (int r = 0; r < RG; ++r)
+#pragma unroll
+          for (int Sx = 0; Sx < NS; ++Sx) A0[r][Sx] = A1[r][Sx] = (f32x4){1.f, 2.f, 3.f, 4.f};
+      }
+      int rows_cur[RG], rows_nxt[RG];
+      int k1 = next_k(k);
+      fetch_rows(k, rows_cur);
+      fetch_rows(k1, rows_nxt);
+      load_stage(A0, k, c, 0, rows_cur);
+      wait_all_vmem();
+      __builtin_amdgcn_s_barrier();
+      for (;;) {
+        int k2, c2;
+        // ---- even stage: multiply A0 / slot 0, fetch A1 / slot 1
+        if (c + 1 < nchunk) { k2 = k; c2 = c + 1; } else { k2 = k1; c2 = 0; }
+        if (rem > 1) {
+          if (k2 != k) {
+#pragma unroll
+            for (int r = 0; r < RG; ++r) rows_cur[r] = rows_nxt[r];
+            k1 = next_k(k2);
+            fetch_rows(k1, rows_nxt);
+          }
+          load_stage(A1, k2, c2, 1, rows_cur);
+        }
+        compute(A0, k, 0);
+        wait_all_vmem();
+        __builtin_amdgcn_s_barrier();
+        if (--rem == 0) break;
+        k = k2; c = c2;
+        // ---- odd stage: multiply A1 / slot 1, fetch A0 / slot 0
+        if (c + 1 < nchunk) { k2 = k; c2 = c + 1; } else { k2 = k1; c2 = 0; }
+        if (rem > 1) {
+          if (k2 != k) {
+#pragma unroll
+            for (int r = 0; r < RG; ++r) rows_cur[r] = rows_nxt[r];
+            k1 = next_k(k2);
+            fetch_rows(k1, rows_nxt);
+          }
+          load_stage(A0, k2, c2, 0, rows_cur);
+        }
+        compute(A1, k, 1);
+        wait_all_vmem();
+        __builtin_amdgcn_s_barrier();
+        if (--rem == 0) break;
+        k = k2; c = c2;
+      }
+    }
+
+    if (!owner) {
+      // publish this part: write-through stores, every wave drains, one flag
+      float* P = a.slab + (size_t)w * (kTile * BN) + (size_t)tid * 4;
+#pragma unroll
+      for (int r = 0; r < RG; ++r)
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct) store_sc1(P + (r * NCT + ct) * 1024, acc[r][ct]);
+      wait_all_vmem();
+      __syncthreads();
+      if (tid == 0) __hip_atomic_store(a.flags + w, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+      if (s0 > 0) {
+        // parts of the lower tickets, down to the workgroup that holds stage 0
+        // (the largest w' with share_begin(w') <= Cu + ov: floor(tot w' / G) <= X  <=>  w' < (X + 1) G / tot)
+        const int wf = (int)(((Cu + ov + 1) * G + tot - 1) / tot) - 1;
+        // every flag is polled by its own thread; ONE acquire for the workgroup; then the parts are read with all
+        // their loads in flight and added in a fixed order
+        for (int wp = wf + tid; wp < w; wp += 256) {
+          unsigned spins = 0;
+          while (__hip_atomic_load(a.flags + wp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+            __builtin_amdgcn_s_sleep(2);
+            if (++spins > (1u << 24)) {   // seconds: never in a healthy run; do not hang the device
+              if (a.fail) *a.fail = 1;
+              break;
+            }
+          }
+        }
+        __syncthreads();
+        if (tid == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        __syncthreads();
+        const float* P0 = a.slab + (size_t)tid * 4;
+        for (int wp = w - 1; wp >= wf; --wp) {   // fixed order: own part, then the parts of the tickets below, descending
+          const float* Pa = P0 + (size_t)wp * (kTile * BN);
+          f32x4 pa[RG][NCT];
+#pragma unroll
+          for (int r = 0; r < RG; ++r)
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct) pa[r][ct] = *(const f32x4*)(Pa + (r * NCT + ct) * 1024);
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int r = 0; r < RG; ++r)
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct) acc[r][ct] += pa[r][ct];
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < RG; ++r) {
+        const int myrow = r0 + wrow + 16 * r;
+        if (myrow < a.c.n_out) {
+          const int orow = a.c.out_map ? a.c.out_map[myrow] : myrow;
+          float* po = a.c.out + (size_t)orow * a.c.ldo + ct0 * 16 + 4 * g;
+          const float* pr = a.c.res ? a.c.res + (size_t)orow * a.c.ldr + ct0 * 16 + 4 * g : nullptr;
+          f32x4 rv[NCT];
+          if (pr) {
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct) rv[ct] = *(const f32x4*)(pr + ct * 16);
+          }
+#pragma unroll
+          for (int ct = 0; ct < NCT; ++ct) {
+            f32x4 v = acc[r][ct];
+            if (a.c.scale) v *= *(const f32x4*)(a.c.scale + (ct0 + ct) * 16 + 4 * g);
+            if (a.c.shift) v += *(const f32x4*)(a.c.shift + (ct0 + ct) * 16 + 4 * g);
+            if (pr) v += rv[ct];
+            if (a.c.relu) {
+#pragma unroll
+              for (int tt = 0; tt < 4; ++tt) v[tt] = fmaxf(v[tt], 0.f);
+            }
+            *(f32x4*)(po + ct * 16) = v;
+          }
+        }
+      }
+    }
+  }
+}
+
 static int conv2_ch(int cin, int bn) {   // input channels per stage: largest of 96/64/32 dividing cin with a ring <= 74 KB
   static int forced = -1;
   if (forced < 0) {
@@ -688,7 +1078,8 @@ struct ConvPlan {
   size_t lds, partial_floats;
 };
 
-constexpr int kMaxQueuesPerOp = 128;   // cout tiles x k splits
+constexpr int kMaxQueuesPerOp = 1024;  // ints of zeroed per-op state: k_conv_sk ticket [0], failure word [1], hand-off flags [2..2+G)
+constexpr int kSkMaxG = 512;
 
 static ConvPlan plan_conv(int n_rows, int K, int cin, int cout) {
   ConvPlan p;
@@ -718,6 +1109,60 @@ static ConvPlan plan_conv(int n_rows, int K, int cin, int cout) {
   return p;
 }
 
+
+// ---- k_conv_sk: launch geometry
+struct SkPlan {
+  int bn, ch, rg, nchunk, ov, n_cblk, G, ntile;
+  size_t lds, slab_floats;
+};
+static int sk_env(const char* name, int dflt) {
+  const char* e = getenv(name);
+  return e ? atoi(e) : dflt;
+}
+static int sk_ch(int cin, int bn) {   // input channels per stage: largest of 96/64/32 dividing cin whose two-slot ring fits
+  const int cand[3] = {96, 64, 32};
+  for (int i = 0; i < 3; ++i)
+    if (cin % cand[i] == 0 && 2 * cand[i] * bn * 4 + 64 <= 80 * 1024) return cand[i];
+  return 0;
+}
+static SkPlan plan_sk(int n_rows, int K, int cin, int cout, bool handoff) {
+  static int ov_env = sk_env("A3D_SK_OV", 0), share_env = sk_env("A3D_SK_MINSHARE", 0), g_env = sk_env("A3D_SK_G", 0);
+  static int rg_env = sk_env("A3D_SK_RG", 0), rg_rows = sk_env("A3D_SK_RG_ROWS", 200000);
+  SkPlan p;
+  p.rg = rg_env ? rg_env : (n_rows >= rg_rows ? 2 : 1);   // 16-row groups per wave: 64- or 128-row tiles
+  p.ntile = (n_rows + 64 * p.rg - 1) / (64 * p.rg);
+  if (p.ntile < 1) p.ntile = 1;
+  const int k_eff = K == 27 ? 13 : K;   // a 3^3 map has 11-17 of its 27 offsets per tile (the kernel uses the exact counts)
+  int gmax = g_env ? g_env : 512;
+  if (gmax > kSkMaxG) gmax = kSkMaxG;
+  for (int pass = 0; pass < 2; ++pass) {
+    p.bn = (cout % 128 == 0) ? 128 : cout;
+    // a level too small to give every CU a share with 128-column workgroups is cut into 64-column ones: twice the
+    // shares for the same number of workgroups per tile (the gathers of a tile are repeated, its stages are not)
+    if (pass == 1 && cout % 64 == 0 && p.bn > 64) p.bn = 64;
+    p.ch = sk_ch(cin, p.bn);
+    p.nchunk = p.ch ? cin / p.ch : 1;
+    p.n_cblk = cout / p.bn;
+    const int mfma_per_stage = p.ch / 4 * (p.bn / 16) * p.rg;
+    p.ov = ov_env ? ov_env : (mfma_per_stage >= 128 ? 1 : 2);
+    p.lds = (size_t)2 * p.ch * p.bn * 4 + 64;
+    const long long est = (long long)p.n_cblk * p.ntile * ((long long)p.nchunk * k_eff + p.ov);
+    const int min_share = share_env ? share_env : (mfma_per_stage >= 128 ? 6 : 8);
+    if (handoff) {
+      long long G = est / min_share;
+      p.G = (int)(G < 1 ? 1 : (G > gmax ? gmax : G));
+      p.slab_floats = (size_t)p.G * 64 * p.rg * p.bn;
+      if (p.G >= 256 || p.bn <= 64 || cout % 64) break;
+    } else {
+      const long long nu = (long long)p.n_cblk * p.ntile;
+      p.G = (int)(nu < gmax ? nu : gmax);
+      p.slab_floats = 0;
+      break;
+    }
+  }
+  return p;
+}
+
 static void allow_big_lds() {
   static bool done = false;
   if (done) return;
@@ -728,13 +1173,28 @@ static void allow_big_lds() {
   A3D_BIG2(32, 32) A3D_BIG2(32, 64) A3D_BIG2(32, 96) A3D_BIG2(64, 32) A3D_BIG2(64, 64) A3D_BIG2(64, 96)
   A3D_BIG2(96, 32) A3D_BIG2(96, 48) A3D_BIG2(96, 64) A3D_BIG2(96, 96) A3D_BIG2(128, 32) A3D_BIG2(128, 64)
 #undef A3D_BIG2
+#define A3D_BIG3(BN_, CH_) \
+  (void)hipFuncSetAttribute((const void*)k_conv_sk<BN_, CH_, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+  (void)hipFuncSetAttribute((const void*)k_conv_sk<BN_, CH_, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  A3D_BIG3(32, 32) A3D_BIG3(32, 64) A3D_BIG3(32, 96) A3D_BIG3(64, 32) A3D_BIG3(64, 64) A3D_BIG3(64, 96)
+  A3D_BIG3(96, 32) A3D_BIG3(96, 64) A3D_BIG3(96, 96) A3D_BIG3(128, 32) A3D_BIG3(128, 64)
+#undef A3D_BIG3
   (void)hipFuncSetAttribute((const void*)k_dense<8, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   (void)hipFuncSetAttribute((const void*)k_dense<8, 6>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   (void)hipFuncSetAttribute((const void*)k_dense<6, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   (void)hipFuncSetAttribute((const void*)k_dense<6, 6>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 }
 
-static int launch_conv(ConvArgs a, float* partial_ws, size_t partial_ws_floats, int* queue_heads, hipStream_t st) {
+static int launch_conv_sk(ConvArgs c, const int* pre64, const int* pre128, float* slab_ws, size_t slab_ws_floats, int* state, hipStream_t st);
+static bool use_sk() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("A3D_CONV_SK"); v = e ? atoi(e) : 1; }
+  return v != 0;
+}
+static int launch_conv(ConvArgs a, float* partial_ws, size_t partial_ws_floats, int* queue_heads, hipStream_t st,
+                       const int* pre = nullptr, const int* pre128 = nullptr) {
+  if (use_sk() && (a.K == 1 || (pre && pre128)))
+    return launch_conv_sk(a, pre, pre128, partial_ws, partial_ws_floats, queue_heads, st);
   allow_big_lds();
   {
     static int dbg = -1;
@@ -825,6 +1285,74 @@ static int launch_conv(ConvArgs a, float* partial_ws, size_t partial_ws_floats, 
   return A3D_OK;
 }
 
+
+static int launch_conv_sk(ConvArgs c, const int* pre64, const int* pre128, float* slab_ws, size_t slab_ws_floats, int* state,
+                          hipStream_t st) {
+  allow_big_lds();
+  if (c.cin % 32 != 0 || c.cout % 16 != 0 || !(c.cout % 128 == 0 || c.cout == 32 || c.cout == 64 || c.cout == 96)) {
+    set_error("spconv: unsupported channels cin=%d cout=%d", c.cin, c.cout);
+    return A3D_ERR_UNSUPPORTED;
+  }
+  if (c.K > 27) {
+    set_error("spconv: kernel volume %d > 27", c.K);
+    return A3D_ERR_UNSUPPORTED;
+  }
+  if ((uint64_t)(c.n_in + 1) * (uint64_t)c.ldi * 4ull >= (1ull << 32)) {
+    set_error("spconv: input of %d rows x %d floats exceeds the 4 GB gather window", c.n_in, c.ldi);
+    return A3D_ERR_UNSUPPORTED;
+  }
+  // hand-offs (shares cut inside tiles) pay where a tile is long and tiles are few: the 3^3 maps, and the 2^3 maps of
+  // the small levels.  1x1 layers and 2^3 maps with a tile per workgroup slot or more run whole tiles: no ticket, no
+  // search, no flags -- their fixed latency is what matters
+  bool handoff = state != nullptr && c.K > 1;
+  if (handoff && c.K <= 8) {
+    const SkPlan q = plan_sk(c.n_out, c.K, c.cin, c.cout, false);
+    if ((long long)q.ntile * q.n_cblk >= 192) handoff = false;
+  }
+  SkPlan p = plan_sk(c.n_out, c.K, c.cin, c.cout, handoff);
+  if (!p.ch) {
+    set_error("spconv: no stage size for cin=%d with %d-column workgroups", c.cin, p.bn);
+    return A3D_ERR_UNSUPPORTED;
+  }
+  if (handoff && p.slab_floats > slab_ws_floats) {
+    set_error("spconv: hand-off workspace too small");
+    return A3D_ERR_WORKSPACE;
+  }
+  SkArgs a;
+  memset(&a, 0, sizeof(a));
+  c.n_tiles = p.ntile;
+  c.kper = c.K;
+  a.c = c;
+  const int* pre = p.rg == 2 ? pre128 : pre64;
+  a.pre = c.K > 1 ? pre : nullptr;
+  a.nchunk = p.nchunk;
+  a.ov = p.ov;
+  a.n_cblk = p.n_cblk;
+  a.G = p.G;
+  a.ticket = handoff ? state : nullptr;
+  a.fail = handoff ? state + 1 : nullptr;
+  a.flags = handoff ? (unsigned*)(state + 2) : nullptr;
+  a.slab = slab_ws;
+  a.in_row_bytes = (unsigned)c.ldi * 4u;
+  {
+    static int dbg = sk_env("A3D_DBG", 0);
+    a.dbg = dbg;
+  }
+  if (c.K > 1 && !pre) {
+    set_error("spconv: a gathered convolution needs the scene's tile prefix table");
+    return A3D_ERR_INVALID;
+  }
+  ProfScope ps(st, A3D_PROF_SPCONV, p.bn, c.K, c.cin, c.cout, c.n_out, c.tag_table, c.tag_level, 1);
+#define A3D_L3(BN_, CH_) \
+  if (p.bn == BN_ && p.ch == CH_) { if (p.rg == 2) k_conv_sk<BN_, CH_, 2><<<p.G, 256, p.lds, st>>>(a); else k_conv_sk<BN_, CH_, 1><<<p.G, 256, p.lds, st>>>(a); } else
+  A3D_L3(32, 32) A3D_L3(32, 64) A3D_L3(32, 96) A3D_L3(64, 32) A3D_L3(64, 64) A3D_L3(64, 96)
+  A3D_L3(96, 32) A3D_L3(96, 64) A3D_L3(96, 96) A3D_L3(128, 32) A3D_L3(128, 64)
+  { set_error("spconv: no kernel for BN %d CH %d", p.bn, p.ch); return A3D_ERR_UNSUPPORTED; }
+#undef A3D_L3
+  A3D_LAUNCH_CHECK();
+  return A3D_OK;
+}
+
 // ------------------------------------------------------------------------------ program
 struct ProgLayout {
   size_t buf_off[64];
@@ -861,6 +1389,8 @@ static int layout_program(const a3d_scene* s, const a3d_buf_desc* bufs, int n_bu
     }
     ConvPlan p = plan_conv(s->lv[lvl_out].n, o.kernel_volume, o.cin, o.cout);
     if (p.partial_floats > pf) pf = p.partial_floats;
+    SkPlan q = plan_sk(s->lv[lvl_out].n, o.kernel_volume, o.cin, o.cout, true);
+    if (q.slab_floats > pf) pf = q.slab_floats;
   }
   L.partial_off = off;
   L.partial_floats = pf;
@@ -1014,6 +1544,8 @@ extern "C" int a3d_program_run(const a3d_scene* s, const a3d_buf_desc* bufs, int
     a.n_out = s->lv[lvl_out].n;
     a.tag_table = o.kind;
     a.tag_level = Lin;
+    const int* pre = nullptr;
+    const int* pre128 = nullptr;
     switch (o.kind) {
       case A3D_OP_CONV3:
         if (o.kernel_volume != 27) { set_error("op %d: CONV3 needs kernel volume 27", i); return A3D_ERR_INVALID; }
@@ -1025,12 +1557,16 @@ extern "C" int a3d_program_run(const a3d_scene* s, const a3d_buf_desc* bufs, int
           if (use_order < 0) { const char* e = getenv("A3D_TILE_ORDER"); use_order = e ? atoi(e) : 1; }
           a.tile_order = use_order ? s->lv[Lin].order27 : nullptr;   // 64-row tiles
         }
+        pre = s->lv[Lin].pre27;
+        pre128 = s->lv[Lin].pre27b;
         break;
       case A3D_OP_DOWN:
         if (o.kernel_volume != 8 || Lin >= A3D_NUM_LEVELS - 1) { set_error("op %d: bad DOWN", i); return A3D_ERR_INVALID; }
         a.nbr = s->lv[Lin].child8;
         a.nbr_stride = s->lv[Lin + 1].npad;
         a.gmask = s->lv[Lin].gmask_down;
+        pre = s->lv[Lin].pre_down;
+        pre128 = s->lv[Lin].pre_downb;
         break;
       case A3D_OP_UP:
         if (o.kernel_volume != 8 || Lin < 1) { set_error("op %d: bad UP", i); return A3D_ERR_INVALID; }
@@ -1038,6 +1574,8 @@ extern "C" int a3d_program_run(const a3d_scene* s, const a3d_buf_desc* bufs, int
         a.nbr_stride = s->lv[Lin - 1].npad;
         a.gmask = s->lv[Lin - 1].gmask_up;
         a.out_map = s->lv[Lin - 1].up_rows;
+        pre = s->lv[Lin - 1].pre_up;
+        pre128 = s->lv[Lin - 1].pre_upb;
         break;
       case A3D_OP_LINEAR:
         if (o.kernel_volume != 1) { set_error("op %d: LINEAR needs kernel volume 1", i); return A3D_ERR_INVALID; }
@@ -1050,7 +1588,7 @@ extern "C" int a3d_program_run(const a3d_scene* s, const a3d_buf_desc* bufs, int
       rc = launch_dense(a.in, a.ldi, nullptr, 0, a.n_out, a.cin, a.cout, a.w, a.scale, a.shift, a.res, a.ldr, a.relu,
                         a.out, a.ldo, a.zero_row, Lin, a.out_map, st);
     else
-      rc = launch_conv(a, partial, L.partial_floats, queues + (size_t)i * kMaxQueuesPerOp, st);
+      rc = launch_conv(a, partial, L.partial_floats, queues + (size_t)i * kMaxQueuesPerOp, st, pre, pre128);
     if (rc != A3D_OK) return rc;
   }
   return A3D_OK;

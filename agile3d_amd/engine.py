@@ -329,6 +329,7 @@ class _SceneState:
         self.posenc = None      # list[Tensor [n_b,128]]
         self.minmax = None      # list[Tensor [6]]
         self.engine_id = None
+        self.train = False      # produced by the training-mode forward (no inference workspace, aux placeholders)
 
 
 class Engine:
@@ -337,26 +338,48 @@ class Engine:
         self.model = model
         self.device = device
         self._stale = True
+        self._stale_dec = True
         self._version = None
+        self._version_dec = None
+        self._dec_tensors = None
+        self._all_tensors = None
         self.program = None
         self.decoder = None
 
     def mark_stale(self):
         self._stale = True
+        self._stale_dec = True
 
-    def _weights_version(self):
-        return sum(int(t._version) for t in self.model.state_dict(keep_vars=True).values())
+    def _weights_version(self, decoder_only=False):
+        if self._dec_tensors is None:
+            sd = self.model.state_dict(keep_vars=True)
+            self._all_tensors = list(sd.values())
+            self._dec_tensors = [v for k, v in sd.items() if not k.startswith("backbone.") and not k.startswith("lin_squeeze_head.")]
+        return sum(int(t._version) for t in (self._dec_tensors if decoder_only else self._all_tensors))
 
     def refresh_weights_if_stale(self, check_versions=False):
+        """Packed weights of the inference path: the folded/packed backbone program and the decoder pack.  They are
+        rebuilt when marked stale or (``check_versions``) when a parameter tensor was written since (an optimiser step)."""
         if not self._stale and check_versions:
             if self._weights_version() != self._version:
-                self._stale = True
+                self._stale = self._stale_dec = True
         if self._stale:
             with torch.no_grad():
                 self.program = BackboneProgram(self.model, self.device)
-                self.decoder = DecoderPack(self.model, self.device)
             self._version = self._weights_version()
             self._stale = False
+        self.refresh_decoder_if_stale()
+
+    def refresh_decoder_if_stale(self, check_versions=False):
+        """The decoder's packed weights only: what forward_mask needs (the no-grad click rounds of a training
+        iteration, engine.py:82-115, must not re-fold and re-pack the whole backbone)."""
+        if not self._stale_dec and check_versions and self._weights_version(True) != self._version_dec:
+            self._stale_dec = True
+        if self._stale_dec or self.decoder is None:
+            with torch.no_grad():
+                self.decoder = DecoderPack(self.model, self.device)
+            self._version_dec = self._weights_version(True)
+            self._stale_dec = False
 
     # ---------------------------------------------------------------- forward_backbone
     def forward_backbone(self, x, raw_coordinates=None):
@@ -396,12 +419,85 @@ class Engine:
         pos_encodings_pcd = [[[None] * len(st.ranges)] for _ in range(4)] + [[list(st.posenc)]]
         return pcd_features, aux, coordinates, pos_encodings_pcd
 
+    def forward_backbone_train(self, x, raw_coordinates=None):
+        """``forward_backbone`` of a model in training mode (engine.py:53 of the reference): BatchNorm on the statistics
+        of this batch (running statistics updated), every activation kept for the backward pass (BackboneTape), the
+        result tied into torch.autograd -- ``pcd_features.F`` depends on every backbone parameter."""
+        from .autograd import BackboneFn, _Holder
+        from .train_backbone import BackboneTape
+        lib = L.load()
+        self.refresh_decoder_if_stale(check_versions=True)      # gauss_B for the position encodings
+        if not isinstance(x, SparseTensor) or x.device != self.device:
+            x = SparseTensor(features=x.F, coordinates=x.C, device=self.device)
+        if raw_coordinates is None:
+            raise ValueError("forward_backbone needs raw_coordinates (agile3d.py:163)")
+        raw = raw_coordinates.to(self.device, torch.float32).contiguous()
+        n = len(x)
+        if raw.shape != (n, 3):
+            raise ValueError("raw_coordinates must be [N,3]")
+        st = _SceneState()
+        st.engine_id = id(self)
+        st.train = True
+        with torch.no_grad():
+            st.scene = Scene(x.C)
+            tape = BackboneTape(self.model, st.scene, x.F.detach())
+            st.ranges = st.scene.batch_ranges
+            st.posenc, st.minmax = [], []
+            tmp = torch.empty(256 * 6 * 4, dtype=torch.uint8, device=self.device)
+            for (s, e) in st.ranges:
+                nb = e - s
+                pe = torch.empty((nb, 128), dtype=torch.float32, device=self.device)
+                mm = torch.empty(6, dtype=torch.float32, device=self.device)
+                L.check(lib.a3d_posenc_fourier(_ptr(raw[s:e]), nb, self.decoder.gauss_B_ptr, _ptr(mm), _ptr(pe),
+                                               _ptr(tmp), tmp.numel(), _stream()), "a3d_posenc_fourier")
+                st.posenc.append(pe)
+                st.minmax.append(mm)
+        named = [(k, p) for k, p in self.model.named_parameters()
+                 if k.startswith("backbone.") or k.startswith("lin_squeeze_head.")]
+        holder = _Holder(tape=tape, names=[k for k, _ in named])
+        out = BackboneFn.apply(holder, *[p for _, p in named]) if torch.is_grad_enabled() else tape.output
+        pcd_features = SparseTensor(features=out, coordinates=x.C)
+        pcd_features._a3d = st
+        coordinates = SparseTensor(features=raw, coordinates=x.C)
+        pos_encodings_pcd = [[[None] * len(st.ranges)] for _ in range(4)] + [[list(st.posenc)]]
+        return pcd_features, [None] * 5, coordinates, pos_encodings_pcd
+
+    def forward_mask_train(self, pcd_features, aux, coordinates, pos_encodings_pcd, click_idx=None, click_time_idx=None):
+        """``forward_mask`` of a model in training mode (engine.py:120-122): one DecoderTape per batch sample
+        (agile3d.py:192 loops over the samples), logits tied into torch.autograd."""
+        from .autograd import DecoderFn, _Holder
+        from .train_decoder import DecoderTape
+        st = getattr(pcd_features, "_a3d", None)
+        if st is None or st.engine_id != id(self):
+            raise RuntimeError("forward_mask needs the objects returned by this model's forward_backbone")
+        if click_idx is None or click_time_idx is None:
+            raise ValueError("click_idx and click_time_idx are required")
+        named = [(k, p) for k, p in self.model.named_parameters()
+                 if not (k.startswith("backbone.") or k.startswith("lin_squeeze_head."))]
+        names, params = [k for k, _ in named], [p for _, p in named]
+        n_layers = self.model.num_decoders
+        preds = [[] for _ in range(n_layers)]
+        for b, (s, e) in enumerate(st.ranges):
+            rows = pcd_features.F[s:e]
+            with torch.no_grad():
+                tape = DecoderTape(self.model, rows.detach(), st.posenc[b], click_idx[b], click_time_idx[b])
+            if torch.is_grad_enabled():
+                logits = DecoderFn.apply(_Holder(tape=tape, names=names), rows, *params)
+            else:
+                logits = tape.logits
+            for l in range(n_layers):
+                preds[l].append(logits[l])
+        out = {"pred_masks": preds[-1], "backbone_features": pcd_features}
+        if self.model.aux:
+            out["aux_outputs"] = [{"pred_masks": p} for p in preds[:-1]]
+        return out
+
     def decoder_inputs(self, feats128: torch.Tensor, raw_xyz: torch.Tensor):
         """Single-sample decoder inputs from an explicit [N,128] feature matrix (what
         forward_backbone would have produced) -- used by the golden-vector parity tests, which
         hold the reference's decoder inputs directly."""
         lib = L.load()
-        self.refresh_weights_if_stale(check_versions=True)
+        self.refresh_decoder_if_stale(check_versions=True)
         feats = feats128.to(self.device, torch.float32).contiguous()
         raw = raw_xyz.to(self.device, torch.float32).contiguous()
         n = feats.shape[0]
@@ -426,7 +522,7 @@ class Engine:
         forward_backbone returns for it -- the training iteration runs its no-grad click rounds on the training-mode
         backbone's features this way (engine.py:82-116 of the reference)."""
         lib = L.load()
-        self.refresh_weights_if_stale(check_versions=True)
+        self.refresh_decoder_if_stale(check_versions=True)
         feats = feats128.to(self.device, torch.float32).contiguous()
         raw = raw_xyz.to(self.device, torch.float32).contiguous()
         n = feats.shape[0]
@@ -458,6 +554,7 @@ class Engine:
             raise RuntimeError("forward_mask needs the objects returned by this model's forward_backbone")
         if click_idx is None or click_time_idx is None:
             raise ValueError("click_idx and click_time_idx are required")
+        self.refresh_decoder_if_stale(check_versions=True)
         W = self.decoder.W
         n_layers = self.decoder.n_layers
         preds = [[] for _ in range(n_layers)]
@@ -490,7 +587,7 @@ class Engine:
                 ws = torch.empty(wsb, dtype=torch.uint8, device=self.device)
                 logits = torch.empty((n_layers, nb, K + 1), dtype=torch.float32, device=self.device)
                 arr = lambda v: (C.c_int32 * max(1, len(v)))(*v)
-                feats = pcd_features.F[s:e]
+                feats = pcd_features.F.detach()[s:e]
                 a_rows, a_objs, a_times = arr(rows), arr(objs), arr(times)
                 keep += [ws, feats, a_rows, a_objs, a_times]
                 sp = samples[b]

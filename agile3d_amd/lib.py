@@ -17,7 +17,7 @@ A3D_MAX_DEC_LAYERS = 8
 OP_STEM, OP_CONV3, OP_DOWN, OP_UP, OP_LINEAR = 0, 1, 2, 3, 4
 BUF_NONE, BUF_EXT_OUT = -1, -2
 (TAB_XYZB, TAB_NBR27, TAB_GMASK27, TAB_CHILD8, TAB_GMASKDOWN, TAB_UP8, TAB_GMASKUP, TAB_UPROWS,
- TAB_ORIGROW, TAB_ORDER27) = range(10)
+ TAB_ORIGROW, TAB_ORDER27, TAB_PRE27, TAB_PREDOWN, TAB_PREUP) = range(13)
 
 c_float_p = C.c_void_p  # device pointers travel as integers
 

@@ -7,7 +7,8 @@ Drop-in for the reference's model boundary:
                                     pos_encodings_pcd, click_idx, click_time_idx)
 Same argument meaning, same return structures, same ``state_dict`` keys.  All arithmetic
 runs in ``libagile3d_hip.so`` (hand-written gfx950 kernels); there is NO CPU fallback --
-calling a forward without the HIP library or on a non-GPU tensor raises.
+calling a forward without the HIP library or on a non-GPU tensor raises.  Both modes of the ``nn.Module`` are
+served: ``eval()`` by the fused inference kernels, ``train()`` by the training path tied into torch.autograd.
 """
 from __future__ import annotations
 
@@ -88,10 +89,6 @@ class Agile3d(nn.Module):
                                "there is no CPU path")
         if self._engine is None or self._engine.device != dev:
             self._engine = Engine(self, dev)
-        if self.training:
-            raise RuntimeError("agile3d_amd: round-1 kernels implement eval-mode forward only "
-                               "(BatchNorm uses running statistics); call model.eval()")
-        self._engine.refresh_weights_if_stale()
         return self._engine
 
     def load_state_dict(self, state_dict, strict=True, **kw):
@@ -109,14 +106,25 @@ class Agile3d(nn.Module):
     def forward_backbone(self, x, raw_coordinates=None):
         """Reference ``agile3d.py:163-181``.  ``x``: SparseTensor of int32 [N,4] coords +
         fp32 [N,3] colours; ``raw_coordinates`` fp32 [N,3].  Returns
-        (pcd_features, aux, coordinates, pos_encodings_pcd), opaque to callers."""
-        return self._get_engine().forward_backbone(x, raw_coordinates)
+        (pcd_features, aux, coordinates, pos_encodings_pcd), opaque to callers.
+
+        ``model.eval()``: the inference kernels (BatchNorm folded from the running statistics).  ``model.train()``
+        (engine.py:38,53 of the reference): BatchNorm on the batch statistics, activations kept, the result part of
+        torch's autograd graph -- ``losses.backward()`` fills ``.grad`` of every parameter (agile3d_amd/autograd.py)."""
+        eng = self._get_engine()
+        if self.training:
+            return eng.forward_backbone_train(x, raw_coordinates)
+        eng.refresh_weights_if_stale()
+        return eng.forward_backbone(x, raw_coordinates)
 
     def forward_mask(self, pcd_features, aux, coordinates, pos_encodings_pcd,
                      click_idx=None, click_time_idx=None):
-        """Reference ``agile3d.py:183-339``."""
-        return self._get_engine().forward_mask(pcd_features, aux, coordinates, pos_encodings_pcd,
-                                               click_idx, click_time_idx)
+        """Reference ``agile3d.py:183-339``.  Accepts the results of either mode's ``forward_backbone`` (the training
+        loop runs its no-grad click rounds in eval mode on the training-mode backbone's features, engine.py:82-115)."""
+        eng = self._get_engine()
+        if self.training:
+            return eng.forward_mask_train(pcd_features, aux, coordinates, pos_encodings_pcd, click_idx, click_time_idx)
+        return eng.forward_mask(pcd_features, aux, coordinates, pos_encodings_pcd, click_idx, click_time_idx)
 
 
 def build_agile3d(args):

@@ -273,6 +273,9 @@ class DecoderTape:
         dev = pcd.device
         K = len(click_idx) - 1
         fg_split = [len(click_idx[str(i)]) for i in range(1, K + 1)]
+        for i, c in enumerate(fg_split):
+            if c == 0:   # an empty group has no maximum: the reference fails on it too (agile3d.py:353)
+                raise ValueError(f"object {i + 1} has no click (the reference fails on an empty max, agile3d.py:353)")
         fg_rows = [r for i in range(1, K + 1) for r in click_idx[str(i)]]
         fg_times = [t for i in range(1, K + 1) for t in click_time_idx[str(i)]]
         bg_rows, bg_times = list(click_idx["0"]), list(click_time_idx["0"])

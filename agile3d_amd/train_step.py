@@ -73,8 +73,8 @@ def train_one_step(model, criterion, optimizer, batch, device, max_norm: float =
     num_forward_iters = random.randint(0, 19)
     model.eval()
     eng = model._get_engine()
-    eng.mark_stale()                         # the optimiser writes the parameters in place, behind torch's back
-    eng.refresh_weights_if_stale()
+    eng.refresh_decoder_if_stale()           # only the decoder's packed weights are used here (the previous step's
+                                             # optimiser marked everything stale; the backbone program is rebuilt on demand)
     dec_in = eng.decoder_inputs_batch(pcd, raw_coords, ranges)
     pos_enc = dec_in[3][4][0]
     for it in range(num_forward_iters + 1):
@@ -134,6 +134,89 @@ def train_one_step(model, criterion, optimizer, batch, device, max_norm: float =
         print("train_one_step: " + ", ".join(f"{n} {1e3 * (t - marks[i][1]):.1f} ms" for i, (n, t) in enumerate(marks[1:])),
               file=sys.stderr)
     return {"loss": total, "grad_norm": norm, "loss_dict": {k: float(v) for k, v in loss_dict.items()},
+            "clicks": [sum(len(v) for v in c.values()) for c in click_idx]}
+
+
+def train_one_step_api(model, criterion, optimizer, batch, device, max_norm: float = 0.1):
+    """The same iteration written the way the reference's ``train_one_epoch`` body is (engine.py:38-150), against
+    nothing but the model's public interface and torch: ``model.train()`` -> ``forward_backbone`` -> object sampling
+    -> ``model.eval()`` + ``no_grad`` click rounds through ``forward_mask`` -> ``model.train()`` -> ``forward_mask`` ->
+    ``criterion`` -> weighted sum -> ``optimizer.zero_grad(); losses.backward(); clip_grad_norm_; optimizer.step()``
+    with a ``torch.optim`` optimiser.  Forward and backward arithmetic run in the HIP library (agile3d_amd/autograd.py
+    ties the tapes into torch's graph).  Same random-number consumption as ``train_one_step``; with
+    ``torch.distributed`` initialised the ``.grad`` tensors are averaged over the ranks before the clip."""
+    from .sparse import SparseTensor
+    coords, raw_coords, feats, labels, _, _, click_idx, _scene_name, _num_obj = batch
+    coords = coords.to(device)
+    raw_coords = raw_coords.to(device)
+    feats = feats.to(device)
+    labels = [l.to(device) for l in labels]
+    click_idx = [dict(c) for c in click_idx]
+    model.train()
+    criterion.train()
+    data = SparseTensor(coordinates=coords, features=feats, device=device)
+    pcd_features, aux, coordinates, pos_encodings_pcd = model.forward_backbone(data, raw_coordinates=raw_coords)
+
+    batch_idx = coords[:, 0]
+    n_samples = int(batch_idx.max()) + 1
+    labels_new = []
+    for idx in range(n_samples):
+        sample_labels = labels[idx]
+        valid = torch.unique(sample_labels)
+        valid = valid[valid != -1]
+        max_num_obj = len(valid)
+        num_obj = np.random.randint(1, min(10, max_num_obj) + 1)
+        obj_idxs = valid[torch.randperm(max_num_obj)[:num_obj].to(valid.device)]
+        new = torch.zeros(sample_labels.shape[0], device=device)
+        for i, obj_id in enumerate(obj_idxs):
+            new[sample_labels == obj_id] = i + 1
+            click_idx[idx][str(i + 1)] = []
+        click_idx[idx]["0"] = []
+        labels_new.append(new)
+    click_time_idx = copy.deepcopy(click_idx)
+
+    num_forward_iters = random.randint(0, 19)
+    with torch.no_grad():
+        model.eval()
+        masks = [batch_idx == i for i in range(n_samples)]
+        for it in range(num_forward_iters + 1):
+            if it:
+                out = model.forward_mask(pcd_features, aux, coordinates, pos_encodings_pcd, click_idx=click_idx,
+                                         click_time_idx=click_time_idx)
+            for idx in range(n_samples):
+                if it == 0:
+                    pred = torch.zeros(int(masks[idx].sum()), device=device)
+                else:
+                    pred = out["pred_masks"][idx].argmax(-1)
+                    for obj_id, cids in click_idx[idx].items():
+                        pred[cids] = int(obj_id)
+                new_clicks, _, _, new_time = get_simulated_clicks(pred, labels_new[idx], raw_coords[masks[idx]], it,
+                                                                  training=True)
+                if new_clicks is not None:
+                    click_idx[idx], click_time_idx[idx] = extend_clicks(click_idx[idx], click_time_idx[idx], new_clicks,
+                                                                        new_time)
+        model.train()
+
+    outputs = model.forward_mask(pcd_features, aux, coordinates, pos_encodings_pcd, click_idx=click_idx,
+                                 click_time_idx=click_time_idx)
+    click_weights = cal_click_loss_weights(batch_idx, raw_coords, torch.cat(labels_new), click_idx)
+    loss_dict = criterion(outputs, labels_new, click_weights)
+    weight_dict = criterion.weight_dict
+    losses = sum(loss_dict[k] * weight_dict[k] for k in loss_dict.keys() if k in weight_dict)
+    loss_value = float(losses.detach())
+    if not np.isfinite(loss_value):
+        raise FloatingPointError(f"Loss is {loss_value}, stopping training")
+    optimizer.zero_grad()
+    losses.backward()
+    if torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
+        grads = {k: p.grad for k, p in model.named_parameters() if p.grad is not None}
+        allreduce_mean_(grads)
+    grad_total_norm = None
+    if max_norm > 0:
+        grad_total_norm = torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm)
+    optimizer.step()
+    return {"loss": loss_value, "grad_norm": None if grad_total_norm is None else float(grad_total_norm),
+            "loss_dict": {k: float(v.detach()) for k, v in loss_dict.items()},
             "clicks": [sum(len(v) for v in c.values()) for c in click_idx]}
 
 

@@ -101,7 +101,10 @@ enum {
   A3D_TAB_GMASKUP   = 6,  /* uint32 [npad/16]                                                     */
   A3D_TAB_UPROWS    = 7,  /* int32 [npad] virtual row -> row of `level`                           */
   A3D_TAB_ORIGROW   = 8,  /* int32 [n0]   internal level-0 row -> caller's row                    */
-  A3D_TAB_ORDER27   = 9   /* int32 [npad/64] 64-row tiles sorted by number of 3^3 offsets, most first */
+  A3D_TAB_ORDER27   = 9,  /* int32 [npad/64] 64-row tiles sorted by number of 3^3 offsets, most first */
+  A3D_TAB_PRE27     = 10, /* int32 [npad/64+1] (tile, offset) pairs of the 3^3 map before each 64-row tile */
+  A3D_TAB_PREDOWN   = 11, /* int32 [npad(level+1)/64+1] same for the stride-2 map                       */
+  A3D_TAB_PREUP     = 12  /* int32 [npad/64+1] same for the transposed map                              */
 };
 int a3d_scene_table(const a3d_scene* s, int level, int which, const void** ptr_dev, int64_t* count);
 

@@ -547,3 +547,83 @@ def test_attention_primitives_long_dimensions(Lq, Lk, Hh, dh, tr):
         ref = 0.5 * torch.einsum("hij,jhd->ihd", P.cpu().double(), k.cpu().double().view(Lk, Hh, dh)).reshape(Lq, C_)
     err = (out.cpu().double() - ref).abs().max().item()
     assert err <= 2e-5 * max(1.0, ref.abs().max().item()), err
+
+
+def test_reference_training_sequence_through_the_model_api():
+    """The literal sequence of the reference's training loop (engine.py:38-150) on the public interface only:
+    ``model.train(); forward_backbone; (eval + no_grad click rounds); forward_mask; criterion; losses.backward();
+    torch.nn.utils.clip_grad_norm_; optimizer.step()`` with a torch.optim optimiser.  The HIP tapes sit behind
+    torch.autograd (agile3d_amd/autograd.py).  Checked against ``train_one_step`` (the same arithmetic driven by hand)
+    from identical weights and random draws: same clicks, same loss, same gradient norm, and -- with plain SGD on both
+    sides, so that the update is linear in the gradient -- the same parameters after every step (Adam turns the 1e-9
+    rounding noise of mathematically-zero gradients, e.g. the key bias of an attention layer, into +-lr steps, which
+    says nothing about the gradients).  A third step then runs with torch.optim.AdamW as the reference does."""
+    import copy
+    import random
+
+    from agile3d_amd import batched_coordinates, build_model, default_args
+    from agile3d_amd.criterion import build_mask_criterion
+    from agile3d_amd.train_step import train_one_step, train_one_step_api
+    args = default_args(bce_loss_coef=1.0, dice_loss_coef=2.0, losses=["bce", "dice"])
+    scenes = [make_scene(3000, seed=50), make_scene(2600, seed=51)]
+    batch = (batched_coordinates([s["coords"][:, 1:] for s in scenes]),
+             torch.from_numpy(np.concatenate([s["raw_xyz"] for s in scenes])),
+             torch.from_numpy(np.concatenate([s["feats"] for s in scenes])),
+             [torch.from_numpy(s["labels"].astype(np.int64)) for s in scenes], None, None, [{}, {}],
+             ("scene0050_00", "scene0051_00"), (0, 0))
+    dev = torch.device("cuda")
+    torch.manual_seed(5)
+    model_a = build_model(args).cuda()
+    model_b = copy.deepcopy(model_a)
+    crit = build_mask_criterion(args)
+    lr = 1e-2
+
+    class HandSGD:            # train_one_step's optimiser interface: step(gradients by name, clip coefficient)
+        def __init__(self, model):
+            self.params, self.lr = dict(model.named_parameters()), lr
+
+        def step(self, grads, coef):
+            with torch.no_grad():
+                for k, g in grads.items():
+                    self.params[k].add_(g.reshape(self.params[k].shape), alpha=-self.lr * coef)
+    opt_a = torch.optim.SGD(model_a.parameters(), lr=lr)
+    opt_b = HandSGD(model_b)
+    pb = dict(model_b.named_parameters())
+    sd_keys_bn = [k for k in model_a.state_dict() if k.endswith("running_mean") or k.endswith("running_var")]
+    for step in range(2):
+        np.random.seed(7 + step), torch.manual_seed(7 + step), random.seed(7 + step)
+        sa = train_one_step_api(model_a, crit, opt_a, batch, dev, max_norm=0.1)
+        np.random.seed(7 + step), torch.manual_seed(7 + step), random.seed(7 + step)
+        sb = train_one_step(model_b, crit, opt_b, batch, dev, max_norm=0.1)
+        print(f"step {step}: api loss {sa['loss']:.6f} norm {sa['grad_norm']:.5f} | hand-driven loss {sb['loss']:.6f} "
+              f"norm {sb['grad_norm']:.5f} clicks {sa['clicks']}")
+        assert sa["clicks"] == sb["clicks"]
+        assert abs(sa["loss"] - sb["loss"]) <= 1e-5 * max(1.0, abs(sb["loss"]))
+        assert abs(sa["grad_norm"] - sb["grad_norm"]) <= 1e-4 * sb["grad_norm"]
+        for k in sb["loss_dict"]:
+            assert abs(sa["loss_dict"][k] - sb["loss_dict"][k]) <= 1e-5 * max(1.0, abs(sb["loss_dict"][k])), k
+        worst = 0.0
+        for k, p in model_a.named_parameters():
+            d = (p.detach() - pb[k].detach()).abs().max().item()
+            worst = max(worst, d / max(1e-2, pb[k].detach().abs().max().item()))
+        print(f"parameters after step {step}: worst difference relative to the tensor's scale {worst:.2e}")
+        assert worst <= 1e-5
+        for k in sd_keys_bn:
+            assert torch.allclose(model_a.state_dict()[k], model_b.state_dict()[k], rtol=1e-5, atol=1e-6), k
+        # every step starts from bit-identical weights: the click simulator takes discrete decisions (arg-max labels,
+        # largest error cluster), so a 1e-7 difference in a parameter can move a click and with it the next loss
+        model_b.load_state_dict(model_a.state_dict())
+    n_grad = sum(1 for p in model_a.parameters() if p.grad is not None)
+    assert n_grad >= 268, n_grad                       # every trained tensor received a gradient through autograd
+    # the reference's optimiser (main.py:125): one more iteration with torch.optim.AdamW
+    before = {k: v.detach().clone() for k, v in model_a.named_parameters()}
+    opt = torch.optim.AdamW(model_a.parameters(), lr=1e-4, weight_decay=1e-4)
+    np.random.seed(9), torch.manual_seed(9), random.seed(9)
+    sc = train_one_step_api(model_a, crit, opt, batch, dev, max_norm=0.1)
+    assert np.isfinite(sc["loss"]) and sc["grad_norm"] > 0
+    assert sum(1 for k, v in model_a.named_parameters() if not torch.equal(v.detach(), before[k])) >= 268
+    # eval after training through the API: the inference path picks the new weights up by itself
+    model_a.eval()
+    x = SparseTensor(features=batch[2], coordinates=batch[0], device="cuda")
+    r = model_a.forward_backbone(x, raw_coordinates=batch[1].cuda())
+    assert torch.isfinite(r[0].F).all()

@@ -245,6 +245,37 @@ def test_full_size_properties(model_and_sd):
     assert (r4[0].F - r1[0].F).abs().max().item() <= 1e-5
 
 
+@pytest.mark.parametrize("voxels,n_obj,per_obj,seed", [(80_000, 5, 2, 0), (300_000, 5, 4, 2)])
+def test_benchmark_sizes_match_oracle(model_and_sd, voxels, n_obj, per_obj, seed):
+    """BASELINE.json configs[1] (80 k voxels, 10 clicks) and configs[4] (300 k voxels, 20 clicks) against the CPU oracle
+    itself, not only through size-independent properties: forward_backbone's features and the logits of all three
+    decoder iterations within north_star's 1e-3 (fp32).  The oracle needs ~3 s / ~30 s at these sizes with 8 threads
+    (torch's default of one thread per core is several times slower on a many-core host: the per-offset GEMMs are small)."""
+    model, sd = model_and_sd
+    sc = make_scene(voxels, seed=seed)
+    ci, ct = make_clicks(sc["labels"], n_obj, per_obj, 0, seed=seed)
+    pcd, aux, coords, pos = _run_backbone(model, sc)
+    out = model.forward_mask(pcd, aux, coords, pos, click_idx=[ci], click_time_idx=[ct])
+    got = [a["pred_masks"][0].cpu() for a in out["aux_outputs"]] + [out["pred_masks"][0].cpu()]
+    feats_gpu = pcd.F.cpu()
+    nthr = torch.get_num_threads()
+    torch.set_num_threads(min(8, nthr))
+    try:
+        ref_b = ob.forward_backbone(sd, sc["coords"], torch.from_numpy(sc["feats"]), torch.from_numpy(sc["raw_xyz"]))
+        ref = od.forward_mask(sd, ref_b["pcd_features"], torch.from_numpy(sc["raw_xyz"]), ref_b["pos_enc"], ci, ct)
+    finally:
+        torch.set_num_threads(nthr)
+    err_b = (feats_gpu - ref_b["pcd_features"]).abs().max().item()
+    print(f"{len(sc['coords'])} voxels: pcd_features max|diff| = {err_b:.3e} (scale {ref_b['pcd_features'].abs().max():.2f})")
+    assert err_b <= TOL * max(1.0, ref_b["pcd_features"].abs().max().item())
+    for i in range(3):
+        err = (got[i] - ref[i]).abs().max().item()
+        print(f"{len(sc['coords'])} voxels, {n_obj * per_obj} clicks, iteration {i}: logits max|diff| = {err:.3e} "
+              f"(scale {ref[i].abs().max():.2f})")
+        assert err <= TOL * max(1.0, ref[i].abs().max().item())
+    assert got[-1].shape == (len(sc["coords"]), n_obj + 1)
+
+
 def test_two_scenes_in_flight_on_two_streams(model_and_sd):
     """bench.py issues consecutive scenes round-robin on two HIP streams.  The library keeps no state
     between calls that two in-flight scenes could share: results must be bit-identical to serial runs."""

@@ -70,7 +70,7 @@ def main():
         ms = {}
         for i in range(n):
             ms.setdefault(buf[i].id, []).append(buf[i].ms)
-        t_conv = float(np.median(ms[0]))
+        t_conv = float(np.median(ms[0] if 0 in ms else ms[L.PROF_DENSE]))
         t_epi = float(np.median(ms.get(1, [0.0])))
         if kind == L.OP_CONV3:
             pairs, slots = pairs3[lvl]

@@ -26,6 +26,12 @@ def main():
     for root in sys.argv[1:]:
         for path in sorted(glob.glob(os.path.join(root, "**", "*.db"), recursive=True)):
             out, tabs = from_db(path)
+            if "top_kernels" in tabs:   # kernel-trace durations next to the counters (clock = GRBM_GUI_ACTIVE / duration)
+                db = sqlite3.connect(path)
+                for name, calls, total, avg, pct in db.execute(
+                        "select name, total_calls, total_duration, average, percentage from top_kernels"):
+                    if "a3d" in name:
+                        print(f"DURATION {name.split('(')[0][-40:]} calls={calls} avg_ns={avg:.1f}")
             if not out:
                 print(path, "no counters_collection; tables:", tabs[:40])
             for k, cs in out.items():
