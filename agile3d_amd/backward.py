@@ -161,6 +161,65 @@ def bn_train_backward(x, y, dy, gamma, mean, rstd, relu=False, want_dres=False):
     return dx, dgamma, dbeta, dres
 
 
+def bn_sync_forward(x, gamma, beta, eps=1e-5, res=None, relu=False, running_mean=None, running_var=None, momentum=0.1,
+                    group=None):
+    """BatchNorm in training mode with statistics over the rows of ALL data-parallel ranks (SyncBN): the reference
+    normalises over every row of the batch on one device (models/modules/common.py:20-22); with the batch's scenes
+    spread over ranks the strict equivalent exchanges [2C+1] numbers per layer.  Per rank: row
+    count, mean, sum of squared deviations (a3d_bn_local_stats, fp64) -> one all_gather -> Chan's parallel combination
+    -> the same mean / rstd on every rank -> a3d_bn_apply.  Returns (y, mean, rstd, n_global)."""
+    import torch.distributed as dist
+    lib = L.load()
+    x = x.contiguous()
+    n, C_ = x.shape
+    ws = _ws(n, C_, x.device)
+    st = torch.empty(2 * C_ + 1, dtype=torch.float64, device=x.device)
+    L.check(lib.a3d_bn_local_stats(_ptr(x), C_, n, C_, _ptr(st), _ptr(ws), ws.numel(), _stream()), "a3d_bn_local_stats")
+    st[2 * C_] = float(n)
+    from .optim import dist_all_gather
+    allst = dist_all_gather(st, group)                           # [world, 2C+1]
+    cnt = allst[:, 2 * C_:2 * C_ + 1]                            # [world, 1]
+    n_glob = cnt.sum()
+    mean = (allst[:, :C_] * cnt).sum(0) / n_glob
+    m2 = (allst[:, C_:2 * C_] + cnt * (allst[:, :C_] - mean) ** 2).sum(0)
+    var = m2 / n_glob
+    mean_f = mean.to(torch.float32)
+    rstd = (1.0 / torch.sqrt(var.to(torch.float32) + eps))
+    if running_mean is not None:
+        unbiased = (m2 / (n_glob - 1.0)).to(torch.float32) if float(n_glob) > 1 else var.to(torch.float32)
+        running_mean.mul_(1.0 - momentum).add_(mean_f, alpha=momentum)
+        running_var.mul_(1.0 - momentum).add_(unbiased, alpha=momentum)
+    y = torch.empty_like(x)
+    res = res.contiguous() if res is not None else None
+    L.check(lib.a3d_bn_apply(_ptr(x), C_, n, C_, _ptr(gamma), _ptr(beta), _ptr(mean_f), _ptr(rstd), _ptr(res), C_,
+                             int(relu), _ptr(y), C_, _stream()), "a3d_bn_apply")
+    return y, mean_f, rstd, int(n_glob.item())
+
+
+def bn_sync_backward(x, y, dy, gamma, mean, rstd, n_global, relu=False, want_dres=False, group=None):
+    """Backward of ``bn_sync_forward``: sum g and sum g xhat are all-reduced (2C numbers), dx uses the global sums and
+    row count; dgamma / dbeta are this rank's sums (the gradient all-reduce averages them with everything else)."""
+    import torch.distributed as dist
+    lib = L.load()
+    x, dy = x.contiguous(), dy.contiguous()
+    n, C_ = x.shape
+    ws = _ws(n, C_, x.device)
+    local = torch.empty(2 * C_, dtype=torch.float64, device=x.device)
+    yy = y.contiguous() if relu else None
+    L.check(lib.a3d_bn_backward_sums(_ptr(x), C_, _ptr(yy), C_, _ptr(dy), C_, n, C_, _ptr(mean), _ptr(rstd), int(relu),
+                                     _ptr(local), _ptr(ws), ws.numel(), _stream()), "a3d_bn_backward_sums")
+    from .optim import dist_all_reduce
+    glob = dist_all_reduce(local.clone(), group)
+    dx = torch.empty_like(x)
+    dres = torch.empty_like(x) if want_dres else None
+    dgamma = torch.empty(C_, dtype=torch.float32, device=x.device)
+    dbeta = torch.empty_like(dgamma)
+    L.check(lib.a3d_bn_backward_apply(_ptr(x), C_, _ptr(yy), C_, _ptr(dy), C_, n, C_, _ptr(gamma), _ptr(mean), _ptr(rstd),
+                                      int(relu), _ptr(glob), int(n_global), _ptr(local), _ptr(dx), C_, _ptr(dres), C_,
+                                      _ptr(dgamma), _ptr(dbeta), _stream()), "a3d_bn_backward_apply")
+    return dx, dgamma, dbeta, dres
+
+
 def column_sums(x):
     lib = L.load()
     x = x.contiguous()

@@ -76,6 +76,10 @@ __global__ void k_col_final(const float* __restrict__ partial, int nblocks, int 
   out[c] = s;
 }
 
+__global__ void k_scale_f64(const double* in, int C, double f, double* out) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c < C) out[c] = in[c] * f;
+}
 __global__ void k_bn_mean(const double* sums, int C, double n, float* mean) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c < C) mean[c] = (float)(sums[c] / n);
@@ -117,7 +121,9 @@ __global__ void k_bn_apply(const ApplyArgs a) {
 
 struct BwdArgs {
   const float *x, *y, *dy, *mean, *rstd, *gamma;
-  const double* sums;   // [2][C]: sum g, sum g xhat
+  const double* sums;         // [2][C]: sum g, sum g xhat over the rows the statistics were taken over
+  const double* param_sums;   // [2][C]: the same over THIS call's rows (dgamma / dbeta)
+  double n_stat;              // number of rows the statistics were taken over
   int ldx, ldy, lddy, lddx, lddres, n, C, relu;
   float *dx, *dres, *dgamma, *dbeta;
 };
@@ -136,7 +142,7 @@ __global__ void k_bn_bwd_apply(const BwdArgs a) {
   if (a.dres) *(f32x4*)(a.dres + (size_t)r * a.lddres + 4 * col) = g;
   const f32x4 m = *(const f32x4*)(a.mean + 4 * col), rs = *(const f32x4*)(a.rstd + 4 * col);
   const f32x4 ga = *(const f32x4*)(a.gamma + 4 * col);
-  const float inv_n = 1.f / (float)a.n;
+  const float inv_n = (float)(1.0 / a.n_stat);
   f32x4 dx;
 #pragma unroll
   for (int t = 0; t < 4; ++t) {
@@ -148,8 +154,8 @@ __global__ void k_bn_bwd_apply(const BwdArgs a) {
   if (r == 0) {
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
-      a.dbeta[4 * col + t] = (float)a.sums[4 * col + t];
-      a.dgamma[4 * col + t] = (float)a.sums[a.C + 4 * col + t];
+      a.dbeta[4 * col + t] = (float)a.param_sums[4 * col + t];
+      a.dgamma[4 * col + t] = (float)a.param_sums[a.C + 4 * col + t];
     }
   }
 }
@@ -256,7 +262,8 @@ using namespace a3d;
 
 extern "C" size_t a3d_bn_workspace_bytes(int64_t n, int C) {
   if (n <= 0 || C <= 0) return 0;
-  return align256((size_t)kBnMaxBlocks * 2 * C * sizeof(float)) + align256((size_t)2 * C * sizeof(double)) + 256;
+  return align256((size_t)kBnMaxBlocks * 2 * C * sizeof(float)) + align256((size_t)2 * C * sizeof(double)) +
+         align256((size_t)C * sizeof(float)) + 256;
 }
 
 extern "C" int a3d_bn_train_forward(const float* x_dev, int ldx, int64_t n, int C, const float* gamma_dev,
@@ -326,7 +333,8 @@ extern "C" int a3d_bn_train_backward(const float* x_dev, int ldx, const float* y
   k_col_final<<<(unsigned)((2 * C + 255) / 256), 256, 0, st>>>(partial, blocks, 2, C, sums);
   BwdArgs b;
   b.x = x_dev, b.y = y_dev, b.dy = dy_dev, b.mean = save_mean_dev, b.rstd = save_rstd_dev, b.gamma = gamma_dev;
-  b.sums = sums, b.ldx = ldx, b.ldy = ldy, b.lddy = lddy, b.lddx = lddx, b.lddres = lddres, b.n = (int)n, b.C = C;
+  b.sums = sums, b.param_sums = sums, b.n_stat = (double)n;
+  b.ldx = ldx, b.ldy = ldy, b.lddy = lddy, b.lddx = lddx, b.lddres = lddres, b.n = (int)n, b.C = C;
   b.relu = relu, b.dx = dx_dev, b.dres = dres_dev, b.dgamma = dgamma_dev, b.dbeta = dbeta_dev;
   const size_t total = (size_t)n * (C / 4);
   k_bn_bwd_apply<<<(unsigned)((total + 255) / 256), 256, 0, st>>>(b);
@@ -335,6 +343,109 @@ extern "C" int a3d_bn_train_backward(const float* x_dev, int ldx, const float* y
 }
 
 // column sums of a [n][C] matrix (bias gradient of lin_squeeze_head: sum over rows of dy)
+// ---- the same BatchNorm in pieces, for statistics that span the data-parallel ranks (SyncBN): the caller exchanges
+// the per-rank numbers (torch.distributed) between the calls.  Reference semantics: ME.MinkowskiBatchNorm normalises
+// over ALL rows of the batch on one device (models/modules/common.py:20-22); with one scene per rank the strict
+// equivalent needs [2C+1] numbers per layer across the ranks.
+//   a3d_bn_local_stats     : stats[0..C) = mean of this rank's rows, stats[C..2C) = sum (x - that mean)^2   (fp64)
+//   a3d_bn_apply           : y = relu?((x - mean) rstd gamma + beta (+ res)) with the GIVEN mean / rstd
+//   a3d_bn_backward_sums   : sums[0..C) = sum g, sums[C..2C) = sum g xhat over this rank's rows (fp64), g = dy (y > 0)
+//   a3d_bn_backward_apply  : dx from the GLOBAL sums and row count; dgamma / dbeta = the LOCAL sums (averaged over the
+//                            ranks with every other parameter gradient afterwards, as DDP + SyncBatchNorm do)
+extern "C" int a3d_bn_local_stats(const float* x_dev, int ldx, int64_t n, int C, double* stats_dev, void* workspace_dev,
+                                  size_t workspace_bytes, void* stream) {
+  if (!x_dev || !stats_dev || !workspace_dev || !bn_shape_ok(n, C, ldx, 4, 4)) {
+    set_error("a3d_bn_local_stats: bad arguments");
+    return A3D_ERR_INVALID;
+  }
+  if (workspace_bytes < a3d_bn_workspace_bytes(n, C) || ((uintptr_t)workspace_dev & 15)) {
+    set_error("a3d_bn_local_stats: workspace too small or misaligned");
+    return A3D_ERR_WORKSPACE;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  float* partial = (float*)workspace_dev;
+  double* sums = (double*)((char*)workspace_dev + align256((size_t)kBnMaxBlocks * 2 * C * sizeof(float)));
+  float* meanf = (float*)((char*)sums + align256((size_t)2 * C * sizeof(double)));
+  ColArgs c;
+  memset(&c, 0, sizeof(c));
+  c.x = x_dev, c.ldx = ldx, c.n = (int)n, c.C = C, c.partial = partial;
+  const int blocks = bn_blocks(n, c.rows_per_block);
+  const unsigned cb = (unsigned)((2 * C + 255) / 256);
+  c.mode = 0;
+  k_col_partial<<<blocks, kBnThreads, 0, st>>>(c);
+  k_col_final<<<cb, 256, 0, st>>>(partial, blocks, 1, C, sums);
+  k_bn_mean<<<cb, 256, 0, st>>>(sums, C, (double)n, meanf);
+  k_scale_f64<<<cb, 256, 0, st>>>(sums, C, 1.0 / (double)n, stats_dev);              // the mean in fp64
+  c.mode = 1, c.mean = meanf;
+  k_col_partial<<<blocks, kBnThreads, 0, st>>>(c);
+  k_col_final<<<cb, 256, 0, st>>>(partial, blocks, 1, C, stats_dev + C);
+  A3D_LAUNCH_CHECK();
+  return A3D_OK;
+}
+
+extern "C" int a3d_bn_apply(const float* x_dev, int ldx, int64_t n, int C, const float* gamma_dev, const float* beta_dev,
+                            const float* mean_dev, const float* rstd_dev, const float* res_dev, int ldr, int relu,
+                            float* y_dev, int ldy, void* stream) {
+  if (!x_dev || !gamma_dev || !beta_dev || !mean_dev || !rstd_dev || !y_dev || !bn_shape_ok(n, C, ldx, ldy, res_dev ? ldr : 4)) {
+    set_error("a3d_bn_apply: bad arguments");
+    return A3D_ERR_INVALID;
+  }
+  ApplyArgs a;
+  a.x = x_dev, a.mean = mean_dev, a.rstd = rstd_dev, a.gamma = gamma_dev, a.beta = beta_dev, a.res = res_dev;
+  a.ldx = ldx, a.ldr = ldr, a.ldy = ldy, a.n = (int)n, a.C = C, a.relu = relu, a.y = y_dev;
+  const size_t total = (size_t)n * (C / 4);
+  k_bn_apply<<<(unsigned)((total + 255) / 256), 256, 0, (hipStream_t)stream>>>(a);
+  A3D_LAUNCH_CHECK();
+  return A3D_OK;
+}
+
+extern "C" int a3d_bn_backward_sums(const float* x_dev, int ldx, const float* y_dev, int ldy, const float* dy_dev, int lddy,
+                                    int64_t n, int C, const float* mean_dev, const float* rstd_dev, int relu,
+                                    double* sums_dev, void* workspace_dev, size_t workspace_bytes, void* stream) {
+  if (!x_dev || !dy_dev || !mean_dev || !rstd_dev || !sums_dev || !workspace_dev || (relu && !y_dev) ||
+      !bn_shape_ok(n, C, ldx, lddy, 4) || (relu && ldy % 4)) {
+    set_error("a3d_bn_backward_sums: bad arguments");
+    return A3D_ERR_INVALID;
+  }
+  if (workspace_bytes < a3d_bn_workspace_bytes(n, C) || ((uintptr_t)workspace_dev & 15)) {
+    set_error("a3d_bn_backward_sums: workspace too small or misaligned");
+    return A3D_ERR_WORKSPACE;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  float* partial = (float*)workspace_dev;
+  ColArgs c;
+  memset(&c, 0, sizeof(c));
+  c.x = x_dev, c.y = y_dev, c.dy = dy_dev, c.mean = mean_dev, c.rstd = rstd_dev;
+  c.ldx = ldx, c.ldy = ldy, c.lddy = lddy, c.n = (int)n, c.C = C, c.relu = relu, c.mode = 2, c.partial = partial;
+  const int blocks = bn_blocks(n, c.rows_per_block);
+  k_col_partial<<<blocks, kBnThreads, 0, st>>>(c);
+  k_col_final<<<(unsigned)((2 * C + 255) / 256), 256, 0, st>>>(partial, blocks, 2, C, sums_dev);
+  A3D_LAUNCH_CHECK();
+  return A3D_OK;
+}
+
+extern "C" int a3d_bn_backward_apply(const float* x_dev, int ldx, const float* y_dev, int ldy, const float* dy_dev, int lddy,
+                                     int64_t n, int C, const float* gamma_dev, const float* mean_dev, const float* rstd_dev,
+                                     int relu, const double* global_sums_dev, int64_t n_global, const double* local_sums_dev,
+                                     float* dx_dev, int lddx, float* dres_dev, int lddres, float* dgamma_dev,
+                                     float* dbeta_dev, void* stream) {
+  if (!x_dev || !dy_dev || !gamma_dev || !mean_dev || !rstd_dev || !global_sums_dev || !local_sums_dev || !dx_dev ||
+      !dgamma_dev || !dbeta_dev || n_global < n || (relu && !y_dev) || !bn_shape_ok(n, C, ldx, lddy, lddx) ||
+      (relu && ldy % 4) || (dres_dev && lddres % 4)) {
+    set_error("a3d_bn_backward_apply: bad arguments");
+    return A3D_ERR_INVALID;
+  }
+  BwdArgs b;
+  b.x = x_dev, b.y = y_dev, b.dy = dy_dev, b.mean = mean_dev, b.rstd = rstd_dev, b.gamma = gamma_dev;
+  b.sums = global_sums_dev, b.param_sums = local_sums_dev, b.n_stat = (double)n_global;
+  b.ldx = ldx, b.ldy = ldy, b.lddy = lddy, b.lddx = lddx, b.lddres = lddres, b.n = (int)n, b.C = C;
+  b.relu = relu, b.dx = dx_dev, b.dres = dres_dev, b.dgamma = dgamma_dev, b.dbeta = dbeta_dev;
+  const size_t total = (size_t)n * (C / 4);
+  k_bn_bwd_apply<<<(unsigned)((total + 255) / 256), 256, 0, (hipStream_t)stream>>>(b);
+  A3D_LAUNCH_CHECK();
+  return A3D_OK;
+}
+
 extern "C" int a3d_column_sums(const float* x_dev, int ldx, int64_t n, int C, float* out_dev, void* workspace_dev,
                                size_t workspace_bytes, void* stream) {
   if (!x_dev || !out_dev || !workspace_dev || !bn_shape_ok(n, C, ldx, 4, 4)) {

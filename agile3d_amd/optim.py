@@ -75,6 +75,29 @@ class AdamW:
                                        _stream(p)), "a3d_adamw_step")
 
 
+def dist_all_reduce(t, group=None):
+    """all_reduce(sum) in place; the gloo backend (CPU tests, and the two-ranks-on-one-GPU test) goes through host
+    memory, nccl (= RCCL) works on the device tensor directly."""
+    import torch.distributed as dist
+    if t.is_cuda and dist.get_backend(group) == "gloo":
+        h = t.cpu()
+        dist.all_reduce(h, group=group)
+        t.copy_(h)
+    else:
+        dist.all_reduce(t, group=group)
+    return t
+
+
+def dist_all_gather(t, group=None):
+    """-> [world, ...] stack of every rank's ``t`` (same staging rule as dist_all_reduce)."""
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    src = t.cpu() if (t.is_cuda and dist.get_backend(group) == "gloo") else t
+    parts = [torch.empty_like(src) for _ in range(world)]
+    dist.all_gather(parts, src, group=group)
+    return torch.stack(parts).to(t.device)
+
+
 def allreduce_mean_(grads: dict, group=None, bucket_bytes: int = 64 << 20):
     """Average the gradients over the data-parallel ranks in place: tensors are packed into ~64 MB buckets (few, large
     collectives: the xGMI links are bound per ring step) and all-reduced with torch.distributed
@@ -92,7 +115,7 @@ def allreduce_mean_(grads: dict, group=None, bucket_bytes: int = 64 << 20):
             size += grads[names[i]].numel() * 4
             i += 1
         flat = torch.cat([grads[n].reshape(-1) for n in bucket])
-        dist.all_reduce(flat, group=group)
+        dist_all_reduce(flat, group)
         flat /= world
         off = 0
         for n in bucket:

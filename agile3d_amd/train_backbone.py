@@ -50,11 +50,21 @@ def _run_stem(scene, w, feats3, kvol):
     return ws[off:off + n0 * 32 * 4].view(torch.float32).view(n0, 32).clone()
 
 
+def _sync_bn_default():
+    """SyncBN is opt-in: ``A3D_SYNC_BN=1`` (or ``BackboneTape(..., sync_bn=True)``) and an initialised process group of
+    more than one rank.  Off, every rank normalises over its own scenes (what plain DDP does)."""
+    import os
+
+    import torch.distributed as dist
+    return os.environ.get("A3D_SYNC_BN", "0") == "1" and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+
+
 class BackboneTape:
-    def __init__(self, model, scene, feats3: torch.Tensor):
+    def __init__(self, model, scene, feats3: torch.Tensor, sync_bn=None):
         if not feats3.is_cuda:
             raise RuntimeError("BackboneTape runs on the GPU only")
         self.model, self.scene = model, scene
+        self.sync_bn = _sync_bn_default() if sync_bn is None else bool(sync_bn)
         self.feats3 = feats3.to(torch.float32).contiguous()
         self.steps = []          # backward closures, in forward order
         self.relu_levels = []
@@ -81,14 +91,25 @@ class BackboneTape:
 
     def _bn(self, x: _T, norm, res: _T | None = None, relu=True) -> _T:
         b = norm.bn
-        v, mean, rstd = B.bn_train_forward(x.v, b.weight.detach(), b.bias.detach(), b.eps, res.v if res is not None else None,
-                                           relu, b.running_mean, b.running_var, b.momentum)
+        n_glob = None
+        if self.sync_bn:
+            v, mean, rstd, n_glob = B.bn_sync_forward(x.v, b.weight.detach(), b.bias.detach(), b.eps,
+                                                      res.v if res is not None else None, relu, b.running_mean,
+                                                      b.running_var, b.momentum)
+        else:
+            v, mean, rstd = B.bn_train_forward(x.v, b.weight.detach(), b.bias.detach(), b.eps,
+                                               res.v if res is not None else None, relu, b.running_mean, b.running_var,
+                                               b.momentum)
         y = _T(v, x.level)
         if relu:
             self.relu_levels.append((x.level, y))       # forward order of the ReLUs (tests read the 0/1 masks off y.v)
 
         def back():
-            dx, dg, db, dres = B.bn_train_backward(x.v, y.v, y.g, b.weight.detach(), mean, rstd, relu, res is not None)
+            if self.sync_bn:
+                dx, dg, db, dres = B.bn_sync_backward(x.v, y.v, y.g, b.weight.detach(), mean, rstd, n_glob, relu,
+                                                      res is not None)
+            else:
+                dx, dg, db, dres = B.bn_train_backward(x.v, y.v, y.g, b.weight.detach(), mean, rstd, relu, res is not None)
             self._pgrad(b.weight, dg)
             self._pgrad(b.bias, db)
             x.add_grad(dx)

@@ -198,6 +198,28 @@ int    a3d_bn_train_backward(const float* x_dev, int ldx, const float* y_dev, in
                              const float* save_rstd_dev, int relu, float* dx_dev, int lddx, float* dres_dev,
                              int lddres, float* dgamma_dev, float* dbeta_dev,
                              void* workspace_dev, size_t workspace_bytes, void* stream);
+/* The same BatchNorm in pieces, for statistics that span the data-parallel ranks (SyncBN; the reference normalises over
+ * all rows of the batch on ONE device, models/modules/common.py:20-22 -- with one scene per rank the strict equivalent
+ * exchanges [2C+1] numbers per layer).  The caller combines the per-rank numbers between the calls
+ * (agile3d_amd/backward.py: all_gather + Chan's parallel variance for the forward, all_reduce for the backward).
+ *   a3d_bn_local_stats    : stats[0..C) = mean of THIS call's rows, stats[C..2C) = sum (x - that mean)^2   (fp64)
+ *   a3d_bn_apply          : y = relu?((x - mean) rstd gamma + beta (+ res)) with the GIVEN mean / rstd
+ *   a3d_bn_backward_sums  : sums[0..C) = sum g, sums[C..2C) = sum g xhat over THIS call's rows (fp64), g = dy (y > 0)
+ *   a3d_bn_backward_apply : dx from the GLOBAL sums / row count; dgamma, dbeta = the LOCAL sums (they are averaged over
+ *                           the ranks with every other parameter gradient afterwards, as DDP + SyncBatchNorm do) */
+int    a3d_bn_local_stats(const float* x_dev, int ldx, int64_t n, int C, double* stats_dev, void* workspace_dev,
+                          size_t workspace_bytes, void* stream);
+int    a3d_bn_apply(const float* x_dev, int ldx, int64_t n, int C, const float* gamma_dev, const float* beta_dev,
+                    const float* mean_dev, const float* rstd_dev, const float* res_dev, int ldr, int relu,
+                    float* y_dev, int ldy, void* stream);
+int    a3d_bn_backward_sums(const float* x_dev, int ldx, const float* y_dev, int ldy, const float* dy_dev, int lddy,
+                            int64_t n, int C, const float* mean_dev, const float* rstd_dev, int relu,
+                            double* sums_dev, void* workspace_dev, size_t workspace_bytes, void* stream);
+int    a3d_bn_backward_apply(const float* x_dev, int ldx, const float* y_dev, int ldy, const float* dy_dev, int lddy,
+                             int64_t n, int C, const float* gamma_dev, const float* mean_dev, const float* rstd_dev,
+                             int relu, const double* global_sums_dev, int64_t n_global, const double* local_sums_dev,
+                             float* dx_dev, int lddx, float* dres_dev, int lddres, float* dgamma_dev,
+                             float* dbeta_dev, void* stream);
 /* out[c] = sum over rows of x[i][c] (bias gradient of lin_squeeze_head, agile3d.py:43-45); workspace as above */
 int    a3d_column_sums(const float* x_dev, int ldx, int64_t n, int C, float* out_dev,
                        void* workspace_dev, size_t workspace_bytes, void* stream);

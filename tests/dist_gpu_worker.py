@@ -1,0 +1,95 @@
+"""Worker of tests/test_gpu_distributed.py: one data-parallel rank (two of them share the one GPU of the test box;
+gloo backend, rendezvous on 127.0.0.1).  Usage: python dist_gpu_worker.py <mode> <rank> <world> <port> <out_dir>"""
+import os
+import random
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def scene_batch(seed, n):
+    from agile3d_amd import batched_coordinates
+    from agile3d_amd.synthetic import make_scene
+    s = make_scene(n, seed=seed)
+    return s, (batched_coordinates([s["coords"][:, 1:]]), torch.from_numpy(s["raw_xyz"]), torch.from_numpy(s["feats"]),
+               [torch.from_numpy(s["labels"].astype(np.int64))], None, None, [{}], (f"scene{seed:04d}_00",), (0,))
+
+
+def layer_cases():
+    return {"n5000_c64_relu_res": (5000, 64, True, True), "n301_c256": (301, 256, False, False), "n1000_c96_relu": (1000, 96, True, False)}
+
+
+def layer_data(n, C, with_res):
+    g = torch.Generator().manual_seed(n * 7 + C)
+    x = torch.randn(n, C, generator=g) * 2 + 0.5
+    gamma, beta = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.1
+    res = torch.randn(n, C, generator=g) if with_res else None
+    return x, gamma, beta, res, torch.randn(n, C, generator=g)
+
+
+class CaptureSGD:
+    """train_one_step's optimiser interface; keeps the (averaged, unclipped) gradients and the clip coefficient."""
+
+    def __init__(self, model, lr):
+        self.params, self.lr, self.grads, self.coef = dict(model.named_parameters()), lr, None, None
+
+    def step(self, grads, coef):
+        self.grads, self.coef = {k: g.detach().clone() for k, g in grads.items()}, coef
+        with torch.no_grad():
+            for k, g in grads.items():
+                self.params[k].add_(g.reshape(self.params[k].shape), alpha=-self.lr * coef)
+
+
+def main():
+    mode, rank, world, port, out = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), sys.argv[4], sys.argv[5]
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", port
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from agile3d_amd import build_model, default_args
+    dev = torch.device("cuda")
+    args = default_args(bce_loss_coef=1.0, dice_loss_coef=2.0, losses=["bce", "dice"])
+    torch.manual_seed(3)
+    model = build_model(args).to(dev)
+    if mode == "syncbn":
+        from agile3d_amd.engine import Scene
+        from agile3d_amd.train_backbone import BackboneTape
+        s, batch = scene_batch(60 + rank, 30000 + 3000 * rank)
+        model.train()
+        tape = BackboneTape(model, Scene(batch[0].to(dev).to(torch.int32).contiguous()), batch[2].to(dev), sync_bn=True)
+        grads = tape.backward(tape.output.clone())        # L = |pcd_features|^2 / 2: a coherent gradient (random ones
+                                                          # cancel to sums that one flipped ReLU element dominates)
+        # one layer on its own: this rank's rows of a fixed matrix (no chain of ReLUs behind it: exact comparison)
+        from agile3d_amd import backward as B
+        layer = {}
+        for name, (n, C, relu, with_res) in layer_cases().items():
+            x, gamma, beta, res, dy = layer_data(n, C, with_res)
+            lo, hi = (0, n // 3) if rank == 0 else (n // 3, n)
+            xs, rs, ds = x[lo:hi].to(dev), (res[lo:hi].to(dev) if res is not None else None), dy[lo:hi].to(dev)
+            y, m, r, ng = B.bn_sync_forward(xs, gamma.to(dev), beta.to(dev), 1e-5, rs, relu)
+            dx, dg, db, dres = B.bn_sync_backward(xs, y, ds, gamma.to(dev), m, r, ng, relu, with_res)
+            layer[name] = {"y": y.cpu(), "dx": dx.cpu(), "dgamma": dg.cpu(), "dbeta": db.cpu(), "n_global": ng,
+                           "dres": dres.cpu() if dres is not None else None}
+        torch.save({"out": tape.output.cpu(), "grads": {k: v.cpu() for k, v in grads.items()}, "layer": layer,
+                    "bn": {k: v.cpu() for k, v in model.state_dict().items() if "running" in k}},
+                   os.path.join(out, f"syncbn_{rank}.pt"))
+    elif mode == "dp_step":
+        from agile3d_amd.criterion import build_mask_criterion
+        from agile3d_amd.train_step import train_one_step
+        s, batch = scene_batch(70 + rank, 2500 + 200 * rank)
+        opt = CaptureSGD(model, 1e-2)
+        np.random.seed(11 + rank), torch.manual_seed(11 + rank), random.seed(11 + rank)     # main.py:97: seed + rank
+        st = train_one_step(model, build_mask_criterion(args), opt, batch, dev, max_norm=0.1)
+        torch.save({"params": {k: v.detach().cpu() for k, v in model.named_parameters()}, "stats": st,
+                    "grads": {k: v.cpu() for k, v in opt.grads.items()}, "coef": opt.coef},
+                   os.path.join(out, f"dp_{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
