@@ -117,7 +117,6 @@ struct Level {
   uint32_t hmask = 0;
   int* nbr27 = nullptr;         // [27][npad]
   uint32_t* gmask27 = nullptr;  // [npad/16]
-  int* order27 = nullptr;       // [npad/64] 64-row tiles, most offsets first
   // exclusive prefix sums over 64-row tiles of the number of offsets a tile has (popcount of the OR of its four group
   // masks): the conv kernel cuts the (tile, offset) work of a layer into equal shares with them (spconv.hip)
   int* pre27 = nullptr;         // [npad/64 + 1]

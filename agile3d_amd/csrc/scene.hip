@@ -347,36 +347,6 @@ __global__ void k_remap_nbr(const LevelSet S) {
   }
 }
 
-// 64-row conv tiles ordered by cost (number of kernel offsets any of their 4 groups has), most expensive
-// first: a counting sort, one workgroup per level.  Longest-processing-time-first order for the persistent conv
-// workgroups' tile queue -- the cheap tiles fill the tail.  Ties land in arbitrary order (no result depends
-// on the order tiles are processed in).
-__global__ void __launch_bounds__(1024) k_tile_order(const LevelSet S) {
-  __shared__ int hist[32], base[32];
-  const Level& lv = S.lv[blockIdx.x];
-  const uint32_t* gmask = lv.gmask27;
-  const int ntile = lv.npad / 64;
-  if (threadIdx.x < 32) hist[threadIdx.x] = 0;
-  __syncthreads();
-  for (int t = threadIdx.x; t < ntile; t += 1024) {
-    const uint32_t un = gmask[4 * t] | gmask[4 * t + 1] | gmask[4 * t + 2] | gmask[4 * t + 3];
-    atomicAdd(&hist[__popc(un)], 1);
-  }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    int acc = 0;
-    for (int c = 31; c >= 0; --c) {
-      base[c] = acc;
-      acc += hist[c];
-    }
-  }
-  __syncthreads();
-  for (int t = threadIdx.x; t < ntile; t += 1024) {
-    const uint32_t un = gmask[4 * t] | gmask[4 * t + 1] | gmask[4 * t + 2] | gmask[4 * t + 3];
-    lv.order27[atomicAdd(&base[__popc(un)], 1)] = t;
-  }
-}
-
 // pre[t] = number of (tile, offset) pairs of the tiles before tile t, for the three mask tables of a level
 // (blockIdx.y: 0 = 3^3, 1 = stride-2 down, 2 = transposed up) and two tile heights (blockIdx.z: 64 / 128 rows); one
 // workgroup per (level, table, height), serial over 1024-tile chunks (a 1 M-voxel level has 16 k tiles)
@@ -585,7 +555,6 @@ static void carve_phase2(Bump& b, const int* sizes, a3d_scene* sc, Phase2Tmp& t,
     lv.hkeys = b.take<uint64_t>((size_t)lv.hmask + 1);
     lv.hvals = b.take<int>((size_t)lv.hmask + 1);
     lv.nbr27 = b.take<int>((size_t)27 * lv.npad);
-    lv.order27 = b.take<int>(lv.npad / 64);
     lv.pre27 = b.take<int>(lv.npad / 64 + 1);
     lv.pre27b = b.take<int>(lv.npad / 128 + 1);
     if (L < A3D_NUM_LEVELS - 1) {
@@ -619,17 +588,26 @@ extern "C" int a3d_profile_enable(int on) {
   return A3D_OK;
 }
 extern "C" int a3d_profile_read(a3d_prof_entry* out, int max_entries) {
-  int n = 0;
+  int n = 0, bad = 0;
+  hipError_t first = hipSuccess;
   for (auto& r : g_prof) {
-    (void)hipEventSynchronize(r.e1);
+    hipError_t e = hipEventSynchronize(r.e1);
     float ms = 0.f;
-    (void)hipEventElapsedTime(&ms, r.e0, r.e1);
+    if (e == hipSuccess) e = hipEventElapsedTime(&ms, r.e0, r.e1);
+    if (e != hipSuccess) {   // the entry is still returned (ms = -1), the call reports the failure
+      ms = -1.f;
+      if (!bad++) first = e;
+    }
     r.e.ms = ms;
     if (out && n < max_entries) out[n++] = r.e;
     g_event_pool.push_back(r.e0);
     g_event_pool.push_back(r.e1);
   }
   g_prof.clear();
+  if (bad) {
+    set_error("a3d_profile_read: %d event pair(s) could not be read: %s", bad, hipGetErrorString(first));
+    return A3D_ERR_HIP;
+  }
   return n;
 }
 extern "C" const char* a3d_last_error(void) { return a3d::get_error(); }
@@ -815,7 +793,6 @@ extern "C" int a3d_scene_create(const int32_t* coords4_dev, int64_t n_voxels, vo
   k_perm_from_sorted<<<g, T, 0, st>>>(S, 0);
   g = blocks(NL, [&](int L) { return (int64_t)sc->lv[L].npad; });
   k_remap_nbr<<<dim3(g, 27), T, 0, st>>>(S);
-  k_tile_order<<<NL, 1024, 0, st>>>(S);
   g = blocks(NL, [&](int L) { return std::max<int64_t>(sc->lv[L].n, (int64_t)sc->lv[L].hmask + 1); });
   k_xyzb_hashfix<<<g, T, 0, st>>>(S);
   A3D_LAUNCH_CHECK();
@@ -873,7 +850,6 @@ extern "C" int a3d_scene_table(const a3d_scene* s, int level, int which, const v
     case A3D_TAB_XYZB: *ptr_dev = lv.xyzb; *count = (int64_t)lv.n * 4; break;
     case A3D_TAB_NBR27: *ptr_dev = lv.nbr27; *count = (int64_t)27 * lv.npad; break;
     case A3D_TAB_GMASK27: *ptr_dev = lv.gmask27; *count = lv.npad / 16; break;
-    case A3D_TAB_ORDER27: *ptr_dev = lv.order27; *count = lv.npad / 64; break;
     case A3D_TAB_PRE27: *ptr_dev = lv.pre27; *count = lv.npad / 64 + 1; break;
     case A3D_TAB_PREDOWN: if (!has_coarse) goto bad; *ptr_dev = lv.pre_down; *count = npadC / 64 + 1; break;
     case A3D_TAB_PREUP: if (!has_coarse) goto bad; *ptr_dev = lv.pre_up; *count = lv.npad / 64 + 1; break;

@@ -7,18 +7,21 @@
 //
 //   out[u, :] = act( (sum_k in[nbr[k][u], :] @ W[k]) * scale + shift + res[u, :] )
 //
-// k_spconv2 covers the 3^3, 2^3-stride-2, transposed 2^3 and small 1x1 layers: they only differ in the
+// k_conv_sk covers the 3^3, 2^3-stride-2, transposed 2^3 and small 1x1 layers: they only differ in the
 // neighbour table.  k_dense is the gather-free GEMM for the N-point linears of the decoder and the large 1x1
 // convolutions.  k_stem is the 5^3 input convolution (Cin = 3).
 //
 // gfx950 mapping:
-//   * workgroup = 4 waves = 64 output rows x BN output channels; a wave owns one 16-row MFMA group;
-//     v_mfma_f32_16x16x4_f32 (exact fp32) accumulates 16x16 tiles in registers;
+//   * workgroup = 4 waves = 64 (or 128) output rows x BN output channels; a wave owns one (or two) 16-row MFMA
+//     groups; v_mfma_f32_16x16x4_f32 (exact fp32) accumulates 16x16 tiles in registers;
 //   * stage = (kernel offset k, up to 96 input channels): every lane loads its own A fragments of the NEXT stage
 //     straight from global memory (gathered row, 16 bytes per 16-channel step) while the current stage is
-//     multiplied; the packed weight slice goes global->LDS by global_load_lds_dwordx4 into a two-slot ring;
+//     multiplied; the packed weight slice goes global -> LDS by LDS-DMA (global_load_lds_dwordx4, inline asm)
+//     into a two-slot ring;
 //   * offsets k absent from a whole 16-row group are skipped (no gather, no MFMA): rows were sorted by
-//     neighbour pattern when the scene was built (scene.hip), tiles are handed out longest first;
+//     neighbour pattern when the scene was built (scene.hip);
+//   * a layer's (tile, offset, channel chunk) stages are cut into equal shares, one per workgroup; a tile cut by a
+//     share boundary is finished inside the kernel (hand-off of partial accumulators, fixed summation order);
 //   * the K dimension inside a 16-channel step is permuted (channel = 16S + 4g + t for lane group g, MFMA t)
 //     identically for both operands, so one 16-byte load / ds_read_b128 feeds four MFMAs;
 //   * weights are the MFMA A operand: a lane ends up with 4 consecutive output channels of one row, so
@@ -46,312 +49,13 @@ struct ConvArgs {
   const float* res;
   int ldr;
   int relu;
-  float* partial;
-  int kper;
   int zero_row;
   int tag_table, tag_level;   // profiling only
-  int* tile_counter;          // per (cout tile, k split) queue heads, zeroed by the caller; nullptr = static
-  const int* tile_order;      // [n_tiles] order in which 64-row tiles are handed out (most offsets first) or nullptr
   int n_tiles;
-  unsigned long long* dbg_cycles;   // [8] phase cycle sums (A3D_DBG & 64)
-  int dbg;                    // A3D_DBG env: 1 no A gather, 2 no W load, 4 no MFMA, (8 unused), 16 no stage barrier,
-                              // 32 all offsets present, 64 phase cycle sums, 4096 per-tile timeline
 };
 
-// global -> LDS DMA of 64 x 16 bytes: per-lane SOURCE address, LDS image = uniform base + 16 * lane.
-// Issued through inline asm so that hipcc neither tracks it in its s_waitcnt bookkeeping nor drains
-// it with a vmcnt(0) of its own (cdna_hip_programming.md 5.7): completion is waited for explicitly
-// (s_waitcnt vmcnt(0) at the end of every stage).  M0 (the LDS base) is saved and restored.
-__device__ __forceinline__ void glds16(const float* src, unsigned lds_byte_addr) {
-  const unsigned lds_addr = __builtin_amdgcn_readfirstlane(lds_byte_addr);
-  unsigned keep;
-  asm volatile(
-      "s_mov_b32 %0, m0\n\t"
-      "s_mov_b32 m0, %2\n\t"
-      "s_nop 0\n\t"
-      "global_load_lds_dwordx4 %1, off\n\t"
-      "s_mov_b32 m0, %0"
-      : "=&s"(keep)
-      : "v"(src), "s"(lds_addr)
-      : "memory");
-}
-
-template <int N>
-__device__ __forceinline__ void wait_vmcnt() {
-  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
-}
-
-// ------------------------------------------------------------------------------ k_spconv2
-// Second-generation kernel: stage = (offset k, CH input channels) with CH up to 96, so a 96-channel layer
-// has ONE barrier per offset (k_spconv: three), and the gathered rows never touch LDS:
-//   * each lane loads its own MFMA A-fragments straight from global memory (row nbr[k][16w+j], channels
-//     16S+4g..+3 -- the K permutation makes that one 16-byte load), for the NEXT stage while the current
-//     one is multiplied: a whole stage of MFMA time (144 MFMAs at 96x96) hides the gather latency;
-//   * the packed weight slice of the next stage is loaded to registers at the same time and written to the
-//     other half of a two-slot LDS ring after the MFMAs; all loads are plain compiler-tracked loads, so
-//     every wait is exact (no counted-vmcnt protocol, no LDS-DMA);
-//   * a wave whose 16-row group lacks offset k issues neither loads nor MFMAs for it.
-// Workgroup = 4 waves = 64 output rows x BN columns; persistent, tiles from an atomic queue; split-K and the
-// epilogue are those of k_spconv.
-template <int BN, int CH, bool TR>
-__global__ void __launch_bounds__(256, CH >= 64 ? 2 : 3) k_spconv2(const ConvArgs a) {
-  constexpr int NCT = BN / 16, NS = CH / 16, NW = 4, kTile = 64;
-  constexpr int NPIECE = NS * NCT;             // 1 KiB weight pieces per stage
-  constexpr int WV = (NPIECE + NW - 1) / NW;   // pieces per wave (the last ones guarded when NPIECE % NW != 0)
-  constexpr int WF = NPIECE * 256;             // floats per ring slot
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  float* wring = (float*)smem;                         // [2][WF]
-  int* idx_lds = (int*)(wring + 2 * WF);               // [kper][64] gather rows of the tile
-  int* tile_slot = idx_lds + a.kper * kTile;
-  const unsigned ring_addr = (unsigned)(size_t)wring;
-
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int g = lane >> 4, j = lane & 15;
-  const int ct0 = blockIdx.y * NCT;
-  const int kbeg = blockIdx.z * a.kper;
-  const int kend = min(a.K, kbeg + a.kper);
-  const int nchunk = a.cin / CH;
-  const int cin16 = a.cin >> 4, cout16 = a.cout >> 4;
-  int* counter = a.tile_counter ? a.tile_counter + (blockIdx.y * gridDim.z + blockIdx.z) : nullptr;
-  const float* wlane = a.w + (size_t)ct0 * 256 + lane * 4;
-  // this wave's weight pieces q = wave + NW*i of a stage: source offset (floats) and LDS byte offset
-  int wsrc[WV];
-  unsigned wdst[WV];
-#pragma unroll
-  for (int i = 0; i < WV; ++i) {
-    const int q = wave + NW * i;
-    wsrc[i] = ((q / NCT) * cout16 + (q % NCT)) * 256;
-    wdst[i] = (unsigned)q * 1024u;
-  }
-  const bool timing = (a.dbg & 64) && a.dbg_cycles;   // phase cycle sums (A3D_DBG=64), see launch_conv
-  unsigned long long tc[6] = {0, 0, 0, 0, 0, 0};
-  unsigned long long t_prev = timing ? __builtin_amdgcn_s_memtime() : 0;
-  auto lap = [&](int slot) {
-    if (timing) {
-      const unsigned long long t = __builtin_amdgcn_s_memtime();
-      tc[slot] += t - t_prev;
-      t_prev = t;
-    }
-  };
-
-  for (int tile = blockIdx.x;; tile += gridDim.x) {
-    if (counter) {
-      if (tid == 0) *tile_slot = atomicAdd(counter, 1);
-      __syncthreads();
-      tile = *tile_slot;
-    }
-    if (tile >= a.n_tiles) break;
-    const int r0 = (a.tile_order ? a.tile_order[tile] : tile) * kTile;
-    const int myrow = r0 + 16 * wave + j;          // this lane's output row (and gather row of its group)
-    const bool tl = (a.dbg & 4096) && a.dbg_cycles && tid == 0 && tile < 8000;   // per-tile timeline (A3D_DBG=4096)
-    unsigned long long* rec = a.dbg_cycles + 16 + (size_t)tile * 8;
-    if (tl) {
-      rec[0] = __builtin_amdgcn_s_memtime();
-      rec[4] = __builtin_amdgcn_s_getreg(((32 - 1) << 11) | 4);      // HW_ID
-      rec[5] = __builtin_amdgcn_s_getreg(((4 - 1) << 11) | 20);      // XCC_ID
-      rec[6] = blockIdx.x;
-    }
-    uint32_t un = 0xffffffffu, gm = 0xffffffffu;
-    if (a.gmask) {
-      const uint32_t* gp = a.gmask + (r0 >> 4);
-      un = gp[0] | gp[1] | gp[2] | gp[3];
-      gm = __builtin_amdgcn_readfirstlane(gp[wave]);
-    }
-    un = __builtin_amdgcn_readfirstlane(un);
-    if (a.dbg & 32) un = gm = 0xffffffffu;   // experiment: every offset present in every group
-    if (kend < 32) un &= (1u << kend) - 1u;
-    un &= ~((1u << kbeg) - 1u);
-    // gather rows of the tile for every offset of this split: all loads in flight, then the LDS stores
-    {
-      const int total = (kend - kbeg) * kTile;
-      for (int base = tid; base < total; base += 8 * 256) {
-        int v[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          const int e = base + u * 256;
-          const int kk = e >> 6, r = e & 63;
-          v[u] = 0;
-          if (e < total) v[u] = a.nbr ? a.nbr[(size_t)(kbeg + kk) * a.nbr_stride + r0 + r] : min(r0 + r, a.n_in - 1);
-        }
-#pragma unroll
-        for (int u = 0; u < 8; ++u)
-          if (base + u * 256 < total) idx_lds[base + u * 256] = v[u];
-      }
-    }
-    __syncthreads();
-    lap(0);   // queue + masks + idx table
-
-    f32x4 acc[NCT];
-#pragma unroll
-    for (int ct = 0; ct < NCT; ++ct) acc[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    auto next_k = [&](int k) {               // next offset of the tile after k (32 = none)
-      const uint32_t rest = k >= 31 ? 0u : un & ~((2u << k) - 1u);
-      return rest ? __builtin_ctz(rest) : 32;
-    };
-    // neighbour row of this lane for offset k (the zero row when the group does not have k: never read then)
-    auto nbr_row = [&](int k) -> int {
-      if (a.dbg & 1) return j;
-      return idx_lds[(k - kbeg) * kTile + 16 * wave + j];
-    };
-    f32x4 an[NS];
-    // stage (k, c): this lane's A fragments (if its group has k) into registers, this wave's weight pieces by
-    // LDS-DMA into ring slot `slot`.  The DMA is inline asm the compiler does not track: every stage ends with
-    // an explicit vmcnt(0) before the barrier, by which time both have had a whole stage of MFMAs to land.
-    auto load_stage = [&](int k, int c, int slot, int row) {
-      if ((gm >> k) & 1u) {
-        const float* ar = a.in + (size_t)row * a.ldi + c * CH + 4 * g;
-#pragma unroll
-        for (int S = 0; S < NS; ++S) an[S] = *(const f32x4*)(ar + 16 * S);
-      }
-      const float* wst = wlane + ((size_t)k * cin16 + (size_t)c * NS) * cout16 * 256;
-      const unsigned dst = ring_addr + (unsigned)slot * (WF * 4u);
-#pragma unroll
-      for (int i = 0; i < WV; ++i)
-        if ((NPIECE % NW == 0 || wave + NW * i < NPIECE) && !(a.dbg & 2)) glds16(wst + wsrc[i], dst + wdst[i]);
-    };
-    // gather rows are requested one offset ahead of the A loads that need them:
-    //   row_cur = row for offset k (being computed / chunk-loaded), row_nxt = row for the offset after k
-    int k = un ? __builtin_ctz(un) : 32, c = 0, slot = 0;
-    int k1 = k < 32 ? next_k(k) : 32;
-    int row_cur = 0, row_nxt = 0;
-    if (k < 32) {
-      if ((gm >> k) & 1u) row_cur = nbr_row(k);
-      if (k1 < 32 && ((gm >> k1) & 1u)) row_nxt = nbr_row(k1);
-      load_stage(k, 0, 0, row_cur);
-    }
-    wait_vmcnt<0>();
-    __builtin_amdgcn_s_barrier();
-    if (tl) rec[1] = __builtin_amdgcn_s_memtime();
-    while (k < 32) {
-      f32x4 ac[NS];
-      const bool present = (gm >> k) & 1u;
-#pragma unroll
-      for (int S = 0; S < NS; ++S) ac[S] = an[S];
-      // next stage: another chunk of k, or the first chunk of k1
-      const bool same_k = c + 1 < nchunk;
-      const int k2 = same_k ? k : k1, c2 = same_k ? c + 1 : 0;
-      if (k2 < 32) {
-        load_stage(k2, c2, slot ^ 1, same_k ? row_cur : row_nxt);   // in flight behind this stage's MFMAs
-        if (!same_k) {
-          row_cur = row_nxt;
-          k1 = next_k(k2);
-          if (k1 < 32 && ((gm >> k1) & 1u)) row_nxt = nbr_row(k1);   // lands during the next stage
-        }
-      }
-      lap(1);   // stage control + load issue
-      if (present && !(a.dbg & 4)) {
-        const f32x4* Ws = (const f32x4*)(wring + slot * WF) + lane;
-        f32x4 b[2][NCT];
-#pragma unroll
-        for (int ct = 0; ct < NCT; ++ct) b[0][ct] = Ws[ct * 64];
-#pragma unroll
-        for (int S = 0; S < NS; ++S) {
-          if (S + 1 < NS) {           // next k-step's weight fragments before this one's MFMAs
-#pragma unroll
-            for (int ct = 0; ct < NCT; ++ct) b[(S + 1) & 1][ct] = Ws[((S + 1) * NCT + ct) * 64];
-          }
-          __builtin_amdgcn_sched_barrier(0);          // ... and no further ahead than that (VGPRs)
-          // weights as the A operand: D[i][j] = sum_k W[k][16ct+i] X[row j][k], i.e. lane (g, j) ends up with
-          // output channels 16ct+4g..+3 of row j -> 16-byte epilogue accesses
-#pragma unroll
-          for (int t = 0; t < 4; ++t)
-#pragma unroll
-            for (int ct = 0; ct < NCT; ++ct)
-              acc[ct] = TR ? __builtin_amdgcn_mfma_f32_16x16x4f32(b[S & 1][ct][t], ac[S][t], acc[ct], 0, 0, 0)
-                           : __builtin_amdgcn_mfma_f32_16x16x4f32(ac[S][t], b[S & 1][ct][t], acc[ct], 0, 0, 0);
-        }
-      }
-      lap(4);   // fragment reads + MFMA
-      wait_vmcnt<0>();
-      if (!(a.dbg & 16)) __builtin_amdgcn_s_barrier();   // next slot landed for every wave; current one is free
-      lap(2);   // wait + barrier
-      slot ^= 1;
-      k = k2;
-      c = c2;
-    }
-
-    if constexpr (TR) {
-    if (tl) rec[2] = __builtin_amdgcn_s_memtime();
-    // ---- epilogue: acc[ct] = output channels (ct0+ct)*16 + 4g .. +3 of row `myrow`
-    if (a.partial) {
-      float* P = a.partial + (size_t)blockIdx.z * ((size_t)a.n_tiles * kTile) * a.cout + (size_t)myrow * a.cout;
-#pragma unroll
-      for (int ct = 0; ct < NCT; ++ct) *(f32x4*)(P + (ct0 + ct) * 16 + 4 * g) = acc[ct];
-    } else if (myrow < a.n_out) {
-      const int orow = a.out_map ? a.out_map[myrow] : myrow;
-      float* po = a.out + (size_t)orow * a.ldo + ct0 * 16 + 4 * g;
-      const float* pr = a.res ? a.res + (size_t)orow * a.ldr + ct0 * 16 + 4 * g : nullptr;
-      f32x4 rv[NCT];
-      if (pr) {
-#pragma unroll
-        for (int ct = 0; ct < NCT; ++ct) rv[ct] = *(const f32x4*)(pr + ct * 16);
-      }
-#pragma unroll
-      for (int ct = 0; ct < NCT; ++ct) {
-        f32x4 v = acc[ct];
-        if (a.scale) v *= *(const f32x4*)(a.scale + (ct0 + ct) * 16 + 4 * g);
-        if (a.shift) v += *(const f32x4*)(a.shift + (ct0 + ct) * 16 + 4 * g);
-        if (pr) v += rv[ct];
-        if (a.relu) {
-#pragma unroll
-          for (int t = 0; t < 4; ++t) v[t] = fmaxf(v[t], 0.f);
-        }
-        *(f32x4*)(po + ct * 16) = v;
-      }
-    }
-    } else {
-      // untransposed accumulators: column = lane & 15, row = 4 * (lane >> 4) + reg
-      const int rg = r0 + 16 * wave + 4 * g;
-      if (a.partial) {
-        float* P = a.partial + (size_t)blockIdx.z * ((size_t)a.n_tiles * kTile) * a.cout;
-#pragma unroll
-        for (int ct = 0; ct < NCT; ++ct)
-#pragma unroll
-          for (int t = 0; t < 4; ++t) P[(size_t)(rg + t) * a.cout + (ct0 + ct) * 16 + j] = acc[ct][t];
-      } else {
-        int orow[4];
-        bool ok[4];
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-          ok[t] = rg + t < a.n_out;
-          orow[t] = ok[t] ? rg + t : a.n_out - 1;
-        }
-        if (a.out_map) {
-#pragma unroll
-          for (int t = 0; t < 4; ++t) orow[t] = a.out_map[orow[t]];
-        }
-#pragma unroll
-        for (int ct = 0; ct < NCT; ++ct) {
-          const int col = (ct0 + ct) * 16 + j;
-          const float sc = a.scale ? a.scale[col] : 1.f, sh = a.shift ? a.shift[col] : 0.f;
-#pragma unroll
-          for (int t = 0; t < 4; ++t) {
-            float v = acc[ct][t] * sc + sh;
-            if (a.res) v += a.res[(size_t)orow[t] * a.ldr + col];
-            if (a.relu) v = fmaxf(v, 0.f);
-            if (ok[t]) a.out[(size_t)orow[t] * a.ldo + col] = v;
-          }
-        }
-      }
-    }
-    if (!a.partial && a.zero_row >= 0 && tile == 0 && tid < BN) a.out[(size_t)a.zero_row * a.ldo + ct0 * 16 + tid] = 0.f;
-    __syncthreads();   // tile_slot / the idx table are rewritten for the next tile
-    if (tl) {
-      rec[3] = __builtin_amdgcn_s_memtime();
-      rec[7] = __builtin_popcount(un);
-    }
-    lap(5);   // epilogue + end-of-tile barrier
-  }
-  if (timing && lane == 0) {
-#pragma unroll
-    for (int i = 0; i < 6; ++i) atomicAdd(&a.dbg_cycles[i], tc[i]);
-    atomicAdd(&a.dbg_cycles[6], 1ULL);
-  }
-}
-
 // ------------------------------------------------------------------------------ k_conv_sk
-// Third-generation kernel: the stage loop of k_spconv2 with
+// The convolution kernel:
 //   * a STATIC equal-share partition of the layer's work ("stream-K"): the (cout block, 64-row tile, offset, channel
 //     chunk) stages of a layer form one line; workgroup w of G owns the stretch [w Tot / G, (w+1) Tot / G) of it
 //     (cost of a tile = its number of stages + `ov` units for its prologue/epilogue, prefix sums from the scene's
@@ -404,7 +108,8 @@ __device__ __forceinline__ void glds16_s(const float* sbase, unsigned voff, unsi
 // the MFMAs -- which would also wait for the LDS-DMA pieces it cannot see.  simm16: vmcnt 0, expcnt 7, lgkmcnt 15.
 __device__ __forceinline__ void wait_all_vmem() { __builtin_amdgcn_s_waitcnt(0x0F70); }
 
-template <int BN, int CH, int RG>   // BN output columns, CH input channels per stage, RG 16-row groups per wave
+template <int BN, int CH, int RG, bool DBG = false>   // BN output columns, CH input channels per stage, RG 16-row groups per
+                                                      // wave; DBG: the A3D_DBG ablation switches (compiled out of the product kernels)
 __global__ void __launch_bounds__(256, 2) k_conv_sk(const SkArgs a) {
   constexpr int NCT = BN / 16, NS = CH / 16, NW = 4, kTile = 64 * RG;
   constexpr int NPIECE = NS * NCT;
@@ -555,7 +260,7 @@ __global__ void __launch_bounds__(256, 2) k_conv_sk(const SkArgs a) {
       // stage (k, c): this lane's A fragments (for its groups that have k), this wave's weight pieces by LDS-DMA
       auto load_stage = [&](f32x4 (&A)[RG][NS], int kk, int cc, int slot, const int (&rows)[RG]) {
         const char* ar = inb + (size_t)cc * (CH * 4);
-        if (((gm >> kk) & 1u) && !(a.dbg & 1)) {
+        if (((gm >> kk) & 1u) && !(DBG && (a.dbg & 1))) {
 #pragma unroll
           for (int r = 0; r < RG; ++r) {
             const unsigned roff = (unsigned)rows[r] * a.in_row_bytes + lane_a_off;
@@ -567,10 +272,10 @@ __global__ void __launch_bounds__(256, 2) k_conv_sk(const SkArgs a) {
         const unsigned dst = ring_addr + (unsigned)slot * (WF * 4u);
 #pragma unroll
         for (int i = 0; i < WV; ++i)
-          if ((NPIECE % NW == 0 || wave + NW * i < NPIECE) && !(a.dbg & 2)) glds16_s(wst, wsrc[i], dst + wdst[i]);
+          if ((NPIECE % NW == 0 || wave + NW * i < NPIECE) && !(DBG && (a.dbg & 2))) glds16_s(wst, wsrc[i], dst + wdst[i]);
       };
       auto compute = [&](const f32x4 (&A)[RG][NS], int kk, int slot) {
-        if (!((gm >> kk) & 1u) || (a.dbg & 4)) return;
+        if (!((gm >> kk) & 1u) || (DBG && (a.dbg & 4))) return;
         const f32x4* Ws = (const f32x4*)(wring + slot * WF) + lane;
         if constexpr (RG == 1) {
           // one group per wave: the weight fragments of a whole 16-channel step in registers, the next step's read
@@ -615,7 +320,7 @@ __global__ void __launch_bounds__(256, 2) k_conv_sk(const SkArgs a) {
         }
       };
       f32x4 A0[RG][NS], A1[RG][NS];
-      if (a.dbg & 1) {
+      if (DBG && (a.dbg & 1)) {
 #pragma unroll
         for (int r = 0; r < RG; ++r)
 #pragma unroll
@@ -738,54 +443,6 @@ __global__ void __launch_bounds__(256, 2) k_conv_sk(const SkArgs a) {
       }
     }
   }
-}
-
-static int conv2_ch(int cin, int bn) {   // input channels per stage: largest of 96/64/32 dividing cin with a ring <= 74 KB
-  static int forced = -1;
-  if (forced < 0) {
-    const char* e = getenv("A3D_CONV2_CH");   // experiment: force CH for 96-column workgroups
-    forced = e ? atoi(e) : 0;
-  }
-  if (forced && bn == 96 && cin % forced == 0) return forced;
-  const int cand[3] = {96, 64, 32};
-  for (int i = 0; i < 3; ++i)
-    if (cin % cand[i] == 0 && 2 * cand[i] * bn * 4 <= 74 * 1024) return cand[i];
-  return 0;
-}
-
-// sum the split-K partials and apply the epilogue
-__global__ void k_splitk_epilogue(const float* __restrict__ partial, int ksplit, size_t split_stride,
-                                  int n_out, int cout, const int* __restrict__ out_map,
-                                  const float* __restrict__ scale, const float* __restrict__ shift,
-                                  const float* __restrict__ res, int ldr, int relu, float* out, int ldo,
-                                  int zero_row) {
-  const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const int c4 = cout >> 2;
-  const size_t total = (size_t)n_out * c4;
-  if (e < total) {
-    const int vrow = (int)(e / c4), col = (int)(e % c4) * 4;
-    f32x4 s = (f32x4){0.f, 0.f, 0.f, 0.f};
-    // loads in batches of 9 so their latencies overlap; the additions keep the z order (bit-stable)
-    const float* pp = partial + (size_t)vrow * cout + col;
-    int z = 0;
-    for (; z + 9 <= ksplit; z += 9) {
-      f32x4 v[9];
-#pragma unroll
-      for (int u = 0; u < 9; ++u) v[u] = *(const f32x4*)(pp + (size_t)(z + u) * split_stride);
-#pragma unroll
-      for (int u = 0; u < 9; ++u) s += v[u];
-    }
-    for (; z < ksplit; ++z) s += *(const f32x4*)(pp + (size_t)z * split_stride);
-    const int orow = out_map ? out_map[vrow] : vrow;
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      float v = s[t] * (scale ? scale[col + t] : 1.f) + (shift ? shift[col + t] : 0.f);
-      if (res) v += res[(size_t)orow * ldr + col + t];
-      if (relu) v = fmaxf(v, 0.f);
-      out[(size_t)orow * ldo + col + t] = v;
-    }
-  }
-  if (zero_row >= 0 && e < (size_t)cout) out[(size_t)zero_row * ldo + e] = 0.f;
 }
 
 // ------------------------------------------------------------------------------ dense GEMM
@@ -1073,42 +730,8 @@ __global__ void k_pack_weight(const float* __restrict__ w, int K, int cin, int c
 }
 
 // ------------------------------------------------------------------------------ host: launch
-struct ConvPlan {
-  int bn, tile, ksplit, kper, ntile, grid_x, ch;
-  size_t lds, partial_floats;
-};
-
 constexpr int kMaxQueuesPerOp = 1024;  // ints of zeroed per-op state: k_conv_sk ticket [0], failure word [1], hand-off flags [2..2+G)
 constexpr int kSkMaxG = 512;
-
-static ConvPlan plan_conv(int n_rows, int K, int cin, int cout) {
-  ConvPlan p;
-  p.tile = 64;   // k_spconv2: 4 waves x one 16-row group
-  const int kConvTile = p.tile;
-  p.ntile = (int)((n_rows + kConvTile - 1) / kConvTile);
-  if (p.ntile < 1) p.ntile = 1;
-  int bn = (cout % 128 == 0) ? 128 : cout;
-  if (cout % 64 == 0 && (int64_t)p.ntile * (cout / bn) < 256 && bn > 64) bn = 64;
-  p.bn = bn;
-  const int blocks = p.ntile * (cout / bn);
-  int ksplit = 1;
-  if (K > 1 && blocks < 512) {
-    ksplit = (768 + blocks - 1) / blocks;
-    if (ksplit > K) ksplit = K;
-  }
-  p.kper = (K + ksplit - 1) / ksplit;
-  p.ksplit = (K + p.kper - 1) / p.kper;
-  p.ch = conv2_ch(cin, bn);
-  p.lds = (size_t)2 * p.ch * bn * 4 + (size_t)p.kper * kConvTile * 4 + 16;   // two-slot weight ring + gather-row table
-  p.partial_floats = p.ksplit > 1 ? (size_t)p.ksplit * p.ntile * kConvTile * cout : 0;
-  const int per_cu = (int)(160 * 1024 / p.lds > 4 ? 4 : 160 * 1024 / p.lds);
-  const int max_resident = 256 * per_cu;   // CUs x resident workgroups
-  int gx = max_resident / ((cout / bn) * p.ksplit);
-  if (gx < 1) gx = 1;
-  p.grid_x = p.ntile < gx ? p.ntile : gx;
-  return p;
-}
-
 
 // ---- k_conv_sk: launch geometry
 struct SkPlan {
@@ -1167,124 +790,20 @@ static void allow_big_lds() {
   static bool done = false;
   if (done) return;
   done = true;
-#define A3D_BIG2(BN_, CH_) \
-  (void)hipFuncSetAttribute((const void*)k_spconv2<BN_, CH_, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
-  (void)hipFuncSetAttribute((const void*)k_spconv2<BN_, CH_, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  A3D_BIG2(32, 32) A3D_BIG2(32, 64) A3D_BIG2(32, 96) A3D_BIG2(64, 32) A3D_BIG2(64, 64) A3D_BIG2(64, 96)
-  A3D_BIG2(96, 32) A3D_BIG2(96, 48) A3D_BIG2(96, 64) A3D_BIG2(96, 96) A3D_BIG2(128, 32) A3D_BIG2(128, 64)
-#undef A3D_BIG2
 #define A3D_BIG3(BN_, CH_) \
   (void)hipFuncSetAttribute((const void*)k_conv_sk<BN_, CH_, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
   (void)hipFuncSetAttribute((const void*)k_conv_sk<BN_, CH_, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   A3D_BIG3(32, 32) A3D_BIG3(32, 64) A3D_BIG3(32, 96) A3D_BIG3(64, 32) A3D_BIG3(64, 64) A3D_BIG3(64, 96)
   A3D_BIG3(96, 32) A3D_BIG3(96, 64) A3D_BIG3(96, 96) A3D_BIG3(128, 32) A3D_BIG3(128, 64)
 #undef A3D_BIG3
+  (void)hipFuncSetAttribute((const void*)k_conv_sk<96, 96, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  (void)hipFuncSetAttribute((const void*)k_conv_sk<96, 96, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  (void)hipFuncSetAttribute((const void*)k_conv_sk<128, 64, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   (void)hipFuncSetAttribute((const void*)k_dense<8, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   (void)hipFuncSetAttribute((const void*)k_dense<8, 6>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   (void)hipFuncSetAttribute((const void*)k_dense<6, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   (void)hipFuncSetAttribute((const void*)k_dense<6, 6>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 }
-
-static int launch_conv_sk(ConvArgs c, const int* pre64, const int* pre128, float* slab_ws, size_t slab_ws_floats, int* state, hipStream_t st);
-static bool use_sk() {
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("A3D_CONV_SK"); v = e ? atoi(e) : 1; }
-  return v != 0;
-}
-static int launch_conv(ConvArgs a, float* partial_ws, size_t partial_ws_floats, int* queue_heads, hipStream_t st,
-                       const int* pre = nullptr, const int* pre128 = nullptr) {
-  if (use_sk() && (a.K == 1 || (pre && pre128)))
-    return launch_conv_sk(a, pre, pre128, partial_ws, partial_ws_floats, queue_heads, st);
-  allow_big_lds();
-  {
-    static int dbg = -1;
-    if (dbg < 0) {
-      const char* e = getenv("A3D_DBG");
-      dbg = e ? atoi(e) : 0;
-    }
-    a.dbg = dbg;
-    a.dbg_cycles = nullptr;
-    if (dbg & (64 | 4096)) {
-      static unsigned long long* buf = nullptr;
-      if (!buf) (void)hipMalloc(&buf, (size_t)1 << 20);
-      (void)hipMemsetAsync(buf, 0, (size_t)1 << 20, st);
-      a.dbg_cycles = buf;
-    }
-  }
-  if (a.cin % 32 != 0 || a.cout % 16 != 0 || !(a.cout % 128 == 0 || a.cout == 32 || a.cout == 64 || a.cout == 96)) {
-    set_error("spconv: unsupported channels cin=%d cout=%d", a.cin, a.cout);
-    return A3D_ERR_UNSUPPORTED;
-  }
-  if (a.K > 32) {
-    set_error("spconv: kernel volume %d > 32", a.K);
-    return A3D_ERR_UNSUPPORTED;
-  }
-  ConvPlan p = plan_conv(a.n_out, a.K, a.cin, a.cout);
-  a.kper = p.kper;
-  a.n_tiles = p.ntile;
-  a.tile_counter = nullptr;
-  a.partial = nullptr;
-  int grid_x = p.ntile;
-  if (queue_heads && (a.cout / p.bn) * p.ksplit <= kMaxQueuesPerOp && p.grid_x < p.ntile) {
-    a.tile_counter = queue_heads;   // persistent workgroups + dynamic tile queue
-    grid_x = p.grid_x;
-  }
-  if (p.ksplit > 1) {
-    if (p.partial_floats > partial_ws_floats) {
-      set_error("spconv: split-K workspace too small");
-      return A3D_ERR_WORKSPACE;
-    }
-    a.partial = partial_ws;
-  }
-  dim3 grid(grid_x, a.cout / p.bn, p.ksplit);
-  {
-  ProfScope ps(st, A3D_PROF_SPCONV, p.bn, a.K, a.cin, a.cout, a.n_out, a.tag_table, a.tag_level, p.ksplit);
-  if (!p.ch) {
-    set_error("spconv: no stage size for cin=%d with %d-column workgroups", a.cin, p.bn);
-    return A3D_ERR_UNSUPPORTED;
-  }
-  {
-    static int tr = -1;
-    if (tr < 0) { const char* e = getenv("A3D_CONV2_TR"); tr = e ? atoi(e) : 1; }
-#define A3D_L2(BN_, CH_) \
-  if (p.bn == BN_ && p.ch == CH_) { if (tr) k_spconv2<BN_, CH_, true><<<grid, 256, p.lds, st>>>(a); else k_spconv2<BN_, CH_, false><<<grid, 256, p.lds, st>>>(a); } else
-    A3D_L2(32, 32) A3D_L2(32, 64) A3D_L2(32, 96) A3D_L2(64, 32) A3D_L2(64, 64) A3D_L2(64, 96)
-    A3D_L2(96, 32) A3D_L2(96, 48) A3D_L2(96, 64) A3D_L2(96, 96) A3D_L2(128, 32) A3D_L2(128, 64)
-    { set_error("spconv2: no kernel for BN %d CH %d", p.bn, p.ch); return A3D_ERR_UNSUPPORTED; }
-#undef A3D_L2
-  }
-  }
-  A3D_LAUNCH_CHECK();
-  if (a.dbg_cycles && (a.dbg & 4096)) {
-    static unsigned long long tl[8000 * 8 + 16];
-    (void)hipMemcpyAsync(tl, a.dbg_cycles, sizeof(tl), hipMemcpyDeviceToHost, st);
-    (void)hipStreamSynchronize(st);
-    for (int t = 0; t < p.ntile && t < 8000; ++t) {
-      const unsigned long long* r = tl + 16 + (size_t)t * 8;
-      fprintf(stderr, "TT %d wg %llu hwid %llu xcc %llu stages %llu t %llu %llu %llu %llu\n", t, r[6], r[4], r[5], r[7], r[0],
-              r[1], r[2], r[3]);
-    }
-  }
-  if (a.dbg_cycles && (a.dbg & 64)) {
-    unsigned long long h[8];
-    (void)hipMemcpyAsync(h, a.dbg_cycles, 64, hipMemcpyDeviceToHost, st);
-    (void)hipStreamSynchronize(st);
-    const double w = (double)(h[6] ? h[6] : 1);
-    fprintf(stderr, "[spconv<%d> K=%d %d->%d n=%d] per-wave cycles: setup %.0f ctrl %.0f wait+barrier %.0f issue %.0f mfma %.0f epilogue %.0f (waves %llu)\n",
-            p.bn, a.K, a.cin, a.cout, a.n_out, h[0] / w, h[1] / w, h[2] / w, h[3] / w, h[4] / w, h[5] / w, h[6]);
-  }
-  if (p.ksplit > 1) {
-    ProfScope ps(st, A3D_PROF_SPLITK, p.bn, a.K, a.cin, a.cout, a.n_out, a.tag_table, a.tag_level, p.ksplit);
-    const size_t total = (size_t)a.n_out * (a.cout / 4);
-    const size_t thr = total > (size_t)a.cout ? total : (size_t)a.cout;
-    k_splitk_epilogue<<<(unsigned)((thr + 255) / 256), 256, 0, st>>>(
-        partial_ws, p.ksplit, (size_t)p.ntile * p.tile * a.cout, a.n_out, a.cout, a.out_map, a.scale, a.shift,
-        a.res, a.ldr, a.relu, a.out, a.ldo, a.zero_row);
-    A3D_LAUNCH_CHECK();
-  }
-  return A3D_OK;
-}
-
 
 static int launch_conv_sk(ConvArgs c, const int* pre64, const int* pre128, float* slab_ws, size_t slab_ws_floats, int* state,
                           hipStream_t st) {
@@ -1321,7 +840,6 @@ static int launch_conv_sk(ConvArgs c, const int* pre64, const int* pre128, float
   SkArgs a;
   memset(&a, 0, sizeof(a));
   c.n_tiles = p.ntile;
-  c.kper = c.K;
   a.c = c;
   const int* pre = p.rg == 2 ? pre128 : pre64;
   a.pre = c.K > 1 ? pre : nullptr;
@@ -1343,6 +861,16 @@ static int launch_conv_sk(ConvArgs c, const int* pre64, const int* pre128, float
     return A3D_ERR_INVALID;
   }
   ProfScope ps(st, A3D_PROF_SPCONV, p.bn, c.K, c.cin, c.cout, c.n_out, c.tag_table, c.tag_level, 1);
+  if (a.dbg) {   // ablation builds of the two shapes the measurements of DESIGN.md 4.1 use
+    if (p.bn == 96 && p.ch == 96 && p.rg == 1) k_conv_sk<96, 96, 1, true><<<p.G, 256, p.lds, st>>>(a);
+    else if (p.bn == 96 && p.ch == 96 && p.rg == 2) k_conv_sk<96, 96, 2, true><<<p.G, 256, p.lds, st>>>(a);
+    else if (p.bn == 128 && p.ch == 64 && p.rg == 1) k_conv_sk<128, 64, 1, true><<<p.G, 256, p.lds, st>>>(a);
+    else a.dbg = 0;
+    if (a.dbg) {
+      A3D_LAUNCH_CHECK();
+      return A3D_OK;
+    }
+  }
 #define A3D_L3(BN_, CH_) \
   if (p.bn == BN_ && p.ch == CH_) { if (p.rg == 2) k_conv_sk<BN_, CH_, 2><<<p.G, 256, p.lds, st>>>(a); else k_conv_sk<BN_, CH_, 1><<<p.G, 256, p.lds, st>>>(a); } else
   A3D_L3(32, 32) A3D_L3(32, 64) A3D_L3(32, 96) A3D_L3(64, 32) A3D_L3(64, 64) A3D_L3(64, 96)
@@ -1387,8 +915,6 @@ static int layout_program(const a3d_scene* s, const a3d_buf_desc* bufs, int n_bu
       set_error("program: op %d leaves the level range", i);
       return A3D_ERR_INVALID;
     }
-    ConvPlan p = plan_conv(s->lv[lvl_out].n, o.kernel_volume, o.cin, o.cout);
-    if (p.partial_floats > pf) pf = p.partial_floats;
     SkPlan q = plan_sk(s->lv[lvl_out].n, o.kernel_volume, o.cin, o.cout, true);
     if (q.slab_floats > pf) pf = q.slab_floats;
   }
@@ -1552,11 +1078,6 @@ extern "C" int a3d_program_run(const a3d_scene* s, const a3d_buf_desc* bufs, int
         a.nbr = s->lv[Lin].nbr27;
         a.nbr_stride = s->lv[Lin].npad;
         a.gmask = s->lv[Lin].gmask27;
-        {
-          static int use_order = -1;
-          if (use_order < 0) { const char* e = getenv("A3D_TILE_ORDER"); use_order = e ? atoi(e) : 1; }
-          a.tile_order = use_order ? s->lv[Lin].order27 : nullptr;   // 64-row tiles
-        }
         pre = s->lv[Lin].pre27;
         pre128 = s->lv[Lin].pre27b;
         break;
@@ -1588,7 +1109,7 @@ extern "C" int a3d_program_run(const a3d_scene* s, const a3d_buf_desc* bufs, int
       rc = launch_dense(a.in, a.ldi, nullptr, 0, a.n_out, a.cin, a.cout, a.w, a.scale, a.shift, a.res, a.ldr, a.relu,
                         a.out, a.ldo, a.zero_row, Lin, a.out_map, st);
     else
-      rc = launch_conv(a, partial, L.partial_floats, queues + (size_t)i * kMaxQueuesPerOp, st, pre, pre128);
+      rc = launch_conv_sk(a, pre, pre128, partial, L.partial_floats, queues + (size_t)i * kMaxQueuesPerOp, st);
     if (rc != A3D_OK) return rc;
   }
   return A3D_OK;
@@ -1629,7 +1150,7 @@ extern "C" int a3d_linear(const float* in_dev, int ldi, const float* in_add_dev,
   a.zero_row = -1;
   a.tag_table = A3D_OP_LINEAR;
   a.tag_level = -1;
-  // workspace (optional): >= 512 bytes of ZEROED memory = the tile queue heads of this call
-  int* queues = (workspace_dev && workspace_bytes >= (size_t)kMaxQueuesPerOp * 4) ? (int*)workspace_dev : nullptr;
-  return launch_conv(a, nullptr, 0, queues, (hipStream_t)stream);
+  (void)workspace_dev;
+  (void)workspace_bytes;   // a 1x1 layer runs whole tiles (no hand-off state)
+  return launch_conv_sk(a, nullptr, nullptr, nullptr, 0, nullptr, (hipStream_t)stream);
 }

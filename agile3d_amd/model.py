@@ -33,6 +33,40 @@ def default_args(**overrides):
     return a
 
 
+def kernel_order_permutation(kernel_volume: int):
+    """perm[k_x_fastest] = k_z_fastest for a cubic kernel of ``kernel_volume`` = s^3 offsets: the library (and
+    oracle/backbone.py) enumerate kernel offsets with x fastest, k = ix + s iy + s^2 iz (from
+    memory of MinkowskiEngine v0.5 -- its source is not available offline); a checkpoint written by a build that
+    enumerates z fastest holds the weight of offset (ix, iy, iz) at k' = iz + s iy + s^2 ix."""
+    s = round(kernel_volume ** (1.0 / 3.0))
+    if s * s * s != kernel_volume:
+        return None
+    perm = []
+    for k in range(kernel_volume):
+        ix, iy, iz = k % s, (k // s) % s, k // (s * s)
+        perm.append(iz + s * iy + s * s * ix)
+    return perm
+
+
+def convert_kernel_order(state_dict, kernel_order: str):
+    """A copy of ``state_dict`` whose sparse-conv kernels ([K, Cin, Cout], K = 8 / 27 / 125) are re-indexed from
+    ``kernel_order`` ("x_fastest" = the library's own order: no change; "z_fastest") to the library's order.  The load-time
+    switch SURVEY.md section 7 ("Hard parts") asks for: which enumeration the authors' checkpoint uses can only be told
+    by IoU@5 on ScanNet once weights and data are supplied; random-weight parity does not depend on it."""
+    if kernel_order in (None, "", "x_fastest"):
+        return dict(state_dict)
+    if kernel_order != "z_fastest":
+        raise ValueError(f"kernel_order must be 'x_fastest' or 'z_fastest', not {kernel_order!r}")
+    out = {}
+    for k, v in state_dict.items():
+        if k.endswith(".kernel") and torch.is_tensor(v) and v.dim() == 3 and v.shape[0] > 1:
+            perm = kernel_order_permutation(v.shape[0])
+            if perm is not None:
+                v = v[torch.tensor(perm, dtype=torch.long, device=v.device)]
+        out[k] = v
+    return out
+
+
 class Agile3d(nn.Module):
     """Parameter layout of ``models/agile3d.py:19-138``; compute in HIP."""
 
@@ -91,8 +125,12 @@ class Agile3d(nn.Module):
             self._engine = Engine(self, dev)
         return self._engine
 
-    def load_state_dict(self, state_dict, strict=True, **kw):
-        sd = dict(state_dict)
+    def load_state_dict(self, state_dict, strict=True, kernel_order=None, **kw):
+        """``kernel_order``: enumeration of the kernel offsets in the file ("x_fastest" default, "z_fastest"); also
+        settable as ``args.kernel_order`` or A3D_KERNEL_ORDER (see ``convert_kernel_order``)."""
+        import os
+        order = kernel_order or getattr(self.args, "kernel_order", None) or os.environ.get("A3D_KERNEL_ORDER")
+        sd = convert_kernel_order(state_dict, order)
         own = self.state_dict()   # accept ME<0.5 checkpoints holding 1x1 kernels as [1,Cin,Cout]
         for k, v in list(sd.items()):
             if k in own and own[k].dim() == 2 and v.dim() == 3 and v.shape[0] == 1 and k.endswith(".kernel"):

@@ -32,9 +32,10 @@ class SparseConvParams(nn.Module):
         self.reset_parameters()
 
     def reset_parameters(self):
-        # ME initialises with kaiming_normal-like statistics over (Cin * volume); the exact
-        # init law is irrelevant for inference parity (weights come from the checkpoint).
-        n = self.cin * (1 if self.transposed else self.kernel_volume)
+        # ME's reset_parameters: uniform(-1/sqrt(n), 1/sqrt(n)) with n = in_channels * kernel_volume for a convolution
+        # and out_channels * kernel_volume for a transposed one (is_transpose=True); it matters when training from
+        # scratch (inference weights come from the checkpoint)
+        n = (self.cout if self.transposed else self.cin) * self.kernel_volume
         std = 1.0 / math.sqrt(n)
         with torch.no_grad():
             self.kernel.uniform_(-std, std)

@@ -57,7 +57,8 @@ class AdamW:
         self.params = dict(named_params)
         self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
         self.state = {}
-        self.step_count = 0
+        self.steps = {}            # per parameter, like torch.optim.AdamW's state[p]['step']
+        self.step_count = 0        # number of step() calls (= every parameter's step when all of them get gradients)
 
     def step(self, grads: dict, grad_scale: float = 1.0):
         lib = L.load()
@@ -70,7 +71,8 @@ class AdamW:
             if st is None:
                 st = self.state[name] = (torch.zeros_like(p), torch.zeros_like(p))
             g = g.reshape(p.shape).contiguous()
-            L.check(lib.a3d_adamw_step(_ptr(p.data), _ptr(g), _ptr(st[0]), _ptr(st[1]), p.numel(), self.step_count,
+            t = self.steps[name] = self.steps.get(name, 0) + 1     # bias correction counts THIS parameter's updates
+            L.check(lib.a3d_adamw_step(_ptr(p.data), _ptr(g), _ptr(st[0]), _ptr(st[1]), p.numel(), t,
                                        self.lr, self.betas[0], self.betas[1], self.eps, self.weight_decay, grad_scale,
                                        _stream(p)), "a3d_adamw_step")
 
@@ -131,7 +133,7 @@ def _adamw_state_dict(self):
     state = {}
     for i, n in enumerate(names):
         if n in self.state:
-            state[i] = {"step": torch.tensor(float(self.step_count)), "exp_avg": self.state[n][0].detach().cpu().clone(),
+            state[i] = {"step": torch.tensor(float(self.steps.get(n, self.step_count))), "exp_avg": self.state[n][0].detach().cpu().clone(),
                         "exp_avg_sq": self.state[n][1].detach().cpu().clone()}
     group = {"lr": self.lr, "betas": tuple(self.betas), "eps": self.eps, "weight_decay": self.weight_decay,
              "amsgrad": False, "params": list(range(len(names)))}
@@ -142,13 +144,13 @@ def _adamw_load_state_dict(self, sd):
     names = list(self.params)
     g = sd["param_groups"][0]
     self.lr, self.betas, self.eps, self.weight_decay = g["lr"], tuple(g["betas"]), g["eps"], g["weight_decay"]
-    self.state, steps = {}, []
+    self.state, self.steps = {}, {}
     for i, st in sd["state"].items():
         p = self.params[names[int(i)]]
         self.state[names[int(i)]] = (st["exp_avg"].to(p.device, torch.float32).contiguous().clone(),
                                      st["exp_avg_sq"].to(p.device, torch.float32).contiguous().clone())
-        steps.append(int(float(st["step"])))
-    self.step_count = max(steps) if steps else 0
+        self.steps[names[int(i)]] = int(float(st["step"]))
+    self.step_count = max(self.steps.values()) if self.steps else 0
 
 
 AdamW.state_dict = _adamw_state_dict

@@ -252,8 +252,13 @@ class MultiStepLR:
     def state_dict(self):
         return {"last_epoch": self.last_epoch, "base_lr": self.base_lr, "milestones": self.milestones, "gamma": self.gamma}
 
-    def load_state_dict(self, sd):
-        self.last_epoch, self.base_lr, self.milestones, self.gamma = sd["last_epoch"], sd["base_lr"], sd["milestones"], sd["gamma"]
+    def load_state_dict(self, sd, keep_base_lr=False):
+        """``keep_base_lr``: restore the position in the schedule (epoch, milestones, gamma) but keep the base learning
+        rate of the RUNNING configuration -- what resuming with a changed --lr means (main.py:131-152 keeps the new
+        lr of the param groups and does not load the scheduler's)."""
+        self.last_epoch, self.milestones, self.gamma = sd["last_epoch"], sd["milestones"], sd["gamma"]
+        if not keep_base_lr:
+            self.base_lr = sd["base_lr"]
         self.optimizer.lr = self.base_lr * self.gamma ** sum(1 for m in self.milestones if m <= self.last_epoch)
 
 
@@ -281,7 +286,8 @@ def load_checkpoint(path, model, optimizer=None, lr_scheduler=None):
         optimizer.load_state_dict(ck["optimizer"])
         optimizer.lr = lr
         if lr_scheduler is not None and ck.get("lr_scheduler") is not None:
-            lr_scheduler.load_state_dict(ck["lr_scheduler"])
+            lr_scheduler.base_lr = lr                                   # a changed --lr stays in force after the resume
+            lr_scheduler.load_state_dict(ck["lr_scheduler"], keep_base_lr=True)
         start = ck["epoch"] + 1
     return start
 

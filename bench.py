@@ -347,8 +347,8 @@ def main():
                 pairs["conv3"].append(int((nb[:, :scn.n[lvl]] < scn.n[lvl]).sum()))
             n_prof = 10
             agg = profile_pass(lambda: one_scene()[1], pairs, n_prof)   # one step at a time: clean kernel times
-            conv = {k: v for k, v in agg.items() if k.startswith("k_spconv") or k.startswith("k_dense")}
-            dom = max((k for k in conv if k.startswith("k_spconv")), key=lambda k: conv[k]["ms"])
+            conv = {k: v for k, v in agg.items() if k.startswith("k_conv") or k.startswith("k_dense")}
+            dom = max((k for k in conv if k.startswith("k_conv")), key=lambda k: conv[k]["ms"])
             d = conv[dom]
             achieved = d["flops"] / (d["ms"] * 1e-3) / 1e12
             traffic = None
@@ -386,7 +386,7 @@ def main():
             Q = args.objects * args.clicks_per_object + 10
             dec_flops = args.batch * 3 * (2.0 * n0 * 128 * 128 * 2 + 4.0 * Q * n0 * 128 + 2.0 * n0 * 128 * 128 * 2
                                           + 4.0 * n0 * Q * 128 + 2.0 * n0 * 128 * Q)
-            conv_only = sum(v["flops"] for k, v in conv.items() if k.startswith("k_spconv") or k in ("k_dense<6,8>", "k_dense<8,6>"))
+            conv_only = sum(v["flops"] for k, v in conv.items() if k.startswith("k_conv") or k in ("k_dense<6,8>", "k_dense<8,6>"))
             step_gf = (conv_only + dec_flops) / 1e9
             res["pipeline_algorithmic_gflop_per_step"] = round(step_gf, 1)
             res["pipeline_frac"] = round(step_gf / res["ms_per_step"] / PEAK_FP32_MFMA_TFLOPS, 4)   # GF / ms = TF/s
@@ -412,6 +412,34 @@ def main():
             r1 = model.forward_backbone(SparseTensor(features=f1, coordinates=c1), raw_coordinates=w1)
             t_dec1, _ = wall(lambda: model.forward_mask(*r1, click_idx=[ci], click_time_idx=[ct]), reps=30)
             res["decoder_pass_ms_single"] = round(t_dec1, 4)
+            # one round of the evaluation protocol (eval_multi_obj.py:112-160) on that scene: forward_mask -> label argmax
+            # with the clicked rows overwritten -> IoU -> click simulator -> extend_clicks; median of 20 rounds
+            import random as _random
+            from agile3d_amd import clicks as pc
+            lab_np = np.zeros(n0, np.int64)
+            sizes = sorted(((int((sc["labels"] == i).sum()), i) for i in np.unique(sc["labels"]) if i > 0), reverse=True)
+            for k_, (_, i) in enumerate(sizes[:args.objects], start=1):
+                lab_np[sc["labels"] == i] = k_
+            lab = torch.from_numpy(lab_np).to(dev)
+            eci = {str(k_): [] for k_ in range(args.objects + 1)}
+            ect = {str(k_): [] for k_ in range(args.objects + 1)}
+            pred = torch.zeros(n0, dtype=torch.int32, device=dev)
+            _random.seed(0)
+            rounds = []
+            for rnd in range(24):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                if rnd:
+                    o = model.forward_mask(*r1, click_idx=[eci], click_time_idx=[ect])["pred_masks"][0]
+                    pred = pc.argmax_labels(o, eci)
+                pc.mean_iou_scene(pred, lab)
+                new, _, _, nt = pc.get_simulated_clicks(pred, lab, w1, rnd, training=False)
+                if new is not None:
+                    pc.extend_clicks(eci, ect, new, nt)
+                torch.cuda.synchronize()
+                if rnd >= 4:
+                    rounds.append(1e3 * (time.perf_counter() - t0))
+            res["eval_round_ms"] = round(float(np.median(rounds)), 4)
         if not args.no_cpu_baseline:
             res["cpu_baseline"], diff = cpu_baseline(sd, sc, ci, ct, gpu_logits0, gpu_feats0)
             res["parity_vs_oracle"] = diff

@@ -46,7 +46,7 @@ int         a3d_memcpy_d2h(void* dst_host, const void* src_dev, size_t bytes, vo
  * ------------------------------------------------------------------------------------------ */
 enum {
   A3D_PROF_SPCONV = 0,      /* k_spconv2<bn,ch> (3^3 / 2^3 s2 / transposed / small 1x1)      */
-  A3D_PROF_SPLITK = 1,      /* split-K reduction + epilogue                              */
+  A3D_PROF_SPLITK = 1,      /* retired (the split-K reduction launches of round 1)          */
   A3D_PROF_STEM = 2,        /* 5^3 stem                                                  */
   A3D_PROF_C2S = 3,         /* click-to-scene attention                                  */
   A3D_PROF_QUERY = 4,       /* query-side chain (one workgroup)                          */
@@ -101,7 +101,7 @@ enum {
   A3D_TAB_GMASKUP   = 6,  /* uint32 [npad/16]                                                     */
   A3D_TAB_UPROWS    = 7,  /* int32 [npad] virtual row -> row of `level`                           */
   A3D_TAB_ORIGROW   = 8,  /* int32 [n0]   internal level-0 row -> caller's row                    */
-  A3D_TAB_ORDER27   = 9,  /* int32 [npad/64] 64-row tiles sorted by number of 3^3 offsets, most first */
+  /* 9: retired (tile order of the former dynamic tile queue) */
   A3D_TAB_PRE27     = 10, /* int32 [npad/64+1] (tile, offset) pairs of the 3^3 map before each 64-row tile */
   A3D_TAB_PREDOWN   = 11, /* int32 [npad(level+1)/64+1] same for the stride-2 map                       */
   A3D_TAB_PREUP     = 12  /* int32 [npad/64+1] same for the transposed map                              */
@@ -281,8 +281,8 @@ int    a3d_adamw_step(float* param_dev, const float* grad_dev, float* exp_avg_de
  * (models/modules/attention_block.py:91-94; `in_add` is the position encoding the reference adds to
  * its queries / keys before projecting them, attention_block.py:25-26,88-90).  96/128 -> 96/128
  * channels run on a dedicated HBM-bound kernel (k_dense); other shapes fall back to the sparse-conv
- * kernel with kernel volume 1 (no in_add there; workspace (optional): >= 512 bytes of ZEROED device
- * memory used as its dynamic tile queue, NULL = static tile assignment). */
+ * kernel with kernel volume 1 (no in_add there; the workspace arguments are not used: whole tiles are assigned
+ * statically, pass NULL / 0). */
 int a3d_linear(const float* in_dev, int ldi, const float* in_add_dev, int ldi_add,
                int64_t n, int cin, int cout,
                const float* w_packed_dev, const float* scale_dev, const float* shift_dev,
