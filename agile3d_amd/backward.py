@@ -33,6 +33,19 @@ def _stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+_arena: dict = {}
+
+
+def _workspace(nbytes, device, tag):
+    """One growing scratch allocation per (device, stream, tag): the training tapes issue hundreds of calls per iteration
+    on one stream, each used to allocate (and zero) its own workspace."""
+    key = (str(device), torch.cuda.current_stream(device).cuda_stream, tag)
+    ws = _arena.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = _arena[key] = torch.empty(int(nbytes * 1.25) + 4096, dtype=torch.uint8, device=device)
+    return ws
+
+
 def level_out(kind, level_in):
     return level_in + (1 if kind == L.OP_DOWN else -1 if kind == L.OP_UP else 0)
 
@@ -77,6 +90,56 @@ def run_conv(scene, kind, level_in, w_packed, x, cin, cout):
     return view(1, n_out, cout)[:n_out].clone()
 
 
+def conv_apply(scene, kind, level_in, w_packed, x, cin, cout, out=None, out_cols=None, zero_row=True):
+    """a3d_conv_apply: one conv directly on the caller's tensors.  ``x`` [n_in + 1, ldx] with its zero row (row n_in);
+    returns y [n_out + 1, cout] (row n_out zeroed) or writes ``cout`` columns into ``out[:, out_cols[0]:]``."""
+    lib = L.load()
+    lo = level_out(kind, level_in)
+    n_in, n_out = scene.n[level_in], scene.n[lo]
+    if x.shape[0] != n_in + 1 or not x.is_contiguous():
+        raise ValueError(f"conv_apply: input must be a contiguous [{n_in + 1}, C] tensor carrying the zero row")
+    if out is None:
+        out = torch.empty((n_out + 1, cout), dtype=torch.float32, device=x.device)
+        y, ldy = out, cout
+    else:
+        ldy = out.shape[1]
+        y = out[:, out_cols[0]:] if out_cols else out
+    nbytes = lib.a3d_conv_apply_workspace_bytes(scene.handle, kind, level_in, cin, cout)
+    if nbytes == 0:
+        raise L.A3DError(lib.a3d_last_error().decode())
+    ws = _workspace(nbytes, x.device, "conv")
+    L.check(lib.a3d_conv_apply(scene.handle, kind, level_in, _ptr(x), x.shape[1], cin, _ptr(w_packed), cout,
+                               C.c_void_p(y.data_ptr()), ldy, int(zero_row), _ptr(ws), ws.numel(), _stream()),
+            "a3d_conv_apply")
+    return out
+
+
+def packed_input_grad_weights(kind, w: torch.Tensor):
+    """The packed weight slices of the input-gradient conv of y = conv(x; w): [(first input channel, width, packed)].
+    W' = W^T (3^3: offsets reversed); output widths the conv kernel supports (192 = 128 + 64 ...)."""
+    K, cin, cout = w.shape
+    wt = w.transpose(1, 2)
+    if kind == L.OP_CONV3:
+        wt = wt.flip(0)
+    parts, c0 = [], 0
+    while c0 < cin:
+        rest = cin - c0
+        width = rest if (rest % 128 == 0 or rest in (32, 64, 96)) else max(w_ for w_ in (128, 96, 64, 32) if w_ <= rest)
+        parts.append((c0, width, pack_weight(wt[:, :, c0:c0 + width].contiguous())))
+        c0 += width
+    return parts
+
+
+def conv_input_grad_apply(scene, kind, level_in, parts, dy, cin, cout):
+    """dL/dx [n_in + 1, cin] (with its zero row) from dL/dy [n_out + 1, cout] and ``packed_input_grad_weights``."""
+    back_kind = {L.OP_CONV3: L.OP_CONV3, L.OP_DOWN: L.OP_UP, L.OP_UP: L.OP_DOWN, L.OP_LINEAR: L.OP_LINEAR}[kind]
+    lo = level_out(kind, level_in)
+    dx = torch.empty((scene.n[level_in] + 1, cin), dtype=torch.float32, device=dy.device)
+    for c0, width, wp in parts:
+        conv_apply(scene, back_kind, lo, wp, dy, cout, width, out=dx, out_cols=(c0, c0 + width))
+    return dx
+
+
 def conv_input_grad(scene, kind, level_in, w: torch.Tensor, dy: torch.Tensor) -> torch.Tensor:
     """dL/dx [n_in, Cin] of y = conv(x; W) from dL/dy [n_out, Cout]; ``w`` is the forward weight [K, Cin, Cout]."""
     K, cin, cout = w.shape
@@ -114,55 +177,59 @@ def conv_weight_grad(scene, kind, level_in, x: torch.Tensor, dy: torch.Tensor) -
     nbytes = lib.a3d_conv_wgrad_workspace_bytes(scene.handle, kind, level_in, cin, cout)
     if nbytes == 0:
         raise L.A3DError(lib.a3d_last_error().decode())
-    ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+    ws = _workspace(nbytes, x.device, "wgrad")
     L.check(lib.a3d_conv_wgrad(scene.handle, kind, level_in, _ptr(x), x.shape[1], _ptr(dy), dy.shape[1], cin, cout,
-                               _ptr(dw), _ptr(ws), nbytes, _stream()), "a3d_conv_wgrad")
+                               _ptr(dw), _ptr(ws), ws.numel(), _stream()), "a3d_conv_wgrad")
     return dw
 
 
 def _ws(n, C, device):
     lib = L.load()
-    return torch.empty(lib.a3d_bn_workspace_bytes(n, C), dtype=torch.uint8, device=device)
+    return _workspace(lib.a3d_bn_workspace_bytes(n, C), device, "bn")
 
 
-def bn_train_forward(x, gamma, beta, eps=1e-5, res=None, relu=False, running_mean=None, running_var=None, momentum=0.1):
+def bn_train_forward(x, gamma, beta, eps=1e-5, res=None, relu=False, running_mean=None, running_var=None, momentum=0.1,
+                     zero_row=False):
     """ME.MinkowskiBatchNorm in training mode (+ residual, + ReLU): returns (y, save_mean, save_rstd); running
-    statistics, when given, are updated in place like torch's."""
+    statistics, when given, are updated in place like torch's.  ``zero_row``: y gets one extra all-zero row (what a
+    missing neighbour gathers when y feeds a3d_conv_apply)."""
     lib = L.load()
     if not x.is_cuda or x.dtype != torch.float32:
         raise RuntimeError("agile3d_amd.backward runs on the GPU only (fp32 CUDA tensors)")
     x = x.contiguous()
     n, C_ = x.shape
-    y = torch.empty_like(x)
+    y = torch.empty((n + 1 if zero_row else n, C_), dtype=torch.float32, device=x.device)
     mean = torch.empty(C_, dtype=torch.float32, device=x.device)
     rstd = torch.empty_like(mean)
     res = res.contiguous() if res is not None else None
     ws = _ws(n, C_, x.device)
     L.check(lib.a3d_bn_train_forward(_ptr(x), C_, n, C_, _ptr(gamma), _ptr(beta), eps, _ptr(res), C_, int(relu), _ptr(y),
                                      C_, _ptr(mean), _ptr(rstd), _ptr(running_mean), _ptr(running_var), momentum,
-                                     _ptr(ws), ws.numel(), _stream()), "a3d_bn_train_forward")
+                                     int(zero_row), _ptr(ws), ws.numel(), _stream()), "a3d_bn_train_forward")
     return y, mean, rstd
 
 
-def bn_train_backward(x, y, dy, gamma, mean, rstd, relu=False, want_dres=False):
-    """-> (dx, dgamma, dbeta, dres or None); ``y`` (the forward output) gives the ReLU mask."""
+def bn_train_backward(x, y, dy, gamma, mean, rstd, relu=False, want_dres=False, zero_row=False):
+    """-> (dx, dgamma, dbeta, dres or None); ``y`` (the forward output) gives the ReLU mask.  ``zero_row``: dx / dres get
+    one extra all-zero row (they feed a3d_conv_apply as the input-gradient convs' dy)."""
     lib = L.load()
     x, dy = x.contiguous(), dy.contiguous()
     n, C_ = x.shape
-    dx = torch.empty_like(x)
-    dres = torch.empty_like(x) if want_dres else None
+    rows = n + 1 if zero_row else n
+    dx = torch.empty((rows, C_), dtype=torch.float32, device=x.device)
+    dres = torch.empty((rows, C_), dtype=torch.float32, device=x.device) if want_dres else None
     dgamma = torch.empty(C_, dtype=torch.float32, device=x.device)
     dbeta = torch.empty_like(dgamma)
     ws = _ws(n, C_, x.device)
     L.check(lib.a3d_bn_train_backward(_ptr(x), C_, _ptr(y.contiguous()) if relu else None, C_, _ptr(dy), C_, n, C_,
                                       _ptr(gamma), _ptr(mean), _ptr(rstd), int(relu), _ptr(dx), C_, _ptr(dres), C_,
-                                      _ptr(dgamma), _ptr(dbeta), _ptr(ws), ws.numel(), _stream()),
+                                      _ptr(dgamma), _ptr(dbeta), int(zero_row), _ptr(ws), ws.numel(), _stream()),
             "a3d_bn_train_backward")
     return dx, dgamma, dbeta, dres
 
 
 def bn_sync_forward(x, gamma, beta, eps=1e-5, res=None, relu=False, running_mean=None, running_var=None, momentum=0.1,
-                    group=None):
+                    group=None, zero_row=False):
     """BatchNorm in training mode with statistics over the rows of ALL data-parallel ranks (SyncBN): the reference
     normalises over every row of the batch on one device (models/modules/common.py:20-22); with the batch's scenes
     spread over ranks the strict equivalent exchanges [2C+1] numbers per layer.  Per rank: row
@@ -189,14 +256,14 @@ def bn_sync_forward(x, gamma, beta, eps=1e-5, res=None, relu=False, running_mean
         unbiased = (m2 / (n_glob - 1.0)).to(torch.float32) if float(n_glob) > 1 else var.to(torch.float32)
         running_mean.mul_(1.0 - momentum).add_(mean_f, alpha=momentum)
         running_var.mul_(1.0 - momentum).add_(unbiased, alpha=momentum)
-    y = torch.empty_like(x)
+    y = torch.empty((n + 1 if zero_row else n, C_), dtype=torch.float32, device=x.device)
     res = res.contiguous() if res is not None else None
     L.check(lib.a3d_bn_apply(_ptr(x), C_, n, C_, _ptr(gamma), _ptr(beta), _ptr(mean_f), _ptr(rstd), _ptr(res), C_,
-                             int(relu), _ptr(y), C_, _stream()), "a3d_bn_apply")
+                             int(relu), _ptr(y), C_, int(zero_row), _stream()), "a3d_bn_apply")
     return y, mean_f, rstd, int(n_glob.item())
 
 
-def bn_sync_backward(x, y, dy, gamma, mean, rstd, n_global, relu=False, want_dres=False, group=None):
+def bn_sync_backward(x, y, dy, gamma, mean, rstd, n_global, relu=False, want_dres=False, group=None, zero_row=False):
     """Backward of ``bn_sync_forward``: sum g and sum g xhat are all-reduced (2C numbers), dx uses the global sums and
     row count; dgamma / dbeta are this rank's sums (the gradient all-reduce averages them with everything else)."""
     import torch.distributed as dist
@@ -210,13 +277,14 @@ def bn_sync_backward(x, y, dy, gamma, mean, rstd, n_global, relu=False, want_dre
                                      _ptr(local), _ptr(ws), ws.numel(), _stream()), "a3d_bn_backward_sums")
     from .optim import dist_all_reduce
     glob = dist_all_reduce(local.clone(), group)
-    dx = torch.empty_like(x)
-    dres = torch.empty_like(x) if want_dres else None
+    rows = n + 1 if zero_row else n
+    dx = torch.empty((rows, C_), dtype=torch.float32, device=x.device)
+    dres = torch.empty((rows, C_), dtype=torch.float32, device=x.device) if want_dres else None
     dgamma = torch.empty(C_, dtype=torch.float32, device=x.device)
     dbeta = torch.empty_like(dgamma)
     L.check(lib.a3d_bn_backward_apply(_ptr(x), C_, _ptr(yy), C_, _ptr(dy), C_, n, C_, _ptr(gamma), _ptr(mean), _ptr(rstd),
                                       int(relu), _ptr(glob), int(n_global), _ptr(local), _ptr(dx), C_, _ptr(dres), C_,
-                                      _ptr(dgamma), _ptr(dbeta), _stream()), "a3d_bn_backward_apply")
+                                      _ptr(dgamma), _ptr(dbeta), int(zero_row), _stream()), "a3d_bn_backward_apply")
     return dx, dgamma, dbeta, dres
 
 

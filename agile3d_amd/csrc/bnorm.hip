@@ -67,6 +67,65 @@ __global__ void __launch_bounds__(kBnThreads) k_col_partial(const ColArgs a) {
   }
 }
 
+// Forward statistics in ONE sweep kernel + one combine kernel (3 launches per BatchNorm layer with the apply pass;
+// the first version took 7): every row block sums its rows, takes ITS mean, and sums the squared deviations from it in a
+// second loop over the same rows (L2-resident by then); k_bn_combine merges the blocks' (count, mean, M2) in block order
+// with Chan's update in fp64 -- the variance is still taken around a mean, never as E[x^2] - E[x]^2.
+__global__ void __launch_bounds__(kBnThreads) k_bn_block_stats(const ColArgs a) {
+  __shared__ f32x4 red[kBnThreads];
+  __shared__ f32x4 bmean[kBnThreads];
+  const int c4n = a.C >> 2;
+  const int col = threadIdx.x % c4n, rsub = threadIdx.x / c4n, rstep = kBnThreads / c4n;
+  const int r0 = blockIdx.x * a.rows_per_block, r1 = min(a.n, r0 + a.rows_per_block);
+  f32x4 s0 = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int r = r0 + rsub; r < r1; r += rstep) s0 += *(const f32x4*)(a.x + (size_t)r * a.ldx + 4 * col);
+  red[threadIdx.x] = s0;
+  __syncthreads();
+  if (rsub == 0) {
+    for (int k = 1; k < rstep; ++k) s0 += red[k * c4n + col];
+    bmean[col] = s0 * (1.f / (float)(r1 - r0));
+    *(f32x4*)(a.partial + (size_t)blockIdx.x * 2 * a.C + 4 * col) = s0;
+  }
+  __syncthreads();
+  const f32x4 m = bmean[col];
+  f32x4 s1 = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int r = r0 + rsub; r < r1; r += rstep) {
+    const f32x4 d = *(const f32x4*)(a.x + (size_t)r * a.ldx + 4 * col) - m;
+    s1 += d * d;
+  }
+  red[threadIdx.x] = s1;
+  __syncthreads();
+  if (rsub == 0) {
+    for (int k = 1; k < rstep; ++k) s1 += red[k * c4n + col];
+    *(f32x4*)(a.partial + (size_t)blockIdx.x * 2 * a.C + a.C + 4 * col) = s1;
+  }
+}
+__global__ void k_bn_combine(const float* __restrict__ partial, int nblocks, int rows_per_block, int n, int C, float eps,
+                             float* mean_out, float* rstd_out, float* running_mean, float* running_var, float momentum) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double cnt = 0.0, mean = 0.0, m2 = 0.0;
+  for (int b = 0; b < nblocks; ++b) {
+    const double nb = (double)(min(n, (b + 1) * rows_per_block) - b * rows_per_block);
+    const double bs = (double)partial[(size_t)b * 2 * C + c], bm2 = (double)partial[(size_t)b * 2 * C + C + c];
+    // the block's M2 was taken around the fp32 block mean the kernel used, not around bs / nb: shift it (exact identity)
+    const double bm_used = (double)((float)bs * (1.f / (float)nb)), bm = bs / nb;
+    const double bm2c = bm2 - nb * (bm - bm_used) * (bm - bm_used);
+    const double delta = bm - mean, tot = cnt + nb;
+    mean += delta * nb / tot;
+    m2 += bm2c + delta * delta * cnt * nb / tot;
+    cnt = tot;
+  }
+  const float var = (float)(m2 / cnt);
+  mean_out[c] = (float)mean;
+  rstd_out[c] = 1.0f / sqrtf(var + eps);
+  if (running_mean) {
+    const float unbiased = cnt > 1.0 ? (float)(m2 / (cnt - 1.0)) : var;
+    running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
+    running_var[c] = (1.f - momentum) * running_var[c] + momentum * unbiased;
+  }
+}
+
 // one thread per column: partials in block order, fp64
 __global__ void k_col_final(const float* __restrict__ partial, int nblocks, int nsum, int C, double* out) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
@@ -100,11 +159,13 @@ __global__ void k_bn_rstd(const double* sq, int C, double n, float eps, float* r
 struct ApplyArgs {
   const float *x, *mean, *rstd, *gamma, *beta, *res;
   int ldx, ldr, ldy, n, C, relu;
+  int zero_row;   // != 0: row n of y is written as zeros (the row a missing neighbour gathers in the next conv)
   float* y;
 };
 __global__ void k_bn_apply(const ApplyArgs a) {
   const int c4n = a.C >> 2;
   const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (a.zero_row && e < (size_t)c4n) *(f32x4*)(a.y + (size_t)a.n * a.ldy + 4 * e) = (f32x4){0.f, 0.f, 0.f, 0.f};
   if (e >= (size_t)a.n * c4n) return;
   const int r = (int)(e / c4n), col = (int)(e % c4n);
   const f32x4 xv = *(const f32x4*)(a.x + (size_t)r * a.ldx + 4 * col);
@@ -124,12 +185,17 @@ struct BwdArgs {
   const double* sums;         // [2][C]: sum g, sum g xhat over the rows the statistics were taken over
   const double* param_sums;   // [2][C]: the same over THIS call's rows (dgamma / dbeta)
   double n_stat;              // number of rows the statistics were taken over
+  int zero_row;               // != 0: dx (and dres) have n + 1 rows, row n is written as zeros
   int ldx, ldy, lddy, lddx, lddres, n, C, relu;
   float *dx, *dres, *dgamma, *dbeta;
 };
 __global__ void k_bn_bwd_apply(const BwdArgs a) {
   const int c4n = a.C >> 2;
   const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (a.zero_row && e < (size_t)c4n) {
+    *(f32x4*)(a.dx + (size_t)a.n * a.lddx + 4 * e) = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (a.dres) *(f32x4*)(a.dres + (size_t)a.n * a.lddres + 4 * e) = (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
   if (e >= (size_t)a.n * c4n) return;
   const int r = (int)(e / c4n), col = (int)(e % c4n);
   const f32x4 xv = *(const f32x4*)(a.x + (size_t)r * a.ldx + 4 * col);
@@ -269,7 +335,7 @@ extern "C" size_t a3d_bn_workspace_bytes(int64_t n, int C) {
 extern "C" int a3d_bn_train_forward(const float* x_dev, int ldx, int64_t n, int C, const float* gamma_dev,
                                     const float* beta_dev, float eps, const float* res_dev, int ldr, int relu,
                                     float* y_dev, int ldy, float* save_mean_dev, float* save_rstd_dev,
-                                    float* running_mean_dev, float* running_var_dev, float momentum,
+                                    float* running_mean_dev, float* running_var_dev, float momentum, int y_zero_row,
                                     void* workspace_dev, size_t workspace_bytes, void* stream) {
   if (!x_dev || !gamma_dev || !beta_dev || !y_dev || !save_mean_dev || !save_rstd_dev || !workspace_dev ||
       !bn_shape_ok(n, C, ldx, ldy, res_dev ? ldr : 4) || (running_mean_dev == nullptr) != (running_var_dev == nullptr)) {
@@ -288,18 +354,14 @@ extern "C" int a3d_bn_train_forward(const float* x_dev, int ldx, int64_t n, int 
   c.x = x_dev, c.ldx = ldx, c.n = (int)n, c.C = C, c.partial = partial;
   const int blocks = bn_blocks(n, c.rows_per_block);
   const unsigned cb = (unsigned)((2 * C + 255) / 256);
-  c.mode = 0;
-  k_col_partial<<<blocks, kBnThreads, 0, st>>>(c);
-  k_col_final<<<cb, 256, 0, st>>>(partial, blocks, 1, C, sums);
-  k_bn_mean<<<cb, 256, 0, st>>>(sums, C, (double)n, save_mean_dev);
-  c.mode = 1, c.mean = save_mean_dev;
-  k_col_partial<<<blocks, kBnThreads, 0, st>>>(c);
-  k_col_final<<<cb, 256, 0, st>>>(partial, blocks, 1, C, sums);
-  k_bn_rstd<<<cb, 256, 0, st>>>(sums, C, (double)n, eps, save_rstd_dev, save_mean_dev, running_mean_dev, running_var_dev,
-                               momentum);
+  (void)sums;
+  (void)cb;
+  k_bn_block_stats<<<blocks, kBnThreads, 0, st>>>(c);
+  k_bn_combine<<<(unsigned)((C + 255) / 256), 256, 0, st>>>(partial, blocks, c.rows_per_block, (int)n, C, eps, save_mean_dev,
+                                                             save_rstd_dev, running_mean_dev, running_var_dev, momentum);
   ApplyArgs a;
   a.x = x_dev, a.mean = save_mean_dev, a.rstd = save_rstd_dev, a.gamma = gamma_dev, a.beta = beta_dev, a.res = res_dev;
-  a.ldx = ldx, a.ldr = ldr, a.ldy = ldy, a.n = (int)n, a.C = C, a.relu = relu, a.y = y_dev;
+  a.ldx = ldx, a.ldr = ldr, a.ldy = ldy, a.n = (int)n, a.C = C, a.relu = relu, a.y = y_dev, a.zero_row = y_zero_row;
   const size_t total = (size_t)n * (C / 4);
   k_bn_apply<<<(unsigned)((total + 255) / 256), 256, 0, st>>>(a);
   A3D_LAUNCH_CHECK();
@@ -309,7 +371,7 @@ extern "C" int a3d_bn_train_forward(const float* x_dev, int ldx, int64_t n, int 
 extern "C" int a3d_bn_train_backward(const float* x_dev, int ldx, const float* y_dev, int ldy, const float* dy_dev,
                                      int lddy, int64_t n, int C, const float* gamma_dev, const float* save_mean_dev,
                                      const float* save_rstd_dev, int relu, float* dx_dev, int lddx, float* dres_dev,
-                                     int lddres, float* dgamma_dev, float* dbeta_dev, void* workspace_dev,
+                                     int lddres, float* dgamma_dev, float* dbeta_dev, int zero_row, void* workspace_dev,
                                      size_t workspace_bytes, void* stream) {
   if (!x_dev || !dy_dev || !gamma_dev || !save_mean_dev || !save_rstd_dev || !dx_dev || !dgamma_dev || !dbeta_dev ||
       !workspace_dev || (relu && !y_dev) || !bn_shape_ok(n, C, ldx, lddy, lddx) || (relu && ldy % 4) ||
@@ -333,7 +395,7 @@ extern "C" int a3d_bn_train_backward(const float* x_dev, int ldx, const float* y
   k_col_final<<<(unsigned)((2 * C + 255) / 256), 256, 0, st>>>(partial, blocks, 2, C, sums);
   BwdArgs b;
   b.x = x_dev, b.y = y_dev, b.dy = dy_dev, b.mean = save_mean_dev, b.rstd = save_rstd_dev, b.gamma = gamma_dev;
-  b.sums = sums, b.param_sums = sums, b.n_stat = (double)n;
+  b.sums = sums, b.param_sums = sums, b.n_stat = (double)n, b.zero_row = zero_row;
   b.ldx = ldx, b.ldy = ldy, b.lddy = lddy, b.lddx = lddx, b.lddres = lddres, b.n = (int)n, b.C = C;
   b.relu = relu, b.dx = dx_dev, b.dres = dres_dev, b.dgamma = dgamma_dev, b.dbeta = dbeta_dev;
   const size_t total = (size_t)n * (C / 4);
@@ -385,14 +447,14 @@ extern "C" int a3d_bn_local_stats(const float* x_dev, int ldx, int64_t n, int C,
 
 extern "C" int a3d_bn_apply(const float* x_dev, int ldx, int64_t n, int C, const float* gamma_dev, const float* beta_dev,
                             const float* mean_dev, const float* rstd_dev, const float* res_dev, int ldr, int relu,
-                            float* y_dev, int ldy, void* stream) {
+                            float* y_dev, int ldy, int y_zero_row, void* stream) {
   if (!x_dev || !gamma_dev || !beta_dev || !mean_dev || !rstd_dev || !y_dev || !bn_shape_ok(n, C, ldx, ldy, res_dev ? ldr : 4)) {
     set_error("a3d_bn_apply: bad arguments");
     return A3D_ERR_INVALID;
   }
   ApplyArgs a;
   a.x = x_dev, a.mean = mean_dev, a.rstd = rstd_dev, a.gamma = gamma_dev, a.beta = beta_dev, a.res = res_dev;
-  a.ldx = ldx, a.ldr = ldr, a.ldy = ldy, a.n = (int)n, a.C = C, a.relu = relu, a.y = y_dev;
+  a.ldx = ldx, a.ldr = ldr, a.ldy = ldy, a.n = (int)n, a.C = C, a.relu = relu, a.y = y_dev, a.zero_row = y_zero_row;
   const size_t total = (size_t)n * (C / 4);
   k_bn_apply<<<(unsigned)((total + 255) / 256), 256, 0, (hipStream_t)stream>>>(a);
   A3D_LAUNCH_CHECK();
@@ -428,7 +490,7 @@ extern "C" int a3d_bn_backward_apply(const float* x_dev, int ldx, const float* y
                                      int64_t n, int C, const float* gamma_dev, const float* mean_dev, const float* rstd_dev,
                                      int relu, const double* global_sums_dev, int64_t n_global, const double* local_sums_dev,
                                      float* dx_dev, int lddx, float* dres_dev, int lddres, float* dgamma_dev,
-                                     float* dbeta_dev, void* stream) {
+                                     float* dbeta_dev, int zero_row, void* stream) {
   if (!x_dev || !dy_dev || !gamma_dev || !mean_dev || !rstd_dev || !global_sums_dev || !local_sums_dev || !dx_dev ||
       !dgamma_dev || !dbeta_dev || n_global < n || (relu && !y_dev) || !bn_shape_ok(n, C, ldx, lddy, lddx) ||
       (relu && ldy % 4) || (dres_dev && lddres % 4)) {
@@ -437,7 +499,7 @@ extern "C" int a3d_bn_backward_apply(const float* x_dev, int ldx, const float* y
   }
   BwdArgs b;
   b.x = x_dev, b.y = y_dev, b.dy = dy_dev, b.mean = mean_dev, b.rstd = rstd_dev, b.gamma = gamma_dev;
-  b.sums = global_sums_dev, b.param_sums = local_sums_dev, b.n_stat = (double)n_global;
+  b.sums = global_sums_dev, b.param_sums = local_sums_dev, b.n_stat = (double)n_global, b.zero_row = zero_row;
   b.ldx = ldx, b.ldy = ldy, b.lddy = lddy, b.lddx = lddx, b.lddres = lddres, b.n = (int)n, b.C = C;
   b.relu = relu, b.dx = dx_dev, b.dres = dres_dev, b.dgamma = dgamma_dev, b.dbeta = dbeta_dev;
   const size_t total = (size_t)n * (C / 4);

@@ -1115,6 +1115,96 @@ extern "C" int a3d_program_run(const a3d_scene* s, const a3d_buf_desc* bufs, int
   return A3D_OK;
 }
 
+// One sparse convolution on the caller's own buffers (the training tapes; the inference path runs whole programs):
+//   y[n_out (+1)][ldy] = conv(x[n_in + 1][ldx]; Wp)      kind / level_in as in a3d_op, no epilogue
+// x must carry the zero row (row n_in all zeros: what a missing neighbour gathers); row n_out of y is written as the
+// zero row of the next layer when `y_zero_row` is set.  Transposed convs scatter through the scene's row map as in
+// the program.  Workspace: a3d_conv_apply_workspace_bytes (hand-off state, zeroed here, + partial-accumulator slab).
+extern "C" size_t a3d_conv_apply_workspace_bytes(const a3d_scene* s, int kind, int level_in, int cin, int cout) {
+  if (!s || level_in < 0 || level_in >= A3D_NUM_LEVELS) return 0;
+  int lvl_out = level_in + (kind == A3D_OP_DOWN ? 1 : kind == A3D_OP_UP ? -1 : 0);
+  if (lvl_out < 0 || lvl_out >= A3D_NUM_LEVELS) return 0;
+  const int K = kind == A3D_OP_CONV3 ? 27 : kind == A3D_OP_LINEAR ? 1 : 8;
+  SkPlan q = plan_sk(s->lv[lvl_out].n, K, cin, cout, true);
+  return align256((size_t)kMaxQueuesPerOp * 4) + align256(q.slab_floats * 4) + 256;
+}
+
+extern "C" int a3d_conv_apply(const a3d_scene* s, int kind, int level_in, const float* x_dev, int ldx, int cin,
+                              const float* w_packed_dev, int cout, float* y_dev, int ldy, int y_zero_row,
+                              void* workspace_dev, size_t workspace_bytes, void* stream) {
+  if (!s || !x_dev || !w_packed_dev || !y_dev || level_in < 0 || level_in >= A3D_NUM_LEVELS || (ldx & 3) || (ldy & 3) ||
+      ldx < cin || ldy < cout) {
+    set_error("a3d_conv_apply: bad arguments");
+    return A3D_ERR_INVALID;
+  }
+  const int Lin = level_in;
+  int lvl_out = Lin + (kind == A3D_OP_DOWN ? 1 : kind == A3D_OP_UP ? -1 : 0);
+  if (lvl_out < 0 || lvl_out >= A3D_NUM_LEVELS) {
+    set_error("a3d_conv_apply: the op leaves the level range");
+    return A3D_ERR_INVALID;
+  }
+  const size_t need = a3d_conv_apply_workspace_bytes(s, kind, level_in, cin, cout);
+  if (!workspace_dev || workspace_bytes < need || ((uintptr_t)workspace_dev & 255)) {
+    set_error("a3d_conv_apply: workspace too small or misaligned (%zu < %zu)", workspace_bytes, need);
+    return A3D_ERR_WORKSPACE;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  ConvArgs a;
+  memset(&a, 0, sizeof(a));
+  a.in = x_dev;
+  a.ldi = ldx;
+  a.n_in = s->lv[Lin].n;
+  a.w = w_packed_dev;
+  a.cin = cin;
+  a.cout = cout;
+  a.out = y_dev;
+  a.ldo = ldy;
+  a.n_out = s->lv[lvl_out].n;
+  a.zero_row = y_zero_row ? s->lv[lvl_out].n : -1;
+  a.tag_table = kind;
+  a.tag_level = Lin;
+  const int* pre = nullptr;
+  const int* pre128 = nullptr;
+  switch (kind) {
+    case A3D_OP_CONV3:
+      a.K = 27;
+      a.nbr = s->lv[Lin].nbr27;
+      a.nbr_stride = s->lv[Lin].npad;
+      a.gmask = s->lv[Lin].gmask27;
+      pre = s->lv[Lin].pre27;
+      pre128 = s->lv[Lin].pre27b;
+      break;
+    case A3D_OP_DOWN:
+      a.K = 8;
+      a.nbr = s->lv[Lin].child8;
+      a.nbr_stride = s->lv[Lin + 1].npad;
+      a.gmask = s->lv[Lin].gmask_down;
+      pre = s->lv[Lin].pre_down;
+      pre128 = s->lv[Lin].pre_downb;
+      break;
+    case A3D_OP_UP:
+      a.K = 8;
+      a.nbr = s->lv[Lin - 1].up8;
+      a.nbr_stride = s->lv[Lin - 1].npad;
+      a.gmask = s->lv[Lin - 1].gmask_up;
+      a.out_map = s->lv[Lin - 1].up_rows;
+      pre = s->lv[Lin - 1].pre_up;
+      pre128 = s->lv[Lin - 1].pre_upb;
+      break;
+    case A3D_OP_LINEAR:
+      a.K = 1;
+      break;
+    default:
+      set_error("a3d_conv_apply: unknown kind %d", kind);
+      return A3D_ERR_INVALID;
+  }
+  int* state = (int*)workspace_dev;
+  float* slab = (float*)((char*)workspace_dev + align256((size_t)kMaxQueuesPerOp * 4));
+  const size_t slab_floats = (workspace_bytes - align256((size_t)kMaxQueuesPerOp * 4)) / 4;
+  A3D_HIP_CHECK(hipMemsetAsync(state, 0, (size_t)kMaxQueuesPerOp * 4, st));
+  return launch_conv_sk(a, pre, pre128, slab, slab_floats, state, st);
+}
+
 extern "C" int a3d_linear(const float* in_dev, int ldi, const float* in_add_dev, int ldi_add, int64_t n, int cin,
                           int cout, const float* w_packed_dev, const float* scale_dev, const float* shift_dev,
                           const float* res_dev, int ldr, int relu, float* out_dev, int ldo, void* workspace_dev,

@@ -66,6 +66,16 @@ class Scene:
         L.check(lib.a3d_memcpy_d2h(out.ctypes.data_as(C.c_void_p), p, out.nbytes, _stream()), "a3d_memcpy_d2h")
         return out
 
+    def table_dev(self, level: int, which: int) -> torch.Tensor:
+        """One scene table as an int32 tensor VIEW of the scene's device workspace (no copy, no synchronisation; valid as
+        long as this Scene lives)."""
+        lib = L.load()
+        p, cnt = C.c_void_p(), C.c_int64()
+        L.check(lib.a3d_scene_table(self.handle, level, which, C.byref(p), C.byref(cnt)), "a3d_scene_table")
+        off = p.value - self.workspace.data_ptr()
+        assert 0 <= off and off + 4 * cnt.value <= self.workspace.numel() and off % 4 == 0
+        return self.workspace[off:off + 4 * cnt.value].view(torch.int32)
+
     def __del__(self):
         try:
             if getattr(self, "handle", None):
@@ -349,6 +359,9 @@ class Engine:
     def mark_stale(self):
         self._stale = True
         self._stale_dec = True
+        pw = getattr(self.model, "_a3d_packed_train", None)      # the training tapes' packed conv weights
+        if pw is not None:
+            pw.invalidate()
 
     def _weights_version(self, decoder_only=False):
         if self._dec_tensors is None:

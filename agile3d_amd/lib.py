@@ -105,17 +105,20 @@ SYMBOLS = {
     "a3d_conv_wgrad_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]),
     "a3d_conv_wgrad": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int,
                                  C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "a3d_conv_apply_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "a3d_conv_apply": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int,
+                                 C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
     "a3d_stem_wgrad_workspace_bytes": (C.c_size_t, [C.c_int]),
     "a3d_stem_wgrad": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                  C.c_size_t, C.c_void_p]),
     "a3d_bn_local_stats": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "a3d_bn_apply": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
-                               C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
+                               C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "a3d_bn_backward_sums": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int64, C.c_int,
                                        C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "a3d_bn_backward_apply": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int64, C.c_int,
                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_void_p,
-                                        C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+                                        C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "a3d_layernorm_forward": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_float,
                                         C.c_void_p, C.c_int, C.c_void_p]),
     "a3d_layernorm_backward": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_void_p,
@@ -144,10 +147,10 @@ SYMBOLS = {
     "a3d_bn_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int]),
     "a3d_bn_train_forward": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_float,
                                        C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
-                                       C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_size_t, C.c_void_p]),
+                                       C.c_void_p, C.c_void_p, C.c_float, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
     "a3d_bn_train_backward": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int64,
                                         C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
-                                        C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
+                                        C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_size_t,
                                         C.c_void_p]),
     "a3d_column_sums": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t,
                                   C.c_void_p]),

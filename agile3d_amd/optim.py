@@ -50,6 +50,11 @@ def clip_grad_norm_(grads: dict, max_norm: float):
     return norm, coef
 
 
+# bumped by every AdamW.step(): the update kernel writes the parameters through raw pointers, which torch's tensor version
+# counters do not see; caches of derived data (packed conv weights of the training tapes) key on it
+WEIGHT_EPOCH = [0]
+
+
 class AdamW:
     """torch.optim.AdamW's update rule, one kernel launch per parameter tensor; state lives next to the parameters."""
 
@@ -63,6 +68,7 @@ class AdamW:
     def step(self, grads: dict, grad_scale: float = 1.0):
         lib = L.load()
         self.step_count += 1
+        WEIGHT_EPOCH[0] += 1
         for name, g in grads.items():
             p = self.params[name]
             if not p.is_cuda or p.dtype != torch.float32 or not p.is_contiguous():

@@ -5,12 +5,13 @@ backbone half of SURVEY.md section 8 row f-2 (``engine.py:26-179``: ``model.trai
     pcd = tape.output                                [N, 128] in the caller's row order (agile3d.py:179)
     grads = tape.backward(d_pcd)                     {state-dict key: gradient} for every backbone parameter
 
-Every FLOP runs in libagile3d_hip (conv forward = the inference kernels, conv input gradient = the same kernels on the
-transposed maps, k_wgrad, the BatchNorm training kernels, k_stem_wgrad); this module is the reverse-mode bookkeeping:
-which activation feeds which layer, the two-way fan-outs of the residual / skip connections (a tensor add), the channel
-split of the concatenations.  A layer-at-a-time executor meant for parity, not yet for speed: every conv call goes
-through a one-op program with its own workspace.  The decoder's half is ``train_decoder.DecoderTape``, the whole
-iteration ``train_step.train_one_step``.
+Every FLOP runs in libagile3d_hip (conv forward = the inference kernel on the caller's buffers, a3d_conv_apply; conv input
+gradient = the same kernel on the transposed maps; k_wgrad; the BatchNorm training kernels; k_stem_wgrad); this module is
+the reverse-mode bookkeeping: which activation feeds which layer, the two-way fan-outs of the residual / skip
+connections (a tensor add), the channel split of the concatenations.  Activations and gradients carry the zero row the
+conv kernels gather for a missing neighbour ([n + 1, C] tensors, written by the producing kernel), both orientations of
+every conv weight are packed once per weight version (``PackedWeights``), workspaces come from one arena.  The decoder's
+half is ``train_decoder.DecoderTape``, the whole iteration ``train_step.train_one_step``.
 """
 from __future__ import annotations
 
@@ -21,7 +22,7 @@ from . import lib as L
 
 
 class _T:
-    """Activation node: value, level, accumulated gradient."""
+    """Activation node: value [n + 1, C] (row n = the zero row), level, accumulated gradient (same shape)."""
     __slots__ = ("v", "level", "g")
 
     def __init__(self, v, level):
@@ -31,8 +32,48 @@ class _T:
         self.g = g if self.g is None else self.g + g
 
 
+class _View:
+    """What the tests read off ``relu_levels``: the [n, C] rows of an activation."""
+    __slots__ = ("v",)
+
+    def __init__(self, v):
+        self.v = v
+
+
+class PackedWeights:
+    """Both orientations of every sparse-conv kernel in the MFMA fragment order, packed once per weight version: the
+    forward weight and the slices of the input-gradient conv's W' (backward.packed_input_grad_weights).  A tape asks
+    ``get(conv)``; entries are refreshed when the parameter tensor was written (torch bumps ``_version``), after a step of
+    the library's own AdamW (it writes through raw pointers and bumps ``optim.WEIGHT_EPOCH``) or after ``invalidate()``."""
+
+    def __init__(self):
+        self._c = {}
+        self.epoch = 0
+
+    def invalidate(self):
+        self.epoch += 1
+
+    def get(self, conv, kind):
+        from .optim import WEIGHT_EPOCH
+        key = id(conv.kernel)
+        ver = (int(conv.kernel._version), self.epoch, WEIGHT_EPOCH[0], conv.kernel.data_ptr())
+        hit = self._c.get(key)
+        if hit is None or hit[0] != ver:
+            w = conv.kernel3().detach().contiguous()
+            hit = self._c[key] = (ver, B.pack_weight(w), B.packed_input_grad_weights(kind, w))
+        return hit[1], hit[2]
+
+
+def packed_weights_of(model) -> PackedWeights:
+    pw = getattr(model, "_a3d_packed_train", None)
+    if pw is None:
+        pw = PackedWeights()
+        object.__setattr__(model, "_a3d_packed_train", pw)
+    return pw
+
+
 def _run_stem(scene, w, feats3, kvol):
-    """conv0p1s1 on its own (OP_STEM reads the caller-ordered features) -> [n0, 32] internal order."""
+    """conv0p1s1 on its own (OP_STEM reads the caller-ordered features) -> [n0 + 1, 32] internal order, zero row last."""
     lib = L.load()
     n0 = scene.n[0]
     bufs = (L.BufDesc * 1)(L.BufDesc(0, 32))
@@ -43,11 +84,11 @@ def _run_stem(scene, w, feats3, kvol):
     o.w_dev, o.scale_dev, o.shift_dev = w.data_ptr(), None, None
     ops = (L.Op * 1)(o)
     nbytes = lib.a3d_program_workspace_bytes(scene.handle, bufs, 1, ops, 1)
-    ws = torch.zeros(nbytes, dtype=torch.uint8, device=feats3.device)
+    ws = B._workspace(nbytes, feats3.device, "stem")
     L.check(lib.a3d_program_run(scene.handle, bufs, 1, ops, 1, B._ptr(feats3), None, 0, B._ptr(ws), nbytes, B._stream()),
             "a3d_program_run")
     off = lib.a3d_program_buffer_offset(scene.handle, bufs, 1, 0)
-    return ws[off:off + n0 * 32 * 4].view(torch.float32).view(n0, 32).clone()
+    return ws[off:off + (n0 + 1) * 32 * 4].view(torch.float32).view(n0 + 1, 32).clone()
 
 
 def _sync_bn_default():
@@ -70,6 +111,7 @@ class BackboneTape:
         self.relu_levels = []
         self.grads = {}
         self._names = {id(p): n for n, p in model.named_parameters()}
+        self.packed = packed_weights_of(model)
         self._forward()
 
     # ------------------------------------------------------------------ layers
@@ -79,37 +121,40 @@ class BackboneTape:
         self.grads[name] = g if name not in self.grads else self.grads[name] + g
 
     def _conv(self, kind, x: _T, conv) -> _T:
-        w = conv.kernel3().detach()
-        K, cin, cout = w.shape
-        y = _T(B.run_conv(self.scene, kind, x.level, B.pack_weight(w), x.v, cin, cout), B.level_out(kind, x.level))
+        K, cin, cout = conv.kernel3().shape
+        wf, wb = self.packed.get(conv, kind)
+        sc = self.scene
+        y = _T(B.conv_apply(sc, kind, x.level, wf, x.v, cin, cout), B.level_out(kind, x.level))
+        n_in, n_out = sc.n[x.level], sc.n[y.level]
 
         def back():
-            self._pgrad(conv.kernel, B.conv_weight_grad(self.scene, kind, x.level, x.v, y.g))
-            x.add_grad(B.conv_input_grad(self.scene, kind, x.level, w, y.g))
+            self._pgrad(conv.kernel, B.conv_weight_grad(sc, kind, x.level, x.v[:n_in], y.g[:n_out]))
+            x.add_grad(B.conv_input_grad_apply(sc, kind, x.level, wb, y.g, cin, cout))
         self.steps.append(back)
         return y
 
     def _bn(self, x: _T, norm, res: _T | None = None, relu=True) -> _T:
         b = norm.bn
+        n = self.scene.n[x.level]
+        xv, rv = x.v[:n], (res.v[:n] if res is not None else None)
         n_glob = None
         if self.sync_bn:
-            v, mean, rstd, n_glob = B.bn_sync_forward(x.v, b.weight.detach(), b.bias.detach(), b.eps,
-                                                      res.v if res is not None else None, relu, b.running_mean,
-                                                      b.running_var, b.momentum)
+            v, mean, rstd, n_glob = B.bn_sync_forward(xv, b.weight.detach(), b.bias.detach(), b.eps, rv, relu, b.running_mean,
+                                                      b.running_var, b.momentum, zero_row=True)
         else:
-            v, mean, rstd = B.bn_train_forward(x.v, b.weight.detach(), b.bias.detach(), b.eps,
-                                               res.v if res is not None else None, relu, b.running_mean, b.running_var,
-                                               b.momentum)
+            v, mean, rstd = B.bn_train_forward(xv, b.weight.detach(), b.bias.detach(), b.eps, rv, relu, b.running_mean,
+                                               b.running_var, b.momentum, zero_row=True)
         y = _T(v, x.level)
         if relu:
-            self.relu_levels.append((x.level, y))       # forward order of the ReLUs (tests read the 0/1 masks off y.v)
+            self.relu_levels.append((x.level, _View(v[:n])))   # forward order of the ReLUs (tests read the 0/1 masks)
 
         def back():
             if self.sync_bn:
-                dx, dg, db, dres = B.bn_sync_backward(x.v, y.v, y.g, b.weight.detach(), mean, rstd, n_glob, relu,
-                                                      res is not None)
+                dx, dg, db, dres = B.bn_sync_backward(xv, v[:n], y.g[:n], b.weight.detach(), mean, rstd, n_glob, relu,
+                                                      res is not None, zero_row=True)
             else:
-                dx, dg, db, dres = B.bn_train_backward(x.v, y.v, y.g, b.weight.detach(), mean, rstd, relu, res is not None)
+                dx, dg, db, dres = B.bn_train_backward(xv, v[:n], y.g[:n], b.weight.detach(), mean, rstd, relu,
+                                                       res is not None, zero_row=True)
             self._pgrad(b.weight, dg)
             self._pgrad(b.bias, db)
             x.add_grad(dx)
@@ -149,7 +194,7 @@ class BackboneTape:
         stem = _T(_run_stem(sc, w0, self.feats3, w0.shape[0]), 0)
 
         def stem_back():
-            self._pgrad(bb.conv0p1s1.kernel, B.stem_weight_grad(sc, self.feats3, stem.g, w0.shape[0]))
+            self._pgrad(bb.conv0p1s1.kernel, B.stem_weight_grad(sc, self.feats3, stem.g[:sc.n[0]], w0.shape[0]))
         self.steps.append(stem_back)
         out_p1 = self._bn(stem, bb.bn0)
         out = self._bn(self._conv(L.OP_DOWN, out_p1, bb.conv1p1s2), bb.bn1)
@@ -172,19 +217,22 @@ class BackboneTape:
         head = self.model.lin_squeeze_head
         y = self._conv(L.OP_LINEAR, out, head)
         self.head_out = y
-        self.orig_row = torch.from_numpy(sc.table(0, L.TAB_ORIGROW)).to(self.feats3.device).long()
+        self.orig_row = sc.table_dev(0, L.TAB_ORIGROW)[:sc.n[0]].long()
         bias = head.bias.detach().reshape(1, -1)
-        pcd = torch.empty_like(y.v)
-        pcd[self.orig_row] = y.v + bias
+        n0 = sc.n[0]
+        pcd = torch.empty((n0, y.v.shape[1]), dtype=torch.float32, device=y.v.device)
+        pcd[self.orig_row] = y.v[:n0] + bias
         self.output = pcd
 
     # ------------------------------------------------------------------ backward
     def backward(self, d_output: torch.Tensor) -> dict:
         """``d_output`` = dL/d(pcd_features) [N, 128] in the caller's row order -> gradients keyed like state_dict()."""
         head = self.model.lin_squeeze_head
-        g = d_output.to(torch.float32)[self.orig_row].contiguous()          # internal row order
+        n0 = self.scene.n[0]
+        g = torch.zeros((n0 + 1, d_output.shape[1]), dtype=torch.float32, device=d_output.device)
+        g[:n0] = d_output.to(torch.float32)[self.orig_row]                    # internal row order + the zero row
         self.grads = {}
-        self._pgrad(head.bias, B.column_sums(g))
+        self._pgrad(head.bias, B.column_sums(g[:n0]))
         self.head_out.g = g
         for back in reversed(self.steps):
             back()

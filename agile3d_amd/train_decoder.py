@@ -110,12 +110,21 @@ class DecoderTape:
         b = self.P[bname].detach() if bname else None
         if rows is not None:
             W, b = W[rows[0]:rows[1]], (b[rows[0]:rows[1]] if b is not None else None)
-        W = W.contiguous()
-        key = (wname, rows)
-        if key not in self._packed:          # both orientations packed once per tape (the weights do not change in it)
-            self._packed[key] = (_pack(W.t().contiguous()), _pack(W))
-        fwd_w, bwd_w = self._packed[key]
-        y = _T(_linear(x.v, fwd_w, b.contiguous() if b is not None else None))
+        # both orientations packed once per weight version, shared by the tapes of a batch (one tape per sample)
+        from .optim import WEIGHT_EPOCH
+        cache = getattr(self.model, "_a3d_packed_dec", None)
+        if cache is None:
+            cache = {}
+            object.__setattr__(self.model, "_a3d_packed_dec", cache)
+        p = self.P[wname]
+        ver = (int(p._version), WEIGHT_EPOCH[0], p.data_ptr())
+        hit = cache.get((wname, rows))
+        if hit is None or hit[0] != ver:
+            W = W.contiguous()
+            hit = cache[(wname, rows)] = (ver, _pack(W.t().contiguous()), _pack(W),
+                                          b.contiguous() if b is not None else None)
+        _, fwd_w, bwd_w, bc = hit
+        y = _T(_linear(x.v, fwd_w, bc))
 
         def back():
             if y.g is None:

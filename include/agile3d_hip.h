@@ -174,6 +174,16 @@ int    a3d_conv_wgrad(const a3d_scene* s, int kind, int level_in, const float* x
                       const float* dy_dev, int ldy, int cin, int cout, float* dw_dev,
                       void* workspace_dev, size_t workspace_bytes, void* stream);
 
+/* One sparse convolution on the caller's own buffers -- the forward AND (on the transposed map, see above) the input
+ * gradient of the training tapes, which keep every activation; the inference path runs whole programs instead.
+ *   y[n_out (+1)][ldy] = conv(x[n_in + 1][ldx]; w_packed)      no BatchNorm / ReLU / residual
+ * x carries the zero row (row n_in all zeros: what a missing neighbour gathers); with y_zero_row != 0 row n_out of y is
+ * written as zeros (the zero row of the next layer).  Deterministic.  Workspace: a3d_conv_apply_workspace_bytes. */
+size_t a3d_conv_apply_workspace_bytes(const a3d_scene* s, int kind, int level_in, int cin, int cout);
+int    a3d_conv_apply(const a3d_scene* s, int kind, int level_in, const float* x_dev, int ldx, int cin,
+                      const float* w_packed_dev, int cout, float* y_dev, int ldy, int y_zero_row,
+                      void* workspace_dev, size_t workspace_bytes, void* stream);
+
 /* weight gradient of the input convolution conv0p1s1 (5^3 or 3^3, 3 -> 32; res16unet.py:225): feats3_dev in the
  * caller's row order as for a3d_program_run, dy_dev [n0][lddy >= 32] in internal row order, dw_dev [K][3][32] */
 size_t a3d_stem_wgrad_workspace_bytes(int kernel_volume);
@@ -183,20 +193,22 @@ int    a3d_stem_wgrad(const a3d_scene* s, const float* feats3_dev, const float* 
 /* BatchNorm in training mode over the [n][C] rows (ME.MinkowskiBatchNorm = nn.BatchNorm1d over the rows of the whole
  * batch, models/modules/common.py:22), with the residual add and ReLU of BasicBlock.forward (resnet_block.py:48-64):
  *   forward : y = relu?((x - mean) * rstd * gamma + beta (+ res)); mean / rstd of THIS batch are saved for the
- *             backward; running statistics (optional) are updated like torch (momentum, unbiased variance)
+ *             backward; running statistics (optional) are updated like torch (momentum, unbiased variance);
+ *             y_zero_row != 0: y has n + 1 rows and row n is written as zeros (what a missing neighbour gathers)
  *   backward: g = dy masked by (y > 0) when relu; dres (optional) = g; dbeta = sum g; dgamma = sum g * xhat;
- *             dx = gamma * rstd * (g - dbeta / n - xhat * dgamma / n)
+ *             dx = gamma * rstd * (g - dbeta / n - xhat * dgamma / n); zero_row != 0: dx (and dres) have n + 1 rows,
+ *             row n written as zeros
  * C a multiple of 32 that divides 768 (32 .. 384), leading dimensions multiples of 4.  Deterministic. */
 size_t a3d_bn_workspace_bytes(int64_t n, int C);
 int    a3d_bn_train_forward(const float* x_dev, int ldx, int64_t n, int C, const float* gamma_dev,
                             const float* beta_dev, float eps, const float* res_dev, int ldr, int relu,
                             float* y_dev, int ldy, float* save_mean_dev, float* save_rstd_dev,
-                            float* running_mean_dev, float* running_var_dev, float momentum,
+                            float* running_mean_dev, float* running_var_dev, float momentum, int y_zero_row,
                             void* workspace_dev, size_t workspace_bytes, void* stream);
 int    a3d_bn_train_backward(const float* x_dev, int ldx, const float* y_dev, int ldy, const float* dy_dev, int lddy,
                              int64_t n, int C, const float* gamma_dev, const float* save_mean_dev,
                              const float* save_rstd_dev, int relu, float* dx_dev, int lddx, float* dres_dev,
-                             int lddres, float* dgamma_dev, float* dbeta_dev,
+                             int lddres, float* dgamma_dev, float* dbeta_dev, int zero_row,
                              void* workspace_dev, size_t workspace_bytes, void* stream);
 /* The same BatchNorm in pieces, for statistics that span the data-parallel ranks (SyncBN; the reference normalises over
  * all rows of the batch on ONE device, models/modules/common.py:20-22 -- with one scene per rank the strict equivalent
@@ -211,7 +223,7 @@ int    a3d_bn_local_stats(const float* x_dev, int ldx, int64_t n, int C, double*
                           size_t workspace_bytes, void* stream);
 int    a3d_bn_apply(const float* x_dev, int ldx, int64_t n, int C, const float* gamma_dev, const float* beta_dev,
                     const float* mean_dev, const float* rstd_dev, const float* res_dev, int ldr, int relu,
-                    float* y_dev, int ldy, void* stream);
+                    float* y_dev, int ldy, int y_zero_row, void* stream);
 int    a3d_bn_backward_sums(const float* x_dev, int ldx, const float* y_dev, int ldy, const float* dy_dev, int lddy,
                             int64_t n, int C, const float* mean_dev, const float* rstd_dev, int relu,
                             double* sums_dev, void* workspace_dev, size_t workspace_bytes, void* stream);
@@ -219,7 +231,7 @@ int    a3d_bn_backward_apply(const float* x_dev, int ldx, const float* y_dev, in
                              int64_t n, int C, const float* gamma_dev, const float* mean_dev, const float* rstd_dev,
                              int relu, const double* global_sums_dev, int64_t n_global, const double* local_sums_dev,
                              float* dx_dev, int lddx, float* dres_dev, int lddres, float* dgamma_dev,
-                             float* dbeta_dev, void* stream);
+                             float* dbeta_dev, int zero_row, void* stream);
 /* out[c] = sum over rows of x[i][c] (bias gradient of lin_squeeze_head, agile3d.py:43-45); workspace as above */
 int    a3d_column_sums(const float* x_dev, int ldx, int64_t n, int C, float* out_dev,
                        void* workspace_dev, size_t workspace_bytes, void* stream);
