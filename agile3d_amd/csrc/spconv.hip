@@ -110,7 +110,7 @@ __device__ __forceinline__ void wait_all_vmem() { __builtin_amdgcn_s_waitcnt(0x0
 
 template <int BN, int CH, int RG, bool DBG = false>   // BN output columns, CH input channels per stage, RG 16-row groups per
                                                       // wave; DBG: the A3D_DBG ablation switches (compiled out of the product kernels)
-__global__ void __launch_bounds__(256, 2) k_conv_sk(const SkArgs a) {
+__global__ void __launch_bounds__(256, (BN <= 96 && CH <= 48) ? 3 : 2) k_conv_sk(const SkArgs a) {
   constexpr int NCT = BN / 16, NS = CH / 16, NW = 4, kTile = 64 * RG;
   constexpr int NPIECE = NS * NCT;
   constexpr int WV = (NPIECE + NW - 1) / NW;
@@ -731,7 +731,7 @@ __global__ void k_pack_weight(const float* __restrict__ w, int K, int cin, int c
 
 // ------------------------------------------------------------------------------ host: launch
 constexpr int kMaxQueuesPerOp = 1024;  // ints of zeroed per-op state: k_conv_sk ticket [0], failure word [1], hand-off flags [2..2+G)
-constexpr int kSkMaxG = 512;
+constexpr int kSkMaxG = 1020;
 
 // ---- k_conv_sk: launch geometry
 struct SkPlan {
@@ -742,22 +742,40 @@ static int sk_env(const char* name, int dflt) {
   const char* e = getenv(name);
   return e ? atoi(e) : dflt;
 }
-static int sk_ch(int cin, int bn) {   // input channels per stage: largest of 96/64/32 dividing cin whose two-slot ring fits
+static int sk_ch(int cin, int bn) {   // input channels per stage
+  static int forced = sk_env("A3D_SK_CH", 0);   // experiment: stage width of the 96-column kernels
+  if (forced && bn == 96 && cin % forced == 0) return forced;
+  // 96-column workgroups: 32-channel stages -- 157 registers, a 25 KB weight ring: THREE workgroups per CU, the third
+  // covers the per-tile prologues / epilogues and the stage barriers of the other two (measured on the 4-scene batch:
+  // L0 96 -> 96 700 -> 620 us = 108 TF/s, 128 -> 96 850 -> 790 us = 113 TF/s against 96- / 64-channel stages with two)
+  if (bn == 96 && cin % 32 == 0) return 32;
   const int cand[3] = {96, 64, 32};
   for (int i = 0; i < 3; ++i)
     if (cin % cand[i] == 0 && 2 * cand[i] * bn * 4 + 64 <= 80 * 1024) return cand[i];
   return 0;
 }
+// resident workgroups per CU of k_conv_sk<bn, ch, 1>: registers (hipcc's allocation, checked with
+// -Rpass-analysis=kernel-resource-usage: 83 / 104 / 122 / 120 / 142 / 160 / 157 / 176 / 196 / 191 / 214 VGPRs) and LDS
+static int sk_wgs_per_cu(int bn, int ch, int rg, size_t lds) {
+  int by_regs = 2;
+  if (rg == 1) {
+    if (bn == 32) by_regs = ch <= 32 ? 5 : 4;
+    else if (bn == 64) by_regs = ch <= 32 ? 4 : 3;
+    else if (bn == 96) by_regs = ch <= 48 ? 3 : 2;
+  }
+  const int by_lds = (int)(160 * 1024 / lds);
+  const int w = by_regs < by_lds ? by_regs : by_lds;
+  return w < 1 ? 1 : (w > 4 ? 4 : w);
+}
 static SkPlan plan_sk(int n_rows, int K, int cin, int cout, bool handoff) {
   static int ov_env = sk_env("A3D_SK_OV", 0), share_env = sk_env("A3D_SK_MINSHARE", 0), g_env = sk_env("A3D_SK_G", 0);
-  static int rg_env = sk_env("A3D_SK_RG", 0), rg_rows = sk_env("A3D_SK_RG_ROWS", 200000);
+  static int rg_env = sk_env("A3D_SK_RG", 0);
   SkPlan p;
-  p.rg = rg_env ? rg_env : (n_rows >= rg_rows ? 2 : 1);   // 16-row groups per wave: 64- or 128-row tiles
+  p.rg = rg_env ? rg_env : 1;   // 16-row groups per wave (2: 128-row tiles, an experiment that did not pay)
   p.ntile = (n_rows + 64 * p.rg - 1) / (64 * p.rg);
   if (p.ntile < 1) p.ntile = 1;
   const int k_eff = K == 27 ? 13 : K;   // a 3^3 map has 11-17 of its 27 offsets per tile (the kernel uses the exact counts)
-  int gmax = g_env ? g_env : 512;
-  if (gmax > kSkMaxG) gmax = kSkMaxG;
+  int gmax = 512;
   for (int pass = 0; pass < 2; ++pass) {
     p.bn = (cout % 128 == 0) ? 128 : cout;
     // a level too small to give every CU a share with 128-column workgroups is cut into 64-column ones: twice the
@@ -767,8 +785,10 @@ static SkPlan plan_sk(int n_rows, int K, int cin, int cout, bool handoff) {
     p.nchunk = p.ch ? cin / p.ch : 1;
     p.n_cblk = cout / p.bn;
     const int mfma_per_stage = p.ch / 4 * (p.bn / 16) * p.rg;
-    p.ov = ov_env ? ov_env : (mfma_per_stage >= 128 ? 1 : 2);
+    p.ov = ov_env ? ov_env : (mfma_per_stage >= 128 ? 1 : mfma_per_stage >= 64 ? 2 : 3);   // per-tile overhead in stages
     p.lds = (size_t)2 * p.ch * p.bn * 4 + 64;
+    gmax = g_env ? g_env : 256 * sk_wgs_per_cu(p.bn, p.ch, p.rg, p.lds);
+    if (gmax > kSkMaxG) gmax = kSkMaxG;
     const long long est = (long long)p.n_cblk * p.ntile * ((long long)p.nchunk * k_eff + p.ov);
     const int min_share = share_env ? share_env : (mfma_per_stage >= 128 ? 6 : 8);
     if (handoff) {
@@ -794,7 +814,7 @@ static void allow_big_lds() {
   (void)hipFuncSetAttribute((const void*)k_conv_sk<BN_, CH_, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
   (void)hipFuncSetAttribute((const void*)k_conv_sk<BN_, CH_, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   A3D_BIG3(32, 32) A3D_BIG3(32, 64) A3D_BIG3(32, 96) A3D_BIG3(64, 32) A3D_BIG3(64, 64) A3D_BIG3(64, 96)
-  A3D_BIG3(96, 32) A3D_BIG3(96, 64) A3D_BIG3(96, 96) A3D_BIG3(128, 32) A3D_BIG3(128, 64)
+  A3D_BIG3(96, 32) A3D_BIG3(96, 48) A3D_BIG3(96, 64) A3D_BIG3(96, 96) A3D_BIG3(128, 32) A3D_BIG3(128, 64)
 #undef A3D_BIG3
   (void)hipFuncSetAttribute((const void*)k_conv_sk<96, 96, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   (void)hipFuncSetAttribute((const void*)k_conv_sk<96, 96, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -874,7 +894,7 @@ static int launch_conv_sk(ConvArgs c, const int* pre64, const int* pre128, float
 #define A3D_L3(BN_, CH_) \
   if (p.bn == BN_ && p.ch == CH_) { if (p.rg == 2) k_conv_sk<BN_, CH_, 2><<<p.G, 256, p.lds, st>>>(a); else k_conv_sk<BN_, CH_, 1><<<p.G, 256, p.lds, st>>>(a); } else
   A3D_L3(32, 32) A3D_L3(32, 64) A3D_L3(32, 96) A3D_L3(64, 32) A3D_L3(64, 64) A3D_L3(64, 96)
-  A3D_L3(96, 32) A3D_L3(96, 64) A3D_L3(96, 96) A3D_L3(128, 32) A3D_L3(128, 64)
+  A3D_L3(96, 32) A3D_L3(96, 48) A3D_L3(96, 64) A3D_L3(96, 96) A3D_L3(128, 32) A3D_L3(128, 64)
   { set_error("spconv: no kernel for BN %d CH %d", p.bn, p.ch); return A3D_ERR_UNSUPPORTED; }
 #undef A3D_L3
   A3D_LAUNCH_CHECK();

@@ -141,9 +141,11 @@ def test_argmax_labels_and_click_overwrite():
     assert torch.equal(pc.argmax_labels(logits).cpu().long(), logits.cpu().argmax(-1))
 
 
-def test_full_size_scene_vs_kdtree():
-    """BASELINE size: 80 k voxels, 10 objects, a prediction with large wrong regions."""
-    sc = make_scene(80_000, seed=0)
+@pytest.mark.parametrize("voxels", [80_000, 300_000])
+def test_full_size_scene_vs_kdtree(voxels):
+    """BASELINE sizes (configs 2 and 5): 80 k / 300 k voxels, 10 objects, a prediction with large wrong regions.  From
+    32 k points on the simulator runs its pruned search (cell buckets, chunk boxes); the float64 k-d tree is exact."""
+    sc = make_scene(voxels, seed=0)
     rng = np.random.default_rng(0)
     labels = np.where(sc["labels"] <= 10, sc["labels"], 0).astype(np.int32)
     xyz = sc["raw_xyz"]
