@@ -34,6 +34,7 @@ def _stream():
 
 
 _arena: dict = {}
+_POISON = __import__("os").environ.get("A3D_POISON", "0") == "1"   # debugging aid, see tests/conftest.py
 
 
 def _workspace(nbytes, device, tag):
@@ -43,6 +44,8 @@ def _workspace(nbytes, device, tag):
     ws = _arena.get(key)
     if ws is None or ws.numel() < nbytes:
         ws = _arena[key] = torch.empty(int(nbytes * 1.25) + 4096, dtype=torch.uint8, device=device)
+    if _POISON:
+        ws.fill_(255)   # NaN patterns: a kernel that reads scratch it did not write shows up in the results
     return ws
 
 

@@ -108,9 +108,13 @@ __device__ __forceinline__ void glds16_s(const float* sbase, unsigned voff, unsi
 // the MFMAs -- which would also wait for the LDS-DMA pieces it cannot see.  simm16: vmcnt 0, expcnt 7, lgkmcnt 15.
 __device__ __forceinline__ void wait_all_vmem() { __builtin_amdgcn_s_waitcnt(0x0F70); }
 
-template <int BN, int CH, int RG, bool DBG = false>   // BN output columns, CH input channels per stage, RG 16-row groups per
-                                                      // wave; DBG: the A3D_DBG ablation switches (compiled out of the product kernels)
-__global__ void __launch_bounds__(256, (BN <= 96 && CH <= 48) ? 3 : 2) k_conv_sk(const SkArgs a) {
+// BN output columns, CH input channels per stage; PAIR: weight fragments two at a time (16 registers for the B operand
+// instead of 8 BN / 16: the low-register build, 3-4 workgroups per CU); DBG: the A3D_DBG ablation switches (compiled out
+// of the product kernels)
+template <int BN, int CH, int PAIR, bool DBG = false>
+__global__ void __launch_bounds__(256, PAIR ? ((BN <= 96 && CH <= 32) ? 4 : 3) : ((BN <= 96 && CH <= 48) ? 3 : 2))
+    k_conv_sk(const SkArgs a) {
+  constexpr int RG = 1;   // 16-row groups per wave (two per wave -- 128-row tiles -- was tried and did not pay)
   constexpr int NCT = BN / 16, NS = CH / 16, NW = 4, kTile = 64 * RG;
   constexpr int NPIECE = NS * NCT;
   constexpr int WV = (NPIECE + NW - 1) / NW;
@@ -277,9 +281,9 @@ __global__ void __launch_bounds__(256, (BN <= 96 && CH <= 48) ? 3 : 2) k_conv_sk
       auto compute = [&](const f32x4 (&A)[RG][NS], int kk, int slot) {
         if (!((gm >> kk) & 1u) || (DBG && (a.dbg & 4))) return;
         const f32x4* Ws = (const f32x4*)(wring + slot * WF) + lane;
-        if constexpr (RG == 1) {
-          // one group per wave: the weight fragments of a whole 16-channel step in registers, the next step's read
-          // behind this step's MFMAs; consecutive MFMAs go to different accumulators
+        if constexpr (PAIR == 0) {
+          // the weight fragments of a whole 16-channel step in registers, the next step's read behind this step's MFMAs;
+          // consecutive MFMAs go to different accumulators
           f32x4 b[2][NCT];
 #pragma unroll
           for (int ct = 0; ct < NCT; ++ct) b[0][ct] = Ws[ct * 64];
@@ -297,25 +301,29 @@ __global__ void __launch_bounds__(256, (BN <= 96 && CH <= 48) ? 3 : 2) k_conv_sk
                 acc[0][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[Sx & 1][ct][tt], A[0][Sx][tt], acc[0][ct], 0, 0, 0);
           }
         } else {
-          // two groups per wave share every weight fragment: ONE fragment (4 registers) feeds 8 MFMAs (two
-          // accumulators alternating), the next fragment's ds_read_b128 is in flight behind them -- the weight
-          // operand costs 8 registers instead of 2 * 4 * NCT
-          f32x4 bc = Ws[0];
+          // two weight fragments at a time: 8 MFMAs on two alternating accumulators behind which the next pair's
+          // ds_read_b128s are in flight -- 16 registers of B operand; with 3-4 waves per SIMD the other waves fill the
+          // issue slots a wave's own short dependence chains leave
+          static_assert(NCT % 2 == 0, "pairs of 16-column tiles");
+          constexpr int NP = NS * NCT / 2;
+          f32x4 c0 = Ws[0], c1 = Ws[64];
 #pragma unroll
-          for (int Sx = 0; Sx < NS; ++Sx) {
-#pragma unroll
-            for (int ct = 0; ct < NCT; ++ct) {
-              f32x4 bn = bc;
-              if (Sx * NCT + ct + 1 < NS * NCT) bn = Ws[(Sx * NCT + ct + 1) * 64];
-              __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-              for (int tt = 0; tt < 4; ++tt)
-#pragma unroll
-                for (int r = 0; r < RG; ++r)
-                  acc[r][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(bc[tt], A[r][Sx][tt], acc[r][ct], 0, 0, 0);
-              __builtin_amdgcn_sched_barrier(0);
-              bc = bn;
+          for (int pi = 0; pi < NP; ++pi) {
+            const int Sx = pi / (NCT / 2), ct = 2 * (pi % (NCT / 2));
+            f32x4 n0 = c0, n1 = c1;
+            if (pi + 1 < NP) {
+              n0 = Ws[(2 * pi + 2) * 64];
+              n1 = Ws[(2 * pi + 3) * 64];
             }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int tt = 0; tt < 4; ++tt) {
+              acc[0][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(c0[tt], A[0][Sx][tt], acc[0][ct], 0, 0, 0);
+              acc[0][ct + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(c1[tt], A[0][Sx][tt], acc[0][ct + 1], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            c0 = n0;
+            c1 = n1;
           }
         }
       };
@@ -735,7 +743,7 @@ constexpr int kSkMaxG = 1020;
 
 // ---- k_conv_sk: launch geometry
 struct SkPlan {
-  int bn, ch, rg, nchunk, ov, n_cblk, G, ntile;
+  int bn, ch, pair, nchunk, ov, n_cblk, G, ntile;
   size_t lds, slab_floats;
 };
 static int sk_env(const char* name, int dflt) {
@@ -745,6 +753,8 @@ static int sk_env(const char* name, int dflt) {
 static int sk_ch(int cin, int bn) {   // input channels per stage
   static int forced = sk_env("A3D_SK_CH", 0);   // experiment: stage width of the 96-column kernels
   if (forced && bn == 96 && cin % forced == 0) return forced;
+  static int small = sk_env("A3D_SK_SMALLCH", 0);   // experiment: stage width of the 64-column kernels
+  if (small && bn == 64 && cin % small == 0) return small;
   // 96-column workgroups: 32-channel stages -- 157 registers, a 25 KB weight ring: THREE workgroups per CU, the third
   // covers the per-tile prologues / epilogues and the stage barriers of the other two (measured on the 4-scene batch:
   // L0 96 -> 96 700 -> 620 us = 108 TF/s, 128 -> 96 850 -> 790 us = 113 TF/s against 96- / 64-channel stages with two)
@@ -754,11 +764,20 @@ static int sk_ch(int cin, int bn) {   // input channels per stage
     if (cin % cand[i] == 0 && 2 * cand[i] * bn * 4 + 64 <= 80 * 1024) return cand[i];
   return 0;
 }
-// resident workgroups per CU of k_conv_sk<bn, ch, 1>: registers (hipcc's allocation, checked with
-// -Rpass-analysis=kernel-resource-usage: 83 / 104 / 122 / 120 / 142 / 160 / 157 / 176 / 196 / 191 / 214 VGPRs) and LDS
-static int sk_wgs_per_cu(int bn, int ch, int rg, size_t lds) {
+// which build: PAIR = 1 is the low-register one (weight fragments two at a time).  Measured on the 4-scene batch: the
+// 96-column kernels gain from it (127 registers -> FOUR workgroups per CU: L0 96 -> 96 640 -> 607 us = 110 TF/s,
+// 128 -> 96 816 -> 770 us = 116 TF/s, L1 174 -> 169 us); 64- and 128-column kernels are within 2 % either way
+static int sk_pair(int bn, int ch) {
+  (void)ch;
+  return bn == 96;
+}
+// resident workgroups per CU of k_conv_sk<bn, ch, pair>: registers (hipcc's allocation, -Rpass-analysis=
+// kernel-resource-usage; PAIR = 0: 83 / 104 / 122 / 120 / 142 / 160 / 157 / 176 / 196 / 191 / 214 VGPRs) and LDS
+static int sk_wgs_per_cu(int bn, int ch, int pair, size_t lds) {
   int by_regs = 2;
-  if (rg == 1) {
+  if (pair) {
+    by_regs = (bn <= 96 && ch <= 32) ? 4 : 3;
+  } else {
     if (bn == 32) by_regs = ch <= 32 ? 5 : 4;
     else if (bn == 64) by_regs = ch <= 32 ? 4 : 3;
     else if (bn == 96) by_regs = ch <= 48 ? 3 : 2;
@@ -769,10 +788,9 @@ static int sk_wgs_per_cu(int bn, int ch, int rg, size_t lds) {
 }
 static SkPlan plan_sk(int n_rows, int K, int cin, int cout, bool handoff) {
   static int ov_env = sk_env("A3D_SK_OV", 0), share_env = sk_env("A3D_SK_MINSHARE", 0), g_env = sk_env("A3D_SK_G", 0);
-  static int rg_env = sk_env("A3D_SK_RG", 0);
+  static int pair_env = sk_env("A3D_SK_PAIR", -1);
   SkPlan p;
-  p.rg = rg_env ? rg_env : 1;   // 16-row groups per wave (2: 128-row tiles, an experiment that did not pay)
-  p.ntile = (n_rows + 64 * p.rg - 1) / (64 * p.rg);
+  p.ntile = (n_rows + 63) / 64;
   if (p.ntile < 1) p.ntile = 1;
   const int k_eff = K == 27 ? 13 : K;   // a 3^3 map has 11-17 of its 27 offsets per tile (the kernel uses the exact counts)
   int gmax = 512;
@@ -784,17 +802,18 @@ static SkPlan plan_sk(int n_rows, int K, int cin, int cout, bool handoff) {
     p.ch = sk_ch(cin, p.bn);
     p.nchunk = p.ch ? cin / p.ch : 1;
     p.n_cblk = cout / p.bn;
-    const int mfma_per_stage = p.ch / 4 * (p.bn / 16) * p.rg;
+    p.pair = pair_env >= 0 ? pair_env : sk_pair(p.bn, p.ch);
+    const int mfma_per_stage = p.ch / 4 * (p.bn / 16);
     p.ov = ov_env ? ov_env : (mfma_per_stage >= 128 ? 1 : mfma_per_stage >= 64 ? 2 : 3);   // per-tile overhead in stages
     p.lds = (size_t)2 * p.ch * p.bn * 4 + 64;
-    gmax = g_env ? g_env : 256 * sk_wgs_per_cu(p.bn, p.ch, p.rg, p.lds);
+    gmax = g_env ? g_env : 256 * sk_wgs_per_cu(p.bn, p.ch, p.pair, p.lds);
     if (gmax > kSkMaxG) gmax = kSkMaxG;
     const long long est = (long long)p.n_cblk * p.ntile * ((long long)p.nchunk * k_eff + p.ov);
     const int min_share = share_env ? share_env : (mfma_per_stage >= 128 ? 6 : 8);
     if (handoff) {
       long long G = est / min_share;
       p.G = (int)(G < 1 ? 1 : (G > gmax ? gmax : G));
-      p.slab_floats = (size_t)p.G * 64 * p.rg * p.bn;
+      p.slab_floats = (size_t)p.G * 64 * p.bn;
       if (p.G >= 256 || p.bn <= 64 || cout % 64) break;
     } else {
       const long long nu = (long long)p.n_cblk * p.ntile;
@@ -811,14 +830,15 @@ static void allow_big_lds() {
   if (done) return;
   done = true;
 #define A3D_BIG3(BN_, CH_) \
-  (void)hipFuncSetAttribute((const void*)k_conv_sk<BN_, CH_, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
-  (void)hipFuncSetAttribute((const void*)k_conv_sk<BN_, CH_, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  A3D_BIG3(32, 32) A3D_BIG3(32, 64) A3D_BIG3(32, 96) A3D_BIG3(64, 32) A3D_BIG3(64, 64) A3D_BIG3(64, 96)
+  (void)hipFuncSetAttribute((const void*)k_conv_sk<BN_, CH_, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+  (void)hipFuncSetAttribute((const void*)k_conv_sk<BN_, CH_, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  A3D_BIG3(32, 32) A3D_BIG3(32, 64) A3D_BIG3(32, 96) A3D_BIG3(64, 32) A3D_BIG3(64, 64) A3D_BIG3(64, 96) A3D_BIG3(64, 128)
   A3D_BIG3(96, 32) A3D_BIG3(96, 48) A3D_BIG3(96, 64) A3D_BIG3(96, 96) A3D_BIG3(128, 32) A3D_BIG3(128, 64)
 #undef A3D_BIG3
-  (void)hipFuncSetAttribute((const void*)k_conv_sk<96, 96, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  (void)hipFuncSetAttribute((const void*)k_conv_sk<96, 96, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  (void)hipFuncSetAttribute((const void*)k_conv_sk<128, 64, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  (void)hipFuncSetAttribute((const void*)k_conv_sk<64, 64, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  (void)hipFuncSetAttribute((const void*)k_conv_sk<96, 32, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  (void)hipFuncSetAttribute((const void*)k_conv_sk<96, 96, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  (void)hipFuncSetAttribute((const void*)k_conv_sk<128, 64, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   (void)hipFuncSetAttribute((const void*)k_dense<8, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   (void)hipFuncSetAttribute((const void*)k_dense<8, 6>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   (void)hipFuncSetAttribute((const void*)k_dense<6, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -861,7 +881,8 @@ static int launch_conv_sk(ConvArgs c, const int* pre64, const int* pre128, float
   memset(&a, 0, sizeof(a));
   c.n_tiles = p.ntile;
   a.c = c;
-  const int* pre = p.rg == 2 ? pre128 : pre64;
+  (void)pre128;
+  const int* pre = pre64;
   a.pre = c.K > 1 ? pre : nullptr;
   a.nchunk = p.nchunk;
   a.ov = p.ov;
@@ -880,11 +901,12 @@ static int launch_conv_sk(ConvArgs c, const int* pre64, const int* pre128, float
     set_error("spconv: a gathered convolution needs the scene's tile prefix table");
     return A3D_ERR_INVALID;
   }
-  ProfScope ps(st, A3D_PROF_SPCONV, p.bn, c.K, c.cin, c.cout, c.n_out, c.tag_table, c.tag_level, 1);
+  ProfScope ps(st, A3D_PROF_SPCONV, p.bn, c.K, c.cin, c.cout, c.n_out, c.tag_table, c.tag_level, p.ch);   // last field: stage width
   if (a.dbg) {   // ablation builds of the two shapes the measurements of DESIGN.md 4.1 use
-    if (p.bn == 96 && p.ch == 96 && p.rg == 1) k_conv_sk<96, 96, 1, true><<<p.G, 256, p.lds, st>>>(a);
-    else if (p.bn == 96 && p.ch == 96 && p.rg == 2) k_conv_sk<96, 96, 2, true><<<p.G, 256, p.lds, st>>>(a);
-    else if (p.bn == 128 && p.ch == 64 && p.rg == 1) k_conv_sk<128, 64, 1, true><<<p.G, 256, p.lds, st>>>(a);
+    if (p.bn == 64 && p.ch == 64 && p.pair == 0) k_conv_sk<64, 64, 0, true><<<p.G, 256, p.lds, st>>>(a);
+    else if (p.bn == 96 && p.ch == 32 && p.pair == 0) k_conv_sk<96, 32, 0, true><<<p.G, 256, p.lds, st>>>(a);
+    else if (p.bn == 96 && p.ch == 96 && p.pair == 0) k_conv_sk<96, 96, 0, true><<<p.G, 256, p.lds, st>>>(a);
+    else if (p.bn == 128 && p.ch == 64 && p.pair == 0) k_conv_sk<128, 64, 0, true><<<p.G, 256, p.lds, st>>>(a);
     else a.dbg = 0;
     if (a.dbg) {
       A3D_LAUNCH_CHECK();
@@ -892,8 +914,8 @@ static int launch_conv_sk(ConvArgs c, const int* pre64, const int* pre128, float
     }
   }
 #define A3D_L3(BN_, CH_) \
-  if (p.bn == BN_ && p.ch == CH_) { if (p.rg == 2) k_conv_sk<BN_, CH_, 2><<<p.G, 256, p.lds, st>>>(a); else k_conv_sk<BN_, CH_, 1><<<p.G, 256, p.lds, st>>>(a); } else
-  A3D_L3(32, 32) A3D_L3(32, 64) A3D_L3(32, 96) A3D_L3(64, 32) A3D_L3(64, 64) A3D_L3(64, 96)
+  if (p.bn == BN_ && p.ch == CH_) { if (p.pair) k_conv_sk<BN_, CH_, 1><<<p.G, 256, p.lds, st>>>(a); else k_conv_sk<BN_, CH_, 0><<<p.G, 256, p.lds, st>>>(a); } else
+  A3D_L3(32, 32) A3D_L3(32, 64) A3D_L3(32, 96) A3D_L3(64, 32) A3D_L3(64, 64) A3D_L3(64, 96) A3D_L3(64, 128)
   A3D_L3(96, 32) A3D_L3(96, 48) A3D_L3(96, 64) A3D_L3(96, 96) A3D_L3(128, 32) A3D_L3(128, 64)
   { set_error("spconv: no kernel for BN %d CH %d", p.bn, p.ch); return A3D_ERR_UNSUPPORTED; }
 #undef A3D_L3

@@ -87,8 +87,8 @@ def kernel_name(e):
     from agile3d_amd import lib as L
     name = L.PROF_NAMES[e.id]
     if e.id == 0:
-        ch = next(c for c in (96, 64, 32) if e.cin % c == 0 and 2 * c * e.bn * 4 <= 74 * 1024)
-        name = f"k_conv_sk<{e.bn},{ch}>"   # BN columns per workgroup, CH input channels per stage (plan_sk)
+        name = f"k_conv_sk<{e.bn},{e.ksplit}>"   # BN columns per workgroup, CH input channels per stage (plan_sk; the
+                                                  # profile entry's last integer field carries CH)
     elif e.id == L.PROF_DENSE:
         name = f"k_dense<{e.cin // 16},{e.cout // 16}>"
     return name
@@ -222,6 +222,10 @@ def main():
     ap.add_argument("--clicks-per-object", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--steps-only", action="store_true",
+                    help="only the 4-scene steps (warm-up, timed region, instrumented pass): no latency / phase / eval-round "
+                         "/ CPU passes -- the command tools/profile_round.sh traces for profiles/kernel_avg_us.json, so that "
+                         "every launch of a kernel in the trace is a launch of the step the roofline object describes")
     ap.add_argument("--batch", type=int, default=int(os.environ.get("A3D_BENCH_BATCH", "4")),
                     help="scenes per step and rank (one batched SparseTensor, as the reference's collate builds)")
     ap.add_argument("--streams", type=int, default=int(os.environ.get("A3D_BENCH_STREAMS", "4")),
@@ -329,15 +333,16 @@ def main():
             r = model.forward_backbone(SparseTensor(features=f1, coordinates=c1), raw_coordinates=w1)
             return model.forward_mask(*r, click_idx=[ci], click_time_idx=[ct])
         lat = []
-        for i in range(60):
+        for i in range(0 if args.steps_only else 60):
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             single()
             torch.cuda.synchronize()
             if i >= 10:
                 lat.append(1e3 * (time.perf_counter() - t0))
-        res["latency_ms_per_scene"] = round(float(np.median(lat)), 4)
-        res["latency_note"] = "batch 1, 1 stream, one scene at a time: median of 50 after 10 warm-ups (host wall, device sync both sides)"
+        if lat:
+            res["latency_ms_per_scene"] = round(float(np.median(lat)), 4)
+            res["latency_note"] = "batch 1, 1 stream, one scene at a time: median of 50 after 10 warm-ups (host wall, device sync both sides)"
         if not args.no_profile:
             scn = Scene(coords)
             pairs = {"n": scn.n, "conv3": []}
@@ -373,6 +378,7 @@ def main():
                     if want:
                         got = 1e3 * d["ms"] / d["launches"]
                         res["roofline"]["rocprof_avg_launch_us"] = want
+                        res["roofline"]["rocprof_command"] = "rocprofv3 --kernel-trace --stats -- python bench.py --steps-only --streams 1"
                         res["roofline"]["agrees_with_profiles_within_10pct"] = bool(abs(got - want) <= 0.1 * want)
                 except Exception:
                     pass
@@ -390,6 +396,7 @@ def main():
             step_gf = (conv_only + dec_flops) / 1e9
             res["pipeline_algorithmic_gflop_per_step"] = round(step_gf, 1)
             res["pipeline_frac"] = round(step_gf / res["ms_per_step"] / PEAK_FP32_MFMA_TFLOPS, 4)   # GF / ms = TF/s
+        if not args.no_profile and not args.steps_only:
             # the three phases on their own (one step at a time, one stream, wall clock with a device
             # sync around each) and the eval loop's number, decoder passes/s (backbone results reused per round)
             def wall(fn, reps=10):
@@ -440,7 +447,7 @@ def main():
                 if rnd >= 4:
                     rounds.append(1e3 * (time.perf_counter() - t0))
             res["eval_round_ms"] = round(float(np.median(rounds)), 4)
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and not args.steps_only:
             res["cpu_baseline"], diff = cpu_baseline(sd, sc, ci, ct, gpu_logits0, gpu_feats0)
             res["parity_vs_oracle"] = diff
             res["max_abs_diff"] = diff["logits_max_abs_diff"] if diff else None

@@ -15,6 +15,24 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+if os.environ.get("A3D_POISON", "0") == "1":
+    # debugging aid: every torch.empty / empty_like of the run starts out as NaN (0xFF bytes for integers), and the
+    # training tapes' shared scratch is re-poisoned at every use (agile3d_amd/backward.py) -- a kernel that reads memory
+    # nothing wrote turns the results into NaN instead of into a small, allocation-history-dependent error
+    _empty, _empty_like = torch.empty, torch.empty_like
+
+    def _poison(t):
+        if t.numel():
+            if t.is_floating_point():
+                t.fill_(float("nan"))
+            elif t.dtype != torch.bool:
+                t.view(torch.uint8).fill_(255) if t.is_contiguous() else None
+        return t
+
+    torch.empty = lambda *a, **k: _poison(_empty(*a, **k))
+    torch.empty_like = lambda *a, **k: _poison(_empty_like(*a, **k))
+
+
 def has_gpu():
     return torch.cuda.is_available()
 

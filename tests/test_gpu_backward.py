@@ -442,7 +442,7 @@ def test_whole_network_gradients_match_autograd():
     gd, d_pcd = dtp.backward([r.cuda() for r in R])
     grads = dict(gd)
     grads.update(bt.backward(d_pcd))
-    # ---- oracle on the same branch
+    # ---- oracle on the same branch (the 0/1 ReLU masks and the attention masks of the HIP run)
     lv = ob.SparseLevels(coords)
     maps = [torch.from_numpy(internal_to_oracle_rows(sc, lv, i)) for i in range(5)]
     bmasks = []
@@ -459,20 +459,38 @@ def test_whole_network_gradients_match_autograd():
           for k, v in sd0.items()}
     itb, itd = iter(bmasks), iter(dmasks)
     ob.RELU, od.RELU = (lambda z: z * next(itb)), (lambda z: z * next(itd))
+    # The decoder of this random-weight network is ill-conditioned in its INPUT: moving pcd_features by 1e-5 (what two
+    # summation orders of the conv kernel differ by) moves its parameter gradients by up to 1.4e-2 (measured with
+    # A3D_SK_OV=2 / 3; near-ties in the sharp attention softmaxes).  So the float64 decoder is evaluated AT the HIP
+    # backbone's features (checked against the float64 backbone's to 1e-4 first) and the float64 backbone is driven by
+    # the float64 decoder's dL/d(pcd_features): the chain rule end to end, each half at a well-conditioned point.
     try:
         out, _ = ob.res16unet34c_forward(sd, lv, feats.to(DT), bn=ob.batch_norm_train)
         Wh = sd["lin_squeeze_head.kernel"]
         pcd_o = out @ (Wh if Wh.dim() == 2 else Wh[0]) + sd["lin_squeeze_head.bias"].reshape(1, -1)
-        outs = od.forward_mask(sd, pcd_o, xyz.to(DT), pos, ci, ct, grad=True, force_masks=[m.cpu().bool() for m in dtp.attn_masks])
+        fwd_err = (bt.output.cpu().to(DT) - pcd_o.detach()).abs().max().item() / pcd_o.detach().abs().max().item()
+        print(f"whole network: forward pcd_features relative error {fwd_err:.2e}")
+        assert fwd_err <= 1e-4, fwd_err
+        pcd_leaf = bt.output.cpu().to(DT).clone().requires_grad_()
+        outs = od.forward_mask(sd, pcd_leaf, xyz.to(DT), pos, ci, ct, grad=True, force_masks=[m.cpu().bool() for m in dtp.attn_masks])
     finally:
         ob.RELU = od.RELU = torch.relu
     sum((o * r.to(DT)).sum() for o, r in zip(outs, R)).backward()
+    e_hand = (d_pcd.cpu().to(DT) - pcd_leaf.grad).abs().max().item() / pcd_leaf.grad.abs().max().item()
+    (pcd_o * pcd_leaf.grad).sum().backward()
     names = [k for k in sd if sd[k].requires_grad and sd[k].grad is not None]
     assert len(names) == 268 and set(grads) == set(names), set(names) ^ set(grads)
-    worst = max(((grads[k].cpu().to(DT) - sd[k].grad).abs().max().item() / max(1e-3, sd[k].grad.abs().max().item()), k)
-                for k in names)
-    print(f"whole network: 268 gradients, worst relative error {worst[0]:.2e} ({worst[1]})")
-    assert worst[0] <= 3e-3, worst
+
+    def rel(keys):
+        errs = sorted(((grads[k].cpu().to(DT) - sd[k].grad).abs().max().item() / max(1e-3, sd[k].grad.abs().max().item()), k) for k in keys)
+        return errs[len(errs) // 2][0], errs[-1]
+    dec_med, dec_worst = rel([k for k in names if k in dict(gd)])
+    bb_med, bb_worst = rel([k for k in names if k not in dict(gd)])
+    print(f"whole network: 268 gradients; decoder median {dec_med:.2e} worst {dec_worst[0]:.2e} ({dec_worst[1]}); "
+          f"dL/d(pcd_features) {e_hand:.2e}; backbone median {bb_med:.2e} worst {bb_worst[0]:.2e} ({bb_worst[1]})")
+    assert dec_worst[0] <= 1e-4 and e_hand <= 1e-4, (dec_worst, e_hand)
+    # the backbone's worst tensors are the level-4 kernels: BatchNorm over the ~10 rows this scene has there
+    assert bb_med <= 1e-3 and bb_worst[0] <= 5e-3, (bb_med, bb_worst)
 
 
 def test_checkpoint_resume_continues_bit_identically(tmp_path):

@@ -201,3 +201,54 @@ def test_linear_other_shapes_use_the_conv_kernel_and_reject_in_add():
     rc = lib.a3d_linear(_ptr(X), 64, _ptr(X), 64, n, 64, 32, _ptr(pack_weight(W.unsqueeze(0))), None, None, None, 0, 0,
                         _ptr(out), 32, None, 0, _stream())
     assert rc == -6      # A3D_ERR_UNSUPPORTED
+
+
+@pytest.fixture(scope="module")
+def small_world():
+    coords = make_scene(3000, seed=14)["coords"]
+    sc = Scene(torch.from_numpy(coords).cuda())
+    lv = ob.SparseLevels(coords)
+    maps = [torch.from_numpy(internal_to_oracle_rows(sc, lv, i)) for i in range(5)]
+    return coords, sc, lv, maps
+
+
+_WIDTHS_IN = [32, 64, 96, 128, 192, 256, 384]
+_WIDTHS_OUT = [32, 64, 96, 128, 256]
+
+
+@pytest.mark.parametrize("kind", ["conv3", "down", "up"])
+@pytest.mark.parametrize("level", [0, 1, 2, 3, 4])
+def test_conv_apply_every_shape_class_small_scene(small_world, kind, level):
+    """a3d_conv_apply (the training tapes' conv: forward AND input-gradient passes, so every (cin, cout) pairing occurs)
+    on the 3000-voxel scene of the gradient tests, against float64 gather-GEMM-scatter: the small levels are where a
+    layer is cut into shares inside tiles (hand-off), with a handful of rows per level."""
+    from agile3d_amd import backward as B
+    coords, sc, lv, maps = small_world
+    if kind == "down" and level == 4 or kind == "up" and level == 0:
+        pytest.skip("leaves the level range")
+    K = 27 if kind == "conv3" else 8
+    code = {"conv3": L.OP_CONV3, "down": L.OP_DOWN, "up": L.OP_UP}[kind]
+    lo = level + (1 if kind == "down" else -1 if kind == "up" else 0)
+    n_in, n_out = sc.n[level], sc.n[lo]
+    if kind == "conv3":
+        kmap = lv.kernel_map(level, 3)
+    elif kind == "down":
+        kmap = lv.stride_map(level)
+    else:
+        kmap = [(rc, rf) for (rf, rc) in lv.stride_map(level - 1)]
+    worst = 0.0
+    for cin in _WIDTHS_IN:
+        for cout in _WIDTHS_OUT:
+            g = torch.Generator().manual_seed(level * 100000 + cin * 100 + cout)
+            X = torch.randn(n_in, cin, generator=g, dtype=torch.float64)
+            W = torch.randn(K, cin, cout, generator=g, dtype=torch.float64) / (cin * K / 2) ** 0.5
+            x = torch.zeros(n_in + 1, cin, device="cuda")
+            x[:n_in] = X[maps[level]].float().cuda()
+            y = B.conv_apply(sc, code, level, pack_weight(W.float().cuda()), x, cin, cout)
+            ref = ob.sparse_conv(X.float().double(), W.float().double(), kmap, n_out)[maps[lo]]
+            got = y[:n_out].double().cpu()
+            err = (got - ref).abs().max().item() / max(1.0, ref.abs().max().item())
+            worst = max(worst, err)
+            assert err <= 2e-5, (kind, level, cin, cout, err)
+            assert (y[n_out] == 0).all()
+    print(f"conv_apply {kind} L{level}: worst relative error {worst:.2e} over {len(_WIDTHS_IN) * len(_WIDTHS_OUT)} shapes")

@@ -26,6 +26,8 @@ CASES = [  # name, kind, level_in, cin, cout, kvol
     ("L2_conv3_128_128", L.OP_CONV3, 2, 128, 128, 27),
     ("L3_conv3_256_256", L.OP_CONV3, 3, 256, 256, 27),
     ("L4_conv3_256_256", L.OP_CONV3, 4, 256, 256, 27),
+    ("L3_conv3_128_128", L.OP_CONV3, 3, 128, 128, 27),
+    ("L4_conv3_128_256", L.OP_CONV3, 4, 128, 256, 27),
     ("L0_linear_128_128", L.OP_LINEAR, 0, 128, 128, 1),
     ("L0_linear_128_96", L.OP_LINEAR, 0, 128, 96, 1),
     ("L1_up_96_96", L.OP_UP, 1, 96, 96, 8),

@@ -1,0 +1,28 @@
+#!/usr/bin/env python3
+"""kernel-trace stats text (tools/rocprof_summary.py) -> profiles/kernel_avg_us.json: average launch duration in us per
+kernel under the names bench.py uses (k_conv_sk<BN,CH>, k_dense<NS,NCT>, others by bare name).  bench.py compares its
+live HIP-event average of the dominant kernel with this file (roofline.agrees_with_profiles_within_10pct)."""
+import json
+import re
+import sys
+
+out = {"_note": "rocprofv3 --kernel-trace --stats average launch duration (us); made by tools/kernel_avg.py from " + sys.argv[1].split("/")[-1]}
+acc = {}
+for line in open(sys.argv[1]):
+    f = line.split(None, 4)
+    if len(f) < 5 or not f[0].isdigit():
+        continue
+    calls, total = int(f[0]), float(f[1])
+    name = f[4].strip().replace("void ", "").replace("a3d::", "")
+    m = re.match(r"k_conv_sk<(\d+), (\d+), (\d+), (true|false)>", name)
+    if m:
+        key = f"k_conv_sk<{m.group(1)},{m.group(2)}>"
+    else:
+        m = re.match(r"k_dense<(\d+), (\d+)>", name)
+        key = f"k_dense<{m.group(1)},{m.group(2)}>" if m else name.split("(")[0]
+    c, t = acc.get(key, (0, 0.0))
+    acc[key] = (c + calls, t + total)
+for k, (c, t) in sorted(acc.items(), key=lambda kv: -kv[1][1]):
+    out[k] = round(t / c, 3)
+json.dump(out, open(sys.argv[2], "w"), indent=1)
+print("wrote", sys.argv[2], len(acc), "kernels")

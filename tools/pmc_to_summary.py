@@ -6,18 +6,18 @@ import re
 import sys
 
 raw = json.load(open(sys.argv[1]))
-out = {"_note": "rocprofv3 --pmc passes of `python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-profile "
-                "--streams 1` on MI355X (tools/profile_round.sh). Separate passes for FETCH_SIZE, WRITE_SIZE and the SQ "
+out = {"_note": "rocprofv3 --pmc passes of `python bench.py --steps-only --no-profile --steps 5 --warmup 2 --reps 1 "
+                "--streams 1` (only 4-scene steps) on MI355X (tools/profile_round.sh). Separate passes for FETCH_SIZE, WRITE_SIZE and the SQ "
                 "group (never combined with tracing). hbm_bytes_per_launch = (2*FETCH_SIZE + WRITE_SIZE) KiB: on gfx950 "
                 "FETCH_SIZE reports half the bytes of a wide coalesced read (MI355X_MICROARCH.md, HBM section); WRITE_SIZE "
                 "is taken as is (uncalibrated). mfma_util = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs * GRBM_GUI_ACTIVE / 8 "
-                "XCDs); wave_residency = 4*SQ_WAVE_CYCLES / waves / (GRBM_GUI_ACTIVE / 8) is reported for the conv kernels."}
+                "XCDs); bench.py reads hbm_bytes_per_launch of its dominant kernel as roofline.traffic."}
 for name, c in raw.items():
     short = name.replace("void ", "").replace("a3d::", "")
-    m = re.match(r"k_spconv2<(\d+), (\d+), (true|false)>", short)
+    m = re.match(r"k_conv_sk<(\d+), (\d+), (\d+), (true|false)>", short)   # <BN, CH, PAIR, DBG>: bench.py's key is <BN,CH>
     key = short
     if m:
-        key = f"k_spconv2<{m.group(1)},{m.group(2)}>"
+        key = f"k_conv_sk<{m.group(1)},{m.group(2)}>"
     m = re.match(r"k_dense<(\d+), (\d+)>", short)
     if m:
         key = f"k_dense<{m.group(1)},{m.group(2)}>"

@@ -1,18 +1,22 @@
 #!/bin/bash
-# Regenerate the profiles/ artefacts of a round on the GPU box:  bash tools/profile_round.sh r01
+# Regenerate the profiles/ artefacts of a round on the GPU box:  bash tools/profile_round.sh r02
 # (run through gpurun; raw rocprofv3 databases stay in /tmp, text/JSON summaries go to gpurun_out/<tag>/).
-# Passes: kernel trace + stats, then SEPARATE --pmc passes (FETCH_SIZE, WRITE_SIZE, SQ group) -- counters are
-# never combined with the hip/hsa/memory trace domains.
-TAG=${1:-r01}
+# Passes: kernel trace + stats of the DEFAULT bench command (4 scenes x 4 streams in flight + the instrumented pass) and
+# of `bench.py --steps-only --streams 1` (only the 4-scene steps, stream-serial: kernels never overlap and every launch
+# of a kernel is a launch of the step the bench line's roofline object describes -> kernel_avg_us.json), then SEPARATE
+# --pmc passes (FETCH_SIZE, WRITE_SIZE, SQ group) -- counters are never combined with the hip/hsa/memory trace domains.
+TAG=${1:-r02}
 R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
-CMD="python $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --streams 1"
 python $R/bench.py > $OUT/bench.json 2> $OUT/bench.err
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats -d /tmp/$TAG/trace -o t -- $CMD > $OUT/bench_under_rocprof.json 2> $OUT/trace.err
+rocprofv3 --kernel-trace --stats -d /tmp/$TAG/trace -o t -- python $R/bench.py --no-cpu-baseline > $OUT/bench_under_rocprof.json 2> $OUT/trace.err
 python $R/tools/rocprof_summary.py /tmp/$TAG/trace > $OUT/kernel_trace_stats.txt 2>&1
-PMC="python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-profile --streams 1"
+rocprofv3 --kernel-trace --stats -d /tmp/$TAG/trace1 -o t -- python $R/bench.py --steps-only --streams 1 > $OUT/bench_under_rocprof_steps_only.json 2> $OUT/trace1.err
+python $R/tools/rocprof_summary.py /tmp/$TAG/trace1 > $OUT/kernel_trace_stats_steps_only.txt 2>&1
+python $R/tools/kernel_avg.py $OUT/kernel_trace_stats_steps_only.txt $OUT/kernel_avg_us.json
+PMC="python $R/bench.py --steps-only --no-profile --steps 5 --warmup 2 --reps 1 --streams 1"
 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d /tmp/$TAG/pmc_fetch -o p -- $PMC > /dev/null 2> $OUT/pmc_fetch.err
 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d /tmp/$TAG/pmc_write -o p -- $PMC > /dev/null 2> $OUT/pmc_write.err
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_LDS_BANK_CONFLICT SQ_WAVE_CYCLES --kernel-trace -d /tmp/$TAG/pmc_sq -o p -- $PMC > /dev/null 2> $OUT/pmc_sq.err
