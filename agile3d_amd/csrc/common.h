@@ -42,6 +42,27 @@ struct ProfScope {
 static inline int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
 static inline size_t align256(size_t x) { return (x + 255) & ~size_t(255); }
 
+// ---- radix sort of (uint64 key, int32 value) pairs (radix.hip) ------------------------------
+constexpr int kRadixMaxPasses = 8;
+struct RadixPass {
+  int shift, bits;   // digit = (key >> shift) & ((1 << bits) - 1), bits <= 8
+};
+// digits covering key bits [bit_begin, bit_end), least significant first; returns their number (<= kRadixMaxPasses)
+static inline int radix_passes(int bit_begin, int bit_end, RadixPass* out, int n_before = 0) {
+  int np = n_before;
+  for (int b = bit_begin; b < bit_end && np < kRadixMaxPasses; b += 8) {
+    out[np].shift = b;
+    out[np].bits = bit_end - b < 8 ? bit_end - b : 8;
+    ++np;
+  }
+  return np;
+}
+size_t radix_sort_temp_bytes(int n_max);
+// stable, ascending in the listed digits; digits that are constant over the input are skipped on the device;
+// keys_in / vals_in are only read, temp must be 256-byte aligned
+int radix_sort_pairs(void* temp, size_t temp_bytes, const uint64_t* keys_in, uint64_t* keys_out, const int* vals_in,
+                     int* vals_out, int n, const RadixPass* passes, int npass, hipStream_t st);
+
 // ---- geometry constants -------------------------------------------------------------------
 constexpr int kTileRows = 128;   // output rows per conv workgroup
 constexpr int kGroupRows = 16;   // MFMA row granularity (v_mfma_f32_16x16x4_f32)

@@ -1,0 +1,324 @@
+// Stable LSD radix sort of (uint64 key, int32 value) pairs for the scene build (scene.hip): one histogram sweep for
+// all digits, one planning workgroup, then ONE kernel per digit (chained scan with decoupled look-back: a workgroup
+// publishes its digit counts, adds up the counts of the workgroups before it and scatters).  Digits whose value is the
+// same for every key are skipped ON THE DEVICE (the pass exits at once): the level-0 Morton keys are 64 bits wide but
+// only the bits the scene's extent touches differ, and which those are is not known on the host before the sort.
+//
+// Why not rocPRIM: below ~1 M items its radix_sort_pairs is a merge sort of ~18 dependent launches, and the scene build
+// runs three sorts per batch (rows of level 0 by Morton key; rows of all levels by neighbour pattern; fine rows by child
+// slot) -- 0.4 of the 0.74 ms of a 4-scene build, launch-bound at one scene.  Here a sort is 2 + (number of digits)
+// launches, typically 3-7.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "common.h"
+
+namespace a3d {
+
+namespace {
+
+constexpr int kRsThreads = 256;
+constexpr int kRsKeysPerThread = 16;
+constexpr int kRsBlockKeys = kRsThreads * kRsKeysPerThread;   // 4096
+constexpr int kLook = 16;   // look-back words in flight (an agent-scope load is a ~1 us round trip past the XCD's L2)
+constexpr uint32_t kFlagAgg = 1u << 30, kFlagInc = 1u << 31, kValMask = (1u << 30) - 1u;
+
+struct RsPlanDev {      // written by k_rs_plan, read by every pass
+  int skip[kRadixMaxPasses];
+  int src[kRadixMaxPasses];   // 0 = the caller's input, 1 = the caller's output, 2 = the temporary pair
+  int dst[kRadixMaxPasses];
+};
+
+struct RsArgs {
+  const uint64_t* keys_in;
+  const int* vals_in;
+  uint64_t *keys_out, *keys_tmp;
+  int *vals_out, *vals_tmp;
+  int n, npass, nblocks;
+  int shift[kRadixMaxPasses], bits[kRadixMaxPasses];
+  uint32_t* ghist;     // [npass][256]  counts, then exclusive starts
+  RsPlanDev* plan;
+  int* tickets;        // [npass]
+  uint32_t* status;    // [npass][nblocks][256]  look-back words
+};
+
+__device__ __forceinline__ int rs_digit(uint64_t k, int shift, int bits) { return (int)((k >> shift) & ((1u << bits) - 1u)); }
+
+// every digit's histogram in one sweep
+__global__ void __launch_bounds__(kRsThreads) k_rs_hist(const RsArgs a) {
+  __shared__ uint32_t h[kRadixMaxPasses * 256];
+  for (int i = threadIdx.x; i < a.npass * 256; i += kRsThreads) h[i] = 0;
+  __syncthreads();
+  for (int i = blockIdx.x * kRsThreads + threadIdx.x; i < a.n; i += gridDim.x * kRsThreads) {
+    const uint64_t k = a.keys_in[i];
+    for (int p = 0; p < a.npass; ++p) atomicAdd(&h[p * 256 + rs_digit(k, a.shift[p], a.bits[p])], 1u);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < a.npass * 256; i += kRsThreads)
+    if (h[i]) atomicAdd(&a.ghist[i], h[i]);
+}
+
+// one workgroup: exclusive starts per digit, which passes are trivial, which buffer each pass reads / writes
+__global__ void __launch_bounds__(256) k_rs_plan(const RsArgs a) {
+  __shared__ int lds[8];
+  __shared__ int trivial[kRadixMaxPasses];
+  const int d = threadIdx.x, lane = d & 63, w = d >> 6;
+  for (int p = 0; p < a.npass; ++p) {
+    const uint32_t c = a.ghist[p * 256 + d];
+    if (d == 0) trivial[p] = 0;
+    __syncthreads();
+    if (c == (uint32_t)a.n) trivial[p] = 1;   // one digit value holds every key
+    // exclusive scan of the 256 counts
+    int v = (int)c;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int t = __shfl_up(v, o, 64);
+      if (lane >= o) v += t;
+    }
+    if (lane == 63) lds[w] = v;
+    __syncthreads();
+    int base = 0;
+    for (int q = 0; q < w; ++q) base += lds[q];
+    a.ghist[p * 256 + d] = (uint32_t)(base + v - (int)c);
+    __syncthreads();
+  }
+  if (d == 0) {
+    int m = 0;
+    for (int p = 0; p < a.npass; ++p) m += trivial[p] ? 0 : 1;
+    if (m == 0) trivial[0] = 0, m = 1;   // nothing to sort: the first pass copies input -> output
+    int j = 0, cur = 0;
+    for (int p = 0; p < a.npass; ++p) {
+      a.plan->skip[p] = trivial[p];
+      if (trivial[p]) continue;
+      ++j;
+      const int dst = ((m - j) & 1) ? 2 : 1;   // the last executed pass lands in the caller's output
+      a.plan->src[p] = cur;
+      a.plan->dst[p] = dst;
+      cur = dst;
+    }
+  }
+}
+
+// one digit: 4096 keys per workgroup, stable
+__global__ void __launch_bounds__(kRsThreads) k_rs_pass(const RsArgs a, int p) {
+  if (a.plan->skip[p]) return;
+  __shared__ uint64_t skeys[kRsBlockKeys];
+  __shared__ int svals[kRsBlockKeys];
+  __shared__ uint32_t whist[4][256];   // per-wave digit counts, then per-wave exclusive offsets
+  __shared__ int lstart[256];          // first slot of a digit in the workgroup's sorted order
+  __shared__ int gpos[256];            // global position of slot 0 of a digit, minus lstart
+  __shared__ int misc[8];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int shift = a.shift[p], bits = a.bits[p];
+  const int s = a.plan->src[p], t = a.plan->dst[p];
+  const uint64_t* kin = s == 0 ? a.keys_in : (s == 1 ? a.keys_out : a.keys_tmp);
+  const int* vin = s == 0 ? a.vals_in : (s == 1 ? a.vals_out : a.vals_tmp);
+  uint64_t* kout = t == 1 ? a.keys_out : a.keys_tmp;
+  int* vout = t == 1 ? a.vals_out : a.vals_tmp;
+
+  if (tid == 0) misc[0] = atomicAdd(&a.tickets[p], 1);   // workgroups before this one in key order are already running
+  for (int i = tid; i < 4 * 256; i += kRsThreads) (&whist[0][0])[i] = 0;
+  __syncthreads();
+  const int b = misc[0];
+  const int base = b * kRsBlockKeys;
+  const int cnt = min(kRsBlockKeys, a.n - base);
+
+  // ---- rank every key among the keys of its wave with the same digit (rows of 64 in index order)
+  uint64_t key[kRsKeysPerThread];
+  int val[kRsKeysPerThread], rank[kRsKeysPerThread];
+  const unsigned long long lt = (1ull << lane) - 1ull;
+#pragma unroll
+  for (int r = 0; r < kRsKeysPerThread; ++r) {
+    const int li = w * (kRsBlockKeys / 4) + r * 64 + lane;
+    const bool ok = li < cnt;
+    key[r] = ok ? kin[base + li] : ~0ull;
+    val[r] = ok ? vin[base + li] : 0;
+  }
+#pragma unroll
+  for (int r = 0; r < kRsKeysPerThread; ++r) {
+    const int li = w * (kRsBlockKeys / 4) + r * 64 + lane;
+    const bool ok = li < cnt;
+    const int d = rs_digit(key[r], shift, bits);
+    unsigned long long peers = __ballot(ok);
+#pragma unroll
+    for (int bit = 0; bit < 8; ++bit) {
+      if (bit < bits) {   // uniform
+        const unsigned long long bal = __ballot((d >> bit) & 1);
+        peers &= ((d >> bit) & 1) ? bal : ~bal;
+      }
+    }
+    int before = 0;
+    if (ok) {
+      const int leader = __builtin_ctzll(peers);
+      if (lane == leader) {
+        before = (int)whist[w][d];
+        whist[w][d] = (uint32_t)(before + __builtin_popcountll(peers));
+      }
+      before = __shfl(before, leader, 64);
+    }
+    rank[r] = before + __builtin_popcountll(peers & lt);
+  }
+  __syncthreads();
+
+  // ---- digit d = thread d: counts of the workgroup, per-wave offsets, look-back
+  {
+    const int d = tid;
+    const uint32_t c0 = whist[0][d], c1 = whist[1][d], c2 = whist[2][d], c3 = whist[3][d];
+    const uint32_t tot = c0 + c1 + c2 + c3;
+    whist[0][d] = 0;
+    whist[1][d] = c0;
+    whist[2][d] = c0 + c1;
+    whist[3][d] = c0 + c1 + c2;
+    uint32_t* st = a.status + ((size_t)p * a.nblocks + b) * 256 + d;
+    __hip_atomic_store(st, tot | (b == 0 ? kFlagInc : kFlagAgg), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // exclusive scan of tot over the digits -> lstart
+    int v = (int)tot;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int x = __shfl_up(v, o, 64);
+      if (lane >= o) v += x;
+    }
+    if (lane == 63) misc[1 + w] = v;
+    __syncthreads();
+    int wbase = 0;
+    for (int q = 0; q < w; ++q) wbase += misc[1 + q];
+    const int ls = wbase + v - (int)tot;
+    lstart[d] = ls;
+    // look back, kLook workgroups at a time (their loads are in flight together; only a word not yet published is
+    // polled): a workgroup meets mostly AGGREGATE words -- all workgroups of a pass run at once
+    uint32_t excl = 0;
+    for (int pb = b - 1; pb >= 0; pb -= kLook) {
+      uint32_t x[kLook];
+#pragma unroll
+      for (int u = 0; u < kLook; ++u)
+        x[u] = pb - u >= 0 ? __hip_atomic_load(a.status + ((size_t)p * a.nblocks + (pb - u)) * 256 + d, __ATOMIC_RELAXED,
+                                               __HIP_MEMORY_SCOPE_AGENT)
+                           : kFlagInc;
+      bool done = false;
+#pragma unroll
+      for (int u = 0; u < kLook; ++u) {
+        if (done) break;
+        while ((x[u] & (kFlagAgg | kFlagInc)) == 0u) {
+          __builtin_amdgcn_s_sleep(1);
+          x[u] = __hip_atomic_load(a.status + ((size_t)p * a.nblocks + (pb - u)) * 256 + d, __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+        }
+        excl += x[u] & kValMask;
+        done = (x[u] & kFlagInc) != 0u;
+      }
+      if (done) break;
+    }
+    if (b > 0) __hip_atomic_store(st, (excl + tot) | kFlagInc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    gpos[d] = (int)(a.ghist[p * 256 + d] + excl) - ls;
+  }
+  __syncthreads();
+
+  // ---- into sorted order inside the workgroup (LDS), then out in runs
+#pragma unroll
+  for (int r = 0; r < kRsKeysPerThread; ++r) {
+    const int li = w * (kRsBlockKeys / 4) + r * 64 + lane;
+    if (li < cnt) {
+      const int d = rs_digit(key[r], shift, bits);
+      const int slot = lstart[d] + (int)whist[w][d] + rank[r];
+      skeys[slot] = key[r];
+      svals[slot] = val[r];
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < kRsKeysPerThread; ++r) {
+    const int slot = r * kRsThreads + tid;
+    if (slot < cnt) {
+      const uint64_t k = skeys[slot];
+      const int dst = gpos[rs_digit(k, shift, bits)] + slot;
+      kout[dst] = k;
+      vout[dst] = svals[slot];
+    }
+  }
+}
+
+inline int rs_blocks(int n) { return (n + kRsBlockKeys - 1) / kRsBlockKeys; }
+
+}  // namespace
+
+size_t radix_sort_temp_bytes(int n_max) {
+  const size_t nb = (size_t)rs_blocks(n_max > 0 ? n_max : 1);
+  size_t b = 0;
+  b += align256((size_t)n_max * sizeof(uint64_t));                        // keys_tmp
+  b += align256((size_t)n_max * sizeof(int));                             // vals_tmp
+  b += align256((size_t)kRadixMaxPasses * 256 * sizeof(uint32_t));        // ghist      } zeroed per sort,
+  b += align256((size_t)kRadixMaxPasses * sizeof(int));                   // tickets    } one memset
+  b += align256((size_t)kRadixMaxPasses * nb * 256 * sizeof(uint32_t));   // status     }
+  b += align256(sizeof(RsPlanDev));
+  return b + 256;
+}
+
+int radix_sort_pairs(void* temp, size_t temp_bytes, const uint64_t* keys_in, uint64_t* keys_out, const int* vals_in,
+                     int* vals_out, int n, const RadixPass* passes, int npass, hipStream_t st) {
+  if (n <= 0) return A3D_OK;
+  if (npass < 1 || npass > kRadixMaxPasses || !temp || ((uintptr_t)temp & 255) || temp_bytes < radix_sort_temp_bytes(n)) {
+    set_error("radix_sort_pairs: bad arguments (n=%d, passes=%d, temp=%zu)", n, npass, temp_bytes);
+    return A3D_ERR_INVALID;
+  }
+  RsArgs a;
+  memset(&a, 0, sizeof(a));
+  a.keys_in = keys_in;
+  a.vals_in = vals_in;
+  a.keys_out = keys_out;
+  a.vals_out = vals_out;
+  a.n = n;
+  a.npass = npass;
+  a.nblocks = rs_blocks(n);
+  for (int p = 0; p < npass; ++p) {
+    if (passes[p].bits < 1 || passes[p].bits > 8 || passes[p].shift < 0 || passes[p].shift + passes[p].bits > 64) {
+      set_error("radix_sort_pairs: digit %d (shift %d, %d bits)", p, passes[p].shift, passes[p].bits);
+      return A3D_ERR_INVALID;
+    }
+    a.shift[p] = passes[p].shift;
+    a.bits[p] = passes[p].bits;
+  }
+  char* c = (char*)temp;
+  a.keys_tmp = (uint64_t*)c;
+  c += align256((size_t)n * sizeof(uint64_t));
+  a.vals_tmp = (int*)c;
+  c += align256((size_t)n * sizeof(int));
+  char* zero_begin = c;
+  a.ghist = (uint32_t*)c;
+  c += align256((size_t)kRadixMaxPasses * 256 * sizeof(uint32_t));
+  a.tickets = (int*)c;
+  c += align256((size_t)kRadixMaxPasses * sizeof(int));
+  a.status = (uint32_t*)c;
+  c += align256((size_t)npass * a.nblocks * 256 * sizeof(uint32_t));
+  char* zero_end = c;
+  a.plan = (RsPlanDev*)c;
+  A3D_HIP_CHECK(hipMemsetAsync(zero_begin, 0, (size_t)(zero_end - zero_begin), st));
+  int hb = (n + kRsThreads * 8 - 1) / (kRsThreads * 8);
+  if (hb > 512) hb = 512;
+  k_rs_hist<<<hb, kRsThreads, 0, st>>>(a);
+  k_rs_plan<<<1, 256, 0, st>>>(a);
+  for (int p = 0; p < npass; ++p) k_rs_pass<<<a.nblocks, kRsThreads, 0, st>>>(a, p);
+  A3D_LAUNCH_CHECK();
+  return A3D_OK;
+}
+
+}  // namespace a3d
+
+// Test / utility entry: stable sort of (key, value) pairs by the key bits [bit_begin, bit_end), ascending.
+extern "C" size_t a3d_sort_pairs_workspace_bytes(int64_t n) {
+  if (n <= 0 || n > (int64_t)1 << 28) return 0;
+  return a3d::radix_sort_temp_bytes((int)n);
+}
+extern "C" int a3d_sort_pairs_u64(const uint64_t* keys_in_dev, const int32_t* vals_in_dev, int64_t n, int bit_begin,
+                                  int bit_end, uint64_t* keys_out_dev, int32_t* vals_out_dev, void* workspace_dev,
+                                  size_t workspace_bytes, void* stream) {
+  using namespace a3d;
+  if (n < 0 || n > (int64_t)1 << 28 || bit_begin < 0 || bit_end > 64 || bit_end <= bit_begin || !keys_in_dev || !vals_in_dev ||
+      !keys_out_dev || !vals_out_dev) {
+    set_error("a3d_sort_pairs_u64: bad arguments");
+    return A3D_ERR_INVALID;
+  }
+  RadixPass ps[kRadixMaxPasses];
+  const int np = radix_passes(bit_begin, bit_end, ps);
+  return radix_sort_pairs(workspace_dev, workspace_bytes, keys_in_dev, keys_out_dev, vals_in_dev, vals_out_dev, (int)n, ps, np,
+                          (hipStream_t)stream);
+}

@@ -15,7 +15,6 @@
 //   * kernel maps are output-major neighbour tables int32[K][npad] (k-major: the 128 rows of a
 //     workgroup tile are contiguous for every offset) with "missing" = the all-zero row n.
 #include "common.h"
-#include <rocprim/rocprim.hpp>
 #include <algorithm>
 #include <limits.h>
 #include <stdarg.h>
@@ -424,13 +423,30 @@ __global__ void k_child(const LevelSet S) {
     const int slot = (int)(f.keys[i] & 7);
     const int pf = c.perm[f.parentM[i]];
     f.child8[(size_t)slot * c.npad + pf] = f.perm[i];
-    // up to 128 children set the same 8 bits of a group word: skip the atomic when the bit is already visible
-    if (!(__builtin_nontemporal_load(&f.gmask_down[pf >> 4]) & (1u << slot))) atomicOr(&f.gmask_down[pf >> 4], 1u << slot);
   }
   {   // i as an internal row of the fine level
     S.cat_keys[S.off[L] + i] = ((uint64_t)L << S.level_shift) | ((uint64_t)(i >> S.st_shift) << 27) | (f.keys[f.inv[i]] & 7);
     S.cat_vals[S.off[L] + i] = S.off[L] + i;
   }
+}
+
+// gmask_down[g] = child slots present in the 16 coarse rows of group g, read back from child8 (one thread per coarse
+// row, a group is 16 consecutive lanes; k_child used to set these bits with up to 128 atomics per word: 84 us)
+__global__ void k_gmask_down(const LevelSet S) {
+  int lb;
+  const int L = ls_level(S, lb);
+  const Level& f = S.lv[L];
+  const Level& c = S.lv[L + 1];
+  const int pf = lb * blockDim.x + threadIdx.x;
+  if (pf >= c.npad) return;   // npad is a multiple of 128: whole waves leave together
+  const int lane = threadIdx.x & 63;
+  uint32_t word = 0;
+#pragma unroll
+  for (int s = 0; s < 8; ++s) {
+    const unsigned long long bal = __ballot(f.child8[(size_t)s * c.npad + pf] != f.n);
+    if ((bal >> (lane & 48)) & 0xffffULL) word |= 1u << s;
+  }
+  if ((lane & 15) == 0) f.gmask_down[pf >> 4] = word;
 }
 
 // transposed-conv tables over virtual rows v (fine rows sorted by child slot inside super tiles)
@@ -446,7 +462,16 @@ __global__ void k_up(const LevelSet S) {
     const int m = f.inv[f.up_rows[v]];
     slot = (int)(f.keys[m] & 7);
     pf = c.perm[f.parentM[m]];
-    atomicOr(&f.gmask_up[v >> 4], 1u << slot);
+  }
+  {   // slots present in each 16-row group (a group is 16 consecutive lanes: no atomics)
+    const int lane = threadIdx.x & 63;
+    uint32_t word = 0;
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      const unsigned long long bal = __ballot(slot == s);
+      if ((bal >> (lane & 48)) & 0xffffULL) word |= 1u << s;
+    }
+    if ((lane & 15) == 0) f.gmask_up[v >> 4] = word;
   }
 #pragma unroll
   for (int s = 0; s < 8; ++s) f.up8[(size_t)s * f.npad + v] = (s == slot) ? pf : c.n;
@@ -491,14 +516,9 @@ static uint32_t hash_capacity(int n) {
   return c;
 }
 
-// (rocPRIM sorts < 1 M items with a merge sort, ~18 dependent launches; forcing its Onesweep path through a
-// radix_sort_config with a lower merge limit measured SLOWER here: 261 vs 165 us for the 321 k-key first sort.)
-static size_t sort_temp_bytes(int n) {
-  size_t bytes = 0;
-  (void)rocprim::radix_sort_pairs(nullptr, bytes, (uint64_t*)nullptr, (uint64_t*)nullptr, (int*)nullptr,
-                                  (int*)nullptr, (size_t)n, 0, 64, (hipStream_t)0, false);
-  return bytes;
-}
+// the three sorts of a scene build are radix.hip's (rocPRIM's radix_sort_pairs is a merge sort of ~18 dependent launches
+// below 1 M items: 0.4 of the 0.74 ms of a 4-scene build, launch-bound at one scene)
+static size_t sort_temp_bytes(int n) { return radix_sort_temp_bytes(n); }
 
 // phase-1 arrays (sized by the n0 upper bound) and phase-2 tables (sized by the real level sizes)
 struct Phase1 {
@@ -666,9 +686,12 @@ extern "C" int a3d_scene_create(const int32_t* coords4_dev, int64_t n_voxels, vo
   A3D_HIP_CHECK(hipMemcpyAsync(p.sizes_dev, sizes, sizeof(sizes), hipMemcpyHostToDevice, st));
   k_make_keys<<<nblk(n0, T), T, 0, st>>>(coords4_dev, n0, p.keys_in, p.vals_in, p.sizes_dev);
   A3D_LAUNCH_CHECK();
-  size_t tb = p.sort_temp_bytes;
-  A3D_HIP_CHECK(rocprim::radix_sort_pairs(p.sort_temp, tb, p.keys_in, p.keys[0], p.vals_in, p.vals_sorted,
-                                          (size_t)n0, 0, 64, st, false));
+  {   // all 64 key bits: the digits the batch's extent does not touch are skipped on the device
+    RadixPass ps[kRadixMaxPasses];
+    const int np = radix_passes(0, 64, ps);
+    int rc = radix_sort_pairs(p.sort_temp, p.sort_temp_bytes, p.keys_in, p.keys[0], p.vals_in, p.vals_sorted, n0, ps, np, st);
+    if (rc) return rc;
+  }
   k_check_dups<<<nblk(n0, T), T, 0, st>>>(p.keys[0], n0, p.sizes_dev);
   A3D_LAUNCH_CHECK();
   const int nb = (n0 + 1023) / 1024;
@@ -768,11 +791,18 @@ extern "C" int a3d_scene_create(const int32_t* coords4_dev, int64_t n_voxels, vo
     for (int L = 0; L < nlev; ++L) S.blk[L + 1] = S.blk[L] + (int)nblk((int64_t)count(L), T);
     return (unsigned)S.blk[nlev];
   };
-  auto sort_cat = [&](int nlev) -> int {
-    size_t tb = p.sort_temp_bytes;
-    A3D_HIP_CHECK(rocprim::radix_sort_pairs(p.sort_temp, tb, t.cat_keys, t.cat_keys_sorted, t.cat_vals, t.cat_vals_sorted,
-                                            (size_t)S.off[nlev], 0, S.level_shift + 3, st, false));
-    return A3D_OK;
+  // key = level | super tile | small key (27-bit neighbour mask or 3-bit child slot): only the bits in use are sorted
+  auto sort_cat = [&](int nlev, int small_bits) -> int {
+    RadixPass ps[kRadixMaxPasses];
+    int np;
+    if (small_bits == 27) {
+      np = radix_passes(0, S.level_shift + 3, ps);
+    } else {
+      np = radix_passes(0, small_bits, ps);
+      np = radix_passes(27, S.level_shift + 3, ps, np);
+    }
+    return radix_sort_pairs(p.sort_temp, p.sort_temp_bytes, t.cat_keys, t.cat_keys_sorted, t.cat_vals, t.cat_vals_sorted,
+                            S.off[nlev], ps, np, st);
   };
   const int NL = A3D_NUM_LEVELS;
   unsigned g;
@@ -786,7 +816,7 @@ extern "C" int a3d_scene_create(const int32_t* coords4_dev, int64_t n_voxels, vo
   A3D_LAUNCH_CHECK();
   // ---- stage B: ONE stable radix sort re-orders the rows of all levels inside their super tiles
   {
-    int rc = sort_cat(NL);
+    int rc = sort_cat(NL, 27);
     if (rc) { delete sc; return rc; }
   }
   // ---- stage C: tables in the new row order
@@ -803,10 +833,12 @@ extern "C" int a3d_scene_create(const int32_t* coords4_dev, int64_t n_voxels, vo
   k_child<<<g, T, 0, st>>>(S);
   A3D_LAUNCH_CHECK();
   {
-    int rc = sort_cat(NL - 1);
+    int rc = sort_cat(NL - 1, 3);
     if (rc) { delete sc; return rc; }
   }
   k_perm_from_sorted<<<g, T, 0, st>>>(S, 1);
+  g = blocks(NL - 1, [&](int L) { return (int64_t)sc->lv[L + 1].npad; });
+  k_gmask_down<<<g, T, 0, st>>>(S);
   g = blocks(NL - 1, [&](int L) { return (int64_t)sc->lv[L].npad; });
   k_up<<<g, T, 0, st>>>(S);
   A3D_LAUNCH_CHECK();

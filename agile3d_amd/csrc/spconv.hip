@@ -131,7 +131,9 @@ __global__ void __launch_bounds__(256, PAIR ? ((BN <= 96 && CH <= 32) ? 4 : 3) :
   const int T = a.c.n_tiles;
   const int cin16 = a.c.cin >> 4, cout16 = a.c.cout >> 4;
 
+  if (DBG && (a.dbg & 32)) return;   // launch only
   int w = blockIdx.x;
+  const long long pre_T = a.pre ? (long long)a.pre[T] : (long long)K * T;   // requested before the ticket's round trip
   if (a.ticket) {
     if (tid == 0) misc[0] = atomicAdd(a.ticket, 1);
     __syncthreads();
@@ -144,7 +146,7 @@ __global__ void __launch_bounds__(256, PAIR ? ((BN <= 96 && CH <= 32) ? 4 : 3) :
     const long long n = a.pre ? (long long)a.pre[t] : (long long)K * t;
     return n * nchunk + (long long)ov * t;
   };
-  const long long tile_tot = prefix(T);                       // one pass over all tiles
+  const long long tile_tot = pre_T * nchunk + (long long)ov * T;   // = prefix(T): one pass over all tiles
   const long long tot = (long long)a.n_cblk * tile_tot;
   const int G = (int)min((long long)a.G, tot);
   if (w >= G) return;
@@ -152,22 +154,24 @@ __global__ void __launch_bounds__(256, PAIR ? ((BN <= 96 && CH <= 32) ? 4 : 3) :
   // 64-ary search, every wave on its own (no LDS): lane i probes the i-th of 64 evenly spaced tiles of the current
   // range, a ballot finds the last one at or below r; three rounds cover 2^18 tiles (a binary search is 13+ dependent
   // loads per workgroup before its first MFMA)
-  auto locate = [&](long long x) -> int {
-    const int cb = (int)(x / tile_tot);
-    const long long r = x - (long long)cb * tile_tot;
-    int lo_t = 0, hi_t = T;   // prefix(lo_t) <= r < prefix(hi_t)
-    while (hi_t - lo_t > 1) {
-      const int span = hi_t - lo_t;
-      const int step = (span + 63) >> 6;
-      const int tp = lo_t + lane * step;                       // lane 0 probes lo_t itself (always <= r)
-      const bool le = tp < hi_t && prefix(tp) <= r;
-      const unsigned long long m = __ballot(le);
-      const int last = 63 - __builtin_clzll(m);                // m has bit 0 set
-      const int nlo = lo_t + last * step;
-      hi_t = min(hi_t, nlo + step);
-      lo_t = nlo;
+  // the two ends of a share are searched in lockstep (their probes are independent loads: one round trip per round)
+  auto locate2 = [&](long long x0, long long x1, int& u0, int& u1) {
+    const int cb0 = (int)(x0 / tile_tot), cb1 = (int)(x1 / tile_tot);
+    const long long r0 = x0 - (long long)cb0 * tile_tot, r1 = x1 - (long long)cb1 * tile_tot;
+    int lo0 = 0, hi0 = T, lo1 = 0, hi1 = T;   // prefix(lo) <= r < prefix(hi)
+    while (hi0 - lo0 > 1 || hi1 - lo1 > 1) {
+      const int step0 = (hi0 - lo0 + 63) >> 6, step1 = (hi1 - lo1 + 63) >> 6;
+      const int tp0 = lo0 + lane * step0, tp1 = lo1 + lane * step1;   // lane 0 probes lo itself (always <= r)
+      const long long p0 = prefix(min(tp0, T)), p1 = prefix(min(tp1, T));
+      const unsigned long long m0 = __ballot(tp0 < hi0 && p0 <= r0), m1 = __ballot(tp1 < hi1 && p1 <= r1);
+      const int n0 = lo0 + (63 - __builtin_clzll(m0)) * step0, n1 = lo1 + (63 - __builtin_clzll(m1)) * step1;
+      hi0 = min(hi0, n0 + step0);
+      lo0 = n0;
+      hi1 = min(hi1, n1 + step1);
+      lo1 = n1;
     }
-    return cb * T + __builtin_amdgcn_readfirstlane(lo_t);
+    u0 = cb0 * T + __builtin_amdgcn_readfirstlane(lo0);
+    u1 = cb1 * T + __builtin_amdgcn_readfirstlane(lo1);
   };
 
   long long lo, hi;
@@ -176,8 +180,7 @@ __global__ void __launch_bounds__(256, PAIR ? ((BN <= 96 && CH <= 32) ? 4 : 3) :
     lo = share_begin(w);
     hi = share_begin(w + 1);
     if (hi <= lo) return;
-    u_lo = locate(lo);
-    u_hi = locate(hi - 1);
+    locate2(lo, hi - 1, u_lo, u_hi);
   } else {   // whole tiles: no tile is shared (w < a.G <= number of tiles: the launch guarantees it)
     const long long NU = (long long)a.n_cblk * T;
     u_lo = (int)(NU * w / a.G);
@@ -187,6 +190,10 @@ __global__ void __launch_bounds__(256, PAIR ? ((BN <= 96 && CH <= 32) ? 4 : 3) :
     hi = tot;
   }
 
+  if (DBG && (a.dbg & 16)) {   // launch + ticket + share search only
+    if (u_lo + u_hi == -12345) a.c.out[0] = 0.f;
+    return;
+  }
   // this wave's weight pieces q = wave + NW*i of a stage: constant per-lane source byte offset, LDS byte offset
   unsigned wsrc[WV], wdst[WV];
 #pragma unroll
@@ -378,6 +385,10 @@ __global__ void __launch_bounds__(256, PAIR ? ((BN <= 96 && CH <= 32) ? 4 : 3) :
       }
     }
 
+    if (DBG && (a.dbg & 8)) {   // no hand-off: parts are dropped, owners do not wait
+      if (!owner) continue;
+      s0 = 0;
+    }
     if (!owner) {
       // publish this part: write-through stores, every wave drains, one flag
       float* P = a.slab + (size_t)w * (kTile * BN) + (size_t)tid * 4;
@@ -409,18 +420,26 @@ __global__ void __launch_bounds__(256, PAIR ? ((BN <= 96 && CH <= 32) ? 4 : 3) :
         if (tid == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         __syncthreads();
         const float* P0 = a.slab + (size_t)tid * 4;
-        for (int wp = w - 1; wp >= wf; --wp) {   // fixed order: own part, then the parts of the tickets below, descending
-          const float* Pa = P0 + (size_t)wp * (kTile * BN);
-          f32x4 pa[RG][NCT];
+        // fixed order: own part, then the parts of the tickets below, descending; U parts' loads in flight at a time
+        constexpr int U = NCT <= 4 ? 2 : 1;
+        for (int wp = w - 1; wp >= wf; wp -= U) {
+          f32x4 pa[U][NCT];
 #pragma unroll
-          for (int r = 0; r < RG; ++r)
+          for (int u = 0; u < U; ++u) {
+            if (wp - u >= wf) {
+              const float* Pa = P0 + (size_t)(wp - u) * (kTile * BN);
 #pragma unroll
-            for (int ct = 0; ct < NCT; ++ct) pa[r][ct] = *(const f32x4*)(Pa + (r * NCT + ct) * 1024);
+              for (int ct = 0; ct < NCT; ++ct) pa[u][ct] = *(const f32x4*)(Pa + ct * 1024);
+            } else {
+#pragma unroll
+              for (int ct = 0; ct < NCT; ++ct) pa[u][ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
+          }
           __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-          for (int r = 0; r < RG; ++r)
+          for (int u = 0; u < U; ++u)
 #pragma unroll
-            for (int ct = 0; ct < NCT; ++ct) acc[r][ct] += pa[r][ct];
+            for (int ct = 0; ct < NCT; ++ct) acc[0][ct] += pa[u][ct];
         }
       }
 #pragma unroll
@@ -753,8 +772,6 @@ static int sk_env(const char* name, int dflt) {
 static int sk_ch(int cin, int bn) {   // input channels per stage
   static int forced = sk_env("A3D_SK_CH", 0);   // experiment: stage width of the 96-column kernels
   if (forced && bn == 96 && cin % forced == 0) return forced;
-  static int small = sk_env("A3D_SK_SMALLCH", 0);   // experiment: stage width of the 64-column kernels
-  if (small && bn == 64 && cin % small == 0) return small;
   // 96-column workgroups: 32-channel stages -- 157 registers, a 25 KB weight ring: THREE workgroups per CU, the third
   // covers the per-tile prologues / epilogues and the stage barriers of the other two (measured on the 4-scene batch:
   // L0 96 -> 96 700 -> 620 us = 108 TF/s, 128 -> 96 850 -> 790 us = 113 TF/s against 96- / 64-channel stages with two)
@@ -812,6 +829,14 @@ static SkPlan plan_sk(int n_rows, int K, int cin, int cout, bool handoff) {
     const int min_share = share_env ? share_env : (mfma_per_stage >= 128 ? 6 : 8);
     if (handoff) {
       long long G = est / min_share;
+      // a level too small to hand every CU a share of that size: shorter shares (each workgroup's chain of stages is
+      // what the layer waits for; the hand-off of a tile grows with the number of its parts, so not below small_share)
+      static int small_env = sk_env("A3D_SK_SMALLSHARE", 0);
+      const int small_share = small_env ? small_env : 4;
+      if (G < 256 && small_share < min_share) {
+        G = est / small_share;
+        if (G > 256) G = 256;
+      }
       p.G = (int)(G < 1 ? 1 : (G > gmax ? gmax : G));
       p.slab_floats = (size_t)p.G * 64 * p.bn;
       if (p.G >= 256 || p.bn <= 64 || cout % 64) break;
@@ -832,7 +857,7 @@ static void allow_big_lds() {
 #define A3D_BIG3(BN_, CH_) \
   (void)hipFuncSetAttribute((const void*)k_conv_sk<BN_, CH_, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
   (void)hipFuncSetAttribute((const void*)k_conv_sk<BN_, CH_, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  A3D_BIG3(32, 32) A3D_BIG3(32, 64) A3D_BIG3(32, 96) A3D_BIG3(64, 32) A3D_BIG3(64, 64) A3D_BIG3(64, 96) A3D_BIG3(64, 128)
+  A3D_BIG3(32, 32) A3D_BIG3(32, 64) A3D_BIG3(32, 96) A3D_BIG3(64, 32) A3D_BIG3(64, 64) A3D_BIG3(64, 96)
   A3D_BIG3(96, 32) A3D_BIG3(96, 48) A3D_BIG3(96, 64) A3D_BIG3(96, 96) A3D_BIG3(128, 32) A3D_BIG3(128, 64)
 #undef A3D_BIG3
   (void)hipFuncSetAttribute((const void*)k_conv_sk<64, 64, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -915,7 +940,7 @@ static int launch_conv_sk(ConvArgs c, const int* pre64, const int* pre128, float
   }
 #define A3D_L3(BN_, CH_) \
   if (p.bn == BN_ && p.ch == CH_) { if (p.pair) k_conv_sk<BN_, CH_, 1><<<p.G, 256, p.lds, st>>>(a); else k_conv_sk<BN_, CH_, 0><<<p.G, 256, p.lds, st>>>(a); } else
-  A3D_L3(32, 32) A3D_L3(32, 64) A3D_L3(32, 96) A3D_L3(64, 32) A3D_L3(64, 64) A3D_L3(64, 96) A3D_L3(64, 128)
+  A3D_L3(32, 32) A3D_L3(32, 64) A3D_L3(32, 96) A3D_L3(64, 32) A3D_L3(64, 64) A3D_L3(64, 96)
   A3D_L3(96, 32) A3D_L3(96, 48) A3D_L3(96, 64) A3D_L3(96, 96) A3D_L3(128, 32) A3D_L3(128, 64)
   { set_error("spconv: no kernel for BN %d CH %d", p.bn, p.ch); return A3D_ERR_UNSUPPORTED; }
 #undef A3D_L3

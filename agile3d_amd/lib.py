@@ -85,6 +85,9 @@ SYMBOLS = {
     "a3d_profile_enable": (C.c_int, [C.c_int]),
     "a3d_profile_read": (C.c_int, [C.POINTER(ProfEntry), C.c_int]),
     "a3d_scene_workspace_bytes": (C.c_size_t, [C.c_int64]),
+    "a3d_sort_pairs_workspace_bytes": (C.c_size_t, [C.c_int64]),
+    "a3d_sort_pairs_u64": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                     C.c_size_t, C.c_void_p]),
     "a3d_scene_create": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_size_t, C.c_void_p,
                                    C.POINTER(C.c_void_p)]),
     "a3d_scene_destroy": (None, [C.c_void_p]),

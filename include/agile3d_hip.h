@@ -75,6 +75,15 @@ int a3d_profile_read(a3d_prof_entry* out, int max_entries);   /* returns #entrie
  * ------------------------------------------------------------------------------------------ */
 typedef struct a3d_scene a3d_scene;
 
+/* Stable ascending sort of (uint64 key, int32 value) pairs by the key bits [bit_begin, bit_end): the LSD radix sort the
+ * scene build uses for its three sorts (csrc/radix.hip; replaces the sorts MinkowskiEngine's coordinate manager runs
+ * inside `ME.SparseTensor(...)` / `MinkowskiConvolution` kernel-map construction, reference models/agile3d.py:163-170).
+ * Exposed for the tests.  keys_in / vals_in are only read. */
+size_t  a3d_sort_pairs_workspace_bytes(int64_t n);
+int     a3d_sort_pairs_u64(const uint64_t* keys_in_dev, const int32_t* vals_in_dev, int64_t n, int bit_begin, int bit_end,
+                           uint64_t* keys_out_dev, int32_t* vals_out_dev, void* workspace_dev, size_t workspace_bytes,
+                           void* stream);
+
 size_t  a3d_scene_workspace_bytes(int64_t n_voxels);
 int     a3d_scene_create(const int32_t* coords4_dev, int64_t n_voxels,
                          void* workspace_dev, size_t workspace_bytes,

@@ -165,3 +165,41 @@ def test_batch_ranges_and_malformed_batches():
     for bad in (swapped, interleaved, gap):
         with pytest.raises(A3DError):
             Scene(torch.from_numpy(np.ascontiguousarray(bad)).cuda())
+
+
+def _sort_pairs(keys, vals, b0, b1):
+    import ctypes as C
+    lib = L.load()
+    n = keys.numel()
+    ko, vo = torch.empty_like(keys), torch.empty_like(vals)
+    ws = torch.empty(max(256, lib.a3d_sort_pairs_workspace_bytes(max(n, 1))), dtype=torch.uint8, device="cuda")
+    L.check(lib.a3d_sort_pairs_u64(C.c_void_p(keys.data_ptr()), C.c_void_p(vals.data_ptr()), n, b0, b1, C.c_void_p(ko.data_ptr()),
+                                   C.c_void_p(vo.data_ptr()), C.c_void_p(ws.data_ptr()), ws.numel(),
+                                   C.c_void_p(torch.cuda.current_stream().cuda_stream)), "a3d_sort_pairs_u64")
+    return ko, vo
+
+
+@pytest.mark.parametrize("n", [1, 2, 63, 64, 65, 4095, 4096, 4097, 8193, 100_003, 1_300_000])
+@pytest.mark.parametrize("kind", ["random63", "few_bits", "constant", "descending", "morton_like"])
+def test_radix_sort_pairs_is_a_stable_sort(n, kind):
+    """csrc/radix.hip against torch.sort(stable=True): every workgroup-boundary size, keys with constant digits (skipped
+    on the device), all-equal keys (the order of the values must survive), a partial bit range."""
+    g = torch.Generator().manual_seed(n * 7 + len(kind))
+    if kind == "random63":
+        keys = torch.randint(0, 2 ** 62, (n,), generator=g, dtype=torch.int64)
+    elif kind == "few_bits":       # 5 distinct values far apart: most digits constant, long runs of ties
+        keys = torch.randint(0, 5, (n,), generator=g, dtype=torch.int64) << 37
+    elif kind == "constant":
+        keys = torch.full((n,), 0x0123456789ABCDE, dtype=torch.int64)
+    elif kind == "descending":
+        keys = torch.arange(n, 0, -1, dtype=torch.int64) * 977
+    else:                           # batch index on top, ~30 varying bits below, an offset bit pattern in between
+        keys = (torch.randint(0, 4, (n,), generator=g, dtype=torch.int64) << 54) | (0x2492 << 38) | \
+            torch.randint(0, 2 ** 30, (n,), generator=g, dtype=torch.int64)
+    vals = torch.randperm(n, generator=g, dtype=torch.int64).to(torch.int32)
+    b0, b1 = (0, 64) if kind != "descending" else (0, 40)
+    ko, vo = _sort_pairs(keys.cuda(), vals.cuda(), b0, b1)
+    field = (keys >> b0) & ((1 << (b1 - b0)) - 1) if b1 - b0 < 64 else keys
+    order = torch.sort(field, stable=True)[1]
+    assert torch.equal(ko.cpu(), keys[order]), kind
+    assert torch.equal(vo.cpu(), vals[order]), kind

@@ -11,15 +11,10 @@ run() {  # label, env...
     done
   done
 }
-run base A3D_X=0
-run "dbg1 (no gather)" A3D_DBG=1
-run "dbg2 (no weight DMA)" A3D_DBG=2
-run "dbg3 (no loads)" A3D_DBG=3
+run "base" A3D_X=0
+run "dbg32 (launch only)" A3D_DBG=32
+run "dbg16 (launch + ticket + search)" A3D_DBG=16
+run "dbg15 (no loads, no MFMA, no hand-off)" A3D_DBG=15
 run "dbg7 (no loads, no MFMA)" A3D_DBG=7
-run minshare2 A3D_SK_MINSHARE=2
-run minshare4 A3D_SK_MINSHARE=4
-run minshare12 A3D_SK_MINSHARE=12
-run minshare24 A3D_SK_MINSHARE=24
-run smallch128 A3D_SK_SMALLCH=128
-run "smallch128 minshare3" A3D_SK_SMALLCH=128 A3D_SK_MINSHARE=3
+run "dbg8 (no hand-off)" A3D_DBG=8
 cat $OUT
