@@ -135,6 +135,15 @@ __global__ void k_col_final(const float* __restrict__ partial, int nblocks, int 
   out[c] = s;
 }
 
+// the same sum written as fp32 (a3d_column_sums: one launch instead of k_col_final + a conversion kernel)
+__global__ void k_col_final_f32(const float* __restrict__ partial, int nblocks, int C, float* out) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double s = 0.0;
+  for (int b = 0; b < nblocks; ++b) s += (double)partial[(size_t)b * C + c];
+  out[c] = (float)s;
+}
+
 __global__ void k_scale_f64(const double* in, int C, double f, double* out) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c < C) out[c] = in[c] * f;
@@ -520,14 +529,12 @@ extern "C" int a3d_column_sums(const float* x_dev, int ldx, int64_t n, int C, fl
   }
   hipStream_t st = (hipStream_t)stream;
   float* partial = (float*)workspace_dev;
-  double* sums = (double*)((char*)workspace_dev + align256((size_t)kBnMaxBlocks * 2 * C * sizeof(float)));
   ColArgs c;
   memset(&c, 0, sizeof(c));
   c.x = x_dev, c.ldx = ldx, c.n = (int)n, c.C = C, c.partial = partial, c.mode = 0;
   const int blocks = bn_blocks(n, c.rows_per_block);
   k_col_partial<<<blocks, kBnThreads, 0, st>>>(c);
-  k_col_final<<<(unsigned)((C + 255) / 256), 256, 0, st>>>(partial, blocks, 1, C, sums);
-  k_bn_mean<<<(unsigned)((C + 255) / 256), 256, 0, st>>>(sums, C, 1.0, out_dev);
+  k_col_final_f32<<<(unsigned)((C + 255) / 256), 256, 0, st>>>(partial, blocks, C, out_dev);
   A3D_LAUNCH_CHECK();
   return A3D_OK;
 }

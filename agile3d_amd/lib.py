@@ -147,6 +147,10 @@ SYMBOLS = {
     "a3d_sum_squares_accumulate": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "a3d_adamw_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_float,
                                  C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p]),
+    "a3d_mt_workspace_bytes": (C.c_size_t, [C.c_int64]),
+    "a3d_sum_squares_multi": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "a3d_adamw_step_multi": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float,
+                                       C.c_float, C.c_void_p]),
     "a3d_bn_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int]),
     "a3d_bn_train_forward": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_float,
                                        C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,

@@ -25,21 +25,46 @@ def _stream(t):
     return C.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
 
 
+MT_CHUNK = 4096   # A3D_MT_CHUNK
+_MT_DTYPE = None
+
+
+def _mt_table(entries, device):
+    """entries: [(p, g, m, v, n, bias1, bias2_sqrt)] with tensors or None -> (device table of a3d_mt_tensor, n_chunks)."""
+    global _MT_DTYPE
+    import numpy as np
+    if _MT_DTYPE is None:
+        _MT_DTYPE = np.dtype([("p", "<u8"), ("g", "<u8"), ("m", "<u8"), ("v", "<u8"), ("n", "<i8"), ("chunk0", "<i4"),
+                              ("bias1", "<f4"), ("bias2_sqrt", "<f4"), ("pad", "<i4")])
+        assert _MT_DTYPE.itemsize == 56
+    tab = np.zeros(len(entries), _MT_DTYPE)
+    chunk = 0
+    for i, (p, g, m, v, n, b1, b2) in enumerate(entries):
+        tab[i] = (p.data_ptr() if p is not None else 0, g.data_ptr(), m.data_ptr() if m is not None else 0,
+                  v.data_ptr() if v is not None else 0, n, chunk, b1, b2, 0)
+        chunk += (n + MT_CHUNK - 1) // MT_CHUNK
+    return torch.from_numpy(tab.view(np.uint8)).to(device), chunk
+
+
 def total_grad_norm(grads: dict) -> float:
-    """sqrt(sum over all tensors of sum g^2): the 2-norm clip_grad_norm_ computes (fp64 accumulation on the device)."""
+    """sqrt(sum over all tensors of sum g^2): the 2-norm clip_grad_norm_ computes (fp64 accumulation on the device, all
+    tensors in one launch + one ordered final sum)."""
     lib = L.load()
-    ws = acc = None
+    gs = []
     for g in grads.values():
         if not g.is_cuda or g.dtype != torch.float32:
             raise RuntimeError("agile3d_amd.optim runs on the GPU only (fp32 CUDA tensors)")
-        g = g.contiguous()
-        if ws is None:
-            ws = torch.empty(lib.a3d_sum_squares_workspace_bytes(), dtype=torch.uint8, device=g.device)
-            acc = torch.zeros(1, dtype=torch.float64, device=g.device)
-        L.check(lib.a3d_sum_squares_accumulate(_ptr(g), g.numel(), _ptr(acc), _ptr(ws), ws.numel(), _stream(g)),
-                "a3d_sum_squares_accumulate")
-    total = float(acc.item()) if acc is not None else 0.0      # the one host synchronisation of the clip
-    return math.sqrt(total)
+        if g.numel():
+            gs.append(g.contiguous())
+    if not gs:
+        return 0.0
+    dev = gs[0].device
+    tab, nchunks = _mt_table([(None, g, None, None, g.numel(), 1.0, 1.0) for g in gs], dev)
+    ws = torch.empty(lib.a3d_mt_workspace_bytes(nchunks), dtype=torch.uint8, device=dev)
+    out = torch.empty(1, dtype=torch.float64, device=dev)
+    L.check(lib.a3d_sum_squares_multi(_ptr(tab), len(gs), nchunks, _ptr(out), _ptr(ws), ws.numel(), _stream(gs[0])),
+            "a3d_sum_squares_multi")
+    return math.sqrt(float(out.item()))      # the one host synchronisation of the clip
 
 
 def clip_grad_norm_(grads: dict, max_norm: float):
@@ -56,7 +81,7 @@ WEIGHT_EPOCH = [0]
 
 
 class AdamW:
-    """torch.optim.AdamW's update rule, one kernel launch per parameter tensor; state lives next to the parameters."""
+    """torch.optim.AdamW's update rule, ONE kernel launch for all parameter tensors; state lives next to the parameters."""
 
     def __init__(self, named_params, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2):
         self.params = dict(named_params)
@@ -69,6 +94,7 @@ class AdamW:
         lib = L.load()
         self.step_count += 1
         WEIGHT_EPOCH[0] += 1
+        entries, keep = [], []
         for name, g in grads.items():
             p = self.params[name]
             if not p.is_cuda or p.dtype != torch.float32 or not p.is_contiguous():
@@ -77,10 +103,19 @@ class AdamW:
             if st is None:
                 st = self.state[name] = (torch.zeros_like(p), torch.zeros_like(p))
             g = g.reshape(p.shape).contiguous()
+            keep.append(g)
             t = self.steps[name] = self.steps.get(name, 0) + 1     # bias correction counts THIS parameter's updates
-            L.check(lib.a3d_adamw_step(_ptr(p.data), _ptr(g), _ptr(st[0]), _ptr(st[1]), p.numel(), t,
-                                       self.lr, self.betas[0], self.betas[1], self.eps, self.weight_decay, grad_scale,
-                                       _stream(p)), "a3d_adamw_step")
+            # bias corrections in double on the host, like torch's scalar path
+            b1 = 1.0 - self.betas[0] ** t
+            b2 = 1.0 - self.betas[1] ** t
+            if p.numel():
+                entries.append((p.data, g, st[0], st[1], p.numel(), b1, math.sqrt(b2)))
+        if not entries:
+            return
+        dev = entries[0][0].device
+        tab, nchunks = _mt_table(entries, dev)
+        L.check(lib.a3d_adamw_step_multi(_ptr(tab), len(entries), nchunks, self.lr, self.betas[0], self.betas[1], self.eps,
+                                         self.weight_decay, grad_scale, _stream(entries[0][0])), "a3d_adamw_step_multi")
 
 
 def dist_all_reduce(t, group=None):

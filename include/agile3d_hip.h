@@ -297,6 +297,26 @@ int    a3d_adamw_step(float* param_dev, const float* grad_dev, float* exp_avg_de
                       int step, float lr, float beta1, float beta2, float eps, float weight_decay, float grad_scale,
                       void* stream);
 
+/* The same two operations over ALL parameter tensors in one launch each (a training step updates 268 tensors).  The
+ * caller uploads a table of a3d_mt_tensor entries, one per tensor in any fixed order: chunk0 = number of
+ * A3D_MT_CHUNK-element chunks of the tensors before it, bias1 = 1 - beta1^step, bias2_sqrt = sqrt(1 - beta2^step) of
+ * THAT tensor's step count (torch.optim.AdamW's per-parameter state['step']).  a3d_sum_squares_multi writes
+ * sum over all tensors of sum g^2 to *out_dev (fp64, deterministic); a3d_adamw_step_multi = a3d_adamw_step on every
+ * entry (bit-identical results). */
+#define A3D_MT_CHUNK 4096
+typedef struct a3d_mt_tensor {
+  float* p; const float* g; float* m; float* v;
+  int64_t n;
+  int32_t chunk0;
+  float bias1, bias2_sqrt;
+  int32_t pad_;
+} a3d_mt_tensor;
+size_t a3d_mt_workspace_bytes(int64_t n_chunks);
+int    a3d_sum_squares_multi(const a3d_mt_tensor* table_dev, int n_tensors, int64_t n_chunks, double* out_dev,
+                             void* workspace_dev, size_t workspace_bytes, void* stream);
+int    a3d_adamw_step_multi(const a3d_mt_tensor* table_dev, int n_tensors, int64_t n_chunks, float lr, float beta1,
+                            float beta2, float eps, float weight_decay, float grad_scale, void* stream);
+
 /* Dense row-major GEMM: out[n][cout] = act(((in (+ in_add))[n][cin] @ W) * scale + shift + res).
  * Replaces the nn.Linear / in_proj pieces of nn.MultiheadAttention that run over all N points
  * (models/modules/attention_block.py:91-94; `in_add` is the position encoding the reference adds to
