@@ -125,8 +125,10 @@ struct QueryMeta {   // device-resident, uploaded once per forward_mask
 
 struct QueryBufs {   // all [QP][...] fp32 in global scratch
   float *queries, *qpos, *qproj, *ks, *vs, *E;
-  float *attn, *tmp, *tgt, *qk, *vc, *hidden;
+  float *attn, *tmp, *tgt, *qk, *vc, *hidden;   // hidden: FFN partial sums of the helper workgroups [kQlMaxHelpers][QP][128]
+  unsigned* sync;                                // [A3D_MAX_DEC_LAYERS][16] hand-off flags of k_query_layer (zeroed per pass)
 };
+constexpr int kQlMaxHelpers = 8;
 
 // ---- one batch sample as the query-side kernels see it (k_query_init, k_c2s_combine, k_query_layer: blockIdx.y)
 struct QuerySample {
@@ -1004,6 +1006,7 @@ struct QueryLayerW {
   const float *dn_w, *dn_b, *m_w0t, *m_b0, *m_w2t, *m_b2;
   const float *next_c2s_in_wt, *next_c2s_in_b;   // nullptr on the last layer
   int dim_ff;
+  int layer;
   unsigned long long* dbg;                       // A3D_DEC_DBG=2: s_memtime marks of workgroup (0, 0), else nullptr
 };
 
@@ -1230,7 +1233,11 @@ __global__ void __launch_bounds__(512) k_query_layer(const QuerySample* __restri
   constexpr int QP = QT * 16;
   const QueryMeta* meta = qs[blockIdx.y].meta;
   QueryBufs B = qs[blockIdx.y].B;
-  const int q0 = blockIdx.x * QP;
+  // PART 0 with gridDim.x > 1: workgroup 0 runs the layer, workgroups 1.. are FFN helpers (each takes the hidden chunks
+  // c = x, x + nh, ... of the 1024-wide FFN, whose 1 MB of weights is what one workgroup alone spends 44 % of the
+  // layer pulling through one CU); hand-off through global memory with coherent (agent-scope) loads / stores + flags
+  const int nh = PART == 0 ? (int)gridDim.x : 1, hx = PART == 0 ? (int)blockIdx.x : 0;
+  const int q0 = PART == 0 ? 0 : blockIdx.x * QP;
   const int Qall = meta->nq;
   const float* all_qk = B.qk;
   const float* all_vc = B.vc;
@@ -1250,6 +1257,78 @@ __global__ void __launch_bounds__(512) k_query_layer(const QuerySample* __restri
     if (W.dbg && tid == 0 && blockIdx.x == 0 && blockIdx.y == 0) W.dbg[i] = __builtin_amdgcn_s_memtime();
   };
   mark(0);
+
+  if constexpr (PART == 0) {
+    if (hx > 0) {   // ---- FFN helper
+      const int nchunk = W.dim_ff >> 7;
+      if (hx >= nchunk) return;
+      unsigned* flags = B.sync + W.layer * 16;
+      qload_w(W.ffn_w1t, D, hx * 128 + 16 * wave, 0, wfa);            // first chunk's weights while waiting
+      if (tid == 0) {
+        unsigned spins = 0;
+        while (__hip_atomic_load(flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+          __builtin_amdgcn_s_sleep(2);
+          if (++spins > (1u << 26)) break;                             // seconds: never in a healthy run
+        }
+      }
+      __syncthreads();
+      for (int e = tid; e < QP * 128; e += nt) {
+        const int q = e >> 7, c = e & 127;
+        cur[q * kQLD + c] = __hip_atomic_load(B.tgt + (size_t)q * D + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      __syncthreads();
+      f32x4 facc[QT];
+      qzero<QT>(facc);
+      for (int c = hx; c < nchunk; c += nh) {
+        qload_w(W.ffn_w2t, W.dim_ff, 16 * wave, c * 128, wfb);
+        qzero<QT>(acc);
+        qmm<QT>(cur, wfa, acc);
+        qstore<QT>(acc, W.ffn_b1, c * 128 + 16 * wave, 1.f, true, xb, kQLD, 16 * wave, QP);
+        if (c + nh < nchunk) qload_w(W.ffn_w1t, D, (c + nh) * 128 + 16 * wave, 0, wfa);
+        __syncthreads();
+        qmm<QT>(xb, wfb, facc);
+        __syncthreads();
+      }
+      {   // partial sums out, coherent stores, then the flag
+        const int lane = tid & 63, g = lane >> 4, j = lane & 15;
+        float* part = B.hidden + (size_t)hx * QP * D;
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt)
+#pragma unroll
+          for (int t = 0; t < 4; ++t)
+            __hip_atomic_store(part + (size_t)(qt * 16 + 4 * g + t) * D + 16 * wave + j, facc[qt][t], __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+      }
+      __builtin_amdgcn_s_waitcnt(0x0F70);
+      __syncthreads();
+      if (tid == 0) __hip_atomic_store(flags + hx, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      // ---- second job of helpers 1..3: one of the projections that depend only on the layer's new queries
+      if (nh < 4 || nchunk < 4 || hx > 3 || (hx == 3 && !W.next_c2s_in_wt)) return;
+      const float* wsrc = hx == 1 ? W.s2c_in_wt + (size_t)D * D : hx == 2 ? W.s2c_in_wt + (size_t)2 * D * D : W.next_c2s_in_wt;
+      qload_w(wsrc, D, 16 * wave, 0, wfa);
+      if (tid == 0) {
+        unsigned spins = 0;
+        while (__hip_atomic_load(flags + 8, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+          __builtin_amdgcn_s_sleep(2);
+          if (++spins > (1u << 26)) break;
+        }
+      }
+      __syncthreads();
+      for (int e = tid; e < QP * 128; e += nt) {
+        const int q = e >> 7, c = e & 127;
+        float v = __hip_atomic_load(B.tgt + (size_t)q * D + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (hx != 2) v += q < Q ? B.qpos[(size_t)q * D + c] : 0.f;   // keys / next query projection take queries + qpos
+        xa[q * kQLD + c] = v;
+      }
+      __syncthreads();
+      qzero<QT>(acc);
+      qmm<QT>(xa, wfa, acc);
+      if (hx == 1) qstore<QT>(acc, W.s2c_in_b, D + 16 * wave, 0.25f, false, B.ks, D, 16 * wave, Q);        // keys pre-scaled
+      else if (hx == 2) qstore<QT>(acc, W.s2c_in_b, 2 * D + 16 * wave, 1.f, false, B.vs, D, 16 * wave, Q);
+      else qstore<QT>(acc, W.next_c2s_in_b, 16 * wave, 0.25f, false, B.qproj, D, 16 * wave, Q);
+      return;
+    }
+  }
 
   if constexpr (PART != 2) {
   // ---- load the layer inputs (queries, qpos, click-to-scene attention result) into LDS
@@ -1376,50 +1455,96 @@ __global__ void __launch_bounds__(512) k_query_layer(const QuerySample* __restri
   __syncthreads();
   qadd_ln(cur, xb, Q, W.c2c_norm_w, W.c2c_norm_b, cur, nullptr);
   __syncthreads();
+  if (PART == 0 && nh > 1) {   // hand tgt to the FFN helpers
+    for (int e = tid; e < QP * 128; e += nt) {
+      const int q = e >> 7, c = e & 127;
+      __hip_atomic_store(B.tgt + (size_t)q * D + c, cur[q * kQLD + c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    __syncthreads();
+    if (tid == 0) __hip_atomic_store(B.sync + W.layer * 16, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
   mark(5);
   // ---- 3. FFN (attention_block.py:151-155) in hidden chunks of 128: wave w computes hidden tile w of
   //         the chunk into xb, then accumulates output tile w over the chunk
   f32x4 facc[QT];
   qzero<QT>(facc);
   const int nchunk = W.dim_ff >> 7;
-  for (int c = 0; c < nchunk; ++c) {
+  for (int c = 0; c < nchunk; c += nh) {
     qload_w(W.ffn_w2t, W.dim_ff, 16 * wave, c * 128, wfb);          // linear2 rows (output cols), chunk cols
     qzero<QT>(acc);
     qmm<QT>(cur, wfa, acc);
     qstore<QT>(acc, W.ffn_b1, c * 128 + 16 * wave, 1.f, true, xb, kQLD, 16 * wave, QP);
-    if (c + 1 < nchunk) qload_w(W.ffn_w1t, D, (c + 1) * 128 + 16 * wave, 0, wfa);
+    if (c + nh < nchunk) qload_w(W.ffn_w1t, D, (c + nh) * 128 + 16 * wave, 0, wfa);
     __syncthreads();
     qmm<QT>(xb, wfb, facc);
     __syncthreads();
   }
+  if (PART == 0 && nh > 1) {   // the helpers' partial sums, in helper order
+    const int nhelp = min(nh, nchunk) - 1;
+    if (tid < nhelp) {
+      unsigned spins = 0;
+      while (__hip_atomic_load(B.sync + W.layer * 16 + 1 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+        __builtin_amdgcn_s_sleep(2);
+        if (++spins > (1u << 26)) break;
+      }
+    }
+    __syncthreads();
+    const int lane = tid & 63, g = lane >> 4, j = lane & 15;
+    for (int h = 1; h <= nhelp; ++h) {
+      const float* part = B.hidden + (size_t)h * QP * D;
+#pragma unroll
+      for (int qt = 0; qt < QT; ++qt)
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+          facc[qt][t] += __hip_atomic_load(part + (size_t)(qt * 16 + 4 * g + t) * D + 16 * wave + j, __ATOMIC_RELAXED,
+                                           __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
   mark(6);
   qstore<QT>(facc, W.ffn_b2, 16 * wave, 1.f, false, xa, kQLD, 16 * wave, QP);
-  qload_w(W.s2c_in_wt, D, D + 16 * wave, 0, wfa);                   // s2c k rows
-  qload_w(W.s2c_in_wt, D, 2 * D + 16 * wave, 0, wfb);               // s2c v rows
+  const bool deleg = PART == 0 && nh >= 4 && nchunk >= 4;           // helpers 1..3 take the s2c keys / values / next qproj
+  if (!deleg) {
+    qload_w(W.s2c_in_wt, D, D + 16 * wave, 0, wfa);                 // s2c k rows
+    qload_w(W.s2c_in_wt, D, 2 * D + 16 * wave, 0, wfb);             // s2c v rows
+  } else {
+    qload_w(W.m_w0t, D, 16 * wave, 0, wfa);
+  }
   __syncthreads();
   qadd_ln(cur, xa, Q, W.ffn_norm_w, W.ffn_norm_b, cur, B.queries);   // cur = queries (also to global)
   __syncthreads();
+  if (deleg) {
+    for (int e = tid; e < QP * 128; e += nt) {
+      const int q = e >> 7, c = e & 127;
+      __hip_atomic_store(B.tgt + (size_t)q * D + c, cur[q * kQLD + c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    __syncthreads();
+    if (tid == 0) __hip_atomic_store(B.sync + W.layer * 16 + 8, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
   mark(7);
   // ---- 4. everything that depends only on the new queries: s2c keys/values, mask MLP layer 0, next
   //         iteration's c2s query projection
   qadd_ln(cur, nullptr, Q, W.dn_w, W.dn_b, xb, nullptr);             // decoder_norm(queries)
-  for (int e = tid; e < QP * 128; e += nt) {
-    const int q = e >> 7, c = e & 127;
-    xa[q * kQLD + c] = cur[q * kQLD + c] + qpos[q * kQLD + c];
-  }
-  __syncthreads();
-  qzero<QT>(acc);
-  qmm<QT>(xa, wfa, acc);
-  qstore<QT>(acc, W.s2c_in_b, D + 16 * wave, 0.25f, false, B.ks, D, 16 * wave, Q);   // keys pre-scaled
-  qload_w(W.m_w0t, D, 16 * wave, 0, wfa);
-  qzero<QT>(acc);
-  qmm<QT>(cur, wfb, acc);
-  qstore<QT>(acc, W.s2c_in_b, 2 * D + 16 * wave, 1.f, false, B.vs, D, 16 * wave, Q);
-  if (W.next_c2s_in_wt) {
-    qload_w(W.next_c2s_in_wt, D, 16 * wave, 0, wfb);
+  if (!deleg) {
+    for (int e = tid; e < QP * 128; e += nt) {
+      const int q = e >> 7, c = e & 127;
+      xa[q * kQLD + c] = cur[q * kQLD + c] + qpos[q * kQLD + c];
+    }
+    __syncthreads();
     qzero<QT>(acc);
-    qmm<QT>(xa, wfb, acc);
-    qstore<QT>(acc, W.next_c2s_in_b, 16 * wave, 0.25f, false, B.qproj, D, 16 * wave, Q);
+    qmm<QT>(xa, wfa, acc);
+    qstore<QT>(acc, W.s2c_in_b, D + 16 * wave, 0.25f, false, B.ks, D, 16 * wave, Q);   // keys pre-scaled
+    qload_w(W.m_w0t, D, 16 * wave, 0, wfa);
+    qzero<QT>(acc);
+    qmm<QT>(cur, wfb, acc);
+    qstore<QT>(acc, W.s2c_in_b, 2 * D + 16 * wave, 1.f, false, B.vs, D, 16 * wave, Q);
+    if (W.next_c2s_in_wt) {
+      qload_w(W.next_c2s_in_wt, D, 16 * wave, 0, wfb);
+      qzero<QT>(acc);
+      qmm<QT>(xa, wfb, acc);
+      qstore<QT>(acc, W.next_c2s_in_b, 16 * wave, 0.25f, false, B.qproj, D, 16 * wave, Q);
+    }
   }
   __syncthreads();                                                   // everyone is done reading xa / qpos
   qzero<QT>(acc);
@@ -1471,7 +1596,7 @@ static int check_weights(const a3d_decoder_weights* w) {
 
 namespace {
 struct DecLayout {
-  size_t buf[4], labels, counts, part, meta, desc, q[12], total;
+  size_t buf[4], labels, counts, part, meta, desc, q[12], sync, total;
   int qp, nchunk;
 };
 int round_qp(int nq) { return nq <= 16 ? 16 : nq <= 32 ? 32 : nq <= 48 ? 48 : (nq + 63) / 64 * 64; }
@@ -1494,7 +1619,8 @@ void dec_layout(int64_t n, int nq, DecLayout& L) {
   for (int i = 0; i < 9; ++i) L.q[i] = take(qb);        // queries qpos qproj ks vs E attn tmp tgt
   L.q[9] = take(2 * qb);                                // qk
   L.q[10] = take(qb);                                   // vc
-  L.q[11] = take((size_t)L.qp * 4096 * 4);              // hidden (dim_ff <= 4096)
+  L.q[11] = take((size_t)L.qp * 4096 * 4);              // hidden: kQlMaxHelpers x [qp][128] FFN partial sums fit (dim_ff <= 4096)
+  L.sync = take((size_t)kMaxBatchSamples * A3D_MAX_DEC_LAYERS * 16 * 4);   // k_query_layer flags of a batched call (first sample's workspace)
   L.total = off;
 }
 }  // namespace
@@ -1655,8 +1781,11 @@ static int run_decoder(const a3d_decoder_weights* w, Prepared* P, int ns, hipStr
     // pageable source: the runtime stages it before returning (like the QueryMeta copies above)
     A3D_HIP_CHECK(hipMemcpyAsync(samples_dev, hd, sizeof(DecSampleDev) * ns, hipMemcpyHostToDevice, st));
     QuerySample hq[kMaxBatchSamples];
+    unsigned* sync0 = (unsigned*)(P[0].ws + P[0].L.sync);
+    A3D_HIP_CHECK(hipMemsetAsync(sync0, 0, (size_t)ns * A3D_MAX_DEC_LAYERS * 16 * 4, st));
     for (int si = 0; si < ns; ++si) {
       Prepared& p = P[si];
+      p.B.sync = sync0 + (size_t)si * A3D_MAX_DEC_LAYERS * 16;
       hq[si].meta = p.meta;
       hq[si].B = p.B;
       hq[si].feats = p.feats;
@@ -1713,6 +1842,7 @@ static int run_decoder(const a3d_decoder_weights* w, Prepared* P, int ns, hipStr
     QW.next_c2s_in_wt = l + 1 < w->n_layers ? w->layers[l + 1].c2s_in_w : nullptr;
     QW.next_c2s_in_b = l + 1 < w->n_layers ? w->layers[l + 1].c2s_in_b : nullptr;
     QW.dim_ff = w->dim_ff;
+    QW.layer = l;
     QW.dbg = nullptr;
     {
       static int dbg_on = -1;
@@ -1729,7 +1859,14 @@ static int run_decoder(const a3d_decoder_weights* w, Prepared* P, int ns, hipStr
       k_c2s_combine<<<dim3(nq_max * H, ns), 64, 0, st>>>(qs_dev, P[0].L.qp);
       const size_t ql_lds = (size_t)4 * QP * kQLD * 4;
       if (nblk == 1) {
-        k_query_layer<QT, 0><<<dim3(1, ns), 512, ql_lds, st>>>(qs_dev, QW);
+        // FFN helper workgroups next to the layer's workgroup (A3D_QL_HELPERS = total workgroups per sample, 1 = none)
+        static int nh_env = -1;
+        if (nh_env < 0) {
+          const char* e = getenv("A3D_QL_HELPERS");
+          nh_env = e ? atoi(e) : kQlMaxHelpers;
+          nh_env = nh_env < 1 ? 1 : nh_env > kQlMaxHelpers ? kQlMaxHelpers : nh_env;
+        }
+        k_query_layer<QT, 0><<<dim3(nh_env, ns), 512, ql_lds, st>>>(qs_dev, QW);
       } else {
         k_query_layer<QT, 1><<<dim3(nblk, ns), 512, ql_lds, st>>>(qs_dev, QW);
         k_query_layer<QT, 2><<<dim3(nblk, ns), 512, ql_lds, st>>>(qs_dev, QW);
