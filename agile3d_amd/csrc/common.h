@@ -63,6 +63,11 @@ size_t radix_sort_temp_bytes(int n_max);
 int radix_sort_pairs(void* temp, size_t temp_bytes, const uint64_t* keys_in, uint64_t* keys_out, const int* vals_in,
                      int* vals_out, int n, const RadixPass* passes, int npass, hipStream_t st);
 
+// a_incl = inclusive prefix sums of a, b_excl = exclusive prefix sums of b (radix.hip; in place allowed)
+size_t scan2_temp_bytes(int64_t n);
+int scan2_incl_excl(void* temp, size_t temp_bytes, const int* a, const int* b, int64_t n, int* a_incl, int* b_excl,
+                    hipStream_t st);
+
 // ---- geometry constants -------------------------------------------------------------------
 constexpr int kTileRows = 128;   // output rows per conv workgroup
 constexpr int kGroupRows = 16;   // MFMA row granularity (v_mfma_f32_16x16x4_f32)

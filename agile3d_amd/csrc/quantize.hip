@@ -8,10 +8,9 @@
 //   unique_map  = that first point of every voxel;  inverse_map[i] = voxel row of point i
 //
 // Integer work, bit-exact by construction: 63-bit packed keys -> stable radix sort of (key, point) pairs
-// (rocPRIM) -> run heads; the first element of a run is the smallest point index of the voxel; a scan of
+// (radix.hip) -> run heads; the first element of a run is the smallest point index of the voxel; a scan of
 // "is a voxel's first point" flags IN POINT ORDER numbers the voxels by first occurrence without a second sort.
 #include "common.h"
-#include <rocprim/rocprim.hpp>
 
 namespace a3d {
 
@@ -93,10 +92,7 @@ static QuantWs carve_quant(void* base, int64_t n) {
   w.seg = (int*)take((size_t)n * 4);
   w.rank = (int*)take((size_t)n * 4);
   w.run_voxel = (int*)take((size_t)n * 4);
-  size_t t1 = 0, t2 = 0;
-  (void)rocprim::radix_sort_pairs(nullptr, t1, (uint64_t*)nullptr, (uint64_t*)nullptr, (int*)nullptr, (int*)nullptr,
-                                  (size_t)n, 0, 63);
-  (void)rocprim::inclusive_scan(nullptr, t2, (int*)nullptr, (int*)nullptr, (size_t)n, rocprim::plus<int>());
+  const size_t t1 = radix_sort_temp_bytes((int)n), t2 = scan2_temp_bytes(n);
   w.temp_bytes = (t1 > t2 ? t1 : t2) + 1024;
   w.temp = take(w.temp_bytes);
   w.bytes = off;
@@ -111,14 +107,18 @@ static int run_quantize(const T* xyz, int64_t n, double qs, int32_t* coords_out,
   A3D_HIP_CHECK(hipMemsetAsync(w.first, 0, (size_t)n * 4, st));
   k_quant_keys<T><<<nb, 256, 0, st>>>(xyz, n, (T)qs, w.keys_in, w.vals_in, w.flags);
   A3D_LAUNCH_CHECK();
-  size_t tb = w.temp_bytes;
-  A3D_HIP_CHECK(rocprim::radix_sort_pairs(w.temp, tb, w.keys_in, w.keys, w.vals_in, w.vals, (size_t)n, 0, 63, st, false));
+  {
+    RadixPass ps[kRadixMaxPasses];
+    const int np = radix_passes(0, 63, ps);   // digits the cloud's extent does not touch are skipped on the device
+    const int rc = radix_sort_pairs(w.temp, w.temp_bytes, w.keys_in, w.keys, w.vals_in, w.vals, (int)n, ps, np, st);
+    if (rc) return rc;
+  }
   k_quant_heads<<<nb, 256, 0, st>>>(w.keys, w.vals, n, w.head, w.first);
   A3D_LAUNCH_CHECK();
-  tb = w.temp_bytes;
-  A3D_HIP_CHECK(rocprim::inclusive_scan(w.temp, tb, w.head, w.seg, (size_t)n, rocprim::plus<int>(), st, false));
-  tb = w.temp_bytes;
-  A3D_HIP_CHECK(rocprim::exclusive_scan(w.temp, tb, w.first, w.rank, 0, (size_t)n, rocprim::plus<int>(), st, false));
+  {
+    const int rc = scan2_incl_excl(w.temp, w.temp_bytes, w.head, w.first, n, w.seg, w.rank, st);
+    if (rc) return rc;
+  }
   k_quant_emit<<<nb, 256, 0, st>>>(w.keys, w.vals, w.head, w.seg, w.rank, n, w.run_voxel, coords_out, unique_map);
   k_quant_inverse<<<nb, 256, 0, st>>>(w.vals, w.seg, w.run_voxel, n, inverse_map);
   A3D_LAUNCH_CHECK();
@@ -139,7 +139,7 @@ static int run_quantize(const T* xyz, int64_t n, double qs, int32_t* coords_out,
 using namespace a3d;
 
 extern "C" size_t a3d_quantize_workspace_bytes(int64_t n_points) {
-  if (n_points <= 0 || n_points > (int64_t)1 << 30) return 0;
+  if (n_points <= 0 || n_points > (int64_t)1 << 28) return 0;
   return carve_quant(nullptr, n_points).bytes;
 }
 
@@ -147,7 +147,7 @@ extern "C" int a3d_sparse_quantize(const void* xyz_dev, int is_f64, int64_t n_po
                                    int32_t* coords_out_dev, int64_t* unique_map_dev, int64_t* inverse_map_dev,
                                    int64_t* n_voxels, void* workspace_dev, size_t workspace_bytes, void* stream) {
   if (!xyz_dev || !coords_out_dev || !unique_map_dev || !inverse_map_dev || !n_voxels || n_points <= 0 ||
-      n_points > (int64_t)1 << 30 || !(quantization_size > 0.0)) {
+      n_points > (int64_t)1 << 28 || !(quantization_size > 0.0)) {
     set_error("a3d_sparse_quantize: bad arguments");
     return A3D_ERR_INVALID;
   }

@@ -301,6 +301,105 @@ int radix_sort_pairs(void* temp, size_t temp_bytes, const uint64_t* keys_in, uin
   return A3D_OK;
 }
 
+// ---- prefix sums of two int arrays in one go (quantize.hip: run numbers of the sorted keys and voxel numbers in point
+// order): a inclusive, b exclusive.  Three launches: 4096-element block sums, one workgroup scans them, blocks re-scan.
+namespace {
+constexpr int kScanBlock = 4096, kScanThreads = 256, kScanPer = kScanBlock / kScanThreads;   // 16 per thread
+__device__ __forceinline__ int scan_wave_incl(int v, int lane) {
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int t = __shfl_up(v, o, 64);
+    if (lane >= o) v += t;
+  }
+  return v;
+}
+__global__ void __launch_bounds__(kScanThreads) k_scan2_sums(const int* __restrict__ a, const int* __restrict__ b, int64_t n,
+                                                             int* sums /*[2][nblocks]*/, int nblocks) {
+  __shared__ int red[2][4];
+  const int64_t base = (int64_t)blockIdx.x * kScanBlock;
+  int sa = 0, sb = 0;
+  for (int e = threadIdx.x; e < kScanBlock; e += kScanThreads)
+    if (base + e < n) sa += a[base + e], sb += b[base + e];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) sa += __shfl_xor(sa, o, 64), sb += __shfl_xor(sb, o, 64);
+  if ((threadIdx.x & 63) == 0) red[0][threadIdx.x >> 6] = sa, red[1][threadIdx.x >> 6] = sb;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    sums[blockIdx.x] = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+    sums[nblocks + blockIdx.x] = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+  }
+}
+__global__ void __launch_bounds__(1024) k_scan2_blocks(int* sums, int nblocks) {   // exclusive, in place; grid = 2
+  __shared__ int wsum[16];
+  __shared__ int carry;
+  int* s = sums + (size_t)blockIdx.x * nblocks;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  if (threadIdx.x == 0) carry = 0;
+  __syncthreads();
+  for (int i0 = 0; i0 < nblocks; i0 += 1024) {
+    const int i = i0 + threadIdx.x;
+    const int v = i < nblocks ? s[i] : 0;
+    const int inc = scan_wave_incl(v, lane);
+    if (lane == 63) wsum[w] = inc;
+    __syncthreads();
+    int wbase = 0;
+    for (int q = 0; q < w; ++q) wbase += wsum[q];
+    const int c = carry;
+    if (i < nblocks) s[i] = c + wbase + inc - v;
+    __syncthreads();
+    if (threadIdx.x == 1023) carry = c + wbase + inc;
+    __syncthreads();
+  }
+}
+__global__ void __launch_bounds__(kScanThreads) k_scan2_apply(const int* __restrict__ a, const int* __restrict__ b, int64_t n,
+                                                              const int* __restrict__ sums, int nblocks, int* a_incl,
+                                                              int* b_excl) {
+  __shared__ int wsum[2][4];
+  const int64_t base = (int64_t)blockIdx.x * kScanBlock + (int64_t)threadIdx.x * kScanPer;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  int va[kScanPer], vb[kScanPer], ta = 0, tb = 0;
+#pragma unroll
+  for (int e = 0; e < kScanPer; ++e) {
+    va[e] = base + e < n ? a[base + e] : 0;
+    vb[e] = base + e < n ? b[base + e] : 0;
+    ta += va[e];
+    tb += vb[e];
+  }
+  const int ia = scan_wave_incl(ta, lane), ib = scan_wave_incl(tb, lane);
+  if (lane == 63) wsum[0][w] = ia, wsum[1][w] = ib;
+  __syncthreads();
+  int oa = sums[blockIdx.x] + ia - ta, ob = sums[nblocks + blockIdx.x] + ib - tb;
+  for (int q = 0; q < w; ++q) oa += wsum[0][q], ob += wsum[1][q];
+#pragma unroll
+  for (int e = 0; e < kScanPer; ++e) {
+    oa += va[e];
+    if (base + e < n) {
+      a_incl[base + e] = oa;
+      b_excl[base + e] = ob;
+    }
+    ob += vb[e];
+  }
+}
+}  // namespace
+
+size_t scan2_temp_bytes(int64_t n) { return align256((size_t)2 * ((n + kScanBlock - 1) / kScanBlock) * sizeof(int)) + 256; }
+
+int scan2_incl_excl(void* temp, size_t temp_bytes, const int* a, const int* b, int64_t n, int* a_incl, int* b_excl,
+                    hipStream_t st) {
+  if (n <= 0) return A3D_OK;
+  if (!temp || temp_bytes < scan2_temp_bytes(n) || n > (int64_t)1 << 31) {
+    set_error("scan2: bad arguments");
+    return A3D_ERR_INVALID;
+  }
+  const int nblocks = (int)((n + kScanBlock - 1) / kScanBlock);
+  int* sums = (int*)temp;
+  k_scan2_sums<<<nblocks, kScanThreads, 0, st>>>(a, b, n, sums, nblocks);
+  k_scan2_blocks<<<2, 1024, 0, st>>>(sums, nblocks);
+  k_scan2_apply<<<nblocks, kScanThreads, 0, st>>>(a, b, n, sums, nblocks, a_incl, b_excl);
+  A3D_LAUNCH_CHECK();
+  return A3D_OK;
+}
+
 }  // namespace a3d
 
 // Test / utility entry: stable sort of (key, value) pairs by the key bits [bit_begin, bit_end), ascending.
