@@ -279,7 +279,8 @@ __global__ void __launch_bounds__(256, PAIR ? ((BN <= 96 && CH <= 32) ? 4 : 3) :
             for (int Sx = 0; Sx < NS; ++Sx) A[r][Sx] = *(const f32x4*)(ar + roff + 64 * Sx);
           }
         }
-        const float* wst = wbase + ((size_t)kk * cin16 + (size_t)cc * NS) * cout16 * 256;
+        const float* wst = (DBG && (a.dbg & 64)) ? wbase   // ablation: every stage reads the same (cache-hot) weight slice
+                                                : wbase + ((size_t)kk * cin16 + (size_t)cc * NS) * cout16 * 256;
         const unsigned dst = ring_addr + (unsigned)slot * (WF * 4u);
 #pragma unroll
         for (int i = 0; i < WV; ++i)
