@@ -610,34 +610,51 @@ static int launch_dense(const float* X, int ldx, const float* X2, int ldx2, int 
 // 5^3 (or 3^3) conv with Cin = 3 (res16unet.py:39-47,225-227; conv1_kernel_size main.py:37).
 // FLOPs are negligible (0.6 GF at 80 k voxels); the cost is 125 hash probes per voxel, so the
 // kernel map is never materialised: probe -> LDS table -> 3x32 FMAs per existing neighbour.
-template <int NT>   // threads per 64-voxel workgroup: NT / 64 threads share a voxel, 32 * 64 / NT output channels each
+template <int NT, int KS>   // threads per 64-voxel workgroup: NT / 64 threads share a voxel, 32 * 64 / NT output channels each;
+                            // KS: kernel size (compile-time: the index arithmetic of the 125 lookups is divisions by it)
 __global__ void __launch_bounds__(NT) k_stem(const int32_t* __restrict__ xyzb, int n,
                                               const uint64_t* __restrict__ hk, const int* __restrict__ hv,
                                               uint32_t hmask, const f32x4* __restrict__ feats4,
-                                              const float* __restrict__ w, int ks,
+                                              const float* __restrict__ w, int /*ks*/,
                                               const float* __restrict__ scale, const float* __restrict__ shift,
                                               int relu, float* out, int ldo, int zero_row, const Level glv) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int K = ks * ks * ks;
+  constexpr int ks = KS, K = KS * KS * KS;
   float* W = (float*)smem;              // [K][3][32]
   int* nb = (int*)(W + K * 96);         // [64][K]
   const int tid = threadIdx.x;
   for (int e = tid; e < K * 96; e += NT) W[e] = w[e];
   const int v0 = blockIdx.x * 64;
   const int h = ks / 2;
-  if (glv.grid) {
-    // dense level-0 grid (scene.hip): one 4-byte load per neighbour, x fastest -> the ks lanes of one (y, z) offset
-    // read consecutive cells; eight lookups in flight per thread
+  constexpr int TPV = NT / 64, CPT = 32 / TPV;
+  constexpr int SEG = (K + TPV - 1) / TPV;   // neighbour entries per thread
+  const int v = tid / TPV, cg = tid % TPV;
+  const int row = v0 + v;
+  int mine[SEG];
+  const bool fused = glv.grid && n < (1 << 25);
+  if (fused) {
+    // dense level-0 grid (scene.hip): one 4-byte load per neighbour; the TPV threads of a voxel look up SEG consecutive
+    // offsets each (x fastest: runs of ks consecutive cells), all of a thread's lookups in flight, results kept in registers
+    int4 c = (int4){0, 0, 0, 0};
+    if (row < n) c = *(const int4*)(xyzb + 4 * row);
+#pragma unroll
+    for (int u = 0; u < SEG; ++u) {
+      const int k = cg * SEG + u;
+      mine[u] = -1;
+      if (k < K && row < n)
+        mine[u] = glv.grid[grid_cell(glv, c.w, c.x + (k % ks) - h, c.y + ((k / ks) % ks) - h, c.z + (k / (ks * ks)) - h)];
+    }
+  } else if (glv.grid) {
     for (int e0 = tid; e0 < 64 * K; e0 += 8 * NT) {
       int res[8];
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
         const int e = e0 + u * NT;
-        const int v = e / K, k = e - v * K;
-        const int row = v0 + v;
+        const int vv = e / K, k = e - vv * K;
+        const int rr = v0 + vv;
         res[u] = -1;
-        if (e < 64 * K && row < n) {
-          const int4 c = *(const int4*)(xyzb + 4 * row);
+        if (e < 64 * K && rr < n) {
+          const int4 c = *(const int4*)(xyzb + 4 * rr);
           res[u] = glv.grid[grid_cell(glv, c.w, c.x + (k % ks) - h, c.y + ((k / ks) % ks) - h, c.z + (k / (ks * ks)) - h)];
         }
       }
@@ -699,12 +716,50 @@ __global__ void __launch_bounds__(NT) k_stem(const int32_t* __restrict__ xyzb, i
       if (e0 + u * NT < 64 * K) nb[e0 + u * NT] = res[u];
   }
   __syncthreads();
-  constexpr int TPV = NT / 64, CPT = 32 / TPV;
-  const int v = tid / TPV, cg = tid % TPV;
-  const int row = v0 + v;
   float acc[CPT];
 #pragma unroll
   for (int c = 0; c < CPT; ++c) acc[c] = 0.f;
+  if (n < (1 << 25)) {
+    // a surface voxel has ~40 of its 125 neighbours: the TPV threads of a voxel compact its list (ascending k, so the
+    // sums keep their order), k packed above the row; then EIGHT gathers in flight per thread over the present
+    // neighbours only (was: five in flight over all 125, 25 dependent rounds per workgroup)
+    constexpr int seg = SEG;
+    int cnt = 0;
+#pragma unroll
+    for (int u = 0; u < SEG; ++u) {
+      const int k = cg * seg + u;
+      if (!fused) mine[u] = k < K ? nb[v * K + k] : -1;
+      cnt += mine[u] >= 0 ? 1 : 0;
+    }
+    int incl = cnt;   // inclusive prefix over the TPV consecutive lanes of this voxel
+#pragma unroll
+    for (int o = 1; o < TPV; o <<= 1) {
+      const int t = __shfl_up(incl, o, 64);
+      if (cg >= o) incl += t;
+    }
+    const int total = __shfl(incl, (threadIdx.x & 63) | (TPV - 1), 64);
+    if (!fused) __syncthreads();   // every entry is in registers: the list can be overwritten
+    int pos = incl - cnt;
+#pragma unroll
+    for (int u = 0; u < SEG; ++u)
+      if (mine[u] >= 0) nb[v * K + pos++] = (int)((uint32_t)mine[u] | ((uint32_t)(cg * seg + u) << 25));
+    __syncthreads();
+    for (int i0 = 0; i0 < total; i0 += 8) {
+      uint32_t e[8];
+      f32x4 f[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) e[u] = i0 + u < total ? (uint32_t)nb[v * K + i0 + u] : 0u;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) f[u] = feats4[e[u] & 0x1ffffffu];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        if (i0 + u >= total) continue;
+        const float* wk = W + (e[u] >> 25) * 96 + cg * CPT;
+#pragma unroll
+        for (int c = 0; c < CPT; ++c) acc[c] += f[u][0] * wk[c] + f[u][1] * wk[32 + c] + f[u][2] * wk[64 + c];
+      }
+    }
+  } else
   // neighbour features: five gathers in flight per thread (missing neighbours read row 0 and are masked)
   for (int k0 = 0; k0 < K; k0 += 5) {
     int r[5];
@@ -1105,8 +1160,12 @@ extern "C" int a3d_program_run(const a3d_scene* s, const a3d_buf_desc* bufs, int
       // 8 waves per 64-voxel workgroup (measured: 4 waves 229 us, 8 waves 164 us, 16 waves 159 us)
       Level glv = lv;
       if (ks / 2 > kGridPad) glv.grid = nullptr;   // the grid's empty border covers 5^3 neighbourhoods
-      k_stem<512><<<(lv.n + 63) / 64, 512, lds, st>>>(lv.xyzb, lv.n, lv.hkeys, lv.hvals, lv.hmask, feats4, o.w_dev, ks,
-                                                o.scale_dev, o.shift_dev, o.relu, out, ldo, zero_row, glv);
+      if (ks == 5)
+        k_stem<512, 5><<<(lv.n + 63) / 64, 512, lds, st>>>(lv.xyzb, lv.n, lv.hkeys, lv.hvals, lv.hmask, feats4, o.w_dev, ks,
+                                                           o.scale_dev, o.shift_dev, o.relu, out, ldo, zero_row, glv);
+      else
+        k_stem<512, 3><<<(lv.n + 63) / 64, 512, lds, st>>>(lv.xyzb, lv.n, lv.hkeys, lv.hvals, lv.hmask, feats4, o.w_dev, ks,
+                                                           o.scale_dev, o.shift_dev, o.relu, out, ldo, zero_row, glv);
       A3D_LAUNCH_CHECK();
       continue;
     }
