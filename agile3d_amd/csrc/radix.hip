@@ -198,8 +198,10 @@ __global__ void __launch_bounds__(kRsThreads) k_rs_pass(const RsArgs a, int p) {
 #pragma unroll
       for (int u = 0; u < kLook; ++u) {
         if (done) break;
+        unsigned spins = 0;
         while ((x[u] & (kFlagAgg | kFlagInc)) == 0u) {
           __builtin_amdgcn_s_sleep(1);
+          if (++spins > (1u << 26)) break;   // seconds: never in a healthy run (every workgroup publishes before it looks back); do not hang the device
           x[u] = __hip_atomic_load(a.status + ((size_t)p * a.nblocks + (pb - u)) * 256 + d, __ATOMIC_RELAXED,
                                    __HIP_MEMORY_SCOPE_AGENT);
         }

@@ -324,7 +324,9 @@ def main():
     if numa is not None:
         res["config"]["launch_thread_numa_node"] = numa
 
-    if rank == 0 and world == 1:
+    if rank == 0:
+        # (N = 1: everything below; N > 1: rank 0 still measures the roofline object of its own GPU while the other
+        # ranks wait at the closing barrier -- the line of every N carries it; latency / phase / CPU passes are N = 1 only)
         # SURVEY 8(d) latency configuration: batch 1, one stream, every scene timed on its own (device sync on
         # both sides), median of 50 after 10 warm-ups -- the interactive product's operating point
         c1, f1, w1 = coords[:n0].contiguous(), feats[:n0].contiguous(), raw[:n0].contiguous()
@@ -333,7 +335,7 @@ def main():
             r = model.forward_backbone(SparseTensor(features=f1, coordinates=c1), raw_coordinates=w1)
             return model.forward_mask(*r, click_idx=[ci], click_time_idx=[ct])
         lat = []
-        for i in range(0 if args.steps_only else 60):
+        for i in range(0 if (args.steps_only or world > 1) else 60):
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             single()
@@ -396,7 +398,7 @@ def main():
             step_gf = (conv_only + dec_flops) / 1e9
             res["pipeline_algorithmic_gflop_per_step"] = round(step_gf, 1)
             res["pipeline_frac"] = round(step_gf / res["ms_per_step"] / PEAK_FP32_MFMA_TFLOPS, 4)   # GF / ms = TF/s
-        if not args.no_profile and not args.steps_only:
+        if not args.no_profile and not args.steps_only and world == 1:
             # the three phases on their own (one step at a time, one stream, wall clock with a device
             # sync around each) and the eval loop's number, decoder passes/s (backbone results reused per round)
             def wall(fn, reps=10):
@@ -447,7 +449,7 @@ def main():
                 if rnd >= 4:
                     rounds.append(1e3 * (time.perf_counter() - t0))
             res["eval_round_ms"] = round(float(np.median(rounds)), 4)
-        if not args.no_cpu_baseline and not args.steps_only:
+        if not args.no_cpu_baseline and not args.steps_only and world == 1:
             res["cpu_baseline"], diff = cpu_baseline(sd, sc, ci, ct, gpu_logits0, gpu_feats0)
             res["parity_vs_oracle"] = diff
             res["max_abs_diff"] = diff["logits_max_abs_diff"] if diff else None
