@@ -45,7 +45,9 @@ static inline size_t align256(size_t x) { return (x + 255) & ~size_t(255); }
 // ---- radix sort of (uint64 key, int32 value) pairs (radix.hip) ------------------------------
 constexpr int kRadixMaxPasses = 8;
 struct RadixPass {
-  int shift, bits;   // digit = (key >> shift) & ((1 << bits) - 1), bits <= 8
+  int shift, bits;          // digit = (key >> shift) & ((1 << bits) - 1), bits <= 8 ...
+  int shift2 = 0, bits2 = 0;   // ... | ((key >> shift2) & ((1 << bits2) - 1)) << bits: a second, more significant field
+                               // (bits + bits2 <= 8): two narrow fields of the key sorted in ONE pass
 };
 // digits covering key bits [bit_begin, bit_end), least significant first; returns their number (<= kRadixMaxPasses)
 static inline int radix_passes(int bit_begin, int bit_end, RadixPass* out, int n_before = 0) {
@@ -53,6 +55,7 @@ static inline int radix_passes(int bit_begin, int bit_end, RadixPass* out, int n
   for (int b = bit_begin; b < bit_end && np < kRadixMaxPasses; b += 8) {
     out[np].shift = b;
     out[np].bits = bit_end - b < 8 ? bit_end - b : 8;
+    out[np].shift2 = out[np].bits2 = 0;
     ++np;
   }
   return np;
@@ -148,9 +151,6 @@ struct Level {
   int* pre27 = nullptr;         // [npad/64 + 1]
   int* pre_down = nullptr;      // [npad(level+1)/64 + 1]   (levels 0..3)
   int* pre_up = nullptr;        // [npad/64 + 1]            (levels 0..3)
-  int* pre27b = nullptr;        // the same three over 128-row tiles: [npad/128 + 1], [npad(level+1)/128 + 1], [npad/128 + 1]
-  int* pre_downb = nullptr;
-  int* pre_upb = nullptr;
   int* child8 = nullptr;        // [8][npad(level+1)]     (levels 0..3)
   uint32_t* gmask_down = nullptr;
   int* up8 = nullptr;           // [8][npad]              (levels 0..3)

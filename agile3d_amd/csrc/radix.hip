@@ -35,14 +35,16 @@ struct RsArgs {
   uint64_t *keys_out, *keys_tmp;
   int *vals_out, *vals_tmp;
   int n, npass, nblocks;
-  int shift[kRadixMaxPasses], bits[kRadixMaxPasses];
+  int shift[kRadixMaxPasses], bits[kRadixMaxPasses], shift2[kRadixMaxPasses], bits2[kRadixMaxPasses];
   uint32_t* ghist;     // [npass][256]  counts, then exclusive starts
   RsPlanDev* plan;
   int* tickets;        // [npass]
   uint32_t* status;    // [npass][nblocks][256]  look-back words
 };
 
-__device__ __forceinline__ int rs_digit(uint64_t k, int shift, int bits) { return (int)((k >> shift) & ((1u << bits) - 1u)); }
+__device__ __forceinline__ int rs_digit(uint64_t k, int shift, int bits, int shift2, int bits2) {
+  return (int)(((k >> shift) & ((1u << bits) - 1u)) | (((k >> shift2) & ((1u << bits2) - 1u)) << bits));
+}
 
 // every digit's histogram in one sweep
 __global__ void __launch_bounds__(kRsThreads) k_rs_hist(const RsArgs a) {
@@ -51,7 +53,7 @@ __global__ void __launch_bounds__(kRsThreads) k_rs_hist(const RsArgs a) {
   __syncthreads();
   for (int i = blockIdx.x * kRsThreads + threadIdx.x; i < a.n; i += gridDim.x * kRsThreads) {
     const uint64_t k = a.keys_in[i];
-    for (int p = 0; p < a.npass; ++p) atomicAdd(&h[p * 256 + rs_digit(k, a.shift[p], a.bits[p])], 1u);
+    for (int p = 0; p < a.npass; ++p) atomicAdd(&h[p * 256 + rs_digit(k, a.shift[p], a.bits[p], a.shift2[p], a.bits2[p])], 1u);
   }
   __syncthreads();
   for (int i = threadIdx.x; i < a.npass * 256; i += kRsThreads)
@@ -109,7 +111,7 @@ __global__ void __launch_bounds__(kRsThreads) k_rs_pass(const RsArgs a, int p) {
   __shared__ int gpos[256];            // global position of slot 0 of a digit, minus lstart
   __shared__ int misc[8];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  const int shift = a.shift[p], bits = a.bits[p];
+  const int shift = a.shift[p], bits = a.bits[p], shift2 = a.shift2[p], bits2 = a.bits2[p];
   const int s = a.plan->src[p], t = a.plan->dst[p];
   const uint64_t* kin = s == 0 ? a.keys_in : (s == 1 ? a.keys_out : a.keys_tmp);
   const int* vin = s == 0 ? a.vals_in : (s == 1 ? a.vals_out : a.vals_tmp);
@@ -138,11 +140,11 @@ __global__ void __launch_bounds__(kRsThreads) k_rs_pass(const RsArgs a, int p) {
   for (int r = 0; r < kRsKeysPerThread; ++r) {
     const int li = w * (kRsBlockKeys / 4) + r * 64 + lane;
     const bool ok = li < cnt;
-    const int d = rs_digit(key[r], shift, bits);
+    const int d = rs_digit(key[r], shift, bits, shift2, bits2);
     unsigned long long peers = __ballot(ok);
 #pragma unroll
     for (int bit = 0; bit < 8; ++bit) {
-      if (bit < bits) {   // uniform
+      if (bit < bits + bits2) {   // uniform
         const unsigned long long bal = __ballot((d >> bit) & 1);
         peers &= ((d >> bit) & 1) ? bal : ~bal;
       }
@@ -220,7 +222,7 @@ __global__ void __launch_bounds__(kRsThreads) k_rs_pass(const RsArgs a, int p) {
   for (int r = 0; r < kRsKeysPerThread; ++r) {
     const int li = w * (kRsBlockKeys / 4) + r * 64 + lane;
     if (li < cnt) {
-      const int d = rs_digit(key[r], shift, bits);
+      const int d = rs_digit(key[r], shift, bits, shift2, bits2);
       const int slot = lstart[d] + (int)whist[w][d] + rank[r];
       skeys[slot] = key[r];
       svals[slot] = val[r];
@@ -232,7 +234,7 @@ __global__ void __launch_bounds__(kRsThreads) k_rs_pass(const RsArgs a, int p) {
     const int slot = r * kRsThreads + tid;
     if (slot < cnt) {
       const uint64_t k = skeys[slot];
-      const int dst = gpos[rs_digit(k, shift, bits)] + slot;
+      const int dst = gpos[rs_digit(k, shift, bits, shift2, bits2)] + slot;
       kout[dst] = k;
       vout[dst] = svals[slot];
     }
@@ -272,12 +274,15 @@ int radix_sort_pairs(void* temp, size_t temp_bytes, const uint64_t* keys_in, uin
   a.npass = npass;
   a.nblocks = rs_blocks(n);
   for (int p = 0; p < npass; ++p) {
-    if (passes[p].bits < 1 || passes[p].bits > 8 || passes[p].shift < 0 || passes[p].shift + passes[p].bits > 64) {
+    if (passes[p].bits < 1 || passes[p].bits2 < 0 || passes[p].bits + passes[p].bits2 > 8 || passes[p].shift < 0 ||
+        passes[p].shift + passes[p].bits > 64 || passes[p].shift2 < 0 || passes[p].shift2 + passes[p].bits2 > 64) {
       set_error("radix_sort_pairs: digit %d (shift %d, %d bits)", p, passes[p].shift, passes[p].bits);
       return A3D_ERR_INVALID;
     }
     a.shift[p] = passes[p].shift;
     a.bits[p] = passes[p].bits;
+    a.shift2[p] = passes[p].shift2;
+    a.bits2[p] = passes[p].bits2;
   }
   char* c = (char*)temp;
   a.keys_tmp = (uint64_t*)c;

@@ -347,22 +347,22 @@ __global__ void k_remap_nbr(const LevelSet S) {
 }
 
 // pre[t] = number of (tile, offset) pairs of the tiles before tile t, for the three mask tables of a level
-// (blockIdx.y: 0 = 3^3, 1 = stride-2 down, 2 = transposed up) and two tile heights (blockIdx.z: 64 / 128 rows); one
-// workgroup per (level, table, height), serial over 1024-tile chunks (a 1 M-voxel level has 16 k tiles)
+// (blockIdx.y: 0 = 3^3, 1 = stride-2 down, 2 = transposed up) over 64-row tiles; one
+// workgroup per (level, table), serial over 1024-tile chunks (a 1 M-voxel level has 16 k tiles)
 __global__ void __launch_bounds__(1024) k_tile_prefix(const LevelSet S) {
   __shared__ int lds[17];
   __shared__ int carry;
   const Level& lv = S.lv[blockIdx.x];
-  const int gpt = blockIdx.z ? 8 : 4;   // 16-row groups per tile
+  const int gpt = 4;   // 16-row groups per 64-row tile
   const uint32_t* gmask;
   int* pre;
   int npad;
   if (blockIdx.y == 0) {
-    gmask = lv.gmask27, pre = blockIdx.z ? lv.pre27b : lv.pre27, npad = lv.npad;
+    gmask = lv.gmask27, pre = lv.pre27, npad = lv.npad;
   } else {
     if ((int)blockIdx.x >= A3D_NUM_LEVELS - 1) return;
-    if (blockIdx.y == 1) gmask = lv.gmask_down, pre = blockIdx.z ? lv.pre_downb : lv.pre_down, npad = S.lv[blockIdx.x + 1].npad;
-    else gmask = lv.gmask_up, pre = blockIdx.z ? lv.pre_upb : lv.pre_up, npad = lv.npad;
+    if (blockIdx.y == 1) gmask = lv.gmask_down, pre = lv.pre_down, npad = S.lv[blockIdx.x + 1].npad;
+    else gmask = lv.gmask_up, pre = lv.pre_up, npad = lv.npad;
   }
   const int ntile = npad / (16 * gpt);
   if (threadIdx.x == 0) carry = 0;
@@ -576,13 +576,10 @@ static void carve_phase2(Bump& b, const int* sizes, a3d_scene* sc, Phase2Tmp& t,
     lv.hvals = b.take<int>((size_t)lv.hmask + 1);
     lv.nbr27 = b.take<int>((size_t)27 * lv.npad);
     lv.pre27 = b.take<int>(lv.npad / 64 + 1);
-    lv.pre27b = b.take<int>(lv.npad / 128 + 1);
     if (L < A3D_NUM_LEVELS - 1) {
       const int npadC = sc->lv[L + 1].npad;
       lv.pre_down = b.take<int>(npadC / 64 + 1);
       lv.pre_up = b.take<int>(lv.npad / 64 + 1);
-      lv.pre_downb = b.take<int>(npadC / 128 + 1);
-      lv.pre_upb = b.take<int>(lv.npad / 128 + 1);
       lv.child8 = b.take<int>((size_t)8 * npadC);
       lv.up8 = b.take<int>((size_t)8 * lv.npad);
     }
@@ -797,6 +794,9 @@ extern "C" int a3d_scene_create(const int32_t* coords4_dev, int64_t n_voxels, vo
     int np;
     if (small_bits == 27) {
       np = radix_passes(0, S.level_shift + 3, ps);
+    } else if (small_bits + S.level_shift + 3 - 27 <= 8) {   // child slot + super tile + level fit one digit
+      ps[0].shift = 0, ps[0].bits = small_bits, ps[0].shift2 = 27, ps[0].bits2 = S.level_shift + 3 - 27;
+      np = 1;
     } else {
       np = radix_passes(0, small_bits, ps);
       np = radix_passes(27, S.level_shift + 3, ps, np);
@@ -843,7 +843,7 @@ extern "C" int a3d_scene_create(const int32_t* coords4_dev, int64_t n_voxels, vo
   k_up<<<g, T, 0, st>>>(S);
   A3D_LAUNCH_CHECK();
   k_orig_row<<<nblk(n0, T), T, 0, st>>>(p.vals_sorted, sc->lv[0].inv, n0, sc->orig_row);
-  k_tile_prefix<<<dim3(NL, 3, 2), 1024, 0, st>>>(S);   // all three mask tables are final here
+  k_tile_prefix<<<dim3(NL, 3), 1024, 0, st>>>(S);   // all three mask tables are final here
   A3D_LAUNCH_CHECK();
   *out = sc;
   return A3D_OK;

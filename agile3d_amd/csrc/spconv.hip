@@ -926,7 +926,7 @@ static void allow_big_lds() {
   (void)hipFuncSetAttribute((const void*)k_dense<6, 6>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 }
 
-static int launch_conv_sk(ConvArgs c, const int* pre64, const int* pre128, float* slab_ws, size_t slab_ws_floats, int* state,
+static int launch_conv_sk(ConvArgs c, const int* pre64, float* slab_ws, size_t slab_ws_floats, int* state,
                           hipStream_t st) {
   allow_big_lds();
   if (c.cin % 32 != 0 || c.cout % 16 != 0 || !(c.cout % 128 == 0 || c.cout == 32 || c.cout == 64 || c.cout == 96)) {
@@ -962,7 +962,6 @@ static int launch_conv_sk(ConvArgs c, const int* pre64, const int* pre128, float
   memset(&a, 0, sizeof(a));
   c.n_tiles = p.ntile;
   a.c = c;
-  (void)pre128;
   const int* pre = pre64;
   a.pre = c.K > 1 ? pre : nullptr;
   a.nchunk = p.nchunk;
@@ -1198,7 +1197,6 @@ extern "C" int a3d_program_run(const a3d_scene* s, const a3d_buf_desc* bufs, int
     a.tag_table = o.kind;
     a.tag_level = Lin;
     const int* pre = nullptr;
-    const int* pre128 = nullptr;
     switch (o.kind) {
       case A3D_OP_CONV3:
         if (o.kernel_volume != 27) { set_error("op %d: CONV3 needs kernel volume 27", i); return A3D_ERR_INVALID; }
@@ -1206,7 +1204,6 @@ extern "C" int a3d_program_run(const a3d_scene* s, const a3d_buf_desc* bufs, int
         a.nbr_stride = s->lv[Lin].npad;
         a.gmask = s->lv[Lin].gmask27;
         pre = s->lv[Lin].pre27;
-        pre128 = s->lv[Lin].pre27b;
         break;
       case A3D_OP_DOWN:
         if (o.kernel_volume != 8 || Lin >= A3D_NUM_LEVELS - 1) { set_error("op %d: bad DOWN", i); return A3D_ERR_INVALID; }
@@ -1214,7 +1211,6 @@ extern "C" int a3d_program_run(const a3d_scene* s, const a3d_buf_desc* bufs, int
         a.nbr_stride = s->lv[Lin + 1].npad;
         a.gmask = s->lv[Lin].gmask_down;
         pre = s->lv[Lin].pre_down;
-        pre128 = s->lv[Lin].pre_downb;
         break;
       case A3D_OP_UP:
         if (o.kernel_volume != 8 || Lin < 1) { set_error("op %d: bad UP", i); return A3D_ERR_INVALID; }
@@ -1223,7 +1219,6 @@ extern "C" int a3d_program_run(const a3d_scene* s, const a3d_buf_desc* bufs, int
         a.gmask = s->lv[Lin - 1].gmask_up;
         a.out_map = s->lv[Lin - 1].up_rows;
         pre = s->lv[Lin - 1].pre_up;
-        pre128 = s->lv[Lin - 1].pre_upb;
         break;
       case A3D_OP_LINEAR:
         if (o.kernel_volume != 1) { set_error("op %d: LINEAR needs kernel volume 1", i); return A3D_ERR_INVALID; }
@@ -1236,7 +1231,7 @@ extern "C" int a3d_program_run(const a3d_scene* s, const a3d_buf_desc* bufs, int
       rc = launch_dense(a.in, a.ldi, nullptr, 0, a.n_out, a.cin, a.cout, a.w, a.scale, a.shift, a.res, a.ldr, a.relu,
                         a.out, a.ldo, a.zero_row, Lin, a.out_map, st);
     else
-      rc = launch_conv_sk(a, pre, pre128, partial, L.partial_floats, queues + (size_t)i * kMaxQueuesPerOp, st);
+      rc = launch_conv_sk(a, pre, partial, L.partial_floats, queues + (size_t)i * kMaxQueuesPerOp, st);
     if (rc != A3D_OK) return rc;
   }
   return A3D_OK;
@@ -1291,7 +1286,6 @@ extern "C" int a3d_conv_apply(const a3d_scene* s, int kind, int level_in, const 
   a.tag_table = kind;
   a.tag_level = Lin;
   const int* pre = nullptr;
-  const int* pre128 = nullptr;
   switch (kind) {
     case A3D_OP_CONV3:
       a.K = 27;
@@ -1299,7 +1293,6 @@ extern "C" int a3d_conv_apply(const a3d_scene* s, int kind, int level_in, const 
       a.nbr_stride = s->lv[Lin].npad;
       a.gmask = s->lv[Lin].gmask27;
       pre = s->lv[Lin].pre27;
-      pre128 = s->lv[Lin].pre27b;
       break;
     case A3D_OP_DOWN:
       a.K = 8;
@@ -1307,7 +1300,6 @@ extern "C" int a3d_conv_apply(const a3d_scene* s, int kind, int level_in, const 
       a.nbr_stride = s->lv[Lin + 1].npad;
       a.gmask = s->lv[Lin].gmask_down;
       pre = s->lv[Lin].pre_down;
-      pre128 = s->lv[Lin].pre_downb;
       break;
     case A3D_OP_UP:
       a.K = 8;
@@ -1316,7 +1308,6 @@ extern "C" int a3d_conv_apply(const a3d_scene* s, int kind, int level_in, const 
       a.gmask = s->lv[Lin - 1].gmask_up;
       a.out_map = s->lv[Lin - 1].up_rows;
       pre = s->lv[Lin - 1].pre_up;
-      pre128 = s->lv[Lin - 1].pre_upb;
       break;
     case A3D_OP_LINEAR:
       a.K = 1;
@@ -1329,7 +1320,7 @@ extern "C" int a3d_conv_apply(const a3d_scene* s, int kind, int level_in, const 
   float* slab = (float*)((char*)workspace_dev + align256((size_t)kMaxQueuesPerOp * 4));
   const size_t slab_floats = (workspace_bytes - align256((size_t)kMaxQueuesPerOp * 4)) / 4;
   A3D_HIP_CHECK(hipMemsetAsync(state, 0, (size_t)kMaxQueuesPerOp * 4, st));
-  return launch_conv_sk(a, pre, pre128, slab, slab_floats, state, st);
+  return launch_conv_sk(a, pre, slab, slab_floats, state, st);
 }
 
 extern "C" int a3d_linear(const float* in_dev, int ldi, const float* in_add_dev, int ldi_add, int64_t n, int cin,
@@ -1369,5 +1360,5 @@ extern "C" int a3d_linear(const float* in_dev, int ldi, const float* in_add_dev,
   a.tag_level = -1;
   (void)workspace_dev;
   (void)workspace_bytes;   // a 1x1 layer runs whole tiles (no hand-off state)
-  return launch_conv_sk(a, nullptr, nullptr, nullptr, 0, nullptr, (hipStream_t)stream);
+  return launch_conv_sk(a, nullptr, nullptr, 0, nullptr, (hipStream_t)stream);
 }
