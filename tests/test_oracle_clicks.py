@@ -35,7 +35,8 @@ def test_cluster_table(name):
     want = G[f"{name}/clusters"]
     assert [c["cluster_id"] for c in got] == [int(v) for v in want[:, 0]]
     assert [c["row"] for c in got] == [int(v) for v in want[:, 1]]
-    assert np.array_equal(np.array([c["error_size"] for c in got]), want[:, 2])   # same torch.cdist: bit equal
+    # same torch.cdist formula; its last bit depends on the host CPU's vector width (the goldens were made on one machine)
+    assert np.allclose(np.array([c["error_size"] for c in got]), want[:, 2], rtol=2e-6, atol=1e-7)
 
 
 @pytest.mark.parametrize("name", NAMES)
@@ -71,7 +72,7 @@ def test_iou_extend_weights(name):
     want_t = unflat(G[f"{name}/extend/keys"], G[f"{name}/extend/lens"], G[f"{name}/extend/times"])
     assert c2 == want_c and t2 == want_t
     w = oc.click_loss_weights(xyz, c2)
-    assert np.array_equal(w.numpy(), G[f"{name}/weights"])
+    assert np.allclose(w.numpy(), G[f"{name}/weights"], rtol=2e-6, atol=1e-7)
 
 
 def test_no_error_returns_none():
