@@ -3,6 +3,8 @@
   * forward_mask vs the golden vectors captured from the REFERENCE's own forward_mask
     (tests/golden, |diff| <= 1e-3 as north_star states; the oracle itself is <= 1e-5);
   * size-independent properties at the benchmark size (80 k voxels)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -357,3 +359,42 @@ assert worst <= 1e-3
     res = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=600)
     assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
     assert "WORST" in res.stdout
+
+
+def test_query_chain_helper_workgroups_match_single_workgroup(tmp_path):
+    """The decoder's query-side layer with FFN / projection helper workgroups (default, A3D_QL_HELPERS=8) against the
+    single-workgroup chain (A3D_QL_HELPERS=1): the switch is read once per process, so each setting runs in its own
+    interpreter; the FFN's sum over hidden chunks is re-associated (eight partial sums), everything else is identical."""
+    import subprocess
+    import sys
+    script = r'''
+import sys, numpy as np, torch
+sys.path.insert(0, sys.argv[1])
+from agile3d_amd import SparseTensor, build_model, default_args, randomize_bn_stats
+from agile3d_amd.synthetic import make_clicks, make_scene
+torch.manual_seed(3)
+model = randomize_bn_stats(build_model(default_args())).eval().cuda()
+outs = []
+for n, objs, cpo in ((6000, 3, 2), (9000, 5, 4)):          # 16 and 30+ queries: two query-tile counts
+    sc = make_scene(n, seed=n)
+    ci, ct = make_clicks(sc["labels"], objs, cpo, 1, seed=1)
+    x = SparseTensor(features=torch.from_numpy(sc["feats"]).cuda(), coordinates=torch.from_numpy(sc["coords"]).cuda())
+    r = model.forward_backbone(x, raw_coordinates=torch.from_numpy(sc["raw_xyz"]).cuda())
+    o = model.forward_mask(*r, click_idx=[ci], click_time_idx=[ct])
+    outs.append(o["pred_masks"][0].cpu().numpy())
+    outs += [a["pred_masks"][0].cpu().numpy() for a in o["aux_outputs"]]
+np.savez(sys.argv[2], *outs)
+'''
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = {}
+    for nh in ("1", "8"):
+        out = str(tmp_path / f"logits_{nh}.npz")
+        env = dict(os.environ, A3D_QL_HELPERS=nh)
+        subprocess.run([sys.executable, "-c", script, root, out], check=True, env=env, timeout=600)
+        z = np.load(out)
+        res[nh] = [z[k] for k in z.files]
+    assert len(res["1"]) == len(res["8"]) == 6
+    worst = max(float(np.abs(a - b).max()) for a, b in zip(res["1"], res["8"]))
+    scale = max(float(np.abs(a).max()) for a in res["1"])
+    print(f"helper workgroups vs single workgroup: max |diff| {worst:.2e} on logits of scale {scale:.1f}")
+    assert worst <= 1e-4 * max(1.0, scale)
