@@ -239,13 +239,21 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if args.gpus > 1 and world == 1:
         raise SystemExit("for --gpus N>1 launch with: python -m torch.distributed.run --nproc-per-node N bench.py ...")
+    # A3D_BENCH_ONE_GPU=1: every rank on cuda:0 with the gloo backend -- only to exercise the N > 1 code path
+    # (barriers, MAX over ranks, the line rank 0 prints) on a single-GPU box; never a measurement
+    one_gpu = os.environ.get("A3D_BENCH_ONE_GPU", "0") == "1"
+    if one_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     numa = pin_to_gpu_numa_node(local_rank) if world > 1 else None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if one_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     import __graft_entry__ as g
     if rank == 0:

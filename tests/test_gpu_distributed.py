@@ -134,3 +134,24 @@ def test_syncbn_two_ranks_equal_one_rank_batch_of_two(tmp_path):
     for k, v in r[0]["bn"].items():
         assert torch.allclose(v, r[1]["bn"][k])                              # same statistics on both ranks
         assert torch.allclose(sd[k].cpu().float(), v.float(), rtol=1e-4, atol=1e-6), k
+
+
+def test_bench_multi_rank_code_path_on_one_gpu():
+    """bench.py's N > 1 path (torch.distributed.run, barriers, MAX over ranks, one JSON line from rank 0) with two ranks
+    sharing this box's single GPU (A3D_BENCH_ONE_GPU=1: gloo instead of RCCL) -- checks the plumbing the driver's
+    2/4/8-GPU runs go through, not a number."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, A3D_BENCH_ONE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29547", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--reps", "1",
+           "--no-profile"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["warmup"] == 1 and d["scaling"] == "weak"
+    assert d["value"] > 0 and d["config"]["global_batch"] == 8
