@@ -57,7 +57,7 @@ def pack_weight(w: torch.Tensor) -> torch.Tensor:
     """[K, Cin, Cout] (ME layout) -> the MFMA fragment order the conv kernels read (a3d_pack_conv_weight)."""
     lib = L.load()
     w = w.contiguous()
-    out = torch.empty_like(w)
+    out = torch.empty(lib.a3d_conv_weight_packed_floats(w.shape[0], w.shape[1], w.shape[2]), dtype=torch.float32, device=w.device)
     L.check(lib.a3d_pack_conv_weight(_ptr(w), w.shape[0], w.shape[1], w.shape[2], _ptr(out), _stream()),
             "a3d_pack_conv_weight")
     return out

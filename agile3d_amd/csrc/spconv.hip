@@ -111,12 +111,18 @@ __device__ __forceinline__ void wait_all_vmem() { __builtin_amdgcn_s_waitcnt(0x0
 // BN output columns, CH input channels per stage; PAIR: weight fragments two at a time (16 registers for the B operand
 // instead of 8 BN / 16: the low-register build, 3-4 workgroups per CU); DBG: the A3D_DBG ablation switches (compiled out
 // of the product kernels)
+// PAIR == 2 (opt-in, A3D_CONV_EMU=1, 96 columns x 32 channels only): fp32 products from SIX bf16 MFMAs -- both operands
+// split into three bf16 planes (x = h + m + l by truncation, every remainder exact), h h + h m + m h + h l + m m + l h on
+// v_mfma_f32_16x16x32_bf16 with fp32 accumulation.  Error no larger than the exact fp32 MFMA chain's (tools/
+// bf16x6_ubench.hip: 5.1e-6 against 7.5e-6 over 2592 products), stage loop 1.84x faster; weights packed as three planes.
 template <int BN, int CH, int PAIR, bool DBG = false>
 __global__ void __launch_bounds__(256, PAIR ? ((BN <= 96 && CH <= 32) ? 4 : 3) : ((BN <= 96 && CH <= 48) ? 3 : 2))
     k_conv_sk(const SkArgs a) {
   constexpr int RG = 1;   // 16-row groups per wave (two per wave -- 128-row tiles -- was tried and did not pay)
+  constexpr bool EMU = PAIR == 2;
+  static_assert(!EMU || CH == 32, "one 16x16x32 block per stage and column tile");
   constexpr int NCT = BN / 16, NS = CH / 16, NW = 4, kTile = 64 * RG;
-  constexpr int NPIECE = NS * NCT;
+  constexpr int NPIECE = EMU ? 3 * NCT : NS * NCT;   // 1 KB pieces of a stage's weights: 3 bf16 planes per column tile / fp32
   constexpr int WV = (NPIECE + NW - 1) / NW;
   constexpr int WF = NPIECE * 256;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -199,10 +205,11 @@ __global__ void __launch_bounds__(256, PAIR ? ((BN <= 96 && CH <= 32) ? 4 : 3) :
 #pragma unroll
   for (int i = 0; i < WV; ++i) {
     const int q = wave + NW * i;
-    wsrc[i] = (unsigned)(((q / NCT) * cout16 + (q % NCT)) * 1024 + lane * 16);
+    wsrc[i] = EMU ? (unsigned)(q * 1024 + lane * 16)
+                  : (unsigned)(((q / NCT) * cout16 + (q % NCT)) * 1024 + lane * 16);
     wdst[i] = (unsigned)q * 1024u;
   }
-  const unsigned lane_a_off = 16u * g;   // channels 4g..4g+3 of a 16-channel step
+  const unsigned lane_a_off = EMU ? 32u * g : 16u * g;   // channels 4g..4g+3 of a 16-channel step (EMU: 8g..8g+7 of the 32)
   const int wrow = 16 * RG * wave + j;   // this lane's row inside the tile for its group 0 (group r: + 16 r)
 
   const int n_u = u_hi - u_lo + 1;
@@ -276,11 +283,12 @@ __global__ void __launch_bounds__(256, PAIR ? ((BN <= 96 && CH <= 32) ? 4 : 3) :
           for (int r = 0; r < RG; ++r) {
             const unsigned roff = (unsigned)rows[r] * a.in_row_bytes + lane_a_off;
 #pragma unroll
-            for (int Sx = 0; Sx < NS; ++Sx) A[r][Sx] = *(const f32x4*)(ar + roff + 64 * Sx);
+            for (int Sx = 0; Sx < NS; ++Sx) A[r][Sx] = *(const f32x4*)(ar + roff + (EMU ? 16 : 64) * Sx);
           }
         }
         const float* wst = (DBG && (a.dbg & 64)) ? wbase   // ablation: every stage reads the same (cache-hot) weight slice
-                                                : wbase + ((size_t)kk * cin16 + (size_t)cc * NS) * cout16 * 256;
+                           : EMU ? a.c.w + (((size_t)kk * nchunk + cc) * cout16 + ct0) * (3 * 256)
+                                 : wbase + ((size_t)kk * cin16 + (size_t)cc * NS) * cout16 * 256;
         const unsigned dst = ring_addr + (unsigned)slot * (WF * 4u);
 #pragma unroll
         for (int i = 0; i < WV; ++i)
@@ -289,7 +297,44 @@ __global__ void __launch_bounds__(256, PAIR ? ((BN <= 96 && CH <= 32) ? 4 : 3) :
       auto compute = [&](const f32x4 (&A)[RG][NS], int kk, int slot) {
         if (!((gm >> kk) & 1u) || (DBG && (a.dbg & 4))) return;
         const f32x4* Ws = (const f32x4*)(wring + slot * WF) + lane;
-        if constexpr (PAIR == 0) {
+        if constexpr (EMU) {
+          typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+          typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+          // this lane's 8 channels of its row -> three bf16 planes (truncation: v = h + r1, r1 = m + r2, exact in fp32)
+          u32x4 x[3];
+#pragma unroll
+          for (int pq = 0; pq < 4; ++pq) {
+            uint32_t hh[2], mm[2], ll[2];
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+              const float v = A[0][pq >> 1][2 * (pq & 1) + e];
+              const uint32_t hb = __float_as_uint(v) & 0xffff0000u;
+              const float r1 = v - __uint_as_float(hb);
+              const uint32_t mb = __float_as_uint(r1) & 0xffff0000u;
+              const float r2 = r1 - __uint_as_float(mb);
+              hh[e] = hb, mm[e] = mb, ll[e] = __float_as_uint(r2) & 0xffff0000u;
+            }
+            x[0][pq] = (hh[0] >> 16) | hh[1];
+            x[1][pq] = (mm[0] >> 16) | mm[1];
+            x[2][pq] = (ll[0] >> 16) | ll[1];
+          }
+          const bf16x8 xh = __builtin_bit_cast(bf16x8, x[0]), xm = __builtin_bit_cast(bf16x8, x[1]),
+                       xl = __builtin_bit_cast(bf16x8, x[2]);
+          const u32x4* Wq = (const u32x4*)Ws;
+#pragma unroll
+          for (int ct = 0; ct < NCT; ++ct) {
+            const bf16x8 wh = __builtin_bit_cast(bf16x8, Wq[(3 * ct + 0) * 64]), wm = __builtin_bit_cast(bf16x8, Wq[(3 * ct + 1) * 64]),
+                         wl = __builtin_bit_cast(bf16x8, Wq[(3 * ct + 2) * 64]);
+            f32x4 c = acc[0][ct];   // smallest terms first
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl, xh, c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xl, c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm, xm, c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm, xh, c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xm, c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xh, c, 0, 0, 0);
+            acc[0][ct] = c;
+          }
+        } else if constexpr (PAIR == 0) {
           // the weight fragments of a whole 16-channel step in registers, the next step's read behind this step's MFMAs;
           // consecutive MFMAs go to different accumulators
           f32x4 b[2][NCT];
@@ -812,6 +857,42 @@ __global__ void k_pack_weight(const float* __restrict__ w, int K, int cin, int c
   out[e] = w[((size_t)k * cin + 16 * S + 4 * g + t) * cout + 16 * ct + j];
 }
 
+// the same weights as three bf16 planes for the emulated-fp32 build of the 96-column kernel:
+//   Wb[K][cin/32][cout/16][plane h, m, l][lane = 16 g + j][e] = plane(W[k][32 c + 8 g + e][16 ct + j]),  8 bf16 per lane
+__global__ void k_pack_weight_emu(const float* __restrict__ w, int K, int cin, int cout, uint16_t* out) {
+  const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;   // one thread per weight
+  const size_t total = (size_t)K * cin * cout;
+  if (e >= total) return;
+  const int el = (int)(e & 7), lane = (int)((e >> 3) & 63);
+  size_t rest = e >> 9;
+  const int cout16 = cout >> 4, cin32 = cin >> 5;
+  const int ct = (int)(rest % cout16);
+  rest /= cout16;
+  const int c = (int)(rest % cin32);
+  const int k = (int)(rest / cin32);
+  const int g = lane >> 4, j = lane & 15;
+  const float v = w[((size_t)k * cin + 32 * c + 8 * g + el) * cout + 16 * ct + j];
+  const uint32_t hb = __float_as_uint(v) & 0xffff0000u;
+  const float r1 = v - __uint_as_float(hb);
+  const uint32_t mb = __float_as_uint(r1) & 0xffff0000u;
+  const float r2 = r1 - __uint_as_float(mb);
+  const uint32_t lb = __float_as_uint(r2) & 0xffff0000u;
+  const size_t tile = (((size_t)k * cin32 + c) * cout16 + ct) * 3;   // 1 KB planes
+  out[(tile + 0) * 512 + lane * 8 + el] = (uint16_t)(hb >> 16);
+  out[(tile + 1) * 512 + lane * 8 + el] = (uint16_t)(mb >> 16);
+  out[(tile + 2) * 512 + lane * 8 + el] = (uint16_t)(lb >> 16);
+}
+
+// which layers run the emulated-fp32 build (and have their weights packed for it): opt-in
+static bool conv_emu(int K, int cin, int cout) {
+  static int on = -1;
+  if (on < 0) {
+    const char* e = getenv("A3D_CONV_EMU");
+    on = e ? atoi(e) : 0;
+  }
+  return on && K > 1 && cout == 96 && cin % 32 == 0;
+}
+
 // ------------------------------------------------------------------------------ host: launch
 constexpr int kMaxQueuesPerOp = 1024;  // ints of zeroed per-op state: k_conv_sk ticket [0], failure word [1], hand-off flags [2..2+G)
 constexpr int kSkMaxG = 1020;
@@ -876,9 +957,10 @@ static SkPlan plan_sk(int n_rows, int K, int cin, int cout, bool handoff) {
     p.nchunk = p.ch ? cin / p.ch : 1;
     p.n_cblk = cout / p.bn;
     p.pair = pair_env >= 0 ? pair_env : sk_pair(p.bn, p.ch);
+    if (conv_emu(K, cin, cout) && p.bn == 96 && p.ch == 32) p.pair = 2;
     const int mfma_per_stage = p.ch / 4 * (p.bn / 16);
     p.ov = ov_env ? ov_env : (mfma_per_stage >= 128 ? 1 : mfma_per_stage >= 64 ? 2 : 3);   // per-tile overhead in stages
-    p.lds = (size_t)2 * p.ch * p.bn * 4 + 64;
+    p.lds = (size_t)2 * p.ch * p.bn * (p.pair == 2 ? 6 : 4) + 64;   // three bf16 planes: 6 bytes per weight
     gmax = g_env ? g_env : 256 * sk_wgs_per_cu(p.bn, p.ch, p.pair, p.lds);
     if (gmax > kSkMaxG) gmax = kSkMaxG;
     const long long est = (long long)p.n_cblk * p.ntile * ((long long)p.nchunk * k_eff + p.ov);
@@ -916,6 +998,7 @@ static void allow_big_lds() {
   A3D_BIG3(32, 32) A3D_BIG3(32, 64) A3D_BIG3(32, 96) A3D_BIG3(64, 32) A3D_BIG3(64, 64) A3D_BIG3(64, 96)
   A3D_BIG3(96, 32) A3D_BIG3(96, 48) A3D_BIG3(96, 64) A3D_BIG3(96, 96) A3D_BIG3(128, 32) A3D_BIG3(128, 64)
 #undef A3D_BIG3
+  (void)hipFuncSetAttribute((const void*)k_conv_sk<96, 32, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   (void)hipFuncSetAttribute((const void*)k_conv_sk<64, 64, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   (void)hipFuncSetAttribute((const void*)k_conv_sk<96, 32, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   (void)hipFuncSetAttribute((const void*)k_conv_sk<96, 96, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -993,6 +1076,11 @@ static int launch_conv_sk(ConvArgs c, const int* pre64, float* slab_ws, size_t s
       return A3D_OK;
     }
   }
+  if (p.pair == 2) {
+    k_conv_sk<96, 32, 2><<<p.G, 256, p.lds, st>>>(a);
+    A3D_LAUNCH_CHECK();
+    return A3D_OK;
+  }
 #define A3D_L3(BN_, CH_) \
   if (p.bn == BN_ && p.ch == CH_) { if (p.pair) k_conv_sk<BN_, CH_, 1><<<p.G, 256, p.lds, st>>>(a); else k_conv_sk<BN_, CH_, 0><<<p.G, 256, p.lds, st>>>(a); } else
   A3D_L3(32, 32) A3D_L3(32, 64) A3D_L3(32, 96) A3D_L3(64, 32) A3D_L3(64, 64) A3D_L3(64, 96)
@@ -1060,9 +1148,18 @@ extern "C" int a3d_pack_conv_weight(const float* w_dev, int kernel_volume, int c
     return A3D_ERR_INVALID;
   }
   const size_t total = (size_t)kernel_volume * cin * cout;
-  k_pack_weight<<<(unsigned)((total + 255) / 256), 256, 0, (hipStream_t)stream>>>(w_dev, kernel_volume, cin, cout, packed_dev);
+  if (conv_emu(kernel_volume, cin, cout))
+    k_pack_weight_emu<<<(unsigned)((total + 255) / 256), 256, 0, (hipStream_t)stream>>>(w_dev, kernel_volume, cin, cout,
+                                                                                      (uint16_t*)packed_dev);
+  else
+    k_pack_weight<<<(unsigned)((total + 255) / 256), 256, 0, (hipStream_t)stream>>>(w_dev, kernel_volume, cin, cout, packed_dev);
   A3D_LAUNCH_CHECK();
   return A3D_OK;
+}
+
+extern "C" size_t a3d_conv_weight_packed_floats(int kernel_volume, int cin, int cout) {
+  const size_t total = (size_t)kernel_volume * cin * cout;
+  return conv_emu(kernel_volume, cin, cout) ? total + total / 2 : total;   // three bf16 planes = 1.5 floats per weight
 }
 
 extern "C" size_t a3d_program_workspace_bytes(const a3d_scene* s, const a3d_buf_desc* bufs, int n_bufs,

@@ -118,7 +118,7 @@ class BackboneProgram:
         def pack(conv):
             w = conv.kernel3().detach().to(dev, torch.float32).contiguous()
             K, cin, cout = w.shape
-            out = torch.empty_like(w)
+            out = torch.empty(lib.a3d_conv_weight_packed_floats(K, cin, cout), dtype=torch.float32, device=dev)
             L.check(lib.a3d_pack_conv_weight(_ptr(w), K, cin, cout, _ptr(out), _stream()), "a3d_pack_conv_weight")
             self.keep.append(out)
             return out

@@ -157,6 +157,10 @@ typedef struct {
 /* W[K][cin][cout] (ME layout, models/modules/common.py:137-155) -> MFMA B-fragment order */
 int a3d_pack_conv_weight(const float* w_dev, int kernel_volume, int cin, int cout,
                          float* packed_dev, void* stream);
+/* floats the packed form of a [kernel_volume][cin][cout] weight occupies: kernel_volume * cin * cout, except for the layers
+ * the opt-in emulated-fp32 build runs (A3D_CONV_EMU=1: 96-column gathered convolutions, three bf16 planes = 1.5 floats per
+ * weight).  Size `packed_dev` of a3d_pack_conv_weight with it. */
+size_t a3d_conv_weight_packed_floats(int kernel_volume, int cin, int cout);
 
 size_t a3d_program_workspace_bytes(const a3d_scene* s, const a3d_buf_desc* bufs, int n_bufs,
                                    const a3d_op* ops, int n_ops);

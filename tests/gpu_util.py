@@ -32,7 +32,7 @@ def pack_weight(w):
     lib = L.load()
     w = w.contiguous()
     K, cin, cout = w.shape
-    out = torch.empty_like(w)
+    out = torch.empty(lib.a3d_conv_weight_packed_floats(K, cin, cout), dtype=torch.float32, device=w.device)
     L.check(lib.a3d_pack_conv_weight(_ptr(w), K, cin, cout, _ptr(out), _stream()), "pack")
     return out
 
