@@ -890,7 +890,10 @@ static bool conv_emu(int K, int cin, int cout) {
     const char* e = getenv("A3D_CONV_EMU");
     on = e ? atoi(e) : 0;
   }
-  return on && K > 1 && cout == 96 && cin % 32 == 0;
+  // on == 1: the 96-column kernels (levels 0 / 1 of the decoder side, 40 % of a step's kernel time); on == 2: every gathered conv
+  if (!on || K <= 1 || cin % 32 != 0) return false;
+  if (cout == 96) return true;
+  return on >= 2 && (cout == 32 || cout == 64 || cout % 128 == 0);
 }
 
 // ------------------------------------------------------------------------------ host: launch
@@ -957,7 +960,11 @@ static SkPlan plan_sk(int n_rows, int K, int cin, int cout, bool handoff) {
     p.nchunk = p.ch ? cin / p.ch : 1;
     p.n_cblk = cout / p.bn;
     p.pair = pair_env >= 0 ? pair_env : sk_pair(p.bn, p.ch);
-    if (conv_emu(K, cin, cout) && p.bn == 96 && p.ch == 32) p.pair = 2;
+    if (conv_emu(K, cin, cout)) {
+      p.ch = 32;
+      p.nchunk = cin / 32;
+      p.pair = 2;
+    }
     const int mfma_per_stage = p.ch / 4 * (p.bn / 16);
     p.ov = ov_env ? ov_env : (mfma_per_stage >= 128 ? 1 : mfma_per_stage >= 64 ? 2 : 3);   // per-tile overhead in stages
     p.lds = (size_t)2 * p.ch * p.bn * (p.pair == 2 ? 6 : 4) + 64;   // three bf16 planes: 6 bytes per weight
@@ -999,6 +1006,9 @@ static void allow_big_lds() {
   A3D_BIG3(96, 32) A3D_BIG3(96, 48) A3D_BIG3(96, 64) A3D_BIG3(96, 96) A3D_BIG3(128, 32) A3D_BIG3(128, 64)
 #undef A3D_BIG3
   (void)hipFuncSetAttribute((const void*)k_conv_sk<96, 32, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  (void)hipFuncSetAttribute((const void*)k_conv_sk<128, 32, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  (void)hipFuncSetAttribute((const void*)k_conv_sk<64, 32, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  (void)hipFuncSetAttribute((const void*)k_conv_sk<32, 32, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   (void)hipFuncSetAttribute((const void*)k_conv_sk<64, 64, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   (void)hipFuncSetAttribute((const void*)k_conv_sk<96, 32, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   (void)hipFuncSetAttribute((const void*)k_conv_sk<96, 96, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -1077,7 +1087,10 @@ static int launch_conv_sk(ConvArgs c, const int* pre64, float* slab_ws, size_t s
     }
   }
   if (p.pair == 2) {
-    k_conv_sk<96, 32, 2><<<p.G, 256, p.lds, st>>>(a);
+    if (p.bn == 96) k_conv_sk<96, 32, 2><<<p.G, 256, p.lds, st>>>(a);
+    else if (p.bn == 128) k_conv_sk<128, 32, 2><<<p.G, 256, p.lds, st>>>(a);
+    else if (p.bn == 64) k_conv_sk<64, 32, 2><<<p.G, 256, p.lds, st>>>(a);
+    else k_conv_sk<32, 32, 2><<<p.G, 256, p.lds, st>>>(a);
     A3D_LAUNCH_CHECK();
     return A3D_OK;
   }

@@ -255,16 +255,16 @@ def test_conv_apply_every_shape_class_small_scene(small_world, kind, level):
 
 
 def test_emulated_fp32_build_keeps_parity():
-    """A3D_CONV_EMU=1 (96-column conv kernels form every fp32 product from six bf16-MFMA terms; read once per process, so
+    """A3D_CONV_EMU=2 (every gathered conv kernel forms its fp32 products from six bf16-MFMA terms; read once per process, so
     it runs in its own interpreter): the conv tests that reach those kernels and the end-to-end smoke comparison with the
     oracle, at their unchanged tolerances."""
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, A3D_CONV_EMU="1")
+    env = dict(os.environ, A3D_CONV_EMU="2")
     out = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_conv.py"), "-x", "-q", "-p",
-                          "no:cacheprovider", "-k", "test_conv3 or test_up or every_shape_class"], env=env, capture_output=True,
+                          "no:cacheprovider", "-k", "test_conv3 or test_up or test_down or every_shape_class"], env=env, capture_output=True,
                          text=True, timeout=1200, cwd=root)
     assert out.returncode == 0, out.stdout[-3000:]
     out = subprocess.run([sys.executable, "-c", "import __graft_entry__ as g; g.smoke()"], env=env, capture_output=True, text=True,
