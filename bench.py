@@ -174,6 +174,7 @@ def cpu_baseline(sd, sc, ci, ct, gpu_logits=None, gpu_feats=None, samples=3):
                 "pcd_features_max_abs_diff": float((gpu_feats.cpu() - r["pcd_features"]).abs().max()),
                 "pcd_features_scale": float(r["pcd_features"].abs().max()),
                 "note": "GPU output of scene 0 of the timed workload vs the CPU oracle on the same inputs (bar 1e-3)"}
+    cpu_baseline.last_logits = lg[-1]      # the oracle's logits of that scene (the emulated-fp32 pass is compared with them too)
     return res, diff
 
 
@@ -222,6 +223,7 @@ def main():
     ap.add_argument("--clicks-per-object", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--dump-logits", default="", help="write scene 0's logits of the first step to this file (torch.save)")
     ap.add_argument("--steps-only", action="store_true",
                     help="only the 4-scene steps (warm-up, timed region, instrumented pass): no latency / phase / eval-round "
                          "/ CPU passes -- the command tools/profile_round.sh traces for profiles/kernel_avg_us.json, so that "
@@ -293,6 +295,8 @@ def main():
     assert torch.isfinite(out0["pred_masks"][0]).all()
     gpu_logits0 = out0["pred_masks"][0].clone()
     gpu_feats0 = r0[0].F[:n0].clone()
+    if args.dump_logits and rank == 0:
+        torch.save(gpu_logits0.cpu(), args.dump_logits)
     streams = [torch.cuda.Stream(device=dev) for _ in range(args.streams)] if args.streams > 1 else None
     issued = [0]
 
@@ -467,13 +471,21 @@ def main():
         try:
             import subprocess
             env = dict(os.environ, A3D_CONV_EMU="2")
+            import tempfile
+            dump = os.path.join(tempfile.gettempdir(), f"a3d_bench_emu_logits_{os.getpid()}.pt")
             out = subprocess.run([sys.executable, os.path.abspath(__file__), "--steps-only", "--no-profile", "--reps", "5",
                                   "--steps", str(args.steps), "--warmup", str(args.warmup), "--batch", str(args.batch),
-                                  "--streams", str(args.streams)], env=env, capture_output=True, text=True, timeout=600)
+                                  "--streams", str(args.streams), "--dump-logits", dump], env=env, capture_output=True,
+                                 text=True, timeout=600)
             line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
             d = json.loads(line)
+            emu_logits = torch.load(dump)
+            os.remove(dump)
+            ref = getattr(cpu_baseline, "last_logits", None)
             res["emulated_fp32_products"] = {
                 "value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"],
+                "max_abs_diff": float((emu_logits - ref).abs().max()) if ref is not None else None,
+                "max_abs_diff_vs_exact_build": float((emu_logits - gpu_logits0.cpu()).abs().max()),
                 "note": "same workload with A3D_CONV_EMU=2: the gathered conv kernels form each fp32 product from 6 bf16-MFMA terms "
                         "(3-way operand split, fp32 accumulation; error <= the exact fp32 MFMA chain's, tools/bf16x6_ubench.hip; "
                         "parity tests unchanged). Opt-in: not the arithmetic `value` is measured with"}
