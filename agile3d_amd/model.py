@@ -126,11 +126,12 @@ class Agile3d(nn.Module):
         return self._engine
 
     def load_state_dict(self, state_dict, strict=True, kernel_order=None, **kw):
-        """``kernel_order``: enumeration of the kernel offsets in the file ("x_fastest" default, "z_fastest"); also
-        settable as ``args.kernel_order`` or A3D_KERNEL_ORDER (see ``convert_kernel_order``)."""
-        import os
-        order = kernel_order or getattr(self.args, "kernel_order", None) or os.environ.get("A3D_KERNEL_ORDER")
-        sd = convert_kernel_order(state_dict, order)
+        """``kernel_order``: enumeration of the kernel offsets in the FILE ("x_fastest" = the library's own, default;
+        "z_fastest": see ``convert_kernel_order``).  The permutation is applied only when the caller passes the
+        argument: state dicts this library wrote (``save_checkpoint``, ``model_a.state_dict()``) are already in its
+        own order, so a sticky default (args / environment) would permute them a second time on every resume.
+        Importing a foreign checkpoint is the explicit step ``import_state_dict``."""
+        sd = convert_kernel_order(state_dict, kernel_order)
         own = self.state_dict()   # accept ME<0.5 checkpoints holding 1x1 kernels as [1,Cin,Cout]
         for k, v in list(sd.items()):
             if k in own and own[k].dim() == 2 and v.dim() == 3 and v.shape[0] == 1 and k.endswith(".kernel"):
@@ -139,6 +140,13 @@ class Agile3d(nn.Module):
         if self._engine is not None:
             self._engine.mark_stale()
         return res
+
+    def import_state_dict(self, state_dict, strict=False, kernel_order=None):
+        """Load a checkpoint written by the REFERENCE (``ckpt['model']``, eval_multi_obj.py:60-63): the one place where
+        ``args.kernel_order`` / A3D_KERNEL_ORDER are consulted for the enumeration of kernel offsets in the file."""
+        import os
+        order = kernel_order or getattr(self.args, "kernel_order", None) or os.environ.get("A3D_KERNEL_ORDER")
+        return self.load_state_dict(state_dict, strict=strict, kernel_order=order)
 
     # ------------------------------------------------------------------ the hot path
     def forward_backbone(self, x, raw_coordinates=None):

@@ -18,9 +18,10 @@ def scenes_of_rank(n_scenes: int, rank: int, world: int):
     return list(range(rank, n_scenes, world))
 
 
-def timed_steps(step, steps: int, world: int, device, sync=None):
+def timed_steps(step, steps: int, world: int, device, sync=None, own=None):
     """Time exactly `steps` calls of `step()` bracketed by barrier + device sync on both sides and
-    return the MAX over ranks in seconds (the contract of bench.py)."""
+    return the MAX over ranks in seconds (the contract of bench.py).  `own` (a list) receives this
+    rank's own time before the MAX."""
     import torch.distributed as dist
     sync = sync or (torch.cuda.synchronize if device.type == "cuda" else (lambda: None))
     sync()
@@ -36,6 +37,8 @@ def timed_steps(step, steps: int, world: int, device, sync=None):
         dist.barrier()
     sync()
     dt = time.perf_counter() - t0
+    if own is not None:
+        own.append(dt)
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=device if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

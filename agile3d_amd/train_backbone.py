@@ -112,7 +112,17 @@ class BackboneTape:
         self.grads = {}
         self._names = {id(p): n for n, p in model.named_parameters()}
         self.packed = packed_weights_of(model)
+        self._bns = []           # the BatchNorms this forward pass ran through (running statistics updated in place)
         self._forward()
+        # the kernels wrote running_mean / running_var through raw device pointers: torch's version counters did not
+        # move, so (1) count the batch like nn.BatchNorm1d does (state-dict parity with torch, one multi-tensor launch;
+        # the buffers' version bump is what refresh_weights_if_stale(check_versions=True) sees) and (2) tell the
+        # inference engine directly that its folded backbone program is out of date
+        if self._bns:
+            torch._foreach_add_([b.num_batches_tracked for b in self._bns], 1)
+        eng = getattr(model, "_engine", None)
+        if eng is not None:
+            eng._stale = True
 
     # ------------------------------------------------------------------ layers
     def _pgrad(self, param, g):
@@ -135,6 +145,7 @@ class BackboneTape:
 
     def _bn(self, x: _T, norm, res: _T | None = None, relu=True) -> _T:
         b = norm.bn
+        self._bns.append(b)
         n = self.scene.n[x.level]
         xv, rv = x.v[:n], (res.v[:n] if res is not None else None)
         n_glob = None

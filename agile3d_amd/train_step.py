@@ -253,10 +253,16 @@ class MultiStepLR:
     def load_state_dict(self, sd, keep_base_lr=False):
         """``keep_base_lr``: restore the position in the schedule (epoch, milestones, gamma) but keep the base learning
         rate of the RUNNING configuration -- what resuming with a changed --lr means (main.py:131-152 keeps the new
-        lr of the param groups and does not load the scheduler's)."""
-        self.last_epoch, self.milestones, self.gamma = sd["last_epoch"], sd["milestones"], sd["gamma"]
+        lr of the param groups).  Accepts this class's own state and torch.optim.lr_scheduler.MultiStepLR's
+        (``base_lrs`` list, ``milestones`` as a Counter)."""
+        ms = sd["milestones"]
+        self.milestones = sorted(ms.elements()) if hasattr(ms, "elements") else sorted(ms)
+        self.last_epoch, self.gamma = sd["last_epoch"], sd["gamma"]
         if not keep_base_lr:
-            self.base_lr = sd["base_lr"]
+            if "base_lr" in sd:
+                self.base_lr = sd["base_lr"]
+            elif sd.get("base_lrs"):
+                self.base_lr = sd["base_lrs"][0]
         self.optimizer.lr = self.base_lr * self.gamma ** sum(1 for m in self.milestones if m <= self.last_epoch)
 
 
@@ -268,9 +274,15 @@ def save_checkpoint(path, model, optimizer, lr_scheduler, epoch, args=None):
                 "args": args}, path)
 
 
-def load_checkpoint(path, model, optimizer=None, lr_scheduler=None):
+def load_checkpoint(path, model, optimizer=None, lr_scheduler=None, reference_schedule=False):
     """Resume like main.py:131-152: weights with strict=False, then optimiser state and epoch when the file has them
-    (the learning rate of the running configuration is kept, as the reference does).  Returns the epoch to start from."""
+    (the learning rate of the running configuration is kept, as the reference does).  Returns the epoch to start from.
+
+    Scheduler: the reference does NOT load the scheduler's state (the line is commented out, main.py:146) -- it calls
+    ``lr_scheduler.step(lr_scheduler.last_epoch)`` on the fresh scheduler, so after a resume past ``lr_drop`` it trains
+    at the undropped rate again.  Default here (a deliberate deviation): the position in the schedule is restored from
+    the file, so a resumed run continues the uninterrupted run bit for bit (tests/test_gpu_backward.py).
+    ``reference_schedule=True`` gives the reference's behaviour: the scheduler is left at epoch 0 of the running lr."""
     ck = torch.load(path, map_location="cpu", weights_only=False)
     missing, unexpected = model.load_state_dict(ck["model"], strict=False)
     unexpected = [k for k in unexpected if not (k.endswith("total_params") or k.endswith("total_ops"))]
@@ -283,9 +295,10 @@ def load_checkpoint(path, model, optimizer=None, lr_scheduler=None):
         lr = optimizer.lr
         optimizer.load_state_dict(ck["optimizer"])
         optimizer.lr = lr
-        if lr_scheduler is not None and ck.get("lr_scheduler") is not None:
+        if lr_scheduler is not None:
             lr_scheduler.base_lr = lr                                   # a changed --lr stays in force after the resume
-            lr_scheduler.load_state_dict(ck["lr_scheduler"], keep_base_lr=True)
+            if ck.get("lr_scheduler") is not None and not reference_schedule:
+                lr_scheduler.load_state_dict(ck["lr_scheduler"], keep_base_lr=True)
         start = ck["epoch"] + 1
     return start
 

@@ -12,7 +12,7 @@ latency-bound coarse levels and scene build overlap another's fine-level convolu
 is strictly one scene at a time.  N GPUs = N ranks with their own scenes (scene-sharded, no data-path
 collective): weak scaling.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W          (N > 1: launches its own N ranks through torch.distributed.run)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 The timed region (exactly --steps steps between barrier + device sync, MAX over ranks) is repeated --reps
@@ -211,6 +211,22 @@ def pin_to_gpu_numa_node(local_rank):
     return None
 
 
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher: re-run this command line as N ranks under torch.distributed.run
+    (--nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port <free port>) and hand its output through."""
+    import socket
+    import subprocess
+    with socket.socket() as s_:
+        s_.bind(("127.0.0.1", 0))
+        port = s_.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "8")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -239,16 +255,21 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    if args.gpus > 1 and world == 1:
-        raise SystemExit("for --gpus N>1 launch with: python -m torch.distributed.run --nproc-per-node N bench.py ...")
-    # A3D_BENCH_ONE_GPU=1: every rank on cuda:0 with the gloo backend -- only to exercise the N > 1 code path
-    # (barriers, MAX over ranks, the line rank 0 prints) on a single-GPU box; never a measurement
-    one_gpu = os.environ.get("A3D_BENCH_ONE_GPU", "0") == "1"
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` launches its own N ranks (one process per GPU) through torch.distributed.run,
+        # exactly the command the driver would have typed; rank 0's JSON line is this process's only stdout line
+        raise SystemExit(self_launch(args.gpus))
+    # fewer GPUs on the box than ranks (or A3D_BENCH_ONE_GPU=1): ranks share devices round-robin and talk over gloo
+    # instead of RCCL -- exercises the N > 1 code path (barriers, MAX over ranks, the line rank 0 prints) on a
+    # single-GPU box; the line says so (`ranks_share_gpus`) and is never a scaling measurement
+    n_dev = torch.cuda.device_count()
+    one_gpu = os.environ.get("A3D_BENCH_ONE_GPU", "0") == "1" or (world > 1 and n_dev < world)
     if one_gpu:
-        local_rank = 0
+        local_rank = local_rank % max(1, n_dev) if os.environ.get("A3D_BENCH_ONE_GPU", "0") != "1" else 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     numa = pin_to_gpu_numa_node(local_rank) if world > 1 else None
+    ranks_seen = 1
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -256,6 +277,10 @@ def main():
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=dev)
+        # how many ranks the collective backend really connects: an all-reduce of ones (over RCCL on a multi-GPU node)
+        ones = torch.ones(1, dtype=torch.float32, device="cpu" if one_gpu else dev)
+        dist.all_reduce(ones)
+        ranks_seen = int(ones.item())
 
     import __graft_entry__ as g
     if rank == 0:
@@ -312,11 +337,16 @@ def main():
         step()
     # the timed region (exactly --steps steps between barrier + device sync, MAX over ranks) is repeated --reps
     # times; the line reports the MEDIAN repetition and lists them all
-    rep_dt = []
+    rep_dt, own_dt = [], []
     for _ in range(max(1, args.reps)):
-        dt_, out = timed_steps(step, args.steps, world, dev)
+        dt_, out = timed_steps(step, args.steps, world, dev, own=own_dt)
         rep_dt.append(dt_)
     dt = float(np.median(rep_dt))
+    per_rank_ms = [1e3 * float(np.median(own_dt)) / args.steps]
+    if world > 1:
+        gathered = [None] * world
+        dist.all_gather_object(gathered, per_rank_ms[0])
+        per_rank_ms = [float(x) for x in gathered]
     assert torch.isfinite(out["pred_masks"][0]).all()
 
     res = {
@@ -335,6 +365,15 @@ def main():
     }
     if numa is not None:
         res["config"]["launch_thread_numa_node"] = numa
+    if world > 1:
+        res["ranks_seen"] = ranks_seen
+        res["ms_per_step_per_rank"] = [round(x, 4) for x in per_rank_ms]
+        res["config"]["backend"] = "gloo" if one_gpu else "nccl (RCCL)"
+        res["config"]["gpus_visible"] = n_dev
+        if one_gpu:
+            res["ranks_share_gpus"] = True
+            res["note_multi_rank"] = (f"{world} ranks on {max(1, n_dev)} visible GPU(s): plumbing check of the N > 1 path, "
+                                      "not a scaling measurement")
 
     if rank == 0:
         # (N = 1: everything below; N > 1: rank 0 still measures the roofline object of its own GPU while the other

@@ -137,16 +137,16 @@ def test_syncbn_two_ranks_equal_one_rank_batch_of_two(tmp_path):
 
 
 def test_bench_multi_rank_code_path_on_one_gpu():
-    """bench.py's N > 1 path (torch.distributed.run, barriers, MAX over ranks, one JSON line from rank 0) with two ranks
-    sharing this box's single GPU (A3D_BENCH_ONE_GPU=1: gloo instead of RCCL) -- checks the plumbing the driver's
-    2/4/8-GPU runs go through, not a number."""
+    """The literal `python bench.py --gpus 2`: bench.py launches its own two ranks (torch.distributed.run), which on this
+    one-GPU box share the device and talk over gloo -- barriers, MAX over ranks, ranks_seen, one JSON line from rank 0.
+    Checks the plumbing the driver's 2/4/8-GPU runs go through, not a number."""
     import json
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, A3D_BENCH_ONE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29547", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--reps", "1",
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "A3D_BENCH_ONE_GPU")}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--reps", "1",
            "--no-profile"]
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=root)
     assert out.returncode == 0, out.stderr[-2000:]
@@ -155,3 +155,6 @@ def test_bench_multi_rank_code_path_on_one_gpu():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 3 and d["warmup"] == 1 and d["scaling"] == "weak"
     assert d["value"] > 0 and d["config"]["global_batch"] == 8
+    assert d["ranks_seen"] == 2 and len(d["ms_per_step_per_rank"]) == 2
+    if torch.cuda.device_count() < 2:
+        assert d["ranks_share_gpus"] is True and d["config"]["backend"] == "gloo"

@@ -398,3 +398,26 @@ np.savez(sys.argv[2], *outs)
     scale = max(float(np.abs(a).max()) for a in res["1"])
     print(f"helper workgroups vs single workgroup: max |diff| {worst:.2e} on logits of scale {scale:.1f}")
     assert worst <= 1e-4 * max(1.0, scale)
+
+
+def test_training_mode_forward_invalidates_the_folded_backbone():
+    """A train-mode forward moves the BatchNorm running statistics (through raw pointers); with no optimiser step after it
+    (BN recalibration under no_grad) the next eval-mode forward must fold the NEW statistics, and num_batches_tracked
+    counts the batch like nn.BatchNorm1d does."""
+    torch.manual_seed(1)
+    model = randomize_bn_stats(build_model(default_args())).cuda().eval()
+    sc = make_scene(3000, seed=5)
+    before = _run_backbone(model, sc)[0].F.clone()
+    nbt0 = int(model.backbone.bn0.bn.num_batches_tracked)
+    model.train()
+    with torch.no_grad():
+        _run_backbone(model, sc)
+    model.eval()
+    assert int(model.backbone.bn0.bn.num_batches_tracked) == nbt0 + 1
+    after = _run_backbone(model, sc)[0].F
+    sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    ref = ob.forward_backbone(sd, sc["coords"], torch.from_numpy(sc["feats"]), torch.from_numpy(sc["raw_xyz"]))
+    err = (after.cpu() - ref["pcd_features"]).abs().max().item()
+    moved = (after - before).abs().max().item()
+    print(f"eval after a train-mode forward: vs oracle on the new statistics {err:.2e}; moved by {moved:.2e}")
+    assert moved > 1e-3 and err <= TOL * max(1.0, ref["pcd_features"].abs().max().item())

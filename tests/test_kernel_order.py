@@ -6,6 +6,7 @@ can only be decided with weights + data; a checkpoint in the other (z fastest) e
 import numpy as np
 import torch
 
+from agile3d_amd import build_model, default_args
 from agile3d_amd.model import convert_kernel_order, kernel_order_permutation
 from oracle import backbone as ob
 
@@ -74,3 +75,21 @@ def test_model_load_state_dict_switch(full_model_cpu):
         assert torch.equal(v, sd[k]), k
     changed = [k for k in sd if not torch.equal(sd[k], z_file[k])]
     assert len(changed) == 46 + 1 + 8 and all(k.endswith(".kernel") for k in changed)     # 3^3, 5^3 and the 2^3 kernels
+
+
+def test_load_state_dict_does_not_reapply_a_sticky_order(monkeypatch):
+    """A state dict written by this library is in its own order: neither args.kernel_order nor A3D_KERNEL_ORDER may permute
+    it on load (resume after importing the authors' weights, model_b.load_state_dict(model_a.state_dict())); the permutation
+    happens only on an explicit argument or through import_state_dict."""
+    torch.manual_seed(3)
+    args = default_args()
+    args.kernel_order = "z_fastest"
+    monkeypatch.setenv("A3D_KERNEL_ORDER", "z_fastest")
+    a, b = build_model(args), build_model(args)
+    sd = {k: v.clone() for k, v in a.state_dict().items()}
+    b.load_state_dict(sd, strict=True)
+    name = "backbone.block1.0.conv1.kernel"
+    assert torch.equal(b.state_dict()[name], sd[name])
+    b.import_state_dict(sd, strict=True)                      # the explicit import path reads the sticky setting
+    assert torch.equal(b.state_dict()[name], sd[name][kernel_order_permutation(27)])
+    assert not torch.equal(b.state_dict()[name], sd[name])
