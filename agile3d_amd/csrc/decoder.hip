@@ -997,6 +997,271 @@ __global__ void __launch_bounds__(512) k_out_ln_mask(const DecSampleDev* __restr
     if (hist[e]) atomicAdd(&counts[e], hist[e]);
 }
 
+// ---- the whole scene-to-click half of a layer in ONE pass (<= ~24 queries) --------------------------------------
+// k_q_s2c + k_out_ln_mask without the round trip of the attention output O through HBM: per 16-point group the lane that
+// holds O[point j][16h+4g..+3] after head h's P V product is holding exactly the B fragment of the output projection's
+// K-step S = h, so y += Wo[S = h] O_h is accumulated head by head (y starts as bias + residual row) and LayerNorm, the
+// mask head, label argmax and histogram follow from registers.  Reads src + pos, writes Y and the logits: 3 N d floats
+// per layer instead of 6 N d (SURVEY 8(d)'s fused-ideal figure).  Both packed weight matrices (128 KB) are LDS
+// resident, so the queries' keys / transposed values get compact rows (nq rounded up to 4) and the mask embeddings sit
+// in registers; more queries than fit fall back to the two-kernel path.  The logits MFMA is taken transposed
+// (queries x points): a lane ends up with the logits of ITS point, the per-object max is a masked in-lane max + one
+// row reduction, no LDS scratch for the [16][Q] logits tile.
+template <int QT>
+__global__ void __launch_bounds__(512) k_s2c_out(const DecSampleDev* __restrict__ samples, int ns, int layer,
+                                                 const float* __restrict__ Wq, const float* __restrict__ bq,
+                                                 const float* __restrict__ Wo, const float* __restrict__ bo,
+                                                 const float* __restrict__ gamma, const float* __restrict__ beta, int nqr_max,
+                                                 int Kmax) {
+  constexpr int LD = 132, NW = 8;
+  const DecSampleDev& sm = sample_of_wg(samples, ns);
+  const int lb = blockIdx.x - sm.wg_begin, nwg = sm.wg_end - sm.wg_begin;
+  const int n = sm.n, ngroups = (n + 15) / 16, nq = sm.nq, n_fg = sm.n_fg, K = sm.K;
+  const float* __restrict__ X = layer_input(sm, layer);
+  const float* __restrict__ Pe = sm.posenc;
+  float* __restrict__ Y = (layer & 1) ? sm.bufD : sm.bufC;
+  float* logits = sm.logits + (size_t)layer * n * (K + 1);
+  unsigned char* labels = sm.labels;
+  int* counts = sm.counts + (size_t)layer * (A3D_MAX_QUERIES + 1);
+  const int LT = nqr_max + 4;                     // row stride of the transposed values
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  f32x4* Wql = (f32x4*)smem;                      // [8 S][8 ct][64]
+  f32x4* Wol = Wql + 8 * 8 * 64;                  // [8 S][8 ct][64]
+  float* ks_l = (float*)(Wol + 8 * 8 * 64);       // [nqr_max][132]
+  float* vt_l = ks_l + nqr_max * LD;              // [128][LT]
+  float* bq_l = vt_l + D * LT;                    // [128] x 4: q bias, out bias, LayerNorm weight and bias
+  float* bo_l = bq_l + D;
+  float* ga_l = bo_l + D;
+  float* be_l = ga_l + D;
+  float* O_l = be_l + D;                          // [NW][16][Kmax+1] logits staging
+  int* hist = (int*)(O_l + NW * 16 * (Kmax + 1)); // [Kmax+1]
+  int* qr_l = hist + Kmax + 1;                    // [Kmax+2]
+  for (int e = threadIdx.x; e <= K + 1; e += 512) qr_l[e] = sm.qrange[e];
+  for (int e = threadIdx.x; e <= K; e += 512) hist[e] = 0;
+  if (threadIdx.x < D) {
+    bq_l[threadIdx.x] = bq[threadIdx.x];
+    bo_l[threadIdx.x] = bo[threadIdx.x];
+    ga_l[threadIdx.x] = gamma[threadIdx.x];
+    be_l[threadIdx.x] = beta[threadIdx.x];
+  }
+  {
+    constexpr int TOT = 8 * 8 * 64;
+    for (int base = threadIdx.x; base < TOT; base += 4 * 512) {
+      f32x4 t8[8];
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (base + u * 512 < TOT) {
+          t8[u] = ((const f32x4*)Wq)[base + u * 512];
+          t8[4 + u] = ((const f32x4*)Wo)[base + u * 512];
+        }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (base + u * 512 < TOT) {
+          Wql[base + u * 512] = t8[u];
+          Wol[base + u * 512] = t8[4 + u];
+        }
+    }
+  }
+  for (int e = threadIdx.x; e < nqr_max * 32; e += 512) {
+    const int r = e >> 5, c4 = (e & 31) * 4;
+    f32x4 k4 = (f32x4){0.f, 0.f, 0.f, 0.f}, v4 = k4;
+    if (r < nq) {
+      k4 = *(const f32x4*)(sm.ks + (size_t)r * D + c4);
+      v4 = *(const f32x4*)(sm.vs + (size_t)r * D + c4);
+    }
+    *(f32x4*)(ks_l + r * LD + c4) = k4;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) vt_l[(c4 + t) * LT + r] = v4[t];
+  }
+  for (int e = threadIdx.x; e < D * 4; e += 512) vt_l[(e >> 2) * LT + nqr_max + (e & 3)] = 0.f;   // the pad columns are read (x 0)
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int g = lane >> 4, j = lane & 15;
+  __syncthreads();
+  float* Ow = O_l + wave * 16 * (Kmax + 1);
+  const int stride = nwg * NW;
+  int grp = lb * NW + wave;
+  f32x4 nx[8], np[8];
+  auto fetch = [&](int gq) {
+    const size_t row = (size_t)min(gq * 16 + j, n - 1);
+    const float* xr = X + row * D + 4 * g;
+    const float* pr = Pe + row * D + 4 * g;
+#pragma unroll
+    for (int S = 0; S < 8; ++S) nx[S] = *(const f32x4*)(xr + 16 * S);
+#pragma unroll
+    for (int S = 0; S < 8; ++S) np[S] = *(const f32x4*)(pr + 16 * S);
+  };
+  if (grp < ngroups) fetch(grp);
+  while (grp < ngroups) {
+    const int p0 = grp * 16;
+    const int prow = min(p0 + j, n - 1);
+    f32x4 xp[8], y[8];
+#pragma unroll
+    for (int S = 0; S < 8; ++S) {
+      xp[S] = nx[S] + np[S];
+      y[S] = *(const f32x4*)(bo_l + 16 * S + 4 * g) + nx[S];   // bias + residual row: channels 16 ct + 4 g ..+3 of point j
+    }
+    const int next = grp + stride;
+    // heads two at a time: the Q projection of a head is a chain of 32 MFMAs on ONE accumulator and the P V product a chain
+    // of 4 QT (40 cycles of dependent latency per 32-cycle MFMA); two heads' chains interleaved keep the matrix pipe fed
+#pragma unroll 1
+    for (int h = 0; h < H; h += 2) {
+      // the next group's rows are requested late in the head loop (two heads + the LayerNorm / logits phase cover the
+      // latency): 64 registers that would otherwise be live next to xp and y for the whole group
+      if (h == 4 && next < ngroups) fetch(next);
+      f32x4 qf[2];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) qf[u] = *(const f32x4*)(bq_l + 16 * (h + u) + 4 * g);   // Q[point j][16h+4g..+3]
+#pragma unroll
+      for (int S = 0; S < 8; ++S) {
+        f32x4 w[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) w[u] = Wql[(S * 8 + h + u) * 64 + lane];
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+          for (int u = 0; u < 2; ++u) qf[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[u][t], xp[S][t], qf[u], 0, 0, 0);
+      }
+      f32x4 sc[2][QT];
+      float mx[2] = {kNegBig, kNegBig};
+#pragma unroll
+      for (int kt = 0; kt < QT; ++kt) {
+        f32x4 kf[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          kf[u] = *(const f32x4*)(ks_l + (kt * 16 + j) * LD + (h + u) * DH + 4 * g);
+          sc[u][kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+          for (int u = 0; u < 2; ++u) sc[u][kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[u][t], qf[u][t], sc[u][kt], 0, 0, 0);
+      }
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int kt = 0; kt < QT; ++kt)
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            if (kt * 16 + 4 * g + t >= nq) sc[u][kt][t] = kNegBig;
+            mx[u] = fmaxf(mx[u], sc[u][kt][t]);
+          }
+      float inv[2];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        mx[u] = rows_max(mx[u]);
+        float sum = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < QT; ++kt)
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            sc[u][kt][t] = fast_exp(sc[u][kt][t] - mx[u]);
+            sum += sc[u][kt][t];
+          }
+        sum = rows_sum(sum);
+        inv[u] = __builtin_amdgcn_rcpf(sum);
+      }
+      f32x4 acc[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+      for (int kt = 0; kt < QT; ++kt) {
+        f32x4 vf[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) vf[u] = *(const f32x4*)(vt_l + ((h + u) * DH + j) * LT + kt * 16 + 4 * g);   // V^T: keys 4g..4g+3 of channel 16h+j
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+          for (int u = 0; u < 2; ++u) acc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(vf[u][t], sc[u][kt][t] * inv[u], acc[u], 0, 0, 0);
+      }
+      // acc[u] = O[point j][16(h+u)+4g..+3] = the B fragment of the output projection's K-step h + u
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int ct = 0; ct < 8; ++ct) {
+          const f32x4 w = Wol[((h + u) * 8 + ct) * 64 + lane];
+#pragma unroll
+          for (int t = 0; t < 4; ++t) y[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[t], acc[u][t], y[ct], 0, 0, 0);
+        }
+    }
+    // LayerNorm over the 128 channels of point j (4 g-lanes x 8 ct x 4)
+    float sum = 0.f;
+#pragma unroll
+    for (int ct = 0; ct < 8; ++ct) sum += y[ct][0] + y[ct][1] + y[ct][2] + y[ct][3];
+    sum = rows_sum(sum);
+    const float mean = sum * (1.f / D);
+    float var = 0.f;
+#pragma unroll
+    for (int ct = 0; ct < 8; ++ct)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const float d = y[ct][t] - mean;
+        var += d * d;
+      }
+    var = rows_sum(var);
+    const float rstd = rsqrtf(var * (1.f / D) + kLnEps);
+    float* yrow = Y + (size_t)prow * D;
+#pragma unroll
+    for (int ct = 0; ct < 8; ++ct) {
+      const f32x4 ga = *(const f32x4*)(ga_l + 16 * ct + 4 * g);
+      const f32x4 be = *(const f32x4*)(be_l + 16 * ct + 4 * g);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) y[ct][t] = (y[ct][t] - mean) * rstd * ga[t] + be[t];
+      if (p0 + j < n) *(f32x4*)(yrow + 16 * ct + 4 * g) = y[ct];
+    }
+    // mask embeddings of the queries as A fragments of the transposed logits product, E[query 16 qt + j][16 S + 4 g ..+3]:
+    // re-read per group (16 KB, cache resident; requested behind the next group's rows, which went out three heads ago) --
+    // held in registers for the whole group they cost 64 registers next to xp, y and the prefetch (spills)
+    f32x4 ef[QT][8];
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) {
+      const float* er = sm.E + (size_t)min(qt * 16 + j, nq - 1) * D + 4 * g;
+#pragma unroll
+      for (int S = 0; S < 8; ++S) ef[qt][S] = *(const f32x4*)(er + 16 * S);
+    }
+    // logits^T: lg[qt][t] = logit of query 16 qt + 4 g + t for point j (rows >= nq repeat the last query: never selected)
+    f32x4 lg[QT];
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) {
+      lg[qt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int S = 0; S < 8; ++S)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) lg[qt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ef[qt][S][t], y[S][t], lg[qt], 0, 0, 0);
+    }
+    // per-object max over the object's queries (k_out_ln_mask's order of comparisons: ascending query index; max is
+    // order-independent), first-max argmax over the objects
+    float best = 0.f;
+    int bi = 0;
+    for (int o = 0; o <= K; ++o) {
+      const int qb = o == 0 ? n_fg : qr_l[o], qe = o == 0 ? nq : qr_l[o + 1];
+      float mxv = -3.4e38f;
+#pragma unroll
+      for (int qt = 0; qt < QT; ++qt)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const int q = qt * 16 + 4 * g + t;
+          if (q >= qb && q < qe) mxv = fmaxf(mxv, lg[qt][t]);
+        }
+      mxv = rows_max(mxv);
+      if (g == (o & 3)) Ow[j * (K + 1) + o] = mxv;
+      if (o == 0 || mxv > best) {
+        best = mxv;
+        bi = o;
+      }
+    }
+    if (g == 0 && p0 + j < n) {
+      labels[p0 + j] = (unsigned char)bi;
+      atomicAdd(&hist[bi], 1);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // wave-private staging: written above, read below by other lanes
+    const int rows = min(16, n - p0);
+    for (int e = lane; e < rows * (K + 1); e += 64) logits[(size_t)p0 * (K + 1) + e] = Ow[e];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // rewritten by the next group
+    grp = next;
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e <= K; e += 512)
+    if (hist[e]) atomicAdd(&counts[e], hist[e]);
+}
+
 // ------------------------------------------------------------------------------ query side
 struct QueryLayerW {
   const float *c2s_in_wt, *c2s_in_b, *c2s_out_wt, *c2s_out_b, *c2s_norm_w, *c2s_norm_b;
@@ -1706,6 +1971,8 @@ static int run_decoder(const a3d_decoder_weights* w, Prepared* P, int ns, hipStr
       (void)hipFuncSetAttribute((const void*)k_out_ln_mask<2>, hipFuncAttributeMaxDynamicSharedMemorySize, big_lds);
       (void)hipFuncSetAttribute((const void*)k_out_ln_mask<3>, hipFuncAttributeMaxDynamicSharedMemorySize, big_lds);
       (void)hipFuncSetAttribute((const void*)k_out_ln_mask<4>, hipFuncAttributeMaxDynamicSharedMemorySize, big_lds);
+      (void)hipFuncSetAttribute((const void*)k_s2c_out<1>, hipFuncAttributeMaxDynamicSharedMemorySize, big_lds);
+      (void)hipFuncSetAttribute((const void*)k_s2c_out<2>, hipFuncAttributeMaxDynamicSharedMemorySize, big_lds);
       (void)hipFuncSetAttribute((const void*)k_kv_c2s<1>, hipFuncAttributeMaxDynamicSharedMemorySize, big_lds);
       (void)hipFuncSetAttribute((const void*)k_kv_c2s<2>, hipFuncAttributeMaxDynamicSharedMemorySize, big_lds);
       (void)hipFuncSetAttribute((const void*)k_ln_mask<4>, hipFuncAttributeMaxDynamicSharedMemorySize, big_lds);
@@ -1737,6 +2004,17 @@ static int run_decoder(const a3d_decoder_weights* w, Prepared* P, int ns, hipStr
   const bool fuse_c2s = fused_c2s() && QT <= 2;
   const bool fuse_s2c = fused_c2s() && nblk == 1;
   const bool fuse_out = fuse_s2c && fused_lds <= 160 * 1024;
+  // scene-to-click + output projection + LayerNorm + mask head as ONE kernel when both packed weight matrices and the
+  // queries' compact keys / values fit the LDS (about 24 queries at 5 objects); A3D_FUSED_S2C=0 keeps the two kernels
+  const int nqr_max = (nq_max + 3) & ~3;
+  const size_t s2c_out_lds = (size_t)128 * 1024 + ((size_t)nqr_max * 132 + (size_t)D * (nqr_max + 4) + 4 * D +
+                                                   (size_t)8 * 16 * (Kmax + 1) + 2 * Kmax + 3) * 4;
+  static int fused_s2c_env = -1;
+  if (fused_s2c_env < 0) {
+    const char* e = getenv("A3D_FUSED_S2C");
+    fused_s2c_env = e ? atoi(e) : 1;
+  }
+  const bool fuse_all = fuse_out && fused_s2c_env && QT <= 2 && s2c_out_lds <= 160 * 1024;
   // ---- sample table: workgroups of the persistent kernels in proportion to the samples' point groups
   int grid = 0;
   DecSampleDev* samples_dev = (DecSampleDev*)(P[0].ws + P[0].L.desc);
@@ -1883,6 +2161,16 @@ static int run_decoder(const a3d_decoder_weights* w, Prepared* P, int ns, hipStr
               h[8] - h[0]);
     }
     // ---- scene-to-click: Q = (src + pos) Wq^T + bq; attention; Y = O Wo^T + bo + src; LN
+    if (fuse_all) {
+      // the whole half in one pass: O never reaches HBM (k_s2c_out)
+      ProfScope ps(st, A3D_PROF_S2C, 0, 0, 0, 0, (int)n_total);
+      if constexpr (QT <= 2) {
+        k_s2c_out<QT><<<grid, 512, s2c_out_lds, st>>>(samples_dev, ns, l, LW.s2c_wq_packed, LW.s2c_in_b, LW.s2c_wo_packed,
+                                                      LW.s2c_out_b, LW.s2c_norm_w, LW.s2c_norm_b, nqr_max, Kmax);
+      }
+      A3D_LAUNCH_CHECK();
+      continue;
+    }
     if (fuse_s2c) {
       ProfScope ps(st, A3D_PROF_S2C, 0, 0, 0, 0, (int)n_total);
       static int dec_dbg = -1;

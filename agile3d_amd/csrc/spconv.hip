@@ -33,6 +33,11 @@ namespace a3d {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+static int sk_env_early(const char* name, int dflt) {
+  const char* e = getenv(name);
+  return e ? atoi(e) : dflt;
+}
+
 struct ConvArgs {
   const float* in;
   int ldi, n_in;
@@ -138,6 +143,11 @@ __global__ void __launch_bounds__(256, PAIR ? ((BN <= 96 && CH <= 32) ? 4 : 3) :
   const int cin16 = a.c.cin >> 4, cout16 = a.c.cout >> 4;
 
   if (DBG && (a.dbg & 32)) return;   // launch only
+  // A3D_DBG & 128: one line per workgroup (ticket, XCC / HW ids, start / end cycles, stages, cycles spent at stage ends and in
+  // the hand-off wait) -- tools/wg_timeline.py
+  unsigned long long tl_t0 = 0, tl_wait = 0, tl_hand = 0;
+  int tl_stages = 0, tl_tiles = 0;
+  if (DBG && (a.dbg & 128)) tl_t0 = __builtin_amdgcn_s_memtime();
   int w = blockIdx.x;
   const long long pre_T = a.pre ? (long long)a.pre[T] : (long long)K * T;   // requested before the ticket's round trip
   if (a.ticket) {
@@ -408,8 +418,16 @@ __global__ void __launch_bounds__(256, PAIR ? ((BN <= 96 && CH <= 32) ? 4 : 3) :
           load_stage(A1, k2, c2, 1, rows_cur);
         }
         compute(A0, k, 0);
-        wait_all_vmem();
-        __builtin_amdgcn_s_barrier();
+        if (DBG && (a.dbg & 256)) {
+          const unsigned long long tw = __builtin_amdgcn_s_memtime();
+          wait_all_vmem();
+          __builtin_amdgcn_s_barrier();
+          tl_wait += __builtin_amdgcn_s_memtime() - tw;
+        } else {
+          wait_all_vmem();
+          __builtin_amdgcn_s_barrier();
+        }
+        if (DBG) ++tl_stages;
         if (--rem == 0) break;
         k = k2; c = c2;
         // ---- odd stage: multiply A1 / slot 1, fetch A0 / slot 0
@@ -424,8 +442,16 @@ __global__ void __launch_bounds__(256, PAIR ? ((BN <= 96 && CH <= 32) ? 4 : 3) :
           load_stage(A0, k2, c2, 0, rows_cur);
         }
         compute(A1, k, 1);
-        wait_all_vmem();
-        __builtin_amdgcn_s_barrier();
+        if (DBG && (a.dbg & 256)) {
+          const unsigned long long tw = __builtin_amdgcn_s_memtime();
+          wait_all_vmem();
+          __builtin_amdgcn_s_barrier();
+          tl_wait += __builtin_amdgcn_s_memtime() - tw;
+        } else {
+          wait_all_vmem();
+          __builtin_amdgcn_s_barrier();
+        }
+        if (DBG) ++tl_stages;
         if (--rem == 0) break;
         k = k2; c = c2;
       }
@@ -452,6 +478,7 @@ __global__ void __launch_bounds__(256, PAIR ? ((BN <= 96 && CH <= 32) ? 4 : 3) :
         const int wf = (int)(((Cu + ov + 1) * G + tot - 1) / tot) - 1;
         // every flag is polled by its own thread; ONE acquire for the workgroup; then the parts are read with all
         // their loads in flight and added in a fixed order
+        const unsigned long long th0 = (DBG && (a.dbg & 128)) ? __builtin_amdgcn_s_memtime() : 0ull;
         for (int wp = wf + tid; wp < w; wp += 256) {
           unsigned spins = 0;
           while (__hip_atomic_load(a.flags + wp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
@@ -465,6 +492,7 @@ __global__ void __launch_bounds__(256, PAIR ? ((BN <= 96 && CH <= 32) ? 4 : 3) :
         __syncthreads();
         if (tid == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         __syncthreads();
+        if (DBG && (a.dbg & 128)) tl_hand += __builtin_amdgcn_s_memtime() - th0;
         const float* P0 = a.slab + (size_t)tid * 4;
         // fixed order: own part, then the parts of the tickets below, descending; U parts' loads in flight at a time
         constexpr int U = NCT <= 4 ? 2 : 1;
@@ -515,7 +543,175 @@ __global__ void __launch_bounds__(256, PAIR ? ((BN <= 96 && CH <= 32) ? 4 : 3) :
         }
       }
     }
+    if (DBG) ++tl_tiles;
   }
+  if (DBG && (a.dbg & 128) && tid == 0) {
+    unsigned hwid, xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    printf("TL w %d xcc %u hw %u t0 %llu t1 %llu stages %d tiles %d wait %llu hand %llu\n", w, xcc & 15u, hwid, tl_t0,
+           (unsigned long long)__builtin_amdgcn_s_memtime(), tl_stages, tl_tiles, tl_wait, tl_hand);
+  }
+}
+
+// ------------------------------------------------------------------------------ k_conv_wl
+// Gathered convolution with the WHOLE packed weight set resident in LDS (K cin cout 4 bytes <= 144 KB: the 3^3 32 -> 32
+// layers of level 1, 110 KB, and the 2^3 stride-2 layers 32 -> 32 / 64 -> 64).  With 32 input channels a stage of
+// k_conv_sk is 16 MFMAs per wave between two workgroup barriers, each behind a global-memory round trip: latency-bound
+// (35 TF/s on 72 k rows).  Here nothing is shared after the one-time weight load, so there is no barrier and no weight
+// DMA in the loop: one persistent workgroup per CU, 16 waves, every wave walks its own sequence of 16-row groups
+// (group i -> wave i mod W: rows are sorted by neighbour mask, so every wave gets the same mix of light and heavy
+// groups); per (group, present offset): one neighbour-index load two pairs ahead, the gathered A fragments one pair
+// ahead, NS NCT ds_read_b128 + 4 NS NCT MFMAs.  Same summation order per output element as k_conv_sk run without
+// hand-offs (offsets ascending, channels ascending), so results are bit-identical to it.
+template <int NS, int NCT>
+__global__ void __launch_bounds__(1024) k_conv_wl(const ConvArgs c, int ngroups) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  f32x4* Wl = (f32x4*)smem;   // [K][NS][NCT][64]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), nw = blockDim.x >> 6;
+  const int g = lane >> 4, j = lane & 15;
+  const int K = c.K;
+  if (blockIdx.x == 0 && c.zero_row >= 0)
+    for (int cidx = tid; cidx < c.cout; cidx += blockDim.x) c.out[(size_t)c.zero_row * c.ldo + cidx] = 0.f;
+  const int W = gridDim.x * nw;
+  int grp = wave * gridDim.x + blockIdx.x;   // consecutive groups on different CUs
+  const uint32_t full = K >= 32 ? 0xffffffffu : (1u << K) - 1u;
+  auto mask_of = [&](int gq) -> uint32_t {
+    return gq < ngroups ? (c.gmask ? c.gmask[gq] & full : full) : 0u;
+  };
+  // ---- pipeline state: pair p0 = (g0, k0) is multiplied, p1 has its A fragments in flight, p2 its row index
+  auto row_index = [&](int gq, int k) -> int {
+    return c.nbr[(size_t)k * c.nbr_stride + gq * 16 + j];
+  };
+  const char* inb = (const char*)c.in;
+  const unsigned row_bytes = (unsigned)c.ldi * 4u;
+  auto load_a = [&](f32x4 (&A)[NS], int idx) {
+    const char* ar = inb + (size_t)(unsigned)idx * row_bytes + 16u * g;
+#pragma unroll
+    for (int S = 0; S < NS; ++S) A[S] = *(const f32x4*)(ar + 64 * S);
+  };
+  // iterator over (group, offset) pairs of this wave: (gq, rest) -> next pair; groups without offsets are skipped
+  int it_g = grp;
+  uint32_t it_m = mask_of(it_g);
+  uint32_t it_mnext = mask_of(it_g + W);   // the mask of the group after: requested a whole group ahead
+  auto advance = [&](int& og, int& ok) -> bool {   // false: no more pairs
+    while (it_m == 0u) {
+      if (it_g >= ngroups) return false;
+      it_g += W;
+      it_m = it_mnext;
+      it_mnext = mask_of(it_g + W);
+    }
+    ok = __builtin_ctz(it_m);
+    og = it_g;
+    it_m &= it_m - 1u;
+    return true;
+  };
+  // pipeline: pair p0 is multiplied, p1 and p2 have their A fragments in flight, p3 its row index (a pair's 4 NS NCT
+  // MFMAs take 0.2-0.9 us of a SIMD shared by four waves; a gathered row takes 1-2 us under load: two pairs of cover)
+  int g0 = 0, k0 = 0, g1 = 0, k1 = 0, g2 = 0, k2 = 0, g3 = 0, k3 = 0;
+  bool v0 = advance(g0, k0), v1 = v0 && advance(g1, k1), v2 = v1 && advance(g2, k2), v3 = v2 && advance(g3, k3);
+  int idx3 = 0;
+  f32x4 A0[NS], A1[NS], A2[NS];
+  {
+    int i0 = 0, i1 = 0, i2 = 0;
+    if (v0) i0 = row_index(g0, k0);
+    if (v1) i1 = row_index(g1, k1);
+    if (v2) i2 = row_index(g2, k2);
+    if (v3) idx3 = row_index(g3, k3);
+    if (v0) load_a(A0, i0);
+    if (v1) load_a(A1, i1);
+    if (v2) load_a(A2, i2);
+  }
+  {  // the packed weights: 8 independent 16-byte loads in flight per thread, then the LDS stores
+    const int TOT = K * NS * NCT * 64, bd = blockDim.x;
+    for (int base = tid; base < TOT; base += 8 * bd) {
+      f32x4 t8[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (base + u * bd < TOT) t8[u] = ((const f32x4*)c.w)[base + u * bd];
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (base + u * bd < TOT) Wl[base + u * bd] = t8[u];
+    }
+  }
+  __syncthreads();
+  f32x4 acc[NCT];
+#pragma unroll
+  for (int ct = 0; ct < NCT; ++ct) acc[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  while (v0) {
+    // fragments of the pair three ahead (its index was requested an iteration ago), the index of the pair four ahead
+    f32x4 A3[NS];
+    if (v3) load_a(A3, idx3);
+    int g4 = 0, k4 = 0;
+    const bool v4 = v3 && advance(g4, k4);
+    if (v4) idx3 = row_index(g4, k4);
+    const f32x4* Ws = Wl + (size_t)k0 * (NS * NCT * 64) + lane;
+#pragma unroll
+    for (int S = 0; S < NS; ++S) {
+      f32x4 b[NCT];
+#pragma unroll
+      for (int ct = 0; ct < NCT; ++ct) b[ct] = Ws[(S * NCT + ct) * 64];
+#pragma unroll
+      for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct) acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[ct][tt], A0[S][tt], acc[ct], 0, 0, 0);
+    }
+    if (!v1 || g1 != g0) {   // last offset of group g0: epilogue (as k_conv_sk's)
+      const int myrow = g0 * 16 + j;
+      if (myrow < c.n_out) {
+        const int orow = c.out_map ? c.out_map[myrow] : myrow;
+        float* po = c.out + (size_t)orow * c.ldo + 4 * g;
+        const float* pr = c.res ? c.res + (size_t)orow * c.ldr + 4 * g : nullptr;
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct) {
+          f32x4 v = acc[ct];
+          if (c.scale) v *= *(const f32x4*)(c.scale + ct * 16 + 4 * g);
+          if (c.shift) v += *(const f32x4*)(c.shift + ct * 16 + 4 * g);
+          if (pr) v += *(const f32x4*)(pr + ct * 16);
+          if (c.relu) {
+#pragma unroll
+            for (int tt = 0; tt < 4; ++tt) v[tt] = fmaxf(v[tt], 0.f);
+          }
+          *(f32x4*)(po + ct * 16) = v;
+        }
+      }
+#pragma unroll
+      for (int ct = 0; ct < NCT; ++ct) acc[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int S = 0; S < NS; ++S) {
+      A0[S] = A1[S];
+      A1[S] = A2[S];
+      A2[S] = A3[S];
+    }
+    g0 = g1, k0 = k1, v0 = v1;
+    g1 = g2, k1 = k2, v1 = v2;
+    g2 = g3, k2 = k3, v2 = v3;
+    g3 = g4, k3 = k4, v3 = v4;
+  }
+}
+
+static bool conv_wl_supported(const ConvArgs& c) {
+  static int off = sk_env_early("A3D_NO_WL", 0);
+  if (off || c.K <= 1 || !c.nbr || !c.gmask) return false;
+  if (!(c.cin == 32 && c.cout == 32)) return false;   // 64 -> 64 stride-2 (128 KB) measured slower than k_conv_sk (21 vs 18 us)
+  return (size_t)c.K * c.cin * c.cout * 4 <= 144 * 1024;
+}
+
+static int launch_conv_wl(const ConvArgs& c, hipStream_t st) {
+  const int ngroups = (c.n_out + 15) / 16;
+  const size_t lds = (size_t)c.K * c.cin * c.cout * 4;
+  // one workgroup per CU; 16 waves when there are groups for them, never fewer than 4
+  int grid = 256, nw = 16;
+  while (nw > 4 && (long long)grid * nw > 2LL * ngroups) nw >>= 1;
+  if ((long long)grid * nw > ngroups) grid = (ngroups + nw - 1) / nw;
+  if (grid < 1) grid = 1;
+  ProfScope ps(st, A3D_PROF_SPCONV, c.cout, c.K, c.cin, c.cout, c.n_out, c.tag_table, c.tag_level, 0);   // stage width 0: k_conv_wl
+  if (c.cin == 32) k_conv_wl<2, 2><<<grid, 64 * nw, lds, st>>>(c, ngroups);
+  else k_conv_wl<4, 4><<<grid, 64 * nw, lds, st>>>(c, ngroups);
+  A3D_LAUNCH_CHECK();
+  return A3D_OK;
 }
 
 // ------------------------------------------------------------------------------ dense GEMM
@@ -1011,8 +1207,11 @@ static void allow_big_lds() {
   (void)hipFuncSetAttribute((const void*)k_conv_sk<32, 32, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   (void)hipFuncSetAttribute((const void*)k_conv_sk<64, 64, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   (void)hipFuncSetAttribute((const void*)k_conv_sk<96, 32, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  (void)hipFuncSetAttribute((const void*)k_conv_sk<96, 32, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   (void)hipFuncSetAttribute((const void*)k_conv_sk<96, 96, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   (void)hipFuncSetAttribute((const void*)k_conv_sk<128, 64, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  (void)hipFuncSetAttribute((const void*)k_conv_wl<2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  (void)hipFuncSetAttribute((const void*)k_conv_wl<4, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   (void)hipFuncSetAttribute((const void*)k_dense<8, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   (void)hipFuncSetAttribute((const void*)k_dense<8, 6>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   (void)hipFuncSetAttribute((const void*)k_dense<6, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -1034,6 +1233,7 @@ static int launch_conv_sk(ConvArgs c, const int* pre64, float* slab_ws, size_t s
     set_error("spconv: input of %d rows x %d floats exceeds the 4 GB gather window", c.n_in, c.ldi);
     return A3D_ERR_UNSUPPORTED;
   }
+  if (conv_wl_supported(c) && !conv_emu(c.K, c.cin, c.cout)) return launch_conv_wl(c, st);
   // hand-offs (shares cut inside tiles) pay where a tile is long and tiles are few: the 3^3 maps, and the 2^3 maps of
   // the small levels.  1x1 layers and 2^3 maps with a tile per workgroup slot or more run whole tiles: no ticket, no
   // search, no flags -- their fixed latency is what matters
@@ -1078,6 +1278,7 @@ static int launch_conv_sk(ConvArgs c, const int* pre64, float* slab_ws, size_t s
   if (a.dbg) {   // ablation builds of the two shapes the measurements of DESIGN.md 4.1 use
     if (p.bn == 64 && p.ch == 64 && p.pair == 0) k_conv_sk<64, 64, 0, true><<<p.G, 256, p.lds, st>>>(a);
     else if (p.bn == 96 && p.ch == 32 && p.pair == 0) k_conv_sk<96, 32, 0, true><<<p.G, 256, p.lds, st>>>(a);
+    else if (p.bn == 96 && p.ch == 32 && p.pair == 1) k_conv_sk<96, 32, 1, true><<<p.G, 256, p.lds, st>>>(a);
     else if (p.bn == 96 && p.ch == 96 && p.pair == 0) k_conv_sk<96, 96, 0, true><<<p.G, 256, p.lds, st>>>(a);
     else if (p.bn == 128 && p.ch == 64 && p.pair == 0) k_conv_sk<128, 64, 0, true><<<p.G, 256, p.lds, st>>>(a);
     else a.dbg = 0;

@@ -168,6 +168,62 @@ def allreduce_mean_(grads: dict, group=None, bucket_bytes: int = 64 << 20):
     return grads
 
 
+class OverlappedAllReduce:
+    """Gradient averaging overlapped with the backward pass: gradients are handed over as they become final
+    (``add``), packed into buckets of ``bucket_bytes`` and all-reduced asynchronously while the layers below are
+    still being differentiated; ``finish`` waits, divides by the world size and writes the averages back.
+
+    Order of completion in a training iteration: the decoder's parameters (all tapes done), then the U-Net from
+    ``lin_squeeze_head`` / block8 down to the stem -- so the first buckets fly during the 20+ ms of backbone
+    backward.  RCCL (backend nccl): the collective runs on the process group's own stream, which is ordered behind
+    the stream that produced the bucket; gloo (CPU tests / two ranks on one GPU): the bucket is staged to host
+    memory and reduced by gloo's thread.  Results do not depend on the bucket layout for two ranks (a sum of two
+    numbers has one order); for more ranks a ring's order per element follows the layout, like any bucketed DDP."""
+
+    def __init__(self, group=None, bucket_bytes: int = 32 << 20):
+        import torch.distributed as dist
+        self.group, self.bucket_bytes = group, bucket_bytes
+        self.active = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+        self.world = dist.get_world_size(group) if self.active else 1
+        self.gloo = self.active and dist.get_backend(group) == "gloo"
+        self.pending, self.pending_bytes, self.flights = [], 0, []
+
+    def add(self, name, g):
+        if not self.active:
+            return
+        self.pending.append((name, g))
+        self.pending_bytes += g.numel() * 4
+        if self.pending_bytes >= self.bucket_bytes:
+            self.flush()
+
+    def flush(self):
+        import torch.distributed as dist
+        if not self.active or not self.pending:
+            return
+        items, self.pending, self.pending_bytes = self.pending, [], 0
+        flat = torch.cat([g.reshape(-1) for _, g in items])
+        buf = flat.cpu() if (self.gloo and flat.is_cuda) else flat
+        work = dist.all_reduce(buf, group=self.group, async_op=True)
+        self.flights.append((items, flat, buf, work))
+
+    def finish(self, grads: dict):
+        """Wait for every bucket and write the averaged gradients into ``grads`` (in place where the tensor is there)."""
+        self.flush()
+        for items, flat, buf, work in self.flights:
+            work.wait()
+            if buf is not flat:
+                flat.copy_(buf)
+            flat /= self.world
+            off = 0
+            for n, g in items:
+                k = g.numel()
+                g.copy_(flat[off:off + k].view_as(g))
+                grads[n] = g
+                off += k
+        self.flights = []
+        return grads
+
+
 # ---- optimiser state in torch.optim.AdamW's state_dict() layout (so checkpoints interchange with the reference's)
 def _adamw_state_dict(self):
     names = list(self.params)

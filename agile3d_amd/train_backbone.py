@@ -236,8 +236,11 @@ class BackboneTape:
         self.output = pcd
 
     # ------------------------------------------------------------------ backward
-    def backward(self, d_output: torch.Tensor) -> dict:
-        """``d_output`` = dL/d(pcd_features) [N, 128] in the caller's row order -> gradients keyed like state_dict()."""
+    def backward(self, d_output: torch.Tensor, on_grad=None) -> dict:
+        """``d_output`` = dL/d(pcd_features) [N, 128] in the caller's row order -> gradients keyed like state_dict().
+        ``on_grad(name, tensor)`` is called for every parameter as soon as its gradient is final (every backbone
+        parameter is used by exactly one layer): the data-parallel all-reduce starts on the upper U-Net's gradients
+        while the encoder is still being differentiated (optim.OverlappedAllReduce)."""
         head = self.model.lin_squeeze_head
         n0 = self.scene.n[0]
         g = torch.zeros((n0 + 1, d_output.shape[1]), dtype=torch.float32, device=d_output.device)
@@ -245,6 +248,12 @@ class BackboneTape:
         self.grads = {}
         self._pgrad(head.bias, B.column_sums(g[:n0]))
         self.head_out.g = g
+        seen = set()
         for back in reversed(self.steps):
             back()
+            if on_grad is not None and len(self.grads) != len(seen):
+                for k in self.grads:
+                    if k not in seen:
+                        seen.add(k)
+                        on_grad(k, self.grads[k])
         return self.grads

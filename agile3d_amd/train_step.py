@@ -118,11 +118,18 @@ def train_one_step(model, criterion, optimizer, batch, device, max_norm: float =
         for k, v in g.items():
             grads[k] = v if k not in grads else grads[k] + v
     mark("decoder backward")
-    grads.update(bb.backward(d_pcd))
+    # ---- data-parallel average (engine.py runs under DDP: main.py:115-127), overlapped with the backbone backward: the
+    # decoder's gradients are final here, the U-Net's become final from the head down to the stem
+    from .optim import OverlappedAllReduce
+    reducer = OverlappedAllReduce(bucket_bytes=int(float(os.environ.get("A3D_DP_BUCKET_MB", "32")) * (1 << 20)))
+    for k in sorted(grads):
+        reducer.add(k, grads[k])
+    reducer.flush()
+    grads.update(bb.backward(d_pcd, on_grad=reducer.add if reducer.active else None))
     mark("backbone backward")
+    reducer.finish(grads)
 
-    # ---- data-parallel average, clip, AdamW (engine.py:143-150)
-    allreduce_mean_(grads)
+    # ---- clip, AdamW (engine.py:143-150)
     norm, coef = clip_grad_norm_(grads, max_norm)
     optimizer.step(grads, coef)
     eng.mark_stale()

@@ -87,6 +87,18 @@ def main():
         torch.save({"params": {k: v.detach().cpu() for k, v in model.named_parameters()}, "stats": st,
                     "grads": {k: v.cpu() for k, v in opt.grads.items()}, "coef": opt.coef},
                    os.path.join(out, f"dp_{rank}.pt"))
+    elif mode == "dp_epoch":
+        # train_one_epoch over three batches with the library's AdamW; A3D_DP_BUCKET_MB (set by the test) makes the
+        # overlapped all-reduce issue many small buckets while the backbone backward is still running
+        from agile3d_amd.criterion import build_mask_criterion
+        from agile3d_amd.optim import AdamW
+        from agile3d_amd.train_step import train_one_epoch
+        loader = [scene_batch(80 + 10 * i + rank, 2300 + 150 * i + 100 * rank)[1] for i in range(3)]
+        opt = AdamW(model.named_parameters(), lr=1e-3, weight_decay=1e-4)
+        np.random.seed(21 + rank), torch.manual_seed(21 + rank), random.seed(21 + rank)
+        stats, it = train_one_epoch(model, build_mask_criterion(args), loader, opt, dev, epoch=0, max_norm=0.1, log=None)
+        torch.save({"params": {k: v.detach().cpu() for k, v in model.named_parameters()}, "stats": stats, "iters": it},
+                   os.path.join(out, f"epoch_{rank}.pt"))
     dist.barrier()
     dist.destroy_process_group()
 

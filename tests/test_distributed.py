@@ -89,6 +89,51 @@ def _grad_worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
+def _overlap_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from agile3d_amd.optim import OverlappedAllReduce
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    g = torch.Generator().manual_seed(200 + rank)
+    shapes = [(27, 32, 32), (96,), (5, 7), (1, 128), (8, 96, 96), (256,)]
+    grads = {f"p{i}": torch.randn(shape, generator=g) for i, shape in enumerate(shapes)}
+    before = {k: v.clone() for k, v in grads.items()}
+    red = OverlappedAllReduce(bucket_bytes=27 * 32 * 32 * 4)             # several buckets in flight at once
+    assert red.active and red.world == world
+    for k in ["p3", "p1", "p0"]:                                         # handed over as they "become final" ...
+        red.add(k, grads[k])
+    other = torch.randn(64, 64, generator=g) @ torch.randn(64, 64, generator=g)   # ... with work in between
+    for k in ["p5", "p4", "p2"]:
+        red.add(k, grads[k])
+    out = red.finish({})
+    assert sorted(out) == sorted(grads) and all(out[k] is grads[k] for k in grads) and other.shape == (64, 64)
+    q.put((rank, {k: v.numpy() for k, v in before.items()}, {k: v.numpy() for k, v in grads.items()}))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_overlapped_allreduce_world2():
+    """optim.OverlappedAllReduce (what train_one_step uses): gradients handed over one by one, asynchronous buckets, every
+    rank ends with the mean in the tensors it handed over."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_overlap_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=120) for _ in range(world)), key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (_, b0, a0), (_, b1, a1) = res
+    for k in b0:
+        want = (b0[k] + b1[k]) / 2
+        assert a0[k].shape == b0[k].shape and np.allclose(a0[k], want, atol=1e-7) and np.array_equal(a0[k], a1[k])
+
+
 def test_gradient_allreduce_mean_world2():
     """Training DP: every rank ends up with the mean of the ranks' gradients, tensor shapes untouched."""
     world = 2

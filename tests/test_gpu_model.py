@@ -421,3 +421,55 @@ def test_training_mode_forward_invalidates_the_folded_backbone():
     moved = (after - before).abs().max().item()
     print(f"eval after a train-mode forward: vs oracle on the new statistics {err:.2e}; moved by {moved:.2e}")
     assert moved > 1e-3 and err <= TOL * max(1.0, ref["pcd_features"].abs().max().item())
+
+
+def test_one_pass_scene_to_click_half_matches_the_two_kernel_path(tmp_path):
+    """k_s2c_out (scene-to-click attention + output projection + LayerNorm + mask head in one pass, <= ~24 queries,
+    default) against k_q_s2c + k_out_ln_mask (A3D_FUSED_S2C=0): same arithmetic per element, so the logits, the label
+    bytes feeding the next layer's attention mask and the intermediate (aux) logits agree to rounding; both against the
+    reference's goldens.  The switch is read once per process -> two interpreters."""
+    import subprocess
+    import sys
+    script = r'''
+import sys, numpy as np, torch
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[1] + "/tests")
+from agile3d_amd import SparseTensor, build_model, default_args, randomize_bn_stats
+from agile3d_amd.synthetic import make_clicks, make_scene
+from conftest import arrays_to_clicks, load_case
+torch.manual_seed(0)
+model = randomize_bn_stats(build_model(default_args())).eval().cuda()
+outs, worst = [], 0.0
+for name in ("n4096_k5x2", "n3000_k10_bg", "n2048_k1"):
+    c = load_case(name)
+    ci, ct = arrays_to_clicks(c["click_rows"], c["click_objs"], c["click_times"], int(c["K"]))
+    r = model._get_engine().decoder_inputs(torch.from_numpy(c["feats128"]), torch.from_numpy(c["xyz"]))
+    out = model.forward_mask(*r, click_idx=[ci], click_time_idx=[ct])
+    got = [a["pred_masks"][0] for a in out["aux_outputs"]] + [out["pred_masks"][0]]
+    for i in range(3):
+        worst = max(worst, float(np.abs(got[i].cpu().numpy() - c[f"logits{i}"]).max()))
+        outs.append(got[i].cpu().numpy())
+assert worst <= 1e-3, worst
+# a batch of two scenes with different query counts (12 and 20 queries) through forward_backbone + forward_mask
+scs = [make_scene(5000, seed=21, batch_index=0), make_scene(7000, seed=22, batch_index=1)]
+cl = [make_clicks(scs[0]["labels"], 1, 2, 0, seed=1), make_clicks(scs[1]["labels"], 5, 2, 0, seed=2)]
+x = SparseTensor(features=torch.from_numpy(np.concatenate([s["feats"] for s in scs])).cuda(),
+                 coordinates=torch.from_numpy(np.concatenate([s["coords"] for s in scs])).cuda())
+r = model.forward_backbone(x, raw_coordinates=torch.from_numpy(np.concatenate([s["raw_xyz"] for s in scs])).cuda())
+o = model.forward_mask(*r, click_idx=[c[0] for c in cl], click_time_idx=[c[1] for c in cl])
+outs += [p.cpu().numpy() for p in o["pred_masks"]]
+np.savez(sys.argv[2], *outs)
+print("WORST", worst)
+'''
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = {}
+    for sw in ("0", "1"):
+        out = str(tmp_path / f"logits_{sw}.npz")
+        env = dict(os.environ, A3D_FUSED_S2C=sw)
+        subprocess.run([sys.executable, "-c", script, root, out], check=True, env=env, timeout=600)
+        z = np.load(out)
+        res[sw] = [z[k] for k in z.files]
+    assert len(res["0"]) == len(res["1"]) == 11
+    worst = max(float(np.abs(a - b).max()) for a, b in zip(res["0"], res["1"]))
+    scale = max(float(np.abs(a).max()) for a in res["0"])
+    print(f"one-pass scene-to-click half vs two kernels: max |diff| {worst:.2e} on logits of scale {scale:.1f}")
+    assert worst <= 1e-4 * max(1.0, scale)

@@ -12,8 +12,10 @@ torch.manual_seed(0)
 model = randomize_bn_stats(build_model(default_args())).eval().cuda()
 import numpy as np
 B = int(os.environ.get("LT_BATCH", "1"))
-scs = [make_scene(80_000, seed=b, batch_index=b) for b in range(B)]
-cl = [make_clicks(s["labels"], 5, 2, 0, seed=b) for b, s in enumerate(scs)]
+VOX = int(os.environ.get("LT_VOXELS", "80000"))      # LT_VOXELS=300000 LT_CPO=4: BASELINE.json config 5 (300 k voxels, 20 clicks)
+CPO = int(os.environ.get("LT_CPO", "2"))
+scs = [make_scene(VOX, seed=b, batch_index=b) for b in range(B)]
+cl = [make_clicks(s["labels"], 5, CPO, 0, seed=b) for b, s in enumerate(scs)]
 cis, cts = [c[0] for c in cl], [c[1] for c in cl]
 coords, feats, raw = (torch.from_numpy(np.concatenate([s[k] for s in scs])).cuda() for k in ("coords", "feats", "raw_xyz"))
 def step():

@@ -14,7 +14,7 @@ out = {"_note": "rocprofv3 --pmc passes of `python bench.py --steps-only --no-pr
                 "XCDs); bench.py reads hbm_bytes_per_launch of its dominant kernel as roofline.traffic."}
 for name, c in raw.items():
     short = name.replace("void ", "").replace("a3d::", "")
-    m = re.match(r"k_conv_sk<(\d+), (\d+), (\d+), (true|false)>", short)   # <BN, CH, PAIR, DBG>: bench.py's key is <BN,CH>
+    m = re.match(r"k_conv_sk<(\d+), (\d+), (\d+), (true|false)(, \d+)?>", short)   # <BN, CH, PAIR, DBG>: bench.py's key is <BN,CH>
     key = short
     if m:
         key = f"k_conv_sk<{m.group(1)},{m.group(2)}>"

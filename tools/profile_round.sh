@@ -22,4 +22,9 @@ rocprofv3 --pmc WRITE_SIZE --kernel-trace -d /tmp/$TAG/pmc_write -o p -- $PMC > 
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_LDS_BANK_CONFLICT SQ_WAVE_CYCLES --kernel-trace -d /tmp/$TAG/pmc_sq -o p -- $PMC > /dev/null 2> $OUT/pmc_sq.err
 PMC_JSON=$OUT/pmc_raw.json python $R/tools/rocprof_summary.py /tmp/$TAG/pmc_fetch /tmp/$TAG/pmc_write /tmp/$TAG/pmc_sq > $OUT/pmc_counters.txt 2>&1
 python $R/tools/pmc_to_summary.py $OUT/pmc_raw.json $OUT/pmc_summary.json
+# BASELINE.json config 5 (KITTI-like 300 k voxels, 20 clicks): its own bench line and per-launch table
+python $R/bench.py --voxels 300000 --clicks-per-object 4 --batch 1 --streams 2 --steps 10 --warmup 3 --reps 7 > $OUT/bench_config5.json 2> $OUT/bench_config5.err
+LT_BATCH=1 LT_VOXELS=300000 LT_CPO=4 python $R/tools/layer_table.py > $OUT/layer_table_config5.txt 2>&1
+LT_BATCH=4 python $R/tools/layer_table.py > $OUT/layer_table_4scenes.txt 2>&1
+LT_BATCH=1 python $R/tools/layer_table.py > $OUT/layer_table_1scene.txt 2>&1
 ls -la $OUT
