@@ -9,7 +9,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libagile3d_hip.so")
-SOURCES = ["scene.hip", "radix.hip", "spconv.hip", "decoder.hip", "clicks.hip", "quantize.hip", "criterion.hip", "wgrad.hip", "bnorm.hip", "optim.hip", "attn_train.hip"]
+SOURCES = ["scene.hip", "radix.hip", "spconv.hip", "decoder.hip", "clicks.hip", "quantize.hip", "criterion.hip", "wgrad.hip", "bnorm.hip", "optim.hip", "attn_train.hip", "attn_flash.hip"]
 
 
 STAMP = LIB + ".stamp"

@@ -378,29 +378,48 @@ __global__ void __launch_bounds__(512) k_kv_c2s(const DecSampleDev* __restrict__
       const float bvj = bv_l[16 * (h0 + hl) + j];
       vv[hl] = (f32x4){bvj, bvj, bvj, bvj};
     }
+    {
+      // weight fragments one (K-step, head) ahead of the eight MFMAs that use them: left to itself the compiler issues a
+      // step's ds_read_b128 right in front of their MFMAs and waits out the LDS latency three times per K-step
+      f32x4 wk = Wkl[(0 * 8 + h0) * 64 + lane], wv = Wvl[(0 * 8 + h0) * 64 + lane];
 #pragma unroll
-    for (int S = 0; S < 8; ++S) {
-      const f32x4 xp = xs[S] + pe[S];
+      for (int S = 0; S < 8; ++S) {
+        const f32x4 xp = xs[S] + pe[S];
 #pragma unroll
-      for (int hl = 0; hl < HW; ++hl) {
-        const f32x4 wk = Wkl[(S * 8 + h0 + hl) * 64 + lane], wv = Wvl[(S * 8 + h0 + hl) * 64 + lane];
+        for (int hl = 0; hl < HW; ++hl) {
+          const int i2 = S * HW + hl + 1, S2 = i2 / HW, hl2 = i2 % HW;
+          f32x4 nk = wk, nv = wv;
+          if (i2 < 8 * HW) {
+            nk = Wkl[(S2 * 8 + h0 + hl2) * 64 + lane];
+            nv = Wvl[(S2 * 8 + h0 + hl2) * 64 + lane];
+          }
+          __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-          kf[hl] = __builtin_amdgcn_mfma_f32_16x16x4f32(wk[t], xp[t], kf[hl], 0, 0, 0);
-          vv[hl] = __builtin_amdgcn_mfma_f32_16x16x4f32(xs[S][t], wv[t], vv[hl], 0, 0, 0);
+          for (int t = 0; t < 4; ++t) {
+            kf[hl] = __builtin_amdgcn_mfma_f32_16x16x4f32(wk[t], xp[t], kf[hl], 0, 0, 0);
+            vv[hl] = __builtin_amdgcn_mfma_f32_16x16x4f32(xs[S][t], wv[t], vv[hl], 0, 0, 0);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          wk = nk;
+          wv = nv;
         }
+        xs[S] = *(const f32x4*)(X + nrow * D + 16 * S + 4 * g);
+        pe[S] = *(const f32x4*)(Pe + nrow * D + 16 * S + 4 * g);
+        __builtin_amdgcn_sched_barrier(0);
       }
-      xs[S] = *(const f32x4*)(X + nrow * D + 16 * S + 4 * g);
-      pe[S] = *(const f32x4*)(Pe + nrow * D + 16 * S + 4 * g);
-      __builtin_amdgcn_sched_barrier(0);   // one k-step of weight fragments in registers at a time
     }
     // ---- attention of the 16 points against every query, flash-style running state per (head, query tile)
+    f32x4 qf_n = *(const f32x4*)(qp_l + j * LDQ + h0 * DH + 4 * g);   // the next tile's fragment, one tile ahead
 #pragma unroll
     for (int hl = 0; hl < HW; ++hl) {
       const int h = h0 + hl;
 #pragma unroll
       for (int qt = 0; qt < QT; ++qt) {
-        const f32x4 qf = *(const f32x4*)(qp_l + (qt * 16 + j) * LDQ + h * DH + 4 * g);
+        const f32x4 qf = qf_n;
+        {
+          const int i2 = hl * QT + qt + 1;
+          if (i2 < HW * QT) qf_n = *(const f32x4*)(qp_l + ((i2 % QT) * 16 + j) * LDQ + (h0 + i2 / QT) * DH + 4 * g);
+        }
         f32x4 sc4 = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int t = 0; t < 4; ++t) sc4 = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[hl][t], qf[t], sc4, 0, 0, 0);
@@ -1111,30 +1130,45 @@ __global__ void __launch_bounds__(512) k_s2c_out(const DecSampleDev* __restrict_
       f32x4 qf[2];
 #pragma unroll
       for (int u = 0; u < 2; ++u) qf[u] = *(const f32x4*)(bq_l + 16 * (h + u) + 4 * g);   // Q[point j][16h+4g..+3]
+      {
+        // weight fragments one K-step ahead of the MFMAs that use them (left to itself the compiler issues the two
+        // ds_read_b128 of a step right in front of its eight MFMAs and waits out the LDS latency every 256 cycles)
+        f32x4 w0 = Wql[(0 * 8 + h) * 64 + lane], w1 = Wql[(0 * 8 + h + 1) * 64 + lane];
 #pragma unroll
-      for (int S = 0; S < 8; ++S) {
-        f32x4 w[2];
+        for (int S = 0; S < 8; ++S) {
+          f32x4 n0 = w0, n1 = w1;
+          if (S + 1 < 8) {
+            n0 = Wql[((S + 1) * 8 + h) * 64 + lane];
+            n1 = Wql[((S + 1) * 8 + h + 1) * 64 + lane];
+          }
+          __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int u = 0; u < 2; ++u) w[u] = Wql[(S * 8 + h + u) * 64 + lane];
-#pragma unroll
-        for (int t = 0; t < 4; ++t)
-#pragma unroll
-          for (int u = 0; u < 2; ++u) qf[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[u][t], xp[S][t], qf[u], 0, 0, 0);
+          for (int t = 0; t < 4; ++t) {
+            qf[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(w0[t], xp[S][t], qf[0], 0, 0, 0);
+            qf[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(w1[t], xp[S][t], qf[1], 0, 0, 0);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          w0 = n0;
+          w1 = n1;
+        }
       }
       f32x4 sc[2][QT];
       float mx[2] = {kNegBig, kNegBig};
+      {
+        f32x4 kf[2][QT];
 #pragma unroll
-      for (int kt = 0; kt < QT; ++kt) {
-        f32x4 kf[2];
+        for (int kt = 0; kt < QT; ++kt)
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-          kf[u] = *(const f32x4*)(ks_l + (kt * 16 + j) * LD + (h + u) * DH + 4 * g);
-          sc[u][kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        }
+          for (int u = 0; u < 2; ++u) {
+            kf[u][kt] = *(const f32x4*)(ks_l + (kt * 16 + j) * LD + (h + u) * DH + 4 * g);
+            sc[u][kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+          }
 #pragma unroll
         for (int t = 0; t < 4; ++t)
 #pragma unroll
-          for (int u = 0; u < 2; ++u) sc[u][kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[u][t], qf[u][t], sc[u][kt], 0, 0, 0);
+          for (int kt = 0; kt < QT; ++kt)
+#pragma unroll
+            for (int u = 0; u < 2; ++u) sc[u][kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[u][kt][t], qf[u][t], sc[u][kt], 0, 0, 0);
       }
 #pragma unroll
       for (int u = 0; u < 2; ++u)
@@ -1161,25 +1195,42 @@ __global__ void __launch_bounds__(512) k_s2c_out(const DecSampleDev* __restrict_
         inv[u] = __builtin_amdgcn_rcpf(sum);
       }
       f32x4 acc[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
+      // the first output-projection fragments are requested before the P V products, every later pair one step ahead
+      f32x4 wo0 = Wol[(h * 8 + 0) * 64 + lane], wo1 = Wol[(h * 8 + 1) * 64 + lane];
+      {
+        f32x4 vf[2][QT];
 #pragma unroll
-      for (int kt = 0; kt < QT; ++kt) {
-        f32x4 vf[2];
+        for (int kt = 0; kt < QT; ++kt)
 #pragma unroll
-        for (int u = 0; u < 2; ++u) vf[u] = *(const f32x4*)(vt_l + ((h + u) * DH + j) * LT + kt * 16 + 4 * g);   // V^T: keys 4g..4g+3 of channel 16h+j
+          for (int u = 0; u < 2; ++u) vf[u][kt] = *(const f32x4*)(vt_l + ((h + u) * DH + j) * LT + kt * 16 + 4 * g);   // V^T: keys 4g..4g+3 of channel 16h+j
 #pragma unroll
-        for (int t = 0; t < 4; ++t)
+        for (int kt = 0; kt < QT; ++kt)
 #pragma unroll
-          for (int u = 0; u < 2; ++u) acc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(vf[u][t], sc[u][kt][t] * inv[u], acc[u], 0, 0, 0);
+          for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int u = 0; u < 2; ++u) acc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(vf[u][kt][t], sc[u][kt][t] * inv[u], acc[u], 0, 0, 0);
       }
-      // acc[u] = O[point j][16(h+u)+4g..+3] = the B fragment of the output projection's K-step h + u
+      // acc[u] = O[point j][16(h+u)+4g..+3] = the B fragment of the output projection's K-step h + u; two column tiles at a
+      // time (consecutive MFMAs never hit the same accumulator)
 #pragma unroll
-      for (int u = 0; u < 2; ++u)
-#pragma unroll
-        for (int ct = 0; ct < 8; ++ct) {
-          const f32x4 w = Wol[((h + u) * 8 + ct) * 64 + lane];
-#pragma unroll
-          for (int t = 0; t < 4; ++t) y[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[t], acc[u][t], y[ct], 0, 0, 0);
+      for (int i = 0; i < 8; ++i) {          // i = 4 u + ct / 2
+        const int u = i >> 2, ct = 2 * (i & 3);
+        f32x4 n0 = wo0, n1 = wo1;
+        if (i + 1 < 8) {
+          const int u2 = (i + 1) >> 2, ct2 = 2 * ((i + 1) & 3);
+          n0 = Wol[((h + u2) * 8 + ct2) * 64 + lane];
+          n1 = Wol[((h + u2) * 8 + ct2 + 1) * 64 + lane];
         }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          y[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(wo0[t], acc[u][t], y[ct], 0, 0, 0);
+          y[ct + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wo1[t], acc[u][t], y[ct + 1], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        wo0 = n0;
+        wo1 = n1;
+      }
     }
     // LayerNorm over the 128 channels of point j (4 g-lanes x 8 ct x 4)
     float sum = 0.f;
@@ -1217,15 +1268,21 @@ __global__ void __launch_bounds__(512) k_s2c_out(const DecSampleDev* __restrict_
       for (int S = 0; S < 8; ++S) ef[qt][S] = *(const f32x4*)(er + 16 * S);
     }
     // logits^T: lg[qt][t] = logit of query 16 qt + 4 g + t for point j (rows >= nq repeat the last query: never selected)
-    f32x4 lg[QT];
+    // (even / odd K-steps on separate accumulators, query tiles interleaved: no back-to-back dependent MFMAs)
+    f32x4 lg[QT], lg2[QT];
 #pragma unroll
-    for (int qt = 0; qt < QT; ++qt) {
-      lg[qt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int qt = 0; qt < QT; ++qt) lg[qt] = lg2[qt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int S = 0; S < 8; ++S)
+    for (int S = 0; S < 8; S += 2)
 #pragma unroll
-        for (int t = 0; t < 4; ++t) lg[qt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ef[qt][S][t], y[S][t], lg[qt], 0, 0, 0);
-    }
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt) {
+          lg[qt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ef[qt][S][t], y[S][t], lg[qt], 0, 0, 0);
+          lg2[qt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ef[qt][S + 1][t], y[S + 1][t], lg2[qt], 0, 0, 0);
+        }
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) lg[qt] += lg2[qt];
     // per-object max over the object's queries (k_out_ln_mask's order of comparisons: ascending query index; max is
     // order-independent), first-max argmax over the objects
     float best = 0.f;

@@ -87,6 +87,7 @@ struct SkArgs {
   float* slab;           // [G][64 * BN] partial accumulators
   unsigned in_row_bytes; // ldi * 4
   int* fail;             // set when a bounded wait ran out (never in a healthy run)
+  int prio;              // 1: static wave priority by occupancy layer (ticket / 256), see the kernel
   int dbg;               // A3D_DBG ablations: 1 no A gather, 2 no weight DMA, 4 no MFMA, 8 no stage-end vmcnt wait
 };
 
@@ -157,6 +158,19 @@ __global__ void __launch_bounds__(256, PAIR ? ((BN <= 96 && CH <= 32) ? 4 : 3) :
   }
   if (w == 0 && a.c.zero_row >= 0)
     for (int cidx = tid; cidx < a.c.cout; cidx += 256) a.c.out[(size_t)a.c.zero_row * a.c.ldo + cidx] = 0.f;
+  // The four waves of a workgroup sit on the four SIMDs of a CU, each next to the waves of the 2-3 other resident
+  // workgroups, and meet at a barrier every stage: a wave that loses the arbitration on ITS SIMD holds up its three
+  // siblings (SQ counters: a third of a wave's life parked at stage ends).  A static priority by occupancy layer
+  // (workgroups are dispatched CU after CU, so ticket / 256 numbers the workgroups of a CU) makes every SIMD prefer
+  // the SAME workgroup: its waves reach the barrier together, the next layer's run behind them.
+  if (a.prio) {
+    switch ((w >> 8) & 3) {
+      case 0: __builtin_amdgcn_s_setprio(3); break;
+      case 1: __builtin_amdgcn_s_setprio(2); break;
+      case 2: __builtin_amdgcn_s_setprio(1); break;
+      default: __builtin_amdgcn_s_setprio(0); break;
+    }
+  }
 
   auto prefix = [&](int t) -> long long {   // cost units of one cout block before tile t
     const long long n = a.pre ? (long long)a.pre[t] : (long long)K * t;
@@ -1269,6 +1283,8 @@ static int launch_conv_sk(ConvArgs c, const int* pre64, float* slab_ws, size_t s
   {
     static int dbg = sk_env("A3D_DBG", 0);
     a.dbg = dbg;
+    static int prio = sk_env("A3D_SK_PRIO", 0);
+    a.prio = handoff && p.G > 256 ? prio : 0;
   }
   if (c.K > 1 && !pre) {
     set_error("spconv: a gathered convolution needs the scene's tile prefix table");

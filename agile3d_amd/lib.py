@@ -143,6 +143,17 @@ SYMBOLS = {
     "a3d_group_max": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
                                 C.c_void_p]),
     "a3d_group_max_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "a3d_flash_c2s_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int64]),
+    "a3d_flash_c2s_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p,
+                                        C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "a3d_flash_c2s_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p,
+                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
+                                         C.c_void_p]),
+    "a3d_flash_s2c_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int64]),
+    "a3d_flash_s2c_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p,
+                                        C.c_void_p]),
+    "a3d_flash_s2c_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p,
+                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "a3d_sum_squares_workspace_bytes": (C.c_size_t, []),
     "a3d_sum_squares": (C.c_int, [C.c_void_p, C.c_int64, C.POINTER(C.c_double), C.c_void_p, C.c_size_t, C.c_void_p]),
     "a3d_sum_squares_accumulate": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),

@@ -24,6 +24,10 @@ from . import lib as L
 from .engine import time_table
 
 H, DH = 8, 16
+# A3D_TRAIN_FLASH=0: the attentions over the N points keep their [8, Lq, Lk] score matrices (attn_train.hip), the path the
+# flash kernels (attn_flash.hip, default) are checked against
+import os as _os
+FLASH = _os.environ.get("A3D_TRAIN_FLASH", "1") != "0"
 
 
 class _T:
@@ -237,6 +241,68 @@ class DecoderTape:
         self.steps.append(back)
         return y
 
+    # ---- the same two attentions in the flash formulation (csrc/attn_flash.hip): no [8, Lq, Lk] matrix, the softmax
+    # statistics of the forward pass are what the backward pass recomputes the probabilities from
+    def attention_flash_c2s(self, q: _T, k: _T, v: _T, mask=None) -> _T:
+        """Few queries over the N points (click-to-scene), optional uint8 mask [Lq, Lk] (1 = blocked)."""
+        lib = L.load()
+        Lq, Lk = q.v.shape[0], k.v.shape[0]
+        dev = q.v.device
+        qs = (q.v * 0.25).contiguous()                                     # 1 / sqrt(16): exact
+        kv, vv = k.v.contiguous(), v.v.contiguous()
+        nbytes = lib.a3d_flash_c2s_workspace_bytes(Lq, Lk)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        o = torch.empty((Lq, H * DH), dtype=torch.float32, device=dev)
+        stats = torch.empty((2, H, Lq), dtype=torch.float32, device=dev)
+        L.check(lib.a3d_flash_c2s_forward(_ptr(qs), _ptr(kv), _ptr(vv), _ptr(mask), Lq, Lk, _ptr(o), _ptr(stats), _ptr(ws),
+                                          nbytes, _stream()), "flash_c2s_forward")
+        del ws
+        y = _T(o)
+
+        def back():
+            if y.g is None:
+                return
+            do = y.g.contiguous()
+            w2 = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+            dqs, dk, dv = torch.empty_like(qs), torch.empty_like(kv), torch.empty_like(vv)
+            L.check(lib.a3d_flash_c2s_backward(_ptr(qs), _ptr(kv), _ptr(vv), _ptr(mask), Lq, Lk, _ptr(o), _ptr(stats),
+                                               _ptr(do), _ptr(dqs), _ptr(dk), _ptr(dv), _ptr(w2), nbytes, _stream()),
+                    "flash_c2s_backward")
+            q.add_grad(dqs * 0.25)
+            k.add_grad(dk)
+            v.add_grad(dv)
+        self.steps.append(back)
+        return y
+
+    def attention_flash_s2c(self, q: _T, k: _T, v: _T) -> _T:
+        """The N points as queries over few keys (scene-to-click), no mask."""
+        lib = L.load()
+        Lq, Lk = q.v.shape[0], k.v.shape[0]
+        dev = q.v.device
+        qs = (q.v * 0.25).contiguous()
+        kv, vv = k.v.contiguous(), v.v.contiguous()
+        o = torch.empty((Lq, H * DH), dtype=torch.float32, device=dev)
+        stats = torch.empty((Lq, H, 2), dtype=torch.float32, device=dev)
+        L.check(lib.a3d_flash_s2c_forward(_ptr(qs), _ptr(kv), _ptr(vv), Lq, Lk, _ptr(o), _ptr(stats), _stream()),
+                "flash_s2c_forward")
+        y = _T(o)
+
+        def back():
+            if y.g is None:
+                return
+            do = y.g.contiguous()
+            nbytes = lib.a3d_flash_s2c_workspace_bytes(Lq, Lk)
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+            dqs, dk, dv = torch.empty_like(qs), torch.empty_like(kv), torch.empty_like(vv)
+            L.check(lib.a3d_flash_s2c_backward(_ptr(qs), _ptr(kv), _ptr(vv), Lq, Lk, _ptr(o), _ptr(stats), _ptr(do),
+                                               _ptr(dqs), _ptr(dk), _ptr(dv), _ptr(ws), nbytes, _stream()),
+                    "flash_s2c_backward")
+            q.add_grad(dqs * 0.25)
+            k.add_grad(dk)
+            v.add_grad(dv)
+        self.steps.append(back)
+        return y
+
     def mha(self, prefix, query: _T, key: _T, value: _T, mask=None) -> _T:
         """nn.MultiheadAttention (attention_block.py:25-26,88-94): in_proj slices, attention, out_proj."""
         w, b = prefix + "in_proj_weight", prefix + "in_proj_bias"
@@ -244,7 +310,13 @@ class DecoderTape:
         k = self.lin(key, w, b, rows=(128, 256))
         v = self.lin(value, w, b, rows=(256, 384))
         long_queries = mask is None and q.v.shape[0] >= 1024 and q.v.shape[0] > 8 * k.v.shape[0]
-        a = self.attention_t(q, k, v) if long_queries else self.attention(q, k, v, mask)
+        long_keys = k.v.shape[0] >= 1024 and k.v.shape[0] > 8 * q.v.shape[0]
+        if FLASH and long_queries:
+            a = self.attention_flash_s2c(q, k, v)
+        elif FLASH and long_keys:
+            a = self.attention_flash_c2s(q, k, v, mask)
+        else:
+            a = self.attention_t(q, k, v) if long_queries else self.attention(q, k, v, mask)
         return self.lin(a, prefix + "out_proj.weight", prefix + "out_proj.bias")
 
     def mask_head(self, queries: _T, src: _T, groups):

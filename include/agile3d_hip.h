@@ -286,6 +286,30 @@ int a3d_group_max(const float* lq_dev, int64_t N, int Q, const int32_t* qbeg_dev
 int a3d_group_max_backward(const float* dout_dev, const int32_t* arg_dev, int64_t N, int Q, int G, float* dlq_dev,
                            void* stream);
 
+/* The same attention in the flash formulation, for the two attentions of a decoder layer that have the N points on one
+ * side (attention_block.py:86-98 as called at agile3d.py:283-290 and :305-312; 8 heads x 16 channels fixed): nothing of
+ * size [heads, Lq, Lk] is written; the forward pass keeps the softmax statistics (row maximum, row sum), the backward
+ * pass recomputes the probabilities tile by tile from them.  q_scaled = q / sqrt(16) (the caller scales: exact), so
+ * dL/dq = dq_scaled / 4.  mask_dev: uint8 [Lq][Lk], non-zero = blocked, or NULL.
+ *   click-to-scene (few queries, Lk = N keys):  o [Lq][128], stats [2][8][Lq] (max, sum)
+ *   scene-to-click (Lq = N queries, few keys):  o [Lq][128], stats [Lq][8][2]
+ * Reductions over the N points (dq of click-to-scene; dk, dv of scene-to-click) are per-chunk partial sums added in
+ * chunk order by a second kernel: results are bit-identical run to run. */
+size_t a3d_flash_c2s_workspace_bytes(int64_t Lq, int64_t Lk);
+int a3d_flash_c2s_forward(const float* q_scaled_dev, const float* k_dev, const float* v_dev, const unsigned char* mask_dev,
+                          int64_t Lq, int64_t Lk, float* o_dev, float* stats_dev, void* workspace_dev,
+                          size_t workspace_bytes, void* stream);
+int a3d_flash_c2s_backward(const float* q_scaled_dev, const float* k_dev, const float* v_dev, const unsigned char* mask_dev,
+                           int64_t Lq, int64_t Lk, const float* o_dev, const float* stats_dev, const float* d_o_dev,
+                           float* dq_scaled_dev, float* dk_dev, float* dv_dev, void* workspace_dev, size_t workspace_bytes,
+                           void* stream);
+size_t a3d_flash_s2c_workspace_bytes(int64_t Lq, int64_t Lk);
+int a3d_flash_s2c_forward(const float* q_scaled_dev, const float* k_dev, const float* v_dev, int64_t Lq, int64_t Lk,
+                          float* o_dev, float* stats_dev, void* stream);
+int a3d_flash_s2c_backward(const float* q_scaled_dev, const float* k_dev, const float* v_dev, int64_t Lq, int64_t Lk,
+                           const float* o_dev, const float* stats_dev, const float* d_o_dev, float* dq_scaled_dev,
+                           float* dk_dev, float* dv_dev, void* workspace_dev, size_t workspace_bytes, void* stream);
+
 /* Optimiser step of the reference's training loop: torch.optim.AdamW(lr, weight_decay) (main.py:125-127) after
  * clip_grad_norm_(parameters, max_norm) (engine.py:145-150).  a3d_sum_squares returns sum g^2 of one tensor to the
  * host (the caller adds the tensors, clip coefficient = min(1, max_norm / (sqrt(total) + 1e-6))); a3d_adamw_step is

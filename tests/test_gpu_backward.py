@@ -648,3 +648,89 @@ def test_reference_training_sequence_through_the_model_api():
     x = SparseTensor(features=batch[2], coordinates=batch[0], device="cuda")
     r = model_a.forward_backbone(x, raw_coordinates=batch[1].cuda())
     assert torch.isfinite(r[0].F).all()
+
+
+def _ptr(t):
+    import ctypes as C
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def _stream():
+    import ctypes as C
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _mha_ref(q, k, v, mask):
+    """softmax(q k^T / 4 + mask) v per head (8 x 16) in float64 with autograd: (o, dq, dk, dv) for the loss sum(o * w)."""
+    q, k, v = (t.double().clone().requires_grad_(True) for t in (q, k, v))
+    Lq, Lk = q.shape[0], k.shape[0]
+    s = torch.einsum("ihd,jhd->hij", q.view(Lq, 8, 16), k.view(Lk, 8, 16)) / 4.0
+    if mask is not None:
+        s = s.masked_fill(mask.bool()[None], float("-inf"))
+    o = torch.einsum("hij,jhd->ihd", torch.softmax(s, -1), v.view(Lk, 8, 16)).reshape(Lq, 128)
+    return o, q, k, v
+
+
+@pytest.mark.parametrize("Lq,Lk,masked", [(37, 5003, True), (20, 3000, False), (130, 1700, True)])
+def test_flash_click_to_scene_attention_vs_float64_autograd(Lq, Lk, masked):
+    """a3d_flash_c2s_forward / _backward (no [8, Lq, Lk] matrix; softmax statistics kept, probabilities recomputed in the
+    backward pass) against float64 autograd of the plain formula: output, dq, dk, dv; ragged sizes (Lq, Lk not multiples
+    of 16 / 64), a mask that blocks 60 % of the entries and whole 64-key chunks of some queries."""
+    lib = L.load()
+    g = torch.Generator().manual_seed(Lq * 7 + Lk)
+    q, k, v = (torch.randn(n, 128, generator=g) for n in (Lq, Lk, Lk))
+    w = torch.randn(Lq, 128, generator=g)
+    mask = None
+    if masked:
+        mask = (torch.rand(Lq, Lk, generator=g) < 0.6)
+        mask[:, 5] = False                                  # no row fully blocked (the reference's mask_module guarantees it)
+        mask[3, 64:640] = True                              # whole chunks blocked for one query
+        mask = mask.to(torch.uint8)
+    o_ref, qr, kr, vr = _mha_ref(q, k, v, mask)
+    (o_ref * w.double()).sum().backward()
+    dev = torch.device("cuda")
+    qs, kd, vd, md, wd = (q * 0.25).to(dev), k.to(dev), v.to(dev), (mask.to(dev).contiguous() if masked else None), w.to(dev)
+    nb = lib.a3d_flash_c2s_workspace_bytes(Lq, Lk)
+    ws = torch.empty(nb, dtype=torch.uint8, device=dev)
+    o = torch.empty(Lq, 128, device=dev)
+    stats = torch.empty(2, 8, Lq, device=dev)
+    L.check(lib.a3d_flash_c2s_forward(_ptr(qs), _ptr(kd), _ptr(vd), _ptr(md), Lq, Lk, _ptr(o), _ptr(stats), _ptr(ws), nb,
+                                      _stream()), "fwd")
+    dq, dk, dv = torch.empty_like(qs), torch.empty_like(kd), torch.empty_like(vd)
+    L.check(lib.a3d_flash_c2s_backward(_ptr(qs), _ptr(kd), _ptr(vd), _ptr(md), Lq, Lk, _ptr(o), _ptr(stats), _ptr(wd), _ptr(dq),
+                                       _ptr(dk), _ptr(dv), _ptr(ws), nb, _stream()), "bwd")
+    dq2, dk2, dv2 = torch.empty_like(qs), torch.empty_like(kd), torch.empty_like(vd)
+    L.check(lib.a3d_flash_c2s_backward(_ptr(qs), _ptr(kd), _ptr(vd), _ptr(md), Lq, Lk, _ptr(o), _ptr(stats), _ptr(wd), _ptr(dq2),
+                                       _ptr(dk2), _ptr(dv2), _ptr(ws), nb, _stream()), "bwd")
+    assert torch.equal(dq, dq2) and torch.equal(dk, dk2) and torch.equal(dv, dv2)      # deterministic
+    for name, got, want in (("o", o, o_ref), ("dq", dq * 0.25, qr.grad), ("dk", dk, kr.grad), ("dv", dv, vr.grad)):
+        err = (got.double().cpu() - want.detach()).abs().max().item()
+        scale = max(1e-6, want.detach().abs().max().item())
+        print(f"flash c2s {Lq}x{Lk} {name}: max|diff| {err:.2e} (scale {scale:.2e})")
+        assert err <= 2e-5 * scale, (name, err, scale)
+
+
+@pytest.mark.parametrize("Lq,Lk", [(5003, 37), (3000, 20), (1700, 130)])
+def test_flash_scene_to_click_attention_vs_float64_autograd(Lq, Lk):
+    """a3d_flash_s2c_forward / _backward (the N points as queries over few keys) against float64 autograd."""
+    lib = L.load()
+    g = torch.Generator().manual_seed(Lq * 3 + Lk)
+    q, k, v = (torch.randn(n, 128, generator=g) for n in (Lq, Lk, Lk))
+    w = torch.randn(Lq, 128, generator=g)
+    o_ref, qr, kr, vr = _mha_ref(q, k, v, None)
+    (o_ref * w.double()).sum().backward()
+    dev = torch.device("cuda")
+    qs, kd, vd, wd = (q * 0.25).to(dev), k.to(dev), v.to(dev), w.to(dev)
+    o = torch.empty(Lq, 128, device=dev)
+    stats = torch.empty(Lq, 8, 2, device=dev)
+    L.check(lib.a3d_flash_s2c_forward(_ptr(qs), _ptr(kd), _ptr(vd), Lq, Lk, _ptr(o), _ptr(stats), _stream()), "fwd")
+    nb = lib.a3d_flash_s2c_workspace_bytes(Lq, Lk)
+    ws = torch.empty(nb, dtype=torch.uint8, device=dev)
+    dq, dk, dv = torch.empty_like(qs), torch.empty_like(kd), torch.empty_like(vd)
+    L.check(lib.a3d_flash_s2c_backward(_ptr(qs), _ptr(kd), _ptr(vd), Lq, Lk, _ptr(o), _ptr(stats), _ptr(wd), _ptr(dq), _ptr(dk),
+                                       _ptr(dv), _ptr(ws), nb, _stream()), "bwd")
+    for name, got, want in (("o", o, o_ref), ("dq", dq * 0.25, qr.grad), ("dk", dk, kr.grad), ("dv", dv, vr.grad)):
+        err = (got.double().cpu() - want.detach()).abs().max().item()
+        scale = max(1e-6, want.detach().abs().max().item())
+        print(f"flash s2c {Lq}x{Lk} {name}: max|diff| {err:.2e} (scale {scale:.2e})")
+        assert err <= 2e-5 * scale, (name, err, scale)
