@@ -34,6 +34,7 @@ class BackboneFn(torch.autograd.Function):
     def backward(ctx, d_out):
         h = ctx.holder
         grads = h.tape.backward(d_out.contiguous())
+        h.tape.release()                     # torch runs a node's backward once: free the activations now (tape <-> closure cycle)
         return (None,) + tuple(grads.get(n) for n in h.names)
 
 
@@ -49,6 +50,7 @@ class DecoderFn(torch.autograd.Function):
     def backward(ctx, *d_logits):
         h = ctx.holder
         grads, d_pcd = h.tape.backward([None if g is None else g.contiguous() for g in d_logits])
+        h.tape.release()
         return (None, d_pcd) + tuple(grads.get(n) for n in h.names)
 
 

@@ -235,6 +235,12 @@ class BackboneTape:
         pcd[self.orig_row] = y.v[:n0] + bias
         self.output = pcd
 
+    def release(self):
+        """Drop the recorded steps and activations (the backward closures and the tape refer to each other: without this the
+        activations of an iteration live until Python's cycle collector runs, see DecoderTape.release)."""
+        self.steps, self.relu_levels = [], []
+        self.head_out = None
+
     # ------------------------------------------------------------------ backward
     def backward(self, d_output: torch.Tensor, on_grad=None) -> dict:
         """``d_output`` = dL/d(pcd_features) [N, 128] in the caller's row order -> gradients keyed like state_dict().

@@ -82,15 +82,24 @@ def _col_sums(dy):
 
 
 class DecoderTape:
+    """One tape for a whole batch: ``pcd_features`` / ``pos_enc`` / ``click_idx`` / ``click_time_idx`` are lists with one
+    entry per batch sample (agile3d.py:192 loops over the samples: they only share the weights), or single objects for a
+    one-sample tape.  Row-wise operations (projections, LayerNorm, FFN, residual adds) run ONCE over the concatenated rows
+    of all samples -- points [N_total, 128] and queries [Q_total, 128] --, attention and the mask head per sample on row
+    ranges: a third of the launches and of the host-side bookkeeping of one tape per sample."""
+
     def __init__(self, model, pcd_features, pos_enc, click_idx, click_time_idx):
-        if not pcd_features.is_cuda:
+        self._single = torch.is_tensor(pcd_features)
+        if self._single:
+            pcd_features, pos_enc, click_idx, click_time_idx = [pcd_features], [pos_enc], [click_idx], [click_time_idx]
+        if not pcd_features[0].is_cuda:
             raise RuntimeError("DecoderTape runs on the GPU only")
         self.model = model
         self.P = dict(model.named_parameters())
         self.steps, self.grads, self._packed = [], {}, {}
         self.relu_masks, self.attn_masks, self.args = [], [], []      # what a reference needs to follow the same branch
-        self._forward(pcd_features.to(torch.float32).contiguous(), pos_enc.to(torch.float32).contiguous(), click_idx,
-                      click_time_idx)
+        self._forward([p.to(torch.float32).contiguous() for p in pcd_features],
+                      [p.to(torch.float32).contiguous() for p in pos_enc], list(click_idx), list(click_time_idx))
 
     # ------------------------------------------------------------------ primitive ops with their backward
     def _pg(self, name, g):
@@ -176,254 +185,312 @@ class DecoderTape:
         self.steps.append(back)
         return y
 
-    def attention(self, q: _T, k: _T, v: _T, mask=None) -> _T:
-        """softmax(q k^T / sqrt(dh) + mask) v per head; q [Lq,128], k / v [Lk,128]; mask uint8 [Lq,Lk] (1 = blocked)."""
+    # ---- attention, per batch sample on row ranges of the batched tensors.  Three implementations of
+    # softmax(q k^T / sqrt(dh) + mask) v per head, each a (forward, backward) pair on plain tensors:
+    #   "flash_c2s"  few queries over the N points, masked   (csrc/attn_flash.hip: no [8, Lq, Lk] matrix)
+    #   "flash_s2c"  the N points as queries over few keys   (csrc/attn_flash.hip)
+    #   "dense"      scores materialised (csrc/attn_train.hip): the click-to-click self attention, and everything when
+    #                A3D_TRAIN_FLASH=0 (the path the flash kernels are checked against)
+    @staticmethod
+    def _dense_fwd(qv, kv, vv, mask):
         lib = L.load()
-        Lq, Lk = q.v.shape[0], k.v.shape[0]
+        Lq, Lk = qv.shape[0], kv.shape[0]
+        dev = qv.device
         scale = 1.0 / (DH ** 0.5)
-        dev = q.v.device
-        Pm = torch.empty((H, Lq, Lk), dtype=torch.float32, device=dev)
-        L.check(lib.a3d_attn_scores(_ptr(q.v), _ptr(k.v), Lq, Lk, H, DH, scale, _ptr(mask), _ptr(Pm), _stream()), "scores")
-        L.check(lib.a3d_softmax_rows(_ptr(Pm), H * Lq, Lk, _stream()), "softmax")
-        o = torch.empty((Lq, H * DH), dtype=torch.float32, device=dev)
-        _apply(Pm, v.v, Lq, Lk, H, DH, 0, 1.0, o)
-        y = _T(o)
+        transposed = mask is None and Lq >= 1024 and Lq > 8 * Lk      # the long index fastest in every kernel
+        if transposed:
+            Pm = torch.empty((H, Lk, Lq), dtype=torch.float32, device=dev)                      # P^T[h][key][query]
+            L.check(lib.a3d_attn_scores(_ptr(kv), _ptr(qv), Lk, Lq, H, DH, scale, None, _ptr(Pm), _stream()), "scores")
+            L.check(lib.a3d_softmax_cols(_ptr(Pm), H, Lk, Lq, _stream()), "softmax_cols")         # over the keys
+            o = torch.empty((Lq, H * DH), dtype=torch.float32, device=dev)
+            _apply(Pm, vv, Lk, Lq, H, DH, 1, 1.0, o)
+        else:
+            Pm = torch.empty((H, Lq, Lk), dtype=torch.float32, device=dev)
+            L.check(lib.a3d_attn_scores(_ptr(qv), _ptr(kv), Lq, Lk, H, DH, scale, _ptr(mask), _ptr(Pm), _stream()), "scores")
+            L.check(lib.a3d_softmax_rows(_ptr(Pm), H * Lq, Lk, _stream()), "softmax")
+            o = torch.empty((Lq, H * DH), dtype=torch.float32, device=dev)
+            _apply(Pm, vv, Lq, Lk, H, DH, 0, 1.0, o)
+        return o, (Pm, transposed)
 
-        def back():
-            if y.g is None:
-                return
-            do = y.g.contiguous()
-            dP = torch.empty_like(Pm)
-            L.check(lib.a3d_attn_scores(_ptr(do), _ptr(v.v), Lq, Lk, H, DH, 1.0, None, _ptr(dP), _stream()), "scores")
-            dv = torch.empty_like(v.v)
+    @staticmethod
+    def _dense_bwd(qv, kv, vv, mask, o, saved, do, dq, dk, dv):
+        lib = L.load()
+        Pm, transposed = saved
+        Lq, Lk = qv.shape[0], kv.shape[0]
+        scale = 1.0 / (DH ** 0.5)
+        dP = torch.empty_like(Pm)
+        if transposed:
+            L.check(lib.a3d_attn_scores(_ptr(vv), _ptr(do), Lk, Lq, H, DH, 1.0, None, _ptr(dP), _stream()), "scores")
+            _apply(Pm, do, Lk, Lq, H, DH, 0, 1.0, dv)                                        # dv[key] = sum_query P^T dO
+            L.check(lib.a3d_softmax_cols_backward(_ptr(Pm), _ptr(dP), H, Lk, Lq, _stream()), "softmax_cols_bwd")
+            _apply(dP, kv, Lk, Lq, H, DH, 1, scale, dq)                                      # dq[query] = sum_key dS^T k
+            _apply(dP, qv, Lk, Lq, H, DH, 0, scale, dk)                                      # dk[key] = sum_query dS^T q
+        else:
+            L.check(lib.a3d_attn_scores(_ptr(do), _ptr(vv), Lq, Lk, H, DH, 1.0, None, _ptr(dP), _stream()), "scores")
             _apply(Pm, do, Lq, Lk, H, DH, 1, 1.0, dv)
             L.check(lib.a3d_softmax_rows_backward(_ptr(Pm), _ptr(dP), H * Lq, Lk, _stream()), "softmax_bwd")   # dP <- dS
-            dq = torch.empty_like(q.v)
-            _apply(dP, k.v, Lq, Lk, H, DH, 0, scale, dq)
-            dk = torch.empty_like(k.v)
-            _apply(dP, q.v, Lq, Lk, H, DH, 1, scale, dk)
-            q.add_grad(dq)
-            k.add_grad(dk)
-            v.add_grad(dv)
-        self.steps.append(back)
-        return y
+            _apply(dP, kv, Lq, Lk, H, DH, 0, scale, dq)
+            _apply(dP, qv, Lq, Lk, H, DH, 1, scale, dk)
 
-    def attention_t(self, q: _T, k: _T, v: _T) -> _T:
-        """The same attention for MANY queries over FEW keys (scene-to-click: 80 k points x ~20 click queries), with the
-        score matrix kept transposed, [head][key][query]: the long index is the fastest one in every kernel."""
+    @staticmethod
+    def _c2s_fwd(qv, kv, vv, mask):
         lib = L.load()
-        Lq, Lk = q.v.shape[0], k.v.shape[0]
-        scale = 1.0 / (DH ** 0.5)
-        dev = q.v.device
-        Pt = torch.empty((H, Lk, Lq), dtype=torch.float32, device=dev)                      # P^T[h][key][query]
-        L.check(lib.a3d_attn_scores(_ptr(k.v), _ptr(q.v), Lk, Lq, H, DH, scale, None, _ptr(Pt), _stream()), "scores")
-        L.check(lib.a3d_softmax_cols(_ptr(Pt), H, Lk, Lq, _stream()), "softmax_cols")         # over the keys
-        o = torch.empty((Lq, H * DH), dtype=torch.float32, device=dev)
-        _apply(Pt, v.v, Lk, Lq, H, DH, 1, 1.0, o)                                            # o[query] = sum_key P^T v[key]
-        y = _T(o)
-
-        def back():
-            if y.g is None:
-                return
-            do = y.g.contiguous()
-            dPt = torch.empty_like(Pt)
-            L.check(lib.a3d_attn_scores(_ptr(v.v), _ptr(do), Lk, Lq, H, DH, 1.0, None, _ptr(dPt), _stream()), "scores")
-            dv = torch.empty_like(v.v)
-            _apply(Pt, do, Lk, Lq, H, DH, 0, 1.0, dv)                                        # dv[key] = sum_query P^T dO
-            L.check(lib.a3d_softmax_cols_backward(_ptr(Pt), _ptr(dPt), H, Lk, Lq, _stream()), "softmax_cols_bwd")
-            dq = torch.empty_like(q.v)
-            _apply(dPt, k.v, Lk, Lq, H, DH, 1, scale, dq)                                    # dq[query] = sum_key dS^T k
-            dk = torch.empty_like(k.v)
-            _apply(dPt, q.v, Lk, Lq, H, DH, 0, scale, dk)                                    # dk[key] = sum_query dS^T q
-            q.add_grad(dq)
-            k.add_grad(dk)
-            v.add_grad(dv)
-        self.steps.append(back)
-        return y
-
-    # ---- the same two attentions in the flash formulation (csrc/attn_flash.hip): no [8, Lq, Lk] matrix, the softmax
-    # statistics of the forward pass are what the backward pass recomputes the probabilities from
-    def attention_flash_c2s(self, q: _T, k: _T, v: _T, mask=None) -> _T:
-        """Few queries over the N points (click-to-scene), optional uint8 mask [Lq, Lk] (1 = blocked)."""
-        lib = L.load()
-        Lq, Lk = q.v.shape[0], k.v.shape[0]
-        dev = q.v.device
-        qs = (q.v * 0.25).contiguous()                                     # 1 / sqrt(16): exact
-        kv, vv = k.v.contiguous(), v.v.contiguous()
+        Lq, Lk = qv.shape[0], kv.shape[0]
+        dev = qv.device
+        qs = qv * 0.25                                                     # 1 / sqrt(16): exact
         nbytes = lib.a3d_flash_c2s_workspace_bytes(Lq, Lk)
         ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
         o = torch.empty((Lq, H * DH), dtype=torch.float32, device=dev)
         stats = torch.empty((2, H, Lq), dtype=torch.float32, device=dev)
         L.check(lib.a3d_flash_c2s_forward(_ptr(qs), _ptr(kv), _ptr(vv), _ptr(mask), Lq, Lk, _ptr(o), _ptr(stats), _ptr(ws),
                                           nbytes, _stream()), "flash_c2s_forward")
-        del ws
-        y = _T(o)
+        return o, (qs, stats)
 
-        def back():
-            if y.g is None:
-                return
-            do = y.g.contiguous()
-            w2 = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-            dqs, dk, dv = torch.empty_like(qs), torch.empty_like(kv), torch.empty_like(vv)
-            L.check(lib.a3d_flash_c2s_backward(_ptr(qs), _ptr(kv), _ptr(vv), _ptr(mask), Lq, Lk, _ptr(o), _ptr(stats),
-                                               _ptr(do), _ptr(dqs), _ptr(dk), _ptr(dv), _ptr(w2), nbytes, _stream()),
-                    "flash_c2s_backward")
-            q.add_grad(dqs * 0.25)
-            k.add_grad(dk)
-            v.add_grad(dv)
-        self.steps.append(back)
-        return y
-
-    def attention_flash_s2c(self, q: _T, k: _T, v: _T) -> _T:
-        """The N points as queries over few keys (scene-to-click), no mask."""
+    @staticmethod
+    def _c2s_bwd(qv, kv, vv, mask, o, saved, do, dq, dk, dv):
         lib = L.load()
-        Lq, Lk = q.v.shape[0], k.v.shape[0]
-        dev = q.v.device
-        qs = (q.v * 0.25).contiguous()
-        kv, vv = k.v.contiguous(), v.v.contiguous()
+        qs, stats = saved
+        Lq, Lk = qv.shape[0], kv.shape[0]
+        nbytes = lib.a3d_flash_c2s_workspace_bytes(Lq, Lk)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=qv.device)
+        L.check(lib.a3d_flash_c2s_backward(_ptr(qs), _ptr(kv), _ptr(vv), _ptr(mask), Lq, Lk, _ptr(o), _ptr(stats), _ptr(do),
+                                           _ptr(dq), _ptr(dk), _ptr(dv), _ptr(ws), nbytes, _stream()), "flash_c2s_backward")
+        dq *= 0.25
+
+    @staticmethod
+    def _s2c_fwd(qv, kv, vv, mask):
+        lib = L.load()
+        Lq, Lk = qv.shape[0], kv.shape[0]
+        dev = qv.device
+        qs = qv * 0.25
         o = torch.empty((Lq, H * DH), dtype=torch.float32, device=dev)
         stats = torch.empty((Lq, H, 2), dtype=torch.float32, device=dev)
         L.check(lib.a3d_flash_s2c_forward(_ptr(qs), _ptr(kv), _ptr(vv), Lq, Lk, _ptr(o), _ptr(stats), _stream()),
                 "flash_s2c_forward")
-        y = _T(o)
+        return o, (qs, stats)
+
+    @staticmethod
+    def _s2c_bwd(qv, kv, vv, mask, o, saved, do, dq, dk, dv):
+        lib = L.load()
+        qs, stats = saved
+        Lq, Lk = qv.shape[0], kv.shape[0]
+        nbytes = lib.a3d_flash_s2c_workspace_bytes(Lq, Lk)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=qv.device)
+        L.check(lib.a3d_flash_s2c_backward(_ptr(qs), _ptr(kv), _ptr(vv), Lq, Lk, _ptr(o), _ptr(stats), _ptr(do), _ptr(dq),
+                                           _ptr(dk), _ptr(dv), _ptr(ws), nbytes, _stream()), "flash_s2c_backward")
+        dq *= 0.25
+
+    def attention_seg(self, q: _T, k: _T, v: _T, q_ranges, k_ranges, masks=None) -> _T:
+        """Attention of every batch sample on ITS rows: sample b's queries are rows q_ranges[b] of ``q``, its keys / values
+        rows k_ranges[b] of ``k`` / ``v`` (contiguous row ranges of the batched tensors: views, no copies); masks[b] uint8
+        [Lq_b, Lk_b] (1 = blocked) or None.  One tape step for the whole batch."""
+        qv, kv, vv = q.v.contiguous(), k.v.contiguous(), v.v.contiguous()
+        out = torch.empty((qv.shape[0], H * DH), dtype=torch.float32, device=qv.device)
+        saved = []
+        for b, ((q0, q1), (k0, k1)) in enumerate(zip(q_ranges, k_ranges)):
+            mask = masks[b] if masks is not None else None
+            Lq, Lk = q1 - q0, k1 - k0
+            if FLASH and mask is None and Lq >= 1024 and Lq > 8 * Lk:
+                kind = "s2c"
+            elif FLASH and Lk >= 1024 and Lk > 8 * Lq:
+                kind = "c2s"
+            else:
+                kind = "dense"
+            fwd = {"s2c": self._s2c_fwd, "c2s": self._c2s_fwd, "dense": self._dense_fwd}[kind]
+            o, sv = fwd(qv[q0:q1], kv[k0:k1], vv[k0:k1], mask)
+            out[q0:q1] = o
+            saved.append((kind, o, sv, mask))
+        y = _T(out)
 
         def back():
             if y.g is None:
                 return
             do = y.g.contiguous()
-            nbytes = lib.a3d_flash_s2c_workspace_bytes(Lq, Lk)
-            ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-            dqs, dk, dv = torch.empty_like(qs), torch.empty_like(kv), torch.empty_like(vv)
-            L.check(lib.a3d_flash_s2c_backward(_ptr(qs), _ptr(kv), _ptr(vv), Lq, Lk, _ptr(o), _ptr(stats), _ptr(do),
-                                               _ptr(dqs), _ptr(dk), _ptr(dv), _ptr(ws), nbytes, _stream()),
-                    "flash_s2c_backward")
-            q.add_grad(dqs * 0.25)
+            dq, dk, dv = torch.empty_like(qv), torch.empty_like(kv), torch.empty_like(vv)
+            for ((q0, q1), (k0, k1)), (kind, o, sv, mask) in zip(zip(q_ranges, k_ranges), saved):
+                bwd = {"s2c": self._s2c_bwd, "c2s": self._c2s_bwd, "dense": self._dense_bwd}[kind]
+                bwd(qv[q0:q1], kv[k0:k1], vv[k0:k1], mask, o, sv, do[q0:q1], dq[q0:q1], dk[k0:k1], dv[k0:k1])
+            q.add_grad(dq)
             k.add_grad(dk)
             v.add_grad(dv)
         self.steps.append(back)
         return y
 
-    def mha(self, prefix, query: _T, key: _T, value: _T, mask=None) -> _T:
-        """nn.MultiheadAttention (attention_block.py:25-26,88-94): in_proj slices, attention, out_proj."""
+    def mha(self, prefix, query: _T, key: _T, value: _T, q_ranges, k_ranges, masks=None) -> _T:
+        """nn.MultiheadAttention (attention_block.py:25-26,88-94): in_proj slices (one GEMM each over the rows of the whole
+        batch), attention per sample, out_proj."""
         w, b = prefix + "in_proj_weight", prefix + "in_proj_bias"
         q = self.lin(query, w, b, rows=(0, 128))
         k = self.lin(key, w, b, rows=(128, 256))
         v = self.lin(value, w, b, rows=(256, 384))
-        long_queries = mask is None and q.v.shape[0] >= 1024 and q.v.shape[0] > 8 * k.v.shape[0]
-        long_keys = k.v.shape[0] >= 1024 and k.v.shape[0] > 8 * q.v.shape[0]
-        if FLASH and long_queries:
-            a = self.attention_flash_s2c(q, k, v)
-        elif FLASH and long_keys:
-            a = self.attention_flash_c2s(q, k, v, mask)
-        else:
-            a = self.attention_t(q, k, v) if long_queries else self.attention(q, k, v, mask)
+        a = self.attention_seg(q, k, v, q_ranges, k_ranges, masks)
         return self.lin(a, prefix + "out_proj.weight", prefix + "out_proj.bias")
 
-    def mask_head(self, queries: _T, src: _T, groups):
-        """Agile3d.mask_module (agile3d.py:342-384): per-object max over its queries of src . MLP(LN(q))."""
+    def mask_head(self, queries: _T, src: _T, n_ranges, q_ranges, groups):
+        """Agile3d.mask_module (agile3d.py:342-384): per-object max over its queries of src . MLP(LN(q)); the MLP runs over
+        the queries of the whole batch, the products per sample.  Returns one [N_b, 1 + K_b] node per sample."""
         lib = L.load()
         e = self.ln(queries, "decoder_norm.")
         e = self.relu(self.lin(e, "mask_embed_head.0.weight", "mask_embed_head.0.bias"))
         E = self.lin(e, "mask_embed_head.2.weight", "mask_embed_head.2.bias")
-        N, Q, G = src.v.shape[0], E.v.shape[0], len(groups)
         dev = src.v.device
-        lq = torch.empty((N, Q), dtype=torch.float32, device=dev)
-        L.check(lib.a3d_attn_scores(_ptr(src.v), _ptr(E.v), N, Q, 1, 128, 1.0, None, _ptr(lq), _stream()), "scores")
-        qb = torch.tensor([g[0] for g in groups], dtype=torch.int32, device=dev)
-        qe = torch.tensor([g[1] for g in groups], dtype=torch.int32, device=dev)
-        out = torch.empty((N, G), dtype=torch.float32, device=dev)
-        arg = torch.empty((N, G), dtype=torch.int32, device=dev)
-        L.check(lib.a3d_group_max(_ptr(lq), N, Q, _ptr(qb), _ptr(qe), G, _ptr(out), _ptr(arg), _stream()), "group_max")
-        y = _T(out)
-        self.args.append(arg)
+        outs, saved = [], []
+        for (n0, n1), (q0, q1), grp in zip(n_ranges, q_ranges, groups):
+            N, Q, G = n1 - n0, q1 - q0, len(grp)
+            sv, Ev = src.v[n0:n1], E.v[q0:q1]
+            lq = torch.empty((N, Q), dtype=torch.float32, device=dev)
+            L.check(lib.a3d_attn_scores(_ptr(sv), _ptr(Ev), N, Q, 1, 128, 1.0, None, _ptr(lq), _stream()), "scores")
+            qb = torch.tensor([g[0] for g in grp], dtype=torch.int32, device=dev)
+            qe = torch.tensor([g[1] for g in grp], dtype=torch.int32, device=dev)
+            out = torch.empty((N, G), dtype=torch.float32, device=dev)
+            arg = torch.empty((N, G), dtype=torch.int32, device=dev)
+            L.check(lib.a3d_group_max(_ptr(lq), N, Q, _ptr(qb), _ptr(qe), G, _ptr(out), _ptr(arg), _stream()), "group_max")
+            outs.append(_T(out))
+            saved.append(arg)
+            self.args.append(arg)
 
         def back():
-            dlq = torch.empty_like(lq)
-            L.check(lib.a3d_group_max_backward(_ptr(y.g.contiguous()), _ptr(arg), N, Q, G, _ptr(dlq), _stream()), "gm_bwd")
-            dsrc = torch.empty_like(src.v)
-            _apply(dlq, E.v, N, Q, 1, 128, 0, 1.0, dsrc)
-            dE = torch.empty_like(E.v)
-            _apply(dlq, src.v, N, Q, 1, 128, 1, 1.0, dE)
+            dsrc = torch.zeros_like(src.v)
+            dE = torch.zeros_like(E.v)
+            for (n0, n1), (q0, q1), grp, y, arg in zip(n_ranges, q_ranges, groups, outs, saved):
+                if y.g is None:
+                    continue
+                N, Q, G = n1 - n0, q1 - q0, len(grp)
+                dlq = torch.empty((N, Q), dtype=torch.float32, device=dev)
+                L.check(lib.a3d_group_max_backward(_ptr(y.g.contiguous()), _ptr(arg), N, Q, G, _ptr(dlq), _stream()), "gm_bwd")
+                _apply(dlq, E.v[q0:q1], N, Q, 1, 128, 0, 1.0, dsrc[n0:n1])
+                # dE [Q, 128] = dlq^T src is a weight gradient (rows = the MFMA k dimension, wgrad.hip): the N-long reduction
+                # runs on the matrix cores instead of the one-thread-per-output split kernel (0.47 ms per call); the kernel
+                # wants channel counts in multiples of 32, so the Q columns are padded with zeros
+                Qp = (Q + 31) // 32 * 32
+                if Qp != Q:
+                    dlq_p = torch.zeros((N, Qp), dtype=torch.float32, device=dev)
+                    dlq_p[:, :Q] = dlq
+                else:
+                    dlq_p = dlq
+                dE[q0:q1] = B.linear_weight_grad(dlq_p, src.v[n0:n1])[:Q]
             src.add_grad(dsrc)
             E.add_grad(dE)
         self.steps.append(back)
-        return y
+        return outs
 
-    # ------------------------------------------------------------------ forward (agile3d.py:192-323)
-    def _forward(self, pcd, pos_enc, click_idx, click_time_idx):
-        dev = pcd.device
-        K = len(click_idx) - 1
-        fg_split = [len(click_idx[str(i)]) for i in range(1, K + 1)]
-        for i, c in enumerate(fg_split):
-            if c == 0:   # an empty group has no maximum: the reference fails on it too (agile3d.py:353)
-                raise ValueError(f"object {i + 1} has no click (the reference fails on an empty max, agile3d.py:353)")
-        fg_rows = [r for i in range(1, K + 1) for r in click_idx[str(i)]]
-        fg_times = [t for i in range(1, K + 1) for t in click_time_idx[str(i)]]
-        bg_rows, bg_times = list(click_idx["0"]), list(click_time_idx["0"])
+    # ------------------------------------------------------------------ forward (agile3d.py:192-323), whole batch
+    def _forward(self, pcds, pos_encs, click_idxs, click_time_idxs):
+        dev = pcds[0].device
         tt = time_table(128, 200).to(dev)
-        n_fg, n_bgl = len(fg_rows), self.P["bg_query_feat.weight"].shape[0]
-        rows = torch.tensor(fg_rows + bg_rows, dtype=torch.long, device=dev)
-        fixed_pos = pos_enc[rows] + tt[torch.tensor(fg_times + bg_times, dtype=torch.long, device=dev)]
-        self.pcd = _T(pcd)
-        pos = _T(pos_enc)
-        # queries: clicked rows of pcd_features (+ learned background queries in between), their position encodings
         bgq, bgp = self.P["bg_query_feat.weight"].detach(), self.P["bg_query_pos.weight"].detach()
-        q0 = _T(torch.cat([pcd[rows[:n_fg]], bgq, pcd[rows[n_fg:]]], 0).contiguous())
-        qpos = _T(torch.cat([fixed_pos[:n_fg], bgp, fixed_pos[n_fg:]], 0).contiguous())
+        n_bgl = bgq.shape[0]
+        n_ranges, q_ranges, groups, samples = [], [], [], []
+        n_at = q_at = 0
+        q_parts, qpos_parts = [], []
+        for pcd, pos_enc, click_idx, click_time_idx in zip(pcds, pos_encs, click_idxs, click_time_idxs):
+            K = len(click_idx) - 1
+            fg_split = [len(click_idx[str(i)]) for i in range(1, K + 1)]
+            for i, c in enumerate(fg_split):
+                if c == 0:   # an empty group has no maximum: the reference fails on it too (agile3d.py:353)
+                    raise ValueError(f"object {i + 1} has no click (the reference fails on an empty max, agile3d.py:353)")
+            fg_rows = [r for i in range(1, K + 1) for r in click_idx[str(i)]]
+            fg_times = [t for i in range(1, K + 1) for t in click_time_idx[str(i)]]
+            bg_rows, bg_times = list(click_idx["0"]), list(click_time_idx["0"])
+            n_fg = len(fg_rows)
+            rows = torch.tensor(fg_rows + bg_rows, dtype=torch.long, device=dev)
+            fixed_pos = pos_enc[rows] + tt[torch.tensor(fg_times + bg_times, dtype=torch.long, device=dev)]
+            # queries: clicked rows of pcd_features (+ learned background queries in between), their position encodings
+            q_parts += [pcd[rows[:n_fg]], bgq, pcd[rows[n_fg:]]]
+            qpos_parts += [fixed_pos[:n_fg], bgp, fixed_pos[n_fg:]]
+            Q = n_fg + n_bgl + len(bg_rows)
+            grp = [(n_fg, Q)]                       # column 0 = background queries, then the objects
+            s_ = 0
+            for c in fg_split:
+                grp.append((s_, s_ + c))
+                s_ += c
+            gq = [0] * Q
+            for g_i, (b0, b1) in enumerate(grp):
+                for qq in range(b0, b1):
+                    gq[qq] = g_i
+            samples.append({"rows": rows, "n_fg": n_fg, "Q": Q, "n0": n_at, "q0": q_at,
+                            "grp_of_query": torch.tensor(gq, dtype=torch.long, device=dev)})   # mask-head column of each query
+            n_ranges.append((n_at, n_at + pcd.shape[0]))
+            q_ranges.append((q_at, q_at + Q))
+            groups.append(grp)
+            n_at += pcd.shape[0]
+            q_at += Q
+        self.n_ranges, self.q_ranges = n_ranges, q_ranges
+        pcd_all = pcds[0] if len(pcds) == 1 else torch.cat(pcds, 0)
+        self.pcd = _T(pcd_all.contiguous())
+        pos = _T((pos_encs[0] if len(pos_encs) == 1 else torch.cat(pos_encs, 0)).contiguous())
+        q0 = _T(torch.cat(q_parts, 0).contiguous())
+        qpos = _T(torch.cat(qpos_parts, 0).contiguous())
 
         def q0_back():
             g = q0.g
-            d = torch.zeros_like(pcd)
-            d.index_add_(0, rows, torch.cat([g[:n_fg], g[n_fg + n_bgl:]], 0))   # a row clicked twice gets both
+            d = torch.zeros_like(self.pcd.v)
+            dbq = torch.zeros_like(bgq)
+            dbp = torch.zeros_like(bgp)
+            for sm in samples:
+                a0, n_fg, Q = sm["q0"], sm["n_fg"], sm["Q"]
+                gs = g[a0:a0 + Q]
+                d.index_add_(0, sm["rows"] + sm["n0"], torch.cat([gs[:n_fg], gs[n_fg + n_bgl:]], 0))   # a row clicked twice gets both
+                dbq += gs[n_fg:n_fg + n_bgl]
+                if qpos.g is not None:
+                    dbp += qpos.g[a0 + n_fg:a0 + n_fg + n_bgl]
             self.pcd.add_grad(d)
-            self._pg("bg_query_feat.weight", g[n_fg:n_fg + n_bgl])
+            self._pg("bg_query_feat.weight", dbq)
             if qpos.g is not None:
-                self._pg("bg_query_pos.weight", qpos.g[n_fg:n_fg + n_bgl])
+                self._pg("bg_query_pos.weight", dbp)
         self.steps.append(q0_back)
-        Q = q0.v.shape[0]
-        groups = [(n_fg, Q)]                       # column 0 = background queries, then the objects
-        s = 0
-        for c in fg_split:
-            groups.append((s, s + c))
-            s += c
-        src, tgt, mask = self.pcd, q0, None
-        self.logits_nodes = []
+        src, tgt, masks = self.pcd, q0, None
+        self.logits_nodes = []                     # [layer][sample]
         for d in range(self.model.num_decoders):
             li = 0 if self.model.shared_decoder else d
-            a = self.mha(f"c2s_attention.{li}.0.multihead_attn.", self.add(tgt, qpos), self.add(src, pos), src, mask)
+            a = self.mha(f"c2s_attention.{li}.0.multihead_attn.", self.add(tgt, qpos), self.add(src, pos), src, q_ranges, n_ranges,
+                         masks)
             tgt = self.ln(self.add(tgt, a), f"c2s_attention.{li}.0.norm.")
             qk = self.add(tgt, qpos)
-            a = self.mha(f"c2c_attention.{li}.0.self_attn.", qk, qk, tgt)
+            a = self.mha(f"c2c_attention.{li}.0.self_attn.", qk, qk, tgt, q_ranges, q_ranges)
             tgt = self.ln(self.add(tgt, a), f"c2c_attention.{li}.0.norm.")
             h = self.relu(self.lin(tgt, f"ffn_attention.{li}.0.linear1.weight", f"ffn_attention.{li}.0.linear1.bias"))
             f = self.lin(h, f"ffn_attention.{li}.0.linear2.weight", f"ffn_attention.{li}.0.linear2.bias")
             tgt = self.ln(self.add(tgt, f), f"ffn_attention.{li}.0.norm.")
-            a = self.mha(f"s2c_attention.{li}.0.multihead_attn.", self.add(src, pos), self.add(tgt, qpos), tgt)
+            a = self.mha(f"s2c_attention.{li}.0.multihead_attn.", self.add(src, pos), self.add(tgt, qpos), tgt, n_ranges, q_ranges)
             src = self.ln(self.add(src, a), f"s2c_attention.{li}.0.norm.")
-            out = self.mask_head(tgt, src, groups)
-            self.logits_nodes.append(out)
-            # attention mask of the next layer from this layer's labels (agile3d.py:362-383): not differentiated
-            labels = out.v.argmax(1)
-            m = torch.empty((Q, pcd.shape[0]), dtype=torch.bool, device=dev)
-            for g_i, (b0, b1) in enumerate(groups):
-                row = labels != g_i
-                if bool(row.all()):
-                    row = torch.zeros_like(row)
-                m[b0:b1] = row
-            mask = m.to(torch.uint8).contiguous()
-            self.attn_masks.append(mask)
-        self.logits = [n.v for n in self.logits_nodes]
+            outs = self.mask_head(tgt, src, n_ranges, q_ranges, groups)
+            self.logits_nodes.append(outs)
+            # attention masks of the next layer from this layer's labels (agile3d.py:362-383): not differentiated.  No host
+            # round trip: "all points blocked -> nothing blocked" (agile3d.py:369,375) is "no point carries the group's
+            # label", i.e. a zero in the label histogram; a `bool(row.all())` per group would drain the GPU queue G + 1
+            # times per layer and sample
+            masks = []
+            for out, sm, grp in zip(outs, samples, groups):
+                labels = out.v.argmax(1)
+                counts = torch.bincount(labels, minlength=len(grp))
+                gqv = sm["grp_of_query"]
+                m = (labels[None, :] != gqv[:, None]) & (counts[gqv] > 0)[:, None]
+                masks.append(m.to(torch.uint8).contiguous())
+            self.attn_masks.append(masks[0] if self._single else masks)
+        if self._single:
+            self.logits = [layer[0].v for layer in self.logits_nodes]
+        else:
+            self.logits = [[n.v for n in layer] for layer in self.logits_nodes]
+
+    def release(self):
+        """Drop the recorded steps and activations.  The backward closures refer to the tape and the tape to them: a
+        reference cycle, i.e. without this every iteration's activations (gigabytes at 4 x 80 k voxels) stay allocated
+        until Python's cycle collector gets to them -- the caching allocator then answers the next iteration with fresh
+        hipMallocs (measured: 350 device allocations and +12 GB reserved per iteration, 107 GB after ten)."""
+        self.steps, self.logits_nodes, self.relu_masks, self.attn_masks, self.args = [], [], [], [], []
+        self.pcd = None
 
     # ------------------------------------------------------------------ backward
     def backward(self, d_logits):
-        """``d_logits``: list of dL/dlogits per decoder layer ([N, 1+K] each, None = no loss on that layer)."""
+        """``d_logits``: dL/dlogits per decoder layer -- one [N, 1+K] tensor per layer for a single-sample tape, a list over
+        the samples per layer for a batched one (None = no loss there).  Returns (gradients keyed like state_dict(),
+        dL/d(pcd_features) [N_total, 128])."""
         self.grads = {}
-        for node, g in zip(self.logits_nodes, d_logits):
-            if g is not None:
-                node.g = g.to(torch.float32).contiguous()
-        for n in self.logits_nodes:
-            if n.g is None:
-                n.g = torch.zeros_like(n.v)
+        for nodes, g in zip(self.logits_nodes, d_logits):
+            gs = [g] if self._single else list(g)
+            for node, gg in zip(nodes, gs):
+                node.g = gg.to(torch.float32).contiguous() if gg is not None else torch.zeros_like(node.v)
         for back in reversed(self.steps):
             back()
         return self.grads, self.pcd.g

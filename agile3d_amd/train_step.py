@@ -27,6 +27,21 @@ from .train_decoder import DecoderTape
 
 
 def train_one_step(model, criterion, optimizer, batch, device, max_norm: float = 0.1):
+    """One iteration of engine.py:38-150 (see the module docstring).  Python's cycle collector is held off for the duration
+    of the iteration: the tapes create tens of thousands of container objects, a generation-2 collection in the middle of
+    a phase costs 50-100 ms (measured as phases that randomly take 80 ms instead of 2), and the tapes break their own
+    reference cycles when they are released at the end."""
+    import gc
+    gc_was_on = gc.isenabled()
+    gc.disable()
+    try:
+        return _train_one_step(model, criterion, optimizer, batch, device, max_norm)
+    finally:
+        if gc_was_on:
+            gc.enable()
+
+
+def _train_one_step(model, criterion, optimizer, batch, device, max_norm):
     coords, raw_coords, feats, labels, _, _, click_idx, _scene_name, _num_obj = batch
     timing = os.environ.get("A3D_TRAIN_TIMING")           # phase wall times (device-synchronised) on stderr
     marks = []
@@ -92,11 +107,13 @@ def train_one_step(model, criterion, optimizer, batch, device, max_norm: float =
     model.train()
     mark(f"click simulation ({num_forward_iters} decoder rounds)")
 
-    # ---- decoder, training mode, one tape per sample (agile3d.py:192 loops over the samples)
-    tapes = [DecoderTape(model, pcd[s:e], pos_enc[i], click_idx[i], click_time_idx[i]) for i, (s, e) in enumerate(ranges)]
-    n_layers = len(tapes[0].logits)
-    outputs = {"pred_masks": [t.logits[-1] for t in tapes],
-               "aux_outputs": [{"pred_masks": [t.logits[l] for t in tapes]} for l in range(n_layers - 1)]}
+    # ---- decoder, training mode: ONE tape for the batch (agile3d.py:192 loops over the samples, which only share the
+    # weights: row-wise layers run once over all samples' rows, attention and the mask head per sample on row ranges)
+    tape = DecoderTape(model, [pcd[s:e] for (s, e) in ranges], [pos_enc[i] for i in range(len(ranges))], click_idx,
+                       click_time_idx)
+    n_layers = len(tape.logits)
+    outputs = {"pred_masks": list(tape.logits[-1]),
+               "aux_outputs": [{"pred_masks": list(tape.logits[l])} for l in range(n_layers - 1)]}
 
     mark("decoder forward")
     # ---- losses (engine.py:124-128) and their gradient with respect to every level's logits
@@ -109,14 +126,10 @@ def train_one_step(model, criterion, optimizer, batch, device, max_norm: float =
 
     mark("losses")
     # ---- backward: decoders, then the backbone through d(pcd_features)
-    grads = {}
-    d_pcd = torch.empty_like(pcd)
-    for i, ((s, e), t) in enumerate(zip(ranges, tapes)):
-        dl = [gl["aux_outputs"][l][i] for l in range(n_layers - 1)] + [gl["pred_masks"][i]]
-        g, dp = t.backward(dl)
-        d_pcd[s:e] = dp
-        for k, v in g.items():
-            grads[k] = v if k not in grads else grads[k] + v
+    n_s = len(ranges)
+    dl = [[gl["aux_outputs"][l][i] for i in range(n_s)] for l in range(n_layers - 1)] + [[gl["pred_masks"][i] for i in range(n_s)]]
+    grads, d_pcd = tape.backward(dl)         # rows of the samples are contiguous and in order: d_pcd is [N_total, 128]
+    grads = dict(grads)
     mark("decoder backward")
     # ---- data-parallel average (engine.py runs under DDP: main.py:115-127), overlapped with the backbone backward: the
     # decoder's gradients are final here, the U-Net's become final from the head down to the stem
@@ -128,6 +141,9 @@ def train_one_step(model, criterion, optimizer, batch, device, max_norm: float =
     grads.update(bb.backward(d_pcd, on_grad=reducer.add if reducer.active else None))
     mark("backbone backward")
     reducer.finish(grads)
+    tape.release()                       # break the tape <-> closure cycles: the activations are freed NOW, the next
+    bb.release()                         # iteration reuses their blocks instead of growing the allocator's pools
+    del tape, bb
 
     # ---- clip, AdamW (engine.py:143-150)
     norm, coef = clip_grad_norm_(grads, max_norm)

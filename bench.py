@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- scenes/s of the AGILE3D hot path on MI355X (BASELINE.json metric).
 
-One *step* = one batch of --batch (default 4) independent scenes through the whole hot path, inputs already
+One *step* = one batch of --batch (default 16) independent scenes through the whole hot path, inputs already
 resident in HBM: ONE batched SparseTensor as the reference's collate builds it (batch index in column 0),
 coordinate manager build (a3d_scene_create) + forward_backbone over the batch + ONE forward_mask (one decoder
 pass per sample).  Every scene is BASELINE.json configs[1]: a seeded synthetic 80k-voxel scene, 10 clicks
@@ -322,7 +322,7 @@ def main():
                     help="only the 4-scene steps (warm-up, timed region, instrumented pass): no latency / phase / eval-round "
                          "/ CPU passes -- the command tools/profile_round.sh traces for profiles/kernel_avg_us.json, so that "
                          "every launch of a kernel in the trace is a launch of the step the roofline object describes")
-    ap.add_argument("--batch", type=int, default=int(os.environ.get("A3D_BENCH_BATCH", "4")),
+    ap.add_argument("--batch", type=int, default=int(os.environ.get("A3D_BENCH_BATCH", "16")),
                     help="scenes per step and rank (one batched SparseTensor, as the reference's collate builds)")
     ap.add_argument("--streams", type=int, default=int(os.environ.get("A3D_BENCH_STREAMS", "4")),
                     help="scenes in flight per GPU: consecutive steps are issued round-robin on this many HIP streams")
@@ -588,6 +588,40 @@ def main():
                 if rnd >= 4:
                     rounds.append(1e3 * (time.perf_counter() - t0))
             res["eval_round_ms"] = round(float(np.median(rounds)), 4)
+            # the same protocol with the whole batch in flight: ONE batched forward_mask per round (a launch per decoder
+            # kernel for all scenes), then label argmax / IoU / click simulator per scene; scene-rounds per second
+            rB = model.forward_backbone(SparseTensor(features=feats, coordinates=coords), raw_coordinates=raw)
+            labs, raws = [], []
+            for b_, s_ in enumerate(scenes):
+                lb = np.zeros(len(s_["coords"]), np.int64)
+                sz = sorted(((int((s_["labels"] == i).sum()), i) for i in np.unique(s_["labels"]) if i > 0), reverse=True)
+                for k_, (_, i) in enumerate(sz[:args.objects], start=1):
+                    lb[s_["labels"] == i] = k_
+                labs.append(torch.from_numpy(lb).to(dev))
+                raws.append(torch.from_numpy(s_["raw_xyz"]).to(dev))
+            ecis = [{str(k_): [] for k_ in range(args.objects + 1)} for _ in scenes]
+            ects = [{str(k_): [] for k_ in range(args.objects + 1)} for _ in scenes]
+            preds = [torch.zeros(len(s_["coords"]), dtype=torch.int32, device=dev) for s_ in scenes]
+            _random.seed(0)
+            brounds = []
+            for rnd in range(16):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                if rnd:
+                    outs = model.forward_mask(*rB, click_idx=ecis, click_time_idx=ects)["pred_masks"]
+                for b_ in range(len(scenes)):
+                    if rnd:
+                        preds[b_] = pc.argmax_labels(outs[b_], ecis[b_])
+                    pc.mean_iou_scene(preds[b_], labs[b_])
+                    new, _, _, nt = pc.get_simulated_clicks(preds[b_], labs[b_], raws[b_], rnd, training=False)
+                    if new is not None:
+                        pc.extend_clicks(ecis[b_], ects[b_], new, nt)
+                torch.cuda.synchronize()
+                if rnd >= 3:
+                    brounds.append(time.perf_counter() - t0)
+            res["eval_rounds_per_s"] = round(len(scenes) / float(np.median(brounds)), 1)
+            res["eval_rounds_note"] = (f"{len(scenes)} scenes advance in lock-step (eval_multi_obj.py:114,162-166 with a batch): one "
+                                       "batched forward_mask + per-scene argmax / IoU / click simulator per round; scene-rounds per second")
         if not args.no_cpu_baseline and not args.steps_only and world == 1:
             res["cpu_baseline"], diff = cpu_baseline(sd, sc, ci, ct, gpu_logits0, gpu_feats0)
             res["parity_vs_oracle"] = diff

@@ -110,12 +110,15 @@ def step_time(voxels, batch):
          tuple(f"scene{i:04d}_00" for i in range(batch)), tuple(0 for _ in scenes))
     opt = AdamW(model.named_parameters(), lr=1e-4, weight_decay=1e-4)
     np.random.seed(1), random.seed(1)
-    for it in range(4):
+    for it in range(int(os.environ.get("A3D_BB_ITERS", "4"))):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         st = train_one_step(model, crit, opt, b, torch.device("cuda"), 0.1)
         torch.cuda.synchronize()
-        print(f"training iteration {it}: {1e3 * (time.perf_counter() - t0):.0f} ms, loss {st['loss']:.3f}, clicks {st['clicks']}")
+        ms = torch.cuda.memory_stats()
+        print(f"training iteration {it}: {1e3 * (time.perf_counter() - t0):.0f} ms, loss {st['loss']:.3f}, clicks {st['clicks']}, "
+              f"device allocations so far {ms.get('num_device_alloc', 0)}, frees {ms.get('num_device_free', 0)}, reserved "
+              f"{ms.get('reserved_bytes.all.current', 0) >> 20} MB")
 
 
 if __name__ == "__main__":
