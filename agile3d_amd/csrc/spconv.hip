@@ -1283,7 +1283,7 @@ static int launch_conv_sk(ConvArgs c, const int* pre64, float* slab_ws, size_t s
   {
     static int dbg = sk_env("A3D_DBG", 0);
     a.dbg = dbg;
-    static int prio = sk_env("A3D_SK_PRIO", 0);
+    static int prio = sk_env("A3D_SK_PRIO", 1);   // measured +1 % on the 96-column layers (L0 593 -> 588 us); 0 switches it off
     a.prio = handoff && p.G > 256 ? prio : 0;
   }
   if (c.K > 1 && !pre) {

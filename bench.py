@@ -186,7 +186,7 @@ def cpu_baseline(sd, sc, ci, ct, gpu_logits=None, gpu_feats=None, samples=5):
     return res, diff
 
 
-def iou_at_k(model, sd, dev, n_scenes=2, voxels=6000, objects=3, max_clicks=15):
+def iou_at_k(model, sd, dev, n_scenes=2, voxels=6000, objects=3, max_clicks=20):
     """BASELINE.json's "IoU@k vs ref" on what exists offline: the interactive protocol (eval_multi_obj.py:76-173 ->
     evaluation/evaluator_MO.py IoU@k / NoC@q) run twice on seeded labelled synthetic scenes with the same random-init
     weights and the same `random` seed -- once by the GPU product (agile3d_amd.Evaluate: HIP decoder, label argmax, IoU
@@ -319,7 +319,7 @@ def main():
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--dump-logits", default="", help="write scene 0's logits of the first step to this file (torch.save)")
     ap.add_argument("--steps-only", action="store_true",
-                    help="only the 4-scene steps (warm-up, timed region, instrumented pass): no latency / phase / eval-round "
+                    help="only the batched steps (warm-up, timed region, instrumented pass): no latency / phase / eval-round "
                          "/ CPU passes -- the command tools/profile_round.sh traces for profiles/kernel_avg_us.json, so that "
                          "every launch of a kernel in the trace is a launch of the step the roofline object describes")
     ap.add_argument("--batch", type=int, default=int(os.environ.get("A3D_BENCH_BATCH", "16")),
