@@ -25,6 +25,26 @@
 namespace a3d {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+// A pointer read out of a descriptor table in memory is "generic" to the compiler: accesses through it become FLAT
+// instructions, which count in BOTH vmcnt and lgkmcnt and are only ever waited for with s_waitcnt 0 -- every LDS wait of
+// the loop then also waits for the point rows in flight from HBM and no prefetch survives.  These state the address
+// space (global_load / global_store: vmcnt only, in order).
+#define A3D_GLOBAL __attribute__((address_space(1)))
+template <typename T>
+__device__ __forceinline__ T gld(const T* p) { return *(const T A3D_GLOBAL*)p; }
+template <typename T>
+__device__ __forceinline__ void gst(T* p, T v) { *(T A3D_GLOBAL*)p = v; }
+__device__ __forceinline__ f32x4 gld4(const float* p) { return *(const f32x4 A3D_GLOBAL*)p; }
+__device__ __forceinline__ void gst4(float* p, f32x4 v) { *(f32x4 A3D_GLOBAL*)p = v; }
+// agent-scope (coherent across workgroups) relaxed accesses of the in-kernel hand-offs
+template <typename T>
+__device__ __forceinline__ T gld_agent(const T* p) {
+  return __hip_atomic_load((const T A3D_GLOBAL*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+template <typename T>
+__device__ __forceinline__ void gst_agent(T* p, T v) {
+  __hip_atomic_store((T A3D_GLOBAL*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 constexpr int D = 128;        // hidden_dim
 constexpr int H = 8;          // heads
 constexpr int DH = 16;        // head dim
@@ -309,11 +329,11 @@ __global__ void __launch_bounds__(512) k_kv_c2s(const DecSampleDev* __restrict__
   unsigned lab_nx = 0u;
   if (slot < ngroups) {
     const size_t row = (size_t)min(slot * 16 + j, n - 1);
-    if (labels) lab_nx = *(const unsigned*)(labels + slot * 16 + 4 * g);
+    if (labels) lab_nx = gld((const unsigned*)(labels + slot * 16 + 4 * g));
 #pragma unroll
-    for (int S = 0; S < 8; ++S) xs[S] = *(const f32x4*)(X + row * D + 16 * S + 4 * g);
+    for (int S = 0; S < 8; ++S) xs[S] = gld4(X + row * D + 16 * S + 4 * g);
 #pragma unroll
-    for (int S = 0; S < 8; ++S) pe[S] = *(const f32x4*)(Pe + row * D + 16 * S + 4 * g);
+    for (int S = 0; S < 8; ++S) pe[S] = gld4(Pe + row * D + 16 * S + 4 * g);
   }
   {
     constexpr int TOT = 2 * 8 * 8 * 64;
@@ -331,7 +351,7 @@ __global__ void __launch_bounds__(512) k_kv_c2s(const DecSampleDev* __restrict__
   }
   for (int e = threadIdx.x; e < QP * 32; e += 512) {
     const int r = e >> 5, c4 = (e & 31) * 4;
-    *(f32x4*)(qp_l + r * LDQ + c4) = *(const f32x4*)(qproj + (size_t)r * D + c4);
+    *(f32x4*)(qp_l + r * LDQ + c4) = gld4(qproj + (size_t)r * D + c4);
   }
   if (threadIdx.x < D) {
     bk_l[threadIdx.x] = bk[threadIdx.x];
@@ -341,8 +361,8 @@ __global__ void __launch_bounds__(512) k_kv_c2s(const DecSampleDev* __restrict__
   bool qmask[QT];
 #pragma unroll
   for (int qt = 0; qt < QT; ++qt) {
-    obj[qt] = qobj[qt * 16 + j];
-    qmask[qt] = labels != nullptr && obj[qt] >= 0 && counts[obj[qt]] > 0;
+    obj[qt] = gld(qobj + qt * 16 + j);
+    qmask[qt] = labels != nullptr && obj[qt] >= 0 && gld(counts + obj[qt]) > 0;
   }
   __syncthreads();
   // two waves share a sequence of point groups: wave 2s takes heads 0..3 of it, wave 2s+1 heads 4..7 (the flash
@@ -366,7 +386,7 @@ __global__ void __launch_bounds__(512) k_kv_c2s(const DecSampleDev* __restrict__
     // compiler from sinking the prefetch into one conditional block behind the attention phase)
     const int next = grp + nslots < ngroups ? grp + nslots : grp;
     const size_t nrow = (size_t)min(next * 16 + j, n - 1);
-    if (labels) lab_nx = *(const unsigned*)(labels + next * 16 + 4 * g);
+    if (labels) lab_nx = gld((const unsigned*)(labels + next * 16 + 4 * g));
     // ---- projections of this wave's four heads, k-step by k-step: K^T slice kf[hl] = channels 16h+4g..+3 of point j,
     // V slice vv[hl] = channel 16h+j of points 4g..4g+3.  A k-step's row fragments are dead once its MFMAs are
     // issued, so the SAME registers take the next group's rows right away: the loads have the rest of this phase
@@ -403,8 +423,8 @@ __global__ void __launch_bounds__(512) k_kv_c2s(const DecSampleDev* __restrict__
           wk = nk;
           wv = nv;
         }
-        xs[S] = *(const f32x4*)(X + nrow * D + 16 * S + 4 * g);
-        pe[S] = *(const f32x4*)(Pe + nrow * D + 16 * S + 4 * g);
+        xs[S] = gld4(X + nrow * D + 16 * S + 4 * g);
+        pe[S] = gld4(Pe + nrow * D + 16 * S + 4 * g);
         __builtin_amdgcn_sched_barrier(0);
       }
     }
@@ -461,11 +481,11 @@ __global__ void __launch_bounds__(512) k_kv_c2s(const DecSampleDev* __restrict__
       lt = rows_sum(lt);
       float* pq = P + (size_t)(qt * 16 + j) * kPartStride;
       if (g == 0) {
-        pq[0] = m[hl][qt];
-        pq[1] = lt;
+        gst(pq, m[hl][qt]);
+        gst(pq + 1, lt);
       }
 #pragma unroll
-      for (int t = 0; t < 4; ++t) pq[2 + 4 * g + t] = acc[hl][qt][t];
+      for (int t = 0; t < 4; ++t) gst(pq + 2 + 4 * g + t, acc[hl][qt][t]);
     }
   }
 }
@@ -484,12 +504,12 @@ __global__ void __launch_bounds__(64) k_c2s_combine(const QuerySample* __restric
   for (int d = 0; d < DH; ++d) o[d] = 0.f;
   for (int ch = lane; ch < nchunk; ch += 64) {
     const float* p = part + (((size_t)ch * H + h) * QP + q) * kPartStride;
-    const float pm = p[0];
+    const float pm = gld(p);
     const float mn = fmaxf(m, pm);
     const float a = expf(m - mn), b = expf(pm - mn);
-    l = l * a + p[1] * b;
+    l = l * a + gld(p + 1) * b;
 #pragma unroll
-    for (int d = 0; d < DH; ++d) o[d] = o[d] * a + p[2 + d] * b;
+    for (int d = 0; d < DH; ++d) o[d] = o[d] * a + gld(p + 2 + d) * b;
     m = mn;
   }
   float M = m;
@@ -504,7 +524,7 @@ __global__ void __launch_bounds__(64) k_c2s_combine(const QuerySample* __restric
     float v = o[d] * sc;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-    if (lane == d) attn[(size_t)q * D + h * DH + d] = v / l;
+    if (lane == d) gst(attn + (size_t)q * D + h * DH + d, v / l);
   }
 }
 
@@ -742,8 +762,8 @@ __global__ void __launch_bounds__(512) k_q_s2c(const DecSampleDev* __restrict__ 
   }
   for (int e = threadIdx.x; e < QP * 32; e += 512) {
     const int r = e >> 5, c4 = (e & 31) * 4;
-    *(f32x4*)(ks_l + r * LD + c4) = *(const f32x4*)(ks + (size_t)r * D + c4);
-    const f32x4 v4 = *(const f32x4*)(vs + (size_t)r * D + c4);
+    *(f32x4*)(ks_l + r * LD + c4) = gld4(ks + (size_t)r * D + c4);
+    const f32x4 v4 = gld4(vs + (size_t)r * D + c4);
 #pragma unroll
     for (int t = 0; t < 4; ++t) vt_l[(c4 + t) * LT + r] = v4[t];
   }
@@ -758,9 +778,9 @@ __global__ void __launch_bounds__(512) k_q_s2c(const DecSampleDev* __restrict__ 
     const float* xr = X + row * D + 4 * g;
     const float* pr = Pe + row * D + 4 * g;
 #pragma unroll
-    for (int S = 0; S < 8; ++S) nx[S] = *(const f32x4*)(xr + 16 * S);
+    for (int S = 0; S < 8; ++S) nx[S] = gld4(xr + 16 * S);
 #pragma unroll
-    for (int S = 0; S < 8; ++S) np[S] = *(const f32x4*)(pr + 16 * S);
+    for (int S = 0; S < 8; ++S) np[S] = gld4(pr + 16 * S);
   };
   if (grp < ngroups) fetch(grp);
   const unsigned long long t_loop = dbg ? __builtin_amdgcn_s_memtime() : 0;
@@ -834,7 +854,7 @@ __global__ void __launch_bounds__(512) k_q_s2c(const DecSampleDev* __restrict__ 
 #pragma unroll
         for (int t = 0; t < 4; ++t) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(vf[t], sc[kt][t] * inv, acc, 0, 0, 0);
       }
-      if (p0 + j < n) *(f32x4*)(orow + h * DH + 4 * g) = acc;
+      if (p0 + j < n) gst4(orow + h * DH + 4 * g, acc);
       if (dbg) {
         asm volatile("v_mov_b32 %0, %0" : "+v"(acc[0]));
         lap(2);
@@ -885,7 +905,7 @@ __global__ void __launch_bounds__(512) k_out_ln_mask(const DecSampleDev* __restr
   float* O_l = L_l + NW * 16 * LL;                // [NW][16][K+1]
   int* hist = (int*)(O_l + NW * 16 * (K + 1));    // [K+1]
   int* qr_l = hist + K + 1;                       // [K+2] query range of every object
-  for (int e = threadIdx.x; e <= K + 1; e += 512) qr_l[e] = qrange[e];
+  for (int e = threadIdx.x; e <= K + 1; e += 512) qr_l[e] = gld(qrange + e);
   {
     constexpr int TOT = 8 * 8 * 64;
     for (int base = threadIdx.x; base < TOT; base += 8 * 512) {
@@ -900,7 +920,7 @@ __global__ void __launch_bounds__(512) k_out_ln_mask(const DecSampleDev* __restr
   }
   for (int e = threadIdx.x; e < QP * 32; e += 512) {
     const int r = e >> 5, c4 = (e & 31) * 4;
-    *(f32x4*)(E_l + r * LD + c4) = *(const f32x4*)(E + (size_t)r * D + c4);
+    *(f32x4*)(E_l + r * LD + c4) = gld4(E + (size_t)r * D + c4);
   }
   for (int e = threadIdx.x; e <= K; e += 512) hist[e] = 0;
   if (threadIdx.x < D) {
@@ -921,9 +941,9 @@ __global__ void __launch_bounds__(512) k_out_ln_mask(const DecSampleDev* __restr
     const float* orow = O + row * D + 4 * g;
     const float* rrow = Xres + row * D + 4 * g;
 #pragma unroll
-    for (int S = 0; S < 8; ++S) nx[S] = *(const f32x4*)(orow + 16 * S);
+    for (int S = 0; S < 8; ++S) nx[S] = gld4(orow + 16 * S);
 #pragma unroll
-    for (int S = 0; S < 8; ++S) nr[S] = *(const f32x4*)(rrow + 16 * S);   // residual rows: channels 16ct+4g..+3
+    for (int S = 0; S < 8; ++S) nr[S] = gld4(rrow + 16 * S);   // residual rows: channels 16ct+4g..+3
   };
   if (grp < ngroups) fetch(grp);
   while (grp < ngroups) {
@@ -970,7 +990,7 @@ __global__ void __launch_bounds__(512) k_out_ln_mask(const DecSampleDev* __restr
       const f32x4 be = *(const f32x4*)(be_l + 16 * ct + 4 * g);
 #pragma unroll
       for (int t = 0; t < 4; ++t) y[ct][t] = (y[ct][t] - mean) * rstd * ga[t] + be[t];
-      if (p0 + j < n) *(f32x4*)(yrow + 16 * ct + 4 * g) = y[ct];
+      if (p0 + j < n) gst4(yrow + 16 * ct + 4 * g, y[ct]);
     }
     // logits of the 16 points against every query (C layout: row = point 4g+t, column = query j)
 #pragma unroll
@@ -1003,11 +1023,11 @@ __global__ void __launch_bounds__(512) k_out_ln_mask(const DecSampleDev* __restr
           bi = o;
         }
       }
-      labels[p0 + lane] = (unsigned char)bi;
+      gst(labels + p0 + lane, (unsigned char)bi);
       atomicAdd(&hist[bi], 1);
     }
     const int rows = min(16, n - p0);
-    for (int e = lane; e < rows * (K + 1); e += 64) logits[(size_t)p0 * (K + 1) + e] = Ow[e];
+    for (int e = lane; e < rows * (K + 1); e += 64) gst(logits + (size_t)p0 * (K + 1) + e, Ow[e]);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // scratch is rewritten by the next group
     grp = next;
   }
@@ -1055,7 +1075,7 @@ __global__ void __launch_bounds__(512) k_s2c_out(const DecSampleDev* __restrict_
   float* O_l = be_l + D;                          // [NW][16][Kmax+1] logits staging
   int* hist = (int*)(O_l + NW * 16 * (Kmax + 1)); // [Kmax+1]
   int* qr_l = hist + Kmax + 1;                    // [Kmax+2]
-  for (int e = threadIdx.x; e <= K + 1; e += 512) qr_l[e] = sm.qrange[e];
+  for (int e = threadIdx.x; e <= K + 1; e += 512) qr_l[e] = gld(sm.qrange + e);
   for (int e = threadIdx.x; e <= K; e += 512) hist[e] = 0;
   if (threadIdx.x < D) {
     bq_l[threadIdx.x] = bq[threadIdx.x];
@@ -1085,8 +1105,8 @@ __global__ void __launch_bounds__(512) k_s2c_out(const DecSampleDev* __restrict_
     const int r = e >> 5, c4 = (e & 31) * 4;
     f32x4 k4 = (f32x4){0.f, 0.f, 0.f, 0.f}, v4 = k4;
     if (r < nq) {
-      k4 = *(const f32x4*)(sm.ks + (size_t)r * D + c4);
-      v4 = *(const f32x4*)(sm.vs + (size_t)r * D + c4);
+      k4 = gld4(sm.ks + (size_t)r * D + c4);
+      v4 = gld4(sm.vs + (size_t)r * D + c4);
     }
     *(f32x4*)(ks_l + r * LD + c4) = k4;
 #pragma unroll
@@ -1105,9 +1125,9 @@ __global__ void __launch_bounds__(512) k_s2c_out(const DecSampleDev* __restrict_
     const float* xr = X + row * D + 4 * g;
     const float* pr = Pe + row * D + 4 * g;
 #pragma unroll
-    for (int S = 0; S < 8; ++S) nx[S] = *(const f32x4*)(xr + 16 * S);
+    for (int S = 0; S < 8; ++S) nx[S] = gld4(xr + 16 * S);
 #pragma unroll
-    for (int S = 0; S < 8; ++S) np[S] = *(const f32x4*)(pr + 16 * S);
+    for (int S = 0; S < 8; ++S) np[S] = gld4(pr + 16 * S);
   };
   if (grp < ngroups) fetch(grp);
   while (grp < ngroups) {
@@ -1255,7 +1275,7 @@ __global__ void __launch_bounds__(512) k_s2c_out(const DecSampleDev* __restrict_
       const f32x4 be = *(const f32x4*)(be_l + 16 * ct + 4 * g);
 #pragma unroll
       for (int t = 0; t < 4; ++t) y[ct][t] = (y[ct][t] - mean) * rstd * ga[t] + be[t];
-      if (p0 + j < n) *(f32x4*)(yrow + 16 * ct + 4 * g) = y[ct];
+      if (p0 + j < n) gst4(yrow + 16 * ct + 4 * g, y[ct]);
     }
     // mask embeddings of the queries as A fragments of the transposed logits product, E[query 16 qt + j][16 S + 4 g ..+3]:
     // re-read per group (16 KB, cache resident; requested behind the next group's rows, which went out three heads ago) --
@@ -1265,7 +1285,7 @@ __global__ void __launch_bounds__(512) k_s2c_out(const DecSampleDev* __restrict_
     for (int qt = 0; qt < QT; ++qt) {
       const float* er = sm.E + (size_t)min(qt * 16 + j, nq - 1) * D + 4 * g;
 #pragma unroll
-      for (int S = 0; S < 8; ++S) ef[qt][S] = *(const f32x4*)(er + 16 * S);
+      for (int S = 0; S < 8; ++S) ef[qt][S] = gld4(er + 16 * S);
     }
     // logits^T: lg[qt][t] = logit of query 16 qt + 4 g + t for point j (rows >= nq repeat the last query: never selected)
     // (even / odd K-steps on separate accumulators, query tiles interleaved: no back-to-back dependent MFMAs)
@@ -1305,12 +1325,12 @@ __global__ void __launch_bounds__(512) k_s2c_out(const DecSampleDev* __restrict_
       }
     }
     if (g == 0 && p0 + j < n) {
-      labels[p0 + j] = (unsigned char)bi;
+      gst(labels + p0 + j, (unsigned char)bi);
       atomicAdd(&hist[bi], 1);
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // wave-private staging: written above, read below by other lanes
     const int rows = min(16, n - p0);
-    for (int e = lane; e < rows * (K + 1); e += 64) logits[(size_t)p0 * (K + 1) + e] = Ow[e];
+    for (int e = lane; e < rows * (K + 1); e += 64) gst(logits + (size_t)p0 * (K + 1) + e, Ow[e]);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // rewritten by the next group
     grp = next;
   }
@@ -1336,7 +1356,7 @@ struct QueryLayerW {
 // Y[q][n] = ((X[q][:] (+ Xadd[q][:])) . W[n][:] + bias[n]) * scale, optional relu -- a skinny GEMM
 // on the matrix cores.  W is the torch weight [N][ldw] (K contiguous): lane (g, j) loads
 // W[n0 + j][16 S + 4 g .. +3] as one float4 = the B fragments of four MFMAs (same K permutation as
-// spconv.hip).  X (<= 64 rows) is staged through LDS in 256-column slices (row stride 260 floats:
+// spconv.hip).  X (<= 64 rows, global memory) is staged through LDS in 256-column slices (row stride 260 floats:
 // conflict-free b128 A-fragment reads; vector loads only -- X was written earlier in this kernel).
 // 8 waves; wave w owns output column tiles w, w+8, ...
 constexpr int kLinKC = 256, kLinLD = kLinKC + 4;
@@ -1361,8 +1381,8 @@ __device__ __noinline__ void lin(const float* X, int ldx, const float* Xadd, int
         const int q = e / (kcur >> 2), k4 = (e - q * (kcur >> 2)) * 4;
         f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
         if (q < Q) {
-          v = *(const f32x4*)(X + (size_t)q * ldx + kc + k4);
-          if (Xadd) v += *(const f32x4*)(Xadd + (size_t)q * D + kc + k4);
+          v = gld4(X + (size_t)q * ldx + kc + k4);
+          if (Xadd) v += gld4(Xadd + (size_t)q * D + kc + k4);
         }
         *(f32x4*)(lds + q * kLinLD + k4) = v;
       }
@@ -1371,7 +1391,7 @@ __device__ __noinline__ void lin(const float* X, int ldx, const float* Xadd, int
         const float* wrow = W + (size_t)(ntile * 16 + j) * ldw + kc + 4 * g;
 #pragma unroll 4
         for (int S = 0; S < (kcur >> 4); ++S) {
-          const f32x4 b = *(const f32x4*)(wrow + 16 * S);
+          const f32x4 b = gld4(wrow + 16 * S);
 #pragma unroll
           for (int qt = 0; qt < QT; ++qt) {
             const f32x4 a = *(const f32x4*)(lds + (qt * 16 + j) * kLinLD + 16 * S + 4 * g);
@@ -1383,7 +1403,7 @@ __device__ __noinline__ void lin(const float* X, int ldx, const float* Xadd, int
     }
     if (active) {
       const int col = ntile * 16 + j;
-      const float b = bias ? bias[col] : 0.f;
+      const float b = bias ? gld(bias + col) : 0.f;
 #pragma unroll
       for (int qt = 0; qt < QT; ++qt)
 #pragma unroll
@@ -1392,7 +1412,7 @@ __device__ __noinline__ void lin(const float* X, int ldx, const float* Xadd, int
           if (q < Q) {
             float y = (acc[qt][t] + b) * scale;
             if (relu) y = fmaxf(y, 0.f);
-            Y[(size_t)q * ldy + col] = y;
+            gst(Y + (size_t)q * ldy + col, y);
           }
         }
     }
@@ -1441,7 +1461,7 @@ __global__ void __launch_bounds__(512) k_query_init(const QuerySample* __restric
   B.queries += (size_t)q0 * D; B.qpos += (size_t)q0 * D; B.qproj += (size_t)q0 * D;
   B.ks += (size_t)q0 * D; B.vs += (size_t)q0 * D; B.E += (size_t)q0 * D;
   if (blockIdx.x == 0)
-    for (int e = threadIdx.x; e < n_counts; e += blockDim.x) counts[e] = 0;
+    for (int e = threadIdx.x; e < n_counts; e += blockDim.x) gst(counts + e, 0);
   for (int e = threadIdx.x; e < QP * D; e += blockDim.x) {
     const int c = e & 127;
     const int q = q0 + (e >> 7);
@@ -1449,20 +1469,20 @@ __global__ void __launch_bounds__(512) k_query_init(const QuerySample* __restric
     if (q < meta->nq) {
       const int r = meta->row[q];
       if (r >= 0) {   // clicked query: feature + Fourier(click xyz) + time encoding (agile3d.py:213-264)
-        f = feats128[(size_t)r * D + c];
-        p = posenc[(size_t)r * D + c] + time_table[(size_t)meta->time[q] * D + c];
+        f = gld(feats128 + (size_t)r * D + c);
+        p = gld(posenc + (size_t)r * D + c) + time_table[(size_t)meta->time[q] * D + c];
       } else {        // learned background query
         const int b = q - n_fg;
         f = bg_feat[(size_t)b * D + c];
         p = bg_pos[(size_t)b * D + c];
       }
     }
-    B.queries[e] = f;
-    B.qpos[e] = p;
-    B.qproj[e] = 0.f;
-    B.ks[e] = 0.f;
-    B.vs[e] = 0.f;
-    B.E[e] = 0.f;
+    gst(B.queries + e, f);
+    gst(B.qpos + e, p);
+    gst(B.qproj + e, 0.f);
+    gst(B.ks + e, 0.f);
+    gst(B.vs + e, 0.f);
+    gst(B.E + e, 0.f);
   }
   (void)n_bgl;
   __syncthreads();
@@ -1481,7 +1501,7 @@ __device__ __forceinline__ void qload_w(const float* __restrict__ W, int ldw, in
   const int lane = threadIdx.x & 63, g = lane >> 4, j = lane & 15;
   const float* p = W + (size_t)(row0 + j) * ldw + col0 + 4 * g;
 #pragma unroll
-  for (int S = 0; S < 8; ++S) wf[S] = *(const f32x4*)(p + 16 * S);
+  for (int S = 0; S < 8; ++S) wf[S] = gld4(p + 16 * S);
 }
 template <int QT>
 __device__ __forceinline__ void qmm(const float* Xl, const f32x4 (&wf)[8], f32x4 (&acc)[QT]) {
@@ -1495,12 +1515,12 @@ __device__ __forceinline__ void qmm(const float* Xl, const f32x4 (&wf)[8], f32x4
       for (int t = 0; t < 4; ++t) acc[qt] = __builtin_amdgcn_mfma_f32_16x16x4f32(x[t], wf[S][t], acc[qt], 0, 0, 0);
     }
 }
-// y[q][col0 + j] = act((acc + bias) * scale) for q < Q; dst row stride ld (LDS or global)
-template <int QT>
+// y[q][col0 + j] = act((acc + bias) * scale) for q < Q; dst row stride ld (LDS, or global with G)
+template <int QT, bool G = false>
 __device__ __forceinline__ void qstore(const f32x4 (&acc)[QT], const float* __restrict__ bias, int bcol, float scale,
                                        bool relu, float* dst, int ld, int col0, int Q) {
   const int lane = threadIdx.x & 63, g = lane >> 4, j = lane & 15;
-  const float b = bias ? bias[bcol + j] : 0.f;
+  const float b = bias ? gld(bias + bcol + j) : 0.f;
 #pragma unroll
   for (int qt = 0; qt < QT; ++qt)
 #pragma unroll
@@ -1509,7 +1529,8 @@ __device__ __forceinline__ void qstore(const f32x4 (&acc)[QT], const float* __re
       if (q < Q) {
         float y = (acc[qt][t] + b) * scale;
         if (relu) y = fmaxf(y, 0.f);
-        dst[(size_t)q * ld + col0 + j] = y;
+        if constexpr (G) gst(dst + (size_t)q * ld + col0 + j, y);
+        else dst[(size_t)q * ld + col0 + j] = y;
       }
     }
 }
@@ -1537,12 +1558,12 @@ __device__ __forceinline__ void qadd_ln(const float* a, const float* b, int Q, c
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     const float rstd = rsqrtf(v * (1.f / D) + kLnEps);
-    const float y0 = d0 * rstd * w[lane] + bias[lane], y1 = d1 * rstd * w[64 + lane] + bias[64 + lane];
+    const float y0 = d0 * rstd * gld(w + lane) + gld(bias + lane), y1 = d1 * rstd * gld(w + 64 + lane) + gld(bias + 64 + lane);
     dst[q * kQLD + lane] = y0;
     dst[q * kQLD + 64 + lane] = y1;
     if (gdst) {
-      gdst[(size_t)q * D + lane] = y0;
-      gdst[(size_t)q * D + 64 + lane] = y1;
+      gst(gdst + (size_t)q * D + lane, y0);
+      gst(gdst + (size_t)q * D + 64 + lane, y1);
     }
   }
 }
@@ -1588,7 +1609,7 @@ __global__ void __launch_bounds__(512) k_query_layer(const QuerySample* __restri
       qload_w(W.ffn_w1t, D, hx * 128 + 16 * wave, 0, wfa);            // first chunk's weights while waiting
       if (tid == 0) {
         unsigned spins = 0;
-        while (__hip_atomic_load(flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+        while (gld_agent(flags) == 0u) {
           __builtin_amdgcn_s_sleep(2);
           if (++spins > (1u << 26)) break;                             // seconds: never in a healthy run
         }
@@ -1596,7 +1617,7 @@ __global__ void __launch_bounds__(512) k_query_layer(const QuerySample* __restri
       __syncthreads();
       for (int e = tid; e < QP * 128; e += nt) {
         const int q = e >> 7, c = e & 127;
-        cur[q * kQLD + c] = __hip_atomic_load(B.tgt + (size_t)q * D + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        cur[q * kQLD + c] = gld_agent(B.tgt + (size_t)q * D + c);
       }
       __syncthreads();
       f32x4 facc[QT];
@@ -1618,19 +1639,18 @@ __global__ void __launch_bounds__(512) k_query_layer(const QuerySample* __restri
         for (int qt = 0; qt < QT; ++qt)
 #pragma unroll
           for (int t = 0; t < 4; ++t)
-            __hip_atomic_store(part + (size_t)(qt * 16 + 4 * g + t) * D + 16 * wave + j, facc[qt][t], __ATOMIC_RELAXED,
-                               __HIP_MEMORY_SCOPE_AGENT);
+            gst_agent(part + (size_t)(qt * 16 + 4 * g + t) * D + 16 * wave + j, facc[qt][t]);
       }
       __builtin_amdgcn_s_waitcnt(0x0F70);
       __syncthreads();
-      if (tid == 0) __hip_atomic_store(flags + hx, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (tid == 0) gst_agent(flags + hx, 1u);
       // ---- second job of helpers 1..3: one of the projections that depend only on the layer's new queries
       if (nh < 4 || nchunk < 4 || hx > 3 || (hx == 3 && !W.next_c2s_in_wt)) return;
       const float* wsrc = hx == 1 ? W.s2c_in_wt + (size_t)D * D : hx == 2 ? W.s2c_in_wt + (size_t)2 * D * D : W.next_c2s_in_wt;
       qload_w(wsrc, D, 16 * wave, 0, wfa);
       if (tid == 0) {
         unsigned spins = 0;
-        while (__hip_atomic_load(flags + 8, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+        while (gld_agent(flags + 8) == 0u) {
           __builtin_amdgcn_s_sleep(2);
           if (++spins > (1u << 26)) break;
         }
@@ -1638,16 +1658,16 @@ __global__ void __launch_bounds__(512) k_query_layer(const QuerySample* __restri
       __syncthreads();
       for (int e = tid; e < QP * 128; e += nt) {
         const int q = e >> 7, c = e & 127;
-        float v = __hip_atomic_load(B.tgt + (size_t)q * D + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (hx != 2) v += q < Q ? B.qpos[(size_t)q * D + c] : 0.f;   // keys / next query projection take queries + qpos
+        float v = gld_agent(B.tgt + (size_t)q * D + c);
+        if (hx != 2) v += q < Q ? gld(B.qpos + (size_t)q * D + c) : 0.f;   // keys / next query projection take queries + qpos
         xa[q * kQLD + c] = v;
       }
       __syncthreads();
       qzero<QT>(acc);
       qmm<QT>(xa, wfa, acc);
-      if (hx == 1) qstore<QT>(acc, W.s2c_in_b, D + 16 * wave, 0.25f, false, B.ks, D, 16 * wave, Q);        // keys pre-scaled
-      else if (hx == 2) qstore<QT>(acc, W.s2c_in_b, 2 * D + 16 * wave, 1.f, false, B.vs, D, 16 * wave, Q);
-      else qstore<QT>(acc, W.next_c2s_in_b, 16 * wave, 0.25f, false, B.qproj, D, 16 * wave, Q);
+      if (hx == 1) qstore<QT, true>(acc, W.s2c_in_b, D + 16 * wave, 0.25f, false, B.ks, D, 16 * wave, Q);        // keys pre-scaled
+      else if (hx == 2) qstore<QT, true>(acc, W.s2c_in_b, 2 * D + 16 * wave, 1.f, false, B.vs, D, 16 * wave, Q);
+      else qstore<QT, true>(acc, W.next_c2s_in_b, 16 * wave, 0.25f, false, B.qproj, D, 16 * wave, Q);
       return;
     }
   }
@@ -1659,9 +1679,9 @@ __global__ void __launch_bounds__(512) k_query_layer(const QuerySample* __restri
     const int q = e >> 5, c4 = (e & 31) * 4;
     f32x4 vq = (f32x4){0.f, 0.f, 0.f, 0.f}, vp = vq, va = vq;
     if (q < Q) {
-      vq = *(const f32x4*)(B.queries + (size_t)q * D + c4);
-      vp = *(const f32x4*)(B.qpos + (size_t)q * D + c4);
-      va = *(const f32x4*)(B.attn + (size_t)q * D + c4);
+      vq = gld4(B.queries + (size_t)q * D + c4);
+      vp = gld4(B.qpos + (size_t)q * D + c4);
+      va = gld4(B.attn + (size_t)q * D + c4);
     }
     *(f32x4*)(cur + q * kQLD + c4) = vq;
     *(f32x4*)(qpos + q * kQLD + c4) = vp;
@@ -1701,26 +1721,26 @@ __global__ void __launch_bounds__(512) k_query_layer(const QuerySample* __restri
     __syncthreads();                                                                            // xa fully consumed
     qstore<QT>(accq, W.c2c_in_b, 16 * wave, 0.25f, false, xa, kQLD, 16 * wave, Q);              // q (pre-scaled)
   } else {
-    qstore<QT>(accq, W.c2c_in_b, 16 * wave, 0.25f, false, B.qk, 2 * D, 16 * wave, Q);           // q (pre-scaled)
-    qstore<QT>(acc, W.c2c_in_b, D + 16 * wave, 1.f, false, B.qk, 2 * D, D + 16 * wave, Q);      // k
+    qstore<QT, true>(accq, W.c2c_in_b, 16 * wave, 0.25f, false, B.qk, 2 * D, 16 * wave, Q);           // q (pre-scaled)
+    qstore<QT, true>(acc, W.c2c_in_b, D + 16 * wave, 1.f, false, B.qk, 2 * D, D + 16 * wave, Q);      // k
     qload_w(W.c2c_in_wt, D, 2 * D + 16 * wave, 0, wfa);                                         // v rows
     qzero<QT>(acc);
     qmm<QT>(cur, wfa, acc);
-    qstore<QT>(acc, W.c2c_in_b, 2 * D + 16 * wave, 1.f, false, B.vc, D, 16 * wave, Q);          // v
+    qstore<QT, true>(acc, W.c2c_in_b, 2 * D + 16 * wave, 1.f, false, B.vc, D, 16 * wave, Q);          // v
   }
   if constexpr (PART == 1) {
     for (int e = tid; e < QP * 32; e += nt) {
       const int q = e >> 5, c4 = (e & 31) * 4;
-      *(f32x4*)(B.tgt + (size_t)q * D + c4) = *(const f32x4*)(cur + q * kQLD + c4);
+      gst4(B.tgt + (size_t)q * D + c4, *(const f32x4*)(cur + q * kQLD + c4));
     }
     return;
   }
   } else {
     for (int e = tid; e < QP * 32; e += nt) {
       const int q = e >> 5, c4 = (e & 31) * 4;
-      *(f32x4*)(cur + q * kQLD + c4) = *(const f32x4*)(B.tgt + (size_t)q * D + c4);
+      *(f32x4*)(cur + q * kQLD + c4) = gld4(B.tgt + (size_t)q * D + c4);
       f32x4 vp = (f32x4){0.f, 0.f, 0.f, 0.f};
-      if (q < Q) vp = *(const f32x4*)(B.qpos + (size_t)q * D + c4);
+      if (q < Q) vp = gld4(B.qpos + (size_t)q * D + c4);
       *(f32x4*)(qpos + q * kQLD + c4) = vp;
     }
   }
@@ -1731,16 +1751,20 @@ __global__ void __launch_bounds__(512) k_query_layer(const QuerySample* __restri
   const float* kbase = PART == 0 ? xb : all_qk + D;
   const float* vbase = PART == 0 ? qpos : all_vc;
   const int kld = PART == 0 ? kQLD : 2 * D, vld = PART == 0 ? kQLD : D;
+  auto kvld = [](const float* p) {   // LDS in the single-block layer, the blocks' global buffers otherwise
+    if constexpr (PART == 0) return *p;
+    else return gld(p);
+  };
   for (int e = tid; e < Q * H; e += nt) {
     const int q = e / H, h = e % H;
     float qv[DH];
 #pragma unroll
-    for (int d = 0; d < DH; ++d) qv[d] = PART == 0 ? xa[q * kQLD + h * DH + d] : B.qk[(size_t)q * 2 * D + h * DH + d];
+    for (int d = 0; d < DH; ++d) qv[d] = PART == 0 ? xa[q * kQLD + h * DH + d] : gld(B.qk + (size_t)q * 2 * D + h * DH + d);
     float mx = kNegBig;
     for (int k = 0; k < Qall; ++k) {
       float sdot = 0.f;
 #pragma unroll
-      for (int d = 0; d < DH; ++d) sdot += qv[d] * kbase[(size_t)k * kld + h * DH + d];
+      for (int d = 0; d < DH; ++d) sdot += qv[d] * kvld(kbase + (size_t)k * kld + h * DH + d);
       mx = fmaxf(mx, sdot);
     }
     float sum = 0.f, o[DH];
@@ -1749,11 +1773,11 @@ __global__ void __launch_bounds__(512) k_query_layer(const QuerySample* __restri
     for (int k = 0; k < Qall; ++k) {
       float sdot = 0.f;
 #pragma unroll
-      for (int d = 0; d < DH; ++d) sdot += qv[d] * kbase[(size_t)k * kld + h * DH + d];
+      for (int d = 0; d < DH; ++d) sdot += qv[d] * kvld(kbase + (size_t)k * kld + h * DH + d);
       const float pw = expf(sdot - mx);
       sum += pw;
 #pragma unroll
-      for (int d = 0; d < DH; ++d) o[d] += pw * vbase[(size_t)k * vld + h * DH + d];
+      for (int d = 0; d < DH; ++d) o[d] += pw * kvld(vbase + (size_t)k * vld + h * DH + d);
     }
     const float inv = 1.f / sum;
 #pragma unroll
@@ -1766,7 +1790,7 @@ __global__ void __launch_bounds__(512) k_query_layer(const QuerySample* __restri
     for (int e = tid; e < QP * 32; e += nt) {
       const int q = e >> 5, c4 = (e & 31) * 4;
       f32x4 vp = (f32x4){0.f, 0.f, 0.f, 0.f};
-      if (q < Q) vp = *(const f32x4*)(B.qpos + (size_t)q * D + c4);
+      if (q < Q) vp = gld4(B.qpos + (size_t)q * D + c4);
       *(f32x4*)(qpos + q * kQLD + c4) = vp;
     }
   }
@@ -1780,11 +1804,11 @@ __global__ void __launch_bounds__(512) k_query_layer(const QuerySample* __restri
   if (PART == 0 && nh > 1) {   // hand tgt to the FFN helpers
     for (int e = tid; e < QP * 128; e += nt) {
       const int q = e >> 7, c = e & 127;
-      __hip_atomic_store(B.tgt + (size_t)q * D + c, cur[q * kQLD + c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      gst_agent(B.tgt + (size_t)q * D + c, cur[q * kQLD + c]);
     }
     __builtin_amdgcn_s_waitcnt(0x0F70);
     __syncthreads();
-    if (tid == 0) __hip_atomic_store(B.sync + W.layer * 16, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid == 0) gst_agent(B.sync + W.layer * 16, 1u);
   }
   mark(5);
   // ---- 3. FFN (attention_block.py:151-155) in hidden chunks of 128: wave w computes hidden tile w of
@@ -1806,7 +1830,7 @@ __global__ void __launch_bounds__(512) k_query_layer(const QuerySample* __restri
     const int nhelp = min(nh, nchunk) - 1;
     if (tid < nhelp) {
       unsigned spins = 0;
-      while (__hip_atomic_load(B.sync + W.layer * 16 + 1 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+      while (gld_agent(B.sync + W.layer * 16 + 1 + tid) == 0u) {
         __builtin_amdgcn_s_sleep(2);
         if (++spins > (1u << 26)) break;
       }
@@ -1819,8 +1843,7 @@ __global__ void __launch_bounds__(512) k_query_layer(const QuerySample* __restri
       for (int qt = 0; qt < QT; ++qt)
 #pragma unroll
         for (int t = 0; t < 4; ++t)
-          facc[qt][t] += __hip_atomic_load(part + (size_t)(qt * 16 + 4 * g + t) * D + 16 * wave + j, __ATOMIC_RELAXED,
-                                           __HIP_MEMORY_SCOPE_AGENT);
+          facc[qt][t] += gld_agent(part + (size_t)(qt * 16 + 4 * g + t) * D + 16 * wave + j);
     }
   }
   mark(6);
@@ -1838,11 +1861,11 @@ __global__ void __launch_bounds__(512) k_query_layer(const QuerySample* __restri
   if (deleg) {
     for (int e = tid; e < QP * 128; e += nt) {
       const int q = e >> 7, c = e & 127;
-      __hip_atomic_store(B.tgt + (size_t)q * D + c, cur[q * kQLD + c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      gst_agent(B.tgt + (size_t)q * D + c, cur[q * kQLD + c]);
     }
     __builtin_amdgcn_s_waitcnt(0x0F70);
     __syncthreads();
-    if (tid == 0) __hip_atomic_store(B.sync + W.layer * 16 + 8, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid == 0) gst_agent(B.sync + W.layer * 16 + 8, 1u);
   }
   mark(7);
   // ---- 4. everything that depends only on the new queries: s2c keys/values, mask MLP layer 0, next
@@ -1856,16 +1879,16 @@ __global__ void __launch_bounds__(512) k_query_layer(const QuerySample* __restri
     __syncthreads();
     qzero<QT>(acc);
     qmm<QT>(xa, wfa, acc);
-    qstore<QT>(acc, W.s2c_in_b, D + 16 * wave, 0.25f, false, B.ks, D, 16 * wave, Q);   // keys pre-scaled
+    qstore<QT, true>(acc, W.s2c_in_b, D + 16 * wave, 0.25f, false, B.ks, D, 16 * wave, Q);   // keys pre-scaled
     qload_w(W.m_w0t, D, 16 * wave, 0, wfa);
     qzero<QT>(acc);
     qmm<QT>(cur, wfb, acc);
-    qstore<QT>(acc, W.s2c_in_b, 2 * D + 16 * wave, 1.f, false, B.vs, D, 16 * wave, Q);
+    qstore<QT, true>(acc, W.s2c_in_b, 2 * D + 16 * wave, 1.f, false, B.vs, D, 16 * wave, Q);
     if (W.next_c2s_in_wt) {
       qload_w(W.next_c2s_in_wt, D, 16 * wave, 0, wfb);
       qzero<QT>(acc);
       qmm<QT>(xa, wfb, acc);
-      qstore<QT>(acc, W.next_c2s_in_b, 16 * wave, 0.25f, false, B.qproj, D, 16 * wave, Q);
+      qstore<QT, true>(acc, W.next_c2s_in_b, 16 * wave, 0.25f, false, B.qproj, D, 16 * wave, Q);
     }
   }
   __syncthreads();                                                   // everyone is done reading xa / qpos
@@ -1876,7 +1899,7 @@ __global__ void __launch_bounds__(512) k_query_layer(const QuerySample* __restri
   __syncthreads();
   qzero<QT>(acc);
   qmm<QT>(qpos, wfa, acc);
-  qstore<QT>(acc, W.m_b2, 16 * wave, 1.f, false, B.E, D, 16 * wave, Q);
+  qstore<QT, true>(acc, W.m_b2, 16 * wave, 1.f, false, B.E, D, 16 * wave, Q);
   mark(8);
 }
 

@@ -1122,6 +1122,10 @@ static int sk_env(const char* name, int dflt) {
 static int sk_ch(int cin, int bn) {   // input channels per stage
   static int forced = sk_env("A3D_SK_CH", 0);   // experiment: stage width of the 96-column kernels
   if (forced && bn == 96 && cin % forced == 0) return forced;
+  // 128-column workgroups: 32-channel stages as well (A3D_SK_CH128=64 for the wide ones).  Measured on the 16-scene
+  // batch (profiles/r03_experiments.txt): every <128,*> layer 1-3 % faster, L4 128 -> 256 63 -> 53 us
+  static int ch128 = sk_env("A3D_SK_CH128", 32);
+  if (bn == 128 && ch128 > 0 && cin % ch128 == 0) return ch128;
   // 96-column workgroups: 32-channel stages -- 157 registers, a 25 KB weight ring: THREE workgroups per CU, the third
   // covers the per-tile prologues / epilogues and the stage barriers of the other two (measured on the 4-scene batch:
   // L0 96 -> 96 700 -> 620 us = 108 TF/s, 128 -> 96 850 -> 790 us = 113 TF/s against 96- / 64-channel stages with two)
@@ -1134,8 +1138,10 @@ static int sk_ch(int cin, int bn) {   // input channels per stage
 // which build: PAIR = 1 is the low-register one (weight fragments two at a time).  Measured on the 4-scene batch: the
 // 96-column kernels gain from it (127 registers -> FOUR workgroups per CU: L0 96 -> 96 640 -> 607 us = 110 TF/s,
 // 128 -> 96 816 -> 770 us = 116 TF/s, L1 174 -> 169 us); 64- and 128-column kernels are within 2 % either way
-static int sk_pair(int bn, int ch) {
-  (void)ch;
+// -- on the 16-scene batch the 128-column kernels with 32-channel stages gain 4-6 % from it on the big levels (L2 128 -> 128
+// 303 -> 280 us, L3 256 -> 256 299 -> 283 us) and lose 2 % on L4 (2.5 k rows): by row count
+static int sk_pair(int bn, int ch, int n_rows) {
+  if (bn == 128) return ch == 32 && n_rows >= 8192;
   return bn == 96;
 }
 // resident workgroups per CU of k_conv_sk<bn, ch, pair>: registers (hipcc's allocation, -Rpass-analysis=
@@ -1169,7 +1175,7 @@ static SkPlan plan_sk(int n_rows, int K, int cin, int cout, bool handoff) {
     p.ch = sk_ch(cin, p.bn);
     p.nchunk = p.ch ? cin / p.ch : 1;
     p.n_cblk = cout / p.bn;
-    p.pair = pair_env >= 0 ? pair_env : sk_pair(p.bn, p.ch);
+    p.pair = pair_env >= 0 ? pair_env : sk_pair(p.bn, p.ch, n_rows);
     if (conv_emu(K, cin, cout)) {
       p.ch = 32;
       p.nchunk = cin / 32;
