@@ -75,10 +75,33 @@ def iou_counts(pred, labels, inverse_map=None, n_ids: int | None = None) -> np.n
     return host[:-1].reshape(3, n_ids)
 
 
-def mean_iou_scene(pred, labels, inverse_map=None):
-    """utils/seg.py:44-58.  Returns (mean IoU as a 0-d float32 tensor, {object id: IoU}); the fp32
-    arithmetic (int counts -> fp32 divide -> sequential fp32 sum) is the reference's."""
-    c = iou_counts(pred, labels, inverse_map)
+def iou_counts_batch(preds, labels, inverse_maps=None, n_ids: int = 256):
+    """``iou_counts`` of several samples with one device-to-host copy: list of int64 [3][n_ids] arrays."""
+    lib = L.load()
+    if not preds:
+        return []
+    dev = preds[0].device
+    counts = torch.empty(len(preds), 3 * n_ids + 1, dtype=torch.int64, device=dev)
+    keep = []
+    for i, (pr, lb) in enumerate(zip(preds, labels)):
+        p, l = _i32(pr), _i32(lb)
+        inv = None
+        if inverse_maps is not None and inverse_maps[i] is not None:
+            inv = inverse_maps[i].to(device=dev, dtype=torch.int64).contiguous()
+            if inv.numel() != l.numel():
+                raise RuntimeError("iou_counts: inverse_map and labels differ in length")
+        elif p.numel() != l.numel():
+            raise RuntimeError("iou_counts: pred and labels differ in length")
+        keep.append((p, l, inv))
+        L.check(lib.a3d_iou_counts(p.data_ptr(), p.numel(), inv.data_ptr() if inv is not None else None, l.data_ptr(),
+                                   l.numel(), n_ids, counts[i].data_ptr(), _stream(p)), "a3d_iou_counts")
+    host = counts.cpu().numpy()
+    if host[:, -1].any():
+        raise RuntimeError("iou_counts: inverse_map holds rows outside the prediction")
+    return [host[i, :-1].reshape(3, n_ids) for i in range(len(preds))]
+
+
+def _mean_iou_from_counts(c):
     ids = [i for i in range(1, c.shape[1]) if c[2, i] > 0]
     total = np.float32(0.0)
     per_obj = {}
@@ -91,41 +114,50 @@ def mean_iou_scene(pred, labels, inverse_map=None):
     return torch.tensor(total, dtype=torch.float32), per_obj
 
 
+def mean_iou_scene_batch(preds, labels, inverse_maps=None):
+    """``mean_iou_scene`` per sample of a batch, one host round trip for all of them."""
+    return [_mean_iou_from_counts(c) for c in iou_counts_batch(preds, labels, inverse_maps)]
+
+
+def mean_iou_scene(pred, labels, inverse_map=None):
+    """utils/seg.py:44-58.  Returns (mean IoU as a 0-d float32 tensor, {object id: IoU}); the fp32
+    arithmetic (int counts -> fp32 divide -> sequential fp32 sum) is the reference's."""
+    return _mean_iou_from_counts(iou_counts(pred, labels, inverse_map))
+
+
 _ws_cache: dict = {}
+_REC = np.dtype([("cluster_id", "<i4"), ("row", "<i4"), ("label", "<i4"), ("pred", "<i4"), ("error_size", "<f4")])
+_OUT_BYTES = MAX_CLUSTERS * C.sizeof(L.ClickCluster) + 16
 
 
-def error_clusters(pred, labels, coords):
-    """Per error cluster (ascending cluster id = 96*label + 11*pred, utils/seg.py:206): the point
-    farthest from everything outside the cluster and that distance.  List of dicts
-    {cluster_id, row, label, pred, error_size}."""
-    lib = L.load()
-    p, l = _i32(pred), _i32(labels)
-    xyz = coords.to(torch.float32).contiguous()
+def _cluster_buffers(device, n, slot=0):
+    """Workspace + result buffer of one sample in flight (slot = its place in a batch), grown on demand."""
+    key = (device.index, slot)
+    ws = _ws_cache.get(key)
+    need = L.load().a3d_click_workspace_bytes(n)
+    if ws is None or ws[0].numel() < need:
+        ws = _ws_cache[key] = (torch.empty(need, dtype=torch.uint8, device=device),
+                               torch.empty(_OUT_BYTES, dtype=torch.uint8, device=device),
+                               torch.empty(_OUT_BYTES, dtype=torch.uint8).pin_memory())
+    return ws
+
+
+def _launch_clusters(p, l, xyz, work, out):
     n = p.numel()
     if xyz.shape != (n, 3) or l.numel() != n:
         raise RuntimeError("error_clusters: pred [N], labels [N], coords [N,3] expected")
-    if n == 0:
-        return []
-    key = (p.device.index, n)
-    ws = _ws_cache.get(key)
-    if ws is None:
-        _ws_cache.clear()
-        ws = _ws_cache[key] = (torch.empty(lib.a3d_click_workspace_bytes(n), dtype=torch.uint8, device=p.device),
-                               torch.empty(MAX_CLUSTERS * C.sizeof(L.ClickCluster) + 16, dtype=torch.uint8,
-                                           device=p.device))
-    work, out = ws
-    n_out_ptr = out.data_ptr() + MAX_CLUSTERS * C.sizeof(L.ClickCluster)
-    L.check(lib.a3d_click_clusters(xyz.data_ptr(), p.data_ptr(), l.data_ptr(), n, out.data_ptr(), MAX_CLUSTERS,
-                                   n_out_ptr, work.data_ptr(), work.numel(), _stream(p)), "a3d_click_clusters")
-    host = out.cpu().numpy()
+    L.check(L.load().a3d_click_clusters(xyz.data_ptr(), p.data_ptr(), l.data_ptr(), n, out.data_ptr(), MAX_CLUSTERS,
+                                        out.data_ptr() + MAX_CLUSTERS * C.sizeof(L.ClickCluster), work.data_ptr(),
+                                        work.numel(), _stream(p)), "a3d_click_clusters")
+
+
+def _parse_clusters(host: np.ndarray):
     count = int(host[MAX_CLUSTERS * C.sizeof(L.ClickCluster):][:4].view(np.int32)[0])
     if count < 0:
         raise RuntimeError("error_clusters: labels / predictions must be object ids in 0..255")
     if count > MAX_CLUSTERS:
         raise RuntimeError(f"error_clusters: {count} error clusters > {MAX_CLUSTERS}")
-    recs = np.frombuffer(host[:count * C.sizeof(L.ClickCluster)].tobytes(),
-                         dtype=np.dtype([("cluster_id", "<i4"), ("row", "<i4"), ("label", "<i4"), ("pred", "<i4"),
-                                         ("error_size", "<f4")]))
+    recs = np.frombuffer(host[:count * C.sizeof(L.ClickCluster)].tobytes(), dtype=_REC)
     res = []
     for r in recs:
         if not np.isfinite(r["error_size"]):
@@ -134,19 +166,69 @@ def error_clusters(pred, labels, coords):
     return res
 
 
-def get_simulated_clicks(pred_qv, labels_qv, coords_qv, current_num_clicks=None, training=True):
-    """utils/seg.py:177-228.  Same returns: (new_clicks {str(label): [rows]}, click_num,
-    new_click_pos {str(label): [xyz tensors]}, new_click_time {str(label): [order]}), or four Nones when
-    the prediction is already right.  Consumes the global ``random`` stream like the reference
-    (one ``random.shuffle`` of the selected cluster ids)."""
-    clusters = error_clusters(pred_qv, labels_qv, coords_qv)
+def error_clusters(pred, labels, coords):
+    """Per error cluster (ascending cluster id = 96*label + 11*pred, utils/seg.py:206): the point
+    farthest from everything outside the cluster and that distance.  List of dicts
+    {cluster_id, row, label, pred, error_size}."""
+    p, l = _i32(pred), _i32(labels)
+    xyz = coords.to(torch.float32).contiguous()
+    if p.numel() == 0:
+        return []
+    work, out, _ = _cluster_buffers(p.device, p.numel())
+    _launch_clusters(p, l, xyz, work, out)
+    return _parse_clusters(out.cpu().numpy())
+
+
+_side_streams: dict = {}
+
+
+def _side(device, i):
+    pool = _side_streams.setdefault(device.index, [])
+    while len(pool) <= i:
+        pool.append(torch.cuda.Stream(device=device))
+    return pool[i]
+
+
+def error_clusters_batch(preds, labels, coords, max_streams: int = 8):
+    """``error_clusters`` of several samples with ONE host synchronisation: sample i's kernels (a latency chain of a
+    dozen small launches) run on side stream i % max_streams next to the other samples', the records come back through
+    pinned buffers.  Same results as the per-sample call, in sample order."""
+    if not preds:
+        return []
+    dev = preds[0].device
+    cur = torch.cuda.current_stream(dev)
+    pend = []
+    for i, (pr, lb, xyz) in enumerate(zip(preds, labels, coords)):
+        p, l = _i32(pr), _i32(lb)
+        x = xyz.to(torch.float32).contiguous()
+        if p.numel() == 0:
+            pend.append(None)
+            continue
+        work, out, host = _cluster_buffers(dev, p.numel(), slot=1 + i)
+        st = _side(dev, i % max_streams)
+        st.wait_stream(cur)
+        with torch.cuda.stream(st):
+            _launch_clusters(p, l, x, work, out)
+            host.copy_(out, non_blocking=True)
+        pend.append((st, host, (p, l, x)))       # the inputs stay referenced until the stream is drained
+    res = []
+    for item in pend:
+        if item is None:
+            res.append([])
+            continue
+        item[0].synchronize()
+        res.append(_parse_clusters(item[1].numpy()))
+    return res
+
+
+def _pick_clicks(clusters, coords_qv, num_obj, current_num_clicks, training):
+    """The host half of utils/seg.py:177-228 (ranking, the one ``random.shuffle``, the click dictionaries)."""
     if not clusters:
         return None, None, None, None
     by_id = {c["cluster_id"]: c for c in clusters}
     # ranked by error size, largest first; equal sizes keep ascending-id order (stable sort)
     ranked = sorted(by_id, key=lambda cid: by_id[cid]["error_size"], reverse=True)
     if training:
-        num_obj = int((torch.unique(labels_qv) != 0).sum())
         chosen = ranked[:num_obj] if len(ranked) >= num_obj else ranked
     else:
         chosen = ranked if current_num_clicks == 0 else ranked[:1]
@@ -159,6 +241,32 @@ def get_simulated_clicks(pred_qv, labels_qv, coords_qv, current_num_clicks=None,
         new_pos.setdefault(key, []).append(coords_qv[c["row"]])
         new_time.setdefault(key, []).append(order)
     return new_clicks, len(chosen), new_pos, new_time
+
+
+def get_simulated_clicks_batch(preds, labels, coords, current_num_clicks=None, training=True, num_objs=None):
+    """``get_simulated_clicks`` for every sample of a batch (engine.py:103-116 / eval_multi_obj.py:162-166 loop over the
+    samples): the error clusters of all samples are computed side by side (``error_clusters_batch``), the clicks are then
+    picked in sample order, so the global ``random`` stream is consumed exactly as by the per-sample loop.  ``num_objs``
+    (training): the number of objects per sample when the caller knows it -- saves a ``torch.unique`` + host round trip
+    per sample and round."""
+    clusters = error_clusters_batch(preds, labels, coords)
+    out = []
+    for i, cl in enumerate(clusters):
+        num_obj = None
+        if training and cl:
+            num_obj = num_objs[i] if num_objs is not None else int((torch.unique(labels[i]) != 0).sum())
+        out.append(_pick_clicks(cl, coords[i], num_obj, current_num_clicks, training))
+    return out
+
+
+def get_simulated_clicks(pred_qv, labels_qv, coords_qv, current_num_clicks=None, training=True):
+    """utils/seg.py:177-228.  Same returns: (new_clicks {str(label): [rows]}, click_num,
+    new_click_pos {str(label): [xyz tensors]}, new_click_time {str(label): [order]}), or four Nones when
+    the prediction is already right.  Consumes the global ``random`` stream like the reference
+    (one ``random.shuffle`` of the selected cluster ids)."""
+    clusters = error_clusters(pred_qv, labels_qv, coords_qv)
+    num_obj = int((torch.unique(labels_qv) != 0).sum()) if training and clusters else None
+    return _pick_clicks(clusters, coords_qv, num_obj, current_num_clicks, training)
 
 
 def extend_clicks(current_clicks, current_clicks_time, new_clicks, new_click_time):

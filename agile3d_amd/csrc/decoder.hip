@@ -1347,6 +1347,7 @@ struct QueryLayerW {
   const float *s2c_in_wt, *s2c_in_b;
   const float *dn_w, *dn_b, *m_w0t, *m_b0, *m_w2t, *m_b2;
   const float *next_c2s_in_wt, *next_c2s_in_b;   // nullptr on the last layer
+  const float *qpack, *next_qpack, *mpack;       // fragment-order copies (k_query_block): this layer's, the next layer's, the mask head's
   int dim_ff;
   int layer;
   unsigned long long* dbg;                       // A3D_DEC_DBG=2: s_memtime marks of workgroup (0, 0), else nullptr
@@ -1903,6 +1904,473 @@ __global__ void __launch_bounds__(512) k_query_layer(const QuerySample* __restri
   mark(8);
 }
 
+
+// ---- the single-block layer (nq <= 64), second build ---------------------------------------------------------
+// Same arithmetic as k_query_layer<QT, 0>; what changed is what the workgroup WAITS for.  Measured on the first build
+// (20 queries, phase marks): 62 us of which the MFMAs are ~6 -- every phase ended in an on-demand global load (a bias, a
+// LayerNorm vector) whose vmcnt wait also drained the weight prefetch behind it, a 6-step LDS-shuffle reduction per
+// LayerNorm row, and a scalar click-to-click attention on 2.5 waves.  Here:
+//   * the 20 bias / LayerNorm vectors go to LDS once, next to the activations, in the load phase;
+//   * four weight-fragment sets rotate, so every GEMM's weights were requested at least one full phase earlier and the
+//     only vector-memory traffic of a phase is the prefetch;
+//   * LayerNorm takes 16 rows per wave in the MFMA fragment order (lane (g, j): row j, channels 16 S + 4 g ..+3): a row's
+//     sums are in-lane adds + two permlane swaps, and the writer also emits what the next phase stages (tgt + qpos, the
+//     hand-off copy for the helper workgroups);
+//   * click-to-click attention runs on the matrix cores, one head per wave (S^T = K Q^T, softmax over the keys in the
+//     C layout, O^T = V^T P^T -- the chain of k_s2c_out).
+// Fragment-order copies of the query side's matrices (a3d_decoder_pack_query_weights).  A [N][K] torch matrix becomes
+// [N/16 tiles][K/16 steps][64 lanes] float4 with lane (g, j) of (tile t, step S) = W[16t + j][16S + 4g ..+3]: what qload_w
+// gathers from 16 rows (64 B each) is one contiguous 1 KB here -- 35 -> 140 GB/s into one CU (tools/qload_ubench.hip).
+constexpr size_t kQpC2sOut = 0, kQpC2cIn = 16384, kQpC2cOut = 65536, kQpS2cKV = 81920, kQpC2sQ = 114688, kQpFfn1 = 131072;
+__host__ __device__ constexpr size_t qpack_ffn2(int dim_ff) { return kQpFfn1 + (size_t)dim_ff * 128; }
+__host__ __device__ constexpr size_t qpack_floats(int dim_ff) { return kQpFfn1 + (size_t)2 * dim_ff * 128; }
+constexpr size_t kMpW0 = 0, kMpW2 = 16384, kMpFloats = 32768;
+__global__ void __launch_bounds__(256) k_pack_rows(const float* __restrict__ W, int N, int K, float* __restrict__ out) {
+  const int KS = K >> 4;
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;          // one float4 of the output
+  if (i >= (size_t)(N >> 4) * KS * 64) return;
+  const int lane = (int)(i & 63), g = lane >> 4, j = lane & 15;
+  const size_t ts = i >> 6;
+  const int S = (int)(ts % KS), t = (int)(ts / KS);
+  ((f32x4*)out)[i] = *(const f32x4*)(W + (size_t)(16 * t + j) * K + 16 * S + 4 * g);
+}
+// wf[S] = fragment (tile, S0 + S) of a packed matrix with KS steps per tile
+__device__ __forceinline__ void qload_p(const float* P, int KS, int tile, int S0, f32x4 (&wf)[8]) {
+  const f32x4 A3D_GLOBAL* p = (const f32x4 A3D_GLOBAL*)P + ((size_t)tile * KS + S0) * 64 + (threadIdx.x & 63);
+#pragma unroll
+  for (int S = 0; S < 8; ++S) wf[S] = p[S * 64];
+}
+constexpr int kQVec = 2560;   // floats of the vector table
+enum {
+  V_C2S_OUT_B = 0, V_C2S_NW = 128, V_C2S_NB = 256, V_C2C_IN_B = 384, V_C2C_OUT_B = 768, V_C2C_NW = 896, V_C2C_NB = 1024,
+  V_FFN_B2 = 1152, V_FFN_NW = 1280, V_FFN_NB = 1408, V_S2C_IN_B = 1536, V_DN_W = 1920, V_DN_B = 2048, V_M_B0 = 2176,
+  V_M_B2 = 2304, V_NEXT_B = 2432
+};
+__device__ __forceinline__ const float* ql_vec_src(const QueryLayerW& W, int s) {   // 128-float segment s of the table
+  switch (s) {
+    case 0: return W.c2s_out_b;
+    case 1: return W.c2s_norm_w;
+    case 2: return W.c2s_norm_b;
+    case 3: return W.c2c_in_b;
+    case 4: return W.c2c_in_b + 128;
+    case 5: return W.c2c_in_b + 256;
+    case 6: return W.c2c_out_b;
+    case 7: return W.c2c_norm_w;
+    case 8: return W.c2c_norm_b;
+    case 9: return W.ffn_b2;
+    case 10: return W.ffn_norm_w;
+    case 11: return W.ffn_norm_b;
+    case 12: return W.s2c_in_b;
+    case 13: return W.s2c_in_b + 128;
+    case 14: return W.s2c_in_b + 256;
+    case 15: return W.dn_w;
+    case 16: return W.dn_b;
+    case 17: return W.m_b0;
+    case 18: return W.m_b2;
+    default: return W.next_c2s_in_b;
+  }
+}
+// y[q][col0 + j] = act((acc + b) * scale) for q < Q, the lane's bias value already in a register
+template <int QT, bool G = false>
+__device__ __forceinline__ void qstore_b(const f32x4 (&acc)[QT], float b, float scale, bool relu, float* dst, int ld,
+                                         int col0, int Q) {
+  const int lane = threadIdx.x & 63, g = lane >> 4, j = lane & 15;
+#pragma unroll
+  for (int qt = 0; qt < QT; ++qt)
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int q = qt * 16 + 4 * g + t;
+      if (q < Q) {
+        float y = (acc[qt][t] + b) * scale;
+        if (relu) y = fmaxf(y, 0.f);
+        if constexpr (G) gst(dst + (size_t)q * ld + col0 + j, y);
+        else dst[(size_t)q * ld + col0 + j] = y;
+      }
+    }
+}
+// dst[q] = LayerNorm(a[q] + b[q]) (b optional) for the rows q < Q of [QP][132] LDS tiles, waves 0 .. QT-1, 16 rows each.
+// Optional extra outputs of the same rows: dst2 = y + add2 (LDS), gdst = y (global), gagent = y (global, agent scope: the
+// hand-off to the helper workgroups).  dst / dst2 may alias a / b: a lane only rewrites the elements it read.
+template <int QT>
+__device__ __forceinline__ void qln16(const float* a, const float* b, int Q, const float* w_l, const float* b_l, float* dst,
+                                      float* dst2, const float* add2, float* gdst, float* gagent) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, j = lane & 15;
+  if (wave >= QT) return;
+  const int q = 16 * wave + j;
+  f32x4 x[8];
+  float s = 0.f;
+#pragma unroll
+  for (int S = 0; S < 8; ++S) {
+    x[S] = *(const f32x4*)(a + q * kQLD + 16 * S + 4 * g);
+    if (b) x[S] += *(const f32x4*)(b + q * kQLD + 16 * S + 4 * g);
+    s += (x[S][0] + x[S][1]) + (x[S][2] + x[S][3]);
+  }
+  s = rows_sum(s);
+  const float mean = s * (1.f / D);
+  float v = 0.f;
+#pragma unroll
+  for (int S = 0; S < 8; ++S)
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      x[S][t] -= mean;
+      v += x[S][t] * x[S][t];
+    }
+  v = rows_sum(v);
+  const float rstd = rsqrtf(v * (1.f / D) + kLnEps);
+  if (q >= Q) return;
+#pragma unroll
+  for (int S = 0; S < 8; ++S) {
+    const int c = 16 * S + 4 * g;
+    const f32x4 y = x[S] * rstd * *(const f32x4*)(w_l + c) + *(const f32x4*)(b_l + c);
+    *(f32x4*)(dst + q * kQLD + c) = y;
+    if (dst2) *(f32x4*)(dst2 + q * kQLD + c) = y + *(const f32x4*)(add2 + q * kQLD + c);
+    if (gdst) gst4(gdst + (size_t)q * D + c, y);
+    if (gagent) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) gst_agent(gagent + (size_t)q * D + c + t, y[t]);
+    }
+  }
+}
+// click-to-click attention of head h = wave on the matrix cores, all operands [QP][132] LDS tiles: q_l holds the
+// pre-scaled queries on entry and the attention output on exit (a wave rewrites only its own head's 16 columns, row tile
+// by row tile after reading them).  Keys >= Qall are masked; output rows >= Q are zero.
+template <int QT>
+__device__ __forceinline__ void qattn_mfma(float* q_l, const float* k_l, const float* v_l, int Q, int Qall) {
+  const int lane = threadIdx.x & 63, h = threadIdx.x >> 6, g = lane >> 4, j = lane & 15;
+  f32x4 kf[QT], vf[QT];
+#pragma unroll
+  for (int kt = 0; kt < QT; ++kt) {
+    kf[kt] = *(const f32x4*)(k_l + (16 * kt + j) * kQLD + 16 * h + 4 * g);   // K[key 16kt+j][16h+4g..+3]
+#pragma unroll
+    for (int t = 0; t < 4; ++t) vf[kt][t] = v_l[(16 * kt + 4 * g + t) * kQLD + 16 * h + j];   // V^T[16h+j][key 16kt+4g+t]
+  }
+#pragma unroll
+  for (int qt = 0; qt < QT; ++qt) {
+    const f32x4 qf = *(const f32x4*)(q_l + (16 * qt + j) * kQLD + 16 * h + 4 * g);
+    f32x4 sc[QT];
+    float mx = kNegBig;
+#pragma unroll
+    for (int kt = 0; kt < QT; ++kt) {
+      sc[kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int t = 0; t < 4; ++t) sc[kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[kt][t], qf[t], sc[kt], 0, 0, 0);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        if (16 * kt + 4 * g + t >= Qall) sc[kt][t] = kNegBig;
+        mx = fmaxf(mx, sc[kt][t]);
+      }
+    }
+    mx = rows_max(mx);
+    float sum = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < QT; ++kt)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        sc[kt][t] = fast_exp(sc[kt][t] - mx);
+        sum += sc[kt][t];
+      }
+    sum = rows_sum(sum);
+    const float inv = 1.f / sum;
+    f32x4 o = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kt = 0; kt < QT; ++kt)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) o = __builtin_amdgcn_mfma_f32_16x16x4f32(vf[kt][t], sc[kt][t] * inv, o, 0, 0, 0);
+    // o[t] = O[query 16qt+j][16h+4g+t]
+    if (16 * qt + j >= Q) o = (f32x4){0.f, 0.f, 0.f, 0.f};
+    *(f32x4*)(q_l + (16 * qt + j) * kQLD + 16 * h + 4 * g) = o;
+  }
+}
+
+template <int QT>
+__global__ void __launch_bounds__(512) k_query_block(const QuerySample* __restrict__ qs, QueryLayerW W) {
+  constexpr int QP = QT * 16;
+  const QueryMeta* meta = qs[blockIdx.y].meta;
+  QueryBufs B = qs[blockIdx.y].B;
+  // workgroup 0 runs the layer; workgroups 1.. are FFN helpers (hidden chunks hx, hx + nh, ... of the 1024-wide FFN, whose
+  // 1 MB of weights one workgroup alone would pull through one CU), helpers 1..3 then take one projection of the layer's new
+  // queries each; hand-off through global memory with agent-scope loads / stores + flags
+  const int nh = (int)gridDim.x, hx = (int)blockIdx.x;
+  const int Q = max(0, min(QP, gld(&meta->nq)));
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* qpos = (float*)smem;            // [QP][132]  query position encodings (c2c values in between; mask MLP hidden)
+  float* cur = qpos + QP * kQLD;         // queries -> tgt -> queries
+  float* xa = cur + QP * kQLD;           // GEMM input staging
+  float* xb = xa + QP * kQLD;            // GEMM output staging / FFN hidden chunk
+  float* vec_l = xb + QP * kQLD;         // [kQVec] biases and LayerNorm vectors
+  const int tid = threadIdx.x, nt = 512;
+  const int wave = tid >> 6, lane = tid & 63, j = lane & 15;
+  const int nchunk = W.dim_ff >> 7;
+  unsigned* flags = B.sync + W.layer * 16;
+  f32x4 wfa[8], wfb[8], wfc[8], wfd[8], acc[QT];
+  constexpr bool kDeep = QT <= 2;   // the fourth fragment set in flight across the load phase and the attention (registers)
+  auto mark = [&](int i) {
+    if (W.dbg && tid == 0 && hx == 0 && blockIdx.y == 0) W.dbg[i] = __builtin_amdgcn_s_memtime();
+  };
+  mark(0);
+
+  if (hx > 0) {   // ---- FFN helper
+    if (hx >= nchunk) return;
+    // everything this workgroup will multiply by is requested before it starts to wait
+    qload_p(W.qpack + kQpFfn1, 8, hx * 8 + wave, 0, wfa);
+    qload_p(W.qpack + qpack_ffn2(W.dim_ff), W.dim_ff >> 4, wave, hx * 8, wfb);
+    float fb1 = gld(W.ffn_b1 + hx * 128 + 16 * wave + j);
+    const bool second = nh >= 4 && nchunk >= 4 && hx <= 3 && (hx < 3 || W.next_c2s_in_wt);
+    float sb = 0.f;
+    if (second) {
+      const float* wsrc = hx == 1 ? W.qpack + kQpS2cKV : hx == 2 ? W.qpack + kQpS2cKV + 16384 : W.next_qpack + kQpC2sQ;
+      const float* bsrc = hx == 1 ? W.s2c_in_b + D : hx == 2 ? W.s2c_in_b + 2 * D : W.next_c2s_in_b;
+      qload_p(wsrc, 8, wave, 0, wfc);
+      sb = gld(bsrc + 16 * wave + j);
+    }
+    if (tid == 0) {
+      unsigned spins = 0;
+      while (gld_agent(flags) == 0u) {
+        __builtin_amdgcn_s_sleep(1);
+        if (++spins > (1u << 26)) break;                             // seconds: never in a healthy run
+      }
+    }
+    __syncthreads();
+    for (int e = tid; e < QP * 128; e += nt) {
+      const int q = e >> 7, c = e & 127;
+      cur[q * kQLD + c] = q < Q ? gld_agent(B.tgt + (size_t)q * D + c) : 0.f;
+    }
+    __syncthreads();
+    f32x4 facc[QT];
+    qzero<QT>(facc);
+    for (int c = hx; c < nchunk; c += nh) {
+      qzero<QT>(acc);
+      qmm<QT>(cur, wfa, acc);
+      qstore_b<QT>(acc, fb1, 1.f, true, xb, kQLD, 16 * wave, QP);
+      if (c + nh < nchunk) {
+        qload_p(W.qpack + kQpFfn1, 8, (c + nh) * 8 + wave, 0, wfa);
+        fb1 = gld(W.ffn_b1 + (c + nh) * 128 + 16 * wave + j);
+      }
+      __syncthreads();
+      qmm<QT>(xb, wfb, facc);
+      if (c + nh < nchunk) qload_p(W.qpack + qpack_ffn2(W.dim_ff), W.dim_ff >> 4, wave, (c + nh) * 8, wfb);
+      __syncthreads();
+    }
+    {   // partial sums out, coherent stores, then the flag
+      const int g = lane >> 4;
+      float* part = B.hidden + (size_t)hx * QP * D;
+#pragma unroll
+      for (int qt = 0; qt < QT; ++qt)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) gst_agent(part + (size_t)(qt * 16 + 4 * g + t) * D + 16 * wave + j, facc[qt][t]);
+    }
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    __syncthreads();
+    if (tid == 0) gst_agent(flags + hx, 1u);
+    // ---- second job of helpers 1..3: one of the projections that depend only on the layer's new queries
+    if (!second) return;
+    if (tid == 0) {
+      unsigned spins = 0;
+      while (gld_agent(flags + 8) == 0u) {
+        __builtin_amdgcn_s_sleep(1);
+        if (++spins > (1u << 26)) break;
+      }
+    }
+    __syncthreads();
+    for (int e = tid; e < QP * 128; e += nt) {
+      const int q = e >> 7, c = e & 127;
+      float v = 0.f;
+      if (q < Q) {
+        v = gld_agent(B.tgt + (size_t)q * D + c);
+        if (hx != 2) v += gld(B.qpos + (size_t)q * D + c);   // keys / next query projection take queries + qpos
+      }
+      xa[q * kQLD + c] = v;
+    }
+    __syncthreads();
+    qzero<QT>(acc);
+    qmm<QT>(xa, wfc, acc);
+    if (hx == 1) qstore_b<QT, true>(acc, sb, 0.25f, false, B.ks, D, 16 * wave, Q);        // keys pre-scaled
+    else if (hx == 2) qstore_b<QT, true>(acc, sb, 1.f, false, B.vs, D, 16 * wave, Q);
+    else qstore_b<QT, true>(acc, sb, 0.25f, false, B.qproj, D, 16 * wave, Q);
+    return;
+  }
+
+  // ---- the layer's workgroup.  Load phase: the small vectors and the activations first (vmcnt is in order: their waits
+  // must not stand behind the weights), then the weights of the first FOUR GEMMs
+  const bool deleg = nh >= 4 && nchunk >= 4;             // helpers 1..3 take the s2c keys / values / next qproj
+  {
+    float tv[5];
+#pragma unroll
+    for (int s5 = 0; s5 < 5; ++s5) {
+      tv[s5] = 0.f;
+#pragma unroll
+      for (int gi = 0; gi < 4; ++gi) {
+        const int sgm = 4 * s5 + gi;
+        const float* src = ql_vec_src(W, sgm);
+        if ((tid >> 7) == gi && src) tv[s5] = gld(src + (tid & 127));
+      }
+    }
+    f32x4 vq[QT], vp[QT], va[QT];
+#pragma unroll
+    for (int u = 0; u < QT; ++u) {
+      const int e = tid + u * nt, q = e >> 5, c4 = (e & 31) * 4;
+      // all QP rows exist in the scratch buffers: the loads do not wait for the query count (rows >= Q are zeroed below)
+      vq[u] = gld4(B.queries + (size_t)q * D + c4);
+      vp[u] = gld4(B.qpos + (size_t)q * D + c4);
+      va[u] = gld4(B.attn + (size_t)q * D + c4);
+    }
+    qload_p(W.qpack + kQpC2sOut, 8, wave, 0, wfa);
+    qload_p(W.qpack + kQpC2cIn, 8, wave, 0, wfb);                      // q rows of the c2c in_proj
+    qload_p(W.qpack + kQpC2cIn, 8, 8 + wave, 0, wfc);                  // k rows
+    if constexpr (kDeep) qload_p(W.qpack + kQpC2cIn, 8, 16 + wave, 0, wfd);   // v rows
+#pragma unroll
+    for (int s5 = 0; s5 < 5; ++s5) vec_l[(4 * s5 + (tid >> 7)) * 128 + (tid & 127)] = tv[s5];
+#pragma unroll
+    for (int u = 0; u < QT; ++u) {
+      const int e = tid + u * nt, q = e >> 5, c4 = (e & 31) * 4;
+      const f32x4 z = (f32x4){0.f, 0.f, 0.f, 0.f};
+      *(f32x4*)(cur + q * kQLD + c4) = q < Q ? vq[u] : z;
+      *(f32x4*)(qpos + q * kQLD + c4) = q < Q ? vp[u] : z;
+      *(f32x4*)(xa + q * kQLD + c4) = q < Q ? va[u] : z;
+    }
+    if constexpr (!kDeep) qload_p(W.qpack + kQpC2cIn, 8, 16 + wave, 0, wfd);
+  }
+  __syncthreads();
+  mark(1);
+  const int cw = 16 * wave + j;                           // this lane's output column in every 128-wide GEMM
+  // ---- 1. click-to-scene output projection + residual + LayerNorm (attention_block.py:95-96)
+  qzero<QT>(acc);
+  qmm<QT>(xa, wfa, acc);
+  qstore_b<QT>(acc, vec_l[V_C2S_OUT_B + cw], 1.f, false, xb, kQLD, 16 * wave, QP);
+  qload_p(W.qpack + kQpC2cOut, 8, wave, 0, wfa);
+  __syncthreads();
+  qln16<QT>(cur, xb, Q, vec_l + V_C2S_NW, vec_l + V_C2S_NB, cur, xa, qpos, nullptr, nullptr);   // cur = tgt, xa = tgt + qpos
+  __syncthreads();
+  mark(2);
+  // ---- 2. click-to-click self attention (attention_block.py:32-36): q | k from tgt + qpos, v from tgt; all three stay in
+  //         LDS (k -> xb, v -> the qpos buffer, q -> xa once every wave is done reading xa)
+  {
+    qzero<QT>(acc);
+    qmm<QT>(xa, wfc, acc);
+    qstore_b<QT>(acc, vec_l[V_C2C_IN_B + D + cw], 1.f, false, xb, kQLD, 16 * wave, Q);            // k (xb, qpos: read before the barrier above)
+    qzero<QT>(acc);
+    qmm<QT>(cur, wfd, acc);
+    qstore_b<QT>(acc, vec_l[V_C2C_IN_B + 2 * D + cw], 1.f, false, qpos, kQLD, 16 * wave, Q);      // v
+    qzero<QT>(acc);
+    qmm<QT>(xa, wfb, acc);
+    __syncthreads();                                                                              // xa fully consumed
+    qstore_b<QT>(acc, vec_l[V_C2C_IN_B + cw], 0.25f, false, xa, kQLD, 16 * wave, Q);              // q (pre-scaled)
+  }
+  float fb1 = gld(W.ffn_b1 + cw);
+  qload_p(W.qpack + kQpFfn1, 8, wave, 0, wfb);                          // FFN chunk 0, hidden tile `wave`
+  qload_p(W.qpack + qpack_ffn2(W.dim_ff), W.dim_ff >> 4, wave, 0, wfc);                   // linear2 rows (output columns), chunk 0 columns
+  auto load_d = [&]() {
+    if (deleg) qload_p(W.mpack + kMpW0, 8, wave, 0, wfd);
+    else qload_p(W.qpack + kQpS2cKV, 8, wave, 0, wfd);             // s2c k rows
+  };
+  if constexpr (kDeep) load_d();
+  __syncthreads();
+  mark(3);
+  qattn_mfma<QT>(xa, xb, qpos, Q, Q);
+  if constexpr (!kDeep) load_d();
+  __syncthreads();
+  mark(4);
+  if (!deleg) {   // the qpos buffer held v: restore the position encodings for step 4
+    for (int e = tid; e < QP * 32; e += nt) {
+      const int q = e >> 5, c4 = (e & 31) * 4;
+      f32x4 vp = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (q < Q) vp = gld4(B.qpos + (size_t)q * D + c4);
+      *(f32x4*)(qpos + q * kQLD + c4) = vp;
+    }
+  }
+  qzero<QT>(acc);
+  qmm<QT>(xa, wfa, acc);
+  qstore_b<QT>(acc, vec_l[V_C2C_OUT_B + cw], 1.f, false, xb, kQLD, 16 * wave, QP);
+  if (deleg) qload_p(W.mpack + kMpW2, 8, wave, 0, wfa);
+  else qload_p(W.qpack + kQpS2cKV, 8, 8 + wave, 0, wfa);           // s2c v rows
+  __syncthreads();
+  qln16<QT>(cur, xb, Q, vec_l + V_C2C_NW, vec_l + V_C2C_NB, cur, nullptr, nullptr, nullptr, nh > 1 ? B.tgt : nullptr);
+  if (nh > 1) {   // tgt is with the FFN helpers once the flag is up
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    __syncthreads();
+    if (tid == 0) gst_agent(flags, 1u);
+  } else {
+    __syncthreads();
+  }
+  mark(5);
+  // ---- 3. FFN (attention_block.py:151-155) in hidden chunks of 128: wave w computes hidden tile w of the chunk into
+  //         xb, then accumulates output tile w over the chunk
+  f32x4 facc[QT];
+  qzero<QT>(facc);
+  for (int c = 0; c < nchunk; c += nh) {
+    qzero<QT>(acc);
+    qmm<QT>(cur, wfb, acc);
+    qstore_b<QT>(acc, fb1, 1.f, true, xb, kQLD, 16 * wave, QP);
+    if (c + nh < nchunk) {
+      qload_p(W.qpack + kQpFfn1, 8, (c + nh) * 8 + wave, 0, wfb);
+      fb1 = gld(W.ffn_b1 + (c + nh) * 128 + cw);
+    }
+    __syncthreads();
+    qmm<QT>(xb, wfc, facc);
+    if (c + nh < nchunk) qload_p(W.qpack + qpack_ffn2(W.dim_ff), W.dim_ff >> 4, wave, (c + nh) * 8, wfc);
+    __syncthreads();
+  }
+  if (nh > 1) {   // the helpers' partial sums, in helper order
+    const int nhelp = min(nh, nchunk) - 1;
+    if (tid < nhelp) {
+      unsigned spins = 0;
+      while (gld_agent(flags + 1 + tid) == 0u) {
+        __builtin_amdgcn_s_sleep(1);
+        if (++spins > (1u << 26)) break;
+      }
+    }
+    __syncthreads();
+    const int g = lane >> 4;
+    for (int h = 1; h <= nhelp; ++h) {
+      const float* part = B.hidden + (size_t)h * QP * D;
+#pragma unroll
+      for (int qt = 0; qt < QT; ++qt)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) facc[qt][t] += gld_agent(part + (size_t)(qt * 16 + 4 * g + t) * D + 16 * wave + j);
+    }
+  }
+  mark(6);
+  qstore_b<QT>(facc, vec_l[V_FFN_B2 + cw], 1.f, false, xa, kQLD, 16 * wave, QP);
+  __syncthreads();
+  // cur = the layer's new queries (also to global; to the helpers when they take the projections; + qpos for this workgroup's own)
+  qln16<QT>(cur, xa, Q, vec_l + V_FFN_NW, vec_l + V_FFN_NB, cur, deleg ? nullptr : xa, qpos, B.queries, deleg ? B.tgt : nullptr);
+  if (deleg) {
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    __syncthreads();
+    if (tid == 0) gst_agent(flags + 8, 1u);
+  } else {
+    __syncthreads();
+  }
+  mark(7);
+  // ---- 4. everything that depends only on the new queries: s2c keys / values, mask MLP, next layer's c2s query projection
+  qln16<QT>(cur, nullptr, Q, vec_l + V_DN_W, vec_l + V_DN_B, xb, nullptr, nullptr, nullptr, nullptr);   // decoder_norm(queries)
+  if (!deleg) {
+    qzero<QT>(acc);
+    qmm<QT>(xa, wfd, acc);
+    qstore_b<QT, true>(acc, vec_l[V_S2C_IN_B + D + cw], 0.25f, false, B.ks, D, 16 * wave, Q);   // keys pre-scaled
+    qload_p(W.mpack + kMpW0, 8, wave, 0, wfd);
+    qzero<QT>(acc);
+    qmm<QT>(cur, wfa, acc);
+    qstore_b<QT, true>(acc, vec_l[V_S2C_IN_B + 2 * D + cw], 1.f, false, B.vs, D, 16 * wave, Q);
+    qload_p(W.mpack + kMpW2, 8, wave, 0, wfa);
+    if (W.next_c2s_in_wt) {
+      qload_p(W.next_qpack + kQpC2sQ, 8, wave, 0, wfb);
+      qzero<QT>(acc);
+      qmm<QT>(xa, wfb, acc);
+      qstore_b<QT, true>(acc, vec_l[V_NEXT_B + cw], 0.25f, false, B.qproj, D, 16 * wave, Q);
+    }
+  }
+  __syncthreads();                                                   // xb = decoder_norm rows are complete; qpos is free
+  qzero<QT>(acc);
+  qmm<QT>(xb, wfd, acc);
+  qstore_b<QT>(acc, vec_l[V_M_B0 + cw], 1.f, true, qpos, kQLD, 16 * wave, QP);   // mask MLP hidden
+  __syncthreads();
+  qzero<QT>(acc);
+  qmm<QT>(qpos, wfa, acc);
+  qstore_b<QT, true>(acc, vec_l[V_M_B2 + cw], 1.f, false, B.E, D, 16 * wave, Q);
+  mark(8);
+}
+
 }  // namespace a3d
 
 using namespace a3d;
@@ -1977,6 +2445,45 @@ extern "C" size_t a3d_decoder_workspace_bytes(int64_t n, int n_queries) {
   return L.total + 256;
 }
 
+extern "C" size_t a3d_decoder_query_pack_floats(int32_t dim_ff) { return dim_ff > 0 && dim_ff % 128 == 0 ? qpack_floats(dim_ff) : 0; }
+extern "C" size_t a3d_decoder_mask_pack_floats(void) { return kMpFloats; }
+extern "C" int a3d_decoder_pack_query_weights(const a3d_decoder_weights* w, int32_t layer, float* out_dev, void* stream) {
+  int rc = check_weights(w);
+  if (rc) return rc;
+  if (!out_dev || layer < -1 || layer >= w->n_layers) {
+    set_error("a3d_decoder_pack_query_weights: bad arguments");
+    return A3D_ERR_INVALID;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  auto pack = [&](const float* W, int N, int K, size_t off) {
+    const size_t n4 = (size_t)(N >> 4) * (K >> 4) * 64;
+    k_pack_rows<<<(unsigned)((n4 + 255) / 256), 256, 0, st>>>(W, N, K, out_dev + off);
+  };
+  if (layer < 0) {
+    if (!w->mask_w0 || !w->mask_w2) {
+      set_error("a3d_decoder_pack_query_weights: mask head weights missing");
+      return A3D_ERR_INVALID;
+    }
+    pack(w->mask_w0, D, D, kMpW0);
+    pack(w->mask_w2, D, D, kMpW2);
+  } else {
+    const a3d_decoder_layer& LW = w->layers[layer];
+    if (!LW.c2s_out_w || !LW.c2c_in_w || !LW.c2c_out_w || !LW.s2c_in_w || !LW.c2s_in_w || !LW.ffn_w1 || !LW.ffn_w2) {
+      set_error("a3d_decoder_pack_query_weights: layer %d weights missing", layer);
+      return A3D_ERR_INVALID;
+    }
+    pack(LW.c2s_out_w, D, D, kQpC2sOut);
+    pack(LW.c2c_in_w, 3 * D, D, kQpC2cIn);
+    pack(LW.c2c_out_w, D, D, kQpC2cOut);
+    pack(LW.s2c_in_w + (size_t)D * D, 2 * D, D, kQpS2cKV);
+    pack(LW.c2s_in_w, D, D, kQpC2sQ);
+    pack(LW.ffn_w1, w->dim_ff, D, kQpFfn1);
+    pack(LW.ffn_w2, D, w->dim_ff, qpack_ffn2(w->dim_ff));
+  }
+  A3D_LAUNCH_CHECK();
+  return A3D_OK;
+}
+
 static bool fused_c2s() {   // A3D_FUSED_C2S=0 keeps the separate K / V GEMMs + k_c2s_attn (A/B switch)
   static int v = -1;
   if (v < 0) {
@@ -2040,6 +2547,10 @@ static int run_decoder(const a3d_decoder_weights* w, Prepared* P, int ns, hipStr
       (void)hipFuncSetAttribute((const void*)k_query_layer<2, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, big_lds);
       (void)hipFuncSetAttribute((const void*)k_query_layer<3, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, big_lds);
       (void)hipFuncSetAttribute((const void*)k_query_layer<4, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, big_lds);
+      (void)hipFuncSetAttribute((const void*)k_query_block<1>, hipFuncAttributeMaxDynamicSharedMemorySize, big_lds);
+      (void)hipFuncSetAttribute((const void*)k_query_block<2>, hipFuncAttributeMaxDynamicSharedMemorySize, big_lds);
+      (void)hipFuncSetAttribute((const void*)k_query_block<3>, hipFuncAttributeMaxDynamicSharedMemorySize, big_lds);
+      (void)hipFuncSetAttribute((const void*)k_query_block<4>, hipFuncAttributeMaxDynamicSharedMemorySize, big_lds);
       (void)hipFuncSetAttribute((const void*)k_query_layer<4, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, big_lds);
       (void)hipFuncSetAttribute((const void*)k_query_layer<4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, big_lds);
       (void)hipFuncSetAttribute((const void*)k_s2c_attn_wide<4>, hipFuncAttributeMaxDynamicSharedMemorySize, big_lds);
@@ -2199,6 +2710,9 @@ static int run_decoder(const a3d_decoder_weights* w, Prepared* P, int ns, hipStr
     QW.m_w0t = w->mask_w0; QW.m_b0 = w->mask_b0; QW.m_w2t = w->mask_w2; QW.m_b2 = w->mask_b2;
     QW.next_c2s_in_wt = l + 1 < w->n_layers ? w->layers[l + 1].c2s_in_w : nullptr;
     QW.next_c2s_in_b = l + 1 < w->n_layers ? w->layers[l + 1].c2s_in_b : nullptr;
+    QW.qpack = LW.query_pack;
+    QW.next_qpack = l + 1 < w->n_layers ? w->layers[l + 1].query_pack : nullptr;
+    QW.mpack = w->mask_pack;
     QW.dim_ff = w->dim_ff;
     QW.layer = l;
     QW.dbg = nullptr;
@@ -2224,7 +2738,14 @@ static int run_decoder(const a3d_decoder_weights* w, Prepared* P, int ns, hipStr
           nh_env = e ? atoi(e) : kQlMaxHelpers;
           nh_env = nh_env < 1 ? 1 : nh_env > kQlMaxHelpers ? kQlMaxHelpers : nh_env;
         }
-        k_query_layer<QT, 0><<<dim3(nh_env, ns), 512, ql_lds, st>>>(qs_dev, QW);
+        static int v1 = -1;   // A3D_QL_V1=1: the first build of the single-block layer (A/B switch)
+        if (v1 < 0) {
+          const char* e = getenv("A3D_QL_V1");
+          v1 = e ? atoi(e) : 0;
+        }
+        const bool have_packs = QW.qpack && QW.mpack && (QW.next_qpack || !QW.next_c2s_in_wt);
+        if (v1 || !have_packs) k_query_layer<QT, 0><<<dim3(nh_env, ns), 512, ql_lds, st>>>(qs_dev, QW);
+        else k_query_block<QT><<<dim3(nh_env, ns), 512, ql_lds + (size_t)kQVec * 4, st>>>(qs_dev, QW);
       } else {
         k_query_layer<QT, 1><<<dim3(nblk, ns), 512, ql_lds, st>>>(qs_dev, QW);
         k_query_layer<QT, 2><<<dim3(nblk, ns), 512, ql_lds, st>>>(qs_dev, QW);

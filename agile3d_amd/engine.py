@@ -324,6 +324,16 @@ class DecoderPack:
         W.bg_query_feat, W.bg_query_pos = dv(model.bg_query_feat.weight), dv(model.bg_query_pos.weight)
         W.gauss_B = dv(model.pos_enc.gauss_B)
         W.time_table = dv(time_table(d, 200))
+        # the query side's matrices once more, in the order the single-block layer kernel's waves read them
+        for l in range(n_layers):
+            qp = torch.empty(lib.a3d_decoder_query_pack_floats(W.dim_ff), dtype=torch.float32, device=dev)
+            L.check(lib.a3d_decoder_pack_query_weights(C.byref(W), l, _ptr(qp), _stream()), "a3d_decoder_pack_query_weights")
+            self.keep.append(qp)
+            W.layers[l].query_pack = qp.data_ptr()
+        mp = torch.empty(lib.a3d_decoder_mask_pack_floats(), dtype=torch.float32, device=dev)
+        L.check(lib.a3d_decoder_pack_query_weights(C.byref(W), -1, _ptr(mp), _stream()), "a3d_decoder_pack_query_weights")
+        self.keep.append(mp)
+        W.mask_pack = mp.data_ptr()
         self.W = W
         self.n_layers = n_layers
         self.gauss_B_ptr = W.gauss_B

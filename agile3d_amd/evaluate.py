@@ -19,7 +19,7 @@ import os
 import numpy as np
 import torch
 
-from .clicks import argmax_labels, extend_clicks, get_simulated_clicks, mean_iou_scene
+from .clicks import argmax_labels, extend_clicks, get_simulated_clicks_batch, mean_iou_scene_batch
 from .sparse import SparseTensor
 
 
@@ -45,7 +45,7 @@ def Evaluate(model, data_loader, args, device, on_round=None):
             data = SparseTensor(coordinates=coords, features=feats, device=device)
             batch_idx = coords[:, 0]
             n_samples = int(batch_idx.max()) + 1
-            masks = [batch_idx == i for i in range(n_samples)]
+            raw_s = [raw_coords[batch_idx == i] for i in range(n_samples)]
             for sample_clicks in click_idx:               # click ids set null
                 for obj_id in sample_clicks:
                     sample_clicks[obj_id] = []
@@ -58,18 +58,20 @@ def Evaluate(model, data_loader, args, device, on_round=None):
                 if current:
                     logits = model.forward_mask(*backbone_out, click_idx=click_idx,
                                                 click_time_idx=click_time_idx)["pred_masks"]
+                # the samples of a batch side by side: one host round trip for the IoU counts, one for the error
+                # clusters (their kernels overlap on side streams); clicks are picked in sample order
+                preds = [torch.zeros(labels[idx].shape[0], dtype=torch.int32, device=device) if current == 0
+                         else argmax_labels(logits[idx], click_idx[idx])          # + sparse-gt update
+                         for idx in range(n_samples)]
+                ious = mean_iou_scene_batch(preds, labels_full, inverse_map)
                 for idx in range(n_samples):
-                    if current == 0:
-                        pred = torch.zeros(labels[idx].shape[0], dtype=torch.int32, device=device)
-                    else:
-                        pred = argmax_labels(logits[idx], click_idx[idx])     # + sparse-gt update
-                    iou, _ = mean_iou_scene(pred, labels_full[idx], inverse_map[idx])
+                    iou = ious[idx][0]
                     f.write(f"{instance_counter + idx} {scene_name[idx].replace('scene', '')} {num_obj[idx]} "
                             f"{current / num_obj[idx]} {iou.cpu().numpy()}\n")
                     if on_round is not None:
-                        on_round(idx, current, pred, iou, click_idx[idx], click_time_idx[idx])
-                    new_clicks, _, _, new_time = get_simulated_clicks(pred, labels[idx], raw_coords[masks[idx]],
-                                                                      current, training=False)
+                        on_round(idx, current, preds[idx], iou, click_idx[idx], click_time_idx[idx])
+                sims = get_simulated_clicks_batch(preds, labels, raw_s, current, training=False)
+                for idx, (new_clicks, _, _, new_time) in enumerate(sims):
                     if new_clicks is not None:
                         extend_clicks(click_idx[idx], click_time_idx[idx], new_clicks, new_time)
                 current += num_obj[n_samples - 1] if current == 0 else 1
@@ -100,7 +102,7 @@ def EvaluateSingle(model, data_loader, args, device, on_round=None):
             data = SparseTensor(coordinates=coords, features=feats, device=device)
             batch_idx = coords[:, 0]
             n_samples = int(batch_idx.max()) + 1
-            masks = [batch_idx == i for i in range(n_samples)]
+            raw_s = [raw_coords[batch_idx == i] for i in range(n_samples)]
             click_idx = [{"0": [], "1": []} for _ in range(n_samples)]
             click_time_idx = copy.deepcopy(click_idx)
             backbone_out = model.forward_backbone(data, raw_coordinates=raw_coords)
@@ -108,18 +110,17 @@ def EvaluateSingle(model, data_loader, args, device, on_round=None):
                 if current:
                     logits = model.forward_mask(*backbone_out, click_idx=click_idx,
                                                 click_time_idx=click_time_idx)["pred_masks"]
+                preds = [torch.zeros(labels[idx].shape[0], dtype=torch.int32, device=device) if current == 0
+                         else argmax_labels(logits[idx], click_idx[idx]) for idx in range(n_samples)]
+                ious = mean_iou_scene_batch(preds, labels_full, inverse_map)
                 for idx in range(n_samples):
-                    if current == 0:
-                        pred = torch.zeros(labels[idx].shape[0], dtype=torch.int32, device=device)
-                    else:
-                        pred = argmax_labels(logits[idx], click_idx[idx])
-                    iou, _ = mean_iou_scene(pred, labels_full[idx], inverse_map[idx])
+                    iou = ious[idx][0]
                     f.write(f"{instance_counter + idx} {scene_name[idx].replace('scene', '')} {object_id[idx]} "
                             f"{current} {iou.cpu().numpy()}\n")
                     if on_round is not None:
-                        on_round(idx, current, pred, iou, click_idx[idx], click_time_idx[idx])
-                    new_clicks, _, _, new_time = get_simulated_clicks(pred, labels[idx], raw_coords[masks[idx]],
-                                                                      current, training=False)
+                        on_round(idx, current, preds[idx], iou, click_idx[idx], click_time_idx[idx])
+                sims = get_simulated_clicks_batch(preds, labels, raw_s, current, training=False)
+                for idx, (new_clicks, _, _, new_time) in enumerate(sims):
                     if new_clicks is not None:
                         extend_clicks(click_idx[idx], click_time_idx[idx], new_clicks, new_time)
             instance_counter += len(object_id)

@@ -38,7 +38,7 @@ _LAYER_FIELDS = ["c2s_in_w", "c2s_in_b", "c2s_out_w", "c2s_out_b", "c2s_norm_w",
                  "c2c_in_w", "c2c_in_b", "c2c_out_w", "c2c_out_b", "c2c_norm_w", "c2c_norm_b",
                  "ffn_w1", "ffn_b1", "ffn_w2", "ffn_b2", "ffn_norm_w", "ffn_norm_b",
                  "s2c_in_w", "s2c_in_b", "s2c_out_w", "s2c_out_b", "s2c_norm_w", "s2c_norm_b",
-                 "c2s_wk_packed", "c2s_wv_packed", "s2c_wq_packed", "s2c_wo_packed"]
+                 "c2s_wk_packed", "c2s_wv_packed", "s2c_wq_packed", "s2c_wo_packed", "query_pack"]
 
 
 class DecoderLayer(C.Structure):
@@ -51,7 +51,7 @@ class DecoderWeights(C.Structure):
                 ("decoder_norm_w", C.c_void_p), ("decoder_norm_b", C.c_void_p),
                 ("mask_w0", C.c_void_p), ("mask_b0", C.c_void_p), ("mask_w2", C.c_void_p), ("mask_b2", C.c_void_p),
                 ("bg_query_feat", C.c_void_p), ("bg_query_pos", C.c_void_p),
-                ("gauss_B", C.c_void_p), ("time_table", C.c_void_p)]
+                ("gauss_B", C.c_void_p), ("time_table", C.c_void_p), ("mask_pack", C.c_void_p)]
 
 
 class ProfEntry(C.Structure):
@@ -106,6 +106,9 @@ SYMBOLS = {
     "a3d_posenc_fourier": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                      C.c_size_t, C.c_void_p]),
     "a3d_decoder_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int]),
+    "a3d_decoder_query_pack_floats": (C.c_size_t, [C.c_int32]),
+    "a3d_decoder_mask_pack_floats": (C.c_size_t, []),
+    "a3d_decoder_pack_query_weights": (C.c_int, [C.POINTER(DecoderWeights), C.c_int32, C.c_void_p, C.c_void_p]),
     "a3d_conv_wgrad_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]),
     "a3d_conv_wgrad": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int,
                                  C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),

@@ -19,7 +19,7 @@ import time
 import numpy as np
 import torch
 
-from .clicks import argmax_labels, cal_click_loss_weights, extend_clicks, get_simulated_clicks
+from .clicks import argmax_labels, cal_click_loss_weights, extend_clicks, get_simulated_clicks, get_simulated_clicks_batch
 from .engine import Scene
 from .optim import allreduce_mean_, clip_grad_norm_
 from .train_backbone import BackboneTape
@@ -68,7 +68,7 @@ def _train_one_step(model, criterion, optimizer, batch, device, max_norm):
     mark("backbone forward")
 
     # ---- objects of this iteration, engine.py:55-77
-    labels_new = []
+    labels_new, num_objs = [], []
     for idx in range(n_samples):
         sample_labels = labels[idx]
         valid = torch.unique(sample_labels)
@@ -82,6 +82,7 @@ def _train_one_step(model, criterion, optimizer, batch, device, max_norm):
             click_idx[idx][str(i + 1)] = []
         click_idx[idx]["0"] = []
         labels_new.append(new)
+        num_objs.append(num_obj)          # = the nonzero ids of labels_new[idx] (every chosen object has points)
     click_time_idx = copy.deepcopy(click_idx)
 
     # ---- click simulation with the current weights, no gradient (engine.py:82-116)
@@ -92,15 +93,16 @@ def _train_one_step(model, criterion, optimizer, batch, device, max_norm):
                                              # optimiser marked everything stale; the backbone program is rebuilt on demand)
     dec_in = eng.decoder_inputs_batch(pcd, raw_coords, ranges)
     pos_enc = dec_in[3][4][0]
+    raw_s = [raw_coords[s:e] for (s, e) in ranges]
     for it in range(num_forward_iters + 1):
         if it:                                 # one batched decoder pass for all samples (5 launches per layer)
             out = eng.forward_mask(*dec_in, click_idx=click_idx, click_time_idx=click_time_idx)
-        for idx, (s, e) in enumerate(ranges):
-            if it == 0:
-                pred = torch.zeros(e - s, device=device)
-            else:   # argmax + "update prediction with sparse gt" (engine.py:96-101) in one kernel instead of 1 + K torch ops
-                pred = argmax_labels(out["pred_masks"][idx], click_idx[idx])
-            new_clicks, _, _, new_time = get_simulated_clicks(pred, labels_new[idx], raw_coords[s:e], it, training=True)
+        # argmax + "update prediction with sparse gt" (engine.py:96-101) in one kernel instead of 1 + K torch ops; then the
+        # samples' error clusters side by side (one host round trip per round, not one per sample), clicks in sample order
+        preds = [torch.zeros(e - s, device=device) if it == 0 else argmax_labels(out["pred_masks"][idx], click_idx[idx])
+                 for idx, (s, e) in enumerate(ranges)]
+        sims = get_simulated_clicks_batch(preds, labels_new, raw_s, it, training=True, num_objs=num_objs)
+        for idx, (new_clicks, _, _, new_time) in enumerate(sims):
             if new_clicks is not None:
                 click_idx[idx], click_time_idx[idx] = extend_clicks(click_idx[idx], click_time_idx[idx], new_clicks,
                                                                     new_time)

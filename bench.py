@@ -609,11 +609,10 @@ def main():
                 t0 = time.perf_counter()
                 if rnd:
                     outs = model.forward_mask(*rB, click_idx=ecis, click_time_idx=ects)["pred_masks"]
-                for b_ in range(len(scenes)):
-                    if rnd:
-                        preds[b_] = pc.argmax_labels(outs[b_], ecis[b_])
-                    pc.mean_iou_scene(preds[b_], labs[b_])
-                    new, _, _, nt = pc.get_simulated_clicks(preds[b_], labs[b_], raws[b_], rnd, training=False)
+                if rnd:
+                    preds = [pc.argmax_labels(outs[b_], ecis[b_]) for b_ in range(len(scenes))]
+                pc.mean_iou_scene_batch(preds, labs)
+                for b_, (new, _, _, nt) in enumerate(pc.get_simulated_clicks_batch(preds, labs, raws, rnd, training=False)):
                     if new is not None:
                         pc.extend_clicks(ecis[b_], ects[b_], new, nt)
                 torch.cuda.synchronize()
@@ -621,7 +620,7 @@ def main():
                     brounds.append(time.perf_counter() - t0)
             res["eval_rounds_per_s"] = round(len(scenes) / float(np.median(brounds)), 1)
             res["eval_rounds_note"] = (f"{len(scenes)} scenes advance in lock-step (eval_multi_obj.py:114,162-166 with a batch): one "
-                                       "batched forward_mask + per-scene argmax / IoU / click simulator per round; scene-rounds per second")
+                                       "batched forward_mask, then the scenes' label argmax / IoU counts / error clusters side by side (two host round trips per round); scene-rounds per second")
         if not args.no_cpu_baseline and not args.steps_only and world == 1:
             res["cpu_baseline"], diff = cpu_baseline(sd, sc, ci, ct, gpu_logits0, gpu_feats0)
             res["parity_vs_oracle"] = diff

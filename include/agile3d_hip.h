@@ -389,6 +389,11 @@ typedef struct {
   /* the [128][128] blocks that multiply all N points (c2s Wk, Wv; s2c Wq, Wo), as W^T packed by
    * a3d_pack_conv_weight(kernel_volume=1) */
   const float *c2s_wk_packed, *c2s_wv_packed, *s2c_wq_packed, *s2c_wo_packed;
+  /* every matrix the QUERY side of the layer multiplies by (c2s out_proj, c2c in/out_proj, s2c k/v rows, c2s q rows,
+   * FFN), in MFMA fragment order, made by a3d_decoder_pack_query_weights(w, layer, ...): a wave's weight load is 1 KB
+   * contiguous instead of 64 B of each of 16 rows (35 -> 140 GB/s into one CU, tools/qload_ubench.hip).  Optional:
+   * with NULL here (or in a3d_decoder_weights::mask_pack) the query-side kernel reads the torch-layout matrices. */
+  const float* query_pack;
 } a3d_decoder_layer;
 
 typedef struct {
@@ -401,7 +406,15 @@ typedef struct {
   const float *bg_query_feat, *bg_query_pos;              /* [n_bg][128] */
   const float *gauss_B;                                   /* [3][64] */
   const float *time_table;                                /* [200][128] PositionalEncoding1D */
+  const float *mask_pack;                                 /* mask_w0, mask_w2 in fragment order (layer = -1 below), or NULL */
 } a3d_decoder_weights;
+
+/* Fragment-order copies of the query-side matrices of one decoder layer (layer >= 0: a3d_decoder_query_pack_floats(dim_ff)
+ * floats) or of the mask head (layer = -1: a3d_decoder_mask_pack_floats()), read from the torch-layout pointers of `w`.
+ * Re-run after the parameters change. */
+size_t a3d_decoder_query_pack_floats(int32_t dim_ff);
+size_t a3d_decoder_mask_pack_floats(void);
+int a3d_decoder_pack_query_weights(const a3d_decoder_weights* w, int32_t layer, float* out_dev, void* stream);
 
 size_t a3d_decoder_workspace_bytes(int64_t n, int n_queries);
 

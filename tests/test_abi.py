@@ -32,8 +32,8 @@ def test_struct_layouts_match_header():
     from agile3d_amd import lib
     assert C.sizeof(lib.Op) == 12 * 4 + 3 * 8
     assert C.sizeof(lib.BufDesc) == 8
-    assert C.sizeof(lib.DecoderLayer) == 28 * 8
-    assert C.sizeof(lib.DecoderWeights) == 16 + 8 * 28 * 8 + 10 * 8
+    assert C.sizeof(lib.DecoderLayer) == 29 * 8
+    assert C.sizeof(lib.DecoderWeights) == 16 + 8 * 29 * 8 + 11 * 8
 
 
 def test_sparse_quantize_first_occurrence():

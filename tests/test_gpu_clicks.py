@@ -90,6 +90,35 @@ def test_simulated_clicks_vs_reference(name, mode):
     assert np.array_equal(got_pos, G[f"{name}/{mode}/pos"])
 
 
+@pytest.mark.parametrize("mode", ["eval0", "evalk", "train"])
+def test_batched_round_equals_the_per_sample_loop(mode):
+    """get_simulated_clicks_batch / mean_iou_scene_batch over all golden cases as ONE batch (error clusters on side
+    streams, one host round trip) against the per-sample calls in the same order with the same ``random`` seed:
+    identical clicks, order, positions and IoU bits -- and therefore identical to the reference's goldens."""
+    xs = [torch.from_numpy(G[f"{n}/xyz"]).cuda() for n in NAMES]
+    labs = [torch.from_numpy(G[f"{n}/labels"]).cuda().long() for n in NAMES]
+    prs = [torch.from_numpy(G[f"{n}/pred"]).cuda().long() for n in NAMES]
+    cur, training = {"eval0": (0, False), "evalk": (7, False), "train": (None, True)}[mode]
+    if mode == "eval0":
+        prs = [torch.zeros(len(l), device="cuda") for l in labs]
+    random.seed(123)
+    single = [pc.get_simulated_clicks(p, l, x, cur, training=training) for p, l, x in zip(prs, labs, xs)]
+    random.seed(123)
+    batch = pc.get_simulated_clicks_batch(prs, labs, xs, cur, training=training)
+    nobj = [int((torch.unique(l) != 0).sum()) for l in labs]
+    random.seed(123)
+    batch_n = pc.get_simulated_clicks_batch(prs, labs, xs, cur, training=training, num_objs=nobj)
+    for a, b, c in zip(single, batch, batch_n):
+        for other in (b, c):
+            assert a[0] == other[0] and (a[0] is None or list(a[0]) == list(other[0])) and a[1] == other[1] and a[3] == other[3]
+            if a[2] is not None:
+                assert all(torch.equal(u, v) for k in a[2] for u, v in zip(a[2][k], other[2][k]))
+    ious = pc.mean_iou_scene_batch(prs, labs)
+    for (iou_b, per_b), p, l in zip(ious, prs, labs):
+        iou_s, per_s = pc.mean_iou_scene(p, l)
+        assert (np.float32(iou_b.numpy()) == np.float32(iou_s.numpy()) or (np.isnan(iou_b.numpy()) and np.isnan(iou_s.numpy()))) and per_b == per_s
+
+
 @pytest.mark.parametrize("name", NAMES)
 def test_iou_and_weights_vs_reference(name):
     xyz, pred, lab = (torch.from_numpy(G[f"{name}/{k}"]).cuda() for k in ("xyz", "pred", "labels"))

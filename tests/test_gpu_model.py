@@ -423,8 +423,11 @@ def test_training_mode_forward_invalidates_the_folded_backbone():
     assert moved > 1e-3 and err <= TOL * max(1.0, ref["pcd_features"].abs().max().item())
 
 
-def test_one_pass_scene_to_click_half_matches_the_two_kernel_path(tmp_path):
-    """k_s2c_out (scene-to-click attention + output projection + LayerNorm + mask head in one pass, <= ~24 queries,
+@pytest.mark.parametrize("switch", ["A3D_FUSED_S2C", "A3D_QL_V1"])
+def test_one_pass_scene_to_click_half_matches_the_two_kernel_path(tmp_path, switch):
+    """A3D_QL_V1: the single-block query layer's second build (k_query_block: packed weights, vector table in LDS,
+    click-to-click attention on the matrix cores) against the first (k_query_layer<QT, 0>, torch-layout weights).
+    A3D_FUSED_S2C: k_s2c_out (scene-to-click attention + output projection + LayerNorm + mask head in one pass, <= ~24 queries,
     default) against k_q_s2c + k_out_ln_mask (A3D_FUSED_S2C=0): same arithmetic per element, so the logits, the label
     bytes feeding the next layer's attention mask and the intermediate (aux) logits agree to rounding; both against the
     reference's goldens.  The switch is read once per process -> two interpreters."""
@@ -464,12 +467,12 @@ print("WORST", worst)
     res = {}
     for sw in ("0", "1"):
         out = str(tmp_path / f"logits_{sw}.npz")
-        env = dict(os.environ, A3D_FUSED_S2C=sw)
+        env = dict(os.environ, **{switch: sw})
         subprocess.run([sys.executable, "-c", script, root, out], check=True, env=env, timeout=600)
         z = np.load(out)
         res[sw] = [z[k] for k in z.files]
     assert len(res["0"]) == len(res["1"]) == 11
     worst = max(float(np.abs(a - b).max()) for a, b in zip(res["0"], res["1"]))
     scale = max(float(np.abs(a).max()) for a in res["0"])
-    print(f"one-pass scene-to-click half vs two kernels: max |diff| {worst:.2e} on logits of scale {scale:.1f}")
+    print(f"{switch} = 0 vs 1: max |diff| {worst:.2e} on logits of scale {scale:.1f}")
     assert worst <= 1e-4 * max(1.0, scale)
