@@ -2082,16 +2082,96 @@ __device__ __forceinline__ void qattn_mfma(float* q_l, const float* k_l, const f
   }
 }
 
+// The same attention with the keys / values of ALL query blocks in global memory (PART 2 of the multi-block layer): flash
+// over 16-key tiles, the next tile's fragments requested before the current tile's products.  qk: this block's rows of
+// [q (pre-scaled) | k]; all_qk / all_vc: every block's rows.  Keys >= Qall are masked (their V lanes zeroed: the rows
+// were never written).
 template <int QT>
+__device__ __forceinline__ void qattn_mfma_global(float* o_l, const float* qk, const float* all_qk, const float* all_vc,
+                                                  int Q, int Qall) {
+  const int lane = threadIdx.x & 63, h = threadIdx.x >> 6, g = lane >> 4, j = lane & 15;
+  f32x4 qf[QT], o[QT];
+  float m[QT], l[QT];
+#pragma unroll
+  for (int qt = 0; qt < QT; ++qt) {
+    qf[qt] = gld4(qk + (size_t)(16 * qt + j) * 2 * D + 16 * h + 4 * g);
+    o[qt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    m[qt] = kNegBig;
+    l[qt] = 0.f;
+  }
+  const int nkt = (Qall + 15) >> 4;
+  auto fetch = [&](int kt, f32x4& kf, f32x4& vf) {
+    kf = gld4(all_qk + (size_t)(16 * kt + j) * 2 * D + D + 16 * h + 4 * g);          // K[key 16kt+j][16h+4g..+3]
+#pragma unroll
+    for (int t = 0; t < 4; ++t) vf[t] = gld(all_vc + (size_t)(16 * kt + 4 * g + t) * D + 16 * h + j);   // V^T[16h+j][key]
+  };
+  f32x4 kn, vn;
+  fetch(0, kn, vn);
+  for (int kt = 0; kt < nkt; ++kt) {
+    f32x4 kf = kn, vf = vn;
+    if (kt + 1 < nkt) fetch(kt + 1, kn, vn);
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+      if (16 * kt + 4 * g + t >= Qall) vf[t] = 0.f;
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) {
+      f32x4 sc = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int t = 0; t < 4; ++t) sc = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[t], qf[qt][t], sc, 0, 0, 0);
+      float mx = kNegBig;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        if (16 * kt + 4 * g + t >= Qall) sc[t] = kNegBig;
+        mx = fmaxf(mx, sc[t]);
+      }
+      mx = rows_max(mx);
+      const float mnew = fmaxf(m[qt], mx);
+      const float scl = fast_exp(m[qt] - mnew);
+      m[qt] = mnew;
+      float ps = 0.f;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        sc[t] = fast_exp(sc[t] - mnew);
+        ps += sc[t];
+      }
+      l[qt] = l[qt] * scl + ps;
+      o[qt] *= scl;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) o[qt] = __builtin_amdgcn_mfma_f32_16x16x4f32(vf[t], sc[t], o[qt], 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int qt = 0; qt < QT; ++qt) {
+    const float lt = rows_sum(l[qt]);
+    f32x4 r = o[qt] * (1.f / lt);
+    if (16 * qt + j >= Q) r = (f32x4){0.f, 0.f, 0.f, 0.f};
+    *(f32x4*)(o_l + (16 * qt + j) * kQLD + 16 * h + 4 * g) = r;
+  }
+}
+
+// More than 64 queries: blocks of 64 rows, one workgroup (+ helpers) each, in two launches around the click-to-click
+// attention, which needs every block's keys / values: PART 1 = steps 1-2 up to the q / k / v projections (to B.qk, B.vc; tgt
+// to B.tgt), PART 2 = the attention (flash over all blocks' keys, read from global memory) and everything after it.
+// PART 0 = the whole layer (one block).  Grid (helpers + 1, blocks, samples).
+constexpr int kMaxQBlocks = A3D_MAX_QUERIES / 64;
+template <int QT, int PART>
 __global__ void __launch_bounds__(512) k_query_block(const QuerySample* __restrict__ qs, QueryLayerW W) {
   constexpr int QP = QT * 16;
-  const QueryMeta* meta = qs[blockIdx.y].meta;
-  QueryBufs B = qs[blockIdx.y].B;
+  const QueryMeta* meta = qs[blockIdx.z].meta;
+  QueryBufs B = qs[blockIdx.z].B;
+  const int blk = (int)blockIdx.y, q0 = blk * QP;
+  const float* all_qk = B.qk;
+  const float* all_vc = B.vc;
+  B.queries += (size_t)q0 * D; B.qpos += (size_t)q0 * D; B.qproj += (size_t)q0 * D; B.attn += (size_t)q0 * D;
+  B.ks += (size_t)q0 * D; B.vs += (size_t)q0 * D; B.E += (size_t)q0 * D; B.tgt += (size_t)q0 * D;
+  B.qk += (size_t)q0 * 2 * D; B.vc += (size_t)q0 * D;
+  B.hidden += (size_t)blk * kQlMaxHelpers * QP * D;
   // workgroup 0 runs the layer; workgroups 1.. are FFN helpers (hidden chunks hx, hx + nh, ... of the 1024-wide FFN, whose
   // 1 MB of weights one workgroup alone would pull through one CU), helpers 1..3 then take one projection of the layer's new
   // queries each; hand-off through global memory with agent-scope loads / stores + flags
   const int nh = (int)gridDim.x, hx = (int)blockIdx.x;
-  const int Q = max(0, min(QP, gld(&meta->nq)));
+  const int Qall = gld(&meta->nq);
+  const int Q = max(0, min(QP, Qall - q0));
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* qpos = (float*)smem;            // [QP][132]  query position encodings (c2c values in between; mask MLP hidden)
   float* cur = qpos + QP * kQLD;         // queries -> tgt -> queries
@@ -2101,15 +2181,15 @@ __global__ void __launch_bounds__(512) k_query_block(const QuerySample* __restri
   const int tid = threadIdx.x, nt = 512;
   const int wave = tid >> 6, lane = tid & 63, j = lane & 15;
   const int nchunk = W.dim_ff >> 7;
-  unsigned* flags = B.sync + W.layer * 16;
+  unsigned* flags = B.sync + (W.layer * kMaxQBlocks + blk) * 16;
   f32x4 wfa[8], wfb[8], wfc[8], wfd[8], acc[QT];
   constexpr bool kDeep = QT <= 2;   // the fourth fragment set in flight across the load phase and the attention (registers)
   auto mark = [&](int i) {
-    if (W.dbg && tid == 0 && hx == 0 && blockIdx.y == 0) W.dbg[i] = __builtin_amdgcn_s_memtime();
+    if (W.dbg && tid == 0 && hx == 0 && blockIdx.y == 0 && blockIdx.z == 0) W.dbg[i] = __builtin_amdgcn_s_memtime();
   };
   mark(0);
 
-  if (hx > 0) {   // ---- FFN helper
+  if (PART != 1 && hx > 0) {   // ---- FFN helper
     if (hx >= nchunk) return;
     // everything this workgroup will multiply by is requested before it starts to wait
     qload_p(W.qpack + kQpFfn1, 8, hx * 8 + wave, 0, wfa);
@@ -2192,7 +2272,12 @@ __global__ void __launch_bounds__(512) k_query_block(const QuerySample* __restri
 
   // ---- the layer's workgroup.  Load phase: the small vectors and the activations first (vmcnt is in order: their waits
   // must not stand behind the weights), then the weights of the first FOUR GEMMs
-  const bool deleg = nh >= 4 && nchunk >= 4;             // helpers 1..3 take the s2c keys / values / next qproj
+  const bool deleg = PART != 1 && nh >= 4 && nchunk >= 4;   // helpers 1..3 take the s2c keys / values / next qproj
+  auto load_d = [&]() {
+    if (deleg) qload_p(W.mpack + kMpW0, 8, wave, 0, wfd);
+    else qload_p(W.qpack + kQpS2cKV, 8, wave, 0, wfd);             // s2c k rows
+  };
+  float fb1 = 0.f;
   {
     float tv[5];
 #pragma unroll
@@ -2210,14 +2295,28 @@ __global__ void __launch_bounds__(512) k_query_block(const QuerySample* __restri
     for (int u = 0; u < QT; ++u) {
       const int e = tid + u * nt, q = e >> 5, c4 = (e & 31) * 4;
       // all QP rows exist in the scratch buffers: the loads do not wait for the query count (rows >= Q are zeroed below)
-      vq[u] = gld4(B.queries + (size_t)q * D + c4);
-      vp[u] = gld4(B.qpos + (size_t)q * D + c4);
-      va[u] = gld4(B.attn + (size_t)q * D + c4);
+      if constexpr (PART != 2) {
+        vq[u] = gld4(B.queries + (size_t)q * D + c4);
+        vp[u] = gld4(B.qpos + (size_t)q * D + c4);
+        va[u] = gld4(B.attn + (size_t)q * D + c4);
+      } else {
+        vq[u] = gld4(B.tgt + (size_t)q * D + c4);                    // tgt of PART 1
+        vp[u] = gld4(B.qpos + (size_t)q * D + c4);
+      }
     }
-    qload_p(W.qpack + kQpC2sOut, 8, wave, 0, wfa);
-    qload_p(W.qpack + kQpC2cIn, 8, wave, 0, wfb);                      // q rows of the c2c in_proj
-    qload_p(W.qpack + kQpC2cIn, 8, 8 + wave, 0, wfc);                  // k rows
-    if constexpr (kDeep) qload_p(W.qpack + kQpC2cIn, 8, 16 + wave, 0, wfd);   // v rows
+    if constexpr (PART != 2) {
+      qload_p(W.qpack + kQpC2sOut, 8, wave, 0, wfa);
+      if constexpr (PART == 0) {
+        qload_p(W.qpack + kQpC2cIn, 8, wave, 0, wfb);                  // q rows of the c2c in_proj
+        qload_p(W.qpack + kQpC2cIn, 8, 8 + wave, 0, wfc);              // k rows
+        if constexpr (kDeep) qload_p(W.qpack + kQpC2cIn, 8, 16 + wave, 0, wfd);   // v rows
+      }
+    } else {
+      qload_p(W.qpack + kQpC2cOut, 8, wave, 0, wfa);
+      fb1 = gld(W.ffn_b1 + 16 * wave + j);
+      qload_p(W.qpack + kQpFfn1, 8, wave, 0, wfb);
+      qload_p(W.qpack + qpack_ffn2(W.dim_ff), W.dim_ff >> 4, wave, 0, wfc);
+    }
 #pragma unroll
     for (int s5 = 0; s5 < 5; ++s5) vec_l[(4 * s5 + (tid >> 7)) * 128 + (tid & 127)] = tv[s5];
 #pragma unroll
@@ -2226,25 +2325,43 @@ __global__ void __launch_bounds__(512) k_query_block(const QuerySample* __restri
       const f32x4 z = (f32x4){0.f, 0.f, 0.f, 0.f};
       *(f32x4*)(cur + q * kQLD + c4) = q < Q ? vq[u] : z;
       *(f32x4*)(qpos + q * kQLD + c4) = q < Q ? vp[u] : z;
-      *(f32x4*)(xa + q * kQLD + c4) = q < Q ? va[u] : z;
+      if constexpr (PART != 2) *(f32x4*)(xa + q * kQLD + c4) = q < Q ? va[u] : z;
     }
-    if constexpr (!kDeep) qload_p(W.qpack + kQpC2cIn, 8, 16 + wave, 0, wfd);
+    if constexpr (PART == 0 && !kDeep) qload_p(W.qpack + kQpC2cIn, 8, 16 + wave, 0, wfd);
   }
   __syncthreads();
   mark(1);
   const int cw = 16 * wave + j;                           // this lane's output column in every 128-wide GEMM
+  if constexpr (PART != 2) {
   // ---- 1. click-to-scene output projection + residual + LayerNorm (attention_block.py:95-96)
   qzero<QT>(acc);
   qmm<QT>(xa, wfa, acc);
   qstore_b<QT>(acc, vec_l[V_C2S_OUT_B + cw], 1.f, false, xb, kQLD, 16 * wave, QP);
-  qload_p(W.qpack + kQpC2cOut, 8, wave, 0, wfa);
+  if constexpr (PART == 0) {
+    qload_p(W.qpack + kQpC2cOut, 8, wave, 0, wfa);
+  } else {   // 64-row blocks: the registers of the load phase do not leave room for these any earlier
+    qload_p(W.qpack + kQpC2cIn, 8, wave, 0, wfb);
+    qload_p(W.qpack + kQpC2cIn, 8, 8 + wave, 0, wfc);
+  }
   __syncthreads();
-  qln16<QT>(cur, xb, Q, vec_l + V_C2S_NW, vec_l + V_C2S_NB, cur, xa, qpos, nullptr, nullptr);   // cur = tgt, xa = tgt + qpos
+  qln16<QT>(cur, xb, Q, vec_l + V_C2S_NW, vec_l + V_C2S_NB, cur, xa, qpos, PART == 1 ? B.tgt : nullptr, nullptr);   // cur = tgt, xa = tgt + qpos
   __syncthreads();
   mark(2);
-  // ---- 2. click-to-click self attention (attention_block.py:32-36): q | k from tgt + qpos, v from tgt; all three stay in
-  //         LDS (k -> xb, v -> the qpos buffer, q -> xa once every wave is done reading xa)
-  {
+  // ---- 2. click-to-click self attention (attention_block.py:32-36): q | k from tgt + qpos, v from tgt
+  if constexpr (PART == 1) {   // to the buffers every block reads in PART 2
+    qload_p(W.qpack + kQpC2cIn, 8, 16 + wave, 0, wfd);
+    qzero<QT>(acc);
+    qmm<QT>(xa, wfc, acc);
+    qstore_b<QT, true>(acc, vec_l[V_C2C_IN_B + D + cw], 1.f, false, B.qk, 2 * D, D + 16 * wave, Q);   // k
+    qzero<QT>(acc);
+    qmm<QT>(cur, wfd, acc);
+    qstore_b<QT, true>(acc, vec_l[V_C2C_IN_B + 2 * D + cw], 1.f, false, B.vc, D, 16 * wave, Q);       // v
+    qzero<QT>(acc);
+    qmm<QT>(xa, wfb, acc);
+    qstore_b<QT, true>(acc, vec_l[V_C2C_IN_B + cw], 0.25f, false, B.qk, 2 * D, 16 * wave, Q);         // q (pre-scaled)
+    return;
+  } else {
+    // single block: all three stay in LDS (k -> xb, v -> the qpos buffer, q -> xa once every wave is done reading xa)
     qzero<QT>(acc);
     qmm<QT>(xa, wfc, acc);
     qstore_b<QT>(acc, vec_l[V_C2C_IN_B + D + cw], 1.f, false, xb, kQLD, 16 * wave, Q);            // k (xb, qpos: read before the barrier above)
@@ -2256,13 +2373,9 @@ __global__ void __launch_bounds__(512) k_query_block(const QuerySample* __restri
     __syncthreads();                                                                              // xa fully consumed
     qstore_b<QT>(acc, vec_l[V_C2C_IN_B + cw], 0.25f, false, xa, kQLD, 16 * wave, Q);              // q (pre-scaled)
   }
-  float fb1 = gld(W.ffn_b1 + cw);
-  qload_p(W.qpack + kQpFfn1, 8, wave, 0, wfb);                          // FFN chunk 0, hidden tile `wave`
-  qload_p(W.qpack + qpack_ffn2(W.dim_ff), W.dim_ff >> 4, wave, 0, wfc);                   // linear2 rows (output columns), chunk 0 columns
-  auto load_d = [&]() {
-    if (deleg) qload_p(W.mpack + kMpW0, 8, wave, 0, wfd);
-    else qload_p(W.qpack + kQpS2cKV, 8, wave, 0, wfd);             // s2c k rows
-  };
+  fb1 = gld(W.ffn_b1 + cw);
+  qload_p(W.qpack + kQpFfn1, 8, wave, 0, wfb);                       // FFN chunk 0, hidden tile `wave`
+  qload_p(W.qpack + qpack_ffn2(W.dim_ff), W.dim_ff >> 4, wave, 0, wfc);   // linear2 rows (output columns), chunk 0 columns
   if constexpr (kDeep) load_d();
   __syncthreads();
   mark(3);
@@ -2277,6 +2390,14 @@ __global__ void __launch_bounds__(512) k_query_block(const QuerySample* __restri
       if (q < Q) vp = gld4(B.qpos + (size_t)q * D + c4);
       *(f32x4*)(qpos + q * kQLD + c4) = vp;
     }
+  }
+  } else {
+    // ---- 2 (continued): attention of this block's queries over every block's keys / values
+    mark(3);
+    qattn_mfma_global<QT>(xa, B.qk, all_qk, all_vc, Q, Qall);
+    load_d();
+    __syncthreads();
+    mark(4);
   }
   qzero<QT>(acc);
   qmm<QT>(xa, wfa, acc);
@@ -2433,7 +2554,7 @@ void dec_layout(int64_t n, int nq, DecLayout& L) {
   L.q[9] = take(2 * qb);                                // qk
   L.q[10] = take(qb);                                   // vc
   L.q[11] = take((size_t)L.qp * 4096 * 4);              // hidden: kQlMaxHelpers x [qp][128] FFN partial sums fit (dim_ff <= 4096)
-  L.sync = take((size_t)kMaxBatchSamples * A3D_MAX_DEC_LAYERS * 16 * 4);   // k_query_layer flags of a batched call (first sample's workspace)
+  L.sync = take((size_t)kMaxBatchSamples * A3D_MAX_DEC_LAYERS * kMaxQBlocks * 16 * 4);   // k_query_layer flags of a batched call (first sample's workspace)
   L.total = off;
 }
 }  // namespace
@@ -2547,10 +2668,12 @@ static int run_decoder(const a3d_decoder_weights* w, Prepared* P, int ns, hipStr
       (void)hipFuncSetAttribute((const void*)k_query_layer<2, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, big_lds);
       (void)hipFuncSetAttribute((const void*)k_query_layer<3, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, big_lds);
       (void)hipFuncSetAttribute((const void*)k_query_layer<4, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, big_lds);
-      (void)hipFuncSetAttribute((const void*)k_query_block<1>, hipFuncAttributeMaxDynamicSharedMemorySize, big_lds);
-      (void)hipFuncSetAttribute((const void*)k_query_block<2>, hipFuncAttributeMaxDynamicSharedMemorySize, big_lds);
-      (void)hipFuncSetAttribute((const void*)k_query_block<3>, hipFuncAttributeMaxDynamicSharedMemorySize, big_lds);
-      (void)hipFuncSetAttribute((const void*)k_query_block<4>, hipFuncAttributeMaxDynamicSharedMemorySize, big_lds);
+      (void)hipFuncSetAttribute((const void*)k_query_block<1, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, big_lds);
+      (void)hipFuncSetAttribute((const void*)k_query_block<2, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, big_lds);
+      (void)hipFuncSetAttribute((const void*)k_query_block<3, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, big_lds);
+      (void)hipFuncSetAttribute((const void*)k_query_block<4, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, big_lds);
+      (void)hipFuncSetAttribute((const void*)k_query_block<4, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, big_lds);
+      (void)hipFuncSetAttribute((const void*)k_query_block<4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, big_lds);
       (void)hipFuncSetAttribute((const void*)k_query_layer<4, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, big_lds);
       (void)hipFuncSetAttribute((const void*)k_query_layer<4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, big_lds);
       (void)hipFuncSetAttribute((const void*)k_s2c_attn_wide<4>, hipFuncAttributeMaxDynamicSharedMemorySize, big_lds);
@@ -2651,10 +2774,10 @@ static int run_decoder(const a3d_decoder_weights* w, Prepared* P, int ns, hipStr
     A3D_HIP_CHECK(hipMemcpyAsync(samples_dev, hd, sizeof(DecSampleDev) * ns, hipMemcpyHostToDevice, st));
     QuerySample hq[kMaxBatchSamples];
     unsigned* sync0 = (unsigned*)(P[0].ws + P[0].L.sync);
-    A3D_HIP_CHECK(hipMemsetAsync(sync0, 0, (size_t)ns * A3D_MAX_DEC_LAYERS * 16 * 4, st));
+    A3D_HIP_CHECK(hipMemsetAsync(sync0, 0, (size_t)ns * A3D_MAX_DEC_LAYERS * kMaxQBlocks * 16 * 4, st));
     for (int si = 0; si < ns; ++si) {
       Prepared& p = P[si];
-      p.B.sync = sync0 + (size_t)si * A3D_MAX_DEC_LAYERS * 16;
+      p.B.sync = sync0 + (size_t)si * A3D_MAX_DEC_LAYERS * kMaxQBlocks * 16;
       hq[si].meta = p.meta;
       hq[si].B = p.B;
       hq[si].feats = p.feats;
@@ -2730,25 +2853,29 @@ static int run_decoder(const a3d_decoder_weights* w, Prepared* P, int ns, hipStr
       ProfScope ps(st, A3D_PROF_QUERY, 0, 0, 0, 0, nq_max);
       k_c2s_combine<<<dim3(nq_max * H, ns), 64, 0, st>>>(qs_dev, P[0].L.qp);
       const size_t ql_lds = (size_t)4 * QP * kQLD * 4;
-      if (nblk == 1) {
-        // FFN helper workgroups next to the layer's workgroup (A3D_QL_HELPERS = total workgroups per sample, 1 = none)
-        static int nh_env = -1;
-        if (nh_env < 0) {
-          const char* e = getenv("A3D_QL_HELPERS");
-          nh_env = e ? atoi(e) : kQlMaxHelpers;
-          nh_env = nh_env < 1 ? 1 : nh_env > kQlMaxHelpers ? kQlMaxHelpers : nh_env;
+      // FFN helper workgroups next to a block's workgroup (A3D_QL_HELPERS = total workgroups per block, 1 = none)
+      static int nh_env = -1, v1 = -1;   // A3D_QL_V1=1: the first build of the layer kernel (A/B switch)
+      if (nh_env < 0) {
+        const char* e = getenv("A3D_QL_HELPERS");
+        nh_env = e ? atoi(e) : kQlMaxHelpers;
+        nh_env = nh_env < 1 ? 1 : nh_env > kQlMaxHelpers ? kQlMaxHelpers : nh_env;
+        e = getenv("A3D_QL_V1");
+        v1 = e ? atoi(e) : 0;
+      }
+      const bool have_packs = QW.qpack && QW.mpack && (QW.next_qpack || !QW.next_c2s_in_wt);
+      const size_t qb_lds = ql_lds + (size_t)kQVec * 4;
+      if (v1 || !have_packs) {   // torch-layout weights
+        if (nblk == 1) {
+          k_query_layer<QT, 0><<<dim3(nh_env, ns), 512, ql_lds, st>>>(qs_dev, QW);
+        } else {
+          k_query_layer<QT, 1><<<dim3(nblk, ns), 512, ql_lds, st>>>(qs_dev, QW);
+          k_query_layer<QT, 2><<<dim3(nblk, ns), 512, ql_lds, st>>>(qs_dev, QW);
         }
-        static int v1 = -1;   // A3D_QL_V1=1: the first build of the single-block layer (A/B switch)
-        if (v1 < 0) {
-          const char* e = getenv("A3D_QL_V1");
-          v1 = e ? atoi(e) : 0;
-        }
-        const bool have_packs = QW.qpack && QW.mpack && (QW.next_qpack || !QW.next_c2s_in_wt);
-        if (v1 || !have_packs) k_query_layer<QT, 0><<<dim3(nh_env, ns), 512, ql_lds, st>>>(qs_dev, QW);
-        else k_query_block<QT><<<dim3(nh_env, ns), 512, ql_lds + (size_t)kQVec * 4, st>>>(qs_dev, QW);
-      } else {
-        k_query_layer<QT, 1><<<dim3(nblk, ns), 512, ql_lds, st>>>(qs_dev, QW);
-        k_query_layer<QT, 2><<<dim3(nblk, ns), 512, ql_lds, st>>>(qs_dev, QW);
+      } else if (nblk == 1) {
+        k_query_block<QT, 0><<<dim3(nh_env, 1, ns), 512, qb_lds, st>>>(qs_dev, QW);
+      } else if constexpr (QT == 4) {
+        k_query_block<4, 1><<<dim3(1, nblk, ns), 512, qb_lds, st>>>(qs_dev, QW);
+        k_query_block<4, 2><<<dim3(nh_env, nblk, ns), 512, qb_lds, st>>>(qs_dev, QW);
       }
     }
     A3D_LAUNCH_CHECK();

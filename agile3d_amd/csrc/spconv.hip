@@ -1393,6 +1393,44 @@ extern "C" int a3d_pack_conv_weight(const float* w_dev, int kernel_volume, int c
   return A3D_OK;
 }
 
+// every job's pack in one launch: a workgroup takes one 4096-element chunk, its job found by binary search (as optim.hip)
+__global__ void __launch_bounds__(256) k_pack_weight_multi(const a3d_pack_job* __restrict__ tab, int nj) {
+  int lo = 0, hi = nj;
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (tab[mid].chunk0 <= (int)blockIdx.x) lo = mid; else hi = mid;
+  }
+  const a3d_pack_job jb = tab[lo];
+  const size_t total = (size_t)jb.K * jb.cin * jb.cout;
+  const size_t base = (size_t)((int)blockIdx.x - jb.chunk0) * A3D_MT_CHUNK;
+  const int cout16 = jb.cout >> 4, cin16 = jb.cin >> 4;
+  for (int i = threadIdx.x; i < A3D_MT_CHUNK; i += 256) {
+    const size_t e = base + i;
+    if (e >= total) break;
+    const int t = (int)(e & 3), lane = (int)((e >> 2) & 63);
+    size_t rest = e >> 8;
+    const int ct = (int)(rest % cout16);
+    rest /= cout16;
+    const int S = (int)(rest % cin16);
+    const int k = (int)(rest / cin16);
+    const int ci = 16 * S + 4 * (lane >> 4) + t, co = 16 * ct + (lane & 15);
+    size_t si;
+    if (jb.transposed) si = ((size_t)(jb.flip ? jb.K - 1 - k : k) * jb.src_cin + jb.c0 + co) * jb.src_cout + ci;
+    else si = ((size_t)k * jb.src_cin + ci) * jb.src_cout + co;
+    jb.dst[e] = jb.src[si];
+  }
+}
+
+extern "C" int a3d_pack_conv_weights_multi(const a3d_pack_job* table_dev, int n_jobs, int64_t n_chunks, void* stream) {
+  if (!table_dev || n_jobs < 1 || n_chunks < 1 || n_chunks > (int64_t)1 << 30) {
+    set_error("a3d_pack_conv_weights_multi: bad arguments");
+    return A3D_ERR_INVALID;
+  }
+  k_pack_weight_multi<<<(unsigned)n_chunks, 256, 0, (hipStream_t)stream>>>(table_dev, n_jobs);
+  A3D_LAUNCH_CHECK();
+  return A3D_OK;
+}
+
 extern "C" size_t a3d_conv_weight_packed_floats(int kernel_volume, int cin, int cout) {
   const size_t total = (size_t)kernel_volume * cin * cout;
   return conv_emu(kernel_volume, cin, cout) ? total + total / 2 : total;   // three bf16 planes = 1.5 floats per weight

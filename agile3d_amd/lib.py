@@ -54,6 +54,13 @@ class DecoderWeights(C.Structure):
                 ("gauss_B", C.c_void_p), ("time_table", C.c_void_p), ("mask_pack", C.c_void_p)]
 
 
+class PackJob(C.Structure):
+    """a3d_pack_job: one weight of a3d_pack_conv_weights_multi."""
+    _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("K", C.c_int32), ("cin", C.c_int32), ("cout", C.c_int32),
+                ("src_cin", C.c_int32), ("src_cout", C.c_int32), ("transposed", C.c_int32), ("flip", C.c_int32),
+                ("c0", C.c_int32), ("chunk0", C.c_int32), ("pad_", C.c_int32)]
+
+
 class ProfEntry(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("id", "bn", "kernel_volume", "cin", "cout", "n_out", "table", "level",
                                          "ksplit")] + [("ms", C.c_float)]
@@ -97,6 +104,7 @@ SYMBOLS = {
     "a3d_scene_table": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]),
     "a3d_pack_conv_weight": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "a3d_conv_weight_packed_floats": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
+    "a3d_pack_conv_weights_multi": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_void_p]),
     "a3d_program_workspace_bytes": (C.c_size_t, [C.c_void_p, C.POINTER(BufDesc), C.c_int, C.POINTER(Op), C.c_int]),
     "a3d_program_buffer_offset": (C.c_size_t, [C.c_void_p, C.POINTER(BufDesc), C.c_int, C.c_int]),
     "a3d_program_run": (C.c_int, [C.c_void_p, C.POINTER(BufDesc), C.c_int, C.POINTER(Op), C.c_int, C.c_void_p,

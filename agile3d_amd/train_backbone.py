@@ -44,24 +44,76 @@ class PackedWeights:
     """Both orientations of every sparse-conv kernel in the MFMA fragment order, packed once per weight version: the
     forward weight and the slices of the input-gradient conv's W' (backward.packed_input_grad_weights).  A tape asks
     ``get(conv)``; entries are refreshed when the parameter tensor was written (torch bumps ``_version``), after a step of
-    the library's own AdamW (it writes through raw pointers and bumps ``optim.WEIGHT_EPOCH``) or after ``invalidate()``."""
+    the library's own AdamW (it writes through raw pointers and bumps ``optim.WEIGHT_EPOCH``) or after ``invalidate()``.
+
+    ``refresh_all()`` (called when a tape starts) repacks EVERY known entry that went stale with one launch of
+    ``a3d_pack_conv_weights_multi`` into the buffers the entries already own: after an optimiser step that is all of them
+    -- one launch instead of ~230 packs plus the transposes / flips / slice copies that fed them."""
 
     def __init__(self):
-        self._c = {}
+        self._c = {}             # id(param) -> [version, packed forward, input-grad parts, conv, kind]
         self.epoch = 0
+        self._table = None       # (device job table, n_jobs, n_chunks, signature)
 
     def invalidate(self):
         self.epoch += 1
 
-    def get(self, conv, kind):
+    def _version(self, conv):
         from .optim import WEIGHT_EPOCH
+        return (int(conv.kernel._version), self.epoch, WEIGHT_EPOCH[0], conv.kernel.data_ptr())
+
+    def get(self, conv, kind):
         key = id(conv.kernel)
-        ver = (int(conv.kernel._version), self.epoch, WEIGHT_EPOCH[0], conv.kernel.data_ptr())
+        ver = self._version(conv)
         hit = self._c.get(key)
         if hit is None or hit[0] != ver:
             w = conv.kernel3().detach().contiguous()
-            hit = self._c[key] = (ver, B.pack_weight(w), B.packed_input_grad_weights(kind, w))
+            hit = self._c[key] = [ver, B.pack_weight(w), B.packed_input_grad_weights(kind, w), conv, kind]
+            self._table = None
         return hit[1], hit[2]
+
+    def _build_table(self):
+        import numpy as np
+        lib = L.load()
+        dt = np.dtype([("src", "<u8"), ("dst", "<u8"), ("K", "<i4"), ("cin", "<i4"), ("cout", "<i4"), ("src_cin", "<i4"),
+                       ("src_cout", "<i4"), ("transposed", "<i4"), ("flip", "<i4"), ("c0", "<i4"), ("chunk0", "<i4"),
+                       ("pad", "<i4")])
+        assert dt.itemsize == 56
+        rows, chunk, sig, dev = [], 0, [], None
+        for key, (ver, wf, parts, conv, kind) in self._c.items():
+            w = conv.kernel3().detach()
+            K, cin, cout = w.shape
+            if not w.is_contiguous() or lib.a3d_conv_weight_packed_floats(K, cin, cout) != K * cin * cout:
+                return None          # a weight the one-launch pack does not cover (emulated-fp32 build, strided view)
+            dev = w.device
+            jobs = [(w.data_ptr(), wf.data_ptr(), K, cin, cout, cin, cout, 0, 0, 0)]
+            for c0, width, pk in parts:
+                if lib.a3d_conv_weight_packed_floats(K, cout, width) != K * cout * width:
+                    return None
+                jobs.append((w.data_ptr(), pk.data_ptr(), K, cout, width, cin, cout, 1, 1 if kind == L.OP_CONV3 else 0, c0))
+            for j in jobs:
+                rows.append(j + (chunk, 0))
+                chunk += (j[2] * j[3] * j[4] + 4095) // 4096
+            sig.append((key, w.data_ptr()))
+        if not rows:
+            return None
+        tab = np.array(rows, dtype=dt)
+        return (torch.from_numpy(tab.view(np.uint8)).to(dev), len(rows), chunk, tuple(sig))
+
+    def refresh_all(self):
+        stale = [h for h in self._c.values() if h[0] != self._version(h[3])]
+        if not stale:
+            return
+        sig = tuple((k, h[3].kernel3().data_ptr()) for k, h in self._c.items())
+        if self._table is None or self._table[3] != sig:
+            self._table = self._build_table()
+        if self._table is None:
+            return                   # get() repacks entry by entry
+        tab, n_jobs, n_chunks, _ = self._table
+        L.check(L.load().a3d_pack_conv_weights_multi(tab.data_ptr(), n_jobs, n_chunks, B._stream()),
+                "a3d_pack_conv_weights_multi")
+        for h in self._c.values():
+            h[0] = self._version(h[3])
 
 
 def packed_weights_of(model) -> PackedWeights:
@@ -112,6 +164,7 @@ class BackboneTape:
         self.grads = {}
         self._names = {id(p): n for n, p in model.named_parameters()}
         self.packed = packed_weights_of(model)
+        self.packed.refresh_all()
         self._bns = []           # the BatchNorms this forward pass ran through (running statistics updated in place)
         self._forward()
         # the kernels wrote running_mean / running_var through raw device pointers: torch's version counters did not

@@ -345,6 +345,25 @@ int    a3d_sum_squares_multi(const a3d_mt_tensor* table_dev, int n_tensors, int6
 int    a3d_adamw_step_multi(const a3d_mt_tensor* table_dev, int n_tensors, int64_t n_chunks, float lr, float beta1,
                             float beta2, float eps, float weight_decay, float grad_scale, void* stream);
 
+/* Many conv weights packed by ONE launch (a training iteration repacks both orientations of every sparse-conv kernel
+ * after the optimiser step: ~230 a3d_pack_conv_weight calls plus the transposes / flips / slices feeding them).  Job i
+ * writes the packed [K][cin][cout] weight to dst, reading
+ *   transposed = 0:  W[k][ci][co]      = src[k][ci][co]                         (src is [K][cin][cout])
+ *   transposed = 1:  W[k][ci][co]      = src[flip ? K-1-k : k][c0 + co][ci]     (src is [K][src_cin][cin]: the weight of
+ *                                        the input-gradient conv, output channels = the slice [c0, c0 + cout) of src's inputs)
+ * chunk0 = number of A3D_MT_CHUNK-element chunks of the jobs before it (as a3d_mt_tensor).  Exact-fp32 packs only
+ * (a3d_conv_weight_packed_floats(K, cin, cout) == K * cin * cout). */
+typedef struct a3d_pack_job {
+  const float* src;
+  float* dst;
+  int32_t K, cin, cout;
+  int32_t src_cin, src_cout;
+  int32_t transposed, flip, c0;
+  int32_t chunk0;
+  int32_t pad_;
+} a3d_pack_job;
+int a3d_pack_conv_weights_multi(const a3d_pack_job* table_dev, int n_jobs, int64_t n_chunks, void* stream);
+
 /* Dense row-major GEMM: out[n][cout] = act(((in (+ in_add))[n][cin] @ W) * scale + shift + res).
  * Replaces the nn.Linear / in_proj pieces of nn.MultiheadAttention that run over all N points
  * (models/modules/attention_block.py:91-94; `in_add` is the position encoding the reference adds to

@@ -306,6 +306,22 @@ def test_backbone_trains_with_clip_and_adamw():
         norm, coef = clip_grad_norm_(grads, 0.1)
         assert np.isfinite(norm) and 0.0 < coef <= 1.0
         opt.step(grads, coef)
+        if step == 2:
+            # after an optimiser step every packed weight is stale: the next tape repacks all of them with ONE launch
+            # (a3d_pack_conv_weights_multi) into the buffers they already own -- the same bits as packing weight by weight
+            from agile3d_amd import backward as B
+            from agile3d_amd.train_backbone import packed_weights_of
+            pw = packed_weights_of(model)
+            ptrs = {k: h[1].data_ptr() for k, h in pw._c.items()}
+            pw.refresh_all()
+            assert pw._table is not None and pw._table[1] > len(pw._c) and len(pw._c) >= 40
+            for k, (ver, wf, parts, conv, kind) in pw._c.items():
+                w = conv.kernel3().detach().contiguous()
+                assert wf.data_ptr() == ptrs[k] and ver == pw._version(conv)
+                assert torch.equal(wf, B.pack_weight(w)), k
+                fresh = B.packed_input_grad_weights(kind, w)
+                assert [(a, b) for a, b, _ in fresh] == [(a, b) for a, b, _ in parts]
+                assert all(torch.equal(x[2], y[2]) for x, y in zip(fresh, parts)), k
     print("losses", [round(v, 4) for v in losses])
     assert all(np.isfinite(losses)) and losses[-1] < 0.9 * losses[0], losses
 

@@ -110,10 +110,18 @@ def step_time(voxels, batch):
          tuple(f"scene{i:04d}_00" for i in range(batch)), tuple(0 for _ in scenes))
     opt = AdamW(model.named_parameters(), lr=1e-4, weight_decay=1e-4)
     np.random.seed(1), random.seed(1)
+    prof_it = int(os.environ.get("A3D_BB_CPROFILE", "-1"))     # host profile (cProfile) of this iteration, top 45 by cumulative time
     for it in range(int(os.environ.get("A3D_BB_ITERS", "4"))):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        st = train_one_step(model, crit, opt, b, torch.device("cuda"), 0.1)
+        if it == prof_it:
+            import cProfile
+            import pstats
+            pr = cProfile.Profile()
+            st = pr.runcall(train_one_step, model, crit, opt, b, torch.device("cuda"), 0.1)
+            pstats.Stats(pr).sort_stats("cumulative").print_stats(45)
+        else:
+            st = train_one_step(model, crit, opt, b, torch.device("cuda"), 0.1)
         torch.cuda.synchronize()
         ms = torch.cuda.memory_stats()
         print(f"training iteration {it}: {1e3 * (time.perf_counter() - t0):.0f} ms, loss {st['loss']:.3f}, clicks {st['clicks']}, "
