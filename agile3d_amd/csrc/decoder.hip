@@ -305,7 +305,14 @@ __global__ void __launch_bounds__(512) k_kv_c2s(const DecSampleDev* __restrict__
                                                 const float* __restrict__ Wk, const float* __restrict__ Wv,
                                                 const float* __restrict__ bk, const float* __restrict__ bv) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int QP = QT * 16, LDQ = 132;
+  constexpr int QP = QT * 16;
+  // up to 32 queries: two waves share a sequence of point groups, four heads each (8 heads of flash state do not fit the
+  // register file).  48 / 64 queries double the state per head: four waves share a group, two heads each.  At 64 queries the
+  // projected queries get [64][128] rows with the float4 column XOR-ed by the row (conflict-free b128 reads without the
+  // 4-float pad) and the biases stay in registers: 128 KB of weights + 32 KB = exactly the 160 KB of LDS
+  constexpr int HW = QT <= 2 ? 4 : 2, WPG = H / HW, SPW = 8 / WPG;
+  constexpr bool SWZ = QT == 4;
+  constexpr int LDQ = SWZ ? 128 : 132;
   const DecSampleDev& sm = sample_of_wg(samples, ns);
   const int lb = blockIdx.x - sm.wg_begin, nwg = sm.wg_end - sm.wg_begin;
   const int n = sm.n, ngroups = (n + 15) / 16, qp_total = QP;
@@ -323,7 +330,7 @@ __global__ void __launch_bounds__(512) k_kv_c2s(const DecSampleDev* __restrict__
   float* bv_l = bk_l + D;                     // the point rows (vmcnt is in order: any other load would wait for them)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int g = lane >> 4, j = lane & 15;
-  const int slot = lb * 4 + (wave >> 1), nslots = nwg * 4;
+  const int slot = lb * SPW + wave / WPG, nslots = nwg * SPW;
   // rows of the first group: in flight behind the weight staging
   f32x4 xs[8], pe[8];
   unsigned lab_nx = 0u;
@@ -350,10 +357,10 @@ __global__ void __launch_bounds__(512) k_kv_c2s(const DecSampleDev* __restrict__
     }
   }
   for (int e = threadIdx.x; e < QP * 32; e += 512) {
-    const int r = e >> 5, c4 = (e & 31) * 4;
-    *(f32x4*)(qp_l + r * LDQ + c4) = gld4(qproj + (size_t)r * D + c4);
+    const int r = e >> 5, c = e & 31;
+    *(f32x4*)(qp_l + r * LDQ + (SWZ ? (c ^ (r & 15)) : c) * 4) = gld4(qproj + (size_t)r * D + c * 4);
   }
-  if (threadIdx.x < D) {
+  if (!SWZ && threadIdx.x < D) {
     bk_l[threadIdx.x] = bk[threadIdx.x];
     bv_l[threadIdx.x] = bv[threadIdx.x];
   }
@@ -365,10 +372,19 @@ __global__ void __launch_bounds__(512) k_kv_c2s(const DecSampleDev* __restrict__
     qmask[qt] = labels != nullptr && obj[qt] >= 0 && gld(counts + obj[qt]) > 0;
   }
   __syncthreads();
-  // two waves share a sequence of point groups: wave 2s takes heads 0..3 of it, wave 2s+1 heads 4..7 (the flash
-  // state of 8 heads does not fit the register file next to the activation fragments)
-  constexpr int HW = H / 2;
-  const int h0 = (wave & 1) * HW;
+  // WPG waves share a sequence of point groups, HW heads each
+  const int h0 = (wave % WPG) * HW;
+  f32x4 bkr[HW];
+  float bvr[HW];
+#pragma unroll
+  for (int hl = 0; hl < HW; ++hl) {
+    bkr[hl] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    bvr[hl] = 0.f;
+    if constexpr (SWZ) {
+      bkr[hl] = *(const f32x4*)(bk + 16 * (h0 + hl) + 4 * g);
+      bvr[hl] = bv[16 * (h0 + hl) + j];
+    }
+  }
   float m[HW][QT], l[HW][QT];
   f32x4 acc[HW][QT];
 #pragma unroll
@@ -394,8 +410,8 @@ __global__ void __launch_bounds__(512) k_kv_c2s(const DecSampleDev* __restrict__
     f32x4 kf[HW], vv[HW];
 #pragma unroll
     for (int hl = 0; hl < HW; ++hl) {
-      kf[hl] = *(const f32x4*)(bk_l + 16 * (h0 + hl) + 4 * g);
-      const float bvj = bv_l[16 * (h0 + hl) + j];
+      kf[hl] = SWZ ? bkr[hl] : *(const f32x4*)(bk_l + 16 * (h0 + hl) + 4 * g);
+      const float bvj = SWZ ? bvr[hl] : bv_l[16 * (h0 + hl) + j];
       vv[hl] = (f32x4){bvj, bvj, bvj, bvj};
     }
     {
@@ -429,7 +445,11 @@ __global__ void __launch_bounds__(512) k_kv_c2s(const DecSampleDev* __restrict__
       }
     }
     // ---- attention of the 16 points against every query, flash-style running state per (head, query tile)
-    f32x4 qf_n = *(const f32x4*)(qp_l + j * LDQ + h0 * DH + 4 * g);   // the next tile's fragment, one tile ahead
+    auto qfrag = [&](int qt, int h) {   // projected queries [16 qt + j][16 h + 4 g ..+3]
+      const int c = 4 * h + g;
+      return *(const f32x4*)(qp_l + (qt * 16 + j) * LDQ + (SWZ ? (c ^ j) : c) * 4);
+    };
+    f32x4 qf_n = qfrag(0, h0);   // the next tile's fragment, one tile ahead
 #pragma unroll
     for (int hl = 0; hl < HW; ++hl) {
       const int h = h0 + hl;
@@ -438,7 +458,7 @@ __global__ void __launch_bounds__(512) k_kv_c2s(const DecSampleDev* __restrict__
         const f32x4 qf = qf_n;
         {
           const int i2 = hl * QT + qt + 1;
-          if (i2 < HW * QT) qf_n = *(const f32x4*)(qp_l + ((i2 % QT) * 16 + j) * LDQ + (h0 + i2 / QT) * DH + 4 * g);
+          if (i2 < HW * QT) qf_n = qfrag(i2 % QT, h0 + i2 / QT);
         }
         f32x4 sc4 = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -2689,6 +2709,8 @@ static int run_decoder(const a3d_decoder_weights* w, Prepared* P, int ns, hipStr
       (void)hipFuncSetAttribute((const void*)k_s2c_out<2>, hipFuncAttributeMaxDynamicSharedMemorySize, big_lds);
       (void)hipFuncSetAttribute((const void*)k_kv_c2s<1>, hipFuncAttributeMaxDynamicSharedMemorySize, big_lds);
       (void)hipFuncSetAttribute((const void*)k_kv_c2s<2>, hipFuncAttributeMaxDynamicSharedMemorySize, big_lds);
+      (void)hipFuncSetAttribute((const void*)k_kv_c2s<3>, hipFuncAttributeMaxDynamicSharedMemorySize, big_lds);
+      (void)hipFuncSetAttribute((const void*)k_kv_c2s<4>, hipFuncAttributeMaxDynamicSharedMemorySize, big_lds);
       (void)hipFuncSetAttribute((const void*)k_ln_mask<4>, hipFuncAttributeMaxDynamicSharedMemorySize, big_lds);
     }
   }
@@ -2715,7 +2737,8 @@ static int run_decoder(const a3d_decoder_weights* w, Prepared* P, int ns, hipStr
     }
   }
   // which of the wide phases run as one fused launch for the batch
-  const bool fuse_c2s = fused_c2s() && QT <= 2;
+  const bool fuse_c2s = fused_c2s() && nblk == 1;   // up to 64 queries (k_kv_c2s<1..4>)
+  constexpr int c2s_spw = QT <= 2 ? 4 : 2;           // point groups in flight per workgroup = flash partials per workgroup
   const bool fuse_s2c = fused_c2s() && nblk == 1;
   const bool fuse_out = fuse_s2c && fused_lds <= 160 * 1024;
   // scene-to-click + output projection + LayerNorm + mask head as ONE kernel when both packed weight matrices and the
@@ -2784,7 +2807,7 @@ static int run_decoder(const a3d_decoder_weights* w, Prepared* P, int ns, hipStr
       hq[si].posenc = p.posenc;
       hq[si].counts = p.counts;
       hq[si].part = p.part;
-      hq[si].n_part = fuse_c2s ? (p.wg_end - p.wg_begin) * 4 : p.L.nchunk;
+      hq[si].n_part = fuse_c2s ? (p.wg_end - p.wg_begin) * c2s_spw : p.L.nchunk;
     }
     A3D_HIP_CHECK(hipMemcpyAsync(qs_dev, hq, sizeof(QuerySample) * ns, hipMemcpyHostToDevice, st));
   }
@@ -2801,8 +2824,9 @@ static int run_decoder(const a3d_decoder_weights* w, Prepared* P, int ns, hipStr
     if (fuse_c2s) {
       // K / V projections fused in (K, V never reach HBM), all samples in one launch
       ProfScope ps(st, A3D_PROF_C2S, 0, 0, 0, 0, (int)n_total);
-      k_kv_c2s<(QT <= 2 ? QT : 1)><<<grid, 512, 128 * 1024 + ((size_t)(QT <= 2 ? QT : 1) * 16 * 132 + 2 * D) * 4, st>>>(
-          samples_dev, ns, l, LW.c2s_wk_packed, LW.c2s_wv_packed, LW.c2s_in_b + D, LW.c2s_in_b + 2 * D);
+      const size_t c2s_lds = (size_t)128 * 1024 + (QT == 4 ? (size_t)QP * 128 * 4 : ((size_t)QP * 132 + 2 * D) * 4);
+      k_kv_c2s<QT><<<grid, 512, c2s_lds, st>>>(samples_dev, ns, l, LW.c2s_wk_packed, LW.c2s_wv_packed, LW.c2s_in_b + D,
+                                               LW.c2s_in_b + 2 * D);
       A3D_LAUNCH_CHECK();
     } else {
       for (int si = 0; si < ns; ++si) {

@@ -119,7 +119,9 @@ def step_time(voxels, batch):
             import pstats
             pr = cProfile.Profile()
             st = pr.runcall(train_one_step, model, crit, opt, b, torch.device("cuda"), 0.1)
-            pstats.Stats(pr).sort_stats("cumulative").print_stats(45)
+            ps_ = pstats.Stats(pr).sort_stats("cumulative")
+            ps_.print_stats(45)
+            ps_.print_callers("torch.empty|method 'to' of|torch.tensor|torch.zeros")
         else:
             st = train_one_step(model, crit, opt, b, torch.device("cuda"), 0.1)
         torch.cuda.synchronize()
