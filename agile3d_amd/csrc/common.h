@@ -64,7 +64,7 @@ size_t radix_sort_temp_bytes(int n_max);
 // stable, ascending in the listed digits; digits that are constant over the input are skipped on the device;
 // keys_in / vals_in are only read, temp must be 256-byte aligned
 int radix_sort_pairs(void* temp, size_t temp_bytes, const uint64_t* keys_in, uint64_t* keys_out, const int* vals_in,
-                     int* vals_out, int n, const RadixPass* passes, int npass, hipStream_t st);
+                     int* vals_out, int n, const RadixPass* passes, int npass, hipStream_t st, int* fail_dev = nullptr);
 
 // a_incl = inclusive prefix sums of a, b_excl = exclusive prefix sums of b (radix.hip; in place allowed)
 size_t scan2_temp_bytes(int64_t n);

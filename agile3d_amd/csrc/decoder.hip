@@ -1628,14 +1628,18 @@ __global__ void __launch_bounds__(512) k_query_layer(const QuerySample* __restri
       if (hx >= nchunk) return;
       unsigned* flags = B.sync + W.layer * 16;
       qload_w(W.ffn_w1t, D, hx * 128 + 16 * wave, 0, wfa);            // first chunk's weights while waiting
+      int late = 0;   // a wait that gives up (seconds: never in a healthy run) turns what this workgroup hands on into NaN
       if (tid == 0) {
         unsigned spins = 0;
         while (gld_agent(flags) == 0u) {
           __builtin_amdgcn_s_sleep(2);
-          if (++spins > (1u << 26)) break;                             // seconds: never in a healthy run
+          if (++spins > (1u << 26)) {
+            late = 1;
+            break;
+          }
         }
       }
-      __syncthreads();
+      const float bad = __syncthreads_or(late) ? __builtin_nanf("") : 0.f;
       for (int e = tid; e < QP * 128; e += nt) {
         const int q = e >> 7, c = e & 127;
         cur[q * kQLD + c] = gld_agent(B.tgt + (size_t)q * D + c);
@@ -1660,7 +1664,7 @@ __global__ void __launch_bounds__(512) k_query_layer(const QuerySample* __restri
         for (int qt = 0; qt < QT; ++qt)
 #pragma unroll
           for (int t = 0; t < 4; ++t)
-            gst_agent(part + (size_t)(qt * 16 + 4 * g + t) * D + 16 * wave + j, facc[qt][t]);
+            gst_agent(part + (size_t)(qt * 16 + 4 * g + t) * D + 16 * wave + j, facc[qt][t] + bad);
       }
       __builtin_amdgcn_s_waitcnt(0x0F70);
       __syncthreads();
@@ -1669,17 +1673,21 @@ __global__ void __launch_bounds__(512) k_query_layer(const QuerySample* __restri
       if (nh < 4 || nchunk < 4 || hx > 3 || (hx == 3 && !W.next_c2s_in_wt)) return;
       const float* wsrc = hx == 1 ? W.s2c_in_wt + (size_t)D * D : hx == 2 ? W.s2c_in_wt + (size_t)2 * D * D : W.next_c2s_in_wt;
       qload_w(wsrc, D, 16 * wave, 0, wfa);
+      late = 0;
       if (tid == 0) {
         unsigned spins = 0;
         while (gld_agent(flags + 8) == 0u) {
           __builtin_amdgcn_s_sleep(2);
-          if (++spins > (1u << 26)) break;
+          if (++spins > (1u << 26)) {
+            late = 1;
+            break;
+          }
         }
       }
-      __syncthreads();
+      const float bad2 = __syncthreads_or(late) ? __builtin_nanf("") : 0.f;
       for (int e = tid; e < QP * 128; e += nt) {
         const int q = e >> 7, c = e & 127;
-        float v = gld_agent(B.tgt + (size_t)q * D + c);
+        float v = gld_agent(B.tgt + (size_t)q * D + c) + bad2;
         if (hx != 2) v += q < Q ? gld(B.qpos + (size_t)q * D + c) : 0.f;   // keys / next query projection take queries + qpos
         xa[q * kQLD + c] = v;
       }
@@ -1849,14 +1857,21 @@ __global__ void __launch_bounds__(512) k_query_layer(const QuerySample* __restri
   }
   if (PART == 0 && nh > 1) {   // the helpers' partial sums, in helper order
     const int nhelp = min(nh, nchunk) - 1;
+    int late = 0;
     if (tid < nhelp) {
       unsigned spins = 0;
       while (gld_agent(B.sync + W.layer * 16 + 1 + tid) == 0u) {
         __builtin_amdgcn_s_sleep(2);
-        if (++spins > (1u << 26)) break;
+        if (++spins > (1u << 26)) {
+          late = 1;
+          break;
+        }
       }
     }
-    __syncthreads();
+    if (__syncthreads_or(late)) {
+#pragma unroll
+      for (int qt = 0; qt < QT; ++qt) facc[qt] += __builtin_nanf("");
+    }
     const int lane = tid & 63, g = lane >> 4, j = lane & 15;
     for (int h = 1; h <= nhelp; ++h) {
       const float* part = B.hidden + (size_t)h * QP * D;
@@ -2223,14 +2238,20 @@ __global__ void __launch_bounds__(512) k_query_block(const QuerySample* __restri
       qload_p(wsrc, 8, wave, 0, wfc);
       sb = gld(bsrc + 16 * wave + j);
     }
+    // a wait that gives up (seconds: never in a healthy run; the device must not hang) poisons what this workgroup hands
+    // on: the layer's result is then NaN, not a plausible number computed from data that never arrived
+    int late = 0;
     if (tid == 0) {
       unsigned spins = 0;
       while (gld_agent(flags) == 0u) {
         __builtin_amdgcn_s_sleep(1);
-        if (++spins > (1u << 26)) break;                             // seconds: never in a healthy run
+        if (++spins > (1u << 26)) {
+          late = 1;
+          break;
+        }
       }
     }
-    __syncthreads();
+    const float bad = __syncthreads_or(late) ? __builtin_nanf("") : 0.f;
     for (int e = tid; e < QP * 128; e += nt) {
       const int q = e >> 7, c = e & 127;
       cur[q * kQLD + c] = q < Q ? gld_agent(B.tgt + (size_t)q * D + c) : 0.f;
@@ -2257,21 +2278,25 @@ __global__ void __launch_bounds__(512) k_query_block(const QuerySample* __restri
 #pragma unroll
       for (int qt = 0; qt < QT; ++qt)
 #pragma unroll
-        for (int t = 0; t < 4; ++t) gst_agent(part + (size_t)(qt * 16 + 4 * g + t) * D + 16 * wave + j, facc[qt][t]);
+        for (int t = 0; t < 4; ++t) gst_agent(part + (size_t)(qt * 16 + 4 * g + t) * D + 16 * wave + j, facc[qt][t] + bad);
     }
     __builtin_amdgcn_s_waitcnt(0x0F70);
     __syncthreads();
     if (tid == 0) gst_agent(flags + hx, 1u);
     // ---- second job of helpers 1..3: one of the projections that depend only on the layer's new queries
     if (!second) return;
+    late = 0;
     if (tid == 0) {
       unsigned spins = 0;
       while (gld_agent(flags + 8) == 0u) {
         __builtin_amdgcn_s_sleep(1);
-        if (++spins > (1u << 26)) break;
+        if (++spins > (1u << 26)) {
+          late = 1;
+          break;
+        }
       }
     }
-    __syncthreads();
+    if (__syncthreads_or(late)) sb = __builtin_nanf("");
     for (int e = tid; e < QP * 128; e += nt) {
       const int q = e >> 7, c = e & 127;
       float v = 0.f;
@@ -2453,14 +2478,21 @@ __global__ void __launch_bounds__(512) k_query_block(const QuerySample* __restri
   }
   if (nh > 1) {   // the helpers' partial sums, in helper order
     const int nhelp = min(nh, nchunk) - 1;
+    int late = 0;
     if (tid < nhelp) {
       unsigned spins = 0;
       while (gld_agent(flags + 1 + tid) == 0u) {
         __builtin_amdgcn_s_sleep(1);
-        if (++spins > (1u << 26)) break;
+        if (++spins > (1u << 26)) {   // a helper that never reported: the layer's result is NaN, not a partial sum
+          late = 1;
+          break;
+        }
       }
     }
-    __syncthreads();
+    if (__syncthreads_or(late)) {
+#pragma unroll
+      for (int qt = 0; qt < QT; ++qt) facc[qt] += __builtin_nanf("");
+    }
     const int g = lane >> 4;
     for (int h = 1; h <= nhelp; ++h) {
       const float* part = B.hidden + (size_t)h * QP * D;

@@ -110,7 +110,7 @@ static int run_quantize(const T* xyz, int64_t n, double qs, int32_t* coords_out,
   {
     RadixPass ps[kRadixMaxPasses];
     const int np = radix_passes(0, 63, ps);   // digits the cloud's extent does not touch are skipped on the device
-    const int rc = radix_sort_pairs(w.temp, w.temp_bytes, w.keys_in, w.keys, w.vals_in, w.vals, (int)n, ps, np, st);
+    const int rc = radix_sort_pairs(w.temp, w.temp_bytes, w.keys_in, w.keys, w.vals_in, w.vals, (int)n, ps, np, st, w.flags);
     if (rc) return rc;
   }
   k_quant_heads<<<nb, 256, 0, st>>>(w.keys, w.vals, n, w.head, w.first);
@@ -126,6 +126,10 @@ static int run_quantize(const T* xyz, int64_t n, double qs, int32_t* coords_out,
   A3D_HIP_CHECK(hipMemcpyAsync(&host[0], w.flags, 4, hipMemcpyDeviceToHost, st));
   A3D_HIP_CHECK(hipMemcpyAsync(&host[1], w.seg + (n - 1), 4, hipMemcpyDeviceToHost, st));
   A3D_HIP_CHECK(hipStreamSynchronize(st));
+  if (host[0] < 0) {   // only the sort's look-back writes a negative code here
+    set_error("a3d_sparse_quantize: the device-side sort gave up waiting for a workgroup (starved queue?)");
+    return A3D_ERR_HIP;
+  }
   if (host[0]) {
     set_error("a3d_sparse_quantize: a coordinate is NaN/inf or its voxel index is outside +-2^20");
     return A3D_ERR_COORD_RANGE;

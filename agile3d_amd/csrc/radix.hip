@@ -40,6 +40,7 @@ struct RsArgs {
   RsPlanDev* plan;
   int* tickets;        // [npass]
   uint32_t* status;    // [npass][nblocks][256]  look-back words
+  int* fail;           // optional: receives A3D_ERR_HIP (atomicMin) when a look-back gives up waiting
 };
 
 __device__ __forceinline__ int rs_digit(uint64_t k, int shift, int bits, int shift2, int bits2) {
@@ -203,7 +204,10 @@ __global__ void __launch_bounds__(kRsThreads) k_rs_pass(const RsArgs a, int p) {
         unsigned spins = 0;
         while ((x[u] & (kFlagAgg | kFlagInc)) == 0u) {
           __builtin_amdgcn_s_sleep(1);
-          if (++spins > (1u << 26)) break;   // seconds: never in a healthy run (every workgroup publishes before it looks back); do not hang the device
+          if (++spins > (1u << 26)) {        // seconds: never in a healthy run (every workgroup publishes before it looks back);
+            if (a.fail) atomicMin(a.fail, A3D_ERR_HIP);   // do not hang the device, and say that the result is not a sort
+            break;
+          }
           x[u] = __hip_atomic_load(a.status + ((size_t)p * a.nblocks + (pb - u)) * 256 + d, __ATOMIC_RELAXED,
                                    __HIP_MEMORY_SCOPE_AGENT);
         }
@@ -258,7 +262,7 @@ size_t radix_sort_temp_bytes(int n_max) {
 }
 
 int radix_sort_pairs(void* temp, size_t temp_bytes, const uint64_t* keys_in, uint64_t* keys_out, const int* vals_in,
-                     int* vals_out, int n, const RadixPass* passes, int npass, hipStream_t st) {
+                     int* vals_out, int n, const RadixPass* passes, int npass, hipStream_t st, int* fail_dev) {
   if (n <= 0) return A3D_OK;
   if (npass < 1 || npass > kRadixMaxPasses || !temp || ((uintptr_t)temp & 255) || temp_bytes < radix_sort_temp_bytes(n)) {
     set_error("radix_sort_pairs: bad arguments (n=%d, passes=%d, temp=%zu)", n, npass, temp_bytes);
@@ -273,6 +277,7 @@ int radix_sort_pairs(void* temp, size_t temp_bytes, const uint64_t* keys_in, uin
   a.n = n;
   a.npass = npass;
   a.nblocks = rs_blocks(n);
+  a.fail = fail_dev;
   for (int p = 0; p < npass; ++p) {
     if (passes[p].bits < 1 || passes[p].bits2 < 0 || passes[p].bits + passes[p].bits2 > 8 || passes[p].shift < 0 ||
         passes[p].shift + passes[p].bits > 64 || passes[p].shift2 < 0 || passes[p].shift2 + passes[p].bits2 > 64) {

@@ -693,7 +693,8 @@ extern "C" int a3d_scene_create(const int32_t* coords4_dev, int64_t n_voxels, vo
   {   // all 64 key bits: the digits the batch's extent does not touch are skipped on the device
     RadixPass ps[kRadixMaxPasses];
     const int np = radix_passes(0, 64, ps);
-    int rc = radix_sort_pairs(p.sort_temp, p.sort_temp_bytes, p.keys_in, p.keys[0], p.vals_in, p.vals_sorted, n0, ps, np, st);
+    int rc = radix_sort_pairs(p.sort_temp, p.sort_temp_bytes, p.keys_in, p.keys[0], p.vals_in, p.vals_sorted, n0, ps, np, st,
+                              p.sizes_dev + 5);   // a look-back that gives up reports A3D_ERR_HIP through the error word read below
     if (rc) return rc;
   }
   k_check_dups<<<nblk(n0, T), T, 0, st>>>(p.keys[0], n0, p.sizes_dev);
@@ -716,6 +717,7 @@ extern "C" int a3d_scene_create(const int32_t* coords4_dev, int64_t n_voxels, vo
   if (sizes[5] != 0) {
     set_error(sizes[5] == A3D_ERR_DUPLICATE     ? "a3d_scene_create: duplicate voxel coordinates"
               : sizes[5] == A3D_ERR_COORD_RANGE ? "a3d_scene_create: coordinate out of range"
+              : sizes[5] == A3D_ERR_HIP         ? "a3d_scene_create: the device-side sort gave up waiting for a workgroup (starved queue?)"
                                                 : "a3d_scene_create: rows of a batch sample are not contiguous");
     return sizes[5];
   }

@@ -27,4 +27,13 @@ python $R/bench.py --voxels 300000 --clicks-per-object 4 --batch 1 --streams 2 -
 LT_BATCH=1 LT_VOXELS=300000 LT_CPO=4 python $R/tools/layer_table.py > $OUT/layer_table_config5.txt 2>&1
 LT_BATCH=4 python $R/tools/layer_table.py > $OUT/layer_table_4scenes.txt 2>&1
 LT_BATCH=1 python $R/tools/layer_table.py > $OUT/layer_table_1scene.txt 2>&1
+LT_BATCH=16 python $R/tools/layer_table.py > $OUT/layer_table_16scenes.txt 2>&1
+# decoder pass by query count (5 objects x LT_CPO clicks + 10 learned queries; one 80 k scene)
+for CPO in 5 10 15 30; do
+  echo "== clicks per object $CPO" >> $OUT/decoder_by_queries.txt
+  LT_CPO=$CPO LT_BATCH=1 python $R/tools/layer_table.py 2>&1 | awk '/posenc/{p=1} p' >> $OUT/decoder_by_queries.txt
+done
+# training iterations (4 x 80 k voxels, the real train_one_step): phase times, then plain wall clock
+A3D_BB_ITERS=10 A3D_TRAIN_TIMING=1 python $R/tools/backward_bench.py --step --reps 1 2>&1 | grep -E "training iteration|train_one_step" > $OUT/training_iterations.txt
+A3D_BB_ITERS=10 python $R/tools/backward_bench.py --step --reps 1 2>&1 | grep -E "training iteration" >> $OUT/training_iterations.txt
 ls -la $OUT
