@@ -36,6 +36,15 @@ template <typename T>
 __device__ __forceinline__ void gst(T* p, T v) { *(T A3D_GLOBAL*)p = v; }
 __device__ __forceinline__ f32x4 gld4(const float* p) { return *(const f32x4 A3D_GLOBAL*)p; }
 __device__ __forceinline__ void gst4(float* p, f32x4 v) { *(f32x4 A3D_GLOBAL*)p = v; }
+// "did any thread see its wait give up": through one word of the kernel's own dynamic LDS (__syncthreads_or keeps a static
+// __shared__ word of its own, which the 160 KB kernels of this file cannot afford)
+__device__ __forceinline__ bool block_any(int pred, int* slot) {
+  if (threadIdx.x == 0) *slot = 0;
+  __syncthreads();
+  if (pred) *slot = 1;
+  __syncthreads();
+  return *(volatile int*)slot != 0;
+}
 // agent-scope (coherent across workgroups) relaxed accesses of the in-kernel hand-offs
 template <typename T>
 __device__ __forceinline__ T gld_agent(const T* p) {
@@ -1613,6 +1622,7 @@ __global__ void __launch_bounds__(512) k_query_layer(const QuerySample* __restri
   float* cur = qpos + QP * kQLD;         // queries -> tgt -> queries
   float* xa = cur + QP * kQLD;           // GEMM input staging
   float* xb = xa + QP * kQLD;            // GEMM output staging / FFN hidden chunk
+  int* any_slot = (int*)(xb + QP * kQLD);   // one word behind the tiles (block_any)
   const int Q = max(0, min(QP, Qall - q0));
   const int tid = threadIdx.x, nt = blockDim.x;
   const int wave = tid >> 6;
@@ -1639,7 +1649,7 @@ __global__ void __launch_bounds__(512) k_query_layer(const QuerySample* __restri
           }
         }
       }
-      const float bad = __syncthreads_or(late) ? __builtin_nanf("") : 0.f;
+      const float bad = block_any(late, any_slot) ? __builtin_nanf("") : 0.f;
       for (int e = tid; e < QP * 128; e += nt) {
         const int q = e >> 7, c = e & 127;
         cur[q * kQLD + c] = gld_agent(B.tgt + (size_t)q * D + c);
@@ -1684,7 +1694,7 @@ __global__ void __launch_bounds__(512) k_query_layer(const QuerySample* __restri
           }
         }
       }
-      const float bad2 = __syncthreads_or(late) ? __builtin_nanf("") : 0.f;
+      const float bad2 = block_any(late, any_slot) ? __builtin_nanf("") : 0.f;
       for (int e = tid; e < QP * 128; e += nt) {
         const int q = e >> 7, c = e & 127;
         float v = gld_agent(B.tgt + (size_t)q * D + c) + bad2;
@@ -1868,7 +1878,7 @@ __global__ void __launch_bounds__(512) k_query_layer(const QuerySample* __restri
         }
       }
     }
-    if (__syncthreads_or(late)) {
+    if (block_any(late, any_slot)) {
 #pragma unroll
       for (int qt = 0; qt < QT; ++qt) facc[qt] += __builtin_nanf("");
     }
@@ -2213,6 +2223,7 @@ __global__ void __launch_bounds__(512) k_query_block(const QuerySample* __restri
   float* xa = cur + QP * kQLD;           // GEMM input staging
   float* xb = xa + QP * kQLD;            // GEMM output staging / FFN hidden chunk
   float* vec_l = xb + QP * kQLD;         // [kQVec] biases and LayerNorm vectors
+  int* any_slot = (int*)(vec_l + kQVec);   // one word behind the table (block_any)
   const int tid = threadIdx.x, nt = 512;
   const int wave = tid >> 6, lane = tid & 63, j = lane & 15;
   const int nchunk = W.dim_ff >> 7;
@@ -2251,7 +2262,7 @@ __global__ void __launch_bounds__(512) k_query_block(const QuerySample* __restri
         }
       }
     }
-    const float bad = __syncthreads_or(late) ? __builtin_nanf("") : 0.f;
+    const float bad = block_any(late, any_slot) ? __builtin_nanf("") : 0.f;
     for (int e = tid; e < QP * 128; e += nt) {
       const int q = e >> 7, c = e & 127;
       cur[q * kQLD + c] = q < Q ? gld_agent(B.tgt + (size_t)q * D + c) : 0.f;
@@ -2296,7 +2307,7 @@ __global__ void __launch_bounds__(512) k_query_block(const QuerySample* __restri
         }
       }
     }
-    if (__syncthreads_or(late)) sb = __builtin_nanf("");
+    if (block_any(late, any_slot)) sb = __builtin_nanf("");
     for (int e = tid; e < QP * 128; e += nt) {
       const int q = e >> 7, c = e & 127;
       float v = 0.f;
@@ -2489,7 +2500,7 @@ __global__ void __launch_bounds__(512) k_query_block(const QuerySample* __restri
         }
       }
     }
-    if (__syncthreads_or(late)) {
+    if (block_any(late, any_slot)) {
 #pragma unroll
       for (int qt = 0; qt < QT; ++qt) facc[qt] += __builtin_nanf("");
     }
@@ -2908,7 +2919,7 @@ static int run_decoder(const a3d_decoder_weights* w, Prepared* P, int ns, hipStr
     {   // one workgroup (or chain of query blocks) per sample: blockIdx.y
       ProfScope ps(st, A3D_PROF_QUERY, 0, 0, 0, 0, nq_max);
       k_c2s_combine<<<dim3(nq_max * H, ns), 64, 0, st>>>(qs_dev, P[0].L.qp);
-      const size_t ql_lds = (size_t)4 * QP * kQLD * 4;
+      const size_t ql_lds = (size_t)4 * QP * kQLD * 4 + 16;   // four [QP][132] tiles + the word of block_any
       // FFN helper workgroups next to a block's workgroup (A3D_QL_HELPERS = total workgroups per block, 1 = none)
       static int nh_env = -1, v1 = -1;   // A3D_QL_V1=1: the first build of the layer kernel (A/B switch)
       if (nh_env < 0) {
