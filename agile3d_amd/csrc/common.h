@@ -60,6 +60,17 @@ static inline int radix_passes(int bit_begin, int bit_end, RadixPass* out, int n
   }
   return np;
 }
+// Raise a kernel's dynamic-LDS limit.  A failure (e.g. a static __shared__ word sneaking into a kernel that asks for all
+// 160 KB) must not stay behind as HIP's sticky last error, where the NEXT launch check would blame an innocent kernel: it
+// is cleared and reported here; the launch that needs the LDS then fails under its own name.
+#define A3D_ALLOW_LDS(BYTES, ...)                                                                                        \
+  do {                                                                                                                   \
+    if (hipFuncSetAttribute((const void*)(__VA_ARGS__), hipFuncAttributeMaxDynamicSharedMemorySize, (BYTES)) != hipSuccess) { \
+      (void)hipGetLastError();                                                                                           \
+      fprintf(stderr, "agile3d_hip: cannot raise the dynamic LDS limit of %s to %d bytes\n", #__VA_ARGS__, (int)(BYTES)); \
+    }                                                                                                                    \
+  } while (0)
+
 size_t radix_sort_temp_bytes(int n_max);
 // stable, ascending in the listed digits; digits that are constant over the input are skipped on the device;
 // keys_in / vals_in are only read, temp must be 256-byte aligned

@@ -2727,34 +2727,34 @@ static int run_decoder(const a3d_decoder_weights* w, Prepared* P, int ns, hipStr
     if (!big) {
       big = true;
       const int big_lds = 160 * 1024;
-      (void)hipFuncSetAttribute((const void*)k_query_layer<1, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, big_lds);
-      (void)hipFuncSetAttribute((const void*)k_query_layer<2, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, big_lds);
-      (void)hipFuncSetAttribute((const void*)k_query_layer<3, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, big_lds);
-      (void)hipFuncSetAttribute((const void*)k_query_layer<4, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, big_lds);
-      (void)hipFuncSetAttribute((const void*)k_query_block<1, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, big_lds);
-      (void)hipFuncSetAttribute((const void*)k_query_block<2, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, big_lds);
-      (void)hipFuncSetAttribute((const void*)k_query_block<3, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, big_lds);
-      (void)hipFuncSetAttribute((const void*)k_query_block<4, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, big_lds);
-      (void)hipFuncSetAttribute((const void*)k_query_block<4, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, big_lds);
-      (void)hipFuncSetAttribute((const void*)k_query_block<4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, big_lds);
-      (void)hipFuncSetAttribute((const void*)k_query_layer<4, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, big_lds);
-      (void)hipFuncSetAttribute((const void*)k_query_layer<4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, big_lds);
-      (void)hipFuncSetAttribute((const void*)k_s2c_attn_wide<4>, hipFuncAttributeMaxDynamicSharedMemorySize, big_lds);
-      (void)hipFuncSetAttribute((const void*)k_q_s2c<1>, hipFuncAttributeMaxDynamicSharedMemorySize, big_lds);
-      (void)hipFuncSetAttribute((const void*)k_q_s2c<2>, hipFuncAttributeMaxDynamicSharedMemorySize, big_lds);
-      (void)hipFuncSetAttribute((const void*)k_q_s2c<3>, hipFuncAttributeMaxDynamicSharedMemorySize, big_lds);
-      (void)hipFuncSetAttribute((const void*)k_q_s2c<4>, hipFuncAttributeMaxDynamicSharedMemorySize, big_lds);
-      (void)hipFuncSetAttribute((const void*)k_out_ln_mask<1>, hipFuncAttributeMaxDynamicSharedMemorySize, big_lds);
-      (void)hipFuncSetAttribute((const void*)k_out_ln_mask<2>, hipFuncAttributeMaxDynamicSharedMemorySize, big_lds);
-      (void)hipFuncSetAttribute((const void*)k_out_ln_mask<3>, hipFuncAttributeMaxDynamicSharedMemorySize, big_lds);
-      (void)hipFuncSetAttribute((const void*)k_out_ln_mask<4>, hipFuncAttributeMaxDynamicSharedMemorySize, big_lds);
-      (void)hipFuncSetAttribute((const void*)k_s2c_out<1>, hipFuncAttributeMaxDynamicSharedMemorySize, big_lds);
-      (void)hipFuncSetAttribute((const void*)k_s2c_out<2>, hipFuncAttributeMaxDynamicSharedMemorySize, big_lds);
-      (void)hipFuncSetAttribute((const void*)k_kv_c2s<1>, hipFuncAttributeMaxDynamicSharedMemorySize, big_lds);
-      (void)hipFuncSetAttribute((const void*)k_kv_c2s<2>, hipFuncAttributeMaxDynamicSharedMemorySize, big_lds);
-      (void)hipFuncSetAttribute((const void*)k_kv_c2s<3>, hipFuncAttributeMaxDynamicSharedMemorySize, big_lds);
-      (void)hipFuncSetAttribute((const void*)k_kv_c2s<4>, hipFuncAttributeMaxDynamicSharedMemorySize, big_lds);
-      (void)hipFuncSetAttribute((const void*)k_ln_mask<4>, hipFuncAttributeMaxDynamicSharedMemorySize, big_lds);
+      A3D_ALLOW_LDS(big_lds, k_query_layer<1, 0>);
+      A3D_ALLOW_LDS(big_lds, k_query_layer<2, 0>);
+      A3D_ALLOW_LDS(big_lds, k_query_layer<3, 0>);
+      A3D_ALLOW_LDS(big_lds, k_query_layer<4, 0>);
+      A3D_ALLOW_LDS(big_lds, k_query_block<1, 0>);
+      A3D_ALLOW_LDS(big_lds, k_query_block<2, 0>);
+      A3D_ALLOW_LDS(big_lds, k_query_block<3, 0>);
+      A3D_ALLOW_LDS(big_lds, k_query_block<4, 0>);
+      A3D_ALLOW_LDS(big_lds, k_query_block<4, 1>);
+      A3D_ALLOW_LDS(big_lds, k_query_block<4, 2>);
+      A3D_ALLOW_LDS(big_lds, k_query_layer<4, 1>);
+      A3D_ALLOW_LDS(big_lds, k_query_layer<4, 2>);
+      A3D_ALLOW_LDS(big_lds, k_s2c_attn_wide<4>);
+      A3D_ALLOW_LDS(big_lds, k_q_s2c<1>);
+      A3D_ALLOW_LDS(big_lds, k_q_s2c<2>);
+      A3D_ALLOW_LDS(big_lds, k_q_s2c<3>);
+      A3D_ALLOW_LDS(big_lds, k_q_s2c<4>);
+      A3D_ALLOW_LDS(big_lds, k_out_ln_mask<1>);
+      A3D_ALLOW_LDS(big_lds, k_out_ln_mask<2>);
+      A3D_ALLOW_LDS(big_lds, k_out_ln_mask<3>);
+      A3D_ALLOW_LDS(big_lds, k_out_ln_mask<4>);
+      A3D_ALLOW_LDS(big_lds, k_s2c_out<1>);
+      A3D_ALLOW_LDS(big_lds, k_s2c_out<2>);
+      A3D_ALLOW_LDS(big_lds, k_kv_c2s<1>);
+      A3D_ALLOW_LDS(big_lds, k_kv_c2s<2>);
+      A3D_ALLOW_LDS(big_lds, k_kv_c2s<3>);
+      A3D_ALLOW_LDS(big_lds, k_kv_c2s<4>);
+      A3D_ALLOW_LDS(big_lds, k_ln_mask<4>);
     }
   }
   const int n_counts = A3D_MAX_DEC_LAYERS * (A3D_MAX_QUERIES + 1);

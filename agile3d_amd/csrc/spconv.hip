@@ -1216,26 +1216,26 @@ static void allow_big_lds() {
   if (done) return;
   done = true;
 #define A3D_BIG3(BN_, CH_) \
-  (void)hipFuncSetAttribute((const void*)k_conv_sk<BN_, CH_, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
-  (void)hipFuncSetAttribute((const void*)k_conv_sk<BN_, CH_, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  A3D_ALLOW_LDS(160 * 1024, k_conv_sk<BN_, CH_, 0>); \
+  A3D_ALLOW_LDS(160 * 1024, k_conv_sk<BN_, CH_, 1>);
   A3D_BIG3(32, 32) A3D_BIG3(32, 64) A3D_BIG3(32, 96) A3D_BIG3(64, 32) A3D_BIG3(64, 64) A3D_BIG3(64, 96)
   A3D_BIG3(96, 32) A3D_BIG3(96, 48) A3D_BIG3(96, 64) A3D_BIG3(96, 96) A3D_BIG3(128, 32) A3D_BIG3(128, 64)
 #undef A3D_BIG3
-  (void)hipFuncSetAttribute((const void*)k_conv_sk<96, 32, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  (void)hipFuncSetAttribute((const void*)k_conv_sk<128, 32, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  (void)hipFuncSetAttribute((const void*)k_conv_sk<64, 32, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  (void)hipFuncSetAttribute((const void*)k_conv_sk<32, 32, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  (void)hipFuncSetAttribute((const void*)k_conv_sk<64, 64, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  (void)hipFuncSetAttribute((const void*)k_conv_sk<96, 32, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  (void)hipFuncSetAttribute((const void*)k_conv_sk<96, 32, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  (void)hipFuncSetAttribute((const void*)k_conv_sk<96, 96, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  (void)hipFuncSetAttribute((const void*)k_conv_sk<128, 64, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  (void)hipFuncSetAttribute((const void*)k_conv_wl<2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  (void)hipFuncSetAttribute((const void*)k_conv_wl<4, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  (void)hipFuncSetAttribute((const void*)k_dense<8, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  (void)hipFuncSetAttribute((const void*)k_dense<8, 6>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  (void)hipFuncSetAttribute((const void*)k_dense<6, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  (void)hipFuncSetAttribute((const void*)k_dense<6, 6>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  A3D_ALLOW_LDS(160 * 1024, k_conv_sk<96, 32, 2>);
+  A3D_ALLOW_LDS(160 * 1024, k_conv_sk<128, 32, 2>);
+  A3D_ALLOW_LDS(160 * 1024, k_conv_sk<64, 32, 2>);
+  A3D_ALLOW_LDS(160 * 1024, k_conv_sk<32, 32, 2>);
+  A3D_ALLOW_LDS(160 * 1024, k_conv_sk<64, 64, 0, true>);
+  A3D_ALLOW_LDS(160 * 1024, k_conv_sk<96, 32, 0, true>);
+  A3D_ALLOW_LDS(160 * 1024, k_conv_sk<96, 32, 1, true>);
+  A3D_ALLOW_LDS(160 * 1024, k_conv_sk<96, 96, 0, true>);
+  A3D_ALLOW_LDS(160 * 1024, k_conv_sk<128, 64, 0, true>);
+  A3D_ALLOW_LDS(160 * 1024, k_conv_wl<2, 2>);
+  A3D_ALLOW_LDS(160 * 1024, k_conv_wl<4, 4>);
+  A3D_ALLOW_LDS(160 * 1024, k_dense<8, 8>);
+  A3D_ALLOW_LDS(160 * 1024, k_dense<8, 6>);
+  A3D_ALLOW_LDS(160 * 1024, k_dense<6, 8>);
+  A3D_ALLOW_LDS(160 * 1024, k_dense<6, 6>);
 }
 
 static int launch_conv_sk(ConvArgs c, const int* pre64, float* slab_ws, size_t slab_ws_floats, int* state,

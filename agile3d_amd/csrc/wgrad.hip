@@ -349,7 +349,7 @@ extern "C" int a3d_linear_wgrad(const float* x_dev, int ldx, const float* dy_dev
   const size_t lds = (size_t)16 * p.cx * 16 * p.cy * sizeof(float);
 #define A3D_WG(CX_, CY_)                                                                                          \
   if (p.cx == CX_ && p.cy == CY_) {                                                                               \
-    (void)hipFuncSetAttribute((const void*)k_wgrad<CX_, CY_>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024); \
+    A3D_ALLOW_LDS(64 * 1024, k_wgrad<CX_, CY_>); \
     k_wgrad<CX_, CY_><<<grid, 256, lds, st>>>(a);                                                                  \
   } else
   A3D_WG(2, 2) A3D_WG(2, 4) A3D_WG(2, 6) A3D_WG(2, 8) A3D_WG(4, 2) A3D_WG(4, 4) A3D_WG(4, 6) A3D_WG(4, 8)
@@ -428,7 +428,7 @@ extern "C" int a3d_conv_wgrad(const a3d_scene* s, int kind, int level_in, const 
   const size_t lds = (size_t)16 * p.cx * 16 * p.cy * sizeof(float);
 #define A3D_WG(CX_, CY_)                                                                                          \
   if (p.cx == CX_ && p.cy == CY_) {                                                                               \
-    (void)hipFuncSetAttribute((const void*)k_wgrad<CX_, CY_>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024); \
+    A3D_ALLOW_LDS(64 * 1024, k_wgrad<CX_, CY_>); \
     k_wgrad<CX_, CY_><<<grid, 256, lds, st>>>(a);                                                                  \
   } else
   A3D_WG(2, 2) A3D_WG(2, 4) A3D_WG(2, 6) A3D_WG(2, 8) A3D_WG(4, 2) A3D_WG(4, 4) A3D_WG(4, 6) A3D_WG(4, 8)
