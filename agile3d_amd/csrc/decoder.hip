@@ -1075,13 +1075,16 @@ __global__ void __launch_bounds__(512) k_out_ln_mask(const DecSampleDev* __restr
 // in registers; more queries than fit fall back to the two-kernel path.  The logits MFMA is taken transposed
 // (queries x points): a lane ends up with the logits of ITS point, the per-object max is a masked in-lane max + one
 // row reduction, no LDS scratch for the [16][Q] logits tile.
-template <int QT>
-__global__ void __launch_bounds__(512) k_s2c_out(const DecSampleDev* __restrict__ samples, int ns, int layer,
+// NW = waves per workgroup: 8 (two per SIMD, the next group's rows prefetched into 64 registers) or 12 (three per SIMD at
+// <= 168 registers: no register prefetch -- the third wave covers a wave's wait for its rows)
+template <int QT, int NW>
+__global__ void __launch_bounds__(NW * 64) k_s2c_out(const DecSampleDev* __restrict__ samples, int ns, int layer,
                                                  const float* __restrict__ Wq, const float* __restrict__ bq,
                                                  const float* __restrict__ Wo, const float* __restrict__ bo,
                                                  const float* __restrict__ gamma, const float* __restrict__ beta, int nqr_max,
                                                  int Kmax) {
-  constexpr int LD = 132, NW = 8;
+  constexpr int LD = 132, NT = NW * 64;
+  constexpr bool PF = NW == 8;   // register prefetch of the next group
   const DecSampleDev& sm = sample_of_wg(samples, ns);
   const int lb = blockIdx.x - sm.wg_begin, nwg = sm.wg_end - sm.wg_begin;
   const int n = sm.n, ngroups = (n + 15) / 16, nq = sm.nq, n_fg = sm.n_fg, K = sm.K;
@@ -1104,8 +1107,8 @@ __global__ void __launch_bounds__(512) k_s2c_out(const DecSampleDev* __restrict_
   float* O_l = be_l + D;                          // [NW][16][Kmax+1] logits staging
   int* hist = (int*)(O_l + NW * 16 * (Kmax + 1)); // [Kmax+1]
   int* qr_l = hist + Kmax + 1;                    // [Kmax+2]
-  for (int e = threadIdx.x; e <= K + 1; e += 512) qr_l[e] = gld(sm.qrange + e);
-  for (int e = threadIdx.x; e <= K; e += 512) hist[e] = 0;
+  for (int e = threadIdx.x; e <= K + 1; e += NT) qr_l[e] = gld(sm.qrange + e);
+  for (int e = threadIdx.x; e <= K; e += NT) hist[e] = 0;
   if (threadIdx.x < D) {
     bq_l[threadIdx.x] = bq[threadIdx.x];
     bo_l[threadIdx.x] = bo[threadIdx.x];
@@ -1114,23 +1117,23 @@ __global__ void __launch_bounds__(512) k_s2c_out(const DecSampleDev* __restrict_
   }
   {
     constexpr int TOT = 8 * 8 * 64;
-    for (int base = threadIdx.x; base < TOT; base += 4 * 512) {
+    for (int base = threadIdx.x; base < TOT; base += 4 * NT) {
       f32x4 t8[8];
 #pragma unroll
       for (int u = 0; u < 4; ++u)
-        if (base + u * 512 < TOT) {
-          t8[u] = ((const f32x4*)Wq)[base + u * 512];
-          t8[4 + u] = ((const f32x4*)Wo)[base + u * 512];
+        if (base + u * NT < TOT) {
+          t8[u] = ((const f32x4*)Wq)[base + u * NT];
+          t8[4 + u] = ((const f32x4*)Wo)[base + u * NT];
         }
 #pragma unroll
       for (int u = 0; u < 4; ++u)
-        if (base + u * 512 < TOT) {
-          Wql[base + u * 512] = t8[u];
-          Wol[base + u * 512] = t8[4 + u];
+        if (base + u * NT < TOT) {
+          Wql[base + u * NT] = t8[u];
+          Wol[base + u * NT] = t8[4 + u];
         }
     }
   }
-  for (int e = threadIdx.x; e < nqr_max * 32; e += 512) {
+  for (int e = threadIdx.x; e < nqr_max * 32; e += NT) {
     const int r = e >> 5, c4 = (e & 31) * 4;
     f32x4 k4 = (f32x4){0.f, 0.f, 0.f, 0.f}, v4 = k4;
     if (r < nq) {
@@ -1141,7 +1144,7 @@ __global__ void __launch_bounds__(512) k_s2c_out(const DecSampleDev* __restrict_
 #pragma unroll
     for (int t = 0; t < 4; ++t) vt_l[(c4 + t) * LT + r] = v4[t];
   }
-  for (int e = threadIdx.x; e < D * 4; e += 512) vt_l[(e >> 2) * LT + nqr_max + (e & 3)] = 0.f;   // the pad columns are read (x 0)
+  for (int e = threadIdx.x; e < D * 4; e += NT) vt_l[(e >> 2) * LT + nqr_max + (e & 3)] = 0.f;   // the pad columns are read (x 0)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int g = lane >> 4, j = lane & 15;
   __syncthreads();
@@ -1158,8 +1161,9 @@ __global__ void __launch_bounds__(512) k_s2c_out(const DecSampleDev* __restrict_
 #pragma unroll
     for (int S = 0; S < 8; ++S) np[S] = gld4(pr + 16 * S);
   };
-  if (grp < ngroups) fetch(grp);
+  if (PF && grp < ngroups) fetch(grp);
   while (grp < ngroups) {
+    if constexpr (!PF) fetch(grp);
     const int p0 = grp * 16;
     const int prow = min(p0 + j, n - 1);
     f32x4 xp[8], y[8];
@@ -1175,7 +1179,7 @@ __global__ void __launch_bounds__(512) k_s2c_out(const DecSampleDev* __restrict_
     for (int h = 0; h < H; h += 2) {
       // the next group's rows are requested late in the head loop (two heads + the LayerNorm / logits phase cover the
       // latency): 64 registers that would otherwise be live next to xp and y for the whole group
-      if (h == 4 && next < ngroups) fetch(next);
+      if (PF && h == 4 && next < ngroups) fetch(next);
       f32x4 qf[2];
 #pragma unroll
       for (int u = 0; u < 2; ++u) qf[u] = *(const f32x4*)(bq_l + 16 * (h + u) + 4 * g);   // Q[point j][16h+4g..+3]
@@ -1364,7 +1368,7 @@ __global__ void __launch_bounds__(512) k_s2c_out(const DecSampleDev* __restrict_
     grp = next;
   }
   __syncthreads();
-  for (int e = threadIdx.x; e <= K; e += 512)
+  for (int e = threadIdx.x; e <= K; e += NT)
     if (hist[e]) atomicAdd(&counts[e], hist[e]);
 }
 
@@ -2748,8 +2752,10 @@ static int run_decoder(const a3d_decoder_weights* w, Prepared* P, int ns, hipStr
       A3D_ALLOW_LDS(big_lds, k_out_ln_mask<2>);
       A3D_ALLOW_LDS(big_lds, k_out_ln_mask<3>);
       A3D_ALLOW_LDS(big_lds, k_out_ln_mask<4>);
-      A3D_ALLOW_LDS(big_lds, k_s2c_out<1>);
-      A3D_ALLOW_LDS(big_lds, k_s2c_out<2>);
+      A3D_ALLOW_LDS(big_lds, k_s2c_out<1, 8>);
+      A3D_ALLOW_LDS(big_lds, k_s2c_out<2, 8>);
+      A3D_ALLOW_LDS(big_lds, k_s2c_out<1, 12>);
+      A3D_ALLOW_LDS(big_lds, k_s2c_out<2, 12>);
       A3D_ALLOW_LDS(big_lds, k_kv_c2s<1>);
       A3D_ALLOW_LDS(big_lds, k_kv_c2s<2>);
       A3D_ALLOW_LDS(big_lds, k_kv_c2s<3>);
@@ -2789,6 +2795,7 @@ static int run_decoder(const a3d_decoder_weights* w, Prepared* P, int ns, hipStr
   const int nqr_max = (nq_max + 3) & ~3;
   const size_t s2c_out_lds = (size_t)128 * 1024 + ((size_t)nqr_max * 132 + (size_t)D * (nqr_max + 4) + 4 * D +
                                                    (size_t)8 * 16 * (Kmax + 1) + 2 * Kmax + 3) * 4;
+  const size_t s2c_out_lds12 = s2c_out_lds + (size_t)4 * 16 * (Kmax + 1) * 4;   // twelve waves' logits staging
   static int fused_s2c_env = -1;
   if (fused_s2c_env < 0) {
     const char* e = getenv("A3D_FUSED_S2C");
@@ -2960,8 +2967,17 @@ static int run_decoder(const a3d_decoder_weights* w, Prepared* P, int ns, hipStr
       // the whole half in one pass: O never reaches HBM (k_s2c_out)
       ProfScope ps(st, A3D_PROF_S2C, 0, 0, 0, 0, (int)n_total);
       if constexpr (QT <= 2) {
-        k_s2c_out<QT><<<grid, 512, s2c_out_lds, st>>>(samples_dev, ns, l, LW.s2c_wq_packed, LW.s2c_in_b, LW.s2c_wo_packed,
-                                                      LW.s2c_out_b, LW.s2c_norm_w, LW.s2c_norm_b, nqr_max, Kmax);
+        static int s2c_w12 = -1;   // A3D_S2C_WAVES=8: the two-waves-per-SIMD build with the register prefetch
+        if (s2c_w12 < 0) {
+          const char* e = getenv("A3D_S2C_WAVES");
+          s2c_w12 = e ? atoi(e) == 12 : 1;
+        }
+        if (s2c_w12 && s2c_out_lds12 <= 160 * 1024)
+          k_s2c_out<QT, 12><<<grid, 768, s2c_out_lds12, st>>>(samples_dev, ns, l, LW.s2c_wq_packed, LW.s2c_in_b, LW.s2c_wo_packed,
+                                                             LW.s2c_out_b, LW.s2c_norm_w, LW.s2c_norm_b, nqr_max, Kmax);
+        else
+          k_s2c_out<QT, 8><<<grid, 512, s2c_out_lds, st>>>(samples_dev, ns, l, LW.s2c_wq_packed, LW.s2c_in_b, LW.s2c_wo_packed,
+                                                          LW.s2c_out_b, LW.s2c_norm_w, LW.s2c_norm_b, nqr_max, Kmax);
       }
       A3D_LAUNCH_CHECK();
       continue;
