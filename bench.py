@@ -112,7 +112,9 @@ def profile_pass(step, scene_pairs, n_steps):
     cap = 4000 * n_steps
     buf = (L.ProfEntry * cap)()
     n = lib.a3d_profile_read(buf, cap)
-    assert n % n_steps == 0 and n < cap, (n, n_steps)
+    if n >= cap or n % n_steps:
+        raise RuntimeError(f"profile_pass: {n} instrumented launches in {n_steps} steps (buffer holds {cap}; every step must "
+                           f"launch the same sequence) -- raise the cap or check that nothing else launched in between")
     per = n // n_steps
     agg = {}
     for i in range(per):
