@@ -114,7 +114,9 @@ __global__ void __launch_bounds__(256) k_minmax_partial(const float* __restrict_
   if (threadIdx.x < 6) part[blockIdx.x * 6 + threadIdx.x] = s[threadIdx.x][0];
 }
 __global__ void k_minmax_final(const float* __restrict__ part, int nb, float* minmax) {
-  // 6 waves, one per statistic (min x,y,z, max x,y,z) over the nb block partials
+  // 6 waves, one per statistic (min x,y,z, max x,y,z) over the nb block partials; blockIdx.x = sample of a batch
+  part += (size_t)blockIdx.x * nb * 6;
+  minmax += 6 * blockIdx.x;
   const int a = threadIdx.x >> 6, lane = threadIdx.x & 63;
   float v = a < 3 ? 3.4e38f : -3.4e38f;
   for (int b = lane; b < nb; b += 64) v = a < 3 ? fminf(v, part[b * 6 + a]) : fmaxf(v, part[b * 6 + a]);
@@ -126,22 +128,70 @@ __global__ void k_minmax_final(const float* __restrict__ part, int nb, float* mi
   if (lane == 0) minmax[a] = v;
 }
 // get_fourier_embeddings with normalize=True: u = (x-min)/(max-min); p = (2 pi u) @ B; [sin p, cos p]
-__global__ void k_fourier(const float* __restrict__ xyz, int n, const float* __restrict__ gaussB,
-                          const float* __restrict__ minmax, float* out) {
-  const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= (size_t)n * 64) return;
-  const int i = (int)(e >> 6), jj = (int)(e & 63);
+__device__ __forceinline__ void fourier_row(const float* __restrict__ xyz, size_t i, int jj, const float* __restrict__ gaussB,
+                                            const float* __restrict__ minmax, float* out) {
   const float two_pi = 6.283185307179586f;
   float p = 0.f;
 #pragma unroll
   for (int a = 0; a < 3; ++a) {
     const float mn = minmax[a], mx = minmax[3 + a];
-    float u = (xyz[3 * (size_t)i + a] - mn) / (mx - mn);
+    float u = (xyz[3 * i + a] - mn) / (mx - mn);
     u *= two_pi;
     p += u * gaussB[a * 64 + jj];
   }
-  out[(size_t)i * D + jj] = sinf(p);
-  out[(size_t)i * D + 64 + jj] = cosf(p);
+  out[i * D + jj] = sinf(p);
+  out[i * D + 64 + jj] = cosf(p);
+}
+__global__ void k_fourier(const float* __restrict__ xyz, int n, const float* __restrict__ gaussB,
+                          const float* __restrict__ minmax, float* out) {
+  const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= (size_t)n * 64) return;
+  fourier_row(xyz, e >> 6, (int)(e & 63), gaussB, minmax, out);
+}
+// ---- the same for every sample of a batch in three launches (rows of sample b = [start[b], start[b+1]) of one matrix)
+constexpr int kPosBlocks = 16;   // partial-reduction blocks per sample
+struct PosBatch {
+  int ns;
+  int start[64 + 1];
+};
+__global__ void __launch_bounds__(256) k_minmax_partial_b(const float* __restrict__ xyz, const PosBatch pb, float* part) {
+  __shared__ float s[6][256];
+  const int b = blockIdx.y, r0 = pb.start[b], r1 = pb.start[b + 1];
+  float mn[3] = {3.4e38f, 3.4e38f, 3.4e38f}, mx[3] = {-3.4e38f, -3.4e38f, -3.4e38f};
+  for (int i = r0 + blockIdx.x * 256 + threadIdx.x; i < r1; i += kPosBlocks * 256) {
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      const float v = xyz[3 * (size_t)i + a];
+      mn[a] = fminf(mn[a], v);
+      mx[a] = fmaxf(mx[a], v);
+    }
+  }
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    s[a][threadIdx.x] = mn[a];
+    s[3 + a][threadIdx.x] = mx[a];
+  }
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) {
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        s[a][threadIdx.x] = fminf(s[a][threadIdx.x], s[a][threadIdx.x + o]);
+        s[3 + a][threadIdx.x] = fmaxf(s[3 + a][threadIdx.x], s[3 + a][threadIdx.x + o]);
+      }
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x < 6) part[((size_t)b * kPosBlocks + blockIdx.x) * 6 + threadIdx.x] = s[threadIdx.x][0];
+}
+__global__ void k_fourier_b(const float* __restrict__ xyz, const PosBatch pb, const float* __restrict__ gaussB,
+                            const float* __restrict__ minmax, float* out) {
+  // blockIdx.y = sample (uniform: its row range comes from scalar loads), blockIdx.x = 4-row block inside it
+  const int b = blockIdx.y, r0 = pb.start[b], r1 = pb.start[b + 1];
+  const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t i = (size_t)r0 + (e >> 6);
+  if (i >= (size_t)r1) return;
+  fourier_row(xyz, i, (int)(e & 63), gaussB, minmax + 6 * b, out);
 }
 
 struct QueryMeta {   // device-resident, uploaded once per forward_mask
@@ -2582,6 +2632,43 @@ extern "C" int a3d_posenc_fourier(const float* xyz_dev, int64_t n, const float* 
   k_minmax_final<<<1, 384, 0, st>>>(part, nb, minmax_dev);
   const size_t total = (size_t)n * 64;
   k_fourier<<<(unsigned)((total + 255) / 256), 256, 0, st>>>(xyz_dev, (int)n, gauss_B_dev, minmax_dev, out_dev);
+  A3D_LAUNCH_CHECK();
+  return A3D_OK;
+}
+
+extern "C" size_t a3d_posenc_batch_workspace_bytes(int n_samples) {
+  return n_samples >= 1 && n_samples <= 64 ? (size_t)n_samples * kPosBlocks * 6 * 4 : 0;
+}
+extern "C" int a3d_posenc_fourier_batch(const float* xyz_dev, const int64_t* starts_host, int n_samples,
+                                        const float* gauss_B_dev, float* minmax_dev, float* out_dev, void* workspace_dev,
+                                        size_t workspace_bytes, void* stream) {
+  if (!xyz_dev || !starts_host || !gauss_B_dev || !minmax_dev || !out_dev || n_samples < 1 || n_samples > 64) {
+    set_error("a3d_posenc_fourier_batch: bad arguments (1..64 samples)");
+    return A3D_ERR_INVALID;
+  }
+  PosBatch pb;
+  pb.ns = n_samples;
+  for (int b = 0; b <= n_samples; ++b) {
+    if (starts_host[b] < 0 || starts_host[b] > ((int64_t)1 << 30) || (b && starts_host[b] <= starts_host[b - 1])) {
+      set_error("a3d_posenc_fourier_batch: sample %d has no rows (starts must ascend)", b - 1);
+      return A3D_ERR_INVALID;
+    }
+    pb.start[b] = (int)starts_host[b];
+  }
+  if (!workspace_dev || workspace_bytes < a3d_posenc_batch_workspace_bytes(n_samples)) {
+    set_error("a3d_posenc_fourier_batch: workspace needs >= %zu bytes", a3d_posenc_batch_workspace_bytes(n_samples));
+    return A3D_ERR_WORKSPACE;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  float* part = (float*)workspace_dev;
+  const int n_total = pb.start[n_samples];
+  ProfScope ps(st, A3D_PROF_POSENC, 0, 0, 3, 128, n_total);
+  k_minmax_partial_b<<<dim3(kPosBlocks, n_samples), 256, 0, st>>>(xyz_dev, pb, part);
+  k_minmax_final<<<n_samples, 384, 0, st>>>(part, kPosBlocks, minmax_dev);
+  int n_max = 0;
+  for (int b = 0; b < n_samples; ++b) n_max = std::max(n_max, pb.start[b + 1] - pb.start[b]);
+  k_fourier_b<<<dim3((unsigned)(((size_t)n_max * 64 + 255) / 256), n_samples), 256, 0, st>>>(xyz_dev, pb, gauss_B_dev, minmax_dev,
+                                                                                            out_dev);
   A3D_LAUNCH_CHECK();
   return A3D_OK;
 }

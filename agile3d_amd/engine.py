@@ -425,16 +425,7 @@ class Engine:
             out = torch.empty((n, self.model.mask_dim), dtype=torch.float32, device=self.device)
             st.ws = self.program.run(st.scene, x.F, out)
             st.ranges = st.scene.batch_ranges      # from the scene build's single read-back, no torch kernels
-            st.posenc, st.minmax = [], []
-            tmp = torch.empty(256 * 6 * 4, dtype=torch.uint8, device=self.device)
-            for (s, e) in st.ranges:
-                nb = e - s
-                pe = torch.empty((nb, 128), dtype=torch.float32, device=self.device)
-                mm = torch.empty(6, dtype=torch.float32, device=self.device)
-                L.check(lib.a3d_posenc_fourier(_ptr(raw[s:e]), nb, self.decoder.gauss_B_ptr, _ptr(mm), _ptr(pe),
-                                               _ptr(tmp), tmp.numel(), _stream()), "a3d_posenc_fourier")
-                st.posenc.append(pe)
-                st.minmax.append(mm)
+            st.posenc, st.minmax = self._posenc_batch(raw, st.ranges)
         pcd_features = SparseTensor(features=out, coordinates=x.C)
         pcd_features._a3d = st
         coordinates = SparseTensor(features=raw, coordinates=x.C)
@@ -465,16 +456,7 @@ class Engine:
             st.scene = Scene(x.C)
             tape = BackboneTape(self.model, st.scene, x.F.detach())
             st.ranges = st.scene.batch_ranges
-            st.posenc, st.minmax = [], []
-            tmp = torch.empty(256 * 6 * 4, dtype=torch.uint8, device=self.device)
-            for (s, e) in st.ranges:
-                nb = e - s
-                pe = torch.empty((nb, 128), dtype=torch.float32, device=self.device)
-                mm = torch.empty(6, dtype=torch.float32, device=self.device)
-                L.check(lib.a3d_posenc_fourier(_ptr(raw[s:e]), nb, self.decoder.gauss_B_ptr, _ptr(mm), _ptr(pe),
-                                               _ptr(tmp), tmp.numel(), _stream()), "a3d_posenc_fourier")
-                st.posenc.append(pe)
-                st.minmax.append(mm)
+            st.posenc, st.minmax = self._posenc_batch(raw, st.ranges)
         named = [(k, p) for k, p in self.model.named_parameters()
                  if k.startswith("backbone.") or k.startswith("lin_squeeze_head.")]
         holder = _Holder(tape=tape, names=[k for k, _ in named])
@@ -553,21 +535,39 @@ class Engine:
         st = _SceneState()
         st.engine_id = id(self)
         st.ranges = [(int(s), int(e)) for s, e in ranges]
-        st.posenc, st.minmax = [], []
         with torch.no_grad():
-            tmp = torch.empty(256 * 6 * 4, dtype=torch.uint8, device=self.device)
             for b, (s, e) in enumerate(st.ranges):
                 C4[s:e, 0] = b
-                pe = torch.empty((e - s, 128), dtype=torch.float32, device=self.device)
-                mm = torch.empty(6, dtype=torch.float32, device=self.device)
-                L.check(lib.a3d_posenc_fourier(_ptr(raw[s:e]), e - s, self.decoder.gauss_B_ptr, _ptr(mm), _ptr(pe), _ptr(tmp),
-                                               tmp.numel(), _stream()), "a3d_posenc_fourier")
-                st.posenc.append(pe)
-                st.minmax.append(mm)
+            st.posenc, st.minmax = self._posenc_batch(raw, st.ranges)
         pcd = SparseTensor(features=feats, coordinates=C4)
         pcd._a3d = st
         coordinates = SparseTensor(features=raw, coordinates=C4)
         return pcd, None, coordinates, [[[None] * len(st.ranges)] for _ in range(4)] + [[list(st.posenc)]]
+
+    def _posenc_batch(self, raw, ranges):
+        """Fourier position encodings of every sample of a batch (agile3d.py:141-161 loops over the samples; each has its
+        own min / max) in three launches: (list of [n_b, 128] views of one matrix, list of [6] min/max views)."""
+        lib = L.load()
+        ns = len(ranges)
+        if ns > 64 or any(ranges[i][1] != ranges[i + 1][0] for i in range(ns - 1)) or any(e <= s for s, e in ranges):
+            pes, mms = [], []          # unusual layouts: sample by sample
+            tmp = torch.empty(256 * 6 * 4, dtype=torch.uint8, device=self.device)
+            for (s, e) in ranges:
+                pe = torch.empty((e - s, 128), dtype=torch.float32, device=self.device)
+                mm = torch.empty(6, dtype=torch.float32, device=self.device)
+                L.check(lib.a3d_posenc_fourier(_ptr(raw[s:e]), e - s, self.decoder.gauss_B_ptr, _ptr(mm), _ptr(pe), _ptr(tmp),
+                                               tmp.numel(), _stream()), "a3d_posenc_fourier")
+                pes.append(pe)
+                mms.append(mm)
+            return pes, mms
+        s0, e1 = ranges[0][0], ranges[-1][1]
+        starts = (C.c_int64 * (ns + 1))(*([r[0] - s0 for r in ranges] + [e1 - s0]))
+        pe_all = torch.empty((e1 - s0, 128), dtype=torch.float32, device=self.device)
+        mm_all = torch.empty((ns, 6), dtype=torch.float32, device=self.device)
+        tmp = torch.empty(lib.a3d_posenc_batch_workspace_bytes(ns), dtype=torch.uint8, device=self.device)
+        L.check(lib.a3d_posenc_fourier_batch(_ptr(raw[s0:e1]), starts, ns, self.decoder.gauss_B_ptr, _ptr(mm_all), _ptr(pe_all),
+                                             _ptr(tmp), tmp.numel(), _stream()), "a3d_posenc_fourier_batch")
+        return [pe_all[s - s0:e - s0] for (s, e) in ranges], [mm_all[b] for b in range(ns)]
 
     # ---------------------------------------------------------------- forward_mask
     def forward_mask(self, pcd_features, aux, coordinates, pos_encodings_pcd, click_idx=None, click_time_idx=None):

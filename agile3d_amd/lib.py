@@ -113,6 +113,9 @@ SYMBOLS = {
                              C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
     "a3d_posenc_fourier": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                      C.c_size_t, C.c_void_p]),
+    "a3d_posenc_batch_workspace_bytes": (C.c_size_t, [C.c_int]),
+    "a3d_posenc_fourier_batch": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                           C.c_void_p, C.c_size_t, C.c_void_p]),
     "a3d_decoder_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int]),
     "a3d_decoder_query_pack_floats": (C.c_size_t, [C.c_int32]),
     "a3d_decoder_mask_pack_floats": (C.c_size_t, []),

@@ -386,6 +386,13 @@ int a3d_linear(const float* in_dev, int ldi, const float* in_add_dev, int ldi_ad
 int a3d_posenc_fourier(const float* xyz_dev, int64_t n, const float* gauss_B_dev /*[3][64]*/,
                        float* minmax_dev /*[6]*/, float* out_dev /*[n][128]*/,
                        void* workspace_dev, size_t workspace_bytes, void* stream);
+/* The same for every sample of a batch in three launches: rows [starts_host[b], starts_host[b+1]) of xyz_dev / out_dev
+ * belong to sample b (1..64 samples, each with its own min / max: agile3d.py:141-161 loops over the batch);
+ * minmax_dev is [n_samples][6].  Bit-identical to a3d_posenc_fourier per sample. */
+size_t a3d_posenc_batch_workspace_bytes(int n_samples);
+int a3d_posenc_fourier_batch(const float* xyz_dev, const int64_t* starts_host, int n_samples,
+                             const float* gauss_B_dev /*[3][64]*/, float* minmax_dev /*[n_samples][6]*/,
+                             float* out_dev /*[N][128]*/, void* workspace_dev, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Click-query decoder.

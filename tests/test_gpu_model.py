@@ -127,6 +127,35 @@ def test_forward_mask_many_clicks(model_and_sd, decoder_weights, n_obj, per_obj,
         assert err <= TOL * max(1.0, ref[i].abs().max().item())
 
 
+def test_batched_position_encoding_equals_per_sample_calls(model_and_sd):
+    """a3d_posenc_fourier_batch (three launches for the whole batch, what forward_backbone calls) against one
+    a3d_posenc_fourier per sample: every sample is normalised by ITS OWN min / max (agile3d.py:141-161) -- same bits."""
+    import ctypes as C
+    from agile3d_amd import lib as L
+    model, _ = model_and_sd
+    eng = model._get_engine()
+    eng.refresh_decoder_if_stale(check_versions=True)
+    lib = L.load()
+    g = torch.Generator().manual_seed(77)
+    sizes = [1, 37, 5000, 256, 12345]
+    xyz = torch.cat([torch.rand(n, 3, generator=g) * torch.tensor([8.0, 6.0, 2.6]) + 3.0 * i for i, n in enumerate(sizes)]).cuda()
+    ranges, s = [], 0
+    for n in sizes:
+        ranges.append((s, s + n))
+        s += n
+    pes, mms = eng._posenc_batch(xyz, ranges)
+    tmp = torch.empty(256 * 6 * 4, dtype=torch.uint8, device="cuda")
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    for (a, b), pe, mm in zip(ranges, pes, mms):
+        if b - a < 2:
+            continue          # a single point has max == min: both paths divide by zero alike, nothing to compare
+        ref = torch.empty((b - a, 128), dtype=torch.float32, device="cuda")
+        rmm = torch.empty(6, dtype=torch.float32, device="cuda")
+        L.check(lib.a3d_posenc_fourier(C.c_void_p(xyz[a:b].data_ptr()), b - a, eng.decoder.gauss_B_ptr, C.c_void_p(rmm.data_ptr()),
+                                       C.c_void_p(ref.data_ptr()), C.c_void_p(tmp.data_ptr()), tmp.numel(), st), "a3d_posenc_fourier")
+        assert torch.equal(mm, rmm) and torch.equal(pe, ref), (a, b)
+
+
 def test_too_many_clicks_is_an_error(model_and_sd):
     model, _ = model_and_sd
     eng = model._get_engine()
