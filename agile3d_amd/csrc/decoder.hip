@@ -139,8 +139,10 @@ __device__ __forceinline__ void fourier_row(const float* __restrict__ xyz, size_
     u *= two_pi;
     p += u * gaussB[a * 64 + jj];
   }
-  out[i * D + jj] = sinf(p);
-  out[i * D + 64 + jj] = cosf(p);
+  float sn, cs;
+  sincosf(p, &sn, &cs);   // one argument reduction for both (full precision: the encoding's bar is 1e-4)
+  out[i * D + jj] = sn;
+  out[i * D + 64 + jj] = cs;
 }
 __global__ void k_fourier(const float* __restrict__ xyz, int n, const float* __restrict__ gaussB,
                           const float* __restrict__ minmax, float* out) {
