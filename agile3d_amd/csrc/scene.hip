@@ -144,32 +144,33 @@ __global__ void k_make_keys(const int32_t* __restrict__ coords4, int n, uint64_t
   }
 }
 
-__global__ void k_check_dups(const uint64_t* __restrict__ keys, int n, int* sizes_dev) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= 1 && i < n && keys[i] == keys[i - 1]) atomicMin(&sizes_dev[5], A3D_ERR_DUPLICATE);
-}
-
 // ---- coarser levels: key_{L}(voxel) = key_0 >> 3L, so a row of level L is a run of equal (key_0 >> 3L) in the
 // sorted level-0 keys and ALL four coarser levels come out of one pass over them (3 launches instead of 12):
 // head_L[i] = first element of its level-L run; rank_L(i) = #heads_L in [0, i] - 1 = the level-L row of voxel i.
 struct CoarseOut {
   uint64_t* keys[A3D_NUM_LEVELS - 1];   // keys[L-1] = level-L keys
   int* parentM[A3D_NUM_LEVELS - 1];     // parentM[L] : level-L row -> level-(L+1) row
+  int* firstM[A3D_NUM_LEVELS - 1];      // firstM[L] : level-(L+1) row -> its first level-L row (siblings are consecutive)
 };
-__device__ __forceinline__ void head_flags(const uint64_t* __restrict__ keys, int n, int i, int (&f)[A3D_NUM_LEVELS - 1]) {
+// returns true when voxel i repeats its predecessor's key (a duplicate coordinate)
+__device__ __forceinline__ bool head_flags(const uint64_t* __restrict__ keys, int n, int i, int (&f)[A3D_NUM_LEVELS - 1]) {
 #pragma unroll
   for (int L = 1; L < A3D_NUM_LEVELS; ++L) f[L - 1] = 0;
   if (i < n) {
     const uint64_t k = keys[i], kp = i > 0 ? keys[i - 1] : 0;
 #pragma unroll
     for (int L = 1; L < A3D_NUM_LEVELS; ++L) f[L - 1] = (i == 0) || ((k >> (3 * L)) != (kp >> (3 * L)));
+    return i > 0 && k == kp;
   }
+  return false;
 }
-// pass 1: heads per block of 1024 voxels, blocksums[L-1][block]
-__global__ void __launch_bounds__(1024) k_heads_count(const uint64_t* __restrict__ keys, int n, int nb, int* blocksums) {
+// pass 1: heads per block of 1024 voxels, blocksums[L-1][block]; also the duplicate-coordinate check (equal neighbours
+// in the sorted keys)
+__global__ void __launch_bounds__(1024) k_heads_count(const uint64_t* __restrict__ keys, int n, int nb, int* blocksums,
+                                                      int* sizes_dev) {
   __shared__ int lds[17];
   int f[A3D_NUM_LEVELS - 1];
-  head_flags(keys, n, blockIdx.x * 1024 + threadIdx.x, f);
+  if (head_flags(keys, n, blockIdx.x * 1024 + threadIdx.x, f)) atomicMin(&sizes_dev[5], A3D_ERR_DUPLICATE);
 #pragma unroll
   for (int L = 0; L < A3D_NUM_LEVELS - 1; ++L) {
     int total;
@@ -210,7 +211,10 @@ __global__ void __launch_bounds__(1024) k_heads_write(const uint64_t* __restrict
   const uint64_t k = keys[i];
 #pragma unroll
   for (int L = 1; L < A3D_NUM_LEVELS; ++L) {
-    if (f[L - 1]) out.keys[L - 1][rank[L]] = k >> (3 * L);
+    if (f[L - 1]) {
+      out.keys[L - 1][rank[L]] = k >> (3 * L);
+      out.firstM[L - 1][rank[L]] = rank[L - 1];   // a voxel that heads a level-L run heads its level-(L-1) run too
+    }
     // voxel i is a row of level L-1 iff it heads its level-(L-1) run (every voxel is a row of level 0)
     if (L == 1 || f[L - 2]) out.parentM[L - 1][rank[L - 1]] = rank[L];
   }
@@ -222,12 +226,15 @@ __global__ void __launch_bounds__(1024) k_heads_write(const uint64_t* __restrict
 struct LevelSet {
   Level lv[A3D_NUM_LEVELS];
   int* nbrM[A3D_NUM_LEVELS];   // [27][npad] neighbour rows in Morton order
+  const int* firstM[A3D_NUM_LEVELS - 1];   // level-(L+1) Morton row -> first level-L Morton row
   int off[A3D_NUM_LEVELS + 1]; // start of every level in the concatenated row list of the sorts
   int blk[A3D_NUM_LEVELS + 1]; // first block of every level in THIS launch
   int nlev;                    // levels taking part in this launch
   int st_shift, level_shift;
   uint64_t* cat_keys;
   int *cat_vals, *cat_sorted;
+  const int* vals_sorted0;     // Morton row of level 0 -> caller row (values of the first sort)
+  int* orig_row;               // internal row of level 0 -> caller row
 };
 __device__ __forceinline__ int ls_level(const LevelSet& S, int& local_block) {
   int L = 0;
@@ -236,13 +243,7 @@ __device__ __forceinline__ int ls_level(const LevelSet& S, int& local_block) {
   return L;
 }
 
-// hash table of a level: fill with the empty key, then insert (two launches: the fill must be complete first)
-__global__ void k_hash_clear(const LevelSet S) {
-  int lb;
-  const Level& lv = S.lv[ls_level(S, lb)];
-  const uint32_t i = lb * blockDim.x + threadIdx.x;
-  if (i <= lv.hmask && !lv.grid) lv.hkeys[i] = kEmptyKey;
-}
+// hash table of a level (the keys start out as kEmptyKey: the host clears the whole region with one memset)
 __global__ void k_hash_insert(const LevelSet S) {
   int lb;
   const Level& lv = S.lv[ls_level(S, lb)];
@@ -325,6 +326,7 @@ __global__ void k_perm_from_sorted(const LevelSet S, int up) {
   } else {
     lv.perm[src] = p;
     lv.inv[p] = src;
+    if (L == 0) S.orig_row[p] = S.vals_sorted0[src];
   }
 }
 
@@ -407,50 +409,39 @@ __global__ void k_xyzb_hashfix(const LevelSet S) {
     lv.xyzb[4 * f + 2] = Z;
     lv.xyzb[4 * f + 3] = b;
     if (lv.grid) lv.grid[grid_cell(lv, b, X, Y, Z)] = f;
+    if (L < A3D_NUM_LEVELS - 1) {   // sort key of the second sort: the child slot of internal row f inside its super tile
+      S.cat_keys[S.off[L] + f] = ((uint64_t)L << S.level_shift) | ((uint64_t)(f >> S.st_shift) << 27) | (lv.keys[lv.inv[f]] & 7);
+      S.cat_vals[S.off[L] + f] = S.off[L] + f;
+    }
   }
   if (!lv.grid && f <= lv.hmask && lv.hkeys[f] != kEmptyKey) lv.hvals[f] = lv.perm[lv.hvals[f]];
 }
 
-// child8[slot][coarse row] = fine row (fine level L, coarse L+1), initialised to "missing" = n_fine by k_child_clear
-__global__ void k_child_clear(const LevelSet S) {
-  int lb;
-  const int L = ls_level(S, lb);
-  const size_t i = (size_t)lb * blockDim.x + threadIdx.x;
-  if (i < (size_t)8 * S.lv[L + 1].npad) S.lv[L].child8[i] = S.lv[L].n;
-}
-// ... and the child-slot sort key of every fine row (second radix sort)
-__global__ void k_child(const LevelSet S) {
-  int lb;
-  const int L = ls_level(S, lb);
-  const Level& f = S.lv[L];
-  const Level& c = S.lv[L + 1];
-  const int i = lb * blockDim.x + threadIdx.x;
-  if (i >= f.n) return;
-  {   // i as a Morton row of the fine level
-    const int slot = (int)(f.keys[i] & 7);
-    const int pf = c.perm[f.parentM[i]];
-    f.child8[(size_t)slot * c.npad + pf] = f.perm[i];
-  }
-  {   // i as an internal row of the fine level
-    S.cat_keys[S.off[L] + i] = ((uint64_t)L << S.level_shift) | ((uint64_t)(i >> S.st_shift) << 27) | (f.keys[f.inv[i]] & 7);
-    S.cat_vals[S.off[L] + i] = S.off[L] + i;
-  }
-}
-
-// gmask_down[g] = child slots present in the 16 coarse rows of group g, read back from child8 (one thread per coarse
-// row, a group is 16 consecutive lanes; k_child used to set these bits with up to 128 atomics per word: 84 us)
-__global__ void k_gmask_down(const LevelSet S) {
+// child8[slot][coarse row] = fine row (fine level L, coarse L+1; missing = n_fine) and gmask_down[g] = child slots present
+// in the 16 coarse rows of group g.  One thread per coarse row: its children are consecutive Morton rows of the fine
+// level, in slot order (firstM from the level compaction) -- every entry is written exactly once, nothing is cleared first,
+// and a group is 16 consecutive lanes (ballots, no atomics).
+__global__ void k_child8(const LevelSet S) {
   int lb;
   const int L = ls_level(S, lb);
   const Level& f = S.lv[L];
   const Level& c = S.lv[L + 1];
   const int pf = lb * blockDim.x + threadIdx.x;
   if (pf >= c.npad) return;   // npad is a multiple of 128: whole waves leave together
+  int m = 0, m1 = 0;
+  if (pf < c.n) {
+    const int mc = c.inv[pf];
+    m = S.firstM[L][mc];
+    m1 = mc + 1 < c.n ? S.firstM[L][mc + 1] : f.n;
+  }
   const int lane = threadIdx.x & 63;
   uint32_t word = 0;
 #pragma unroll
   for (int s = 0; s < 8; ++s) {
-    const unsigned long long bal = __ballot(f.child8[(size_t)s * c.npad + pf] != f.n);
+    int v = f.n;
+    if (m < m1 && (int)(f.keys[m] & 7) == s) v = f.perm[m++];
+    f.child8[(size_t)s * c.npad + pf] = v;
+    const unsigned long long bal = __ballot(v != f.n);
     if ((bal >> (lane & 48)) & 0xffffULL) word |= 1u << s;
   }
   if ((lane & 15) == 0) f.gmask_down[pf >> 4] = word;
@@ -482,12 +473,6 @@ __global__ void k_up(const LevelSet S) {
   }
 #pragma unroll
   for (int s = 0; s < 8; ++s) f.up8[(size_t)s * f.npad + v] = (s == slot) ? pf : c.n;
-}
-
-__global__ void k_orig_row(const int* __restrict__ vals_sorted, const int* __restrict__ inv0, int n,
-                           int* orig_row) {
-  const int f = blockIdx.x * blockDim.x + threadIdx.x;
-  if (f < n) orig_row[f] = vals_sorted[inv0[f]];
 }
 
 // ------------------------------------------------------------------------------ host side
@@ -530,7 +515,7 @@ static size_t sort_temp_bytes(int n) { return radix_sort_temp_bytes(n); }
 // phase-1 arrays (sized by the n0 upper bound) and phase-2 tables (sized by the real level sizes)
 struct Phase1 {
   uint64_t *keys_in, *keys[A3D_NUM_LEVELS];
-  int *vals_in, *vals_sorted, *parentM[A3D_NUM_LEVELS - 1], *blocksums, *sizes_dev;
+  int *vals_in, *vals_sorted, *parentM[A3D_NUM_LEVELS - 1], *firstM[A3D_NUM_LEVELS - 1], *blocksums, *sizes_dev;
   void* sort_temp;
   size_t sort_temp_bytes;
 };
@@ -540,6 +525,7 @@ static void carve_phase1(Bump& b, int n0, Phase1& p) {
   p.vals_sorted = b.take<int>(n0);
   for (int L = 0; L < A3D_NUM_LEVELS; ++L) p.keys[L] = b.take<uint64_t>(n0);
   for (int L = 0; L < A3D_NUM_LEVELS - 1; ++L) p.parentM[L] = b.take<int>(n0);
+  for (int L = 0; L < A3D_NUM_LEVELS - 1; ++L) p.firstM[L] = b.take<int>(n0);
   p.blocksums = b.take<int>((size_t)(A3D_NUM_LEVELS - 1) * (n0 / 1024 + 2));
   p.sizes_dev = b.take<int>(kSizesInts);
   p.sort_temp_bytes = sort_temp_bytes(A3D_NUM_LEVELS * n0 + 1024);   // also used for the concatenated per-level row sorts (sum of n_L <= 5 n0)
@@ -550,6 +536,7 @@ struct Phase2Tmp {
   uint64_t *cat_keys, *cat_keys_sorted;
   int *cat_vals, *cat_vals_sorted;
   size_t zero_begin, zero_end;   // workspace byte range of the zero-initialised tables
+  size_t ones_begin, ones_end;   // ... and of the tables that start out as all-ones bytes (empty hash keys, empty grid cells)
 };
 static void carve_phase2(Bump& b, const int* sizes, a3d_scene* sc, Phase2Tmp& t, int64_t grid_cells) {
   for (int L = 0; L < A3D_NUM_LEVELS; ++L) {
@@ -572,14 +559,23 @@ static void carve_phase2(Bump& b, const int* sizes, a3d_scene* sc, Phase2Tmp& t,
   }
   b.off = align256(b.off);
   t.zero_end = b.off;
+  // hash keys of every level (kEmptyKey = all ones) and the level-0 grid (-1 = empty) in one region: one memset instead
+  // of a clearing kernel + a memset; a level 0 that has the grid keeps no hash table (a token 1024 slots)
+  t.ones_begin = b.off;
+  for (int L = 0; L < A3D_NUM_LEVELS; ++L) {
+    Level& lv = sc->lv[L];
+    lv.hmask = (L == 0 && grid_cells > 0 ? 1024u : hash_capacity(lv.n)) - 1;
+    lv.hkeys = b.take<uint64_t>((size_t)lv.hmask + 1);
+  }
+  sc->lv[0].grid = grid_cells > 0 ? b.take<int>((size_t)grid_cells) : nullptr;
+  b.off = align256(b.off);
+  t.ones_end = b.off;
   int tot = 0;
   for (int L = 0; L < A3D_NUM_LEVELS; ++L) {
     Level& lv = sc->lv[L];
     lv.perm = b.take<int>(lv.npad);
     lv.inv = b.take<int>(lv.npad);
     lv.xyzb = b.take<int32_t>((size_t)lv.npad * 4);
-    lv.hmask = hash_capacity(lv.n) - 1;
-    lv.hkeys = b.take<uint64_t>((size_t)lv.hmask + 1);
     lv.hvals = b.take<int>((size_t)lv.hmask + 1);
     lv.nbr27 = b.take<int>((size_t)27 * lv.npad);
     lv.pre27 = b.take<int>(lv.npad / 64 + 1);
@@ -594,7 +590,6 @@ static void carve_phase2(Bump& b, const int* sizes, a3d_scene* sc, Phase2Tmp& t,
     tot += lv.npad;
   }
   sc->orig_row = b.take<int>(sc->lv[0].npad);
-  sc->lv[0].grid = grid_cells > 0 ? b.take<int>((size_t)grid_cells) : nullptr;
   t.cat_keys = b.take<uint64_t>(tot);
   t.cat_keys_sorted = b.take<uint64_t>(tot);
   t.cat_vals = b.take<int>(tot);
@@ -697,16 +692,15 @@ extern "C" int a3d_scene_create(const int32_t* coords4_dev, int64_t n_voxels, vo
                               p.sizes_dev + 5);   // a look-back that gives up reports A3D_ERR_HIP through the error word read below
     if (rc) return rc;
   }
-  k_check_dups<<<nblk(n0, T), T, 0, st>>>(p.keys[0], n0, p.sizes_dev);
-  A3D_LAUNCH_CHECK();
   const int nb = (n0 + 1023) / 1024;
   {
     CoarseOut co;
     for (int L = 0; L < A3D_NUM_LEVELS - 1; ++L) {
       co.keys[L] = p.keys[L + 1];
       co.parentM[L] = p.parentM[L];
+      co.firstM[L] = p.firstM[L];
     }
-    k_heads_count<<<nb, 1024, 0, st>>>(p.keys[0], n0, nb, p.blocksums);
+    k_heads_count<<<nb, 1024, 0, st>>>(p.keys[0], n0, nb, p.blocksums, p.sizes_dev);
     k_heads_scan<<<A3D_NUM_LEVELS - 1, 1024, 0, st>>>(p.blocksums, nb, p.sizes_dev);
     k_heads_write<<<nb, 1024, 0, st>>>(p.keys[0], n0, nb, p.blocksums, co);
     A3D_LAUNCH_CHECK();
@@ -770,7 +764,7 @@ extern "C" int a3d_scene_create(const int32_t* coords4_dev, int64_t n_voxels, vo
   }
   ProfScope prof2(st, A3D_PROF_SCENE_TABLES, 0, 0, 0, 0, n0);
   A3D_HIP_CHECK(hipMemsetAsync((char*)workspace_dev + t.zero_begin, 0, t.zero_end - t.zero_begin, st));
-  if (sc->lv[0].grid) A3D_HIP_CHECK(hipMemsetAsync(sc->lv[0].grid, 0xff, (size_t)grid_cells * sizeof(int), st));   // -1 = empty
+  A3D_HIP_CHECK(hipMemsetAsync((char*)workspace_dev + t.ones_begin, 0xff, t.ones_end - t.ones_begin, st));   // empty keys, grid cells = -1
   LevelSet S;
   memset(&S, 0, sizeof(S));
   S.st_shift = super_tile_shift();
@@ -781,6 +775,8 @@ extern "C" int a3d_scene_create(const int32_t* coords4_dev, int64_t n_voxels, vo
   S.cat_keys = t.cat_keys;
   S.cat_vals = t.cat_vals;
   S.cat_sorted = t.cat_vals_sorted;
+  S.vals_sorted0 = p.vals_sorted;
+  S.orig_row = sc->orig_row;
   S.off[0] = 0;
   for (int L = 0; L < A3D_NUM_LEVELS; ++L) {
     Level& lv = sc->lv[L];
@@ -788,6 +784,7 @@ extern "C" int a3d_scene_create(const int32_t* coords4_dev, int64_t n_voxels, vo
     lv.parentM = L < A3D_NUM_LEVELS - 1 ? p.parentM[L] : nullptr;
     S.lv[L] = lv;
     S.nbrM[L] = t.nbrM[L];
+    if (L < A3D_NUM_LEVELS - 1) S.firstM[L] = p.firstM[L];
     S.off[L + 1] = S.off[L] + lv.n;
   }
   // one launch per kernel for all levels: blocks [blk[L], blk[L+1]) belong to level L
@@ -816,8 +813,6 @@ extern "C" int a3d_scene_create(const int32_t* coords4_dev, int64_t n_voxels, vo
   const int NL = A3D_NUM_LEVELS;
   unsigned g;
   // ---- stage A: hash, neighbours in Morton order, sort keys
-  g = blocks(NL, [&](int L) { return (int64_t)sc->lv[L].hmask + 1; });
-  k_hash_clear<<<g, T, 0, st>>>(S);
   g = blocks(NL, [&](int L) { return (int64_t)sc->lv[L].n; });
   k_hash_insert<<<g, T, 0, st>>>(S);
   k_nbr_morton<<<dim3(g, 27), T, 0, st>>>(S);
@@ -836,22 +831,18 @@ extern "C" int a3d_scene_create(const int32_t* coords4_dev, int64_t n_voxels, vo
   k_xyzb_hashfix<<<g, T, 0, st>>>(S);
   A3D_LAUNCH_CHECK();
   // ---- stage D: stride-2 tables + child-slot sort keys of the fine rows (levels 0..3), second sort, up tables
-  g = blocks(NL - 1, [&](int L) { return (int64_t)8 * sc->lv[L + 1].npad; });
-  k_child_clear<<<g, T, 0, st>>>(S);
-  g = blocks(NL - 1, [&](int L) { return (int64_t)sc->lv[L].n; });
-  k_child<<<g, T, 0, st>>>(S);
+  g = blocks(NL - 1, [&](int L) { return (int64_t)sc->lv[L + 1].npad; });
+  k_child8<<<g, T, 0, st>>>(S);
   A3D_LAUNCH_CHECK();
   {
     int rc = sort_cat(NL - 1, 3);
     if (rc) { delete sc; return rc; }
   }
+  g = blocks(NL - 1, [&](int L) { return (int64_t)sc->lv[L].n; });
   k_perm_from_sorted<<<g, T, 0, st>>>(S, 1);
-  g = blocks(NL - 1, [&](int L) { return (int64_t)sc->lv[L + 1].npad; });
-  k_gmask_down<<<g, T, 0, st>>>(S);
   g = blocks(NL - 1, [&](int L) { return (int64_t)sc->lv[L].npad; });
   k_up<<<g, T, 0, st>>>(S);
   A3D_LAUNCH_CHECK();
-  k_orig_row<<<nblk(n0, T), T, 0, st>>>(p.vals_sorted, sc->lv[0].inv, n0, sc->orig_row);
   k_tile_prefix<<<dim3(NL, 3), 1024, 0, st>>>(S);   // all three mask tables are final here
   A3D_LAUNCH_CHECK();
   *out = sc;
