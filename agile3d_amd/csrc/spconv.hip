@@ -835,20 +835,24 @@ static int launch_dense(const float* X, int ldx, const float* X2, int ldx2, int 
   }
   allow_big_lds();
   const int ngroups = (n + 15) / 16;
-  static int nw = 0, wg_per_cu = 0;
-  if (!nw) {   // measured (80 k rows, 128 -> 128): 4x2 41 us, 8x2 48, 8x1 47, 12x1 46, 6x2 60
+  // workgroup shape by row count.  80 k rows, 128 -> 128: 4x2 41 us, 8x2 48, 8x1 47, 12x1 46, 6x2 60; 1.28 M rows (16-scene
+  // batch), 128 -> 96 / 96 -> 128: 4x2 387 / 366 us, 6x2 461 / 441, 8x2 379 / 364, 12x1 350 / 335 -- the kernel is latency-bound
+  // on its row loads (TCP pending-stall 0.5-0.66 of its active cycles), twelve waves per CU keep more of them in flight; a
+  // 128-register build with sixteen waves per CU measured the same 351 / 334 us and was dropped
+  static int shape_env = -1;
+  if (shape_env < 0) {
     const char* e = getenv("A3D_DENSE_SHAPE");   // "<waves per workgroup><workgroups per CU>", e.g. 42
-    const int v = e ? atoi(e) : 42;
-    nw = v / 10;
-    wg_per_cu = v % 10;
-    if (nw < 1 || nw > 12 || wg_per_cu < 1 || wg_per_cu > 2) nw = 4, wg_per_cu = 2;
+    shape_env = e ? atoi(e) : 0;
   }
+  const int shape = shape_env ? shape_env : (n >= 200000 ? 121 : 42);
+  int nw = shape / 10, wg_per_cu = shape % 10;
+  if (nw < 1 || nw > 12 || wg_per_cu < 1 || wg_per_cu > 2) nw = 4, wg_per_cu = 2;
   static int dbg = -1;
   if (dbg < 0) { const char* e = getenv("A3D_DENSE_DBG"); dbg = e ? atoi(e) : 0; }
-  const int max_grid = 256 * wg_per_cu;
-  const int grid = (ngroups + nw - 1) / nw < max_grid ? (ngroups + nw - 1) / nw : max_grid;
   const size_t lds = (size_t)(cin / 16) * (cout / 16) * 1024;
   ProfScope ps(st, A3D_PROF_DENSE, 0, 1, cin, cout, n, A3D_OP_LINEAR, tag_level, 1);
+  const int max_grid = 256 * wg_per_cu;
+  const int grid = (ngroups + nw - 1) / nw < max_grid ? (ngroups + nw - 1) / nw : max_grid;
 #define A3D_DENSE(NS_, NCT_) \
   k_dense<NS_, NCT_><<<grid, 64 * nw, lds, st>>>(X, ldx, X2, ldx2, n, Wp, scale, shift, res, ldr, relu, Y, ldy, ngroups, \
                                              zero_row, out_map, dbg)
