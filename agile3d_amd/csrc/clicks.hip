@@ -9,10 +9,17 @@
 //
 // The simulator's cost is measure_error_size: for every wrongly labelled point the distance to the
 // nearest point that is NOT in its error cluster (the reference builds the full [other x cluster]
-// torch.cdist matrix per cluster).  Here it is ONE exact brute-force pass for all clusters at once:
+// torch.cdist matrix per cluster).  Here it is an exact brute-force pass for all clusters at once:
 // candidates are wave-uniform, so they stream through the scalar cache as SGPR operands and the inner
 // loop is 9 VALU ops per (query, candidate) with no LDS or vector-memory traffic.
+// Only a cluster's MAXIMUM of these distances (and its first arg-max) is ever used, so the pass is bounded
+// (round 3, exact): (A) the same kernel against every 16th point gives every wrong point an UPPER bound of its
+// distance (a minimum over a subset), (B) the point with the largest upper bound of each cluster gets its exact
+// distance -- a LOWER bound of the cluster's maximum --, (C) only points whose upper bound reaches their cluster's
+// lower bound can be the arg-max (ties included) and go through the full pass.  Every pair distance is the same
+// expression in all three phases, so the comparisons are exact in floating point.
 #include "common.h"
+#include <stdlib.h>
 
 namespace a3d {
 
@@ -21,6 +28,10 @@ constexpr unsigned kInfBits = 0x7f800000u;
 constexpr int kQueriesPerThread = 2;
 constexpr int kNearestBlock = 256;
 constexpr int kNearestSplit = 128;           // candidate chunks (grid.y): enough waves when only a few thousand points are wrong
+constexpr int kSample = 16;                  // phase A: every kSample-th point is a candidate (A3D_CLICK_SAMPLE overrides: 4..64)
+constexpr long long kSmallPairs = 1ll << 30;  // (wrong points) x (points) below which phase A is skipped: the plain pass is ~0.15 ms
+constexpr int kMaxChamp = 1024;              // clusters that get a lower bound (phase B); further ones are not pruned
+constexpr int kChampSplit = 8;
 
 // ---- argmax over the 1+K mask logits of every point (first maximum wins, like torch.argmax) ------
 __global__ void k_argmax_labels(const float* __restrict__ logits, int64_t n, int C, int32_t* __restrict__ pred) {
@@ -78,7 +89,7 @@ __global__ void k_iou_counts(const int32_t* __restrict__ pred, const int64_t* __
 __global__ void k_err_compact(const float* __restrict__ xyz, const int32_t* __restrict__ pred,
                               const int32_t* __restrict__ labels, int64_t n, float4* __restrict__ cand,
                               int32_t* __restrict__ err_rows, unsigned* __restrict__ d2bits,
-                              int* __restrict__ n_err, int* __restrict__ err) {
+                              int* __restrict__ n_err, int* __restrict__ err, float4* __restrict__ samp, int stride) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   bool wrong = false;
   if (i < n) {
@@ -86,7 +97,9 @@ __global__ void k_err_compact(const float* __restrict__ xyz, const int32_t* __re
     if (p < 0 || p > 255 || l < 0 || l > 255) atomicOr(err, 2);
     wrong = p != l;
     const int cid = wrong ? 96 * l + 11 * p : -1;
-    cand[i] = make_float4(xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2], __int_as_float(cid));
+    const float4 c = make_float4(xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2], __int_as_float(cid));
+    cand[i] = c;
+    if (samp && i % stride == 0) samp[i / stride] = c;
   }
   const unsigned long long m = __ballot(wrong);
   const int lane = threadIdx.x & 63;
@@ -100,20 +113,26 @@ __global__ void k_err_compact(const float* __restrict__ xyz, const int32_t* __re
   }
 }
 
-__global__ __launch_bounds__(kNearestBlock) void k_nearest_other(const float4* __restrict__ cand, int64_t n,
+// pts: all points (the queries' coordinates, by row); cand / n: the candidates of this pass (all points, or the sample)
+__global__ __launch_bounds__(kNearestBlock) void k_nearest_other(const float4* __restrict__ pts,
+                                                                 const float4* __restrict__ cand, int64_t n,
                                                                  const int32_t* __restrict__ err_rows,
                                                                  const int* __restrict__ n_err_p,
-                                                                 unsigned* __restrict__ d2bits, int chunk) {
+                                                                 unsigned* __restrict__ d2bits, int chunk,
+                                                                 long long skip_below) {
   const int n_err = *n_err_p;
   const int q0 = blockIdx.x * (kNearestBlock * kQueriesPerThread);
   if (q0 >= n_err) return;
+  // phase A of the bounded pass on a sample with few wrong points: not worth its time -- the upper bounds stay +inf,
+  // every point survives and phase C is the plain pass
+  if (skip_below && (long long)n_err * skip_below < kSmallPairs) return;   // skip_below = number of points (phase A only)
   float qx[kQueriesPerThread], qy[kQueriesPerThread], qz[kQueriesPerThread], best[kQueriesPerThread];
   int qc[kQueriesPerThread];
 #pragma unroll
   for (int u = 0; u < kQueriesPerThread; ++u) {
     const int e = q0 + u * kNearestBlock + threadIdx.x;
     float4 c = make_float4(0.f, 0.f, 0.f, __int_as_float(-2));
-    if (e < n_err) c = cand[err_rows[e]];
+    if (e < n_err) c = pts[err_rows[e]];
     qx[u] = c.x; qy[u] = c.y; qz[u] = c.z; qc[u] = __float_as_int(c.w);
     best[u] = __uint_as_float(kInfBits);
   }
@@ -146,10 +165,88 @@ __global__ void k_cluster_best(const float4* __restrict__ cand, const int32_t* _
                                const int* __restrict__ n_err_p, const unsigned* __restrict__ d2bits,
                                unsigned long long* __restrict__ table) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= *n_err_p) return;
-  const int row = err_rows[e];
-  const int cid = __float_as_int(cand[row].w);
-  atomicMax(&table[cid], ((unsigned long long)d2bits[e] << 32) | (0xffffffffu - (unsigned)row));
+  int cid = -1;
+  unsigned long long key = 0;
+  if (e < *n_err_p) {
+    const int row = err_rows[e];
+    cid = __float_as_int(cand[row].w);
+    key = ((unsigned long long)d2bits[e] << 32) | (0xffffffffu - (unsigned)row);
+  }
+  // one atomic per (wave, cluster) instead of one per point: a sample has a handful of clusters, so tens of thousands of
+  // atomics queued on a few addresses (154 us at 90 k wrong points); the lanes of a wave mostly share one or two clusters
+  unsigned long long todo = __ballot(cid >= 0);
+  while (todo) {
+    const int lead = __builtin_amdgcn_readlane(cid, __builtin_ctzll(todo));
+    const bool mine = cid == lead;
+    unsigned long long k = mine ? key : 0ull;
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+      const unsigned long long other = __shfl_xor(k, o);
+      k = other > k ? other : k;
+    }
+    const unsigned long long members = __ballot(mine);
+    if ((threadIdx.x & 63) == __builtin_ctzll(members)) atomicMax(&table[lead], k);
+    todo &= ~members;
+  }
+}
+
+// ---- the bounded pass (see the head of the file) ---------------------------------------------------------
+// phase B, step 1: the clusters' champions (largest upper bound, from k_cluster_best on the upper bounds) as a list;
+// lbtab[cluster] starts at +inf for a listed cluster, stays 0 (= nothing is pruned) for one that did not fit
+__global__ void k_champ_list(const unsigned long long* __restrict__ table_ub, int2* __restrict__ champ,
+                             int* __restrict__ n_champ, unsigned* __restrict__ lbtab) {
+  const int cid = blockIdx.x * blockDim.x + threadIdx.x;
+  if (cid >= kClusterTable) return;
+  const unsigned long long e = table_ub[cid];
+  if (!e) return;
+  const int slot = atomicAdd(n_champ, 1);
+  if (slot >= kMaxChamp) return;
+  champ[slot] = make_int2(cid, (int)(0xffffffffu - (unsigned)(e & 0xffffffffu)));
+  lbtab[cid] = kInfBits;
+}
+// phase B, step 2: exact distance of every champion = lower bound of its cluster's maximum; block = (champion, candidate range)
+__global__ void __launch_bounds__(256) k_champ_exact(const float4* __restrict__ cand, int64_t n, const int2* __restrict__ champ,
+                                                     const int* __restrict__ n_champ, unsigned* __restrict__ lbtab) {
+  const int c = blockIdx.x;
+  if (c >= min(*n_champ, kMaxChamp)) return;
+  const int2 ch = champ[c];
+  const float4 q = cand[ch.y];
+  const int qc = __float_as_int(q.w);
+  const int64_t per = (n + kChampSplit - 1) / kChampSplit;
+  const int64_t j0 = (int64_t)blockIdx.y * per, j1 = min(j0 + per, n);
+  float best = __uint_as_float(kInfBits);
+  for (int64_t j = j0 + threadIdx.x; j < j1; j += 256) {
+    const float4 cc = cand[j];
+    const float dx = q.x - cc.x, dy = q.y - cc.y, dz = q.z - cc.z;
+    const float d2 = fmaf(dz, dz, fmaf(dy, dy, dx * dx));   // the expression of k_nearest_other: bit-identical pair values
+    best = fminf(best, __float_as_int(cc.w) != qc ? d2 : __uint_as_float(kInfBits));
+  }
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) best = fminf(best, __shfl_xor(best, o));
+  if ((threadIdx.x & 63) == 0) atomicMin(&lbtab[ch.x], __float_as_uint(best));
+}
+// phase C, step 1: the points that can still be their cluster's arg-max
+__global__ void k_survivors(const float4* __restrict__ cand, const int32_t* __restrict__ err_rows,
+                            const int* __restrict__ n_err_p, const unsigned* __restrict__ ub2bits,
+                            const unsigned* __restrict__ lbtab, int32_t* __restrict__ surv_rows,
+                            unsigned* __restrict__ d2s, int* __restrict__ n_surv) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  bool keep = false;
+  int row = 0;
+  if (e < *n_err_p) {
+    row = err_rows[e];
+    keep = ub2bits[e] >= lbtab[__float_as_int(cand[row].w)];   // d2 >= 0: bit order == value order
+  }
+  const unsigned long long m = __ballot(keep);
+  const int lane = threadIdx.x & 63;
+  int base = 0;
+  if (lane == 0 && m) base = atomicAdd(n_surv, __popcll(m));
+  base = __shfl(base, 0);
+  if (keep) {
+    const int slot = base + __popcll(m & ((1ull << lane) - 1));
+    surv_rows[slot] = row;
+    d2s[slot] = kInfBits;
+  }
 }
 
 // ordered compaction of the table (ascending cluster id, like torch.unique)
@@ -224,6 +321,15 @@ struct ClickWs {
   unsigned long long* table;
   int* n_err;
   int* err;
+  // the bounded pass: table_ub / lbtab / counters sit right behind `table` (one memset clears them all)
+  unsigned long long* table_ub;
+  unsigned* lbtab;
+  int *n_surv, *n_champ;
+  int2* champ;
+  float4* samp;
+  int32_t* surv_rows;
+  unsigned* d2s;
+  size_t zero_bytes;   // bytes from `table` on that start out as zeros
   size_t bytes;
 };
 static ClickWs carve_click(void* base, int64_t n) {
@@ -237,9 +343,18 @@ static ClickWs carve_click(void* base, int64_t n) {
   w.table = (unsigned long long*)take((size_t)kClusterTable * 8);
   w.n_err = (int*)take(256);
   w.err = w.n_err ? w.n_err + 1 : nullptr;
+  w.n_surv = w.n_err ? w.n_err + 2 : nullptr;
+  w.n_champ = w.n_err ? w.n_err + 3 : nullptr;
+  w.table_ub = (unsigned long long*)take((size_t)kClusterTable * 8);
+  w.lbtab = (unsigned*)take((size_t)kClusterTable * 4);
+  w.zero_bytes = off;
+  w.champ = (int2*)take((size_t)kMaxChamp * 8);
   w.cand = (float4*)take((size_t)n * 16);
+  w.samp = (float4*)take((size_t)(n / 4 + 8) * 16);   // stride >= 4
   w.err_rows = (int32_t*)take((size_t)n * 4);
   w.d2bits = (unsigned*)take((size_t)n * 4);
+  w.surv_rows = (int32_t*)take((size_t)n * 4);
+  w.d2s = (unsigned*)take((size_t)n * 4);
   w.bytes = off;
   return w;
 }
@@ -313,18 +428,48 @@ extern "C" int a3d_click_clusters(const float* xyz_dev, const int32_t* pred_dev,
     return A3D_ERR_WORKSPACE;
   }
   ProfScope prof(st, A3D_PROF_CLICKS);
-  A3D_HIP_CHECK(hipMemsetAsync(w.table, 0, (size_t)kClusterTable * 8 + 256, st));   // table + counters
+  static int prune = -1;   // A3D_CLICK_PRUNE=0: the plain pass over all points (A/B)
+  if (prune < 0) {
+    const char* e = getenv("A3D_CLICK_PRUNE");
+    prune = e ? atoi(e) : 1;
+  }
+  static int stride = 0;   // A3D_CLICK_SAMPLE: sampling stride of phase A (measurements)
+  if (!stride) {
+    const char* e = getenv("A3D_CLICK_SAMPLE");
+    stride = e ? atoi(e) : kSample;
+    if (stride < 4 || stride > 64) stride = kSample;
+  }
+  const bool bounded = prune && n >= 64 * stride;
+  A3D_HIP_CHECK(hipMemsetAsync(w.table, 0, w.zero_bytes, st));   // tables + counters
   const unsigned nb = (unsigned)((n + 255) / 256);
-  k_err_compact<<<nb, 256, 0, st>>>(xyz_dev, pred_dev, labels_dev, n, w.cand, w.err_rows, w.d2bits, w.n_err, w.err);
+  k_err_compact<<<nb, 256, 0, st>>>(xyz_dev, pred_dev, labels_dev, n, w.cand, w.err_rows, w.d2bits, w.n_err, w.err,
+                                    bounded ? w.samp : nullptr, stride);
   A3D_LAUNCH_CHECK();
   const int per_block = kNearestBlock * kQueriesPerThread;
-  int chunk = (int)((n + kNearestSplit - 1) / kNearestSplit);
-  chunk = (chunk + 3) & ~3;
-  dim3 grid((unsigned)((n + per_block - 1) / per_block), (unsigned)((n + chunk - 1) / chunk));
-  k_nearest_other<<<grid, kNearestBlock, 0, st>>>(w.cand, n, w.err_rows, w.n_err, w.d2bits, chunk);
-  A3D_LAUNCH_CHECK();
-  k_cluster_best<<<nb, 256, 0, st>>>(w.cand, w.err_rows, w.n_err, w.d2bits, w.table);
-  A3D_LAUNCH_CHECK();
+  auto nearest = [&](const float4* cands, int64_t n_cands, const int32_t* rows, const int* n_rows, unsigned* out,
+                     long long skip_below) {
+    int chunk = (int)((n_cands + kNearestSplit - 1) / kNearestSplit);
+    chunk = (chunk + 3) & ~3;
+    dim3 grid((unsigned)((n + per_block - 1) / per_block), (unsigned)((n_cands + chunk - 1) / chunk));
+    k_nearest_other<<<grid, kNearestBlock, 0, st>>>(w.cand, cands, n_cands, rows, n_rows, out, chunk, skip_below);
+  };
+  if (!bounded) {
+    nearest(w.cand, n, w.err_rows, w.n_err, w.d2bits, 0);
+    A3D_LAUNCH_CHECK();
+    k_cluster_best<<<nb, 256, 0, st>>>(w.cand, w.err_rows, w.n_err, w.d2bits, w.table);
+    A3D_LAUNCH_CHECK();
+  } else {
+    const int64_t n_samp = (n + stride - 1) / stride;
+    nearest(w.samp, n_samp, w.err_rows, w.n_err, w.d2bits, (long long)n);                         // A: upper bounds
+    k_cluster_best<<<nb, 256, 0, st>>>(w.cand, w.err_rows, w.n_err, w.d2bits, w.table_ub);        // B: champions ...
+    k_champ_list<<<kClusterTable / 256, 256, 0, st>>>(w.table_ub, w.champ, w.n_champ, w.lbtab);
+    k_champ_exact<<<dim3(kMaxChamp, kChampSplit), 256, 0, st>>>(w.cand, n, w.champ, w.n_champ, w.lbtab);   // ... lower bounds
+    A3D_LAUNCH_CHECK();
+    k_survivors<<<nb, 256, 0, st>>>(w.cand, w.err_rows, w.n_err, w.d2bits, w.lbtab, w.surv_rows, w.d2s, w.n_surv);   // C
+    nearest(w.cand, n, w.surv_rows, w.n_surv, w.d2s, 0);
+    k_cluster_best<<<nb, 256, 0, st>>>(w.cand, w.surv_rows, w.n_surv, w.d2s, w.table);
+    A3D_LAUNCH_CHECK();
+  }
   k_cluster_list<<<1, 1024, 0, st>>>(w.table, pred_dev, labels_dev, out_dev, max_out, n_out_dev, w.err);
   A3D_LAUNCH_CHECK();
   return A3D_OK;

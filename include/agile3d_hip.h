@@ -507,7 +507,10 @@ typedef struct {
 } a3d_click_cluster;
 size_t a3d_click_workspace_bytes(int64_t n);
 /* *n_out_dev = number of clusters (may exceed max_out: only max_out are written), -1 if a label or
- * prediction was outside 0..255. */
+ * prediction was outside 0..255.  The search is exact: only a cluster's largest distance and its first
+ * arg-max are ever used, so wrong points are first bounded from above against every 16th point, each
+ * cluster's best candidate is measured exactly (a lower bound of the cluster's maximum), and only the
+ * points whose upper bound reaches it go through the pass over all points (clicks.hip). */
 int    a3d_click_clusters(const float* xyz_dev, const int32_t* pred_dev, const int32_t* labels_dev,
                           int64_t n, a3d_click_cluster* out_dev, int max_out, int32_t* n_out_dev,
                           void* workspace_dev, size_t workspace_bytes, void* stream);

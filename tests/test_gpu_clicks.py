@@ -173,7 +173,7 @@ def test_argmax_labels_and_click_overwrite():
 @pytest.mark.parametrize("voxels", [80_000, 300_000])
 def test_full_size_scene_vs_kdtree(voxels):
     """BASELINE sizes (configs 2 and 5): 80 k / 300 k voxels, 10 objects, a prediction with large wrong regions.  From
-    32 k points on the simulator runs its pruned search (cell buckets, chunk boxes); the float64 k-d tree is exact."""
+    1 k points on the simulator runs its bounded search (sampled upper bounds, champions, survivors); the float64 k-d tree is exact."""
     sc = make_scene(voxels, seed=0)
     rng = np.random.default_rng(0)
     labels = np.where(sc["labels"] <= 10, sc["labels"], 0).astype(np.int32)
@@ -190,6 +190,65 @@ def test_full_size_scene_vs_kdtree(voxels):
     check_clusters(zero, xyz, np.zeros_like(labels), labels)
     assert pc.error_clusters(t(labels), t(labels), t(xyz)) == []
     assert pc.get_simulated_clicks(t(labels), t(labels), t(xyz), 3, training=False) == (None, None, None, None)
+
+
+def _prune_cases():
+    """Seeded (pred, labels, xyz) triples that stress the bounded search: salt-and-pepper errors (hundreds of tiny clusters),
+    large blobs, everything wrong, sizes around the sampling stride, exact distance ties (points on an integer lattice)."""
+    rng = np.random.default_rng(7)
+    out = []
+    for n, kind in [(1024, "noise"), (1500, "blobs"), (4099, "noise"), (20_011, "blobs"), (20_011, "all_wrong"),
+                    (8192, "lattice")]:
+        xyz = rng.uniform(0, 4, (n, 3)).astype(np.float32)
+        if kind == "lattice":
+            xyz = rng.integers(0, 24, (n, 3)).astype(np.float32) * 0.05
+        labels = (xyz[:, 0] // 1).astype(np.int32) % 5
+        pred = labels.copy()
+        if kind == "noise":
+            m = rng.random(n) < 0.3
+            pred[m] = rng.integers(0, 7, m.sum())
+        elif kind in ("blobs", "lattice"):
+            for _ in range(6):
+                c = xyz[rng.integers(n)]
+                pred[np.linalg.norm(xyz - c, axis=1) < rng.uniform(0.3, 1.5)] = rng.integers(0, 7)
+        elif kind == "all_wrong":
+            pred = (labels + 1 + rng.integers(0, 2, n)).astype(np.int32)
+        out.append((pred.astype(np.int32), labels.astype(np.int32), xyz))
+    return out
+
+
+_PLAIN_SCRIPT = """
+import sys, pickle, torch
+sys.path.insert(0, {root!r}); sys.path.insert(0, {tests!r})
+import test_gpu_clicks as T
+from agile3d_amd import clicks as pc
+res = [pc.error_clusters(*(torch.from_numpy(a).cuda() for a in case)) for case in T._prune_cases()]
+pickle.dump(res, open(sys.argv[1], "wb"))
+"""
+
+
+def test_bounded_search_equals_plain_pass(tmp_path):
+    """The click simulator's bounded search (upper bounds from every 16th point, one exact champion per cluster, full pass
+    for the survivors) against the plain pass over all points in a second interpreter (A3D_CLICK_PRUNE=0): identical cluster
+    lists -- rows and the bits of the error sizes -- and both against the float64 k-d tree."""
+    import pickle, subprocess, sys
+    out = tmp_path / "plain.pkl"
+    env = dict(os.environ, A3D_CLICK_PRUNE="0")
+    subprocess.run([sys.executable, "-c", _PLAIN_SCRIPT.format(root=os.path.dirname(HERE), tests=HERE), str(out)],
+                   check=True, env=env, timeout=600)
+    plain = pickle.load(open(out, "rb"))
+    for (pred, labels, xyz), want in zip(_prune_cases(), plain):
+        got = pc.error_clusters(*(torch.from_numpy(a).cuda() for a in (pred, labels, xyz)))
+        assert len(got) == len(want) and len(got) >= 1
+        for g, w in zip(got, want):
+            assert g["cluster_id"] == w["cluster_id"] and g["row"] == w["row"], (g, w)
+            assert np.float32(g["error_size"]).tobytes() == np.float32(w["error_size"]).tobytes(), (g, w)
+        check_clusters(got, xyz, pred, labels)
+    # one cluster covering the whole sample has no outside point at all: every bound is infinite, nothing is pruned,
+    # and the call fails like the reference does
+    n = 3000
+    with pytest.raises(RuntimeError):
+        pc.error_clusters(torch.full((n,), 3, device="cuda"), torch.full((n,), 2, device="cuda"), torch.rand(n, 3, device="cuda"))
 
 
 def test_bad_inputs_fail_loudly():
