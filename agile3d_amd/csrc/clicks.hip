@@ -163,7 +163,8 @@ __global__ __launch_bounds__(kNearestBlock) void k_nearest_other(const float4* _
 // largest "distance to the nearest outside point" per cluster; ties -> lowest row (torch.where(...)[0][0])
 __global__ void k_cluster_best(const float4* __restrict__ cand, const int32_t* __restrict__ err_rows,
                                const int* __restrict__ n_err_p, const unsigned* __restrict__ d2bits,
-                               unsigned long long* __restrict__ table) {
+                               unsigned long long* __restrict__ table, long long skip_below) {
+  if (skip_below && (long long)*n_err_p * skip_below < kSmallPairs) return;   // phase B of a sample with few wrong points
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   int cid = -1;
   unsigned long long key = 0;
@@ -207,8 +208,8 @@ __global__ void k_champ_list(const unsigned long long* __restrict__ table_ub, in
 // phase B, step 2: exact distance of every champion = lower bound of its cluster's maximum; block = (champion, candidate range)
 __global__ void __launch_bounds__(256) k_champ_exact(const float4* __restrict__ cand, int64_t n, const int2* __restrict__ champ,
                                                      const int* __restrict__ n_champ, unsigned* __restrict__ lbtab) {
-  const int c = blockIdx.x;
-  if (c >= min(*n_champ, kMaxChamp)) return;
+  const int nc = min(*n_champ, kMaxChamp);
+  for (int c = blockIdx.x; c < nc; c += gridDim.x) {
   const int2 ch = champ[c];
   const float4 q = cand[ch.y];
   const int qc = __float_as_int(q.w);
@@ -224,6 +225,7 @@ __global__ void __launch_bounds__(256) k_champ_exact(const float4* __restrict__ 
 #pragma unroll
   for (int o = 32; o >= 1; o >>= 1) best = fminf(best, __shfl_xor(best, o));
   if ((threadIdx.x & 63) == 0) atomicMin(&lbtab[ch.x], __float_as_uint(best));
+  }
 }
 // phase C, step 1: the points that can still be their cluster's arg-max
 __global__ void k_survivors(const float4* __restrict__ cand, const int32_t* __restrict__ err_rows,
@@ -456,18 +458,18 @@ extern "C" int a3d_click_clusters(const float* xyz_dev, const int32_t* pred_dev,
   if (!bounded) {
     nearest(w.cand, n, w.err_rows, w.n_err, w.d2bits, 0);
     A3D_LAUNCH_CHECK();
-    k_cluster_best<<<nb, 256, 0, st>>>(w.cand, w.err_rows, w.n_err, w.d2bits, w.table);
+    k_cluster_best<<<nb, 256, 0, st>>>(w.cand, w.err_rows, w.n_err, w.d2bits, w.table, 0);
     A3D_LAUNCH_CHECK();
   } else {
     const int64_t n_samp = (n + stride - 1) / stride;
     nearest(w.samp, n_samp, w.err_rows, w.n_err, w.d2bits, (long long)n);                         // A: upper bounds
-    k_cluster_best<<<nb, 256, 0, st>>>(w.cand, w.err_rows, w.n_err, w.d2bits, w.table_ub);        // B: champions ...
+    k_cluster_best<<<nb, 256, 0, st>>>(w.cand, w.err_rows, w.n_err, w.d2bits, w.table_ub, (long long)n);   // B: champions ...
     k_champ_list<<<kClusterTable / 256, 256, 0, st>>>(w.table_ub, w.champ, w.n_champ, w.lbtab);
-    k_champ_exact<<<dim3(kMaxChamp, kChampSplit), 256, 0, st>>>(w.cand, n, w.champ, w.n_champ, w.lbtab);   // ... lower bounds
+    k_champ_exact<<<dim3(128, kChampSplit), 256, 0, st>>>(w.cand, n, w.champ, w.n_champ, w.lbtab);   // ... lower bounds
     A3D_LAUNCH_CHECK();
     k_survivors<<<nb, 256, 0, st>>>(w.cand, w.err_rows, w.n_err, w.d2bits, w.lbtab, w.surv_rows, w.d2s, w.n_surv);   // C
     nearest(w.cand, n, w.surv_rows, w.n_surv, w.d2s, 0);
-    k_cluster_best<<<nb, 256, 0, st>>>(w.cand, w.surv_rows, w.n_surv, w.d2s, w.table);
+    k_cluster_best<<<nb, 256, 0, st>>>(w.cand, w.surv_rows, w.n_surv, w.d2s, w.table, 0);
     A3D_LAUNCH_CHECK();
   }
   k_cluster_list<<<1, 1024, 0, st>>>(w.table, pred_dev, labels_dev, out_dev, max_out, n_out_dev, w.err);
