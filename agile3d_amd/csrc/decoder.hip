@@ -3244,15 +3244,70 @@ extern "C" int a3d_decoder_forward_batch(const a3d_decoder_weights* w, const a3d
     if (rc) return rc;
   }
   hipStream_t st = (hipStream_t)stream;
-  // consecutive samples with the same padded query count go through the kernels together
+  // consecutive samples with the same padded query count go through the kernels together; several such groups (the click
+  // rounds of training and of the evaluation protocol: every sample has its own number of objects and clicks, and from 65
+  // queries on a sample runs alone) are independent chains of 20-60 mostly latency-bound launches on their own workspaces:
+  // group g goes on side stream g mod 4 (forked from / joined to the caller's stream with events), group 0 stays on it
+  struct Side {
+    hipStream_t s[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t fork = nullptr, done[4] = {nullptr, nullptr, nullptr, nullptr};
+    bool ok = false, tried = false;
+  };
+  static thread_local Side side;
+  int n_groups = 0;
   for (int i = 0; i < n_samples;) {
     int e = i + 1;
     while (e < n_samples && e - i < kMaxBatchSamples && P[(size_t)e].L.qp == P[(size_t)i].L.qp) ++e;
-    rc = dispatch_decoder(w, &P[(size_t)i], e - i, st);
-    if (rc) return rc;
+    ++n_groups;
     i = e;
   }
-  return A3D_OK;
+  static int side_env = -1;   // A3D_DEC_SIDE=0: every group on the caller's stream (A/B)
+  if (side_env < 0) {
+    const char* e = getenv("A3D_DEC_SIDE");
+    side_env = e ? atoi(e) : 1;
+  }
+  bool use_side = n_groups > 1 && side_env;
+  if (use_side && !side.tried) {
+    side.tried = true;
+    bool ok = hipEventCreateWithFlags(&side.fork, hipEventDisableTiming) == hipSuccess;
+    for (int k = 0; ok && k < 4; ++k)
+      ok = hipStreamCreateWithFlags(&side.s[k], hipStreamNonBlocking) == hipSuccess &&
+           hipEventCreateWithFlags(&side.done[k], hipEventDisableTiming) == hipSuccess;
+    if (!ok) (void)hipGetLastError();
+    side.ok = ok;
+  }
+  use_side = use_side && side.ok;
+  bool used[4] = {false, false, false, false};
+  if (use_side) A3D_HIP_CHECK(hipEventRecord(side.fork, st));
+  int g = 0, rc_all = A3D_OK;
+  for (int i = 0; i < n_samples && rc_all == A3D_OK;) {
+    int e = i + 1;
+    while (e < n_samples && e - i < kMaxBatchSamples && P[(size_t)e].L.qp == P[(size_t)i].L.qp) ++e;
+    hipStream_t gs = st;
+    if (use_side && g > 0) {
+      const int k = (g - 1) & 3;
+      gs = side.s[k];
+      if (!used[k]) {
+        used[k] = true;
+        if (hipStreamWaitEvent(gs, side.fork, 0) != hipSuccess) rc_all = A3D_ERR_HIP;
+      }
+    }
+    if (rc_all == A3D_OK) rc_all = dispatch_decoder(w, &P[(size_t)i], e - i, gs);
+    ++g;
+    i = e;
+  }
+  // join: the caller's stream continues after every side stream's work (also when a later group failed)
+  for (int k = 0; k < 4; ++k)
+    if (used[k]) {
+      if (hipEventRecord(side.done[k], side.s[k]) != hipSuccess || hipStreamWaitEvent(st, side.done[k], 0) != hipSuccess) {
+        (void)hipStreamSynchronize(side.s[k]);
+        if (rc_all == A3D_OK) {
+          set_error("a3d_decoder_forward_batch: joining a side stream failed");
+          rc_all = A3D_ERR_HIP;
+        }
+      }
+    }
+  return rc_all;
 }
 
 extern "C" int a3d_decoder_forward(const a3d_decoder_weights* w, const float* feats128_dev, const float* xyz_dev,

@@ -192,10 +192,11 @@ def test_batch_of_two_equals_two_single_scenes(model_and_sd):
 
 def test_batched_decoder_equals_per_sample_runs(model_and_sd):
     """a3d_decoder_forward_batch: samples with the same padded query count share one launch of each wide kernel per
-    layer (sample table), others go separately.  Four samples -- 14, 22 and 26 queries (the last two share launches),
-    one with 44 -- different object counts: every layer's logits must equal the single-sample results."""
+    layer (sample table), others go separately -- as independent launch chains on side streams, joined to the caller's
+    stream before the call returns.  Five samples -- 14, 22 and 26 queries (the last two share launches), one with 44, one
+    with 85 (two query blocks) -- different object counts: every layer's logits must equal the single-sample results."""
     model, sd = model_and_sd
-    specs = [(2600, 11, 2, 2, 0), (3100, 12, 3, 4, 0), (2800, 13, 4, 3, 4), (3000, 14, 2, 15, 4)]
+    specs = [(2600, 11, 2, 2, 0), (3100, 12, 3, 4, 0), (2800, 13, 4, 3, 4), (3000, 14, 2, 15, 4), (3200, 15, 5, 15, 0)]
     scenes = [make_scene(n, seed=sd_) for n, sd_, *_ in specs]
     clicks = [make_clicks(sc["labels"], sp[2], sp[3], sp[4], seed=sp[1]) for sc, sp in zip(scenes, specs)]
     singles = []
