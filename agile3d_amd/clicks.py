@@ -259,6 +259,81 @@ def get_simulated_clicks_batch(preds, labels, coords, current_num_clicks=None, t
     return out
 
 
+def mean_iou_and_clusters_batch(preds, labels_iou, inverse_maps, labels_qv, coords, n_ids: int = 256):
+    """What one round of the interactive protocol needs from the device, with ONE host synchronisation: the IoU counts of
+    every sample (``mean_iou_scene``, on the caller's stream) and its error clusters (``error_clusters``, on side streams)
+    are launched back to back, their records come back through pinned buffers, then everything is awaited once.  Returns
+    ``(ious, clusters)`` = what ``mean_iou_scene_batch`` and ``error_clusters_batch`` return."""
+    lib = L.load()
+    if not preds:
+        return [], []
+    if len(preds) > 8:      # two samples per side stream from here on: the two-phase round measured the same or better
+        return mean_iou_scene_batch(preds, labels_iou, inverse_maps), error_clusters_batch(preds, labels_qv, coords)
+    dev = preds[0].device
+    cur = torch.cuda.current_stream(dev)
+    ns = len(preds)
+    key = (dev.index, "iou", ns, n_ids)
+    buf = _ws_cache.get(key)
+    if buf is None:
+        buf = _ws_cache[key] = (torch.empty(ns, 3 * n_ids + 1, dtype=torch.int64, device=dev),
+                                torch.empty(ns, 3 * n_ids + 1, dtype=torch.int64).pin_memory())
+    counts, counts_host = buf
+    # the clusters first (on the side streams: the longer chains), then the IoU kernels back to back on the caller's stream
+    pend = []
+    for i in range(ns):
+        pq, lq = _i32(preds[i]), _i32(labels_qv[i])
+        x = coords[i].to(torch.float32).contiguous()
+        if pq.numel() == 0:
+            pend.append(None)
+            continue
+        work, out, host = _cluster_buffers(dev, pq.numel(), slot=1 + i)
+        st = _side(dev, i)
+        st.wait_stream(cur)
+        with torch.cuda.stream(st):
+            _launch_clusters(pq, lq, x, work, out)
+            host.copy_(out, non_blocking=True)
+        pend.append((st, host, (pq, lq, x)))
+    keep = []
+    for i in range(ns):
+        p, l = _i32(preds[i]), _i32(labels_iou[i])
+        inv = None
+        if inverse_maps is not None and inverse_maps[i] is not None:
+            inv = inverse_maps[i].to(device=dev, dtype=torch.int64).contiguous()
+            if inv.numel() != l.numel():
+                raise RuntimeError("iou_counts: inverse_map and labels differ in length")
+        elif p.numel() != l.numel():
+            raise RuntimeError("iou_counts: pred and labels differ in length")
+        keep.append((p, l, inv))
+        L.check(lib.a3d_iou_counts(p.data_ptr(), p.numel(), inv.data_ptr() if inv is not None else None, l.data_ptr(),
+                                   l.numel(), n_ids, counts[i].data_ptr(), _stream(p)), "a3d_iou_counts")
+    counts_host.copy_(counts, non_blocking=True)
+    cur.synchronize()
+    hc = counts_host.numpy()
+    if hc[:, -1].any():
+        raise RuntimeError("iou_counts: inverse_map holds rows outside the prediction")
+    ious = [_mean_iou_from_counts(hc[i, :-1].reshape(3, n_ids).copy()) for i in range(ns)]
+    clusters = []
+    for item in pend:
+        if item is None:
+            clusters.append([])
+            continue
+        item[0].synchronize()
+        clusters.append(_parse_clusters(item[1].numpy()))
+    return ious, clusters
+
+
+def pick_clicks_batch(clusters, labels, coords, current_num_clicks=None, training=True, num_objs=None):
+    """The host half of ``get_simulated_clicks_batch`` for clusters that are already there (sample order: the global
+    ``random`` stream is consumed exactly as by the per-sample loop)."""
+    out = []
+    for i, cl in enumerate(clusters):
+        num_obj = None
+        if training and cl:
+            num_obj = num_objs[i] if num_objs is not None else int((torch.unique(labels[i]) != 0).sum())
+        out.append(_pick_clicks(cl, coords[i], num_obj, current_num_clicks, training))
+    return out
+
+
 def get_simulated_clicks(pred_qv, labels_qv, coords_qv, current_num_clicks=None, training=True):
     """utils/seg.py:177-228.  Same returns: (new_clicks {str(label): [rows]}, click_num,
     new_click_pos {str(label): [xyz tensors]}, new_click_time {str(label): [order]}), or four Nones when

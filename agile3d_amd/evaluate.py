@@ -19,7 +19,7 @@ import os
 import numpy as np
 import torch
 
-from .clicks import argmax_labels, extend_clicks, get_simulated_clicks_batch, mean_iou_scene_batch
+from .clicks import argmax_labels, extend_clicks, mean_iou_and_clusters_batch, pick_clicks_batch
 from .sparse import SparseTensor
 
 
@@ -58,19 +58,19 @@ def Evaluate(model, data_loader, args, device, on_round=None):
                 if current:
                     logits = model.forward_mask(*backbone_out, click_idx=click_idx,
                                                 click_time_idx=click_time_idx)["pred_masks"]
-                # the samples of a batch side by side: one host round trip for the IoU counts, one for the error
-                # clusters (their kernels overlap on side streams); clicks are picked in sample order
+                # the samples of a batch side by side, IoU counts and error clusters behind ONE host round trip (the clusters
+                # do not depend on the IoU; their kernels overlap on side streams); clicks are picked in sample order
                 preds = [torch.zeros(labels[idx].shape[0], dtype=torch.int32, device=device) if current == 0
                          else argmax_labels(logits[idx], click_idx[idx])          # + sparse-gt update
                          for idx in range(n_samples)]
-                ious = mean_iou_scene_batch(preds, labels_full, inverse_map)
+                ious, clusters = mean_iou_and_clusters_batch(preds, labels_full, inverse_map, labels, raw_s)
                 for idx in range(n_samples):
                     iou = ious[idx][0]
                     f.write(f"{instance_counter + idx} {scene_name[idx].replace('scene', '')} {num_obj[idx]} "
                             f"{current / num_obj[idx]} {iou.cpu().numpy()}\n")
                     if on_round is not None:
                         on_round(idx, current, preds[idx], iou, click_idx[idx], click_time_idx[idx])
-                sims = get_simulated_clicks_batch(preds, labels, raw_s, current, training=False)
+                sims = pick_clicks_batch(clusters, labels, raw_s, current, training=False)
                 for idx, (new_clicks, _, _, new_time) in enumerate(sims):
                     if new_clicks is not None:
                         extend_clicks(click_idx[idx], click_time_idx[idx], new_clicks, new_time)
@@ -112,14 +112,16 @@ def EvaluateSingle(model, data_loader, args, device, on_round=None):
                                                 click_time_idx=click_time_idx)["pred_masks"]
                 preds = [torch.zeros(labels[idx].shape[0], dtype=torch.int32, device=device) if current == 0
                          else argmax_labels(logits[idx], click_idx[idx]) for idx in range(n_samples)]
-                ious = mean_iou_scene_batch(preds, labels_full, inverse_map)
+                # IoU counts and error clusters of all samples behind ONE host synchronisation (the clusters do not depend
+                # on the IoU; the clicks are picked afterwards, in sample order, so the random stream is consumed as before)
+                ious, clusters = mean_iou_and_clusters_batch(preds, labels_full, inverse_map, labels, raw_s)
                 for idx in range(n_samples):
                     iou = ious[idx][0]
                     f.write(f"{instance_counter + idx} {scene_name[idx].replace('scene', '')} {object_id[idx]} "
                             f"{current} {iou.cpu().numpy()}\n")
                     if on_round is not None:
                         on_round(idx, current, preds[idx], iou, click_idx[idx], click_time_idx[idx])
-                sims = get_simulated_clicks_batch(preds, labels, raw_s, current, training=False)
+                sims = pick_clicks_batch(clusters, labels, raw_s, current, training=False)
                 for idx, (new_clicks, _, _, new_time) in enumerate(sims):
                     if new_clicks is not None:
                         extend_clicks(click_idx[idx], click_time_idx[idx], new_clicks, new_time)

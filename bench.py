@@ -582,8 +582,8 @@ def main():
                 if rnd:
                     o = model.forward_mask(*r1, click_idx=[eci], click_time_idx=[ect])["pred_masks"][0]
                     pred = pc.argmax_labels(o, eci)
-                pc.mean_iou_scene(pred, lab)
-                new, _, _, nt = pc.get_simulated_clicks(pred, lab, w1, rnd, training=False)
+                _, cl_ = pc.mean_iou_and_clusters_batch([pred], [lab], None, [lab], [w1])     # IoU + error clusters, one host sync
+                new, _, _, nt = pc.pick_clicks_batch(cl_, [lab], [w1], rnd, training=False)[0]
                 if new is not None:
                     pc.extend_clicks(eci, ect, new, nt)
                 torch.cuda.synchronize()
@@ -613,8 +613,8 @@ def main():
                     outs = model.forward_mask(*rB, click_idx=ecis, click_time_idx=ects)["pred_masks"]
                 if rnd:
                     preds = [pc.argmax_labels(outs[b_], ecis[b_]) for b_ in range(len(scenes))]
-                pc.mean_iou_scene_batch(preds, labs)
-                for b_, (new, _, _, nt) in enumerate(pc.get_simulated_clicks_batch(preds, labs, raws, rnd, training=False)):
+                _, cls_ = pc.mean_iou_and_clusters_batch(preds, labs, None, labs, raws)
+                for b_, (new, _, _, nt) in enumerate(pc.pick_clicks_batch(cls_, labs, raws, rnd, training=False)):
                     if new is not None:
                         pc.extend_clicks(ecis[b_], ects[b_], new, nt)
                 torch.cuda.synchronize()
@@ -622,7 +622,7 @@ def main():
                     brounds.append(time.perf_counter() - t0)
             res["eval_rounds_per_s"] = round(len(scenes) / float(np.median(brounds)), 1)
             res["eval_rounds_note"] = (f"{len(scenes)} scenes advance in lock-step (eval_multi_obj.py:114,162-166 with a batch): one "
-                                       "batched forward_mask, then the scenes' label argmax / IoU counts / error clusters side by side (two host round trips per round); scene-rounds per second")
+                                       "batched forward_mask, then the scenes' label argmax / IoU counts / error clusters side by side (one host round trip per round); scene-rounds per second")
         if not args.no_cpu_baseline and not args.steps_only and world == 1:
             res["cpu_baseline"], diff = cpu_baseline(sd, sc, ci, ct, gpu_logits0, gpu_feats0)
             res["parity_vs_oracle"] = diff

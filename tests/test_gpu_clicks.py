@@ -251,6 +251,31 @@ def test_bounded_search_equals_plain_pass(tmp_path):
         pc.error_clusters(torch.full((n,), 3, device="cuda"), torch.full((n,), 2, device="cuda"), torch.rand(n, 3, device="cuda"))
 
 
+def test_one_sync_round_equals_the_two_calls():
+    """mean_iou_and_clusters_batch (IoU counts on the caller's stream, error clusters on side streams, one host
+    synchronisation) returns what mean_iou_scene_batch and error_clusters_batch return, inverse maps included."""
+    rng = np.random.default_rng(3)
+    preds, labs, labs_full, invs, xyzs = [], [], [], [], []
+    for n in (1500, 4097, 2600):
+        xyz = rng.uniform(0, 3, (n, 3)).astype(np.float32)
+        lab = (xyz[:, 0] // 0.75).astype(np.int32)
+        pred = lab.copy()
+        m = rng.random(n) < 0.2
+        pred[m] = rng.integers(0, 5, m.sum())
+        inv = rng.integers(0, n, 2 * n)
+        preds.append(torch.from_numpy(pred).cuda())
+        labs.append(torch.from_numpy(lab).cuda())
+        labs_full.append(torch.from_numpy(lab[inv]).cuda())
+        invs.append(torch.from_numpy(inv).cuda())
+        xyzs.append(torch.from_numpy(xyz).cuda())
+    ious, clusters = pc.mean_iou_and_clusters_batch(preds, labs_full, invs, labs, xyzs)
+    want_iou = pc.mean_iou_scene_batch(preds, labs_full, invs)
+    want_cl = pc.error_clusters_batch(preds, labs, xyzs)
+    assert clusters == want_cl
+    for (a, pa), (b, pb) in zip(ious, want_iou):
+        assert a.numpy().tobytes() == b.numpy().tobytes() and pa == pb
+
+
 def test_bad_inputs_fail_loudly():
     with pytest.raises(RuntimeError):
         pc.error_clusters(torch.zeros(10), torch.zeros(10), torch.zeros(10, 3))          # CPU tensors
