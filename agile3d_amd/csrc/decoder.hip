@@ -3253,7 +3253,10 @@ extern "C" int a3d_decoder_forward_batch(const a3d_decoder_weights* w, const a3d
     hipEvent_t fork = nullptr, done[4] = {nullptr, nullptr, nullptr, nullptr};
     bool ok = false, tried = false;
   };
-  static thread_local Side side;
+  static thread_local Side sides[16];   // per device: a stream belongs to the device that was current when it was made
+  int dev_id = 0;
+  (void)hipGetDevice(&dev_id);
+  Side& side = sides[dev_id & 15];
   int n_groups = 0;
   for (int i = 0; i < n_samples;) {
     int e = i + 1;
