@@ -219,6 +219,7 @@ struct QuerySample {
   int* counts;
   const float* part;             // click-to-scene flash partials of this sample and how many there are
   int n_part;
+  int n_part0;                   // ... in the first layer when it runs on cached keys / values (one per 128-point chunk)
 };
 
 // ---- one batch sample as the fused wide kernels see it (a3d_decoder_forward_batch) ------------------------------
@@ -573,12 +574,12 @@ __global__ void __launch_bounds__(512) k_kv_c2s(const DecSampleDev* __restrict__
 constexpr int kFusedC2SGrid = 256;   // one persistent 8-wave workgroup per CU (128 KB of weights in LDS)
 
 // merge the per-chunk flash partials (m, l, acc[16]) of one (query, head): one wave per pair
-__global__ void __launch_bounds__(64) k_c2s_combine(const QuerySample* __restrict__ qs, int QP) {
+__global__ void __launch_bounds__(64) k_c2s_combine(const QuerySample* __restrict__ qs, int QP, int cached0) {
   const QuerySample& smp = qs[blockIdx.y];
   const int q = blockIdx.x / H, h = blockIdx.x % H, lane = threadIdx.x;
   if (q >= smp.meta->nq) return;
   const float* __restrict__ part = smp.part;
-  const int nchunk = smp.n_part;
+  const int nchunk = cached0 ? smp.n_part0 : smp.n_part;
   float* attn = smp.B.attn;
   float m = kNegBig, l = 0.f, o[DH];
 #pragma unroll
@@ -2778,6 +2779,8 @@ struct Prepared {
   const float *feats, *posenc;
   int n;
   float* logits;
+  float* kv0 = nullptr;   // the scene's cached first-layer keys / values [2][n][128] (a3d_decoder_sample::kv0_dev) and their state
+  int kv0_state = 0;
   // views
   float *bufA, *bufB, *bufC, *bufD, *part;
   unsigned char* labels;
@@ -2947,6 +2950,7 @@ static int run_decoder(const a3d_decoder_weights* w, Prepared* P, int ns, hipStr
       hq[si].counts = p.counts;
       hq[si].part = p.part;
       hq[si].n_part = fuse_c2s ? (p.wg_end - p.wg_begin) * c2s_spw : p.L.nchunk;
+      hq[si].n_part0 = p.L.nchunk;
     }
     A3D_HIP_CHECK(hipMemcpyAsync(qs_dev, hq, sizeof(QuerySample) * ns, hipMemcpyHostToDevice, st));
   }
@@ -2960,7 +2964,26 @@ static int run_decoder(const a3d_decoder_weights* w, Prepared* P, int ns, hipStr
     const a3d_decoder_layer& LW = w->layers[l];
     int rc;
     // ---- click-to-scene
-    if (fuse_c2s) {
+    // first layer on the scene's cached keys / values (a3d_decoder_sample::kv0_dev): K = (feats + pos) Wk^T + bk and
+    // V = feats Wv^T + bv depend on the scene only, the interactive loop runs ~100 passes on it
+    bool cached0 = l == 0;
+    for (int si = 0; si < ns && cached0; ++si) cached0 = P[si].kv0 != nullptr && P[si].kv0_state != 0;
+    if (cached0) {
+      for (int si = 0; si < ns; ++si) {
+        Prepared& p = P[si];
+        float* K0 = p.kv0;
+        float* V0 = p.kv0 + (size_t)p.n * D;
+        if (p.kv0_state == 1) {
+          rc = a3d_linear(p.feats, D, p.posenc, D, p.n, D, D, LW.c2s_wk_packed, nullptr, LW.c2s_in_b + D, nullptr, 0, 0, K0, D, nullptr, 0, st);
+          if (rc) return rc;
+          rc = a3d_linear(p.feats, D, nullptr, 0, p.n, D, D, LW.c2s_wv_packed, nullptr, LW.c2s_in_b + 2 * D, nullptr, 0, 0, V0, D, nullptr, 0, st);
+          if (rc) return rc;
+        }
+        ProfScope ps(st, A3D_PROF_C2S, 0, 0, 0, 0, p.n);
+        k_c2s_attn<QT><<<dim3(p.L.nchunk, nblk), 512, 0, st>>>(K0, V0, p.n, p.B.qproj, p.meta->obj, nullptr, nullptr, p.part, p.L.qp);
+        A3D_LAUNCH_CHECK();
+      }
+    } else if (fuse_c2s) {
       // K / V projections fused in (K, V never reach HBM), all samples in one launch
       ProfScope ps(st, A3D_PROF_C2S, 0, 0, 0, 0, (int)n_total);
       const size_t c2s_lds = (size_t)128 * 1024 + (QT == 4 ? (size_t)QP * 128 * 4 : ((size_t)QP * 132 + 2 * D) * 4);
@@ -3014,7 +3037,7 @@ static int run_decoder(const a3d_decoder_weights* w, Prepared* P, int ns, hipStr
     }
     {   // one workgroup (or chain of query blocks) per sample: blockIdx.y
       ProfScope ps(st, A3D_PROF_QUERY, 0, 0, 0, 0, nq_max);
-      k_c2s_combine<<<dim3(nq_max * H, ns), 64, 0, st>>>(qs_dev, P[0].L.qp);
+      k_c2s_combine<<<dim3(nq_max * H, ns), 64, 0, st>>>(qs_dev, P[0].L.qp, cached0 ? 1 : 0);
       const size_t ql_lds = (size_t)4 * QP * kQLD * 4 + 16;   // four [QP][132] tiles + the word of block_any
       // FFN helper workgroups next to a block's workgroup (A3D_QL_HELPERS = total workgroups per block, 1 = none)
       static int nh_env = -1, v1 = -1;   // A3D_QL_V1=1: the first build of the layer kernel (A/B switch)
@@ -3213,6 +3236,12 @@ static int prepare_sample(const a3d_decoder_weights* w, const a3d_decoder_sample
   P.posenc = posenc_dev;
   P.n = (int)n;
   P.logits = sp.logits_dev;
+  P.kv0 = sp.kv0_dev;
+  P.kv0_state = sp.kv0_dev ? sp.kv0_state : 0;
+  if (P.kv0_state < 0 || P.kv0_state > 2 || ((uintptr_t)sp.kv0_dev & 15)) {
+    set_error("a3d_decoder_forward: bad kv0 cache (state %d)", sp.kv0_state);
+    return A3D_ERR_INVALID;
+  }
   P.bind();
   return A3D_OK;
 }
@@ -3331,5 +3360,7 @@ extern "C" int a3d_decoder_forward(const a3d_decoder_weights* w, const float* fe
   sp.logits_dev = logits_dev;
   sp.workspace_dev = workspace_dev;
   sp.workspace_bytes = workspace_bytes;
+  sp.kv0_dev = nullptr;
+  sp.kv0_state = 0;
   return a3d_decoder_forward_batch(w, &sp, 1, stream);
 }

@@ -339,6 +339,18 @@ class DecoderPack:
         self.gauss_B_ptr = W.gauss_B
 
 
+_KV_MB = None
+
+
+def _kv_cache_mb():
+    """Cap of the per-scene key / value cache of forward_mask in MB (A3D_KV_CACHE_MB, default 4096; 0 = off)."""
+    global _KV_MB
+    if _KV_MB is None:
+        import os
+        _KV_MB = int(os.environ.get("A3D_KV_CACHE_MB", "4096"))
+    return _KV_MB
+
+
 class _SceneState:
     """Everything forward_mask needs from forward_backbone; rides on the returned pcd_features."""
 
@@ -350,6 +362,11 @@ class _SceneState:
         self.minmax = None      # list[Tensor [6]]
         self.engine_id = None
         self.train = False      # produced by the training-mode forward (no inference workspace, aux placeholders)
+        # per-scene cache of the first decoder layer's click-to-scene keys / values (click-independent): allocated and
+        # filled by the SECOND forward_mask on this backbone output, read by every later one
+        self.mask_calls = 0
+        self.kv0 = None         # list[Tensor [2, n_b, 128]]
+        self.kv0_version = None
 
 
 class Engine:
@@ -403,6 +420,7 @@ class Engine:
                 self.decoder = DecoderPack(self.model, self.device)
             self._version_dec = self._weights_version(True)
             self._stale_dec = False
+            self._dec_epoch = getattr(self, "_dec_epoch", 0) + 1     # what a scene's cached keys / values were made with
 
     # ---------------------------------------------------------------- forward_backbone
     def forward_backbone(self, x, raw_coordinates=None):
@@ -581,6 +599,20 @@ class Engine:
         W = self.decoder.W
         n_layers = self.decoder.n_layers
         preds = [[] for _ in range(n_layers)]
+        # The interactive loop calls forward_mask ~100 times on one backbone output (eval_multi_obj.py:112-160): from the
+        # second call on the scene's first-layer keys / values are kept (82 MB per 80 k voxels; A3D_KV_CACHE_MB caps the
+        # total, 0 switches the cache off).  A single call per scene -- the throughput benchmark -- allocates nothing.
+        st.mask_calls += 1
+        kv_state = 0
+        if st.mask_calls >= 2 and _kv_cache_mb() > 0:
+            if st.kv0 is not None and st.kv0_version == self._dec_epoch:
+                kv_state = 2
+            else:
+                total = sum(e - s for s, e in st.ranges) * 2 * 128 * 4
+                if total <= _kv_cache_mb() * (1 << 20):
+                    st.kv0 = [torch.empty((2, e - s, 128), dtype=torch.float32, device=self.device) for s, e in st.ranges]
+                    st.kv0_version = self._dec_epoch
+                    kv_state = 1
         with torch.no_grad():
             # the reference loops over the batch samples (agile3d.py:192); here every sample is described once and
             # the whole batch goes through a3d_decoder_forward_batch (one launch of each wide kernel per layer)
@@ -620,6 +652,7 @@ class Engine:
                 sp.click_time = C.cast(a_times, C.POINTER(C.c_int32))
                 sp.n_clicks, sp.n_objects = nc, K
                 sp.logits_dev, sp.workspace_dev, sp.workspace_bytes = _ptr(logits), _ptr(ws), wsb
+                sp.kv0_dev, sp.kv0_state = (_ptr(st.kv0[b]), kv_state) if kv_state else (None, 0)
                 for l in range(n_layers):
                     preds[l].append(logits[l])
             L.check(lib.a3d_decoder_forward_batch(C.byref(W), samples, len(st.ranges), _stream()),

@@ -71,7 +71,8 @@ class DecoderSample(C.Structure):
     _fields_ = [("feats128_dev", C.c_void_p), ("posenc_dev", C.c_void_p), ("n", C.c_int64),
                 ("click_row", C.POINTER(C.c_int32)), ("click_obj", C.POINTER(C.c_int32)),
                 ("click_time", C.POINTER(C.c_int32)), ("n_clicks", C.c_int32), ("n_objects", C.c_int32),
-                ("logits_dev", C.c_void_p), ("workspace_dev", C.c_void_p), ("workspace_bytes", C.c_size_t)]
+                ("logits_dev", C.c_void_p), ("workspace_dev", C.c_void_p), ("workspace_bytes", C.c_size_t),
+                ("kv0_dev", C.c_void_p), ("kv0_state", C.c_int32)]
 
 
 class ClickCluster(C.Structure):

@@ -562,6 +562,9 @@ def main():
             r1 = model.forward_backbone(SparseTensor(features=f1, coordinates=c1), raw_coordinates=w1)
             t_dec1, _ = wall(lambda: model.forward_mask(*r1, click_idx=[ci], click_time_idx=[ct]), reps=30)
             res["decoder_pass_ms_single"] = round(t_dec1, 4)
+            res["decoder_pass_note"] = ("repeated passes on ONE backbone output, as the interactive loop runs them: from the third pass on "
+                                        "the first layer's click-to-scene keys / values come from the per-scene cache (A3D_KV_CACHE_MB=0 "
+                                        "switches it off); the timed steps of `value` run one pass per fresh scene and never use it")
             # one round of the evaluation protocol (eval_multi_obj.py:112-160) on that scene: forward_mask -> label argmax
             # with the clicked rows overwritten -> IoU -> click simulator -> extend_clicks; median of 20 rounds
             import random as _random

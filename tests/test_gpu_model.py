@@ -221,6 +221,60 @@ def test_batched_decoder_equals_per_sample_runs(model_and_sd):
             assert (g - ref).abs().max().item() <= 1e-4, (b, (g - ref).abs().max().item())
 
 
+def test_scene_cache_of_first_layer_keys_and_values(model_and_sd):
+    """forward_mask keeps the click-independent keys / values of the first layer's click-to-scene attention per scene from
+    its second call on one backbone output (the interactive loop's ~100 passes, eval_multi_obj.py:112-160): the first call
+    (fused kernel), the second (fills the cache) and the later ones (read it) agree, for a batch with a growing click set --
+    20, then 44, then 85 queries (the multi-block path) --, each against a fresh backbone output that has no cache; the
+    cache is dropped when the decoder's weights change."""
+    model, sd = model_and_sd
+    scenes = [make_scene(2700, seed=21), make_scene(3300, seed=22)]
+    coords = []
+    for b, sc in enumerate(scenes):
+        c = sc["coords"].copy()
+        c[:, 0] = b
+        coords.append(c)
+    x = SparseTensor(features=torch.from_numpy(np.concatenate([sc["feats"] for sc in scenes])),
+                     coordinates=torch.from_numpy(np.concatenate(coords)), device="cuda")
+    raw = torch.from_numpy(np.concatenate([sc["raw_xyz"] for sc in scenes])).cuda()
+    r = model.forward_backbone(x, raw_coordinates=raw)
+    st = r[0]._a3d
+    rounds = [(2, 5, 0), (2, 15, 4), (5, 15, 0), (5, 15, 0)]         # (objects, clicks per object, background clicks)
+    for k, (n_obj, per, n_bg) in enumerate(rounds):
+        clicks = [make_clicks(sc["labels"], n_obj, per, n_bg, seed=40 + b) for b, sc in enumerate(scenes)]
+        got = model.forward_mask(*r, click_idx=[c[0] for c in clicks], click_time_idx=[c[1] for c in clicks])
+        fresh = model.forward_backbone(x, raw_coordinates=raw)       # first call on a new scene state: no cache
+        want = model.forward_mask(*fresh, click_idx=[c[0] for c in clicks], click_time_idx=[c[1] for c in clicks])
+        assert fresh[0]._a3d.kv0 is None
+        assert (st.kv0 is None) == (k == 0)
+        for b in range(2):
+            assert (got["pred_masks"][b] - want["pred_masks"][b]).abs().max().item() <= 1e-4, (k, b)
+            for ga, wa in zip(got["aux_outputs"], want["aux_outputs"]):
+                assert (ga["pred_masks"][b] - wa["pred_masks"][b]).abs().max().item() <= 1e-4, (k, b)
+    # new decoder weights: the cached keys / values are stale and must be refilled, not reused
+    eng = model._get_engine()
+    old_epoch = st.kv0_version
+    saved = {name: prm.detach().clone() for name, prm in model.named_parameters() if name.startswith("c2s_attention")}
+    assert saved
+    with torch.no_grad():
+        for name, prm in model.named_parameters():
+            if name in saved:
+                prm.mul_(1.5)
+    eng.mark_stale()
+    clicks = [make_clicks(sc["labels"], 2, 5, 0, seed=40 + b) for b, sc in enumerate(scenes)]
+    got = model.forward_mask(*r, click_idx=[c[0] for c in clicks], click_time_idx=[c[1] for c in clicks])
+    assert st.kv0_version != old_epoch
+    fresh = model.forward_backbone(x, raw_coordinates=raw)
+    want = model.forward_mask(*fresh, click_idx=[c[0] for c in clicks], click_time_idx=[c[1] for c in clicks])
+    for b in range(2):
+        assert (got["pred_masks"][b] - want["pred_masks"][b]).abs().max().item() <= 1e-4
+    with torch.no_grad():                                            # the module-scoped model goes back to its weights
+        for name, prm in model.named_parameters():
+            if name in saved:
+                prm.copy_(saved[name])
+    eng.mark_stale()
+
+
 def test_many_small_samples_in_one_batch(model_and_sd):
     """70 samples: more than one sample table (64 entries) -> the batch is cut into two groups of launches; the
     workgroup shares of tiny samples are clamped to what their few 16-point groups can use."""
