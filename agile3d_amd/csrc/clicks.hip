@@ -89,14 +89,18 @@ __global__ void k_iou_counts(const int32_t* __restrict__ pred, const int64_t* __
 __global__ void k_err_compact(const float* __restrict__ xyz, const int32_t* __restrict__ pred,
                               const int32_t* __restrict__ labels, int64_t n, float4* __restrict__ cand,
                               int32_t* __restrict__ err_rows, unsigned* __restrict__ d2bits,
-                              int* __restrict__ n_err, int* __restrict__ err, float4* __restrict__ samp, int stride) {
+                              int* __restrict__ n_err, int* __restrict__ err, float4* __restrict__ samp, int stride,
+                              int* __restrict__ max_cid) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   bool wrong = false;
+  int my_cid = -1;
   if (i < n) {
     const int p = pred[i], l = labels[i];
-    if (p < 0 || p > 255 || l < 0 || l > 255) atomicOr(err, 2);
-    wrong = p != l;
+    const bool bad = p < 0 || p > 255 || l < 0 || l > 255;   // reported through err (the call fails); never used as a table index
+    if (bad) atomicOr(err, 2);
+    wrong = p != l && !bad;
     const int cid = wrong ? 96 * l + 11 * p : -1;
+    my_cid = cid;
     const float4 c = make_float4(xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2], __int_as_float(cid));
     cand[i] = c;
     if (samp && i % stride == 0) samp[i / stride] = c;
@@ -110,6 +114,13 @@ __global__ void k_err_compact(const float* __restrict__ xyz, const int32_t* __re
     const int slot = base + __popcll(m & ((1ull << lane) - 1));
     err_rows[slot] = (int)i;
     d2bits[slot] = kInfBits;
+  }
+  // the largest cluster id of the sample: k_cluster_list scans the table up to it (a handful of objects -> ids of a few
+  // hundred, not 32 k)
+  if (m) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) my_cid = max(my_cid, __shfl_xor(my_cid, o));
+    if (lane == 0) atomicMax(max_cid, my_cid);
   }
 }
 
@@ -254,8 +265,9 @@ __global__ void k_survivors(const float4* __restrict__ cand, const int32_t* __re
 // ordered compaction of the table (ascending cluster id, like torch.unique)
 __global__ void k_cluster_list(const unsigned long long* __restrict__ table, const int32_t* __restrict__ pred,
                                const int32_t* __restrict__ labels, a3d_click_cluster* __restrict__ out,
-                               int max_out, int32_t* __restrict__ n_out, const int* __restrict__ err) {
-  constexpr int PER = kClusterTable / 1024;
+                               int max_out, int32_t* __restrict__ n_out, const int* __restrict__ err,
+                               const int* __restrict__ max_cid) {
+  const int PER = min(kClusterTable / 1024, *max_cid / 1024 + 1);   // ids per thread: up to the largest one present
   __shared__ int sums[1024];
   const int t = threadIdx.x;
   int cnt = 0;
@@ -326,7 +338,7 @@ struct ClickWs {
   // the bounded pass: table_ub / lbtab / counters sit right behind `table` (one memset clears them all)
   unsigned long long* table_ub;
   unsigned* lbtab;
-  int *n_surv, *n_champ;
+  int *n_surv, *n_champ, *max_cid;
   int2* champ;
   float4* samp;
   int32_t* surv_rows;
@@ -347,6 +359,7 @@ static ClickWs carve_click(void* base, int64_t n) {
   w.err = w.n_err ? w.n_err + 1 : nullptr;
   w.n_surv = w.n_err ? w.n_err + 2 : nullptr;
   w.n_champ = w.n_err ? w.n_err + 3 : nullptr;
+  w.max_cid = w.n_err ? w.n_err + 4 : nullptr;
   w.table_ub = (unsigned long long*)take((size_t)kClusterTable * 8);
   w.lbtab = (unsigned*)take((size_t)kClusterTable * 4);
   w.zero_bytes = off;
@@ -445,7 +458,7 @@ extern "C" int a3d_click_clusters(const float* xyz_dev, const int32_t* pred_dev,
   A3D_HIP_CHECK(hipMemsetAsync(w.table, 0, w.zero_bytes, st));   // tables + counters
   const unsigned nb = (unsigned)((n + 255) / 256);
   k_err_compact<<<nb, 256, 0, st>>>(xyz_dev, pred_dev, labels_dev, n, w.cand, w.err_rows, w.d2bits, w.n_err, w.err,
-                                    bounded ? w.samp : nullptr, stride);
+                                    bounded ? w.samp : nullptr, stride, w.max_cid);
   A3D_LAUNCH_CHECK();
   const int per_block = kNearestBlock * kQueriesPerThread;
   auto nearest = [&](const float4* cands, int64_t n_cands, const int32_t* rows, const int* n_rows, unsigned* out,
@@ -472,7 +485,7 @@ extern "C" int a3d_click_clusters(const float* xyz_dev, const int32_t* pred_dev,
     k_cluster_best<<<nb, 256, 0, st>>>(w.cand, w.surv_rows, w.n_surv, w.d2s, w.table, 0);
     A3D_LAUNCH_CHECK();
   }
-  k_cluster_list<<<1, 1024, 0, st>>>(w.table, pred_dev, labels_dev, out_dev, max_out, n_out_dev, w.err);
+  k_cluster_list<<<1, 1024, 0, st>>>(w.table, pred_dev, labels_dev, out_dev, max_out, n_out_dev, w.err, w.max_cid);
   A3D_LAUNCH_CHECK();
   return A3D_OK;
 }
