@@ -105,22 +105,37 @@ __global__ void k_err_compact(const float* __restrict__ xyz, const int32_t* __re
     cand[i] = c;
     if (samp && i % stride == 0) samp[i / stride] = c;
   }
+  // one pair of atomics per WORKGROUP (the waves' counts and maxima meet in LDS): a sample's thousands of waves would queue
+  // on the two counter words otherwise (58 us at 300 k points, an order of magnitude above the kernel's memory time)
+  __shared__ int wcnt[4], wmax[4], wbase[4];
   const unsigned long long m = __ballot(wrong);
-  const int lane = threadIdx.x & 63;
-  int base = 0;
-  if (lane == 0 && m) base = atomicAdd(n_err, __popcll(m));
-  base = __shfl(base, 0);
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) my_cid = max(my_cid, __shfl_xor(my_cid, o));
+  if (lane == 0) {
+    wcnt[wv] = __popcll(m);
+    wmax[wv] = my_cid;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int tot = wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
+    int b = 0;
+    if (tot) {
+      b = atomicAdd(n_err, tot);
+      // the largest cluster id of the sample: k_cluster_list scans the table up to it (a handful of objects -> ids of a
+      // few hundred, not 32 k)
+      atomicMax(max_cid, max(max(wmax[0], wmax[1]), max(wmax[2], wmax[3])));
+    }
+    wbase[0] = b;
+    wbase[1] = b + wcnt[0];
+    wbase[2] = b + wcnt[0] + wcnt[1];
+    wbase[3] = b + wcnt[0] + wcnt[1] + wcnt[2];
+  }
+  __syncthreads();
   if (wrong) {
-    const int slot = base + __popcll(m & ((1ull << lane) - 1));
+    const int slot = wbase[wv] + __popcll(m & ((1ull << lane) - 1));
     err_rows[slot] = (int)i;
     d2bits[slot] = kInfBits;
-  }
-  // the largest cluster id of the sample: k_cluster_list scans the table up to it (a handful of objects -> ids of a few
-  // hundred, not 32 k)
-  if (m) {
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) my_cid = max(my_cid, __shfl_xor(my_cid, o));
-    if (lane == 0) atomicMax(max_cid, my_cid);
   }
 }
 

@@ -26,7 +26,10 @@ if os.environ.get("A3D_POISON", "0") == "1":
             if t.is_floating_point():
                 t.fill_(float("nan"))
             elif t.dtype != torch.bool:
-                t.view(torch.uint8).fill_(255) if t.is_contiguous() else None
+                if t.dim() == 0:               # (torch's DataLoader makes a 0-d int64: no byte view of that)
+                    t.fill_(-1)
+                elif t.is_contiguous():
+                    t.view(torch.uint8).fill_(255)
         return t
 
     torch.empty = lambda *a, **k: _poison(_empty(*a, **k))
