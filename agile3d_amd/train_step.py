@@ -14,6 +14,7 @@ from __future__ import annotations
 import copy
 import os
 import random
+import sys
 import time
 
 import numpy as np
@@ -94,18 +95,34 @@ def _train_one_step(model, criterion, optimizer, batch, device, max_norm):
     dec_in = eng.decoder_inputs_batch(pcd, raw_coords, ranges)
     pos_enc = dec_in[3][4][0]
     raw_s = [raw_coords[s:e] for (s, e) in ranges]
+    fine = timing == "2"                      # A3D_TRAIN_TIMING=2: the click rounds by part (device-synchronised: slower)
+    parts = [0.0, 0.0, 0.0, 0.0]
+
+    def lap(i, t0):
+        if fine:
+            torch.cuda.synchronize()
+            parts[i] += time.perf_counter() - t0
+        return time.perf_counter()
     for it in range(num_forward_iters + 1):
+        t0 = lap(3, time.perf_counter()) if fine else 0.0
         if it:                                 # one batched decoder pass for all samples (5 launches per layer)
             out = eng.forward_mask(*dec_in, click_idx=click_idx, click_time_idx=click_time_idx)
+        t0 = lap(0, t0)
         # argmax + "update prediction with sparse gt" (engine.py:96-101) in one kernel instead of 1 + K torch ops; then the
         # samples' error clusters side by side (one host round trip per round, not one per sample), clicks in sample order
         preds = [torch.zeros(e - s, device=device) if it == 0 else argmax_labels(out["pred_masks"][idx], click_idx[idx])
                  for idx, (s, e) in enumerate(ranges)]
+        t0 = lap(1, t0)
         sims = get_simulated_clicks_batch(preds, labels_new, raw_s, it, training=True, num_objs=num_objs)
+        t0 = lap(2, t0)
         for idx, (new_clicks, _, _, new_time) in enumerate(sims):
             if new_clicks is not None:
                 click_idx[idx], click_time_idx[idx] = extend_clicks(click_idx[idx], click_time_idx[idx], new_clicks,
                                                                     new_time)
+    if fine:
+        os.write(2, ("click rounds by part: decoder passes %.1f ms, argmax %.1f ms, clusters + clicks %.1f ms, host between %.1f ms; "
+                     "queries at the end %s\n" % (1e3 * parts[0], 1e3 * parts[1], 1e3 * parts[2], 1e3 * parts[3],
+                                                    [sum(len(v) for v in c.values()) + 10 for c in click_idx])).encode())
     model.train()
     mark(f"click simulation ({num_forward_iters} decoder rounds)")
 
