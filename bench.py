@@ -625,7 +625,9 @@ def main():
                     brounds.append(time.perf_counter() - t0)
             res["eval_rounds_per_s"] = round(len(scenes) / float(np.median(brounds)), 1)
             res["eval_rounds_note"] = (f"{len(scenes)} scenes advance in lock-step (eval_multi_obj.py:114,162-166 with a batch): one "
-                                       "batched forward_mask, then the scenes' label argmax / IoU counts / error clusters side by side (one host round trip per round); scene-rounds per second")
+                                       "batched forward_mask, then the scenes' label argmax / IoU counts / error clusters side by side ("
+                                       + ("one host round trip" if len(scenes) <= 8 else "two host round trips: more than eight samples")
+                                       + " per round); scene-rounds per second")
         if not args.no_cpu_baseline and not args.steps_only and world == 1:
             res["cpu_baseline"], diff = cpu_baseline(sd, sc, ci, ct, gpu_logits0, gpu_feats0)
             res["parity_vs_oracle"] = diff
