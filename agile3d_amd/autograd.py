@@ -33,8 +33,13 @@ class BackboneFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, d_out):
         h = ctx.holder
+        if getattr(h, "released", False):
+            raise RuntimeError("the backbone tape was released by the first backward through it: a second backward "
+                               "(retain_graph=True, or two losses back-propagated separately) is not supported -- sum the "
+                               "losses and call backward once")
         grads = h.tape.backward(d_out.contiguous())
         h.tape.release()                     # torch runs a node's backward once: free the activations now (tape <-> closure cycle)
+        h.released = True
         return (None,) + tuple(grads.get(n) for n in h.names)
 
 
@@ -49,8 +54,13 @@ class DecoderFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, *d_logits):
         h = ctx.holder
+        if getattr(h, "released", False):
+            raise RuntimeError("the decoder tape was released by the first backward through it: a second backward "
+                               "(retain_graph=True, or two losses back-propagated separately) is not supported -- sum the "
+                               "losses and call backward once")
         grads, d_pcd = h.tape.backward([None if g is None else g.contiguous() for g in d_logits])
         h.tape.release()
+        h.released = True
         return (None, d_pcd) + tuple(grads.get(n) for n in h.names)
 
 

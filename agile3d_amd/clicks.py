@@ -197,27 +197,31 @@ def error_clusters_batch(preds, labels, coords, max_streams: int = 8):
         return []
     dev = preds[0].device
     cur = torch.cuda.current_stream(dev)
-    pend = []
-    for i, (pr, lb, xyz) in enumerate(zip(preds, labels, coords)):
-        p, l = _i32(pr), _i32(lb)
-        x = xyz.to(torch.float32).contiguous()
-        if p.numel() == 0:
-            pend.append(None)
-            continue
-        work, out, host = _cluster_buffers(dev, p.numel(), slot=1 + i)
-        st = _side(dev, i % max_streams)
-        st.wait_stream(cur)
-        with torch.cuda.stream(st):
-            _launch_clusters(p, l, x, work, out)
-            host.copy_(out, non_blocking=True)
-        pend.append((st, host, (p, l, x)))       # the inputs stay referenced until the stream is drained
-    res = []
-    for item in pend:
-        if item is None:
-            res.append([])
-            continue
-        item[0].synchronize()
-        res.append(_parse_clusters(item[1].numpy()))
+    pend, used, res = [], [], []
+    try:                                         # every side stream is drained before ANY exit (see mean_iou_and_clusters_batch)
+        for i, (pr, lb, xyz) in enumerate(zip(preds, labels, coords)):
+            p, l = _i32(pr), _i32(lb)
+            x = xyz.to(torch.float32).contiguous()
+            if p.numel() == 0:
+                pend.append(None)
+                continue
+            work, out, host = _cluster_buffers(dev, p.numel(), slot=1 + i)
+            st = _side(dev, i % max_streams)
+            st.wait_stream(cur)
+            used.append(st)
+            with torch.cuda.stream(st):
+                _launch_clusters(p, l, x, work, out)
+                host.copy_(out, non_blocking=True)
+            pend.append((st, host, (p, l, x)))       # the inputs stay referenced until the stream is drained
+        for item in pend:
+            if item is None:
+                res.append([])
+                continue
+            item[0].synchronize()
+            res.append(_parse_clusters(item[1].numpy()))
+    finally:
+        for st in used:
+            st.synchronize()
     return res
 
 
@@ -280,45 +284,52 @@ def mean_iou_and_clusters_batch(preds, labels_iou, inverse_maps, labels_qv, coor
     counts, counts_host = buf
     # the clusters first (on the side streams: the longer chains), then the IoU kernels back to back on the caller's stream
     pend = []
-    for i in range(ns):
-        pq, lq = _i32(preds[i]), _i32(labels_qv[i])
-        x = coords[i].to(torch.float32).contiguous()
-        if pq.numel() == 0:
-            pend.append(None)
-            continue
-        work, out, host = _cluster_buffers(dev, pq.numel(), slot=1 + i)
-        st = _side(dev, i)
-        st.wait_stream(cur)
-        with torch.cuda.stream(st):
-            _launch_clusters(pq, lq, x, work, out)
-            host.copy_(out, non_blocking=True)
-        pend.append((st, host, (pq, lq, x)))
-    keep = []
-    for i in range(ns):
-        p, l = _i32(preds[i]), _i32(labels_iou[i])
-        inv = None
-        if inverse_maps is not None and inverse_maps[i] is not None:
-            inv = inverse_maps[i].to(device=dev, dtype=torch.int64).contiguous()
-            if inv.numel() != l.numel():
-                raise RuntimeError("iou_counts: inverse_map and labels differ in length")
-        elif p.numel() != l.numel():
-            raise RuntimeError("iou_counts: pred and labels differ in length")
-        keep.append((p, l, inv))
-        L.check(lib.a3d_iou_counts(p.data_ptr(), p.numel(), inv.data_ptr() if inv is not None else None, l.data_ptr(),
-                                   l.numel(), n_ids, counts[i].data_ptr(), _stream(p)), "a3d_iou_counts")
-    counts_host.copy_(counts, non_blocking=True)
-    cur.synchronize()
-    hc = counts_host.numpy()
-    if hc[:, -1].any():
-        raise RuntimeError("iou_counts: inverse_map holds rows outside the prediction")
-    ious = [_mean_iou_from_counts(hc[i, :-1].reshape(3, n_ids).copy()) for i in range(ns)]
-    clusters = []
-    for item in pend:
-        if item is None:
-            clusters.append([])
-            continue
-        item[0].synchronize()
-        clusters.append(_parse_clusters(item[1].numpy()))
+    used = []                # side streams with work in flight: drained before ANY exit (an error would otherwise drop the
+    try:                     # last references to buffers kernels are still reading, and the cached work buffers are reused)
+        for i in range(ns):
+            pq, lq = _i32(preds[i]), _i32(labels_qv[i])
+            x = coords[i].to(torch.float32).contiguous()
+            if pq.numel() == 0:
+                pend.append(None)
+                continue
+            work, out, host = _cluster_buffers(dev, pq.numel(), slot=1 + i)
+            st = _side(dev, i)
+            st.wait_stream(cur)
+            used.append(st)
+            with torch.cuda.stream(st):
+                _launch_clusters(pq, lq, x, work, out)
+                host.copy_(out, non_blocking=True)
+            pend.append((st, host, (pq, lq, x)))
+        keep = []
+        for i in range(ns):
+            p, l = _i32(preds[i]), _i32(labels_iou[i])
+            inv = None
+            if inverse_maps is not None and inverse_maps[i] is not None:
+                inv = inverse_maps[i].to(device=dev, dtype=torch.int64).contiguous()
+                if inv.numel() != l.numel():
+                    raise RuntimeError("iou_counts: inverse_map and labels differ in length")
+            elif p.numel() != l.numel():
+                raise RuntimeError("iou_counts: pred and labels differ in length")
+            keep.append((p, l, inv))
+            L.check(lib.a3d_iou_counts(p.data_ptr(), p.numel(), inv.data_ptr() if inv is not None else None, l.data_ptr(),
+                                       l.numel(), n_ids, counts[i].data_ptr(), _stream(p)), "a3d_iou_counts")
+        counts_host.copy_(counts, non_blocking=True)
+        cur.synchronize()
+        hc = counts_host.numpy()
+        if hc[:, -1].any():
+            raise RuntimeError("iou_counts: inverse_map holds rows outside the prediction")
+        ious = [_mean_iou_from_counts(hc[i, :-1].reshape(3, n_ids).copy()) for i in range(ns)]
+        clusters = []
+        for item in pend:
+            if item is None:
+                clusters.append([])
+                continue
+            item[0].synchronize()
+            clusters.append(_parse_clusters(item[1].numpy()))
+    finally:
+        for st in used:
+            st.synchronize()
+        cur.synchronize()
     return ious, clusters
 
 

@@ -604,15 +604,21 @@ class Engine:
         # total, 0 switches the cache off).  A single call per scene -- the throughput benchmark -- allocates nothing.
         st.mask_calls += 1
         kv_state = 0
+        kv_fill = None
+        # what the cached keys / values were made from: the decoder pack AND the feature rows (a tensor swapped or
+        # written in place between two calls must not be served stale keys)
+        F_ = pcd_features.F
+        kv_key = (self._dec_epoch, F_.data_ptr(), int(F_._version), tuple(st.ranges))
         if st.mask_calls >= 2 and _kv_cache_mb() > 0:
-            if st.kv0 is not None and st.kv0_version == self._dec_epoch:
+            if st.kv0 is not None and st.kv0_version == kv_key:
                 kv_state = 2
             else:
+                st.kv0, st.kv0_version = None, None
                 total = sum(e - s for s, e in st.ranges) * 2 * 128 * 4
                 if total <= _kv_cache_mb() * (1 << 20):
-                    st.kv0 = [torch.empty((2, e - s, 128), dtype=torch.float32, device=self.device) for s, e in st.ranges]
-                    st.kv0_version = self._dec_epoch
+                    kv_fill = [torch.empty((2, e - s, 128), dtype=torch.float32, device=self.device) for s, e in st.ranges]
                     kv_state = 1
+        kv_bufs = st.kv0 if kv_state == 2 else kv_fill
         with torch.no_grad():
             # the reference loops over the batch samples (agile3d.py:192); here every sample is described once and
             # the whole batch goes through a3d_decoder_forward_batch (one launch of each wide kernel per layer)
@@ -652,11 +658,17 @@ class Engine:
                 sp.click_time = C.cast(a_times, C.POINTER(C.c_int32))
                 sp.n_clicks, sp.n_objects = nc, K
                 sp.logits_dev, sp.workspace_dev, sp.workspace_bytes = _ptr(logits), _ptr(ws), wsb
-                sp.kv0_dev, sp.kv0_state = (_ptr(st.kv0[b]), kv_state) if kv_state else (None, 0)
+                sp.kv0_dev, sp.kv0_state = (_ptr(kv_bufs[b]), kv_state) if kv_state else (None, 0)
                 for l in range(n_layers):
                     preds[l].append(logits[l])
-            L.check(lib.a3d_decoder_forward_batch(C.byref(W), samples, len(st.ranges), _stream()),
-                    "a3d_decoder_forward_batch")
+            try:
+                L.check(lib.a3d_decoder_forward_batch(C.byref(W), samples, len(st.ranges), _stream()),
+                        "a3d_decoder_forward_batch")
+            except Exception:
+                st.kv0, st.kv0_version = None, None     # a failed call leaves no cache behind (filled or being read)
+                raise
+            if kv_state == 1:                           # stamped valid only once the fill has been issued without an error
+                st.kv0, st.kv0_version = kv_fill, kv_key
         out = {"pred_masks": preds[-1], "backbone_features": pcd_features}
         if self.model.aux:
             out["aux_outputs"] = [{"pred_masks": p} for p in preds[:-1]]

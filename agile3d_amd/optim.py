@@ -180,17 +180,54 @@ class OverlappedAllReduce:
     memory and reduced by gloo's thread.  Results do not depend on the bucket layout for two ranks (a sum of two
     numbers has one order); for more ranks a ring's order per element follows the layout, like any bucketed DDP."""
 
-    def __init__(self, group=None, bucket_bytes: int = 32 << 20):
+    _bucket_groups = {}      # parent group -> the communicator the buckets travel on (created once, collectively)
+    _checked = set()         # (group, key-list digest) pairs every rank has already agreed on
+
+    def __init__(self, group=None, bucket_bytes: int = 32 << 20, expected=None, single_rank: bool = False):
+        """``expected``: {name: numel} of every gradient this iteration will hand over (the same on every rank: the
+        bucket layout follows the order of ``add`` calls).  Its digest is all-gathered ONCE per process group, so ranks
+        that disagree fail with an error instead of hanging inside a mis-sized collective; ``add`` refuses unknown
+        names and ``finish`` refuses to wait when one is missing.  ``single_rank``: run the collectives even in a
+        world of one rank (exercises the RCCL path -- communicator, its stream, ordering -- on a single-GPU box)."""
         import torch.distributed as dist
-        self.group, self.bucket_bytes = group, bucket_bytes
-        self.active = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
-        self.world = dist.get_world_size(group) if self.active else 1
+        self.bucket_bytes = bucket_bytes
+        up = dist.is_available() and dist.is_initialized()
+        self.world = dist.get_world_size(group) if up else 1
+        self.active = up and (self.world > 1 or single_rank)
+        self.parent = group
+        self.group = group
+        self.expected = dict(expected) if expected is not None else None
+        self.seen = set()
         self.gloo = self.active and dist.get_backend(group) == "gloo"
         self.pending, self.pending_bytes, self.flights = [], 0, []
+        if self.active:
+            # the buckets get their own communicator: SyncBN's blocking all-reduces of the next iteration's forward (and
+            # any other collective of the default group) then do not queue behind them on one RCCL stream
+            key = id(group) if group is not None else None
+            if key not in OverlappedAllReduce._bucket_groups:
+                OverlappedAllReduce._bucket_groups[key] = dist.new_group(ranks=dist.get_process_group_ranks(group)
+                                                                         if group is not None else None)
+            self.group = OverlappedAllReduce._bucket_groups[key]
+            if self.expected is not None:
+                import hashlib
+                digest = hashlib.sha256(repr(sorted(self.expected.items())).encode()).hexdigest()
+                if (key, digest) not in OverlappedAllReduce._checked:
+                    got = [None] * self.world
+                    dist.all_gather_object(got, digest, group=group)
+                    if any(d != digest for d in got):
+                        raise RuntimeError("OverlappedAllReduce: the ranks disagree on the list of gradients "
+                                           f"(digests {sorted(set(got))}); every rank must hand over the same tensors")
+                    OverlappedAllReduce._checked.add((key, digest))
 
     def add(self, name, g):
         if not self.active:
             return
+        if self.expected is not None:
+            if name not in self.expected or self.expected[name] != g.numel():
+                raise RuntimeError(f"OverlappedAllReduce.add: unexpected gradient {name!r} ({g.numel()} elements)")
+            if name in self.seen:
+                raise RuntimeError(f"OverlappedAllReduce.add: gradient {name!r} handed over twice")
+        self.seen.add(name)
         self.pending.append((name, g))
         self.pending_bytes += g.numel() * 4
         if self.pending_bytes >= self.bucket_bytes:
@@ -208,6 +245,10 @@ class OverlappedAllReduce:
 
     def finish(self, grads: dict):
         """Wait for every bucket and write the averaged gradients into ``grads`` (in place where the tensor is there)."""
+        if self.active and self.expected is not None and len(self.seen) != len(self.expected):
+            missing = sorted(set(self.expected) - self.seen)
+            raise RuntimeError(f"OverlappedAllReduce.finish: {len(missing)} expected gradients were never handed over "
+                               f"(first: {missing[:3]}); the other ranks' buckets would not match")
         self.flush()
         for items, flat, buf, work in self.flights:
             work.wait()

@@ -23,9 +23,11 @@ def timed_steps(step, steps: int, world: int, device, sync=None, own=None):
     return the MAX over ranks in seconds (the contract of bench.py).  `own` (a list) receives this
     rank's own time before the MAX."""
     import torch.distributed as dist
+    # a process group at world size 1 (bench.py's RCCL check on a one-GPU box) goes through the same barriers / MAX
+    lined_up = world > 1 or (dist.is_available() and dist.is_initialized())
     sync = sync or (torch.cuda.synchronize if device.type == "cuda" else (lambda: None))
     sync()
-    if world > 1:
+    if lined_up:
         dist.barrier()
     sync()
     t0 = time.perf_counter()
@@ -33,13 +35,13 @@ def timed_steps(step, steps: int, world: int, device, sync=None, own=None):
     for _ in range(steps):
         out = step()
     sync()
-    if world > 1:
+    if lined_up:
         dist.barrier()
     sync()
     dt = time.perf_counter() - t0
     if own is not None:
         own.append(dt)
-    if world > 1:
+    if lined_up:
         t = torch.tensor([dt], dtype=torch.float64, device=device if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())

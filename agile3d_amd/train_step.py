@@ -153,7 +153,9 @@ def _train_one_step(model, criterion, optimizer, batch, device, max_norm):
     # ---- data-parallel average (engine.py runs under DDP: main.py:115-127), overlapped with the backbone backward: the
     # decoder's gradients are final here, the U-Net's become final from the head down to the stem
     from .optim import OverlappedAllReduce
-    reducer = OverlappedAllReduce(bucket_bytes=int(float(os.environ.get("A3D_DP_BUCKET_MB", "32")) * (1 << 20)))
+    reducer = OverlappedAllReduce(bucket_bytes=int(float(os.environ.get("A3D_DP_BUCKET_MB", "32")) * (1 << 20)),
+                                  expected={k: p.numel() for k, p in model.named_parameters() if p.requires_grad},
+                                  single_rank=os.environ.get("A3D_DP_SINGLE_RANK", "0") == "1")
     for k in sorted(grads):
         reducer.add(k, grads[k])
     reducer.flush()

@@ -350,7 +350,10 @@ def main():
     dev = torch.device("cuda", local_rank)
     numa = pin_to_gpu_numa_node(local_rank) if world > 1 else None
     ranks_seen = 1
-    if world > 1:
+    # A3D_BENCH_DIST_AT_1=1 under torch.distributed.run with ONE rank: the distributed path (RCCL communicator, barriers,
+    # MAX over ranks, ranks_seen) stays on at world size 1 -- how the nccl branch is exercised on a one-GPU box
+    dist_on = world > 1 or (os.environ.get("A3D_BENCH_DIST_AT_1", "0") == "1" and "WORLD_SIZE" in os.environ)
+    if dist_on:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if one_gpu:
@@ -367,7 +370,7 @@ def main():
         from agile3d_amd import build as _b
         if _b.needs_build():
             g.build()
-    if world > 1:
+    if dist_on:
         dist.barrier()
     from agile3d_amd import SparseTensor, build_model, default_args, lib as L, randomize_bn_stats
     from agile3d_amd.engine import Scene
@@ -423,7 +426,7 @@ def main():
         rep_dt.append(dt_)
     dt = float(np.median(rep_dt))
     per_rank_ms = [1e3 * float(np.median(own_dt)) / args.steps]
-    if world > 1:
+    if dist_on:
         gathered = [None] * world
         dist.all_gather_object(gathered, per_rank_ms[0])
         per_rank_ms = [float(x) for x in gathered]
@@ -446,7 +449,7 @@ def main():
     }
     if numa is not None:
         res["config"]["launch_thread_numa_node"] = numa
-    if world > 1:
+    if dist_on:
         res["ranks_seen"] = ranks_seen
         res["ms_per_step_per_rank"] = [round(x, 4) for x in per_rank_ms]
         res["config"]["backend"] = "gloo" if one_gpu else "nccl (RCCL)"
@@ -664,7 +667,7 @@ def main():
             res["emulated_fp32_products"] = {"error": str(e)[:200]}
     if rank == 0:
         print(json.dumps(res), flush=True)
-    if world > 1:
+    if dist_on:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -45,11 +45,22 @@ class CaptureSGD:
                 self.params[k].add_(g.reshape(self.params[k].shape), alpha=-self.lr * coef)
 
 
+def out_dir_(p):
+    os.makedirs(p, exist_ok=True)
+    return p
+
+
 def main():
     mode, rank, world, port, out = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), sys.argv[4], sys.argv[5]
     import torch.distributed as dist
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", port
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    if mode == "rccl1":
+        # ONE rank on the one GPU over the real backend: nccl (= RCCL) builds its communicator, owns its stream, and the
+        # bucketed all-reduce is ordered behind the producing stream -- what the 8-GPU node runs, at world size 1
+        torch.cuda.set_device(0)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", 0))
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
     from agile3d_amd import build_model, default_args
     dev = torch.device("cuda")
     args = default_args(bce_loss_coef=1.0, dice_loss_coef=2.0, losses=["bce", "dice"])
@@ -77,6 +88,48 @@ def main():
         torch.save({"out": tape.output.cpu(), "grads": {k: v.cpu() for k, v in grads.items()}, "layer": layer,
                     "bn": {k: v.cpu() for k, v in model.state_dict().items() if "running" in k}},
                    os.path.join(out, f"syncbn_{rank}.pt"))
+    elif mode == "rccl1":
+        from agile3d_amd.criterion import build_mask_criterion
+        from agile3d_amd.optim import OverlappedAllReduce, allreduce_mean_, dist_all_reduce
+        from agile3d_amd.train_step import train_one_step
+        assert dist.get_backend() == "nccl" and dist.get_world_size() == 1
+        ones = torch.ones(1, device=dev)
+        dist.all_reduce(ones)                                   # bench.py's ranks_seen probe
+        # (a) the overlapped reducer on RCCL: buckets produced by kernels still in flight on the current stream
+        g = torch.Generator(device="cpu").manual_seed(5)
+        shapes = [(27, 96, 96), (96,), (8, 128, 96), (1, 128), (27, 32, 32), (256,)]
+        host = {f"p{i}": torch.randn(sh, generator=g) for i, sh in enumerate(shapes)}
+        side = torch.cuda.Stream()
+        grads = {}
+        with torch.cuda.stream(side):                           # a non-default producing stream
+            big = torch.randn(4096, 4096, device=dev)
+            for k, v in host.items():
+                x = v.to(dev, non_blocking=True)
+                big = big @ big.clamp(-1e-3, 1e-3)              # work queued in front of the producer
+                grads[k] = x * 2.0 + big[0, 0] * 0.0            # the gradient depends on that queued work
+            red = OverlappedAllReduce(bucket_bytes=27 * 96 * 96 * 4, expected={k: v.numel() for k, v in host.items()},
+                                      single_rank=True)
+            assert red.active and red.world == 1 and not red.gloo and red.group is not None
+            for k in ["p3", "p1", "p0", "p5", "p4", "p2"]:
+                red.add(k, grads[k])
+            n_flights = len(red.flights)
+            out = red.finish({})
+        side.synchronize()
+        ok = all(torch.equal(out[k].cpu(), host[k] * 2.0) for k in host)
+        # (b) the real training iteration with the reducer forced on (A3D_DP_SINGLE_RANK=1) vs the plain iteration
+        res = {}
+        for tag, flag in (("plain", "0"), ("rccl", "1")):
+            os.environ["A3D_DP_SINGLE_RANK"] = flag
+            torch.manual_seed(3)
+            m = build_model(args).to(dev)
+            s, batch = scene_batch(70, 2500)
+            opt = CaptureSGD(m, 1e-2)
+            np.random.seed(11), torch.manual_seed(11), random.seed(11)
+            st = train_one_step(m, build_mask_criterion(args), opt, batch, dev, max_norm=0.1)
+            res[tag] = ({k: v.detach().cpu() for k, v in m.named_parameters()}, st)
+        same = all(torch.equal(res["plain"][0][k], res["rccl"][0][k]) for k in res["plain"][0])
+        torch.save({"ranks_seen": int(ones.item()), "bucket_values_ok": ok, "flights": n_flights, "train_step_identical": same,
+                    "n_params": len(res["plain"][0]), "loss": res["rccl"][1]["loss"]}, os.path.join(out_dir_(out), "rccl1.pt"))
     elif mode == "dp_step":
         from agile3d_amd.criterion import build_mask_criterion
         from agile3d_amd.train_step import train_one_step

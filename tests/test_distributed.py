@@ -100,8 +100,14 @@ def _overlap_worker(rank, world, port, q):
     shapes = [(27, 32, 32), (96,), (5, 7), (1, 128), (8, 96, 96), (256,)]
     grads = {f"p{i}": torch.randn(shape, generator=g) for i, shape in enumerate(shapes)}
     before = {k: v.clone() for k, v in grads.items()}
-    red = OverlappedAllReduce(bucket_bytes=27 * 32 * 32 * 4)             # several buckets in flight at once
-    assert red.active and red.world == world
+    red = OverlappedAllReduce(bucket_bytes=27 * 32 * 32 * 4,             # several buckets in flight at once
+                              expected={k: v.numel() for k, v in grads.items()})
+    assert red.active and red.world == world and red.group is not None   # the buckets' own communicator
+    try:
+        red.add("nobody", torch.zeros(3))
+        raise SystemExit("an unexpected gradient name must be refused")
+    except RuntimeError:
+        pass
     for k in ["p3", "p1", "p0"]:                                         # handed over as they "become final" ...
         red.add(k, grads[k])
     other = torch.randn(64, 64, generator=g) @ torch.randn(64, 64, generator=g)   # ... with work in between
@@ -112,6 +118,48 @@ def _overlap_worker(rank, world, port, q):
     q.put((rank, {k: v.numpy() for k, v in before.items()}, {k: v.numpy() for k, v in grads.items()}))
     dist.barrier()
     dist.destroy_process_group()
+
+
+def _mismatch_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from agile3d_amd.optim import OverlappedAllReduce
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    expected = {"a": 4, "b": 8} if rank == 0 else {"a": 4}               # rank 1 lacks one gradient
+    try:
+        OverlappedAllReduce(expected=expected)
+        q.put((rank, "constructed"))
+    except RuntimeError as e:
+        q.put((rank, "refused: " + str(e)[:60]))
+    # a missing hand-over is refused before anything waits on a collective
+    red = OverlappedAllReduce(expected={"a": 4, "b": 8} if False else {"c": 2, "d": 2})
+    red.add("c", torch.zeros(2))
+    try:
+        red.finish({})
+        q.put((rank, "finished"))
+    except RuntimeError as e:
+        q.put((rank, "incomplete: " + str(e)[:40]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_overlapped_allreduce_refuses_ranks_that_disagree():
+    """Ranks whose gradient lists differ fail with an error at construction (one all-gather of a digest per process
+    group) instead of hanging in a mis-sized collective; a gradient never handed over is reported by finish()."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_mismatch_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=120) for _ in range(2 * world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert sorted(m.split(":")[0] for _, m in got) == ["incomplete", "incomplete", "refused", "refused"], got
 
 
 def test_overlapped_allreduce_world2():

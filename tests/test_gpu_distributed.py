@@ -178,3 +178,37 @@ def test_bench_multi_rank_code_path_on_one_gpu():
     assert d["ranks_seen"] == 2 and len(d["ms_per_step_per_rank"]) == 2
     if torch.cuda.device_count() < 2:
         assert d["ranks_share_gpus"] is True and d["config"]["backend"] == "gloo"
+
+
+def test_rccl_backend_single_rank_on_the_one_gpu(tmp_path):
+    """The `nccl` (= RCCL) branch that the 8-GPU node runs, at world size 1 on this box's one GPU (RCCL refuses two ranks
+    per device, so every multi-rank test above is gloo): init_process_group("nccl", device_id=...), the all-reduce of
+    ones that bench.py prints as ranks_seen, OverlappedAllReduce's asynchronous buckets on the communicator's own stream
+    ordered behind a non-default producing stream (values exact), and the real train_one_step with the reducer forced on
+    ending with bit-identical parameters to the run without it (a mean over one rank is the identity)."""
+    _run_world("rccl1", tmp_path, world=1)
+    r = torch.load(tmp_path / "rccl1.pt", weights_only=False)
+    assert r["ranks_seen"] == 1
+    assert r["bucket_values_ok"] and r["flights"] >= 2
+    assert r["train_step_identical"] and r["n_params"] >= 260 and np.isfinite(r["loss"])
+
+
+def test_bench_rccl_branch_at_world_size_one():
+    """bench.py's own `nccl` branch (init with device_id, ranks_seen, barriers, MAX over ranks through the backend) under
+    torch.distributed.run with ONE rank: A3D_BENCH_DIST_AT_1=1 keeps the distributed path on at world size 1."""
+    import json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "A3D_BENCH_ONE_GPU")}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    env["A3D_BENCH_DIST_AT_1"] = "1"
+    port = str(31500 + os.getpid() % 2000)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", port, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--reps", "1",
+           "--batch", "4", "--no-profile", "--no-cpu-baseline", "--steps-only"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["ranks_seen"] == 1 and d["config"]["backend"] == "nccl (RCCL)"
+    assert d["value"] > 0 and len(d["ms_per_step_per_rank"]) == 1
