@@ -171,12 +171,15 @@ def _train_one_step(model, criterion, optimizer, batch, device, max_norm):
     optimizer.step(grads, coef)
     eng.mark_stale()
     mark("clip + AdamW")
+    stats = {"loss": total, "grad_norm": norm, "loss_dict": {k: float(v) for k, v in loss_dict.items()},
+             "clicks": [sum(len(v) for v in c.values()) for c in click_idx], "click_rounds": num_forward_iters}
     if timing:
         import sys
-        print("train_one_step: " + ", ".join(f"{n} {1e3 * (t - marks[i][1]):.1f} ms" for i, (n, t) in enumerate(marks[1:])),
-              file=sys.stderr)
-    return {"loss": total, "grad_norm": norm, "loss_dict": {k: float(v) for k, v in loss_dict.items()},
-            "clicks": [sum(len(v) for v in c.values()) for c in click_idx]}
+        stats["phases_ms"] = {n.split(" (")[0]: 1e3 * (t - marks[i][1]) for i, (n, t) in enumerate(marks[1:])}
+        if timing != "quiet":
+            print("train_one_step: " + ", ".join(f"{n} {1e3 * (t - marks[i][1]):.1f} ms" for i, (n, t) in enumerate(marks[1:])),
+                  file=sys.stderr)
+    return stats
 
 
 def train_one_step_api(model, criterion, optimizer, batch, device, max_norm: float = 0.1):

@@ -83,6 +83,28 @@ def algorithmic_bytes(entry, pairs):
     return 4.0 * (n_in * entry.cin + n_out * entry.cout + entry.kernel_volume * entry.cin * entry.cout) + 8.0 * p
 
 
+def workload_key(voxels, batch, queries):
+    """Key of a workload in profiles/pmc_summary.json and profiles/kernel_avg_us.json."""
+    return f"{round(voxels / 1000)}k_b{batch}_q{queries}"
+
+
+def profile_file(name, wkey):
+    """The per-kernel table of workload `wkey` in a committed profiles/ file ({} when the file has none for it)."""
+    try:
+        return json.load(open(os.path.join(ROOT, "profiles", name))).get("workloads", {}).get(wkey, {}) or {}
+    except Exception:
+        return {}
+
+
+def hbm_traffic_frac(traffic, avg_launch_ms):
+    """Measured fabric bytes per launch / launch duration / peak; None without counters of THIS workload, and never a
+    fraction above 1 (that would mean the counters are of something else)."""
+    if not traffic:
+        return None
+    f = traffic / (avg_launch_ms * 1e-3) / 1e9 / PEAK_HBM_GBS
+    return f if f <= 1.0 else None
+
+
 def kernel_name(e):
     from agile3d_amd import lib as L
     name = L.PROF_NAMES[e.id]
@@ -253,6 +275,61 @@ def iou_at_k(model, sd, dev, n_scenes=2, voxels=6000, objects=3, max_clicks=20):
                     "(interactive_rounds), both through EvaluatorMO; ScanNet + the authors' checkpoint are not available offline"}
 
 
+def train_iter_ms(dev, voxels=80_000, batch=4, iters=5, warm=3):
+    """BASELINE.json config 4's iteration (engine.py:38-150: training-mode backbone, no-grad click rounds, training-mode
+    decoder, losses, backward, clip, AdamW) on ONE GPU: `iters` seeded iterations on a batch of 4 x 80 k-voxel labelled
+    synthetic scenes after `warm` warm-ups (the first iterations grow the allocator's pools).  The number of click rounds
+    is drawn per iteration (0..19, engine.py:83), so they are stated separately: `ms_without_click_rounds` is the median
+    of (iteration - click rounds), phases device-synchronised."""
+    import random
+    from agile3d_amd import batched_coordinates, build_model, default_args
+    from agile3d_amd.criterion import build_mask_criterion
+    from agile3d_amd.optim import AdamW
+    from agile3d_amd.train_step import train_one_step
+    torch.manual_seed(0)
+    targs = default_args(bce_loss_coef=1.0, dice_loss_coef=2.0, losses=["bce", "dice"])
+    model = build_model(targs).to(dev)
+    crit = build_mask_criterion(targs)
+    scenes = [make_scene_(voxels, seed=b) for b in range(batch)]
+    b = (batched_coordinates([s["coords"][:, 1:] for s in scenes]),
+         torch.from_numpy(np.concatenate([s["raw_xyz"] for s in scenes])),
+         torch.from_numpy(np.concatenate([s["feats"] for s in scenes])),
+         [torch.from_numpy(s["labels"].astype(np.int64)) for s in scenes], None, None, [{} for _ in scenes],
+         tuple(f"scene{i:04d}_00" for i in range(batch)), tuple(0 for _ in scenes))
+    opt = AdamW(model.named_parameters(), lr=1e-4, weight_decay=1e-4)
+    np.random.seed(1), random.seed(1)
+    old = os.environ.get("A3D_TRAIN_TIMING")
+    os.environ["A3D_TRAIN_TIMING"] = "quiet"
+    rows = []
+    try:
+        for it in range(warm + iters):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            st = train_one_step(model, crit, opt, b, dev, 0.1)
+            torch.cuda.synchronize()
+            if it >= warm:
+                ph = st["phases_ms"]
+                click = ph.get("click simulation", 0.0)
+                rows.append({"ms": round(1e3 * (time.perf_counter() - t0), 2), "click_rounds": st["click_rounds"],
+                             "click_rounds_ms": round(click, 2), "phases_ms": {k: round(v, 2) for k, v in ph.items()}})
+    finally:
+        if old is None:
+            os.environ.pop("A3D_TRAIN_TIMING", None)
+        else:
+            os.environ["A3D_TRAIN_TIMING"] = old
+    del model, opt
+    torch.cuda.empty_cache()
+    wo = [r["ms"] - r["click_rounds_ms"] for r in rows]
+    per_round = [r["click_rounds_ms"] / r["click_rounds"] for r in rows if r["click_rounds"]]
+    return {"ms_without_click_rounds": round(float(np.median(wo)), 2), "ms_all": [r["ms"] for r in rows],
+            "click_rounds": [r["click_rounds"] for r in rows],
+            "ms_per_click_round": round(float(np.median(per_round)), 2) if per_round else None,
+            "phases_ms_median": {k: round(float(np.median([r["phases_ms"].get(k, 0.0) for r in rows])), 2)
+                                 for k in rows[0]["phases_ms"]},
+            "workload": f"{batch} x {voxels}-voxel labelled synthetic scenes per iteration, 1 GPU, fp32, AdamW + clip 0.1; "
+                        f"median of {iters} seeded iterations after {warm} warm-ups"}
+
+
 def make_scene_(voxels, seed):
     from agile3d_amd.synthetic import make_scene
     return make_scene(voxels, seed=seed)
@@ -319,6 +396,7 @@ def main():
     ap.add_argument("--clicks-per-object", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--no-train", action="store_true", help="skip the training-iteration timing (train_iter)")
     ap.add_argument("--dump-logits", default="", help="write scene 0's logits of the first step to this file (torch.save)")
     ap.add_argument("--steps-only", action="store_true",
                     help="only the batched steps (warm-up, timed region, instrumented pass): no latency / phase / eval-round "
@@ -493,35 +571,33 @@ def main():
             dom = max((k for k in conv if k.startswith("k_conv")), key=lambda k: conv[k]["ms"])
             d = conv[dom]
             achieved = d["flops"] / (d["ms"] * 1e-3) / 1e12
-            traffic = None
-            pmc = os.path.join(ROOT, "profiles", "pmc_summary.json")
-            if os.path.exists(pmc):
-                try:
-                    traffic = json.load(open(pmc)).get(dom, {}).get("hbm_bytes_per_launch")
-                except Exception:
-                    traffic = None
+            # counters / rocprofv3 averages are only evidence for the workload they were collected on: the committed files
+            # are keyed by workload ("<k voxels>k_b<batch>_q<queries>"), anything else prints null
+            Q = args.objects * args.clicks_per_object + 10
+            wkey = workload_key(n0, args.batch, Q)
+            traffic = (profile_file("pmc_summary.json", wkey).get(dom) or {}).get("hbm_bytes_per_launch")
             hbm_gbs = d["bytes"] / (d["ms"] * 1e-3) / 1e9          # algorithmic (compulsory) bytes / measured time
             res["roofline"] = {"bound": "mfma", "kernel": dom, "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS,
                                "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic,
                                "hbm_achieved_gbs": hbm_gbs, "hbm_peak_gbs": PEAK_HBM_GBS, "hbm_frac": hbm_gbs / PEAK_HBM_GBS,
-                               "hbm_traffic_frac": (traffic / (d["ms"] / d["launches"] * 1e-3) / 1e9 / PEAK_HBM_GBS) if traffic else None,
+                               "hbm_traffic_frac": hbm_traffic_frac(traffic, d["ms"] / d["launches"]),
                                "avg_launch_ms": d["ms"] / d["launches"], "launches_per_step": d["launches_per_step"],
                                "algorithmic_gflop_per_launch": d["flops"] / d["launches"] / 1e9,
                                "algorithmic_bytes_per_launch": d["bytes"] / d["launches"],
                                "how": f"per launch position: median of {n_prof} HIP-event samples; kernel = sum over its "
                                       f"launches; dominant = largest sum"}
-            # agreement with the committed rocprofv3 --kernel-trace --stats summary of the same command
-            ref_us = os.path.join(ROOT, "profiles", "kernel_avg_us.json")
-            if os.path.exists(ref_us):
-                try:
-                    want = json.load(open(ref_us)).get(dom)
-                    if want:
-                        got = 1e3 * d["ms"] / d["launches"]
-                        res["roofline"]["rocprof_avg_launch_us"] = want
-                        res["roofline"]["rocprof_command"] = "rocprofv3 --kernel-trace --stats -- python bench.py --steps-only --streams 1"
-                        res["roofline"]["agrees_with_profiles_within_10pct"] = bool(abs(got - want) <= 0.1 * want)
-                except Exception:
-                    pass
+            # agreement with the committed rocprofv3 --kernel-trace --stats summary of the same command on the same workload
+            res["roofline"]["profiles_workload"] = wkey if (traffic is not None or profile_file("kernel_avg_us.json", wkey)) else None
+            want = profile_file("kernel_avg_us.json", wkey).get(dom)
+            if want:
+                got = 1e3 * d["ms"] / d["launches"]
+                res["roofline"]["rocprof_avg_launch_us"] = want
+                res["roofline"]["rocprof_command"] = ("rocprofv3 --kernel-trace --stats -- python bench.py --steps-only --streams 1"
+                                                      + ("" if wkey == workload_key(80_000, 16, 20) else
+                                                         f" --voxels {args.voxels} --clicks-per-object {args.clicks_per_object} --batch {args.batch}"))
+                res["roofline"]["agrees_with_profiles_within_10pct"] = bool(abs(got - want) <= 0.1 * want)
+            else:
+                res["roofline"]["rocprof_avg_launch_us"] = None
             tot_flops = sum(v["flops"] for v in conv.values())
             res["kernels_ms_per_step"] = {k: round(v["ms_per_step"], 4) for k, v in sorted(agg.items())}
             res["conv_tflops"] = {k: round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2) for k, v in conv.items()}
@@ -631,6 +707,30 @@ def main():
                                        "batched forward_mask, then the scenes' label argmax / IoU counts / error clusters side by side ("
                                        + ("one host round trip" if len(scenes) <= 8 else "two host round trips: more than eight samples")
                                        + " per round); scene-rounds per second")
+        if not args.steps_only and world == 1 and args.batch > 4:
+            # the SAME scenes through round 2's protocol (4 scenes per step, the same number of steps in flight), so that a
+            # change of `value` can be told apart from a change of protocol: `value_batch4`
+            nb4 = sum(len(s_["coords"]) for s_ in scenes[:4])
+            c4, f4, w4 = coords[:nb4].contiguous(), feats[:nb4].contiguous(), raw[:nb4].contiguous()
+
+            def step4():
+                stq = streams[issued[0] % len(streams)] if streams else torch.cuda.current_stream()
+                with torch.cuda.stream(stq):
+                    issued[0] += 1
+                    r = model.forward_backbone(SparseTensor(features=f4, coordinates=c4), raw_coordinates=w4)
+                    return model.forward_mask(*r, click_idx=cis[:4], click_time_idx=cts[:4])
+            for _ in range(args.warmup):
+                step4()
+            rep4 = [timed_steps(step4, args.steps, 1, dev)[0] for _ in range(max(1, min(args.reps, 7)))]
+            res["value_batch4"] = round(4 * args.steps / float(np.median(rep4)), 2)
+            res["value_batch4_note"] = (f"same scenes, 4 per step (round 2's protocol), {args.streams} steps in flight, median of "
+                                        f"{len(rep4)} repetitions of {args.steps} steps")
+        if not args.steps_only and world == 1 and not args.no_train:
+            try:
+                res["train_iter"] = train_iter_ms(dev)
+                res["train_iter_ms"] = res["train_iter"]["ms_without_click_rounds"]
+            except Exception as e:   # never lose the headline line over the extra
+                res["train_iter"] = {"error": f"{type(e).__name__}: {e}"[:300]}
         if not args.no_cpu_baseline and not args.steps_only and world == 1:
             res["cpu_baseline"], diff = cpu_baseline(sd, sc, ci, ct, gpu_logits0, gpu_feats0)
             res["parity_vs_oracle"] = diff

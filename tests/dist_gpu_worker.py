@@ -107,15 +107,15 @@ def main():
                 x = v.to(dev, non_blocking=True)
                 big = big @ big.clamp(-1e-3, 1e-3)              # work queued in front of the producer
                 grads[k] = x * 2.0 + big[0, 0] * 0.0            # the gradient depends on that queued work
-            red = OverlappedAllReduce(bucket_bytes=27 * 96 * 96 * 4, expected={k: v.numel() for k, v in host.items()},
+            red = OverlappedAllReduce(bucket_bytes=256 * 1024, expected={k: v.numel() for k, v in host.items()},
                                       single_rank=True)
             assert red.active and red.world == 1 and not red.gloo and red.group is not None
             for k in ["p3", "p1", "p0", "p5", "p4", "p2"]:
                 red.add(k, grads[k])
             n_flights = len(red.flights)
-            out = red.finish({})
+            reduced = red.finish({})
         side.synchronize()
-        ok = all(torch.equal(out[k].cpu(), host[k] * 2.0) for k in host)
+        ok = all(torch.equal(reduced[k].cpu(), host[k] * 2.0) for k in host)
         # (b) the real training iteration with the reducer forced on (A3D_DP_SINGLE_RANK=1) vs the plain iteration
         res = {}
         for tag, flag in (("plain", "0"), ("rccl", "1")):

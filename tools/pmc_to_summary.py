@@ -5,13 +5,21 @@ import json
 import re
 import sys
 
+import os
 raw = json.load(open(sys.argv[1]))
-out = {"_note": "rocprofv3 --pmc passes of `python bench.py --steps-only --no-profile --steps 5 --warmup 2 --reps 1 "
-                "--streams 1` (only 4-scene steps) on MI355X (tools/profile_round.sh). Separate passes for FETCH_SIZE, WRITE_SIZE and the SQ "
-                "group (never combined with tracing). hbm_bytes_per_launch = (2*FETCH_SIZE + WRITE_SIZE) KiB: on gfx950 "
-                "FETCH_SIZE reports half the bytes of a wide coalesced read (MI355X_MICROARCH.md, HBM section); WRITE_SIZE "
-                "is taken as is (uncalibrated). mfma_util = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs * GRBM_GUI_ACTIVE / 8 "
-                "XCDs); bench.py reads hbm_bytes_per_launch of its dominant kernel as roofline.traffic."}
+wkey = sys.argv[3] if len(sys.argv) > 3 else "80k_b16_q20"       # bench.workload_key of the traced command
+full = json.load(open(sys.argv[2])) if os.path.exists(sys.argv[2]) else {}
+if "workloads" not in full:
+    full = {"workloads": {}}
+full["_note"] = ("rocprofv3 --pmc passes of `python bench.py --steps-only --no-profile --steps 5 --warmup 2 --reps 1 --streams 1 "
+                 "[--voxels .. --clicks-per-object .. --batch ..]` on MI355X (tools/profile_round.sh), one table per workload "
+                 "(<k voxels>k_b<scenes per step>_q<queries per scene>).  Separate passes for FETCH_SIZE, WRITE_SIZE and the SQ "
+                 "group (never combined with tracing). hbm_bytes_per_launch = (2*FETCH_SIZE + WRITE_SIZE) KiB: on gfx950 "
+                 "FETCH_SIZE reports half the bytes of a wide coalesced read (MI355X_MICROARCH.md, HBM section); WRITE_SIZE "
+                 "is taken as is (uncalibrated). mfma_util = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs * GRBM_GUI_ACTIVE / 8 "
+                 "XCDs); bench.py reads hbm_bytes_per_launch of its dominant kernel as roofline.traffic -- only from the table "
+                 "of the workload it is running.")
+out = {}
 for name, c in raw.items():
     short = name.replace("void ", "").replace("a3d::", "")
     m = re.match(r"k_conv_sk<(\d+), (\d+), (\d+), (true|false)(, \d+)?>", short)   # <BN, CH, PAIR, DBG>: bench.py's key is <BN,CH>
@@ -35,5 +43,6 @@ for name, c in raw.items():
 for e in out.values():
     if isinstance(e, dict):
         e.pop("_n", None)
-json.dump(out, open(sys.argv[2], "w"), indent=1)
-print("wrote", sys.argv[2], len(out) - 1, "kernels")
+full["workloads"][wkey] = out
+json.dump(full, open(sys.argv[2], "w"), indent=1)
+print("wrote", sys.argv[2], wkey, len(out), "kernels")

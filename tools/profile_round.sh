@@ -15,15 +15,28 @@ rocprofv3 --kernel-trace --stats -d /tmp/$TAG/trace -o t -- python $R/bench.py -
 python $R/tools/rocprof_summary.py /tmp/$TAG/trace > $OUT/kernel_trace_stats.txt 2>&1
 rocprofv3 --kernel-trace --stats -d /tmp/$TAG/trace1 -o t -- python $R/bench.py --steps-only --streams 1 > $OUT/bench_under_rocprof_steps_only.json 2> $OUT/trace1.err
 python $R/tools/rocprof_summary.py /tmp/$TAG/trace1 > $OUT/kernel_trace_stats_steps_only.txt 2>&1
-python $R/tools/kernel_avg.py $OUT/kernel_trace_stats_steps_only.txt $OUT/kernel_avg_us.json
+cp $R/profiles/kernel_avg_us.json $OUT/kernel_avg_us.json 2>/dev/null; cp $R/profiles/pmc_summary.json $OUT/pmc_summary.json 2>/dev/null
+python $R/tools/kernel_avg.py $OUT/kernel_trace_stats_steps_only.txt $OUT/kernel_avg_us.json 80k_b16_q20
 PMC="python $R/bench.py --steps-only --no-profile --steps 5 --warmup 2 --reps 1 --streams 1"
 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d /tmp/$TAG/pmc_fetch -o p -- $PMC > /dev/null 2> $OUT/pmc_fetch.err
 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d /tmp/$TAG/pmc_write -o p -- $PMC > /dev/null 2> $OUT/pmc_write.err
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_LDS_BANK_CONFLICT SQ_WAVE_CYCLES --kernel-trace -d /tmp/$TAG/pmc_sq -o p -- $PMC > /dev/null 2> $OUT/pmc_sq.err
 PMC_JSON=$OUT/pmc_raw.json python $R/tools/rocprof_summary.py /tmp/$TAG/pmc_fetch /tmp/$TAG/pmc_write /tmp/$TAG/pmc_sq > $OUT/pmc_counters.txt 2>&1
-python $R/tools/pmc_to_summary.py $OUT/pmc_raw.json $OUT/pmc_summary.json
+python $R/tools/pmc_to_summary.py $OUT/pmc_raw.json $OUT/pmc_summary.json 80k_b16_q20
+# the same passes on BASELINE.json config 5 (one 300 k-voxel scene, 20 clicks): its own tables in the two JSON files
+C5="--voxels 300000 --clicks-per-object 4 --batch 1"
+rocprofv3 --kernel-trace --stats -d /tmp/$TAG/trace5 -o t -- python $R/bench.py --steps-only --streams 1 $C5 > $OUT/bench_under_rocprof_steps_only_config5.json 2> $OUT/trace5.err
+python $R/tools/rocprof_summary.py /tmp/$TAG/trace5 > $OUT/kernel_trace_stats_steps_only_config5.txt 2>&1
+python $R/tools/kernel_avg.py $OUT/kernel_trace_stats_steps_only_config5.txt $OUT/kernel_avg_us.json 300k_b1_q30
+PMC5="python $R/bench.py --steps-only --no-profile --steps 10 --warmup 2 --reps 1 --streams 1 $C5"
+rocprofv3 --pmc FETCH_SIZE --kernel-trace -d /tmp/$TAG/pmc5_fetch -o p -- $PMC5 > /dev/null 2> $OUT/pmc5_fetch.err
+rocprofv3 --pmc WRITE_SIZE --kernel-trace -d /tmp/$TAG/pmc5_write -o p -- $PMC5 > /dev/null 2> $OUT/pmc5_write.err
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_LDS_BANK_CONFLICT SQ_WAVE_CYCLES --kernel-trace -d /tmp/$TAG/pmc5_sq -o p -- $PMC5 > /dev/null 2> $OUT/pmc5_sq.err
+PMC_JSON=$OUT/pmc_raw_config5.json python $R/tools/rocprof_summary.py /tmp/$TAG/pmc5_fetch /tmp/$TAG/pmc5_write /tmp/$TAG/pmc5_sq > $OUT/pmc_counters_config5.txt 2>&1
+python $R/tools/pmc_to_summary.py $OUT/pmc_raw_config5.json $OUT/pmc_summary.json 300k_b1_q30
+cp $OUT/kernel_avg_us.json $OUT/pmc_summary.json $R/profiles/      # so that the config-5 line below reads ITS tables
 # BASELINE.json config 5 (KITTI-like 300 k voxels, 20 clicks): its own bench line and per-launch table
-python $R/bench.py --voxels 300000 --clicks-per-object 4 --batch 1 --streams 2 --steps 10 --warmup 3 --reps 7 > $OUT/bench_config5.json 2> $OUT/bench_config5.err
+python $R/bench.py --voxels 300000 --clicks-per-object 4 --batch 1 --streams 2 --steps 10 --warmup 3 --reps 7 --no-train > $OUT/bench_config5.json 2> $OUT/bench_config5.err
 LT_BATCH=1 LT_VOXELS=300000 LT_CPO=4 python $R/tools/layer_table.py > $OUT/layer_table_config5.txt 2>&1
 LT_BATCH=4 python $R/tools/layer_table.py > $OUT/layer_table_4scenes.txt 2>&1
 LT_BATCH=1 python $R/tools/layer_table.py > $OUT/layer_table_1scene.txt 2>&1
