@@ -728,187 +728,6 @@ static int launch_conv_wl(const ConvArgs& c, hipStream_t st) {
   return A3D_OK;
 }
 
-// ------------------------------------------------------------------------------ k_conv_rs
-// Gathered convolution with NOTHING shared between waves: no LDS, no barrier, no hand-off.  A work unit is one wave x RG
-// 16-row groups (RG = 4: a 64-row tile per WAVE); the wave streams its own weight fragments from the packed matrix
-// straight into registers (the packed order makes a wave's fragment load 1 KB contiguous; every wave of the chip reads
-// the same <= 1 MB, L2-resident), each fragment feeds RG row groups -- the same weight traffic per MFMA as k_conv_sk's
-// four-wave tile, without coupling four SIMDs' instruction queues through a barrier every stage.  Stage = (offset k,
-// 16 input channels): NCT + RG 16-byte loads per lane for the NEXT stage are in flight behind the <= 4 RG NCT MFMAs of
-// the current one; the loads of a stage are unconditional (a group that lacks offset k gathers the zero row through its
-// neighbour table and skips the MFMAs), so the compiler's counted vmcnt waits leave exactly the next stage's loads in
-// flight.  Units are handed out by an atomic counter (no inter-unit dependences: the result does not depend on who
-// computes what): the bulk as RG-group units, the last groups one at a time to trim the tail.  Summation order per output
-// element: offsets ascending, channels ascending (= k_conv_wl = k_conv_sk without hand-offs).
-template <int NCT, int RG>
-__global__ void __launch_bounds__(64, RG >= 4 ? 2 : 3) k_conv_rs(const ConvArgs c, int ngroups, int n_big, int n_units,
-                                                                 int* __restrict__ ctr) {
-  const int lane = threadIdx.x, g = lane >> 4, j = lane & 15;
-  const int K = c.K, nchunk = c.cin >> 4, cout16 = c.cout >> 4;
-  if (blockIdx.x == 0 && c.zero_row >= 0)
-    for (int cidx = lane; cidx < c.cout; cidx += 64) c.out[(size_t)c.zero_row * c.ldo + cidx] = 0.f;
-  const uint32_t full = K >= 32 ? 0xffffffffu : (1u << K) - 1u;
-  const char* inb = (const char*)c.in;
-  const unsigned row_bytes = (unsigned)c.ldi * 4u;
-  const f32x4* wl = (const f32x4*)c.w + lane;
-  auto dequeue = [&]() -> int {
-    int v = 0;
-    if (lane == 0) v = atomicAdd(ctr, 1);
-    return __builtin_amdgcn_readfirstlane(v);
-  };
-  int u = dequeue();
-  while (u < n_units) {
-    int g0, ng;
-    if (u < n_big) { g0 = u * RG; ng = RG; } else { g0 = n_big * RG + (u - n_big); ng = 1; }
-    uint32_t m[RG], un = 0;
-    int gi[RG];
-#pragma unroll
-    for (int r = 0; r < RG; ++r) {
-      gi[r] = min(g0 + r, ngroups - 1);
-      uint32_t mm = c.gmask ? c.gmask[gi[r]] & full : full;
-      m[r] = __builtin_amdgcn_readfirstlane(r < ng ? mm : 0u);
-      un |= m[r];
-    }
-    f32x4 acc[RG][NCT];
-#pragma unroll
-    for (int r = 0; r < RG; ++r)
-#pragma unroll
-      for (int ct = 0; ct < NCT; ++ct) acc[r][ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    if (un) {
-      // Every load of the loops below is UNCONDITIONAL (a stage past the end of the unit re-reads offset 0: L2 hits nobody
-      // uses): with a load under a branch the compiler's wait-count pass must assume the shorter queue at the merge and
-      // waits for the prefetch it has just issued.
-      auto next_k = [&](int k) -> int {   // next offset of the unit after k (32 = none)
-        const uint32_t rest = k >= 31 ? 0u : un & ~((2u << k) - 1u);
-        return rest ? __builtin_ctz(rest) : 32;
-      };
-      auto fetch_idx = [&](int kk, int (&idx)[RG]) {   // this lane's gathered rows for offset kk (raw row numbers)
-        const int kc = kk < 32 ? kk : 0;
-#pragma unroll
-        for (int r = 0; r < RG; ++r) idx[r] = c.nbr[(size_t)kc * c.nbr_stride + gi[r] * 16 + j];
-      };
-      auto load_stage = [&](f32x4 (&Wr)[NCT], f32x4 (&A)[RG], int kk, int cc, const unsigned (&roff)[RG]) {
-        const f32x4* ws = wl + ((size_t)kk * nchunk + cc) * cout16 * 64;
-#pragma unroll
-        for (int ct = 0; ct < NCT; ++ct) Wr[ct] = ws[ct * 64];
-        const char* ar = inb + (size_t)cc * 64;
-#pragma unroll
-        for (int r = 0; r < RG; ++r) A[r] = *(const f32x4*)(ar + roff[r]);
-      };
-      auto compute = [&](const f32x4 (&Wr)[NCT], const f32x4 (&A)[RG], int kk) {
-#pragma unroll
-        for (int r = 0; r < RG; ++r) {
-          if ((m[r] >> kk) & 1u) {
-#pragma unroll
-            for (int tt = 0; tt < 4; ++tt)
-#pragma unroll
-              for (int ct = 0; ct < NCT; ++ct)
-                acc[r][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(Wr[ct][tt], A[r][tt], acc[r][ct], 0, 0, 0);
-          }
-        }
-      };
-      const int nk = __builtin_popcount(un);
-      int k = __builtin_ctz(un), k1 = next_k(k);
-      unsigned ro_cur[RG], ro_nxt[RG];
-      int idx_nn[RG];
-      {
-        int i0[RG], i1[RG];
-        fetch_idx(k, i0);
-        fetch_idx(k1, i1);
-#pragma unroll
-        for (int r = 0; r < RG; ++r) {
-          ro_cur[r] = (unsigned)i0[r] * row_bytes + 16u * g;
-          ro_nxt[r] = (unsigned)i1[r] * row_bytes + 16u * g;
-        }
-      }
-      f32x4 W0[NCT], W1[NCT], A0[RG], A1[RG];
-      load_stage(W0, A0, k, 0, ro_cur);
-      for (int ik = 0; ik < nk; ++ik) {
-        const int k2 = next_k(k1 < 32 ? k1 : 31);
-        fetch_idx(k2, idx_nn);                       // rows of the offset after next: used at the end of this offset
-        const int k1c = k1 < 32 ? k1 : 0;
-        int cc = 0;
-        do {                                         // nchunk is even and >= 2 (cin % 32 == 0): at least one pass, so the
-          load_stage(W1, A1, k, cc + 1, ro_cur);     // row numbers requested above are known to be older than 20 loads
-          compute(W0, A0, k);
-          const bool last = cc + 2 >= nchunk;
-          unsigned ro_sel[RG];
-#pragma unroll
-          for (int r = 0; r < RG; ++r) ro_sel[r] = last ? ro_nxt[r] : ro_cur[r];
-          load_stage(W0, A0, last ? k1c : k, last ? 0 : cc + 2, ro_sel);
-          compute(W1, A1, k);
-          cc += 2;
-        } while (cc < nchunk);
-#pragma unroll
-        for (int r = 0; r < RG; ++r) {
-          asm volatile("" : "+v"(idx_nn[r]));        // consumed HERE (not rotated to the top of the next offset)
-          ro_cur[r] = ro_nxt[r];
-          ro_nxt[r] = (unsigned)idx_nn[r] * row_bytes + 16u * g;
-        }
-        k = k1;
-        k1 = k2;
-      }
-    }
-    const int u_next = dequeue();          // its round trip overlaps the epilogue's loads and stores
-#pragma unroll
-    for (int r = 0; r < RG; ++r) {
-      const int myrow = (g0 + r) * 16 + j;
-      if (r < ng && myrow < c.n_out) {
-        const int orow = c.out_map ? c.out_map[myrow] : myrow;
-        float* po = c.out + (size_t)orow * c.ldo + 4 * g;
-        const float* pr = c.res ? c.res + (size_t)orow * c.ldr + 4 * g : nullptr;
-        f32x4 rv[NCT];
-        if (pr) {
-#pragma unroll
-          for (int ct = 0; ct < NCT; ++ct) rv[ct] = *(const f32x4*)(pr + ct * 16);
-        }
-#pragma unroll
-        for (int ct = 0; ct < NCT; ++ct) {
-          f32x4 v = acc[r][ct];
-          if (c.scale) v *= *(const f32x4*)(c.scale + ct * 16 + 4 * g);
-          if (c.shift) v += *(const f32x4*)(c.shift + ct * 16 + 4 * g);
-          if (pr) v += rv[ct];
-          if (c.relu) {
-#pragma unroll
-            for (int tt = 0; tt < 4; ++tt) v[tt] = fmaxf(v[tt], 0.f);
-          }
-          *(f32x4*)(po + ct * 16) = v;
-        }
-      }
-    }
-    u = u_next;
-  }
-}
-
-// which layers: A3D_CONV_RS = RG (4 or 2; 0 = off), 3^3 maps with 96 output columns and enough groups to keep every wave
-// slot of the chip busy for several units
-static int conv_rs_mode() {
-  static int v = sk_env_early("A3D_CONV_RS", 0);
-  return v;
-}
-static bool conv_rs_supported(const ConvArgs& c) {
-  static int min_groups = sk_env_early("A3D_CONV_RS_MIN", 16384);
-  const int mode = conv_rs_mode();
-  if (!(mode == 2 || mode == 4) || c.K != 27 || !c.nbr || !c.gmask || c.cout != 96 || c.cin % 32) return false;
-  return (c.n_out + 15) / 16 >= min_groups;
-}
-static int launch_conv_rs(const ConvArgs& c, int* state, hipStream_t st) {
-  const int RGm = conv_rs_mode();
-  const int ngroups = (c.n_out + 15) / 16;
-  const int waves = 256 * 4 * (RGm >= 4 ? 2 : 3);
-  static int tail_mul = sk_env_early("A3D_CONV_RS_TAIL", 2);
-  int n_small = waves * tail_mul;                       // the last groups go out one at a time
-  if (n_small > ngroups) n_small = ngroups;
-  const int n_big = (ngroups - n_small) / RGm;
-  const int n_units = n_big + (ngroups - n_big * RGm);
-  const int grid = n_units < waves ? n_units : waves;
-  ProfScope ps(st, A3D_PROF_SPCONV, c.cout, c.K, c.cin, c.cout, c.n_out, c.tag_table, c.tag_level, 16);   // stage width 16: k_conv_rs
-  if (RGm >= 4) k_conv_rs<6, 4><<<grid, 64, 0, st>>>(c, ngroups, n_big, n_units, state);
-  else k_conv_rs<6, 2><<<grid, 64, 0, st>>>(c, ngroups, n_big, n_units, state);
-  A3D_LAUNCH_CHECK();
-  return A3D_OK;
-}
-
 // ------------------------------------------------------------------------------ dense GEMM
 // Y[n][16*NCT] = act(((X (+ X2))[n][16*NS] @ W) * scale + shift + res): the N-point nn.Linear pieces of the
 // decoder and the 1x1 convolutions (no gather, no masks).  HBM-bound (reads X (+X2), writes Y once), so the
@@ -1439,7 +1258,6 @@ static int launch_conv_sk(ConvArgs c, const int* pre64, float* slab_ws, size_t s
     return A3D_ERR_UNSUPPORTED;
   }
   if (conv_wl_supported(c) && !conv_emu(c.K, c.cin, c.cout)) return launch_conv_wl(c, st);
-  if (state && conv_rs_supported(c) && !conv_emu(c.K, c.cin, c.cout)) return launch_conv_rs(c, state, st);
   // hand-offs (shares cut inside tiles) pay where a tile is long and tiles are few: the 3^3 maps, and the 2^3 maps of
   // the small levels.  1x1 layers and 2^3 maps with a tile per workgroup slot or more run whole tiles: no ticket, no
   // search, no flags -- their fixed latency is what matters
