@@ -100,20 +100,40 @@ __global__ void __launch_bounds__(kBnThreads) k_bn_block_stats(const ColArgs a) 
     *(f32x4*)(a.partial + (size_t)blockIdx.x * 2 * a.C + a.C + 4 * col) = s1;
   }
 }
-__global__ void k_bn_combine(const float* __restrict__ partial, int nblocks, int rows_per_block, int n, int C, float eps,
-                             float* mean_out, float* rstd_out, float* running_mean, float* running_var, float momentum) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
+// The second level of the column reductions.  One thread per column walking up to 1024 block partials is a chain of a
+// thousand dependent L2 loads (38 us for a few KB of arithmetic; 130 of these launches per training iteration): a
+// 256-thread workgroup takes 16 consecutive columns, thread (bl, cc) folds the blocks bl, bl + 16, ... of column cc (64-byte
+// row segments per load), then one thread per column folds the 16 partial results in bl order -- fixed orders, fp64.
+constexpr int kFinCols = 16, kFinLanes = 16;
+__global__ void __launch_bounds__(256) k_bn_combine(const float* __restrict__ partial, int nblocks, int rows_per_block, int n,
+                                                    int C, float eps, float* mean_out, float* rstd_out, float* running_mean,
+                                                    float* running_var, float momentum) {
+  __shared__ double s_cnt[kFinLanes][kFinCols], s_mean[kFinLanes][kFinCols], s_m2[kFinLanes][kFinCols];
+  const int cc = threadIdx.x % kFinCols, bl = threadIdx.x / kFinCols;
+  const int c = blockIdx.x * kFinCols + cc;
   double cnt = 0.0, mean = 0.0, m2 = 0.0;
-  for (int b = 0; b < nblocks; ++b) {
-    const double nb = (double)(min(n, (b + 1) * rows_per_block) - b * rows_per_block);
-    const double bs = (double)partial[(size_t)b * 2 * C + c], bm2 = (double)partial[(size_t)b * 2 * C + C + c];
-    // the block's M2 was taken around the fp32 block mean the kernel used, not around bs / nb: shift it (exact identity)
-    const double bm_used = (double)((float)bs * (1.f / (float)nb)), bm = bs / nb;
-    const double bm2c = bm2 - nb * (bm - bm_used) * (bm - bm_used);
-    const double delta = bm - mean, tot = cnt + nb;
+  if (c < C) {
+    for (int b = bl; b < nblocks; b += kFinLanes) {
+      const double nb = (double)(min(n, (b + 1) * rows_per_block) - b * rows_per_block);
+      const double bs = (double)partial[(size_t)b * 2 * C + c], bm2 = (double)partial[(size_t)b * 2 * C + C + c];
+      // the block's M2 was taken around the fp32 block mean the kernel used, not around bs / nb: shift it (exact identity)
+      const double bm_used = (double)((float)bs * (1.f / (float)nb)), bm = bs / nb;
+      const double bm2c = bm2 - nb * (bm - bm_used) * (bm - bm_used);
+      const double delta = bm - mean, tot = cnt + nb;
+      mean += delta * nb / tot;
+      m2 += bm2c + delta * delta * cnt * nb / tot;
+      cnt = tot;
+    }
+  }
+  s_cnt[bl][cc] = cnt, s_mean[bl][cc] = mean, s_m2[bl][cc] = m2;
+  __syncthreads();
+  if (bl != 0 || c >= C) return;
+  for (int k = 1; k < kFinLanes; ++k) {          // Chan's merge of two partial (count, mean, M2) triples, in bl order
+    const double nb = s_cnt[k][cc];
+    if (nb == 0.0) continue;
+    const double delta = s_mean[k][cc] - mean, tot = cnt + nb;
     mean += delta * nb / tot;
-    m2 += bm2c + delta * delta * cnt * nb / tot;
+    m2 += s_m2[k][cc] + delta * delta * cnt * nb / tot;
     cnt = tot;
   }
   const float var = (float)(m2 / cnt);
@@ -126,22 +146,34 @@ __global__ void k_bn_combine(const float* __restrict__ partial, int nblocks, int
   }
 }
 
-// one thread per column: partials in block order, fp64
-__global__ void k_col_final(const float* __restrict__ partial, int nblocks, int nsum, int C, double* out) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= nsum * C) return;
+// column sums of the block partials, fp64: ncol = nsum * C columns of [nblocks][ncol] (launch: ceil(ncol / 16) x 256)
+__device__ __forceinline__ double col_final_sum(const float* __restrict__ partial, int nblocks, int ncol, int c, int bl, int cc,
+                                                double (*sh)[kFinCols]) {
   double s = 0.0;
-  for (int b = 0; b < nblocks; ++b) s += (double)partial[(size_t)b * nsum * C + c];
-  out[c] = s;
+  if (c < ncol)
+    for (int b = bl; b < nblocks; b += kFinLanes) s += (double)partial[(size_t)b * ncol + c];
+  sh[bl][cc] = s;
+  __syncthreads();
+  double t = 0.0;
+  if (bl == 0)
+    for (int k = 0; k < kFinLanes; ++k) t += sh[k][cc];
+  return t;
+}
+__global__ void __launch_bounds__(256) k_col_final(const float* __restrict__ partial, int nblocks, int nsum, int C, double* out) {
+  __shared__ double sh[kFinLanes][kFinCols];
+  const int cc = threadIdx.x % kFinCols, bl = threadIdx.x / kFinCols;
+  const int c = blockIdx.x * kFinCols + cc;
+  const double t = col_final_sum(partial, nblocks, nsum * C, c, bl, cc, sh);
+  if (bl == 0 && c < nsum * C) out[c] = t;
 }
 
 // the same sum written as fp32 (a3d_column_sums: one launch instead of k_col_final + a conversion kernel)
-__global__ void k_col_final_f32(const float* __restrict__ partial, int nblocks, int C, float* out) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  double s = 0.0;
-  for (int b = 0; b < nblocks; ++b) s += (double)partial[(size_t)b * C + c];
-  out[c] = (float)s;
+__global__ void __launch_bounds__(256) k_col_final_f32(const float* __restrict__ partial, int nblocks, int C, float* out) {
+  __shared__ double sh[kFinLanes][kFinCols];
+  const int cc = threadIdx.x % kFinCols, bl = threadIdx.x / kFinCols;
+  const int c = blockIdx.x * kFinCols + cc;
+  const double t = col_final_sum(partial, nblocks, C, c, bl, cc, sh);
+  if (bl == 0 && c < C) out[c] = (float)t;
 }
 
 __global__ void k_scale_f64(const double* in, int C, double f, double* out) {
@@ -366,7 +398,7 @@ extern "C" int a3d_bn_train_forward(const float* x_dev, int ldx, int64_t n, int 
   (void)sums;
   (void)cb;
   k_bn_block_stats<<<blocks, kBnThreads, 0, st>>>(c);
-  k_bn_combine<<<(unsigned)((C + 255) / 256), 256, 0, st>>>(partial, blocks, c.rows_per_block, (int)n, C, eps, save_mean_dev,
+  k_bn_combine<<<(unsigned)((C + kFinCols - 1) / kFinCols), 256, 0, st>>>(partial, blocks, c.rows_per_block, (int)n, C, eps, save_mean_dev,
                                                              save_rstd_dev, running_mean_dev, running_var_dev, momentum);
   ApplyArgs a;
   a.x = x_dev, a.mean = save_mean_dev, a.rstd = save_rstd_dev, a.gamma = gamma_dev, a.beta = beta_dev, a.res = res_dev;
@@ -401,7 +433,7 @@ extern "C" int a3d_bn_train_backward(const float* x_dev, int ldx, const float* y
   c.ldx = ldx, c.ldy = ldy, c.lddy = lddy, c.n = (int)n, c.C = C, c.relu = relu, c.mode = 2, c.partial = partial;
   const int blocks = bn_blocks(n, c.rows_per_block);
   k_col_partial<<<blocks, kBnThreads, 0, st>>>(c);
-  k_col_final<<<(unsigned)((2 * C + 255) / 256), 256, 0, st>>>(partial, blocks, 2, C, sums);
+  k_col_final<<<(unsigned)((2 * C + kFinCols - 1) / kFinCols), 256, 0, st>>>(partial, blocks, 2, C, sums);
   BwdArgs b;
   b.x = x_dev, b.y = y_dev, b.dy = dy_dev, b.mean = save_mean_dev, b.rstd = save_rstd_dev, b.gamma = gamma_dev;
   b.sums = sums, b.param_sums = sums, b.n_stat = (double)n, b.zero_row = zero_row;
@@ -444,12 +476,13 @@ extern "C" int a3d_bn_local_stats(const float* x_dev, int ldx, int64_t n, int C,
   const unsigned cb = (unsigned)((2 * C + 255) / 256);
   c.mode = 0;
   k_col_partial<<<blocks, kBnThreads, 0, st>>>(c);
-  k_col_final<<<cb, 256, 0, st>>>(partial, blocks, 1, C, sums);
+  const unsigned fb = (unsigned)((C + kFinCols - 1) / kFinCols);
+  k_col_final<<<fb, 256, 0, st>>>(partial, blocks, 1, C, sums);
   k_bn_mean<<<cb, 256, 0, st>>>(sums, C, (double)n, meanf);
   k_scale_f64<<<cb, 256, 0, st>>>(sums, C, 1.0 / (double)n, stats_dev);              // the mean in fp64
   c.mode = 1, c.mean = meanf;
   k_col_partial<<<blocks, kBnThreads, 0, st>>>(c);
-  k_col_final<<<cb, 256, 0, st>>>(partial, blocks, 1, C, stats_dev + C);
+  k_col_final<<<fb, 256, 0, st>>>(partial, blocks, 1, C, stats_dev + C);
   A3D_LAUNCH_CHECK();
   return A3D_OK;
 }
@@ -490,7 +523,7 @@ extern "C" int a3d_bn_backward_sums(const float* x_dev, int ldx, const float* y_
   c.ldx = ldx, c.ldy = ldy, c.lddy = lddy, c.n = (int)n, c.C = C, c.relu = relu, c.mode = 2, c.partial = partial;
   const int blocks = bn_blocks(n, c.rows_per_block);
   k_col_partial<<<blocks, kBnThreads, 0, st>>>(c);
-  k_col_final<<<(unsigned)((2 * C + 255) / 256), 256, 0, st>>>(partial, blocks, 2, C, sums_dev);
+  k_col_final<<<(unsigned)((2 * C + kFinCols - 1) / kFinCols), 256, 0, st>>>(partial, blocks, 2, C, sums_dev);
   A3D_LAUNCH_CHECK();
   return A3D_OK;
 }
@@ -534,7 +567,7 @@ extern "C" int a3d_column_sums(const float* x_dev, int ldx, int64_t n, int C, fl
   c.x = x_dev, c.ldx = ldx, c.n = (int)n, c.C = C, c.partial = partial, c.mode = 0;
   const int blocks = bn_blocks(n, c.rows_per_block);
   k_col_partial<<<blocks, kBnThreads, 0, st>>>(c);
-  k_col_final_f32<<<(unsigned)((C + 255) / 256), 256, 0, st>>>(partial, blocks, C, out_dev);
+  k_col_final_f32<<<(unsigned)((C + kFinCols - 1) / kFinCols), 256, 0, st>>>(partial, blocks, C, out_dev);
   A3D_LAUNCH_CHECK();
   return A3D_OK;
 }
@@ -575,7 +608,7 @@ extern "C" int a3d_layernorm_backward(const float* x_dev, int ldx, const float* 
   a.ldx = ldx, a.ldy = lddy, a.n = (int)n, a.C = C, a.eps = eps;
   const int blocks = bn_blocks(n, a.rows_per_block);
   k_ln_backward<<<blocks, 256, 0, st>>>(a);
-  k_col_final<<<(unsigned)((2 * C + 255) / 256), 256, 0, st>>>(partial, blocks, 2, C, sums);
+  k_col_final<<<(unsigned)((2 * C + kFinCols - 1) / kFinCols), 256, 0, st>>>(partial, blocks, 2, C, sums);
   k_ln_params<<<(unsigned)((C + 255) / 256), 256, 0, st>>>(sums, C, dgamma_dev, dbeta_dev);
   A3D_LAUNCH_CHECK();
   return A3D_OK;

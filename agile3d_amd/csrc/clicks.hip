@@ -28,7 +28,7 @@ constexpr unsigned kInfBits = 0x7f800000u;
 constexpr int kQueriesPerThread = 2;
 constexpr int kNearestBlock = 256;
 constexpr int kNearestSplit = 128;           // candidate chunks (grid.y): enough waves when only a few thousand points are wrong
-constexpr int kSample = 16;                  // phase A: every kSample-th point is a candidate (A3D_CLICK_SAMPLE overrides: 4..64)
+constexpr int kSample = 16;                  // phase A: every kSample-th point is a candidate
 constexpr long long kSmallPairs = 1ll << 30;  // (wrong points) x (points) below which phase A is skipped: the plain pass is ~0.15 ms
 constexpr int kMaxChamp = 1024;              // clusters that get a lower bound (phase B); further ones are not pruned
 constexpr int kChampSplit = 8;
@@ -463,12 +463,7 @@ extern "C" int a3d_click_clusters(const float* xyz_dev, const int32_t* pred_dev,
     const char* e = getenv("A3D_CLICK_PRUNE");
     prune = e ? atoi(e) : 1;
   }
-  static int stride = 0;   // A3D_CLICK_SAMPLE: sampling stride of phase A (measurements)
-  if (!stride) {
-    const char* e = getenv("A3D_CLICK_SAMPLE");
-    stride = e ? atoi(e) : kSample;
-    if (stride < 4 || stride > 64) stride = kSample;
-  }
+  const int stride = kSample;   // strides 8 / 16 / 32 / 64 measured in round 3: 16 is the best or second best everywhere
   const bool bounded = prune && n >= 64 * stride;
   A3D_HIP_CHECK(hipMemsetAsync(w.table, 0, w.zero_bytes, st));   // tables + counters
   const unsigned nb = (unsigned)((n + 255) / 256);

@@ -11,7 +11,7 @@
 //                                                  never materialises [heads,Q,N]; the label-derived
 //                                                  mask (agile3d.py:367-380) is evaluated from one
 //                                                  byte per point + per-label counts
-//   everything of size [Q,128]                  -> k_query_layer: one workgroup, activations resident
+//   everything of size [Q,128]                  -> k_query_block: one workgroup + FFN helpers per 64-query block, activations resident
 //                                                  in LDS (Q <= 64); for 64 < Q <= 256 the queries are
 //                                                  processed in blocks of 64 (one workgroup per block,
 //                                                  split in two launches around the self attention)
@@ -207,11 +207,11 @@ struct QueryMeta {   // device-resident, uploaded once per forward_mask
 struct QueryBufs {   // all [QP][...] fp32 in global scratch
   float *queries, *qpos, *qproj, *ks, *vs, *E;
   float *attn, *tmp, *tgt, *qk, *vc, *hidden;   // hidden: FFN partial sums of the helper workgroups [kQlMaxHelpers][QP][128]
-  unsigned* sync;                                // [A3D_MAX_DEC_LAYERS][16] hand-off flags of k_query_layer (zeroed per pass)
+  unsigned* sync;                                // [A3D_MAX_DEC_LAYERS][16] hand-off flags of k_query_block (zeroed per pass)
 };
 constexpr int kQlMaxHelpers = 8;
 
-// ---- one batch sample as the query-side kernels see it (k_query_init, k_c2s_combine, k_query_layer: blockIdx.y)
+// ---- one batch sample as the query-side kernels see it (k_query_init, k_c2s_combine, k_query_block: blockIdx.y / z)
 struct QuerySample {
   const QueryMeta* meta;
   QueryBufs B;
@@ -811,8 +811,7 @@ __global__ void __launch_bounds__(256) k_ln_mask(float* Y, int n, const float* _
 // Persistent 8-wave workgroups: packed Wq (64 KB) + the queries' keys / values in LDS.
 template <int QT>
 __global__ void __launch_bounds__(512) k_q_s2c(const DecSampleDev* __restrict__ samples, int ns, int layer,
-                                               const float* __restrict__ Wq, const float* __restrict__ bq,
-                                               unsigned long long* dbg) {
+                                               const float* __restrict__ Wq, const float* __restrict__ bq) {
   constexpr int QP = QT * 16, LD = 132, NW = 8;
   const DecSampleDev& sm = sample_of_wg(samples, ns);
   const int lb = blockIdx.x - sm.wg_begin, nwg = sm.wg_end - sm.wg_begin;
@@ -822,7 +821,6 @@ __global__ void __launch_bounds__(512) k_q_s2c(const DecSampleDev* __restrict__ 
   const float* ks = sm.ks;
   const float* vs = sm.vs;
   float* __restrict__ O = sm.bufB;
-  const unsigned long long t_start = dbg ? __builtin_amdgcn_s_memtime() : 0;   // A3D_DEC_DBG=1: per-wave phase cycles
   extern __shared__ __attribute__((aligned(16))) char smem[];
   f32x4* Wl = (f32x4*)smem;                       // [8 S][8 ct][64]
   constexpr int LT = QP + 4;                      // row stride of the transposed values (16-byte rows, bank spread)
@@ -865,16 +863,6 @@ __global__ void __launch_bounds__(512) k_q_s2c(const DecSampleDev* __restrict__ 
     for (int S = 0; S < 8; ++S) np[S] = gld4(pr + 16 * S);
   };
   if (grp < ngroups) fetch(grp);
-  const unsigned long long t_loop = dbg ? __builtin_amdgcn_s_memtime() : 0;
-  unsigned long long tc[4] = {0, 0, 0, 0}, t_prev = t_loop;
-  int ngrp_done = 0;
-  auto lap = [&](int i) {
-    if (dbg) {
-      const unsigned long long t = __builtin_amdgcn_s_memtime();
-      tc[i] += t - t_prev;
-      t_prev = t;
-    }
-  };
   while (grp < ngroups) {
     const int p0 = grp * 16;
     const int prow = min(p0 + j, n - 1);
@@ -884,11 +872,6 @@ __global__ void __launch_bounds__(512) k_q_s2c(const DecSampleDev* __restrict__ 
     const int next = grp + stride;
     if (next < ngroups) fetch(next);
     float* orow = O + (size_t)prow * D;
-    ++ngrp_done;
-    if (dbg) {
-      asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-      lap(0);   // waiting for this group's rows
-    }
 #pragma unroll 2
     for (int h = 0; h < H; ++h) {
       // bias from LDS: the only vector-memory traffic inside the loop is the prefetch and the stores (vmcnt is
@@ -899,10 +882,6 @@ __global__ void __launch_bounds__(512) k_q_s2c(const DecSampleDev* __restrict__ 
         const f32x4 w = Wl[(S * 8 + h) * 64 + lane];
 #pragma unroll
         for (int t = 0; t < 4; ++t) qf = __builtin_amdgcn_mfma_f32_16x16x4f32(w[t], xp[S][t], qf, 0, 0, 0);
-      }
-      if (dbg) {
-        asm volatile("v_mov_b32 %0, %0" : "+v"(qf[0]));   // the clock is read after the MFMA chain
-        lap(1);
       }
       f32x4 sc[QT];
       float mx = kNegBig;
@@ -937,21 +916,8 @@ __global__ void __launch_bounds__(512) k_q_s2c(const DecSampleDev* __restrict__ 
         for (int t = 0; t < 4; ++t) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(vf[t], sc[kt][t] * inv, acc, 0, 0, 0);
       }
       if (p0 + j < n) gst4(orow + h * DH + 4 * g, acc);
-      if (dbg) {
-        asm volatile("v_mov_b32 %0, %0" : "+v"(acc[0]));
-        lap(2);
-      }
     }
     grp = next;
-  }
-  if (dbg && lane == 0) {
-    unsigned long long* r = dbg + (size_t)(blockIdx.x * NW + wave) * 8;
-    r[0] = t_loop - t_start;                                // prologue
-    r[1] = __builtin_amdgcn_s_memtime() - t_loop;           // loop
-    r[2] = tc[0], r[3] = tc[1], r[4] = tc[2];
-    r[5] = ngrp_done;
-    r[6] = t_start;
-    r[7] = __builtin_amdgcn_s_memtime();
   }
 }
 
@@ -1130,13 +1096,16 @@ __global__ void __launch_bounds__(512) k_out_ln_mask(const DecSampleDev* __restr
 // row reduction, no LDS scratch for the [16][Q] logits tile.
 // NW = waves per workgroup: 8 (two per SIMD, the next group's rows prefetched into 64 registers) or 12 (three per SIMD at
 // <= 168 registers: no register prefetch -- the third wave covers a wave's wait for its rows)
-template <int QT, int NW>
+// KG: the queries' key rows come from global memory (16 KB, cache resident; requested a whole Q projection before their
+// MFMAs) instead of LDS -- the build for 25..32 queries, where keys + transposed values + both weight matrices do not fit
+template <int QT, int NW, bool KG = false>
 __global__ void __launch_bounds__(NW * 64) k_s2c_out(const DecSampleDev* __restrict__ samples, int ns, int layer,
                                                  const float* __restrict__ Wq, const float* __restrict__ bq,
                                                  const float* __restrict__ Wo, const float* __restrict__ bo,
                                                  const float* __restrict__ gamma, const float* __restrict__ beta, int nqr_max,
                                                  int Kmax) {
-  constexpr int LD = 132, NT = NW * 64;
+  constexpr int LD = 136, NT = NW * 64;   // 136: the key fragments' ds_read_b128 (row 16 kt + j, floats 16 h + 4 g ..) are bank-
+                                          // conflict-free ((8 j + 4 g) mod 64 distinct inside a 16-lane service group; 132 was 2-way)
   constexpr bool PF = NW == 8;   // register prefetch of the next group
   const DecSampleDev& sm = sample_of_wg(samples, ns);
   const int lb = blockIdx.x - sm.wg_begin, nwg = sm.wg_end - sm.wg_begin;
@@ -1151,8 +1120,8 @@ __global__ void __launch_bounds__(NW * 64) k_s2c_out(const DecSampleDev* __restr
   extern __shared__ __attribute__((aligned(16))) char smem[];
   f32x4* Wql = (f32x4*)smem;                      // [8 S][8 ct][64]
   f32x4* Wol = Wql + 8 * 8 * 64;                  // [8 S][8 ct][64]
-  float* ks_l = (float*)(Wol + 8 * 8 * 64);       // [nqr_max][132]
-  float* vt_l = ks_l + nqr_max * LD;              // [128][LT]
+  float* ks_l = (float*)(Wol + 8 * 8 * 64);       // [nqr_max][LD] (not with KG)
+  float* vt_l = ks_l + (KG ? 0 : nqr_max * LD);   // [128][LT]
   float* bq_l = vt_l + D * LT;                    // [128] x 4: q bias, out bias, LayerNorm weight and bias
   float* bo_l = bq_l + D;
   float* ga_l = bo_l + D;
@@ -1193,7 +1162,7 @@ __global__ void __launch_bounds__(NW * 64) k_s2c_out(const DecSampleDev* __restr
       k4 = gld4(sm.ks + (size_t)r * D + c4);
       v4 = gld4(sm.vs + (size_t)r * D + c4);
     }
-    *(f32x4*)(ks_l + r * LD + c4) = k4;
+    if constexpr (!KG) *(f32x4*)(ks_l + r * LD + c4) = k4;
 #pragma unroll
     for (int t = 0; t < 4; ++t) vt_l[(c4 + t) * LT + r] = v4[t];
   }
@@ -1236,6 +1205,13 @@ __global__ void __launch_bounds__(NW * 64) k_s2c_out(const DecSampleDev* __restr
       f32x4 qf[2];
 #pragma unroll
       for (int u = 0; u < 2; ++u) qf[u] = *(const f32x4*)(bq_l + 16 * (h + u) + 4 * g);   // Q[point j][16h+4g..+3]
+      f32x4 kfg[2][QT];
+      if constexpr (KG) {
+#pragma unroll
+        for (int kt = 0; kt < QT; ++kt)
+#pragma unroll
+          for (int u = 0; u < 2; ++u) kfg[u][kt] = gld4(sm.ks + (size_t)min(kt * 16 + j, nq - 1) * D + (h + u) * DH + 4 * g);
+      }
       {
         // weight fragments one K-step ahead of the MFMAs that use them (left to itself the compiler issues the two
         // ds_read_b128 of a step right in front of its eight MFMAs and waits out the LDS latency every 256 cycles)
@@ -1266,7 +1242,8 @@ __global__ void __launch_bounds__(NW * 64) k_s2c_out(const DecSampleDev* __restr
         for (int kt = 0; kt < QT; ++kt)
 #pragma unroll
           for (int u = 0; u < 2; ++u) {
-            kf[u][kt] = *(const f32x4*)(ks_l + (kt * 16 + j) * LD + (h + u) * DH + 4 * g);
+            if constexpr (KG) kf[u][kt] = kfg[u][kt];
+            else kf[u][kt] = *(const f32x4*)(ks_l + (kt * 16 + j) * LD + (h + u) * DH + 4 * g);
             sc[u][kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
           }
 #pragma unroll
@@ -1436,7 +1413,6 @@ struct QueryLayerW {
   const float *qpack, *next_qpack, *mpack;       // fragment-order copies (k_query_block): this layer's, the next layer's, the mask head's
   int dim_ff;
   int layer;
-  unsigned long long* dbg;                       // A3D_DEC_DBG=2: s_memtime marks of workgroup (0, 0), else nullptr
 };
 
 
@@ -1578,18 +1554,10 @@ __global__ void __launch_bounds__(512) k_query_init(const QuerySample* __restric
 }
 
 // ---- query-side layer with all [Q,128] activations resident in LDS ---------------------------
-// 8 waves; in every GEMM round wave w owns output column tile(s) w (+8, ...).  Weight fragments are
-// loaded straight from the torch-layout rows (lane (g,j): W[n0+j][16S+4g..+3]) into registers, where
-// possible one round ahead of their use; activations never leave LDS between rounds (row stride 132
-// floats: conflict-free b128 A-fragment reads).
+// 8 waves; in every GEMM round wave w owns output column tile(s) w (+8, ...); activations never leave LDS between
+// rounds (row stride 132 floats: conflict-free b128 A-fragment reads).
 constexpr int kQLD = 132;
 
-__device__ __forceinline__ void qload_w(const float* __restrict__ W, int ldw, int row0, int col0, f32x4 (&wf)[8]) {
-  const int lane = threadIdx.x & 63, g = lane >> 4, j = lane & 15;
-  const float* p = W + (size_t)(row0 + j) * ldw + col0 + 4 * g;
-#pragma unroll
-  for (int S = 0; S < 8; ++S) wf[S] = gld4(p + 16 * S);
-}
 template <int QT>
 __device__ __forceinline__ void qmm(const float* Xl, const f32x4 (&wf)[8], f32x4 (&acc)[QT]) {
   const int lane = threadIdx.x & 63, g = lane >> 4, j = lane & 15;
@@ -1602,413 +1570,13 @@ __device__ __forceinline__ void qmm(const float* Xl, const f32x4 (&wf)[8], f32x4
       for (int t = 0; t < 4; ++t) acc[qt] = __builtin_amdgcn_mfma_f32_16x16x4f32(x[t], wf[S][t], acc[qt], 0, 0, 0);
     }
 }
-// y[q][col0 + j] = act((acc + bias) * scale) for q < Q; dst row stride ld (LDS, or global with G)
-template <int QT, bool G = false>
-__device__ __forceinline__ void qstore(const f32x4 (&acc)[QT], const float* __restrict__ bias, int bcol, float scale,
-                                       bool relu, float* dst, int ld, int col0, int Q) {
-  const int lane = threadIdx.x & 63, g = lane >> 4, j = lane & 15;
-  const float b = bias ? gld(bias + bcol + j) : 0.f;
-#pragma unroll
-  for (int qt = 0; qt < QT; ++qt)
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      const int q = qt * 16 + 4 * g + t;
-      if (q < Q) {
-        float y = (acc[qt][t] + b) * scale;
-        if (relu) y = fmaxf(y, 0.f);
-        if constexpr (G) gst(dst + (size_t)q * ld + col0 + j, y);
-        else dst[(size_t)q * ld + col0 + j] = y;
-      }
-    }
-}
 template <int QT>
 __device__ __forceinline__ void qzero(f32x4 (&acc)[QT]) {
 #pragma unroll
   for (int qt = 0; qt < QT; ++qt) acc[qt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 }
-// dst[q] = LayerNorm(a[q] + b[q]) (b optional), all LDS, rows q < Q; one wave per row
-__device__ __forceinline__ void qadd_ln(const float* a, const float* b, int Q, const float* __restrict__ w,
-                                        const float* __restrict__ bias, float* dst, float* gdst) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
-  for (int q = wave; q < Q; q += nw) {
-    float x0 = a[q * kQLD + lane], x1 = a[q * kQLD + 64 + lane];
-    if (b) {
-      x0 += b[q * kQLD + lane];
-      x1 += b[q * kQLD + 64 + lane];
-    }
-    float s = x0 + x1;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
-    const float mean = s * (1.f / D);
-    const float d0 = x0 - mean, d1 = x1 - mean;
-    float v = d0 * d0 + d1 * d1;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    const float rstd = rsqrtf(v * (1.f / D) + kLnEps);
-    const float y0 = d0 * rstd * gld(w + lane) + gld(bias + lane), y1 = d1 * rstd * gld(w + 64 + lane) + gld(bias + 64 + lane);
-    dst[q * kQLD + lane] = y0;
-    dst[q * kQLD + 64 + lane] = y1;
-    if (gdst) {
-      gst(gdst + (size_t)q * D + lane, y0);
-      gst(gdst + (size_t)q * D + 64 + lane, y1);
-    }
-  }
-}
-
-// PART 0: the whole layer in one workgroup (nq <= 64).  More queries run as blocks of QP rows, one
-// workgroup each, in two launches around the click-to-click attention (which needs every block's
-// keys/values): PART 1 = steps 1-2 up to the q/k/v projections (tgt kept in B.tgt), PART 2 = the rest.
-template <int QT, int PART>
-__global__ void __launch_bounds__(512) k_query_layer(const QuerySample* __restrict__ qs, QueryLayerW W) {
-  constexpr int QP = QT * 16;
-  const QueryMeta* meta = qs[blockIdx.y].meta;
-  QueryBufs B = qs[blockIdx.y].B;
-  // PART 0 with gridDim.x > 1: workgroup 0 runs the layer, workgroups 1.. are FFN helpers (each takes the hidden chunks
-  // c = x, x + nh, ... of the 1024-wide FFN, whose 1 MB of weights is what one workgroup alone spends 44 % of the
-  // layer pulling through one CU); hand-off through global memory with coherent (agent-scope) loads / stores + flags
-  const int nh = PART == 0 ? (int)gridDim.x : 1, hx = PART == 0 ? (int)blockIdx.x : 0;
-  const int q0 = PART == 0 ? 0 : blockIdx.x * QP;
-  const int Qall = meta->nq;
-  const float* all_qk = B.qk;
-  const float* all_vc = B.vc;
-  B.queries += (size_t)q0 * D; B.qpos += (size_t)q0 * D; B.qproj += (size_t)q0 * D; B.attn += (size_t)q0 * D;
-  B.ks += (size_t)q0 * D; B.vs += (size_t)q0 * D; B.E += (size_t)q0 * D; B.tgt += (size_t)q0 * D;
-  B.qk += (size_t)q0 * 2 * D; B.vc += (size_t)q0 * D;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  float* qpos = (float*)smem;            // [QP][132]  query position encodings (later: mask MLP hidden)
-  float* cur = qpos + QP * kQLD;         // queries -> tgt -> queries
-  float* xa = cur + QP * kQLD;           // GEMM input staging
-  float* xb = xa + QP * kQLD;            // GEMM output staging / FFN hidden chunk
-  int* any_slot = (int*)(xb + QP * kQLD);   // one word behind the tiles (block_any)
-  const int Q = max(0, min(QP, Qall - q0));
-  const int tid = threadIdx.x, nt = blockDim.x;
-  const int wave = tid >> 6;
-  f32x4 wfa[8], wfb[8], acc[QT];
-  auto mark = [&](int i) {
-    if (W.dbg && tid == 0 && blockIdx.x == 0 && blockIdx.y == 0) W.dbg[i] = __builtin_amdgcn_s_memtime();
-  };
-  mark(0);
-
-  if constexpr (PART == 0) {
-    if (hx > 0) {   // ---- FFN helper
-      const int nchunk = W.dim_ff >> 7;
-      if (hx >= nchunk) return;
-      unsigned* flags = B.sync + W.layer * 16;
-      qload_w(W.ffn_w1t, D, hx * 128 + 16 * wave, 0, wfa);            // first chunk's weights while waiting
-      int late = 0;   // a wait that gives up (seconds: never in a healthy run) turns what this workgroup hands on into NaN
-      if (tid == 0) {
-        unsigned spins = 0;
-        while (gld_agent(flags) == 0u) {
-          __builtin_amdgcn_s_sleep(2);
-          if (++spins > (1u << 26)) {
-            late = 1;
-            break;
-          }
-        }
-      }
-      const float bad = block_any(late, any_slot) ? __builtin_nanf("") : 0.f;
-      for (int e = tid; e < QP * 128; e += nt) {
-        const int q = e >> 7, c = e & 127;
-        cur[q * kQLD + c] = gld_agent(B.tgt + (size_t)q * D + c);
-      }
-      __syncthreads();
-      f32x4 facc[QT];
-      qzero<QT>(facc);
-      for (int c = hx; c < nchunk; c += nh) {
-        qload_w(W.ffn_w2t, W.dim_ff, 16 * wave, c * 128, wfb);
-        qzero<QT>(acc);
-        qmm<QT>(cur, wfa, acc);
-        qstore<QT>(acc, W.ffn_b1, c * 128 + 16 * wave, 1.f, true, xb, kQLD, 16 * wave, QP);
-        if (c + nh < nchunk) qload_w(W.ffn_w1t, D, (c + nh) * 128 + 16 * wave, 0, wfa);
-        __syncthreads();
-        qmm<QT>(xb, wfb, facc);
-        __syncthreads();
-      }
-      {   // partial sums out, coherent stores, then the flag
-        const int lane = tid & 63, g = lane >> 4, j = lane & 15;
-        float* part = B.hidden + (size_t)hx * QP * D;
-#pragma unroll
-        for (int qt = 0; qt < QT; ++qt)
-#pragma unroll
-          for (int t = 0; t < 4; ++t)
-            gst_agent(part + (size_t)(qt * 16 + 4 * g + t) * D + 16 * wave + j, facc[qt][t] + bad);
-      }
-      __builtin_amdgcn_s_waitcnt(0x0F70);
-      __syncthreads();
-      if (tid == 0) gst_agent(flags + hx, 1u);
-      // ---- second job of helpers 1..3: one of the projections that depend only on the layer's new queries
-      if (nh < 4 || nchunk < 4 || hx > 3 || (hx == 3 && !W.next_c2s_in_wt)) return;
-      const float* wsrc = hx == 1 ? W.s2c_in_wt + (size_t)D * D : hx == 2 ? W.s2c_in_wt + (size_t)2 * D * D : W.next_c2s_in_wt;
-      qload_w(wsrc, D, 16 * wave, 0, wfa);
-      late = 0;
-      if (tid == 0) {
-        unsigned spins = 0;
-        while (gld_agent(flags + 8) == 0u) {
-          __builtin_amdgcn_s_sleep(2);
-          if (++spins > (1u << 26)) {
-            late = 1;
-            break;
-          }
-        }
-      }
-      const float bad2 = block_any(late, any_slot) ? __builtin_nanf("") : 0.f;
-      for (int e = tid; e < QP * 128; e += nt) {
-        const int q = e >> 7, c = e & 127;
-        float v = gld_agent(B.tgt + (size_t)q * D + c) + bad2;
-        if (hx != 2) v += q < Q ? gld(B.qpos + (size_t)q * D + c) : 0.f;   // keys / next query projection take queries + qpos
-        xa[q * kQLD + c] = v;
-      }
-      __syncthreads();
-      qzero<QT>(acc);
-      qmm<QT>(xa, wfa, acc);
-      if (hx == 1) qstore<QT, true>(acc, W.s2c_in_b, D + 16 * wave, 0.25f, false, B.ks, D, 16 * wave, Q);        // keys pre-scaled
-      else if (hx == 2) qstore<QT, true>(acc, W.s2c_in_b, 2 * D + 16 * wave, 1.f, false, B.vs, D, 16 * wave, Q);
-      else qstore<QT, true>(acc, W.next_c2s_in_b, 16 * wave, 0.25f, false, B.qproj, D, 16 * wave, Q);
-      return;
-    }
-  }
-
-  if constexpr (PART != 2) {
-  // ---- load the layer inputs (queries, qpos, click-to-scene attention result) into LDS
-  qload_w(W.c2s_out_wt, D, 16 * wave, 0, wfa);                      // first round's weights meanwhile
-  for (int e = tid; e < QP * 32; e += nt) {
-    const int q = e >> 5, c4 = (e & 31) * 4;
-    f32x4 vq = (f32x4){0.f, 0.f, 0.f, 0.f}, vp = vq, va = vq;
-    if (q < Q) {
-      vq = gld4(B.queries + (size_t)q * D + c4);
-      vp = gld4(B.qpos + (size_t)q * D + c4);
-      va = gld4(B.attn + (size_t)q * D + c4);
-    }
-    *(f32x4*)(cur + q * kQLD + c4) = vq;
-    *(f32x4*)(qpos + q * kQLD + c4) = vp;
-    *(f32x4*)(xa + q * kQLD + c4) = va;
-  }
-  __syncthreads();
-  mark(1);
-  // ---- 1. click-to-scene output projection + residual + LayerNorm (attention_block.py:95-96)
-  qzero<QT>(acc);
-  qmm<QT>(xa, wfa, acc);
-  qstore<QT>(acc, W.c2s_out_b, 16 * wave, 1.f, false, xb, kQLD, 16 * wave, QP);
-  qload_w(W.c2c_in_wt, D, 16 * wave, 0, wfa);                       // q rows of the c2c in_proj
-  qload_w(W.c2c_in_wt, D, D + 16 * wave, 0, wfb);                   // k rows
-  __syncthreads();
-  qadd_ln(cur, xb, Q, W.c2s_norm_w, W.c2s_norm_b, cur, nullptr);     // cur = tgt
-  __syncthreads();
-  mark(2);
-  // ---- 2. click-to-click self attention (attention_block.py:32-36): q|k from tgt+qpos, v from tgt
-  for (int e = tid; e < QP * 128; e += nt) {
-    const int q = e >> 7, c = e & 127;
-    xa[q * kQLD + c] = cur[q * kQLD + c] + qpos[q * kQLD + c];
-  }
-  __syncthreads();
-  f32x4 accq[QT];
-  qzero<QT>(accq);
-  qmm<QT>(xa, wfa, accq);
-  qzero<QT>(acc);
-  qmm<QT>(xa, wfb, acc);
-  if constexpr (PART == 0) {
-    // single block: q, k, v stay in LDS (k -> xb, v -> the qpos buffer, which is re-read from global after the
-    // attention; q -> xa once every wave is done reading xa): the attention loop below never touches global memory
-    qstore<QT>(acc, W.c2c_in_b, D + 16 * wave, 1.f, false, xb, kQLD, 16 * wave, Q);             // k
-    qload_w(W.c2c_in_wt, D, 2 * D + 16 * wave, 0, wfa);                                         // v rows
-    qzero<QT>(acc);
-    qmm<QT>(cur, wfa, acc);
-    qstore<QT>(acc, W.c2c_in_b, 2 * D + 16 * wave, 1.f, false, qpos, kQLD, 16 * wave, Q);       // v
-    __syncthreads();                                                                            // xa fully consumed
-    qstore<QT>(accq, W.c2c_in_b, 16 * wave, 0.25f, false, xa, kQLD, 16 * wave, Q);              // q (pre-scaled)
-  } else {
-    qstore<QT, true>(accq, W.c2c_in_b, 16 * wave, 0.25f, false, B.qk, 2 * D, 16 * wave, Q);           // q (pre-scaled)
-    qstore<QT, true>(acc, W.c2c_in_b, D + 16 * wave, 1.f, false, B.qk, 2 * D, D + 16 * wave, Q);      // k
-    qload_w(W.c2c_in_wt, D, 2 * D + 16 * wave, 0, wfa);                                         // v rows
-    qzero<QT>(acc);
-    qmm<QT>(cur, wfa, acc);
-    qstore<QT, true>(acc, W.c2c_in_b, 2 * D + 16 * wave, 1.f, false, B.vc, D, 16 * wave, Q);          // v
-  }
-  if constexpr (PART == 1) {
-    for (int e = tid; e < QP * 32; e += nt) {
-      const int q = e >> 5, c4 = (e & 31) * 4;
-      gst4(B.tgt + (size_t)q * D + c4, *(const f32x4*)(cur + q * kQLD + c4));
-    }
-    return;
-  }
-  } else {
-    for (int e = tid; e < QP * 32; e += nt) {
-      const int q = e >> 5, c4 = (e & 31) * 4;
-      *(f32x4*)(cur + q * kQLD + c4) = gld4(B.tgt + (size_t)q * D + c4);
-      f32x4 vp = (f32x4){0.f, 0.f, 0.f, 0.f};
-      if (q < Q) vp = gld4(B.qpos + (size_t)q * D + c4);
-      *(f32x4*)(qpos + q * kQLD + c4) = vp;
-    }
-  }
-  mark(3);
-  qload_w(W.c2c_out_wt, D, 16 * wave, 0, wfa);                      // next round's weights
-  __syncthreads();
-  // keys / values of the attention: LDS (PART 0) or the global buffers every block wrote (PART 2)
-  const float* kbase = PART == 0 ? xb : all_qk + D;
-  const float* vbase = PART == 0 ? qpos : all_vc;
-  const int kld = PART == 0 ? kQLD : 2 * D, vld = PART == 0 ? kQLD : D;
-  auto kvld = [](const float* p) {   // LDS in the single-block layer, the blocks' global buffers otherwise
-    if constexpr (PART == 0) return *p;
-    else return gld(p);
-  };
-  for (int e = tid; e < Q * H; e += nt) {
-    const int q = e / H, h = e % H;
-    float qv[DH];
-#pragma unroll
-    for (int d = 0; d < DH; ++d) qv[d] = PART == 0 ? xa[q * kQLD + h * DH + d] : gld(B.qk + (size_t)q * 2 * D + h * DH + d);
-    float mx = kNegBig;
-    for (int k = 0; k < Qall; ++k) {
-      float sdot = 0.f;
-#pragma unroll
-      for (int d = 0; d < DH; ++d) sdot += qv[d] * kvld(kbase + (size_t)k * kld + h * DH + d);
-      mx = fmaxf(mx, sdot);
-    }
-    float sum = 0.f, o[DH];
-#pragma unroll
-    for (int d = 0; d < DH; ++d) o[d] = 0.f;
-    for (int k = 0; k < Qall; ++k) {
-      float sdot = 0.f;
-#pragma unroll
-      for (int d = 0; d < DH; ++d) sdot += qv[d] * kvld(kbase + (size_t)k * kld + h * DH + d);
-      const float pw = expf(sdot - mx);
-      sum += pw;
-#pragma unroll
-      for (int d = 0; d < DH; ++d) o[d] += pw * kvld(vbase + (size_t)k * vld + h * DH + d);
-    }
-    const float inv = 1.f / sum;
-#pragma unroll
-    for (int d = 0; d < DH; ++d) xa[q * kQLD + h * DH + d] = o[d] * inv;
-  }
-  mark(4);
-  for (int e = tid; e < (QP - Q) * 128; e += nt) xa[(Q + (e >> 7)) * kQLD + (e & 127)] = 0.f;   // padded rows
-  __syncthreads();
-  if constexpr (PART == 0) {   // the qpos buffer held v: restore the position encodings for step 4
-    for (int e = tid; e < QP * 32; e += nt) {
-      const int q = e >> 5, c4 = (e & 31) * 4;
-      f32x4 vp = (f32x4){0.f, 0.f, 0.f, 0.f};
-      if (q < Q) vp = gld4(B.qpos + (size_t)q * D + c4);
-      *(f32x4*)(qpos + q * kQLD + c4) = vp;
-    }
-  }
-  qzero<QT>(acc);
-  qmm<QT>(xa, wfa, acc);
-  qstore<QT>(acc, W.c2c_out_b, 16 * wave, 1.f, false, xb, kQLD, 16 * wave, QP);
-  qload_w(W.ffn_w1t, D, 16 * wave, 0, wfa);                         // FFN chunk 0, hidden tile `wave`
-  __syncthreads();
-  qadd_ln(cur, xb, Q, W.c2c_norm_w, W.c2c_norm_b, cur, nullptr);
-  __syncthreads();
-  if (PART == 0 && nh > 1) {   // hand tgt to the FFN helpers
-    for (int e = tid; e < QP * 128; e += nt) {
-      const int q = e >> 7, c = e & 127;
-      gst_agent(B.tgt + (size_t)q * D + c, cur[q * kQLD + c]);
-    }
-    __builtin_amdgcn_s_waitcnt(0x0F70);
-    __syncthreads();
-    if (tid == 0) gst_agent(B.sync + W.layer * 16, 1u);
-  }
-  mark(5);
-  // ---- 3. FFN (attention_block.py:151-155) in hidden chunks of 128: wave w computes hidden tile w of
-  //         the chunk into xb, then accumulates output tile w over the chunk
-  f32x4 facc[QT];
-  qzero<QT>(facc);
-  const int nchunk = W.dim_ff >> 7;
-  for (int c = 0; c < nchunk; c += nh) {
-    qload_w(W.ffn_w2t, W.dim_ff, 16 * wave, c * 128, wfb);          // linear2 rows (output cols), chunk cols
-    qzero<QT>(acc);
-    qmm<QT>(cur, wfa, acc);
-    qstore<QT>(acc, W.ffn_b1, c * 128 + 16 * wave, 1.f, true, xb, kQLD, 16 * wave, QP);
-    if (c + nh < nchunk) qload_w(W.ffn_w1t, D, (c + nh) * 128 + 16 * wave, 0, wfa);
-    __syncthreads();
-    qmm<QT>(xb, wfb, facc);
-    __syncthreads();
-  }
-  if (PART == 0 && nh > 1) {   // the helpers' partial sums, in helper order
-    const int nhelp = min(nh, nchunk) - 1;
-    int late = 0;
-    if (tid < nhelp) {
-      unsigned spins = 0;
-      while (gld_agent(B.sync + W.layer * 16 + 1 + tid) == 0u) {
-        __builtin_amdgcn_s_sleep(2);
-        if (++spins > (1u << 26)) {
-          late = 1;
-          break;
-        }
-      }
-    }
-    if (block_any(late, any_slot)) {
-#pragma unroll
-      for (int qt = 0; qt < QT; ++qt) facc[qt] += __builtin_nanf("");
-    }
-    const int lane = tid & 63, g = lane >> 4, j = lane & 15;
-    for (int h = 1; h <= nhelp; ++h) {
-      const float* part = B.hidden + (size_t)h * QP * D;
-#pragma unroll
-      for (int qt = 0; qt < QT; ++qt)
-#pragma unroll
-        for (int t = 0; t < 4; ++t)
-          facc[qt][t] += gld_agent(part + (size_t)(qt * 16 + 4 * g + t) * D + 16 * wave + j);
-    }
-  }
-  mark(6);
-  qstore<QT>(facc, W.ffn_b2, 16 * wave, 1.f, false, xa, kQLD, 16 * wave, QP);
-  const bool deleg = PART == 0 && nh >= 4 && nchunk >= 4;           // helpers 1..3 take the s2c keys / values / next qproj
-  if (!deleg) {
-    qload_w(W.s2c_in_wt, D, D + 16 * wave, 0, wfa);                 // s2c k rows
-    qload_w(W.s2c_in_wt, D, 2 * D + 16 * wave, 0, wfb);             // s2c v rows
-  } else {
-    qload_w(W.m_w0t, D, 16 * wave, 0, wfa);
-  }
-  __syncthreads();
-  qadd_ln(cur, xa, Q, W.ffn_norm_w, W.ffn_norm_b, cur, B.queries);   // cur = queries (also to global)
-  __syncthreads();
-  if (deleg) {
-    for (int e = tid; e < QP * 128; e += nt) {
-      const int q = e >> 7, c = e & 127;
-      gst_agent(B.tgt + (size_t)q * D + c, cur[q * kQLD + c]);
-    }
-    __builtin_amdgcn_s_waitcnt(0x0F70);
-    __syncthreads();
-    if (tid == 0) gst_agent(B.sync + W.layer * 16 + 8, 1u);
-  }
-  mark(7);
-  // ---- 4. everything that depends only on the new queries: s2c keys/values, mask MLP layer 0, next
-  //         iteration's c2s query projection
-  qadd_ln(cur, nullptr, Q, W.dn_w, W.dn_b, xb, nullptr);             // decoder_norm(queries)
-  if (!deleg) {
-    for (int e = tid; e < QP * 128; e += nt) {
-      const int q = e >> 7, c = e & 127;
-      xa[q * kQLD + c] = cur[q * kQLD + c] + qpos[q * kQLD + c];
-    }
-    __syncthreads();
-    qzero<QT>(acc);
-    qmm<QT>(xa, wfa, acc);
-    qstore<QT, true>(acc, W.s2c_in_b, D + 16 * wave, 0.25f, false, B.ks, D, 16 * wave, Q);   // keys pre-scaled
-    qload_w(W.m_w0t, D, 16 * wave, 0, wfa);
-    qzero<QT>(acc);
-    qmm<QT>(cur, wfb, acc);
-    qstore<QT, true>(acc, W.s2c_in_b, 2 * D + 16 * wave, 1.f, false, B.vs, D, 16 * wave, Q);
-    if (W.next_c2s_in_wt) {
-      qload_w(W.next_c2s_in_wt, D, 16 * wave, 0, wfb);
-      qzero<QT>(acc);
-      qmm<QT>(xa, wfb, acc);
-      qstore<QT, true>(acc, W.next_c2s_in_b, 16 * wave, 0.25f, false, B.qproj, D, 16 * wave, Q);
-    }
-  }
-  __syncthreads();                                                   // everyone is done reading xa / qpos
-  qzero<QT>(acc);
-  qmm<QT>(xb, wfa, acc);
-  qstore<QT>(acc, W.m_b0, 16 * wave, 1.f, true, qpos, kQLD, 16 * wave, QP);          // mask MLP hidden
-  qload_w(W.m_w2t, D, 16 * wave, 0, wfa);
-  __syncthreads();
-  qzero<QT>(acc);
-  qmm<QT>(qpos, wfa, acc);
-  qstore<QT, true>(acc, W.m_b2, 16 * wave, 1.f, false, B.E, D, 16 * wave, Q);
-  mark(8);
-}
-
-
 // ---- the single-block layer (nq <= 64), second build ---------------------------------------------------------
-// Same arithmetic as k_query_layer<QT, 0>; what changed is what the workgroup WAITS for.  Measured on the first build
+// The first build (k_query_layer, removed in round 4) spent its time WAITING.  Measured on it
 // (20 queries, phase marks): 62 us of which the MFMAs are ~6 -- every phase ended in an on-demand global load (a bias, a
 // LayerNorm vector) whose vmcnt wait also drained the weight prefetch behind it, a 6-step LDS-shuffle reduction per
 // LayerNorm row, and a scalar click-to-click attention on 2.5 waves.  Here:
@@ -2287,10 +1855,6 @@ __global__ void __launch_bounds__(512) k_query_block(const QuerySample* __restri
   unsigned* flags = B.sync + (W.layer * kMaxQBlocks + blk) * 16;
   f32x4 wfa[8], wfb[8], wfc[8], wfd[8], acc[QT];
   constexpr bool kDeep = QT <= 2;   // the fourth fragment set in flight across the load phase and the attention (registers)
-  auto mark = [&](int i) {
-    if (W.dbg && tid == 0 && hx == 0 && blockIdx.y == 0 && blockIdx.z == 0) W.dbg[i] = __builtin_amdgcn_s_memtime();
-  };
-  mark(0);
 
   if (PART != 1 && hx > 0) {   // ---- FFN helper
     if (hx >= nchunk) return;
@@ -2443,7 +2007,6 @@ __global__ void __launch_bounds__(512) k_query_block(const QuerySample* __restri
     if constexpr (PART == 0 && !kDeep) qload_p(W.qpack + kQpC2cIn, 8, 16 + wave, 0, wfd);
   }
   __syncthreads();
-  mark(1);
   const int cw = 16 * wave + j;                           // this lane's output column in every 128-wide GEMM
   if constexpr (PART != 2) {
   // ---- 1. click-to-scene output projection + residual + LayerNorm (attention_block.py:95-96)
@@ -2459,7 +2022,6 @@ __global__ void __launch_bounds__(512) k_query_block(const QuerySample* __restri
   __syncthreads();
   qln16<QT>(cur, xb, Q, vec_l + V_C2S_NW, vec_l + V_C2S_NB, cur, xa, qpos, PART == 1 ? B.tgt : nullptr, nullptr);   // cur = tgt, xa = tgt + qpos
   __syncthreads();
-  mark(2);
   // ---- 2. click-to-click self attention (attention_block.py:32-36): q | k from tgt + qpos, v from tgt
   if constexpr (PART == 1) {   // to the buffers every block reads in PART 2
     qload_p(W.qpack + kQpC2cIn, 8, 16 + wave, 0, wfd);
@@ -2491,11 +2053,9 @@ __global__ void __launch_bounds__(512) k_query_block(const QuerySample* __restri
   qload_p(W.qpack + qpack_ffn2(W.dim_ff), W.dim_ff >> 4, wave, 0, wfc);   // linear2 rows (output columns), chunk 0 columns
   if constexpr (kDeep) load_d();
   __syncthreads();
-  mark(3);
   qattn_mfma<QT>(xa, xb, qpos, Q, Q);
   if constexpr (!kDeep) load_d();
   __syncthreads();
-  mark(4);
   if (!deleg) {   // the qpos buffer held v: restore the position encodings for step 4
     for (int e = tid; e < QP * 32; e += nt) {
       const int q = e >> 5, c4 = (e & 31) * 4;
@@ -2506,11 +2066,9 @@ __global__ void __launch_bounds__(512) k_query_block(const QuerySample* __restri
   }
   } else {
     // ---- 2 (continued): attention of this block's queries over every block's keys / values
-    mark(3);
     qattn_mfma_global<QT>(xa, B.qk, all_qk, all_vc, Q, Qall);
     load_d();
     __syncthreads();
-    mark(4);
   }
   qzero<QT>(acc);
   qmm<QT>(xa, wfa, acc);
@@ -2526,7 +2084,6 @@ __global__ void __launch_bounds__(512) k_query_block(const QuerySample* __restri
   } else {
     __syncthreads();
   }
-  mark(5);
   // ---- 3. FFN (attention_block.py:151-155) in hidden chunks of 128: wave w computes hidden tile w of the chunk into
   //         xb, then accumulates output tile w over the chunk
   f32x4 facc[QT];
@@ -2570,7 +2127,6 @@ __global__ void __launch_bounds__(512) k_query_block(const QuerySample* __restri
         for (int t = 0; t < 4; ++t) facc[qt][t] += gld_agent(part + (size_t)(qt * 16 + 4 * g + t) * D + 16 * wave + j);
     }
   }
-  mark(6);
   qstore_b<QT>(facc, vec_l[V_FFN_B2 + cw], 1.f, false, xa, kQLD, 16 * wave, QP);
   __syncthreads();
   // cur = the layer's new queries (also to global; to the helpers when they take the projections; + qpos for this workgroup's own)
@@ -2582,7 +2138,6 @@ __global__ void __launch_bounds__(512) k_query_block(const QuerySample* __restri
   } else {
     __syncthreads();
   }
-  mark(7);
   // ---- 4. everything that depends only on the new queries: s2c keys / values, mask MLP, next layer's c2s query projection
   qln16<QT>(cur, nullptr, Q, vec_l + V_DN_W, vec_l + V_DN_B, xb, nullptr, nullptr, nullptr, nullptr);   // decoder_norm(queries)
   if (!deleg) {
@@ -2609,7 +2164,6 @@ __global__ void __launch_bounds__(512) k_query_block(const QuerySample* __restri
   qzero<QT>(acc);
   qmm<QT>(qpos, wfa, acc);
   qstore_b<QT, true>(acc, vec_l[V_M_B2 + cw], 1.f, false, B.E, D, 16 * wave, Q);
-  mark(8);
 }
 
 }  // namespace a3d
@@ -2711,7 +2265,7 @@ void dec_layout(int64_t n, int nq, DecLayout& L) {
   L.q[9] = take(2 * qb);                                // qk
   L.q[10] = take(qb);                                   // vc
   L.q[11] = take((size_t)L.qp * 4096 * 4);              // hidden: kQlMaxHelpers x [qp][128] FFN partial sums fit (dim_ff <= 4096)
-  L.sync = take((size_t)kMaxBatchSamples * A3D_MAX_DEC_LAYERS * kMaxQBlocks * 16 * 4);   // k_query_layer flags of a batched call (first sample's workspace)
+  L.sync = take((size_t)kMaxBatchSamples * A3D_MAX_DEC_LAYERS * kMaxQBlocks * 16 * 4);   // k_query_block flags of a batched call (first sample's workspace)
   L.total = off;
 }
 }  // namespace
@@ -2823,18 +2377,12 @@ static int run_decoder(const a3d_decoder_weights* w, Prepared* P, int ns, hipStr
     if (!big) {
       big = true;
       const int big_lds = 160 * 1024;
-      A3D_ALLOW_LDS(big_lds, k_query_layer<1, 0>);
-      A3D_ALLOW_LDS(big_lds, k_query_layer<2, 0>);
-      A3D_ALLOW_LDS(big_lds, k_query_layer<3, 0>);
-      A3D_ALLOW_LDS(big_lds, k_query_layer<4, 0>);
       A3D_ALLOW_LDS(big_lds, k_query_block<1, 0>);
       A3D_ALLOW_LDS(big_lds, k_query_block<2, 0>);
       A3D_ALLOW_LDS(big_lds, k_query_block<3, 0>);
       A3D_ALLOW_LDS(big_lds, k_query_block<4, 0>);
       A3D_ALLOW_LDS(big_lds, k_query_block<4, 1>);
       A3D_ALLOW_LDS(big_lds, k_query_block<4, 2>);
-      A3D_ALLOW_LDS(big_lds, k_query_layer<4, 1>);
-      A3D_ALLOW_LDS(big_lds, k_query_layer<4, 2>);
       A3D_ALLOW_LDS(big_lds, k_s2c_attn_wide<4>);
       A3D_ALLOW_LDS(big_lds, k_q_s2c<1>);
       A3D_ALLOW_LDS(big_lds, k_q_s2c<2>);
@@ -2848,6 +2396,10 @@ static int run_decoder(const a3d_decoder_weights* w, Prepared* P, int ns, hipStr
       A3D_ALLOW_LDS(big_lds, k_s2c_out<2, 8>);
       A3D_ALLOW_LDS(big_lds, k_s2c_out<1, 12>);
       A3D_ALLOW_LDS(big_lds, k_s2c_out<2, 12>);
+      A3D_ALLOW_LDS(big_lds, (k_s2c_out<2, 12, true>));
+      A3D_ALLOW_LDS(big_lds, (k_s2c_out<2, 8, true>));
+      A3D_ALLOW_LDS(big_lds, (k_s2c_out<1, 12, true>));
+      A3D_ALLOW_LDS(big_lds, (k_s2c_out<1, 8, true>));
       A3D_ALLOW_LDS(big_lds, k_kv_c2s<1>);
       A3D_ALLOW_LDS(big_lds, k_kv_c2s<2>);
       A3D_ALLOW_LDS(big_lds, k_kv_c2s<3>);
@@ -2885,9 +2437,13 @@ static int run_decoder(const a3d_decoder_weights* w, Prepared* P, int ns, hipStr
   // scene-to-click + output projection + LayerNorm + mask head as ONE kernel when both packed weight matrices and the
   // queries' compact keys / values fit the LDS (about 24 queries at 5 objects); A3D_FUSED_S2C=0 keeps the two kernels
   const int nqr_max = (nq_max + 3) & ~3;
-  const size_t s2c_out_lds = (size_t)128 * 1024 + ((size_t)nqr_max * 132 + (size_t)D * (nqr_max + 4) + 4 * D +
-                                                   (size_t)8 * 16 * (Kmax + 1) + 2 * Kmax + 3) * 4;
-  const size_t s2c_out_lds12 = s2c_out_lds + (size_t)4 * 16 * (Kmax + 1) * 4;   // twelve waves' logits staging
+  const size_t s2c_rest = ((size_t)D * (nqr_max + 4) + 4 * D + (size_t)8 * 16 * (Kmax + 1) + 2 * Kmax + 3) * 4;
+  const size_t s2c_keys = (size_t)nqr_max * 136 * 4;
+  const size_t staging12 = (size_t)4 * 16 * (Kmax + 1) * 4;   // twelve waves' logits staging
+  // the keys move out of LDS (k_s2c_out<.., KG>) when everything else still fits: 25..32 queries at 5 objects
+  const bool s2c_kg = (size_t)128 * 1024 + s2c_keys + s2c_rest + staging12 > 160 * 1024;
+  const size_t s2c_out_lds = (size_t)128 * 1024 + (s2c_kg ? 0 : s2c_keys) + s2c_rest;
+  const size_t s2c_out_lds12 = s2c_out_lds + staging12;
   static int fused_s2c_env = -1;
   if (fused_s2c_env < 0) {
     const char* e = getenv("A3D_FUSED_S2C");
@@ -3024,40 +2580,25 @@ static int run_decoder(const a3d_decoder_weights* w, Prepared* P, int ns, hipStr
     QW.mpack = w->mask_pack;
     QW.dim_ff = w->dim_ff;
     QW.layer = l;
-    QW.dbg = nullptr;
-    {
-      static int dbg_on = -1;
-      static unsigned long long* qdbg = nullptr;
-      if (dbg_on < 0) {
-        const char* e = getenv("A3D_DEC_DBG");
-        dbg_on = e && atoi(e) == 2;
-        if (dbg_on) (void)hipMalloc(&qdbg, 16 * sizeof(unsigned long long));
-      }
-      if (dbg_on && l == 0) QW.dbg = qdbg;
-    }
     {   // one workgroup (or chain of query blocks) per sample: blockIdx.y
       ProfScope ps(st, A3D_PROF_QUERY, 0, 0, 0, 0, nq_max);
       k_c2s_combine<<<dim3(nq_max * H, ns), 64, 0, st>>>(qs_dev, P[0].L.qp, cached0 ? 1 : 0);
       const size_t ql_lds = (size_t)4 * QP * kQLD * 4 + 16;   // four [QP][132] tiles + the word of block_any
-      // FFN helper workgroups next to a block's workgroup (A3D_QL_HELPERS = total workgroups per block, 1 = none)
-      static int nh_env = -1, v1 = -1;   // A3D_QL_V1=1: the first build of the layer kernel (A/B switch)
+      // FFN helper workgroups next to a block's workgroup (A3D_QL_HELPERS = total workgroups per block, 1 = none: the
+      // switch the tests use to compare the hand-off with the single-workgroup chain)
+      static int nh_env = -1;
       if (nh_env < 0) {
         const char* e = getenv("A3D_QL_HELPERS");
         nh_env = e ? atoi(e) : kQlMaxHelpers;
         nh_env = nh_env < 1 ? 1 : nh_env > kQlMaxHelpers ? kQlMaxHelpers : nh_env;
-        e = getenv("A3D_QL_V1");
-        v1 = e ? atoi(e) : 0;
       }
-      const bool have_packs = QW.qpack && QW.mpack && (QW.next_qpack || !QW.next_c2s_in_wt);
+      if (!(QW.qpack && QW.mpack && (QW.next_qpack || !QW.next_c2s_in_wt))) {
+        set_error("a3d_decoder_forward: the decoder weights carry no query-side packs (a3d_decoder_pack_query_weights "
+                  "fills a3d_decoder_layer::query_pack and a3d_decoder_weights::mask_pack)");
+        return A3D_ERR_INVALID;
+      }
       const size_t qb_lds = ql_lds + (size_t)kQVec * 4;
-      if (v1 || !have_packs) {   // torch-layout weights
-        if (nblk == 1) {
-          k_query_layer<QT, 0><<<dim3(nh_env, ns), 512, ql_lds, st>>>(qs_dev, QW);
-        } else {
-          k_query_layer<QT, 1><<<dim3(nblk, ns), 512, ql_lds, st>>>(qs_dev, QW);
-          k_query_layer<QT, 2><<<dim3(nblk, ns), 512, ql_lds, st>>>(qs_dev, QW);
-        }
-      } else if (nblk == 1) {
+      if (nblk == 1) {
         k_query_block<QT, 0><<<dim3(nh_env, 1, ns), 512, qb_lds, st>>>(qs_dev, QW);
       } else if constexpr (QT == 4) {
         k_query_block<4, 1><<<dim3(1, nblk, ns), 512, qb_lds, st>>>(qs_dev, QW);
@@ -3065,26 +2606,18 @@ static int run_decoder(const a3d_decoder_weights* w, Prepared* P, int ns, hipStr
       }
     }
     A3D_LAUNCH_CHECK();
-    if (QW.dbg) {   // phase marks of the query-side workgroup of sample 0 (debugging aid, synchronous)
-      unsigned long long h[16];
-      (void)hipMemcpyAsync(h, QW.dbg, sizeof(h), hipMemcpyDeviceToHost, st);
-      (void)hipStreamSynchronize(st);
-      fprintf(stderr, "k_query_layer dbg (ticks): load %llu | c2s out+LN %llu | qkv proj %llu | c2c attn %llu | "
-                      "c2c out+LN %llu | FFN %llu | LN %llu | s2c kv, qproj, mask MLP %llu | total %llu\n",
-              h[1] - h[0], h[2] - h[1], h[3] - h[2], h[4] - h[3], h[5] - h[4], h[6] - h[5], h[7] - h[6], h[8] - h[7],
-              h[8] - h[0]);
-    }
     // ---- scene-to-click: Q = (src + pos) Wq^T + bq; attention; Y = O Wo^T + bo + src; LN
     if (fuse_all) {
       // the whole half in one pass: O never reaches HBM (k_s2c_out)
       ProfScope ps(st, A3D_PROF_S2C, 0, 0, 0, 0, (int)n_total);
       if constexpr (QT <= 2) {
-        static int s2c_w12 = -1;   // A3D_S2C_WAVES=8: the two-waves-per-SIMD build with the register prefetch
-        if (s2c_w12 < 0) {
-          const char* e = getenv("A3D_S2C_WAVES");
-          s2c_w12 = e ? atoi(e) == 12 : 1;
-        }
-        if (s2c_w12 && s2c_out_lds12 <= 160 * 1024)
+        if (s2c_kg && s2c_out_lds12 <= 160 * 1024)
+          k_s2c_out<QT, 12, true><<<grid, 768, s2c_out_lds12, st>>>(samples_dev, ns, l, LW.s2c_wq_packed, LW.s2c_in_b, LW.s2c_wo_packed,
+                                                                   LW.s2c_out_b, LW.s2c_norm_w, LW.s2c_norm_b, nqr_max, Kmax);
+        else if (s2c_kg)
+          k_s2c_out<QT, 8, true><<<grid, 512, s2c_out_lds, st>>>(samples_dev, ns, l, LW.s2c_wq_packed, LW.s2c_in_b, LW.s2c_wo_packed,
+                                                                LW.s2c_out_b, LW.s2c_norm_w, LW.s2c_norm_b, nqr_max, Kmax);
+        else if (s2c_out_lds12 <= 160 * 1024)   // twelve waves (three per SIMD) when their logits staging fits, else eight
           k_s2c_out<QT, 12><<<grid, 768, s2c_out_lds12, st>>>(samples_dev, ns, l, LW.s2c_wq_packed, LW.s2c_in_b, LW.s2c_wo_packed,
                                                              LW.s2c_out_b, LW.s2c_norm_w, LW.s2c_norm_b, nqr_max, Kmax);
         else
@@ -3096,33 +2629,8 @@ static int run_decoder(const a3d_decoder_weights* w, Prepared* P, int ns, hipStr
     }
     if (fuse_s2c) {
       ProfScope ps(st, A3D_PROF_S2C, 0, 0, 0, 0, (int)n_total);
-      static int dec_dbg = -1;
-      static unsigned long long* dbg_buf = nullptr;
-      if (dec_dbg < 0) {
-        const char* e = getenv("A3D_DEC_DBG");
-        dec_dbg = e ? atoi(e) : 0;
-        if (dec_dbg) (void)hipMalloc(&dbg_buf, (size_t)256 * 8 * 8 * sizeof(unsigned long long));
-      }
-      k_q_s2c<QT><<<grid, 512, (size_t)64 * 1024 + qs2c_lds, st>>>(samples_dev, ns, l, LW.s2c_wq_packed, LW.s2c_in_b, dbg_buf);
+      k_q_s2c<QT><<<grid, 512, (size_t)64 * 1024 + qs2c_lds, st>>>(samples_dev, ns, l, LW.s2c_wq_packed, LW.s2c_in_b);
       A3D_LAUNCH_CHECK();
-      if (dbg_buf && l == 0) {   // per-wave phase cycles of the first layer's launch (debugging aid, synchronous)
-        static unsigned long long hb[256 * 8 * 8];
-        (void)hipMemcpyAsync(hb, dbg_buf, (size_t)grid * 8 * 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st);
-        (void)hipStreamSynchronize(st);
-        double sum[6] = {0, 0, 0, 0, 0, 0};
-        unsigned long long t0 = ~0ull, t1 = 0, mx_loop = 0;
-        for (int wv = 0; wv < grid * 8; ++wv) {
-          const unsigned long long* r = hb + (size_t)wv * 8;
-          for (int i = 0; i < 6; ++i) sum[i] += (double)r[i];
-          t0 = r[6] < t0 ? r[6] : t0;
-          t1 = r[7] > t1 ? r[7] : t1;
-          mx_loop = r[1] > mx_loop ? r[1] : mx_loop;
-        }
-        const double nw = grid * 8.0;
-        fprintf(stderr, "k_q_s2c dbg (memtime ticks, mean per wave): prologue %.0f loop %.0f (max %llu) = wait %.0f + qproj %.0f + attn %.0f; "
-                        "groups/wave %.2f; kernel span %llu ticks\n", sum[0] / nw, sum[1] / nw, mx_loop, sum[2] / nw, sum[3] / nw,
-                sum[4] / nw, sum[5] / nw, t1 - t0);
-      }
     } else {
       for (int si = 0; si < ns; ++si) {
         Prepared& p = P[si];
@@ -3293,12 +2801,7 @@ extern "C" int a3d_decoder_forward_batch(const a3d_decoder_weights* w, const a3d
     ++n_groups;
     i = e;
   }
-  static int side_env = -1;   // A3D_DEC_SIDE=0: every group on the caller's stream (A/B)
-  if (side_env < 0) {
-    const char* e = getenv("A3D_DEC_SIDE");
-    side_env = e ? atoi(e) : 1;
-  }
-  bool use_side = n_groups > 1 && side_env;
+  bool use_side = n_groups > 1;
   if (use_side && !side.tried) {
     side.tried = true;
     bool ok = hipEventCreateWithFlags(&side.fork, hipEventDisableTiming) == hipSuccess;

@@ -33,11 +33,6 @@ namespace a3d {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-static int sk_env_early(const char* name, int dflt) {
-  const char* e = getenv(name);
-  return e ? atoi(e) : dflt;
-}
-
 struct ConvArgs {
   const float* in;
   int ldi, n_in;
@@ -88,7 +83,6 @@ struct SkArgs {
   unsigned in_row_bytes; // ldi * 4
   int* fail;             // set when a bounded wait ran out (never in a healthy run)
   int prio;              // 1: static wave priority by occupancy layer (ticket / 256), see the kernel
-  int dbg;               // A3D_DBG ablations: 1 no A gather, 2 no weight DMA, 4 no MFMA, 8 no stage-end vmcnt wait
 };
 
 __device__ __forceinline__ void store_sc1(float* p, f32x4 v) {   // write-through (agent scope) 16-byte store
@@ -115,13 +109,12 @@ __device__ __forceinline__ void glds16_s(const float* sbase, unsigned voff, unsi
 __device__ __forceinline__ void wait_all_vmem() { __builtin_amdgcn_s_waitcnt(0x0F70); }
 
 // BN output columns, CH input channels per stage; PAIR: weight fragments two at a time (16 registers for the B operand
-// instead of 8 BN / 16: the low-register build, 3-4 workgroups per CU); DBG: the A3D_DBG ablation switches (compiled out
-// of the product kernels)
+// instead of 8 BN / 16: the low-register build, 3-4 workgroups per CU)
 // PAIR == 2 (opt-in, A3D_CONV_EMU=1, 96 columns x 32 channels only): fp32 products from SIX bf16 MFMAs -- both operands
 // split into three bf16 planes (x = h + m + l by truncation, every remainder exact), h h + h m + m h + h l + m m + l h on
 // v_mfma_f32_16x16x32_bf16 with fp32 accumulation.  Error no larger than the exact fp32 MFMA chain's (tools/
 // bf16x6_ubench.hip: 5.1e-6 against 7.5e-6 over 2592 products), stage loop 1.84x faster; weights packed as three planes.
-template <int BN, int CH, int PAIR, bool DBG = false>
+template <int BN, int CH, int PAIR>
 __global__ void __launch_bounds__(256, PAIR ? ((BN <= 96 && CH <= 32) ? 4 : 3) : ((BN <= 96 && CH <= 48) ? 3 : 2))
     k_conv_sk(const SkArgs a) {
   constexpr int RG = 1;   // 16-row groups per wave (two per wave -- 128-row tiles -- was tried and did not pay)
@@ -143,12 +136,6 @@ __global__ void __launch_bounds__(256, PAIR ? ((BN <= 96 && CH <= 32) ? 4 : 3) :
   const int T = a.c.n_tiles;
   const int cin16 = a.c.cin >> 4, cout16 = a.c.cout >> 4;
 
-  if (DBG && (a.dbg & 32)) return;   // launch only
-  // A3D_DBG & 128: one line per workgroup (ticket, XCC / HW ids, start / end cycles, stages, cycles spent at stage ends and in
-  // the hand-off wait) -- tools/wg_timeline.py
-  unsigned long long tl_t0 = 0, tl_wait = 0, tl_hand = 0;
-  int tl_stages = 0, tl_tiles = 0;
-  if (DBG && (a.dbg & 128)) tl_t0 = __builtin_amdgcn_s_memtime();
   int w = blockIdx.x;
   const long long pre_T = a.pre ? (long long)a.pre[T] : (long long)K * T;   // requested before the ticket's round trip
   if (a.ticket) {
@@ -220,10 +207,6 @@ __global__ void __launch_bounds__(256, PAIR ? ((BN <= 96 && CH <= 32) ? 4 : 3) :
     hi = tot;
   }
 
-  if (DBG && (a.dbg & 16)) {   // launch + ticket + share search only
-    if (u_lo + u_hi == -12345) a.c.out[0] = 0.f;
-    return;
-  }
   // this wave's weight pieces q = wave + NW*i of a stage: constant per-lane source byte offset, LDS byte offset
   unsigned wsrc[WV], wdst[WV];
 #pragma unroll
@@ -302,7 +285,7 @@ __global__ void __launch_bounds__(256, PAIR ? ((BN <= 96 && CH <= 32) ? 4 : 3) :
       // stage (k, c): this lane's A fragments (for its groups that have k), this wave's weight pieces by LDS-DMA
       auto load_stage = [&](f32x4 (&A)[RG][NS], int kk, int cc, int slot, const int (&rows)[RG]) {
         const char* ar = inb + (size_t)cc * (CH * 4);
-        if (((gm >> kk) & 1u) && !(DBG && (a.dbg & 1))) {
+        if ((gm >> kk) & 1u) {
 #pragma unroll
           for (int r = 0; r < RG; ++r) {
             const unsigned roff = (unsigned)rows[r] * a.in_row_bytes + lane_a_off;
@@ -310,16 +293,15 @@ __global__ void __launch_bounds__(256, PAIR ? ((BN <= 96 && CH <= 32) ? 4 : 3) :
             for (int Sx = 0; Sx < NS; ++Sx) A[r][Sx] = *(const f32x4*)(ar + roff + (EMU ? 16 : 64) * Sx);
           }
         }
-        const float* wst = (DBG && (a.dbg & 64)) ? wbase   // ablation: every stage reads the same (cache-hot) weight slice
-                           : EMU ? a.c.w + (((size_t)kk * nchunk + cc) * cout16 + ct0) * (3 * 256)
-                                 : wbase + ((size_t)kk * cin16 + (size_t)cc * NS) * cout16 * 256;
+        const float* wst = EMU ? a.c.w + (((size_t)kk * nchunk + cc) * cout16 + ct0) * (3 * 256)
+                               : wbase + ((size_t)kk * cin16 + (size_t)cc * NS) * cout16 * 256;
         const unsigned dst = ring_addr + (unsigned)slot * (WF * 4u);
 #pragma unroll
         for (int i = 0; i < WV; ++i)
-          if ((NPIECE % NW == 0 || wave + NW * i < NPIECE) && !(DBG && (a.dbg & 2))) glds16_s(wst, wsrc[i], dst + wdst[i]);
+          if (NPIECE % NW == 0 || wave + NW * i < NPIECE) glds16_s(wst, wsrc[i], dst + wdst[i]);
       };
       auto compute = [&](const f32x4 (&A)[RG][NS], int kk, int slot) {
-        if (!((gm >> kk) & 1u) || (DBG && (a.dbg & 4))) return;
+        if (!((gm >> kk) & 1u)) return;
         const f32x4* Ws = (const f32x4*)(wring + slot * WF) + lane;
         if constexpr (EMU) {
           typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
@@ -405,12 +387,6 @@ __global__ void __launch_bounds__(256, PAIR ? ((BN <= 96 && CH <= 32) ? 4 : 3) :
         }
       };
       f32x4 A0[RG][NS], A1[RG][NS];
-      if (DBG && (a.dbg & 1)) {
-#pragma unroll
-        for (int r = 0; r < RG; ++r)
-#pragma unroll
-          for (int Sx = 0; Sx < NS; ++Sx) A0[r][Sx] = A1[r][Sx] = (f32x4){1.f, 2.f, 3.f, 4.f};
-      }
       int rows_cur[RG], rows_nxt[RG];
       int k1 = next_k(k);
       fetch_rows(k, rows_cur);
@@ -432,16 +408,8 @@ __global__ void __launch_bounds__(256, PAIR ? ((BN <= 96 && CH <= 32) ? 4 : 3) :
           load_stage(A1, k2, c2, 1, rows_cur);
         }
         compute(A0, k, 0);
-        if (DBG && (a.dbg & 256)) {
-          const unsigned long long tw = __builtin_amdgcn_s_memtime();
-          wait_all_vmem();
-          __builtin_amdgcn_s_barrier();
-          tl_wait += __builtin_amdgcn_s_memtime() - tw;
-        } else {
-          wait_all_vmem();
-          __builtin_amdgcn_s_barrier();
-        }
-        if (DBG) ++tl_stages;
+        wait_all_vmem();
+        __builtin_amdgcn_s_barrier();
         if (--rem == 0) break;
         k = k2; c = c2;
         // ---- odd stage: multiply A1 / slot 1, fetch A0 / slot 0
@@ -456,25 +424,13 @@ __global__ void __launch_bounds__(256, PAIR ? ((BN <= 96 && CH <= 32) ? 4 : 3) :
           load_stage(A0, k2, c2, 0, rows_cur);
         }
         compute(A1, k, 1);
-        if (DBG && (a.dbg & 256)) {
-          const unsigned long long tw = __builtin_amdgcn_s_memtime();
-          wait_all_vmem();
-          __builtin_amdgcn_s_barrier();
-          tl_wait += __builtin_amdgcn_s_memtime() - tw;
-        } else {
-          wait_all_vmem();
-          __builtin_amdgcn_s_barrier();
-        }
-        if (DBG) ++tl_stages;
+        wait_all_vmem();
+        __builtin_amdgcn_s_barrier();
         if (--rem == 0) break;
         k = k2; c = c2;
       }
     }
 
-    if (DBG && (a.dbg & 8)) {   // no hand-off: parts are dropped, owners do not wait
-      if (!owner) continue;
-      s0 = 0;
-    }
     if (!owner) {
       // publish this part: write-through stores, every wave drains, one flag
       float* P = a.slab + (size_t)w * (kTile * BN) + (size_t)tid * 4;
@@ -492,7 +448,6 @@ __global__ void __launch_bounds__(256, PAIR ? ((BN <= 96 && CH <= 32) ? 4 : 3) :
         const int wf = (int)(((Cu + ov + 1) * G + tot - 1) / tot) - 1;
         // every flag is polled by its own thread; ONE acquire for the workgroup; then the parts are read with all
         // their loads in flight and added in a fixed order
-        const unsigned long long th0 = (DBG && (a.dbg & 128)) ? __builtin_amdgcn_s_memtime() : 0ull;
         for (int wp = wf + tid; wp < w; wp += 256) {
           unsigned spins = 0;
           while (__hip_atomic_load(a.flags + wp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
@@ -506,7 +461,6 @@ __global__ void __launch_bounds__(256, PAIR ? ((BN <= 96 && CH <= 32) ? 4 : 3) :
         __syncthreads();
         if (tid == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         __syncthreads();
-        if (DBG && (a.dbg & 128)) tl_hand += __builtin_amdgcn_s_memtime() - th0;
         const float* P0 = a.slab + (size_t)tid * 4;
         // fixed order: own part, then the parts of the tickets below, descending; U parts' loads in flight at a time
         constexpr int U = NCT <= 4 ? 2 : 1;
@@ -557,14 +511,6 @@ __global__ void __launch_bounds__(256, PAIR ? ((BN <= 96 && CH <= 32) ? 4 : 3) :
         }
       }
     }
-    if (DBG) ++tl_tiles;
-  }
-  if (DBG && (a.dbg & 128) && tid == 0) {
-    unsigned hwid, xcc;
-    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
-    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-    printf("TL w %d xcc %u hw %u t0 %llu t1 %llu stages %d tiles %d wait %llu hand %llu\n", w, xcc & 15u, hwid, tl_t0,
-           (unsigned long long)__builtin_amdgcn_s_memtime(), tl_stages, tl_tiles, tl_wait, tl_hand);
   }
 }
 
@@ -707,8 +653,7 @@ __global__ void __launch_bounds__(1024) k_conv_wl(const ConvArgs c, int ngroups)
 }
 
 static bool conv_wl_supported(const ConvArgs& c) {
-  static int off = sk_env_early("A3D_NO_WL", 0);
-  if (off || c.K <= 1 || !c.nbr || !c.gmask) return false;
+  if (c.K <= 1 || !c.nbr || !c.gmask) return false;
   if (!(c.cin == 32 && c.cout == 32)) return false;   // 64 -> 64 stride-2 (128 KB) measured slower than k_conv_sk (21 vs 18 us)
   return (size_t)c.K * c.cin * c.cout * 4 <= 144 * 1024;
 }
@@ -737,13 +682,13 @@ static int launch_conv_wl(const ConvArgs& c, hipStream_t st) {
 // wave's NEXT 16-row group are in flight behind the MFMAs of the current one, and the product is computed
 // TRANSPOSED (weights as the A operand), which leaves
 // four consecutive output channels of one row in each lane: 16-byte stores, 16-byte scale/shift/res loads.
-template <int NS, int NCT>
+template <int NS, int NCT, bool HAS2>   // HAS2: a second operand X2 is added to X (its 4 NS registers exist only then)
 __global__ void __launch_bounds__(768) k_dense(const float* __restrict__ X, int ldx, const float* __restrict__ X2,
                                                    int ldx2, int n, const float* __restrict__ Wp,
                                                    const float* __restrict__ scale, const float* __restrict__ shift,
                                                    const float* __restrict__ res, int ldr, int relu,
                                                    float* __restrict__ Y, int ldy, int ngroups, int zero_row,
-                                                   const int* __restrict__ out_map, int dbg) {
+                                                   const int* __restrict__ out_map) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   f32x4* Wl = (f32x4*)smem;                         // [NS][NCT][64 lanes]
   if (zero_row >= 0 && blockIdx.x == 0 && threadIdx.x < 16 * NCT) Y[(size_t)zero_row * ldy + threadIdx.x] = 0.f;
@@ -753,13 +698,13 @@ __global__ void __launch_bounds__(768) k_dense(const float* __restrict__ X, int 
   const int nw = blockDim.x >> 6;
   const int stride = gridDim.x * nw;
   int grp = blockIdx.x * nw + wave;
-  f32x4 nx[NS], nx2[NS];
+  f32x4 nx[NS], nx2[HAS2 ? NS : 1];
   auto fetch = [&](int gq) {
-    const int row = (dbg & 1) ? j : min(gq * 16 + j, n - 1);
+    const int row = min(gq * 16 + j, n - 1);
     const float* xr = X + (size_t)row * ldx + 4 * g;
 #pragma unroll
     for (int S = 0; S < NS; ++S) nx[S] = *(const f32x4*)(xr + 16 * S);
-    if (X2) {
+    if constexpr (HAS2) {
       const float* x2r = X2 + (size_t)row * ldx2 + 4 * g;
 #pragma unroll
       for (int S = 0; S < NS; ++S) nx2[S] = *(const f32x4*)(x2r + 16 * S);
@@ -783,26 +728,44 @@ __global__ void __launch_bounds__(768) k_dense(const float* __restrict__ X, int 
   while (grp < ngroups) {
     f32x4 a[NS];
 #pragma unroll
-    for (int S = 0; S < NS; ++S) a[S] = X2 ? nx[S] + nx2[S] : nx[S];
+    for (int S = 0; S < NS; ++S) {
+      if constexpr (HAS2) a[S] = nx[S] + nx2[S];
+      else a[S] = nx[S];
+    }
     const int next = grp + stride;
     if (next < ngroups) fetch(next);                // in flight behind this group's 32 NS NCT/8 k-cycles of MFMA
     f32x4 acc[NCT];
 #pragma unroll
     for (int ct = 0; ct < NCT; ++ct) acc[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    {
+      // two column tiles at a time on alternating accumulators (four MFMAs in a row on ONE accumulator wait out the
+      // matrix pipe's latency: a dependent issue every ~40 cycles instead of 32), the next pair's ds_read_b128s in flight
+      // behind the current pair's eight MFMAs (k_conv_sk's low-register loop)
+      static_assert(NCT % 2 == 0, "pairs of 16-column tiles");
+      constexpr int NP = NS * NCT / 2;
+      const f32x4* Ws = Wl + lane;
+      f32x4 c0 = Ws[0], c1 = Ws[64];
 #pragma unroll
-    for (int S = 0; S < NS; ++S) {
+      for (int pi = 0; pi < NP; ++pi) {
+        const int S = pi / (NCT / 2), ct = 2 * (pi % (NCT / 2));
+        f32x4 n0 = c0, n1 = c1;
+        if (pi + 1 < NP) {
+          n0 = Ws[(2 * pi + 2) * 64];
+          n1 = Ws[(2 * pi + 3) * 64];
+        }
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int ct = 0; ct < NCT; ++ct) {
-        const f32x4 w = Wl[(S * NCT + ct) * 64 + lane];
-        if (!(dbg & 4)) {
-#pragma unroll
-        for (int t = 0; t < 4; ++t) acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[t], a[S][t], acc[ct], 0, 0, 0);
-        } else acc[ct] += w * a[S];
+        for (int t = 0; t < 4; ++t) {
+          acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(c0[t], a[S][t], acc[ct], 0, 0, 0);
+          acc[ct + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(c1[t], a[S][t], acc[ct + 1], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        c0 = n0;
+        c1 = n1;
       }
-      asm volatile("" ::: "memory");   // keep the weight reads of later k-steps from being hoisted (256 VGPRs + spills)
     }
     // acc[ct][t] = Y[16 grp + j][16 ct + 4 g + t]
-    if (grp * 16 + j < n && (!(dbg & 2) || acc[0][0] == 123.456f)) {
+    if (grp * 16 + j < n) {
       const int row = out_map ? out_map[grp * 16 + j] : grp * 16 + j;
 #pragma unroll
       for (int ct = 0; ct < NCT; ++ct) {
@@ -839,23 +802,18 @@ static int launch_dense(const float* X, int ldx, const float* X2, int ldx2, int 
   // batch), 128 -> 96 / 96 -> 128: 4x2 387 / 366 us, 6x2 461 / 441, 8x2 379 / 364, 12x1 350 / 335 -- the kernel is latency-bound
   // on its row loads (TCP pending-stall 0.5-0.66 of its active cycles), twelve waves per CU keep more of them in flight; a
   // 128-register build with sixteen waves per CU measured the same 351 / 334 us and was dropped
-  static int shape_env = -1;
-  if (shape_env < 0) {
-    const char* e = getenv("A3D_DENSE_SHAPE");   // "<waves per workgroup><workgroups per CU>", e.g. 42
-    shape_env = e ? atoi(e) : 0;
-  }
-  const int shape = shape_env ? shape_env : (n >= 200000 ? 121 : 42);
-  int nw = shape / 10, wg_per_cu = shape % 10;
-  if (nw < 1 || nw > 12 || wg_per_cu < 1 || wg_per_cu > 2) nw = 4, wg_per_cu = 2;
-  static int dbg = -1;
-  if (dbg < 0) { const char* e = getenv("A3D_DENSE_DBG"); dbg = e ? atoi(e) : 0; }
+  const int nw = n >= 200000 ? 12 : 4, wg_per_cu = n >= 200000 ? 1 : 2;
   const size_t lds = (size_t)(cin / 16) * (cout / 16) * 1024;
   ProfScope ps(st, A3D_PROF_DENSE, 0, 1, cin, cout, n, A3D_OP_LINEAR, tag_level, 1);
   const int max_grid = 256 * wg_per_cu;
   const int grid = (ngroups + nw - 1) / nw < max_grid ? (ngroups + nw - 1) / nw : max_grid;
 #define A3D_DENSE(NS_, NCT_) \
-  k_dense<NS_, NCT_><<<grid, 64 * nw, lds, st>>>(X, ldx, X2, ldx2, n, Wp, scale, shift, res, ldr, relu, Y, ldy, ngroups, \
-                                             zero_row, out_map, dbg)
+  do { \
+    if (X2) k_dense<NS_, NCT_, true><<<grid, 64 * nw, lds, st>>>(X, ldx, X2, ldx2, n, Wp, scale, shift, res, ldr, relu, Y, ldy, ngroups, \
+                                                                 zero_row, out_map); \
+    else k_dense<NS_, NCT_, false><<<grid, 64 * nw, lds, st>>>(X, ldx, X2, ldx2, n, Wp, scale, shift, res, ldr, relu, Y, ldy, ngroups, \
+                                                               zero_row, out_map); \
+  } while (0)
   if (cin == 128 && cout == 128) A3D_DENSE(8, 8);
   else if (cin == 128 && cout == 96) A3D_DENSE(8, 6);
   else if (cin == 96 && cout == 128) A3D_DENSE(6, 8);
@@ -1119,17 +1077,10 @@ struct SkPlan {
   int bn, ch, pair, nchunk, ov, n_cblk, G, ntile;
   size_t lds, slab_floats;
 };
-static int sk_env(const char* name, int dflt) {
-  const char* e = getenv(name);
-  return e ? atoi(e) : dflt;
-}
 static int sk_ch(int cin, int bn) {   // input channels per stage
-  static int forced = sk_env("A3D_SK_CH", 0);   // experiment: stage width of the 96-column kernels
-  if (forced && bn == 96 && cin % forced == 0) return forced;
-  // 128-column workgroups: 32-channel stages as well (A3D_SK_CH128=64 for the wide ones).  Measured on the 16-scene
-  // batch (profiles/r03_experiments.txt): every <128,*> layer 1-3 % faster, L4 128 -> 256 63 -> 53 us
-  static int ch128 = sk_env("A3D_SK_CH128", 32);
-  if (bn == 128 && ch128 > 0 && cin % ch128 == 0) return ch128;
+  // 128-column workgroups: 32-channel stages as well.  Measured on the 16-scene batch against 64-channel stages
+  // (profiles/r03_experiments.txt): every <128,*> layer 1-3 % faster, L4 128 -> 256 63 -> 53 us
+  if (bn == 128 && cin % 32 == 0) return 32;
   // 96-column workgroups: 32-channel stages -- 157 registers, a 25 KB weight ring: THREE workgroups per CU, the third
   // covers the per-tile prologues / epilogues and the stage barriers of the other two (measured on the 4-scene batch:
   // L0 96 -> 96 700 -> 620 us = 108 TF/s, 128 -> 96 850 -> 790 us = 113 TF/s against 96- / 64-channel stages with two)
@@ -1164,8 +1115,6 @@ static int sk_wgs_per_cu(int bn, int ch, int pair, size_t lds) {
   return w < 1 ? 1 : (w > 4 ? 4 : w);
 }
 static SkPlan plan_sk(int n_rows, int K, int cin, int cout, bool handoff) {
-  static int ov_env = sk_env("A3D_SK_OV", 0), share_env = sk_env("A3D_SK_MINSHARE", 0), g_env = sk_env("A3D_SK_G", 0);
-  static int pair_env = sk_env("A3D_SK_PAIR", -1);
   SkPlan p;
   p.ntile = (n_rows + 63) / 64;
   if (p.ntile < 1) p.ntile = 1;
@@ -1179,25 +1128,24 @@ static SkPlan plan_sk(int n_rows, int K, int cin, int cout, bool handoff) {
     p.ch = sk_ch(cin, p.bn);
     p.nchunk = p.ch ? cin / p.ch : 1;
     p.n_cblk = cout / p.bn;
-    p.pair = pair_env >= 0 ? pair_env : sk_pair(p.bn, p.ch, n_rows);
+    p.pair = sk_pair(p.bn, p.ch, n_rows);
     if (conv_emu(K, cin, cout)) {
       p.ch = 32;
       p.nchunk = cin / 32;
       p.pair = 2;
     }
     const int mfma_per_stage = p.ch / 4 * (p.bn / 16);
-    p.ov = ov_env ? ov_env : (mfma_per_stage >= 128 ? 1 : mfma_per_stage >= 64 ? 2 : 3);   // per-tile overhead in stages
+    p.ov = mfma_per_stage >= 128 ? 1 : mfma_per_stage >= 64 ? 2 : 3;   // per-tile overhead in stages (swept in round 2)
     p.lds = (size_t)2 * p.ch * p.bn * (p.pair == 2 ? 6 : 4) + 64;   // three bf16 planes: 6 bytes per weight
-    gmax = g_env ? g_env : 256 * sk_wgs_per_cu(p.bn, p.ch, p.pair, p.lds);
+    gmax = 256 * sk_wgs_per_cu(p.bn, p.ch, p.pair, p.lds);
     if (gmax > kSkMaxG) gmax = kSkMaxG;
     const long long est = (long long)p.n_cblk * p.ntile * ((long long)p.nchunk * k_eff + p.ov);
-    const int min_share = share_env ? share_env : (mfma_per_stage >= 128 ? 6 : 8);
+    const int min_share = mfma_per_stage >= 128 ? 6 : 8;
     if (handoff) {
       long long G = est / min_share;
       // a level too small to hand every CU a share of that size: shorter shares (each workgroup's chain of stages is
       // what the layer waits for; the hand-off of a tile grows with the number of its parts, so not below small_share)
-      static int small_env = sk_env("A3D_SK_SMALLSHARE", 0);
-      const int small_share = small_env ? small_env : 4;
+      const int small_share = 4;   // 3 and 5 measured the same, 2 and 8 slower (round 2)
       if (G < 256 && small_share < min_share) {
         G = est / small_share;
         if (G > 256) G = 256;
@@ -1229,17 +1177,16 @@ static void allow_big_lds() {
   A3D_ALLOW_LDS(160 * 1024, k_conv_sk<128, 32, 2>);
   A3D_ALLOW_LDS(160 * 1024, k_conv_sk<64, 32, 2>);
   A3D_ALLOW_LDS(160 * 1024, k_conv_sk<32, 32, 2>);
-  A3D_ALLOW_LDS(160 * 1024, k_conv_sk<64, 64, 0, true>);
-  A3D_ALLOW_LDS(160 * 1024, k_conv_sk<96, 32, 0, true>);
-  A3D_ALLOW_LDS(160 * 1024, k_conv_sk<96, 32, 1, true>);
-  A3D_ALLOW_LDS(160 * 1024, k_conv_sk<96, 96, 0, true>);
-  A3D_ALLOW_LDS(160 * 1024, k_conv_sk<128, 64, 0, true>);
   A3D_ALLOW_LDS(160 * 1024, k_conv_wl<2, 2>);
   A3D_ALLOW_LDS(160 * 1024, k_conv_wl<4, 4>);
-  A3D_ALLOW_LDS(160 * 1024, k_dense<8, 8>);
-  A3D_ALLOW_LDS(160 * 1024, k_dense<8, 6>);
-  A3D_ALLOW_LDS(160 * 1024, k_dense<6, 8>);
-  A3D_ALLOW_LDS(160 * 1024, k_dense<6, 6>);
+  A3D_ALLOW_LDS(160 * 1024, (k_dense<8, 8, false>));
+  A3D_ALLOW_LDS(160 * 1024, (k_dense<8, 6, false>));
+  A3D_ALLOW_LDS(160 * 1024, (k_dense<6, 8, false>));
+  A3D_ALLOW_LDS(160 * 1024, (k_dense<6, 6, false>));
+  A3D_ALLOW_LDS(160 * 1024, (k_dense<8, 8, true>));
+  A3D_ALLOW_LDS(160 * 1024, (k_dense<8, 6, true>));
+  A3D_ALLOW_LDS(160 * 1024, (k_dense<6, 8, true>));
+  A3D_ALLOW_LDS(160 * 1024, (k_dense<6, 6, true>));
 }
 
 static int launch_conv_sk(ConvArgs c, const int* pre64, float* slab_ws, size_t slab_ws_floats, int* state,
@@ -1290,29 +1237,12 @@ static int launch_conv_sk(ConvArgs c, const int* pre64, float* slab_ws, size_t s
   a.flags = handoff ? (unsigned*)(state + 2) : nullptr;
   a.slab = slab_ws;
   a.in_row_bytes = (unsigned)c.ldi * 4u;
-  {
-    static int dbg = sk_env("A3D_DBG", 0);
-    a.dbg = dbg;
-    static int prio = sk_env("A3D_SK_PRIO", 1);   // measured +1 % on the 96-column layers (L0 593 -> 588 us); 0 switches it off
-    a.prio = handoff && p.G > 256 ? prio : 0;
-  }
+  a.prio = handoff && p.G > 256;   // static wave priorities: measured +1 % on the 96-column layers (L0 593 -> 588 us)
   if (c.K > 1 && !pre) {
     set_error("spconv: a gathered convolution needs the scene's tile prefix table");
     return A3D_ERR_INVALID;
   }
   ProfScope ps(st, A3D_PROF_SPCONV, p.bn, c.K, c.cin, c.cout, c.n_out, c.tag_table, c.tag_level, p.ch);   // last field: stage width
-  if (a.dbg) {   // ablation builds of the two shapes the measurements of DESIGN.md 4.1 use
-    if (p.bn == 64 && p.ch == 64 && p.pair == 0) k_conv_sk<64, 64, 0, true><<<p.G, 256, p.lds, st>>>(a);
-    else if (p.bn == 96 && p.ch == 32 && p.pair == 0) k_conv_sk<96, 32, 0, true><<<p.G, 256, p.lds, st>>>(a);
-    else if (p.bn == 96 && p.ch == 32 && p.pair == 1) k_conv_sk<96, 32, 1, true><<<p.G, 256, p.lds, st>>>(a);
-    else if (p.bn == 96 && p.ch == 96 && p.pair == 0) k_conv_sk<96, 96, 0, true><<<p.G, 256, p.lds, st>>>(a);
-    else if (p.bn == 128 && p.ch == 64 && p.pair == 0) k_conv_sk<128, 64, 0, true><<<p.G, 256, p.lds, st>>>(a);
-    else a.dbg = 0;
-    if (a.dbg) {
-      A3D_LAUNCH_CHECK();
-      return A3D_OK;
-    }
-  }
   if (p.pair == 2) {
     if (p.bn == 96) k_conv_sk<96, 32, 2><<<p.G, 256, p.lds, st>>>(a);
     else if (p.bn == 128) k_conv_sk<128, 32, 2><<<p.G, 256, p.lds, st>>>(a);

@@ -195,15 +195,10 @@ static bool wgrad_plan(int n_pos, int K, int cin, int cout, WgradPlan& p) {
   if (!best) return false;
   p.nblocks = (cin / (16 * p.cx)) * (cout / (16 * p.cy));
   const int ngroups = (n_pos + 15) / 16;
-  static int target = -1;
-  if (target < 0) {
-    const char* e = getenv("A3D_WGRAD_WGS");
-    target = e ? atoi(e) : 0;
-  }
   // workgroups over the whole launch: (chunk, offset) items differ a lot in work (rows are sorted by neighbour mask,
   // so an offset's pairs cluster in some chunks) -- many small items balance the big levels (measured: 3072 at 320 k
   // rows, 1536 below); every chunk costs a fold and a pass of the reduce kernel, so 1x1 maps stay at <= 256 chunks
-  const int tgt = target > 0 ? target : (n_pos > 200000 ? 3072 : 1536);
+  const int tgt = n_pos > 200000 ? 3072 : 1536;
   int chunks = (tgt + K * p.nblocks - 1) / (K * p.nblocks);
   if (chunks > 256) chunks = 256;
   if (chunks > (ngroups + 3) / 4) chunks = (ngroups + 3) / 4;      // at least one group per wave

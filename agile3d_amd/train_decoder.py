@@ -24,10 +24,9 @@ from . import lib as L
 from .engine import time_table
 
 H, DH = 8, 16
-# A3D_TRAIN_FLASH=0: the attentions over the N points keep their [8, Lq, Lk] score matrices (attn_train.hip), the path the
-# flash kernels (attn_flash.hip, default) are checked against
-import os as _os
-FLASH = _os.environ.get("A3D_TRAIN_FLASH", "1") != "0"
+# FLASH = False (tests set it): the attentions over the N points keep their [8, Lq, Lk] score matrices (attn_train.hip), the
+# path the flash kernels (attn_flash.hip) are checked against
+FLASH = True
 
 
 class _T:
@@ -190,7 +189,7 @@ class DecoderTape:
     #   "flash_c2s"  few queries over the N points, masked   (csrc/attn_flash.hip: no [8, Lq, Lk] matrix)
     #   "flash_s2c"  the N points as queries over few keys   (csrc/attn_flash.hip)
     #   "dense"      scores materialised (csrc/attn_train.hip): the click-to-click self attention, and everything when
-    #                A3D_TRAIN_FLASH=0 (the path the flash kernels are checked against)
+    #                FLASH is False (the path the flash kernels are checked against)
     @staticmethod
     def _dense_fwd(qv, kv, vv, mask):
         lib = L.load()

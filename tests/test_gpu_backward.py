@@ -483,7 +483,7 @@ def test_whole_network_gradients_match_autograd():
     ob.RELU, od.RELU = (lambda z: z * next(itb)), (lambda z: z * next(itd))
     # The decoder of this random-weight network is ill-conditioned in its INPUT: moving pcd_features by 1e-5 (what two
     # summation orders of the conv kernel differ by) moves its parameter gradients by up to 1.4e-2 (measured with
-    # A3D_SK_OV=2 / 3; near-ties in the sharp attention softmaxes).  So the float64 decoder is evaluated AT the HIP
+    # two share partitions of the conv kernel (round 2); near-ties in the sharp attention softmaxes).  So the float64 decoder is evaluated AT the HIP
     # backbone's features (checked against the float64 backbone's to 1e-4 first) and the float64 backbone is driven by
     # the float64 decoder's dL/d(pcd_features): the chain rule end to end, each half at a well-conditioned point.
     try:

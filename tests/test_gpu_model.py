@@ -507,11 +507,9 @@ def test_training_mode_forward_invalidates_the_folded_backbone():
     assert moved > 1e-3 and err <= TOL * max(1.0, ref["pcd_features"].abs().max().item())
 
 
-@pytest.mark.parametrize("switch", ["A3D_FUSED_S2C", "A3D_QL_V1"])
+@pytest.mark.parametrize("switch", ["A3D_FUSED_S2C"])
 def test_one_pass_scene_to_click_half_matches_the_two_kernel_path(tmp_path, switch):
-    """A3D_QL_V1: the single-block query layer's second build (k_query_block: packed weights, vector table in LDS,
-    click-to-click attention on the matrix cores) against the first (k_query_layer<QT, 0>, torch-layout weights).
-    A3D_FUSED_S2C: k_s2c_out (scene-to-click attention + output projection + LayerNorm + mask head in one pass, <= ~24 queries,
+    """A3D_FUSED_S2C: k_s2c_out (scene-to-click attention + output projection + LayerNorm + mask head in one pass, <= ~24 queries,
     default) against k_q_s2c + k_out_ln_mask (A3D_FUSED_S2C=0): same arithmetic per element, so the logits, the label
     bytes feeding the next layer's attention mask and the intermediate (aux) logits agree to rounding; both against the
     reference's goldens.  The switch is read once per process -> two interpreters."""
