@@ -1129,6 +1129,8 @@ __global__ void __launch_bounds__(NW * 64) k_s2c_out(const DecSampleDev* __restr
   float* O_l = be_l + D;                          // [NW][16][Kmax+1] logits staging
   int* hist = (int*)(O_l + NW * 16 * (Kmax + 1)); // [Kmax+1]
   int* qr_l = hist + Kmax + 1;                    // [Kmax+2]
+  float* sb_l = (float*)(qr_l + Kmax + 2);        // [QT*16] score bias: 0 for a real query, kNegBig for a padded one
+  for (int e = threadIdx.x; e < QT * 16; e += NT) sb_l[e] = e < nq ? 0.f : kNegBig;
   for (int e = threadIdx.x; e <= K + 1; e += NT) qr_l[e] = gld(sm.qrange + e);
   for (int e = threadIdx.x; e <= K; e += NT) hist[e] = 0;
   if (threadIdx.x < D) {
@@ -1173,6 +1175,28 @@ __global__ void __launch_bounds__(NW * 64) k_s2c_out(const DecSampleDev* __restr
   float* Ow = O_l + wave * 16 * (Kmax + 1);
   const int stride = nwg * NW;
   int grp = lb * NW + wave;
+  // On gfx950 a VALU instruction takes the fp32 matrix pipe's issue time (tools/coissue_ubench.hip: 24 MFMAs + 24 v_fma run
+  // 16 % longer than the MFMAs alone, packed or not), so what this lane would otherwise recompute per group is fixed here:
+  //   sb_l:  the score accumulators start at 0 for a real query and at kNegBig for a padded one (no compare / select per
+  //          score and head; read from LDS: eight more registers spill the twelve-wave build);
+  //   oidp:  the object of each of this lane's QT x 4 query slots, one byte each (255 = padded): the per-object maximum
+  //          of the logits is one SDWA byte compare + select + max per slot.
+  unsigned oidp[QT];
+#pragma unroll
+  for (int kt = 0; kt < QT; ++kt) {
+    oidp[kt] = 0u;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int q = kt * 16 + 4 * g + t;
+      unsigned o = 255u;
+      if (q < nq) {
+        o = 0u;                                   // background: [n_fg, nq)
+        for (int oo = 1; oo <= K; ++oo)
+          if (q >= qr_l[oo] && q < qr_l[oo + 1]) o = (unsigned)oo;
+      }
+      oidp[kt] |= o << (8 * t);
+    }
+  }
   f32x4 nx[8], np[8];
   auto fetch = [&](int gq) {
     const size_t row = (size_t)min(gq * 16 + j, n - 1);
@@ -1244,7 +1268,7 @@ __global__ void __launch_bounds__(NW * 64) k_s2c_out(const DecSampleDev* __restr
           for (int u = 0; u < 2; ++u) {
             if constexpr (KG) kf[u][kt] = kfg[u][kt];
             else kf[u][kt] = *(const f32x4*)(ks_l + (kt * 16 + j) * LD + (h + u) * DH + 4 * g);
-            sc[u][kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            sc[u][kt] = *(const f32x4*)(sb_l + kt * 16 + 4 * g);
           }
 #pragma unroll
         for (int t = 0; t < 4; ++t)
@@ -1258,10 +1282,7 @@ __global__ void __launch_bounds__(NW * 64) k_s2c_out(const DecSampleDev* __restr
 #pragma unroll
         for (int kt = 0; kt < QT; ++kt)
 #pragma unroll
-          for (int t = 0; t < 4; ++t) {
-            if (kt * 16 + 4 * g + t >= nq) sc[u][kt][t] = kNegBig;
-            mx[u] = fmaxf(mx[u], sc[u][kt][t]);
-          }
+          for (int t = 0; t < 4; ++t) mx[u] = fmaxf(mx[u], sc[u][kt][t]);   // padded queries sit at kNegBig (sb_l)
       float inv[2];
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
@@ -1291,8 +1312,10 @@ __global__ void __launch_bounds__(NW * 64) k_s2c_out(const DecSampleDev* __restr
 #pragma unroll
           for (int t = 0; t < 4; ++t)
 #pragma unroll
-            for (int u = 0; u < 2; ++u) acc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(vf[u][kt][t], sc[u][kt][t] * inv[u], acc[u], 0, 0, 0);
+            for (int u = 0; u < 2; ++u) acc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(vf[u][kt][t], sc[u][kt][t], acc[u], 0, 0, 0);
       }
+#pragma unroll
+      for (int u = 0; u < 2; ++u) acc[u] *= inv[u];   // the softmax normaliser once per output instead of once per weight
       // acc[u] = O[point j][16(h+u)+4g..+3] = the B fragment of the output projection's K-step h + u; two column tiles at a
       // time (consecutive MFMAs never hit the same accumulator)
 #pragma unroll
@@ -1371,15 +1394,12 @@ __global__ void __launch_bounds__(NW * 64) k_s2c_out(const DecSampleDev* __restr
     float best = 0.f;
     int bi = 0;
     for (int o = 0; o <= K; ++o) {
-      const int qb = o == 0 ? n_fg : qr_l[o], qe = o == 0 ? nq : qr_l[o + 1];
       float mxv = -3.4e38f;
 #pragma unroll
       for (int qt = 0; qt < QT; ++qt)
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-          const int q = qt * 16 + 4 * g + t;
-          if (q >= qb && q < qe) mxv = fmaxf(mxv, lg[qt][t]);
-        }
+        for (int t = 0; t < 4; ++t)
+          if (((oidp[qt] >> (8 * t)) & 255u) == (unsigned)o) mxv = fmaxf(mxv, lg[qt][t]);
       mxv = rows_max(mxv);
       if (g == (o & 3)) Ow[j * (K + 1) + o] = mxv;
       if (o == 0 || mxv > best) {
@@ -2437,7 +2457,7 @@ static int run_decoder(const a3d_decoder_weights* w, Prepared* P, int ns, hipStr
   // scene-to-click + output projection + LayerNorm + mask head as ONE kernel when both packed weight matrices and the
   // queries' compact keys / values fit the LDS (about 24 queries at 5 objects); A3D_FUSED_S2C=0 keeps the two kernels
   const int nqr_max = (nq_max + 3) & ~3;
-  const size_t s2c_rest = ((size_t)D * (nqr_max + 4) + 4 * D + (size_t)8 * 16 * (Kmax + 1) + 2 * Kmax + 3) * 4;
+  const size_t s2c_rest = ((size_t)D * (nqr_max + 4) + 4 * D + (size_t)8 * 16 * (Kmax + 1) + 2 * Kmax + 3 + QT * 16 + 1) * 4;
   const size_t s2c_keys = (size_t)nqr_max * 136 * 4;
   const size_t staging12 = (size_t)4 * 16 * (Kmax + 1) * 4;   // twelve waves' logits staging
   // the keys move out of LDS (k_s2c_out<.., KG>) when everything else still fits: 25..32 queries at 5 objects

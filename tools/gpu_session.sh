@@ -2,7 +2,6 @@
 # the current GPU session's command list (overwritten per session; results land in gpurun_out/)
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
-O=gpurun_out/s6; mkdir -p $O
-timeout 1500 python -m pytest tests -m gpu -x -q > $O/pytest.log 2>&1; echo "pytest rc=$?" >> $O/pytest.log
-tail -n 4 $O/pytest.log
-python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2
+O=gpurun_out/s7; mkdir -p $O
+timeout 300 tools/bin/coissue > $O/coissue.txt 2>&1
+cat $O/coissue.txt
