@@ -82,6 +82,13 @@ __device__ __forceinline__ float rows_sum(float x) {
 // exp for the softmax weights (argument <= 0 after the max is subtracted): v_exp_f32 on x log2(e), ~2 ulp, against
 // the ~15-instruction expf; the decoder's 1e-3 logits bar leaves four orders of magnitude of room
 __device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.4426950408889634f); }
+// The two attentions with the N points on one side work in the LOG2 domain: the query-side operand of their score product
+// (the projected queries of click-to-scene, the keys of scene-to-click) is produced pre-scaled by 1 / sqrt(d_h) * log2(e),
+// so a softmax weight is exp2(score - max) -- one v_exp_f32 without the multiply in front of it (a VALU instruction costs
+// matrix-pipe time on gfx950), in every consumer: k_kv_c2s, k_c2s_attn, k_c2s_combine, k_s2c_out, k_q_s2c, k_s2c_attn_wide.
+constexpr float kLog2e = 1.4426950408889634f;
+constexpr float kPointScoreScale = 0.25f * kLog2e;
+__device__ __forceinline__ float exp2_fast(float x) { return __builtin_amdgcn_exp2f(x); }
 
 // ------------------------------------------------------------------------------ posenc
 __global__ void __launch_bounds__(256) k_minmax_partial(const float* __restrict__ xyz, int n, float* part) {
@@ -323,13 +330,13 @@ __global__ void __launch_bounds__(512) k_c2s_attn(const float* __restrict__ Kc, 
       }
       mx = rows_max(mx);
       const float mnew = fmaxf(m[qt], mx);
-      const float sc = fast_exp(m[qt] - mnew);
+      const float sc = exp2_fast(m[qt] - mnew);
       m[qt] = mnew;
       f32x4 p;
       float ps = 0.f;
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
-        p[t] = fast_exp(s[t] - mnew);
+        p[t] = exp2_fast(s[t] - mnew);
         ps += p[t];
       }
       l[qt] = l[qt] * sc + ps;
@@ -512,6 +519,19 @@ __global__ void __launch_bounds__(512) k_kv_c2s(const DecSampleDev* __restrict__
       return *(const f32x4*)(qp_l + (qt * 16 + j) * LDQ + (SWZ ? (c ^ j) : c) * 4);
     };
     f32x4 qf_n = qfrag(0, h0);   // the next tile's fragment, one tile ahead
+    // which (point, query) pairs are blocked does not depend on the head: the mask is taken ONCE per group and query
+    // tile as the initial value of the score accumulators (0 / kNegBig; kNegBig + a dot product is kNegBig again) instead
+    // of a compare + select per score and head -- VALU instructions cost matrix-pipe time on gfx950 (tools/coissue_ubench.hip)
+    f32x4 mb[QT];
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int pr = p0 + 4 * g + t;
+        const int lab = (int)((lab4 >> (8 * t)) & 0xffu);
+        const bool blocked = pr >= n || (qmask[qt] && lab != obj[qt]);
+        mb[qt][t] = blocked ? kNegBig : 0.f;
+      }
 #pragma unroll
     for (int hl = 0; hl < HW; ++hl) {
       const int h = h0 + hl;
@@ -522,27 +542,21 @@ __global__ void __launch_bounds__(512) k_kv_c2s(const DecSampleDev* __restrict__
           const int i2 = hl * QT + qt + 1;
           if (i2 < HW * QT) qf_n = qfrag(i2 % QT, h0 + i2 / QT);
         }
-        f32x4 sc4 = (f32x4){0.f, 0.f, 0.f, 0.f};
+        f32x4 sc4 = mb[qt];
 #pragma unroll
         for (int t = 0; t < 4; ++t) sc4 = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[hl][t], qf[t], sc4, 0, 0, 0);
         float mx = kNegBig;
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-          const int pr = p0 + 4 * g + t;
-          const int lab = (int)((lab4 >> (8 * t)) & 0xffu);
-          const bool blocked = pr >= n || (qmask[qt] && lab != obj[qt]);
-          sc4[t] = blocked ? kNegBig : sc4[t];
-          mx = fmaxf(mx, sc4[t]);
-        }
+        for (int t = 0; t < 4; ++t) mx = fmaxf(mx, sc4[t]);
         mx = rows_max(mx);
         const float mnew = fmaxf(m[hl][qt], mx);
-        const float scl = fast_exp(m[hl][qt] - mnew);
+        const float scl = exp2_fast(m[hl][qt] - mnew);
         m[hl][qt] = mnew;
         f32x4 pw;
         float ps = 0.f;
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-          pw[t] = fast_exp(sc4[t] - mnew);
+          pw[t] = exp2_fast(sc4[t] - mnew);
           ps += pw[t];
         }
         l[hl][qt] = l[hl][qt] * scl + ps;
@@ -588,7 +602,7 @@ __global__ void __launch_bounds__(64) k_c2s_combine(const QuerySample* __restric
     const float* p = part + (((size_t)ch * H + h) * QP + q) * kPartStride;
     const float pm = gld(p);
     const float mn = fmaxf(m, pm);
-    const float a = expf(m - mn), b = expf(pm - mn);
+    const float a = exp2f(m - mn), b = exp2f(pm - mn);   // the partials' maxima are log2-domain scores
     l = l * a + gld(p + 1) * b;
 #pragma unroll
     for (int d = 0; d < DH; ++d) o[d] = o[d] * a + gld(p + 2 + d) * b;
@@ -597,7 +611,7 @@ __global__ void __launch_bounds__(64) k_c2s_combine(const QuerySample* __restric
   float M = m;
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) M = fmaxf(M, __shfl_xor(M, off, 64));
-  const float sc = expf(m - M);
+  const float sc = exp2f(m - M);
   l *= sc;
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) l += __shfl_xor(l, off, 64);
@@ -664,14 +678,14 @@ __global__ void __launch_bounds__(512) k_s2c_attn_wide(const float* __restrict__
       }
       mx = rows_max(mx);
       const float mnew = fmaxf(m[h], mx);
-      const float sc = fast_exp(m[h] - mnew);
+      const float sc = exp2_fast(m[h] - mnew);
       m[h] = mnew;
       float ps = 0.f;
 #pragma unroll
       for (int kt = 0; kt < QT; ++kt)
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-          s[kt][t] = fast_exp(s[kt][t] - mnew);
+          s[kt][t] = exp2_fast(s[kt][t] - mnew);
           ps += s[kt][t];
         }
       l[h] = l[h] * sc + ps;
@@ -903,7 +917,7 @@ __global__ void __launch_bounds__(512) k_q_s2c(const DecSampleDev* __restrict__ 
       for (int kt = 0; kt < QT; ++kt)
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-          sc[kt][t] = fast_exp(sc[kt][t] - mx);
+          sc[kt][t] = exp2_fast(sc[kt][t] - mx);
           sum += sc[kt][t];
         }
       sum = rows_sum(sum);
@@ -1292,7 +1306,7 @@ __global__ void __launch_bounds__(NW * 64) k_s2c_out(const DecSampleDev* __restr
         for (int kt = 0; kt < QT; ++kt)
 #pragma unroll
           for (int t = 0; t < 4; ++t) {
-            sc[u][kt][t] = fast_exp(sc[u][kt][t] - mx[u]);
+            sc[u][kt][t] = exp2_fast(sc[u][kt][t] - mx[u]);
             sum += sc[u][kt][t];
           }
         sum = rows_sum(sum);
@@ -1570,7 +1584,7 @@ __global__ void __launch_bounds__(512) k_query_init(const QuerySample* __restric
   (void)n_bgl;
   __syncthreads();
   // c2s query projection of the first layer, pre-scaled by 1/sqrt(head_dim)
-  lin<QT>(B.queries, D, B.qpos, Q, D, c2s_in_wt, D, c2s_in_b, D, B.qproj, D, false, 0.25f, lds);
+  lin<QT>(B.queries, D, B.qpos, Q, D, c2s_in_wt, D, c2s_in_b, D, B.qproj, D, false, kPointScoreScale, lds);
 }
 
 // ---- query-side layer with all [Q,128] activations resident in LDS ---------------------------
@@ -1961,9 +1975,9 @@ __global__ void __launch_bounds__(512) k_query_block(const QuerySample* __restri
     __syncthreads();
     qzero<QT>(acc);
     qmm<QT>(xa, wfc, acc);
-    if (hx == 1) qstore_b<QT, true>(acc, sb, 0.25f, false, B.ks, D, 16 * wave, Q);        // keys pre-scaled
+    if (hx == 1) qstore_b<QT, true>(acc, sb, kPointScoreScale, false, B.ks, D, 16 * wave, Q);        // keys pre-scaled (log2 domain)
     else if (hx == 2) qstore_b<QT, true>(acc, sb, 1.f, false, B.vs, D, 16 * wave, Q);
-    else qstore_b<QT, true>(acc, sb, 0.25f, false, B.qproj, D, 16 * wave, Q);
+    else qstore_b<QT, true>(acc, sb, kPointScoreScale, false, B.qproj, D, 16 * wave, Q);
     return;
   }
 
@@ -2163,7 +2177,7 @@ __global__ void __launch_bounds__(512) k_query_block(const QuerySample* __restri
   if (!deleg) {
     qzero<QT>(acc);
     qmm<QT>(xa, wfd, acc);
-    qstore_b<QT, true>(acc, vec_l[V_S2C_IN_B + D + cw], 0.25f, false, B.ks, D, 16 * wave, Q);   // keys pre-scaled
+    qstore_b<QT, true>(acc, vec_l[V_S2C_IN_B + D + cw], kPointScoreScale, false, B.ks, D, 16 * wave, Q);   // keys pre-scaled (log2 domain)
     qload_p(W.mpack + kMpW0, 8, wave, 0, wfd);
     qzero<QT>(acc);
     qmm<QT>(cur, wfa, acc);
@@ -2173,7 +2187,7 @@ __global__ void __launch_bounds__(512) k_query_block(const QuerySample* __restri
       qload_p(W.next_qpack + kQpC2sQ, 8, wave, 0, wfb);
       qzero<QT>(acc);
       qmm<QT>(xa, wfb, acc);
-      qstore_b<QT, true>(acc, vec_l[V_NEXT_B + cw], 0.25f, false, B.qproj, D, 16 * wave, Q);
+      qstore_b<QT, true>(acc, vec_l[V_NEXT_B + cw], kPointScoreScale, false, B.qproj, D, 16 * wave, Q);
     }
   }
   __syncthreads();                                                   // xb = decoder_norm rows are complete; qpos is free
