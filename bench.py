@@ -85,7 +85,7 @@ def algorithmic_bytes(entry, pairs):
 
 def workload_key(voxels, batch, queries):
     """Key of a workload in profiles/pmc_summary.json and profiles/kernel_avg_us.json."""
-    return f"{round(voxels / 1000)}k_b{batch}_q{queries}"
+    return f"{int(float(f'{voxels:.2g}')) // 1000}k_b{batch}_q{queries}"      # two significant digits: 79 736 -> 80k, 301 193 -> 300k
 
 
 def profile_file(name, wkey):

@@ -24,7 +24,7 @@ for line in open(sys.argv[1]):
         continue
     calls, total = int(f[0]), float(f[1])
     name = f[4].strip().replace("void ", "").replace("a3d::", "")
-    m = re.match(r"k_conv_sk<(\d+), (\d+), (\d+), (true|false)(, \d+)?>", name)
+    m = re.match(r"k_conv_sk<(\d+), (\d+), (\d+)(, (true|false))?(, \d+)?>", name)
     mw = re.match(r"k_conv_wl<(\d+), (\d+)>", name)
     if m:
         key = f"k_conv_sk<{m.group(1)},{m.group(2)}>"

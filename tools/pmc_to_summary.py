@@ -22,7 +22,7 @@ full["_note"] = ("rocprofv3 --pmc passes of `python bench.py --steps-only --no-p
 out = {}
 for name, c in raw.items():
     short = name.replace("void ", "").replace("a3d::", "")
-    m = re.match(r"k_conv_sk<(\d+), (\d+), (\d+), (true|false)(, \d+)?>", short)   # <BN, CH, PAIR, DBG>: bench.py's key is <BN,CH>
+    m = re.match(r"k_conv_sk<(\d+), (\d+), (\d+)(, (true|false))?(, \d+)?>", short)   # <BN, CH, PAIR, DBG>: bench.py's key is <BN,CH>
     key = short
     if m:
         key = f"k_conv_sk<{m.group(1)},{m.group(2)}>"
