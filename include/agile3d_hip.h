@@ -417,8 +417,9 @@ typedef struct {
   const float *c2s_wk_packed, *c2s_wv_packed, *s2c_wq_packed, *s2c_wo_packed;
   /* every matrix the QUERY side of the layer multiplies by (c2s out_proj, c2c in/out_proj, s2c k/v rows, c2s q rows,
    * FFN), in MFMA fragment order, made by a3d_decoder_pack_query_weights(w, layer, ...): a wave's weight load is 1 KB
-   * contiguous instead of 64 B of each of 16 rows (35 -> 140 GB/s into one CU, tools/qload_ubench.hip).  Optional:
-   * with NULL here (or in a3d_decoder_weights::mask_pack) the query-side kernel reads the torch-layout matrices. */
+   * contiguous instead of 64 B of each of 16 rows (35 -> 140 GB/s into one CU, tools/qload_ubench.hip).  REQUIRED since
+   * round 4 (the kernel that read the torch-layout matrices is gone): with NULL here or in
+   * a3d_decoder_weights::mask_pack the decoder entry points fail with A3D_ERR_INVALID. */
   const float* query_pack;
 } a3d_decoder_layer;
 
@@ -432,7 +433,7 @@ typedef struct {
   const float *bg_query_feat, *bg_query_pos;              /* [n_bg][128] */
   const float *gauss_B;                                   /* [3][64] */
   const float *time_table;                                /* [200][128] PositionalEncoding1D */
-  const float *mask_pack;                                 /* mask_w0, mask_w2 in fragment order (layer = -1 below), or NULL */
+  const float *mask_pack;                                 /* mask_w0, mask_w2 in fragment order (layer = -1 below); required */
 } a3d_decoder_weights;
 
 /* Fragment-order copies of the query-side matrices of one decoder layer (layer >= 0: a3d_decoder_query_pack_floats(dim_ff)
