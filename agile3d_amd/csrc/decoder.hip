@@ -1187,6 +1187,10 @@ __global__ void __launch_bounds__(NW * 64) k_s2c_out(const DecSampleDev* __restr
   const int g = lane >> 4, j = lane & 15;
   __syncthreads();
   float* Ow = O_l + wave * 16 * (Kmax + 1);
+  const unsigned lds0 = (unsigned)(size_t)smem;                                         // 32-bit LDS address of Wql
+  const unsigned ks_a0 = (unsigned)(size_t)ks_l + (unsigned)(j * LD + 4 * g) * 4u;      // key row j, floats 4 g ..
+  const unsigned vt_a0 = (unsigned)(size_t)vt_l + (unsigned)(j * LT + 4 * g) * 4u;      // value channel j, keys 4 g ..
+  auto lds4 = [](unsigned addr) -> f32x4 { return *(const __attribute__((address_space(3))) f32x4*)addr; };
   const int stride = nwg * NW;
   int grp = lb * NW + wave;
   // On gfx950 a VALU instruction takes the fp32 matrix pipe's issue time (tools/coissue_ubench.hip: 24 MFMAs + 24 v_fma run
@@ -1240,6 +1244,17 @@ __global__ void __launch_bounds__(NW * 64) k_s2c_out(const DecSampleDev* __restr
       // the next group's rows are requested late in the head loop (two heads + the LayerNorm / logits phase cover the
       // latency): 64 registers that would otherwise be live next to xp and y for the whole group
       if (PF && h == 4 && next < ngroups) fetch(next);
+      // 32-bit LDS addresses of this head pair, each pinned in ONE register: every read below is base + a 16-bit
+      // immediate.  (The weight matrices sit 64 / 128 KB into the LDS, beyond the ds_read offset field, and h is a run-time
+      // value: left alone the compiler spends an address add per read -- 38 of the pair's 133 vector instructions, and a
+      // vector instruction costs matrix-pipe time.)
+      unsigned wq_a = lds0 + (unsigned)(h * 64 + lane) * 16u;                          // + (S * 512 + u * 64) * 16
+      unsigned wo_a = lds0 + 65536u + (unsigned)(h * 512 + lane) * 16u;               // + (u * 512 + ct * 64) * 16
+      unsigned ks_a = KG ? 0u : ks_a0 + (unsigned)(h * DH) * 4u;                       // + (kt * 16 * LD + u * DH) * 4
+      unsigned vt_a = vt_a0 + (unsigned)(h * DH * LT) * 4u;                            // + kt * 64 (u = 1: vt_a + DH * LT * 4)
+      asm volatile("" : "+v"(wq_a), "+v"(wo_a), "+v"(vt_a));
+      if constexpr (!KG) asm volatile("" : "+v"(ks_a));
+      const unsigned vt_a1 = vt_a + (unsigned)(DH * LT) * 4u;
       f32x4 qf[2];
 #pragma unroll
       for (int u = 0; u < 2; ++u) qf[u] = *(const f32x4*)(bq_l + 16 * (h + u) + 4 * g);   // Q[point j][16h+4g..+3]
@@ -1253,13 +1268,13 @@ __global__ void __launch_bounds__(NW * 64) k_s2c_out(const DecSampleDev* __restr
       {
         // weight fragments one K-step ahead of the MFMAs that use them (left to itself the compiler issues the two
         // ds_read_b128 of a step right in front of its eight MFMAs and waits out the LDS latency every 256 cycles)
-        f32x4 w0 = Wql[(0 * 8 + h) * 64 + lane], w1 = Wql[(0 * 8 + h + 1) * 64 + lane];
+        f32x4 w0 = lds4(wq_a), w1 = lds4(wq_a + 64 * 16);
 #pragma unroll
         for (int S = 0; S < 8; ++S) {
           f32x4 n0 = w0, n1 = w1;
           if (S + 1 < 8) {
-            n0 = Wql[((S + 1) * 8 + h) * 64 + lane];
-            n1 = Wql[((S + 1) * 8 + h + 1) * 64 + lane];
+            n0 = lds4(wq_a + (S + 1) * 512 * 16);
+            n1 = lds4(wq_a + ((S + 1) * 512 + 64) * 16);
           }
           __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -1281,7 +1296,7 @@ __global__ void __launch_bounds__(NW * 64) k_s2c_out(const DecSampleDev* __restr
 #pragma unroll
           for (int u = 0; u < 2; ++u) {
             if constexpr (KG) kf[u][kt] = kfg[u][kt];
-            else kf[u][kt] = *(const f32x4*)(ks_l + (kt * 16 + j) * LD + (h + u) * DH + 4 * g);
+            else kf[u][kt] = lds4(ks_a + (kt * 16 * LD + u * DH) * 4);
             sc[u][kt] = *(const f32x4*)(sb_l + kt * 16 + 4 * g);
           }
 #pragma unroll
@@ -1314,13 +1329,13 @@ __global__ void __launch_bounds__(NW * 64) k_s2c_out(const DecSampleDev* __restr
       }
       f32x4 acc[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
       // the first output-projection fragments are requested before the P V products, every later pair one step ahead
-      f32x4 wo0 = Wol[(h * 8 + 0) * 64 + lane], wo1 = Wol[(h * 8 + 1) * 64 + lane];
+      f32x4 wo0 = lds4(wo_a), wo1 = lds4(wo_a + 64 * 16);
       {
         f32x4 vf[2][QT];
 #pragma unroll
         for (int kt = 0; kt < QT; ++kt)
 #pragma unroll
-          for (int u = 0; u < 2; ++u) vf[u][kt] = *(const f32x4*)(vt_l + ((h + u) * DH + j) * LT + kt * 16 + 4 * g);   // V^T: keys 4g..4g+3 of channel 16h+j
+          for (int u = 0; u < 2; ++u) vf[u][kt] = lds4((u ? vt_a1 : vt_a) + kt * 64);   // V^T: keys 4g..4g+3 of channel 16h+j
 #pragma unroll
         for (int kt = 0; kt < QT; ++kt)
 #pragma unroll
@@ -1338,8 +1353,8 @@ __global__ void __launch_bounds__(NW * 64) k_s2c_out(const DecSampleDev* __restr
         f32x4 n0 = wo0, n1 = wo1;
         if (i + 1 < 8) {
           const int u2 = (i + 1) >> 2, ct2 = 2 * ((i + 1) & 3);
-          n0 = Wol[((h + u2) * 8 + ct2) * 64 + lane];
-          n1 = Wol[((h + u2) * 8 + ct2 + 1) * 64 + lane];
+          n0 = lds4(wo_a + (u2 * 512 + ct2 * 64) * 16);
+          n1 = lds4(wo_a + (u2 * 512 + ct2 * 64 + 64) * 16);
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
