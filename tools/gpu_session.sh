@@ -2,15 +2,15 @@
 # the current GPU session's command list (overwritten per session; results land in gpurun_out/)
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
-O=gpurun_out/s10; mkdir -p $O
-timeout 300 tools/bin/coissue > $O/coissue.txt 2>&1
-timeout 900 python bench.py > $O/bench.json 2> $O/bench.err
-timeout 600 python bench.py --voxels 300000 --clicks-per-object 4 --batch 1 --streams 2 --steps 10 --warmup 3 --reps 7 --no-train > $O/bench_config5.json 2> $O/bench5.err
+O=gpurun_out/s11; mkdir -p $O
+timeout 1200 python -m pytest tests/test_gpu_model.py -x -q > $O/pytest.log 2>&1; echo "pytest rc=$?" >> $O/pytest.log
+tail -n 3 $O/pytest.log
+LT_BATCH=16 timeout 300 python tools/layer_table.py > $O/layer_table_16.txt 2>&1
+LT_BATCH=1 LT_VOXELS=300000 LT_CPO=4 timeout 300 python tools/layer_table.py > $O/layer_table_c5.txt 2>&1
+grep -E "s2c_attn|c2s_attn|^sum" $O/layer_table_16.txt $O/layer_table_c5.txt
+timeout 600 python bench.py --no-cpu-baseline --no-train > $O/bench.json 2> $O/bench.err
 python - <<'P'
 import json
-for f in ('bench','bench_config5'):
-    d=json.loads(open(f'gpurun_out/s10/{f}.json').read().strip().splitlines()[-1])
-    r=d['roofline']
-    print(f, d['value'], d.get('value_batch4'), r['frac'], r['traffic'], r.get('hbm_traffic_frac'), r.get('profiles_workload'), r.get('rocprof_avg_launch_us'), r.get('agrees_with_profiles_within_10pct'))
+d=json.loads(open('gpurun_out/s11/bench.json').read().strip().splitlines()[-1])
+print(d['value'], d.get('value_batch4'), d.get('latency_ms_per_scene'), d['roofline']['frac'], d.get('kernels_ms_per_step'))
 P
-tail -n 20 $O/coissue.txt
