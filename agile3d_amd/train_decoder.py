@@ -30,13 +30,33 @@ FLASH = True
 
 
 class _T:
-    __slots__ = ("v", "g")
+    """A value of the tape with its accumulated gradient.  ``needs_grad=False`` (the position encodings: no parameter
+    behind them) drops what flows there instead of summing [N, 128] tensors nobody reads.  ``own`` says that ``g`` is a
+    tensor only this node refers to (a sum made here), so further contributions are added in place."""
+    __slots__ = ("v", "g", "needs_grad", "own")
 
-    def __init__(self, v):
-        self.v, self.g = v, None
+    def __init__(self, v, needs_grad=True):
+        self.v, self.g, self.needs_grad, self.own = v, None, needs_grad, False
 
     def add_grad(self, g):
-        self.g = g if self.g is None else self.g + g
+        if not self.needs_grad:
+            return
+        if self.g is None:
+            self.g, self.own = g, False          # may be shared with other nodes (e.g. both inputs of an add)
+        elif self.own:
+            self.g.add_(g)
+        else:
+            self.g, self.own = self.g + g, True
+
+    def add_grad_rows(self, rows, vals):
+        """g[rows] += vals (a row listed twice gets both) without a zero-filled [N, C] temporary + a full-size add."""
+        if not self.needs_grad:
+            return
+        if self.g is None:
+            self.g, self.own = torch.zeros_like(self.v), True
+        elif not self.own:
+            self.g, self.own = self.g.clone(), True
+        self.g.index_add_(0, rows, vals)
 
 
 def _ptr(t):
@@ -417,23 +437,21 @@ class DecoderTape:
         self.n_ranges, self.q_ranges = n_ranges, q_ranges
         pcd_all = pcds[0] if len(pcds) == 1 else torch.cat(pcds, 0)
         self.pcd = _T(pcd_all.contiguous())
-        pos = _T((pos_encs[0] if len(pos_encs) == 1 else torch.cat(pos_encs, 0)).contiguous())
+        pos = _T((pos_encs[0] if len(pos_encs) == 1 else torch.cat(pos_encs, 0)).contiguous(), needs_grad=False)
         q0 = _T(torch.cat(q_parts, 0).contiguous())
         qpos = _T(torch.cat(qpos_parts, 0).contiguous())
 
         def q0_back():
             g = q0.g
-            d = torch.zeros_like(self.pcd.v)
             dbq = torch.zeros_like(bgq)
             dbp = torch.zeros_like(bgp)
             for sm in samples:
                 a0, n_fg, Q = sm["q0"], sm["n_fg"], sm["Q"]
                 gs = g[a0:a0 + Q]
-                d.index_add_(0, sm["rows"] + sm["n0"], torch.cat([gs[:n_fg], gs[n_fg + n_bgl:]], 0))   # a row clicked twice gets both
+                self.pcd.add_grad_rows(sm["rows"] + sm["n0"], torch.cat([gs[:n_fg], gs[n_fg + n_bgl:]], 0))   # a row clicked twice gets both
                 dbq += gs[n_fg:n_fg + n_bgl]
                 if qpos.g is not None:
                     dbp += qpos.g[a0 + n_fg:a0 + n_fg + n_bgl]
-            self.pcd.add_grad(d)
             self._pg("bg_query_feat.weight", dbq)
             if qpos.g is not None:
                 self._pg("bg_query_pos.weight", dbp)
