@@ -408,7 +408,9 @@ __global__ void k_xyzb_hashfix(const LevelSet S) {
     lv.xyzb[4 * f + 1] = Y;
     lv.xyzb[4 * f + 2] = Z;
     lv.xyzb[4 * f + 3] = b;
-    if (lv.grid) lv.grid[grid_cell(lv, b, X, Y, Z)] = f;
+    // (the level-0 grid keeps the MORTON rows k_level0_grid wrote: its users -- the stem and its weight gradient -- walk the
+    // voxels in Morton order, where the cells and feature rows of neighbouring threads share cache lines, and map to
+    // internal rows through perm where they need them)
     if (L < A3D_NUM_LEVELS - 1) {   // sort key of the second sort: the child slot of internal row f inside its super tile
       S.cat_keys[S.off[L] + f] = ((uint64_t)L << S.level_shift) | ((uint64_t)(f >> S.st_shift) << 27) | (lv.keys[lv.inv[f]] & 7);
       S.cat_vals[S.off[L] + f] = S.off[L] + f;

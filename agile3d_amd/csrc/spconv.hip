@@ -846,14 +846,23 @@ __global__ void __launch_bounds__(NT) k_stem(const int32_t* __restrict__ xyzb, i
   constexpr int TPV = NT / 64, CPT = 32 / TPV;
   constexpr int SEG = (K + TPV - 1) / TPV;   // neighbour entries per thread
   const int v = tid / TPV, cg = tid % TPV;
-  const int row = v0 + v;
-  int mine[SEG];
   const bool fused = glv.grid && n < (1 << 25);
+  // Grid path: the workgroup's 64 voxels are 64 consecutive MORTON rows (a compact patch of the surface: their 5^3
+  // neighbourhoods overlap, so the grid cells and -- the grid holds Morton rows, feats4 is in Morton order -- the gathered
+  // feature rows of neighbouring threads share cache lines; in the internal, mask-sorted order every lookup was its own
+  // 64-byte sector from the fabric).  The result goes to the voxel's internal row (perm).
+  const int mrow = v0 + v;
+  const int row = fused ? (mrow < n ? glv.perm[mrow] : n) : mrow;
+  int mine[SEG];
   if (fused) {
     // dense level-0 grid (scene.hip): one 4-byte load per neighbour; the TPV threads of a voxel look up SEG consecutive
     // offsets each (x fastest: runs of ks consecutive cells), all of a thread's lookups in flight, results kept in registers
     int4 c = (int4){0, 0, 0, 0};
-    if (row < n) c = *(const int4*)(xyzb + 4 * row);
+    if (mrow < n) {
+      int b_, X_, Y_, Z_;
+      decode_key(glv.keys[mrow], 0, b_, X_, Y_, Z_);
+      c = (int4){X_, Y_, Z_, b_};
+    }
 #pragma unroll
     for (int u = 0; u < SEG; ++u) {
       const int k = cg * SEG + u;
@@ -873,6 +882,7 @@ __global__ void __launch_bounds__(NT) k_stem(const int32_t* __restrict__ xyzb, i
         if (e < 64 * K && rr < n) {
           const int4 c = *(const int4*)(xyzb + 4 * rr);
           res[u] = glv.grid[grid_cell(glv, c.w, c.x + (k % ks) - h, c.y + ((k / ks) % ks) - h, c.z + (k / (ks * ks)) - h)];
+          if (res[u] >= 0) res[u] = glv.perm[res[u]];   // the grid holds Morton rows; this path works on internal rows
         }
       }
 #pragma unroll
@@ -1005,11 +1015,12 @@ __global__ void __launch_bounds__(NT) k_stem(const int32_t* __restrict__ xyzb, i
   if (zero_row >= 0 && blockIdx.x == 0 && tid < 32) out[(size_t)zero_row * ldo + tid] = 0.f;
 }
 
+// feats4[f] = the colours of internal row f -- or, with `perm` (Morton row -> internal row), of MORTON row f
 __global__ void k_gather_feats(const float* __restrict__ feats3, const int* __restrict__ orig_row, int n,
-                               f32x4* feats4) {
+                               f32x4* feats4, const int* __restrict__ perm) {
   const int f = blockIdx.x * blockDim.x + threadIdx.x;
   if (f >= n) return;
-  const float* p = feats3 + (size_t)orig_row[f] * 3;
+  const float* p = feats3 + (size_t)orig_row[perm ? perm[f] : f] * 3;
   feats4[f] = (f32x4){p[0], p[1], p[2], 0.f};
 }
 
@@ -1454,11 +1465,12 @@ extern "C" int a3d_program_run(const a3d_scene* s, const a3d_buf_desc* bufs, int
         return A3D_ERR_UNSUPPORTED;
       }
       const Level& lv = s->lv[0];
+      const int ks = o.kernel_volume == 125 ? 5 : 3;
+      const bool morton = lv.grid && ks / 2 <= kGridPad && lv.n < (1 << 25);   // = k_stem's `fused` path
       if (!feats_ready) {
-        k_gather_feats<<<(lv.n + 255) / 256, 256, 0, st>>>(feats3_dev, s->orig_row, lv.n, feats4);
+        k_gather_feats<<<(lv.n + 255) / 256, 256, 0, st>>>(feats3_dev, s->orig_row, lv.n, feats4, morton ? lv.perm : nullptr);
         feats_ready = true;
       }
-      const int ks = o.kernel_volume == 125 ? 5 : 3;
       const size_t lds = (size_t)o.kernel_volume * 96 * 4 + (size_t)64 * o.kernel_volume * 4;
       ProfScope ps(st, A3D_PROF_STEM, 0, o.kernel_volume, 3, 32, lv.n);
       // 8 waves per 64-voxel workgroup (measured: 4 waves 229 us, 8 waves 164 us, 16 waves 159 us)

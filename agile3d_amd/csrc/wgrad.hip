@@ -266,6 +266,7 @@ __global__ void __launch_bounds__(256) k_stem_wgrad(const Level lv, const float*
     int nb = -1;
     if (lv.grid && h <= kGridPad) {
       nb = lv.grid[grid_cell(lv, c.w, X, Y, Z)];
+      if (nb >= 0) nb = lv.perm[nb];   // the grid holds Morton rows
     } else {
       const int lim = kCoordOff;
       if (X >= -lim && X < lim && Y >= -lim && Y < lim && Z >= -lim && Z < lim)

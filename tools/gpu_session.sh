@@ -1,13 +1,10 @@
 #!/bin/bash
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
-O=gpurun_out/s13; mkdir -p $O
-rocm-smi --showpower --showclocks --showmaxpower --showtemp > $O/smi_idle.txt 2>&1
-( for i in $(seq 1 40); do rocm-smi --showpower --showclocks 2>/dev/null | grep -E "Power|sclk|mclk|fclk" | tr '\n' ' '; echo; sleep 0.25; done ) > $O/smi_conv.txt 2>&1 &
-timeout 300 python tools/conv_bench.py --voxels 1280000 --reps 400 --only L0_conv3_96_96 > $O/conv.txt 2>&1
-wait
-( for i in $(seq 1 40); do rocm-smi --showpower --showclocks 2>/dev/null | grep -E "Power|sclk|mclk|fclk" | tr '\n' ' '; echo; sleep 0.25; done ) > $O/smi_ubench.txt 2>&1 &
-UB_ITERS=200000 timeout 120 tools/bin/coissue > $O/coissue.txt 2>&1
-wait
-tail -n 3 $O/conv.txt; head -n 30 $O/smi_idle.txt; sed -n 10,30p $O/smi_conv.txt; sed -n 5,25p $O/smi_ubench.txt
-timeout 1500 python -m pytest tests/test_gpu_backward.py -x -q > $O/pytest.log 2>&1; tail -n 3 $O/pytest.log
+O=gpurun_out/s15; mkdir -p $O
+timeout 1500 python -m pytest tests/test_gpu_conv.py tests/test_gpu_scene.py tests/test_gpu_model.py tests/test_gpu_backward.py -x -q > $O/pytest.log 2>&1; echo "pytest rc=$?" >> $O/pytest.log
+tail -n 4 $O/pytest.log
+A3D_GRID=0 timeout 600 python -m pytest tests/test_gpu_conv.py tests/test_gpu_scene.py -x -q 2>&1 | tail -n 2
+LT_BATCH=16 timeout 300 python tools/layer_table.py 2>&1 | grep -E "^ *(0|1|2) |^sum"
+LT_BATCH=1 timeout 300 python tools/layer_table.py 2>&1 | grep -E "^ *(0|1|2) |^sum"
+timeout 600 python bench.py --steps-only --no-profile --reps 9 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['value'], d['ms_per_step'])"
