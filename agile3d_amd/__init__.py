@@ -9,6 +9,8 @@ Public surface (mirrors the reference):
 Around the path (same names as the reference): ``datasets`` (scan datasets + collate), ``ply`` (binary PLY),
 ``evaluate`` (Evaluate loops, NoC / IoU@k tables), ``clicks`` (click simulator, IoU), ``criterion`` (mask losses).
 """
+from .hostcpu import cap_host_threads
+cap_host_threads()       # torch's CPU pool sized to the container's CPU quota (hostcpu.py: an oversized pool freezes the launch thread)
 from .model import build_model, build_agile3d, Agile3d, default_args, randomize_bn_stats  # noqa: F401
 from .sparse import SparseTensor, sparse_quantize, batched_coordinates  # noqa: F401
 from . import utils  # noqa: F401  (ME.utils.sparse_quantize / ME.utils.batched_coordinates)

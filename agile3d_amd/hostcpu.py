@@ -1,0 +1,68 @@
+"""CPU time this process is really allowed to use, and torch's CPU thread pool sized to it.
+
+Found in round 4 (``profiles/r04_experiments.txt``, "host CPU quota"): the MI355X boxes show 256 CPUs, but the process lives in a
+cgroup with a CFS quota of 16 CPUs.  torch sizes its intra-op pool from the CPU count (128 threads); every small CPU tensor
+operation of the host code between launches wakes that pool, its workers spin for a while after the parallel region, the
+cgroup's quota for the 100 ms period is burnt within a few milliseconds and EVERY thread of the process -- the one that
+launches kernels included -- is frozen until the next period: launches and host waits that sporadically take 5 ... 85 ms
+(quantised by the scheduler's slices), training iterations that take 150-290 ms instead of a reproducible 90-125.  Nothing
+on the device is slow; the host is stopped.  ``cap_host_threads`` is called when the package is imported.
+"""
+from __future__ import annotations
+
+import math
+import os
+
+
+def cpu_quota() -> float:
+    """CPUs' worth of time per wall second this process may consume: the smaller of its affinity mask and its cgroup's
+    CFS quota (cgroup v2 ``cpu.max``, v1 ``cpu.cfs_quota_us`` / ``cpu.cfs_period_us``; no quota = the affinity mask)."""
+    try:
+        n = float(len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        n = float(os.cpu_count() or 1)
+    try:
+        rel = "/"
+        for line in open("/proc/self/cgroup"):
+            parts = line.strip().split(":", 2)
+            if len(parts) == 3 and parts[0] == "0":
+                rel = parts[2]
+        # the limit of the process's own group and of every ancestor applies (walk up inside the mounted hierarchy)
+        path = os.path.normpath("/sys/fs/cgroup/" + rel)
+        while path.startswith("/sys/fs/cgroup"):
+            f = os.path.join(path, "cpu.max")
+            if os.path.exists(f):
+                quota, period = open(f).read().split()[:2]
+                if quota != "max":
+                    n = min(n, float(quota) / float(period))
+            if path == "/sys/fs/cgroup":
+                break
+            path = os.path.dirname(path)
+    except (OSError, ValueError):
+        pass
+    try:
+        q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        p = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        if q > 0 and p > 0:
+            n = min(n, q / p)
+    except (OSError, ValueError):
+        pass
+    return max(n, 1.0)
+
+
+def cap_host_threads() -> int:
+    """torch's intra-op CPU threads = at most HALF the quota (the launch thread, the HIP runtime's helpers and the other
+    streams' launch threads need the rest), never more than torch chose itself (OMP_NUM_THREADS is respected).
+    ``A3D_HOST_THREADS=<n>`` forces n, ``A3D_HOST_THREADS=0`` leaves torch alone.  Returns the thread count in force."""
+    import torch
+    forced = os.environ.get("A3D_HOST_THREADS")
+    cur = torch.get_num_threads()
+    if forced is not None:
+        want = int(forced)
+        if want <= 0:
+            return cur
+    else:
+        want = min(cur, max(1, int(math.floor(cpu_quota() / 2))))
+    if want != cur:
+        torch.set_num_threads(want)
+    return want

@@ -176,7 +176,8 @@ def cpu_baseline(sd, sc, ci, ct, gpu_logits=None, gpu_feats=None, samples=5):
         lg = od.forward_mask(sd, r["pcd_features"], raw, r["pos_enc"], ci, ct)
         return time.time() - t0, r, lg
 
-    ncpu = os.cpu_count() or 1
+    from agile3d_amd.hostcpu import cpu_quota
+    ncpu = max(1, int(cpu_quota()))               # what the container lets this process use, not the CPUs it can see
     probes = {}
     levels = None
     for nt in sorted({min(8, ncpu), min(32, ncpu)}):
@@ -194,7 +195,7 @@ def cpu_baseline(sd, sc, ci, ct, gpu_logits=None, gpu_feats=None, samples=5):
     res = {"value": 1.0 / med, "unit": "scenes/s", "cores": best, "kind": "port",
            "sample": f"median of {samples} full scenes of the same {len(sc['coords'])}-voxel/"
                      f"{sum(len(v) for v in ci.values())}-click workload through oracle/ (Res16UNet34C + 1 decoder pass; "
-                     f"kernel maps built once outside the timed part), {best} threads of {ncpu} host cores (probes incl. "
+                     f"kernel maps built once outside the timed part), {best} threads of the {ncpu} CPUs of this container's quota ({os.cpu_count()} visible; probes incl. "
                      f"kernel-map construction: " + ", ".join(f"{k} thr {v:.1f} s" for k, v in probes.items())
                      + f"), samples {[round(t, 2) for t in times]} s, torch {torch.__version__} CPU",
            "seconds_per_scene": med, "seconds_per_scene_incl_kernel_maps": float(probes[best]),
@@ -207,6 +208,7 @@ def cpu_baseline(sd, sc, ci, ct, gpu_logits=None, gpu_feats=None, samples=5):
                 "pcd_features_scale": float(r["pcd_features"].abs().max()),
                 "note": "GPU output of scene 0 of the timed workload vs the CPU oracle on the same inputs (bar 1e-3)"}
     cpu_baseline.last_logits = lg[-1]      # the oracle's logits of that scene (the emulated-fp32 pass is compared with them too)
+    torch.set_num_threads(max(1, ncpu // 2))      # back to the package's setting for the legs that follow (hostcpu.py)
     return res, diff
 
 
@@ -544,6 +546,9 @@ def main():
     }
     if numa is not None:
         res["config"]["launch_thread_numa_node"] = numa
+    from agile3d_amd.hostcpu import cpu_quota
+    res["config"]["host_cpu"] = {"visible": os.cpu_count(), "container_quota": round(cpu_quota(), 2),
+                                 "torch_threads": torch.get_num_threads()}
     if dist_on:
         res["ranks_seen"] = ranks_seen
         res["ms_per_step_per_rank"] = [round(x, 4) for x in per_rank_ms]

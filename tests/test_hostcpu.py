@@ -1,0 +1,36 @@
+"""Host-side thread policy (agile3d_amd/hostcpu.py): torch's CPU pool follows the container's CPU quota."""
+import os
+import subprocess
+import sys
+
+import torch
+
+from agile3d_amd import hostcpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_quota_is_positive_and_within_the_affinity_mask():
+    q = hostcpu.cpu_quota()
+    assert 1.0 <= q <= len(os.sched_getaffinity(0))
+
+
+def test_import_caps_the_pool_to_half_the_quota():
+    want = max(1, int(hostcpu.cpu_quota() // 2))
+    assert torch.get_num_threads() <= max(want, 1)
+    assert hostcpu.cap_host_threads() == torch.get_num_threads()
+
+
+def _threads_in_child(env):
+    e = dict(os.environ, **env)
+    out = subprocess.run([sys.executable, "-c", "import torch, agile3d_amd; print(torch.get_num_threads())"], cwd=ROOT, env=e,
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    return int(out.stdout.strip().splitlines()[-1])
+
+
+def test_switch_forces_a_count_or_leaves_torch_alone():
+    assert _threads_in_child({"A3D_HOST_THREADS": "3"}) == 3
+    assert _threads_in_child({"A3D_HOST_THREADS": "0", "OMP_NUM_THREADS": "5"}) == 5
+    # OMP_NUM_THREADS below the cap is respected (the cap never raises the count)
+    assert _threads_in_child({"OMP_NUM_THREADS": "1"}) == 1
