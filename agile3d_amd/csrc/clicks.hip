@@ -18,6 +18,9 @@
 // distance -- a LOWER bound of the cluster's maximum --, (C) only points whose upper bound reaches their cluster's
 // lower bound can be the arg-max (ties included) and go through the full pass.  Every pair distance is the same
 // expression in all three phases, so the comparisons are exact in floating point.
+// Round 4: the bounding runs TWICE, coarse to fine -- first against every 256th point (1/16 of phase A's pairs), whose
+// survivors alone meet every 16th point; with large wrong regions (training with early weights, 300 k-voxel scenes) the
+// first stage removes all but the few per cent of points near a cluster's deepest spot and phase A shrinks by ~10x.
 #include "common.h"
 #include <stdlib.h>
 
@@ -29,6 +32,8 @@ constexpr int kQueriesPerThread = 2;
 constexpr int kNearestBlock = 256;
 constexpr int kNearestSplit = 128;           // candidate chunks (grid.y): enough waves when only a few thousand points are wrong
 constexpr int kSample = 16;                  // phase A: every kSample-th point is a candidate
+constexpr int kSampleCoarse = 256;           // ... after a first bounding stage against every kSampleCoarse-th point (a subset of them)
+constexpr int kMinChunk = 32;                // candidates per workgroup row of k_nearest_other at least (small samples: fewer, fuller blocks)
 constexpr long long kSmallPairs = 1ll << 30;  // (wrong points) x (points) below which phase A is skipped: the plain pass is ~0.15 ms
 constexpr int kMaxChamp = 1024;              // clusters that get a lower bound (phase B); further ones are not pruned
 constexpr int kChampSplit = 8;
@@ -90,7 +95,7 @@ __global__ void k_err_compact(const float* __restrict__ xyz, const int32_t* __re
                               const int32_t* __restrict__ labels, int64_t n, float4* __restrict__ cand,
                               int32_t* __restrict__ err_rows, unsigned* __restrict__ d2bits,
                               int* __restrict__ n_err, int* __restrict__ err, float4* __restrict__ samp, int stride,
-                              int* __restrict__ max_cid) {
+                              float4* __restrict__ samp_coarse, int stride_coarse, int* __restrict__ max_cid) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   bool wrong = false;
   int my_cid = -1;
@@ -104,6 +109,7 @@ __global__ void k_err_compact(const float* __restrict__ xyz, const int32_t* __re
     const float4 c = make_float4(xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2], __int_as_float(cid));
     cand[i] = c;
     if (samp && i % stride == 0) samp[i / stride] = c;
+    if (samp_coarse && i % stride_coarse == 0) samp_coarse[i / stride_coarse] = c;
   }
   // one pair of atomics per WORKGROUP (the waves' counts and maxima meet in LDS): a sample's thousands of waves would queue
   // on the two counter words otherwise (58 us at 300 k points, an order of magnitude above the kernel's memory time)
@@ -358,6 +364,14 @@ struct ClickWs {
   float4* samp;
   int32_t* surv_rows;
   unsigned* d2s;
+  // the coarse bounding stage in front (its survivors are `surv_rows`; the fine stage's go to surv_c_rows)
+  unsigned long long* table_ub_c;
+  unsigned* lbtab_c;
+  int *n_surv_c, *n_champ_c;
+  int2* champ_c;
+  float4* samp_coarse;
+  int32_t* surv_c_rows;
+  unsigned* d2s_c;
   size_t zero_bytes;   // bytes from `table` on that start out as zeros
   size_t bytes;
 };
@@ -375,16 +389,24 @@ static ClickWs carve_click(void* base, int64_t n) {
   w.n_surv = w.n_err ? w.n_err + 2 : nullptr;
   w.n_champ = w.n_err ? w.n_err + 3 : nullptr;
   w.max_cid = w.n_err ? w.n_err + 4 : nullptr;
+  w.n_surv_c = w.n_err ? w.n_err + 5 : nullptr;
+  w.n_champ_c = w.n_err ? w.n_err + 6 : nullptr;
   w.table_ub = (unsigned long long*)take((size_t)kClusterTable * 8);
   w.lbtab = (unsigned*)take((size_t)kClusterTable * 4);
+  w.table_ub_c = (unsigned long long*)take((size_t)kClusterTable * 8);
+  w.lbtab_c = (unsigned*)take((size_t)kClusterTable * 4);
   w.zero_bytes = off;
   w.champ = (int2*)take((size_t)kMaxChamp * 8);
+  w.champ_c = (int2*)take((size_t)kMaxChamp * 8);
   w.cand = (float4*)take((size_t)n * 16);
   w.samp = (float4*)take((size_t)(n / 4 + 8) * 16);   // stride >= 4
   w.err_rows = (int32_t*)take((size_t)n * 4);
   w.d2bits = (unsigned*)take((size_t)n * 4);
   w.surv_rows = (int32_t*)take((size_t)n * 4);
   w.d2s = (unsigned*)take((size_t)n * 4);
+  w.samp_coarse = (float4*)take((size_t)(n / kSampleCoarse + 8) * 16);
+  w.surv_c_rows = (int32_t*)take((size_t)n * 4);
+  w.d2s_c = (unsigned*)take((size_t)n * 4);
   w.bytes = off;
   return w;
 }
@@ -465,18 +487,33 @@ extern "C" int a3d_click_clusters(const float* xyz_dev, const int32_t* pred_dev,
   }
   const int stride = kSample;   // strides 8 / 16 / 32 / 64 measured in round 3: 16 is the best or second best everywhere
   const bool bounded = prune && n >= 64 * stride;
+  const bool two_stage = bounded && prune != 3 && n >= 64 * kSampleCoarse;   // A3D_CLICK_PRUNE=3: the one-stage search of round 3 (A/B)
   A3D_HIP_CHECK(hipMemsetAsync(w.table, 0, w.zero_bytes, st));   // tables + counters
   const unsigned nb = (unsigned)((n + 255) / 256);
   k_err_compact<<<nb, 256, 0, st>>>(xyz_dev, pred_dev, labels_dev, n, w.cand, w.err_rows, w.d2bits, w.n_err, w.err,
-                                    bounded ? w.samp : nullptr, stride, w.max_cid);
+                                    bounded ? w.samp : nullptr, stride, two_stage ? w.samp_coarse : nullptr, kSampleCoarse,
+                                    w.max_cid);
   A3D_LAUNCH_CHECK();
   const int per_block = kNearestBlock * kQueriesPerThread;
   auto nearest = [&](const float4* cands, int64_t n_cands, const int32_t* rows, const int* n_rows, unsigned* out,
                      long long skip_below) {
     int chunk = (int)((n_cands + kNearestSplit - 1) / kNearestSplit);
+    chunk = chunk < kMinChunk ? kMinChunk : chunk;
     chunk = (chunk + 3) & ~3;
     dim3 grid((unsigned)((n + per_block - 1) / per_block), (unsigned)((n_cands + chunk - 1) / chunk));
     k_nearest_other<<<grid, kNearestBlock, 0, st>>>(w.cand, cands, n_cands, rows, n_rows, out, chunk, skip_below);
+  };
+  // one bounding stage: upper bounds of `rows` against a sample (A), one exact champion per cluster = lower bound of the
+  // cluster's maximum (B), the rows that can still be their cluster's arg-max -> rows_out (C, step 1).  `skip`: the stage does
+  // nothing (every row survives) when rows x skip < kSmallPairs -- decided on the device, the host never learns the count
+  auto bounding_stage = [&](const float4* sample, int64_t n_sample, const int32_t* rows, const int* n_rows, unsigned* ub,
+                            unsigned long long* table_ub, unsigned* lbtab, int2* champ, int* n_champ, int32_t* rows_out,
+                            unsigned* d2_out, int* n_out, long long skip) {
+    nearest(sample, n_sample, rows, n_rows, ub, skip);
+    k_cluster_best<<<nb, 256, 0, st>>>(w.cand, rows, n_rows, ub, table_ub, skip);
+    k_champ_list<<<kClusterTable / 256, 256, 0, st>>>(table_ub, champ, n_champ, lbtab);
+    k_champ_exact<<<dim3(128, kChampSplit), 256, 0, st>>>(w.cand, n, champ, n_champ, lbtab);
+    k_survivors<<<nb, 256, 0, st>>>(w.cand, rows, n_rows, ub, lbtab, rows_out, d2_out, n_out);
   };
   if (!bounded) {
     nearest(w.cand, n, w.err_rows, w.n_err, w.d2bits, 0);
@@ -485,12 +522,24 @@ extern "C" int a3d_click_clusters(const float* xyz_dev, const int32_t* pred_dev,
     A3D_LAUNCH_CHECK();
   } else {
     const int64_t n_samp = (n + stride - 1) / stride;
-    nearest(w.samp, n_samp, w.err_rows, w.n_err, w.d2bits, (long long)n);                         // A: upper bounds
-    k_cluster_best<<<nb, 256, 0, st>>>(w.cand, w.err_rows, w.n_err, w.d2bits, w.table_ub, (long long)n);   // B: champions ...
-    k_champ_list<<<kClusterTable / 256, 256, 0, st>>>(w.table_ub, w.champ, w.n_champ, w.lbtab);
-    k_champ_exact<<<dim3(128, kChampSplit), 256, 0, st>>>(w.cand, n, w.champ, w.n_champ, w.lbtab);   // ... lower bounds
+    const int32_t* rows = w.err_rows;
+    const int* n_rows = w.n_err;
+    unsigned* ub = w.d2bits;
+    if (two_stage) {
+      // worth its five launches only with many wrong points (the fine stage's phase A is rows x n / 16 pairs): 2x the
+      // threshold of the fine stage
+      bounding_stage(w.samp_coarse, (n + kSampleCoarse - 1) / kSampleCoarse, rows, n_rows, ub, w.table_ub_c, w.lbtab_c, w.champ_c,
+                     w.n_champ_c, w.surv_c_rows, w.d2s_c, w.n_surv_c, (long long)(n / 2));
+      A3D_LAUNCH_CHECK();
+      rows = w.surv_c_rows;
+      n_rows = w.n_surv_c;
+      ub = w.d2s_c;
+    }
+    // behind a coarse stage the rows are few and the launches are issued anyway: the fine stage runs from a quarter of the
+    // pair count (what it saves is the final pass over ALL points for most of its rows)
+    bounding_stage(w.samp, n_samp, rows, n_rows, ub, w.table_ub, w.lbtab, w.champ, w.n_champ, w.surv_rows, w.d2s, w.n_surv,
+                   two_stage ? 4ll * n : (long long)n);
     A3D_LAUNCH_CHECK();
-    k_survivors<<<nb, 256, 0, st>>>(w.cand, w.err_rows, w.n_err, w.d2bits, w.lbtab, w.surv_rows, w.d2s, w.n_surv);   // C
     nearest(w.cand, n, w.surv_rows, w.n_surv, w.d2s, 0);
     k_cluster_best<<<nb, 256, 0, st>>>(w.cand, w.surv_rows, w.n_surv, w.d2s, w.table, 0);
     A3D_LAUNCH_CHECK();

@@ -72,15 +72,16 @@ def _pack(w_in_out):
     return B.pack_weight(w_in_out.reshape(1, cin, cout)), cin, cout
 
 
-def _linear(x, packed, bias=None):
-    """x [n, cin] @ w [cin, cout] (+ bias) through a3d_linear; ``packed`` = _pack(w)."""
+def _linear(x, packed, bias=None, acc=None):
+    """x [n, cin] @ w [cin, cout] (+ bias) through a3d_linear; ``packed`` = _pack(w).  ``acc`` [n, cout]: the product is ADDED
+    to it in place (the kernel's residual input and its output are the same rows: one rounding, like ``acc + product``)."""
     lib = L.load()
     wp, cin, cout = packed
     x = x.contiguous()
     n = x.shape[0]
-    y = torch.empty((n, cout), dtype=torch.float32, device=x.device)
-    L.check(lib.a3d_linear(_ptr(x), cin, None, 0, n, cin, cout, _ptr(wp), None, _ptr(bias), None, 0, 0, _ptr(y), cout,
-                           None, 0, _stream()), "a3d_linear")
+    y = acc if acc is not None else torch.empty((n, cout), dtype=torch.float32, device=x.device)
+    L.check(lib.a3d_linear(_ptr(x), cin, None, 0, n, cin, cout, _ptr(wp), None, _ptr(bias), _ptr(acc), cout if acc is not None else 0,
+                           0, _ptr(y), cout, None, 0, _stream()), "a3d_linear")
     return y
 
 
@@ -162,7 +163,10 @@ class DecoderTape:
             if y.g is None:
                 return
             dy = y.g.contiguous()
-            x.add_grad(_linear(dy, bwd_w))                               # dy @ W
+            if x.needs_grad and x.g is not None and x.own and x.g.is_contiguous():
+                _linear(dy, bwd_w, acc=x.g)                              # x.g += dy @ W in the GEMM's epilogue (no [N, 128] add)
+            elif x.needs_grad:
+                x.add_grad(_linear(dy, bwd_w))                           # dy @ W
             dW = B.linear_weight_grad(x.v, dy).t()                        # [out, in]
             if rows is None:
                 self._pg(wname, dW)
@@ -211,7 +215,7 @@ class DecoderTape:
     #   "dense"      scores materialised (csrc/attn_train.hip): the click-to-click self attention, and everything when
     #                FLASH is False (the path the flash kernels are checked against)
     @staticmethod
-    def _dense_fwd(qv, kv, vv, mask):
+    def _dense_fwd(qv, kv, vv, mask, o):
         lib = L.load()
         Lq, Lk = qv.shape[0], kv.shape[0]
         dev = qv.device
@@ -221,15 +225,13 @@ class DecoderTape:
             Pm = torch.empty((H, Lk, Lq), dtype=torch.float32, device=dev)                      # P^T[h][key][query]
             L.check(lib.a3d_attn_scores(_ptr(kv), _ptr(qv), Lk, Lq, H, DH, scale, None, _ptr(Pm), _stream()), "scores")
             L.check(lib.a3d_softmax_cols(_ptr(Pm), H, Lk, Lq, _stream()), "softmax_cols")         # over the keys
-            o = torch.empty((Lq, H * DH), dtype=torch.float32, device=dev)
             _apply(Pm, vv, Lk, Lq, H, DH, 1, 1.0, o)
         else:
             Pm = torch.empty((H, Lq, Lk), dtype=torch.float32, device=dev)
             L.check(lib.a3d_attn_scores(_ptr(qv), _ptr(kv), Lq, Lk, H, DH, scale, _ptr(mask), _ptr(Pm), _stream()), "scores")
             L.check(lib.a3d_softmax_rows(_ptr(Pm), H * Lq, Lk, _stream()), "softmax")
-            o = torch.empty((Lq, H * DH), dtype=torch.float32, device=dev)
             _apply(Pm, vv, Lq, Lk, H, DH, 0, 1.0, o)
-        return o, (Pm, transposed)
+        return Pm, transposed
 
     @staticmethod
     def _dense_bwd(qv, kv, vv, mask, o, saved, do, dq, dk, dv):
@@ -252,18 +254,17 @@ class DecoderTape:
             _apply(dP, qv, Lq, Lk, H, DH, 1, scale, dk)
 
     @staticmethod
-    def _c2s_fwd(qv, kv, vv, mask):
+    def _c2s_fwd(qv, kv, vv, mask, o):
         lib = L.load()
         Lq, Lk = qv.shape[0], kv.shape[0]
         dev = qv.device
         qs = qv * 0.25                                                     # 1 / sqrt(16): exact
         nbytes = lib.a3d_flash_c2s_workspace_bytes(Lq, Lk)
         ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-        o = torch.empty((Lq, H * DH), dtype=torch.float32, device=dev)
         stats = torch.empty((2, H, Lq), dtype=torch.float32, device=dev)
         L.check(lib.a3d_flash_c2s_forward(_ptr(qs), _ptr(kv), _ptr(vv), _ptr(mask), Lq, Lk, _ptr(o), _ptr(stats), _ptr(ws),
                                           nbytes, _stream()), "flash_c2s_forward")
-        return o, (qs, stats)
+        return qs, stats
 
     @staticmethod
     def _c2s_bwd(qv, kv, vv, mask, o, saved, do, dq, dk, dv):
@@ -277,27 +278,27 @@ class DecoderTape:
         dq *= 0.25
 
     @staticmethod
-    def _s2c_fwd(qv, kv, vv, mask):
+    def _s2c_fwd(qv, kv, vv, mask, o):
+        # the 1 / sqrt(16) goes on the FEW keys, not on the N queries: q . (k / 4) has the bits of (q / 4) . k (a power of two),
+        # and the kernel's dq = dS (k / 4) is then already the gradient of the unscaled queries
         lib = L.load()
         Lq, Lk = qv.shape[0], kv.shape[0]
-        dev = qv.device
-        qs = qv * 0.25
-        o = torch.empty((Lq, H * DH), dtype=torch.float32, device=dev)
-        stats = torch.empty((Lq, H, 2), dtype=torch.float32, device=dev)
-        L.check(lib.a3d_flash_s2c_forward(_ptr(qs), _ptr(kv), _ptr(vv), Lq, Lk, _ptr(o), _ptr(stats), _stream()),
+        ks = kv * 0.25
+        stats = torch.empty((Lq, H, 2), dtype=torch.float32, device=qv.device)
+        L.check(lib.a3d_flash_s2c_forward(_ptr(qv), _ptr(ks), _ptr(vv), Lq, Lk, _ptr(o), _ptr(stats), _stream()),
                 "flash_s2c_forward")
-        return o, (qs, stats)
+        return ks, stats
 
     @staticmethod
     def _s2c_bwd(qv, kv, vv, mask, o, saved, do, dq, dk, dv):
         lib = L.load()
-        qs, stats = saved
+        ks, stats = saved
         Lq, Lk = qv.shape[0], kv.shape[0]
         nbytes = lib.a3d_flash_s2c_workspace_bytes(Lq, Lk)
         ws = torch.empty(nbytes, dtype=torch.uint8, device=qv.device)
-        L.check(lib.a3d_flash_s2c_backward(_ptr(qs), _ptr(kv), _ptr(vv), Lq, Lk, _ptr(o), _ptr(stats), _ptr(do), _ptr(dq),
+        L.check(lib.a3d_flash_s2c_backward(_ptr(qv), _ptr(ks), _ptr(vv), Lq, Lk, _ptr(o), _ptr(stats), _ptr(do), _ptr(dq),
                                            _ptr(dk), _ptr(dv), _ptr(ws), nbytes, _stream()), "flash_s2c_backward")
-        dq *= 0.25
+        dk *= 0.25
 
     def attention_seg(self, q: _T, k: _T, v: _T, q_ranges, k_ranges, masks=None) -> _T:
         """Attention of every batch sample on ITS rows: sample b's queries are rows q_ranges[b] of ``q``, its keys / values
@@ -316,8 +317,8 @@ class DecoderTape:
             else:
                 kind = "dense"
             fwd = {"s2c": self._s2c_fwd, "c2s": self._c2s_fwd, "dense": self._dense_fwd}[kind]
-            o, sv = fwd(qv[q0:q1], kv[k0:k1], vv[k0:k1], mask)
-            out[q0:q1] = o
+            o = out[q0:q1]                                  # the sample's rows of the batched result: written in place
+            sv = fwd(qv[q0:q1], kv[k0:k1], vv[k0:k1], mask, o)
             saved.append((kind, o, sv, mask))
         y = _T(out)
 
@@ -369,10 +370,11 @@ class DecoderTape:
             self.args.append(arg)
 
         def back():
-            dsrc = torch.zeros_like(src.v)
+            dsrc = torch.empty_like(src.v)                # every sample's rows are written below (or cleared: no loss there)
             dE = torch.zeros_like(E.v)
             for (n0, n1), (q0, q1), grp, y, arg in zip(n_ranges, q_ranges, groups, outs, saved):
                 if y.g is None:
+                    dsrc[n0:n1].zero_()
                     continue
                 N, Q, G = n1 - n0, q1 - q0, len(grp)
                 dlq = torch.empty((N, Q), dtype=torch.float32, device=dev)

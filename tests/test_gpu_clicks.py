@@ -197,11 +197,16 @@ def _prune_cases():
     large blobs, everything wrong, sizes around the sampling stride, exact distance ties (points on an integer lattice)."""
     rng = np.random.default_rng(7)
     out = []
+    # from 16 384 points on a coarse bounding stage (every 256th point) runs in front; it is skipped on the device unless
+    # wrong points x points >= 2^31: the last three cases are beyond that, the two before them around the size threshold
     for n, kind in [(1024, "noise"), (1500, "blobs"), (4099, "noise"), (20_011, "blobs"), (20_011, "all_wrong"),
-                    (8192, "lattice")]:
+                    (8192, "lattice"), (16_383, "blobs"), (16_384, "noise"), (65_537, "all_wrong"), (70_001, "half_wrong"),
+                    (60_000, "lattice_big")]:
         xyz = rng.uniform(0, 4, (n, 3)).astype(np.float32)
         if kind == "lattice":
             xyz = rng.integers(0, 24, (n, 3)).astype(np.float32) * 0.05
+        if kind == "lattice_big":
+            xyz = rng.integers(0, 48, (n, 3)).astype(np.float32) * 0.05
         labels = (xyz[:, 0] // 1).astype(np.int32) % 5
         pred = labels.copy()
         if kind == "noise":
@@ -213,6 +218,12 @@ def _prune_cases():
                 pred[np.linalg.norm(xyz - c, axis=1) < rng.uniform(0.3, 1.5)] = rng.integers(0, 7)
         elif kind == "all_wrong":
             pred = (labels + 1 + rng.integers(0, 2, n)).astype(np.int32)
+        elif kind == "half_wrong":          # a few huge coherent regions (what a prediction of early weights looks like)
+            m = (np.sin(2.1 * xyz[:, 0]) + np.cos(1.7 * xyz[:, 1]) + 0.3 * xyz[:, 2]) > 0.4
+            pred[m] = (labels[m] + 1 + (xyz[m, 1] // 2).astype(np.int32)) % 6
+        elif kind == "lattice_big":         # exact distance ties everywhere, most points wrong
+            m = xyz.sum(1) > 1.0
+            pred[m] = (labels[m] + 1) % 5
         out.append((pred.astype(np.int32), labels.astype(np.int32), xyz))
     return out
 
@@ -228,8 +239,8 @@ pickle.dump(res, open(sys.argv[1], "wb"))
 
 
 def test_bounded_search_equals_plain_pass(tmp_path):
-    """The click simulator's bounded search (upper bounds from every 16th point, one exact champion per cluster, full pass
-    for the survivors) against the plain pass over all points in a second interpreter (A3D_CLICK_PRUNE=0): identical cluster
+    """The click simulator's bounded search (a coarse and a fine bounding stage: upper bounds from every 256th / 16th point, one
+    exact champion per cluster, the survivors on to the next stage and finally the full pass) against the plain pass over all points in a second interpreter (A3D_CLICK_PRUNE=0): identical cluster
     lists -- rows and the bits of the error sizes -- and both against the float64 k-d tree."""
     import pickle, subprocess, sys
     out = tmp_path / "plain.pkl"
