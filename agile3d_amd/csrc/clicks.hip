@@ -18,15 +18,13 @@
 // distance -- a LOWER bound of the cluster's maximum --, (C) only points whose upper bound reaches their cluster's
 // lower bound can be the arg-max (ties included) and go through the full pass.  Every pair distance is the same
 // expression in all three phases, so the comparisons are exact in floating point.
-// Round 4, near field first: most wrong points of a real prediction sit within a few voxels of a point outside their cluster
-// (noisy labels, thin rims), where sampled bounds prune nothing.  All points are binned into a uniform cell grid over the
-// sample's bounding box (about one cell per point, <= 15 points kept per cell); a wrong point scans the rings of cells around
-// its own and is RESOLVED -- exact distance -- once its best distance is below what any unscanned cell can hold; only the
-// points still unresolved after two rings (deep inside a large wrong region, or next to an overfull cell) go through the
-// bounded brute-force search below.  Same pair expression everywhere: the result is bit-identical to the plain pass.
 // Round 4: the bounding runs TWICE, coarse to fine -- first against every 256th point (1/16 of phase A's pairs), whose
 // survivors alone meet every 16th point; with large wrong regions (training with early weights, 300 k-voxel scenes) the
-// first stage removes all but the few per cent of points near a cluster's deepest spot and phase A shrinks by ~10x.
+// first stage removes all but the few per cent of points near a cluster's deepest spot and phase A shrinks by ~10x
+// (300 k voxels, 60 % wrong: 1.07 -> 0.79 ms; from kCoarseFrom points on -- at 80 k its launches cost what it saves).
+// A cell-list search for the NEAR field in front of all this (points binned into a uniform grid, rings of cells scanned
+// by 32 lanes per wrong point, only unresolved points to the brute-force search) was built, verified bit-identical and
+// measured slower in every regime but one (profiles/r04_experiments.txt): removed.
 #include "common.h"
 #include <stdlib.h>
 
@@ -39,9 +37,7 @@ constexpr int kNearestBlock = 256;
 constexpr int kNearestSplit = 128;           // candidate chunks (grid.y): enough waves when only a few thousand points are wrong
 constexpr int kSample = 16;                  // phase A: every kSample-th point is a candidate
 constexpr int kSampleCoarse = 256;           // ... after a first bounding stage against every kSampleCoarse-th point (a subset of them)
-constexpr int kBucket = 15;                  // points kept per grid cell (a cell with more is "overfull": its neighbours stay unresolved)
-constexpr int kRings = 2;                    // rings of cells a wrong point scans before it is handed to the brute-force search
-constexpr int kCoarseFrom = 150000;          // the coarse bounding stage runs from this many points (80 k: its five launches cost what it saves)
+constexpr int kCoarseFrom = 150000;          // ... from this many points (80 k voxels: its five launches cost what it saves)
 constexpr int kMinChunk = 32;                // candidates per workgroup row of k_nearest_other at least (small samples: fewer, fuller blocks)
 constexpr long long kSmallPairs = 1ll << 30;  // (wrong points) x (points) below which phase A is skipped: the plain pass is ~0.15 ms
 constexpr int kMaxChamp = 1024;              // clusters that get a lower bound (phase B); further ones are not pruned
@@ -98,58 +94,16 @@ __global__ void k_iou_counts(const int32_t* __restrict__ pred, const int64_t* __
 }
 
 // ---- click simulator --------------------------------------------------------------------------
-// float -> unsigned with the same order (and back)
-__device__ __forceinline__ unsigned ordered_bits(float f) {
-  const unsigned b = __float_as_uint(f);
-  return b ^ ((b >> 31) ? 0xffffffffu : 0x80000000u);
-}
-__device__ __forceinline__ float from_ordered_bits(unsigned u) {
-  return __uint_as_float(u ^ ((u >> 31) ? 0x80000000u : 0xffffffffu));
-}
-// The cell grid of a sample: derived from its bounding box by every thread that needs it (same arithmetic -> same grid).
-// About one cell per point (surfaces: a handful of points per occupied cell), at most `cap` cells, at most 1024 per axis.
-struct CellGrid {
-  float x0, y0, z0, inv_c, c;
-  int dx, dy, dz;
-};
-__device__ __forceinline__ CellGrid cell_grid(const unsigned* __restrict__ bbox, int64_t n, int cap) {
-  CellGrid g;
-  g.x0 = from_ordered_bits(~bbox[0]);
-  g.y0 = from_ordered_bits(~bbox[1]);
-  g.z0 = from_ordered_bits(~bbox[2]);
-  const float ex = fmaxf(from_ordered_bits(bbox[3]) - g.x0, 1e-6f), ey = fmaxf(from_ordered_bits(bbox[4]) - g.y0, 1e-6f),
-              ez = fmaxf(from_ordered_bits(bbox[5]) - g.z0, 1e-6f);
-  const float emax = fmaxf(ex, fmaxf(ey, ez));
-  float c = fmaxf(cbrtf(ex * ey * ez / (float)n), emax * (1.f / 1000.f));
-  for (int it = 0; it < 64; ++it) {
-    g.dx = (int)(ex / c) + 1;
-    g.dy = (int)(ey / c) + 1;
-    g.dz = (int)(ez / c) + 1;
-    if ((long long)g.dx * g.dy * g.dz <= cap) break;
-    c *= 1.25f;
-  }
-  g.c = c;
-  g.inv_c = 1.f / c;
-  return g;
-}
-__device__ __forceinline__ void cell_of(const CellGrid& g, float x, float y, float z, int& cx, int& cy, int& cz) {
-  cx = min(max((int)((x - g.x0) * g.inv_c), 0), g.dx - 1);
-  cy = min(max((int)((y - g.y0) * g.inv_c), 0), g.dy - 1);
-  cz = min(max((int)((z - g.z0) * g.inv_c), 0), g.dz - 1);
-}
-
 // cand[i] = (x, y, z, cluster id bits) for EVERY point (cluster -1 = correctly labelled);
 // err_rows = rows of wrongly labelled points in arbitrary order (the result does not depend on it).
 __global__ void k_err_compact(const float* __restrict__ xyz, const int32_t* __restrict__ pred,
                               const int32_t* __restrict__ labels, int64_t n, float4* __restrict__ cand,
                               int32_t* __restrict__ err_rows, unsigned* __restrict__ d2bits,
                               int* __restrict__ n_err, int* __restrict__ err, float4* __restrict__ samp, int stride,
-                              float4* __restrict__ samp_coarse, int stride_coarse, int* __restrict__ max_cid,
-                              unsigned* __restrict__ bbox) {
+                              float4* __restrict__ samp_coarse, int stride_coarse, int* __restrict__ max_cid) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   bool wrong = false;
   int my_cid = -1;
-  float lo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, hi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
   if (i < n) {
     const int p = pred[i], l = labels[i];
     const bool bad = p < 0 || p > 255 || l < 0 || l > 255;   // reported through err (the call fails); never used as a table index
@@ -161,24 +115,6 @@ __global__ void k_err_compact(const float* __restrict__ xyz, const int32_t* __re
     cand[i] = c;
     if (samp && i % stride == 0) samp[i / stride] = c;
     if (samp_coarse && i % stride_coarse == 0) samp_coarse[i / stride_coarse] = c;
-    lo[0] = hi[0] = c.x; lo[1] = hi[1] = c.y; lo[2] = hi[2] = c.z;
-  }
-  if (bbox) {   // bounding box of the sample (cell grid of the near-field search): wave reduction, six atomics per wave
-#pragma unroll
-    for (int a = 0; a < 3; ++a) {
-#pragma unroll
-      for (int o = 32; o >= 1; o >>= 1) {
-        lo[a] = fminf(lo[a], __shfl_xor(lo[a], o));
-        hi[a] = fmaxf(hi[a], __shfl_xor(hi[a], o));
-      }
-      if ((threadIdx.x & 63) == 0) {
-        // zero-initialised words: a maximum of the complement is a minimum.  Read first: after the first waves almost no
-        // wave widens the box, and thousands of atomics on six words would queue (100 us instead of 20)
-        const unsigned l = ~ordered_bits(lo[a]), h = ordered_bits(hi[a]);
-        if (l > __atomic_load_n(&bbox[a], __ATOMIC_RELAXED)) atomicMax(&bbox[a], l);
-        if (h > __atomic_load_n(&bbox[3 + a], __ATOMIC_RELAXED)) atomicMax(&bbox[3 + a], h);
-      }
-    }
   }
   // one pair of atomics per WORKGROUP (the waves' counts and maxima meet in LDS): a sample's thousands of waves would queue
   // on the two counter words otherwise (58 us at 300 k points, an order of magnitude above the kernel's memory time)
@@ -261,106 +197,6 @@ __global__ __launch_bounds__(kNearestBlock) void k_nearest_other(const float4* _
   }
 }
 
-
-// ---- near field: cell lists -----------------------------------------------------------------------------
-// every point into its cell: counts[cell] points, the first kBucket of them listed (rows, arbitrary order: only minima are taken)
-__global__ void k_cell_bin(const float4* __restrict__ cand, int64_t n, const unsigned* __restrict__ bbox, int cap,
-                           int* __restrict__ counts, int32_t* __restrict__ buckets) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const CellGrid g = cell_grid(bbox, n, cap);
-  const float4 p = cand[i];
-  int cx, cy, cz;
-  cell_of(g, p.x, p.y, p.z, cx, cy, cz);
-  const int cell = (cz * g.dy + cy) * g.dx + cx;
-  const int slot = atomicAdd(&counts[cell], 1);
-  if (slot < kBucket) buckets[(size_t)cell * kBucket + slot] = (int32_t)i;
-}
-
-// 32 lanes per wrong point, one cell each: rings of cells around the point's own (27 cells = one step, the 98 of the second
-// ring = four).  After rings 0..r every point not yet seen lies in a ring >= r + 1, i.e. at least r cell sizes away along
-// some axis: a best distance below r * c (minus a rounding margin) is exact.  Unresolved after kRings rings, or an overfull
-// cell in reach: the point goes to the brute-force search (deep_rows) with the best distance found so far as its upper
-// bound, and is marked in d2bits (0xffffffff: not a value, k_cluster_best skips it).  A workgroup takes kCellQueries points
-// (eight at a time) and appends its unresolved ones with ONE atomic.
-constexpr int kCellQueries = 64;
-__global__ void __launch_bounds__(256) k_cell_nearest(const float4* __restrict__ cand, int64_t n,
-                                                      const int32_t* __restrict__ err_rows, const int* __restrict__ n_err_p,
-                                                      const unsigned* __restrict__ bbox, int cap,
-                                                      const int* __restrict__ counts, const int32_t* __restrict__ buckets,
-                                                      unsigned* __restrict__ d2bits, int32_t* __restrict__ deep_rows,
-                                                      unsigned* __restrict__ d2deep, int* __restrict__ n_deep) {
-  const int n_err = *n_err_p;
-  const int e0 = blockIdx.x * kCellQueries;
-  if (e0 >= n_err) return;
-  __shared__ int s_row[kCellQueries];
-  __shared__ unsigned s_ub[kCellQueries];
-  __shared__ int s_n, s_base;
-  if (threadIdx.x == 0) s_n = 0;
-  __syncthreads();
-  const CellGrid g = cell_grid(bbox, n, cap);
-  const int sub = threadIdx.x & 31, grp = threadIdx.x >> 5;
-  for (int it = 0; it < kCellQueries / 8; ++it) {
-    const int e = e0 + it * 8 + grp;
-    if (e >= n_err) continue;                    // uniform over the 32 lanes of a point
-    const int row = err_rows[e];
-    const float4 q = cand[row];
-    const int qc = __float_as_int(q.w);
-    int cx, cy, cz;
-    cell_of(g, q.x, q.y, q.z, cx, cy, cz);
-    float best = __uint_as_float(kInfBits);
-    int overfull = 0;
-    auto visit_cell = [&](int x, int y, int z) {
-      if ((unsigned)x >= (unsigned)g.dx || (unsigned)y >= (unsigned)g.dy || (unsigned)z >= (unsigned)g.dz) return;
-      const int cell = (z * g.dy + y) * g.dx + x;
-      const int cnt = counts[cell];
-      overfull |= cnt > kBucket;
-      const int32_t* b = buckets + (size_t)cell * kBucket;
-      for (int s_ = 0; s_ < min(cnt, kBucket); ++s_) {
-        const float4 c = cand[b[s_]];
-        const float dx = q.x - c.x, dy = q.y - c.y, dz = q.z - c.z;
-        const float d2 = fmaf(dz, dz, fmaf(dy, dy, dx * dx));   // the expression of k_nearest_other: bit-identical pair values
-        best = fminf(best, __float_as_int(c.w) != qc ? d2 : __uint_as_float(kInfBits));
-      }
-    };
-    auto combine = [&]() {                       // over the 32 lanes of the point (xor offsets below 32 stay inside them)
-#pragma unroll
-      for (int o = 16; o >= 1; o >>= 1) {
-        best = fminf(best, __shfl_xor(best, o));
-        overfull |= __shfl_xor(overfull, o);
-      }
-    };
-    if (sub < 27) visit_cell(cx + sub % 3 - 1, cy + (sub / 3) % 3 - 1, cz + sub / 9 - 1);
-    combine();
-    float lim = g.c * (1.f - 1e-4f);
-    bool resolved = !overfull && best < lim * lim;
-    if (!resolved && !overfull && kRings >= 2) {
-      for (int k = sub; k < 125; k += 32) {
-        const int ox = k % 5 - 2, oy = (k / 5) % 5 - 2, oz = k / 25 - 2;
-        if (max(abs(ox), max(abs(oy), abs(oz))) == 2) visit_cell(cx + ox, cy + oy, cz + oz);
-      }
-      combine();
-      lim = 2.f * g.c * (1.f - 1e-4f);
-      resolved = !overfull && best < lim * lim;
-    }
-    if (sub == 0) {
-      d2bits[e] = resolved ? __float_as_uint(best) : 0xffffffffu;
-      if (!resolved) {
-        const int k = atomicAdd(&s_n, 1);        // LDS counter: cheap
-        s_row[k] = row;
-        s_ub[k] = __float_as_uint(best);         // an upper bound (possibly +inf): k_nearest_other takes minima into it
-      }
-    }
-  }
-  __syncthreads();
-  if (threadIdx.x == 0) s_base = s_n ? atomicAdd(n_deep, s_n) : 0;
-  __syncthreads();
-  for (int k = threadIdx.x; k < s_n; k += blockDim.x) {
-    deep_rows[s_base + k] = s_row[k];
-    d2deep[s_base + k] = s_ub[k];
-  }
-}
-
 // largest "distance to the nearest outside point" per cluster; ties -> lowest row (torch.where(...)[0][0])
 __global__ void k_cluster_best(const float4* __restrict__ cand, const int32_t* __restrict__ err_rows,
                                const int* __restrict__ n_err_p, const unsigned* __restrict__ d2bits,
@@ -369,7 +205,7 @@ __global__ void k_cluster_best(const float4* __restrict__ cand, const int32_t* _
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   int cid = -1;
   unsigned long long key = 0;
-  if (e < *n_err_p && d2bits[e] != 0xffffffffu) {   // 0xffffffff: handed to the brute-force search (k_cell_nearest)
+  if (e < *n_err_p) {
     const int row = err_rows[e];
     cid = __float_as_int(cand[row].w);
     key = ((unsigned long long)d2bits[e] << 32) | (0xffffffffu - (unsigned)row);
@@ -541,14 +377,6 @@ struct ClickWs {
   float4* samp_coarse;
   int32_t* surv_c_rows;
   unsigned* d2s_c;
-  // near field: cell grid (counts inside the zeroed region), the rows left to the brute-force search
-  unsigned* bbox;
-  int* n_deep;
-  int cell_cap;
-  int* counts;
-  int32_t* buckets;
-  int32_t* deep_rows;
-  unsigned* d2deep;
   size_t zero_bytes;   // bytes from `table` on that start out as zeros
   size_t bytes;
 };
@@ -568,14 +396,10 @@ static ClickWs carve_click(void* base, int64_t n) {
   w.max_cid = w.n_err ? w.n_err + 4 : nullptr;
   w.n_surv_c = w.n_err ? w.n_err + 5 : nullptr;
   w.n_champ_c = w.n_err ? w.n_err + 6 : nullptr;
-  w.n_deep = w.n_err ? w.n_err + 7 : nullptr;
-  w.bbox = w.n_err ? (unsigned*)(w.n_err + 8) : nullptr;   // 6 words
   w.table_ub = (unsigned long long*)take((size_t)kClusterTable * 8);
   w.lbtab = (unsigned*)take((size_t)kClusterTable * 4);
   w.table_ub_c = (unsigned long long*)take((size_t)kClusterTable * 8);
   w.lbtab_c = (unsigned*)take((size_t)kClusterTable * 4);
-  w.cell_cap = (int)(2 * n < 4096 ? 4096 : (2 * n > (int64_t)1 << 28 ? (int64_t)1 << 28 : 2 * n));
-  w.counts = (int*)take((size_t)w.cell_cap * 4);
   w.zero_bytes = off;
   w.champ = (int2*)take((size_t)kMaxChamp * 8);
   w.champ_c = (int2*)take((size_t)kMaxChamp * 8);
@@ -588,9 +412,6 @@ static ClickWs carve_click(void* base, int64_t n) {
   w.samp_coarse = (float4*)take((size_t)(n / kSampleCoarse + 8) * 16);
   w.surv_c_rows = (int32_t*)take((size_t)n * 4);
   w.d2s_c = (unsigned*)take((size_t)n * 4);
-  w.buckets = (int32_t*)take((size_t)w.cell_cap * kBucket * 4);
-  w.deep_rows = (int32_t*)take((size_t)n * 4);
-  w.d2deep = (unsigned*)take((size_t)n * 4);
   w.bytes = off;
   return w;
 }
@@ -671,13 +492,12 @@ extern "C" int a3d_click_clusters(const float* xyz_dev, const int32_t* pred_dev,
   }
   const int stride = kSample;   // strides 8 / 16 / 32 / 64 measured in round 3: 16 is the best or second best everywhere
   const bool bounded = prune && n >= 64 * stride;
-  const bool cells = bounded && prune != 3;      // A3D_CLICK_PRUNE=3: the bounded brute-force search alone (round 3; A/B)
-  const bool two_stage = bounded && n >= kCoarseFrom;
+  const bool two_stage = bounded && prune != 3 && n >= kCoarseFrom;   // A3D_CLICK_PRUNE=3: the one-stage search of round 3 (A/B)
   A3D_HIP_CHECK(hipMemsetAsync(w.table, 0, w.zero_bytes, st));   // tables + counters
   const unsigned nb = (unsigned)((n + 255) / 256);
   k_err_compact<<<nb, 256, 0, st>>>(xyz_dev, pred_dev, labels_dev, n, w.cand, w.err_rows, w.d2bits, w.n_err, w.err,
                                     bounded ? w.samp : nullptr, stride, two_stage ? w.samp_coarse : nullptr, kSampleCoarse,
-                                    w.max_cid, cells ? w.bbox : nullptr);
+                                    w.max_cid);
   A3D_LAUNCH_CHECK();
   const int per_block = kNearestBlock * kQueriesPerThread;
   auto nearest = [&](const float4* cands, int64_t n_cands, const int32_t* rows, const int* n_rows, unsigned* out,
@@ -710,17 +530,6 @@ extern "C" int a3d_click_clusters(const float* xyz_dev, const int32_t* pred_dev,
     const int32_t* rows = w.err_rows;
     const int* n_rows = w.n_err;
     unsigned* ub = w.d2bits;
-    if (cells) {
-      // near field: exact distances for every wrong point with an outside point within two cells; the rest -> deep_rows
-      k_cell_bin<<<nb, 256, 0, st>>>(w.cand, n, w.bbox, w.cell_cap, w.counts, w.buckets);
-      k_cell_nearest<<<(unsigned)((n + kCellQueries - 1) / kCellQueries), 256, 0, st>>>(w.cand, n, w.err_rows, w.n_err, w.bbox, w.cell_cap, w.counts, w.buckets, w.d2bits,
-                                         w.deep_rows, w.d2deep, w.n_deep);
-      k_cluster_best<<<nb, 256, 0, st>>>(w.cand, w.err_rows, w.n_err, w.d2bits, w.table, 0);   // the resolved ones
-      A3D_LAUNCH_CHECK();
-      rows = w.deep_rows;
-      n_rows = w.n_deep;
-      ub = w.d2deep;
-    }
     if (two_stage) {
       // worth its five launches only with many wrong points (the fine stage's phase A is rows x n / 16 pairs): 2x the
       // threshold of the fine stage
