@@ -1,7 +1,11 @@
 #!/bin/bash
-# s28: full GPU suite + bench on the build with the decoder-tape changes and the coarse click stage
-mkdir -p gpurun_out/s28
-timeout 2400 python -m pytest tests -m gpu -x -q > gpurun_out/s28/pytest.log 2>&1; echo "pytest rc=$?" >> gpurun_out/s28/pytest.log
-python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/s28/smoke.log 2>&1; echo "smoke rc=$?" >> gpurun_out/s28/smoke.log
-python bench.py > gpurun_out/s28/bench.json 2> gpurun_out/s28/bench.err
-A3D_BB_ITERS=14 python tools/backward_bench.py --step --reps 1 2>&1 | grep "training iteration" | cut -c1-70 > gpurun_out/s28/train.log
+# s29: hand-off reduction with 16/NCT parts in flight (full-register builds): 1-scene and 16-scene layer tables, A/B vs tools/bin/lib_base.so
+mkdir -p gpurun_out/s29
+timeout 900 python -m pytest tests/test_gpu_conv.py tests/test_gpu_model.py -x -q > gpurun_out/s29/pytest.log 2>&1; echo "pytest rc=$?" >> gpurun_out/s29/pytest.log
+for rep in 1 2; do
+for lib in base new; do
+  if [ $lib = base ]; then export A3D_LIB_PATH=$PWD/tools/bin/lib_base.so; else unset A3D_LIB_PATH; fi
+  LT_BATCH=1 python tools/layer_table.py > gpurun_out/s29/lt1_${lib}_$rep.txt 2>&1
+  LT_BATCH=16 python tools/layer_table.py > gpurun_out/s29/lt16_${lib}_$rep.txt 2>&1
+  python bench.py --no-train --steps-only 2>/dev/null | tail -1 > gpurun_out/s29/bench_${lib}_$rep.json
+done; done
