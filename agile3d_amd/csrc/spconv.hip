@@ -462,11 +462,8 @@ __global__ void __launch_bounds__(256, PAIR ? ((BN <= 96 && CH <= 32) ? 4 : 3) :
         if (tid == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         __syncthreads();
         const float* P0 = a.slab + (size_t)tid * 4;
-        // fixed order: own part, then the parts of the tickets below, descending; U parts' loads in flight at a time.  A tile
-        // of a small level is cut into 10-20 parts (one scene, level 4: 21), each round of loads is a trip to the L2: the
-        // full-register builds (the small and medium levels) take 16 / NCT parts per trip, the low-register builds of the
-        // large levels (one or two parts per tile, 127 registers) stay at one or two
-        constexpr int U = (PAIR == 0 && CH != 48) ? 16 / NCT : (NCT <= 4 ? 2 : 1);
+        // fixed order: own part, then the parts of the tickets below, descending; U parts' loads in flight at a time
+        constexpr int U = NCT <= 4 ? 2 : 1;
         for (int wp = w - 1; wp >= wf; wp -= U) {
           f32x4 pa[U][NCT];
 #pragma unroll
