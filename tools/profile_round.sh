@@ -36,7 +36,8 @@ PMC_JSON=$OUT/pmc_raw_config5.json python $R/tools/rocprof_summary.py /tmp/$TAG/
 python $R/tools/pmc_to_summary.py $OUT/pmc_raw_config5.json $OUT/pmc_summary.json 300k_b1_q30
 cp $OUT/kernel_avg_us.json $OUT/pmc_summary.json $R/profiles/      # so that the config-5 line below reads ITS tables
 # BASELINE.json config 5 (KITTI-like 300 k voxels, 20 clicks): its own bench line and per-launch table
-python $R/bench.py --voxels 300000 --clicks-per-object 4 --batch 1 --streams 2 --steps 10 --warmup 3 --reps 7 --no-train > $OUT/bench_config5.json 2> $OUT/bench_config5.err
+# (four steps in flight like the headline; 40 steps per repetition: with 10 the fill and drain of the four streams are a tenth of the region)
+python $R/bench.py --voxels 300000 --clicks-per-object 4 --batch 1 --streams 4 --steps 40 --warmup 4 --reps 7 --no-train > $OUT/bench_config5.json 2> $OUT/bench_config5.err
 LT_BATCH=1 LT_VOXELS=300000 LT_CPO=4 python $R/tools/layer_table.py > $OUT/layer_table_config5.txt 2>&1
 LT_BATCH=4 python $R/tools/layer_table.py > $OUT/layer_table_4scenes.txt 2>&1
 LT_BATCH=1 python $R/tools/layer_table.py > $OUT/layer_table_1scene.txt 2>&1
@@ -49,4 +50,11 @@ done
 # training iterations (4 x 80 k voxels, the real train_one_step): phase times, then plain wall clock
 A3D_BB_ITERS=10 A3D_TRAIN_TIMING=1 python $R/tools/backward_bench.py --step --reps 1 2>&1 | grep -E "training iteration|train_one_step" > $OUT/training_iterations.txt
 A3D_BB_ITERS=10 python $R/tools/backward_bench.py --step --reps 1 2>&1 | grep -E "training iteration" >> $OUT/training_iterations.txt
+# kernel trace of four training iterations
+rm -rf /tmp/$TAG/trt
+A3D_TRAIN_TIMING=1 rocprofv3 --kernel-trace --stats -d /tmp/$TAG/trt -o t -- python $R/tools/backward_bench.py --step --reps 1 > $OUT/train_trace.log 2>&1
+python $R/tools/rocprof_summary.py /tmp/$TAG/trt > $OUT/training_kernel_trace.txt 2>&1
+python $R/tools/rocprof_stalls.py /tmp/$TAG/trt 10 > $OUT/training_stalls.txt 2>&1
+# steps per repetition: what the fill and drain of the four streams cost at the driver's 20 steps
+for K in 20 80; do echo -n "steps=$K: "; python $R/bench.py --steps-only --no-profile --steps $K --reps 9 2>/dev/null | tail -1 | python -c "import json,sys; r=json.loads(sys.stdin.read()); print(round(r['value'],1), 'scenes/s', round(r['ms_per_step'],3), 'ms per step')"; done > $OUT/steps_per_repetition.txt 2>&1
 ls -la $OUT
