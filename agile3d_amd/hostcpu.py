@@ -51,8 +51,9 @@ def cpu_quota() -> float:
 
 
 def cap_host_threads() -> int:
-    """torch's intra-op CPU threads = at most HALF the quota (the launch thread, the HIP runtime's helpers and the other
-    streams' launch threads need the rest), never more than torch chose itself (OMP_NUM_THREADS is respected).
+    """torch's intra-op CPU threads = at most HALF this process's share of the quota (the launch thread, the HIP runtime's
+    helpers and the other streams' launch threads need the rest; the ranks of a node -- LOCAL_WORLD_SIZE, set by
+    torch.distributed.run -- share one quota), never more than torch chose itself (OMP_NUM_THREADS is respected).
     ``A3D_HOST_THREADS=<n>`` forces n, ``A3D_HOST_THREADS=0`` leaves torch alone.  Returns the thread count in force."""
     import torch
     forced = os.environ.get("A3D_HOST_THREADS")
@@ -62,7 +63,8 @@ def cap_host_threads() -> int:
         if want <= 0:
             return cur
     else:
-        want = min(cur, max(1, int(math.floor(cpu_quota() / 2))))
+        ranks = max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1") or 1))
+        want = min(cur, max(1, int(math.floor(cpu_quota() / (2 * ranks)))))
     if want != cur:
         torch.set_num_threads(want)
     return want

@@ -397,7 +397,8 @@ def self_launch(n):
         port = s_.getsockname()[1]
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    env.setdefault("OMP_NUM_THREADS", "8")
+    from agile3d_amd.hostcpu import cpu_quota
+    env.setdefault("OMP_NUM_THREADS", str(max(1, min(8, int(cpu_quota() // (2 * n))))))   # the ranks share the container's CPU quota
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
     return subprocess.run(cmd, env=env).returncode

@@ -34,3 +34,6 @@ def test_switch_forces_a_count_or_leaves_torch_alone():
     assert _threads_in_child({"A3D_HOST_THREADS": "0", "OMP_NUM_THREADS": "5"}) == 5
     # OMP_NUM_THREADS below the cap is respected (the cap never raises the count)
     assert _threads_in_child({"OMP_NUM_THREADS": "1"}) == 1
+    # the ranks of a node share the quota
+    want = max(1, int(hostcpu.cpu_quota() // (2 * 4)))
+    assert _threads_in_child({"LOCAL_WORLD_SIZE": "4"}) <= want
