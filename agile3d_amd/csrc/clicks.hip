@@ -369,7 +369,7 @@ struct ClickWs {
   float4* samp;
   int32_t* surv_rows;
   unsigned* d2s;
-  // the coarse bounding stage in front (its survivors are `surv_rows`; the fine stage's go to surv_c_rows)
+  // the coarse bounding stage in front of the fine one (its survivors: surv_c_rows / d2s_c; the fine stage's: surv_rows / d2s)
   unsigned long long* table_ub_c;
   unsigned* lbtab_c;
   int *n_surv_c, *n_champ_c;
