@@ -52,6 +52,10 @@ struct ConvArgs {
   int zero_row;
   int tag_table, tag_level;   // profiling only
   int n_tiles;
+  // fused residual projection (3^3 only): out += in2 W2, W2 = the 1x1 weight packed right behind the 27 offsets'
+  // (as "offset 27" with cin2 / 16 channel steps); in2 rows = the output rows; cin2 = 0: none
+  const float* in2;
+  int ldi2, cin2;
 };
 
 // ------------------------------------------------------------------------------ k_conv_sk
@@ -83,6 +87,8 @@ struct SkArgs {
   unsigned in_row_bytes; // ldi * 4
   int* fail;             // set when a bounded wait ran out (never in a healthy run)
   int prio;              // 1: static wave priority by occupancy layer (ticket / 256), see the kernel
+  int nchunk2;           // FUSE: stages of the fused 1x1 projection per tile (cin2 / CH), run as offset 27 after the tile's own
+  unsigned in2_row_bytes;
 };
 
 __device__ __forceinline__ void store_sc1(float* p, f32x4 v) {   // write-through (agent scope) 16-byte store
@@ -114,9 +120,15 @@ __device__ __forceinline__ void wait_all_vmem() { __builtin_amdgcn_s_waitcnt(0x0
 // split into three bf16 planes (x = h + m + l by truncation, every remainder exact), h h + h m + m h + h l + m m + l h on
 // v_mfma_f32_16x16x32_bf16 with fp32 accumulation.  Error no larger than the exact fp32 MFMA chain's (tools/
 // bf16x6_ubench.hip: 5.1e-6 against 7.5e-6 over 2592 products), stage loop 1.84x faster; weights packed as three planes.
-template <int BN, int CH, int PAIR>
+// FUSE: the block's residual projection (BasicBlock.downsample: 1x1 conv + BatchNorm on the block input,
+// resnet_block.py:59-61) as one more "offset" of the block's second conv: every tile ends with cin2 / CH stages that
+// gather the output rows themselves from the block input and multiply them with the 1x1 weight (both BatchNorm scales
+// folded into the packed weights by the host, the two shifts added).  Same stage loop, same hand-offs; a separate
+// instantiation, so the plain kernels are untouched.
+template <int BN, int CH, int PAIR, bool FUSE = false>
 __global__ void __launch_bounds__(256, PAIR ? ((BN <= 96 && CH <= 32) ? 4 : 3) : ((BN <= 96 && CH <= 48) ? 3 : 2))
     k_conv_sk(const SkArgs a) {
+  static_assert(!FUSE || PAIR != 2, "the fused projection runs on the exact-fp32 builds");
   constexpr int RG = 1;   // 16-row groups per wave (two per wave -- 128-row tiles -- was tried and did not pay)
   constexpr bool EMU = PAIR == 2;
   static_assert(!EMU || CH == 32, "one 16x16x32 block per stage and column tile");
@@ -132,7 +144,9 @@ __global__ void __launch_bounds__(256, PAIR ? ((BN <= 96 && CH <= 32) ? 4 : 3) :
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int g = lane >> 4, j = lane & 15;
-  const int K = a.c.K, nchunk = a.nchunk, ov = a.ov;
+  const int K = a.c.K, nchunk = a.nchunk;
+  const int nchunk2 = FUSE ? a.nchunk2 : 0;   // stages of the fused projection: the LAST stages of every tile
+  const int ov = a.ov;
   const int T = a.c.n_tiles;
   const int cin16 = a.c.cin >> 4, cout16 = a.c.cout >> 4;
 
@@ -161,9 +175,9 @@ __global__ void __launch_bounds__(256, PAIR ? ((BN <= 96 && CH <= 32) ? 4 : 3) :
 
   auto prefix = [&](int t) -> long long {   // cost units of one cout block before tile t
     const long long n = a.pre ? (long long)a.pre[t] : (long long)K * t;
-    return n * nchunk + (long long)ov * t;
+    return n * nchunk + (long long)(ov + nchunk2) * t;
   };
-  const long long tile_tot = pre_T * nchunk + (long long)ov * T;   // = prefix(T): one pass over all tiles
+  const long long tile_tot = pre_T * nchunk + (long long)(ov + nchunk2) * T;   // = prefix(T): one pass over all tiles
   const long long tot = (long long)a.n_cblk * tile_tot;
   const int G = (int)min((long long)a.G, tot);
   if (w >= G) return;
@@ -241,7 +255,12 @@ __global__ void __launch_bounds__(256, PAIR ? ((BN <= 96 && CH <= 32) ? 4 : 3) :
     }
     un = __builtin_amdgcn_readfirstlane(un);
     gm = __builtin_amdgcn_readfirstlane(gm);
-    const int S = __builtin_popcount(un) * nchunk;
+    const int S_own = __builtin_popcount(un) * nchunk;   // stages of the tile's own offsets
+    const int S = S_own + nchunk2;
+    if constexpr (FUSE) {   // "offset 27": present in every tile and every group (K = 27: bit 27 is free)
+      un |= 1u << 27;
+      gm |= 1u << 27;
+    }
     int s0 = 0, s1 = S;
     bool owner = true;
     long long Cu = 0;
@@ -269,26 +288,36 @@ __global__ void __launch_bounds__(256, PAIR ? ((BN <= 96 && CH <= 32) ? 4 : 3) :
       };
       // first stage of the part: skip s0 / nchunk offsets
       int k = __builtin_ctz(un), c = s0 % nchunk;
-      for (int i = s0 / nchunk; i > 0; --i) k = next_k(k);
+      if (FUSE && s0 >= S_own) {
+        k = 27;
+        c = s0 - S_own;
+      } else {
+        for (int i = s0 / nchunk; i > 0; --i) k = next_k(k);
+      }
       int rem = s1 - s0;
       const float* wbase = a.c.w + (size_t)ct0 * 256;
       const char* inb = (const char*)a.c.in;
       // gather rows of offset kk for this lane's groups, straight from the neighbour table (requested one offset
       // before the A loads that need them); a missing neighbour is the zero row
       auto fetch_rows = [&](int kk, int (&rows)[RG]) {
-        const int kc = kk < 32 ? kk : 0;   // unconditional loads (no select behind them: the loop-carried register is
-                                           // the load's destination, nothing waits for it before its use a stage later)
+        const int kc = kk < K ? kk : 0;    // unconditional loads (no select behind them: the loop-carried register is
+                                           // the load's destination, nothing waits for it before its use a stage later);
+                                           // 32 = no further offset, 27 (FUSE) = the projection: no table row, entry unused
 #pragma unroll
         for (int r = 0; r < RG; ++r)
           rows[r] = a.c.nbr ? a.c.nbr[(size_t)kc * a.c.nbr_stride + r0 + wrow + 16 * r] : min(r0 + wrow + 16 * r, a.c.n_in - 1);
       };
       // stage (k, c): this lane's A fragments (for its groups that have k), this wave's weight pieces by LDS-DMA
       auto load_stage = [&](f32x4 (&A)[RG][NS], int kk, int cc, int slot, const int (&rows)[RG]) {
-        const char* ar = inb + (size_t)cc * (CH * 4);
+        const bool proj = FUSE && kk == 27;   // wave-uniform: the projection's stages read the block input at the output rows
+        const char* ar = (proj ? (const char*)a.c.in2 : inb) + (size_t)cc * (CH * 4);
+        const unsigned row_bytes = proj ? a.in2_row_bytes : a.in_row_bytes;
         if ((gm >> kk) & 1u) {
 #pragma unroll
           for (int r = 0; r < RG; ++r) {
-            const unsigned roff = (unsigned)rows[r] * a.in_row_bytes + lane_a_off;
+            // (the select sits at the USE of the table entry requested a stage earlier, not behind its load)
+            const int row = proj ? min(r0 + wrow + 16 * r, a.c.n_out) : rows[r];   // n_out = the zero row of in2
+            const unsigned roff = (unsigned)row * row_bytes + lane_a_off;
 #pragma unroll
             for (int Sx = 0; Sx < NS; ++Sx) A[r][Sx] = *(const f32x4*)(ar + roff + (EMU ? 16 : 64) * Sx);
           }
@@ -397,7 +426,7 @@ __global__ void __launch_bounds__(256, PAIR ? ((BN <= 96 && CH <= 32) ? 4 : 3) :
       for (;;) {
         int k2, c2;
         // ---- even stage: multiply A0 / slot 0, fetch A1 / slot 1
-        if (c + 1 < nchunk) { k2 = k; c2 = c + 1; } else { k2 = k1; c2 = 0; }
+        if (c + 1 < ((FUSE && k == 27) ? nchunk2 : nchunk)) { k2 = k; c2 = c + 1; } else { k2 = k1; c2 = 0; }
         if (rem > 1) {
           if (k2 != k) {
 #pragma unroll
@@ -413,7 +442,7 @@ __global__ void __launch_bounds__(256, PAIR ? ((BN <= 96 && CH <= 32) ? 4 : 3) :
         if (--rem == 0) break;
         k = k2; c = c2;
         // ---- odd stage: multiply A1 / slot 1, fetch A0 / slot 0
-        if (c + 1 < nchunk) { k2 = k; c2 = c + 1; } else { k2 = k1; c2 = 0; }
+        if (c + 1 < ((FUSE && k == 27) ? nchunk2 : nchunk)) { k2 = k; c2 = c + 1; } else { k2 = k1; c2 = 0; }
         if (rem > 1) {
           if (k2 != k) {
 #pragma unroll
@@ -1184,6 +1213,11 @@ static void allow_big_lds() {
   A3D_BIG3(32, 32) A3D_BIG3(32, 64) A3D_BIG3(32, 96) A3D_BIG3(64, 32) A3D_BIG3(64, 64) A3D_BIG3(64, 96)
   A3D_BIG3(96, 32) A3D_BIG3(96, 48) A3D_BIG3(96, 64) A3D_BIG3(96, 96) A3D_BIG3(128, 32) A3D_BIG3(128, 64)
 #undef A3D_BIG3
+#define A3D_BIGF(BN_, CH_) \
+  A3D_ALLOW_LDS(160 * 1024, (k_conv_sk<BN_, CH_, 0, true>)); \
+  A3D_ALLOW_LDS(160 * 1024, (k_conv_sk<BN_, CH_, 1, true>));
+  A3D_BIGF(64, 32) A3D_BIGF(64, 64) A3D_BIGF(96, 32) A3D_BIGF(128, 32)
+#undef A3D_BIGF
   A3D_ALLOW_LDS(160 * 1024, k_conv_sk<96, 32, 2>);
   A3D_ALLOW_LDS(160 * 1024, k_conv_sk<128, 32, 2>);
   A3D_ALLOW_LDS(160 * 1024, k_conv_sk<64, 32, 2>);
@@ -1215,7 +1249,7 @@ static int launch_conv_sk(ConvArgs c, const int* pre64, float* slab_ws, size_t s
     set_error("spconv: input of %d rows x %d floats exceeds the 4 GB gather window", c.n_in, c.ldi);
     return A3D_ERR_UNSUPPORTED;
   }
-  if (conv_wl_supported(c) && !conv_emu(c.K, c.cin, c.cout)) return launch_conv_wl(c, st);
+  if (c.cin2 == 0 && conv_wl_supported(c) && !conv_emu(c.K, c.cin, c.cout)) return launch_conv_wl(c, st);
   // hand-offs (shares cut inside tiles) pay where a tile is long and tiles are few: the 3^3 maps, and the 2^3 maps of
   // the small levels.  1x1 layers and 2^3 maps with a tile per workgroup slot or more run whole tiles: no ticket, no
   // search, no flags -- their fixed latency is what matters
@@ -1253,7 +1287,25 @@ static int launch_conv_sk(ConvArgs c, const int* pre64, float* slab_ws, size_t s
     set_error("spconv: a gathered convolution needs the scene's tile prefix table");
     return A3D_ERR_INVALID;
   }
-  ProfScope ps(st, A3D_PROF_SPCONV, p.bn, c.K, c.cin, c.cout, c.n_out, c.tag_table, c.tag_level, p.ch);   // last field: stage width
+  // kernel-volume field: K, plus the fused projection's input channels in the bits above (cin2 << 8); last field: stage width
+  ProfScope ps(st, A3D_PROF_SPCONV, p.bn, c.K | (c.cin2 << 8), c.cin, c.cout, c.n_out, c.tag_table, c.tag_level, p.ch);
+  if (c.cin2 > 0) {
+    // fused residual projection: the exact-fp32 builds of the shapes the U-Net's second block convs run on
+    if (c.K != 27 || !c.in2 || p.pair == 2 || c.cin2 % p.ch != 0 || (c.ldi2 & 3) ||
+        (uint64_t)(c.n_out + 1) * (uint64_t)c.ldi2 * 4ull >= (1ull << 32)) {
+      set_error("spconv: fused projection unsupported here (K=%d cin2=%d stage %d emulated=%d)", c.K, c.cin2, p.ch, p.pair == 2);
+      return A3D_ERR_UNSUPPORTED;
+    }
+    a.nchunk2 = c.cin2 / p.ch;
+    a.in2_row_bytes = (unsigned)c.ldi2 * 4u;
+#define A3D_LF(BN_, CH_) \
+  if (p.bn == BN_ && p.ch == CH_) { if (p.pair) k_conv_sk<BN_, CH_, 1, true><<<p.G, 256, p.lds, st>>>(a); else k_conv_sk<BN_, CH_, 0, true><<<p.G, 256, p.lds, st>>>(a); } else
+    A3D_LF(64, 32) A3D_LF(64, 64) A3D_LF(96, 32) A3D_LF(128, 32)
+    { set_error("spconv: no fused kernel for BN %d CH %d", p.bn, p.ch); return A3D_ERR_UNSUPPORTED; }
+#undef A3D_LF
+    A3D_LAUNCH_CHECK();
+    return A3D_OK;
+  }
   if (p.pair == 2) {
     if (p.bn == 96) k_conv_sk<96, 32, 2><<<p.G, 256, p.lds, st>>>(a);
     else if (p.bn == 128) k_conv_sk<128, 32, 2><<<p.G, 256, p.lds, st>>>(a);
@@ -1513,6 +1565,16 @@ extern "C" int a3d_program_run(const a3d_scene* s, const a3d_buf_desc* bufs, int
     a.n_out = s->lv[lvl_out].n;
     a.tag_table = o.kind;
     a.tag_level = Lin;
+    if (o.proj_cin > 0) {   // fused residual projection (see a3d_op)
+      if (o.kind != A3D_OP_CONV3 || o.proj_buf < 0 || o.proj_buf >= n_bufs || bufs[o.proj_buf].level != Lin ||
+          o.proj_coff + o.proj_cin > bufs[o.proj_buf].channels || o.scale_dev) {
+        set_error("op %d: bad fused projection", i);
+        return A3D_ERR_INVALID;
+      }
+      a.in2 = buf_ptr(o.proj_buf) + o.proj_coff;
+      a.ldi2 = bufs[o.proj_buf].channels;
+      a.cin2 = o.proj_cin;
+    }
     const int* pre = nullptr;
     switch (o.kind) {
       case A3D_OP_CONV3:

@@ -13,6 +13,7 @@ from __future__ import annotations
 
 import ctypes as C
 import math
+import os
 
 import numpy as np
 import torch
@@ -106,7 +107,7 @@ class _Pool:
 class BackboneProgram:
     """Res16UNet34C + lin_squeeze_head as a list of ``a3d_op`` (built once per weight version)."""
 
-    def __init__(self, model, device):
+    def __init__(self, model, device, fuse_proj=None):
         lib = L.load()
         self.keep = []          # tensors referenced by raw pointers
         self.ops = []
@@ -115,8 +116,15 @@ class BackboneProgram:
         bb = model.backbone
         dev = device
 
-        def pack(conv):
-            w = conv.kernel3().detach().to(dev, torch.float32).contiguous()
+        # the residual projections (BasicBlock.downsample) run inside the block's second conv (a3d_op.proj_*): not with the
+        # emulated-fp32 conv products (their weights are packed as bf16 planes), and A3D_FUSE_PROJ=0 keeps the separate
+        # 1x1 launches (tests compare the two)
+        fuse_proj = (os.environ.get("A3D_FUSE_PROJ", "1") != "0" and os.environ.get("A3D_CONV_EMU", "0") == "0"
+                     if fuse_proj is None else fuse_proj)
+        self.fused_projections = 0
+
+        def pack(conv, w=None):
+            w = (conv.kernel3().detach() if w is None else w).to(dev, torch.float32).contiguous()
             K, cin, cout = w.shape
             out = torch.empty(lib.a3d_conv_weight_packed_floats(K, cin, cout), dtype=torch.float32, device=dev)
             L.check(lib.a3d_pack_conv_weight(_ptr(w), K, cin, cout, _ptr(out), _stream()), "a3d_pack_conv_weight")
@@ -131,7 +139,7 @@ class BackboneProgram:
             self.keep += [scale, shift]
             return scale, shift
 
-        def op(kind, level_in, cin, cout, src, dst, res, relu, kvol, w, scale, shift):
+        def op(kind, level_in, cin, cout, src, dst, res, relu, kvol, w, scale, shift, proj=None):
             o = L.Op()
             o.kind, o.level_in, o.cin, o.cout = kind, level_in, cin, cout
             o.in_buf, o.in_coff = src
@@ -141,6 +149,8 @@ class BackboneProgram:
             o.w_dev = w.data_ptr()
             o.scale_dev = scale.data_ptr() if scale is not None else None
             o.shift_dev = shift.data_ptr() if shift is not None else None
+            if proj is not None:
+                (o.proj_buf, o.proj_coff), o.proj_cin = proj[0], proj[1]
             self.ops.append(o)
 
         def basic_block(blk, level, src, cin, cout, dst):
@@ -149,6 +159,21 @@ class BackboneProgram:
             s1, h1 = fold(blk.norm1)
             op(L.OP_CONV3, level, cin, cout, src, (tmp, 0), None, True, 27, pack(blk.conv1), s1, h1)
             res, proj = src, None
+            if blk.downsample is not None and fuse_proj and cin % 64 == 0:
+                # out = relu(s2 conv2(h) + h2 + sp (x Wp) + hp): both scales into the weights, one accumulator, one launch.
+                # (cin % 64: the kernel's stage width at these shapes is 32 or 64 channels -- the 32 -> 64 block of level 2
+                # keeps its own 1x1 launch)
+                s2, h2 = fold(blk.norm2)
+                sp, hp = fold(blk.downsample[1])
+                w2 = blk.conv2.kernel3().detach().to(dev, torch.float32) * s2[None, None, :]
+                wp = blk.downsample[0].kernel3().detach().to(dev, torch.float32) * sp[None, None, :]
+                both = torch.cat([pack(None, w2), pack(None, wp)]).contiguous()
+                shift = (h2 + hp).contiguous()
+                self.keep += [both, shift]
+                op(L.OP_CONV3, level, cout, cout, (tmp, 0), dst, None, True, 27, both, None, shift, proj=(src, cin))
+                self.fused_projections += 1
+                self.pool.put(tmp)
+                return
             if blk.downsample is not None:
                 proj = self.pool.get(level, cout)
                 sp, hp = fold(blk.downsample[1])

@@ -64,7 +64,8 @@ def algorithmic_flops(entry, pairs):
         p = pairs["n"][entry.level - 1]        # every fine voxel receives once
     else:
         p = entry.n_out
-    return 2.0 * p * entry.cin * entry.cout
+    # a fused residual projection (a3d_op.proj_cin, reported in the bits above the kernel volume): one more product per row
+    return 2.0 * p * entry.cin * entry.cout + 2.0 * entry.n_out * (entry.kernel_volume >> 8) * entry.cout
 
 
 def algorithmic_bytes(entry, pairs):
@@ -80,7 +81,8 @@ def algorithmic_bytes(entry, pairs):
         n_in, p = pairs["n"][entry.level], pairs["n"][entry.level - 1]
     else:
         n_in, p = n_out, 0
-    return 4.0 * (n_in * entry.cin + n_out * entry.cout + entry.kernel_volume * entry.cin * entry.cout) + 8.0 * p
+    kv, cin2 = entry.kernel_volume & 0xff, entry.kernel_volume >> 8
+    return 4.0 * (n_in * entry.cin + n_out * (entry.cout + cin2) + (kv * entry.cin + cin2) * entry.cout) + 8.0 * p
 
 
 def workload_key(voxels, batch, queries):

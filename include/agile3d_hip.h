@@ -152,6 +152,12 @@ typedef struct {
   const float* w_dev;          /* weights packed by a3d_pack_conv_weight (STEM: raw [K][3][32]) */
   const float* scale_dev;      /* [cout] folded BatchNorm scale, or NULL (=1)                   */
   const float* shift_dev;      /* [cout] folded BatchNorm shift / bias, or NULL (=0)            */
+  /* CONV3 only, proj_cin > 0: the block's residual projection fused into this conv (BasicBlock.downsample: 1x1 conv +
+   * BatchNorm on the BLOCK INPUT, resnet_block.py:59-61; models/resnet.py:108-123) -- out = act(conv3(in) + proj_in W1x1 +
+   * shift).  w_dev then holds the 27 offsets' packed weights followed by the packed 1x1 weight [proj_cin][cout], BOTH with
+   * their BatchNorm scale already multiplied in (scale_dev = NULL), shift_dev the sum of the two shifts; proj_in = columns
+   * [proj_coff, proj_coff + proj_cin) of buffer proj_buf (same level).  proj_cin = 0: no projection. */
+  int32_t proj_buf, proj_coff, proj_cin, reserved_;
 } a3d_op;
 
 /* W[K][cin][cout] (ME layout, models/modules/common.py:137-155) -> MFMA B-fragment order */

@@ -58,6 +58,31 @@ def test_forward_backbone_matches_oracle(model_and_sd, n, seed):
         assert e <= TOL * max(1.0, ref["feature_maps"][i].abs().max().item()), (i, e)
 
 
+@pytest.mark.parametrize("n,batch", [(3000, 1), (20000, 2)])
+def test_fused_residual_projections_equal_the_separate_launches(model_and_sd, n, batch):
+    """The BasicBlock downsample projections run inside the blocks' second convs (a3d_op.proj_*: one more "offset" with the
+    block input as its source, both BatchNorm scales folded into the packed weights).  Against the program with separate
+    1x1 launches (BackboneProgram(fuse_proj=False)): every feature map and the output, to rounding (the scale is applied
+    to the weights instead of to the sum)."""
+    from agile3d_amd.engine import BackboneProgram
+    model, _ = model_and_sd
+    eng = model._get_engine()
+    scs = [make_scene(n, seed=10 + b, batch_index=b) for b in range(batch)]
+    sc = {k: np.concatenate([s_[k] for s_ in scs]) for k in ("coords", "feats", "raw_xyz")}
+    outs = []
+    for fuse in (True, False):
+        eng.refresh_weights_if_stale()
+        with torch.no_grad():
+            eng.program = BackboneProgram(model, eng.device, fuse_proj=fuse)
+        assert eng.program.fused_projections == (6 if fuse else 0)
+        pcd, aux, _, _ = _run_backbone(model, sc)
+        outs.append([pcd.F.clone()] + [a.F.clone() for a in aux])
+    eng.mark_stale()
+    for a, b in zip(*outs):
+        scale = max(1.0, b.abs().max().item())
+        assert (a - b).abs().max().item() <= 2e-5 * scale, (a - b).abs().max().item()
+
+
 def test_forward_mask_matches_oracle_end_to_end(model_and_sd):
     model, sd = model_and_sd
     sc = make_scene(4000, seed=3)
