@@ -22,7 +22,7 @@ rocprofv3 --pmc FETCH_SIZE --kernel-trace -d /tmp/$TAG/pmc_fetch -o p -- $PMC > 
 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d /tmp/$TAG/pmc_write -o p -- $PMC > /dev/null 2> $OUT/pmc_write.err
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_LDS_BANK_CONFLICT SQ_WAVE_CYCLES --kernel-trace -d /tmp/$TAG/pmc_sq -o p -- $PMC > /dev/null 2> $OUT/pmc_sq.err
 PMC_JSON=$OUT/pmc_raw.json python $R/tools/rocprof_summary.py /tmp/$TAG/pmc_fetch /tmp/$TAG/pmc_write /tmp/$TAG/pmc_sq > $OUT/pmc_counters.txt 2>&1
-python $R/tools/pmc_to_summary.py $OUT/pmc_raw.json $OUT/pmc_summary.json 80k_b16_q20
+python $R/tools/pmc_to_summary.py $OUT/pmc_raw.json $OUT/pmc_summary.json 80k_b16_q20 $OUT/kernel_trace_stats_steps_only.txt
 # the same passes on BASELINE.json config 5 (one 300 k-voxel scene, 20 clicks): its own tables in the two JSON files
 C5="--voxels 300000 --clicks-per-object 4 --batch 1"
 rocprofv3 --kernel-trace --stats -d /tmp/$TAG/trace5 -o t -- python $R/bench.py --steps-only --streams 1 $C5 > $OUT/bench_under_rocprof_steps_only_config5.json 2> $OUT/trace5.err
@@ -33,7 +33,7 @@ rocprofv3 --pmc FETCH_SIZE --kernel-trace -d /tmp/$TAG/pmc5_fetch -o p -- $PMC5 
 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d /tmp/$TAG/pmc5_write -o p -- $PMC5 > /dev/null 2> $OUT/pmc5_write.err
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_LDS_BANK_CONFLICT SQ_WAVE_CYCLES --kernel-trace -d /tmp/$TAG/pmc5_sq -o p -- $PMC5 > /dev/null 2> $OUT/pmc5_sq.err
 PMC_JSON=$OUT/pmc_raw_config5.json python $R/tools/rocprof_summary.py /tmp/$TAG/pmc5_fetch /tmp/$TAG/pmc5_write /tmp/$TAG/pmc5_sq > $OUT/pmc_counters_config5.txt 2>&1
-python $R/tools/pmc_to_summary.py $OUT/pmc_raw_config5.json $OUT/pmc_summary.json 300k_b1_q30
+python $R/tools/pmc_to_summary.py $OUT/pmc_raw_config5.json $OUT/pmc_summary.json 300k_b1_q30 $OUT/kernel_trace_stats_steps_only_config5.txt
 cp $OUT/kernel_avg_us.json $OUT/pmc_summary.json $R/profiles/      # so that the config-5 line below reads ITS tables
 # BASELINE.json config 5 (KITTI-like 300 k voxels, 20 clicks): its own bench line and per-launch table
 # (four steps in flight like the headline; 40 steps per repetition: with 10 the fill and drain of the four streams are a tenth of the region)
