@@ -2288,6 +2288,23 @@ static int check_weights(const a3d_decoder_weights* w) {
   return A3D_OK;
 }
 
+// the query-side packs are required by every forward path: refused BEFORE anything is enqueued into the caller's workspace
+// and logits buffers (the per-layer check inside the launch loop only fires after layer 0's kernels are in flight)
+static int check_packs(const a3d_decoder_weights* w) {
+  if (!w->mask_pack) {
+    set_error("a3d_decoder_forward: the decoder weights carry no mask-head pack (a3d_decoder_pack_query_weights fills "
+              "a3d_decoder_layer::query_pack and a3d_decoder_weights::mask_pack)");
+    return A3D_ERR_INVALID;
+  }
+  for (int l = 0; l < w->n_layers; ++l)
+    if (!w->layers[l].query_pack) {
+      set_error("a3d_decoder_forward: decoder layer %d carries no query-side pack (a3d_decoder_pack_query_weights fills "
+                "a3d_decoder_layer::query_pack and a3d_decoder_weights::mask_pack)", l);
+      return A3D_ERR_INVALID;
+    }
+  return A3D_OK;
+}
+
 namespace {
 struct DecLayout {
   size_t buf[4], labels, counts, part, meta, desc, q[12], sync, total;
@@ -2815,6 +2832,8 @@ static int dispatch_decoder(const a3d_decoder_weights* w, Prepared* P, int ns, h
 extern "C" int a3d_decoder_forward_batch(const a3d_decoder_weights* w, const a3d_decoder_sample* samples, int n_samples,
                                          void* stream) {
   int rc = check_weights(w);
+  if (rc) return rc;
+  rc = check_packs(w);
   if (rc) return rc;
   if (!samples || n_samples < 1 || n_samples > 1024) {
     set_error("a3d_decoder_forward_batch: bad arguments");

@@ -89,7 +89,20 @@ struct SkArgs {
   int prio;              // 1: static wave priority by occupancy layer (ticket / 256), see the kernel
   int nchunk2;           // FUSE: stages of the fused 1x1 projection per tile (cin2 / CH), run as offset 27 after the tile's own
   unsigned in2_row_bytes;
+  // STATS (training-mode BatchNorm): per 64-row tile and output column the sum of the tile's rows and the sum of their
+  // squared deviations from the TILE mean, [n_tiles][2][stats_ld] -- what k_bn_combine merges into the batch statistics
+  float* stats;
+  int stats_ld;
 };
+
+// sum over the 16 lanes that share lane >> 4 (the 16 rows of an MFMA group), result in every lane; fixed order
+__device__ __forceinline__ float row16_sum(float v) {
+  v += __shfl_xor(v, 1, 16);
+  v += __shfl_xor(v, 2, 16);
+  v += __shfl_xor(v, 4, 16);
+  v += __shfl_xor(v, 8, 16);
+  return v;
+}
 
 __device__ __forceinline__ void store_sc1(float* p, f32x4 v) {   // write-through (agent scope) 16-byte store
   asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
@@ -125,7 +138,9 @@ __device__ __forceinline__ void wait_all_vmem() { __builtin_amdgcn_s_waitcnt(0x0
 // gather the output rows themselves from the block input and multiply them with the 1x1 weight (both BatchNorm scales
 // folded into the packed weights by the host, the two shifts added).  Same stage loop, same hand-offs; a separate
 // instantiation, so the plain kernels are untouched.
-template <int BN, int CH, int PAIR, bool FUSE = false>
+// STATS: the owner's epilogue also writes the tile's BatchNorm partial statistics (training path; a separate instantiation,
+// the inference kernels are untouched).
+template <int BN, int CH, int PAIR, bool FUSE = false, bool STATS = false>
 __global__ void __launch_bounds__(256, PAIR ? ((BN <= 96 && CH <= 32) ? 4 : 3) : ((BN <= 96 && CH <= 48) ? 3 : 2))
     k_conv_sk(const SkArgs a) {
   static_assert(!FUSE || PAIR != 2, "the fused projection runs on the exact-fp32 builds");
@@ -513,6 +528,48 @@ __global__ void __launch_bounds__(256, PAIR ? ((BN <= 96 && CH <= 32) ? 4 : 3) :
             for (int ct = 0; ct < NCT; ++ct) acc[0][ct] += pa[u][ct];
         }
       }
+      if constexpr (STATS) {
+        // BatchNorm statistics of the RAW output (before scale / shift / residual / ReLU, which the training path does
+        // not pass): column sums over the tile's valid rows, then the squared deviations from the tile mean -- wave-level
+        // shuffles over the 16 rows of a group, the four waves through LDS behind the weight ring, fixed orders
+        float* sst = (float*)(misc + 16);   // [2][4][BN]
+        const bool valid = r0 + wrow < a.c.n_out;
+        f32x4 sv[NCT];
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct) {
+          sv[ct] = valid ? acc[0][ct] : (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int tt = 0; tt < 4; ++tt) sv[ct][tt] = row16_sum(sv[ct][tt]);
+        }
+        if (j == 0) {
+#pragma unroll
+          for (int ct = 0; ct < NCT; ++ct) *(f32x4*)(sst + wave * BN + ct * 16 + 4 * g) = sv[ct];
+        }
+        __syncthreads();
+        const int cnt = min(kTile, a.c.n_out - r0);
+        const float inv = 1.f / (float)cnt;
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct) {
+          const float* sp = sst + ct * 16 + 4 * g;
+          const f32x4 tot = ((*(const f32x4*)sp + *(const f32x4*)(sp + BN)) + *(const f32x4*)(sp + 2 * BN)) + *(const f32x4*)(sp + 3 * BN);
+          const f32x4 d = valid ? acc[0][ct] - tot * inv : (f32x4){0.f, 0.f, 0.f, 0.f};
+          sv[ct] = d * d;
+#pragma unroll
+          for (int tt = 0; tt < 4; ++tt) sv[ct][tt] = row16_sum(sv[ct][tt]);
+        }
+        if (j == 0) {
+#pragma unroll
+          for (int ct = 0; ct < NCT; ++ct) *(f32x4*)(sst + 4 * BN + wave * BN + ct * 16 + 4 * g) = sv[ct];
+        }
+        __syncthreads();
+        if (tid < BN) {
+          const float* s1p = sst + tid;
+          const float* s2p = sst + 4 * BN + tid;
+          float* P = a.stats + (size_t)t * 2 * a.stats_ld + cb * BN + tid;
+          P[0] = ((s1p[0] + s1p[BN]) + s1p[2 * BN]) + s1p[3 * BN];
+          P[a.stats_ld] = ((s2p[0] + s2p[BN]) + s2p[2 * BN]) + s2p[3 * BN];
+        }
+      }
 #pragma unroll
       for (int r = 0; r < RG; ++r) {
         const int myrow = r0 + wrow + 16 * r;
@@ -553,8 +610,10 @@ __global__ void __launch_bounds__(256, PAIR ? ((BN <= 96 && CH <= 32) ? 4 : 3) :
 // groups); per (group, present offset): one neighbour-index load two pairs ahead, the gathered A fragments one pair
 // ahead, NS NCT ds_read_b128 + 4 NS NCT MFMAs.  Same summation order per output element as k_conv_sk run without
 // hand-offs (offsets ascending, channels ascending), so results are bit-identical to it.
-template <int NS, int NCT>
-__global__ void __launch_bounds__(1024) k_conv_wl(const ConvArgs c, int ngroups) {
+// STATS (training): every finished 16-row group also writes its BatchNorm partials (column sums, squared deviations from
+// the GROUP mean) to stats[group][2][stats_ld] -- a group belongs to one wave, so this needs no LDS and no barrier.
+template <int NS, int NCT, bool STATS = false>
+__global__ void __launch_bounds__(1024) k_conv_wl(const ConvArgs c, int ngroups, float* stats = nullptr, int stats_ld = 0) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   f32x4* Wl = (f32x4*)smem;   // [K][NS][NCT][64]
   const int tid = threadIdx.x, lane = tid & 63;
@@ -648,6 +707,25 @@ __global__ void __launch_bounds__(1024) k_conv_wl(const ConvArgs c, int ngroups)
     }
     if (!v1 || g1 != g0) {   // last offset of group g0: epilogue (as k_conv_sk's)
       const int myrow = g0 * 16 + j;
+      if constexpr (STATS) {
+        const bool valid = myrow < c.n_out;
+        const float inv = 1.f / (float)min(16, c.n_out - g0 * 16);
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct) {
+          f32x4 sv = valid ? acc[ct] : (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int tt = 0; tt < 4; ++tt) sv[tt] = row16_sum(sv[tt]);
+          f32x4 d = valid ? acc[ct] - sv * inv : (f32x4){0.f, 0.f, 0.f, 0.f};
+          d = d * d;
+#pragma unroll
+          for (int tt = 0; tt < 4; ++tt) d[tt] = row16_sum(d[tt]);
+          if (j == 0) {
+            float* P = stats + (size_t)g0 * 2 * stats_ld + ct * 16 + 4 * g;
+            *(f32x4*)P = sv;
+            *(f32x4*)(P + stats_ld) = d;
+          }
+        }
+      }
       if (myrow < c.n_out) {
         const int orow = c.out_map ? c.out_map[myrow] : myrow;
         float* po = c.out + (size_t)orow * c.ldo + 4 * g;
@@ -687,7 +765,7 @@ static bool conv_wl_supported(const ConvArgs& c) {
   return (size_t)c.K * c.cin * c.cout * 4 <= 144 * 1024;
 }
 
-static int launch_conv_wl(const ConvArgs& c, hipStream_t st) {
+static int launch_conv_wl(const ConvArgs& c, hipStream_t st, float* stats = nullptr, int stats_ld = 0) {
   const int ngroups = (c.n_out + 15) / 16;
   const size_t lds = (size_t)c.K * c.cin * c.cout * 4;
   // one workgroup per CU; 16 waves when there are groups for them, never fewer than 4
@@ -696,7 +774,13 @@ static int launch_conv_wl(const ConvArgs& c, hipStream_t st) {
   if ((long long)grid * nw > ngroups) grid = (ngroups + nw - 1) / nw;
   if (grid < 1) grid = 1;
   ProfScope ps(st, A3D_PROF_SPCONV, c.cout, c.K, c.cin, c.cout, c.n_out, c.tag_table, c.tag_level, 0);   // stage width 0: k_conv_wl
-  if (c.cin == 32) k_conv_wl<2, 2><<<grid, 64 * nw, lds, st>>>(c, ngroups);
+  if (stats) {
+    if (c.cin != 32) {
+      set_error("spconv: no statistics build of the 64-channel LDS-resident kernel");
+      return A3D_ERR_UNSUPPORTED;
+    }
+    k_conv_wl<2, 2, true><<<grid, 64 * nw, lds, st>>>(c, ngroups, stats, stats_ld);
+  } else if (c.cin == 32) k_conv_wl<2, 2><<<grid, 64 * nw, lds, st>>>(c, ngroups);
   else k_conv_wl<4, 4><<<grid, 64 * nw, lds, st>>>(c, ngroups);
   A3D_LAUNCH_CHECK();
   return A3D_OK;
@@ -1209,7 +1293,9 @@ static void allow_big_lds() {
   done = true;
 #define A3D_BIG3(BN_, CH_) \
   A3D_ALLOW_LDS(160 * 1024, k_conv_sk<BN_, CH_, 0>); \
-  A3D_ALLOW_LDS(160 * 1024, k_conv_sk<BN_, CH_, 1>);
+  A3D_ALLOW_LDS(160 * 1024, k_conv_sk<BN_, CH_, 1>); \
+  A3D_ALLOW_LDS(160 * 1024, (k_conv_sk<BN_, CH_, 0, false, true>)); \
+  A3D_ALLOW_LDS(160 * 1024, (k_conv_sk<BN_, CH_, 1, false, true>));
   A3D_BIG3(32, 32) A3D_BIG3(32, 64) A3D_BIG3(32, 96) A3D_BIG3(64, 32) A3D_BIG3(64, 64) A3D_BIG3(64, 96)
   A3D_BIG3(96, 32) A3D_BIG3(96, 48) A3D_BIG3(96, 64) A3D_BIG3(96, 96) A3D_BIG3(128, 32) A3D_BIG3(128, 64)
 #undef A3D_BIG3
@@ -1224,6 +1310,7 @@ static void allow_big_lds() {
   A3D_ALLOW_LDS(160 * 1024, k_conv_sk<32, 32, 2>);
   A3D_ALLOW_LDS(160 * 1024, k_conv_wl<2, 2>);
   A3D_ALLOW_LDS(160 * 1024, k_conv_wl<4, 4>);
+  A3D_ALLOW_LDS(160 * 1024, (k_conv_wl<2, 2, true>));
   A3D_ALLOW_LDS(160 * 1024, (k_dense<8, 8, false>));
   A3D_ALLOW_LDS(160 * 1024, (k_dense<8, 6, false>));
   A3D_ALLOW_LDS(160 * 1024, (k_dense<6, 8, false>));
@@ -1234,9 +1321,24 @@ static void allow_big_lds() {
   A3D_ALLOW_LDS(160 * 1024, (k_dense<6, 6, true>));
 }
 
+// does a fused-projection build of k_conv_sk exist for what plan_sk picks at this row count?  (the stage width and the
+// column block depend on the rows; a3d_program_run falls back to conv + separate 1x1 launch when not)
+static bool sk_fused_ok(int n_rows, int cin, int cout, int cin2) {
+  if (cin % 32 != 0 || cout % 16 != 0 || !(cout % 128 == 0 || cout == 32 || cout == 64 || cout == 96)) return false;
+  const SkPlan p = plan_sk(n_rows, 27, cin, cout, true);
+  if (!p.ch || p.pair == 2 || cin2 <= 0 || cin2 % p.ch != 0) return false;
+  return (p.bn == 64 && (p.ch == 32 || p.ch == 64)) || (p.bn == 96 && p.ch == 32) || (p.bn == 128 && p.ch == 32);
+}
+
+// stats != nullptr (training): the kernel's epilogue also writes BatchNorm partials, [blocks][2][stats_ld] with
+// *stats_rows rows per block (64: k_conv_sk tiles, 16: the groups of k_conv_wl); the op must carry no scale / shift / residual
 static int launch_conv_sk(ConvArgs c, const int* pre64, float* slab_ws, size_t slab_ws_floats, int* state,
-                          hipStream_t st) {
+                          hipStream_t st, float* stats = nullptr, int stats_ld = 0, int* stats_rows = nullptr) {
   allow_big_lds();
+  if (stats && (c.scale || c.shift || c.relu || c.cin2 > 0 || conv_emu(c.K, c.cin, c.cout) || !stats_rows)) {
+    set_error("spconv: BatchNorm statistics are taken of a raw convolution (no epilogue, no fused projection, exact fp32)");
+    return A3D_ERR_UNSUPPORTED;
+  }
   if (c.cin % 32 != 0 || c.cout % 16 != 0 || !(c.cout % 128 == 0 || c.cout == 32 || c.cout == 64 || c.cout == 96)) {
     set_error("spconv: unsupported channels cin=%d cout=%d", c.cin, c.cout);
     return A3D_ERR_UNSUPPORTED;
@@ -1249,7 +1351,10 @@ static int launch_conv_sk(ConvArgs c, const int* pre64, float* slab_ws, size_t s
     set_error("spconv: input of %d rows x %d floats exceeds the 4 GB gather window", c.n_in, c.ldi);
     return A3D_ERR_UNSUPPORTED;
   }
-  if (c.cin2 == 0 && conv_wl_supported(c) && !conv_emu(c.K, c.cin, c.cout)) return launch_conv_wl(c, st);
+  if (c.cin2 == 0 && conv_wl_supported(c) && !conv_emu(c.K, c.cin, c.cout)) {
+    if (stats) *stats_rows = 16;
+    return launch_conv_wl(c, st, stats, stats_ld);
+  }
   // hand-offs (shares cut inside tiles) pay where a tile is long and tiles are few: the 3^3 maps, and the 2^3 maps of
   // the small levels.  1x1 layers and 2^3 maps with a tile per workgroup slot or more run whole tiles: no ticket, no
   // search, no flags -- their fixed latency is what matters
@@ -1311,6 +1416,20 @@ static int launch_conv_sk(ConvArgs c, const int* pre64, float* slab_ws, size_t s
     else if (p.bn == 128) k_conv_sk<128, 32, 2><<<p.G, 256, p.lds, st>>>(a);
     else if (p.bn == 64) k_conv_sk<64, 32, 2><<<p.G, 256, p.lds, st>>>(a);
     else k_conv_sk<32, 32, 2><<<p.G, 256, p.lds, st>>>(a);
+    A3D_LAUNCH_CHECK();
+    return A3D_OK;
+  }
+  if (stats) {
+    a.stats = stats;
+    a.stats_ld = stats_ld;
+    *stats_rows = 64;
+    const size_t lds_s = p.lds + (size_t)2 * 4 * p.bn * 4;
+#define A3D_LS(BN_, CH_) \
+  if (p.bn == BN_ && p.ch == CH_) { if (p.pair) k_conv_sk<BN_, CH_, 1, false, true><<<p.G, 256, lds_s, st>>>(a); else k_conv_sk<BN_, CH_, 0, false, true><<<p.G, 256, lds_s, st>>>(a); } else
+    A3D_LS(32, 32) A3D_LS(32, 64) A3D_LS(32, 96) A3D_LS(64, 32) A3D_LS(64, 64) A3D_LS(64, 96)
+    A3D_LS(96, 32) A3D_LS(96, 48) A3D_LS(96, 64) A3D_LS(96, 96) A3D_LS(128, 32) A3D_LS(128, 64)
+    { set_error("spconv: no kernel for BN %d CH %d", p.bn, p.ch); return A3D_ERR_UNSUPPORTED; }
+#undef A3D_LS
     A3D_LAUNCH_CHECK();
     return A3D_OK;
   }
@@ -1605,6 +1724,27 @@ extern "C" int a3d_program_run(const a3d_scene* s, const a3d_buf_desc* bufs, int
       default:
         set_error("op %d: unknown kind %d", i, o.kind);
         return A3D_ERR_INVALID;
+    }
+    if (a.cin2 > 0 && !sk_fused_ok(a.n_out, a.cin, a.cout, a.cin2)) {
+      // no fused build for this (row count, shape): the same arithmetic as two launches on the same packed weights --
+      // the 27 offsets into `out` without the ReLU, then the 1x1 slice (packed right behind them) added in place
+      ConvArgs c1 = a;
+      c1.in2 = nullptr, c1.cin2 = 0, c1.ldi2 = 0, c1.relu = 0;
+      rc = launch_conv_sk(c1, pre, partial, L.partial_floats, queues + (size_t)i * kMaxQueuesPerOp, st);
+      if (rc != A3D_OK) return rc;
+      if (conv_emu(27, a.cin, a.cout) || a.out_map) {
+        set_error("op %d: fused projection has no fallback in the emulated-fp32 build", i);
+        return A3D_ERR_UNSUPPORTED;
+      }
+      ConvArgs c2;
+      memset(&c2, 0, sizeof(c2));
+      c2.in = a.in2, c2.ldi = a.ldi2, c2.n_in = a.n_out, c2.K = 1, c2.cin = a.cin2, c2.cout = a.cout;
+      c2.w = a.w + (size_t)27 * a.cin * a.cout;
+      c2.out = a.out, c2.ldo = a.ldo, c2.n_out = a.n_out, c2.res = a.out, c2.ldr = a.ldo, c2.relu = a.relu;
+      c2.zero_row = a.zero_row, c2.tag_table = A3D_OP_LINEAR, c2.tag_level = Lin;
+      rc = launch_conv_sk(c2, nullptr, nullptr, 0, nullptr, st);
+      if (rc != A3D_OK) return rc;
+      continue;
     }
     if (o.kind == A3D_OP_LINEAR && dense_supported(a.cin, a.cout) && a.n_out >= 4096)
       rc = launch_dense(a.in, a.ldi, nullptr, 0, a.n_out, a.cin, a.cout, a.w, a.scale, a.shift, a.res, a.ldr, a.relu,

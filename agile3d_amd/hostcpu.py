@@ -50,6 +50,36 @@ def cpu_quota() -> float:
     return max(n, 1.0)
 
 
+def cpu_throttle_stats() -> dict:
+    """The cgroup's CFS counters of this process (cgroup v2 ``cpu.stat``, v1 ``cpu/cpu.stat``): {'nr_periods', 'nr_throttled',
+    'throttled_usec', 'usage_usec'} -- whatever the file has; {} when it cannot be read.  ``nr_throttled`` moving during a
+    timed region means the kernel froze every thread of the process (the launch thread included) for the rest of a period:
+    the failure an over-subscribed multi-rank run meets first (bench.py prints the difference around its timed region)."""
+    out = {}
+    paths = []
+    try:
+        rel = "/"
+        for line in open("/proc/self/cgroup"):
+            parts = line.strip().split(":", 2)
+            if len(parts) == 3 and parts[0] == "0":
+                rel = parts[2]
+        paths.append(os.path.normpath("/sys/fs/cgroup/" + rel + "/cpu.stat"))
+    except OSError:
+        pass
+    paths += ["/sys/fs/cgroup/cpu.stat", "/sys/fs/cgroup/cpu/cpu.stat"]
+    for f in paths:
+        try:
+            for line in open(f):
+                k, _, v = line.strip().partition(" ")
+                if k in ("nr_periods", "nr_throttled", "throttled_usec", "throttled_time", "usage_usec"):
+                    out[k] = int(v)
+            if out:
+                return out
+        except (OSError, ValueError):
+            continue
+    return out
+
+
 def cap_host_threads() -> int:
     """torch's intra-op CPU threads = at most HALF this process's share of the quota (the launch thread, the HIP runtime's
     helpers and the other streams' launch threads need the rest; the ranks of a node -- LOCAL_WORLD_SIZE, set by
@@ -59,11 +89,20 @@ def cap_host_threads() -> int:
     forced = os.environ.get("A3D_HOST_THREADS")
     cur = torch.get_num_threads()
     if forced is not None:
-        want = int(forced)
+        try:
+            want = int(forced)
+        except ValueError:       # a malformed value must not make `import agile3d_amd` raise: say so, fall back to the policy
+            import warnings
+            warnings.warn(f"agile3d_amd: A3D_HOST_THREADS={forced!r} is not an integer; using the quota-based default")
+            forced = None
+    if forced is not None:
         if want <= 0:
             return cur
-    else:
-        ranks = max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1") or 1))
+    if forced is None:
+        try:
+            ranks = max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1") or 1))
+        except ValueError:
+            ranks = 1
         want = min(cur, max(1, int(math.floor(cpu_quota() / (2 * ranks)))))
     if want != cur:
         torch.set_num_threads(want)

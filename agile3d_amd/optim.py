@@ -180,15 +180,37 @@ class OverlappedAllReduce:
     memory and reduced by gloo's thread.  Results do not depend on the bucket layout for two ranks (a sum of two
     numbers has one order); for more ranks a ring's order per element follows the layout, like any bucketed DDP."""
 
-    _bucket_groups = {}      # parent group -> the communicator the buckets travel on (created once, collectively)
-    _checked = set()         # (group, key-list digest) pairs every rank has already agreed on
+    _bucket_groups = {}      # id(parent group object) -> (parent group object, the communicator the buckets travel on)
+
+    @classmethod
+    def _bucket_group(cls, parent):
+        """The buckets' own communicator for the LIVE process group ``parent`` (created once per group, collectively, with the
+        parent's backend).  Entries are keyed on the group object itself -- a strong reference is kept, so an id cannot be
+        reused while its entry exists -- and entries whose parent is no longer registered with torch.distributed (after
+        ``destroy_process_group()`` + ``init_process_group()`` in one process: tests, notebooks) are dropped, so a stale
+        communicator is never handed out."""
+        import torch.distributed as dist
+        try:
+            live = dist.distributed_c10d._world.pg_map
+            for k in [k for k, (pg, _) in cls._bucket_groups.items() if pg not in live]:
+                del cls._bucket_groups[k]
+        except Exception:                    # private API moved: fall back to "the default group changed -> forget everything"
+            if any(pg is not parent for pg, _ in cls._bucket_groups.values()):
+                cls._bucket_groups.clear()
+        hit = cls._bucket_groups.get(id(parent))
+        if hit is None or hit[0] is not parent:
+            sub = dist.new_group(ranks=dist.get_process_group_ranks(parent), backend=dist.get_backend(parent))
+            hit = cls._bucket_groups[id(parent)] = (parent, sub)
+        return hit[1]
 
     def __init__(self, group=None, bucket_bytes: int = 32 << 20, expected=None, single_rank: bool = False):
         """``expected``: {name: numel} of every gradient this iteration will hand over (the same on every rank: the
-        bucket layout follows the order of ``add`` calls).  Its digest is all-gathered ONCE per process group, so ranks
-        that disagree fail with an error instead of hanging inside a mis-sized collective; ``add`` refuses unknown
-        names and ``finish`` refuses to wait when one is missing.  ``single_rank``: run the collectives even in a
-        world of one rank (exercises the RCCL path -- communicator, its stream, ordering -- on a single-GPU box)."""
+        bucket layout follows the order of ``add`` calls).  A 63-bit digest of it is compared over the ranks by ONE small
+        all-reduce per reducer -- every rank runs it every time, whatever it has seen before, so a rank whose list changed
+        cannot enter a collective alone -- and ranks that disagree fail with an error instead of hanging inside a mis-sized
+        bucket; ``add`` refuses unknown names and ``finish`` refuses to wait when one is missing.  ``single_rank``: run the
+        collectives even in a world of one rank (exercises the RCCL path -- communicator, its stream, ordering -- on a
+        single-GPU box)."""
         import torch.distributed as dist
         self.bucket_bytes = bucket_bytes
         up = dist.is_available() and dist.is_initialized()
@@ -198,26 +220,25 @@ class OverlappedAllReduce:
         self.group = group
         self.expected = dict(expected) if expected is not None else None
         self.seen = set()
-        self.gloo = self.active and dist.get_backend(group) == "gloo"
+        self.gloo = False
         self.pending, self.pending_bytes, self.flights = [], 0, []
         if self.active:
+            parent = group if group is not None else dist.distributed_c10d._get_default_group()
             # the buckets get their own communicator: SyncBN's blocking all-reduces of the next iteration's forward (and
             # any other collective of the default group) then do not queue behind them on one RCCL stream
-            key = id(group) if group is not None else None
-            if key not in OverlappedAllReduce._bucket_groups:
-                OverlappedAllReduce._bucket_groups[key] = dist.new_group(ranks=dist.get_process_group_ranks(group)
-                                                                         if group is not None else None)
-            self.group = OverlappedAllReduce._bucket_groups[key]
+            self.group = OverlappedAllReduce._bucket_group(parent)
+            self.gloo = dist.get_backend(self.group) == "gloo"      # staging follows the communicator the buckets really use
             if self.expected is not None:
                 import hashlib
-                digest = hashlib.sha256(repr(sorted(self.expected.items())).encode()).hexdigest()
-                if (key, digest) not in OverlappedAllReduce._checked:
-                    got = [None] * self.world
-                    dist.all_gather_object(got, digest, group=group)
-                    if any(d != digest for d in got):
-                        raise RuntimeError("OverlappedAllReduce: the ranks disagree on the list of gradients "
-                                           f"(digests {sorted(set(got))}); every rank must hand over the same tensors")
-                    OverlappedAllReduce._checked.add((key, digest))
+                h = int.from_bytes(hashlib.sha256(repr(sorted(self.expected.items())).encode()).digest()[:8], "big") >> 1
+                dev = "cpu" if self.gloo else torch.device("cuda", torch.cuda.current_device())
+                t = torch.tensor([h, -h], dtype=torch.int64, device=dev)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)       # [max h, -min h]
+                hi, neg_lo = (int(v) for v in t.tolist())
+                if hi != h or -neg_lo != h:
+                    raise RuntimeError("OverlappedAllReduce: the ranks disagree on the list of gradients (digest of this "
+                                       f"rank {h:x}, over the ranks {-neg_lo:x}..{hi:x}); every rank must hand over the "
+                                       "same tensors")
 
     def add(self, name, g):
         if not self.active:

@@ -50,8 +50,17 @@ def _train_one_step(model, criterion, optimizer, batch, device, max_norm):
     def mark(name):
         if timing:
             torch.cuda.synchronize()
+            if timing == "mark":              # one marker dispatch per phase boundary (tools/train_phase_trace.py splits a trace there)
+                torch.cuda._sleep(1)
+                torch.cuda.synchronize()
             marks.append((name, time.perf_counter()))
     mark("start")
+    # the gradient reducer (one small blocking digest all-reduce over the ranks) is made HERE, where the device is idle
+    # anyway, not between the decoder's and the backbone's backward where the host would stall behind the queue
+    from .optim import OverlappedAllReduce
+    reducer = OverlappedAllReduce(bucket_bytes=int(float(os.environ.get("A3D_DP_BUCKET_MB", "32")) * (1 << 20)),
+                                  expected={k: p.numel() for k, p in model.named_parameters() if p.requires_grad},
+                                  single_rank=os.environ.get("A3D_DP_SINGLE_RANK", "0") == "1")
     coords = coords.to(device)
     raw_coords = raw_coords.to(device)
     feats = feats.to(device)
@@ -152,10 +161,6 @@ def _train_one_step(model, criterion, optimizer, batch, device, max_norm):
     mark("decoder backward")
     # ---- data-parallel average (engine.py runs under DDP: main.py:115-127), overlapped with the backbone backward: the
     # decoder's gradients are final here, the U-Net's become final from the head down to the stem
-    from .optim import OverlappedAllReduce
-    reducer = OverlappedAllReduce(bucket_bytes=int(float(os.environ.get("A3D_DP_BUCKET_MB", "32")) * (1 << 20)),
-                                  expected={k: p.numel() for k, p in model.named_parameters() if p.requires_grad},
-                                  single_rank=os.environ.get("A3D_DP_SINGLE_RANK", "0") == "1")
     for k in sorted(grads):
         reducer.add(k, grads[k])
     reducer.flush()
@@ -176,7 +181,7 @@ def _train_one_step(model, criterion, optimizer, batch, device, max_norm):
     if timing:
         import sys
         stats["phases_ms"] = {n.split(" (")[0]: 1e3 * (t - marks[i][1]) for i, (n, t) in enumerate(marks[1:])}
-        if timing != "quiet":
+        if timing not in ("quiet", "mark"):
             print("train_one_step: " + ", ".join(f"{n} {1e3 * (t - marks[i][1]):.1f} ms" for i, (n, t) in enumerate(marks[1:])),
                   file=sys.stderr)
     return stats

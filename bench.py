@@ -180,6 +180,7 @@ def cpu_baseline(sd, sc, ci, ct, gpu_logits=None, gpu_feats=None, samples=5):
 
     from agile3d_amd.hostcpu import cpu_quota
     ncpu = max(1, int(cpu_quota()))               # what the container lets this process use, not the CPUs it can see
+    threads_before = torch.get_num_threads()
     probes = {}
     levels = None
     for nt in sorted({min(8, ncpu), min(32, ncpu)}):
@@ -210,11 +211,113 @@ def cpu_baseline(sd, sc, ci, ct, gpu_logits=None, gpu_feats=None, samples=5):
                 "pcd_features_scale": float(r["pcd_features"].abs().max()),
                 "note": "GPU output of scene 0 of the timed workload vs the CPU oracle on the same inputs (bar 1e-3)"}
     cpu_baseline.last_logits = lg[-1]      # the oracle's logits of that scene (the emulated-fp32 pass is compared with them too)
-    torch.set_num_threads(max(1, ncpu // 2))      # back to the package's setting for the legs that follow (hostcpu.py)
+    torch.set_num_threads(threads_before)         # back to what was in force before this leg (hostcpu.cap_host_threads's policy)
     return res, diff
 
 
-def iou_at_k(dev, n_scenes=4, voxels=5000, objects=3, max_clicks=20, fit_iters=120, lr=1e-3):
+def explain_forks(model, sd, items, oracle_bb, gpu_log, oracle_log, dev, logit_tol=1e-4):
+    """Why the two free-running protocols of `iou_at_k` (GPU product / CPU oracle, same state dict, same `random` seed) stop
+    agreeing, scene by scene, with the numbers that show it.  A scene's rounds are compared while both sides hold the SAME
+    clicks; a round that differs must be one of
+      * "logit tie": same clicks, labels differ only at points whose two best logits are within `logit_tol` on both sides
+        (the GPU's logits differ from the oracle's by ~1e-5, an argmax there is a coin flip; utils/seg.py and
+        eval_multi_obj.py:126 take the argmax at face value);
+      * "distance tie": same labels, but the next click differs -- both sides' candidates are the arg-max of the cluster's
+        outside distance IN THEIR OWN ARITHMETIC (the reference and the oracle use torch.cdist = the matmul formula, error
+        ~sqrt(eps)|x| near zero, utils/seg.py:161-175; clicks.hip the exact difference expression), and their float64
+        distances differ by less than cdist's own error on those two points;
+    anything else is reported as "unexplained" (a bug).  After its first fork a scene's two runs hold different clicks and
+    are not compared any further.  Returns {"scenes": [...], "unexplained": n, "compared_rounds": n, "identical_rounds": n}."""
+    from agile3d_amd import SparseTensor
+    from agile3d_amd import clicks as pc
+    from oracle import clicks as oc, decoder as od
+    per_scene = len(gpu_log) // len(items)
+    out = {"scenes": [], "unexplained": 0, "compared_rounds": 0, "identical_rounds": 0, "logit_tol": logit_tol}
+
+    def gpu_logits(i, ci, ct):
+        sc = items[i]["scene"]
+        x = SparseTensor(features=torch.from_numpy(sc["feats"]), coordinates=torch.from_numpy(sc["coords"]), device=dev)
+        bo = model.forward_backbone(x, raw_coordinates=torch.from_numpy(sc["raw_xyz"]).to(dev))
+        return model.forward_mask(*bo, click_idx=[ci], click_time_idx=[ct])["pred_masks"][0].cpu()
+
+    for i, it in enumerate(items):
+        g = gpu_log[i * per_scene:(i + 1) * per_scene]
+        o = oracle_log[i * per_scene:(i + 1) * per_scene]
+        xyz = torch.from_numpy(it["scene"]["raw_xyz"])
+        lab = torch.from_numpy(it["labels"])
+        rec = {"scene": it["name"], "rounds": len(g), "events": []}
+        for j, (a, b) in enumerate(zip(g, o)):
+            if a[2] != b[2]:                                   # the clicks picked after round j - 1 differ: the fork
+                pa, pb = g[j - 1][3], o[j - 1][3]
+                ev = {"round": j, "kind": None}
+                if not torch.equal(pa, pb):
+                    ev["kind"] = "follows a logit tie"           # the labels the clicks were picked from differed (that round's event)
+                else:
+                    cg = {c["cluster_id"]: c for c in pc.error_clusters(pa.to(dev), lab.to(dev), xyz.to(dev))}
+                    co = {c["cluster_id"]: c for c in oc.error_clusters(pa, lab, xyz)}
+                    ties = []
+                    x64 = xyz.double()
+                    cid_all = lab.float() * 96 + pa.float() * 11
+                    wrong = pa != lab
+                    for cid in sorted(set(cg) | set(co)):
+                        if cid not in cg or cid not in co:
+                            ties.append({"cluster": cid, "missing_on_one_side": True})
+                            continue
+                        ra, rb = cg[cid]["row"], co[cid]["row"]
+                        if ra == rb:
+                            continue
+                        member = wrong & (cid_all == cid)
+                        d64 = torch.cdist(x64[[ra, rb]], x64[~member]).min(1).values           # float64: exact to 1e-16
+                        dcd = torch.cdist(xyz[~member], xyz[[ra, rb]]).min(0).values.double()   # the reference's arithmetic
+                        err_cd = float((dcd - d64).abs().sum())
+                        ulp = float(np.spacing(np.float32(d64.max())))
+                        ties.append({"cluster": cid, "gpu_row": ra, "oracle_row": rb,
+                                     "float64": [float(d64[0]), float(d64[1])], "torch_cdist": [float(dcd[0]), float(dcd[1])],
+                                     "gpu_error_size": cg[cid]["error_size"], "oracle_error_size": co[cid]["error_size"],
+                                     "float64_gap": float((d64[0] - d64[1]).abs()), "cdist_error_on_the_two": err_cd,
+                                     "proven": bool(d64[0] >= d64[1] - 2 * ulp and dcd[1] >= dcd[0]
+                                                    and float((d64[0] - d64[1]).abs()) <= err_cd + 2 * ulp)})
+                    # the cluster ranking (largest error size first) can tie too: sizes in both arithmetics
+                    rank_g = sorted(cg, key=lambda c: cg[c]["error_size"], reverse=True)
+                    rank_o = sorted(co, key=lambda c: co[c]["error_size"], reverse=True)
+                    ev["ties"] = ties
+                    ev["top_cluster"] = {"gpu": rank_g[:1], "oracle": rank_o[:1],
+                                         "gpu_sizes": [cg[c]["error_size"] for c in rank_g[:2]],
+                                         "oracle_sizes": [co[c]["error_size"] for c in rank_o[:2]]}
+                    rank_tie = rank_g[:1] != rank_o[:1] and len(rank_g) > 1 and \
+                        abs(cg[rank_g[0]]["error_size"] - cg[rank_g[1]]["error_size"]) <= 2e-3
+                    ok = bool(ties or rank_tie) and all(t.get("proven") for t in ties)
+                    ev["kind"] = "distance tie" if ok else "unexplained"
+                    out["unexplained"] += 0 if ok else 1
+                rec["events"].append(ev)
+                rec["forked_at_round"] = j
+                break
+            out["compared_rounds"] += 1
+            same_pred = torch.equal(a[3], b[3])
+            if same_pred and abs(a[1] - b[1]) <= 1e-6:
+                out["identical_rounds"] += 1
+                continue
+            ev = {"round": j, "iou_gpu": a[1], "iou_oracle": b[1]}
+            if same_pred:
+                ev["kind"] = "unexplained"                       # same labels, different IoU
+            else:
+                rows = torch.nonzero(a[3] != b[3]).flatten()
+                lg = gpu_logits(i, a[2], a[4])
+                lo = od.forward_mask(sd, oracle_bb[i]["pcd_features"], xyz, oracle_bb[i]["pos_enc"], b[2], b[4])[-1]
+                mg = lg[rows].topk(2, dim=-1).values
+                mo = lo[rows].topk(2, dim=-1).values
+                margin = torch.maximum(mg[:, 0] - mg[:, 1], mo[:, 0] - mo[:, 1])
+                ev.update({"points_with_different_labels": int(rows.numel()), "largest_top2_margin": float(margin.max()),
+                           "max_logit_diff_gpu_vs_oracle": float((lg - lo).abs().max())})
+                ev["kind"] = "logit tie" if float(margin.max()) <= logit_tol else "unexplained"
+            out["unexplained"] += 1 if ev["kind"] == "unexplained" else 0
+            rec["events"].append(ev)
+        out["scenes"].append(rec)
+    return out
+
+
+def iou_at_k(dev, n_scenes=4, voxels=5000, objects=3, max_clicks=20, fit_iters=120, lr=1e-3, min_iou5=0.5, more_iters=40,
+             max_fit_iters=360):
     """BASELINE.json's "IoU@k vs ref" on what exists offline, in the regime the reference operates in.  ScanNet and the
     authors' checkpoint cannot be had here, so the state dict is FITTED first: `fit_iters` iterations of the repository's
     own training path (agile3d_amd.fit = train_step.train_one_step = the reference's engine.py:38-150 on the HIP kernels,
@@ -240,34 +343,52 @@ def iou_at_k(dev, n_scenes=4, voxels=5000, objects=3, max_clicks=20, fit_iters=1
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     losses = fit(model, items, dev, iters=fit_iters, lr=lr, batch=2, seed=7)
+    # training is deterministic per build, not across builds (a kernel that rounds differently in the last bits fits to
+    # another point of the same curve: round 4 saw IoU@5 0.71 and 0.86 from two builds): fit on in steps of `more_iters`
+    # until the GPU protocol reaches `min_iou5` at 5 clicks per object, so that the comparison below always runs in the
+    # regime it is meant for; the line reports the iterations it took
+    loader, val = eval_loader(items)
+    tmp = tempfile.mkdtemp(prefix="a3d_iou_")
+    json.dump(val, open(os.path.join(tmp, "val.json"), "w"))
+    while min_iou5 is not None and len(losses) < max_fit_iters:
+        probe = types.SimpleNamespace(output_dir=os.path.join(tmp, f"probe{len(losses)}"), max_num_clicks=5, val_list=None)
+        at5 = []
+        random.seed(11)
+        with contextlib.redirect_stdout(io.StringIO()):
+            Evaluate(model, loader, probe, dev,
+                     lambda idx, cur, pred, iou, ci_, ct_: at5.append(float(iou)) if cur == 5 * objects else None)
+        if float(np.mean(at5)) >= min_iou5:
+            break
+        losses += fit(model, items, dev, iters=more_iters, lr=lr, batch=2, seed=7 + len(losses), optimizer=fit.optimizer)
+    fit_iters = len(losses)
     torch.cuda.synchronize()
     fit_s = time.perf_counter() - t0
     model.eval()
     sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
-    loader, val = eval_loader(items)
-    tmp = tempfile.mkdtemp(prefix="a3d_iou_")
-    json.dump(val, open(os.path.join(tmp, "val.json"), "w"))
     # ---- GPU product
     args = types.SimpleNamespace(output_dir=os.path.join(tmp, "gpu"), max_num_clicks=max_clicks, val_list=os.path.join(tmp, "val.json"))
     gpu_log = []
     random.seed(11)
     with contextlib.redirect_stdout(io.StringIO()):
         res_gpu = Evaluate(model, loader, args, dev,
-                           lambda idx, cur, pred, iou, ci_, ct_: gpu_log.append((cur, float(iou), {k: list(v) for k, v in ci_.items()})))
+                           lambda idx, cur, pred, iou, ci_, ct_: gpu_log.append(
+                               (cur, float(iou), {k: list(v) for k, v in ci_.items()}, pred.cpu().clone().long(),
+                                {k: list(v) for k, v in ct_.items()})))
     # ---- CPU oracle, same state dict, same seed
     os.makedirs(os.path.join(tmp, "cpu"), exist_ok=True)
-    oracle_log = []
+    oracle_log, oracle_bb = [], []
     random.seed(11)
     with open(os.path.join(tmp, "cpu", "val_results_multi.csv"), "w") as f:
         for i, it in enumerate(items):
             sc, lab = it["scene"], torch.from_numpy(it["labels"])
             xyz = torch.from_numpy(sc["raw_xyz"])
             rb = ob.forward_backbone(sd, sc["coords"], torch.from_numpy(sc["feats"]), xyz)
+            oracle_bb.append(rb)
             recs = oc.interactive_rounds(lambda ci_, ct_: od.forward_mask(sd, rb["pcd_features"], xyz, rb["pos_enc"], ci_, ct_)[-1],
                                          lab, xyz, objects, max_clicks)
             for r in recs:
                 f.write(f"{i} {it['name'].replace('scene', '')} {objects} {r['num_clicks'] / objects} {r['iou']}\n")
-                oracle_log.append((r["num_clicks"], float(r["iou"]), r["click_idx"]))
+                oracle_log.append((r["num_clicks"], float(r["iou"]), r["click_idx"], r["pred"].long(), r["click_time_idx"]))
     with contextlib.redirect_stdout(io.StringIO()):
         res_cpu = EvaluatorMO(os.path.join(tmp, "val.json"), os.path.join(tmp, "cpu", "val_results_multi.csv"),
                               [0.5, 0.65, 0.8, 0.85, 0.9]).eval_results()
@@ -275,6 +396,7 @@ def iou_at_k(dev, n_scenes=4, voxels=5000, objects=3, max_clicks=20, fit_iters=1
     same_clicks = [a_[0] == b_[0] and a_[2] == b_[2] for a_, b_ in zip(gpu_log, oracle_log)]
     same_iou = [abs(a_[1] - b_[1]) <= 1e-6 for a_, b_ in zip(gpu_log, oracle_log)]
     first_div = next((i for i, (c_, u_) in enumerate(zip(same_clicks, same_iou)) if not (c_ and u_)), None)
+    forks = explain_forks(model, sd, items, oracle_bb, gpu_log, oracle_log, dev)
     ks = (1, 3, 5, 10, 15)
     noc_g = {k_: round(float(v), 4) for k_, v in res_gpu.items() if k_.startswith("NoC")}
     noc_c = {k_: round(float(v), 4) for k_, v in res_cpu.items() if k_.startswith("NoC")}
@@ -286,7 +408,7 @@ def iou_at_k(dev, n_scenes=4, voxels=5000, objects=3, max_clicks=20, fit_iters=1
             "noc_gpu": noc_g, "noc_oracle": noc_c,
             "noc_thresholds_crossed_before_max_clicks": sorted(k_ for k_, v in noc_g.items() if v < max_clicks),
             "rounds": rounds, "rounds_with_identical_clicks": int(sum(same_clicks)), "rounds_with_identical_iou": int(sum(same_iou)),
-            "first_differing_round": first_div,
+            "first_differing_round": first_div, "forks": forks,
             "weights": {"kind": "fitted", "fit_iterations": fit_iters, "lr": lr, "fit_seconds": round(fit_s, 1),
                         "ms_per_iteration": round(1e3 * fit_s / fit_iters, 1),
                         "loss_first5_mean": round(float(np.mean(losses[:5])), 4), "loss_last5_mean": round(float(np.mean(losses[-5:])), 4)},
@@ -520,10 +642,13 @@ def main():
         step()
     # the timed region (exactly --steps steps between barrier + device sync, MAX over ranks) is repeated --reps
     # times; the line reports the MEDIAN repetition and lists them all
+    from agile3d_amd.hostcpu import cpu_throttle_stats
+    thr0 = cpu_throttle_stats()
     rep_dt, own_dt = [], []
     for _ in range(max(1, args.reps)):
         dt_, out = timed_steps(step, args.steps, world, dev, own=own_dt)
         rep_dt.append(dt_)
+    thr1 = cpu_throttle_stats()
     dt = float(np.median(rep_dt))
     per_rank_ms = [1e3 * float(np.median(own_dt)) / args.steps]
     if dist_on:
@@ -551,7 +676,10 @@ def main():
         res["config"]["launch_thread_numa_node"] = numa
     from agile3d_amd.hostcpu import cpu_quota
     res["config"]["host_cpu"] = {"visible": os.cpu_count(), "container_quota": round(cpu_quota(), 2),
-                                 "torch_threads": torch.get_num_threads()}
+                                 "torch_threads": torch.get_num_threads(),
+                                 # CFS throttling of the container during the timed region (all ranks share the cgroup):
+                                 # nr_throttled > 0 = the kernel froze every thread, launch threads included, for part of a period
+                                 "cfs_during_timed_region": {k: thr1[k] - thr0[k] for k in thr1 if k in thr0} or None}
     if dist_on:
         res["ranks_seen"] = ranks_seen
         res["ms_per_step_per_rank"] = [round(x, 4) for x in per_rank_ms]

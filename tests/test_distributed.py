@@ -145,9 +145,59 @@ def _mismatch_worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
+def _reinit_worker(rank, world, ports, q):
+    """destroy_process_group() + init_process_group() in ONE process (tests, notebooks): the reducer must not hand out the
+    first world's bucket communicator, and a rank whose gradient list changes LATER (after lists that agreed) must be
+    caught by the same check -- every rank runs the digest collective every time."""
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from agile3d_amd.optim import OverlappedAllReduce
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    seen_groups = []
+    for port in ports:
+        os.environ["MASTER_PORT"] = str(port)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        for it in range(2):                                             # twice per world: the second hits the cache
+            g = {"a": torch.full((4,), float(rank + 1)), "b": torch.full((8,), float(10 * (rank + 1)))}
+            red = OverlappedAllReduce(expected={k: v.numel() for k, v in g.items()})
+            seen_groups.append(red.group)
+            for k in g:
+                red.add(k, g[k])
+            red.finish({})
+            assert torch.allclose(g["a"], torch.full((4,), 1.5)) and torch.allclose(g["b"], torch.full((8,), 15.0))
+        assert seen_groups[-1] is seen_groups[-2]                       # one communicator per live world ...
+        if len(seen_groups) > 2:
+            assert seen_groups[-1] is not seen_groups[0]                # ... and not the destroyed world's
+        # same world, lists that agreed so far; now rank 1's list changes: both ranks must get the error, nobody hangs
+        try:
+            OverlappedAllReduce(expected={"a": 4, "b": 8} if rank == 0 else {"a": 4, "b": 9})
+            q.put((rank, "constructed"))
+        except RuntimeError:
+            q.put((rank, "refused"))
+        dist.barrier()
+        dist.destroy_process_group()
+    assert len(OverlappedAllReduce._bucket_groups) <= 1                 # the first world's entry was dropped
+    q.put((rank, "done"))
+
+
+def test_overlapped_allreduce_survives_reinit_and_late_disagreement():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ports = [_free_port(), _free_port()]
+    procs = [ctx.Process(target=_reinit_worker, args=(r, world, ports, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=180) for _ in range(3 * world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert sorted(m for _, m in got) == ["done"] * 2 + ["refused"] * 4, got
+
+
 def test_overlapped_allreduce_refuses_ranks_that_disagree():
-    """Ranks whose gradient lists differ fail with an error at construction (one all-gather of a digest per process
-    group) instead of hanging in a mis-sized collective; a gradient never handed over is reported by finish()."""
+    """Ranks whose gradient lists differ fail with an error at construction (one small all-reduce of a digest per
+    reducer) instead of hanging in a mis-sized collective; a gradient never handed over is reported by finish()."""
     world = 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()

@@ -197,16 +197,19 @@ def _prune_cases():
     large blobs, everything wrong, sizes around the sampling stride, exact distance ties (points on an integer lattice)."""
     rng = np.random.default_rng(7)
     out = []
-    # from 16 384 points on a coarse bounding stage (every 256th point) runs in front; it is skipped on the device unless
-    # wrong points x points >= 2^31: the last three cases are beyond that, the two before them around the size threshold
+    # from kCoarseFrom = 150 000 points on (clicks.hip) a coarse bounding stage (every 256th point) runs in front of the fine
+    # one (every 16th): the last three cases are beyond that size -- coherent regions, everything wrong, and exact distance
+    # ties on a lattice --, the ones before them exercise the one-stage search around its own size thresholds
     for n, kind in [(1024, "noise"), (1500, "blobs"), (4099, "noise"), (20_011, "blobs"), (20_011, "all_wrong"),
                     (8192, "lattice"), (16_383, "blobs"), (16_384, "noise"), (65_537, "all_wrong"), (70_001, "half_wrong"),
-                    (60_000, "lattice_big")]:
+                    (60_000, "lattice_big"), (150_001, "half_wrong"), (163_841, "all_wrong"), (180_000, "lattice_huge")]:
         xyz = rng.uniform(0, 4, (n, 3)).astype(np.float32)
         if kind == "lattice":
             xyz = rng.integers(0, 24, (n, 3)).astype(np.float32) * 0.05
         if kind == "lattice_big":
             xyz = rng.integers(0, 48, (n, 3)).astype(np.float32) * 0.05
+        if kind == "lattice_huge":
+            xyz = rng.integers(0, 72, (n, 3)).astype(np.float32) * 0.05
         labels = (xyz[:, 0] // 1).astype(np.int32) % 5
         pred = labels.copy()
         if kind == "noise":
@@ -221,7 +224,7 @@ def _prune_cases():
         elif kind == "half_wrong":          # a few huge coherent regions (what a prediction of early weights looks like)
             m = (np.sin(2.1 * xyz[:, 0]) + np.cos(1.7 * xyz[:, 1]) + 0.3 * xyz[:, 2]) > 0.4
             pred[m] = (labels[m] + 1 + (xyz[m, 1] // 2).astype(np.int32)) % 6
-        elif kind == "lattice_big":         # exact distance ties everywhere, most points wrong
+        elif kind in ("lattice_big", "lattice_huge"):         # exact distance ties everywhere, most points wrong
             m = xyz.sum(1) > 1.0
             pred[m] = (labels[m] + 1) % 5
         out.append((pred.astype(np.int32), labels.astype(np.int32), xyz))

@@ -254,6 +254,54 @@ def test_conv_apply_every_shape_class_small_scene(small_world, kind, level):
     print(f"conv_apply {kind} L{level}: worst relative error {worst:.2e} over {len(_WIDTHS_IN) * len(_WIDTHS_OUT)} shapes")
 
 
+@pytest.mark.parametrize("level,cin,cout,cin2", [(1, 96, 96, 128), (2, 128, 128, 192), (1, 96, 64, 64), (0, 32, 32, 64)])
+def test_fused_projection_op_and_its_fallback(world, level, cin, cout, cin2):
+    """a3d_op with a fused residual projection (proj_buf / proj_cin: BasicBlock.downsample as a 28th offset of the block's
+    second conv, resnet_block.py:59-61) through the C ABI against float64: the shapes the U-Net uses run the fused build;
+    96 -> 64 and 32 -> 32 have no fused instantiation (stage width 96 / the LDS-resident 32-channel kernel) -- the program
+    falls back to the conv + a 1x1 launch added in place instead of failing mid-forward."""
+    import ctypes as C
+    from agile3d_amd.engine import _ptr, _stream
+    coords, sc, lv, maps = world
+    lib = L.load()
+    g = torch.Generator().manual_seed(level * 7919 + cin * 31 + cout + cin2)
+    n = sc.n[level]
+    X = torch.randn(n, cin, generator=g)
+    X2 = torch.randn(n, cin2, generator=g)
+    W = torch.randn(27, cin, cout, generator=g) / (cin * 14) ** 0.5
+    Wp = torch.randn(1, cin2, cout, generator=g) / cin2 ** 0.5
+    shift = torch.randn(cout, generator=g).cuda()
+    both = torch.cat([pack_weight(W.cuda()), pack_weight(Wp.cuda())]).contiguous()
+    descs = [(level, cin), (level, cout), (level, cin2 + 32)]
+    bufs = (L.BufDesc * 3)(*[L.BufDesc(a, b) for a, b in descs])
+    o = L.Op()
+    o.kind, o.level_in, o.cin, o.cout = L.OP_CONV3, level, cin, cout
+    o.in_buf, o.in_coff, o.out_buf, o.out_coff = 0, 0, 1, 0
+    o.res_buf, o.res_coff, o.relu, o.kernel_volume = L.BUF_NONE, 0, 1, 27
+    o.w_dev, o.scale_dev, o.shift_dev = both.data_ptr(), None, shift.data_ptr()
+    o.proj_buf, o.proj_coff, o.proj_cin = 2, 32, cin2
+    ops = (L.Op * 1)(o)
+    nbytes = lib.a3d_program_workspace_bytes(sc.handle, bufs, 3, ops, 1)
+    assert nbytes > 0, lib.a3d_last_error()
+    ws = torch.zeros(nbytes, dtype=torch.uint8, device="cuda")
+
+    def buf(i):
+        off = lib.a3d_program_buffer_offset(sc.handle, bufs, 3, i)
+        lvl, ch = descs[i]
+        return ws[off:off + (sc.n[lvl] + 1) * ch * 4].view(torch.float32).view(sc.n[lvl] + 1, ch)
+    m = maps[level]
+    buf(0)[:n] = X[m].cuda()
+    buf(2)[:n, 32:] = X2[m].cuda()
+    buf(1).fill_(float("nan"))
+    L.check(lib.a3d_program_run(sc.handle, bufs, 3, ops, 1, None, None, 0, _ptr(ws), nbytes, _stream()), "a3d_program_run")
+    torch.cuda.synchronize()
+    ref = torch.relu(ob.sparse_conv(X.double(), W.double(), lv.kernel_map(level, 3), n) + X2.double() @ Wp[0].double()
+                     + shift.cpu().double())
+    out = buf(1).cpu()
+    _check(out[:n].double(), ref[m], f"fused projection L{level} {cin}->{cout} (+{cin2})", tol=2e-5)
+    assert (out[n] == 0).all(), "zero row not written"
+
+
 def test_emulated_fp32_build_keeps_parity():
     """A3D_CONV_EMU=2 (every gathered conv kernel forms its fp32 products from six bf16-MFMA terms; read once per process, so
     it runs in its own interpreter): the conv tests that reach those kernels and the end-to-end smoke comparison with the

@@ -180,6 +180,46 @@ def test_bench_multi_rank_code_path_on_one_gpu():
         assert d["ranks_share_gpus"] is True and d["config"]["backend"] == "gloo"
 
 
+def test_eight_ranks_share_the_one_gpu_host_side():
+    """`A3D_BENCH_ONE_GPU=1 python bench.py --gpus 8 --batch 2`: EIGHT launch loops (one per rank, four streams each)
+    on one host under the container's CPU quota, sharing the one GPU over gloo -- the same total device load as the
+    single-rank headline (16 scenes in flight per step).  A plumbing + host-contention check of what an 8-GPU node's host
+    side has to sustain (hostcpu.py: eight Python launch threads, torch pools capped to quota / 16 each), NOT a scaling
+    number: every rank progresses at the same pace, the kernel does not throttle the container during the timed region
+    (cpu.stat nr_throttled, printed in the line), and the ranks together are not much slower than one rank driving the
+    same load."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    env["A3D_BENCH_ONE_GPU"] = "1"
+
+    def run(extra):
+        cmd = [sys.executable, os.path.join(root, "bench.py"), "--steps", "20", "--warmup", "3", "--reps", "3", "--no-profile",
+               "--steps-only", "--no-train", "--no-cpu-baseline"] + extra
+        out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=1500, cwd=root)
+        assert out.returncode == 0, out.stderr[-3000:]
+        lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+        assert len(lines) == 1, out.stdout[-2000:]
+        return json.loads(lines[0])
+    d8 = run(["--gpus", "8", "--batch", "2"])
+    per = d8["ms_per_step_per_rank"]
+    cfs = d8["config"]["host_cpu"]["cfs_during_timed_region"]
+    print("8 ranks on one GPU:", round(d8["value"], 1), "scenes/s; per rank ms/step", per, "cfs", cfs,
+          "host", d8["config"]["host_cpu"])
+    assert d8["n_gpus"] == 8 and d8["ranks_seen"] == 8 and len(per) == 8 and d8["ranks_share_gpus"] is True
+    assert d8["config"]["global_batch"] == 16
+    assert max(per) <= 1.3 * min(per), per                     # nobody is starved (observed spread: a few per cent)
+    if cfs and "nr_throttled" in cfs and "nr_periods" in cfs:
+        assert cfs["nr_throttled"] <= max(2, cfs["nr_periods"] // 20), cfs      # the container is not being frozen
+    env.pop("A3D_BENCH_ONE_GPU")
+    d1 = run(["--gpus", "1", "--batch", "16"])
+    print("1 rank, same load:", round(d1["value"], 1), "scenes/s")
+    assert d8["value"] >= 0.7 * d1["value"], (d8["value"], d1["value"])
+
+
 def test_rccl_backend_single_rank_on_the_one_gpu(tmp_path):
     """The `nccl` (= RCCL) branch that the 8-GPU node runs, at world size 1 on this box's one GPU (RCCL refuses two ranks
     per device, so every multi-rank test above is gloo): init_process_group("nccl", device_id=...), the all-reduce of

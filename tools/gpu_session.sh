@@ -1,7 +1,18 @@
 #!/bin/bash
 # Scratch script of the current GPU session (overwritten per session; `gpurun -- 'bash tools/gpu_session.sh'`).
-# Every command under its own `timeout`: a host-side hang otherwise runs into the session limit (s33, r04_experiments.txt).
-mkdir -p gpurun_out/check
-timeout 2400 python -m pytest tests -m gpu -x -q > gpurun_out/check/pytest.log 2>&1; echo "pytest rc=$?" >> gpurun_out/check/pytest.log
-timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/check/smoke.log 2>&1; echo "smoke rc=$?" >> gpurun_out/check/smoke.log
-timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/check/bench.json 2> gpurun_out/check/bench.err
+# Every command under its own `timeout`: a host-side hang otherwise runs into the session limit.
+R=$GRAFT_REPO_ROOT
+O=$R/gpurun_out/s1
+mkdir -p $O
+cd $R
+timeout 900 python -m pytest tests/test_gpu_conv.py -x -q -k "fused_projection" > $O/t_conv.log 2>&1; echo "rc=$?" >> $O/t_conv.log
+timeout 900 python -m pytest tests/test_gpu_clicks.py -x -q -k "bounded" > $O/t_clicks.log 2>&1; echo "rc=$?" >> $O/t_clicks.log
+timeout 1500 python -m pytest tests/test_gpu_fit.py -x -q -s > $O/t_fit.log 2>&1; echo "rc=$?" >> $O/t_fit.log
+timeout 1500 python -m pytest tests/test_gpu_distributed.py -x -q -s -k "eight_ranks" > $O/t_dist8.log 2>&1; echo "rc=$?" >> $O/t_dist8.log
+cd /tmp && export TMPDIR=/tmp
+rm -rf /tmp/trt
+A3D_BB_ITERS=6 A3D_TRAIN_TIMING=mark timeout 900 rocprofv3 --kernel-trace -d /tmp/trt -o t -- python $R/tools/backward_bench.py --step --reps 1 > $O/train_trace.log 2>&1
+python $R/tools/train_phase_trace.py /tmp/trt 2 40 > $O/train_phases.txt 2>&1
+cd $R
+A3D_BB_ITERS=8 A3D_TRAIN_TIMING=1 timeout 600 python tools/backward_bench.py --step --reps 1 2>&1 | grep -E "training iteration|train_one_step" > $O/training_iterations.txt
+ls -la $O
