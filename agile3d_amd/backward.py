@@ -49,6 +49,30 @@ def _workspace(nbytes, device, tag):
     return ws
 
 
+def _rows(t):
+    """A [rows, C] operand the kernels can read in place: unit stride along the channels, any row stride (a column slice
+    of a wider buffer is passed as pointer + leading dimension, never copied)."""
+    return t if t.stride(1) == 1 and t.stride(0) % 4 == 0 else t.contiguous()
+
+
+class StateArena:
+    """The conv kernels' hand-off state (ticket, failure word, flags: a3d_conv_state_bytes() per launch) for every conv of
+    a training iteration, zeroed with ONE memset when the tape starts instead of one per launch."""
+
+    def __init__(self, device, slots):
+        self.bytes = int(L.load().a3d_conv_state_bytes())
+        self.buf = torch.zeros(slots * self.bytes, dtype=torch.uint8, device=device)
+        self.next, self.slots = 0, slots
+
+    def take(self):
+        if self.next >= self.slots:          # more launches than planned: a fresh zeroed block
+            self.buf = torch.zeros(self.slots * self.bytes, dtype=torch.uint8, device=self.buf.device)
+            self.next = 0
+        p = self.buf.data_ptr() + self.next * self.bytes
+        self.next += 1
+        return C.c_void_p(p)
+
+
 def level_out(kind, level_in):
     return level_in + (1 if kind == L.OP_DOWN else -1 if kind == L.OP_UP else 0)
 
@@ -117,6 +141,77 @@ def conv_apply(scene, kind, level_in, w_packed, x, cin, cout, out=None, out_cols
     return out
 
 
+def conv_apply_acc(scene, kind, level_in, w_packed, x, cin, cout, y, acc=False, zero_row=True, state=None):
+    """a3d_conv_apply_acc: y[:, :cout] (a [n_out + 1, >= cout] view, any row stride) = conv(x) (+ y when ``acc``: the
+    accumulation happens in the conv kernel's epilogue).  ``x`` [n_in + 1, >= cin] view carrying the zero row."""
+    lib = L.load()
+    x = _rows(x)
+    if y.stride(1) != 1:
+        raise ValueError("conv_apply_acc: the output view must have unit channel stride")
+    nbytes = lib.a3d_conv_apply_workspace_bytes(scene.handle, kind, level_in, cin, cout)
+    if nbytes == 0:
+        raise L.A3DError(lib.a3d_last_error().decode())
+    ws = _workspace(nbytes, x.device, "conv")
+    L.check(lib.a3d_conv_apply_acc(scene.handle, kind, level_in, _ptr(x), x.stride(0), cin, _ptr(w_packed), cout,
+                                   _ptr(y), y.stride(0), int(zero_row), _ptr(y) if acc else None, y.stride(0) if acc else 0,
+                                   state.take() if state is not None else None, _ptr(ws), ws.numel(), _stream()),
+            "a3d_conv_apply_acc")
+    return y
+
+
+def conv_input_grad_into(scene, kind, level_in, parts, dy, cin, cout, out, acc=False, state=None):
+    """dL/dx written (or, with ``acc``, added in the kernels' epilogues) into ``out`` [n_in + 1, >= cin] (a view: the
+    gradient buffer of a node, possibly a column slice of a concatenation's); ``dy`` [n_out + 1, cout] with its zero row."""
+    back_kind = {L.OP_CONV3: L.OP_CONV3, L.OP_DOWN: L.OP_UP, L.OP_UP: L.OP_DOWN, L.OP_LINEAR: L.OP_LINEAR}[kind]
+    lo = level_out(kind, level_in)
+    for c0, width, wp in parts:
+        conv_apply_acc(scene, back_kind, lo, wp, dy, cout, width, out[:, c0:c0 + width], acc=acc, state=state)
+    return out
+
+
+def conv_bn_train_forward(scene, kind, level_in, w_packed, x, cin, cout, gamma, beta, eps, res, relu, y, running_mean,
+                          running_var, momentum, state=None):
+    """a3d_conv_bn_train_forward: raw = conv(x); y = relu?(BatchNorm_train(raw) (+ res)) with the batch statistics taken
+    in the conv kernel's epilogue.  ``x`` [n_in + 1, >= cin] view with its zero row, ``y`` [n_out + 1, >= cout] view (row
+    n_out is written as zeros), ``res`` [>= n_out, >= cout] view or None.  Returns (raw [n_out, cout], mean, rstd)."""
+    lib = L.load()
+    x = _rows(x)
+    lo = level_out(kind, level_in)
+    n_out = scene.n[lo]
+    raw = torch.empty((n_out, cout), dtype=torch.float32, device=x.device)
+    mean = torch.empty(cout, dtype=torch.float32, device=x.device)
+    rstd = torch.empty_like(mean)
+    nbytes = lib.a3d_conv_bn_train_workspace_bytes(scene.handle, kind, level_in, cin, cout)
+    if nbytes == 0:
+        raise L.A3DError(lib.a3d_last_error().decode())
+    ws = _workspace(nbytes, x.device, "convbn")
+    res = _rows(res) if res is not None else None
+    L.check(lib.a3d_conv_bn_train_forward(scene.handle, kind, level_in, _ptr(x), x.stride(0), cin, _ptr(w_packed), cout,
+                                          _ptr(raw), cout, _ptr(gamma), _ptr(beta), eps, _ptr(res),
+                                          res.stride(0) if res is not None else 0, int(relu), _ptr(y), y.stride(0), 1,
+                                          _ptr(mean), _ptr(rstd), _ptr(running_mean), _ptr(running_var), momentum,
+                                          state.take() if state is not None else None, _ptr(ws), ws.numel(), _stream()),
+            "a3d_conv_bn_train_forward")
+    return raw, mean, rstd
+
+
+def bn_train_backward_into(x, y, dy, gamma, mean, rstd, relu, dx, dres=None):
+    """a3d_bn_train_backward on views: x (raw) [n, C], y / dy [>= n, C] views (any row stride), dx [n + 1, C] (row n is
+    written as zeros), dres view [n + 1, C] or None.  Returns (dgamma, dbeta)."""
+    lib = L.load()
+    n, C_ = x.shape
+    x, dy = _rows(x), _rows(dy)
+    yy = _rows(y) if relu else None
+    dgamma = torch.empty(C_, dtype=torch.float32, device=x.device)
+    dbeta = torch.empty_like(dgamma)
+    ws = _ws(n, C_, x.device)
+    L.check(lib.a3d_bn_train_backward(_ptr(x), x.stride(0), _ptr(yy), yy.stride(0) if yy is not None else 0, _ptr(dy),
+                                      dy.stride(0), n, C_, _ptr(gamma), _ptr(mean), _ptr(rstd), int(relu), _ptr(dx),
+                                      dx.stride(0), _ptr(dres), dres.stride(0) if dres is not None else 0, _ptr(dgamma),
+                                      _ptr(dbeta), 1, _ptr(ws), ws.numel(), _stream()), "a3d_bn_train_backward")
+    return dgamma, dbeta
+
+
 def packed_input_grad_weights(kind, w: torch.Tensor):
     """The packed weight slices of the input-gradient conv of y = conv(x; w): [(first input channel, width, packed)].
     W' = W^T (3^3: offsets reversed); output widths the conv kernel supports (192 = 128 + 64 ...)."""
@@ -174,14 +269,14 @@ def conv_weight_grad(scene, kind, level_in, x: torch.Tensor, dy: torch.Tensor) -
     cin, cout = x.shape[1], dy.shape[1]
     if x.shape[0] != scene.n[level_in] or dy.shape[0] != scene.n[lo]:
         raise ValueError("x / dy row counts do not match the scene levels")
-    x, dy = x.contiguous(), dy.contiguous()
+    x, dy = _rows(x), _rows(dy)
     K = _KVOL[kind]
     dw = torch.empty((K, cin, cout), dtype=torch.float32, device=x.device)
     nbytes = lib.a3d_conv_wgrad_workspace_bytes(scene.handle, kind, level_in, cin, cout)
     if nbytes == 0:
         raise L.A3DError(lib.a3d_last_error().decode())
     ws = _workspace(nbytes, x.device, "wgrad")
-    L.check(lib.a3d_conv_wgrad(scene.handle, kind, level_in, _ptr(x), x.shape[1], _ptr(dy), dy.shape[1], cin, cout,
+    L.check(lib.a3d_conv_wgrad(scene.handle, kind, level_in, _ptr(x), x.stride(0), _ptr(dy), dy.stride(0), cin, cout,
                                _ptr(dw), _ptr(ws), ws.numel(), _stream()), "a3d_conv_wgrad")
     return dw
 

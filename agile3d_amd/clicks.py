@@ -364,15 +364,16 @@ def extend_clicks(current_clicks, current_clicks_time, new_clicks, new_click_tim
     return current_clicks, current_clicks_time
 
 
-def cal_click_loss_weights(batch_idx, raw_coords, labels, click_idx, alpha=0.8, beta=2.0, tita=0.3):
+def cal_click_loss_weights(batch_idx, raw_coords, labels, click_idx, alpha=0.8, beta=2.0, tita=0.3, ranges=None):
     """utils/seg.py:71-89: per sample, weights[i] = alpha + (beta-alpha)(1 - min(d_i, tita)/tita) with
-    d_i the distance of point i to the nearest click of any object."""
+    d_i the distance of point i to the nearest click of any object.  ``ranges`` [(first row, end row)] per sample, when the
+    caller knows them (the rows of a sample are contiguous in a collated batch): no boolean-mask gathers, no host syncs."""
     lib = L.load()
     if not raw_coords.is_cuda:
         raise RuntimeError("cal_click_loss_weights runs on the GPU only")
     weights = []
-    for i in range(int(batch_idx.max()) + 1):
-        xyz = raw_coords[batch_idx == i].to(torch.float32).contiguous()
+    for i in range(len(ranges) if ranges is not None else int(batch_idx.max()) + 1):
+        xyz = (raw_coords[ranges[i][0]:ranges[i][1]] if ranges is not None else raw_coords[batch_idx == i]).to(torch.float32).contiguous()
         rows = [int(r) for v in click_idx[i].values() for r in v]
         r, rp = _host_i32(rows)
         w = torch.empty(xyz.shape[0], dtype=torch.float32, device=xyz.device)

@@ -53,13 +53,15 @@ class SetCriterion:
         wb = self.weight_dict.get("loss_bce" + suffix, 0.0) if "bce" in self.losses else 0.0
         wd = self.weight_dict.get("loss_dice" + suffix, 0.0) if "dice" in self.losses else 0.0
         nb = len(pred_masks)
-        tot = torch.zeros(2, dtype=torch.float32, device=pred_masks[0].device)
-        grads = []
+        outs, grads = [], []
         for i in range(nb):
             out, g = _losses_one(pred_masks[i], targets[i], None if weights is None else weights[i], wb / nb, wd / nb,
                                  want_grad)
-            tot = tot + out
+            outs.append(out)
             grads.append(g)
+        tot = outs[0]
+        for o in outs[1:]:                # sample order, like the reference's running sum (models/criterion.py:93-101)
+            tot = tot + o
         tot = tot / nb
         d = {}
         if "bce" in self.losses:
@@ -95,6 +97,20 @@ class SetCriterion:
             if "loss_dice" + suffix in losses:
                 losses["loss_dice" + suffix] = out[2 * l + 1]
         return losses
+
+    def forward_and_grad(self, outputs, targets, weights=None):
+        """``forward`` and ``grad_logits`` from ONE pass of a3d_mask_losses per level and sample (the kernel produces the
+        loss values and the gradient together): -> (loss dict of device scalars, the structure ``grad_logits`` returns)."""
+        levels = [("", outputs["pred_masks"])] + [(f"_{i}", aux["pred_masks"]) for i, aux in enumerate(outputs.get("aux_outputs", []))]
+        losses, res = {}, {"pred_masks": None, "aux_outputs": []}
+        for li, (suffix, preds) in enumerate(levels):
+            d, g = self._level([p.detach() for p in preds], targets, weights, suffix, True)
+            losses.update(d)
+            if li == 0:
+                res["pred_masks"] = g
+            else:
+                res["aux_outputs"].append(g)
+        return losses, res
 
     def grad_logits(self, outputs, targets, weights=None):
         """{'pred_masks': [grad per sample], 'aux_outputs': [[grad per sample] per level]}: gradient of

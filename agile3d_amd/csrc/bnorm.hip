@@ -146,6 +146,58 @@ __global__ void __launch_bounds__(256) k_bn_combine(const float* __restrict__ pa
   }
 }
 
+// The same merge for MANY small blocks (the conv kernels' epilogues hand over one (sum, M2 around the block mean) pair per
+// 64-row tile or 16-row group: 5 000 - 20 000 blocks at 320 k rows) without a dependent chain of divisions: pass 1 sums the
+// block sums (fp64) -> the batch mean; pass 2 shifts every block's M2 to that mean with the exact identity
+//   sum (v - mean)^2 = M2_b + 2 (m_b - mean) (S_b - n_b m_b) + n_b (m_b - mean)^2        (m_b = the fp32 mean the block used)
+// 64 lanes per column, 16 columns per 1024-thread workgroup, every partial sum in a fixed order.
+constexpr int kFin2Lanes = 64;
+__global__ void __launch_bounds__(1024) k_bn_combine_tiles(const float* __restrict__ partial, int nblocks, int rows_per_block, int n,
+                                                           int C, float eps, float* mean_out, float* rstd_out, float* running_mean,
+                                                           float* running_var, float momentum) {
+  __shared__ double sh[kFin2Lanes][kFinCols];
+  __shared__ double s_mean[kFinCols];
+  const int cc = threadIdx.x % kFinCols, bl = threadIdx.x / kFinCols;
+  const int c = blockIdx.x * kFinCols + cc;
+  double s = 0.0;
+  if (c < C)
+    for (int b = bl; b < nblocks; b += kFin2Lanes) s += (double)partial[(size_t)b * 2 * C + c];
+  sh[bl][cc] = s;
+  __syncthreads();
+  if (bl == 0) {
+    double t = 0.0;
+    for (int k = 0; k < kFin2Lanes; ++k) t += sh[k][cc];
+    s_mean[cc] = t / (double)n;
+  }
+  __syncthreads();
+  const double mean = s_mean[cc];
+  double q = 0.0;
+  if (c < C)
+    for (int b = bl; b < nblocks; b += kFin2Lanes) {
+      const int nbi = min(n, (b + 1) * rows_per_block) - b * rows_per_block;
+      const float bsf = partial[(size_t)b * 2 * C + c];
+      const double nb = (double)nbi, bs = (double)bsf, bm2 = (double)partial[(size_t)b * 2 * C + C + c];
+      const double m_used = (double)(bsf * (1.f / (float)nbi));
+      const double dm = m_used - mean;
+      q += bm2 + 2.0 * dm * (bs - nb * m_used) + nb * dm * dm;
+    }
+  sh[bl][cc] = q;
+  __syncthreads();
+  if (bl != 0 || c >= C) return;
+  double m2 = 0.0;
+  for (int k = 0; k < kFin2Lanes; ++k) m2 += sh[k][cc];
+  if (m2 < 0.0) m2 = 0.0;
+  const double cnt = (double)n;
+  const float var = (float)(m2 / cnt);
+  mean_out[c] = (float)mean;
+  rstd_out[c] = 1.0f / sqrtf(var + eps);
+  if (running_mean) {
+    const float unbiased = cnt > 1.0 ? (float)(m2 / (cnt - 1.0)) : var;
+    running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
+    running_var[c] = (1.f - momentum) * running_var[c] + momentum * unbiased;
+  }
+}
+
 // column sums of the block partials, fp64: ncol = nsum * C columns of [nblocks][ncol] (launch: ceil(ncol / 16) x 256)
 __device__ __forceinline__ double col_final_sum(const float* __restrict__ partial, int nblocks, int ncol, int c, int bl, int cc,
                                                 double (*sh)[kFinCols]) {
@@ -355,6 +407,28 @@ __global__ void k_ln_params(const double* sums, int C, float* dgamma, float* dbe
 static bool bn_shape_ok(int64_t n, int C, int ld0, int ld1, int ld2) {
   return n > 0 && n <= (int64_t)1 << 30 && C >= 32 && C % 32 == 0 && kBnThreads % (C / 4) == 0 && ld0 % 4 == 0 &&
          ld1 % 4 == 0 && ld2 % 4 == 0;
+}
+static int bn_blocks(int64_t n, int& rows_per_block);
+// BatchNorm(train) from the conv epilogues' block partials (spconv.hip: a3d_conv_bn_train_forward): merge + apply
+int bn_finish_from_partials(const float* partial, int nblocks, int rows_per_block, const float* x, int ldx, int64_t n, int C,
+                            const float* gamma, const float* beta, float eps, const float* res, int ldr, int relu, float* y,
+                            int ldy, int y_zero_row, float* save_mean, float* save_rstd, float* running_mean,
+                            float* running_var, float momentum, hipStream_t st) {
+  if (!partial || !x || !gamma || !beta || !y || !save_mean || !save_rstd || n <= 0 || n > (int64_t)1 << 30 || C < 32 || C % 32 ||
+      (ldx & 3) || (ldy & 3) || (res && (ldr & 3)) || (running_mean == nullptr) != (running_var == nullptr) || nblocks < 1 ||
+      (int64_t)(nblocks - 1) * rows_per_block >= n) {
+    set_error("bn_finish_from_partials: bad arguments");
+    return A3D_ERR_INVALID;
+  }
+  k_bn_combine_tiles<<<(unsigned)((C + kFinCols - 1) / kFinCols), 1024, 0, st>>>(partial, nblocks, rows_per_block, (int)n, C, eps, save_mean,
+                                                                               save_rstd, running_mean, running_var, momentum);
+  ApplyArgs a;
+  a.x = x, a.mean = save_mean, a.rstd = save_rstd, a.gamma = gamma, a.beta = beta, a.res = res;
+  a.ldx = ldx, a.ldr = ldr, a.ldy = ldy, a.n = (int)n, a.C = C, a.relu = relu, a.y = y, a.zero_row = y_zero_row;
+  const size_t total = (size_t)n * (C / 4);
+  k_bn_apply<<<(unsigned)((total + 255) / 256), 256, 0, st>>>(a);
+  A3D_LAUNCH_CHECK();
+  return A3D_OK;
 }
 static int bn_blocks(int64_t n, int& rows_per_block) {
   int blocks = (int)((n + 511) / 512);

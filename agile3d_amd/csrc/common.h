@@ -82,6 +82,12 @@ size_t scan2_temp_bytes(int64_t n);
 int scan2_incl_excl(void* temp, size_t temp_bytes, const int* a, const int* b, int64_t n, int* a_incl, int* b_excl,
                     hipStream_t st);
 
+// BatchNorm(train) of a conv output whose block partials the conv's epilogue wrote (bnorm.hip; called from spconv.hip)
+int bn_finish_from_partials(const float* partial, int nblocks, int rows_per_block, const float* x, int ldx, int64_t n, int C,
+                            const float* gamma, const float* beta, float eps, const float* res, int ldr, int relu, float* y,
+                            int ldy, int y_zero_row, float* save_mean, float* save_rstd, float* running_mean,
+                            float* running_var, float momentum, hipStream_t st);
+
 // ---- geometry constants -------------------------------------------------------------------
 constexpr int kTileRows = 128;   // output rows per conv workgroup
 constexpr int kGroupRows = 16;   // MFMA row granularity (v_mfma_f32_16x16x4_f32)

@@ -534,16 +534,13 @@ __global__ void __launch_bounds__(256, PAIR ? ((BN <= 96 && CH <= 32) ? 4 : 3) :
         // shuffles over the 16 rows of a group, the four waves through LDS behind the weight ring, fixed orders
         float* sst = (float*)(misc + 16);   // [2][4][BN]
         const bool valid = r0 + wrow < a.c.n_out;
-        f32x4 sv[NCT];
 #pragma unroll
-        for (int ct = 0; ct < NCT; ++ct) {
-          sv[ct] = valid ? acc[0][ct] : (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int ct = 0; ct < NCT; ++ct) {   // one column tile at a time (sched_barrier: no interleaving, four live temporaries)
+          f32x4 sv = valid ? acc[0][ct] : (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-          for (int tt = 0; tt < 4; ++tt) sv[ct][tt] = row16_sum(sv[ct][tt]);
-        }
-        if (j == 0) {
-#pragma unroll
-          for (int ct = 0; ct < NCT; ++ct) *(f32x4*)(sst + wave * BN + ct * 16 + 4 * g) = sv[ct];
+          for (int tt = 0; tt < 4; ++tt) sv[tt] = row16_sum(sv[tt]);
+          if (j == 0) *(f32x4*)(sst + wave * BN + ct * 16 + 4 * g) = sv;
+          __builtin_amdgcn_sched_barrier(0);
         }
         __syncthreads();
         const int cnt = min(kTile, a.c.n_out - r0);
@@ -552,14 +549,12 @@ __global__ void __launch_bounds__(256, PAIR ? ((BN <= 96 && CH <= 32) ? 4 : 3) :
         for (int ct = 0; ct < NCT; ++ct) {
           const float* sp = sst + ct * 16 + 4 * g;
           const f32x4 tot = ((*(const f32x4*)sp + *(const f32x4*)(sp + BN)) + *(const f32x4*)(sp + 2 * BN)) + *(const f32x4*)(sp + 3 * BN);
-          const f32x4 d = valid ? acc[0][ct] - tot * inv : (f32x4){0.f, 0.f, 0.f, 0.f};
-          sv[ct] = d * d;
+          f32x4 d = valid ? acc[0][ct] - tot * inv : (f32x4){0.f, 0.f, 0.f, 0.f};
+          d = d * d;
 #pragma unroll
-          for (int tt = 0; tt < 4; ++tt) sv[ct][tt] = row16_sum(sv[ct][tt]);
-        }
-        if (j == 0) {
-#pragma unroll
-          for (int ct = 0; ct < NCT; ++ct) *(f32x4*)(sst + 4 * BN + wave * BN + ct * 16 + 4 * g) = sv[ct];
+          for (int tt = 0; tt < 4; ++tt) d[tt] = row16_sum(d[tt]);
+          if (j == 0) *(f32x4*)(sst + 4 * BN + wave * BN + ct * 16 + 4 * g) = d;
+          __builtin_amdgcn_sched_barrier(0);
         }
         __syncthreads();
         if (tid < BN) {
@@ -1770,26 +1765,27 @@ extern "C" size_t a3d_conv_apply_workspace_bytes(const a3d_scene* s, int kind, i
   return align256((size_t)kMaxQueuesPerOp * 4) + align256(q.slab_floats * 4) + 256;
 }
 
-extern "C" int a3d_conv_apply(const a3d_scene* s, int kind, int level_in, const float* x_dev, int ldx, int cin,
-                              const float* w_packed_dev, int cout, float* y_dev, int ldy, int y_zero_row,
-                              void* workspace_dev, size_t workspace_bytes, void* stream) {
+// shared body of a3d_conv_apply / a3d_conv_apply_acc / a3d_conv_bn_train_forward
+static int conv_apply_impl(const a3d_scene* s, int kind, int level_in, const float* x_dev, int ldx, int cin,
+                           const float* w_packed_dev, int cout, float* y_dev, int ldy, int y_zero_row, const float* res_dev,
+                           int ldr, int* state_dev, float* stats, int stats_ld, int* stats_rows, void* workspace_dev,
+                           size_t workspace_bytes, hipStream_t st, const char* who) {
   if (!s || !x_dev || !w_packed_dev || !y_dev || level_in < 0 || level_in >= A3D_NUM_LEVELS || (ldx & 3) || (ldy & 3) ||
-      ldx < cin || ldy < cout) {
-    set_error("a3d_conv_apply: bad arguments");
+      ldx < cin || ldy < cout || (res_dev && ((ldr & 3) || ldr < cout))) {
+    set_error("%s: bad arguments", who);
     return A3D_ERR_INVALID;
   }
   const int Lin = level_in;
   int lvl_out = Lin + (kind == A3D_OP_DOWN ? 1 : kind == A3D_OP_UP ? -1 : 0);
   if (lvl_out < 0 || lvl_out >= A3D_NUM_LEVELS) {
-    set_error("a3d_conv_apply: the op leaves the level range");
+    set_error("%s: the op leaves the level range", who);
     return A3D_ERR_INVALID;
   }
   const size_t need = a3d_conv_apply_workspace_bytes(s, kind, level_in, cin, cout);
   if (!workspace_dev || workspace_bytes < need || ((uintptr_t)workspace_dev & 255)) {
-    set_error("a3d_conv_apply: workspace too small or misaligned (%zu < %zu)", workspace_bytes, need);
+    set_error("%s: workspace too small or misaligned (%zu < %zu)", who, workspace_bytes, need);
     return A3D_ERR_WORKSPACE;
   }
-  hipStream_t st = (hipStream_t)stream;
   ConvArgs a;
   memset(&a, 0, sizeof(a));
   a.in = x_dev;
@@ -1800,6 +1796,8 @@ extern "C" int a3d_conv_apply(const a3d_scene* s, int kind, int level_in, const 
   a.cout = cout;
   a.out = y_dev;
   a.ldo = ldy;
+  a.res = res_dev;
+  a.ldr = ldr;
   a.n_out = s->lv[lvl_out].n;
   a.zero_row = y_zero_row ? s->lv[lvl_out].n : -1;
   a.tag_table = kind;
@@ -1832,14 +1830,69 @@ extern "C" int a3d_conv_apply(const a3d_scene* s, int kind, int level_in, const 
       a.K = 1;
       break;
     default:
-      set_error("a3d_conv_apply: unknown kind %d", kind);
+      set_error("%s: unknown kind %d", who, kind);
       return A3D_ERR_INVALID;
   }
-  int* state = (int*)workspace_dev;
+  // the hand-off state (ticket, failure word, flags): the caller's zeroed block, or the head of the workspace zeroed here
+  int* state = state_dev ? state_dev : (int*)workspace_dev;
   float* slab = (float*)((char*)workspace_dev + align256((size_t)kMaxQueuesPerOp * 4));
   const size_t slab_floats = (workspace_bytes - align256((size_t)kMaxQueuesPerOp * 4)) / 4;
-  A3D_HIP_CHECK(hipMemsetAsync(state, 0, (size_t)kMaxQueuesPerOp * 4, st));
-  return launch_conv_sk(a, pre, slab, slab_floats, state, st);
+  if (!state_dev) A3D_HIP_CHECK(hipMemsetAsync(state, 0, (size_t)kMaxQueuesPerOp * 4, st));
+  return launch_conv_sk(a, pre, slab, slab_floats, state, st, stats, stats_ld, stats_rows);
+}
+
+extern "C" int a3d_conv_apply(const a3d_scene* s, int kind, int level_in, const float* x_dev, int ldx, int cin,
+                              const float* w_packed_dev, int cout, float* y_dev, int ldy, int y_zero_row,
+                              void* workspace_dev, size_t workspace_bytes, void* stream) {
+  return conv_apply_impl(s, kind, level_in, x_dev, ldx, cin, w_packed_dev, cout, y_dev, ldy, y_zero_row, nullptr, 0, nullptr,
+                         nullptr, 0, nullptr, workspace_dev, workspace_bytes, (hipStream_t)stream, "a3d_conv_apply");
+}
+
+extern "C" size_t a3d_conv_state_bytes(void) { return (size_t)kMaxQueuesPerOp * 4; }
+
+extern "C" int a3d_conv_apply_acc(const a3d_scene* s, int kind, int level_in, const float* x_dev, int ldx, int cin,
+                                  const float* w_packed_dev, int cout, float* y_dev, int ldy, int y_zero_row,
+                                  const float* res_dev, int ldr, void* state_dev, void* workspace_dev,
+                                  size_t workspace_bytes, void* stream) {
+  return conv_apply_impl(s, kind, level_in, x_dev, ldx, cin, w_packed_dev, cout, y_dev, ldy, y_zero_row, res_dev, ldr,
+                         (int*)state_dev, nullptr, 0, nullptr, workspace_dev, workspace_bytes, (hipStream_t)stream,
+                         "a3d_conv_apply_acc");
+}
+
+extern "C" size_t a3d_conv_bn_train_workspace_bytes(const a3d_scene* s, int kind, int level_in, int cin, int cout) {
+  const size_t conv = a3d_conv_apply_workspace_bytes(s, kind, level_in, cin, cout);
+  if (!conv) return 0;
+  const int lvl_out = level_in + (kind == A3D_OP_DOWN ? 1 : kind == A3D_OP_UP ? -1 : 0);
+  const size_t groups = ((size_t)s->lv[lvl_out].n + 15) / 16;                  // the finest partial granularity (k_conv_wl)
+  return align256(conv) + align256(groups * 2 * (size_t)cout * 4) + 256;
+}
+
+extern "C" int a3d_conv_bn_train_forward(const a3d_scene* s, int kind, int level_in, const float* x_dev, int ldx, int cin,
+                                         const float* w_packed_dev, int cout, float* raw_dev, int ld_raw,
+                                         const float* gamma_dev, const float* beta_dev, float eps, const float* res_dev,
+                                         int ldr, int relu, float* y_dev, int ldy, int y_zero_row, float* save_mean_dev,
+                                         float* save_rstd_dev, float* running_mean_dev, float* running_var_dev,
+                                         float momentum, void* state_dev, void* workspace_dev, size_t workspace_bytes,
+                                         void* stream) {
+  const size_t need = a3d_conv_bn_train_workspace_bytes(s, kind, level_in, cin, cout);
+  if (!s || !need || !workspace_dev || workspace_bytes < need || ((uintptr_t)workspace_dev & 255) || !raw_dev || !y_dev) {
+    set_error("a3d_conv_bn_train_forward: bad arguments or workspace too small (%zu < %zu)", workspace_bytes, need);
+    return A3D_ERR_INVALID;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  const size_t conv_bytes = align256(a3d_conv_apply_workspace_bytes(s, kind, level_in, cin, cout));
+  float* partial = (float*)((char*)workspace_dev + conv_bytes);
+  int rows_per_block = 0;
+  int rc = conv_apply_impl(s, kind, level_in, x_dev, ldx, cin, w_packed_dev, cout, raw_dev, ld_raw, 0, nullptr, 0,
+                           (int*)state_dev, partial, cout, &rows_per_block, workspace_dev, conv_bytes, st,
+                           "a3d_conv_bn_train_forward");
+  if (rc != A3D_OK) return rc;
+  const int lvl_out = level_in + (kind == A3D_OP_DOWN ? 1 : kind == A3D_OP_UP ? -1 : 0);
+  const int n = s->lv[lvl_out].n;
+  const int nblocks = (n + rows_per_block - 1) / rows_per_block;
+  return bn_finish_from_partials(partial, nblocks, rows_per_block, raw_dev, ld_raw, n, cout, gamma_dev, beta_dev, eps, res_dev,
+                                 ldr, relu, y_dev, ldy, y_zero_row, save_mean_dev, save_rstd_dev, running_mean_dev,
+                                 running_var_dev, momentum, st);
 }
 
 extern "C" int a3d_linear(const float* in_dev, int ldi, const float* in_add_dev, int ldi_add, int64_t n, int cin,

@@ -29,40 +29,67 @@ MT_CHUNK = 4096   # A3D_MT_CHUNK
 _MT_DTYPE = None
 
 
-def _mt_table(entries, device):
-    """entries: [(p, g, m, v, n, bias1, bias2_sqrt)] with tensors or None -> (device table of a3d_mt_tensor, n_chunks)."""
+def _mt_dtype():
     global _MT_DTYPE
     import numpy as np
     if _MT_DTYPE is None:
         _MT_DTYPE = np.dtype([("p", "<u8"), ("g", "<u8"), ("m", "<u8"), ("v", "<u8"), ("n", "<i8"), ("chunk0", "<i4"),
                               ("bias1", "<f4"), ("bias2_sqrt", "<f4"), ("pad", "<i4")])
         assert _MT_DTYPE.itemsize == 56
-    tab = np.zeros(len(entries), _MT_DTYPE)
-    chunk = 0
-    for i, (p, g, m, v, n, b1, b2) in enumerate(entries):
-        tab[i] = (p.data_ptr() if p is not None else 0, g.data_ptr(), m.data_ptr() if m is not None else 0,
-                  v.data_ptr() if v is not None else 0, n, chunk, b1, b2, 0)
-        chunk += (n + MT_CHUNK - 1) // MT_CHUNK
-    return torch.from_numpy(tab.view(np.uint8)).to(device), chunk
+    return _MT_DTYPE
+
+
+def _mt_layout(sizes):
+    """The static half of a table of a3d_mt_tensor for tensors of ``sizes`` elements: (table with n / chunk0 filled in,
+    number of chunks).  Built once per list of tensors (the 268 parameters of an iteration are the same every time)."""
+    import numpy as np
+    n = np.asarray(sizes, dtype=np.int64)
+    chunks = (n + MT_CHUNK - 1) // MT_CHUNK
+    tab = np.zeros(len(n), _mt_dtype())
+    tab["n"] = n
+    tab["chunk0"] = np.concatenate([[0], np.cumsum(chunks)[:-1]]).astype(np.int32)
+    tab["bias1"] = 1.0
+    tab["bias2_sqrt"] = 1.0
+    return tab, int(chunks.sum())
+
+
+def _to_device(tab, device):
+    import numpy as np
+    return torch.from_numpy(tab.view(np.uint8)).to(device)
+
+
+_norm_layouts: dict = {}
 
 
 def total_grad_norm(grads: dict) -> float:
     """sqrt(sum over all tensors of sum g^2): the 2-norm clip_grad_norm_ computes (fp64 accumulation on the device, all
-    tensors in one launch + one ordered final sum)."""
+    tensors in one launch + one ordered final sum).  Non-contiguous gradients are replaced IN ``grads`` by contiguous
+    copies (the optimiser then reads those, it does not copy again)."""
     lib = L.load()
-    gs = []
-    for g in grads.values():
+    names, gs = [], []
+    for k, g in grads.items():
         if not g.is_cuda or g.dtype != torch.float32:
             raise RuntimeError("agile3d_amd.optim runs on the GPU only (fp32 CUDA tensors)")
         if g.numel():
-            gs.append(g.contiguous())
+            if not g.is_contiguous():
+                g = grads[k] = g.contiguous()
+            names.append(k)
+            gs.append(g)
     if not gs:
         return 0.0
     dev = gs[0].device
-    tab, nchunks = _mt_table([(None, g, None, None, g.numel(), 1.0, 1.0) for g in gs], dev)
+    key = tuple(g.numel() for g in gs)
+    lay = _norm_layouts.get(key)
+    if lay is None:
+        if len(_norm_layouts) > 8:
+            _norm_layouts.clear()
+        lay = _norm_layouts[key] = _mt_layout(key)
+    tab, nchunks = lay[0].copy(), lay[1]
+    tab["g"] = [g.data_ptr() for g in gs]
+    tabd = _to_device(tab, dev)
     ws = torch.empty(lib.a3d_mt_workspace_bytes(nchunks), dtype=torch.uint8, device=dev)
     out = torch.empty(1, dtype=torch.float64, device=dev)
-    L.check(lib.a3d_sum_squares_multi(_ptr(tab), len(gs), nchunks, _ptr(out), _ptr(ws), ws.numel(), _stream(gs[0])),
+    L.check(lib.a3d_sum_squares_multi(_ptr(tabd), len(gs), nchunks, _ptr(out), _ptr(ws), ws.numel(), _stream(gs[0])),
             "a3d_sum_squares_multi")
     return math.sqrt(float(out.item()))      # the one host synchronisation of the clip
 
@@ -89,33 +116,53 @@ class AdamW:
         self.state = {}
         self.steps = {}            # per parameter, like torch.optim.AdamW's state[p]['step']
         self.step_count = 0        # number of step() calls (= every parameter's step when all of them get gradients)
+        self._layouts = {}         # names -> (static table, chunks, parameter pointers)
 
     def step(self, grads: dict, grad_scale: float = 1.0):
+        """One launch for all tensors.  The table's static half (parameter / state pointers, sizes, chunk offsets) is kept
+        per list of names -- the same every iteration --, only the gradient pointers and the bias corrections are filled
+        in per call (the per-tensor Python of 268 entries was a third of the 3 ms this phase took)."""
+        import numpy as np
         lib = L.load()
         self.step_count += 1
         WEIGHT_EPOCH[0] += 1
-        entries, keep = [], []
-        for name, g in grads.items():
-            p = self.params[name]
-            if not p.is_cuda or p.dtype != torch.float32 or not p.is_contiguous():
-                raise RuntimeError("AdamW: parameters must be contiguous fp32 CUDA tensors")
-            st = self.state.get(name)
-            if st is None:
-                st = self.state[name] = (torch.zeros_like(p), torch.zeros_like(p))
-            g = g.reshape(p.shape).contiguous()
-            keep.append(g)
-            t = self.steps[name] = self.steps.get(name, 0) + 1     # bias correction counts THIS parameter's updates
-            # bias corrections in double on the host, like torch's scalar path
-            b1 = 1.0 - self.betas[0] ** t
-            b2 = 1.0 - self.betas[1] ** t
-            if p.numel():
-                entries.append((p.data, g, st[0], st[1], p.numel(), b1, math.sqrt(b2)))
-        if not entries:
+        names = tuple(k for k, g in grads.items() if self.params[k].numel())
+        if not names:
             return
-        dev = entries[0][0].device
-        tab, nchunks = _mt_table(entries, dev)
-        L.check(lib.a3d_adamw_step_multi(_ptr(tab), len(entries), nchunks, self.lr, self.betas[0], self.betas[1], self.eps,
-                                         self.weight_decay, grad_scale, _stream(entries[0][0])), "a3d_adamw_step_multi")
+        lay = self._layouts.get(names)
+        ptrs = tuple(self.params[k].data_ptr() for k in names)
+        if lay is None or lay[2] != ptrs:
+            for k in names:
+                p = self.params[k]
+                if not p.is_cuda or p.dtype != torch.float32 or not p.is_contiguous():
+                    raise RuntimeError("AdamW: parameters must be contiguous fp32 CUDA tensors")
+                if k not in self.state:
+                    self.state[k] = (torch.zeros_like(p), torch.zeros_like(p))
+            tab, nchunks = _mt_layout([self.params[k].numel() for k in names])
+            tab["p"] = ptrs
+            tab["m"] = [self.state[k][0].data_ptr() for k in names]
+            tab["v"] = [self.state[k][1].data_ptr() for k in names]
+            if len(self._layouts) > 4:
+                self._layouts.clear()
+            lay = self._layouts[names] = (tab, nchunks, ptrs)
+        tab, nchunks = lay[0].copy(), lay[1]
+        keep = []
+        for k in names:
+            g, p = grads[k], self.params[k]
+            if g.shape != p.shape or not g.is_contiguous():
+                g = g.reshape(p.shape).contiguous()
+            keep.append(g)
+        tab["g"] = [g.data_ptr() for g in keep]
+        # bias corrections in double on the host, like torch's scalar path; every parameter counts ITS updates
+        t = np.array([self.steps.get(k, 0) + 1 for k in names], dtype=np.float64)
+        for k, tk in zip(names, t):
+            self.steps[k] = int(tk)
+        tab["bias1"] = 1.0 - self.betas[0] ** t
+        tab["bias2_sqrt"] = np.sqrt(1.0 - self.betas[1] ** t)
+        dev = self.params[names[0]].device
+        tabd = _to_device(tab, dev)
+        L.check(lib.a3d_adamw_step_multi(_ptr(tabd), len(names), nchunks, self.lr, self.betas[0], self.betas[1], self.eps,
+                                         self.weight_decay, grad_scale, _stream(self.params[names[0]])), "a3d_adamw_step_multi")
 
 
 def dist_all_reduce(t, group=None):
@@ -304,6 +351,7 @@ def _adamw_load_state_dict(self, sd):
     g = sd["param_groups"][0]
     self.lr, self.betas, self.eps, self.weight_decay = g["lr"], tuple(g["betas"]), g["eps"], g["weight_decay"]
     self.state, self.steps = {}, {}
+    self._layouts = {}             # the cached tables point at the old state tensors
     for i, st in sd["state"].items():
         p = self.params[names[int(i)]]
         self.state[names[int(i)]] = (st["exp_avg"].to(p.device, torch.float32).contiguous().clone(),

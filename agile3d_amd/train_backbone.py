@@ -22,14 +22,18 @@ from . import lib as L
 
 
 class _T:
-    """Activation node: value [n + 1, C] (row n = the zero row), level, accumulated gradient (same shape)."""
-    __slots__ = ("v", "level", "g")
+    """Activation node: value [n + 1, C] (row n = the zero row; possibly a column slice of a concatenation's buffer),
+    level, gradient buffer (same shape; ``ginit`` says whether something has been written to it yet -- the first
+    contribution is a plain write, later ones are added inside the producing kernel's epilogue)."""
+    __slots__ = ("v", "level", "g", "ginit")
 
     def __init__(self, v, level):
-        self.v, self.level, self.g = v, level, None
+        self.v, self.level, self.g, self.ginit = v, level, None, False
 
-    def add_grad(self, g):
-        self.g = g if self.g is None else self.g + g
+    def grad_buffer(self):
+        if self.g is None:
+            self.g = torch.empty((self.v.shape[0], self.v.shape[1]), dtype=torch.float32, device=self.v.device)
+        return self.g
 
 
 class _View:
@@ -153,11 +157,19 @@ def _sync_bn_default():
 
 
 class BackboneTape:
+    """Round 5: one library call per conv + BatchNorm (+ residual)(+ ReLU) unit in the forward (the batch statistics come
+    out of the conv kernel's epilogue: no statistics pass over the raw output), concatenations are column slices of one
+    buffer (producers write into their slice, nothing is copied), and in the backward every fan-in is summed inside the
+    producing kernel's epilogue (the input-gradient convs accumulate into the node's gradient buffer): no torch add /
+    cat / copy on the tape.  ``sync_bn`` and the emulated-fp32 build (A3D_CONV_EMU) keep the layer-at-a-time BatchNorm."""
+
     def __init__(self, model, scene, feats3: torch.Tensor, sync_bn=None):
+        import os
         if not feats3.is_cuda:
             raise RuntimeError("BackboneTape runs on the GPU only")
         self.model, self.scene = model, scene
         self.sync_bn = _sync_bn_default() if sync_bn is None else bool(sync_bn)
+        self.fused_bn = not self.sync_bn and os.environ.get("A3D_CONV_EMU", "0") == "0"
         self.feats3 = feats3.to(torch.float32).contiguous()
         self.steps = []          # backward closures, in forward order
         self.relu_levels = []
@@ -165,6 +177,7 @@ class BackboneTape:
         self._names = {id(p): n for n, p in model.named_parameters()}
         self.packed = packed_weights_of(model)
         self.packed.refresh_all()
+        self.state = B.StateArena(self.feats3.device, 320)    # 63 forward convs + <= 4 launches per conv in the backward
         self._bns = []           # the BatchNorms this forward pass ran through (running statistics updated in place)
         self._forward()
         # the kernels wrote running_mean / running_var through raw device pointers: torch's version counters did not
@@ -183,110 +196,183 @@ class BackboneTape:
         g = g.reshape(param.shape)
         self.grads[name] = g if name not in self.grads else self.grads[name] + g
 
-    def _conv(self, kind, x: _T, conv) -> _T:
+    def _new(self, level, C_):
+        return torch.empty((self.scene.n[level] + 1, C_), dtype=torch.float32, device=self.feats3.device)
+
+    def _conv_bn(self, kind, x: _T, conv, norm, res: _T | None = None, relu=True, out=None) -> _T:
+        """conv -> BatchNorm on batch statistics (+ res)(ReLU): one unit of res16unet.py:222-295 / resnet_block.py:48-64.
+        ``out``: the [n_out + 1, cout] view the result is written to (a slice of a concatenation's buffer)."""
         K, cin, cout = conv.kernel3().shape
         wf, wb = self.packed.get(conv, kind)
-        sc = self.scene
-        y = _T(B.conv_apply(sc, kind, x.level, wf, x.v, cin, cout), B.level_out(kind, x.level))
-        n_in, n_out = sc.n[x.level], sc.n[y.level]
-
-        def back():
-            self._pgrad(conv.kernel, B.conv_weight_grad(sc, kind, x.level, x.v[:n_in], y.g[:n_out]))
-            x.add_grad(B.conv_input_grad_apply(sc, kind, x.level, wb, y.g, cin, cout))
-        self.steps.append(back)
-        return y
-
-    def _bn(self, x: _T, norm, res: _T | None = None, relu=True) -> _T:
-        b = norm.bn
+        sc, b = self.scene, norm.bn
         self._bns.append(b)
-        n = self.scene.n[x.level]
-        xv, rv = x.v[:n], (res.v[:n] if res is not None else None)
+        lo = B.level_out(kind, x.level)
+        n_in, n_out = sc.n[x.level], sc.n[lo]
+        yv = out if out is not None else self._new(lo, cout)
+        gamma, beta = b.weight.detach(), b.bias.detach()
         n_glob = None
-        if self.sync_bn:
-            v, mean, rstd, n_glob = B.bn_sync_forward(xv, b.weight.detach(), b.bias.detach(), b.eps, rv, relu, b.running_mean,
-                                                      b.running_var, b.momentum, zero_row=True)
+        if self.fused_bn:
+            raw, mean, rstd = B.conv_bn_train_forward(sc, kind, x.level, wf, x.v, cin, cout, gamma, beta, b.eps,
+                                                      res.v if res is not None else None, relu, yv, b.running_mean,
+                                                      b.running_var, b.momentum, state=self.state)
         else:
-            v, mean, rstd = B.bn_train_forward(xv, b.weight.detach(), b.bias.detach(), b.eps, rv, relu, b.running_mean,
-                                               b.running_var, b.momentum, zero_row=True)
-        y = _T(v, x.level)
+            rawz = self._new(lo, cout)
+            B.conv_apply_acc(sc, kind, x.level, wf, x.v, cin, cout, rawz, zero_row=False, state=self.state)
+            raw = rawz[:n_out]
+            rv = res.v[:n_out] if res is not None else None
+            if self.sync_bn:
+                v, mean, rstd, n_glob = B.bn_sync_forward(raw, gamma, beta, b.eps, rv, relu, b.running_mean, b.running_var,
+                                                          b.momentum, zero_row=True)
+            else:
+                v, mean, rstd = B.bn_train_forward(raw, gamma, beta, b.eps, rv, relu, b.running_mean, b.running_var,
+                                                   b.momentum, zero_row=True)
+            yv.copy_(v)
+        y = _T(yv, lo)
         if relu:
-            self.relu_levels.append((x.level, _View(v[:n])))   # forward order of the ReLUs (tests read the 0/1 masks)
+            self.relu_levels.append((lo, _View(yv[:n_out])))   # forward order of the ReLUs (tests read the 0/1 masks)
 
         def back():
+            # BatchNorm: g = dy (y > 0) -> d(raw) (with its zero row: the input-gradient conv gathers it), d(res) = g
+            draw = self._new(lo, cout)
+            dres = None
+            if res is not None:
+                dres = res.grad_buffer()
+                assert not res.ginit, "the residual branch's gradient is always the first contribution to its node"
+                res.ginit = True
             if self.sync_bn:
-                dx, dg, db, dres = B.bn_sync_backward(xv, v[:n], y.g[:n], b.weight.detach(), mean, rstd, n_glob, relu,
-                                                      res is not None, zero_row=True)
+                dx, dg, db, dr = B.bn_sync_backward(raw, yv[:n_out], y.g[:n_out], gamma, mean, rstd, n_glob, relu,
+                                                    res is not None, zero_row=True)
+                draw.copy_(dx)
+                if dres is not None:
+                    dres.copy_(dr)
             else:
-                dx, dg, db, dres = B.bn_train_backward(xv, v[:n], y.g[:n], b.weight.detach(), mean, rstd, relu,
-                                                       res is not None, zero_row=True)
+                dg, db = B.bn_train_backward_into(raw, yv, y.g, gamma, mean, rstd, relu, draw, dres)
             self._pgrad(b.weight, dg)
             self._pgrad(b.bias, db)
-            x.add_grad(dx)
-            if res is not None:
-                res.add_grad(dres)
+            y.g = None
+            # conv: weight gradient, then the input gradient written / accumulated into the input node's buffer
+            self._pgrad(conv.kernel, B.conv_weight_grad(sc, kind, x.level, x.v[:n_in], draw[:n_out]))
+            B.conv_input_grad_into(sc, kind, x.level, wb, draw, cin, cout, x.grad_buffer(), acc=x.ginit, state=self.state)
+            x.ginit = True
         self.steps.append(back)
         return y
 
-    def _cat(self, a: _T, b: _T) -> _T:
-        y = _T(torch.cat([a.v, b.v], 1), a.level)
+    def _cat(self, buf, a: _T, b: _T) -> _T:
+        """me.cat(a, b) (res16unet.py:257,267,277,287): both producers already wrote into their column slices of ``buf``;
+        in the backward the consumers write into one gradient buffer whose slices ARE the producers' gradients."""
+        y = _T(buf, a.level)
         ca = a.v.shape[1]
 
         def back():
-            a.add_grad(y.g[:, :ca].contiguous())
-            b.add_grad(y.g[:, ca:].contiguous())
+            g = y.g
+            a.g, a.ginit = g[:, :ca], True                 # the up-sampled half has no other consumer
+            if b.g is None:
+                b.g, b.ginit = g[:, ca:], True              # the skip half: its encoder-side consumer accumulates into it later
+            else:
+                b.g.add_(g[:, ca:])
         self.steps.append(back)
         return y
 
-    def _block(self, blk, x: _T) -> _T:
+    def _block(self, blk, x: _T, out=None) -> _T:
         """BasicBlock.forward (resnet_block.py:48-64)."""
-        out = self._bn(self._conv(L.OP_CONV3, x, blk.conv1), blk.norm1)
-        out = self._conv(L.OP_CONV3, out, blk.conv2)
+        h = self._conv_bn(L.OP_CONV3, x, blk.conv1, blk.norm1)
         res = x
         if blk.downsample is not None:
-            res = self._bn(self._conv(L.OP_LINEAR, x, blk.downsample[0]), blk.downsample[1], relu=False)
-        return self._bn(out, blk.norm2, res=res, relu=True)
+            res = self._conv_bn(L.OP_LINEAR, x, blk.downsample[0], blk.downsample[1], relu=False)
+        # conv2 -> norm2 (+ residual) -> ReLU.  Backward order inside the closure list: this unit first (its d(res) is the
+        # first write into the residual node), then the projection, then conv1 -- both accumulate into x
+        return self._conv_bn(L.OP_CONV3, h, blk.conv2, blk.norm2, res=res, relu=True, out=out)
 
-    def _layer(self, blocks, x: _T) -> _T:
-        for blk in blocks:
-            x = self._block(blk, x)
+    def _layer(self, blocks, x: _T, out=None) -> _T:
+        for i, blk in enumerate(blocks):
+            x = self._block(blk, x, out if i == len(blocks) - 1 else None)
         return x
 
     # ------------------------------------------------------------------ forward (res16unet.py:222-295)
     def _forward(self):
         bb, sc = self.model.backbone, self.scene
+        P = bb.PLANES
         w0 = bb.conv0p1s1.kernel3().detach().contiguous()
+        # the concatenation buffers [up-sampled | skip] (me.cat puts the skip LAST): the encoder's skip tensors and the
+        # transposed convs' outputs are written straight into their column slices
+        cat8 = self._new(0, P[7] + 32)
+        cat7 = self._new(1, P[6] + P[0])
+        cat6 = self._new(2, P[5] + P[1])
+        cat5 = self._new(3, P[4] + P[2])
         stem = _T(_run_stem(sc, w0, self.feats3, w0.shape[0]), 0)
 
         def stem_back():
             self._pgrad(bb.conv0p1s1.kernel, B.stem_weight_grad(sc, self.feats3, stem.g[:sc.n[0]], w0.shape[0]))
         self.steps.append(stem_back)
-        out_p1 = self._bn(stem, bb.bn0)
-        out = self._bn(self._conv(L.OP_DOWN, out_p1, bb.conv1p1s2), bb.bn1)
-        out_b1p2 = self._layer(bb.block1, out)
-        out = self._bn(self._conv(L.OP_DOWN, out_b1p2, bb.conv2p2s2), bb.bn2)
-        out_b2p4 = self._layer(bb.block2, out)
-        out = self._bn(self._conv(L.OP_DOWN, out_b2p4, bb.conv3p4s2), bb.bn3)
-        out_b3p8 = self._layer(bb.block3, out)
-        out = self._bn(self._conv(L.OP_DOWN, out_b3p8, bb.conv4p8s2), bb.bn4)
+        out_p1 = self._bn_only(stem, bb.bn0, cat8[:, P[7]:])
+        out = self._conv_bn(L.OP_DOWN, out_p1, bb.conv1p1s2, bb.bn1)
+        out_b1p2 = self._layer(bb.block1, out, cat7[:, P[6]:])
+        out = self._conv_bn(L.OP_DOWN, out_b1p2, bb.conv2p2s2, bb.bn2)
+        out_b2p4 = self._layer(bb.block2, out, cat6[:, P[5]:])
+        out = self._conv_bn(L.OP_DOWN, out_b2p4, bb.conv3p4s2, bb.bn3)
+        out_b3p8 = self._layer(bb.block3, out, cat5[:, P[4]:])
+        out = self._conv_bn(L.OP_DOWN, out_b3p8, bb.conv4p8s2, bb.bn4)
         out = self._layer(bb.block4, out)
-        out = self._bn(self._conv(L.OP_UP, out, bb.convtr4p16s2), bb.bntr4)
-        out = self._layer(bb.block5, self._cat(out, out_b3p8))
-        out = self._bn(self._conv(L.OP_UP, out, bb.convtr5p8s2), bb.bntr5)
-        out = self._layer(bb.block6, self._cat(out, out_b2p4))
-        out = self._bn(self._conv(L.OP_UP, out, bb.convtr6p4s2), bb.bntr6)
-        out = self._layer(bb.block7, self._cat(out, out_b1p2))
-        out = self._bn(self._conv(L.OP_UP, out, bb.convtr7p2s2), bb.bntr7)
-        out = self._layer(bb.block8, self._cat(out, out_p1))
+        up = self._conv_bn(L.OP_UP, out, bb.convtr4p16s2, bb.bntr4, out=cat5[:, :P[4]])
+        out = self._layer(bb.block5, self._cat(cat5, up, out_b3p8))
+        up = self._conv_bn(L.OP_UP, out, bb.convtr5p8s2, bb.bntr5, out=cat6[:, :P[5]])
+        out = self._layer(bb.block6, self._cat(cat6, up, out_b2p4))
+        up = self._conv_bn(L.OP_UP, out, bb.convtr6p4s2, bb.bntr6, out=cat7[:, :P[6]])
+        out = self._layer(bb.block7, self._cat(cat7, up, out_b1p2))
+        up = self._conv_bn(L.OP_UP, out, bb.convtr7p2s2, bb.bntr7, out=cat8[:, :P[7]])
+        out = self._layer(bb.block8, self._cat(cat8, up, out_p1))
         # lin_squeeze_head: 1x1 conv + bias (agile3d.py:43-45,179), back to the caller's row order
         head = self.model.lin_squeeze_head
-        y = self._conv(L.OP_LINEAR, out, head)
-        self.head_out = y
-        self.orig_row = sc.table_dev(0, L.TAB_ORIGROW)[:sc.n[0]].long()
-        bias = head.bias.detach().reshape(1, -1)
+        K, cin, cout = head.kernel3().shape
+        wf, wb = self.packed.get(head, L.OP_LINEAR)
         n0 = sc.n[0]
-        pcd = torch.empty((n0, y.v.shape[1]), dtype=torch.float32, device=y.v.device)
-        pcd[self.orig_row] = y.v[:n0] + bias
+        yh = self._new(0, cout)
+        B.conv_apply_acc(sc, L.OP_LINEAR, 0, wf, out.v, cin, cout, yh, state=self.state)
+        self.head_out = _T(yh, 0)
+        x_head = out
+
+        def head_back():
+            g = self.head_out.g
+            self._pgrad(head.kernel, B.conv_weight_grad(sc, L.OP_LINEAR, 0, x_head.v[:n0], g[:n0]))
+            B.conv_input_grad_into(sc, L.OP_LINEAR, 0, wb, g, cin, cout, x_head.grad_buffer(), acc=x_head.ginit, state=self.state)
+            x_head.ginit = True
+        self.steps.append(head_back)
+        self.orig_row = sc.table_dev(0, L.TAB_ORIGROW)[:n0].long()
+        bias = head.bias.detach().reshape(1, -1)
+        pcd = torch.empty((n0, cout), dtype=torch.float32, device=yh.device)
+        pcd[self.orig_row] = yh[:n0] + bias
         self.output = pcd
+
+    def _bn_only(self, x: _T, norm, out) -> _T:
+        """bn0 + ReLU behind the input convolution (res16unet.py:225-227): the stem kernel has no statistics epilogue."""
+        b = norm.bn
+        self._bns.append(b)
+        n = self.scene.n[x.level]
+        xv = x.v[:n]
+        gamma, beta = b.weight.detach(), b.bias.detach()
+        n_glob = None
+        if self.sync_bn:
+            v, mean, rstd, n_glob = B.bn_sync_forward(xv, gamma, beta, b.eps, None, True, b.running_mean, b.running_var,
+                                                      b.momentum, zero_row=True)
+        else:
+            v, mean, rstd = B.bn_train_forward(xv, gamma, beta, b.eps, None, True, b.running_mean, b.running_var, b.momentum,
+                                               zero_row=True)
+        out.copy_(v)
+        y = _T(out, x.level)
+        self.relu_levels.append((x.level, _View(out[:n])))
+
+        def back():
+            dx = x.grad_buffer()
+            if self.sync_bn:
+                d, dg, db, _ = B.bn_sync_backward(xv, out[:n], y.g[:n], gamma, mean, rstd, n_glob, True, False, zero_row=True)
+                dx.copy_(d)
+            else:
+                dg, db = B.bn_train_backward_into(xv, out, y.g, gamma, mean, rstd, True, dx, None)
+            x.ginit = True
+            self._pgrad(b.weight, dg)
+            self._pgrad(b.bias, db)
+        self.steps.append(back)
+        return y
 
     def release(self):
         """Drop the recorded steps and activations (the backward closures and the tape refer to each other: without this the

@@ -355,41 +355,43 @@ class DecoderTape:
         E = self.lin(e, "mask_embed_head.2.weight", "mask_embed_head.2.bias")
         dev = src.v.device
         outs, saved = [], []
+
+        def padded(Q):      # the GEMM kernels write 32 / 64 / 96 or multiples of 128 output columns
+            return 32 if Q <= 32 else 64 if Q <= 64 else 96 if Q <= 96 else (Q + 127) // 128 * 128
         for (n0, n1), (q0, q1), grp in zip(n_ranges, q_ranges, groups):
             N, Q, G = n1 - n0, q1 - q0, len(grp)
-            sv, Ev = src.v[n0:n1], E.v[q0:q1]
-            lq = torch.empty((N, Q), dtype=torch.float32, device=dev)
-            L.check(lib.a3d_attn_scores(_ptr(sv), _ptr(Ev), N, Q, 1, 128, 1.0, None, _ptr(lq), _stream()), "scores")
+            Qp = padded(Q)
+            sv = src.v[n0:n1]
+            # logits of every query on the matrix cores: [N, 128] x [128, Qp] with the embeddings zero-padded to Qp
+            # columns (round 5; the one-thread-per-output kernel took 170 us per sample and layer at 80 k points); the
+            # padded columns stay in the row layout, no group covers them
+            Ep = torch.zeros((Qp, 128), dtype=torch.float32, device=dev)
+            Ep[:Q] = E.v[q0:q1]
+            lq = _linear(sv, _pack(Ep.t().contiguous()))
             qb = torch.tensor([g[0] for g in grp], dtype=torch.int32, device=dev)
             qe = torch.tensor([g[1] for g in grp], dtype=torch.int32, device=dev)
             out = torch.empty((N, G), dtype=torch.float32, device=dev)
             arg = torch.empty((N, G), dtype=torch.int32, device=dev)
-            L.check(lib.a3d_group_max(_ptr(lq), N, Q, _ptr(qb), _ptr(qe), G, _ptr(out), _ptr(arg), _stream()), "group_max")
+            L.check(lib.a3d_group_max(_ptr(lq), N, Qp, _ptr(qb), _ptr(qe), G, _ptr(out), _ptr(arg), _stream()), "group_max")
             outs.append(_T(out))
-            saved.append(arg)
+            saved.append((arg, Ep, Qp))
             self.args.append(arg)
 
         def back():
             dsrc = torch.empty_like(src.v)                # every sample's rows are written below (or cleared: no loss there)
             dE = torch.zeros_like(E.v)
-            for (n0, n1), (q0, q1), grp, y, arg in zip(n_ranges, q_ranges, groups, outs, saved):
+            for (n0, n1), (q0, q1), grp, y, (arg, Ep, Qp) in zip(n_ranges, q_ranges, groups, outs, saved):
                 if y.g is None:
                     dsrc[n0:n1].zero_()
                     continue
                 N, Q, G = n1 - n0, q1 - q0, len(grp)
-                dlq = torch.empty((N, Q), dtype=torch.float32, device=dev)
-                L.check(lib.a3d_group_max_backward(_ptr(y.g.contiguous()), _ptr(arg), N, Q, G, _ptr(dlq), _stream()), "gm_bwd")
-                _apply(dlq, E.v[q0:q1], N, Q, 1, 128, 0, 1.0, dsrc[n0:n1])
-                # dE [Q, 128] = dlq^T src is a weight gradient (rows = the MFMA k dimension, wgrad.hip): the N-long reduction
-                # runs on the matrix cores instead of the one-thread-per-output split kernel (0.47 ms per call); the kernel
-                # wants channel counts in multiples of 32, so the Q columns are padded with zeros
-                Qp = (Q + 31) // 32 * 32
-                if Qp != Q:
-                    dlq_p = torch.zeros((N, Qp), dtype=torch.float32, device=dev)
-                    dlq_p[:, :Q] = dlq
-                else:
-                    dlq_p = dlq
-                dE[q0:q1] = B.linear_weight_grad(dlq_p, src.v[n0:n1])[:Q]
+                dlq = torch.empty((N, Qp), dtype=torch.float32, device=dev)
+                L.check(lib.a3d_group_max_backward(_ptr(y.g.contiguous()), _ptr(arg), N, Qp, G, _ptr(dlq), _stream()), "gm_bwd")
+                # d(src) = dlq Ep and dE = dlq^T src: both on the matrix cores (a GEMM and a weight-gradient reduction over
+                # the N rows, wgrad.hip), the padded query columns carry zeros
+                lib_out = _linear(dlq, _pack(Ep))
+                dsrc[n0:n1] = lib_out
+                dE[q0:q1] = B.linear_weight_grad(dlq, src.v[n0:n1])[:Q]
             src.add_grad(dsrc)
             E.add_grad(dE)
         self.steps.append(back)

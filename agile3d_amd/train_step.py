@@ -145,12 +145,15 @@ def _train_one_step(model, criterion, optimizer, batch, device, max_norm):
 
     mark("decoder forward")
     # ---- losses (engine.py:124-128) and their gradient with respect to every level's logits
-    click_weights = cal_click_loss_weights(batch_idx, raw_coords, torch.cat(labels_new), click_idx)
-    loss_dict = criterion(outputs, labels_new, click_weights)
-    total = sum(float(loss_dict[k]) * criterion.weight_dict[k] for k in loss_dict if k in criterion.weight_dict)
+    # one pass of the loss kernel per level and sample gives the values AND the gradient; one host round trip for all values
+    click_weights = cal_click_loss_weights(batch_idx, raw_coords, None, click_idx, ranges=ranges)
+    targets = [l.to(torch.int32) for l in labels_new]
+    loss_dict, gl = criterion.forward_and_grad(outputs, targets, click_weights)
+    loss_keys = list(loss_dict)
+    loss_vals = dict(zip(loss_keys, torch.stack([loss_dict[k] for k in loss_keys]).tolist()))
+    total = sum(loss_vals[k] * criterion.weight_dict[k] for k in loss_keys if k in criterion.weight_dict)
     if not np.isfinite(total):
         raise FloatingPointError(f"Loss is {total}, stopping training")
-    gl = criterion.grad_logits(outputs, labels_new, click_weights)
 
     mark("losses")
     # ---- backward: decoders, then the backbone through d(pcd_features)
@@ -176,7 +179,7 @@ def _train_one_step(model, criterion, optimizer, batch, device, max_norm):
     optimizer.step(grads, coef)
     eng.mark_stale()
     mark("clip + AdamW")
-    stats = {"loss": total, "grad_norm": norm, "loss_dict": {k: float(v) for k, v in loss_dict.items()},
+    stats = {"loss": total, "grad_norm": norm, "loss_dict": loss_vals,
              "clicks": [sum(len(v) for v in c.values()) for c in click_idx], "click_rounds": num_forward_iters}
     if timing:
         import sys

@@ -203,6 +203,29 @@ int    a3d_conv_apply(const a3d_scene* s, int kind, int level_in, const float* x
                       const float* w_packed_dev, int cout, float* y_dev, int ldy, int y_zero_row,
                       void* workspace_dev, size_t workspace_bytes, void* stream);
 
+/* The same convolution with what the training tapes need on top (round 5):
+ *   a3d_conv_apply_acc: y = conv(x) + res  -- res_dev [n_out][ldr] may be y itself: a gradient accumulated IN the conv's
+ *     epilogue (the input-gradient convs of a node with several consumers: no separate add pass);
+ *     state_dev: a3d_conv_state_bytes() bytes ZEROED by the caller (the kernel's hand-off ticket and flags; one block per
+ *     conv of an iteration, cleared with one memset for all of them) or NULL (cleared here, one memset per call).
+ *   a3d_conv_bn_train_forward: conv -> BatchNorm on the statistics of THIS batch (+ res)(ReLU), the block of
+ *     BasicBlock.forward (resnet_block.py:48-64) in training mode: raw_dev [n_out][ld_raw] = the conv's output (kept for
+ *     the backward), y_dev as a3d_bn_train_forward's.  The batch statistics come out of the conv kernel's epilogue (per
+ *     64-row tile: column sums and squared deviations from the tile mean, merged in fp64 in a fixed order), so the raw
+ *     output is not read again for them.  Exact-fp32 builds only (not under A3D_CONV_EMU). */
+size_t a3d_conv_state_bytes(void);
+int    a3d_conv_apply_acc(const a3d_scene* s, int kind, int level_in, const float* x_dev, int ldx, int cin,
+                          const float* w_packed_dev, int cout, float* y_dev, int ldy, int y_zero_row,
+                          const float* res_dev, int ldr, void* state_dev, void* workspace_dev, size_t workspace_bytes,
+                          void* stream);
+size_t a3d_conv_bn_train_workspace_bytes(const a3d_scene* s, int kind, int level_in, int cin, int cout);
+int    a3d_conv_bn_train_forward(const a3d_scene* s, int kind, int level_in, const float* x_dev, int ldx, int cin,
+                                 const float* w_packed_dev, int cout, float* raw_dev, int ld_raw,
+                                 const float* gamma_dev, const float* beta_dev, float eps, const float* res_dev, int ldr,
+                                 int relu, float* y_dev, int ldy, int y_zero_row, float* save_mean_dev,
+                                 float* save_rstd_dev, float* running_mean_dev, float* running_var_dev, float momentum,
+                                 void* state_dev, void* workspace_dev, size_t workspace_bytes, void* stream);
+
 /* weight gradient of the input convolution conv0p1s1 (5^3 or 3^3, 3 -> 32; res16unet.py:225): feats3_dev in the
  * caller's row order as for a3d_program_run, dy_dev [n0][lddy >= 32] in internal row order, dw_dev [K][3][32] */
 size_t a3d_stem_wgrad_workspace_bytes(int kernel_volume);

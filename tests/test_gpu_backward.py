@@ -144,6 +144,63 @@ def test_batchnorm_training_forward_backward_vs_torch(n, C, relu, with_res):
     assert torch.equal(B.column_sums(dy.cuda()), s)      # deterministic
 
 
+FUSED = [(L.OP_CONV3, 0, 96, 96), (L.OP_CONV3, 0, 128, 96), (L.OP_CONV3, 1, 32, 32), (L.OP_CONV3, 2, 64, 64),
+         (L.OP_CONV3, 3, 128, 128), (L.OP_CONV3, 4, 256, 256), (L.OP_DOWN, 0, 32, 32), (L.OP_DOWN, 2, 64, 64),
+         (L.OP_UP, 1, 96, 96), (L.OP_UP, 4, 256, 256), (L.OP_LINEAR, 0, 128, 96), (L.OP_LINEAR, 3, 384, 256),
+         (L.OP_LINEAR, 2, 32, 64)]
+
+
+@pytest.mark.parametrize("kind,level_in,cin,cout", FUSED)
+def test_conv_bn_unit_with_statistics_from_the_conv_epilogue(world, kind, level_in, cin, cout):
+    """a3d_conv_bn_train_forward (round 5: conv -> BatchNorm(train) (+ res)(ReLU) in one call, the batch statistics taken
+    per tile in the conv kernel's epilogue) against float64: raw output, mean / rstd, running statistics, y written into a
+    column slice of a wider buffer, for every kernel family the training convs run on (k_conv_sk with and without
+    hand-offs, the LDS-resident 32-channel kernel, 1x1)."""
+    sc, lv, maps = world
+    lo = B.level_out(kind, level_in)
+    n_in, n_out = sc.n[level_in], sc.n[lo]
+    g = torch.Generator().manual_seed(kind * 1000 + level_in * 100 + cin + cout)
+    K = {L.OP_CONV3: 27, L.OP_DOWN: 8, L.OP_UP: 8, L.OP_LINEAR: 1}[kind]
+    X = torch.randn(n_in, cin, generator=g)
+    W = torch.randn(K, cin, cout, generator=g) / (cin * 4) ** 0.5
+    R = torch.randn(n_out, cout, generator=g)
+    gamma, beta = torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g)
+    rm, rv = torch.randn(cout, generator=g) * 0.1, torch.rand(cout, generator=g) + 0.5
+    m_in, m_out = maps[level_in], maps[lo]
+    raw_ref = ob.sparse_conv(X.double(), W.double(), _kmap(lv, kind, level_in), n_out) + 0.3     # a mean away from zero
+    raw_ref = raw_ref - 0.3
+    rm_ref, rv_ref = rm.double().clone(), rv.double().clone()
+    y_ref = torch.relu(torch.nn.functional.batch_norm(raw_ref, rm_ref, rv_ref, gamma.double(), beta.double(), training=True,
+                                                      momentum=0.02, eps=1e-5) + R.double())
+    x = torch.zeros(n_in + 1, cin + 32, device="cuda")
+    x[:n_in, 32:] = X[m_in].cuda()
+    ybuf = torch.full((n_out + 1, cout + 64), float("nan"), device="cuda")
+    rm_d, rv_d = rm.cuda(), rv.cuda()
+    state = B.StateArena(torch.device("cuda"), 4)
+    raw, mean, rstd = B.conv_bn_train_forward(sc, kind, level_in, B.pack_weight(W.cuda()), x[:, 32:], cin, cout, gamma.cuda(),
+                                              beta.cuda(), 1e-5, R[m_out].cuda(), True, ybuf[:, 64:], rm_d, rv_d, 0.02, state=state)
+    scale = max(1.0, raw_ref.abs().max().item())
+    assert (raw.cpu().double() - raw_ref[m_out]).abs().max().item() <= 2e-5 * scale
+    assert (mean.cpu().double() - raw_ref.mean(0)).abs().max().item() <= 2e-6 * scale
+    var = raw_ref.var(0, unbiased=False)
+    assert ((rstd.cpu().double() - 1 / torch.sqrt(var + 1e-5)).abs() * torch.sqrt(var + 1e-5)).max().item() <= 2e-5
+    assert (ybuf[:n_out, 64:].cpu().double() - y_ref[m_out]).abs().max().item() <= 5e-5 * scale
+    assert (ybuf[n_out, 64:] == 0).all() and torch.isnan(ybuf[:, :64]).all()          # zero row written, nothing outside the slice
+    assert (rm_d.cpu().double() - rm_ref).abs().max().item() <= 2e-6 * scale
+    assert (rv_d.cpu().double() - rv_ref).abs().max().item() <= 2e-5 * max(1.0, rv_ref.abs().max().item())
+    # bit-determinism of the statistics (fixed summation orders, hand-offs included)
+    ybuf2 = torch.empty_like(ybuf)
+    raw2, mean2, rstd2 = B.conv_bn_train_forward(sc, kind, level_in, B.pack_weight(W.cuda()), x[:, 32:], cin, cout, gamma.cuda(),
+                                                 beta.cuda(), 1e-5, R[m_out].cuda(), True, ybuf2[:, 64:], rm.cuda(), rv.cuda(), 0.02,
+                                                 state=state)
+    assert torch.equal(mean, mean2) and torch.equal(rstd, rstd2) and torch.equal(raw, raw2)
+    # accumulation in the epilogue: y += conv(x) on a column slice
+    acc = torch.randn(n_out + 1, cout + 32, generator=g).cuda()
+    want = acc[:n_out, 32:].double().cpu() + raw_ref[m_out]
+    B.conv_apply_acc(sc, kind, level_in, B.pack_weight(W.cuda()), x[:, 32:], cin, cout, acc[:, 32:], acc=True, state=state)
+    assert (acc[:n_out, 32:].cpu().double() - want).abs().max().item() <= 2e-5 * max(1.0, want.abs().max().item())
+
+
 @pytest.mark.parametrize("ks", [5, 3])
 def test_stem_weight_grad_matches_autograd(world, ks):
     sc, lv, maps = world

@@ -1,14 +1,13 @@
 #!/bin/bash
 # Scratch script of the current GPU session (overwritten per session; `gpurun -- 'bash tools/gpu_session.sh'`).
-# Every command under its own `timeout`: a host-side hang otherwise runs into the session limit.
 R=$GRAFT_REPO_ROOT
-O=$R/gpurun_out/s1
+O=$R/gpurun_out/s2
 mkdir -p $O
 cd $R
-timeout 900 python -m pytest tests/test_gpu_conv.py -x -q -k "fused_projection" > $O/t_conv.log 2>&1; echo "rc=$?" >> $O/t_conv.log
-timeout 900 python -m pytest tests/test_gpu_clicks.py -x -q -k "bounded" > $O/t_clicks.log 2>&1; echo "rc=$?" >> $O/t_clicks.log
+timeout 1500 python -m pytest tests/test_gpu_backward.py -x -q -k "conv_bn_unit or batchnorm" > $O/t_unit.log 2>&1; echo "rc=$?" >> $O/t_unit.log
+timeout 2400 python -m pytest tests/test_gpu_backward.py -x -q > $O/t_backward.log 2>&1; echo "rc=$?" >> $O/t_backward.log
+timeout 1500 python -m pytest tests/test_gpu_distributed.py -x -q > $O/t_dist.log 2>&1; echo "rc=$?" >> $O/t_dist.log
 timeout 1500 python -m pytest tests/test_gpu_fit.py -x -q -s > $O/t_fit.log 2>&1; echo "rc=$?" >> $O/t_fit.log
-timeout 1500 python -m pytest tests/test_gpu_distributed.py -x -q -s -k "eight_ranks" > $O/t_dist8.log 2>&1; echo "rc=$?" >> $O/t_dist8.log
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/trt
 A3D_BB_ITERS=6 A3D_TRAIN_TIMING=mark timeout 900 rocprofv3 --kernel-trace -d /tmp/trt -o t -- python $R/tools/backward_bench.py --step --reps 1 > $O/train_trace.log 2>&1
