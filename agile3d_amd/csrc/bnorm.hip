@@ -151,43 +151,58 @@ __global__ void __launch_bounds__(256) k_bn_combine(const float* __restrict__ pa
 // block sums (fp64) -> the batch mean; pass 2 shifts every block's M2 to that mean with the exact identity
 //   sum (v - mean)^2 = M2_b + 2 (m_b - mean) (S_b - n_b m_b) + n_b (m_b - mean)^2        (m_b = the fp32 mean the block used)
 // 64 lanes per column, 16 columns per 1024-thread workgroup, every partial sum in a fixed order.
-constexpr int kFin2Lanes = 64;
+constexpr int kFin2Lanes = 256;
 __global__ void __launch_bounds__(1024) k_bn_combine_tiles(const float* __restrict__ partial, int nblocks, int rows_per_block, int n,
                                                            int C, float eps, float* mean_out, float* rstd_out, float* running_mean,
                                                            float* running_var, float momentum) {
-  __shared__ double sh[kFin2Lanes][kFinCols];
+  // thread (bl, q): block lane bl of 256, column quad q of the workgroup's 4 (16 columns per workgroup): one 16-byte load
+  // per block and thread, blocks bl, bl + 256, ... (20 rounds for the 5 000 tiles of a 320 k-row level)
+  __shared__ double sh[kFin2Lanes][kFinCols + 1];
   __shared__ double s_mean[kFinCols];
-  const int cc = threadIdx.x % kFinCols, bl = threadIdx.x / kFinCols;
-  const int c = blockIdx.x * kFinCols + cc;
-  double s = 0.0;
-  if (c < C)
-    for (int b = bl; b < nblocks; b += kFin2Lanes) s += (double)partial[(size_t)b * 2 * C + c];
-  sh[bl][cc] = s;
+  const int q = threadIdx.x & 3, bl = threadIdx.x >> 2;
+  const int c0 = blockIdx.x * kFinCols + 4 * q;
+  const bool live = c0 < C;                          // C is a multiple of 4 (of 32)
+  double s[4] = {0.0, 0.0, 0.0, 0.0};
+  if (live)
+    for (int b = bl; b < nblocks; b += kFin2Lanes) {
+      const f32x4 v = *(const f32x4*)(partial + (size_t)b * 2 * C + c0);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) s[t] += (double)v[t];
+    }
+#pragma unroll
+  for (int t = 0; t < 4; ++t) sh[bl][4 * q + t] = s[t];
   __syncthreads();
-  if (bl == 0) {
+  if (threadIdx.x < kFinCols) {
     double t = 0.0;
-    for (int k = 0; k < kFin2Lanes; ++k) t += sh[k][cc];
-    s_mean[cc] = t / (double)n;
+    for (int k = 0; k < kFin2Lanes; ++k) t += sh[k][threadIdx.x];
+    s_mean[threadIdx.x] = t / (double)n;
   }
   __syncthreads();
-  const double mean = s_mean[cc];
-  double q = 0.0;
-  if (c < C)
+  double m2s[4] = {0.0, 0.0, 0.0, 0.0};
+  if (live)
     for (int b = bl; b < nblocks; b += kFin2Lanes) {
       const int nbi = min(n, (b + 1) * rows_per_block) - b * rows_per_block;
-      const float bsf = partial[(size_t)b * 2 * C + c];
-      const double nb = (double)nbi, bs = (double)bsf, bm2 = (double)partial[(size_t)b * 2 * C + C + c];
-      const double m_used = (double)(bsf * (1.f / (float)nbi));
-      const double dm = m_used - mean;
-      q += bm2 + 2.0 * dm * (bs - nb * m_used) + nb * dm * dm;
+      const f32x4 bsf = *(const f32x4*)(partial + (size_t)b * 2 * C + c0);
+      const f32x4 bq = *(const f32x4*)(partial + (size_t)b * 2 * C + C + c0);
+      const double nb = (double)nbi;
+      const float invf = 1.f / (float)nbi;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const double m_used = (double)(bsf[t] * invf);
+        const double dm = m_used - s_mean[4 * q + t];
+        m2s[t] += (double)bq[t] + 2.0 * dm * ((double)bsf[t] - nb * m_used) + nb * dm * dm;
+      }
     }
-  sh[bl][cc] = q;
   __syncthreads();
-  if (bl != 0 || c >= C) return;
+#pragma unroll
+  for (int t = 0; t < 4; ++t) sh[bl][4 * q + t] = m2s[t];
+  __syncthreads();
+  const int c = blockIdx.x * kFinCols + threadIdx.x;
+  if (threadIdx.x >= kFinCols || c >= C) return;
   double m2 = 0.0;
-  for (int k = 0; k < kFin2Lanes; ++k) m2 += sh[k][cc];
+  for (int k = 0; k < kFin2Lanes; ++k) m2 += sh[k][threadIdx.x];
   if (m2 < 0.0) m2 = 0.0;
-  const double cnt = (double)n;
+  const double cnt = (double)n, mean = s_mean[threadIdx.x];
   const float var = (float)(m2 / cnt);
   mean_out[c] = (float)mean;
   rstd_out[c] = 1.0f / sqrtf(var + eps);
@@ -397,6 +412,96 @@ __global__ void __launch_bounds__(256) k_ln_backward(const LnArgs a) {
     // [2][C]: dbeta sums first, dgamma second (k_col_final sums column-wise over the blocks)
     a.partial[(size_t)blockIdx.x * 2 * a.C + c] = red[1][0][c] + red[1][1][c] + red[1][2][c] + red[1][3][c];
     a.partial[(size_t)blockIdx.x * 2 * a.C + a.C + c] = red[0][0][c] + red[0][1][c] + red[0][2][c] + red[0][3][c];
+  }
+}
+// C = 128 (every LayerNorm of the decoder): FOUR rows per wave -- 16 lanes per row, 8 channels (two 16-byte accesses) per
+// lane, the row reductions over 16 lanes --, the next four rows' loads in flight behind the current ones' arithmetic.  The
+// one-row-per-wave kernels above issue 4-byte accesses and four dependent shuffle trees per row: 950 us for the backward
+// over 320 k rows (0.5 GB: 100 us at the HBM rate).
+__device__ __forceinline__ float ln16_sum(float v) {
+  v += __shfl_xor(v, 1, 16);
+  v += __shfl_xor(v, 2, 16);
+  v += __shfl_xor(v, 4, 16);
+  v += __shfl_xor(v, 8, 16);
+  return v;
+}
+__global__ void __launch_bounds__(256) k_ln_forward128(const LnArgs a) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane >> 4, j = lane & 15;
+  const int row = blockIdx.x * 16 + wave * 4 + r;
+  if (row >= a.n) return;
+  const float* xp = a.x + (size_t)row * a.ldx + 8 * j;
+  const f32x4 v0 = *(const f32x4*)xp, v1 = *(const f32x4*)(xp + 4);
+  const float mean = ln16_sum(((v0[0] + v0[1]) + (v0[2] + v0[3])) + ((v1[0] + v1[1]) + (v1[2] + v1[3]))) * (1.f / 128.f);
+  const f32x4 d0 = v0 - mean, d1 = v1 - mean;
+  const float q = ln16_sum(((d0[0] * d0[0] + d0[1] * d0[1]) + (d0[2] * d0[2] + d0[3] * d0[3])) +
+                           ((d1[0] * d1[0] + d1[1] * d1[1]) + (d1[2] * d1[2] + d1[3] * d1[3])));
+  const float rstd = 1.0f / sqrtf(q * (1.f / 128.f) + a.eps);
+  const f32x4 g0 = *(const f32x4*)(a.gamma + 8 * j), g1 = *(const f32x4*)(a.gamma + 8 * j + 4);
+  const f32x4 b0 = *(const f32x4*)(a.beta + 8 * j), b1 = *(const f32x4*)(a.beta + 8 * j + 4);
+  float* yp = a.y + (size_t)row * a.ldy + 8 * j;
+  *(f32x4*)yp = d0 * rstd * g0 + b0;
+  *(f32x4*)(yp + 4) = d1 * rstd * g1 + b1;
+}
+__global__ void __launch_bounds__(256) k_ln_backward128(const LnArgs a) {
+  __shared__ __attribute__((aligned(16))) float red[2][4][128];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane >> 4, j = lane & 15;
+  const int r0 = blockIdx.x * a.rows_per_block, r1 = min(a.n, r0 + a.rows_per_block);
+  const f32x4 ga0 = *(const f32x4*)(a.gamma + 8 * j), ga1 = *(const f32x4*)(a.gamma + 8 * j + 4);
+  f32x4 dg0 = (f32x4){0.f, 0.f, 0.f, 0.f}, dg1 = dg0, db0 = dg0, db1 = dg0;
+  int row = r0 + wave * 4 + r;
+  f32x4 nv0 = dg0, nv1 = dg0, ng0 = dg0, ng1 = dg0;
+  auto fetch = [&](int rw) {
+    if (rw < r1) {
+      const float* xp = a.x + (size_t)rw * a.ldx + 8 * j;
+      const float* gp = a.dy + (size_t)rw * a.ldy + 8 * j;
+      nv0 = *(const f32x4*)xp, nv1 = *(const f32x4*)(xp + 4);
+      ng0 = *(const f32x4*)gp, ng1 = *(const f32x4*)(gp + 4);
+    }
+  };
+  fetch(row);
+  // (a wave's four row slots run in lock step: the loop bound is the slot-0 row, slots past the end are masked)
+  for (int base = r0 + wave * 4; base < r1; base += 16) {
+    const bool ok = row < r1;
+    f32x4 v0 = nv0, v1 = nv1, g0 = ng0, g1 = ng1;
+    if (!ok) v0 = v1 = g0 = g1 = (f32x4){0.f, 0.f, 0.f, 0.f};
+    fetch(row + 16);
+    const float mean = ln16_sum(((v0[0] + v0[1]) + (v0[2] + v0[3])) + ((v1[0] + v1[1]) + (v1[2] + v1[3]))) * (1.f / 128.f);
+    f32x4 x0 = v0 - mean, x1 = v1 - mean;
+    const float q = ln16_sum(((x0[0] * x0[0] + x0[1] * x0[1]) + (x0[2] * x0[2] + x0[3] * x0[3])) +
+                             ((x1[0] * x1[0] + x1[1] * x1[1]) + (x1[2] * x1[2] + x1[3] * x1[3])));
+    const float rstd = 1.0f / sqrtf(q * (1.f / 128.f) + a.eps);
+    x0 = x0 * rstd, x1 = x1 * rstd;            // xhat
+    dg0 += g0 * x0, dg1 += g1 * x1;
+    db0 += g0, db1 += g1;
+    g0 = g0 * ga0, g1 = g1 * ga1;              // gh
+    const float m1 = ln16_sum(((g0[0] + g0[1]) + (g0[2] + g0[3])) + ((g1[0] + g1[1]) + (g1[2] + g1[3]))) * (1.f / 128.f);
+    const float m2 = ln16_sum(((g0[0] * x0[0] + g0[1] * x0[1]) + (g0[2] * x0[2] + g0[3] * x0[3])) +
+                              ((g1[0] * x1[0] + g1[1] * x1[1]) + (g1[2] * x1[2] + g1[3] * x1[3]))) * (1.f / 128.f);
+    if (ok) {
+      float* dp = a.dx + (size_t)row * a.ldx + 8 * j;
+      *(f32x4*)dp = rstd * (g0 - m1 - x0 * m2);
+      *(f32x4*)(dp + 4) = rstd * (g1 - m1 - x1 * m2);
+    }
+    row += 16;
+  }
+  // fold the four row slots of the wave (lanes j, j + 16, j + 32, j + 48), then the four waves through LDS: fixed orders
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    dg0[t] += __shfl_xor(dg0[t], 16, 64), dg0[t] += __shfl_xor(dg0[t], 32, 64);
+    dg1[t] += __shfl_xor(dg1[t], 16, 64), dg1[t] += __shfl_xor(dg1[t], 32, 64);
+    db0[t] += __shfl_xor(db0[t], 16, 64), db0[t] += __shfl_xor(db0[t], 32, 64);
+    db1[t] += __shfl_xor(db1[t], 16, 64), db1[t] += __shfl_xor(db1[t], 32, 64);
+  }
+  if (r == 0) {
+    *(f32x4*)&red[0][wave][8 * j] = dg0, *(f32x4*)&red[0][wave][8 * j + 4] = dg1;
+    *(f32x4*)&red[1][wave][8 * j] = db0, *(f32x4*)&red[1][wave][8 * j + 4] = db1;
+  }
+  __syncthreads();
+  if (threadIdx.x < 128) {
+    const int c = threadIdx.x;
+    // [2][C]: dbeta sums first, dgamma second (k_col_final sums column-wise over the blocks)
+    a.partial[(size_t)blockIdx.x * 256 + c] = red[1][0][c] + red[1][1][c] + red[1][2][c] + red[1][3][c];
+    a.partial[(size_t)blockIdx.x * 256 + 128 + c] = red[0][0][c] + red[0][1][c] + red[0][2][c] + red[0][3][c];
   }
 }
 __global__ void k_ln_params(const double* sums, int C, float* dgamma, float* dbeta) {
@@ -656,7 +761,8 @@ extern "C" int a3d_layernorm_forward(const float* x_dev, int ldx, int64_t n, int
   LnArgs a;
   memset(&a, 0, sizeof(a));
   a.x = x_dev, a.gamma = gamma_dev, a.beta = beta_dev, a.y = y_dev, a.ldx = ldx, a.ldy = ldy, a.n = (int)n, a.C = C, a.eps = eps;
-  k_ln_forward<<<(unsigned)((n + 3) / 4), 256, 0, (hipStream_t)stream>>>(a);
+  if (C == 128 && !(ldx & 3) && !(ldy & 3)) k_ln_forward128<<<(unsigned)((n + 15) / 16), 256, 0, (hipStream_t)stream>>>(a);
+  else k_ln_forward<<<(unsigned)((n + 3) / 4), 256, 0, (hipStream_t)stream>>>(a);
   A3D_LAUNCH_CHECK();
   return A3D_OK;
 }
@@ -681,7 +787,8 @@ extern "C" int a3d_layernorm_backward(const float* x_dev, int ldx, const float* 
   a.x = x_dev, a.dy = dy_dev, a.gamma = gamma_dev, a.dx = dx_dev, a.partial = partial;
   a.ldx = ldx, a.ldy = lddy, a.n = (int)n, a.C = C, a.eps = eps;
   const int blocks = bn_blocks(n, a.rows_per_block);
-  k_ln_backward<<<blocks, 256, 0, st>>>(a);
+  if (C == 128 && !(ldx & 3) && !(lddy & 3)) k_ln_backward128<<<blocks, 256, 0, st>>>(a);
+  else k_ln_backward<<<blocks, 256, 0, st>>>(a);
   k_col_final<<<(unsigned)((2 * C + kFinCols - 1) / kFinCols), 256, 0, st>>>(partial, blocks, 2, C, sums);
   k_ln_params<<<(unsigned)((C + 255) / 256), 256, 0, st>>>(sums, C, dgamma_dev, dbeta_dev);
   A3D_LAUNCH_CHECK();

@@ -56,6 +56,12 @@ struct ConvArgs {
   // (as "offset 27" with cin2 / 16 channel steps); in2 rows = the output rows; cin2 = 0: none
   const float* in2;
   int ldi2, cin2;
+  // fused 1x1 head on the finished output rows (HEAD builds): head_out[head_map[row]][0 .. head_cout) = out_row @ head_w + bias
+  const float* head_w;
+  const float* head_bias;
+  float* head_out;
+  const int* head_map;
+  int head_ld, head_cout;
 };
 
 // ------------------------------------------------------------------------------ k_conv_sk
@@ -140,7 +146,10 @@ __device__ __forceinline__ void wait_all_vmem() { __builtin_amdgcn_s_waitcnt(0x0
 // instantiation, so the plain kernels are untouched.
 // STATS: the owner's epilogue also writes the tile's BatchNorm partial statistics (training path; a separate instantiation,
 // the inference kernels are untouched).
-template <int BN, int CH, int PAIR, bool FUSE = false, bool STATS = false>
+// HEAD: the owner's epilogue multiplies the finished rows (all BN = cout columns are in this workgroup's registers, in exactly
+// the B-operand layout of the next MFMA: lane (g, j) holds channels 16 ct + 4 g + t of row j) with a packed 1x1 weight and
+// writes the product to a second output -- lin_squeeze_head behind block8's last conv, without re-reading the rows.
+template <int BN, int CH, int PAIR, bool FUSE = false, bool STATS = false, bool HEAD = false>
 __global__ void __launch_bounds__(256, PAIR ? ((BN <= 96 && CH <= 32) ? 4 : 3) : ((BN <= 96 && CH <= 48) ? 3 : 2))
     k_conv_sk(const SkArgs a) {
   static_assert(!FUSE || PAIR != 2, "the fused projection runs on the exact-fp32 builds");
@@ -588,6 +597,41 @@ __global__ void __launch_bounds__(256, PAIR ? ((BN <= 96 && CH <= 32) ? 4 : 3) :
               for (int tt = 0; tt < 4; ++tt) v[tt] = fmaxf(v[tt], 0.f);
             }
             *(f32x4*)(po + ct * 16) = v;
+            if constexpr (HEAD) acc[r][ct] = v;   // the finished row stays in the accumulator registers for the head below
+          }
+        }
+      }
+      if constexpr (HEAD) {
+        // second GEMM on the finished tile: pcd[row][16 c2 + 4 g + r] = sum over the BN channels.  The weight fragments come
+        // straight from global memory (48 KB, shared by every workgroup: L1 / L2 hits), four output column tiles at a time
+        const f32x4* Wh = (const f32x4*)a.c.head_w + lane;
+        const int hct = a.c.head_cout >> 4;
+        const int myrow = r0 + wrow;
+        const bool valid = myrow < a.c.n_out;
+        float* ho = nullptr;
+        if (valid) ho = a.c.head_out + (size_t)(a.c.head_map ? a.c.head_map[myrow] : myrow) * a.c.head_ld + 4 * g;
+        for (int c0 = 0; c0 < hct; c0 += 4) {
+          f32x4 h2[4];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) h2[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int Sx = 0; Sx < NCT; ++Sx) {
+            f32x4 wv[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) wv[q] = c0 + q < hct ? Wh[(Sx * hct + c0 + q) * 64] : (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+              for (int q = 0; q < 4; ++q) h2[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[q][tt], acc[0][Sx][tt], h2[q], 0, 0, 0);
+          }
+          if (valid) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+              if (c0 + q < hct) {
+                f32x4 o = h2[q];
+                if (a.c.head_bias) o += *(const f32x4*)(a.c.head_bias + (c0 + q) * 16 + 4 * g);
+                *(f32x4*)(ho + (c0 + q) * 16) = o;
+              }
           }
         }
       }
@@ -1299,6 +1343,7 @@ static void allow_big_lds() {
   A3D_ALLOW_LDS(160 * 1024, (k_conv_sk<BN_, CH_, 1, true>));
   A3D_BIGF(64, 32) A3D_BIGF(64, 64) A3D_BIGF(96, 32) A3D_BIGF(128, 32)
 #undef A3D_BIGF
+  A3D_ALLOW_LDS(160 * 1024, (k_conv_sk<96, 32, 1, false, false, true>));
   A3D_ALLOW_LDS(160 * 1024, k_conv_sk<96, 32, 2>);
   A3D_ALLOW_LDS(160 * 1024, k_conv_sk<128, 32, 2>);
   A3D_ALLOW_LDS(160 * 1024, k_conv_sk<64, 32, 2>);
@@ -1327,6 +1372,14 @@ static bool sk_fused_ok(int n_rows, int cin, int cout, int cin2) {
 
 // stats != nullptr (training): the kernel's epilogue also writes BatchNorm partials, [blocks][2][stats_ld] with
 // *stats_rows rows per block (64: k_conv_sk tiles, 16: the groups of k_conv_wl); the op must carry no scale / shift / residual
+// is there a fused-head build for what plan_sk picks here?  (a3d_program_run runs the 1x1 layer on its own otherwise)
+static bool sk_head_ok(int n_rows, int K, int cin, int cout, int head_cout, bool handoff) {
+  if (cout != 96 || head_cout <= 0 || head_cout % 16 || head_cout > 256 || cin % 32) return false;
+  if (conv_emu(K, cin, cout)) return false;
+  const SkPlan p = plan_sk(n_rows, K, cin, cout, handoff);
+  return p.bn == 96 && p.ch == 32 && p.pair == 1;
+}
+
 static int launch_conv_sk(ConvArgs c, const int* pre64, float* slab_ws, size_t slab_ws_floats, int* state,
                           hipStream_t st, float* stats = nullptr, int stats_ld = 0, int* stats_rows = nullptr) {
   allow_big_lds();
@@ -1388,7 +1441,9 @@ static int launch_conv_sk(ConvArgs c, const int* pre64, float* slab_ws, size_t s
     return A3D_ERR_INVALID;
   }
   // kernel-volume field: K, plus the fused projection's input channels in the bits above (cin2 << 8); last field: stage width
-  ProfScope ps(st, A3D_PROF_SPCONV, p.bn, c.K | (c.cin2 << 8), c.cin, c.cout, c.n_out, c.tag_table, c.tag_level, p.ch);
+  // ... and a fused head's output columns above those (head_cout << 20)
+  ProfScope ps(st, A3D_PROF_SPCONV, p.bn, c.K | (c.cin2 << 8) | (c.head_cout << 20), c.cin, c.cout, c.n_out, c.tag_table, c.tag_level,
+               p.ch);
   if (c.cin2 > 0) {
     // fused residual projection: the exact-fp32 builds of the shapes the U-Net's second block convs run on
     if (c.K != 27 || !c.in2 || p.pair == 2 || c.cin2 % p.ch != 0 || (c.ldi2 & 3) ||
@@ -1411,6 +1466,15 @@ static int launch_conv_sk(ConvArgs c, const int* pre64, float* slab_ws, size_t s
     else if (p.bn == 128) k_conv_sk<128, 32, 2><<<p.G, 256, p.lds, st>>>(a);
     else if (p.bn == 64) k_conv_sk<64, 32, 2><<<p.G, 256, p.lds, st>>>(a);
     else k_conv_sk<32, 32, 2><<<p.G, 256, p.lds, st>>>(a);
+    A3D_LAUNCH_CHECK();
+    return A3D_OK;
+  }
+  if (c.head_cout > 0) {
+    if (!(p.bn == 96 && p.ch == 32 && p.pair == 1) || c.cin2 > 0 || stats || !c.head_w || !c.head_out) {
+      set_error("spconv: no fused-head build for BN %d CH %d pair %d", p.bn, p.ch, p.pair);
+      return A3D_ERR_UNSUPPORTED;
+    }
+    k_conv_sk<96, 32, 1, false, false, true><<<p.G, 256, p.lds, st>>>(a);
     A3D_LAUNCH_CHECK();
     return A3D_OK;
   }
@@ -1720,6 +1784,29 @@ extern "C" int a3d_program_run(const a3d_scene* s, const a3d_buf_desc* bufs, int
         set_error("op %d: unknown kind %d", i, o.kind);
         return A3D_ERR_INVALID;
     }
+    bool head_after = false;
+    if (o.head_cout > 0) {
+      if (!o.head_w_dev || !ext_out_dev || lvl_out != 0 || o.kind == A3D_OP_UP || o.out_buf == A3D_BUF_EXT_OUT ||
+          o.head_cout % 16 || o.head_cout > ext_out_ld) {
+        set_error("op %d: a fused head needs a level-0 op into a buffer, packed head weights and the external output", i);
+        return A3D_ERR_INVALID;
+      }
+      bool handoff_h = o.kernel_volume > 1;
+      if (handoff_h && o.kernel_volume <= 8) {
+        const SkPlan q = plan_sk(a.n_out, a.K, a.cin, a.cout, false);
+        if ((long long)q.ntile * q.n_cblk >= 192) handoff_h = false;
+      }
+      if (o.kind != A3D_OP_LINEAR && a.cin2 == 0 && !(conv_wl_supported(a)) && sk_head_ok(a.n_out, a.K, a.cin, a.cout, o.head_cout, handoff_h)) {
+        a.head_w = o.head_w_dev;
+        a.head_bias = o.head_bias_dev;
+        a.head_out = ext_out_dev;
+        a.head_ld = ext_out_ld;
+        a.head_cout = o.head_cout;
+        a.head_map = s->orig_row;
+      } else {
+        head_after = true;   // same arithmetic as its own launch below
+      }
+    }
     if (a.cin2 > 0 && !sk_fused_ok(a.n_out, a.cin, a.cout, a.cin2)) {
       // no fused build for this (row count, shape): the same arithmetic as two launches on the same packed weights --
       // the 27 offsets into `out` without the ReLU, then the 1x1 slice (packed right behind them) added in place
@@ -1739,14 +1826,27 @@ extern "C" int a3d_program_run(const a3d_scene* s, const a3d_buf_desc* bufs, int
       c2.zero_row = a.zero_row, c2.tag_table = A3D_OP_LINEAR, c2.tag_level = Lin;
       rc = launch_conv_sk(c2, nullptr, nullptr, 0, nullptr, st);
       if (rc != A3D_OK) return rc;
-      continue;
-    }
+    } else
     if (o.kind == A3D_OP_LINEAR && dense_supported(a.cin, a.cout) && a.n_out >= 4096)
       rc = launch_dense(a.in, a.ldi, nullptr, 0, a.n_out, a.cin, a.cout, a.w, a.scale, a.shift, a.res, a.ldr, a.relu,
                         a.out, a.ldo, a.zero_row, Lin, a.out_map, st);
     else
       rc = launch_conv_sk(a, pre, partial, L.partial_floats, queues + (size_t)i * kMaxQueuesPerOp, st);
     if (rc != A3D_OK) return rc;
+    if (head_after) {   // the head as its own 1x1 launch over the op's finished rows
+      if (dense_supported(o.cout, o.head_cout) && a.n_out >= 4096)
+        rc = launch_dense(out, ldo, nullptr, 0, a.n_out, o.cout, o.head_cout, o.head_w_dev, nullptr, o.head_bias_dev, nullptr, 0, 0,
+                          ext_out_dev, ext_out_ld, -1, Lin, s->orig_row, st);
+      else {
+        ConvArgs h;
+        memset(&h, 0, sizeof(h));
+        h.in = out, h.ldi = ldo, h.n_in = a.n_out, h.w = o.head_w_dev, h.K = 1, h.cin = o.cout, h.cout = o.head_cout;
+        h.out = ext_out_dev, h.ldo = ext_out_ld, h.n_out = a.n_out, h.out_map = s->orig_row, h.shift = o.head_bias_dev;
+        h.zero_row = -1, h.tag_table = A3D_OP_LINEAR, h.tag_level = Lin;
+        rc = launch_conv_sk(h, nullptr, nullptr, 0, nullptr, st);
+      }
+      if (rc != A3D_OK) return rc;
+    }
   }
   return A3D_OK;
 }

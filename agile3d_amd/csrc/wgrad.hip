@@ -157,15 +157,26 @@ __global__ void __launch_bounds__(256) k_wgrad(const WgradArgs a) {
   for (int e = threadIdx.x; e < TILE4; e += 256) P[e] = fold4[e];
 }
 
-// dw[k][ci][co] = sum over chunks (chunk order) of the fragment-layout partials: element e of a block is
-// (tile = tx * CY + ty, lane = 16 g + j, r) -> ci = block_x * 16 CX + CX (4g + r) + tx, co = block_y * 16 CY + CY j + ty
-__global__ void k_wgrad_reduce(const float* __restrict__ part, int nchunk, int K, int cin, int cout, int cx, int cy,
-                               float* __restrict__ dw) {
+// dw[k][ci][co] = sum over chunks of the fragment-layout partials: element e of a block is
+// (tile = tx * CY + ty, lane = 16 g + j, r) -> ci = block_x * 16 CX + CX (4g + r) + tx, co = block_y * 16 CY + CY j + ty.
+// 64 elements x kRedLanes chunk lanes per workgroup: lane p adds chunks p, p + kRedLanes, ... (independent loads in flight;
+// one thread per element walking up to 256 chunks was a chain of dependent round trips: 25-30 us per weight, 120 launches
+// per training iteration), the lanes' sums are folded in lane order -- a fixed order either way.
+constexpr int kRedLanes = 8;
+__global__ void __launch_bounds__(64 * kRedLanes) k_wgrad_reduce(const float* __restrict__ part, int nchunk, int K, int cin, int cout,
+                                                                 int cx, int cy, float* __restrict__ dw) {
+  __shared__ float sh[kRedLanes][64];
   const size_t total = (size_t)K * cin * cout;
-  const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= total) return;
+  const int el = threadIdx.x & 63, p = threadIdx.x >> 6;
+  const size_t e = (size_t)blockIdx.x * 64 + el;
   float s = 0.f;
-  for (int c = 0; c < nchunk; ++c) s += part[(size_t)c * total + e];
+  if (e < total)
+    for (int c = p; c < nchunk; c += kRedLanes) s += part[(size_t)c * total + e];
+  sh[p][el] = s;
+  __syncthreads();
+  if (p != 0 || e >= total) return;
+#pragma unroll
+  for (int q = 1; q < kRedLanes; ++q) s += sh[q][el];
   const int block_elems = 16 * cx * 16 * cy, nbx = cin / (16 * cx);
   const int per_k = cin * cout;
   const int k = (int)(e / per_k), rem = (int)(e % per_k);
@@ -355,8 +366,8 @@ extern "C" int a3d_linear_wgrad(const float* x_dev, int ldx, const float* dy_dev
   }
 #undef A3D_WG
   A3D_LAUNCH_CHECK();
-  k_wgrad_reduce<<<(unsigned)(((size_t)cin * cout + 255) / 256), 256, 0, st>>>(a.part, p.chunks, 1, cin, cout, p.cx, p.cy,
-                                                                              dw_dev);
+  k_wgrad_reduce<<<(unsigned)(((size_t)cin * cout + 63) / 64), 64 * kRedLanes, 0, st>>>(a.part, p.chunks, 1, cin, cout, p.cx, p.cy,
+                                                                                        dw_dev);
   A3D_LAUNCH_CHECK();
   return A3D_OK;
 }
@@ -435,7 +446,7 @@ extern "C" int a3d_conv_wgrad(const a3d_scene* s, int kind, int level_in, const 
 #undef A3D_WG
   A3D_LAUNCH_CHECK();
   const size_t total = (size_t)a.K * cin * cout;
-  k_wgrad_reduce<<<(unsigned)((total + 255) / 256), 256, 0, st>>>(a.part, p.chunks, a.K, cin, cout, p.cx, p.cy, dw_dev);
+  k_wgrad_reduce<<<(unsigned)((total + 63) / 64), 64 * kRedLanes, 0, st>>>(a.part, p.chunks, a.K, cin, cout, p.cx, p.cy, dw_dev);
   A3D_LAUNCH_CHECK();
   return A3D_OK;
 }

@@ -247,7 +247,17 @@ class BackboneProgram:
         head = model.lin_squeeze_head
         hb = head.bias.detach().reshape(-1).to(dev, torch.float32).contiguous()
         self.keep.append(hb)
-        op(L.OP_LINEAR, 0, P[7], model.mask_dim, (f4, 0), (L.BUF_EXT_OUT, 0), None, False, 1, pack(head), None, hb)
+        hw = pack(head)
+        last = self.ops[-1]                   # block8's last conv: its workgroups hold complete 96-column output rows
+        if (os.environ.get("A3D_FUSE_HEAD", "1") != "0" and last.kind == L.OP_CONV3 and last.out_buf == f4
+                and last.proj_cin == 0):
+            # lin_squeeze_head as a second GEMM in that conv's epilogue (SURVEY 2.1's second fusion): the [N, 96] rows are
+            # not read back, one launch less.  The library runs the head as its own 1x1 launch where no fused build exists.
+            last.head_w_dev, last.head_bias_dev, last.head_cout = hw.data_ptr(), hb.data_ptr(), model.mask_dim
+            self.fused_head = True
+        else:
+            op(L.OP_LINEAR, 0, P[7], model.mask_dim, (f4, 0), (L.BUF_EXT_OUT, 0), None, False, 1, hw, None, hb)
+            self.fused_head = False
 
         self.n_ops = len(self.ops)
         self.ops_arr = (L.Op * self.n_ops)(*self.ops)

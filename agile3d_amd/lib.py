@@ -32,7 +32,8 @@ class Op(C.Structure):
                 ("res_buf", C.c_int32), ("res_coff", C.c_int32), ("relu", C.c_int32),
                 ("kernel_volume", C.c_int32),
                 ("w_dev", C.c_void_p), ("scale_dev", C.c_void_p), ("shift_dev", C.c_void_p),
-                ("proj_buf", C.c_int32), ("proj_coff", C.c_int32), ("proj_cin", C.c_int32), ("reserved_", C.c_int32)]
+                ("proj_buf", C.c_int32), ("proj_coff", C.c_int32), ("proj_cin", C.c_int32), ("reserved_", C.c_int32),
+                ("head_w_dev", C.c_void_p), ("head_bias_dev", C.c_void_p), ("head_cout", C.c_int32), ("reserved2_", C.c_int32)]
 
 
 _LAYER_FIELDS = ["c2s_in_w", "c2s_in_b", "c2s_out_w", "c2s_out_b", "c2s_norm_w", "c2s_norm_b",

@@ -101,6 +101,67 @@ def _col_sums(dy):
     return torch.cat([B.column_sums(dy[:, i:i + 128].contiguous()) for i in range(0, c, 128)])
 
 
+class DecoderPacks:
+    """Packed weights of the decoder's nn.Linear layers for the training tape, both orientations: entry (name, row slice) ->
+    (forward pack of W^T [in, out], backward pack of W [out, in]).  Keyed on the parameter's version, the
+    library optimiser's WEIGHT_EPOCH and the storage pointer; after an optimiser step every entry is stale and all of them are
+    repacked by ONE launch of a3d_pack_conv_weights_multi into the buffers they already own (was: two packs and two
+    transposing copies per layer and iteration, ~100 launches)."""
+
+    def __init__(self):
+        self.e = {}            # (name, rows) -> [version, (packed, cin, cout) fwd, (packed, cin, cout) bwd, bias, param, rows]
+        self._table = None     # (device table, n_jobs, n_chunks, signature)
+
+    @staticmethod
+    def _version(p):
+        from .optim import WEIGHT_EPOCH
+        return (int(p._version), WEIGHT_EPOCH[0], p.data_ptr())
+
+    def get(self, p, name, rows):
+        key = (name, rows)
+        hit = self.e.get(key)
+        if hit is None:
+            out_f, in_f = p.shape
+            r0, r1 = rows if rows is not None else (0, out_f)
+            n = (r1 - r0) * in_f
+            dev = p.device
+            hit = self.e[key] = [None, (torch.empty(n, dtype=torch.float32, device=dev), in_f, r1 - r0),
+                                 (torch.empty(n, dtype=torch.float32, device=dev), r1 - r0, in_f), None, p, (r0, r1)]
+            self._table = None
+        if hit[0] != self._version(p):
+            self._refresh()
+        return hit[1], hit[2]
+
+    def _refresh(self):
+        import numpy as np
+        lib = L.load()
+        sig = tuple((k, h[4].data_ptr()) for k, h in self.e.items())
+        if self._table is None or self._table[3] != sig:
+            dt = np.dtype([("src", "<u8"), ("dst", "<u8"), ("K", "<i4"), ("cin", "<i4"), ("cout", "<i4"), ("src_cin", "<i4"),
+                           ("src_cout", "<i4"), ("transposed", "<i4"), ("flip", "<i4"), ("c0", "<i4"), ("chunk0", "<i4"),
+                           ("pad", "<i4")])
+            rows_, chunk = [], 0
+            for (name, _), h in self.e.items():
+                p, (r0, r1) = h[4], h[5]
+                if not p.is_contiguous():
+                    raise RuntimeError(f"DecoderPacks: parameter {name} is not contiguous")
+                out_f, in_f = p.shape
+                w = r1 - r0
+                # forward: packed(W^T): element (ci = in, co = out) = W[r0 + co][ci]  -> a transposed job over the [out, in] source
+                rows_.append((p.data_ptr(), h[1][0].data_ptr(), 1, in_f, w, out_f, in_f, 1, 0, r0, chunk, 0))
+                chunk += (in_f * w + 4095) // 4096
+                # backward: packed(W): element (ci = out, co = in) = W[r0 + ci][co]  -> a plain job on the slice's rows
+                rows_.append((p.data_ptr() + 4 * r0 * in_f, h[2][0].data_ptr(), 1, w, in_f, w, in_f, 0, 0, 0, chunk, 0))
+                chunk += (in_f * w + 4095) // 4096
+            tab = np.array(rows_, dtype=dt)
+            dev = next(iter(self.e.values()))[4].device
+            self._table = (torch.from_numpy(tab.view(np.uint8)).to(dev), len(rows_), chunk, sig)
+        tab, n_jobs, n_chunks, _ = self._table
+        L.check(lib.a3d_pack_conv_weights_multi(tab.data_ptr(), n_jobs, n_chunks, _stream()), "a3d_pack_conv_weights_multi")
+        for h in self.e.values():
+            h[0] = self._version(h[4])
+
+
 class DecoderTape:
     """One tape for a whole batch: ``pcd_features`` / ``pos_enc`` / ``click_idx`` / ``click_time_idx`` are lists with one
     entry per batch sample (agile3d.py:192 loops over the samples: they only share the weights), or single objects for a
@@ -143,20 +204,14 @@ class DecoderTape:
         b = self.P[bname].detach() if bname else None
         if rows is not None:
             W, b = W[rows[0]:rows[1]], (b[rows[0]:rows[1]] if b is not None else None)
-        # both orientations packed once per weight version, shared by the tapes of a batch (one tape per sample)
-        from .optim import WEIGHT_EPOCH
-        cache = getattr(self.model, "_a3d_packed_dec", None)
-        if cache is None:
-            cache = {}
-            object.__setattr__(self.model, "_a3d_packed_dec", cache)
-        p = self.P[wname]
-        ver = (int(p._version), WEIGHT_EPOCH[0], p.data_ptr())
-        hit = cache.get((wname, rows))
-        if hit is None or hit[0] != ver:
-            W = W.contiguous()
-            hit = cache[(wname, rows)] = (ver, _pack(W.t().contiguous()), _pack(W),
-                                          b.contiguous() if b is not None else None)
-        _, fwd_w, bwd_w, bc = hit
+        # both orientations packed once per weight version (DecoderPacks: every entry that went stale -- after an optimiser
+        # step, all of them -- is repacked by ONE launch when the next tape asks for its first weight)
+        packs = getattr(self.model, "_a3d_packed_dec", None)
+        if not isinstance(packs, DecoderPacks):
+            packs = DecoderPacks()
+            object.__setattr__(self.model, "_a3d_packed_dec", packs)
+        fwd_w, bwd_w = packs.get(self.P[wname], wname, rows)
+        bc = b                 # a contiguous slice of the 1-D parameter: always current, nothing to cache
         y = _T(_linear(x.v, fwd_w, bc))
 
         def back():

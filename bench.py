@@ -64,8 +64,10 @@ def algorithmic_flops(entry, pairs):
         p = pairs["n"][entry.level - 1]        # every fine voxel receives once
     else:
         p = entry.n_out
-    # a fused residual projection (a3d_op.proj_cin, reported in the bits above the kernel volume): one more product per row
-    return 2.0 * p * entry.cin * entry.cout + 2.0 * entry.n_out * (entry.kernel_volume >> 8) * entry.cout
+    # a fused residual projection (a3d_op.proj_cin, reported in bits 8-19 of the kernel-volume field): one more product per
+    # row; a fused head (a3d_op.head_cout, bits 20+): one more GEMM on the finished rows
+    cin2, head = (entry.kernel_volume >> 8) & 0xfff, entry.kernel_volume >> 20
+    return 2.0 * p * entry.cin * entry.cout + 2.0 * entry.n_out * cin2 * entry.cout + 2.0 * entry.n_out * entry.cout * head
 
 
 def algorithmic_bytes(entry, pairs):
@@ -81,8 +83,8 @@ def algorithmic_bytes(entry, pairs):
         n_in, p = pairs["n"][entry.level], pairs["n"][entry.level - 1]
     else:
         n_in, p = n_out, 0
-    kv, cin2 = entry.kernel_volume & 0xff, entry.kernel_volume >> 8
-    return 4.0 * (n_in * entry.cin + n_out * (entry.cout + cin2) + (kv * entry.cin + cin2) * entry.cout) + 8.0 * p
+    kv, cin2, head = entry.kernel_volume & 0xff, (entry.kernel_volume >> 8) & 0xfff, entry.kernel_volume >> 20
+    return 4.0 * (n_in * entry.cin + n_out * (entry.cout + cin2 + head) + (kv * entry.cin + cin2 + head) * entry.cout) + 8.0 * p
 
 
 def workload_key(voxels, batch, queries):

@@ -158,6 +158,15 @@ typedef struct {
    * their BatchNorm scale already multiplied in (scale_dev = NULL), shift_dev the sum of the two shifts; proj_in = columns
    * [proj_coff, proj_coff + proj_cin) of buffer proj_buf (same level).  proj_cin = 0: no projection. */
   int32_t proj_buf, proj_coff, proj_cin, reserved_;
+  /* head_cout > 0 (a level-0 op whose output has <= 128 columns): a 1x1 layer applied to this op's OUTPUT rows as a second
+   * GEMM in the same kernel's epilogue -- lin_squeeze_head behind block8's last conv (models/agile3d.py:43-45,179): the
+   * workgroup holds complete output rows, so ext_out[caller row][0 .. head_cout) = out_row @ head_w + head_bias is
+   * written without reading the rows back.  head_w_dev: packed [1][cout][head_cout] (a3d_pack_conv_weight), head_bias_dev
+   * [head_cout] or NULL; the result goes to a3d_program_run's ext_out (rows in the CALLER's order).  Shapes without a fused
+   * build run the 1x1 layer as its own launch (same arithmetic). */
+  const float* head_w_dev;
+  const float* head_bias_dev;
+  int32_t head_cout, reserved2_;
 } a3d_op;
 
 /* W[K][cin][cout] (ME layout, models/modules/common.py:137-155) -> MFMA B-fragment order */

@@ -30,7 +30,7 @@ def test_library_exports_every_declared_symbol():
 def test_struct_layouts_match_header():
     import ctypes as C
     from agile3d_amd import lib
-    assert C.sizeof(lib.Op) == 12 * 4 + 3 * 8 + 4 * 4      # + proj_buf, proj_coff, proj_cin, reserved_ (the fused projection)
+    assert C.sizeof(lib.Op) == 12 * 4 + 3 * 8 + 4 * 4 + 2 * 8 + 2 * 4   # + the fused projection's and the fused head's fields
     assert C.sizeof(lib.BufDesc) == 8
     assert C.sizeof(lib.DecoderLayer) == 29 * 8
     assert C.sizeof(lib.DecoderWeights) == 16 + 8 * 29 * 8 + 11 * 8

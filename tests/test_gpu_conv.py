@@ -302,6 +302,61 @@ def test_fused_projection_op_and_its_fallback(world, level, cin, cout, cin2):
     assert (out[n] == 0).all(), "zero row not written"
 
 
+@pytest.mark.parametrize("level,cin,cout,head", [(0, 96, 96, 128), (0, 128, 96, 128), (1, 96, 96, 128), (0, 96, 64, 128), (0, 32, 32, 64)])
+def test_fused_head_op_and_its_fallback(world, level, cin, cout, head):
+    """a3d_op.head_*: lin_squeeze_head (agile3d.py:43-45,179) as a second GEMM in the epilogue of the conv that produces its
+    input -- the workgroup holds complete 96-column rows in exactly the operand layout of the next MFMA -- against float64,
+    rows of the external output in the CALLER's order; the op's own output must be unchanged.  Level 1 and the 64- / 32-column
+    shapes have no fused build: the library runs the head as its own launch (level 1: not a level-0 op -> refused)."""
+    from agile3d_amd.engine import _ptr, _stream
+    coords, sc, lv, maps = world
+    lib = L.load()
+    g = torch.Generator().manual_seed(level * 977 + cin * 13 + cout + head)
+    n = sc.n[level]
+    X = torch.randn(n, cin, generator=g)
+    W = torch.randn(27, cin, cout, generator=g) / (cin * 14) ** 0.5
+    Wh = torch.randn(1, cout, head, generator=g) / cout ** 0.5
+    bias = torch.randn(head, generator=g).cuda()
+    scale, shift = (torch.rand(cout, generator=g) + 0.5).cuda(), torch.randn(cout, generator=g).cuda()
+    R = torch.randn(n, cout, generator=g)
+    wp, hp = pack_weight(W.cuda()), pack_weight(Wh.cuda())
+    descs = [(level, cin), (level, cout), (level, cout)]
+    bufs = (L.BufDesc * 3)(*[L.BufDesc(a, b) for a, b in descs])
+    o = L.Op()
+    o.kind, o.level_in, o.cin, o.cout = L.OP_CONV3, level, cin, cout
+    o.in_buf, o.in_coff, o.out_buf, o.out_coff = 0, 0, 1, 0
+    o.res_buf, o.res_coff, o.relu, o.kernel_volume = 2, 0, 1, 27
+    o.w_dev, o.scale_dev, o.shift_dev = wp.data_ptr(), scale.data_ptr(), shift.data_ptr()
+    o.head_w_dev, o.head_bias_dev, o.head_cout = hp.data_ptr(), bias.data_ptr(), head
+    ops = (L.Op * 1)(o)
+    nbytes = lib.a3d_program_workspace_bytes(sc.handle, bufs, 3, ops, 1)
+    assert nbytes > 0, lib.a3d_last_error()
+    ws = torch.zeros(nbytes, dtype=torch.uint8, device="cuda")
+
+    def buf(i):
+        off = lib.a3d_program_buffer_offset(sc.handle, bufs, 3, i)
+        lvl, ch = descs[i]
+        return ws[off:off + (sc.n[lvl] + 1) * ch * 4].view(torch.float32).view(sc.n[lvl] + 1, ch)
+    m = maps[level]
+    buf(0)[:n] = X[m].cuda()
+    buf(2)[:n] = R[m].cuda()
+    ext = torch.full((sc.n[0], head + 32), float("nan"), device="cuda")
+    rc = lib.a3d_program_run(sc.handle, bufs, 3, ops, 1, None, _ptr(ext), head + 32, _ptr(ws), nbytes, _stream())
+    if level != 0:
+        assert rc != 0                         # a head writes the level-0 external output
+        return
+    L.check(rc, "a3d_program_run")
+    torch.cuda.synchronize()
+    y_ref = torch.relu(ob.sparse_conv(X.double(), W.double(), lv.kernel_map(level, 3), n) * scale.cpu().double()
+                       + shift.cpu().double() + R.double())
+    h_ref = y_ref @ Wh[0].double() + bias.cpu().double()
+    _check(buf(1).cpu()[:n].double(), y_ref[m], f"conv with head L{level} {cin}->{cout}: own output", tol=2e-5)
+    # the scene was built from `coords` in the oracle's (= caller's) row order: ext rows are caller rows
+    got = ext.cpu()
+    _check(got[:, :head].double(), h_ref, f"fused head {cout}->{head}", tol=2e-5)
+    assert torch.isnan(got[:, head:]).all(), "wrote outside the head's columns"
+
+
 def test_emulated_fp32_build_keeps_parity():
     """A3D_CONV_EMU=2 (every gathered conv kernel forms its fp32 products from six bf16-MFMA terms; read once per process, so
     it runs in its own interpreter): the conv tests that reach those kernels and the end-to-end smoke comparison with the
