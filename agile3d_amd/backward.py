@@ -399,16 +399,16 @@ def column_sums(x):
 def stem_weight_grad(scene, feats3, dy, kernel_volume=125):
     """dW [K, 3, 32] of the input convolution; ``feats3`` [n0, 3] in the caller's row order, ``dy`` [n0, 32] internal."""
     lib = L.load()
-    feats3, dy = feats3.contiguous(), dy.contiguous()
+    feats3, dy = feats3.contiguous(), _rows(dy)
     if feats3.shape != (scene.n[0], 3) or dy.shape[0] != scene.n[0] or dy.shape[1] < 32:
         raise ValueError("stem_weight_grad: feats3 [n0, 3], dy [n0, >= 32] expected")
     dw = torch.empty((kernel_volume, 3, 32), dtype=torch.float32, device=dy.device)
-    nbytes = lib.a3d_stem_wgrad_workspace_bytes(kernel_volume)
+    nbytes = lib.a3d_stem_wgrad_scene_workspace_bytes(scene.handle, kernel_volume)
     if nbytes == 0:
         raise L.A3DError("stem_weight_grad: kernel volume must be 125 or 27")
-    ws = torch.empty(nbytes, dtype=torch.uint8, device=dy.device)
-    L.check(lib.a3d_stem_wgrad(scene.handle, _ptr(feats3), _ptr(dy), dy.shape[1], kernel_volume, _ptr(dw), _ptr(ws),
-                               nbytes, _stream()), "a3d_stem_wgrad")
+    ws = _workspace(nbytes, dy.device, "stem_wgrad")
+    L.check(lib.a3d_stem_wgrad(scene.handle, _ptr(feats3), _ptr(dy), dy.stride(0), kernel_volume, _ptr(dw), _ptr(ws),
+                               ws.numel(), _stream()), "a3d_stem_wgrad")
     return dw
 
 

@@ -268,37 +268,50 @@ __global__ void k_hash_insert(const LevelSet S) {
   }
 }
 
-// 3^3 neighbours in Morton row ids: nbrM[k][npad] (-1 = missing); one thread per (row, offset = blockIdx.y)
+// 3^3 neighbours in Morton row ids: nbrM[k][npad] (-1 = missing), AND the sort key of the row re-ordering (round 5: one
+// thread per ROW with its 27 lookups in flight together -- the key is decoded once instead of 27 times, the three x-adjacent
+// cells of a (y, z) pair are one 12-byte run of the level-0 grid, Morton-adjacent threads share those runs, and the presence
+// mask falls out of the lookups: no second kernel re-reading the 27 tables.  One thread per (row, offset) read 3.2 GB for
+// the 16-scene batch, a 64-byte sector per lookup).
+// Rows are re-ordered inside super tiles of 2^st_shift consecutive rows by a small key (the 27-bit neighbour
+// presence mask / the child slot): ALL levels go through one stable device-wide radix sort of
+//   key = level << (27 + super-tile bits) | super tile << 27 | small key,   value = position in the concatenated row list.
 __global__ void k_nbr_morton(const LevelSet S) {
   int lb;
   const int L = ls_level(S, lb);
   const Level& lv = S.lv[L];
   const int i = lb * blockDim.x + threadIdx.x;
-  const int k = blockIdx.y;
   if (i >= lv.n) return;
-  int r = i;
-  if (k != 13) {
-    int b, X, Y, Z;
-    decode_key(lv.keys[i], L, b, X, Y, Z);
-    const int lim = kCoordOff >> L;
-    const int x = X + k % 3 - 1, y = Y + (k / 3) % 3 - 1, z = Z + k / 9 - 1;  // x fastest
-    r = -1;
-    if (lv.grid)
-      r = lv.grid[grid_cell(lv, b, x, y, z)];
-    else if (x >= -lim && x < lim && y >= -lim && y < lim && z >= -lim && z < lim)
-      r = hash_lookup(lv.hkeys, lv.hvals, lv.hmask, make_key(b, x, y, z, L));
+  int b, X, Y, Z;
+  decode_key(lv.keys[i], L, b, X, Y, Z);
+  const int lim = kCoordOff >> L;
+  int r[27];
+  if (lv.grid) {
+    const ptrdiff_t c0 = (ptrdiff_t)grid_cell(lv, b, X, Y, Z);
+#pragma unroll
+    for (int k = 0; k < 27; ++k)     // x fastest; the grid's empty border covers the 3^3 neighbourhood
+      r[k] = lv.grid[c0 + ((ptrdiff_t)(k / 9 - 1) * lv.gdim[1] + ((k / 3) % 3 - 1)) * lv.gdim[0] + (k % 3 - 1)];
+  } else {
+    // hash levels: the first probe of all 27 lookups in flight together (most lookups end there: hit or empty slot), the
+    // few that collide finish with the serial probe loop
+    uint64_t want[27], got[27];
+    uint32_t h[27];
+#pragma unroll
+    for (int k = 0; k < 27; ++k) {
+      const int x = X + k % 3 - 1, y = Y + (k / 3) % 3 - 1, z = Z + k / 9 - 1;
+      const bool in = x >= -lim && x < lim && y >= -lim && y < lim && z >= -lim && z < lim;
+      want[k] = in ? make_key(b, x, y, z, L) : kEmptyKey;
+      h[k] = hash64(want[k]) & lv.hmask;
+      got[k] = in ? lv.hkeys[h[k]] : kEmptyKey;
+    }
+#pragma unroll
+    for (int k = 0; k < 27; ++k) {
+      if (want[k] == kEmptyKey || got[k] == kEmptyKey) r[k] = -1;
+      else if (got[k] == want[k]) r[k] = lv.hvals[h[k]];
+      else r[k] = hash_lookup(lv.hkeys, lv.hvals, lv.hmask, want[k]);
+    }
   }
-  S.nbrM[L][(size_t)k * lv.npad + i] = r;
-}
-// Rows are re-ordered inside super tiles of 2^st_shift consecutive rows by a small key (the 27-bit neighbour
-// presence mask / the child slot): ALL levels go through one stable device-wide radix sort of
-//   key = level << (27 + super-tile bits) | super tile << 27 | small key,   value = position in the concatenated row list.
-__global__ void k_mask27(const LevelSet S) {
-  int lb;
-  const int L = ls_level(S, lb);
-  const Level& lv = S.lv[L];
-  const int i = lb * blockDim.x + threadIdx.x;
-  if (i >= lv.n) return;
+  r[13] = i;
   // sort key = the 27 presence bits, the 12 edge offsets most significant, then the 8 corners, the 6 faces, the centre:
   // rows are grouped 16 at a time, a group multiplies for every offset ANY of its rows has, and the offsets a sort
   // does not reach (the low bits of the key) end up in nearly every group's union -- so the high bits should be the ones
@@ -308,7 +321,10 @@ __global__ void k_mask27(const LevelSet S) {
   constexpr int kKeyBit[27] = {14, 26, 13, 25, 6, 24, 12, 23, 11, 22, 5, 21, 4, 0, 3, 20, 2, 19, 10, 18, 9, 17, 1, 16, 8, 15, 7};
   uint32_t m = 0;
 #pragma unroll
-  for (int k = 0; k < 27; ++k) m |= (S.nbrM[L][(size_t)k * lv.npad + i] >= 0 ? 1u : 0u) << kKeyBit[k];
+  for (int k = 0; k < 27; ++k) {
+    S.nbrM[L][(size_t)k * lv.npad + i] = r[k];
+    m |= (r[k] >= 0 ? 1u : 0u) << kKeyBit[k];
+  }
   S.cat_keys[S.off[L] + i] = ((uint64_t)L << S.level_shift) | ((uint64_t)(i >> S.st_shift) << 27) | m;
   S.cat_vals[S.off[L] + i] = S.off[L] + i;
 }
@@ -330,29 +346,38 @@ __global__ void k_perm_from_sorted(const LevelSet S, int up) {
   }
 }
 
-// nbr27[k][f] in internal row ids (missing / padding -> n) + per-16-row-group presence masks
+// nbr27[k][f] in internal row ids (missing / padding -> n) + per-16-row-group presence masks: one thread per ROW (its old
+// position is read once, the 27 table entries and their new row ids are independent gathers in flight together), the group
+// mask is the OR over the group's 16 lanes -- no atomics, every word written exactly once
 __global__ void k_remap_nbr(const LevelSet S) {
   int lb;
   const int L = ls_level(S, lb);
   const Level& lv = S.lv[L];
   const int f = lb * blockDim.x + threadIdx.x;
-  const int k = blockIdx.y;
-  if (f >= lv.npad) return;
-  int o = lv.n;
-  bool present = false;
+  if (f >= lv.npad) return;            // npad is a multiple of 128: whole waves leave together
+  int v[27];
+  uint32_t word = 0;
   if (f < lv.n) {
-    const int v = S.nbrM[L][(size_t)k * lv.npad + lv.inv[f]];
-    if (v >= 0) {
-      o = lv.perm[v];
-      present = true;
+    const int mrow = lv.inv[f];
+#pragma unroll
+    for (int k = 0; k < 27; ++k) v[k] = S.nbrM[L][(size_t)k * lv.npad + mrow];
+#pragma unroll
+    for (int k = 0; k < 27; ++k) {
+      const bool present = v[k] >= 0;
+      v[k] = present ? lv.perm[v[k]] : lv.n;
+      word |= (present ? 1u : 0u) << k;
     }
+  } else {
+#pragma unroll
+    for (int k = 0; k < 27; ++k) v[k] = lv.n;
   }
-  lv.nbr27[(size_t)k * lv.npad + f] = o;
-  const unsigned long long bal = __ballot(present);
-  const int lane = threadIdx.x & 63;
-  if ((lane & 15) == 0) {
-    if ((bal >> lane) & 0xffffULL) atomicOr(&lv.gmask27[f >> 4], 1u << k);
-  }
+#pragma unroll
+  for (int k = 0; k < 27; ++k) lv.nbr27[(size_t)k * lv.npad + f] = v[k];
+  word |= __shfl_xor((int)word, 1, 16);
+  word |= __shfl_xor((int)word, 2, 16);
+  word |= __shfl_xor((int)word, 4, 16);
+  word |= __shfl_xor((int)word, 8, 16);
+  if ((threadIdx.x & 15) == 0) lv.gmask27[f >> 4] = word;
 }
 
 // pre[t] = number of (tile, offset) pairs of the tiles before tile t, for the three mask tables of a level
@@ -814,8 +839,7 @@ extern "C" int a3d_scene_create(const int32_t* coords4_dev, int64_t n_voxels, vo
   // ---- stage A: hash, neighbours in Morton order, sort keys
   g = blocks(NL, [&](int L) { return (int64_t)sc->lv[L].n; });
   k_hash_insert<<<g, T, 0, st>>>(S);
-  k_nbr_morton<<<dim3(g, 27), T, 0, st>>>(S);
-  k_mask27<<<g, T, 0, st>>>(S);
+  k_nbr_morton<<<g, T, 0, st>>>(S);      // neighbour rows + presence masks + the sort keys, one thread per row
   A3D_LAUNCH_CHECK();
   // ---- stage B: ONE stable radix sort re-orders the rows of all levels inside their super tiles
   {
@@ -825,7 +849,7 @@ extern "C" int a3d_scene_create(const int32_t* coords4_dev, int64_t n_voxels, vo
   // ---- stage C: tables in the new row order
   k_perm_from_sorted<<<g, T, 0, st>>>(S, 0);
   g = blocks(NL, [&](int L) { return (int64_t)sc->lv[L].npad; });
-  k_remap_nbr<<<dim3(g, 27), T, 0, st>>>(S);
+  k_remap_nbr<<<g, T, 0, st>>>(S);
   g = blocks(NL, [&](int L) { return std::max<int64_t>(sc->lv[L].n, (int64_t)sc->lv[L].hmask + 1); });
   k_xyzb_hashfix<<<g, T, 0, st>>>(S);
   A3D_LAUNCH_CHECK();

@@ -610,19 +610,31 @@ __global__ void __launch_bounds__(256, PAIR ? ((BN <= 96 && CH <= 32) ? 4 : 3) :
         const bool valid = myrow < a.c.n_out;
         float* ho = nullptr;
         if (valid) ho = a.c.head_out + (size_t)(a.c.head_map ? a.c.head_map[myrow] : myrow) * a.c.head_ld + 4 * g;
+        // (c0, Sx) steps of four weight fragments x 16 MFMAs; the NEXT step's fragments are requested before the current
+        // step's MFMAs (an L2 round trip behind 16 MFMAs: without it every step waited out its own loads -- the head cost
+        // 460 us on the 16-scene batch against 336 for the separate k_dense launch)
+        f32x4 wv[4], wn[4];
+        auto fetch = [&](int c0, int Sx, f32x4 (&w)[4]) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) w[q] = c0 + q < hct ? Wh[(Sx * hct + c0 + q) * 64] : (f32x4){0.f, 0.f, 0.f, 0.f};
+        };
+        fetch(0, 0, wv);
         for (int c0 = 0; c0 < hct; c0 += 4) {
           f32x4 h2[4];
 #pragma unroll
           for (int q = 0; q < 4; ++q) h2[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
           for (int Sx = 0; Sx < NCT; ++Sx) {
-            f32x4 wv[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) wv[q] = c0 + q < hct ? Wh[(Sx * hct + c0 + q) * 64] : (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (Sx + 1 < NCT) fetch(c0, Sx + 1, wn);
+            else if (c0 + 4 < hct) fetch(c0 + 4, 0, wn);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int tt = 0; tt < 4; ++tt)
 #pragma unroll
               for (int q = 0; q < 4; ++q) h2[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[q][tt], acc[0][Sx][tt], h2[q], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) wv[q] = wn[q];
           }
           if (valid) {
 #pragma unroll
@@ -1277,7 +1289,9 @@ static int sk_wgs_per_cu(int bn, int ch, int pair, size_t lds) {
   const int w = by_regs < by_lds ? by_regs : by_lds;
   return w < 1 ? 1 : (w > 4 ? 4 : w);
 }
-static SkPlan plan_sk(int n_rows, int K, int cin, int cout, bool handoff) {
+// force_ch > 0: that stage width instead of sk_ch's choice (a fused projection whose input channels the preferred width does
+// not divide: the 32 -> 64 block of level 2 runs its 64 -> 64 conv with 32-channel stages)
+static SkPlan plan_sk(int n_rows, int K, int cin, int cout, bool handoff, int force_ch = 0) {
   SkPlan p;
   p.ntile = (n_rows + 63) / 64;
   if (p.ntile < 1) p.ntile = 1;
@@ -1288,7 +1302,7 @@ static SkPlan plan_sk(int n_rows, int K, int cin, int cout, bool handoff) {
     // a level too small to give every CU a share with 128-column workgroups is cut into 64-column ones: twice the
     // shares for the same number of workgroups per tile (the gathers of a tile are repeated, its stages are not)
     if (pass == 1 && cout % 64 == 0 && p.bn > 64) p.bn = 64;
-    p.ch = sk_ch(cin, p.bn);
+    p.ch = force_ch > 0 && cin % force_ch == 0 ? force_ch : sk_ch(cin, p.bn);
     p.nchunk = p.ch ? cin / p.ch : 1;
     p.n_cblk = cout / p.bn;
     p.pair = sk_pair(p.bn, p.ch, n_rows);
@@ -1365,8 +1379,10 @@ static void allow_big_lds() {
 // column block depend on the rows; a3d_program_run falls back to conv + separate 1x1 launch when not)
 static bool sk_fused_ok(int n_rows, int cin, int cout, int cin2) {
   if (cin % 32 != 0 || cout % 16 != 0 || !(cout % 128 == 0 || cout == 32 || cout == 64 || cout == 96)) return false;
-  const SkPlan p = plan_sk(n_rows, 27, cin, cout, true);
-  if (!p.ch || p.pair == 2 || cin2 <= 0 || cin2 % p.ch != 0) return false;
+  if (cin2 <= 0) return false;
+  SkPlan p = plan_sk(n_rows, 27, cin, cout, true);
+  if (p.ch && cin2 % p.ch != 0 && cin2 % 32 == 0) p = plan_sk(n_rows, 27, cin, cout, true, 32);
+  if (!p.ch || p.pair == 2 || cin2 % p.ch != 0) return false;
   return (p.bn == 64 && (p.ch == 32 || p.ch == 64)) || (p.bn == 96 && p.ch == 32) || (p.bn == 128 && p.ch == 32);
 }
 
@@ -1412,6 +1428,7 @@ static int launch_conv_sk(ConvArgs c, const int* pre64, float* slab_ws, size_t s
     if ((long long)q.ntile * q.n_cblk >= 192) handoff = false;
   }
   SkPlan p = plan_sk(c.n_out, c.K, c.cin, c.cout, handoff);
+  if (c.cin2 > 0 && p.ch && c.cin2 % p.ch != 0 && c.cin2 % 32 == 0) p = plan_sk(c.n_out, c.K, c.cin, c.cout, handoff, 32);
   if (!p.ch) {
     set_error("spconv: no stage size for cin=%d with %d-column workgroups", c.cin, p.bn);
     return A3D_ERR_UNSUPPORTED;
@@ -1538,6 +1555,10 @@ static int layout_program(const a3d_scene* s, const a3d_buf_desc* bufs, int n_bu
     }
     SkPlan q = plan_sk(s->lv[lvl_out].n, o.kernel_volume, o.cin, o.cout, true);
     if (q.slab_floats > pf) pf = q.slab_floats;
+    if (o.proj_cin > 0) {   // the fused projection may run with 32-channel stages (launch_conv_sk): another share count
+      q = plan_sk(s->lv[lvl_out].n, o.kernel_volume, o.cin, o.cout, true, 32);
+      if (q.slab_floats > pf) pf = q.slab_floats;
+    }
   }
   L.partial_off = off;
   L.partial_floats = pf;

@@ -310,12 +310,92 @@ __global__ void __launch_bounds__(256) k_stem_wgrad(const Level lv, const float*
     __syncthreads();
   }
 }
-__global__ void k_stem_wgrad_reduce(const float* __restrict__ part, int total, float* __restrict__ dw) {
-  const int e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= total) return;
+// 64 elements x 8 part lanes per workgroup (as k_wgrad_reduce): lane p adds parts p, p + 8, ..., the lanes fold in order
+__global__ void __launch_bounds__(512) k_stem_wgrad_reduce(const float* __restrict__ part, int total, float* __restrict__ dw,
+                                                           int nparts, int stride) {
+  __shared__ float sh[8][64];
+  const int el = threadIdx.x & 63, p = threadIdx.x >> 6;
+  const int e = blockIdx.x * 64 + el;
   float s = 0.f;
-  for (int sp = 0; sp < kStemSplits; ++sp) s += part[(size_t)sp * total + e];
+  if (e < total)
+    for (int sp = p; sp < nparts; sp += 8) s += part[(size_t)sp * stride + e];
+  sh[p][el] = s;
+  __syncthreads();
+  if (p != 0 || e >= total) return;
+#pragma unroll
+  for (int q = 1; q < 8; ++q) s += sh[q][el];
   dw[e] = s;
+}
+
+// The same gradient on the matrix cores (round 5; dense level-0 grid only): dW as ONE [384 x 32] accumulator per wave --
+// m = 3 k + ci (375 of 384 rows used), n = co --, the voxels as the MFMA k dimension, four per step: lane (g, j) supplies
+// A[m = 16 mt + j][voxel g] = the neighbour's colour (0 when the cell is empty) for the 24 row tiles and B[voxel g][n] = dy
+// for the two column tiles, 48 MFMAs per step.  Voxels are walked in MORTON order (a wave's 4-voxel steps are neighbours:
+// their 125-cell lookups share cache lines) against colours gathered into Morton order; the grid holds Morton rows, so a
+// lookup is grid cell -> colour, two dependent loads.  The thread-per-row kernel above read every dy row once per offset
+// (125 x) and folded 96 sums per thread through LDS: 1.18 ms at 320 k voxels.
+constexpr int kStemMfmaWgs = 512;
+__global__ void __launch_bounds__(256) k_stem_wgrad_mfma(const Level lv, const f32x4* __restrict__ feats4m,
+                                                         const float* __restrict__ dy, int lddy, float* __restrict__ part) {
+  extern __shared__ __attribute__((aligned(16))) float fold[];   // [384][32]
+  constexpr int KS = 5, K = 125, NMT = 24;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, j = lane & 15;
+  // this lane's 24 (offset, colour channel) pairs: m = 16 mt + j -> k = m / 3, ci = m % 3; relative cell offsets packed
+  int cell_dx[NMT], cell_ci[NMT];
+#pragma unroll
+  for (int mt = 0; mt < NMT; ++mt) {
+    const int m = 16 * mt + j, k = m / 3;
+    cell_ci[mt] = m < 3 * K ? m - 3 * k : -1;
+    const int ox = k % KS - 2, oy = (k / KS) % KS - 2, oz = k / (KS * KS) - 2;
+    cell_dx[mt] = m < 3 * K ? (oz * lv.gdim[1] + oy) * lv.gdim[0] + ox : 0;
+  }
+  f32x4 acc[NMT][2];
+#pragma unroll
+  for (int mt = 0; mt < NMT; ++mt) acc[mt][0] = acc[mt][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const int nsteps = (lv.n + 3) >> 2;
+  const int W = gridDim.x * 4;
+  const float* f1 = (const float*)feats4m;
+  for (int st = blockIdx.x * 4 + wave; st < nsteps; st += W) {
+    const int mr = 4 * st + g;                       // this lane's voxel (Morton row)
+    const bool ok = mr < lv.n;
+    size_t cell0 = 0;
+    int irow = 0;
+    if (ok) {
+      int b_, X_, Y_, Z_;
+      decode_key(lv.keys[mr], 0, b_, X_, Y_, Z_);
+      cell0 = grid_cell(lv, b_, X_, Y_, Z_);
+      irow = lv.perm[mr];
+    }
+    const float b0 = ok ? dy[(size_t)irow * lddy + j] : 0.f, b1 = ok ? dy[(size_t)irow * lddy + 16 + j] : 0.f;
+    int nb[NMT];
+#pragma unroll
+    for (int mt = 0; mt < NMT; ++mt) nb[mt] = (ok && cell_ci[mt] >= 0) ? lv.grid[(ptrdiff_t)cell0 + cell_dx[mt]] : -1;
+    float av[NMT];
+#pragma unroll
+    for (int mt = 0; mt < NMT; ++mt) av[mt] = nb[mt] >= 0 ? f1[4 * (size_t)nb[mt] + cell_ci[mt]] : 0.f;
+#pragma unroll
+    for (int mt = 0; mt < NMT; ++mt) {
+      acc[mt][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mt], b0, acc[mt][0], 0, 0, 0);
+      acc[mt][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mt], b1, acc[mt][1], 0, 0, 0);
+    }
+  }
+  // fold the four waves in wave order: lane (g, j) holds D[m = 16 mt + 4 g + r][n = 16 nt + j]
+  for (int w = 0; w < 4; ++w) {
+    if (wave == w) {
+#pragma unroll
+      for (int mt = 0; mt < NMT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float* f = fold + (16 * mt + 4 * g + r) * 32 + 16 * nt + j;
+            *f = w == 0 ? acc[mt][nt][r] : *f + acc[mt][nt][r];
+          }
+    }
+    __syncthreads();
+  }
+  float* P = part + (size_t)blockIdx.x * (384 * 32);
+  for (int e = threadIdx.x; e < 384 * 32; e += 256) P[e] = fold[e];
 }
 
 }  // namespace a3d
@@ -374,7 +454,25 @@ extern "C" int a3d_linear_wgrad(const float* x_dev, int ldx, const float* dy_dev
 
 extern "C" size_t a3d_stem_wgrad_workspace_bytes(int kernel_volume) {
   if (kernel_volume != 125 && kernel_volume != 27) return 0;
-  return (size_t)kStemSplits * kernel_volume * 96 * sizeof(float) + 256;
+  // the larger of the two paths: per-offset splits (hash / 3^3) or the matrix-core kernel's per-workgroup partials
+  const size_t a = (size_t)kStemSplits * kernel_volume * 96 * sizeof(float);
+  const size_t b = (size_t)kStemMfmaWgs * 384 * 32 * sizeof(float);
+  return (a > b ? a : b) + 256;
+}
+extern "C" size_t a3d_stem_wgrad_scene_workspace_bytes(const a3d_scene* s, int kernel_volume) {
+  const size_t base = a3d_stem_wgrad_workspace_bytes(kernel_volume);
+  if (!s || !base) return 0;
+  return align256((size_t)kStemMfmaWgs * 384 * 32 * sizeof(float)) + (size_t)s->lv[0].npad * 16 + 256 > base
+             ? align256((size_t)kStemMfmaWgs * 384 * 32 * sizeof(float)) + (size_t)s->lv[0].npad * 16 + 256
+             : base;
+}
+// Morton-ordered colours for the matrix-core path (spconv.hip's k_gather_feats: feats4[f] = colours of Morton row f)
+__global__ void k_stem_gather_morton(const float* __restrict__ feats3, const int* __restrict__ orig_row, const int* __restrict__ perm,
+                                     int n, f32x4* __restrict__ feats4) {
+  const int f = blockIdx.x * blockDim.x + threadIdx.x;
+  if (f >= n) return;
+  const float* p = feats3 + (size_t)orig_row[perm[f]] * 3;
+  feats4[f] = (f32x4){p[0], p[1], p[2], 0.f};
 }
 
 extern "C" int a3d_stem_wgrad(const a3d_scene* s, const float* feats3_dev, const float* dy_dev, int lddy,
@@ -391,10 +489,26 @@ extern "C" int a3d_stem_wgrad(const a3d_scene* s, const float* feats3_dev, const
   }
   hipStream_t st = (hipStream_t)stream;
   const int ks = kernel_volume == 125 ? 5 : 3;
+  const int total = kernel_volume * 96;
+  const Level& lv0 = s->lv[0];
+  const size_t part_bytes = align256((size_t)kStemMfmaWgs * 384 * 32 * sizeof(float));
+  if (ks == 5 && lv0.grid && lv0.n < (1 << 25) && workspace_bytes >= part_bytes + (size_t)lv0.npad * 16) {
+    // matrix-core path: colours in Morton order (behind the partials in the workspace: a3d_stem_wgrad_scene_workspace_bytes),
+    // one [384 x 32] accumulator per wave
+    f32x4* f4 = (f32x4*)((char*)workspace_dev + part_bytes);
+    k_stem_gather_morton<<<(lv0.n + 255) / 256, 256, 0, st>>>(feats3_dev, s->orig_row, lv0.perm, lv0.n, f4);
+    const int steps = (lv0.n + 3) / 4;
+    int wgs = (steps + 3) / 4;
+    if (wgs > kStemMfmaWgs) wgs = kStemMfmaWgs;
+    A3D_ALLOW_LDS(64 * 1024, k_stem_wgrad_mfma);
+    k_stem_wgrad_mfma<<<wgs, 256, 384 * 32 * sizeof(float), st>>>(lv0, f4, dy_dev, lddy, (float*)workspace_dev);
+    k_stem_wgrad_reduce<<<(total + 63) / 64, 512, 0, st>>>((const float*)workspace_dev, total, dw_dev, wgs, 384 * 32);
+    A3D_LAUNCH_CHECK();
+    return A3D_OK;
+  }
   k_stem_wgrad<<<dim3(kernel_volume, kStemSplits), 256, 0, st>>>(s->lv[0], feats3_dev, s->orig_row, dy_dev, lddy, ks,
                                                                (float*)workspace_dev);
-  const int total = kernel_volume * 96;
-  k_stem_wgrad_reduce<<<(total + 255) / 256, 256, 0, st>>>((const float*)workspace_dev, total, dw_dev);
+  k_stem_wgrad_reduce<<<(total + 63) / 64, 512, 0, st>>>((const float*)workspace_dev, total, dw_dev, kStemSplits, total);
   A3D_LAUNCH_CHECK();
   return A3D_OK;
 }

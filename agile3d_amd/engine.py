@@ -159,10 +159,10 @@ class BackboneProgram:
             s1, h1 = fold(blk.norm1)
             op(L.OP_CONV3, level, cin, cout, src, (tmp, 0), None, True, 27, pack(blk.conv1), s1, h1)
             res, proj = src, None
-            if blk.downsample is not None and fuse_proj and cin % 64 == 0:
+            if blk.downsample is not None and fuse_proj and cin % 32 == 0:
                 # out = relu(s2 conv2(h) + h2 + sp (x Wp) + hp): both scales into the weights, one accumulator, one launch.
-                # (cin % 64: the kernel's stage width at these shapes is 32 or 64 channels -- the 32 -> 64 block of level 2
-                # keeps its own 1x1 launch)
+                # (the kernel's stage width at these shapes is 32 or 64 channels; the 32 -> 64 block of level 2 runs its
+                # 64 -> 64 conv with 32-channel stages so that its 32-channel projection is a whole stage: all seven fused)
                 s2, h2 = fold(blk.norm2)
                 sp, hp = fold(blk.downsample[1])
                 w2 = blk.conv2.kernel3().detach().to(dev, torch.float32) * s2[None, None, :]

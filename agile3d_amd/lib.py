@@ -139,6 +139,7 @@ SYMBOLS = {
                                             C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                             C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "a3d_stem_wgrad_workspace_bytes": (C.c_size_t, [C.c_int]),
+    "a3d_stem_wgrad_scene_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int]),
     "a3d_stem_wgrad": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                  C.c_size_t, C.c_void_p]),
     "a3d_bn_local_stats": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),

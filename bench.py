@@ -117,6 +117,8 @@ def kernel_name(e):
     elif e.id == 0:
         name = f"k_conv_sk<{e.bn},{e.ksplit}>"   # BN columns per workgroup, CH input channels per stage (plan_sk; the
                                                   # profile entry's last integer field carries CH)
+        if e.kernel_volume >> 20:                 # the fused-head instantiation (k_conv_sk<..., HEAD = true>): its own kernel
+            name += "+head"
     elif e.id == L.PROF_DENSE:
         name = f"k_dense<{e.cin // 16},{e.cout // 16}>"
     return name

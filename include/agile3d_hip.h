@@ -238,6 +238,10 @@ int    a3d_conv_bn_train_forward(const a3d_scene* s, int kind, int level_in, con
 /* weight gradient of the input convolution conv0p1s1 (5^3 or 3^3, 3 -> 32; res16unet.py:225): feats3_dev in the
  * caller's row order as for a3d_program_run, dy_dev [n0][lddy >= 32] in internal row order, dw_dev [K][3][32] */
 size_t a3d_stem_wgrad_workspace_bytes(int kernel_volume);
+/* the size that also lets a3d_stem_wgrad run its matrix-core path (round 5: dW as one [384 x 32] MFMA accumulator per wave,
+ * voxels walked in Morton order against Morton-ordered colours kept behind the partials; dense level-0 grid, 5^3 only) --
+ * with the smaller workspace above the per-offset kernel runs */
+size_t a3d_stem_wgrad_scene_workspace_bytes(const a3d_scene* s, int kernel_volume);
 int    a3d_stem_wgrad(const a3d_scene* s, const float* feats3_dev, const float* dy_dev, int lddy, int kernel_volume,
                       float* dw_dev, void* workspace_dev, size_t workspace_bytes, void* stream);
 

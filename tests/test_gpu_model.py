@@ -74,7 +74,7 @@ def test_fused_residual_projections_equal_the_separate_launches(model_and_sd, n,
         eng.refresh_weights_if_stale()
         with torch.no_grad():
             eng.program = BackboneProgram(model, eng.device, fuse_proj=fuse)
-        assert eng.program.fused_projections == (6 if fuse else 0)
+        assert eng.program.fused_projections == (7 if fuse else 0)      # all seven BasicBlock.downsample projections
         pcd, aux, _, _ = _run_backbone(model, sc)
         outs.append([pcd.F.clone()] + [a.F.clone() for a in aux])
     eng.mark_stale()

@@ -1,17 +1,19 @@
 #!/bin/bash
 # Scratch script of the current GPU session (overwritten per session; `gpurun -- 'bash tools/gpu_session.sh'`).
 R=$GRAFT_REPO_ROOT
-O=$R/gpurun_out/s3
+O=$R/gpurun_out/s4
 mkdir -p $O
 cd $R
-timeout 2400 python -m pytest tests/test_gpu_backward.py -x -q > $O/t_backward.log 2>&1; echo "rc=$?" >> $O/t_backward.log
-timeout 1500 python -m pytest tests/test_gpu_distributed.py -x -q > $O/t_dist.log 2>&1; echo "rc=$?" >> $O/t_dist.log
-timeout 1500 python -m pytest tests/test_gpu_fit.py -x -q -s > $O/t_fit.log 2>&1; echo "rc=$?" >> $O/t_fit.log
+timeout 900 python -m pytest tests/test_gpu_conv.py -x -q -k "fused_head or fused_projection" > $O/t_head.log 2>&1; echo "rc=$?" >> $O/t_head.log
+timeout 900 python -m pytest tests/test_gpu_backward.py -x -q -k "stem or batchnorm or backbone_training" > $O/t_stem.log 2>&1; echo "rc=$?" >> $O/t_stem.log
+timeout 2700 python -m pytest tests -m gpu -x -q > $O/t_all.log 2>&1; echo "rc=$?" >> $O/t_all.log
+timeout 900 python bench.py > $O/bench.json 2> $O/bench.err
+A3D_FUSE_HEAD=0 timeout 600 python bench.py --steps-only --no-profile --reps 9 > $O/bench_nohead.json 2> $O/bench_nohead.err
+timeout 600 python bench.py --steps-only --no-profile --reps 9 > $O/bench_head.json 2> $O/bench_head.err
+LT_BATCH=16 timeout 300 python tools/layer_table.py > $O/layer_table_16scenes.txt 2>&1
+LT_BATCH=1 timeout 300 python tools/layer_table.py > $O/layer_table_1scene.txt 2>&1
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/trt
 A3D_BB_ITERS=6 A3D_TRAIN_TIMING=mark timeout 900 rocprofv3 --kernel-trace -d /tmp/trt -o t -- python $R/tools/backward_bench.py --step --reps 1 > $O/train_trace.log 2>&1
 python $R/tools/train_phase_trace.py /tmp/trt 2 40 > $O/train_phases.txt 2>&1
-cd $R
-A3D_BB_ITERS=8 A3D_TRAIN_TIMING=1 timeout 600 python tools/backward_bench.py --step --reps 1 2>&1 | grep -E "training iteration|train_one_step" > $O/training_iterations.txt
-timeout 2700 python -m pytest tests -m gpu -x -q > $O/t_all.log 2>&1; echo "rc=$?" >> $O/t_all.log
 ls -la $O
