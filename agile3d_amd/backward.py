@@ -195,6 +195,44 @@ def conv_bn_train_forward(scene, kind, level_in, w_packed, x, cin, cout, gamma, 
     return raw, mean, rstd
 
 
+def conv_dgrad_bn(scene, kind, level_in, part, dy, cout_fwd, out, acc, y, raw, mean, rstd, relu, state=None):
+    """a3d_conv_dgrad_bn for the conv y' = conv(x; w) of kind / level_in (FORWARD op) whose input x is the output of a
+    BatchNorm(+ReLU) unit (y, raw, mean, rstd): ``out`` [n_in + 1, cin] gets g = (dL/dx (+ out when ``acc``)) masked by y > 0;
+    returns the fp64 sums [2, cin] (sum g, sum g xhat).  ``part`` = the single (c0 = 0, width = cin, packed) entry of
+    packed_input_grad_weights, ``dy`` [n_out + 1, cout_fwd] with its zero row."""
+    lib = L.load()
+    back_kind = {L.OP_CONV3: L.OP_CONV3, L.OP_DOWN: L.OP_UP, L.OP_UP: L.OP_DOWN, L.OP_LINEAR: L.OP_LINEAR}[kind]
+    lo = level_out(kind, level_in)
+    c0, width, wp = part
+    dy = _rows(dy)
+    nbytes = lib.a3d_conv_bn_train_workspace_bytes(scene.handle, back_kind, lo, cout_fwd, width)
+    if nbytes == 0:
+        raise L.A3DError(lib.a3d_last_error().decode())
+    ws = _workspace(nbytes, dy.device, "convbn")
+    sums = torch.empty((2, width), dtype=torch.float64, device=dy.device)
+    yy = _rows(y) if relu else None
+    L.check(lib.a3d_conv_dgrad_bn(scene.handle, back_kind, lo, _ptr(dy), dy.stride(0), cout_fwd, _ptr(wp), width, _ptr(out),
+                                  out.stride(0), int(acc), _ptr(yy), yy.stride(0) if yy is not None else 0, _ptr(raw),
+                                  raw.stride(0), _ptr(mean), _ptr(rstd), int(relu), _ptr(sums),
+                                  state.take() if state is not None else None, _ptr(ws), ws.numel(), _stream()),
+            "a3d_conv_dgrad_bn")
+    return sums
+
+
+def bn_backward_from_sums(x, g, gamma, mean, rstd, sums, dx):
+    """BatchNorm backward from the sums a3d_conv_dgrad_bn produced: g [>= n, C] (already masked by the ReLU), x = raw [n, C],
+    dx [n + 1, C] (row n written as zeros).  Returns (dgamma, dbeta)."""
+    lib = L.load()
+    n, C_ = x.shape
+    x, g = _rows(x), _rows(g)
+    dgamma = torch.empty(C_, dtype=torch.float32, device=x.device)
+    dbeta = torch.empty_like(dgamma)
+    L.check(lib.a3d_bn_backward_apply(_ptr(x), x.stride(0), None, 0, _ptr(g), g.stride(0), n, C_, _ptr(gamma), _ptr(mean),
+                                      _ptr(rstd), 0, _ptr(sums), n, _ptr(sums), _ptr(dx), dx.stride(0), None, 0, _ptr(dgamma),
+                                      _ptr(dbeta), 1, _stream()), "a3d_bn_backward_apply")
+    return dgamma, dbeta
+
+
 def bn_train_backward_into(x, y, dy, gamma, mean, rstd, relu, dx, dres=None):
     """a3d_bn_train_backward on views: x (raw) [n, C], y / dy [>= n, C] views (any row stride), dx [n + 1, C] (row n is
     written as zeros), dres view [n + 1, C] or None.  Returns (dgamma, dbeta)."""

@@ -552,6 +552,37 @@ int bn_finish_from_partials(const float* partial, int nblocks, int rows_per_bloc
   A3D_LAUNCH_CHECK();
   return A3D_OK;
 }
+// [blocks][2][C] fp32 partials (the input-gradient conv's epilogue) -> sums [2][C] fp64, blocks added in a fixed order
+// column sums of MANY block partials (one per 64-row tile or 16-row group of a conv epilogue): 256 block lanes x 4 column
+// quads per workgroup, one 16-byte load per block and thread (k_col_final's 16 lanes per column walked 300+ blocks each)
+__global__ void __launch_bounds__(1024) k_col_final_tiles(const float* __restrict__ partial, int nblocks, int ncol, double* out) {
+  __shared__ double sh[kFin2Lanes][kFinCols + 1];
+  const int q = threadIdx.x & 3, bl = threadIdx.x >> 2;
+  const int c0 = blockIdx.x * kFinCols + 4 * q;
+  double s[4] = {0.0, 0.0, 0.0, 0.0};
+  if (c0 < ncol)
+    for (int b = bl; b < nblocks; b += kFin2Lanes) {
+      const f32x4 v = *(const f32x4*)(partial + (size_t)b * ncol + c0);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) s[t] += (double)v[t];
+    }
+#pragma unroll
+  for (int t = 0; t < 4; ++t) sh[bl][4 * q + t] = s[t];
+  __syncthreads();
+  const int c = blockIdx.x * kFinCols + threadIdx.x;
+  if (threadIdx.x >= kFinCols || c >= ncol) return;
+  double t = 0.0;
+  for (int k = 0; k < kFin2Lanes; ++k) t += sh[k][threadIdx.x];
+  out[c] = t;
+}
+int bn_sums_from_partials(const float* partial, int nblocks, int C, double* sums, hipStream_t st) {
+  if (nblocks >= 64)
+    k_col_final_tiles<<<(unsigned)((2 * C + kFinCols - 1) / kFinCols), 1024, 0, st>>>(partial, nblocks, 2 * C, sums);
+  else
+    k_col_final<<<(unsigned)((2 * C + kFinCols - 1) / kFinCols), 256, 0, st>>>(partial, nblocks, 2, C, sums);
+  A3D_LAUNCH_CHECK();
+  return A3D_OK;
+}
 static int bn_blocks(int64_t n, int& rows_per_block) {
   int blocks = (int)((n + 511) / 512);
   if (blocks > kBnMaxBlocks) blocks = kBnMaxBlocks;

@@ -88,6 +88,8 @@ int bn_finish_from_partials(const float* partial, int nblocks, int rows_per_bloc
                             int ldy, int y_zero_row, float* save_mean, float* save_rstd, float* running_mean,
                             float* running_var, float momentum, hipStream_t st);
 
+int bn_sums_from_partials(const float* partial, int nblocks, int C, double* sums, hipStream_t st);
+
 // ---- geometry constants -------------------------------------------------------------------
 constexpr int kTileRows = 128;   // output rows per conv workgroup
 constexpr int kGroupRows = 16;   // MFMA row granularity (v_mfma_f32_16x16x4_f32)

@@ -280,38 +280,6 @@ __global__ void k_nbr_morton(const LevelSet S) {
   int lb;
   const int L = ls_level(S, lb);
   const Level& lv = S.lv[L];
-  const int i = lb * blockDim.x + threadIdx.x;
-  if (i >= lv.n) return;
-  int b, X, Y, Z;
-  decode_key(lv.keys[i], L, b, X, Y, Z);
-  const int lim = kCoordOff >> L;
-  int r[27];
-  if (lv.grid) {
-    const ptrdiff_t c0 = (ptrdiff_t)grid_cell(lv, b, X, Y, Z);
-#pragma unroll
-    for (int k = 0; k < 27; ++k)     // x fastest; the grid's empty border covers the 3^3 neighbourhood
-      r[k] = lv.grid[c0 + ((ptrdiff_t)(k / 9 - 1) * lv.gdim[1] + ((k / 3) % 3 - 1)) * lv.gdim[0] + (k % 3 - 1)];
-  } else {
-    // hash levels: the first probe of all 27 lookups in flight together (most lookups end there: hit or empty slot), the
-    // few that collide finish with the serial probe loop
-    uint64_t want[27], got[27];
-    uint32_t h[27];
-#pragma unroll
-    for (int k = 0; k < 27; ++k) {
-      const int x = X + k % 3 - 1, y = Y + (k / 3) % 3 - 1, z = Z + k / 9 - 1;
-      const bool in = x >= -lim && x < lim && y >= -lim && y < lim && z >= -lim && z < lim;
-      want[k] = in ? make_key(b, x, y, z, L) : kEmptyKey;
-      h[k] = hash64(want[k]) & lv.hmask;
-      got[k] = in ? lv.hkeys[h[k]] : kEmptyKey;
-    }
-#pragma unroll
-    for (int k = 0; k < 27; ++k) {
-      if (want[k] == kEmptyKey || got[k] == kEmptyKey) r[k] = -1;
-      else if (got[k] == want[k]) r[k] = lv.hvals[h[k]];
-      else r[k] = hash_lookup(lv.hkeys, lv.hvals, lv.hmask, want[k]);
-    }
-  }
-  r[13] = i;
   // sort key = the 27 presence bits, the 12 edge offsets most significant, then the 8 corners, the 6 faces, the centre:
   // rows are grouped 16 at a time, a group multiplies for every offset ANY of its rows has, and the offsets a sort
   // does not reach (the low bits of the key) end up in nearly every group's union -- so the high bits should be the ones
@@ -319,6 +287,44 @@ __global__ void k_nbr_morton(const LevelSet S) {
   // Offsets issued per row on the bench scenes, plain k order -> this order: L1 12.28 -> 12.16, L2 15.83 -> 15.36,
   // L3 19.05 -> 18.49 (real neighbours per row: 11.65 / 13.61 / 14.94).
   constexpr int kKeyBit[27] = {14, 26, 13, 25, 6, 24, 12, 23, 11, 22, 5, 21, 4, 0, 3, 20, 2, 19, 10, 18, 9, 17, 1, 16, 8, 15, 7};
+  if (!lv.grid) {
+    // hash levels (the coarse levels; level 0 of far-apart inputs): a hash probe is a chain of dependent loads, so the 27
+    // lookups of a row go to 27 LANES (half a wave per row, the launch gives these levels 32 threads per row) and the
+    // presence mask is a ballot
+    const int k = threadIdx.x & 31;
+    const int i = lb * (blockDim.x >> 5) + (threadIdx.x >> 5);
+    int r = -1;
+    if (i < lv.n && k < 27) {
+      int b, X, Y, Z;
+      decode_key(lv.keys[i], L, b, X, Y, Z);
+      const int lim = kCoordOff >> L;
+      const int x = X + k % 3 - 1, y = Y + (k / 3) % 3 - 1, z = Z + k / 9 - 1;
+      if (k == 13) r = i;
+      else if (x >= -lim && x < lim && y >= -lim && y < lim && z >= -lim && z < lim)
+        r = hash_lookup(lv.hkeys, lv.hvals, lv.hmask, make_key(b, x, y, z, L));
+      S.nbrM[L][(size_t)k * lv.npad + i] = r;
+    }
+    const unsigned long long bal = __ballot(r >= 0);
+    if (k == 0 && i < lv.n) {
+      const uint32_t have = (uint32_t)(bal >> (threadIdx.x & 32)) & 0x7ffffffu;
+      uint32_t m = 0;
+#pragma unroll
+      for (int kk = 0; kk < 27; ++kk) m |= ((have >> kk) & 1u) << kKeyBit[kk];
+      S.cat_keys[S.off[L] + i] = ((uint64_t)L << S.level_shift) | ((uint64_t)(i >> S.st_shift) << 27) | m;
+      S.cat_vals[S.off[L] + i] = S.off[L] + i;
+    }
+    return;
+  }
+  const int i = lb * blockDim.x + threadIdx.x;
+  if (i >= lv.n) return;
+  int b, X, Y, Z;
+  decode_key(lv.keys[i], L, b, X, Y, Z);
+  int r[27];
+  const ptrdiff_t c0 = (ptrdiff_t)grid_cell(lv, b, X, Y, Z);
+#pragma unroll
+  for (int k = 0; k < 27; ++k)     // x fastest; the grid's empty border covers the 3^3 neighbourhood
+    r[k] = lv.grid[c0 + ((ptrdiff_t)(k / 9 - 1) * lv.gdim[1] + ((k / 3) % 3 - 1)) * lv.gdim[0] + (k % 3 - 1)];
+  r[13] = i;
   uint32_t m = 0;
 #pragma unroll
   for (int k = 0; k < 27; ++k) {
@@ -839,7 +845,10 @@ extern "C" int a3d_scene_create(const int32_t* coords4_dev, int64_t n_voxels, vo
   // ---- stage A: hash, neighbours in Morton order, sort keys
   g = blocks(NL, [&](int L) { return (int64_t)sc->lv[L].n; });
   k_hash_insert<<<g, T, 0, st>>>(S);
-  k_nbr_morton<<<g, T, 0, st>>>(S);      // neighbour rows + presence masks + the sort keys, one thread per row
+  // neighbour rows + presence masks + the sort keys: one thread per row on the level-0 grid, 32 threads per row on hash levels
+  g = blocks(NL, [&](int L) { return sc->lv[L].grid ? (int64_t)sc->lv[L].n : (int64_t)sc->lv[L].n * 32; });
+  k_nbr_morton<<<g, T, 0, st>>>(S);
+  g = blocks(NL, [&](int L) { return (int64_t)sc->lv[L].n; });
   A3D_LAUNCH_CHECK();
   // ---- stage B: ONE stable radix sort re-orders the rows of all levels inside their super tiles
   {

@@ -99,14 +99,34 @@ struct SkArgs {
   // squared deviations from the TILE mean, [n_tiles][2][stats_ld] -- what k_bn_combine merges into the batch statistics
   float* stats;
   int stats_ld;
+  // STATS == 2 (input-gradient conv whose output is the COMPLETE gradient dy of a BatchNorm(+ReLU) unit's output y): the
+  // epilogue masks it (g = dy where y > 0), stores g, and writes per tile the two column sums the BatchNorm backward needs,
+  // stats[tile][0][c] = sum g, stats[tile][1][c] = sum g * xhat with xhat = (raw - mean) rstd -- no pass over dy, y and raw
+  // for the sums afterwards
+  const float* bw_y;
+  const float* bw_raw;
+  const float* bw_mean;
+  const float* bw_rstd;
+  int bw_ldy, bw_ldraw, bw_relu;
+};
+struct BwArgs {   // the same for k_conv_wl (and the host-side plumbing)
+  const float *y, *raw, *mean, *rstd;
+  int ldy, ldraw, relu;
 };
 
 // sum over the 16 lanes that share lane >> 4 (the 16 rows of an MFMA group), result in every lane; fixed order
+// (DPP row operations: four VALU adds with a lane permutation as operand modifier.  The first version used __shfl_xor =
+// ds_bpermute_b32: 192 of them per tile epilogue, four dependent LDS round trips per value -- the statistics epilogue cost
+// 9-13 % of the conv's time, profiles/r05_experiments.txt)
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
 __device__ __forceinline__ float row16_sum(float v) {
-  v += __shfl_xor(v, 1, 16);
-  v += __shfl_xor(v, 2, 16);
-  v += __shfl_xor(v, 4, 16);
-  v += __shfl_xor(v, 8, 16);
+  v += dpp_mov<0xB1>(v);    // quad_perm [1, 0, 3, 2]
+  v += dpp_mov<0x4E>(v);    // quad_perm [2, 3, 0, 1]: every lane holds its quad's sum
+  v += dpp_mov<0x141>(v);   // row_half_mirror: + the other quad of the 8-lane half
+  v += dpp_mov<0x140>(v);   // row_mirror: + the other half of the 16-lane row
   return v;
 }
 
@@ -149,7 +169,7 @@ __device__ __forceinline__ void wait_all_vmem() { __builtin_amdgcn_s_waitcnt(0x0
 // HEAD: the owner's epilogue multiplies the finished rows (all BN = cout columns are in this workgroup's registers, in exactly
 // the B-operand layout of the next MFMA: lane (g, j) holds channels 16 ct + 4 g + t of row j) with a packed 1x1 weight and
 // writes the product to a second output -- lin_squeeze_head behind block8's last conv, without re-reading the rows.
-template <int BN, int CH, int PAIR, bool FUSE = false, bool STATS = false, bool HEAD = false>
+template <int BN, int CH, int PAIR, bool FUSE = false, int STATS = 0, bool HEAD = false>
 __global__ void __launch_bounds__(256, PAIR ? ((BN <= 96 && CH <= 32) ? 4 : 3) : ((BN <= 96 && CH <= 48) ? 3 : 2))
     k_conv_sk(const SkArgs a) {
   static_assert(!FUSE || PAIR != 2, "the fused projection runs on the exact-fp32 builds");
@@ -537,7 +557,7 @@ __global__ void __launch_bounds__(256, PAIR ? ((BN <= 96 && CH <= 32) ? 4 : 3) :
             for (int ct = 0; ct < NCT; ++ct) acc[0][ct] += pa[u][ct];
         }
       }
-      if constexpr (STATS) {
+      if constexpr (STATS == 1) {
         // BatchNorm statistics of the RAW output (before scale / shift / residual / ReLU, which the training path does
         // not pass): column sums over the tile's valid rows, then the squared deviations from the tile mean -- wave-level
         // shuffles over the 16 rows of a group, the four waves through LDS behind the weight ring, fixed orders
@@ -574,6 +594,48 @@ __global__ void __launch_bounds__(256, PAIR ? ((BN <= 96 && CH <= 32) ? 4 : 3) :
           P[a.stats_ld] = ((s2p[0] + s2p[BN]) + s2p[2 * BN]) + s2p[3 * BN];
         }
       }
+      if constexpr (STATS == 2) {
+        // dy = acc (+ the gradient already in the buffer) -> g = dy masked by (y > 0) -> stored; column sums of g and g xhat
+        // over the tile: shuffles over the 16 rows of a group, the four waves through LDS, fixed orders
+        float* sst = (float*)(misc + 16);   // [2][4][BN]
+        const int myrow = r0 + wrow;
+        const bool valid = myrow < a.c.n_out;
+        const int orow = valid ? (a.c.out_map ? a.c.out_map[myrow] : myrow) : 0;
+        float* po = a.c.out + (size_t)orow * a.c.ldo + ct0 * 16 + 4 * g;
+        const float* pr = a.c.res ? a.c.res + (size_t)orow * a.c.ldr + ct0 * 16 + 4 * g : nullptr;
+        const float* py = a.bw_y + (size_t)orow * a.bw_ldy + ct0 * 16 + 4 * g;
+        const float* pw = a.bw_raw + (size_t)orow * a.bw_ldraw + ct0 * 16 + 4 * g;
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct) {
+          f32x4 v = acc[0][ct];
+          if (pr) v += *(const f32x4*)(pr + ct * 16);
+          if (a.bw_relu) {
+            const f32x4 yv = *(const f32x4*)(py + ct * 16);
+#pragma unroll
+            for (int tt = 0; tt < 4; ++tt) v[tt] = yv[tt] > 0.f ? v[tt] : 0.f;
+          }
+          const f32x4 xh = (*(const f32x4*)(pw + ct * 16) - *(const f32x4*)(a.bw_mean + (ct0 + ct) * 16 + 4 * g)) *
+                           *(const f32x4*)(a.bw_rstd + (ct0 + ct) * 16 + 4 * g);
+          if (valid) *(f32x4*)(po + ct * 16) = v;
+          f32x4 s1 = valid ? v : (f32x4){0.f, 0.f, 0.f, 0.f};
+          f32x4 s2 = s1 * xh;
+#pragma unroll
+          for (int tt = 0; tt < 4; ++tt) s1[tt] = row16_sum(s1[tt]), s2[tt] = row16_sum(s2[tt]);
+          if (j == 0) {
+            *(f32x4*)(sst + wave * BN + ct * 16 + 4 * g) = s1;
+            *(f32x4*)(sst + 4 * BN + wave * BN + ct * 16 + 4 * g) = s2;
+          }
+        }
+        __syncthreads();
+        if (tid < BN) {
+          const float* s1p = sst + tid;
+          const float* s2p = sst + 4 * BN + tid;
+          float* P = a.stats + (size_t)t * 2 * a.stats_ld + cb * BN + tid;
+          P[0] = ((s1p[0] + s1p[BN]) + s1p[2 * BN]) + s1p[3 * BN];
+          P[a.stats_ld] = ((s2p[0] + s2p[BN]) + s2p[2 * BN]) + s2p[3 * BN];
+        }
+        __syncthreads();   // the scratch is rewritten by this workgroup's next owned tile
+      } else {
 #pragma unroll
       for (int r = 0; r < RG; ++r) {
         const int myrow = r0 + wrow + 16 * r;
@@ -600,6 +662,7 @@ __global__ void __launch_bounds__(256, PAIR ? ((BN <= 96 && CH <= 32) ? 4 : 3) :
             if constexpr (HEAD) acc[r][ct] = v;   // the finished row stays in the accumulator registers for the head below
           }
         }
+      }
       }
       if constexpr (HEAD) {
         // second GEMM on the finished tile: pcd[row][16 c2 + 4 g + r] = sum over the BN channels.  The weight fragments come
@@ -663,8 +726,9 @@ __global__ void __launch_bounds__(256, PAIR ? ((BN <= 96 && CH <= 32) ? 4 : 3) :
 // hand-offs (offsets ascending, channels ascending), so results are bit-identical to it.
 // STATS (training): every finished 16-row group also writes its BatchNorm partials (column sums, squared deviations from
 // the GROUP mean) to stats[group][2][stats_ld] -- a group belongs to one wave, so this needs no LDS and no barrier.
-template <int NS, int NCT, bool STATS = false>
-__global__ void __launch_bounds__(1024) k_conv_wl(const ConvArgs c, int ngroups, float* stats = nullptr, int stats_ld = 0) {
+template <int NS, int NCT, int STATS = 0>
+__global__ void __launch_bounds__(1024) k_conv_wl(const ConvArgs c, int ngroups, float* stats = nullptr, int stats_ld = 0,
+                                                  const BwArgs bw = BwArgs()) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   f32x4* Wl = (f32x4*)smem;   // [K][NS][NCT][64]
   const int tid = threadIdx.x, lane = tid & 63;
@@ -758,7 +822,34 @@ __global__ void __launch_bounds__(1024) k_conv_wl(const ConvArgs c, int ngroups,
     }
     if (!v1 || g1 != g0) {   // last offset of group g0: epilogue (as k_conv_sk's)
       const int myrow = g0 * 16 + j;
-      if constexpr (STATS) {
+      if constexpr (STATS == 2) {   // input-gradient conv: g = (dy (+ res)) masked by y > 0, stored; sums of g and g xhat per group
+        const bool valid = myrow < c.n_out;
+        const int orow = valid ? (c.out_map ? c.out_map[myrow] : myrow) : 0;
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct) {
+          f32x4 v = acc[ct];
+          if (c.res) v += *(const f32x4*)(c.res + (size_t)orow * c.ldr + ct * 16 + 4 * g);
+          if (bw.relu) {
+            const f32x4 yv = *(const f32x4*)(bw.y + (size_t)orow * bw.ldy + ct * 16 + 4 * g);
+#pragma unroll
+            for (int tt = 0; tt < 4; ++tt) v[tt] = yv[tt] > 0.f ? v[tt] : 0.f;
+          }
+          const f32x4 xh = (*(const f32x4*)(bw.raw + (size_t)orow * bw.ldraw + ct * 16 + 4 * g) - *(const f32x4*)(bw.mean + ct * 16 + 4 * g)) *
+                           *(const f32x4*)(bw.rstd + ct * 16 + 4 * g);
+          if (valid) *(f32x4*)(c.out + (size_t)orow * c.ldo + ct * 16 + 4 * g) = v;
+          f32x4 s1 = valid ? v : (f32x4){0.f, 0.f, 0.f, 0.f};
+          f32x4 s2 = s1 * xh;
+#pragma unroll
+          for (int tt = 0; tt < 4; ++tt) s1[tt] = row16_sum(s1[tt]), s2[tt] = row16_sum(s2[tt]);
+          if (j == 0) {
+            float* P = stats + (size_t)g0 * 2 * stats_ld + ct * 16 + 4 * g;
+            *(f32x4*)P = s1;
+            *(f32x4*)(P + stats_ld) = s2;
+          }
+          acc[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+      } else {
+      if constexpr (STATS == 1) {
         const bool valid = myrow < c.n_out;
         const float inv = 1.f / (float)min(16, c.n_out - g0 * 16);
 #pragma unroll
@@ -796,6 +887,7 @@ __global__ void __launch_bounds__(1024) k_conv_wl(const ConvArgs c, int ngroups,
       }
 #pragma unroll
       for (int ct = 0; ct < NCT; ++ct) acc[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      }
     }
 #pragma unroll
     for (int S = 0; S < NS; ++S) {
@@ -816,7 +908,7 @@ static bool conv_wl_supported(const ConvArgs& c) {
   return (size_t)c.K * c.cin * c.cout * 4 <= 144 * 1024;
 }
 
-static int launch_conv_wl(const ConvArgs& c, hipStream_t st, float* stats = nullptr, int stats_ld = 0) {
+static int launch_conv_wl(const ConvArgs& c, hipStream_t st, float* stats = nullptr, int stats_ld = 0, const BwArgs* bw = nullptr) {
   const int ngroups = (c.n_out + 15) / 16;
   const size_t lds = (size_t)c.K * c.cin * c.cout * 4;
   // one workgroup per CU; 16 waves when there are groups for them, never fewer than 4
@@ -830,7 +922,8 @@ static int launch_conv_wl(const ConvArgs& c, hipStream_t st, float* stats = null
       set_error("spconv: no statistics build of the 64-channel LDS-resident kernel");
       return A3D_ERR_UNSUPPORTED;
     }
-    k_conv_wl<2, 2, true><<<grid, 64 * nw, lds, st>>>(c, ngroups, stats, stats_ld);
+    if (bw) k_conv_wl<2, 2, 2><<<grid, 64 * nw, lds, st>>>(c, ngroups, stats, stats_ld, *bw);
+    else k_conv_wl<2, 2, 1><<<grid, 64 * nw, lds, st>>>(c, ngroups, stats, stats_ld);
   } else if (c.cin == 32) k_conv_wl<2, 2><<<grid, 64 * nw, lds, st>>>(c, ngroups);
   else k_conv_wl<4, 4><<<grid, 64 * nw, lds, st>>>(c, ngroups);
   A3D_LAUNCH_CHECK();
@@ -1347,8 +1440,10 @@ static void allow_big_lds() {
 #define A3D_BIG3(BN_, CH_) \
   A3D_ALLOW_LDS(160 * 1024, k_conv_sk<BN_, CH_, 0>); \
   A3D_ALLOW_LDS(160 * 1024, k_conv_sk<BN_, CH_, 1>); \
-  A3D_ALLOW_LDS(160 * 1024, (k_conv_sk<BN_, CH_, 0, false, true>)); \
-  A3D_ALLOW_LDS(160 * 1024, (k_conv_sk<BN_, CH_, 1, false, true>));
+  A3D_ALLOW_LDS(160 * 1024, (k_conv_sk<BN_, CH_, 0, false, 1>)); \
+  A3D_ALLOW_LDS(160 * 1024, (k_conv_sk<BN_, CH_, 1, false, 1>)); \
+  A3D_ALLOW_LDS(160 * 1024, (k_conv_sk<BN_, CH_, 0, false, 2>)); \
+  A3D_ALLOW_LDS(160 * 1024, (k_conv_sk<BN_, CH_, 1, false, 2>));
   A3D_BIG3(32, 32) A3D_BIG3(32, 64) A3D_BIG3(32, 96) A3D_BIG3(64, 32) A3D_BIG3(64, 64) A3D_BIG3(64, 96)
   A3D_BIG3(96, 32) A3D_BIG3(96, 48) A3D_BIG3(96, 64) A3D_BIG3(96, 96) A3D_BIG3(128, 32) A3D_BIG3(128, 64)
 #undef A3D_BIG3
@@ -1357,14 +1452,15 @@ static void allow_big_lds() {
   A3D_ALLOW_LDS(160 * 1024, (k_conv_sk<BN_, CH_, 1, true>));
   A3D_BIGF(64, 32) A3D_BIGF(64, 64) A3D_BIGF(96, 32) A3D_BIGF(128, 32)
 #undef A3D_BIGF
-  A3D_ALLOW_LDS(160 * 1024, (k_conv_sk<96, 32, 1, false, false, true>));
+  A3D_ALLOW_LDS(160 * 1024, (k_conv_sk<96, 32, 1, false, 0, true>));
   A3D_ALLOW_LDS(160 * 1024, k_conv_sk<96, 32, 2>);
   A3D_ALLOW_LDS(160 * 1024, k_conv_sk<128, 32, 2>);
   A3D_ALLOW_LDS(160 * 1024, k_conv_sk<64, 32, 2>);
   A3D_ALLOW_LDS(160 * 1024, k_conv_sk<32, 32, 2>);
   A3D_ALLOW_LDS(160 * 1024, k_conv_wl<2, 2>);
   A3D_ALLOW_LDS(160 * 1024, k_conv_wl<4, 4>);
-  A3D_ALLOW_LDS(160 * 1024, (k_conv_wl<2, 2, true>));
+  A3D_ALLOW_LDS(160 * 1024, (k_conv_wl<2, 2, 1>));
+  A3D_ALLOW_LDS(160 * 1024, (k_conv_wl<2, 2, 2>));
   A3D_ALLOW_LDS(160 * 1024, (k_dense<8, 8, false>));
   A3D_ALLOW_LDS(160 * 1024, (k_dense<8, 6, false>));
   A3D_ALLOW_LDS(160 * 1024, (k_dense<6, 8, false>));
@@ -1396,10 +1492,13 @@ static bool sk_head_ok(int n_rows, int K, int cin, int cout, int head_cout, bool
   return p.bn == 96 && p.ch == 32 && p.pair == 1;
 }
 
+// bw != nullptr (with stats): the BatchNorm-BACKWARD sums instead (STATS == 2: the op is an input-gradient conv, a residual =
+// the gradient already accumulated in the buffer is allowed)
 static int launch_conv_sk(ConvArgs c, const int* pre64, float* slab_ws, size_t slab_ws_floats, int* state,
-                          hipStream_t st, float* stats = nullptr, int stats_ld = 0, int* stats_rows = nullptr) {
+                          hipStream_t st, float* stats = nullptr, int stats_ld = 0, int* stats_rows = nullptr,
+                          const BwArgs* bw = nullptr) {
   allow_big_lds();
-  if (stats && (c.scale || c.shift || c.relu || c.cin2 > 0 || conv_emu(c.K, c.cin, c.cout) || !stats_rows)) {
+  if (stats && (c.scale || c.shift || c.relu || c.cin2 > 0 || conv_emu(c.K, c.cin, c.cout) || !stats_rows || (c.res && !bw))) {
     set_error("spconv: BatchNorm statistics are taken of a raw convolution (no epilogue, no fused projection, exact fp32)");
     return A3D_ERR_UNSUPPORTED;
   }
@@ -1417,7 +1516,7 @@ static int launch_conv_sk(ConvArgs c, const int* pre64, float* slab_ws, size_t s
   }
   if (c.cin2 == 0 && conv_wl_supported(c) && !conv_emu(c.K, c.cin, c.cout)) {
     if (stats) *stats_rows = 16;
-    return launch_conv_wl(c, st, stats, stats_ld);
+    return launch_conv_wl(c, st, stats, stats_ld, bw);
   }
   // hand-offs (shares cut inside tiles) pay where a tile is long and tiles are few: the 3^3 maps, and the 2^3 maps of
   // the small levels.  1x1 layers and 2^3 maps with a tile per workgroup slot or more run whole tiles: no ticket, no
@@ -1491,7 +1590,7 @@ static int launch_conv_sk(ConvArgs c, const int* pre64, float* slab_ws, size_t s
       set_error("spconv: no fused-head build for BN %d CH %d pair %d", p.bn, p.ch, p.pair);
       return A3D_ERR_UNSUPPORTED;
     }
-    k_conv_sk<96, 32, 1, false, false, true><<<p.G, 256, p.lds, st>>>(a);
+    k_conv_sk<96, 32, 1, false, 0, true><<<p.G, 256, p.lds, st>>>(a);
     A3D_LAUNCH_CHECK();
     return A3D_OK;
   }
@@ -1500,8 +1599,20 @@ static int launch_conv_sk(ConvArgs c, const int* pre64, float* slab_ws, size_t s
     a.stats_ld = stats_ld;
     *stats_rows = 64;
     const size_t lds_s = p.lds + (size_t)2 * 4 * p.bn * 4;
+    if (bw) {
+      a.bw_y = bw->y, a.bw_raw = bw->raw, a.bw_mean = bw->mean, a.bw_rstd = bw->rstd;
+      a.bw_ldy = bw->ldy, a.bw_ldraw = bw->ldraw, a.bw_relu = bw->relu;
+#define A3D_LB(BN_, CH_) \
+  if (p.bn == BN_ && p.ch == CH_) { if (p.pair) k_conv_sk<BN_, CH_, 1, false, 2><<<p.G, 256, lds_s, st>>>(a); else k_conv_sk<BN_, CH_, 0, false, 2><<<p.G, 256, lds_s, st>>>(a); } else
+      A3D_LB(32, 32) A3D_LB(32, 64) A3D_LB(32, 96) A3D_LB(64, 32) A3D_LB(64, 64) A3D_LB(64, 96)
+      A3D_LB(96, 32) A3D_LB(96, 48) A3D_LB(96, 64) A3D_LB(96, 96) A3D_LB(128, 32) A3D_LB(128, 64)
+      { set_error("spconv: no kernel for BN %d CH %d", p.bn, p.ch); return A3D_ERR_UNSUPPORTED; }
+#undef A3D_LB
+      A3D_LAUNCH_CHECK();
+      return A3D_OK;
+    }
 #define A3D_LS(BN_, CH_) \
-  if (p.bn == BN_ && p.ch == CH_) { if (p.pair) k_conv_sk<BN_, CH_, 1, false, true><<<p.G, 256, lds_s, st>>>(a); else k_conv_sk<BN_, CH_, 0, false, true><<<p.G, 256, lds_s, st>>>(a); } else
+  if (p.bn == BN_ && p.ch == CH_) { if (p.pair) k_conv_sk<BN_, CH_, 1, false, 1><<<p.G, 256, lds_s, st>>>(a); else k_conv_sk<BN_, CH_, 0, false, 1><<<p.G, 256, lds_s, st>>>(a); } else
     A3D_LS(32, 32) A3D_LS(32, 64) A3D_LS(32, 96) A3D_LS(64, 32) A3D_LS(64, 64) A3D_LS(64, 96)
     A3D_LS(96, 32) A3D_LS(96, 48) A3D_LS(96, 64) A3D_LS(96, 96) A3D_LS(128, 32) A3D_LS(128, 64)
     { set_error("spconv: no kernel for BN %d CH %d", p.bn, p.ch); return A3D_ERR_UNSUPPORTED; }
@@ -1890,7 +2001,7 @@ extern "C" size_t a3d_conv_apply_workspace_bytes(const a3d_scene* s, int kind, i
 static int conv_apply_impl(const a3d_scene* s, int kind, int level_in, const float* x_dev, int ldx, int cin,
                            const float* w_packed_dev, int cout, float* y_dev, int ldy, int y_zero_row, const float* res_dev,
                            int ldr, int* state_dev, float* stats, int stats_ld, int* stats_rows, void* workspace_dev,
-                           size_t workspace_bytes, hipStream_t st, const char* who) {
+                           size_t workspace_bytes, hipStream_t st, const char* who, const BwArgs* bw = nullptr) {
   if (!s || !x_dev || !w_packed_dev || !y_dev || level_in < 0 || level_in >= A3D_NUM_LEVELS || (ldx & 3) || (ldy & 3) ||
       ldx < cin || ldy < cout || (res_dev && ((ldr & 3) || ldr < cout))) {
     set_error("%s: bad arguments", who);
@@ -1959,7 +2070,7 @@ static int conv_apply_impl(const a3d_scene* s, int kind, int level_in, const flo
   float* slab = (float*)((char*)workspace_dev + align256((size_t)kMaxQueuesPerOp * 4));
   const size_t slab_floats = (workspace_bytes - align256((size_t)kMaxQueuesPerOp * 4)) / 4;
   if (!state_dev) A3D_HIP_CHECK(hipMemsetAsync(state, 0, (size_t)kMaxQueuesPerOp * 4, st));
-  return launch_conv_sk(a, pre, slab, slab_floats, state, st, stats, stats_ld, stats_rows);
+  return launch_conv_sk(a, pre, slab, slab_floats, state, st, stats, stats_ld, stats_rows, bw);
 }
 
 extern "C" int a3d_conv_apply(const a3d_scene* s, int kind, int level_in, const float* x_dev, int ldx, int cin,
@@ -1978,6 +2089,34 @@ extern "C" int a3d_conv_apply_acc(const a3d_scene* s, int kind, int level_in, co
   return conv_apply_impl(s, kind, level_in, x_dev, ldx, cin, w_packed_dev, cout, y_dev, ldy, y_zero_row, res_dev, ldr,
                          (int*)state_dev, nullptr, 0, nullptr, workspace_dev, workspace_bytes, (hipStream_t)stream,
                          "a3d_conv_apply_acc");
+}
+
+// Input-gradient conv whose output is the complete gradient of a BatchNorm(+ReLU) unit's output: see a3d_conv_dgrad_bn in
+// the header.  sums_dev [2][cout] fp64 = (sum g, sum g xhat) over all rows: what a3d_bn_backward_apply takes.
+extern "C" int a3d_conv_dgrad_bn(const a3d_scene* s, int kind, int level_in, const float* x_dev, int ldx, int cin,
+                                 const float* w_packed_dev, int cout, float* g_dev, int ldg, int acc, const float* y_dev,
+                                 int ldy, const float* raw_dev, int ld_raw, const float* mean_dev, const float* rstd_dev,
+                                 int relu, double* sums_dev, void* state_dev, void* workspace_dev, size_t workspace_bytes,
+                                 void* stream) {
+  const size_t need = a3d_conv_bn_train_workspace_bytes(s, kind, level_in, cin, cout);
+  if (!s || !need || !workspace_dev || workspace_bytes < need || ((uintptr_t)workspace_dev & 255) || !g_dev || !raw_dev ||
+      !mean_dev || !rstd_dev || !sums_dev || (relu && !y_dev) || (ldy & 3) || (ld_raw & 3)) {
+    set_error("a3d_conv_dgrad_bn: bad arguments or workspace too small (%zu < %zu)", workspace_bytes, need);
+    return A3D_ERR_INVALID;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  const size_t conv_bytes = align256(a3d_conv_apply_workspace_bytes(s, kind, level_in, cin, cout));
+  float* partial = (float*)((char*)workspace_dev + conv_bytes);
+  BwArgs bw;
+  bw.y = y_dev, bw.raw = raw_dev, bw.mean = mean_dev, bw.rstd = rstd_dev, bw.ldy = ldy, bw.ldraw = ld_raw, bw.relu = relu;
+  int rows_per_block = 0;
+  int rc = conv_apply_impl(s, kind, level_in, x_dev, ldx, cin, w_packed_dev, cout, g_dev, ldg, 1, acc ? g_dev : nullptr, ldg,
+                           (int*)state_dev, partial, cout, &rows_per_block, workspace_dev, conv_bytes, st, "a3d_conv_dgrad_bn",
+                           &bw);
+  if (rc != A3D_OK) return rc;
+  const int lvl_out = level_in + (kind == A3D_OP_DOWN ? 1 : kind == A3D_OP_UP ? -1 : 0);
+  const int n = s->lv[lvl_out].n;
+  return bn_sums_from_partials(partial, (n + rows_per_block - 1) / rows_per_block, cout, sums_dev, st);
 }
 
 extern "C" size_t a3d_conv_bn_train_workspace_bytes(const a3d_scene* s, int kind, int level_in, int cin, int cout) {

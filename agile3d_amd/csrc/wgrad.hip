@@ -119,6 +119,8 @@ __global__ void __launch_bounds__(256) k_wgrad(const WgradArgs a) {
     const int ngrp = next_group(grp + 4);
     int xi_n, yi_n;
     load_pairs(ngrp, xi_n, yi_n);
+    // (round 5: four rotating row buffers with the step loop unrolled -- no register copies -- measured 8 % SLOWER on
+    // <6,6> (462 -> 498 us): the copies are not what this loop waits for; profiles/r05_experiments.txt)
 #pragma unroll 1
     for (int s = 0; s < 4; ++s) {
 #pragma unroll
@@ -212,6 +214,9 @@ static bool wgrad_plan(int n_pos, int K, int cin, int cout, WgradPlan& p) {
   const int tgt = n_pos > 200000 ? 3072 : 1536;
   int chunks = (tgt + K * p.nblocks - 1) / (K * p.nblocks);
   if (chunks > 256) chunks = 256;
+  // (round 5: fewer chunks on the small levels -- at least 9 row groups per wave, so that a 256 -> 256 layer of level 4
+  // writes 14 MB of partials instead of 56 -- measured SLOWER, <8,4> 66 -> 88 us: a wave's groups are a chain of two-deep
+  // row fetches, more workgroups hide it better than less partial traffic pays)
   if (chunks > (ngroups + 3) / 4) chunks = (ngroups + 3) / 4;      // at least one group per wave
   if (chunks < 1) chunks = 1;
   p.chunk_groups = (ngroups + chunks - 1) / chunks;

@@ -249,10 +249,14 @@ class BackboneProgram:
         self.keep.append(hb)
         hw = pack(head)
         last = self.ops[-1]                   # block8's last conv: its workgroups hold complete 96-column output rows
-        if (os.environ.get("A3D_FUSE_HEAD", "1") != "0" and last.kind == L.OP_CONV3 and last.out_buf == f4
+        if (os.environ.get("A3D_FUSE_HEAD", "0") == "1" and last.kind == L.OP_CONV3 and last.out_buf == f4
                 and last.proj_cin == 0):
             # lin_squeeze_head as a second GEMM in that conv's epilogue (SURVEY 2.1's second fusion): the [N, 96] rows are
             # not read back, one launch less.  The library runs the head as its own 1x1 launch where no fused build exists.
+            # OPT-IN (A3D_FUSE_HEAD=1): built and measured in round 5 -- the fused launch takes 2 650-2 760 us on the 16-scene
+            # batch against 2 190 + 336 for conv + k_dense (four workgroups per CU each stream the 48 KB head weights through
+            # the CU's L1 for every 64-row tile), 640-643 vs 643-646 scenes/s; one scene: 208 vs 172 + 33 us
+            # (profiles/r05_experiments.txt).  The separate launch stays the default.
             last.head_w_dev, last.head_bias_dev, last.head_cout = hw.data_ptr(), hb.data_ptr(), model.mask_dim
             self.fused_head = True
         else:

@@ -25,10 +25,13 @@ class _T:
     """Activation node: value [n + 1, C] (row n = the zero row; possibly a column slice of a concatenation's buffer),
     level, gradient buffer (same shape; ``ginit`` says whether something has been written to it yet -- the first
     contribution is a plain write, later ones are added inside the producing kernel's epilogue)."""
-    __slots__ = ("v", "level", "g", "ginit")
+    __slots__ = ("v", "level", "g", "ginit", "bn", "pending", "sums")
 
     def __init__(self, v, level):
         self.v, self.level, self.g, self.ginit = v, level, None, False
+        self.bn = None        # (raw, mean, rstd, relu) of the conv + BatchNorm unit that produced this node (fused path)
+        self.pending = 0      # gradient contributions still to come (consumers of the forward pass)
+        self.sums = None      # fp64 [2, C]: the BatchNorm-backward sums, when the LAST contribution's conv produced them
 
     def grad_buffer(self):
         if self.g is None:
@@ -170,6 +173,7 @@ class BackboneTape:
         self.model, self.scene = model, scene
         self.sync_bn = _sync_bn_default() if sync_bn is None else bool(sync_bn)
         self.fused_bn = not self.sync_bn and os.environ.get("A3D_CONV_EMU", "0") == "0"
+        self.fuse_bwd = os.environ.get("A3D_FUSE_BN_BWD", "1") != "0"     # tests / A-B: the layer-at-a-time BatchNorm backward
         self.feats3 = feats3.to(torch.float32).contiguous()
         self.steps = []          # backward closures, in forward order
         self.relu_levels = []
@@ -228,6 +232,11 @@ class BackboneTape:
                                                    b.momentum, zero_row=True)
             yv.copy_(v)
         y = _T(yv, lo)
+        if self.fused_bn and self.fuse_bwd:
+            y.bn = (raw, mean, rstd, relu)
+        x.pending += 1
+        if res is not None:
+            res.pending += 1
         if relu:
             self.relu_levels.append((lo, _View(yv[:n_out])))   # forward order of the ReLUs (tests read the 0/1 masks)
 
@@ -236,10 +245,18 @@ class BackboneTape:
             draw = self._new(lo, cout)
             dres = None
             if res is not None:
-                dres = res.grad_buffer()
                 assert not res.ginit, "the residual branch's gradient is always the first contribution to its node"
+                res.pending -= 1
+                if y.sums is None:
+                    dres = res.grad_buffer()
                 res.ginit = True
-            if self.sync_bn:
+            if y.sums is not None:
+                # the last contribution to dL/dy was an input-gradient conv that masked it (g) and summed g, g xhat in its
+                # epilogue: no pass over dy / y / raw for the sums, and d(res) = g IS the buffer (no copy)
+                dg, db = B.bn_backward_from_sums(raw, y.g, gamma, mean, rstd, y.sums, draw)
+                if res is not None:
+                    res.g = y.g
+            elif self.sync_bn:
                 dx, dg, db, dr = B.bn_sync_backward(raw, yv[:n_out], y.g[:n_out], gamma, mean, rstd, n_glob, relu,
                                                     res is not None, zero_row=True)
                 draw.copy_(dx)
@@ -252,7 +269,15 @@ class BackboneTape:
             y.g = None
             # conv: weight gradient, then the input gradient written / accumulated into the input node's buffer
             self._pgrad(conv.kernel, B.conv_weight_grad(sc, kind, x.level, x.v[:n_in], draw[:n_out]))
-            B.conv_input_grad_into(sc, kind, x.level, wb, draw, cin, cout, x.grad_buffer(), acc=x.ginit, state=self.state)
+            x.pending -= 1
+            if x.pending == 0 and x.bn is not None and len(wb) == 1:
+                # this conv completes dL/dx and x is the output of a conv + BatchNorm unit: mask + BatchNorm-backward sums in
+                # this launch's epilogue (a3d_conv_dgrad_bn)
+                xr, xm, xs, xrelu = x.bn
+                x.sums = B.conv_dgrad_bn(sc, kind, x.level, wb[0], draw, cout, x.grad_buffer(), x.ginit, x.v, xr, xm, xs, xrelu,
+                                         state=self.state)
+            else:
+                B.conv_input_grad_into(sc, kind, x.level, wb, draw, cin, cout, x.grad_buffer(), acc=x.ginit, state=self.state)
             x.ginit = True
         self.steps.append(back)
         return y
@@ -262,6 +287,7 @@ class BackboneTape:
         in the backward the consumers write into one gradient buffer whose slices ARE the producers' gradients."""
         y = _T(buf, a.level)
         ca = a.v.shape[1]
+        a.bn = b.bn = None          # their gradients arrive as column slices of the concatenation's: no fused BatchNorm backward
 
         def back():
             g = y.g
@@ -330,11 +356,19 @@ class BackboneTape:
         B.conv_apply_acc(sc, L.OP_LINEAR, 0, wf, out.v, cin, cout, yh, state=self.state)
         self.head_out = _T(yh, 0)
         x_head = out
+        x_head.pending += 1
 
         def head_back():
             g = self.head_out.g
             self._pgrad(head.kernel, B.conv_weight_grad(sc, L.OP_LINEAR, 0, x_head.v[:n0], g[:n0]))
-            B.conv_input_grad_into(sc, L.OP_LINEAR, 0, wb, g, cin, cout, x_head.grad_buffer(), acc=x_head.ginit, state=self.state)
+            x_head.pending -= 1
+            if x_head.pending == 0 and x_head.bn is not None and len(wb) == 1:
+                xr, xm, xs, xrelu = x_head.bn
+                x_head.sums = B.conv_dgrad_bn(sc, L.OP_LINEAR, 0, wb[0], g, cout, x_head.grad_buffer(), x_head.ginit, x_head.v,
+                                              xr, xm, xs, xrelu, state=self.state)
+            else:
+                B.conv_input_grad_into(sc, L.OP_LINEAR, 0, wb, g, cin, cout, x_head.grad_buffer(), acc=x_head.ginit,
+                                       state=self.state)
             x_head.ginit = True
         self.steps.append(head_back)
         self.orig_row = sc.table_dev(0, L.TAB_ORIGROW)[:n0].long()

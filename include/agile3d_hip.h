@@ -227,6 +227,15 @@ int    a3d_conv_apply_acc(const a3d_scene* s, int kind, int level_in, const floa
                           const float* w_packed_dev, int cout, float* y_dev, int ldy, int y_zero_row,
                           const float* res_dev, int ldr, void* state_dev, void* workspace_dev, size_t workspace_bytes,
                           void* stream);
+/*   a3d_conv_dgrad_bn: the input-gradient conv (kind / level_in of the BACKWARD op, i.e. the transposed map) whose result
+ *     completes dL/dy of a BatchNorm(+ReLU) unit's output y [n_out][ldy]: g = (conv(x) (+ g when acc)) masked by y > 0 is
+ *     written to g_dev (row n_out zeroed) and sums_dev [2][cout] (fp64) = sum g, sum g xhat with xhat = (raw - mean) rstd come
+ *     out of the conv kernel's epilogue -- what a3d_bn_backward_apply needs (with relu = 0: g is masked already), without a
+ *     pass over dy, y and raw for the sums.  Workspace: a3d_conv_bn_train_workspace_bytes of the same op. */
+int    a3d_conv_dgrad_bn(const a3d_scene* s, int kind, int level_in, const float* x_dev, int ldx, int cin,
+                         const float* w_packed_dev, int cout, float* g_dev, int ldg, int acc, const float* y_dev, int ldy,
+                         const float* raw_dev, int ld_raw, const float* mean_dev, const float* rstd_dev, int relu,
+                         double* sums_dev, void* state_dev, void* workspace_dev, size_t workspace_bytes, void* stream);
 size_t a3d_conv_bn_train_workspace_bytes(const a3d_scene* s, int kind, int level_in, int cin, int cout);
 int    a3d_conv_bn_train_forward(const a3d_scene* s, int kind, int level_in, const float* x_dev, int ldx, int cin,
                                  const float* w_packed_dev, int cout, float* raw_dev, int ld_raw,

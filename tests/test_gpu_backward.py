@@ -201,6 +201,58 @@ def test_conv_bn_unit_with_statistics_from_the_conv_epilogue(world, kind, level_
     assert (acc[:n_out, 32:].cpu().double() - want).abs().max().item() <= 2e-5 * max(1.0, want.abs().max().item())
 
 
+@pytest.mark.parametrize("kind,level_in,cin,cout", [(L.OP_CONV3, 0, 96, 96), (L.OP_CONV3, 1, 32, 32), (L.OP_CONV3, 2, 64, 128),
+                                                    (L.OP_CONV3, 4, 256, 256), (L.OP_DOWN, 1, 32, 32), (L.OP_UP, 3, 256, 128),
+                                                    (L.OP_LINEAR, 0, 96, 128), (L.OP_LINEAR, 3, 128, 256)])
+@pytest.mark.parametrize("acc,relu", [(False, True), (True, True), (True, False)])
+def test_input_gradient_conv_with_batchnorm_backward_sums(world, kind, level_in, cin, cout, acc, relu):
+    """a3d_conv_dgrad_bn (round 5): the input-gradient conv that completes dL/dx of a conv + BatchNorm(+ReLU) unit's output x
+    masks it and sums g, g xhat in its epilogue.  Against the plain input-gradient conv (checked against autograd above)
+    followed by the mask and float64 sums; then a3d_bn_backward_apply on those sums against the layer-at-a-time
+    a3d_bn_train_backward."""
+    sc, lv, maps = world
+    lo = B.level_out(kind, level_in)
+    n_in, n_out = sc.n[level_in], sc.n[lo]
+    g = torch.Generator().manual_seed(kind * 131 + level_in * 17 + cin + 3 * cout + acc + 2 * relu)
+    K = {L.OP_CONV3: 27, L.OP_DOWN: 8, L.OP_UP: 8, L.OP_LINEAR: 1}[kind]
+    W = (torch.randn(K, cin, cout, generator=g) / (cin * 4) ** 0.5).cuda()
+    dy = torch.zeros(n_out + 1, cout, device="cuda")
+    dy[:n_out] = torch.randn(n_out, cout, generator=g).cuda()
+    raw = (torch.randn(n_in, cin, generator=g) * 1.5 + 0.2).cuda()
+    gamma, beta = (torch.rand(cin, generator=g) + 0.5).cuda(), torch.randn(cin, generator=g).cuda()
+    y, mean, rstd = B.bn_train_forward(raw, gamma, beta, 1e-5, None, relu, None, None, 0.1, zero_row=True)
+    prev = torch.randn(n_in + 1, cin, generator=g).cuda()
+    parts = B.packed_input_grad_weights(kind, W)
+    assert len(parts) == 1
+    state = B.StateArena(torch.device("cuda"), 8)
+    plain = prev.clone()
+    B.conv_input_grad_into(sc, kind, level_in, parts, dy, cin, cout, plain, acc=acc, state=state)
+    want_g = plain[:n_in].double()
+    if relu:
+        want_g = want_g * (y[:n_in] > 0)
+    xhat = (raw.double() - mean.double()) * rstd.double()
+    want_sums = torch.stack([want_g.sum(0), (want_g * xhat).sum(0)])
+    out = prev.clone()
+    sums = B.conv_dgrad_bn(sc, kind, level_in, parts[0], dy, cout, out, acc, y, raw, mean, rstd, relu, state=state)
+    assert torch.equal(out[:n_in], want_g.float()) or (out[:n_in].double() - want_g).abs().max().item() <= 1e-6 * max(1.0, want_g.abs().max().item())
+    assert (out[n_in] == 0).all()
+    scale = max(1.0, want_sums.abs().max().item())
+    assert (sums - want_sums).abs().max().item() <= 2e-5 * scale, (sums - want_sums).abs().max().item()
+    # deterministic
+    out2 = prev.clone()
+    sums2 = B.conv_dgrad_bn(sc, kind, level_in, parts[0], dy, cout, out2, acc, y, raw, mean, rstd, relu, state=state)
+    assert torch.equal(sums, sums2) and torch.equal(out, out2)
+    # BatchNorm backward from those sums == the layer-at-a-time backward on the unmasked gradient
+    dx = torch.empty(n_in + 1, cin, device="cuda")
+    dg, db = B.bn_backward_from_sums(raw, out, gamma, mean, rstd, sums, dx)
+    dx_ref, dg_ref, db_ref, _ = B.bn_train_backward(raw, y[:n_in], plain[:n_in].contiguous(), gamma, mean, rstd, relu, False,
+                                                    zero_row=True)
+    sx = max(1.0, dx_ref.abs().max().item())
+    assert (dx - dx_ref).abs().max().item() <= 2e-5 * sx and (dx[n_in] == 0).all()
+    assert (dg - dg_ref).abs().max().item() <= 2e-4 * max(1.0, dg_ref.abs().max().item())
+    assert (db - db_ref).abs().max().item() <= 2e-4 * max(1.0, db_ref.abs().max().item())
+
+
 @pytest.mark.parametrize("ks", [5, 3])
 def test_stem_weight_grad_matches_autograd(world, ks):
     sc, lv, maps = world

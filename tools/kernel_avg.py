@@ -24,14 +24,14 @@ for line in open(sys.argv[1]):
         continue
     calls, total = int(f[0]), float(f[1])
     name = f[4].strip().replace("void ", "").replace("a3d::", "")
-    m = re.match(r"k_conv_sk<(\d+), (\d+), (\d+)(, (true|false))?(, \d+)?>", name)
-    mw = re.match(r"k_conv_wl<(\d+), (\d+)>", name)
+    m = re.match(r"k_conv_sk<(\d+), (\d+), (\d+)(?:, (?:true|false))?(?:, \d+)?(?:, (true|false))?>", name)
+    mw = re.match(r"k_conv_wl<(\d+), (\d+)(?:, \d+)?>", name)
     if m:
-        key = f"k_conv_sk<{m.group(1)},{m.group(2)}>"
+        key = f"k_conv_sk<{m.group(1)},{m.group(2)}>" + ("+head" if m.group(4) == "true" else "")   # <BN, CH, PAIR, FUSE, STATS, HEAD>
     elif mw:
         key = f"k_conv_wl<{mw.group(1)},{mw.group(2)}>"
     else:
-        m = re.match(r"k_dense<(\d+), (\d+)>", name)
+        m = re.match(r"k_dense<(\d+), (\d+)(?:, (?:true|false))?>", name)
         key = f"k_dense<{m.group(1)},{m.group(2)}>" if m else name.split("(")[0]
     c, t = acc.get(key, (0, 0.0))
     acc[key] = (c + calls, t + total)

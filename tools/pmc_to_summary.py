@@ -33,11 +33,11 @@ out = {}
 groups = {}
 for name, c in raw.items():
     short = name.replace("void ", "").replace("a3d::", "")
-    m = re.match(r"k_conv_sk<(\d+), (\d+), (\d+)(, (true|false))?(, \d+)?>", short)   # <BN, CH, PAIR, DBG>: bench.py's key is <BN,CH>
+    m = re.match(r"k_conv_sk<(\d+), (\d+), (\d+)(?:, (?:true|false))?(?:, \d+)?(?:, (true|false))?>", short)   # <BN, CH, PAIR, DBG>: bench.py's key is <BN,CH>
     key = short
     if m:
-        key = f"k_conv_sk<{m.group(1)},{m.group(2)}>"
-    m = re.match(r"k_dense<(\d+), (\d+)>", short)
+        key = f"k_conv_sk<{m.group(1)},{m.group(2)}>" + ("+head" if m.group(4) == "true" else "")
+    m = re.match(r"k_dense<(\d+), (\d+)(?:, (?:true|false))?>", short)
     if m:
         key = f"k_dense<{m.group(1)},{m.group(2)}>"
     groups.setdefault(key, []).append((short, c))

@@ -38,6 +38,7 @@ def main():
             print(f"# {path}: {len(rows)} dispatches, {n_mark} markers = {n_mark / per_iter:.2f} iterations; first {skip} skipped")
             agg = [defaultdict(lambda: [0, 0.0]) for _ in PHASES]
             wall = [0.0] * len(PHASES)
+            union = [0.0] * len(PHASES)      # time with at least one kernel running (streams overlap: <= kernel sum, <= span)
             busy = [0.0] * len(PHASES)
             launches = [0] * len(PHASES)
             m = -1                      # markers seen - 1: the segment behind marker m is phase m % per_iter of iteration m // per_iter
@@ -52,6 +53,11 @@ def main():
                     return
                 done_iters.add(it)
                 wall[p] += (max(r[2] for r in seg) - seg[0][1]) / 1e3
+                end = seg[0][1]
+                for _, s_, e_ in seg:              # sorted by start
+                    if e_ > end:
+                        union[p] += (e_ - max(s_, end)) / 1e3
+                        end = e_
                 for name, s_, e_ in seg:
                     a_ = agg[p][short(name)]
                     a_[0] += 1
@@ -70,7 +76,7 @@ def main():
             tot_l = tot_b = tot_w = 0
             for p, nm in enumerate(PHASES):
                 print(f"== {nm}: {launches[p] / iters:.0f} launches, kernel sum {busy[p] / iters / 1e3:.2f} ms, "
-                      f"first-start..last-end {wall[p] / iters / 1e3:.2f} ms per iteration")
+                      f"device busy {union[p] / iters / 1e3:.2f} ms, first-start..last-end {wall[p] / iters / 1e3:.2f} ms per iteration")
                 tot_l += launches[p] / iters
                 tot_b += busy[p] / iters / 1e3
                 tot_w += wall[p] / iters / 1e3
