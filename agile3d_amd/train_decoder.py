@@ -519,8 +519,8 @@ class DecoderTape:
         self.logits_nodes = []                     # [layer][sample]
         for d in range(self.model.num_decoders):
             li = 0 if self.model.shared_decoder else d
-            a = self.mha(f"c2s_attention.{li}.0.multihead_attn.", self.add(tgt, qpos), self.add(src, pos), src, q_ranges, n_ranges,
-                         masks)
+            src_pos = self.add(src, pos)        # the keys of click-to-scene AND the queries of scene-to-click (src changes after both)
+            a = self.mha(f"c2s_attention.{li}.0.multihead_attn.", self.add(tgt, qpos), src_pos, src, q_ranges, n_ranges, masks)
             tgt = self.ln(self.add(tgt, a), f"c2s_attention.{li}.0.norm.")
             qk = self.add(tgt, qpos)
             a = self.mha(f"c2c_attention.{li}.0.self_attn.", qk, qk, tgt, q_ranges, q_ranges)
@@ -528,7 +528,7 @@ class DecoderTape:
             h = self.relu(self.lin(tgt, f"ffn_attention.{li}.0.linear1.weight", f"ffn_attention.{li}.0.linear1.bias"))
             f = self.lin(h, f"ffn_attention.{li}.0.linear2.weight", f"ffn_attention.{li}.0.linear2.bias")
             tgt = self.ln(self.add(tgt, f), f"ffn_attention.{li}.0.norm.")
-            a = self.mha(f"s2c_attention.{li}.0.multihead_attn.", self.add(src, pos), self.add(tgt, qpos), tgt, n_ranges, q_ranges)
+            a = self.mha(f"s2c_attention.{li}.0.multihead_attn.", src_pos, self.add(tgt, qpos), tgt, n_ranges, q_ranges)
             src = self.ln(self.add(src, a), f"s2c_attention.{li}.0.norm.")
             outs = self.mask_head(tgt, src, n_ranges, q_ranges, groups)
             self.logits_nodes.append(outs)
