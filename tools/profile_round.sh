@@ -55,6 +55,15 @@ rm -rf /tmp/$TAG/trt
 A3D_TRAIN_TIMING=1 rocprofv3 --kernel-trace --stats -d /tmp/$TAG/trt -o t -- python $R/tools/backward_bench.py --step --reps 1 > $OUT/train_trace.log 2>&1
 python $R/tools/rocprof_summary.py /tmp/$TAG/trt > $OUT/training_kernel_trace.txt 2>&1
 python $R/tools/rocprof_stalls.py /tmp/$TAG/trt 10 > $OUT/training_stalls.txt 2>&1
+# the same four iterations (+ two warm-ups) split by PHASE: one marker dispatch per phase boundary (A3D_TRAIN_TIMING=mark)
+rm -rf /tmp/$TAG/trp
+A3D_BB_ITERS=6 A3D_TRAIN_TIMING=mark rocprofv3 --kernel-trace -d /tmp/$TAG/trp -o t -- python $R/tools/backward_bench.py --step --reps 1 > $OUT/train_phase_trace.log 2>&1
+python $R/tools/train_phase_trace.py /tmp/$TAG/trp 2 40 > $OUT/training_phases.txt 2>&1
+# eight ranks sharing the one GPU (host-side check of an 8-rank run) next to one rank driving the same 16 scenes per step
+A3D_BENCH_ONE_GPU=1 python $R/bench.py --gpus 8 --batch 2 --steps 20 --warmup 3 --reps 3 --no-profile --steps-only --no-train --no-cpu-baseline > $OUT/bench_8ranks_one_gpu.json 2> $OUT/bench_8ranks.err
+python $R/bench.py --gpus 1 --batch 16 --steps 20 --warmup 3 --reps 3 --no-profile --steps-only --no-train --no-cpu-baseline > $OUT/bench_1rank_same_load.json 2> $OUT/bench_1rank.err
+# config 5 at round 3's protocol too (two steps in flight, 10 steps per repetition)
+python $R/bench.py --voxels 300000 --clicks-per-object 4 --batch 1 --streams 2 --steps 10 --warmup 4 --reps 7 --no-train --no-profile --steps-only > $OUT/bench_config5_r3_protocol.json 2> $OUT/bench_config5_r3.err
 # steps per repetition: what the fill and drain of the four streams cost at the driver's 20 steps
 for K in 20 80; do echo -n "steps=$K: "; python $R/bench.py --steps-only --no-profile --steps $K --reps 9 2>/dev/null | tail -1 | python -c "import json,sys; r=json.loads(sys.stdin.read()); print(round(r['value'],1), 'scenes/s', round(r['ms_per_step'],3), 'ms per step')"; done > $OUT/steps_per_repetition.txt 2>&1
 ls -la $OUT
