@@ -714,6 +714,305 @@ __global__ void __launch_bounds__(256, PAIR ? ((BN <= 96 && CH <= 32) ? 4 : 3) :
   }
 }
 
+// ------------------------------------------------------------------------------ k_conv_deep
+// The same convolution for the SMALL levels (a few hundred to a few thousand rows: levels 2-4 of one scene), where k_conv_sk
+// is bound by its chain of dependent round trips, not by the matrix cores: ticket -> prefix table -> share search -> group
+// masks -> neighbour rows -> first fragments, then one weight-slice round trip per stage behind a two-slot ring (a 256 -> 256
+// layer on 140 rows: 25 us for 2 us of MFMA work and 7 MB of weights; profiles/r02_small_level_ablations.txt).  Here
+//   * the partition is static per (64-row tile, column block) UNIT: its stages (present offsets x channel chunks, + the fused
+//     projection's) are cut into P equal parts, workgroup = (unit, part) = blockIdx.x -- no ticket, no prefix table, no search;
+//     the only thing a workgroup needs before it can issue loads is its tile's four group masks;
+//   * the tile's whole neighbour table (K x 64 row ids) goes to LDS in the same round trip as the masks;
+//   * BOTH operands of a stage travel by LDS-DMA (global_load_lds_dwordx4: the weight slice as in k_conv_sk, and every wave's
+//     gathered 16 rows x CH channels: a lane's 16 bytes land at lane x 16 of the wave's piece, which the same lane reads back
+//     with one ds_read_b128) into a FOUR-slot ring, three stages ahead of the MFMAs: no load of the loop has a register
+//     destination, so the loop's only waits are counted s_waitcnt vmcnt(N) (N = the DMA instructions of the stages still in
+//     flight: loads retire in order) followed by the stage barrier (MI355X_MICROARCH.md item 7: what orders a ds_read behind
+//     an LDS-DMA);
+//   * a unit cut into parts is finished WITHOUT anybody waiting: every part writes its accumulators to the slab
+//     (write-through) and counts itself on the unit's counter; the part that finds P - 1 others there adds all parts in part
+//     order (its own from registers: the same values) and runs the epilogue.  No spinning, so no assumption about dispatch
+//     order or residency, and the sum does not depend on who arrives last: bit-identical run to run.
+// One workgroup per CU (96-135 KB of LDS); the launch is used when the layer has at most a few stages per CU (plan_deep).
+struct DeepArgs {
+  ConvArgs c;
+  int P;               // parts per unit
+  int n_cblk;          // cout / BN
+  int nchunk, nchunk2; // stages per offset (cin / CH); stages of the fused projection (cin2 / CH)
+  int* cnt;            // [units] zeroed by the caller
+  float* slab;         // [units * P][64 * BN]
+  unsigned in_row_bytes, in2_row_bytes;
+  unsigned long long* dbg;   // A3D_DEEP_DBG: [G][6] timestamps (100 MHz) of a workgroup's phases; nullptr otherwise
+};
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {   // vmcnt <= N (expcnt 7, lgkmcnt 15: not waited for)
+  __builtin_amdgcn_s_waitcnt(0x0F70 | (N & 15) | ((N >> 4) << 14));
+}
+
+// ABL (tuning builds only, tools/conv_bench.py --ablate): 1 = no gathered pieces, 2 = no weight pieces, 4 = no MFMAs
+template <int BN, int CH, bool FUSE, int ABL = 0>
+__global__ void __launch_bounds__(256, 1) k_conv_deep(const DeepArgs a) {
+  constexpr int NCT = BN / 16, NS = CH / 16, NW = 4;
+  constexpr int NPW = NS * NCT;          // 1 KB pieces of a stage's weight slice
+  static_assert(NPW % NW == 0, "every wave moves the same number of weight pieces (the vmcnt arithmetic)");
+  constexpr int WV = NPW / NW;
+  constexpr int WF = NPW * 256;          // floats of the weight slice
+  constexpr int AF = NW * NS * 256;      // floats of the four waves' gathered fragments
+  constexpr int SLOT = WF + AF;
+  constexpr int D = 4, PW = 3;           // ring slots; stages in flight ahead of the one multiplied
+  constexpr int NL = ((ABL & 1) ? 0 : NS) + ((ABL & 2) ? 0 : WV);   // DMA instructions per wave and stage
+  static_assert((PW - 1) * NL <= 63, "vmcnt is a 6-bit counter");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* ring = (float*)smem;                         // [D][SLOT]
+  int* nbrs = (int*)(ring + D * SLOT);                // [28][64]
+  int* misc = nbrs + 28 * 64;
+  const unsigned ring_addr = (unsigned)(size_t)ring;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = lane >> 4, j = lane & 15;
+  const int K = a.c.K, nchunk = a.nchunk;
+  const int nchunk2 = FUSE ? a.nchunk2 : 0;
+  const int T = a.c.n_tiles, P = a.P;
+  const int cin16 = a.c.cin >> 4, cout16 = a.c.cout >> 4;
+  const int u = (int)blockIdx.x / P, p = (int)blockIdx.x - u * P;
+  const int cb = u / T, t = u - cb * T;
+  const int ct0 = cb * NCT, r0 = t * 64;
+  const int wrow = 16 * wave + j;
+  auto stamp = [&](int i) {
+    if (a.dbg && tid == 0) {
+      a.dbg[(size_t)blockIdx.x * 6 + i] = __builtin_amdgcn_s_memrealtime();
+      if (blockIdx.x == 0 && (i == 0 || i == 3)) a.dbg[(size_t)gridDim.x * 6 + (i ? 1 : 0)] = __builtin_amdgcn_s_memtime();
+    }
+  };
+  stamp(0);
+
+  // ---- round trip 1: the tile's group masks and its neighbour table
+  uint32_t un = K >= 32 ? 0xffffffffu : (1u << K) - 1u, gm = un;
+  if (a.c.gmask) {
+    const uint32_t* gp = a.c.gmask + (r0 >> 4);
+    const uint32_t m0 = gp[0], m1 = gp[1], m2 = gp[2], m3 = gp[3];
+    un &= (m0 | m1) | (m2 | m3);
+    gm = wave == 0 ? m0 : wave == 1 ? m1 : wave == 2 ? m2 : m3;
+  }
+  if (a.c.nbr) {
+    for (int idx = tid; idx < K * 64; idx += 256) nbrs[idx] = a.c.nbr[(size_t)(idx >> 6) * a.c.nbr_stride + r0 + (idx & 63)];
+  } else if (tid < 64) {
+    nbrs[tid] = min(r0 + tid, a.c.n_in - 1);
+  }
+  if (blockIdx.x == 0 && a.c.zero_row >= 0)
+    for (int cidx = tid; cidx < a.c.cout; cidx += 256) a.c.out[(size_t)a.c.zero_row * a.c.ldo + cidx] = 0.f;
+  un = __builtin_amdgcn_readfirstlane(un);
+  gm = __builtin_amdgcn_readfirstlane(gm);
+  const int S_own = __builtin_popcount(un) * nchunk;
+  const int S = S_own + nchunk2;
+  if constexpr (FUSE) {
+    un |= 1u << 27;
+    gm |= 1u << 27;
+  }
+  const int s0 = S * p / P, s1 = S * (p + 1) / P;   // S <= 28 x 12 stages, P <= 24: 32-bit
+  const int n = s1 - s0;
+  __syncthreads();   // the neighbour table is in LDS (no DMA is pending yet: a plain barrier)
+  stamp(1);
+
+  f32x4 acc[NCT];
+#pragma unroll
+  for (int ct = 0; ct < NCT; ++ct) acc[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  if (n > 0) {
+    auto next_k = [&](int k) -> int {
+      const uint32_t rest = k >= 31 ? 0u : un & ~((2u << k) - 1u);
+      return rest ? __builtin_ctz(rest) : 32;
+    };
+    auto adv = [&](int& k, int& c) {
+      if (c + 1 < ((FUSE && k == 27) ? nchunk2 : nchunk)) {
+        ++c;
+      } else {
+        k = next_k(k);
+        c = 0;
+      }
+    };
+    int ik, ic;   // the stage issued next
+    if (FUSE && s0 >= S_own) {
+      ik = 27;
+      ic = s0 - S_own;
+    } else {
+      ik = __builtin_ctz(un);
+      for (int i = s0 / nchunk; i > 0; --i) ik = next_k(ik);
+      ic = s0 % nchunk;
+    }
+    int ck = ik, cc = ic;   // the stage multiplied next
+    unsigned wsrc[WV], wdst[WV];
+#pragma unroll
+    for (int i = 0; i < WV; ++i) {
+      const int q = wave + NW * i;
+      wsrc[i] = (unsigned)(((q / NCT) * cout16 + (q % NCT)) * 1024 + lane * 16);
+      wdst[i] = (unsigned)q * 1024u;
+    }
+    const float* wbase = a.c.w + (size_t)ct0 * 256;
+    const unsigned a_dst = (unsigned)(WF * 4 + wave * NS * 1024);
+    // the DMA instructions of one stage: NS gathered pieces of this wave's 16 rows, WV pieces of the weight slice.  In the
+    // loop they are issued BETWEEN the MFMA blocks of the stage being multiplied (a piece costs 60-180 cycles of issue:
+    // in front of the MFMAs they delayed every stage by a third of its matrix time)
+    struct Stage {
+      const float* ab;
+      const float* wst;
+      unsigned roff, sl;
+    };
+    auto stage_of = [&](int k, int c, int slot) -> Stage {
+      const bool proj = FUSE && k == 27;   // wave-uniform: the projection reads the block input at the output rows
+      const int row = proj ? min(r0 + wrow, a.c.n_out) : nbrs[(k < K ? k : 0) * 64 + wrow];
+      Stage st;
+      st.roff = (unsigned)row * (proj ? a.in2_row_bytes : a.in_row_bytes) + 16u * g;
+      st.ab = (proj ? a.c.in2 : a.c.in) + (size_t)c * CH;
+      st.sl = ring_addr + (unsigned)slot * (SLOT * 4u);
+      st.wst = wbase + ((size_t)k * cin16 + (size_t)c * NS) * cout16 * 256;
+      return st;
+    };
+    auto issue_piece = [&](const Stage& st, int q) {   // q compile-time after unrolling: 0 .. NL - 1
+      constexpr int NA = (ABL & 1) ? 0 : NS;
+      if (q < NA) glds16_s(st.ab + 16 * q, st.roff, st.sl + a_dst + q * 1024u);
+      else glds16_s(st.wst, wsrc[q - NA], st.sl + wdst[q - NA]);
+    };
+    auto issue = [&](int k, int c, int slot) {
+      const Stage st = stage_of(k, c, slot);
+#pragma unroll
+      for (int q = 0; q < NL; ++q) issue_piece(st, q);
+    };
+    // multiply stage (k, slot); `nx` != nullptr: the pieces of that stage are issued behind the MFMA blocks
+    auto compute = [&](int k, int slot, const Stage* nx) {
+      constexpr int PER = (NL + NS - 1) / NS;   // pieces per 16-channel step
+      if ((ABL & 4) || !((gm >> k) & 1u)) {
+        if (nx) {
+#pragma unroll
+          for (int q = 0; q < NL; ++q) issue_piece(*nx, q);
+        }
+        return;
+      }
+      const f32x4* Ws = (const f32x4*)(ring + slot * SLOT) + lane;
+      const f32x4* As = (const f32x4*)(ring + slot * SLOT + WF) + wave * NS * 64 + lane;
+      f32x4 b[2][NCT], av[2];
+#pragma unroll
+      for (int ct = 0; ct < NCT; ++ct) b[0][ct] = Ws[ct * 64];
+      av[0] = As[0];
+#pragma unroll
+      for (int Sx = 0; Sx < NS; ++Sx) {
+        if (Sx + 1 < NS) {
+#pragma unroll
+          for (int ct = 0; ct < NCT; ++ct) b[(Sx + 1) & 1][ct] = Ws[((Sx + 1) * NCT + ct) * 64];
+          av[(Sx + 1) & 1] = As[(Sx + 1) * 64];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+          for (int ct = 0; ct < NCT; ++ct)
+            acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[Sx & 1][ct][tt], av[Sx & 1][tt], acc[ct], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (nx) {
+#pragma unroll
+          for (int q = Sx * PER; q < (Sx + 1) * PER && q < NL; ++q) issue_piece(*nx, q);
+        }
+      }
+    };
+    for (int q = 0; q < PW && q < n; ++q) {
+      issue(ik, ic, q);
+      adv(ik, ic);
+    }
+    for (int i = 0; i < n; ++i) {
+      // stages i + 1 .. i + PW - 1 (as far as the part goes) are the loads allowed to stay in flight
+      const int rem = n - 1 - i;
+      if (rem >= 2) wait_vmcnt<2 * NL>();
+      else if (rem == 1) wait_vmcnt<NL>();
+      else wait_vmcnt<0>();
+      __builtin_amdgcn_s_barrier();   // every wave's pieces of stage i have landed; every wave is done reading slot (i - 1) % D
+      if (i == 0) stamp(2);
+      if (i + PW < n) {
+        const Stage nx = stage_of(ik, ic, (i + PW) & (D - 1));
+        adv(ik, ic);
+        compute(ck, i & (D - 1), &nx);
+      } else {
+        compute(ck, i & (D - 1), nullptr);
+      }
+      adv(ck, cc);
+    }
+  }
+  stamp(3);
+
+  if (P > 1) {
+    float* Pm = a.slab + (size_t)blockIdx.x * (64 * BN) + (size_t)tid * 4;
+    if (n > 0) {
+#pragma unroll
+      for (int ct = 0; ct < NCT; ++ct) store_sc1(Pm + ct * 1024, acc[ct]);
+    }
+    wait_all_vmem();
+    __syncthreads();
+    if (tid == 0) misc[0] = __hip_atomic_fetch_add(a.cnt + u, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    stamp(4);
+    if (misc[0] != P - 1) return;
+    if (tid == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    __syncthreads();
+    // all parts in part order, this workgroup's own from its registers
+    f32x4 tot[NCT];
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct) tot[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const float* P0 = a.slab + (size_t)u * P * (64 * BN) + (size_t)tid * 4;
+    // 16 loads of 16 bytes in flight per thread: a 10-part tile of 32 columns is two round trips, not five (measured on the
+    // 140-row level: 4.0 -> 1.5 us of the last arriver's life)
+    constexpr int U = 16 / NCT;
+    for (int q0 = 0; q0 < P; q0 += U) {
+      f32x4 pa[U][NCT];
+#pragma unroll
+      for (int uu = 0; uu < U; ++uu) {
+        const int q = q0 + uu;
+        const bool has = q < P && S * (q + 1) / P > S * q / P;
+        if (has && q != p) {
+          const float* Pa = P0 + (size_t)q * (64 * BN);
+#pragma unroll
+          for (int ct = 0; ct < NCT; ++ct) pa[uu][ct] = *(const f32x4*)(Pa + ct * 1024);
+        } else {
+#pragma unroll
+          for (int ct = 0; ct < NCT; ++ct) pa[uu][ct] = (has && q == p) ? acc[ct] : (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int uu = 0; uu < U; ++uu)
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct) tot[ct] += pa[uu][ct];
+    }
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct) acc[ct] = tot[ct];
+  }
+
+  const int myrow = r0 + wrow;
+  if (myrow < a.c.n_out) {
+    const int orow = a.c.out_map ? a.c.out_map[myrow] : myrow;
+    float* po = a.c.out + (size_t)orow * a.c.ldo + ct0 * 16 + 4 * g;
+    const float* pr = a.c.res ? a.c.res + (size_t)orow * a.c.ldr + ct0 * 16 + 4 * g : nullptr;
+    f32x4 rv[NCT];
+    if (pr) {
+#pragma unroll
+      for (int ct = 0; ct < NCT; ++ct) rv[ct] = *(const f32x4*)(pr + ct * 16);
+    }
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct) {
+      f32x4 v = acc[ct];
+      if (a.c.scale) v *= *(const f32x4*)(a.c.scale + (ct0 + ct) * 16 + 4 * g);
+      if (a.c.shift) v += *(const f32x4*)(a.c.shift + (ct0 + ct) * 16 + 4 * g);
+      if (pr) v += rv[ct];
+      if (a.c.relu) {
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt) v[tt] = fmaxf(v[tt], 0.f);
+      }
+      *(f32x4*)(po + ct * 16) = v;
+    }
+  }
+  stamp(5);
+}
+
 // ------------------------------------------------------------------------------ k_conv_wl
 // Gathered convolution with the WHOLE packed weight set resident in LDS (K cin cout 4 bytes <= 144 KB: the 3^3 32 -> 32
 // layers of level 1, 110 KB, and the 2^3 stride-2 layers 32 -> 32 / 64 -> 64).  With 32 input channels a stage of
@@ -1433,6 +1732,92 @@ static SkPlan plan_sk(int n_rows, int K, int cin, int cout, bool handoff, int fo
   return p;
 }
 
+// ---- k_conv_deep: which small layers it takes, and their geometry
+// The model behind the choice (us; fitted to per-workgroup phase timestamps and ablation builds on the levels of one 80 k-voxel
+// scene, profiles/r05_experiments.txt): a workgroup's life = 2.6 (masks + table, then the first slices' round trip) + its
+// stages x (0.3 skeleton + 0.04 per LDS-DMA instruction of a wave + the stage's MFMA time: the DMA issue does not hide behind
+// the MFMAs of a lone wave) + the hand-off of a unit cut into P parts (1.0 publish + 0.25 per 16 KB part read by the last
+// arriver: 65 GB/s into one CU); one workgroup per CU, so G > 256 runs in rounds.  A 64-row tile issues the UNION of its rows' offsets: 22 of 27
+// on levels of up to a few thousand rows, 14-17 on the large ones (rows sorted by neighbour pattern).
+// The kernel is preferred while the layer's matrix work per CU stays below A3D_DEEP_MAX_US (18): beyond that the stream-K
+// kernel's two workgroups per CU win (measured: level 3 384 -> 256 a tie at 23 us of work per CU, level 2 192 -> 128 lost).
+// A3D_CONV_DEEP=0 switches the kernel off (A/B).
+struct DeepPlan {
+  bool use;
+  int bn, ch, P, G, n_cblk, ntile, nchunk;
+  size_t lds, slab_floats;
+  float est_us;
+};
+static int g_deep_mode = -1;
+static int deep_mode() {
+  if (g_deep_mode < 0) {
+    const char* e = getenv("A3D_CONV_DEEP");
+    g_deep_mode = e ? atoi(e) : 1;
+  }
+  return g_deep_mode;
+}
+static DeepPlan plan_deep(int n_rows, int K, int cin, int cout, int cin2) {
+  DeepPlan best;
+  memset(&best, 0, sizeof(best));
+  if (!deep_mode() || K < 2 || K > 27 || cin % 32 || cout % 32 || conv_emu(K, cin, cout)) return best;
+  static float max_us = -1.f;
+  if (max_us < 0.f) {
+    const char* e = getenv("A3D_DEEP_MAX_US");
+    max_us = e ? (float)atof(e) : 18.f;
+  }
+  const int ntile = n_rows > 0 ? (n_rows + 63) / 64 : 1;
+  const int k_eff = K == 27 ? (n_rows < 8000 ? 22 : n_rows < 32000 ? 17 : 14) : K;
+  static const int cand[5][2] = {{128, 32}, {64, 64}, {64, 32}, {32, 64}, {32, 32}};
+  float best_t = 1e30f;
+  for (int ci = 0; ci < 5; ++ci) {
+    const int bn = cand[ci][0], ch = cand[ci][1];
+    if (cout % bn || cin % ch || (cin2 > 0 && cin2 % ch)) continue;
+    const int units = cout / bn * ntile;
+    if (units > kMaxQueuesPerOp - 2) continue;
+    const int S = k_eff * (cin / ch) + (cin2 > 0 ? cin2 / ch : 0);
+    const int ns = ch / 16, nct = bn / 16;
+    const float mf = (float)ns * (float)nct * 0.0533f;
+    const float tstage = (ns < 4 ? 0.45f : 0.3f) + 0.04f * (float)(ns + ns * nct / 4) + mf;   // two-step stages expose their LDS reads
+    if ((float)units * (float)S * mf / 256.f > max_us) continue;   // matrix-bound: the stream-K kernel's ground
+    for (int P = 1; P <= 24; ++P) {
+      if (P > 1 && S / P < 2) break;
+      const int G = units * P;
+      if (G > kSkMaxG) break;
+      const int rounds = (G + 255) / 256;
+      const float t = rounds * (2.6f + (float)((S + P - 1) / P) * tstage) + (P > 1 ? 1.0f + 0.25f * P * bn / 64.f : 0.f);
+      if (t < best_t) {
+        best_t = t;
+        best.bn = bn, best.ch = ch, best.P = P, best.G = G, best.n_cblk = cout / bn, best.ntile = ntile, best.nchunk = cin / ch;
+      }
+    }
+  }
+  // mode >= 16 (experiments, tools/conv_bench.py --sweep): bits 0-3 = bn / 32, bits 4-7 = ch / 32, bits 8-15 = P (0: 256 / units):
+  // that geometry wherever it divides the layer
+  int force[3] = {0, 0, 0};
+  if (deep_mode() >= 16) force[0] = (deep_mode() & 15) * 32, force[1] = ((deep_mode() >> 4) & 15) * 32, force[2] = (deep_mode() >> 8) & 255;
+  if (force[0] > 0 && force[1] > 0 && cout % force[0] == 0 && cin % force[1] == 0 && (cin2 <= 0 || cin2 % force[1] == 0)) {
+    const int bn = force[0], ch = force[1], units = cout / bn * ntile;
+    const int S = k_eff * (cin / ch) + (cin2 > 0 ? cin2 / ch : 0);
+    int P = force[2];
+    if (P <= 0) {
+      P = 256 / units;
+      if (P > S / 2) P = S / 2;
+    }
+    if (P < 1) P = 1;
+    if (units * P <= kSkMaxG && units <= kMaxQueuesPerOp - 2) {
+      best.bn = bn, best.ch = ch, best.P = P, best.G = units * P, best.n_cblk = cout / bn, best.ntile = ntile, best.nchunk = cin / ch;
+      best_t = 0.f;
+    }
+  }
+  if (best_t > 1e29f) return best;
+  best.use = true;
+  best.est_us = best_t;
+  const int ns = best.ch / 16, nct = best.bn / 16;
+  best.lds = (size_t)4 * (ns * nct + 4 * ns) * 1024 + 28 * 64 * 4 + 64;
+  best.slab_floats = best.P > 1 ? (size_t)best.G * 64 * best.bn : 0;
+  return best;
+}
+
 static void allow_big_lds() {
   static bool done = false;
   if (done) return;
@@ -1457,6 +1842,16 @@ static void allow_big_lds() {
   A3D_ALLOW_LDS(160 * 1024, k_conv_sk<128, 32, 2>);
   A3D_ALLOW_LDS(160 * 1024, k_conv_sk<64, 32, 2>);
   A3D_ALLOW_LDS(160 * 1024, k_conv_sk<32, 32, 2>);
+#define A3D_BIGD(BN_, CH_) \
+  A3D_ALLOW_LDS(160 * 1024, (k_conv_deep<BN_, CH_, false>)); \
+  A3D_ALLOW_LDS(160 * 1024, (k_conv_deep<BN_, CH_, true>));
+  A3D_BIGD(128, 32) A3D_BIGD(64, 64) A3D_BIGD(64, 32) A3D_BIGD(32, 64) A3D_BIGD(32, 32)
+#undef A3D_BIGD
+#define A3D_BIGA(ABL_) \
+  A3D_ALLOW_LDS(160 * 1024, (k_conv_deep<64, 64, false, ABL_>)); \
+  A3D_ALLOW_LDS(160 * 1024, (k_conv_deep<32, 64, false, ABL_>));
+  A3D_BIGA(1) A3D_BIGA(2) A3D_BIGA(3) A3D_BIGA(4) A3D_BIGA(5) A3D_BIGA(6) A3D_BIGA(7)
+#undef A3D_BIGA
   A3D_ALLOW_LDS(160 * 1024, k_conv_wl<2, 2>);
   A3D_ALLOW_LDS(160 * 1024, k_conv_wl<4, 4>);
   A3D_ALLOW_LDS(160 * 1024, (k_conv_wl<2, 2, 1>));
@@ -1517,6 +1912,80 @@ static int launch_conv_sk(ConvArgs c, const int* pre64, float* slab_ws, size_t s
   if (c.cin2 == 0 && conv_wl_supported(c) && !conv_emu(c.K, c.cin, c.cout)) {
     if (stats) *stats_rows = 16;
     return launch_conv_wl(c, st, stats, stats_ld, bw);
+  }
+  if (state && !stats && c.head_cout == 0 && c.K > 1) {
+    const DeepPlan d = plan_deep(c.n_out, c.K, c.cin, c.cout, c.cin2);
+    if (d.use && d.slab_floats <= slab_ws_floats && (c.cin2 == 0 || (c.K == 27 && c.in2 && !(c.ldi2 & 3) &&
+        (uint64_t)(c.n_out + 1) * (uint64_t)c.ldi2 * 4ull < (1ull << 32)))) {
+      DeepArgs a;
+      memset(&a, 0, sizeof(a));
+      c.n_tiles = d.ntile;
+      a.c = c;
+      a.P = d.P;
+      a.n_cblk = d.n_cblk;
+      a.nchunk = d.nchunk;
+      a.nchunk2 = c.cin2 > 0 ? c.cin2 / d.ch : 0;
+      a.cnt = state + 2;
+      a.slab = slab_ws;
+      a.in_row_bytes = (unsigned)c.ldi * 4u;
+      a.in2_row_bytes = (unsigned)c.ldi2 * 4u;
+      // the kernel-volume field as k_conv_sk's (K | cin2 << 8); the column field carries 1000 + BN: "deep" in the layer tables
+      ProfScope ps(st, A3D_PROF_SPCONV, 1000 + d.bn, c.K | (c.cin2 << 8), c.cin, c.cout, c.n_out, c.tag_table, c.tag_level, d.ch);
+      // A3D_DEEP_DBG=1 (tuning): per-workgroup phase timestamps of every launch, summarised on stderr (synchronises the stream)
+      static int dbg_on = -1;
+      static unsigned long long* dbg_buf = nullptr;
+      if (dbg_on < 0) {
+        const char* e = getenv("A3D_DEEP_DBG");
+        dbg_on = e ? atoi(e) : 0;
+        if (dbg_on && hipMalloc(&dbg_buf, (size_t)(kSkMaxG * 6 + 2) * 8) != hipSuccess) dbg_on = 0;
+      }
+      if (dbg_on) {
+        a.dbg = dbg_buf;
+        (void)hipMemsetAsync(dbg_buf, 0, (size_t)kSkMaxG * 6 * 8, st);
+      }
+      const int abl = deep_mode() >= 16 ? (deep_mode() >> 16) & 7 : 0;
+      if (abl && c.cin2 == 0 && ((d.bn == 64 && d.ch == 64) || (d.bn == 32 && d.ch == 64))) {
+#define A3D_LA(ABL_) \
+  if (abl == ABL_) { if (d.bn == 64) k_conv_deep<64, 64, false, ABL_><<<d.G, 256, d.lds, st>>>(a); else k_conv_deep<32, 64, false, ABL_><<<d.G, 256, d.lds, st>>>(a); } else
+        A3D_LA(1) A3D_LA(2) A3D_LA(3) A3D_LA(4) A3D_LA(5) A3D_LA(6) A3D_LA(7) {}
+#undef A3D_LA
+      } else {
+#define A3D_LD(BN_, CH_) \
+  if (d.bn == BN_ && d.ch == CH_) { if (c.cin2 > 0) k_conv_deep<BN_, CH_, true><<<d.G, 256, d.lds, st>>>(a); else k_conv_deep<BN_, CH_, false><<<d.G, 256, d.lds, st>>>(a); } else
+      A3D_LD(128, 32) A3D_LD(64, 64) A3D_LD(64, 32) A3D_LD(32, 64) A3D_LD(32, 32)
+      { set_error("spconv: no deep kernel for BN %d CH %d", d.bn, d.ch); return A3D_ERR_UNSUPPORTED; }
+#undef A3D_LD
+      }
+      A3D_LAUNCH_CHECK();
+      if (dbg_on) {
+        static unsigned long long host[kSkMaxG * 6 + 2];
+        (void)hipStreamSynchronize(st);
+        (void)hipMemcpy(host, dbg_buf, (size_t)(d.G * 6 + 2) * 8, hipMemcpyDeviceToHost);
+        unsigned long long t0min = ~0ull, tend = 0;
+        for (int w = 0; w < d.G; ++w) {
+          if (host[w * 6] < t0min) t0min = host[w * 6];
+          for (int q = 0; q < 6; ++q) if (host[w * 6 + q] > tend) tend = host[w * 6 + q];
+        }
+        double sum[6] = {0, 0, 0, 0, 0, 0}, mx[6] = {0, 0, 0, 0, 0, 0};
+        int cntq[6] = {0, 0, 0, 0, 0, 0};
+        for (int w = 0; w < d.G; ++w)
+          for (int q = 0; q < 6; ++q)
+            if (host[w * 6 + q]) {
+              const double v = (double)(host[w * 6 + q] - t0min) * 0.01;
+              sum[q] += v, ++cntq[q];
+              if (v > mx[q]) mx[q] = v;
+            }
+        fprintf(stderr, "deep<%d,%d>%s K=%d %d->%d rows=%d units=%d P=%d G=%d span %.2f us | avg/max since first start:", d.bn, d.ch,
+                c.cin2 > 0 ? "+p" : "", c.K, c.cin, c.cout, c.n_out, d.G / d.P, d.P, d.G, (double)(tend - t0min) * 0.01);
+        const char* nm[6] = {"start", "table", "stage0", "loop", "publish", "end"};
+        for (int q = 0; q < 6; ++q)
+          fprintf(stderr, " %s %.2f/%.2f", nm[q], cntq[q] ? sum[q] / cntq[q] : 0.0, mx[q]);
+        if (host[3] > host[0])   // workgroup 0: shader-clock ticks per 10 ns tick between its start and the end of its loop
+          fprintf(stderr, " | clock %.0f MHz", (double)(host[d.G * 6 + 1] - host[d.G * 6]) / (double)(host[3] - host[0]) * 100.0);
+        fprintf(stderr, "\n");
+      }
+      return A3D_OK;
+    }
   }
   // hand-offs (shares cut inside tiles) pay where a tile is long and tiles are few: the 3^3 maps, and the 2^3 maps of
   // the small levels.  1x1 layers and 2^3 maps with a tile per workgroup slot or more run whole tiles: no ticket, no
@@ -1670,6 +2139,8 @@ static int layout_program(const a3d_scene* s, const a3d_buf_desc* bufs, int n_bu
       q = plan_sk(s->lv[lvl_out].n, o.kernel_volume, o.cin, o.cout, true, 32);
       if (q.slab_floats > pf) pf = q.slab_floats;
     }
+    const DeepPlan dp = plan_deep(s->lv[lvl_out].n, o.kernel_volume, o.cin, o.cout, o.proj_cin);
+    if (dp.use && dp.slab_floats > pf) pf = dp.slab_floats;
   }
   L.partial_off = off;
   L.partial_floats = pf;
@@ -1994,7 +2465,10 @@ extern "C" size_t a3d_conv_apply_workspace_bytes(const a3d_scene* s, int kind, i
   if (lvl_out < 0 || lvl_out >= A3D_NUM_LEVELS) return 0;
   const int K = kind == A3D_OP_CONV3 ? 27 : kind == A3D_OP_LINEAR ? 1 : 8;
   SkPlan q = plan_sk(s->lv[lvl_out].n, K, cin, cout, true);
-  return align256((size_t)kMaxQueuesPerOp * 4) + align256(q.slab_floats * 4) + 256;
+  size_t slab = q.slab_floats;
+  const DeepPlan dp = plan_deep(s->lv[lvl_out].n, K, cin, cout, 0);
+  if (dp.use && dp.slab_floats > slab) slab = dp.slab_floats;
+  return align256((size_t)kMaxQueuesPerOp * 4) + align256(slab * 4) + 256;
 }
 
 // shared body of a3d_conv_apply / a3d_conv_apply_acc / a3d_conv_bn_train_forward
@@ -2081,6 +2555,12 @@ extern "C" int a3d_conv_apply(const a3d_scene* s, int kind, int level_in, const 
 }
 
 extern "C" size_t a3d_conv_state_bytes(void) { return (size_t)kMaxQueuesPerOp * 4; }
+
+extern "C" int a3d_conv_deep_mode(int mode) {
+  const int before = deep_mode();
+  if (mode >= 0) g_deep_mode = mode;
+  return before;
+}
 
 extern "C" int a3d_conv_apply_acc(const a3d_scene* s, int kind, int level_in, const float* x_dev, int ldx, int cin,
                                   const float* w_packed_dev, int cout, float* y_dev, int ldy, int y_zero_row,

@@ -108,6 +108,7 @@ SYMBOLS = {
     "a3d_pack_conv_weight": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "a3d_conv_weight_packed_floats": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     "a3d_pack_conv_weights_multi": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_void_p]),
+    "a3d_conv_deep_mode": (C.c_int, [C.c_int]),
     "a3d_program_workspace_bytes": (C.c_size_t, [C.c_void_p, C.POINTER(BufDesc), C.c_int, C.POINTER(Op), C.c_int]),
     "a3d_program_buffer_offset": (C.c_size_t, [C.c_void_p, C.POINTER(BufDesc), C.c_int, C.c_int]),
     "a3d_program_run": (C.c_int, [C.c_void_p, C.POINTER(BufDesc), C.c_int, C.POINTER(Op), C.c_int, C.c_void_p,

@@ -114,6 +114,8 @@ def kernel_name(e):
     name = L.PROF_NAMES[e.id]
     if e.id == 0 and e.ksplit == 0:
         name = f"k_conv_wl<{e.cin // 16},{e.cout // 16}>"   # whole weight set resident in LDS (spconv.hip)
+    elif e.id == 0 and e.bn >= 1000:
+        name = f"k_conv_deep<{e.bn - 1000},{e.ksplit}>"   # the small-level kernel (spconv.hip: static parts, LDS-DMA ring)
     elif e.id == 0:
         name = f"k_conv_sk<{e.bn},{e.ksplit}>"   # BN columns per workgroup, CH input channels per stage (plan_sk; the
                                                   # profile entry's last integer field carries CH)

@@ -223,6 +223,13 @@ int    a3d_conv_apply(const a3d_scene* s, int kind, int level_in, const float* x
  *     64-row tile: column sums and squared deviations from the tile mean, merged in fp64 in a fixed order), so the raw
  *     output is not read again for them.  Exact-fp32 builds only (not under A3D_CONV_EMU). */
 size_t a3d_conv_state_bytes(void);
+/* Small levels (a layer with a few stages of work per CU: levels 2-4 of one scene; res16unet.py:89-147,242-259) run on
+ * k_conv_deep -- static (tile, column block, part) workgroups, both operands by LDS-DMA three stages ahead, a cut tile
+ * finished by its last arriver -- instead of the stream-K kernel.  mode 1 (default; A3D_CONV_DEEP in the environment) uses it
+ * where its cost model prefers it, 0 never; mode < 0 only queries; mode >= 16 forces a geometry (tuning only: bn / 32 |
+ * ch / 32 << 4 | parts << 8, tools/conv_bench.py --sweep).  Returns the mode in force before the call.  Workspaces
+ * sized under one mode stay valid under the other (the launch falls back to the stream-K kernel when the slab is short). */
+int    a3d_conv_deep_mode(int mode);
 int    a3d_conv_apply_acc(const a3d_scene* s, int kind, int level_in, const float* x_dev, int ldx, int cin,
                           const float* w_packed_dev, int cout, float* y_dev, int ldy, int y_zero_row,
                           const float* res_dev, int ldr, void* state_dev, void* workspace_dev, size_t workspace_bytes,

@@ -13,6 +13,16 @@ from oracle import backbone as ob
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(params=[1, 0], ids=["deep", "streamk"])
+def conv_kernel_family(request):
+    """The gathered-convolution tests run twice: with the small-level kernel (k_conv_deep: on this 6 k-voxel scene it takes every
+    gathered convolution its cost model allows) and with the stream-K kernel only (a3d_conv_deep_mode)."""
+    lib = L.load()
+    before = lib.a3d_conv_deep_mode(request.param)
+    yield request.param
+    lib.a3d_conv_deep_mode(before)
+
+
 @pytest.fixture(scope="module")
 def world():
     coords = make_scene(6000, seed=5)["coords"]
@@ -34,7 +44,7 @@ CONV3 = [(0, 32, 32), (0, 128, 96), (1, 96, 96), (1, 32, 64), (2, 192, 128), (3,
 
 @pytest.mark.parametrize("level,cin,cout", CONV3)
 @pytest.mark.parametrize("epi", ["plain", "bn_res_relu"])
-def test_conv3(world, level, cin, cout, epi):
+def test_conv3(world, conv_kernel_family, level, cin, cout, epi):
     coords, sc, lv, maps = world
     g = torch.Generator().manual_seed(level * 1000 + cin + cout)
     n = sc.n[level]
@@ -63,7 +73,7 @@ def test_conv3(world, level, cin, cout, epi):
 
 
 @pytest.mark.parametrize("level,c", [(0, 32), (1, 32), (2, 64), (3, 128)])
-def test_down(world, level, c):
+def test_down(world, conv_kernel_family, level, c):
     coords, sc, lv, maps = world
     g = torch.Generator().manual_seed(7 + level)
     n, nC = sc.n[level], sc.n[level + 1]
@@ -79,7 +89,7 @@ def test_down(world, level, c):
 
 
 @pytest.mark.parametrize("level_in,cin,cout", [(4, 256, 256), (3, 256, 128), (2, 128, 96), (1, 96, 96)])
-def test_up(world, level_in, cin, cout):
+def test_up(world, conv_kernel_family, level_in, cin, cout):
     coords, sc, lv, maps = world
     g = torch.Generator().manual_seed(11 + level_in)
     nC, nF = sc.n[level_in], sc.n[level_in - 1]
@@ -218,7 +228,7 @@ _WIDTHS_OUT = [32, 64, 96, 128, 256]
 
 @pytest.mark.parametrize("kind", ["conv3", "down", "up"])
 @pytest.mark.parametrize("level", [0, 1, 2, 3, 4])
-def test_conv_apply_every_shape_class_small_scene(small_world, kind, level):
+def test_conv_apply_every_shape_class_small_scene(small_world, conv_kernel_family, kind, level):
     """a3d_conv_apply (the training tapes' conv: forward AND input-gradient passes, so every (cin, cout) pairing occurs)
     on the 3000-voxel scene of the gradient tests, against float64 gather-GEMM-scatter: the small levels are where a
     layer is cut into shares inside tiles (hand-off), with a handful of rows per level."""
@@ -255,7 +265,7 @@ def test_conv_apply_every_shape_class_small_scene(small_world, kind, level):
 
 
 @pytest.mark.parametrize("level,cin,cout,cin2", [(1, 96, 96, 128), (2, 128, 128, 192), (1, 96, 64, 64), (0, 32, 32, 64)])
-def test_fused_projection_op_and_its_fallback(world, level, cin, cout, cin2):
+def test_fused_projection_op_and_its_fallback(world, conv_kernel_family, level, cin, cout, cin2):
     """a3d_op with a fused residual projection (proj_buf / proj_cin: BasicBlock.downsample as a 28th offset of the block's
     second conv, resnet_block.py:59-61) through the C ABI against float64: the shapes the U-Net uses run the fused build;
     96 -> 64 and 32 -> 32 have no fused instantiation (stage width 96 / the LDS-resident 32-channel kernel) -- the program

@@ -83,6 +83,47 @@ def test_fused_residual_projections_equal_the_separate_launches(model_and_sd, n,
         assert (a - b).abs().max().item() <= 2e-5 * scale, (a - b).abs().max().item()
 
 
+@pytest.mark.parametrize("n,batch", [(3000, 1), (20000, 2), (80000, 1)])
+def test_small_level_kernel_equals_stream_k_and_is_deterministic(model_and_sd, n, batch):
+    """Levels with a few stages of work per CU run on k_conv_deep (static parts, both operands by LDS-DMA, a cut tile finished
+    by its last arriver; spconv.hip) instead of the stream-K kernel (a3d_conv_deep_mode).  Same arithmetic, another
+    partition of the sums: every feature map and the output agree to rounding; two runs of either are bit-identical (the
+    order in which the parts of a tile are added does not depend on which part arrives last); and the profile shows that
+    the small-level kernel really ran."""
+    from agile3d_amd import lib as L
+    model, _ = model_and_sd
+    lib = L.load()
+    scs = [make_scene(n, seed=20 + b, batch_index=b) for b in range(batch)]
+    sc = {k: np.concatenate([s_[k] for s_ in scs]) for k in ("coords", "feats", "raw_xyz")}
+    before = lib.a3d_conv_deep_mode(-1)
+    outs = {}
+    try:
+        for mode in (1, 0):
+            lib.a3d_conv_deep_mode(mode)
+            runs = []
+            for rep in range(2):
+                if rep == 1:
+                    lib.a3d_profile_read(None, 0)
+                    lib.a3d_profile_enable(1)
+                pcd, aux, _, _ = _run_backbone(model, sc)
+                torch.cuda.synchronize()
+                runs.append([pcd.F.clone()] + [a.F.clone() for a in aux])
+            lib.a3d_profile_enable(0)
+            buf = (L.ProfEntry * 4096)()
+            cnt = lib.a3d_profile_read(buf, 4096)
+            deep = sum(1 for i in range(cnt) if buf[i].id == 0 and buf[i].bn >= 1000)
+            assert (deep > 0) == (mode == 1), (mode, deep)
+            print(f"n={n} x {batch}, mode {mode}: {deep} of {cnt} profiled launches on k_conv_deep")
+            for a, b in zip(*runs):
+                assert torch.equal(a, b), "two runs differ"
+            outs[mode] = runs[0]
+    finally:
+        lib.a3d_conv_deep_mode(before)
+    for a, b in zip(outs[1], outs[0]):
+        scale = max(1.0, b.abs().max().item())
+        assert (a - b).abs().max().item() <= 2e-5 * scale, (a - b).abs().max().item()
+
+
 def test_forward_mask_matches_oracle_end_to_end(model_and_sd):
     model, sd = model_and_sd
     sc = make_scene(4000, seed=3)

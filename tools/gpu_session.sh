@@ -1,6 +1,12 @@
 #!/bin/bash
-# Scratch script of the current GPU session (overwritten per session; `gpurun -- 'bash tools/gpu_session.sh'`).
 R=$GRAFT_REPO_ROOT
 cd $R
-timeout 5000 bash tools/profile_round.sh r05 > gpurun_out/r05_profile_round.log 2>&1
-ls -la gpurun_out/r05
+O=gpurun_out/d6
+mkdir -p $O
+python tools/latency_one_scene.py --deep 0
+python tools/latency_one_scene.py --deep 1
+python tools/latency_one_scene.py --deep 0
+python tools/latency_one_scene.py --deep 1
+timeout 900 python tools/conv_bench.py --sweep --reps 10 --only conv3_ > $O/sweep80.txt 2>&1
+grep -v "^L0\|^L1" $O/sweep80.txt
+timeout 900 python tools/conv_bench.py --sweep --reps 10 --voxels 300000 --only "L2_\|L3_\|L4_" > $O/sweep300.txt 2>&1

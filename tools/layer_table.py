@@ -44,7 +44,7 @@ for i in range(per):
     name = L.PROF_NAMES[e.id]
     if e.id == 0:
         fl = bench.algorithmic_flops(e, pairs)
-        print(f"{i:3d} spconv<{e.bn:3d}> {kinds.get(e.table,'?'):5s} L{e.level} {e.cin:4d}->{e.cout:4d} K={e.kernel_volume & 255:3d}{'+p' if (e.kernel_volume >> 8) & 0xfff else '+h' if e.kernel_volume >> 20 else '  '} rows={e.n_out:6d} "
+        print(f"{i:3d} {'deep  ' if e.bn >= 1000 else 'spconv'}<{e.bn % 1000:3d}> {kinds.get(e.table,'?'):5s} L{e.level} {e.cin:4d}->{e.cout:4d} K={e.kernel_volume & 255:3d}{'+p' if (e.kernel_volume >> 8) & 0xfff else '+h' if e.kernel_volume >> 20 else '  '} rows={e.n_out:6d} "
               f"ch={e.ksplit:3d} {1e3*ms:8.1f} us {fl/ms/1e9:7.1f} TF/s")
     elif e.id == L.PROF_DENSE:
         fl = 2.0 * e.n_out * e.cin * e.cout
