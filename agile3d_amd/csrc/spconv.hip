@@ -751,7 +751,7 @@ __device__ __forceinline__ void wait_vmcnt() {   // vmcnt <= N (expcnt 7, lgkmcn
 }
 
 // ABL (tuning builds only, tools/conv_bench.py --ablate): 1 = no gathered pieces, 2 = no weight pieces, 4 = no MFMAs
-template <int BN, int CH, bool FUSE, int ABL = 0>
+template <int BN, int CH, bool FUSE, int ABL = 0, int D = 3>
 __global__ void __launch_bounds__(256, 1) k_conv_deep(const DeepArgs a) {
   constexpr int NCT = BN / 16, NS = CH / 16, NW = 4;
   constexpr int NPW = NS * NCT;          // 1 KB pieces of a stage's weight slice
@@ -760,7 +760,7 @@ __global__ void __launch_bounds__(256, 1) k_conv_deep(const DeepArgs a) {
   constexpr int WF = NPW * 256;          // floats of the weight slice
   constexpr int AF = NW * NS * 256;      // floats of the four waves' gathered fragments
   constexpr int SLOT = WF + AF;
-  constexpr int D = 4, PW = 3;           // ring slots; stages in flight ahead of the one multiplied
+  constexpr int PW = D - 1;              // D ring slots; PW stages in flight ahead of the one multiplied
   constexpr int NL = ((ABL & 1) ? 0 : NS) + ((ABL & 2) ? 0 : WV);   // DMA instructions per wave and stage
   static_assert((PW - 1) * NL <= 63, "vmcnt is a 6-bit counter");
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -920,22 +920,25 @@ __global__ void __launch_bounds__(256, 1) k_conv_deep(const DeepArgs a) {
       issue(ik, ic, q);
       adv(ik, ic);
     }
+    int slot_cur = 0, slot_nx = PW % D;   // ring slots of stage i and of stage i + PW
     for (int i = 0; i < n; ++i) {
       // stages i + 1 .. i + PW - 1 (as far as the part goes) are the loads allowed to stay in flight
       const int rem = n - 1 - i;
-      if (rem >= 2) wait_vmcnt<2 * NL>();
-      else if (rem == 1) wait_vmcnt<NL>();
+      if (PW >= 3 && rem >= 2) wait_vmcnt<2 * NL>();
+      else if (PW >= 2 && rem >= 1) wait_vmcnt<NL>();
       else wait_vmcnt<0>();
       __builtin_amdgcn_s_barrier();   // every wave's pieces of stage i have landed; every wave is done reading slot (i - 1) % D
       if (i == 0) stamp(2);
       if (i + PW < n) {
-        const Stage nx = stage_of(ik, ic, (i + PW) & (D - 1));
+        const Stage nx = stage_of(ik, ic, slot_nx);
         adv(ik, ic);
-        compute(ck, i & (D - 1), &nx);
+        compute(ck, slot_cur, &nx);
       } else {
-        compute(ck, i & (D - 1), nullptr);
+        compute(ck, slot_cur, nullptr);
       }
       adv(ck, cc);
+      slot_cur = slot_cur + 1 == D ? 0 : slot_cur + 1;
+      slot_nx = slot_nx + 1 == D ? 0 : slot_nx + 1;
     }
   }
   stamp(3);
@@ -1736,15 +1739,15 @@ static SkPlan plan_sk(int n_rows, int K, int cin, int cout, bool handoff, int fo
 // The model behind the choice (us; fitted to per-workgroup phase timestamps and ablation builds on the levels of one 80 k-voxel
 // scene, profiles/r05_experiments.txt): a workgroup's life = 2.6 (masks + table, then the first slices' round trip) + its
 // stages x (0.3 skeleton + 0.04 per LDS-DMA instruction of a wave + the stage's MFMA time: the DMA issue does not hide behind
-// the MFMAs of a lone wave) + the hand-off of a unit cut into P parts (1.0 publish + 0.25 per 16 KB part read by the last
-// arriver: 65 GB/s into one CU); one workgroup per CU, so G > 256 runs in rounds.  A 64-row tile issues the UNION of its rows' offsets: 22 of 27
+// the MFMAs of a lone wave) + the hand-off of a unit cut into P parts (1.0 publish + 0.3-0.45 per part read by the last
+// arriver: round trips to write-through data of other XCDs, 65 GB/s into one CU); one workgroup per CU: layers that need more than 256 are left to the stream-K kernel.  A 64-row tile issues the UNION of its rows' offsets: 22 of 27
 // on levels of up to a few thousand rows, 14-17 on the large ones (rows sorted by neighbour pattern).
 // The kernel is preferred while the layer's matrix work per CU stays below A3D_DEEP_MAX_US (18): beyond that the stream-K
 // kernel's two workgroups per CU win (measured: level 3 384 -> 256 a tie at 23 us of work per CU, level 2 192 -> 128 lost).
 // A3D_CONV_DEEP=0 switches the kernel off (A/B).
 struct DeepPlan {
   bool use;
-  int bn, ch, P, G, n_cblk, ntile, nchunk;
+  int bn, ch, P, G, n_cblk, ntile, nchunk, D;
   size_t lds, slab_floats;
   float est_us;
 };
@@ -1756,18 +1759,20 @@ static int deep_mode() {
   }
   return g_deep_mode;
 }
-static DeepPlan plan_deep(int n_rows, int K, int cin, int cout, int cin2) {
+// `up`: a transposed 2^3 layer -- its fine rows are sorted by child slot, a tile has one or two of the eight offsets
+static DeepPlan plan_deep(int n_rows, int K, int cin, int cout, int cin2, bool up = false) {
   DeepPlan best;
   memset(&best, 0, sizeof(best));
   if (!deep_mode() || K < 2 || K > 27 || cin % 32 || cout % 32 || conv_emu(K, cin, cout)) return best;
   static float max_us = -1.f;
   if (max_us < 0.f) {
     const char* e = getenv("A3D_DEEP_MAX_US");
-    max_us = e ? (float)atof(e) : 18.f;
+    max_us = e ? (float)atof(e) : 23.f;
   }
   const int ntile = n_rows > 0 ? (n_rows + 63) / 64 : 1;
-  const int k_eff = K == 27 ? (n_rows < 8000 ? 22 : n_rows < 32000 ? 17 : 14) : K;
+  const int k_eff = K == 27 ? (n_rows < 8000 ? 22 : n_rows < 32000 ? 17 : 14) : up ? 2 : K;
   static const int cand[5][2] = {{128, 32}, {64, 64}, {64, 32}, {32, 64}, {32, 32}};
+  auto lds_of = [](int bn, int ch, int D) -> size_t { return (size_t)D * ((ch / 16) * (bn / 16) + 4 * (ch / 16)) * 1024 + 28 * 64 * 4 + 64; };
   float best_t = 1e30f;
   for (int ci = 0; ci < 5; ++ci) {
     const int bn = cand[ci][0], ch = cand[ci][1];
@@ -1779,20 +1784,28 @@ static DeepPlan plan_deep(int n_rows, int K, int cin, int cout, int cin2) {
     const float mf = (float)ns * (float)nct * 0.0533f;
     const float tstage = (ns < 4 ? 0.45f : 0.3f) + 0.04f * (float)(ns + ns * nct / 4) + mf;   // two-step stages expose their LDS reads
     if ((float)units * (float)S * mf / 256.f > max_us) continue;   // matrix-bound: the stream-K kernel's ground
-    for (int P = 1; P <= 24; ++P) {
-      if (P > 1 && S / P < 2) break;
-      const int G = units * P;
-      if (G > kSkMaxG) break;
-      const int rounds = (G + 255) / 256;
-      const float t = rounds * (2.6f + (float)((S + P - 1) / P) * tstage) + (P > 1 ? 1.0f + 0.25f * P * bn / 64.f : 0.f);
-      if (t < best_t) {
-        best_t = t;
-        best.bn = bn, best.ch = ch, best.P = P, best.G = G, best.n_cblk = cout / bn, best.ntile = ntile, best.nchunk = cin / ch;
+    for (int D = 3; D >= 2; --D) {
+      // three ring slots, or two when that lets a second workgroup onto the CU (its waves fill the issue slots the first
+      // one's DMA instructions and barriers leave: measured 10-15 % on the 128- / 256-channel layers of levels 2 / 3)
+      const int per_cu = 160 * 1024 / lds_of(bn, ch, D) >= 2 ? 2 : 1;
+      if (D == 2 && (per_cu < 2 || 160 * 1024 / lds_of(bn, ch, 3) >= 2)) continue;
+      for (int P = 1; P <= 24; ++P) {
+        if (P > 1 && S / P < 2) break;
+        const int G = units * P;
+        if (G > 256 * per_cu) break;   // every workgroup resident at once: a second round would start when the first ends
+        const int stages = (S + P - 1) / P;
+        const float ts = G > 256 ? fmaxf(tstage + 0.1f, 2.2f * mf + 0.3f) : tstage + (D == 2 ? 0.05f : 0.f);   // two on a CU share its matrix cores
+        const float t = 2.6f + (float)stages * ts + (P > 1 ? 1.0f + (float)P * (0.2f + 0.12f * bn / 32.f) * (G > 256 ? 1.5f : 1.f) : 0.f);
+        if (t < best_t) {
+          best_t = t;
+          best.bn = bn, best.ch = ch, best.P = P, best.G = G, best.n_cblk = cout / bn, best.ntile = ntile, best.nchunk = cin / ch;
+          best.D = D;
+        }
       }
     }
   }
-  // mode >= 16 (experiments, tools/conv_bench.py --sweep): bits 0-3 = bn / 32, bits 4-7 = ch / 32, bits 8-15 = P (0: 256 / units):
-  // that geometry wherever it divides the layer
+  // mode >= 16 (experiments, tools/conv_bench.py --sweep): bits 0-3 = bn / 32, bits 4-7 = ch / 32, bits 8-15 = P (0: 256 / units),
+  // bits 19-20 = ring slots (0: three): that geometry wherever it divides the layer
   int force[3] = {0, 0, 0};
   if (deep_mode() >= 16) force[0] = (deep_mode() & 15) * 32, force[1] = ((deep_mode() >> 4) & 15) * 32, force[2] = (deep_mode() >> 8) & 255;
   if (force[0] > 0 && force[1] > 0 && cout % force[0] == 0 && cin % force[1] == 0 && (cin2 <= 0 || cin2 % force[1] == 0)) {
@@ -1806,14 +1819,15 @@ static DeepPlan plan_deep(int n_rows, int K, int cin, int cout, int cin2) {
     if (P < 1) P = 1;
     if (units * P <= kSkMaxG && units <= kMaxQueuesPerOp - 2) {
       best.bn = bn, best.ch = ch, best.P = P, best.G = units * P, best.n_cblk = cout / bn, best.ntile = ntile, best.nchunk = cin / ch;
+      const int dsel = (deep_mode() >> 19) & 3;
+      best.D = dsel == 1 ? 2 : dsel == 2 ? 4 : 3;
       best_t = 0.f;
     }
   }
   if (best_t > 1e29f) return best;
   best.use = true;
   best.est_us = best_t;
-  const int ns = best.ch / 16, nct = best.bn / 16;
-  best.lds = (size_t)4 * (ns * nct + 4 * ns) * 1024 + 28 * 64 * 4 + 64;
+  best.lds = lds_of(best.bn, best.ch, best.D);
   best.slab_floats = best.P > 1 ? (size_t)best.G * 64 * best.bn : 0;
   return best;
 }
@@ -1843,10 +1857,14 @@ static void allow_big_lds() {
   A3D_ALLOW_LDS(160 * 1024, k_conv_sk<64, 32, 2>);
   A3D_ALLOW_LDS(160 * 1024, k_conv_sk<32, 32, 2>);
 #define A3D_BIGD(BN_, CH_) \
-  A3D_ALLOW_LDS(160 * 1024, (k_conv_deep<BN_, CH_, false>)); \
-  A3D_ALLOW_LDS(160 * 1024, (k_conv_deep<BN_, CH_, true>));
+  A3D_ALLOW_LDS(160 * 1024, (k_conv_deep<BN_, CH_, false, 0, 3>)); \
+  A3D_ALLOW_LDS(160 * 1024, (k_conv_deep<BN_, CH_, true, 0, 3>)); \
+  A3D_ALLOW_LDS(160 * 1024, (k_conv_deep<BN_, CH_, false, 0, 2>)); \
+  A3D_ALLOW_LDS(160 * 1024, (k_conv_deep<BN_, CH_, true, 0, 2>));
   A3D_BIGD(128, 32) A3D_BIGD(64, 64) A3D_BIGD(64, 32) A3D_BIGD(32, 64) A3D_BIGD(32, 32)
 #undef A3D_BIGD
+  A3D_ALLOW_LDS(160 * 1024, (k_conv_deep<64, 64, false, 0, 4>));
+  A3D_ALLOW_LDS(160 * 1024, (k_conv_deep<32, 64, false, 0, 4>));
 #define A3D_BIGA(ABL_) \
   A3D_ALLOW_LDS(160 * 1024, (k_conv_deep<64, 64, false, ABL_>)); \
   A3D_ALLOW_LDS(160 * 1024, (k_conv_deep<32, 64, false, ABL_>));
@@ -1914,7 +1932,7 @@ static int launch_conv_sk(ConvArgs c, const int* pre64, float* slab_ws, size_t s
     return launch_conv_wl(c, st, stats, stats_ld, bw);
   }
   if (state && !stats && c.head_cout == 0 && c.K > 1) {
-    const DeepPlan d = plan_deep(c.n_out, c.K, c.cin, c.cout, c.cin2);
+    const DeepPlan d = plan_deep(c.n_out, c.K, c.cin, c.cout, c.cin2, c.tag_table == A3D_OP_UP);
     if (d.use && d.slab_floats <= slab_ws_floats && (c.cin2 == 0 || (c.K == 27 && c.in2 && !(c.ldi2 & 3) &&
         (uint64_t)(c.n_out + 1) * (uint64_t)c.ldi2 * 4ull < (1ull << 32)))) {
       DeepArgs a;
@@ -1944,16 +1962,24 @@ static int launch_conv_sk(ConvArgs c, const int* pre64, float* slab_ws, size_t s
         (void)hipMemsetAsync(dbg_buf, 0, (size_t)kSkMaxG * 6 * 8, st);
       }
       const int abl = deep_mode() >= 16 ? (deep_mode() >> 16) & 7 : 0;
-      if (abl && c.cin2 == 0 && ((d.bn == 64 && d.ch == 64) || (d.bn == 32 && d.ch == 64))) {
+      if ((abl || d.D == 4) && c.cin2 == 0 && ((d.bn == 64 && d.ch == 64) || (d.bn == 32 && d.ch == 64))) {   // tuning builds
+        if (d.D == 4) {
+          if (d.bn == 64) k_conv_deep<64, 64, false, 0, 4><<<d.G, 256, d.lds, st>>>(a); else k_conv_deep<32, 64, false, 0, 4><<<d.G, 256, d.lds, st>>>(a);
+        } else {
 #define A3D_LA(ABL_) \
   if (abl == ABL_) { if (d.bn == 64) k_conv_deep<64, 64, false, ABL_><<<d.G, 256, d.lds, st>>>(a); else k_conv_deep<32, 64, false, ABL_><<<d.G, 256, d.lds, st>>>(a); } else
-        A3D_LA(1) A3D_LA(2) A3D_LA(3) A3D_LA(4) A3D_LA(5) A3D_LA(6) A3D_LA(7) {}
+          A3D_LA(1) A3D_LA(2) A3D_LA(3) A3D_LA(4) A3D_LA(5) A3D_LA(6) A3D_LA(7) {}
 #undef A3D_LA
+        }
       } else {
+        const bool two = d.D == 2;
 #define A3D_LD(BN_, CH_) \
-  if (d.bn == BN_ && d.ch == CH_) { if (c.cin2 > 0) k_conv_deep<BN_, CH_, true><<<d.G, 256, d.lds, st>>>(a); else k_conv_deep<BN_, CH_, false><<<d.G, 256, d.lds, st>>>(a); } else
-      A3D_LD(128, 32) A3D_LD(64, 64) A3D_LD(64, 32) A3D_LD(32, 64) A3D_LD(32, 32)
-      { set_error("spconv: no deep kernel for BN %d CH %d", d.bn, d.ch); return A3D_ERR_UNSUPPORTED; }
+  if (d.bn == BN_ && d.ch == CH_) { \
+    if (c.cin2 > 0) { if (two) k_conv_deep<BN_, CH_, true, 0, 2><<<d.G, 256, d.lds, st>>>(a); else k_conv_deep<BN_, CH_, true, 0, 3><<<d.G, 256, d.lds, st>>>(a); } \
+    else { if (two) k_conv_deep<BN_, CH_, false, 0, 2><<<d.G, 256, d.lds, st>>>(a); else k_conv_deep<BN_, CH_, false, 0, 3><<<d.G, 256, d.lds, st>>>(a); } \
+  } else
+        A3D_LD(128, 32) A3D_LD(64, 64) A3D_LD(64, 32) A3D_LD(32, 64) A3D_LD(32, 32)
+        { set_error("spconv: no deep kernel for BN %d CH %d", d.bn, d.ch); return A3D_ERR_UNSUPPORTED; }
 #undef A3D_LD
       }
       A3D_LAUNCH_CHECK();
@@ -1975,7 +2001,7 @@ static int launch_conv_sk(ConvArgs c, const int* pre64, float* slab_ws, size_t s
               sum[q] += v, ++cntq[q];
               if (v > mx[q]) mx[q] = v;
             }
-        fprintf(stderr, "deep<%d,%d>%s K=%d %d->%d rows=%d units=%d P=%d G=%d span %.2f us | avg/max since first start:", d.bn, d.ch,
+        fprintf(stderr, "deep<%d,%d,D%d>%s K=%d %d->%d rows=%d units=%d P=%d G=%d span %.2f us | avg/max since first start:", d.bn, d.ch, d.D,
                 c.cin2 > 0 ? "+p" : "", c.K, c.cin, c.cout, c.n_out, d.G / d.P, d.P, d.G, (double)(tend - t0min) * 0.01);
         const char* nm[6] = {"start", "table", "stage0", "loop", "publish", "end"};
         for (int q = 0; q < 6; ++q)
@@ -2139,7 +2165,7 @@ static int layout_program(const a3d_scene* s, const a3d_buf_desc* bufs, int n_bu
       q = plan_sk(s->lv[lvl_out].n, o.kernel_volume, o.cin, o.cout, true, 32);
       if (q.slab_floats > pf) pf = q.slab_floats;
     }
-    const DeepPlan dp = plan_deep(s->lv[lvl_out].n, o.kernel_volume, o.cin, o.cout, o.proj_cin);
+    const DeepPlan dp = plan_deep(s->lv[lvl_out].n, o.kernel_volume, o.cin, o.cout, o.proj_cin, o.kind == A3D_OP_UP);
     if (dp.use && dp.slab_floats > pf) pf = dp.slab_floats;
   }
   L.partial_off = off;
@@ -2466,7 +2492,7 @@ extern "C" size_t a3d_conv_apply_workspace_bytes(const a3d_scene* s, int kind, i
   const int K = kind == A3D_OP_CONV3 ? 27 : kind == A3D_OP_LINEAR ? 1 : 8;
   SkPlan q = plan_sk(s->lv[lvl_out].n, K, cin, cout, true);
   size_t slab = q.slab_floats;
-  const DeepPlan dp = plan_deep(s->lv[lvl_out].n, K, cin, cout, 0);
+  const DeepPlan dp = plan_deep(s->lv[lvl_out].n, K, cin, cout, 0, kind == A3D_OP_UP);
   if (dp.use && dp.slab_floats > slab) slab = dp.slab_floats;
   return align256((size_t)kMaxQueuesPerOp * 4) + align256(slab * 4) + 256;
 }

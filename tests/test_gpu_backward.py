@@ -234,7 +234,9 @@ def test_input_gradient_conv_with_batchnorm_backward_sums(world, kind, level_in,
     want_sums = torch.stack([want_g.sum(0), (want_g * xhat).sum(0)])
     out = prev.clone()
     sums = B.conv_dgrad_bn(sc, kind, level_in, parts[0], dy, cout, out, acc, y, raw, mean, rstd, relu, state=state)
-    assert torch.equal(out[:n_in], want_g.float()) or (out[:n_in].double() - want_g).abs().max().item() <= 1e-6 * max(1.0, want_g.abs().max().item())
+    # (the plain conv of a small level may run on k_conv_deep, the one with the sums on the stream-K kernel: the same terms in
+    # another partition of the sum -- rounding, not bit-identity)
+    assert torch.equal(out[:n_in], want_g.float()) or (out[:n_in].double() - want_g).abs().max().item() <= 2e-5 * max(1.0, want_g.abs().max().item())
     assert (out[n_in] == 0).all()
     scale = max(1.0, want_sums.abs().max().item())
     assert (sums - want_sums).abs().max().item() <= 2e-5 * scale, (sums - want_sums).abs().max().item()

@@ -102,6 +102,9 @@ def main():
                 lib.a3d_conv_deep_mode((bn // 32) | (ch // 32) << 4 | parts << 8 | abl << 16)
                 b, _, t, _ = measure()
                 row.append(f"abl{abl} {t * 1e3:6.1f}")
+            for dsel, dd in ((1, 2), (2, 4)):   # two / four ring slots instead of three
+                lib.a3d_conv_deep_mode((bn // 32) | (ch // 32) << 4 | parts << 8 | dsel << 19)
+                row.append(f"| D={dd} {measure()[2] * 1e3:6.1f}")
             lib.a3d_conv_deep_mode(1)
             print(" ".join(row), flush=True)
             continue
