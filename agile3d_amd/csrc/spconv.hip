@@ -743,6 +743,11 @@ struct DeepArgs {
   float* slab;         // [units * P][64 * BN]
   unsigned in_row_bytes, in2_row_bytes;
   unsigned long long* dbg;   // A3D_DEEP_DBG: [G][6] timestamps (100 MHz) of a workgroup's phases; nullptr otherwise
+  // STATS builds (training, as k_conv_sk's): per 64-row tile and column the BatchNorm partials [n_tiles][2][stats_ld];
+  // STATS == 2: the input-gradient conv's mask + sums (bw: y, raw, mean, rstd of the unit)
+  float* stats;
+  int stats_ld;
+  BwArgs bw;
 };
 
 template <int N>
@@ -751,8 +756,9 @@ __device__ __forceinline__ void wait_vmcnt() {   // vmcnt <= N (expcnt 7, lgkmcn
 }
 
 // ABL (tuning builds only, tools/conv_bench.py --ablate): 1 = no gathered pieces, 2 = no weight pieces, 4 = no MFMAs
-template <int BN, int CH, bool FUSE, int ABL = 0, int D = 3>
+template <int BN, int CH, bool FUSE, int ABL = 0, int D = 3, int STATS = 0>
 __global__ void __launch_bounds__(256, 1) k_conv_deep(const DeepArgs a) {
+  static_assert(!STATS || !FUSE, "BatchNorm statistics are taken of a raw convolution");
   constexpr int NCT = BN / 16, NS = CH / 16, NW = 4;
   constexpr int NPW = NS * NCT;          // 1 KB pieces of a stage's weight slice
   static_assert(NPW % NW == 0, "every wave moves the same number of weight pieces (the vmcnt arithmetic)");
@@ -991,6 +997,82 @@ __global__ void __launch_bounds__(256, 1) k_conv_deep(const DeepArgs a) {
   }
 
   const int myrow = r0 + wrow;
+  if constexpr (STATS == 1) {
+    // BatchNorm statistics of the raw tile, exactly as k_conv_sk<..., STATS = 1> takes them (the same fixed orders: the
+    // partials of a tile do not depend on which kernel produced it beyond the rounding of the accumulators)
+    float* sst = (float*)(misc + 16);   // [2][4][BN]
+    const bool valid = myrow < a.c.n_out;
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct) {
+      f32x4 sv = valid ? acc[ct] : (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int tt = 0; tt < 4; ++tt) sv[tt] = row16_sum(sv[tt]);
+      if (j == 0) *(f32x4*)(sst + wave * BN + ct * 16 + 4 * g) = sv;
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    __syncthreads();
+    const float inv = 1.f / (float)min(64, a.c.n_out - r0);
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct) {
+      const float* sp = sst + ct * 16 + 4 * g;
+      const f32x4 tsum = ((*(const f32x4*)sp + *(const f32x4*)(sp + BN)) + *(const f32x4*)(sp + 2 * BN)) + *(const f32x4*)(sp + 3 * BN);
+      f32x4 dv = valid ? acc[ct] - tsum * inv : (f32x4){0.f, 0.f, 0.f, 0.f};
+      dv = dv * dv;
+#pragma unroll
+      for (int tt = 0; tt < 4; ++tt) dv[tt] = row16_sum(dv[tt]);
+      if (j == 0) *(f32x4*)(sst + 4 * BN + wave * BN + ct * 16 + 4 * g) = dv;
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    __syncthreads();
+    if (tid < BN) {
+      const float* s1p = sst + tid;
+      const float* s2p = sst + 4 * BN + tid;
+      float* Pq = a.stats + (size_t)t * 2 * a.stats_ld + cb * BN + tid;
+      Pq[0] = ((s1p[0] + s1p[BN]) + s1p[2 * BN]) + s1p[3 * BN];
+      Pq[a.stats_ld] = ((s2p[0] + s2p[BN]) + s2p[2 * BN]) + s2p[3 * BN];
+    }
+  }
+  if constexpr (STATS == 2) {
+    // input-gradient conv: g = (dy (+ the gradient already in the buffer)) masked by y > 0, stored; tile sums of g and g xhat
+    float* sst = (float*)(misc + 16);   // [2][4][BN]
+    const bool valid = myrow < a.c.n_out;
+    const int orow = valid ? (a.c.out_map ? a.c.out_map[myrow] : myrow) : 0;
+    float* po = a.c.out + (size_t)orow * a.c.ldo + ct0 * 16 + 4 * g;
+    const float* pr = a.c.res ? a.c.res + (size_t)orow * a.c.ldr + ct0 * 16 + 4 * g : nullptr;
+    const float* py = a.bw.y + (size_t)orow * a.bw.ldy + ct0 * 16 + 4 * g;
+    const float* pw = a.bw.raw + (size_t)orow * a.bw.ldraw + ct0 * 16 + 4 * g;
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct) {
+      f32x4 v = acc[ct];
+      if (pr) v += *(const f32x4*)(pr + ct * 16);
+      if (a.bw.relu) {
+        const f32x4 yv = *(const f32x4*)(py + ct * 16);
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt) v[tt] = yv[tt] > 0.f ? v[tt] : 0.f;
+      }
+      const f32x4 xh = (*(const f32x4*)(pw + ct * 16) - *(const f32x4*)(a.bw.mean + (ct0 + ct) * 16 + 4 * g)) *
+                       *(const f32x4*)(a.bw.rstd + (ct0 + ct) * 16 + 4 * g);
+      if (valid) *(f32x4*)(po + ct * 16) = v;
+      f32x4 s1 = valid ? v : (f32x4){0.f, 0.f, 0.f, 0.f};
+      f32x4 s2 = s1 * xh;
+#pragma unroll
+      for (int tt = 0; tt < 4; ++tt) s1[tt] = row16_sum(s1[tt]), s2[tt] = row16_sum(s2[tt]);
+      if (j == 0) {
+        *(f32x4*)(sst + wave * BN + ct * 16 + 4 * g) = s1;
+        *(f32x4*)(sst + 4 * BN + wave * BN + ct * 16 + 4 * g) = s2;
+      }
+    }
+    __syncthreads();
+    if (tid < BN) {
+      const float* s1p = sst + tid;
+      const float* s2p = sst + 4 * BN + tid;
+      float* Pq = a.stats + (size_t)t * 2 * a.stats_ld + cb * BN + tid;
+      Pq[0] = ((s1p[0] + s1p[BN]) + s1p[2 * BN]) + s1p[3 * BN];
+      Pq[a.stats_ld] = ((s2p[0] + s2p[BN]) + s2p[2 * BN]) + s2p[3 * BN];
+    }
+    stamp(5);
+    return;
+  }
   if (myrow < a.c.n_out) {
     const int orow = a.c.out_map ? a.c.out_map[myrow] : myrow;
     float* po = a.c.out + (size_t)orow * a.c.ldo + ct0 * 16 + 4 * g;
@@ -1860,7 +1942,11 @@ static void allow_big_lds() {
   A3D_ALLOW_LDS(160 * 1024, (k_conv_deep<BN_, CH_, false, 0, 3>)); \
   A3D_ALLOW_LDS(160 * 1024, (k_conv_deep<BN_, CH_, true, 0, 3>)); \
   A3D_ALLOW_LDS(160 * 1024, (k_conv_deep<BN_, CH_, false, 0, 2>)); \
-  A3D_ALLOW_LDS(160 * 1024, (k_conv_deep<BN_, CH_, true, 0, 2>));
+  A3D_ALLOW_LDS(160 * 1024, (k_conv_deep<BN_, CH_, true, 0, 2>)); \
+  A3D_ALLOW_LDS(160 * 1024, (k_conv_deep<BN_, CH_, false, 0, 3, 1>)); \
+  A3D_ALLOW_LDS(160 * 1024, (k_conv_deep<BN_, CH_, false, 0, 2, 1>)); \
+  A3D_ALLOW_LDS(160 * 1024, (k_conv_deep<BN_, CH_, false, 0, 3, 2>)); \
+  A3D_ALLOW_LDS(160 * 1024, (k_conv_deep<BN_, CH_, false, 0, 2, 2>));
   A3D_BIGD(128, 32) A3D_BIGD(64, 64) A3D_BIGD(64, 32) A3D_BIGD(32, 64) A3D_BIGD(32, 32)
 #undef A3D_BIGD
   A3D_ALLOW_LDS(160 * 1024, (k_conv_deep<64, 64, false, 0, 4>));
@@ -1931,7 +2017,7 @@ static int launch_conv_sk(ConvArgs c, const int* pre64, float* slab_ws, size_t s
     if (stats) *stats_rows = 16;
     return launch_conv_wl(c, st, stats, stats_ld, bw);
   }
-  if (state && !stats && c.head_cout == 0 && c.K > 1) {
+  if (state && c.head_cout == 0 && c.K > 1) {
     const DeepPlan d = plan_deep(c.n_out, c.K, c.cin, c.cout, c.cin2, c.tag_table == A3D_OP_UP);
     if (d.use && d.slab_floats <= slab_ws_floats && (c.cin2 == 0 || (c.K == 27 && c.in2 && !(c.ldi2 & 3) &&
         (uint64_t)(c.n_out + 1) * (uint64_t)c.ldi2 * 4ull < (1ull << 32)))) {
@@ -1947,6 +2033,14 @@ static int launch_conv_sk(ConvArgs c, const int* pre64, float* slab_ws, size_t s
       a.slab = slab_ws;
       a.in_row_bytes = (unsigned)c.ldi * 4u;
       a.in2_row_bytes = (unsigned)c.ldi2 * 4u;
+      size_t lds = d.lds;
+      if (stats) {   // training: the last arriver's epilogue writes the tile's BatchNorm partials (k_conv_sk's layout and orders)
+        a.stats = stats;
+        a.stats_ld = stats_ld;
+        *stats_rows = 64;
+        if (bw) a.bw = *bw;
+        lds += (size_t)8 * d.bn * 4;
+      }
       // the kernel-volume field as k_conv_sk's (K | cin2 << 8); the column field carries 1000 + BN: "deep" in the layer tables
       ProfScope ps(st, A3D_PROF_SPCONV, 1000 + d.bn, c.K | (c.cin2 << 8), c.cin, c.cout, c.n_out, c.tag_table, c.tag_level, d.ch);
       // A3D_DEEP_DBG=1 (tuning): per-workgroup phase timestamps of every launch, summarised on stderr (synchronises the stream)
@@ -1971,6 +2065,16 @@ static int launch_conv_sk(ConvArgs c, const int* pre64, float* slab_ws, size_t s
           A3D_LA(1) A3D_LA(2) A3D_LA(3) A3D_LA(4) A3D_LA(5) A3D_LA(6) A3D_LA(7) {}
 #undef A3D_LA
         }
+      } else if (stats) {
+        const bool two = d.D == 2;
+#define A3D_LT(BN_, CH_) \
+  if (d.bn == BN_ && d.ch == CH_) { \
+    if (bw) { if (two) k_conv_deep<BN_, CH_, false, 0, 2, 2><<<d.G, 256, lds, st>>>(a); else k_conv_deep<BN_, CH_, false, 0, 3, 2><<<d.G, 256, lds, st>>>(a); } \
+    else { if (two) k_conv_deep<BN_, CH_, false, 0, 2, 1><<<d.G, 256, lds, st>>>(a); else k_conv_deep<BN_, CH_, false, 0, 3, 1><<<d.G, 256, lds, st>>>(a); } \
+  } else
+        A3D_LT(128, 32) A3D_LT(64, 64) A3D_LT(64, 32) A3D_LT(32, 64) A3D_LT(32, 32)
+        { set_error("spconv: no deep kernel for BN %d CH %d", d.bn, d.ch); return A3D_ERR_UNSUPPORTED; }
+#undef A3D_LT
       } else {
         const bool two = d.D == 2;
 #define A3D_LD(BN_, CH_) \
