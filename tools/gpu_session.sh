@@ -1,7 +1,6 @@
 #!/bin/bash
+# Scratch script of the current GPU session (overwritten per session; `gpurun -- 'bash tools/gpu_session.sh'`).
 R=$GRAFT_REPO_ROOT
 cd $R
-O=gpurun_out/d15
-mkdir -p $O
-timeout 2400 python -m pytest tests -m gpu -q > $O/gpu_tests.log 2>&1; echo "gpu tests rc=$?"
-tail -4 $O/gpu_tests.log
+timeout 5400 bash tools/profile_round.sh r05 > gpurun_out/r05_profile_round.log 2>&1
+ls -la gpurun_out/r05
