@@ -217,6 +217,7 @@ struct QueryBufs {   // all [QP][...] fp32 in global scratch
   unsigned* sync;                                // [A3D_MAX_DEC_LAYERS][16] hand-off flags of k_query_block (zeroed per pass)
 };
 constexpr int kQlMaxHelpers = 8;
+constexpr int kMaxQBlocks = A3D_MAX_QUERIES / 64;
 
 // ---- one batch sample as the query-side kernels see it (k_query_init, k_c2s_combine, k_query_block: blockIdx.y / z)
 struct QuerySample {
@@ -1572,8 +1573,11 @@ __global__ void __launch_bounds__(512) k_query_init(const QuerySample* __restric
   const int Q = max(0, min(QP, meta->nq - q0)), n_fg = meta->n_fg, n_bgl = meta->n_bgl;
   B.queries += (size_t)q0 * D; B.qpos += (size_t)q0 * D; B.qproj += (size_t)q0 * D;
   B.ks += (size_t)q0 * D; B.vs += (size_t)q0 * D; B.E += (size_t)q0 * D;
-  if (blockIdx.x == 0)
+  if (blockIdx.x == 0) {
     for (int e = threadIdx.x; e < n_counts; e += blockDim.x) gst(counts + e, 0);
+    // the hand-off flags of this sample's k_query_block launches (every layer, every query block)
+    for (int e = threadIdx.x; e < A3D_MAX_DEC_LAYERS * kMaxQBlocks * 16; e += blockDim.x) B.sync[e] = 0u;
+  }
   for (int e = threadIdx.x; e < QP * D; e += blockDim.x) {
     const int c = e & 127;
     const int q = q0 + (e >> 7);
@@ -1872,7 +1876,6 @@ __device__ __forceinline__ void qattn_mfma_global(float* o_l, const float* qk, c
 // attention, which needs every block's keys / values: PART 1 = steps 1-2 up to the q / k / v projections (to B.qk, B.vc; tgt
 // to B.tgt), PART 2 = the attention (flash over all blocks' keys, read from global memory) and everything after it.
 // PART 0 = the whole layer (one block).  Grid (helpers + 1, blocks, samples).
-constexpr int kMaxQBlocks = A3D_MAX_QUERIES / 64;
 template <int QT, int PART>
 __global__ void __launch_bounds__(512) k_query_block(const QuerySample* __restrict__ qs, QueryLayerW W) {
   constexpr int QP = QT * 16;
@@ -2324,8 +2327,11 @@ void dec_layout(int64_t n, int nq, DecLayout& L) {
   L.labels = take((size_t)n + 64);
   L.counts = take((size_t)A3D_MAX_DEC_LAYERS * (A3D_MAX_QUERIES + 1) * 4);
   L.part = take((size_t)(L.nchunk > kFusedC2SGrid * 8 ? L.nchunk : kFusedC2SGrid * 8) * H * L.qp * kPartStride * 4);
-  L.meta = take(sizeof(QueryMeta));
-  L.desc = take((sizeof(DecSampleDev) + sizeof(QuerySample)) * kMaxBatchSamples);   // sample tables of a batched call (kept in the first sample's workspace)
+  // everything a call uploads -- the samples' QueryMeta records and the two sample tables, packed back to back for the number
+  // of samples at hand -- lives in the FIRST sample's workspace and travels in ONE host-to-device copy (round 5: a copy per
+  // sample + two table copies + a memset were five 5-us slots of the stream in front of a 0.67 ms decoder pass)
+  L.desc = take((sizeof(QueryMeta) + 16 + sizeof(DecSampleDev) + sizeof(QuerySample)) * kMaxBatchSamples + 64);
+  L.meta = L.desc;
   const size_t qb = (size_t)L.qp * D * 4;
   for (int i = 0; i < 9; ++i) L.q[i] = take(qb);        // queries qpos qproj ks vs E attn tmp tgt
   L.q[9] = take(2 * qb);                                // qk
@@ -2481,8 +2487,13 @@ static int run_decoder(const a3d_decoder_weights* w, Prepared* P, int ns, hipStr
     n_total += p.n;
     Kmax = p.hm.K > Kmax ? p.hm.K : Kmax;
     nq_max = p.hm.nq > nq_max ? p.hm.nq : nq_max;
-    A3D_HIP_CHECK(hipMemcpyAsync(p.meta, &p.hm, sizeof(QueryMeta), hipMemcpyHostToDevice, st));
   }
+  // the upload block in the first sample's workspace: [ns QueryMeta][ns DecSampleDev][ns QuerySample]
+  char* const up_dev = P[0].ws + P[0].L.desc;
+  const size_t up_meta = 0, up_samples = (sizeof(QueryMeta) * ns + 15) & ~(size_t)15;
+  const size_t up_qs = (up_samples + sizeof(DecSampleDev) * ns + 15) & ~(size_t)15;
+  const size_t up_bytes = up_qs + sizeof(QuerySample) * ns;
+  for (int si = 0; si < ns; ++si) P[si].meta = (QueryMeta*)(up_dev + up_meta) + si;
   const size_t s2c_lds = (size_t)2 * QP * 132 * 4;             // keys + values of the queries (k_s2c_attn_wide)
   const size_t qs2c_lds = ((size_t)QP * 132 + (size_t)D * (QP + 4) + D) * 4;   // k_q_s2c: keys, transposed values, bias
   const size_t fused_lds = (size_t)64 * 1024 + ((size_t)3 * D + QP * 132 + 8 * 16 * (QP + 1) + 8 * 16 * (Kmax + 1)) * 4 +
@@ -2518,10 +2529,12 @@ static int run_decoder(const a3d_decoder_weights* w, Prepared* P, int ns, hipStr
   const bool fuse_all = fuse_out && fused_s2c_env && QT <= 2 && s2c_out_lds <= 160 * 1024;
   // ---- sample table: workgroups of the persistent kernels in proportion to the samples' point groups
   int grid = 0;
-  DecSampleDev* samples_dev = (DecSampleDev*)(P[0].ws + P[0].L.desc);
-  QuerySample* qs_dev = (QuerySample*)(samples_dev + kMaxBatchSamples);
+  DecSampleDev* samples_dev = (DecSampleDev*)(up_dev + up_samples);
+  QuerySample* qs_dev = (QuerySample*)(up_dev + up_qs);
   {
-    DecSampleDev hd[kMaxBatchSamples];
+    std::vector<char> up_host(up_bytes);
+    for (int si = 0; si < ns; ++si) memcpy(up_host.data() + up_meta + sizeof(QueryMeta) * si, &P[si].hm, sizeof(QueryMeta));
+    DecSampleDev* hd = (DecSampleDev*)(up_host.data() + up_samples);
     int64_t tot_groups = 0;
     for (int si = 0; si < ns; ++si) tot_groups += (P[si].n + 15) / 16;
     const int max_grid = 256;
@@ -2557,11 +2570,8 @@ static int run_decoder(const a3d_decoder_weights* w, Prepared* P, int ns, hipStr
       d.vs = p.B.vs;
       d.E = p.B.E;
     }
-    // pageable source: the runtime stages it before returning (like the QueryMeta copies above)
-    A3D_HIP_CHECK(hipMemcpyAsync(samples_dev, hd, sizeof(DecSampleDev) * ns, hipMemcpyHostToDevice, st));
-    QuerySample hq[kMaxBatchSamples];
-    unsigned* sync0 = (unsigned*)(P[0].ws + P[0].L.sync);
-    A3D_HIP_CHECK(hipMemsetAsync(sync0, 0, (size_t)ns * A3D_MAX_DEC_LAYERS * kMaxQBlocks * 16 * 4, st));
+    QuerySample* hq = (QuerySample*)(up_host.data() + up_qs);
+    unsigned* sync0 = (unsigned*)(P[0].ws + P[0].L.sync);   // zeroed by k_query_init (a sample's first query block)
     for (int si = 0; si < ns; ++si) {
       Prepared& p = P[si];
       p.B.sync = sync0 + (size_t)si * A3D_MAX_DEC_LAYERS * kMaxQBlocks * 16;
@@ -2574,7 +2584,8 @@ static int run_decoder(const a3d_decoder_weights* w, Prepared* P, int ns, hipStr
       hq[si].n_part = fuse_c2s ? (p.wg_end - p.wg_begin) * c2s_spw : p.L.nchunk;
       hq[si].n_part0 = p.L.nchunk;
     }
-    A3D_HIP_CHECK(hipMemcpyAsync(qs_dev, hq, sizeof(QuerySample) * ns, hipMemcpyHostToDevice, st));
+    // pageable source: the runtime stages it before returning
+    A3D_HIP_CHECK(hipMemcpyAsync(up_dev, up_host.data(), up_bytes, hipMemcpyHostToDevice, st));
   }
   {
     ProfScope ps(st, A3D_PROF_QUERY, 0, 0, 0, 0, nq_max);
