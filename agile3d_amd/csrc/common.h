@@ -39,6 +39,30 @@ struct ProfScope {
   }
 };
 
+// Barrier over all workgroups of a launch whose workgroups are ALL RESIDENT (a few hundred small ones): a monotonic counter
+// (`target` = workgroups x number of this barrier, counted from 1), release fence before the arrival and acquire after the wait
+// (what other XCDs' workgroups wrote before is visible behind it).  The spin is bounded like every wait of this library: a
+// give-up reports A3D_ERR_HIP through `fail` instead of hanging the device.
+#ifdef __HIPCC__
+__device__ inline void grid_barrier_counter(unsigned* bar, unsigned target, int* fail) {
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    unsigned spins = 0;
+    while (__hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+      __builtin_amdgcn_s_sleep(1);
+      if (++spins > (1u << 26)) {
+        if (fail) atomicMin(fail, A3D_ERR_HIP);
+        break;
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  }
+  __syncthreads();
+}
+#endif
+
 static inline int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
 static inline size_t align256(size_t x) { return (x + 255) & ~size_t(255); }
 
@@ -74,8 +98,12 @@ static inline int radix_passes(int bit_begin, int bit_end, RadixPass* out, int n
 size_t radix_sort_temp_bytes(int n_max);
 // stable, ascending in the listed digits; digits that are constant over the input are skipped on the device;
 // keys_in / vals_in are only read, temp must be 256-byte aligned
+// one_launch: a scene-sized input (<= 128 k keys) may run as ONE launch with grid barriers inside.  Its workgroups spin at
+// those barriers, so the caller must make sure that no second barrier kernel of this process can be in flight next to it
+// (a3d_scene_create: only its first phase, which ends in a host synchronisation, and only one call at a time)
 int radix_sort_pairs(void* temp, size_t temp_bytes, const uint64_t* keys_in, uint64_t* keys_out, const int* vals_in,
-                     int* vals_out, int n, const RadixPass* passes, int npass, hipStream_t st, int* fail_dev = nullptr);
+                     int* vals_out, int n, const RadixPass* passes, int npass, hipStream_t st, int* fail_dev = nullptr,
+                     bool one_launch = false);
 
 // a_incl = inclusive prefix sums of a, b_excl = exclusive prefix sums of b (radix.hip; in place allowed)
 size_t scan2_temp_bytes(int64_t n);
@@ -193,7 +221,8 @@ __device__ __forceinline__ size_t grid_cell(const Level& lv, int b, int x, int y
 namespace a3d {
 constexpr int kBBox = 8 + 1024;        // kBBoxSlots x {min x,y,z, max x,y,z, -, -} of the level-0 coordinates (slot = block % slots:
 constexpr int kBBoxSlots = 64;         // thousands of atomics on six addresses would serialise; the host folds the slots)
-constexpr int kSizesInts = kBBox + 8 * kBBoxSlots;  // device-side size/error/batch-start/bounding-box block read back by a3d_scene_create
+constexpr int kSizesBar = kBBox + 8 * kBBoxSlots;   // one word behind the bounding-box slots: the grid-barrier counter of k_heads_all (uploaded as 0)
+constexpr int kSizesInts = kSizesBar + 8;  // device-side size/error/batch-start/bounding-box block read back by a3d_scene_create
 }
 
 struct a3d_scene {

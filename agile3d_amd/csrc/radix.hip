@@ -10,6 +10,7 @@
 // launches, typically 3-7.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "common.h"
 
@@ -102,44 +103,47 @@ __global__ void __launch_bounds__(256) k_rs_plan(const RsArgs a) {
   }
 }
 
-// one digit: 4096 keys per workgroup, stable
-__global__ void __launch_bounds__(kRsThreads) k_rs_pass(const RsArgs a, int p) {
-  if (a.plan->skip[p]) return;
-  __shared__ uint64_t skeys[kRsBlockKeys];
-  __shared__ int svals[kRsBlockKeys];
+// one digit of one 4096-key block, stable: block b of pass p from buffer s to buffer t (0 = the caller's input, 1 = the
+// caller's output, 2 = the temporary pair); gstart = the exclusive digit starts of the pass.  b < 0: the block number is a
+// ticket drawn here (k_rs_pass: workgroups before this one in key order are then already running).
+template <int KPT>   // keys per thread: 16 in the launch chain, 4 in the one-launch sort (four times the workgroups, a quarter of the chain each)
+__device__ __forceinline__ void rs_block(const RsArgs& a, int p, int b_in, int s, int t, const uint32_t* gstart) {
+  constexpr int kBlockKeys = kRsThreads * KPT;
+  __shared__ uint64_t skeys[kBlockKeys];
+  __shared__ int svals[kBlockKeys];
   __shared__ uint32_t whist[4][256];   // per-wave digit counts, then per-wave exclusive offsets
   __shared__ int lstart[256];          // first slot of a digit in the workgroup's sorted order
   __shared__ int gpos[256];            // global position of slot 0 of a digit, minus lstart
   __shared__ int misc[8];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int shift = a.shift[p], bits = a.bits[p], shift2 = a.shift2[p], bits2 = a.bits2[p];
-  const int s = a.plan->src[p], t = a.plan->dst[p];
   const uint64_t* kin = s == 0 ? a.keys_in : (s == 1 ? a.keys_out : a.keys_tmp);
   const int* vin = s == 0 ? a.vals_in : (s == 1 ? a.vals_out : a.vals_tmp);
   uint64_t* kout = t == 1 ? a.keys_out : a.keys_tmp;
   int* vout = t == 1 ? a.vals_out : a.vals_tmp;
 
-  if (tid == 0) misc[0] = atomicAdd(&a.tickets[p], 1);   // workgroups before this one in key order are already running
+  __syncthreads();   // (a workgroup that walks several blocks: the previous block's LDS reads are over)
+  if (tid == 0) misc[0] = b_in >= 0 ? b_in : atomicAdd(&a.tickets[p], 1);
   for (int i = tid; i < 4 * 256; i += kRsThreads) (&whist[0][0])[i] = 0;
   __syncthreads();
   const int b = misc[0];
-  const int base = b * kRsBlockKeys;
-  const int cnt = min(kRsBlockKeys, a.n - base);
+  const int base = b * kBlockKeys;
+  const int cnt = min(kBlockKeys, a.n - base);
 
   // ---- rank every key among the keys of its wave with the same digit (rows of 64 in index order)
-  uint64_t key[kRsKeysPerThread];
-  int val[kRsKeysPerThread], rank[kRsKeysPerThread];
+  uint64_t key[KPT];
+  int val[KPT], rank[KPT];
   const unsigned long long lt = (1ull << lane) - 1ull;
 #pragma unroll
-  for (int r = 0; r < kRsKeysPerThread; ++r) {
-    const int li = w * (kRsBlockKeys / 4) + r * 64 + lane;
+  for (int r = 0; r < KPT; ++r) {
+    const int li = w * (kBlockKeys / 4) + r * 64 + lane;
     const bool ok = li < cnt;
     key[r] = ok ? kin[base + li] : ~0ull;
     val[r] = ok ? vin[base + li] : 0;
   }
 #pragma unroll
-  for (int r = 0; r < kRsKeysPerThread; ++r) {
-    const int li = w * (kRsBlockKeys / 4) + r * 64 + lane;
+  for (int r = 0; r < KPT; ++r) {
+    const int li = w * (kBlockKeys / 4) + r * 64 + lane;
     const bool ok = li < cnt;
     const int d = rs_digit(key[r], shift, bits, shift2, bits2);
     unsigned long long peers = __ballot(ok);
@@ -190,16 +194,17 @@ __global__ void __launch_bounds__(kRsThreads) k_rs_pass(const RsArgs a, int p) {
     // look back, kLook workgroups at a time (their loads are in flight together; only a word not yet published is
     // polled): a workgroup meets mostly AGGREGATE words -- all workgroups of a pass run at once
     uint32_t excl = 0;
-    for (int pb = b - 1; pb >= 0; pb -= kLook) {
-      uint32_t x[kLook];
+    constexpr int kLookN = KPT <= 4 ? 2 * kLook : kLook;   // the one-launch sort has four times the blocks to look back over
+    for (int pb = b - 1; pb >= 0; pb -= kLookN) {
+      uint32_t x[kLookN];
 #pragma unroll
-      for (int u = 0; u < kLook; ++u)
+      for (int u = 0; u < kLookN; ++u)
         x[u] = pb - u >= 0 ? __hip_atomic_load(a.status + ((size_t)p * a.nblocks + (pb - u)) * 256 + d, __ATOMIC_RELAXED,
                                                __HIP_MEMORY_SCOPE_AGENT)
                            : kFlagInc;
       bool done = false;
 #pragma unroll
-      for (int u = 0; u < kLook; ++u) {
+      for (int u = 0; u < kLookN; ++u) {
         if (done) break;
         unsigned spins = 0;
         while ((x[u] & (kFlagAgg | kFlagInc)) == 0u) {
@@ -217,14 +222,14 @@ __global__ void __launch_bounds__(kRsThreads) k_rs_pass(const RsArgs a, int p) {
       if (done) break;
     }
     if (b > 0) __hip_atomic_store(st, (excl + tot) | kFlagInc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    gpos[d] = (int)(a.ghist[p * 256 + d] + excl) - ls;
+    gpos[d] = (int)(gstart[d] + excl) - ls;
   }
   __syncthreads();
 
   // ---- into sorted order inside the workgroup (LDS), then out in runs
 #pragma unroll
-  for (int r = 0; r < kRsKeysPerThread; ++r) {
-    const int li = w * (kRsBlockKeys / 4) + r * 64 + lane;
+  for (int r = 0; r < KPT; ++r) {
+    const int li = w * (kBlockKeys / 4) + r * 64 + lane;
     if (li < cnt) {
       const int d = rs_digit(key[r], shift, bits, shift2, bits2);
       const int slot = lstart[d] + (int)whist[w][d] + rank[r];
@@ -234,7 +239,7 @@ __global__ void __launch_bounds__(kRsThreads) k_rs_pass(const RsArgs a, int p) {
   }
   __syncthreads();
 #pragma unroll
-  for (int r = 0; r < kRsKeysPerThread; ++r) {
+  for (int r = 0; r < KPT; ++r) {
     const int slot = r * kRsThreads + tid;
     if (slot < cnt) {
       const uint64_t k = skeys[slot];
@@ -245,24 +250,111 @@ __global__ void __launch_bounds__(kRsThreads) k_rs_pass(const RsArgs a, int p) {
   }
 }
 
+__global__ void __launch_bounds__(kRsThreads) k_rs_pass(const RsArgs a, int p) {
+  if (a.plan->skip[p]) return;
+  rs_block<kRsKeysPerThread>(a, p, -1, a.plan->src[p], a.plan->dst[p], a.ghist + p * 256);
+}
+
+// ---- the whole sort in ONE launch (small inputs: <= kRsOneLaunchBlocks blocks of 1024 keys, i.e. a scene or a small batch, where the
+// 3-11 launches of the chain above ARE the sort's time: 93 us for 80 k keys, five of its eight digit launches exiting at
+// once).  One workgroup per block, all resident: histogram sweep -> grid barrier -> every workgroup derives the plan (which
+// digits are trivial, the buffers' ping-pong, a digit's exclusive starts) from the global histogram by itself -> per
+// non-trivial digit the block pass above and a grid barrier.  The barrier is a monotonic counter (release fence before the
+// arrival, acquire after the wait: a pass reads what workgroups of other XCDs wrote); its spin is bounded like the
+// look-back's.  Large inputs keep the launch chain (their workgroups would not all be resident next to other streams' work),
+// and so does every sort whose caller cannot rule out a second barrier kernel of the process in flight (the `one_launch` argument).
+constexpr int kRsSmallKpt = 4;               // 1024 keys per workgroup
+constexpr int kRsOneLaunchBlocks = 128;      // <= 131 072 keys: one scene.  (A 4-scene batch -- 313 blocks -- measured 2 % SLOWER with
+                                             // four steps in flight: 313 workgroups spinning at barriers next to the other streams' kernels)
+__global__ void __launch_bounds__(kRsThreads) k_rs_sort(const RsArgs a, unsigned* bar) {
+  __shared__ uint32_t h[kRadixMaxPasses * 256];   // this workgroup's histograms, then the current digit's exclusive starts
+  __shared__ int plan_l[3 * kRadixMaxPasses + 4];
+  __shared__ int scan_l[8];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const unsigned G = gridDim.x;
+  for (int i = tid; i < a.npass * 256; i += kRsThreads) h[i] = 0;
+  __syncthreads();
+  for (int i = blockIdx.x * kRsThreads + tid; i < a.n; i += gridDim.x * kRsThreads) {
+    const uint64_t k = a.keys_in[i];
+    for (int p = 0; p < a.npass; ++p) atomicAdd(&h[p * 256 + rs_digit(k, a.shift[p], a.bits[p], a.shift2[p], a.bits2[p])], 1u);
+  }
+  __syncthreads();
+  for (int i = tid; i < a.npass * 256; i += kRsThreads)
+    if (h[i]) atomicAdd(&a.ghist[i], h[i]);
+  unsigned epoch = 1;
+  grid_barrier_counter(bar, G * epoch++, a.fail);
+  // ---- the plan, by every workgroup for itself (as k_rs_plan)
+  for (int i = tid; i < a.npass * 256; i += kRsThreads)
+    h[i] = __hip_atomic_load(a.ghist + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (tid < kRadixMaxPasses) plan_l[tid] = 0;
+  __syncthreads();
+  for (int i = tid; i < a.npass * 256; i += kRsThreads)
+    if (h[i] == (uint32_t)a.n) plan_l[i >> 8] = 1;   // one digit value holds every key: trivial
+  __syncthreads();
+  if (tid == 0) {
+    int m = 0;
+    for (int p = 0; p < a.npass; ++p) m += plan_l[p] ? 0 : 1;
+    if (m == 0) plan_l[0] = 0, m = 1;
+    int j = 0, cur = 0;
+    for (int p = 0; p < a.npass; ++p) {
+      if (plan_l[p]) continue;
+      ++j;
+      const int dst = ((m - j) & 1) ? 2 : 1;
+      plan_l[kRadixMaxPasses + p] = cur;
+      plan_l[2 * kRadixMaxPasses + p] = dst;
+      cur = dst;
+    }
+  }
+  __syncthreads();
+  for (int p = 0; p < a.npass; ++p) {
+    if (plan_l[p]) continue;   // uniform over the grid
+    {   // exclusive scan of the digit's 256 counts, in place
+      const uint32_t c = h[p * 256 + tid];
+      int v = (int)c;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const int x = __shfl_up(v, o, 64);
+        if (lane >= o) v += x;
+      }
+      if (lane == 63) scan_l[w] = v;
+      __syncthreads();
+      int base = 0;
+      for (int q = 0; q < w; ++q) base += scan_l[q];
+      h[p * 256 + tid] = (uint32_t)(base + v - (int)c);
+      __syncthreads();
+    }
+    for (int b = blockIdx.x; b < a.nblocks; b += gridDim.x)
+      rs_block<kRsSmallKpt>(a, p, b, plan_l[kRadixMaxPasses + p], plan_l[2 * kRadixMaxPasses + p], h + p * 256);
+    grid_barrier_counter(bar, G * epoch++, a.fail);
+  }
+}
+
 inline int rs_blocks(int n) { return (n + kRsBlockKeys - 1) / kRsBlockKeys; }
+inline int rs_blocks_small(int n) { return (n + kRsThreads * kRsSmallKpt - 1) / (kRsThreads * kRsSmallKpt); }
+// status words enough for every n <= n_max (a temporary sized once serves smaller sorts too): the chain's blocks at n_max, or
+// the one-launch sort's (four times as many at the same n, but never more than kRsOneLaunchBlocks)
+inline size_t rs_status_blocks(int n_max) {
+  const size_t big = (size_t)rs_blocks(n_max), small = (size_t)rs_blocks_small(n_max);
+  const size_t cap = small < (size_t)kRsOneLaunchBlocks ? small : (size_t)kRsOneLaunchBlocks;
+  return big > cap ? big : cap;
+}
 
 }  // namespace
 
 size_t radix_sort_temp_bytes(int n_max) {
-  const size_t nb = (size_t)rs_blocks(n_max > 0 ? n_max : 1);
+  const size_t nb = rs_status_blocks(n_max > 0 ? n_max : 1);
   size_t b = 0;
   b += align256((size_t)n_max * sizeof(uint64_t));                        // keys_tmp
   b += align256((size_t)n_max * sizeof(int));                             // vals_tmp
   b += align256((size_t)kRadixMaxPasses * 256 * sizeof(uint32_t));        // ghist      } zeroed per sort,
-  b += align256((size_t)kRadixMaxPasses * sizeof(int));                   // tickets    } one memset
+  b += align256((size_t)kRadixMaxPasses * sizeof(int) + 64);              // tickets, grid-barrier counter   } one memset
   b += align256((size_t)kRadixMaxPasses * nb * 256 * sizeof(uint32_t));   // status     }
   b += align256(sizeof(RsPlanDev));
   return b + 256;
 }
 
 int radix_sort_pairs(void* temp, size_t temp_bytes, const uint64_t* keys_in, uint64_t* keys_out, const int* vals_in,
-                     int* vals_out, int n, const RadixPass* passes, int npass, hipStream_t st, int* fail_dev) {
+                     int* vals_out, int n, const RadixPass* passes, int npass, hipStream_t st, int* fail_dev, bool allow_one_launch) {
   if (n <= 0) return A3D_OK;
   if (npass < 1 || npass > kRadixMaxPasses || !temp || ((uintptr_t)temp & 255) || temp_bytes < radix_sort_temp_bytes(n)) {
     set_error("radix_sort_pairs: bad arguments (n=%d, passes=%d, temp=%zu)", n, npass, temp_bytes);
@@ -298,12 +390,25 @@ int radix_sort_pairs(void* temp, size_t temp_bytes, const uint64_t* keys_in, uin
   a.ghist = (uint32_t*)c;
   c += align256((size_t)kRadixMaxPasses * 256 * sizeof(uint32_t));
   a.tickets = (int*)c;
-  c += align256((size_t)kRadixMaxPasses * sizeof(int));
+  unsigned* bar = (unsigned*)(a.tickets + kRadixMaxPasses);   // 64 bytes behind the tickets
+  c += align256((size_t)kRadixMaxPasses * sizeof(int) + 64);
+  static int one_launch = -1;
+  if (one_launch < 0) {
+    const char* e = getenv("A3D_SORT_ONE_LAUNCH");   // 0: the launch chain for every size (A/B, tests)
+    one_launch = e ? atoi(e) : 1;
+  }
+  const bool small = allow_one_launch && one_launch && rs_blocks_small(n) <= kRsOneLaunchBlocks;
+  if (small) a.nblocks = rs_blocks_small(n);
   a.status = (uint32_t*)c;
   c += align256((size_t)npass * a.nblocks * 256 * sizeof(uint32_t));
   char* zero_end = c;
   a.plan = (RsPlanDev*)c;
   A3D_HIP_CHECK(hipMemsetAsync(zero_begin, 0, (size_t)(zero_end - zero_begin), st));
+  if (small) {
+    k_rs_sort<<<a.nblocks, kRsThreads, 0, st>>>(a, bar);
+    A3D_LAUNCH_CHECK();
+    return A3D_OK;
+  }
   int hb = (n + kRsThreads * 8 - 1) / (kRsThreads * 8);
   if (hb > 512) hb = 512;
   k_rs_hist<<<hb, kRsThreads, 0, st>>>(a);
@@ -430,6 +535,7 @@ extern "C" int a3d_sort_pairs_u64(const uint64_t* keys_in_dev, const int32_t* va
   }
   RadixPass ps[kRadixMaxPasses];
   const int np = radix_passes(bit_begin, bit_end, ps);
+  // (a stand-alone sort: the one-launch form for scene-sized inputs, like the first sort of a scene build)
   return radix_sort_pairs(workspace_dev, workspace_bytes, keys_in_dev, keys_out_dev, vals_in_dev, vals_out_dev, (int)n, ps, np,
-                          (hipStream_t)stream);
+                          (hipStream_t)stream, nullptr, true);
 }

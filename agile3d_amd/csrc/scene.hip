@@ -15,6 +15,7 @@
 //   * kernel maps are output-major neighbour tables int32[K][npad] (k-major: the 128 rows of a
 //     workgroup tile are contiguous for every offset) with "missing" = the all-zero row n.
 #include "common.h"
+#include <atomic>
 #include <algorithm>
 #include <limits.h>
 #include <stdarg.h>
@@ -23,6 +24,7 @@
 namespace a3d {
 
 static thread_local char g_err[512] = "";
+static std::atomic<int> g_phase1_calls{0};   // a3d_scene_create calls between their first launch and their host synchronisation
 void set_error(const char* fmt, ...) {
   va_list ap;
   va_start(ap, fmt);
@@ -216,6 +218,51 @@ __global__ void __launch_bounds__(1024) k_heads_write(const uint64_t* __restrict
       out.firstM[L - 1][rank[L]] = rank[L - 1];   // a voxel that heads a level-L run heads its level-(L-1) run too
     }
     // voxel i is a row of level L-1 iff it heads its level-(L-1) run (every voxel is a row of level 0)
+    if (L == 1 || f[L - 2]) out.parentM[L - 1][rank[L - 1]] = rank[L];
+  }
+}
+
+// the three passes above in ONE launch for a scene-sized input (every workgroup resident: nb <= kHeadsOneLaunch): counts ->
+// grid barrier -> every workgroup adds up the block sums in front of it (and the last one writes the level sizes) -> keys and
+// parent maps.  The flags and in-block scans of the first pass stay in registers.
+constexpr int kHeadsOneLaunch = 128;
+__global__ void __launch_bounds__(1024) k_heads_all(const uint64_t* __restrict__ keys, int n, int nb, int* blocksums,
+                                                    int* sizes_dev, CoarseOut out) {
+  __shared__ int lds[17];
+  __shared__ int offs[A3D_NUM_LEVELS - 1];
+  const int i = blockIdx.x * 1024 + threadIdx.x;
+  int f[A3D_NUM_LEVELS - 1], sc[A3D_NUM_LEVELS - 1], tot[A3D_NUM_LEVELS - 1];
+  if (head_flags(keys, n, i, f)) atomicMin(&sizes_dev[5], A3D_ERR_DUPLICATE);
+#pragma unroll
+  for (int L = 0; L < A3D_NUM_LEVELS - 1; ++L) {
+    sc[L] = block_incl_scan(f[L], lds, &tot[L]);
+    if (threadIdx.x == 0) __hip_atomic_store(blocksums + L * nb + blockIdx.x, tot[L], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  grid_barrier_counter((unsigned*)(sizes_dev + kSizesBar), gridDim.x, sizes_dev + 5);
+#pragma unroll
+  for (int L = 0; L < A3D_NUM_LEVELS - 1; ++L) {   // nb <= 1024: one value per thread
+    const int v = (int)threadIdx.x < (int)blockIdx.x
+                      ? __hip_atomic_load(blocksums + L * nb + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+    int before;
+    block_incl_scan(v, lds, &before);
+    if (threadIdx.x == 0) {
+      offs[L] = before;
+      if (blockIdx.x == gridDim.x - 1) sizes_dev[1 + L] = before + tot[L];
+    }
+  }
+  __syncthreads();
+  if (i >= n) return;
+  int rank[A3D_NUM_LEVELS];
+  rank[0] = i;
+#pragma unroll
+  for (int L = 0; L < A3D_NUM_LEVELS - 1; ++L) rank[L + 1] = offs[L] + sc[L] - 1;
+  const uint64_t k = keys[i];
+#pragma unroll
+  for (int L = 1; L < A3D_NUM_LEVELS; ++L) {
+    if (f[L - 1]) {
+      out.keys[L - 1][rank[L]] = k >> (3 * L);
+      out.firstM[L - 1][rank[L]] = rank[L - 1];
+    }
     if (L == 1 || f[L - 2]) out.parentM[L - 1][rank[L - 1]] = rank[L];
   }
 }
@@ -705,10 +752,19 @@ extern "C" int a3d_scene_create(const int32_t* coords4_dev, int64_t n_voxels, vo
   const int T = 256;
   auto nblk = [](int64_t n, int t) { return (unsigned)((n + t - 1) / t); };
 
+  // The two barrier kernels of phase 1 (the one-launch sort, k_heads_all) spin at grid barriers: all their workgroups must get
+  // onto the chip, which two of them waiting side by side could deny each other.  Phase 1 ends in a host synchronisation, so
+  // a process-wide count of the calls between here and there is exact: only a call that finds itself ALONE uses them, a
+  // concurrent one (another host thread, another stream) takes the launch chains.
+  struct SoloPhase1 {
+    bool alone;
+    SoloPhase1() : alone(g_phase1_calls.fetch_add(1, std::memory_order_acq_rel) == 0) {}
+    ~SoloPhase1() { g_phase1_calls.fetch_sub(1, std::memory_order_acq_rel); }
+  } solo;
   // ---- phase 1: keys, sort, levels (all sized by the n0 bound; real sizes stay on the device)
   int prof1 = prof_enabled() ? prof_begin(st, A3D_PROF_SCENE_SORT, 0, 0, 0, 0, n0) : -1;
   int sizes[kSizesInts];
-  for (int i = 0; i < kSizesInts; ++i) sizes[i] = i < 8 ? 0 : -1;
+  for (int i = 0; i < kSizesInts; ++i) sizes[i] = i < 8 || i >= kSizesBar ? 0 : -1;
   for (int sl = 0; sl < kBBoxSlots; ++sl)
     for (int a = 0; a < 3; ++a) sizes[kBBox + 8 * sl + a] = INT_MAX, sizes[kBBox + 8 * sl + 3 + a] = INT_MIN;
   sizes[0] = n0;
@@ -719,7 +775,8 @@ extern "C" int a3d_scene_create(const int32_t* coords4_dev, int64_t n_voxels, vo
     RadixPass ps[kRadixMaxPasses];
     const int np = radix_passes(0, 64, ps);
     int rc = radix_sort_pairs(p.sort_temp, p.sort_temp_bytes, p.keys_in, p.keys[0], p.vals_in, p.vals_sorted, n0, ps, np, st,
-                              p.sizes_dev + 5);   // a look-back that gives up reports A3D_ERR_HIP through the error word read below
+                              p.sizes_dev + 5,   // a look-back that gives up reports A3D_ERR_HIP through the error word read below
+                              solo.alone);
     if (rc) return rc;
   }
   const int nb = (n0 + 1023) / 1024;
@@ -730,9 +787,13 @@ extern "C" int a3d_scene_create(const int32_t* coords4_dev, int64_t n_voxels, vo
       co.parentM[L] = p.parentM[L];
       co.firstM[L] = p.firstM[L];
     }
-    k_heads_count<<<nb, 1024, 0, st>>>(p.keys[0], n0, nb, p.blocksums, p.sizes_dev);
-    k_heads_scan<<<A3D_NUM_LEVELS - 1, 1024, 0, st>>>(p.blocksums, nb, p.sizes_dev);
-    k_heads_write<<<nb, 1024, 0, st>>>(p.keys[0], n0, nb, p.blocksums, co);
+    if (nb <= kHeadsOneLaunch && solo.alone) {
+      k_heads_all<<<nb, 1024, 0, st>>>(p.keys[0], n0, nb, p.blocksums, p.sizes_dev, co);
+    } else {
+      k_heads_count<<<nb, 1024, 0, st>>>(p.keys[0], n0, nb, p.blocksums, p.sizes_dev);
+      k_heads_scan<<<A3D_NUM_LEVELS - 1, 1024, 0, st>>>(p.blocksums, nb, p.sizes_dev);
+      k_heads_write<<<nb, 1024, 0, st>>>(p.keys[0], n0, nb, p.blocksums, co);
+    }
     A3D_LAUNCH_CHECK();
   }
   if (prof1 >= 0) prof_end(st, prof1);

@@ -179,7 +179,7 @@ def _sort_pairs(keys, vals, b0, b1):
     return ko, vo
 
 
-@pytest.mark.parametrize("n", [1, 2, 63, 64, 65, 4095, 4096, 4097, 8193, 100_003, 1_300_000])
+@pytest.mark.parametrize("n", [1, 2, 63, 64, 65, 4095, 4096, 4097, 8193, 100_003, 131_072, 131_073, 393_217, 1_300_000])   # <= 128 blocks of 1024 keys: the one-launch sort; above: the launch chain
 @pytest.mark.parametrize("kind", ["random63", "few_bits", "constant", "descending", "morton_like"])
 def test_radix_sort_pairs_is_a_stable_sort(n, kind):
     """csrc/radix.hip against torch.sort(stable=True): every workgroup-boundary size, keys with constant digits (skipped

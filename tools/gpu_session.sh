@@ -1,10 +1,17 @@
 #!/bin/bash
 R=$GRAFT_REPO_ROOT
 cd $R
-O=gpurun_out/d16
+O=gpurun_out/d20
 mkdir -p $O
 timeout 2400 python -m pytest tests -m gpu -q -x > $O/gpu_tests.log 2>&1; echo "gpu tests rc=$?"
 tail -4 $O/gpu_tests.log
 python tools/latency_one_scene.py --deep 1
+A3D_SORT_ONE_LAUNCH=0 python tools/latency_one_scene.py --deep 1
 python tools/latency_one_scene.py --deep 1
-timeout 600 python bench.py --no-cpu-baseline --no-train 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('value', round(d['value'],1), 'lat', d['latency_ms_per_scene'], 'dec_single', d.get('decoder_pass_ms_single'), 'eval_round', d.get('eval_round_ms'), 'eval_rounds_per_s', d.get('eval_rounds_per_s'), 'b4', d.get('value_batch4'))"
+A3D_SORT_ONE_LAUNCH=0 python tools/latency_one_scene.py --deep 1
+for m in 1 0 1 0; do
+A3D_SORT_ONE_LAUNCH=$m timeout 300 python bench.py --batch 4 --steps-only --no-profile --reps 7 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('batch4 x4 streams one_launch=$m', round(d['value'],1))"
+done
+for m in 1 0; do
+A3D_SORT_ONE_LAUNCH=$m timeout 300 python bench.py --batch 1 --steps-only --no-profile --reps 7 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('batch1 x4 streams one_launch=$m', round(d['value'],1))"
+done
