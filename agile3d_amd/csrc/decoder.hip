@@ -264,15 +264,15 @@ template <int QT>
 __global__ void __launch_bounds__(512) k_c2s_attn(const float* __restrict__ Kc, const float* __restrict__ V,
                                                   int n, const float* qproj, const int* qobj,
                                                   const unsigned char* labels, const int* counts,
-                                                  float* part, int qp_total, int chunk) {
+                                                  float* part, int qp_total) {
   const int lane = threadIdx.x & 63;
   const int qb0 = blockIdx.y * (QT * 16);   // first query of this launch's query block
   qproj += (size_t)qb0 * D;
   qobj += qb0;
   const int h = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int g = lane >> 4, j = lane & 15;
-  const int pbeg = blockIdx.x * chunk;
-  const int pend = min(n, pbeg + chunk);
+  const int pbeg = blockIdx.x * kC2SChunk;
+  const int pend = min(n, pbeg + kC2SChunk);
 
   f32x4 qf[QT];
   int obj[QT];
@@ -2311,7 +2311,7 @@ static int check_packs(const a3d_decoder_weights* w) {
 namespace {
 struct DecLayout {
   size_t buf[4], labels, counts, part, meta, desc, q[12], sync, total;
-  int qp, nchunk, chunk;
+  int qp, nchunk;
 };
 int round_qp(int nq) { return nq <= 16 ? 16 : nq <= 32 ? 32 : nq <= 48 ? 48 : (nq + 63) / 64 * 64; }
 void dec_layout(int64_t n, int nq, DecLayout& L) {
@@ -2322,11 +2322,7 @@ void dec_layout(int64_t n, int nq, DecLayout& L) {
     return o;
   };
   L.qp = round_qp(nq);
-  // points per click-to-scene workgroup of the UNFUSED path = one flash partial per (query, head): 128, or 512 with more than
-  // 64 queries -- several query blocks give the launch its workgroups anyway, and k_c2s_combine reads a quarter of the partials
-  // (80 k points, 160 queries: 625 x 18 floats per (query, head) -> 157; 32 -> 12 us per call, 113 calls per training iteration)
-  L.chunk = nq > 64 ? 4 * kC2SChunk : kC2SChunk;
-  L.nchunk = (int)((n + L.chunk - 1) / L.chunk);
+  L.nchunk = (int)((n + kC2SChunk - 1) / kC2SChunk);
   for (int i = 0; i < 4; ++i) L.buf[i] = take((size_t)n * D * 4);
   L.labels = take((size_t)n + 64);
   L.counts = take((size_t)A3D_MAX_DEC_LAYERS * (A3D_MAX_QUERIES + 1) * 4);
@@ -2617,7 +2613,7 @@ static int run_decoder(const a3d_decoder_weights* w, Prepared* P, int ns, hipStr
           if (rc) return rc;
         }
         ProfScope ps(st, A3D_PROF_C2S, 0, 0, 0, 0, p.n);
-        k_c2s_attn<QT><<<dim3(p.L.nchunk, nblk), 512, 0, st>>>(K0, V0, p.n, p.B.qproj, p.meta->obj, nullptr, nullptr, p.part, p.L.qp, p.L.chunk);
+        k_c2s_attn<QT><<<dim3(p.L.nchunk, nblk), 512, 0, st>>>(K0, V0, p.n, p.B.qproj, p.meta->obj, nullptr, nullptr, p.part, p.L.qp);
         A3D_LAUNCH_CHECK();
       }
     } else if (fuse_c2s) {
@@ -2639,7 +2635,7 @@ static int run_decoder(const a3d_decoder_weights* w, Prepared* P, int ns, hipStr
         if (rc) return rc;
         ProfScope ps(st, A3D_PROF_C2S, 0, 0, 0, 0, p.n);
         k_c2s_attn<QT><<<dim3(p.L.nchunk, nblk), 512, 0, st>>>(p.bufA, p.bufB, p.n, p.B.qproj, p.meta->obj,
-                                                              l > 0 ? p.labels : nullptr, prev_counts, p.part, p.L.qp, p.L.chunk);
+                                                              l > 0 ? p.labels : nullptr, prev_counts, p.part, p.L.qp);
         A3D_LAUNCH_CHECK();
       }
     }
