@@ -78,12 +78,18 @@ typedef struct a3d_scene a3d_scene;
 /* Stable ascending sort of (uint64 key, int32 value) pairs by the key bits [bit_begin, bit_end): the LSD radix sort the
  * scene build uses for its three sorts (csrc/radix.hip; replaces the sorts MinkowskiEngine's coordinate manager runs
  * inside `ME.SparseTensor(...)` / `MinkowskiConvolution` kernel-map construction, reference models/agile3d.py:163-170).
- * Exposed for the tests.  keys_in / vals_in are only read. */
+ * Exposed for the tests (a stand-alone call: up to 128 k pairs as ONE launch with grid barriers, so not next to another
+ * barrier kernel of the process).  keys_in / vals_in are only read. */
 size_t  a3d_sort_pairs_workspace_bytes(int64_t n);
 int     a3d_sort_pairs_u64(const uint64_t* keys_in_dev, const int32_t* vals_in_dev, int64_t n, int bit_begin, int bit_end,
                            uint64_t* keys_out_dev, int32_t* vals_out_dev, void* workspace_dev, size_t workspace_bytes,
                            void* stream);
 
+/* a3d_scene_create synchronises `stream` once (the level sizes come back to the host).  It may be called from several host
+ * threads / on several streams at once: a scene-sized input (<= 128 k voxels) runs its first sort and the level compaction as
+ * ONE launch each with grid barriers inside, but only when no other call of the process is between its first launch and that
+ * synchronisation (a process-wide counter); every other case uses launch chains whose workgroups wait only for workgroups
+ * that already run.  A3D_SORT_ONE_LAUNCH=0 keeps the chains everywhere. */
 size_t  a3d_scene_workspace_bytes(int64_t n_voxels);
 int     a3d_scene_create(const int32_t* coords4_dev, int64_t n_voxels,
                          void* workspace_dev, size_t workspace_bytes,
