@@ -419,6 +419,62 @@ extern "C" int a3d_group_max(const float* lq_dev, int64_t N, int Q, const int32_
   A3D_LAUNCH_CHECK();
   return A3D_OK;
 }
+// ---- the attention mask of the NEXT decoder layer from this layer's mask logits (agile3d.py:362-383; not differentiated)
+// label[n] = first arg-max over the 1 + K mask logits of point n; count[g] = points labelled g;
+// mask[q][n] = label[n] != group(q) && count[group(q)] > 0   ("all points blocked -> nothing blocked", agile3d.py:369,375, is
+// "no point carries the group's label").  Two kernels instead of the tape's eight torch launches per sample and layer.
+__global__ void __launch_bounds__(256) k_tr_labels(const float* __restrict__ logits, int N, int G, unsigned char* __restrict__ labels,
+                                                   int* __restrict__ counts) {
+  __shared__ int h[256];
+  h[threadIdx.x] = 0;
+  __syncthreads();
+  const int n = blockIdx.x * 256 + threadIdx.x;
+  if (n < N) {
+    const float* r = logits + (size_t)n * G;
+    float best = r[0];
+    int arg = 0;
+    for (int g = 1; g < G; ++g) {
+      const float v = r[g];
+      if (v > best) best = v, arg = g;
+    }
+    labels[n] = (unsigned char)arg;
+    atomicAdd(&h[arg], 1);
+  }
+  __syncthreads();
+  if ((int)threadIdx.x < G && h[threadIdx.x]) atomicAdd(&counts[threadIdx.x], h[threadIdx.x]);
+}
+__global__ void __launch_bounds__(256) k_tr_next_mask(const unsigned char* __restrict__ labels, const int* __restrict__ counts, int N,
+                                                      const int32_t* __restrict__ gq, int Q, unsigned char* __restrict__ mask) {
+  __shared__ int grp[A3D_MAX_QUERIES];   // the group a query blocks other labels for, or -1 when its group owns no point
+  for (int q = threadIdx.x; q < Q; q += 256) {
+    const int g = gq[q];
+    grp[q] = counts[g] > 0 ? g : -1;
+  }
+  __syncthreads();
+  const int n = blockIdx.x * 256 + threadIdx.x;
+  if (n >= N) return;
+  const int lab = labels[n];
+  for (int q = 0; q < Q; ++q) mask[(size_t)q * N + n] = (unsigned char)(grp[q] >= 0 && lab != grp[q]);
+}
+extern "C" size_t a3d_next_layer_mask_workspace_bytes(int64_t N, int G) {
+  return N > 0 && G > 0 && G <= 256 ? (size_t)1024 + (size_t)((N + 255) / 256 * 256) : 0;
+}
+extern "C" int a3d_next_layer_mask(const float* logits_dev, int64_t N, int G, const int32_t* group_of_query_dev, int Q,
+                                   unsigned char* mask_dev, void* workspace_dev, size_t workspace_bytes, void* stream) {
+  if (!logits_dev || !group_of_query_dev || !mask_dev || !workspace_dev || N <= 0 || N >= (int64_t)1 << 31 || G <= 0 || G > 256 ||
+      Q <= 0 || Q > A3D_MAX_QUERIES || workspace_bytes < a3d_next_layer_mask_workspace_bytes(N, G)) {
+    set_error("a3d_next_layer_mask: bad arguments (N=%lld G=%d Q=%d)", (long long)N, G, Q);
+    return A3D_ERR_INVALID;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  int* counts = (int*)workspace_dev;
+  unsigned char* labels = (unsigned char*)workspace_dev + 1024;
+  A3D_HIP_CHECK(hipMemsetAsync(counts, 0, 1024, st));
+  k_tr_labels<<<blocks_of((size_t)N, 256), 256, 0, st>>>(logits_dev, (int)N, G, labels, counts);
+  k_tr_next_mask<<<blocks_of((size_t)N, 256), 256, 0, st>>>(labels, counts, (int)N, group_of_query_dev, Q, mask_dev);
+  A3D_LAUNCH_CHECK();
+  return A3D_OK;
+}
 extern "C" int a3d_group_max_backward(const float* dout_dev, const int32_t* arg_dev, int64_t N, int Q, int G, float* dlq_dev,
                                       void* stream) {
   if (!dout_dev || !arg_dev || !dlq_dev || N <= 0 || Q <= 0 || G <= 0) {

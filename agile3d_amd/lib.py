@@ -173,6 +173,8 @@ SYMBOLS = {
                                  C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "a3d_group_max": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
                                 C.c_void_p]),
+    "a3d_next_layer_mask_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int]),
+    "a3d_next_layer_mask": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "a3d_group_max_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "a3d_flash_c2s_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int64]),
     "a3d_flash_c2s_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p,

@@ -75,6 +75,22 @@ def _rows_as_one(ts):
     return torch.as_strided(t0, (sum(t.shape[0] for t in ts), t0.shape[1]), (t0.shape[1], 1), t0.storage_offset())
 
 
+def _next_layer_mask(logits, grp_of_query, n_groups):
+    """uint8 [Q, N] attention mask of the next layer's click-to-scene attention from this layer's [N, 1 + K] mask logits
+    (agile3d.py:362-383): a3d_next_layer_mask -- label arg-max + histogram, then the mask, instead of eight torch launches."""
+    lib = L.load()
+    N, G = logits.shape
+    Q = grp_of_query.numel()
+    if G != n_groups or G > 256:
+        raise RuntimeError("next-layer mask: the logits have one column per group (at most 256)")
+    lg = logits.contiguous()
+    mask = torch.empty((Q, N), dtype=torch.uint8, device=logits.device)
+    wsb = lib.a3d_next_layer_mask_workspace_bytes(N, G)
+    ws = torch.empty(wsb, dtype=torch.uint8, device=logits.device)
+    L.check(lib.a3d_next_layer_mask(_ptr(lg), N, G, _ptr(grp_of_query), Q, _ptr(mask), _ptr(ws), wsb, _stream()), "a3d_next_layer_mask")
+    return mask
+
+
 def _ptr(t):
     return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
 
@@ -503,7 +519,7 @@ class DecoderTape:
                 for qq in range(b0, b1):
                     gq[qq] = g_i
             samples.append({"rows": rows, "n_fg": n_fg, "Q": Q, "n0": n_at, "q0": q_at,
-                            "grp_of_query": torch.tensor(gq, dtype=torch.long, device=dev)})   # mask-head column of each query
+                            "grp_of_query": torch.tensor(gq, dtype=torch.int32, device=dev)})   # mask-head column of each query
             n_ranges.append((n_at, n_at + pcd.shape[0]))
             q_ranges.append((q_at, q_at + Q))
             groups.append(grp)
@@ -554,11 +570,7 @@ class DecoderTape:
             # times per layer and sample
             masks = []
             for out, sm, grp in zip(outs, samples, groups):
-                labels = out.v.argmax(1)
-                counts = torch.bincount(labels, minlength=len(grp))
-                gqv = sm["grp_of_query"]
-                m = (labels[None, :] != gqv[:, None]) & (counts[gqv] > 0)[:, None]
-                masks.append(m.to(torch.uint8).contiguous())
+                masks.append(_next_layer_mask(out.v, sm["grp_of_query"], len(grp)))
             self.attn_masks.append(masks[0] if self._single else masks)
         if self._single:
             self.logits = [layer[0].v for layer in self.logits_nodes]

@@ -349,6 +349,13 @@ int a3d_group_max(const float* lq_dev, int64_t N, int Q, const int32_t* qbeg_dev
                   float* out_dev, int32_t* arg_dev, void* stream);
 int a3d_group_max_backward(const float* dout_dev, const int32_t* arg_dev, int64_t N, int Q, int G, float* dlq_dev,
                            void* stream);
+/* The attention mask of the NEXT decoder layer from this layer's mask logits (agile3d.py:362-383: `attn_mask` of the
+ * click-to-scene attention; not differentiated): label[n] = first arg-max over the G = 1 + K logits of point n,
+ * mask[q][n] = (label[n] != group_of_query[q]) && (some point carries group_of_query[q])  -- uint8 [Q][N], non-zero = blocked;
+ * the second term is the reference's "a query that would be blocked everywhere is blocked nowhere" (agile3d.py:369,375). */
+size_t a3d_next_layer_mask_workspace_bytes(int64_t N, int G);
+int a3d_next_layer_mask(const float* logits_dev, int64_t N, int G, const int32_t* group_of_query_dev, int Q,
+                        unsigned char* mask_dev, void* workspace_dev, size_t workspace_bytes, void* stream);
 
 /* The same attention in the flash formulation, for the two attentions of a decoder layer that have the N points on one
  * side (attention_block.py:86-98 as called at agile3d.py:283-290 and :305-312; 8 heads x 16 channels fixed): nothing of

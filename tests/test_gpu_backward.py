@@ -915,3 +915,27 @@ def test_batched_decoder_tape_equals_one_tape_per_sample():
     assert worst[1] <= 2e-5 and rel_p <= 2e-5, (worst, rel_p)
     batched.release()
     assert batched.steps == [] and batched.pcd is None
+
+
+@pytest.mark.parametrize("N,G,Q", [(1, 2, 11), (255, 3, 12), (4097, 6, 40), (80_000, 11, 200), (3000, 256, 256)])
+def test_next_layer_mask_matches_the_torch_expression(N, G, Q):
+    """a3d_next_layer_mask (the training tape's attention mask of the next decoder layer, agile3d.py:362-383) against the torch
+    expression it replaces: label = first arg-max over the 1 + K logits, mask[q][n] = label[n] != group(q) and some point
+    carries group(q).  Ties (equal logits), groups that own no point and groups no query belongs to are in the data."""
+    from agile3d_amd.train_decoder import _next_layer_mask
+    g = torch.Generator().manual_seed(N + 7 * G + Q)
+    logits = torch.randn(N, G, generator=g)
+    logits[:, G - 1] = -50.0                                   # a group that never wins: "nothing blocked" for its queries
+    if N > 4:
+        logits[1::3] = torch.round(logits[1::3])               # ties: the FIRST maximum counts
+        logits[2] = 1.0
+    gq = torch.randint(0, G, (Q,), generator=g, dtype=torch.int32)
+    gq[0] = G - 1
+    lg, gqd = logits.cuda(), gq.cuda()
+    got = _next_layer_mask(lg, gqd, G)
+    labels = lg.argmax(1)
+    counts = torch.bincount(labels, minlength=G)
+    want = ((labels[None, :] != gqd.long()[:, None]) & (counts[gqd.long()] > 0)[:, None]).to(torch.uint8)
+    assert got.shape == (Q, N) and got.dtype == torch.uint8
+    assert torch.equal(got, want)
+    assert not got[0].any()
