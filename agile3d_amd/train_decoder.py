@@ -38,11 +38,14 @@ class _T:
     def __init__(self, v, needs_grad=True):
         self.v, self.g, self.needs_grad, self.own = v, None, needs_grad, False
 
-    def add_grad(self, g):
+    def add_grad(self, g, fresh=False):
+        """``fresh``: ``g`` was made for this call and nobody else refers to it (a GEMM's output, a kernel's dx): the node owns
+        it from the start, so the NEXT contribution is already added in place / in a GEMM's epilogue instead of by a
+        three-operand torch add over [N, 128]."""
         if not self.needs_grad:
             return
         if self.g is None:
-            self.g, self.own = g, False          # may be shared with other nodes (e.g. both inputs of an add)
+            self.g, self.own = g, bool(fresh)    # not fresh: may be shared with other nodes (e.g. both inputs of an add)
         elif self.own:
             self.g.add_(g)
         else:
@@ -104,14 +107,17 @@ def _pack(w_in_out):
     return B.pack_weight(w_in_out.reshape(1, cin, cout)), cin, cout
 
 
-def _linear(x, packed, bias=None, acc=None):
+def _linear(x, packed, bias=None, acc=None, out=None):
     """x [n, cin] @ w [cin, cout] (+ bias) through a3d_linear; ``packed`` = _pack(w).  ``acc`` [n, cout]: the product is ADDED
-    to it in place (the kernel's residual input and its output are the same rows: one rounding, like ``acc + product``)."""
+    to it in place (the kernel's residual input and its output are the same rows: one rounding, like ``acc + product``).
+    ``out`` [n, cout] contiguous rows (e.g. a sample's row range of a batched tensor): the product is written there."""
     lib = L.load()
     wp, cin, cout = packed
     x = x.contiguous()
     n = x.shape[0]
-    y = acc if acc is not None else torch.empty((n, cout), dtype=torch.float32, device=x.device)
+    if out is not None and (acc is not None or out.shape != (n, cout) or not out.is_contiguous() or out.dtype != torch.float32):
+        raise RuntimeError("_linear: out must be a contiguous fp32 [n, cout] block (and excludes acc)")
+    y = acc if acc is not None else out if out is not None else torch.empty((n, cout), dtype=torch.float32, device=x.device)
     L.check(lib.a3d_linear(_ptr(x), cin, None, 0, n, cin, cout, _ptr(wp), None, _ptr(bias), _ptr(acc), cout if acc is not None else 0,
                            0, _ptr(y), cout, None, 0, _stream()), "a3d_linear")
     return y
@@ -211,6 +217,7 @@ class DecoderTape:
         self.P = dict(model.named_parameters())
         self.steps, self.grads, self._packed = [], {}, {}
         self.relu_masks, self.attn_masks, self.args = [], [], []      # what a reference needs to follow the same branch
+        self._group_tabs = {}
         self._forward([p.to(torch.float32).contiguous() for p in pcd_features],
                       [p.to(torch.float32).contiguous() for p in pos_enc], list(click_idx), list(click_time_idx))
 
@@ -253,7 +260,7 @@ class DecoderTape:
             if x.needs_grad and x.g is not None and x.own and x.g.is_contiguous():
                 _linear(dy, bwd_w, acc=x.g)                              # x.g += dy @ W in the GEMM's epilogue (no [N, 128] add)
             elif x.needs_grad:
-                x.add_grad(_linear(dy, bwd_w))                           # dy @ W
+                x.add_grad(_linear(dy, bwd_w), fresh=True)               # dy @ W
             dW = B.linear_weight_grad(x.v, dy).t()                        # [out, in]
             if rows is None:
                 self._pg(wname, dW)
@@ -277,7 +284,7 @@ class DecoderTape:
 
         def back():
             if y.g is not None:
-                x.add_grad(y.g * mask)
+                x.add_grad(y.g * mask, fresh=True)
         self.steps.append(back)
         return y
 
@@ -289,7 +296,7 @@ class DecoderTape:
             if y.g is None:
                 return
             dx, dg, db = B.layernorm_backward(x.v, y.g, g_)
-            x.add_grad(dx)
+            x.add_grad(dx, fresh=True)
             self._pg(prefix + "weight", dg)
             self._pg(prefix + "bias", db)
         self.steps.append(back)
@@ -417,9 +424,9 @@ class DecoderTape:
             for ((q0, q1), (k0, k1)), (kind, o, sv, mask) in zip(zip(q_ranges, k_ranges), saved):
                 bwd = {"s2c": self._s2c_bwd, "c2s": self._c2s_bwd, "dense": self._dense_bwd}[kind]
                 bwd(qv[q0:q1], kv[k0:k1], vv[k0:k1], mask, o, sv, do[q0:q1], dq[q0:q1], dk[k0:k1], dv[k0:k1])
-            q.add_grad(dq)
-            k.add_grad(dk)
-            v.add_grad(dv)
+            q.add_grad(dq, fresh=True)
+            k.add_grad(dk, fresh=True)
+            v.add_grad(dv, fresh=True)
         self.steps.append(back)
         return y
 
@@ -455,8 +462,11 @@ class DecoderTape:
             Ep = torch.zeros((Qp, 128), dtype=torch.float32, device=dev)
             Ep[:Q] = E.v[q0:q1]
             lq = _linear(sv, _pack(Ep.t().contiguous()))
-            qb = torch.tensor([g[0] for g in grp], dtype=torch.int32, device=dev)
-            qe = torch.tensor([g[1] for g in grp], dtype=torch.int32, device=dev)
+            tabs = self._group_tabs.get(id(grp))       # the groups' query ranges: the same in every layer of the pass
+            if tabs is None:
+                tabs = self._group_tabs[id(grp)] = (torch.tensor([g[0] for g in grp], dtype=torch.int32, device=dev),
+                                                    torch.tensor([g[1] for g in grp], dtype=torch.int32, device=dev), grp)
+            qb, qe = tabs[0], tabs[1]
             out = torch.empty((N, G), dtype=torch.float32, device=dev)
             arg = torch.empty((N, G), dtype=torch.int32, device=dev)
             L.check(lib.a3d_group_max(_ptr(lq), N, Qp, _ptr(qb), _ptr(qe), G, _ptr(out), _ptr(arg), _stream()), "group_max")
@@ -476,11 +486,10 @@ class DecoderTape:
                 L.check(lib.a3d_group_max_backward(_ptr(y.g.contiguous()), _ptr(arg), N, Qp, G, _ptr(dlq), _stream()), "gm_bwd")
                 # d(src) = dlq Ep and dE = dlq^T src: both on the matrix cores (a GEMM and a weight-gradient reduction over
                 # the N rows, wgrad.hip), the padded query columns carry zeros
-                lib_out = _linear(dlq, _pack(Ep))
-                dsrc[n0:n1] = lib_out
+                _linear(dlq, _pack(Ep), out=dsrc[n0:n1])      # straight into the sample's rows (no [N, 128] copy)
                 dE[q0:q1] = B.linear_weight_grad(dlq, src.v[n0:n1])[:Q]
-            src.add_grad(dsrc)
-            E.add_grad(dE)
+            src.add_grad(dsrc, fresh=True)
+            E.add_grad(dE, fresh=True)
         self.steps.append(back)
         return outs
 
@@ -583,7 +592,7 @@ class DecoderTape:
         until Python's cycle collector gets to them -- the caching allocator then answers the next iteration with fresh
         hipMallocs (measured: 350 device allocations and +12 GB reserved per iteration, 107 GB after ten)."""
         self.steps, self.logits_nodes, self.relu_masks, self.attn_masks, self.args = [], [], [], [], []
-        self.pcd = None
+        self.pcd, self._group_tabs = None, {}
 
     # ------------------------------------------------------------------ backward
     def backward(self, d_logits):
