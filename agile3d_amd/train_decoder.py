@@ -107,7 +107,7 @@ def _pack(w_in_out):
     return B.pack_weight(w_in_out.reshape(1, cin, cout)), cin, cout
 
 
-def _linear(x, packed, bias=None, acc=None, out=None):
+def _linear(x, packed, bias=None, acc=None, out=None, res=None):
     """x [n, cin] @ w [cin, cout] (+ bias) through a3d_linear; ``packed`` = _pack(w).  ``acc`` [n, cout]: the product is ADDED
     to it in place (the kernel's residual input and its output are the same rows: one rounding, like ``acc + product``).
     ``out`` [n, cout] contiguous rows (e.g. a sample's row range of a batched tensor): the product is written there."""
@@ -118,7 +118,12 @@ def _linear(x, packed, bias=None, acc=None, out=None):
     if out is not None and (acc is not None or out.shape != (n, cout) or not out.is_contiguous() or out.dtype != torch.float32):
         raise RuntimeError("_linear: out must be a contiguous fp32 [n, cout] block (and excludes acc)")
     y = acc if acc is not None else out if out is not None else torch.empty((n, cout), dtype=torch.float32, device=x.device)
-    L.check(lib.a3d_linear(_ptr(x), cin, None, 0, n, cin, cout, _ptr(wp), None, _ptr(bias), _ptr(acc), cout if acc is not None else 0,
+    r = acc
+    if res is not None:                 # ``res`` [n, cout]: a residual read in the GEMM's epilogue, y = res + x w (+ bias) in fresh rows
+        if acc is not None or res.shape != (n, cout) or not res.is_contiguous():
+            raise RuntimeError("_linear: res must be a contiguous [n, cout] block (and excludes acc)")
+        r = res
+    L.check(lib.a3d_linear(_ptr(x), cin, None, 0, n, cin, cout, _ptr(wp), None, _ptr(bias), _ptr(r), cout if r is not None else 0,
                            0, _ptr(y), cout, None, 0, _stream()), "a3d_linear")
     return y
 
@@ -237,8 +242,10 @@ class DecoderTape:
         self.steps.append(back)
         return y
 
-    def lin(self, x: _T, wname, bname=None, rows=None) -> _T:
-        """nn.Linear with weight [out, in] (optionally the row slice ``rows`` of an in_proj matrix)."""
+    def lin(self, x: _T, wname, bname=None, rows=None, res: _T = None) -> _T:
+        """nn.Linear with weight [out, in] (optionally the row slice ``rows`` of an in_proj matrix).  ``res``: a residual added in
+        the GEMM's epilogue -- y = res + x W^T + b as ONE node (the ``tgt + dropout(attn)`` / ``src + ...`` of
+        attention_block.py:96,153,207 without a separate [N, 128] add); its gradient is y's, like an add's."""
         W = self.P[wname].detach()
         b = self.P[bname].detach() if bname else None
         if rows is not None:
@@ -251,12 +258,14 @@ class DecoderTape:
             object.__setattr__(self.model, "_a3d_packed_dec", packs)
         fwd_w, bwd_w = packs.get(self.P[wname], wname, rows)
         bc = b                 # a contiguous slice of the 1-D parameter: always current, nothing to cache
-        y = _T(_linear(x.v, fwd_w, bc))
+        y = _T(_linear(x.v, fwd_w, bc, res=res.v.contiguous() if res is not None else None))
 
         def back():
             if y.g is None:
                 return
             dy = y.g.contiguous()
+            if res is not None:
+                res.add_grad(y.g)
             if x.needs_grad and x.g is not None and x.own and x.g.is_contiguous():
                 _linear(dy, bwd_w, acc=x.g)                              # x.g += dy @ W in the GEMM's epilogue (no [N, 128] add)
             elif x.needs_grad:
@@ -430,15 +439,15 @@ class DecoderTape:
         self.steps.append(back)
         return y
 
-    def mha(self, prefix, query: _T, key: _T, value: _T, q_ranges, k_ranges, masks=None) -> _T:
+    def mha(self, prefix, query: _T, key: _T, value: _T, q_ranges, k_ranges, masks=None, res: _T = None) -> _T:
         """nn.MultiheadAttention (attention_block.py:25-26,88-94): in_proj slices (one GEMM each over the rows of the whole
-        batch), attention per sample, out_proj."""
+        batch), attention per sample, out_proj (+ ``res``: the layer's residual, added in out_proj's epilogue)."""
         w, b = prefix + "in_proj_weight", prefix + "in_proj_bias"
         q = self.lin(query, w, b, rows=(0, 128))
         k = self.lin(key, w, b, rows=(128, 256))
         v = self.lin(value, w, b, rows=(256, 384))
         a = self.attention_seg(q, k, v, q_ranges, k_ranges, masks)
-        return self.lin(a, prefix + "out_proj.weight", prefix + "out_proj.bias")
+        return self.lin(a, prefix + "out_proj.weight", prefix + "out_proj.bias", res=res)
 
     def mask_head(self, queries: _T, src: _T, n_ranges, q_ranges, groups):
         """Agile3d.mask_module (agile3d.py:342-384): per-object max over its queries of src . MLP(LN(q)); the MLP runs over
@@ -561,16 +570,17 @@ class DecoderTape:
         for d in range(self.model.num_decoders):
             li = 0 if self.model.shared_decoder else d
             src_pos = self.add(src, pos)        # the keys of click-to-scene AND the queries of scene-to-click (src changes after both)
-            a = self.mha(f"c2s_attention.{li}.0.multihead_attn.", self.add(tgt, qpos), src_pos, src, q_ranges, n_ranges, masks)
-            tgt = self.ln(self.add(tgt, a), f"c2s_attention.{li}.0.norm.")
+            # every residual (x + sublayer(x), attention_block.py:96,153,207) rides in the sublayer's last GEMM
+            a = self.mha(f"c2s_attention.{li}.0.multihead_attn.", self.add(tgt, qpos), src_pos, src, q_ranges, n_ranges, masks, res=tgt)
+            tgt = self.ln(a, f"c2s_attention.{li}.0.norm.")
             qk = self.add(tgt, qpos)
-            a = self.mha(f"c2c_attention.{li}.0.self_attn.", qk, qk, tgt, q_ranges, q_ranges)
-            tgt = self.ln(self.add(tgt, a), f"c2c_attention.{li}.0.norm.")
+            a = self.mha(f"c2c_attention.{li}.0.self_attn.", qk, qk, tgt, q_ranges, q_ranges, res=tgt)
+            tgt = self.ln(a, f"c2c_attention.{li}.0.norm.")
             h = self.relu(self.lin(tgt, f"ffn_attention.{li}.0.linear1.weight", f"ffn_attention.{li}.0.linear1.bias"))
-            f = self.lin(h, f"ffn_attention.{li}.0.linear2.weight", f"ffn_attention.{li}.0.linear2.bias")
-            tgt = self.ln(self.add(tgt, f), f"ffn_attention.{li}.0.norm.")
-            a = self.mha(f"s2c_attention.{li}.0.multihead_attn.", src_pos, self.add(tgt, qpos), tgt, n_ranges, q_ranges)
-            src = self.ln(self.add(src, a), f"s2c_attention.{li}.0.norm.")
+            f = self.lin(h, f"ffn_attention.{li}.0.linear2.weight", f"ffn_attention.{li}.0.linear2.bias", res=tgt)
+            tgt = self.ln(f, f"ffn_attention.{li}.0.norm.")
+            a = self.mha(f"s2c_attention.{li}.0.multihead_attn.", src_pos, self.add(tgt, qpos), tgt, n_ranges, q_ranges, res=src)
+            src = self.ln(a, f"s2c_attention.{li}.0.norm.")
             outs = self.mask_head(tgt, src, n_ranges, q_ranges, groups)
             self.logits_nodes.append(outs)
             # attention masks of the next layer from this layer's labels (agile3d.py:362-383): not differentiated.  No host
