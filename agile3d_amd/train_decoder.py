@@ -78,6 +78,25 @@ def _rows_as_one(ts):
     return torch.as_strided(t0, (sum(t.shape[0] for t in ts), t0.shape[1]), (t0.shape[1], 1), t0.storage_offset())
 
 
+class _Alias:
+    """x + c with c a constant of the tape (the position encodings): the sum's gradient IS x's, so the node forwards every
+    contribution to x -- a GEMM that would add into the sum's gradient adds into x's (no [N, 128] add when the sum is done)."""
+    __slots__ = ("v", "t")
+
+    def __init__(self, v, target):
+        self.v, self.t = v, target
+
+    g = property(lambda self: self.t.g)
+    own = property(lambda self: self.t.own)
+    needs_grad = property(lambda self: self.t.needs_grad)
+
+    def add_grad(self, g, fresh=False):
+        self.t.add_grad(g, fresh)
+
+    def add_grad_rows(self, rows, vals):
+        self.t.add_grad_rows(rows, vals)
+
+
 def _next_layer_mask(logits, grp_of_query, n_groups):
     """uint8 [Q, N] attention mask of the next layer's click-to-scene attention from this layer's [N, 1 + K] mask logits
     (agile3d.py:362-383): a3d_next_layer_mask -- label arg-max + histogram, then the mask, instead of eight torch launches."""
@@ -232,6 +251,10 @@ class DecoderTape:
         self.grads[name] = g if name not in self.grads else self.grads[name] + g
 
     def add(self, a: _T, b: _T) -> _T:
+        if a.needs_grad and not b.needs_grad:
+            return _Alias(a.v + b.v, a)
+        if b.needs_grad and not a.needs_grad:
+            return _Alias(a.v + b.v, b)
         y = _T(a.v + b.v)
 
         def back():
@@ -264,8 +287,6 @@ class DecoderTape:
             if y.g is None:
                 return
             dy = y.g.contiguous()
-            if res is not None:
-                res.add_grad(y.g)
             if x.needs_grad and x.g is not None and x.own and x.g.is_contiguous():
                 _linear(dy, bwd_w, acc=x.g)                              # x.g += dy @ W in the GEMM's epilogue (no [N, 128] add)
             elif x.needs_grad:
@@ -283,6 +304,10 @@ class DecoderTape:
                     fb = torch.zeros_like(self.P[bname])
                     fb[rows[0]:rows[1]] = _col_sums(dy)
                     self._pg(bname, fb)
+            if res is not None:
+                # last, when nothing reads dy any more: a gradient this node owned exclusively passes to the residual WITH its
+                # ownership, so what arrives there later is added in place / in a GEMM epilogue (no copy-add over [N, 128])
+                res.add_grad(y.g, fresh=y.own)
         self.steps.append(back)
         return y
 
