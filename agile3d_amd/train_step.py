@@ -94,6 +94,8 @@ def _train_one_step(model, criterion, optimizer, batch, device, max_norm):
         labels_new.append(new)
         num_objs.append(num_obj)          # = the nonzero ids of labels_new[idx] (every chosen object has points)
     click_time_idx = copy.deepcopy(click_idx)
+    labels_i32 = [l.to(torch.int32) for l in labels_new]     # once: the click simulator and the criterion read ids (a float -> int
+                                                             # conversion per sample and round otherwise)
 
     # ---- click simulation with the current weights, no gradient (engine.py:82-116)
     num_forward_iters = random.randint(0, 19)
@@ -119,10 +121,10 @@ def _train_one_step(model, criterion, optimizer, batch, device, max_norm):
         t0 = lap(0, t0)
         # argmax + "update prediction with sparse gt" (engine.py:96-101) in one kernel instead of 1 + K torch ops; then the
         # samples' error clusters side by side (one host round trip per round, not one per sample), clicks in sample order
-        preds = [torch.zeros(e - s, device=device) if it == 0 else argmax_labels(out["pred_masks"][idx], click_idx[idx])
+        preds = [torch.zeros(e - s, dtype=torch.int32, device=device) if it == 0 else argmax_labels(out["pred_masks"][idx], click_idx[idx])
                  for idx, (s, e) in enumerate(ranges)]
         t0 = lap(1, t0)
-        sims = get_simulated_clicks_batch(preds, labels_new, raw_s, it, training=True, num_objs=num_objs)
+        sims = get_simulated_clicks_batch(preds, labels_i32, raw_s, it, training=True, num_objs=num_objs)
         t0 = lap(2, t0)
         for idx, (new_clicks, _, _, new_time) in enumerate(sims):
             if new_clicks is not None:
@@ -147,7 +149,7 @@ def _train_one_step(model, criterion, optimizer, batch, device, max_norm):
     # ---- losses (engine.py:124-128) and their gradient with respect to every level's logits
     # one pass of the loss kernel per level and sample gives the values AND the gradient; one host round trip for all values
     click_weights = cal_click_loss_weights(batch_idx, raw_coords, None, click_idx, ranges=ranges)
-    targets = [l.to(torch.int32) for l in labels_new]
+    targets = labels_i32
     loss_dict, gl = criterion.forward_and_grad(outputs, targets, click_weights)
     loss_keys = list(loss_dict)
     loss_vals = dict(zip(loss_keys, torch.stack([loss_dict[k] for k in loss_keys]).tolist()))
