@@ -246,6 +246,7 @@ struct DecSampleDev {
   float* part;                     // click-to-scene flash partials [slots][H][QP][kPartStride]
   const int *qobj, *qrange;        // QueryMeta::obj / qrange (device)
   const float *qproj, *ks, *vs, *E;
+  const float* q0;                 // the scene's cached layer-0 scene-to-click queries (src + pos) Wq^T + bq [n][128], or nullptr
 };
 constexpr int kMaxBatchSamples = 64;
 __device__ __forceinline__ const DecSampleDev& sample_of_wg(const DecSampleDev* samples, int ns) {
@@ -824,7 +825,9 @@ __global__ void __launch_bounds__(256) k_ln_mask(float* Y, int n, const float* _
 // Q = (src + pos) Wq^T + bq per 16-point group, head by head, in the transposed accumulator layout = the B fragment
 // of S^T = ks_h Q_h^T; softmax over the (few) queries in registers; O^T = vs_h^T P.  Q never reaches HBM.
 // Persistent 8-wave workgroups: packed Wq (64 KB) + the queries' keys / values in LDS.
-template <int QT>
+// QC: the layer's queries come from the scene's cache (a3d_decoder_sample::kv0_dev, third block: they depend on the scene only
+// in the first layer, and the interactive loop runs ~100 passes on one scene): no projection, no read of src and pos
+template <int QT, bool QC = false>
 __global__ void __launch_bounds__(512) k_q_s2c(const DecSampleDev* __restrict__ samples, int ns, int layer,
                                                const float* __restrict__ Wq, const float* __restrict__ bq) {
   constexpr int QP = QT * 16, LD = 132, NW = 8;
@@ -870,12 +873,18 @@ __global__ void __launch_bounds__(512) k_q_s2c(const DecSampleDev* __restrict__ 
   f32x4 nx[8], np[8];
   auto fetch = [&](int gq) {
     const size_t row = (size_t)min(gq * 16 + j, n - 1);
-    const float* xr = X + row * D + 4 * g;
-    const float* pr = Pe + row * D + 4 * g;
+    if constexpr (QC) {   // head h's fragment of the cached queries: the position-encoding rows' access pattern
+      const float* qr = sm.q0 + row * D + 4 * g;
 #pragma unroll
-    for (int S = 0; S < 8; ++S) nx[S] = gld4(xr + 16 * S);
+      for (int S = 0; S < 8; ++S) np[S] = gld4(qr + 16 * S);
+    } else {
+      const float* xr = X + row * D + 4 * g;
+      const float* pr = Pe + row * D + 4 * g;
 #pragma unroll
-    for (int S = 0; S < 8; ++S) np[S] = gld4(pr + 16 * S);
+      for (int S = 0; S < 8; ++S) nx[S] = gld4(xr + 16 * S);
+#pragma unroll
+      for (int S = 0; S < 8; ++S) np[S] = gld4(pr + 16 * S);
+    }
   };
   if (grp < ngroups) fetch(grp);
   while (grp < ngroups) {
@@ -883,20 +892,21 @@ __global__ void __launch_bounds__(512) k_q_s2c(const DecSampleDev* __restrict__ 
     const int prow = min(p0 + j, n - 1);
     f32x4 xp[8];
 #pragma unroll
-    for (int S = 0; S < 8; ++S) xp[S] = nx[S] + np[S];
+    for (int S = 0; S < 8; ++S) xp[S] = QC ? np[S] : nx[S] + np[S];
     const int next = grp + stride;
     if (next < ngroups) fetch(next);
     float* orow = O + (size_t)prow * D;
-#pragma unroll 2
-    for (int h = 0; h < H; ++h) {
+    auto head = [&](int h, f32x4 qf) {
+      if constexpr (!QC) {
       // bias from LDS: the only vector-memory traffic inside the loop is the prefetch and the stores (vmcnt is
       // in order -- a global load here would wait for the whole prefetch and the previous head's store)
-      f32x4 qf = *(const f32x4*)(bq_l + 16 * h + 4 * g);   // Q[point j][16h+4g..+3]
+      qf = *(const f32x4*)(bq_l + 16 * h + 4 * g);   // Q[point j][16h+4g..+3]
 #pragma unroll
       for (int S = 0; S < 8; ++S) {
         const f32x4 w = Wl[(S * 8 + h) * 64 + lane];
 #pragma unroll
         for (int t = 0; t < 4; ++t) qf = __builtin_amdgcn_mfma_f32_16x16x4f32(w[t], xp[S][t], qf, 0, 0, 0);
+      }
       }
       f32x4 sc[QT];
       float mx = kNegBig;
@@ -931,6 +941,13 @@ __global__ void __launch_bounds__(512) k_q_s2c(const DecSampleDev* __restrict__ 
         for (int t = 0; t < 4; ++t) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(vf[t], sc[kt][t] * inv, acc, 0, 0, 0);
       }
       if (p0 + j < n) gst4(orow + h * DH + 4 * g, acc);
+    };
+    if constexpr (QC) {   // unrolled: xp[h] is a register, not an indexed array
+#pragma unroll
+      for (int h = 0; h < H; ++h) head(h, xp[h]);
+    } else {
+#pragma unroll 2
+      for (int h = 0; h < H; ++h) head(h, (f32x4){0.f, 0.f, 0.f, 0.f});
     }
     grp = next;
   }
@@ -1113,7 +1130,9 @@ __global__ void __launch_bounds__(512) k_out_ln_mask(const DecSampleDev* __restr
 // <= 168 registers: no register prefetch -- the third wave covers a wave's wait for its rows)
 // KG: the queries' key rows come from global memory (16 KB, cache resident; requested a whole Q projection before their
 // MFMAs) instead of LDS -- the build for 25..32 queries, where keys + transposed values + both weight matrices do not fit
-template <int QT, int NW, bool KG = false>
+// QC: the queries of the layer from the scene's cache (as k_q_s2c<.., QC>): the Q projection -- 256 of a group's ~700 MFMAs -- and
+// the read of the position encodings are skipped
+template <int QT, int NW, bool KG = false, bool QC = false>
 __global__ void __launch_bounds__(NW * 64) k_s2c_out(const DecSampleDev* __restrict__ samples, int ns, int layer,
                                                  const float* __restrict__ Wq, const float* __restrict__ bq,
                                                  const float* __restrict__ Wo, const float* __restrict__ bo,
@@ -1220,7 +1239,7 @@ __global__ void __launch_bounds__(NW * 64) k_s2c_out(const DecSampleDev* __restr
   auto fetch = [&](int gq) {
     const size_t row = (size_t)min(gq * 16 + j, n - 1);
     const float* xr = X + row * D + 4 * g;
-    const float* pr = Pe + row * D + 4 * g;
+    const float* pr = (QC ? sm.q0 : Pe) + row * D + 4 * g;   // QC: head h's fragment of the cached queries sits where pos's S = h does
 #pragma unroll
     for (int S = 0; S < 8; ++S) nx[S] = gld4(xr + 16 * S);
 #pragma unroll
@@ -1234,7 +1253,7 @@ __global__ void __launch_bounds__(NW * 64) k_s2c_out(const DecSampleDev* __restr
     f32x4 xp[8], y[8];
 #pragma unroll
     for (int S = 0; S < 8; ++S) {
-      xp[S] = nx[S] + np[S];
+      xp[S] = QC ? np[S] : nx[S] + np[S];
       y[S] = *(const f32x4*)(bo_l + 16 * S + 4 * g) + nx[S];   // bias + residual row: channels 16 ct + 4 g ..+3 of point j
     }
     const int next = grp + stride;
@@ -1257,8 +1276,13 @@ __global__ void __launch_bounds__(NW * 64) k_s2c_out(const DecSampleDev* __restr
       if constexpr (!KG) asm volatile("" : "+v"(ks_a));
       const unsigned vt_a1 = vt_a + (unsigned)(DH * LT) * 4u;
       f32x4 qf[2];
+      if constexpr (QC) {   // h is a run-time value (the loop is not unrolled): three selects per component instead of an indexed array
+        qf[0] = h == 0 ? xp[0] : h == 2 ? xp[2] : h == 4 ? xp[4] : xp[6];
+        qf[1] = h == 0 ? xp[1] : h == 2 ? xp[3] : h == 4 ? xp[5] : xp[7];
+      } else {
 #pragma unroll
       for (int u = 0; u < 2; ++u) qf[u] = *(const f32x4*)(bq_l + 16 * (h + u) + 4 * g);   // Q[point j][16h+4g..+3]
+      }
       f32x4 kfg[2][QT];
       if constexpr (KG) {
 #pragma unroll
@@ -1266,7 +1290,7 @@ __global__ void __launch_bounds__(NW * 64) k_s2c_out(const DecSampleDev* __restr
 #pragma unroll
           for (int u = 0; u < 2; ++u) kfg[u][kt] = gld4(sm.ks + (size_t)min(kt * 16 + j, nq - 1) * D + (h + u) * DH + 4 * g);
       }
-      {
+      if constexpr (!QC) {
         // weight fragments one K-step ahead of the MFMAs that use them (left to itself the compiler issues the two
         // ds_read_b128 of a step right in front of its eight MFMAs and waits out the LDS latency every 256 cycles)
         f32x4 w0 = lds4(wq_a), w1 = lds4(wq_a + 64 * 16);
@@ -2405,7 +2429,7 @@ struct Prepared {
   const float *feats, *posenc;
   int n;
   float* logits;
-  float* kv0 = nullptr;   // the scene's cached first-layer keys / values [2][n][128] (a3d_decoder_sample::kv0_dev) and their state
+  float* kv0 = nullptr;   // the scene's cached first-layer keys / values / scene-to-click queries [3][n][128] (a3d_decoder_sample::kv0_dev) and their state
   int kv0_state = 0;
   // views
   float *bufA, *bufB, *bufC, *bufD, *part;
@@ -2472,6 +2496,14 @@ static int run_decoder(const a3d_decoder_weights* w, Prepared* P, int ns, hipStr
       A3D_ALLOW_LDS(big_lds, (k_s2c_out<2, 8, true>));
       A3D_ALLOW_LDS(big_lds, (k_s2c_out<1, 12, true>));
       A3D_ALLOW_LDS(big_lds, (k_s2c_out<1, 8, true>));
+      A3D_ALLOW_LDS(big_lds, (k_q_s2c<1, true>));
+      A3D_ALLOW_LDS(big_lds, (k_q_s2c<2, true>));
+      A3D_ALLOW_LDS(big_lds, (k_q_s2c<3, true>));
+      A3D_ALLOW_LDS(big_lds, (k_q_s2c<4, true>));
+      A3D_ALLOW_LDS(big_lds, (k_s2c_out<1, 12, false, true>));
+      A3D_ALLOW_LDS(big_lds, (k_s2c_out<2, 12, false, true>));
+      A3D_ALLOW_LDS(big_lds, (k_s2c_out<1, 12, true, true>));
+      A3D_ALLOW_LDS(big_lds, (k_s2c_out<2, 12, true, true>));
       A3D_ALLOW_LDS(big_lds, k_kv_c2s<1>);
       A3D_ALLOW_LDS(big_lds, k_kv_c2s<2>);
       A3D_ALLOW_LDS(big_lds, k_kv_c2s<3>);
@@ -2569,6 +2601,7 @@ static int run_decoder(const a3d_decoder_weights* w, Prepared* P, int ns, hipStr
       d.ks = p.B.ks;
       d.vs = p.B.vs;
       d.E = p.B.E;
+      d.q0 = p.kv0 && p.kv0_state != 0 ? p.kv0 + (size_t)2 * p.n * D : nullptr;
     }
     QuerySample* hq = (QuerySample*)(up_host.data() + up_qs);
     unsigned* sync0 = (unsigned*)(P[0].ws + P[0].L.sync);   // zeroed by k_query_init (a sample's first query block)
@@ -2601,6 +2634,7 @@ static int run_decoder(const a3d_decoder_weights* w, Prepared* P, int ns, hipStr
     // V = feats Wv^T + bv depend on the scene only, the interactive loop runs ~100 passes on it
     bool cached0 = l == 0;
     for (int si = 0; si < ns && cached0; ++si) cached0 = P[si].kv0 != nullptr && P[si].kv0_state != 0;
+    const bool qc0 = cached0;   // the scene-to-click half of this layer reads its queries from the cache too
     if (cached0) {
       for (int si = 0; si < ns; ++si) {
         Prepared& p = P[si];
@@ -2610,6 +2644,10 @@ static int run_decoder(const a3d_decoder_weights* w, Prepared* P, int ns, hipStr
           rc = a3d_linear(p.feats, D, p.posenc, D, p.n, D, D, LW.c2s_wk_packed, nullptr, LW.c2s_in_b + D, nullptr, 0, 0, K0, D, nullptr, 0, st);
           if (rc) return rc;
           rc = a3d_linear(p.feats, D, nullptr, 0, p.n, D, D, LW.c2s_wv_packed, nullptr, LW.c2s_in_b + 2 * D, nullptr, 0, 0, V0, D, nullptr, 0, st);
+          if (rc) return rc;
+          // ... and the scene-to-click QUERIES of the first layer, (feats + pos) Wq^T + bq: click-independent too (agile3d.py:305-312)
+          rc = a3d_linear(p.feats, D, p.posenc, D, p.n, D, D, LW.s2c_wq_packed, nullptr, LW.s2c_in_b, nullptr, 0, 0,
+                          p.kv0 + (size_t)2 * p.n * D, D, nullptr, 0, st);
           if (rc) return rc;
         }
         ProfScope ps(st, A3D_PROF_C2S, 0, 0, 0, 0, p.n);
@@ -2688,7 +2726,13 @@ static int run_decoder(const a3d_decoder_weights* w, Prepared* P, int ns, hipStr
       // the whole half in one pass: O never reaches HBM (k_s2c_out)
       ProfScope ps(st, A3D_PROF_S2C, 0, 0, 0, 0, (int)n_total);
       if constexpr (QT <= 2) {
-        if (s2c_kg && s2c_out_lds12 <= 160 * 1024)
+        if (qc0 && s2c_kg && s2c_out_lds12 <= 160 * 1024)
+          k_s2c_out<QT, 12, true, true><<<grid, 768, s2c_out_lds12, st>>>(samples_dev, ns, l, LW.s2c_wq_packed, LW.s2c_in_b, LW.s2c_wo_packed,
+                                                                         LW.s2c_out_b, LW.s2c_norm_w, LW.s2c_norm_b, nqr_max, Kmax);
+        else if (qc0 && !s2c_kg && s2c_out_lds12 <= 160 * 1024)
+          k_s2c_out<QT, 12, false, true><<<grid, 768, s2c_out_lds12, st>>>(samples_dev, ns, l, LW.s2c_wq_packed, LW.s2c_in_b, LW.s2c_wo_packed,
+                                                                          LW.s2c_out_b, LW.s2c_norm_w, LW.s2c_norm_b, nqr_max, Kmax);
+        else if (s2c_kg && s2c_out_lds12 <= 160 * 1024)
           k_s2c_out<QT, 12, true><<<grid, 768, s2c_out_lds12, st>>>(samples_dev, ns, l, LW.s2c_wq_packed, LW.s2c_in_b, LW.s2c_wo_packed,
                                                                    LW.s2c_out_b, LW.s2c_norm_w, LW.s2c_norm_b, nqr_max, Kmax);
         else if (s2c_kg)
@@ -2706,16 +2750,22 @@ static int run_decoder(const a3d_decoder_weights* w, Prepared* P, int ns, hipStr
     }
     if (fuse_s2c) {
       ProfScope ps(st, A3D_PROF_S2C, 0, 0, 0, 0, (int)n_total);
-      k_q_s2c<QT><<<grid, 512, (size_t)64 * 1024 + qs2c_lds, st>>>(samples_dev, ns, l, LW.s2c_wq_packed, LW.s2c_in_b);
+      if (qc0) k_q_s2c<QT, true><<<grid, 512, (size_t)64 * 1024 + qs2c_lds, st>>>(samples_dev, ns, l, LW.s2c_wq_packed, LW.s2c_in_b);
+      else k_q_s2c<QT><<<grid, 512, (size_t)64 * 1024 + qs2c_lds, st>>>(samples_dev, ns, l, LW.s2c_wq_packed, LW.s2c_in_b);
       A3D_LAUNCH_CHECK();
     } else {
       for (int si = 0; si < ns; ++si) {
         Prepared& p = P[si];
         const float* src = l == 0 ? p.feats : (((l - 1) & 1) ? p.bufD : p.bufC);
-        rc = a3d_linear(src, D, p.posenc, D, p.n, D, D, LW.s2c_wq_packed, nullptr, LW.s2c_in_b, nullptr, 0, 0, p.bufA, D, nullptr, 0, st);
-        if (rc) return rc;
+        const float* Qs = p.bufA;
+        if (qc0) {
+          Qs = p.kv0 + (size_t)2 * p.n * D;     // the cached queries of the first layer
+        } else {
+          rc = a3d_linear(src, D, p.posenc, D, p.n, D, D, LW.s2c_wq_packed, nullptr, LW.s2c_in_b, nullptr, 0, 0, p.bufA, D, nullptr, 0, st);
+          if (rc) return rc;
+        }
         ProfScope ps(st, A3D_PROF_S2C, 0, 0, 0, 0, p.n);
-        k_s2c_attn_wide<QT><<<(p.n + 127) / 128, 512, s2c_lds, st>>>(p.bufA, p.n, p.B.ks, p.B.vs, p.hm.nq, nblk, p.bufB);
+        k_s2c_attn_wide<QT><<<(p.n + 127) / 128, 512, s2c_lds, st>>>(Qs, p.n, p.B.ks, p.B.vs, p.hm.nq, nblk, p.bufB);
         A3D_LAUNCH_CHECK();
       }
     }

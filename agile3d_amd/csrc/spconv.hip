@@ -755,8 +755,9 @@ __device__ __forceinline__ void wait_vmcnt() {   // vmcnt <= N (expcnt 7, lgkmcn
   __builtin_amdgcn_s_waitcnt(0x0F70 | (N & 15) | ((N >> 4) << 14));
 }
 
-// ABL (tuning builds only, tools/conv_bench.py --ablate): 1 = no gathered pieces, 2 = no weight pieces, 4 = no MFMAs
-template <int BN, int CH, bool FUSE, int ABL = 0, int D = 3, int STATS = 0>
+// (the ablation builds the round's measurements used -- no gathered pieces / no weight pieces / no MFMAs, four ring slots --
+// were compiled out again: profiles/r05_experiments.txt has their numbers)
+template <int BN, int CH, bool FUSE, int D = 3, int STATS = 0>
 __global__ void __launch_bounds__(256, 1) k_conv_deep(const DeepArgs a) {
   static_assert(!STATS || !FUSE, "BatchNorm statistics are taken of a raw convolution");
   constexpr int NCT = BN / 16, NS = CH / 16, NW = 4;
@@ -767,7 +768,7 @@ __global__ void __launch_bounds__(256, 1) k_conv_deep(const DeepArgs a) {
   constexpr int AF = NW * NS * 256;      // floats of the four waves' gathered fragments
   constexpr int SLOT = WF + AF;
   constexpr int PW = D - 1;              // D ring slots; PW stages in flight ahead of the one multiplied
-  constexpr int NL = ((ABL & 1) ? 0 : NS) + ((ABL & 2) ? 0 : WV);   // DMA instructions per wave and stage
+  constexpr int NL = NS + WV;            // DMA instructions per wave and stage
   static_assert((PW - 1) * NL <= 63, "vmcnt is a 6-bit counter");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* ring = (float*)smem;                         // [D][SLOT]
@@ -877,7 +878,7 @@ __global__ void __launch_bounds__(256, 1) k_conv_deep(const DeepArgs a) {
       return st;
     };
     auto issue_piece = [&](const Stage& st, int q) {   // q compile-time after unrolling: 0 .. NL - 1
-      constexpr int NA = (ABL & 1) ? 0 : NS;
+      constexpr int NA = NS;
       if (q < NA) glds16_s(st.ab + 16 * q, st.roff, st.sl + a_dst + q * 1024u);
       else glds16_s(st.wst, wsrc[q - NA], st.sl + wdst[q - NA]);
     };
@@ -889,7 +890,7 @@ __global__ void __launch_bounds__(256, 1) k_conv_deep(const DeepArgs a) {
     // multiply stage (k, slot); `nx` != nullptr: the pieces of that stage are issued behind the MFMA blocks
     auto compute = [&](int k, int slot, const Stage* nx) {
       constexpr int PER = (NL + NS - 1) / NS;   // pieces per 16-channel step
-      if ((ABL & 4) || !((gm >> k) & 1u)) {
+      if (!((gm >> k) & 1u)) {
         if (nx) {
 #pragma unroll
           for (int q = 0; q < NL; ++q) issue_piece(*nx, q);
@@ -1887,7 +1888,7 @@ static DeepPlan plan_deep(int n_rows, int K, int cin, int cout, int cin2, bool u
     }
   }
   // mode >= 16 (experiments, tools/conv_bench.py --sweep): bits 0-3 = bn / 32, bits 4-7 = ch / 32, bits 8-15 = P (0: 256 / units),
-  // bits 19-20 = ring slots (0: three): that geometry wherever it divides the layer
+  // bit 19 = two ring slots instead of three: that geometry wherever it divides the layer
   int force[3] = {0, 0, 0};
   if (deep_mode() >= 16) force[0] = (deep_mode() & 15) * 32, force[1] = ((deep_mode() >> 4) & 15) * 32, force[2] = (deep_mode() >> 8) & 255;
   if (force[0] > 0 && force[1] > 0 && cout % force[0] == 0 && cin % force[1] == 0 && (cin2 <= 0 || cin2 % force[1] == 0)) {
@@ -1901,8 +1902,7 @@ static DeepPlan plan_deep(int n_rows, int K, int cin, int cout, int cin2, bool u
     if (P < 1) P = 1;
     if (units * P <= kSkMaxG && units <= kMaxQueuesPerOp - 2) {
       best.bn = bn, best.ch = ch, best.P = P, best.G = units * P, best.n_cblk = cout / bn, best.ntile = ntile, best.nchunk = cin / ch;
-      const int dsel = (deep_mode() >> 19) & 3;
-      best.D = dsel == 1 ? 2 : dsel == 2 ? 4 : 3;
+      best.D = ((deep_mode() >> 19) & 1) ? 2 : 3;
       best_t = 0.f;
     }
   }
@@ -1939,23 +1939,16 @@ static void allow_big_lds() {
   A3D_ALLOW_LDS(160 * 1024, k_conv_sk<64, 32, 2>);
   A3D_ALLOW_LDS(160 * 1024, k_conv_sk<32, 32, 2>);
 #define A3D_BIGD(BN_, CH_) \
-  A3D_ALLOW_LDS(160 * 1024, (k_conv_deep<BN_, CH_, false, 0, 3>)); \
-  A3D_ALLOW_LDS(160 * 1024, (k_conv_deep<BN_, CH_, true, 0, 3>)); \
-  A3D_ALLOW_LDS(160 * 1024, (k_conv_deep<BN_, CH_, false, 0, 2>)); \
-  A3D_ALLOW_LDS(160 * 1024, (k_conv_deep<BN_, CH_, true, 0, 2>)); \
-  A3D_ALLOW_LDS(160 * 1024, (k_conv_deep<BN_, CH_, false, 0, 3, 1>)); \
-  A3D_ALLOW_LDS(160 * 1024, (k_conv_deep<BN_, CH_, false, 0, 2, 1>)); \
-  A3D_ALLOW_LDS(160 * 1024, (k_conv_deep<BN_, CH_, false, 0, 3, 2>)); \
-  A3D_ALLOW_LDS(160 * 1024, (k_conv_deep<BN_, CH_, false, 0, 2, 2>));
+  A3D_ALLOW_LDS(160 * 1024, (k_conv_deep<BN_, CH_, false, 3>)); \
+  A3D_ALLOW_LDS(160 * 1024, (k_conv_deep<BN_, CH_, true, 3>)); \
+  A3D_ALLOW_LDS(160 * 1024, (k_conv_deep<BN_, CH_, false, 2>)); \
+  A3D_ALLOW_LDS(160 * 1024, (k_conv_deep<BN_, CH_, true, 2>)); \
+  A3D_ALLOW_LDS(160 * 1024, (k_conv_deep<BN_, CH_, false, 3, 1>)); \
+  A3D_ALLOW_LDS(160 * 1024, (k_conv_deep<BN_, CH_, false, 2, 1>)); \
+  A3D_ALLOW_LDS(160 * 1024, (k_conv_deep<BN_, CH_, false, 3, 2>)); \
+  A3D_ALLOW_LDS(160 * 1024, (k_conv_deep<BN_, CH_, false, 2, 2>));
   A3D_BIGD(128, 32) A3D_BIGD(64, 64) A3D_BIGD(64, 32) A3D_BIGD(32, 64) A3D_BIGD(32, 32)
 #undef A3D_BIGD
-  A3D_ALLOW_LDS(160 * 1024, (k_conv_deep<64, 64, false, 0, 4>));
-  A3D_ALLOW_LDS(160 * 1024, (k_conv_deep<32, 64, false, 0, 4>));
-#define A3D_BIGA(ABL_) \
-  A3D_ALLOW_LDS(160 * 1024, (k_conv_deep<64, 64, false, ABL_>)); \
-  A3D_ALLOW_LDS(160 * 1024, (k_conv_deep<32, 64, false, ABL_>));
-  A3D_BIGA(1) A3D_BIGA(2) A3D_BIGA(3) A3D_BIGA(4) A3D_BIGA(5) A3D_BIGA(6) A3D_BIGA(7)
-#undef A3D_BIGA
   A3D_ALLOW_LDS(160 * 1024, k_conv_wl<2, 2>);
   A3D_ALLOW_LDS(160 * 1024, k_conv_wl<4, 4>);
   A3D_ALLOW_LDS(160 * 1024, (k_conv_wl<2, 2, 1>));
@@ -2055,22 +2048,12 @@ static int launch_conv_sk(ConvArgs c, const int* pre64, float* slab_ws, size_t s
         a.dbg = dbg_buf;
         (void)hipMemsetAsync(dbg_buf, 0, (size_t)kSkMaxG * 6 * 8, st);
       }
-      const int abl = deep_mode() >= 16 ? (deep_mode() >> 16) & 7 : 0;
-      if ((abl || d.D == 4) && c.cin2 == 0 && ((d.bn == 64 && d.ch == 64) || (d.bn == 32 && d.ch == 64))) {   // tuning builds
-        if (d.D == 4) {
-          if (d.bn == 64) k_conv_deep<64, 64, false, 0, 4><<<d.G, 256, d.lds, st>>>(a); else k_conv_deep<32, 64, false, 0, 4><<<d.G, 256, d.lds, st>>>(a);
-        } else {
-#define A3D_LA(ABL_) \
-  if (abl == ABL_) { if (d.bn == 64) k_conv_deep<64, 64, false, ABL_><<<d.G, 256, d.lds, st>>>(a); else k_conv_deep<32, 64, false, ABL_><<<d.G, 256, d.lds, st>>>(a); } else
-          A3D_LA(1) A3D_LA(2) A3D_LA(3) A3D_LA(4) A3D_LA(5) A3D_LA(6) A3D_LA(7) {}
-#undef A3D_LA
-        }
-      } else if (stats) {
+      if (stats) {
         const bool two = d.D == 2;
 #define A3D_LT(BN_, CH_) \
   if (d.bn == BN_ && d.ch == CH_) { \
-    if (bw) { if (two) k_conv_deep<BN_, CH_, false, 0, 2, 2><<<d.G, 256, lds, st>>>(a); else k_conv_deep<BN_, CH_, false, 0, 3, 2><<<d.G, 256, lds, st>>>(a); } \
-    else { if (two) k_conv_deep<BN_, CH_, false, 0, 2, 1><<<d.G, 256, lds, st>>>(a); else k_conv_deep<BN_, CH_, false, 0, 3, 1><<<d.G, 256, lds, st>>>(a); } \
+    if (bw) { if (two) k_conv_deep<BN_, CH_, false, 2, 2><<<d.G, 256, lds, st>>>(a); else k_conv_deep<BN_, CH_, false, 3, 2><<<d.G, 256, lds, st>>>(a); } \
+    else { if (two) k_conv_deep<BN_, CH_, false, 2, 1><<<d.G, 256, lds, st>>>(a); else k_conv_deep<BN_, CH_, false, 3, 1><<<d.G, 256, lds, st>>>(a); } \
   } else
         A3D_LT(128, 32) A3D_LT(64, 64) A3D_LT(64, 32) A3D_LT(32, 64) A3D_LT(32, 32)
         { set_error("spconv: no deep kernel for BN %d CH %d", d.bn, d.ch); return A3D_ERR_UNSUPPORTED; }
@@ -2079,8 +2062,8 @@ static int launch_conv_sk(ConvArgs c, const int* pre64, float* slab_ws, size_t s
         const bool two = d.D == 2;
 #define A3D_LD(BN_, CH_) \
   if (d.bn == BN_ && d.ch == CH_) { \
-    if (c.cin2 > 0) { if (two) k_conv_deep<BN_, CH_, true, 0, 2><<<d.G, 256, d.lds, st>>>(a); else k_conv_deep<BN_, CH_, true, 0, 3><<<d.G, 256, d.lds, st>>>(a); } \
-    else { if (two) k_conv_deep<BN_, CH_, false, 0, 2><<<d.G, 256, d.lds, st>>>(a); else k_conv_deep<BN_, CH_, false, 0, 3><<<d.G, 256, d.lds, st>>>(a); } \
+    if (c.cin2 > 0) { if (two) k_conv_deep<BN_, CH_, true, 2><<<d.G, 256, d.lds, st>>>(a); else k_conv_deep<BN_, CH_, true, 3><<<d.G, 256, d.lds, st>>>(a); } \
+    else { if (two) k_conv_deep<BN_, CH_, false, 2><<<d.G, 256, d.lds, st>>>(a); else k_conv_deep<BN_, CH_, false, 3><<<d.G, 256, d.lds, st>>>(a); } \
   } else
         A3D_LD(128, 32) A3D_LD(64, 64) A3D_LD(64, 32) A3D_LD(32, 64) A3D_LD(32, 32)
         { set_error("spconv: no deep kernel for BN %d CH %d", d.bn, d.ch); return A3D_ERR_UNSUPPORTED; }

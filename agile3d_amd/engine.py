@@ -404,7 +404,7 @@ class _SceneState:
         # per-scene cache of the first decoder layer's click-to-scene keys / values (click-independent): allocated and
         # filled by the SECOND forward_mask on this backbone output, read by every later one
         self.mask_calls = 0
-        self.kv0 = None         # list[Tensor [2, n_b, 128]]
+        self.kv0 = None         # list[Tensor [3, n_b, 128]]: keys, values, scene-to-click queries of the first layer
         self.kv0_version = None
 
 
@@ -639,7 +639,7 @@ class Engine:
         n_layers = self.decoder.n_layers
         preds = [[] for _ in range(n_layers)]
         # The interactive loop calls forward_mask ~100 times on one backbone output (eval_multi_obj.py:112-160): from the
-        # second call on the scene's first-layer keys / values are kept (82 MB per 80 k voxels; A3D_KV_CACHE_MB caps the
+        # second call on the scene's first-layer keys / values / scene-to-click queries are kept (123 MB per 80 k voxels; A3D_KV_CACHE_MB caps the
         # total, 0 switches the cache off).  A single call per scene -- the throughput benchmark -- allocates nothing.
         st.mask_calls += 1
         kv_state = 0
@@ -653,9 +653,9 @@ class Engine:
                 kv_state = 2
             else:
                 st.kv0, st.kv0_version = None, None
-                total = sum(e - s for s, e in st.ranges) * 2 * 128 * 4
+                total = sum(e - s for s, e in st.ranges) * 3 * 128 * 4      # keys, values, scene-to-click queries of the first layer
                 if total <= _kv_cache_mb() * (1 << 20):
-                    kv_fill = [torch.empty((2, e - s, 128), dtype=torch.float32, device=self.device) for s, e in st.ranges]
+                    kv_fill = [torch.empty((3, e - s, 128), dtype=torch.float32, device=self.device) for s, e in st.ranges]
                     kv_state = 1
         kv_bufs = st.kv0 if kv_state == 2 else kv_fill
         with torch.no_grad():

@@ -233,7 +233,7 @@ size_t a3d_conv_state_bytes(void);
  * k_conv_deep -- static (tile, column block, part) workgroups, both operands by LDS-DMA three stages ahead, a cut tile
  * finished by its last arriver -- instead of the stream-K kernel.  mode 1 (default; A3D_CONV_DEEP in the environment) uses it
  * where its cost model prefers it, 0 never; mode < 0 only queries; mode >= 16 forces a geometry (tuning only: bn / 32 |
- * ch / 32 << 4 | parts << 8, tools/conv_bench.py --sweep).  Returns the mode in force before the call.  Workspaces
+ * ch / 32 << 4 | parts << 8 | two-slot ring << 19, tools/conv_bench.py --sweep).  Returns the mode in force before the call.  Workspaces
  * sized under one mode stay valid under the other (the launch falls back to the stream-K kernel when the slab is short). */
 int    a3d_conv_deep_mode(int mode);
 int    a3d_conv_apply_acc(const a3d_scene* s, int kind, int level_in, const float* x_dev, int ldx, int cin,
@@ -529,7 +529,9 @@ typedef struct a3d_decoder_sample {
   size_t workspace_bytes;
   /* Per-scene cache of the click-independent part of a pass (eval_multi_obj.py:112-160 runs ~100 passes per scene on
    * the same backbone output): the key / value projections of the FIRST layer's click-to-scene attention depend on
-   * the scene only (agile3d.py:283-290 with src = pcd_features).  kv0_dev: [2][n][128] floats owned by the caller;
+   * the scene only (agile3d.py:283-290 with src = pcd_features).  kv0_dev: [3][n][128] floats owned by the caller
+   * (keys, values, and -- round 5 -- the first layer's scene-to-click QUERIES (feats + pos) Wq^T + bq, agile3d.py:305-312, which
+   * depend on the scene only as well);
    * kv0_state 0 = not used, 1 = computed into kv0_dev by this call and used, 2 = valid from an earlier call with the same
    * features, position encodings and weights.  With the cache the first layer's attention reads K / V instead of
    * projecting them inside the fused kernel (39 instead of 75 us at 80 k points). */

@@ -49,7 +49,6 @@ def main():
     ap.add_argument("--reps", type=int, default=20)
     ap.add_argument("--only", default="")
     ap.add_argument("--sweep", action="store_true", help="small-level kernel: every geometry (bn, ch, parts) per case, against stream-K")
-    ap.add_argument("--ablate", default="", help="bn,ch,parts: that geometry with the ablation builds 0..7 (1 no gathers, 2 no weights, 4 no MFMAs)")
     a = ap.parse_args()
     lib = L.load()
     sc = make_scene(a.voxels, seed=0)
@@ -93,21 +92,6 @@ def main():
         else:
             pairs = slots = scene.n[lvl]
         fl = 2.0 * pairs * cin * cout
-        if a.ablate:
-            bn, ch, parts = (int(x) for x in a.ablate.split(","))
-            if cout % bn or cin % ch:
-                continue
-            row = [f"{name:20s} ({bn},{ch}) P={parts}:"]
-            for abl in range(8):
-                lib.a3d_conv_deep_mode((bn // 32) | (ch // 32) << 4 | parts << 8 | abl << 16)
-                b, _, t, _ = measure()
-                row.append(f"abl{abl} {t * 1e3:6.1f}")
-            for dsel, dd in ((1, 2), (2, 4)):   # two / four ring slots instead of three
-                lib.a3d_conv_deep_mode((bn // 32) | (ch // 32) << 4 | parts << 8 | dsel << 19)
-                row.append(f"| D={dd} {measure()[2] * 1e3:6.1f}")
-            lib.a3d_conv_deep_mode(1)
-            print(" ".join(row), flush=True)
-            continue
         if a.sweep:
             before = lib.a3d_conv_deep_mode(0)
             _, _, t_sk, _ = measure()
