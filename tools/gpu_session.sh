@@ -1,9 +1,6 @@
 #!/bin/bash
+# Scratch script of the current GPU session (overwritten per session; `gpurun -- 'bash tools/gpu_session.sh'`).
 R=$GRAFT_REPO_ROOT
 cd $R
-timeout 900 python bench.py --no-cpu-baseline > gpurun_out/bench_try.json 2>/dev/null
-python - <<'PY'
-import json
-d=json.loads(open("gpurun_out/bench_try.json").read().strip().splitlines()[-1])
-print(round(d["value"],1), d["latency_ms_per_scene"], d["value_batch4"], d["train_iter"])
-PY
+timeout 5400 bash tools/profile_round.sh r05 > gpurun_out/r05_profile_round.log 2>&1
+ls gpurun_out/r05 | wc -l
