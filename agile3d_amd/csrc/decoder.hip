@@ -243,7 +243,8 @@ struct DecSampleDev {
   float* logits;                   // [layers][n][K+1]
   unsigned char* labels;           // [n] arg-max object of the previous layer's mask
   int* counts;                     // [layers][A3D_MAX_QUERIES+1] points per object
-  float* part;                     // click-to-scene flash partials [slots][H][QP][kPartStride]
+  float* part;                     // click-to-scene flash partials [H][QP][slots][kPartStride]: the slots of one (head, query)
+                                   // side by side, which is what k_c2s_combine walks (coalesced 72-byte records)
   const int *qobj, *qrange;        // QueryMeta::obj / qrange (device)
   const float *qproj, *ks, *vs, *E;
   const float* q0;                 // the scene's cached layer-0 scene-to-click queries (src + pos) Wq^T + bq [n][128], or nullptr
@@ -347,12 +348,12 @@ __global__ void __launch_bounds__(512) k_c2s_attn(const float* __restrict__ Kc, 
       for (int t = 0; t < 4; ++t) acc[qt] = __builtin_amdgcn_mfma_f32_16x16x4f32(vf[t], p[t], acc[qt], 0, 0, 0);
     }
   }
-  float* P = part + (((size_t)blockIdx.x * H + h) * qp_total + qb0) * kPartStride;
+  // record of (head h, query q, chunk): [h][q][chunk] -- the chunks of a (head, query) are contiguous for k_c2s_combine
 #pragma unroll
   for (int qt = 0; qt < QT; ++qt) {
     float lt = l[qt];
     lt = rows_sum(lt);
-    float* pq = P + (size_t)(qt * 16 + j) * kPartStride;
+    float* pq = part + (((size_t)h * qp_total + qb0 + qt * 16 + j) * gridDim.x + blockIdx.x) * kPartStride;
     if (g == 0) {
       pq[0] = m[qt];
       pq[1] = lt;
@@ -572,12 +573,11 @@ __global__ void __launch_bounds__(512) k_kv_c2s(const DecSampleDev* __restrict__
 #pragma unroll
   for (int hl = 0; hl < HW; ++hl) {
     const int h = h0 + hl;
-    float* P = part + ((size_t)slot * H + h) * qp_total * kPartStride;
 #pragma unroll
     for (int qt = 0; qt < QT; ++qt) {
       float lt = l[hl][qt];
       lt = rows_sum(lt);
-      float* pq = P + (size_t)(qt * 16 + j) * kPartStride;
+      float* pq = part + (((size_t)h * qp_total + qt * 16 + j) * nslots + slot) * kPartStride;
       if (g == 0) {
         gst(pq, m[hl][qt]);
         gst(pq + 1, lt);
@@ -601,7 +601,7 @@ __global__ void __launch_bounds__(64) k_c2s_combine(const QuerySample* __restric
 #pragma unroll
   for (int d = 0; d < DH; ++d) o[d] = 0.f;
   for (int ch = lane; ch < nchunk; ch += 64) {
-    const float* p = part + (((size_t)ch * H + h) * QP + q) * kPartStride;
+    const float* p = part + (((size_t)h * QP + q) * nchunk + ch) * kPartStride;
     const float pm = gld(p);
     const float mn = fmaxf(m, pm);
     const float a = exp2f(m - mn), b = exp2f(pm - mn);   // the partials' maxima are log2-domain scores
