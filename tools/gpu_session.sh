@@ -1,10 +1,11 @@
 #!/bin/bash
+# Scratch script of the current GPU session (overwritten per session; `gpurun -- 'bash tools/gpu_session.sh'`).
 R=$GRAFT_REPO_ROOT
 cd $R
-O=gpurun_out/d26
+O=gpurun_out/final
 mkdir -p $O
-timeout 3000 python -m pytest tests/test_gpu_model.py tests/test_gpu_clicks.py tests/test_gpu_fit.py -q -x > $O/tests.log 2>&1; echo "tests rc=$?"
-tail -3 $O/tests.log
-python tools/qc_probe.py 2>&1 | grep -v amdgpu | sed -n 1,12p
-CPO=8 python tools/qc_probe.py 2>&1 | grep -v amdgpu | sed -n 1,15p
-CPO=30 python tools/qc_probe.py 2>&1 | grep -v amdgpu | grep -E "query_chain|back-to-back"
+python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; echo "smoke rc=$?"; tail -2 $O/smoke.log
+timeout 3000 python -m pytest tests -m gpu -q > $O/gpu_tests.log 2>&1; echo "gpu tests rc=$?"
+tail -3 $O/gpu_tests.log
+timeout 5400 bash tools/profile_round.sh r05 > gpurun_out/r05_profile_round.log 2>&1
+ls gpurun_out/r05 | wc -l
