@@ -157,8 +157,10 @@ __device__ __forceinline__ void wait_all_vmem() { __builtin_amdgcn_s_waitcnt(0x0
 // instead of 8 BN / 16: the low-register build, 3-4 workgroups per CU)
 // PAIR == 2 (opt-in, A3D_CONV_EMU=1, 96 columns x 32 channels only): fp32 products from SIX bf16 MFMAs -- both operands
 // split into three bf16 planes (x = h + m + l by truncation, every remainder exact), h h + h m + m h + h l + m m + l h on
-// v_mfma_f32_16x16x32_bf16 with fp32 accumulation.  Error no larger than the exact fp32 MFMA chain's (tools/
-// bf16x6_ubench.hip: 5.1e-6 against 7.5e-6 over 2592 products), stage loop 1.84x faster; weights packed as three planes.
+// v_mfma_f32_16x16x32_bf16 with fp32 accumulation.  Error: tools/bf16x6_ubench.hip (5.1e-6 against the exact chain's 7.5e-6
+// over 2592 products) and, bounded per shape class on adversarial inputs, tests/test_gpu_conv.py::
+// test_emulated_fp32_products_error_bound (a-priori (2^-20 + 6 (K cin / 32) 2^-24) sum|x||w|; domain |x| >= 2^-100 or 0: the
+// matrix cores drop subnormal bf16 planes); stage loop 1.84x faster; weights packed as three planes.
 // FUSE: the block's residual projection (BasicBlock.downsample: 1x1 conv + BatchNorm on the block input,
 // resnet_block.py:59-61) as one more "offset" of the block's second conv: every tile ends with cin2 / CH stages that
 // gather the output rows themselves from the block input and multiply them with the 1x1 weight (both BatchNorm scales

@@ -38,8 +38,9 @@ def Evaluate(model, data_loader, args, device, on_round=None):
             coords, raw_coords, feats, labels, labels_full, inverse_map, click_idx, scene_name, num_obj = batch
             coords = coords.to(device)
             raw_coords = raw_coords.to(device)
-            labels = [l.to(device) for l in labels]
-            labels_full = [l.to(device) for l in labels_full]
+            # object ids as int32 ONCE per scene: the IoU / click kernels read int32 and would convert per round otherwise
+            labels = [l.to(device=device, dtype=torch.int32) for l in labels]
+            labels_full = [l.to(device=device, dtype=torch.int32) for l in labels_full]
             inverse_map = [(m if torch.is_tensor(m) else torch.as_tensor(np.asarray(m))).to(device)
                            for m in inverse_map]
             data = SparseTensor(coordinates=coords, features=feats, device=device)
@@ -95,8 +96,9 @@ def EvaluateSingle(model, data_loader, args, device, on_round=None):
             coords, raw_coords, feats, labels, labels_full, inverse_map, _click_idx, scene_name, object_id = batch
             coords = coords.to(device)
             raw_coords = raw_coords.to(device)
-            labels = [l.to(device) for l in labels]
-            labels_full = [l.to(device) for l in labels_full]
+            # object ids as int32 ONCE per scene: the IoU / click kernels read int32 and would convert per round otherwise
+            labels = [l.to(device=device, dtype=torch.int32) for l in labels]
+            labels_full = [l.to(device=device, dtype=torch.int32) for l in labels_full]
             inverse_map = [(m if torch.is_tensor(m) else torch.as_tensor(np.asarray(m))).to(device)
                            for m in inverse_map]
             data = SparseTensor(coordinates=coords, features=feats, device=device)

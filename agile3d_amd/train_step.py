@@ -379,7 +379,8 @@ def evaluate(model, criterion, data_loader, args, epoch, device):
             coords, raw_coords, feats, labels, labels_full, inverse_map, click_idx, scene_name, num_obj = batch
             coords, raw_coords = coords.to(device), raw_coords.to(device)
             labels = [l.to(device) for l in labels]
-            labels_full = [l.to(device) for l in labels_full]
+            labels_full = [l.to(device=device, dtype=torch.int32) for l in labels_full]
+            labels_i32 = [l.to(torch.int32) for l in labels]     # for the IoU / click kernels: converted once, not per round
             inverse_map = [(m if torch.is_tensor(m) else torch.as_tensor(np.asarray(m))).to(device) for m in inverse_map]
             batch_idx = coords[:, 0]
             n_samples = int(batch_idx.max()) + 1
@@ -405,11 +406,11 @@ def evaluate(model, criterion, data_loader, args, epoch, device):
                         pred = torch.zeros(labels[idx].shape[0], dtype=torch.int32, device=device)
                     else:
                         pred = argmax_labels(outputs["pred_masks"][idx], click_idx[idx])        # + sparse-gt update
-                        miou += float(mean_iou_scene(pred, labels[idx])[0])
+                        miou += float(mean_iou_scene(pred, labels_i32[idx])[0])
                     iou, _ = mean_iou_scene(pred, labels_full[idx], inverse_map[idx])
                     f.write(f"{instance_counter + idx} {scene_name[idx].replace('scene', '')} {num_obj[idx]} "
                             f"{current / num_obj[idx]} {iou.cpu().numpy()}\n")
-                    new_clicks, _, _, new_time = get_simulated_clicks(pred, labels[idx], raw_coords[masks[idx]], current,
+                    new_clicks, _, _, new_time = get_simulated_clicks(pred, labels_i32[idx], raw_coords[masks[idx]], current,
                                                                       training=False)
                     if new_clicks is not None:
                         extend_clicks(click_idx[idx], click_time_idx[idx], new_clicks, new_time)

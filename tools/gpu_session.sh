@@ -1,11 +1,16 @@
 #!/bin/bash
-# Scratch script of the current GPU session (overwritten per session; `gpurun -- 'bash tools/gpu_session.sh'`).
-R=$GRAFT_REPO_ROOT
+set -u
+R=$(pwd); O=$R/gpurun_out/s15; mkdir -p $O
 cd $R
-O=gpurun_out/final
-mkdir -p $O
-python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; echo "smoke rc=$?"; tail -2 $O/smoke.log
-timeout 3000 python -m pytest tests -m gpu -q > $O/gpu_tests.log 2>&1; echo "gpu tests rc=$?"
-tail -3 $O/gpu_tests.log
-timeout 5400 bash tools/profile_round.sh r05 > gpurun_out/r05_profile_round.log 2>&1
-ls gpurun_out/r05 | wc -l
+timeout 1700 python -m pytest tests/test_gpu_conv.py -x -q -m gpu -k "error_bound" > $O/emu_bound.txt 2>&1; echo "emu bound rc=$?"; tail -1 $O/emu_bound.txt
+timeout 2400 python -m pytest tests/test_gpu_clicks.py tests/test_gpu_fit.py tests/test_gpu_model.py tests/test_gpu_backward.py -x -q -m gpu -k "eval or valid or Eval or fit or epoch or click" > $O/eval_tests.txt 2>&1; echo "eval tests rc=$?"; tail -2 $O/eval_tests.txt
+cd /tmp; export TMPDIR=/tmp
+timeout 1200 python $R/bench.py > $O/bench.json 2> $O/bench.err; echo "bench rc=$?"
+python - <<PY
+import json
+d = json.loads([l for l in open("$O/bench.json") if l.startswith("{")][-1])
+for k in ("value", "latency_ms_per_scene", "decoder_pass_ms_single", "eval_round_ms", "eval_rounds_per_s", "value_batch4"):
+    print(k, d.get(k))
+print(json.dumps(d.get("emulated_fp32_products"), indent=1)[:1500])
+print(d["roofline"]["frac"], d["train_iter"]["ms_without_click_rounds"], d["train_iter"]["ms_per_click_round"])
+PY
