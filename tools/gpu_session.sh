@@ -1,17 +1,9 @@
 #!/bin/bash
+# final validation of the round: smoke, the whole GPU suite, then every r05 artefact regenerated from HEAD
 set -u
-R=$(pwd); O=$R/gpurun_out/s16; mkdir -p $O
-cd /tmp; export TMPDIR=/tmp
-ER_BATCH=1 ER_ROUNDS=12 timeout 600 rocprofv3 --kernel-trace --stats -d $O/prof -o er -- python $R/tools/eval_round_probe.py > $O/prof.log 2>&1
-python - <<PY
-import sqlite3, glob
-db = sqlite3.connect(glob.glob("$O/prof/*.db")[0])
-c = db.cursor()
-rows = list(c.execute("select name, start, end from kernels order by start"))
-# the last full round: from the last k_query_init to the end
-idx = [i for i, r in enumerate(rows) if "k_query_init" in r[0]]
-a = idx[-2]; b = idx[-1]
-t0 = rows[a][1]
-for r in rows[a:b]:
-    print("%8.1f %7.1f  %s" % ((r[1] - t0) / 1e3, (r[2] - r[1]) / 1e3, r[0][:90]))
-PY
+R=$(pwd); O=$R/gpurun_out/final; mkdir -p $O
+cd $R
+timeout 600 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; echo "smoke rc=$?"; tail -2 $O/smoke.log
+timeout 2400 python -m pytest tests/ -x -q -m gpu > $O/gpu_tests.log 2>&1; echo "gpu tests rc=$?"; tail -2 $O/gpu_tests.log
+timeout 2400 bash tools/profile_round.sh r05 > $R/gpurun_out/r05_profile_round.log 2>&1; echo "profile_round rc=$?"
+tail -5 $R/gpurun_out/r05_profile_round.log
