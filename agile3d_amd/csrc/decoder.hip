@@ -569,22 +569,56 @@ __global__ void __launch_bounds__(512) k_kv_c2s(const DecSampleDev* __restrict__
       }
     }
   }
-  // one flash partial (m, l, acc[16]) per wave slot, head and query -- merged by k_c2s_combine
+  // The SPW slot groups of the workgroup hold flash states of the same heads and queries over different points: they are
+  // merged here, through the LDS the weights no longer need, and the workgroup writes ONE partial (m, l, acc[16]) per head
+  // and query -- a quarter / half of the records k_c2s_combine has to walk (1 024 -> 256 per (head, query) for one scene).
+  // A lane's l is still its own partial sum (rows_sum is linear), m is uniform over the four lanes of a query column.
+  {
+    constexpr int REC = 6 * 64;   // floats per (wave, head, query tile): m, l, acc[4] x 64 lanes, lane-contiguous
+    float* red = (float*)smem;    // [SPW - 1][WPG][HW * QT][6][64]
+    const int sg = wave / WPG, wl = wave % WPG;
+    __syncthreads();              // every wave is through with the weights
+    if (sg > 0) {
 #pragma unroll
-  for (int hl = 0; hl < HW; ++hl) {
-    const int h = h0 + hl;
+      for (int hl = 0; hl < HW; ++hl)
 #pragma unroll
-    for (int qt = 0; qt < QT; ++qt) {
-      float lt = l[hl][qt];
-      lt = rows_sum(lt);
-      float* pq = part + (((size_t)h * qp_total + qt * 16 + j) * nslots + slot) * kPartStride;
-      if (g == 0) {
-        gst(pq, m[hl][qt]);
-        gst(pq + 1, lt);
-      }
+        for (int qt = 0; qt < QT; ++qt) {
+          float* r = red + ((size_t)((sg - 1) * WPG + wl) * (HW * QT) + hl * QT + qt) * REC + lane;
+          r[0] = m[hl][qt];
+          r[64] = l[hl][qt];
 #pragma unroll
-      for (int t = 0; t < 4; ++t) gst(pq + 2 + 4 * g + t, acc[hl][qt][t]);
+          for (int t = 0; t < 4; ++t) r[128 + 64 * t] = acc[hl][qt][t];
+        }
     }
+    __syncthreads();
+    if (sg > 0) return;
+#pragma unroll
+    for (int hl = 0; hl < HW; ++hl)
+#pragma unroll
+      for (int qt = 0; qt < QT; ++qt) {
+        float mm = m[hl][qt], ll = l[hl][qt];
+        f32x4 aa = acc[hl][qt];
+#pragma unroll
+        for (int o = 1; o < SPW; ++o) {
+          const float* r = red + ((size_t)((o - 1) * WPG + wl) * (HW * QT) + hl * QT + qt) * REC + lane;
+          const float mo = r[0];
+          const float mnew = fmaxf(mm, mo);
+          const float sa = exp2_fast(mm - mnew), sb = exp2_fast(mo - mnew);
+          mm = mnew;
+          ll = ll * sa + r[64] * sb;
+#pragma unroll
+          for (int t = 0; t < 4; ++t) aa[t] = aa[t] * sa + r[128 + 64 * t] * sb;
+        }
+        const int h = h0 + hl;
+        const float lt = rows_sum(ll);
+        float* pq = part + (((size_t)h * qp_total + qt * 16 + j) * nwg + lb) * kPartStride;
+        if (g == 0) {
+          gst(pq, mm);
+          gst(pq + 1, lt);
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) gst(pq + 2 + 4 * g + t, aa[t]);
+      }
   }
 }
 constexpr int kFusedC2SGrid = 256;   // one persistent 8-wave workgroup per CU (128 KB of weights in LDS)
@@ -2540,7 +2574,6 @@ static int run_decoder(const a3d_decoder_weights* w, Prepared* P, int ns, hipStr
   }
   // which of the wide phases run as one fused launch for the batch
   const bool fuse_c2s = fused_c2s() && nblk == 1;   // up to 64 queries (k_kv_c2s<1..4>)
-  constexpr int c2s_spw = QT <= 2 ? 4 : 2;           // point groups in flight per workgroup = flash partials per workgroup
   const bool fuse_s2c = fused_c2s() && nblk == 1;
   const bool fuse_out = fuse_s2c && fused_lds <= 160 * 1024;
   // scene-to-click + output projection + LayerNorm + mask head as ONE kernel when both packed weight matrices and the
@@ -2614,7 +2647,7 @@ static int run_decoder(const a3d_decoder_weights* w, Prepared* P, int ns, hipStr
       hq[si].posenc = p.posenc;
       hq[si].counts = p.counts;
       hq[si].part = p.part;
-      hq[si].n_part = fuse_c2s ? (p.wg_end - p.wg_begin) * c2s_spw : p.L.nchunk;
+      hq[si].n_part = fuse_c2s ? (p.wg_end - p.wg_begin) : p.L.nchunk;   // k_kv_c2s merges its slot groups: one partial per workgroup
       hq[si].n_part0 = p.L.nchunk;
     }
     // pageable source: the runtime stages it before returning
