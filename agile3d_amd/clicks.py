@@ -120,7 +120,7 @@ def mean_iou_scene_batch(preds, labels, inverse_maps=None):
 
 
 def mean_iou_scene(pred, labels, inverse_map=None):
-    """utils/seg.py:44-58.  Returns (mean IoU as a 0-d float32 tensor, {object id: IoU}); the fp32
+    """utils/seg.py:44-59.  Returns (mean IoU as a 0-d float32 tensor, {object id: IoU}); the fp32
     arithmetic (int counts -> fp32 divide -> sequential fp32 sum) is the reference's."""
     return _mean_iou_from_counts(iou_counts(pred, labels, inverse_map))
 
@@ -167,7 +167,7 @@ def _parse_clusters(host: np.ndarray):
 
 
 def error_clusters(pred, labels, coords):
-    """Per error cluster (ascending cluster id = 96*label + 11*pred, utils/seg.py:206): the point
+    """Per error cluster (ascending cluster id = 96*label + 11*pred, utils/seg.py:186): the point
     farthest from everything outside the cluster and that distance.  List of dicts
     {cluster_id, row, label, pred, error_size}."""
     p, l = _i32(pred), _i32(labels)
@@ -226,7 +226,7 @@ def error_clusters_batch(preds, labels, coords, max_streams: int = 8):
 
 
 def _pick_clicks(clusters, coords_qv, num_obj, current_num_clicks, training):
-    """The host half of utils/seg.py:177-228 (ranking, the one ``random.shuffle``, the click dictionaries)."""
+    """The host half of utils/seg.py:173-226 (ranking, the one ``random.shuffle``, the click dictionaries)."""
     if not clusters:
         return None, None, None, None
     by_id = {c["cluster_id"]: c for c in clusters}
@@ -346,7 +346,7 @@ def pick_clicks_batch(clusters, labels, coords, current_num_clicks=None, trainin
 
 
 def get_simulated_clicks(pred_qv, labels_qv, coords_qv, current_num_clicks=None, training=True):
-    """utils/seg.py:177-228.  Same returns: (new_clicks {str(label): [rows]}, click_num,
+    """utils/seg.py:173-226.  Same returns: (new_clicks {str(label): [rows]}, click_num,
     new_click_pos {str(label): [xyz tensors]}, new_click_time {str(label): [order]}), or four Nones when
     the prediction is already right.  Consumes the global ``random`` stream like the reference
     (one ``random.shuffle`` of the selected cluster ids)."""
@@ -356,7 +356,7 @@ def get_simulated_clicks(pred_qv, labels_qv, coords_qv, current_num_clicks=None,
 
 
 def extend_clicks(current_clicks, current_clicks_time, new_clicks, new_click_time):
-    """utils/seg.py:231-242."""
+    """utils/seg.py:229-239."""
     offset = sum(len(v) for v in current_clicks_time.values())
     for obj_id, rows in new_clicks.items():
         current_clicks[obj_id].extend(rows)
@@ -365,7 +365,7 @@ def extend_clicks(current_clicks, current_clicks_time, new_clicks, new_click_tim
 
 
 def cal_click_loss_weights(batch_idx, raw_coords, labels, click_idx, alpha=0.8, beta=2.0, tita=0.3, ranges=None):
-    """utils/seg.py:71-89: per sample, weights[i] = alpha + (beta-alpha)(1 - min(d_i, tita)/tita) with
+    """utils/seg.py:72-89: per sample, weights[i] = alpha + (beta-alpha)(1 - min(d_i, tita)/tita) with
     d_i the distance of point i to the nearest click of any object.  ``ranges`` [(first row, end row)] per sample, when the
     caller knows them (the rows of a sample are contiguous in a collated batch): no boolean-mask gathers, no host syncs."""
     lib = L.load()

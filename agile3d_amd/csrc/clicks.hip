@@ -3,9 +3,9 @@
 //
 // Replaces (reference file:line):
 //   p.argmax(-1) + "update prediction with sparse gt"      eval_multi_obj.py:119-134
-//   mean_iou_scene / mean_iou_single                        utils/seg.py:10-18,44-58
+//   mean_iou_scene / mean_iou_single                        utils/seg.py:10-18,44-59
 //   get_simulated_clicks / measure_error_size / get_next_click_coo_torch   utils/seg.py:93-239
-//   loss_weights                                            utils/seg.py:60-69
+//   loss_weights                                            utils/seg.py:62-70
 //
 // The simulator's cost is measure_error_size: for every wrongly labelled point the distance to the
 // nearest point that is NOT in its error cluster (the reference builds the full [other x cluster]

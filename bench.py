@@ -231,7 +231,7 @@ def explain_forks(model, sd, items, oracle_bb, gpu_log, oracle_log, dev, logit_t
         eval_multi_obj.py:126 take the argmax at face value);
       * "distance tie": same labels, but the next click differs -- both sides' candidates are the arg-max of the cluster's
         outside distance IN THEIR OWN ARITHMETIC (the reference and the oracle use torch.cdist = the matmul formula, error
-        ~sqrt(eps)|x| near zero, utils/seg.py:161-175; clicks.hip the exact difference expression), and their float64
+        ~sqrt(eps)|x| near zero, utils/seg.py:157-171; clicks.hip the exact difference expression), and their float64
         distances differ by less than cdist's own error on those two points;
     anything else is reported as "unexplained" (a bug).  After its first fork a scene's two runs hold different clicks and
     are not compared any further.  Returns {"scenes": [...], "unexplained": n, "compared_rounds": n, "identical_rounds": n}."""

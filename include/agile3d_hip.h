@@ -559,8 +559,8 @@ int    a3d_decoder_forward(const a3d_decoder_weights* w,
 /* ------------------------------------------------------------------------------------------
  * The interactive loop around forward_mask.
  * Replaces: `p.argmax(-1)` + "update prediction with sparse gt" (eval_multi_obj.py:119-134),
- * mean_iou_scene (utils/seg.py:44-58), get_simulated_clicks + measure_error_size +
- * get_next_click_coo_torch (utils/seg.py:93-239) and loss_weights (utils/seg.py:60-69).
+ * mean_iou_scene (utils/seg.py:44-59), get_simulated_clicks + measure_error_size +
+ * get_next_click_coo_torch (utils/seg.py:93-239) and loss_weights (utils/seg.py:62-70).
  * Labels and predictions are int32 object ids in 0..255 (0 = background).
  * ------------------------------------------------------------------------------------------ */
 #define A3D_MAX_CLICKS 256
@@ -580,7 +580,7 @@ int    a3d_iou_counts(const int32_t* pred_dev, int64_t n_pred, const int64_t* in
                       int64_t* counts_dev, void* stream);
 
 /* One entry per error cluster (cluster id = 96*label + 11*pred over the wrongly labelled points,
- * utils/seg.py:206): `row` is the cluster point farthest from every point outside the cluster
+ * utils/seg.py:186): `row` is the cluster point farthest from every point outside the cluster
  * (lowest row on ties), `error_size` that distance -- the next simulated click and the key the
  * reference sorts clusters by.  Entries come out in ascending cluster id (torch.unique order). */
 typedef struct {

@@ -6,10 +6,10 @@ plain torch-CPU; PINNED: ``tests/golden/make_click_goldens.py`` runs the referen
 inputs and ``tests/test_oracle_clicks.py`` re-checks this file against the stored outputs
 (click rows, click order under the same ``random.seed``, IoU bits, weights).
 
-Reference lines followed: mean_iou_scene utils/seg.py:44-58, loss_weights :60-69,
-cal_click_loss_weights :71-89, get_next_click_coo_torch :93-118,
-get_next_simulated_click_multi :120-158, measure_error_size :161-175,
-get_simulated_clicks :177-228, extend_clicks :231-242.
+Reference lines followed: mean_iou_scene utils/seg.py:44-59, loss_weights :62-70,
+cal_click_loss_weights :72-89, get_next_click_coo_torch :93-117,
+get_next_simulated_click_multi :119-154, measure_error_size :157-171,
+get_simulated_clicks :173-226, extend_clicks :229-239.
 """
 from __future__ import annotations
 
@@ -27,7 +27,7 @@ def iou_single(pred_is_obj: torch.Tensor, label_is_obj: torch.Tensor) -> torch.T
 
 
 def mean_iou_scene(pred: torch.Tensor, labels: torch.Tensor):
-    """utils/seg.py:44-58 -- mean over the non-zero object ids present in ``labels``."""
+    """utils/seg.py:44-59 -- mean over the non-zero object ids present in ``labels``."""
     ids = torch.unique(labels)
     ids = ids[ids != 0]
     total = 0.0
@@ -41,19 +41,19 @@ def mean_iou_scene(pred: torch.Tensor, labels: torch.Tensor):
 
 
 def loss_weights(points: torch.Tensor, clicks: torch.Tensor, tita: float, alpha: float, beta: float):
-    """utils/seg.py:60-69."""
+    """utils/seg.py:62-70."""
     d = torch.cdist(points, clicks).min(dim=1).values
     return alpha + (beta - alpha) * (1 - torch.clamp(d, max=tita) / tita)
 
 
 def click_loss_weights(raw_coords: torch.Tensor, click_idx: dict, alpha=0.8, beta=2.0, tita=0.3):
-    """One sample of cal_click_loss_weights (utils/seg.py:71-89): clicks of all objects, dict order."""
+    """One sample of cal_click_loss_weights (utils/seg.py:72-89): clicks of all objects, dict order."""
     rows = [int(r) for v in click_idx.values() for r in v]
     return loss_weights(raw_coords, raw_coords[rows], tita, alpha, beta)
 
 
 def outside_distance(coords: torch.Tensor, in_cluster: torch.Tensor):
-    """measure_error_size (utils/seg.py:161-175): for every cluster point the distance to the nearest
+    """measure_error_size (utils/seg.py:157-171): for every cluster point the distance to the nearest
     point outside the cluster, in cluster-local order; None if either side is empty."""
     if int(in_cluster.sum()) == 0 or int((~in_cluster).sum()) == 0:
         return None
@@ -61,7 +61,7 @@ def outside_distance(coords: torch.Tensor, in_cluster: torch.Tensor):
 
 
 def error_clusters(pred: torch.Tensor, labels: torch.Tensor, coords: torch.Tensor):
-    """The per-cluster part of get_simulated_clicks (utils/seg.py:183-213).
+    """The per-cluster part of get_simulated_clicks (utils/seg.py:186-211).
 
     Returns a list (ascending cluster id, = torch.unique order) of dicts
     {cluster_id, row, label, pred, error_size}: ``row`` is the first cluster point (global row)
@@ -88,7 +88,7 @@ def error_clusters(pred: torch.Tensor, labels: torch.Tensor, coords: torch.Tenso
 
 
 def get_simulated_clicks(pred, labels, coords, current_num_clicks=None, training=True):
-    """utils/seg.py:177-228 (+ :120-158).  Uses the global ``random`` stream exactly once
+    """utils/seg.py:173-226 (+ :119-154).  Uses the global ``random`` stream exactly once
     (``random.shuffle`` of the selected cluster ids), as the reference does."""
     clusters = error_clusters(pred, labels, coords)
     if not clusters:
@@ -113,7 +113,7 @@ def get_simulated_clicks(pred, labels, coords, current_num_clicks=None, training
 
 
 def extend_clicks(current_clicks, current_clicks_time, new_clicks, new_click_time):
-    """utils/seg.py:231-242: append, shifting the new times by the number of clicks so far."""
+    """utils/seg.py:229-239: append, shifting the new times by the number of clicks so far."""
     base = sum(len(v) for v in current_clicks_time.values())
     for obj_id, rows in new_clicks.items():
         current_clicks[obj_id].extend(rows)

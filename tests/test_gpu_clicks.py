@@ -128,7 +128,7 @@ def test_iou_and_weights_vs_reference(name):
     assert np.array_equal(np.array(list(per.values())), G[f"{name}/iou_vals"])
     c2 = unflat(G[f"{name}/extend/keys"], G[f"{name}/extend/lens"], G[f"{name}/extend/rows"])
     w = pc.cal_click_loss_weights(torch.zeros(len(lab), dtype=torch.long, device="cuda"), xyz, [lab], [c2])[0]
-    # exact float64 statement of utils/seg.py:60-69 ...
+    # exact float64 statement of utils/seg.py:62-70 ...
     x64 = G[f"{name}/xyz"].astype(np.float64)
     rows = [r for v in c2.values() for r in v]
     d = cKDTree(x64[rows]).query(x64)[0]
