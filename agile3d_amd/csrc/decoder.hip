@@ -259,6 +259,8 @@ __device__ __forceinline__ const float* layer_input(const DecSampleDev& sm, int 
   return l == 0 ? sm.feats : (((l - 1) & 1) ? sm.bufD : sm.bufC);
 }
 
+#include "decoder_wide.h"
+
 // ------------------------------------------------------------------------------ click-to-scene
 // One wave = one head over a chunk of points.  S = K_h q_h^T (A = key rows, B = q^T), online
 // softmax per query column (lane-local: column = lane & 15), O^T += V_h^T P.
@@ -2455,6 +2457,15 @@ static bool fused_c2s() {   // A3D_FUSED_C2S=0 keeps the separate K / V GEMMs + 
   return v != 0;
 }
 
+static bool fused_wide() {   // A3D_FUSED_WIDE=0 (or A3D_FUSED_C2S=0) keeps the unfused kernels above 64 queries (A/B switch, tests)
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("A3D_FUSED_WIDE");
+    v = e ? atoi(e) : 1;
+  }
+  return v != 0 && fused_c2s();
+}
+
 // one batch sample on the host: validated query list, workspace layout and the views into its workspace
 struct Prepared {
   QueryMeta hm;
@@ -2465,6 +2476,7 @@ struct Prepared {
   float* logits;
   float* kv0 = nullptr;   // the scene's cached first-layer keys / values / scene-to-click queries [3][n][128] (a3d_decoder_sample::kv0_dev) and their state
   int kv0_state = 0;
+  int qtw = 0;            // tile count of the fused wide tier (decoder_wide.h) that serves this sample, 0 = none
   // views
   float *bufA, *bufB, *bufC, *bufD, *part;
   unsigned char* labels;
@@ -2495,6 +2507,140 @@ struct Prepared {
     B.hidden = (float*)(ws + L.q[11]);
   }
 };
+
+// The device tables of one call -- the samples' QueryMeta records, the wide kernels' sample table (workgroups in proportion to
+// the samples' point groups) and the query-side table -- built on the host and uploaded in ONE copy into the first sample's
+// workspace.  wg_per_group: a workgroup (not a wave) takes a 16-point group (decoder_wide.h); part_per_wg: the click-to-scene
+// kernel writes one flash partial per workgroup.
+struct DecTables {
+  int grid;
+  DecSampleDev* samples_dev;
+  QuerySample* qs_dev;
+};
+static int upload_tables(Prepared* P, int ns, bool wg_per_group, bool part_per_wg, hipStream_t st, DecTables& T) {
+  // the upload block in the first sample's workspace: [ns QueryMeta][ns DecSampleDev][ns QuerySample]
+  char* const up_dev = P[0].ws + P[0].L.desc;
+  const size_t up_meta = 0, up_samples = (sizeof(QueryMeta) * ns + 15) & ~(size_t)15;
+  const size_t up_qs = (up_samples + sizeof(DecSampleDev) * ns + 15) & ~(size_t)15;
+  const size_t up_bytes = up_qs + sizeof(QuerySample) * ns;
+  for (int si = 0; si < ns; ++si) P[si].meta = (QueryMeta*)(up_dev + up_meta) + si;
+  // ---- sample table: workgroups of the persistent kernels in proportion to the samples' point groups
+  int grid = 0;
+  T.samples_dev = (DecSampleDev*)(up_dev + up_samples);
+  T.qs_dev = (QuerySample*)(up_dev + up_qs);
+  {
+    std::vector<char> up_host(up_bytes);
+    for (int si = 0; si < ns; ++si) memcpy(up_host.data() + up_meta + sizeof(QueryMeta) * si, &P[si].hm, sizeof(QueryMeta));
+    DecSampleDev* hd = (DecSampleDev*)(up_host.data() + up_samples);
+    int64_t tot_groups = 0;
+    for (int si = 0; si < ns; ++si) tot_groups += (P[si].n + 15) / 16;
+    const int max_grid = 256;
+    for (int si = 0; si < ns; ++si) {
+      Prepared& p = P[si];
+      const int ngroups = (p.n + 15) / 16;
+      int share = (int)((int64_t)max_grid * ngroups / tot_groups);
+      const int useful = wg_per_group ? ngroups : (ngroups + 7) / 8;   // eight waves take a group each, or the workgroup takes one
+      share = share < 1 ? 1 : share;
+      share = share > useful ? useful : share;
+      p.wg_begin = grid;
+      p.wg_end = grid += share;
+      DecSampleDev& d = hd[si];
+      d.wg_begin = p.wg_begin;
+      d.wg_end = p.wg_end;
+      d.n = p.n;
+      d.nq = p.hm.nq;
+      d.K = p.hm.K;
+      d.n_fg = p.hm.n_fg;
+      d.feats = p.feats;
+      d.posenc = p.posenc;
+      d.bufB = p.bufB;
+      d.bufC = p.bufC;
+      d.bufD = p.bufD;
+      d.logits = p.logits;
+      d.labels = p.labels;
+      d.counts = p.counts;
+      d.part = p.part;
+      d.qobj = p.meta->obj;          // addresses inside the device copy of QueryMeta
+      d.qrange = p.meta->qrange;
+      d.qproj = p.B.qproj;
+      d.ks = p.B.ks;
+      d.vs = p.B.vs;
+      d.E = p.B.E;
+      d.q0 = p.kv0 && p.kv0_state != 0 ? p.kv0 + (size_t)2 * p.n * D : nullptr;
+    }
+    QuerySample* hq = (QuerySample*)(up_host.data() + up_qs);
+    unsigned* sync0 = (unsigned*)(P[0].ws + P[0].L.sync);   // zeroed by k_query_init (a sample's first query block)
+    for (int si = 0; si < ns; ++si) {
+      Prepared& p = P[si];
+      p.B.sync = sync0 + (size_t)si * A3D_MAX_DEC_LAYERS * kMaxQBlocks * 16;
+      hq[si].meta = p.meta;
+      hq[si].B = p.B;
+      hq[si].feats = p.feats;
+      hq[si].posenc = p.posenc;
+      hq[si].counts = p.counts;
+      hq[si].part = p.part;
+      hq[si].n_part = part_per_wg ? (p.wg_end - p.wg_begin) : p.L.nchunk;   // k_kv_c2s merges its slot groups: one partial per workgroup
+      hq[si].n_part0 = p.L.nchunk;
+    }
+    // pageable source: the runtime stages it before returning
+    A3D_HIP_CHECK(hipMemcpyAsync(up_dev, up_host.data(), up_bytes, hipMemcpyHostToDevice, st));
+  }
+  T.grid = grid;
+  return A3D_OK;
+}
+
+// the query side of decoder layer l for every sample of a call: merge of the click-to-scene partials, then one workgroup
+// (or chain of 64-query blocks, QT = 4) per sample
+template <int QT>
+static int launch_query_side(const a3d_decoder_weights* w, int l, QuerySample* qs_dev, int qp, int nblk, int ns, int nq_max,
+                             bool cached0, hipStream_t st) {
+  constexpr int QP = QT * 16;
+  const a3d_decoder_layer& LW = w->layers[l];
+    QueryLayerW QW;
+  QW.c2s_in_wt = LW.c2s_in_w; QW.c2s_in_b = LW.c2s_in_b; QW.c2s_out_wt = LW.c2s_out_w; QW.c2s_out_b = LW.c2s_out_b;
+  QW.c2s_norm_w = LW.c2s_norm_w; QW.c2s_norm_b = LW.c2s_norm_b;
+  QW.c2c_in_wt = LW.c2c_in_w; QW.c2c_in_b = LW.c2c_in_b; QW.c2c_out_wt = LW.c2c_out_w; QW.c2c_out_b = LW.c2c_out_b;
+  QW.c2c_norm_w = LW.c2c_norm_w; QW.c2c_norm_b = LW.c2c_norm_b;
+  QW.ffn_w1t = LW.ffn_w1; QW.ffn_b1 = LW.ffn_b1; QW.ffn_w2t = LW.ffn_w2; QW.ffn_b2 = LW.ffn_b2;
+  QW.ffn_norm_w = LW.ffn_norm_w; QW.ffn_norm_b = LW.ffn_norm_b;
+  QW.s2c_in_wt = LW.s2c_in_w; QW.s2c_in_b = LW.s2c_in_b;
+  QW.dn_w = w->decoder_norm_w; QW.dn_b = w->decoder_norm_b;
+  QW.m_w0t = w->mask_w0; QW.m_b0 = w->mask_b0; QW.m_w2t = w->mask_w2; QW.m_b2 = w->mask_b2;
+  QW.next_c2s_in_wt = l + 1 < w->n_layers ? w->layers[l + 1].c2s_in_w : nullptr;
+  QW.next_c2s_in_b = l + 1 < w->n_layers ? w->layers[l + 1].c2s_in_b : nullptr;
+  QW.qpack = LW.query_pack;
+  QW.next_qpack = l + 1 < w->n_layers ? w->layers[l + 1].query_pack : nullptr;
+  QW.mpack = w->mask_pack;
+  QW.dim_ff = w->dim_ff;
+  QW.layer = l;
+  {   // one workgroup (or chain of query blocks) per sample: blockIdx.y
+    ProfScope ps(st, A3D_PROF_QUERY, 0, 0, 0, 0, nq_max);
+    k_c2s_combine<<<dim3(nq_max * H, ns), 64, 0, st>>>(qs_dev, qp, cached0 ? 1 : 0);
+    const size_t ql_lds = (size_t)4 * QP * kQLD * 4 + 16;   // four [QP][132] tiles + the word of block_any
+    // FFN helper workgroups next to a block's workgroup (A3D_QL_HELPERS = total workgroups per block, 1 = none: the
+    // switch the tests use to compare the hand-off with the single-workgroup chain)
+    static int nh_env = -1;
+    if (nh_env < 0) {
+      const char* e = getenv("A3D_QL_HELPERS");
+      nh_env = e ? atoi(e) : kQlMaxHelpers;
+      nh_env = nh_env < 1 ? 1 : nh_env > kQlMaxHelpers ? kQlMaxHelpers : nh_env;
+    }
+    if (!(QW.qpack && QW.mpack && (QW.next_qpack || !QW.next_c2s_in_wt))) {
+      set_error("a3d_decoder_forward: the decoder weights carry no query-side packs (a3d_decoder_pack_query_weights "
+                "fills a3d_decoder_layer::query_pack and a3d_decoder_weights::mask_pack)");
+      return A3D_ERR_INVALID;
+    }
+    const size_t qb_lds = ql_lds + (size_t)kQVec * 4;
+    if (nblk == 1) {
+      k_query_block<QT, 0><<<dim3(nh_env, 1, ns), 512, qb_lds, st>>>(qs_dev, QW);
+    } else if constexpr (QT == 4) {
+      k_query_block<4, 1><<<dim3(1, nblk, ns), 512, qb_lds, st>>>(qs_dev, QW);
+      k_query_block<4, 2><<<dim3(nh_env, nblk, ns), 512, qb_lds, st>>>(qs_dev, QW);
+    }
+  }
+  A3D_LAUNCH_CHECK();
+  return A3D_OK;
+}
 
 // All samples of one call share QT (= padded query count / 16).  Per decoder layer: ONE launch of each fused wide
 // kernel for the whole batch (DecSampleDev table), the small query-side kernels once per sample in between.
@@ -2554,12 +2700,6 @@ static int run_decoder(const a3d_decoder_weights* w, Prepared* P, int ns, hipStr
     Kmax = p.hm.K > Kmax ? p.hm.K : Kmax;
     nq_max = p.hm.nq > nq_max ? p.hm.nq : nq_max;
   }
-  // the upload block in the first sample's workspace: [ns QueryMeta][ns DecSampleDev][ns QuerySample]
-  char* const up_dev = P[0].ws + P[0].L.desc;
-  const size_t up_meta = 0, up_samples = (sizeof(QueryMeta) * ns + 15) & ~(size_t)15;
-  const size_t up_qs = (up_samples + sizeof(DecSampleDev) * ns + 15) & ~(size_t)15;
-  const size_t up_bytes = up_qs + sizeof(QuerySample) * ns;
-  for (int si = 0; si < ns; ++si) P[si].meta = (QueryMeta*)(up_dev + up_meta) + si;
   const size_t s2c_lds = (size_t)2 * QP * 132 * 4;             // keys + values of the queries (k_s2c_attn_wide)
   const size_t qs2c_lds = ((size_t)QP * 132 + (size_t)D * (QP + 4) + D) * 4;   // k_q_s2c: keys, transposed values, bias
   const size_t fused_lds = (size_t)64 * 1024 + ((size_t)3 * D + QP * 132 + 8 * 16 * (QP + 1) + 8 * 16 * (Kmax + 1)) * 4 +
@@ -2592,67 +2732,14 @@ static int run_decoder(const a3d_decoder_weights* w, Prepared* P, int ns, hipStr
     fused_s2c_env = e ? atoi(e) : 1;
   }
   const bool fuse_all = fuse_out && fused_s2c_env && QT <= 2 && s2c_out_lds <= 160 * 1024;
-  // ---- sample table: workgroups of the persistent kernels in proportion to the samples' point groups
-  int grid = 0;
-  DecSampleDev* samples_dev = (DecSampleDev*)(up_dev + up_samples);
-  QuerySample* qs_dev = (QuerySample*)(up_dev + up_qs);
+  DecTables T;
   {
-    std::vector<char> up_host(up_bytes);
-    for (int si = 0; si < ns; ++si) memcpy(up_host.data() + up_meta + sizeof(QueryMeta) * si, &P[si].hm, sizeof(QueryMeta));
-    DecSampleDev* hd = (DecSampleDev*)(up_host.data() + up_samples);
-    int64_t tot_groups = 0;
-    for (int si = 0; si < ns; ++si) tot_groups += (P[si].n + 15) / 16;
-    const int max_grid = 256;
-    for (int si = 0; si < ns; ++si) {
-      Prepared& p = P[si];
-      const int ngroups = (p.n + 15) / 16;
-      int share = (int)((int64_t)max_grid * ngroups / tot_groups);
-      const int useful = (ngroups + 7) / 8;
-      share = share < 1 ? 1 : share;
-      share = share > useful ? useful : share;
-      p.wg_begin = grid;
-      p.wg_end = grid += share;
-      DecSampleDev& d = hd[si];
-      d.wg_begin = p.wg_begin;
-      d.wg_end = p.wg_end;
-      d.n = p.n;
-      d.nq = p.hm.nq;
-      d.K = p.hm.K;
-      d.n_fg = p.hm.n_fg;
-      d.feats = p.feats;
-      d.posenc = p.posenc;
-      d.bufB = p.bufB;
-      d.bufC = p.bufC;
-      d.bufD = p.bufD;
-      d.logits = p.logits;
-      d.labels = p.labels;
-      d.counts = p.counts;
-      d.part = p.part;
-      d.qobj = p.meta->obj;          // addresses inside the device copy of QueryMeta
-      d.qrange = p.meta->qrange;
-      d.qproj = p.B.qproj;
-      d.ks = p.B.ks;
-      d.vs = p.B.vs;
-      d.E = p.B.E;
-      d.q0 = p.kv0 && p.kv0_state != 0 ? p.kv0 + (size_t)2 * p.n * D : nullptr;
-    }
-    QuerySample* hq = (QuerySample*)(up_host.data() + up_qs);
-    unsigned* sync0 = (unsigned*)(P[0].ws + P[0].L.sync);   // zeroed by k_query_init (a sample's first query block)
-    for (int si = 0; si < ns; ++si) {
-      Prepared& p = P[si];
-      p.B.sync = sync0 + (size_t)si * A3D_MAX_DEC_LAYERS * kMaxQBlocks * 16;
-      hq[si].meta = p.meta;
-      hq[si].B = p.B;
-      hq[si].feats = p.feats;
-      hq[si].posenc = p.posenc;
-      hq[si].counts = p.counts;
-      hq[si].part = p.part;
-      hq[si].n_part = fuse_c2s ? (p.wg_end - p.wg_begin) : p.L.nchunk;   // k_kv_c2s merges its slot groups: one partial per workgroup
-      hq[si].n_part0 = p.L.nchunk;
-    }
-    // pageable source: the runtime stages it before returning
-    A3D_HIP_CHECK(hipMemcpyAsync(up_dev, up_host.data(), up_bytes, hipMemcpyHostToDevice, st));
+    const int rc_t = upload_tables(P, ns, false, fuse_c2s, st, T);
+    if (rc_t) return rc_t;
   }
+  const int grid = T.grid;
+  DecSampleDev* const samples_dev = T.samples_dev;
+  QuerySample* const qs_dev = T.qs_dev;
   {
     ProfScope ps(st, A3D_PROF_QUERY, 0, 0, 0, 0, nq_max);
     k_query_init<QT><<<dim3(nblk, ns), 512, 0, st>>>(qs_dev, w->bg_query_feat, w->bg_query_pos, w->time_table,
@@ -2711,49 +2798,8 @@ static int run_decoder(const a3d_decoder_weights* w, Prepared* P, int ns, hipStr
       }
     }
     // ---- query side, per sample
-    QueryLayerW QW;
-    QW.c2s_in_wt = LW.c2s_in_w; QW.c2s_in_b = LW.c2s_in_b; QW.c2s_out_wt = LW.c2s_out_w; QW.c2s_out_b = LW.c2s_out_b;
-    QW.c2s_norm_w = LW.c2s_norm_w; QW.c2s_norm_b = LW.c2s_norm_b;
-    QW.c2c_in_wt = LW.c2c_in_w; QW.c2c_in_b = LW.c2c_in_b; QW.c2c_out_wt = LW.c2c_out_w; QW.c2c_out_b = LW.c2c_out_b;
-    QW.c2c_norm_w = LW.c2c_norm_w; QW.c2c_norm_b = LW.c2c_norm_b;
-    QW.ffn_w1t = LW.ffn_w1; QW.ffn_b1 = LW.ffn_b1; QW.ffn_w2t = LW.ffn_w2; QW.ffn_b2 = LW.ffn_b2;
-    QW.ffn_norm_w = LW.ffn_norm_w; QW.ffn_norm_b = LW.ffn_norm_b;
-    QW.s2c_in_wt = LW.s2c_in_w; QW.s2c_in_b = LW.s2c_in_b;
-    QW.dn_w = w->decoder_norm_w; QW.dn_b = w->decoder_norm_b;
-    QW.m_w0t = w->mask_w0; QW.m_b0 = w->mask_b0; QW.m_w2t = w->mask_w2; QW.m_b2 = w->mask_b2;
-    QW.next_c2s_in_wt = l + 1 < w->n_layers ? w->layers[l + 1].c2s_in_w : nullptr;
-    QW.next_c2s_in_b = l + 1 < w->n_layers ? w->layers[l + 1].c2s_in_b : nullptr;
-    QW.qpack = LW.query_pack;
-    QW.next_qpack = l + 1 < w->n_layers ? w->layers[l + 1].query_pack : nullptr;
-    QW.mpack = w->mask_pack;
-    QW.dim_ff = w->dim_ff;
-    QW.layer = l;
-    {   // one workgroup (or chain of query blocks) per sample: blockIdx.y
-      ProfScope ps(st, A3D_PROF_QUERY, 0, 0, 0, 0, nq_max);
-      k_c2s_combine<<<dim3(nq_max * H, ns), 64, 0, st>>>(qs_dev, P[0].L.qp, cached0 ? 1 : 0);
-      const size_t ql_lds = (size_t)4 * QP * kQLD * 4 + 16;   // four [QP][132] tiles + the word of block_any
-      // FFN helper workgroups next to a block's workgroup (A3D_QL_HELPERS = total workgroups per block, 1 = none: the
-      // switch the tests use to compare the hand-off with the single-workgroup chain)
-      static int nh_env = -1;
-      if (nh_env < 0) {
-        const char* e = getenv("A3D_QL_HELPERS");
-        nh_env = e ? atoi(e) : kQlMaxHelpers;
-        nh_env = nh_env < 1 ? 1 : nh_env > kQlMaxHelpers ? kQlMaxHelpers : nh_env;
-      }
-      if (!(QW.qpack && QW.mpack && (QW.next_qpack || !QW.next_c2s_in_wt))) {
-        set_error("a3d_decoder_forward: the decoder weights carry no query-side packs (a3d_decoder_pack_query_weights "
-                  "fills a3d_decoder_layer::query_pack and a3d_decoder_weights::mask_pack)");
-        return A3D_ERR_INVALID;
-      }
-      const size_t qb_lds = ql_lds + (size_t)kQVec * 4;
-      if (nblk == 1) {
-        k_query_block<QT, 0><<<dim3(nh_env, 1, ns), 512, qb_lds, st>>>(qs_dev, QW);
-      } else if constexpr (QT == 4) {
-        k_query_block<4, 1><<<dim3(1, nblk, ns), 512, qb_lds, st>>>(qs_dev, QW);
-        k_query_block<4, 2><<<dim3(nh_env, nblk, ns), 512, qb_lds, st>>>(qs_dev, QW);
-      }
-    }
-    A3D_LAUNCH_CHECK();
+    rc = launch_query_side<QT>(w, l, qs_dev, P[0].L.qp, nblk, ns, nq_max, cached0, st);
+    if (rc) return rc;
     // ---- scene-to-click: Q = (src + pos) Wq^T + bq; attention; Y = O Wo^T + bo + src; LN
     if (fuse_all) {
       // the whole half in one pass: O never reaches HBM (k_s2c_out)
@@ -2828,6 +2874,87 @@ static int run_decoder(const a3d_decoder_weights* w, Prepared* P, int ns, hipStr
   return A3D_OK;
 }
 
+// ---- the fused wide tier (decoder_wide.h): 65 .. 224 queries, QT = padded queries / 16 of the three point-side kernels; the
+// query side runs its 64-query blocks on buffers of L.qp rows as before
+template <int QT>
+static int run_decoder_wide(const a3d_decoder_weights* w, Prepared* P, int ns, hipStream_t st) {
+  const int qp = P[0].L.qp, nblk = qp / 64;
+  {
+    static bool big = false;
+    if (!big) {
+      big = true;
+      const int big_lds = 160 * 1024;
+      A3D_ALLOW_LDS(big_lds, k_query_block<4, 1>);
+      A3D_ALLOW_LDS(big_lds, k_query_block<4, 2>);
+    }
+  }
+  const int n_counts = A3D_MAX_DEC_LAYERS * (A3D_MAX_QUERIES + 1);
+  int64_t n_total = 0;
+  int Kmax = 0, nq_max = 0;
+  for (int si = 0; si < ns; ++si) {
+    n_total += P[si].n;
+    Kmax = P[si].hm.K > Kmax ? P[si].hm.K : Kmax;
+    nq_max = P[si].hm.nq > nq_max ? P[si].hm.nq : nq_max;
+  }
+  const size_t stage_lds = (size_t)2 * 2 * kWTile * 4;                       // two slots of (rows, position encodings)
+  const size_t out_lds = ((size_t)3 * kWTile + 16 * 16 + 16 * (QT * 16 + 1) + 16 * (Kmax + 1)) * 4 + (size_t)(2 * Kmax + 3) * 4;
+  DecTables T;
+  int rc = upload_tables(P, ns, true, true, st, T);
+  if (rc) return rc;
+  {
+    ProfScope ps(st, A3D_PROF_QUERY, 0, 0, 0, 0, nq_max);
+    k_query_init<4><<<dim3(nblk, ns), 512, 0, st>>>(T.qs_dev, w->bg_query_feat, w->bg_query_pos, w->time_table,
+                                                   w->layers[0].c2s_in_w, w->layers[0].c2s_in_b, n_counts);
+    A3D_LAUNCH_CHECK();
+  }
+  for (int l = 0; l < w->n_layers; ++l) {
+    const a3d_decoder_layer& LW = w->layers[l];
+    // ---- click-to-scene; the first layer on the scene's cached keys / values when every sample has them
+    bool cached0 = l == 0;
+    for (int si = 0; si < ns && cached0; ++si) cached0 = P[si].kv0 != nullptr && P[si].kv0_state != 0;
+    const bool qc0 = cached0;
+    if (cached0) {
+      for (int si = 0; si < ns; ++si) {
+        Prepared& p = P[si];
+        float* K0 = p.kv0;
+        float* V0 = p.kv0 + (size_t)p.n * D;
+        if (p.kv0_state == 1) {
+          rc = a3d_linear(p.feats, D, p.posenc, D, p.n, D, D, LW.c2s_wk_packed, nullptr, LW.c2s_in_b + D, nullptr, 0, 0, K0, D, nullptr, 0, st);
+          if (rc) return rc;
+          rc = a3d_linear(p.feats, D, nullptr, 0, p.n, D, D, LW.c2s_wv_packed, nullptr, LW.c2s_in_b + 2 * D, nullptr, 0, 0, V0, D, nullptr, 0, st);
+          if (rc) return rc;
+          rc = a3d_linear(p.feats, D, p.posenc, D, p.n, D, D, LW.s2c_wq_packed, nullptr, LW.s2c_in_b, nullptr, 0, 0,
+                          p.kv0 + (size_t)2 * p.n * D, D, nullptr, 0, st);
+          if (rc) return rc;
+        }
+        ProfScope ps(st, A3D_PROF_C2S, 0, 0, 0, 0, p.n);
+        k_c2s_attn<QT><<<dim3(p.L.nchunk, 1), 512, 0, st>>>(K0, V0, p.n, p.B.qproj, p.meta->obj, nullptr, nullptr, p.part, qp);
+        A3D_LAUNCH_CHECK();
+      }
+    } else {
+      ProfScope ps(st, A3D_PROF_C2S, 0, 0, 0, 0, (int)n_total);
+      k_c2s_w<QT><<<T.grid, 512, stage_lds, st>>>(T.samples_dev, ns, l, LW.c2s_wk_packed, LW.c2s_wv_packed, LW.c2s_in_b + D,
+                                                  LW.c2s_in_b + 2 * D, qp);
+      A3D_LAUNCH_CHECK();
+    }
+    rc = launch_query_side<4>(w, l, T.qs_dev, qp, nblk, ns, nq_max, cached0, st);
+    if (rc) return rc;
+    // ---- scene-to-click attention, then output projection + residual + LayerNorm + mask head
+    {
+      ProfScope ps(st, A3D_PROF_S2C, 0, 0, 0, 0, (int)n_total);
+      if (qc0) k_s2c_w<QT, true><<<T.grid, 512, 0, st>>>(T.samples_dev, ns, l, LW.s2c_wq_packed, LW.s2c_in_b);
+      else k_s2c_w<QT, false><<<T.grid, 512, stage_lds, st>>>(T.samples_dev, ns, l, LW.s2c_wq_packed, LW.s2c_in_b);
+      A3D_LAUNCH_CHECK();
+    }
+    {
+      ProfScope ps(st, A3D_PROF_LNMASK, 0, 0, 0, 0, (int)n_total);
+      k_out_w<QT><<<T.grid, 512, out_lds, st>>>(T.samples_dev, ns, l, LW.s2c_wo_packed, LW.s2c_out_b, LW.s2c_norm_w, LW.s2c_norm_b, Kmax);
+      A3D_LAUNCH_CHECK();
+    }
+  }
+  return A3D_OK;
+}
+
 // validate one sample and lay out its workspace (a3d_decoder_forward / a3d_decoder_forward_batch)
 static int prepare_sample(const a3d_decoder_weights* w, const a3d_decoder_sample& sp, Prepared& P) {
   const float* feats128_dev = sp.feats128_dev;
@@ -2895,6 +3022,7 @@ static int prepare_sample(const a3d_decoder_weights* w, const a3d_decoder_sample
     hm.row[i] = -1;
   }
   dec_layout(n, nq, P.L);
+  P.qtw = fused_wide() ? wide_qt(nq) : 0;
   if (!sp.workspace_dev || sp.workspace_bytes < P.L.total || ((uintptr_t)sp.workspace_dev & 255)) {
     set_error("a3d_decoder_forward: workspace too small or misaligned (%zu < %zu)", sp.workspace_bytes, P.L.total);
     return A3D_ERR_WORKSPACE;
@@ -2915,6 +3043,16 @@ static int prepare_sample(const a3d_decoder_weights* w, const a3d_decoder_sample
 }
 
 static int dispatch_decoder(const a3d_decoder_weights* w, Prepared* P, int ns, hipStream_t st) {
+  switch (P[0].qtw) {
+    case 5: return run_decoder_wide<5>(w, P, ns, st);
+    case 6: return run_decoder_wide<6>(w, P, ns, st);
+    case 7: return run_decoder_wide<7>(w, P, ns, st);
+    case 8: return run_decoder_wide<8>(w, P, ns, st);
+    case 10: return run_decoder_wide<10>(w, P, ns, st);
+    case 12: return run_decoder_wide<12>(w, P, ns, st);
+    case 14: return run_decoder_wide<14>(w, P, ns, st);
+    default: break;
+  }
   switch (P[0].L.qp) {
     case 16: return run_decoder<1>(w, P, ns, st);
     case 32: return run_decoder<2>(w, P, ns, st);
@@ -2959,7 +3097,7 @@ extern "C" int a3d_decoder_forward_batch(const a3d_decoder_weights* w, const a3d
   int n_groups = 0;
   for (int i = 0; i < n_samples;) {
     int e = i + 1;
-    while (e < n_samples && e - i < kMaxBatchSamples && P[(size_t)e].L.qp == P[(size_t)i].L.qp) ++e;
+    while (e < n_samples && e - i < kMaxBatchSamples && P[(size_t)e].L.qp == P[(size_t)i].L.qp && P[(size_t)e].qtw == P[(size_t)i].qtw) ++e;
     ++n_groups;
     i = e;
   }
@@ -2979,7 +3117,7 @@ extern "C" int a3d_decoder_forward_batch(const a3d_decoder_weights* w, const a3d
   int g = 0, rc_all = A3D_OK;
   for (int i = 0; i < n_samples && rc_all == A3D_OK;) {
     int e = i + 1;
-    while (e < n_samples && e - i < kMaxBatchSamples && P[(size_t)e].L.qp == P[(size_t)i].L.qp) ++e;
+    while (e < n_samples && e - i < kMaxBatchSamples && P[(size_t)e].L.qp == P[(size_t)i].L.qp && P[(size_t)e].qtw == P[(size_t)i].qtw) ++e;
     hipStream_t gs = st;
     if (use_side && g > 0) {
       const int k = (g - 1) & 3;

@@ -1,0 +1,466 @@
+// The fused decoder tier for 65 .. 224 queries (included by decoder.hip inside namespace a3d, after the sample tables).
+//
+// Reference: Agile3d.forward_mask's three attention blocks per decoder layer (models/agile3d.py:271-325) and mask_module
+// (agile3d.py:342-384) for any number of queries; the multi-object protocol reaches num_obj x 20 clicks + 10 background
+// queries (eval_multi_obj.py:70,116-118), training U[0,19] click rounds on up to 10 objects (engine.py:83-93).
+//
+// The <= 64-query kernels keep packed weight matrices (64 KB each) in LDS and give every wave its own 16-point group; past 64
+// queries the queries' keys / values / embeddings no longer fit next to the weights.  Here the roles turn around:
+//   * a WORKGROUP owns a 16-point group, a WAVE owns one 16-column slice of the layer's matrices -- head h of the K / V / Q
+//     projections, output tile w of the output projection -- so a wave's slice of every weight matrix is 8 float4 per lane
+//     and stays in REGISTERS for the life of a persistent workgroup, next to the wave's slice of the query side (head h of
+//     the projected queries, of the queries' keys and transposed values; the mask embeddings of query tile w);
+//   * LDS holds only what the eight waves share: the group's point rows (two slots, written a whole iteration ahead by
+//     all 512 threads, one barrier per group) and the exchanges of the output half (LayerNorm statistics, the normalised
+//     rows, the logits tile);
+//   * nothing of size [heads, Q, N] or K / V / Q [N, 128] reaches HBM; the attention output O makes one round trip
+//     (k_s2c_w -> k_out_w).
+// Granularity: 19.5 point groups per workgroup for one 80 k-point sample instead of 2.4 per wave.
+// Algorithmic work per 16-point group and layer (QT = padded queries / 16): c2s 512 + 64 QT MFMAs, s2c 256 + 64 QT, output
+// half 256 + 32 QT (v_mfma_f32_16x16x4_f32, 2 048 FLOPs each).
+
+constexpr int kWLD = 136;                       // row stride (floats) of the staged 16 x 128 tiles: conflict-free b128 fragment reads
+constexpr int kWTile = 16 * kWLD;               // floats per staged tile
+constexpr int kWideGridMax = 256;               // persistent workgroups (one per CU: 8 waves x up to 256 VGPRs)
+
+// smallest wide-tier tile count that holds nq queries (0: not served -- more than 224 queries run the unfused kernels)
+__host__ __device__ constexpr int wide_qt(int nq) {
+  return nq <= 64 ? 0 : nq <= 80 ? 5 : nq <= 96 ? 6 : nq <= 112 ? 7 : nq <= 128 ? 8 : nq <= 160 ? 10 : nq <= 192 ? 12 : nq <= 224 ? 14 : 0;
+}
+
+// the 512 threads of a workgroup move one group's rows of X and of the position encodings (16 x 128 floats each):
+// thread -> (row lr, float4 column lc)
+struct WideLoader {
+  f32x4 rx, rp;
+  __device__ __forceinline__ void issue(const float* __restrict__ X, const float* __restrict__ Pe, int grp, int n) {
+    const int lr = threadIdx.x >> 5, lc = (threadIdx.x & 31) * 4;
+    const size_t row = (size_t)min(grp * 16 + lr, n - 1);
+    rx = gld4(X + row * D + lc);
+    rp = gld4(Pe + row * D + lc);
+  }
+  __device__ __forceinline__ void commit(float* slot) const {
+    const int lr = threadIdx.x >> 5, lc = (threadIdx.x & 31) * 4;
+    *(f32x4*)(slot + lr * kWLD + lc) = rx;
+    *(f32x4*)(slot + kWTile + lr * kWLD + lc) = rp;
+  }
+};
+
+// ---- click-to-scene: K / V projections + flash attention of every query over the workgroup's points, wave = head ---------
+// S = K_h q_h^T per 16-point group (A = the projected key slice, straight from the projection's accumulators), online
+// softmax per query column, O^T += V_h^T P; one partial (m, l, acc[16]) per (head, query) and workgroup for k_c2s_combine.
+template <int QT>
+__global__ void __launch_bounds__(512) k_c2s_w(const DecSampleDev* __restrict__ samples, int ns, int layer,
+                                               const float* __restrict__ Wk, const float* __restrict__ Wv,
+                                               const float* __restrict__ bk, const float* __restrict__ bv, int qp_total) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* tiles = (float*)smem;   // [2 slots][X, P][16][kWLD]
+  const DecSampleDev& sm = sample_of_wg(samples, ns);
+  const int lb = blockIdx.x - sm.wg_begin, nwg = sm.wg_end - sm.wg_begin;
+  const int n = sm.n, ngroups = (n + 15) / 16;
+  const float* __restrict__ X = layer_input(sm, layer);
+  const float* __restrict__ Pe = sm.posenc;
+  const unsigned char* labels = layer > 0 ? sm.labels : nullptr;                       // previous layer's mask labels
+  const int* counts = layer > 0 ? sm.counts + (size_t)(layer - 1) * (A3D_MAX_QUERIES + 1) : nullptr;
+  const int lane = threadIdx.x & 63, h = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int g = lane >> 4, j = lane & 15;
+  // ---- the wave's constants: head h's slices of Wk / Wv (fragment order), its biases, the projected queries, the mask ids
+  f32x4 wk[8], wv[8];
+#pragma unroll
+  for (int S = 0; S < 8; ++S) {
+    wk[S] = ((const f32x4 A3D_GLOBAL*)Wk)[(S * 8 + h) * 64 + lane];
+    wv[S] = ((const f32x4 A3D_GLOBAL*)Wv)[(S * 8 + h) * 64 + lane];
+  }
+  const f32x4 bk4 = gld4(bk + 16 * h + 4 * g);
+  const float bvj = gld(bv + 16 * h + j);
+  f32x4 qf[QT];
+  int obj[QT];
+#pragma unroll
+  for (int qt = 0; qt < QT; ++qt) {
+    qf[qt] = gld4(sm.qproj + (size_t)(qt * 16 + j) * D + 16 * h + 4 * g);
+    const int o = gld(sm.qobj + qt * 16 + j);
+    // a query is masked only if its object currently owns at least one point (agile3d.py:369,375); -1 = not masked
+    obj[qt] = labels != nullptr && o >= 0 && gld(counts + o) > 0 ? o : -1;
+  }
+  float m[QT], l[QT];
+  f32x4 acc[QT];
+#pragma unroll
+  for (int qt = 0; qt < QT; ++qt) {
+    m[qt] = kNegBig;
+    l[qt] = 0.f;
+    acc[qt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
+  WideLoader ld;
+  unsigned lab_nx = 0u;
+  int grp = lb;
+  if (grp < ngroups) {
+    ld.issue(X, Pe, grp, n);
+    if (labels) lab_nx = gld((const unsigned*)(labels + grp * 16 + 4 * g));
+    ld.commit(tiles);
+  }
+  __syncthreads();
+  for (int it = 0; grp < ngroups; ++it, grp += nwg) {
+    const int p0 = grp * 16;
+    const unsigned lab4 = lab_nx;
+    const int next = grp + nwg;
+    const bool has_next = next < ngroups;
+    if (has_next) {   // the next group's rows: a whole projection phase to land, then into the other slot
+      ld.issue(X, Pe, next, n);
+      if (labels) lab_nx = gld((const unsigned*)(labels + next * 16 + 4 * g));
+    }
+    const float* tx = tiles + (it & 1) * 2 * kWTile + j * kWLD + 4 * g;
+    // ---- projections: kf = K[point j][16h+4g..+3] (transposed product), vv = V[points 4g..4g+3][16h+j]
+    f32x4 kf = bk4, vv = (f32x4){bvj, bvj, bvj, bvj};
+    {
+      f32x4 xs = *(const f32x4*)tx, pe = *(const f32x4*)(tx + kWTile);
+#pragma unroll
+      for (int S = 0; S < 8; ++S) {
+        f32x4 nxs = xs, npe = pe;
+        if (S + 1 < 8) {
+          nxs = *(const f32x4*)(tx + 16 * (S + 1));
+          npe = *(const f32x4*)(tx + kWTile + 16 * (S + 1));
+        }
+        const f32x4 xp = xs + pe;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          kf = __builtin_amdgcn_mfma_f32_16x16x4f32(wk[S][t], xp[t], kf, 0, 0, 0);
+          vv = __builtin_amdgcn_mfma_f32_16x16x4f32(xs[t], wv[S][t], vv, 0, 0, 0);
+        }
+        xs = nxs;
+        pe = npe;
+      }
+    }
+    if (has_next) ld.commit(tiles + ((it + 1) & 1) * 2 * kWTile);
+    // ---- attention of the 16 points against every query tile
+    int lab[4];
+    bool oob[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      lab[t] = (int)((lab4 >> (8 * t)) & 0xffu);
+      oob[t] = p0 + 4 * g + t >= n;
+    }
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) {
+      f32x4 sc4;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) sc4[t] = oob[t] || (obj[qt] >= 0 && lab[t] != obj[qt]) ? kNegBig : 0.f;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) sc4 = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[t], qf[qt][t], sc4, 0, 0, 0);
+      float mx = fmaxf(fmaxf(sc4[0], sc4[1]), fmaxf(sc4[2], sc4[3]));
+      mx = rows_max(mx);
+      const float mnew = fmaxf(m[qt], mx);
+      const float scl = exp2_fast(m[qt] - mnew);
+      m[qt] = mnew;
+      f32x4 pw;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) pw[t] = exp2_fast(sc4[t] - mnew);
+      l[qt] = l[qt] * scl + ((pw[0] + pw[1]) + (pw[2] + pw[3]));
+      acc[qt] *= scl;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) acc[qt] = __builtin_amdgcn_mfma_f32_16x16x4f32(vv[t], pw[t], acc[qt], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+  // one partial per (head, query) and workgroup: [h][q][workgroup] -- what k_c2s_combine walks
+#pragma unroll
+  for (int qt = 0; qt < QT; ++qt) {
+    const float lt = rows_sum(l[qt]);
+    float* pq = sm.part + (((size_t)h * qp_total + qt * 16 + j) * nwg + lb) * kPartStride;
+    if (g == 0) {
+      gst(pq, m[qt]);
+      gst(pq + 1, lt);
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) gst(pq + 2 + 4 * g + t, acc[qt][t]);
+  }
+}
+
+// ---- scene-to-click attention: Q projection + softmax over the queries + P V, wave = head -----------------------------
+// Head h's slice of Wq, of the queries' keys (A fragments of S^T = ks_h Q_h^T) and of their transposed values (A fragments
+// of O^T = vs_h^T P) are register constants; the group's attention output goes to sm.bufB (k_out_w reads it back).
+// QC: the first layer's queries come from the scene's cache (as k_q_s2c<.., QC>): no projection, no staging, no barrier.
+template <int QT, bool QC>
+__global__ void __launch_bounds__(512) k_s2c_w(const DecSampleDev* __restrict__ samples, int ns, int layer,
+                                               const float* __restrict__ Wq, const float* __restrict__ bq) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* tiles = (float*)smem;   // [2 slots][X, P][16][kWLD]
+  const DecSampleDev& sm = sample_of_wg(samples, ns);
+  const int lb = blockIdx.x - sm.wg_begin, nwg = sm.wg_end - sm.wg_begin;
+  const int n = sm.n, ngroups = (n + 15) / 16, nq = sm.nq;
+  const float* __restrict__ X = layer_input(sm, layer);
+  const float* __restrict__ Pe = sm.posenc;
+  float* __restrict__ O = sm.bufB;
+  const int lane = threadIdx.x & 63, h = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int g = lane >> 4, j = lane & 15;
+  f32x4 wq[8];
+  f32x4 bq4 = (f32x4){0.f, 0.f, 0.f, 0.f};
+  if constexpr (!QC) {
+#pragma unroll
+    for (int S = 0; S < 8; ++S) wq[S] = ((const f32x4 A3D_GLOBAL*)Wq)[(S * 8 + h) * 64 + lane];
+    bq4 = gld4(bq + 16 * h + 4 * g);
+  }
+  f32x4 kf[QT], vf[QT];
+#pragma unroll
+  for (int kt = 0; kt < QT; ++kt) {
+    kf[kt] = gld4(sm.ks + (size_t)(kt * 16 + j) * D + 16 * h + 4 * g);   // ks[key 16kt+j][16h+4g..+3] (pre-scaled, log2 domain)
+#pragma unroll
+    for (int t = 0; t < 4; ++t) vf[kt][t] = gld(sm.vs + (size_t)(kt * 16 + 4 * g + t) * D + 16 * h + j);   // V^T: keys 4g..4g+3 of channel 16h+j
+  }
+  // score bias of the padded queries: only the last two tiles can hold any (wide_qt)
+  f32x4 sbA, sbB;
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    sbA[t] = (QT - 2) * 16 + 4 * g + t < nq ? 0.f : kNegBig;
+    sbB[t] = (QT - 1) * 16 + 4 * g + t < nq ? 0.f : kNegBig;
+  }
+  WideLoader ld;
+  f32x4 qn = (f32x4){0.f, 0.f, 0.f, 0.f};
+  int grp = lb;
+  if (grp < ngroups) {
+    if constexpr (QC) {
+      qn = gld4(sm.q0 + (size_t)min(grp * 16 + j, n - 1) * D + 16 * h + 4 * g);
+    } else {
+      ld.issue(X, Pe, grp, n);
+      ld.commit(tiles);
+    }
+  }
+  if constexpr (!QC) __syncthreads();
+  for (int it = 0; grp < ngroups; ++it, grp += nwg) {
+    const int p0 = grp * 16;
+    const int next = grp + nwg;
+    const bool has_next = next < ngroups;
+    f32x4 qf;
+    if constexpr (QC) {
+      qf = qn;
+      if (has_next) qn = gld4(sm.q0 + (size_t)min(next * 16 + j, n - 1) * D + 16 * h + 4 * g);
+    } else {
+      if (has_next) ld.issue(X, Pe, next, n);
+      const float* tx = tiles + (it & 1) * 2 * kWTile + j * kWLD + 4 * g;
+      // Q[point j][16h+4g..+3]: even / odd K-steps on two accumulators (a chain of 32 dependent MFMAs otherwise)
+      f32x4 q0 = bq4, q1 = (f32x4){0.f, 0.f, 0.f, 0.f};
+      f32x4 xa = *(const f32x4*)tx + *(const f32x4*)(tx + kWTile);
+      f32x4 xb = *(const f32x4*)(tx + 16) + *(const f32x4*)(tx + kWTile + 16);
+#pragma unroll
+      for (int S = 0; S < 8; S += 2) {
+        f32x4 na = xa, nb = xb;
+        if (S + 2 < 8) {
+          na = *(const f32x4*)(tx + 16 * (S + 2)) + *(const f32x4*)(tx + kWTile + 16 * (S + 2));
+          nb = *(const f32x4*)(tx + 16 * (S + 3)) + *(const f32x4*)(tx + kWTile + 16 * (S + 3));
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          q0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wq[S][t], xa[t], q0, 0, 0, 0);
+          q1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wq[S + 1][t], xb[t], q1, 0, 0, 0);
+        }
+        xa = na;
+        xb = nb;
+      }
+      qf = q0 + q1;
+      if (has_next) ld.commit(tiles + ((it + 1) & 1) * 2 * kWTile);
+    }
+    // S^T[key 16kt+4g+t][point j]
+    f32x4 sc[QT];
+#pragma unroll
+    for (int kt = 0; kt < QT; ++kt) sc[kt] = kt == QT - 1 ? sbB : kt == QT - 2 ? sbA : (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int kt = 0; kt < QT; ++kt) sc[kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[kt][t], qf[t], sc[kt], 0, 0, 0);
+    float mx = kNegBig;
+#pragma unroll
+    for (int kt = 0; kt < QT; ++kt) mx = fmaxf(mx, fmaxf(fmaxf(sc[kt][0], sc[kt][1]), fmaxf(sc[kt][2], sc[kt][3])));
+    mx = rows_max(mx);
+    float sum = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < QT; ++kt) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) sc[kt][t] = exp2_fast(sc[kt][t] - mx);
+      sum += (sc[kt][0] + sc[kt][1]) + (sc[kt][2] + sc[kt][3]);
+    }
+    sum = rows_sum(sum);
+    const float inv = __builtin_amdgcn_rcpf(sum);
+    // O^T[channel 16h+4g+t][point j]: two accumulators over alternating key tiles
+    f32x4 a0 = (f32x4){0.f, 0.f, 0.f, 0.f}, a1 = a0;
+#pragma unroll
+    for (int kt = 0; kt + 1 < QT; kt += 2)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(vf[kt][t], sc[kt][t], a0, 0, 0, 0);
+        a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(vf[kt + 1][t], sc[kt + 1][t], a1, 0, 0, 0);
+      }
+    if constexpr (QT & 1) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(vf[QT - 1][t], sc[QT - 1][t], a0, 0, 0, 0);
+    }
+    if (p0 + j < n) gst4(O + (size_t)(p0 + j) * D + 16 * h + 4 * g, (a0 + a1) * inv);
+    if constexpr (!QC) __syncthreads();
+  }
+}
+
+// ---- output projection + residual + LayerNorm + mask head, wave = output column tile ------------------------------------
+// y[point j][16w+4g..+3] = bo + src + O Wo^T from the wave's register-resident slice of Wo; LayerNorm over the eight waves'
+// tiles through per-wave (mean, M2) pairs merged exactly (Chan); the normalised rows are exchanged through LDS and wave w
+// multiplies them with the mask embeddings of query tiles w (and w + 8), also register constants; per-object maximum,
+// label argmax, histogram and the logits rows as k_out_ln_mask.  Four barriers per 16-point group.
+template <int QT>
+__global__ void __launch_bounds__(512) k_out_w(const DecSampleDev* __restrict__ samples, int ns, int layer,
+                                               const float* __restrict__ Wo, const float* __restrict__ bo,
+                                               const float* __restrict__ gamma, const float* __restrict__ beta, int Kmax) {
+  constexpr int NTW = QT > 8 ? 2 : 1;          // query tiles per wave
+  constexpr int LL = QT * 16 + 1;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* o_l = (float*)smem;                   // [2 slots][16][kWLD] attention output rows
+  float* y_l = o_l + 2 * kWTile;               // [16][kWLD] normalised rows
+  float* st_l = y_l + kWTile;                  // [16 points][8 waves][2] LayerNorm partials
+  float* L_l = st_l + 16 * 16;                 // [16][LL] logits of the group
+  float* Ol = L_l + 16 * LL;                   // [16][Kmax+1] per-object maxima
+  int* hist = (int*)(Ol + 16 * (Kmax + 1));    // [Kmax+1]
+  int* qr_l = hist + Kmax + 1;                 // [Kmax+2]
+  const DecSampleDev& sm = sample_of_wg(samples, ns);
+  const int lb = blockIdx.x - sm.wg_begin, nwg = sm.wg_end - sm.wg_begin;
+  const int n = sm.n, ngroups = (n + 15) / 16, nq = sm.nq, n_fg = sm.n_fg, K = sm.K;
+  const float* __restrict__ O = sm.bufB;
+  const float* __restrict__ Xres = layer_input(sm, layer);
+  float* __restrict__ Y = (layer & 1) ? sm.bufD : sm.bufC;
+  float* logits = sm.logits + (size_t)layer * n * (K + 1);
+  unsigned char* labels = sm.labels;
+  int* counts = sm.counts + (size_t)layer * (A3D_MAX_QUERIES + 1);
+  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = lane >> 4, j = lane & 15;
+  for (int e = tid; e <= K + 1; e += 512) qr_l[e] = gld(sm.qrange + e);
+  for (int e = tid; e <= K; e += 512) hist[e] = 0;
+  f32x4 wo[8];
+#pragma unroll
+  for (int S = 0; S < 8; ++S) wo[S] = ((const f32x4 A3D_GLOBAL*)Wo)[(S * 8 + w) * 64 + lane];
+  const f32x4 bo4 = gld4(bo + 16 * w + 4 * g), ga4 = gld4(gamma + 16 * w + 4 * g), be4 = gld4(beta + 16 * w + 4 * g);
+  // mask embeddings E[query 16 qt + j][16 S + 4 g ..+3] of the wave's query tiles (B fragments of the logits product)
+  f32x4 ef[NTW][8];
+#pragma unroll
+  for (int i = 0; i < NTW; ++i) {
+    const int qt = w + 8 * i;
+#pragma unroll
+    for (int S = 0; S < 8; ++S)
+      ef[i][S] = qt < QT ? gld4(sm.E + (size_t)(qt * 16 + j) * D + 16 * S + 4 * g) : (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
+  const int lr = tid >> 5, lc = (tid & 31) * 4;
+  int grp = lb;
+  f32x4 ro = (f32x4){0.f, 0.f, 0.f, 0.f}, rres = ro;
+  if (grp < ngroups) {
+    ro = gld4(O + (size_t)min(grp * 16 + lr, n - 1) * D + lc);
+    rres = gld4(Xres + (size_t)min(grp * 16 + j, n - 1) * D + 16 * w + 4 * g);
+    *(f32x4*)(o_l + lr * kWLD + lc) = ro;
+  }
+  __syncthreads();
+  for (int it = 0; grp < ngroups; ++it, grp += nwg) {
+    const int p0 = grp * 16;
+    const int next = grp + nwg;
+    const bool has_next = next < ngroups;
+    const f32x4 res = rres;
+    if (has_next) {
+      ro = gld4(O + (size_t)min(next * 16 + lr, n - 1) * D + lc);
+      rres = gld4(Xres + (size_t)min(next * 16 + j, n - 1) * D + 16 * w + 4 * g);
+    }
+    // ---- y tile: bias + residual + O Wo^T (even / odd K-steps on two accumulators)
+    const float* to = o_l + (it & 1) * kWTile + j * kWLD + 4 * g;
+    f32x4 y0 = bo4 + res, y1 = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int S = 0; S < 8; S += 2) {
+      const f32x4 oa = *(const f32x4*)(to + 16 * S), ob = *(const f32x4*)(to + 16 * (S + 1));
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        y0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wo[S][t], oa[t], y0, 0, 0, 0);
+        y1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wo[S + 1][t], ob[t], y1, 0, 0, 0);
+      }
+    }
+    f32x4 y = y0 + y1;
+    // ---- LayerNorm: the wave's 16 channels of point j -> (mean, M2), merged over the eight waves
+    const float mw = rows_sum((y[0] + y[1]) + (y[2] + y[3])) * (1.f / 16.f);
+    float m2 = 0.f;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) m2 += (y[t] - mw) * (y[t] - mw);
+    m2 = rows_sum(m2);
+    if (g == 0) *(float2*)(st_l + (j * 8 + w) * 2) = make_float2(mw, m2);
+    if (has_next) *(f32x4*)(o_l + ((it + 1) & 1) * kWTile + lr * kWLD + lc) = ro;
+    __syncthreads();                                                       // (1) statistics
+    float mean, var;
+    {
+      f32x4 s4[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) s4[u] = *(const f32x4*)(st_l + j * 16 + 4 * u);   // waves 2u, 2u+1: (mean, M2) x 2
+      mean = 0.f;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) mean += s4[u][0] + s4[u][2];
+      mean *= 0.125f;
+      var = 0.f;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const float d0 = s4[u][0] - mean, d1 = s4[u][2] - mean;
+        var += (s4[u][1] + s4[u][3]) + 16.f * (d0 * d0 + d1 * d1);
+      }
+    }
+    const float rstd = rsqrtf(var * (1.f / D) + kLnEps);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) y[t] = (y[t] - mean) * rstd * ga4[t] + be4[t];
+    if (p0 + j < n) gst4(Y + (size_t)(p0 + j) * D + 16 * w + 4 * g, y);
+    *(f32x4*)(y_l + j * kWLD + 16 * w + 4 * g) = y;
+    __syncthreads();                                                       // (2) normalised rows
+    // ---- logits of the 16 points against the wave's query tiles (C layout: row = point 4g+t, column = query j)
+    if (w < QT) {
+      const float* ty = y_l + j * kWLD + 4 * g;
+      f32x4 la[NTW], lb2[NTW];
+#pragma unroll
+      for (int i = 0; i < NTW; ++i) la[i] = lb2[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int S = 0; S < 8; S += 2) {
+        const f32x4 ya = *(const f32x4*)(ty + 16 * S), yb = *(const f32x4*)(ty + 16 * (S + 1));
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+          for (int i = 0; i < NTW; ++i) {
+            la[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(ya[t], ef[i][S][t], la[i], 0, 0, 0);
+            lb2[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(yb[t], ef[i][S + 1][t], lb2[i], 0, 0, 0);
+          }
+      }
+#pragma unroll
+      for (int i = 0; i < NTW; ++i) {
+        const int qt = w + 8 * i;
+        if (qt < QT) {
+          const f32x4 lg = la[i] + lb2[i];
+#pragma unroll
+          for (int t = 0; t < 4; ++t) L_l[(4 * g + t) * LL + qt * 16 + j] = lg[t];
+        }
+      }
+    }
+    __syncthreads();                                                       // (3) logits tile
+    // per-object max over that object's queries: object o >= 1 -> fg queries [qrange[o], qrange[o+1]); object 0 -> all
+    // background queries [n_fg, nq)   (agile3d.py:348-365)
+    {
+      const int p = tid & 15;
+      for (int o = tid >> 4; o <= K; o += 32) {
+        const int qb = o == 0 ? n_fg : qr_l[o], qe = o == 0 ? nq : qr_l[o + 1];
+        float mxv = -3.4e38f;
+        for (int q = qb; q < qe; ++q) mxv = fmaxf(mxv, L_l[p * LL + q]);
+        Ol[p * (K + 1) + o] = mxv;
+      }
+    }
+    __syncthreads();                                                       // (4) per-object maxima
+    if (tid < 16 && p0 + tid < n) {
+      float best = Ol[tid * (K + 1)];
+      int bi = 0;
+      for (int o = 1; o <= K; ++o) {
+        const float v = Ol[tid * (K + 1) + o];
+        if (v > best) {
+          best = v;
+          bi = o;
+        }
+      }
+      gst(labels + p0 + tid, (unsigned char)bi);
+      atomicAdd(&hist[bi], 1);
+    }
+    const int rows = min(16, n - p0);
+    for (int e = tid; e < rows * (K + 1); e += 512) gst(logits + (size_t)p0 * (K + 1) + e, Ol[e]);
+    // the next iteration rewrites st_l before barrier (1) and Ol only behind barrier (3): both behind every reader of this one
+  }
+  __syncthreads();
+  for (int e = tid; e <= K; e += 512)
+    if (hist[e]) atomicAdd(&counts[e], hist[e]);
+}

@@ -197,6 +197,18 @@ def main():
         "n777_k4_ragged": dict(n=777, K=4, clicks_per_obj=[5, 1, 1, 2], n_bg=1, seed=6, feat_scale=3.0),
         "n48_k10_tiny": dict(n=48, K=10, clicks_per_obj=1, n_bg=0, seed=7),
         "n100_k10_tiny": dict(n=100, K=10, clicks_per_obj=2, n_bg=4, seed=8, feat_scale=0.3),
+        # more than 64 queries (clicks + 10 learned background queries): the multi-object protocol adds clicks up to
+        # num_obj x 20 (eval_multi_obj.py:70,116-118).  One case per tile count of the fused wide tier (decoder_wide.h):
+        # 75 .. 205 queries; q80, q144 and q205 hit the all-True-row rule (an object without points after iteration 0 or 1)
+        "n1500_k7_q75": dict(n=1500, K=7, clicks_per_obj=9, n_bg=2, seed=9),
+        "n100_k10_q90": dict(n=100, K=10, clicks_per_obj=8, n_bg=0, seed=10, feat_scale=0.3),
+        "n800_k5_q105": dict(n=800, K=5, clicks_per_obj=18, n_bg=5, seed=11),
+        "n1100_k9_q124": dict(n=1100, K=9, clicks_per_obj=12, n_bg=6, seed=12, feat_scale=0.5),
+        "n1200_k8_q138": dict(n=1200, K=8, clicks_per_obj=15, n_bg=8, seed=13, dup_click=True),
+        "n1000_k9_q180": dict(n=1000, K=9, clicks_per_obj=18, n_bg=8, seed=14),
+        "n220_k10_q205": dict(n=220, K=10, clicks_per_obj=19, n_bg=5, seed=27, feat_scale=0.3),
+        "n80_k10_q80": dict(n=80, K=10, clicks_per_obj=7, n_bg=0, seed=20, feat_scale=0.3),
+        "n150_k12_q144": dict(n=150, K=12, clicks_per_obj=11, n_bg=2, seed=20, feat_scale=0.3),
     }
     for name, kw in cases.items():
         c = make_case(ref, **kw)
