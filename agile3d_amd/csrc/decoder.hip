@@ -217,7 +217,7 @@ struct QueryBufs {   // all [QP][...] fp32 in global scratch
   unsigned* sync;                                // [A3D_MAX_DEC_LAYERS][16] hand-off flags of k_query_block (zeroed per pass)
 };
 constexpr int kQlMaxHelpers = 8;
-constexpr int kMaxQBlocks = A3D_MAX_QUERIES / 64;
+constexpr int kMaxQBlocks = A3D_MAX_QUERIES / 32;   // query blocks of a sample: 64 rows in the unfused path, 32 in the wide tier
 
 // ---- one batch sample as the query-side kernels see it (k_query_init, k_c2s_combine, k_query_block: blockIdx.y / z)
 struct QuerySample {
@@ -2633,9 +2633,9 @@ static int launch_query_side(const a3d_decoder_weights* w, int l, QuerySample* q
     const size_t qb_lds = ql_lds + (size_t)kQVec * 4;
     if (nblk == 1) {
       k_query_block<QT, 0><<<dim3(nh_env, 1, ns), 512, qb_lds, st>>>(qs_dev, QW);
-    } else if constexpr (QT == 4) {
-      k_query_block<4, 1><<<dim3(1, nblk, ns), 512, qb_lds, st>>>(qs_dev, QW);
-      k_query_block<4, 2><<<dim3(nh_env, nblk, ns), 512, qb_lds, st>>>(qs_dev, QW);
+    } else if constexpr (QT == 4 || QT == 2) {   // blocks of 64 rows (unfused path) or of 32 (wide tier: more, shorter chains)
+      k_query_block<QT, 1><<<dim3(1, nblk, ns), 512, qb_lds, st>>>(qs_dev, QW);
+      k_query_block<QT, 2><<<dim3(nh_env, nblk, ns), 512, qb_lds, st>>>(qs_dev, QW);
     }
   }
   A3D_LAUNCH_CHECK();
@@ -2878,14 +2878,14 @@ static int run_decoder(const a3d_decoder_weights* w, Prepared* P, int ns, hipStr
 // query side runs its 64-query blocks on buffers of L.qp rows as before
 template <int QT>
 static int run_decoder_wide(const a3d_decoder_weights* w, Prepared* P, int ns, hipStream_t st) {
-  const int qp = P[0].L.qp, nblk = qp / 64;
+  const int qp = P[0].L.qp;
   {
     static bool big = false;
     if (!big) {
       big = true;
       const int big_lds = 160 * 1024;
-      A3D_ALLOW_LDS(big_lds, k_query_block<4, 1>);
-      A3D_ALLOW_LDS(big_lds, k_query_block<4, 2>);
+      A3D_ALLOW_LDS(big_lds, k_query_block<2, 1>);
+      A3D_ALLOW_LDS(big_lds, k_query_block<2, 2>);
     }
   }
   const int n_counts = A3D_MAX_DEC_LAYERS * (A3D_MAX_QUERIES + 1);
@@ -2897,16 +2897,19 @@ static int run_decoder_wide(const a3d_decoder_weights* w, Prepared* P, int ns, h
     nq_max = P[si].hm.nq > nq_max ? P[si].hm.nq : nq_max;
   }
   const size_t stage_lds = (size_t)2 * 2 * kWTile * 4;                       // two slots of (rows, position encodings)
-  const size_t out_lds = ((size_t)3 * kWTile + 16 * 16 + 16 * (QT * 16 + 1) + 16 * (Kmax + 1)) * 4 + (size_t)(2 * Kmax + 3) * 4;
+  const size_t out_lds = ((size_t)6 * kWTile + 2 * 256 + 2 * 32 * (Kmax + 1)) * 4 + (size_t)(Kmax + 1) * 4;   // k_out_w: O slots, rows, statistics, maxima, histogram
   DecTables T;
   int rc = upload_tables(P, ns, true, true, st, T);
   if (rc) return rc;
   {
     ProfScope ps(st, A3D_PROF_QUERY, 0, 0, 0, 0, nq_max);
-    k_query_init<4><<<dim3(nblk, ns), 512, 0, st>>>(T.qs_dev, w->bg_query_feat, w->bg_query_pos, w->time_table,
-                                                   w->layers[0].c2s_in_w, w->layers[0].c2s_in_b, n_counts);
+    // every row of the query-side buffers is initialised (the point-side kernels read 16 QT rows), 32 per workgroup
+    k_query_init<2><<<dim3(qp / 32, ns), 512, 0, st>>>(T.qs_dev, w->bg_query_feat, w->bg_query_pos, w->time_table,
+                                                      w->layers[0].c2s_in_w, w->layers[0].c2s_in_b, n_counts);
     A3D_LAUNCH_CHECK();
   }
+  // the query side in blocks of 32 rows: as many as the longest query list of the call needs
+  const int nblk = (nq_max + 31) / 32;
   for (int l = 0; l < w->n_layers; ++l) {
     const a3d_decoder_layer& LW = w->layers[l];
     // ---- click-to-scene; the first layer on the scene's cached keys / values when every sample has them
@@ -2937,7 +2940,7 @@ static int run_decoder_wide(const a3d_decoder_weights* w, Prepared* P, int ns, h
                                                   LW.c2s_in_b + 2 * D, qp);
       A3D_LAUNCH_CHECK();
     }
-    rc = launch_query_side<4>(w, l, T.qs_dev, qp, nblk, ns, nq_max, cached0, st);
+    rc = launch_query_side<2>(w, l, T.qs_dev, qp, nblk, ns, nq_max, cached0, st);
     if (rc) return rc;
     // ---- scene-to-click attention, then output projection + residual + LayerNorm + mask head
     {

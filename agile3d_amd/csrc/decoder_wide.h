@@ -299,155 +299,193 @@ __global__ void __launch_bounds__(512) k_s2c_w(const DecSampleDev* __restrict__ 
 // ---- output projection + residual + LayerNorm + mask head, wave = output column tile ------------------------------------
 // y[point j][16w+4g..+3] = bo + src + O Wo^T from the wave's register-resident slice of Wo; LayerNorm over the eight waves'
 // tiles through per-wave (mean, M2) pairs merged exactly (Chan); the normalised rows are exchanged through LDS and wave w
-// multiplies them with the mask embeddings of query tiles w (and w + 8), also register constants; per-object maximum,
-// label argmax, histogram and the logits rows as k_out_ln_mask.  Four barriers per 16-point group.
+// multiplies them with the mask embeddings of query tiles w (and w + 8), also register constants.  A lane then holds the
+// logits of four points against ONE query, whose object is a lane constant: the per-object maximum (agile3d.py:348-365) is
+// one LDS float-max atomic per value into [point][object] -- no logits tile, no scan.  Two 16-point groups per iteration
+// (four independent MFMA chains, three barriers per 32 points); label argmax, histogram and the logits rows as k_out_ln_mask.
 template <int QT>
 __global__ void __launch_bounds__(512) k_out_w(const DecSampleDev* __restrict__ samples, int ns, int layer,
                                                const float* __restrict__ Wo, const float* __restrict__ bo,
                                                const float* __restrict__ gamma, const float* __restrict__ beta, int Kmax) {
   constexpr int NTW = QT > 8 ? 2 : 1;          // query tiles per wave
-  constexpr int LL = QT * 16 + 1;
+  constexpr int MG = 2;                        // point groups per iteration
+  typedef __attribute__((address_space(3))) float lds_float;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  float* o_l = (float*)smem;                   // [2 slots][16][kWLD] attention output rows
-  float* y_l = o_l + 2 * kWTile;               // [16][kWLD] normalised rows
-  float* st_l = y_l + kWTile;                  // [16 points][8 waves][2] LayerNorm partials
-  float* L_l = st_l + 16 * 16;                 // [16][LL] logits of the group
-  float* Ol = L_l + 16 * LL;                   // [16][Kmax+1] per-object maxima
-  int* hist = (int*)(Ol + 16 * (Kmax + 1));    // [Kmax+1]
-  int* qr_l = hist + Kmax + 1;                 // [Kmax+2]
+  float* o_l = (float*)smem;                   // [2 slots][MG][16][kWLD] attention output rows
+  float* y_l = o_l + 2 * MG * kWTile;          // [MG][16][kWLD] normalised rows
+  float* st_l = y_l + MG * kWTile;             // [MG][16 points][8 waves][2] LayerNorm partials
+  float* Ol = st_l + MG * 16 * 16;             // [2 slots][MG * 16][Kmax+1] per-object maxima
+  int* hist = (int*)(Ol + 2 * MG * 16 * (Kmax + 1));   // [Kmax+1]
   const DecSampleDev& sm = sample_of_wg(samples, ns);
   const int lb = blockIdx.x - sm.wg_begin, nwg = sm.wg_end - sm.wg_begin;
-  const int n = sm.n, ngroups = (n + 15) / 16, nq = sm.nq, n_fg = sm.n_fg, K = sm.K;
+  const int n = sm.n, npairs = (n + 16 * MG - 1) / (16 * MG), K = sm.K, K1 = K + 1;
   const float* __restrict__ O = sm.bufB;
   const float* __restrict__ Xres = layer_input(sm, layer);
   float* __restrict__ Y = (layer & 1) ? sm.bufD : sm.bufC;
-  float* logits = sm.logits + (size_t)layer * n * (K + 1);
+  float* logits = sm.logits + (size_t)layer * n * K1;
   unsigned char* labels = sm.labels;
   int* counts = sm.counts + (size_t)layer * (A3D_MAX_QUERIES + 1);
   const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int g = lane >> 4, j = lane & 15;
-  for (int e = tid; e <= K + 1; e += 512) qr_l[e] = gld(sm.qrange + e);
   for (int e = tid; e <= K; e += 512) hist[e] = 0;
   f32x4 wo[8];
 #pragma unroll
   for (int S = 0; S < 8; ++S) wo[S] = ((const f32x4 A3D_GLOBAL*)Wo)[(S * 8 + w) * 64 + lane];
   const f32x4 bo4 = gld4(bo + 16 * w + 4 * g), ga4 = gld4(gamma + 16 * w + 4 * g), be4 = gld4(beta + 16 * w + 4 * g);
-  // mask embeddings E[query 16 qt + j][16 S + 4 g ..+3] of the wave's query tiles (B fragments of the logits product)
+  // mask embeddings E[query 16 qt + j][16 S + 4 g ..+3] of the wave's query tiles (B fragments of the logits product) and
+  // the object of query 16 qt + j (0 = background, -1 = padding)
   f32x4 ef[NTW][8];
+  int oq[NTW];
 #pragma unroll
   for (int i = 0; i < NTW; ++i) {
     const int qt = w + 8 * i;
+    oq[i] = qt < QT ? gld(sm.qobj + qt * 16 + j) : -1;
 #pragma unroll
     for (int S = 0; S < 8; ++S)
       ef[i][S] = qt < QT ? gld4(sm.E + (size_t)(qt * 16 + j) * D + 16 * S + 4 * g) : (f32x4){0.f, 0.f, 0.f, 0.f};
   }
   const int lr = tid >> 5, lc = (tid & 31) * 4;
-  int grp = lb;
-  f32x4 ro = (f32x4){0.f, 0.f, 0.f, 0.f}, rres = ro;
-  if (grp < ngroups) {
-    ro = gld4(O + (size_t)min(grp * 16 + lr, n - 1) * D + lc);
-    rres = gld4(Xres + (size_t)min(grp * 16 + j, n - 1) * D + 16 * w + 4 * g);
-    *(f32x4*)(o_l + lr * kWLD + lc) = ro;
+  int pr = lb;                                 // pair of point groups
+  f32x4 ro[MG], rres[MG];
+#pragma unroll
+  for (int mg = 0; mg < MG; ++mg) ro[mg] = rres[mg] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  if (pr < npairs) {
+#pragma unroll
+    for (int mg = 0; mg < MG; ++mg) {
+      ro[mg] = gld4(O + (size_t)min((pr * MG + mg) * 16 + lr, n - 1) * D + lc);
+      rres[mg] = gld4(Xres + (size_t)min((pr * MG + mg) * 16 + j, n - 1) * D + 16 * w + 4 * g);
+      *(f32x4*)(o_l + mg * kWTile + lr * kWLD + lc) = ro[mg];
+    }
   }
   __syncthreads();
-  for (int it = 0; grp < ngroups; ++it, grp += nwg) {
-    const int p0 = grp * 16;
-    const int next = grp + nwg;
-    const bool has_next = next < ngroups;
-    const f32x4 res = rres;
+  for (int it = 0; pr < npairs; ++it, pr += nwg) {
+    const int p0 = pr * MG * 16;
+    const int next = pr + nwg;
+    const bool has_next = next < npairs;
+    f32x4 res[MG];
+#pragma unroll
+    for (int mg = 0; mg < MG; ++mg) res[mg] = rres[mg];
     if (has_next) {
-      ro = gld4(O + (size_t)min(next * 16 + lr, n - 1) * D + lc);
-      rres = gld4(Xres + (size_t)min(next * 16 + j, n - 1) * D + 16 * w + 4 * g);
-    }
-    // ---- y tile: bias + residual + O Wo^T (even / odd K-steps on two accumulators)
-    const float* to = o_l + (it & 1) * kWTile + j * kWLD + 4 * g;
-    f32x4 y0 = bo4 + res, y1 = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int S = 0; S < 8; S += 2) {
-      const f32x4 oa = *(const f32x4*)(to + 16 * S), ob = *(const f32x4*)(to + 16 * (S + 1));
-#pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        y0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wo[S][t], oa[t], y0, 0, 0, 0);
-        y1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wo[S + 1][t], ob[t], y1, 0, 0, 0);
+      for (int mg = 0; mg < MG; ++mg) {
+        ro[mg] = gld4(O + (size_t)min((next * MG + mg) * 16 + lr, n - 1) * D + lc);
+        rres[mg] = gld4(Xres + (size_t)min((next * MG + mg) * 16 + j, n - 1) * D + 16 * w + 4 * g);
       }
     }
-    f32x4 y = y0 + y1;
-    // ---- LayerNorm: the wave's 16 channels of point j -> (mean, M2), merged over the eight waves
-    const float mw = rows_sum((y[0] + y[1]) + (y[2] + y[3])) * (1.f / 16.f);
-    float m2 = 0.f;
-#pragma unroll
-    for (int t = 0; t < 4; ++t) m2 += (y[t] - mw) * (y[t] - mw);
-    m2 = rows_sum(m2);
-    if (g == 0) *(float2*)(st_l + (j * 8 + w) * 2) = make_float2(mw, m2);
-    if (has_next) *(f32x4*)(o_l + ((it + 1) & 1) * kWTile + lr * kWLD + lc) = ro;
-    __syncthreads();                                                       // (1) statistics
-    float mean, var;
+    // this iteration's per-object maxima start at -inf (the slot's previous readers are two iterations back)
+    float* Oc = Ol + (it & 1) * MG * 16 * K1;
+    for (int e = tid; e < MG * 16 * K1; e += 512) Oc[e] = -3.4e38f;
+    // ---- y tiles: bias + residual + O Wo^T (even / odd K-steps and the two groups: four chains)
+    const float* to = o_l + (it & 1) * MG * kWTile + j * kWLD + 4 * g;
+    f32x4 y[MG];
     {
+      f32x4 ya[MG], yb[MG];
+#pragma unroll
+      for (int mg = 0; mg < MG; ++mg) {
+        ya[mg] = bo4 + res[mg];
+        yb[mg] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      }
+#pragma unroll
+      for (int S = 0; S < 8; S += 2) {
+        f32x4 oa[MG], ob[MG];
+#pragma unroll
+        for (int mg = 0; mg < MG; ++mg) {
+          oa[mg] = *(const f32x4*)(to + mg * kWTile + 16 * S);
+          ob[mg] = *(const f32x4*)(to + mg * kWTile + 16 * (S + 1));
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+          for (int mg = 0; mg < MG; ++mg) {
+            ya[mg] = __builtin_amdgcn_mfma_f32_16x16x4f32(wo[S][t], oa[mg][t], ya[mg], 0, 0, 0);
+            yb[mg] = __builtin_amdgcn_mfma_f32_16x16x4f32(wo[S + 1][t], ob[mg][t], yb[mg], 0, 0, 0);
+          }
+      }
+#pragma unroll
+      for (int mg = 0; mg < MG; ++mg) y[mg] = ya[mg] + yb[mg];
+    }
+    // ---- LayerNorm: the wave's 16 channels of point j -> (mean, M2), merged over the eight waves
+#pragma unroll
+    for (int mg = 0; mg < MG; ++mg) {
+      const float mw = rows_sum((y[mg][0] + y[mg][1]) + (y[mg][2] + y[mg][3])) * (1.f / 16.f);
+      float m2 = 0.f;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) m2 += (y[mg][t] - mw) * (y[mg][t] - mw);
+      m2 = rows_sum(m2);
+      if (g == 0) *(float2*)(st_l + mg * 256 + (j * 8 + w) * 2) = make_float2(mw, m2);
+    }
+    if (has_next) {
+#pragma unroll
+      for (int mg = 0; mg < MG; ++mg) *(f32x4*)(o_l + (((it + 1) & 1) * MG + mg) * kWTile + lr * kWLD + lc) = ro[mg];
+    }
+    __syncthreads();                                                       // (1) statistics
+#pragma unroll
+    for (int mg = 0; mg < MG; ++mg) {
       f32x4 s4[4];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) s4[u] = *(const f32x4*)(st_l + j * 16 + 4 * u);   // waves 2u, 2u+1: (mean, M2) x 2
-      mean = 0.f;
+      for (int u = 0; u < 4; ++u) s4[u] = *(const f32x4*)(st_l + mg * 256 + j * 16 + 4 * u);   // waves 2u, 2u+1: (mean, M2) x 2
+      float mean = 0.f;
 #pragma unroll
       for (int u = 0; u < 4; ++u) mean += s4[u][0] + s4[u][2];
       mean *= 0.125f;
-      var = 0.f;
+      float var = 0.f;
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const float d0 = s4[u][0] - mean, d1 = s4[u][2] - mean;
         var += (s4[u][1] + s4[u][3]) + 16.f * (d0 * d0 + d1 * d1);
       }
-    }
-    const float rstd = rsqrtf(var * (1.f / D) + kLnEps);
+      const float rstd = rsqrtf(var * (1.f / D) + kLnEps);
 #pragma unroll
-    for (int t = 0; t < 4; ++t) y[t] = (y[t] - mean) * rstd * ga4[t] + be4[t];
-    if (p0 + j < n) gst4(Y + (size_t)(p0 + j) * D + 16 * w + 4 * g, y);
-    *(f32x4*)(y_l + j * kWLD + 16 * w + 4 * g) = y;
+      for (int t = 0; t < 4; ++t) y[mg][t] = (y[mg][t] - mean) * rstd * ga4[t] + be4[t];
+      const int row = p0 + mg * 16 + j;
+      if (row < n) gst4(Y + (size_t)row * D + 16 * w + 4 * g, y[mg]);
+      *(f32x4*)(y_l + mg * kWTile + j * kWLD + 16 * w + 4 * g) = y[mg];
+    }
     __syncthreads();                                                       // (2) normalised rows
-    // ---- logits of the 16 points against the wave's query tiles (C layout: row = point 4g+t, column = query j)
+    // ---- logits of the 2 x 16 points against the wave's query tiles (C layout: row = point 4g+t, column = query j), then
+    // the per-object maxima
     if (w < QT) {
       const float* ty = y_l + j * kWLD + 4 * g;
-      f32x4 la[NTW], lb2[NTW];
+      f32x4 la[MG][NTW], lc2[MG][NTW];
 #pragma unroll
-      for (int i = 0; i < NTW; ++i) la[i] = lb2[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      for (int mg = 0; mg < MG; ++mg)
+#pragma unroll
+        for (int i = 0; i < NTW; ++i) la[mg][i] = lc2[mg][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int S = 0; S < 8; S += 2) {
-        const f32x4 ya = *(const f32x4*)(ty + 16 * S), yb = *(const f32x4*)(ty + 16 * (S + 1));
+        f32x4 ya[MG], yb[MG];
+#pragma unroll
+        for (int mg = 0; mg < MG; ++mg) {
+          ya[mg] = *(const f32x4*)(ty + mg * kWTile + 16 * S);
+          yb[mg] = *(const f32x4*)(ty + mg * kWTile + 16 * (S + 1));
+        }
 #pragma unroll
         for (int t = 0; t < 4; ++t)
 #pragma unroll
-          for (int i = 0; i < NTW; ++i) {
-            la[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(ya[t], ef[i][S][t], la[i], 0, 0, 0);
-            lb2[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(yb[t], ef[i][S + 1][t], lb2[i], 0, 0, 0);
+          for (int mg = 0; mg < MG; ++mg)
+#pragma unroll
+            for (int i = 0; i < NTW; ++i) {
+              la[mg][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(ya[mg][t], ef[i][S][t], la[mg][i], 0, 0, 0);
+              lc2[mg][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(yb[mg][t], ef[i][S + 1][t], lc2[mg][i], 0, 0, 0);
+            }
+      }
+#pragma unroll
+      for (int mg = 0; mg < MG; ++mg)
+#pragma unroll
+        for (int i = 0; i < NTW; ++i)
+          if (oq[i] >= 0) {
+            const f32x4 lg = la[mg][i] + lc2[mg][i];
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+              __builtin_amdgcn_ds_fmaxf((lds_float*)(Oc + (mg * 16 + 4 * g + t) * K1 + oq[i]), lg[t], 0, 0, false);
           }
-      }
-#pragma unroll
-      for (int i = 0; i < NTW; ++i) {
-        const int qt = w + 8 * i;
-        if (qt < QT) {
-          const f32x4 lg = la[i] + lb2[i];
-#pragma unroll
-          for (int t = 0; t < 4; ++t) L_l[(4 * g + t) * LL + qt * 16 + j] = lg[t];
-        }
-      }
     }
-    __syncthreads();                                                       // (3) logits tile
-    // per-object max over that object's queries: object o >= 1 -> fg queries [qrange[o], qrange[o+1]); object 0 -> all
-    // background queries [n_fg, nq)   (agile3d.py:348-365)
-    {
-      const int p = tid & 15;
-      for (int o = tid >> 4; o <= K; o += 32) {
-        const int qb = o == 0 ? n_fg : qr_l[o], qe = o == 0 ? nq : qr_l[o + 1];
-        float mxv = -3.4e38f;
-        for (int q = qb; q < qe; ++q) mxv = fmaxf(mxv, L_l[p * LL + q]);
-        Ol[p * (K + 1) + o] = mxv;
-      }
-    }
-    __syncthreads();                                                       // (4) per-object maxima
-    if (tid < 16 && p0 + tid < n) {
-      float best = Ol[tid * (K + 1)];
+    __syncthreads();                                                       // (3) per-object maxima
+    if (tid < MG * 16 && p0 + tid < n) {
+      float best = Oc[tid * K1];
       int bi = 0;
       for (int o = 1; o <= K; ++o) {
-        const float v = Ol[tid * (K + 1) + o];
+        const float v = Oc[tid * K1 + o];
         if (v > best) {
           best = v;
           bi = o;
@@ -456,9 +494,8 @@ __global__ void __launch_bounds__(512) k_out_w(const DecSampleDev* __restrict__ 
       gst(labels + p0 + tid, (unsigned char)bi);
       atomicAdd(&hist[bi], 1);
     }
-    const int rows = min(16, n - p0);
-    for (int e = tid; e < rows * (K + 1); e += 512) gst(logits + (size_t)p0 * (K + 1) + e, Ol[e]);
-    // the next iteration rewrites st_l before barrier (1) and Ol only behind barrier (3): both behind every reader of this one
+    const int rows = min(MG * 16, n - p0);
+    for (int e = tid; e < rows * K1; e += 512) gst(logits + (size_t)p0 * K1 + e, Oc[e]);
   }
   __syncthreads();
   for (int e = tid; e <= K; e += 512)
