@@ -72,40 +72,51 @@ __global__ void __launch_bounds__(512) k_c2s_w(const DecSampleDev* __restrict__ 
   }
   const f32x4 bk4 = gld4(bk + 16 * h + 4 * g);
   const float bvj = gld(bv + 16 * h + j);
+  // The attention mask (agile3d.py:367-380: a query whose object currently owns points sees only those points) is ONE more
+  // MFMA in front of each score tile instead of a compare + select per score: -2^20 (lab_p - obj_q)^2 is the rank-3 product
+  // (lab^2, -2 lab, 1) . (1, obj, obj^2) (-2^20), exact in fp32 for ids <= 254 -- 0 for the object's own points, <= -2^20
+  // (a weight of exactly 0) elsewhere, all zeros for an unmasked query -- and the fourth K slot carries -m, the query's
+  // running reference maximum, so the accumulator comes out as score - m: a weight is one v_exp_f32 (a vector instruction
+  // costs matrix-pipe time on gfx950).  mq = the lane's entry of that B operand: B[k = g][query j].
   f32x4 qf[QT];
-  int obj[QT];
+  float mq[QT];
 #pragma unroll
   for (int qt = 0; qt < QT; ++qt) {
     qf[qt] = gld4(sm.qproj + (size_t)(qt * 16 + j) * D + 16 * h + 4 * g);
     const int o = gld(sm.qobj + qt * 16 + j);
-    // a query is masked only if its object currently owns at least one point (agile3d.py:369,375); -1 = not masked
-    obj[qt] = labels != nullptr && o >= 0 && gld(counts + o) > 0 ? o : -1;
+    // a query is masked only if its object currently owns at least one point (agile3d.py:369,375)
+    const bool masked = labels != nullptr && o >= 0 && gld(counts + o) > 0;
+    const float fo = (float)o;
+    mq[qt] = !masked || g == 3 ? 0.f : -1048576.f * (g == 0 ? 1.f : g == 1 ? fo : fo * fo);
   }
+  // m is a REFERENCE maximum, not the exact one: it moves only when a score exceeds it by more than 2^kLazy (the first group
+  // sets it), so the common group costs no rescale of l and acc; what k_c2s_combine needs is l and acc relative to the m it reads
+  constexpr float kLazy = 8.f;
   float m[QT], l[QT];
   f32x4 acc[QT];
 #pragma unroll
   for (int qt = 0; qt < QT; ++qt) {
-    m[qt] = kNegBig;
+    m[qt] = 0.f;
     l[qt] = 0.f;
     acc[qt] = (f32x4){0.f, 0.f, 0.f, 0.f};
   }
   WideLoader ld;
-  unsigned lab_nx = 0u;
+  unsigned lab_nx = 0u;   // label byte of point j of the next group
   int grp = lb;
   if (grp < ngroups) {
     ld.issue(X, Pe, grp, n);
-    if (labels) lab_nx = gld((const unsigned*)(labels + grp * 16 + 4 * g));
+    if (labels) lab_nx = gld(labels + min(grp * 16 + j, n - 1));
     ld.commit(tiles);
   }
   __syncthreads();
   for (int it = 0; grp < ngroups; ++it, grp += nwg) {
     const int p0 = grp * 16;
-    const unsigned lab4 = lab_nx;
+    const float labj = (float)lab_nx;
     const int next = grp + nwg;
     const bool has_next = next < ngroups;
-    if (has_next) {   // the next group's rows: a whole projection phase to land, then into the other slot
+    if (has_next) {   // the next group's rows: the whole iteration to land, then into the other slot
       ld.issue(X, Pe, next, n);
-      if (labels) lab_nx = gld((const unsigned*)(labels + next * 16 + 4 * g));
+      if (labels) lab_nx = gld(labels + min(next * 16 + j, n - 1));
     }
     const float* tx = tiles + (it & 1) * 2 * kWTile + j * kWLD + 4 * g;
     // ---- projections: kf = K[point j][16h+4g..+3] (transposed product), vv = V[points 4g..4g+3][16h+j]
@@ -129,35 +140,44 @@ __global__ void __launch_bounds__(512) k_c2s_w(const DecSampleDev* __restrict__ 
         pe = npe;
       }
     }
-    if (has_next) ld.commit(tiles + ((it + 1) & 1) * 2 * kWTile);
     // ---- attention of the 16 points against every query tile
-    int lab[4];
-    bool oob[4];
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      lab[t] = (int)((lab4 >> (8 * t)) & 0xffu);
-      oob[t] = p0 + 4 * g + t >= n;
-    }
+    const float am = g == 0 ? labj * labj : g == 1 ? -2.f * labj : 1.f;   // A[point j][k = g] of the mask product
+    const bool tail = p0 + 16 > n;                                        // rows beyond the sample: blocked for every query
 #pragma unroll
     for (int qt = 0; qt < QT; ++qt) {
       f32x4 sc4;
+      auto scores = [&]() {
+        sc4 = __builtin_amdgcn_mfma_f32_16x16x4f32(am, mq[qt], (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
 #pragma unroll
-      for (int t = 0; t < 4; ++t) sc4[t] = oob[t] || (obj[qt] >= 0 && lab[t] != obj[qt]) ? kNegBig : 0.f;
+        for (int t = 0; t < 4; ++t) sc4 = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[t], qf[qt][t], sc4, 0, 0, 0);
+        if (tail) {
 #pragma unroll
-      for (int t = 0; t < 4; ++t) sc4 = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[t], qf[qt][t], sc4, 0, 0, 0);
-      float mx = fmaxf(fmaxf(sc4[0], sc4[1]), fmaxf(sc4[2], sc4[3]));
-      mx = rows_max(mx);
-      const float mnew = fmaxf(m[qt], mx);
-      const float scl = exp2_fast(m[qt] - mnew);
-      m[qt] = mnew;
+          for (int t = 0; t < 4; ++t)
+            if (p0 + 4 * g + t >= n) sc4[t] = kNegBig;
+        }
+      };
+      scores();
+      const float mx4 = fmaxf(fmaxf(sc4[0], sc4[1]), fmaxf(sc4[2], sc4[3]));
+      if (it == 0 || __builtin_amdgcn_ballot_w64(mx4 > kLazy) != 0) {   // wave-uniform: move the reference, redo the tile
+        const float mx = rows_max(mx4);
+        // the first group centres every column (a column whose points are all blocked stops at -2^16: a later real
+        // score is then still resolved to 2^-7 before the tile is recomputed against the new reference)
+        const float delta = it == 0 ? fmaxf(mx, -65536.f) : fmaxf(mx, 0.f);
+        const float scl = it == 0 ? 0.f : exp2_fast(-delta);
+        m[qt] += delta;
+        l[qt] *= scl;
+        acc[qt] *= scl;
+        if (g == 3) mq[qt] = -m[qt];
+        scores();
+      }
       f32x4 pw;
 #pragma unroll
-      for (int t = 0; t < 4; ++t) pw[t] = exp2_fast(sc4[t] - mnew);
-      l[qt] = l[qt] * scl + ((pw[0] + pw[1]) + (pw[2] + pw[3]));
-      acc[qt] *= scl;
+      for (int t = 0; t < 4; ++t) pw[t] = exp2_fast(sc4[t]);
+      l[qt] += (pw[0] + pw[1]) + (pw[2] + pw[3]);
 #pragma unroll
       for (int t = 0; t < 4; ++t) acc[qt] = __builtin_amdgcn_mfma_f32_16x16x4f32(vv[t], pw[t], acc[qt], 0, 0, 0);
     }
+    if (has_next) ld.commit(tiles + ((it + 1) & 1) * 2 * kWTile);
     __syncthreads();
   }
   // one partial per (head, query) and workgroup: [h][q][workgroup] -- what k_c2s_combine walks
@@ -255,7 +275,6 @@ __global__ void __launch_bounds__(512) k_s2c_w(const DecSampleDev* __restrict__ 
         xb = nb;
       }
       qf = q0 + q1;
-      if (has_next) ld.commit(tiles + ((it + 1) & 1) * 2 * kWTile);
     }
     // S^T[key 16kt+4g+t][point j]
     f32x4 sc[QT];
@@ -292,7 +311,10 @@ __global__ void __launch_bounds__(512) k_s2c_w(const DecSampleDev* __restrict__ 
       for (int t = 0; t < 4; ++t) a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(vf[QT - 1][t], sc[QT - 1][t], a0, 0, 0, 0);
     }
     if (p0 + j < n) gst4(O + (size_t)(p0 + j) * D + 16 * h + 4 * g, (a0 + a1) * inv);
-    if constexpr (!QC) __syncthreads();
+    if constexpr (!QC) {
+      if (has_next) ld.commit(tiles + ((it + 1) & 1) * 2 * kWTile);   // the rows have had the whole iteration to land
+      __syncthreads();
+    }
   }
 }
 
@@ -414,10 +436,6 @@ __global__ void __launch_bounds__(512) k_out_w(const DecSampleDev* __restrict__ 
       m2 = rows_sum(m2);
       if (g == 0) *(float2*)(st_l + mg * 256 + (j * 8 + w) * 2) = make_float2(mw, m2);
     }
-    if (has_next) {
-#pragma unroll
-      for (int mg = 0; mg < MG; ++mg) *(f32x4*)(o_l + (((it + 1) & 1) * MG + mg) * kWTile + lr * kWLD + lc) = ro[mg];
-    }
     __syncthreads();                                                       // (1) statistics
 #pragma unroll
     for (int mg = 0; mg < MG; ++mg) {
@@ -479,6 +497,10 @@ __global__ void __launch_bounds__(512) k_out_w(const DecSampleDev* __restrict__ 
             for (int t = 0; t < 4; ++t)
               __builtin_amdgcn_ds_fmaxf((lds_float*)(Oc + (mg * 16 + 4 * g + t) * K1 + oq[i]), lg[t], 0, 0, false);
           }
+    }
+    if (has_next) {   // the next pair's attention rows: issued at the top of the iteration
+#pragma unroll
+      for (int mg = 0; mg < MG; ++mg) *(f32x4*)(o_l + (((it + 1) & 1) * MG + mg) * kWTile + lr * kWLD + lc) = ro[mg];
     }
     __syncthreads();                                                       // (3) per-object maxima
     if (tid < MG * 16 && p0 + tid < n) {

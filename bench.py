@@ -809,6 +809,15 @@ def main():
             r1 = model.forward_backbone(SparseTensor(features=f1, coordinates=c1), raw_coordinates=w1)
             t_dec1, _ = wall(lambda: model.forward_mask(*r1, click_idx=[ci], click_time_idx=[ct]), reps=30)
             res["decoder_pass_ms_single"] = round(t_dec1, 4)
+            # one decoder pass on that scene by query count (5 objects x k clicks + 10 learned queries): 20 / 60 run the
+            # <= 64-query kernels, 85 / 160 the fused wide tier (decoder_wide.h); the reference's protocol adds clicks up
+            # to num_obj x 20 (eval_multi_obj.py:116-118), training up to 19 click rounds (engine.py:83-93)
+            by_q = {}
+            for cpo in (2, 10, 15, 30):
+                ciq, ctq = make_clicks(sc["labels"], args.objects, cpo, 0, seed=11 + cpo)
+                tq, _ = wall(lambda: model.forward_mask(*r1, click_idx=[ciq], click_time_idx=[ctq]), reps=20)
+                by_q[str(args.objects * cpo + 10)] = round(tq, 4)
+            res["decoder_pass_ms_by_queries"] = by_q
             res["decoder_pass_note"] = ("repeated passes on ONE backbone output, as the interactive loop runs them: from the third pass on "
                                         "the first layer's click-to-scene keys / values come from the per-scene cache (A3D_KV_CACHE_MB=0 "
                                         "switches it off); the timed steps of `value` run one pass per fresh scene and never use it")
