@@ -20,6 +20,8 @@
 // The position encoding is added to the GEMM input on the fly (K = (src + pos) Wk^T, Q likewise):
 // k_dense reads both operands once, nothing click-independent is cached.
 #include "common.h"
+#include <algorithm>
+#include <type_traits>
 #include <vector>
 
 namespace a3d {
@@ -228,6 +230,7 @@ struct QuerySample {
   const float* part;             // click-to-scene flash partials of this sample and how many there are
   int n_part;
   int n_part0;                   // ... in the first layer when it runs on cached keys / values (one per 128-point chunk)
+  int qp;                        // rows of the sample's query-side buffers (the partials' [h][qp][part] layout)
 };
 
 // ---- one batch sample as the fused wide kernels see it (a3d_decoder_forward_batch) ------------------------------
@@ -248,6 +251,7 @@ struct DecSampleDev {
   const int *qobj, *qrange;        // QueryMeta::obj / qrange (device)
   const float *qproj, *ks, *vs, *E;
   const float* q0;                 // the scene's cached layer-0 scene-to-click queries (src + pos) Wq^T + bq [n][128], or nullptr
+  int qp, nqt;                     // rows of this sample's query-side buffers; its 16-query tiles (wide tier: the samples of a launch differ)
 };
 constexpr int kMaxBatchSamples = 64;
 __device__ __forceinline__ const DecSampleDev& sample_of_wg(const DecSampleDev* samples, int ns) {
@@ -626,8 +630,9 @@ __global__ void __launch_bounds__(512) k_kv_c2s(const DecSampleDev* __restrict__
 constexpr int kFusedC2SGrid = 256;   // one persistent 8-wave workgroup per CU (128 KB of weights in LDS)
 
 // merge the per-chunk flash partials (m, l, acc[16]) of one (query, head): one wave per pair
-__global__ void __launch_bounds__(64) k_c2s_combine(const QuerySample* __restrict__ qs, int QP, int cached0) {
+__global__ void __launch_bounds__(64) k_c2s_combine(const QuerySample* __restrict__ qs, int cached0) {
   const QuerySample& smp = qs[blockIdx.y];
+  const int QP = smp.qp;
   const int q = blockIdx.x / H, h = blockIdx.x % H, lane = threadIdx.x;
   if (q >= smp.meta->nq) return;
   const float* __restrict__ part = smp.part;
@@ -1630,6 +1635,7 @@ __global__ void __launch_bounds__(512) k_query_init(const QuerySample* __restric
   int* counts = qs[blockIdx.y].counts;
   __shared__ __attribute__((aligned(16))) float lds[QP * kLinLD];
   const int q0 = blockIdx.x * QP;                 // this workgroup's block of queries
+  if (q0 >= qs[blockIdx.y].qp) return;            // the grid serves the longest query list of the call
   const int Q = max(0, min(QP, meta->nq - q0)), n_fg = meta->n_fg, n_bgl = meta->n_bgl;
   B.queries += (size_t)q0 * D; B.qpos += (size_t)q0 * D; B.qproj += (size_t)q0 * D;
   B.ks += (size_t)q0 * D; B.vs += (size_t)q0 * D; B.E += (size_t)q0 * D;
@@ -1638,7 +1644,8 @@ __global__ void __launch_bounds__(512) k_query_init(const QuerySample* __restric
     // the hand-off flags of this sample's k_query_block launches (every layer, every query block)
     for (int e = threadIdx.x; e < A3D_MAX_DEC_LAYERS * kMaxQBlocks * 16; e += blockDim.x) B.sync[e] = 0u;
   }
-  for (int e = threadIdx.x; e < QP * D; e += blockDim.x) {
+  const int rows_here = min(QP, qs[blockIdx.y].qp - q0);   // the last block of a 16- or 48-row buffer is short
+  for (int e = threadIdx.x; e < rows_here * D; e += blockDim.x) {
     const int c = e & 127;
     const int q = q0 + (e >> 7);
     float f = 0.f, p = 0.f;
@@ -1953,6 +1960,7 @@ __global__ void __launch_bounds__(512) k_query_block(const QuerySample* __restri
   // queries each; hand-off through global memory with agent-scope loads / stores + flags
   const int nh = (int)gridDim.x, hx = (int)blockIdx.x;
   const int Qall = gld(&meta->nq);
+  if (PART != 0 && q0 >= Qall) return;   // a block of another sample's longer query list: no rows, nothing anybody reads
   const int Q = max(0, min(QP, Qall - q0));
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* qpos = (float*)smem;            // [QP][132]  query position encodings (c2c values in between; mask MLP hidden)
@@ -2567,6 +2575,8 @@ static int upload_tables(Prepared* P, int ns, bool wg_per_group, bool part_per_w
       d.vs = p.B.vs;
       d.E = p.B.E;
       d.q0 = p.kv0 && p.kv0_state != 0 ? p.kv0 + (size_t)2 * p.n * D : nullptr;
+      d.qp = p.L.qp;
+      d.nqt = (p.hm.nq + 15) / 16;
     }
     QuerySample* hq = (QuerySample*)(up_host.data() + up_qs);
     unsigned* sync0 = (unsigned*)(P[0].ws + P[0].L.sync);   // zeroed by k_query_init (a sample's first query block)
@@ -2581,6 +2591,7 @@ static int upload_tables(Prepared* P, int ns, bool wg_per_group, bool part_per_w
       hq[si].part = p.part;
       hq[si].n_part = part_per_wg ? (p.wg_end - p.wg_begin) : p.L.nchunk;   // k_kv_c2s merges its slot groups: one partial per workgroup
       hq[si].n_part0 = p.L.nchunk;
+      hq[si].qp = p.L.qp;
     }
     // pageable source: the runtime stages it before returning
     A3D_HIP_CHECK(hipMemcpyAsync(up_dev, up_host.data(), up_bytes, hipMemcpyHostToDevice, st));
@@ -2615,7 +2626,7 @@ static int launch_query_side(const a3d_decoder_weights* w, int l, QuerySample* q
   QW.layer = l;
   {   // one workgroup (or chain of query blocks) per sample: blockIdx.y
     ProfScope ps(st, A3D_PROF_QUERY, 0, 0, 0, 0, nq_max);
-    k_c2s_combine<<<dim3(nq_max * H, ns), 64, 0, st>>>(qs_dev, qp, cached0 ? 1 : 0);
+    k_c2s_combine<<<dim3(nq_max * H, ns), 64, 0, st>>>(qs_dev, cached0 ? 1 : 0);
     const size_t ql_lds = (size_t)4 * QP * kQLD * 4 + 16;   // four [QP][132] tiles + the word of block_any
     // FFN helper workgroups next to a block's workgroup (A3D_QL_HELPERS = total workgroups per block, 1 = none: the
     // switch the tests use to compare the hand-off with the single-workgroup chain)
@@ -2878,7 +2889,8 @@ static int run_decoder(const a3d_decoder_weights* w, Prepared* P, int ns, hipStr
 // query side runs its 64-query blocks on buffers of L.qp rows as before
 template <int QT>
 static int run_decoder_wide(const a3d_decoder_weights* w, Prepared* P, int ns, hipStream_t st) {
-  const int qp = P[0].L.qp;
+  int qp = 0;   // rows of the longest query-side buffers of the group
+  for (int si = 0; si < ns; ++si) qp = std::max(qp, P[si].L.qp);
   {
     static bool big = false;
     if (!big) {
@@ -2904,7 +2916,7 @@ static int run_decoder_wide(const a3d_decoder_weights* w, Prepared* P, int ns, h
   {
     ProfScope ps(st, A3D_PROF_QUERY, 0, 0, 0, 0, nq_max);
     // every row of the query-side buffers is initialised (the point-side kernels read 16 QT rows), 32 per workgroup
-    k_query_init<2><<<dim3(qp / 32, ns), 512, 0, st>>>(T.qs_dev, w->bg_query_feat, w->bg_query_pos, w->time_table,
+    k_query_init<2><<<dim3((qp + 31) / 32, ns), 512, 0, st>>>(T.qs_dev, w->bg_query_feat, w->bg_query_pos, w->time_table,
                                                       w->layers[0].c2s_in_w, w->layers[0].c2s_in_b, n_counts);
     A3D_LAUNCH_CHECK();
   }
@@ -2931,13 +2943,27 @@ static int run_decoder_wide(const a3d_decoder_weights* w, Prepared* P, int ns, h
           if (rc) return rc;
         }
         ProfScope ps(st, A3D_PROF_C2S, 0, 0, 0, 0, p.n);
-        k_c2s_attn<QT><<<dim3(p.L.nchunk, 1), 512, 0, st>>>(K0, V0, p.n, p.B.qproj, p.meta->obj, nullptr, nullptr, p.part, qp);
+        // the unfused flash kernel over the cached keys / values, by the sample's OWN tile count (it reads 16 QT query rows)
+        const dim3 cg(p.L.nchunk, 1);
+        switch (wide_qt_of_tiles((p.hm.nq + 15) / 16)) {
+          case 1: k_c2s_attn<1><<<cg, 512, 0, st>>>(K0, V0, p.n, p.B.qproj, p.meta->obj, nullptr, nullptr, p.part, p.L.qp); break;
+          case 2: k_c2s_attn<2><<<cg, 512, 0, st>>>(K0, V0, p.n, p.B.qproj, p.meta->obj, nullptr, nullptr, p.part, p.L.qp); break;
+          case 3: k_c2s_attn<3><<<cg, 512, 0, st>>>(K0, V0, p.n, p.B.qproj, p.meta->obj, nullptr, nullptr, p.part, p.L.qp); break;
+          case 4: k_c2s_attn<4><<<cg, 512, 0, st>>>(K0, V0, p.n, p.B.qproj, p.meta->obj, nullptr, nullptr, p.part, p.L.qp); break;
+          case 5: k_c2s_attn<5><<<cg, 512, 0, st>>>(K0, V0, p.n, p.B.qproj, p.meta->obj, nullptr, nullptr, p.part, p.L.qp); break;
+          case 6: k_c2s_attn<6><<<cg, 512, 0, st>>>(K0, V0, p.n, p.B.qproj, p.meta->obj, nullptr, nullptr, p.part, p.L.qp); break;
+          case 7: k_c2s_attn<7><<<cg, 512, 0, st>>>(K0, V0, p.n, p.B.qproj, p.meta->obj, nullptr, nullptr, p.part, p.L.qp); break;
+          case 8: k_c2s_attn<8><<<cg, 512, 0, st>>>(K0, V0, p.n, p.B.qproj, p.meta->obj, nullptr, nullptr, p.part, p.L.qp); break;
+          case 10: k_c2s_attn<10><<<cg, 512, 0, st>>>(K0, V0, p.n, p.B.qproj, p.meta->obj, nullptr, nullptr, p.part, p.L.qp); break;
+          case 12: k_c2s_attn<12><<<cg, 512, 0, st>>>(K0, V0, p.n, p.B.qproj, p.meta->obj, nullptr, nullptr, p.part, p.L.qp); break;
+          default: k_c2s_attn<14><<<cg, 512, 0, st>>>(K0, V0, p.n, p.B.qproj, p.meta->obj, nullptr, nullptr, p.part, p.L.qp); break;
+        }
         A3D_LAUNCH_CHECK();
       }
     } else {
       ProfScope ps(st, A3D_PROF_C2S, 0, 0, 0, 0, (int)n_total);
       k_c2s_w<QT><<<T.grid, 512, stage_lds, st>>>(T.samples_dev, ns, l, LW.c2s_wk_packed, LW.c2s_wv_packed, LW.c2s_in_b + D,
-                                                  LW.c2s_in_b + 2 * D, qp);
+                                                  LW.c2s_in_b + 2 * D);
       A3D_LAUNCH_CHECK();
     }
     rc = launch_query_side<2>(w, l, T.qs_dev, qp, nblk, ns, nq_max, cached0, st);
@@ -3046,7 +3072,10 @@ static int prepare_sample(const a3d_decoder_weights* w, const a3d_decoder_sample
 }
 
 static int dispatch_decoder(const a3d_decoder_weights* w, Prepared* P, int ns, hipStream_t st) {
-  switch (P[0].qtw) {
+  int qtw = 0;   // the wide build that holds the longest query list of the group (0: the group runs the <= 64 / unfused kernels)
+  if (P[0].qtw > 0)
+    for (int i = 0; i < ns; ++i) qtw = std::max(qtw, std::max(P[i].qtw, wide_qt(P[i].hm.nq)));
+  switch (qtw) {
     case 5: return run_decoder_wide<5>(w, P, ns, st);
     case 6: return run_decoder_wide<6>(w, P, ns, st);
     case 7: return run_decoder_wide<7>(w, P, ns, st);
@@ -3084,10 +3113,38 @@ extern "C" int a3d_decoder_forward_batch(const a3d_decoder_weights* w, const a3d
     if (rc) return rc;
   }
   hipStream_t st = (hipStream_t)stream;
-  // consecutive samples with the same padded query count go through the kernels together; several such groups (the click
-  // rounds of training and of the evaluation protocol: every sample has its own number of objects and clicks, and from 65
-  // queries on a sample runs alone) are independent chains of 20-60 mostly latency-bound launches on their own workspaces:
-  // group g goes on side stream g mod 4 (forked from / joined to the caller's stream with events), group 0 stays on it
+  // Launch groups.  The samples that the fused wide tier serves (more than 64 queries, decoder_wide.h) go through its kernels
+  // TOGETHER, whatever their query counts (the kernels take each sample's tile count from the table; the build is the one
+  // that holds the longest list): one launch per kernel and layer instead of one per sample -- four 80 k-point samples of a
+  // training click round pay the persistent kernels' start-up and tail once.  The others: consecutive samples with the same
+  // padded query count share the <= 64-query kernels.  Several groups are independent chains of launches on their own
+  // workspaces: group g goes on side stream g mod 4 (forked from / joined to the caller's stream with events), group 0 stays.
+  // A3D_WIDE_MERGE=0: one group per padded query count as before; 2: when the samples of a call do not share ONE padded
+  // query count, all of them go through the wide kernels.
+  static int merge_mode = -1;
+  if (merge_mode < 0) {
+    const char* e = getenv("A3D_WIDE_MERGE");
+    merge_mode = e ? atoi(e) : 1;
+  }
+  {
+    bool mixed = false;
+    for (int i = 1; i < n_samples; ++i) mixed = mixed || P[(size_t)i].L.qp != P[0].L.qp || P[(size_t)i].qtw != P[0].qtw;
+    if (fused_wide() && merge_mode == 2 && mixed)
+      for (int i = 0; i < n_samples; ++i)
+        if (P[(size_t)i].qtw == 0 && P[(size_t)i].hm.nq <= 224) P[(size_t)i].qtw = 5;
+    if (merge_mode != 0) {   // wide samples first (stable): they form the leading group(s)
+      std::vector<Prepared> Q;
+      Q.reserve((size_t)n_samples);
+      for (int pass = 0; pass < 2; ++pass)
+        for (int i = 0; i < n_samples; ++i)
+          if ((P[(size_t)i].qtw > 0) == (pass == 0)) Q.push_back(P[(size_t)i]);
+      P.swap(Q);
+    }
+  }
+  auto same_group = [&](const Prepared& a, const Prepared& b) {
+    if (merge_mode != 0 && a.qtw > 0 && b.qtw > 0) return true;
+    return a.L.qp == b.L.qp && a.qtw == b.qtw;
+  };
   struct Side {
     hipStream_t s[4] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t fork = nullptr, done[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -3100,7 +3157,7 @@ extern "C" int a3d_decoder_forward_batch(const a3d_decoder_weights* w, const a3d
   int n_groups = 0;
   for (int i = 0; i < n_samples;) {
     int e = i + 1;
-    while (e < n_samples && e - i < kMaxBatchSamples && P[(size_t)e].L.qp == P[(size_t)i].L.qp && P[(size_t)e].qtw == P[(size_t)i].qtw) ++e;
+    while (e < n_samples && e - i < kMaxBatchSamples && same_group(P[(size_t)i], P[(size_t)e])) ++e;
     ++n_groups;
     i = e;
   }
@@ -3120,7 +3177,7 @@ extern "C" int a3d_decoder_forward_batch(const a3d_decoder_weights* w, const a3d
   int g = 0, rc_all = A3D_OK;
   for (int i = 0; i < n_samples && rc_all == A3D_OK;) {
     int e = i + 1;
-    while (e < n_samples && e - i < kMaxBatchSamples && P[(size_t)e].L.qp == P[(size_t)i].L.qp && P[(size_t)e].qtw == P[(size_t)i].qtw) ++e;
+    while (e < n_samples && e - i < kMaxBatchSamples && same_group(P[(size_t)i], P[(size_t)e])) ++e;
     hipStream_t gs = st;
     if (use_side && g > 0) {
       const int k = (g - 1) & 3;

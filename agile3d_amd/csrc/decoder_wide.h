@@ -28,6 +28,11 @@ __host__ __device__ constexpr int wide_qt(int nq) {
   return nq <= 64 ? 0 : nq <= 80 ? 5 : nq <= 96 ? 6 : nq <= 112 ? 7 : nq <= 128 ? 8 : nq <= 160 ? 10 : nq <= 192 ? 12 : nq <= 224 ? 14 : 0;
 }
 
+// tile count of the k_c2s_attn build that holds `tiles` 16-query tiles of a sample whose buffers have round_qp(nq) rows
+__host__ __device__ constexpr int wide_qt_of_tiles(int tiles) {
+  return tiles <= 8 ? tiles : tiles <= 10 ? 10 : tiles <= 12 ? 12 : 14;
+}
+
 // the 512 threads of a workgroup move one group's rows of X and of the position encodings (16 x 128 floats each):
 // thread -> (row lr, float4 column lc)
 struct WideLoader {
@@ -51,12 +56,12 @@ struct WideLoader {
 template <int QT>
 __global__ void __launch_bounds__(512) k_c2s_w(const DecSampleDev* __restrict__ samples, int ns, int layer,
                                                const float* __restrict__ Wk, const float* __restrict__ Wv,
-                                               const float* __restrict__ bk, const float* __restrict__ bv, int qp_total) {
+                                               const float* __restrict__ bk, const float* __restrict__ bv) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* tiles = (float*)smem;   // [2 slots][X, P][16][kWLD]
   const DecSampleDev& sm = sample_of_wg(samples, ns);
   const int lb = blockIdx.x - sm.wg_begin, nwg = sm.wg_end - sm.wg_begin;
-  const int n = sm.n, ngroups = (n + 15) / 16;
+  const int n = sm.n, ngroups = (n + 15) / 16, nqt = sm.nqt;   // nqt <= QT: the sample's own query tiles (uniform)
   const float* __restrict__ X = layer_input(sm, layer);
   const float* __restrict__ Pe = sm.posenc;
   const unsigned char* labels = layer > 0 ? sm.labels : nullptr;                       // previous layer's mask labels
@@ -82,12 +87,16 @@ __global__ void __launch_bounds__(512) k_c2s_w(const DecSampleDev* __restrict__ 
   float mq[QT];
 #pragma unroll
   for (int qt = 0; qt < QT; ++qt) {
-    qf[qt] = gld4(sm.qproj + (size_t)(qt * 16 + j) * D + 16 * h + 4 * g);
-    const int o = gld(sm.qobj + qt * 16 + j);
-    // a query is masked only if its object currently owns at least one point (agile3d.py:369,375)
-    const bool masked = labels != nullptr && o >= 0 && gld(counts + o) > 0;
-    const float fo = (float)o;
-    mq[qt] = !masked || g == 3 ? 0.f : -1048576.f * (g == 0 ? 1.f : g == 1 ? fo : fo * fo);
+    qf[qt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    mq[qt] = 0.f;
+    if (qt < nqt) {
+      qf[qt] = gld4(sm.qproj + (size_t)(qt * 16 + j) * D + 16 * h + 4 * g);
+      const int o = gld(sm.qobj + qt * 16 + j);
+      // a query is masked only if its object currently owns at least one point (agile3d.py:369,375)
+      const bool masked = labels != nullptr && o >= 0 && gld(counts + o) > 0;
+      const float fo = (float)o;
+      mq[qt] = !masked || g == 3 ? 0.f : -1048576.f * (g == 0 ? 1.f : g == 1 ? fo : fo * fo);
+    }
   }
   // m is a REFERENCE maximum, not the exact one: it moves only when a score exceeds it by more than 2^kLazy (the first group
   // sets it), so the common group costs no rescale of l and acc; what k_c2s_combine needs is l and acc relative to the m it reads
@@ -145,6 +154,7 @@ __global__ void __launch_bounds__(512) k_c2s_w(const DecSampleDev* __restrict__ 
     const bool tail = p0 + 16 > n;                                        // rows beyond the sample: blocked for every query
 #pragma unroll
     for (int qt = 0; qt < QT; ++qt) {
+      if (qt < nqt) {   // (no break: the loop must stay fully unrolled -- its arrays are registers)
       f32x4 sc4;
       auto scores = [&]() {
         sc4 = __builtin_amdgcn_mfma_f32_16x16x4f32(am, mq[qt], (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
@@ -177,20 +187,23 @@ __global__ void __launch_bounds__(512) k_c2s_w(const DecSampleDev* __restrict__ 
 #pragma unroll
       for (int t = 0; t < 4; ++t) acc[qt] = __builtin_amdgcn_mfma_f32_16x16x4f32(vv[t], pw[t], acc[qt], 0, 0, 0);
     }
+    }
     if (has_next) ld.commit(tiles + ((it + 1) & 1) * 2 * kWTile);
     __syncthreads();
   }
   // one partial per (head, query) and workgroup: [h][q][workgroup] -- what k_c2s_combine walks
 #pragma unroll
   for (int qt = 0; qt < QT; ++qt) {
-    const float lt = rows_sum(l[qt]);
-    float* pq = sm.part + (((size_t)h * qp_total + qt * 16 + j) * nwg + lb) * kPartStride;
-    if (g == 0) {
-      gst(pq, m[qt]);
-      gst(pq + 1, lt);
-    }
+    if (qt < nqt) {
+      const float lt = rows_sum(l[qt]);
+      float* pq = sm.part + (((size_t)h * sm.qp + qt * 16 + j) * nwg + lb) * kPartStride;
+      if (g == 0) {
+        gst(pq, m[qt]);
+        gst(pq + 1, lt);
+      }
 #pragma unroll
-    for (int t = 0; t < 4; ++t) gst(pq + 2 + 4 * g + t, acc[qt][t]);
+      for (int t = 0; t < 4; ++t) gst(pq + 2 + 4 * g + t, acc[qt][t]);
+    }
   }
 }
 
@@ -218,20 +231,21 @@ __global__ void __launch_bounds__(512) k_s2c_w(const DecSampleDev* __restrict__ 
     for (int S = 0; S < 8; ++S) wq[S] = ((const f32x4 A3D_GLOBAL*)Wq)[(S * 8 + h) * 64 + lane];
     bq4 = gld4(bq + 16 * h + 4 * g);
   }
+  const int nqt = sm.nqt;   // the sample's own key tiles (<= QT, uniform); tiles beyond it are never touched
   f32x4 kf[QT], vf[QT];
 #pragma unroll
   for (int kt = 0; kt < QT; ++kt) {
-    kf[kt] = gld4(sm.ks + (size_t)(kt * 16 + j) * D + 16 * h + 4 * g);   // ks[key 16kt+j][16h+4g..+3] (pre-scaled, log2 domain)
+    kf[kt] = vf[kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (kt < nqt) {
+      kf[kt] = gld4(sm.ks + (size_t)(kt * 16 + j) * D + 16 * h + 4 * g);   // ks[key 16kt+j][16h+4g..+3] (pre-scaled, log2 domain)
 #pragma unroll
-    for (int t = 0; t < 4; ++t) vf[kt][t] = gld(sm.vs + (size_t)(kt * 16 + 4 * g + t) * D + 16 * h + j);   // V^T: keys 4g..4g+3 of channel 16h+j
+      for (int t = 0; t < 4; ++t) vf[kt][t] = gld(sm.vs + (size_t)(kt * 16 + 4 * g + t) * D + 16 * h + j);   // V^T: keys 4g..4g+3 of channel 16h+j
+    }
   }
-  // score bias of the padded queries: only the last two tiles can hold any (wide_qt)
-  f32x4 sbA, sbB;
+  // score bias of the padded queries of the sample's LAST tile (rows of its buffers beyond nq are zero, k_query_init)
+  f32x4 sbL;
 #pragma unroll
-  for (int t = 0; t < 4; ++t) {
-    sbA[t] = (QT - 2) * 16 + 4 * g + t < nq ? 0.f : kNegBig;
-    sbB[t] = (QT - 1) * 16 + 4 * g + t < nq ? 0.f : kNegBig;
-  }
+  for (int t = 0; t < 4; ++t) sbL[t] = (nqt - 1) * 16 + 4 * g + t < nq ? 0.f : kNegBig;
   WideLoader ld;
   f32x4 qn = (f32x4){0.f, 0.f, 0.f, 0.f};
   int grp = lb;
@@ -276,40 +290,55 @@ __global__ void __launch_bounds__(512) k_s2c_w(const DecSampleDev* __restrict__ 
       }
       qf = q0 + q1;
     }
-    // S^T[key 16kt+4g+t][point j]
-    f32x4 sc[QT];
-#pragma unroll
-    for (int kt = 0; kt < QT; ++kt) sc[kt] = kt == QT - 1 ? sbB : kt == QT - 2 ? sbA : (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int t = 0; t < 4; ++t)
-#pragma unroll
-      for (int kt = 0; kt < QT; ++kt) sc[kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[kt][t], qf[t], sc[kt], 0, 0, 0);
+    // S^T[key 16kt+4g+t][point j]; key tiles two at a time (one uniform test per pair; an odd last tile's partner holds
+    // zero keys and values: its weights are finite and meet zeros)
+    f32x4 sc[QT + 1];
     float mx = kNegBig;
 #pragma unroll
-    for (int kt = 0; kt < QT; ++kt) mx = fmaxf(mx, fmaxf(fmaxf(sc[kt][0], sc[kt][1]), fmaxf(sc[kt][2], sc[kt][3])));
+    for (int kt = 0; kt < QT; kt += 2) {
+      if (kt < nqt) {   // (no break: the loops stay fully unrolled -- their arrays are registers)
+      sc[kt] = sc[kt + 1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      const f32x4 kb = kt + 1 < QT ? kf[kt + 1] : (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        sc[kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[kt][t], qf[t], sc[kt], 0, 0, 0);
+        sc[kt + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(kb[t], qf[t], sc[kt + 1], 0, 0, 0);
+      }
+      if (kt + 2 >= nqt) {   // the pair that holds the sample's last tile: padded queries out of the softmax
+        if (kt + 1 == nqt) {
+          sc[kt] += sbL;
+          sc[kt + 1] = (f32x4){kNegBig, kNegBig, kNegBig, kNegBig};
+        } else {
+          sc[kt + 1] += sbL;
+        }
+      }
+      mx = fmaxf(mx, fmaxf(fmaxf(sc[kt][0], sc[kt][1]), fmaxf(sc[kt][2], sc[kt][3])));
+      mx = fmaxf(mx, fmaxf(fmaxf(sc[kt + 1][0], sc[kt + 1][1]), fmaxf(sc[kt + 1][2], sc[kt + 1][3])));
+      }
+    }
     mx = rows_max(mx);
     float sum = 0.f;
-#pragma unroll
-    for (int kt = 0; kt < QT; ++kt) {
-#pragma unroll
-      for (int t = 0; t < 4; ++t) sc[kt][t] = exp2_fast(sc[kt][t] - mx);
-      sum += (sc[kt][0] + sc[kt][1]) + (sc[kt][2] + sc[kt][3]);
-    }
-    sum = rows_sum(sum);
-    const float inv = __builtin_amdgcn_rcpf(sum);
-    // O^T[channel 16h+4g+t][point j]: two accumulators over alternating key tiles
+    // O^T[channel 16h+4g+t][point j]: one accumulator per tile of the pair
     f32x4 a0 = (f32x4){0.f, 0.f, 0.f, 0.f}, a1 = a0;
 #pragma unroll
-    for (int kt = 0; kt + 1 < QT; kt += 2)
+    for (int kt = 0; kt < QT; kt += 2) {
+      if (kt < nqt) {
+      const f32x4 vb = kt + 1 < QT ? vf[kt + 1] : (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        sc[kt][t] = exp2_fast(sc[kt][t] - mx);
+        sc[kt + 1][t] = exp2_fast(sc[kt + 1][t] - mx);
+      }
+      sum += ((sc[kt][0] + sc[kt][1]) + (sc[kt][2] + sc[kt][3])) + ((sc[kt + 1][0] + sc[kt + 1][1]) + (sc[kt + 1][2] + sc[kt + 1][3]));
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
         a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(vf[kt][t], sc[kt][t], a0, 0, 0, 0);
-        a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(vf[kt + 1][t], sc[kt + 1][t], a1, 0, 0, 0);
+        a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(vb[t], sc[kt + 1][t], a1, 0, 0, 0);
       }
-    if constexpr (QT & 1) {
-#pragma unroll
-      for (int t = 0; t < 4; ++t) a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(vf[QT - 1][t], sc[QT - 1][t], a0, 0, 0, 0);
+      }
     }
+    sum = rows_sum(sum);
+    const float inv = __builtin_amdgcn_rcpf(sum);
     if (p0 + j < n) gst4(O + (size_t)(p0 + j) * D + 16 * h + 4 * g, (a0 + a1) * inv);
     if constexpr (!QC) {
       if (has_next) ld.commit(tiles + ((it + 1) & 1) * 2 * kWTile);   // the rows have had the whole iteration to land
@@ -358,13 +387,14 @@ __global__ void __launch_bounds__(512) k_out_w(const DecSampleDev* __restrict__ 
   // the object of query 16 qt + j (0 = background, -1 = padding)
   f32x4 ef[NTW][8];
   int oq[NTW];
+  const int nqt = sm.nqt;   // the sample's own query tiles (<= QT, uniform)
 #pragma unroll
   for (int i = 0; i < NTW; ++i) {
     const int qt = w + 8 * i;
-    oq[i] = qt < QT ? gld(sm.qobj + qt * 16 + j) : -1;
+    oq[i] = qt < nqt ? gld(sm.qobj + qt * 16 + j) : -1;
 #pragma unroll
     for (int S = 0; S < 8; ++S)
-      ef[i][S] = qt < QT ? gld4(sm.E + (size_t)(qt * 16 + j) * D + 16 * S + 4 * g) : (f32x4){0.f, 0.f, 0.f, 0.f};
+      ef[i][S] = qt < nqt ? gld4(sm.E + (size_t)(qt * 16 + j) * D + 16 * S + 4 * g) : (f32x4){0.f, 0.f, 0.f, 0.f};
   }
   const int lr = tid >> 5, lc = (tid & 31) * 4;
   int pr = lb;                                 // pair of point groups
@@ -462,13 +492,15 @@ __global__ void __launch_bounds__(512) k_out_w(const DecSampleDev* __restrict__ 
     __syncthreads();                                                       // (2) normalised rows
     // ---- logits of the 2 x 16 points against the wave's query tiles (C layout: row = point 4g+t, column = query j), then
     // the per-object maxima
-    if (w < QT) {
+    // (a wave whose second tile lies beyond the sample's queries runs the one-tile form: samples of one launch differ)
+    auto logits_tiles = [&](auto nt_c) {
+      constexpr int NT = decltype(nt_c)::value;
       const float* ty = y_l + j * kWLD + 4 * g;
-      f32x4 la[MG][NTW], lc2[MG][NTW];
+      f32x4 la[MG][NT], lc2[MG][NT];
 #pragma unroll
       for (int mg = 0; mg < MG; ++mg)
 #pragma unroll
-        for (int i = 0; i < NTW; ++i) la[mg][i] = lc2[mg][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int i = 0; i < NT; ++i) la[mg][i] = lc2[mg][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int S = 0; S < 8; S += 2) {
         f32x4 ya[MG], yb[MG];
@@ -482,7 +514,7 @@ __global__ void __launch_bounds__(512) k_out_w(const DecSampleDev* __restrict__ 
 #pragma unroll
           for (int mg = 0; mg < MG; ++mg)
 #pragma unroll
-            for (int i = 0; i < NTW; ++i) {
+            for (int i = 0; i < NT; ++i) {
               la[mg][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(ya[mg][t], ef[i][S][t], la[mg][i], 0, 0, 0);
               lc2[mg][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(yb[mg][t], ef[i][S + 1][t], lc2[mg][i], 0, 0, 0);
             }
@@ -490,14 +522,16 @@ __global__ void __launch_bounds__(512) k_out_w(const DecSampleDev* __restrict__ 
 #pragma unroll
       for (int mg = 0; mg < MG; ++mg)
 #pragma unroll
-        for (int i = 0; i < NTW; ++i)
+        for (int i = 0; i < NT; ++i)
           if (oq[i] >= 0) {
             const f32x4 lg = la[mg][i] + lc2[mg][i];
 #pragma unroll
             for (int t = 0; t < 4; ++t)
               __builtin_amdgcn_ds_fmaxf((lds_float*)(Oc + (mg * 16 + 4 * g + t) * K1 + oq[i]), lg[t], 0, 0, false);
           }
-    }
+    };
+    if (NTW == 2 && w + 8 < nqt) logits_tiles(std::integral_constant<int, NTW>{});
+    else if (w < nqt) logits_tiles(std::integral_constant<int, 1>{});
     if (has_next) {   // the next pair's attention rows: issued at the top of the iteration
 #pragma unroll
       for (int mg = 0; mg < MG; ++mg) *(f32x4*)(o_l + (((it + 1) & 1) * MG + mg) * kWTile + lr * kWLD + lc) = ro[mg];

@@ -287,6 +287,44 @@ def test_batched_decoder_equals_per_sample_runs(model_and_sd):
             assert (g - ref).abs().max().item() <= 1e-4, (b, (g - ref).abs().max().item())
 
 
+def test_wide_tier_samples_of_different_query_counts_share_one_launch_group(model_and_sd):
+    """More than 64 queries: the samples of a call go through the fused wide kernels (csrc/decoder_wide.h) TOGETHER, each with
+    its own tile count from the sample table, under the build that holds the longest list -- 70, 97, 139, 171 and 210
+    queries here (4 to 11 objects), plus one 20-query sample that keeps the <= 64-query kernels on a side stream.  Every
+    layer's logits must equal the single-sample results (where each sample runs the build of ITS size) and the oracle's;
+    the second call on the same backbone output reads the first layer's keys / values / queries from the scene cache."""
+    model, sd = model_and_sd
+    specs = [(2600, 31, 4, 15, 0), (3100, 32, 11, 7, 10), (2800, 33, 7, 18, 3), (3000, 34, 5, 2, 0), (3300, 35, 8, 20, 1),
+             (2900, 36, 10, 19, 10)]
+    scenes = [make_scene(n, seed=sd_) for n, sd_, *_ in specs]
+    clicks = [make_clicks(sc["labels"], sp[2], sp[3], sp[4], seed=sp[1]) for sc, sp in zip(scenes, specs)]
+    assert [sum(len(v) for v in c[0].values()) + 10 for c in clicks] == [70, 97, 139, 20, 171, 210]
+    singles = []
+    for sc, (ci, ct) in zip(scenes, clicks):
+        r = _run_backbone(model, sc)
+        o = model.forward_mask(*r, click_idx=[ci], click_time_idx=[ct])
+        singles.append([o["pred_masks"][0]] + [a["pred_masks"][0] for a in o["aux_outputs"]])
+        ref = od.forward_mask(sd, r[0].F.cpu(), torch.from_numpy(sc["raw_xyz"]), r[3][4][0][0].cpu(), ci, ct)
+        err = (singles[-1][0].cpu() - ref[-1]).abs().max().item()
+        assert err <= TOL * max(1.0, ref[-1].abs().max().item()), err
+    coords = []
+    for b, sc in enumerate(scenes):
+        c = sc["coords"].copy()
+        c[:, 0] = b
+        coords.append(c)
+    x = SparseTensor(features=torch.from_numpy(np.concatenate([sc["feats"] for sc in scenes])),
+                     coordinates=torch.from_numpy(np.concatenate(coords)), device="cuda")
+    raw = torch.from_numpy(np.concatenate([sc["raw_xyz"] for sc in scenes])).cuda()
+    r = model.forward_backbone(x, raw_coordinates=raw)
+    for call in range(3):   # fused first layer, the call that fills the scene cache, a call that reads it
+        out = model.forward_mask(*r, click_idx=[c[0] for c in clicks], click_time_idx=[c[1] for c in clicks])
+        for b in range(len(scenes)):
+            got = [out["pred_masks"][b]] + [a["pred_masks"][b] for a in out["aux_outputs"]]
+            for g, ref in zip(got, singles[b]):
+                assert g.shape == ref.shape
+                assert (g - ref).abs().max().item() <= 1e-4, (call, b, (g - ref).abs().max().item())
+
+
 def test_scene_cache_of_first_layer_keys_and_values(model_and_sd):
     """forward_mask keeps the click-independent keys / values of the first layer's click-to-scene attention per scene from
     its second call on one backbone output (the interactive loop's ~100 passes, eval_multi_obj.py:112-160): the first call
