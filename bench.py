@@ -222,105 +222,176 @@ def cpu_baseline(sd, sc, ci, ct, gpu_logits=None, gpu_feats=None, samples=5):
     return res, diff
 
 
-def explain_forks(model, sd, items, oracle_bb, gpu_log, oracle_log, dev, logit_tol=1e-4):
-    """Why the two free-running protocols of `iou_at_k` (GPU product / CPU oracle, same state dict, same `random` seed) stop
-    agreeing, scene by scene, with the numbers that show it.  A scene's rounds are compared while both sides hold the SAME
-    clicks; a round that differs must be one of
-      * "logit tie": same clicks, labels differ only at points whose two best logits are within `logit_tol` on both sides
-        (the GPU's logits differ from the oracle's by ~1e-5, an argmax there is a coin flip; utils/seg.py and
-        eval_multi_obj.py:126 take the argmax at face value);
-      * "distance tie": same labels, but the next click differs -- both sides' candidates are the arg-max of the cluster's
-        outside distance IN THEIR OWN ARITHMETIC (the reference and the oracle use torch.cdist = the matmul formula, error
-        ~sqrt(eps)|x| near zero, utils/seg.py:157-171; clicks.hip the exact difference expression), and their float64
-        distances differ by less than cdist's own error on those two points;
-    anything else is reported as "unexplained" (a bug).  After its first fork a scene's two runs hold different clicks and
-    are not compared any further.  Returns {"scenes": [...], "unexplained": n, "compared_rounds": n, "identical_rounds": n}."""
+def _size64(x64, member):
+    """float64 error size of a cluster (largest distance of a member to the nearest non-member) and the row attaining it"""
+    rows = torch.nonzero(member).flatten()
+    best, arg = -1.0, -1
+    other = x64[~member]
+    for s0 in range(0, len(rows), 1024):                    # chunks: [1024 x N] float64 at a time
+        d = torch.cdist(x64[rows[s0:s0 + 1024]], other).min(1).values
+        k = int(torch.argmax(d))
+        if float(d[k]) > best:
+            best, arg = float(d[k]), int(rows[s0 + k])
+    return best, arg
+
+
+def oracle_protocol_synced(model, sd, items, gpu_log, objects, max_clicks, dev, logit_tol=1e-4):
+    """The CPU oracle's interactive protocol (oracle.clicks over oracle backbone + decoder, utils/seg.py:173-226 +
+    eval_multi_obj.py:112-160) run NEXT TO the GPU product's log, round by round, with the same `random` stream.  Every
+    round is compared: the oracle holds the clicks the GPU run holds, computes ITS labels / IoU / next clicks, and
+    whatever differs must be PROVEN one of
+      * "logit tie": labels differ only at points whose two best logits are within `logit_tol` on both sides (the GPU's
+        logits differ from the oracle's by ~1e-5; eval_multi_obj.py:126 takes the argmax at face value);
+      * "mask tie in layer l": the same coin flip one or two decoder layers earlier -- the arg-max labels of layer l's mask
+        logits pick the points the NEXT layer's click-to-scene attention may see (agile3d.py:367-380), so one flipped point
+        moves the final logits by ~0.1 although every layer's arithmetic agrees to 1e-5 (the float64 oracle flips too);
+      * "distance tie" inside a cluster: both sides' rows are the arg-max of the outside distance IN THEIR OWN ARITHMETIC
+        (the reference / oracle: torch.cdist, the matmul formula, error ~sqrt(eps)|x| near zero, utils/seg.py:157-171;
+        clicks.hip: the exact difference expression) and their float64 distances differ by no more than cdist's own error
+        on those two rows (+ 2 ulp);
+      * "rank tie" between the two largest clusters: each side's top cluster is the larger one in its own arithmetic and
+        the two clusters' float64 sizes differ by no more than cdist's own error on those two sizes (+ 2 ulp);
+      * "follows a logit tie": the clicks were picked from labels that differed in the (proven) logit tie of that round;
+    anything else counts as "unexplained" (a bug).  After a differing click the oracle CONTINUES FROM THE GPU's CLICKS, so
+    no round is left uncompared.  Returns (oracle_log, oracle_bb, forks)."""
+    import random
     from agile3d_amd import SparseTensor
     from agile3d_amd import clicks as pc
-    from oracle import clicks as oc, decoder as od
+    from oracle import backbone as ob, clicks as oc, decoder as od
     per_scene = len(gpu_log) // len(items)
-    out = {"scenes": [], "unexplained": 0, "compared_rounds": 0, "identical_rounds": 0, "logit_tol": logit_tol}
+    forks = {"scenes": [], "unexplained": 0, "compared_rounds": 0, "identical_rounds": 0, "click_forks": 0,
+             "logit_tol": logit_tol}
+    oracle_log, oracle_bb = [], []
 
     def gpu_logits(i, ci, ct):
         sc = items[i]["scene"]
         x = SparseTensor(features=torch.from_numpy(sc["feats"]), coordinates=torch.from_numpy(sc["coords"]), device=dev)
         bo = model.forward_backbone(x, raw_coordinates=torch.from_numpy(sc["raw_xyz"]).to(dev))
-        return model.forward_mask(*bo, click_idx=[ci], click_time_idx=[ct])["pred_masks"][0].cpu()
+        out_ = model.forward_mask(*bo, click_idx=[ci], click_time_idx=[ct])
+        return [a_["pred_masks"][0].cpu() for a_ in out_["aux_outputs"]] + [out_["pred_masks"][0].cpu()]
 
     for i, it in enumerate(items):
         g = gpu_log[i * per_scene:(i + 1) * per_scene]
-        o = oracle_log[i * per_scene:(i + 1) * per_scene]
-        xyz = torch.from_numpy(it["scene"]["raw_xyz"])
-        lab = torch.from_numpy(it["labels"])
+        sc, lab = it["scene"], torch.from_numpy(it["labels"])
+        xyz = torch.from_numpy(sc["raw_xyz"])
+        x64 = xyz.double()
+        rb = ob.forward_backbone(sd, sc["coords"], torch.from_numpy(sc["feats"]), xyz)
+        oracle_bb.append(rb)
         rec = {"scene": it["name"], "rounds": len(g), "events": []}
-        for j, (a, b) in enumerate(zip(g, o)):
-            if a[2] != b[2]:                                   # the clicks picked after round j - 1 differ: the fork
-                pa, pb = g[j - 1][3], o[j - 1][3]
-                ev = {"round": j, "kind": None}
-                if not torch.equal(pa, pb):
-                    ev["kind"] = "follows a logit tie"           # the labels the clicks were picked from differed (that round's event)
+        ci = {str(k): [] for k in range(objects + 1)}
+        ct = {str(k): [] for k in range(objects + 1)}
+        n_clicks = 0
+        for j, a in enumerate(g):
+            assert a[0] == n_clicks and a[2] == ci and a[4] == ct        # the oracle holds the GPU run's clicks
+            lo = None
+            if n_clicks == 0:
+                pred = torch.zeros(lab.shape)
+            else:
+                lo_all = od.forward_mask(sd, rb["pcd_features"], xyz, rb["pos_enc"], ci, ct)
+                lo = lo_all[-1]
+                pred = lo.argmax(-1)
+                for obj_id, rows in ci.items():
+                    pred[rows] = int(obj_id)
+            iou, _ = oc.mean_iou_scene(pred, lab)
+            pred = pred.long()
+            oracle_log.append((n_clicks, float(np.float32(iou)), {k: list(v) for k, v in ci.items()}, pred.clone(),
+                               {k: list(v) for k, v in ct.items()}))
+            forks["compared_rounds"] += 1
+            same_pred = torch.equal(a[3], pred)
+            label_tie = False
+            if same_pred and abs(a[1] - float(iou)) <= 1e-6:
+                forks["identical_rounds"] += 1
+            else:
+                ev = {"round": j, "iou_gpu": a[1], "iou_oracle": float(iou)}
+                if same_pred:
+                    ev.update({"kind": "unexplained", "proven": False})      # same labels, different IoU
                 else:
-                    cg = {c["cluster_id"]: c for c in pc.error_clusters(pa.to(dev), lab.to(dev), xyz.to(dev))}
-                    co = {c["cluster_id"]: c for c in oc.error_clusters(pa, lab, xyz)}
-                    ties = []
-                    x64 = xyz.double()
-                    cid_all = lab.float() * 96 + pa.float() * 11
-                    wrong = pa != lab
-                    for cid in sorted(set(cg) | set(co)):
-                        if cid not in cg or cid not in co:
-                            ties.append({"cluster": cid, "missing_on_one_side": True})
-                            continue
-                        ra, rb = cg[cid]["row"], co[cid]["row"]
-                        if ra == rb:
+                    # the FIRST decoder layer whose arg-max labels differ: the last one is the prediction itself, an earlier
+                    # one feeds the next layer's attention mask (agile3d.py:367-380: a discrete choice, so one flipped point
+                    # moves the later logits by far more than rounding) -- either way the flip must sit where the two best
+                    # logits of that layer are within logit_tol on BOTH sides, with that layer's logits in agreement
+                    lg_all = gpu_logits(i, a[2], a[4])
+                    first = next((l_ for l_ in range(len(lo_all)) if not torch.equal(lg_all[l_].argmax(-1), lo_all[l_].argmax(-1))),
+                                 len(lo_all) - 1)
+                    lg_f, lo_f = lg_all[first], lo_all[first]
+                    rows = torch.nonzero(lg_f.argmax(-1) != lo_f.argmax(-1)).flatten()
+                    if rows.numel() == 0:       # the labels differ only through the clicked rows' overwrite: cannot happen with equal clicks
+                        rows = torch.nonzero(a[3] != pred).flatten()
+                    mg = lg_f[rows].topk(2, dim=-1).values
+                    mo = lo_f[rows].topk(2, dim=-1).values
+                    margin = torch.maximum(mg[:, 0] - mg[:, 1], mo[:, 0] - mo[:, 1])
+                    agree = float((lg_f - lo_f).abs().max())
+                    label_tie = float(margin.max()) <= logit_tol and agree <= logit_tol
+                    last = first == len(lo_all) - 1
+                    ev.update({"points_with_different_labels": int((a[3] != pred).sum()), "first_layer_with_different_labels": first,
+                               "points_flipped_in_that_layer": int(rows.numel()), "largest_top2_margin_there": float(margin.max()),
+                               "max_logit_diff_gpu_vs_oracle_there": agree,
+                               "max_logit_diff_gpu_vs_oracle_final": float((lg_all[-1] - lo).abs().max()),
+                               "kind": ("logit tie" if last else f"mask tie in layer {first}") if label_tie else "unexplained",
+                               "proven": bool(label_tie)})
+                forks["unexplained"] += 0 if ev["proven"] else 1
+                rec["events"].append(ev)
+            # ---- the oracle's next clicks from ITS labels, against the GPU run's
+            new_clicks, _, _, new_time = oc.get_simulated_clicks(pred, lab, xyz, n_clicks, training=False)
+            nci, nct = {k: list(v) for k, v in ci.items()}, {k: list(v) for k, v in ct.items()}
+            if new_clicks is not None:
+                nci, nct = oc.extend_clicks(nci, nct, new_clicks, new_time)
+            if j + 1 < len(g) and (g[j + 1][2] != nci or g[j + 1][4] != nct):
+                forks["click_forks"] += 1
+                fresh = lambda d: {k: v[len(ci[k]):] for k, v in d.items() if len(v) > len(ci[k])}   # the clicks of this round
+                ev = {"round": j + 1, "kind": None, "proven": False, "gpu_clicks": fresh(g[j + 1][2]), "oracle_clicks": fresh(nci)}
+                if not same_pred:
+                    ev.update({"kind": "follows a logit tie", "proven": bool(label_tie)})
+                else:
+                    cg = {c["cluster_id"]: c for c in pc.error_clusters(pred.to(dev), lab.to(dev), xyz.to(dev))}
+                    co = {c["cluster_id"]: c for c in oc.error_clusters(pred, lab, xyz)}
+                    cid_all = lab.float() * 96 + pred.float() * 11
+                    wrong = pred != lab
+                    ties, ok = [], set(cg) == set(co)
+                    for cid in sorted(set(cg) & set(co)):
+                        ra, rb_ = cg[cid]["row"], co[cid]["row"]
+                        if ra == rb_:
                             continue
                         member = wrong & (cid_all == cid)
-                        d64 = torch.cdist(x64[[ra, rb]], x64[~member]).min(1).values           # float64: exact to 1e-16
-                        dcd = torch.cdist(xyz[~member], xyz[[ra, rb]]).min(0).values.double()   # the reference's arithmetic
+                        d64 = torch.cdist(x64[[ra, rb_]], x64[~member]).min(1).values           # float64: exact to 1e-16
+                        dcd = torch.cdist(xyz[~member], xyz[[ra, rb_]]).min(0).values.double()   # the reference's arithmetic
                         err_cd = float((dcd - d64).abs().sum())
                         ulp = float(np.spacing(np.float32(d64.max())))
-                        ties.append({"cluster": cid, "gpu_row": ra, "oracle_row": rb,
-                                     "float64": [float(d64[0]), float(d64[1])], "torch_cdist": [float(dcd[0]), float(dcd[1])],
-                                     "gpu_error_size": cg[cid]["error_size"], "oracle_error_size": co[cid]["error_size"],
-                                     "float64_gap": float((d64[0] - d64[1]).abs()), "cdist_error_on_the_two": err_cd,
-                                     "proven": bool(d64[0] >= d64[1] - 2 * ulp and dcd[1] >= dcd[0]
-                                                    and float((d64[0] - d64[1]).abs()) <= err_cd + 2 * ulp)})
-                    # the cluster ranking (largest error size first) can tie too: sizes in both arithmetics
+                        proven = bool(d64[0] >= d64[1] - 2 * ulp and dcd[1] >= dcd[0]
+                                      and float((d64[0] - d64[1]).abs()) <= err_cd + 2 * ulp)
+                        ties.append({"cluster": cid, "gpu_row": ra, "oracle_row": rb_, "float64": [float(d64[0]), float(d64[1])],
+                                     "torch_cdist": [float(dcd[0]), float(dcd[1])], "float64_gap": float((d64[0] - d64[1]).abs()),
+                                     "cdist_error_on_the_two": err_cd, "proven": proven})
+                        ok = ok and proven
+                    ev["ties"] = ties
+                    # the ranking of the clusters (largest error size first, stable): the top cluster is what the rounds
+                    # after the first click on (utils/seg.py:213-221)
                     rank_g = sorted(cg, key=lambda c: cg[c]["error_size"], reverse=True)
                     rank_o = sorted(co, key=lambda c: co[c]["error_size"], reverse=True)
-                    ev["ties"] = ties
-                    ev["top_cluster"] = {"gpu": rank_g[:1], "oracle": rank_o[:1],
-                                         "gpu_sizes": [cg[c]["error_size"] for c in rank_g[:2]],
-                                         "oracle_sizes": [co[c]["error_size"] for c in rank_o[:2]]}
-                    rank_tie = rank_g[:1] != rank_o[:1] and len(rank_g) > 1 and \
-                        abs(cg[rank_g[0]]["error_size"] - cg[rank_g[1]]["error_size"]) <= 2e-3
-                    ok = bool(ties or rank_tie) and all(t.get("proven") for t in ties)
-                    ev["kind"] = "distance tie" if ok else "unexplained"
-                    out["unexplained"] += 0 if ok else 1
+                    rank = None
+                    if n_clicks > 0 and rank_g[:1] != rank_o[:1] and set(cg) == set(co):
+                        c1, c2 = rank_g[0], rank_o[0]
+                        s64 = {c: _size64(x64, wrong & (cid_all == c)) for c in (c1, c2)}
+                        err_cd = sum(abs(co[c]["error_size"] - s64[c][0]) for c in (c1, c2))
+                        ulp = float(np.spacing(np.float32(max(s64[c1][0], s64[c2][0]))))
+                        gap = abs(s64[c1][0] - s64[c2][0])
+                        proven = bool(cg[c1]["error_size"] >= cg[c2]["error_size"] and co[c2]["error_size"] >= co[c1]["error_size"]
+                                      and gap <= err_cd + 2 * ulp)
+                        rank = {"gpu_top": c1, "oracle_top": c2, "float64_sizes": [s64[c1][0], s64[c2][0]],
+                                "gpu_sizes": [cg[c1]["error_size"], cg[c2]["error_size"]],
+                                "torch_cdist_sizes": [co[c1]["error_size"], co[c2]["error_size"]], "float64_gap": gap,
+                                "cdist_error_on_the_two": err_cd, "proven": proven}
+                        ok = ok and proven
+                    ev["rank"] = rank
+                    explained = ok and bool(ties or rank)
+                    ev.update({"kind": ("rank tie" if rank else "distance tie") if explained else "unexplained", "proven": explained})
+                forks["unexplained"] += 0 if ev["proven"] else 1
                 rec["events"].append(ev)
-                rec["forked_at_round"] = j
-                break
-            out["compared_rounds"] += 1
-            same_pred = torch.equal(a[3], b[3])
-            if same_pred and abs(a[1] - b[1]) <= 1e-6:
-                out["identical_rounds"] += 1
-                continue
-            ev = {"round": j, "iou_gpu": a[1], "iou_oracle": b[1]}
-            if same_pred:
-                ev["kind"] = "unexplained"                       # same labels, different IoU
-            else:
-                rows = torch.nonzero(a[3] != b[3]).flatten()
-                lg = gpu_logits(i, a[2], a[4])
-                lo = od.forward_mask(sd, oracle_bb[i]["pcd_features"], xyz, oracle_bb[i]["pos_enc"], b[2], b[4])[-1]
-                mg = lg[rows].topk(2, dim=-1).values
-                mo = lo[rows].topk(2, dim=-1).values
-                margin = torch.maximum(mg[:, 0] - mg[:, 1], mo[:, 0] - mo[:, 1])
-                ev.update({"points_with_different_labels": int(rows.numel()), "largest_top2_margin": float(margin.max()),
-                           "max_logit_diff_gpu_vs_oracle": float((lg - lo).abs().max())})
-                ev["kind"] = "logit tie" if float(margin.max()) <= logit_tol else "unexplained"
-            out["unexplained"] += 1 if ev["kind"] == "unexplained" else 0
-            rec["events"].append(ev)
-        out["scenes"].append(rec)
-    return out
+                nci, nct = {k: list(v) for k, v in g[j + 1][2].items()}, {k: list(v) for k, v in g[j + 1][4].items()}
+            ci, ct = nci, nct
+            n_clicks += objects if n_clicks == 0 else 1
+        forks["scenes"].append(rec)
+    return oracle_log, oracle_bb, forks
 
 
 def iou_at_k(dev, n_scenes=4, voxels=5000, objects=3, max_clicks=20, fit_iters=120, lr=1e-3, min_iou5=0.5, more_iters=40,
@@ -381,29 +452,23 @@ def iou_at_k(dev, n_scenes=4, voxels=5000, objects=3, max_clicks=20, fit_iters=1
                            lambda idx, cur, pred, iou, ci_, ct_: gpu_log.append(
                                (cur, float(iou), {k: list(v) for k, v in ci_.items()}, pred.cpu().clone().long(),
                                 {k: list(v) for k, v in ct_.items()})))
-    # ---- CPU oracle, same state dict, same seed
+    # ---- CPU oracle, same state dict, same seed, next to the GPU run's log: every round compared (oracle_protocol_synced)
     os.makedirs(os.path.join(tmp, "cpu"), exist_ok=True)
-    oracle_log, oracle_bb = [], []
     random.seed(11)
+    oracle_log, oracle_bb, forks = oracle_protocol_synced(model, sd, items, gpu_log, objects, max_clicks, dev)
+    per_scene = len(oracle_log) // len(items)
     with open(os.path.join(tmp, "cpu", "val_results_multi.csv"), "w") as f:
-        for i, it in enumerate(items):
-            sc, lab = it["scene"], torch.from_numpy(it["labels"])
-            xyz = torch.from_numpy(sc["raw_xyz"])
-            rb = ob.forward_backbone(sd, sc["coords"], torch.from_numpy(sc["feats"]), xyz)
-            oracle_bb.append(rb)
-            recs = oc.interactive_rounds(lambda ci_, ct_: od.forward_mask(sd, rb["pcd_features"], xyz, rb["pos_enc"], ci_, ct_)[-1],
-                                         lab, xyz, objects, max_clicks)
-            for r in recs:
-                f.write(f"{i} {it['name'].replace('scene', '')} {objects} {r['num_clicks'] / objects} {r['iou']}\n")
-                oracle_log.append((r["num_clicks"], float(r["iou"]), r["click_idx"], r["pred"].long(), r["click_time_idx"]))
+        for k_, r in enumerate(oracle_log):
+            i = k_ // per_scene
+            f.write(f"{i} {items[i]['name'].replace('scene', '')} {objects} {r[0] / objects} {np.float32(r[1])}\n")
     with contextlib.redirect_stdout(io.StringIO()):
         res_cpu = EvaluatorMO(os.path.join(tmp, "val.json"), os.path.join(tmp, "cpu", "val_results_multi.csv"),
                               [0.5, 0.65, 0.8, 0.85, 0.9]).eval_results()
     rounds = min(len(gpu_log), len(oracle_log))
-    same_clicks = [a_[0] == b_[0] and a_[2] == b_[2] for a_, b_ in zip(gpu_log, oracle_log)]
     same_iou = [abs(a_[1] - b_[1]) <= 1e-6 for a_, b_ in zip(gpu_log, oracle_log)]
+    fork_rounds = sorted(si_ * per_scene + e_["round"] for si_, s_ in enumerate(forks["scenes"]) for e_ in s_["events"] if "gpu_clicks" in e_)
+    same_clicks = [k_ not in fork_rounds for k_ in range(rounds)]     # a round whose clicks the oracle would have picked differently
     first_div = next((i for i, (c_, u_) in enumerate(zip(same_clicks, same_iou)) if not (c_ and u_)), None)
-    forks = explain_forks(model, sd, items, oracle_bb, gpu_log, oracle_log, dev)
     ks = (1, 3, 5, 10, 15)
     noc_g = {k_: round(float(v), 4) for k_, v in res_gpu.items() if k_.startswith("NoC")}
     noc_c = {k_: round(float(v), 4) for k_, v in res_cpu.items() if k_.startswith("NoC")}

@@ -33,14 +33,22 @@ def test_fitted_model_interactive_protocol_matches_oracle():
     assert "NoC@50" in r["noc_thresholds_crossed_before_max_clicks"], r      # a threshold is crossed mid-run ...
     assert r["noc_gpu"]["NoC@50"] < 20 and r["noc_oracle"]["NoC@50"] < 20
     assert r["rounds"] >= 2 * 58
-    # ... and the two free-running protocols agree wherever they can be compared: while a scene's two runs hold the same
-    # clicks every round is identical (labels, IoU within 1e-6) or its difference is a PROVEN tie -- labels that differ only
-    # at points whose two best logits are within 1e-4 on both sides, or a next click that differs because the reference's
-    # torch.cdist and the exact distance rank two candidates of one cluster differently with a float64 gap below cdist's
-    # own error (bench.explain_forks has the numbers); a scene that forked is not compared any further
+    # ... and the two protocols agree in EVERY round: the oracle runs next to the GPU run's log with the same `random`
+    # stream (bench.oracle_protocol_synced), holds the clicks the GPU run holds, and every round is identical (labels, IoU
+    # within 1e-6, next clicks) or its difference is a PROVEN tie -- labels that differ only at points whose two best
+    # logits are within 1e-4 on both sides; a next click that differs because the reference's torch.cdist and the exact
+    # distance rank two rows of one cluster, or the two largest clusters, differently with a float64 gap no larger than
+    # cdist's own error on them (float64 numbers in every event).  After a differing click the oracle continues from the
+    # GPU's clicks: no round is left uncompared
     f = r["forks"]
     assert f["unexplained"] == 0, f
-    assert f["compared_rounds"] >= 20, f                                     # the runs did not fork straight away
-    events = sum(len(s_["events"]) for s_ in f["scenes"])
-    assert f["identical_rounds"] >= f["compared_rounds"] - events, f
-    assert r["max_abs_diff"] <= 0.05, r                                       # after a fork: same curve, not the same run
+    assert f["compared_rounds"] == r["rounds"] >= 2 * 58, f
+    events = [e for s_ in f["scenes"] for e in s_["events"]]
+    assert all(e["proven"] for e in events), events
+    for e in events:
+        if e["kind"] in ("distance tie", "rank tie"):                        # float64 evidence, not a tolerance
+            nums = list(e["ties"]) + ([e["rank"]] if e["rank"] else [])
+            assert nums and all(t["float64_gap"] <= t["cdist_error_on_the_two"] + 1e-6 for t in nums), e
+    assert f["identical_rounds"] >= f["compared_rounds"] - len(events), f
+    assert r["rounds_with_identical_clicks"] == r["rounds"] - f["click_forks"], r
+    assert r["max_abs_diff"] <= 0.05, r                                       # the oracle follows the GPU's clicks: same curve

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
-"""Look for fitted state dicts on which the two free-running interactive protocols (GPU product / CPU oracle) stop agreeing,
-and print what bench.explain_forks makes of every difference: the evidence behind "a fork is a tie, not a bug" (VERDICT r04
-weak #2).  Every configuration is one bench.iou_at_k call (fit on the GPU, both protocols, the round-by-round analysis).
+"""Look for fitted state dicts on which the interactive protocols of the GPU product and of the CPU oracle pick different
+clicks, and print what bench.oracle_protocol_synced makes of every difference -- float64 distances / cluster sizes next to
+both arithmetics: the evidence behind "a fork is a tie, not a bug".  Every configuration is one bench.iou_at_k call (fit on
+the GPU, the GPU protocol, the oracle next to its log: EVERY round compared, the oracle continues from the GPU's clicks).
    python tools/fork_hunt.py [fit_iters ...]            (default: 40 60 80 100 140)"""
 import json
 import os
@@ -24,7 +25,7 @@ def main():
         print(json.dumps({"fit_iters": fi, "iou_gpu": r["gpu"], "iou_oracle": r["oracle"], "rounds": r["rounds"],
                           "identical_clicks": r["rounds_with_identical_clicks"], "identical_iou": r["rounds_with_identical_iou"],
                           "compared_rounds": f["compared_rounds"], "identical_compared": f["identical_rounds"],
-                          "unexplained": f["unexplained"], "events": events}))
+                          "click_forks": f["click_forks"], "unexplained": f["unexplained"], "events": events}))
         sys.stdout.flush()
 
 
