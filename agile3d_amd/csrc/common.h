@@ -63,6 +63,10 @@ __device__ inline void grid_barrier_counter(unsigned* bar, unsigned target, int*
 }
 #endif
 
+// A kernel that spins at grid_barrier_counter needs EVERY workgroup of its grid resident at once: true when the current device,
+// as this process sees it (a partitioned device exposes a fraction of the CUs), holds `grid` workgroups of `func` (radix.hip)
+bool barrier_grid_fits(const void* func, int block_threads, size_t dyn_lds_bytes, int grid);
+
 static inline int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
 static inline size_t align256(size_t x) { return (x + 255) & ~size_t(255); }
 

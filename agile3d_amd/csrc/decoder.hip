@@ -3063,8 +3063,9 @@ static int prepare_sample(const a3d_decoder_weights* w, const a3d_decoder_sample
   P.logits = sp.logits_dev;
   P.kv0 = sp.kv0_dev;
   P.kv0_state = sp.kv0_dev ? sp.kv0_state : 0;
-  if (P.kv0_state < 0 || P.kv0_state > 2 || ((uintptr_t)sp.kv0_dev & 15)) {
-    set_error("a3d_decoder_forward: bad kv0 cache (state %d)", sp.kv0_state);
+  if (P.kv0_state < 0 || P.kv0_state > 2 || ((uintptr_t)sp.kv0_dev & 15) || (P.kv0_state != 0 && sp.kv0_blocks < 3)) {
+    set_error("a3d_decoder_forward: bad kv0 cache (state %d, %d blocks of [n][128]; keys, values and first-layer queries = 3)",
+              sp.kv0_state, sp.kv0_blocks);
     return A3D_ERR_INVALID;
   }
   P.bind();
@@ -3225,5 +3226,6 @@ extern "C" int a3d_decoder_forward(const a3d_decoder_weights* w, const float* fe
   sp.workspace_bytes = workspace_bytes;
   sp.kv0_dev = nullptr;
   sp.kv0_state = 0;
+  sp.kv0_blocks = 0;
   return a3d_decoder_forward_batch(w, &sp, 1, stream);
 }

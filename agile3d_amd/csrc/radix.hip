@@ -397,7 +397,8 @@ int radix_sort_pairs(void* temp, size_t temp_bytes, const uint64_t* keys_in, uin
     const char* e = getenv("A3D_SORT_ONE_LAUNCH");   // 0: the launch chain for every size (A/B, tests)
     one_launch = e ? atoi(e) : 1;
   }
-  const bool small = allow_one_launch && one_launch && rs_blocks_small(n) <= kRsOneLaunchBlocks;
+  const bool small = allow_one_launch && one_launch && rs_blocks_small(n) <= kRsOneLaunchBlocks &&
+                     barrier_grid_fits((const void*)k_rs_sort, kRsThreads, 0, (int)rs_blocks_small(n));
   if (small) a.nblocks = rs_blocks_small(n);
   a.status = (uint32_t*)c;
   c += align256((size_t)npass * a.nblocks * 256 * sizeof(uint32_t));
@@ -517,12 +518,22 @@ int scan2_incl_excl(void* temp, size_t temp_bytes, const int* a, const int* b, i
   return A3D_OK;
 }
 
+bool barrier_grid_fits(const void* func, int block_threads, size_t dyn_lds_bytes, int grid) {
+  int dev = 0, cus = 0, per_cu = 0;
+  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
+      hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, func, block_threads, dyn_lds_bytes) != hipSuccess) {
+    (void)hipGetLastError();
+    return false;   // cannot tell: the launch chains need no residency
+  }
+  return (int64_t)per_cu * cus >= grid;
+}
+
 }  // namespace a3d
 
 // Test / utility entry: stable sort of (key, value) pairs by the key bits [bit_begin, bit_end), ascending.
 extern "C" size_t a3d_sort_pairs_workspace_bytes(int64_t n) {
   if (n <= 0 || n > (int64_t)1 << 28) return 0;
-  return a3d::radix_sort_temp_bytes((int)n);
+  return a3d::radix_sort_temp_bytes((int)n) + 256;   // + the give-up word of a one-launch sort
 }
 extern "C" int a3d_sort_pairs_u64(const uint64_t* keys_in_dev, const int32_t* vals_in_dev, int64_t n, int bit_begin,
                                   int bit_end, uint64_t* keys_out_dev, int32_t* vals_out_dev, void* workspace_dev,
@@ -535,7 +546,26 @@ extern "C" int a3d_sort_pairs_u64(const uint64_t* keys_in_dev, const int32_t* va
   }
   RadixPass ps[kRadixMaxPasses];
   const int np = radix_passes(bit_begin, bit_end, ps);
-  // (a stand-alone sort: the one-launch form for scene-sized inputs, like the first sort of a scene build)
-  return radix_sort_pairs(workspace_dev, workspace_bytes, keys_in_dev, keys_out_dev, vals_in_dev, vals_out_dev, (int)n, ps, np,
-                          (hipStream_t)stream, nullptr, true);
+  // A stand-alone sort: the one-launch form for scene-sized inputs, like the first sort of a scene build -- with its own
+  // give-up word (the first int of the workspace's tail, cleared here): a grid barrier that gave up leaves unsorted data, so
+  // the word is read back (this entry synchronises the stream for such inputs) and the sort runs again as a launch chain
+  hipStream_t st = (hipStream_t)stream;
+  const bool maybe_one = n > 0 && rs_blocks_small((int)n) <= kRsOneLaunchBlocks;
+  if (!maybe_one)
+    return radix_sort_pairs(workspace_dev, workspace_bytes, keys_in_dev, keys_out_dev, vals_in_dev, vals_out_dev, (int)n, ps, np, st,
+                            nullptr, false);
+  const size_t need = radix_sort_temp_bytes((int)n);
+  if (!workspace_dev || workspace_bytes < need + 256) {
+    set_error("a3d_sort_pairs_u64: workspace too small (%zu < %zu)", workspace_bytes, need + 256);
+    return A3D_ERR_WORKSPACE;
+  }
+  int* fail_dev = (int*)((char*)workspace_dev + need);
+  A3D_HIP_CHECK(hipMemsetAsync(fail_dev, 0, sizeof(int), st));
+  int rc = radix_sort_pairs(workspace_dev, need, keys_in_dev, keys_out_dev, vals_in_dev, vals_out_dev, (int)n, ps, np, st, fail_dev, true);
+  if (rc) return rc;
+  int fail = 0;
+  A3D_HIP_CHECK(hipMemcpyAsync(&fail, fail_dev, sizeof(int), hipMemcpyDeviceToHost, st));
+  A3D_HIP_CHECK(hipStreamSynchronize(st));
+  if (fail == 0) return A3D_OK;
+  return radix_sort_pairs(workspace_dev, need, keys_in_dev, keys_out_dev, vals_in_dev, vals_out_dev, (int)n, ps, np, st, nullptr, false);
 }

@@ -677,7 +677,7 @@ static void carve_phase2(Bump& b, const int* sizes, a3d_scene* sc, Phase2Tmp& t,
 
 using namespace a3d;
 
-extern "C" int a3d_version(void) { return 1; }
+extern "C" int a3d_version(void) { return A3D_ABI_VERSION; }
 
 extern "C" int a3d_profile_enable(int on) {
   g_prof_on = on != 0;
@@ -762,8 +762,16 @@ extern "C" int a3d_scene_create(const int32_t* coords4_dev, int64_t n_voxels, vo
     ~SoloPhase1() { g_phase1_calls.fetch_sub(1, std::memory_order_acq_rel); }
   } solo;
   // ---- phase 1: keys, sort, levels (all sized by the n0 bound; real sizes stay on the device)
-  int prof1 = prof_enabled() ? prof_begin(st, A3D_PROF_SCENE_SORT, 0, 0, 0, 0, n0) : -1;
+  // The one-launch forms need every workgroup of their grids on the chip at once: they are used only where the device AS
+  // THIS PROCESS SEES IT can hold the grid (barrier_grid_fits: a partitioned device has a fraction of the CUs), and when a
+  // grid barrier gives up all the same (another process's kernels hold the CUs: ranks sharing one device) phase 1 runs
+  // again through the launch chains, which wait only for workgroups that already run.
   int sizes[kSizesInts];
+  const int nb = (n0 + 1023) / 1024;
+  for (int attempt = 0; attempt < 2; ++attempt) {
+  const bool barriers_ok = attempt == 0 && solo.alone;
+  const bool heads_one = barriers_ok && nb <= kHeadsOneLaunch && barrier_grid_fits((const void*)k_heads_all, 1024, 0, nb);
+  int prof1 = prof_enabled() ? prof_begin(st, A3D_PROF_SCENE_SORT, 0, 0, 0, 0, n0) : -1;
   for (int i = 0; i < kSizesInts; ++i) sizes[i] = i < 8 || i >= kSizesBar ? 0 : -1;
   for (int sl = 0; sl < kBBoxSlots; ++sl)
     for (int a = 0; a < 3; ++a) sizes[kBBox + 8 * sl + a] = INT_MAX, sizes[kBBox + 8 * sl + 3 + a] = INT_MIN;
@@ -776,10 +784,9 @@ extern "C" int a3d_scene_create(const int32_t* coords4_dev, int64_t n_voxels, vo
     const int np = radix_passes(0, 64, ps);
     int rc = radix_sort_pairs(p.sort_temp, p.sort_temp_bytes, p.keys_in, p.keys[0], p.vals_in, p.vals_sorted, n0, ps, np, st,
                               p.sizes_dev + 5,   // a look-back that gives up reports A3D_ERR_HIP through the error word read below
-                              solo.alone);
+                              barriers_ok);
     if (rc) return rc;
   }
-  const int nb = (n0 + 1023) / 1024;
   {
     CoarseOut co;
     for (int L = 0; L < A3D_NUM_LEVELS - 1; ++L) {
@@ -787,7 +794,7 @@ extern "C" int a3d_scene_create(const int32_t* coords4_dev, int64_t n_voxels, vo
       co.parentM[L] = p.parentM[L];
       co.firstM[L] = p.firstM[L];
     }
-    if (nb <= kHeadsOneLaunch && solo.alone) {
+    if (heads_one) {
       k_heads_all<<<nb, 1024, 0, st>>>(p.keys[0], n0, nb, p.blocksums, p.sizes_dev, co);
     } else {
       k_heads_count<<<nb, 1024, 0, st>>>(p.keys[0], n0, nb, p.blocksums, p.sizes_dev);
@@ -799,6 +806,9 @@ extern "C" int a3d_scene_create(const int32_t* coords4_dev, int64_t n_voxels, vo
   if (prof1 >= 0) prof_end(st, prof1);
   A3D_HIP_CHECK(hipMemcpyAsync(sizes, p.sizes_dev, sizeof(sizes), hipMemcpyDeviceToHost, st));
   A3D_HIP_CHECK(hipStreamSynchronize(st));
+  if (sizes[5] == A3D_ERR_HIP && barriers_ok) continue;   // a grid barrier gave up: once more through the launch chains
+  break;
+  }
   if (sizes[5] != 0) {
     set_error(sizes[5] == A3D_ERR_DUPLICATE     ? "a3d_scene_create: duplicate voxel coordinates"
               : sizes[5] == A3D_ERR_COORD_RANGE ? "a3d_scene_create: coordinate out of range"

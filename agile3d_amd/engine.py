@@ -698,6 +698,7 @@ class Engine:
                 sp.n_clicks, sp.n_objects = nc, K
                 sp.logits_dev, sp.workspace_dev, sp.workspace_bytes = _ptr(logits), _ptr(ws), wsb
                 sp.kv0_dev, sp.kv0_state = (_ptr(kv_bufs[b]), kv_state) if kv_state else (None, 0)
+                sp.kv0_blocks = int(kv_bufs[b].shape[0]) if kv_state else 0
                 for l in range(n_layers):
                     preds[l].append(logits[l])
             try:

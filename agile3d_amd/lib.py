@@ -74,7 +74,7 @@ class DecoderSample(C.Structure):
                 ("click_row", C.POINTER(C.c_int32)), ("click_obj", C.POINTER(C.c_int32)),
                 ("click_time", C.POINTER(C.c_int32)), ("n_clicks", C.c_int32), ("n_objects", C.c_int32),
                 ("logits_dev", C.c_void_p), ("workspace_dev", C.c_void_p), ("workspace_bytes", C.c_size_t),
-                ("kv0_dev", C.c_void_p), ("kv0_state", C.c_int32)]
+                ("kv0_dev", C.c_void_p), ("kv0_state", C.c_int32), ("kv0_blocks", C.c_int32)]
 
 
 class ClickCluster(C.Structure):
@@ -234,6 +234,9 @@ class A3DError(RuntimeError):
     pass
 
 
+ABI_VERSION = 2   # include/agile3d_hip.h: A3D_ABI_VERSION
+
+
 def load():
     """dlopen the in-tree library and bind every symbol.  Raises if anything is missing."""
     global _lib
@@ -247,6 +250,10 @@ def load():
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
         fn.restype = res
         fn.argtypes = args
+    got = lib.a3d_version()
+    if got != ABI_VERSION:   # struct layouts / buffer contracts of another revision: refuse before the first real call
+        raise A3DError(f"{LIB_PATH} speaks interface version {got}, this binding was written against {ABI_VERSION} "
+                       "(include/agile3d_hip.h: A3D_ABI_VERSION); rebuild the library")
     _lib = lib
     return lib
 

@@ -35,6 +35,10 @@ extern "C" {
 
 #define A3D_NUM_LEVELS 5           /* tensor strides 1,2,4,8,16 (res16unet.py:222-295) */
 
+/* Version of this interface: bumped whenever a struct grows or a buffer contract changes (2: a3d_op's fused-head fields, the
+ * third block of a3d_decoder_sample::kv0_dev + kv0_blocks).  A host binding compares it with the header it was written
+ * against before the first call (agile3d_amd/lib.py does). */
+#define A3D_ABI_VERSION 2
 int         a3d_version(void);
 const char* a3d_last_error(void);
 /* plain hipMemcpy device->host (+ stream sync); lets non-torch hosts and tests read tables */
@@ -537,6 +541,7 @@ typedef struct a3d_decoder_sample {
    * projecting them inside the fused kernel (39 instead of 75 us at 80 k points). */
   float* kv0_dev;
   int32_t kv0_state;
+  int32_t kv0_blocks;                   /* [n][128] blocks kv0_dev holds: the library refuses a cache of fewer than 3 */
 } a3d_decoder_sample;
 /* All samples of a batch in one call: per decoder layer the three wide kernels are launched once for the whole batch
  * (samples with the same padded query count share the launches); results per sample equal a3d_decoder_forward's up to

@@ -20,7 +20,7 @@ def test_library_exports_every_declared_symbol():
     assert declared == set(lib.SYMBOLS), declared ^ set(lib.SYMBOLS)
     for name in declared:
         assert hasattr(L, name)
-    assert L.a3d_version() == 1
+    assert L.a3d_version() == lib.ABI_VERSION == 2
     # pure host-side queries work without a GPU
     assert L.a3d_scene_workspace_bytes(80000) > 80000 * 27 * 4
     assert L.a3d_decoder_workspace_bytes(80000, 20) > 4 * 80000 * 128 * 4
@@ -34,6 +34,7 @@ def test_struct_layouts_match_header():
     assert C.sizeof(lib.BufDesc) == 8
     assert C.sizeof(lib.DecoderLayer) == 29 * 8
     assert C.sizeof(lib.DecoderWeights) == 16 + 8 * 29 * 8 + 11 * 8
+    assert C.sizeof(lib.DecoderSample) == 96    # kv0_blocks sits where the struct's tail padding was
 
 
 def test_sparse_quantize_first_occurrence():
