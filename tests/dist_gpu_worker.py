@@ -152,6 +152,38 @@ def main():
         stats, it = train_one_epoch(model, build_mask_criterion(args), loader, opt, dev, epoch=0, max_norm=0.1, log=None)
         torch.save({"params": {k: v.detach().cpu() for k, v in model.named_parameters()}, "stats": stats, "iters": it},
                    os.path.join(out, f"epoch_{rank}.pt"))
+    elif mode == "dp8_epoch":
+        # BASELINE config 4's collective path at its world size, host side: EIGHT ranks (one ~3 k-voxel scene each) sharing the
+        # one GPU over gloo -- three iterations of the real train_one_step through train_one_epoch with the overlapped gradient
+        # all-reduce in 0.5 MB buckets (A3D_DP_BUCKET_MB, set by the test) and SyncBN over the eight ranks (A3D_SYNC_BN)
+        from agile3d_amd.criterion import build_mask_criterion
+        from agile3d_amd.optim import AdamW, OverlappedAllReduce
+        from agile3d_amd.train_step import train_one_epoch
+        loader = [scene_batch(300 + 10 * i + rank, 2800 + 120 * i + 60 * rank)[1] for i in range(3)]
+        opt = AdamW(model.named_parameters(), lr=1e-3, weight_decay=1e-4)
+        np.random.seed(21 + rank), torch.manual_seed(21 + rank), random.seed(21 + rank)
+        stats, it = train_one_epoch(model, build_mask_criterion(args), loader, opt, dev, epoch=0, max_norm=0.1, log=None)
+        # the digest check with ONE rank out of line: every rank must fail with an error (none may enter a collective alone)
+        expected = {k: v.numel() for k, v in model.named_parameters()}
+        if rank == 5:
+            expected[sorted(expected)[17]] += 1
+        raised = False
+        try:
+            OverlappedAllReduce(bucket_bytes=1 << 19, expected=expected)
+        except RuntimeError as e:
+            raised = "disagree" in str(e)
+        ok = OverlappedAllReduce(bucket_bytes=1 << 19, expected={k: v.numel() for k, v in model.named_parameters()})   # and the group still works
+        torch.save({"params": {k: v.detach().cpu() for k, v in model.named_parameters()}, "stats": stats, "iters": it,
+                    "digest_raised": raised, "reducer_after": bool(ok.active), "bn": {k: v.cpu() for k, v in model.state_dict().items() if "running" in k}},
+                   os.path.join(out, f"epoch8_{rank}.pt"))
+    elif mode == "syncbn8":
+        from agile3d_amd.engine import Scene
+        from agile3d_amd.train_backbone import BackboneTape
+        s, batch = scene_batch(400 + rank, 2600 + 90 * rank)
+        model.train()
+        tape = BackboneTape(model, Scene(batch[0].to(dev).to(torch.int32).contiguous()), batch[2].to(dev), sync_bn=True)
+        torch.save({"out": tape.output.cpu(), "bn": {k: v.cpu() for k, v in model.state_dict().items() if "running" in k}},
+                   os.path.join(out, f"syncbn8_{rank}.pt"))
     dist.barrier()
     dist.destroy_process_group()
 

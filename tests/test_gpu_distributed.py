@@ -252,3 +252,81 @@ def test_bench_rccl_branch_at_world_size_one():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 1 and d["ranks_seen"] == 1 and d["config"]["backend"] == "nccl (RCCL)"
     assert d["value"] > 0 and len(d["ms_per_step_per_rank"]) == 1
+
+
+def test_eight_rank_dp_training_on_the_one_gpu(tmp_path, monkeypatch):
+    """BASELINE.json config 4 (bs 8, one scene per rank, gradient all-reduce only; /root/reference main.py:115-127,
+    engine.py:26-179) at ITS world size, host side: eight gloo ranks share the one GPU.
+      * three iterations of the real train_one_step (train_one_epoch, AdamW + clip) with the gradient all-reduce overlapped
+        with the backward in 0.5 MB buckets on its own communicator and SyncBN over the eight ranks: all eight ranks end with
+        BIT-IDENTICAL parameters and BatchNorm statistics, the parameters moved;
+      * the digest check with one rank's gradient list perturbed: every rank fails with an error, nobody hangs, and the
+        process group is usable afterwards;
+      * one iteration without SyncBN: the gradients every rank steps with are the MEAN of the eight single-rank gradients;
+      * SyncBN's forward over eight ranks == one rank with the eight scenes in one batch.
+    No RCCL here (it refuses two ranks per device) and no scaling number: the eight-GPU node runs the same code over nccl."""
+    from agile3d_amd import batched_coordinates, build_model, default_args
+    from agile3d_amd.criterion import build_mask_criterion
+    from agile3d_amd.engine import Scene
+    from agile3d_amd.train_backbone import BackboneTape
+    from agile3d_amd.train_step import train_one_step
+    args = default_args(bce_loss_coef=1.0, dice_loss_coef=2.0, losses=["bce", "dice"])
+    dev = torch.device("cuda")
+    monkeypatch.setenv("A3D_DP_BUCKET_MB", "0.5")
+    monkeypatch.setenv("A3D_SYNC_BN", "1")
+    monkeypatch.setenv("A3D_HOST_THREADS", "1")
+    _run_world("dp8_epoch", tmp_path, world=8)
+    r = [torch.load(tmp_path / f"epoch8_{i}.pt", weights_only=False) for i in range(8)]
+    torch.manual_seed(3)
+    init = dict(build_model(args).named_parameters())
+    moved = 0
+    for k in r[0]["params"]:
+        for i in range(1, 8):
+            assert torch.equal(r[0]["params"][k], r[i]["params"][k]), (k, i)
+        moved += int(not torch.equal(r[0]["params"][k], init[k].detach()))
+    for k in r[0]["bn"]:
+        for i in range(1, 8):
+            assert torch.equal(r[0]["bn"][k], r[i]["bn"][k]), (k, i)
+    assert moved >= 260, moved
+    assert all(x["iters"] == 3 and x["digest_raised"] and x["reducer_after"] for x in r), [(x["iters"], x["digest_raised"]) for x in r]
+    assert all(np.isfinite(x["stats"]["loss"]) for x in r)
+    # ---- one iteration without SyncBN: averaged gradients == mean of the eight single-rank gradients
+    monkeypatch.setenv("A3D_SYNC_BN", "0")
+    _run_world("dp_step", tmp_path, world=8)
+    d = [torch.load(tmp_path / f"dp_{i}.pt", weights_only=False) for i in range(8)]
+    for i in range(1, 8):
+        assert d[i]["coef"] == d[0]["coef"]
+        for k in d[0]["grads"]:
+            assert torch.equal(d[0]["grads"][k], d[i]["grads"][k]), (k, i)
+    mean = None
+    for rank in range(8):
+        torch.manual_seed(3)
+        model = build_model(args).to(dev)
+        _, batch = W.scene_batch(70 + rank, 2500 + 200 * rank)
+        opt = W.CaptureSGD(model, 0.0)
+        np.random.seed(11 + rank), torch.manual_seed(11 + rank), random.seed(11 + rank)
+        st = train_one_step(model, build_mask_criterion(args), opt, batch, dev, max_norm=0.1)
+        assert st["clicks"] == d[rank]["stats"]["clicks"]
+        mean = {k: g.double() / 8 for k, g in opt.grads.items()} if mean is None else {k: mean[k] + g.double() / 8 for k, g in opt.grads.items()}
+    worst = max((d[0]["grads"][k].to(dev).double() - g).abs().max().item() / max(1e-8, g.abs().max().item()) for k, g in mean.items())
+    print(f"eight ranks: averaged gradients vs mean of the eight single-rank runs, worst relative difference {worst:.2e}")
+    assert worst <= 2e-5
+    # ---- SyncBN forward: eight ranks x one scene == one rank x eight scenes
+    _run_world("syncbn8", tmp_path, world=8)
+    s8 = [torch.load(tmp_path / f"syncbn8_{i}.pt", weights_only=False) for i in range(8)]
+    scenes = [W.scene_batch(400 + i, 2600 + 90 * i)[0] for i in range(8)]
+    torch.manual_seed(3)
+    model = build_model(args).to(dev).train()
+    coords = batched_coordinates([s_["coords"][:, 1:] for s_ in scenes]).to(dev).to(torch.int32).contiguous()
+    feats = torch.from_numpy(np.concatenate([s_["feats"] for s_ in scenes])).to(dev)
+    out = BackboneTape(model, Scene(coords), feats, sync_bn=False).output.cpu()
+    row = 0
+    for i, s_ in enumerate(scenes):
+        n = len(s_["coords"])
+        e = (out[row:row + n] - s8[i]["out"]).abs().max().item()
+        assert e <= 2e-5 * max(1.0, out.abs().max().item()), (i, e)
+        row += n
+    sd = model.state_dict()
+    for k, v in s8[0]["bn"].items():
+        assert all(torch.equal(v, s8[i]["bn"][k]) for i in range(1, 8)), k
+        assert torch.allclose(sd[k].cpu().float(), v.float(), rtol=1e-4, atol=1e-6), k
