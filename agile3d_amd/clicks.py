@@ -179,50 +179,92 @@ def error_clusters(pred, labels, coords):
     return _parse_clusters(out.cpu().numpy())
 
 
-_side_streams: dict = {}
+_MAX_CLICK_BATCH = 64      # csrc/clicks.hip: kMaxClickBatch
+_ORDER_FROM = 20000        # csrc/clicks.hip: kCoarseFrom -- smaller samples run no first bounding stage
+_order_cache: "dict" = {}  # (device, data_ptr, n) -> (order, inv) of a coordinate tensor, most recent last
 
 
-def _side(device, i):
-    pool = _side_streams.setdefault(device.index, [])
-    while len(pool) <= i:
-        pool.append(torch.cuda.Stream(device=device))
-    return pool[i]
+def _spatial_order(xyz):
+    """Morton order of a sample's coordinates and its inverse (``a3d_click_spatial_order``), cached per coordinate tensor: a
+    scene's coordinates do not change over its click rounds (eval_multi_obj.py:112-166, engine.py:83-116).  The cache is
+    keyed on the tensor's address and length; a hit on recycled memory hands the search a stale permutation, which costs it
+    tightness and never exactness (csrc/clicks.hip: any permutation gives valid bounds)."""
+    n = xyz.shape[0]
+    if n < _ORDER_FROM:
+        return None
+    key = (xyz.device.index, xyz.data_ptr(), n)
+    hit = _order_cache.pop(key, None)
+    if hit is None:
+        lib = L.load()
+        order = torch.empty(n, dtype=torch.int32, device=xyz.device)
+        inv = torch.empty(n, dtype=torch.int32, device=xyz.device)
+        ws = torch.empty(lib.a3d_click_spatial_order_workspace_bytes(n), dtype=torch.uint8, device=xyz.device)
+        L.check(lib.a3d_click_spatial_order(xyz.data_ptr(), n, order.data_ptr(), inv.data_ptr(), ws.data_ptr(), ws.numel(),
+                                            _stream(xyz)), "a3d_click_spatial_order")
+        hit = (order, inv)
+        while len(_order_cache) >= 256:
+            _order_cache.pop(next(iter(_order_cache)))
+    _order_cache[key] = hit
+    return hit
 
 
-def error_clusters_batch(preds, labels, coords, max_streams: int = 8):
-    """``error_clusters`` of several samples with ONE host synchronisation: sample i's kernels (a latency chain of a
-    dozen small launches) run on side stream i % max_streams next to the other samples', the records come back through
-    pinned buffers.  Same results as the per-sample call, in sample order."""
+def _launch_clusters_batch(preds, labels, coords):
+    """ONE a3d_click_clusters_batch call (a dozen launches whatever the number of samples) for the non-empty samples, on the
+    current stream, and the copy of all their records into one pinned buffer.  Returns (host buffer, slot of every
+    sample or None, references that must outlive the stream's work)."""
+    dev = preds[0].device
+    lib = L.load()
+    keep, slots, live = [], [], []
+    for i, (pr, lb, xyz) in enumerate(zip(preds, labels, coords)):
+        p, l = _i32(pr), _i32(lb)
+        x = xyz.to(torch.float32).contiguous()
+        n = p.numel()
+        if n == 0:
+            slots.append(None)
+            continue
+        if x.shape != (n, 3) or l.numel() != n:
+            raise RuntimeError("error_clusters: pred [N], labels [N], coords [N,3] expected")
+        slots.append(len(live))
+        live.append((p, l, x, _cluster_buffers(dev, n, slot=1 + i)[0]))
+    if not live:
+        return None, slots, keep
+    if len(live) > _MAX_CLICK_BATCH:
+        raise RuntimeError(f"error_clusters_batch: {len(live)} samples > {_MAX_CLICK_BATCH} per call")
+    key = (dev.index, "cluster_out", len(live))
+    buf = _ws_cache.get(key)
+    if buf is None:
+        buf = _ws_cache[key] = (torch.empty(len(live), _OUT_BYTES, dtype=torch.uint8, device=dev),
+                                torch.empty(len(live), _OUT_BYTES, dtype=torch.uint8).pin_memory())
+    out, host = buf
+    arr = (L.ClickSample * len(live))()
+    rec = MAX_CLUSTERS * C.sizeof(L.ClickCluster)
+    for k, (p, l, x, work) in enumerate(live):
+        sp = arr[k]
+        sp.xyz_dev, sp.pred_dev, sp.labels_dev, sp.n = x.data_ptr(), p.data_ptr(), l.data_ptr(), p.numel()
+        sp.out_dev, sp.n_out_dev, sp.max_out = out[k].data_ptr(), out[k].data_ptr() + rec, MAX_CLUSTERS
+        sp.workspace_dev, sp.workspace_bytes = work.data_ptr(), work.numel()
+        so = _spatial_order(x)
+        sp.order_dev, sp.inv_dev = (so[0].data_ptr(), so[1].data_ptr()) if so is not None else (None, None)
+    L.check(lib.a3d_click_clusters_batch(C.cast(arr, C.c_void_p), len(live), _stream(live[0][0])), "a3d_click_clusters_batch")
+    host.copy_(out, non_blocking=True)
+    keep.append(live)
+    return host, slots, keep
+
+
+def error_clusters_batch(preds, labels, coords):
+    """``error_clusters`` of several samples with ONE set of launches and ONE host synchronisation (round 6: the kernels take
+    the samples from a device table -- csrc/clicks.hip; before, every sample ran its dozen launches on a side stream).  Same
+    results as the per-sample call, in sample order."""
     if not preds:
         return []
     dev = preds[0].device
     cur = torch.cuda.current_stream(dev)
-    pend, used, res = [], [], []
-    try:                                         # every side stream is drained before ANY exit (see mean_iou_and_clusters_batch)
-        for i, (pr, lb, xyz) in enumerate(zip(preds, labels, coords)):
-            p, l = _i32(pr), _i32(lb)
-            x = xyz.to(torch.float32).contiguous()
-            if p.numel() == 0:
-                pend.append(None)
-                continue
-            work, out, host = _cluster_buffers(dev, p.numel(), slot=1 + i)
-            st = _side(dev, i % max_streams)
-            st.wait_stream(cur)
-            used.append(st)
-            with torch.cuda.stream(st):
-                _launch_clusters(p, l, x, work, out)
-                host.copy_(out, non_blocking=True)
-            pend.append((st, host, (p, l, x)))       # the inputs stay referenced until the stream is drained
-        for item in pend:
-            if item is None:
-                res.append([])
-                continue
-            item[0].synchronize()
-            res.append(_parse_clusters(item[1].numpy()))
+    try:
+        host, slots, keep = _launch_clusters_batch(preds, labels, coords)
     finally:
-        for st in used:
-            st.synchronize()
-    return res
+        cur.synchronize()                        # the inputs and the cached work buffers are in use until here
+    hn = host.numpy() if host is not None else None
+    return [[] if k is None else _parse_clusters(hn[k]) for k in slots]
 
 
 def _pick_clicks(clusters, coords_qv, num_obj, current_num_clicks, training):
@@ -264,15 +306,13 @@ def get_simulated_clicks_batch(preds, labels, coords, current_num_clicks=None, t
 
 
 def mean_iou_and_clusters_batch(preds, labels_iou, inverse_maps, labels_qv, coords, n_ids: int = 256):
-    """What one round of the interactive protocol needs from the device, with ONE host synchronisation: the IoU counts of
-    every sample (``mean_iou_scene``, on the caller's stream) and its error clusters (``error_clusters``, on side streams)
-    are launched back to back, their records come back through pinned buffers, then everything is awaited once.  Returns
-    ``(ious, clusters)`` = what ``mean_iou_scene_batch`` and ``error_clusters_batch`` return."""
+    """What one round of the interactive protocol needs from the device, with ONE host synchronisation: the error clusters
+    of every sample (``error_clusters``: one batched set of launches) and its IoU counts (``mean_iou_scene``), all on the
+    caller's stream, their records back through pinned buffers, everything awaited once.  Returns ``(ious, clusters)`` =
+    what ``mean_iou_scene_batch`` and ``error_clusters_batch`` return."""
     lib = L.load()
     if not preds:
         return [], []
-    if len(preds) > 8:      # two samples per side stream from here on: the two-phase round measured the same or better
-        return mean_iou_scene_batch(preds, labels_iou, inverse_maps), error_clusters_batch(preds, labels_qv, coords)
     dev = preds[0].device
     cur = torch.cuda.current_stream(dev)
     ns = len(preds)
@@ -282,25 +322,10 @@ def mean_iou_and_clusters_batch(preds, labels_iou, inverse_maps, labels_qv, coor
         buf = _ws_cache[key] = (torch.empty(ns, 3 * n_ids + 1, dtype=torch.int64, device=dev),
                                 torch.empty(ns, 3 * n_ids + 1, dtype=torch.int64).pin_memory())
     counts, counts_host = buf
-    # the clusters first (on the side streams: the longer chains), then the IoU kernels back to back on the caller's stream
-    pend = []
-    used = []                # side streams with work in flight: drained before ANY exit (an error would otherwise drop the
-    try:                     # last references to buffers kernels are still reading, and the cached work buffers are reused)
-        for i in range(ns):
-            pq, lq = _i32(preds[i]), _i32(labels_qv[i])
-            x = coords[i].to(torch.float32).contiguous()
-            if pq.numel() == 0:
-                pend.append(None)
-                continue
-            work, out, host = _cluster_buffers(dev, pq.numel(), slot=1 + i)
-            st = _side(dev, i)
-            st.wait_stream(cur)
-            used.append(st)
-            with torch.cuda.stream(st):
-                _launch_clusters(pq, lq, x, work, out)
-                host.copy_(out, non_blocking=True)
-            pend.append((st, host, (pq, lq, x)))
-        keep = []
+    keep = []
+    try:                     # the stream is drained before ANY exit: the cached work buffers are reused by the next call
+        host, slots, refs = _launch_clusters_batch(preds, labels_qv, coords)
+        keep.append(refs)
         for i in range(ns):
             p, l = _i32(preds[i]), _i32(labels_iou[i])
             inv = None
@@ -314,22 +339,14 @@ def mean_iou_and_clusters_batch(preds, labels_iou, inverse_maps, labels_qv, coor
             L.check(lib.a3d_iou_counts(p.data_ptr(), p.numel(), inv.data_ptr() if inv is not None else None, l.data_ptr(),
                                        l.numel(), n_ids, counts[i].data_ptr(), _stream(p)), "a3d_iou_counts")
         counts_host.copy_(counts, non_blocking=True)
-        cur.synchronize()
-        hc = counts_host.numpy()
-        if hc[:, -1].any():
-            raise RuntimeError("iou_counts: inverse_map holds rows outside the prediction")
-        ious = [_mean_iou_from_counts(hc[i, :-1].reshape(3, n_ids).copy()) for i in range(ns)]
-        clusters = []
-        for item in pend:
-            if item is None:
-                clusters.append([])
-                continue
-            item[0].synchronize()
-            clusters.append(_parse_clusters(item[1].numpy()))
     finally:
-        for st in used:
-            st.synchronize()
         cur.synchronize()
+    hc = counts_host.numpy()
+    if hc[:, -1].any():
+        raise RuntimeError("iou_counts: inverse_map holds rows outside the prediction")
+    ious = [_mean_iou_from_counts(hc[i, :-1].reshape(3, n_ids).copy()) for i in range(ns)]
+    hn = host.numpy() if host is not None else None
+    clusters = [[] if k is None else _parse_clusters(hn[k]) for k in slots]
     return ious, clusters
 
 

@@ -37,9 +37,12 @@ constexpr int kNearestBlock = 256;
 constexpr int kNearestSplit = 128;           // candidate chunks (grid.y): enough waves when only a few thousand points are wrong
 constexpr int kSample = 16;                  // phase A: every kSample-th point is a candidate
 constexpr int kSampleCoarse = 256;           // ... after a first bounding stage against every kSampleCoarse-th point (a subset of them)
-constexpr int kCoarseFrom = 150000;          // ... from this many points (80 k voxels: its five launches cost what it saves)
+constexpr int kCoarseFrom = 20000;           // ... from this many points (150 k until round 6: the stage's five launches are shared by the samples of a call now)
+static unsigned kNearestWalkers = 1u << 20;      // workgroups per candidate chunk and sample that walk the query blocks of k_nearest_other
 constexpr int kMinChunk = 32;                // candidates per workgroup row of k_nearest_other at least (small samples: fewer, fuller blocks)
-constexpr long long kSmallPairs = 1ll << 30;  // (wrong points) x (points) below which phase A is skipped: the plain pass is ~0.15 ms
+constexpr long long kSmallPairs = 1ll << 26;  // (wrong points) x (points) below which a bounding stage is skipped: the plain pass over them is ~20 us of the chip
+                                              // (2^30 until round 6, when a stage cost five launches PER SAMPLE; 16 random-init samples then met the plain pass with
+                                              //  14 k wrong points each: 4 ms a round)
 constexpr int kMaxChamp = 1024;              // clusters that get a lower bound (phase B); further ones are not pruned
 constexpr int kChampSplit = 8;
 
@@ -94,20 +97,129 @@ __global__ void k_iou_counts(const int32_t* __restrict__ pred, const int64_t* __
 }
 
 // ---- click simulator --------------------------------------------------------------------------
+// Every kernel below serves ALL samples of a call (a3d_click_clusters_batch; round 6): blockIdx.z (or .y) = sample, its
+// pointers and sizes come from a device table (ClickDev), the grid is sized for the largest sample.  The click rounds of
+// training (4 samples) and of a lock-step evaluation (16) were ~12 launches PER SAMPLE on side streams -- 50-200 launches a
+// round whose issue time alone was most of the round's cluster search on a fitted model (a few hundred wrong points).
+struct ClickWs {
+  float4* cand;
+  int32_t* err_rows;
+  unsigned* d2bits;
+  unsigned long long* table;
+  int* n_err;
+  int* err;
+  // the bounded pass: table_ub / lbtab / counters sit right behind `table` (one clear covers them all)
+  unsigned long long* table_ub;
+  unsigned* lbtab;
+  int *n_surv, *n_champ, *max_cid;
+  int2* champ;
+  float4* samp;
+  int32_t* surv_rows;
+  unsigned* d2s;
+  // the coarse bounding stage in front of the fine one (its survivors: surv_c_rows / d2s_c; the fine stage's: surv_rows / d2s)
+  unsigned long long* table_ub_c;
+  unsigned* lbtab_c;
+  int *n_surv_c, *n_champ_c;
+  int2* champ_c;
+  float4* samp_coarse;
+  int32_t* surv_c_rows;
+  unsigned* d2s_c;
+  float4* sorted;      // cand in the sample's spatial order (k_sorted_cand)
+  void* dev_table;     // the call's ClickDev table (first sample's workspace)
+  size_t zero_bytes;   // bytes from `table` on that start out as zeros
+  size_t bytes;
+};
+struct ClickDev {      // one sample of a call as the kernels see it
+  const float* xyz;
+  const int32_t *pred, *labels;
+  int64_t n;
+  a3d_click_cluster* out;
+  int32_t* n_out;
+  int max_out;
+  int bounded, two_stage;   // which passes this sample runs (by its size)
+  const int32_t *order, *inv;   // a spatial order of the sample's points (a3d_click_spatial_order) and its inverse, or nullptr
+  ClickWs w;
+};
+constexpr int kMaxClickBatch = 64;
+constexpr int kWindow = 64;                  // rows on either side of a row in the spatial order that its first upper bound looks at
+enum { ST_PLAIN = 0, ST_COARSE = 1, ST_FINE = 2, ST_FINAL = 3 };
+// what a pass reads and writes: PLAIN / FINAL = exact distances against all points into the cluster table; COARSE / FINE = a
+// bounding stage (upper bounds against a sample of the points, champions, survivors)
+struct StageView {
+  bool on;
+  const float4* cands;
+  int64_t n_cands;
+  const int32_t* rows;
+  const int* n_rows;
+  unsigned* d2;
+  unsigned long long* table;
+  unsigned* lbtab;
+  int2* champ;
+  int* n_champ;
+  int32_t* rows_out;
+  unsigned* d2_out;
+  int* n_out;
+  long long skip;     // the stage does nothing (every row survives) when rows x skip < kSmallPairs: decided on the device
+};
+template <int stage>
+__device__ __forceinline__ StageView stage_view(const ClickDev& s) {
+  const ClickWs& w = s.w;
+  StageView v;
+  v.on = false;
+  v.lbtab = nullptr; v.champ = nullptr; v.n_champ = nullptr; v.rows_out = nullptr; v.d2_out = nullptr; v.n_out = nullptr;
+  v.skip = 0;
+  if constexpr (stage == ST_PLAIN) {
+    v.on = !s.bounded;
+    v.cands = w.cand; v.n_cands = s.n; v.rows = w.err_rows; v.n_rows = w.n_err; v.d2 = w.d2bits; v.table = w.table;
+  } else if constexpr (stage == ST_COARSE) {
+    v.on = s.two_stage != 0;
+    // (with a spatial order the stage's upper bounds come from k_nearest_window instead of the coarse sample; n_cands = the
+    // pairs a row costs there, for the skip rule)
+    v.cands = w.samp_coarse; v.n_cands = s.order ? 2 * kWindow : (s.n + kSampleCoarse - 1) / kSampleCoarse;
+    v.rows = w.err_rows; v.n_rows = w.n_err; v.d2 = w.d2bits; v.table = w.table_ub_c; v.lbtab = w.lbtab_c;
+    v.champ = w.champ_c; v.n_champ = w.n_champ_c; v.rows_out = w.surv_c_rows; v.d2_out = w.d2s_c; v.n_out = w.n_surv_c;
+    v.skip = s.order ? 0 : (long long)(s.n / 2);
+  } else if constexpr (stage == ST_FINE) {
+    v.on = s.bounded != 0;
+    v.cands = w.samp; v.n_cands = (s.n + kSample - 1) / kSample;
+    v.rows = s.two_stage ? w.surv_c_rows : w.err_rows; v.n_rows = s.two_stage ? w.n_surv_c : w.n_err;
+    v.d2 = s.two_stage ? w.d2s_c : w.d2bits; v.table = w.table_ub; v.lbtab = w.lbtab;
+    v.champ = w.champ; v.n_champ = w.n_champ; v.rows_out = w.surv_rows; v.d2_out = w.d2s; v.n_out = w.n_surv;
+    // behind a coarse stage the rows are few and the launches are issued anyway: the fine stage runs from a quarter of the
+    // pair count (what it saves is the final pass over ALL points for most of its rows)
+    v.skip = s.two_stage ? 4ll * s.n : (long long)s.n;
+  } else {
+    v.on = s.bounded != 0;
+    v.cands = w.cand; v.n_cands = s.n; v.rows = w.surv_rows; v.n_rows = w.n_surv; v.d2 = w.d2s; v.table = w.table;
+  }
+  return v;
+}
+// tables + counters of every sample back to zero (one launch instead of a memset per sample)
+__global__ void k_click_clear(const ClickDev* __restrict__ tab) {
+  const ClickDev& s = tab[blockIdx.y];
+  uint4* p = (uint4*)s.w.table;
+  const size_t n16 = s.w.zero_bytes / 16;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (size_t)gridDim.x * blockDim.x)
+    p[i] = make_uint4(0u, 0u, 0u, 0u);
+}
 // cand[i] = (x, y, z, cluster id bits) for EVERY point (cluster -1 = correctly labelled);
 // err_rows = rows of wrongly labelled points in arbitrary order (the result does not depend on it).
-__global__ void k_err_compact(const float* __restrict__ xyz, const int32_t* __restrict__ pred,
-                              const int32_t* __restrict__ labels, int64_t n, float4* __restrict__ cand,
-                              int32_t* __restrict__ err_rows, unsigned* __restrict__ d2bits,
-                              int* __restrict__ n_err, int* __restrict__ err, float4* __restrict__ samp, int stride,
-                              float4* __restrict__ samp_coarse, int stride_coarse, int* __restrict__ max_cid) {
+__global__ void k_err_compact(const ClickDev* __restrict__ tab) {
+  const ClickDev& s = tab[blockIdx.y];
+  const float* __restrict__ xyz = s.xyz;
+  const int64_t n = s.n;
+  float4* __restrict__ cand = s.w.cand;
+  float4* samp = s.bounded ? s.w.samp : nullptr;
+  float4* samp_coarse = s.two_stage ? s.w.samp_coarse : nullptr;
+  const int stride = kSample, stride_coarse = kSampleCoarse;
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if ((int64_t)blockIdx.x * blockDim.x >= n) return;   // a block beyond this sample (the grid serves the largest one)
   bool wrong = false;
   int my_cid = -1;
   if (i < n) {
-    const int p = pred[i], l = labels[i];
+    const int p = s.pred[i], l = s.labels[i];
     const bool bad = p < 0 || p > 255 || l < 0 || l > 255;   // reported through err (the call fails); never used as a table index
-    if (bad) atomicOr(err, 2);
+    if (bad) atomicOr(s.w.err, 2);
     wrong = p != l && !bad;
     const int cid = wrong ? 96 * l + 11 * p : -1;
     my_cid = cid;
@@ -132,10 +244,10 @@ __global__ void k_err_compact(const float* __restrict__ xyz, const int32_t* __re
     const int tot = wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
     int b = 0;
     if (tot) {
-      b = atomicAdd(n_err, tot);
+      b = atomicAdd(s.w.n_err, tot);
       // the largest cluster id of the sample: k_cluster_list scans the table up to it (a handful of objects -> ids of a
       // few hundred, not 32 k)
-      atomicMax(max_cid, max(max(wmax[0], wmax[1]), max(wmax[2], wmax[3])));
+      atomicMax(s.w.max_cid, max(max(wmax[0], wmax[1]), max(wmax[2], wmax[3])));
     }
     wbase[0] = b;
     wbase[1] = b + wcnt[0];
@@ -145,35 +257,49 @@ __global__ void k_err_compact(const float* __restrict__ xyz, const int32_t* __re
   __syncthreads();
   if (wrong) {
     const int slot = wbase[wv] + __popcll(m & ((1ull << lane) - 1));
-    err_rows[slot] = (int)i;
-    d2bits[slot] = kInfBits;
+    s.w.err_rows[slot] = (int)i;
+    s.w.d2bits[slot] = kInfBits;
   }
 }
 
-// pts: all points (the queries' coordinates, by row); cand / n: the candidates of this pass (all points, or the sample)
-__global__ __launch_bounds__(kNearestBlock) void k_nearest_other(const float4* __restrict__ pts,
-                                                                 const float4* __restrict__ cand, int64_t n,
-                                                                 const int32_t* __restrict__ err_rows,
-                                                                 const int* __restrict__ n_err_p,
-                                                                 unsigned* __restrict__ d2bits, int chunk,
-                                                                 long long skip_below) {
-  const int n_err = *n_err_p;
-  const int q0 = blockIdx.x * (kNearestBlock * kQueriesPerThread);
-  if (q0 >= n_err) return;
+// candidates of a pass in chunks (grid.y): at least kMinChunk per workgroup row, a multiple of four
+__device__ __host__ inline int nearest_chunk(int64_t n_cands) {
+  int chunk = (int)((n_cands + kNearestSplit - 1) / kNearestSplit);
+  chunk = chunk < kMinChunk ? kMinChunk : chunk;
+  return (chunk + 3) & ~3;
+}
+// the queries' coordinates come from cand (all points, by row); the candidates of the pass: all points, or a sample of them
+template <int stage>
+__global__ __launch_bounds__(kNearestBlock) void k_nearest_other(const ClickDev* __restrict__ tab) {
+  const ClickDev& s = tab[blockIdx.z];
+  const StageView v = stage_view<stage>(s);
+  if (!v.on) return;
+  if (stage == ST_COARSE && s.order) return;   // this sample's first stage is k_nearest_window
+  const float4* __restrict__ pts = s.w.cand;
+  const float4* __restrict__ cand = v.cands;
+  const int64_t n = v.n_cands;
+  const int n_err = *v.n_rows;
   // phase A of the bounded pass on a sample with few wrong points: not worth its time -- the upper bounds stay +inf,
   // every point survives and phase C is the plain pass
-  if (skip_below && (long long)n_err * skip_below < kSmallPairs) return;   // skip_below = number of points (phase A only)
+  if (v.skip && (long long)n_err * v.skip < kSmallPairs) return;
+  const int chunk = nearest_chunk(n);
+  const int64_t j0l = (int64_t)blockIdx.y * chunk;
+  if (j0l >= n) return;
+  // the host does not know how many rows are wrong: the grid's x dimension is a few workgroups that WALK the query blocks
+  // (sized by the sample it was 157 x 128 workgroups per 80 k-point sample, nearly all of which found nothing to do --
+  // 320 k empty workgroups in a 16-sample launch)
+  for (int q0 = blockIdx.x * (kNearestBlock * kQueriesPerThread); q0 < n_err; q0 += gridDim.x * (kNearestBlock * kQueriesPerThread)) {
   float qx[kQueriesPerThread], qy[kQueriesPerThread], qz[kQueriesPerThread], best[kQueriesPerThread];
   int qc[kQueriesPerThread];
 #pragma unroll
   for (int u = 0; u < kQueriesPerThread; ++u) {
     const int e = q0 + u * kNearestBlock + threadIdx.x;
     float4 c = make_float4(0.f, 0.f, 0.f, __int_as_float(-2));
-    if (e < n_err) c = pts[err_rows[e]];
+    if (e < n_err) c = pts[v.rows[e]];
     qx[u] = c.x; qy[u] = c.y; qz[u] = c.z; qc[u] = __float_as_int(c.w);
     best[u] = __uint_as_float(kInfBits);
   }
-  const int j0 = blockIdx.y * chunk;
+  const int j0 = (int)j0l;
   const int j1 = (int)min((int64_t)j0 + chunk, n);
   auto visit = [&](const float4 c) {
     const int cc = __float_as_int(c.w);
@@ -193,22 +319,66 @@ __global__ __launch_bounds__(kNearestBlock) void k_nearest_other(const float4* _
 #pragma unroll
   for (int u = 0; u < kQueriesPerThread; ++u) {
     const int e = q0 + u * kNearestBlock + threadIdx.x;
-    if (e < n_err) atomicMin(&d2bits[e], __float_as_uint(best[u]));   // d2 >= 0: bit order == value order
+    if (e < n_err) atomicMin(&v.d2[e], __float_as_uint(best[u]));   // d2 >= 0: bit order == value order
+  }
   }
 }
 
+// ---- upper bounds from a spatial order (round 6) ----------------------------------------------------------------------
+// With predictions that are wrong nearly everywhere (early training, random weights) every point has a point of another
+// cluster a voxel or two away, but an upper bound from every 16th / 256th point cannot show it (the sample's spacing is
+// four voxels and more): nearly every wrong point survived the bounding stages and met ALL points in the final pass -- 1.4 ms
+// per training click round, the largest kernel of the iteration.  A point's neighbours in a Morton order of the sample's
+// coordinates (computed once per scene, a3d_click_spatial_order) are mostly its neighbours in space: the nearest point of
+// another cluster among the 2 x kWindow rows around it is a far tighter bound for ~128 pairs per row.  Any permutation
+// gives VALID bounds (a minimum over a subset of the outside points, the same pair expression): a stale or poor order
+// costs time, never exactness.
+__global__ void k_sorted_cand(const ClickDev* __restrict__ tab) {
+  const ClickDev& s = tab[blockIdx.y];
+  if (!s.order || !s.two_stage) return;
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < s.n) s.w.sorted[i] = s.w.cand[s.order[i]];
+}
+__global__ void __launch_bounds__(256) k_nearest_window(const ClickDev* __restrict__ tab) {
+  const ClickDev& s = tab[blockIdx.y];
+  if (!s.order || !s.two_stage) return;
+  const StageView v = stage_view<ST_COARSE>(s);
+  const int n_err = *v.n_rows;
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if ((int)(blockIdx.x * blockDim.x) >= n_err) return;
+  if (e >= n_err) return;
+  const float4* __restrict__ sorted = s.w.sorted;
+  const int row = v.rows[e];
+  const float4 q = s.w.cand[row];
+  const int qc = __float_as_int(q.w);
+  const int pos = s.inv[row];
+  const int j0 = max(0, pos - kWindow), j1 = min((int)s.n, pos + kWindow + 1);
+  float best = __uint_as_float(kInfBits);
+  for (int j = j0; j < j1; ++j) {
+    const float4 c = sorted[j];
+    const float dx = q.x - c.x, dy = q.y - c.y, dz = q.z - c.z;
+    const float d2 = fmaf(dz, dz, fmaf(dy, dy, dx * dx));   // the expression of k_nearest_other: bit-identical pair values
+    best = fminf(best, __float_as_int(c.w) != qc ? d2 : __uint_as_float(kInfBits));
+  }
+  v.d2[e] = __float_as_uint(best);
+}
+
 // largest "distance to the nearest outside point" per cluster; ties -> lowest row (torch.where(...)[0][0])
-__global__ void k_cluster_best(const float4* __restrict__ cand, const int32_t* __restrict__ err_rows,
-                               const int* __restrict__ n_err_p, const unsigned* __restrict__ d2bits,
-                               unsigned long long* __restrict__ table, long long skip_below) {
-  if (skip_below && (long long)*n_err_p * skip_below < kSmallPairs) return;   // phase B of a sample with few wrong points
+template <int stage>
+__global__ void k_cluster_best(const ClickDev* __restrict__ tab) {
+  const ClickDev& s = tab[blockIdx.y];
+  const StageView v = stage_view<stage>(s);
+  if (!v.on) return;
+  const int n_err = *v.n_rows;
+  if ((int)(blockIdx.x * blockDim.x) >= n_err) return;
+  if (v.skip && (long long)n_err * v.skip < kSmallPairs) return;   // phase B of a sample with few wrong points
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   int cid = -1;
   unsigned long long key = 0;
-  if (e < *n_err_p) {
-    const int row = err_rows[e];
-    cid = __float_as_int(cand[row].w);
-    key = ((unsigned long long)d2bits[e] << 32) | (0xffffffffu - (unsigned)row);
+  if (e < n_err) {
+    const int row = v.rows[e];
+    cid = __float_as_int(s.w.cand[row].w);
+    key = ((unsigned long long)v.d2[e] << 32) | (0xffffffffu - (unsigned)row);
   }
   // one atomic per (wave, cluster) instead of one per point: a sample has a handful of clusters, so tens of thousands of
   // atomics queued on a few addresses (154 us at 90 k wrong points); the lanes of a wave mostly share one or two clusters
@@ -223,7 +393,7 @@ __global__ void k_cluster_best(const float4* __restrict__ cand, const int32_t* _
       k = other > k ? other : k;
     }
     const unsigned long long members = __ballot(mine);
-    if ((threadIdx.x & 63) == __builtin_ctzll(members)) atomicMax(&table[lead], k);
+    if ((threadIdx.x & 63) == __builtin_ctzll(members)) atomicMax(&v.table[lead], k);
     todo &= ~members;
   }
 }
@@ -231,23 +401,31 @@ __global__ void k_cluster_best(const float4* __restrict__ cand, const int32_t* _
 // ---- the bounded pass (see the head of the file) ---------------------------------------------------------
 // phase B, step 1: the clusters' champions (largest upper bound, from k_cluster_best on the upper bounds) as a list;
 // lbtab[cluster] starts at +inf for a listed cluster, stays 0 (= nothing is pruned) for one that did not fit
-__global__ void k_champ_list(const unsigned long long* __restrict__ table_ub, int2* __restrict__ champ,
-                             int* __restrict__ n_champ, unsigned* __restrict__ lbtab) {
+template <int stage>
+__global__ void k_champ_list(const ClickDev* __restrict__ tab) {
+  const ClickDev& s = tab[blockIdx.y];
+  const StageView v = stage_view<stage>(s);
+  if (!v.on) return;
   const int cid = blockIdx.x * blockDim.x + threadIdx.x;
-  if (cid >= kClusterTable) return;
-  const unsigned long long e = table_ub[cid];
+  if (cid >= kClusterTable || cid > *s.w.max_cid) return;
+  const unsigned long long e = v.table[cid];
   if (!e) return;
-  const int slot = atomicAdd(n_champ, 1);
+  const int slot = atomicAdd(v.n_champ, 1);
   if (slot >= kMaxChamp) return;
-  champ[slot] = make_int2(cid, (int)(0xffffffffu - (unsigned)(e & 0xffffffffu)));
-  lbtab[cid] = kInfBits;
+  v.champ[slot] = make_int2(cid, (int)(0xffffffffu - (unsigned)(e & 0xffffffffu)));
+  v.lbtab[cid] = kInfBits;
 }
 // phase B, step 2: exact distance of every champion = lower bound of its cluster's maximum; block = (champion, candidate range)
-__global__ void __launch_bounds__(256) k_champ_exact(const float4* __restrict__ cand, int64_t n, const int2* __restrict__ champ,
-                                                     const int* __restrict__ n_champ, unsigned* __restrict__ lbtab) {
-  const int nc = min(*n_champ, kMaxChamp);
+template <int stage>
+__global__ void __launch_bounds__(256) k_champ_exact(const ClickDev* __restrict__ tab) {
+  const ClickDev& s = tab[blockIdx.z];
+  const StageView v = stage_view<stage>(s);
+  if (!v.on) return;
+  const float4* __restrict__ cand = s.w.cand;
+  const int64_t n = s.n;
+  const int nc = min(*v.n_champ, kMaxChamp);
   for (int c = blockIdx.x; c < nc; c += gridDim.x) {
-  const int2 ch = champ[c];
+  const int2 ch = v.champ[c];
   const float4 q = cand[ch.y];
   const int qc = __float_as_int(q.w);
   const int64_t per = (n + kChampSplit - 1) / kChampSplit;
@@ -261,39 +439,43 @@ __global__ void __launch_bounds__(256) k_champ_exact(const float4* __restrict__ 
   }
 #pragma unroll
   for (int o = 32; o >= 1; o >>= 1) best = fminf(best, __shfl_xor(best, o));
-  if ((threadIdx.x & 63) == 0) atomicMin(&lbtab[ch.x], __float_as_uint(best));
+  if ((threadIdx.x & 63) == 0) atomicMin(&v.lbtab[ch.x], __float_as_uint(best));
   }
 }
 // phase C, step 1: the points that can still be their cluster's arg-max
-__global__ void k_survivors(const float4* __restrict__ cand, const int32_t* __restrict__ err_rows,
-                            const int* __restrict__ n_err_p, const unsigned* __restrict__ ub2bits,
-                            const unsigned* __restrict__ lbtab, int32_t* __restrict__ surv_rows,
-                            unsigned* __restrict__ d2s, int* __restrict__ n_surv) {
+template <int stage>
+__global__ void k_survivors(const ClickDev* __restrict__ tab) {
+  const ClickDev& s = tab[blockIdx.y];
+  const StageView v = stage_view<stage>(s);
+  if (!v.on) return;
+  const int n_err = *v.n_rows;
+  if ((int)(blockIdx.x * blockDim.x) >= n_err) return;
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   bool keep = false;
   int row = 0;
-  if (e < *n_err_p) {
-    row = err_rows[e];
-    keep = ub2bits[e] >= lbtab[__float_as_int(cand[row].w)];   // d2 >= 0: bit order == value order
+  if (e < n_err) {
+    row = v.rows[e];
+    keep = v.d2[e] >= v.lbtab[__float_as_int(s.w.cand[row].w)];   // d2 >= 0: bit order == value order
   }
   const unsigned long long m = __ballot(keep);
   const int lane = threadIdx.x & 63;
   int base = 0;
-  if (lane == 0 && m) base = atomicAdd(n_surv, __popcll(m));
+  if (lane == 0 && m) base = atomicAdd(v.n_out, __popcll(m));
   base = __shfl(base, 0);
   if (keep) {
     const int slot = base + __popcll(m & ((1ull << lane) - 1));
-    surv_rows[slot] = row;
-    d2s[slot] = kInfBits;
+    v.rows_out[slot] = row;
+    v.d2_out[slot] = kInfBits;
   }
 }
 
 // ordered compaction of the table (ascending cluster id, like torch.unique)
-__global__ void k_cluster_list(const unsigned long long* __restrict__ table, const int32_t* __restrict__ pred,
-                               const int32_t* __restrict__ labels, a3d_click_cluster* __restrict__ out,
-                               int max_out, int32_t* __restrict__ n_out, const int* __restrict__ err,
-                               const int* __restrict__ max_cid) {
-  const int PER = min(kClusterTable / 1024, *max_cid / 1024 + 1);   // ids per thread: up to the largest one present
+__global__ void k_cluster_list(const ClickDev* __restrict__ tab) {
+  const ClickDev& s = tab[blockIdx.y];
+  const unsigned long long* __restrict__ table = s.w.table;
+  a3d_click_cluster* __restrict__ out = s.out;
+  const int max_out = s.max_out;
+  const int PER = min(kClusterTable / 1024, *s.w.max_cid / 1024 + 1);   // ids per thread: up to the largest one present
   __shared__ int sums[1024];
   const int t = threadIdx.x;
   int cnt = 0;
@@ -307,8 +489,8 @@ __global__ void k_cluster_list(const unsigned long long* __restrict__ table, con
     __syncthreads();
   }
   int pos = sums[t] - cnt;
-  if (*err) {
-    if (t == 1023) *n_out = -1;   // a label or prediction outside 0..255
+  if (*s.w.err) {
+    if (t == 1023) *s.n_out = -1;   // a label or prediction outside 0..255
     return;
   }
   for (int k = 0; k < PER; ++k) {
@@ -319,14 +501,14 @@ __global__ void k_cluster_list(const unsigned long long* __restrict__ table, con
       a3d_click_cluster c;
       c.cluster_id = t * PER + k;
       c.row = row;
-      c.label = labels[row];
-      c.pred = pred[row];
+      c.label = s.labels[row];
+      c.pred = s.pred[row];
       c.error_size = sqrtf(__uint_as_float((unsigned)(e >> 32)));
       out[pos] = c;
     }
     ++pos;
   }
-  if (t == 1023) *n_out = sums[1023];
+  if (t == 1023) *s.n_out = sums[1023];
 }
 
 // ---- loss weights: alpha + (beta-alpha) * (1 - min(d, tita)/tita), d = distance to the nearest click ----
@@ -354,32 +536,6 @@ __global__ void k_click_weights(const float* __restrict__ xyz, int64_t n, ClickR
   w[i] = alpha + (beta - alpha) * (1.f - d / tita);
 }
 
-struct ClickWs {
-  float4* cand;
-  int32_t* err_rows;
-  unsigned* d2bits;
-  unsigned long long* table;
-  int* n_err;
-  int* err;
-  // the bounded pass: table_ub / lbtab / counters sit right behind `table` (one memset clears them all)
-  unsigned long long* table_ub;
-  unsigned* lbtab;
-  int *n_surv, *n_champ, *max_cid;
-  int2* champ;
-  float4* samp;
-  int32_t* surv_rows;
-  unsigned* d2s;
-  // the coarse bounding stage in front of the fine one (its survivors: surv_c_rows / d2s_c; the fine stage's: surv_rows / d2s)
-  unsigned long long* table_ub_c;
-  unsigned* lbtab_c;
-  int *n_surv_c, *n_champ_c;
-  int2* champ_c;
-  float4* samp_coarse;
-  int32_t* surv_c_rows;
-  unsigned* d2s_c;
-  size_t zero_bytes;   // bytes from `table` on that start out as zeros
-  size_t bytes;
-};
 static ClickWs carve_click(void* base, int64_t n) {
   ClickWs w;
   size_t off = 0;
@@ -412,6 +568,8 @@ static ClickWs carve_click(void* base, int64_t n) {
   w.samp_coarse = (float4*)take((size_t)(n / kSampleCoarse + 8) * 16);
   w.surv_c_rows = (int32_t*)take((size_t)n * 4);
   w.d2s_c = (unsigned*)take((size_t)n * 4);
+  w.sorted = (float4*)take((size_t)n * 16);
+  w.dev_table = take((size_t)kMaxClickBatch * sizeof(ClickDev));
   w.bytes = off;
   return w;
 }
@@ -471,87 +629,270 @@ extern "C" size_t a3d_click_workspace_bytes(int64_t n) {
   return carve_click(nullptr, n).bytes;
 }
 
-extern "C" int a3d_click_clusters(const float* xyz_dev, const int32_t* pred_dev, const int32_t* labels_dev,
-                                  int64_t n, a3d_click_cluster* out_dev, int max_out, int32_t* n_out_dev,
-                                  void* workspace_dev, size_t workspace_bytes, void* stream) {
+extern "C" int a3d_click_clusters_batch(const a3d_click_sample* samples, int n_samples, void* stream) {
   hipStream_t st = (hipStream_t)stream;
-  if (n <= 0 || !xyz_dev || !pred_dev || !labels_dev || !out_dev || !n_out_dev || max_out < 1) {
-    set_error("a3d_click_clusters: bad arguments");
+  if (!samples || n_samples < 1 || n_samples > kMaxClickBatch) {
+    set_error("a3d_click_clusters_batch: 1..%d samples per call", kMaxClickBatch);
     return A3D_ERR_INVALID;
   }
-  ClickWs w = carve_click(workspace_dev, n);
-  if (!workspace_dev || workspace_bytes < w.bytes) {
-    set_error("a3d_click_clusters: workspace %zu < %zu", workspace_bytes, w.bytes);
-    return A3D_ERR_WORKSPACE;
-  }
-  ProfScope prof(st, A3D_PROF_CLICKS);
   static int prune = -1;   // A3D_CLICK_PRUNE=0: the plain pass over all points (A/B)
   if (prune < 0) {
     const char* e = getenv("A3D_CLICK_PRUNE");
     prune = e ? atoi(e) : 1;
   }
-  const int stride = kSample;   // strides 8 / 16 / 32 / 64 measured in round 3: 16 is the best or second best everywhere
-  const bool bounded = prune && n >= 64 * stride;
-  const bool two_stage = bounded && prune != 3 && n >= kCoarseFrom;   // A3D_CLICK_PRUNE=3: the one-stage search of round 3 (A/B)
-  A3D_HIP_CHECK(hipMemsetAsync(w.table, 0, w.zero_bytes, st));   // tables + counters
-  const unsigned nb = (unsigned)((n + 255) / 256);
-  k_err_compact<<<nb, 256, 0, st>>>(xyz_dev, pred_dev, labels_dev, n, w.cand, w.err_rows, w.d2bits, w.n_err, w.err,
-                                    bounded ? w.samp : nullptr, stride, two_stage ? w.samp_coarse : nullptr, kSampleCoarse,
-                                    w.max_cid);
+  {
+    static bool walkers_read = false;
+    if (!walkers_read) {
+      walkers_read = true;
+      const char* e = getenv("A3D_CLICK_WALKERS");
+      if (e && atoi(e) > 0) kNearestWalkers = (unsigned)atoi(e);
+    }
+  }
+  static int coarse_from = -1;   // the coarse bounding stage in front of the fine one from this many points on
+  if (coarse_from < 0) {
+    const char* e = getenv("A3D_CLICK_COARSE_FROM");
+    coarse_from = e ? atoi(e) : kCoarseFrom;
+  }
+  ClickDev host[kMaxClickBatch];
+  int64_t n_max = 0;
+  bool any_plain = false, any_bounded = false, any_two = false, any_order = false, any_sampled = false;
+  static int use_order = -1;   // A3D_CLICK_ORDER=0: ignore the samples' spatial orders (A/B, tests)
+  if (use_order < 0) {
+    const char* e = getenv("A3D_CLICK_ORDER");
+    use_order = e ? atoi(e) : 1;
+  }
+  for (int i = 0; i < n_samples; ++i) {
+    const a3d_click_sample& sp = samples[i];
+    if (sp.n <= 0 || !sp.xyz_dev || !sp.pred_dev || !sp.labels_dev || !sp.out_dev || !sp.n_out_dev || sp.max_out < 1) {
+      set_error("a3d_click_clusters: bad arguments (sample %d)", i);
+      return A3D_ERR_INVALID;
+    }
+    ClickDev& d = host[i];
+    d.w = carve_click(sp.workspace_dev, sp.n);
+    if (!sp.workspace_dev || sp.workspace_bytes < d.w.bytes || ((uintptr_t)sp.workspace_dev & 15)) {
+      set_error("a3d_click_clusters: workspace %zu < %zu (sample %d)", sp.workspace_bytes, d.w.bytes, i);
+      return A3D_ERR_WORKSPACE;
+    }
+    d.xyz = sp.xyz_dev;
+    d.pred = sp.pred_dev;
+    d.labels = sp.labels_dev;
+    d.n = sp.n;
+    d.out = sp.out_dev;
+    d.n_out = sp.n_out_dev;
+    d.max_out = sp.max_out;
+    // strides 8 / 16 / 32 / 64 measured in round 3: 16 is the best or second best everywhere
+    d.bounded = prune && sp.n >= 64 * kSample;
+    d.two_stage = d.bounded && prune != 3 && sp.n >= coarse_from;   // A3D_CLICK_PRUNE=3: the one-stage search of round 3 (A/B)
+    d.order = use_order ? sp.order_dev : nullptr;
+    d.inv = use_order ? sp.inv_dev : nullptr;
+    if ((d.order == nullptr) != (d.inv == nullptr)) {
+      set_error("a3d_click_clusters: order_dev and inv_dev come together (sample %d)", i);
+      return A3D_ERR_INVALID;
+    }
+    any_order = any_order || (d.order && d.two_stage);
+    any_sampled = any_sampled || (!d.order && d.two_stage);
+    any_plain = any_plain || !d.bounded;
+    any_bounded = any_bounded || d.bounded;
+    any_two = any_two || d.two_stage;
+    n_max = sp.n > n_max ? sp.n : n_max;
+  }
+  ProfScope prof(st, A3D_PROF_CLICKS);
+  const ClickDev* tab = (const ClickDev*)host[0].w.dev_table;
+  // pageable source: the runtime stages it before returning
+  A3D_HIP_CHECK(hipMemcpyAsync((void*)tab, host, sizeof(ClickDev) * n_samples, hipMemcpyHostToDevice, st));
+  const unsigned ns = (unsigned)n_samples;
+  const unsigned nb = (unsigned)((n_max + 255) / 256);
+  k_click_clear<<<dim3(64, ns), 256, 0, st>>>(tab);
+  k_err_compact<<<dim3(nb, ns), 256, 0, st>>>(tab);
   A3D_LAUNCH_CHECK();
   const int per_block = kNearestBlock * kQueriesPerThread;
-  auto nearest = [&](const float4* cands, int64_t n_cands, const int32_t* rows, const int* n_rows, unsigned* out,
-                     long long skip_below) {
-    int chunk = (int)((n_cands + kNearestSplit - 1) / kNearestSplit);
-    chunk = chunk < kMinChunk ? kMinChunk : chunk;
-    chunk = (chunk + 3) & ~3;
-    dim3 grid((unsigned)((n + per_block - 1) / per_block), (unsigned)((n_cands + chunk - 1) / chunk));
-    k_nearest_other<<<grid, kNearestBlock, 0, st>>>(w.cand, cands, n_cands, rows, n_rows, out, chunk, skip_below);
-  };
-  // one bounding stage: upper bounds of `rows` against a sample (A), one exact champion per cluster = lower bound of the
-  // cluster's maximum (B), the rows that can still be their cluster's arg-max -> rows_out (C, step 1).  `skip`: the stage does
-  // nothing (every row survives) when rows x skip < kSmallPairs -- decided on the device, the host never learns the count
-  auto bounding_stage = [&](const float4* sample, int64_t n_sample, const int32_t* rows, const int* n_rows, unsigned* ub,
-                            unsigned long long* table_ub, unsigned* lbtab, int2* champ, int* n_champ, int32_t* rows_out,
-                            unsigned* d2_out, int* n_out, long long skip) {
-    nearest(sample, n_sample, rows, n_rows, ub, skip);
-    k_cluster_best<<<nb, 256, 0, st>>>(w.cand, rows, n_rows, ub, table_ub, skip);
-    k_champ_list<<<kClusterTable / 256, 256, 0, st>>>(table_ub, champ, n_champ, lbtab);
-    k_champ_exact<<<dim3(128, kChampSplit), 256, 0, st>>>(w.cand, n, champ, n_champ, lbtab);
-    k_survivors<<<nb, 256, 0, st>>>(w.cand, rows, n_rows, ub, lbtab, rows_out, d2_out, n_out);
-  };
-  if (!bounded) {
-    nearest(w.cand, n, w.err_rows, w.n_err, w.d2bits, 0);
-    A3D_LAUNCH_CHECK();
-    k_cluster_best<<<nb, 256, 0, st>>>(w.cand, w.err_rows, w.n_err, w.d2bits, w.table, 0);
-    A3D_LAUNCH_CHECK();
-  } else {
-    const int64_t n_samp = (n + stride - 1) / stride;
-    const int32_t* rows = w.err_rows;
-    const int* n_rows = w.n_err;
-    unsigned* ub = w.d2bits;
-    if (two_stage) {
-      // worth its five launches only with many wrong points (the fine stage's phase A is rows x n / 16 pairs): 2x the
-      // threshold of the fine stage
-      bounding_stage(w.samp_coarse, (n + kSampleCoarse - 1) / kSampleCoarse, rows, n_rows, ub, w.table_ub_c, w.lbtab_c, w.champ_c,
-                     w.n_champ_c, w.surv_c_rows, w.d2s_c, w.n_surv_c, (long long)(n / 2));
-      A3D_LAUNCH_CHECK();
-      rows = w.surv_c_rows;
-      n_rows = w.n_surv_c;
-      ub = w.d2s_c;
+  auto nearest_grid = [&](int stage) {
+    unsigned gy = 1;   // candidate chunks: every sample cuts ITS candidates (nearest_chunk), the grid holds the most any needs
+    for (int i = 0; i < n_samples; ++i) {
+      const int64_t nc = stage == ST_COARSE ? (host[i].n + kSampleCoarse - 1) / kSampleCoarse
+                         : stage == ST_FINE ? (host[i].n + kSample - 1) / kSample : host[i].n;
+      const unsigned c = (unsigned)((nc + nearest_chunk(nc) - 1) / nearest_chunk(nc));
+      gy = c > gy ? c : gy;
     }
-    // behind a coarse stage the rows are few and the launches are issued anyway: the fine stage runs from a quarter of the
-    // pair count (what it saves is the final pass over ALL points for most of its rows)
-    bounding_stage(w.samp, n_samp, rows, n_rows, ub, w.table_ub, w.lbtab, w.champ, w.n_champ, w.surv_rows, w.d2s, w.n_surv,
-                   two_stage ? 4ll * n : (long long)n);
-    A3D_LAUNCH_CHECK();
-    nearest(w.cand, n, w.surv_rows, w.n_surv, w.d2s, 0);
-    k_cluster_best<<<nb, 256, 0, st>>>(w.cand, w.surv_rows, w.n_surv, w.d2s, w.table, 0);
+    const unsigned gx_all = (unsigned)((n_max + per_block - 1) / per_block);
+    return dim3(gx_all < kNearestWalkers ? gx_all : kNearestWalkers, gy, ns);
+  };
+  // (the pass is a template parameter of the kernels: what it reads and writes is fixed at compile time)
+  if (any_plain) {
+    k_nearest_other<ST_PLAIN><<<nearest_grid(ST_PLAIN), kNearestBlock, 0, st>>>(tab);
+    k_cluster_best<ST_PLAIN><<<dim3(nb, ns), 256, 0, st>>>(tab);
     A3D_LAUNCH_CHECK();
   }
-  k_cluster_list<<<1, 1024, 0, st>>>(w.table, pred_dev, labels_dev, out_dev, max_out, n_out_dev, w.err, w.max_cid);
+  if (any_bounded) {
+    // one bounding stage: upper bounds of the stage's rows against a sample of the points (A), one exact champion per
+    // cluster = lower bound of the cluster's maximum (B), the rows that can still be their cluster's arg-max (C, step 1).
+    // The coarse stage is worth its five launches only with many wrong points (the fine stage's phase A is rows x n / 16
+    // pairs): its threshold is 2x the fine stage's (stage_view)
+    if (any_two) {
+      if (any_order) {   // the first stage's upper bounds from the window around the row in the sample's spatial order
+        k_sorted_cand<<<dim3(nb, ns), 256, 0, st>>>(tab);
+        k_nearest_window<<<dim3(nb, ns), 256, 0, st>>>(tab);
+      }
+      if (any_sampled) k_nearest_other<ST_COARSE><<<nearest_grid(ST_COARSE), kNearestBlock, 0, st>>>(tab);
+      k_cluster_best<ST_COARSE><<<dim3(nb, ns), 256, 0, st>>>(tab);
+      k_champ_list<ST_COARSE><<<dim3(kClusterTable / 256, ns), 256, 0, st>>>(tab);
+      k_champ_exact<ST_COARSE><<<dim3(128, kChampSplit, ns), 256, 0, st>>>(tab);
+      k_survivors<ST_COARSE><<<dim3(nb, ns), 256, 0, st>>>(tab);
+    }
+    k_nearest_other<ST_FINE><<<nearest_grid(ST_FINE), kNearestBlock, 0, st>>>(tab);
+    k_cluster_best<ST_FINE><<<dim3(nb, ns), 256, 0, st>>>(tab);
+    k_champ_list<ST_FINE><<<dim3(kClusterTable / 256, ns), 256, 0, st>>>(tab);
+    k_champ_exact<ST_FINE><<<dim3(128, kChampSplit, ns), 256, 0, st>>>(tab);
+    k_survivors<ST_FINE><<<dim3(nb, ns), 256, 0, st>>>(tab);
+    A3D_LAUNCH_CHECK();
+    k_nearest_other<ST_FINAL><<<nearest_grid(ST_FINAL), kNearestBlock, 0, st>>>(tab);
+    k_cluster_best<ST_FINAL><<<dim3(nb, ns), 256, 0, st>>>(tab);
+    A3D_LAUNCH_CHECK();
+  }
+  k_cluster_list<<<dim3(1, ns), 1024, 0, st>>>(tab);
+  A3D_LAUNCH_CHECK();
+  static int dbg = -1;   // A3D_CLICK_DBG=1: the stages' row counts of every sample on stderr (synchronises: tuning only)
+  if (dbg < 0) {
+    const char* e = getenv("A3D_CLICK_DBG");
+    dbg = e ? atoi(e) : 0;
+  }
+  if (dbg) {
+    (void)hipStreamSynchronize(st);
+    for (int i = 0; i < n_samples; ++i) {
+      int c[8];
+      (void)hipMemcpy(c, host[i].w.n_err, sizeof(c), hipMemcpyDeviceToHost);
+      fprintf(stderr, "clicks: sample %d n %lld wrong %d -> first stage survivors %d (champions %d) -> fine stage survivors %d (champions %d)%s\n", i,
+              (long long)host[i].n, c[0], c[5], c[6], c[2], c[3], host[i].order ? " [spatial order]" : "");
+    }
+  }
+  return A3D_OK;
+}
+
+// ---- a spatial order of a sample's points: Morton keys of the coordinates on a 2^16 grid over the bounding box, sorted
+namespace a3d {
+__global__ void k_so_minmax(const float* __restrict__ xyz, int64_t n, unsigned* __restrict__ mm) {   // mm: [3] min, [3] max as ordered uints
+  float mn[3] = {3.4e38f, 3.4e38f, 3.4e38f}, mx[3] = {-3.4e38f, -3.4e38f, -3.4e38f};
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      const float v = xyz[3 * i + a];
+      mn[a] = fminf(mn[a], v);
+      mx[a] = fmaxf(mx[a], v);
+    }
+  auto enc = [](float f) { const unsigned u = __float_as_uint(f); return (u & 0x80000000u) ? ~u : (u | 0x80000000u); };   // order-preserving
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+      mn[a] = fminf(mn[a], __shfl_xor(mn[a], o));
+      mx[a] = fmaxf(mx[a], __shfl_xor(mx[a], o));
+    }
+    if ((threadIdx.x & 63) == 0) {
+      atomicMin(&mm[a], enc(mn[a]));
+      atomicMax(&mm[3 + a], enc(mx[a]));
+    }
+  }
+}
+__device__ __forceinline__ unsigned long long spread16(unsigned v) {   // bit i of v -> bit 3 i
+  unsigned long long x = v & 0xffffu;
+  x = (x | (x << 16)) & 0x0000ff0000ffull;
+  x = (x | (x << 8)) & 0x00f00f00f00full;
+  x = (x | (x << 4)) & 0x0c30c30c30c3ull;
+  x = (x | (x << 2)) & 0x249249249249ull;
+  return x;
+}
+__global__ void k_so_keys(const float* __restrict__ xyz, int64_t n, const unsigned* __restrict__ mm, uint64_t* __restrict__ keys,
+                          int* __restrict__ vals) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  auto dec = [](unsigned u) { return __uint_as_float((u & 0x80000000u) ? (u & 0x7fffffffu) : ~u); };
+  unsigned q[3];
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    const float lo = dec(mm[a]), hi = dec(mm[3 + a]);
+    const float t = hi > lo ? (xyz[3 * i + a] - lo) / (hi - lo) : 0.f;
+    q[a] = (unsigned)fminf(fmaxf(t * 65535.f, 0.f), 65535.f);
+  }
+  keys[i] = spread16(q[0]) | (spread16(q[1]) << 1) | (spread16(q[2]) << 2);
+  vals[i] = (int)i;
+}
+__global__ void k_so_inverse(const int32_t* __restrict__ order, int64_t n, int32_t* __restrict__ inv) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) inv[order[i]] = (int32_t)i;
+}
+struct SoWs {
+  unsigned* mm;
+  uint64_t *keys_in, *keys_out;
+  int* vals_in;
+  void* sort_temp;
+  size_t sort_bytes, bytes;
+};
+static SoWs carve_so(void* base, int64_t n) {
+  SoWs w;
+  size_t off = 0;
+  auto take = [&](size_t b) {
+    void* p = base ? (char*)base + off : nullptr;
+    off += align256(b);
+    return p;
+  };
+  w.mm = (unsigned*)take(256);
+  w.keys_in = (uint64_t*)take((size_t)n * 8);
+  w.keys_out = (uint64_t*)take((size_t)n * 8);
+  w.vals_in = (int*)take((size_t)n * 4);
+  w.sort_bytes = radix_sort_temp_bytes((int)n);
+  w.sort_temp = take(w.sort_bytes);
+  w.bytes = off;
+  return w;
+}
+}  // namespace a3d
+
+extern "C" size_t a3d_click_spatial_order_workspace_bytes(int64_t n) {
+  if (n <= 0 || n > (int64_t)1 << 28) return 0;
+  return carve_so(nullptr, n).bytes;
+}
+extern "C" int a3d_click_spatial_order(const float* xyz_dev, int64_t n, int32_t* order_dev, int32_t* inv_dev, void* workspace_dev,
+                                       size_t workspace_bytes, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  if (n <= 0 || n > (int64_t)1 << 28 || !xyz_dev || !order_dev || !inv_dev) {
+    set_error("a3d_click_spatial_order: bad arguments");
+    return A3D_ERR_INVALID;
+  }
+  SoWs w = carve_so(workspace_dev, n);
+  if (!workspace_dev || workspace_bytes < w.bytes || ((uintptr_t)workspace_dev & 255)) {
+    set_error("a3d_click_spatial_order: workspace %zu < %zu", workspace_bytes, w.bytes);
+    return A3D_ERR_WORKSPACE;
+  }
+  const unsigned init[6] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u};
+  A3D_HIP_CHECK(hipMemcpyAsync(w.mm, init, sizeof(init), hipMemcpyHostToDevice, st));
+  const unsigned nb = (unsigned)((n + 255) / 256);
+  k_so_minmax<<<nb < 512 ? nb : 512, 256, 0, st>>>(xyz_dev, n, w.mm);
+  k_so_keys<<<nb, 256, 0, st>>>(xyz_dev, n, w.mm, w.keys_in, w.vals_in);
+  A3D_LAUNCH_CHECK();
+  RadixPass ps[kRadixMaxPasses];
+  const int np = radix_passes(0, 48, ps);
+  int rc = radix_sort_pairs(w.sort_temp, w.sort_bytes, w.keys_in, w.keys_out, w.vals_in, order_dev, (int)n, ps, np, st, nullptr, false);
+  if (rc) return rc;
+  k_so_inverse<<<nb, 256, 0, st>>>(order_dev, n, inv_dev);
   A3D_LAUNCH_CHECK();
   return A3D_OK;
+}
+
+extern "C" int a3d_click_clusters(const float* xyz_dev, const int32_t* pred_dev, const int32_t* labels_dev,
+                                  int64_t n, a3d_click_cluster* out_dev, int max_out, int32_t* n_out_dev,
+                                  void* workspace_dev, size_t workspace_bytes, void* stream) {
+  a3d_click_sample sp;
+  sp.xyz_dev = xyz_dev;
+  sp.pred_dev = pred_dev;
+  sp.labels_dev = labels_dev;
+  sp.n = n;
+  sp.out_dev = out_dev;
+  sp.max_out = max_out;
+  sp.n_out_dev = n_out_dev;
+  sp.workspace_dev = workspace_dev;
+  sp.workspace_bytes = workspace_bytes;
+  sp.order_dev = nullptr;
+  sp.inv_dev = nullptr;
+  return a3d_click_clusters_batch(&sp, 1, stream);
 }
 
 extern "C" int a3d_click_loss_weights(const float* xyz_dev, int64_t n, const int32_t* click_row, int n_clicks,

@@ -77,6 +77,13 @@ class DecoderSample(C.Structure):
                 ("kv0_dev", C.c_void_p), ("kv0_state", C.c_int32), ("kv0_blocks", C.c_int32)]
 
 
+class ClickSample(C.Structure):
+    """a3d_click_sample: one sample of a3d_click_clusters_batch."""
+    _fields_ = [("xyz_dev", C.c_void_p), ("pred_dev", C.c_void_p), ("labels_dev", C.c_void_p), ("n", C.c_int64),
+                ("out_dev", C.c_void_p), ("n_out_dev", C.c_void_p), ("max_out", C.c_int32), ("workspace_dev", C.c_void_p),
+                ("workspace_bytes", C.c_size_t), ("order_dev", C.c_void_p), ("inv_dev", C.c_void_p)]
+
+
 class ClickCluster(C.Structure):
     _fields_ = [("cluster_id", C.c_int32), ("row", C.c_int32), ("label", C.c_int32), ("pred", C.c_int32),
                 ("error_size", C.c_float)]
@@ -218,6 +225,9 @@ SYMBOLS = {
     "a3d_click_workspace_bytes": (C.c_size_t, [C.c_int64]),
     "a3d_click_clusters": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int,
                                      C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "a3d_click_clusters_batch": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
+    "a3d_click_spatial_order_workspace_bytes": (C.c_size_t, [C.c_int64]),
+    "a3d_click_spatial_order": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "a3d_mask_losses": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_float, C.c_float,
                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "a3d_quantize_workspace_bytes": (C.c_size_t, [C.c_int64]),

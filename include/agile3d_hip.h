@@ -602,6 +602,32 @@ int    a3d_click_clusters(const float* xyz_dev, const int32_t* pred_dev, const i
                           int64_t n, a3d_click_cluster* out_dev, int max_out, int32_t* n_out_dev,
                           void* workspace_dev, size_t workspace_bytes, void* stream);
 
+/* The same for up to 64 samples in ONE set of launches (the samples of a training click round, engine.py:103-116, or of a
+ * lock-step evaluation round, eval_multi_obj.py:162-166): every kernel takes the samples from a device table, so a round
+ * issues ~15 launches whatever the batch size instead of ~12 per sample.  Results per sample are those of
+ * a3d_click_clusters; every sample brings its own workspace (a3d_click_workspace_bytes(n)). */
+typedef struct a3d_click_sample {
+  const float*   xyz_dev;          /* [n][3] */
+  const int32_t *pred_dev, *labels_dev;   /* [n] object ids 0..255 */
+  int64_t        n;
+  a3d_click_cluster* out_dev;      /* max_out records */
+  int32_t*       n_out_dev;
+  int32_t        max_out;
+  void*          workspace_dev;
+  size_t         workspace_bytes;
+  /* optional: a spatial order of the sample's points and its inverse (a3d_click_spatial_order; the coordinates of a scene do
+   * not change over its rounds).  With it the first bounding stage looks at a row's neighbours in that order instead of a
+   * sparse sample of all points: far tighter upper bounds where predictions are wrong nearly everywhere.  Any permutation of
+   * 0..n-1 is VALID (the bounds stay bounds, the search stays exact); both NULL = the sampled stage. */
+  const int32_t *order_dev, *inv_dev;
+} a3d_click_sample;
+int    a3d_click_clusters_batch(const a3d_click_sample* samples, int n_samples, void* stream);
+/* order_dev[s] = row of the s-th point in Morton order of the coordinates (2^16 cells per axis over the bounding box),
+ * inv_dev[row] = s.  No reference counterpart: an index the search above may use (utils/seg.py:157-171 has none). */
+size_t a3d_click_spatial_order_workspace_bytes(int64_t n);
+int    a3d_click_spatial_order(const float* xyz_dev, int64_t n, int32_t* order_dev, int32_t* inv_dev, void* workspace_dev,
+                               size_t workspace_bytes, void* stream);
+
 /* weights[i] = alpha + (beta-alpha) * (1 - min(d_i, tita)/tita), d_i = distance of point i to the
  * nearest clicked point; click_row is a HOST array. */
 int    a3d_click_loss_weights(const float* xyz_dev, int64_t n, const int32_t* click_row, int n_clicks,

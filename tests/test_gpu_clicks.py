@@ -265,6 +265,34 @@ def test_bounded_search_equals_plain_pass(tmp_path):
         pc.error_clusters(torch.full((n,), 3, device="cuda"), torch.full((n,), 2, device="cuda"), torch.rand(n, 3, device="cuda"))
 
 
+def test_batched_clusters_and_spatial_order(monkeypatch):
+    """a3d_click_clusters_batch: the samples of a round through ONE set of launches (device table of samples; sizes from
+    1 k to 70 k points side by side, so every stage is on for some samples and off for others) == the per-sample calls; and
+    the first bounding stage's spatial order (a3d_click_spatial_order: Morton order of the coordinates, cached per
+    coordinate tensor) is a permutation with its inverse -- ANY permutation in its place gives the same clusters (the
+    bounds stay bounds), as does none at all."""
+    cases = [c for c in _prune_cases() if len(c[2]) <= 70_001]
+    t = lambda a: torch.from_numpy(a).cuda()
+    preds, labs, xyzs = [t(c[0]) for c in cases], [t(c[1]) for c in cases], [t(c[2]) for c in cases]
+    single = [pc.error_clusters(p, l, x) for p, l, x in zip(preds, labs, xyzs)]
+    assert pc.error_clusters_batch(preds, labs, xyzs) == single
+    big = max(range(len(cases)), key=lambda i: len(cases[i][2]))
+    order, inv = pc._spatial_order(xyzs[big])
+    n = len(cases[big][2])
+    assert sorted(order.cpu().tolist()) == list(range(n)) and torch.equal(inv[order.long()].cpu(), torch.arange(n, dtype=torch.int32))
+    # neighbours in the order are neighbours in space: median distance of consecutive rows far below that of random pairs
+    x = xyzs[big][order.long()]
+    near = (x[1:] - x[:-1]).norm(dim=1).median().item()
+    rand = (xyzs[big][torch.randperm(n, device="cuda")] - xyzs[big]).norm(dim=1).median().item()
+    assert near < 0.2 * rand, (near, rand)
+    perm = torch.randperm(n, device="cuda").to(torch.int32)
+    pinv = torch.empty_like(perm)
+    pinv[perm.long()] = torch.arange(n, dtype=torch.int32, device="cuda")
+    for fake in ((perm, pinv), None):
+        monkeypatch.setattr(pc, "_spatial_order", lambda xyz, fake=fake: fake if xyz.shape[0] == n else None)
+        assert pc.error_clusters_batch(preds, labs, xyzs) == single
+
+
 def test_one_sync_round_equals_the_two_calls():
     """mean_iou_and_clusters_batch (IoU counts on the caller's stream, error clusters on side streams, one host
     synchronisation) returns what mean_iou_scene_batch and error_clusters_batch return, inverse maps included."""

@@ -1,0 +1,105 @@
+#!/usr/bin/env python3
+"""The lock-step evaluation round (eval_multi_obj.py:112-166 with a batch of scenes) on a FITTED state dict next to the
+random-init one, at 20 / 60 / 100 queries: where the reference's protocol lives (a trained model leaves a few coherent
+error regions; random-init predictions are wrong almost everywhere and the click search walks salt-and-pepper clusters).
+Fits ER_BATCH (16) labelled 80 k-voxel synthetic scenes with the repository's own training path (agile3d_amd.fit; nothing is
+stored), then runs ER_ROUNDS (90) rounds of forward_mask -> label argmax -> IoU + error clusters -> click pick for the whole
+batch and prints, per query count, the round as it runs (host wall clock, one device sync per round) and its parts
+(device-synchronised run), the share of the cluster search, scene-rounds per second, the mean IoU and the wrong-point share.
+    python tools/eval_rounds_fitted.py [fit_iters=160]"""
+import json, os, random, sys, time
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from agile3d_amd import SparseTensor, build_model, default_args, randomize_bn_stats
+from agile3d_amd import clicks as pc
+from agile3d_amd.fit import fit, labelled_scenes
+
+B = int(os.environ.get("ER_BATCH", "16"))
+R = int(os.environ.get("ER_ROUNDS", "90"))
+VOX = int(os.environ.get("ER_VOXELS", "80000"))
+K = 5
+fit_iters = int(sys.argv[1]) if len(sys.argv) > 1 else 160
+dev = torch.device("cuda:0")
+items = labelled_scenes(B, VOX, K)
+scenes = [it["scene"] for it in items]
+coords = []
+for b, s_ in enumerate(scenes):
+    c = s_["coords"].copy(); c[:, 0] = b; coords.append(c)
+coords = torch.from_numpy(np.concatenate(coords)).to(dev)
+feats = torch.cat([torch.from_numpy(s["feats"]) for s in scenes]).to(dev)
+raw = torch.cat([torch.from_numpy(s["raw_xyz"]) for s in scenes]).to(dev)
+labs = [torch.from_numpy(it["labels"]).to(dev).to(torch.int32) for it in items]
+raws = [torch.from_numpy(s_["raw_xyz"]).to(dev) for s_ in scenes]
+WINDOWS = {20: range(4, 9), 60: range(44, 49), 100: range(84, 89)}      # round r holds 14 + r queries (5 objects)
+
+
+def protocol(model, sync_parts):
+    rB = model.forward_backbone(SparseTensor(features=feats, coordinates=coords), raw_coordinates=raw)
+    ecis = [{str(k_): [] for k_ in range(K + 1)} for _ in scenes]
+    ects = [{str(k_): [] for k_ in range(K + 1)} for _ in scenes]
+    preds = [torch.zeros(len(s_["coords"]), dtype=torch.int32, device=dev) for s_ in scenes]
+    random.seed(0)
+    rows = []
+    for rnd in range(R):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter(); t = t0; parts = {}
+        def lap(name):
+            nonlocal t
+            if sync_parts:
+                torch.cuda.synchronize()
+            now = time.perf_counter(); parts[name] = 1e3 * (now - t); t = now
+        if rnd:
+            outs = model.forward_mask(*rB, click_idx=ecis, click_time_idx=ects)["pred_masks"]
+        lap("forward_mask")
+        if rnd:
+            preds = [pc.argmax_labels(outs[b_], ecis[b_]) for b_ in range(B)]
+        lap("argmax")
+        ious, cls_ = pc.mean_iou_and_clusters_batch(preds, labs, None, labs, raws)
+        lap("iou+clusters")
+        for b_, (new, _, _, nt) in enumerate(pc.pick_clicks_batch(cls_, labs, raws, rnd, training=False)):
+            if new is not None:
+                pc.extend_clicks(ecis[b_], ects[b_], new, nt)
+        lap("pick+extend")
+        torch.cuda.synchronize()
+        parts["round"] = 1e3 * (time.perf_counter() - t0)
+        parts["iou"] = float(np.mean([float(i[0] if isinstance(i, (tuple, list)) else i) for i in ious]))
+        parts["wrong"] = float(np.mean([float((p != l).float().mean()) for p, l in zip(preds, labs)]))
+        parts["queries"] = 10 + sum(len(v) for v in ecis[0].values())
+        rows.append(parts)
+    return rows
+
+
+def table(tag, model):
+    synced, free = protocol(model, True), protocol(model, False)
+    out = {}
+    for q, win in WINDOWS.items():
+        if max(win) >= R:
+            continue
+        med = lambda rows, k: float(np.median([rows[r][k] for r in win]))
+        rec = {"round_ms": round(med(free, "round"), 3), "scene_rounds_per_s": round(B / med(free, "round") * 1e3, 1),
+               "parts_ms_device_synchronised": {k: round(med(synced, k), 3) for k in ("forward_mask", "argmax", "iou+clusters", "pick+extend")},
+               "cluster_search_share": round(med(synced, "iou+clusters") / max(1e-9, med(synced, "round")), 3),
+               "mean_iou": round(med(free, "iou"), 4), "wrong_point_share": round(med(free, "wrong"), 4)}
+        out[str(q)] = rec
+        print(f"{tag:12s} {q:4d} queries: round {rec['round_ms']:7.3f} ms = {rec['scene_rounds_per_s']:7.1f} scene-rounds/s | parts "
+              + "  ".join(f"{k} {v:.3f}" for k, v in rec["parts_ms_device_synchronised"].items())
+              + f" | cluster search {100 * rec['cluster_search_share']:.0f} % of the round | IoU {rec['mean_iou']:.3f}, {100 * rec['wrong_point_share']:.1f} % of the points wrong", flush=True)
+    return out
+
+
+torch.manual_seed(0)
+res = {"batch": B, "voxels": VOX, "objects": K, "rounds": R}
+rand_model = randomize_bn_stats(build_model(default_args())).eval().to(dev)
+res["random_init"] = table("random init", rand_model)
+del rand_model
+torch.manual_seed(0)
+model = build_model(default_args()).to(dev)
+torch.cuda.synchronize(); t0 = time.perf_counter()
+losses = fit(model, items, dev, iters=fit_iters, lr=1e-3, batch=4, seed=7)
+torch.cuda.synchronize()
+print(f"fitted: {fit_iters} iterations of train_one_step on {B} x {VOX}-voxel scenes in {time.perf_counter() - t0:.1f} s, loss "
+      f"{np.mean(losses[:5]):.3f} -> {np.mean(losses[-5:]):.3f}", flush=True)
+model.eval()
+res["fitted"] = table("fitted", model)
+res["fit"] = {"iterations": fit_iters, "loss_first5": float(np.mean(losses[:5])), "loss_last5": float(np.mean(losses[-5:]))}
+print(json.dumps(res))
