@@ -43,10 +43,20 @@ LT_BATCH=4 python $R/tools/layer_table.py > $OUT/layer_table_4scenes.txt 2>&1
 LT_BATCH=1 python $R/tools/layer_table.py > $OUT/layer_table_1scene.txt 2>&1
 LT_BATCH=16 python $R/tools/layer_table.py > $OUT/layer_table_16scenes.txt 2>&1
 # decoder pass by query count (5 objects x LT_CPO clicks + 10 learned queries; one 80 k scene)
-for CPO in 5 10 15 30; do
+for CPO in 2 5 10 11 15 22 30 38; do
   echo "== clicks per object $CPO" >> $OUT/decoder_by_queries.txt
   LT_CPO=$CPO LT_BATCH=1 python $R/tools/layer_table.py 2>&1 | awk '/posenc/{p=1} p' >> $OUT/decoder_by_queries.txt
 done
+# PMC counters of the decoder's wide-tier kernels (85 and 160 queries)
+bash $R/tools/pmc_wide.sh $TAG/pmc_wide_q85 15 > /dev/null 2>&1; cp $OUT/pmc_wide_q85/pmc_wide.txt $OUT/pmc_wide_q85.txt 2>/dev/null
+bash $R/tools/pmc_wide.sh $TAG/pmc_wide_q160 30 > /dev/null 2>&1; cp $OUT/pmc_wide_q160/pmc_wide.txt $OUT/pmc_wide_q160.txt 2>/dev/null
+cd /tmp
+# the lock-step evaluation round on a fitted state dict next to the random-init one (20 / 60 / 100 queries)
+python $R/tools/eval_rounds_fitted.py 800 > $OUT/eval_rounds_fitted.txt 2> $OUT/eval_rounds_fitted.err
+# eight data-parallel ranks on the one GPU (gloo): the real training iteration with overlapped buckets + SyncBN
+(cd $R && python -m pytest tests/test_gpu_distributed.py -q -k eight_rank_dp -s 2>&1 | tail -5) > $OUT/dp8_training_one_gpu.txt
+# the fork analysis over several fit lengths
+python $R/tools/fork_hunt.py 40 60 80 100 140 180 > $OUT/fork_evidence.txt 2> $OUT/fork_evidence.err
 # training iterations (4 x 80 k voxels, the real train_one_step): phase times, then plain wall clock
 A3D_BB_ITERS=10 A3D_TRAIN_TIMING=1 python $R/tools/backward_bench.py --step --reps 1 2>&1 | grep -E "training iteration|train_one_step" > $OUT/training_iterations.txt
 A3D_BB_ITERS=10 python $R/tools/backward_bench.py --step --reps 1 2>&1 | grep -E "training iteration" >> $OUT/training_iterations.txt
