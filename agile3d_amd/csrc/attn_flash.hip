@@ -43,68 +43,122 @@ __device__ __forceinline__ f32x4 ld4(const float* base, int64_t row, int64_t nro
   return *(const f32x4*)(base + r * FD + col);
 }
 #define FL_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+// exp through v_exp_f32 (2^x): one multiply + one transcendental instead of expf's ~15 instructions; |x| <= ~100 here, the
+// argument's rounding moves the result by |x| 2^-24 relative -- inside the 2e-5 the float64 comparison allows (tests)
+__device__ __forceinline__ float fl_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.4426950408889634f); }
+// mask bytes [row][col .. col + 3] as one (unaligned) load; `ok`: the four bytes lie inside the row
+__device__ __forceinline__ unsigned ld_mask4(const unsigned char* __restrict__ mask, size_t row, int col, int ncols) {
+  const unsigned char* p = mask + row * (size_t)ncols + col;
+  unsigned u = 0x01010101u;                       // beyond the row: blocked
+  if (col + 4 <= ncols) {
+    __builtin_memcpy(&u, p, 4);
+  } else {
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+      if (col + t < ncols) u = (u & ~(0xffu << (8 * t))) | ((unsigned)p[t] << (8 * t));
+  }
+  return u;
+}
 
 // ------------------------------------------------------------------------------------------------ click-to-scene
 // forward: partial flash state of one (workgroup, head) for every query: part[wg][h][q][18] = m, l, acc[16].  A workgroup
-// walks the 64-key chunks wg, wg + G, ... (G = gridDim.x workgroups), the running state of a query tile lives in registers
-// across all of them.
+// walks the 64-key chunks wg, wg + G, ... (G = gridDim.x workgroups); the running state of EVERY query tile lives in
+// registers across all of them (QT = tiles the build holds, nqt <= QT the call's), so the keys and values are read once --
+// the first build walked all chunks once per query tile -- and the next 16-key group's fragments and mask words are in
+// flight while the current group is multiplied.
+template <int QT>
 __global__ void __launch_bounds__(512) k_fl_c2s_fwd(const float* __restrict__ qs, const float* __restrict__ K,
                                                     const float* __restrict__ V, const unsigned char* __restrict__ mask,
-                                                    int Lq, int Lk, float* __restrict__ part) {
+                                                    int Lq, int Lk, float* __restrict__ part, int q0) {
+  // q0: first query of this launch (a call with more queries than one build holds runs it once per block of 16 QT)
   const int lane = threadIdx.x & 63, h = threadIdx.x >> 6;
   const int g = lane >> 4, j = lane & 15;
-  const int nchunk = (Lk + kFlChunk - 1) / kFlChunk;
-  const int nqt = (Lq + 15) / 16;
-  for (int qt = 0; qt < nqt; ++qt) {
-    const int qrow = qt * 16 + j;                                   // this lane's query in the (keys x queries) layout
-    const f32x4 qf = ld4(qs, qrow, Lq, h * FDH + 4 * g);
-    float m = kFlNeg, l = 0.f;
-    f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};                        // O^T[d = 4g+t][query j]
-    for (int ch = blockIdx.x; ch < nchunk; ch += gridDim.x) {
-      const int pbeg = ch * kFlChunk, pend = min(Lk, pbeg + kFlChunk);
-      for (int p0 = pbeg; p0 < pend; p0 += 16) {
-        const f32x4 kf = ld4(K, p0 + j, Lk, h * FDH + 4 * g);       // A: [key j][d 4g+t]
-        f32x4 s = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const int ngroups = (Lk + 15) / 16;
+  const int nqt = min(QT, (Lq - q0 + 15) / 16);
+  f32x4 qf[QT], acc[QT];
+  float m[QT], l[QT];
 #pragma unroll
-        for (int t = 0; t < 4; ++t) s = FL_MFMA(kf[t], qf[t], s);   // s[t] = S[key 4g+t][query j]
+  for (int qt = 0; qt < QT; ++qt) {
+    qf[qt] = ld4(qs, q0 + qt * 16 + j, Lq, h * FDH + 4 * g);       // this lane's query in the (keys x queries) layout
+    m[qt] = kFlNeg;
+    l[qt] = 0.f;
+    acc[qt] = (f32x4){0.f, 0.f, 0.f, 0.f};                          // O^T[d = 4g+t][query j]
+  }
+  // the workgroup's groups: chunk ch = blockIdx.x, + G, ... of four 16-key groups each
+  constexpr int NG = kFlChunk / 16;
+  auto group_of = [&](int it) { return ((it / NG) * (int)gridDim.x + (int)blockIdx.x) * NG + (it % NG); };
+  f32x4 kf_n = (f32x4){0.f, 0.f, 0.f, 0.f}, vf_n = kf_n;
+  unsigned mk_n[QT];
+  auto fetch = [&](int grp) {
+    const int p0 = grp * 16;
+    kf_n = ld4(K, p0 + j, Lk, h * FDH + 4 * g);                     // A: [key j][d 4g+t]
+#pragma unroll
+    for (int t = 0; t < 4; ++t) vf_n[t] = V[(size_t)min(p0 + 4 * g + t, Lk - 1) * FD + h * FDH + j];   // A: [d j][key 4g+t]
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) {
+      mk_n[qt] = 0u;
+      if (mask && qt < nqt) mk_n[qt] = ld_mask4(mask, (size_t)min(q0 + qt * 16 + j, Lq - 1), p0 + 4 * g, Lk);
+    }
+  };
+  int it = 0, grp = group_of(0);
+  if (grp < ngroups) fetch(grp);
+  while (grp < ngroups) {
+    const int p0 = grp * 16;
+    const f32x4 kf = kf_n, vf = vf_n;
+    unsigned mk[QT];
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) mk[qt] = mk_n[qt];
+    const int nxt = group_of(++it);
+    if (nxt < ngroups) fetch(nxt);
+    bool off[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) off[t] = p0 + 4 * g + t >= Lk;
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) {
+      if (qt < nqt) {
+        f32x4 s4 = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < 4; ++t) s4 = FL_MFMA(kf[t], qf[qt][t], s4);   // s4[t] = S[key 4g+t][query j]
         float mx = kFlNeg;
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-          const int pr = p0 + 4 * g + t;
-          const bool blocked = pr >= Lk || qrow >= Lq || (mask && mask[(size_t)qrow * Lk + pr]);
-          s[t] = blocked ? kFlNeg : s[t];
-          mx = fmaxf(mx, s[t]);
+          const bool blocked = off[t] || ((mk[qt] >> (8 * t)) & 0xffu) != 0u;
+          s4[t] = blocked ? kFlNeg : s4[t];
+          mx = fmaxf(mx, s4[t]);
         }
         mx = fl_rows_max(mx);
-        const float mnew = fmaxf(m, mx);
-        const float sc = expf(m - mnew);
-        m = mnew;
-        f32x4 p;
+        const float mnew = fmaxf(m[qt], mx);
+        const float sc = fl_exp(m[qt] - mnew);
+        m[qt] = mnew;
+        f32x4 pw;
         float ps = 0.f;
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-          p[t] = s[t] <= kFlNeg ? 0.f : expf(s[t] - mnew);
-          ps += p[t];
+          pw[t] = s4[t] <= kFlNeg ? 0.f : fl_exp(s4[t] - mnew);
+          ps += pw[t];
         }
-        l = l * sc + ps;
-        acc *= sc;
+        l[qt] = l[qt] * sc + ps;
+        acc[qt] *= sc;
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-          const int pr = min(p0 + 4 * g + t, Lk - 1);
-          const float vf = V[(size_t)pr * FD + h * FDH + j];        // A: [d j][key 4g+t]
-          acc = FL_MFMA(vf, p[t], acc);
-        }
+        for (int t = 0; t < 4; ++t) acc[qt] = FL_MFMA(vf[t], pw[t], acc[qt]);
       }
     }
-    l = fl_rows_sum(l);
-    float* pq = part + (((size_t)blockIdx.x * FH + h) * Lq + min(qrow, Lq - 1)) * 18;
-    if (qrow < Lq) {
-      if (g == 0) {
-        pq[0] = m;
-        pq[1] = l;
-      }
+    grp = nxt;
+  }
 #pragma unroll
-      for (int t = 0; t < 4; ++t) pq[2 + 4 * g + t] = acc[t];
+  for (int qt = 0; qt < QT; ++qt) {
+    if (qt < nqt) {
+      const int qrow = q0 + qt * 16 + j;
+      const float lt = fl_rows_sum(l[qt]);                           // (every lane takes part in the row sum)
+      if (qrow < Lq) {
+        float* pq = part + (((size_t)blockIdx.x * FH + h) * Lq + qrow) * 18;
+        if (g == 0) {
+          pq[0] = m[qt];
+          pq[1] = lt;
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) pq[2 + 4 * g + t] = acc[qt][t];
+      }
     }
   }
 }
@@ -160,7 +214,16 @@ __global__ void k_fl_rowdot(const float* __restrict__ dO, const float* __restric
 
 // backward: a workgroup walks the 64-key chunks wg, wg + G, ...: dK, dV rows of a chunk are final when it is done; the dQ
 // contributions of its chunks add up in the workgroup's own slab dqp[wg][h][q][16] (read-modify-write by the one wave that
-// owns the (head, query tile): sequential, deterministic)
+// owns the (head, query tile): sequential, deterministic).
+// Round 6: the chunk's key-side fragments (K, V rows, K^T columns of its four groups) are loaded ONCE per chunk and held
+// across the query tiles (they were re-loaded per tile and group: fourteen dependent loads in front of every 28 MFMAs -- the
+// kernel ran at a tenth of the matrix rate), the query side of the NEXT tile and the mask words of all four groups are
+// requested before the current tile's products, mask bytes come four to a load, exp is one v_exp_f32.
+struct FlQSide {   // one query tile as a lane sees it: as a COLUMN (keys x queries: query j) and as four ROWS (queries 4g+t)
+  f32x4 qf, dof;
+  float mj, rlj, Dj;
+  float mq[4], rlq[4], Dq[4], qT[4], doT[4];
+};
 __global__ void __launch_bounds__(512) k_fl_c2s_bwd(const float* __restrict__ qs, const float* __restrict__ K,
                                                     const float* __restrict__ V, const unsigned char* __restrict__ mask,
                                                     int Lq, int Lk, const float* __restrict__ stats,
@@ -174,67 +237,90 @@ __global__ void __launch_bounds__(512) k_fl_c2s_bwd(const float* __restrict__ qs
   const float* Ms = stats + (size_t)h * Lq;
   const float* Ls = stats + (size_t)(FH + h) * Lq;
   const float* Dh = Ds + (size_t)h * Lq;
+  auto load_q = [&](int qt, FlQSide& s) {
+    const int qj = qt * 16 + j, qjc = min(qj, Lq - 1);
+    s.qf = ld4(qs, qj, Lq, h * FDH + 4 * g);                        // q[query j][d 4g+t]
+    s.dof = ld4(dO, qj, Lq, h * FDH + 4 * g);                       // dO[query j][d 4g+t]
+    s.mj = Ms[qjc];
+    s.rlj = 1.f / Ls[qjc];
+    s.Dj = Dh[qjc];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int qr = min(qt * 16 + 4 * g + t, Lq - 1);
+      s.mq[t] = Ms[qr];
+      s.rlq[t] = 1.f / Ls[qr];
+      s.Dq[t] = Dh[qr];
+      s.qT[t] = qs[(size_t)qr * FD + h * FDH + j];                  // A: [d j][query 4g+t]
+      s.doT[t] = dO[(size_t)qr * FD + h * FDH + j];
+    }
+  };
   bool first = true;
   for (int ch = blockIdx.x; ch < nchunk; ch += gridDim.x, first = false) {
-    const int pbeg = ch * kFlChunk, pend = min(Lk, pbeg + kFlChunk);
-    f32x4 adk[NG], adv[NG];                                         // dK^T / dV^T [d 4g+t][key j] of the chunk's groups
+    const int pbeg = ch * kFlChunk;
+    f32x4 kf[NG], vr[NG], kT[NG], adk[NG], adv[NG];
 #pragma unroll
-    for (int i = 0; i < NG; ++i) adk[i] = adv[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int gi = 0; gi < NG; ++gi) {
+      const int p0 = pbeg + gi * 16;
+      kf[gi] = ld4(K, p0 + j, Lk, h * FDH + 4 * g);                 // K[key j][d 4g+t]
+      vr[gi] = ld4(V, p0 + j, Lk, h * FDH + 4 * g);                 // V[key j][d 4g+t]
+#pragma unroll
+      for (int t = 0; t < 4; ++t) kT[gi][t] = K[(size_t)min(p0 + 4 * g + t, Lk - 1) * FD + h * FDH + j];   // A: [d j][key 4g+t]
+      adk[gi] = adv[gi] = (f32x4){0.f, 0.f, 0.f, 0.f};              // dK^T / dV^T [d 4g+t][key j]
+    }
+    FlQSide qn;
+    load_q(0, qn);
     for (int qt = 0; qt < nqt; ++qt) {
-      const int qj = qt * 16 + j, qjc = min(qj, Lq - 1);            // this lane's query as a COLUMN (keys x queries) ...
-      const f32x4 qf = ld4(qs, qj, Lq, h * FDH + 4 * g);            // q[query j][d 4g+t]
-      const f32x4 dof = ld4(dO, qj, Lq, h * FDH + 4 * g);           // dO[query j][d 4g+t]
-      const float mj = Ms[qjc], rlj = 1.f / Ls[qjc], Dj = Dh[qjc];
-      float mq[4], rlq[4], Dq[4], qT[4], doT[4];                    // ... and its four queries as ROWS (queries x keys)
+      const FlQSide q = qn;
+      const int qj = qt * 16 + j, qjc = min(qj, Lq - 1);
+      // mask words of the four groups: keys x queries (query j's row, keys 4g..4g+3: one load) and queries x keys (rows of
+      // queries 4g+t, key j: a byte each)
+      unsigned mkq[NG], mqk[NG];
 #pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        const int qr = min(qt * 16 + 4 * g + t, Lq - 1);
-        mq[t] = Ms[qr];
-        rlq[t] = 1.f / Ls[qr];
-        Dq[t] = Dh[qr];
-        qT[t] = qs[(size_t)qr * FD + h * FDH + j];                  // A: [d j][query 4g+t]
-        doT[t] = dO[(size_t)qr * FD + h * FDH + j];
+      for (int gi = 0; gi < NG; ++gi) {
+        mkq[gi] = mqk[gi] = 0u;
+        if (mask) {
+          const int p0 = pbeg + gi * 16;
+          mkq[gi] = ld_mask4(mask, (size_t)qjc, p0 + 4 * g, Lk);
+          const int pr = min(p0 + j, Lk - 1);
+#pragma unroll
+          for (int t = 0; t < 4; ++t)
+            mqk[gi] |= (unsigned)mask[(size_t)min(qt * 16 + 4 * g + t, Lq - 1) * Lk + pr] << (8 * t);
+        }
       }
+      if (qt + 1 < nqt) load_q(qt + 1, qn);
       f32x4 adq = (f32x4){0.f, 0.f, 0.f, 0.f};                      // dQ^T[d 4g+t][query j]
 #pragma unroll
       for (int gi = 0; gi < NG; ++gi) {
         const int p0 = pbeg + gi * 16;
-        if (p0 >= pend) break;
-        const f32x4 kf = ld4(K, p0 + j, Lk, h * FDH + 4 * g);       // K[key j][d 4g+t]
-        const f32x4 vr = ld4(V, p0 + j, Lk, h * FDH + 4 * g);       // V[key j][d 4g+t]
         // scores and dP in both layouts
         f32x4 s_kq = (f32x4){0.f, 0.f, 0.f, 0.f}, s_qk = s_kq, dp_kq = s_kq, dp_qk = s_kq;
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-          s_kq = FL_MFMA(kf[t], qf[t], s_kq);                       // [key 4g+t][query j]
-          s_qk = FL_MFMA(qf[t], kf[t], s_qk);                       // [query 4g+t][key j]
-          dp_kq = FL_MFMA(vr[t], dof[t], dp_kq);
-          dp_qk = FL_MFMA(dof[t], vr[t], dp_qk);
+          s_kq = FL_MFMA(kf[gi][t], q.qf[t], s_kq);                 // [key 4g+t][query j]
+          s_qk = FL_MFMA(q.qf[t], kf[gi][t], s_qk);                 // [query 4g+t][key j]
+          dp_kq = FL_MFMA(vr[gi][t], q.dof[t], dp_kq);
+          dp_qk = FL_MFMA(q.dof[t], vr[gi][t], dp_qk);
         }
         f32x4 p_qk, ds_qk, ds_kq;
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
           {   // keys x queries: key 4g+t, query j
-            const int pr = p0 + 4 * g + t;
-            const bool blocked = pr >= Lk || qj >= Lq || (mask && mask[(size_t)qjc * Lk + pr]);
-            const float p = blocked ? 0.f : expf(s_kq[t] - mj) * rlj;
-            ds_kq[t] = p * (dp_kq[t] - Dj);
+            const bool blocked = p0 + 4 * g + t >= Lk || qj >= Lq || ((mkq[gi] >> (8 * t)) & 0xffu) != 0u;
+            const float p = blocked ? 0.f : fl_exp(s_kq[t] - q.mj) * q.rlj;
+            ds_kq[t] = p * (dp_kq[t] - q.Dj);
           }
           {   // queries x keys: query 4g+t, key j
-            const int qr = qt * 16 + 4 * g + t, pr = p0 + j;
-            const bool blocked = pr >= Lk || qr >= Lq || (mask && mask[(size_t)min(qr, Lq - 1) * Lk + min(pr, Lk - 1)]);
-            const float p = blocked ? 0.f : expf(s_qk[t] - mq[t]) * rlq[t];
+            const bool blocked = p0 + j >= Lk || qt * 16 + 4 * g + t >= Lq || ((mqk[gi] >> (8 * t)) & 0xffu) != 0u;
+            const float p = blocked ? 0.f : fl_exp(s_qk[t] - q.mq[t]) * q.rlq[t];
             p_qk[t] = p;
-            ds_qk[t] = p * (dp_qk[t] - Dq[t]);
+            ds_qk[t] = p * (dp_qk[t] - q.Dq[t]);
           }
         }
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-          adv[gi] = FL_MFMA(doT[t], p_qk[t], adv[gi]);              // dV^T[d][key] += dO^T[d][q] P[q][key]
-          adk[gi] = FL_MFMA(qT[t], ds_qk[t], adk[gi]);              // dK^T[d][key] += q^T[d][q] dS[q][key]
-          const int pr = min(p0 + 4 * g + t, Lk - 1);
-          const float kT = K[(size_t)pr * FD + h * FDH + j];        // A: [d j][key 4g+t]
-          adq = FL_MFMA(kT, ds_kq[t], adq);                         // dQ^T[d][query] += K^T[d][key] dS[key][query]
+          adv[gi] = FL_MFMA(q.doT[t], p_qk[t], adv[gi]);            // dV^T[d][key] += dO^T[d][q] P[q][key]
+          adk[gi] = FL_MFMA(q.qT[t], ds_qk[t], adk[gi]);            // dK^T[d][key] += q^T[d][q] dS[q][key]
+          adq = FL_MFMA(kT[gi][t], ds_kq[t], adq);                  // dQ^T[d][query] += K^T[d][key] dS[key][query]
         }
       }
       if (qj < Lq) {
@@ -245,7 +331,7 @@ __global__ void __launch_bounds__(512) k_fl_c2s_bwd(const float* __restrict__ qs
 #pragma unroll
     for (int gi = 0; gi < NG; ++gi) {
       const int pr = pbeg + gi * 16 + j;
-      if (pr < pend) {
+      if (pr < Lk) {
         *(f32x4*)(dK + (size_t)pr * FD + h * FDH + 4 * g) = adk[gi];
         *(f32x4*)(dV + (size_t)pr * FD + h * FDH + 4 * g) = adv[gi];
       }
@@ -276,62 +362,86 @@ __global__ void k_fl_reduce_final(const float* __restrict__ tmp, int nslice, int
 }
 
 // ------------------------------------------------------------------------------------------------ scene-to-click
-// forward: per 16-point group and head, online softmax over the key tiles; stats[n][h][2] = m, l
+// forward: per 16-point group and head, online softmax over the key tiles; stats[n][h][2] = m, l.  The workgroup's four
+// 16-point groups walk the key tiles TOGETHER (their flash states and query fragments stay in registers), so a key
+// tile's fragments are loaded once per chunk -- with the next tile's in flight -- instead of once per group.
 __global__ void __launch_bounds__(512) k_fl_s2c_fwd(const float* __restrict__ qs, const float* __restrict__ K,
                                                     const float* __restrict__ V, int Lq, int Lk, float* __restrict__ O,
                                                     float* __restrict__ stats) {
   const int lane = threadIdx.x & 63, h = threadIdx.x >> 6;
   const int g = lane >> 4, j = lane & 15;
   const int nkt = (Lk + 15) / 16;
-  const int pbeg = blockIdx.x * kFlChunk, pend = min(Lq, pbeg + kFlChunk);
-  for (int p0 = pbeg; p0 < pend; p0 += 16) {
-    const f32x4 qf = ld4(qs, p0 + j, Lq, h * FDH + 4 * g);          // B: [d 4g+t][point j]
-    float m = kFlNeg, l = 0.f;
-    f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};                        // O^T[d 4g+t][point j]
-    for (int kt = 0; kt < nkt; ++kt) {
-      const f32x4 kf = ld4(K, kt * 16 + j, Lk, h * FDH + 4 * g);    // A: [key j][d 4g+t]
-      f32x4 s = (f32x4){0.f, 0.f, 0.f, 0.f};
+  constexpr int NG = kFlChunk / 16;
+  const int pbeg = blockIdx.x * kFlChunk;
+  f32x4 qf[NG], acc[NG];
+  float m[NG], l[NG];
 #pragma unroll
-      for (int t = 0; t < 4; ++t) s = FL_MFMA(kf[t], qf[t], s);     // [key 4g+t][point j]
+  for (int gi = 0; gi < NG; ++gi) {
+    qf[gi] = ld4(qs, pbeg + gi * 16 + j, Lq, h * FDH + 4 * g);      // B: [d 4g+t][point j]
+    m[gi] = kFlNeg;
+    l[gi] = 0.f;
+    acc[gi] = (f32x4){0.f, 0.f, 0.f, 0.f};                          // O^T[d 4g+t][point j]
+  }
+  f32x4 kf_n, vf_n;
+  auto fetch = [&](int kt) {
+    kf_n = ld4(K, kt * 16 + j, Lk, h * FDH + 4 * g);                // A: [key j][d 4g+t]
+#pragma unroll
+    for (int t = 0; t < 4; ++t) vf_n[t] = V[(size_t)min(kt * 16 + 4 * g + t, Lk - 1) * FD + h * FDH + j];   // A: [d j][key 4g+t]
+  };
+  fetch(0);
+  for (int kt = 0; kt < nkt; ++kt) {
+    const f32x4 kf = kf_n, vf = vf_n;
+    if (kt + 1 < nkt) fetch(kt + 1);
+    bool off[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) off[t] = kt * 16 + 4 * g + t >= Lk;
+#pragma unroll
+    for (int gi = 0; gi < NG; ++gi) {
+      f32x4 s4 = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int t = 0; t < 4; ++t) s4 = FL_MFMA(kf[t], qf[gi][t], s4);   // [key 4g+t][point j]
       float mx = kFlNeg;
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
-        if (kt * 16 + 4 * g + t >= Lk) s[t] = kFlNeg;
-        mx = fmaxf(mx, s[t]);
+        if (off[t]) s4[t] = kFlNeg;
+        mx = fmaxf(mx, s4[t]);
       }
       mx = fl_rows_max(mx);
-      const float mnew = fmaxf(m, mx);
-      const float sc = expf(m - mnew);
-      m = mnew;
-      f32x4 p;
+      const float mnew = fmaxf(m[gi], mx);
+      const float sc = fl_exp(m[gi] - mnew);
+      m[gi] = mnew;
+      f32x4 pw;
       float ps = 0.f;
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
-        p[t] = s[t] <= kFlNeg ? 0.f : expf(s[t] - mnew);
-        ps += p[t];
+        pw[t] = off[t] ? 0.f : fl_exp(s4[t] - mnew);
+        ps += pw[t];
       }
-      l = l * sc + ps;
-      acc *= sc;
+      l[gi] = l[gi] * sc + ps;
+      acc[gi] *= sc;
 #pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        const int kr = min(kt * 16 + 4 * g + t, Lk - 1);
-        acc = FL_MFMA(V[(size_t)kr * FD + h * FDH + j], p[t], acc); // A: [d j][key 4g+t]
-      }
+      for (int t = 0; t < 4; ++t) acc[gi] = FL_MFMA(vf[t], pw[t], acc[gi]);
     }
-    l = fl_rows_sum(l);
-    const float rl = 1.f / l;
-    if (p0 + j < Lq) {
-      *(f32x4*)(O + (size_t)(p0 + j) * FD + h * FDH + 4 * g) = acc * rl;
+  }
+#pragma unroll
+  for (int gi = 0; gi < NG; ++gi) {
+    const int pr = pbeg + gi * 16 + j;
+    const float lt = fl_rows_sum(l[gi]);
+    if (pr < Lq) {
+      *(f32x4*)(O + (size_t)pr * FD + h * FDH + 4 * g) = acc[gi] * (1.f / lt);
       if (g == 0) {
-        stats[((size_t)(p0 + j) * FH + h) * 2] = m;
-        stats[((size_t)(p0 + j) * FH + h) * 2 + 1] = l;
+        stats[((size_t)pr * FH + h) * 2] = m[gi];
+        stats[((size_t)pr * FH + h) * 2 + 1] = lt;
       }
     }
   }
 }
 
 // backward: a workgroup walks the 64-point chunks wg, wg + G, ...: dQ rows of a chunk are final when it is done; the
-// dK / dV contributions of its chunks add up in the workgroup's own slabs dkp / dvp[wg][h][key][16]
+// dK / dV contributions of its chunks add up in the workgroup's own slabs dkp / dvp[wg][h][key][16].
+// Round 6: the point side of the chunk's four groups (rows and transposed columns of q and dO, statistics, the dO . O row
+// sums) is loaded ONCE per chunk and held across the key tiles, the next key tile's fragments are requested before the
+// current tile's products (both were re-loaded inside the innermost loop, thirteen loads per 28 MFMAs).
 __global__ void __launch_bounds__(512) k_fl_s2c_bwd(const float* __restrict__ qs, const float* __restrict__ K,
                                                     const float* __restrict__ V, int Lq, int Lk, const float* __restrict__ O,
                                                     const float* __restrict__ stats, const float* __restrict__ dO,
@@ -341,69 +451,78 @@ __global__ void __launch_bounds__(512) k_fl_s2c_bwd(const float* __restrict__ qs
   const int nkt = (Lk + 15) / 16;
   const int nchunk = (Lq + kFlChunk - 1) / kFlChunk;
   constexpr int NG = kFlChunk / 16;
+  f32x4 kf_n, vr_n, kT_n;
+  auto fetch = [&](int kt) {
+    kf_n = ld4(K, kt * 16 + j, Lk, h * FDH + 4 * g);                // K[key j][d 4g+t]
+    vr_n = ld4(V, kt * 16 + j, Lk, h * FDH + 4 * g);                // V[key j][d 4g+t]
+#pragma unroll
+    for (int t = 0; t < 4; ++t) kT_n[t] = K[(size_t)min(kt * 16 + 4 * g + t, Lk - 1) * FD + h * FDH + j];   // A: [d j][key 4g+t]
+  };
   bool first = true;
   for (int ch = blockIdx.x; ch < nchunk; ch += gridDim.x, first = false) {
-    const int pbeg = ch * kFlChunk, pend = min(Lq, pbeg + kFlChunk);
-    f32x4 adq[NG];                                                  // dQ^T[d 4g+t][point j] of the chunk's groups
+    const int pbeg = ch * kFlChunk;
+    fetch(0);
+    // ---- the chunk's point side, once
+    f32x4 qf[NG], dof[NG], qT[NG], doT[NG], mp[NG], rlp[NG], Dp[NG], adq[NG];
+    float mj[NG], rlj[NG], Dj[NG];
 #pragma unroll
-    for (int i = 0; i < NG; ++i) adq[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int gi = 0; gi < NG; ++gi) {
+      const int p0 = pbeg + gi * 16;
+      const int pj = min(p0 + j, Lq - 1);
+      qf[gi] = ld4(qs, p0 + j, Lq, h * FDH + 4 * g);                // q[point j][d 4g+t]
+      dof[gi] = ld4(dO, p0 + j, Lq, h * FDH + 4 * g);               // dO[point j][d 4g+t]
+      const f32x4 of = ld4(O, p0 + j, Lq, h * FDH + 4 * g);
+      mj[gi] = stats[((size_t)pj * FH + h) * 2];
+      rlj[gi] = 1.f / stats[((size_t)pj * FH + h) * 2 + 1];
+      float d = dof[gi][0] * of[0] + dof[gi][1] * of[1] + dof[gi][2] * of[2] + dof[gi][3] * of[3];
+      Dj[gi] = fl_rows_sum(d);                                       // sum_d dO[point j][16h+d] O[point j][16h+d]
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int src = 4 * g + t;                                   // lane holding point 4g+t as ITS point j (any row)
+        mp[gi][t] = __shfl(mj[gi], src, 64);
+        rlp[gi][t] = __shfl(rlj[gi], src, 64);
+        Dp[gi][t] = __shfl(Dj[gi], src, 64);
+        const int pr = min(p0 + 4 * g + t, Lq - 1);
+        qT[gi][t] = qs[(size_t)pr * FD + h * FDH + j];               // A: [d j][point 4g+t]
+        doT[gi][t] = dO[(size_t)pr * FD + h * FDH + j];
+      }
+      adq[gi] = (f32x4){0.f, 0.f, 0.f, 0.f};                         // dQ^T[d 4g+t][point j]
+    }
     for (int kt = 0; kt < nkt; ++kt) {
-      const f32x4 kf = ld4(K, kt * 16 + j, Lk, h * FDH + 4 * g);    // K[key j][d 4g+t]
-      const f32x4 vr = ld4(V, kt * 16 + j, Lk, h * FDH + 4 * g);    // V[key j][d 4g+t]
-      float kT[4];
-#pragma unroll
-      for (int t = 0; t < 4; ++t) kT[t] = K[(size_t)min(kt * 16 + 4 * g + t, Lk - 1) * FD + h * FDH + j];   // A: [d j][key 4g+t]
+      const f32x4 kf = kf_n, vr = vr_n, kT = kT_n;
+      if (kt + 1 < nkt) fetch(kt + 1);
       f32x4 adk = (f32x4){0.f, 0.f, 0.f, 0.f}, adv = adk;           // dK^T / dV^T [d 4g+t][key j]
 #pragma unroll
       for (int gi = 0; gi < NG; ++gi) {
         const int p0 = pbeg + gi * 16;
-        if (p0 >= pend) break;
-        const int pj = min(p0 + j, Lq - 1);
-        const f32x4 qf = ld4(qs, p0 + j, Lq, h * FDH + 4 * g);      // q[point j][d 4g+t]
-        const f32x4 dof = ld4(dO, p0 + j, Lq, h * FDH + 4 * g);     // dO[point j][d 4g+t]
-        const f32x4 of = ld4(O, p0 + j, Lq, h * FDH + 4 * g);
-        const float mj = stats[((size_t)pj * FH + h) * 2], rlj = 1.f / stats[((size_t)pj * FH + h) * 2 + 1];
-        float Dj = dof[0] * of[0] + dof[1] * of[1] + dof[2] * of[2] + dof[3] * of[3];
-        Dj = fl_rows_sum(Dj);                                        // sum_d dO[point j][16h+d] O[point j][16h+d]
-        float mp[4], rlp[4], Dp[4], qT[4], doT[4];
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-          const int src = 4 * g + t;                                 // lane holding point 4g+t as ITS point j (any row)
-          mp[t] = __shfl(mj, src, 64);
-          rlp[t] = __shfl(rlj, src, 64);
-          Dp[t] = __shfl(Dj, src, 64);
-          const int pr = min(p0 + 4 * g + t, Lq - 1);
-          qT[t] = qs[(size_t)pr * FD + h * FDH + j];                 // A: [d j][point 4g+t]
-          doT[t] = dO[(size_t)pr * FD + h * FDH + j];
-        }
         f32x4 s_kp = (f32x4){0.f, 0.f, 0.f, 0.f}, s_pk = s_kp, dp_kp = s_kp, dp_pk = s_kp;
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-          s_kp = FL_MFMA(kf[t], qf[t], s_kp);                        // [key 4g+t][point j]
-          s_pk = FL_MFMA(qf[t], kf[t], s_pk);                        // [point 4g+t][key j]
-          dp_kp = FL_MFMA(vr[t], dof[t], dp_kp);
-          dp_pk = FL_MFMA(dof[t], vr[t], dp_pk);
+          s_kp = FL_MFMA(kf[t], qf[gi][t], s_kp);                    // [key 4g+t][point j]
+          s_pk = FL_MFMA(qf[gi][t], kf[t], s_pk);                    // [point 4g+t][key j]
+          dp_kp = FL_MFMA(vr[t], dof[gi][t], dp_kp);
+          dp_pk = FL_MFMA(dof[gi][t], vr[t], dp_pk);
         }
         f32x4 ds_kp, p_pk, ds_pk;
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
           {   // keys x points
             const bool off = kt * 16 + 4 * g + t >= Lk || p0 + j >= Lq;
-            const float p = off ? 0.f : expf(s_kp[t] - mj) * rlj;
-            ds_kp[t] = p * (dp_kp[t] - Dj);
+            const float p = off ? 0.f : fl_exp(s_kp[t] - mj[gi]) * rlj[gi];
+            ds_kp[t] = p * (dp_kp[t] - Dj[gi]);
           }
           {   // points x keys
             const bool off = kt * 16 + j >= Lk || p0 + 4 * g + t >= Lq;
-            const float p = off ? 0.f : expf(s_pk[t] - mp[t]) * rlp[t];
+            const float p = off ? 0.f : fl_exp(s_pk[t] - mp[gi][t]) * rlp[gi][t];
             p_pk[t] = p;
-            ds_pk[t] = p * (dp_pk[t] - Dp[t]);
+            ds_pk[t] = p * (dp_pk[t] - Dp[gi][t]);
           }
         }
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
           adq[gi] = FL_MFMA(kT[t], ds_kp[t], adq[gi]);               // dQ^T[d][point] += K^T[d][key] dS[key][point]
-          adk = FL_MFMA(qT[t], ds_pk[t], adk);                       // dK^T[d][key] += q^T[d][point] dS[point][key]
-          adv = FL_MFMA(doT[t], p_pk[t], adv);                       // dV^T[d][key] += dO^T[d][point] P[point][key]
+          adk = FL_MFMA(qT[gi][t], ds_pk[t], adk);                   // dK^T[d][key] += q^T[d][point] dS[point][key]
+          adv = FL_MFMA(doT[gi][t], p_pk[t], adv);                   // dV^T[d][key] += dO^T[d][point] P[point][key]
         }
       }
       const int kj = kt * 16 + j;
@@ -417,7 +536,7 @@ __global__ void __launch_bounds__(512) k_fl_s2c_bwd(const float* __restrict__ qs
 #pragma unroll
     for (int gi = 0; gi < NG; ++gi) {
       const int pr = pbeg + gi * 16 + j;
-      if (pr < pend) *(f32x4*)(dQ + (size_t)pr * FD + h * FDH + 4 * g) = adq[gi];
+      if (pr < Lq) *(f32x4*)(dQ + (size_t)pr * FD + h * FDH + 4 * g) = adq[gi];
     }
   }
 }
@@ -474,7 +593,16 @@ extern "C" int a3d_flash_c2s_forward(const float* q_scaled_dev, const float* k_d
   hipStream_t st = (hipStream_t)stream;
   const int G = fl_grid(Lk);
   float* part = (float*)workspace_dev;
-  k_fl_c2s_fwd<<<G, 512, 0, st>>>(q_scaled_dev, k_dev, v_dev, mask_dev, (int)Lq, (int)Lk, part);
+  // the build that holds the call's query tiles (or 14 of them per launch)
+  for (int q0 = 0; q0 < (int)Lq; q0 += 16 * 14) {
+    const int tiles = (int)((Lq - q0 + 15) / 16);
+    if (tiles <= 2) k_fl_c2s_fwd<2><<<G, 512, 0, st>>>(q_scaled_dev, k_dev, v_dev, mask_dev, (int)Lq, (int)Lk, part, q0);
+    else if (tiles <= 4) k_fl_c2s_fwd<4><<<G, 512, 0, st>>>(q_scaled_dev, k_dev, v_dev, mask_dev, (int)Lq, (int)Lk, part, q0);
+    else if (tiles <= 6) k_fl_c2s_fwd<6><<<G, 512, 0, st>>>(q_scaled_dev, k_dev, v_dev, mask_dev, (int)Lq, (int)Lk, part, q0);
+    else if (tiles <= 8) k_fl_c2s_fwd<8><<<G, 512, 0, st>>>(q_scaled_dev, k_dev, v_dev, mask_dev, (int)Lq, (int)Lk, part, q0);
+    else if (tiles <= 10) k_fl_c2s_fwd<10><<<G, 512, 0, st>>>(q_scaled_dev, k_dev, v_dev, mask_dev, (int)Lq, (int)Lk, part, q0);
+    else k_fl_c2s_fwd<14><<<G, 512, 0, st>>>(q_scaled_dev, k_dev, v_dev, mask_dev, (int)Lq, (int)Lk, part, q0);
+  }
   k_fl_c2s_combine<<<(unsigned)(Lq * FH), 64, 0, st>>>(part, G, (int)Lq, o_dev, stats_dev);
   A3D_LAUNCH_CHECK();
   return A3D_OK;
