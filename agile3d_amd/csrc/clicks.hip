@@ -22,6 +22,12 @@
 // survivors alone meet every 16th point; with large wrong regions (training with early weights, 300 k-voxel scenes) the
 // first stage removes all but the few per cent of points near a cluster's deepest spot and phase A shrinks by ~10x
 // (300 k voxels, 60 % wrong: 1.07 -> 0.79 ms; from kCoarseFrom points on -- at 80 k its launches cost what it saves).
+// Round 6: every kernel serves ALL samples of a call (device table, a3d_click_clusters_batch: ~17 launches a round
+// whatever the batch size; they were ~12 per sample on side streams), which makes a bounding stage's launches cheap: the
+// first stage runs from kCoarseFrom = 20 k points and its stage-skip rule from 2^26 pairs -- and, where the caller hands
+// over a spatial order of the sample's points (a3d_click_spatial_order, once per scene), takes its upper bounds from a
+// row's neighbours in that order instead of every 256th point (k_nearest_window: with predictions that are wrong nearly
+// everywhere the sampled bounds pruned nothing; 4 x 80 k training samples: final pass 1.38 -> 0.87 ms per round).
 // A cell-list search for the NEAR field in front of all this (points binned into a uniform grid, rings of cells scanned
 // by 32 lanes per wrong point, only unresolved points to the brute-force search) was built, verified bit-identical and
 // measured slower in every regime but one (profiles/r04_experiments.txt): removed.
@@ -38,7 +44,6 @@ constexpr int kNearestSplit = 128;           // candidate chunks (grid.y): enoug
 constexpr int kSample = 16;                  // phase A: every kSample-th point is a candidate
 constexpr int kSampleCoarse = 256;           // ... after a first bounding stage against every kSampleCoarse-th point (a subset of them)
 constexpr int kCoarseFrom = 20000;           // ... from this many points (150 k until round 6: the stage's five launches are shared by the samples of a call now)
-static unsigned kNearestWalkers = 1u << 20;      // workgroups per candidate chunk and sample that walk the query blocks of k_nearest_other
 constexpr int kMinChunk = 32;                // candidates per workgroup row of k_nearest_other at least (small samples: fewer, fuller blocks)
 constexpr long long kSmallPairs = 1ll << 26;  // (wrong points) x (points) below which a bounding stage is skipped: the plain pass over them is ~20 us of the chip
                                               // (2^30 until round 6, when a stage cost five launches PER SAMPLE; 16 random-init samples then met the plain pass with
@@ -285,10 +290,9 @@ __global__ __launch_bounds__(kNearestBlock) void k_nearest_other(const ClickDev*
   const int chunk = nearest_chunk(n);
   const int64_t j0l = (int64_t)blockIdx.y * chunk;
   if (j0l >= n) return;
-  // the host does not know how many rows are wrong: the grid's x dimension is a few workgroups that WALK the query blocks
-  // (sized by the sample it was 157 x 128 workgroups per 80 k-point sample, nearly all of which found nothing to do --
-  // 320 k empty workgroups in a 16-sample launch)
-  for (int q0 = blockIdx.x * (kNearestBlock * kQueriesPerThread); q0 < n_err; q0 += gridDim.x * (kNearestBlock * kQueriesPerThread)) {
+  const int q0 = blockIdx.x * (kNearestBlock * kQueriesPerThread);
+  if (q0 >= n_err) return;   // (the host does not know how many rows are wrong: the grid covers all of them.  A few workgroups WALKING
+                             //  the query blocks instead measured slower in every regime, profiles/r06_experiments.txt)
   float qx[kQueriesPerThread], qy[kQueriesPerThread], qz[kQueriesPerThread], best[kQueriesPerThread];
   int qc[kQueriesPerThread];
 #pragma unroll
@@ -320,7 +324,6 @@ __global__ __launch_bounds__(kNearestBlock) void k_nearest_other(const ClickDev*
   for (int u = 0; u < kQueriesPerThread; ++u) {
     const int e = q0 + u * kNearestBlock + threadIdx.x;
     if (e < n_err) atomicMin(&v.d2[e], __float_as_uint(best[u]));   // d2 >= 0: bit order == value order
-  }
   }
 }
 
@@ -640,14 +643,6 @@ extern "C" int a3d_click_clusters_batch(const a3d_click_sample* samples, int n_s
     const char* e = getenv("A3D_CLICK_PRUNE");
     prune = e ? atoi(e) : 1;
   }
-  {
-    static bool walkers_read = false;
-    if (!walkers_read) {
-      walkers_read = true;
-      const char* e = getenv("A3D_CLICK_WALKERS");
-      if (e && atoi(e) > 0) kNearestWalkers = (unsigned)atoi(e);
-    }
-  }
   static int coarse_from = -1;   // the coarse bounding stage in front of the fine one from this many points on
   if (coarse_from < 0) {
     const char* e = getenv("A3D_CLICK_COARSE_FROM");
@@ -714,8 +709,7 @@ extern "C" int a3d_click_clusters_batch(const a3d_click_sample* samples, int n_s
       const unsigned c = (unsigned)((nc + nearest_chunk(nc) - 1) / nearest_chunk(nc));
       gy = c > gy ? c : gy;
     }
-    const unsigned gx_all = (unsigned)((n_max + per_block - 1) / per_block);
-    return dim3(gx_all < kNearestWalkers ? gx_all : kNearestWalkers, gy, ns);
+    return dim3((unsigned)((n_max + per_block - 1) / per_block), gy, ns);
   };
   // (the pass is a template parameter of the kernels: what it reads and writes is fixed at compile time)
   if (any_plain) {

@@ -197,9 +197,11 @@ def _prune_cases():
     large blobs, everything wrong, sizes around the sampling stride, exact distance ties (points on an integer lattice)."""
     rng = np.random.default_rng(7)
     out = []
-    # from kCoarseFrom = 150 000 points on (clicks.hip) a coarse bounding stage (every 256th point) runs in front of the fine
-    # one (every 16th): the last three cases are beyond that size -- coherent regions, everything wrong, and exact distance
-    # ties on a lattice --, the ones before them exercise the one-stage search around its own size thresholds
+    # from kCoarseFrom = 20 000 points on (clicks.hip; 150 000 until round 6) a first bounding stage runs in front of the fine one
+    # (every 16th point) -- upper bounds from a row's neighbours in a Morton order of the coordinates (error_clusters hands
+    # one over from that size on), or from every 256th point without one (A3D_CLICK_ORDER=0) --: coherent regions, everything
+    # wrong, exact distance ties on a lattice at 20 k .. 180 k points; the cases below that size exercise the one-stage
+    # search around its own size thresholds
     for n, kind in [(1024, "noise"), (1500, "blobs"), (4099, "noise"), (20_011, "blobs"), (20_011, "all_wrong"),
                     (8192, "lattice"), (16_383, "blobs"), (16_384, "noise"), (65_537, "all_wrong"), (70_001, "half_wrong"),
                     (60_000, "lattice_big"), (150_001, "half_wrong"), (163_841, "all_wrong"), (180_000, "lattice_huge")]:
