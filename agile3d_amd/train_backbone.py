@@ -245,7 +245,10 @@ class BackboneTape:
             draw = self._new(lo, cout)
             dres = None
             if res is not None:
-                assert not res.ginit, "the residual branch's gradient is always the first contribution to its node"
+                if res.ginit:   # (not an assert: under python -O a second writer would silently OVERWRITE the first gradient)
+                    raise RuntimeError("BackboneTape: the residual branch's gradient must be the first contribution to its node "
+                                       "(a block input that is also a skip tensor or another block's residual is not a "
+                                       "topology this tape's first-write rule covers)")
                 res.pending -= 1
                 if y.sums is None:
                     dres = res.grad_buffer()

@@ -482,6 +482,8 @@ def iou_at_k(dev, n_scenes=4, voxels=5000, objects=3, max_clicks=20, fit_iters=1
             "rounds": rounds, "rounds_with_identical_clicks": int(sum(same_clicks)), "rounds_with_identical_iou": int(sum(same_iou)),
             "first_differing_round": first_div, "forks": forks,
             "weights": {"kind": "fitted", "fit_iterations": fit_iters, "lr": lr, "fit_seconds": round(fit_s, 1),
+                        "adaptive_fit": min_iou5 is not None,     # fitted ON in steps until the GPU protocol reaches min_iou5 on the scenes
+                        "min_iou5": min_iou5,                     # it is then evaluated on: a best case, not a fixed-iteration protocol
                         "ms_per_iteration": round(1e3 * fit_s / fit_iters, 1),
                         "loss_first5_mean": round(float(np.mean(losses[:5])), 4), "loss_last5_mean": round(float(np.mean(losses[-5:])), 4)},
             "note": f"interactive protocol on {n_scenes} seeded synthetic scenes ({voxels} voxels, {objects} objects, up to "
@@ -549,6 +551,7 @@ def train_iter_ms(dev, voxels=80_000, batch=4, iters=5, warm=3):
             "ms_per_click_round": round(float(np.median(per_round)), 2) if per_round else None,
             "phases_ms_median": {k: round(float(np.median([r["phases_ms"].get(k, 0.0) for r in rows])), 2)
                                  for k in rows[0]["phases_ms"]},
+            "prewarmed": True,     # the seeded draws run once untimed first: allocations of the long click schedules are warm
             "workload": f"{batch} x {voxels}-voxel labelled synthetic scenes per iteration, 1 GPU, fp32, AdamW + clip 0.1; "
                         f"median of {iters} seeded iterations after {warm} warm-ups and one untimed run of the same draws"}
 
