@@ -124,6 +124,7 @@ struct ClickWs {
   // the coarse bounding stage in front of the fine one (its survivors: surv_c_rows / d2s_c; the fine stage's: surv_rows / d2s)
   unsigned long long* table_ub_c;
   unsigned* lbtab_c;
+  unsigned* lbs;       // per cluster: the largest EXACT distance among a sample of its rows (k_lb_sampled): a lower bound of its maximum
   int *n_surv_c, *n_champ_c;
   int2* champ_c;
   float4* samp_coarse;
@@ -147,7 +148,9 @@ struct ClickDev {      // one sample of a call as the kernels see it
 };
 constexpr int kMaxClickBatch = 64;
 constexpr int kWindow = 64;                  // rows on either side of a row in the spatial order that its first upper bound looks at
-enum { ST_PLAIN = 0, ST_COARSE = 1, ST_FINE = 2, ST_FINAL = 3 };
+enum { ST_PLAIN = 0, ST_COARSE = 1, ST_FINE = 2, ST_FINAL = 3, ST_LBS = 4 };
+constexpr int kLbStep = 64;                  // every kLbStep-th wrong row gets its exact distance up front (k_lb_sampled)
+constexpr int kLbMinRows = 4096;             // ... in samples with at least this many wrong rows
 // what a pass reads and writes: PLAIN / FINAL = exact distances against all points into the cluster table; COARSE / FINE = a
 // bounding stage (upper bounds against a sample of the points, champions, survivors)
 struct StageView {
@@ -184,6 +187,10 @@ __device__ __forceinline__ StageView stage_view(const ClickDev& s) {
     v.rows = w.err_rows; v.n_rows = w.n_err; v.d2 = w.d2bits; v.table = w.table_ub_c; v.lbtab = w.lbtab_c;
     v.champ = w.champ_c; v.n_champ = w.n_champ_c; v.rows_out = w.surv_c_rows; v.d2_out = w.d2s_c; v.n_out = w.n_surv_c;
     v.skip = s.order ? 0 : (long long)(s.n / 2);
+  } else if constexpr (stage == ST_LBS) {
+    // exact distances of every kLbStep-th wrong row against ALL points, into the rows' own upper-bound slots
+    v.on = s.two_stage != 0;
+    v.cands = w.cand; v.n_cands = s.n; v.rows = w.err_rows; v.n_rows = w.n_err; v.d2 = w.d2bits; v.table = nullptr;
   } else if constexpr (stage == ST_FINE) {
     v.on = s.bounded != 0;
     v.cands = w.samp; v.n_cands = (s.n + kSample - 1) / kSample;
@@ -283,7 +290,10 @@ __global__ __launch_bounds__(kNearestBlock) void k_nearest_other(const ClickDev*
   const float4* __restrict__ pts = s.w.cand;
   const float4* __restrict__ cand = v.cands;
   const int64_t n = v.n_cands;
-  const int n_err = *v.n_rows;
+  constexpr int STEP = stage == ST_LBS ? kLbStep : 1;                 // rows of this pass: every STEP-th of the stage's list
+  const int n_all = *v.n_rows;
+  if (stage == ST_LBS && n_all < kLbMinRows) return;
+  const int n_err = (n_all + STEP - 1) / STEP;
   // phase A of the bounded pass on a sample with few wrong points: not worth its time -- the upper bounds stay +inf,
   // every point survives and phase C is the plain pass
   if (v.skip && (long long)n_err * v.skip < kSmallPairs) return;
@@ -299,7 +309,7 @@ __global__ __launch_bounds__(kNearestBlock) void k_nearest_other(const ClickDev*
   for (int u = 0; u < kQueriesPerThread; ++u) {
     const int e = q0 + u * kNearestBlock + threadIdx.x;
     float4 c = make_float4(0.f, 0.f, 0.f, __int_as_float(-2));
-    if (e < n_err) c = pts[v.rows[e]];
+    if (e < n_err) c = pts[v.rows[e * STEP]];
     qx[u] = c.x; qy[u] = c.y; qz[u] = c.z; qc[u] = __float_as_int(c.w);
     best[u] = __uint_as_float(kInfBits);
   }
@@ -323,7 +333,7 @@ __global__ __launch_bounds__(kNearestBlock) void k_nearest_other(const ClickDev*
 #pragma unroll
   for (int u = 0; u < kQueriesPerThread; ++u) {
     const int e = q0 + u * kNearestBlock + threadIdx.x;
-    if (e < n_err) atomicMin(&v.d2[e], __float_as_uint(best[u]));   // d2 >= 0: bit order == value order
+    if (e < n_err) atomicMin(&v.d2[e * STEP], __float_as_uint(best[u]));   // d2 >= 0: bit order == value order
   }
 }
 
@@ -445,6 +455,23 @@ __global__ void __launch_bounds__(256) k_champ_exact(const ClickDev* __restrict_
   if ((threadIdx.x & 63) == 0) atomicMin(&v.lbtab[ch.x], __float_as_uint(best));
   }
 }
+// Lower bounds from a SAMPLE of rows (round 6).  The champion of a cluster -- its row with the largest upper bound -- tends to
+// be a row whose bound is loose, so its exact distance sits far below the cluster's maximum and most rows survive it (a
+// 58 k-point cluster of an early-training prediction kept 36 k of them; offline on such a scene: champion 0.027 against a
+// maximum of 0.051, 6 214 survivors -- 368 with the bound below).  Every kLbStep-th wrong row gets its EXACT distance up
+// front (k_nearest_other<ST_LBS>: ~n_err / 64 rows against all points, into the rows' own bound slots, which it also
+// tightens) and the largest of them per cluster is a lower bound of that cluster's maximum like the champion's.
+__global__ void k_lb_sampled(const ClickDev* __restrict__ tab) {
+  const ClickDev& s = tab[blockIdx.y];
+  if (!s.two_stage) return;
+  const int n_all = *s.w.n_err;
+  if (n_all < kLbMinRows) return;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int e = i * kLbStep;
+  if (e >= n_all) return;
+  const int cid = __float_as_int(s.w.cand[s.w.err_rows[e]].w);
+  atomicMax(&s.w.lbs[cid], s.w.d2bits[e]);                            // d2 >= 0: bit order == value order
+}
 // phase C, step 1: the points that can still be their cluster's arg-max
 template <int stage>
 __global__ void k_survivors(const ClickDev* __restrict__ tab) {
@@ -458,7 +485,8 @@ __global__ void k_survivors(const ClickDev* __restrict__ tab) {
   int row = 0;
   if (e < n_err) {
     row = v.rows[e];
-    keep = v.d2[e] >= v.lbtab[__float_as_int(s.w.cand[row].w)];   // d2 >= 0: bit order == value order
+    const int cid = __float_as_int(s.w.cand[row].w);
+    keep = v.d2[e] >= max(v.lbtab[cid], s.w.lbs[cid]);              // d2 >= 0: bit order == value order
   }
   const unsigned long long m = __ballot(keep);
   const int lane = threadIdx.x & 63;
@@ -559,6 +587,7 @@ static ClickWs carve_click(void* base, int64_t n) {
   w.lbtab = (unsigned*)take((size_t)kClusterTable * 4);
   w.table_ub_c = (unsigned long long*)take((size_t)kClusterTable * 8);
   w.lbtab_c = (unsigned*)take((size_t)kClusterTable * 4);
+  w.lbs = (unsigned*)take((size_t)kClusterTable * 4);
   w.zero_bytes = off;
   w.champ = (int2*)take((size_t)kMaxChamp * 8);
   w.champ_c = (int2*)take((size_t)kMaxChamp * 8);
@@ -728,6 +757,13 @@ extern "C" int a3d_click_clusters_batch(const a3d_click_sample* samples, int n_s
         k_nearest_window<<<dim3(nb, ns), 256, 0, st>>>(tab);
       }
       if (any_sampled) k_nearest_other<ST_COARSE><<<nearest_grid(ST_COARSE), kNearestBlock, 0, st>>>(tab);
+      {   // exact distances of a sample of the wrong rows -> lower bounds of the clusters' maxima (behind the bounds above:
+          // k_nearest_window stores, this pass lowers)
+        dim3 gl = nearest_grid(ST_LBS);
+        gl.x = (gl.x + kLbStep - 1) / kLbStep;
+        k_nearest_other<ST_LBS><<<gl, kNearestBlock, 0, st>>>(tab);
+        k_lb_sampled<<<dim3((unsigned)((n_max / kLbStep + 255) / 256 + 1), ns), 256, 0, st>>>(tab);
+      }
       k_cluster_best<ST_COARSE><<<dim3(nb, ns), 256, 0, st>>>(tab);
       k_champ_list<ST_COARSE><<<dim3(kClusterTable / 256, ns), 256, 0, st>>>(tab);
       k_champ_exact<ST_COARSE><<<dim3(128, kChampSplit, ns), 256, 0, st>>>(tab);
