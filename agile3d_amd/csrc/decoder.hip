@@ -2474,6 +2474,21 @@ static bool fused_wide() {   // A3D_FUSED_WIDE=0 (or A3D_FUSED_C2S=0) keeps the 
   return v != 0 && fused_c2s();
 }
 
+// The wide tier's kernels take a sample's tile count from the table, so they serve fewer than 65 queries too (under the
+// 5-tile build).  From 33 queries on they are the default: a pass at 80 k points 0.83 -> 0.80 ms at 35 queries, 0.97 -> 0.83
+// at 60 (k_q_s2c + k_out_ln_mask and a 64-row query block against k_s2c_w + k_out_w and two 32-row blocks), and those samples
+// then share the launch group of a call's larger ones.  Up to 32 queries k_s2c_out (one kernel for the whole scene-to-click
+// half) stays ahead.  A3D_WIDE_FROM=<queries> moves the edge (65: the round's first protocol; A/B, tests).
+static int wide_from() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("A3D_WIDE_FROM");
+    v = e ? atoi(e) : 33;
+    v = v < 17 ? 17 : v;
+  }
+  return v;
+}
+
 // one batch sample on the host: validated query list, workspace layout and the views into its workspace
 struct Prepared {
   QueryMeta hm;
@@ -3052,6 +3067,7 @@ static int prepare_sample(const a3d_decoder_weights* w, const a3d_decoder_sample
   }
   dec_layout(n, nq, P.L);
   P.qtw = fused_wide() ? wide_qt(nq) : 0;
+  if (fused_wide() && nq >= wide_from() && nq <= 64) P.qtw = 5;   // (the smallest build; the kernels take the sample's own tile count)
   if (!sp.workspace_dev || sp.workspace_bytes < P.L.total || ((uintptr_t)sp.workspace_dev & 255)) {
     set_error("a3d_decoder_forward: workspace too small or misaligned (%zu < %zu)", sp.workspace_bytes, P.L.total);
     return A3D_ERR_WORKSPACE;

@@ -199,7 +199,9 @@ def main():
         "n100_k10_tiny": dict(n=100, K=10, clicks_per_obj=2, n_bg=4, seed=8, feat_scale=0.3),
         # more than 64 queries (clicks + 10 learned background queries): the multi-object protocol adds clicks up to
         # num_obj x 20 (eval_multi_obj.py:70,116-118).  One case per tile count of the fused wide tier (decoder_wide.h):
-        # 75 .. 205 queries; q80, q144 and q205 hit the all-True-row rule (an object without points after iteration 0 or 1)
+        # 46 / 62 queries (the 33 .. 64 range: both tiers serve it) and 75 .. 205; q80, q144 and q205 hit the all-True-row rule (an object without points after iteration 0 or 1)
+        "n2000_k6_q46": dict(n=2000, K=6, clicks_per_obj=5, n_bg=6, seed=16),
+        "n1800_k8_q62": dict(n=1800, K=8, clicks_per_obj=6, n_bg=4, seed=17, feat_scale=0.7),
         "n1500_k7_q75": dict(n=1500, K=7, clicks_per_obj=9, n_bg=2, seed=9),
         "n100_k10_q90": dict(n=100, K=10, clicks_per_obj=8, n_bg=0, seed=10, feat_scale=0.3),
         "n800_k5_q105": dict(n=800, K=5, clicks_per_obj=18, n_bg=5, seed=11),
