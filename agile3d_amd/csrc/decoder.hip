@@ -2913,6 +2913,7 @@ static int run_decoder_wide(const a3d_decoder_weights* w, Prepared* P, int ns, h
       const int big_lds = 160 * 1024;
       A3D_ALLOW_LDS(big_lds, k_query_block<2, 1>);
       A3D_ALLOW_LDS(big_lds, k_query_block<2, 2>);
+      A3D_ALLOW_LDS(big_lds, k_out_w<QT>);      // its per-object maxima grow with the objects: past 64 KB from ~43 objects on
     }
   }
   const int n_counts = A3D_MAX_DEC_LAYERS * (A3D_MAX_QUERIES + 1);
@@ -2925,6 +2926,10 @@ static int run_decoder_wide(const a3d_decoder_weights* w, Prepared* P, int ns, h
   }
   const size_t stage_lds = (size_t)2 * 2 * kWTile * 4;                       // two slots of (rows, position encodings)
   const size_t out_lds = ((size_t)6 * kWTile + 2 * 256 + 2 * 32 * (Kmax + 1)) * 4 + (size_t)(Kmax + 1) * 4;   // k_out_w: O slots, rows, statistics, maxima, histogram
+  if (out_lds > 160 * 1024) {
+    set_error("a3d_decoder_forward: %d objects need %zu bytes of LDS in the output half", Kmax, out_lds);
+    return A3D_ERR_UNSUPPORTED;
+  }
   DecTables T;
   int rc = upload_tables(P, ns, true, true, st, T);
   if (rc) return rc;

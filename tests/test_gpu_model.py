@@ -287,6 +287,32 @@ def test_batched_decoder_equals_per_sample_runs(model_and_sd):
             assert (g - ref).abs().max().item() <= 1e-4, (b, (g - ref).abs().max().item())
 
 
+@pytest.mark.parametrize("n,n_obj,per_obj,n_bg", [(5000, 50, 1, 0), (4000, 100, 2, 0), (300, 30, 5, 3), (17, 4, 6, 1)])
+def test_wide_tier_many_objects_and_tiny_samples(model_and_sd, n, n_obj, per_obj, n_bg):
+    """The fused wide tier at the edges of its shapes: many objects with a click or two each (the per-object maxima of
+    k_out_w are an LDS table of 2 x 32 x (objects + 1) floats: past the default 64 KB from ~43 objects on), a sample with
+    fewer points than one workgroup iteration takes (32) and one with 300 -- against the oracle on the same inputs."""
+    model, sd = model_and_sd
+    g = torch.Generator().manual_seed(n * 3 + n_obj)
+    feats = torch.randn(n, 128, generator=g) * 0.5
+    xyz = torch.rand(n, 3, generator=g) * torch.tensor([8.0, 6.0, 2.6])
+    need = n_obj * per_obj + n_bg
+    rows = (torch.randperm(n, generator=g)[:need] if need <= n else torch.randint(0, n, (need,), generator=g)).tolist()
+    order = torch.randperm(len(rows), generator=g).tolist()
+    ci = {str(o): rows[(o - 1) * per_obj:o * per_obj] for o in range(1, n_obj + 1)}
+    ct = {str(o): order[(o - 1) * per_obj:o * per_obj] for o in range(1, n_obj + 1)}
+    ci["0"], ct["0"] = rows[n_obj * per_obj:], order[n_obj * per_obj:]
+    eng = model._get_engine()
+    pcd, aux, coords, pos = eng.decoder_inputs(feats, xyz)
+    out = model.forward_mask(pcd, aux, coords, pos, click_idx=[ci], click_time_idx=[ct])
+    got = [a["pred_masks"][0] for a in out["aux_outputs"]] + [out["pred_masks"][0]]
+    ref = od.forward_mask(sd, feats, xyz, pos[4][0][0].cpu(), ci, ct)
+    for i in range(3):
+        err = (got[i].cpu() - ref[i]).abs().max().item()
+        print(f"{n} points, {n_obj} objects, {len(rows) + 10} queries, iteration {i}: logits max|diff|={err:.3e}")
+        assert got[i].shape == (n, n_obj + 1) and err <= TOL * max(1.0, ref[i].abs().max().item())
+
+
 def test_wide_tier_samples_of_different_query_counts_share_one_launch_group(model_and_sd):
     """More than 64 queries: the samples of a call go through the fused wide kernels (csrc/decoder_wide.h) TOGETHER, each with
     its own tile count from the sample table, under the build that holds the longest list -- 70, 97, 139, 171 and 210
