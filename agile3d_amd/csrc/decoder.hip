@@ -2479,6 +2479,14 @@ static bool fused_wide() {   // A3D_FUSED_WIDE=0 (or A3D_FUSED_C2S=0) keeps the 
 // at 60 (k_q_s2c + k_out_ln_mask and a 64-row query block against k_s2c_w + k_out_w and two 32-row blocks), and those samples
 // then share the launch group of a call's larger ones.  Up to 32 queries k_s2c_out (one kernel for the whole scene-to-click
 // half) stays ahead.  A3D_WIDE_FROM=<queries> moves the edge (65: the round's first protocol; A/B, tests).
+static bool fused_s2o() {   // A3D_FUSED_S2O=0: k_s2c_w + k_out_w for up to five query tiles too (A/B, tests)
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("A3D_FUSED_S2O");
+    v = e ? atoi(e) : 1;
+  }
+  return v != 0;
+}
 static int wide_from() {
   static int v = -1;
   if (v < 0) {
@@ -2914,6 +2922,10 @@ static int run_decoder_wide(const a3d_decoder_weights* w, Prepared* P, int ns, h
       A3D_ALLOW_LDS(big_lds, k_query_block<2, 1>);
       A3D_ALLOW_LDS(big_lds, k_query_block<2, 2>);
       A3D_ALLOW_LDS(big_lds, k_out_w<QT>);      // its per-object maxima grow with the objects: past 64 KB from ~43 objects on
+      if constexpr (QT == 5) {
+        A3D_ALLOW_LDS(big_lds, (k_s2o_w<5, false>));
+        A3D_ALLOW_LDS(big_lds, (k_s2o_w<5, true>));
+      }
     }
   }
   const int n_counts = A3D_MAX_DEC_LAYERS * (A3D_MAX_QUERIES + 1);
@@ -2988,7 +3000,21 @@ static int run_decoder_wide(const a3d_decoder_weights* w, Prepared* P, int ns, h
     }
     rc = launch_query_side<2>(w, l, T.qs_dev, qp, nblk, ns, nq_max, cached0, st);
     if (rc) return rc;
-    // ---- scene-to-click attention, then output projection + residual + LayerNorm + mask head
+    // ---- scene-to-click: up to five query tiles as ONE kernel (k_s2o_w), else attention, then output projection +
+    // residual + LayerNorm + mask head
+    if constexpr (QT == 5) {
+      if (fused_s2o()) {
+        ProfScope ps(st, A3D_PROF_S2C, 0, 0, 0, 0, (int)n_total);
+        const size_t s2o_lds = ((size_t)(4 + 5) * kWTile + 2 * 256 + 2 * 32 * (Kmax + 1) + ((Kmax + 1 + 3) & ~3)) * 4;
+        if (qc0) k_s2o_w<5, true><<<T.grid, 512, s2o_lds, st>>>(T.samples_dev, ns, l, LW.s2c_wq_packed, LW.s2c_in_b, LW.s2c_wo_packed,
+                                                              LW.s2c_out_b, LW.s2c_norm_w, LW.s2c_norm_b, Kmax);
+        else k_s2o_w<5, false><<<T.grid, 512, s2o_lds + (size_t)4 * kWTile * 4, st>>>(T.samples_dev, ns, l, LW.s2c_wq_packed, LW.s2c_in_b,
+                                                                                     LW.s2c_wo_packed, LW.s2c_out_b, LW.s2c_norm_w,
+                                                                                     LW.s2c_norm_b, Kmax);
+        A3D_LAUNCH_CHECK();
+        continue;
+      }
+    }
     {
       ProfScope ps(st, A3D_PROF_S2C, 0, 0, 0, 0, (int)n_total);
       if (qc0) k_s2c_w<QT, true><<<T.grid, 512, 0, st>>>(T.samples_dev, ns, l, LW.s2c_wq_packed, LW.s2c_in_b);

@@ -557,3 +557,291 @@ __global__ void __launch_bounds__(512) k_out_w(const DecSampleDev* __restrict__ 
   for (int e = tid; e <= K; e += 512)
     if (hist[e]) atomicAdd(&counts[e], hist[e]);
 }
+
+// ---- the whole scene-to-click half in ONE kernel for up to 5 query tiles (33 .. 80 queries) ------------------------------
+// k_s2c_w + k_out_w without the round trip of the attention output through HBM, the second launch and its start-up: a wave is
+// head h of the attention AND output tile h of the projection behind it, so its slices of Wq and Wo, of the queries' keys
+// and transposed values are register constants (80 + 8 QT registers: the reason for the limit) and the mask embeddings of
+// query tile h sit in LDS; the eight heads' attention outputs of a 16-point group meet in an LDS tile, everything behind it
+// is k_out_w's (two groups per iteration, LayerNorm by merged per-wave statistics, per-object maxima by LDS float-max
+// atomics).  The staged rows are src + posenc (summed once, at the commit); the residual rows come from memory
+// (L2: the staging loads fetched them); QC (the first layer's queries from the scene cache) stages nothing.
+template <int QT, bool QC>
+__global__ void __launch_bounds__(512) k_s2o_w(const DecSampleDev* __restrict__ samples, int ns, int layer,
+                                               const float* __restrict__ Wq, const float* __restrict__ bq,
+                                               const float* __restrict__ Wo, const float* __restrict__ bo,
+                                               const float* __restrict__ gamma, const float* __restrict__ beta, int Kmax) {
+  constexpr int MG = 2;
+  typedef __attribute__((address_space(3))) float lds_float;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* o_l = (float*)smem;                                  // [MG][16][kWLD] attention output rows of the pair
+  float* y_l = o_l + MG * kWTile;                             // [MG][16][kWLD] normalised rows
+  float* st_l = y_l + MG * kWTile;                            // [MG][16 points][8 waves][2] LayerNorm partials
+  float* Ol = st_l + MG * 16 * 16;                            // [2 slots][MG * 16][Kmax+1] per-object maxima
+  int* hist = (int*)(Ol + 2 * MG * 16 * (Kmax + 1));          // [Kmax+1]
+  float* e_l = (float*)(hist + ((Kmax + 1 + 3) & ~3));        // [QT][16][kWLD] mask embeddings (tile h is wave h's alone)
+  float* tiles = e_l + QT * kWTile;                           // [2 slots][MG][16][kWLD] src + posenc rows (not with QC)
+  const DecSampleDev& sm = sample_of_wg(samples, ns);
+  const int lb = blockIdx.x - sm.wg_begin, nwg = sm.wg_end - sm.wg_begin;
+  const int n = sm.n, npairs = (n + 16 * MG - 1) / (16 * MG), nq = sm.nq, K = sm.K, K1 = K + 1;
+  const float* __restrict__ X = layer_input(sm, layer);
+  const float* __restrict__ Pe = sm.posenc;
+  float* __restrict__ Y = (layer & 1) ? sm.bufD : sm.bufC;
+  float* logits = sm.logits + (size_t)layer * n * K1;
+  unsigned char* labels = sm.labels;
+  int* counts = sm.counts + (size_t)layer * (A3D_MAX_QUERIES + 1);
+  const int tid = threadIdx.x, lane = tid & 63, h = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = lane >> 4, j = lane & 15;
+  for (int e = tid; e <= K; e += 512) hist[e] = 0;
+  // ---- the wave's constants
+  f32x4 wq[8], wo[8];
+  f32x4 bq4 = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int S = 0; S < 8; ++S) {
+    if constexpr (!QC) wq[S] = ((const f32x4 A3D_GLOBAL*)Wq)[(S * 8 + h) * 64 + lane];
+    wo[S] = ((const f32x4 A3D_GLOBAL*)Wo)[(S * 8 + h) * 64 + lane];
+  }
+  if constexpr (!QC) bq4 = gld4(bq + 16 * h + 4 * g);
+  const f32x4 bo4 = gld4(bo + 16 * h + 4 * g), ga4 = gld4(gamma + 16 * h + 4 * g), be4 = gld4(beta + 16 * h + 4 * g);
+  const int nqt = sm.nqt;
+  f32x4 kf[QT], vf[QT];
+#pragma unroll
+  for (int kt = 0; kt < QT; ++kt) {
+    kf[kt] = vf[kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (kt < nqt) {
+      kf[kt] = gld4(sm.ks + (size_t)(kt * 16 + j) * D + 16 * h + 4 * g);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) vf[kt][t] = gld(sm.vs + (size_t)(kt * 16 + 4 * g + t) * D + 16 * h + j);
+    }
+  }
+  f32x4 sbL;
+#pragma unroll
+  for (int t = 0; t < 4; ++t) sbL[t] = (nqt - 1) * 16 + 4 * g + t < nq ? 0.f : kNegBig;
+  const int oq = h < nqt ? gld(sm.qobj + h * 16 + j) : -1;   // the object of query 16 h + j (mask embeddings of query tile h)
+  if (h < nqt) {
+#pragma unroll
+    for (int S = 0; S < 8; ++S) *(f32x4*)(e_l + (h * 16 + j) * kWLD + 16 * S + 4 * g) = gld4(sm.E + (size_t)(h * 16 + j) * D + 16 * S + 4 * g);
+  }
+  // ---- staging: thread -> (row lr, float4 column lc) of each of the pair's tiles
+  const int lr = tid >> 5, lc = (tid & 31) * 4;
+  f32x4 rx[MG], rp[MG];
+  auto issue = [&](int pr) {
+#pragma unroll
+    for (int mg = 0; mg < MG; ++mg) {
+      const size_t row = (size_t)min((pr * MG + mg) * 16 + lr, n - 1);
+      rx[mg] = gld4(X + row * D + lc);
+      rp[mg] = gld4(Pe + row * D + lc);
+    }
+  };
+  auto commit = [&](int slot) {
+#pragma unroll
+    for (int mg = 0; mg < MG; ++mg) *(f32x4*)(tiles + (slot * MG + mg) * kWTile + lr * kWLD + lc) = rx[mg] + rp[mg];
+  };
+  int pr = lb;
+  if constexpr (!QC) {
+    if (pr < npairs) {
+      issue(pr);
+      commit(0);
+    }
+  }
+  __syncthreads();
+  for (int it = 0; pr < npairs; ++it, pr += nwg) {
+    const int p0 = pr * MG * 16;
+    const int next = pr + nwg;
+    const bool has_next = next < npairs;
+    float* Oc = Ol + (it & 1) * MG * 16 * K1;
+    for (int e = tid; e < MG * 16 * K1; e += 512) Oc[e] = -3.4e38f;
+    // ---- scene-to-click attention of head h, one group after the other; O_h into the pair's LDS tiles
+    f32x4 res[MG];
+#pragma unroll
+    for (int mg = 0; mg < MG; ++mg) {
+      f32x4 qf;
+      if constexpr (QC) {
+        const size_t row = (size_t)min(p0 + mg * 16 + j, n - 1);
+        qf = gld4(sm.q0 + row * D + 16 * h + 4 * g);
+        res[mg] = gld4(X + row * D + 16 * h + 4 * g);
+      } else {
+        const float* tx = tiles + ((it & 1) * MG + mg) * kWTile + j * kWLD + 4 * g;
+        f32x4 q0 = bq4, q1 = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int S = 0; S < 8; S += 2) {
+          const f32x4 xa = *(const f32x4*)(tx + 16 * S), xb = *(const f32x4*)(tx + 16 * (S + 1));
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            q0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wq[S][t], xa[t], q0, 0, 0, 0);
+            q1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wq[S + 1][t], xb[t], q1, 0, 0, 0);
+          }
+        }
+        qf = q0 + q1;
+      }
+      f32x4 sc[QT + 1];
+      float mx = kNegBig;
+#pragma unroll
+      for (int kt = 0; kt < QT; kt += 2) {
+        if (kt < nqt) {
+          sc[kt] = sc[kt + 1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+          const f32x4 kb = kt + 1 < QT ? kf[kt + 1] : (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            sc[kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[kt][t], qf[t], sc[kt], 0, 0, 0);
+            sc[kt + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(kb[t], qf[t], sc[kt + 1], 0, 0, 0);
+          }
+          if (kt + 2 >= nqt) {
+            if (kt + 1 == nqt) {
+              sc[kt] += sbL;
+              sc[kt + 1] = (f32x4){kNegBig, kNegBig, kNegBig, kNegBig};
+            } else {
+              sc[kt + 1] += sbL;
+            }
+          }
+          mx = fmaxf(mx, fmaxf(fmaxf(sc[kt][0], sc[kt][1]), fmaxf(sc[kt][2], sc[kt][3])));
+          mx = fmaxf(mx, fmaxf(fmaxf(sc[kt + 1][0], sc[kt + 1][1]), fmaxf(sc[kt + 1][2], sc[kt + 1][3])));
+        }
+      }
+      mx = rows_max(mx);
+      float sum = 0.f;
+      f32x4 a0 = (f32x4){0.f, 0.f, 0.f, 0.f}, a1 = a0;
+#pragma unroll
+      for (int kt = 0; kt < QT; kt += 2) {
+        if (kt < nqt) {
+          const f32x4 vb = kt + 1 < QT ? vf[kt + 1] : (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            sc[kt][t] = exp2_fast(sc[kt][t] - mx);
+            sc[kt + 1][t] = exp2_fast(sc[kt + 1][t] - mx);
+          }
+          sum += ((sc[kt][0] + sc[kt][1]) + (sc[kt][2] + sc[kt][3])) + ((sc[kt + 1][0] + sc[kt + 1][1]) + (sc[kt + 1][2] + sc[kt + 1][3]));
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(vf[kt][t], sc[kt][t], a0, 0, 0, 0);
+            a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(vb[t], sc[kt + 1][t], a1, 0, 0, 0);
+          }
+        }
+      }
+      sum = rows_sum(sum);
+      *(f32x4*)(o_l + mg * kWTile + j * kWLD + 16 * h + 4 * g) = (a0 + a1) * __builtin_amdgcn_rcpf(sum);   // O[point j][16h+4g..+3]
+    }
+    __syncthreads();                                                       // (0) the eight heads' outputs of both groups
+    if constexpr (!QC) {
+      if (has_next) issue(next);      // in flight behind the output half (ahead of the attention they would cost it 16 registers)
+    }
+    // ---- output projection (tile h) + residual, LayerNorm, mask head: k_out_w's
+    f32x4 y[MG];
+    {
+      f32x4 ya[MG], yb[MG];
+#pragma unroll
+      for (int mg = 0; mg < MG; ++mg) {
+        if constexpr (!QC) res[mg] = gld4(X + (size_t)min(p0 + mg * 16 + j, n - 1) * D + 16 * h + 4 * g);   // the residual (an L2 hit)
+        ya[mg] = bo4;
+        yb[mg] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      }
+      const float* to = o_l + j * kWLD + 4 * g;
+#pragma unroll
+      for (int S = 0; S < 8; S += 2) {
+        f32x4 oa[MG], ob[MG];
+#pragma unroll
+        for (int mg = 0; mg < MG; ++mg) {
+          oa[mg] = *(const f32x4*)(to + mg * kWTile + 16 * S);
+          ob[mg] = *(const f32x4*)(to + mg * kWTile + 16 * (S + 1));
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+          for (int mg = 0; mg < MG; ++mg) {
+            ya[mg] = __builtin_amdgcn_mfma_f32_16x16x4f32(wo[S][t], oa[mg][t], ya[mg], 0, 0, 0);
+            yb[mg] = __builtin_amdgcn_mfma_f32_16x16x4f32(wo[S + 1][t], ob[mg][t], yb[mg], 0, 0, 0);
+          }
+      }
+#pragma unroll
+      for (int mg = 0; mg < MG; ++mg) y[mg] = (ya[mg] + yb[mg]) + res[mg];
+    }
+#pragma unroll
+    for (int mg = 0; mg < MG; ++mg) {
+      const float mw = rows_sum((y[mg][0] + y[mg][1]) + (y[mg][2] + y[mg][3])) * (1.f / 16.f);
+      float m2 = 0.f;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) m2 += (y[mg][t] - mw) * (y[mg][t] - mw);
+      m2 = rows_sum(m2);
+      if (g == 0) *(float2*)(st_l + mg * 256 + (j * 8 + h) * 2) = make_float2(mw, m2);
+    }
+    __syncthreads();                                                       // (1) statistics
+#pragma unroll
+    for (int mg = 0; mg < MG; ++mg) {
+      f32x4 s4[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) s4[u] = *(const f32x4*)(st_l + mg * 256 + j * 16 + 4 * u);
+      float mean = 0.f;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) mean += s4[u][0] + s4[u][2];
+      mean *= 0.125f;
+      float var = 0.f;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const float d0 = s4[u][0] - mean, d1 = s4[u][2] - mean;
+        var += (s4[u][1] + s4[u][3]) + 16.f * (d0 * d0 + d1 * d1);
+      }
+      const float rstd = rsqrtf(var * (1.f / D) + kLnEps);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) y[mg][t] = (y[mg][t] - mean) * rstd * ga4[t] + be4[t];
+      const int row = p0 + mg * 16 + j;
+      if (row < n) gst4(Y + (size_t)row * D + 16 * h + 4 * g, y[mg]);
+      *(f32x4*)(y_l + mg * kWTile + j * kWLD + 16 * h + 4 * g) = y[mg];
+    }
+    __syncthreads();                                                       // (2) normalised rows
+    if (h < nqt) {
+      const float* ty = y_l + j * kWLD + 4 * g;
+      const float* te = e_l + (h * 16 + j) * kWLD + 4 * g;
+      f32x4 la[MG], lc2[MG];
+#pragma unroll
+      for (int mg = 0; mg < MG; ++mg) la[mg] = lc2[mg] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int S = 0; S < 8; S += 2) {
+        f32x4 ya[MG], yb[MG];
+        const f32x4 ea = *(const f32x4*)(te + 16 * S), eb = *(const f32x4*)(te + 16 * (S + 1));
+#pragma unroll
+        for (int mg = 0; mg < MG; ++mg) {
+          ya[mg] = *(const f32x4*)(ty + mg * kWTile + 16 * S);
+          yb[mg] = *(const f32x4*)(ty + mg * kWTile + 16 * (S + 1));
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+          for (int mg = 0; mg < MG; ++mg) {
+            la[mg] = __builtin_amdgcn_mfma_f32_16x16x4f32(ya[mg][t], ea[t], la[mg], 0, 0, 0);
+            lc2[mg] = __builtin_amdgcn_mfma_f32_16x16x4f32(yb[mg][t], eb[t], lc2[mg], 0, 0, 0);
+          }
+      }
+      if (oq >= 0) {
+#pragma unroll
+        for (int mg = 0; mg < MG; ++mg) {
+          const f32x4 lg = la[mg] + lc2[mg];
+#pragma unroll
+          for (int t = 0; t < 4; ++t)
+            __builtin_amdgcn_ds_fmaxf((lds_float*)(Oc + (mg * 16 + 4 * g + t) * K1 + oq), lg[t], 0, 0, false);
+        }
+      }
+    }
+    if constexpr (!QC) {
+      if (has_next) commit((it + 1) & 1);
+    }
+    __syncthreads();                                                       // (3) per-object maxima (and the next pair's rows)
+    if (tid < MG * 16 && p0 + tid < n) {
+      float best = Oc[tid * K1];
+      int bi = 0;
+      for (int o = 1; o <= K; ++o) {
+        const float v = Oc[tid * K1 + o];
+        if (v > best) {
+          best = v;
+          bi = o;
+        }
+      }
+      gst(labels + p0 + tid, (unsigned char)bi);
+      atomicAdd(&hist[bi], 1);
+    }
+    const int rows = min(MG * 16, n - p0);
+    for (int e = tid; e < rows * K1; e += 512) gst(logits + (size_t)p0 * K1 + e, Oc[e]);
+  }
+  __syncthreads();
+  for (int e = tid; e <= K; e += 512)
+    if (hist[e]) atomicAdd(&counts[e], hist[e]);
+}

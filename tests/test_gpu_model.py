@@ -543,11 +543,12 @@ def test_outdoor_scan_size_stress(model_and_sd):
     assert err <= 1e-4
 
 
-@pytest.mark.parametrize("switch", ["A3D_FUSED_C2S=0", "A3D_WIDE_FROM=65"])
+@pytest.mark.parametrize("switch", ["A3D_FUSED_C2S=0", "A3D_WIDE_FROM=65", "A3D_FUSED_S2O=0"])
 def test_unfused_decoder_path_still_matches_goldens(switch):
     """The decoder's other LIVE paths against the reference's goldens: A3D_FUSED_C2S=0 keeps the separate projection GEMMs +
     attention kernels at every query count (what 225 .. 256 queries run anyway); A3D_WIDE_FROM=65 keeps k_q_s2c +
-    k_out_ln_mask for 33 .. 64 queries, which the wide tier serves by default.  The library reads the
+    k_out_ln_mask for 33 .. 64 queries, which the wide tier serves by default; A3D_FUSED_S2O=0 runs k_s2c_w + k_out_w
+    instead of the one-kernel scene-to-click half (k_s2o_w) at 33 .. 80 queries.  The library reads the
     variables once per process, hence the subprocess."""
     import os
     import subprocess
