@@ -488,3 +488,25 @@ def linear_weight_grad(x, dy):
     L.check(lib.a3d_linear_wgrad(_ptr(x), cin, _ptr(dy), cout, n, cin, cout, _ptr(dw), _ptr(ws), nbytes, _stream()),
             "a3d_linear_wgrad")
     return dw
+
+
+def linear_weight_grad_into(x, dy, dw, transposed=True, accumulate=False, db=None, db_accumulate=False):
+    """x^T dy written (or added) into ``dw`` -- a contiguous [Cout, Cin] block (``transposed``: nn.Linear.weight's layout, e.g. a
+    row slice of an in_proj matrix) or [Cin, Cout] -- and, with ``db`` [Cout], the bias gradient (column sums of dy) from the
+    same pass over dy: a3d_linear_wgrad_into."""
+    lib = L.load()
+    x, dy = x.contiguous(), dy.contiguous()
+    n, cin = x.shape
+    cout = dy.shape[1]
+    want = (cout, cin) if transposed else (cin, cout)
+    if tuple(dw.shape) != want or not dw.is_contiguous() or dw.dtype != torch.float32 or dy.shape[0] != n:
+        raise ValueError(f"linear_weight_grad_into: dw must be a contiguous fp32 {want} block")
+    if db is not None and (tuple(db.shape) != (cout,) or not db.is_contiguous() or db.dtype != torch.float32):
+        raise ValueError("linear_weight_grad_into: db must be a contiguous fp32 [Cout] vector")
+    nbytes = lib.a3d_linear_wgrad_into_workspace_bytes(n, cin, cout)
+    if nbytes == 0:
+        raise L.A3DError(lib.a3d_last_error().decode())
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+    L.check(lib.a3d_linear_wgrad_into(_ptr(x), cin, _ptr(dy), cout, n, cin, cout, _ptr(dw), want[1], 1 if transposed else 0,
+                                      1 if accumulate else 0, _ptr(db) if db is not None else None, 1 if db_accumulate else 0,
+                                      _ptr(ws), nbytes, _stream()), "a3d_linear_wgrad_into")

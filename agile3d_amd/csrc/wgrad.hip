@@ -35,6 +35,7 @@ struct WgradArgs {
   int chunk_groups;      // 16-position groups per chunk
   int n_chunks;
   float* part;           // [chunks][K][cin][cout]
+  float* bias_part;      // BIAS builds (K = 1): [chunks][cout] column sums of dy, the bias gradient of an nn.Linear
 };
 
 template <int C>
@@ -60,7 +61,7 @@ __device__ __forceinline__ void load_c(const float* p, bool ok, float (&v)[C]) {
   }
 }
 
-template <int CX, int CY>
+template <int CX, int CY, bool BIAS = false>
 __global__ void __launch_bounds__(256) k_wgrad(const WgradArgs a) {
   extern __shared__ __attribute__((aligned(16))) float fold[];   // [16 CX][16 CY] block of dW, waves fold in order
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -102,6 +103,9 @@ __global__ void __launch_bounds__(256) k_wgrad(const WgradArgs a) {
     }
   };
   float xv[CX], yv[CY], x1[CX], y1[CY], x2[CX], y2[CY];
+  float ys[CY];          // BIAS: this lane's column sums of the dy rows it multiplies (rows without a pair load zeros)
+#pragma unroll
+  for (int i = 0; i < CY; ++i) ys[i] = 0.f;
   auto load_rows = [&](int xi, int yi, int s, float (&xd)[CX], float (&yd)[CY]) {   // rows of positions 4s .. 4s+3
     const int xr = __shfl(xi, 4 * s + g, 16), yr = __shfl(yi, 4 * s + g, 16);
     const bool ok = xr < a.n_in && yr < a.n_out;
@@ -130,6 +134,10 @@ __global__ void __launch_bounds__(256) k_wgrad(const WgradArgs a) {
       // two steps ahead (2 waves per SIMD do not cover a row fetch with one step of MFMAs): rows of step s+2 of this
       // group, or of the next group's first steps; past the end it re-reads rows that are never multiplied
       load_rows(s < 2 ? xi : xi_n, s < 2 ? yi : yi_n, (s + 2) & 3, x2, y2);
+      if constexpr (BIAS) {
+#pragma unroll
+        for (int i = 0; i < CY; ++i) ys[i] += yv[i];
+      }
 #pragma unroll
       for (int tx = 0; tx < CX; ++tx)
 #pragma unroll
@@ -157,6 +165,26 @@ __global__ void __launch_bounds__(256) k_wgrad(const WgradArgs a) {
   constexpr int TILE4 = CX * CY * 64;   // f32x4 per block
   f32x4* P = (f32x4*)a.part + (((size_t)chunk * a.K + k) * gridDim.z + blockIdx.z) * TILE4;
   for (int e = threadIdx.x; e < TILE4; e += 256) P[e] = fold4[e];
+  if constexpr (BIAS) {
+    // the chunk's column sums of dy (the input-channel block 0 writes them): the lane's rows, then the four row lanes g,
+    // then the four waves in wave order -- a fixed order like the weights'
+    if (bx != 0) return;
+#pragma unroll
+    for (int i = 0; i < CY; ++i) {
+      ys[i] += __shfl_xor(ys[i], 16, 64);
+      ys[i] += __shfl_xor(ys[i], 32, 64);
+    }
+    __syncthreads();
+    if (g == 0) {
+#pragma unroll
+      for (int i = 0; i < CY; ++i) fold[wave * 16 * CY + CY * j + i] = ys[i];
+    }
+    __syncthreads();
+    if (threadIdx.x < 16 * CY) {
+      const int t = threadIdx.x;
+      a.bias_part[(size_t)chunk * a.cout + by * 16 * CY + t] = ((fold[t] + fold[16 * CY + t]) + fold[32 * CY + t]) + fold[48 * CY + t];
+    }
+  }
 }
 
 // dw[k][ci][co] = sum over chunks of the fragment-layout partials: element e of a block is
@@ -188,6 +216,43 @@ __global__ void __launch_bounds__(64 * kRedLanes) k_wgrad_reduce(const float* __
   const int ci = (blk % nbx) * 16 * cx + cx * (4 * g + r) + tx;
   const int co = (blk / nbx) * 16 * cy + cy * j + ty;
   dw[((size_t)k * cin + ci) * cout + co] = s;
+}
+
+// the same sum for an nn.Linear's gradients with the destination's layout as arguments (a3d_linear_wgrad_into): dW written
+// as [cin][cout] or transposed ([cout][cin]: nn.Linear.weight's own layout) with leading dimension `ld`, assigned or
+// ADDED to what is there; elements past the weights are the bias gradient (column sums of dy over the chunks)
+__global__ void __launch_bounds__(64 * kRedLanes) k_wgrad_reduce_into(const float* __restrict__ part, const float* __restrict__ bias_part,
+                                                                      int nchunk, int cin, int cout, int cx, int cy, float* dw, int ld,
+                                                                      int transposed, int accumulate, float* db, int db_accumulate) {
+  __shared__ float sh[kRedLanes][64];
+  const int total = cin * cout;
+  const int el = threadIdx.x & 63, p = threadIdx.x >> 6;
+  const int e = blockIdx.x * 64 + el;
+  const int all = total + (db ? cout : 0);
+  float s = 0.f;
+  if (e < total) {
+    for (int c = p; c < nchunk; c += kRedLanes) s += part[(size_t)c * total + e];
+  } else if (e < all) {
+    for (int c = p; c < nchunk; c += kRedLanes) s += bias_part[(size_t)c * cout + (e - total)];
+  }
+  sh[p][el] = s;
+  __syncthreads();
+  if (p != 0 || e >= all) return;
+#pragma unroll
+  for (int q = 1; q < kRedLanes; ++q) s += sh[q][el];
+  if (e >= total) {
+    float* d = db + (e - total);
+    *d = db_accumulate ? *d + s : s;
+    return;
+  }
+  const int block_elems = 16 * cx * 16 * cy, nbx = cin / (16 * cx);
+  const int blk = e / block_elems, in_blk = e % block_elems;
+  const int tile = in_blk / 256, lane = (in_blk % 256) / 4, r = in_blk & 3;
+  const int tx = tile / cy, ty = tile % cy, g = lane >> 4, j = lane & 15;
+  const int ci = (blk % nbx) * 16 * cx + cx * (4 * g + r) + tx;
+  const int co = (blk / nbx) * 16 * cy + cy * j + ty;
+  float* d = dw + (transposed ? (size_t)co * ld + ci : (size_t)ci * ld + co);
+  *d = accumulate ? *d + s : s;
 }
 
 struct WgradPlan {
@@ -453,6 +518,63 @@ extern "C" int a3d_linear_wgrad(const float* x_dev, int ldx, const float* dy_dev
   A3D_LAUNCH_CHECK();
   k_wgrad_reduce<<<(unsigned)(((size_t)cin * cout + 63) / 64), 64 * kRedLanes, 0, st>>>(a.part, p.chunks, 1, cin, cout, p.cx, p.cy,
                                                                                         dw_dev);
+  A3D_LAUNCH_CHECK();
+  return A3D_OK;
+}
+
+// the same gradient written where the caller keeps it: dW as [cin][cout] or [cout][cin] (transposed = 1, nn.Linear.weight's
+// layout; a row slice of a packed in_proj matrix is such a block at an offset) with leading dimension ld_dw, assigned or
+// added (accumulate); db_dev != nullptr: the bias gradient (column sums of dy) from the SAME pass over dy -- what took a
+// transposing copy, a zero-filled full-size matrix + slice copy + add per in_proj slice and two column-sum launches per layer
+extern "C" size_t a3d_linear_wgrad_into_workspace_bytes(int64_t n, int cin, int cout) {
+  WgradPlan p;
+  if (n <= 0 || n > (int64_t)1 << 30 || !wgrad_plan((int)n, 1, cin, cout, p)) {
+    set_error("a3d_linear_wgrad_into: channels must be multiples of 32 (got %d -> %d)", cin, cout);
+    return 0;
+  }
+  return align256(p.part_bytes) + align256((size_t)p.chunks * cout * sizeof(float)) + 256;
+}
+extern "C" int a3d_linear_wgrad_into(const float* x_dev, int ldx, const float* dy_dev, int ldy, int64_t n, int cin, int cout,
+                                     float* dw_dev, int ld_dw, int transposed, int accumulate, float* db_dev, int db_accumulate,
+                                     void* workspace_dev, size_t workspace_bytes, void* stream) {
+  WgradPlan p;
+  if (!x_dev || !dy_dev || !dw_dev || !workspace_dev || n <= 0 || n > (int64_t)1 << 30 || ldx < cin || ldy < cout ||
+      (ldx & 1) || (ldy & 1) || ld_dw < (transposed ? cin : cout) || !wgrad_plan((int)n, 1, cin, cout, p)) {
+    set_error("a3d_linear_wgrad_into: bad arguments (channels multiples of 32, even leading dimensions, ld_dw >= row length)");
+    return A3D_ERR_INVALID;
+  }
+  if (workspace_bytes < a3d_linear_wgrad_into_workspace_bytes(n, cin, cout) - 256 || ((uintptr_t)workspace_dev & 15)) {
+    set_error("a3d_linear_wgrad_into: workspace too small or misaligned");
+    return A3D_ERR_WORKSPACE;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  WgradArgs a;
+  memset(&a, 0, sizeof(a));
+  a.x = x_dev, a.dy = dy_dev, a.ldx = ldx, a.ldy = ldy, a.cin = cin, a.cout = cout;
+  a.K = 1, a.n_in = a.n_out = a.n_pos = (int)n;
+  a.chunk_groups = p.chunk_groups;
+  a.n_chunks = p.chunks;
+  a.part = (float*)workspace_dev;
+  a.bias_part = (float*)((char*)workspace_dev + align256(p.part_bytes));
+  const dim3 grid((unsigned)((p.chunks + 7) / 8 * 8), 1, p.nblocks);
+  const size_t lds = (size_t)16 * p.cx * 16 * p.cy * sizeof(float);
+#define A3D_WG(CX_, CY_)                                                                                          \
+  if (p.cx == CX_ && p.cy == CY_) {                                                                               \
+    A3D_ALLOW_LDS(64 * 1024, (k_wgrad<CX_, CY_, true>));                                                           \
+    A3D_ALLOW_LDS(64 * 1024, (k_wgrad<CX_, CY_, false>));                                                          \
+    if (db_dev) k_wgrad<CX_, CY_, true><<<grid, 256, lds, st>>>(a);                                                \
+    else k_wgrad<CX_, CY_, false><<<grid, 256, lds, st>>>(a);                                                      \
+  } else
+  A3D_WG(2, 2) A3D_WG(2, 4) A3D_WG(2, 6) A3D_WG(2, 8) A3D_WG(4, 2) A3D_WG(4, 4) A3D_WG(4, 6) A3D_WG(4, 8)
+  A3D_WG(6, 2) A3D_WG(6, 4) A3D_WG(6, 6) A3D_WG(8, 2) A3D_WG(8, 4) {
+    set_error("a3d_linear_wgrad_into: no kernel for %d x %d channels per lane", p.cx, p.cy);
+    return A3D_ERR_UNSUPPORTED;
+  }
+#undef A3D_WG
+  A3D_LAUNCH_CHECK();
+  const int all = cin * cout + (db_dev ? cout : 0);
+  k_wgrad_reduce_into<<<(unsigned)((all + 63) / 64), 64 * kRedLanes, 0, st>>>(a.part, a.bias_part, p.chunks, cin, cout, p.cx, p.cy, dw_dev,
+                                                                            ld_dw, transposed, accumulate, db_dev, db_accumulate);
   A3D_LAUNCH_CHECK();
   return A3D_OK;
 }

@@ -169,6 +169,9 @@ SYMBOLS = {
     "a3d_linear_wgrad_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int, C.c_int]),
     "a3d_linear_wgrad": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_void_p,
                                    C.c_void_p, C.c_size_t, C.c_void_p]),
+    "a3d_linear_wgrad_into_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int, C.c_int]),
+    "a3d_linear_wgrad_into": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_int,
+                                        C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
     "a3d_attn_scores": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_float, C.c_void_p,
                                   C.c_void_p, C.c_void_p]),
     "a3d_softmax_rows": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]),

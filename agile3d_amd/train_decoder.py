@@ -155,14 +155,6 @@ def _apply(P, V, Lq, Lk, Hh, dh, transposed, scale, out):
             "a3d_attn_apply")
 
 
-def _col_sums(dy):
-    """bias gradient: column sums for any channel count (the kernel takes 128-column slices)."""
-    n, c = dy.shape
-    if c <= 384 and 768 % c == 0 and c % 32 == 0:
-        return B.column_sums(dy)
-    return torch.cat([B.column_sums(dy[:, i:i + 128].contiguous()) for i in range(0, c, 128)])
-
-
 class DecoderPacks:
     """Packed weights of the decoder's nn.Linear layers for the training tape, both orientations: entry (name, row slice) ->
     (forward pack of W^T [in, out], backward pack of W [out, in]).  Keyed on the parameter's version, the
@@ -239,7 +231,7 @@ class DecoderTape:
             raise RuntimeError("DecoderTape runs on the GPU only")
         self.model = model
         self.P = dict(model.named_parameters())
-        self.steps, self.grads, self._packed = [], {}, {}
+        self.steps, self.grads, self._packed, self._grad_written = [], {}, {}, set()
         self.relu_masks, self.attn_masks, self.args = [], [], []      # what a reference needs to follow the same branch
         self._group_tabs = {}
         self._forward([p.to(torch.float32).contiguous() for p in pcd_features],
@@ -249,6 +241,19 @@ class DecoderTape:
     def _pg(self, name, g):
         g = g.reshape(self.P[name].shape)
         self.grads[name] = g if name not in self.grads else self.grads[name] + g
+
+    def _grad_block(self, name, rows):
+        """The block of parameter ``name``'s gradient an nn.Linear writes (all of it, or the row slice ``rows`` of a packed in_proj
+        parameter) and whether this is its first contribution of the backward pass (-> assigned, not added).  A sliced
+        parameter starts as zeros: a slice nothing flows to keeps a zero gradient."""
+        g = self.grads.get(name)
+        if g is None:
+            P = self.P[name]
+            g = self.grads[name] = torch.zeros_like(P) if rows is not None else torch.empty_like(P)
+        key = (name, rows)
+        first = key not in self._grad_written
+        self._grad_written.add(key)
+        return (g if rows is None else g[rows[0]:rows[1]]), first
 
     def add(self, a: _T, b: _T) -> _T:
         if a.needs_grad and not b.needs_grad:
@@ -291,19 +296,12 @@ class DecoderTape:
                 _linear(dy, bwd_w, acc=x.g)                              # x.g += dy @ W in the GEMM's epilogue (no [N, 128] add)
             elif x.needs_grad:
                 x.add_grad(_linear(dy, bwd_w), fresh=True)               # dy @ W
-            dW = B.linear_weight_grad(x.v, dy).t()                        # [out, in]
-            if rows is None:
-                self._pg(wname, dW)
-                if bname:
-                    self._pg(bname, _col_sums(dy))
-            else:                                                          # slice of the packed in_proj parameters
-                full = torch.zeros_like(self.P[wname])
-                full[rows[0]:rows[1]] = dW
-                self._pg(wname, full)
-                if bname:
-                    fb = torch.zeros_like(self.P[bname])
-                    fb[rows[0]:rows[1]] = _col_sums(dy)
-                    self._pg(bname, fb)
+            # dW [out, in] and the bias gradient from ONE pass over dy, written (a parameter's / slice's first contribution) or
+            # added where the tape keeps the parameter's gradient: no transposing copy, no zero-filled full-size matrix + slice
+            # copy + add per in_proj slice, no column-sum launches
+            gw, first_w = self._grad_block(wname, rows)
+            gb, first_b = self._grad_block(bname, rows) if bname else (None, True)
+            B.linear_weight_grad_into(x.v, dy, gw, transposed=True, accumulate=not first_w, db=gb, db_accumulate=not first_b)
             if res is not None:
                 # last, when nothing reads dy any more: a gradient this node owned exclusively passes to the residual WITH its
                 # ownership, so what arrives there later is added in place / in a GEMM epilogue (no copy-add over [N, 128])
@@ -634,7 +632,7 @@ class DecoderTape:
         """``d_logits``: dL/dlogits per decoder layer -- one [N, 1+K] tensor per layer for a single-sample tape, a list over
         the samples per layer for a batched one (None = no loss there).  Returns (gradients keyed like state_dict(),
         dL/d(pcd_features) [N_total, 128])."""
-        self.grads = {}
+        self.grads, self._grad_written = {}, set()
         for nodes, g in zip(self.logits_nodes, d_logits):
             gs = [g] if self._single else list(g)
             for node, gg in zip(nodes, gs):

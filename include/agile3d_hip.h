@@ -329,6 +329,15 @@ int    a3d_layernorm_backward(const float* x_dev, int ldx, const float* dy_dev, 
 size_t a3d_linear_wgrad_workspace_bytes(int64_t n, int cin, int cout);
 int    a3d_linear_wgrad(const float* x_dev, int ldx, const float* dy_dev, int ldy, int64_t n, int cin, int cout,
                         float* dw_dev, void* workspace_dev, size_t workspace_bytes, void* stream);
+/* The same gradient written where the caller accumulates it (what autograd's AccumulateGrad does for an nn.Linear of
+ * attention_block.py / agile3d.py:51-55): dW as [cin][cout] (transposed = 0) or [cout][cin] (transposed = 1: nn.Linear.weight's
+ * layout; a row slice of nn.MultiheadAttention's packed in_proj_weight is such a block at an offset) with leading dimension
+ * ld_dw, assigned (accumulate = 0) or added; db_dev != NULL: the bias gradient, the column sums of dy, from the same pass over
+ * dy, assigned or added (db_accumulate) */
+size_t a3d_linear_wgrad_into_workspace_bytes(int64_t n, int cin, int cout);
+int    a3d_linear_wgrad_into(const float* x_dev, int ldx, const float* dy_dev, int ldy, int64_t n, int cin, int cout,
+                             float* dw_dev, int ld_dw, int transposed, int accumulate, float* db_dev, int db_accumulate,
+                             void* workspace_dev, size_t workspace_bytes, void* stream);
 
 /* Attention and mask-head primitives with their backward (training path of the decoder; the inference path uses the
  * fused kernels behind a3d_decoder_forward).  nn.MultiheadAttention (attention_block.py) = scores -> softmax -> apply
