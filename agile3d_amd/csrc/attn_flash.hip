@@ -13,8 +13,8 @@
 // points, 8 waves = the 8 heads of the same chunk; a workgroup walks chunks wg, wg + G, ...  Reductions over the N points
 // (dQ of click-to-scene, dK / dV of scene-to-click) add up per workgroup in its own slab (sequential read-modify-write)
 // and a two-level reduction adds the <= 256 slabs in a fixed order: deterministic.
-// The scores need each tile in two register layouts (rows x columns and columns x rows, because an MFMA contracts over
-// the lane-group index of BOTH operands): they are simply computed twice -- 8 of the 28 MFMAs per tile.
+// dS is needed in two register layouts (rows x columns and columns x rows, because an MFMA contracts over the lane-group
+// index of BOTH operands): the backward kernels compute it once and transpose it through a wave-private LDS tile.
 #include "common.h"
 
 namespace a3d {
@@ -219,11 +219,22 @@ __global__ void k_fl_rowdot(const float* __restrict__ dO, const float* __restric
 // across the query tiles (they were re-loaded per tile and group: fourteen dependent loads in front of every 28 MFMAs -- the
 // kernel ran at a tenth of the matrix rate), the query side of the NEXT tile and the mask words of all four groups are
 // requested before the current tile's products, mask bytes come four to a load, exp is one v_exp_f32.
-struct FlQSide {   // one query tile as a lane sees it: as a COLUMN (keys x queries: query j) and as four ROWS (queries 4g+t)
+struct FlQSide {   // one query tile as a lane sees it: query j's row fragments, and queries 4g+t: statistics + transposed columns
   f32x4 qf, dof;
-  float mj, rlj, Dj;
   float mq[4], rlq[4], Dq[4], qT[4], doT[4];
 };
+// dS of a 16 x 16 tile from the (rows 4g+t, column j) layout the products over the ROWS need into the (columns 4g+t, row j)
+// layout the product over the COLUMNS needs, through a wave-private LDS tile (a wave's LDS instructions execute in order:
+// no barrier).  The first build computed the scores and dP a second time in the other layout instead: 8 of its 28 MFMAs
+// per tile, a second set of exponentials, masks and statistics.
+constexpr int kFlTLd = 20;          // row stride of the tile in floats: 16-byte aligned rows, conflict-free column writes
+__device__ __forceinline__ f32x4 fl_transpose(float* tile, const f32x4& v, int g, int j) {
+#pragma unroll
+  for (int t = 0; t < 4; ++t) tile[(4 * g + t) * kFlTLd + j] = v[t];
+  __builtin_amdgcn_wave_barrier();
+  asm volatile("" ::: "memory");
+  return *(const f32x4*)(tile + j * kFlTLd + 4 * g);
+}
 __global__ void __launch_bounds__(512) k_fl_c2s_bwd(const float* __restrict__ qs, const float* __restrict__ K,
                                                     const float* __restrict__ V, const unsigned char* __restrict__ mask,
                                                     int Lq, int Lk, const float* __restrict__ stats,
@@ -238,12 +249,9 @@ __global__ void __launch_bounds__(512) k_fl_c2s_bwd(const float* __restrict__ qs
   const float* Ls = stats + (size_t)(FH + h) * Lq;
   const float* Dh = Ds + (size_t)h * Lq;
   auto load_q = [&](int qt, FlQSide& s) {
-    const int qj = qt * 16 + j, qjc = min(qj, Lq - 1);
+    const int qj = qt * 16 + j;
     s.qf = ld4(qs, qj, Lq, h * FDH + 4 * g);                        // q[query j][d 4g+t]
     s.dof = ld4(dO, qj, Lq, h * FDH + 4 * g);                       // dO[query j][d 4g+t]
-    s.mj = Ms[qjc];
-    s.rlj = 1.f / Ls[qjc];
-    s.Dj = Dh[qjc];
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
       const int qr = min(qt * 16 + 4 * g + t, Lq - 1);
@@ -254,6 +262,7 @@ __global__ void __launch_bounds__(512) k_fl_c2s_bwd(const float* __restrict__ qs
       s.doT[t] = dO[(size_t)qr * FD + h * FDH + j];
     }
   };
+  __shared__ __attribute__((aligned(16))) float tr_l[FH][NG][16 * kFlTLd];
   bool first = true;
   for (int ch = blockIdx.x; ch < nchunk; ch += gridDim.x, first = false) {
     const int pbeg = ch * kFlChunk;
@@ -271,16 +280,14 @@ __global__ void __launch_bounds__(512) k_fl_c2s_bwd(const float* __restrict__ qs
     load_q(0, qn);
     for (int qt = 0; qt < nqt; ++qt) {
       const FlQSide q = qn;
-      const int qj = qt * 16 + j, qjc = min(qj, Lq - 1);
-      // mask words of the four groups: keys x queries (query j's row, keys 4g..4g+3: one load) and queries x keys (rows of
-      // queries 4g+t, key j: a byte each)
-      unsigned mkq[NG], mqk[NG];
+      const int qj = qt * 16 + j;
+      // mask bytes of the four groups: rows of queries 4g+t, key j
+      unsigned mqk[NG];
 #pragma unroll
       for (int gi = 0; gi < NG; ++gi) {
-        mkq[gi] = mqk[gi] = 0u;
+        mqk[gi] = 0u;
         if (mask) {
           const int p0 = pbeg + gi * 16;
-          mkq[gi] = ld_mask4(mask, (size_t)qjc, p0 + 4 * g, Lk);
           const int pr = min(p0 + j, Lk - 1);
 #pragma unroll
           for (int t = 0; t < 4; ++t)
@@ -292,36 +299,29 @@ __global__ void __launch_bounds__(512) k_fl_c2s_bwd(const float* __restrict__ qs
 #pragma unroll
       for (int gi = 0; gi < NG; ++gi) {
         const int p0 = pbeg + gi * 16;
-        // scores and dP in both layouts
-        f32x4 s_kq = (f32x4){0.f, 0.f, 0.f, 0.f}, s_qk = s_kq, dp_kq = s_kq, dp_qk = s_kq;
+        // scores and dP as [query 4g+t][key j]
+        f32x4 s_qk = (f32x4){0.f, 0.f, 0.f, 0.f}, dp_qk = s_qk;
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-          s_kq = FL_MFMA(kf[gi][t], q.qf[t], s_kq);                 // [key 4g+t][query j]
-          s_qk = FL_MFMA(q.qf[t], kf[gi][t], s_qk);                 // [query 4g+t][key j]
-          dp_kq = FL_MFMA(vr[gi][t], q.dof[t], dp_kq);
+          s_qk = FL_MFMA(q.qf[t], kf[gi][t], s_qk);
           dp_qk = FL_MFMA(q.dof[t], vr[gi][t], dp_qk);
         }
-        f32x4 p_qk, ds_qk, ds_kq;
+        f32x4 p_qk, ds_qk;
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-          {   // keys x queries: key 4g+t, query j
-            const bool blocked = p0 + 4 * g + t >= Lk || qj >= Lq || ((mkq[gi] >> (8 * t)) & 0xffu) != 0u;
-            const float p = blocked ? 0.f : fl_exp(s_kq[t] - q.mj) * q.rlj;
-            ds_kq[t] = p * (dp_kq[t] - q.Dj);
-          }
-          {   // queries x keys: query 4g+t, key j
-            const bool blocked = p0 + j >= Lk || qt * 16 + 4 * g + t >= Lq || ((mqk[gi] >> (8 * t)) & 0xffu) != 0u;
-            const float p = blocked ? 0.f : fl_exp(s_qk[t] - q.mq[t]) * q.rlq[t];
-            p_qk[t] = p;
-            ds_qk[t] = p * (dp_qk[t] - q.Dq[t]);
-          }
+          const bool blocked = p0 + j >= Lk || qt * 16 + 4 * g + t >= Lq || ((mqk[gi] >> (8 * t)) & 0xffu) != 0u;
+          const float p = blocked ? 0.f : fl_exp(s_qk[t] - q.mq[t]) * q.rlq[t];
+          p_qk[t] = p;
+          ds_qk[t] = p * (dp_qk[t] - q.Dq[t]);
         }
+        const f32x4 ds_kq = fl_transpose(tr_l[h][gi], ds_qk, g, j);   // [key 4g+t][query j]
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
           adv[gi] = FL_MFMA(q.doT[t], p_qk[t], adv[gi]);            // dV^T[d][key] += dO^T[d][q] P[q][key]
           adk[gi] = FL_MFMA(q.qT[t], ds_qk[t], adk[gi]);            // dK^T[d][key] += q^T[d][q] dS[q][key]
-          adq = FL_MFMA(kT[gi][t], ds_kq[t], adq);                  // dQ^T[d][query] += K^T[d][key] dS[key][query]
         }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) adq = FL_MFMA(kT[gi][t], ds_kq[t], adq);   // dQ^T[d][query] += K^T[d][key] dS[key][query]
       }
       if (qj < Lq) {
         f32x4* slot = (f32x4*)(dqp + (((size_t)blockIdx.x * FH + h) * Lq + qj) * FDH + 4 * g);
@@ -458,30 +458,31 @@ __global__ void __launch_bounds__(512) k_fl_s2c_bwd(const float* __restrict__ qs
 #pragma unroll
     for (int t = 0; t < 4; ++t) kT_n[t] = K[(size_t)min(kt * 16 + 4 * g + t, Lk - 1) * FD + h * FDH + j];   // A: [d j][key 4g+t]
   };
+  __shared__ __attribute__((aligned(16))) float tr_l[FH][NG][16 * kFlTLd];
   bool first = true;
   for (int ch = blockIdx.x; ch < nchunk; ch += gridDim.x, first = false) {
     const int pbeg = ch * kFlChunk;
     fetch(0);
     // ---- the chunk's point side, once
     f32x4 qf[NG], dof[NG], qT[NG], doT[NG], mp[NG], rlp[NG], Dp[NG], adq[NG];
-    float mj[NG], rlj[NG], Dj[NG];
 #pragma unroll
     for (int gi = 0; gi < NG; ++gi) {
+      float mj, rlj, Dj;
       const int p0 = pbeg + gi * 16;
       const int pj = min(p0 + j, Lq - 1);
       qf[gi] = ld4(qs, p0 + j, Lq, h * FDH + 4 * g);                // q[point j][d 4g+t]
       dof[gi] = ld4(dO, p0 + j, Lq, h * FDH + 4 * g);               // dO[point j][d 4g+t]
       const f32x4 of = ld4(O, p0 + j, Lq, h * FDH + 4 * g);
-      mj[gi] = stats[((size_t)pj * FH + h) * 2];
-      rlj[gi] = 1.f / stats[((size_t)pj * FH + h) * 2 + 1];
+      mj = stats[((size_t)pj * FH + h) * 2];
+      rlj = 1.f / stats[((size_t)pj * FH + h) * 2 + 1];
       float d = dof[gi][0] * of[0] + dof[gi][1] * of[1] + dof[gi][2] * of[2] + dof[gi][3] * of[3];
-      Dj[gi] = fl_rows_sum(d);                                       // sum_d dO[point j][16h+d] O[point j][16h+d]
+      Dj = fl_rows_sum(d);                                           // sum_d dO[point j][16h+d] O[point j][16h+d]
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
         const int src = 4 * g + t;                                   // lane holding point 4g+t as ITS point j (any row)
-        mp[gi][t] = __shfl(mj[gi], src, 64);
-        rlp[gi][t] = __shfl(rlj[gi], src, 64);
-        Dp[gi][t] = __shfl(Dj[gi], src, 64);
+        mp[gi][t] = __shfl(mj, src, 64);
+        rlp[gi][t] = __shfl(rlj, src, 64);
+        Dp[gi][t] = __shfl(Dj, src, 64);
         const int pr = min(p0 + 4 * g + t, Lq - 1);
         qT[gi][t] = qs[(size_t)pr * FD + h * FDH + j];               // A: [d j][point 4g+t]
         doT[gi][t] = dO[(size_t)pr * FD + h * FDH + j];
@@ -495,35 +496,28 @@ __global__ void __launch_bounds__(512) k_fl_s2c_bwd(const float* __restrict__ qs
 #pragma unroll
       for (int gi = 0; gi < NG; ++gi) {
         const int p0 = pbeg + gi * 16;
-        f32x4 s_kp = (f32x4){0.f, 0.f, 0.f, 0.f}, s_pk = s_kp, dp_kp = s_kp, dp_pk = s_kp;
+        f32x4 s_pk = (f32x4){0.f, 0.f, 0.f, 0.f}, dp_pk = s_pk;       // [point 4g+t][key j]
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-          s_kp = FL_MFMA(kf[t], qf[gi][t], s_kp);                    // [key 4g+t][point j]
-          s_pk = FL_MFMA(qf[gi][t], kf[t], s_pk);                    // [point 4g+t][key j]
-          dp_kp = FL_MFMA(vr[t], dof[gi][t], dp_kp);
+          s_pk = FL_MFMA(qf[gi][t], kf[t], s_pk);
           dp_pk = FL_MFMA(dof[gi][t], vr[t], dp_pk);
         }
-        f32x4 ds_kp, p_pk, ds_pk;
+        f32x4 p_pk, ds_pk;
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-          {   // keys x points
-            const bool off = kt * 16 + 4 * g + t >= Lk || p0 + j >= Lq;
-            const float p = off ? 0.f : fl_exp(s_kp[t] - mj[gi]) * rlj[gi];
-            ds_kp[t] = p * (dp_kp[t] - Dj[gi]);
-          }
-          {   // points x keys
-            const bool off = kt * 16 + j >= Lk || p0 + 4 * g + t >= Lq;
-            const float p = off ? 0.f : fl_exp(s_pk[t] - mp[gi][t]) * rlp[gi][t];
-            p_pk[t] = p;
-            ds_pk[t] = p * (dp_pk[t] - Dp[gi][t]);
-          }
+          const bool off = kt * 16 + j >= Lk || p0 + 4 * g + t >= Lq;
+          const float p = off ? 0.f : fl_exp(s_pk[t] - mp[gi][t]) * rlp[gi][t];
+          p_pk[t] = p;
+          ds_pk[t] = p * (dp_pk[t] - Dp[gi][t]);
         }
+        const f32x4 ds_kp = fl_transpose(tr_l[h][gi], ds_pk, g, j);   // [key 4g+t][point j]
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-          adq[gi] = FL_MFMA(kT[t], ds_kp[t], adq[gi]);               // dQ^T[d][point] += K^T[d][key] dS[key][point]
           adk = FL_MFMA(qT[gi][t], ds_pk[t], adk);                   // dK^T[d][key] += q^T[d][point] dS[point][key]
           adv = FL_MFMA(doT[gi][t], p_pk[t], adv);                   // dV^T[d][key] += dO^T[d][point] P[point][key]
         }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) adq[gi] = FL_MFMA(kT[t], ds_kp[t], adq[gi]);   // dQ^T[d][point] += K^T[d][key] dS[key][point]
       }
       const int kj = kt * 16 + j;
       if (kj < Lk) {
