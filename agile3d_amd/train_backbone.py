@@ -159,6 +159,22 @@ def _sync_bn_default():
     return os.environ.get("A3D_SYNC_BN", "0") == "1" and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
 
 
+_side_streams = {}
+
+
+def _wgrad_stream(device):
+    """The stream the weight-gradient kernels of the backward pass run on (one per device): a unit's weight gradient and its
+    input gradient both depend only on d(raw), so they run side by side -- k_wgrad's waves wait for gathered rows half of
+    the time (0.42-0.5 of the matrix peak), the input-gradient conv's workgroups fill in.  A3D_WGRAD_STREAM=0: one stream."""
+    import os
+    if os.environ.get("A3D_WGRAD_STREAM", "1") == "0":
+        return None
+    key = str(device)
+    if key not in _side_streams:
+        _side_streams[key] = torch.cuda.Stream(device=device)
+    return _side_streams[key]
+
+
 class BackboneTape:
     """Round 5: one library call per conv + BatchNorm (+ residual)(+ ReLU) unit in the forward (the batch statistics come
     out of the conv kernel's epilogue: no statistics pass over the raw output), concatenations are column slices of one
@@ -176,6 +192,7 @@ class BackboneTape:
         self.fuse_bwd = os.environ.get("A3D_FUSE_BN_BWD", "1") != "0"     # tests / A-B: the layer-at-a-time BatchNorm backward
         self.feats3 = feats3.to(torch.float32).contiguous()
         self.steps = []          # backward closures, in forward order
+        self.wgrad_stream, self._side_used = _wgrad_stream(self.feats3.device), False
         self.relu_levels = []
         self.grads = {}
         self._names = {id(p): n for n, p in model.named_parameters()}
@@ -271,7 +288,16 @@ class BackboneTape:
             self._pgrad(b.bias, db)
             y.g = None
             # conv: weight gradient, then the input gradient written / accumulated into the input node's buffer
-            self._pgrad(conv.kernel, B.conv_weight_grad(sc, kind, x.level, x.v[:n_in], draw[:n_out]))
+            side = self.wgrad_stream
+            if side is not None:
+                side.wait_stream(torch.cuda.current_stream())           # d(raw) is complete
+                with torch.cuda.stream(side):
+                    dw = B.conv_weight_grad(sc, kind, x.level, x.v[:n_in], draw[:n_out])
+                draw.record_stream(side)                                # its memory is not handed out again before the kernel is done
+                self._side_used = True
+            else:
+                dw = B.conv_weight_grad(sc, kind, x.level, x.v[:n_in], draw[:n_out])
+            self._pgrad(conv.kernel, dw)
             x.pending -= 1
             if x.pending == 0 and x.bn is not None and len(wb) == 1:
                 # this conv completes dL/dx and x is the output of a conv + BatchNorm unit: mask + BatchNorm-backward sums in
@@ -434,8 +460,15 @@ class BackboneTape:
         for back in reversed(self.steps):
             back()
             if on_grad is not None and len(self.grads) != len(seen):
+                self._join_wgrad_stream()                               # the gradients handed over are complete on THIS stream
                 for k in self.grads:
                     if k not in seen:
                         seen.add(k)
                         on_grad(k, self.grads[k])
+        self._join_wgrad_stream()
         return self.grads
+
+    def _join_wgrad_stream(self):
+        if self._side_used:
+            torch.cuda.current_stream().wait_stream(self.wgrad_stream)
+            self._side_used = False
