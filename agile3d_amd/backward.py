@@ -310,6 +310,7 @@ def conv_weight_grad(scene, kind, level_in, x: torch.Tensor, dy: torch.Tensor) -
     x, dy = _rows(x), _rows(dy)
     K = _KVOL[kind]
     dw = torch.empty((K, cin, cout), dtype=torch.float32, device=x.device)
+    scene.prepare_wgrad()
     nbytes = lib.a3d_conv_wgrad_workspace_bytes(scene.handle, kind, level_in, cin, cout)
     if nbytes == 0:
         raise L.A3DError(lib.a3d_last_error().decode())

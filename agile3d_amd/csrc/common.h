@@ -237,4 +237,11 @@ struct a3d_scene {
   int* orig_row = nullptr;      // [n0] internal level-0 row -> caller row
   void* workspace = nullptr;
   size_t workspace_bytes = 0;
+  // weight-gradient work lists (a3d_scene_build_wgrad_lists, csrc/wgrad.hip): per kernel-map kind (0 = 3^3, 1 = stride-2
+  // down, 2 = transposed up) and level owning the map's group masks, wg_list[k * wg_stride + i] = the i-th 16-position
+  // group that has offset k (ascending), wg_count[k] = how many there are (host copy)
+  int* wg_list[3][A3D_NUM_LEVELS] = {};
+  int wg_stride[3][A3D_NUM_LEVELS] = {};
+  int wg_count[3][A3D_NUM_LEVELS][27] = {};
+  bool wg_ready = false;
 };

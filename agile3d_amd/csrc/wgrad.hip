@@ -6,13 +6,14 @@
 //
 // for the four kernel-map kinds (3^3 stride 1, 2^3 stride 2, 2^3 transposed, 1x1), read from the same scene tables
 // the forward kernels use.  Exact fp32 on v_mfma_f32_16x16x4_f32 with the ROWS as the MFMA k dimension: one MFMA
-// multiplies a [16 ci x 4 rows] slice of x^T with a [4 rows x 16 co] slice of dy.  Lane (g, j) loads CX consecutive
-// input channels of row g (one or two wide loads) and CY consecutive output channels: value tx of the x load is the
-// A operand of the MFMAs for input-channel set {CX*j' + tx}, value ty of the dy load the B operand for output-channel
-// set {CY*j' + ty} -- two loads feed CX*CY MFMAs (36 at 96 x 96 channels).  16-position groups that lack offset k are
-// skipped with the forward kernels' group masks (rows are sorted by neighbour mask).  A workgroup = (row chunk,
-// offset k, channel block); its four waves' accumulators are folded through LDS in wave order and the chunk partials
-// are summed by a second kernel in chunk order: the result does not depend on scheduling.
+// multiplies a [16 ci x 4 rows] slice of x^T with a [4 rows x 16 co] slice of dy.  Lane (g, j) loads CX input channels of
+// row g (one or two wide loads, chan()) and CY output channels: value tx of the x load is the A operand of the MFMAs for
+// input-channel set {chan(CX, j', tx)}, value ty of the dy load the B operand for output-channel set {chan(CY, j', ty)} --
+// two loads feed CX*CY MFMAs (36 at 96 x 96 channels).  Only the 16-position groups that HAVE offset k are walked: the
+// scene keeps, per map and offset, the ascending list of those groups (a3d_scene_build_wgrad_lists), and a workgroup =
+// (offset k, a segment of k's list, channel block); all segments are equally long and every XCD gets the same number of them
+// (wgrad_plan).  Its four waves' accumulators are folded through LDS in wave order and the segments' partials are summed by
+// a second kernel in segment order: the result does not depend on scheduling.
 #include "common.h"
 #include <stdlib.h>
 
@@ -29,125 +30,222 @@ struct WgradArgs {
   const int* tab;        // [K][tab_stride] position -> input row (>= n_in: no pair); nullptr = identity (1x1)
   int tab_stride;
   const int* out_map;    // position -> output row (transposed conv: virtual rows), nullptr = identity
-  const uint32_t* gmask; // per 16 positions: bit k set if any of them has offset k; nullptr = all present
   int n_pos;             // positions (output rows of the kernel map)
   int K, cin, cout;
-  int chunk_groups;      // 16-position groups per chunk
-  int n_chunks;
-  float* part;           // [chunks][K][cin][cout]
-  float* bias_part;      // BIAS builds (K = 1): [chunks][cout] column sums of dy, the bias gradient of an nn.Linear
+  // work items: offset k's groups (list[k * list_stride + i], i < cnt[k]; nullptr: groups 0 .. cnt[0] - 1 of a 1x1 map) are
+  // cut into segments of seg_len; segment s of offset k writes partial slot base[k] + s.  Workgroup b runs on XCD b % 8
+  // (hardware) and takes item b / 8 of that XCD's items: offset k's segments seg_lo[k][x] .. seg_lo[k][x + 1] - 1 -- the
+  // x-th eighth of its list, so an XCD's offsets work on about the same stretch of rows -- offset-major; xbase[x][k] =
+  // items of XCD x before offset k.  The host makes the tables (wgrad_plan): every XCD gets the same number of items +- K / 8.
+  const int* list;
+  int list_stride;
+  int seg_len;
+  int cnt[27];
+  int base[28];
+  int xbase[8][28];
+  int seg_lo[27][9];
+  float* part;           // [slots][cin][cout] in fragment layout
+  float* bias_part;      // BIAS builds (K = 1): [slots][cout] column sums of dy, the bias gradient of an nn.Linear
 };
 
+// Channels of a 16 C-wide block held by a lane: the 16 lanes of a row load CONTIGUOUS pieces -- min(C, 4) floats at
+// 4 min(C, 4) j bytes, and for C = 6 / 8 a second piece of C - 4 floats behind the first 16 min(C, 4) floats -- so a
+// wave's load instruction touches 2 (1) cache lines per row.  (Round 5's C consecutive floats per lane made the 16-byte
+// and the 8-byte load of a 96-channel row touch all three of its lines each: 48 line accesses per step and wave, and
+// the loads' time adds to the MFMAs' in this loop.)  Value t of lane j is channel chan(C, j, t) of the block.
+__host__ __device__ constexpr int chan(int C, int j, int t) {
+  return t < (C < 4 ? C : 4) ? (C < 4 ? C : 4) * j + t : 16 * 4 + (C - 4) * j + (t - 4);
+}
+
+// the lane's pieces at byte offset `off` (first piece) of a raw buffer: rows past the end (offset >= num_records) read as
+// zeros in hardware -- no branch, no select, so the loop below is straight-line code whose loads the compiler counts
+// exactly.  off2 - off = (64 - 4 j + (C - 4) j) floats: the second piece.
 template <int C>
-__device__ __forceinline__ void load_c(const float* p, bool ok, float (&v)[C]) {
-#pragma unroll
-  for (int i = 0; i < C; ++i) v[i] = 0.f;
-  if (!ok) return;
+__device__ __forceinline__ void load_c(__amdgpu_buffer_rsrc_t r, int off, int off2, float (&v)[C]) {
+  // (whole-vector bit casts: __builtin_bit_cast(float, a[i]) on an element of the returned vector makes this compiler load
+  // one dword and use it for every element)
   if constexpr (C == 2) {
-    const f32x2 a = *(const f32x2*)p;
+    const f32x2 a = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(r, off, 0, 0));
     v[0] = a[0], v[1] = a[1];
   } else if constexpr (C == 4) {
-    const f32x4 a = *(const f32x4*)p;
+    const f32x4 a = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0));
 #pragma unroll
     for (int i = 0; i < 4; ++i) v[i] = a[i];
-  } else if constexpr (C == 6) {   // 24 bytes per lane at 8-byte alignment: one dwordx4 + one dwordx2
-    const f32x4u a = *(const f32x4u*)p;
-    const f32x2 b = *(const f32x2*)(p + 4);
-    v[0] = a[0], v[1] = a[1], v[2] = a[2], v[3] = a[3], v[4] = b[0], v[5] = b[1];
+  } else if constexpr (C == 6) {
+    const f32x4 a = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0));
+    const f32x2 b = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(r, off2, 0, 0));
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = a[i];
+    v[4] = b[0], v[5] = b[1];
   } else {
-    const f32x4 a = *(const f32x4*)p, b = *(const f32x4*)(p + 4);
+    const f32x4 a = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0));
+    const f32x4 b = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, off2, 0, 0));
 #pragma unroll
     for (int i = 0; i < 4; ++i) v[i] = a[i], v[4 + i] = b[i];
   }
 }
 
-template <int CX, int CY, bool BIAS = false>
+constexpr unsigned kNoRow = 0xFFFFF000u;   // byte offset of "no pair": past every buffer this kernel accepts (a3d: wgrad_fits)
+
+// 16 / 24 / 32 bytes through a plain pointer (WIDE builds: operands of 4 GB and more, which a buffer descriptor cannot span)
+template <int C>
+__device__ __forceinline__ void load_p(const float* p, const float* p2, float (&v)[C]) {
+  if constexpr (C == 2) {
+    const f32x2 a = *(const f32x2*)p;
+    v[0] = a[0], v[1] = a[1];
+  } else if constexpr (C == 4) {
+    const f32x4u a = *(const f32x4u*)p;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = a[i];
+  } else if constexpr (C == 6) {
+    const f32x4u a = *(const f32x4u*)p;
+    const f32x2 b = *(const f32x2*)p2;
+    v[0] = a[0], v[1] = a[1], v[2] = a[2], v[3] = a[3], v[4] = b[0], v[5] = b[1];
+  } else {
+    const f32x4u a = *(const f32x4u*)p, b = *(const f32x4u*)p2;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = a[i], v[4 + i] = b[i];
+  }
+}
+
+template <int CX, int CY, bool BIAS = false, bool WIDE = false>
 __global__ void __launch_bounds__(256) k_wgrad(const WgradArgs a) {
   extern __shared__ __attribute__((aligned(16))) float fold[];   // [16 CX][16 CY] block of dW, waves fold in order
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int g = lane >> 4, j = lane & 15;
   const int nbx = a.cin / (16 * CX);
-  // workgroup id -> (chunk, offset): consecutive ids go to different XCDs (id % 8), so the K offsets of one row chunk
-  // are given to ONE XCD, back to back -- they read the same dy rows and neighbouring x rows, which then come out of
-  // that XCD's L2 instead of being fetched once per offset
-  const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
-  const int k = q % a.K;
-  const int chunk = (q / a.K) * 8 + xcd;
-  if (chunk >= a.n_chunks) return;
+  // workgroup id -> (XCD x, item i of x) -> (offset k, segment)
+  const int xcd = blockIdx.x & 7, item = blockIdx.x >> 3;
+  if (item >= a.xbase[xcd][27]) return;
+  int k = 0;
+#pragma unroll
+  for (int kk = 1; kk < 27; ++kk) k += item >= a.xbase[xcd][kk] ? 1 : 0;
+  const int seg = a.seg_lo[k][xcd] + (item - a.xbase[xcd][k]);
+  const int cnt = a.cnt[k];
+  const int slot = a.base[k] + seg;
   const int bx = blockIdx.z % nbx, by = blockIdx.z / nbx;       // channel blocks
-  const int ci0 = bx * 16 * CX + CX * j, co0 = by * 16 * CY + CY * j;
-  const int ngroups = (a.n_pos + 15) >> 4;
-  const int g_begin = chunk * a.chunk_groups;
-  const int g_end = min(ngroups, g_begin + a.chunk_groups);
+  const int e_begin = seg * a.seg_len;
+  const int e_end = min(cnt, e_begin + a.seg_len);
+  const int* glist = a.list ? a.list + (size_t)k * a.list_stride : nullptr;
   f32x4 acc[CX][CY];
 #pragma unroll
   for (int tx = 0; tx < CX; ++tx)
 #pragma unroll
     for (int ty = 0; ty < CY; ++ty) acc[tx][ty] = (f32x4){0.f, 0.f, 0.f, 0.f};
   const int* tab = a.tab ? a.tab + (size_t)k * a.tab_stride : nullptr;
+  // x and dy as raw buffers of n rows: a row index >= n turns into an offset past the end, which the hardware answers
+  // with zeros (the product of a missing pair)
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, (int)((unsigned)a.n_in * (unsigned)a.ldx * 4u), 0x00020000);
+  const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void*)a.dy, 0, (int)((unsigned)a.n_out * (unsigned)a.ldy * 4u), 0x00020000);
+  const unsigned cx4 = (unsigned)(bx * 16 * CX + chan(CX, j, 0)) * 4u, cy4 = (unsigned)(by * 16 * CY + chan(CY, j, 0)) * 4u;
+  const unsigned cx4b = (unsigned)(bx * 16 * CX + chan(CX, j, CX > 4 ? 4 : 0)) * 4u;      // the lane's second piece (CX = 6 / 8)
+  const unsigned cy4b = (unsigned)(by * 16 * CY + chan(CY, j, CY > 4 ? 4 : 0)) * 4u;
+  const unsigned ldx4 = (unsigned)a.ldx * 4u, ldy4 = (unsigned)a.ldy * 4u;
 
-  // this wave's groups: g_begin + wave, +4, ... that have offset k.  Software pipeline across groups: the next
-  // group's 16 row pairs are requested while the current group is multiplied, and its first four rows during the
-  // current group's last step, so neither the table nor the row latency is exposed between groups.
-  auto next_group = [&](int from) {
-    int n = from;
-    while (n < g_end && a.gmask && !((a.gmask[n] >> k) & 1u)) n += 4;
-    return n;
+  // this wave's groups: entries e_begin + wave, +4, ... of offset k's list.  The 16 pairs of a group sit in lanes 0..15 of every
+  // 16-lane row as BYTE OFFSETS of their two rows; step s (positions 4s .. 4s+3) fetches them with a bpermute and loads
+  // CX + CY floats per lane.  Four row buffers rotate with the step loop unrolled: the rows of step s+3 are requested
+  // before step s is multiplied and nothing is copied, so three steps of MFMAs (3 x CX CY x 8 passes) cover a row fetch.
+  // (Rounds 3-5 rotated two buffers through register copies: the copy of a buffer one step after its load made every
+  // step wait for ALL outstanding loads -- s_waitcnt vmcnt(0) -- and the "two steps ahead" was one.)
+  auto group_of = [&](int e) { return e < e_end ? (glist ? glist[e] : e) : -1; };   // entry e of the list (wave-uniform: a scalar load)
+  auto request_pairs = [&](int grp, int& xi, int& yi) {          // table entries of group grp (-1: none; judged later)
+    const int p16 = grp * 16 + j;
+    const int pc = (grp >= 0 && p16 < a.n_pos) ? p16 : 0;
+    xi = tab ? tab[pc] : pc;
+    yi = a.out_map ? a.out_map[pc] : pc;
   };
-  auto load_pairs = [&](int grp, int& xi, int& yi) {
-    const int p16 = grp * 16 + j;                                // lanes 0..15 of every 16-lane row hold the 16 pairs
-    xi = a.n_in, yi = a.n_out;
-    if (grp < g_end && p16 < a.n_pos) {
-      xi = tab ? tab[p16] : p16;
-      yi = a.out_map ? a.out_map[p16] : p16;
+  auto pair_offsets = [&](int grp, int xi, int yi, unsigned& xo, unsigned& yo) {
+    const bool ok = grp >= 0 && grp * 16 + j < a.n_pos && (unsigned)xi < (unsigned)a.n_in && (unsigned)yi < (unsigned)a.n_out;
+    if constexpr (WIDE) {   // row indices instead of byte offsets; "no pair" = n (the row count)
+      xo = ok ? (unsigned)xi : (unsigned)a.n_in;
+      yo = ok ? (unsigned)yi : (unsigned)a.n_out;
+    } else {
+      xo = ok ? (unsigned)xi * ldx4 : kNoRow;
+      yo = ok ? (unsigned)yi * ldy4 : kNoRow;
     }
   };
-  float xv[CX], yv[CY], x1[CX], y1[CY], x2[CX], y2[CY];
+  int bperm[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) bperm[s] = ((lane & 48) + 4 * s + g) * 4;
+  float xb[4][CX], yb[4][CY];
   float ys[CY];          // BIAS: this lane's column sums of the dy rows it multiplies (rows without a pair load zeros)
 #pragma unroll
   for (int i = 0; i < CY; ++i) ys[i] = 0.f;
-  auto load_rows = [&](int xi, int yi, int s, float (&xd)[CX], float (&yd)[CY]) {   // rows of positions 4s .. 4s+3
-    const int xr = __shfl(xi, 4 * s + g, 16), yr = __shfl(yi, 4 * s + g, 16);
-    const bool ok = xr < a.n_in && yr < a.n_out;
-    load_c<CX>(a.x + (size_t)(ok ? xr : 0) * a.ldx + ci0, ok, xd);
-    load_c<CY>(a.dy + (size_t)(ok ? yr : 0) * a.ldy + co0, ok, yd);
-  };
-  int grp = next_group(g_begin + wave);
-  int xi, yi;
-  load_pairs(grp, xi, yi);
-  if (grp < g_end) {
-    load_rows(xi, yi, 0, x1, y1);
-    load_rows(xi, yi, 1, x2, y2);
-  }
-  while (grp < g_end) {
-    const int ngrp = next_group(grp + 4);
-    int xi_n, yi_n;
-    load_pairs(ngrp, xi_n, yi_n);
-    // (round 5: four rotating row buffers with the step loop unrolled -- no register copies -- measured 8 % SLOWER on
-    // <6,6> (462 -> 498 us): the copies are not what this loop waits for; profiles/r05_experiments.txt)
-#pragma unroll 1
-    for (int s = 0; s < 4; ++s) {
+  auto load_rows = [&](unsigned xo, unsigned yo, int s, float (&xd)[CX], float (&yd)[CY]) {   // rows of positions 4s .. 4s+3
+    if constexpr (WIDE) {
+      const unsigned xr = (unsigned)__builtin_amdgcn_ds_bpermute(bperm[s], (int)xo);
+      const unsigned yr = (unsigned)__builtin_amdgcn_ds_bpermute(bperm[s], (int)yo);
+      const bool ok = xr < (unsigned)a.n_in;                       // both rows exist or neither (pair_offsets)
+      const float* xp = a.x + (size_t)(ok ? xr : 0u) * a.ldx;
+      const float* yp = a.dy + (size_t)(ok ? yr : 0u) * a.ldy;
+      load_p<CX>(xp + (cx4 >> 2), xp + (cx4b >> 2), xd);
+      load_p<CY>(yp + (cy4 >> 2), yp + (cy4b >> 2), yd);
 #pragma unroll
-      for (int i = 0; i < CX; ++i) xv[i] = x1[i], x1[i] = x2[i];
+      for (int i = 0; i < CX; ++i) xd[i] = ok ? xd[i] : 0.f;
 #pragma unroll
-      for (int i = 0; i < CY; ++i) yv[i] = y1[i], y1[i] = y2[i];
-      // two steps ahead (2 waves per SIMD do not cover a row fetch with one step of MFMAs): rows of step s+2 of this
-      // group, or of the next group's first steps; past the end it re-reads rows that are never multiplied
-      load_rows(s < 2 ? xi : xi_n, s < 2 ? yi : yi_n, (s + 2) & 3, x2, y2);
-      if constexpr (BIAS) {
-#pragma unroll
-        for (int i = 0; i < CY; ++i) ys[i] += yv[i];
-      }
-#pragma unroll
-      for (int tx = 0; tx < CX; ++tx)
-#pragma unroll
-        for (int ty = 0; ty < CY; ++ty)
-          acc[tx][ty] = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[tx], yv[ty], acc[tx][ty], 0, 0, 0);
+      for (int i = 0; i < CY; ++i) yd[i] = ok ? yd[i] : 0.f;
+    } else {
+      const unsigned xr = (unsigned)__builtin_amdgcn_ds_bpermute(bperm[s], (int)xo);
+      const unsigned yr = (unsigned)__builtin_amdgcn_ds_bpermute(bperm[s], (int)yo);
+      load_c<CX>(rx, (int)(xr + cx4), (int)(xr + cx4b), xd);
+      load_c<CY>(ry, (int)(yr + cy4), (int)(yr + cy4b), yd);
     }
-    grp = ngrp, xi = xi_n, yi = yi_n;
+  };
+  auto multiply = [&](const float (&xv)[CX], const float (&yv)[CY]) {
+    if constexpr (BIAS) {
+#pragma unroll
+      for (int i = 0; i < CY; ++i) ys[i] += yv[i];
+    }
+#pragma unroll
+    for (int tx = 0; tx < CX; ++tx)
+#pragma unroll
+      for (int ty = 0; ty < CY; ++ty)
+        acc[tx][ty] = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[tx], yv[ty], acc[tx][ty], 0, 0, 0);
+  };
+  int e = e_begin + wave;                       // this wave's entries: e_begin + wave, + 4, ...
+  int grp = group_of(e), ngrp = group_of(e + 4);
+  int xi, yi, xi_n, yi_n;
+  unsigned xo, yo, xo_n, yo_n;
+  request_pairs(grp, xi, yi);
+  request_pairs(ngrp, xi_n, yi_n);
+  pair_offsets(grp, xi, yi, xo, yo);
+  pair_offsets(ngrp, xi_n, yi_n, xo_n, yo_n);
+  if (grp >= 0) {
+    load_rows(xo, yo, 0, xb[0], yb[0]);
+    load_rows(xo, yo, 1, xb[1], yb[1]);
+    load_rows(xo, yo, 2, xb[2], yb[2]);
+  }
+  while (grp >= 0) {
+    // the group after the next: its table entries are requested now and looked at only at the end of this iteration
+    e += 4;
+    const int nngrp = group_of(e + 4);
+    int xi_nn, yi_nn;
+    request_pairs(nngrp, xi_nn, yi_nn);
+    // (scheduling barriers: left alone, the compiler sinks the loads behind two steps of MFMAs to save registers and
+    // drains the queue to vmcnt(1) before it issues the next ones)
+    load_rows(xo, yo, 3, xb[3], yb[3]);
+    __builtin_amdgcn_sched_barrier(0);
+    multiply(xb[0], yb[0]);
+    __builtin_amdgcn_sched_barrier(0);
+    load_rows(xo_n, yo_n, 0, xb[0], yb[0]);     // past the last group: offsets are kNoRow, the loads touch no memory
+    __builtin_amdgcn_sched_barrier(0);
+    multiply(xb[1], yb[1]);
+    __builtin_amdgcn_sched_barrier(0);
+    load_rows(xo_n, yo_n, 1, xb[1], yb[1]);
+    __builtin_amdgcn_sched_barrier(0);
+    multiply(xb[2], yb[2]);
+    __builtin_amdgcn_sched_barrier(0);
+    load_rows(xo_n, yo_n, 2, xb[2], yb[2]);
+    __builtin_amdgcn_sched_barrier(0);
+    multiply(xb[3], yb[3]);
+    __builtin_amdgcn_sched_barrier(0);
+    grp = ngrp, xo = xo_n, yo = yo_n;
+    ngrp = nngrp;
+    pair_offsets(nngrp, xi_nn, yi_nn, xo_n, yo_n);
   }
   // fold the four waves in wave order, in the accumulators' own layout (one conflict-free 16-byte LDS access per
-  // tile and lane), and write the partial in that layout too: [chunk][k][block][tile][lane] x 4 floats -- the reduce
+  // tile and lane), and write the partial in that layout too: [slot][block][tile][lane] x 4 floats -- the reduce
   // kernel does the (tile, lane, r) -> (ci, co) mapping once per weight instead of once per workgroup
   f32x4* fold4 = (f32x4*)fold;
   for (int w = 0; w < 4; ++w) {
@@ -163,10 +261,10 @@ __global__ void __launch_bounds__(256) k_wgrad(const WgradArgs a) {
     __syncthreads();
   }
   constexpr int TILE4 = CX * CY * 64;   // f32x4 per block
-  f32x4* P = (f32x4*)a.part + (((size_t)chunk * a.K + k) * gridDim.z + blockIdx.z) * TILE4;
+  f32x4* P = (f32x4*)a.part + ((size_t)slot * gridDim.z + blockIdx.z) * TILE4;
   for (int e = threadIdx.x; e < TILE4; e += 256) P[e] = fold4[e];
   if constexpr (BIAS) {
-    // the chunk's column sums of dy (the input-channel block 0 writes them): the lane's rows, then the four row lanes g,
+    // the segment's column sums of dy (the input-channel block 0 writes them): the lane's rows, then the four row lanes g,
     // then the four waves in wave order -- a fixed order like the weights'
     if (bx != 0) return;
 #pragma unroll
@@ -177,52 +275,78 @@ __global__ void __launch_bounds__(256) k_wgrad(const WgradArgs a) {
     __syncthreads();
     if (g == 0) {
 #pragma unroll
-      for (int i = 0; i < CY; ++i) fold[wave * 16 * CY + CY * j + i] = ys[i];
+      for (int i = 0; i < CY; ++i) fold[wave * 16 * CY + chan(CY, j, i)] = ys[i];
     }
     __syncthreads();
     if (threadIdx.x < 16 * CY) {
       const int t = threadIdx.x;
-      a.bias_part[(size_t)chunk * a.cout + by * 16 * CY + t] = ((fold[t] + fold[16 * CY + t]) + fold[32 * CY + t]) + fold[48 * CY + t];
+      a.bias_part[(size_t)slot * a.cout + by * 16 * CY + t] = ((fold[t] + fold[16 * CY + t]) + fold[32 * CY + t]) + fold[48 * CY + t];
     }
   }
 }
 
-// dw[k][ci][co] = sum over chunks of the fragment-layout partials: element e of a block is
-// (tile = tx * CY + ty, lane = 16 g + j, r) -> ci = block_x * 16 CX + CX (4g + r) + tx, co = block_y * 16 CY + CY j + ty.
-// 64 elements x kRedLanes chunk lanes per workgroup: lane p adds chunks p, p + kRedLanes, ... (independent loads in flight;
-// one thread per element walking up to 256 chunks was a chain of dependent round trips: 25-30 us per weight, 120 launches
-// per training iteration), the lanes' sums are folded in lane order -- a fixed order either way.
-constexpr int kRedLanes = 8;
-__global__ void __launch_bounds__(64 * kRedLanes) k_wgrad_reduce(const float* __restrict__ part, int nchunk, int K, int cin, int cout,
-                                                                 int cx, int cy, float* __restrict__ dw) {
-  __shared__ float sh[kRedLanes][64];
-  const size_t total = (size_t)K * cin * cout;
-  const int el = threadIdx.x & 63, p = threadIdx.x >> 6;
-  const size_t e = (size_t)blockIdx.x * 64 + el;
-  float s = 0.f;
-  if (e < total)
-    for (int c = p; c < nchunk; c += kRedLanes) s += part[(size_t)c * total + e];
-  sh[p][el] = s;
-  __syncthreads();
-  if (p != 0 || e >= total) return;
+// dw[k][ci][co] = sum over offset k's slots of the fragment-layout partials: a block's tile (tx, ty) holds, in lane
+// (g, j) and value r, the element ci = chan(CX, 4g + r, tx), co = chan(CY, j, ty).  One workgroup per (k, block, tx, half of
+// the ty): the tiles ty = 0 .. 3 of a lane are four CONSECUTIVE output channels (4j .. 4j + 3; ty = 4 .. of CY = 6 / 8: 64 +
+// (CY - 4) j ..), so a lane sums its tiles over the slots -- each tile of a partial is 1 KB contiguous, float4 per lane --
+// and writes one 16-byte (8-byte) piece per r: the 16 lanes of a row fill 256 (128) contiguous bytes of an output row.
+// Wave w adds slots w, w + NW, ... in ascending order, the waves' sums are folded in wave order through LDS: a fixed
+// order.  (Rounds 3-5: one thread per element, consecutive threads on consecutive r = four different output rows, and a
+// strided 4-byte read per slot: 0.75 TB/s on the 256 -> 256 layers of level 4.)
+struct SlotBase {
+  int base[28];          // offset k's partial slots are base[k] .. base[k + 1] - 1
+};
+template <int NW>          // waves per workgroup: 4, or 16 where an offset has many slots
+__global__ void __launch_bounds__(64 * NW) k_wgrad_reduce(const float* __restrict__ part, const SlotBase sb, int cin, int cout, int cx, int cy,
+                                                         float* __restrict__ dw) {
+  __shared__ f32x4 sh[NW - 1][4][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, j = lane & 15;
+  const int nhalf = cy > 4 ? 2 : 1, nbx = cin / (16 * cx), nblocks = nbx * (cout / (16 * cy));
+  int u = blockIdx.x;
+  const int half = u % nhalf;
+  u /= nhalf;
+  const int tx = u % cx;
+  u /= cx;
+  const int blk = u % nblocks, k = u / nblocks;
+  const int t0 = half ? 4 : 0, nt = half ? cy - 4 : (cy < 4 ? cy : 4);      // 2 or 4 tiles
+  const f32x4* P = (const f32x4*)part;
+  const size_t tiles_per_slot = (size_t)nblocks * cx * cy;
+  const size_t first = ((size_t)blk * cx * cy + tx * cy + t0) * 64 + lane;
+  f32x4 acc[4];
 #pragma unroll
-  for (int q = 1; q < kRedLanes; ++q) s += sh[q][el];
-  const int block_elems = 16 * cx * 16 * cy, nbx = cin / (16 * cx);
-  const int per_k = cin * cout;
-  const int k = (int)(e / per_k), rem = (int)(e % per_k);
-  const int blk = rem / block_elems, in_blk = rem % block_elems;
-  const int tile = in_blk / 256, lane = (in_blk % 256) / 4, r = in_blk & 3;
-  const int tx = tile / cy, ty = tile % cy, g = lane >> 4, j = lane & 15;
-  const int ci = (blk % nbx) * 16 * cx + cx * (4 * g + r) + tx;
-  const int co = (blk / nbx) * 16 * cy + cy * j + ty;
-  dw[((size_t)k * cin + ci) * cout + co] = s;
+  for (int t = 0; t < 4; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int c = sb.base[k] + wave; c < sb.base[k + 1]; c += NW) {
+    const f32x4* q = P + (size_t)c * tiles_per_slot * 64 + first;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+      if (t < nt) acc[t] += q[t * 64];
+  }
+  if (wave) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) sh[wave - 1][t][lane] = acc[t];
+  }
+  __syncthreads();
+  if (wave) return;
+#pragma unroll
+  for (int w = 0; w < NW - 1; ++w)
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[t] += sh[w][t][lane];
+  const int co = (blk / nbx) * 16 * cy + chan(cy, j, t0);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int ci = (blk % nbx) * 16 * cx + chan(cx, 4 * g + r, tx);
+    float* d = dw + ((size_t)k * cin + ci) * cout + co;
+    if (nt == 4) *(f32x4*)d = (f32x4){acc[0][r], acc[1][r], acc[2][r], acc[3][r]};
+    else *(f32x2*)d = (f32x2){acc[0][r], acc[1][r]};
+  }
 }
 
+constexpr int kRedLanes = 8;      // k_wgrad_reduce_into: 64 elements x 8 slot lanes per workgroup
 // the same sum for an nn.Linear's gradients with the destination's layout as arguments (a3d_linear_wgrad_into): dW written
 // as [cin][cout] or transposed ([cout][cin]: nn.Linear.weight's own layout) with leading dimension `ld`, assigned or
-// ADDED to what is there; elements past the weights are the bias gradient (column sums of dy over the chunks)
+// ADDED to what is there; elements past the weights are the bias gradient (column sums of dy over the slots)
 __global__ void __launch_bounds__(64 * kRedLanes) k_wgrad_reduce_into(const float* __restrict__ part, const float* __restrict__ bias_part,
-                                                                      int nchunk, int cin, int cout, int cx, int cy, float* dw, int ld,
+                                                                      int nslots, int cin, int cout, int cx, int cy, float* dw, int ld,
                                                                       int transposed, int accumulate, float* db, int db_accumulate) {
   __shared__ float sh[kRedLanes][64];
   const int total = cin * cout;
@@ -231,9 +355,9 @@ __global__ void __launch_bounds__(64 * kRedLanes) k_wgrad_reduce_into(const floa
   const int all = total + (db ? cout : 0);
   float s = 0.f;
   if (e < total) {
-    for (int c = p; c < nchunk; c += kRedLanes) s += part[(size_t)c * total + e];
+    for (int c = p; c < nslots; c += kRedLanes) s += part[(size_t)c * total + e];
   } else if (e < all) {
-    for (int c = p; c < nchunk; c += kRedLanes) s += bias_part[(size_t)c * cout + (e - total)];
+    for (int c = p; c < nslots; c += kRedLanes) s += bias_part[(size_t)c * cout + (e - total)];
   }
   sh[p][el] = s;
   __syncthreads();
@@ -249,19 +373,43 @@ __global__ void __launch_bounds__(64 * kRedLanes) k_wgrad_reduce_into(const floa
   const int blk = e / block_elems, in_blk = e % block_elems;
   const int tile = in_blk / 256, lane = (in_blk % 256) / 4, r = in_blk & 3;
   const int tx = tile / cy, ty = tile % cy, g = lane >> 4, j = lane & 15;
-  const int ci = (blk % nbx) * 16 * cx + cx * (4 * g + r) + tx;
-  const int co = (blk / nbx) * 16 * cy + cy * j + ty;
+  const int ci = (blk % nbx) * 16 * cx + chan(cx, 4 * g + r, tx);
+  const int co = (blk / nbx) * 16 * cy + chan(cy, j, ty);
   float* d = dw + (transposed ? (size_t)co * ld + ci : (size_t)ci * ld + co);
   *d = accumulate ? *d + s : s;
 }
 
 struct WgradPlan {
-  int cx, cy, nblocks, chunks, chunk_groups;
+  int cx, cy, nblocks, seg_len, slots, grid_items;     // grid_items: items of the fullest XCD
+  int cnt[27], base[28];
+  int xbase[8][28], seg_lo[27][9];
   size_t part_bytes;
 };
 
-static bool wgrad_plan(int n_pos, int K, int cin, int cout, WgradPlan& p) {
-  if (cin % 32 || cout % 32 || cin < 32 || cout < 32) return false;
+// the segment tables of one segment length; returns the items of the fullest XCD
+static int wgrad_cut(const int* cnt, int K, int seg_len, WgradPlan& p) {
+  p.seg_len = seg_len;
+  p.base[0] = 0;
+  for (int k = 0; k < 27; ++k) {
+    const int ns = k < K ? (cnt[k] + seg_len - 1) / seg_len : 0;
+    p.base[k + 1] = p.base[k] + ns;
+    // eighths of the list; the remainder ns % 8 goes to different XCDs for different offsets
+    for (int x = 0; x <= 8; ++x) p.seg_lo[k][x] = (int)(((long long)x * ns + (5 * k) % 8) / 8);
+  }
+  int most = 0;
+  for (int x = 0; x < 8; ++x) {
+    p.xbase[x][0] = 0;
+    for (int k = 0; k < 27; ++k) p.xbase[x][k + 1] = p.xbase[x][k] + (p.seg_lo[k][x + 1] - p.seg_lo[k][x]);
+    if (p.xbase[x][27] > most) most = p.xbase[x][27];
+  }
+  p.slots = p.base[27] > 0 ? p.base[27] : 1;
+  p.grid_items = most;
+  return most;
+}
+
+// counts: groups per offset (the scene's lists), nullptr: every one of the ngroups groups (1x1 maps)
+static bool wgrad_plan(int ngroups, int K, const int* counts, int cin, int cout, WgradPlan& p) {
+  if (cin % 32 || cout % 32 || cin < 32 || cout < 32 || K > 27 || ngroups < 1) return false;
   int best = 0;
   const int cand[4] = {8, 6, 4, 2};
   for (int ix = 0; ix < 4; ++ix)
@@ -272,45 +420,128 @@ static bool wgrad_plan(int n_pos, int K, int cin, int cout, WgradPlan& p) {
     }
   if (!best) return false;
   p.nblocks = (cin / (16 * p.cx)) * (cout / (16 * p.cy));
-  const int ngroups = (n_pos + 15) / 16;
-  // workgroups over the whole launch: (chunk, offset) items differ a lot in work (rows are sorted by neighbour mask,
-  // so an offset's pairs cluster in some chunks) -- many small items balance the big levels (measured: 3072 at 320 k
-  // rows, 1536 below); every chunk costs a fold and a pass of the reduce kernel, so 1x1 maps stay at <= 256 chunks
-  const int tgt = n_pos > 200000 ? 3072 : 1536;
-  int chunks = (tgt + K * p.nblocks - 1) / (K * p.nblocks);
-  if (chunks > 256) chunks = 256;
-  // (round 5: fewer chunks on the small levels -- at least 9 row groups per wave, so that a 256 -> 256 layer of level 4
-  // writes 14 MB of partials instead of 56 -- measured SLOWER, <8,4> 66 -> 88 us: a wave's groups are a chain of two-deep
-  // row fetches, more workgroups hide it better than less partial traffic pays)
-  if (chunks > (ngroups + 3) / 4) chunks = (ngroups + 3) / 4;      // at least one group per wave
-  if (chunks < 1) chunks = 1;
-  p.chunk_groups = (ngroups + chunks - 1) / chunks;
-  p.chunks = (ngroups + p.chunk_groups - 1) / p.chunk_groups;
-  p.part_bytes = (size_t)p.chunks * K * cin * cout * sizeof(float);
+  // Work items of EQUAL size, the same number on every XCD.  Rounds 1-5 cut the ROWS into equal chunks per offset; rows are
+  // sorted by neighbour mask, so an offset's pairs cluster in some chunks and the (chunk, offset) items differed 0 .. 45
+  // groups, and a chunk's offsets went to one XCD whatever they held: the compute units stood idle a quarter of the
+  // level-0 launch (SQ_BUSY_CU_CYCLES), more on the small levels (level 4: five of eight XCDs had work at all).
+  // The segment length is chosen by a model of the launch: items go to the XCD's workgroup slots in rounds (equal items
+  // finish together), a slot's waves share their SIMD's matrix pipe with the other resident workgroups, every item pays a
+  // fixed prologue / fold / partial write and a pass of the reduce kernel.
+  static const int tgt_env = getenv("A3D_WGRAD_SEG") ? atoi(getenv("A3D_WGRAD_SEG")) : 0;     // experiments: a fixed segment length
+  long long total = 0;
+  int cmax = 0;
+  for (int k = 0; k < 27; ++k) {
+    p.cnt[k] = k < K ? (counts ? counts[k] : ngroups) : 0;
+    total += p.cnt[k];
+    if (p.cnt[k] > cmax) cmax = p.cnt[k];
+  }
+  if (cmax < 1) cmax = 1;
+  const int regs = p.cx * p.cy * 4 + 4 * (p.cx + p.cy) + 24;                  // accumulators + four row buffers + the rest
+  const int occ = regs > 170 ? 2 : regs > 128 ? 3 : regs > 102 ? 4 : regs > 85 ? 5 : 6;   // workgroups per CU (512 registers per lane and SIMD)
+  const int slots_xcd = 32 * occ;
+  const double step_clk = 4.0 * p.cx * p.cy * 32.0;                            // one group through one wave's MFMAs
+  const double fixed_clk = 9000.0 + 40.0 * p.cx * p.cy;                        // prologue (three dependent fetches) + fold + partial
+  double best_cost = 0;
+  int best_seg = 0;
+  const int kMinSeg = 4, kMaxSlots = 2048;
+  for (int seg = kMinSeg; ; seg = seg + (seg + 7) / 8) {
+    if (seg > cmax) seg = cmax;
+    if (tgt_env > 0) seg = tgt_env < cmax ? tgt_env : cmax;
+    const int most = wgrad_cut(p.cnt, K, seg, p);
+    if (p.slots <= kMaxSlots || seg == cmax || tgt_env > 0) {
+      const long long wgs = (long long)most * p.nblocks;                       // workgroups of the fullest XCD
+      const int resident = wgs < slots_xcd ? (int)((wgs + 31) / 32) : occ;     // workgroups sharing a CU
+      const double rounds = (double)((wgs + slots_xcd - 1) / slots_xcd);
+      // one wave per SIMD keeps ~0.65 of the matrix pipe busy (it waits for its rows in between), r of them min(0.92, 0.65 r)
+      const double pipe = 0.65 * resident < 0.92 ? 0.65 * resident : 0.92;
+      const double item = ((seg + 3) / 4) * step_clk * resident / pipe + fixed_clk;
+      const double reduce = 5000.0 + (double)p.slots * cin * cout * 4.0 / 800.0;   // a launch + the partials at ~2 TB/s, in clocks
+      const double cost = rounds * item + reduce;
+      if (!best_seg || cost < best_cost) best_cost = cost, best_seg = seg;
+    }
+    if (seg >= cmax || tgt_env > 0) break;
+  }
+  wgrad_cut(p.cnt, K, best_seg, p);
+  p.part_bytes = (size_t)p.slots * cin * cout * sizeof(float);
   return true;
 }
 
-static int wgrad_tables(const a3d_scene* s, int kind, int level_in, WgradArgs& a) {
+static void wgrad_fill(const WgradPlan& p, WgradArgs& a) {
+  a.seg_len = p.seg_len;
+  memcpy(a.cnt, p.cnt, sizeof(a.cnt));
+  memcpy(a.base, p.base, sizeof(a.base));
+  memcpy(a.xbase, p.xbase, sizeof(a.xbase));
+  memcpy(a.seg_lo, p.seg_lo, sizeof(a.seg_lo));
+}
+static void wgrad_reduce_launch(const float* part, const WgradPlan& p, int K, int cin, int cout, float* dw, hipStream_t st) {
+  SlotBase sb;
+  memcpy(sb.base, p.base, sizeof(sb.base));
+  const unsigned units = (unsigned)(K * p.nblocks * p.cx * (p.cy > 4 ? 2 : 1));
+  if (p.slots >= 12 * K) k_wgrad_reduce<16><<<units, 1024, 0, st>>>(part, sb, cin, cout, p.cx, p.cy, dw);
+  else k_wgrad_reduce<4><<<units, 256, 0, st>>>(part, sb, cin, cout, p.cx, p.cy, dw);
+}
+
+// a buffer descriptor spans < 4 GB and the "no pair" offset must lie past the end with room for a row's column offset
+static bool wgrad_fits(const WgradArgs& a) {
+  return (size_t)a.n_in * a.ldx * 4 <= (size_t)kNoRow && (size_t)a.n_out * a.ldy * 4 <= (size_t)kNoRow && a.cin <= 1024 && a.cout <= 1024;
+}
+
+template <int CX, int CY>
+static void wgrad_launch_one(const WgradArgs& a, dim3 grid, bool bias, bool wide, hipStream_t st) {
+  const size_t lds = (size_t)16 * CX * 16 * CY * sizeof(float);
+#define A3D_WG1(B_, W_)                                       \
+  {                                                           \
+    A3D_ALLOW_LDS(64 * 1024, (k_wgrad<CX, CY, B_, W_>));      \
+    k_wgrad<CX, CY, B_, W_><<<grid, 256, lds, st>>>(a);       \
+  }
+  if (bias) {
+    if (wide) A3D_WG1(true, true) else A3D_WG1(true, false)
+  } else {
+    if (wide) A3D_WG1(false, true) else A3D_WG1(false, false)
+  }
+#undef A3D_WG1
+}
+
+// the kernel of the plan's channels-per-lane pair; false: there is none
+static bool wgrad_launch(const WgradArgs& a, const WgradPlan& p, dim3 grid, bool bias, hipStream_t st) {
+  static const bool force_wide = getenv("A3D_WGRAD_WIDE") && atoi(getenv("A3D_WGRAD_WIDE")) != 0;   // tests: the pointer build on small operands
+  const bool wide = force_wide || !wgrad_fits(a);
+#define A3D_WG(CX_, CY_)                                     \
+  if (p.cx == CX_ && p.cy == CY_) {                          \
+    wgrad_launch_one<CX_, CY_>(a, grid, bias, wide, st);     \
+    return true;                                             \
+  }
+  A3D_WG(2, 2) A3D_WG(2, 4) A3D_WG(2, 6) A3D_WG(2, 8) A3D_WG(4, 2) A3D_WG(4, 4) A3D_WG(4, 6) A3D_WG(4, 8)
+  A3D_WG(6, 2) A3D_WG(6, 4) A3D_WG(6, 6) A3D_WG(8, 2) A3D_WG(8, 4)
+#undef A3D_WG
+  return false;
+}
+
+static int wgrad_tables(const a3d_scene* s, int kind, int level_in, WgradArgs& a, const int** counts, int* ngroups) {
   if (!s || level_in < 0 || level_in >= A3D_NUM_LEVELS) {
     set_error("a3d_conv_wgrad: bad scene / level");
     return A3D_ERR_INVALID;
   }
-  a.tab = nullptr, a.out_map = nullptr, a.gmask = nullptr;
+  a.tab = nullptr, a.out_map = nullptr, a.list = nullptr, a.list_stride = 0;
+  int lk = -1, ll = 0;       // list kind / owning level
   switch (kind) {
     case A3D_OP_CONV3:
       a.K = 27, a.n_in = a.n_out = a.n_pos = s->lv[level_in].n;
-      a.tab = s->lv[level_in].nbr27, a.tab_stride = s->lv[level_in].npad, a.gmask = s->lv[level_in].gmask27;
+      a.tab = s->lv[level_in].nbr27, a.tab_stride = s->lv[level_in].npad;
+      lk = 0, ll = level_in;
       break;
     case A3D_OP_DOWN:
       if (level_in >= A3D_NUM_LEVELS - 1) goto bad;
       a.K = 8, a.n_in = s->lv[level_in].n, a.n_out = a.n_pos = s->lv[level_in + 1].n;
-      a.tab = s->lv[level_in].child8, a.tab_stride = s->lv[level_in + 1].npad, a.gmask = s->lv[level_in].gmask_down;
+      a.tab = s->lv[level_in].child8, a.tab_stride = s->lv[level_in + 1].npad;
+      lk = 1, ll = level_in;
       break;
     case A3D_OP_UP:
       if (level_in < 1) goto bad;
       a.K = 8, a.n_in = s->lv[level_in].n, a.n_out = a.n_pos = s->lv[level_in - 1].n;
-      a.tab = s->lv[level_in - 1].up8, a.tab_stride = s->lv[level_in - 1].npad, a.gmask = s->lv[level_in - 1].gmask_up;
+      a.tab = s->lv[level_in - 1].up8, a.tab_stride = s->lv[level_in - 1].npad;
       a.out_map = s->lv[level_in - 1].up_rows;
+      lk = 2, ll = level_in - 1;
       break;
     case A3D_OP_LINEAR:
       a.K = 1, a.n_in = a.n_out = a.n_pos = s->lv[level_in].n;
@@ -320,7 +551,54 @@ static int wgrad_tables(const a3d_scene* s, int kind, int level_in, WgradArgs& a
       set_error("a3d_conv_wgrad: kind %d does not exist at level %d", kind, level_in);
       return A3D_ERR_INVALID;
   }
+  *ngroups = (a.n_pos + 15) / 16;
+  *counts = nullptr;
+  if (lk >= 0) {
+    if (!s->wg_ready) {
+      set_error("a3d_conv_wgrad: the scene has no weight-gradient work lists (call a3d_scene_build_wgrad_lists once per scene)");
+      return A3D_ERR_INVALID;
+    }
+    a.list = s->wg_list[lk][ll], a.list_stride = s->wg_stride[lk][ll];
+    *counts = s->wg_count[lk][ll];
+  }
   return A3D_OK;
+}
+
+// ---- the work lists: for every (map kind, level, offset k) the 16-position groups that have offset k, ascending.  One
+// workgroup per (kind, level, k) walks the level's group masks 1024 at a time (ballot + prefix inside the wave, the 16
+// waves' totals through LDS) and appends; the counts go to the host once per scene (the launch plan needs them).
+struct ListJob {
+  const uint32_t* gmask;
+  int ngroups, k;
+  int* list;             // this offset's list
+  int* count;            // one int
+};
+__global__ void __launch_bounds__(1024) k_wgrad_lists(const ListJob* __restrict__ jobs) {
+  __shared__ int wsum[16];
+  __shared__ int carry;
+  const ListJob jb = jobs[blockIdx.x];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (threadIdx.x == 0) carry = 0;
+  __syncthreads();
+  for (int g0 = 0; g0 < jb.ngroups; g0 += 1024) {
+    const int g = g0 + threadIdx.x;
+    const bool has = g < jb.ngroups && ((jb.gmask[g] >> jb.k) & 1u);
+    const unsigned long long bal = __ballot(has);
+    const int below = __popcll(bal & ((1ull << lane) - 1ull));
+    if (lane == 0) wsum[wave] = __popcll(bal);
+    __syncthreads();
+    int before = carry;
+    for (int w = 0; w < wave; ++w) before += wsum[w];
+    if (has) jb.list[before + below] = g;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      int t = 0;
+      for (int w = 0; w < 16; ++w) t += wsum[w];
+      carry += t;
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *jb.count = carry;
 }
 
 // ---- weight gradient of the input convolution (5^3 or 3^3, 3 -> 32 channels; res16unet.py:225): the neighbours are
@@ -476,7 +754,7 @@ using namespace a3d;
 // points or over the queries: attention_block.py, agile3d.py:51-55): the 1x1 case of a3d_conv_wgrad without a scene
 extern "C" size_t a3d_linear_wgrad_workspace_bytes(int64_t n, int cin, int cout) {
   WgradPlan p;
-  if (n <= 0 || n > (int64_t)1 << 30 || !wgrad_plan((int)n, 1, cin, cout, p)) {
+  if (n <= 0 || n > (int64_t)1 << 30 || !wgrad_plan((int)((n + 15) / 16), 1, nullptr, cin, cout, p)) {
     set_error("a3d_linear_wgrad: channels must be multiples of 32 (got %d -> %d)", cin, cout);
     return 0;
   }
@@ -486,7 +764,7 @@ extern "C" int a3d_linear_wgrad(const float* x_dev, int ldx, const float* dy_dev
                                 float* dw_dev, void* workspace_dev, size_t workspace_bytes, void* stream) {
   WgradPlan p;
   if (!x_dev || !dy_dev || !dw_dev || !workspace_dev || n <= 0 || n > (int64_t)1 << 30 || ldx < cin || ldy < cout ||
-      (ldx & 1) || (ldy & 1) || !wgrad_plan((int)n, 1, cin, cout, p)) {
+      (ldx & 1) || (ldy & 1) || !wgrad_plan((int)((n + 15) / 16), 1, nullptr, cin, cout, p)) {
     set_error("a3d_linear_wgrad: bad arguments (channels multiples of 32, even leading dimensions)");
     return A3D_ERR_INVALID;
   }
@@ -499,25 +777,15 @@ extern "C" int a3d_linear_wgrad(const float* x_dev, int ldx, const float* dy_dev
   memset(&a, 0, sizeof(a));
   a.x = x_dev, a.dy = dy_dev, a.ldx = ldx, a.ldy = ldy, a.cin = cin, a.cout = cout;
   a.K = 1, a.n_in = a.n_out = a.n_pos = (int)n;
-  a.chunk_groups = p.chunk_groups;
-  a.n_chunks = p.chunks;
+  wgrad_fill(p, a);
   a.part = (float*)workspace_dev;
-  const dim3 grid((unsigned)((p.chunks + 7) / 8 * 8), 1, p.nblocks);
-  const size_t lds = (size_t)16 * p.cx * 16 * p.cy * sizeof(float);
-#define A3D_WG(CX_, CY_)                                                                                          \
-  if (p.cx == CX_ && p.cy == CY_) {                                                                               \
-    A3D_ALLOW_LDS(64 * 1024, k_wgrad<CX_, CY_>); \
-    k_wgrad<CX_, CY_><<<grid, 256, lds, st>>>(a);                                                                  \
-  } else
-  A3D_WG(2, 2) A3D_WG(2, 4) A3D_WG(2, 6) A3D_WG(2, 8) A3D_WG(4, 2) A3D_WG(4, 4) A3D_WG(4, 6) A3D_WG(4, 8)
-  A3D_WG(6, 2) A3D_WG(6, 4) A3D_WG(6, 6) A3D_WG(8, 2) A3D_WG(8, 4) {
+  const dim3 grid((unsigned)(p.grid_items * 8), 1, p.nblocks);
+  if (!wgrad_launch(a, p, grid, false, st)) {
     set_error("a3d_linear_wgrad: no kernel for %d x %d channels per lane", p.cx, p.cy);
     return A3D_ERR_UNSUPPORTED;
   }
-#undef A3D_WG
   A3D_LAUNCH_CHECK();
-  k_wgrad_reduce<<<(unsigned)(((size_t)cin * cout + 63) / 64), 64 * kRedLanes, 0, st>>>(a.part, p.chunks, 1, cin, cout, p.cx, p.cy,
-                                                                                        dw_dev);
+  wgrad_reduce_launch(a.part, p, 1, cin, cout, dw_dev, st);
   A3D_LAUNCH_CHECK();
   return A3D_OK;
 }
@@ -528,18 +796,18 @@ extern "C" int a3d_linear_wgrad(const float* x_dev, int ldx, const float* dy_dev
 // transposing copy, a zero-filled full-size matrix + slice copy + add per in_proj slice and two column-sum launches per layer
 extern "C" size_t a3d_linear_wgrad_into_workspace_bytes(int64_t n, int cin, int cout) {
   WgradPlan p;
-  if (n <= 0 || n > (int64_t)1 << 30 || !wgrad_plan((int)n, 1, cin, cout, p)) {
+  if (n <= 0 || n > (int64_t)1 << 30 || !wgrad_plan((int)((n + 15) / 16), 1, nullptr, cin, cout, p)) {
     set_error("a3d_linear_wgrad_into: channels must be multiples of 32 (got %d -> %d)", cin, cout);
     return 0;
   }
-  return align256(p.part_bytes) + align256((size_t)p.chunks * cout * sizeof(float)) + 256;
+  return align256(p.part_bytes) + align256((size_t)p.slots * cout * sizeof(float)) + 256;
 }
 extern "C" int a3d_linear_wgrad_into(const float* x_dev, int ldx, const float* dy_dev, int ldy, int64_t n, int cin, int cout,
                                      float* dw_dev, int ld_dw, int transposed, int accumulate, float* db_dev, int db_accumulate,
                                      void* workspace_dev, size_t workspace_bytes, void* stream) {
   WgradPlan p;
   if (!x_dev || !dy_dev || !dw_dev || !workspace_dev || n <= 0 || n > (int64_t)1 << 30 || ldx < cin || ldy < cout ||
-      (ldx & 1) || (ldy & 1) || ld_dw < (transposed ? cin : cout) || !wgrad_plan((int)n, 1, cin, cout, p)) {
+      (ldx & 1) || (ldy & 1) || ld_dw < (transposed ? cin : cout) || !wgrad_plan((int)((n + 15) / 16), 1, nullptr, cin, cout, p)) {
     set_error("a3d_linear_wgrad_into: bad arguments (channels multiples of 32, even leading dimensions, ld_dw >= row length)");
     return A3D_ERR_INVALID;
   }
@@ -552,28 +820,17 @@ extern "C" int a3d_linear_wgrad_into(const float* x_dev, int ldx, const float* d
   memset(&a, 0, sizeof(a));
   a.x = x_dev, a.dy = dy_dev, a.ldx = ldx, a.ldy = ldy, a.cin = cin, a.cout = cout;
   a.K = 1, a.n_in = a.n_out = a.n_pos = (int)n;
-  a.chunk_groups = p.chunk_groups;
-  a.n_chunks = p.chunks;
+  wgrad_fill(p, a);
   a.part = (float*)workspace_dev;
   a.bias_part = (float*)((char*)workspace_dev + align256(p.part_bytes));
-  const dim3 grid((unsigned)((p.chunks + 7) / 8 * 8), 1, p.nblocks);
-  const size_t lds = (size_t)16 * p.cx * 16 * p.cy * sizeof(float);
-#define A3D_WG(CX_, CY_)                                                                                          \
-  if (p.cx == CX_ && p.cy == CY_) {                                                                               \
-    A3D_ALLOW_LDS(64 * 1024, (k_wgrad<CX_, CY_, true>));                                                           \
-    A3D_ALLOW_LDS(64 * 1024, (k_wgrad<CX_, CY_, false>));                                                          \
-    if (db_dev) k_wgrad<CX_, CY_, true><<<grid, 256, lds, st>>>(a);                                                \
-    else k_wgrad<CX_, CY_, false><<<grid, 256, lds, st>>>(a);                                                      \
-  } else
-  A3D_WG(2, 2) A3D_WG(2, 4) A3D_WG(2, 6) A3D_WG(2, 8) A3D_WG(4, 2) A3D_WG(4, 4) A3D_WG(4, 6) A3D_WG(4, 8)
-  A3D_WG(6, 2) A3D_WG(6, 4) A3D_WG(6, 6) A3D_WG(8, 2) A3D_WG(8, 4) {
+  const dim3 grid((unsigned)(p.grid_items * 8), 1, p.nblocks);
+  if (!wgrad_launch(a, p, grid, db_dev != nullptr, st)) {
     set_error("a3d_linear_wgrad_into: no kernel for %d x %d channels per lane", p.cx, p.cy);
     return A3D_ERR_UNSUPPORTED;
   }
-#undef A3D_WG
   A3D_LAUNCH_CHECK();
   const int all = cin * cout + (db_dev ? cout : 0);
-  k_wgrad_reduce_into<<<(unsigned)((all + 63) / 64), 64 * kRedLanes, 0, st>>>(a.part, a.bias_part, p.chunks, cin, cout, p.cx, p.cy, dw_dev,
+  k_wgrad_reduce_into<<<(unsigned)((all + 63) / 64), 64 * kRedLanes, 0, st>>>(a.part, a.bias_part, p.slots, cin, cout, p.cx, p.cy, dw_dev,
                                                                             ld_dw, transposed, accumulate, db_dev, db_accumulate);
   A3D_LAUNCH_CHECK();
   return A3D_OK;
@@ -642,9 +899,11 @@ extern "C" int a3d_stem_wgrad(const a3d_scene* s, const float* feats3_dev, const
 
 extern "C" size_t a3d_conv_wgrad_workspace_bytes(const a3d_scene* s, int kind, int level_in, int cin, int cout) {
   WgradArgs a;
-  if (wgrad_tables(s, kind, level_in, a) != A3D_OK) return 0;
+  const int* counts;
+  int ngroups;
+  if (wgrad_tables(s, kind, level_in, a, &counts, &ngroups) != A3D_OK) return 0;
   WgradPlan p;
-  if (!wgrad_plan(a.n_pos, a.K, cin, cout, p)) {
+  if (!wgrad_plan(ngroups, a.K, counts, cin, cout, p)) {
     set_error("a3d_conv_wgrad: channels must be multiples of 32 (got %d -> %d)", cin, cout);
     return 0;
   }
@@ -655,11 +914,14 @@ extern "C" int a3d_conv_wgrad(const a3d_scene* s, int kind, int level_in, const 
                               const float* dy_dev, int ldy, int cin, int cout, float* dw_dev, void* workspace_dev,
                               size_t workspace_bytes, void* stream) {
   WgradArgs a;
-  int rc = wgrad_tables(s, kind, level_in, a);
+  memset(&a, 0, sizeof(a));
+  const int* counts;
+  int ngroups;
+  int rc = wgrad_tables(s, kind, level_in, a, &counts, &ngroups);
   if (rc) return rc;
   WgradPlan p;
   if (!x_dev || !dy_dev || !dw_dev || !workspace_dev || ldx < cin || ldy < cout || (ldx & 1) || (ldy & 1) ||
-      !wgrad_plan(a.n_pos, a.K, cin, cout, p)) {
+      !wgrad_plan(ngroups, a.K, counts, cin, cout, p)) {
     set_error("a3d_conv_wgrad: bad arguments (channels multiples of 32, even leading dimensions)");
     return A3D_ERR_INVALID;
   }
@@ -669,25 +931,86 @@ extern "C" int a3d_conv_wgrad(const a3d_scene* s, int kind, int level_in, const 
   }
   hipStream_t st = (hipStream_t)stream;
   a.x = x_dev, a.dy = dy_dev, a.ldx = ldx, a.ldy = ldy, a.cin = cin, a.cout = cout;
-  a.chunk_groups = p.chunk_groups;
-  a.n_chunks = p.chunks;
+  wgrad_fill(p, a);
   a.part = (float*)workspace_dev;
-  const dim3 grid((unsigned)((p.chunks + 7) / 8 * 8 * a.K), 1, p.nblocks);
-  const size_t lds = (size_t)16 * p.cx * 16 * p.cy * sizeof(float);
-#define A3D_WG(CX_, CY_)                                                                                          \
-  if (p.cx == CX_ && p.cy == CY_) {                                                                               \
-    A3D_ALLOW_LDS(64 * 1024, k_wgrad<CX_, CY_>); \
-    k_wgrad<CX_, CY_><<<grid, 256, lds, st>>>(a);                                                                  \
-  } else
-  A3D_WG(2, 2) A3D_WG(2, 4) A3D_WG(2, 6) A3D_WG(2, 8) A3D_WG(4, 2) A3D_WG(4, 4) A3D_WG(4, 6) A3D_WG(4, 8)
-  A3D_WG(6, 2) A3D_WG(6, 4) A3D_WG(6, 6) A3D_WG(8, 2) A3D_WG(8, 4) {
+  const dim3 grid((unsigned)(p.grid_items * 8), 1, p.nblocks);
+  if (!wgrad_launch(a, p, grid, false, st)) {
     set_error("a3d_conv_wgrad: no kernel for %d x %d channels per lane", p.cx, p.cy);
     return A3D_ERR_UNSUPPORTED;
   }
-#undef A3D_WG
   A3D_LAUNCH_CHECK();
-  const size_t total = (size_t)a.K * cin * cout;
-  k_wgrad_reduce<<<(unsigned)((total + 63) / 64), 64 * kRedLanes, 0, st>>>(a.part, p.chunks, a.K, cin, cout, p.cx, p.cy, dw_dev);
+  wgrad_reduce_launch(a.part, p, a.K, cin, cout, dw_dev, st);
   A3D_LAUNCH_CHECK();
+  return A3D_OK;
+}
+
+// ---- the scene's weight-gradient work lists (once per scene, before the first a3d_conv_wgrad on it) ----------------------
+static int wgrad_list_jobs(const a3d_scene* s, ListJob* jobs, int* base_dev, size_t* ints) {
+  // jobs in (kind, level, k) order; lists packed behind one another with a stride of the level's group count
+  int nj = 0;
+  size_t off = 0;
+  for (int kind = 0; kind < 3; ++kind)
+    for (int l = 0; l < A3D_NUM_LEVELS; ++l) {
+      if (kind > 0 && l >= A3D_NUM_LEVELS - 1) continue;
+      const Level& lv = s->lv[l];
+      const int K = kind == 0 ? 27 : 8;
+      const uint32_t* gm = kind == 0 ? lv.gmask27 : kind == 1 ? lv.gmask_down : lv.gmask_up;
+      const int npos = kind == 1 ? s->lv[l + 1].n : lv.n;
+      const int ng = (npos + 15) / 16;
+      const int stride = (ng + 63) / 64 * 64;
+      for (int k = 0; k < K; ++k, ++nj)
+        if (jobs) {
+          jobs[nj].gmask = gm, jobs[nj].ngroups = ng, jobs[nj].k = k;
+          jobs[nj].list = base_dev + off + (size_t)k * stride;
+          jobs[nj].count = nullptr;     // filled by the caller (behind the lists)
+        }
+      off += (size_t)K * stride;
+    }
+  *ints = off;
+  return nj;
+}
+constexpr int kListJobs = 5 * 27 + 4 * 8 + 4 * 8;
+
+extern "C" size_t a3d_scene_wgrad_lists_bytes(const a3d_scene* s) {
+  if (!s) return 0;
+  size_t ints;
+  wgrad_list_jobs(s, nullptr, nullptr, &ints);
+  return align256(ints * sizeof(int)) + align256(kListJobs * sizeof(int)) + align256(kListJobs * sizeof(ListJob)) + 256;
+}
+
+extern "C" int a3d_scene_build_wgrad_lists(a3d_scene* s, void* workspace_dev, size_t workspace_bytes, void* stream) {
+  if (!s || !workspace_dev || ((uintptr_t)workspace_dev & 15) || workspace_bytes < a3d_scene_wgrad_lists_bytes(s) - 256) {
+    set_error("a3d_scene_build_wgrad_lists: bad scene or workspace (a3d_scene_wgrad_lists_bytes)");
+    return A3D_ERR_WORKSPACE;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  size_t ints;
+  ListJob jobs[kListJobs];
+  int* base = (int*)workspace_dev;
+  const int nj = wgrad_list_jobs(s, jobs, base, &ints);
+  int* counts_dev = (int*)((char*)workspace_dev + align256(ints * sizeof(int)));
+  ListJob* jobs_dev = (ListJob*)((char*)counts_dev + align256(kListJobs * sizeof(int)));
+  for (int i = 0; i < nj; ++i) jobs[i].count = counts_dev + i;
+  A3D_HIP_CHECK(hipMemcpyAsync(jobs_dev, jobs, sizeof(ListJob) * nj, hipMemcpyHostToDevice, st));
+  A3D_HIP_CHECK(hipStreamSynchronize(st));          // jobs[] lives on this stack frame
+  k_wgrad_lists<<<nj, 1024, 0, st>>>(jobs_dev);
+  A3D_LAUNCH_CHECK();
+  int counts[kListJobs];
+  A3D_HIP_CHECK(hipMemcpyAsync(counts, counts_dev, sizeof(int) * nj, hipMemcpyDeviceToHost, st));
+  A3D_HIP_CHECK(hipStreamSynchronize(st));
+  int j = 0;
+  size_t off = 0;
+  for (int kind = 0; kind < 3; ++kind)
+    for (int l = 0; l < A3D_NUM_LEVELS; ++l) {
+      if (kind > 0 && l >= A3D_NUM_LEVELS - 1) continue;
+      const int K = kind == 0 ? 27 : 8;
+      const int npos = kind == 1 ? s->lv[l + 1].n : s->lv[l].n;
+      const int stride = ((npos + 15) / 16 + 63) / 64 * 64;
+      s->wg_list[kind][l] = base + off;
+      s->wg_stride[kind][l] = stride;
+      for (int k = 0; k < K; ++k) s->wg_count[kind][l][k] = counts[j++];
+      off += (size_t)K * stride;
+    }
+  s->wg_ready = true;
   return A3D_OK;
 }

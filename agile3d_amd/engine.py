@@ -57,6 +57,16 @@ class Scene:
         # level-0 lookups go through a dense voxel grid when the batch's bounding box is small, else a hash table
         self.grid_dims = tuple(dims) if lib.a3d_scene_grid_dims(h, dims) == 1 else None
 
+    def prepare_wgrad(self):
+        """The weight-gradient work lists of this scene (a3d_scene_build_wgrad_lists), built on the current stream at the first
+        call; a3d_conv_wgrad refuses a scene without them."""
+        if getattr(self, "_wgrad_lists", None) is None:
+            lib = L.load()
+            nbytes = lib.a3d_scene_wgrad_lists_bytes(self.handle)
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=self.workspace.device)
+            L.check(lib.a3d_scene_build_wgrad_lists(self.handle, _ptr(ws), nbytes, _stream()), "a3d_scene_build_wgrad_lists")
+            self._wgrad_lists = ws
+
     def table(self, level: int, which: int) -> np.ndarray:
         """Copy one scene table to the host (tests / debugging)."""
         lib = L.load()

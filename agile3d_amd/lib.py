@@ -131,6 +131,8 @@ SYMBOLS = {
     "a3d_decoder_query_pack_floats": (C.c_size_t, [C.c_int32]),
     "a3d_decoder_mask_pack_floats": (C.c_size_t, []),
     "a3d_decoder_pack_query_weights": (C.c_int, [C.POINTER(DecoderWeights), C.c_int32, C.c_void_p, C.c_void_p]),
+    "a3d_scene_wgrad_lists_bytes": (C.c_size_t, [C.c_void_p]),
+    "a3d_scene_build_wgrad_lists": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "a3d_conv_wgrad_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]),
     "a3d_conv_wgrad": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int,
                                  C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
@@ -247,7 +249,7 @@ class A3DError(RuntimeError):
     pass
 
 
-ABI_VERSION = 2   # include/agile3d_hip.h: A3D_ABI_VERSION
+ABI_VERSION = 3   # include/agile3d_hip.h: A3D_ABI_VERSION
 
 
 def load():

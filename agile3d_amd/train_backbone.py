@@ -193,6 +193,7 @@ class BackboneTape:
         self.feats3 = feats3.to(torch.float32).contiguous()
         self.steps = []          # backward closures, in forward order
         self.wgrad_stream, self._side_used = _wgrad_stream(self.feats3.device), False
+        scene.prepare_wgrad()                 # on THIS stream, before the side stream's first weight gradient
         self.relu_levels = []
         self.grads = {}
         self._names = {id(p): n for n, p in model.named_parameters()}

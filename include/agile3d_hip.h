@@ -36,9 +36,9 @@ extern "C" {
 #define A3D_NUM_LEVELS 5           /* tensor strides 1,2,4,8,16 (res16unet.py:222-295) */
 
 /* Version of this interface: bumped whenever a struct grows or a buffer contract changes (2: a3d_op's fused-head fields, the
- * third block of a3d_decoder_sample::kv0_dev + kv0_blocks).  A host binding compares it with the header it was written
+ * third block of a3d_decoder_sample::kv0_dev + kv0_blocks; 3: a3d_conv_wgrad needs a3d_scene_build_wgrad_lists).  A host binding compares it with the header it was written
  * against before the first call (agile3d_amd/lib.py does). */
-#define A3D_ABI_VERSION 2
+#define A3D_ABI_VERSION 3
 int         a3d_version(void);
 const char* a3d_last_error(void);
 /* plain hipMemcpy device->host (+ stream sync); lets non-torch hosts and tests read tables */
@@ -206,7 +206,14 @@ int    a3d_program_run(const a3d_scene* s, const a3d_buf_desc* bufs, int n_bufs,
  * kind / level_in as in the op struct: A3D_OP_CONV3 / DOWN / UP / LINEAR, x [n_in][ldx], dy [n_out][ldy] in the scene's
  * internal row order, channels multiples of 32, dw_dev [K][cin][cout] (ME layout).  Deterministic (fixed summation
  * order).
+ * a3d_scene_build_wgrad_lists: once per scene before the first a3d_conv_wgrad on it (the 3^3 / stride-2 / transposed kinds
+ * refuse without it): for every kernel map of the scene and every offset k, the 16-position groups that have offset k, so
+ * that the kernel's work items are equal cuts of these lists instead of equal cuts of the rows.  The workspace
+ * (a3d_scene_wgrad_lists_bytes) must live as long as the scene is used for weight gradients; the call synchronises
+ * `stream` once (the list lengths come back to the host, where the launch plans are made).
  * ------------------------------------------------------------------------------------------ */
+size_t a3d_scene_wgrad_lists_bytes(const a3d_scene* s);
+int    a3d_scene_build_wgrad_lists(a3d_scene* s, void* workspace_dev, size_t workspace_bytes, void* stream);
 size_t a3d_conv_wgrad_workspace_bytes(const a3d_scene* s, int kind, int level_in, int cin, int cout);
 int    a3d_conv_wgrad(const a3d_scene* s, int kind, int level_in, const float* x_dev, int ldx,
                       const float* dy_dev, int ldy, int cin, int cout, float* dw_dev,

@@ -20,7 +20,7 @@ def test_library_exports_every_declared_symbol():
     assert declared == set(lib.SYMBOLS), declared ^ set(lib.SYMBOLS)
     for name in declared:
         assert hasattr(L, name)
-    assert L.a3d_version() == lib.ABI_VERSION == 2
+    assert L.a3d_version() == lib.ABI_VERSION == 3
     # pure host-side queries work without a GPU
     assert L.a3d_scene_workspace_bytes(80000) > 80000 * 27 * 4
     assert L.a3d_decoder_workspace_bytes(80000, 20) > 4 * 80000 * 128 * 4

@@ -89,6 +89,52 @@ def test_weight_grad_is_deterministic_and_checks_its_arguments(world):
         B.conv_weight_grad(sc, L.OP_CONV3, 0, x.cpu(), dy.cpu())                # no CPU path
 
 
+def test_weight_grad_needs_the_scene_work_lists_and_balances_over_them():
+    """a3d_conv_wgrad walks the scene's per-offset group lists (a3d_scene_build_wgrad_lists): a scene without them is refused
+    with a message that names the call, the Python wrapper builds them on first use, and the result on a scene where
+    whole offsets are missing from most groups (two far-apart clumps + isolated voxels: long runs of absent groups) still
+    matches a float64 evaluation of the pair sums."""
+    import ctypes as C
+    lib = L.load()
+    g = np.random.default_rng(3)
+    clump = np.stack(np.meshgrid(np.arange(12), np.arange(12), np.arange(12), indexing="ij"), -1).reshape(-1, 3)
+    lonely = g.integers(-400, 400, size=(600, 3)) * 3 + 1000               # no two of them adjacent
+    xyz = np.unique(np.concatenate([clump, clump + 200, lonely]), axis=0)
+    coords = np.concatenate([np.zeros((len(xyz), 1), np.int64), xyz], 1).astype(np.int32)
+    sc = Scene(torch.from_numpy(coords).cuda())
+    assert lib.a3d_conv_wgrad_workspace_bytes(sc.handle, L.OP_CONV3, 0, 32, 32) == 0
+    assert b"a3d_scene_build_wgrad_lists" in lib.a3d_last_error()
+    n = sc.n[0]
+    x = torch.randn(n, 64, generator=torch.Generator().manual_seed(1)).cuda()
+    dy = torch.randn(n, 32, generator=torch.Generator().manual_seed(2)).cuda()
+    dw = B.conv_weight_grad(sc, L.OP_CONV3, 0, x, dy)                        # builds the lists
+    assert lib.a3d_conv_wgrad_workspace_bytes(sc.handle, L.OP_CONV3, 0, 64, 32) > 0
+    npad = (n + 127) // 128 * 128
+    nb = torch.from_numpy(sc.table(0, L.TAB_NBR27).reshape(27, npad)[:, :n].astype(np.int64)).cuda()
+    x64, dy64 = x.double(), dy.double()
+    ref = torch.zeros(27, 64, 32, dtype=torch.float64, device="cuda")
+    for k in range(27):
+        ok = nb[k] < n
+        ref[k] = x64[nb[k][ok]].T @ dy64[ok]
+    err = (dw.double() - ref).abs().max().item()
+    assert err <= 1e-4 * max(1.0, ref.abs().max().item()), err
+    assert torch.equal(dw, B.conv_weight_grad(sc, L.OP_CONV3, 0, x, dy))
+
+
+def test_weight_grad_pointer_build_for_operands_beyond_a_buffer_descriptor():
+    """Operands of 4 GB and more cannot sit behind a buffer descriptor: k_wgrad<..., WIDE> gathers through 64-bit pointers
+    instead.  A3D_WGRAD_WIDE=1 forces that build on the small test operands (read once per process: own interpreter)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, A3D_WGRAD_WIDE="1")
+    out = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_backward.py"), "-x", "-q", "-p",
+                          "no:cacheprovider", "-k", "conv_backward_matches or linear_weight_grad or work_lists"], env=env,
+                         capture_output=True, text=True, timeout=1200, cwd=root)
+    assert out.returncode == 0, out.stdout[-3000:]
+
+
 def test_finite_difference_of_a_small_loss(world):
     """An oracle-free property: for loss = sum(conv(x; W) * R), dW from the kernels predicts the loss change of a
     weight perturbation (first order, fp64 accumulation of the loss on the host)."""

@@ -42,6 +42,7 @@ def main():
     ap.add_argument("--reps", type=int, default=10)
     ap.add_argument("--tape", action="store_true", help="also time a training-mode forward + backward of the backbone")
     ap.add_argument("--step", action="store_true", help="also time complete training iterations")
+    ap.add_argument("--only", type=int, default=-1, help="only this case of the table (PMC passes: one shape per kernel name)")
     a = ap.parse_args()
     coords = np.concatenate([make_scene(a.voxels, seed=b, batch_index=b)["coords"] for b in range(a.batch)])
     sc = Scene(torch.from_numpy(coords).cuda())
@@ -51,7 +52,7 @@ def main():
         npad = (max(sc.n[lvl], 1) + 127) // 128 * 128
         nb = sc.table(lvl, L.TAB_NBR27).reshape(27, npad)
         pairs3.append(int((nb[:, :sc.n[lvl]] < sc.n[lvl]).sum()))
-    for name, kind, lvl, cin, cout in CASES:
+    for name, kind, lvl, cin, cout in (CASES if a.only < 0 else CASES[a.only:a.only + 1]):
         lo = B.level_out(kind, lvl)
         K = {L.OP_CONV3: 27, L.OP_DOWN: 8, L.OP_UP: 8, L.OP_LINEAR: 1}[kind]
         pairs = pairs3[lvl] if kind == L.OP_CONV3 else sc.n[min(lvl, lo)]
