@@ -296,7 +296,8 @@ __global__ void __launch_bounds__(256) k_wgrad(const WgradArgs a) {
 struct SlotBase {
   int base[28];          // offset k's partial slots are base[k] .. base[k + 1] - 1
 };
-template <int NW>          // waves per workgroup: 4, or 16 where an offset has many slots
+constexpr int NW = 4;      // waves per workgroup (small workgroups: the kernel runs next to the input-gradient convs, whose
+                           // workgroups leave a CU only a few wave slots at a time -- 1024-thread workgroups waited 100 us for a place)
 __global__ void __launch_bounds__(64 * NW) k_wgrad_reduce(const float* __restrict__ part, const SlotBase sb, int cin, int cout, int cx, int cy,
                                                          float* __restrict__ dw) {
   __shared__ f32x4 sh[NW - 1][4][64];
@@ -315,11 +316,24 @@ __global__ void __launch_bounds__(64 * NW) k_wgrad_reduce(const float* __restric
   f32x4 acc[4];
 #pragma unroll
   for (int t = 0; t < 4; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  for (int c = sb.base[k] + wave; c < sb.base[k + 1]; c += NW) {
-    const f32x4* q = P + (size_t)c * tiles_per_slot * 64 + first;
+  // four slots per iteration in flight (a wave's slots are a chain of fetch -> add otherwise); the sums stay in slot order
+  const size_t slot_stride = tiles_per_slot * 64;
+  const int c_end = sb.base[k + 1];
+  for (int c = sb.base[k] + wave; c < c_end; c += 4 * NW) {
+    f32x4 v[4][4];
 #pragma unroll
-    for (int t = 0; t < 4; ++t)
-      if (t < nt) acc[t] += q[t * 64];
+    for (int q = 0; q < 4; ++q) {
+      const int cq = c + q * NW;
+      const f32x4* src = P + (size_t)(cq < c_end ? cq : c) * slot_stride + first;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) v[q][t] = src[(t < nt ? t : 0) * 64];
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      if (c + q * NW < c_end) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[t] += v[q][t];
+      }
   }
   if (wave) {
 #pragma unroll
@@ -455,7 +469,8 @@ static bool wgrad_plan(int ngroups, int K, const int* counts, int cin, int cout,
       // one wave per SIMD keeps ~0.65 of the matrix pipe busy (it waits for its rows in between), r of them min(0.92, 0.65 r)
       const double pipe = 0.65 * resident < 0.92 ? 0.65 * resident : 0.92;
       const double item = ((seg + 3) / 4) * step_clk * resident / pipe + fixed_clk;
-      const double reduce = 5000.0 + (double)p.slots * cin * cout * 4.0 / 800.0;   // a launch + the partials at ~2 TB/s, in clocks
+      // a launch + the partials written and read again (measured ~1 TB/s each way next to the input-gradient convs), in clocks
+      const double reduce = 8000.0 + (double)p.slots * cin * cout * 4.0 / 200.0;
       const double cost = rounds * item + reduce;
       if (!best_seg || cost < best_cost) best_cost = cost, best_seg = seg;
     }
@@ -477,8 +492,7 @@ static void wgrad_reduce_launch(const float* part, const WgradPlan& p, int K, in
   SlotBase sb;
   memcpy(sb.base, p.base, sizeof(sb.base));
   const unsigned units = (unsigned)(K * p.nblocks * p.cx * (p.cy > 4 ? 2 : 1));
-  if (p.slots >= 12 * K) k_wgrad_reduce<16><<<units, 1024, 0, st>>>(part, sb, cin, cout, p.cx, p.cy, dw);
-  else k_wgrad_reduce<4><<<units, 256, 0, st>>>(part, sb, cin, cout, p.cx, p.cy, dw);
+  k_wgrad_reduce<<<units, 64 * NW, 0, st>>>(part, sb, cin, cout, p.cx, p.cy, dw);
 }
 
 // a buffer descriptor spans < 4 GB and the "no pair" offset must lie past the end with room for a row's column offset
