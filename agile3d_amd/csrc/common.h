@@ -244,4 +244,5 @@ struct a3d_scene {
   int wg_stride[3][A3D_NUM_LEVELS] = {};
   int wg_count[3][A3D_NUM_LEVELS][27] = {};
   bool wg_ready = false;
+  uint64_t serial = 0;          // unique per scene of the process (a3d_scene_create): key of the launch-plan cache in wgrad.hip
 };

@@ -827,6 +827,10 @@ extern "C" int a3d_scene_create(const int32_t* coords4_dev, int64_t n_voxels, vo
 
   // ---- phase 2: per-level tables with exact sizes
   a3d_scene* sc = new a3d_scene();
+  {
+    static std::atomic<uint64_t> next_serial{1};
+    sc->serial = next_serial.fetch_add(1);
+  }
   sc->n0 = n0;
   sc->n_batch = n_batch;
   for (int bi = 0; bi < n_batch; ++bi) sc->batch_start[bi] = sizes[8 + bi];

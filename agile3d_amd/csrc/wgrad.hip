@@ -16,6 +16,8 @@
 // a second kernel in segment order: the result does not depend on scheduling.
 #include "common.h"
 #include <stdlib.h>
+#include <mutex>
+#include <unordered_map>
 
 namespace a3d {
 
@@ -481,6 +483,41 @@ static bool wgrad_plan(int ngroups, int K, const int* counts, int cin, int cout,
   return true;
 }
 
+// The plan of a (scene map, channel pair) is made once: the search over segment lengths costs the host 13-23 us, an
+// iteration asks ~110 times (each entry point twice: workspace size, then the launch).  serial = 0: a 1x1 map without a scene.
+struct PlanKey {
+  uint64_t serial;
+  int kind_level, ngroups, K, cin, cout;
+  bool operator==(const PlanKey& o) const {
+    return serial == o.serial && kind_level == o.kind_level && ngroups == o.ngroups && K == o.K && cin == o.cin && cout == o.cout;
+  }
+};
+struct PlanKeyHash {
+  size_t operator()(const PlanKey& k) const {
+    uint64_t h = k.serial * 0x9E3779B97F4A7C15ull;
+    for (int v : {k.kind_level, k.ngroups, k.K, k.cin, k.cout}) h = (h ^ (uint64_t)(uint32_t)v) * 0x100000001B3ull;
+    return (size_t)h;
+  }
+};
+static bool wgrad_plan_cached(uint64_t serial, int kind_level, int ngroups, int K, const int* counts, int cin, int cout, WgradPlan& p) {
+  static std::mutex mu;
+  static std::unordered_map<PlanKey, WgradPlan, PlanKeyHash> cache;
+  const PlanKey key{serial, kind_level, ngroups, K, cin, cout};
+  {
+    std::lock_guard<std::mutex> lock(mu);
+    auto it = cache.find(key);
+    if (it != cache.end()) {
+      p = it->second;
+      return true;
+    }
+  }
+  if (!wgrad_plan(ngroups, K, counts, cin, cout, p)) return false;
+  std::lock_guard<std::mutex> lock(mu);
+  if (cache.size() > 2048) cache.clear();      // scenes come and go (one per training iteration): the plans of dead ones are never asked for again
+  cache.emplace(key, p);
+  return true;
+}
+
 static void wgrad_fill(const WgradPlan& p, WgradArgs& a) {
   a.seg_len = p.seg_len;
   memcpy(a.cnt, p.cnt, sizeof(a.cnt));
@@ -581,16 +618,30 @@ static int wgrad_tables(const a3d_scene* s, int kind, int level_in, WgradArgs& a
 // ---- the work lists: for every (map kind, level, offset k) the 16-position groups that have offset k, ascending.  One
 // workgroup per (kind, level, k) walks the level's group masks 1024 at a time (ballot + prefix inside the wave, the 16
 // waves' totals through LDS) and appends; the counts go to the host once per scene (the launch plan needs them).
+constexpr int kListMaps = 5 + 4 + 4;          // 3^3 maps of five levels, stride-2 and transposed maps of four
+struct ListSet {
+  const uint32_t* gmask[kListMaps];
+  int* list[kListMaps];                        // [K][stride]
+  int ngroups[kListMaps], stride[kListMaps];
+  int first_job[kListMaps + 1];                // workgroup (job) b belongs to map m with first_job[m] <= b < first_job[m + 1]: offset k = b - first_job[m]
+  int* counts;                                 // [jobs]
+};
 struct ListJob {
   const uint32_t* gmask;
   int ngroups, k;
   int* list;             // this offset's list
   int* count;            // one int
 };
-__global__ void __launch_bounds__(1024) k_wgrad_lists(const ListJob* __restrict__ jobs) {
+__global__ void __launch_bounds__(1024) k_wgrad_lists(const ListSet S) {
   __shared__ int wsum[16];
   __shared__ int carry;
-  const ListJob jb = jobs[blockIdx.x];
+  int m = 0;
+  while (m + 1 < kListMaps && (int)blockIdx.x >= S.first_job[m + 1]) ++m;
+  ListJob jb;
+  jb.k = blockIdx.x - S.first_job[m];
+  jb.gmask = S.gmask[m], jb.ngroups = S.ngroups[m];
+  jb.list = S.list[m] + (size_t)jb.k * S.stride[m];
+  jb.count = S.counts + blockIdx.x;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   if (threadIdx.x == 0) carry = 0;
   __syncthreads();
@@ -768,7 +819,7 @@ using namespace a3d;
 // points or over the queries: attention_block.py, agile3d.py:51-55): the 1x1 case of a3d_conv_wgrad without a scene
 extern "C" size_t a3d_linear_wgrad_workspace_bytes(int64_t n, int cin, int cout) {
   WgradPlan p;
-  if (n <= 0 || n > (int64_t)1 << 30 || !wgrad_plan((int)((n + 15) / 16), 1, nullptr, cin, cout, p)) {
+  if (n <= 0 || n > (int64_t)1 << 30 || !wgrad_plan_cached(0, 0, (int)((n + 15) / 16), 1, nullptr, cin, cout, p)) {
     set_error("a3d_linear_wgrad: channels must be multiples of 32 (got %d -> %d)", cin, cout);
     return 0;
   }
@@ -778,7 +829,7 @@ extern "C" int a3d_linear_wgrad(const float* x_dev, int ldx, const float* dy_dev
                                 float* dw_dev, void* workspace_dev, size_t workspace_bytes, void* stream) {
   WgradPlan p;
   if (!x_dev || !dy_dev || !dw_dev || !workspace_dev || n <= 0 || n > (int64_t)1 << 30 || ldx < cin || ldy < cout ||
-      (ldx & 1) || (ldy & 1) || !wgrad_plan((int)((n + 15) / 16), 1, nullptr, cin, cout, p)) {
+      (ldx & 1) || (ldy & 1) || !wgrad_plan_cached(0, 0, (int)((n + 15) / 16), 1, nullptr, cin, cout, p)) {
     set_error("a3d_linear_wgrad: bad arguments (channels multiples of 32, even leading dimensions)");
     return A3D_ERR_INVALID;
   }
@@ -810,7 +861,7 @@ extern "C" int a3d_linear_wgrad(const float* x_dev, int ldx, const float* dy_dev
 // transposing copy, a zero-filled full-size matrix + slice copy + add per in_proj slice and two column-sum launches per layer
 extern "C" size_t a3d_linear_wgrad_into_workspace_bytes(int64_t n, int cin, int cout) {
   WgradPlan p;
-  if (n <= 0 || n > (int64_t)1 << 30 || !wgrad_plan((int)((n + 15) / 16), 1, nullptr, cin, cout, p)) {
+  if (n <= 0 || n > (int64_t)1 << 30 || !wgrad_plan_cached(0, 0, (int)((n + 15) / 16), 1, nullptr, cin, cout, p)) {
     set_error("a3d_linear_wgrad_into: channels must be multiples of 32 (got %d -> %d)", cin, cout);
     return 0;
   }
@@ -821,7 +872,7 @@ extern "C" int a3d_linear_wgrad_into(const float* x_dev, int ldx, const float* d
                                      void* workspace_dev, size_t workspace_bytes, void* stream) {
   WgradPlan p;
   if (!x_dev || !dy_dev || !dw_dev || !workspace_dev || n <= 0 || n > (int64_t)1 << 30 || ldx < cin || ldy < cout ||
-      (ldx & 1) || (ldy & 1) || ld_dw < (transposed ? cin : cout) || !wgrad_plan((int)((n + 15) / 16), 1, nullptr, cin, cout, p)) {
+      (ldx & 1) || (ldy & 1) || ld_dw < (transposed ? cin : cout) || !wgrad_plan_cached(0, 0, (int)((n + 15) / 16), 1, nullptr, cin, cout, p)) {
     set_error("a3d_linear_wgrad_into: bad arguments (channels multiples of 32, even leading dimensions, ld_dw >= row length)");
     return A3D_ERR_INVALID;
   }
@@ -917,7 +968,7 @@ extern "C" size_t a3d_conv_wgrad_workspace_bytes(const a3d_scene* s, int kind, i
   int ngroups;
   if (wgrad_tables(s, kind, level_in, a, &counts, &ngroups) != A3D_OK) return 0;
   WgradPlan p;
-  if (!wgrad_plan(ngroups, a.K, counts, cin, cout, p)) {
+  if (!wgrad_plan_cached(s->serial, kind * 16 + level_in, ngroups, a.K, counts, cin, cout, p)) {
     set_error("a3d_conv_wgrad: channels must be multiples of 32 (got %d -> %d)", cin, cout);
     return 0;
   }
@@ -935,7 +986,7 @@ extern "C" int a3d_conv_wgrad(const a3d_scene* s, int kind, int level_in, const 
   if (rc) return rc;
   WgradPlan p;
   if (!x_dev || !dy_dev || !dw_dev || !workspace_dev || ldx < cin || ldy < cout || (ldx & 1) || (ldy & 1) ||
-      !wgrad_plan(ngroups, a.K, counts, cin, cout, p)) {
+      !wgrad_plan_cached(s->serial, kind * 16 + level_in, ngroups, a.K, counts, cin, cout, p)) {
     set_error("a3d_conv_wgrad: bad arguments (channels multiples of 32, even leading dimensions)");
     return A3D_ERR_INVALID;
   }
@@ -959,27 +1010,27 @@ extern "C" int a3d_conv_wgrad(const a3d_scene* s, int kind, int level_in, const 
 }
 
 // ---- the scene's weight-gradient work lists (once per scene, before the first a3d_conv_wgrad on it) ----------------------
-static int wgrad_list_jobs(const a3d_scene* s, ListJob* jobs, int* base_dev, size_t* ints) {
-  // jobs in (kind, level, k) order; lists packed behind one another with a stride of the level's group count
-  int nj = 0;
+// the maps in (kind, level) order; lists packed behind one another with a stride of the level's group count
+static int wgrad_list_set(const a3d_scene* s, int* base_dev, ListSet* S, size_t* ints) {
+  int m = 0, nj = 0;
   size_t off = 0;
   for (int kind = 0; kind < 3; ++kind)
     for (int l = 0; l < A3D_NUM_LEVELS; ++l) {
       if (kind > 0 && l >= A3D_NUM_LEVELS - 1) continue;
       const Level& lv = s->lv[l];
       const int K = kind == 0 ? 27 : 8;
-      const uint32_t* gm = kind == 0 ? lv.gmask27 : kind == 1 ? lv.gmask_down : lv.gmask_up;
       const int npos = kind == 1 ? s->lv[l + 1].n : lv.n;
       const int ng = (npos + 15) / 16;
       const int stride = (ng + 63) / 64 * 64;
-      for (int k = 0; k < K; ++k, ++nj)
-        if (jobs) {
-          jobs[nj].gmask = gm, jobs[nj].ngroups = ng, jobs[nj].k = k;
-          jobs[nj].list = base_dev + off + (size_t)k * stride;
-          jobs[nj].count = nullptr;     // filled by the caller (behind the lists)
-        }
+      if (S) {
+        S->gmask[m] = kind == 0 ? lv.gmask27 : kind == 1 ? lv.gmask_down : lv.gmask_up;
+        S->list[m] = base_dev + off;
+        S->ngroups[m] = ng, S->stride[m] = stride, S->first_job[m] = nj;
+      }
       off += (size_t)K * stride;
+      nj += K, ++m;
     }
+  if (S) S->first_job[m] = nj;
   *ints = off;
   return nj;
 }
@@ -988,8 +1039,8 @@ constexpr int kListJobs = 5 * 27 + 4 * 8 + 4 * 8;
 extern "C" size_t a3d_scene_wgrad_lists_bytes(const a3d_scene* s) {
   if (!s) return 0;
   size_t ints;
-  wgrad_list_jobs(s, nullptr, nullptr, &ints);
-  return align256(ints * sizeof(int)) + align256(kListJobs * sizeof(int)) + align256(kListJobs * sizeof(ListJob)) + 256;
+  wgrad_list_set(s, nullptr, nullptr, &ints);
+  return align256(ints * sizeof(int)) + align256(kListJobs * sizeof(int)) + 256;
 }
 
 extern "C" int a3d_scene_build_wgrad_lists(a3d_scene* s, void* workspace_dev, size_t workspace_bytes, void* stream) {
@@ -999,31 +1050,24 @@ extern "C" int a3d_scene_build_wgrad_lists(a3d_scene* s, void* workspace_dev, si
   }
   hipStream_t st = (hipStream_t)stream;
   size_t ints;
-  ListJob jobs[kListJobs];
+  ListSet S;
   int* base = (int*)workspace_dev;
-  const int nj = wgrad_list_jobs(s, jobs, base, &ints);
-  int* counts_dev = (int*)((char*)workspace_dev + align256(ints * sizeof(int)));
-  ListJob* jobs_dev = (ListJob*)((char*)counts_dev + align256(kListJobs * sizeof(int)));
-  for (int i = 0; i < nj; ++i) jobs[i].count = counts_dev + i;
-  A3D_HIP_CHECK(hipMemcpyAsync(jobs_dev, jobs, sizeof(ListJob) * nj, hipMemcpyHostToDevice, st));
-  A3D_HIP_CHECK(hipStreamSynchronize(st));          // jobs[] lives on this stack frame
-  k_wgrad_lists<<<nj, 1024, 0, st>>>(jobs_dev);
+  const int nj = wgrad_list_set(s, base, &S, &ints);
+  S.counts = (int*)((char*)workspace_dev + align256(ints * sizeof(int)));
+  k_wgrad_lists<<<nj, 1024, 0, st>>>(S);
   A3D_LAUNCH_CHECK();
   int counts[kListJobs];
-  A3D_HIP_CHECK(hipMemcpyAsync(counts, counts_dev, sizeof(int) * nj, hipMemcpyDeviceToHost, st));
+  A3D_HIP_CHECK(hipMemcpyAsync(counts, S.counts, sizeof(int) * nj, hipMemcpyDeviceToHost, st));
   A3D_HIP_CHECK(hipStreamSynchronize(st));
-  int j = 0;
-  size_t off = 0;
+  int j = 0, m = 0;
   for (int kind = 0; kind < 3; ++kind)
     for (int l = 0; l < A3D_NUM_LEVELS; ++l) {
       if (kind > 0 && l >= A3D_NUM_LEVELS - 1) continue;
       const int K = kind == 0 ? 27 : 8;
-      const int npos = kind == 1 ? s->lv[l + 1].n : s->lv[l].n;
-      const int stride = ((npos + 15) / 16 + 63) / 64 * 64;
-      s->wg_list[kind][l] = base + off;
-      s->wg_stride[kind][l] = stride;
+      s->wg_list[kind][l] = S.list[m];
+      s->wg_stride[kind][l] = S.stride[m];
       for (int k = 0; k < K; ++k) s->wg_count[kind][l][k] = counts[j++];
-      off += (size_t)K * stride;
+      ++m;
     }
   s->wg_ready = true;
   return A3D_OK;
