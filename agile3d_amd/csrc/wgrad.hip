@@ -89,6 +89,30 @@ __device__ __forceinline__ void load_c(__amdgpu_buffer_rsrc_t r, int off, int of
 
 constexpr unsigned kNoRow = 0xFFFFF000u;   // byte offset of "no pair": past every buffer this kernel accepts (a3d: wgrad_fits)
 
+// the two pieces of load_c on their own (the step loop spreads a step's loads over its MFMAs)
+template <int C>
+__device__ __forceinline__ void load_piece1(__amdgpu_buffer_rsrc_t r, int off, float (&v)[C]) {
+  if constexpr (C == 2) {
+    const f32x2 a = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(r, off, 0, 0));
+    v[0] = a[0], v[1] = a[1];
+  } else {
+    const f32x4 a = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0));
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = a[i];
+  }
+}
+template <int C>
+__device__ __forceinline__ void load_piece2(__amdgpu_buffer_rsrc_t r, int off2, float (&v)[C]) {
+  if constexpr (C == 6) {
+    const f32x2 b = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(r, off2, 0, 0));
+    v[4] = b[0], v[5] = b[1];
+  } else if constexpr (C == 8) {
+    const f32x4 b = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, off2, 0, 0));
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[4 + i] = b[i];
+  }
+}
+
 // 16 / 24 / 32 bytes through a plain pointer (WIDE builds: operands of 4 GB and more, which a buffer descriptor cannot span)
 template <int C>
 __device__ __forceinline__ void load_p(const float* p, const float* p2, float (&v)[C]) {
@@ -205,6 +229,38 @@ __global__ void __launch_bounds__(256) k_wgrad(const WgradArgs a) {
       for (int ty = 0; ty < CY; ++ty)
         acc[tx][ty] = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[tx], yv[ty], acc[tx][ty], 0, 0, 0);
   };
+  // one step: the MFMAs of (xv, yv) with the loads of a later step (rows 4 s2 .. of the group behind xo2 / yo2, into xd / yd)
+  // SPREAD over them (same-box A/B against the step's two to four load instructions issued back to back: -2 .. -6 %)
+  auto step = [&](const float (&xv)[CX], const float (&yv)[CY], unsigned xo2, unsigned yo2, int s2, float (&xd)[CX], float (&yd)[CY]) {
+    if constexpr (WIDE) {
+      load_rows(xo2, yo2, s2, xd, yd);
+      __builtin_amdgcn_sched_barrier(0);
+      multiply(xv, yv);
+      __builtin_amdgcn_sched_barrier(0);
+    } else {
+      const unsigned xr = (unsigned)__builtin_amdgcn_ds_bpermute(bperm[s2], (int)xo2);
+      const unsigned yr = (unsigned)__builtin_amdgcn_ds_bpermute(bperm[s2], (int)yo2);
+      if constexpr (BIAS) {
+#pragma unroll
+        for (int i = 0; i < CY; ++i) ys[i] += yv[i];
+      }
+      constexpr int nP = 2 + (CX > 4 ? 1 : 0) + (CY > 4 ? 1 : 0);           // load instructions of a step: x1 [x2] y1 [y2]
+      constexpr int iY1 = CX > 4 ? 2 : 1, iY2 = iY1 + 1;
+      auto slot = [](int i) { return i * CX / nP < CX - 1 ? i * CX / nP : CX - 1; };
+#pragma unroll
+      for (int tx = 0; tx < CX; ++tx) {
+#pragma unroll
+        for (int ty = 0; ty < CY; ++ty)
+          acc[tx][ty] = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[tx], yv[ty], acc[tx][ty], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (tx == slot(0)) load_piece1<CX>(rx, (int)(xr + cx4), xd);
+        if (CX > 4 && tx == slot(1)) load_piece2<CX>(rx, (int)(xr + cx4b), xd);
+        if (tx == slot(iY1)) load_piece1<CY>(ry, (int)(yr + cy4), yd);
+        if (CY > 4 && tx == slot(iY2)) load_piece2<CY>(ry, (int)(yr + cy4b), yd);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  };
   int e = e_begin + wave;                       // this wave's entries: e_begin + wave, + 4, ...
   int grp = group_of(e), ngrp = group_of(e + 4);
   int xi, yi, xi_n, yi_n;
@@ -226,22 +282,10 @@ __global__ void __launch_bounds__(256) k_wgrad(const WgradArgs a) {
     request_pairs(nngrp, xi_nn, yi_nn);
     // (scheduling barriers: left alone, the compiler sinks the loads behind two steps of MFMAs to save registers and
     // drains the queue to vmcnt(1) before it issues the next ones)
-    load_rows(xo, yo, 3, xb[3], yb[3]);
-    __builtin_amdgcn_sched_barrier(0);
-    multiply(xb[0], yb[0]);
-    __builtin_amdgcn_sched_barrier(0);
-    load_rows(xo_n, yo_n, 0, xb[0], yb[0]);     // past the last group: offsets are kNoRow, the loads touch no memory
-    __builtin_amdgcn_sched_barrier(0);
-    multiply(xb[1], yb[1]);
-    __builtin_amdgcn_sched_barrier(0);
-    load_rows(xo_n, yo_n, 1, xb[1], yb[1]);
-    __builtin_amdgcn_sched_barrier(0);
-    multiply(xb[2], yb[2]);
-    __builtin_amdgcn_sched_barrier(0);
-    load_rows(xo_n, yo_n, 2, xb[2], yb[2]);
-    __builtin_amdgcn_sched_barrier(0);
-    multiply(xb[3], yb[3]);
-    __builtin_amdgcn_sched_barrier(0);
+    step(xb[0], yb[0], xo, yo, 3, xb[3], yb[3]);
+    step(xb[1], yb[1], xo_n, yo_n, 0, xb[0], yb[0]);     // past the last group: offsets are kNoRow, the loads touch no memory
+    step(xb[2], yb[2], xo_n, yo_n, 1, xb[1], yb[1]);
+    step(xb[3], yb[3], xo_n, yo_n, 2, xb[2], yb[2]);
     grp = ngrp, xo = xo_n, yo = yo_n;
     ngrp = nngrp;
     pair_offsets(nngrp, xi_nn, yi_nn, xo_n, yo_n);
