@@ -974,6 +974,15 @@ def main():
             try:
                 res["train_iter"] = train_iter_ms(dev)
                 res["train_iter_ms"] = res["train_iter"]["ms_without_click_rounds"]
+                # the backbone's training passes against the fp32-MFMA peak: forward + input gradient + weight gradient = 3 x the
+                # algorithmic conv FLOPs of a scene (counted above on the same 80 k-voxel scenes) x 4 scenes / (forward + backward ms)
+                ph = res["train_iter"]["phases_ms_median"]
+                if res.get("scene_algorithmic_gflop_convs") and abs(args.voxels - 80_000) < 1000:
+                    gf = 3.0 * res["scene_algorithmic_gflop_convs"] / args.batch * 4
+                    ms = ph["backbone forward"] + ph["backbone backward"]
+                    res["train_iter"]["backbone_fwd_bwd"] = {"ms": round(ms, 2), "algorithmic_gflop": round(gf, 1),
+                                                            "tflops": round(gf / ms, 1),
+                                                            "frac_of_fp32_mfma_peak": round(gf / ms / PEAK_FP32_MFMA_TFLOPS, 3)}
             except Exception as e:   # never lose the headline line over the extra
                 res["train_iter"] = {"error": f"{type(e).__name__}: {e}"[:300]}
         if not args.no_cpu_baseline and not args.steps_only and world == 1:
