@@ -244,5 +244,12 @@ struct a3d_scene {
   int wg_stride[3][A3D_NUM_LEVELS] = {};
   int wg_count[3][A3D_NUM_LEVELS][27] = {};
   bool wg_ready = false;
+  // the counts come back asynchronously: a3d_scene_build_wgrad_lists leaves a pending read-back (pinned buffer + event from a
+  // process-wide pool) that the first a3d_conv_wgrad on the scene waits for (wgrad.hip: wgrad_lists_finish)
+  void* wg_pending = nullptr;
   uint64_t serial = 0;          // unique per scene of the process (a3d_scene_create): key of the launch-plan cache in wgrad.hip
 };
+
+namespace a3d {
+void wgrad_scene_release(a3d_scene* s);   // wgrad.hip: gives a pending read-back of the work lists' counts back to its pool
+}

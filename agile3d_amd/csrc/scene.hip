@@ -956,7 +956,10 @@ extern "C" int a3d_scene_create(const int32_t* coords4_dev, int64_t n_voxels, vo
   return A3D_OK;
 }
 
-extern "C" void a3d_scene_destroy(a3d_scene* s) { delete s; }
+extern "C" void a3d_scene_destroy(a3d_scene* s) {
+  if (s) a3d::wgrad_scene_release(s);
+  delete s;
+}
 
 extern "C" int a3d_scene_batch_ranges(const a3d_scene* s, int64_t* starts_out, int max_out) {
   if (!s) return A3D_ERR_INVALID;

@@ -18,6 +18,7 @@
 #include <stdlib.h>
 #include <mutex>
 #include <unordered_map>
+#include <vector>
 
 namespace a3d {
 
@@ -612,6 +613,65 @@ static bool wgrad_launch(const WgradArgs& a, const WgradPlan& p, dim3 grid, bool
   return false;
 }
 
+// ---- the read-back of the work lists' counts: pinned buffer + event, pooled over the process (hipHostMalloc / hipEventCreate
+// cost more than the read-back they serve)
+constexpr int kListJobs = 5 * 27 + 4 * 8 + 4 * 8;
+struct ListReadback {
+  int* counts = nullptr;      // pinned [kListJobs]
+  hipEvent_t done = nullptr;
+};
+static std::mutex g_rb_mu;
+static std::vector<ListReadback*> g_rb_free;
+static ListReadback* readback_get() {
+  {
+    std::lock_guard<std::mutex> lock(g_rb_mu);
+    if (!g_rb_free.empty()) {
+      ListReadback* r = g_rb_free.back();
+      g_rb_free.pop_back();
+      return r;
+    }
+  }
+  ListReadback* r = new ListReadback();
+  if (hipHostMalloc((void**)&r->counts, sizeof(int) * kListJobs, hipHostMallocDefault) != hipSuccess ||
+      hipEventCreateWithFlags(&r->done, hipEventDisableTiming) != hipSuccess) {
+    (void)hipGetLastError();
+    if (r->counts) (void)hipHostFree(r->counts);
+    delete r;
+    return nullptr;
+  }
+  return r;
+}
+static void readback_put(ListReadback* r) {
+  std::lock_guard<std::mutex> lock(g_rb_mu);
+  g_rb_free.push_back(r);
+}
+// waits for a pending read-back (if any) and files the counts in the scene
+static int wgrad_lists_finish(a3d_scene* s) {
+  static std::mutex mu;                  // two host threads asking for the same scene's first weight gradient
+  std::lock_guard<std::mutex> lock(mu);
+  ListReadback* r = (ListReadback*)s->wg_pending;
+  if (!r) return A3D_OK;
+  A3D_HIP_CHECK(hipEventSynchronize(r->done));
+  int j = 0;
+  for (int kind = 0; kind < 3; ++kind)
+    for (int l = 0; l < A3D_NUM_LEVELS; ++l) {
+      if (kind > 0 && l >= A3D_NUM_LEVELS - 1) continue;
+      const int K = kind == 0 ? 27 : 8;
+      for (int k = 0; k < K; ++k) s->wg_count[kind][l][k] = r->counts[j++];
+    }
+  s->wg_pending = nullptr;
+  s->wg_ready = true;
+  readback_put(r);
+  return A3D_OK;
+}
+void wgrad_scene_release(a3d_scene* s) {
+  ListReadback* r = (ListReadback*)s->wg_pending;
+  if (!r) return;
+  (void)hipEventSynchronize(r->done);    // the copy into the pinned buffer must not land in the next owner's hands
+  s->wg_pending = nullptr;
+  readback_put(r);
+}
+
 static int wgrad_tables(const a3d_scene* s, int kind, int level_in, WgradArgs& a, const int** counts, int* ngroups) {
   if (!s || level_in < 0 || level_in >= A3D_NUM_LEVELS) {
     set_error("a3d_conv_wgrad: bad scene / level");
@@ -649,6 +709,10 @@ static int wgrad_tables(const a3d_scene* s, int kind, int level_in, WgradArgs& a
   *ngroups = (a.n_pos + 15) / 16;
   *counts = nullptr;
   if (lk >= 0) {
+    if (s->wg_pending) {                 // the lists were requested; their counts arrive now at the latest
+      const int rc = wgrad_lists_finish(const_cast<a3d_scene*>(s));
+      if (rc) return rc;
+    }
     if (!s->wg_ready) {
       set_error("a3d_conv_wgrad: the scene has no weight-gradient work lists (call a3d_scene_build_wgrad_lists once per scene)");
       return A3D_ERR_INVALID;
@@ -1078,8 +1142,6 @@ static int wgrad_list_set(const a3d_scene* s, int* base_dev, ListSet* S, size_t*
   *ints = off;
   return nj;
 }
-constexpr int kListJobs = 5 * 27 + 4 * 8 + 4 * 8;
-
 extern "C" size_t a3d_scene_wgrad_lists_bytes(const a3d_scene* s) {
   if (!s) return 0;
   size_t ints;
@@ -1098,21 +1160,32 @@ extern "C" int a3d_scene_build_wgrad_lists(a3d_scene* s, void* workspace_dev, si
   int* base = (int*)workspace_dev;
   const int nj = wgrad_list_set(s, base, &S, &ints);
   S.counts = (int*)((char*)workspace_dev + align256(ints * sizeof(int)));
+  if (s->wg_pending) wgrad_scene_release(s);      // a second request: the first one's read-back is dropped
+  s->wg_ready = false;
   k_wgrad_lists<<<nj, 1024, 0, st>>>(S);
   A3D_LAUNCH_CHECK();
-  int counts[kListJobs];
-  A3D_HIP_CHECK(hipMemcpyAsync(counts, S.counts, sizeof(int) * nj, hipMemcpyDeviceToHost, st));
-  A3D_HIP_CHECK(hipStreamSynchronize(st));
-  int j = 0, m = 0;
+  ListReadback* r = readback_get();
+  if (!r) {
+    set_error("a3d_scene_build_wgrad_lists: no pinned buffer / event for the read-back");
+    return A3D_ERR_HIP;
+  }
+  // no host round trip here (round 6, second half: the synchronisation stood between the scene build and the first conv
+  // of the training forward -- 0.4 ms of an idle device per iteration): the counts go to a pinned buffer behind an event
+  // that the first a3d_conv_wgrad / a3d_conv_wgrad_workspace_bytes on this scene waits for
+  if (hipMemcpyAsync(r->counts, S.counts, sizeof(int) * nj, hipMemcpyDeviceToHost, st) != hipSuccess ||
+      hipEventRecord(r->done, st) != hipSuccess) {
+    set_error("a3d_scene_build_wgrad_lists: %s", hipGetErrorString(hipGetLastError()));
+    readback_put(r);
+    return A3D_ERR_HIP;
+  }
+  int m = 0;
   for (int kind = 0; kind < 3; ++kind)
     for (int l = 0; l < A3D_NUM_LEVELS; ++l) {
       if (kind > 0 && l >= A3D_NUM_LEVELS - 1) continue;
-      const int K = kind == 0 ? 27 : 8;
       s->wg_list[kind][l] = S.list[m];
       s->wg_stride[kind][l] = S.stride[m];
-      for (int k = 0; k < K; ++k) s->wg_count[kind][l][k] = counts[j++];
       ++m;
     }
-  s->wg_ready = true;
+  s->wg_pending = r;
   return A3D_OK;
 }

@@ -58,8 +58,9 @@ class Scene:
         self.grid_dims = tuple(dims) if lib.a3d_scene_grid_dims(h, dims) == 1 else None
 
     def prepare_wgrad(self):
-        """The weight-gradient work lists of this scene (a3d_scene_build_wgrad_lists), built on the current stream at the first
-        call; a3d_conv_wgrad refuses a scene without them."""
+        """The weight-gradient work lists of this scene (a3d_scene_build_wgrad_lists), requested on the current stream at the
+        first call (no synchronisation: the first weight gradient waits for their lengths); a3d_conv_wgrad refuses a scene
+        without them."""
         if getattr(self, "_wgrad_lists", None) is None:
             lib = L.load()
             nbytes = lib.a3d_scene_wgrad_lists_bytes(self.handle)
@@ -520,6 +521,8 @@ class Engine:
         st.engine_id = id(self)
         st.train = True
         with torch.no_grad():
+            from .train_backbone import packed_weights_of
+            packed_weights_of(self.model).refresh_all()      # scene-independent: queued before the scene build's host round trip
             st.scene = Scene(x.C)
             tape = BackboneTape(self.model, st.scene, x.F.detach())
             st.ranges = st.scene.batch_ranges

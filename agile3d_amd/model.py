@@ -114,6 +114,21 @@ class Agile3d(nn.Module):
         self._engine = None          # lazily created agile3d_amd.engine.Engine
         self._packed_version = None
 
+    def train(self, mode: bool = True):
+        """``nn.Module.train`` walks the module tree recursively (~900 Python calls, 0.4 ms for this model); the training step
+        flips the mode three times per iteration (engine.py:53,84,118 of the reference), twice while the device has nothing
+        queued.  The flat list of modules is kept; the tree is fixed after ``__init__`` (``_flat_modules = None`` after
+        changing it by hand)."""
+        if not isinstance(mode, bool):
+            raise ValueError("training mode is expected to be boolean")
+        flat = self.__dict__.get("_flat_modules")
+        if flat is None:
+            flat = list(self.modules())
+            self.__dict__["_flat_modules"] = flat
+        for m in flat:
+            m.training = mode
+        return self
+
     # ------------------------------------------------------------------ engine plumbing
     def _get_engine(self):
         from .engine import Engine

@@ -55,24 +55,27 @@ def _train_one_step(model, criterion, optimizer, batch, device, max_norm):
                 torch.cuda.synchronize()
             marks.append((name, time.perf_counter()))
     mark("start")
-    # the gradient reducer (one small blocking digest all-reduce over the ranks) is made HERE, where the device is idle
-    # anyway, not between the decoder's and the backbone's backward where the host would stall behind the queue
-    from .optim import OverlappedAllReduce
-    reducer = OverlappedAllReduce(bucket_bytes=int(float(os.environ.get("A3D_DP_BUCKET_MB", "32")) * (1 << 20)),
-                                  expected={k: p.numel() for k, p in model.named_parameters() if p.requires_grad},
-                                  single_rank=os.environ.get("A3D_DP_SINGLE_RANK", "0") == "1")
+    n_samples = int(coords[:, 0].max()) + 1           # on the host copy when the batch arrives there (collation_fn): no device round trip
     coords = coords.to(device)
     raw_coords = raw_coords.to(device)
     feats = feats.to(device)
     labels = [l.to(device) for l in labels]
     batch_idx = coords[:, 0]
-    n_samples = int(batch_idx.max()) + 1
     click_idx = [dict(c) for c in click_idx]
 
     # ---- backbone, training mode (BatchNorm on the statistics of this batch), engine.py:53
     model.train()
+    from .train_backbone import packed_weights_of
+    packed_weights_of(model).refresh_all()      # scene-independent: queued before the scene build's host round trip, not behind it
     scene = Scene(coords.to(torch.int32).contiguous())
     bb = BackboneTape(model, scene, feats)
+    # the gradient reducer (one small blocking digest all-reduce over the ranks, a dict over the 268 parameters) is made HERE,
+    # while the device works through the backbone's launches -- not at the start, where it would sit in front of the first
+    # kernel, and not between the decoder's and the backbone's backward, where the host would stall behind the queue
+    from .optim import OverlappedAllReduce
+    reducer = OverlappedAllReduce(bucket_bytes=int(float(os.environ.get("A3D_DP_BUCKET_MB", "32")) * (1 << 20)),
+                                  expected={k: p.numel() for k, p in model.named_parameters() if p.requires_grad},
+                                  single_rank=os.environ.get("A3D_DP_SINGLE_RANK", "0") == "1")
     pcd = bb.output
     ranges = scene.batch_ranges
     mark("backbone forward")

@@ -209,8 +209,9 @@ int    a3d_program_run(const a3d_scene* s, const a3d_buf_desc* bufs, int n_bufs,
  * a3d_scene_build_wgrad_lists: once per scene before the first a3d_conv_wgrad on it (the 3^3 / stride-2 / transposed kinds
  * refuse without it): for every kernel map of the scene and every offset k, the 16-position groups that have offset k, so
  * that the kernel's work items are equal cuts of these lists instead of equal cuts of the rows.  The workspace
- * (a3d_scene_wgrad_lists_bytes) must live as long as the scene is used for weight gradients; the call synchronises
- * `stream` once (the list lengths come back to the host, where the launch plans are made).
+ * (a3d_scene_wgrad_lists_bytes) must live as long as the scene is used for weight gradients.  The call does not synchronise:
+ * the list lengths travel to a pinned host buffer behind an event, and the first a3d_conv_wgrad /
+ * a3d_conv_wgrad_workspace_bytes on the scene waits for them (the launch plans are made on the host).
  * ------------------------------------------------------------------------------------------ */
 size_t a3d_scene_wgrad_lists_bytes(const a3d_scene* s);
 int    a3d_scene_build_wgrad_lists(a3d_scene* s, void* workspace_dev, size_t workspace_bytes, void* stream);

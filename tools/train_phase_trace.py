@@ -2,7 +2,8 @@
 """Per-PHASE kernel summary of traced training iterations.  train_one_step launches one marker kernel (torch.cuda._sleep ->
 `spin_kernel`) at every phase mark when A3D_TRAIN_TIMING=mark, with the device synchronised on both sides, so the dispatches
 between two markers are exactly one phase.  Reads a rocprofv3 --kernel-trace database.
-   python tools/train_phase_trace.py <rocprofv3 output dir> [iterations to skip = 1] [rows per phase = 14]"""
+   python tools/train_phase_trace.py <rocprofv3 output dir> [iterations to skip = 1] [rows per phase = 14]
+A3D_PHASE_GAPS=<phase index>: also list the longest idle stretches of that phase in the first iteration counted."""
 import glob
 import os
 import sqlite3
@@ -52,6 +53,16 @@ def main():
                 if p >= len(PHASES) or it < skip:
                     return
                 done_iters.add(it)
+                if os.environ.get("A3D_PHASE_GAPS") == str(p) and it == skip:      # the idle stretches of one phase of one iteration
+                    gaps, end_, prev = [], seg[0][2], seg[0][0]
+                    for name, s_, e_ in seg[1:]:
+                        if s_ > end_:
+                            gaps.append(((s_ - end_) / 1e3, (s_ - seg[0][1]) / 1e3, short(prev), short(name)))
+                        if e_ > end_:
+                            end_, prev = e_, name
+                    print(f"# idle stretches of phase '{PHASES[p]}', iteration {it}: {sum(g[0] for g in gaps):.1f} us in {len(gaps)} gaps; the longest:")
+                    for g in sorted(gaps, reverse=True)[:25]:
+                        print(f"#   {g[0]:8.1f} us at {g[1]:9.1f} us   {g[2]} -> {g[3]}")
                 wall[p] += (max(r[2] for r in seg) - seg[0][1]) / 1e3
                 end = seg[0][1]
                 for _, s_, e_ in seg:              # sorted by start
