@@ -682,16 +682,15 @@ class Engine:
                 K = len(ci) - 1
                 rows, objs, times = [], [], []
                 for o in list(range(1, K + 1)) + [0]:
-                    r = list(ci[str(o)])
-                    t = list(ct[str(o)])
+                    r, t = ci[str(o)], ct[str(o)]
                     if len(r) != len(t):
                         raise ValueError("click_idx / click_time_idx length mismatch")
                     if o > 0 and len(r) == 0:
                         raise ValueError(f"object {o} has no click (the reference fails on an empty max, "
                                          "agile3d.py:353)")
-                    rows += [int(v) for v in r]
-                    times += [int(v) for v in t]
-                    objs += [o] * len(r)
+                    rows.extend(map(int, r))
+                    times.extend(map(int, t))
+                    objs.extend([o] * len(r))
                 nc = len(rows)
                 nq = nc + W.n_bg_queries
                 wsb = lib.a3d_decoder_workspace_bytes(nb, nq)
