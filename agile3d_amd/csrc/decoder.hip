@@ -251,6 +251,7 @@ struct DecSampleDev {
   const int *qobj, *qrange;        // QueryMeta::obj / qrange (device)
   const float *qproj, *ks, *vs, *E;
   const float* q0;                 // the scene's cached layer-0 scene-to-click queries (src + pos) Wq^T + bq [n][128], or nullptr
+  const float *k0, *v0;            // the scene's cached layer-0 click-to-scene keys / values [n][128], or nullptr
   int qp, nqt;                     // rows of this sample's query-side buffers; its 16-query tiles (wide tier: the samples of a launch differ)
 };
 constexpr int kMaxBatchSamples = 64;
@@ -268,18 +269,19 @@ __device__ __forceinline__ const float* layer_input(const DecSampleDev& sm, int 
 // ------------------------------------------------------------------------------ click-to-scene
 // One wave = one head over a chunk of points.  S = K_h q_h^T (A = key rows, B = q^T), online
 // softmax per query column (lane-local: column = lane & 15), O^T += V_h^T P.
+// nqt <= QT: the 16-query tiles this sample has (the batched launch serves samples of different query counts with the
+// widest one's kernel: the tiles beyond a sample's own are skipped, not computed); chunk / nchunk: this workgroup's chunk of
+// the sample's points and the number of them (the record layout of k_c2s_combine)
 template <int QT>
-__global__ void __launch_bounds__(512) k_c2s_attn(const float* __restrict__ Kc, const float* __restrict__ V,
-                                                  int n, const float* qproj, const int* qobj,
-                                                  const unsigned char* labels, const int* counts,
-                                                  float* part, int qp_total) {
+__device__ __forceinline__ void c2s_attn_body(const float* __restrict__ Kc, const float* __restrict__ V, int n, const float* qproj,
+                                              const int* qobj, const unsigned char* labels, const int* counts, float* part,
+                                              int qp_total, int qb0, int nqt, int chunk, int nchunk) {
   const int lane = threadIdx.x & 63;
-  const int qb0 = blockIdx.y * (QT * 16);   // first query of this launch's query block
   qproj += (size_t)qb0 * D;
   qobj += qb0;
   const int h = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int g = lane >> 4, j = lane & 15;
-  const int pbeg = blockIdx.x * kC2SChunk;
+  const int pbeg = chunk * kC2SChunk;
   const int pend = min(n, pbeg + kC2SChunk);
 
   f32x4 qf[QT];
@@ -287,8 +289,9 @@ __global__ void __launch_bounds__(512) k_c2s_attn(const float* __restrict__ Kc, 
   bool qmask[QT];
 #pragma unroll
   for (int qt = 0; qt < QT; ++qt) {
-    qf[qt] = *(const f32x4*)(qproj + (size_t)(qt * 16 + j) * D + h * DH + 4 * g);
-    obj[qt] = qobj[qt * 16 + j];
+    const int qr = qt < nqt ? qt * 16 + j : 0;      // tiles past the sample's own are never multiplied: any row will do
+    qf[qt] = *(const f32x4*)(qproj + (size_t)qr * D + h * DH + 4 * g);
+    obj[qt] = qobj[qr];
     // a query is masked only if its object currently owns at least one point (agile3d.py:369,375)
     qmask[qt] = labels != nullptr && obj[qt] >= 0 && counts[obj[qt]] > 0;
   }
@@ -325,6 +328,7 @@ __global__ void __launch_bounds__(512) k_c2s_attn(const float* __restrict__ Kc, 
     if (p0 + 16 < pend) fetch(p0 + 16);
 #pragma unroll
     for (int qt = 0; qt < QT; ++qt) {
+      if (qt >= nqt) break;                 // wave-uniform
       f32x4 s = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int t = 0; t < 4; ++t) s = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[t], qf[qt][t], s, 0, 0, 0);
@@ -357,9 +361,10 @@ __global__ void __launch_bounds__(512) k_c2s_attn(const float* __restrict__ Kc, 
   // record of (head h, query q, chunk): [h][q][chunk] -- the chunks of a (head, query) are contiguous for k_c2s_combine
 #pragma unroll
   for (int qt = 0; qt < QT; ++qt) {
+    if (qt >= nqt) break;
     float lt = l[qt];
     lt = rows_sum(lt);
-    float* pq = part + (((size_t)h * qp_total + qb0 + qt * 16 + j) * gridDim.x + blockIdx.x) * kPartStride;
+    float* pq = part + (((size_t)h * qp_total + qb0 + qt * 16 + j) * nchunk + chunk) * kPartStride;
     if (g == 0) {
       pq[0] = m[qt];
       pq[1] = lt;
@@ -367,6 +372,26 @@ __global__ void __launch_bounds__(512) k_c2s_attn(const float* __restrict__ Kc, 
 #pragma unroll
     for (int t = 0; t < 4; ++t) pq[2 + 4 * g + t] = acc[qt][t];
   }
+}
+
+template <int QT>
+__global__ void __launch_bounds__(512) k_c2s_attn(const float* __restrict__ Kc, const float* __restrict__ V,
+                                                  int n, const float* qproj, const int* qobj,
+                                                  const unsigned char* labels, const int* counts,
+                                                  float* part, int qp_total) {
+  // blockIdx.y: the launch's query block of 16 QT rows
+  c2s_attn_body<QT>(Kc, V, n, qproj, qobj, labels, counts, part, qp_total, (int)blockIdx.y * (QT * 16), QT, (int)blockIdx.x,
+                    (int)gridDim.x);
+}
+// the first layer's attention over the scenes' CACHED keys / values for every sample of a call in ONE launch (blockIdx.y =
+// sample; its own tile count and chunk count come from the table): 4 (training click rounds) .. 16 (lock-step evaluation)
+// launches of 625 workgroups each -- 1.2 rounds of the device's 512 slots, i.e. two -- became one launch of 2 500 .. 10 000
+template <int QT>
+__global__ void __launch_bounds__(512) k_c2s_attn_b(const DecSampleDev* __restrict__ samples) {
+  const DecSampleDev& sm = samples[blockIdx.y];
+  const int nchunk = (sm.n + kC2SChunk - 1) / kC2SChunk;
+  if ((int)blockIdx.x >= nchunk) return;
+  c2s_attn_body<QT>(sm.k0, sm.v0, sm.n, sm.qproj, sm.qobj, nullptr, nullptr, sm.part, sm.qp, 0, min(sm.nqt, QT), (int)blockIdx.x, nchunk);
 }
 
 
@@ -2598,6 +2623,8 @@ static int upload_tables(Prepared* P, int ns, bool wg_per_group, bool part_per_w
       d.vs = p.B.vs;
       d.E = p.B.E;
       d.q0 = p.kv0 && p.kv0_state != 0 ? p.kv0 + (size_t)2 * p.n * D : nullptr;
+      d.k0 = p.kv0 && p.kv0_state != 0 ? p.kv0 : nullptr;
+      d.v0 = p.kv0 && p.kv0_state != 0 ? p.kv0 + (size_t)p.n * D : nullptr;
       d.qp = p.L.qp;
       d.nqt = (p.hm.nq + 15) / 16;
     }
@@ -2804,8 +2831,16 @@ static int run_decoder(const a3d_decoder_weights* w, Prepared* P, int ns, hipStr
                           p.kv0 + (size_t)2 * p.n * D, D, nullptr, 0, st);
           if (rc) return rc;
         }
+        if (nblk == 1) continue;              // one query block: all samples in ONE launch below
         ProfScope ps(st, A3D_PROF_C2S, 0, 0, 0, 0, p.n);
         k_c2s_attn<QT><<<dim3(p.L.nchunk, nblk), 512, 0, st>>>(K0, V0, p.n, p.B.qproj, p.meta->obj, nullptr, nullptr, p.part, p.L.qp);
+        A3D_LAUNCH_CHECK();
+      }
+      if (nblk == 1) {
+        int nchunk_max = 0;
+        for (int si = 0; si < ns; ++si) nchunk_max = P[si].L.nchunk > nchunk_max ? P[si].L.nchunk : nchunk_max;
+        ProfScope ps(st, A3D_PROF_C2S, 0, 0, 0, 0, (int)n_total);
+        k_c2s_attn_b<QT><<<dim3(nchunk_max, ns), 512, 0, st>>>(samples_dev);
         A3D_LAUNCH_CHECK();
       }
     } else if (fuse_c2s) {
@@ -2961,6 +2996,7 @@ static int run_decoder_wide(const a3d_decoder_weights* w, Prepared* P, int ns, h
     for (int si = 0; si < ns && cached0; ++si) cached0 = P[si].kv0 != nullptr && P[si].kv0_state != 0;
     const bool qc0 = cached0;
     if (cached0) {
+      int nchunk_max = 0, nqt_max = 0;
       for (int si = 0; si < ns; ++si) {
         Prepared& p = P[si];
         float* K0 = p.kv0;
@@ -2974,21 +3010,27 @@ static int run_decoder_wide(const a3d_decoder_weights* w, Prepared* P, int ns, h
                           p.kv0 + (size_t)2 * p.n * D, D, nullptr, 0, st);
           if (rc) return rc;
         }
-        ProfScope ps(st, A3D_PROF_C2S, 0, 0, 0, 0, p.n);
-        // the unfused flash kernel over the cached keys / values, by the sample's OWN tile count (it reads 16 QT query rows)
-        const dim3 cg(p.L.nchunk, 1);
-        switch (wide_qt_of_tiles((p.hm.nq + 15) / 16)) {
-          case 1: k_c2s_attn<1><<<cg, 512, 0, st>>>(K0, V0, p.n, p.B.qproj, p.meta->obj, nullptr, nullptr, p.part, p.L.qp); break;
-          case 2: k_c2s_attn<2><<<cg, 512, 0, st>>>(K0, V0, p.n, p.B.qproj, p.meta->obj, nullptr, nullptr, p.part, p.L.qp); break;
-          case 3: k_c2s_attn<3><<<cg, 512, 0, st>>>(K0, V0, p.n, p.B.qproj, p.meta->obj, nullptr, nullptr, p.part, p.L.qp); break;
-          case 4: k_c2s_attn<4><<<cg, 512, 0, st>>>(K0, V0, p.n, p.B.qproj, p.meta->obj, nullptr, nullptr, p.part, p.L.qp); break;
-          case 5: k_c2s_attn<5><<<cg, 512, 0, st>>>(K0, V0, p.n, p.B.qproj, p.meta->obj, nullptr, nullptr, p.part, p.L.qp); break;
-          case 6: k_c2s_attn<6><<<cg, 512, 0, st>>>(K0, V0, p.n, p.B.qproj, p.meta->obj, nullptr, nullptr, p.part, p.L.qp); break;
-          case 7: k_c2s_attn<7><<<cg, 512, 0, st>>>(K0, V0, p.n, p.B.qproj, p.meta->obj, nullptr, nullptr, p.part, p.L.qp); break;
-          case 8: k_c2s_attn<8><<<cg, 512, 0, st>>>(K0, V0, p.n, p.B.qproj, p.meta->obj, nullptr, nullptr, p.part, p.L.qp); break;
-          case 10: k_c2s_attn<10><<<cg, 512, 0, st>>>(K0, V0, p.n, p.B.qproj, p.meta->obj, nullptr, nullptr, p.part, p.L.qp); break;
-          case 12: k_c2s_attn<12><<<cg, 512, 0, st>>>(K0, V0, p.n, p.B.qproj, p.meta->obj, nullptr, nullptr, p.part, p.L.qp); break;
-          default: k_c2s_attn<14><<<cg, 512, 0, st>>>(K0, V0, p.n, p.B.qproj, p.meta->obj, nullptr, nullptr, p.part, p.L.qp); break;
+        nchunk_max = p.L.nchunk > nchunk_max ? p.L.nchunk : nchunk_max;
+        const int t = (p.hm.nq + 15) / 16;
+        nqt_max = t > nqt_max ? t : nqt_max;
+      }
+      {
+        ProfScope ps(st, A3D_PROF_C2S, 0, 0, 0, 0, (int)n_total);
+        // the unfused flash kernel over the cached keys / values, ALL samples in one launch: the widest sample's kernel, every
+        // sample by its OWN tile count (c2s_attn_body skips the tiles past it)
+        const dim3 cg(nchunk_max, ns);
+        switch (wide_qt_of_tiles(nqt_max)) {
+          case 1: k_c2s_attn_b<1><<<cg, 512, 0, st>>>(T.samples_dev); break;
+          case 2: k_c2s_attn_b<2><<<cg, 512, 0, st>>>(T.samples_dev); break;
+          case 3: k_c2s_attn_b<3><<<cg, 512, 0, st>>>(T.samples_dev); break;
+          case 4: k_c2s_attn_b<4><<<cg, 512, 0, st>>>(T.samples_dev); break;
+          case 5: k_c2s_attn_b<5><<<cg, 512, 0, st>>>(T.samples_dev); break;
+          case 6: k_c2s_attn_b<6><<<cg, 512, 0, st>>>(T.samples_dev); break;
+          case 7: k_c2s_attn_b<7><<<cg, 512, 0, st>>>(T.samples_dev); break;
+          case 8: k_c2s_attn_b<8><<<cg, 512, 0, st>>>(T.samples_dev); break;
+          case 10: k_c2s_attn_b<10><<<cg, 512, 0, st>>>(T.samples_dev); break;
+          case 12: k_c2s_attn_b<12><<<cg, 512, 0, st>>>(T.samples_dev); break;
+          default: k_c2s_attn_b<14><<<cg, 512, 0, st>>>(T.samples_dev); break;
         }
         A3D_LAUNCH_CHECK();
       }
