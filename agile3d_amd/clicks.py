@@ -53,6 +53,46 @@ def argmax_labels(logits: torch.Tensor, click_idx: dict | None = None) -> torch.
     return pred
 
 
+_MAX_ROUND_SAMPLES = 64     # include/agile3d_hip.h: A3D_MAX_ROUND_SAMPLES
+
+
+def argmax_labels_batch(logits_list, click_idx_list=None):
+    """``argmax_labels`` of every sample of a round in two launches (``a3d_argmax_labels_batch``; the per-sample calls were two
+    launches each: 32 per lock-step evaluation round of 16 scenes).  Same results, in sample order."""
+    lib = L.load()
+    ns = len(logits_list)
+    if ns == 0:
+        return []
+    if ns > _MAX_ROUND_SAMPLES:
+        return [argmax_labels(lg, None if click_idx_list is None else click_idx_list[i]) for i, lg in enumerate(logits_list)]
+    dev = logits_list[0].device
+    arr = (L.ArgmaxSample * ns)()
+    keep, preds = [], []
+    for i, lg in enumerate(logits_list):
+        lg = lg.contiguous()
+        if lg.dtype != torch.float32 or not lg.is_cuda or lg.dim() != 2:
+            raise RuntimeError("argmax_labels: logits must be a CUDA float32 [N, 1+K] tensor")
+        rows, objs = [], []
+        for obj_id, cids in ((click_idx_list[i] if click_idx_list is not None else None) or {}).items():
+            rows.extend(map(int, cids))
+            objs.extend([int(obj_id)] * len(cids))
+        r, rp = _host_i32(rows)
+        o, op = _host_i32(objs)
+        pred = torch.empty(lg.shape[0], dtype=torch.int32, device=dev)
+        sp = arr[i]
+        sp.logits_dev, sp.n, sp.n_classes, sp.n_clicks = lg.data_ptr(), lg.shape[0], lg.shape[1], len(rows)
+        sp.click_row, sp.click_obj, sp.pred_dev = rp, op, pred.data_ptr()
+        keep.append((lg, r, o))
+        preds.append(pred)
+    key = (dev.index, "argmax_ws", ns)
+    ws = _ws_cache.get(key)
+    if ws is None:
+        ws = _ws_cache[key] = torch.empty(lib.a3d_argmax_labels_batch_workspace_bytes(ns), dtype=torch.uint8, device=dev)
+    L.check(lib.a3d_argmax_labels_batch(C.cast(arr, C.c_void_p), ns, ws.data_ptr(), ws.numel(), _stream(logits_list[0])),
+            "a3d_argmax_labels_batch")
+    return preds
+
+
 def iou_counts(pred, labels, inverse_map=None, n_ids: int | None = None) -> np.ndarray:
     """int64 [3][n_ids]: |pred==id & label==id|, |pred==id|, |label==id| with pred read through
     ``inverse_map`` (voxel -> full-resolution points, eval_multi_obj.py:138) when given."""
@@ -75,13 +115,11 @@ def iou_counts(pred, labels, inverse_map=None, n_ids: int | None = None) -> np.n
     return host[:-1].reshape(3, n_ids)
 
 
-def iou_counts_batch(preds, labels, inverse_maps=None, n_ids: int = 256):
-    """``iou_counts`` of several samples with one device-to-host copy: list of int64 [3][n_ids] arrays."""
+def _launch_iou_counts(preds, labels, inverse_maps, n_ids, counts):
+    """IoU counts of all samples into ``counts`` [ns][3 n_ids + 1] on the current stream: ONE launch + one clear
+    (``a3d_iou_counts_batch``; a launch + a clear per sample before).  Returns the tensors the launch reads."""
     lib = L.load()
-    if not preds:
-        return []
-    dev = preds[0].device
-    counts = torch.empty(len(preds), 3 * n_ids + 1, dtype=torch.int64, device=dev)
+    dev = counts.device
     keep = []
     for i, (pr, lb) in enumerate(zip(preds, labels)):
         p, l = _i32(pr), _i32(lb)
@@ -93,8 +131,25 @@ def iou_counts_batch(preds, labels, inverse_maps=None, n_ids: int = 256):
         elif p.numel() != l.numel():
             raise RuntimeError("iou_counts: pred and labels differ in length")
         keep.append((p, l, inv))
-        L.check(lib.a3d_iou_counts(p.data_ptr(), p.numel(), inv.data_ptr() if inv is not None else None, l.data_ptr(),
-                                   l.numel(), n_ids, counts[i].data_ptr(), _stream(p)), "a3d_iou_counts")
+    for c0 in range(0, len(keep), _MAX_ROUND_SAMPLES):
+        part = keep[c0:c0 + _MAX_ROUND_SAMPLES]
+        arr = (L.IouSample * len(part))()
+        for k, (p, l, inv) in enumerate(part):
+            sp = arr[k]
+            sp.pred_dev, sp.n_pred, sp.inverse_map_dev = p.data_ptr(), p.numel(), inv.data_ptr() if inv is not None else None
+            sp.labels_dev, sp.n_full = l.data_ptr(), l.numel()
+        L.check(lib.a3d_iou_counts_batch(C.cast(arr, C.c_void_p), len(part), n_ids, counts[c0].data_ptr(), _stream(counts)),
+                "a3d_iou_counts_batch")
+    return keep
+
+
+def iou_counts_batch(preds, labels, inverse_maps=None, n_ids: int = 256):
+    """``iou_counts`` of several samples with one launch and one device-to-host copy: list of int64 [3][n_ids] arrays."""
+    if not preds:
+        return []
+    dev = preds[0].device
+    counts = torch.empty(len(preds), 3 * n_ids + 1, dtype=torch.int64, device=dev)
+    keep = _launch_iou_counts(preds, labels, inverse_maps, n_ids, counts)
     host = counts.cpu().numpy()
     if host[:, -1].any():
         raise RuntimeError("iou_counts: inverse_map holds rows outside the prediction")
@@ -326,18 +381,7 @@ def mean_iou_and_clusters_batch(preds, labels_iou, inverse_maps, labels_qv, coor
     try:                     # the stream is drained before ANY exit: the cached work buffers are reused by the next call
         host, slots, refs = _launch_clusters_batch(preds, labels_qv, coords)
         keep.append(refs)
-        for i in range(ns):
-            p, l = _i32(preds[i]), _i32(labels_iou[i])
-            inv = None
-            if inverse_maps is not None and inverse_maps[i] is not None:
-                inv = inverse_maps[i].to(device=dev, dtype=torch.int64).contiguous()
-                if inv.numel() != l.numel():
-                    raise RuntimeError("iou_counts: inverse_map and labels differ in length")
-            elif p.numel() != l.numel():
-                raise RuntimeError("iou_counts: pred and labels differ in length")
-            keep.append((p, l, inv))
-            L.check(lib.a3d_iou_counts(p.data_ptr(), p.numel(), inv.data_ptr() if inv is not None else None, l.data_ptr(),
-                                       l.numel(), n_ids, counts[i].data_ptr(), _stream(p)), "a3d_iou_counts")
+        keep.append(_launch_iou_counts(preds, labels_iou, inverse_maps, n_ids, counts))
         counts_host.copy_(counts, non_blocking=True)
     finally:
         cur.synchronize()

@@ -32,6 +32,7 @@
 // by 32 lanes per wrong point, only unresolved points to the brute-force search) was built, verified bit-identical and
 // measured slower in every regime but one (profiles/r04_experiments.txt): removed.
 #include "common.h"
+#include <vector>
 #include <stdlib.h>
 
 namespace a3d {
@@ -74,6 +75,38 @@ struct ClickList {
 __global__ void k_click_overwrite(ClickList cl, int64_t n, int32_t* __restrict__ pred) {
   for (int i = 0; i < cl.n; ++i)
     if (cl.row[i] >= 0 && cl.row[i] < n) pred[cl.row[i]] = cl.obj[i];
+}
+
+// ---- the same two kernels for all samples of a round (blockIdx.y = sample; the per-sample pointers travel by value) ----
+struct ArgmaxBatch {
+  const float* logits[A3D_MAX_ROUND_SAMPLES];
+  int32_t* pred[A3D_MAX_ROUND_SAMPLES];
+  long long n[A3D_MAX_ROUND_SAMPLES];
+  int C[A3D_MAX_ROUND_SAMPLES];
+  int click_off[A3D_MAX_ROUND_SAMPLES + 1];   // sample i's clicks: entries click_off[i] .. click_off[i + 1] - 1 of the uploaded lists
+};
+__global__ void k_argmax_labels_b(const ArgmaxBatch b) {
+  const int s = blockIdx.y;
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= b.n[s]) return;
+  const int C = b.C[s];
+  const float* r = b.logits[s] + i * C;
+  float best = r[0];
+  int arg = 0;
+  for (int c = 1; c < C; ++c) {
+    const float v = r[c];
+    if (v > best) { best = v; arg = c; }
+  }
+  b.pred[s][i] = arg;
+}
+// one thread per sample, sequential like k_click_overwrite: a row clicked for two objects keeps the LAST one
+__global__ void k_click_overwrite_b(const ArgmaxBatch b, const int32_t* __restrict__ rows, const int32_t* __restrict__ objs) {
+  const int s = blockIdx.x;
+  if (threadIdx.x) return;
+  int32_t* pred = b.pred[s];
+  const long long n = b.n[s];
+  for (int i = b.click_off[s]; i < b.click_off[s + 1]; ++i)
+    if (rows[i] >= 0 && rows[i] < n) pred[rows[i]] = objs[i];
 }
 
 // ---- IoU counts: counts[0][id] = |pred==id & label==id|, [1][id] = |pred==id|, [2][id] = |label==id| ----
@@ -653,6 +686,138 @@ extern "C" int a3d_iou_counts(const int32_t* pred_dev, int64_t n_pred, const int
   k_iou_counts<<<grid, 256, 0, st>>>(pred_dev, inverse_map_dev, labels_dev, n_full, n_pred, n_ids,
                                      (unsigned long long*)counts_dev, (int*)(counts_dev + (size_t)3 * n_ids));
   A3D_LAUNCH_CHECK();
+  return A3D_OK;
+}
+
+struct IouBatch {
+  const int32_t* pred[A3D_MAX_ROUND_SAMPLES];
+  const int64_t* inv[A3D_MAX_ROUND_SAMPLES];
+  const int32_t* lab[A3D_MAX_ROUND_SAMPLES];
+  long long n_full[A3D_MAX_ROUND_SAMPLES];
+  long long n_pred[A3D_MAX_ROUND_SAMPLES];
+};
+// k_iou_counts for sample blockIdx.y (the same per-workgroup histogram, the same atomics)
+__global__ void k_iou_counts_b(const IouBatch b, int n_ids, unsigned long long* __restrict__ counts_all) {
+  __shared__ unsigned h[3 * 256];
+  const int s = blockIdx.y;
+  const int32_t* __restrict__ pred = b.pred[s];
+  const int64_t* __restrict__ inverse_map = b.inv[s];
+  const int32_t* __restrict__ labels = b.lab[s];
+  const long long n_full = b.n_full[s], n_pred = b.n_pred[s];
+  unsigned long long* counts = counts_all + (size_t)s * (3 * n_ids + 1);
+  int* err = (int*)(counts + (size_t)3 * n_ids);
+  for (int i = threadIdx.x; i < 3 * 256; i += blockDim.x) h[i] = 0;
+  __syncthreads();
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n_full; i += stride) {
+    const long long src = inverse_map ? inverse_map[i] : i;
+    if (src < 0 || src >= n_pred) { atomicOr(err, 1); continue; }
+    const int p = pred[src], l = labels[i];
+    if (p >= 0 && p < n_ids) atomicAdd(&h[256 + p], 1u);
+    if (l >= 0 && l < n_ids) {
+      atomicAdd(&h[512 + l], 1u);
+      if (p == l) atomicAdd(&h[l], 1u);
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 3 * 256; i += blockDim.x) {
+    const int id = i & 255;
+    if (id < n_ids && h[i]) atomicAdd(&counts[(size_t)(i >> 8) * n_ids + id], (unsigned long long)h[i]);
+  }
+}
+
+extern "C" int a3d_iou_counts_batch(const a3d_iou_sample* samples, int n_samples, int n_ids, int64_t* counts_all_dev, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  if (!samples || n_samples < 1 || n_samples > A3D_MAX_ROUND_SAMPLES || n_ids < 1 || n_ids > 256 || !counts_all_dev) {
+    set_error("a3d_iou_counts_batch: bad arguments (1..%d samples, 1..256 ids)", A3D_MAX_ROUND_SAMPLES);
+    return A3D_ERR_INVALID;
+  }
+  IouBatch b;
+  memset(&b, 0, sizeof(b));
+  long long n_max = 0;
+  for (int i = 0; i < n_samples; ++i) {
+    const a3d_iou_sample& sp = samples[i];
+    if (sp.n_full < 0 || sp.n_pred < 0 || (sp.n_full > 0 && (!sp.pred_dev || !sp.labels_dev))) {
+      set_error("a3d_iou_counts_batch: sample %d: bad arguments (n_full=%lld)", i, (long long)sp.n_full);
+      return A3D_ERR_INVALID;
+    }
+    b.pred[i] = sp.pred_dev, b.inv[i] = sp.inverse_map_dev, b.lab[i] = sp.labels_dev;
+    b.n_full[i] = sp.n_full, b.n_pred[i] = sp.n_pred;
+    n_max = sp.n_full > n_max ? sp.n_full : n_max;
+  }
+  A3D_HIP_CHECK(hipMemsetAsync(counts_all_dev, 0, (size_t)n_samples * ((size_t)3 * n_ids + 1) * 8, st));
+  if (n_max == 0) return A3D_OK;
+  const long long want = (n_max + 1023) / 1024;
+  const unsigned grid = (unsigned)(want < 2048 ? want : 2048);
+  k_iou_counts_b<<<dim3(grid, n_samples), 256, 0, st>>>(b, n_ids, (unsigned long long*)counts_all_dev);
+  A3D_LAUNCH_CHECK();
+  return A3D_OK;
+}
+
+extern "C" size_t a3d_argmax_labels_batch_workspace_bytes(int n_samples) {
+  if (n_samples < 1 || n_samples > A3D_MAX_ROUND_SAMPLES) return 0;
+  return (size_t)n_samples * A3D_MAX_CLICKS * 8 + 256;
+}
+extern "C" int a3d_argmax_labels_batch(const a3d_argmax_sample* samples, int n_samples, void* workspace_dev, size_t workspace_bytes,
+                                       void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  if (!samples || n_samples < 1 || n_samples > A3D_MAX_ROUND_SAMPLES) {
+    set_error("a3d_argmax_labels_batch: 1..%d samples per call", A3D_MAX_ROUND_SAMPLES);
+    return A3D_ERR_INVALID;
+  }
+  ArgmaxBatch b;
+  memset(&b, 0, sizeof(b));
+  long long n_max = 0;
+  int total = 0;
+  for (int i = 0; i < n_samples; ++i) {
+    const a3d_argmax_sample& sp = samples[i];
+    if (sp.n < 0 || sp.n_classes < 1 || sp.n_clicks < 0 || sp.n_clicks > A3D_MAX_CLICKS || (sp.n && (!sp.logits_dev || !sp.pred_dev)) ||
+        (sp.n_clicks && (!sp.click_row || !sp.click_obj))) {
+      set_error("a3d_argmax_labels_batch: sample %d: bad arguments (n=%lld classes=%d clicks=%d)", i, (long long)sp.n, sp.n_classes,
+                sp.n_clicks);
+      return A3D_ERR_INVALID;
+    }
+    b.logits[i] = sp.logits_dev, b.pred[i] = sp.pred_dev, b.n[i] = sp.n, b.C[i] = sp.n_classes;
+    b.click_off[i] = total;
+    total += sp.n ? sp.n_clicks : 0;
+    n_max = sp.n > n_max ? sp.n : n_max;
+  }
+  b.click_off[n_samples] = total;
+  if (n_max == 0) return A3D_OK;
+  k_argmax_labels_b<<<dim3((unsigned)((n_max + 255) / 256), n_samples), 256, 0, st>>>(b);
+  A3D_LAUNCH_CHECK();
+  if (total) {
+    if (!workspace_dev || ((uintptr_t)workspace_dev & 15) || workspace_bytes < (size_t)total * 8) {
+      set_error("a3d_argmax_labels_batch: workspace too small or misaligned (a3d_argmax_labels_batch_workspace_bytes)");
+      return A3D_ERR_WORKSPACE;
+    }
+    int32_t host[2 * A3D_MAX_ROUND_SAMPLES * A3D_MAX_CLICKS / 8];     // this call's lists, rows then objects (most rounds: a few dozen clicks)
+    std::vector<int32_t> big;
+    int32_t* hp = host;
+    if ((size_t)2 * total > sizeof(host) / sizeof(host[0])) {
+      big.resize((size_t)2 * total);
+      hp = big.data();
+    }
+    int at = 0;
+    for (int i = 0; i < n_samples; ++i) {
+      const a3d_argmax_sample& sp = samples[i];
+      if (!sp.n) continue;
+      for (int c = 0; c < sp.n_clicks; ++c, ++at) {
+        const int o = sp.click_obj[c];
+        if (o < 0 || o > 255) {
+          set_error("a3d_argmax_labels_batch: sample %d: object id %d outside 0..255", i, o);
+          return A3D_ERR_INVALID;
+        }
+        hp[at] = sp.click_row[c];
+        hp[total + at] = o;
+      }
+    }
+    int32_t* rows_dev = (int32_t*)workspace_dev;
+    // (a pageable source: the runtime stages the bytes before the call returns, `host` may go out of scope)
+    A3D_HIP_CHECK(hipMemcpyAsync(rows_dev, hp, (size_t)2 * total * sizeof(int32_t), hipMemcpyHostToDevice, st));
+    k_click_overwrite_b<<<n_samples, 64, 0, st>>>(b, rows_dev, rows_dev + total);
+    A3D_LAUNCH_CHECK();
+  }
   return A3D_OK;
 }
 

@@ -19,7 +19,7 @@ import os
 import numpy as np
 import torch
 
-from .clicks import argmax_labels, extend_clicks, mean_iou_and_clusters_batch, pick_clicks_batch
+from .clicks import argmax_labels_batch, extend_clicks, mean_iou_and_clusters_batch, pick_clicks_batch
 from .sparse import SparseTensor
 
 
@@ -61,9 +61,8 @@ def Evaluate(model, data_loader, args, device, on_round=None):
                                                 click_time_idx=click_time_idx)["pred_masks"]
                 # the samples of a batch side by side, IoU counts and error clusters behind ONE host round trip (the clusters
                 # do not depend on the IoU; their kernels overlap on side streams); clicks are picked in sample order
-                preds = [torch.zeros(labels[idx].shape[0], dtype=torch.int32, device=device) if current == 0
-                         else argmax_labels(logits[idx], click_idx[idx])          # + sparse-gt update
-                         for idx in range(n_samples)]
+                preds = ([torch.zeros(labels[idx].shape[0], dtype=torch.int32, device=device) for idx in range(n_samples)]
+                         if current == 0 else argmax_labels_batch(logits, click_idx))       # + sparse-gt update, all samples in two launches
                 ious, clusters = mean_iou_and_clusters_batch(preds, labels_full, inverse_map, labels, raw_s)
                 for idx in range(n_samples):
                     iou = ious[idx][0]
@@ -112,8 +111,8 @@ def EvaluateSingle(model, data_loader, args, device, on_round=None):
                 if current:
                     logits = model.forward_mask(*backbone_out, click_idx=click_idx,
                                                 click_time_idx=click_time_idx)["pred_masks"]
-                preds = [torch.zeros(labels[idx].shape[0], dtype=torch.int32, device=device) if current == 0
-                         else argmax_labels(logits[idx], click_idx[idx]) for idx in range(n_samples)]
+                preds = ([torch.zeros(labels[idx].shape[0], dtype=torch.int32, device=device) for idx in range(n_samples)]
+                         if current == 0 else argmax_labels_batch(logits, click_idx))
                 # IoU counts and error clusters of all samples behind ONE host synchronisation (the clusters do not depend
                 # on the IoU; the clicks are picked afterwards, in sample order, so the random stream is consumed as before)
                 ious, clusters = mean_iou_and_clusters_batch(preds, labels_full, inverse_map, labels, raw_s)

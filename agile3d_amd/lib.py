@@ -84,6 +84,18 @@ class ClickSample(C.Structure):
                 ("workspace_bytes", C.c_size_t), ("order_dev", C.c_void_p), ("inv_dev", C.c_void_p)]
 
 
+class ArgmaxSample(C.Structure):
+    """a3d_argmax_sample: one sample of a3d_argmax_labels_batch."""
+    _fields_ = [("logits_dev", C.c_void_p), ("n", C.c_int64), ("n_classes", C.c_int32), ("n_clicks", C.c_int32),
+                ("click_row", C.POINTER(C.c_int32)), ("click_obj", C.POINTER(C.c_int32)), ("pred_dev", C.c_void_p)]
+
+
+class IouSample(C.Structure):
+    """a3d_iou_sample: one sample of a3d_iou_counts_batch."""
+    _fields_ = [("pred_dev", C.c_void_p), ("n_pred", C.c_int64), ("inverse_map_dev", C.c_void_p), ("labels_dev", C.c_void_p),
+                ("n_full", C.c_int64)]
+
+
 class ClickCluster(C.Structure):
     _fields_ = [("cluster_id", C.c_int32), ("row", C.c_int32), ("label", C.c_int32), ("pred", C.c_int32),
                 ("error_size", C.c_float)]
@@ -227,6 +239,9 @@ SYMBOLS = {
                                     C.c_int, C.c_void_p, C.c_void_p]),
     "a3d_iou_counts": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p,
                                  C.c_void_p]),
+    "a3d_argmax_labels_batch_workspace_bytes": (C.c_size_t, [C.c_int]),
+    "a3d_argmax_labels_batch": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "a3d_iou_counts_batch": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "a3d_click_workspace_bytes": (C.c_size_t, [C.c_int64]),
     "a3d_click_clusters": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int,
                                      C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),

@@ -20,7 +20,7 @@ import time
 import numpy as np
 import torch
 
-from .clicks import argmax_labels, cal_click_loss_weights, extend_clicks, get_simulated_clicks, get_simulated_clicks_batch
+from .clicks import argmax_labels, argmax_labels_batch, cal_click_loss_weights, extend_clicks, get_simulated_clicks, get_simulated_clicks_batch
 from .engine import Scene
 from .optim import allreduce_mean_, clip_grad_norm_
 from .train_backbone import BackboneTape
@@ -124,8 +124,8 @@ def _train_one_step(model, criterion, optimizer, batch, device, max_norm):
         t0 = lap(0, t0)
         # argmax + "update prediction with sparse gt" (engine.py:96-101) in one kernel instead of 1 + K torch ops; then the
         # samples' error clusters side by side (one host round trip per round, not one per sample), clicks in sample order
-        preds = [torch.zeros(e - s, dtype=torch.int32, device=device) if it == 0 else argmax_labels(out["pred_masks"][idx], click_idx[idx])
-                 for idx, (s, e) in enumerate(ranges)]
+        preds = ([torch.zeros(e - s, dtype=torch.int32, device=device) for (s, e) in ranges] if it == 0
+                 else argmax_labels_batch(out["pred_masks"], click_idx))
         t0 = lap(1, t0)
         sims = get_simulated_clicks_batch(preds, labels_i32, raw_s, it, training=True, num_objs=num_objs)
         t0 = lap(2, t0)

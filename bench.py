@@ -939,7 +939,7 @@ def main():
                 if rnd:
                     outs = model.forward_mask(*rB, click_idx=ecis, click_time_idx=ects)["pred_masks"]
                 if rnd:
-                    preds = [pc.argmax_labels(outs[b_], ecis[b_]) for b_ in range(len(scenes))]
+                    preds = pc.argmax_labels_batch(outs, ecis)
                 _, cls_ = pc.mean_iou_and_clusters_batch(preds, labs, None, labs, raws)
                 for b_, (new, _, _, nt) in enumerate(pc.pick_clicks_batch(cls_, labs, raws, rnd, training=False)):
                     if new is not None:

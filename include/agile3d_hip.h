@@ -593,6 +593,23 @@ int    a3d_argmax_labels(const float* logits_dev, int64_t n, int n_classes,
                          const int32_t* click_row, const int32_t* click_obj, int n_clicks,
                          int32_t* pred_dev, void* stream);
 
+/* The same for every sample of a round in TWO launches (arg-max of all samples; their click lists): the loop over the samples
+ * of eval_multi_obj.py:119-134 / engine.py:96-101 was two launches PER SAMPLE.  click_row / click_obj are HOST arrays;
+ * workspace_dev (a3d_argmax_labels_batch_workspace_bytes, >= 16-byte aligned) takes the device copy of the click lists. */
+typedef struct a3d_argmax_sample {
+  const float*   logits_dev;   /* [n][n_classes] */
+  int64_t        n;
+  int32_t        n_classes;
+  int32_t        n_clicks;     /* <= A3D_MAX_CLICKS */
+  const int32_t* click_row;    /* host */
+  const int32_t* click_obj;    /* host */
+  int32_t*       pred_dev;     /* [n] */
+} a3d_argmax_sample;
+#define A3D_MAX_ROUND_SAMPLES 64
+size_t a3d_argmax_labels_batch_workspace_bytes(int n_samples);
+int    a3d_argmax_labels_batch(const a3d_argmax_sample* samples, int n_samples, void* workspace_dev, size_t workspace_bytes,
+                               void* stream);
+
 /* counts_dev: int64 [3][n_ids] + 1 trailing int64 (non-zero = an inverse_map entry was out of
  * range): [0][id] = |pred==id & label==id|, [1][id] = |pred==id|, [2][id] = |label==id| over the
  * n_full points i, with pred taken at inverse_map_dev[i] (NULL = identity).  IoU(id) =
@@ -600,6 +617,16 @@ int    a3d_argmax_labels(const float* logits_dev, int64_t n, int n_classes,
 int    a3d_iou_counts(const int32_t* pred_dev, int64_t n_pred, const int64_t* inverse_map_dev,
                       const int32_t* labels_dev, int64_t n_full, int n_ids,
                       int64_t* counts_dev, void* stream);
+/* a3d_iou_counts of every sample of a round in one launch + one clear: counts_all_dev = [n_samples][3 n_ids + 1] int64,
+ * sample i's block as a3d_iou_counts lays it out. */
+typedef struct a3d_iou_sample {
+  const int32_t* pred_dev;
+  int64_t        n_pred;
+  const int64_t* inverse_map_dev;   /* or NULL */
+  const int32_t* labels_dev;
+  int64_t        n_full;
+} a3d_iou_sample;
+int    a3d_iou_counts_batch(const a3d_iou_sample* samples, int n_samples, int n_ids, int64_t* counts_all_dev, void* stream);
 
 /* One entry per error cluster (cluster id = 96*label + 11*pred over the wrongly labelled points,
  * utils/seg.py:186): `row` is the cluster point farthest from every point outside the cluster

@@ -442,3 +442,32 @@ def test_evaluate_single_object_protocol(tmp_path):
         assert iou == np.float32(want.numpy()) and line == f"0 0011_00 7 {cur} {iou}"
         assert sum(len(v) for v in ci.values()) == cur and set(ci) == {"0", "1"}
     assert log[1][3]["1"] and not log[1][3]["0"]            # the first click lands on the object
+
+
+def test_batched_argmax_and_iou_counts_equal_the_per_sample_calls():
+    """a3d_argmax_labels_batch / a3d_iou_counts_batch (all samples of a round in two launches / one launch) against the
+    per-sample entry points: ragged sizes, different class counts, an empty click list, a row clicked for two objects (the
+    LAST one wins, as in the reference's dict loop, eval_multi_obj.py:119-134), an inverse map on one sample."""
+    from agile3d_amd import clicks as pc
+    g = torch.Generator().manual_seed(11)
+    sizes, classes = [5000, 1, 777, 20000], [4, 2, 7, 11]
+    logits = [torch.randn(n, c, generator=g).cuda() for n, c in zip(sizes, classes)]
+    clicks = [{"0": [3, 9], "1": [4999, 3], "2": [17]}, {}, {"0": [], "3": [5, 6, 7], "6": [776]}, {"10": [1, 19999], "0": [1]}]
+    batch = pc.argmax_labels_batch(logits, clicks)
+    for lg, ck, got in zip(logits, clicks, batch):
+        want = pc.argmax_labels(lg, ck)
+        assert got.dtype == torch.int32 and torch.equal(got, want)
+        ref = lg.argmax(-1).to(torch.int32)
+        for o, rows in ck.items():
+            for r in rows:
+                ref[r] = int(o)
+        assert torch.equal(got, ref)
+    assert int(batch[0][3]) == 1 and int(batch[3][1]) == 0          # the later dict entry overwrote the earlier one
+    assert pc.argmax_labels_batch([], []) == []
+    labels = [torch.randint(0, c, (n,), generator=g).to(torch.int32).cuda() for n, c in zip(sizes, classes)]
+    inv = [None, None, torch.randint(0, 777, (1500,), generator=g).cuda(), None]
+    labels[2] = torch.randint(0, 7, (1500,), generator=g).to(torch.int32).cuda()
+    got = pc.iou_counts_batch(batch, labels, inv)
+    for i in range(4):
+        want = pc.iou_counts(batch[i], labels[i], inv[i], n_ids=256)
+        assert np.array_equal(got[i], want), i

@@ -43,7 +43,7 @@ def one_round(rnd, timed):
     if rnd:
         outs = model.forward_mask(*rB, click_idx=ecis, click_time_idx=ects)["pred_masks"]
         t0 = lap(t0, "forward_mask")
-        preds = [pc.argmax_labels(outs[b_], ecis[b_]) for b_ in range(B)]
+        preds = pc.argmax_labels_batch(outs, ecis)
         t0 = lap(t0, "argmax")
     _, cls_ = pc.mean_iou_and_clusters_batch(preds, labs, None, labs, raws)
     t0 = lap(t0, "iou + clusters")

@@ -52,7 +52,7 @@ def protocol(model, sync_parts):
             outs = model.forward_mask(*rB, click_idx=ecis, click_time_idx=ects)["pred_masks"]
         lap("forward_mask")
         if rnd:
-            preds = [pc.argmax_labels(outs[b_], ecis[b_]) for b_ in range(B)]
+            preds = pc.argmax_labels_batch(outs, ecis)
         lap("argmax")
         ious, cls_ = pc.mean_iou_and_clusters_batch(preds, labs, None, labs, raws)
         lap("iou+clusters")
